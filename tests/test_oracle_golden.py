@@ -1,0 +1,176 @@
+"""Pins oracle/xlstm_hved_oracle.py to the golden vectors generated from the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import xlstm_hved_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def sd_of(g, prefix="sd."):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def close(a, b, tol, what=""):
+    err = (a.double() - b.double()).abs().max().item()
+    scale = max(b.double().abs().max().item(), 1.0)
+    assert err <= tol * scale, f"{what}: {err:.3e} > {tol:.1e}*{scale:.3e}"
+
+
+STAGES = {
+    "stage_singleconv_ilc": lambda p, x: O.single_conv(p, x, "ilc"),
+    "stage_singleconv_ilc_s2": lambda p, x: O.single_conv(p, x, "ilc", stride=2),
+    "stage_singleconv_gcr": lambda p, x: O.single_conv(p, x, "gcr"),
+    "stage_singleconv_gcr_g1": lambda p, x: O.single_conv(p, x, "gcr"),
+    "stage_encoder_pool": lambda p, x: O.encoder(p, x, pool=True),
+    "stage_encoder_nopool": lambda p, x: O.encoder(p, x, pool=False),
+    "stage_basicconv_1x1": lambda p, x: O.basic_conv(p, x),
+    "stage_basicconv_dw": lambda p, x: O.basic_conv(p, x, groups=8),
+    "stage_decoder_recon": lambda p, skip, x: O.double_conv(
+        p.sub("basic_module"), torch.cat([skip, O.upsample_to(x, skip.shape[2:])], 1)),
+    "stage_decoder_seg": lambda p, skip, x: O.double_conv(
+        p.sub("basic_module"), O.atten_module2(p.sub("atten_module"), O.upsample_to(x, skip.shape[2:]), skip)),
+    "stage_duse_train": lambda p, r, s: O.duse_attention(p, r, s, True),
+    "stage_duse_eval": lambda p, r, s: O.duse_attention(p, r, s, False),
+    "stage_skr_att_train": lambda p, x: O.skip_return_attention(p, x, True, momentum_steps=1),
+    "stage_skr_att_eval": lambda p, x: O.skip_return_attention(p, x, False),
+    "stage_vil_s64": lambda p, x: O.vil_layer(p, x),
+    "stage_vil_s512": lambda p, x: O.vil_layer(p, x),
+}
+
+
+@pytest.mark.parametrize("name", sorted(STAGES))
+def test_stage_matches_reference(name):
+    g = load(name)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd_of(g).items()}
+    ins = []
+    i = 0
+    while f"in{i}" in g:
+        ins.append(g[f"in{i}"].clone().requires_grad_(True))
+        i += 1
+    out = STAGES[name](O.P(sd), *ins)
+    outs = list(out) if isinstance(out, (tuple, list)) else [out]
+    tol = 1e-4 if "vil" in name else 2e-5
+    loss = 0
+    for j, o in enumerate(outs):
+        close(o, g[f"out{j}"], tol, f"{name}.out{j}")
+        loss = loss + (o * g[f"w{j}"]).sum()
+    loss.backward()
+    for j, t in enumerate(ins):
+        close(t.grad, g[f"gin{j}"], tol * 10, f"{name}.gin{j}")
+    for k, v in g.items():
+        if k.startswith("g."):
+            close(sd[k[2:]].grad, v, tol * 10, f"{name}.{k}")
+    for k, v in sd_of(g, "sd_after.").items():
+        close(sd[k].detach(), v, 1e-5, f"{name}.buffer.{k}")
+
+
+def test_mlstm_cell_dense_and_recurrent():
+    g = load("stage_mlstm_cell")
+    a = [g[k].double() for k in ("q", "k", "v", "ig", "fg")]
+    close(O.mlstm_parallel(*a), g["h"], 1e-12, "dense")
+    close(O.mlstm_recurrent(*a), g["h"], 1e-10, "recurrent")
+
+
+def test_product_of_experts_all_subsets():
+    g = load("stage_poe")
+    for idx in range(15):
+        m, l = O.product_of_experts(g["mu"], g["logvar"], O.SUBSETS_MODALITIES[idx])
+        close(m, g[f"mu_{idx}"], 1e-6), close(l, g[f"lv_{idx}"], 1e-6)
+    m, l, mu_after = O.product_of_experts_drop(g["mu"], g["logvar"], g["drop"])
+    close(m, g["mu_drop"], 1e-6), close(l, g["lv_drop"], 1e-6), close(mu_after, g["mu_after"], 0)
+    close(O.reparametrize(m, l, g["eps"]), g["z"], 1e-6)
+
+
+def test_subset_table_order():
+    # RA_HVED.py:733-738: singles, pairs (0,1)(0,2)(0,3)(1,2)(1,3)(2,3), triples, all
+    s = O.SUBSETS_MODALITIES
+    assert s[:4] == [(0,), (1,), (2,), (3,)]
+    assert s[4:10] == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    assert s[14] == (0, 1, 2, 3) and len(s) == 15
+
+
+def _weights(dtype):
+    w = load("weights_seed1")
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in w.items()}
+
+
+def test_network_train_forward_backward_fp32():
+    g = load("net32_train_subset14")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in _weights(torch.float32).items()}
+    eps = [g[f"eps{i}"] for i in range(4)]
+    prob, logits, mu, lv, rec = O.xlstm_hved_forward(sd, g["x"], 14, eps_list=eps, training=True)
+    close(prob, g["seg"], 2e-4, "seg"), close(rec, g["rec"], 2e-4, "rec")
+    # fp64 tie-breaker: fp32 oracle error vs fp64 reference is of the order of the fp32 reference's own
+    e_or = (prob.double() - g["f64.seg"]).abs().max().item()
+    e_ref = (g["seg"].double() - g["f64.seg"]).abs().max().item()
+    assert e_or <= 2 * e_ref + 1e-5
+    for i in range(4):
+        close(mu[i], g[f"mu{i}"], 1e-4), close(lv[i], g[f"lv{i}"], 1e-4)
+
+    def rnd(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+    loss = (prob * rnd(prob.shape, 200)).sum() + 0.1 * (rec * rnd(rec.shape, 201)).sum()
+    for i, (a, b) in enumerate(zip(mu, lv)):
+        loss = loss + 0.05 * ((a * rnd(a.shape, 210 + i)).sum() + (b * rnd(b.shape, 220 + i)).sum())
+    loss.backward()
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("g."))
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g."):
+            err = (sd[k[2:]].grad - v).abs().max().item() / gscale
+            assert err < 5e-4, (k, err)
+            n += 1
+    assert n > 250
+    # parameters the reference never reaches keep no gradient (DDP note)
+    for k in ("rdecoder.finals.0.weight", "mViL.norm.weight", "skr_att.0.0.conv1.dwconv.weight",
+              "srdecoder.dusfe_decoders.0.conv_fuse_ch1.weight"):
+        assert sd[k].grad is None and ("g." + k) not in g
+    for k, v in g.items():
+        if k.startswith("after."):
+            close(sd[k[6:]].detach(), v, 1e-5, k)
+
+
+def test_network_all_subsets_and_instance_missing_fp64():
+    g = load("net32_subsets_eval")
+    w = _weights(torch.float64)
+    x2 = g["x2"].double()
+    for k in range(15):
+        sd = {n: v.clone() for n, v in w.items()}
+        prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, x2[:1], k, eps_list=None, training=False)
+        close(prob.flatten()[g["idx_seg"]], g[f"seg_{k}"], 1e-9), close(rec.flatten()[g["idx_rec"]], g[f"rec_{k}"], 1e-9)
+        close(mu[3].flatten(), g[f"mu3_{k}"], 1e-9)
+    xm = x2.clone()
+    for i, mk in enumerate([(1, 3), (0,)]):
+        for c in range(4):
+            if c not in mk:
+                xm[i, c] = 0
+    S3 = 32 ** 3
+    for train in (True, False):
+        sd = {n: v.clone() for n, v in w.items()}
+        prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, xm, 14, instance_missing=True, eps_list=None, training=train)
+        t = "train" if train else "eval"
+        close(prob.flatten()[torch.cat([g["idx_seg"], g["idx_seg"] + 3 * S3])], g[f"im_{t}_seg"], 1e-9)
+        close(rec.flatten()[torch.cat([g["idx_rec"], g["idx_rec"] + 4 * S3])], g[f"im_{t}_rec"], 1e-9)
+        close(mu[0].flatten()[:8192], g[f"im_{t}_mu0"], 1e-9)
+        if train:
+            for k, v in g.items():
+                if k.startswith("im_train_after."):
+                    close(sd[k[len("im_train_after."):]].double(), v.double(), 1e-9, k)
+
+
+def test_dice_region_metric():
+    prob = torch.tensor([0.6, 0.4, 0.7, 0.2]).view(1, 1, 1, 2, 2).repeat(1, 3, 1, 1, 1)
+    tgt = torch.tensor([1.0, 1.0, 0.0, 0.0]).view(1, 1, 1, 2, 2).repeat(1, 3, 1, 1, 1)
+    d = O.dice_region(prob, tgt)
+    assert torch.allclose(d, torch.full((3,), (2 * 1 + 1e-6) / (4 + 1e-6)))
