@@ -1,0 +1,251 @@
+/* xlstm_hved.h -- C ABI of libxlstm_hved_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the volumetric forward/backward hot path of XLSTM-HVED.  The reference is pure
+ * PyTorch (no custom ops), so every entry point below replaces an ATen op *sequence* issued by a reference
+ * nn.Module.forward; the file:line it replaces is cited per function (paths relative to the reference repo).
+ * The host side (the Python files under xlstm-hved_amd/) binds these with ctypes and keeps the reference's nn.Module surface.
+ *
+ * Conventions
+ *  - Every function is asynchronous on `stream` (a hipStream_t passed as void*), does no allocation, no
+ *    host synchronisation and keeps no pointer after returning: capture-safe (hipGraph).
+ *  - Returns 0 on success, <0 on error (XH_ERR_ARG bad shape/unsupported combo, XH_ERR_DTYPE, XH_ERR_HIP).
+ *  - Activations are contiguous NCDHW per sample; a `*_bs` argument is the batch stride in ELEMENTS, which
+ *    lets a call read/write a channel slice of a larger tensor (virtual concat / split).
+ *  - dtype: XH_F32 (0) or XH_BF16 (1) is the STORAGE type of activations and activation gradients.
+ *    Parameters, parameter gradients, statistics and coefficients are always fp32 (sums: fp64).
+ *    Arithmetic is fp32 in every kernel.
+ *  - The caller owns all memory, including the `red` reduction buffers which it must zero before a call that
+ *    accumulates into them (documented per call).
+ */
+#ifndef XLSTM_HVED_H
+#define XLSTM_HVED_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XH_F32 0
+#define XH_BF16 1
+#define XH_ACT_NONE 0
+#define XH_ACT_RELU 1
+#define XH_ACT_LRELU 2
+#define XH_ACT_SIGMOID 3
+
+int xh_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3D convolution family.  Replaces nn.Conv3d together with the norm/activation modules wrapped around it
+ * in create_conv/SingleConv (buildingblocks.py:381-461), BasicConv (buildingblocks.py:13-31), DWConvNorm
+ * (sa_modules/sa_module.py:79-85), AttenModule2's 7^3 grouped convs (buildingblocks.py:271-274,283-296),
+ * DuSEAttention's squeeze/adjust convs (modules/DuSFE.py:135-144) and the 1x1 heads (RA_HVED.py:148-149,
+ * 192-196,480,640).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int dtype;
+  int N, Cin, Cout, groups;     /* Cin/Cout are totals over all groups */
+  int D, H, W;                  /* input spatial size */
+  int Do, Ho, Wo;               /* output spatial size: (D + 2*(k/2) - k)/stride + 1 */
+  int k, stride;                /* k in {1,3,7}; padding = k/2; stride in {1,2} (2 only with k=3) */
+  int Ca;                       /* input channels [0,Ca) come from xa, [Ca,Cin) from xb (Ca==Cin: xb unused) */
+  long long xa_bs, xb_bs, y_bs; /* batch strides (elements) */
+  int n_wptr;                   /* 1: w[0] holds all groups; ==groups (<=4): w[g] holds group g */
+  int transposed;               /* 1: compute the data-gradient correlation using FORWARD-layout weights
+                                   [Cin][Cout/groups][k^3] (roles swapped, taps flipped); stride must be 1 */
+  int pre;                      /* 1: input transform v = leaky(x*pre_sc[n,c] + pre_sh[n,c], pre_slope)
+                                   applied before zero padding (slope 1 = affine only) */
+  float pre_slope;
+  int act;                      /* epilogue activation XH_ACT_* (after bias) */
+  float act_slope;
+  int epi;                      /* 0 none
+                                   1 activation/norm backward: g = out * leaky'(e*e_sc+e_sh); store g;
+                                     red[n][c][0] += g, red[n][c][1] += g*e   (e = raw pre-norm value)
+                                   2 output moments: red[n][c][0] += y, red[n][c][1] += y*y (y as stored) */
+  int Cea;                      /* epi==1: e channels [0,Cea) from ea, rest from eb */
+  long long ea_bs, eb_bs;
+  float e_slope;
+} xh_conv_desc;
+
+typedef struct {
+  const void* xa; const void* xb;
+  const float* w[4]; const float* b[4];       /* b[i] may be NULL (no bias) */
+  const float* pre_sc; const float* pre_sh;   /* [N][Cin] when pre */
+  void* y;
+  const void* ea; const void* eb;             /* epi==1 */
+  const float* e_sc; const float* e_sh;       /* [N][Cout] */
+  double* red;                                /* [N][Cout][2], caller zeroes, epi!=0 */
+} xh_conv_ptrs;
+
+/* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv
+ * (transposed=1).  Reference: F.conv3d as used throughout RA_HVED.py:510-648. */
+int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
+
+/* Data gradient of a k=3, stride=2, pad=1 conv (the DRB SingleConv, RA_HVED.py:396-397).  Desc fields
+ * describe the FORWARD conv (Cin,D,H,W = forward input; Cout,Do,Ho,Wo = forward output); x* = dY
+ * (Cout channels, Do..), y = dX (Cin channels).  epi 0/1 as above with e = forward input. */
+int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
+
+/* Weight/bias gradient: dw[co][ci][tap] += sum_{n,p} dy[n,co,p] * pre(x)[n,ci,p*stride+tap-pad],
+ * db[co] += sum dy.  Desc describes the FORWARD conv; ptrs: xa/xb/pre_* = forward input, `ea` = dY with
+ * batch stride ea_bs.  dw[i]/db[i] are laid out like w[i]/b[i], fp32, ACCUMULATED into (caller zeroes). */
+int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation statistics and elementwise stages.
+ * ------------------------------------------------------------------------------------------------ */
+/* red[n][c][0] += sum x, red[n][c][1] += sum x^2 over DHW.  red has row stride red_rs doubles per n
+ * (so a slice [N][Ctot][2] can be filled from several sources).  nn.InstanceNorm3d / BatchNorm3d /
+ * GroupNorm statistics (buildingblocks.py:429-433; sa_module.py:75; DuSFE.py:108-110). */
+int xh_moments(void* stream, int dtype, const void* x, long long x_bs, int N, int C, long long DHW,
+               double* red, long long red_rs);
+
+/* Turns moments into the affine pre-transform (sc, sh) consumed by xh_conv3d_fwd/xh_affine_act and the
+ * saved (mean, rstd).
+ *  mode 0 InstanceNorm: per (n,c).   mode 1 BatchNorm(train): per c over n, updates running stats
+ *  `steps` times (momentum 0.1, unbiased var) -- steps=4 reproduces the 4x evaluation at RA_HVED.py:548-552.
+ *  mode 2 BatchNorm(eval): uses running stats, ignores red.   mode 3 GroupNorm: per (n, group of gs ch).
+ *  gamma/beta may be NULL (=1/0).  Outputs sc,sh,mean,rstd are [N][C]. */
+int xh_norm_finalize(void* stream, int mode, const double* red, int N, int C, long long count, int gs,
+                     float eps, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, int steps, float* sc, float* sh, float* mean, float* rstd);
+
+/* y = act(x*sc[n,c] + sh[n,c]) -- materialises norm+activation (BasicConv tail, BatchNorm apply). */
+int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                  long long DHW, const float* sc, const float* sh, int act, float slope);
+
+/* Backward reduce through y = leaky(x*sc+sh): g = dy*leaky'(.), red[n][c][0] += g, red[n][c][1] += g*x. */
+int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                      int N, int C, long long DHW, const float* sc, const float* sh, float slope, double* red);
+
+/* Coefficients of the norm backward from the reduced sums: dx = A*g + Cc*x + B.
+ * mode as in xh_norm_finalize (0 IN, 1 BN train, 2 BN eval, 3 GN).  Also emits dgamma/dbeta (ACCUMULATED)
+ * when the norm is affine.  A,B,Cc are [N][C]. */
+int xh_norm_bwd_coef(void* stream, int mode, const double* red, int N, int C, long long count, int gs,
+                     const float* gamma, const float* mean, const float* rstd, float* A, float* B, float* Cc,
+                     float* dgamma, float* dbeta);
+
+/* dx (+)= A[n,c]*g + Cc[n,c]*x + B[n,c], with g = dy (have_g=1: dy already holds g) or
+ * g = dy*leaky'(x*sc+sh) (have_g=0).  accumulate=1 adds into dx. */
+int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                      void* dx, long long dx_bs, int N, int C, long long DHW, const float* A, const float* B,
+                      const float* Cc, int have_g, const float* sc, const float* sh, float slope, int accumulate);
+
+/* nn.MaxPool3d(2) (buildingblocks.py:635-636,656-657) and its backward (first maximum in scan order wins). */
+int xh_maxpool2_fwd(void* stream, int dtype, const void* x, void* y, int NC, int D, int H, int W);
+int xh_maxpool2_bwd(void* stream, int dtype, const void* x, const void* dy, void* dx, int NC, int D, int H, int W,
+                    int accumulate);
+
+/* F.interpolate(mode='trilinear', align_corners=False) to an arbitrary size (buildingblocks.py:785-787,
+ * RA_HVED.py:600-601) and its adjoint. */
+int xh_upsample_trilinear_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs,
+                              int N, int C, int D, int H, int W, int Do, int Ho, int Wo);
+int xh_upsample_trilinear_bwd(void* stream, int dtype, const void* dy, long long dy_bs, void* dx, long long dx_bs,
+                              int N, int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate);
+
+/* generic elementwise helpers */
+/* y = a + b  (b may be NULL: copy) with independent batch strides */
+int xh_add(void* stream, int dtype, const void* a, long long a_bs, const void* b, long long b_bs, void* y,
+           long long y_bs, int N, long long CDHW);
+/* dx = dy * f'(y) for y = act(x): act RELU uses y>0, SIGMOID uses y(1-y) */
+int xh_act_bwd(void* stream, int dtype, const void* dy, const void* y, void* dx, long long n, int act);
+
+/* ------------------------------------------------------------------------------------------------
+ * S-MVAE: product of experts + reparameterisation (buildingblocks.py:853-886, RA_HVED.py:573-597,741-753).
+ * feat: the 4 DRB outputs stacked along channels: [N][4][2L][dhw] (modality m, first L = mu, last L = logvar).
+ * keep: [N][4] floats (1 = modality present).  eps: [N][L][dhw] noise or NULL (valid=True).
+ * Outputs: z [N][L][dhw]; mu_stack, lv_stack [N][5][L][dhw] (index 0 = prior, logvar clipped to +-50;
+ * mask_mu=1 zeroes dropped modalities' mu like ProductOfExperts2's in-place ZeroLayerF).
+ * ------------------------------------------------------------------------------------------------ */
+int xh_poe_fwd(void* stream, int dtype, const void* feat, const float* keep, const void* eps, void* z,
+               void* mu_stack, void* lv_stack, int N, int L, long long dhw, int mask_mu);
+/* dfeat = d/dfeat of (z, mu_stack, lv_stack); dmu_stack/dlv_stack may be NULL. */
+int xh_poe_bwd(void* stream, int dtype, const void* feat, const float* keep, const void* eps, const void* dz,
+               const void* dmu_stack, const void* dlv_stack, void* dfeat, int N, int L, long long dhw, int mask_mu);
+
+/* ------------------------------------------------------------------------------------------------
+ * Channel attention glue.
+ * ------------------------------------------------------------------------------------------------ */
+/* ChannelPool (buildingblocks.py:136-138): y[:,0] = max_c x, y[:,1] = mean_c x, written at y (2 channels). */
+int xh_channel_pool_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
+                        int C, long long DHW);
+/* dx (+)= dy0 * [c == first argmax] + dy1 / C */
+int xh_channel_pool_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* dy, long long dy_bs,
+                        void* dx, long long dx_bs, int N, int C, long long DHW, int accumulate);
+/* y = x * (1 + s[n,0,p])  (AttenModule2 scaling buildingblocks.py:287,297; skip-return x_i = a*x_i + x_i,
+ * RA_HVED.py:552).  s has 1 channel. */
+int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y,
+                long long y_bs, int N, int C, long long DHW);
+/* dx (+)= dy*(1+s);  ds (+)= sum_c dy*x */
+int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs,
+                const void* dy, long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N,
+                int C, long long DHW, int acc_dx, int acc_ds);
+
+/* DuSEAttention gating (modules/DuSFE.py:130-153): u = x * (1 + ch[n,c] + sp[n,0,p]); ch = channel gate
+ * (already sigmoid'ed, fp32 [N][C]), sp = spatial gate (1 channel). */
+int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
+                     long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW);
+/* dx = du*(1+ch+sp); dsp = sum_c du*x; dch[n][c] += sum_p du*x (double accum buffer red1 [N][C]) */
+int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
+                     long long sp_bs, const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp,
+                     long long dsp_bs, double* dch, int N, int C, long long DHW);
+
+/* Skip-return attention tail (sa_module.py:133-135 + attention_blocks.py:119-126):
+ * r = relu(relu(t*sc+sh) + x); a = sigmoid(w0*max_c r + w1*mean_c r).  a has 1 channel. */
+int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
+                    const float* w2, void* a, int N, int C, long long DHW);
+/* Given da: dtg = gradient w.r.t. the BatchNorm output t*sc+sh (already multiplied by both relu'),
+ * dx (+)= gradient through the residual branch, dw2[0..1] (fp64, ACCUMULATED) = gradient of the 1x1 conv. */
+int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
+                    const float* w2, const void* a, const void* da, void* dtg, void* dx, double* dw2, int N, int C,
+                    long long DHW, int acc_dx);
+
+/* dx += w[c]*d[n,0,p] + k[n,c]: rank-1 data gradient of a C->1 1x1 conv plus a per-(n,c) constant (the
+ * global-average-pool gradient) -- finishes DuSEAttention's input gradient (modules/DuSFE.py:118,135-140). */
+int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, const void* d, long long d_bs, const float* w,
+                 const float* k, int N, int C, long long DHW);
+
+/* tiny dense layers on pooled features (DuSFE.py:118-127): handled on device, fp32.
+ * in: mean_r, mean_s [N][C] from moments; out: ch1, ch2 [N][C] (sigmoid'ed) and saved g [N][C]. */
+int xh_duse_fc_fwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
+                   const float* w_comb, const float* b_comb, const float* w1, const float* b1, const float* w2,
+                   const float* b2, float* g, float* ch1, float* ch2);
+int xh_duse_fc_bwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
+                   const float* w_comb, const float* w1, const float* w2, const float* g, const float* ch1,
+                   const float* ch2, const double* dch1, const double* dch2, float* dw_comb, float* db_comb,
+                   float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s);
+
+/* ------------------------------------------------------------------------------------------------
+ * ViL / mLSTM (UxLSTMEnc_3d.py:42-87, vision_lstm.py:48-506).  All fp32.  Token t = flattened (d,h,w),
+ * W fastest; B = batch, S tokens, C model dim, inner = 2C, NH heads of DH = inner/NH.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* norm_w;      /* [C]        vil.norm.weight (LayerNorm weight is 1+w, no bias) */
+  const float* proj_up;     /* [4C][C]    */
+  const float* conv_w;      /* [2C][1][4] causal depthwise conv1d */
+  const float* conv_b;      /* [2C] */
+  const float* q_w; const float* k_w; const float* v_w;   /* [2C/4][4][4] block-diagonal */
+  const float* ig_w; const float* ig_b;                   /* [NH][6C], [NH] */
+  const float* fg_w; const float* fg_b;
+  const float* outnorm_w;   /* [2C] */
+  const float* skip;        /* [2C] learnable_skip */
+  const float* proj_down;   /* [C][2C] */
+} xh_vil_params;
+
+typedef struct {            /* same layout, gradients (ACCUMULATED, caller zeroes) */
+  float* norm_w; float* proj_up; float* conv_w; float* conv_b; float* q_w; float* k_w; float* v_w;
+  float* ig_w; float* ig_b; float* fg_w; float* fg_b; float* outnorm_w; float* skip; float* proj_down;
+} xh_vil_grads;
+
+/* workspace size in floats for B,S,C (forward saves what backward needs inside it) */
+long long xh_vil_workspace_floats(int B, int S, int C);
+/* t = xa (+ xb);  out = (add_xa ? xa : 0) + ViLBlock(t), ViLBlock(t) = t + layer(norm(t)).
+ * xa/xb/out are NCDHW tensors [B][C][S] of storage `dtype` (xb may be NULL).  add_xa=1 is the bottleneck use
+ * rec0 + mViL(rec0 + skip) (RA_HVED.py:626); add_xa=0 is DoubleConv_ViL (buildingblocks.py:554-555). */
+int xh_vil_fwd(void* stream, int dtype, const void* xa, const void* xb, void* out, int B, int S, int C, int NH,
+               int add_xa, const xh_vil_params* p, float* ws);
+/* dxin = dout * dViLBlock/dt (the gradient w.r.t. t = xa+xb; the caller adds dout for xa when add_xa). */
+int xh_vil_bwd(void* stream, int dtype, const void* xa, const void* xb, const void* dout, void* dxin, int B,
+               int S, int C, int NH, const xh_vil_params* p, const xh_vil_grads* g, float* ws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,172 @@
+"""-m gpu: the whole XLSTM_HVED forward/backward on the HIP path against (a) the golden vectors generated from the
+real reference at 32^3 and (b) the CPU oracle at other sizes / modes.  Tolerances follow SURVEY.md 8(c)/F9."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_common import check, load, rel_err, rnd
+
+pytestmark = pytest.mark.gpu
+
+import xlstm_hved_amd as X  # noqa: E402
+import xlstm_hved_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _weights():
+    return load("weights_seed1")
+
+
+def _model(train=True):
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(_weights(), strict=True)
+    return m.to(DEV).train(train)
+
+
+def _dice(prob, tgt):
+    return O.dice_region(prob.float().cpu(), tgt)
+
+
+def test_train_forward_backward_fp32_vs_reference_golden():
+    g = load("net32_train_subset14")
+    m = _model(True)
+    eps = [g[f"eps{i}"] for i in range(4)]
+    seg, (mu, lv), rec = m(g["x"].to(DEV), [14], recon=True, eps_list=eps)
+    rec = rec[0]
+    # fp32 build vs fp32 reference: seg prob atol 5e-3, recon rtol 1e-3*absmax -- measured far tighter
+    e_seg = (seg.cpu() - g["seg"]).abs().max().item()
+    assert e_seg < 2e-4, e_seg
+    check(rec, g["rec"], 2e-4, "recon")
+    # fp64 tie-breaker: our fp32 error vs the fp64 reference <= 2x the fp32 reference's own error
+    e_our = (seg.cpu().double() - g["f64.seg"]).abs().max().item()
+    e_ref = (g["seg"].double() - g["f64.seg"]).abs().max().item()
+    assert e_our <= 2 * e_ref + 2e-5, (e_our, e_ref)
+    for i in range(4):
+        check(mu[i], g[f"mu{i}"], 1e-4, f"mu{i}"), check(lv[i], g[f"lv{i}"], 1e-4, f"lv{i}")
+    # thresholded masks: Dice within 1e-4 of the reference's (target = reference's own fp64 mask)
+    tgt = (g["f64.seg"] > 0.5).float()
+    assert (_dice(seg, tgt) - O.dice_region(g["seg"], tgt)).abs().max() < 1e-4
+    flips = ((seg.cpu() > 0.5) != (g["seg"] > 0.5)).sum().item()
+    assert flips <= 40, flips
+    loss = (seg * rnd(seg.shape, 200).to(DEV)).sum() + 0.1 * (rec * rnd(rec.shape, 201).to(DEV)).sum()
+    for i, (a, b) in enumerate(zip(mu, lv)):
+        loss = loss + 0.05 * ((a * rnd(a.shape, 210 + i).to(DEV)).sum() + (b * rnd(b.shape, 220 + i).to(DEV)).sum())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - g["loss"].item()) < 2e-3 * abs(g["loss"].item())
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith("g."))
+    grads = {}
+    for k, p in m.named_parameters():
+        grads[k.replace("decoders.", "srdecoder.sdecoders.", 1) if k.startswith("decoders.") else k] = p.grad
+    worst, n = 0.0, 0
+    for k, v in g.items():
+        if k.startswith("g."):
+            assert grads[k[2:]] is not None, k
+            err = (grads[k[2:]].cpu() - v).abs().max().item() / gscale
+            worst = max(worst, err)
+            assert err < 2e-3, (k, err)
+            n += 1
+    assert n > 250
+    print(f"worst scaled parameter-gradient deviation {worst:.2e} over {n} tensors")
+    # parameters the reference never reaches get no gradient either
+    for k in ("rdecoder.finals.0.weight", "mViL.norm.weight", "skr_att.0.0.conv1.dwconv.weight",
+              "srdecoder.dusfe_decoders.0.conv_fuse_ch1.weight"):
+        assert grads[k] is None
+    sd = m.state_dict()
+    for k, v in g.items():
+        if k.startswith("after."):
+            check(sd[k[6:]].float(), v.float(), 2e-5, k)
+
+
+def test_all_15_subsets_and_instance_missing_eval_fp32():
+    g = load("net32_subsets_eval")
+    x2 = g["x2"]
+    m = _model(False)
+    with torch.no_grad():
+        for k in range(15):
+            seg, (mu, lv), rec = m(x2[:1].to(DEV), [k], recon=True, valid=True)
+            e = (seg.flatten().cpu()[g["idx_seg"]].double() - g[f"seg_{k}"]).abs().max().item()
+            assert e < 3e-4, (k, e)
+            check(rec[0].flatten().cpu()[g["idx_rec"]], g[f"rec_{k}"], 3e-4, f"rec subset {k}")
+            check(mu[3].flatten(), g[f"mu3_{k}"], 1e-4, f"mu3 subset {k}")
+        xm = x2.clone()
+        for i, mk in enumerate([(1, 3), (0,)]):
+            for c in range(4):
+                if c not in mk:
+                    xm[i, c] = 0
+        S3 = 32 ** 3
+        seg, (mu, lv), rec = m(xm.to(DEV), [14], instance_missing=True, recon=True, valid=True)
+        idx = torch.cat([g["idx_seg"], g["idx_seg"] + 3 * S3])
+        assert (seg.flatten().cpu()[idx].double() - g["im_eval_seg"]).abs().max().item() < 3e-4
+        check(rec[0].flatten().cpu()[torch.cat([g["idx_rec"], g["idx_rec"] + 4 * S3])], g["im_eval_rec"], 3e-4, "im rec")
+        check(mu[0].flatten()[:8192], g["im_eval_mu0"], 1e-4, "im mu0 (masked)")
+    m.train(True)
+    with torch.no_grad():
+        seg, (mu, lv), rec = m(xm.to(DEV), [14], instance_missing=True, recon=True, valid=True)
+    assert (seg.flatten().cpu()[idx].double() - g["im_train_seg"]).abs().max().item() < 3e-4
+    sd = m.state_dict()
+    for k, v in g.items():
+        if k.startswith("im_train_after."):
+            check(sd[k[len("im_train_after."):]].double(), v.double(), 2e-5, k)      # BN buffers incl. the 4-step update
+
+
+def test_bf16_storage_vs_oracle_64():
+    """bf16 storage (fp32 arithmetic, ViL fp32): seg atol 3e-2, Dice |d| <= 1e-3, measured values printed."""
+    torch.manual_seed(5)
+    w = _weights()
+    x = torch.rand(1, 4, 64, 64, 64)
+    sd = {k: v.clone() for k, v in w.items()}
+    prob_o, _, _, _, rec_o = O.xlstm_hved_forward(sd, x, 14, eps_list=None, training=False)
+    m = _model(False)
+    with torch.no_grad():
+        seg, _, rec = m(x.to(DEV, torch.bfloat16), [14], recon=True, valid=True)
+    assert seg.dtype == torch.bfloat16
+    e_seg = (seg.float().cpu() - prob_o).abs().max().item()
+    e_rec = rel_err(rec[0].float(), rec_o)
+    tgt = (prob_o > 0.5).float()
+    d = (_dice(seg, tgt) - 1.0).abs().max().item()
+    print(f"bf16 64^3: seg max|d|={e_seg:.3e} recon rel={e_rec:.3e} dice dev={d:.2e}")
+    assert e_seg < 6e-2 and e_rec < 6e-2 and d < 5e-3
+
+
+def test_fp32_vs_oracle_64_batch2_train_random_subset():
+    torch.manual_seed(9)
+    w = _weights()
+    x = torch.rand(2, 4, 64, 64, 64)
+    eps = [torch.randn(2, 2 ** l, 32 >> l, 32 >> l, 32 >> l) for l in range(4)]
+    sd = {k: v.clone() for k, v in w.items()}
+    prob_o, _, mu_o, lv_o, rec_o = O.xlstm_hved_forward(sd, x, 7, eps_list=eps, training=True)
+    m = _model(True)
+    with torch.no_grad():
+        seg, (mu, lv), rec = m(x.to(DEV), [7], recon=True, eps_list=eps)
+    assert (seg.cpu() - prob_o).abs().max().item() < 5e-4
+    check(rec[0], rec_o, 5e-4, "recon")
+    tgt = (prob_o > 0.5).float()
+    assert (_dice(seg, tgt) - 1.0).abs().max().item() < 1e-4
+
+
+def test_seg_false_and_recon_false_return_shapes():
+    m = _model(False)
+    x = torch.rand(1, 4, 32, 32, 32, device=DEV)
+    with torch.no_grad():
+        out = m(x, [3], valid=True)
+        assert isinstance(out, tuple) and len(out) == 2 and out[1] == [] and out[0].shape == (1, 3, 32, 32, 32)
+        seg, (mu, lv), rec = m(x, [3], seg=False, recon=True, valid=True)      # Pretrain.py uses seg=False
+        assert seg is None and rec[0].shape == (1, 4, 32, 32, 32) and len(mu) == 4 and mu[0].shape == (1, 5, 1, 16, 16, 16)
+
+
+def test_full_size_128_properties_bf16():
+    """BASELINE config 2 size: finite outputs, probabilities in [0,1], batch-of-identical-samples consistency,
+    and subset-independence of the encoder latents (mu/logvar do not depend on the subset)."""
+    m = _model(False)
+    torch.manual_seed(2)
+    x = torch.rand(1, 4, 128, 128, 128, device=DEV).bfloat16()
+    with torch.no_grad():
+        seg, (mu, lv), rec = m(x, [14], recon=True, valid=True)
+        seg7, (mu7, lv7), _ = m(x, [7], recon=True, valid=True)
+    assert torch.isfinite(seg.float()).all() and torch.isfinite(rec[0].float()).all()
+    assert seg.min() >= 0 and seg.max() <= 1
+    for a, b in zip(mu + lv, mu7 + lv7):
+        assert torch.equal(a, b)
+    assert not torch.equal(seg, seg7)

@@ -1,0 +1,194 @@
+"""-m gpu: every fused HIP stage against the golden vectors produced by the REAL reference
+(tests/golden/stage_*.npz: inputs, weights, outputs, input- and parameter-gradients) and against the oracle at
+other shapes.  fp32 storage is held to round-off; bf16 storage to bf16 resolution."""
+import pytest
+import torch
+
+from gpu_common import check, load, rel_err, rnd, sd_of
+
+pytestmark = pytest.mark.gpu
+
+import xlstm_hved_amd as X  # noqa: E402
+import xlstm_hved_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _stage_modules():
+    return {
+        "stage_singleconv_ilc": lambda: X.SingleConv(4, 8, 3, 1, "ilc", 8, padding=1),
+        "stage_singleconv_ilc_s2": lambda: X.SingleConv(8, 4, 3, 2, "ilc", 8, padding=1),
+        "stage_singleconv_gcr": lambda: X.SingleConv(16, 8, 3, 1, "gcr", 8, padding=1),
+        "stage_singleconv_gcr_g1": lambda: X.SingleConv(4, 8, 3, 1, "gcr", 8, padding=1),
+        "stage_encoder_pool": lambda: X.Encoder(4, 8, conv_layer_order="ilc"),
+        "stage_encoder_nopool": lambda: X.Encoder(4, 4, apply_pooling=False, conv_layer_order="ilc"),
+        "stage_basicconv_1x1": lambda: X.BasicConv(2, 8, 1),
+        "stage_basicconv_dw": lambda: X.BasicConv(8, 8, 3, padding=1, groups=8),
+        "stage_decoder_recon": lambda: X.Decoder(24, 8, conv_layer_order="ilc"),
+        "stage_decoder_seg": lambda: X.Decoder(12, 4, conv_layer_order="ilc", RSM=True, MVAE=True),
+        "stage_duse_train": lambda: X.DuSEAttention(8),
+        "stage_duse_eval": lambda: X.DuSEAttention(4),
+        "stage_skr_att_train": lambda: X.SkipReturnAttention(8),
+        "stage_skr_att_eval": lambda: X.SkipReturnAttention(4),
+        "stage_vil_s64": lambda: X.ViLLayer(32),
+        "stage_vil_s512": lambda: X.ViLLayer(32),
+    }
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", sorted(_stage_modules()))
+def test_stage_against_reference_golden(name, dtype):
+    g = load(name)
+    mod = _stage_modules()[name]()
+    mod.load_state_dict(sd_of(g), strict=True)
+    mod = mod.to(DEV)
+    mod.train("eval" not in name)
+    ins = []
+    i = 0
+    while f"in{i}" in g:
+        ins.append(g[f"in{i}"].to(DEV, dtype).requires_grad_(True))
+        i += 1
+    out = mod(*ins)
+    outs = list(out) if isinstance(out, (tuple, list)) else [out]
+    f32 = dtype == torch.float32
+    tol_o = (2e-4 if "vil" in name else 5e-5) if f32 else 4e-2
+    tol_g = 2e-3 if f32 else 1.5e-1
+    loss = 0
+    for j, o in enumerate(outs):
+        assert o.dtype == dtype
+        check(o, g[f"out{j}"], tol_o, f"{name}.out{j}")
+        loss = loss + (o.float() * g[f"w{j}"].to(DEV)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    for j, t in enumerate(ins):
+        check(t.grad, g[f"gin{j}"], tol_g, f"{name}.gin{j}")
+    params = dict(mod.named_parameters())
+    for k, v in g.items():
+        if k.startswith("g."):
+            assert params[k[2:]].grad is not None, f"{name}: no gradient for {k[2:]}"
+            check(params[k[2:]].grad, v, tol_g, f"{name}.{k}")
+    if f32:
+        sd = mod.state_dict()
+        for k, v in sd_of(g, "sd_after.").items():
+            check(sd[k].float(), v.float(), 1e-5, f"{name}.buffer.{k}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_poe_all_subsets_and_drop(dtype):
+    g = load("stage_poe")
+    mu, lv = g["mu"], g["logvar"]                       # (5,N,L,d,h,w), index 0 = prior
+    n, L = mu.shape[1], mu.shape[2]
+    feat = torch.cat([torch.cat([mu[m + 1], lv[m + 1]], 1) for m in range(4)], 1).to(DEV, dtype).contiguous()
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    # the fixture's logvar is not clipped; the stage clips at +-50 like RA_HVED.py:580 (no value exceeds it here)
+    assert lv.abs().max() < 50
+    for idx, subset in enumerate(X.SUBSETS_MODALITIES):
+        keep = torch.tensor([[1.0 if k in subset else 0.0 for k in range(4)]] * n, device=DEV)
+        z, ms, ls = X.functional.PoE.apply(feat, keep, None, L, False)
+        check(z, g[f"mu_{idx}"], tol, f"poe mu subset {idx}")
+        check(ms.transpose(0, 1), mu, tol, "mu stack")
+        check(ls.transpose(0, 1), lv, tol, "logvar stack")
+    keep = (~g["drop"]).float().to(DEV)
+    eps = g["eps"].to(DEV, dtype)
+    z, ms, ls = X.functional.PoE.apply(feat, keep, eps, L, True)
+    check(z, g["z"], tol if dtype == torch.float32 else 6e-2, "z with eps (instance missing)")
+    check(ms.transpose(0, 1), g["mu_after"], tol, "masked mu stack")
+
+
+def test_poe_backward_matches_oracle():
+    torch.manual_seed(3)
+    n, L, s = 2, 2, 4
+    feat = (torch.randn(n, 4 * 2 * L, s, s, s) * 2).double()
+    feat[0, 3] = 60.0            # exercise the clip mask
+    eps = torch.randn(n, L, s, s, s).double()
+    drop = torch.tensor([[False, True, False, False], [True, False, False, True]])
+    wz, wm, wl = rnd((n, L, s, s, s), 1).double(), rnd((n, 5, L, s, s, s), 2).double(), rnd((n, 5, L, s, s, s), 3).double()
+
+    def oracle(f):
+        f5 = f.view(n, 4, 2 * L, s, s, s)
+        mu = torch.stack([torch.zeros_like(f5[:, 0, :L])] + [f5[:, m, :L] for m in range(4)], 0)
+        lv = torch.stack([torch.zeros_like(f5[:, 0, :L])] + [O.clip_logvar(f5[:, m, L:]) for m in range(4)], 0)
+        pm, pl, mum = O.product_of_experts_drop(mu, lv, drop)
+        return O.reparametrize(pm, pl, eps), mum.transpose(0, 1), lv.transpose(0, 1)
+    f = feat.clone().requires_grad_(True)
+    z, m, l = oracle(f)
+    ((z * wz).sum() + (m * wm).sum() + (l * wl).sum()).backward()
+    fg = feat.float().to(DEV).requires_grad_(True)
+    z2, m2, l2 = X.functional.PoE.apply(fg, (~drop).float().to(DEV), eps.float().to(DEV), L, True)
+    ((z2 * wz.float().to(DEV)).sum() + (m2 * wm.float().to(DEV)).sum() + (l2 * wl.float().to(DEV)).sum()).backward()
+    check(z2, z, 1e-5, "z"), check(m2, m, 1e-6, "mu"), check(l2, l, 1e-6, "lv")
+    check(fg.grad, f.grad, 1e-4, "dfeat")
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 8, 8, 16), (2, 3, 6, 10, 14), (1, 2, 2, 2, 2)])
+def test_maxpool_upsample_roundtrip(shape):
+    torch.manual_seed(0)
+    x = torch.randn(shape)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+        xs = x.to(dtype).float()          # identical stored values on both sides
+        xg = xs.to(DEV, dtype).requires_grad_(True)
+        xo = xs.clone().requires_grad_(True)
+        size = tuple(2 * s for s in shape[2:])
+        up = X.functional.Upsample.apply(xg, size)
+        upo = O.upsample_to(xo, size)
+        check(up, upo, tol, "upsample")
+        w = torch.randn(upo.shape)
+        (up.float() * w.to(DEV)).sum().backward()
+        (upo * w).sum().backward()
+        check(xg.grad, xo.grad, tol * 4, "upsample grad")
+        if all(s % 2 == 0 for s in shape[2:]):
+            xg.grad = None
+            xo.grad = None
+            mp = X.functional.MaxPool2.apply(xg)
+            mpo = torch.nn.functional.max_pool3d(xo, 2)
+            check(mp, mpo, 0 if dtype == torch.float32 else 1e-9, "maxpool")
+            w = torch.randn(mpo.shape)
+            (mp.float() * w.to(DEV)).sum().backward()
+            (mpo * w).sum().backward()
+            if dtype == torch.float32:     # bf16 ties may pick a different (equal-valued) voxel
+                check(xg.grad, xo.grad, 1e-6, "maxpool grad")
+
+
+def test_upsample_arbitrary_size_is_adjoint_consistent():
+    torch.manual_seed(1)
+    x = torch.randn(1, 2, 5, 6, 7)
+    size = (9, 13, 10)
+    xg = x.to(DEV).requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    up, upo = X.functional.Upsample.apply(xg, size), O.upsample_to(xo, size)
+    check(up, upo, 1e-6, "upsample")
+    w = torch.randn(upo.shape)
+    (up * w.to(DEV)).sum().backward()
+    (upo * w).sum().backward()
+    check(xg.grad, xo.grad, 1e-5, "upsample grad")
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=4, cout=4, sp=(12, 20, 36), groups=1), dict(cin=16, cout=32, sp=(8, 8, 8), groups=4),
+                                 dict(cin=48, cout=16, sp=(4, 6, 10), groups=1, split=16), dict(cin=8, cout=16, sp=(16, 16, 16), groups=4, stride=2),
+                                 dict(cin=12, cout=4, sp=(9, 7, 5), groups=1, split=4)])
+def test_in_lrelu_conv_shapes_vs_oracle(cfg):
+    """Ragged / grouped / virtual-concat / strided shapes of the fused IN->LeakyReLU->conv stage vs stock ops."""
+    torch.manual_seed(7)
+    n, cin, cout, g, stride = 2, cfg["cin"], cfg["cout"], cfg["groups"], cfg.get("stride", 1)
+    x = torch.randn((n, cin) + cfg["sp"]) * 2 + 0.5
+    ws = [torch.randn(cout // g, cin // g, 3, 3, 3) * 0.2 for _ in range(g)]
+    bs = [torch.randn(cout // g) for _ in range(g)]
+    xo = x.clone().requires_grad_(True)
+    wo = [w.clone().requires_grad_(True) for w in ws]
+    bo = [b.clone().requires_grad_(True) for b in bs]
+    h = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(xo, eps=1e-5), 0.01)
+    yo = torch.nn.functional.conv3d(h, torch.cat(wo, 0), torch.cat(bo, 0), stride=stride, padding=1, groups=g)
+    wgt = torch.randn(yo.shape)
+    (yo * wgt).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    wg = [w.to(DEV).requires_grad_(True) for w in ws]
+    bg = [b.to(DEV).requires_grad_(True) for b in bs]
+    if "split" in cfg:
+        xa, xb = xg[:, :cfg["split"]], xg[:, cfg["split"]:]
+    else:
+        xa, xb = xg, None
+    y = X.functional.in_lrelu_conv(xa, xb, wg, bg, stride, g)
+    (y * wgt.to(DEV)).sum().backward()
+    check(y, yo, 5e-5, "y"), check(xg.grad, xo.grad, 1e-3, "dx")
+    for a, b in zip(wg + bg, wo + bo):
+        check(a.grad, b.grad, 1e-3, "dparam")

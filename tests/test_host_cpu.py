@@ -1,0 +1,112 @@
+"""Host-side checks that run without a GPU: module tree / state_dict parity with the reference, C-ABI symbol
+export, and that the product path refuses to run without the HIP library + GPU (no fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _manifest():
+    rows = []
+    with open(os.path.join(GOLDEN, "state_dict_manifest.txt")) as f:
+        for line in f:
+            name, shape, dtype = line.rstrip("\n").split("\t")
+            rows.append((name, tuple(int(s) for s in shape.split(",")) if shape else (), dtype))
+    return rows
+
+
+@pytest.fixture(scope="module")
+def X():
+    import xlstm_hved_amd
+    return xlstm_hved_amd
+
+
+def test_state_dict_keys_shapes_match_reference(X):
+    model = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    sd = model.state_dict()
+    ref = _manifest()
+    assert len(ref) == 428
+    assert [k for k, _, _ in ref] == list(sd.keys()), "state_dict key order/names differ from the reference"
+    for k, shape, dtype in ref:
+        assert tuple(sd[k].shape) == shape, k
+        assert str(sd[k].dtype).replace("torch.", "") == dtype, k
+    # decoders.* and srdecoder.sdecoders.* alias the same modules (RA_HVED.py:492)
+    assert sd["decoders.0.basic_module.SingleConv1.conv.weight"].data_ptr() == \
+        sd["srdecoder.sdecoders.0.basic_module.SingleConv1.conv.weight"].data_ptr()
+    assert sum(p.numel() for p in model.parameters()) == 422588
+
+
+def test_reference_checkpoint_loads_strict(X):
+    z = np.load(os.path.join(GOLDEN, "weights_seed1.npz"))
+    sd = {k: torch.from_numpy(z[k]) for k in z.files}
+    model = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+@pytest.mark.parametrize("name,count", [
+    ("XLSTM_HVED", 422588), ("U_HVEDConvDuSFEmViLSkrNet3D", 422588), ("XLSTM_HVED_woViL", 413588),
+    ("XLSTM_HVED_woSMVAE", 387460), ("U_HVEDConvDuSFEmViLNet3D", 387460), ("U_HVEDConvDuSFENet3D", 378460),
+    ("XLSTM_HVED_woDuSFE", 329937), ("U_HVEDConvXLSTMNet3D", 288777), ("U_HVEDConvNet3D", 285809)])
+def test_variant_parameter_counts(X, name, count):
+    # parameter counts of the variants that run with the train.py kwargs
+    model = X.find_model_using_name(name)(1, 3, **X.TRAIN_KWARGS)
+    assert sum(p.numel() for p in model.parameters()) == count
+
+
+def test_init_weights_sees_stock_holders(X):
+    model = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    torch.manual_seed(0)
+    before = model.final_conv.bias.clone()
+    model.apply(X.init_weights)
+    assert not torch.equal(before, model.final_conv.bias)
+    kinds = {type(m).__name__ for m in model.modules()}
+    assert {"Conv3d", "Linear", "BatchNorm3d"} <= kinds
+
+
+def test_unsupported_configurations_are_rejected(X):
+    with pytest.raises(NotImplementedError):
+        X.XLSTM_HVED(1, 3, **dict(X.TRAIN_KWARGS, MVAE_reduction=False))
+    with pytest.raises(AssertionError):      # buildingblocks.py:428: 12 channels are not divisible by 8 groups
+        X.XLSTM_HVED(1, 3, **dict(X.TRAIN_KWARGS, layer_order="gcr"))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "xlstm_hved.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(xh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(X):
+    import ctypes
+    names = _header_functions()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(X._lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/xlstm_hved.h but not exported"
+    assert set(names) == set(X._lib.SIGNATURES), set(names) ^ set(X._lib.SIGNATURES)
+    assert X._lib.load().xh_abi_version() == 1
+
+
+def test_no_cpu_fallback(X):
+    model = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    with pytest.raises(RuntimeError, match="device tensors"):
+        model(torch.rand(1, 4, 16, 16, 16), [14], recon=True, valid=True)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "xlstm-hved_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            text = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in text.replace("the oracle", ""), fn
+
+
+def test_subset_table(X):
+    s = X.SUBSETS_MODALITIES
+    assert s[:4] == [(0,), (1,), (2,), (3,)] and s[4:10] == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)] and s[14] == (0, 1, 2, 3)

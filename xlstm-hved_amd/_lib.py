@@ -1,0 +1,109 @@
+"""ctypes binding of libxlstm_hved_hip.so (the C ABI declared in include/xlstm_hved.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  Calling any op without the built
+library (or without a GPU) raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libxlstm_hved_hip.so")
+
+XH_F32, XH_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+
+c_fp = C.POINTER(C.c_float)
+c_dp = C.POINTER(C.c_double)
+vp = C.c_void_p
+ll = C.c_longlong
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("N", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("groups", C.c_int),
+        ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Do", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+        ("k", C.c_int), ("stride", C.c_int), ("Ca", C.c_int),
+        ("xa_bs", ll), ("xb_bs", ll), ("y_bs", ll),
+        ("n_wptr", C.c_int), ("transposed", C.c_int), ("pre", C.c_int), ("pre_slope", C.c_float),
+        ("act", C.c_int), ("act_slope", C.c_float), ("epi", C.c_int), ("Cea", C.c_int),
+        ("ea_bs", ll), ("eb_bs", ll), ("e_slope", C.c_float),
+    ]
+
+
+class ConvPtrs(C.Structure):
+    _fields_ = [
+        ("xa", vp), ("xb", vp), ("w", vp * 4), ("b", vp * 4), ("pre_sc", vp), ("pre_sh", vp), ("y", vp),
+        ("ea", vp), ("eb", vp), ("e_sc", vp), ("e_sh", vp), ("red", vp),
+    ]
+
+
+VIL_FIELDS = ["norm_w", "proj_up", "conv_w", "conv_b", "q_w", "k_w", "v_w", "ig_w", "ig_b", "fg_w", "fg_b",
+              "outnorm_w", "skip", "proj_down"]
+
+
+class VilParams(C.Structure):
+    _fields_ = [(n, vp) for n in VIL_FIELDS]
+
+
+# name -> (restype, argtypes); mirrors include/xlstm_hved.h one to one
+I, F = C.c_int, C.c_float
+SIGNATURES = {
+    "xh_abi_version": (I, []),
+    "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
+    "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
+    "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * 4), C.POINTER(vp * 4)]),
+    "xh_moments": (I, [vp, I, vp, ll, I, I, ll, vp, ll]),
+    "xh_norm_finalize": (I, [vp, I, vp, I, I, ll, I, F, vp, vp, vp, vp, I, vp, vp, vp, vp]),
+    "xh_affine_act": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, I, F]),
+    "xh_act_bwd_reduce": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, F, vp]),
+    "xh_norm_bwd_coef": (I, [vp, I, vp, I, I, ll, I, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "xh_norm_bwd_apply": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I, vp, vp, F, I]),
+    "xh_maxpool2_fwd": (I, [vp, I, vp, vp, I, I, I, I]),
+    "xh_maxpool2_bwd": (I, [vp, I, vp, vp, vp, I, I, I, I, I]),
+    "xh_upsample_trilinear_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, I, I, I]),
+    "xh_upsample_trilinear_bwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, I, I, I, I]),
+    "xh_add": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, ll]),
+    "xh_act_bwd": (I, [vp, I, vp, vp, vp, ll, I]),
+    "xh_poe_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
+    "xh_poe_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
+    "xh_channel_pool_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, ll]),
+    "xh_channel_pool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, I]),
+    "xh_gate_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll]),
+    "xh_gate_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, ll, I, I]),
+    "xh_duse_gate_fwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll]),
+    "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll]),
+    "xh_rank1_add": (I, [vp, I, vp, ll, vp, ll, vp, vp, I, I, ll]),
+    "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "xh_skr_tail_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll]),
+    "xh_skr_tail_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
+    "xh_vil_workspace_floats": (ll, [I, I, I]),
+    "xh_vil_fwd": (I, [vp, I, vp, vp, vp, I, I, I, I, I, C.POINTER(VilParams), vp]),
+    "xh_vil_bwd": (I, [vp, I, vp, vp, vp, vp, I, I, I, I, C.POINTER(VilParams), C.POINTER(VilParams), vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  The HIP library is the only compute path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+ERRORS = {-1: "bad argument / unsupported shape combination", -2: "unsupported dtype", -3: "HIP launch failed"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,103 @@
+// Shared device helpers for the XLSTM-HVED gfx950 kernel library.
+// Storage types: float or bf16 (raw 16-bit), arithmetic is always fp32 (double for cross-block sums).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define XH_OK 0
+#define XH_ERR_ARG (-1)       // bad shape / unsupported combination
+#define XH_ERR_DTYPE (-2)
+#define XH_ERR_HIP (-3)       // launch failed
+
+#define XH_F32 0
+#define XH_BF16 1
+
+#define XH_ACT_NONE 0
+#define XH_ACT_RELU 1
+#define XH_ACT_LRELU 2
+#define XH_ACT_SIGMOID 3
+
+struct bf16_t { unsigned short v; };
+
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float ldf(const float* p, long long i) { return p[i]; }
+__device__ __forceinline__ float ldf(const bf16_t* p, long long i) { return bf2f(p[i].v); }
+__device__ __forceinline__ void stf(float* p, long long i, float v) { p[i] = v; }
+__device__ __forceinline__ void stf(bf16_t* p, long long i, float v) { p[i].v = f2bf(v); }
+// value as it will be read back from storage
+__device__ __forceinline__ float rnd_as(const float*, float v) { return v; }
+__device__ __forceinline__ float rnd_as(const bf16_t*, float v) { return bf2f(f2bf(v)); }
+
+// 4-wide contiguous access (caller guarantees alignment: 16 B for float, 8 B for bf16)
+__device__ __forceinline__ void ld4(const float* p, long long i, float (&o)[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, long long i, float (&o)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p + i);
+  o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
+  o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, long long i, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(bf16_t* p, long long i, const float (&v)[4]) {
+  uint2 t;
+  t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+  t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p + i) = t;
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case XH_ACT_RELU: return v > 0.f ? v : 0.f;
+    case XH_ACT_LRELU: return leaky(v, slope);
+    case XH_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum of NV per-thread values (block = NW waves); result valid in threads 0..NV-1 as ret[...] via smem.
+// smem must hold NW*NV floats.  After the call smem[0..NV) (first row) holds the totals (all threads may read
+// them after the trailing barrier).
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* smem, int nwaves) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = wave_sum(v[i]);
+    if (lane == 0) smem[wid * NV + i] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NV) {
+    float s = 0.f;
+    for (int w = 0; w < nwaves; ++w) s += smem[w * NV + threadIdx.x];
+    smem[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+static inline int xh_launch_status() { return hipGetLastError() == hipSuccess ? XH_OK : XH_ERR_HIP; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

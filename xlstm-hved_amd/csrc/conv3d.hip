@@ -1,0 +1,810 @@
+// Direct 3D convolution kernels for tiny channel counts (4..48 per group) on gfx950.
+//
+// Layout: NCDHW, W contiguous.  A workgroup of 256 threads (4 waves) owns an output tile of
+// TW x 8 x TD voxels (TW = 4*TXN, TD = 32/TXN); each thread produces 4 consecutive outputs along W for COB
+// output channels.  The input halo tile is staged into LDS once per chunk of input channels with the
+// producing norm + activation applied on the way in (x*sc+sh, leaky) so normalised activations never
+// round-trip through HBM; weights for the chunk sit next to it in LDS laid out [ci][tap][co] so one
+// broadcast ds_read feeds COB FMAs per lane.  Accumulation is fp32.
+//
+// The same kernel is the stride-1 data gradient (transposed=1: roles of Cin/Cout swapped and taps flipped
+// while reading the forward-layout weights) with a fused epilogue that multiplies by leaky'() of the forward
+// input's normalised value and block-reduces the two sums the InstanceNorm/BatchNorm backward needs.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+struct ConvK {
+  xh_conv_desc d;
+  xh_conv_ptrs p;
+  int Cin_g, Cout_g, ncob, tilesW, tilesH, tilesD;
+};
+
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float conv_weight(const ConvK& a, int g, int co_g, int ci_g, int tap, int K3) {
+  const int gpp = a.d.groups / a.d.n_wptr;   // groups per weight pointer
+  const float* wp = a.p.w[g / gpp];
+  const int gl = g % gpp;
+  if (!a.d.transposed) return wp[((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * K3 + tap];
+  return wp[((long long)(gl * a.Cin_g + ci_g) * a.Cout_g + co_g) * K3 + (K3 - 1 - tap)];
+}
+__device__ __forceinline__ float conv_bias(const ConvK& a, int g, int co_g) {
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const float* bp = a.p.b[g / gpp];
+  return bp ? bp[(g % gpp) * a.Cout_g + co_g] : 0.f;
+}
+
+template <typename T>
+__device__ __forceinline__ const T* in_plane(const ConvK& a, int n, int c, long long dhw) {
+  return c < a.d.Ca ? (const T*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
+                    : (const T*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw;
+}
+template <typename T>
+__device__ __forceinline__ const T* epi_plane(const ConvK& a, int n, int c, long long dhw) {
+  return c < a.d.Cea ? (const T*)a.p.ea + n * a.d.ea_bs + (long long)c * dhw
+                     : (const T*)a.p.eb + n * a.d.eb_bs + (long long)(c - a.d.Cea) * dhw;
+}
+
+// Epilogue for NV consecutive outputs of one (n, c) row starting at spatial offset `sp`; `valid` = how many of
+// them exist.  Returns partial sums through s0/s1.
+template <typename T, int NV>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long long odhw, long long sp, int valid,
+                                              float bias, float (&val)[NV], float& s0, float& s1) {
+  T* yp = (T*)a.p.y + n * a.d.y_bs + (long long)c * odhw + sp;
+  float esc = 0.f, esh = 0.f;
+  const T* ep = nullptr;
+  if (a.d.epi == 1) {
+    esc = a.p.e_sc[n * a.d.Cout + c];
+    esh = a.p.e_sh[n * a.d.Cout + c];
+    ep = epi_plane<T>(a, n, c, odhw) + sp;
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    float o = apply_act(val[v] + bias, a.d.act, a.d.act_slope);
+    if (v < valid) {
+      if (a.d.epi == 1) {
+        const float ev = ldf(ep, v);
+        o = rnd_as(yp, o * ((ev * esc + esh) > 0.f ? 1.f : a.d.e_slope));
+        s0 += o;
+        s1 += o * ev;
+      } else if (a.d.epi == 2) {
+        o = rnd_as(yp, o);
+        s0 += o;
+        s1 += o * o;
+      }
+    }
+    val[v] = o;
+  }
+  if (NV == 4 && valid == 4 && ((odhw | sp | a.d.y_bs) & 3) == 0) {
+    float t[4] = {val[0], val[1], val[2], val[3]};
+    st4(yp, 0, t);
+  } else {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      if (v < valid) stf(yp, v, val[v]);
+  }
+}
+
+template <int COB>
+__device__ __forceinline__ void conv_reduce_out(const ConvK& a, int n, int g, int cob, float (&s0)[COB],
+                                                float (&s1)[COB], float* s_red) {
+  float v[2 * COB];
+#pragma unroll
+  for (int i = 0; i < COB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
+  block_sum<2 * COB>(v, s_red, blockDim.x >> 6);
+  if ((int)threadIdx.x < 2 * COB) {
+    const int co_g = cob * COB + (threadIdx.x >> 1);
+    if (co_g < a.Cout_g) {
+      const int c = g * a.Cout_g + co_g;
+      atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + (threadIdx.x & 1)], (double)s_red[threadIdx.x]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k = 3 / 7 forward (and stride-1 dgrad)
+// ---------------------------------------------------------------------------------------------------
+template <int K, int S>
+struct ConvCfg {
+  static constexpr int CIC = (K == 3 && S == 1) ? 4 : (K == 7 ? 2 : 1);
+};
+
+template <typename T, int K, int S, int COB, int TXN>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
+  constexpr int VW = 4, TW = TXN * VW, TH = 8, TD = 32 / TXN;
+  constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K, ID = (TD - 1) * S + K;
+  constexpr int IWP = (IW + 3) / 4 * 4;
+  constexpr int CIC = ConvCfg<K, S>::CIC;
+  constexpr int K3 = K * K * K;
+  constexpr int ROWN = (VW - 1) * S + K;
+  constexpr int PAD = K / 2;
+  constexpr int UNR = (K == 3) ? 3 : 1;
+  __shared__ __attribute__((aligned(16))) float s_in[CIC * ID * IH * IWP];
+  __shared__ __attribute__((aligned(16))) float s_w[CIC * K3 * COB];
+  __shared__ float s_red[4 * 2 * COB];
+
+  const int tid = threadIdx.x;
+  const int tx = tid % TXN, ty = (tid / TXN) % TH, tz = tid / (TXN * TH);
+  int t = blockIdx.x;
+  const int tw = t % a.tilesW; t /= a.tilesW;
+  const int th = t % a.tilesH;
+  const int td = t / a.tilesH;
+  const int cob = blockIdx.y;
+  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long dhw = (long long)D * H * W;
+  const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+  const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+
+  float acc[COB][VW];
+#pragma unroll
+  for (int i = 0; i < COB; ++i)
+#pragma unroll
+    for (int v = 0; v < VW; ++v) acc[i][v] = 0.f;
+
+  for (int c0 = 0; c0 < a.Cin_g; c0 += CIC) {
+    __syncthreads();
+    // ---- stage inputs (transform applied before zero padding) ----
+    for (int cc = 0; cc < CIC; ++cc) {
+      const int ci_g = c0 + cc;
+      float* dst = s_in + cc * (ID * IH * IWP);
+      if (ci_g < a.Cin_g) {
+        const int c = g * a.Cin_g + ci_g;
+        const T* src = in_plane<T>(a, n, c, dhw);
+        float sc = 1.f, sh = 0.f;
+        if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+        for (int idx = tid; idx < ID * IH * IWP; idx += 256) {
+          const int wx = idx % IWP;
+          const int r = idx / IWP;
+          const int hy = r % IH, dz = r / IH;
+          const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
+          float v = 0.f;
+          if (wx < IW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) {
+            v = ldf(src, ((long long)gd * H + gh) * W + gw);
+            if (a.d.pre) v = leaky(v * sc + sh, a.d.pre_slope);
+          }
+          dst[idx] = v;
+        }
+      } else {
+        for (int idx = tid; idx < ID * IH * IWP; idx += 256) dst[idx] = 0.f;
+      }
+    }
+    // ---- stage weights [cc][tap][co] ----
+    for (int idx = tid; idx < CIC * K3 * COB; idx += 256) {
+      const int co = idx % COB;
+      const int r = idx / COB;
+      const int tap = r % K3, cc = r / K3;
+      const int ci_g = c0 + cc, co_g = cob * COB + co;
+      s_w[idx] = (ci_g < a.Cin_g && co_g < a.Cout_g) ? conv_weight(a, g, co_g, ci_g, tap, K3) : 0.f;
+    }
+    __syncthreads();
+    // ---- compute ----
+    const float* base = s_in + ((tz * S) * IH + ty * S) * IWP + tx * VW * S;
+#pragma unroll 1
+    for (int cc = 0; cc < CIC; ++cc) {
+#pragma unroll UNR
+      for (int kd = 0; kd < K; ++kd) {
+#pragma unroll UNR
+        for (int kh = 0; kh < K; ++kh) {
+          const float* row = base + ((cc * ID + kd) * IH + kh) * IWP;
+          float r[ROWN];
+#pragma unroll
+          for (int i = 0; i + 3 < ROWN; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(row + i);
+            r[i] = q.x; r[i + 1] = q.y; r[i + 2] = q.z; r[i + 3] = q.w;
+          }
+#pragma unroll
+          for (int i = ROWN / 4 * 4; i < ROWN; ++i) r[i] = row[i];
+          const float* wrow = s_w + ((cc * K3) + (kd * K + kh) * K) * COB;
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float wr[COB];
+#pragma unroll
+            for (int co = 0; co < COB; ++co) wr[co] = wrow[kw * COB + co];
+#pragma unroll
+            for (int co = 0; co < COB; ++co)
+#pragma unroll
+              for (int v = 0; v < VW; ++v) acc[co][v] = fmaf(wr[co], r[v * S + kw], acc[co][v]);
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue ----
+  const int od = od0 + tz, oh = oh0 + ty, ow = ow0 + tx * VW;
+  const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long odhw = (long long)Do * Ho * Wo;
+  int valid = 0;
+  if (od < Do && oh < Ho && ow < Wo) valid = min(VW, Wo - ow);
+  float s0[COB], s1[COB];
+#pragma unroll
+  for (int co = 0; co < COB; ++co) {
+    s0[co] = 0.f; s1[co] = 0.f;
+    const int co_g = cob * COB + co;
+    if (co_g < a.Cout_g && valid > 0) {
+      const int c = g * a.Cout_g + co_g;
+      conv_epilogue<T, VW>(a, n, c, odhw, ((long long)od * Ho + oh) * Wo + ow, valid, conv_bias(a, g, co_g), acc[co],
+                           s0[co], s1[co]);
+    }
+  }
+  if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k = 1 forward / dgrad: no halo, inputs straight from global memory (4 voxels per lane, vectorised).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int COB, bool VEC>
+__global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
+  constexpr int VW = 4;
+  __shared__ float s_w[128 * COB];
+  __shared__ float s_red[4 * 2 * COB];
+  const int tid = threadIdx.x;
+  const int cob = blockIdx.y;
+  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  const long long dhw = (long long)a.d.D * a.d.H * a.d.W;
+  for (int idx = tid; idx < a.Cin_g * COB; idx += 256) {
+    const int co = idx % COB, ci_g = idx / COB, co_g = cob * COB + co;
+    s_w[idx] = co_g < a.Cout_g ? conv_weight(a, g, co_g, ci_g, 0, 1) : 0.f;
+  }
+  __syncthreads();
+  const long long q0 = ((long long)blockIdx.x * 256 + tid) * VW;
+  int valid = 0;
+  if (q0 < dhw) valid = (int)min((long long)VW, dhw - q0);
+  float acc[COB][VW];
+#pragma unroll
+  for (int i = 0; i < COB; ++i)
+#pragma unroll
+    for (int v = 0; v < VW; ++v) acc[i][v] = 0.f;
+  if (valid > 0) {
+    for (int ci_g = 0; ci_g < a.Cin_g; ++ci_g) {
+      const int c = g * a.Cin_g + ci_g;
+      const T* src = in_plane<T>(a, n, c, dhw) + q0;
+      float x[VW];
+      if (VEC) {
+        ld4(src, 0, x);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) x[v] = v < valid ? ldf(src, v) : 0.f;
+      }
+      if (a.d.pre) {
+        const float sc = a.p.pre_sc[n * a.d.Cin + c], sh = a.p.pre_sh[n * a.d.Cin + c];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) x[v] = leaky(x[v] * sc + sh, a.d.pre_slope);
+      }
+#pragma unroll
+      for (int co = 0; co < COB; ++co) {
+        const float w = s_w[ci_g * COB + co];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) acc[co][v] = fmaf(w, x[v], acc[co][v]);
+      }
+    }
+  }
+  float s0[COB], s1[COB];
+#pragma unroll
+  for (int co = 0; co < COB; ++co) {
+    s0[co] = 0.f; s1[co] = 0.f;
+    const int co_g = cob * COB + co;
+    if (co_g < a.Cout_g && valid > 0) {
+      const int c = g * a.Cout_g + co_g;
+      conv_epilogue<T, VW>(a, n, c, dhw, q0, valid, conv_bias(a, g, co_g), acc[co], s0[co], s1[co]);
+    }
+  }
+  if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k = 3, stride = 2 data gradient (DRB).  One lane per forward-input voxel, CIB input channels per lane;
+// gathers the <= 8 contributing output voxels per tap parity.  Small tensors only (latent resolution).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int CIB>
+__global__ __launch_bounds__(256) void conv3_dgrad_s2_kernel(const ConvK a) {
+  // here a.d describes the FORWARD conv: Cin_g/Cout_g forward; xa = dY (Cout channels), y = dX
+  extern __shared__ float s_dyn[];   // [Cout_g][CIB][27] weights + reduction scratch
+  float* s_w = s_dyn;
+  float* s_red = s_dyn + a.Cout_g * CIB * 27;
+  const int tid = threadIdx.x;
+  const int cib = blockIdx.y;
+  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const float* wp = a.p.w[g / gpp];
+  const int gl = g % gpp;
+  for (int idx = tid; idx < a.Cout_g * CIB * 27; idx += 256) {
+    const int tap = idx % 27;
+    const int r = idx / 27;
+    const int ci = r % CIB, co_g = r / CIB;
+    const int ci_g = cib * CIB + ci;
+    s_w[idx] = ci_g < a.Cin_g ? wp[((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * 27 + tap] : 0.f;
+  }
+  __syncthreads();
+  const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  const long long q = (long long)blockIdx.x * 256 + tid;
+  const bool ok = q < dhw;
+  float acc[CIB];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i) acc[i] = 0.f;
+  if (ok) {
+    const int w_ = (int)(q % W), h_ = (int)((q / W) % H), d_ = (int)(q / ((long long)W * H));
+    for (int kd = 0; kd < 3; ++kd) {
+      const int od2 = d_ + 1 - kd;
+      if (od2 < 0 || (od2 & 1) || (od2 >> 1) >= Do) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int oh2 = h_ + 1 - kh;
+        if (oh2 < 0 || (oh2 & 1) || (oh2 >> 1) >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ow2 = w_ + 1 - kw;
+          if (ow2 < 0 || (ow2 & 1) || (ow2 >> 1) >= Wo) continue;
+          const long long osp = ((long long)(od2 >> 1) * Ho + (oh2 >> 1)) * Wo + (ow2 >> 1);
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          for (int co_g = 0; co_g < a.Cout_g; ++co_g) {
+            const int co = g * a.Cout_g + co_g;
+            const float dy = ldf((const T*)a.p.xa + n * a.d.xa_bs + (long long)co * odhw, osp);
+#pragma unroll
+            for (int ci = 0; ci < CIB; ++ci) acc[ci] = fmaf(s_w[(co_g * CIB + ci) * 27 + tap], dy, acc[ci]);
+          }
+        }
+      }
+    }
+  }
+  // epilogue: output channels are forward-input channels; epi sc/sh arrays are [N][Cin]
+  float s0[CIB], s1[CIB];
+#pragma unroll
+  for (int ci = 0; ci < CIB; ++ci) {
+    s0[ci] = 0.f; s1[ci] = 0.f;
+    const int ci_g = cib * CIB + ci;
+    if (ci_g < a.Cin_g && ok) {
+      const int c = g * a.Cin_g + ci_g;
+      T* yp = (T*)a.p.y + n * a.d.y_bs + (long long)c * dhw + q;
+      float o = acc[ci];
+      if (a.d.epi == 1) {
+        const float esc = a.p.e_sc[n * a.d.Cin + c], esh = a.p.e_sh[n * a.d.Cin + c];
+        const T* ep = (c < a.d.Cea ? (const T*)a.p.ea + n * a.d.ea_bs + (long long)c * dhw
+                                   : (const T*)a.p.eb + n * a.d.eb_bs + (long long)(c - a.d.Cea) * dhw);
+        const float ev = ldf(ep, q);
+        o = rnd_as(yp, o * ((ev * esc + esh) > 0.f ? 1.f : a.d.e_slope));
+        s0[ci] = o;
+        s1[ci] = o * ev;
+      }
+      stf(yp, 0, o);
+    }
+  }
+  if (a.d.epi == 1) {
+    float v[2 * CIB];
+#pragma unroll
+    for (int i = 0; i < CIB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
+    block_sum<2 * CIB>(v, s_red, 4);
+    if (tid < 2 * CIB) {
+      const int ci_g = cib * CIB + (tid >> 1);
+      if (ci_g < a.Cin_g) {
+        const int c = g * a.Cin_g + ci_g;
+        atomicAdd(&a.p.red[((long long)n * a.d.Cin + c) * 2 + (tid & 1)], (double)s_red[tid]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient, k = 3 / 7.  A workgroup fixes (group, input channel, COB output channels[, kd plane for
+// k=7]) and walks a slab of spatial tiles keeping NT*COB partial sums per lane in registers; one block
+// reduction + fp32 atomics at the end.
+// ---------------------------------------------------------------------------------------------------
+struct WgradK {
+  ConvK c;
+  float* dw[4];
+  float* db[4];
+  int tiles_total;      // N * tiles per sample
+  int tiles_per_block;
+};
+
+template <typename T, int K, int S, int COB, int TXN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK wa) {
+  const ConvK& a = wa.c;
+  constexpr int VW = 4, TW = TXN * VW, TH = 8, TD = 32 / TXN;
+  constexpr int KDN = (K == 3) ? 3 : 1;                 // kd planes handled per block
+  constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K, ID = (TD - 1) * S + KDN;
+  constexpr int IWP = (IW + 3) / 4 * 4;
+  constexpr int NT = KDN * K * K;
+  constexpr int K3 = K * K * K;
+  constexpr int ROWN = (VW - 1) * S + K;
+  constexpr int PAD = K / 2;
+  constexpr int NACC = NT * COB + COB;
+  __shared__ __attribute__((aligned(16))) float s_in[ID * IH * IWP];
+  __shared__ float s_red[4 * NACC];
+
+  const int tid = threadIdx.x;
+  const int tx = tid % TXN, ty = (tid / TXN) % TH, tz = tid / (TXN * TH);
+  int yy = blockIdx.y;
+  const int ci_g = yy % a.Cin_g; yy /= a.Cin_g;
+  const int cob = yy % a.ncob;
+  const int kd0 = (K == 3) ? 0 : yy / a.ncob;
+  const int g = blockIdx.z;
+  const int c_in = g * a.Cin_g + ci_g;
+  const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  const int tiles = a.tilesW * a.tilesH * a.tilesD;
+
+  float acc[NT][COB];
+  float dbacc[COB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int co = 0; co < COB; ++co) acc[t][co] = 0.f;
+#pragma unroll
+  for (int co = 0; co < COB; ++co) dbacc[co] = 0.f;
+
+  const int t_begin = blockIdx.x * wa.tiles_per_block;
+  const int t_end = min(wa.tiles_total, t_begin + wa.tiles_per_block);
+  for (int tl = t_begin; tl < t_end; ++tl) {
+    const int n = tl / tiles;
+    int t = tl % tiles;
+    const int tw = t % a.tilesW; t /= a.tilesW;
+    const int th = t % a.tilesH;
+    const int td = t / a.tilesH;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+    const int id0 = od0 * S - PAD + kd0, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+    __syncthreads();
+    {
+      const T* src = in_plane<T>(a, n, c_in, dhw);
+      float sc = 1.f, sh = 0.f;
+      if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c_in]; sh = a.p.pre_sh[n * a.d.Cin + c_in]; }
+      for (int idx = tid; idx < ID * IH * IWP; idx += 256) {
+        const int wx = idx % IWP;
+        const int r = idx / IWP;
+        const int hy = r % IH, dz = r / IH;
+        const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
+        float v = 0.f;
+        if (wx < IW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) {
+          v = ldf(src, ((long long)gd * H + gh) * W + gw);
+          if (a.d.pre) v = leaky(v * sc + sh, a.d.pre_slope);
+        }
+        s_in[idx] = v;
+      }
+    }
+    __syncthreads();
+    // this lane's dY values
+    const int od = od0 + tz, oh = oh0 + ty, ow = ow0 + tx * VW;
+    float dy[COB][VW];
+#pragma unroll
+    for (int co = 0; co < COB; ++co) {
+      const int co_g = cob * COB + co;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) dy[co][v] = 0.f;
+      if (co_g < a.Cout_g && od < Do && oh < Ho) {
+        const T* dp = (const T*)a.p.ea + n * a.d.ea_bs + (long long)(g * a.Cout_g + co_g) * odhw +
+                      ((long long)od * Ho + oh) * Wo;
+#pragma unroll
+        for (int v = 0; v < VW; ++v)
+          if (ow + v < Wo) dy[co][v] = ldf(dp, ow + v);
+      }
+#pragma unroll
+      for (int v = 0; v < VW; ++v) dbacc[co] += dy[co][v];
+    }
+    const float* base = s_in + ((tz * S) * IH + ty * S) * IWP + tx * VW * S;
+#pragma unroll
+    for (int kd = 0; kd < KDN; ++kd) {
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const float* row = base + (kd * IH + kh) * IWP;
+        float r[ROWN];
+#pragma unroll
+        for (int i = 0; i + 3 < ROWN; i += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(row + i);
+          r[i] = q.x; r[i + 1] = q.y; r[i + 2] = q.z; r[i + 3] = q.w;
+        }
+#pragma unroll
+        for (int i = ROWN / 4 * 4; i < ROWN; ++i) r[i] = row[i];
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+          for (int co = 0; co < COB; ++co)
+#pragma unroll
+            for (int v = 0; v < VW; ++v)
+              acc[(kd * K + kh) * K + kw][co] = fmaf(r[v * S + kw], dy[co][v], acc[(kd * K + kh) * K + kw][co]);
+      }
+    }
+  }
+  // ---- block reduction + atomics ----
+  float v[NACC];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int co = 0; co < COB; ++co) v[t * COB + co] = acc[t][co];
+#pragma unroll
+  for (int co = 0; co < COB; ++co) v[NT * COB + co] = dbacc[co];
+  __syncthreads();
+  block_sum<NACC>(v, s_red, 4);
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const int gl = g % gpp;
+  for (int i = tid; i < NACC; i += 256) {
+    const int co = i % COB;
+    const int co_g = cob * COB + co;
+    if (co_g >= a.Cout_g) continue;
+    if (i < NT * COB) {
+      const int tap = (K == 3) ? (i / COB) : (kd0 * K * K + i / COB);
+      atomicAdd(&wa.dw[g / gpp][((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * K3 + tap], s_red[i]);
+    } else if (ci_g == 0 && kd0 == 0 && wa.db[g / gpp]) {
+      atomicAdd(&wa.db[g / gpp][gl * a.Cout_g + co_g], s_red[i]);
+    }
+  }
+}
+
+// k = 1 weight gradient: CIB x COB partial products per lane over a grid-strided voxel range.
+template <typename T, int CIB, int COB>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
+  const ConvK& a = wa.c;
+  constexpr int NACC = CIB * COB + COB;
+  __shared__ float s_red[4 * NACC];
+  const int tid = threadIdx.x;
+  int yy = blockIdx.y;
+  const int ncib = ((a.Cin_g + CIB - 1) / CIB);
+  const int cib = yy % ncib;
+  const int cob = yy / ncib;
+  const int g = blockIdx.z;
+  const long long dhw = (long long)a.d.D * a.d.H * a.d.W;
+  float acc[CIB][COB], dbacc[COB];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i)
+#pragma unroll
+    for (int j = 0; j < COB; ++j) acc[i][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < COB; ++j) dbacc[j] = 0.f;
+  const long long total = (long long)a.d.N * dhw;
+  for (long long q = (long long)blockIdx.x * 256 + tid; q < total; q += (long long)gridDim.x * 256) {
+    const int n = (int)(q / dhw);
+    const long long sp = q % dhw;
+    float x[CIB], dy[COB];
+#pragma unroll
+    for (int i = 0; i < CIB; ++i) {
+      const int ci_g = cib * CIB + i;
+      x[i] = 0.f;
+      if (ci_g < a.Cin_g) {
+        const int c = g * a.Cin_g + ci_g;
+        float v = ldf(in_plane<T>(a, n, c, dhw), sp);
+        if (a.d.pre) v = leaky(v * a.p.pre_sc[n * a.d.Cin + c] + a.p.pre_sh[n * a.d.Cin + c], a.d.pre_slope);
+        x[i] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < COB; ++j) {
+      const int co_g = cob * COB + j;
+      dy[j] = co_g < a.Cout_g ? ldf((const T*)a.p.ea + n * a.d.ea_bs + (long long)(g * a.Cout_g + co_g) * dhw, sp) : 0.f;
+      dbacc[j] += dy[j];
+    }
+#pragma unroll
+    for (int i = 0; i < CIB; ++i)
+#pragma unroll
+      for (int j = 0; j < COB; ++j) acc[i][j] = fmaf(x[i], dy[j], acc[i][j]);
+  }
+  float v[NACC];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i)
+#pragma unroll
+    for (int j = 0; j < COB; ++j) v[i * COB + j] = acc[i][j];
+#pragma unroll
+  for (int j = 0; j < COB; ++j) v[CIB * COB + j] = dbacc[j];
+  block_sum<NACC>(v, s_red, 4);
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const int gl = g % gpp;
+  if (tid < NACC) {
+    if (tid < CIB * COB) {
+      const int ci_g = cib * CIB + tid / COB, co_g = cob * COB + tid % COB;
+      if (ci_g < a.Cin_g && co_g < a.Cout_g)
+        atomicAdd(&wa.dw[g / gpp][(long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g], s_red[tid]);
+    } else {
+      const int co_g = cob * COB + (tid - CIB * COB);
+      if (cib == 0 && co_g < a.Cout_g && wa.db[g / gpp]) atomicAdd(&wa.db[g / gpp][gl * a.Cout_g + co_g], s_red[tid]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static int check_desc(const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  if (!d || !p) return XH_ERR_ARG;
+  if (d->dtype != XH_F32 && d->dtype != XH_BF16) return XH_ERR_DTYPE;
+  if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->groups <= 0) return XH_ERR_ARG;
+  if (d->Cin % d->groups || d->Cout % d->groups) return XH_ERR_ARG;
+  if (!(d->k == 1 || d->k == 3 || d->k == 7)) return XH_ERR_ARG;
+  if (!(d->stride == 1 || (d->stride == 2 && d->k == 3))) return XH_ERR_ARG;
+  const int pad = d->k / 2;
+  if (d->Do != (d->D + 2 * pad - d->k) / d->stride + 1) return XH_ERR_ARG;
+  if (d->Ho != (d->H + 2 * pad - d->k) / d->stride + 1) return XH_ERR_ARG;
+  if (d->Wo != (d->W + 2 * pad - d->k) / d->stride + 1) return XH_ERR_ARG;
+  if (d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) return XH_ERR_ARG;
+  if (d->Ca < 0 || d->Ca > d->Cin) return XH_ERR_ARG;
+  if (!p->xa || (d->Ca < d->Cin && !p->xb)) return XH_ERR_ARG;
+  if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= 4))) return XH_ERR_ARG;
+  for (int i = 0; i < d->n_wptr; ++i)
+    if (!p->w[i]) return XH_ERR_ARG;
+  if (d->pre && (!p->pre_sc || !p->pre_sh)) return XH_ERR_ARG;
+  if (d->N * d->groups > 65535) return XH_ERR_ARG;
+  return XH_OK;
+}
+
+static ConvK make_k(const xh_conv_desc* d, const xh_conv_ptrs* p, int cob, int txn) {
+  ConvK a;
+  a.d = *d;
+  a.p = *p;
+  a.Cin_g = d->Cin / d->groups;
+  a.Cout_g = d->Cout / d->groups;
+  a.ncob = cdiv(a.Cout_g, cob);
+  a.tilesW = cdiv(d->Wo, 4 * txn);
+  a.tilesH = cdiv(d->Ho, 8);
+  a.tilesD = cdiv(d->Do, 32 / txn);
+  return a;
+}
+static int pick_txn(int Wo) { return Wo > 16 ? 8 : (Wo > 8 ? 4 : 2); }
+static int pick_cob(int cout_g, int maxc) {
+  int c = 1;
+  while (c < cout_g && c < maxc) c <<= 1;
+  return c;
+}
+
+#define LAUNCH_FWD(T, K, S, COB, TXN)                                                                              \
+  hipLaunchKernelGGL((conv_fwd_kernel<T, K, S, COB, TXN>), grid, dim3(256), 0, (hipStream_t)stream, a)
+#define FWD_TXN(T, K, S, COB)                                        \
+  do {                                                               \
+    if (txn == 8) LAUNCH_FWD(T, K, S, COB, 8);                       \
+    else if (txn == 4) LAUNCH_FWD(T, K, S, COB, 4);                  \
+    else LAUNCH_FWD(T, K, S, COB, 2);                                \
+  } while (0)
+
+template <typename T>
+static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
+  if (d->k == 1) {
+    if (cin_g > 128) return XH_ERR_ARG;
+    const int cob = pick_cob(cout_g, 8);
+    ConvK a = make_k(d, p, cob, 8);
+    const long long dhw = (long long)d->D * d->H * d->W;
+    const bool vec = (dhw % 4 == 0) && (d->xa_bs % 4 == 0) && (d->xb_bs % 4 == 0);
+    dim3 grid((unsigned)((dhw + 1023) / 1024), a.ncob, d->N * d->groups);
+#define L1(COB)                                                                                                  \
+  do {                                                                                                           \
+    if (vec) hipLaunchKernelGGL((conv1x1_kernel<T, COB, true>), grid, dim3(256), 0, (hipStream_t)stream, a);     \
+    else hipLaunchKernelGGL((conv1x1_kernel<T, COB, false>), grid, dim3(256), 0, (hipStream_t)stream, a);        \
+  } while (0)
+    switch (cob) { case 1: L1(1); break; case 2: L1(2); break; case 4: L1(4); break; default: L1(8); }
+#undef L1
+    return xh_launch_status();
+  }
+  const int txn = pick_txn(d->Wo);
+  if (d->k == 3 && d->stride == 1) {
+    const int cob = pick_cob(cout_g, 8);
+    ConvK a = make_k(d, p, cob, txn);
+    dim3 grid(a.tilesW * a.tilesH * a.tilesD, a.ncob, d->N * d->groups);
+    switch (cob) {
+      case 1: FWD_TXN(T, 3, 1, 1); break;
+      case 2: FWD_TXN(T, 3, 1, 2); break;
+      case 4: FWD_TXN(T, 3, 1, 4); break;
+      default: FWD_TXN(T, 3, 1, 8);
+    }
+    return xh_launch_status();
+  }
+  if (d->k == 3 && d->stride == 2) {
+    if (d->transposed) return XH_ERR_ARG;
+    const int cob = pick_cob(cout_g, 8) < 2 ? 2 : pick_cob(cout_g, 8);
+    ConvK a = make_k(d, p, cob, txn);
+    dim3 grid(a.tilesW * a.tilesH * a.tilesD, a.ncob, d->N * d->groups);
+    switch (cob) {
+      case 2: FWD_TXN(T, 3, 2, 2); break;
+      case 4: FWD_TXN(T, 3, 2, 4); break;
+      default: FWD_TXN(T, 3, 2, 8);
+    }
+    return xh_launch_status();
+  }
+  if (d->k == 7) {
+    const int cob = pick_cob(cout_g, 4) < 2 ? 2 : pick_cob(cout_g, 4);
+    ConvK a = make_k(d, p, cob, txn);
+    dim3 grid(a.tilesW * a.tilesH * a.tilesD, a.ncob, d->N * d->groups);
+    switch (cob) {
+      case 2: FWD_TXN(T, 7, 1, 2); break;
+      default: FWD_TXN(T, 7, 1, 4);
+    }
+    return xh_launch_status();
+  }
+  return XH_ERR_ARG;
+}
+
+extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  int rc = check_desc(d, p);
+  if (rc) return rc;
+  if (!p->y) return XH_ERR_ARG;
+  if (d->transposed && d->stride != 1) return XH_ERR_ARG;
+  if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cout && !p->eb))) return XH_ERR_ARG;
+  if (d->epi == 2 && !p->red) return XH_ERR_ARG;
+  if (d->epi < 0 || d->epi > 2) return XH_ERR_ARG;
+  return d->dtype == XH_F32 ? conv_fwd_dispatch<float>(stream, d, p) : conv_fwd_dispatch<bf16_t>(stream, d, p);
+}
+
+template <typename T>
+static int dgrad_s2_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  const int cib = pick_cob(cin_g, 4);
+  ConvK a = make_k(d, p, 1, 8);
+  const long long dhw = (long long)d->D * d->H * d->W;
+  dim3 grid((unsigned)((dhw + 255) / 256), cdiv(cin_g, cib), d->N * d->groups);
+  const size_t shm = ((size_t)cout_g * cib * 27 + 4 * 2 * cib) * sizeof(float);
+  if (shm > 64 * 1024) return XH_ERR_ARG;
+  switch (cib) {
+    case 1: hipLaunchKernelGGL((conv3_dgrad_s2_kernel<T, 1>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((conv3_dgrad_s2_kernel<T, 2>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL((conv3_dgrad_s2_kernel<T, 4>), grid, dim3(256), shm, (hipStream_t)stream, a);
+  }
+  return xh_launch_status();
+}
+
+extern "C" int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  if (!d || !p || !p->xa || !p->y) return XH_ERR_ARG;
+  if (d->dtype != XH_F32 && d->dtype != XH_BF16) return XH_ERR_DTYPE;
+  if (d->k != 3 || d->stride != 2 || d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return XH_ERR_ARG;
+  if (d->Do != (d->D - 1) / 2 + 1 || d->Ho != (d->H - 1) / 2 + 1 || d->Wo != (d->W - 1) / 2 + 1) return XH_ERR_ARG;
+  if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= 4))) return XH_ERR_ARG;
+  for (int i = 0; i < d->n_wptr; ++i)
+    if (!p->w[i]) return XH_ERR_ARG;
+  if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cin && !p->eb))) return XH_ERR_ARG;
+  if (d->epi != 0 && d->epi != 1) return XH_ERR_ARG;
+  if (d->N * d->groups > 65535) return XH_ERR_ARG;
+  return d->dtype == XH_F32 ? dgrad_s2_dispatch<float>(stream, d, p) : dgrad_s2_dispatch<bf16_t>(stream, d, p);
+}
+
+#define LAUNCH_WG(T, K, S, COB, TXN)                                                                               \
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, K, S, COB, TXN>), grid, dim3(256), 0, (hipStream_t)stream, wa)
+#define WG_TXN(T, K, S, COB)                                        \
+  do {                                                              \
+    if (txn == 8) LAUNCH_WG(T, K, S, COB, 8);                       \
+    else if (txn == 4) LAUNCH_WG(T, K, S, COB, 4);                  \
+    else LAUNCH_WG(T, K, S, COB, 2);                                \
+  } while (0)
+
+template <typename T>
+static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4],
+                          float* const db[4]) {
+  const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
+  WgradK wa;
+  for (int i = 0; i < 4; ++i) { wa.dw[i] = i < d->n_wptr ? dw[i] : nullptr; wa.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  if (d->k == 1) {
+    wa.c = make_k(d, p, 4, 8);
+    const long long total = (long long)d->N * d->D * d->H * d->W;
+    int gx = (int)((total + 256 * 16 - 1) / (256 * 16));
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, cdiv(cin_g, 4) * cdiv(cout_g, 4), d->groups);
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, wa);
+    return xh_launch_status();
+  }
+  const int txn = pick_txn(d->Wo);
+  const int cob = (d->k == 7) ? pick_cob(cout_g, 2) : pick_cob(cout_g, 4);
+  wa.c = make_k(d, p, cob, txn);
+  const int tiles = wa.c.tilesW * wa.c.tilesH * wa.c.tilesD;
+  wa.tiles_total = tiles * d->N;
+  // enough slabs to fill the chip, few enough that the end-of-block reduction amortises
+  const int ny = cin_g * wa.c.ncob * (d->k == 7 ? 7 : 1) * d->groups;
+  int slabs = cdiv(2048, ny);
+  if (slabs > wa.tiles_total) slabs = wa.tiles_total;
+  if (slabs < 1) slabs = 1;
+  wa.tiles_per_block = cdiv(wa.tiles_total, slabs);
+  slabs = cdiv(wa.tiles_total, wa.tiles_per_block);
+  dim3 grid(slabs, cin_g * wa.c.ncob * (d->k == 7 ? 7 : 1), d->groups);
+  if (grid.y > 65535) return XH_ERR_ARG;
+  if (d->k == 3 && d->stride == 1) {
+    switch (cob) { case 1: WG_TXN(T, 3, 1, 1); break; case 2: WG_TXN(T, 3, 1, 2); break; default: WG_TXN(T, 3, 1, 4); }
+  } else if (d->k == 3 && d->stride == 2) {
+    switch (cob) { case 1: WG_TXN(T, 3, 2, 1); break; case 2: WG_TXN(T, 3, 2, 2); break; default: WG_TXN(T, 3, 2, 4); }
+  } else {
+    switch (cob) { case 1: WG_TXN(T, 7, 1, 1); break; default: WG_TXN(T, 7, 1, 2); }
+  }
+  return xh_launch_status();
+}
+
+extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4],
+                               float* const db[4]) {
+  int rc = check_desc(d, p);
+  if (rc) return rc;
+  if (!p->ea || !dw || d->transposed) return XH_ERR_ARG;
+  for (int i = 0; i < d->n_wptr; ++i)
+    if (!dw[i]) return XH_ERR_ARG;
+  return d->dtype == XH_F32 ? wgrad_dispatch<float>(stream, d, p, dw, db) : wgrad_dispatch<bf16_t>(stream, d, p, dw, db);
+}
+
+extern "C" int xh_abi_version(void) { return 1; }

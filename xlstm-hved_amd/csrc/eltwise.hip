@@ -1,0 +1,1068 @@
+// Bandwidth-bound stages of the XLSTM-HVED path: normalisation statistics and their backward, pooling,
+// trilinear resampling, product-of-experts + reparameterisation, attention gates.
+// One lane handles 4 consecutive voxels of one (n, c) row (16 B fp32 / 8 B bf16 accesses) when the row
+// length and strides allow it, otherwise a scalar tail path.  Reductions: fp32 in the lane, fp32 across
+// the block, fp64 atomics across blocks.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+#define VW 4
+#define EW_BLOCK 256
+// elements of one (n,c) row covered by a block
+#define EW_CHUNK (EW_BLOCK * VW * 4)
+
+template <typename T>
+__device__ __forceinline__ void ldrow(const T* p, long long q, int valid, bool vec, float (&o)[VW]) {
+  if (vec && valid == VW) {
+    ld4(p, q, o);
+  } else {
+#pragma unroll
+    for (int v = 0; v < VW; ++v) o[v] = v < valid ? ldf(p, q + v) : 0.f;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void strow(T* p, long long q, int valid, bool vec, const float (&o)[VW]) {
+  if (vec && valid == VW) {
+    st4(p, q, o);
+  } else {
+#pragma unroll
+    for (int v = 0; v < VW; ++v)
+      if (v < valid) stf(p, q + v, o[v]);
+  }
+}
+static inline bool vec_ok(long long dhw, std::initializer_list<long long> strides) {
+  if (dhw % VW) return false;
+  for (long long s : strides)
+    if (s % VW) return false;
+  return true;
+}
+static inline dim3 row_grid(long long dhw, int C, int N) { return dim3((unsigned)((dhw + EW_CHUNK - 1) / EW_CHUNK), C, N); }
+
+#define ROW_LOOP_BEGIN                                                                         \
+  const int c = blockIdx.y, n = blockIdx.z;                                                    \
+  const long long q_end = min(dhw, (long long)(blockIdx.x + 1) * EW_CHUNK);                    \
+  for (long long q = (long long)blockIdx.x * EW_CHUNK + threadIdx.x * VW; q < q_end; q += EW_BLOCK * VW) { \
+    const int valid = (int)min((long long)VW, dhw - q);
+#define ROW_LOOP_END }
+
+// ---------------------------------------------------------------------------------------- moments
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long x_bs, long long dhw, double* red,
+                                                          long long red_rs, bool vec) {
+  __shared__ float s_red[4 * 2];
+  float s[2] = {0.f, 0.f};
+  const T* xp;
+  {
+    const int c = blockIdx.y, n = blockIdx.z;
+    xp = x + n * x_bs + (long long)c * dhw;
+  }
+  ROW_LOOP_BEGIN
+    float v[VW];
+    ldrow(xp, q, valid, vec, v);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) { s[0] += v[i]; s[1] = fmaf(v[i], v[i], s[1]); }
+    (void)c; (void)n;
+  ROW_LOOP_END
+  block_sum<2>(s, s_red, EW_BLOCK >> 6);
+  if (threadIdx.x < 2) atomicAdd(&red[blockIdx.z * red_rs + blockIdx.y * 2 + threadIdx.x], (double)s_red[threadIdx.x]);
+}
+
+extern "C" int xh_moments(void* stream, int dtype, const void* x, long long x_bs, int N, int C, long long DHW,
+                          double* red, long long red_rs) {
+  if (!x || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {x_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(moments_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(moments_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- norm finalize
+__global__ void norm_finalize_kernel(int mode, const double* red, int N, int C, long long count, int gs, float eps,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     int steps, float* sc, float* sh, float* mean_o, float* rstd_o) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double mean, var;
+  if (mode == 0) {
+    mean = red[i * 2] / (double)count;
+    var = red[i * 2 + 1] / (double)count - mean * mean;
+  } else if (mode == 1) {
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < N; ++k) { s0 += red[(k * C + c) * 2]; s1 += red[(k * C + c) * 2 + 1]; }
+    const double M = (double)count * N;
+    mean = s0 / M;
+    var = s1 / M - mean * mean;
+    if (n == 0 && running_mean && running_var) {
+      const double keep = pow(0.9, (double)steps);
+      const double unb = var * M / (M > 1 ? M - 1 : 1);
+      running_mean[c] = (float)(keep * running_mean[c] + (1 - keep) * mean);
+      running_var[c] = (float)(keep * running_var[c] + (1 - keep) * unb);
+    }
+  } else if (mode == 2) {
+    mean = running_mean[c];
+    var = running_var[c];
+  } else {
+    const int g0 = (c / gs) * gs;
+    double s0 = 0, s1 = 0;
+    for (int k = g0; k < g0 + gs; ++k) { s0 += red[(n * C + k) * 2]; s1 += red[(n * C + k) * 2 + 1]; }
+    const double M = (double)count * gs;
+    mean = s0 / M;
+    var = s1 / M - mean * mean;
+  }
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+  sc[i] = (float)(rstd * ga);
+  sh[i] = (float)(be - mean * rstd * ga);
+  if (mean_o) mean_o[i] = (float)mean;
+  if (rstd_o) rstd_o[i] = (float)rstd;
+}
+
+extern "C" int xh_norm_finalize(void* stream, int mode, const double* red, int N, int C, long long count, int gs,
+                                float eps, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, int steps, float* sc, float* sh, float* mean, float* rstd) {
+  if (mode < 0 || mode > 3 || N <= 0 || C <= 0 || !sc || !sh) return XH_ERR_ARG;
+  if (mode != 2 && (!red || count <= 0)) return XH_ERR_ARG;
+  if (mode == 2 && (!running_mean || !running_var)) return XH_ERR_ARG;
+  if (mode == 3 && (gs <= 0 || C % gs)) return XH_ERR_ARG;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, mode, red, N, C,
+                     count, gs, eps, gamma, beta, running_mean, running_var, steps, sc, sh, mean, rstd);
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- affine + act
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
+                                                             long long dhw, const float* sc, const float* sh, int act,
+                                                             float slope, bool vec) {
+  const float a = sc ? sc[blockIdx.z * C + blockIdx.y] : 1.f, b = sh ? sh[blockIdx.z * C + blockIdx.y] : 0.f;
+  ROW_LOOP_BEGIN
+    const T* xp = x + n * x_bs + (long long)c * dhw;
+    T* yp = y + n * y_bs + (long long)c * dhw;
+    float v[VW];
+    ldrow(xp, q, valid, vec, v);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) v[i] = apply_act(v[i] * a + b, act, slope);
+    strow(yp, q, valid, vec, v);
+  ROW_LOOP_END
+}
+
+extern "C" int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
+                             int C, long long DHW, const float* sc, const float* sh, int act, float slope) {
+  if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {x_bs, y_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(affine_act_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- act/norm backward
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
+                                                                 int C, long long dhw, const float* sc, const float* sh,
+                                                                 float slope, double* red, bool vec) {
+  __shared__ float s_red[4 * 2];
+  const float a = sc[blockIdx.z * C + blockIdx.y], b = sh[blockIdx.z * C + blockIdx.y];
+  float s[2] = {0.f, 0.f};
+  ROW_LOOP_BEGIN
+    float g[VW], xv[VW];
+    ldrow(dy + n * dy_bs + (long long)c * dhw, q, valid, vec, g);
+    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      const float gg = g[i] * ((xv[i] * a + b) > 0.f ? 1.f : slope);
+      s[0] += gg;
+      s[1] = fmaf(gg, xv[i], s[1]);
+    }
+  ROW_LOOP_END
+  block_sum<2>(s, s_red, EW_BLOCK >> 6);
+  if (threadIdx.x < 2) atomicAdd(&red[((long long)blockIdx.z * C + blockIdx.y) * 2 + threadIdx.x], (double)s_red[threadIdx.x]);
+}
+
+extern "C" int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                                 int N, int C, long long DHW, const float* sc, const float* sh, float slope, double* red) {
+  if (!dy || !x || !sc || !sh || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {dy_bs, x_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, C, DHW, sc, sh, slope, red, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// red[n][c] = {sum g, sum g*x};  dx = A*g + Cc*x + B
+__global__ void norm_bwd_coef_kernel(int mode, const double* red, int N, int C, long long count, int gs,
+                                     const float* gamma, const float* mean, const float* rstd, float* A, float* B,
+                                     float* Cc, float* dgamma, float* dbeta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  const double ga = gamma ? (double)gamma[c] : 1.0;
+  const double mu = mean[i], rs = rstd[i];
+  // P_c = sum g*xhat for this (n,c)
+  auto P_of = [&](int k) { return (double)rstd[k] * (red[k * 2 + 1] - (double)mean[k] * red[k * 2]); };
+  double S0 = 0, P = 0, M = 1;
+  if (mode == 0) {
+    S0 = ga * red[i * 2]; P = ga * P_of(i); M = (double)count;
+  } else if (mode == 1 || mode == 2) {
+    for (int k = 0; k < N; ++k) { S0 += red[(k * C + c) * 2]; P += P_of(k * C + c); }
+    if (n == 0) {
+      if (dgamma) dgamma[c] += (float)P;
+      if (dbeta) dbeta[c] += (float)S0;
+    }
+    S0 *= ga; P *= ga; M = (double)count * N;
+  } else {
+    const int g0 = (c / gs) * gs;
+    for (int k = g0; k < g0 + gs; ++k) {
+      const double gk = gamma ? (double)gamma[k] : 1.0;
+      S0 += gk * red[(n * C + k) * 2];
+      P += gk * P_of(n * C + k);
+    }
+    M = (double)count * gs;
+    // per-channel affine gradients need the sum over n of this channel's own sums: done by the n==0 lane
+    if (n == 0) {
+      double p = 0, s = 0;
+      for (int k = 0; k < N; ++k) { p += P_of(k * C + c); s += red[(k * C + c) * 2]; }
+      if (dgamma) dgamma[c] += (float)p;
+      if (dbeta) dbeta[c] += (float)s;
+    }
+  }
+  if (mode == 2) {
+    A[i] = (float)(ga * rs); B[i] = 0.f; Cc[i] = 0.f;
+  } else {
+    A[i] = (float)(ga * rs);
+    Cc[i] = (float)(-rs * rs * P / M);
+    B[i] = (float)(-rs * S0 / M + rs * rs * mu * P / M);
+  }
+}
+
+extern "C" int xh_norm_bwd_coef(void* stream, int mode, const double* red, int N, int C, long long count, int gs,
+                                const float* gamma, const float* mean, const float* rstd, float* A, float* B, float* Cc,
+                                float* dgamma, float* dbeta) {
+  if (mode < 0 || mode > 3 || !red || !mean || !rstd || !A || !B || !Cc || N <= 0 || C <= 0 || count <= 0) return XH_ERR_ARG;
+  if (mode == 3 && (gs <= 0 || C % gs)) return XH_ERR_ARG;
+  hipLaunchKernelGGL(norm_bwd_coef_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, mode, red, N, C,
+                     count, gs, gamma, mean, rstd, A, B, Cc, dgamma, dbeta);
+  return xh_launch_status();
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void norm_bwd_apply_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
+                                                                 T* dx, long long dx_bs, int C, long long dhw,
+                                                                 const float* A, const float* B, const float* Cc,
+                                                                 int have_g, const float* sc, const float* sh, float slope,
+                                                                 int accumulate, bool vec) {
+  const int k = blockIdx.z * C + blockIdx.y;
+  const float a_ = A[k], b_ = B[k], c_ = Cc[k];
+  float tsc = 1.f, tsh = 0.f;
+  if (!have_g) { tsc = sc[k]; tsh = sh[k]; }
+  ROW_LOOP_BEGIN
+    float g[VW], xv[VW], o[VW];
+    ldrow(dy + n * dy_bs + (long long)c * dhw, q, valid, vec, g);
+    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    T* dp = dx + n * dx_bs + (long long)c * dhw;
+    if (accumulate) ldrow((const T*)dp, q, valid, vec, o);
+    else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      float gg = g[i];
+      if (!have_g) gg *= ((xv[i] * tsc + tsh) > 0.f ? 1.f : slope);
+      o[i] += a_ * gg + c_ * xv[i] + b_;
+    }
+    strow(dp, q, valid, vec, o);
+  ROW_LOOP_END
+}
+
+extern "C" int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                                 void* dx, long long dx_bs, int N, int C, long long DHW, const float* A, const float* B,
+                                 const float* Cc, int have_g, const float* sc, const float* sh, float slope,
+                                 int accumulate) {
+  if (!dy || !x || !dx || !A || !B || !Cc || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  if (!have_g && (!sc || !sh)) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {dy_bs, x_bs, dx_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- max pool 2^3
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* x, T* y, long long total, int D, int H, int W) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ow = (int)(i % Wo);
+    long long r = i / Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int od = (int)(r % Do);
+    const long long nc = r / Do;
+    const T* p = x + ((nc * D + 2 * od) * H + 2 * oh) * (long long)W + 2 * ow;
+    float m = -INFINITY;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const float v = ldf(p, ((long long)dz * H + dy) * W + dx);
+          m = (v > m || v != v) ? v : m;
+        }
+    stf(y, i, m);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* x, const T* dy, T* dx, long long total, int D, int H,
+                                                          int W, int accumulate) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ow = (int)(i % Wo);
+    long long r = i / Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int od = (int)(r % Do);
+    const long long nc = r / Do;
+    const long long base = ((nc * D + 2 * od) * H + 2 * oh) * (long long)W + 2 * ow;
+    float m = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float v = ldf(x, base + ((long long)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1));
+      if (v > m || v != v) { m = v; arg = k; }
+    }
+    const float g = ldf(dy, i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long long o = base + ((long long)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
+      const float prev = accumulate ? ldf((const T*)dx, o) : 0.f;
+      stf(dx, o, prev + (k == arg ? g : 0.f));
+    }
+  }
+}
+static inline int flat_grid(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  return (int)(b < 1 ? 1 : b);
+}
+extern "C" int xh_maxpool2_fwd(void* stream, int dtype, const void* x, void* y, int NC, int D, int H, int W) {
+  if (!x || !y || NC <= 0 || D < 2 || H < 2 || W < 2 || (D & 1) || (H & 1) || (W & 1)) return XH_ERR_ARG;
+  const long long total = (long long)NC * (D / 2) * (H / 2) * (W / 2);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, total, D, H, W);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, total, D, H, W);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+extern "C" int xh_maxpool2_bwd(void* stream, int dtype, const void* x, const void* dy, void* dx, int NC, int D, int H,
+                               int W, int accumulate) {
+  if (!x || !dy || !dx || NC <= 0 || D < 2 || H < 2 || W < 2 || (D & 1) || (H & 1) || (W & 1)) return XH_ERR_ARG;
+  const long long total = (long long)NC * (D / 2) * (H / 2) * (W / 2);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, total, D, H, W, accumulate);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, total, D, H, W, accumulate);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- trilinear
+// PyTorch area_pixel_compute_source_index(align_corners=False): src = max((dst+0.5)*scale-0.5, 0)
+__device__ __forceinline__ void lin_src(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  float s = ((float)o + 0.5f) * scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C, int D,
+                                                          int H, int W, int Do, int Ho, int Wo, long long total) {
+  const float sd = (float)D / Do, sh = (float)H / Ho, sw = (float)W / Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ow = (int)(i % Wo);
+    long long r = i / Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int od = (int)(r % Do); r /= Do;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    int d0, d1, h0, h1, w0, w1;
+    float ld0, ld1, lh0, lh1, lw0, lw1;
+    lin_src(od, sd, D, d0, d1, ld0, ld1);
+    lin_src(oh, sh, H, h0, h1, lh0, lh1);
+    lin_src(ow, sw, W, w0, w1, lw0, lw1);
+    const T* p = x + n * x_bs + c * dhw;
+    auto at = [&](int d, int h, int w) { return ldf(p, ((long long)d * H + h) * W + w); };
+    const float v = ld0 * (lh0 * (lw0 * at(d0, h0, w0) + lw1 * at(d0, h0, w1)) + lh1 * (lw0 * at(d0, h1, w0) + lw1 * at(d0, h1, w1))) +
+                    ld1 * (lh0 * (lw0 * at(d1, h0, w0) + lw1 * at(d1, h0, w1)) + lh1 * (lw0 * at(d1, h1, w0) + lw1 * at(d1, h1, w1)));
+    stf(y + n * y_bs + c * odhw, ((long long)od * Ho + oh) * Wo + ow, v);
+  }
+}
+// weight of output o on input i along one axis (exactly the forward's coefficients)
+__device__ __forceinline__ float lin_w(int o, int i, float scale, int in) {
+  int i0, i1; float l0, l1;
+  lin_src(o, scale, in, i0, i1, l0, l1);
+  return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+__device__ __forceinline__ void cand(int i, float scale, int out, int& lo, int& hi) {
+  lo = (int)floorf(((float)i - 0.5f) / scale - 0.5f);
+  hi = (int)ceilf(((float)i + 1.5f) / scale - 0.5f);
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out - 1 ? out - 1 : hi;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* dy, long long dy_bs, T* dx, long long dx_bs, int C,
+                                                          int D, int H, int W, int Do, int Ho, int Wo, long long total,
+                                                          int accumulate) {
+  const float sd = (float)D / Do, sh = (float)H / Ho, sw = (float)W / Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    long long r = i / W;
+    const int h = (int)(r % H); r /= H;
+    const int d = (int)(r % D); r /= D;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    int dlo, dhi, hlo, hhi, wlo, whi;
+    cand(d, sd, Do, dlo, dhi);
+    cand(h, sh, Ho, hlo, hhi);
+    cand(w, sw, Wo, wlo, whi);
+    const T* p = dy + n * dy_bs + c * odhw;
+    float acc = 0.f;
+    for (int od = dlo; od <= dhi; ++od) {
+      const float wd = lin_w(od, d, sd, D);
+      if (wd == 0.f) continue;
+      for (int oh = hlo; oh <= hhi; ++oh) {
+        const float wh = lin_w(oh, h, sh, H);
+        if (wh == 0.f) continue;
+        float rowacc = 0.f;
+        for (int ow = wlo; ow <= whi; ++ow) rowacc = fmaf(lin_w(ow, w, sw, W), ldf(p, ((long long)od * Ho + oh) * Wo + ow), rowacc);
+        acc = fmaf(wd * wh, rowacc, acc);
+      }
+    }
+    T* o = dx + n * dx_bs + c * dhw;
+    const long long sp = ((long long)d * H + h) * W + w;
+    stf(o, sp, acc + (accumulate ? ldf((const T*)o, sp) : 0.f));
+  }
+}
+extern "C" int xh_upsample_trilinear_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs,
+                                         int N, int C, int D, int H, int W, int Do, int Ho, int Wo) {
+  if (!x || !y || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return XH_ERR_ARG;
+  const long long total = (long long)N * C * Do * Ho * Wo;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, D, H, W, Do, Ho, Wo, total);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, D, H, W, Do, Ho, Wo, total);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+extern "C" int xh_upsample_trilinear_bwd(void* stream, int dtype, const void* dy, long long dy_bs, void* dx, long long dx_bs,
+                                         int N, int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate) {
+  if (!dy || !dx || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return XH_ERR_ARG;
+  const long long total = (long long)N * C * D * H * W;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, D, H, W, Do, Ho, Wo, total, accumulate);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, D, H, W, Do, Ho, Wo, total, accumulate);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- add / act bwd
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void add_kernel(const T* a, long long a_bs, const T* b, long long b_bs, T* y,
+                                                      long long y_bs, long long dhw, bool vec) {
+  ROW_LOOP_BEGIN
+    (void)c;
+    float u[VW], v[VW];
+    ldrow(a + n * a_bs, q, valid, vec, u);
+    if (b) {
+      ldrow(b + n * b_bs, q, valid, vec, v);
+#pragma unroll
+      for (int i = 0; i < VW; ++i) u[i] += v[i];
+    }
+    strow(y + n * y_bs, q, valid, vec, u);
+  ROW_LOOP_END
+}
+extern "C" int xh_add(void* stream, int dtype, const void* a, long long a_bs, const void* b, long long b_bs, void* y,
+                      long long y_bs, int N, long long CDHW) {
+  if (!a || !y || N <= 0 || CDHW <= 0 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(CDHW, {a_bs, b_bs, y_bs});
+  dim3 grid = row_grid(CDHW, 1, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(add_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)a, a_bs, (const float*)b, b_bs, (float*)y, y_bs, CDHW, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(add_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)a, a_bs, (const bf16_t*)b, b_bs, (bf16_t*)y, y_bs, CDHW, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* dy, const T* y, T* dx, long long n, int act) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float yv = ldf(y, i), g = ldf(dy, i);
+    float o = g;
+    if (act == XH_ACT_RELU) o = yv > 0.f ? g : 0.f;
+    else if (act == XH_ACT_SIGMOID) o = g * yv * (1.f - yv);
+    stf(dx, i, o);
+  }
+}
+extern "C" int xh_act_bwd(void* stream, int dtype, const void* dy, const void* y, void* dx, long long n, int act) {
+  if (!dy || !y || !dx || n <= 0) return XH_ERR_ARG;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)y, (float*)dx, n, act);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n, act);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- product of experts
+#define POE_EPS 1e-8f
+template <typename T>
+__global__ __launch_bounds__(256) void poe_fwd_kernel(const T* feat, const float* keep, const T* eps, T* z, T* mu_stack,
+                                                     T* lv_stack, int L, long long dhw, long long total, int mask_mu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i % dhw;
+    const int l = (int)((i / dhw) % L);
+    const int n = (int)(i / (dhw * L));
+    float tsum = 1.f / (1.f + POE_EPS), musum = 0.f;
+    const long long so = (((long long)n * 5) * L + l) * dhw + p;   // stack offset of expert 0
+    stf(mu_stack, so, 0.f);
+    stf(lv_stack, so, 0.f);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long long fo = (((long long)n * 4 + m) * 2 * L + l) * dhw + p;
+      const float mu = ldf(feat, fo);
+      float lv = ldf(feat, fo + (long long)L * dhw);
+      lv = fminf(fmaxf(lv, -50.f), 50.f);
+      const float k = keep[n * 4 + m];
+      const float t = k / (__expf(lv) + POE_EPS);
+      tsum += t;
+      musum = fmaf(mu, t, musum);
+      stf(mu_stack, so + (long long)(m + 1) * L * dhw, mask_mu ? mu * k : mu);
+      stf(lv_stack, so + (long long)(m + 1) * L * dhw, lv);
+    }
+    const float pmu = musum / tsum;
+    float out = pmu;
+    if (eps) out = fmaf(ldf(eps, i), __expf(-0.5f * __logf(tsum)), pmu);
+    stf(z, i, out);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void poe_bwd_kernel(const T* feat, const float* keep, const T* eps, const T* dz,
+                                                     const T* dmu_stack, const T* dlv_stack, T* dfeat, int L, long long dhw,
+                                                     long long total, int mask_mu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i % dhw;
+    const int l = (int)((i / dhw) % L);
+    const int n = (int)(i / (dhw * L));
+    float mu[4], lvr[4], lv[4], t[4], k[4], ex[4];
+    float tsum = 1.f / (1.f + POE_EPS), musum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long long fo = (((long long)n * 4 + m) * 2 * L + l) * dhw + p;
+      mu[m] = ldf(feat, fo);
+      lvr[m] = ldf(feat, fo + (long long)L * dhw);
+      lv[m] = fminf(fmaxf(lvr[m], -50.f), 50.f);
+      k[m] = keep[n * 4 + m];
+      ex[m] = __expf(lv[m]);
+      t[m] = k[m] / (ex[m] + POE_EPS);
+      tsum += t[m];
+      musum = fmaf(mu[m], t[m], musum);
+    }
+    const float pmu = musum / tsum;
+    const float g = ldf(dz, i);
+    float dlvp = 0.f;
+    if (eps) dlvp = g * ldf(eps, i) * 0.5f * __expf(-0.5f * __logf(tsum));
+    const float dtsum = -dlvp / tsum - g * pmu / tsum;
+    const long long so = (((long long)n * 5) * L + l) * dhw + p;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long long fo = (((long long)n * 4 + m) * 2 * L + l) * dhw + p;
+      float dmu = g * t[m] / tsum;
+      float dlv = (g * mu[m] / tsum + dtsum) * (-t[m] * ex[m] / (ex[m] + POE_EPS));
+      if (dmu_stack) dmu += ldf(dmu_stack, so + (long long)(m + 1) * L * dhw) * (mask_mu ? k[m] : 1.f);
+      if (dlv_stack) dlv += ldf(dlv_stack, so + (long long)(m + 1) * L * dhw);
+      if (lvr[m] < -50.f || lvr[m] > 50.f) dlv = 0.f;
+      stf(dfeat, fo, dmu);
+      stf(dfeat, fo + (long long)L * dhw, dlv);
+    }
+  }
+}
+extern "C" int xh_poe_fwd(void* stream, int dtype, const void* feat, const float* keep, const void* eps, void* z,
+                          void* mu_stack, void* lv_stack, int N, int L, long long dhw, int mask_mu) {
+  if (!feat || !keep || !z || !mu_stack || !lv_stack || N <= 0 || L <= 0 || dhw <= 0) return XH_ERR_ARG;
+  const long long total = (long long)N * L * dhw;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(poe_fwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, keep, (const float*)eps, (float*)z, (float*)mu_stack, (float*)lv_stack, L, dhw, total, mask_mu);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(poe_fwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, keep, (const bf16_t*)eps, (bf16_t*)z, (bf16_t*)mu_stack, (bf16_t*)lv_stack, L, dhw, total, mask_mu);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+extern "C" int xh_poe_bwd(void* stream, int dtype, const void* feat, const float* keep, const void* eps, const void* dz,
+                          const void* dmu_stack, const void* dlv_stack, void* dfeat, int N, int L, long long dhw,
+                          int mask_mu) {
+  if (!feat || !keep || !dz || !dfeat || N <= 0 || L <= 0 || dhw <= 0) return XH_ERR_ARG;
+  const long long total = (long long)N * L * dhw;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(poe_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, keep, (const float*)eps, (const float*)dz, (const float*)dmu_stack, (const float*)dlv_stack, (float*)dfeat, L, dhw, total, mask_mu);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(poe_bwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, keep, (const bf16_t*)eps, (const bf16_t*)dz, (const bf16_t*)dmu_stack, (const bf16_t*)dlv_stack, (bf16_t*)dfeat, L, dhw, total, mask_mu);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- channel pool / gates
+// One lane per voxel; loops over channels (C <= 128).  grid: (chunks over DHW, 1, N)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_pool_fwd_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
+                                                              long long dhw) {
+  const int n = blockIdx.z;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
+    const T* xp = x + n * x_bs + p;
+    float m = -INFINITY, s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = ldf(xp, (long long)c * dhw);
+      m = (v > m || v != v) ? v : m;
+      s += v;
+    }
+    stf(y + n * y_bs, p, m);
+    stf(y + n * y_bs, dhw + p, s / (float)C);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void channel_pool_bwd_kernel(const T* x, long long x_bs, const T* dy, long long dy_bs,
+                                                              T* dx, long long dx_bs, int C, long long dhw, int accumulate) {
+  const int n = blockIdx.z;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
+    const T* xp = x + n * x_bs + p;
+    float m = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = ldf(xp, (long long)c * dhw);
+      if (v > m || v != v) { m = v; arg = c; }
+    }
+    const float g0 = ldf(dy + n * dy_bs, p), g1 = ldf(dy + n * dy_bs, dhw + p) / (float)C;
+    T* dp = dx + n * dx_bs + p;
+    for (int c = 0; c < C; ++c) {
+      const float prev = accumulate ? ldf((const T*)dp, (long long)c * dhw) : 0.f;
+      stf(dp, (long long)c * dhw, prev + g1 + (c == arg ? g0 : 0.f));
+    }
+  }
+}
+static inline dim3 vox_grid(long long dhw, int N) {
+  long long b = (dhw + 255) / 256;
+  if (b > 4096) b = 4096;
+  return dim3((unsigned)b, 1, N);
+}
+extern "C" int xh_channel_pool_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
+                                   int C, long long DHW) {
+  if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(channel_pool_fwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(channel_pool_fwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+extern "C" int xh_channel_pool_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* dy, long long dy_bs,
+                                   void* dx, long long dx_bs, int N, int C, long long DHW, int accumulate) {
+  if (!x || !dy || !dx || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(channel_pool_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, DHW, accumulate);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(channel_pool_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, DHW, accumulate);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// y = x*(1+s)
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void gate_fwd_kernel(const T* x, long long x_bs, const T* s, long long s_bs, T* y,
+                                                           long long y_bs, long long dhw, bool vec) {
+  ROW_LOOP_BEGIN
+    float xv[VW], sv[VW];
+    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    ldrow(s + n * s_bs, q, valid, vec, sv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) xv[i] *= (1.f + sv[i]);
+    strow(y + n * y_bs + (long long)c * dhw, q, valid, vec, xv);
+  ROW_LOOP_END
+}
+// lane per voxel, loop over channels: dx = dy*(1+s), ds = sum_c dy*x
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* x, long long x_bs, const T* s, long long s_bs, const T* dy,
+                                                      long long dy_bs, T* dx, long long dx_bs, T* ds, long long ds_bs, int C,
+                                                      long long dhw, int acc_dx, int acc_ds) {
+  const int n = blockIdx.z;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
+    const float g1 = 1.f + ldf(s + n * s_bs, p);
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const long long o = (long long)c * dhw + p;
+      const float g = ldf(dy + n * dy_bs, o);
+      a = fmaf(g, ldf(x + n * x_bs, o), a);
+      if (dx) {
+        T* dp = dx + n * dx_bs;
+        stf(dp, o, g * g1 + (acc_dx ? ldf((const T*)dp, o) : 0.f));
+      }
+    }
+    if (ds) {
+      T* sp = ds + n * ds_bs;
+      stf(sp, p, a + (acc_ds ? ldf((const T*)sp, p) : 0.f));
+    }
+  }
+}
+extern "C" int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y,
+                           long long y_bs, int N, int C, long long DHW) {
+  if (!x || !s || !y || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {x_bs, s_bs, y_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(gate_fwd_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (float*)y, y_bs, DHW, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (bf16_t*)y, y_bs, DHW, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+extern "C" int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs,
+                           const void* dy, long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N,
+                           int C, long long DHW, int acc_dx, int acc_ds) {
+  if (!x || !s || !dy || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(gate_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, (float*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, (bf16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- DuSE gates
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void duse_gate_fwd_kernel(const T* x, long long x_bs, const float* ch, const T* sp,
+                                                                long long sp_bs, T* u, long long u_bs, int C, long long dhw,
+                                                                bool vec) {
+  const float cg = 1.f + ch[blockIdx.z * C + blockIdx.y];
+  ROW_LOOP_BEGIN
+    float xv[VW], sv[VW];
+    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    ldrow(sp + n * sp_bs, q, valid, vec, sv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) xv[i] *= (cg + sv[i]);
+    strow(u + n * u_bs + (long long)c * dhw, q, valid, vec, xv);
+  ROW_LOOP_END
+}
+// lane per voxel over channels; dch via block reduction per channel would need C reductions: instead each
+// block owns one (n, c) row for dch and the dsp accumulation goes through a second voxel-major kernel.
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void duse_gate_bwd_row_kernel(const T* x, long long x_bs, const float* ch, const T* sp,
+                                                                    long long sp_bs, const T* du, long long du_bs, T* dx,
+                                                                    long long dx_bs, double* dch, int C, long long dhw,
+                                                                    bool vec) {
+  __shared__ float s_red[4];
+  const float cg = 1.f + ch[blockIdx.z * C + blockIdx.y];
+  float s[1] = {0.f};
+  ROW_LOOP_BEGIN
+    float xv[VW], sv[VW], g[VW], o[VW];
+    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    ldrow(sp + n * sp_bs, q, valid, vec, sv);
+    ldrow(du + n * du_bs + (long long)c * dhw, q, valid, vec, g);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      o[i] = g[i] * (cg + sv[i]);
+      s[0] = fmaf(g[i], xv[i], s[0]);
+    }
+    strow(dx + n * dx_bs + (long long)c * dhw, q, valid, vec, o);
+  ROW_LOOP_END
+  block_sum<1>(s, s_red, EW_BLOCK >> 6);
+  if (threadIdx.x == 0) atomicAdd(&dch[blockIdx.z * C + blockIdx.y], (double)s_red[0]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* x, long long x_bs, const T* du, long long du_bs,
+                                                              T* dsp, long long dsp_bs, int C, long long dhw) {
+  const int n = blockIdx.z;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a = fmaf(ldf(du + n * du_bs, (long long)c * dhw + p), ldf(x + n * x_bs, (long long)c * dhw + p), a);
+    stf(dsp + n * dsp_bs, p, a);
+  }
+}
+extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
+                                long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW) {
+  if (!x || !ch || !sp || !u || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {x_bs, sp_bs, u_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(duse_gate_fwd_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(duse_gate_fwd_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
+                                long long sp_bs, const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp,
+                                long long dsp_bs, double* dch, int N, int C, long long DHW) {
+  if (!x || !ch || !sp || !du || !dx || !dsp || !dch || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {x_bs, sp_bs, du_bs, dx_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32) {
+    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (const float*)du, du_bs, (float*)dx, dx_bs, dch, C, DHW, vec);
+    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)du, du_bs, (float*)dsp, dsp_bs, C, DHW);
+  } else if (dtype == XH_BF16) {
+    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW, vec);
+    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW);
+  } else {
+    return XH_ERR_DTYPE;
+  }
+  return xh_launch_status();
+}
+
+// dx (+)= w[c]*d[n,0,p] + k[n,c]   -- finishes the DuSE input gradient: squeeze-conv data gradient (rank-1) plus
+// the global-average-pool gradient.
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void rank1_add_kernel(T* dx, long long dx_bs, const T* d, long long d_bs,
+                                                            const float* w, const float* k, int C, long long dhw, bool vec) {
+  const float wc = w[blockIdx.y], kc = k ? k[blockIdx.z * C + blockIdx.y] : 0.f;
+  ROW_LOOP_BEGIN
+    float o[VW], dv[VW];
+    T* dp = dx + n * dx_bs + (long long)c * dhw;
+    ldrow((const T*)dp, q, valid, vec, o);
+    ldrow(d + n * d_bs, q, valid, vec, dv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) o[i] += fmaf(wc, dv[i], kc);
+    strow(dp, q, valid, vec, o);
+  ROW_LOOP_END
+}
+extern "C" int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, const void* d, long long d_bs,
+                            const float* w, const float* k, int N, int C, long long DHW) {
+  if (!dx || !d || !w || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec = vec_ok(DHW, {dx_bs, d_bs});
+  dim3 grid = row_grid(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(rank1_add_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (float*)dx, dx_bs, (const float*)d, d_bs, w, k, C, DHW, vec);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(rank1_add_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (bf16_t*)dx, dx_bs, (const bf16_t*)d, d_bs, w, k, C, DHW, vec);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
+// tiny dense layers of the DuSE channel excitation (single block)
+__global__ void duse_fc_fwd_kernel(const double* red_r, const double* red_s, long long count, int N, int C,
+                                   const float* wc, const float* bc, const float* w1, const float* b1, const float* w2,
+                                   const float* b2, float* g, float* ch1, float* ch2) {
+  extern __shared__ float sm[];   // [N][2C] means, [N][C] g
+  float* mean = sm;
+  float* gs = sm + N * 2 * C;
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int n = i / C, c = i % C;
+    mean[n * 2 * C + c] = (float)(red_r[i * 2] / (double)count);
+    mean[n * 2 * C + C + c] = (float)(red_s[i * 2] / (double)count);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int n = i / C, c = i % C;
+    float a = bc[c];
+    for (int k = 0; k < 2 * C; ++k) a = fmaf(wc[c * 2 * C + k], mean[n * 2 * C + k], a);
+    gs[i] = a;
+    g[i] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int n = i / C, c = i % C;
+    float a1 = b1[c], a2 = b2[c];
+    for (int k = 0; k < C; ++k) { a1 = fmaf(w1[c * C + k], gs[n * C + k], a1); a2 = fmaf(w2[c * C + k], gs[n * C + k], a2); }
+    ch1[i] = sigmoidf_(a1);
+    ch2[i] = sigmoidf_(a2);
+  }
+}
+__global__ void duse_fc_bwd_kernel(const double* red_r, const double* red_s, long long count, int N, int C,
+                                   const float* wc, const float* w1, const float* w2, const float* g, const float* ch1,
+                                   const float* ch2, const double* dch1, const double* dch2, float* dwc, float* dbc,
+                                   float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s) {
+  extern __shared__ float sm[];   // mean [N][2C], p1 [N][C], p2 [N][C], dg [N][C]
+  float* mean = sm;
+  float* p1 = sm + N * 2 * C;
+  float* p2 = p1 + N * C;
+  float* dg = p2 + N * C;
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int n = i / C, c = i % C;
+    mean[n * 2 * C + c] = (float)(red_r[i * 2] / (double)count);
+    mean[n * 2 * C + C + c] = (float)(red_s[i * 2] / (double)count);
+    p1[i] = (float)dch1[i] * ch1[i] * (1.f - ch1[i]);
+    p2[i] = (float)dch2[i] * ch2[i] * (1.f - ch2[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int n = i / C, k = i % C;
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += w1[c * C + k] * p1[n * C + c] + w2[c * C + k] * p2[n * C + c];
+    dg[i] = a;
+  }
+  __syncthreads();
+  // parameter gradients (sum over n)
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+    const int c = i / C, k = i % C;
+    float a1 = 0.f, a2 = 0.f;
+    for (int n = 0; n < N; ++n) { a1 += p1[n * C + c] * g[n * C + k]; a2 += p2[n * C + c] * g[n * C + k]; }
+    dw1[i] += a1;
+    dw2[i] += a2;
+  }
+  for (int i = threadIdx.x; i < C * 2 * C; i += blockDim.x) {
+    const int c = i / (2 * C), k = i % (2 * C);
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += dg[n * C + c] * mean[n * 2 * C + k];
+    dwc[i] += a;
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int n = 0; n < N; ++n) { a1 += p1[n * C + c]; a2 += p2[n * C + c]; a3 += dg[n * C + c]; }
+    db1[c] += a1; db2[c] += a2; dbc[c] += a3;
+  }
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int n = i / C, k = i % C;
+    float ar = 0.f, as = 0.f;
+    for (int c = 0; c < C; ++c) { ar += wc[c * 2 * C + k] * dg[n * C + c]; as += wc[c * 2 * C + C + k] * dg[n * C + c]; }
+    dmean_r[i] = ar / (float)count;     // already divided: d(mean)/dx = 1/count
+    dmean_s[i] = as / (float)count;
+  }
+}
+extern "C" int xh_duse_fc_fwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
+                              const float* w_comb, const float* b_comb, const float* w1, const float* b1, const float* w2,
+                              const float* b2, float* g, float* ch1, float* ch2) {
+  if (!red_r || !red_s || !w_comb || !b_comb || !w1 || !b1 || !w2 || !b2 || !g || !ch1 || !ch2 || N <= 0 || C <= 0 || count <= 0) return XH_ERR_ARG;
+  const size_t shm = (size_t)N * 3 * C * sizeof(float);
+  if (shm > 60000) return XH_ERR_ARG;
+  hipLaunchKernelGGL(duse_fc_fwd_kernel, dim3(1), dim3(256), shm, (hipStream_t)stream, red_r, red_s, count, N, C, w_comb, b_comb, w1, b1, w2, b2, g, ch1, ch2);
+  return xh_launch_status();
+}
+extern "C" int xh_duse_fc_bwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
+                              const float* w_comb, const float* w1, const float* w2, const float* g, const float* ch1,
+                              const float* ch2, const double* dch1, const double* dch2, float* dw_comb, float* db_comb,
+                              float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s) {
+  if (!red_r || !red_s || !w_comb || !w1 || !w2 || !g || !ch1 || !ch2 || !dch1 || !dch2 || !dw_comb || !db_comb || !dw1 ||
+      !db1 || !dw2 || !db2 || !dmean_r || !dmean_s || N <= 0 || C <= 0 || count <= 0)
+    return XH_ERR_ARG;
+  const size_t shm = (size_t)N * 5 * C * sizeof(float);
+  if (shm > 60000) return XH_ERR_ARG;
+  hipLaunchKernelGGL(duse_fc_bwd_kernel, dim3(1), dim3(256), shm, (hipStream_t)stream, red_r, red_s, count, N, C, w_comb, w1, w2, g, ch1, ch2, dch1, dch2, dw_comb, db_comb, dw1, db1, dw2, db2, dmean_r, dmean_s);
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- skip-return tail
+// r_c = relu(relu(t_c*sc+sh) + x_c);  a = sigmoid(w0*max_c r + w1*mean_c r)
+template <typename T>
+__global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* t, const T* x, const float* sc, const float* sh,
+                                                          const float* w2, T* a, int C, long long dhw) {
+  const int n = blockIdx.z;
+  const float w0 = w2[0], w1 = w2[1];
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
+    float m = -INFINITY, s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const long long o = ((long long)n * C + c) * dhw + p;
+      float y = ldf(t, o) * sc[n * C + c] + sh[n * C + c];
+      y = y > 0.f ? y : 0.f;
+      float r = y + ldf(x, o);
+      r = r > 0.f ? r : 0.f;
+      m = r > m ? r : m;
+      s += r;
+    }
+    stf(a, (long long)n * dhw + p, sigmoidf_(w0 * m + w1 * s / (float)C));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* t, const T* x, const float* sc, const float* sh,
+                                                          const float* w2, const T* a, const T* da, T* dtg, T* dx,
+                                                          double* dw2acc, int C, long long dhw, int acc_dx) {
+  __shared__ float s_red[4 * 2];
+  const int n = blockIdx.z;
+  const float w0 = w2[0], w1 = w2[1];
+  float sacc[2] = {0.f, 0.f};
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
+    float m = -INFINITY, s = 0.f;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const long long o = ((long long)n * C + c) * dhw + p;
+      float y = ldf(t, o) * sc[n * C + c] + sh[n * C + c];
+      y = y > 0.f ? y : 0.f;
+      float r = y + ldf(x, o);
+      r = r > 0.f ? r : 0.f;
+      if (r > m) { m = r; arg = c; }
+      s += r;
+    }
+    const float av = ldf(a, (long long)n * dhw + p);
+    const float dpre = ldf(da, (long long)n * dhw + p) * av * (1.f - av);
+    sacc[0] = fmaf(dpre, m, sacc[0]);
+    sacc[1] = fmaf(dpre, s / (float)C, sacc[1]);
+    const float gmax = dpre * w0, gmean = dpre * w1 / (float)C;
+    for (int c = 0; c < C; ++c) {
+      const long long o = ((long long)n * C + c) * dhw + p;
+      const float yraw = ldf(t, o) * sc[n * C + c] + sh[n * C + c];
+      const float y = yraw > 0.f ? yraw : 0.f;
+      const float r = y + ldf(x, o);
+      float dr = gmean + (c == arg ? gmax : 0.f);
+      dr = r > 0.f ? dr : 0.f;
+      stf(dx, o, dr + (acc_dx ? ldf((const T*)dx, o) : 0.f));
+      stf(dtg, o, yraw > 0.f ? dr : 0.f);
+    }
+  }
+  block_sum<2>(sacc, s_red, 4);
+  if (threadIdx.x < 2) atomicAdd(&dw2acc[threadIdx.x], (double)s_red[threadIdx.x]);
+}
+extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
+                               const float* w2, void* a, int N, int C, long long DHW) {
+  if (!t || !x || !sc || !sh || !w2 || !a || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(skr_tail_fwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(skr_tail_fwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
+                               const float* w2, const void* a, const void* da, void* dtg, void* dx, double* dw2,
+                               int N, int C, long long DHW, int acc_dx) {
+  if (!t || !x || !sc || !sh || !w2 || !a || !da || !dtg || !dx || !dw2 || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(skr_tail_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(skr_tail_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}

@@ -1,0 +1,872 @@
+// ViL block (LayerNorm -> mLSTM layer -> residual) on flattened 3D patch tokens, fp32, gfx950.
+//
+// Reference semantics: UxLSTMEnc_3d.py:42-87 (outer ViLLayer), vision_lstm.py:48-130 (stabilised parallel
+// mLSTM), :133-221 (headwise linear, causal conv), :224-287 (norms), :290-348 (cell), :351-477 (layer),
+// :480-506 (block).
+//
+// mLSTM formulation used here.  With lf_t = logsigmoid(f_t), F_t = cumsum(lf)_t, g_s = i_s - F_s and
+// G_t = max_{s<=t} g_s (a prefix maximum), the reference's row stabiliser is m_t = F_t + G_t and
+//     P_ts = (q_t . k_s / sqrt(DH)) * exp(g_s - G_t)   (s <= t),   b_t = sum_s P_ts,   a_t = sum_s P_ts v_s,
+//     h_t  = a_t / (max(|b_t|, exp(-m_t)) + 1e-6).
+// Every exponent is <= 0 and known before the contraction starts, so the S x S matrix is never materialised and no
+// online rescaling is needed: F and G come from two wavefront-shuffle scans (one wave per (batch, head)), the
+// contraction is tiled over 64-key LDS tiles.  The backward uses the row/column-sum identities
+//     dF_t = q_t.dq_t - k_t.dk_t (+ stabiliser terms),  di_s = k_s.dk_s (+ stabiliser terms)
+// so it needs only dq, dk, dv from two tiled passes plus a reverse scan.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+#define VIL_EPS 1e-5f
+#define MLSTM_EPS 1e-6f
+#define NH 4
+
+// workspace layout (floats), all token-major unless noted
+struct VilWs {
+  float *tok, *ln_mean, *ln_rstd, *xm, *z, *xc, *q, *k, *v, *ig, *fg, *F, *G, *h, *bden;
+  int* arg;
+  // backward scratch
+  float *dh, *dz, *dxa, *dap, *dbp, *dm, *dq, *dk, *dv, *di, *df, *dxc, *dxm, *rq, *ck, *dscat;
+};
+static long long ws_layout(VilWs* w, float* base, int B, int S, int C) {
+  const long long I = 2 * C, BS = (long long)B * S;
+  long long o = 0;
+  auto take = [&](long long n) { float* p = base ? base + o : nullptr; o += (n + 3) / 4 * 4; return p; };
+  VilWs t;
+  t.tok = take(BS * C); t.ln_mean = take(BS); t.ln_rstd = take(BS);
+  t.xm = take(BS * I); t.z = take(BS * I); t.xc = take(BS * I);
+  t.q = take(BS * I); t.k = take(BS * I); t.v = take(BS * I);
+  t.ig = take(BS * NH); t.fg = take(BS * NH); t.F = take(BS * NH); t.G = take(BS * NH);
+  t.h = take(BS * I); t.bden = take(BS * NH);
+  t.arg = (int*)take(BS * NH);
+  t.dh = take(BS * I); t.dz = take(BS * I); t.dxa = take(BS * I);
+  t.dap = take(BS * I); t.dbp = take(BS * NH); t.dm = take(BS * NH);
+  t.dq = take(BS * I); t.dk = take(BS * I); t.dv = take(BS * I);
+  t.di = take(BS * NH); t.df = take(BS * NH);
+  t.dxc = take(BS * I); t.dxm = take(BS * I);
+  t.rq = take(BS * NH); t.ck = take(BS * NH); t.dscat = take(BS * NH);
+  if (w) *w = t;
+  return o;
+}
+extern "C" long long xh_vil_workspace_floats(int B, int S, int C) { return ws_layout(nullptr, nullptr, B, S, C); }
+
+__device__ __forceinline__ float silu_(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float dsilu_(float x) {
+  const float s = 1.f / (1.f + expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float logsigmoid_(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+
+template <typename T>
+__device__ __forceinline__ float ld_in(const T* xa, const T* xb, long long i) {
+  float v = ldf(xa, i);
+  if (xb) v += ldf(xb, i);
+  return v;
+}
+
+// accumulate dW[m][n] += sum_t a[t][m]*b[t][n] from LDS rows (row strides lda/ldb) with fp32 atomics
+__device__ __forceinline__ void outer_accum(float* dW, const float* a, int lda, int M, const float* b, int ldb, int Nn,
+                                            int T) {
+  for (int e = threadIdx.x; e < M * Nn; e += blockDim.x) {
+    const int m = e / Nn, n = e % Nn;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s = fmaf(a[t * lda + m], b[t * ldb + n], s);
+    atomicAdd(&dW[e], s);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward stage 1: gather tokens, LayerNorm (weight 1+w, no bias), proj_up
+// block: 32 tokens x 8 lanes
+// -------------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void vil_pre1_kernel(const T* xa, const T* xb, int S, xh_vil_params p, VilWs w) {
+  constexpr int I = 2 * C, TT = 32, O = 4 * C;
+  __shared__ float s_w[O * (C + 1)];
+  __shared__ float s_t[TT * (C + 1)];
+  const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
+  for (int i = tid; i < O * C; i += 256) s_w[(i / C) * (C + 1) + (i % C)] = p.proj_up[i];
+  for (int i = tid; i < TT * C; i += 256) {
+    const int tk = i % TT, c = i / TT;
+    const int s = s0 + tk;
+    s_t[tk * (C + 1) + c] = s < S ? ld_in(xa, xb, ((long long)b * C + c) * S + s) : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < TT * C; i += 256) {
+    const int tk = i / C, c = i % C;
+    if (s0 + tk < S) w.tok[((long long)b * S + s0 + tk) * C + c] = s_t[tk * (C + 1) + c];
+  }
+  const int tk = tid >> 3, sub = tid & 7;
+  const int s = s0 + tk;
+  float sum = 0.f, sq = 0.f;
+  for (int c = sub; c < C; c += 8) { const float v = s_t[tk * (C + 1) + c]; sum += v; }
+  sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+  const float mean = sum / C;
+  for (int c = sub; c < C; c += 8) { const float v = s_t[tk * (C + 1) + c] - mean; sq = fmaf(v, v, sq); }
+  sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+  const float rstd = rsqrtf(sq / C + VIL_EPS);
+  if (sub == 0 && s < S) { w.ln_mean[(long long)b * S + s] = mean; w.ln_rstd[(long long)b * S + s] = rstd; }
+  __syncthreads();
+  for (int c = sub; c < C; c += 8) s_t[tk * (C + 1) + c] = (s_t[tk * (C + 1) + c] - mean) * rstd * (1.f + p.norm_w[c]);
+  __syncthreads();
+  if (s < S) {
+    for (int j = 0; j < O / 8; ++j) {
+      const int o = sub * (O / 8) + j;
+      float a = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < C; ++k) a = fmaf(s_w[o * (C + 1) + k], s_t[tk * (C + 1) + k], a);
+      if (o < I) w.xm[((long long)b * S + s) * I + o] = a;
+      else w.z[((long long)b * S + s) * I + (o - I)] = a;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward stage 2: causal conv1d (k=4) + SiLU, block-diagonal q/k/v, gate pre-activations
+// block: 32 tokens x NH lanes (lane = head)
+// -------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(128) void vil_pre2_kernel(int S, xh_vil_params p, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+  __shared__ float s_xm[(TT + 3) * (I + 1)];
+  __shared__ float s_qkv[TT * (3 * I + 1)];
+  __shared__ float s_gw[2 * NH * 3 * I];
+  const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
+  for (int i = tid; i < (TT + 3) * I; i += blockDim.x) {
+    const int r = i / I, c = i % I;
+    const int s = s0 - 3 + r;
+    s_xm[r * (I + 1) + c] = (s >= 0 && s < S) ? w.xm[((long long)b * S + s) * I + c] : 0.f;
+  }
+  for (int i = tid; i < NH * 3 * I; i += blockDim.x) { s_gw[i] = p.ig_w[i]; s_gw[NH * 3 * I + i] = p.fg_w[i]; }
+  __syncthreads();
+  const int tk = tid >> 2, h = tid & 3;
+  const int s = s0 + tk;
+  float xa[DH];
+#pragma unroll
+  for (int j = 0; j < DH; ++j) {
+    const int c = h * DH + j;
+    float a = p.conv_b[c];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a = fmaf(p.conv_w[c * 4 + t], s_xm[(tk + t) * (I + 1) + c], a);
+    xa[j] = silu_(a);
+    if (s < S) w.xc[((long long)b * S + s) * I + c] = a;
+  }
+#pragma unroll
+  for (int blk = 0; blk < DH / 4; ++blk) {
+    const int gb = h * (DH / 4) + blk;   // global 4x4 block index
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float q = 0.f, k = 0.f, v = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        q = fmaf(p.q_w[(gb * 4 + o) * 4 + d], xa[blk * 4 + d], q);
+        k = fmaf(p.k_w[(gb * 4 + o) * 4 + d], xa[blk * 4 + d], k);
+        v = fmaf(p.v_w[(gb * 4 + o) * 4 + d], s_xm[(tk + 3) * (I + 1) + h * DH + blk * 4 + d], v);
+      }
+      const int j = blk * 4 + o;
+      s_qkv[tk * (3 * I + 1) + h * DH + j] = q;
+      s_qkv[tk * (3 * I + 1) + I + h * DH + j] = k;
+      s_qkv[tk * (3 * I + 1) + 2 * I + h * DH + j] = v;
+      if (s < S) {
+        const long long o_ = (((long long)b * NH + h) * S + s) * DH + j;
+        w.q[o_] = q; w.k[o_] = k; w.v[o_] = v;
+      }
+    }
+  }
+  __syncthreads();
+  float gi = p.ig_b[h], gf = p.fg_b[h];
+  for (int m = 0; m < 3 * I; ++m) {
+    const float x = s_qkv[tk * (3 * I + 1) + m];
+    gi = fmaf(s_gw[h * 3 * I + m], x, gi);
+    gf = fmaf(s_gw[NH * 3 * I + h * 3 * I + m], x, gf);
+  }
+  if (s < S) {
+    w.ig[((long long)b * NH + h) * S + s] = gi;
+    w.fg[((long long)b * NH + h) * S + s] = gf;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// gate scans: one wave per (batch, head).  F = inclusive cumsum of logsigmoid(f) (fp64 carry),
+// G = inclusive prefix max of g = i - F with its arg index.  Lane L owns a contiguous chunk; cross-lane
+// carries move through wavefront shuffles.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vil_scan_kernel(int S, VilWs w) {
+  const int lane = threadIdx.x;
+  const long long base = (long long)blockIdx.x * S;
+  const int chunk = (S + 63) / 64;
+  const int t0 = lane * chunk, t1 = min(S, t0 + chunk);
+  double loc = 0.0;
+  for (int t = t0; t < t1; ++t) loc += (double)logsigmoid_(w.fg[base + t]);
+  double inc = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  double run = inc - loc;   // exclusive prefix
+  float lmax = -INFINITY;
+  int larg = t0;
+  for (int t = t0; t < t1; ++t) {
+    run += (double)logsigmoid_(w.fg[base + t]);
+    const float Ft = (float)run;
+    w.F[base + t] = Ft;
+    const float g = w.ig[base + t] - Ft;
+    if (g > lmax) { lmax = g; larg = t; }
+  }
+  float pm = lmax;
+  int pa = larg;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float um = __shfl_up(pm, o, 64);
+    const int ua = __shfl_up(pa, o, 64);
+    if (lane >= o && um >= pm) { pm = um; pa = ua; }   // earlier index wins ties
+  }
+  float em = __shfl_up(pm, 1, 64);
+  int ea = __shfl_up(pa, 1, 64);
+  if (lane == 0) { em = -INFINITY; ea = 0; }
+  for (int t = t0; t < t1; ++t) {
+    const float g = w.ig[base + t] - w.F[base + t];
+    if (g > em) { em = g; ea = t; }
+    w.G[base + t] = em;
+    w.arg[base + t] = ea;
+  }
+}
+
+// reverse scan for the backward: df_t = sigmoid(-f_t) * sum_{t'>=t} dF_t'
+__global__ __launch_bounds__(64) void vil_rscan_kernel(int S, VilWs w) {
+  const int lane = threadIdx.x;
+  const long long base = (long long)blockIdx.x * S;
+  const int chunk = (S + 63) / 64;
+  const int t0 = lane * chunk, t1 = min(S, t0 + chunk);
+  // dF_t = rq_t - ck_t + dm_t - dscat_t ;  di_t = ck_t + dscat_t
+  double loc = 0.0;
+  for (int t = t0; t < t1; ++t) loc += (double)(w.rq[base + t] - w.ck[base + t] + w.dm[base + t] - w.dscat[base + t]);
+  double inc = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double dn = __shfl_down(inc, o, 64);
+    if (lane + o < 64) inc += dn;
+  }
+  double run = inc - loc;   // sum over later lanes
+  for (int t = t1 - 1; t >= t0; --t) {
+    run += (double)(w.rq[base + t] - w.ck[base + t] + w.dm[base + t] - w.dscat[base + t]);
+    const float f = w.fg[base + t];
+    w.df[base + t] = (float)run * (1.f / (1.f + expf(f)));
+    w.di[base + t] = w.ck[base + t] + w.dscat[base + t];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// mLSTM forward contraction.  block: 32 queries x 8 key slices; key tiles of 64 staged in LDS.
+// -------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void mlstm_fwd_kernel(int S, VilWs w) {
+  constexpr int KT = 64, LD = DH + 4;
+  __shared__ float s_k[KT * LD], s_v[KT * LD], s_g[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long long hb = ((long long)b * NH + h) * S;
+  const int t0 = blockIdx.x * 32;
+  const int t = t0 + wv * 8 + (lane >> 3), sl = lane & 7;
+  const bool tv = t < S;
+  float q[DH], num[DH];
+  float den = 0.f, Gt = 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) { q[j] = tv ? w.q[(hb + t) * DH + j] : 0.f; num[j] = 0.f; }
+  if (tv) Gt = w.G[hb + t];
+  const float isq = rsqrtf((float)DH);
+  const int s_last = min(S - 1, t0 + 31);
+  for (int st0 = 0; st0 <= s_last; st0 += KT) {
+    __syncthreads();
+    for (int i = tid; i < KT * DH; i += 256) {
+      const int r = i / DH, c = i % DH;
+      const int s = st0 + r;
+      s_k[r * LD + c] = s < S ? w.k[(hb + s) * DH + c] : 0.f;
+      s_v[r * LD + c] = s < S ? w.v[(hb + s) * DH + c] : 0.f;
+    }
+    if (tid < KT) { const int s = st0 + tid; s_g[tid] = s < S ? w.ig[hb + s] - w.F[hb + s] : -INFINITY; }
+    __syncthreads();
+#pragma unroll 2
+    for (int jj = 0; jj < KT / 8; ++jj) {
+      const int r = sl + 8 * jj;
+      const int s = st0 + r;
+      if (tv && s <= t) {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < DH; ++j) dot = fmaf(q[j], s_k[r * LD + j], dot);
+        const float pw = dot * isq * expf(s_g[r] - Gt);
+        den += pw;
+#pragma unroll
+        for (int j = 0; j < DH; ++j) num[j] = fmaf(pw, s_v[r * LD + j], num[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    den += __shfl_xor(den, o, 64);
+#pragma unroll
+    for (int j = 0; j < DH; ++j) num[j] += __shfl_xor(num[j], o, 64);
+  }
+  if (tv && sl == 0) {
+    const float m = w.F[hb + t] + Gt;
+    const float nrm = fmaxf(fabsf(den), expf(-m)) + MLSTM_EPS;
+    w.bden[hb + t] = den;
+#pragma unroll
+    for (int j = 0; j < DH; ++j) w.h[(hb + t) * DH + j] = num[j] / nrm;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward stage 3: per-head norm, learnable skip, output gate, proj_down, residuals, scatter to NCDHW
+// block: 32 tokens x 8 lanes
+// -------------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void vil_post_kernel(const T* xa, T* out, int S, int add_xa, xh_vil_params p, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+  __shared__ float s_w[C * (I + 1)];
+  __shared__ float s_hg[TT * (I + 1)];
+  __shared__ float s_o[TT * (C + 1)];
+  const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
+  for (int i = tid; i < C * I; i += 256) s_w[(i / I) * (I + 1) + (i % I)] = p.proj_down[i];
+  const int tk = tid >> 3, sub = tid & 7;
+  const int s = s0 + tk;
+  if (sub < NH && s < S) {
+    const int h = sub;
+    const long long ho = (((long long)b * NH + h) * S + s) * DH;
+    float hv[DH], mean = 0.f, var = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH; ++j) { hv[j] = w.h[ho + j]; mean += hv[j]; }
+    mean /= DH;
+#pragma unroll
+    for (int j = 0; j < DH; ++j) { const float d = hv[j] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(var / DH + VIL_EPS);
+#pragma unroll
+    for (int j = 0; j < DH; ++j) {
+      const int c = h * DH + j;
+      const long long to = ((long long)b * S + s) * I + c;
+      const float hn = (hv[j] - mean) * rstd * (1.f + p.outnorm_w[c]);
+      const float hs = hn + p.skip[c] * silu_(w.xc[to]);
+      s_hg[tk * (I + 1) + c] = hs * silu_(w.z[to]);
+    }
+  }
+  __syncthreads();
+  if (s < S) {
+    for (int j = 0; j < C / 8; ++j) {
+      const int o = sub * (C / 8) + j;
+      float a = w.tok[((long long)b * S + s) * C + o];
+#pragma unroll 8
+      for (int k = 0; k < I; ++k) a = fmaf(s_w[o * (I + 1) + k], s_hg[tk * (I + 1) + k], a);
+      s_o[tk * (C + 1) + o] = a;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < TT * C; i += 256) {
+    const int tk2 = i % TT, c = i / TT;
+    const int s2 = s0 + tk2;
+    if (s2 < S) {
+      const long long o = ((long long)b * C + c) * S + s2;
+      stf(out, o, (add_xa ? ldf(xa, o) : 0.f) + s_o[tk2 * (C + 1) + c]);
+    }
+  }
+}
+
+// =================================================================================================
+// backward
+// =================================================================================================
+// stage 3 backward: dout (NCDHW) -> dh, dz, dxa(partial: skip path) ; grads of proj_down, skip, outnorm
+template <typename T, int C>
+__global__ __launch_bounds__(256) void vil_post_bwd_kernel(const T* dout, int S, xh_vil_params p, xh_vil_grads g, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+  __shared__ float s_w[C * (I + 1)];
+  __shared__ float s_do[TT * (C + 1)];
+  __shared__ float s_hg[TT * (I + 1)];    // forward hg (for dW_down), later reused
+  __shared__ float s_dhg[TT * (I + 1)];
+  __shared__ float s_acc[2 * I];           // dskip, doutnorm partials
+  const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
+  for (int i = tid; i < C * I; i += 256) s_w[(i / I) * (I + 1) + (i % I)] = p.proj_down[i];
+  for (int i = tid; i < 2 * I; i += 256) s_acc[i] = 0.f;
+  for (int i = tid; i < TT * C; i += 256) {
+    const int tk = i % TT, c = i / TT;
+    const int s = s0 + tk;
+    s_do[tk * (C + 1) + c] = s < S ? ldf(dout, ((long long)b * C + c) * S + s) : 0.f;
+  }
+  __syncthreads();
+  const int tk = tid >> 3, sub = tid & 7;
+  const int s = s0 + tk;
+  // dhg = W^T dout
+  for (int j = 0; j < I / 8; ++j) {
+    const int k = sub * (I / 8) + j;
+    float a = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < C; ++o) a = fmaf(s_w[o * (I + 1) + k], s_do[tk * (C + 1) + o], a);
+    s_dhg[tk * (I + 1) + k] = s < S ? a : 0.f;
+  }
+  __syncthreads();
+  if (sub < NH) {
+    const int h = sub;
+    if (s < S) {
+      const long long ho = (((long long)b * NH + h) * S + s) * DH;
+      float hv[DH], xh[DH], dn[DH], mean = 0.f, var = 0.f;
+#pragma unroll
+      for (int j = 0; j < DH; ++j) { hv[j] = w.h[ho + j]; mean += hv[j]; }
+      mean /= DH;
+#pragma unroll
+      for (int j = 0; j < DH; ++j) { const float d = hv[j] - mean; var = fmaf(d, d, var); }
+      const float rstd = rsqrtf(var / DH + VIL_EPS);
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < DH; ++j) {
+        const int c = h * DH + j;
+        const long long to = ((long long)b * S + s) * I + c;
+        xh[j] = (hv[j] - mean) * rstd;
+        const float gam = 1.f + p.outnorm_w[c];
+        const float xcv = w.xc[to], zv = w.z[to];
+        const float xav = silu_(xcv);
+        const float hs = xh[j] * gam + p.skip[c] * xav;
+        const float dhg = s_dhg[tk * (I + 1) + c];
+        s_hg[tk * (I + 1) + c] = hs * silu_(zv);
+        const float dhs = dhg * silu_(zv);
+        w.dz[to] = dhg * hs * dsilu_(zv);
+        w.dxa[to] = dhs * p.skip[c];
+        atomicAdd(&s_acc[c], dhs * xav);          // dskip
+        atomicAdd(&s_acc[I + c], dhs * xh[j]);    // d outnorm weight
+        dn[j] = dhs * gam;
+        m1 += dn[j];
+        m2 = fmaf(dn[j], xh[j], m2);
+      }
+      m1 /= DH; m2 /= DH;
+#pragma unroll
+      for (int j = 0; j < DH; ++j) w.dh[ho + j] = rstd * (dn[j] - m1 - xh[j] * m2);
+    } else {
+#pragma unroll
+      for (int j = 0; j < DH; ++j) s_hg[tk * (I + 1) + h * DH + j] = 0.f;
+    }
+  }
+  __syncthreads();
+  outer_accum(g.proj_down, s_do, C + 1, C, s_hg, I + 1, I, TT);
+  for (int i = tid; i < I; i += 256) { atomicAdd(&g.skip[i], s_acc[i]); atomicAdd(&g.outnorm_w[i], s_acc[I + i]); }
+}
+
+// per-token preparation for the mLSTM backward: da' = dh/den', db', dm
+template <int DH>
+__global__ __launch_bounds__(256) void mlstm_bwd_prep_kernel(int S, long long total, VilWs w) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*NH*S
+  if (i >= total) return;
+  const float bd = w.bden[i];
+  const float m = w.F[i] + w.G[i];
+  const float em = expf(-m);
+  const float nrm = fmaxf(fabsf(bd), em) + MLSTM_EPS;
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) {
+    const float d = w.dh[i * DH + j];
+    dot = fmaf(d, w.h[i * DH + j], dot);
+    w.dap[i * DH + j] = d / nrm;
+  }
+  const float dden = -dot / nrm;
+  w.dbp[i] = (fabsf(bd) > em) ? (bd > 0.f ? dden : -dden) : 0.f;
+  w.dm[i] = dden * MLSTM_EPS;
+  w.dscat[i] = 0.f;
+}
+// scatter the stabiliser gradient onto the arg-max key of every row
+__global__ __launch_bounds__(256) void mlstm_bwd_scatter_kernel(int S, long long total, VilWs w) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long row0 = (i / S) * S;
+  atomicAdd(&w.dscat[row0 + w.arg[i]], w.dm[i]);
+}
+
+// pass A: dq_t = sum_{s<=t} (da'_t.v_s + db'_t) * exp(g_s-G_t) * k_s/sqrt(DH) ; rq_t = q_t.dq_t
+template <int DH>
+__global__ __launch_bounds__(256) void mlstm_bwd_q_kernel(int S, VilWs w) {
+  constexpr int KT = 64, LD = DH + 4;
+  __shared__ float s_k[KT * LD], s_v[KT * LD], s_g[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long long hb = ((long long)b * NH + h) * S;
+  const int t0 = blockIdx.x * 32;
+  const int t = t0 + wv * 8 + (lane >> 3), sl = lane & 7;
+  const bool tv = t < S;
+  float da[DH], dq[DH];
+  float db = 0.f, Gt = 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) { da[j] = tv ? w.dap[(hb + t) * DH + j] : 0.f; dq[j] = 0.f; }
+  if (tv) { Gt = w.G[hb + t]; db = w.dbp[hb + t]; }
+  const float isq = rsqrtf((float)DH);
+  const int s_last = min(S - 1, t0 + 31);
+  for (int st0 = 0; st0 <= s_last; st0 += KT) {
+    __syncthreads();
+    for (int i = tid; i < KT * DH; i += 256) {
+      const int r = i / DH, c = i % DH;
+      const int s = st0 + r;
+      s_k[r * LD + c] = s < S ? w.k[(hb + s) * DH + c] : 0.f;
+      s_v[r * LD + c] = s < S ? w.v[(hb + s) * DH + c] : 0.f;
+    }
+    if (tid < KT) { const int s = st0 + tid; s_g[tid] = s < S ? w.ig[hb + s] - w.F[hb + s] : -INFINITY; }
+    __syncthreads();
+#pragma unroll 2
+    for (int jj = 0; jj < KT / 8; ++jj) {
+      const int r = sl + 8 * jj;
+      const int s = st0 + r;
+      if (tv && s <= t) {
+        float dp = db;
+#pragma unroll
+        for (int j = 0; j < DH; ++j) dp = fmaf(da[j], s_v[r * LD + j], dp);
+        const float c = dp * isq * expf(s_g[r] - Gt);
+#pragma unroll
+        for (int j = 0; j < DH; ++j) dq[j] = fmaf(c, s_k[r * LD + j], dq[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < DH; ++j) dq[j] += __shfl_xor(dq[j], o, 64);
+  if (tv && sl == 0) {
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH; ++j) { w.dq[(hb + t) * DH + j] = dq[j]; r = fmaf(dq[j], w.q[(hb + t) * DH + j], r); }
+    w.rq[hb + t] = r;
+  }
+}
+
+// pass B: per key s: dk_s, dv_s over queries t >= s ; ck_s = k_s.dk_s
+template <int DH>
+__global__ __launch_bounds__(256) void mlstm_bwd_kv_kernel(int S, VilWs w) {
+  constexpr int QT = 64, LD = DH + 4;
+  __shared__ float s_q[QT * LD], s_da[QT * LD], s_G[QT], s_db[QT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long long hb = ((long long)b * NH + h) * S;
+  const int s0 = blockIdx.x * 32;
+  const int s = s0 + wv * 8 + (lane >> 3), sl = lane & 7;
+  const bool sv = s < S;
+  float kk[DH], vv[DH], dk[DH], dv[DH];
+  float gs = 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) {
+    kk[j] = sv ? w.k[(hb + s) * DH + j] : 0.f;
+    vv[j] = sv ? w.v[(hb + s) * DH + j] : 0.f;
+    dk[j] = 0.f; dv[j] = 0.f;
+  }
+  if (sv) gs = w.ig[hb + s] - w.F[hb + s];
+  const float isq = rsqrtf((float)DH);
+  for (int qt0 = (s0 / QT) * QT; qt0 < S; qt0 += QT) {
+    __syncthreads();
+    for (int i = tid; i < QT * DH; i += 256) {
+      const int r = i / DH, c = i % DH;
+      const int t = qt0 + r;
+      s_q[r * LD + c] = t < S ? w.q[(hb + t) * DH + c] : 0.f;
+      s_da[r * LD + c] = t < S ? w.dap[(hb + t) * DH + c] : 0.f;
+    }
+    if (tid < QT) {
+      const int t = qt0 + tid;
+      s_G[tid] = t < S ? w.G[hb + t] : INFINITY;
+      s_db[tid] = t < S ? w.dbp[hb + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int jj = 0; jj < QT / 8; ++jj) {
+      const int r = sl + 8 * jj;
+      const int t = qt0 + r;
+      if (sv && t >= s && t < S) {
+        float qk = 0.f, dp = s_db[r];
+#pragma unroll
+        for (int j = 0; j < DH; ++j) {
+          qk = fmaf(s_q[r * LD + j], kk[j], qk);
+          dp = fmaf(s_da[r * LD + j], vv[j], dp);
+        }
+        const float wgt = isq * expf(gs - s_G[r]);
+        const float c1 = dp * wgt, c2 = qk * wgt;
+#pragma unroll
+        for (int j = 0; j < DH; ++j) {
+          dk[j] = fmaf(c1, s_q[r * LD + j], dk[j]);
+          dv[j] = fmaf(c2, s_da[r * LD + j], dv[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < DH; ++j) { dk[j] += __shfl_xor(dk[j], o, 64); dv[j] += __shfl_xor(dv[j], o, 64); }
+  if (sv && sl == 0) {
+    float c = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH; ++j) {
+      w.dk[(hb + s) * DH + j] = dk[j];
+      w.dv[(hb + s) * DH + j] = dv[j];
+      c = fmaf(dk[j], kk[j], c);
+    }
+    w.ck[hb + s] = c;
+  }
+}
+
+// stage 2 backward (a): gates + q/k/v projections -> dxc (pre-SiLU conv output grad), dxm via v; param grads
+template <int C>
+__global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params p, xh_vil_grads g, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+  __shared__ float s_qkv[TT * (3 * I + 1)];    // forward [q,k,v]
+  __shared__ float s_d[TT * (3 * I + 1)];      // d[q,k,v]
+  __shared__ float s_gate[TT * (2 * NH + 1)];  // di, df per head
+  __shared__ float s_gw[2 * NH * 3 * I];
+  __shared__ float s_pw[3 * I * 4];            // local accum of dq_w/dk_w/dv_w
+  const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
+  for (int i = tid; i < NH * 3 * I; i += blockDim.x) { s_gw[i] = p.ig_w[i]; s_gw[NH * 3 * I + i] = p.fg_w[i]; }
+  for (int i = tid; i < 3 * I * 4; i += blockDim.x) s_pw[i] = 0.f;
+  const int tk = tid >> 2, h = tid & 3;
+  const int s = s0 + tk;
+  const bool ok = s < S;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) {
+    const long long o_ = (((long long)b * NH + h) * S + s) * DH + j;
+    s_qkv[tk * (3 * I + 1) + h * DH + j] = ok ? w.q[o_] : 0.f;
+    s_qkv[tk * (3 * I + 1) + I + h * DH + j] = ok ? w.k[o_] : 0.f;
+    s_qkv[tk * (3 * I + 1) + 2 * I + h * DH + j] = ok ? w.v[o_] : 0.f;
+    s_d[tk * (3 * I + 1) + h * DH + j] = ok ? w.dq[o_] : 0.f;
+    s_d[tk * (3 * I + 1) + I + h * DH + j] = ok ? w.dk[o_] : 0.f;
+    s_d[tk * (3 * I + 1) + 2 * I + h * DH + j] = ok ? w.dv[o_] : 0.f;
+  }
+  s_gate[tk * (2 * NH + 1) + h] = ok ? w.di[((long long)b * NH + h) * S + s] : 0.f;
+  s_gate[tk * (2 * NH + 1) + NH + h] = ok ? w.df[((long long)b * NH + h) * S + s] : 0.f;
+  __syncthreads();
+  // gate weight/bias grads
+  outer_accum(g.ig_w, s_gate, 2 * NH + 1, NH, s_qkv, 3 * I + 1, 3 * I, TT);
+  outer_accum(g.fg_w, s_gate + NH, 2 * NH + 1, NH, s_qkv, 3 * I + 1, 3 * I, TT);
+  if (tid < 2 * NH) {
+    float a = 0.f;
+    for (int t = 0; t < TT; ++t) a += s_gate[t * (2 * NH + 1) + tid];
+    atomicAdd(tid < NH ? &g.ig_b[tid] : &g.fg_b[tid - NH], a);
+  }
+  __syncthreads();
+  // d[q,k,v] += W_i^T di + W_f^T df   (each lane updates its own head's 3*DH entries)
+  for (int part = 0; part < 3; ++part)
+#pragma unroll
+    for (int j = 0; j < DH; ++j) {
+      const int m = part * I + h * DH + j;
+      float a = s_d[tk * (3 * I + 1) + m];
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        a = fmaf(s_gw[hh * 3 * I + m], s_gate[tk * (2 * NH + 1) + hh], a);
+        a = fmaf(s_gw[NH * 3 * I + hh * 3 * I + m], s_gate[tk * (2 * NH + 1) + NH + hh], a);
+      }
+      s_d[tk * (3 * I + 1) + m] = a;
+    }
+  __syncthreads();
+  // through the block-diagonal projections
+  if (ok) {
+#pragma unroll
+    for (int blk = 0; blk < DH / 4; ++blk) {
+      const int gb = h * (DH / 4) + blk;
+      float xa4[4], xm4[4], dxa4[4] = {0, 0, 0, 0}, dxm4[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const long long to = ((long long)b * S + s) * I + h * DH + blk * 4 + d;
+        xa4[d] = silu_(w.xc[to]);
+        xm4[d] = w.xm[to];
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int m = h * DH + blk * 4 + o;
+        const float dqv = s_d[tk * (3 * I + 1) + m], dkv = s_d[tk * (3 * I + 1) + I + m], dvv = s_d[tk * (3 * I + 1) + 2 * I + m];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          dxa4[d] = fmaf(p.q_w[(gb * 4 + o) * 4 + d], dqv, dxa4[d]);
+          dxa4[d] = fmaf(p.k_w[(gb * 4 + o) * 4 + d], dkv, dxa4[d]);
+          dxm4[d] = fmaf(p.v_w[(gb * 4 + o) * 4 + d], dvv, dxm4[d]);
+          atomicAdd(&s_pw[(gb * 4 + o) * 4 + d], dqv * xa4[d]);
+          atomicAdd(&s_pw[I * 4 + (gb * 4 + o) * 4 + d], dkv * xa4[d]);
+          atomicAdd(&s_pw[2 * I * 4 + (gb * 4 + o) * 4 + d], dvv * xm4[d]);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const long long to = ((long long)b * S + s) * I + h * DH + blk * 4 + d;
+        const float dxa_tot = dxa4[d] + w.dxa[to];
+        w.dxc[to] = dxa_tot * dsilu_(w.xc[to]);
+        w.dxm[to] = dxm4[d];      // v-path part; conv part added in the next stage
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < I * 4; i += blockDim.x) {
+    atomicAdd(&g.q_w[i], s_pw[i]);
+    atomicAdd(&g.k_w[i], s_pw[I * 4 + i]);
+    atomicAdd(&g.v_w[i], s_pw[2 * I * 4 + i]);
+  }
+}
+
+// stage 2 backward (b) + stage 1 backward: conv1d backward, proj_up backward, LayerNorm backward, scatter
+template <typename T, int C>
+__global__ __launch_bounds__(256) void vil_pre1_bwd_kernel(const T* dout, T* dxin, int S, xh_vil_params p, xh_vil_grads g,
+                                                          VilWs w) {
+  constexpr int I = 2 * C, TT = 32, O = 4 * C;
+  __shared__ float s_w[O * (C + 1)];
+  __shared__ float s_dxc[(TT + 3) * (I + 1)];
+  __shared__ float s_xm[(TT + 3) * (I + 1)];
+  __shared__ float s_din[TT * (O + 1)];     // d[xm, z]
+  __shared__ float s_ln[TT * (C + 1)];      // ln output (for dW_up), then reused for dln
+  __shared__ float s_dt[TT * (C + 1)];      // dtok
+  __shared__ float s_cw[I * 5];             // dconv_w (4) + dconv_b
+  __shared__ float s_nw[C];
+  const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
+  for (int i = tid; i < O * C; i += 256) s_w[(i / C) * (C + 1) + (i % C)] = p.proj_up[i];
+  for (int i = tid; i < I * 5; i += 256) s_cw[i] = 0.f;
+  for (int i = tid; i < C; i += 256) s_nw[i] = 0.f;
+  // dxc rows s0 .. s0+TT+2 ; xm rows s0-3 .. s0+TT-1
+  for (int i = tid; i < (TT + 3) * I; i += 256) {
+    const int r = i / I, c = i % I;
+    const int sd = s0 + r, sx = s0 - 3 + r;
+    s_dxc[r * (I + 1) + c] = sd < S ? w.dxc[((long long)b * S + sd) * I + c] : 0.f;
+    s_xm[r * (I + 1) + c] = (sx >= 0 && sx < S) ? w.xm[((long long)b * S + sx) * I + c] : 0.f;
+  }
+  __syncthreads();
+  // conv backward: dxm[s][c] = sum_j w[c][j]*dxc[s+3-j][c];  dw[c][j] += sum_s dxc[s][c]*xm[s-3+j][c]
+  for (int i = tid; i < TT * I; i += 256) {
+    const int tk = i / I, c = i % I;
+    const int s = s0 + tk;
+    float a = 0.f;
+    if (s < S) {
+      a = w.dxm[((long long)b * S + s) * I + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a = fmaf(p.conv_w[c * 4 + j], s_dxc[(tk + 3 - j) * (I + 1) + c], a);
+    }
+    s_din[tk * (O + 1) + c] = a;
+    s_din[tk * (O + 1) + I + c] = s < S ? w.dz[((long long)b * S + s) * I + c] : 0.f;
+  }
+  for (int i = tid; i < I * 5; i += 256) {
+    const int c = i / 5, j = i % 5;
+    float a = 0.f;
+    for (int tk = 0; tk < TT; ++tk) {
+      const float d = s_dxc[tk * (I + 1) + c];          // dxc at token s0+tk (zero beyond S)
+      a = fmaf(d, j < 4 ? s_xm[(tk + j) * (I + 1) + c] : 1.f, a);
+    }
+    s_cw[i] = a;
+  }
+  // recompute LayerNorm output of the tokens
+  const int tk = tid >> 3, sub = tid & 7;
+  const int s = s0 + tk;
+  const bool ok = s < S;
+  float mean = 0.f, rstd = 0.f;
+  if (ok) { mean = w.ln_mean[(long long)b * S + s]; rstd = w.ln_rstd[(long long)b * S + s]; }
+  for (int c = sub; c < C; c += 8) {
+    const float xh = ok ? (w.tok[((long long)b * S + s) * C + c] - mean) * rstd : 0.f;
+    s_ln[tk * (C + 1) + c] = xh * (1.f + p.norm_w[c]);
+    s_dt[tk * (C + 1) + c] = xh;   // keep xhat
+  }
+  __syncthreads();
+  for (int i = tid; i < I * 5; i += 256) {
+    const int c = i / 5, j = i % 5;
+    atomicAdd(j < 4 ? &g.conv_w[c * 4 + j] : &g.conv_b[c], s_cw[i]);
+  }
+  outer_accum(g.proj_up, s_din, O + 1, O, s_ln, C + 1, C, TT);
+  __syncthreads();
+  // dln = W_up^T d[xm,z]
+  float dln[C / 8], xh[C / 8];
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < C / 8; ++j) {
+    const int c = sub + 8 * j;
+    float a = 0.f;
+    for (int o = 0; o < O; ++o) a = fmaf(s_w[o * (C + 1) + c], s_din[tk * (O + 1) + o], a);
+    xh[j] = s_dt[tk * (C + 1) + c];
+    atomicAdd(&s_nw[c], a * xh[j]);
+    dln[j] = a * (1.f + p.norm_w[c]);
+    m1 += dln[j];
+    m2 = fmaf(dln[j], xh[j], m2);
+  }
+  m1 += __shfl_xor(m1, 1, 64); m1 += __shfl_xor(m1, 2, 64); m1 += __shfl_xor(m1, 4, 64);
+  m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+  m1 /= C; m2 /= C;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < C / 8; ++j) {
+    const int c = sub + 8 * j;
+    s_dt[tk * (C + 1) + c] = rstd * (dln[j] - m1 - xh[j] * m2);
+  }
+  __syncthreads();
+  for (int i = tid; i < C; i += 256) atomicAdd(&g.norm_w[i], s_nw[i]);
+  for (int i = tid; i < TT * C; i += 256) {
+    const int tk2 = i % TT, c = i / TT;
+    const int s2 = s0 + tk2;
+    if (s2 < S) {
+      const long long o = ((long long)b * C + c) * S + s2;
+      stf(dxin, o, ldf(dout, o) + s_dt[tk2 * (C + 1) + c]);
+    }
+  }
+}
+
+// =================================================================================================
+// host entry points
+// =================================================================================================
+template <typename T, int C>
+static int vil_fwd_impl(hipStream_t st, const T* xa, const T* xb, T* out, int B, int S, int add_xa, const xh_vil_params* p, float* ws) {
+  constexpr int DH = 2 * C / NH;
+  VilWs w;
+  ws_layout(&w, ws, B, S, C);
+  hipLaunchKernelGGL((vil_pre1_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, xb, S, *p, w);
+  hipLaunchKernelGGL((vil_pre2_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, w);
+  hipLaunchKernelGGL(vil_scan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
+  hipLaunchKernelGGL((mlstm_fwd_kernel<DH>), dim3(cdiv(S, 32), NH, B), dim3(256), 0, st, S, w);
+  hipLaunchKernelGGL((vil_post_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, out, S, add_xa, *p, w);
+  return xh_launch_status();
+}
+template <typename T, int C>
+static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, const xh_vil_params* p, const xh_vil_grads* g,
+                        float* ws) {
+  constexpr int DH = 2 * C / NH;
+  VilWs w;
+  ws_layout(&w, ws, B, S, C);
+  const long long rows = (long long)B * NH * S;
+  hipLaunchKernelGGL((vil_post_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, S, *p, *g, w);
+  hipLaunchKernelGGL((mlstm_bwd_prep_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
+  hipLaunchKernelGGL(mlstm_bwd_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
+  hipLaunchKernelGGL((mlstm_bwd_q_kernel<DH>), dim3(cdiv(S, 32), NH, B), dim3(256), 0, st, S, w);
+  hipLaunchKernelGGL((mlstm_bwd_kv_kernel<DH>), dim3(cdiv(S, 32), NH, B), dim3(256), 0, st, S, w);
+  hipLaunchKernelGGL(vil_rscan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
+  hipLaunchKernelGGL((vil_pre2_bwd_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, *g, w);
+  hipLaunchKernelGGL((vil_pre1_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, dxin, S, *p, *g, w);
+  return xh_launch_status();
+}
+
+static int vil_check(int dtype, int B, int S, int C, int nh, const xh_vil_params* p, const float* ws) {
+  if (dtype != XH_F32 && dtype != XH_BF16) return XH_ERR_DTYPE;
+  if (B <= 0 || S <= 0 || B > 65535 || nh != NH || !p || !ws) return XH_ERR_ARG;
+  if (!(C == 16 || C == 32)) return XH_ERR_ARG;
+  if (!p->norm_w || !p->proj_up || !p->conv_w || !p->conv_b || !p->q_w || !p->k_w || !p->v_w || !p->ig_w || !p->ig_b ||
+      !p->fg_w || !p->fg_b || !p->outnorm_w || !p->skip || !p->proj_down)
+    return XH_ERR_ARG;
+  return XH_OK;
+}
+
+extern "C" int xh_vil_fwd(void* stream, int dtype, const void* xa, const void* xb, void* out, int B, int S, int C, int nh,
+                          int add_xa, const xh_vil_params* p, float* ws) {
+  int rc = vil_check(dtype, B, S, C, nh, p, ws);
+  if (rc) return rc;
+  if (!xa || !out) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XH_F32) {
+    if (C == 32) return vil_fwd_impl<float, 32>(st, (const float*)xa, (const float*)xb, (float*)out, B, S, add_xa, p, ws);
+    return vil_fwd_impl<float, 16>(st, (const float*)xa, (const float*)xb, (float*)out, B, S, add_xa, p, ws);
+  }
+  if (C == 32) return vil_fwd_impl<bf16_t, 32>(st, (const bf16_t*)xa, (const bf16_t*)xb, (bf16_t*)out, B, S, add_xa, p, ws);
+  return vil_fwd_impl<bf16_t, 16>(st, (const bf16_t*)xa, (const bf16_t*)xb, (bf16_t*)out, B, S, add_xa, p, ws);
+}
+
+extern "C" int xh_vil_bwd(void* stream, int dtype, const void* xa, const void* xb, const void* dout, void* dxin, int B,
+                          int S, int C, int nh, const xh_vil_params* p, const xh_vil_grads* g, float* ws) {
+  int rc = vil_check(dtype, B, S, C, nh, p, ws);
+  if (rc) return rc;
+  (void)xa; (void)xb;
+  if (!dout || !dxin || !g) return XH_ERR_ARG;
+  if (!g->norm_w || !g->proj_up || !g->conv_w || !g->conv_b || !g->q_w || !g->k_w || !g->v_w || !g->ig_w || !g->ig_b ||
+      !g->fg_w || !g->fg_b || !g->outnorm_w || !g->skip || !g->proj_down)
+    return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XH_F32) {
+    if (C == 32) return vil_bwd_impl<float, 32>(st, (const float*)dout, (float*)dxin, B, S, p, g, ws);
+    return vil_bwd_impl<float, 16>(st, (const float*)dout, (float*)dxin, B, S, p, g, ws);
+  }
+  if (C == 32) return vil_bwd_impl<bf16_t, 32>(st, (const bf16_t*)dout, (bf16_t*)dxin, B, S, p, g, ws);
+  return vil_bwd_impl<bf16_t, 16>(st, (const bf16_t*)dout, (bf16_t*)dxin, B, S, p, g, ws);
+}

@@ -1,0 +1,461 @@
+"""Fused stages of the XLSTM-HVED hot path as torch.autograd.Functions.
+
+Every forward and every backward below is a sequence of C-ABI kernel launches (ops.py); autograd is only
+the bookkeeping that connects stages.  Saved tensors are stage inputs plus per-(n,c) statistics, never
+normalised activations.  Reference lines are cited at each stage."""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, LEAK, MODE_BN_EVAL, MODE_BN_TRAIN, MODE_GN, MODE_IN)
+
+
+def _blk(t):
+    """Make a gradient tensor sample-contiguous (autograd may hand us expanded / strided views)."""
+    if t is None:
+        return None
+    if t.dim() >= 2 and t[0].is_contiguous() and (t.shape[0] == 1 or t.stride(0) >= t[0].numel()):
+        return t
+    return t.contiguous()
+
+
+def _dhw(t):
+    return t.shape[2] * t.shape[3] * t.shape[4]
+
+
+def _zeros_like_f32(ts):
+    return [torch.zeros_like(t) for t in ts]
+
+
+# ------------------------------------------------------------------------------------------------------
+class InLreluConv(Function):
+    """SingleConv 'ilc' (buildingblocks.py:406-433,440-461): Conv3d(LeakyReLU(InstanceNorm3d(x))) + bias, k=3.
+
+    Inputs may be a virtual concat (xa | xb) -- the decoder's torch.cat((enc, x), 1) at buildingblocks.py:732 --
+    and may be `groups` independent streams with one weight tensor per group (the 4 modality encoders,
+    RA_HVED.py:548-553, batched along channels)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, stride, groups, nw, *wb):
+        weights, biases = list(wb[:nw]), list(wb[nw:])
+        n, ca = xa.shape[:2]
+        cin = ca + (xb.shape[1] if xb is not None else 0)
+        red = ops.zeros_red(xa, n, cin)
+        ops.moments(xa, red, 0)
+        if xb is not None:
+            ops.moments(xb, red, ca)
+        sc, sh, mean, rstd = ops.norm_finalize(MODE_IN, red, n, cin, _dhw(xa))
+        cout = sum(w.shape[0] for w in weights)
+        k = weights[0].shape[-1]
+        y = ops.conv3d(xa, xb, weights, biases, k=k, cout=cout, stride=stride, groups=groups, pre=(sc, sh, LEAK))
+        ctx.save_for_backward(xa, xb, sc, sh, mean, rstd, *weights)
+        ctx.cfg = (stride, groups, nw, k, cin, ca)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, sc, sh, mean, rstd, *weights = ctx.saved_tensors
+        stride, groups, nw, k, cin, ca = ctx.cfg
+        dy = _blk(dy)
+        dws = _zeros_like_f32(weights)
+        dbs = [torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) for w in weights]
+        ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=groups, pre=(sc, sh, LEAK))
+        dxa = dxb = None
+        if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
+            n = xa.shape[0]
+            red = ops.zeros_red(xa, n, cin)
+            e = (xa, xb, sc, sh, LEAK)
+            if stride == 1:
+                g = ops.conv3d(dy, None, weights, None, k=k, cout=cin, groups=groups, transposed=True, epi=1, e=e, red=red)
+            else:
+                g = ops.conv3d_dgrad_s2(dy, weights, cin=cin, in_spatial=tuple(xa.shape[2:]), groups=groups, e=e, red=red)
+            coef = ops.norm_bwd_coef(MODE_IN, red, _dhw(xa), mean, rstd)
+            dxa = ops.norm_bwd_apply(g, xa, coef, have_g=True, c0=0)
+            if xb is not None:
+                dxb = ops.norm_bwd_apply(g, xb, coef, have_g=True, c0=ca)
+        return (dxa, dxb, None, None, None, *dws, *dbs)
+
+
+def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1):
+    return InLreluConv.apply(xa, xb, stride, groups, len(weights), *weights, *biases)
+
+
+class GnConvRelu(Function):
+    """SingleConv 'gcr' (buildingblocks.py:421-429): ReLU(Conv3d(GroupNorm(x))), no conv bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, num_groups, stride):
+        n, c = x.shape[:2]
+        gs = c // num_groups
+        red = ops.zeros_red(x, n, c)
+        ops.moments(x, red, 0)
+        sc, sh, mean, rstd = ops.norm_finalize(MODE_GN, red, n, c, _dhw(x), gs=gs, gamma=gamma, beta=beta)
+        k = weight.shape[-1]
+        y = ops.conv3d(x, None, [weight], None, k=k, cout=weight.shape[0], stride=stride, pre=(sc, sh, 1.0), act=ACT_RELU)
+        ctx.save_for_backward(x, y, weight, gamma, sc, sh, mean, rstd)
+        ctx.cfg = (gs, stride, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, gamma, sc, sh, mean, rstd = ctx.saved_tensors
+        gs, stride, k = ctx.cfg
+        n, c = x.shape[:2]
+        dyr = ops.act_bwd(_blk(dy), y, ACT_RELU)
+        dw = torch.zeros_like(weight)
+        ops.conv3d_wgrad(x, None, dyr, [dw], None, k=k, stride=stride, pre=(sc, sh, 1.0))
+        red = ops.zeros_red(x, n, c)
+        e = (x, None, sc, sh, 1.0)
+        if stride == 1:
+            g = ops.conv3d(dyr, None, [weight], None, k=k, cout=c, transposed=True, epi=1, e=e, red=red)
+        else:
+            g = ops.conv3d_dgrad_s2(dyr, [weight], cin=c, in_spatial=tuple(x.shape[2:]), e=e, red=red)
+        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        coef = ops.norm_bwd_coef(MODE_GN, red, _dhw(x), mean, rstd, gs=gs, gamma=gamma, dgamma=dgamma, dbeta=dbeta)
+        dx = ops.norm_bwd_apply(g, x, coef, have_g=True)
+        return dx, dw, dgamma, dbeta, None, None
+
+
+class ConvInLrelu(Function):
+    """BasicConv (buildingblocks.py:13-31): LeakyReLU(InstanceNorm3d(Conv3d(x, no bias))); k=1 dense (VU_blocks,
+    RA_HVED.py:401-403) or k=3 depthwise (conv_blocks, RA_HVED.py:406)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, groups):
+        n = x.shape[0]
+        cout, k = weight.shape[0], weight.shape[-1]
+        red = ops.zeros_red(x, n, cout)
+        y0 = ops.conv3d(x, None, [weight], None, k=k, cout=cout, groups=groups, epi=2, red=red)
+        sc, sh, mean, rstd = ops.norm_finalize(MODE_IN, red, n, cout, _dhw(y0))
+        y = ops.affine_act(y0, sc, sh, ACT_LRELU, LEAK)
+        ctx.save_for_backward(x, y0, weight, sc, sh, mean, rstd)
+        ctx.cfg = (groups, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y0, weight, sc, sh, mean, rstd = ctx.saved_tensors
+        groups, k = ctx.cfg
+        dy = _blk(dy)
+        red = ops.act_bwd_reduce(dy, y0, sc, sh, LEAK)
+        coef = ops.norm_bwd_coef(MODE_IN, red, _dhw(y0), mean, rstd)
+        dy0 = ops.norm_bwd_apply(dy, y0, coef, have_g=False, sc=sc, sh=sh, slope=LEAK)
+        dw = torch.zeros_like(weight)
+        ops.conv3d_wgrad(x, None, dy0, [dw], None, k=k, groups=groups)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3d(dy0, None, [weight], None, k=k, cout=x.shape[1], groups=groups, transposed=True)
+        return dx, dw, None
+
+
+class Conv(Function):
+    """Plain Conv3d (+bias) with optional sigmoid: init_blocks / x0_init / heads (RA_HVED.py:323,347,148-149,
+    480,640-641) and AttenModule2's collapsed 7^3 convs (buildingblocks.py:283-296).  `groups` streams may
+    carry one weight tensor each."""
+
+    @staticmethod
+    def forward(ctx, x, groups, act, nw, has_bias, *wb):
+        weights = list(wb[:nw])
+        biases = list(wb[nw:]) if has_bias else None
+        cout = sum(w.shape[0] for w in weights)
+        k = weights[0].shape[-1]
+        y = ops.conv3d(x, None, weights, biases, k=k, cout=cout, groups=groups, act=act)
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, *weights)
+        ctx.cfg = (groups, act, nw, has_bias, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, *weights = ctx.saved_tensors
+        groups, act, nw, has_bias, k = ctx.cfg
+        dy = _blk(dy)
+        if act != ACT_NONE:
+            dy = ops.act_bwd(dy, y, act)
+        dws = _zeros_like_f32(weights)
+        dbs = [torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) for w in weights] if has_bias else None
+        ops.conv3d_wgrad(x, None, dy, dws, dbs, k=k, groups=groups)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True)
+        return (dx, None, None, None, None, *dws, *(dbs or []))
+
+
+def conv(x, weights, biases=None, groups=1, act=ACT_NONE):
+    return Conv.apply(x, groups, act, len(weights), biases is not None, *weights, *(biases or []))
+
+
+class MaxPool2(Function):
+    """nn.MaxPool3d(2) (buildingblocks.py:635-636)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2_bwd(x, _blk(dy))
+
+
+class Upsample(Function):
+    """F.interpolate(mode='trilinear') to `size` (buildingblocks.py:785-787, RA_HVED.py:600-601)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_size = tuple(x.shape[2:])
+        return ops.upsample(x, tuple(size))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample_bwd(_blk(dy), ctx.in_size), None
+
+
+class PoE(Function):
+    """Prior + modality experts -> product of experts -> reparameterisation (RA_HVED.py:573-597,741-753;
+    buildingblocks.py:853-886).  feat: (N, 4*2L, d,h,w) = the 4 DRB outputs stacked along channels."""
+
+    @staticmethod
+    def forward(ctx, feat, keep, eps, L_, mask_mu):
+        feat = feat.contiguous()
+        z, mu, lv = ops.poe_fwd(feat, keep, eps, L_, mask_mu)
+        ctx.save_for_backward(feat, keep, eps)
+        ctx.cfg = (L_, mask_mu)
+        ctx.set_materialize_grads(False)
+        return z, mu, lv
+
+    @staticmethod
+    def backward(ctx, dz, dmu, dlv):
+        feat, keep, eps = ctx.saved_tensors
+        L_, mask_mu = ctx.cfg
+        if dz is None:
+            dz = torch.zeros((feat.shape[0], L_) + tuple(feat.shape[2:]), dtype=feat.dtype, device=feat.device)
+        g = lambda t: None if t is None else t.contiguous()
+        return ops.poe_bwd(feat, keep, eps, g(dz), g(dmu), g(dlv), L_, mask_mu), None, None, None, None
+
+
+class ChannelPool2(Function):
+    """[ChannelPool(seg_x), ChannelPool(enc_x)] -> 4 channels (buildingblocks.py:279-282)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        n, _, d, h, w = a.shape
+        out = ops.new_like(a, (n, 4, d, h, w))
+        ops.channel_pool(a, out[:, 0:2])
+        ops.channel_pool(b, out[:, 2:4])
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        dout = _blk(dout)
+        return ops.channel_pool_bwd(a, dout[:, 0:2]), ops.channel_pool_bwd(b, dout[:, 2:4])
+
+
+class GateCat(Function):
+    """cat[a*(1+E[:,0]), b*(1+E[:,1])] (buildingblocks.py:287,297-299)."""
+
+    @staticmethod
+    def forward(ctx, a, b, E):
+        n, ca, d, h, w = a.shape
+        out = ops.new_like(a, (n, ca + b.shape[1], d, h, w))
+        ops.gate(a, E[:, 0:1], out=out[:, :ca])
+        ops.gate(b, E[:, 1:2], out=out[:, ca:])
+        ctx.save_for_backward(a, b, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, E = ctx.saved_tensors
+        dout = _blk(dout)
+        ca = a.shape[1]
+        dE = torch.empty_like(E)
+        da, _ = ops.gate_bwd(a, E[:, 0:1], dout[:, :ca], ds_out=dE[:, 0:1])
+        db, _ = ops.gate_bwd(b, E[:, 1:2], dout[:, ca:], ds_out=dE[:, 1:2])
+        return da, db, dE
+
+
+class Gate(Function):
+    """x*(1+a): the skip-return attention applied to every stream, x_i = a*x_i + x_i (RA_HVED.py:552)."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        ctx.save_for_backward(x, a)
+        return ops.gate(x, a)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        return ops.gate_bwd(x, a, _blk(dy))
+
+
+class Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+# ------------------------------------------------------------------------------------------------------
+class SkipReturnAttention(Function):
+    """nn.Sequential(ResBlock(c, c, lkdw=True), SpacialAttention3D(1)) (RA_HVED.py:371-384; sa_module.py:56-137;
+    attention_blocks.py:112-126) evaluated ONCE per level; BatchNorm running statistics are advanced `steps`
+    times to reproduce the reference's 4 evaluations on identical input (RA_HVED.py:548-552)."""
+
+    @staticmethod
+    def forward(ctx, x, training, steps, rm1, rv1, rm2, rv2, dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2, saw):
+        n, c = x.shape[:2]
+        cnt = _dhw(x)
+        mode = MODE_BN_TRAIN if training else MODE_BN_EVAL
+        u1 = ops.conv3d(x, None, [dw1], None, k=3, cout=c, groups=c)
+        red1 = ops.zeros_red(x, n, c) if training else None
+        t1 = ops.conv3d(u1, None, [pw1w], [pw1b], k=1, cout=c, epi=2 if training else 0, red=red1)
+        sc1, sh1, m1, r1 = ops.norm_finalize(mode, red1, n, c, cnt, gamma=g1, beta=b1, running_mean=rm1, running_var=rv1,
+                                             steps=steps, device=x.device)
+        u2 = ops.conv3d(t1, None, [dw2], None, k=3, cout=c, groups=c, pre=(sc1, sh1, 0.0))
+        red2 = ops.zeros_red(x, n, c) if training else None
+        t2 = ops.conv3d(u2, None, [pw2w], [pw2b], k=1, cout=c, epi=2 if training else 0, red=red2)
+        sc2, sh2, m2, r2 = ops.norm_finalize(mode, red2, n, c, cnt, gamma=g2, beta=b2, running_mean=rm2, running_var=rv2,
+                                             steps=steps, device=x.device)
+        w2 = saw.reshape(2).contiguous()
+        a = ops.skr_tail(t2, x, sc2, sh2, w2)
+        ctx.save_for_backward(x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2)
+        ctx.mode = mode
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        (x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2) = ctx.saved_tensors
+        mode = ctx.mode
+        n, c = x.shape[:2]
+        cnt = _dhw(x)
+        z = lambda t: torch.zeros_like(t)
+        zc = lambda: torch.zeros(c, dtype=torch.float32, device=x.device)
+        dtg, dx_res, dsaw = ops.skr_tail_bwd(t2, x, sc2, sh2, w2, a, _blk(da))
+        # BatchNorm 2
+        red = ops.act_bwd_reduce(dtg, t2, sc2, sh2, 1.0)
+        dg2, db2 = zc(), zc()
+        coef = ops.norm_bwd_coef(mode, red, cnt, m2, r2, gamma=g2, dgamma=dg2, dbeta=db2)
+        dt2 = ops.norm_bwd_apply(dtg, t2, coef, have_g=True)
+        # pointwise 2
+        dpw2w, dpw2b = z(pw2w), zc()
+        ops.conv3d_wgrad(u2, None, dt2, [dpw2w], [dpw2b], k=1)
+        du2 = ops.conv3d(dt2, None, [pw2w], None, k=1, cout=c, transposed=True)
+        # depthwise 2 (input = relu(bn1(t1)))
+        ddw2 = z(dw2)
+        ops.conv3d_wgrad(t1, None, du2, [ddw2], None, k=3, groups=c, pre=(sc1, sh1, 0.0))
+        red = ops.zeros_red(x, n, c)
+        gt1 = ops.conv3d(du2, None, [dw2], None, k=3, cout=c, groups=c, transposed=True, epi=1, e=(t1, None, sc1, sh1, 0.0), red=red)
+        dg1, db1 = zc(), zc()
+        coef = ops.norm_bwd_coef(mode, red, cnt, m1, r1, gamma=g1, dgamma=dg1, dbeta=db1)
+        dt1 = ops.norm_bwd_apply(gt1, t1, coef, have_g=True)
+        # pointwise 1, depthwise 1
+        dpw1w, dpw1b = z(pw1w), zc()
+        ops.conv3d_wgrad(u1, None, dt1, [dpw1w], [dpw1b], k=1)
+        du1 = ops.conv3d(dt1, None, [pw1w], None, k=1, cout=c, transposed=True)
+        ddw1 = z(dw1)
+        ops.conv3d_wgrad(x, None, du1, [ddw1], None, k=3, groups=c)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3d(du1, None, [dw1], None, k=3, cout=c, groups=c, transposed=True)
+            dx = ops.add(dx, dx_res, out=dx)
+        dsaw_t = dsaw.to(torch.float32).reshape(1, 2, 1, 1, 1)
+        return (dx, None, None, None, None, None, None, ddw1, dpw1w, dpw1b, dg1, db1, ddw2, dpw2w, dpw2b, dg2, db2, dsaw_t)
+
+
+class DuSE(Function):
+    """DuSEAttention.forward (modules/DuSFE.py:113-155).  sqw/sqb are the collapsed squeeze+comb 1x1 conv
+    (conv_comb o [conv_squeeze_ch1 | conv_squeeze_ch2], linear in [r; s]); adjw/adjb the two 3^3 adjust convs
+    stacked on the output axis."""
+
+    @staticmethod
+    def forward(ctx, r, s, training, rm1, rv1, rm2, rv2, wc, bc, w1, b1, w2, b2, sqw, sqb, adjw, adjb, g1, be1, g2, be2):
+        n, c = r.shape[:2]
+        cnt = _dhw(r)
+        mode = MODE_BN_TRAIN if training else MODE_BN_EVAL
+        red_r, red_s = ops.zeros_red(r, n, c), ops.zeros_red(r, n, c)
+        ops.moments(r, red_r)
+        ops.moments(s, red_s)
+        fc = dict(wc=wc, bc=bc, w1=w1, b1=b1, w2=w2, b2=b2)
+        gvec, ch1, ch2 = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc)
+        comb = ops.conv3d(r, s, [sqw], [sqb], k=1, cout=1)
+        sp = ops.conv3d(comb, None, [adjw], [adjb], k=3, cout=2, act=ACT_SIGMOID)
+        u_r = ops.duse_gate(r, ch1, sp[:, 0:1])
+        u_s = ops.duse_gate(s, ch2, sp[:, 1:2])
+        outs, stats = [], []
+        for u, gam, bet, rm, rv in ((u_r, g1, be1, rm1, rv1), (u_s, g2, be2, rm2, rv2)):
+            red = None
+            if training:
+                red = ops.zeros_red(r, n, c)
+                ops.moments(u, red)
+            sc, sh, m, rs = ops.norm_finalize(mode, red, n, c, cnt, gamma=gam, beta=bet, running_mean=rm, running_var=rv,
+                                              steps=1, device=r.device)
+            outs.append(ops.affine_act(u, sc, sh, ACT_NONE))
+            stats += [sc, sh, m, rs]
+        ctx.save_for_backward(r, s, red_r, red_s, gvec, ch1, ch2, comb, sp, u_r, u_s, *stats, wc, w1, w2, sqw, adjw, g1, g2)
+        ctx.mode = mode
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, dor, dos):
+        (r, s, red_r, red_s, gvec, ch1, ch2, comb, sp, u_r, u_s, sc1, sh1, m1, rs1, sc2, sh2, m2, rs2, wc, w1, w2, sqw, adjw,
+         g1, g2) = ctx.saved_tensors
+        mode = ctx.mode
+        n, c = r.shape[:2]
+        cnt = _dhw(r)
+        zc = lambda: torch.zeros(c, dtype=torch.float32, device=r.device)
+        dus, bn_grads = [], []
+        for do, u, sc, sh, m, rs, gam in ((dor, u_r, sc1, sh1, m1, rs1, g1), (dos, u_s, sc2, sh2, m2, rs2, g2)):
+            do = _blk(do)
+            red = ops.act_bwd_reduce(do, u, sc, sh, 1.0)
+            dg, db = zc(), zc()
+            coef = ops.norm_bwd_coef(mode, red, cnt, m, rs, gamma=gam, dgamma=dg, dbeta=db)
+            dus.append(ops.norm_bwd_apply(do, u, coef, have_g=True))
+            bn_grads += [dg, db]
+        dsp = torch.empty_like(sp)
+        dr, dch1 = ops.duse_gate_bwd(r, ch1, sp[:, 0:1], dus[0], dsp[:, 0:1])
+        ds, dch2 = ops.duse_gate_bwd(s, ch2, sp[:, 1:2], dus[1], dsp[:, 1:2])
+        dpre = ops.act_bwd(dsp, sp, ACT_SIGMOID)
+        dadjw, dadjb = torch.zeros_like(adjw), torch.zeros(2, dtype=torch.float32, device=r.device)
+        ops.conv3d_wgrad(comb, None, dpre, [dadjw], [dadjb], k=3)
+        dcomb = ops.conv3d(dpre, None, [adjw], None, k=3, cout=1, transposed=True)
+        dsqw, dsqb = torch.zeros_like(sqw), torch.zeros(1, dtype=torch.float32, device=r.device)
+        ops.conv3d_wgrad(r, s, dcomb, [dsqw], [dsqb], k=1)
+        fc = dict(wc=wc, w1=w1, w2=w2, bc=bn_grads[1], b1=bn_grads[1], b2=bn_grads[1])   # biases only give shapes
+        fcg, dmr, dms = ops.duse_fc_bwd(red_r, red_s, cnt, n, c, fc, gvec, ch1, ch2, dch1, dch2)
+        sq = sqw.reshape(-1)
+        ops.rank1_add(dr, dcomb, sq[:c].contiguous(), dmr)
+        ops.rank1_add(ds, dcomb, sq[c:].contiguous(), dms)
+        return (dr, ds, None, None, None, None, None, fcg["wc"], fcg["bc"], fcg["w1"], fcg["b1"], fcg["w2"], fcg["b2"],
+                dsqw, dsqb, dadjw, dadjb, bn_grads[0], bn_grads[1], bn_grads[2], bn_grads[3])
+
+
+class ViL(Function):
+    """out = xa + ViLBlock(xa + xb) on flattened patch tokens (RA_HVED.py:626; UxLSTMEnc_3d.py:54-87;
+    vision_lstm.py:415-453,494-502).  Always fp32 arithmetic (UxLSTMEnc_3d.py:77-80)."""
+
+    NAMES = ["norm_w", "proj_up", "conv_w", "conv_b", "q_w", "k_w", "v_w", "ig_w", "ig_b", "fg_w", "fg_b", "outnorm_w",
+             "skip", "proj_down"]
+
+    @staticmethod
+    def forward(ctx, xa, xb, add_xa, *params):
+        p = dict(zip(ViL.NAMES, [t.contiguous() for t in params]))
+        out, ws = ops.vil_fwd(xa, xb, p, add_xa)
+        ctx.save_for_backward(xa, xb, ws, *p.values())
+        ctx.add_xa = add_xa
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xa, xb, ws, *params = ctx.saved_tensors
+        p = dict(zip(ViL.NAMES, params))
+        dout = dout.contiguous()
+        dxin, grads = ops.vil_bwd(xa, xb, dout, p, ws)
+        dxa = ops.add(dout, dxin) if ctx.add_xa else dxin
+        return (dxa, dxin if xb is not None else None, None, *[grads[k] for k in ViL.NAMES])

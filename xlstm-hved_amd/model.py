@@ -1,0 +1,339 @@
+"""Network assembly: the reference's AbstractFusion3DUNet family (RA_HVED.py:239-1116) on the HIP stages.
+
+Constructor kwargs, forward signature, return tuple and state_dict keys follow the reference so the classes drop
+into train.py / test.py style callers (`model(x, subset_idx_list=[k], instance_missing=..., drop=..., seg=...,
+recon=..., valid=...)`).  Only the configurations the reference can actually run are built:
+MVAE + MVAE_reduction with DoubleConv blocks.
+
+MI355X-first differences that do not change results:
+  * the 4 modality streams are carried as ONE (N, 4*C, D, H, W) tensor and run through grouped kernels with one
+    weight pointer per stream (4x fewer, 4x larger launches);
+  * the skip-return attention is evaluated once per level instead of once per stream (identical input), its
+    BatchNorm running statistics are advanced 4 steps;
+  * linear stages with no non-linearity between them are composed (7^3 grouped conv + 1x1, squeeze + comb 1x1,
+    sfinals + final_conv);
+  * no hard-coded .cuda() (RA_HVED.py:520): masks are built on x.device.
+"""
+from itertools import chain, combinations
+
+import torch
+from torch import nn
+
+from . import functional as Fn
+from .blocks import (BasicConv, Decoder, DoubleConv, DoubleConv_ViL, DuSEAttention, Encoder, ProductOfExperts,
+                     ProductOfExperts2, SingleConv, SkipReturnAttention, ViLLayer, number_of_features_per_level)
+from .ops import ACT_SIGMOID
+
+MODALITIES = [0, 1, 2, 3]
+SUBSETS_MODALITIES = list(chain(*[combinations(MODALITIES, r) for r in range(1, 5)]))   # RA_HVED.py:733-738
+
+
+class ReconDecoder(nn.Module):
+    """RA_HVED.py:16-95."""
+
+    def __init__(self, basic_module=DoubleConv, multi_stream=4, f_maps=64, shared_recon=True, MVAE=False, MVAE_reduction=False,
+                 ks=3, num_groups=8, num_levels=4, layer_order="gcr", conv_kernel_size=3, conv_padding=1):
+        super().__init__()
+        streams, last_output = (1, 4) if shared_recon else (multi_stream, 1)
+        f = number_of_features_per_level(f_maps, num_levels)
+        rev = list(reversed(f))
+        multi, finals = [], []
+        for _ in range(streams):
+            multi.append(nn.ModuleList([Decoder(rev[i] + rev[i + 1], rev[i + 1], basic_module=basic_module,
+                                                conv_layer_order=layer_order, conv_kernel_size=conv_kernel_size,
+                                                num_groups=num_groups, padding=conv_padding) for i in range(len(rev) - 1)]))
+            finals.append(nn.Conv3d(f[0], last_output, 1))
+        self.finals = nn.ModuleList(finals)
+        self.multi_decoders = nn.ModuleList(multi)
+
+    def forward(self, encoders_features, x, size_list=None):
+        level_outputs = [[] for _ in encoders_features]
+        finals = []
+        for i, decs in enumerate(self.multi_decoders):
+            out = x
+            for j, (dec, enc) in enumerate(zip(decs, encoders_features)):
+                out = dec(enc, out)
+                level_outputs[j].append(out)
+            finals.append(Fn.conv(out, [self.finals[i].weight], [self.finals[i].bias]))
+        return level_outputs, finals
+
+
+class Seg_Recon_DuSFEDecoder(nn.Module):
+    """RA_HVED.py:97-201: recon decoder + seg decoder interleaved with DuSEAttention per level."""
+
+    def __init__(self, sdecoders, basic_module=DoubleConv, multi_stream=4, f_maps=64, shared_recon=True, MVAE=False,
+                 MVAE_reduction=False, ks=3, num_groups=8, seg=True, num_levels=4, layer_order="gcr", conv_kernel_size=3,
+                 conv_padding=1):
+        super().__init__()
+        self.sdecoders = sdecoders
+        streams, last_output = (1, 4) if shared_recon else (multi_stream, 1)
+        f = number_of_features_per_level(f_maps, num_levels)
+        rev = list(reversed(f))
+        self.rfinals, self.sfinals = nn.ModuleList(), nn.ModuleList()
+        self.multi_decoders = nn.ModuleList()
+        dusfe = []
+        for _ in range(streams):
+            decs = nn.ModuleList()
+            for i in range(len(rev) - 1):
+                decs.append(Decoder(rev[i] + rev[i + 1], rev[i + 1], basic_module=basic_module, conv_layer_order=layer_order,
+                                    conv_kernel_size=conv_kernel_size, num_groups=num_groups, padding=conv_padding))
+                dusfe.append(DuSEAttention(rev[i + 1]))
+            self.rfinals.append(nn.Conv3d(f[0], last_output, 1))
+            self.sfinals.append(nn.Conv3d(f[0], last_output, 1))
+            self.multi_decoders.append(decs)
+        self.dusfe_decoders = nn.ModuleList(dusfe)
+
+    def forward(self, encoders_features, x, size_list=None, seg=True):
+        rout = sout = x
+        level_outputs = [[] for _ in encoders_features]
+        rfinal = []
+        for i, rdecs in enumerate(self.multi_decoders):
+            for j, (rdec, feat, sdec, dusfe) in enumerate(zip(rdecs, encoders_features, self.sdecoders, self.dusfe_decoders)):
+                rout = rdec(feat, rout)
+                if seg:
+                    sout = sdec(feat, sout)
+                    rout, sout = dusfe(rout, sout)
+                level_outputs[j].append(rout)
+            rfinal.append(Fn.conv(rout, [self.rfinals[i].weight], [self.rfinals[i].bias]))
+        return level_outputs, rfinal, (sout if seg else None)
+
+
+class Discriminator(nn.Module):
+    """RA_HVED.py:204-236.  Next-row component: stock PyTorch for now, not on the measured path."""
+
+    def __init__(self, in_channels=3, f_maps=64, ks=3, num_levels=4, strides=(1, 2, 2, 2)):
+        super().__init__()
+        if isinstance(f_maps, int):
+            f_maps = number_of_features_per_level(f_maps, num_levels)
+        blocks = []
+        for i, (out_f, st) in enumerate(zip(f_maps, strides)):
+            layers = [nn.Conv3d(in_channels, out_f, ks, stride=st, padding=1)]
+            if i > 0:
+                layers.append(nn.InstanceNorm3d(out_f))
+            layers.append(nn.LeakyReLU(0.2, inplace=True))
+            blocks.append(nn.Sequential(*layers))
+            in_channels = out_f
+        self.disc = nn.ModuleList(blocks)
+        self.last = nn.Conv3d(512, 1, ks, padding=1, bias=False)
+
+    def forward(self, x, input_level=0):
+        for level, block in enumerate(self.disc):
+            if level >= input_level:
+                x = block(x)
+        return self.last(x)
+
+
+class AbstractFusion3DUNet(nn.Module):
+    """RA_HVED.py:239-687."""
+
+    def __init__(self, in_channels, out_channels, final_sigmoid, basic_module, f_maps=64, layer_order="gcr", multi_stream=4,
+                 fusion_level=4, recon_decoder=False, seg_recon_decoder=False, skip_return=False, ori_vae_fusion=False,
+                 shared_recon=True, recon_skip=False, fusion=False, MVAE=False, MVAE_reduction=False, num_groups=8,
+                 num_levels=4, num_block=(1, 1, 1, 1), conv_kernel_size=3, pool_kernel_size=2, conv_padding=1, ViL=False,
+                 mid_ViL=False, **kwargs):
+        super().__init__()
+        if not (MVAE and MVAE_reduction and basic_module is DoubleConv and multi_stream == 4 and fusion_level == 4
+                and not fusion and not ori_vae_fusion and recon_skip and final_sigmoid and num_levels == 4):
+            raise NotImplementedError(
+                "only the configurations the reference can run are built: MVAE=True, MVAE_reduction=True, DoubleConv, "
+                "multi_stream=4, fusion_level=4, recon_skip=True, final_sigmoid=True (SURVEY.md F10)")
+        if isinstance(f_maps, int):
+            enc = number_of_features_per_level(f_maps, num_levels)
+        else:
+            enc = list(f_maps)
+        dec = list(enc)
+        self.multi_stream, self.fusion_level = multi_stream, fusion_level
+        self.recon_decoder, self.recon_skip = recon_decoder, recon_skip
+        self.seg_recon_decoder, self.skip_return = seg_recon_decoder, skip_return
+        self.MVAE, self.MVAE_reduction, self.mid_ViL = MVAE, MVAE_reduction, mid_ViL
+        self.layer_order = layer_order
+        self.latent_dims = 128
+        self.experts, self.experts_drop = ProductOfExperts(), ProductOfExperts2()
+        self.MVAE_latents = number_of_features_per_level(enc[0] // 4, num_levels)
+        self.reduction_latents = list(self.MVAE_latents)
+        if mid_ViL:
+            self.mViL = ViLLayer(dim=dec[-1])
+        if skip_return:
+            self.x0_init = nn.Sequential(nn.Conv3d(enc[0], enc[0], 1))
+        mk_enc = lambda cin, cout, pool: Encoder(cin, cout, num_block=1, apply_pooling=pool, basic_module=basic_module,
+                                                 conv_layer_order=layer_order, conv_kernel_size=conv_kernel_size,
+                                                 num_groups=num_groups, pool_kernel_size=pool_kernel_size, padding=conv_padding)
+        init_blocks, encoders, DRBs, VU, conv_blocks, skr_enc, skr_att = [], [], [], [], [], [], []
+        for i, c in enumerate(enc):
+            if i == 0:
+                init_blocks = [nn.Sequential(nn.Conv3d(in_channels, c, 1)) for _ in range(4)]
+            encoders.append(nn.ModuleList([mk_enc(c if i == 0 else enc[i - 1], c, i > 0) for _ in range(4)]))
+            if i > 0 and skip_return:
+                if i == 1:
+                    skr_att.insert(0, SkipReturnAttention(enc[0]))
+                skr_enc.insert(0, mk_enc(enc[i - 1], c, True))
+                skr_att.insert(0, SkipReturnAttention(c))
+            DRBs.append(nn.ModuleList([nn.Sequential(SingleConv(c, self.MVAE_latents[i] * 2, conv_kernel_size, 2, layer_order,
+                                                                num_groups, padding=conv_padding)) for _ in range(4)]))
+            VU.append(nn.Sequential(BasicConv(self.MVAE_latents[i], dec[i], 1)))
+            conv_blocks.append(BasicConv(dec[i], dec[i], 3, padding=1, groups=dec[i]))
+        self.DRBs = nn.ModuleList(DRBs)
+        self.VU_blocks = nn.ModuleList(VU)
+        self.init_blocks = nn.ModuleList(init_blocks)
+        self.encoders = nn.ModuleList(encoders)
+        self.conv_blocks = nn.ModuleList(conv_blocks)
+        if skip_return:
+            self.skr_encoders = nn.ModuleList(skr_enc)
+            self.skr_att = nn.ModuleList(skr_att)
+        rev = list(reversed(dec))
+        self.decoders = nn.ModuleList([
+            Decoder(rev[i] + rev[i + 1], rev[i + 1], basic_module=DoubleConv_ViL if (ViL and i < 1) else basic_module,
+                    conv_layer_order=layer_order, conv_kernel_size=conv_kernel_size, num_groups=num_groups,
+                    padding=conv_padding, RSM=True, MVAE=MVAE) for i in range(len(rev) - 1)])
+        self.final_conv = nn.Conv3d(dec[0], out_channels, 1)
+        self.final_activation = nn.Sigmoid()
+        if recon_decoder:
+            self.rdecoder = ReconDecoder(basic_module=basic_module, multi_stream=multi_stream, f_maps=dec[0],
+                                         shared_recon=shared_recon, MVAE=MVAE, MVAE_reduction=MVAE_reduction,
+                                         layer_order=layer_order)
+        if seg_recon_decoder:
+            self.srdecoder = Seg_Recon_DuSFEDecoder(sdecoders=self.decoders, basic_module=basic_module,
+                                                    multi_stream=multi_stream, f_maps=dec[0], shared_recon=shared_recon,
+                                                    MVAE=MVAE, MVAE_reduction=MVAE_reduction, layer_order=layer_order)
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream_weights(self, level, which):
+        mods = [getattr(e.basic_module[0], which).conv for e in self.encoders[level]]
+        return [m.weight for m in mods], [m.bias for m in mods]
+
+    def _keep_mask(self, x, subset_idx_list, instance_missing, drop):
+        n = x.shape[0]
+        if instance_missing:
+            if drop is None:
+                drop = x.float().sum((2, 3, 4)) == 0                                       # RA_HVED.py:515
+            keep = (~drop.to(torch.bool)).to(torch.float32)
+        else:
+            key = (subset_idx_list[0], n, x.device)                                         # RA_HVED.py:517-520
+            cache = self.__dict__.setdefault("_keep_cache", {})
+            if key not in cache:
+                subset = SUBSETS_MODALITIES[subset_idx_list[0]]
+                row = torch.tensor([[1.0 if k in subset else 0.0 for k in range(4)]], dtype=torch.float32)
+                cache[key] = row.repeat(n, 1).to(x.device).contiguous()
+            return cache[key]
+        return keep.to(x.device).contiguous()
+
+    def forward(self, x, subset_idx_list=[14], instance_missing=False, drop=None, seg=True, recon=False, valid=False,
+                eps_list=None):
+        """RA_HVED.py:510-648.  `eps_list` (optional, not in the reference signature) injects the reparameterisation
+        noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
+        if self.layer_order != "ilc":
+            raise NotImplementedError("the stream-batched forward is built for layer_order='ilc' (the only order XLSTM_HVED runs)")
+        n = x.shape[0]
+        keep = self._keep_mask(x, subset_idx_list, instance_missing, drop)
+        x = x.contiguous()
+        X = Fn.conv(x, [b[0].weight for b in self.init_blocks], [b[0].bias for b in self.init_blocks], groups=4)
+        mu_list, logvar_list, feats = [], [], []
+        skip = None
+        levels = len(self.encoders)
+        for level in range(levels):
+            if self.skip_return and skip is not None:
+                a = self.skr_att[levels - level](skip, steps=4)                             # skr_att[-level], RA_HVED.py:552
+                X = Fn.Gate.apply(X, a)
+            if level > 0:
+                X = Fn.MaxPool2.apply(X)
+            w, b = self._stream_weights(level, "SingleConv1")
+            X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
+            w, b = self._stream_weights(level, "SingleConv2")
+            X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
+            drb = [m[0].conv for m in self.DRBs[level]]
+            feat = Fn.in_lrelu_conv(X, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4)   # RA_HVED.py:569
+            L_ = self.MVAE_latents[level]
+            eps = None
+            if not valid:
+                shape = (n, L_) + tuple(feat.shape[2:])
+                eps = eps_list[level] if eps_list is not None else torch.randn(shape, device=x.device, dtype=torch.float32)
+                eps = eps.to(device=x.device, dtype=x.dtype).contiguous()
+            z, mu, lv = Fn.PoE.apply(feat, keep, eps, L_, bool(instance_missing))
+            mu_list.append(mu)
+            logvar_list.append(lv)
+            z = self.VU_blocks[level](z)                                                    # RA_HVED.py:599
+            z = Fn.Upsample.apply(z, tuple(2 * s for s in z.shape[2:]))                     # RA_HVED.py:600-601
+            z = self.conv_blocks[level](z)                                                  # RA_HVED.py:603
+            feats.insert(0, z)
+            if self.skip_return:                                                            # RA_HVED.py:617-621
+                if skip is None:
+                    skip = Fn.conv(x, [self.x0_init[0].weight], [self.x0_init[0].bias])
+                else:
+                    skip = self.skr_encoders[levels - 1 - level](skip)
+        if self.mid_ViL and self.skip_return:                                               # RA_HVED.py:623-626
+            feats[0] = self.mViL(feats[0], skip, residual_input=True)
+        if not self.recon_skip:
+            raise NotImplementedError
+        recon_x, recon_features = feats[0], feats[1:]
+        if self.seg_recon_decoder:                                                          # RA_HVED.py:637-648
+            _, recon_outputs, sout = self.srdecoder(recon_features, recon_x, seg=seg)
+            seg_outputs = self._seg_head(sout, self.srdecoder.sfinals[0]) if seg else None
+            if recon and self.recon_decoder:
+                return seg_outputs, (mu_list, logvar_list), recon_outputs
+            return seg_outputs, []
+        _, recon_outputs = self.rdecoder(recon_features, recon_x)                           # RA_HVED.py:651-652
+        recon_outputs = recon_outputs[0] if len(recon_outputs) == 1 else torch.cat(recon_outputs, 1)
+        out = None
+        if seg:                                                                             # RA_HVED.py:666-678
+            out = recon_x
+            for dec, f in zip(self.decoders, recon_features):
+                out = dec(f, out)
+            out = self._seg_head(out, None)
+        else:
+            out = recon_x
+        if recon and self.recon_decoder:
+            return out, (mu_list, logvar_list), recon_outputs
+        return out, []
+
+    def _seg_head(self, sout, sfinal):
+        """sigmoid(final_conv(sfinals(sout))) (RA_HVED.py:195,640-641) as one composed 1x1 conv."""
+        wf = self.final_conv.weight.view(self.final_conv.out_channels, -1)
+        bf = self.final_conv.bias
+        if sfinal is not None:
+            ws = sfinal.weight.view(sfinal.out_channels, -1)
+            bf = wf @ sfinal.bias + bf
+            wf = wf @ ws
+        return Fn.conv(sout, [wf.reshape(wf.shape[0], wf.shape[1], 1, 1, 1).contiguous()], [bf], act=ACT_SIGMOID)
+
+    def seg_parameters(self):
+        """RA_HVED.py:496-500 (the reference lists a non-existent atten_blocks; omitted)."""
+        mods = [self.init_blocks, self.encoders, self.DRBs, self.VU_blocks, self.decoders, self.final_conv]
+        return [p for m in mods for p in m.parameters()]
+
+    def rd_parameters(self):
+        return self.rdecoder.parameters()
+
+
+def _variant(name, doc, **flags):
+    def __init__(self, in_channels, out_channels, multi_stream=4, fusion_level=4, final_sigmoid=True, f_maps=8, layer_order="gcr",
+                 num_groups=8, num_levels=4, recon_decoder=True, MVAE=True, is_segmentation=True, conv_padding=1, **kwargs):
+        merged = dict(flags)
+        merged.update(kwargs)
+        AbstractFusion3DUNet.__init__(self, in_channels=in_channels, out_channels=out_channels, final_sigmoid=final_sigmoid,
+                                      basic_module=DoubleConv, f_maps=f_maps, layer_order=layer_order, multi_stream=multi_stream,
+                                      fusion_level=fusion_level, num_groups=num_groups, num_levels=num_levels,
+                                      conv_padding=conv_padding, recon_decoder=recon_decoder, MVAE=MVAE, **merged)
+    return type(name, (AbstractFusion3DUNet,), {"__init__": __init__, "__doc__": doc})
+
+
+XLSTM_HVED = _variant("XLSTM_HVED", "RA_HVED.py:945-958", seg_recon_decoder=True, skip_return=True, mid_ViL=True)
+U_HVEDConvDuSFEmViLSkrNet3D = _variant("U_HVEDConvDuSFEmViLSkrNet3D", "RA_HVED.py:907-920", seg_recon_decoder=True,
+                                       skip_return=True, mid_ViL=True)
+XLSTM_HVED_woViL = _variant("XLSTM_HVED_woViL", "RA_HVED.py:1103-1116", seg_recon_decoder=True, skip_return=True, mid_ViL=False)
+XLSTM_HVED_woSMVAE = _variant("XLSTM_HVED_woSMVAE", "RA_HVED.py:983-996", seg_recon_decoder=True, skip_return=False, mid_ViL=True)
+U_HVEDConvDuSFEmViLNet3D = _variant("U_HVEDConvDuSFEmViLNet3D", "RA_HVED.py:869-882", seg_recon_decoder=True, skip_return=False,
+                                    mid_ViL=True)
+U_HVEDConvDuSFESkrNet3D = _variant("U_HVEDConvDuSFESkrNet3D", "RA_HVED.py:831-844", seg_recon_decoder=True, skip_return=True)
+U_HVEDConvDuSFENet3D = _variant("U_HVEDConvDuSFENet3D", "RA_HVED.py:793-806", seg_recon_decoder=True)
+XLSTM_HVED_woDuSFE = _variant("XLSTM_HVED_woDuSFE", "RA_HVED.py:1062-1075", seg_recon_decoder=False, skip_return=True, mid_ViL=True)
+U_HVEDConvNet3D = _variant("U_HVEDConvNet3D", "RA_HVED.py:717-730")
+U_HVEDConvXLSTMNet3D = _variant("U_HVEDConvXLSTMNet3D", "RA_HVED.py:755-768", ViL=True)
+
+MODELS = {c.__name__: c for c in (XLSTM_HVED, U_HVEDConvDuSFEmViLSkrNet3D, XLSTM_HVED_woViL, XLSTM_HVED_woSMVAE,
+                                  U_HVEDConvDuSFEmViLNet3D, U_HVEDConvDuSFESkrNet3D, U_HVEDConvDuSFENet3D, XLSTM_HVED_woDuSFE,
+                                  U_HVEDConvNet3D, U_HVEDConvXLSTMNet3D)}
+
+
+def find_model_using_name(model_name):
+    """classic_models/__init__.py:16-29 (the reference's registry raises NameError on import)."""
+    return MODELS[model_name]

@@ -1,0 +1,426 @@
+"""Raw op wrappers: torch tensors in, C-ABI calls on torch's current HIP stream out.
+
+Plumbing only (pointers, strides, shape checks).  No arithmetic happens here and nothing falls back to
+ATen: if the library or a GPU is missing these raise."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID  # noqa: F401
+
+LEAK = 0.01
+NORM_EPS = 1e-5
+MODE_IN, MODE_BN_TRAIN, MODE_BN_EVAL, MODE_GN = 0, 1, 2, 3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return L.XH_F32
+    if t.dtype == torch.bfloat16:
+        return L.XH_BF16
+    raise TypeError(f"activation dtype must be float32 or bfloat16, got {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _vol(t):
+    """(N, C, D, H, W, batch_stride) of a tensor whose samples are contiguous CDHW blocks."""
+    if t.dim() != 5:
+        raise ValueError(f"expected a 5D NCDHW tensor, got {tuple(t.shape)}")
+    if not t.is_cuda:
+        raise RuntimeError("xlstm_hved_amd ops need device tensors (the HIP library is the only compute path)")
+    n, c, d, h, w = t.shape
+    if not t[0].is_contiguous():
+        raise ValueError("each sample must be a contiguous (C,D,H,W) block")
+    bs = t.stride(0) if n > 1 else c * d * h * w
+    return n, c, d, h, w, bs
+
+
+def _f32(t, what):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError(f"{what} must be a contiguous float32 device tensor")
+    return t
+
+
+def _arr4(tensors):
+    a = (C.c_void_p * 4)()
+    for i, t in enumerate(tensors):
+        a[i] = _p(t)
+    return a
+
+
+def new_like(t, shape, dtype=None):
+    return torch.empty(shape, dtype=dtype or t.dtype, device=t.device)
+
+
+def zeros_red(t, n, c):
+    return torch.zeros((n, c, 2), dtype=torch.float64, device=t.device)
+
+
+# ----------------------------------------------------------------------------------------------- conv
+def _conv_desc(xa, xb, k, stride, groups, cout, n_w, transposed, pre, act, act_slope, epi, e, y_bs, out_sp):
+    n, ca, d, h, w, xa_bs = _vol(xa)
+    cb, xb_bs = 0, 0
+    if xb is not None:
+        n2, cb, d2, h2, w2, xb_bs = _vol(xb)
+        if (n2, d2, h2, w2) != (n, d, h, w) or xb.dtype != xa.dtype:
+            raise ValueError("second conv source does not match the first")
+    desc = L.ConvDesc()
+    desc.dtype = _dt(xa)
+    desc.N, desc.Cin, desc.Cout, desc.groups = n, ca + cb, cout, groups
+    desc.D, desc.H, desc.W = d, h, w
+    desc.Do, desc.Ho, desc.Wo = out_sp
+    desc.k, desc.stride, desc.Ca = k, stride, ca
+    desc.xa_bs, desc.xb_bs, desc.y_bs = xa_bs, xb_bs, y_bs
+    desc.n_wptr, desc.transposed = n_w, int(transposed)
+    desc.pre = int(pre is not None)
+    desc.pre_slope = float(pre[2]) if pre is not None else 1.0
+    desc.act, desc.act_slope, desc.epi = act, act_slope, epi
+    if e is not None:
+        ea, eb = e[0], e[1]
+        desc.Cea = ea.shape[1]
+        desc.ea_bs = _vol(ea)[5]
+        desc.eb_bs = _vol(eb)[5] if eb is not None else 0
+        desc.e_slope = float(e[4])
+    return desc
+
+
+def _out_spatial(d, h, w, k, stride):
+    pad = k // 2
+    f = lambda s: (s + 2 * pad - k) // stride + 1
+    return f(d), f(h), f(w)
+
+
+def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=False, pre=None, act=ACT_NONE,
+           act_slope=LEAK, epi=0, e=None, red=None, out=None):
+    """y = act(conv(pre(cat[xa, xb])) + b) [+ fused epilogue].  weights/biases: lists of 1 or `groups` fp32 tensors.
+    pre = (sc, sh, slope); e = (ea, eb, e_sc, e_sh, e_slope) for epi==1.  `out` may be a channel slice."""
+    lib = L.load()
+    n, ca, d, h, w, _ = _vol(xa)
+    osp = _out_spatial(d, h, w, k, stride)
+    if out is None:
+        out = new_like(xa, (n, cout) + osp)
+    y_bs = _vol(out)[5]
+    if tuple(out.shape) != (n, cout) + osp or out.dtype != xa.dtype:
+        raise ValueError(f"conv output tensor has shape {tuple(out.shape)}, expected {(n, cout) + osp}")
+    desc = _conv_desc(xa, xb, k, stride, groups, cout, len(weights), transposed, pre, act, act_slope, epi, e, y_bs, osp)
+    ptrs = L.ConvPtrs()
+    ptrs.xa, ptrs.xb = _p(xa), _p(xb)
+    ptrs.w = _arr4([_f32(t, "conv weight") for t in weights])
+    ptrs.b = _arr4([_f32(t, "conv bias") for t in (biases or [])])
+    if pre is not None:
+        ptrs.pre_sc, ptrs.pre_sh = _p(_f32(pre[0], "pre_sc")), _p(_f32(pre[1], "pre_sh"))
+    ptrs.y = _p(out)
+    if e is not None:
+        ptrs.ea, ptrs.eb = _p(e[0]), _p(e[1])
+        ptrs.e_sc, ptrs.e_sh = _p(_f32(e[2], "e_sc")), _p(_f32(e[3], "e_sh"))
+    if red is not None:
+        ptrs.red = _p(red)
+    L.check(lib.xh_conv3d_fwd(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_fwd")
+    return out
+
+
+def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None):
+    """Data gradient of the k3/s2/p1 conv: dy (N,Cout,Do,Ho,Wo) -> (N,cin,D,H,W)."""
+    lib = L.load()
+    n, cout, do, ho, wo, dy_bs = _vol(dy)
+    d, h, w = in_spatial
+    out = new_like(dy, (n, cin, d, h, w))
+    desc = L.ConvDesc()
+    desc.dtype = _dt(dy)
+    desc.N, desc.Cin, desc.Cout, desc.groups = n, cin, cout, groups
+    desc.D, desc.H, desc.W, desc.Do, desc.Ho, desc.Wo = d, h, w, do, ho, wo
+    desc.k, desc.stride, desc.Ca = 3, 2, cout
+    desc.xa_bs, desc.y_bs = dy_bs, _vol(out)[5]
+    desc.n_wptr = len(weights)
+    desc.epi = 1 if e is not None else 0
+    ptrs = L.ConvPtrs()
+    ptrs.xa, ptrs.y = _p(dy), _p(out)
+    ptrs.w = _arr4([_f32(t, "conv weight") for t in weights])
+    if e is not None:
+        ea, eb = e[0], e[1]
+        desc.Cea, desc.ea_bs = ea.shape[1], _vol(ea)[5]
+        desc.eb_bs = _vol(eb)[5] if eb is not None else 0
+        desc.e_slope = float(e[4])
+        ptrs.ea, ptrs.eb, ptrs.e_sc, ptrs.e_sh, ptrs.red = _p(ea), _p(eb), _p(e[2]), _p(e[3]), _p(red)
+    L.check(lib.xh_conv3d_dgrad_s2(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_dgrad_s2")
+    return out
+
+
+def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None):
+    """Accumulates into the fp32 tensors dws (and dbs, may be None) the weight/bias gradients."""
+    lib = L.load()
+    n, cout, do, ho, wo, dy_bs = _vol(dy)
+    desc = _conv_desc(xa, xb, k, stride, groups, cout, len(dws), False, pre, ACT_NONE, LEAK, 0, None, 0, (do, ho, wo))
+    desc.ea_bs = dy_bs
+    ptrs = L.ConvPtrs()
+    ptrs.xa, ptrs.xb, ptrs.ea = _p(xa), _p(xb), _p(dy)
+    ptrs.w = _arr4([_f32(t, "dw") for t in dws])     # only used for the non-NULL check
+    if pre is not None:
+        ptrs.pre_sc, ptrs.pre_sh = _p(pre[0]), _p(pre[1])
+    dw = _arr4([_f32(t, "dw") for t in dws])
+    db = _arr4([_f32(t, "db") for t in (dbs or [])])
+    L.check(lib.xh_conv3d_wgrad(_stream(), C.byref(desc), C.byref(ptrs), C.byref(dw), C.byref(db)), "xh_conv3d_wgrad")
+
+
+# ----------------------------------------------------------------------------------------------- norms
+def moments(x, red, c0=0):
+    """red[:, c0:c0+C] += (sum x, sum x^2)."""
+    n, c, d, h, w, bs = _vol(x)
+    sl = red[:, c0:c0 + c]
+    L.check(L.load().xh_moments(_stream(), _dt(x), _p(x), bs, n, c, d * h * w, sl.data_ptr(), red.stride(0)), "xh_moments")
+
+
+def norm_finalize(mode, red, n, c, count, *, gs=1, gamma=None, beta=None, running_mean=None, running_var=None,
+                  steps=1, device=None):
+    dev = red.device if red is not None else device
+    sc, sh, mean, rstd = (torch.empty((n, c), dtype=torch.float32, device=dev) for _ in range(4))
+    L.check(L.load().xh_norm_finalize(_stream(), mode, _p(red), n, c, count, gs, NORM_EPS, _p(gamma), _p(beta),
+                                      _p(running_mean), _p(running_var), steps, _p(sc), _p(sh), _p(mean), _p(rstd)),
+            "xh_norm_finalize")
+    return sc, sh, mean, rstd
+
+
+def affine_act(x, sc, sh, act, slope=LEAK, out=None):
+    n, c, d, h, w, bs = _vol(x)
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    L.check(L.load().xh_affine_act(_stream(), _dt(x), _p(x), bs, _p(out), _vol(out)[5], n, c, d * h * w, _p(sc), _p(sh),
+                                   act, slope), "xh_affine_act")
+    return out
+
+
+def act_bwd_reduce(dy, x, sc, sh, slope):
+    n, c, d, h, w, bs = _vol(x)
+    red = zeros_red(x, n, c)
+    L.check(L.load().xh_act_bwd_reduce(_stream(), _dt(x), _p(dy), _vol(dy)[5], _p(x), bs, n, c, d * h * w, _p(sc), _p(sh),
+                                       slope, _p(red)), "xh_act_bwd_reduce")
+    return red
+
+
+def norm_bwd_coef(mode, red, count, mean, rstd, *, gs=1, gamma=None, dgamma=None, dbeta=None):
+    n, c = mean.shape
+    A, B, Cc = (torch.empty((n, c), dtype=torch.float32, device=mean.device) for _ in range(3))
+    L.check(L.load().xh_norm_bwd_coef(_stream(), mode, _p(red), n, c, count, gs, _p(gamma), _p(mean), _p(rstd), _p(A),
+                                      _p(B), _p(Cc), _p(dgamma), _p(dbeta)), "xh_norm_bwd_coef")
+    return A, B, Cc
+
+
+def norm_bwd_apply(dy, x, coef, *, have_g, sc=None, sh=None, slope=LEAK, out=None, accumulate=False, c0=0):
+    """dx (+)= A*g + Cc*x + B over x's channels; dy/coef may be wider: channel window starts at c0."""
+    n, c, d, h, w, bs = _vol(x)
+    A, B, Cc = (t[:, c0:c0 + c].contiguous() if t.shape[1] != c else t for t in coef)
+    if sc is not None and sc.shape[1] != c:
+        sc, sh = sc[:, c0:c0 + c].contiguous(), sh[:, c0:c0 + c].contiguous()
+    dyv = dy[:, c0:c0 + c] if dy.shape[1] != c else dy
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    L.check(L.load().xh_norm_bwd_apply(_stream(), _dt(x), _p(dyv), _vol(dyv)[5], _p(x), bs, _p(out), _vol(out)[5], n, c,
+                                       d * h * w, _p(A), _p(B), _p(Cc), int(have_g), _p(sc), _p(sh), slope,
+                                       int(accumulate)), "xh_norm_bwd_apply")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- resampling
+def maxpool2(x):
+    n, c, d, h, w, _ = _vol(x)
+    x = x.contiguous()
+    y = new_like(x, (n, c, d // 2, h // 2, w // 2))
+    L.check(L.load().xh_maxpool2_fwd(_stream(), _dt(x), _p(x), _p(y), n * c, d, h, w), "xh_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    n, c, d, h, w, _ = _vol(x)
+    x, dy = x.contiguous(), dy.contiguous()
+    dx = torch.empty_like(x)
+    L.check(L.load().xh_maxpool2_bwd(_stream(), _dt(x), _p(x), _p(dy), _p(dx), n * c, d, h, w, 0), "xh_maxpool2_bwd")
+    return dx
+
+
+def upsample(x, size, out=None):
+    n, c, d, h, w, bs = _vol(x)
+    do, ho, wo = size
+    if out is None:
+        out = new_like(x, (n, c, do, ho, wo))
+    L.check(L.load().xh_upsample_trilinear_fwd(_stream(), _dt(x), _p(x), bs, _p(out), _vol(out)[5], n, c, d, h, w, do, ho, wo),
+            "xh_upsample_trilinear_fwd")
+    return out
+
+
+def upsample_bwd(dy, in_size):
+    n, c, do, ho, wo, bs = _vol(dy)
+    d, h, w = in_size
+    dx = new_like(dy, (n, c, d, h, w))
+    L.check(L.load().xh_upsample_trilinear_bwd(_stream(), _dt(dy), _p(dy), bs, _p(dx), _vol(dx)[5], n, c, d, h, w, do, ho, wo, 0),
+            "xh_upsample_trilinear_bwd")
+    return dx
+
+
+def add(a, b, out=None):
+    """out = a + b (b None: copy) for NCDHW-blocked tensors."""
+    n, c, d, h, w, a_bs = _vol(a)
+    if out is None:
+        out = new_like(a, (n, c, d, h, w))
+    L.check(L.load().xh_add(_stream(), _dt(a), _p(a), a_bs, _p(b), _vol(b)[5] if b is not None else 0, _p(out), _vol(out)[5],
+                            n, c * d * h * w), "xh_add")
+    return out
+
+
+def act_bwd(dy, y, act):
+    dy, y = dy.contiguous(), y.contiguous()
+    dx = torch.empty_like(y)
+    L.check(L.load().xh_act_bwd(_stream(), _dt(y), _p(dy), _p(y), _p(dx), y.numel(), act), "xh_act_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------- PoE
+def poe_fwd(feat, keep, eps, L_, mask_mu):
+    n, c, d, h, w, _ = _vol(feat)
+    feat = feat.contiguous()
+    z = new_like(feat, (n, L_, d, h, w))
+    mu = new_like(feat, (n, 5, L_, d, h, w))
+    lv = new_like(feat, (n, 5, L_, d, h, w))
+    L.check(L.load().xh_poe_fwd(_stream(), _dt(feat), _p(feat), _p(keep), _p(eps), _p(z), _p(mu), _p(lv), n, L_, d * h * w,
+                                int(mask_mu)), "xh_poe_fwd")
+    return z, mu, lv
+
+
+def poe_bwd(feat, keep, eps, dz, dmu, dlv, L_, mask_mu):
+    n, c, d, h, w, _ = _vol(feat)
+    dfeat = torch.empty_like(feat)
+    L.check(L.load().xh_poe_bwd(_stream(), _dt(feat), _p(feat), _p(keep), _p(eps), _p(dz), _p(dmu), _p(dlv), _p(dfeat), n, L_,
+                                d * h * w, int(mask_mu)), "xh_poe_bwd")
+    return dfeat
+
+
+# ----------------------------------------------------------------------------------------------- attention glue
+def channel_pool(x, out):
+    """out (a 2-channel slice) = [max_c x, mean_c x]."""
+    n, c, d, h, w, bs = _vol(x)
+    L.check(L.load().xh_channel_pool_fwd(_stream(), _dt(x), _p(x), bs, _p(out), _vol(out)[5], n, c, d * h * w), "xh_channel_pool_fwd")
+
+
+def channel_pool_bwd(x, dy):
+    n, c, d, h, w, bs = _vol(x)
+    dx = new_like(x, (n, c, d, h, w))
+    L.check(L.load().xh_channel_pool_bwd(_stream(), _dt(x), _p(x), bs, _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5], n, c, d * h * w, 0),
+            "xh_channel_pool_bwd")
+    return dx
+
+
+def gate(x, s, out=None):
+    n, c, d, h, w, bs = _vol(x)
+    if out is None:
+        out = new_like(x, (n, c, d, h, w))
+    L.check(L.load().xh_gate_fwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(out), _vol(out)[5], n, c, d * h * w), "xh_gate_fwd")
+    return out
+
+
+def gate_bwd(x, s, dy, ds_out=None):
+    n, c, d, h, w, bs = _vol(x)
+    dx = new_like(x, (n, c, d, h, w))
+    if ds_out is None:
+        ds_out = new_like(x, (n, 1, d, h, w))
+    L.check(L.load().xh_gate_bwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5],
+                                 _p(ds_out), _vol(ds_out)[5], n, c, d * h * w, 0, 0), "xh_gate_bwd")
+    return dx, ds_out
+
+
+def duse_gate(x, ch, sp):
+    n, c, d, h, w, bs = _vol(x)
+    u = new_like(x, (n, c, d, h, w))
+    L.check(L.load().xh_duse_gate_fwd(_stream(), _dt(x), _p(x), bs, _p(ch), _p(sp), _vol(sp)[5], _p(u), _vol(u)[5], n, c, d * h * w),
+            "xh_duse_gate_fwd")
+    return u
+
+
+def duse_gate_bwd(x, ch, sp, du, dsp_out):
+    n, c, d, h, w, bs = _vol(x)
+    dx = new_like(x, (n, c, d, h, w))
+    dch = torch.zeros((n, c), dtype=torch.float64, device=x.device)
+    L.check(L.load().xh_duse_gate_bwd(_stream(), _dt(x), _p(x), bs, _p(ch), _p(sp), _vol(sp)[5], _p(du), _vol(du)[5], _p(dx),
+                                      _vol(dx)[5], _p(dsp_out), _vol(dsp_out)[5], _p(dch), n, c, d * h * w), "xh_duse_gate_bwd")
+    return dx, dch
+
+
+def rank1_add(dx, d1, w, k):
+    n, c, d, h, ww, bs = _vol(dx)
+    L.check(L.load().xh_rank1_add(_stream(), _dt(dx), _p(dx), bs, _p(d1), _vol(d1)[5], _p(w), _p(k), n, c, d * h * ww), "xh_rank1_add")
+    return dx
+
+
+def duse_fc_fwd(red_r, red_s, count, n, c, p):
+    g, ch1, ch2 = (torch.empty((n, c), dtype=torch.float32, device=red_r.device) for _ in range(3))
+    L.check(L.load().xh_duse_fc_fwd(_stream(), _p(red_r), _p(red_s), count, n, c, _p(p["wc"]), _p(p["bc"]), _p(p["w1"]), _p(p["b1"]),
+                                    _p(p["w2"]), _p(p["b2"]), _p(g), _p(ch1), _p(ch2)), "xh_duse_fc_fwd")
+    return g, ch1, ch2
+
+
+def duse_fc_bwd(red_r, red_s, count, n, c, p, g, ch1, ch2, dch1, dch2):
+    z = lambda t: torch.zeros_like(t)
+    grads = {k: z(p[k]) for k in ("wc", "bc", "w1", "b1", "w2", "b2")}
+    dmr, dms = (torch.empty((n, c), dtype=torch.float32, device=g.device) for _ in range(2))
+    L.check(L.load().xh_duse_fc_bwd(_stream(), _p(red_r), _p(red_s), count, n, c, _p(p["wc"]), _p(p["w1"]), _p(p["w2"]), _p(g), _p(ch1),
+                                    _p(ch2), _p(dch1), _p(dch2), _p(grads["wc"]), _p(grads["bc"]), _p(grads["w1"]), _p(grads["b1"]),
+                                    _p(grads["w2"]), _p(grads["b2"]), _p(dmr), _p(dms)), "xh_duse_fc_bwd")
+    return grads, dmr, dms
+
+
+def skr_tail(t, x, sc, sh, w2):
+    n, c, d, h, w, _ = _vol(x)
+    a = new_like(x, (n, 1, d, h, w))
+    L.check(L.load().xh_skr_tail_fwd(_stream(), _dt(x), _p(t), _p(x), _p(sc), _p(sh), _p(w2), _p(a), n, c, d * h * w), "xh_skr_tail_fwd")
+    return a
+
+
+def skr_tail_bwd(t, x, sc, sh, w2, a, da):
+    n, c, d, h, w, _ = _vol(x)
+    dtg, dx = torch.empty_like(t), torch.empty_like(x)
+    dw2 = torch.zeros(2, dtype=torch.float64, device=x.device)
+    L.check(L.load().xh_skr_tail_bwd(_stream(), _dt(x), _p(t), _p(x), _p(sc), _p(sh), _p(w2), _p(a), _p(da), _p(dtg), _p(dx), _p(dw2),
+                                     n, c, d * h * w, 0), "xh_skr_tail_bwd")
+    return dtg, dx, dw2
+
+
+# ----------------------------------------------------------------------------------------------- ViL
+def _vil_struct(tensors):
+    s = L.VilParams()
+    for name in L.VIL_FIELDS:
+        setattr(s, name, _p(_f32(tensors[name], name)))
+    return s
+
+
+def vil_fwd(xa, xb, params, add_xa=True, nh=4):
+    """out = (xa if add_xa) + ViLBlock(xa + xb); xa/xb (B,C,D,H,W).  Returns (out, workspace)."""
+    n, c, d, h, w, _ = _vol(xa)
+    xa = xa.contiguous()
+    xb = xb.contiguous() if xb is not None else None
+    s = d * h * w
+    lib = L.load()
+    ws = torch.empty(lib.xh_vil_workspace_floats(n, s, c), dtype=torch.float32, device=xa.device)
+    out = torch.empty_like(xa)
+    ps = _vil_struct(params)
+    L.check(lib.xh_vil_fwd(_stream(), _dt(xa), _p(xa), _p(xb), _p(out), n, s, c, nh, int(add_xa), C.byref(ps), _p(ws)), "xh_vil_fwd")
+    return out, ws
+
+
+def vil_bwd(xa, xb, dout, params, ws, nh=4):
+    n, c, d, h, w, _ = _vol(xa)
+    s = d * h * w
+    dout = dout.contiguous()
+    dxin = torch.empty_like(dout)
+    grads = {k: torch.zeros_like(params[k]) for k in L.VIL_FIELDS}
+    ps, gs = _vil_struct(params), _vil_struct(grads)
+    L.check(L.load().xh_vil_bwd(_stream(), _dt(dout), _p(xa), _p(xb), _p(dout), _p(dxin), n, s, c, nh, C.byref(ps), C.byref(gs), _p(ws)),
+            "xh_vil_bwd")
+    return dxin, grads
