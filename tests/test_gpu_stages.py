@@ -4,7 +4,7 @@ other shapes.  fp32 storage is held to round-off; bf16 storage to bf16 resolutio
 import pytest
 import torch
 
-from gpu_common import check, load, rel_err, rnd, sd_of
+from gpu_common import check, check_grads, l2_err, load, rel_err, rnd, sd_of
 
 pytestmark = pytest.mark.gpu
 
@@ -51,8 +51,10 @@ def test_stage_against_reference_golden(name, dtype):
     out = mod(*ins)
     outs = list(out) if isinstance(out, (tuple, list)) else [out]
     f32 = dtype == torch.float32
+    # fp32 storage: round-off.  bf16 storage: pointwise values to bf16 resolution; gradients in relative L2 (a sign
+    # flip of a near-zero pre-activation moves a LeakyReLU gradient by 100x at that voxel, so max-norm is meaningless;
+    # the skip-return block stacks two ReLUs, a channel arg-max and a third ReLU, hence its wider band)
     tol_o = (2e-4 if "vil" in name else 5e-5) if f32 else 4e-2
-    tol_g = 2e-3 if f32 else 1.5e-1
     loss = 0
     for j, o in enumerate(outs):
         assert o.dtype == dtype
@@ -61,12 +63,14 @@ def test_stage_against_reference_golden(name, dtype):
     loss.backward()
     torch.cuda.synchronize()
     for j, t in enumerate(ins):
-        check(t.grad, g[f"gin{j}"], tol_g, f"{name}.gin{j}")
-    params = dict(mod.named_parameters())
-    for k, v in g.items():
-        if k.startswith("g."):
-            assert params[k[2:]].grad is not None, f"{name}: no gradient for {k[2:]}"
-            check(params[k[2:]].grad, v, tol_g, f"{name}.{k}")
+        if f32:
+            check(t.grad, g[f"gin{j}"], 2e-3, f"{name}.gin{j}")
+        else:
+            e = l2_err(t.grad, g[f"gin{j}"])
+            assert e < (0.4 if "skr" in name else 0.12), f"{name}.gin{j}: relative L2 error {e:.3e}"
+    params = {k: p.grad for k, p in mod.named_parameters()}
+    ref = {k[2:]: v for k, v in g.items() if k.startswith("g.")}
+    check_grads(params, ref, 2e-3 if f32 else (0.4 if "skr" in name else 0.12), name, l2=not f32)
     if f32:
         sd = mod.state_dict()
         for k, v in sd_of(g, "sd_after.").items():
