@@ -1,0 +1,53 @@
+"""world_size-2 gloo test of the data-parallel gradient exchange (runs on CPU)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import xlstm_hved_amd as X
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    dead = torch.nn.Parameter(torch.ones(4))              # never reached: .grad stays None on every rank
+    half = torch.nn.Parameter(torch.ones(2))              # has a gradient on rank 0 only
+    x = torch.full((2, 5), float(rank + 1))
+    loss = lin(x).sum() + (half.sum() if rank == 0 else 0.0)
+    loss.backward()
+    ar = X.parallel.FlatGradAllReduce([lin.weight, lin.bias, dead, half], world)
+    ar()
+    q.put((rank, lin.weight.grad.clone(), lin.bias.grad.clone(), dead.grad, None if half.grad is None else half.grad.clone(),
+           X.parallel.shard_windows(7, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # d/dW of sum(W x + b) = sum over batch of x: rank r contributes 2*(r+1) per entry -> average (2+4)/2 = 3
+    for rank, wg, bg, dead, half, shard in res:
+        assert torch.allclose(wg, torch.full((3, 5), 3.0)) and torch.allclose(bg, torch.full((3,), 2.0))
+        assert dead is None
+        assert shard == list(range(rank, 7, 2))
+    assert torch.allclose(res[0][4], torch.full((2,), 0.5))     # rank 0: (1 + 0) / 2
+    assert res[1][4] is None                                     # rank 1 had no gradient; its zeros were counted

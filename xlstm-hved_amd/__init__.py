@@ -3,7 +3,7 @@
 Import name `xlstm_hved_amd` (see /xlstm_hved_amd.py for the alias of this hyphenated directory).
 Compute lives in csrc/*.hip behind the C ABI of include/xlstm_hved.h; this package is the host-side mirror of the
 reference's nn.Module surface."""
-from . import _lib, functional, ops  # noqa: F401
+from . import _lib, functional, ops, parallel  # noqa: F401
 from .blocks import (AttenModule2, BasicConv, ChannelPool, Decoder, DoubleConv, DoubleConv_ViL, DuSEAttention, Encoder,  # noqa: F401
                      ProductOfExperts, ProductOfExperts2, ResBlock, SingleConv, SkipReturnAttention, SpacialAttention3D,
                      Upsampling, ViLLayer, number_of_features_per_level)
