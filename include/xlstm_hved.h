@@ -31,6 +31,8 @@ extern "C" {
 #define XH_ACT_SIGMOID 3
 
 int xh_abi_version(void);
+/* key 0: use the bf16-MFMA implicit-GEMM conv kernels where eligible (default 1); for A/B tests. */
+int xh_set_option(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * 3D convolution family.  Replaces nn.Conv3d together with the norm/activation modules wrapped around it
@@ -72,11 +74,15 @@ typedef struct {
   const void* ea; const void* eb;             /* epi==1 */
   const float* e_sc; const float* e_sh;       /* [N][Cout] */
   double* red;                                /* [N][Cout][2], caller zeroes, epi!=0 */
+  void* ws; long long ws_bytes;               /* scratch for packed bf16 MFMA weight fragments (may be NULL:
+                                                 the vector kernel is used); size from xh_conv3d_workspace_bytes */
 } xh_conv_ptrs;
 
 /* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv
  * (transposed=1).  Reference: F.conv3d as used throughout RA_HVED.py:510-648. */
 int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
+/* Bytes of p->ws the bf16-MFMA implicit-GEMM path wants for this desc (0: shape not eligible, vector kernel). */
+long long xh_conv3d_workspace_bytes(const xh_conv_desc* d);
 
 /* Data gradient of a k=3, stride=2, pad=1 conv (the DRB SingleConv, RA_HVED.py:396-397).  Desc fields
  * describe the FORWARD conv (Cin,D,H,W = forward input; Cout,Do,Ho,Wo = forward output); x* = dY

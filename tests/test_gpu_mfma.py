@@ -1,0 +1,62 @@
+"""-m gpu: the bf16-MFMA implicit-GEMM conv kernels against the vector kernels (same bf16 inputs) and stock ops."""
+import pytest
+import torch
+
+from gpu_common import l2_err
+
+pytestmark = pytest.mark.gpu
+
+import xlstm_hved_amd as X  # noqa: E402
+
+DEV = "cuda"
+CASES = [
+    dict(cin=16, cout=16, groups=4, sp=(8, 16, 32)),          # the four modality encoders batched (4->4 x4)
+    dict(cin=16, cout=32, groups=4, sp=(8, 8, 64)),           # 4->8 x4: two groups per block set
+    dict(cin=32, cout=64, groups=4, sp=(5, 9, 32)),           # 8->16 x4: one group per set, ragged D/H
+    dict(cin=64, cout=128, groups=4, sp=(4, 8, 32)),          # 16->32 x4: two 16-wide output tiles per set
+    dict(cin=12, cout=4, groups=1, sp=(8, 8, 32), split=4),   # decoder conv on a virtual concat, CINP=12
+    dict(cin=24, cout=8, groups=1, sp=(4, 8, 32), split=8),   # CINP=24
+    dict(cin=4, cout=4, groups=1, sp=(6, 8, 32)),             # CINP=4 (two 8-byte fragment reads)
+    dict(cin=8, cout=8, groups=1, sp=(4, 8, 32)),
+]
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_mfma_conv_forward_backward(cfg):
+    torch.manual_seed(11)
+    n, cin, cout, g = 2, cfg["cin"], cfg["cout"], cfg["groups"]
+    x = (torch.randn((n, cin) + cfg["sp"]) * 1.5 + 0.3).bfloat16()
+    ws = [torch.randn(cout // g, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5 for _ in range(g)]
+    bs = [torch.randn(cout // g) for _ in range(g)]
+    wgt = torch.randn((n, cout) + cfg["sp"])
+
+    def run(mfma):
+        X.ops.set_mfma(mfma)
+        try:
+            xg = x.to(DEV).requires_grad_(True)
+            wg = [w.to(DEV).requires_grad_(True) for w in ws]
+            bg = [b.to(DEV).requires_grad_(True) for b in bs]
+            xa, xb = (xg[:, :cfg["split"]], xg[:, cfg["split"]:]) if "split" in cfg else (xg, None)
+            y = X.functional.in_lrelu_conv(xa, xb, wg, bg, 1, g)
+            (y.float() * wgt.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().float().cpu(), xg.grad.float().cpu(), [w.grad.cpu() for w in wg], [b.grad.cpu() for b in bg]
+        finally:
+            X.ops.set_mfma(True)
+    y1, dx1, dw1, db1 = run(True)
+    y0, dx0, dw0, db0 = run(False)
+    # stock fp32 ops on the same bf16-representable input
+    xo = x.float().requires_grad_(True)
+    wo = [w.clone().requires_grad_(True) for w in ws]
+    bo = [b.clone().requires_grad_(True) for b in bs]
+    h = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(xo, eps=1e-5), 0.01)
+    yo = torch.nn.functional.conv3d(h, torch.cat(wo, 0), torch.cat(bo, 0), padding=1, groups=g)
+    (yo * wgt).sum().backward()
+    # forward: MFMA rounds the normalised activations and the weights to bf16 (2^-9 each) on top of the output rounding
+    e = dict(y_vs_stock=l2_err(y1, yo), y_vs_vector=l2_err(y1, y0), dx_vs_stock=l2_err(dx1, xo.grad), dx_vs_vector=l2_err(dx1, dx0))
+    print(cfg, {k: f"{v:.2e}" for k, v in e.items()})
+    assert e["y_vs_stock"] < 8e-3 and e["y_vs_vector"] < 8e-3, e
+    assert e["dx_vs_stock"] < 5e-2 and e["dx_vs_vector"] < 5e-2, e
+    gmax = max(w.grad.abs().max() for w in wo)
+    for a, b in zip(dw1 + db1, [w.grad for w in wo] + [b.grad for b in bo]):
+        assert l2_err(a, b) < 3e-2 or (a - b).abs().max() < 2e-2 * gmax

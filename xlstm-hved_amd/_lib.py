@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
 class ConvPtrs(C.Structure):
     _fields_ = [
         ("xa", vp), ("xb", vp), ("w", vp * 4), ("b", vp * 4), ("pre_sc", vp), ("pre_sh", vp), ("y", vp),
-        ("ea", vp), ("eb", vp), ("e_sc", vp), ("e_sh", vp), ("red", vp),
+        ("ea", vp), ("eb", vp), ("e_sc", vp), ("e_sh", vp), ("red", vp), ("ws", vp), ("ws_bytes", ll),
     ]
 
 
@@ -48,7 +48,9 @@ class VilParams(C.Structure):
 I, F = C.c_int, C.c_float
 SIGNATURES = {
     "xh_abi_version": (I, []),
+    "xh_set_option": (I, [I, I]),
     "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
+    "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * 4), C.POINTER(vp * 4)]),
     "xh_moments": (I, [vp, I, vp, ll, I, I, ll, vp, ll]),

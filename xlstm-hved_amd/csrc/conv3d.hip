@@ -706,6 +706,15 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
   return XH_ERR_ARG;
 }
 
+int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv3d_mfma.hip
+static int g_use_mfma = 1;
+extern int g_mfma_abl;
+extern "C" int xh_set_option(int key, int value) {
+  if (key == 0) { g_use_mfma = value; return XH_OK; }
+  if (key == 1) { g_mfma_abl = value; return XH_OK; }
+  return XH_ERR_ARG;
+}
+
 extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   int rc = check_desc(d, p);
   if (rc) return rc;
@@ -714,6 +723,10 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
   if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cout && !p->eb))) return XH_ERR_ARG;
   if (d->epi == 2 && !p->red) return XH_ERR_ARG;
   if (d->epi < 0 || d->epi > 2) return XH_ERR_ARG;
+  if (g_use_mfma) {
+    const int r = xh_conv3_mfma_try(stream, d, p);
+    if (r != 1) return r;
+  }
   return d->dtype == XH_F32 ? conv_fwd_dispatch<float>(stream, d, p) : conv_fwd_dispatch<bf16_t>(stream, d, p);
 }
 

@@ -1,0 +1,380 @@
+// bf16-MFMA implicit-GEMM 3x3x3 stride-1 convolution for gfx950 (forward and data gradient), bf16 storage.
+//
+// GEMM view per output row segment of 16 voxels along W:   D[16 vox][16 cout] += A[16 vox][K] * B[K][16 cout]
+// with K = 9 (kd,kh) row segments x (3 taps x CINP channels), walked in 16-byte chunks of 8 bf16.
+//
+//  * The input halo tile lives in LDS channels-last ([d][h][w][CINP] bf16) so that for a fixed (kd,kh) the
+//    3 taps x CINP channels of output voxel w are ONE contiguous run starting at tile column w: an A fragment is a
+//    single 16-byte LDS read per lane, no im2col buffer.  The producer's normalisation + LeakyReLU is applied while
+//    staging (NCDHW planes -> 4-channel x 8-voxel register transpose -> 8-byte LDS writes), zero padding after it.
+//    All global loads of a tile are issued before the first is consumed.
+//  * mfma_f32_16x16x32_bf16: lane l supplies A[row l&15][k 8*(l>>4)..+7] and B[k 8*(l>>4)..+7][col l&15]; lane group
+//    g = l>>4 therefore owns chunk 4*i+g of the K walk in MFMA i.  Chunks past the end of a row segment read the next
+//    voxel's (finite) data against zero weights.
+//  * Weights are packed ONCE per launch by a small kernel into fragment order (caller workspace) and held in registers
+//    (B operands) by every wave for all tiles it computes; groups are block-diagonal zeros inside a 16-wide tile.
+//  * Workgroups are persistent: a grid of ~2 per CU walks the tile list, so fragment loads, bias/scale loads and the
+//    fused reductions are paid once per workgroup instead of once per 1024 voxels; two resident workgroups per CU
+//    overlap one's staging with the other's MFMA phase.
+//  * Epilogue: accumulators are transposed through a wave-private LDS pad so each lane owns 8 consecutive voxels of one
+//    output channel: bias/activation/fused reductions there, then one 16-byte NCDHW store per lane (64 B runs).
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvMK {
+  xh_conv_desc d;
+  xh_conv_ptrs p;
+  int Cin_g, Cout_g;
+  int tilesW, tilesH, tilesD;
+  int cin_blk;      // input channels staged per block (<= CINP)
+  int ntile;        // 16-wide output tiles per set
+  int cout_set;     // output channels per set
+  int cinp, cpr, nch, nm;
+  int abl;          // ablation mask for microbenchmarks (0 in production)
+};
+int g_mfma_abl = 0;
+
+__device__ __forceinline__ float mk_weight(const ConvMK& a, int co, int ci, int tap) {
+  // kernel-view absolute channels; block-diagonal over groups
+  const int g = co / a.Cout_g;
+  if (ci / a.Cin_g != g) return 0.f;
+  const int co_g = co % a.Cout_g, ci_g = ci % a.Cin_g;
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const float* wp = a.p.w[g / gpp];
+  const int gl = g % gpp;
+  if (!a.d.transposed) return wp[((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * 27 + tap];
+  return wp[((long long)(gl * a.Cin_g + ci_g) * a.Cout_g + co_g) * 27 + (26 - tap)];
+}
+
+// ws[y][i][lane][8] = B fragment (k = 8*(lane>>4)..+7, col lane&15) of MFMA i for channel tile y = set*ntile + nt
+__global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
+  const int y = blockIdx.x;
+  const int set = y / a.ntile, nt = y % a.ntile;
+  const int cin0 = set * a.cin_blk;
+  const int co_base = set * a.cout_set + nt * 16;
+  const int co_lim = min(16, a.cout_set - nt * 16);
+  unsigned short* wf = (unsigned short*)a.p.ws + (long long)y * a.nm * 512;
+  for (int idx = threadIdx.x; idx < a.nm * 512; idx += 256) {
+    const int e = idx & 7, l = (idx >> 3) & 63, i = idx >> 9;
+    const int c = 4 * i + (l >> 4);
+    float v = 0.f;
+    if (c < a.nch && (l & 15) < co_lim) {
+      const int r9 = c / a.cpr, j = c % a.cpr;
+      const int flat = j * 8 + e;                     // position inside the row segment: kw*CINP + ci
+      const int kw = flat / a.cinp, ci = flat % a.cinp;
+      if (kw < 3 && ci < a.cin_blk) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
+    }
+    wf[idx] = f2bf(v);
+  }
+}
+
+template <int CINP>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const ConvMK a) {
+  constexpr int TW = 32, TH = 8, TD = 4;
+  constexpr int IH = TH + 2, ID = TD + 2;
+  constexpr int IWP = TW + 4;                         // halo (2) + 2 spare columns for the over-reading tail chunk
+  constexpr int VB = CINP * 2;                        // bytes per voxel in LDS
+  constexpr int CPR = (3 * CINP + 7) / 8;             // 16-byte chunks per (kd,kh) row segment
+  constexpr int NCH = 9 * CPR;
+  constexpr int NM = (NCH + 3) / 4;                   // MFMAs per 16-voxel segment
+  constexpr bool A16 = (CINP % 8) == 0;               // 16-byte aligned fragments
+  constexpr int NQ = CINP / 4, NG = 6;                // channel quads; aligned 8-voxel groups covering [ow0-8, ow0+40)
+  constexpr int NITEM = ID * IH * NG * NQ;
+  constexpr int NIT = (NITEM + 255) / 256;
+  constexpr int EPS = 36;                             // epilogue pad row stride (floats)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_in = smem;                                                     // ID*IH*IWP*VB
+  float* s_ep = reinterpret_cast<float*>(smem + ID * IH * IWP * VB);              // [4 waves][16][EPS]
+  float* s_red = s_ep;                                                            // reused after the tile loop
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g4 = lane >> 4, nn = lane & 15;
+  const int y = blockIdx.y;
+  const int set = y / a.ntile, nt = y % a.ntile;
+  const int n = blockIdx.z;
+  const int cin0 = set * a.cin_blk;
+  const int co_base = set * a.cout_set + nt * 16;
+  const int co_lim = min(16, a.cout_set - nt * 16);
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long dhw = (long long)D * H * W;
+  const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long odhw = (long long)Do * Ho * Wo;
+
+  // ---- B fragments (registers, whole kernel) and A offsets ----
+  bf16x8 bfrag[NM];
+  int aoff[NM];
+  {
+    const bf16x8* wpk = reinterpret_cast<const bf16x8*>(a.p.ws) + (long long)y * NM * 64;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      bfrag[i] = wpk[i * 64 + lane];
+      const int c = 4 * i + g4;
+      const int cc = c < NCH ? c : 0;                 // dummy chunk: any valid address, its weights are zero
+      const int r9 = cc / CPR, j = cc % CPR;
+      aoff[i] = (((r9 / 3) * IH + (r9 % 3)) * IWP + nn) * VB + j * 16;
+    }
+  }
+  // ---- epilogue lane role: output channel lane>>2, voxels (lane&3)*8 .. +7 of a 32-voxel row ----
+  const int eco = lane >> 2, ech = lane & 3;
+  const int co = co_base + eco;
+  const bool co_ok = eco < co_lim;
+  float bias = 0.f, esc = 0.f, esh = 0.f;
+  const bf16_t* eplane = nullptr;
+  if (co_ok) {
+    const int g = co / a.Cout_g, gpp = a.d.groups / a.d.n_wptr;
+    const float* bp = a.p.b[g / gpp];
+    if (bp) bias = bp[(g % gpp) * a.Cout_g + co % a.Cout_g];
+    if (a.d.epi == 1) {
+      esc = a.p.e_sc[n * a.d.Cout + co];
+      esh = a.p.e_sh[n * a.d.Cout + co];
+      eplane = co < a.d.Cea ? (const bf16_t*)a.p.ea + n * a.d.ea_bs + (long long)co * odhw
+                            : (const bf16_t*)a.p.eb + n * a.d.eb_bs + (long long)(co - a.d.Cea) * odhw;
+    }
+  }
+  bf16_t* yplane = (bf16_t*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
+  float* ep = s_ep + wv * 16 * EPS;
+  float s0 = 0.f, s1 = 0.f;
+  const bf16_t* xa = (const bf16_t*)a.p.xa;
+  const bf16_t* xb = (const bf16_t*)a.p.xb;
+
+  const int ntiles = a.tilesW * a.tilesH * a.tilesD;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tw = t % a.tilesW; t /= a.tilesW;
+    const int th = t % a.tilesH;
+    const int td = t / a.tilesH;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+    __syncthreads();                                  // everyone is done reading the previous tile
+    // ---- stage: issue every load of this tile first, then transform + transpose into LDS ----
+    if (!(a.abl & 2)) {
+      uint4 raw[NIT][4];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int item = tid + it * 256;
+        const int q = item % NQ;
+        int r = item / NQ;
+        const int gq = r % NG - 1; r /= NG;
+        const int hy = r % IH, dz = r / IH;
+        const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 + gq * 8;
+        const bool inb = item < NITEM && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int cl = q * 4 + cc;
+          const int c = cin0 + cl;
+          raw[it][cc] = make_uint4(0, 0, 0, 0);
+          if (inb && cl < a.cin_blk) {
+            const bf16_t* src = (c < a.d.Ca ? xa + n * a.d.xa_bs + (long long)c * dhw
+                                            : xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
+                                ((long long)gd * H + gh) * W + gw;
+            raw[it][cc] = *reinterpret_cast<const uint4*>(src);
+          }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int item = tid + it * 256;
+        if (item < NITEM) {
+          const int q = item % NQ;
+          int r = item / NQ;
+          const int gq = r % NG - 1; r /= NG;
+          const int hy = r % IH, dz = r / IH;
+          const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 + gq * 8;
+          const bool inb = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+          float v[4][8];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int cl = q * 4 + cc;
+            const int c = cin0 + cl;
+            const bool live = inb && cl < a.cin_blk;
+            float sc = 1.f, sh = 0.f;
+            if (live && a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+            const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+              if (live && a.d.pre) { lo = leaky(lo * sc + sh, a.d.pre_slope); hi = leaky(hi * sc + sh, a.d.pre_slope); }
+              v[cc][2 * k] = live ? lo : 0.f;
+              v[cc][2 * k + 1] = live ? hi : 0.f;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int wx = gq * 8 + k + 1;            // tile column of voxel gw+k (column 0 = ow0-1)
+            if (wx >= 0 && wx < IWP) {
+              uint2 pk;
+              pk.x = (unsigned)f2bf(v[0][k]) | ((unsigned)f2bf(v[1][k]) << 16);
+              pk.y = (unsigned)f2bf(v[2][k]) | ((unsigned)f2bf(v[3][k]) << 16);
+              *reinterpret_cast<uint2*>(s_in + (((dz * IH + hy) * IWP + wx) * VB + q * 8)) = pk;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    for (int rr = wv; rr < TD * TH; rr += 4) {
+      const int tz = rr / TH, ty = rr % TH;
+      const int od = od0 + tz, oh = oh0 + ty;
+      if (od >= Do || oh >= Ho) continue;             // wave-uniform
+      f32x4 acc[2];
+#pragma unroll
+      for (int wt = 0; wt < 2; ++wt) {
+        const unsigned char* base = s_in + ((tz * IH + ty) * IWP + wt * 16) * VB;
+        acc[wt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(a.abl & 4))
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          bf16x8 av;
+          if (A16) {
+            av = *reinterpret_cast<const bf16x8*>(base + aoff[i]);
+          } else {
+            const uint2 lo = *reinterpret_cast<const uint2*>(base + aoff[i]);
+            const uint2 hi = *reinterpret_cast<const uint2*>(base + aoff[i] + 8);
+            const uint4 q4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            av = __builtin_bit_cast(bf16x8, q4);
+          }
+          acc[wt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bfrag[i], acc[wt], 0, 0, 0);
+        }
+      }
+      // ---- transpose through the wave-private pad: [cout nn][voxel wt*16 + 4*g4 + r] ----
+#pragma unroll
+      for (int wt = 0; wt < 2; ++wt)
+        *reinterpret_cast<f32x4*>(ep + nn * EPS + wt * 16 + g4 * 4) = acc[wt];
+      __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the wave's own LDS writes have landed
+      __builtin_amdgcn_wave_barrier();
+      float o[8];
+      {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + eco * EPS + ech * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + eco * EPS + ech * 8 + 4);
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (co_ok && !(a.abl & 8)) {
+        const long long sp = ((long long)od * Ho + oh) * Wo + ow0 + ech * 8;
+        float ev[8];
+        if (a.d.epi == 1) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(eplane + sp);
+          const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { ev[2 * k] = __uint_as_float(u[k] << 16); ev[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+        }
+        unsigned short ob[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float v = apply_act(o[r] + bias, a.d.act, a.d.act_slope);
+          if (a.d.epi == 1) {
+            v *= ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope);
+            ob[r] = f2bf(v);
+            v = bf2f(ob[r]);
+            s0 += v; s1 += v * ev[r];
+          } else if (a.d.epi == 2) {
+            ob[r] = f2bf(v);
+            v = bf2f(ob[r]);
+            s0 += v; s1 += v * v;
+          } else {
+            ob[r] = f2bf(v);
+          }
+        }
+        uint4 pk;
+        pk.x = (unsigned)ob[0] | ((unsigned)ob[1] << 16);
+        pk.y = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
+        pk.z = (unsigned)ob[4] | ((unsigned)ob[5] << 16);
+        pk.w = (unsigned)ob[6] | ((unsigned)ob[7] << 16);
+        *reinterpret_cast<uint4*>(yplane + sp) = pk;
+      }
+    }
+  }
+  if (a.d.epi) {
+    s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    __syncthreads();
+    if ((lane & 3) == 0) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
+    __syncthreads();
+    if (tid < 32) {
+      const float tot = s_red[tid] + s_red[32 + tid] + s_red[64 + tid] + s_red[96 + tid];
+      const int c = tid >> 1;
+      if (c < co_lim) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co_base + c) * 2 + (tid & 1)], (double)tot);
+    }
+  }
+}
+
+static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
+  if (d->dtype != XH_BF16 || d->k != 3 || d->stride != 1) return 1;
+  if (d->W % 32 != 0 || d->Wo != d->W) return 1;
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  if (cin_g < 4) return 1;                            // depthwise / single-channel convs stay on the vector kernel
+  if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return 1;
+  const long long dhw = (long long)d->D * d->H * d->W;
+  if (dhw % 8) return 1;
+  int gs = 1;                                         // groups per set: as many as fit 24 input / 16 output channels
+  while (gs * 2 <= d->groups && d->groups % (gs * 2) == 0 && gs * 2 * cin_g <= 24 && gs * 2 * cout_g <= 16) gs *= 2;
+  const int cin_blk = gs * cin_g;
+  if (cin_blk > 24) return 1;
+  if (d->N > 65535) return 1;
+  a->d = *d;
+  a->Cin_g = cin_g; a->Cout_g = cout_g;
+  a->tilesW = d->W / 32; a->tilesH = cdiv(d->Ho, 8); a->tilesD = cdiv(d->Do, 4);
+  a->cin_blk = cin_blk;
+  a->cout_set = gs * cout_g;
+  a->ntile = cdiv(a->cout_set, 16);
+  a->cinp = cin_blk <= 4 ? 4 : cin_blk <= 8 ? 8 : cin_blk <= 12 ? 12 : cin_blk <= 16 ? 16 : 24;
+  if (a->cinp == 12 || a->cinp == 24) return 1;      // measured slower than the vector kernel with this staging
+  a->cpr = (3 * a->cinp + 7) / 8;
+  a->nch = 9 * a->cpr;
+  a->nm = (a->nch + 3) / 4;
+  a->abl = g_mfma_abl;
+  const int ny = (d->groups / gs) * a->ntile;
+  if (ny > 65535) return 1;
+  return 0;
+}
+
+extern "C" long long xh_conv3d_workspace_bytes(const xh_conv_desc* d) {
+  ConvMK a;
+  if (!d || d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return 0;
+  if (mfma_plan(d, &a)) return 0;
+  const int gs = a.cin_blk / a.Cin_g;
+  return (long long)(d->groups / gs) * a.ntile * a.nm * 1024;
+}
+
+// returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
+int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  ConvMK a;
+  if (mfma_plan(d, &a)) return 1;
+  const long long need = xh_conv3d_workspace_bytes(d);
+  if (!p->ws || p->ws_bytes < need) return 1;
+  a.p = *p;
+  const int gs = a.cin_blk / a.Cin_g;
+  const int ny = (d->groups / gs) * a.ntile;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3_pack_kernel, dim3(ny), dim3(256), 0, st, a);
+  const int ntiles = a.tilesW * a.tilesH * a.tilesD;
+  // persistent workers: ~2 resident workgroups per CU over all (channel tile, sample) pairs
+  int workers = cdiv(512, ny * d->N);
+  if (workers < 1) workers = 1;
+  if (workers > ntiles) workers = ntiles;
+  dim3 grid(workers, ny, d->N);
+  const size_t shm = (size_t)6 * 10 * 36 * a.cinp * 2 + (size_t)4 * 16 * 36 * sizeof(float);
+#define LM(C)                                                                                                   \
+  do {                                                                                                          \
+    static bool attr_done = false;                                                                              \
+    if (!attr_done) {                                                                                           \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      attr_done = true;                                                                                         \
+    }                                                                                                           \
+    hipLaunchKernelGGL((conv3_mfma_kernel<C>), grid, dim3(256), shm, st, a);                                    \
+  } while (0)
+  switch (a.cinp) {
+    case 4: LM(4); break;
+    case 8: LM(8); break;
+    case 12: LM(12); break;
+    case 16: LM(16); break;
+    default: LM(24);
+  }
+#undef LM
+  return xh_launch_status();
+}

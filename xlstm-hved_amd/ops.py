@@ -58,6 +58,15 @@ def _arr4(tensors):
     return a
 
 
+_MFMA = [True]
+
+
+def set_mfma(enabled):
+    """A/B switch for the bf16-MFMA conv kernels (default on)."""
+    _MFMA[0] = bool(enabled)
+    L.check(L.load().xh_set_option(0, int(bool(enabled))), "xh_set_option")
+
+
 def new_like(t, shape, dtype=None):
     return torch.empty(shape, dtype=dtype or t.dtype, device=t.device)
 
@@ -125,6 +134,10 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
         ptrs.e_sc, ptrs.e_sh = _p(_f32(e[2], "e_sc")), _p(_f32(e[3], "e_sh"))
     if red is not None:
         ptrs.red = _p(red)
+    need = lib.xh_conv3d_workspace_bytes(C.byref(desc)) if _MFMA[0] else 0
+    if need:
+        ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
+        ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
     L.check(lib.xh_conv3d_fwd(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_fwd")
     return out
 
