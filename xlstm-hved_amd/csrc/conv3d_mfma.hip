@@ -3,21 +3,23 @@
 // GEMM view per output row segment of 16 voxels along W:   D[16 vox][16 cout] += A[16 vox][K] * B[K][16 cout]
 // with K = 9 (kd,kh) row segments x (3 taps x CINP channels), walked in 16-byte chunks of 8 bf16.
 //
-//  * The input halo tile lives in LDS channels-last ([d][h][w][CINP] bf16) so that for a fixed (kd,kh) the
-//    3 taps x CINP channels of output voxel w are ONE contiguous run starting at tile column w: an A fragment is a
-//    single 16-byte LDS read per lane, no im2col buffer.  The producer's normalisation + LeakyReLU is applied while
-//    staging (NCDHW planes -> 4-channel x 8-voxel register transpose -> 8-byte LDS writes), zero padding after it.
-//    All global loads of a tile are issued before the first is consumed.
+//  * Input planes live in LDS channels-last ([h][w][CINP] bf16) so that for a fixed (kd,kh) the 3 taps x CINP
+//    channels of output voxel w are ONE contiguous run starting at tile column w: an A fragment is a single 16-byte LDS
+//    read per lane, no im2col buffer.  The producer's normalisation + LeakyReLU is applied while staging (NCDHW planes
+//    -> 4-channel x 8-voxel register transpose -> 8-byte LDS writes), zero padding after it.
+//  * Sliding window along D: a persistent workgroup owns an 8 x 32 (H x W) column and a run of SD output planes and keeps
+//    a ring of 4 input planes in LDS.  Per output plane exactly ONE new input plane is fetched; its global loads are
+//    issued before the MFMA phase of the current plane and land in registers while the matrix cores work (one barrier
+//    per plane).  Depth halo re-reads drop from (TD+2)/TD to (SD+2)/SD.
 //  * mfma_f32_16x16x32_bf16: lane l supplies A[row l&15][k 8*(l>>4)..+7] and B[k 8*(l>>4)..+7][col l&15]; lane group
 //    g = l>>4 therefore owns chunk 4*i+g of the K walk in MFMA i.  Chunks past the end of a row segment read the next
 //    voxel's (finite) data against zero weights.
 //  * Weights are packed ONCE per launch by a small kernel into fragment order (caller workspace) and held in registers
-//    (B operands) by every wave for all tiles it computes; groups are block-diagonal zeros inside a 16-wide tile.
-//  * Workgroups are persistent: a grid of ~2 per CU walks the tile list, so fragment loads, bias/scale loads and the
-//    fused reductions are paid once per workgroup instead of once per 1024 voxels; two resident workgroups per CU
-//    overlap one's staging with the other's MFMA phase.
+//    (B operands) for the workgroup's whole life; groups are block-diagonal zeros inside a 16-wide output tile.
 //  * Epilogue: accumulators are transposed through a wave-private LDS pad so each lane owns 8 consecutive voxels of one
-//    output channel: bias/activation/fused reductions there, then one 16-byte NCDHW store per lane (64 B runs).
+//    output channel: bias/activation/fused reductions there, then one 16-byte NCDHW store per lane (64 B runs).  The
+//    fused reductions (output moments for the next InstanceNorm, or the leaky'-masked gradient sums of the norm
+//    backward) are accumulated in registers over the whole run and reduced once.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
@@ -28,7 +30,8 @@ struct ConvMK {
   xh_conv_desc d;
   xh_conv_ptrs p;
   int Cin_g, Cout_g;
-  int tilesW, tilesH, tilesD;
+  int tilesW, tilesH;
+  int sd, dsegs;    // output planes per worker, number of depth segments
   int cin_blk;      // input channels staged per block (<= CINP)
   int ntile;        // 16-wide output tiles per set
   int cout_set;     // output channels per set
@@ -51,44 +54,52 @@ __device__ __forceinline__ float mk_weight(const ConvMK& a, int co, int ci, int 
 
 // ws[y][i][lane][8] = B fragment (k = 8*(lane>>4)..+7, col lane&15) of MFMA i for channel tile y = set*ntile + nt
 __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
-  const int y = blockIdx.x;
+  const int y = blockIdx.y;
   const int set = y / a.ntile, nt = y % a.ntile;
   const int cin0 = set * a.cin_blk;
   const int co_base = set * a.cout_set + nt * 16;
   const int co_lim = min(16, a.cout_set - nt * 16);
   unsigned short* wf = (unsigned short*)a.p.ws + (long long)y * a.nm * 512;
-  for (int idx = threadIdx.x; idx < a.nm * 512; idx += 256) {
-    const int e = idx & 7, l = (idx >> 3) & 63, i = idx >> 9;
-    const int c = 4 * i + (l >> 4);
-    float v = 0.f;
-    if (c < a.nch && (l & 15) < co_lim) {
-      const int r9 = c / a.cpr, j = c % a.cpr;
-      const int flat = j * 8 + e;                     // position inside the row segment: kw*CINP + ci
-      const int kw = flat / a.cinp, ci = flat % a.cinp;
-      if (kw < 3 && ci < a.cin_blk) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
-    }
-    wf[idx] = f2bf(v);
+  const int idx = blockIdx.x * 256 + threadIdx.x;     // one fragment element per thread
+  if (idx >= a.nm * 512) return;
+  const int e = idx & 7, l = (idx >> 3) & 63, i = idx >> 9;
+  const int c = 4 * i + (l >> 4);
+  float v = 0.f;
+  if (c < a.nch && (l & 15) < co_lim) {
+    const int r9 = c / a.cpr, j = c % a.cpr;
+    const int flat = j * 8 + e;                       // position inside the row segment: kw*CINP + ci
+    const int kw = flat / a.cinp, ci = flat % a.cinp;
+    if (kw < 3 && ci < a.cin_blk) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
   }
+  wf[idx] = f2bf(v);
 }
 
-template <int CINP>
-__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const ConvMK a) {
-  constexpr int TW = 32, TH = 8, TD = 4;
-  constexpr int IH = TH + 2, ID = TD + 2;
+// LDS swizzle: XOR the 16-byte chunk index (bits 4..6) with the 256-byte block index (bits 8..10).  Both the 8-voxel
+// group stride (8*VB) and the row stride are multiples of 128 B for the common layouts, which would make the staging
+// writes (lanes differ in group / row) many-way bank conflicted; the XOR spreads them over all banks.  It is a
+// bijection inside each 128-byte block, so fragment reads apply the same function.
+__device__ __forceinline__ int swz(int off) { return off ^ (((off >> 8) & 7) << 4); }
+
+template <int CINP, int NT>
+__global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
+  constexpr int NWV = NT / 64;
+  constexpr int TW = 32, TH = 8;
+  constexpr int IH = TH + 2;
   constexpr int IWP = TW + 4;                         // halo (2) + 2 spare columns for the over-reading tail chunk
   constexpr int VB = CINP * 2;                        // bytes per voxel in LDS
+  constexpr int PLANE = IH * IWP * VB;                // bytes per ring slot
   constexpr int CPR = (3 * CINP + 7) / 8;             // 16-byte chunks per (kd,kh) row segment
   constexpr int NCH = 9 * CPR;
   constexpr int NM = (NCH + 3) / 4;                   // MFMAs per 16-voxel segment
   constexpr bool A16 = (CINP % 8) == 0;               // 16-byte aligned fragments
   constexpr int NQ = CINP / 4, NG = 6;                // channel quads; aligned 8-voxel groups covering [ow0-8, ow0+40)
-  constexpr int NITEM = ID * IH * NG * NQ;
-  constexpr int NIT = (NITEM + 255) / 256;
+  constexpr int NITEM = IH * NG * NQ;                 // staging items per plane
+  constexpr int NIT = (NITEM + NT - 1) / NT;
   constexpr int EPS = 36;                             // epilogue pad row stride (floats)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* s_in = smem;                                                     // ID*IH*IWP*VB
-  float* s_ep = reinterpret_cast<float*>(smem + ID * IH * IWP * VB);              // [4 waves][16][EPS]
-  float* s_red = s_ep;                                                            // reused after the tile loop
+  unsigned char* s_in = smem;                                                     // 4 * PLANE
+  float* s_ep = reinterpret_cast<float*>(smem + 4 * PLANE);                       // [NWV waves][16][EPS]
+  float* s_red = s_ep;                                                            // reused after the plane loop
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g4 = lane >> 4, nn = lane & 15;
@@ -99,13 +110,20 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const ConvMK a) {
   const int co_base = set * a.cout_set + nt * 16;
   const int co_lim = min(16, a.cout_set - nt * 16);
   const int D = a.d.D, H = a.d.H, W = a.d.W;
-  const long long dhw = (long long)D * H * W;
+  const long long hw = (long long)H * W;
+  const long long dhw = (long long)D * hw;
   const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
   const long long odhw = (long long)Do * Ho * Wo;
+  int wk = blockIdx.x;
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH;
+  const int ds = wk / a.tilesH;
+  const int oh0 = th * TH, ow0 = tw * TW;
+  const int d_begin = ds * a.sd, d_end = min(Do, d_begin + a.sd);
 
   // ---- B fragments (registers, whole kernel) and A offsets ----
   bf16x8 bfrag[NM];
-  int aoff[NM];
+  int aoff[NM], akd[NM];
   {
     const bf16x8* wpk = reinterpret_cast<const bf16x8*>(a.p.ws) + (long long)y * NM * 64;
 #pragma unroll
@@ -114,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const ConvMK a) {
       const int c = 4 * i + g4;
       const int cc = c < NCH ? c : 0;                 // dummy chunk: any valid address, its weights are zero
       const int r9 = cc / CPR, j = cc % CPR;
-      aoff[i] = (((r9 / 3) * IH + (r9 % 3)) * IWP + nn) * VB + j * 16;
+      akd[i] = r9 / 3;
+      aoff[i] = ((r9 % 3) * IWP + nn) * VB + j * 16;
     }
   }
   // ---- epilogue lane role: output channel lane>>2, voxels (lane&3)*8 .. +7 of a 32-voxel row ----
@@ -137,108 +156,120 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const ConvMK a) {
   bf16_t* yplane = (bf16_t*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
   float* ep = s_ep + wv * 16 * EPS;
   float s0 = 0.f, s1 = 0.f;
-  const bf16_t* xa = (const bf16_t*)a.p.xa;
-  const bf16_t* xb = (const bf16_t*)a.p.xb;
 
-  const int ntiles = a.tilesW * a.tilesH * a.tilesD;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int t = tile;
-    const int tw = t % a.tilesW; t /= a.tilesW;
-    const int th = t % a.tilesH;
-    const int td = t / a.tilesH;
-    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
-    __syncthreads();                                  // everyone is done reading the previous tile
-    // ---- stage: issue every load of this tile first, then transform + transpose into LDS ----
-    if (!(a.abl & 2)) {
-      uint4 raw[NIT][4];
+  // ---- per-thread staging plan (identical for every plane) ----
+  const bf16_t* sp_src[NIT][4];     // channel plane base + in-plane offset, or nullptr
+  float sp_sc[NIT][4], sp_sh[NIT][4];
+  int sp_lds[NIT], sp_gq[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int item = tid + it * 256;
-        const int q = item % NQ;
-        int r = item / NQ;
-        const int gq = r % NG - 1; r /= NG;
-        const int hy = r % IH, dz = r / IH;
-        const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 + gq * 8;
-        const bool inb = item < NITEM && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + it * NT;
+    const int gi = item % NG;                         // group fastest: 6 x 16 B = one contiguous 96-byte run per row
+    int r = item / NG;
+    const int q = r % NQ;
+    const int hy = r / NQ;
+    const int gq = gi - 1;
+    const int gh = oh0 - 1 + hy, gw = ow0 + gq * 8;
+    const bool inb = item < NITEM && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+    sp_gq[it] = item < NITEM ? gq : 100;              // 100: no LDS column is ever valid
+    sp_lds[it] = (hy * IWP) * VB + q * 8;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int cl = q * 4 + cc;
-          const int c = cin0 + cl;
-          raw[it][cc] = make_uint4(0, 0, 0, 0);
-          if (inb && cl < a.cin_blk) {
-            const bf16_t* src = (c < a.d.Ca ? xa + n * a.d.xa_bs + (long long)c * dhw
-                                            : xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
-                                ((long long)gd * H + gh) * W + gw;
-            raw[it][cc] = *reinterpret_cast<const uint4*>(src);
+    for (int cc = 0; cc < 4; ++cc) {
+      const int cl = q * 4 + cc;
+      const int c = cin0 + cl;
+      sp_src[it][cc] = nullptr;
+      sp_sc[it][cc] = 1.f; sp_sh[it][cc] = 0.f;
+      if (inb && cl < a.cin_blk) {
+        sp_src[it][cc] = (c < a.d.Ca ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
+                                     : (const bf16_t*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
+                         (long long)gh * W + gw;
+        if (a.d.pre) { sp_sc[it][cc] = a.p.pre_sc[n * a.d.Cin + c]; sp_sh[it][cc] = a.p.pre_sh[n * a.d.Cin + c]; }
+      }
+    }
+  }
+  uint4 raw[NIT][4];
+  auto load_plane = [&](int gd) {
+    const bool dok = (unsigned)gd < (unsigned)D && !(a.abl & 2);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        raw[it][cc] = make_uint4(0, 0, 0, 0);
+        if (dok && sp_src[it][cc]) raw[it][cc] = *reinterpret_cast<const uint4*>(sp_src[it][cc] + (long long)gd * hw);
+      }
+  };
+  auto store_plane = [&](int gd) {
+    if (a.abl & 16) return;
+    const int slot = ((gd + 4) & 3) * PLANE;
+    const bool dok = (unsigned)gd < (unsigned)D;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      float v[4][8];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const bool live = dok && sp_src[it][cc] != nullptr;
+        const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+          if (a.d.pre) {
+            lo = leaky(lo * sp_sc[it][cc] + sp_sh[it][cc], a.d.pre_slope);
+            hi = leaky(hi * sp_sc[it][cc] + sp_sh[it][cc], a.d.pre_slope);
           }
+          v[cc][2 * k] = live ? lo : 0.f;
+          v[cc][2 * k + 1] = live ? hi : 0.f;
         }
       }
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int item = tid + it * 256;
-        if (item < NITEM) {
-          const int q = item % NQ;
-          int r = item / NQ;
-          const int gq = r % NG - 1; r /= NG;
-          const int hy = r % IH, dz = r / IH;
-          const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 + gq * 8;
-          const bool inb = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
-          float v[4][8];
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int cl = q * 4 + cc;
-            const int c = cin0 + cl;
-            const bool live = inb && cl < a.cin_blk;
-            float sc = 1.f, sh = 0.f;
-            if (live && a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
-            const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
-              if (live && a.d.pre) { lo = leaky(lo * sc + sh, a.d.pre_slope); hi = leaky(hi * sc + sh, a.d.pre_slope); }
-              v[cc][2 * k] = live ? lo : 0.f;
-              v[cc][2 * k + 1] = live ? hi : 0.f;
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int wx = gq * 8 + k + 1;            // tile column of voxel gw+k (column 0 = ow0-1)
-            if (wx >= 0 && wx < IWP) {
-              uint2 pk;
-              pk.x = (unsigned)f2bf(v[0][k]) | ((unsigned)f2bf(v[1][k]) << 16);
-              pk.y = (unsigned)f2bf(v[2][k]) | ((unsigned)f2bf(v[3][k]) << 16);
-              *reinterpret_cast<uint2*>(s_in + (((dz * IH + hy) * IWP + wx) * VB + q * 8)) = pk;
-            }
-          }
+      for (int k = 0; k < 8; ++k) {
+        const int wx = sp_gq[it] * 8 + k + 1;         // tile column of voxel gw+k (column 0 = ow0-1)
+        if (wx >= 0 && wx < IWP) {
+          uint2 pk;
+          pk.x = (unsigned)f2bf(v[0][k]) | ((unsigned)f2bf(v[1][k]) << 16);
+          pk.y = (unsigned)f2bf(v[2][k]) | ((unsigned)f2bf(v[3][k]) << 16);
+          *reinterpret_cast<uint2*>(s_in + swz(slot + sp_lds[it] + wx * VB)) = pk;
         }
       }
     }
-    __syncthreads();
+  };
 
-    for (int rr = wv; rr < TD * TH; rr += 4) {
-      const int tz = rr / TH, ty = rr % TH;
-      const int od = od0 + tz, oh = oh0 + ty;
-      if (od >= Do || oh >= Ho) continue;             // wave-uniform
+  // ---- prologue: planes d_begin-1 and d_begin into the ring, d_begin+1 in flight ----
+  load_plane(d_begin - 1);
+  store_plane(d_begin - 1);
+  load_plane(d_begin);
+  store_plane(d_begin);
+  load_plane(d_begin + 1);
+
+  for (int d = d_begin; d < d_end; ++d) {
+    store_plane(d + 1);
+    __syncthreads();                                  // plane d+1 visible; everyone finished computing plane d-1
+    if (d + 1 < d_end) load_plane(d + 2);             // lands while the matrix cores work on plane d
+    const int sbase = d + 3;                          // slot of input plane d-1+kd = (sbase + kd) & 3
+    for (int rr = wv; rr < TH; rr += NWV) {
+      const int oh = oh0 + rr;
+      if (oh >= Ho) continue;                         // wave-uniform
       f32x4 acc[2];
 #pragma unroll
       for (int wt = 0; wt < 2; ++wt) {
-        const unsigned char* base = s_in + ((tz * IH + ty) * IWP + wt * 16) * VB;
+        const int rowoff = (rr * IWP + wt * 16) * VB;
         acc[wt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(a.abl & 4))
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
+          const int ao = ((sbase + akd[i]) & 3) * PLANE + rowoff + aoff[i];
           bf16x8 av;
           if (A16) {
-            av = *reinterpret_cast<const bf16x8*>(base + aoff[i]);
+            av = *reinterpret_cast<const bf16x8*>(s_in + swz(ao));
           } else {
-            const uint2 lo = *reinterpret_cast<const uint2*>(base + aoff[i]);
-            const uint2 hi = *reinterpret_cast<const uint2*>(base + aoff[i] + 8);
+            const uint2 lo = *reinterpret_cast<const uint2*>(s_in + swz(ao));
+            const uint2 hi = *reinterpret_cast<const uint2*>(s_in + swz(ao + 8));
             const uint4 q4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
             av = __builtin_bit_cast(bf16x8, q4);
           }
           acc[wt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bfrag[i], acc[wt], 0, 0, 0);
         }
       }
+      if (a.abl & 32) continue;
       // ---- transpose through the wave-private pad: [cout nn][voxel wt*16 + 4*g4 + r] ----
 #pragma unroll
       for (int wt = 0; wt < 2; ++wt)
@@ -255,11 +286,11 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const ConvMK a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       if (co_ok && !(a.abl & 8)) {
-        const long long sp = ((long long)od * Ho + oh) * Wo + ow0 + ech * 8;
+        const long long sp = ((long long)d * Ho + oh) * Wo + ow0 + ech * 8;
         float ev[8];
         if (a.d.epi == 1) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(eplane + sp);
-          const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+          const uint4 er = *reinterpret_cast<const uint4*>(eplane + sp);
+          const unsigned u[4] = {er.x, er.y, er.z, er.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) { ev[2 * k] = __uint_as_float(u[k] << 16); ev[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
         }
@@ -296,7 +327,9 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const ConvMK a) {
     if ((lane & 3) == 0) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
     __syncthreads();
     if (tid < 32) {
-      const float tot = s_red[tid] + s_red[32 + tid] + s_red[64 + tid] + s_red[96 + tid];
+      float tot = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NWV; ++w8) tot += s_red[w8 * 32 + tid];
       const int c = tid >> 1;
       if (c < co_lim) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co_base + c) * 2 + (tid & 1)], (double)tot);
     }
@@ -318,18 +351,25 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if (d->N > 65535) return 1;
   a->d = *d;
   a->Cin_g = cin_g; a->Cout_g = cout_g;
-  a->tilesW = d->W / 32; a->tilesH = cdiv(d->Ho, 8); a->tilesD = cdiv(d->Do, 4);
+  a->tilesW = d->W / 32; a->tilesH = cdiv(d->Ho, 8);
   a->cin_blk = cin_blk;
   a->cout_set = gs * cout_g;
   a->ntile = cdiv(a->cout_set, 16);
   a->cinp = cin_blk <= 4 ? 4 : cin_blk <= 8 ? 8 : cin_blk <= 12 ? 12 : cin_blk <= 16 ? 16 : 24;
-  if (a->cinp == 12 || a->cinp == 24) return 1;      // measured slower than the vector kernel with this staging
   a->cpr = (3 * a->cinp + 7) / 8;
   a->nch = 9 * a->cpr;
   a->nm = (a->nch + 3) / 4;
   a->abl = g_mfma_abl;
   const int ny = (d->groups / gs) * a->ntile;
   if (ny > 65535) return 1;
+  // depth segments: enough workers for ~2 resident workgroups per CU, but runs of at least 4 planes
+  const int cols = a->tilesW * a->tilesH;
+  int dsegs = cdiv(512, cols * ny * d->N);
+  const int max_segs = d->Do >= 4 ? d->Do / 4 : 1;
+  if (dsegs > max_segs) dsegs = max_segs;
+  if (dsegs < 1) dsegs = 1;
+  a->sd = cdiv(d->Do, dsegs);
+  a->dsegs = cdiv(d->Do, a->sd);
   return 0;
 }
 
@@ -351,22 +391,21 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const int gs = a.cin_blk / a.Cin_g;
   const int ny = (d->groups / gs) * a.ntile;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3_pack_kernel, dim3(ny), dim3(256), 0, st, a);
-  const int ntiles = a.tilesW * a.tilesH * a.tilesD;
-  // persistent workers: ~2 resident workgroups per CU over all (channel tile, sample) pairs
-  int workers = cdiv(512, ny * d->N);
-  if (workers < 1) workers = 1;
-  if (workers > ntiles) workers = ntiles;
-  dim3 grid(workers, ny, d->N);
-  const size_t shm = (size_t)6 * 10 * 36 * a.cinp * 2 + (size_t)4 * 16 * 36 * sizeof(float);
+  hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
+  dim3 grid(a.tilesW * a.tilesH * a.dsegs, ny, d->N);
+  const size_t shm = (size_t)4 * 10 * 36 * a.cinp * 2 + (size_t)8 * 16 * 36 * sizeof(float);
+  // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
+  const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
 #define LM(C)                                                                                                   \
   do {                                                                                                          \
     static bool attr_done = false;                                                                              \
     if (!attr_done) {                                                                                           \
-      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
       attr_done = true;                                                                                         \
     }                                                                                                           \
-    hipLaunchKernelGGL((conv3_mfma_kernel<C>), grid, dim3(256), shm, st, a);                                    \
+    if (big) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256>), grid, dim3(256), shm, st, a);                      \
+    else hipLaunchKernelGGL((conv3_mfma_kernel<C, 512>), grid, dim3(512), shm, st, a);                          \
   } while (0)
   switch (a.cinp) {
     case 4: LM(4); break;
