@@ -49,3 +49,19 @@ if __name__ == "__main__":
             ops.set_mfma(True)
             print(f"{cin}->{cout} g{g} @{S}^3: vector {res[False]:.1f} us, mfma {res[True]:.1f} us "
                   f"({nbytes / res[True] / 1e3:.0f} GB/s algorithmic, {flops / res[True] / 1e6:.1f} TFLOP/s useful)")
+
+if "--wgrad" in sys.argv:
+    for (cin, cout, g, S) in [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (16, 32, 4, 64), (24, 8, 1, 64), (8, 8, 1, 64)]:
+        x = torch.randn(1, cin, S, S, S, device="cuda").bfloat16()
+        dy = torch.randn(1, cout, S, S, S, device="cuda").bfloat16()
+        sc = torch.rand(1, cin, device="cuda") + 0.5; sh = torch.randn(1, cin, device="cuda")
+        dws = [torch.zeros(cout // g, cin // g, 3, 3, 3, device="cuda") for _ in range(g)]
+        dbs = [torch.zeros(cout // g, device="cuda") for _ in range(g)]
+        call = lambda: ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=(sc, sh, 0.01))
+        res = {}
+        for mfma in (False, True):
+            ops.set_mfma(mfma)
+            res[mfma] = bench(call)
+        ops.set_mfma(True)
+        flops = 2 * cout * S ** 3 * 27 * cin / g
+        print(f"wgrad {cin}->{cout} g{g} @{S}^3: vector {res[False]:.1f} us, mfma {res[True]:.1f} us ({flops / res[True] / 1e6:.1f} TFLOP/s useful)")

@@ -707,6 +707,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
 }
 
 int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv3d_mfma.hip
+int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
 static int g_use_mfma = 1;
 extern int g_mfma_abl;
 extern "C" int xh_set_option(int key, int value) {
@@ -817,6 +818,10 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
   if (!p->ea || !dw || d->transposed) return XH_ERR_ARG;
   for (int i = 0; i < d->n_wptr; ++i)
     if (!dw[i]) return XH_ERR_ARG;
+  if (g_use_mfma) {
+    const int r = xh_conv3_wgrad_mfma_try(stream, d, p, dw, db);
+    if (r != 1) return r;
+  }
   return d->dtype == XH_F32 ? wgrad_dispatch<float>(stream, d, p, dw, db) : wgrad_dispatch<bf16_t>(stream, d, p, dw, db);
 }
 

@@ -1,0 +1,284 @@
+// bf16-MFMA weight gradient of the 3x3x3 stride-1 convolution (bf16 storage) for gfx950.
+//
+//   dW[co][ci][kd,kh,kw] = sum over voxels p of dY[co][p] * xa[ci][p + (kd,kh,kw) - 1],   xa = leaky(x*sc+sh)
+//
+// GEMM view: D[16 co][16 columns] += A[16 co][32 voxels] * B[32 voxels][16 columns], K = voxels.
+//  * A (dY): lane (g = l>>4, m = l&15) supplies 8 consecutive voxels along W of output channel m: one 16-byte global
+//    load, reused by every MFMA of the K-step.
+//  * B (xa): column n = (input channel n % CP, row selector n / CP); an MFMA "tile" t fixes kw and assigns the
+//    16/CP row selectors to consecutive (kd,kh) rows, so all lanes of an MFMA share the W shift kw-1.  The input is
+//    kept channel-planar in LDS ([ci][h][48 voxels] bf16, sliding 4-plane ring along D like the forward kernel); for a
+//    (kd,kh) row a lane reads ONE aligned 16-byte chunk plus the dword on either side and builds the three kw-shifted
+//    fragments with v_alignbyte: 3 LDS reads + 8 VALU per 3 MFMAs.
+//  * Each wave keeps all 3*ceil(9/(16/CP)) accumulator tiles in registers for the whole run of planes; one LDS
+//    reduction across waves and one pass of contiguous fp32 atomics per workgroup at the end.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgMK {
+  xh_conv_desc d;
+  xh_conv_ptrs p;
+  float* dw[4];
+  float* db[4];
+  int Cin_g, Cout_g;
+  int tilesW, tilesH, sd, dsegs;
+  int gs;           // groups per set
+  int cin_set;      // input channels of a set (gs * Cin_g)
+  int cout_set;     // output channels of a set
+  int ntile;        // 16-wide output-channel tiles per set
+  int nctile;       // CP-wide input-channel tiles per set
+};
+
+template <int CP, int NT>
+__global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
+  constexpr int NWV = NT / 64;
+  constexpr int TH = 8, IH = TH + 2;
+  constexpr int ROWB = 96;                            // 48 voxels: [ow0-8, ow0+40)
+  constexpr int CHS = IH * ROWB + 16;                 // channel stride, padded so 16 channels hit 16 distinct bank groups
+  constexpr int PLANE = CP * CHS;
+  constexpr int R = 16 / CP;                          // (kd,kh) rows per MFMA tile
+  constexpr int TPK = (9 + R - 1) / R;                // tiles per kw
+  constexpr int NITEM = CP * IH * 6;                  // staging items per plane (one 16-byte chunk each)
+  constexpr int NIT = (NITEM + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_in = smem;                         // 4 * PLANE
+  float* s_dw = reinterpret_cast<float*>(smem);       // reused after the plane loop: [16 co][CP ci][27] + [16] bias sums
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g4 = lane >> 4, nn = lane & 15;
+  int y = blockIdx.y;
+  const int ct = y % a.nctile; y /= a.nctile;
+  const int nt = y % a.ntile;
+  const int set = y / a.ntile;
+  const int n_first = 0;
+  (void)n_first;
+  const int ci0 = set * a.cin_set + ct * CP;          // first input channel of this tile
+  const int ci_lim = min(CP, a.cin_set - ct * CP);
+  const int co_base = set * a.cout_set + nt * 16;
+  const int co_lim = min(16, a.cout_set - nt * 16);
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long odhw = (long long)Do * Ho * Wo;
+  int wk = blockIdx.x;
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH; wk /= a.tilesH;
+  const int ds = wk % a.dsegs;
+  const int n = wk / a.dsegs;
+  const int oh0 = th * TH, ow0 = tw * 32;
+  const int d_begin = ds * a.sd, d_end = min(Do, d_begin + a.sd);
+
+  // ---- column role of this lane ----
+  const int cil = nn % CP, rsel = nn / CP;
+  int boff[TPK], bkd[TPK];                            // in-plane byte offset (row kh, channel, chunk g4+1) and kd per tile
+#pragma unroll
+  for (int t = 0; t < TPK; ++t) {
+    int r9 = t * R + rsel;
+    if (r9 > 8) r9 = 8;                               // column unused: any valid address
+    bkd[t] = r9 / 3;
+    boff[t] = cil * CHS + (r9 % 3) * ROWB + (g4 + 1) * 16;
+  }
+  // ---- A operand source: dY row of channel co_base + nn ----
+  const bool a_ok = nn < co_lim;
+  const bf16_t* dyp = (const bf16_t*)a.p.ea + n * a.d.ea_bs + (long long)(co_base + (a_ok ? nn : 0)) * odhw + ow0 + g4 * 8;
+
+  // ---- staging plan ----
+  const bf16_t* sp_src[NIT];
+  float sp_sc[NIT], sp_sh[NIT];
+  int sp_lds[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + it * NT;
+    const int gi = item % 6;
+    int r = item / 6;
+    const int hy = r % IH;
+    const int cl = r / IH;
+    const int gh = oh0 - 1 + hy, gw = ow0 + (gi - 1) * 8;
+    const int c = ci0 + cl;
+    sp_src[it] = nullptr;
+    sp_sc[it] = 0.f; sp_sh[it] = 0.f;
+    sp_lds[it] = item < NITEM ? cl * CHS + hy * ROWB + gi * 16 : -1;
+    if (item < NITEM && cl < ci_lim && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W) {
+      sp_src[it] = (c < a.d.Ca ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
+                               : (const bf16_t*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
+                   (long long)gh * W + gw;
+      sp_sc[it] = 1.f;
+      if (a.d.pre) { sp_sc[it] = a.p.pre_sc[n * a.d.Cin + c]; sp_sh[it] = a.p.pre_sh[n * a.d.Cin + c]; }
+    }
+  }
+  uint4 raw[NIT];
+  auto load_plane = [&](int gd) {
+    const bool dok = (unsigned)gd < (unsigned)D;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      raw[it] = make_uint4(0, 0, 0, 0);
+      if (dok && sp_src[it]) raw[it] = *reinterpret_cast<const uint4*>(sp_src[it] + (long long)gd * hw);
+    }
+  };
+  auto store_plane = [&](int gd) {
+    const int slot = ((gd + 4) & 3) * PLANE;
+    const bool dok = (unsigned)gd < (unsigned)D;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (sp_lds[it] < 0) continue;
+      const float sc = sp_sc[it], sh = (dok && sp_src[it]) ? sp_sh[it] : 0.f;
+      const unsigned u[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
+      unsigned o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float lo = __uint_as_float(u[k] << 16) * sc + sh, hi = __uint_as_float(u[k] & 0xffff0000u) * sc + sh;
+        lo = fmaxf(lo, lo * a.d.pre_slope);           // leaky for 0 <= slope <= 1
+        hi = fmaxf(hi, hi * a.d.pre_slope);
+        o[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+      }
+      *reinterpret_cast<uint4*>(s_in + slot + sp_lds[it]) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  };
+
+  f32x4 acc[3][TPK];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int t = 0; t < TPK; ++t) acc[kw][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbsum = 0.f;
+
+  load_plane(d_begin - 1);
+  store_plane(d_begin - 1);
+  load_plane(d_begin);
+  store_plane(d_begin);
+  load_plane(d_begin + 1);
+  for (int d = d_begin; d < d_end; ++d) {
+    store_plane(d + 1);
+    __syncthreads();
+    if (d + 1 < d_end) load_plane(d + 2);
+    const int sbase = d + 3;
+    for (int rr = wv; rr < TH; rr += NWV) {
+      const int oh = oh0 + rr;
+      if (oh >= Ho) continue;
+      // A fragment: 8 voxels of dY
+      uint4 araw = make_uint4(0, 0, 0, 0);
+      if (a_ok) araw = *reinterpret_cast<const uint4*>(dyp + ((long long)d * Ho + oh) * Wo);
+      const bf16x8 av = __builtin_bit_cast(bf16x8, araw);
+      {
+        const unsigned u[4] = {araw.x, araw.y, araw.z, araw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dbsum += __uint_as_float(u[k] << 16) + __uint_as_float(u[k] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int t = 0; t < TPK; ++t) {
+        const unsigned char* bp = s_in + ((sbase + bkd[t]) & 3) * PLANE + rr * ROWB + boff[t];
+        const uint4 cur = *reinterpret_cast<const uint4*>(bp);
+        const unsigned prv = *reinterpret_cast<const unsigned*>(bp - 4);
+        const unsigned nxt = *reinterpret_cast<const unsigned*>(bp + 16);
+        // kw = 0: window starts one voxel (2 bytes) earlier; kw = 2: one voxel later
+        uint4 b0, b2;
+        b0.x = __builtin_amdgcn_alignbyte(cur.x, prv, 2);
+        b0.y = __builtin_amdgcn_alignbyte(cur.y, cur.x, 2);
+        b0.z = __builtin_amdgcn_alignbyte(cur.z, cur.y, 2);
+        b0.w = __builtin_amdgcn_alignbyte(cur.w, cur.z, 2);
+        b2.x = __builtin_amdgcn_alignbyte(cur.y, cur.x, 2);
+        b2.y = __builtin_amdgcn_alignbyte(cur.z, cur.y, 2);
+        b2.z = __builtin_amdgcn_alignbyte(cur.w, cur.z, 2);
+        b2.w = __builtin_amdgcn_alignbyte(nxt, cur.w, 2);
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, b0), acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, cur), acc[1][t], 0, 0, 0);
+        acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, b2), acc[2][t], 0, 0, 0);
+      }
+    }
+  }
+  // ---- reduce across waves in LDS (layout of the weight tensor slice [16 co][CP ci][27]) ----
+  __syncthreads();
+  for (int i = tid; i < 16 * CP * 27 + 16; i += NT) s_dw[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int t = 0; t < TPK; ++t) {
+      const int r9 = t * R + rsel;
+      if (r9 < 9) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co_l = g4 * 4 + r;                // D row
+          atomicAdd(&s_dw[(co_l * CP + cil) * 27 + r9 * 3 + kw], acc[kw][t][r]);
+        }
+      }
+    }
+  dbsum += __shfl_xor(dbsum, 16, 64);
+  dbsum += __shfl_xor(dbsum, 32, 64);
+  if (lane < 16) atomicAdd(&s_dw[16 * CP * 27 + lane], dbsum);
+  __syncthreads();
+  const int gpp = a.d.groups / a.d.n_wptr;
+  for (int i = tid; i < 16 * CP * 27; i += NT) {
+    const int tap = i % 27;
+    const int r = i / 27;
+    const int cl = r % CP, co_l = r / CP;
+    if (co_l >= co_lim || cl >= ci_lim) continue;
+    const int co = co_base + co_l, ci = ci0 + cl;
+    const int g = co / a.Cout_g;
+    if (ci / a.Cin_g != g) continue;                  // off the block diagonal
+    float* dst = a.dw[g / gpp] + ((long long)((g % gpp) * a.Cout_g + co % a.Cout_g) * a.Cin_g + ci % a.Cin_g) * 27 + tap;
+    atomicAdd(dst, s_dw[i]);
+  }
+  if (ct == 0 && tid < co_lim) {
+    const int co = co_base + tid, g = co / a.Cout_g;
+    float* dbp = a.db[g / gpp];
+    if (dbp) atomicAdd(&dbp[(g % gpp) * a.Cout_g + co % a.Cout_g], s_dw[16 * CP * 27 + tid]);
+  }
+}
+
+// returns XH_OK if launched, 1 if not eligible
+int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
+  if (d->dtype != XH_BF16 || d->k != 3 || d->stride != 1) return 1;
+  if (d->W % 32 != 0 || d->Wo != d->W) return 1;
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  if (cin_g < 4) return 1;
+  if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return 1;
+  if (((long long)d->D * d->H * d->W) % 8) return 1;
+  if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return 1;
+  WgMK a;
+  a.d = *d; a.p = *p;
+  if (!d->pre) a.d.pre_slope = 1.f;
+  for (int i = 0; i < 4; ++i) { a.dw[i] = i < d->n_wptr ? dw[i] : nullptr; a.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  a.Cin_g = cin_g; a.Cout_g = cout_g;
+  int gs = 1;
+  while (gs * 2 <= d->groups && d->groups % (gs * 2) == 0 && gs * 2 * cin_g <= 16 && gs * 2 * cout_g <= 16) gs *= 2;
+  a.gs = gs;
+  a.cin_set = gs * cin_g;
+  a.cout_set = gs * cout_g;
+  const int cp = a.cin_set <= 4 ? 4 : a.cin_set <= 8 ? 8 : 16;
+  a.ntile = cdiv(a.cout_set, 16);
+  a.nctile = cdiv(a.cin_set, cp);
+  const int ny = (d->groups / gs) * a.ntile * a.nctile;
+  if (ny > 65535) return 1;
+  a.tilesW = d->W / 32; a.tilesH = cdiv(d->Ho, 8);
+  const int cols = a.tilesW * a.tilesH;
+  int dsegs = cdiv(512, cols * ny * d->N);
+  const int max_segs = d->Do >= 4 ? d->Do / 4 : 1;
+  if (dsegs > max_segs) dsegs = max_segs;
+  if (dsegs < 1) dsegs = 1;
+  a.sd = cdiv(d->Do, dsegs);
+  a.dsegs = cdiv(d->Do, a.sd);
+  const long long gx = (long long)cols * a.dsegs * d->N;
+  if (gx > 2147483647LL) return 1;
+  dim3 grid((unsigned)gx, ny, 1);
+  const size_t ring = (size_t)4 * cp * (10 * 96 + 16);
+  const size_t red = (size_t)(16 * cp * 27 + 16) * sizeof(float);
+  const size_t shm = ring > red ? ring : red;
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
+#define LW(C)                                                                                     \
+  do {                                                                                            \
+    if (big) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<C, 256>), grid, dim3(256), shm, st, a);  \
+    else hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<C, 512>), grid, dim3(512), shm, st, a);      \
+  } while (0)
+  switch (cp) {
+    case 4: LW(4); break;
+    case 8: LW(8); break;
+    default: LW(16);
+  }
+#undef LW
+  return xh_launch_status();
+}
