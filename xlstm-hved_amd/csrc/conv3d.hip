@@ -142,9 +142,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
     for (int v = 0; v < VW; ++v) acc[i][v] = 0.f;
 
   for (int c0 = 0; c0 < a.Cin_g; c0 += CIC) {
+    const int ncc = min(CIC, a.Cin_g - c0);           // live input channels of this chunk (1 for depthwise convs)
     __syncthreads();
     // ---- stage inputs (transform applied before zero padding) ----
-    for (int cc = 0; cc < CIC; ++cc) {
+    for (int cc = 0; cc < ncc; ++cc) {
       const int ci_g = c0 + cc;
       float* dst = s_in + cc * (ID * IH * IWP);
       if (ci_g < a.Cin_g) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
       }
     }
     // ---- stage weights [cc][tap][co] ----
-    for (int idx = tid; idx < CIC * K3 * COB; idx += 256) {
+    for (int idx = tid; idx < ncc * K3 * COB; idx += 256) {
       const int co = idx % COB;
       const int r = idx / COB;
       const int tap = r % K3, cc = r / K3;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
     // ---- compute ----
     const float* base = s_in + ((tz * S) * IH + ty * S) * IWP + tx * VW * S;
 #pragma unroll 1
-    for (int cc = 0; cc < CIC; ++cc) {
+    for (int cc = 0; cc < ncc; ++cc) {
 #pragma unroll UNR
       for (int kd = 0; kd < K; ++kd) {
 #pragma unroll UNR
@@ -286,6 +287,76 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
     if (co_g < a.Cout_g && valid > 0) {
       const int c = g * a.Cout_g + co_g;
       conv_epilogue<T, VW>(a, n, c, dhw, q0, valid, conv_bias(a, g, co_g), acc[co], s0[co], s1[co]);
+    }
+  }
+  if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k = 3, stride = 2 forward (the DRB convs, RA_HVED.py:396-397): outputs are 1/8 of the inputs and the tensors are
+// small, so a direct gather (one lane per output voxel, COB output channels, weights in LDS) beats tiling: no
+// per-chunk barriers, full-chip parallelism even for 8^3 outputs.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int COB>
+__global__ __launch_bounds__(256) void conv3_s2_gather_kernel(const ConvK a) {
+  extern __shared__ float s_dyn[];                    // [Cin_g][27][COB] weights, then reduction scratch
+  float* s_w = s_dyn;
+  float* s_red = s_dyn + a.Cin_g * 27 * COB;
+  const int tid = threadIdx.x;
+  const int cob = blockIdx.y;
+  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  for (int idx = tid; idx < a.Cin_g * 27 * COB; idx += 256) {
+    const int co = idx % COB;
+    const int r = idx / COB;
+    const int tap = r % 27, ci_g = r / 27;
+    const int co_g = cob * COB + co;
+    s_w[idx] = co_g < a.Cout_g ? conv_weight(a, g, co_g, ci_g, tap, 27) : 0.f;
+  }
+  __syncthreads();
+  const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  const long long q = (long long)blockIdx.x * 256 + tid;
+  const bool ok = q < odhw;
+  float acc[COB];
+#pragma unroll
+  for (int i = 0; i < COB; ++i) acc[i] = 0.f;
+  if (ok) {
+    const int ow = (int)(q % Wo), oh = (int)((q / Wo) % Ho), od = (int)(q / ((long long)Wo * Ho));
+    for (int ci_g = 0; ci_g < a.Cin_g; ++ci_g) {
+      const int c = g * a.Cin_g + ci_g;
+      const T* src = in_plane<T>(a, n, c, dhw);
+      float sc = 1.f, sh = 0.f;
+      if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int gd = 2 * od - 1 + kd;
+        if ((unsigned)gd >= (unsigned)D) continue;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int gh = 2 * oh - 1 + kh;
+          if ((unsigned)gh >= (unsigned)H) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int gw = 2 * ow - 1 + kw;
+            if ((unsigned)gw >= (unsigned)W) continue;
+            float v = ldf(src, ((long long)gd * H + gh) * W + gw);
+            if (a.d.pre) v = leaky(v * sc + sh, a.d.pre_slope);
+            const float* wr = s_w + (ci_g * 27 + (kd * 3 + kh) * 3 + kw) * COB;
+#pragma unroll
+            for (int co = 0; co < COB; ++co) acc[co] = fmaf(wr[co], v, acc[co]);
+          }
+        }
+      }
+    }
+  }
+  float s0[COB], s1[COB];
+#pragma unroll
+  for (int co = 0; co < COB; ++co) {
+    s0[co] = 0.f; s1[co] = 0.f;
+    const int co_g = cob * COB + co;
+    if (co_g < a.Cout_g && ok) {
+      float v1[1] = {acc[co]};
+      conv_epilogue<T, 1>(a, n, g * a.Cout_g + co_g, odhw, q, 1, conv_bias(a, g, co_g), v1, s0[co], s1[co]);
     }
   }
   if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
@@ -527,11 +598,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK wa) {
   }
 }
 
-// k = 1 weight gradient: CIB x COB partial products per lane over a grid-strided voxel range.
-template <typename T, int CIB, int COB>
+// k = 1 weight gradient: CIB x COB partial products per lane over a grid-strided range of 4-voxel groups
+// (16-byte fp32 / 8-byte bf16 loads when the row length allows it).
+template <typename T, int CIB, int COB, bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
   const ConvK& a = wa.c;
   constexpr int NACC = CIB * COB + COB;
+  constexpr int VW = VEC ? 4 : 1;
   __shared__ float s_red[4 * NACC];
   const int tid = threadIdx.x;
   int yy = blockIdx.y;
@@ -547,32 +620,46 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
     for (int j = 0; j < COB; ++j) acc[i][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < COB; ++j) dbacc[j] = 0.f;
-  const long long total = (long long)a.d.N * dhw;
+  const long long per_n = dhw / VW;
+  const long long total = (long long)a.d.N * per_n;
   for (long long q = (long long)blockIdx.x * 256 + tid; q < total; q += (long long)gridDim.x * 256) {
-    const int n = (int)(q / dhw);
-    const long long sp = q % dhw;
-    float x[CIB], dy[COB];
+    const int n = (int)(q / per_n);
+    const long long sp = (q % per_n) * VW;
+    float x[CIB][4], dy[COB][4];
 #pragma unroll
     for (int i = 0; i < CIB; ++i) {
       const int ci_g = cib * CIB + i;
-      x[i] = 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) x[i][v] = 0.f;
       if (ci_g < a.Cin_g) {
         const int c = g * a.Cin_g + ci_g;
-        float v = ldf(in_plane<T>(a, n, c, dhw), sp);
-        if (a.d.pre) v = leaky(v * a.p.pre_sc[n * a.d.Cin + c] + a.p.pre_sh[n * a.d.Cin + c], a.d.pre_slope);
-        x[i] = v;
+        const T* src = in_plane<T>(a, n, c, dhw);
+        if (VEC) ld4(src, sp, x[i]); else x[i][0] = ldf(src, sp);
+        if (a.d.pre) {
+          const float sc = a.p.pre_sc[n * a.d.Cin + c], sh = a.p.pre_sh[n * a.d.Cin + c];
+#pragma unroll
+          for (int v = 0; v < VW; ++v) x[i][v] = leaky(x[i][v] * sc + sh, a.d.pre_slope);
+        }
       }
     }
 #pragma unroll
     for (int j = 0; j < COB; ++j) {
       const int co_g = cob * COB + j;
-      dy[j] = co_g < a.Cout_g ? ldf((const T*)a.p.ea + n * a.d.ea_bs + (long long)(g * a.Cout_g + co_g) * dhw, sp) : 0.f;
-      dbacc[j] += dy[j];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dy[j][v] = 0.f;
+      if (co_g < a.Cout_g) {
+        const T* dp = (const T*)a.p.ea + n * a.d.ea_bs + (long long)(g * a.Cout_g + co_g) * dhw;
+        if (VEC) ld4(dp, sp, dy[j]); else dy[j][0] = ldf(dp, sp);
+      }
+#pragma unroll
+      for (int v = 0; v < VW; ++v) dbacc[j] += dy[j][v];
     }
 #pragma unroll
     for (int i = 0; i < CIB; ++i)
 #pragma unroll
-      for (int j = 0; j < COB; ++j) acc[i][j] = fmaf(x[i], dy[j], acc[i][j]);
+      for (int j = 0; j < COB; ++j)
+#pragma unroll
+        for (int v = 0; v < VW; ++v) acc[i][j] = fmaf(x[i][v], dy[j][v], acc[i][j]);
   }
   float v[NACC];
 #pragma unroll
@@ -685,11 +772,14 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     if (d->transposed) return XH_ERR_ARG;
     const int cob = pick_cob(cout_g, 8) < 2 ? 2 : pick_cob(cout_g, 8);
     ConvK a = make_k(d, p, cob, txn);
-    dim3 grid(a.tilesW * a.tilesH * a.tilesD, a.ncob, d->N * d->groups);
+    const long long odhw = (long long)d->Do * d->Ho * d->Wo;
+    dim3 grid((unsigned)((odhw + 255) / 256), a.ncob, d->N * d->groups);
+    const size_t shm = ((size_t)cin_g * 27 * cob + 4 * 2 * cob) * sizeof(float);
+    if (shm > 60 * 1024) return XH_ERR_ARG;
     switch (cob) {
-      case 2: FWD_TXN(T, 3, 2, 2); break;
-      case 4: FWD_TXN(T, 3, 2, 4); break;
-      default: FWD_TXN(T, 3, 2, 8);
+      case 2: hipLaunchKernelGGL((conv3_s2_gather_kernel<T, 2>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL((conv3_s2_gather_kernel<T, 4>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
+      default: hipLaunchKernelGGL((conv3_s2_gather_kernel<T, 8>), grid, dim3(256), shm, (hipStream_t)stream, a);
     }
     return xh_launch_status();
   }
@@ -779,12 +869,17 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
   for (int i = 0; i < 4; ++i) { wa.dw[i] = i < d->n_wptr ? dw[i] : nullptr; wa.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
   if (d->k == 1) {
     wa.c = make_k(d, p, 4, 8);
-    const long long total = (long long)d->N * d->D * d->H * d->W;
-    int gx = (int)((total + 256 * 16 - 1) / (256 * 16));
-    if (gx > 1024) gx = 1024;
+    const long long dhw1 = (long long)d->D * d->H * d->W;
+    const bool vec = (dhw1 % 4 == 0) && (d->xa_bs % 4 == 0) && (d->xb_bs % 4 == 0) && (d->ea_bs % 4 == 0);
+    const long long total = (long long)d->N * dhw1 / (vec ? 4 : 1);
+    const int ny1 = cdiv(cin_g, 4) * cdiv(cout_g, 4) * d->groups;
+    int gx = (int)((total + 256 * 8 - 1) / (256 * 8));
+    const int cap = cdiv(2048, ny1);
+    if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     dim3 grid(gx, cdiv(cin_g, 4) * cdiv(cout_g, 4), d->groups);
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, wa);
+    if (vec) hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, wa);
+    else hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, wa);
     return xh_launch_status();
   }
   const int txn = pick_txn(d->Wo);

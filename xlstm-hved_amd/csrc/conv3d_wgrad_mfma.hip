@@ -255,7 +255,9 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   if (ny > 65535) return 1;
   a.tilesW = d->W / 32; a.tilesH = cdiv(d->Ho, 8);
   const int cols = a.tilesW * a.tilesH;
-  int dsegs = cdiv(512, cols * ny * d->N);
+  // small volumes: fewer, longer runs so the per-workgroup LDS reduction + atomics pass amortises
+  const bool big_vol = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
+  int dsegs = cdiv(big_vol ? 512 : 128, cols * ny * d->N);
   const int max_segs = d->Do >= 4 ? d->Do / 4 : 1;
   if (dsegs > max_segs) dsegs = max_segs;
   if (dsegs < 1) dsegs = 1;

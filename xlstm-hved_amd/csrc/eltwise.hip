@@ -448,17 +448,30 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* dy, long lon
     cand(d, sd, Do, dlo, dhi);
     cand(h, sh, Ho, hlo, hhi);
     cand(w, sw, Wo, wlo, whi);
+    // per-axis adjoint weights, evaluated once per lane (<= 8 candidates per axis; exactly 4 for 2x upsampling)
+    constexpr int MC = 8;
+    float wd[MC], wh[MC], ww[MC];
+    dhi = min(dhi, dlo + MC - 1); hhi = min(hhi, hlo + MC - 1); whi = min(whi, wlo + MC - 1);
+#pragma unroll
+    for (int k = 0; k < MC; ++k) {
+      wd[k] = (dlo + k <= dhi) ? lin_w(dlo + k, d, sd, D) : 0.f;
+      wh[k] = (hlo + k <= hhi) ? lin_w(hlo + k, h, sh, H) : 0.f;
+      ww[k] = (wlo + k <= whi) ? lin_w(wlo + k, w, sw, W) : 0.f;
+    }
     const T* p = dy + n * dy_bs + c * odhw;
     float acc = 0.f;
-    for (int od = dlo; od <= dhi; ++od) {
-      const float wd = lin_w(od, d, sd, D);
-      if (wd == 0.f) continue;
-      for (int oh = hlo; oh <= hhi; ++oh) {
-        const float wh = lin_w(oh, h, sh, H);
-        if (wh == 0.f) continue;
+#pragma unroll
+    for (int kd = 0; kd < MC; ++kd) {
+      if (wd[kd] == 0.f) continue;
+#pragma unroll
+      for (int kh = 0; kh < MC; ++kh) {
+        if (wh[kh] == 0.f) continue;
+        const T* row = p + ((long long)(dlo + kd) * Ho + (hlo + kh)) * Wo + wlo;
         float rowacc = 0.f;
-        for (int ow = wlo; ow <= whi; ++ow) rowacc = fmaf(lin_w(ow, w, sw, W), ldf(p, ((long long)od * Ho + oh) * Wo + ow), rowacc);
-        acc = fmaf(wd * wh, rowacc, acc);
+#pragma unroll
+        for (int kw = 0; kw < MC; ++kw)
+          if (ww[kw] != 0.f) rowacc = fmaf(ww[kw], ldf(row, kw), rowacc);
+        acc = fmaf(wd[kd] * wh[kh], rowacc, acc);
       }
     }
     T* o = dx + n * dx_bs + c * dhw;
@@ -481,6 +494,7 @@ extern "C" int xh_upsample_trilinear_fwd(void* stream, int dtype, const void* x,
 extern "C" int xh_upsample_trilinear_bwd(void* stream, int dtype, const void* dy, long long dy_bs, void* dx, long long dx_bs,
                                          int N, int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate) {
   if (!dy || !dx || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return XH_ERR_ARG;
+  if (Do > 3 * D || Ho > 3 * H || Wo > 3 * W) return XH_ERR_ARG;     // adjoint keeps <= 8 candidate outputs per axis
   const long long total = (long long)N * C * D * H * W;
   if (dtype == XH_F32)
     hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, D, H, W, Do, Ho, Wo, total, accumulate);
