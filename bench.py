@@ -110,15 +110,14 @@ def main():
     params = [p for p in model.parameters()]
     g = torch.Generator(device="cpu").manual_seed(1 + rank)   # per-rank synthetic patch
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
-    allreduce = X.parallel.FlatGradAllReduce(params, world) if world > 1 else None
+    grads = X.parallel.FlatGrads(params)                       # p.grad = views of one flat fp32 bucket
 
     def step():
-        for p in params:
-            p.grad = None
+        grads.zero()
         seg, (mu, lv), rec = model(x, [14], recon=True)
         bench_loss(seg, mu, lv, rec[0]).backward()
-        if allreduce is not None:
-            allreduce()
+        if world > 1:
+            grads.all_reduce(world)                             # one in-place RCCL all-reduce of the bucket
 
     def sync_all():
         if world > 1:

@@ -189,3 +189,36 @@ def test_full_size_128_properties_bf16():
     for a, b in zip(mu + lv, mu7 + lv7):
         assert torch.equal(a, b)
     assert not torch.equal(seg, seg7)
+
+
+def test_direct_accumulation_into_flat_grads_matches_autograd_path():
+    """The weight-gradient kernels add straight into pre-existing .grad views of one flat bucket
+    (parallel.FlatGrads); the result must equal the allocate-and-return path, and accumulate across calls."""
+    g = load("net32_train_subset14")
+    m = _model(True)
+    eps = [g[f"eps{i}"] for i in range(4)]
+    x = g["x"].to(DEV)
+
+    def run():
+        seg, (mu, lv), rec = m(x, [14], recon=True, eps_list=eps)
+        loss = (seg * rnd(seg.shape, 200).to(DEV)).sum() + 0.1 * (rec[0] * rnd(rec[0].shape, 201).to(DEV)).sum()
+        for i, (a, b) in enumerate(zip(mu, lv)):
+            loss = loss + 0.05 * ((a * rnd(a.shape, 210 + i).to(DEV)).sum() + (b * rnd(b.shape, 220 + i).to(DEV)).sum())
+        loss.backward()
+    run()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    fg = X.parallel.FlatGrads(m.parameters())
+    run()
+    gscale = max(v.abs().max().item() for v in ref.values())
+    for k, p in m.named_parameters():
+        assert p.grad.data_ptr() >= fg.flat.data_ptr() and p.grad.data_ptr() < fg.flat.data_ptr() + fg.flat.numel() * 4
+        if k in ref:
+            assert (p.grad - ref[k]).abs().max().item() <= 2e-4 * gscale, k
+        else:
+            assert p.grad.abs().max().item() == 0, k
+    run()                                                   # no zero(): gradients accumulate
+    for k, p in m.named_parameters():
+        if k in ref:
+            assert (p.grad - 2 * ref[k]).abs().max().item() <= 4e-4 * gscale, k

@@ -28,8 +28,17 @@ def _worker(rank, world, port, q):
     loss.backward()
     ar = X.parallel.FlatGradAllReduce([lin.weight, lin.bias, dead, half], world)
     ar()
+    # flat bucket variant: gradients accumulate into views of one buffer, all-reduced in place
+    lin2 = torch.nn.Linear(5, 3)
+    dead2 = torch.nn.Parameter(torch.ones(4))
+    fg = X.parallel.FlatGrads([lin2.weight, lin2.bias, dead2])
+    for _ in range(2):                                    # second step checks zero() really resets the views
+        fg.zero()
+        lin2(x).sum().backward()
+        fg.all_reduce(world)
+    assert lin2.weight.grad.data_ptr() == fg.flat.data_ptr()
     q.put((rank, lin.weight.grad.clone(), lin.bias.grad.clone(), dead.grad, None if half.grad is None else half.grad.clone(),
-           X.parallel.shard_windows(7, rank, world)))
+           X.parallel.shard_windows(7, rank, world), lin2.weight.grad.clone(), dead2.grad.clone()))
     dist.destroy_process_group()
 
 
@@ -45,9 +54,10 @@ def test_flat_grad_allreduce_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     # d/dW of sum(W x + b) = sum over batch of x: rank r contributes 2*(r+1) per entry -> average (2+4)/2 = 3
-    for rank, wg, bg, dead, half, shard in res:
+    for rank, wg, bg, dead, half, shard, wg2, dead2 in res:
         assert torch.allclose(wg, torch.full((3, 5), 3.0)) and torch.allclose(bg, torch.full((3,), 2.0))
         assert dead is None
         assert shard == list(range(rank, 7, 2))
+        assert torch.allclose(wg2, torch.full((3, 5), 3.0)) and torch.equal(dead2, torch.zeros(4))
     assert torch.allclose(res[0][4], torch.full((2,), 0.5))     # rank 0: (1 + 0) / 2
     assert res[1][4] is None                                     # rank 1 had no gradient; its zeros were counted

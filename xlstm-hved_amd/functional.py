@@ -25,8 +25,27 @@ def _dhw(t):
     return t.shape[2] * t.shape[3] * t.shape[4]
 
 
-def _zeros_like_f32(ts):
-    return [torch.zeros_like(t) for t in ts]
+DIRECT_GRADS = [True]
+
+
+def _targets(params):
+    """Where the parameter-gradient kernels accumulate, and what autograd gets back.
+
+    All weight/bias gradient kernels ACCUMULATE (+=).  If a leaf parameter already owns a contiguous fp32 .grad
+    (e.g. a view of parallel.FlatGrads' bucket, or last step's gradient after zero_grad(set_to_none=False)) the kernel
+    adds straight into it and autograd receives None: no zero-fill, no AccumulateGrad add, and the flat bucket is ready
+    for the all-reduce.  Otherwise a zeroed tensor is allocated and returned the usual way."""
+    bufs, rets = [], []
+    for p in params:
+        g = p.grad if (p is not None and p.is_leaf) else None
+        if DIRECT_GRADS[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape:
+            bufs.append(g)
+            rets.append(None)
+        else:
+            z = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+            bufs.append(z)
+            rets.append(z)
+    return bufs, rets
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -52,6 +71,7 @@ class InLreluConv(Function):
         y = ops.conv3d(xa, xb, weights, biases, k=k, cout=cout, stride=stride, groups=groups, pre=(sc, sh, LEAK))
         ctx.save_for_backward(xa, xb, sc, sh, mean, rstd, *weights)
         ctx.cfg = (stride, groups, nw, k, cin, ca)
+        ctx.params = (weights, biases)
         return y
 
     @staticmethod
@@ -59,8 +79,8 @@ class InLreluConv(Function):
         xa, xb, sc, sh, mean, rstd, *weights = ctx.saved_tensors
         stride, groups, nw, k, cin, ca = ctx.cfg
         dy = _blk(dy)
-        dws = _zeros_like_f32(weights)
-        dbs = [torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) for w in weights]
+        dws, rws = _targets(ctx.params[0])
+        dbs, rbs = _targets(ctx.params[1])
         ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=groups, pre=(sc, sh, LEAK))
         dxa = dxb = None
         if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
@@ -75,7 +95,7 @@ class InLreluConv(Function):
             dxa = ops.norm_bwd_apply(g, xa, coef, have_g=True, c0=0)
             if xb is not None:
                 dxb = ops.norm_bwd_apply(g, xb, coef, have_g=True, c0=ca)
-        return (dxa, dxb, None, None, None, *dws, *dbs)
+        return (dxa, dxb, None, None, None, *rws, *rbs)
 
 
 def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1):
@@ -96,6 +116,7 @@ class GnConvRelu(Function):
         y = ops.conv3d(x, None, [weight], None, k=k, cout=weight.shape[0], stride=stride, pre=(sc, sh, 1.0), act=ACT_RELU)
         ctx.save_for_backward(x, y, weight, gamma, sc, sh, mean, rstd)
         ctx.cfg = (gs, stride, k)
+        ctx.params = (weight, gamma, beta)
         return y
 
     @staticmethod
@@ -104,7 +125,7 @@ class GnConvRelu(Function):
         gs, stride, k = ctx.cfg
         n, c = x.shape[:2]
         dyr = ops.act_bwd(_blk(dy), y, ACT_RELU)
-        dw = torch.zeros_like(weight)
+        (dw, dgamma, dbeta), (rw, rgamma, rbeta) = _targets(ctx.params)
         ops.conv3d_wgrad(x, None, dyr, [dw], None, k=k, stride=stride, pre=(sc, sh, 1.0))
         red = ops.zeros_red(x, n, c)
         e = (x, None, sc, sh, 1.0)
@@ -112,10 +133,9 @@ class GnConvRelu(Function):
             g = ops.conv3d(dyr, None, [weight], None, k=k, cout=c, transposed=True, epi=1, e=e, red=red)
         else:
             g = ops.conv3d_dgrad_s2(dyr, [weight], cin=c, in_spatial=tuple(x.shape[2:]), e=e, red=red)
-        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
         coef = ops.norm_bwd_coef(MODE_GN, red, _dhw(x), mean, rstd, gs=gs, gamma=gamma, dgamma=dgamma, dbeta=dbeta)
         dx = ops.norm_bwd_apply(g, x, coef, have_g=True)
-        return dx, dw, dgamma, dbeta, None, None
+        return dx, rw, rgamma, rbeta, None, None
 
 
 class ConvInLrelu(Function):
@@ -132,6 +152,7 @@ class ConvInLrelu(Function):
         y = ops.affine_act(y0, sc, sh, ACT_LRELU, LEAK)
         ctx.save_for_backward(x, y0, weight, sc, sh, mean, rstd)
         ctx.cfg = (groups, k)
+        ctx.params = (weight,)
         return y
 
     @staticmethod
@@ -142,12 +163,12 @@ class ConvInLrelu(Function):
         red = ops.act_bwd_reduce(dy, y0, sc, sh, LEAK)
         coef = ops.norm_bwd_coef(MODE_IN, red, _dhw(y0), mean, rstd)
         dy0 = ops.norm_bwd_apply(dy, y0, coef, have_g=False, sc=sc, sh=sh, slope=LEAK)
-        dw = torch.zeros_like(weight)
+        (dw,), (rw,) = _targets(ctx.params)
         ops.conv3d_wgrad(x, None, dy0, [dw], None, k=k, groups=groups)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy0, None, [weight], None, k=k, cout=x.shape[1], groups=groups, transposed=True)
-        return dx, dw, None
+        return dx, rw, None
 
 
 class Conv(Function):
@@ -164,6 +185,7 @@ class Conv(Function):
         y = ops.conv3d(x, None, weights, biases, k=k, cout=cout, groups=groups, act=act)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *weights)
         ctx.cfg = (groups, act, nw, has_bias, k)
+        ctx.params = (weights, biases)
         return y
 
     @staticmethod
@@ -173,13 +195,13 @@ class Conv(Function):
         dy = _blk(dy)
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act)
-        dws = _zeros_like_f32(weights)
-        dbs = [torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) for w in weights] if has_bias else None
+        dws, rws = _targets(ctx.params[0])
+        dbs, rbs = _targets(ctx.params[1]) if has_bias else (None, [])
         ops.conv3d_wgrad(x, None, dy, dws, dbs, k=k, groups=groups)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True)
-        return (dx, None, None, None, None, *dws, *(dbs or []))
+        return (dx, None, None, None, None, *rws, *rbs)
 
 
 def conv(x, weights, biases=None, groups=1, act=ACT_NONE):
@@ -327,6 +349,7 @@ class SkipReturnAttention(Function):
         a = ops.skr_tail(t2, x, sc2, sh2, w2)
         ctx.save_for_backward(x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2)
         ctx.mode = mode
+        ctx.params = (dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2)
         return a
 
     @staticmethod
@@ -335,38 +358,31 @@ class SkipReturnAttention(Function):
         mode = ctx.mode
         n, c = x.shape[:2]
         cnt = _dhw(x)
-        z = lambda t: torch.zeros_like(t)
-        zc = lambda: torch.zeros(c, dtype=torch.float32, device=x.device)
+        (ddw1, dpw1w, dpw1b, dg1, db1, ddw2, dpw2w, dpw2b, dg2, db2), rets = _targets(ctx.params)
         dtg, dx_res, dsaw = ops.skr_tail_bwd(t2, x, sc2, sh2, w2, a, _blk(da))
         # BatchNorm 2
         red = ops.act_bwd_reduce(dtg, t2, sc2, sh2, 1.0)
-        dg2, db2 = zc(), zc()
         coef = ops.norm_bwd_coef(mode, red, cnt, m2, r2, gamma=g2, dgamma=dg2, dbeta=db2)
         dt2 = ops.norm_bwd_apply(dtg, t2, coef, have_g=True)
         # pointwise 2
-        dpw2w, dpw2b = z(pw2w), zc()
         ops.conv3d_wgrad(u2, None, dt2, [dpw2w], [dpw2b], k=1)
         du2 = ops.conv3d(dt2, None, [pw2w], None, k=1, cout=c, transposed=True)
         # depthwise 2 (input = relu(bn1(t1)))
-        ddw2 = z(dw2)
         ops.conv3d_wgrad(t1, None, du2, [ddw2], None, k=3, groups=c, pre=(sc1, sh1, 0.0))
         red = ops.zeros_red(x, n, c)
         gt1 = ops.conv3d(du2, None, [dw2], None, k=3, cout=c, groups=c, transposed=True, epi=1, e=(t1, None, sc1, sh1, 0.0), red=red)
-        dg1, db1 = zc(), zc()
         coef = ops.norm_bwd_coef(mode, red, cnt, m1, r1, gamma=g1, dgamma=dg1, dbeta=db1)
         dt1 = ops.norm_bwd_apply(gt1, t1, coef, have_g=True)
         # pointwise 1, depthwise 1
-        dpw1w, dpw1b = z(pw1w), zc()
         ops.conv3d_wgrad(u1, None, dt1, [dpw1w], [dpw1b], k=1)
         du1 = ops.conv3d(dt1, None, [pw1w], None, k=1, cout=c, transposed=True)
-        ddw1 = z(dw1)
         ops.conv3d_wgrad(x, None, du1, [ddw1], None, k=3, groups=c)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(du1, None, [dw1], None, k=3, cout=c, groups=c, transposed=True)
             dx = ops.add(dx, dx_res, out=dx)
         dsaw_t = dsaw.to(torch.float32).reshape(1, 2, 1, 1, 1)
-        return (dx, None, None, None, None, None, None, ddw1, dpw1w, dpw1b, dg1, db1, ddw2, dpw2w, dpw2b, dg2, db2, dsaw_t)
+        return (dx, None, None, None, None, None, None, *rets, dsaw_t)
 
 
 class DuSE(Function):
@@ -400,6 +416,7 @@ class DuSE(Function):
             stats += [sc, sh, m, rs]
         ctx.save_for_backward(r, s, red_r, red_s, gvec, ch1, ch2, comb, sp, u_r, u_s, *stats, wc, w1, w2, sqw, adjw, g1, g2)
         ctx.mode = mode
+        ctx.params = (wc, bc, w1, b1, w2, b2, sqw, sqb, adjw, adjb, g1, be1, g2, be2)
         return outs[0], outs[1]
 
     @staticmethod
@@ -409,31 +426,27 @@ class DuSE(Function):
         mode = ctx.mode
         n, c = r.shape[:2]
         cnt = _dhw(r)
-        zc = lambda: torch.zeros(c, dtype=torch.float32, device=r.device)
-        dus, bn_grads = [], []
-        for do, u, sc, sh, m, rs, gam in ((dor, u_r, sc1, sh1, m1, rs1, g1), (dos, u_s, sc2, sh2, m2, rs2, g2)):
+        (dwc, dbc, dw1, db1, dw2, db2, dsqw, dsqb, dadjw, dadjb, dg1, dbe1, dg2, dbe2), rets = _targets(ctx.params)
+        dus = []
+        for do, u, sc, sh, m, rs, gam, dg, db in ((dor, u_r, sc1, sh1, m1, rs1, g1, dg1, dbe1), (dos, u_s, sc2, sh2, m2, rs2, g2, dg2, dbe2)):
             do = _blk(do)
             red = ops.act_bwd_reduce(do, u, sc, sh, 1.0)
-            dg, db = zc(), zc()
             coef = ops.norm_bwd_coef(mode, red, cnt, m, rs, gamma=gam, dgamma=dg, dbeta=db)
             dus.append(ops.norm_bwd_apply(do, u, coef, have_g=True))
-            bn_grads += [dg, db]
         dsp = torch.empty_like(sp)
         dr, dch1 = ops.duse_gate_bwd(r, ch1, sp[:, 0:1], dus[0], dsp[:, 0:1])
         ds, dch2 = ops.duse_gate_bwd(s, ch2, sp[:, 1:2], dus[1], dsp[:, 1:2])
         dpre = ops.act_bwd(dsp, sp, ACT_SIGMOID)
-        dadjw, dadjb = torch.zeros_like(adjw), torch.zeros(2, dtype=torch.float32, device=r.device)
         ops.conv3d_wgrad(comb, None, dpre, [dadjw], [dadjb], k=3)
         dcomb = ops.conv3d(dpre, None, [adjw], None, k=3, cout=1, transposed=True)
-        dsqw, dsqb = torch.zeros_like(sqw), torch.zeros(1, dtype=torch.float32, device=r.device)
         ops.conv3d_wgrad(r, s, dcomb, [dsqw], [dsqb], k=1)
-        fc = dict(wc=wc, w1=w1, w2=w2, bc=bn_grads[1], b1=bn_grads[1], b2=bn_grads[1])   # biases only give shapes
-        fcg, dmr, dms = ops.duse_fc_bwd(red_r, red_s, cnt, n, c, fc, gvec, ch1, ch2, dch1, dch2)
+        fc = dict(wc=wc, w1=w1, w2=w2)
+        fcg = dict(wc=dwc, bc=dbc, w1=dw1, b1=db1, w2=dw2, b2=db2)
+        dmr, dms = ops.duse_fc_bwd(red_r, red_s, cnt, n, c, fc, gvec, ch1, ch2, dch1, dch2, fcg)
         sq = sqw.reshape(-1)
         ops.rank1_add(dr, dcomb, sq[:c].contiguous(), dmr)
         ops.rank1_add(ds, dcomb, sq[c:].contiguous(), dms)
-        return (dr, ds, None, None, None, None, None, fcg["wc"], fcg["bc"], fcg["w1"], fcg["b1"], fcg["w2"], fcg["b2"],
-                dsqw, dsqb, dadjw, dadjb, bn_grads[0], bn_grads[1], bn_grads[2], bn_grads[3])
+        return (dr, ds, None, None, None, None, None, *rets)
 
 
 class ViL(Function):
@@ -449,6 +462,7 @@ class ViL(Function):
         out, ws = ops.vil_fwd(xa, xb, p, add_xa)
         ctx.save_for_backward(xa, xb, ws, *p.values())
         ctx.add_xa = add_xa
+        ctx.params = params
         return out
 
     @staticmethod
@@ -456,6 +470,8 @@ class ViL(Function):
         xa, xb, ws, *params = ctx.saved_tensors
         p = dict(zip(ViL.NAMES, params))
         dout = dout.contiguous()
-        dxin, grads = ops.vil_bwd(xa, xb, dout, p, ws)
+        bufs, rets = _targets(ctx.params)
+        # the kernels index contiguous fp32 storage: a non-contiguous parameter got a zeroed contiguous buffer above
+        dxin = ops.vil_bwd(xa, xb, dout, p, ws, dict(zip(ViL.NAMES, bufs)))
         dxa = ops.add(dout, dxin) if ctx.add_xa else dxin
-        return (dxa, dxin if xb is not None else None, None, *[grads[k] for k in ViL.NAMES])
+        return (dxa, dxin if xb is not None else None, None, *rets)

@@ -379,14 +379,13 @@ def duse_fc_fwd(red_r, red_s, count, n, c, p):
     return g, ch1, ch2
 
 
-def duse_fc_bwd(red_r, red_s, count, n, c, p, g, ch1, ch2, dch1, dch2):
-    z = lambda t: torch.zeros_like(t)
-    grads = {k: z(p[k]) for k in ("wc", "bc", "w1", "b1", "w2", "b2")}
+def duse_fc_bwd(red_r, red_s, count, n, c, p, g, ch1, ch2, dch1, dch2, grads):
+    """grads: dict of fp32 buffers (wc, bc, w1, b1, w2, b2) the kernel ACCUMULATES into."""
     dmr, dms = (torch.empty((n, c), dtype=torch.float32, device=g.device) for _ in range(2))
     L.check(L.load().xh_duse_fc_bwd(_stream(), _p(red_r), _p(red_s), count, n, c, _p(p["wc"]), _p(p["w1"]), _p(p["w2"]), _p(g), _p(ch1),
                                     _p(ch2), _p(dch1), _p(dch2), _p(grads["wc"]), _p(grads["bc"]), _p(grads["w1"]), _p(grads["b1"]),
                                     _p(grads["w2"]), _p(grads["b2"]), _p(dmr), _p(dms)), "xh_duse_fc_bwd")
-    return grads, dmr, dms
+    return dmr, dms
 
 
 def skr_tail(t, x, sc, sh, w2):
@@ -427,13 +426,13 @@ def vil_fwd(xa, xb, params, add_xa=True, nh=4):
     return out, ws
 
 
-def vil_bwd(xa, xb, dout, params, ws, nh=4):
+def vil_bwd(xa, xb, dout, params, ws, grads, nh=4):
+    """grads: dict of fp32 buffers (L.VIL_FIELDS) the kernels ACCUMULATE into."""
     n, c, d, h, w, _ = _vol(xa)
     s = d * h * w
     dout = dout.contiguous()
     dxin = torch.empty_like(dout)
-    grads = {k: torch.zeros_like(params[k]) for k in L.VIL_FIELDS}
     ps, gs = _vil_struct(params), _vil_struct(grads)
     L.check(L.load().xh_vil_bwd(_stream(), _dt(dout), _p(xa), _p(xb), _p(dout), _p(dxin), n, s, c, nh, C.byref(ps), C.byref(gs), _p(ws)),
             "xh_vil_bwd")
-    return dxin, grads
+    return dxin

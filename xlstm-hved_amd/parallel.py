@@ -42,6 +42,32 @@ class FlatGradAllReduce:
         self.unpack()
 
 
+class FlatGrads:
+    """One flat fp32 bucket holding every parameter's gradient; `p.grad` are views into it.
+
+    The weight-gradient kernels accumulate directly into an existing `.grad` (functional._targets), so with this
+    bucket a step needs ONE zero-fill instead of one per parameter tensor, autograd performs no AccumulateGrad adds,
+    and the data-parallel exchange is a single in-place all-reduce of the bucket (no pack/unpack copies).
+    Parameters the network never reaches simply keep zero gradients."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        p0 = self.params[0]
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=p0.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, world_size=None, group=None):
+        world = world_size if world_size is not None else dist.get_world_size(group)
+        dist.all_reduce(self.flat, group=group)
+        self.flat.div_(world)
+
+
 def shard_windows(n_items, rank, world):
     """Round-robin assignment of independent work items (sliding-window tiles, evaluation.py:311-333) to ranks."""
     return list(range(rank, n_items, world))
