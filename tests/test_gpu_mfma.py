@@ -18,6 +18,9 @@ CASES = [
     dict(cin=24, cout=8, groups=1, sp=(4, 8, 32), split=8),   # CINP=24
     dict(cin=4, cout=4, groups=1, sp=(6, 8, 32)),             # CINP=4 (two 8-byte fragment reads)
     dict(cin=8, cout=8, groups=1, sp=(4, 8, 32)),
+    dict(cin=64, cout=128, groups=4, sp=(8, 8, 16)),          # 16-wide volumes (level 3 of a 128^3 patch): TW=16 tiles
+    dict(cin=16, cout=16, groups=1, sp=(6, 9, 16)),
+    dict(cin=16, cout=16, groups=16, sp=(5, 8, 32)),          # depthwise: dedicated no-LDS kernel (not MFMA)
 ]
 
 
@@ -26,8 +29,9 @@ def test_mfma_conv_forward_backward(cfg):
     torch.manual_seed(11)
     n, cin, cout, g = 2, cfg["cin"], cfg["cout"], cfg["groups"]
     x = (torch.randn((n, cin) + cfg["sp"]) * 1.5 + 0.3).bfloat16()
-    ws = [torch.randn(cout // g, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5 for _ in range(g)]
-    bs = [torch.randn(cout // g) for _ in range(g)]
+    nw = g if g <= 4 else 1                             # the C ABI takes one weight pointer, or one per group (<= 4)
+    ws = [torch.randn(cout // nw, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5 for _ in range(nw)]
+    bs = [torch.randn(cout // nw) for _ in range(nw)]
     wgt = torch.randn((n, cout) + cfg["sp"])
 
     def run(mfma):

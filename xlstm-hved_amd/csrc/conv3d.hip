@@ -231,6 +231,96 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Depthwise k = 3, stride 1 (BasicConv conv_blocks, the skip-return ResBlock's dwconvs, and their data gradients).
+// 27 FMA per output against 2+2 bytes: bandwidth bound, so no LDS tile -- each lane produces 4 consecutive outputs of
+// one channel from 9 row segments read straight through L1/L2 (rows are shared by neighbouring lanes/blocks).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
+  __shared__ float s_red[4 * 2];
+  const int tid = threadIdx.x;
+  const int tx = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long dhw = (long long)D * H * W;
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const float* wp = a.p.w[c / gpp] + (long long)(c % gpp) * 27;
+  float wgt[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) wgt[i] = wp[a.d.transposed ? 26 - i : i];
+  float sc = 1.f, sh = 0.f;
+  if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+  const T* src = in_plane<T>(a, n, c, dhw);
+  const bool vec4 = (W % 4 == 0) && (dhw % 4 == 0) && (a.d.xa_bs % 4 == 0) && (a.d.xb_bs % 4 == 0);
+  float s0 = 0.f, s1 = 0.f;
+  const float* bp = a.p.b[c / gpp];
+  const float bias = bp ? bp[c % gpp] : 0.f;
+  // persistent over tiles: the fused reduction costs one atomic per workgroup, not one per tile (same-address fp64
+  // atomics from thousands of tiny workgroups serialise at the memory side)
+  const int ntiles = a.tilesW * a.tilesH * a.tilesD;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  int t = tile;
+  const int tw = t % a.tilesW; t /= a.tilesW;
+  const int th = t % a.tilesH;
+  const int td = t / a.tilesH;
+  const int od = td * 4 + tz, oh = th * 8 + ty, ow = tw * 32 + tx * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int valid = 0;
+  if (od < D && oh < H && ow < W) {
+    valid = min(4, W - ow);
+    // phase 1: issue every load of the 3x3 row neighbourhood (one aligned 4-voxel vector + 2 neighbours per row)
+    float q[9][6];
+    bool rok[9];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int gd = od - 1 + kd, gh = oh - 1 + kh;
+        const int ri = kd * 3 + kh;
+        rok[ri] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) q[ri][i] = 0.f;
+        if (rok[ri]) {
+          const T* row = src + ((long long)gd * H + gh) * W;
+          if (vec4 && valid == 4) {
+            float t4[4];
+            ld4(row, ow, t4);
+            q[ri][1] = t4[0]; q[ri][2] = t4[1]; q[ri][3] = t4[2]; q[ri][4] = t4[3];
+          } else {
+#pragma unroll
+            for (int i = 1; i < 5; ++i)
+              if (ow - 1 + i < W) q[ri][i] = ldf(row, ow - 1 + i);
+          }
+          if (ow > 0) q[ri][0] = ldf(row, ow - 1);
+          if (ow + 4 < W) q[ri][5] = ldf(row, ow + 4);
+        }
+      }
+    // phase 2: transform (zero padding stays zero) + 27 x 4 FMAs
+#pragma unroll
+    for (int ri = 0; ri < 9; ++ri) {
+      if (a.d.pre) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int gw = ow - 1 + i;
+          q[ri][i] = (rok[ri] && (unsigned)gw < (unsigned)W) ? leaky(q[ri][i] * sc + sh, a.d.pre_slope) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = fmaf(wgt[ri * 3 + kw], q[ri][v + kw], acc[v]);
+    }
+  }
+  if (valid > 0) conv_epilogue<T, 4>(a, n, c, dhw, ((long long)od * H + oh) * W + ow, valid, bias, acc, s0, s1);
+  }
+  if (a.d.epi) {
+    float v[2] = {s0, s1};
+    block_sum<2>(v, s_red, 4);
+    if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], (double)s_red[tid]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k = 1 forward / dgrad: no halo, inputs straight from global memory (4 voxels per lane, vectorised).
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int COB, bool VEC>
@@ -247,15 +337,17 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
     s_w[idx] = co_g < a.Cout_g ? conv_weight(a, g, co_g, ci_g, 0, 1) : 0.f;
   }
   __syncthreads();
-  const long long q0 = ((long long)blockIdx.x * 256 + tid) * VW;
-  int valid = 0;
-  if (q0 < dhw) valid = (int)min((long long)VW, dhw - q0);
+  float s0[COB], s1[COB];
+#pragma unroll
+  for (int co = 0; co < COB; ++co) { s0[co] = 0.f; s1[co] = 0.f; }
+  for (long long q0 = ((long long)blockIdx.x * 256 + tid) * VW; q0 < dhw; q0 += (long long)gridDim.x * 256 * VW) {
+  const int valid = (int)min((long long)VW, dhw - q0);
   float acc[COB][VW];
 #pragma unroll
   for (int i = 0; i < COB; ++i)
 #pragma unroll
     for (int v = 0; v < VW; ++v) acc[i][v] = 0.f;
-  if (valid > 0) {
+  {
     for (int ci_g = 0; ci_g < a.Cin_g; ++ci_g) {
       const int c = g * a.Cin_g + ci_g;
       const T* src = in_plane<T>(a, n, c, dhw) + q0;
@@ -279,15 +371,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
       }
     }
   }
-  float s0[COB], s1[COB];
 #pragma unroll
   for (int co = 0; co < COB; ++co) {
-    s0[co] = 0.f; s1[co] = 0.f;
     const int co_g = cob * COB + co;
-    if (co_g < a.Cout_g && valid > 0) {
+    if (co_g < a.Cout_g) {
       const int c = g * a.Cout_g + co_g;
       conv_epilogue<T, VW>(a, n, c, dhw, q0, valid, conv_bias(a, g, co_g), acc[co], s0[co], s1[co]);
     }
+  }
   }
   if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
 }
@@ -745,7 +836,10 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     ConvK a = make_k(d, p, cob, 8);
     const long long dhw = (long long)d->D * d->H * d->W;
     const bool vec = (dhw % 4 == 0) && (d->xa_bs % 4 == 0) && (d->xb_bs % 4 == 0);
-    dim3 grid((unsigned)((dhw + 1023) / 1024), a.ncob, d->N * d->groups);
+    long long gx1 = (dhw + 1023) / 1024;
+    const long long cap1 = cdiv(2048, a.ncob * d->N * d->groups);
+    if (gx1 > cap1) gx1 = cap1;
+    dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
 #define L1(COB)                                                                                                  \
   do {                                                                                                           \
     if (vec) hipLaunchKernelGGL((conv1x1_kernel<T, COB, true>), grid, dim3(256), 0, (hipStream_t)stream, a);     \
@@ -756,6 +850,15 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     return xh_launch_status();
   }
   const int txn = pick_txn(d->Wo);
+  if (d->k == 3 && d->stride == 1 && cin_g == 1 && cout_g == 1 && d->Cin < 65536) {
+    ConvK a = make_k(d, p, 1, 8);
+    int gx = a.tilesW * a.tilesH * a.tilesD;
+    const int cap = cdiv(2048, d->Cin * d->N);
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, d->Cin, d->N);
+    hipLaunchKernelGGL((conv_dw3_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    return xh_launch_status();
+  }
   if (d->k == 3 && d->stride == 1) {
     const int cob = pick_cob(cout_g, 8);
     ConvK a = make_k(d, p, cob, txn);

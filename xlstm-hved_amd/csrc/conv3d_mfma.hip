@@ -30,7 +30,7 @@ struct ConvMK {
   xh_conv_desc d;
   xh_conv_ptrs p;
   int Cin_g, Cout_g;
-  int tilesW, tilesH;
+  int tilesW, tilesH, tw;
   int sd, dsegs;    // output planes per worker, number of depth segments
   int cin_blk;      // input channels staged per block (<= CINP)
   int ntile;        // 16-wide output tiles per set
@@ -80,10 +80,10 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
 // bijection inside each 128-byte block, so fragment reads apply the same function.
 __device__ __forceinline__ int swz(int off) { return off ^ (((off >> 8) & 7) << 4); }
 
-template <int CINP, int NT>
+template <int CINP, int NT, int TW>
 __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
   constexpr int NWV = NT / 64;
-  constexpr int TW = 32, TH = 8;
+  constexpr int TH = 8, NSEG = TW / 16;
   constexpr int IH = TH + 2;
   constexpr int IWP = TW + 4;                         // halo (2) + 2 spare columns for the over-reading tail chunk
   constexpr int VB = CINP * 2;                        // bytes per voxel in LDS
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
   constexpr int NCH = 9 * CPR;
   constexpr int NM = (NCH + 3) / 4;                   // MFMAs per 16-voxel segment
   constexpr bool A16 = (CINP % 8) == 0;               // 16-byte aligned fragments
-  constexpr int NQ = CINP / 4, NG = 6;                // channel quads; aligned 8-voxel groups covering [ow0-8, ow0+40)
+  constexpr int NQ = CINP / 4, NG = TW / 8 + 2;       // channel quads; aligned 8-voxel groups covering [ow0-8, ow0+TW+8)
   constexpr int NITEM = IH * NG * NQ;                 // staging items per plane
   constexpr int NIT = (NITEM + NT - 1) / NT;
   constexpr int EPS = 36;                             // epilogue pad row stride (floats)
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
     for (int rr = wv; rr < TH; rr += NWV) {
       const int oh = oh0 + rr;
       if (oh >= Ho) continue;                         // wave-uniform
-      f32x4 acc[2];
+      f32x4 acc[NSEG];
 #pragma unroll
-      for (int wt = 0; wt < 2; ++wt) {
+      for (int wt = 0; wt < NSEG; ++wt) {
         const int rowoff = (rr * IWP + wt * 16) * VB;
         acc[wt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(a.abl & 4))
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
       if (a.abl & 32) continue;
       // ---- transpose through the wave-private pad: [cout nn][voxel wt*16 + 4*g4 + r] ----
 #pragma unroll
-      for (int wt = 0; wt < 2; ++wt)
+      for (int wt = 0; wt < NSEG; ++wt)
         *reinterpret_cast<f32x4*>(ep + nn * EPS + wt * 16 + g4 * 4) = acc[wt];
       __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the wave's own LDS writes have landed
       __builtin_amdgcn_wave_barrier();
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
-      if (co_ok && !(a.abl & 8)) {
+      if (co_ok && ech * 8 < TW && !(a.abl & 8)) {
         const long long sp = ((long long)d * Ho + oh) * Wo + ow0 + ech * 8;
         float ev[8];
         if (a.d.epi == 1) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
 
 static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if (d->dtype != XH_BF16 || d->k != 3 || d->stride != 1) return 1;
-  if (d->W % 32 != 0 || d->Wo != d->W) return 1;
+  if (d->W % 16 != 0 || d->Wo != d->W) return 1;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g < 4) return 1;                            // depthwise / single-channel convs stay on the vector kernel
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return 1;
@@ -351,7 +351,8 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if (d->N > 65535) return 1;
   a->d = *d;
   a->Cin_g = cin_g; a->Cout_g = cout_g;
-  a->tilesW = d->W / 32; a->tilesH = cdiv(d->Ho, 8);
+  a->tw = (d->W % 32 == 0) ? 32 : 16;
+  a->tilesW = d->W / a->tw; a->tilesH = cdiv(d->Ho, 8);
   a->cin_blk = cin_blk;
   a->cout_set = gs * cout_g;
   a->ntile = cdiv(a->cout_set, 16);
@@ -393,19 +394,21 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
   dim3 grid(a.tilesW * a.tilesH * a.dsegs, ny, d->N);
-  const size_t shm = (size_t)4 * 10 * 36 * a.cinp * 2 + (size_t)8 * 16 * 36 * sizeof(float);
+  const size_t shm = (size_t)4 * 10 * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 16 * 36 * sizeof(float);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
 #define LM(C)                                                                                                   \
   do {                                                                                                          \
     static bool attr_done = false;                                                                              \
     if (!attr_done) {                                                                                           \
-      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
       attr_done = true;                                                                                         \
     }                                                                                                           \
-    if (big) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256>), grid, dim3(256), shm, st, a);                      \
-    else hipLaunchKernelGGL((conv3_mfma_kernel<C, 512>), grid, dim3(512), shm, st, a);                          \
+    if (a.tw == 16) hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 16>), grid, dim3(512), shm, st, a);           \
+    else if (big) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256, 32>), grid, dim3(256), shm, st, a);             \
+    else hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 32>), grid, dim3(512), shm, st, a);                      \
   } while (0)
   switch (a.cinp) {
     case 4: LM(4); break;
