@@ -6,42 +6,74 @@
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
-#define VW 4
 #define EW_BLOCK 256
-// elements of one (n,c) row covered by a block
-#define EW_CHUNK (EW_BLOCK * VW * 4)
+// voxels per lane: 16-byte accesses for both storage types (4 fp32 or 8 bf16)
+template <typename T> struct VWT { static constexpr int v = 4; };
+template <> struct VWT<bf16_t> { static constexpr int v = 8; };
+// elements of one (n,c) row covered by a block: 16 vector iterations per lane, so a 128^3 row is 128 (fp32: 256)
+// workgroups -- enough to fill the chip with >= 4 channels, and few enough that the per-workgroup fp64 atomics of
+// the reducing kernels do not serialise on one address
+template <typename T> constexpr int ew_chunk() { return EW_BLOCK * VWT<T>::v * 16; }
 
-template <typename T>
-__device__ __forceinline__ void ldrow(const T* p, long long q, int valid, bool vec, float (&o)[VW]) {
-  if (vec && valid == VW) {
-    ld4(p, q, o);
+__device__ __forceinline__ void ldvec(const float* p, long long q, float (&o)[4]) { ld4(p, q, o); }
+__device__ __forceinline__ void stvec(float* p, long long q, const float (&o)[4]) { st4(p, q, o); }
+__device__ __forceinline__ void ldvec(const bf16_t* p, long long q, float (&o)[8]) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p + q);
+  const unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(u[k] << 16); o[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+}
+__device__ __forceinline__ void stvec(bf16_t* p, long long q, const float (&o)[8]) {
+  uint4 t;
+  t.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+  t.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+  t.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
+  t.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+  *reinterpret_cast<uint4*>(p + q) = t;
+}
+template <typename T, int N>
+__device__ __forceinline__ void ldrow(const T* p, long long q, int valid, bool vec, float (&o)[N]) {
+  if (vec && valid == N) {
+    ldvec(p, q, o);
   } else {
 #pragma unroll
-    for (int v = 0; v < VW; ++v) o[v] = v < valid ? ldf(p, q + v) : 0.f;
+    for (int v = 0; v < N; ++v) o[v] = v < valid ? ldf(p, q + v) : 0.f;
   }
 }
-template <typename T>
-__device__ __forceinline__ void strow(T* p, long long q, int valid, bool vec, const float (&o)[VW]) {
-  if (vec && valid == VW) {
-    st4(p, q, o);
+template <typename T, int N>
+__device__ __forceinline__ void strow(T* p, long long q, int valid, bool vec, const float (&o)[N]) {
+  if (vec && valid == N) {
+    stvec(p, q, o);
   } else {
 #pragma unroll
-    for (int v = 0; v < VW; ++v)
+    for (int v = 0; v < N; ++v)
       if (v < valid) stf(p, q + v, o[v]);
   }
 }
+template <typename T>
 static inline bool vec_ok(long long dhw, std::initializer_list<long long> strides) {
+  constexpr int VW = VWT<T>::v;
   if (dhw % VW) return false;
   for (long long s : strides)
     if (s % VW) return false;
   return true;
 }
-static inline dim3 row_grid(long long dhw, int C, int N) { return dim3((unsigned)((dhw + EW_CHUNK - 1) / EW_CHUNK), C, N); }
+// ~2048 workgroups per launch whatever the channel count: few workgroups per (n,c) row when there are many rows (so
+// the per-workgroup fp64 atomics of the reducing kernels do not pile up on one address), many when there are few.
+template <typename T>
+static inline dim3 row_grid(long long dhw, int C, int N) {
+  const long long maxb = (dhw + EW_BLOCK * VWT<T>::v - 1) / (EW_BLOCK * VWT<T>::v);
+  long long want = (2048 + (long long)C * N - 1) / ((long long)C * N);
+  if (want < 1) want = 1;
+  return dim3((unsigned)(want < maxb ? want : maxb), C, N);
+}
 
 #define ROW_LOOP_BEGIN                                                                         \
+  constexpr int VW = VWT<T>::v;                                                                \
   const int c = blockIdx.y, n = blockIdx.z;                                                    \
-  const long long q_end = min(dhw, (long long)(blockIdx.x + 1) * EW_CHUNK);                    \
-  for (long long q = (long long)blockIdx.x * EW_CHUNK + threadIdx.x * VW; q < q_end; q += EW_BLOCK * VW) { \
+  const long long q_per = ((dhw + gridDim.x - 1) / gridDim.x + EW_BLOCK * VW - 1) / (EW_BLOCK * VW) * (EW_BLOCK * VW); \
+  const long long q_end = min(dhw, (long long)(blockIdx.x + 1) * q_per);                       \
+  for (long long q = (long long)blockIdx.x * q_per + threadIdx.x * VW; q < q_end; q += EW_BLOCK * VW) { \
     const int valid = (int)min((long long)VW, dhw - q);
 #define ROW_LOOP_END }
 
@@ -70,12 +102,12 @@ __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long
 extern "C" int xh_moments(void* stream, int dtype, const void* x, long long x_bs, int N, int C, long long DHW,
                           double* red, long long red_rs) {
   if (!x || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {x_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {x_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(moments_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs, vec);
+    hipLaunchKernelGGL(moments_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(moments_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs, vec);
+    hipLaunchKernelGGL(moments_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -156,12 +188,12 @@ __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long l
 extern "C" int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
                              int C, long long DHW, const float* sc, const float* sh, int act, float slope) {
   if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {x_bs, y_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {x_bs, y_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, y_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(affine_act_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope, vec);
+    hipLaunchKernelGGL(affine_act_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope, vec);
+    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -193,12 +225,12 @@ __global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_kernel(const T* dy, l
 extern "C" int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
                                  int N, int C, long long DHW, const float* sc, const float* sh, float slope, double* red) {
   if (!dy || !x || !sc || !sh || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {dy_bs, x_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red, vec);
+    hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, C, DHW, sc, sh, slope, red, vec);
+    hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, C, DHW, sc, sh, slope, red, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -276,7 +308,10 @@ __global__ __launch_bounds__(EW_BLOCK) void norm_bwd_apply_kernel(const T* dy, l
     ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
     T* dp = dx + n * dx_bs + (long long)c * dhw;
     if (accumulate) ldrow((const T*)dp, q, valid, vec, o);
-    else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+    else {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) o[i] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       float gg = g[i];
@@ -293,12 +328,12 @@ extern "C" int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long l
                                  int accumulate) {
   if (!dy || !x || !dx || !A || !B || !Cc || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   if (!have_g && (!sc || !sh)) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {dy_bs, x_bs, dx_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -524,12 +559,12 @@ __global__ __launch_bounds__(EW_BLOCK) void add_kernel(const T* a, long long a_b
 extern "C" int xh_add(void* stream, int dtype, const void* a, long long a_bs, const void* b, long long b_bs, void* y,
                       long long y_bs, int N, long long CDHW) {
   if (!a || !y || N <= 0 || CDHW <= 0 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(CDHW, {a_bs, b_bs, y_bs});
-  dim3 grid = row_grid(CDHW, 1, N);
+  const bool vec32 = vec_ok<float>(CDHW, {a_bs, b_bs, y_bs}), vec16 = vec_ok<bf16_t>(CDHW, {a_bs, b_bs, y_bs});
+  const dim3 grid32 = row_grid<float>(CDHW, 1, N), grid16 = row_grid<bf16_t>(CDHW, 1, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(add_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)a, a_bs, (const float*)b, b_bs, (float*)y, y_bs, CDHW, vec);
+    hipLaunchKernelGGL(add_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)a, a_bs, (const float*)b, b_bs, (float*)y, y_bs, CDHW, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(add_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)a, a_bs, (const bf16_t*)b, b_bs, (bf16_t*)y, y_bs, CDHW, vec);
+    hipLaunchKernelGGL(add_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)a, a_bs, (const bf16_t*)b, b_bs, (bf16_t*)y, y_bs, CDHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -761,12 +796,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* x, long long x_b
 extern "C" int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y,
                            long long y_bs, int N, int C, long long DHW) {
   if (!x || !s || !y || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {x_bs, s_bs, y_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {x_bs, s_bs, y_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, s_bs, y_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(gate_fwd_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (float*)y, y_bs, DHW, vec);
+    hipLaunchKernelGGL(gate_fwd_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (float*)y, y_bs, DHW, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (bf16_t*)y, y_bs, DHW, vec);
+    hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (bf16_t*)y, y_bs, DHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -837,12 +872,12 @@ __global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* x, long 
 extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                                 long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW) {
   if (!x || !ch || !sp || !u || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {x_bs, sp_bs, u_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {x_bs, sp_bs, u_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, sp_bs, u_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(duse_gate_fwd_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW, vec);
+    hipLaunchKernelGGL(duse_gate_fwd_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(duse_gate_fwd_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW, vec);
+    hipLaunchKernelGGL(duse_gate_fwd_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -851,13 +886,13 @@ extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long lon
                                 long long sp_bs, const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp,
                                 long long dsp_bs, double* dch, int N, int C, long long DHW) {
   if (!x || !ch || !sp || !du || !dx || !dsp || !dch || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {x_bs, sp_bs, du_bs, dx_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {x_bs, sp_bs, du_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, sp_bs, du_bs, dx_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32) {
-    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (const float*)du, du_bs, (float*)dx, dx_bs, dch, C, DHW, vec);
+    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (const float*)du, du_bs, (float*)dx, dx_bs, dch, C, DHW, vec32);
     hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)du, du_bs, (float*)dsp, dsp_bs, C, DHW);
   } else if (dtype == XH_BF16) {
-    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW, vec);
+    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW, vec16);
     hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW);
   } else {
     return XH_ERR_DTYPE;
@@ -884,12 +919,12 @@ __global__ __launch_bounds__(EW_BLOCK) void rank1_add_kernel(T* dx, long long dx
 extern "C" int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, const void* d, long long d_bs,
                             const float* w, const float* k, int N, int C, long long DHW) {
   if (!dx || !d || !w || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec = vec_ok(DHW, {dx_bs, d_bs});
-  dim3 grid = row_grid(DHW, C, N);
+  const bool vec32 = vec_ok<float>(DHW, {dx_bs, d_bs}), vec16 = vec_ok<bf16_t>(DHW, {dx_bs, d_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(rank1_add_kernel<float>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (float*)dx, dx_bs, (const float*)d, d_bs, w, k, C, DHW, vec);
+    hipLaunchKernelGGL(rank1_add_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (float*)dx, dx_bs, (const float*)d, d_bs, w, k, C, DHW, vec32);
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(rank1_add_kernel<bf16_t>, grid, dim3(EW_BLOCK), 0, (hipStream_t)stream, (bf16_t*)dx, dx_bs, (const bf16_t*)d, d_bs, w, k, C, DHW, vec);
+    hipLaunchKernelGGL(rank1_add_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (bf16_t*)dx, dx_bs, (const bf16_t*)d, d_bs, w, k, C, DHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
