@@ -268,42 +268,42 @@ __global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
   int valid = 0;
   if (od < D && oh < H && ow < W) {
     valid = min(4, W - ow);
-    // phase 1: issue every load of the 3x3 row neighbourhood (one aligned 4-voxel vector + 2 neighbours per row)
-    float q[9][6];
-    bool rok[9];
+    // Every load is unconditional on a clamped (always valid) address and masked arithmetically afterwards, so the
+    // 27 loads issue back to back behind ONE wait instead of 27 exec-masked branches with a wait each.
+    float q[9][6], rmask[9];
+    const int owl = max(ow - 1, 0), owr = min(ow + 4, W - 1);
+    const float lmask = ow > 0 ? 1.f : 0.f, rmk = (ow + 4 < W) ? 1.f : 0.f;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int gd = od - 1 + kd, gh = oh - 1 + kh;
         const int ri = kd * 3 + kh;
-        rok[ri] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+        rmask[ri] = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) ? 1.f : 0.f;
+        const T* row = src + ((long long)min(max(gd, 0), D - 1) * H + min(max(gh, 0), H - 1)) * W;
+        if (vec4 && valid == 4) {                    // block-uniform in practice (W % 4 == 0)
+          float t4[4];
+          ld4(row, ow, t4);
+          q[ri][1] = t4[0]; q[ri][2] = t4[1]; q[ri][3] = t4[2]; q[ri][4] = t4[3];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) q[ri][i] = 0.f;
-        if (rok[ri]) {
-          const T* row = src + ((long long)gd * H + gh) * W;
-          if (vec4 && valid == 4) {
-            float t4[4];
-            ld4(row, ow, t4);
-            q[ri][1] = t4[0]; q[ri][2] = t4[1]; q[ri][3] = t4[2]; q[ri][4] = t4[3];
-          } else {
-#pragma unroll
-            for (int i = 1; i < 5; ++i)
-              if (ow - 1 + i < W) q[ri][i] = ldf(row, ow - 1 + i);
-          }
-          if (ow > 0) q[ri][0] = ldf(row, ow - 1);
-          if (ow + 4 < W) q[ri][5] = ldf(row, ow + 4);
+          for (int i = 1; i < 5; ++i) q[ri][i] = ldf(row, min(ow - 1 + i, W - 1));
         }
+        q[ri][0] = ldf(row, owl);
+        q[ri][5] = ldf(row, owr);
       }
-    // phase 2: transform (zero padding stays zero) + 27 x 4 FMAs
 #pragma unroll
     for (int ri = 0; ri < 9; ++ri) {
-      if (a.d.pre) {
+      float m[6];
+      m[0] = rmask[ri] * lmask;
+      m[5] = rmask[ri] * rmk;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int gw = ow - 1 + i;
-          q[ri][i] = (rok[ri] && (unsigned)gw < (unsigned)W) ? leaky(q[ri][i] * sc + sh, a.d.pre_slope) : 0.f;
-        }
+      for (int i = 1; i < 5; ++i) m[i] = (ow - 1 + i < W) ? rmask[ri] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float v = q[ri][i];
+        if (a.d.pre) v = leaky(v * sc + sh, a.d.pre_slope);
+        q[ri][i] = v * m[i];                         // zero padding is applied after the transform
       }
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw)
