@@ -10,10 +10,10 @@ gradients (data parallel; weak scaling).  The step is captured once into a hipGr
 then exactly K timed replays between barrier + synchronize pairs; the slowest rank's time is used.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel family of the step, timed per launch with HIP events on the launch stream during an
-                instrumented (non-graph) pass over the same K steps; algorithmic bytes/flops from the launch's shapes.
+  roofline      dominant conv kernel of the step (by total time), timed per launch with HIP events on the launch stream
+                during an instrumented pass over the same steps; algorithmic bytes/flops from the launch's shapes.
   cpu_baseline  the CPU oracle (port of the reference path; the reference sources do not travel to the GPU box)
-                timed on the host cores on the same workload.
+                timed on a bounded number of host threads on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -27,7 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
-FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak (the conv kernels of this round are fp32-FMA bound, not MFMA)
+FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak: the fp32 (parity mode) conv kernels are FMA kernels on the VALU
+BF16_MFMA_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (MI355X_MICROARCH.md): the bf16 conv kernels are implicit GEMMs on MFMA
 
 
 def parse():
@@ -52,19 +53,21 @@ def bench_loss(seg, mu, lv, rec):
     return loss
 
 
-def cpu_baseline(size, batch, steps_budget_s=30.0):
-    """Times the CPU oracle (functional restatement of the reference path, stock torch ops, fp32) on this host."""
+def cpu_baseline(size, batch, budget_s=45.0, max_threads=16):
+    """Times the CPU oracle (functional restatement of the reference path, stock torch ops, fp32) on this host.
+    Bounded: at most `max_threads` torch threads (stock CPU conv3d stops scaling long before a 256-thread host is
+    full), one 1x4x64^3 fwd+bwd step first; the full-size step runs only if its extrapolated time fits the budget."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import xlstm_hved_oracle as O
     import xlstm_hved_amd as X
-    cores = os.cpu_count() or 1
+    cores = max(1, min(os.cpu_count() or 1, max_threads))
     torch.set_num_threads(cores)
     torch.manual_seed(1)
     model = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     model.apply(X.init_weights)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(1)
-    # bounded sample: one 1x4x64^3 warm-up, then as many full-size steps as fit the budget (at least one)
+
     def run(s):
         x = torch.rand(batch, 4, s, s, s, generator=g)
         eps = [torch.randn(batch, 2 ** l, s >> (l + 1), s >> (l + 1), s >> (l + 1), generator=g) for l in range(4)]
@@ -73,15 +76,16 @@ def cpu_baseline(size, batch, steps_budget_s=30.0):
         prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True)
         O.bench_loss(prob, mu, lv, rec).backward()
         return time.perf_counter() - t0
-    run(min(size, 64))
-    times = []
-    t_all = time.perf_counter()
-    while not times or (time.perf_counter() - t_all + times[-1] < steps_budget_s and len(times) < 3):
-        times.append(run(size))
-    best = min(times)
-    return {"value": batch * size ** 3 / best, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} fwd+bwd step(s) of {batch}x4x{size}^3 fp32 through oracle/xlstm_hved_oracle.py "
-                      f"(torch {torch.__version__} CPU ops, {cores} threads), best {best:.2f} s"}
+    small = min(size, 64)
+    run(small)                                    # untimed: thread pool + allocator warm-up
+    t_small = min(run(small), run(small))
+    used, t = small, t_small
+    if size > small and t_small * (size / small) ** 3 <= budget_s:
+        used, t = size, run(size)
+    return {"value": batch * used ** 3 / t, "unit": "voxels/s", "cores": cores, "kind": "port",
+            "sample": f"one fwd+bwd step of {batch}x4x{used}^3 fp32 through oracle/xlstm_hved_oracle.py (torch "
+                      f"{torch.__version__} CPU ops, {cores} threads of {os.cpu_count()}): {t:.2f} s"
+                      + ("" if used == size else f"; the {size}^3 step was extrapolated to exceed {budget_s:.0f} s and was not run")}
 
 
 def main():
@@ -181,60 +185,104 @@ def main():
 
 
 def roofline_pass(step, ops, nsteps, dtype):
-    """Instrumented eager pass: every xh_conv3d_fwd launch (forward convs and stride-1 data gradients: the dominant
-    kernel family) is bracketed by HIP events on torch's current stream = the launch stream.  Algorithmic work per
-    launch comes from the launch's own shapes: bytes = input + output elements x storage size (+ fp32 weights),
-    flops = 2 * out_elements * k^3 * Cin/groups."""
+    """Per-launch timing of the conv kernels inside the real step.
+
+    Every xh_conv3d_fwd (forward convs + stride-1 data gradients) and xh_conv3d_wgrad call of `nsteps` steps is
+    bracketed by HIP events on torch's current stream (= the stream the C ABI launches on).  The pass runs eagerly,
+    so each step is queued behind a ~60 ms device-side delay: the host finishes enqueueing the step while the GPU
+    waits, and the kernels then execute back to back exactly as in the hipGraph replay (without it the GPU idles
+    between launches and the clocks drop).  Launches are grouped by the kernel template instance the library
+    reports (xh_last_conv_kernel, the spelling rocprofv3 prints); the instance with the largest total time is the
+    dominant kernel.  Algorithmic work per launch comes from the launch's shapes: bytes = every input and output
+    element once at its storage size (+ fp32 weights / weight gradients), flops = 2*out_elements*k^3*Cin/groups."""
     records = []
-    orig = ops.conv3d
+    orig_fwd, orig_wg = ops.conv3d, ops.conv3d_wgrad
     esz = 2 if dtype == torch.bfloat16 else 4
 
-    def timed(xa, xb, weights, biases, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def timed_fwd(xa, xb, weights, biases, **kw):
+        e0, e1 = ev(), ev()
         e0.record()
-        y = orig(xa, xb, weights, biases, **kw)
+        y = orig_fwd(xa, xb, weights, biases, **kw)
         e1.record()
         cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
         k, groups = kw["k"], kw.get("groups", 1)
         in_el = xa.numel() + (xb.numel() if xb is not None else 0)
-        e_el = in_el if kw.get("epi", 0) == 1 and False else 0
-        if kw.get("epi", 0) == 1:
-            e_el = y.numel()
+        e_el = y.numel() if kw.get("epi", 0) == 1 else 0          # epi 1 also reads the saved activation once
         nbytes = (in_el + y.numel() + e_el) * esz + sum(w.numel() for w in weights) * 4
         flops = 2.0 * y.numel() * k ** 3 * cin / groups
-        key = f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{y.shape[1]} @{tuple(y.shape[2:])}" + (" dgrad" if kw.get("transposed") else "")
-        records.append((key, e0, e1, nbytes, flops))
+        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops))
         return y
-    ops.conv3d = timed
+
+    def timed_wg(xa, xb, dy, dws, dbs, **kw):
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = orig_wg(xa, xb, dy, dws, dbs, **kw)
+        e1.record()
+        cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
+        k, groups = kw["k"], kw.get("groups", 1)
+        in_el = xa.numel() + (xb.numel() if xb is not None else 0)
+        nbytes = (in_el + dy.numel()) * esz + sum(w.numel() for w in dws) * 4
+        flops = 2.0 * dy.numel() * k ** 3 * cin / groups
+        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops))
+        return r
+    # calibrate the spin kernel's tick rate, then use a bounded ~60 ms delay per step
+    c0, c1 = ev(), ev()
+    c0.record()
+    torch.cuda._sleep(1_000_000)
+    c1.record()
+    torch.cuda.synchronize()
+    ticks_per_ms = 1_000_000 / max(c0.elapsed_time(c1), 1e-3)
+    delay = int(min(60.0 * ticks_per_ms, 4e9))
+    ops.conv3d, ops.conv3d_wgrad = timed_fwd, timed_wg
     try:
         for _ in range(nsteps):
+            torch.cuda._sleep(delay)
             step()
         torch.cuda.synchronize()
     finally:
-        ops.conv3d = orig
+        ops.conv3d, ops.conv3d_wgrad = orig_fwd, orig_wg
     agg = {}
-    for key, e0, e1, nbytes, flops in records:
-        a = agg.setdefault(key, [0, 0.0, nbytes, flops])
+    for name, e0, e1, nbytes, flops in records:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
+        a[2] += nbytes
+        a[3] += flops
     total_ms = sum(a[1] for a in agg.values())
-    # dominant = the shape class with the largest share of conv time
-    key, (cnt, ms_sum, nbytes, flops) = max(agg.items(), key=lambda kv: kv[1][1])
-    avg_ms = ms_sum / cnt
+    name, (cnt, ms_sum, bytes_sum, flops_sum) = max(agg.items(), key=lambda kv: kv[1][1])
+    avg_ms, nbytes, flops = ms_sum / cnt, bytes_sum / cnt, flops_sum / cnt
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
     tfl = flops / (avg_ms * 1e-3) / 1e12
-    ai = flops / nbytes
-    # the class is fp32-FMA (vector ALU) bound when its arithmetic intensity exceeds peak_flops/peak_bw
-    bound = "hbm" if ai < FP32_VALU_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9) else "valu"
-    if bound == "hbm":
+    mfma = "mfma" in name
+    peak_tf = BF16_MFMA_PEAK_TFLOPS if mfma else FP32_VALU_PEAK_TFLOPS
+    # roofline: the kernel is HBM-bound when its arithmetic intensity is below peak_flops / peak_bandwidth
+    if flops / nbytes < peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
         r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
     else:
-        r = {"bound": "mfma", "achieved": tfl, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_VALU_PEAK_TFLOPS,
-             "note": "fp32 FMA on the vector ALU / f32-MFMA rate (157.3 TFLOP/s); bf16 MFMA is not used by this kernel yet"}
-    r.update({"traffic": None, "kernel": "conv_fwd_kernel (xh_conv3d_fwd) " + key, "launches_per_step": cnt // nsteps,
-              "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
-              "hbm_equiv_GBps": gbs, "share_of_conv_time": ms_sum / total_ms,
-              "timing": "HIP events on the launch stream around each launch, eager pass over the same steps"})
+        r = {"bound": "mfma", "achieved": tfl, "peak": peak_tf, "unit": "TFLOP/s", "frac": tfl / peak_tf,
+             "note": None if mfma else "fp32 FMA on the vector ALU (157.3 TFLOP/s); this instance does not use MFMA"}
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            t = json.load(f)
+        if name in t.get("kernels", {}) and t.get("dtype") == ("bf16" if esz == 2 else "fp32"):
+            traffic = t["kernels"][name]["hbm_bytes_per_launch"]
+    r.update({"traffic": traffic,
+              "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)",
+              "kernel": name, "launches_per_step": cnt / nsteps, "avg_launch_us": avg_ms * 1e3,
+              "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+              "arithmetic_intensity_flop_per_byte": flops / nbytes, "tflops": tfl,
+              "share_of_conv_time": ms_sum / total_ms, "conv_time_per_step_ms": total_ms / nsteps,
+              "other_conv_kernels": {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3,
+                                          "GBps": v[2] / v[1] / 1e6}
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:6]},
+              "timing": "HIP events on the launch stream around each launch of the real step (queued behind a device-side "
+                        "delay so launches run back to back as in the graph replay); the events also span the weight "
+                        "pre-pack / zero-fill launches the call issues"})
     return r
 
 

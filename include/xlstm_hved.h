@@ -33,6 +33,9 @@ extern "C" {
 int xh_abi_version(void);
 /* key 0: use the bf16-MFMA implicit-GEMM conv kernels where eligible (default 1); for A/B tests. */
 int xh_set_option(int key, int value);
+/* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call launched (static storage;
+ * the same spelling rocprofv3 prints), so measurements can be attributed to a kernel without a profiler attached. */
+const char* xh_last_conv_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------
  * 3D convolution family.  Replaces nn.Conv3d together with the norm/activation modules wrapped around it

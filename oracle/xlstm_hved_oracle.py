@@ -71,8 +71,12 @@ def single_conv(p, x, order="ilc", stride=1, num_groups=8):
 
 
 def double_conv(p, x, order="ilc"):
-    """buildingblocks.py:464-507 DoubleConv: two SingleConvs (channel plan lives in the weights)."""
-    return single_conv(p.sub("SingleConv2"), single_conv(p.sub("SingleConv1"), x, order), order)
+    """buildingblocks.py:464-507 DoubleConv: two SingleConvs (channel plan lives in the weights).
+    DoubleConv_ViL (buildingblocks.py:509-555) appends LeakyReLU() and a ViLLayer when its parameters are present."""
+    y = single_conv(p.sub("SingleConv2"), single_conv(p.sub("SingleConv1"), x, order), order)
+    if p.get("ViL.vil.norm.weight") is not None:
+        y = vil_layer(p.sub("ViL"), F.leaky_relu(y, LEAK))
+    return y
 
 
 def encoder(p, x, pool, order="ilc"):
@@ -303,7 +307,7 @@ def vil_layer(p, x, recurrent=False):
 # ----------------------------------------------------------------------------------------------
 def xlstm_hved_forward(sd, x, subset_idx=14, instance_missing=False, drop=None, seg=True, recon=True,
                        eps_list=None, training=True, mid_vil=True, skip_return=True, levels=4,
-                       recurrent_mlstm=False, taps=None):
+                       recurrent_mlstm=False, taps=None, order="ilc", seg_recon_decoder=True):
     """RA_HVED.py:510-648 AbstractFusion3DUNet.forward for the XLSTM_HVED flag set
     (RA_HVED.py:945-958: skip_return, mid_ViL, seg_recon_decoder, MVAE, MVAE_reduction, 'ilc').
 
@@ -329,11 +333,11 @@ def xlstm_hved_forward(sd, x, subset_idx=14, instance_missing=False, drop=None, 
             a = skip_return_attention(p.sub(f"skr_att.{levels - level}"), skip, training)   # skr_att[-level]
             tap(f"skr_att.{level}", a)
             x_list = [a * xi + xi for xi in x_list]                                 # RA_HVED.py:552
-        x_list = [encoder(p.sub(f"encoders.{level}.{i}"), x_list[i], pool=level > 0) for i in range(4)]
+        x_list = [encoder(p.sub(f"encoders.{level}.{i}"), x_list[i], pool=level > 0, order=order) for i in range(4)]
         tap(f"enc.{level}.0", x_list[0])
         mod_mu, mod_lv = [], []
         for j in range(4):
-            f = single_conv(p.sub(f"DRBs.{level}.{j}.0"), x_list[j], stride=2)      # RA_HVED.py:569
+            f = single_conv(p.sub(f"DRBs.{level}.{j}.0"), x_list[j], order, stride=2)      # RA_HVED.py:569
             L = f.shape[1] // 2
             mod_mu.append(f[:, :L])
             mod_lv.append(clip_logvar(f[:, L:]))
@@ -356,22 +360,42 @@ def xlstm_hved_forward(sd, x, subset_idx=14, instance_missing=False, drop=None, 
             if skip is None:
                 skip = F.conv3d(x, p["x0_init.0.weight"], p["x0_init.0.bias"])
             else:
-                skip = encoder(p.sub(f"skr_encoders.{levels - 1 - level}"), skip, pool=True)
+                skip = encoder(p.sub(f"skr_encoders.{levels - 1 - level}"), skip, pool=True, order=order)
     if mid_vil and skip_return:                                                     # RA_HVED.py:623-626
         v = vil_layer(p.sub("mViL"), feats[0] + skip, recurrent_mlstm)
         tap("vil", v)
         feats[0] = feats[0] + v
+    if not seg_recon_decoder:
+        # RA_HVED.py:651-687: separate ReconDecoder (RA_HVED.py:68-95) then the seg decoders (AttenModule2 + DoubleConv)
+        rout = feats[0]
+        for j in range(levels - 1):
+            skipf = feats[j + 1]
+            rout = double_conv(p.sub(f"rdecoder.multi_decoders.0.{j}.basic_module"),
+                               torch.cat([skipf, upsample_to(rout, skipf.shape[2:])], 1), order)
+        rec = F.conv3d(rout, p["rdecoder.finals.0.weight"], p["rdecoder.finals.0.bias"])
+        logits = prob = None
+        if seg:
+            sout = feats[0]
+            for j in range(levels - 1):
+                skipf = feats[j + 1]
+                dp = p.sub(f"decoders.{j}")
+                sout = double_conv(dp.sub("basic_module"),
+                                   atten_module2(dp.sub("atten_module"), upsample_to(sout, skipf.shape[2:]), skipf), order)
+                tap(f"dec.{j}", sout)
+            logits = F.conv3d(sout, p["final_conv.weight"], p["final_conv.bias"])
+            prob = torch.sigmoid(logits)
+        return prob, logits, mu_list, logvar_list, rec
     # Seg_Recon_DuSFEDecoder.forward, RA_HVED.py:158-201
     rout = sout = feats[0]
     for j in range(levels - 1):
         skipf = feats[j + 1]
         size = skipf.shape[2:]
         rd = p.sub(f"srdecoder.multi_decoders.0.{j}")
-        rout = double_conv(rd.sub("basic_module"), torch.cat([skipf, upsample_to(rout, size)], 1))
+        rout = double_conv(rd.sub("basic_module"), torch.cat([skipf, upsample_to(rout, size)], 1), order)
         if seg:
             sdp = p.sub(f"srdecoder.sdecoders.{j}")
             sout = double_conv(sdp.sub("basic_module"),
-                               atten_module2(sdp.sub("atten_module"), upsample_to(sout, size), skipf))
+                               atten_module2(sdp.sub("atten_module"), upsample_to(sout, size), skipf), order)
             tap(f"dec.{j}.pre_duse", (rout, sout))
             rout, sout = duse_attention(p.sub(f"srdecoder.dusfe_decoders.{j}"), rout, sout, training)
         tap(f"dec.{j}", (rout, sout))

@@ -18,8 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_shim  # noqa: E402
 import xlstm_hved_oracle as O  # noqa: E402
+from seeded_weights import seeded_state, entries_of  # noqa: E402
 
 torch.set_num_threads(8)
 ns = ref_shim.load_reference()
@@ -321,8 +323,92 @@ def network_cases():
     print("wrote state_dict_manifest.txt", len(names))
 
 
+VARIANTS = {
+    # tag: (reference class, ctor overrides, oracle flags)
+    # 'gcr' needs channel counts divisible by num_groups=8 (f_maps=8) and skip_return needs f_maps == 4 modalities
+    # (x0_init, RA_HVED.py:621) as does seg_recon_decoder (sfinals emits 4 channels into final_conv, RA_HVED.py:640), so
+    # 'gcr' is only reachable in the classes without either: U_HVEDConvNet3D and U_HVEDConvXLSTMNet3D.
+    "uhved_conv_gcr": ("U_HVEDConvNet3D", dict(layer_order="gcr", f_maps=8),
+                       dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False)),
+    "uhved_convxlstm_gcr": ("U_HVEDConvXLSTMNet3D", dict(layer_order="gcr", f_maps=8),
+                            dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False)),
+    "xlstm_hved_wodusfe": ("XLSTM_HVED_woDuSFE", dict(),
+                           dict(order="ilc", mid_vil=True, skip_return=True, seg_recon_decoder=False)),
+}
+
+
+def variant_cases():
+    """Secondary configurations of the same forward (RA_HVED.py:651-687 non-DuSFE decoder path, 'gcr' SingleConv order,
+    DoubleConv_ViL decoder): fp64 reference run pins the oracle; the fixture keeps weights + sampled outputs + per-parameter
+    gradient sums so the CPU suite can replay it."""
+    S = 32
+    gx = torch.Generator().manual_seed(11)
+    x = torch.rand(1, 4, S, S, S, generator=gx)
+    gi = torch.Generator().manual_seed(8)
+    idx_seg = torch.randint(0, 3 * S ** 3, (4096,), generator=gi)
+    idx_rec = torch.randint(0, 4 * S ** 3, (4096,), generator=gi)
+    orig_rep = R.reparametrize
+    for tag, (cls, over, flags) in VARIANTS.items():
+        m = ref_shim.build_reference_model(ns, seed=2, cls=cls, **over)
+        ents = entries_of(m.state_dict())
+        sd0 = seeded_state(ents, seed=5)
+        m.load_state_dict(sd0, strict=True)
+        m = m.double().train()
+        fm = over.get("f_maps", 4)
+        shapes = [(1, fm // 4 * 2 ** l, S // 2 ** (l + 1), S // 2 ** (l + 1), S // 2 ** (l + 1)) for l in range(4)]
+        torch.manual_seed(321)
+        eps = [torch.empty(s).normal_() for s in shapes]
+        _inject_eps(eps)
+        seg, (mu, lv), rec = m(x.double().clone(), [14], recon=True, valid=False)
+        R.reparametrize = orig_rep
+        rec = rec[0] if isinstance(rec, (list, tuple)) else rec
+        ws, wr = rnd(seg.shape, 300).double(), rnd(rec.shape, 301).double()
+        loss = (seg * ws).sum() + 0.1 * (rec * wr).sum()
+        for i, (a, b) in enumerate(zip(mu, lv)):
+            loss = loss + 0.05 * ((a * rnd(a.shape, 310 + i).double()).sum() + (b * rnd(b.shape, 320 + i).double()).sum())
+        loss.backward()
+        has_sr = hasattr(m, "srdecoder")
+        rg = {}
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None:
+                kk = k.replace("decoders.", "srdecoder.sdecoders.", 1) if (has_sr and k.startswith("decoders.")) else k
+                rg[kk] = p_.grad
+        # oracle, same weights/inputs
+        sd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        prob, _, omu, olv, orec = O.xlstm_hved_forward(sd, x.double().clone(), 14, eps_list=[e.double() for e in eps],
+                                                       training=True, **flags)
+        oloss = (prob * ws).sum() + 0.1 * (orec * wr).sum()
+        for i, (a, b) in enumerate(zip(omu, olv)):
+            oloss = oloss + 0.05 * ((a * rnd(a.shape, 310 + i).double()).sum() + (b * rnd(b.shape, 320 + i).double()).sum())
+        oloss.backward()
+        check(f"{tag} seg", prob, seg, 1e-9)
+        check(f"{tag} rec", orec, rec, 1e-9)
+        for i in range(4):
+            check(f"{tag} mu{i}", omu[i], mu[i], 1e-9)
+            check(f"{tag} lv{i}", olv[i], lv[i], 1e-9)
+        gscale = max(g.abs().max().item() for g in rg.values())
+        n_checked = 0
+        for k, g in rg.items():
+            og = sd[k].grad
+            assert og is not None, f"{tag}: oracle left {k} without gradient"
+            err = (og - g).abs().max().item() / gscale
+            assert err < 1e-9, f"{tag}: grad {k} deviates by {err:.2e}"
+            n_checked += 1
+        print(f"  oracle vs reference [{tag}]: outputs + {n_checked} parameter gradients agree (fp64)")
+        arrs = dict(names=np.array([e[0] for e in ents]), shapes=np.array([",".join(map(str, e[1])) for e in ents]),
+                    isfloat=np.array([e[2] for e in ents]))
+        arrs.update(x=x, idx_seg=idx_seg, idx_rec=idx_rec, seg=seg.flatten()[idx_seg], rec=rec.flatten()[idx_rec],
+                    mu3=mu[3].flatten(), lv3=lv[3].flatten(), loss=loss.detach(),
+                    gnames=np.array(list(rg.keys())), gsum=torch.stack([g.sum() for g in rg.values()]),
+                    gabs=torch.stack([g.abs().sum() for g in rg.values()]))
+        arrs.update({f"eps{i}": e for i, e in enumerate(eps)})
+        save("variant_" + tag, **arrs)
+
+
 if __name__ == "__main__":
     stage_cases()
     poe_cases()
     network_cases()
+    variant_cases()
     print("all fixtures written and certified against the oracle")

@@ -222,3 +222,71 @@ def test_direct_accumulation_into_flat_grads_matches_autograd_path():
     for k, p in m.named_parameters():
         if k in ref:
             assert (p.grad - 2 * ref[k]).abs().max().item() <= 4e-4 * gscale, k
+
+
+VARIANTS = {
+    # fixture tag: (class, ctor overrides, oracle flags)  -- tests/golden/make_golden.py VARIANTS
+    "uhved_conv_gcr": ("U_HVEDConvNet3D", dict(layer_order="gcr", f_maps=8),
+                       dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False)),
+    "uhved_convxlstm_gcr": ("U_HVEDConvXLSTMNet3D", dict(layer_order="gcr", f_maps=8),
+                            dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False)),
+    "xlstm_hved_wodusfe": ("XLSTM_HVED_woDuSFE", dict(),
+                           dict(order="ilc", mid_vil=True, skip_return=True, seg_recon_decoder=False)),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_variant_classes_fp32_vs_reference_fixture_and_oracle(tag):
+    """'gcr' SingleConv order, DoubleConv_ViL decoder and the separate recon/seg decoder path (RA_HVED.py:651-687):
+    HIP fp32 forward against the reference's fp64 outputs stored in the fixture, gradients against the fp64 oracle."""
+    from seeded_weights import seeded_state, entries_of
+    cls, over, flags = VARIANTS[tag]
+    z = np.load(f"{__import__('gpu_common').GOLDEN}/variant_{tag}.npz")
+    kw = dict(X.TRAIN_KWARGS)
+    kw.update(over)
+    m = getattr(X, cls)(1, 3, **kw)
+    ents = entries_of(m.state_dict())
+    assert [e[0] for e in ents] == [str(n) for n in z["names"]]
+    sd0 = seeded_state(ents, seed=5)
+    m.load_state_dict(sd0, strict=True)
+    m = m.to(DEV).train()
+    x = torch.from_numpy(z["x"])
+    eps = [torch.from_numpy(z[f"eps{i}"]) for i in range(4)]
+    seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps)
+    rec = rec[0] if isinstance(rec, (list, tuple)) else rec
+    e_seg = (seg.flatten().cpu().double()[z["idx_seg"]] - torch.from_numpy(z["seg"])).abs().max().item()
+    e_rec = rel_err(rec.flatten().cpu()[z["idx_rec"]], torch.from_numpy(z["rec"]))
+    e_mu = rel_err(mu[3].flatten(), torch.from_numpy(z["mu3"]))
+    print(f"{tag}: seg |d| {e_seg:.2e}  recon rel {e_rec:.2e}  mu3 rel {e_mu:.2e} (fp32 HIP vs fp64 reference)")
+    assert e_seg < 5e-3 and e_rec < 1e-3 and e_mu < 1e-3
+    loss = (seg * rnd(seg.shape, 300).to(DEV)).sum() + 0.1 * (rec * rnd(rec.shape, 301).to(DEV)).sum()
+    for i, (a, b) in enumerate(zip(mu, lv)):
+        loss = loss + 0.05 * ((a * rnd(a.shape, 310 + i).to(DEV)).sum() + (b * rnd(b.shape, 320 + i).to(DEV)).sum())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(z["loss"])) < 2e-3 * abs(float(z["loss"]))
+    # oracle gradients (fp64) on the same weights
+    sd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    sd = {k: v.requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    prob, _, omu, olv, orec = O.xlstm_hved_forward(sd, x.double(), 14, eps_list=[e.double() for e in eps], training=True, **flags)
+    ol = (prob * rnd(prob.shape, 300).double()).sum() + 0.1 * (orec * rnd(orec.shape, 301).double()).sum()
+    for i, (a, b) in enumerate(zip(omu, olv)):
+        ol = ol + 0.05 * ((a * rnd(a.shape, 310 + i).double()).sum() + (b * rnd(b.shape, 320 + i).double()).sum())
+    ol.backward()
+    gscale = max(float(np.abs(z["gabs"]).max()), 1e-30)
+    ref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    gmax = max(g.abs().max().item() for g in ref.values())
+    worst, n = 0.0, 0
+    for k, p in m.named_parameters():
+        if k.startswith("init_blocks.") and flags["order"] == "ilc":
+            continue                      # mathematically zero gradient (feeds an InstanceNorm), round-off in both
+        if k not in ref:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        err = (p.grad.cpu().double() - ref[k]).abs().max().item() / gmax
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+        n += 1
+    print(f"{tag}: worst scaled parameter-gradient deviation {worst:.2e} over {n} tensors")
+    assert n > 200

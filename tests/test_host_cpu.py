@@ -79,7 +79,7 @@ def test_unsupported_configurations_are_rejected(X):
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "xlstm_hved.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|long long)\s+(xh_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long long|const char\*)\s+(xh_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(X):
@@ -110,3 +110,22 @@ def test_product_code_never_imports_the_oracle():
 def test_subset_table(X):
     s = X.SUBSETS_MODALITIES
     assert s[:4] == [(0,), (1,), (2,), (3,)] and s[4:10] == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)] and s[14] == (0, 1, 2, 3)
+
+
+@pytest.mark.parametrize("tag,cls,over", [
+    ("uhved_conv_gcr", "U_HVEDConvNet3D", dict(layer_order="gcr", f_maps=8)),
+    ("uhved_convxlstm_gcr", "U_HVEDConvXLSTMNet3D", dict(layer_order="gcr", f_maps=8)),
+    ("xlstm_hved_wodusfe", "XLSTM_HVED_woDuSFE", dict()),
+])
+def test_variant_state_dict_matches_reference_fixture(tag, cls, over):
+    """state_dict key order and shapes of the secondary classes equal the reference's (names/shapes stored by
+    tests/golden/make_golden.py variant_cases from the real reference)."""
+    import numpy as np
+    import xlstm_hved_amd as X
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"variant_{tag}.npz"))
+    kw = dict(X.TRAIN_KWARGS)
+    kw.update(over)
+    m = getattr(X, cls)(1, 3, **kw)
+    got = [(k, ",".join(str(d) for d in v.shape)) for k, v in m.state_dict().items()]
+    want = [(str(n), str(s)) for n, s in zip(z["names"], z["shapes"])]
+    assert got == want

@@ -174,3 +174,51 @@ def test_dice_region_metric():
     tgt = torch.tensor([1.0, 1.0, 0.0, 0.0]).view(1, 1, 1, 2, 2).repeat(1, 3, 1, 1, 1)
     d = O.dice_region(prob, tgt)
     assert torch.allclose(d, torch.full((3,), (2 * 1 + 1e-6) / (4 + 1e-6)))
+
+
+# Secondary configurations (SURVEY.md section 2 variant classes that the reference can actually run):
+VARIANT_FLAGS = {
+    "uhved_conv_gcr": dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False),
+    "uhved_convxlstm_gcr": dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False),
+    "xlstm_hved_wodusfe": dict(order="ilc", mid_vil=True, skip_return=True, seg_recon_decoder=False),
+}
+
+
+def variant_state(g, dtype):
+    from seeded_weights import seeded_state
+    ents = [(str(n), tuple(int(d) for d in str(s).split(",") if d), bool(f))
+            for n, s, f in zip(g["names"], g["shapes"], g["isfloat"])]
+    sd = seeded_state(ents, seed=5)
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def load_np(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: (z[k] if z[k].dtype.kind in "US" else torch.from_numpy(z[k])) for k in z.files}
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANT_FLAGS))
+def test_variant_forward_backward_fp64(tag):
+    """gcr order / DoubleConv_ViL decoder / separate recon+seg decoders (RA_HVED.py:651-687) against the reference's fp64
+    outputs and per-parameter gradient sums."""
+    g = load_np("variant_" + tag)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in variant_state(g, torch.float64).items()}
+    eps = [g[f"eps{i}"].double() for i in range(4)]
+    prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, g["x"].double(), 14, eps_list=eps, training=True, **VARIANT_FLAGS[tag])
+    close(prob.flatten()[g["idx_seg"]], g["seg"], 1e-9, "seg")
+    close(rec.flatten()[g["idx_rec"]], g["rec"], 1e-9, "rec")
+    close(mu[3].flatten(), g["mu3"], 1e-9, "mu3"), close(lv[3].flatten(), g["lv3"], 1e-9, "lv3")
+
+    def rnd(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed)).double()
+    loss = (prob * rnd(prob.shape, 300)).sum() + 0.1 * (rec * rnd(rec.shape, 301)).sum()
+    for i, (a, b) in enumerate(zip(mu, lv)):
+        loss = loss + 0.05 * ((a * rnd(a.shape, 310 + i)).sum() + (b * rnd(b.shape, 320 + i)).sum())
+    close(loss.detach(), g["loss"], 1e-10, "loss")
+    loss.backward()
+    scale = g["gabs"].max().item()
+    for name, gsum, gabs in zip(g["gnames"], g["gsum"], g["gabs"]):
+        gr = sd[str(name)].grad
+        assert gr is not None, name
+        assert abs(gr.sum().item() - gsum.item()) <= 1e-9 * scale, name
+        assert abs(gr.abs().sum().item() - gabs.item()) <= 1e-9 * scale, name

@@ -49,6 +49,7 @@ I, F = C.c_int, C.c_float
 SIGNATURES = {
     "xh_abi_version": (I, []),
     "xh_set_option": (I, [I, I]),
+    "xh_last_conv_kernel": (C.c_char_p, []),
     "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),

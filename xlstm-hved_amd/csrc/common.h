@@ -99,5 +99,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* smem, int nwave
   __syncthreads();
 }
 
+// name of the template instance the last conv launch used (bench.py's roofline object reports it; rocprof names agree)
+void xh_note_kernel(const char* fmt, ...);
 static inline int xh_launch_status() { return hipGetLastError() == hipSuccess ? XH_OK : XH_ERR_HIP; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

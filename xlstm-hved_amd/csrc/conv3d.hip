@@ -10,6 +10,8 @@
 // The same kernel is the stride-1 data gradient (transposed=1: roles of Cin/Cout swapped and taps flipped
 // while reading the forward-layout weights) with a fused epilogue that multiplies by leaky'() of the forward
 // input's normalised value and block-reduces the two sums the InstanceNorm/BatchNorm backward needs.
+#include <cstdarg>
+#include <cstdio>
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
@@ -902,6 +904,14 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
 int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv3d_mfma.hip
 int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
 static int g_use_mfma = 1;
+static char g_last_kernel[96] = "";
+void xh_note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* xh_last_conv_kernel(void) { return g_last_kernel; }
 extern int g_mfma_abl;
 extern "C" int xh_set_option(int key, int value) {
   if (key == 0) { g_use_mfma = value; return XH_OK; }
@@ -921,6 +931,7 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
     const int r = xh_conv3_mfma_try(stream, d, p);
     if (r != 1) return r;
   }
+  xh_note_kernel("conv_fwd_kernel<%s,k%d,s%d>", d->dtype == XH_F32 ? "float" : "bf16", d->k, d->stride);
   return d->dtype == XH_F32 ? conv_fwd_dispatch<float>(stream, d, p) : conv_fwd_dispatch<bf16_t>(stream, d, p);
 }
 
@@ -1020,6 +1031,7 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
     const int r = xh_conv3_wgrad_mfma_try(stream, d, p, dw, db);
     if (r != 1) return r;
   }
+  xh_note_kernel("conv_wgrad_kernel<%s,k%d,s%d>", d->dtype == XH_F32 ? "float" : "bf16", d->k, d->stride);
   return d->dtype == XH_F32 ? wgrad_dispatch<float>(stream, d, p, dw, db) : wgrad_dispatch<bf16_t>(stream, d, p, dw, db);
 }
 

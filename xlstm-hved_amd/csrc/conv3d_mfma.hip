@@ -410,6 +410,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     else if (big) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256, 32>), grid, dim3(256), shm, st, a);             \
     else hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 32>), grid, dim3(512), shm, st, a);                      \
   } while (0)
+  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d>", a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32);
   switch (a.cinp) {
     case 4: LM(4); break;
     case 8: LM(8); break;

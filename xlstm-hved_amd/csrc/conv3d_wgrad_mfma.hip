@@ -276,6 +276,7 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
     if (big) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<C, 256>), grid, dim3(256), shm, st, a);  \
     else hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<C, 512>), grid, dim3(512), shm, st, a);      \
   } while (0)
+  xh_note_kernel("conv3_wgrad_mfma_kernel<%d, %d>", cp, big ? 256 : 512);
   switch (cp) {
     case 4: LW(4); break;
     case 8: LW(8); break;

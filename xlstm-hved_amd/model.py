@@ -221,27 +221,34 @@ class AbstractFusion3DUNet(nn.Module):
                 eps_list=None):
         """RA_HVED.py:510-648.  `eps_list` (optional, not in the reference signature) injects the reparameterisation
         noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
-        if self.layer_order != "ilc":
-            raise NotImplementedError("the stream-batched forward is built for layer_order='ilc' (the only order XLSTM_HVED runs)")
+        batched = self.layer_order == "ilc"     # 'ilc' runs the 4 modality streams as one grouped launch per stage
         n = x.shape[0]
         keep = self._keep_mask(x, subset_idx_list, instance_missing, drop)
         x = x.contiguous()
-        X = Fn.conv(x, [b[0].weight for b in self.init_blocks], [b[0].bias for b in self.init_blocks], groups=4)
+        if batched:
+            X = Fn.conv(x, [b[0].weight for b in self.init_blocks], [b[0].bias for b in self.init_blocks], groups=4)
+        else:
+            X = [Fn.conv(x[:, i:i + 1].contiguous(), [b[0].weight], [b[0].bias]) for i, b in enumerate(self.init_blocks)]
         mu_list, logvar_list, feats = [], [], []
         skip = None
         levels = len(self.encoders)
         for level in range(levels):
             if self.skip_return and skip is not None:
                 a = self.skr_att[levels - level](skip, steps=4)                             # skr_att[-level], RA_HVED.py:552
-                X = Fn.Gate.apply(X, a)
-            if level > 0:
-                X = Fn.MaxPool2.apply(X)
-            w, b = self._stream_weights(level, "SingleConv1")
-            X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
-            w, b = self._stream_weights(level, "SingleConv2")
-            X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
-            drb = [m[0].conv for m in self.DRBs[level]]
-            feat = Fn.in_lrelu_conv(X, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4)   # RA_HVED.py:569
+                X = Fn.Gate.apply(X, a) if batched else [Fn.Gate.apply(xi, a) for xi in X]
+            if batched:
+                if level > 0:
+                    X = Fn.MaxPool2.apply(X)
+                w, b = self._stream_weights(level, "SingleConv1")
+                X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
+                w, b = self._stream_weights(level, "SingleConv2")
+                X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
+                drb = [m[0].conv for m in self.DRBs[level]]
+                feat = Fn.in_lrelu_conv(X, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4)   # RA_HVED.py:569
+            else:
+                # 'gcr' (U_HVEDConvNet3D / U_HVEDConvXLSTMNet3D defaults): one stream at a time through the same HIP stages
+                X = [enc(xi) for enc, xi in zip(self.encoders[level], X)]
+                feat = torch.cat([m(xi) for m, xi in zip(self.DRBs[level], X)], 1)
             L_ = self.MVAE_latents[level]
             eps = None
             if not valid:

@@ -67,6 +67,11 @@ def set_mfma(enabled):
     L.check(L.load().xh_set_option(0, int(bool(enabled))), "xh_set_option")
 
 
+def last_conv_kernel():
+    """Template instance launched by the most recent conv3d / conv3d_wgrad call (bench.py attributes timings with it)."""
+    return L.load().xh_last_conv_kernel().decode()
+
+
 def new_like(t, shape, dtype=None):
     return torch.empty(shape, dtype=dtype or t.dtype, device=t.device)
 
