@@ -31,7 +31,9 @@ extern "C" {
 #define XH_ACT_SIGMOID 3
 
 int xh_abi_version(void);
-/* key 0: use the bf16-MFMA implicit-GEMM conv kernels where eligible (default 1); for A/B tests. */
+/* key 0: use the bf16-MFMA implicit-GEMM conv kernels where eligible (default 1); for A/B tests.
+ * key 1: MFMA kernel ablation mask (microbenchmarks only).
+ * key 2: disable mask for specialised kernels: bit 0 sliding-window depthwise conv, bit 1 exact-2x trilinear kernels. */
 int xh_set_option(int key, int value);
 /* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call launched (static storage;
  * the same spelling rocprofv3 prints), so measurements can be attributed to a kernel without a profiler attached. */

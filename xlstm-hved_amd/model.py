@@ -22,6 +22,7 @@ from torch import nn
 from . import functional as Fn
 from .blocks import (BasicConv, Decoder, DoubleConv, DoubleConv_ViL, DuSEAttention, Encoder, ProductOfExperts,
                      ProductOfExperts2, SingleConv, SkipReturnAttention, ViLLayer, number_of_features_per_level)
+from . import ops
 from .ops import ACT_SIGMOID
 
 MODALITIES = [0, 1, 2, 3]
@@ -222,6 +223,7 @@ class AbstractFusion3DUNet(nn.Module):
         """RA_HVED.py:510-648.  `eps_list` (optional, not in the reference signature) injects the reparameterisation
         noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
         batched = self.layer_order == "ilc"     # 'ilc' runs the 4 modality streams as one grouped launch per stage
+        ops.red_arena_reset(x.device)
         n = x.shape[0]
         keep = self._keep_mask(x, subset_idx_list, instance_missing, drop)
         x = x.contiguous()

@@ -76,8 +76,40 @@ def new_like(t, shape, dtype=None):
     return torch.empty(shape, dtype=dtype or t.dtype, device=t.device)
 
 
+# fp64 reduction scratch.  Every fused reduction (norm moments, norm-backward sums, gate sums) accumulates into a
+# zeroed (n, c, 2) fp64 buffer that is consumed a launch or two later inside the same autograd Function.  A step needs
+# >100 of them; handing them out of one arena that the model zeroes with ONE fill at the start of forward() replaces >100
+# tiny fill launches per step.  Without a reset (stages called on their own) the arena runs out and fresh zeros are used.
+_ARENA_DOUBLES = 1 << 19          # 4 MiB
+_ARENA = {}
+
+
+def zeros_f64(device, shape):
+    numel = 1
+    for s_ in shape:
+        numel *= int(s_)
+    a = _ARENA.get(device)
+    if a is None:
+        a = _ARENA[device] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=device), 0]
+    need = (numel + 15) & ~15
+    if a[1] + need > _ARENA_DOUBLES:
+        return torch.zeros(shape, dtype=torch.float64, device=device)
+    t = a[0][a[1]:a[1] + numel].view(shape)
+    a[1] += need
+    return t
+
+
+def red_arena_reset(device):
+    """Zeroes what has been handed out since the last reset (one fill) and starts over.  Called where no arena slice
+    is live: the start of the network's forward()."""
+    a = _ARENA.get(device)
+    if a is not None and a[1] > 0:
+        a[0][:a[1]].zero_()
+        a[1] = 0
+
+
 def zeros_red(t, n, c):
-    return torch.zeros((n, c, 2), dtype=torch.float64, device=t.device)
+    return zeros_f64(t.device, (n, c, 2))
 
 
 # ----------------------------------------------------------------------------------------------- conv
@@ -365,7 +397,7 @@ def duse_gate(x, ch, sp):
 def duse_gate_bwd(x, ch, sp, du, dsp_out):
     n, c, d, h, w, bs = _vol(x)
     dx = new_like(x, (n, c, d, h, w))
-    dch = torch.zeros((n, c), dtype=torch.float64, device=x.device)
+    dch = zeros_f64(x.device, (n, c))
     L.check(L.load().xh_duse_gate_bwd(_stream(), _dt(x), _p(x), bs, _p(ch), _p(sp), _vol(sp)[5], _p(du), _vol(du)[5], _p(dx),
                                       _vol(dx)[5], _p(dsp_out), _vol(dsp_out)[5], _p(dch), n, c, d * h * w), "xh_duse_gate_bwd")
     return dx, dch
@@ -403,7 +435,7 @@ def skr_tail(t, x, sc, sh, w2):
 def skr_tail_bwd(t, x, sc, sh, w2, a, da):
     n, c, d, h, w, _ = _vol(x)
     dtg, dx = torch.empty_like(t), torch.empty_like(x)
-    dw2 = torch.zeros(2, dtype=torch.float64, device=x.device)
+    dw2 = zeros_f64(x.device, (2,))
     L.check(L.load().xh_skr_tail_bwd(_stream(), _dt(x), _p(t), _p(x), _p(sc), _p(sh), _p(w2), _p(a), _p(da), _p(dtg), _p(dx), _p(dw2),
                                      n, c, d * h * w, 0), "xh_skr_tail_bwd")
     return dtg, dx, dw2
