@@ -213,7 +213,9 @@ def roofline_pass(step, ops, nsteps, dtype):
         e_el = y.numel() if kw.get("epi", 0) == 1 else 0          # epi 1 also reads the saved activation once
         nbytes = (in_el + y.numel() + e_el) * esz + sum(w.numel() for w in weights) * 4
         flops = 2.0 * y.numel() * k ** 3 * cin / groups
-        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops))
+        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops,
+                        f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{y.shape[1]} @{'x'.join(map(str, y.shape[2:]))}"
+                        + (" dgrad" if kw.get("transposed") else "")))
         return y
 
     def timed_wg(xa, xb, dy, dws, dbs, **kw):
@@ -226,7 +228,8 @@ def roofline_pass(step, ops, nsteps, dtype):
         in_el = xa.numel() + (xb.numel() if xb is not None else 0)
         nbytes = (in_el + dy.numel()) * esz + sum(w.numel() for w in dws) * 4
         flops = 2.0 * dy.numel() * k ** 3 * cin / groups
-        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops))
+        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops,
+                        f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{dy.shape[1]} @{'x'.join(map(str, dy.shape[2:]))} wgrad"))
         return r
     # calibrate the spin kernel's tick rate, then use a bounded ~60 ms delay per step
     c0, c1 = ev(), ev()
@@ -245,14 +248,15 @@ def roofline_pass(step, ops, nsteps, dtype):
     finally:
         ops.conv3d, ops.conv3d_wgrad = orig_fwd, orig_wg
     agg = {}
-    for name, e0, e1, nbytes, flops in records:
-        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+    for name, e0, e1, nbytes, flops, shape in records:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, {}])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += nbytes
         a[3] += flops
+        a[4][shape] = a[4].get(shape, 0) + 1
     total_ms = sum(a[1] for a in agg.values())
-    name, (cnt, ms_sum, bytes_sum, flops_sum) = max(agg.items(), key=lambda kv: kv[1][1])
+    name, (cnt, ms_sum, bytes_sum, flops_sum, shapes) = max(agg.items(), key=lambda kv: kv[1][1])
     avg_ms, nbytes, flops = ms_sum / cnt, bytes_sum / cnt, flops_sum / cnt
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
     tfl = flops / (avg_ms * 1e-3) / 1e12
@@ -274,12 +278,13 @@ def roofline_pass(step, ops, nsteps, dtype):
     r.update({"traffic": traffic,
               "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)",
               "kernel": name, "launches_per_step": cnt / nsteps, "avg_launch_us": avg_ms * 1e3,
+              "shapes": {k: v / nsteps for k, v in shapes.items()},
               "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
               "arithmetic_intensity_flop_per_byte": flops / nbytes, "tflops": tfl,
               "share_of_conv_time": ms_sum / total_ms, "conv_time_per_step_ms": total_ms / nsteps,
               "other_conv_kernels": {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3,
-                                          "GBps": v[2] / v[1] / 1e6}
-                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:6]},
+                                          "GBps": v[2] / v[1] / 1e6, "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()}}
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:8]},
               "timing": "HIP events on the launch stream around each launch of the real step (queued behind a device-side "
                         "delay so launches run back to back as in the graph replay); the events also span the weight "
                         "pre-pack / zero-fill launches the call issues"})

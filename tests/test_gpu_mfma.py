@@ -21,6 +21,9 @@ CASES = [
     dict(cin=64, cout=128, groups=4, sp=(8, 8, 16)),          # 16-wide volumes (level 3 of a 128^3 patch): TW=16 tiles
     dict(cin=16, cout=16, groups=1, sp=(6, 9, 16)),
     dict(cin=16, cout=16, groups=16, sp=(5, 8, 32)),          # depthwise: dedicated no-LDS kernel (not MFMA)
+    dict(cin=48, cout=16, groups=1, sp=(8, 8, 32), split=16), # > 24 input channels: split-K launches with fp32 partials
+    dict(cin=96, cout=32, groups=1, sp=(4, 8, 16), split=32),
+    dict(cin=28, cout=8, groups=1, sp=(4, 8, 32)),            # uneven split (16 + 12)
 ]
 
 

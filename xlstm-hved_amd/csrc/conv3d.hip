@@ -963,13 +963,17 @@ static int pick_cob(int cout_g, int maxc) {
   return c;
 }
 
+template <typename T> static const char* tname() { return sizeof(T) == 2 ? "bf16_t" : "float"; }
 #define LAUNCH_FWD(T, K, S, COB, TXN)                                                                              \
-  hipLaunchKernelGGL((conv_fwd_kernel<T, K, S, COB, TXN>), grid, dim3(256), 0, (hipStream_t)stream, a)
+  do {                                                                                                             \
+    xh_note_kernel("conv_fwd_kernel<%s, %d, %d, %d, %d>", tname<T>(), K, S, COB, TXN);                            \
+    hipLaunchKernelGGL((conv_fwd_kernel<T, K, S, COB, TXN>), grid, dim3(256), 0, (hipStream_t)stream, a);          \
+  } while (0)
 #define FWD_TXN(T, K, S, COB)                                        \
   do {                                                               \
-    if (txn == 8) LAUNCH_FWD(T, K, S, COB, 8);                       \
-    else if (txn == 4) LAUNCH_FWD(T, K, S, COB, 4);                  \
-    else LAUNCH_FWD(T, K, S, COB, 2);                                \
+    if (txn == 8) { LAUNCH_FWD(T, K, S, COB, 8); }                   \
+    else if (txn == 4) { LAUNCH_FWD(T, K, S, COB, 4); }              \
+    else { LAUNCH_FWD(T, K, S, COB, 2); }                            \
   } while (0)
 
 template <typename T>
@@ -1103,7 +1107,7 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
     const int r = xh_conv3_mfma_try(stream, d, p);
     if (r != 1) return r;
   }
-  xh_note_kernel("conv_fwd_kernel<%s,k%d,s%d>", d->dtype == XH_F32 ? "float" : "bf16", d->k, d->stride);
+  xh_note_kernel("conv k%d s%d (vector kernel family)", d->k, d->stride);
   return d->dtype == XH_F32 ? conv_fwd_dispatch<float>(stream, d, p) : conv_fwd_dispatch<bf16_t>(stream, d, p);
 }
 
@@ -1139,12 +1143,15 @@ extern "C" int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_
 }
 
 #define LAUNCH_WG(T, K, S, COB, TXN)                                                                               \
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, K, S, COB, TXN>), grid, dim3(256), 0, (hipStream_t)stream, wa)
+  do {                                                                                                             \
+    xh_note_kernel("conv_wgrad_kernel<%s, %d, %d, %d, %d>", tname<T>(), K, S, COB, TXN);                          \
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, K, S, COB, TXN>), grid, dim3(256), 0, (hipStream_t)stream, wa);       \
+  } while (0)
 #define WG_TXN(T, K, S, COB)                                        \
   do {                                                              \
-    if (txn == 8) LAUNCH_WG(T, K, S, COB, 8);                       \
-    else if (txn == 4) LAUNCH_WG(T, K, S, COB, 4);                  \
-    else LAUNCH_WG(T, K, S, COB, 2);                                \
+    if (txn == 8) { LAUNCH_WG(T, K, S, COB, 8); }                   \
+    else if (txn == 4) { LAUNCH_WG(T, K, S, COB, 4); }              \
+    else { LAUNCH_WG(T, K, S, COB, 2); }                            \
   } while (0)
 
 template <typename T>
@@ -1203,7 +1210,7 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
     const int r = xh_conv3_wgrad_mfma_try(stream, d, p, dw, db);
     if (r != 1) return r;
   }
-  xh_note_kernel("conv_wgrad_kernel<%s,k%d,s%d>", d->dtype == XH_F32 ? "float" : "bf16", d->k, d->stride);
+  xh_note_kernel("conv wgrad k%d s%d (vector kernel family)", d->k, d->stride);
   return d->dtype == XH_F32 ? wgrad_dispatch<float>(stream, d, p, dw, db) : wgrad_dispatch<bf16_t>(stream, d, p, dw, db);
 }
 

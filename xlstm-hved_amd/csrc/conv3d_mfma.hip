@@ -37,6 +37,11 @@ struct ConvMK {
   int cout_set;     // output channels per set
   int cinp, cpr, nch, nm;
   int abl;          // ablation mask for microbenchmarks (0 in production)
+  // split-K over input channels (ungrouped convs with more than 24 of them: the decoders' virtual concats).  Launch s
+  // covers channels [cin_off, cin_off + cin_blk); all but the last write fp32 partial sums to `part`, all but the first
+  // add the partials in; only the last runs the epilogue proper.
+  int nsplit, cin_off, part_in, part_out;
+  float* part;
 };
 int g_mfma_abl = 0;
 
@@ -56,7 +61,7 @@ __device__ __forceinline__ float mk_weight(const ConvMK& a, int co, int ci, int 
 __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
   const int y = blockIdx.y;
   const int set = y / a.ntile, nt = y % a.ntile;
-  const int cin0 = set * a.cin_blk;
+  const int cin0 = set * a.cin_blk + a.cin_off;
   const int co_base = set * a.cout_set + nt * 16;
   const int co_lim = min(16, a.cout_set - nt * 16);
   unsigned short* wf = (unsigned short*)a.p.ws + (long long)y * a.nm * 512;
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
     const int r9 = c / a.cpr, j = c % a.cpr;
     const int flat = j * 8 + e;                       // position inside the row segment: kw*CINP + ci
     const int kw = flat / a.cinp, ci = flat % a.cinp;
-    if (kw < 3 && ci < a.cin_blk) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
+    if (kw < 3 && ci < a.cin_blk && cin0 + ci < a.d.Cin) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
   }
   wf[idx] = f2bf(v);
 }
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
   const int y = blockIdx.y;
   const int set = y / a.ntile, nt = y % a.ntile;
   const int n = blockIdx.z;
-  const int cin0 = set * a.cin_blk;
+  const int cin0 = set * a.cin_blk + a.cin_off;
   const int co_base = set * a.cout_set + nt * 16;
   const int co_lim = min(16, a.cout_set - nt * 16);
   const int D = a.d.D, H = a.d.H, W = a.d.W;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
       const int c = cin0 + cl;
       sp_src[it][cc] = nullptr;
       sp_sc[it][cc] = 1.f; sp_sh[it][cc] = 0.f;
-      if (inb && cl < a.cin_blk) {
+      if (inb && cl < a.cin_blk && c < a.d.Cin) {
         sp_src[it][cc] = (c < a.d.Ca ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
                                      : (const bf16_t*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
                          (long long)gh * W + gw;
@@ -285,7 +290,20 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
-      if (co_ok && ech * 8 < TW && !(a.abl & 8)) {
+      if (co_ok && ech * 8 < TW && (a.part_in | a.part_out)) {          // split-K partial sums (fp32, [n][cout][dhw])
+        const long long sp = ((long long)d * Ho + oh) * Wo + ow0 + ech * 8;
+        float* pp = a.part + ((long long)n * a.d.Cout + co) * odhw + sp;
+        if (a.part_in) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 4);
+          o[0] += lo[0]; o[1] += lo[1]; o[2] += lo[2]; o[3] += lo[3];
+          o[4] += hi[0]; o[5] += hi[1]; o[6] += hi[2]; o[7] += hi[3];
+        }
+        if (a.part_out) {
+          *reinterpret_cast<f32x4*>(pp) = f32x4{o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(pp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+      }
+      if (co_ok && ech * 8 < TW && !(a.abl & 8) && !a.part_out) {
         const long long sp = ((long long)d * Ho + oh) * Wo + ow0 + ech * 8;
         float ev[8];
         if (a.d.epi == 1) {
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
       }
     }
   }
-  if (a.d.epi) {
+  if (a.d.epi && !a.part_out) {
     s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
     s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
     __syncthreads();
@@ -348,8 +366,15 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if (dhw % 8) return 1;
   int gs = 1;                                         // groups per set: as many as fit 24 input / 16 output channels
   while (gs * 2 <= d->groups && d->groups % (gs * 2) == 0 && gs * 2 * cin_g <= 24 && gs * 2 * cout_g <= 16) gs *= 2;
-  const int cin_blk = gs * cin_g;
-  if (cin_blk > 24) return 1;
+  int cin_blk = gs * cin_g;
+  a->nsplit = 1;
+  if (cin_blk > 24) {
+    if (d->groups != 1) return 1;
+    a->nsplit = cdiv(cin_blk, 24);
+    cin_blk = cdiv(cdiv(cin_blk, a->nsplit), 4) * 4;  // equal chunks, whole channel quads
+    if (cin_blk > 24 || a->nsplit > 8) return 1;
+  }
+  a->cin_off = 0; a->part_in = a->part_out = 0; a->part = nullptr;
   if (d->N > 65535) return 1;
   a->d = *d;
   a->Cin_g = cin_g; a->Cout_g = cout_g;
@@ -376,12 +401,17 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   return 0;
 }
 
+static long long pack_bytes(const xh_conv_desc* d, const ConvMK& a) {
+  const int gs = a.nsplit > 1 ? 1 : a.cin_blk / a.Cin_g;
+  return (long long)(d->groups / gs) * a.ntile * a.nm * 1024;
+}
 extern "C" long long xh_conv3d_workspace_bytes(const xh_conv_desc* d) {
   ConvMK a;
   if (!d || d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return 0;
   if (mfma_plan(d, &a)) return 0;
-  const int gs = a.cin_blk / a.Cin_g;
-  return (long long)(d->groups / gs) * a.ntile * a.nm * 1024;
+  long long need = pack_bytes(d, a) * a.nsplit;
+  if (a.nsplit > 1) need += (long long)d->N * d->Cout * d->Do * d->Ho * d->Wo * (long long)sizeof(float);
+  return need;
 }
 
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
@@ -391,14 +421,24 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const long long need = xh_conv3d_workspace_bytes(d);
   if (!p->ws || p->ws_bytes < need) return 1;
   a.p = *p;
-  const int gs = a.cin_blk / a.Cin_g;
+  const long long pb = pack_bytes(d, a);
+  const int gs = a.nsplit > 1 ? 1 : a.cin_blk / a.Cin_g;
   const int ny = (d->groups / gs) * a.ntile;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
   dim3 grid(a.tilesW * a.tilesH * a.dsegs, ny, d->N);
   const size_t shm = (size_t)4 * 10 * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 16 * 36 * sizeof(float);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
+  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d>", a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32);
+  for (int sidx = 0; sidx < a.nsplit; ++sidx) {
+  if (a.nsplit > 1) {
+    a.cin_off = sidx * a.cin_blk;
+    a.part_in = sidx > 0;
+    a.part_out = sidx + 1 < a.nsplit;
+    a.part = reinterpret_cast<float*>((char*)p->ws + pb * a.nsplit);
+    a.p.ws = (char*)p->ws + pb * sidx;
+  }
+  hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
 #define LM(C)                                                                                                   \
   do {                                                                                                          \
     static bool attr_done = false;                                                                              \
@@ -412,13 +452,13 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     else if (big) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256, 32>), grid, dim3(256), shm, st, a);             \
     else hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 32>), grid, dim3(512), shm, st, a);                      \
   } while (0)
-  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d>", a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32);
   switch (a.cinp) {
     case 4: LM(4); break;
     case 8: LM(8); break;
     case 12: LM(12); break;
     case 16: LM(16); break;
     default: LM(24);
+  }
   }
 #undef LM
   return xh_launch_status();
