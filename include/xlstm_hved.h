@@ -256,6 +256,26 @@ int xh_vil_fwd(void* stream, int dtype, const void* xa, const void* xb, void* ou
 int xh_vil_bwd(void* stream, int dtype, const void* xa, const void* xb, const void* dout, void* dxin, int B,
                int S, int C, int NH, const xh_vil_params* p, const xh_vil_grads* g, float* ws);
 
+/* ------------------------------------------------------------------------------------------------
+ * Parameter compositions (fp32, parameter-sized).  Linear stages with no non-linearity between them are applied as ONE
+ * conv with composed weights; these build the composed weights and scatter their gradients back (accumulating, +=).
+ *  - AttenModule2 (buildingblocks.py:271-274,283-296): grouped k^3 conv (E outputs per input channel) followed by a
+ *    1x1 conv to one channel, for the seg gate (NS pooled channels) and the enc gate (NE pooled channels):
+ *    w[2][NE][K3] (row 0 = seg gate, zero for channels >= NS), b[2].
+ *  - DuSEAttention (modules/DuSFE.py:129-144): conv_comb o [conv_squeeze_ch1|conv_squeeze_ch2] -> sqw[2C], sqb[1], and
+ *    conv_adjust_ch1/ch2 stacked -> adjw[2][27], adjb[2].  params/grads order: comb_w, comb_b, sq1_w, sq1_b, sq2_w, sq2_b,
+ *    adj1_w, adj1_b, adj2_w, adj2_b. */
+int xh_compose_atten_fwd(void* stream, const float* seg_w, const float* seg_b, const float* seg2_w, const float* seg2_b,
+                         const float* enc_w, const float* enc_b, const float* enc2_w, const float* enc2_b, int NS, int NE,
+                         int E, int K3, float* w, float* b);
+int xh_compose_atten_bwd(void* stream, const float* seg_w, const float* seg_b, const float* seg2_w, const float* enc_w,
+                         const float* enc_b, const float* enc2_w, int NS, int NE, int E, int K3, const float* gw,
+                         const float* gb, float* d_seg_w, float* d_seg_b, float* d_seg2_w, float* d_seg2_b, float* d_enc_w,
+                         float* d_enc_b, float* d_enc2_w, float* d_enc2_b);
+int xh_compose_duse_fwd(void* stream, const float* const params[10], int C, float* sqw, float* sqb, float* adjw, float* adjb);
+int xh_compose_duse_bwd(void* stream, const float* const params[10], int C, const float* dsqw, const float* dsqb,
+                        const float* dadjw, const float* dadjb, float* const grads[10]);
+
 #ifdef __cplusplus
 }
 #endif

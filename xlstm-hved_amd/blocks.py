@@ -174,13 +174,10 @@ class AttenModule2(nn.Module):
         self.seg_spatial2 = nn.Conv3d(self.expan * in_cha, 1, 1, stride=1)
 
     def composed(self):
-        e = self.expan
-        we = (self.enc_spatial2.weight.view(4, e, 1) * self.enc_spatial.weight.view(4, e, 343)).sum(1)      # (4,343)
-        ws = (self.seg_spatial2.weight.view(2, e, 1) * self.seg_spatial.weight.view(2, e, 343)).sum(1)      # (2,343)
-        w = torch.stack([torch.cat([ws, torch.zeros_like(ws)], 0), we], 0).view(2, 4, 7, 7, 7).contiguous()
-        bs = (self.seg_spatial2.weight.view(-1) * self.seg_spatial.bias).sum() + self.seg_spatial2.bias[0]
-        be = (self.enc_spatial2.weight.view(-1) * self.enc_spatial.bias).sum() + self.enc_spatial2.bias[0]
-        return w, torch.stack([bs, be])
+        """w (2,4,7,7,7): row 0 = seg gate over pooled channels 0,1 (rows 2,3 zero), row 1 = enc gate; b (2,)."""
+        return Fn.ComposeAtten.apply(2, 4, self.expan, self.seg_spatial.weight, self.seg_spatial.bias, self.seg_spatial2.weight,
+                                     self.seg_spatial2.bias, self.enc_spatial.weight, self.enc_spatial.bias,
+                                     self.enc_spatial2.weight, self.enc_spatial2.bias)
 
     def forward(self, seg_x, enc_x, recon_x=None):
         pooled = Fn.ChannelPool2.apply(seg_x, enc_x)
@@ -274,12 +271,10 @@ class DuSEAttention(nn.Module):
 
     def forward(self, inp_ch1, inp_ch2):
         c = inp_ch1.shape[1]
-        wc = self.conv_comb.weight.view(2)
-        sqw = torch.cat([wc[0] * self.conv_squeeze_ch1.weight.view(1, c), wc[1] * self.conv_squeeze_ch2.weight.view(1, c)], 1)
-        sqw = sqw.view(1, 2 * c, 1, 1, 1).contiguous()
-        sqb = wc[0] * self.conv_squeeze_ch1.bias + wc[1] * self.conv_squeeze_ch2.bias + self.conv_comb.bias
-        adjw = torch.cat([self.conv_adjust_ch1.weight, self.conv_adjust_ch2.weight], 0).contiguous()
-        adjb = torch.cat([self.conv_adjust_ch1.bias, self.conv_adjust_ch2.bias], 0)
+        sqw, sqb, adjw, adjb = Fn.ComposeDuSE.apply(
+            c, self.conv_comb.weight, self.conv_comb.bias, self.conv_squeeze_ch1.weight, self.conv_squeeze_ch1.bias,
+            self.conv_squeeze_ch2.weight, self.conv_squeeze_ch2.bias, self.conv_adjust_ch1.weight, self.conv_adjust_ch1.bias,
+            self.conv_adjust_ch2.weight, self.conv_adjust_ch2.bias)
         b1, b2 = self.bn_fuse_ch1, self.bn_fuse_ch2
         out = Fn.DuSE.apply(inp_ch1, inp_ch2, self.training, b1.running_mean, b1.running_var, b2.running_mean,
                             b2.running_var, self.fc_comb.weight, self.fc_comb.bias, self.fc_ch1.weight, self.fc_ch1.bias,

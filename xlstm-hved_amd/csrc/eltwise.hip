@@ -1343,3 +1343,147 @@ extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const voi
     return XH_ERR_DTYPE;
   return xh_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------- parameter compositions
+// Linear stages with no non-linearity between them are applied as one conv with composed weights.
+// The composition and its adjoint are parameter-sized: one small kernel each instead of ~40 framework launches.
+//
+// AttenModule2 (buildingblocks.py:271-296): grouped k^3 conv (groups = input channels, E outputs each) followed by a 1x1
+// conv to one channel.  w[0] = seg gate over input channels [0, NS) (the remaining NE-NS rows are zero), w[1] = enc gate
+// over all NE input channels;  w[r][ci][tap] = sum_e w2[ci*E+e] * w1[(ci*E+e)][tap],  b[r] = sum_o w2[o]*b1[o] + b2.
+struct AttenCompose {
+  const float *seg_w, *seg_b, *seg2_w, *seg2_b, *enc_w, *enc_b, *enc2_w, *enc2_b;
+  int NS, NE, E, K3;
+};
+__global__ __launch_bounds__(256) void compose_atten_fwd_kernel(AttenCompose a, float* w, float* b) {
+  const int total = 2 * a.NE * a.K3;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int tap = idx % a.K3, ci = (idx / a.K3) % a.NE, r = idx / (a.K3 * a.NE);
+    const float* w1 = r ? a.enc_w : a.seg_w;
+    const float* w2 = r ? a.enc2_w : a.seg2_w;
+    float v = 0.f;
+    if (r == 1 || ci < a.NS)
+      for (int e = 0; e < a.E; ++e) v = fmaf(w2[ci * a.E + e], w1[(long long)(ci * a.E + e) * a.K3 + tap], v);
+    w[idx] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    const int r = threadIdx.x;
+    const float* b1 = r ? a.enc_b : a.seg_b;
+    const float* w2 = r ? a.enc2_w : a.seg2_w;
+    const int no = (r ? a.NE : a.NS) * a.E;
+    float v = r ? a.enc2_b[0] : a.seg2_b[0];
+    for (int o = 0; o < no; ++o) v = fmaf(w2[o], b1[o], v);
+    b[r] = v;
+  }
+}
+struct AttenComposeGrad { float *seg_w, *seg_b, *seg2_w, *seg2_b, *enc_w, *enc_b, *enc2_w, *enc2_b; };
+// one workgroup per first-stage output channel o (seg: NS*E of them, then enc: NE*E); every gradient is accumulated (+=)
+__global__ __launch_bounds__(256) void compose_atten_bwd_kernel(AttenCompose a, AttenComposeGrad g, const float* gw,
+                                                               const float* gb) {
+  __shared__ float s_red[4];
+  const int nso = a.NS * a.E;
+  const int r = (int)blockIdx.x >= nso ? 1 : 0;
+  const int o = r ? blockIdx.x - nso : blockIdx.x;
+  const int ci = o / a.E;
+  const float* w1 = (r ? a.enc_w : a.seg_w) + (long long)o * a.K3;
+  const float w2 = (r ? a.enc2_w : a.seg2_w)[o];
+  float* dw1 = (r ? g.enc_w : g.seg_w) + (long long)o * a.K3;
+  const float* grow = gw + (long long)(r * a.NE + ci) * a.K3;
+  float acc[1] = {0.f};
+  for (int tap = threadIdx.x; tap < a.K3; tap += 256) {
+    const float gv = grow[tap];
+    dw1[tap] += w2 * gv;
+    acc[0] = fmaf(w1[tap], gv, acc[0]);
+  }
+  block_sum<1>(acc, s_red, 4);
+  if (threadIdx.x == 0) {
+    const float b1 = (r ? a.enc_b : a.seg_b)[o];
+    (r ? g.enc2_w : g.seg2_w)[o] += s_red[0] + b1 * gb[r];
+    (r ? g.enc_b : g.seg_b)[o] += w2 * gb[r];
+    if (o == 0) (r ? g.enc2_b : g.seg2_b)[0] += gb[r];
+  }
+}
+extern "C" int xh_compose_atten_fwd(void* stream, const float* seg_w, const float* seg_b, const float* seg2_w,
+                                    const float* seg2_b, const float* enc_w, const float* enc_b, const float* enc2_w,
+                                    const float* enc2_b, int NS, int NE, int E, int K3, float* w, float* b) {
+  if (!seg_w || !seg_b || !seg2_w || !seg2_b || !enc_w || !enc_b || !enc2_w || !enc2_b || !w || !b) return XH_ERR_ARG;
+  if (NS <= 0 || NE < NS || E <= 0 || K3 <= 0) return XH_ERR_ARG;
+  AttenCompose a{seg_w, seg_b, seg2_w, seg2_b, enc_w, enc_b, enc2_w, enc2_b, NS, NE, E, K3};
+  hipLaunchKernelGGL(compose_atten_fwd_kernel, dim3(cdiv(2 * NE * K3, 256)), dim3(256), 0, (hipStream_t)stream, a, w, b);
+  return xh_launch_status();
+}
+extern "C" int xh_compose_atten_bwd(void* stream, const float* seg_w, const float* seg_b, const float* seg2_w,
+                                    const float* enc_w, const float* enc_b, const float* enc2_w, int NS, int NE, int E,
+                                    int K3, const float* gw, const float* gb, float* d_seg_w, float* d_seg_b,
+                                    float* d_seg2_w, float* d_seg2_b, float* d_enc_w, float* d_enc_b, float* d_enc2_w,
+                                    float* d_enc2_b) {
+  if (!seg_w || !seg_b || !seg2_w || !enc_w || !enc_b || !enc2_w || !gw || !gb || !d_seg_w || !d_seg_b || !d_seg2_w ||
+      !d_seg2_b || !d_enc_w || !d_enc_b || !d_enc2_w || !d_enc2_b)
+    return XH_ERR_ARG;
+  if (NS <= 0 || NE < NS || E <= 0 || K3 <= 0) return XH_ERR_ARG;
+  AttenCompose a{seg_w, seg_b, seg2_w, nullptr, enc_w, enc_b, enc2_w, nullptr, NS, NE, E, K3};
+  AttenComposeGrad g{d_seg_w, d_seg_b, d_seg2_w, d_seg2_b, d_enc_w, d_enc_b, d_enc2_w, d_enc2_b};
+  hipLaunchKernelGGL(compose_atten_bwd_kernel, dim3((NS + NE) * E), dim3(256), 0, (hipStream_t)stream, a, g, gw, gb);
+  return xh_launch_status();
+}
+
+// DuSEAttention (modules/DuSFE.py:129-144): conv_comb o [conv_squeeze_ch1 | conv_squeeze_ch2] as one 2C->1 1x1 conv
+// (sqw[2C], sqb[1]) and the two 3^3 adjust convs stacked (adjw[2][27], adjb[2]).
+struct DuseCompose {
+  const float *comb_w, *comb_b, *sq1_w, *sq1_b, *sq2_w, *sq2_b, *adj1_w, *adj1_b, *adj2_w, *adj2_b;
+  int C;
+};
+__global__ __launch_bounds__(256) void compose_duse_fwd_kernel(DuseCompose a, float* sqw, float* sqb, float* adjw, float* adjb) {
+  const float w0 = a.comb_w[0], w1 = a.comb_w[1];
+  for (int j = threadIdx.x; j < 2 * a.C; j += 256) sqw[j] = j < a.C ? w0 * a.sq1_w[j] : w1 * a.sq2_w[j - a.C];
+  for (int j = threadIdx.x; j < 54; j += 256) adjw[j] = j < 27 ? a.adj1_w[j] : a.adj2_w[j - 27];
+  if (threadIdx.x == 0) {
+    sqb[0] = w0 * a.sq1_b[0] + w1 * a.sq2_b[0] + a.comb_b[0];
+    adjb[0] = a.adj1_b[0];
+    adjb[1] = a.adj2_b[0];
+  }
+}
+struct DuseComposeGrad { float *comb_w, *comb_b, *sq1_w, *sq1_b, *sq2_w, *sq2_b, *adj1_w, *adj1_b, *adj2_w, *adj2_b; };
+__global__ __launch_bounds__(256) void compose_duse_bwd_kernel(DuseCompose a, DuseComposeGrad g, const float* dsqw,
+                                                              const float* dsqb, const float* dadjw, const float* dadjb) {
+  __shared__ float s_red[4 * 2];
+  const float w0 = a.comb_w[0], w1 = a.comb_w[1];
+  float acc[2] = {0.f, 0.f};
+  for (int j = threadIdx.x; j < a.C; j += 256) {
+    g.sq1_w[j] += w0 * dsqw[j];
+    g.sq2_w[j] += w1 * dsqw[a.C + j];
+    acc[0] = fmaf(a.sq1_w[j], dsqw[j], acc[0]);
+    acc[1] = fmaf(a.sq2_w[j], dsqw[a.C + j], acc[1]);
+  }
+  for (int j = threadIdx.x; j < 27; j += 256) { g.adj1_w[j] += dadjw[j]; g.adj2_w[j] += dadjw[27 + j]; }
+  block_sum<2>(acc, s_red, 4);
+  if (threadIdx.x == 0) {
+    const float db = dsqb[0];
+    g.comb_w[0] += s_red[0] + a.sq1_b[0] * db;
+    g.comb_w[1] += s_red[1] + a.sq2_b[0] * db;
+    g.sq1_b[0] += w0 * db;
+    g.sq2_b[0] += w1 * db;
+    g.comb_b[0] += db;
+    g.adj1_b[0] += dadjb[0];
+    g.adj2_b[0] += dadjb[1];
+  }
+}
+extern "C" int xh_compose_duse_fwd(void* stream, const float* const params[10], int C, float* sqw, float* sqb, float* adjw,
+                                   float* adjb) {
+  if (!params || !sqw || !sqb || !adjw || !adjb || C <= 0) return XH_ERR_ARG;
+  for (int i = 0; i < 10; ++i)
+    if (!params[i]) return XH_ERR_ARG;
+  DuseCompose a{params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7], params[8], params[9], C};
+  hipLaunchKernelGGL(compose_duse_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, sqw, sqb, adjw, adjb);
+  return xh_launch_status();
+}
+extern "C" int xh_compose_duse_bwd(void* stream, const float* const params[10], int C, const float* dsqw, const float* dsqb,
+                                   const float* dadjw, const float* dadjb, float* const grads[10]) {
+  if (!params || !grads || !dsqw || !dsqb || !dadjw || !dadjb || C <= 0) return XH_ERR_ARG;
+  for (int i = 0; i < 10; ++i)
+    if (!params[i] || !grads[i]) return XH_ERR_ARG;
+  DuseCompose a{params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7], params[8], params[9], C};
+  DuseComposeGrad g{grads[0], grads[1], grads[2], grads[3], grads[4], grads[5], grads[6], grads[7], grads[8], grads[9]};
+  hipLaunchKernelGGL(compose_duse_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, g, dsqw, dsqb, dadjw, dadjb);
+  return xh_launch_status();
+}

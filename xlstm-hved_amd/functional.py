@@ -35,16 +35,25 @@ def _targets(params):
     (e.g. a view of parallel.FlatGrads' bucket, or last step's gradient after zero_grad(set_to_none=False)) the kernel
     adds straight into it and autograd receives None: no zero-fill, no AccumulateGrad add, and the flat bucket is ready
     for the all-reduce.  Otherwise a zeroed tensor is allocated and returned the usual way."""
-    bufs, rets = [], []
-    for p in params:
+    bufs, rets, need = [], [], []
+    for i, p in enumerate(params):
         g = p.grad if (p is not None and p.is_leaf) else None
         if DIRECT_GRADS[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape:
             bufs.append(g)
             rets.append(None)
         else:
-            z = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
-            bufs.append(z)
-            rets.append(z)
+            bufs.append(None)
+            rets.append(None)
+            need.append(i)
+    if need:                                  # one zero-fill for all of them (16-float aligned views)
+        offs, total = [], 0
+        for i in need:
+            offs.append(total)
+            total += (params[i].numel() + 15) // 16 * 16
+        flat = torch.zeros(total, dtype=torch.float32, device=params[need[0]].device)
+        for i, o in zip(need, offs):
+            z = flat[o:o + params[i].numel()].view(params[i].shape)
+            bufs[i] = rets[i] = z
     return bufs, rets
 
 
@@ -475,3 +484,43 @@ class ViL(Function):
         dxin = ops.vil_bwd(xa, xb, dout, p, ws, dict(zip(ViL.NAMES, bufs)))
         dxa = ops.add(dout, dxin) if ctx.add_xa else dxin
         return (dxa, dxin if xb is not None else None, None, *rets)
+
+
+class ComposeAtten(Function):
+    """AttenModule2's grouped 7^3 conv o 1x1 conv as ONE 7^3 conv's weights (blocks.AttenModule2.composed)."""
+
+    @staticmethod
+    def forward(ctx, ns, ne, e, *params):
+        params = tuple(t.contiguous() for t in params)
+        ctx.cfg = (ns, ne, e)
+        ctx.params = params
+        ctx.save_for_backward(*params)
+        w, b = ops.compose_atten_fwd(params, ns, ne, e)
+        k = round(w.shape[-1] ** (1.0 / 3.0))
+        return w.view(2, ne, k, k, k), b
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        ns, ne, e = ctx.cfg
+        grads, rets = _targets(ctx.params)
+        ops.compose_atten_bwd(ctx.saved_tensors, ns, ne, e, gw.contiguous(), gb.contiguous(), grads)
+        return (None, None, None, *rets)
+
+
+class ComposeDuSE(Function):
+    """DuSEAttention's conv_comb o conv_squeeze_ch{1,2} and stacked adjust convs (blocks.DuSEAttention.composed)."""
+
+    @staticmethod
+    def forward(ctx, c, *params):
+        params = tuple(t.contiguous() for t in params)
+        ctx.c = c
+        ctx.params = params
+        ctx.save_for_backward(*params)
+        return ops.compose_duse_fwd(params, c)
+
+    @staticmethod
+    def backward(ctx, dsqw, dsqb, dadjw, dadjb):
+        grads, rets = _targets(ctx.params)
+        ops.compose_duse_bwd(ctx.saved_tensors, ctx.c, dsqw.contiguous(), dsqb.contiguous(), dadjw.contiguous(),
+                             dadjb.contiguous(), grads)
+        return (None, *rets)

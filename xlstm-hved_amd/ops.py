@@ -409,6 +409,42 @@ def rank1_add(dx, d1, w, k):
     return dx
 
 
+def compose_atten_fwd(params, ns, ne, e):
+    """params: seg_w, seg_b, seg2_w, seg2_b, enc_w, enc_b, enc2_w, enc2_b (fp32, contiguous)."""
+    seg_w = params[0]
+    k3 = seg_w[0].numel()
+    w = torch.empty((2, ne, k3), dtype=torch.float32, device=seg_w.device)
+    b = torch.empty(2, dtype=torch.float32, device=seg_w.device)
+    L.check(L.load().xh_compose_atten_fwd(_stream(), *[_p(t) for t in params], ns, ne, e, k3, _p(w), _p(b)), "xh_compose_atten_fwd")
+    return w, b
+
+
+def compose_atten_bwd(params, ns, ne, e, gw, gb, grads):
+    seg_w, seg_b, seg2_w, _, enc_w, enc_b, enc2_w, _ = params
+    k3 = seg_w[0].numel()
+    L.check(L.load().xh_compose_atten_bwd(_stream(), _p(seg_w), _p(seg_b), _p(seg2_w), _p(enc_w), _p(enc_b), _p(enc2_w), ns, ne, e,
+                                          k3, _p(gw), _p(gb), *[_p(g) for g in grads]), "xh_compose_atten_bwd")
+
+
+def _ptr10(ts):
+    return (C.c_void_p * 10)(*[_p(t) for t in ts])
+
+
+def compose_duse_fwd(params, c):
+    dev = params[0].device
+    sqw = torch.empty(2 * c, dtype=torch.float32, device=dev)
+    sqb = torch.empty(1, dtype=torch.float32, device=dev)
+    adjw = torch.empty((2, 1, 3, 3, 3), dtype=torch.float32, device=dev)
+    adjb = torch.empty(2, dtype=torch.float32, device=dev)
+    L.check(L.load().xh_compose_duse_fwd(_stream(), C.byref(_ptr10(params)), c, _p(sqw), _p(sqb), _p(adjw), _p(adjb)), "xh_compose_duse_fwd")
+    return sqw.view(1, 2 * c, 1, 1, 1), sqb, adjw, adjb
+
+
+def compose_duse_bwd(params, c, dsqw, dsqb, dadjw, dadjb, grads):
+    L.check(L.load().xh_compose_duse_bwd(_stream(), C.byref(_ptr10(params)), c, _p(dsqw), _p(dsqb), _p(dadjw), _p(dadjb),
+                                         C.byref(_ptr10(grads))), "xh_compose_duse_bwd")
+
+
 def duse_fc_fwd(red_r, red_s, count, n, c, p):
     g, ch1, ch2 = (torch.empty((n, c), dtype=torch.float32, device=red_r.device) for _ in range(3))
     L.check(L.load().xh_duse_fc_fwd(_stream(), _p(red_r), _p(red_s), count, n, c, _p(p["wc"]), _p(p["bc"]), _p(p["w1"]), _p(p["b1"]),
