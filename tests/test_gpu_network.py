@@ -298,3 +298,28 @@ def test_variant_classes_fp32_vs_reference_fixture_and_oracle(tag):
         n += 1
     print(f"{tag}: worst scaled parameter-gradient deviation {worst:.2e} over {n} tensors")
     assert n > 200
+
+
+def test_two_forwards_before_one_backward_match_separate_steps():
+    """train.py:224-262 runs the generator twice (full modalities + a random subset) and back-propagates both at once;
+    nothing saved for backward by the first forward may be recycled by the second (scratch-arena lifetime)."""
+    torch.manual_seed(4)
+    x = torch.rand(1, 4, 32, 32, 32)
+    eps = [torch.randn(1, 2 ** l, 16 >> l, 16 >> l, 16 >> l) for l in range(4)]
+
+    def loss_of(m, subset):
+        seg, (mu, lv), rec = m(x.to(DEV), [subset], recon=True, eps_list=eps)
+        return (seg * seg).mean() + rec[0].abs().mean() + sum((a * a).mean() + b.mean() for a, b in zip(mu, lv))
+    m = _model(True)
+    (loss_of(m, 14) + loss_of(m, 6)).backward()
+    both = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m2 = _model(True)
+    loss_of(m2, 14).backward()
+    loss_of(m2, 6).backward()
+    sep = {k: p.grad for k, p in m2.named_parameters() if p.grad is not None}
+    assert both.keys() == sep.keys()
+    gmax = max(v.abs().max().item() for v in sep.values())
+    for k in sep:
+        if k.startswith("init_blocks."):
+            continue
+        assert (both[k] - sep[k]).abs().max().item() <= 2e-4 * gmax, k

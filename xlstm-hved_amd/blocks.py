@@ -63,9 +63,14 @@ class SingleConv(nn.Module):
         if padding != kernel_size // 2:
             raise NotImplementedError("only 'same' padding is supported")
 
-    def forward(self, x, x2=None):
+    def forward(self, x, x2=None, in_stats=None, out_stats=False):
+        """in_stats / out_stats ('ilc' only): take the input's channel sums from the producer's epilogue / also return
+        (y, sums of y) accumulated by this conv's epilogue, so chained stages skip their statistics pass."""
         if self.order == "ilc":
-            return Fn.in_lrelu_conv(x, x2, [self.conv.weight], [self.conv.bias], self.stride)
+            return Fn.in_lrelu_conv(x, x2, [self.conv.weight], [self.conv.bias], self.stride, in_stats=in_stats,
+                                    out_stats=out_stats)
+        if out_stats:
+            raise NotImplementedError("out_stats is an 'ilc' feature")
         if x2 is not None:
             x = torch.cat([x, x2], 1)
         return Fn.GnConvRelu.apply(x, self.conv.weight, self.groupnorm.weight, self.groupnorm.bias, self.num_groups, self.stride)
@@ -85,8 +90,11 @@ class DoubleConv(nn.Module):
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, 1, order, num_groups, padding=padding))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, pool_stride, order, num_groups, padding=padding))
 
-    def forward(self, x, x2=None):
-        return self.SingleConv2(self.SingleConv1(x, x2))
+    def forward(self, x, x2=None, out_stats=False):
+        if self.SingleConv1.order != "ilc":
+            return self.SingleConv2(self.SingleConv1(x, x2))
+        y1, st1 = self.SingleConv1(x, x2, out_stats=True)          # conv1's epilogue feeds conv2's InstanceNorm
+        return self.SingleConv2(y1, in_stats=st1, out_stats=out_stats)
 
 
 class DoubleConv_ViL(DoubleConv):
@@ -218,13 +226,14 @@ class Decoder(nn.Module):
         self.basic_module = basic_module(in_channels, out_channels, encoder=False, kernel_size=conv_kernel_size,
                                          order=conv_layer_order, num_groups=num_groups, padding=padding)
 
-    def forward(self, encoder_features, x, up_size=None, recon_features=None):
+    def forward(self, encoder_features, x, up_size=None, recon_features=None, out_stats=False):
+        kw = dict(out_stats=True) if out_stats else {}
         x = self.upsampling(encoder_features, x, up_size)
         if self.RSM:
-            return self.basic_module(self.atten_module(x, encoder_features))
+            return self.basic_module(self.atten_module(x, encoder_features), **kw)
         if encoder_features is not None:
-            return self.basic_module(encoder_features, x)      # virtual torch.cat((enc, x), 1)
-        return self.basic_module(x)
+            return self.basic_module(encoder_features, x, **kw)      # virtual torch.cat((enc, x), 1)
+        return self.basic_module(x, **kw)
 
 
 class ProductOfExperts(nn.Module):
@@ -269,14 +278,15 @@ class DuSEAttention(nn.Module):
         self.conv_fuse_ch2 = nn.Conv3d(c * 3, c, kernel_size=3, padding=1, bias=True)     # dead in the reference
         self.bn_fuse_ch2 = nn.BatchNorm3d(c)
 
-    def forward(self, inp_ch1, inp_ch2):
+    def forward(self, inp_ch1, inp_ch2, stats1=None, stats2=None):
+        """stats1/stats2 (optional): per-(n,c) fp64 [sum, sum of squares] of the inputs from their producers' epilogues."""
         c = inp_ch1.shape[1]
         sqw, sqb, adjw, adjb = Fn.ComposeDuSE.apply(
             c, self.conv_comb.weight, self.conv_comb.bias, self.conv_squeeze_ch1.weight, self.conv_squeeze_ch1.bias,
             self.conv_squeeze_ch2.weight, self.conv_squeeze_ch2.bias, self.conv_adjust_ch1.weight, self.conv_adjust_ch1.bias,
             self.conv_adjust_ch2.weight, self.conv_adjust_ch2.bias)
         b1, b2 = self.bn_fuse_ch1, self.bn_fuse_ch2
-        out = Fn.DuSE.apply(inp_ch1, inp_ch2, self.training, b1.running_mean, b1.running_var, b2.running_mean,
+        out = Fn.DuSE.apply(inp_ch1, inp_ch2, stats1, stats2, self.training, b1.running_mean, b1.running_var, b2.running_mean,
                             b2.running_var, self.fc_comb.weight, self.fc_comb.bias, self.fc_ch1.weight, self.fc_ch1.bias,
                             self.fc_ch2.weight, self.fc_ch2.bias, sqw, sqb, adjw, adjb, b1.weight, b1.bias, b2.weight, b2.bias)
         if self.training:

@@ -66,25 +66,36 @@ class InLreluConv(Function):
     RA_HVED.py:548-553, batched along channels)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, stride, groups, nw, *wb):
+    def forward(ctx, xa, xb, in_stats, out_stats, stride, groups, nw, *wb):
+        """in_stats: the (n, C, 2) fp64 sums [sum x, sum x^2] of xa if its producer already accumulated them in its
+        epilogue (then no moments pass is run here); out_stats: also return the same sums of the output, accumulated by
+        this conv's epilogue, for the next stage."""
         weights, biases = list(wb[:nw]), list(wb[nw:])
         n, ca = xa.shape[:2]
         cin = ca + (xb.shape[1] if xb is not None else 0)
-        red = ops.zeros_red(xa, n, cin)
-        ops.moments(xa, red, 0)
-        if xb is not None:
-            ops.moments(xb, red, ca)
+        if in_stats is not None and xb is None:
+            red = in_stats
+        else:
+            red = ops.zeros_red(xa, n, cin)
+            ops.moments(xa, red, 0)
+            if xb is not None:
+                ops.moments(xb, red, ca)
         sc, sh, mean, rstd = ops.norm_finalize(MODE_IN, red, n, cin, _dhw(xa))
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
-        y = ops.conv3d(xa, xb, weights, biases, k=k, cout=cout, stride=stride, groups=groups, pre=(sc, sh, LEAK))
+        red_y = ops.zeros_red(xa, n, cout) if out_stats else None
+        y = ops.conv3d(xa, xb, weights, biases, k=k, cout=cout, stride=stride, groups=groups, pre=(sc, sh, LEAK),
+                       epi=2 if out_stats else 0, red=red_y)
         ctx.save_for_backward(xa, xb, sc, sh, mean, rstd, *weights)
         ctx.cfg = (stride, groups, nw, k, cin, ca)
         ctx.params = (weights, biases)
+        if out_stats:
+            ctx.mark_non_differentiable(red_y)
+            return y, red_y
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dred=None):
         xa, xb, sc, sh, mean, rstd, *weights = ctx.saved_tensors
         stride, groups, nw, k, cin, ca = ctx.cfg
         dy = _blk(dy)
@@ -104,11 +115,11 @@ class InLreluConv(Function):
             dxa = ops.norm_bwd_apply(g, xa, coef, have_g=True, c0=0)
             if xb is not None:
                 dxb = ops.norm_bwd_apply(g, xb, coef, have_g=True, c0=ca)
-        return (dxa, dxb, None, None, None, *rws, *rbs)
+        return (dxa, dxb, None, None, None, None, None, *rws, *rbs)
 
 
-def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1):
-    return InLreluConv.apply(xa, xb, stride, groups, len(weights), *weights, *biases)
+def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, out_stats=False):
+    return InLreluConv.apply(xa, xb, in_stats, bool(out_stats), stride, groups, len(weights), *weights, *biases)
 
 
 class GnConvRelu(Function):
@@ -400,13 +411,19 @@ class DuSE(Function):
     stacked on the output axis."""
 
     @staticmethod
-    def forward(ctx, r, s, training, rm1, rv1, rm2, rv2, wc, bc, w1, b1, w2, b2, sqw, sqb, adjw, adjb, g1, be1, g2, be2):
+    def forward(ctx, r, s, stats_r, stats_s, training, rm1, rv1, rm2, rv2, wc, bc, w1, b1, w2, b2, sqw, sqb, adjw, adjb, g1, be1,
+                g2, be2):
         n, c = r.shape[:2]
         cnt = _dhw(r)
         mode = MODE_BN_TRAIN if training else MODE_BN_EVAL
-        red_r, red_s = ops.zeros_red(r, n, c), ops.zeros_red(r, n, c)
-        ops.moments(r, red_r)
-        ops.moments(s, red_s)
+        # the channel sums are saved for backward, so they must outlive the per-forward scratch arena: own storage
+        # (a producer conv's epilogue sums, when given, are copied instead of running a moments pass)
+        red_r = stats_r.clone() if stats_r is not None else torch.zeros((n, c, 2), dtype=torch.float64, device=r.device)
+        red_s = stats_s.clone() if stats_s is not None else torch.zeros((n, c, 2), dtype=torch.float64, device=r.device)
+        if stats_r is None:
+            ops.moments(r, red_r)
+        if stats_s is None:
+            ops.moments(s, red_s)
         fc = dict(wc=wc, bc=bc, w1=w1, b1=b1, w2=w2, b2=b2)
         gvec, ch1, ch2 = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc)
         comb = ops.conv3d(r, s, [sqw], [sqb], k=1, cout=1)
@@ -455,7 +472,7 @@ class DuSE(Function):
         sq = sqw.reshape(-1)
         ops.rank1_add(dr, dcomb, sq[:c].contiguous(), dmr)
         ops.rank1_add(ds, dcomb, sq[c:].contiguous(), dms)
-        return (dr, ds, None, None, None, None, None, *rets)
+        return (dr, ds, None, None, None, None, None, None, None, *rets)
 
 
 class ViL(Function):

@@ -90,10 +90,17 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
         rfinal = []
         for i, rdecs in enumerate(self.multi_decoders):
             for j, (rdec, feat, sdec, dusfe) in enumerate(zip(rdecs, encoders_features, self.sdecoders, self.dusfe_decoders)):
-                rout = rdec(feat, rout)
-                if seg:
-                    sout = sdec(feat, sout)
-                    rout, sout = dusfe(rout, sout)
+                fused = seg and type(rdec.basic_module) is DoubleConv and type(sdec.basic_module) is DoubleConv \
+                    and rdec.basic_module.SingleConv1.order == "ilc"
+                if fused:                  # the decoders' last convs hand their output sums to DuSE's channel squeeze
+                    rout, st_r = rdec(feat, rout, out_stats=True)
+                    sout, st_s = sdec(feat, sout, out_stats=True)
+                    rout, sout = dusfe(rout, sout, st_r, st_s)
+                else:
+                    rout = rdec(feat, rout)
+                    if seg:
+                        sout = sdec(feat, sout)
+                        rout, sout = dusfe(rout, sout)
                 level_outputs[j].append(rout)
             rfinal.append(Fn.conv(rout, [self.rfinals[i].weight], [self.rfinals[i].bias]))
         return level_outputs, rfinal, (sout if seg else None)
@@ -241,12 +248,13 @@ class AbstractFusion3DUNet(nn.Module):
             if batched:
                 if level > 0:
                     X = Fn.MaxPool2.apply(X)
+                # each conv's epilogue accumulates the channel sums the next InstanceNorm needs (no separate pass)
                 w, b = self._stream_weights(level, "SingleConv1")
-                X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
+                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, out_stats=True)
                 w, b = self._stream_weights(level, "SingleConv2")
-                X = Fn.in_lrelu_conv(X, None, w, b, 1, 4)
+                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st, out_stats=True)
                 drb = [m[0].conv for m in self.DRBs[level]]
-                feat = Fn.in_lrelu_conv(X, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4)   # RA_HVED.py:569
+                feat = Fn.in_lrelu_conv(X, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4, in_stats=st)   # RA_HVED.py:569
             else:
                 # 'gcr' (U_HVEDConvNet3D / U_HVEDConvXLSTMNet3D defaults): one stream at a time through the same HIP stages
                 X = [enc(xi) for enc, xi in zip(self.encoders[level], X)]
