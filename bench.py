@@ -6,8 +6,9 @@
 One process per GPU (for N>1 launch with torch.distributed.run; RANK/LOCAL_RANK/WORLD_SIZE are read from the
 environment).  A step = one forward + backward of XLSTM_HVED (train mode, all 4 modalities, recon=True, loss of
 SURVEY.md 8(d)) on one synthetic 1x4x128^3 patch per rank, plus for N>1 the flat RCCL all-reduce of the generator's
-gradients (data parallel; weak scaling).  The step is captured once into a hipGraph and replayed; W warm-up replays,
-then exactly K timed replays between barrier + synchronize pairs; the slowest rank's time is used.
+gradients (data parallel; weak scaling).  Forward+backward are captured once into a hipGraph and replayed (the
+all-reduce is issued eagerly after each replay, on the same stream); W warm-up steps, then exactly K timed steps
+between barrier + synchronize pairs; the slowest rank's time is used.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant conv kernel of the step (by total time), timed per launch with HIP events on the launch stream
@@ -116,10 +117,13 @@ def main():
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
     grads = X.parallel.FlatGrads(params)                       # p.grad = views of one flat fp32 bucket
 
-    def step():
+    def compute():
         grads.zero()
         seg, (mu, lv), rec = model(x, [14], recon=True)
         bench_loss(seg, mu, lv, rec[0]).backward()
+
+    def step():
+        compute()
         if world > 1:
             grads.all_reduce(world)                             # one in-place RCCL all-reduce of the bucket
 
@@ -141,8 +145,13 @@ def main():
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            step()
-    run = graph.replay if graph is not None else step
+            compute()                                           # the collective stays outside the capture
+
+    def run_graph():
+        graph.replay()
+        if world > 1:
+            grads.all_reduce(world)
+    run = run_graph if graph is not None else step
     for _ in range(args.warmup):
         run()
     sync_all()

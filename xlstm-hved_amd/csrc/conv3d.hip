@@ -470,60 +470,67 @@ __global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int 
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int COB, bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
-  constexpr int VW = 4;
-  __shared__ float s_w[128 * COB];
+  constexpr int VW = VEC ? VWT<T>::v : 4;              // 16-byte runs when the layout allows
+  constexpr int CIC = 4;                               // input channels per step: their loads are issued together
+  __shared__ float s_w[132 * COB];
   __shared__ float s_red[4 * 2 * COB];
   const int tid = threadIdx.x;
   const int cob = blockIdx.y;
   const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
   const long long dhw = (long long)a.d.D * a.d.H * a.d.W;
-  for (int idx = tid; idx < a.Cin_g * COB; idx += 256) {
+  const int cin_pad = (a.Cin_g + CIC - 1) / CIC * CIC;
+  for (int idx = tid; idx < cin_pad * COB; idx += 256) {
     const int co = idx % COB, ci_g = idx / COB, co_g = cob * COB + co;
-    s_w[idx] = co_g < a.Cout_g ? conv_weight(a, g, co_g, ci_g, 0, 1) : 0.f;
+    s_w[idx] = (co_g < a.Cout_g && ci_g < a.Cin_g) ? conv_weight(a, g, co_g, ci_g, 0, 1) : 0.f;   // pad rows: zero weight
   }
   __syncthreads();
   double s0[COB], s1[COB];
 #pragma unroll
   for (int co = 0; co < COB; ++co) { s0[co] = 0.0; s1[co] = 0.0; }
   for (long long q0 = ((long long)blockIdx.x * 256 + tid) * VW; q0 < dhw; q0 += (long long)gridDim.x * 256 * VW) {
-  const int valid = (int)min((long long)VW, dhw - q0);
-  float acc[COB][VW];
+    const int valid = (int)min((long long)VW, dhw - q0);
+    float acc[COB][VW];
 #pragma unroll
-  for (int i = 0; i < COB; ++i)
+    for (int i = 0; i < COB; ++i)
 #pragma unroll
-    for (int v = 0; v < VW; ++v) acc[i][v] = 0.f;
-  {
-    for (int ci_g = 0; ci_g < a.Cin_g; ++ci_g) {
-      const int c = g * a.Cin_g + ci_g;
-      const T* src = in_plane<T>(a, n, c, dhw) + q0;
-      float x[VW];
-      if (VEC) {
-        ld4(src, 0, x);
-      } else {
+      for (int v = 0; v < VW; ++v) acc[i][v] = 0.f;
+    for (int ci0 = 0; ci0 < a.Cin_g; ci0 += CIC) {
+      float x[CIC][VW];
 #pragma unroll
-        for (int v = 0; v < VW; ++v) x[v] = v < valid ? ldf(src, v) : 0.f;
-      }
-      if (a.d.pre) {
-        const float sc = a.p.pre_sc[n * a.d.Cin + c], sh = a.p.pre_sh[n * a.d.Cin + c];
+      for (int j = 0; j < CIC; ++j) {                  // clamped channel: always a valid address, its weight is zero
+        const int c = g * a.Cin_g + min(ci0 + j, a.Cin_g - 1);
+        const T* src = in_plane<T>(a, n, c, dhw) + q0;
+        if constexpr (VEC) {
+          ldvec(src, 0, x[j]);
+        } else {
 #pragma unroll
-        for (int v = 0; v < VW; ++v) x[v] = leaky(x[v] * sc + sh, a.d.pre_slope);
+          for (int v = 0; v < VW; ++v) x[j][v] = v < valid ? ldf(src, v) : 0.f;
+        }
       }
 #pragma unroll
-      for (int co = 0; co < COB; ++co) {
-        const float w = s_w[ci_g * COB + co];
+      for (int j = 0; j < CIC; ++j) {
+        if (a.d.pre) {
+          const int c = g * a.Cin_g + min(ci0 + j, a.Cin_g - 1);
+          const float sc = a.p.pre_sc[n * a.d.Cin + c], sh = a.p.pre_sh[n * a.d.Cin + c];
 #pragma unroll
-        for (int v = 0; v < VW; ++v) acc[co][v] = fmaf(w, x[v], acc[co][v]);
+          for (int v = 0; v < VW; ++v) x[j][v] = leaky(x[j][v] * sc + sh, a.d.pre_slope);
+        }
+#pragma unroll
+        for (int co = 0; co < COB; ++co) {
+          const float w = s_w[(ci0 + j) * COB + co];
+#pragma unroll
+          for (int v = 0; v < VW; ++v) acc[co][v] = fmaf(w, x[j][v], acc[co][v]);
+        }
       }
     }
-  }
 #pragma unroll
-  for (int co = 0; co < COB; ++co) {
-    const int co_g = cob * COB + co;
-    if (co_g < a.Cout_g) {
-      const int c = g * a.Cout_g + co_g;
-      conv_epilogue<T, VW>(a, n, c, dhw, q0, valid, conv_bias(a, g, co_g), acc[co], s0[co], s1[co]);
+    for (int co = 0; co < COB; ++co) {
+      const int co_g = cob * COB + co;
+      if (co_g < a.Cout_g) {
+        const int c = g * a.Cout_g + co_g;
+        conv_epilogue<T, VW>(a, n, c, dhw, q0, valid, conv_bias(a, g, co_g), acc[co], s0[co], s1[co]);
+      }
     }
-  }
   }
   if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
 }
@@ -834,13 +841,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK wa) {
   }
 }
 
-// k = 1 weight gradient: CIB x COB partial products per lane over a grid-strided range of 4-voxel groups
-// (16-byte fp32 / 8-byte bf16 loads when the row length allows it).
+// k = 1 weight gradient: CIB x COB partial products per lane over a grid-strided range of 16-byte runs
+// (4 fp32 / 8 bf16 voxels) when the layout allows it.
 template <typename T, int CIB, int COB, bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
   const ConvK& a = wa.c;
   constexpr int NACC = CIB * COB + COB;
-  constexpr int VW = VEC ? 4 : 1;
+  constexpr int VW = VEC ? VWT<T>::v : 1;              // 16-byte runs when the layout allows
   __shared__ float s_red[4 * NACC];
   const int tid = threadIdx.x;
   int yy = blockIdx.y;
@@ -856,40 +863,55 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
     for (int j = 0; j < COB; ++j) acc[i][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < COB; ++j) dbacc[j] = 0.f;
+  // channels past the end are clamped (always valid addresses, all loads issue together) and masked arithmetically
+  int cx[CIB], cy[COB];
+  float mx[CIB], my[COB];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i) {
+    const int ci_g = cib * CIB + i;
+    mx[i] = ci_g < a.Cin_g ? 1.f : 0.f;
+    cx[i] = g * a.Cin_g + min(ci_g, a.Cin_g - 1);
+  }
+#pragma unroll
+  for (int j = 0; j < COB; ++j) {
+    const int co_g = cob * COB + j;
+    my[j] = co_g < a.Cout_g ? 1.f : 0.f;
+    cy[j] = g * a.Cout_g + min(co_g, a.Cout_g - 1);
+  }
   const long long per_n = dhw / VW;
   const long long total = (long long)a.d.N * per_n;
   for (long long q = (long long)blockIdx.x * 256 + tid; q < total; q += (long long)gridDim.x * 256) {
     const int n = (int)(q / per_n);
     const long long sp = (q % per_n) * VW;
-    float x[CIB][4], dy[COB][4];
+    float x[CIB][VW], dy[COB][VW];
 #pragma unroll
     for (int i = 0; i < CIB; ++i) {
-      const int ci_g = cib * CIB + i;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) x[i][v] = 0.f;
-      if (ci_g < a.Cin_g) {
-        const int c = g * a.Cin_g + ci_g;
-        const T* src = in_plane<T>(a, n, c, dhw);
-        if (VEC) ld4(src, sp, x[i]); else x[i][0] = ldf(src, sp);
-        if (a.d.pre) {
-          const float sc = a.p.pre_sc[n * a.d.Cin + c], sh = a.p.pre_sh[n * a.d.Cin + c];
-#pragma unroll
-          for (int v = 0; v < VW; ++v) x[i][v] = leaky(x[i][v] * sc + sh, a.d.pre_slope);
-        }
-      }
+      const T* src = in_plane<T>(a, n, cx[i], dhw);
+      if constexpr (VEC) ldvec(src, sp, x[i]); else x[i][0] = ldf(src, sp);
     }
 #pragma unroll
     for (int j = 0; j < COB; ++j) {
-      const int co_g = cob * COB + j;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) dy[j][v] = 0.f;
-      if (co_g < a.Cout_g) {
-        const T* dp = (const T*)a.p.ea + n * a.d.ea_bs + (long long)(g * a.Cout_g + co_g) * dhw;
-        if (VEC) ld4(dp, sp, dy[j]); else dy[j][0] = ldf(dp, sp);
-      }
-#pragma unroll
-      for (int v = 0; v < VW; ++v) dbacc[j] += dy[j][v];
+      const T* dp = (const T*)a.p.ea + n * a.d.ea_bs + (long long)cy[j] * dhw;
+      if constexpr (VEC) ldvec(dp, sp, dy[j]); else dy[j][0] = ldf(dp, sp);
     }
+#pragma unroll
+    for (int i = 0; i < CIB; ++i) {
+      float sc = 1.f, sh = 0.f;
+      if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + cx[i]]; sh = a.p.pre_sh[n * a.d.Cin + cx[i]]; }
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        float xv = x[i][v];
+        if (a.d.pre) xv = leaky(xv * sc + sh, a.d.pre_slope);
+        x[i][v] = xv * mx[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < COB; ++j)
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        dy[j][v] *= my[j];
+        dbacc[j] += dy[j][v];
+      }
 #pragma unroll
     for (int i = 0; i < CIB; ++i)
 #pragma unroll
@@ -984,8 +1006,10 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     const int cob = pick_cob(cout_g, 8);
     ConvK a = make_k(d, p, cob, 8);
     const long long dhw = (long long)d->D * d->H * d->W;
-    const bool vec = (dhw % 4 == 0) && (d->xa_bs % 4 == 0) && (d->xb_bs % 4 == 0);
-    long long gx1 = (dhw + 1023) / 1024;
+    constexpr int VW1 = VWT<T>::v;
+    const bool vec = (dhw % VW1 == 0) && (d->xa_bs % VW1 == 0) && (d->xb_bs % VW1 == 0) && (d->y_bs % VW1 == 0) &&
+                     (d->epi != 1 || (d->ea_bs % VW1 == 0 && d->eb_bs % VW1 == 0));
+    long long gx1 = (dhw + 256 * VW1 - 1) / (256 * VW1);
     const long long cap1 = cdiv(2048, a.ncob * d->N * d->groups);
     if (gx1 > cap1) gx1 = cap1;
     dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
@@ -1154,6 +1178,153 @@ extern "C" int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_
     else { LAUNCH_WG(T, K, S, COB, 2); }                            \
   } while (0)
 
+// ---------------------------------------------------------------------------------------------------
+// Depthwise k = 3 weight gradient, large volumes: the same sliding window as conv_dw3_slide_kernel.  A lane owns one
+// 16-byte run of a row and marches along D; each x plane is read once (3 rows + wave-shuffle neighbours, producer
+// norm/activation applied), each dY plane once, and the 27 tap sums live in registers until one block reduction.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int TXN>
+__global__ __launch_bounds__(256) void conv_dw3_wgrad_slide_kernel(const WgradK wa, int sd) {
+  const ConvK& a = wa.c;
+  constexpr int VW = VWT<T>::v, TH = 256 / TXN;
+  __shared__ float s_red[4 * 28];
+  const int tid = threadIdx.x;
+  const int tx = tid % TXN, ty = tid / TXN;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  int t = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = t % a.tilesW; t /= a.tilesW;
+  const int th = t % a.tilesH;
+  const int ds = t / a.tilesH;
+  const int oh = th * TH + ty, ow = tw * TXN * VW + tx * VW;
+  const bool active = oh < H && ow < W;
+  const int owc = active ? ow : 0, ohc = min(oh, H - 1);
+  const int d_begin = ds * sd, d_end = min(D, d_begin + sd);
+  float sc = 1.f, sh = 0.f;
+  if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+  const T* src = in_plane<T>(a, n, c, dhw);
+  const T* dyp = (const T*)a.p.ea + n * a.d.ea_bs + (long long)c * dhw + (long long)ohc * W + owc;
+  int roff[3];
+  float rmask[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int gh = oh - 1 + kh;
+    rmask[kh] = (active && (unsigned)gh < (unsigned)H) ? 1.f : 0.f;
+    roff[kh] = min(max(gh, 0), H - 1) * W;
+  }
+  const bool multi_w = a.tilesW > 1;
+  const bool edge_l = tx == 0, edge_r = tx == TXN - 1 || ow + VW >= W;
+  const bool need_l = multi_w && edge_l && ow > 0, need_r = multi_w && edge_r && ow + VW < W;
+  const int col_l = max(ow - 1, 0), col_r = min(ow + VW, W - 1);
+  const float amask = active ? 1.f : 0.f;
+
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+  float dbs = 0.f;
+  float dyA[VW], dyB[VW], dyC[VW], dyN[VW];            // dY planes q-1, q, q+1 and the prefetched q+2
+#pragma unroll
+  for (int v = 0; v < VW; ++v) dyA[v] = dyB[v] = dyC[v] = dyN[v] = 0.f;
+  float nxt[3][VW], nhl[3] = {0.f, 0.f, 0.f}, nhr[3] = {0.f, 0.f, 0.f};
+  auto load_x = [&](int q) {
+    const T* pl = src + (long long)q * hw;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      ldvec(pl, roff[kh] + owc, nxt[kh]);
+      if (multi_w) {
+        nhl[kh] = ldf(pl, roff[kh] + col_l);
+        nhr[kh] = ldf(pl, roff[kh] + col_r);
+      }
+    }
+  };
+  auto load_dy = [&](int p, float (&o)[VW]) {           // zero outside this block's planes
+    if (p >= d_begin && p < d_end) {
+      ldvec(dyp, (long long)p * hw, o);
+#pragma unroll
+      for (int v = 0; v < VW; ++v) o[v] *= amask;
+    } else {
+#pragma unroll
+      for (int v = 0; v < VW; ++v) o[v] = 0.f;
+    }
+  };
+  // x planes q = d_begin-1 .. d_end pair with dY planes q+1 (kd=0), q (kd=1), q-1 (kd=2)
+  bool nxt_ok = d_begin - 1 >= 0;
+  if (nxt_ok) load_x(d_begin - 1);
+  load_dy(d_begin, dyC);                                // q = d_begin-1: dyA = dy[q-1] = 0, dyB = dy[q] = 0 (not ours), dyC = dy[q+1]
+  load_dy(d_begin + 1, dyN);
+  for (int q = d_begin - 1; q <= d_end; ++q) {          // block-uniform
+    float cur[3][VW], hl[3], hr[3];
+    const bool cur_ok = nxt_ok;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int v = 0; v < VW; ++v) cur[kh][v] = nxt[kh][v];
+      hl[kh] = nhl[kh];
+      hr[kh] = nhr[kh];
+    }
+    float dyQ[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) dyQ[v] = 0.f;
+    if (q + 1 <= d_end) {
+      nxt_ok = q + 1 < D;
+      if (nxt_ok) load_x(q + 1);
+      load_dy(q + 3, dyQ);                              // becomes dyN after the rotation below
+    }
+    if (cur_ok) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        float r[VW + 2];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          float x = cur[kh][v];
+          if (a.d.pre) x = leaky(x * sc + sh, a.d.pre_slope);
+          r[v + 1] = x * rmask[kh];
+        }
+        float l = __shfl_up(r[VW], 1, 64), rr = __shfl_down(r[1], 1, 64);
+        if (edge_l) {
+          float x = hl[kh];
+          if (a.d.pre) x = leaky(x * sc + sh, a.d.pre_slope);
+          l = need_l ? x * rmask[kh] : 0.f;
+        }
+        if (edge_r) {
+          float x = hr[kh];
+          if (a.d.pre) x = leaky(x * sc + sh, a.d.pre_slope);
+          rr = need_r ? x * rmask[kh] : 0.f;
+        }
+        r[0] = l;
+        r[VW + 1] = rr;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int v = 0; v < VW; ++v) {
+            s0 = fmaf(r[v + kw], dyC[v], s0);           // kd = 0: dY plane q+1
+            s1 = fmaf(r[v + kw], dyB[v], s1);           // kd = 1: dY plane q
+            s2 = fmaf(r[v + kw], dyA[v], s2);           // kd = 2: dY plane q-1
+          }
+          acc[0 * 9 + kh * 3 + kw] += s0;
+          acc[1 * 9 + kh * 3 + kw] += s1;
+          acc[2 * 9 + kh * 3 + kw] += s2;
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      dbs += dyB[v];                                     // every owned dY plane is dyB exactly once
+      dyA[v] = dyB[v]; dyB[v] = dyC[v]; dyC[v] = dyN[v]; dyN[v] = dyQ[v];
+    }
+  }
+  float v28[28];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) v28[i] = acc[i];
+  v28[27] = dbs;
+  block_sum<28>(v28, s_red, 4);
+  const int gpp = a.d.groups / a.d.n_wptr;
+  if (tid < 27) atomicAdd(&wa.dw[c / gpp][(long long)(c % gpp) * 27 + tid], s_red[tid]);
+  if (tid == 27 && wa.db[c / gpp]) atomicAdd(&wa.db[c / gpp][c % gpp], s_red[27]);
+}
+
 template <typename T>
 static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4],
                           float* const db[4]) {
@@ -1163,8 +1334,9 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
   if (d->k == 1) {
     wa.c = make_k(d, p, 4, 8);
     const long long dhw1 = (long long)d->D * d->H * d->W;
-    const bool vec = (dhw1 % 4 == 0) && (d->xa_bs % 4 == 0) && (d->xb_bs % 4 == 0) && (d->ea_bs % 4 == 0);
-    const long long total = (long long)d->N * dhw1 / (vec ? 4 : 1);
+    constexpr int VW1 = VWT<T>::v;
+    const bool vec = (dhw1 % VW1 == 0) && (d->xa_bs % VW1 == 0) && (d->xb_bs % VW1 == 0) && (d->ea_bs % VW1 == 0);
+    const long long total = (long long)d->N * dhw1 / (vec ? VW1 : 1);
     const int ny1 = cdiv(cin_g, 4) * cdiv(cout_g, 4) * d->groups;
     int gx = (int)((total + 256 * 8 - 1) / (256 * 8));
     const int cap = cdiv(2048, ny1);
@@ -1174,6 +1346,33 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
     if (vec) hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, wa);
     else hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, wa);
     return xh_launch_status();
+  }
+  if (d->k == 3 && d->stride == 1 && cin_g == 1 && cout_g == 1 && !(g_xh_disable & 1)) {
+    constexpr int VW = VWT<T>::v;
+    const long long dhw3 = (long long)d->D * d->H * d->W;
+    const bool al = d->W % VW == 0 && dhw3 % VW == 0 && d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && d->ea_bs % VW == 0;
+    if (al && d->H >= 32 && d->W >= 4 * VW && d->D >= 8 && d->Cin < 65536 && d->N < 65536) {
+      wa.c = make_k(d, p, 1, 8);
+      int txn = 4;
+      while (txn < 32 && txn * VW < d->W) txn *= 2;
+      wa.c.tilesW = cdiv(d->W, txn * VW);
+      wa.c.tilesH = cdiv(d->H, 256 / txn);
+      const int base = wa.c.tilesW * wa.c.tilesH * d->Cin * d->N;
+      int dsegs = cdiv(1024, base);
+      if (dsegs > d->D / 8) dsegs = d->D / 8;
+      if (dsegs < 1) dsegs = 1;
+      const int sd = cdiv(d->D, dsegs);
+      dsegs = cdiv(d->D, sd);
+      dim3 grid(wa.c.tilesW * wa.c.tilesH * dsegs, d->Cin, d->N);
+      xh_note_kernel("conv_dw3_wgrad_slide_kernel<%s, %d>", tname<T>(), txn);
+      switch (txn) {
+        case 4: hipLaunchKernelGGL((conv_dw3_wgrad_slide_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, wa, sd); break;
+        case 8: hipLaunchKernelGGL((conv_dw3_wgrad_slide_kernel<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, wa, sd); break;
+        case 16: hipLaunchKernelGGL((conv_dw3_wgrad_slide_kernel<T, 16>), grid, dim3(256), 0, (hipStream_t)stream, wa, sd); break;
+        default: hipLaunchKernelGGL((conv_dw3_wgrad_slide_kernel<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, wa, sd);
+      }
+      return xh_launch_status();
+    }
   }
   const int txn = pick_txn(d->Wo);
   const int cob = (d->k == 7) ? pick_cob(cout_g, 2) : pick_cob(cout_g, 4);

@@ -30,7 +30,7 @@ struct ConvMK {
   xh_conv_desc d;
   xh_conv_ptrs p;
   int Cin_g, Cout_g;
-  int tilesW, tilesH, tw;
+  int tilesW, tilesH, tw, th;
   int sd, dsegs;    // output planes per worker, number of depth segments
   int cin_blk;      // input channels staged per block (<= CINP)
   int ntile;        // 16-wide output tiles per set
@@ -85,10 +85,10 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
 // bijection inside each 128-byte block, so fragment reads apply the same function.
 __device__ __forceinline__ int swz(int off) { return off ^ (((off >> 8) & 7) << 4); }
 
-template <int CINP, int NT, int TW>
-__global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
+template <int CINP, int NT, int TW, int TH = 8>
+__global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const ConvMK a) {
   constexpr int NWV = NT / 64;
-  constexpr int TH = 8, NSEG = TW / 16;
+  constexpr int NSEG = TW / 16;
   constexpr int IH = TH + 2;
   constexpr int IWP = TW + 4;                         // halo (2) + 2 spare columns for the over-reading tail chunk
   constexpr int VB = CINP * 2;                        // bytes per voxel in LDS
@@ -238,27 +238,33 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
     }
   };
 
-  // ---- prologue: planes d_begin-1 and d_begin into the ring, d_begin+1 in flight ----
+  // ---- prologue: planes d_begin-1, d_begin, d_begin+1 into the ring ----
   load_plane(d_begin - 1);
   store_plane(d_begin - 1);
   load_plane(d_begin);
   store_plane(d_begin);
   load_plane(d_begin + 1);
+  store_plane(d_begin + 1);
+  __syncthreads();
 
+  constexpr int RPW = (TH + NWV - 1) / NWV;           // output rows per wave
   for (int d = d_begin; d < d_end; ++d) {
-    store_plane(d + 1);
-    __syncthreads();                                  // plane d+1 visible; everyone finished computing plane d-1
-    if (d + 1 < d_end) load_plane(d + 2);             // lands while the matrix cores work on plane d
+    // Order inside a plane: (1) issue the global loads of plane d+2, (2) MFMA pass over this wave's rows, (3) the loads
+    // have landed: transform + LDS-write plane d+2 into the slot nobody reads, (4) epilogue: transpose, global stores,
+    // (5) barrier.  The stores are the last memory operations of the iteration, so the only vmcnt wait (step 3 of the
+    // NEXT plane) finds them long drained instead of stalling every plane on their acknowledgement.
+    const bool more = d + 1 < d_end;
+    if (more) load_plane(d + 2);
     const int sbase = d + 3;                          // slot of input plane d-1+kd = (sbase + kd) & 3
-    for (int rr = wv; rr < TH; rr += NWV) {
-      const int oh = oh0 + rr;
-      if (oh >= Ho) continue;                         // wave-uniform
-      f32x4 acc[NSEG];
+    f32x4 accs[RPW][NSEG];
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) {
+      const int rr = wv + ri * NWV;
 #pragma unroll
       for (int wt = 0; wt < NSEG; ++wt) {
         const int rowoff = (rr * IWP + wt * 16) * VB;
-        acc[wt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(a.abl & 4))
+        accs[ri][wt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rr < TH && oh0 + rr < Ho && !(a.abl & 4))   // wave-uniform
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
           const int ao = ((sbase + akd[i]) & 3) * PLANE + rowoff + aoff[i];
@@ -271,9 +277,17 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
             const uint4 q4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
             av = __builtin_bit_cast(bf16x8, q4);
           }
-          acc[wt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bfrag[i], acc[wt], 0, 0, 0);
+          accs[ri][wt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bfrag[i], accs[ri][wt], 0, 0, 0);
         }
       }
+    }
+    if (more) store_plane(d + 2);
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) {
+      const int rr = wv + ri * NWV;
+      const int oh = oh0 + rr;
+      if (rr >= TH || oh >= Ho) continue;             // wave-uniform
+      f32x4 (&acc)[NSEG] = accs[ri];
       if (a.abl & 32) continue;
       // ---- transpose through the wave-private pad: [cout nn][voxel wt*16 + 4*g4 + r] ----
 #pragma unroll
@@ -339,6 +353,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_mfma_kernel(const ConvMK a) {
         *reinterpret_cast<uint4*>(yplane + sp) = pk;
       }
     }
+    __syncthreads();                                  // plane d+2 visible; everyone is done reading planes d-1..d+1
   }
   if (a.d.epi && !a.part_out) {
     s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
@@ -379,7 +394,10 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   a->d = *d;
   a->Cin_g = cin_g; a->Cout_g = cout_g;
   a->tw = (d->W % 32 == 0) ? 32 : 16;
-  a->tilesW = d->W / a->tw; a->tilesH = cdiv(d->Ho, 8);
+  // 4-row tiles (ablation bit 64): 37 KB of LDS per workgroup -> 3 resident workgroups per CU instead of 2
+  // (measured: 158 us vs 103 us for 16->16 @128^3 -- the per-plane fixed work per workgroup dominates -- so not used)
+  a->th = (g_mfma_abl & 64) ? 4 : 8;
+  a->tilesW = d->W / a->tw; a->tilesH = cdiv(d->Ho, a->th);
   a->cin_blk = cin_blk;
   a->cout_set = gs * cout_g;
   a->ntile = cdiv(a->cout_set, 16);
@@ -392,7 +410,7 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if (ny > 65535) return 1;
   // depth segments: enough workers for ~2 resident workgroups per CU, but runs of at least 4 planes
   const int cols = a->tilesW * a->tilesH;
-  int dsegs = cdiv(512, cols * ny * d->N);
+  int dsegs = cdiv(a->th == 4 ? 1024 : 512, cols * ny * d->N);
   const int max_segs = d->Do >= 4 ? d->Do / 4 : 1;
   if (dsegs > max_segs) dsegs = max_segs;
   if (dsegs < 1) dsegs = 1;
@@ -426,10 +444,10 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const int ny = (d->groups / gs) * a.ntile;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(a.tilesW * a.tilesH * a.dsegs, ny, d->N);
-  const size_t shm = (size_t)4 * 10 * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 16 * 36 * sizeof(float);
+  const size_t shm = (size_t)4 * (a.th + 2) * (a.tw + 4) * a.cinp * 2 + (size_t)(a.th == 4 ? 4 : 8) * 16 * 36 * sizeof(float);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
-  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d>", a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32);
+  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d, %d>", a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32, a.th);
   for (int sidx = 0; sidx < a.nsplit; ++sidx) {
   if (a.nsplit > 1) {
     a.cin_off = sidx * a.cin_blk;
@@ -449,6 +467,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
       attr_done = true;                                                                                         \
     }                                                                                                           \
     if (a.tw == 16) hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 16>), grid, dim3(512), shm, st, a);           \
+    else if (a.th == 4) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256, 32, 4>), grid, dim3(256), shm, st, a);    \
     else if (big) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256, 32>), grid, dim3(256), shm, st, a);             \
     else hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 32>), grid, dim3(512), shm, st, a);                      \
   } while (0)
