@@ -33,7 +33,8 @@ extern "C" {
 int xh_abi_version(void);
 /* key 0: use the bf16-MFMA implicit-GEMM conv kernels where eligible (default 1); for A/B tests.
  * key 1: MFMA kernel ablation mask (microbenchmarks only).
- * key 2: disable mask for specialised kernels: bit 0 sliding-window depthwise conv, bit 1 exact-2x trilinear kernels. */
+ * key 2: disable mask for specialised kernels: bit 0 sliding-window depthwise conv (+wgrad), bit 1 exact-2x trilinear
+ *        kernels, bit 2 vectorised stride-2 conv forward / data gradient. */
 int xh_set_option(int key, int value);
 /* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call launched (static storage;
  * the same spelling rocprofv3 prints), so measurements can be attributed to a kernel without a profiler attached. */

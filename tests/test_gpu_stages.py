@@ -170,7 +170,10 @@ def test_upsample_arbitrary_size_is_adjoint_consistent():
 
 @pytest.mark.parametrize("cfg", [dict(cin=4, cout=4, sp=(12, 20, 36), groups=1), dict(cin=16, cout=32, sp=(8, 8, 8), groups=4),
                                  dict(cin=48, cout=16, sp=(4, 6, 10), groups=1, split=16), dict(cin=8, cout=16, sp=(16, 16, 16), groups=4, stride=2),
-                                 dict(cin=12, cout=4, sp=(9, 7, 5), groups=1, split=4)])
+                                 dict(cin=12, cout=4, sp=(9, 7, 5), groups=1, split=4),
+                                 dict(cin=16, cout=8, sp=(8, 12, 32), groups=4, stride=2),     # vectorised stride-2 fwd / dgrad
+                                 dict(cin=4, cout=6, sp=(6, 4, 64), groups=1, stride=2),
+                                 dict(cin=4, cout=4, sp=(7, 9, 10), groups=1, stride=2)])      # odd sizes: gather kernels
 def test_in_lrelu_conv_shapes_vs_oracle(cfg):
     """Ragged / grouped / virtual-concat / strided shapes of the fused IN->LeakyReLU->conv stage vs stock ops."""
     torch.manual_seed(7)

@@ -606,6 +606,89 @@ __global__ __launch_bounds__(256) void conv3_s2_gather_kernel(const ConvK a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k = 3, stride = 2 forward, vectorised: a lane produces VW/2 consecutive outputs of one row from 16-byte input runs
+// (input columns 2*ow0 .. 2*ow0+VW-1; the one column to the left comes from the neighbouring lane by wave shuffle),
+// i.e. 9 wide loads per input channel instead of 27 two-byte ones per output.  Lanes of a wave tile whole rows.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int COB>
+__global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW) {
+  constexpr int VW = VWT<T>::v, OW = VW / 2;
+  extern __shared__ float s_dyn[];                    // [Cin_g][27][COB] weights, then reduction scratch
+  float* s_w = s_dyn;
+  float* s_red = s_dyn + a.Cin_g * 27 * COB;
+  const int tid = threadIdx.x;
+  const int cob = blockIdx.y;
+  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  for (int idx = tid; idx < a.Cin_g * 27 * COB; idx += 256) {
+    const int co = idx % COB;
+    const int r = idx / COB;
+    const int tap = r % 27, ci_g = r / 27;
+    const int co_g = cob * COB + co;
+    s_w[idx] = co_g < a.Cout_g ? conv_weight(a, g, co_g, ci_g, tap, 27) : 0.f;
+  }
+  __syncthreads();
+  const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  const long long lane_id = (long long)blockIdx.x * 256 + tid;
+  const int tx = (int)(lane_id % LW);
+  const long long row = lane_id / LW;
+  const bool ok = row < (long long)Do * Ho;
+  const int oh = (int)(row % Ho), od = (int)min(row / Ho, (long long)Do - 1);
+  const int ow0 = tx * OW;
+  float acc[COB][OW];
+#pragma unroll
+  for (int i = 0; i < COB; ++i)
+#pragma unroll
+    for (int j = 0; j < OW; ++j) acc[i][j] = 0.f;
+  for (int ci_g = 0; ci_g < a.Cin_g; ++ci_g) {
+    const int c = g * a.Cin_g + ci_g;
+    const T* src = in_plane<T>(a, n, c, dhw) + 2 * ow0;
+    float sc = 1.f, sh = 0.f;
+    if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+    float x[9][VW], m[9];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {                // clamped rows: always valid addresses, masked below
+        const int gd = 2 * od - 1 + kd, gh = 2 * oh - 1 + kh;
+        m[kd * 3 + kh] = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) ? 1.f : 0.f;
+        ldvec(src, ((long long)min(max(gd, 0), D - 1) * H + min(max(gh, 0), H - 1)) * W, x[kd * 3 + kh]);
+      }
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9) {
+      float r[VW + 1];
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        float xv = x[r9][v];
+        if (a.d.pre) xv = leaky(xv * sc + sh, a.d.pre_slope);
+        r[v + 1] = xv * m[r9];                        // zero padding after the transform
+      }
+      const float l = __shfl_up(r[VW], 1, 64);
+      r[0] = tx == 0 ? 0.f : l;                       // column -1 of the volume is padding
+      const float* wr = s_w + (ci_g * 27 + r9 * 3) * COB;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int co = 0; co < COB; ++co) {
+          const float w = wr[kw * COB + co];
+#pragma unroll
+          for (int j = 0; j < OW; ++j) acc[co][j] = fmaf(w, r[2 * j + kw], acc[co][j]);
+        }
+    }
+  }
+  double s0[COB], s1[COB];
+#pragma unroll
+  for (int co = 0; co < COB; ++co) {
+    s0[co] = 0.0; s1[co] = 0.0;
+    const int co_g = cob * COB + co;
+    if (co_g < a.Cout_g && ok)
+      conv_epilogue<T, OW>(a, n, g * a.Cout_g + co_g, odhw, ((long long)od * Ho + oh) * Wo + ow0, OW, conv_bias(a, g, co_g),
+                           acc[co], s0[co], s1[co]);
+  }
+  if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k = 3, stride = 2 data gradient (DRB).  One lane per forward-input voxel, CIB input channels per lane;
 // gathers the <= 8 contributing output voxels per tap parity.  Small tensors only (latent resolution).
 // ---------------------------------------------------------------------------------------------------
@@ -1079,6 +1162,24 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     dim3 grid((unsigned)((odhw + 255) / 256), a.ncob, d->N * d->groups);
     const size_t shm = ((size_t)cin_g * 27 * cob + 4 * 2 * cob) * sizeof(float);
     if (shm > 60 * 1024) return XH_ERR_ARG;
+    {
+      constexpr int VW = VWT<T>::v;
+      const int lw = d->W / VW;
+      const long long dhw2 = (long long)d->D * d->H * d->W;
+      const bool al = d->W % VW == 0 && d->Wo * 2 == d->W && lw >= 1 && lw <= 64 && (64 % lw) == 0 && dhw2 % VW == 0 &&
+                      d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && !(g_xh_disable & 4);
+      if (al) {
+        const long long lanes = (long long)d->Do * d->Ho * lw;
+        dim3 gridv((unsigned)((lanes + 255) / 256), a.ncob, d->N * d->groups);
+        xh_note_kernel("conv3_s2_vec_kernel<%s, %d>", tname<T>(), cob);
+        switch (cob) {
+          case 2: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 2>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw); break;
+          case 4: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 4>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw); break;
+          default: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 8>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw);
+        }
+        return xh_launch_status();
+      }
+    }
     switch (cob) {
       case 2: hipLaunchKernelGGL((conv3_s2_gather_kernel<T, 2>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
       case 4: hipLaunchKernelGGL((conv3_s2_gather_kernel<T, 4>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
@@ -1135,6 +1236,139 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
   return d->dtype == XH_F32 ? conv_fwd_dispatch<float>(stream, d, p) : conv_fwd_dispatch<bf16_t>(stream, d, p);
 }
 
+__device__ __forceinline__ void ldhalf_c(const float* p, float (&o)[2]) {
+  const float2 t = *reinterpret_cast<const float2*>(p); o[0] = t.x; o[1] = t.y;
+}
+__device__ __forceinline__ void ldhalf_c(const bf16_t* p, float (&o)[4]) { ld4(p, 0, o); }
+
+// ---------------------------------------------------------------------------------------------------
+// k = 3, stride = 2 data gradient, vectorised.  A lane produces one 16-byte run of dX (VW voxels of one row, CIB input
+// channels).  Along each axis an input voxel v receives tap k from output (v+1-k)/2 when v+1-k is even: an even voxel
+// only tap 1, an odd voxel taps 0 and 2.  Workgroups are sorted by the (d, h) parity class of their rows, so the tap
+// set is uniform per workgroup; along W the VW voxels of a lane need dY columns c0 .. c0+VW/2 (one VW/2-wide load +
+// the next lane's first column by wave shuffle).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int CIB>
+__global__ __launch_bounds__(256) void conv3_dgrad_s2_vec_kernel(const ConvK a, int LW, int rows_per_class) {
+  constexpr int VW = VWT<T>::v, OW = VW / 2;
+  extern __shared__ float s_dyn[];   // [Cout_g][CIB][27] weights + reduction scratch
+  float* s_w = s_dyn;
+  float* s_red = s_dyn + a.Cout_g * CIB * 27;
+  const int tid = threadIdx.x;
+  const int cib = blockIdx.y;
+  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const float* wp = a.p.w[g / gpp];
+  const int gl = g % gpp;
+  for (int idx = tid; idx < a.Cout_g * CIB * 27; idx += 256) {
+    const int tap = idx % 27;
+    const int r = idx / 27;
+    const int ci = r % CIB, co_g = r / CIB;
+    const int ci_g = cib * CIB + ci;
+    s_w[idx] = ci_g < a.Cin_g ? wp[((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * 27 + tap] : 0.f;
+  }
+  __syncthreads();
+  const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  const int blocks_per_class = gridDim.x / 4;
+  const int cls = blockIdx.x / blocks_per_class;                        // (d & 1) * 2 + (h & 1)
+  const int pd = cls >> 1, ph = cls & 1;
+  const long long lane_id = (long long)(blockIdx.x % blocks_per_class) * 256 + tid;
+  const int tx = (int)(lane_id % LW);
+  const long long row = lane_id / LW;
+  const int HH = (H - ph + 1) / 2, DD = (D - pd + 1) / 2;               // rows of this parity along H and D
+  const bool ok = row < (long long)DD * HH;
+  const int hh = (int)(row % max(HH, 1)), dd = (int)min(row / max(HH, 1), (long long)max(DD - 1, 0));
+  const int d_ = 2 * dd + pd, h_ = 2 * hh + ph;
+  const int w0 = tx * VW, c0 = tx * OW;
+  // taps per axis: even -> {1}; odd -> {0, 2}.  output index = (v + 1 - k) / 2
+  const int nkd = pd ? 2 : 1, nkh = ph ? 2 : 1;
+  float acc[CIB][VW];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i)
+#pragma unroll
+    for (int v = 0; v < VW; ++v) acc[i][v] = 0.f;
+  for (int td = 0; td < nkd; ++td) {                                    // block-uniform trip counts
+    const int kd = pd ? 2 * td : 1;
+    const int od = (d_ + 1 - kd) >> 1;
+    const float md = (od >= 0 && od < Do) ? 1.f : 0.f;
+    for (int th = 0; th < nkh; ++th) {
+      const int kh = ph ? 2 * th : 1;
+      const int oh = (h_ + 1 - kh) >> 1;
+      const float m = (oh >= 0 && oh < Ho && ok) ? md : 0.f;
+      const long long osp = ((long long)min(max(od, 0), Do - 1) * Ho + min(max(oh, 0), Ho - 1)) * Wo + c0;
+      const int tap0 = (kd * 3 + kh) * 3;
+      for (int co_g = 0; co_g < a.Cout_g; ++co_g) {
+        const T* dyr = (const T*)a.p.xa + n * a.d.xa_bs + (long long)(g * a.Cout_g + co_g) * odhw + osp;
+        float dv[OW + 1];
+        {
+          float t[OW];
+          ldhalf_c(dyr, t);
+#pragma unroll
+          for (int j = 0; j < OW; ++j) dv[j] = t[j] * m;
+        }
+        const float nx = __shfl_down(dv[0], 1, 64);
+        dv[OW] = (tx == LW - 1) ? 0.f : nx;                             // column Wo is outside the volume
+        const float* wr = s_w + co_g * CIB * 27 + tap0;
+#pragma unroll
+        for (int ci = 0; ci < CIB; ++ci) {
+          const float w0_ = wr[ci * 27 + 0], w1_ = wr[ci * 27 + 1], w2_ = wr[ci * 27 + 2];
+#pragma unroll
+          for (int j = 0; j < OW; ++j) {
+            acc[ci][2 * j] = fmaf(w1_, dv[j], acc[ci][2 * j]);                                   // even voxel: kw = 1
+            acc[ci][2 * j + 1] = fmaf(w0_, dv[j + 1], fmaf(w2_, dv[j], acc[ci][2 * j + 1]));     // odd: kw = 0 and 2
+          }
+        }
+      }
+    }
+  }
+  // epilogue: output channels are forward-input channels; epi sc/sh arrays are [N][Cin]
+  double s0[CIB], s1[CIB];
+  const long long q = ((long long)d_ * H + h_) * W + w0;
+#pragma unroll
+  for (int ci = 0; ci < CIB; ++ci) {
+    s0[ci] = 0.0; s1[ci] = 0.0;
+    const int ci_g = cib * CIB + ci;
+    if (ci_g < a.Cin_g && ok) {
+      const int c = g * a.Cin_g + ci_g;
+      T* yp = (T*)a.p.y + n * a.d.y_bs + (long long)c * dhw + q;
+      float o[VW];
+#pragma unroll
+      for (int v = 0; v < VW; ++v) o[v] = acc[ci][v];
+      if (a.d.epi == 1) {
+        const float esc = a.p.e_sc[n * a.d.Cin + c], esh = a.p.e_sh[n * a.d.Cin + c];
+        const T* ep = (c < a.d.Cea ? (const T*)a.p.ea + n * a.d.ea_bs + (long long)c * dhw
+                                   : (const T*)a.p.eb + n * a.d.eb_bs + (long long)(c - a.d.Cea) * dhw);
+        float ev[VW];
+        ldvec(ep, q, ev);
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          o[v] = rnd_as(yp, o[v] * ((ev[v] * esc + esh) > 0.f ? 1.f : a.d.e_slope));
+          t0 += o[v];
+          t1 += o[v] * ev[v];
+        }
+        s0[ci] = t0;
+        s1[ci] = t1;
+      }
+      stvec(yp, 0, o);
+    }
+  }
+  if (a.d.epi == 1) {
+    float v[2 * CIB];
+#pragma unroll
+    for (int i = 0; i < CIB; ++i) { v[2 * i] = (float)s0[i]; v[2 * i + 1] = (float)s1[i]; }
+    block_sum<2 * CIB>(v, s_red, 4);
+    if (tid < 2 * CIB) {
+      const int ci_g = cib * CIB + (tid >> 1);
+      if (ci_g < a.Cin_g) {
+        const int c = g * a.Cin_g + ci_g;
+        atomicAdd(&a.p.red[((long long)n * a.d.Cin + c) * 2 + (tid & 1)], (double)s_red[tid]);
+      }
+    }
+  }
+}
+
 template <typename T>
 static int dgrad_s2_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
@@ -1144,6 +1378,25 @@ static int dgrad_s2_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
   dim3 grid((unsigned)((dhw + 255) / 256), cdiv(cin_g, cib), d->N * d->groups);
   const size_t shm = ((size_t)cout_g * cib * 27 + 4 * 2 * cib) * sizeof(float);
   if (shm > 64 * 1024) return XH_ERR_ARG;
+  {
+    constexpr int VW = VWT<T>::v;
+    const int lw = d->W / VW;
+    const bool al = d->W % VW == 0 && d->Wo * 2 == d->W && d->D % 2 == 0 && d->H % 2 == 0 && lw >= 1 && lw <= 64 &&
+                    (64 % lw) == 0 && dhw % VW == 0 && d->xa_bs % (VW / 2) == 0 && d->y_bs % VW == 0 &&
+                    ((long long)d->Do * d->Ho * d->Wo) % (VW / 2) == 0 &&
+                    (d->epi != 1 || (d->ea_bs % VW == 0 && d->eb_bs % VW == 0)) && !(g_xh_disable & 4);
+    if (al) {
+      const long long rows = (long long)(d->D / 2) * (d->H / 2);        // per (d, h) parity class
+      const int bpc = (int)((rows * lw + 255) / 256);
+      dim3 gridv(4 * bpc, cdiv(cin_g, cib), d->N * d->groups);
+      switch (cib) {
+        case 1: hipLaunchKernelGGL((conv3_dgrad_s2_vec_kernel<T, 1>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw, (int)rows); break;
+        case 2: hipLaunchKernelGGL((conv3_dgrad_s2_vec_kernel<T, 2>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw, (int)rows); break;
+        default: hipLaunchKernelGGL((conv3_dgrad_s2_vec_kernel<T, 4>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw, (int)rows);
+      }
+      return xh_launch_status();
+    }
+  }
   switch (cib) {
     case 1: hipLaunchKernelGGL((conv3_dgrad_s2_kernel<T, 1>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
     case 2: hipLaunchKernelGGL((conv3_dgrad_s2_kernel<T, 2>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
