@@ -51,7 +51,9 @@ if __name__ == "__main__":
                   f"({nbytes / res[True] / 1e3:.0f} GB/s algorithmic, {flops / res[True] / 1e6:.1f} TFLOP/s useful)")
 
 if "--wgrad" in sys.argv:
-    for (cin, cout, g, S) in [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (16, 32, 4, 64), (24, 8, 1, 64), (8, 8, 1, 64)]:
+    caps = [(0, "cp<=16")] + ([(128, "cp<=8"), (256, "cp=4")] if "--cp" in sys.argv else [])
+    for (cin, cout, g, S) in [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (16, 32, 4, 64), (24, 8, 1, 64), (8, 8, 1, 64),
+                              (16, 16, 1, 32), (48, 16, 1, 32), (32, 32, 4, 32)]:
         x = torch.randn(1, cin, S, S, S, device="cuda").bfloat16()
         dy = torch.randn(1, cout, S, S, S, device="cuda").bfloat16()
         sc = torch.rand(1, cin, device="cuda") + 0.5; sh = torch.randn(1, cin, device="cuda")
@@ -64,4 +66,9 @@ if "--wgrad" in sys.argv:
             res[mfma] = bench(call)
         ops.set_mfma(True)
         flops = 2 * cout * S ** 3 * 27 * cin / g
-        print(f"wgrad {cin}->{cout} g{g} @{S}^3: vector {res[False]:.1f} us, mfma {res[True]:.1f} us ({flops / res[True] / 1e6:.1f} TFLOP/s useful)")
+        extra = ""
+        for mask, nm in caps[1:]:
+            L.load().xh_set_option(1, mask)
+            extra += f", {nm}: {bench(call):.1f} us"
+        L.load().xh_set_option(1, 0)
+        print(f"wgrad {cin}->{cout} g{g} @{S}^3: vector {res[False]:.1f} us, mfma {res[True]:.1f} us ({flops / res[True] / 1e6:.1f} TFLOP/s useful){extra}")

@@ -248,7 +248,16 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   a.gs = gs;
   a.cin_set = gs * cin_g;
   a.cout_set = gs * cout_g;
-  const int cp = a.cin_set <= 4 ? 4 : a.cin_set <= 8 ? 8 : 16;
+  // Input channels per workgroup.  4 wins at every shape of this network (measured, tools/microbench_conv.py --wgrad
+  // --cp): 4x more workgroups on the small volumes (16->16 @32^3: 27 us vs 87 us with 16) and a 4x smaller LDS
+  // reduction + atomics tail per workgroup, for 36 instead of 27 MFMAs per 16 channels.  Wider tiles stay selectable
+  // for experiments (xh_set_option(1, 128 | 256)).
+  int cp = 4;
+  {
+    extern int g_mfma_abl;
+    if ((g_mfma_abl & 128) && a.cin_set > 4) cp = 8;
+    if ((g_mfma_abl & 256) && a.cin_set > 8) cp = 16;
+  }
   a.ntile = cdiv(a.cout_set, 16);
   a.nctile = cdiv(a.cin_set, cp);
   const int ny = (d->groups / gs) * a.ntile * a.nctile;
