@@ -67,3 +67,39 @@ def test_mfma_conv_forward_backward(cfg):
     gmax = max(w.grad.abs().max() for w in wo)
     for a, b in zip(dw1 + db1, [w.grad for w in wo] + [b.grad for b in bo]):
         assert l2_err(a, b) < 3e-2 or (a - b).abs().max() < 2e-2 * gmax
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 12, 20, 32), (2, 4, 9, 16, 64), (1, 4, 5, 7, 32)])
+def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape):
+    """AttenModule2's composed 7^3 conv (4 pooled channels -> 2 sigmoid gates) and its data gradient (2 -> 4) on the
+    Toeplitz-in-H MFMA kernel, against the vector kernel and stock fp32 ops on the same bf16-representable input."""
+    torch.manual_seed(3)
+    x = torch.randn(shape).bfloat16()
+    w = torch.randn(2, 4, 7, 7, 7) * 0.05
+    b = torch.randn(2) * 0.1
+    g = torch.randn((shape[0], 2) + shape[2:])
+
+    def run(mfma):
+        X.ops.set_mfma(mfma)
+        try:
+            xg = x.to(DEV).requires_grad_(True)
+            wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+            y = X.functional.conv(xg, [wg], [bg], act=X.ops.ACT_SIGMOID)
+            name = X.ops.last_conv_kernel()
+            (y.float() * g.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().float().cpu(), xg.grad.float().cpu(), wg.grad.cpu(), bg.grad.cpu(), name
+        finally:
+            X.ops.set_mfma(True)
+    y1, dx1, dw1, db1, name1 = run(True)
+    y0, dx0, dw0, db0, name0 = run(False)
+    assert "conv7_mfma_kernel" in name1 and "conv7_mfma_kernel" not in name0
+    xo, wo, bo = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = torch.sigmoid(torch.nn.functional.conv3d(xo, wo, bo, padding=3))
+    (yo * g).sum().backward()
+    e = dict(y_vs_stock=l2_err(y1, yo), y_vs_vector=l2_err(y1, y0), dx_vs_stock=l2_err(dx1, xo.grad), dx_vs_vector=l2_err(dx1, dx0),
+             dw_vs_stock=l2_err(dw1, wo.grad), db_vs_stock=l2_err(db1, bo.grad))
+    print(shape, {k: f"{v:.2e}" for k, v in e.items()})
+    assert e["y_vs_stock"] < 8e-3 and e["y_vs_vector"] < 8e-3, e
+    assert e["dx_vs_stock"] < 2e-2 and e["dx_vs_vector"] < 2e-2, e
+    assert e["dw_vs_stock"] < 2e-2 and e["db_vs_stock"] < 2e-2, e

@@ -26,7 +26,8 @@ def bench(fn, n=20, reps=5):
 
 if __name__ == "__main__":
     abl = "--abl" in sys.argv
-    shapes = [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (16, 32, 4, 64), (24, 8, 1, 64), (8, 8, 1, 64)]
+    shapes = [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (16, 32, 4, 64), (24, 8, 1, 64), (8, 8, 1, 64),
+              (16, 16, 1, 32), (48, 16, 1, 32), (32, 32, 4, 32)]
     for (cin, cout, g, S) in shapes[:2] if abl else shapes:
         x = torch.randn(1, cin, S, S, S, device="cuda").bfloat16()
         ws = [torch.randn(cout // g, cin // g, 3, 3, 3, device="cuda") * 0.1 for _ in range(g)]
@@ -47,8 +48,13 @@ if __name__ == "__main__":
                 ops.set_mfma(mfma)
                 res[mfma] = bench(call)
             ops.set_mfma(True)
+            extra = ""
+            if "--th4" in sys.argv:
+                L.load().xh_set_option(1, 64)
+                extra = f", 4-row tiles: {bench(call):.1f} us"
+                L.load().xh_set_option(1, 0)
             print(f"{cin}->{cout} g{g} @{S}^3: vector {res[False]:.1f} us, mfma {res[True]:.1f} us "
-                  f"({nbytes / res[True] / 1e3:.0f} GB/s algorithmic, {flops / res[True] / 1e6:.1f} TFLOP/s useful)")
+                  f"({nbytes / res[True] / 1e3:.0f} GB/s algorithmic, {flops / res[True] / 1e6:.1f} TFLOP/s useful){extra}")
 
 if "--wgrad" in sys.argv:
     caps = [(0, "cp<=16")] + ([(128, "cp<=8"), (256, "cp=4")] if "--cp" in sys.argv else [])

@@ -1,0 +1,236 @@
+// bf16-MFMA 7x7x7 stride-1 convolution for the AttenModule2 gate convs (buildingblocks.py:271-296 after composition:
+// 4 pooled channels -> 2 gates forward, 2 -> 4 data gradient), bf16 storage, fp32 accumulation.
+//
+// With only 2 (4) output channels a plain implicit GEMM wastes 14 (12) of the 16 MFMA columns.  Here the N dimension
+// carries OUTPUT ROWS as well: for one input row rr of the halo tile and one depth tap kd
+//
+//     D[16 voxels along W][(j, co)] += A[16 voxels][(kw, ci)] * B[(kw, ci)][(j, co)],   B = W[co][ci][kd][kh = rr - j][kw]
+//
+// i.e. the weight matrix is Toeplitz in H: input row rr feeds output row j through tap kh = rr - j (zero outside 0..6).
+// N = JR rows x CO channels = 16 exactly (JR = 8 for CO = 2, 4 for CO = 4); K = 8 kw slots (7 used) x CI channels, and
+// for CI = 2 two depth taps share one MFMA so K is 32 either way.  MFMAs per output voxel drop 4x against channel
+// padding, and the accumulator layout (lane = 4 consecutive voxels of one (row, channel)) stores straight to NCDHW.
+//
+//  * input planes: channels-last in LDS ([row][w][CI] bf16), ring of 8 slots, sliding along D like the 3x3x3 kernel
+//    (one new plane per output plane, loaded to registers behind the MFMAs, written to the slot nobody reads);
+//  * B fragments: a 8 KB LDS table [kd][kh (+1 zero row)][k-group][co] built by the workgroup from the fp32 weights;
+//    every lane indexes it with its own kh = rr - j, one 16-byte read per (kd, rr), shared by the wave's two M tiles;
+//  * a workgroup is 2 waves (one JR-row tile each) on a 32-wide column: 62 KB of LDS, two workgroups per CU.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Conv7K {
+  xh_conv_desc d;
+  xh_conv_ptrs p;
+  int tilesW, tilesH, sd, dsegs;
+};
+
+template <int CI, int CO>
+__global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
+  constexpr int PPM = 32 / (8 * CI);                  // depth taps per MFMA (1 for CI = 4, 2 for CI = 2)
+  constexpr int NKD = (7 + PPM - 1) / PPM;            // MFMA steps along kd
+  constexpr int JR = 16 / CO;                         // output rows per N tile
+  constexpr int RT = 2;                               // row tiles per workgroup (one per wave)
+  constexpr int TW = 32, MT = 2;                      // tile width, M tiles per wave
+  constexpr int IH = RT * JR + 6, IWP = TW + 8;       // halo tile rows / columns (38 used + 2 for the kw = 7 over-read)
+  constexpr int VB = CI * 2;                          // bytes per voxel in LDS
+  constexpr int PLANE = IH * IWP * VB;
+  constexpr int NG = TW / 8 + 2;                      // aligned 8-voxel groups covering [ow0 - 8, ow0 + TW + 8)
+  constexpr int NITEM = IH * NG, NIT = (NITEM + 127) / 128;
+  constexpr int GS = 4 / PPM;                         // k-groups per depth tap (4 or 2)
+  constexpr int TBL = 8 * 8 * GS * CO * 16;           // B table bytes: [kd 8][kh 8][gslot][co] x 16 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_in = smem;                         // 8 * PLANE
+  unsigned char* s_tb = smem + 8 * PLANE;             // TBL
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g4 = lane >> 4, nn = lane & 15;
+  const int n = blockIdx.z;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH;
+  const int ds = wk / a.tilesH;
+  const int oh0 = th * (RT * JR), ow0 = tw * TW;
+  const int d_begin = ds * a.sd, d_end = min(D, d_begin + a.sd);
+
+  // ---- B table: entry (kd, kh, gslot, co) = 8 bf16: element e -> (kw, ci) of the k-group ----
+  {
+    const float* wp = a.p.w[0];
+    for (int idx = tid; idx < 8 * 8 * GS * CO * 8; idx += 128) {
+      const int e = idx & 7;
+      int r = idx >> 3;
+      const int co = r % CO; r /= CO;
+      const int gs = r % GS; r /= GS;
+      const int kh = r & 7, kd = r >> 3;
+      const int kw = gs * (8 / CI) + e / CI, ci = e % CI;
+      float v = 0.f;
+      if (kd < 7 && kh < 7 && kw < 7) {
+        const int tap = (kd * 7 + kh) * 7 + kw;
+        v = a.d.transposed ? wp[((long long)ci * CO + co) * 343 + (342 - tap)] : wp[((long long)co * CI + ci) * 343 + tap];
+      }
+      reinterpret_cast<unsigned short*>(s_tb)[idx] = f2bf(v);
+    }
+  }
+  // lane roles: N column nn = (j, co); this lane's B row offset for (kd step, rr) and A offsets
+  const int jn = nn / CO, con = nn % CO;
+  const int kd_l = PPM == 1 ? 0 : (g4 >> 1);          // which of the step's depth taps this lane's k-group belongs to
+  const int gs_l = PPM == 1 ? g4 : (g4 & 1);
+  const int a_col = PPM == 1 ? 2 * g4 : 4 * (g4 & 1); // first voxel (kw) of this lane's k-group
+  float bias = 0.f;
+  if (a.p.b[0]) bias = a.p.b[0][con];
+
+  // ---- staging plan ----
+  const bf16_t* sp_src[NIT][CI];
+  int sp_lds[NIT], sp_gq[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + it * 128;
+    const int gi = item % NG, hy = item / NG;
+    const int gq = gi - 1;
+    const int gh = oh0 - 3 + hy, gw = ow0 + gq * 8;
+    const bool inb = item < NITEM && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+    sp_gq[it] = item < NITEM ? gq : 100;
+    sp_lds[it] = hy * IWP * VB;
+#pragma unroll
+    for (int c = 0; c < CI; ++c)
+      sp_src[it][c] = inb ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw + (long long)gh * W + gw : nullptr;
+  }
+  uint4 raw[NIT][CI];
+  auto load_plane = [&](int gd) {
+    const bool dok = (unsigned)gd < (unsigned)D;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        raw[it][c] = make_uint4(0, 0, 0, 0);
+        if (dok && sp_src[it][c]) raw[it][c] = *reinterpret_cast<const uint4*>(sp_src[it][c] + (long long)gd * hw);
+      }
+  };
+  auto store_plane = [&](int gd) {
+    const int slot = ((gd + 8) & 7) * PLANE;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      unsigned short v[CI][8];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const unsigned u[4] = {raw[it][c].x, raw[it][c].y, raw[it][c].z, raw[it][c].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[c][2 * k] = (unsigned short)(u[k] & 0xffffu); v[c][2 * k + 1] = (unsigned short)(u[k] >> 16); }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int col = sp_gq[it] * 8 + k + 3;        // tile column of voxel gw + k (column 0 = ow0 - 3)
+        if (col >= 0 && col < IWP) {
+          unsigned char* dst = s_in + slot + sp_lds[it] + col * VB;
+          if (CI == 4) {
+            uint2 pk;
+            pk.x = (unsigned)v[0][k] | ((unsigned)v[1][k] << 16);
+            pk.y = (unsigned)v[2][k] | ((unsigned)v[3][k] << 16);
+            *reinterpret_cast<uint2*>(dst) = pk;
+          } else {
+            *reinterpret_cast<unsigned*>(dst) = (unsigned)v[0][k] | ((unsigned)v[1][k] << 16);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- prologue: input planes d_begin-3 .. d_begin+3 ----
+  for (int q = d_begin - 3; q <= d_begin + 3; ++q) {
+    load_plane(q);
+    store_plane(q);
+  }
+  __syncthreads();
+
+  bf16_t* ybase = (bf16_t*)a.p.y + n * a.d.y_bs + (long long)con * dhw;
+  for (int d = d_begin; d < d_end; ++d) {
+    const bool more = d + 1 < d_end;
+    if (more) load_plane(d + 4);                      // lands behind the MFMAs
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < NKD; ++ks) {
+      const int kd = ks * PPM + kd_l;                 // this lane's depth tap; kd = 7 is the dummy half of the last step:
+      const int kda = kd < 7 ? kd : 6;                // zero weights, and a resident (finite) plane to multiply them with
+      const unsigned char* pl = s_in + ((d + kda - 3 + 8) & 7) * PLANE;
+      const unsigned char* tb = s_tb + ((kd * 8) * GS + gs_l) * CO * 16 + con * 16;
+#pragma unroll
+      for (int rr = 0; rr < JR + 6; ++rr) {
+        const int kh = rr - jn;
+        const int khx = (unsigned)kh < 7u ? kh : 7;   // row 7 of the table is zero
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(tb + khx * GS * CO * 16);
+        const unsigned char* ar = pl + ((wv * JR + rr) * IWP + nn + a_col) * VB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned char* ap = ar + mt * 16 * VB;
+          bf16x8 av;
+          if (CI == 4) {
+            const uint2 lo = *reinterpret_cast<const uint2*>(ap);
+            const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
+            av = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          } else {
+            const unsigned* a32 = reinterpret_cast<const unsigned*>(ap);
+            av = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
+          }
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_plane(d + 4);
+    // ---- epilogue: lane = voxels 4*g4 .. +3 of M tile mt, output row jn of this wave's row tile, channel con ----
+    const int oh = oh0 + wv * JR + jn;
+    if (oh < H) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[mt][r] + bias, a.d.act, a.d.act_slope);
+        st4(ybase, ((long long)d * H + oh) * W + ow0 + mt * 16 + 4 * g4, o);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
+int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  if (d->dtype != XH_BF16 || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
+  if (!((d->Cin == 4 && d->Cout == 2) || (d->Cin == 2 && d->Cout == 4))) return 1;
+  if (d->pre || d->epi || d->Ca != d->Cin) return 1;
+  if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return 1;
+  if ((d->xa_bs & 7) || (d->y_bs & 3) || (((long long)d->D * d->H * d->W) & 7)) return 1;
+  if (d->N > 65535) return 1;
+  Conv7K a;
+  a.d = *d;
+  a.p = *p;
+  const int rows = 2 * (16 / d->Cout);
+  a.tilesW = d->W / 32;
+  a.tilesH = cdiv(d->H, rows);
+  const int cols = a.tilesW * a.tilesH;
+  int dsegs = cdiv(512, cols * d->N);
+  const int max_segs = d->D >= 8 ? d->D / 8 : 1;      // runs of >= 8 planes: 6 halo planes are staged per run
+  if (dsegs > max_segs) dsegs = max_segs;
+  if (dsegs < 1) dsegs = 1;
+  a.sd = cdiv(d->D, dsegs);
+  a.dsegs = cdiv(d->D, a.sd);
+  dim3 grid(cols * a.dsegs, 1, d->N);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->Cin == 4) {
+    const size_t shm = (size_t)8 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)conv7_mfma_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
+    xh_note_kernel("conv7_mfma_kernel<4, 2>");
+    hipLaunchKernelGGL((conv7_mfma_kernel<4, 2>), grid, dim3(128), shm, st, a);
+  } else {
+    const size_t shm = (size_t)8 * (2 * 4 + 6) * 40 * 4 + 8 * 8 * 2 * 4 * 16;
+    xh_note_kernel("conv7_mfma_kernel<2, 4>");
+    hipLaunchKernelGGL((conv7_mfma_kernel<2, 4>), grid, dim3(128), shm, st, a);
+  }
+  return xh_launch_status();
+}
