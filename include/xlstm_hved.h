@@ -99,6 +99,9 @@ int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* 
  * db[co] += sum dy.  Desc describes the FORWARD conv; ptrs: xa/xb/pre_* = forward input, `ea` = dY with
  * batch stride ea_bs.  dw[i]/db[i] are laid out like w[i]/b[i], fp32, ACCUMULATED into (caller zeroes). */
 int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
+/* Scratch (bytes) xh_conv3d_wgrad wants in p->ws for this shape (per-workgroup partial gradients of the 7^3 MFMA weight
+ * gradient); 0 = none.  With less, the call uses the vector kernel. */
+long long xh_conv3d_wgrad_workspace_bytes(const xh_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation statistics and elementwise stages.

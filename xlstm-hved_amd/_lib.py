@@ -52,6 +52,7 @@ SIGNATURES = {
     "xh_last_conv_kernel": (C.c_char_p, []),
     "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
+    "xh_conv3d_wgrad_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * 4), C.POINTER(vp * 4)]),
     "xh_moments": (I, [vp, I, vp, ll, I, I, ll, vp, ll]),

@@ -1202,6 +1202,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
 
 int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv3d_mfma.hip
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv7_mfma.hip
+int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
 int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
 static int g_use_mfma = 1;
 int g_xh_disable = 0;
@@ -1660,7 +1661,7 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
   for (int i = 0; i < d->n_wptr; ++i)
     if (!dw[i]) return XH_ERR_ARG;
   if (g_use_mfma) {
-    const int r = xh_conv3_wgrad_mfma_try(stream, d, p, dw, db);
+    const int r = d->k == 7 ? xh_conv7_wgrad_mfma_try(stream, d, p, dw, db) : xh_conv3_wgrad_mfma_try(stream, d, p, dw, db);
     if (r != 1) return r;
   }
   xh_note_kernel("conv wgrad k%d s%d (vector kernel family)", d->k, d->stride);

@@ -1,0 +1,238 @@
+// bf16-MFMA weight gradient of the 7x7x7 gate conv (4 pooled channels -> 2 gates), bf16 storage, fp32 accumulation.
+//
+//   dW[co][ci][kd][kh][kw] = sum_{d,h,w} x[ci][d+kd-3][h+kh-3][w+kw-3] * dY[co][d][h][w]
+//
+// GEMM per (x plane p, x row r, 32-voxel run along W) and depth tap kd, with K = the 32 voxels:
+//
+//   C_kd[(kw, ci)][(kh, co)] += A[(kw, ci)][w] * B_kd[w][(kh, co)],   A = x[ci][p][r][w + kw - 3],
+//                                                                       B_kd = dY[co][p - kd + 3][r - kh + 3][w]
+//
+// M = 8 kw slots x 4 ci = two 16-row tiles, N = 8 kh slots x 2 co = 16 (slot 7 of kw / kh is a dummy), so one x row feeds
+// 14 MFMAs (7 kd x 2 M tiles) from 2 A and 7 B fragments, and the 7^3 x 8 weight gradient lives in 14 accumulator tiles
+// per wave for the whole run.
+//  * the kw shift is a 2-byte-granular shift along the contraction axis, which a 16-byte LDS fragment read cannot do;
+//    so the x rows are staged as 8 pre-shifted copies ([ci][row][kw][32 w], built in registers with constant byte
+//    aligns from the neighbouring 16-byte chunks): every A fragment is one aligned 16-byte read;
+//  * dY planes p-3 .. p+3 live in an 8-slot LDS ring ([co][14 rows][32 w]); the workgroup slides along D over x planes;
+//  * per-workgroup partial gradients go to a scratch buffer (plain stores) and a second tiny kernel adds them into dW/db:
+//    512 workgroups x 2744 same-address atomics would serialise.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Wg7K {
+  xh_conv_desc d;
+  const bf16_t* x;      // (N, 4, D, H, W)
+  const bf16_t* dy;     // (N, 2, D, H, W)
+  long long x_bs, dy_bs;
+  float* part;          // [workgroups][NPART]
+  int tilesW, tilesH, sd, dsegs;
+};
+constexpr int K7_NW = 2 * 4 * 343;          // 2744 weight gradients
+constexpr int K7_NPART = K7_NW + 8;         // + 2 bias gradients (padded)
+
+__global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int XROW = 8 * 64;                        // bytes per (ci, row): 8 shifted copies x 32 bf16
+  constexpr int XBUF = 4 * TH * XROW;                 // 16 KB
+  constexpr int DYROWS = TH + 6, DYPL = 2 * DYROWS * 64;   // bytes per dY plane slot (1792)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_x = smem;                          // 2 * XBUF (double buffer)
+  unsigned char* s_dy = smem + 2 * XBUF;              // 8 * DYPL
+  unsigned char* s_zero = s_dy + 8 * DYPL;            // 64 B of zeros (dummy kh = 7 columns)
+  float* s_red = reinterpret_cast<float*>(smem);      // after the plane loop: [K7_NPART]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g4 = lane >> 4, nn = lane & 15;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH; wk /= a.tilesH;
+  const int ds = wk % a.dsegs;
+  const int n = wk / a.dsegs;
+  const int oh0 = th * TH, ow0 = tw * TW;
+  const int p_begin = ds * a.sd, p_end = min(D, p_begin + a.sd);
+  if (tid < 16) reinterpret_cast<unsigned*>(s_zero)[tid] = 0u;
+
+  // ---- staging roles: threads 0..127 stage x (ci, row, chunk); threads 128..255 stage dY (co, row, chunk) ----
+  const bool xrole = tid < 128;
+  const int it = tid & 127;
+  // x item
+  const int xc = it & 3, xrow = (it >> 2) & 7, xci = it >> 5;
+  const int xh = oh0 + xrow;
+  const bool x_ok = xh < H;
+  const bf16_t* xsrc = a.x + n * a.x_bs + (long long)xci * dhw + (long long)min(xh, H - 1) * W + ow0 + 8 * xc;
+  const bool x_prev = ow0 + 8 * xc - 8 >= 0, x_next = ow0 + 8 * xc + 8 < W;
+  // dY item (112 of the 128 threads)
+  const int yc = it & 3, yrow = (it >> 2) % DYROWS, yco = (it >> 2) / DYROWS;
+  const int yh = oh0 - 3 + yrow;
+  const bool y_item = !xrole && it < 2 * DYROWS * 4;
+  const bool y_ok = y_item && (unsigned)yh < (unsigned)H;
+  const bf16_t* ysrc = a.dy + n * a.dy_bs + (long long)min(yco, 1) * dhw + (long long)min(max(yh, 0), H - 1) * W + ow0 + 8 * yc;
+  const bool y_own_row = yrow >= 3 && yrow < 3 + TH;  // a row of the tile proper (bias gradient counts those once)
+
+  uint4 r_prev, r_cur, r_next;                        // x role: the chunk and its neighbours; dY role: r_cur only
+  float dbs = 0.f;
+  auto load_x = [&](int p) {
+    r_prev = r_cur = r_next = make_uint4(0, 0, 0, 0);
+    if (x_ok && (unsigned)p < (unsigned)D) {
+      const bf16_t* s = xsrc + (long long)p * hw;
+      r_cur = *reinterpret_cast<const uint4*>(s);
+      if (x_prev) r_prev = *reinterpret_cast<const uint4*>(s - 8);
+      if (x_next) r_next = *reinterpret_cast<const uint4*>(s + 8);
+    }
+  };
+  auto store_x = [&](int buf) {
+    const unsigned w[12] = {r_prev.x, r_prev.y, r_prev.z, r_prev.w, r_cur.x, r_cur.y, r_cur.z, r_cur.w,
+                            r_next.x, r_next.y, r_next.z, r_next.w};
+    unsigned char* dst = s_x + buf * XBUF + (xci * TH + xrow) * XROW + xc * 16;
+#pragma unroll
+    for (int kw = 0; kw < 8; ++kw) {
+      const int o = 8 + kw - 3;                       // first element of the shifted window inside prev|cur|next
+      unsigned q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        q[j] = (o & 1) ? __builtin_amdgcn_alignbyte(w[(o + 1) / 2 + j], w[(o - 1) / 2 + j], 2) : w[o / 2 + j];
+      *reinterpret_cast<uint4*>(dst + kw * 64) = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+  };
+  auto load_dy = [&](int q) {
+    r_cur = make_uint4(0, 0, 0, 0);
+    if (y_ok && (unsigned)q < (unsigned)D) r_cur = *reinterpret_cast<const uint4*>(ysrc + (long long)q * hw);
+  };
+  auto store_dy = [&](int q) {
+    if (!y_item) return;
+    *reinterpret_cast<uint4*>(s_dy + ((q + 8) & 7) * DYPL + (yco * DYROWS + yrow) * 64 + yc * 16) = r_cur;
+    if (y_own_row && q >= p_begin && q < p_end) {
+      const unsigned u[4] = {r_cur.x, r_cur.y, r_cur.z, r_cur.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dbs += __uint_as_float(u[k] << 16) + __uint_as_float(u[k] & 0xffff0000u);
+    }
+  };
+
+  // ---- prologue: x plane p_begin, dY planes p_begin-3 .. p_begin+3 ----
+  if (xrole) {
+    load_x(p_begin);
+    store_x(0);
+  } else {
+    for (int q = p_begin - 3; q <= p_begin + 3; ++q) {
+      load_dy(q);
+      store_dy(q);
+    }
+  }
+  __syncthreads();
+
+  // lane roles in the MFMAs
+  const int a_off0 = (((nn & 3) * TH) * 8 + (nn >> 2)) * 64 + g4 * 16;      // M tile 0: kw = nn>>2, ci = nn&3
+  const int a_off1 = a_off0 + 4 * 64;                                       // M tile 1: kw + 4
+  const int kh_l = nn >> 1, co_l = nn & 1;
+  f32x4 acc[7][2];
+#pragma unroll
+  for (int kd = 0; kd < 7; ++kd) { acc[kd][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[kd][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  int buf = 0;
+  for (int p = p_begin; p < p_end; ++p) {
+    const bool more = p + 1 < p_end;
+    if (more) { if (xrole) load_x(p + 1); else load_dy(p + 4); }
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri) {
+      const int r = wv * 2 + ri;                      // x row of the tile (wave-uniform)
+      const unsigned char* xr = s_x + buf * XBUF + r * XROW;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(xr + a_off0);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(xr + a_off1);
+      const int ry = r + 6 - kh_l;                    // dY row (ring-relative) this lane's column pairs with
+#pragma unroll
+      for (int kd = 0; kd < 7; ++kd) {
+        const unsigned char* bp = kh_l < 7 ? s_dy + ((p - kd + 3 + 8) & 7) * DYPL + (co_l * DYROWS + ry) * 64 + g4 * 16
+                                           : s_zero + g4 * 16;
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bp);
+        acc[kd][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bv, acc[kd][0], 0, 0, 0);
+        acc[kd][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bv, acc[kd][1], 0, 0, 0);
+      }
+    }
+    if (more) { if (xrole) store_x(buf ^ 1); else store_dy(p + 4); }
+    buf ^= 1;
+    __syncthreads();
+  }
+
+  // ---- reduce the four waves' tiles in LDS: C[(kw, ci)][(kh, co)]: lane holds rows 4*g4 + r -> kw = 4*mt + g4, ci = r ----
+  for (int i = tid; i < K7_NPART; i += 256) s_red[i] = 0.f;
+  __syncthreads();
+  if (kh_l < 7) {
+#pragma unroll
+    for (int kd = 0; kd < 7; ++kd)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int kw = 4 * mt + g4;
+        if (kw < 7) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            atomicAdd(&s_red[(co_l * 4 + r) * 343 + (kd * 7 + kh_l) * 7 + kw], acc[kd][mt][r]);
+        }
+      }
+  }
+  if (!xrole && y_item) atomicAdd(&s_red[K7_NW + yco], dbs);
+  __syncthreads();
+  float* out = a.part + (long long)blockIdx.x * K7_NPART;
+  for (int i = tid; i < K7_NPART; i += 256) out[i] = s_red[i];
+}
+
+// second stage: 2746 outputs x 32 slices of the partials; one float atomic per (output, slice)
+__global__ __launch_bounds__(256) void conv7_wgrad_reduce_kernel(const float* part, int nparts, float* dw, float* db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K7_NW + 2) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = blockIdx.y; k < nparts; k += gridDim.y) s += part[(long long)k * K7_NPART + i];
+  if (i < K7_NW) atomicAdd(&dw[i], s);
+  else if (db) atomicAdd(&db[i - K7_NW], s);
+}
+
+static bool wg7_eligible(const xh_conv_desc* d) {
+  if (d->dtype != XH_BF16 || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return false;
+  if (d->Cin != 4 || d->Cout != 2 || d->pre || d->Ca != d->Cin || d->transposed) return false;
+  if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
+  if ((d->xa_bs & 7) || (d->ea_bs & 7) || (((long long)d->D * d->H * d->W) & 7)) return false;
+  return true;
+}
+static void wg7_plan(const xh_conv_desc* d, Wg7K* a) {
+  a->tilesW = d->W / 32;
+  a->tilesH = cdiv(d->H, 8);
+  const int cols = a->tilesW * a->tilesH;
+  int dsegs = cdiv(512, cols * d->N);
+  const int max_segs = d->D >= 8 ? d->D / 8 : 1;
+  if (dsegs > max_segs) dsegs = max_segs;
+  if (dsegs < 1) dsegs = 1;
+  a->sd = cdiv(d->D, dsegs);
+  a->dsegs = cdiv(d->D, a->sd);
+}
+extern "C" long long xh_conv3d_wgrad_workspace_bytes(const xh_conv_desc* d) {
+  if (!d || !wg7_eligible(d)) return 0;
+  Wg7K a;
+  wg7_plan(d, &a);
+  return (long long)a.tilesW * a.tilesH * a.dsegs * d->N * K7_NPART * (long long)sizeof(float);
+}
+
+// returns XH_OK if launched, 1 if not eligible (caller falls back to the vector kernel)
+int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
+  if (!wg7_eligible(d)) return 1;
+  const long long need = xh_conv3d_wgrad_workspace_bytes(d);
+  if (!p->ws || p->ws_bytes < need) return 1;
+  Wg7K a;
+  a.d = *d;
+  wg7_plan(d, &a);
+  a.x = (const bf16_t*)p->xa; a.x_bs = d->xa_bs;
+  a.dy = (const bf16_t*)p->ea; a.dy_bs = d->ea_bs;
+  a.part = (float*)p->ws;
+  const int nwg = a.tilesW * a.tilesH * a.dsegs * d->N;
+  const size_t shm = 2 * 4 * 8 * 8 * 64 + 8 * 2 * 14 * 64 + 64;
+  hipStream_t st = (hipStream_t)stream;
+  xh_note_kernel("conv7_wgrad_mfma_kernel");
+  hipLaunchKernelGGL(conv7_wgrad_mfma_kernel, dim3(nwg), dim3(256), shm, st, a);
+  hipLaunchKernelGGL(conv7_wgrad_reduce_kernel, dim3(cdiv(K7_NW + 2, 256), nwg < 32 ? nwg : 32), dim3(256), 0, st,
+                     (const float*)a.part, nwg, dw[0], db ? db[0] : nullptr);
+  return xh_launch_status();
+}

@@ -219,6 +219,10 @@ def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None):
         ptrs.pre_sc, ptrs.pre_sh = _p(pre[0]), _p(pre[1])
     dw = _arr4([_f32(t, "dw") for t in dws])
     db = _arr4([_f32(t, "db") for t in (dbs or [])])
+    need = lib.xh_conv3d_wgrad_workspace_bytes(C.byref(desc)) if _MFMA[0] else 0
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
+        ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
     L.check(lib.xh_conv3d_wgrad(_stream(), C.byref(desc), C.byref(ptrs), C.byref(dw), C.byref(db)), "xh_conv3d_wgrad")
 
 
