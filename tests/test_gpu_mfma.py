@@ -24,6 +24,7 @@ CASES = [
     dict(cin=48, cout=16, groups=1, sp=(8, 8, 32), split=16), # > 24 input channels: split-K launches with fp32 partials
     dict(cin=96, cout=32, groups=1, sp=(4, 8, 16), split=32),
     dict(cin=28, cout=8, groups=1, sp=(4, 8, 32)),            # uneven split (16 + 12)
+    dict(cin=128, cout=64, groups=4, sp=(4, 8, 16)),          # grouped, 32 channels per group: split-K inside each group
 ]
 
 

@@ -105,16 +105,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long
 
 template <int COB>
 __device__ __forceinline__ void conv_reduce_out(const ConvK& a, int n, int g, int cob, double (&s0)[COB],
-                                                double (&s1)[COB], float* s_red) {
-  float v[2 * COB];
+                                                double (&s1)[COB], double* s_red) {
+  double v[2 * COB];
 #pragma unroll
-  for (int i = 0; i < COB; ++i) { v[2 * i] = (float)s0[i]; v[2 * i + 1] = (float)s1[i]; }
-  block_sum<2 * COB>(v, s_red, blockDim.x >> 6);
+  for (int i = 0; i < COB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
+  block_sum_d<2 * COB>(v, s_red, blockDim.x >> 6);
   if ((int)threadIdx.x < 2 * COB) {
     const int co_g = cob * COB + (threadIdx.x >> 1);
     if (co_g < a.Cout_g) {
       const int c = g * a.Cout_g + co_g;
-      atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + (threadIdx.x & 1)], (double)s_red[threadIdx.x]);
+      atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + (threadIdx.x & 1)], s_red[threadIdx.x]);
     }
   }
 }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   constexpr int UNR = (K == 3) ? 3 : 1;
   __shared__ __attribute__((aligned(16))) float s_in[CIC * ID * IH * IWP];
   __shared__ __attribute__((aligned(16))) float s_w[CIC * K3 * COB];
-  __shared__ float s_red[4 * 2 * COB];
+  __shared__ double s_red[4 * 2 * COB];
 
   const int tid = threadIdx.x;
   const int tx = tid % TXN, ty = (tid / TXN) % TH, tz = tid / (TXN * TH);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
-  __shared__ float s_red[4 * 2];
+  __shared__ double s_red[4 * 2];
   const int tid = threadIdx.x;
   const int tx = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
   const int c = blockIdx.y, n = blockIdx.z;
@@ -333,9 +333,9 @@ __global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
   if (valid > 0) conv_epilogue<T, 4>(a, n, c, dhw, ((long long)od * H + oh) * W + ow, valid, bias, acc, s0, s1);
   }
   if (a.d.epi) {
-    float v[2] = {(float)s0, (float)s1};
-    block_sum<2>(v, s_red, 4);
-    if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], (double)s_red[tid]);
+    double v[2] = {s0, s1};
+    block_sum_d<2>(v, s_red, 4);
+    if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], s_red[tid]);
   }
 }
 
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
 template <typename T, int TXN>
 __global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int sd) {
   constexpr int VW = VWT<T>::v, TH = 256 / TXN;
-  __shared__ float s_red[4 * 2];
+  __shared__ double s_red[4 * 2];
   const int tid = threadIdx.x;
   const int tx = tid % TXN, ty = tid / TXN;
   const int c = blockIdx.y, n = blockIdx.z;
@@ -459,9 +459,9 @@ __global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int 
     for (int v = 0; v < VW; ++v) { accA[v] = accB[v]; accB[v] = accC[v]; accC[v] = 0.f; }
   }
   if (a.d.epi) {
-    float v[2] = {(float)s0, (float)s1};
-    block_sum<2>(v, s_red, 4);
-    if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], (double)s_red[tid]);
+    double v[2] = {s0, s1};
+    block_sum_d<2>(v, s_red, 4);
+    if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], s_red[tid]);
   }
 }
 
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
   constexpr int VW = VEC ? VWT<T>::v : 4;              // 16-byte runs when the layout allows
   constexpr int CIC = 4;                               // input channels per step: their loads are issued together
   __shared__ float s_w[132 * COB];
-  __shared__ float s_red[4 * 2 * COB];
+  __shared__ double s_red[4 * 2 * COB];
   const int tid = threadIdx.x;
   const int cob = blockIdx.y;
   const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
@@ -544,7 +544,7 @@ template <typename T, int COB>
 __global__ __launch_bounds__(256) void conv3_s2_gather_kernel(const ConvK a) {
   extern __shared__ float s_dyn[];                    // [Cin_g][27][COB] weights, then reduction scratch
   float* s_w = s_dyn;
-  float* s_red = s_dyn + a.Cin_g * 27 * COB;
+  double* s_red = reinterpret_cast<double*>(s_dyn + ((a.Cin_g * 27 * COB + 1) & ~1));
   const int tid = threadIdx.x;
   const int cob = blockIdx.y;
   const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
   constexpr int VW = VWT<T>::v, OW = VW / 2;
   extern __shared__ float s_dyn[];                    // [Cin_g][27][COB] weights, then reduction scratch
   float* s_w = s_dyn;
-  float* s_red = s_dyn + a.Cin_g * 27 * COB;
+  double* s_red = reinterpret_cast<double*>(s_dyn + ((a.Cin_g * 27 * COB + 1) & ~1));
   const int tid = threadIdx.x;
   const int cob = blockIdx.y;
   const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void conv3_dgrad_s2_kernel(const ConvK a) {
   // here a.d describes the FORWARD conv: Cin_g/Cout_g forward; xa = dY (Cout channels), y = dX
   extern __shared__ float s_dyn[];   // [Cout_g][CIB][27] weights + reduction scratch
   float* s_w = s_dyn;
-  float* s_red = s_dyn + a.Cout_g * CIB * 27;
+  double* s_red = reinterpret_cast<double*>(s_dyn + ((a.Cout_g * CIB * 27 + 1) & ~1));
   const int tid = threadIdx.x;
   const int cib = blockIdx.y;
   const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
@@ -765,15 +765,15 @@ __global__ __launch_bounds__(256) void conv3_dgrad_s2_kernel(const ConvK a) {
     }
   }
   if (a.d.epi == 1) {
-    float v[2 * CIB];
+    double v[2 * CIB];
 #pragma unroll
-    for (int i = 0; i < CIB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
-    block_sum<2 * CIB>(v, s_red, 4);
+    for (int i = 0; i < CIB; ++i) { v[2 * i] = (double)s0[i]; v[2 * i + 1] = (double)s1[i]; }
+    block_sum_d<2 * CIB>(v, s_red, 4);
     if (tid < 2 * CIB) {
       const int ci_g = cib * CIB + (tid >> 1);
       if (ci_g < a.Cin_g) {
         const int c = g * a.Cin_g + ci_g;
-        atomicAdd(&a.p.red[((long long)n * a.d.Cin + c) * 2 + (tid & 1)], (double)s_red[tid]);
+        atomicAdd(&a.p.red[((long long)n * a.d.Cin + c) * 2 + (tid & 1)], s_red[tid]);
       }
     }
   }
@@ -1160,7 +1160,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     ConvK a = make_k(d, p, cob, txn);
     const long long odhw = (long long)d->Do * d->Ho * d->Wo;
     dim3 grid((unsigned)((odhw + 255) / 256), a.ncob, d->N * d->groups);
-    const size_t shm = ((size_t)cin_g * 27 * cob + 4 * 2 * cob) * sizeof(float);
+    const size_t shm = ((size_t)cin_g * 27 * cob + 2 + 2 * 4 * 2 * cob) * sizeof(float);
     if (shm > 60 * 1024) return XH_ERR_ARG;
     {
       constexpr int VW = VWT<T>::v;
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(256) void conv3_dgrad_s2_vec_kernel(const ConvK a, 
   constexpr int VW = VWT<T>::v, OW = VW / 2;
   extern __shared__ float s_dyn[];   // [Cout_g][CIB][27] weights + reduction scratch
   float* s_w = s_dyn;
-  float* s_red = s_dyn + a.Cout_g * CIB * 27;
+  double* s_red = reinterpret_cast<double*>(s_dyn + ((a.Cout_g * CIB * 27 + 1) & ~1));
   const int tid = threadIdx.x;
   const int cib = blockIdx.y;
   const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
@@ -1357,15 +1357,15 @@ __global__ __launch_bounds__(256) void conv3_dgrad_s2_vec_kernel(const ConvK a, 
     }
   }
   if (a.d.epi == 1) {
-    float v[2 * CIB];
+    double v[2 * CIB];
 #pragma unroll
-    for (int i = 0; i < CIB; ++i) { v[2 * i] = (float)s0[i]; v[2 * i + 1] = (float)s1[i]; }
-    block_sum<2 * CIB>(v, s_red, 4);
+    for (int i = 0; i < CIB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
+    block_sum_d<2 * CIB>(v, s_red, 4);
     if (tid < 2 * CIB) {
       const int ci_g = cib * CIB + (tid >> 1);
       if (ci_g < a.Cin_g) {
         const int c = g * a.Cin_g + ci_g;
-        atomicAdd(&a.p.red[((long long)n * a.d.Cin + c) * 2 + (tid & 1)], (double)s_red[tid]);
+        atomicAdd(&a.p.red[((long long)n * a.d.Cin + c) * 2 + (tid & 1)], s_red[tid]);
       }
     }
   }
@@ -1378,7 +1378,7 @@ static int dgrad_s2_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
   ConvK a = make_k(d, p, 1, 8);
   const long long dhw = (long long)d->D * d->H * d->W;
   dim3 grid((unsigned)((dhw + 255) / 256), cdiv(cin_g, cib), d->N * d->groups);
-  const size_t shm = ((size_t)cout_g * cib * 27 + 4 * 2 * cib) * sizeof(float);
+  const size_t shm = ((size_t)cout_g * cib * 27 + 2 + 2 * 4 * 2 * cib) * sizeof(float);
   if (shm > 64 * 1024) return XH_ERR_ARG;
   {
     constexpr int VW = VWT<T>::v;

@@ -41,6 +41,7 @@ struct ConvMK {
   // covers channels [cin_off, cin_off + cin_blk); all but the last write fp32 partial sums to `part`, all but the first
   // add the partials in; only the last runs the epilogue proper.
   int nsplit, cin_off, part_in, part_out;
+  int cin_stride;   // input channels between consecutive sets (= cin_blk unless split: then the whole group's cin_g)
   float* part;
 };
 int g_mfma_abl = 0;
@@ -61,7 +62,8 @@ __device__ __forceinline__ float mk_weight(const ConvMK& a, int co, int ci, int 
 __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
   const int y = blockIdx.y;
   const int set = y / a.ntile, nt = y % a.ntile;
-  const int cin0 = set * a.cin_blk + a.cin_off;
+  const int cin0 = set * a.cin_stride + a.cin_off;
+  const int cin_end = (set + 1) * a.cin_stride;
   const int co_base = set * a.cout_set + nt * 16;
   const int co_lim = min(16, a.cout_set - nt * 16);
   unsigned short* wf = (unsigned short*)a.p.ws + (long long)y * a.nm * 512;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
     const int r9 = c / a.cpr, j = c % a.cpr;
     const int flat = j * 8 + e;                       // position inside the row segment: kw*CINP + ci
     const int kw = flat / a.cinp, ci = flat % a.cinp;
-    if (kw < 3 && ci < a.cin_blk && cin0 + ci < a.d.Cin) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
+    if (kw < 3 && ci < a.cin_blk && cin0 + ci < cin_end) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
   }
   wf[idx] = f2bf(v);
 }
@@ -104,14 +106,15 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_in = smem;                                                     // 4 * PLANE
   float* s_ep = reinterpret_cast<float*>(smem + 4 * PLANE);                       // [NWV waves][16][EPS]
-  float* s_red = s_ep;                                                            // reused after the plane loop
+  double* s_red = reinterpret_cast<double*>(s_ep);                                // reused after the plane loop
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g4 = lane >> 4, nn = lane & 15;
   const int y = blockIdx.y;
   const int set = y / a.ntile, nt = y % a.ntile;
   const int n = blockIdx.z;
-  const int cin0 = set * a.cin_blk + a.cin_off;
+  const int cin0 = set * a.cin_stride + a.cin_off;
+  const int cin_end = (set + 1) * a.cin_stride;
   const int co_base = set * a.cout_set + nt * 16;
   const int co_lim = min(16, a.cout_set - nt * 16);
   const int D = a.d.D, H = a.d.H, W = a.d.W;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
       const int c = cin0 + cl;
       sp_src[it][cc] = nullptr;
       sp_sc[it][cc] = 1.f; sp_sh[it][cc] = 0.f;
-      if (inb && cl < a.cin_blk && c < a.d.Cin) {
+      if (inb && cl < a.cin_blk && c < cin_end) {
         sp_src[it][cc] = (c < a.d.Ca ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
                                      : (const bf16_t*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
                          (long long)gh * W + gw;
@@ -359,14 +362,14 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
     s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
     s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
     __syncthreads();
-    if ((lane & 3) == 0) { s_red[wv * 32 + eco * 2] = (float)s0; s_red[wv * 32 + eco * 2 + 1] = (float)s1; }
+    if ((lane & 3) == 0) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
     __syncthreads();
     if (tid < 32) {
-      float tot = 0.f;
+      double tot = 0.0;
 #pragma unroll
       for (int w8 = 0; w8 < NWV; ++w8) tot += s_red[w8 * 32 + tid];
       const int c = tid >> 1;
-      if (c < co_lim) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co_base + c) * 2 + (tid & 1)], (double)tot);
+      if (c < co_lim) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co_base + c) * 2 + (tid & 1)], tot);
     }
   }
 }
@@ -383,8 +386,8 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   while (gs * 2 <= d->groups && d->groups % (gs * 2) == 0 && gs * 2 * cin_g <= 24 && gs * 2 * cout_g <= 16) gs *= 2;
   int cin_blk = gs * cin_g;
   a->nsplit = 1;
-  if (cin_blk > 24) {
-    if (d->groups != 1) return 1;
+  a->cin_stride = cin_blk;
+  if (cin_blk > 24) {                                 // gs == 1 here: one group (or the whole ungrouped conv) per set
     a->nsplit = cdiv(cin_blk, 24);
     cin_blk = cdiv(cdiv(cin_blk, a->nsplit), 4) * 4;  // equal chunks, whole channel quads
     if (cin_blk > 24 || a->nsplit > 8) return 1;

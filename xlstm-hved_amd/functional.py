@@ -197,19 +197,23 @@ class Conv(Function):
     carry one weight tensor each."""
 
     @staticmethod
-    def forward(ctx, x, groups, act, nw, has_bias, *wb):
+    def forward(ctx, x, groups, act, nw, has_bias, out_stats, *wb):
         weights = list(wb[:nw])
         biases = list(wb[nw:]) if has_bias else None
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
-        y = ops.conv3d(x, None, weights, biases, k=k, cout=cout, groups=groups, act=act)
+        red_y = ops.zeros_red(x, x.shape[0], cout) if out_stats else None     # output channel sums for the next norm
+        y = ops.conv3d(x, None, weights, biases, k=k, cout=cout, groups=groups, act=act, epi=2 if out_stats else 0, red=red_y)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *weights)
         ctx.cfg = (groups, act, nw, has_bias, k)
         ctx.params = (weights, biases)
+        if out_stats:
+            ctx.mark_non_differentiable(red_y)
+            return y, red_y
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dred=None):
         x, y, *weights = ctx.saved_tensors
         groups, act, nw, has_bias, k = ctx.cfg
         dy = _blk(dy)
@@ -221,11 +225,11 @@ class Conv(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True)
-        return (dx, None, None, None, None, *rws, *rbs)
+        return (dx, None, None, None, None, None, *rws, *rbs)
 
 
-def conv(x, weights, biases=None, groups=1, act=ACT_NONE):
-    return Conv.apply(x, groups, act, len(weights), biases is not None, *weights, *(biases or []))
+def conv(x, weights, biases=None, groups=1, act=ACT_NONE, out_stats=False):
+    return Conv.apply(x, groups, act, len(weights), biases is not None, bool(out_stats), *weights, *(biases or []))
 
 
 class MaxPool2(Function):
