@@ -247,7 +247,30 @@ def roofline_pass(step, ops, nsteps, dtype):
     c1.record()
     torch.cuda.synchronize()
     ticks_per_ms = 1_000_000 / max(c0.elapsed_time(c1), 1e-3)
-    delay = int(min(60.0 * ticks_per_ms, 4e9))
+    # the delay must outlast the host's enqueue time of one instrumented step (else the GPU catches up and a bracket
+    # also spans host launch latency): time one instrumented enqueue, then wait 1.5x that (+20 ms), at most 600 ms
+    ops.conv3d, ops.conv3d_wgrad = timed_fwd, timed_wg
+    try:
+        t_h = time.perf_counter()
+        step()
+        host_ms = (time.perf_counter() - t_h) * 1e3
+        torch.cuda.synchronize()
+    finally:
+        ops.conv3d, ops.conv3d_wgrad = orig_fwd, orig_wg
+    records.clear()
+    delay_ms = min(1.5 * host_ms + 20.0, 600.0)
+    delay = int(delay_ms * ticks_per_ms)
+    # an event pair costs a few microseconds of its own (two marker packets): measure empty brackets under the same
+    # queued conditions and subtract their median from every bracket
+    torch.cuda._sleep(delay)
+    empties = []
+    for _ in range(200):
+        e0, e1 = ev(), ev()
+        e0.record()
+        e1.record()
+        empties.append((e0, e1))
+    torch.cuda.synchronize()
+    overhead_ms = sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
     ops.conv3d, ops.conv3d_wgrad = timed_fwd, timed_wg
     try:
         for _ in range(nsteps):
@@ -260,7 +283,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     for name, e0, e1, nbytes, flops, shape in records:
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, {}])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1)
+        a[1] += max(e0.elapsed_time(e1) - overhead_ms, 1e-3)
         a[2] += nbytes
         a[3] += flops
         a[4][shape] = a[4].get(shape, 0) + 1
@@ -294,9 +317,10 @@ def roofline_pass(step, ops, nsteps, dtype):
               "other_conv_kernels": {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3,
                                           "GBps": v[2] / v[1] / 1e6, "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()}}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:8]},
+              "event_pair_overhead_us": overhead_ms * 1e3, "host_enqueue_ms_per_step": host_ms, "device_delay_ms": delay_ms,
               "timing": "HIP events on the launch stream around each launch of the real step (queued behind a device-side "
-                        "delay so launches run back to back as in the graph replay); the events also span the weight "
-                        "pre-pack / zero-fill launches the call issues"})
+                        "delay so launches run back to back as in the graph replay), minus the median empty event pair; the "
+                        "events also span the weight pre-pack / second-stage reduce launches the call issues"})
     return r
 
 

@@ -1098,6 +1098,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
 #define L1(COB)                                                                                                  \
   do {                                                                                                           \
+    xh_note_kernel("conv1x1_kernel<%s, %d, %s>", tname<T>(), COB, vec ? "true" : "false");                       \
     if (vec) hipLaunchKernelGGL((conv1x1_kernel<T, COB, true>), grid, dim3(256), 0, (hipStream_t)stream, a);     \
     else hipLaunchKernelGGL((conv1x1_kernel<T, COB, false>), grid, dim3(256), 0, (hipStream_t)stream, a);        \
   } while (0)
@@ -1139,6 +1140,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     const int cap = cdiv(2048, d->Cin * d->N);
     if (gx > cap) gx = cap;
     dim3 grid(gx, d->Cin, d->N);
+    xh_note_kernel("conv_dw3_kernel<%s>", tname<T>());
     hipLaunchKernelGGL((conv_dw3_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return xh_launch_status();
   }
@@ -1180,6 +1182,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
         return xh_launch_status();
       }
     }
+    xh_note_kernel("conv3_s2_gather_kernel<%s, %d>", tname<T>(), cob);
     switch (cob) {
       case 2: hipLaunchKernelGGL((conv3_s2_gather_kernel<T, 2>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
       case 4: hipLaunchKernelGGL((conv3_s2_gather_kernel<T, 4>), grid, dim3(256), shm, (hipStream_t)stream, a); break;
@@ -1598,6 +1601,7 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     dim3 grid(gx, cdiv(cin_g, 4) * cdiv(cout_g, 4), d->groups);
+    xh_note_kernel("conv1x1_wgrad_kernel<%s, 4, 4, %s>", tname<T>(), vec ? "true" : "false");
     if (vec) hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, wa);
     else hipLaunchKernelGGL((conv1x1_wgrad_kernel<T, 4, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, wa);
     return xh_launch_status();
