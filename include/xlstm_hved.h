@@ -142,6 +142,12 @@ int xh_norm_bwd_coef(void* stream, int mode, const double* red, int N, int C, lo
 int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
                       void* dx, long long dx_bs, int N, int C, long long DHW, const float* A, const float* B,
                       const float* Cc, int have_g, const float* sc, const float* sh, float slope, int accumulate);
+/* InstanceNorm backward in one launch: coefficients derived per (n, c) row from the raw sums red = (sum g, sum g*x) of
+ * xh_act_bwd_reduce / the conv epilogue, and the forward's mean / rstd.  red, mean, rstd (and sc, sh when have_g == 0)
+ * point at this tensor's first channel inside arrays whose rows are stat_rs channels wide (virtual concat). */
+int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs, void* dx,
+                    long long dx_bs, int N, int C, long long DHW, const double* red, const float* mean, const float* rstd,
+                    int stat_rs, int have_g, const float* sc, const float* sh, float slope, int accumulate);
 
 /* nn.MaxPool3d(2) (buildingblocks.py:635-636,656-657) and its backward (first maximum in scan order wins). */
 int xh_maxpool2_fwd(void* stream, int dtype, const void* x, void* y, int NC, int D, int H, int W);

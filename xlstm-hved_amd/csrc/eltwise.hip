@@ -312,6 +312,58 @@ __global__ __launch_bounds__(EW_BLOCK) void norm_bwd_apply_kernel(const T* dy, l
   ROW_LOOP_END
 }
 
+// InstanceNorm flavour with the coefficient step folded in: every workgroup derives A, B, C of its (n, c) row from the
+// raw fp64 sums (sum g, sum g*x), mean and rstd -- a handful of flops -- so the one-block coefficient launch disappears.
+// The statistics arrays may be wider than this tensor's channel count (virtual concat): row stride `stat_rs`.
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
+                                                               T* dx, long long dx_bs, int C, long long dhw,
+                                                               const double* red, const float* mean, const float* rstd,
+                                                               int stat_rs, double count, int have_g, const float* sc,
+                                                               const float* sh, float slope, int accumulate, bool vec) {
+  const int k = blockIdx.z * stat_rs + blockIdx.y;
+  const double rs = rstd[k], mu = mean[k];
+  const double S0 = red[k * 2], P = rs * (red[k * 2 + 1] - mu * red[k * 2]);
+  const float a_ = (float)rs, c_ = (float)(-rs * rs * P / count), b_ = (float)(-rs * S0 / count + rs * rs * mu * P / count);
+  float tsc = 1.f, tsh = 0.f;
+  if (!have_g) { tsc = sc[k]; tsh = sh[k]; }
+  ROW_LOOP_BEGIN
+    float g[VW], xv[VW], o[VW];
+    ldrow(dy + n * dy_bs + (long long)c * dhw, q, valid, vec, g);
+    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    T* dp = dx + n * dx_bs + (long long)c * dhw;
+    if (accumulate) ldrow((const T*)dp, q, valid, vec, o);
+    else {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) o[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      float gg = g[i];
+      if (!have_g) gg *= ((xv[i] * tsc + tsh) > 0.f ? 1.f : slope);
+      o[i] += a_ * gg + c_ * xv[i] + b_;
+    }
+    strow(dp, q, valid, vec, o);
+  ROW_LOOP_END
+}
+extern "C" int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                               void* dx, long long dx_bs, int N, int C, long long DHW, const double* red,
+                               const float* mean, const float* rstd, int stat_rs, int have_g, const float* sc,
+                               const float* sh, float slope, int accumulate) {
+  if (!dy || !x || !dx || !red || !mean || !rstd || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535 || stat_rs < C)
+    return XH_ERR_ARG;
+  if (!have_g && (!sc || !sh)) return XH_ERR_ARG;
+  const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
+  if (dtype == XH_F32)
+    hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec32);
+  else if (dtype == XH_BF16)
+    hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec16);
+  else
+    return XH_ERR_DTYPE;
+  return xh_launch_status();
+}
+
 extern "C" int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
                                  void* dx, long long dx_bs, int N, int C, long long DHW, const float* A, const float* B,
                                  const float* Cc, int have_g, const float* sc, const float* sh, float slope,

@@ -111,10 +111,9 @@ class InLreluConv(Function):
                 g = ops.conv3d(dy, None, weights, None, k=k, cout=cin, groups=groups, transposed=True, epi=1, e=e, red=red)
             else:
                 g = ops.conv3d_dgrad_s2(dy, weights, cin=cin, in_spatial=tuple(xa.shape[2:]), groups=groups, e=e, red=red)
-            coef = ops.norm_bwd_coef(MODE_IN, red, _dhw(xa), mean, rstd)
-            dxa = ops.norm_bwd_apply(g, xa, coef, have_g=True, c0=0)
+            dxa = ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0)
             if xb is not None:
-                dxb = ops.norm_bwd_apply(g, xb, coef, have_g=True, c0=ca)
+                dxb = ops.in_bwd_apply(g, xb, red, mean, rstd, have_g=True, c0=ca)
         return (dxa, dxb, None, None, None, None, None, *rws, *rbs)
 
 
@@ -181,8 +180,7 @@ class ConvInLrelu(Function):
         groups, k = ctx.cfg
         dy = _blk(dy)
         red = ops.act_bwd_reduce(dy, y0, sc, sh, LEAK)
-        coef = ops.norm_bwd_coef(MODE_IN, red, _dhw(y0), mean, rstd)
-        dy0 = ops.norm_bwd_apply(dy, y0, coef, have_g=False, sc=sc, sh=sh, slope=LEAK)
+        dy0 = ops.in_bwd_apply(dy, y0, red, mean, rstd, have_g=False, sc=sc, sh=sh, slope=LEAK)
         (dw,), (rw,) = _targets(ctx.params)
         ops.conv3d_wgrad(x, None, dy0, [dw], None, k=k, groups=groups)
         dx = None

@@ -284,6 +284,19 @@ def norm_bwd_apply(dy, x, coef, *, have_g, sc=None, sh=None, slope=LEAK, out=Non
     return out
 
 
+def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK, c0=0):
+    """InstanceNorm backward of x's channels (window starting at c0 of dy / the statistics) in one launch."""
+    n, c, d, h, w, bs = _vol(x)
+    rs = mean.shape[1]
+    dyv = dy[:, c0:c0 + c] if dy.shape[1] != c else dy
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    off = lambda t, scale=1: None if t is None else t.data_ptr() + c0 * scale * t.element_size()
+    L.check(L.load().xh_in_bwd_apply(_stream(), _dt(x), _p(dyv), _vol(dyv)[5], _p(x), bs, _p(out), _vol(out)[5], n, c,
+                                     d * h * w, off(red, 2), off(mean), off(rstd), rs, int(have_g), off(sc), off(sh), slope,
+                                     0), "xh_in_bwd_apply")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- resampling
 def maxpool2(x):
     n, c, d, h, w, _ = _vol(x)
