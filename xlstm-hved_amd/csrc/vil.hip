@@ -258,7 +258,12 @@ __global__ __launch_bounds__(64) void vil_rscan_kernel(int S, VilWs w) {
 
 // -------------------------------------------------------------------------------------------------
 // mLSTM forward contraction.  block: 32 queries x 8 key slices; key tiles of 64 staged in LDS.
+// All exponents are known before the contraction (no online rescaling), so partial sums over disjoint key sets simply
+// add: the key tiles of a query tile are dealt round-robin to MSPLIT workgroups (balanced under the causal limit, 4x
+// shorter serial chain, 4x more workgroups) that accumulate numerator and denominator with float atomics;
+// mlstm_norm_kernel then divides.
 // -------------------------------------------------------------------------------------------------
+constexpr int MSPLIT = 4;
 template <int DH>
 __global__ __launch_bounds__(256) void mlstm_fwd_kernel(int S, VilWs w) {
   constexpr int KT = 64, LD = DH + 4;
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void mlstm_fwd_kernel(int S, VilWs w) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const long long hb = ((long long)b * NH + h) * S;
-  const int t0 = blockIdx.x * 32;
+  const int t0 = (blockIdx.x / MSPLIT) * 32, ks = blockIdx.x % MSPLIT;
   const int t = t0 + wv * 8 + (lane >> 3), sl = lane & 7;
   const bool tv = t < S;
   float q[DH], num[DH];
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void mlstm_fwd_kernel(int S, VilWs w) {
   if (tv) Gt = w.G[hb + t];
   const float isq = rsqrtf((float)DH);
   const int s_last = min(S - 1, t0 + 31);
-  for (int st0 = 0; st0 <= s_last; st0 += KT) {
+  for (int st0 = ks * KT; st0 <= s_last; st0 += MSPLIT * KT) {
     __syncthreads();
     for (int i = tid; i < KT * DH; i += 256) {
       const int r = i / DH, c = i % DH;
@@ -307,13 +312,21 @@ __global__ __launch_bounds__(256) void mlstm_fwd_kernel(int S, VilWs w) {
 #pragma unroll
     for (int j = 0; j < DH; ++j) num[j] += __shfl_xor(num[j], o, 64);
   }
-  if (tv && sl == 0) {
-    const float m = w.F[hb + t] + Gt;
-    const float nrm = fmaxf(fabsf(den), expf(-m)) + MLSTM_EPS;
-    w.bden[hb + t] = den;
+  if (tv && sl == 0) {                                 // partial sums of this key subset (h / bden are zeroed before the launch)
+    atomicAdd(&w.bden[hb + t], den);
 #pragma unroll
-    for (int j = 0; j < DH; ++j) w.h[(hb + t) * DH + j] = num[j] / nrm;
+    for (int j = 0; j < DH; ++j) atomicAdd(&w.h[(hb + t) * DH + j], num[j]);
   }
+}
+// h_t = num_t / (max(|den_t|, exp(-m_t)) + eps) once all key subsets have been added
+template <int DH>
+__global__ __launch_bounds__(256) void mlstm_norm_kernel(long long total, VilWs w) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*NH*S rows
+  if (i >= total) return;
+  const float m = w.F[i] + w.G[i];
+  const float inv = 1.f / (fmaxf(fabsf(w.bden[i]), expf(-m)) + MLSTM_EPS);
+#pragma unroll
+  for (int j = 0; j < DH; ++j) w.h[i * DH + j] *= inv;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -467,6 +480,8 @@ __global__ __launch_bounds__(256) void mlstm_bwd_prep_kernel(int S, long long to
   w.dbp[i] = (fabsf(bd) > em) ? (bd > 0.f ? dden : -dden) : 0.f;
   w.dm[i] = dden * MLSTM_EPS;
   w.dscat[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) { w.dq[i * DH + j] = 0.f; w.dk[i * DH + j] = 0.f; w.dv[i * DH + j] = 0.f; }   // atomically accumulated below
 }
 // scatter the stabiliser gradient onto the arg-max key of every row
 __global__ __launch_bounds__(256) void mlstm_bwd_scatter_kernel(int S, long long total, VilWs w) {
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(256) void mlstm_bwd_q_kernel(int S, VilWs w) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const long long hb = ((long long)b * NH + h) * S;
-  const int t0 = blockIdx.x * 32;
+  const int t0 = (blockIdx.x / MSPLIT) * 32, ks = blockIdx.x % MSPLIT;
   const int t = t0 + wv * 8 + (lane >> 3), sl = lane & 7;
   const bool tv = t < S;
   float da[DH], dq[DH];
@@ -494,7 +509,7 @@ __global__ __launch_bounds__(256) void mlstm_bwd_q_kernel(int S, VilWs w) {
   if (tv) { Gt = w.G[hb + t]; db = w.dbp[hb + t]; }
   const float isq = rsqrtf((float)DH);
   const int s_last = min(S - 1, t0 + 31);
-  for (int st0 = 0; st0 <= s_last; st0 += KT) {
+  for (int st0 = ks * KT; st0 <= s_last; st0 += MSPLIT * KT) {
     __syncthreads();
     for (int i = tid; i < KT * DH; i += 256) {
       const int r = i / DH, c = i % DH;
@@ -523,11 +538,23 @@ __global__ __launch_bounds__(256) void mlstm_bwd_q_kernel(int S, VilWs w) {
 #pragma unroll
     for (int j = 0; j < DH; ++j) dq[j] += __shfl_xor(dq[j], o, 64);
   if (tv && sl == 0) {
-    float r = 0.f;
 #pragma unroll
-    for (int j = 0; j < DH; ++j) { w.dq[(hb + t) * DH + j] = dq[j]; r = fmaf(dq[j], w.q[(hb + t) * DH + j], r); }
-    w.rq[hb + t] = r;
+    for (int j = 0; j < DH; ++j) atomicAdd(&w.dq[(hb + t) * DH + j], dq[j]);
   }
+}
+// rq_t = q_t.dq_t and ck_s = k_s.dk_s once every partial has been added
+template <int DH>
+__global__ __launch_bounds__(256) void mlstm_bwd_dots_kernel(long long total, VilWs w) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*NH*S rows
+  if (i >= total) return;
+  float r = 0.f, c = 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) {
+    r = fmaf(w.dq[i * DH + j], w.q[i * DH + j], r);
+    c = fmaf(w.dk[i * DH + j], w.k[i * DH + j], c);
+  }
+  w.rq[i] = r;
+  w.ck[i] = c;
 }
 
 // pass B: per key s: dk_s, dv_s over queries t >= s ; ck_s = k_s.dk_s
@@ -538,7 +565,7 @@ __global__ __launch_bounds__(256) void mlstm_bwd_kv_kernel(int S, VilWs w) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const long long hb = ((long long)b * NH + h) * S;
-  const int s0 = blockIdx.x * 32;
+  const int s0 = (blockIdx.x / MSPLIT) * 32, ks = blockIdx.x % MSPLIT;
   const int s = s0 + wv * 8 + (lane >> 3), sl = lane & 7;
   const bool sv = s < S;
   float kk[DH], vv[DH], dk[DH], dv[DH];
@@ -551,7 +578,7 @@ __global__ __launch_bounds__(256) void mlstm_bwd_kv_kernel(int S, VilWs w) {
   }
   if (sv) gs = w.ig[hb + s] - w.F[hb + s];
   const float isq = rsqrtf((float)DH);
-  for (int qt0 = (s0 / QT) * QT; qt0 < S; qt0 += QT) {
+  for (int qt0 = (s0 / QT + ks) * QT; qt0 < S; qt0 += MSPLIT * QT) {
     __syncthreads();
     for (int i = tid; i < QT * DH; i += 256) {
       const int r = i / DH, c = i % DH;
@@ -591,14 +618,11 @@ __global__ __launch_bounds__(256) void mlstm_bwd_kv_kernel(int S, VilWs w) {
 #pragma unroll
     for (int j = 0; j < DH; ++j) { dk[j] += __shfl_xor(dk[j], o, 64); dv[j] += __shfl_xor(dv[j], o, 64); }
   if (sv && sl == 0) {
-    float c = 0.f;
 #pragma unroll
     for (int j = 0; j < DH; ++j) {
-      w.dk[(hb + s) * DH + j] = dk[j];
-      w.dv[(hb + s) * DH + j] = dv[j];
-      c = fmaf(dk[j], kk[j], c);
+      atomicAdd(&w.dk[(hb + s) * DH + j], dk[j]);
+      atomicAdd(&w.dv[(hb + s) * DH + j], dv[j]);
     }
-    w.ck[hb + s] = c;
   }
 }
 
@@ -807,7 +831,11 @@ static int vil_fwd_impl(hipStream_t st, const T* xa, const T* xb, T* out, int B,
   hipLaunchKernelGGL((vil_pre1_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, xb, S, *p, w);
   hipLaunchKernelGGL((vil_pre2_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, w);
   hipLaunchKernelGGL(vil_scan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
-  hipLaunchKernelGGL((mlstm_fwd_kernel<DH>), dim3(cdiv(S, 32), NH, B), dim3(256), 0, st, S, w);
+  const long long rows_f = (long long)B * NH * S;
+  (void)hipMemsetAsync(w.h, 0, (size_t)rows_f * DH * sizeof(float), st);
+  (void)hipMemsetAsync(w.bden, 0, (size_t)rows_f * sizeof(float), st);
+  hipLaunchKernelGGL((mlstm_fwd_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
+  hipLaunchKernelGGL((mlstm_norm_kernel<DH>), dim3((unsigned)((rows_f + 255) / 256)), dim3(256), 0, st, rows_f, w);
   hipLaunchKernelGGL((vil_post_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, out, S, add_xa, *p, w);
   return xh_launch_status();
 }
@@ -821,8 +849,9 @@ static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, co
   hipLaunchKernelGGL((vil_post_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, S, *p, *g, w);
   hipLaunchKernelGGL((mlstm_bwd_prep_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
   hipLaunchKernelGGL(mlstm_bwd_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
-  hipLaunchKernelGGL((mlstm_bwd_q_kernel<DH>), dim3(cdiv(S, 32), NH, B), dim3(256), 0, st, S, w);
-  hipLaunchKernelGGL((mlstm_bwd_kv_kernel<DH>), dim3(cdiv(S, 32), NH, B), dim3(256), 0, st, S, w);
+  hipLaunchKernelGGL((mlstm_bwd_q_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
+  hipLaunchKernelGGL((mlstm_bwd_kv_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
+  hipLaunchKernelGGL((mlstm_bwd_dots_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, w);
   hipLaunchKernelGGL(vil_rscan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
   hipLaunchKernelGGL((vil_pre2_bwd_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, *g, w);
   hipLaunchKernelGGL((vil_pre1_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, dxin, S, *p, *g, w);
