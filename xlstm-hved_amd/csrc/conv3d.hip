@@ -1158,7 +1158,10 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
   }
   if (d->k == 3 && d->stride == 2) {
     if (d->transposed) return XH_ERR_ARG;
-    const int cob = pick_cob(cout_g, 8) < 2 ? 2 : pick_cob(cout_g, 8);
+    int cob = pick_cob(cout_g, 8) < 2 ? 2 : pick_cob(cout_g, 8);
+    // small outputs (the deep DRB levels): few lanes, so the per-lane chain cin_g x 27 x COB is the run time -- use
+    // narrow channel blocks to get 4x more workgroups with 4x shorter chains
+    if ((long long)d->Do * d->Ho * d->Wo * d->N * d->groups <= (1 << 16) && cob > 2) cob = 2;
     ConvK a = make_k(d, p, cob, txn);
     const long long odhw = (long long)d->Do * d->Ho * d->Wo;
     dim3 grid((unsigned)((odhw + 255) / 256), a.ncob, d->N * d->groups);
