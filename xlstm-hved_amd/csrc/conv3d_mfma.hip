@@ -414,7 +414,9 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   // depth segments: enough workers for ~2 resident workgroups per CU, but runs of at least 4 planes
   const int cols = a->tilesW * a->tilesH;
   int dsegs = cdiv(a->th == 4 ? 1024 : 512, cols * ny * d->N);
-  const int max_segs = d->Do >= 4 ? d->Do / 4 : 1;
+  // runs of >= 4 planes (2 on small volumes, where workgroup count matters more than the 2 halo planes per run)
+  const int min_run = ((long long)d->Do * d->Ho * d->Wo <= (1 << 16) && !(g_mfma_abl & 512)) ? 2 : 4;
+  const int max_segs = d->Do >= min_run ? d->Do / min_run : 1;
   if (dsegs > max_segs) dsegs = max_segs;
   if (dsegs < 1) dsegs = 1;
   a->sd = cdiv(d->Do, dsegs);
