@@ -91,6 +91,7 @@ class InLreluConv(Function):
         ctx.params = (weights, biases)
         if out_stats:
             ctx.mark_non_differentiable(red_y)
+            ctx.set_materialize_grads(False)          # no zero-filled "gradient" for the statistics output
             return y, red_y
         return y
 
@@ -207,6 +208,7 @@ class Conv(Function):
         ctx.params = (weights, biases)
         if out_stats:
             ctx.mark_non_differentiable(red_y)
+            ctx.set_materialize_grads(False)
             return y, red_y
         return y
 
