@@ -195,8 +195,12 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
       }
     }
   }
-  uint4 raw[NIT][4];
-  auto load_plane = [&](int gd) {
+  // Small channel counts have too little MFMA work per plane to hide a global load behind it: their staging loads are
+  // issued TWO planes ahead (a second register buffer), so a load has a whole plane iteration to land.
+  constexpr bool DEEP = CINP <= 8;
+  constexpr int AHEAD = DEEP ? 3 : 2;
+  uint4 rawA[NIT][4], rawB[DEEP ? NIT : 1][4];
+  auto load_plane = [&](int gd, uint4 (&raw)[NIT][4]) {
     const bool dok = (unsigned)gd < (unsigned)D && !(a.abl & 2);
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
         if (dok && sp_src[it][cc]) raw[it][cc] = *reinterpret_cast<const uint4*>(sp_src[it][cc] + (long long)gd * hw);
       }
   };
-  auto store_plane = [&](int gd) {
+  auto store_plane = [&](int gd, uint4 (&raw)[NIT][4]) {
     if (a.abl & 16) return;
     const int slot = ((gd + 4) & 3) * PLANE;
     const bool dok = (unsigned)gd < (unsigned)D;
@@ -242,22 +246,22 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
   };
 
   // ---- prologue: planes d_begin-1, d_begin, d_begin+1 into the ring ----
-  load_plane(d_begin - 1);
-  store_plane(d_begin - 1);
-  load_plane(d_begin);
-  store_plane(d_begin);
-  load_plane(d_begin + 1);
-  store_plane(d_begin + 1);
+  load_plane(d_begin - 1, rawA);
+  store_plane(d_begin - 1, rawA);
+  load_plane(d_begin, rawA);
+  store_plane(d_begin, rawA);
+  load_plane(d_begin + 1, rawA);
+  store_plane(d_begin + 1, rawA);
   __syncthreads();
 
   constexpr int RPW = (TH + NWV - 1) / NWV;           // output rows per wave
-  for (int d = d_begin; d < d_end; ++d) {
+  auto plane_step = [&](int d, uint4 (&rl)[NIT][4], uint4 (&rs)[NIT][4]) {
     // Order inside a plane: (1) issue the global loads of plane d+2, (2) MFMA pass over this wave's rows, (3) the loads
     // have landed: transform + LDS-write plane d+2 into the slot nobody reads, (4) epilogue: transpose, global stores,
     // (5) barrier.  The stores are the last memory operations of the iteration, so the only vmcnt wait (step 3 of the
     // NEXT plane) finds them long drained instead of stalling every plane on their acknowledgement.
-    const bool more = d + 1 < d_end;
-    if (more) load_plane(d + 2);
+    const bool more = d + 2 <= d_end;                 // plane d+2 is still to be staged
+    if (d + AHEAD <= d_end) load_plane(d + AHEAD, rl);
     const int sbase = d + 3;                          // slot of input plane d-1+kd = (sbase + kd) & 3
     f32x4 accs[RPW][NSEG];
 #pragma unroll
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
         }
       }
     }
-    if (more) store_plane(d + 2);
+    if (more) store_plane(d + 2, rs);
 #pragma unroll
     for (int ri = 0; ri < RPW; ++ri) {
       const int rr = wv + ri * NWV;
@@ -357,6 +361,15 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
       }
     }
     __syncthreads();                                  // plane d+2 visible; everyone is done reading planes d-1..d+1
+  };
+  if constexpr (DEEP) {
+    if (d_begin + 2 <= d_end) load_plane(d_begin + 2, rawA);
+    for (int d = d_begin; d < d_end; d += 2) {
+      plane_step(d, rawB, rawA);                      // loads plane d+3 into B, stages plane d+2 from A
+      if (d + 1 < d_end) plane_step(d + 1, rawA, rawB);
+    }
+  } else {
+    for (int d = d_begin; d < d_end; ++d) plane_step(d, rawA, rawA);
   }
   if (a.d.epi && !a.part_out) {
     s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
