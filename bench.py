@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time forward-only and the shared-encoder two-forward step")
     return ap.parse_args()
 
 
@@ -184,6 +185,8 @@ def main():
     }
     if roof is not None:
         out["roofline"] = roof
+    if args.extras and rank == 0:
+        out["extras"] = extras(model, x, grads, args.steps)
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(S, B)
     if rank == 0:
@@ -191,6 +194,46 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def extras(model, x, grads, nsteps):
+    """Not part of the headline metric: forward-only time (SURVEY 8(d) asks for it) and the training step's two
+    forwards (`[14]` + a random subset, train.py:224-225) with and without the shared encoder (forward_shared)."""
+    def timed(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / nsteps * 1e3
+
+    def fwd_only():
+        with torch.no_grad():
+            model(x, [14], recon=True)
+
+    def two_plain():
+        grads.zero()
+        a = model(x, [14], recon=True)
+        b = model(x, [6], recon=True)
+        (bench_loss(a[0], a[1][0], a[1][1], a[2][0]) + bench_loss(b[0], b[1][0], b[1][1], b[2][0])).backward()
+
+    def two_shared():
+        grads.zero()
+        a, b = model.forward_shared(x, [dict(subset_idx_list=[14]), dict(subset_idx_list=[6])], recon=True)
+        (bench_loss(a[0], a[1][0], a[1][1], a[2][0]) + bench_loss(b[0], b[1][0], b[1][1], b[2][0])).backward()
+    return {"forward_only_ms": timed(fwd_only), "two_forwards_fwd_bwd_ms": timed(two_plain),
+            "two_forwards_shared_encoder_fwd_bwd_ms": timed(two_shared)}
 
 
 def roofline_pass(step, ops, nsteps, dtype):

@@ -323,3 +323,38 @@ def test_two_forwards_before_one_backward_match_separate_steps():
         if k.startswith("init_blocks."):
             continue
         assert (both[k] - sep[k]).abs().max().item() <= 2e-4 * gmax, k
+
+
+def test_forward_shared_equals_two_forwards():
+    """SURVEY 8(f) f4: `model(x, [14])` and `model(x, subset)` of one training step share everything up to the PoE;
+    forward_shared runs that part once.  Outputs, BatchNorm buffers and parameter gradients must match two plain forwards."""
+    torch.manual_seed(9)
+    x = torch.rand(1, 4, 32, 32, 32)
+    eps = [torch.randn(1, 2 ** l, 16 >> l, 16 >> l, 16 >> l) for l in range(4)]
+
+    def loss_of(out):
+        seg, (mu, lv), rec = out
+        return (seg * seg).mean() + rec[0].abs().mean() + sum((a * a).mean() + b.mean() for a, b in zip(mu, lv))
+    m1 = _model(True)
+    o14 = m1(x.to(DEV), [14], recon=True, eps_list=eps)
+    o6 = m1(x.to(DEV), [6], recon=True, eps_list=eps)
+    (loss_of(o14) + loss_of(o6)).backward()
+    m2 = _model(True)
+    s14, s6 = m2.forward_shared(x.to(DEV), [dict(subset_idx_list=[14], eps_list=eps), dict(subset_idx_list=[6], eps_list=eps)],
+                                recon=True)
+    (loss_of(s14) + loss_of(s6)).backward()
+    for a, b in ((o14, s14), (o6, s6)):
+        check(b[0], a[0], 1e-5, "seg"), check(b[2][0], a[2][0], 1e-5, "rec")
+        for l in range(4):
+            check(b[1][0][l], a[1][0][l], 1e-6, "mu"), check(b[1][1][l], a[1][1][l], 1e-6, "logvar")
+    g1 = {k: p.grad for k, p in m1.named_parameters() if p.grad is not None}
+    g2 = {k: p.grad for k, p in m2.named_parameters() if p.grad is not None}
+    assert g1.keys() == g2.keys()
+    gmax = max(v.abs().max().item() for v in g1.values())
+    for k in g1:
+        if not k.startswith("init_blocks."):
+            assert (g1[k] - g2[k]).abs().max().item() <= 2e-4 * gmax, k
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        if "running" in k or "num_batches" in k:
+            check(sd2[k].float(), sd1[k].float(), 1e-5, k)

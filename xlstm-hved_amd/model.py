@@ -229,10 +229,27 @@ class AbstractFusion3DUNet(nn.Module):
                 eps_list=None):
         """RA_HVED.py:510-648.  `eps_list` (optional, not in the reference signature) injects the reparameterisation
         noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
+        enc = self._encode(x, bn_steps=4)
+        return self._decode(enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list)
+
+    def forward_shared(self, x, calls, seg=True, recon=False):
+        """Several forwards of the SAME input that differ only in the modality subset / sampling (train.py:224-225 runs
+        `model(x, [14])` and `model(x, subset)` back to back): init blocks, encoders, DRBs and the skip-return path are
+        functions of the input alone (mu/logvar stacks are bit-identical between such calls), so they run
+        once and only PoE -> reparameterisation -> decoders run per call.  `calls` is a list of dicts with the per-call
+        keyword arguments of forward() (subset_idx_list, instance_missing, drop, valid, eps_list).  Returns the list of
+        forward() results.  BatchNorm buffers of the skip-return attention advance 4 steps per call, as they would."""
+        enc = self._encode(x, bn_steps=4 * len(calls))
+        outs = []
+        for kw in calls:
+            outs.append(self._decode(enc, kw.get("subset_idx_list", [14]), kw.get("instance_missing", False), kw.get("drop"),
+                                     seg, recon, kw.get("valid", False), kw.get("eps_list")))
+        return outs
+
+    def _encode(self, x, bn_steps):
+        """The input-only part: per-level DRB outputs (4 streams x [mu | logvar] before PoE) and the skip-return feature."""
         batched = self.layer_order == "ilc"     # 'ilc' runs the 4 modality streams as one grouped launch per stage
         ops.red_arena_reset(x.device)
-        n = x.shape[0]
-        keep = self._keep_mask(x, subset_idx_list, instance_missing, drop)
         x = x.contiguous()
         st0 = None
         if batched:
@@ -240,12 +257,12 @@ class AbstractFusion3DUNet(nn.Module):
                              out_stats=True)               # level 0's first InstanceNorm takes its sums from here
         else:
             X = [Fn.conv(x[:, i:i + 1].contiguous(), [b[0].weight], [b[0].bias]) for i, b in enumerate(self.init_blocks)]
-        mu_list, logvar_list, feats = [], [], []
+        feat_list = []
         skip = None
         levels = len(self.encoders)
         for level in range(levels):
             if self.skip_return and skip is not None:
-                a = self.skr_att[levels - level](skip, steps=4)                             # skr_att[-level], RA_HVED.py:552
+                a = self.skr_att[levels - level](skip, steps=bn_steps)                      # skr_att[-level], RA_HVED.py:552
                 X = Fn.Gate.apply(X, a) if batched else [Fn.Gate.apply(xi, a) for xi in X]
             if batched:
                 if level > 0:
@@ -261,6 +278,21 @@ class AbstractFusion3DUNet(nn.Module):
                 # 'gcr' (U_HVEDConvNet3D / U_HVEDConvXLSTMNet3D defaults): one stream at a time through the same HIP stages
                 X = [enc(xi) for enc, xi in zip(self.encoders[level], X)]
                 feat = torch.cat([m(xi) for m, xi in zip(self.DRBs[level], X)], 1)
+            feat_list.append(feat)
+            if self.skip_return:                                                            # RA_HVED.py:617-621
+                if skip is None:
+                    skip = Fn.conv(x, [self.x0_init[0].weight], [self.x0_init[0].bias])
+                else:
+                    skip = self.skr_encoders[levels - 1 - level](skip)
+        return x, feat_list, skip
+
+    def _decode(self, enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list):
+        """PoE over the chosen experts -> reparameterisation -> VU blocks -> (mid ViL) -> decoders -> heads."""
+        x, feat_list, skip = enc
+        n = x.shape[0]
+        keep = self._keep_mask(x, subset_idx_list, instance_missing, drop)
+        mu_list, logvar_list, feats = [], [], []
+        for level, feat in enumerate(feat_list):
             L_ = self.MVAE_latents[level]
             eps = None
             if not valid:
@@ -274,11 +306,6 @@ class AbstractFusion3DUNet(nn.Module):
             z = Fn.Upsample.apply(z, tuple(2 * s for s in z.shape[2:]))                     # RA_HVED.py:600-601
             z = self.conv_blocks[level](z)                                                  # RA_HVED.py:603
             feats.insert(0, z)
-            if self.skip_return:                                                            # RA_HVED.py:617-621
-                if skip is None:
-                    skip = Fn.conv(x, [self.x0_init[0].weight], [self.x0_init[0].bias])
-                else:
-                    skip = self.skr_encoders[levels - 1 - level](skip)
         if self.mid_ViL and self.skip_return:                                               # RA_HVED.py:623-626
             feats[0] = self.mViL(feats[0], skip, residual_input=True)
         if not self.recon_skip:
