@@ -232,8 +232,23 @@ def extras(model, x, grads, nsteps):
         grads.zero()
         a, b = model.forward_shared(x, [dict(subset_idx_list=[14]), dict(subset_idx_list=[6])], recon=True)
         (bench_loss(a[0], a[1][0], a[1][1], a[2][0]) + bench_loss(b[0], b[1][0], b[1][1], b[2][0])).backward()
-    return {"forward_only_ms": timed(fwd_only), "two_forwards_fwd_bwd_ms": timed(two_plain),
-            "two_forwards_shared_encoder_fwd_bwd_ms": timed(two_shared)}
+    res = {"forward_only_ms": timed(fwd_only), "two_forwards_fwd_bwd_ms": timed(two_plain),
+           "two_forwards_shared_encoder_fwd_bwd_ms": timed(two_shared)}
+    # one 240 x 240 x 155 volume, 128^3 windows every 64 voxels (18 windows), posterior mean, eval mode
+    from xlstm_hved_amd.inference import eval_overlap_volume
+    vol = torch.rand(1, 4, 240, 240, 155, device=x.device).to(x.dtype)
+    model.eval()
+    try:
+        for use_graph in (False, True):
+            eval_overlap_volume(model, vol, 14, use_graph=use_graph)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eval_overlap_volume(model, vol, 14, use_graph=use_graph)
+            torch.cuda.synchronize()
+            res["tiler_240x240x155_18_windows_ms" + ("_graph" if use_graph else "_eager")] = (time.perf_counter() - t0) * 1e3
+    finally:
+        model.train()
+    return res
 
 
 def roofline_pass(step, ops, nsteps, dtype):
