@@ -172,7 +172,7 @@ def main():
     # ---- roofline of the dominant kernel family: per-launch HIP events on the launch stream ------------
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = roofline_pass(step, ops, min(args.steps, 5), dtype)
+        roof = roofline_pass(compute, ops, min(args.steps, 5), dtype)      # rank-local: no collective inside
 
     out = {
         "metric": "voxels/sec fwd+bwd, 4-modality 128^3 patch", "value": value, "unit": "voxels/s", "n_gpus": world,
