@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and issue the gradient all-reduce even with one rank (exercises the N>1 code path)")
     ap.add_argument("--extras", action="store_true", help="also time forward-only and the shared-encoder two-forward step")
     return ap.parse_args()
 
@@ -103,9 +105,15 @@ def main():
     from xlstm_hved_amd import ops
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     S, B = args.size, args.batch
 
@@ -125,11 +133,11 @@ def main():
 
     def step():
         compute()
-        if world > 1:
+        if use_dist:
             grads.all_reduce(world)                             # one in-place RCCL all-reduce of the bucket
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -145,12 +153,13 @@ def main():
     graph = None
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: RCCL's watchdog thread may query events while this thread captures; that must not abort the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if use_dist else "global"):
             compute()                                           # the collective stays outside the capture
 
     def run_graph():
         graph.replay()
-        if world > 1:
+        if use_dist:
             grads.all_reduce(world)
     run = run_graph if graph is not None else step
     for _ in range(args.warmup):
@@ -161,7 +170,7 @@ def main():
         run()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,8 +200,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(S, B)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
+        dist.barrier()                                          # rank 0 arrives after its roofline pass
         dist.destroy_process_group()
 
 
