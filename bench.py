@@ -94,6 +94,12 @@ def cpu_baseline(size, batch, budget_s=45.0, max_threads=16):
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE line (the JSON).  Native libraries (RCCL prints a version banner at communicator
+    # creation, flushed at exit) write to file descriptor 1 too, so fd 1 is pointed at stderr for the whole run and the
+    # JSON is written to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,7 +205,7 @@ def main():
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(S, B)
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         import torch.distributed as dist
         dist.barrier()                                          # rank 0 arrives after its roofline pass
