@@ -1586,6 +1586,94 @@ __global__ __launch_bounds__(256) void conv_dw3_wgrad_slide_kernel(const WgradK 
   if (tid == 27 && wa.db[c / gpp]) atomicAdd(&wa.db[c / gpp][c % gpp], s_red[27]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k = 3, stride = 2 weight gradient, vectorised (the DRB convs).  A workgroup fixes (group, input channel ci); a lane
+// owns VW/2 consecutive outputs of one output row: it reads the 9 input rows of its channel as 16-byte runs (left
+// neighbour column by wave shuffle, producer norm/activation applied) and the dY run of every output channel of the
+// group, and keeps the 27 x COUT_G partial sums in registers until one block reduction.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_kernel(const WgradK wa, int LW) {
+  const ConvK& a = wa.c;
+  constexpr int VW = VWT<T>::v, OW = VW / 2, NACC = 27 * CO + CO;
+  __shared__ float s_red[4 * NACC];
+  const int tid = threadIdx.x;
+  const int ci_g = blockIdx.y;
+  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
+  const int c = g * a.Cin_g + ci_g;
+  float sc = 1.f, sh = 0.f;
+  if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+  float acc[27][CO], dbs[CO];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[t][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < CO; ++j) dbs[j] = 0.f;
+  const long long rows = (long long)Do * Ho;
+  const long long lanes = rows * LW;
+  for (long long lane_id = (long long)blockIdx.x * 256 + tid; lane_id - tid < lanes; lane_id += (long long)gridDim.x * 256) {
+    const int tx = (int)(lane_id % LW);
+    const long long row = lane_id / LW;
+    const bool ok = row < rows;
+    const int oh = (int)(row % Ho), od = (int)min(row / Ho, (long long)Do - 1);
+    const int ow0 = tx * OW;
+    const float okm = ok ? 1.f : 0.f;
+    float dyv[CO][OW];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) {
+      const T* dp = (const T*)a.p.ea + n * a.d.ea_bs + (long long)(g * a.Cout_g + j) * odhw + ((long long)od * Ho + oh) * Wo + ow0;
+      ldhalf_c(dp, dyv[j]);
+#pragma unroll
+      for (int v = 0; v < OW; ++v) { dyv[j][v] *= okm; dbs[j] += dyv[j][v]; }
+    }
+    const T* src = in_plane<T>(a, n, c, dhw) + 2 * ow0;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int gd = 2 * od - 1 + kd, gh = 2 * oh - 1 + kh;
+        const float m = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) ? 1.f : 0.f;
+        float x[VW], r[VW + 1];
+        ldvec(src, ((long long)min(max(gd, 0), D - 1) * H + min(max(gh, 0), H - 1)) * W, x);
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          float xv = x[v];
+          if (a.d.pre) xv = leaky(xv * sc + sh, a.d.pre_slope);
+          r[v + 1] = xv * m;
+        }
+        const float l = __shfl_up(r[VW], 1, 64);
+        r[0] = tx == 0 ? 0.f : l;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int j = 0; j < CO; ++j) {
+            float t = acc[(kd * 3 + kh) * 3 + kw][j];
+#pragma unroll
+            for (int v = 0; v < OW; ++v) t = fmaf(r[2 * v + kw], dyv[j][v], t);
+            acc[(kd * 3 + kh) * 3 + kw][j] = t;
+          }
+      }
+  }
+  float v[NACC];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int j = 0; j < CO; ++j) v[t * CO + j] = acc[t][j];
+#pragma unroll
+  for (int j = 0; j < CO; ++j) v[27 * CO + j] = dbs[j];
+  block_sum<NACC>(v, s_red, 4);
+  const int gpp = a.d.groups / a.d.n_wptr, gl = g % gpp;
+  if (tid < 27 * CO) {
+    const int t = tid / CO, j = tid % CO;
+    atomicAdd(&wa.dw[g / gpp][((long long)(gl * a.Cout_g + j) * a.Cin_g + ci_g) * 27 + t], s_red[tid]);
+  } else if (tid < NACC && ci_g == 0 && wa.db[g / gpp]) {
+    atomicAdd(&wa.db[g / gpp][gl * a.Cout_g + (tid - 27 * CO)], s_red[tid]);
+  }
+}
+
 template <typename T>
 static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4],
                           float* const db[4]) {
@@ -1633,6 +1721,27 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
         case 16: hipLaunchKernelGGL((conv_dw3_wgrad_slide_kernel<T, 16>), grid, dim3(256), 0, (hipStream_t)stream, wa, sd); break;
         default: hipLaunchKernelGGL((conv_dw3_wgrad_slide_kernel<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, wa, sd);
       }
+      return xh_launch_status();
+    }
+  }
+  if (d->k == 3 && d->stride == 2 && (cout_g == 2 || cout_g == 4) && !(g_xh_disable & 4)) {
+    constexpr int VW = VWT<T>::v;
+    const int lw = d->W / VW;
+    const long long dhw2 = (long long)d->D * d->H * d->W, odhw2 = (long long)d->Do * d->Ho * d->Wo;
+    const bool al = d->W % VW == 0 && d->Wo * 2 == d->W && lw >= 1 && lw <= 64 && (64 % lw) == 0 && dhw2 % VW == 0 &&
+                    odhw2 % (VW / 2) == 0 && d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && d->ea_bs % (VW / 2) == 0 &&
+                    cin_g <= 65535 && (long long)d->N * d->groups <= 65535;
+    if (al) {
+      wa.c = make_k(d, p, 1, 8);
+      const long long lanes = (long long)d->Do * d->Ho * lw;
+      long long gx = (lanes + 255) / 256;
+      const long long cap = cdiv(4096, cin_g * d->groups * d->N);          // few enough workgroups that the atomics tail stays small
+      if (gx > cap) gx = cap;
+      if (gx < 1) gx = 1;
+      dim3 grid((unsigned)gx, cin_g, d->N * d->groups);
+      xh_note_kernel("conv3_s2_wgrad_vec_kernel<%s, %d>", tname<T>(), cout_g);
+      if (cout_g == 2) hipLaunchKernelGGL((conv3_s2_wgrad_vec_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, wa, lw);
+      else hipLaunchKernelGGL((conv3_s2_wgrad_vec_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, wa, lw);
       return xh_launch_status();
     }
   }
