@@ -150,17 +150,35 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
   load_plane(d_begin);
   store_plane(d_begin);
   load_plane(d_begin + 1);
+  // The A operand (dY rows) comes straight from global memory: fetch it one plane ahead so its latency hides behind the
+  // previous plane's MFMAs instead of stalling every row.
+  constexpr int RPW = (TH + NWV - 1) / NWV;
+  uint4 a_nxt[RPW];
+  auto load_dy = [&](int d) {
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) {
+      const int oh = oh0 + wv + ri * NWV;
+      a_nxt[ri] = make_uint4(0, 0, 0, 0);
+      if (a_ok && wv + ri * NWV < TH && oh < Ho) a_nxt[ri] = *reinterpret_cast<const uint4*>(dyp + ((long long)d * Ho + oh) * Wo);
+    }
+  };
+  load_dy(d_begin);
   for (int d = d_begin; d < d_end; ++d) {
     store_plane(d + 1);
     __syncthreads();
     if (d + 1 < d_end) load_plane(d + 2);
+    uint4 a_cur[RPW];
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) a_cur[ri] = a_nxt[ri];
+    if (d + 1 < d_end) load_dy(d + 1);
     const int sbase = d + 3;
-    for (int rr = wv; rr < TH; rr += NWV) {
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) {
+      const int rr = wv + ri * NWV;
       const int oh = oh0 + rr;
-      if (oh >= Ho) continue;
+      if (rr >= TH || oh >= Ho) continue;
       // A fragment: 8 voxels of dY
-      uint4 araw = make_uint4(0, 0, 0, 0);
-      if (a_ok) araw = *reinterpret_cast<const uint4*>(dyp + ((long long)d * Ho + oh) * Wo);
+      const uint4 araw = a_cur[ri];
       const bf16x8 av = __builtin_bit_cast(bf16x8, araw);
       {
         const unsigned u[4] = {araw.x, araw.y, araw.z, araw.w};
