@@ -82,6 +82,11 @@ typedef struct {
   double* red;                                /* [N][Cout][2], caller zeroes, epi!=0 */
   void* ws; long long ws_bytes;               /* scratch for packed bf16 MFMA weight fragments (may be NULL:
                                                  the vector kernel is used); size from xh_conv3d_workspace_bytes */
+  /* Optional fused InstanceNorm finalisation (MFMA path only; needs pre == 1): when fin_red is given, the weight-pack
+   * launch that precedes the conv also turns the raw sums fin_red[n][c] = (sum x, sum x^2) over fin_count voxels into
+   * pre_sc = rstd, pre_sh = -mean*rstd (WRITTEN here, then read by the conv) and fin_mean / fin_rstd (kept for the
+   * backward), replacing a separate xh_norm_finalize launch.  A call that cannot take the MFMA path returns an error. */
+  const double* fin_red; float* fin_mean; float* fin_rstd; long long fin_count;
 } xh_conv_ptrs;
 
 /* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv

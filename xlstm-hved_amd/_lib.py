@@ -33,6 +33,7 @@ class ConvPtrs(C.Structure):
     _fields_ = [
         ("xa", vp), ("xb", vp), ("w", vp * 4), ("b", vp * 4), ("pre_sc", vp), ("pre_sh", vp), ("y", vp),
         ("ea", vp), ("eb", vp), ("e_sc", vp), ("e_sh", vp), ("red", vp), ("ws", vp), ("ws_bytes", ll),
+        ("fin_red", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_count", ll),
     ]
 
 

@@ -1236,10 +1236,12 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
   if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cout && !p->eb))) return XH_ERR_ARG;
   if (d->epi == 2 && !p->red) return XH_ERR_ARG;
   if (d->epi < 0 || d->epi > 2) return XH_ERR_ARG;
+  if (p->fin_red && (!d->pre || !p->fin_mean || !p->fin_rstd || p->fin_count <= 0 || d->k != 3)) return XH_ERR_ARG;
   if (g_use_mfma) {
     const int r = d->k == 7 ? xh_conv7_mfma_try(stream, d, p) : xh_conv3_mfma_try(stream, d, p);
     if (r != 1) return r;
   }
+  if (p->fin_red) return XH_ERR_ARG;                  // the fused finalisation exists on the MFMA path only
   xh_note_kernel("conv k%d s%d (vector kernel family)", d->k, d->stride);
   return d->dtype == XH_F32 ? conv_fwd_dispatch<float>(stream, d, p) : conv_fwd_dispatch<bf16_t>(stream, d, p);
 }

@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
     if (kw < 3 && ci < a.cin_blk && cin0 + ci < cin_end) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
   }
   wf[idx] = f2bf(v);
+  // fused InstanceNorm finalisation (xh_conv_ptrs.fin_red): one workgroup turns the raw sums into scale / shift
+  if (a.p.fin_red && blockIdx.x == 0 && blockIdx.y == 0 && a.cin_off == 0) {
+    const int total = a.d.N * a.d.Cin;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const double cnt = (double)a.p.fin_count;
+      const double mean = a.p.fin_red[2 * i] / cnt;
+      double var = a.p.fin_red[2 * i + 1] / cnt - mean * mean;
+      if (var < 0) var = 0;
+      const double rstd = 1.0 / sqrt(var + 1e-5);
+      const_cast<float*>(a.p.pre_sc)[i] = (float)rstd;
+      const_cast<float*>(a.p.pre_sh)[i] = (float)(-mean * rstd);
+      a.p.fin_mean[i] = (float)mean;
+      a.p.fin_rstd[i] = (float)rstd;
+    }
+  }
 }
 
 // LDS swizzle: XOR the 16-byte chunk index (bits 4..6) with the 256-byte block index (bits 8..10).  Both the 8-voxel

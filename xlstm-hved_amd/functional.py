@@ -80,12 +80,11 @@ class InLreluConv(Function):
             ops.moments(xa, red, 0)
             if xb is not None:
                 ops.moments(xb, red, ca)
-        sc, sh, mean, rstd = ops.norm_finalize(MODE_IN, red, n, cin, _dhw(xa))
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
         red_y = ops.zeros_red(xa, n, cout) if out_stats else None
-        y = ops.conv3d(xa, xb, weights, biases, k=k, cout=cout, stride=stride, groups=groups, pre=(sc, sh, LEAK),
-                       epi=2 if out_stats else 0, red=red_y)
+        y, sc, sh, mean, rstd = ops.conv3d(xa, xb, weights, biases, k=k, cout=cout, stride=stride, groups=groups,
+                                           in_stats=(red, _dhw(xa), LEAK), epi=2 if out_stats else 0, red=red_y)
         ctx.save_for_backward(xa, xb, sc, sh, mean, rstd, *weights)
         ctx.cfg = (stride, groups, nw, k, cin, ca)
         ctx.params = (weights, biases)

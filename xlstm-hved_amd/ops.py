@@ -147,9 +147,11 @@ def _out_spatial(d, h, w, k, stride):
 
 
 def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=False, pre=None, act=ACT_NONE,
-           act_slope=LEAK, epi=0, e=None, red=None, out=None):
+           act_slope=LEAK, epi=0, e=None, red=None, out=None, in_stats=None):
     """y = act(conv(pre(cat[xa, xb])) + b) [+ fused epilogue].  weights/biases: lists of 1 or `groups` fp32 tensors.
-    pre = (sc, sh, slope); e = (ea, eb, e_sc, e_sh, e_slope) for epi==1.  `out` may be a channel slice."""
+    pre = (sc, sh, slope); e = (ea, eb, e_sc, e_sh, e_slope) for epi==1.  `out` may be a channel slice.
+    in_stats = (red, count, slope) instead of pre: InstanceNorm + LeakyReLU of the input from its raw channel sums; returns
+    (y, sc, sh, mean, rstd).  On the MFMA path the finalisation rides on the weight-pack launch, else xh_norm_finalize runs."""
     lib = L.load()
     n, ca, d, h, w, _ = _vol(xa)
     osp = _out_spatial(d, h, w, k, stride)
@@ -158,6 +160,11 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     y_bs = _vol(out)[5]
     if tuple(out.shape) != (n, cout) + osp or out.dtype != xa.dtype:
         raise ValueError(f"conv output tensor has shape {tuple(out.shape)}, expected {(n, cout) + osp}")
+    stats = None
+    if in_stats is not None:
+        cin = ca + (xb.shape[1] if xb is not None else 0)
+        stats = tuple(torch.empty((n, cin), dtype=torch.float32, device=xa.device) for _ in range(4))   # sc, sh, mean, rstd
+        pre = (stats[0], stats[1], in_stats[2])
     desc = _conv_desc(xa, xb, k, stride, groups, cout, len(weights), transposed, pre, act, act_slope, epi, e, y_bs, osp)
     ptrs = L.ConvPtrs()
     ptrs.xa, ptrs.xb = _p(xa), _p(xb)
@@ -175,7 +182,16 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     if need:
         ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
         ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
+    if stats is not None:
+        if need:            # MFMA path: the pack launch finalises the statistics
+            ptrs.fin_red, ptrs.fin_mean, ptrs.fin_rstd, ptrs.fin_count = _p(in_stats[0]), _p(stats[2]), _p(stats[3]), int(in_stats[1])
+        else:
+            L.check(lib.xh_norm_finalize(_stream(), 0, _p(in_stats[0]), n, stats[0].shape[1], int(in_stats[1]), 1, NORM_EPS, None,
+                                         None, None, None, 1, _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3])),
+                    "xh_norm_finalize")
     L.check(lib.xh_conv3d_fwd(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_fwd")
+    if stats is not None:
+        return (out,) + stats
     return out
 
 
