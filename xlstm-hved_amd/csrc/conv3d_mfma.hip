@@ -117,11 +117,9 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
   constexpr int NQ = CINP / 4, NG = TW / 8 + 2;       // channel quads; aligned 8-voxel groups covering [ow0-8, ow0+TW+8)
   constexpr int NITEM = IH * NG * NQ;                 // staging items per plane
   constexpr int NIT = (NITEM + NT - 1) / NT;
-  constexpr int EPS = 36;                             // epilogue pad row stride (floats)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_in = smem;                                                     // 4 * PLANE
-  float* s_ep = reinterpret_cast<float*>(smem + 4 * PLANE);                       // [NWV waves][16][EPS]
-  double* s_red = reinterpret_cast<double*>(s_ep);                                // reused after the plane loop
+  double* s_red = reinterpret_cast<double*>(smem + 4 * PLANE);                    // [NWV waves][32] after the plane loop
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g4 = lane >> 4, nn = lane & 15;
@@ -159,8 +157,11 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
       aoff[i] = ((r9 % 3) * IWP + nn) * VB + j * 16;
     }
   }
-  // ---- epilogue lane role: output channel lane>>2, voxels (lane&3)*8 .. +7 of a 32-voxel row ----
-  const int eco = lane >> 2, ech = lane & 3;
+  // ---- epilogue lane role: the accumulator layout itself -- lane (nn, g4) holds output channel nn, voxels 4*g4 .. +3 of
+  // each 16-voxel segment: bias / activation / fused sums in registers and one 8-byte NCDHW store per segment, with no
+  // transpose through LDS (a 16-byte-store epilogue via a wave-private LDS pad cost two LDS round trips and two wave
+  // barriers per row, and 18 KB of LDS) ----
+  const int eco = nn;
   const int co = co_base + eco;
   const bool co_ok = eco < co_lim;
   float bias = 0.f, esc = 0.f, esh = 0.f;
@@ -177,7 +178,6 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
     }
   }
   bf16_t* yplane = (bf16_t*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
-  float* ep = s_ep + wv * 16 * EPS;
   double s0 = 0.0, s1 = 0.0;     // running statistics in fp64 (block_sum_d note in common.h)
 
   // ---- per-thread staging plan (identical for every plane) ----
@@ -311,68 +311,40 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
       if (rr >= TH || oh >= Ho) continue;             // wave-uniform
       f32x4 (&acc)[NSEG] = accs[ri];
       if (a.abl & 32) continue;
-      // ---- transpose through the wave-private pad: [cout nn][voxel wt*16 + 4*g4 + r] ----
+      if (!co_ok) continue;                            // lanes of unused output columns
 #pragma unroll
-      for (int wt = 0; wt < NSEG; ++wt)
-        *reinterpret_cast<f32x4*>(ep + nn * EPS + wt * 16 + g4 * 4) = acc[wt];
-      __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the wave's own LDS writes have landed
-      __builtin_amdgcn_wave_barrier();
-      float o[8];
-      {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + eco * EPS + ech * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + eco * EPS + ech * 8 + 4);
-        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      if (co_ok && ech * 8 < TW && (a.part_in | a.part_out)) {          // split-K partial sums (fp32, [n][cout][dhw])
-        const long long sp = ((long long)d * Ho + oh) * Wo + ow0 + ech * 8;
-        float* pp = a.part + ((long long)n * a.d.Cout + co) * odhw + sp;
-        if (a.part_in) {
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 4);
-          o[0] += lo[0]; o[1] += lo[1]; o[2] += lo[2]; o[3] += lo[3];
-          o[4] += hi[0]; o[5] += hi[1]; o[6] += hi[2]; o[7] += hi[3];
-        }
-        if (a.part_out) {
-          *reinterpret_cast<f32x4*>(pp) = f32x4{o[0], o[1], o[2], o[3]};
-          *reinterpret_cast<f32x4*>(pp + 4) = f32x4{o[4], o[5], o[6], o[7]};
-        }
-      }
-      if (co_ok && ech * 8 < TW && !(a.abl & 8) && !a.part_out) {
-        const long long sp = ((long long)d * Ho + oh) * Wo + ow0 + ech * 8;
-        float ev[8];
-        if (a.d.epi == 1) {
-          const uint4 er = *reinterpret_cast<const uint4*>(eplane + sp);
-          const unsigned u[4] = {er.x, er.y, er.z, er.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { ev[2 * k] = __uint_as_float(u[k] << 16); ev[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
-        }
-        unsigned short ob[8];
-        float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          float v = apply_act(o[r] + bias, a.d.act, a.d.act_slope);
-          if (a.d.epi == 1) {
-            v *= ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope);
-            ob[r] = f2bf(v);
-            v = bf2f(ob[r]);
-            t0 += v; t1 += v * ev[r];
-          } else if (a.d.epi == 2) {
-            ob[r] = f2bf(v);
-            v = bf2f(ob[r]);
-            t0 += v; t1 += v * v;
-          } else {
-            ob[r] = f2bf(v);
+      for (int wt = 0; wt < NSEG; ++wt) {
+        const long long sp = ((long long)d * Ho + oh) * Wo + ow0 + wt * 16 + 4 * g4;
+        float o[4] = {acc[wt][0], acc[wt][1], acc[wt][2], acc[wt][3]};
+        if (a.part_in | a.part_out) {                   // split-K partial sums (fp32, [n][cout][dhw])
+          float* pp = a.part + ((long long)n * a.d.Cout + co) * odhw + sp;
+          if (a.part_in) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pp);
+            o[0] += pv[0]; o[1] += pv[1]; o[2] += pv[2]; o[3] += pv[3];
+          }
+          if (a.part_out) {
+            *reinterpret_cast<f32x4*>(pp) = f32x4{o[0], o[1], o[2], o[3]};
+            continue;
           }
         }
+        if (a.abl & 8) continue;
+        float ev[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.d.epi == 1) ld4(eplane, sp, ev);
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = apply_act(o[r] + bias, a.d.act, a.d.act_slope);
+          if (a.d.epi == 1) {
+            v = bf2f(f2bf(v * ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope)));
+            t0 += v; t1 += v * ev[r];
+          } else if (a.d.epi == 2) {
+            v = bf2f(f2bf(v));
+            t0 += v; t1 += v * v;
+          }
+          o[r] = v;
+        }
         if (a.d.epi) { s0 += (double)t0; s1 += (double)t1; }
-        uint4 pk;
-        pk.x = (unsigned)ob[0] | ((unsigned)ob[1] << 16);
-        pk.y = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
-        pk.z = (unsigned)ob[4] | ((unsigned)ob[5] << 16);
-        pk.w = (unsigned)ob[6] | ((unsigned)ob[7] << 16);
-        *reinterpret_cast<uint4*>(yplane + sp) = pk;
+        st4(yplane, sp, o);
       }
     }
     __syncthreads();                                  // plane d+2 visible; everyone is done reading planes d-1..d+1
@@ -387,10 +359,10 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
     for (int d = d_begin; d < d_end; ++d) plane_step(d, rawA, rawA);
   }
   if (a.d.epi && !a.part_out) {
-    s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
-    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
     __syncthreads();
-    if ((lane & 3) == 0) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
+    if (lane < 16) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
     __syncthreads();
     if (tid < 32) {
       double tot = 0.0;
@@ -477,7 +449,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const int ny = (d->groups / gs) * a.ntile;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(a.tilesW * a.tilesH * a.dsegs, ny, d->N);
-  const size_t shm = (size_t)4 * (a.th + 2) * (a.tw + 4) * a.cinp * 2 + (size_t)(a.th == 4 ? 4 : 8) * 16 * 36 * sizeof(float);
+  const size_t shm = (size_t)4 * (a.th + 2) * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 32 * sizeof(double);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
   xh_note_kernel("conv3_mfma_kernel<%d, %d, %d, %d>", a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32, a.th);
