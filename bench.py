@@ -288,8 +288,9 @@ def roofline_pass(step, ops, nsteps, dtype):
     def timed_fwd(xa, xb, weights, biases, **kw):
         e0, e1 = ev(), ev()
         e0.record()
-        y = orig_fwd(xa, xb, weights, biases, **kw)
+        res = orig_fwd(xa, xb, weights, biases, **kw)
         e1.record()
+        y = res[0] if isinstance(res, tuple) else res         # (y, sc, sh, mean, rstd) when the norm finalisation is fused
         cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
         k, groups = kw["k"], kw.get("groups", 1)
         in_el = xa.numel() + (xb.numel() if xb is not None else 0)
@@ -299,7 +300,7 @@ def roofline_pass(step, ops, nsteps, dtype):
         records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops,
                         f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{y.shape[1]} @{'x'.join(map(str, y.shape[2:]))}"
                         + (" dgrad" if kw.get("transposed") else "")))
-        return y
+        return res
 
     def timed_wg(xa, xb, dy, dws, dbs, **kw):
         e0, e1 = ev(), ev()

@@ -19,14 +19,15 @@ orig = ops.conv3d
 
 
 def counted(xa, xb, weights, biases, **kw):
-    y = orig(xa, xb, weights, biases, **kw)
+    res = orig(xa, xb, weights, biases, **kw)
+    y = res[0] if isinstance(res, tuple) else res
     cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
     k, g = kw["k"], kw.get("groups", 1)
     t = tot[f"k{k}" + (" depthwise" if g == cin and g > 1 else "") + (" stride 2" if kw.get("stride", 1) == 2 else "")]
     t[0] += 1
     t[1] += 2.0 * y.numel() * k ** 3 * cin / g
     t[2] += xa.numel() + (xb.numel() if xb is not None else 0) + y.numel()
-    return y
+    return res
 
 
 ops.conv3d = counted
