@@ -16,10 +16,10 @@
 //    voxel's (finite) data against zero weights.
 //  * Weights are packed ONCE per launch by a small kernel into fragment order (caller workspace) and held in registers
 //    (B operands) for the workgroup's whole life; groups are block-diagonal zeros inside a 16-wide output tile.
-//  * Epilogue: accumulators are transposed through a wave-private LDS pad so each lane owns 8 consecutive voxels of one
-//    output channel: bias/activation/fused reductions there, then one 16-byte NCDHW store per lane (64 B runs).  The
+//  * Epilogue: straight from the accumulator layout -- lane (nn, g4) owns output channel nn and voxels 4*g4..+3 of each
+//    16-voxel segment: bias / activation / fused reductions in registers, one 8-byte NCDHW store per segment.  The
 //    fused reductions (output moments for the next InstanceNorm, or the leaky'-masked gradient sums of the norm
-//    backward) are accumulated in registers over the whole run and reduced once.
+//    backward) are accumulated in fp64 registers over the whole run and reduced once.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
