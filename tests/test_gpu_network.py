@@ -384,3 +384,43 @@ def test_sliding_window_tiler_vs_oracle_windows():
     assert (_dice(got, (want > 0.5).float()) - 1).abs().max() < 1e-3
     got_g = eval_overlap_volume(m, x.to(DEV), 14, (32, 32, 32), (8, 8, 8), batch_size=2, use_graph=True).cpu()
     assert (got_g - got).abs().max().item() < 1e-6          # hipGraph replay of the window forward: same kernels, same result
+
+
+def test_full_size_128_specialised_kernels_vs_generic_train():
+    """BASELINE config 2 size, forward + backward: the large-volume kernel variants (256-thread MFMA tiles, 7^3 Toeplitz
+    MFMA, sliding-window depthwise, exact-2x trilinear, vectorised stride-2) against the generic kernels they replace.
+    (a) specialised elementwise/depthwise/stride-2 kernels off: same arithmetic on the same bf16 inputs -> tight;
+    (b) MFMA off as well (fp32-FMA vector kernels): MFMA additionally rounds normalised activations and weights to bf16,
+        and the network amplifies that -> loose, but far from the O(1) error of an indexing bug."""
+    from gpu_common import l2_err
+    torch.manual_seed(4)
+    x = torch.rand(1, 4, 128, 128, 128).bfloat16()
+    eps = [torch.randn(1, 2 ** l, 64 >> l, 64 >> l, 64 >> l) for l in range(4)]
+    lib = X._lib.load()
+
+    def run():
+        m = _model(True)
+        seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps)
+        (seg.float().mean() + rec[0].float().mean() + sum(a.float().mean() + b.float().mean() for a, b in zip(mu, lv))).backward()
+        torch.cuda.synchronize()
+        g = {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None and not k.startswith("init_blocks.")}
+        return seg.float().cpu(), rec[0].float().cpu(), g
+    try:
+        seg1, rec1, g1 = run()
+        lib.xh_set_option(2, 7)
+        seg2, rec2, g2 = run()
+        X.ops.set_mfma(False)
+        seg3, rec3, g3 = run()
+    finally:
+        lib.xh_set_option(2, 0)
+        X.ops.set_mfma(True)
+    assert torch.isfinite(seg1).all() and torch.isfinite(rec1).all()
+    ea = (l2_err(seg1, seg2), l2_err(rec1, rec2))
+    eb = (l2_err(seg2, seg3), l2_err(rec2, rec3))
+    gmax = max(v.abs().max().item() for v in g2.values())
+    ga = max((g1[k] - g2[k]).abs().max().item() for k in g2) / gmax
+    gb = max((g2[k] - g3[k]).abs().max().item() for k in g2) / gmax
+    print(f"128^3 bf16 train: specialised vs generic seg/rec L2 {ea[0]:.2e}/{ea[1]:.2e}, grads {ga:.2e}; "
+          f"MFMA vs vector seg/rec L2 {eb[0]:.2e}/{eb[1]:.2e}, grads {gb:.2e}")
+    assert max(ea) < 5e-2 and ga < 5e-2
+    assert max(eb) < 0.35 and gb < 0.35
