@@ -147,7 +147,8 @@ int xh_norm_bwd_coef(void* stream, int mode, const double* red, int N, int C, lo
 int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
                       void* dx, long long dx_bs, int N, int C, long long DHW, const float* A, const float* B,
                       const float* Cc, int have_g, const float* sc, const float* sh, float slope, int accumulate);
-/* InstanceNorm backward in one launch: coefficients derived per (n, c) row from the raw sums red = (sum g, sum g*x) of
+/* InstanceNorm backward in one launch (autograd of nn.InstanceNorm3d in create_conv, buildingblocks.py:431, and in BasicConv,
+ * buildingblocks.py:21-24): coefficients derived per (n, c) row from the raw sums red = (sum g, sum g*x) of
  * xh_act_bwd_reduce / the conv epilogue, and the forward's mean / rstd.  red, mean, rstd (and sc, sh when have_g == 0)
  * point at this tensor's first channel inside arrays whose rows are stat_rs channels wide (virtual concat). */
 int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs, void* dx,
