@@ -11,9 +11,11 @@
  *  - Returns 0 on success, <0 on error (XH_ERR_ARG bad shape/unsupported combo, XH_ERR_DTYPE, XH_ERR_HIP).
  *  - Activations are contiguous NCDHW per sample; a `*_bs` argument is the batch stride in ELEMENTS, which
  *    lets a call read/write a channel slice of a larger tensor (virtual concat / split).
- *  - dtype: XH_F32 (0) or XH_BF16 (1) is the STORAGE type of activations and activation gradients.
+ *  - dtype: XH_F32 (0), XH_BF16 (1) or XH_F16 (2) is the STORAGE type of activations and activation gradients
+ *    (fp16 = IEEE half, the reference's own AMP dtype, train.py:218; its 5-bit exponent needs the caller's loss scaling
+ *    in backward exactly like the reference's GradScaler, train.py:207,265-268 -- the library never scales).
  *    Parameters, parameter gradients, statistics and coefficients are always fp32 (sums: fp64).
- *    Arithmetic is fp32 in every kernel.
+ *    Arithmetic is fp32 in every kernel; the MFMA conv kernels multiply 16-bit operands and accumulate in fp32.
  *  - The caller owns all memory, including the `red` reduction buffers which it must zero before a call that
  *    accumulates into them (documented per call).
  */
@@ -25,6 +27,7 @@ extern "C" {
 
 #define XH_F32 0
 #define XH_BF16 1
+#define XH_F16 2
 #define XH_ACT_NONE 0
 #define XH_ACT_RELU 1
 #define XH_ACT_LRELU 2

@@ -1,4 +1,6 @@
-"""-m gpu: the bf16-MFMA implicit-GEMM conv kernels against the vector kernels (same bf16 inputs) and stock ops."""
+"""-m gpu: the 16-bit MFMA implicit-GEMM conv kernels (bf16 and fp16 storage) against the vector kernels (same 16-bit inputs)
+and stock fp32 ops -- at small shapes (512-thread instances) and at the 128^3 shapes of BASELINE config 2, where the
+256-thread `big` instances that carry the headline run."""
 import pytest
 import torch
 
@@ -28,11 +30,17 @@ CASES = [
 ]
 
 
+DTYPES = [torch.bfloat16, torch.float16]
+# relative-L2 bands: bf16 rounds operands to 2^-9, fp16 to 2^-12
+TOL = {torch.bfloat16: dict(y=8e-3, dx=5e-2, dw=3e-2), torch.float16: dict(y=1.5e-3, dx=8e-3, dw=5e-3)}
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("cfg", CASES)
-def test_mfma_conv_forward_backward(cfg):
+def test_mfma_conv_forward_backward(cfg, dtype):
     torch.manual_seed(11)
     n, cin, cout, g = 2, cfg["cin"], cfg["cout"], cfg["groups"]
-    x = (torch.randn((n, cin) + cfg["sp"]) * 1.5 + 0.3).bfloat16()
+    x = (torch.randn((n, cin) + cfg["sp"]) * 1.5 + 0.3).to(dtype)
     nw = g if g <= 4 else 1                             # the C ABI takes one weight pointer, or one per group (<= 4)
     ws = [torch.randn(cout // nw, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5 for _ in range(nw)]
     bs = [torch.randn(cout // nw) for _ in range(nw)]
@@ -62,20 +70,22 @@ def test_mfma_conv_forward_backward(cfg):
     (yo * wgt).sum().backward()
     # forward: MFMA rounds the normalised activations and the weights to bf16 (2^-9 each) on top of the output rounding
     e = dict(y_vs_stock=l2_err(y1, yo), y_vs_vector=l2_err(y1, y0), dx_vs_stock=l2_err(dx1, xo.grad), dx_vs_vector=l2_err(dx1, dx0))
-    print(cfg, {k: f"{v:.2e}" for k, v in e.items()})
-    assert e["y_vs_stock"] < 8e-3 and e["y_vs_vector"] < 8e-3, e
-    assert e["dx_vs_stock"] < 5e-2 and e["dx_vs_vector"] < 5e-2, e
+    print(cfg, dtype, {k: f"{v:.2e}" for k, v in e.items()})
+    t = TOL[dtype]
+    assert e["y_vs_stock"] < t["y"] and e["y_vs_vector"] < t["y"], e
+    assert e["dx_vs_stock"] < t["dx"] and e["dx_vs_vector"] < t["dx"], e
     gmax = max(w.grad.abs().max() for w in wo)
     for a, b in zip(dw1 + db1, [w.grad for w in wo] + [b.grad for b in bo]):
-        assert l2_err(a, b) < 3e-2 or (a - b).abs().max() < 2e-2 * gmax
+        assert l2_err(a, b) < t["dw"] or (a - b).abs().max() < t["dw"] * 0.7 * gmax
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(1, 4, 12, 20, 32), (2, 4, 9, 16, 64), (1, 4, 5, 7, 32)])
-def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape):
+def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape, dtype):
     """AttenModule2's composed 7^3 conv (4 pooled channels -> 2 sigmoid gates) and its data gradient (2 -> 4) on the
     Toeplitz-in-H MFMA kernel, against the vector kernel and stock fp32 ops on the same bf16-representable input."""
     torch.manual_seed(3)
-    x = torch.randn(shape).bfloat16()
+    x = torch.randn(shape).to(dtype)
     w = torch.randn(2, 4, 7, 7, 7) * 0.05
     b = torch.randn(2) * 0.1
     g = torch.randn((shape[0], 2) + shape[2:])
@@ -100,7 +110,106 @@ def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape):
     (yo * g).sum().backward()
     e = dict(y_vs_stock=l2_err(y1, yo), y_vs_vector=l2_err(y1, y0), dx_vs_stock=l2_err(dx1, xo.grad), dx_vs_vector=l2_err(dx1, dx0),
              dw_vs_stock=l2_err(dw1, wo.grad), db_vs_stock=l2_err(db1, bo.grad))
-    print(shape, {k: f"{v:.2e}" for k, v in e.items()})
-    assert e["y_vs_stock"] < 8e-3 and e["y_vs_vector"] < 8e-3, e
-    assert e["dx_vs_stock"] < 2e-2 and e["dx_vs_vector"] < 2e-2, e
-    assert e["dw_vs_stock"] < 2e-2 and e["db_vs_stock"] < 2e-2, e
+    print(shape, dtype, {k: f"{v:.2e}" for k, v in e.items()})
+    k = 1.0 if dtype == torch.bfloat16 else 0.2
+    assert e["y_vs_stock"] < 8e-3 * k and e["y_vs_vector"] < 8e-3 * k, e
+    assert e["dx_vs_stock"] < 2e-2 * k and e["dx_vs_vector"] < 2e-2 * k, e
+    assert e["dw_vs_stock"] < 2e-2 * k and e["db_vs_stock"] < 2e-2 * k, e
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-size (BASELINE config 2: 128^3) instances.  Volumes of >= 2^20 voxels select the 256-thread `big` instances of the
+# k=3 forward / data-gradient / weight-gradient MFMA kernels; these are the launches that carry the headline number, so each
+# is checked here on its own against stock fp32 conv3d (CPU) on the same 16-bit-rounded inputs -- forward with the fused
+# InstanceNorm+LeakyReLU prologue and the output-moments epilogue (epi 2), data gradient with the norm-backward epilogue
+# (epi 1, inside InLreluConv.backward), weight and bias gradients.
+BIG = [
+    dict(cin=4, cout=4, groups=1),                 # conv3_mfma_kernel<F, 4, 256, 32, 8>: decoder level 0 second conv, skr encoder
+    dict(cin=12, cout=4, groups=1, split=4),       # <F, 12, 256, 32, 8>: decoder level 0 first conv on the virtual concat
+    dict(cin=16, cout=16, groups=4),               # <F, 16, 256, 32, 8>: the four modality encoders, level 0
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+@pytest.mark.parametrize("cfg", BIG, ids=lambda c: f"{c['cin']}to{c['cout']}g{c['groups']}")
+def test_mfma_conv_full_size_128_vs_stock(cfg, dtype):
+    torch.manual_seed(21)
+    torch.set_num_threads(min(32, torch.get_num_threads() * 4, __import__("os").cpu_count() or 1))
+    S = 128
+    n, cin, cout, g = 1, cfg["cin"], cfg["cout"], cfg["groups"]
+    x = (torch.randn(n, cin, S, S, S) * 1.5 + 0.3).to(dtype)
+    nw = g if g <= 4 else 1
+    ws = [torch.randn(cout // nw, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5 for _ in range(nw)]
+    bs = [torch.randn(cout // nw) for _ in range(nw)]
+    wgt = torch.randn(n, cout, S, S, S)
+    xg = x.to(DEV).requires_grad_(True)
+    wg = [w.to(DEV).requires_grad_(True) for w in ws]
+    bg = [b.to(DEV).requires_grad_(True) for b in bs]
+    xa, xb = (xg[:, :cfg["split"]], xg[:, cfg["split"]:]) if "split" in cfg else (xg, None)
+    y, red = X.functional.in_lrelu_conv(xa, xb, wg, bg, 1, g, out_stats=True)
+    k_fwd = X.ops.last_conv_kernel()
+    assert "conv3_mfma_kernel" in k_fwd and ", 256, 32, 8>" in k_fwd, k_fwd
+    (y.float() * wgt.to(DEV)).sum().backward()
+    k_bwd = X.ops.last_conv_kernel()              # the data gradient is the last conv launch of InLreluConv.backward
+    assert "conv3_mfma_kernel" in k_bwd and ", 256, 32, 8>" in k_bwd, k_bwd
+    torch.cuda.synchronize()
+    xo = x.float().requires_grad_(True)
+    wo = [w.clone().requires_grad_(True) for w in ws]
+    bo = [b.clone().requires_grad_(True) for b in bs]
+    h = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(xo, eps=1e-5), 0.01)
+    yo = torch.nn.functional.conv3d(h, torch.cat(wo, 0), torch.cat(bo, 0), padding=1, groups=g)
+    (yo * wgt).sum().backward()
+    t = TOL[dtype]
+    e = dict(y=l2_err(y, yo), dx=l2_err(xg.grad, xo.grad))
+    # epilogue 2: channel sums of the STORED output (what the next InstanceNorm will see)
+    ys = y.detach().double().cpu()
+    s0, s1 = ys.sum((2, 3, 4)), (ys * ys).sum((2, 3, 4))
+    e["sum"] = ((red[..., 0].cpu() - s0).abs() / ys.abs().sum((2, 3, 4))).max().item()
+    e["sumsq"] = ((red[..., 1].cpu() - s1).abs() / s1).max().item()
+    print(cfg, dtype, k_fwd, {k: f"{v:.2e}" for k, v in e.items()})
+    assert e["y"] < t["y"] and e["dx"] < t["dx"], e
+    assert e["sum"] < 1e-6 and e["sumsq"] < 1e-6, e      # quads are summed in fp32, everything above them in fp64
+    gmax = max(w.grad.abs().max() for w in wo)
+    for a, b in zip([w.grad.cpu() for w in wg] + [b.grad.cpu() for b in bg], [w.grad for w in wo] + [b.grad for b in bo]):
+        assert l2_err(a, b) < t["dw"] or (a - b).abs().max() < t["dw"] * 0.7 * gmax, (l2_err(a, b), a.shape)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+def test_wgrad_mfma_full_size_128_kernel_name(dtype):
+    """The weight gradient at 128^3 goes through conv3_wgrad_mfma_kernel<F, 4, 256> (checked numerically by the test above
+    through InLreluConv.backward); this pins the instance selection so a plan change cannot silently drop the coverage."""
+    x = torch.randn(1, 4, 128, 128, 128, device=DEV).to(dtype)
+    dy = torch.randn(1, 4, 128, 128, 128, device=DEV).to(dtype)
+    dw, db = torch.zeros(4, 4, 3, 3, 3, device=DEV), torch.zeros(4, device=DEV)
+    X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
+    name = X.ops.last_conv_kernel()
+    assert "conv3_wgrad_mfma_kernel" in name and name.endswith(", 4, 256>"), name
+    ref = torch.nn.functional.conv3d(x.float().transpose(0, 1), dy.float().transpose(0, 1), padding=1).transpose(0, 1)
+    assert l2_err(dw, ref) < TOL[dtype]["dw"]
+    assert l2_err(db, dy.float().sum((0, 2, 3, 4))) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+def test_k7_gate_conv_full_size_128_vs_stock(dtype):
+    """conv7_mfma_kernel<F,4,2> (forward), <F,2,4> (data gradient) and conv7_wgrad_mfma_kernel<F> at 128^3 against stock fp32
+    conv3d on the CPU (11.5 GFLOP: a few seconds)."""
+    torch.manual_seed(23)
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    S = 128
+    x = torch.randn(1, 4, S, S, S).to(dtype)
+    w = torch.randn(2, 4, 7, 7, 7) * 0.05
+    b = torch.randn(2) * 0.1
+    g = torch.randn(1, 2, S, S, S)
+    xg = x.to(DEV).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = X.functional.conv(xg, [wg], [bg], act=X.ops.ACT_SIGMOID)
+    assert "conv7_mfma_kernel" in X.ops.last_conv_kernel()
+    (y.float() * g.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    xo, wo, bo = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = torch.sigmoid(torch.nn.functional.conv3d(xo, wo, bo, padding=3))
+    (yo * g).sum().backward()
+    e = dict(y=l2_err(y, yo), dx=l2_err(xg.grad, xo.grad), dw=l2_err(wg.grad, wo.grad), db=l2_err(bg.grad, bo.grad))
+    print("k7 128^3", dtype, {k: f"{v:.2e}" for k, v in e.items()})
+    k = 1.0 if dtype == torch.bfloat16 else 0.2
+    assert e["y"] < 8e-3 * k and e["dx"] < 2e-2 * k and e["dw"] < 2e-2 * k and e["db"] < 2e-2 * k, e

@@ -131,28 +131,132 @@ def test_all_15_subsets_and_instance_missing_eval_fp32():
             check(sd[k[len("im_train_after."):]].double(), v.double(), 2e-5, k)      # BN buffers incl. the 4-step update
 
 
-def test_bf16_storage_vs_oracle_64():
-    """bf16 STORAGE of activations (fp32 arithmetic, ViL fp32) against the fp32 oracle.  Every bf16 kernel is correct to
-    bf16 rounding (test_gpu_stages), but this randomly initialised network amplifies perturbations by ~1e4 (it turns
-    fp32 round-off into 1e-3 at the output), so rounding every stored activation to 8 bits moves the output
-    by several percent.  The numbers are printed and bounded here; the parity mode is fp32 storage."""
-    torch.manual_seed(5)
-    w = _weights()
-    x = torch.rand(1, 4, 64, 64, 64)
-    sd = {k: v.clone() for k, v in w.items()}
-    prob_o, _, _, _, rec_o = O.xlstm_hved_forward(sd, x, 14, eps_list=None, training=False)
+def _yardstick():
+    import json
+    import os
+    from gpu_common import GOLDEN
+    with open(os.path.join(GOLDEN, "amp_yardstick.json")) as f:
+        return json.load(f)["cases"]
+
+
+STORAGE = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["64_seed5_subset14_eval", "64_seed5_subset7_eval", "128_seed2_subset14_eval"])
+def test_16bit_storage_vs_oracle_within_reference_amp_deviation(case, mode):
+    """16-bit STORAGE of activations (fp32 arithmetic, ViL fp32) against the fp32 oracle, judged by the yardstick the
+    reference itself provides: the deviation of the REFERENCE under torch.autocast (its own mixed-precision mode,
+    train.py:218, ViL kept in fp32 like UxLSTMEnc_3d.py:77-80) from the reference in fp32, on the same weights and the
+    same input (tests/golden/amp_yardstick.json, written by tests/golden/make_amp_yardstick.py from the real reference).
+    A randomly initialised XLSTM_HVED amplifies perturbations ~1e4x, so any 16-bit mode moves the output by
+    percents -- the reference's own AMP included; the bar is to deviate no more than the reference does:
+        Dice deviation <= max(1e-3, reference-AMP Dice deviation of the same dtype),
+        seg / recon relative L2 <= 2x the reference-AMP figure of the same dtype.
+    Both modes are additionally held below the fp16-AMP figures (the reference's actual AMP dtype).  Measured on MI355X
+    at 64^3 / 128^3: bf16 storage seg L2 0.068-0.072, Dice deviation 0.023-0.025; fp16 storage 0.0085-0.010, 2.9e-3-3.6e-3;
+    reference fp16-AMP 0.081-0.111, 0.029-0.040; reference bf16-AMP 0.118-0.179, 0.041-0.067."""
+    seed, size, subset = {"64_seed5_subset14_eval": (5, 64, 14), "64_seed5_subset7_eval": (5, 64, 7),
+                          "128_seed2_subset14_eval": (2, 128, 14)}[case]
+    ys = _yardstick()[case]
+    ref = ys[f"{mode}.vil_fp32"]
+    ref16 = ys["fp16.vil_fp32"]
+    torch.manual_seed(seed)
+    x = torch.rand(1, 4, size, size, size)
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    sd = {k: v.clone() for k, v in _weights().items()}
+    with torch.no_grad():
+        prob_o, _, _, _, rec_o = O.xlstm_hved_forward(sd, x, subset, eps_list=None, training=False)
     m = _model(False)
     with torch.no_grad():
-        seg, _, rec = m(x.to(DEV, torch.bfloat16), [14], recon=True, valid=True)
-    assert seg.dtype == torch.bfloat16
-    e_seg = (seg.float().cpu() - prob_o).abs().max().item()
-    e_rec = rel_err(rec[0].float(), rec_o)
+        seg, _, rec = m(x.to(DEV, STORAGE[mode]), [subset], recon=True, valid=True)
+    assert seg.dtype == STORAGE[mode]
+    seg, rec = seg.float().cpu(), rec[0].float().cpu()
+    l2 = ((seg - prob_o).norm() / prob_o.norm()).item()
+    r2 = ((rec - rec_o).norm() / rec_o.norm()).item()
     tgt = (prob_o > 0.5).float()
     d = (_dice(seg, tgt) - 1.0).abs().max().item()
-    print(f"bf16 64^3: seg max|d|={e_seg:.3e} recon rel={e_rec:.3e} dice dev={d:.2e}")
-    l2 = ((seg.float().cpu() - prob_o).norm() / prob_o.norm()).item()
-    print(f"bf16 64^3: seg relative L2 {l2:.3e}")
-    assert l2 < 0.3 and e_rec < 0.5 and d < 0.1
+    flips = int(((seg > 0.5) != (prob_o > 0.5)).sum())
+    print(f"{mode} storage {case}: seg rel L2 {l2:.3e} (reference {mode}-AMP {ref['seg_rel_l2']:.3e}, fp16-AMP {ref16['seg_rel_l2']:.3e}); "
+          f"recon rel L2 {r2:.3e} ({ref['recon_rel_l2']:.3e}, {ref16['recon_rel_l2']:.3e}); Dice dev {d:.3e} "
+          f"({ref['dice_dev']:.3e}, {ref16['dice_dev']:.3e}); mask flips {flips} ({ref['mask_flips']}, {ref16['mask_flips']}) of {seg.numel()}")
+    assert d <= max(1e-3, ref["dice_dev"]), (d, ref["dice_dev"])
+    assert l2 <= 2 * ref["seg_rel_l2"] and r2 <= 2 * ref["recon_rel_l2"], (l2, r2)
+    # both storage modes also stay below the deviation of the reference's ACTUAL AMP dtype (fp16), not merely within 2x
+    assert l2 <= ref16["seg_rel_l2"] and r2 <= ref16["recon_rel_l2"] and d <= ref16["dice_dev"], (l2, r2, d)
+    if mode == "fp16":        # 11 significant bits: an order of magnitude below it (measured 0.010 / 3.4e-3 vs 0.081 / 2.9e-2)
+        assert l2 <= 0.25 * ref16["seg_rel_l2"] and d <= 0.25 * ref16["dice_dev"], (l2, d)
+
+
+def test_fp16_backward_with_loss_scaling_matches_fp32_gradients():
+    """fp16 storage in backward needs the caller's loss scaling, exactly like the reference's GradScaler
+    (train.py:207,265-268): activation gradients of a mean() loss at 64^3 are ~1e-7 and vanish in fp16 unscaled.  With
+    the scale the fp32 parameter gradients (unscaled afterwards) agree with the fp32-storage run."""
+    torch.manual_seed(9)
+    x = torch.rand(1, 4, 64, 64, 64)
+    eps = [torch.randn(1, 2 ** l, 32 >> l, 32 >> l, 32 >> l) for l in range(4)]
+
+    def run(dtype, scale):
+        m = _model(True)
+        seg, (mu, lv), rec = m(x.to(DEV, dtype), [14], recon=True, eps_list=eps)
+        loss = seg.float().mean() + rec[0].float().mean() + sum(a.float().mean() + b.float().mean() for a, b in zip(mu, lv))
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.float().cpu() / scale for k, p in m.named_parameters()
+                if p.grad is not None and not k.startswith("init_blocks.")}
+    g32 = run(torch.float32, 1.0)
+    g16 = run(torch.float16, 65536.0)             # GradScaler's initial scale
+    g16u = run(torch.float16, 1.0)
+    assert all(torch.isfinite(v).all() for v in g16.values())
+    num = sum(((g16[k] - g32[k]) ** 2).sum().item() for k in g32)
+    den = sum((g32[k] ** 2).sum().item() for k in g32)
+    numu = sum(((g16u[k] - g32[k]) ** 2).sum().item() for k in g32)
+    e, eu = (num / den) ** 0.5, (numu / den) ** 0.5
+    print(f"fp16 storage, 64^3 train: parameter-gradient relative L2 vs fp32 storage: scaled {e:.3e}, unscaled {eu:.3e}")
+    assert e < 0.25 and e <= 1.05 * eu
+
+
+@pytest.mark.parametrize("cfg", ["n1_subset14_train", "n2_instance_missing_train"])
+def test_fp32_full_size_128_vs_oracle(cfg):
+    """BASELINE configs 2 and 3 at FULL size (128^3), fp32 storage, against the CPU oracle (not only properties):
+    N=1 all modalities, and N=2 with per-sample modality dropout (instance_missing, masks drawn from the 15 subsets).
+    Tolerances of SURVEY 8(c): seg atol 5e-3, recon 1e-3 of its absmax, Dice deviation 1e-4."""
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    torch.manual_seed(12)
+    n = 1 if cfg.startswith("n1") else 2
+    x = torch.rand(n, 4, 128, 128, 128)
+    eps = [torch.randn(n, 2 ** l, 64 >> l, 64 >> l, 64 >> l) for l in range(4)]
+    kw = {}
+    if n == 2:
+        for i, sub in enumerate([X.SUBSETS_MODALITIES[6], X.SUBSETS_MODALITIES[11]]):     # (0,3) and (0,1,3)
+            for c in range(4):
+                if c not in sub:
+                    x[i, c] = 0
+        kw = dict(instance_missing=True)
+    sd = {k: v.clone() for k, v in _weights().items()}
+    with torch.no_grad():
+        prob_o, _, mu_o, lv_o, rec_o = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True, **kw)
+    m = _model(True)
+    with torch.no_grad():
+        seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps, **kw)
+    e_seg, e_rec = (seg.cpu() - prob_o).abs().max().item(), rel_err(rec[0], rec_o)
+    tgt = (prob_o > 0.5).float()
+    d = (_dice(seg, tgt) - 1.0).abs().max().item()
+    flips = ((seg.cpu() > 0.5) != (prob_o > 0.5)).sum().item()
+    print(f"fp32 128^3 {cfg}: seg |d| {e_seg:.2e} recon rel {e_rec:.2e} dice dev {d:.2e} mask flips {flips}/{seg.numel()}")
+    assert e_seg < 5e-3 and e_rec < 1e-3 and d < 1e-4
+    # latents of the PRESENT modalities (+ the prior).  A dropped modality's stream sees an all-zero input: every conv
+    # output in it is a constant, every InstanceNorm divides round-off by sqrt(eps), so its (masked, unused) mu / logvar
+    # are amplified round-off in the reference as well -- not comparable between two implementations.
+    subs = [X.SUBSETS_MODALITIES[14]] if n == 1 else [X.SUBSETS_MODALITIES[6], X.SUBSETS_MODALITIES[11]]
+    for i in range(4):
+        for b_, sub in enumerate(subs):
+            rows = [0] + [c + 1 for c in sub]
+            check(mu[i][b_, rows], mu_o[i][b_, rows], 5e-4, f"mu{i}[{b_}]"), check(lv[i][b_, rows], lv_o[i][b_, rows], 5e-4, f"lv{i}[{b_}]")
+    sdm = m.state_dict()
+    for k in sd:                                   # BatchNorm buffers after the step (incl. the 4-step skr_att update)
+        if "running" in k:
+            check(sdm[k].float().cpu(), sd[k].float(), 1e-4, k)
 
 
 def test_fp32_vs_oracle_64_batch2_train_random_subset():
@@ -360,21 +464,28 @@ def test_forward_shared_equals_two_forwards():
             check(sd2[k].float(), sd1[k].float(), 1e-5, k)
 
 
-def test_sliding_window_tiler_vs_oracle_windows():
+@pytest.mark.parametrize("subset", [14, 5])
+def test_sliding_window_tiler_vs_oracle_windows(subset):
     """eval_overlap (evaluation.py:279-384): 32^3 windows every 8 voxels over a 40 x 32 x 41 volume, posterior mean, eval mode;
-    the device-side tiler against the same accumulation driven by the CPU oracle."""
+    the device-side tiler against the same accumulation driven by the CPU oracle.  For a partial subset (5 = modalities
+    0 and 2) the reference zeroes the other modalities in the volume first (evaluation.py:305-307): the oracle windows are
+    cut from the zeroed input."""
     from xlstm_hved_amd.inference import eval_overlap_volume, window_list
     torch.manual_seed(2)
     x = torch.rand(1, 4, 40, 32, 41)
     m = _model(False)
-    got = eval_overlap_volume(m, x.to(DEV), 14, (32, 32, 32), (8, 8, 8), batch_size=2).cpu()
+    got = eval_overlap_volume(m, x.to(DEV), subset, (32, 32, 32), (8, 8, 8), batch_size=2).cpu()
     w32 = {k: v.clone() for k, v in _weights().items()}
     sum_tot, cnt = torch.zeros(1, 3, 40, 32, 41), torch.zeros(1, 1, 40, 32, 41)
     wins = window_list((40, 32, 41), (32, 32, 32), (8, 8, 8))
     assert len(wins) == 2 * 1 * 3
+    xz = x.clone()
+    for c in range(4):
+        if c not in X.SUBSETS_MODALITIES[subset]:
+            xz[:, c] = 0
     with torch.no_grad():
         for d, h, w in wins:
-            p = O.xlstm_hved_forward(w32, x[:, :, d:d + 32, h:h + 32, w:w + 32], 14, eps_list=None, training=False)[0]
+            p = O.xlstm_hved_forward(w32, xz[:, :, d:d + 32, h:h + 32, w:w + 32], subset, eps_list=None, training=False)[0]
             sum_tot[:, :, d:d + 32, h:h + 32, w:w + 32] += p
             cnt[:, :, d:d + 32, h:h + 32, w:w + 32] += 1
     want = sum_tot / cnt
@@ -382,7 +493,7 @@ def test_sliding_window_tiler_vs_oracle_windows():
     print(f"tiler vs oracle windows: max |d| {e:.2e}")
     assert e < 5e-3
     assert (_dice(got, (want > 0.5).float()) - 1).abs().max() < 1e-3
-    got_g = eval_overlap_volume(m, x.to(DEV), 14, (32, 32, 32), (8, 8, 8), batch_size=2, use_graph=True).cpu()
+    got_g = eval_overlap_volume(m, x.to(DEV), subset, (32, 32, 32), (8, 8, 8), batch_size=2, use_graph=True).cpu()
     assert (got_g - got).abs().max().item() < 1e-6          # hipGraph replay of the window forward: same kernels, same result
 
 

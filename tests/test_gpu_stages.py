@@ -35,7 +35,7 @@ def _stage_modules():
     }
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name", sorted(_stage_modules()))
 def test_stage_against_reference_golden(name, dtype):
     g = load(name)
@@ -54,7 +54,9 @@ def test_stage_against_reference_golden(name, dtype):
     # fp32 storage: round-off.  bf16 storage: pointwise values to bf16 resolution; gradients in relative L2 (a sign
     # flip of a near-zero pre-activation moves a LeakyReLU gradient by 100x at that voxel, so max-norm is meaningless;
     # the skip-return block stacks two ReLUs, a channel arg-max and a third ReLU, hence its wider band)
-    tol_o = (2e-4 if "vil" in name else 5e-5) if f32 else 4e-2
+    # fp16 storage (the reference's AMP dtype): 11 significant bits instead of 8 -> 8x tighter bands than bf16
+    h16 = dtype == torch.float16
+    tol_o = (2e-4 if "vil" in name else 5e-5) if f32 else (6e-3 if h16 else 4e-2)
     loss = 0
     for j, o in enumerate(outs):
         assert o.dtype == dtype
@@ -67,23 +69,23 @@ def test_stage_against_reference_golden(name, dtype):
             check(t.grad, g[f"gin{j}"], 2e-3, f"{name}.gin{j}")
         else:
             e = l2_err(t.grad, g[f"gin{j}"])
-            assert e < (0.4 if "skr" in name else 0.12), f"{name}.gin{j}: relative L2 error {e:.3e}"
+            assert e < (0.4 if "skr" in name else 0.12) * (0.2 if h16 else 1.0), f"{name}.gin{j}: relative L2 error {e:.3e}"
     params = {k: p.grad for k, p in mod.named_parameters()}
     ref = {k[2:]: v for k, v in g.items() if k.startswith("g.")}
-    check_grads(params, ref, 2e-3 if f32 else (0.4 if "skr" in name else 0.12), name, l2=not f32)
+    check_grads(params, ref, 2e-3 if f32 else (0.4 if "skr" in name else 0.12) * (0.2 if h16 else 1.0), name, l2=not f32)
     if f32:
         sd = mod.state_dict()
         for k, v in sd_of(g, "sd_after.").items():
             check(sd[k].float(), v.float(), 1e-5, f"{name}.buffer.{k}")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_poe_all_subsets_and_drop(dtype):
     g = load("stage_poe")
     mu, lv = g["mu"], g["logvar"]                       # (5,N,L,d,h,w), index 0 = prior
     n, L = mu.shape[1], mu.shape[2]
     feat = torch.cat([torch.cat([mu[m + 1], lv[m + 1]], 1) for m in range(4)], 1).to(DEV, dtype).contiguous()
-    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    tol = 1e-5 if dtype == torch.float32 else (4e-3 if dtype == torch.float16 else 3e-2)
     # the fixture's logvar is not clipped; the stage clips at +-50 like RA_HVED.py:580 (no value exceeds it here)
     assert lv.abs().max() < 50
     for idx, subset in enumerate(X.SUBSETS_MODALITIES):
@@ -95,7 +97,7 @@ def test_poe_all_subsets_and_drop(dtype):
     keep = (~g["drop"]).float().to(DEV)
     eps = g["eps"].to(DEV, dtype)
     z, ms, ls = X.functional.PoE.apply(feat, keep, eps, L, True)
-    check(z, g["z"], tol if dtype == torch.float32 else 6e-2, "z with eps (instance missing)")
+    check(z, g["z"], tol if dtype == torch.float32 else (8e-3 if dtype == torch.float16 else 6e-2), "z with eps (instance missing)")
     check(ms.transpose(0, 1), g["mu_after"], tol, "masked mu stack")
 
 
@@ -129,7 +131,7 @@ def test_poe_backward_matches_oracle():
 def test_maxpool_upsample_roundtrip(shape):
     torch.manual_seed(0)
     x = torch.randn(shape)
-    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
         xs = x.to(dtype).float()          # identical stored values on both sides
         xg = xs.to(DEV, dtype).requires_grad_(True)
         xo = xs.clone().requires_grad_(True)
@@ -203,7 +205,7 @@ def test_in_lrelu_conv_shapes_vs_oracle(cfg):
 
 
 @pytest.mark.parametrize("shape", [(1, 4, 32, 32, 32), (2, 3, 16, 40, 48), (1, 2, 9, 70, 160), (1, 5, 8, 33, 64)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_depthwise_k3_sliding_window_kernel_vs_stock(shape, dtype):
     """Depthwise 3^3 conv (BasicConv conv_blocks, ResBlock dwconvs) on volumes large enough for the sliding-window kernel:
     BasicConv forward (conv -> InstanceNorm -> LeakyReLU) and backward against stock fp32 ops."""

@@ -72,6 +72,26 @@ def test_tiler_matches_reference_loop(batch_size):
     assert torch.allclose(got, want, atol=1e-6)
 
 
+def test_tiler_zeroes_modalities_outside_the_subset():
+    """evaluation.py:305-307: `x_batch[:, mod_list == False] = 0` (mod_list is a bool ndarray row) before cropping."""
+    torch.manual_seed(0)
+    x = torch.rand(1, 4, 16, 16, 16)
+    seen = []
+
+    def spy(crop, subset_idx_list=(14,), valid=True):
+        seen.append(crop.clone())
+        return stub_model(crop, subset_idx_list, valid)
+    got = eval_overlap_volume(spy, x, 5, (8, 8, 8), (8, 8, 8))           # subset 5 = modalities (0, 2)
+    assert X.SUBSETS_MODALITIES[5] == (0, 2)
+    for c in seen:
+        assert c[:, 1].abs().sum() == 0 and c[:, 3].abs().sum() == 0 and c[:, 0].abs().sum() > 0 and c[:, 2].abs().sum() > 0
+    xz = x.clone()
+    xz[:, [1, 3]] = 0
+    want = stub_model(xz, [5])[0]
+    assert torch.allclose(got, want, atol=1e-6)
+    assert x[:, 1].abs().sum() > 0                                        # the caller's volume is left alone
+
+
 def _rank_main(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -37,8 +37,18 @@ def _worker(rank, world, port, q):
         lin2(x).sum().backward()
         fg.all_reduce(world)
     assert lin2.weight.grad.data_ptr() == fg.flat.data_ptr()
-    q.put((rank, lin.weight.grad.clone(), lin.bias.grad.clone(), dead.grad, None if half.grad is None else half.grad.clone(),
-           X.parallel.shard_windows(7, rank, world), lin2.weight.grad.clone(), dead2.grad.clone()))
+    # optimizer.zero_grad() (set_to_none=True by default; the reference calls it at train.py:264) detaches the views:
+    # backward allocates fresh gradients, and all_reduce must gather them instead of reducing a stale bucket
+    opt = torch.optim.SGD([lin2.weight, lin2.bias, dead2], lr=0.1)
+    opt.zero_grad()
+    lin2(x).sum().backward()
+    assert lin2.weight.grad.data_ptr() != fg.flat.data_ptr() and not fg.check()
+    fg.all_reduce(world)
+    assert fg.check() and lin2.weight.grad.data_ptr() == fg.flat.data_ptr()
+    # plain numpy payloads: a tensor in a Queue is shared by file descriptor and needs the sender alive when it is read
+    q.put((rank, lin.weight.grad.numpy().copy(), lin.bias.grad.numpy().copy(), dead.grad,
+           None if half.grad is None else half.grad.numpy().copy(),
+           X.parallel.shard_windows(7, rank, world), lin2.weight.grad.numpy().copy(), dead2.grad.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -54,6 +64,7 @@ def test_flat_grad_allreduce_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     # d/dW of sum(W x + b) = sum over batch of x: rank r contributes 2*(r+1) per entry -> average (2+4)/2 = 3
+    res = [tuple(torch.from_numpy(v) if hasattr(v, "dtype") else v for v in r) for r in res]
     for rank, wg, bg, dead, half, shard, wg2, dead2 in res:
         assert torch.allclose(wg, torch.full((3, 5), 3.0)) and torch.allclose(bg, torch.full((3,), 2.0))
         assert dead is None

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libxlstm_hved_hip.so")
 
-XH_F32, XH_BF16 = 0, 1
+XH_F32, XH_BF16, XH_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 
 c_fp = C.POINTER(C.c_float)

@@ -63,12 +63,13 @@ class SingleConv(nn.Module):
         if padding != kernel_size // 2:
             raise NotImplementedError("only 'same' padding is supported")
 
-    def forward(self, x, x2=None, in_stats=None, out_stats=False):
+    def forward(self, x, x2=None, in_stats=None, out_stats=False, drop_bias=False):
         """in_stats / out_stats ('ilc' only): take the input's channel sums from the producer's epilogue / also return
-        (y, sums of y) accumulated by this conv's epilogue, so chained stages skip their statistics pass."""
+        (y, sums of y) accumulated by this conv's epilogue, so chained stages skip their statistics pass.
+        drop_bias ('ilc' only): the only consumer is an InstanceNorm (Fn.in_lrelu_conv)."""
         if self.order == "ilc":
             return Fn.in_lrelu_conv(x, x2, [self.conv.weight], [self.conv.bias], self.stride, in_stats=in_stats,
-                                    out_stats=out_stats)
+                                    out_stats=out_stats, drop_bias=drop_bias)
         if out_stats:
             raise NotImplementedError("out_stats is an 'ilc' feature")
         if x2 is not None:
@@ -93,7 +94,8 @@ class DoubleConv(nn.Module):
     def forward(self, x, x2=None, out_stats=False):
         if self.SingleConv1.order != "ilc":
             return self.SingleConv2(self.SingleConv1(x, x2))
-        y1, st1 = self.SingleConv1(x, x2, out_stats=True)          # conv1's epilogue feeds conv2's InstanceNorm
+        # conv1's epilogue feeds conv2's InstanceNorm -- its only consumer, so conv1's bias add is an identity (drop_bias)
+        y1, st1 = self.SingleConv1(x, x2, out_stats=True, drop_bias=True)
         return self.SingleConv2(y1, in_stats=st1, out_stats=out_stats)
 
 

@@ -1,5 +1,5 @@
 // Shared device helpers for the XLSTM-HVED gfx950 kernel library.
-// Storage types: float or bf16 (raw 16-bit), arithmetic is always fp32 (double for cross-block sums).
+// Storage types: float, bf16 or fp16 (raw 16-bit), arithmetic is always fp32 (double for cross-block sums).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,65 +11,106 @@
 
 #define XH_F32 0
 #define XH_BF16 1
+#define XH_F16 2
 
 #define XH_ACT_NONE 0
 #define XH_ACT_RELU 1
 #define XH_ACT_LRELU 2
 #define XH_ACT_SIGMOID 3
 
-struct bf16_t { unsigned short v; };
+// 16-bit storage formats: one struct template so that every helper below is written once.  FMT 0 = bfloat16 (8 exponent /
+// 7 mantissa bits), FMT 1 = IEEE half (5 / 10: the reference's own AMP dtype, train.py:218).
+template <int FMT> struct h16 { unsigned short v; };
+typedef h16<0> bf16_t;
+typedef h16<1> f16_t;
 
 __device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {
   __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
   return __builtin_bit_cast(unsigned short, b);
 }
+__device__ __forceinline__ float hf2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ unsigned short f2hf(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // RNE, overflow -> inf
+
+// format-generic scalar / packed-pair conversions
+template <int FMT> __device__ __forceinline__ float cvt_in(unsigned short v) { return FMT == 0 ? bf2f(v) : hf2f(v); }
+template <int FMT> __device__ __forceinline__ unsigned short cvt_out(float f) { return FMT == 0 ? f2bf(f) : f2hf(f); }
+template <int FMT> __device__ __forceinline__ float cvt_lo(unsigned u) {       // low half of a packed pair
+  return FMT == 0 ? __uint_as_float(u << 16) : hf2f((unsigned short)(u & 0xffffu));
+}
+template <int FMT> __device__ __forceinline__ float cvt_hi(unsigned u) {
+  return FMT == 0 ? __uint_as_float(u & 0xffff0000u) : hf2f((unsigned short)(u >> 16));
+}
+template <int FMT> __device__ __forceinline__ unsigned cvt_pack(float a, float b) {
+  return (unsigned)cvt_out<FMT>(a) | ((unsigned)cvt_out<FMT>(b) << 16);
+}
+template <typename T> struct FmtOf { static constexpr int v = -1; };
+template <int FMT> struct FmtOf<h16<FMT>> { static constexpr int v = FMT; };
+
 __device__ __forceinline__ float ldf(const float* p, long long i) { return p[i]; }
-__device__ __forceinline__ float ldf(const bf16_t* p, long long i) { return bf2f(p[i].v); }
+template <int F> __device__ __forceinline__ float ldf(const h16<F>* p, long long i) { return cvt_in<F>(p[i].v); }
 __device__ __forceinline__ void stf(float* p, long long i, float v) { p[i] = v; }
-__device__ __forceinline__ void stf(bf16_t* p, long long i, float v) { p[i].v = f2bf(v); }
+template <int F> __device__ __forceinline__ void stf(h16<F>* p, long long i, float v) { p[i].v = cvt_out<F>(v); }
 // value as it will be read back from storage
 __device__ __forceinline__ float rnd_as(const float*, float v) { return v; }
-__device__ __forceinline__ float rnd_as(const bf16_t*, float v) { return bf2f(f2bf(v)); }
+template <int F> __device__ __forceinline__ float rnd_as(const h16<F>*, float v) { return cvt_in<F>(cvt_out<F>(v)); }
 
-// 4-wide contiguous access (caller guarantees alignment: 16 B for float, 8 B for bf16)
+// 4-wide contiguous access (caller guarantees alignment: 16 B for float, 8 B for the 16-bit formats)
 __device__ __forceinline__ void ld4(const float* p, long long i, float (&o)[4]) {
   float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
 }
-__device__ __forceinline__ void ld4(const bf16_t* p, long long i, float (&o)[4]) {
+template <int F> __device__ __forceinline__ void ld4(const h16<F>* p, long long i, float (&o)[4]) {
   uint2 t = *reinterpret_cast<const uint2*>(p + i);
-  o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
-  o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+  o[0] = cvt_lo<F>(t.x); o[1] = cvt_hi<F>(t.x);
+  o[2] = cvt_lo<F>(t.y); o[3] = cvt_hi<F>(t.y);
 }
 __device__ __forceinline__ void st4(float* p, long long i, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ void st4(bf16_t* p, long long i, const float (&v)[4]) {
+template <int F> __device__ __forceinline__ void st4(h16<F>* p, long long i, const float (&v)[4]) {
   uint2 t;
-  t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-  t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  t.x = cvt_pack<F>(v[0], v[1]);
+  t.y = cvt_pack<F>(v[2], v[3]);
   *reinterpret_cast<uint2*>(p + i) = t;
 }
 
-// widest (16-byte) contiguous access per lane: 4 floats or 8 bf16
+// widest (16-byte) contiguous access per lane: 4 floats or 8 16-bit values
 template <typename T> struct VWT { static constexpr int v = 4; };
-template <> struct VWT<bf16_t> { static constexpr int v = 8; };
+template <int F> struct VWT<h16<F>> { static constexpr int v = 8; };
 __device__ __forceinline__ void ldvec(const float* p, long long q, float (&o)[4]) { ld4(p, q, o); }
 __device__ __forceinline__ void stvec(float* p, long long q, const float (&o)[4]) { st4(p, q, o); }
-__device__ __forceinline__ void ldvec(const bf16_t* p, long long q, float (&o)[8]) {
+template <int F> __device__ __forceinline__ void ldvec(const h16<F>* p, long long q, float (&o)[8]) {
   const uint4 t = *reinterpret_cast<const uint4*>(p + q);
   const unsigned u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(u[k] << 16); o[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+  for (int k = 0; k < 4; ++k) { o[2 * k] = cvt_lo<F>(u[k]); o[2 * k + 1] = cvt_hi<F>(u[k]); }
 }
-__device__ __forceinline__ void stvec(bf16_t* p, long long q, const float (&o)[8]) {
+template <int F> __device__ __forceinline__ void stvec(h16<F>* p, long long q, const float (&o)[8]) {
   uint4 t;
-  t.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-  t.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-  t.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
-  t.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+  t.x = cvt_pack<F>(o[0], o[1]);
+  t.y = cvt_pack<F>(o[2], o[3]);
+  t.z = cvt_pack<F>(o[4], o[5]);
+  t.w = cvt_pack<F>(o[6], o[7]);
   *reinterpret_cast<uint4*>(p + q) = t;
 }
+
+// 16x16x32 MFMA on either 16-bit format (operands carried as 8 raw shorts = 4 VGPRs; fp32 accumulate)
+typedef short h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int FMT> __device__ __forceinline__ f32x4_t mfma16x16x32(h16x8 a, h16x8 b, f32x4_t c) {
+  if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// one dtype switch for every entry point: expands BODY with T = float / bf16_t / f16_t (else: return XH_ERR_DTYPE)
+#define XH_DISPATCH_T(dtype, ...)                                   \
+  do {                                                              \
+    if ((dtype) == XH_F32) { typedef float T; __VA_ARGS__ }         \
+    else if ((dtype) == XH_BF16) { typedef bf16_t T; __VA_ARGS__ }  \
+    else if ((dtype) == XH_F16) { typedef f16_t T; __VA_ARGS__ }    \
+    else return XH_ERR_DTYPE;                                       \
+  } while (0)
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }

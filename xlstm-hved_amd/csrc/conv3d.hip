@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
 // ---------------------------------------------------------------------------------------------------
 static int check_desc(const xh_conv_desc* d, const xh_conv_ptrs* p) {
   if (!d || !p) return XH_ERR_ARG;
-  if (d->dtype != XH_F32 && d->dtype != XH_BF16) return XH_ERR_DTYPE;
+  if (d->dtype != XH_F32 && d->dtype != XH_BF16 && d->dtype != XH_F16) return XH_ERR_DTYPE;
   if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->groups <= 0) return XH_ERR_ARG;
   if (d->Cin % d->groups || d->Cout % d->groups) return XH_ERR_ARG;
   if (!(d->k == 1 || d->k == 3 || d->k == 7)) return XH_ERR_ARG;
@@ -1068,7 +1068,7 @@ static int pick_cob(int cout_g, int maxc) {
   return c;
 }
 
-template <typename T> static const char* tname() { return sizeof(T) == 2 ? "bf16_t" : "float"; }
+template <typename T> static const char* tname() { return FmtOf<T>::v == 0 ? "bf16_t" : FmtOf<T>::v == 1 ? "f16_t" : "float"; }
 #define LAUNCH_FWD(T, K, S, COB, TXN)                                                                              \
   do {                                                                                                             \
     xh_note_kernel("conv_fwd_kernel<%s, %d, %d, %d, %d>", tname<T>(), K, S, COB, TXN);                            \
@@ -1126,7 +1126,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
         const int sd = cdiv(d->D, dsegs);
         dsegs = cdiv(d->D, sd);
         dim3 grid(a.tilesW * a.tilesH * dsegs, d->Cin, d->N);
-        xh_note_kernel("conv_dw3_slide_kernel<%s, %d>", d->dtype == XH_F32 ? "float" : "bf16_t", txn);
+        xh_note_kernel("conv_dw3_slide_kernel<%s, %d>", tname<T>(), txn);
         switch (txn) {
           case 4: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, a, sd); break;
           case 8: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, a, sd); break;
@@ -1243,13 +1243,13 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
   }
   if (p->fin_red) return XH_ERR_ARG;                  // the fused finalisation exists on the MFMA path only
   xh_note_kernel("conv k%d s%d (vector kernel family)", d->k, d->stride);
-  return d->dtype == XH_F32 ? conv_fwd_dispatch<float>(stream, d, p) : conv_fwd_dispatch<bf16_t>(stream, d, p);
+  XH_DISPATCH_T(d->dtype, return conv_fwd_dispatch<T>(stream, d, p););
 }
 
 __device__ __forceinline__ void ldhalf_c(const float* p, float (&o)[2]) {
   const float2 t = *reinterpret_cast<const float2*>(p); o[0] = t.x; o[1] = t.y;
 }
-__device__ __forceinline__ void ldhalf_c(const bf16_t* p, float (&o)[4]) { ld4(p, 0, o); }
+template <int F> __device__ __forceinline__ void ldhalf_c(const h16<F>* p, float (&o)[4]) { ld4(p, 0, o); }
 
 // ---------------------------------------------------------------------------------------------------
 // k = 3, stride = 2 data gradient, vectorised.  A lane produces one 16-byte run of dX (VW voxels of one row, CIB input
@@ -1417,7 +1417,7 @@ static int dgrad_s2_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
 
 extern "C" int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   if (!d || !p || !p->xa || !p->y) return XH_ERR_ARG;
-  if (d->dtype != XH_F32 && d->dtype != XH_BF16) return XH_ERR_DTYPE;
+  if (d->dtype != XH_F32 && d->dtype != XH_BF16 && d->dtype != XH_F16) return XH_ERR_DTYPE;
   if (d->k != 3 || d->stride != 2 || d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return XH_ERR_ARG;
   if (d->Do != (d->D - 1) / 2 + 1 || d->Ho != (d->H - 1) / 2 + 1 || d->Wo != (d->W - 1) / 2 + 1) return XH_ERR_ARG;
   if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= 4))) return XH_ERR_ARG;
@@ -1426,7 +1426,7 @@ extern "C" int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_
   if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cin && !p->eb))) return XH_ERR_ARG;
   if (d->epi != 0 && d->epi != 1) return XH_ERR_ARG;
   if (d->N * d->groups > 65535) return XH_ERR_ARG;
-  return d->dtype == XH_F32 ? dgrad_s2_dispatch<float>(stream, d, p) : dgrad_s2_dispatch<bf16_t>(stream, d, p);
+  XH_DISPATCH_T(d->dtype, return dgrad_s2_dispatch<T>(stream, d, p););
 }
 
 #define LAUNCH_WG(T, K, S, COB, TXN)                                                                               \
@@ -1783,7 +1783,7 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
     if (r != 1) return r;
   }
   xh_note_kernel("conv wgrad k%d s%d (vector kernel family)", d->k, d->stride);
-  return d->dtype == XH_F32 ? wgrad_dispatch<float>(stream, d, p, dw, db) : wgrad_dispatch<bf16_t>(stream, d, p, dw, db);
+  XH_DISPATCH_T(d->dtype, return wgrad_dispatch<T>(stream, d, p, dw, db););
 }
 
 extern "C" int xh_abi_version(void) { return 1; }

@@ -23,8 +23,8 @@
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
+typedef f32x4_t f32x4;
 
 struct ConvMK {
   xh_conv_desc d;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
     const int kw = flat / a.cinp, ci = flat % a.cinp;
     if (kw < 3 && ci < a.cin_blk && cin0 + ci < cin_end) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
   }
-  wf[idx] = f2bf(v);
+  wf[idx] = a.d.dtype == XH_F16 ? f2hf(v) : f2bf(v);
   // fused InstanceNorm finalisation (xh_conv_ptrs.fin_red): one workgroup turns the raw sums into scale / shift
   if (a.p.fin_red && blockIdx.x == 0 && blockIdx.y == 0 && a.cin_off == 0) {
     const int total = a.d.N * a.d.Cin;
@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
 // bijection inside each 128-byte block, so fragment reads apply the same function.
 __device__ __forceinline__ int swz(int off) { return off ^ (((off >> 8) & 7) << 4); }
 
-template <int CINP, int NT, int TW, int TH = 8>
+template <int FMT, int CINP, int NT, int TW, int TH = 8>
 __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const ConvMK a) {
+  typedef h16<FMT> ST;                                // storage type of activations: ST or f16_t
   constexpr int NWV = NT / 64;
   constexpr int NSEG = TW / 16;
   constexpr int IH = TH + 2;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
   const int co = co_base + eco;
   const bool co_ok = eco < co_lim;
   float bias = 0.f, esc = 0.f, esh = 0.f;
-  const bf16_t* eplane = nullptr;
+  const ST* eplane = nullptr;
   if (co_ok) {
     const int g = co / a.Cout_g, gpp = a.d.groups / a.d.n_wptr;
     const float* bp = a.p.b[g / gpp];
@@ -173,15 +174,15 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
     if (a.d.epi == 1) {
       esc = a.p.e_sc[n * a.d.Cout + co];
       esh = a.p.e_sh[n * a.d.Cout + co];
-      eplane = co < a.d.Cea ? (const bf16_t*)a.p.ea + n * a.d.ea_bs + (long long)co * odhw
-                            : (const bf16_t*)a.p.eb + n * a.d.eb_bs + (long long)(co - a.d.Cea) * odhw;
+      eplane = co < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co * odhw
+                            : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co - a.d.Cea) * odhw;
     }
   }
-  bf16_t* yplane = (bf16_t*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
+  ST* yplane = (ST*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
   double s0 = 0.0, s1 = 0.0;     // running statistics in fp64 (block_sum_d note in common.h)
 
   // ---- per-thread staging plan (identical for every plane) ----
-  const bf16_t* sp_src[NIT][4];     // channel plane base + in-plane offset, or nullptr
+  const ST* sp_src[NIT][4];     // channel plane base + in-plane offset, or nullptr
   float sp_sc[NIT][4], sp_sh[NIT][4];
   int sp_lds[NIT], sp_gq[NIT];
 #pragma unroll
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
       sp_src[it][cc] = nullptr;
       sp_sc[it][cc] = 1.f; sp_sh[it][cc] = 0.f;
       if (inb && cl < a.cin_blk && c < cin_end) {
-        sp_src[it][cc] = (c < a.d.Ca ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
-                                     : (const bf16_t*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
+        sp_src[it][cc] = (c < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
+                                     : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
                          (long long)gh * W + gw;
         if (a.d.pre) { sp_sc[it][cc] = a.p.pre_sc[n * a.d.Cin + c]; sp_sh[it][cc] = a.p.pre_sh[n * a.d.Cin + c]; }
       }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
         const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+          float lo = cvt_lo<FMT>(u[k]), hi = cvt_hi<FMT>(u[k]);
           if (a.d.pre) {
             lo = leaky(lo * sp_sc[it][cc] + sp_sh[it][cc], a.d.pre_slope);
             hi = leaky(hi * sp_sc[it][cc] + sp_sh[it][cc], a.d.pre_slope);
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
         const int wx = sp_gq[it] * 8 + k + 1;         // tile column of voxel gw+k (column 0 = ow0-1)
         if (wx >= 0 && wx < IWP) {
           uint2 pk;
-          pk.x = (unsigned)f2bf(v[0][k]) | ((unsigned)f2bf(v[1][k]) << 16);
-          pk.y = (unsigned)f2bf(v[2][k]) | ((unsigned)f2bf(v[3][k]) << 16);
+          pk.x = cvt_pack<FMT>(v[0][k], v[1][k]);
+          pk.y = cvt_pack<FMT>(v[2][k], v[3][k]);
           *reinterpret_cast<uint2*>(s_in + swz(slot + sp_lds[it] + wx * VB)) = pk;
         }
       }
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
             const uint4 q4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
             av = __builtin_bit_cast(bf16x8, q4);
           }
-          accs[ri][wt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bfrag[i], accs[ri][wt], 0, 0, 0);
+          accs[ri][wt] = mfma16x16x32<FMT>(av, bfrag[i], accs[ri][wt]);
         }
       }
     }
@@ -335,10 +336,10 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
         for (int r = 0; r < 4; ++r) {
           float v = apply_act(o[r] + bias, a.d.act, a.d.act_slope);
           if (a.d.epi == 1) {
-            v = bf2f(f2bf(v * ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope)));
+            v = cvt_in<FMT>(cvt_out<FMT>(v * ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope)));
             t0 += v; t1 += v * ev[r];
           } else if (a.d.epi == 2) {
-            v = bf2f(f2bf(v));
+            v = cvt_in<FMT>(cvt_out<FMT>(v));
             t0 += v; t1 += v * v;
           }
           o[r] = v;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const
 }
 
 static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
-  if (d->dtype != XH_BF16 || d->k != 3 || d->stride != 1) return 1;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return 1;
   if (d->W % 16 != 0 || d->Wo != d->W) return 1;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g < 4) return 1;                            // depthwise / single-channel convs stay on the vector kernel
@@ -452,7 +453,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const size_t shm = (size_t)4 * (a.th + 2) * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 32 * sizeof(double);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
-  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d, %d>", a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32, a.th);
+  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d, %d, %d>", d->dtype == XH_F16 ? 1 : 0, a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32, a.th);
   for (int sidx = 0; sidx < a.nsplit; ++sidx) {
   if (a.nsplit > 1) {
     a.cin_off = sidx * a.cin_blk;
@@ -462,28 +463,34 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     a.p.ws = (char*)p->ws + pb * sidx;
   }
   hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
-#define LM(C)                                                                                                   \
+#define LM(F, C)                                                                                                \
   do {                                                                                                          \
     static bool attr_done = false;                                                                              \
     if (!attr_done) {                                                                                           \
-      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<C, 512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<F, C, 256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<F, C, 512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<F, C, 512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
       attr_done = true;                                                                                         \
     }                                                                                                           \
-    if (a.tw == 16) hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 16>), grid, dim3(512), shm, st, a);           \
-    else if (a.th == 4) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256, 32, 4>), grid, dim3(256), shm, st, a);    \
-    else if (big) hipLaunchKernelGGL((conv3_mfma_kernel<C, 256, 32>), grid, dim3(256), shm, st, a);             \
-    else hipLaunchKernelGGL((conv3_mfma_kernel<C, 512, 32>), grid, dim3(512), shm, st, a);                      \
+    if (a.tw == 16) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 512, 16>), grid, dim3(512), shm, st, a);        \
+    else if (a.th == 4) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 256, 32, 4>), grid, dim3(256), shm, st, a); \
+    else if (big) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 256, 32>), grid, dim3(256), shm, st, a);          \
+    else hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 512, 32>), grid, dim3(512), shm, st, a);                   \
+  } while (0)
+#define LMF(C)                            \
+  do {                                    \
+    if (d->dtype == XH_F16) LM(1, C);     \
+    else LM(0, C);                        \
   } while (0)
   switch (a.cinp) {
-    case 4: LM(4); break;
-    case 8: LM(8); break;
-    case 12: LM(12); break;
-    case 16: LM(16); break;
-    default: LM(24);
+    case 4: LMF(4); break;
+    case 8: LMF(8); break;
+    case 12: LMF(12); break;
+    case 16: LMF(16); break;
+    default: LMF(24);
   }
   }
+#undef LMF
 #undef LM
   return xh_launch_status();
 }

@@ -15,8 +15,8 @@
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
+typedef f32x4_t f32x4;
 
 struct WgMK {
   xh_conv_desc d;
@@ -32,8 +32,9 @@ struct WgMK {
   int nctile;       // CP-wide input-channel tiles per set
 };
 
-template <int CP, int NT>
+template <int FMT, int CP, int NT>
 __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
+  typedef h16<FMT> ST;                                // storage type: ST or f16_t
   constexpr int NWV = NT / 64;
   constexpr int TH = 8, IH = TH + 2;
   constexpr int ROWB = 96;                            // 48 voxels: [ow0-8, ow0+40)
@@ -83,10 +84,10 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
   }
   // ---- A operand source: dY row of channel co_base + nn ----
   const bool a_ok = nn < co_lim;
-  const bf16_t* dyp = (const bf16_t*)a.p.ea + n * a.d.ea_bs + (long long)(co_base + (a_ok ? nn : 0)) * odhw + ow0 + g4 * 8;
+  const ST* dyp = (const ST*)a.p.ea + n * a.d.ea_bs + (long long)(co_base + (a_ok ? nn : 0)) * odhw + ow0 + g4 * 8;
 
   // ---- staging plan ----
-  const bf16_t* sp_src[NIT];
+  const ST* sp_src[NIT];
   float sp_sc[NIT], sp_sh[NIT];
   int sp_lds[NIT];
 #pragma unroll
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
     sp_sc[it] = 0.f; sp_sh[it] = 0.f;
     sp_lds[it] = item < NITEM ? cl * CHS + hy * ROWB + gi * 16 : -1;
     if (item < NITEM && cl < ci_lim && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W) {
-      sp_src[it] = (c < a.d.Ca ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
-                               : (const bf16_t*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
+      sp_src[it] = (c < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
+                               : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
                    (long long)gh * W + gw;
       sp_sc[it] = 1.f;
       if (a.d.pre) { sp_sc[it] = a.p.pre_sc[n * a.d.Cin + c]; sp_sh[it] = a.p.pre_sh[n * a.d.Cin + c]; }
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
       unsigned o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float lo = __uint_as_float(u[k] << 16) * sc + sh, hi = __uint_as_float(u[k] & 0xffff0000u) * sc + sh;
+        float lo = cvt_lo<FMT>(u[k]) * sc + sh, hi = cvt_hi<FMT>(u[k]) * sc + sh;
         lo = fmaxf(lo, lo * a.d.pre_slope);           // leaky for 0 <= slope <= 1
         hi = fmaxf(hi, hi * a.d.pre_slope);
-        o[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        o[k] = cvt_pack<FMT>(lo, hi);
       }
       *reinterpret_cast<uint4*>(s_in + slot + sp_lds[it]) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
       {
         const unsigned u[4] = {araw.x, araw.y, araw.z, araw.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dbsum += __uint_as_float(u[k] << 16) + __uint_as_float(u[k] & 0xffff0000u);
+        for (int k = 0; k < 4; ++k) dbsum += cvt_lo<FMT>(u[k]) + cvt_hi<FMT>(u[k]);
       }
 #pragma unroll
       for (int t = 0; t < TPK; ++t) {
@@ -201,9 +202,9 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
         b2.y = __builtin_amdgcn_alignbyte(cur.z, cur.y, 2);
         b2.z = __builtin_amdgcn_alignbyte(cur.w, cur.z, 2);
         b2.w = __builtin_amdgcn_alignbyte(nxt, cur.w, 2);
-        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, b0), acc[0][t], 0, 0, 0);
-        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, cur), acc[1][t], 0, 0, 0);
-        acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, b2), acc[2][t], 0, 0, 0);
+        acc[0][t] = mfma16x16x32<FMT>(av, __builtin_bit_cast(bf16x8, b0), acc[0][t]);
+        acc[1][t] = mfma16x16x32<FMT>(av, __builtin_bit_cast(bf16x8, cur), acc[1][t]);
+        acc[2][t] = mfma16x16x32<FMT>(av, __builtin_bit_cast(bf16x8, b2), acc[2][t]);
       }
     }
   }
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
 
 // returns XH_OK if launched, 1 if not eligible
 int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
-  if (d->dtype != XH_BF16 || d->k != 3 || d->stride != 1) return 1;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return 1;
   if (d->W % 32 != 0 || d->Wo != d->W) return 1;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g < 4) return 1;
@@ -300,10 +301,15 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
 #define LW(C)                                                                                     \
   do {                                                                                            \
-    if (big) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<C, 256>), grid, dim3(256), shm, st, a);  \
-    else hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<C, 512>), grid, dim3(512), shm, st, a);      \
+    if (d->dtype == XH_F16) {                                                                     \
+      if (big) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<1, C, 256>), grid, dim3(256), shm, st, a);  \
+      else hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<1, C, 512>), grid, dim3(512), shm, st, a);      \
+    } else {                                                                                      \
+      if (big) hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<0, C, 256>), grid, dim3(256), shm, st, a);  \
+      else hipLaunchKernelGGL((conv3_wgrad_mfma_kernel<0, C, 512>), grid, dim3(512), shm, st, a);      \
+    }                                                                                             \
   } while (0)
-  xh_note_kernel("conv3_wgrad_mfma_kernel<%d, %d>", cp, big ? 256 : 512);
+  xh_note_kernel("conv3_wgrad_mfma_kernel<%d, %d, %d>", d->dtype == XH_F16 ? 1 : 0, cp, big ? 256 : 512);
   switch (cp) {
     case 4: LW(4); break;
     case 8: LW(8); break;

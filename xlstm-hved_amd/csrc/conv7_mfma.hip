@@ -19,8 +19,8 @@
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
+typedef f32x4_t f32x4;
 
 struct Conv7K {
   xh_conv_desc d;
@@ -28,8 +28,9 @@ struct Conv7K {
   int tilesW, tilesH, sd, dsegs;
 };
 
-template <int CI, int CO>
+template <int FMT, int CI, int CO>
 __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
+  typedef h16<FMT> ST;                                // storage type: ST or f16_t
   constexpr int PPM = 32 / (8 * CI);                  // depth taps per MFMA (1 for CI = 4, 2 for CI = 2)
   constexpr int NKD = (7 + PPM - 1) / PPM;            // MFMA steps along kd
   constexpr int JR = 16 / CO;                         // output rows per N tile
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
         const int tap = (kd * 7 + kh) * 7 + kw;
         v = a.d.transposed ? wp[((long long)ci * CO + co) * 343 + (342 - tap)] : wp[((long long)co * CI + ci) * 343 + tap];
       }
-      reinterpret_cast<unsigned short*>(s_tb)[idx] = f2bf(v);
+      reinterpret_cast<unsigned short*>(s_tb)[idx] = cvt_out<FMT>(v);
     }
   }
   // lane roles: N column nn = (j, co); this lane's B row offset for (kd step, rr) and A offsets
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
   if (a.p.b[0]) bias = a.p.b[0][con];
 
   // ---- staging plan ----
-  const bf16_t* sp_src[NIT][CI];
+  const ST* sp_src[NIT][CI];
   int sp_lds[NIT], sp_gq[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
     sp_lds[it] = hy * IWP * VB;
 #pragma unroll
     for (int c = 0; c < CI; ++c)
-      sp_src[it][c] = inb ? (const bf16_t*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw + (long long)gh * W + gw : nullptr;
+      sp_src[it][c] = inb ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw + (long long)gh * W + gw : nullptr;
   }
   uint4 raw[NIT][CI];
   auto load_plane = [&](int gd) {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
   }
   __syncthreads();
 
-  bf16_t* ybase = (bf16_t*)a.p.y + n * a.d.y_bs + (long long)con * dhw;
+  ST* ybase = (ST*)a.p.y + n * a.d.y_bs + (long long)con * dhw;
   for (int d = d_begin; d < d_end; ++d) {
     const bool more = d + 1 < d_end;
     if (more) load_plane(d + 4);                      // lands behind the MFMAs
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
             const unsigned* a32 = reinterpret_cast<const unsigned*>(ap);
             av = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
           }
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[mt], 0, 0, 0);
+          acc[mt] = mfma16x16x32<FMT>(av, bv, acc[mt]);
         }
       }
     }
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
 
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
-  if (d->dtype != XH_BF16 || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
   if (!((d->Cin == 4 && d->Cout == 2) || (d->Cin == 2 && d->Cout == 4))) return 1;
   if (d->pre || d->epi || d->Ca != d->Cin) return 1;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return 1;
@@ -221,16 +222,23 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   a.dsegs = cdiv(d->D, a.sd);
   dim3 grid(cols * a.dsegs, 1, d->N);
   hipStream_t st = (hipStream_t)stream;
+  const int f = d->dtype == XH_F16 ? 1 : 0;
   if (d->Cin == 4) {
     const size_t shm = (size_t)8 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16;
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)conv7_mfma_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
-    xh_note_kernel("conv7_mfma_kernel<4, 2>");
-    hipLaunchKernelGGL((conv7_mfma_kernel<4, 2>), grid, dim3(128), shm, st, a);
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)conv7_mfma_kernel<0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv7_mfma_kernel<1, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      done = true;
+    }
+    xh_note_kernel("conv7_mfma_kernel<%d, 4, 2>", f);
+    if (f) hipLaunchKernelGGL((conv7_mfma_kernel<1, 4, 2>), grid, dim3(128), shm, st, a);
+    else hipLaunchKernelGGL((conv7_mfma_kernel<0, 4, 2>), grid, dim3(128), shm, st, a);
   } else {
     const size_t shm = (size_t)8 * (2 * 4 + 6) * 40 * 4 + 8 * 8 * 2 * 4 * 16;
-    xh_note_kernel("conv7_mfma_kernel<2, 4>");
-    hipLaunchKernelGGL((conv7_mfma_kernel<2, 4>), grid, dim3(128), shm, st, a);
+    xh_note_kernel("conv7_mfma_kernel<%d, 2, 4>", f);
+    if (f) hipLaunchKernelGGL((conv7_mfma_kernel<1, 2, 4>), grid, dim3(128), shm, st, a);
+    else hipLaunchKernelGGL((conv7_mfma_kernel<0, 2, 4>), grid, dim3(128), shm, st, a);
   }
   return xh_launch_status();
 }

@@ -19,8 +19,8 @@
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
+typedef f32x4_t f32x4;
 
 struct Wg7K {
   xh_conv_desc d;
@@ -33,6 +33,7 @@ struct Wg7K {
 constexpr int K7_NW = 2 * 4 * 343;          // 2744 weight gradients
 constexpr int K7_NPART = K7_NW + 8;         // + 2 bias gradients (padded)
 
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) {
   constexpr int TH = 8, TW = 32;
   constexpr int XROW = 8 * 64;                        // bytes per (ci, row): 8 shifted copies x 32 bf16
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) 
     if (y_own_row && q >= p_begin && q < p_end) {
       const unsigned u[4] = {r_cur.x, r_cur.y, r_cur.z, r_cur.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dbs += __uint_as_float(u[k] << 16) + __uint_as_float(u[k] & 0xffff0000u);
+      for (int k = 0; k < 4; ++k) dbs += cvt_lo<FMT>(u[k]) + cvt_hi<FMT>(u[k]);
     }
   };
 
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) 
         const unsigned char* bp = kh_l < 7 ? s_dy + ((p - kd + 3 + 8) & 7) * DYPL + (co_l * DYROWS + ry) * 64 + g4 * 16
                                            : s_zero + g4 * 16;
         const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bp);
-        acc[kd][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bv, acc[kd][0], 0, 0, 0);
-        acc[kd][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bv, acc[kd][1], 0, 0, 0);
+        acc[kd][0] = mfma16x16x32<FMT>(a0, bv, acc[kd][0]);
+        acc[kd][1] = mfma16x16x32<FMT>(a1, bv, acc[kd][1]);
       }
     }
     if (more) { if (xrole) store_x(buf ^ 1); else store_dy(p + 4); }
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void conv7_wgrad_reduce_kernel(const float* pa
 }
 
 static bool wg7_eligible(const xh_conv_desc* d) {
-  if (d->dtype != XH_BF16 || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return false;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return false;
   if (d->Cin != 4 || d->Cout != 2 || d->pre || d->Ca != d->Cin || d->transposed) return false;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
   if ((d->xa_bs & 7) || (d->ea_bs & 7) || (((long long)d->D * d->H * d->W) & 7)) return false;
@@ -230,8 +231,9 @@ int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   const int nwg = a.tilesW * a.tilesH * a.dsegs * d->N;
   const size_t shm = 2 * 4 * 8 * 8 * 64 + 8 * 2 * 14 * 64 + 64;
   hipStream_t st = (hipStream_t)stream;
-  xh_note_kernel("conv7_wgrad_mfma_kernel");
-  hipLaunchKernelGGL(conv7_wgrad_mfma_kernel, dim3(nwg), dim3(256), shm, st, a);
+  xh_note_kernel("conv7_wgrad_mfma_kernel<%d>", d->dtype == XH_F16 ? 1 : 0);
+  if (d->dtype == XH_F16) hipLaunchKernelGGL(conv7_wgrad_mfma_kernel<1>, dim3(nwg), dim3(256), shm, st, a);
+  else hipLaunchKernelGGL(conv7_wgrad_mfma_kernel<0>, dim3(nwg), dim3(256), shm, st, a);
   hipLaunchKernelGGL(conv7_wgrad_reduce_kernel, dim3(cdiv(K7_NW + 2, 256), nwg < 32 ? nwg : 32), dim3(256), 0, st,
                      (const float*)a.part, nwg, dw[0], db ? db[0] : nullptr);
   return xh_launch_status();

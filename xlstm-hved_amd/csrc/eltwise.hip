@@ -95,6 +95,8 @@ extern "C" int xh_moments(void* stream, int dtype, const void* x, long long x_bs
     hipLaunchKernelGGL(moments_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(moments_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(moments_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, DHW, red, red_rs, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -181,6 +183,8 @@ extern "C" int xh_affine_act(void* stream, int dtype, const void* x, long long x
     hipLaunchKernelGGL(affine_act_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(affine_act_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, sc, sh, act, slope, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -221,6 +225,8 @@ extern "C" int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long l
     hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, C, DHW, sc, sh, slope, red, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(act_bwd_reduce_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, C, DHW, sc, sh, slope, red, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -359,6 +365,8 @@ extern "C" int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long lon
     hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(in_bwd_apply_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -376,6 +384,8 @@ extern "C" int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long l
     hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -444,6 +454,8 @@ extern "C" int xh_maxpool2_fwd(void* stream, int dtype, const void* x, void* y, 
     hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, total, D, H, W);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, total, D, H, W);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<f16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, (f16_t*)y, total, D, H, W);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -456,6 +468,8 @@ extern "C" int xh_maxpool2_bwd(void* stream, int dtype, const void* x, const voi
     hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, total, D, H, W, accumulate);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, total, D, H, W, accumulate);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<f16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, (const f16_t*)dy, (f16_t*)dx, total, D, H, W, accumulate);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -566,15 +580,15 @@ __device__ __forceinline__ void ldhalf(const float* p, long long q, float (&o)[N
   static_assert(N == 2, "");
   const float2 t = *reinterpret_cast<const float2*>(p + q); o[0] = t.x; o[1] = t.y;
 }
-template <int N>
-__device__ __forceinline__ void ldhalf(const bf16_t* p, long long q, float (&o)[N]) {
+template <int N, int F>
+__device__ __forceinline__ void ldhalf(const h16<F>* p, long long q, float (&o)[N]) {
   static_assert(N == 4, "");
   ld4(p, q, o);
 }
 __device__ __forceinline__ void sthalf(float* p, long long q, const float (&o)[2]) {
   *reinterpret_cast<float2*>(p + q) = make_float2(o[0], o[1]);
 }
-__device__ __forceinline__ void sthalf(bf16_t* p, long long q, const float (&o)[4]) { st4(p, q, o); }
+template <int F> __device__ __forceinline__ void sthalf(h16<F>* p, long long q, const float (&o)[4]) { st4(p, q, o); }
 
 template <typename T, int TXN>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C, int D,
@@ -786,15 +800,18 @@ extern "C" int xh_upsample_trilinear_fwd(void* stream, int dtype, const void* x,
                                          int N, int C, int D, int H, int W, int Do, int Ho, int Wo) {
   if (!x || !y || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return XH_ERR_ARG;
   const long long total = (long long)N * C * Do * Ho * Wo;
-  if (Do == 2 * D && Ho == 2 * H && Wo == 2 * W && (dtype == XH_F32 || dtype == XH_BF16) && !(g_xh_disable & 2)) {
-    const int r = dtype == XH_F32 ? upsample2x_fwd_try<float>(stream, x, x_bs, y, y_bs, N, C, D, H, W)
-                                  : upsample2x_fwd_try<bf16_t>(stream, x, x_bs, y, y_bs, N, C, D, H, W);
+  if (Do == 2 * D && Ho == 2 * H && Wo == 2 * W && (dtype == XH_F32 || dtype == XH_BF16 || dtype == XH_F16) && !(g_xh_disable & 2)) {
+    const int r = dtype == XH_F32    ? upsample2x_fwd_try<float>(stream, x, x_bs, y, y_bs, N, C, D, H, W)
+                  : dtype == XH_BF16 ? upsample2x_fwd_try<bf16_t>(stream, x, x_bs, y, y_bs, N, C, D, H, W)
+                                     : upsample2x_fwd_try<f16_t>(stream, x, x_bs, y, y_bs, N, C, D, H, W);
     if (r != 1) return r;
   }
   if (dtype == XH_F32)
     hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, D, H, W, Do, Ho, Wo, total);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, D, H, W, Do, Ho, Wo, total);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(upsample_fwd_kernel<f16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, D, H, W, Do, Ho, Wo, total);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -804,15 +821,18 @@ extern "C" int xh_upsample_trilinear_bwd(void* stream, int dtype, const void* dy
   if (!dy || !dx || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return XH_ERR_ARG;
   if (Do > 3 * D || Ho > 3 * H || Wo > 3 * W) return XH_ERR_ARG;     // adjoint keeps <= 8 candidate outputs per axis
   const long long total = (long long)N * C * D * H * W;
-  if (Do == 2 * D && Ho == 2 * H && Wo == 2 * W && (dtype == XH_F32 || dtype == XH_BF16) && !(g_xh_disable & 2)) {
-    const int r = dtype == XH_F32 ? upsample2x_bwd_try<float>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, accumulate)
-                                  : upsample2x_bwd_try<bf16_t>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, accumulate);
+  if (Do == 2 * D && Ho == 2 * H && Wo == 2 * W && (dtype == XH_F32 || dtype == XH_BF16 || dtype == XH_F16) && !(g_xh_disable & 2)) {
+    const int r = dtype == XH_F32    ? upsample2x_bwd_try<float>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, accumulate)
+                  : dtype == XH_BF16 ? upsample2x_bwd_try<bf16_t>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, accumulate)
+                                     : upsample2x_bwd_try<f16_t>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, accumulate);
     if (r != 1) return r;
   }
   if (dtype == XH_F32)
     hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, D, H, W, Do, Ho, Wo, total, accumulate);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, D, H, W, Do, Ho, Wo, total, accumulate);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(upsample_bwd_kernel<f16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, C, D, H, W, Do, Ho, Wo, total, accumulate);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -843,6 +863,8 @@ extern "C" int xh_add(void* stream, int dtype, const void* a, long long a_bs, co
     hipLaunchKernelGGL(add_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)a, a_bs, (const float*)b, b_bs, (float*)y, y_bs, CDHW, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(add_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)a, a_bs, (const bf16_t*)b, b_bs, (bf16_t*)y, y_bs, CDHW, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(add_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)a, a_bs, (const f16_t*)b, b_bs, (f16_t*)y, y_bs, CDHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -864,6 +886,8 @@ extern "C" int xh_act_bwd(void* stream, int dtype, const void* dy, const void* y
     hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)y, (float*)dx, n, act);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n, act);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(act_bwd_kernel<f16_t>, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)dy, (const f16_t*)y, (f16_t*)dx, n, act);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -950,6 +974,8 @@ extern "C" int xh_poe_fwd(void* stream, int dtype, const void* feat, const float
     hipLaunchKernelGGL(poe_fwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, keep, (const float*)eps, (float*)z, (float*)mu_stack, (float*)lv_stack, L, dhw, total, mask_mu);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(poe_fwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, keep, (const bf16_t*)eps, (bf16_t*)z, (bf16_t*)mu_stack, (bf16_t*)lv_stack, L, dhw, total, mask_mu);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(poe_fwd_kernel<f16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)feat, keep, (const f16_t*)eps, (f16_t*)z, (f16_t*)mu_stack, (f16_t*)lv_stack, L, dhw, total, mask_mu);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -963,6 +989,8 @@ extern "C" int xh_poe_bwd(void* stream, int dtype, const void* feat, const float
     hipLaunchKernelGGL(poe_bwd_kernel<float>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, keep, (const float*)eps, (const float*)dz, (const float*)dmu_stack, (const float*)dlv_stack, (float*)dfeat, L, dhw, total, mask_mu);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(poe_bwd_kernel<bf16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, keep, (const bf16_t*)eps, (const bf16_t*)dz, (const bf16_t*)dmu_stack, (const bf16_t*)dlv_stack, (bf16_t*)dfeat, L, dhw, total, mask_mu);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(poe_bwd_kernel<f16_t>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)feat, keep, (const f16_t*)eps, (const f16_t*)dz, (const f16_t*)dmu_stack, (const f16_t*)dlv_stack, (f16_t*)dfeat, L, dhw, total, mask_mu);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1018,6 +1046,8 @@ extern "C" int xh_channel_pool_fwd(void* stream, int dtype, const void* x, long 
     hipLaunchKernelGGL(channel_pool_fwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(channel_pool_fwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(channel_pool_fwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1029,6 +1059,8 @@ extern "C" int xh_channel_pool_bwd(void* stream, int dtype, const void* x, long 
     hipLaunchKernelGGL(channel_pool_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, DHW, accumulate);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(channel_pool_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, DHW, accumulate);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(channel_pool_bwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, C, DHW, accumulate);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1080,6 +1112,8 @@ extern "C" int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_b
     hipLaunchKernelGGL(gate_fwd_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (float*)y, y_bs, DHW, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (bf16_t*)y, y_bs, DHW, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(gate_fwd_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (f16_t*)y, y_bs, DHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1092,6 +1126,8 @@ extern "C" int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_b
     hipLaunchKernelGGL(gate_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, (float*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, (bf16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(gate_bwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, (f16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1158,6 +1194,8 @@ extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long lon
     hipLaunchKernelGGL(duse_gate_fwd_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(duse_gate_fwd_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(duse_gate_fwd_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (f16_t*)u, u_bs, C, DHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1174,6 +1212,9 @@ extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long lon
   } else if (dtype == XH_BF16) {
     hipLaunchKernelGGL(duse_gate_bwd_row_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW, vec16);
     hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW);
+  } else if (dtype == XH_F16) {
+    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (const f16_t*)du, du_bs, (f16_t*)dx, dx_bs, dch, C, DHW, vec16);
+    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)du, du_bs, (f16_t*)dsp, dsp_bs, C, DHW);
   } else {
     return XH_ERR_DTYPE;
   }
@@ -1205,6 +1246,8 @@ extern "C" int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, 
     hipLaunchKernelGGL(rank1_add_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (float*)dx, dx_bs, (const float*)d, d_bs, w, k, C, DHW, vec32);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(rank1_add_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (bf16_t*)dx, dx_bs, (const bf16_t*)d, d_bs, w, k, C, DHW, vec16);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(rank1_add_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (f16_t*)dx, dx_bs, (const f16_t*)d, d_bs, w, k, C, DHW, vec16);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1379,6 +1422,8 @@ extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const voi
     hipLaunchKernelGGL(skr_tail_fwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(skr_tail_fwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(skr_tail_fwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1391,6 +1436,8 @@ extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const voi
     hipLaunchKernelGGL(skr_tail_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx);
   else if (dtype == XH_BF16)
     hipLaunchKernelGGL(skr_tail_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx);
+  else if (dtype == XH_F16)
+    hipLaunchKernelGGL(skr_tail_bwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx);
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();

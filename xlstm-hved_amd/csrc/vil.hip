@@ -859,7 +859,7 @@ static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, co
 }
 
 static int vil_check(int dtype, int B, int S, int C, int nh, const xh_vil_params* p, const float* ws) {
-  if (dtype != XH_F32 && dtype != XH_BF16) return XH_ERR_DTYPE;
+  if (dtype != XH_F32 && dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
   if (B <= 0 || S <= 0 || B > 65535 || nh != NH || !p || !ws) return XH_ERR_ARG;
   if (!(C == 16 || C == 32)) return XH_ERR_ARG;
   if (!p->norm_w || !p->proj_up || !p->conv_w || !p->conv_b || !p->q_w || !p->k_w || !p->v_w || !p->ig_w || !p->ig_b ||
@@ -874,12 +874,9 @@ extern "C" int xh_vil_fwd(void* stream, int dtype, const void* xa, const void* x
   if (rc) return rc;
   if (!xa || !out) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == XH_F32) {
-    if (C == 32) return vil_fwd_impl<float, 32>(st, (const float*)xa, (const float*)xb, (float*)out, B, S, add_xa, p, ws);
-    return vil_fwd_impl<float, 16>(st, (const float*)xa, (const float*)xb, (float*)out, B, S, add_xa, p, ws);
-  }
-  if (C == 32) return vil_fwd_impl<bf16_t, 32>(st, (const bf16_t*)xa, (const bf16_t*)xb, (bf16_t*)out, B, S, add_xa, p, ws);
-  return vil_fwd_impl<bf16_t, 16>(st, (const bf16_t*)xa, (const bf16_t*)xb, (bf16_t*)out, B, S, add_xa, p, ws);
+  XH_DISPATCH_T(dtype,
+    if (C == 32) return vil_fwd_impl<T, 32>(st, (const T*)xa, (const T*)xb, (T*)out, B, S, add_xa, p, ws);
+    return vil_fwd_impl<T, 16>(st, (const T*)xa, (const T*)xb, (T*)out, B, S, add_xa, p, ws););
 }
 
 extern "C" int xh_vil_bwd(void* stream, int dtype, const void* xa, const void* xb, const void* dout, void* dxin, int B,
@@ -892,10 +889,7 @@ extern "C" int xh_vil_bwd(void* stream, int dtype, const void* xa, const void* x
       !g->fg_w || !g->fg_b || !g->outnorm_w || !g->skip || !g->proj_down)
     return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == XH_F32) {
-    if (C == 32) return vil_bwd_impl<float, 32>(st, (const float*)dout, (float*)dxin, B, S, p, g, ws);
-    return vil_bwd_impl<float, 16>(st, (const float*)dout, (float*)dxin, B, S, p, g, ws);
-  }
-  if (C == 32) return vil_bwd_impl<bf16_t, 32>(st, (const bf16_t*)dout, (bf16_t*)dxin, B, S, p, g, ws);
-  return vil_bwd_impl<bf16_t, 16>(st, (const bf16_t*)dout, (bf16_t*)dxin, B, S, p, g, ws);
+  XH_DISPATCH_T(dtype,
+    if (C == 32) return vil_bwd_impl<T, 32>(st, (const T*)dout, (T*)dxin, B, S, p, g, ws);
+    return vil_bwd_impl<T, 16>(st, (const T*)dout, (T*)dxin, B, S, p, g, ws););
 }

@@ -37,7 +37,7 @@ def _targets(params):
     for the all-reduce.  Otherwise a zeroed tensor is allocated and returned the usual way."""
     bufs, rets, need = [], [], []
     for i, p in enumerate(params):
-        g = p.grad if (p is not None and p.is_leaf) else None
+        g = p.grad if (p is not None and p.is_leaf and p.requires_grad) else None
         if DIRECT_GRADS[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape:
             bufs.append(g)
             rets.append(None)
@@ -66,10 +66,10 @@ class InLreluConv(Function):
     RA_HVED.py:548-553, batched along channels)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, in_stats, out_stats, stride, groups, nw, *wb):
+    def forward(ctx, xa, xb, in_stats, out_stats, stride, groups, nw, drop_bias, *wb):
         """in_stats: the (n, C, 2) fp64 sums [sum x, sum x^2] of xa if its producer already accumulated them in its
         epilogue (then no moments pass is run here); out_stats: also return the same sums of the output, accumulated by
-        this conv's epilogue, for the next stage."""
+        this conv's epilogue, for the next stage.  drop_bias: see in_lrelu_conv."""
         weights, biases = list(wb[:nw]), list(wb[nw:])
         n, ca = xa.shape[:2]
         cin = ca + (xb.shape[1] if xb is not None else 0)
@@ -83,8 +83,8 @@ class InLreluConv(Function):
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
         red_y = ops.zeros_red(xa, n, cout) if out_stats else None
-        y, sc, sh, mean, rstd = ops.conv3d(xa, xb, weights, biases, k=k, cout=cout, stride=stride, groups=groups,
-                                           in_stats=(red, _dhw(xa), LEAK), epi=2 if out_stats else 0, red=red_y)
+        y, sc, sh, mean, rstd = ops.conv3d(xa, xb, weights, None if drop_bias else biases, k=k, cout=cout, stride=stride,
+                                           groups=groups, in_stats=(red, _dhw(xa), LEAK), epi=2 if out_stats else 0, red=red_y)
         ctx.save_for_backward(xa, xb, sc, sh, mean, rstd, *weights)
         ctx.cfg = (stride, groups, nw, k, cin, ca)
         ctx.params = (weights, biases)
@@ -114,11 +114,16 @@ class InLreluConv(Function):
             dxa = ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0)
             if xb is not None:
                 dxb = ops.in_bwd_apply(g, xb, red, mean, rstd, have_g=True, c0=ca)
-        return (dxa, dxb, None, None, None, None, None, *rws, *rbs)
+        return (dxa, dxb, None, None, None, None, None, None, *rws, *rbs)
 
 
-def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, out_stats=False):
-    return InLreluConv.apply(xa, xb, in_stats, bool(out_stats), stride, groups, len(weights), *weights, *biases)
+def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, out_stats=False, drop_bias=False):
+    """drop_bias=True: the caller guarantees that every consumer of the output is an InstanceNorm (which subtracts the
+    per-channel mean, so IN(conv + b) == IN(conv) exactly): the bias add is skipped and the tensor is stored without the
+    offset.  With 16-bit storage that matters: the reference initialises biases N(0,1) (utils.py:199), and a channel
+    stored as `offset + small signal` spends its significant bits on the offset.  The bias still gets its gradient (the sum
+    of dY, mathematically zero behind an InstanceNorm -- the reference returns round-off there too)."""
+    return InLreluConv.apply(xa, xb, in_stats, bool(out_stats), stride, groups, len(weights), bool(drop_bias), *weights, *biases)
 
 
 class GnConvRelu(Function):
@@ -195,13 +200,14 @@ class Conv(Function):
     carry one weight tensor each."""
 
     @staticmethod
-    def forward(ctx, x, groups, act, nw, has_bias, out_stats, *wb):
+    def forward(ctx, x, groups, act, nw, has_bias, out_stats, drop_bias, *wb):
         weights = list(wb[:nw])
         biases = list(wb[nw:]) if has_bias else None
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
         red_y = ops.zeros_red(x, x.shape[0], cout) if out_stats else None     # output channel sums for the next norm
-        y = ops.conv3d(x, None, weights, biases, k=k, cout=cout, groups=groups, act=act, epi=2 if out_stats else 0, red=red_y)
+        y = ops.conv3d(x, None, weights, None if drop_bias else biases, k=k, cout=cout, groups=groups, act=act,
+                       epi=2 if out_stats else 0, red=red_y)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *weights)
         ctx.cfg = (groups, act, nw, has_bias, k)
         ctx.params = (weights, biases)
@@ -224,11 +230,14 @@ class Conv(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True)
-        return (dx, None, None, None, None, None, *rws, *rbs)
+        return (dx, None, None, None, None, None, None, *rws, *rbs)
 
 
-def conv(x, weights, biases=None, groups=1, act=ACT_NONE, out_stats=False):
-    return Conv.apply(x, groups, act, len(weights), biases is not None, bool(out_stats), *weights, *(biases or []))
+def conv(x, weights, biases=None, groups=1, act=ACT_NONE, out_stats=False, drop_bias=False):
+    """drop_bias: as in in_lrelu_conv (output consumed only by InstanceNorm; needs act == ACT_NONE)."""
+    if drop_bias and act != ACT_NONE:
+        raise ValueError("drop_bias needs a linear output")
+    return Conv.apply(x, groups, act, len(weights), biases is not None, bool(out_stats), bool(drop_bias), *weights, *(biases or []))
 
 
 class MaxPool2(Function):

@@ -6,6 +6,7 @@ the volume and divided by the per-voxel window count.  Differences, all delibera
 
 * evaluation.py:316-321 appends `D - patch_size` with `patch_size` a *list* (a TypeError whenever the branch is taken);
   the rule implemented here is the evident intent, `D - patch_size[axis]`;
+* like the reference (evaluation.py:305-307) the modalities outside the subset are zeroed in the volume before cropping;
 * sums and counts are accumulated on the device, not copied to the host per window;
 * the window list can be sharded round-robin over ranks (`rank`, `world`): every rank accumulates its own windows and ONE
   all-reduce of (sum, count) finishes the volume -- windows are independent, so there is no other exchange step.
@@ -39,7 +40,7 @@ def window_list(shape, patch_size, overlap_stepsize):
 
 @torch.no_grad()
 def eval_overlap_volume(model, x, subset_idx=14, patch_size=(128, 128, 128), overlap_stepsize=(64, 64, 64), batch_size=1,
-                        draw=None, num_classes=3, rank=0, world=1, group=None, drop_missing=False, use_graph=False):
+                        draw=None, num_classes=3, rank=0, world=1, group=None, use_graph=False):
     """x: (1, 4, D, H, W) on the model's device.  Returns the (1, num_classes, D, H, W) fp32 overlap-averaged
     probabilities (on every rank when world > 1).  `draw=None` uses the posterior mean (valid=True); an integer averages
     that many random draws per window (evaluation.py:286-291,339-349).  use_graph=True (device tensors, posterior mean
@@ -49,12 +50,12 @@ def eval_overlap_volume(model, x, subset_idx=14, patch_size=(128, 128, 128), ove
         raise ValueError("expected one volume shaped (1, C, D, H, W)")
     valid = draw is None
     ndraw = 1 if draw is None else int(draw)
-    # evaluation.py:305-306 means to zero the modalities outside the subset, but `x_batch[:, mod_list == False] = 0` compares a
-    # tuple with False and indexes with the scalar False: a no-op, so the reference's skip-return path (x0_init(x),
-    # RA_HVED.py:621) still sees every modality.  drop_missing=False reproduces that; True applies the evident intent.
-    if drop_missing:
-        keep = torch.zeros(x.shape[1], dtype=torch.bool, device=x.device)
-        keep[list(SUBSETS_MODALITIES[subset_idx])] = True
+    # evaluation.py:305-307: `x_batch[:, mod_list == False] = 0` -- SUBSETS_MODALITIES there is a (15, 4) bool ndarray
+    # (evaluation.py:15-21), so `mod_list == False` is a boolean channel mask: the modalities outside the subset are zeroed
+    # in the input BEFORE cropping, which is what the skip-return path (x0_init(x), RA_HVED.py:621) then sees.
+    keep = torch.zeros(x.shape[1], dtype=torch.bool, device=x.device)
+    keep[list(SUBSETS_MODALITIES[subset_idx])] = True
+    if not bool(keep.all()):
         x = x * keep.view(1, -1, 1, 1, 1).to(x.dtype)
     D, H, W = x.shape[2:]
     pd, ph, pw = patch_size

@@ -253,8 +253,10 @@ class AbstractFusion3DUNet(nn.Module):
         x = x.contiguous()
         st0 = None
         if batched:
+            # level 0's first InstanceNorm takes its sums from here; it is the init blocks' only consumer, so their bias add
+            # is an identity (drop_bias: a channel w*x + b with a small w would otherwise spend its 16-bit mantissa on b)
             X, st0 = Fn.conv(x, [b[0].weight for b in self.init_blocks], [b[0].bias for b in self.init_blocks], groups=4,
-                             out_stats=True)               # level 0's first InstanceNorm takes its sums from here
+                             out_stats=True, drop_bias=True)
         else:
             X = [Fn.conv(x[:, i:i + 1].contiguous(), [b[0].weight], [b[0].bias]) for i, b in enumerate(self.init_blocks)]
         feat_list = []
@@ -269,7 +271,8 @@ class AbstractFusion3DUNet(nn.Module):
                     X = Fn.MaxPool2.apply(X)
                 # each conv's epilogue accumulates the channel sums the next InstanceNorm needs (no separate pass)
                 w, b = self._stream_weights(level, "SingleConv1")
-                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0 if level == 0 else None, out_stats=True)
+                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0 if level == 0 else None, out_stats=True,
+                                         drop_bias=True)                  # consumed by SingleConv2's InstanceNorm only
                 w, b = self._stream_weights(level, "SingleConv2")
                 X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st, out_stats=True)
                 drb = [m[0].conv for m in self.DRBs[level]]

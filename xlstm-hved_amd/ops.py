@@ -23,7 +23,9 @@ def _dt(t):
         return L.XH_F32
     if t.dtype == torch.bfloat16:
         return L.XH_BF16
-    raise TypeError(f"activation dtype must be float32 or bfloat16, got {t.dtype}")
+    if t.dtype == torch.float16:
+        return L.XH_F16
+    raise TypeError(f"activation dtype must be float32, bfloat16 or float16, got {t.dtype}")
 
 
 def _p(t):
@@ -90,21 +92,24 @@ def zeros_f64(device, shape):
         numel *= int(s_)
     a = _ARENA.get(device)
     if a is None:
-        a = _ARENA[device] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=device), 0]
+        a = _ARENA[device] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=device), 0, 0]
     need = (numel + 15) & ~15
     if a[1] + need > _ARENA_DOUBLES:
         return torch.zeros(shape, dtype=torch.float64, device=device)
     t = a[0][a[1]:a[1] + numel].view(shape)
     a[1] += need
+    a[2] = max(a[2], a[1])
     return t
 
 
 def red_arena_reset(device):
-    """Zeroes what has been handed out since the last reset (one fill) and starts over.  Called where no arena slice
-    is live: the start of the network's forward()."""
+    """Zeroes the arena up to its HIGH-WATER mark (one fill) and starts over.  Called where no arena slice is live: the
+    start of the network's forward().  The high-water mark (largest extent ever handed out, captures included) rather than
+    the current offset: a hipGraph replay dirties the extent it had at capture time without moving the Python-side
+    offset, so a smaller eager pass in between must not shrink what the next reset clears."""
     a = _ARENA.get(device)
-    if a is not None and a[1] > 0:
-        a[0][:a[1]].zero_()
+    if a is not None and a[2] > 0:
+        a[0][:a[2]].zero_()
         a[1] = 0
 
 

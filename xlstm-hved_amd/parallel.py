@@ -54,15 +54,42 @@ class FlatGrads:
         self.params = [p for p in params if p.requires_grad]
         p0 = self.params[0]
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=p0.device)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.attach()
+
+    def attach(self):
+        """(Re-)points every p.grad at its view of the bucket.  A gradient that something else has replaced in the
+        meantime (optimizer.zero_grad() defaults to set_to_none=True, train.py:264 -> backward then allocates fresh
+        per-parameter gradients) is copied into the bucket first, so nothing is lost."""
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()                      # no gradient this step = a zero contribution (not last step's values)
+                p.grad = v
+            elif g.data_ptr() != v.data_ptr() or g.shape != v.shape or g.dtype != torch.float32:
+                v.copy_(g)
+                p.grad = v
+
+    def check(self):
+        """True when every p.grad still aliases the bucket."""
+        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
 
     def zero(self):
+        """Use this instead of optimizer.zero_grad(): one fill, and the views stay attached (re-attached if lost)."""
+        if not self.check():
+            for p in self.params:                      # drop foreign gradients: zero() means zero
+                p.grad = None
+            self.attach()
         self.flat.zero_()
 
     def all_reduce(self, world_size=None, group=None):
+        """Averages the bucket across ranks in place.  Gradients that no longer alias the bucket (see attach) are
+        gathered into it first -- reducing a stale bucket would silently stop synchronising the ranks."""
+        if not self.check():
+            self.attach()
         world = world_size if world_size is not None else dist.get_world_size(group)
         dist.all_reduce(self.flat, group=group)
         self.flat.div_(world)
