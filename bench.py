@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- voxels/s of the XLSTM-HVED forward+backward hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--size 128] [--no-graph] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--size 128] [--no-graph] [--no-cpu]
 
-One process per GPU (for N>1 launch with torch.distributed.run; RANK/LOCAL_RANK/WORLD_SIZE are read from the
-environment).  A step = one forward + backward of XLSTM_HVED (train mode, all 4 modalities, recon=True, loss of
+One process per GPU.  Under torch.distributed.run RANK/LOCAL_RANK/WORLD_SIZE are read from the environment; a plain
+`python bench.py --gpus N` (no launcher) spawns its own N worker processes before anything touches a GPU.  A step = one forward + backward of XLSTM_HVED (train mode, all 4 modalities, recon=True, loss of
 SURVEY.md 8(d)) on one synthetic 1x4x128^3 patch per rank, plus for N>1 the flat RCCL all-reduce of the generator's
 gradients (data parallel; weak scaling).  Forward+backward are captured once into a hipGraph and replayed (the
 all-reduce is issued eagerly after each replay, on the same stream); W warm-up steps, then exactly K timed steps
@@ -14,8 +14,12 @@ Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant conv kernel of the step (by total time), timed per launch with HIP events on the launch stream
                 during an instrumented pass over the same steps; algorithmic bytes/flops from the launch's shapes.
   cpu_baseline  the CPU oracle (port of the reference path; the reference sources do not travel to the GPU box)
-                timed on a bounded number of host threads on a bounded sample of the same workload.
+                timed on the best of a small thread-count sweep on a bounded sample of the same workload; it runs in a
+                child process next to the GPU legs (a 256-thread host; the GPU timed region is one graph launch per step).
+  modes         ms/step and voxels/s of the same step in the other storage modes (fp32 = the parity mode, fp16 = the
+                reference's AMP dtype, bf16), each with the measured deviation class it belongs to (tests/test_gpu_network.py).
 """
+import subprocess
 import argparse
 import json
 import os
@@ -29,7 +33,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak: the fp32 (parity mode) conv kernels are FMA kernels on the VALU
-BF16_MFMA_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (MI355X_MICROARCH.md): the bf16 conv kernels are implicit GEMMs on MFMA
+BF16_MFMA_PEAK_TFLOPS = 2500.0 # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md): the 16-bit conv kernels are implicit GEMMs on MFMA
+LOSS_SCALE_FP16 = 65536.0      # torch.cuda.amp.GradScaler's initial scale (the reference's AMP, train.py:207)
+# deviation class of each storage mode from the fp32 reference path (tests/test_gpu_network.py, measured on MI355X at 64^3 / 128^3;
+# yardstick = the reference's own fp16-autocast deviation on the same weights / inputs, tests/golden/amp_yardstick.json)
+MODE_PARITY = {
+    "fp32": "parity mode: seg |d| <= 8e-4, Dice deviation <= 1e-5 vs the CPU oracle at 128^3 (SURVEY 8c tolerances 5e-3 / 1e-4)",
+    "fp16": "seg rel-L2 0.010, Dice deviation 3.6e-3 at 128^3 (reference fp16-AMP: 0.111, 4.0e-2)",
+    "bf16": "seg rel-L2 0.072, Dice deviation 2.5e-2 at 128^3 (reference fp16-AMP: 0.111, 4.0e-2; bf16-AMP: 0.179, 6.7e-2)",
+}
 
 
 def parse():
@@ -37,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
@@ -46,6 +58,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and issue the gradient all-reduce even with one rank (exercises the N>1 code path)")
     ap.add_argument("--extras", action="store_true", help="also time forward-only and the shared-encoder two-forward step")
+    ap.add_argument("--no-modes", action="store_true", help="skip timing the other storage modes")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the N=1 run
     return ap.parse_args()
 
 
@@ -57,15 +71,15 @@ def bench_loss(seg, mu, lv, rec):
     return loss
 
 
-def cpu_baseline(size, batch, budget_s=45.0, max_threads=16):
+def cpu_baseline(size, batch, budget_s=60.0, sweep=(8, 16, 32, 64)):
     """Times the CPU oracle (functional restatement of the reference path, stock torch ops, fp32) on this host.
-    Bounded: at most `max_threads` torch threads (stock CPU conv3d stops scaling long before a 256-thread host is
-    full), one 1x4x64^3 fwd+bwd step first; the full-size step runs only if its extrapolated time fits the budget."""
+    Thread-count sweep on one 1x4x64^3 fwd+bwd step (stock CPU conv3d stops scaling long before a 256-thread host is
+    full: 256 threads took 771 s per 128^3 step); the best count then runs the full-size step if its extrapolated time
+    fits the budget.  Never touches the GPU (runs in a child process of the N=1 bench)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import xlstm_hved_oracle as O
     import xlstm_hved_amd as X
-    cores = max(1, min(os.cpu_count() or 1, max_threads))
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     torch.manual_seed(1)
     model = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     model.apply(X.init_weights)
@@ -81,19 +95,57 @@ def cpu_baseline(size, batch, budget_s=45.0, max_threads=16):
         O.bench_loss(prob, mu, lv, rec).backward()
         return time.perf_counter() - t0
     small = min(size, 64)
-    run(small)                                    # untimed: thread pool + allocator warm-up
-    t_small = min(run(small), run(small))
-    used, t = small, t_small
-    if size > small and t_small * (size / small) ** 3 <= budget_s:
+    counts = sorted({min(c, ncpu) for c in sweep})
+    times = {}
+    for c in counts:
+        torch.set_num_threads(c)
+        run(small)                                # untimed: thread pool + allocator warm-up at this count
+        times[c] = run(small)
+    cores = min(times, key=times.get)
+    torch.set_num_threads(cores)
+    used, t = small, times[cores]
+    if size > small and t * (size / small) ** 3 <= budget_s:
         used, t = size, run(size)
+    sw = ", ".join(f"{c}: {v:.2f} s" for c, v in times.items())
     return {"value": batch * used ** 3 / t, "unit": "voxels/s", "cores": cores, "kind": "port",
             "sample": f"one fwd+bwd step of {batch}x4x{used}^3 fp32 through oracle/xlstm_hved_oracle.py (torch "
-                      f"{torch.__version__} CPU ops, {cores} threads of {os.cpu_count()}): {t:.2f} s"
+                      f"{torch.__version__} CPU ops) on {cores} threads of {ncpu}: {t:.2f} s; thread sweep on the "
+                      f"{batch}x4x{small}^3 step: {sw}"
                       + ("" if used == size else f"; the {size}^3 step was extrapolated to exceed {budget_s:.0f} s and was not run")}
+
+
+def spawn_workers(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this script (one per GPU, RCCL
+    rendezvous on 127.0.0.1) BEFORE this process touches a GPU, relay rank 0's JSON line, exit with the worst code."""
+    import socket
+    n_dev = torch.cuda.device_count()             # does not initialise the GPU runtime
+    if n_dev < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {n_dev} device(s) visible\n")
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.size, args.batch)))
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_workers(args))
     # stdout must carry exactly ONE line (the JSON).  Native libraries (RCCL prints a version banner at communicator
     # creation, flushed at exit) write to file descriptor 1 too, so fd 1 is pointed at stderr for the whole run and the
     # JSON is written to a private duplicate of the original stdout.
@@ -105,8 +157,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    cpu_proc = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        # the CPU baseline runs NEXT TO the GPU legs in its own process (it never touches the GPU): the device is busy while
+        # the driver samples it, and the run is not 40 s of idle GPU followed by 3 s of work
+        cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
+                                     "--batch", str(args.batch)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     import xlstm_hved_amd as X
     from xlstm_hved_amd import ops
     torch.cuda.set_device(local_rank)
@@ -120,7 +176,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
         else:
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+    dtype = DT[args.dtype]
     S, B = args.size, args.batch
 
     torch.manual_seed(1)                                      # same weights on every rank
@@ -132,10 +189,22 @@ def main():
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
     grads = X.parallel.FlatGrads(params)                       # p.grad = views of one flat fp32 bucket
 
-    def compute():
-        grads.zero()
-        seg, (mu, lv), rec = model(x, [14], recon=True)
-        bench_loss(seg, mu, lv, rec[0]).backward()
+    def make_compute(xin):
+        # fp16 storage: the activation gradients need the caller's loss scaling, as the reference's GradScaler provides
+        # (train.py:207,265-268; initial scale 65536); the unscale of the fp32 parameter gradients is part of the step
+        scale = LOSS_SCALE_FP16 if xin.dtype == torch.float16 else 1.0
+
+        def compute():
+            grads.zero()
+            seg, (mu, lv), rec = model(xin, [14], recon=True)
+            loss = bench_loss(seg, mu, lv, rec[0])
+            if scale != 1.0:
+                (loss * scale).backward()
+                grads.flat.mul_(1.0 / scale)
+            else:
+                loss.backward()
+        return compute
+    compute = make_compute(x)
 
     def step():
         compute()
@@ -200,16 +269,52 @@ def main():
     }
     if roof is not None:
         out["roofline"] = roof
+    out["parity"] = MODE_PARITY[args.dtype]
+    if rank == 0 and world == 1 and not args.no_modes:
+        # the same step in the other storage modes (same weights, same patch, hipGraph replay, no collective), so the
+        # parity-mode throughput is measured in the same run as the headline
+        modes = {args.dtype: {"ms_per_step": ms, "voxels_per_s": B * S ** 3 / (ms * 1e-3), "parity": MODE_PARITY[args.dtype]}}
+        for name, dt_ in DT.items():
+            if name == args.dtype:
+                continue
+            ms_m = time_graph(make_compute(x.to(dt_)), args.steps, args.warmup, thread_local=use_dist)
+            modes[name] = {"ms_per_step": ms_m, "voxels_per_s": B * S ** 3 / (ms_m * 1e-3), "parity": MODE_PARITY[name]}
+        out["modes"] = modes
     if args.extras and rank == 0:
         out["extras"] = extras(model, x, grads, args.steps)
-    if rank == 0 and not args.no_cpu and world == 1:
-        out["cpu_baseline"] = cpu_baseline(S, B)
+    if cpu_proc is not None:
+        cpu_out, _ = cpu_proc.communicate()
+        try:
+            out["cpu_baseline"] = json.loads(cpu_out.decode().strip().splitlines()[-1])
+        except Exception as e:                                  # the GPU result must survive a CPU-leg failure
+            out["cpu_baseline"] = {"value": None, "unit": "voxels/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         import torch.distributed as dist
         dist.barrier()                                          # rank 0 arrives after its roofline pass
         dist.destroy_process_group()
+
+
+def time_graph(fn, nsteps, warmup=3, thread_local=False):
+    """ms per replay of `fn` captured once into a hipGraph (one untimed eager pass first)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local" if thread_local else "global"):
+        fn()
+    for _ in range(warmup):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / nsteps * 1e3
 
 
 def extras(model, x, grads, nsteps):
@@ -280,7 +385,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     element once at its storage size (+ fp32 weights / weight gradients), flops = 2*out_elements*k^3*Cin/groups."""
     records = []
     orig_fwd, orig_wg = ops.conv3d, ops.conv3d_wgrad
-    esz = 2 if dtype == torch.bfloat16 else 4
+    esz = 4 if dtype == torch.float32 else 2
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
@@ -394,7 +499,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     if os.path.exists(tpath):
         with open(tpath) as f:
             t = json.load(f)
-        if name in t.get("kernels", {}) and t.get("dtype") == ("bf16" if esz == 2 else "fp32"):
+        if name in t.get("kernels", {}) and t.get("dtype") == {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[dtype]:
             traffic = t["kernels"][name]["hbm_bytes_per_launch"]
     r.update({"traffic": traffic,
               "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)",

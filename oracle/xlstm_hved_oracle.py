@@ -385,25 +385,32 @@ def xlstm_hved_forward(sd, x, subset_idx=14, instance_missing=False, drop=None, 
             logits = F.conv3d(sout, p["final_conv.weight"], p["final_conv.bias"])
             prob = torch.sigmoid(logits)
         return prob, logits, mu_list, logvar_list, rec
-    # Seg_Recon_DuSFEDecoder.forward, RA_HVED.py:158-201
-    rout = sout = feats[0]
-    for j in range(levels - 1):
-        skipf = feats[j + 1]
-        size = skipf.shape[2:]
-        rd = p.sub(f"srdecoder.multi_decoders.0.{j}")
-        rout = double_conv(rd.sub("basic_module"), torch.cat([skipf, upsample_to(rout, size)], 1), order)
+    # Seg_Recon_DuSFEDecoder.forward, RA_HVED.py:158-201.  shared_recon=True: one stream; shared_recon=False (Pretrain.py:142):
+    # four recon decoder streams, each restarting from feats[0]; the seg decoders and the first three DuSE blocks are shared
+    # by every stream (the zip at RA_HVED.py:171 stops after three of the twelve registered DuSE blocks).
+    n_streams = 1 if "srdecoder.multi_decoders.1.0.basic_module.SingleConv1.conv.weight" not in sd else 4
+    recs, sfins = [], []
+    for i in range(n_streams):
+        rout = sout = feats[0]
+        for j in range(levels - 1):
+            skipf = feats[j + 1]
+            size = skipf.shape[2:]
+            rd = p.sub(f"srdecoder.multi_decoders.{i}.{j}")
+            rout = double_conv(rd.sub("basic_module"), torch.cat([skipf, upsample_to(rout, size)], 1), order)
+            if seg:
+                sdp = p.sub(f"srdecoder.sdecoders.{j}")
+                sout = double_conv(sdp.sub("basic_module"),
+                                   atten_module2(sdp.sub("atten_module"), upsample_to(sout, size), skipf), order)
+                tap(f"dec.{j}.pre_duse", (rout, sout))
+                rout, sout = duse_attention(p.sub(f"srdecoder.dusfe_decoders.{j}"), rout, sout, training)
+            tap(f"dec.{j}", (rout, sout))
+        recs.append(F.conv3d(rout, p[f"srdecoder.rfinals.{i}.weight"], p[f"srdecoder.rfinals.{i}.bias"]))
         if seg:
-            sdp = p.sub(f"srdecoder.sdecoders.{j}")
-            sout = double_conv(sdp.sub("basic_module"),
-                               atten_module2(sdp.sub("atten_module"), upsample_to(sout, size), skipf), order)
-            tap(f"dec.{j}.pre_duse", (rout, sout))
-            rout, sout = duse_attention(p.sub(f"srdecoder.dusfe_decoders.{j}"), rout, sout, training)
-        tap(f"dec.{j}", (rout, sout))
-    rec = F.conv3d(rout, p["srdecoder.rfinals.0.weight"], p["srdecoder.rfinals.0.bias"])
+            sfins.append(F.conv3d(sout, p[f"srdecoder.sfinals.{i}.weight"], p[f"srdecoder.sfinals.{i}.bias"]))
+    rec = recs[0] if n_streams == 1 else torch.cat(recs, 1)          # the reference returns the list (RA_HVED.py:644)
     logits = prob = None
     if seg:
-        sfin = F.conv3d(sout, p["srdecoder.sfinals.0.weight"], p["srdecoder.sfinals.0.bias"])
-        logits = F.conv3d(sfin, p["final_conv.weight"], p["final_conv.bias"])      # RA_HVED.py:640
+        logits = F.conv3d(torch.cat(sfins, 1), p["final_conv.weight"], p["final_conv.bias"])      # RA_HVED.py:199,640
         prob = torch.sigmoid(logits)                                               # RA_HVED.py:641
     return prob, logits, mu_list, logvar_list, rec
 

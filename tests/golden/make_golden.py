@@ -334,6 +334,8 @@ VARIANTS = {
                             dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False)),
     "xlstm_hved_wodusfe": ("XLSTM_HVED_woDuSFE", dict(),
                            dict(order="ilc", mid_vil=True, skip_return=True, seg_recon_decoder=False)),
+    # shared_recon=False (Pretrain.py:142): four recon decoder streams behind shared seg decoders / DuSE blocks
+    "xlstm_hved_noshared": ("XLSTM_HVED", dict(shared_recon=False), dict(order="ilc", mid_vil=True, skip_return=True)),
 }
 
 
@@ -361,7 +363,8 @@ def variant_cases():
         _inject_eps(eps)
         seg, (mu, lv), rec = m(x.double().clone(), [14], recon=True, valid=False)
         R.reparametrize = orig_rep
-        rec = rec[0] if isinstance(rec, (list, tuple)) else rec
+        if isinstance(rec, (list, tuple)):
+            rec = rec[0] if len(rec) == 1 else torch.cat(list(rec), 1)
         ws, wr = rnd(seg.shape, 300).double(), rnd(rec.shape, 301).double()
         loss = (seg * ws).sum() + 0.1 * (rec * wr).sum()
         for i, (a, b) in enumerate(zip(mu, lv)):

@@ -344,6 +344,8 @@ VARIANTS = {
                             dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False)),
     "xlstm_hved_wodusfe": ("XLSTM_HVED_woDuSFE", dict(),
                            dict(order="ilc", mid_vil=True, skip_return=True, seg_recon_decoder=False)),
+    # shared_recon=False (Pretrain.py:142): four recon streams, shared seg decoders, sfinals outputs concatenated
+    "xlstm_hved_noshared": ("XLSTM_HVED", dict(shared_recon=False), dict(order="ilc", mid_vil=True, skip_return=True)),
 }
 
 
@@ -365,7 +367,8 @@ def test_variant_classes_fp32_vs_reference_fixture_and_oracle(tag):
     x = torch.from_numpy(z["x"])
     eps = [torch.from_numpy(z[f"eps{i}"]) for i in range(4)]
     seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps)
-    rec = rec[0] if isinstance(rec, (list, tuple)) else rec
+    if isinstance(rec, (list, tuple)):
+        rec = rec[0] if len(rec) == 1 else torch.cat(list(rec), 1)
     e_seg = (seg.flatten().cpu().double()[z["idx_seg"]] - torch.from_numpy(z["seg"])).abs().max().item()
     e_rec = rel_err(rec.flatten().cpu()[z["idx_rec"]], torch.from_numpy(z["rec"]))
     e_mu = rel_err(mu[3].flatten(), torch.from_numpy(z["mu3"]))
@@ -392,6 +395,8 @@ def test_variant_classes_fp32_vs_reference_fixture_and_oracle(tag):
     for k, p in m.named_parameters():
         if k.startswith("init_blocks."):
             continue     # mathematically zero gradient (feeds an InstanceNorm / per-channel GroupNorm): round-off in both
+        if k.startswith("decoders.") and hasattr(m, "srdecoder"):
+            k = k.replace("decoders.", "srdecoder.sdecoders.", 1)       # the same modules under their second name (RA_HVED.py:492)
         if k not in ref:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue

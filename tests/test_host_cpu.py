@@ -116,6 +116,7 @@ def test_subset_table(X):
     ("uhved_conv_gcr", "U_HVEDConvNet3D", dict(layer_order="gcr", f_maps=8)),
     ("uhved_convxlstm_gcr", "U_HVEDConvXLSTMNet3D", dict(layer_order="gcr", f_maps=8)),
     ("xlstm_hved_wodusfe", "XLSTM_HVED_woDuSFE", dict()),
+    ("xlstm_hved_noshared", "XLSTM_HVED", dict(shared_recon=False)),
 ])
 def test_variant_state_dict_matches_reference_fixture(tag, cls, over):
     """state_dict key order and shapes of the secondary classes equal the reference's (names/shapes stored by

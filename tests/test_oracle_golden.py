@@ -181,6 +181,7 @@ VARIANT_FLAGS = {
     "uhved_conv_gcr": dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False),
     "uhved_convxlstm_gcr": dict(order="gcr", mid_vil=False, skip_return=False, seg_recon_decoder=False),
     "xlstm_hved_wodusfe": dict(order="ilc", mid_vil=True, skip_return=True, seg_recon_decoder=False),
+    "xlstm_hved_noshared": dict(order="ilc", mid_vil=True, skip_return=True),       # shared_recon=False (Pretrain.py:142)
 }
 
 

@@ -90,7 +90,7 @@ def eval_overlap_volume(model, x, subset_idx=14, patch_size=(128, 128, 128), ove
         for j, (d, h, w) in enumerate(chunk):
             sum_tot[:, :, d:d + pd, h:h + ph, w:w + pw] += pred[j]
             count_tot[:, :, d:d + pd, h:h + ph, w:w + pw] += 1
-    if world > 1:
+    if world > 1 or group is not None:            # one exchange step: the (sum, count) all-reduce
         import torch.distributed as dist
         dist.all_reduce(sum_tot, group=group)
         dist.all_reduce(count_tot, group=group)

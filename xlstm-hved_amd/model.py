@@ -85,10 +85,13 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
         self.dusfe_decoders = nn.ModuleList(dusfe)
 
     def forward(self, encoders_features, x, size_list=None, seg=True):
-        rout = sout = x
+        """Returns (level_outputs, [recon output per stream], [seg feature per stream] or None).  Every stream restarts from
+        `x` (RA_HVED.py:171-183); the seg decoders and the FIRST three DuSE blocks are shared by all streams, exactly like the
+        reference's zip over `self.dusfe_decoders` (RA_HVED.py:171)."""
         level_outputs = [[] for _ in encoders_features]
-        rfinal = []
+        rfinal, souts = [], []
         for i, rdecs in enumerate(self.multi_decoders):
+            rout = sout = x
             for j, (rdec, feat, sdec, dusfe) in enumerate(zip(rdecs, encoders_features, self.sdecoders, self.dusfe_decoders)):
                 fused = seg and type(rdec.basic_module) is DoubleConv and type(sdec.basic_module) is DoubleConv \
                     and rdec.basic_module.SingleConv1.order == "ilc"
@@ -103,7 +106,8 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
                         rout, sout = dusfe(rout, sout)
                 level_outputs[j].append(rout)
             rfinal.append(Fn.conv(rout, [self.rfinals[i].weight], [self.rfinals[i].bias]))
-        return level_outputs, rfinal, (sout if seg else None)
+            souts.append(sout)
+        return level_outputs, rfinal, (souts if seg else None)
 
 
 class Discriminator(nn.Module):
@@ -316,7 +320,7 @@ class AbstractFusion3DUNet(nn.Module):
         recon_x, recon_features = feats[0], feats[1:]
         if self.seg_recon_decoder:                                                          # RA_HVED.py:637-648
             _, recon_outputs, sout = self.srdecoder(recon_features, recon_x, seg=seg)
-            seg_outputs = self._seg_head(sout, self.srdecoder.sfinals[0]) if seg else None
+            seg_outputs = self._seg_head(sout, list(self.srdecoder.sfinals)) if seg else None
             if recon and self.recon_decoder:
                 return seg_outputs, (mu_list, logvar_list), recon_outputs
             return seg_outputs, []
@@ -334,15 +338,25 @@ class AbstractFusion3DUNet(nn.Module):
             return out, (mu_list, logvar_list), recon_outputs
         return out, []
 
-    def _seg_head(self, sout, sfinal):
-        """sigmoid(final_conv(sfinals(sout))) (RA_HVED.py:195,640-641) as one composed 1x1 conv."""
-        wf = self.final_conv.weight.view(self.final_conv.out_channels, -1)
-        bf = self.final_conv.bias
-        if sfinal is not None:
-            ws = sfinal.weight.view(sfinal.out_channels, -1)
-            bf = wf @ sfinal.bias + bf
-            wf = wf @ ws
-        return Fn.conv(sout, [wf.reshape(wf.shape[0], wf.shape[1], 1, 1, 1).contiguous()], [bf], act=ACT_SIGMOID)
+    def _seg_head(self, souts, sfinals):
+        """sigmoid(final_conv(cat_i sfinals[i](sout_i))) (RA_HVED.py:192-199,640-641).  With the shared decoder (one stream)
+        the two 1x1 convs compose into ONE 1x1 conv.  The composition is parameter-sized fp32 arithmetic and must stay fp32
+        under a caller's `with autocast():` (train.py:218), hence the explicit autocast-off region."""
+        with torch.autocast(device_type=self.final_conv.weight.device.type, enabled=False):
+            wf = self.final_conv.weight.float().view(self.final_conv.out_channels, -1)
+            bf = self.final_conv.bias.float()
+            if sfinals is None:
+                sout = souts
+            elif len(sfinals) == 1:
+                sout = souts[0]
+                ws = sfinals[0].weight.float().view(sfinals[0].out_channels, -1)
+                bf = wf @ sfinals[0].bias.float() + bf
+                wf = wf @ ws
+            else:
+                # shared_recon=False (Pretrain.py:142): one 1-channel sfinals conv per stream, concatenated (RA_HVED.py:199)
+                sout = torch.cat([Fn.conv(so, [sf.weight], [sf.bias]) for so, sf in zip(souts, sfinals)], 1)
+            wf = wf.reshape(wf.shape[0], wf.shape[1], 1, 1, 1).contiguous()
+        return Fn.conv(sout, [wf], [bf], act=ACT_SIGMOID)
 
     def seg_parameters(self):
         """RA_HVED.py:496-500 (the reference lists a non-existent atten_blocks; omitted)."""

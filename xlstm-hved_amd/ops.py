@@ -151,6 +151,23 @@ def _out_spatial(d, h, w, k, stride):
     return f(d), f(h), f(w)
 
 
+def _check_weights(weights, biases, cin, cout, groups, k, transposed, what):
+    """The kernels index weights from (Cin, Cout, groups, k) alone: a tensor of another shape would be read out of bounds."""
+    nw = len(weights)
+    if nw != 1 and nw != groups:
+        raise ValueError(f"{what}: {nw} weight tensors for {groups} groups (need 1 or one per group)")
+    if cin % groups or cout % groups:
+        raise ValueError(f"{what}: channels ({cin} -> {cout}) not divisible by groups={groups}")
+    rows, cols = (cin, cout) if transposed else (cout, cin)      # transposed: forward-layout weights [Cin_fwd... ] = [rows][cols/groups]
+    want = (rows // nw, cols // groups, k, k, k)
+    for w in weights:
+        if tuple(w.shape) != want:
+            raise ValueError(f"{what}: weight shape {tuple(w.shape)}, expected {want} (Cin={cin}, Cout={cout}, groups={groups}, k={k})")
+    for b in biases or []:
+        if b is not None and tuple(b.shape) != (cout // nw,):
+            raise ValueError(f"{what}: bias shape {tuple(b.shape)}, expected {(cout // nw,)}")
+
+
 def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=False, pre=None, act=ACT_NONE,
            act_slope=LEAK, epi=0, e=None, red=None, out=None, in_stats=None):
     """y = act(conv(pre(cat[xa, xb])) + b) [+ fused epilogue].  weights/biases: lists of 1 or `groups` fp32 tensors.
@@ -159,6 +176,7 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     (y, sc, sh, mean, rstd).  On the MFMA path the finalisation rides on the weight-pack launch, else xh_norm_finalize runs."""
     lib = L.load()
     n, ca, d, h, w, _ = _vol(xa)
+    _check_weights(weights, biases, ca + (xb.shape[1] if xb is not None else 0), cout, groups, k, transposed, "conv3d")
     osp = _out_spatial(d, h, w, k, stride)
     if out is None:
         out = new_like(xa, (n, cout) + osp)
@@ -204,6 +222,7 @@ def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None)
     """Data gradient of the k3/s2/p1 conv: dy (N,Cout,Do,Ho,Wo) -> (N,cin,D,H,W)."""
     lib = L.load()
     n, cout, do, ho, wo, dy_bs = _vol(dy)
+    _check_weights(weights, None, cin, cout, groups, 3, False, "conv3d_dgrad_s2")
     d, h, w = in_spatial
     out = new_like(dy, (n, cin, d, h, w))
     desc = L.ConvDesc()
@@ -231,6 +250,7 @@ def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None):
     """Accumulates into the fp32 tensors dws (and dbs, may be None) the weight/bias gradients."""
     lib = L.load()
     n, cout, do, ho, wo, dy_bs = _vol(dy)
+    _check_weights(dws, dbs, xa.shape[1] + (xb.shape[1] if xb is not None else 0), cout, groups, k, False, "conv3d_wgrad")
     desc = _conv_desc(xa, xb, k, stride, groups, cout, len(dws), False, pre, ACT_NONE, LEAK, 0, None, 0, (do, ho, wo))
     desc.ea_bs = dy_bs
     ptrs = L.ConvPtrs()

@@ -8,7 +8,10 @@ from torch.nn import init
 
 
 def init_weights(m):
-    """utils.py:191-215: kaiming-normal Conv3d weights, N(0,1) biases, xavier Linear, BatchNorm N(1,0.02)/0."""
+    """utils.py:191-215: kaiming-normal Conv3d weights, N(0,1) biases, xavier Linear, BatchNorm N(1,0.02)/0, and the
+    reference's nn.ModuleList branch (utils.py:213-215): under `model.apply(init_weights)` the DIRECT children of every
+    ModuleList are initialised a second time (apply visits them as well), which advances the RNG -- reproduced so that
+    the same seed draws the same weights as the reference."""
     if isinstance(m, nn.Conv3d):
         init.kaiming_normal_(m.weight.data)
         if m.bias is not None:
@@ -24,6 +27,9 @@ def init_weights(m):
         init.xavier_normal_(m.weight.data)
         if m.bias is not None:
             init.normal_(m.bias.data)
+    elif isinstance(m, nn.ModuleList):
+        for l in m:
+            init_weights(l)
 
 
 def subset_idx(subset_size=(4,)):
