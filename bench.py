@@ -59,6 +59,10 @@ def parse():
                     help="initialise RCCL and issue the gradient all-reduce even with one rank (exercises the N>1 code path)")
     ap.add_argument("--extras", action="store_true", help="also time forward-only and the shared-encoder two-forward step")
     ap.add_argument("--no-modes", action="store_true", help="skip timing the other storage modes")
+    ap.add_argument("--wgrad-overlap", action="store_true",
+                    help="launch the weight-gradient kernels on a second HIP stream (measured on MI355X: no gain, 9.88-10.7 ms "
+                         "vs 9.96 ms -- the hipGraph's cross-stream dependencies cost what the overlap saves; off by default)")
+    ap.add_argument("--wgrad-batch", type=int, default=12, help="weight-gradient calls forked to the side stream per batch")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the N=1 run
     return ap.parse_args()
 
@@ -188,6 +192,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1 + rank)   # per-rank synthetic patch
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
     grads = X.parallel.FlatGrads(params)                       # p.grad = views of one flat fp32 bucket
+    ops.set_wgrad_overlap(args.wgrad_overlap, args.wgrad_batch)           # weight gradients on a second HIP stream, joined once per step
 
     def make_compute(xin):
         # fp16 storage: the activation gradients need the caller's loss scaling, as the reference's GradScaler provides
@@ -200,9 +205,11 @@ def main():
             loss = bench_loss(seg, mu, lv, rec[0])
             if scale != 1.0:
                 (loss * scale).backward()
+                ops.join_wgrad_stream()
                 grads.flat.mul_(1.0 / scale)
             else:
                 loss.backward()
+                ops.join_wgrad_stream()                       # the weight-gradient branch rejoins the step here
         return compute
     compute = make_compute(x)
 
@@ -384,6 +391,8 @@ def roofline_pass(step, ops, nsteps, dtype):
     dominant kernel.  Algorithmic work per launch comes from the launch's shapes: bytes = every input and output
     element once at its storage size (+ fp32 weights / weight gradients), flops = 2*out_elements*k^3*Cin/groups."""
     records = []
+    overlap_was = ops._WG["on"]
+    ops.set_wgrad_overlap(False)          # per-launch brackets need every conv launch on the one (current) stream
     orig_fwd, orig_wg = ops.conv3d, ops.conv3d_wgrad
     esz = 4 if dtype == torch.float32 else 2
 
@@ -481,6 +490,7 @@ def roofline_pass(step, ops, nsteps, dtype):
         a[2] += sum(c[1] for c in calls)
         a[3] += sum(c[2] for c in calls)
         a[4][shape] = a[4].get(shape, 0) + len(calls)
+    ops.set_wgrad_overlap(overlap_was)
     total_ms = sum(a[1] for a in agg.values())
     name, (cnt, ms_sum, bytes_sum, flops_sum, shapes) = max(agg.items(), key=lambda kv: kv[1][1])
     avg_ms, nbytes, flops = ms_sum / cnt, bytes_sum / cnt, flops_sum / cnt

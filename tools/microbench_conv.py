@@ -49,6 +49,12 @@ if __name__ == "__main__":
                 res[mfma] = bench(call)
             ops.set_mfma(True)
             extra = ""
+            if "--occ" in sys.argv:
+                for occ in (0, 1):
+                    for wgs in (512, 1024, 2048, 4096):
+                        L.load().xh_set_option(3, wgs); L.load().xh_set_option(4, occ)
+                        extra += f", occ{occ}/wg{wgs}: {bench(call):.1f}"
+                L.load().xh_set_option(3, 512); L.load().xh_set_option(4, 0)
             if "--th4" in sys.argv:
                 L.load().xh_set_option(1, 64)
                 extra = f", 4-row tiles: {bench(call):.1f} us"

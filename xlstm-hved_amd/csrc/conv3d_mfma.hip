@@ -45,6 +45,8 @@ struct ConvMK {
   float* part;
 };
 int g_mfma_abl = 0;
+int g_mfma_wgs = 512;      // xh_set_option(3, n): target workgroup count of the k3 MFMA forward kernel (experiments)
+int g_mfma_occ = 0;        // xh_set_option(4, 1): high-occupancy (<=128 VGPR) instances for CINP <= 8 at 128^3-class volumes
 
 __device__ __forceinline__ float mk_weight(const ConvMK& a, int co, int ci, int tap) {
   // kernel-view absolute channels; block-diagonal over groups
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
 // bijection inside each 128-byte block, so fragment reads apply the same function.
 __device__ __forceinline__ int swz(int off) { return off ^ (((off >> 8) & 7) << 4); }
 
-template <int FMT, int CINP, int NT, int TW, int TH = 8>
-__global__ __launch_bounds__(NT, (TH == 4 ? 3 : 2)) void conv3_mfma_kernel(const ConvMK a) {
+template <int FMT, int CINP, int NT, int TW, int TH = 8, int MW = (TH == 4 ? 3 : 2)>
+__global__ __launch_bounds__(NT, MW) void conv3_mfma_kernel(const ConvMK a) {
   typedef h16<FMT> ST;                                // storage type of activations: ST or f16_t
   constexpr int NWV = NT / 64;
   constexpr int NSEG = TW / 16;
@@ -414,7 +416,7 @@ static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if (ny > 65535) return 1;
   // depth segments: enough workers for ~2 resident workgroups per CU, but runs of at least 4 planes
   const int cols = a->tilesW * a->tilesH;
-  int dsegs = cdiv(a->th == 4 ? 1024 : 512, cols * ny * d->N);
+  int dsegs = cdiv(a->th == 4 ? 1024 : g_mfma_wgs, cols * ny * d->N);
   // runs of >= 4 planes (2 on small volumes, where workgroup count matters more than the 2 halo planes per run)
   const int min_run = ((long long)d->Do * d->Ho * d->Wo <= (1 << 16) && !(g_mfma_abl & 512)) ? 2 : 4;
   const int max_segs = d->Do >= min_run ? d->Do / min_run : 1;
@@ -474,6 +476,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     }                                                                                                           \
     if (a.tw == 16) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 512, 16>), grid, dim3(512), shm, st, a);        \
     else if (a.th == 4) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 256, 32, 4>), grid, dim3(256), shm, st, a); \
+    else if (big && g_mfma_occ && C <= 8) hipLaunchKernelGGL((conv3_mfma_kernel<F, (C <= 8 ? C : 4), 256, 32, 8, 4>), grid, dim3(256), shm, st, a); \
     else if (big) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 256, 32>), grid, dim3(256), shm, st, a);          \
     else hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 512, 32>), grid, dim3(512), shm, st, a);                   \
   } while (0)

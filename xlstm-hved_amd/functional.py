@@ -25,6 +25,12 @@ def _dhw(t):
     return t.shape[2] * t.shape[3] * t.shape[4]
 
 
+def _direct(*rets):
+    """True when every gradient target of a wgrad call is an existing .grad buffer (nothing is returned to autograd), so
+    the launch may run on the weight-gradient side stream (ops.set_wgrad_overlap)."""
+    return all(r is None for r in rets)
+
+
 DIRECT_GRADS = [True]
 
 
@@ -101,7 +107,7 @@ class InLreluConv(Function):
         dy = _blk(dy)
         dws, rws = _targets(ctx.params[0])
         dbs, rbs = _targets(ctx.params[1])
-        ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=groups, pre=(sc, sh, LEAK))
+        ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=groups, pre=(sc, sh, LEAK), side=_direct(*rws, *rbs))
         dxa = dxb = None
         if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
             n = xa.shape[0]
@@ -150,7 +156,7 @@ class GnConvRelu(Function):
         n, c = x.shape[:2]
         dyr = ops.act_bwd(_blk(dy), y, ACT_RELU)
         (dw, dgamma, dbeta), (rw, rgamma, rbeta) = _targets(ctx.params)
-        ops.conv3d_wgrad(x, None, dyr, [dw], None, k=k, stride=stride, pre=(sc, sh, 1.0))
+        ops.conv3d_wgrad(x, None, dyr, [dw], None, k=k, stride=stride, pre=(sc, sh, 1.0), side=_direct(rw))
         red = ops.zeros_red(x, n, c)
         e = (x, None, sc, sh, 1.0)
         if stride == 1:
@@ -187,7 +193,7 @@ class ConvInLrelu(Function):
         red = ops.act_bwd_reduce(dy, y0, sc, sh, LEAK)
         dy0 = ops.in_bwd_apply(dy, y0, red, mean, rstd, have_g=False, sc=sc, sh=sh, slope=LEAK)
         (dw,), (rw,) = _targets(ctx.params)
-        ops.conv3d_wgrad(x, None, dy0, [dw], None, k=k, groups=groups)
+        ops.conv3d_wgrad(x, None, dy0, [dw], None, k=k, groups=groups, side=_direct(rw))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy0, None, [weight], None, k=k, cout=x.shape[1], groups=groups, transposed=True)
@@ -226,7 +232,7 @@ class Conv(Function):
             dy = ops.act_bwd(dy, y, act)
         dws, rws = _targets(ctx.params[0])
         dbs, rbs = _targets(ctx.params[1]) if has_bias else (None, [])
-        ops.conv3d_wgrad(x, None, dy, dws, dbs, k=k, groups=groups)
+        ops.conv3d_wgrad(x, None, dy, dws, dbs, k=k, groups=groups, side=_direct(*rws, *rbs))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True)
@@ -391,24 +397,25 @@ class SkipReturnAttention(Function):
         n, c = x.shape[:2]
         cnt = _dhw(x)
         (ddw1, dpw1w, dpw1b, dg1, db1, ddw2, dpw2w, dpw2b, dg2, db2), rets = _targets(ctx.params)
+        sd = _direct(*rets)
         dtg, dx_res, dsaw = ops.skr_tail_bwd(t2, x, sc2, sh2, w2, a, _blk(da))
         # BatchNorm 2
         red = ops.act_bwd_reduce(dtg, t2, sc2, sh2, 1.0)
         coef = ops.norm_bwd_coef(mode, red, cnt, m2, r2, gamma=g2, dgamma=dg2, dbeta=db2)
         dt2 = ops.norm_bwd_apply(dtg, t2, coef, have_g=True)
         # pointwise 2
-        ops.conv3d_wgrad(u2, None, dt2, [dpw2w], [dpw2b], k=1)
+        ops.conv3d_wgrad(u2, None, dt2, [dpw2w], [dpw2b], k=1, side=sd)
         du2 = ops.conv3d(dt2, None, [pw2w], None, k=1, cout=c, transposed=True)
         # depthwise 2 (input = relu(bn1(t1)))
-        ops.conv3d_wgrad(t1, None, du2, [ddw2], None, k=3, groups=c, pre=(sc1, sh1, 0.0))
+        ops.conv3d_wgrad(t1, None, du2, [ddw2], None, k=3, groups=c, pre=(sc1, sh1, 0.0), side=sd)
         red = ops.zeros_red(x, n, c)
         gt1 = ops.conv3d(du2, None, [dw2], None, k=3, cout=c, groups=c, transposed=True, epi=1, e=(t1, None, sc1, sh1, 0.0), red=red)
         coef = ops.norm_bwd_coef(mode, red, cnt, m1, r1, gamma=g1, dgamma=dg1, dbeta=db1)
         dt1 = ops.norm_bwd_apply(gt1, t1, coef, have_g=True)
         # pointwise 1, depthwise 1
-        ops.conv3d_wgrad(u1, None, dt1, [dpw1w], [dpw1b], k=1)
+        ops.conv3d_wgrad(u1, None, dt1, [dpw1w], [dpw1b], k=1, side=sd)
         du1 = ops.conv3d(dt1, None, [pw1w], None, k=1, cout=c, transposed=True)
-        ops.conv3d_wgrad(x, None, du1, [ddw1], None, k=3, groups=c)
+        ops.conv3d_wgrad(x, None, du1, [ddw1], None, k=3, groups=c, side=sd)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(du1, None, [dw1], None, k=3, cout=c, groups=c, transposed=True)

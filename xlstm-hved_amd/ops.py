@@ -246,8 +246,64 @@ def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None)
     return out
 
 
-def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None):
-    """Accumulates into the fp32 tensors dws (and dbs, may be None) the weight/bias gradients."""
+# Weight gradients are off the critical path of backward: nothing downstream in the step reads them until the optimizer /
+# the gradient all-reduce.  With overlap enabled they are launched on a second HIP stream that forks from the compute
+# stream at the call (everything issued so far -- dY, the saved input, the zeroed gradient bucket -- is ordered before
+# it) and is joined once, by join_wgrad_stream(), before the gradients are consumed.  The small-volume weight gradients
+# are latency-bound (a few dozen workgroups): next to the data-gradient chain they cost almost nothing.  Inside a hipGraph
+# capture the fork/join becomes a parallel branch of the graph.  Only calls whose targets are existing .grad buffers
+# (functional._targets "direct" accumulation, e.g. parallel.FlatGrads) may overlap: a freshly allocated gradient that
+# autograd consumes on the compute stream must be complete when backward() returns it.
+_WG = {"on": False, "streams": {}, "keep": [], "forked": set(), "pending": [], "batch": 12}
+
+
+def set_wgrad_overlap(enabled, batch=None):
+    """Enable / disable launching weight-gradient kernels on a side stream (default off).  The caller must then call
+    join_wgrad_stream() after backward() and before reading gradients (parallel.FlatGrads.all_reduce / .zero do).
+    `batch`: weight-gradient calls are collected and forked to the side stream `batch` at a time (one cross-stream
+    dependency per batch instead of one per call; a fork costs a few microseconds of its own)."""
+    if not enabled:
+        join_wgrad_stream()
+    _WG["on"] = bool(enabled)
+    if batch is not None:
+        _WG["batch"] = max(1, int(batch))
+
+
+def _flush_wgrads():
+    pend = _WG["pending"]
+    if not pend:
+        return
+    dev = pend[0][0].device
+    st = _WG["streams"].get(dev)
+    if st is None:
+        st = _WG["streams"][dev] = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))          # every dY / input of the batch has been issued by now
+    _WG["forked"].add(dev)
+    with torch.cuda.stream(st):
+        for xa, xb, dy, dws, dbs, kw in pend:
+            conv3d_wgrad(xa, xb, dy, dws, dbs, side=False, **kw)
+    _WG["keep"].extend(pend)                                 # alive until the join: the allocator must not recycle them
+    _WG["pending"] = []
+
+
+def join_wgrad_stream():
+    """Launches what is still pending and orders the compute stream behind every weight-gradient launch issued on the
+    side stream since the last join."""
+    _flush_wgrads()
+    for dev in list(_WG["forked"]):
+        torch.cuda.current_stream(dev).wait_stream(_WG["streams"][dev])
+    _WG["forked"].clear()
+    _WG["keep"].clear()
+
+
+def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=False):
+    """Accumulates into the fp32 tensors dws (and dbs, may be None) the weight/bias gradients.  side=True: the targets are
+    long-lived gradient buffers, so the launch may go to the weight-gradient stream when overlap is enabled."""
+    if side and _WG["on"] and xa.is_cuda:
+        _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre)))
+        if len(_WG["pending"]) >= _WG["batch"]:
+            _flush_wgrads()
+        return
     lib = L.load()
     n, cout, do, ho, wo, dy_bs = _vol(dy)
     _check_weights(dws, dbs, xa.shape[1] + (xb.shape[1] if xb is not None else 0), cout, groups, k, False, "conv3d_wgrad")
@@ -264,6 +320,8 @@ def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None):
     if need > 0:
         ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
         ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
+        if _WG["forked"]:
+            _WG["keep"].append(ws)
     L.check(lib.xh_conv3d_wgrad(_stream(), C.byref(desc), C.byref(ptrs), C.byref(dw), C.byref(db)), "xh_conv3d_wgrad")
 
 

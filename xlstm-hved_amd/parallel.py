@@ -79,6 +79,8 @@ class FlatGrads:
 
     def zero(self):
         """Use this instead of optimizer.zero_grad(): one fill, and the views stay attached (re-attached if lost)."""
+        from . import ops
+        ops.join_wgrad_stream()
         if not self.check():
             for p in self.params:                      # drop foreign gradients: zero() means zero
                 p.grad = None
@@ -90,6 +92,8 @@ class FlatGrads:
         gathered into it first -- reducing a stale bucket would silently stop synchronising the ranks."""
         if not self.check():
             self.attach()
+        from . import ops
+        ops.join_wgrad_stream()            # weight-gradient kernels on the side stream (ops.set_wgrad_overlap) finish first
         world = world_size if world_size is not None else dist.get_world_size(group)
         dist.all_reduce(self.flat, group=group)
         self.flat.div_(world)
