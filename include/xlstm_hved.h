@@ -37,7 +37,8 @@ int xh_abi_version(void);
 /* key 0: use the bf16-MFMA implicit-GEMM conv kernels where eligible (default 1); for A/B tests.
  * key 1: MFMA kernel ablation mask (microbenchmarks only).
  * key 2: disable mask for specialised kernels: bit 0 sliding-window depthwise conv (+wgrad), bit 1 exact-2x trilinear
- *        kernels, bit 2 vectorised stride-2 conv forward / data gradient.
+ *        kernels, bit 2 vectorised stride-2 conv forward / data gradient, bit 3 chunk-recurrent mLSTM (falls back to the
+ *        tiled O(S^2) contraction; A/B tests).
  * key 3: target workgroup count of the k3 MFMA forward kernel (default 512 = 2 per CU; microbenchmarks: 1024-4096 were 7-25 % slower).
  * key 4: 1 = <=128-VGPR instances of the k3 MFMA forward kernel for <= 8 input channels (microbenchmarks: spills, 2x slower). */
 int xh_set_option(int key, int value);

@@ -26,7 +26,12 @@ struct VilWs {
   int* arg;
   // backward scratch
   float *dh, *dz, *dxa, *dap, *dbp, *dm, *dq, *dk, *dv, *di, *df, *dxc, *dxm, *rq, *ck, *dscat;
+  // chunk-recurrent mLSTM: per (batch, head, chunk of 64 tokens) the carried matrix memory C (16x16) + normaliser n (16)
+  // in front of the chunk, and the mirror-image state R, r of the backward (contributions of all LATER chunks)
+  float *cst, *rst;
 };
+constexpr int CL = 64;                  // chunk length = one wavefront of tokens
+constexpr int STF = 16 * 16 + 16;       // floats per chunk state
 static long long ws_layout(VilWs* w, float* base, int B, int S, int C) {
   const long long I = 2 * C, BS = (long long)B * S;
   long long o = 0;
@@ -44,6 +49,8 @@ static long long ws_layout(VilWs* w, float* base, int B, int S, int C) {
   t.di = take(BS * NH); t.df = take(BS * NH);
   t.dxc = take(BS * I); t.dxm = take(BS * I);
   t.rq = take(BS * NH); t.ck = take(BS * NH); t.dscat = take(BS * NH);
+  const long long nst = (long long)B * NH * ((S + CL - 1) / CL) * STF;
+  t.cst = take(nst); t.rst = take(nst);
   if (w) *w = t;
   return o;
 }
@@ -379,6 +386,268 @@ __global__ __launch_bounds__(256) void vil_post_kernel(const T* xa, T* out, int 
     if (s2 < S) {
       const long long o = ((long long)b * C + c) * S + s2;
       stf(out, o, (add_xa ? ldf(xa, o) : 0.f) + s_o[tk2 * (C + 1) + c]);
+    }
+  }
+}
+
+// =================================================================================================
+// Chunk-recurrent mLSTM on the matrix cores (head dimension 16).
+//
+// Tokens are cut into chunks of CL = 64 (one wavefront).  With w_s = exp(g_s - M) for a reference M >= every g_s involved
+// (all exponents <= 0, like the tiled form above), everything a query t of chunk c needs from EARLIER chunks is the
+// 16x16 matrix memory  C_c = sum_{s < cL} w_s k_s v_s^T  and the normaliser  n_c = sum w_s k_s,  referenced to
+// M_c = G_{cL-1}:
+//     a_t = isq [ sum_{s in chunk, s<=t} (q_t.k_s) e^{g_s-G_t} v_s  +  e^{M_c-G_t} C_c^T q_t ],   b_t likewise with n_c
+// (vision_lstm.py:99-128 evaluates the same sums as one S x S matrix; the recurrent form of oracle.mlstm_recurrent carries
+// exactly this C, n).  Three launches: (1) every chunk's own contribution dC_c in parallel, (2) a 272-lane scan over the
+// chunks of one (batch, head) that turns them into the carried states, (3) every chunk's intra-chunk 64x64 block + the
+// carried state in parallel.  All contractions -- Q K^T, P V, K^T (w V), Q C -- are v_mfma_f32_16x16x4_f32: exact fp32
+// like the reference's fp32-forced ViL (UxLSTMEnc_3d.py:77-80), at the vector rate but off the VALU.  O(S * 64 * DH)
+// instead of O(S^2 * DH): S = 4096 costs what S = 64 x 64 costs, and S = 32 768 (DoubleConv_ViL at 128^3) is 8x that.
+// The backward mirrors it with the reverse state R_c = sum_{t >= (c+1)L} e^{Mr_c - G_t} q_t da'_t^T (+ r_c with db'_t),
+// Mr_c = G_{(c+1)L}, and recomputes the 64x64 blocks per chunk.
+// =================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// MFMA 16x16x4 f32 lane roles: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; D[i = 4*(lane>>4) + r][j = lane&15]
+
+// (1) local states.  REV = 0: dC_c[k][j] = sum_{s in c} e^{g_s - G_end(c)} k_s[k] v_s[j], dn_c[k] likewise (forward).
+//                    REV = 1: dR_c[a][b] = sum_{t in c} e^{G_first(c) - G_t} q_t[a] da'_t[b], dr_c[a] = sum ... db'_t q_t[a].
+template <int REV>
+__global__ __launch_bounds__(64) void mlstm_chunk_dstate_kernel(int S, int nchunk, VilWs w) {
+  const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  const long long hb = ((long long)b * NH + h) * S;
+  const int s_base = c * CL, s_end = min(S, s_base + CL);
+  const float ref = REV ? w.G[hb + s_base] : w.G[hb + s_end - 1];
+  const int kj = lane & 15, sg = lane >> 4;
+  const float* ap = REV ? w.q : w.k;
+  const float* bp = REV ? w.dap : w.v;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float nacc = 0.f;
+#pragma unroll 4
+  for (int s0 = 0; s0 < CL; s0 += 4) {
+    const int s = s_base + s0 + sg;
+    float a = 0.f, bv = 0.f, nw = 1.f;
+    if (s < S) {
+      const float wt = REV ? expf(ref - w.G[hb + s]) : expf(w.ig[hb + s] - w.F[hb + s] - ref);
+      a = wt * ap[(hb + s) * 16 + kj];
+      bv = bp[(hb + s) * 16 + kj];
+      if (REV) nw = w.dbp[hb + s];
+    }
+    acc = MFMA4(a, bv, acc);
+    nacc = fmaf(a, nw, nacc);
+  }
+  float* st = (REV ? w.rst : w.cst) + ((((long long)b * NH + h) * nchunk) + c) * STF;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) st[(sg * 4 + r) * 16 + kj] = acc[r];
+  nacc += __shfl_xor(nacc, 16, 64);
+  nacc += __shfl_xor(nacc, 32, 64);
+  if (lane < 16) st[256 + lane] = nacc;
+}
+
+// (2) exclusive scan of the local states over the chunks of one (batch, head), in place; one lane per state element.
+//     forward: st[c] <- state carried INTO chunk c (reference M_c = G_{cL-1});  reverse: st[c] <- state of all chunks AFTER
+//     c (reference Mr_c = G_{(c+1)L}).
+template <int REV>
+__global__ __launch_bounds__(320) void mlstm_chunk_scan_kernel(int S, int nchunk, VilWs w) {
+  const int e = threadIdx.x;
+  if (e >= STF) return;
+  const long long hb = (long long)blockIdx.x * S;
+  float* st = (REV ? w.rst : w.cst) + (long long)blockIdx.x * nchunk * STF;
+  float run = 0.f;
+  if (!REV) {
+    for (int c = 0; c < nchunk; ++c) {
+      const float d = st[(long long)c * STF + e];
+      st[(long long)c * STF + e] = run;
+      const float dec = c > 0 ? expf(w.G[hb + c * CL - 1] - w.G[hb + min(S, (c + 1) * CL) - 1]) : 0.f;
+      run = fmaf(run, dec, d);
+    }
+  } else {
+    for (int c = nchunk - 1; c >= 0; --c) {
+      const float d = st[(long long)c * STF + e];
+      st[(long long)c * STF + e] = run;
+      const float dec = c < nchunk - 1 ? expf(w.G[hb + c * CL] - w.G[hb + (c + 1) * CL]) : 0.f;
+      run = fmaf(run, dec, d);
+    }
+  }
+}
+
+constexpr int CLD = 17;      // LDS row stride of the 64 x 16 token tiles (conflict-free A/B operand reads)
+constexpr int CPD = 66;      // LDS row stride of the 64 x 64 score tiles
+
+__device__ __forceinline__ void chunk_load_rows(float* dst, const float* src, long long row0, int rows_valid, int tid) {
+  // 64 rows x 16 floats, 256 threads: one float4 each
+  const int r = tid >> 2, c4 = (tid & 3) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < rows_valid) v = *reinterpret_cast<const float4*>(src + (row0 + r) * 16 + c4);
+  dst[r * CLD + c4] = v.x; dst[r * CLD + c4 + 1] = v.y; dst[r * CLD + c4 + 2] = v.z; dst[r * CLD + c4 + 3] = v.w;
+}
+
+// (3) forward: one workgroup (4 waves) per chunk; wave wv owns query rows 16*wv .. +15.
+__global__ __launch_bounds__(256) void mlstm_chunk_fwd_kernel(int S, int nchunk, VilWs w) {
+  __shared__ float s_q[CL * CLD], s_k[CL * CLD], s_v[CL * CLD], s_P[CL * CPD];
+  __shared__ float s_g[CL], s_G[CL], s_F[CL], s_C[STF];
+  const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kj = lane & 15, sg = lane >> 4;
+  const long long hb = ((long long)b * NH + h) * S;
+  const int s_base = c * CL, nv = min(CL, S - s_base);
+  chunk_load_rows(s_q, w.q, hb + s_base, nv, tid);
+  chunk_load_rows(s_k, w.k, hb + s_base, nv, tid);
+  chunk_load_rows(s_v, w.v, hb + s_base, nv, tid);
+  if (tid < CL) {
+    const bool ok = tid < nv;
+    const float Fv = ok ? w.F[hb + s_base + tid] : 0.f;
+    s_F[tid] = Fv;
+    s_g[tid] = ok ? w.ig[hb + s_base + tid] - Fv : -INFINITY;
+    s_G[tid] = ok ? w.G[hb + s_base + tid] : 0.f;
+  }
+  const float* cst = w.cst + ((((long long)b * NH + h) * nchunk) + c) * STF;
+  for (int i = tid; i < STF; i += 256) s_C[i] = cst[i];
+  __syncthreads();
+  const float isq = 0.25f;                        // 1 / sqrt(16)
+  float Gt[4], den[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Gt[r] = s_G[16 * wv + sg * 4 + r];
+  for (int kb = 0; kb <= wv; ++kb) {              // causal: key blocks up to the wave's own
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4)
+      acc = MFMA4(s_q[(16 * wv + kj) * CLD + k0 + sg], s_k[(16 * kb + kj) * CLD + k0 + sg], acc);
+    const int sl = 16 * kb + kj;
+    const float gs = s_g[sl];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tl = 16 * wv + sg * 4 + r;
+      const float pv = (sl <= tl && tl < nv) ? isq * acc[r] * expf(gs - Gt[r]) : 0.f;
+      den[r] += pv;
+      s_P[tl * CPD + sl] = pv;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) den[r] += __shfl_xor(den[r], o, 64);
+  f32x4 accA = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < 16 * (wv + 1); s0 += 4)    // P rows of this wave x V
+    accA = MFMA4(s_P[(16 * wv + kj) * CPD + s0 + sg], s_v[(s0 + sg) * CLD + kj], accA);
+  f32x4 accI = {0.f, 0.f, 0.f, 0.f}, accN = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k0 = 0; k0 < 16; k0 += 4) {
+    const float a = s_q[(16 * wv + kj) * CLD + k0 + sg];
+    accI = MFMA4(a, s_C[(k0 + sg) * 16 + kj], accI);          // (C^T q_t)[j]
+    accN = MFMA4(a, s_C[256 + k0 + sg], accN);                // q_t . n   (every column)
+  }
+  const float Mc = c > 0 ? w.G[hb + s_base - 1] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int tl = 16 * wv + sg * 4 + r;
+    if (tl >= nv) continue;
+    const float sc = c > 0 ? isq * expf(Mc - Gt[r]) : 0.f;
+    const float num = fmaf(sc, accI[r], accA[r]);
+    const float bd = fmaf(sc, accN[r], den[r]);
+    const float m = s_F[tl] + Gt[r];
+    const float nrm = fmaxf(fabsf(bd), expf(-m)) + MLSTM_EPS;
+    w.h[(hb + s_base + tl) * 16 + kj] = num / nrm;
+    if (kj == 0) w.bden[hb + s_base + tl] = bd;
+  }
+}
+
+// (3') backward: dq, dk, dv of one chunk.  Phase (i): wave wv computes the masked, weighted 16-row strips
+// EW[t][s] = (da'_t.v_s + db'_t) isq e^{g_s-G_t} and SW[t][s] = (q_t.k_s) isq e^{g_s-G_t} of its query rows and dq of
+// those rows; phase (ii) (after a barrier): the same wave, now owning KEY rows 16*wv.., reads the strips column-wise for
+// dk_s = sum_t EW[t][s] q_t, dv_s = sum_t SW[t][s] da'_t, and adds the later chunks' contribution through R, r.
+__global__ __launch_bounds__(256) void mlstm_chunk_bwd_kernel(int S, int nchunk, VilWs w) {
+  __shared__ float s_q[CL * CLD], s_k[CL * CLD], s_v[CL * CLD], s_da[CL * CLD], s_EW[CL * CPD], s_SW[CL * CPD];
+  __shared__ float s_g[CL], s_G[CL], s_db[CL], s_C[STF], s_R[STF];
+  const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kj = lane & 15, sg = lane >> 4;
+  const long long hb = ((long long)b * NH + h) * S;
+  const int s_base = c * CL, nv = min(CL, S - s_base);
+  chunk_load_rows(s_q, w.q, hb + s_base, nv, tid);
+  chunk_load_rows(s_k, w.k, hb + s_base, nv, tid);
+  chunk_load_rows(s_v, w.v, hb + s_base, nv, tid);
+  chunk_load_rows(s_da, w.dap, hb + s_base, nv, tid);
+  if (tid < CL) {
+    const bool ok = tid < nv;
+    s_g[tid] = ok ? w.ig[hb + s_base + tid] - w.F[hb + s_base + tid] : -INFINITY;
+    s_G[tid] = ok ? w.G[hb + s_base + tid] : 0.f;
+    s_db[tid] = ok ? w.dbp[hb + s_base + tid] : 0.f;
+  }
+  const long long so = ((((long long)b * NH + h) * nchunk) + c) * STF;
+  for (int i = tid; i < STF; i += 256) { s_C[i] = w.cst[so + i]; s_R[i] = w.rst[so + i]; }
+  __syncthreads();
+  const float isq = 0.25f;
+  float Gt[4], dbt[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { Gt[r] = s_G[16 * wv + sg * 4 + r]; dbt[r] = s_db[16 * wv + sg * 4 + r]; }
+  // ---- phase (i): strips of the wave's query rows, dq ----
+  for (int kb = 0; kb < 4; ++kb) {
+    if (kb > wv) {                                   // above the diagonal: zeros (phase (ii) reads whole columns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s_EW[(16 * wv + sg * 4 + r) * CPD + 16 * kb + kj] = 0.f;
+        s_SW[(16 * wv + sg * 4 + r) * CPD + 16 * kb + kj] = 0.f;
+      }
+      continue;
+    }
+    f32x4 aS = {0.f, 0.f, 0.f, 0.f}, aE = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) {
+      aS = MFMA4(s_q[(16 * wv + kj) * CLD + k0 + sg], s_k[(16 * kb + kj) * CLD + k0 + sg], aS);
+      aE = MFMA4(s_da[(16 * wv + kj) * CLD + k0 + sg], s_v[(16 * kb + kj) * CLD + k0 + sg], aE);
+    }
+    const int sl = 16 * kb + kj;
+    const float gs = s_g[sl];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tl = 16 * wv + sg * 4 + r;
+      const float wg = (sl <= tl && tl < nv) ? isq * expf(gs - Gt[r]) : 0.f;      // padded query rows: exactly zero
+      s_EW[tl * CPD + sl] = (aE[r] + dbt[r]) * wg;
+      s_SW[tl * CPD + sl] = aS[r] * wg;
+    }
+  }
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accX = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < 16 * (wv + 1); s0 += 4)
+      acc = MFMA4(s_EW[(16 * wv + kj) * CPD + s0 + sg], s_k[(s0 + sg) * CLD + kj], acc);
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4)              // (C da'_t)[j] = sum_k C[j][k] da'_t[k]
+      accX = MFMA4(s_da[(16 * wv + kj) * CLD + k0 + sg], s_C[kj * 16 + k0 + sg], accX);
+    const float Mc = c > 0 ? w.G[hb + s_base - 1] : 0.f;
+    const float nj = s_C[256 + kj];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tl = 16 * wv + sg * 4 + r;
+      if (tl >= nv) continue;
+      const float sc = c > 0 ? isq * expf(Mc - Gt[r]) : 0.f;
+      w.dq[(hb + s_base + tl) * 16 + kj] = fmaf(sc, fmaf(dbt[r], nj, accX[r]), acc[r]);
+    }
+  }
+  __syncthreads();
+  // ---- phase (ii): the wave's key rows ----
+  {
+    f32x4 aK = {0.f, 0.f, 0.f, 0.f}, aV = {0.f, 0.f, 0.f, 0.f}, xK = {0.f, 0.f, 0.f, 0.f}, xV = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 16 * wv; t0 < CL; t0 += 4) {
+      aK = MFMA4(s_EW[(t0 + sg) * CPD + 16 * wv + kj], s_q[(t0 + sg) * CLD + kj], aK);
+      aV = MFMA4(s_SW[(t0 + sg) * CPD + 16 * wv + kj], s_da[(t0 + sg) * CLD + kj], aV);
+    }
+    const bool later = c < nchunk - 1;
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) {
+      xK = MFMA4(s_v[(16 * wv + kj) * CLD + k0 + sg], s_R[kj * 16 + k0 + sg], xK);     // (R v_s)[j]
+      xV = MFMA4(s_k[(16 * wv + kj) * CLD + k0 + sg], s_R[(k0 + sg) * 16 + kj], xV);   // (R^T k_s)[j]
+    }
+    const float Mr = later ? w.G[hb + s_base + CL] : 0.f;
+    const float rj = s_R[256 + kj];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int sl = 16 * wv + sg * 4 + r;
+      if (sl >= nv) continue;
+      const float sc = later ? isq * expf(s_g[sl] - Mr) : 0.f;
+      w.dk[(hb + s_base + sl) * 16 + kj] = fmaf(sc, xK[r] + rj, aK[r]);
+      w.dv[(hb + s_base + sl) * 16 + kj] = fmaf(sc, xV[r], aV[r]);
     }
   }
 }
@@ -832,10 +1101,17 @@ static int vil_fwd_impl(hipStream_t st, const T* xa, const T* xb, T* out, int B,
   hipLaunchKernelGGL((vil_pre2_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, w);
   hipLaunchKernelGGL(vil_scan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
   const long long rows_f = (long long)B * NH * S;
-  (void)hipMemsetAsync(w.h, 0, (size_t)rows_f * DH * sizeof(float), st);
-  (void)hipMemsetAsync(w.bden, 0, (size_t)rows_f * sizeof(float), st);
-  hipLaunchKernelGGL((mlstm_fwd_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
-  hipLaunchKernelGGL((mlstm_norm_kernel<DH>), dim3((unsigned)((rows_f + 255) / 256)), dim3(256), 0, st, rows_f, w);
+  if (DH == 16 && !(g_xh_disable & 8)) {              // chunk-recurrent form on the matrix cores
+    const int nchunk = cdiv(S, CL);
+    hipLaunchKernelGGL(mlstm_chunk_dstate_kernel<0>, dim3(nchunk, NH, B), dim3(64), 0, st, S, nchunk, w);
+    hipLaunchKernelGGL(mlstm_chunk_scan_kernel<0>, dim3(B * NH), dim3(320), 0, st, S, nchunk, w);
+    hipLaunchKernelGGL(mlstm_chunk_fwd_kernel, dim3(nchunk, NH, B), dim3(256), 0, st, S, nchunk, w);
+  } else {
+    (void)hipMemsetAsync(w.h, 0, (size_t)rows_f * DH * sizeof(float), st);
+    (void)hipMemsetAsync(w.bden, 0, (size_t)rows_f * sizeof(float), st);
+    hipLaunchKernelGGL((mlstm_fwd_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
+    hipLaunchKernelGGL((mlstm_norm_kernel<DH>), dim3((unsigned)((rows_f + 255) / 256)), dim3(256), 0, st, rows_f, w);
+  }
   hipLaunchKernelGGL((vil_post_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, out, S, add_xa, *p, w);
   return xh_launch_status();
 }
@@ -849,8 +1125,16 @@ static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, co
   hipLaunchKernelGGL((vil_post_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, S, *p, *g, w);
   hipLaunchKernelGGL((mlstm_bwd_prep_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
   hipLaunchKernelGGL(mlstm_bwd_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
-  hipLaunchKernelGGL((mlstm_bwd_q_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
-  hipLaunchKernelGGL((mlstm_bwd_kv_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
+  if (DH == 16 && !(g_xh_disable & 8)) {
+    // the forward's carried states C, n are still in the workspace; the reverse states are built here
+    const int nchunk = cdiv(S, CL);
+    hipLaunchKernelGGL(mlstm_chunk_dstate_kernel<1>, dim3(nchunk, NH, B), dim3(64), 0, st, S, nchunk, w);
+    hipLaunchKernelGGL(mlstm_chunk_scan_kernel<1>, dim3(B * NH), dim3(320), 0, st, S, nchunk, w);
+    hipLaunchKernelGGL(mlstm_chunk_bwd_kernel, dim3(nchunk, NH, B), dim3(256), 0, st, S, nchunk, w);
+  } else {
+    hipLaunchKernelGGL((mlstm_bwd_q_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
+    hipLaunchKernelGGL((mlstm_bwd_kv_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
+  }
   hipLaunchKernelGGL((mlstm_bwd_dots_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, w);
   hipLaunchKernelGGL(vil_rscan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
   hipLaunchKernelGGL((vil_pre2_bwd_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, *g, w);
