@@ -298,6 +298,38 @@ int xh_compose_duse_fwd(void* stream, const float* const params[10], int C, floa
 int xh_compose_duse_bwd(void* stream, const float* const params[10], int C, const float* dsqw, const float* dsqb,
                         const float* dadjw, const float* dadjb, float* const grads[10]);
 
+/* ------------------------------------------------------------------------------------------------
+ * Loss / metric epilogues of the training step (train.py:232-262,288-296): one pass per tensor pair.
+ * ------------------------------------------------------------------------------------------------ */
+/* red[n][c][0..5] += (sum a'b, sum a'^2, sum b^2, sum (a'-b)^2, sum a', sum b) over DHW, a' = a or (a > thr ? 1 : 0) when
+ * thr_on.  b may be fp32 (b_dtype = XH_F32) while a is in a 16-bit storage type, or NULL (= the constant bval).
+ * Serves DiceLoss (loss.py:257-285: slots 0,1,2), nn.MSELoss / GANLoss (train.py:173, loss.py:167-186: slot 3) and the
+ * thresholded DiceCoefficient / DiceRegion metrics (metrics.py:27-107: slots 0,4,5).  red: fp64 [N][C][6], caller zeroes. */
+int xh_pair_sums(void* stream, int dtype, const void* a, long long a_bs, int b_dtype, const void* b, long long b_bs, float bval,
+                 int N, int C, long long DHW, int thr_on, float thr, double* red);
+/* out[n,c,:] (+)= ca[n,c]*a + cb[n,c]*b + cc[n,c]: the backward of the losses above (their gradient w.r.t. a is linear in
+ * a and b with per-(n,c) coefficients).  out has a's dtype; cc may be NULL. */
+int xh_lincomb(void* stream, int dtype, const void* a, long long a_bs, int b_dtype, const void* b, long long b_bs, float bval,
+               void* out, long long o_bs, int N, int C, long long DHW, const float* ca, const float* cb, const float* cc,
+               const float* gscale, int accumulate);
+/* Sums of xh_pair_sums -> scalar loss / per-channel metric + the per-(n,c) coefficients of xh_lincomb, on the device:
+ * kind 0 DiceLoss, 1 mean squared difference (count = number of elements), 2 thresholded Dice metric (out[C]).
+ * gscale (xh_lincomb, xh_kld_bwd): optional device scalar multiplying the result (the upstream gradient). */
+int xh_loss_finalize(void* stream, int kind, const double* red, int N, int C, double count, double eps, float* out, float* ca,
+                     float* cb);
+/* compute_KLD (loss.py:29-40,85-115) for ONE modality subset on the (N,5,L,dhw) stacks xh_poe_fwd returns: product of
+ * the kept experts and the prior, then KL(posterior || prior) summed over all latent voxels: red[0] += sum
+ * (0.5 * mean is applied by the caller).  keep as in xh_poe_fwd.  bwd: d(scale * sum)/d(mu_stack, lv_stack). */
+int xh_kld_fwd(void* stream, int dtype, const void* mu_stack, const void* lv_stack, const float* keep, int N, int L, long long dhw,
+               double* red);
+int xh_kld_bwd(void* stream, int dtype, const void* mu_stack, const void* lv_stack, const float* keep, int N, int L, long long dhw,
+               float scale, const float* gscale, void* dmu_stack, void* dlv_stack);
+/* Nested tumour-region weight map (train.py:244-248,252-256): from the 3 sigmoid channels (WT, TC, ET) of seg,
+ * w = p0 > .5 ? p0 : 0, overridden by p1 where p1 > .5, then by p2 where p2 > .5.  w has 1 channel. */
+int xh_nested_weight(void* stream, int dtype, const void* seg, long long seg_bs, void* w, long long w_bs, int N, long long DHW);
+/* out[0..n) = v in the storage type (constant upstream gradients of mean-type losses). */
+int xh_fill(void* stream, int dtype, void* out, long long n, float v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -426,6 +426,52 @@ def dice_region(prob, target, eps=1e-6):
     return ((2 * inter + eps) / (den + eps)).mean(0)
 
 
+# ----------------------------------------------------------------------------------------------
+# loss / metric restatements (training-step epilogues)
+# ----------------------------------------------------------------------------------------------
+def dice_loss(prob, target, eps=1e-6):
+    """loss.py:188-209 DiceLoss + compute_per_channel_dice (loss.py:257-285): channel-first flatten over batch and space,
+    2 sum(p t) / clamp(sum p^2 + sum t^2, eps), loss = 1 - mean over channels."""
+    C = prob.shape[1]
+    p = prob.transpose(0, 1).reshape(C, -1)
+    t = target.to(prob.dtype).transpose(0, 1).reshape(C, -1)
+    inter = (p * t).sum(-1)
+    den = (p * p).sum(-1) + (t * t).sum(-1)
+    return 1.0 - (2 * (inter / den.clamp(min=eps))).mean()
+
+
+def kl_divergence(mu1, lv1, mu2, lv2, eps=1e-8):
+    """loss.py:29-40 with an explicit second distribution."""
+    return 0.5 * torch.mean(-1 + lv2 - lv1 + (lv1.exp() + (mu1 - mu2) ** 2) / (lv2.exp() + eps))
+
+
+def compute_kld(mu_stack, lv_stack, subset_index_list):
+    """loss.py:85-115: stacks (B,5,L,...) -> transpose to (5,B,...); PoE over prior + subset; KL against the prior."""
+    mu, lv = mu_stack.transpose(0, 1), lv_stack.transpose(0, 1)
+    tot = 0.0
+    for idx in subset_index_list:
+        sm, sl = product_of_experts(mu, lv, SUBSETS_MODALITIES[idx])
+        tot = tot + kl_divergence(sm, sl, mu[0], lv[0])
+    return tot / len(subset_index_list)
+
+
+def nested_weight(seg):
+    """train.py:244-248: where(p > .5, p, 0); channel 0 overridden by channel 1, then channel 2, where those exceed .5."""
+    w = torch.where(seg > 0.5, seg, torch.zeros_like(seg))
+    out = w[:, 0].clone()
+    out[w[:, 1] > 0.5] = w[:, 1][w[:, 1] > 0.5]
+    out[w[:, 2] > 0.5] = w[:, 2][w[:, 2] > 0.5]
+    return out.unsqueeze(1)
+
+
+def dice_coefficient(prob, target, eps=1e-6):
+    """metrics.py:27-48 (the metrics.py variant thresholds at 0.5): per-channel (2 I + eps)/(sum + eps), mean over batch."""
+    pred = (prob > 0.5).to(target.dtype)
+    inter = (pred * target).sum((2, 3, 4))
+    den = (pred + target).sum((2, 3, 4))
+    return ((2 * inter + eps) / (den + eps)).mean(0)
+
+
 def bench_loss(prob, mu_list, logvar_list, rec):
     """loss that reaches every used parameter."""
     loss = prob.float().mean() + rec.float().mean()

@@ -409,9 +409,68 @@ def variant_cases():
         save("variant_" + tag, **arrs)
 
 
+def loss_cases():
+    """Training-step epilogues from the reference's own loss.py / metrics.py (train.py:171-175,232-262): inputs, values
+    and input gradients; the oracle restatements are certified against them."""
+    import contextlib
+    import io
+    import loss as RL            # reference module (on sys.path via the shim)
+    import metrics as RM
+    n, S = 2, (6, 10, 12)
+    prob = torch.sigmoid(rnd((n, 3) + S, 401) * 2).requires_grad_(True)
+    tgt = (rnd((n, 3) + S, 402) > 0.3).float()
+    rec = rnd((n, 4) + S, 403).requires_grad_(True)
+    xin = rnd((n, 4) + S, 404)
+    disc = rnd((n, 1, 3, 5, 6), 405).requires_grad_(True)
+    L_ = 2
+    mu = (rnd((n, 5, L_) + S, 406)).clone()
+    lv = (rnd((n, 5, L_) + S, 407) * 0.7).clone()
+    mu[:, 0] = 0
+    lv[:, 0] = 0
+    mu.requires_grad_(True)
+    lv.requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()):      # compute_per_channel_dice prints its shapes (loss.py:269-270)
+        dice = RL.DiceLoss()(prob, tgt)
+    mse = torch.nn.MSELoss()(rec, xin)
+    gan_t, gan_f = RL.GANLoss()(disc, True), RL.GANLoss()(disc, False)
+    kld7 = RL.compute_KLD(mu, lv, [7])
+    kld_multi = RL.compute_KLD(mu, lv, [2, 12])
+    tot = 1.3 * dice + 0.2 * mse + 0.1 * gan_t + 0.05 * gan_f + 0.2 * kld7 + 0.3 * kld_multi
+    tot.backward()
+    # nested weights exactly as train.py:244-250
+    f_weight = prob.detach()
+    f_weight = torch.where(f_weight > 0.5, f_weight, torch.zeros_like(f_weight))
+    f_nested_w = f_weight[:, 0]
+    f_nested_w[f_weight[:, 1] > 0.5] = f_weight[:, 1][f_weight[:, 1] > 0.5]
+    f_nested_w[f_weight[:, 2] > 0.5] = f_weight[:, 2][f_weight[:, 2] > 0.5]
+    atten = rec.detach() * (1 + f_nested_w.unsqueeze(1))
+    dc = RM.DiceCoefficient()(prob.detach(), tgt)
+    dcr = torch.stack([RM.DiceRegion()(prob.detach(), tgt, r) for r in ("WT", "TC", "EC")])
+    # oracle
+    po, ro, do_, muo, lvo = (t.detach().clone().requires_grad_(True) for t in (prob, rec, disc, mu, lv))
+    o_dice, o_mse = O.dice_loss(po, tgt), ((ro - xin) ** 2).mean()
+    o_gt, o_gf = ((do_ - 1.0) ** 2).mean(), (do_ ** 2).mean()
+    o_k7, o_km = O.compute_kld(muo, lvo, [7]), O.compute_kld(muo, lvo, [2, 12])
+    (1.3 * o_dice + 0.2 * o_mse + 0.1 * o_gt + 0.05 * o_gf + 0.2 * o_k7 + 0.3 * o_km).backward()
+    for tag, a, b in (("dice", o_dice, dice), ("mse", o_mse, mse), ("gan_t", o_gt, gan_t), ("gan_f", o_gf, gan_f), ("kld7", o_k7, kld7),
+                      ("kld_multi", o_km, kld_multi), ("dprob", po.grad, prob.grad), ("drec", ro.grad, rec.grad),
+                      ("ddisc", do_.grad, disc.grad), ("dmu", muo.grad, mu.grad), ("dlv", lvo.grad, lv.grad),
+                      ("nested", O.nested_weight(prob.detach()), f_nested_w.unsqueeze(1)),
+                      ("dice_coefficient", O.dice_coefficient(prob.detach(), tgt).mean(), dc),
+                      ("dice_region", O.dice_region(prob.detach(), tgt), dcr)):
+        check("loss " + tag, a, b, 2e-6)
+    save("stage_losses", prob=prob, tgt=tgt, rec=rec, xin=xin, disc=disc, mu=mu, lv=lv, dice=dice, mse=mse, gan_t=gan_t,
+         gan_f=gan_f, kld7=kld7, kld_multi=kld_multi, dprob=prob.grad, drec=rec.grad, ddisc=disc.grad, dmu=mu.grad, dlv=lv.grad,
+         nested=f_nested_w.unsqueeze(1), atten=atten, dice_coefficient=dc, dice_region=dcr)
+
+
 if __name__ == "__main__":
+    if "--losses-only" in sys.argv:
+        loss_cases()
+        sys.exit(0)
     stage_cases()
     poe_cases()
     network_cases()
     variant_cases()
+    loss_cases()
     print("all fixtures written and certified against the oracle")

@@ -223,3 +223,21 @@ def test_variant_forward_backward_fp64(tag):
         assert gr is not None, name
         assert abs(gr.sum().item() - gsum.item()) <= 1e-9 * scale, name
         assert abs(gr.abs().sum().item() - gabs.item()) <= 1e-9 * scale, name
+
+
+def test_loss_and_metric_restatements_vs_reference_fixture():
+    """DiceLoss / MSE / GANLoss / compute_KLD / nested weights / DiceCoefficient / DiceRegion (loss.py, metrics.py,
+    train.py:232-262): values and input gradients of the reference's own objects, stored by make_golden.loss_cases."""
+    g = load_np("stage_losses")
+    po, ro, do_, muo, lvo = (g[k].clone().requires_grad_(True) for k in ("prob", "rec", "disc", "mu", "lv"))
+    tgt, xin = g["tgt"], g["xin"]
+    o_dice, o_mse = O.dice_loss(po, tgt), ((ro - xin) ** 2).mean()
+    o_gt, o_gf = ((do_ - 1.0) ** 2).mean(), (do_ ** 2).mean()
+    o_k7, o_km = O.compute_kld(muo, lvo, [7]), O.compute_kld(muo, lvo, [2, 12])
+    (1.3 * o_dice + 0.2 * o_mse + 0.1 * o_gt + 0.05 * o_gf + 0.2 * o_k7 + 0.3 * o_km).backward()
+    for a, k in ((o_dice, "dice"), (o_mse, "mse"), (o_gt, "gan_t"), (o_gf, "gan_f"), (o_k7, "kld7"), (o_km, "kld_multi"),
+                 (po.grad, "dprob"), (ro.grad, "drec"), (do_.grad, "ddisc"), (muo.grad, "dmu"), (lvo.grad, "dlv")):
+        close(a.detach(), g[k], 2e-6, k)
+    close(O.nested_weight(g["prob"]), g["nested"], 0, "nested")
+    close(O.dice_coefficient(g["prob"], tgt).mean(), g["dice_coefficient"], 1e-6, "dice coefficient")
+    close(O.dice_region(g["prob"], tgt), g["dice_region"], 1e-6, "dice region")

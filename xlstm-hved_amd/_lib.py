@@ -86,6 +86,13 @@ SIGNATURES = {
     "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_skr_tail_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll]),
     "xh_skr_tail_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
+    "xh_pair_sums": (I, [vp, I, vp, ll, I, vp, ll, F, I, I, ll, I, F, vp]),
+    "xh_lincomb": (I, [vp, I, vp, ll, I, vp, ll, F, vp, ll, I, I, ll, vp, vp, vp, vp, I]),
+    "xh_loss_finalize": (I, [vp, I, vp, I, I, C.c_double, C.c_double, vp, vp, vp]),
+    "xh_kld_fwd": (I, [vp, I, vp, vp, vp, I, I, ll, vp]),
+    "xh_kld_bwd": (I, [vp, I, vp, vp, vp, I, I, ll, F, vp, vp, vp]),
+    "xh_nested_weight": (I, [vp, I, vp, ll, vp, ll, I, ll]),
+    "xh_fill": (I, [vp, I, vp, ll, F]),
     "xh_vil_workspace_floats": (ll, [I, I, I]),
     "xh_vil_fwd": (I, [vp, I, vp, vp, vp, I, I, I, I, I, C.POINTER(VilParams), vp]),
     "xh_vil_bwd": (I, [vp, I, vp, vp, vp, vp, I, I, I, I, C.POINTER(VilParams), C.POINTER(VilParams), vp]),

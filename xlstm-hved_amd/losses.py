@@ -1,0 +1,157 @@
+"""Loss and metric epilogues of the training step on the HIP path: same names and call signatures as
+the reference's loss.py / metrics.py objects that train.py:171-175,232-262,288-296 uses, so the step reads the same.
+
+Each loss is ONE reduction pass over its tensors (fp64 sums) + a one-workgroup finalisation on the device; its backward
+is one linear-combination pass scaled by the upstream gradient, which stays on the device (no .item(), no chain of
+full-resolution ATen temporaries).  Predictions may be in a 16-bit storage type while targets are fp32."""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .model import SUBSETS_MODALITIES
+
+
+class _Dice(Function):
+    @staticmethod
+    def forward(ctx, p, t, eps):
+        red = ops.pair_sums(p, t)
+        loss, ca, cb = ops.loss_finalize(0, red, eps=eps)
+        ctx.save_for_backward(p, t, ca, cb)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, ca, cb = ctx.saved_tensors
+        return ops.lincomb(p, t, ca, cb, gscale=g.float().reshape(1).contiguous()), None, None
+
+
+class DiceLoss(torch.nn.Module):
+    """loss.py:188-209 + compute_per_channel_dice (loss.py:257-285): 1 - mean_c 2 sum(p t) / max(sum p^2 + sum t^2, 1e-6),
+    sums over batch and space; the input is already a probability (the reference applies no normalisation)."""
+
+    def __init__(self, weight=None, epsilon=1e-6):
+        super().__init__()
+        if weight is not None:
+            raise NotImplementedError("per-class weights are not used by train.py")
+        self.epsilon = epsilon
+
+    def forward(self, input, target):
+        if input.shape != target.shape:
+            raise ValueError("'input' and 'target' must have the same shape")
+        return _Dice.apply(input, _as_target(target, input), self.epsilon)
+
+
+def _as_target(t, like):
+    """Targets are consumed as fp32 or in the prediction's dtype (xh_pair_sums reads either)."""
+    if t.dtype == like.dtype or t.dtype == torch.float32:
+        return t.contiguous()
+    return t.float().contiguous()
+
+
+class _MSE(Function):
+    @staticmethod
+    def forward(ctx, a, b, bval):
+        red = ops.pair_sums(a, b, bval=bval)
+        loss, ca, cb = ops.loss_finalize(1, red, count=a.numel())
+        ctx.save_for_backward(a, b, ca, cb)
+        ctx.bval = bval
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, ca, cb = ctx.saved_tensors
+        gs = g.float().reshape(1).contiguous()
+        da = ops.lincomb(a, b, ca, cb, bval=ctx.bval, gscale=gs)
+        db = None
+        if b is not None and ctx.needs_input_grad[1]:
+            db = ops.lincomb(b, a, ca, cb, gscale=gs) if b.dtype == a.dtype else None
+        return da, db, None
+
+
+def mse_loss(a, b):
+    """nn.MSELoss() of train.py:173,234: mean (a - b)^2.  b (the input patch) may be fp32 next to a 16-bit reconstruction."""
+    return _MSE.apply(a, _as_target(b, a), 0.0)
+
+
+class MSELoss(torch.nn.Module):
+    def forward(self, input, target):
+        return mse_loss(input, target)
+
+
+class GANLoss(torch.nn.Module):
+    """loss.py:167-186 with use_lsgan=True (train.py:172): mean (d - label)^2 against a constant label."""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0):
+        super().__init__()
+        if not use_lsgan:
+            raise NotImplementedError("train.py uses the least-squares GAN loss")
+        self.real_label, self.fake_label = float(target_real_label), float(target_fake_label)
+
+    def forward(self, input, target_is_real):
+        return _MSE.apply(input, None, self.real_label if target_is_real else self.fake_label)
+
+
+class _KLD(Function):
+    @staticmethod
+    def forward(ctx, mu, lv, keep):
+        mu, lv = mu.contiguous(), lv.contiguous()
+        red = ops.kld_fwd(mu, lv, keep)
+        n, _, L_, d, h, w = mu.shape
+        ctx.count = n * L_ * d * h * w
+        ctx.save_for_backward(mu, lv, keep)
+        return (red * (0.5 / ctx.count)).float().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, lv, keep = ctx.saved_tensors
+        dmu, dlv = ops.kld_bwd(mu, lv, keep, 0.5 / ctx.count, gscale=g.float().reshape(1).contiguous())
+        return dmu, dlv, None
+
+
+_KEEP = {}
+
+
+def compute_KLD(mu_list, logvar_list, subset_index_list=(14,), choices=(0, 1, 2, 3)):
+    """loss.py:85-115 on the (B, 5, L, d, h, w) stacks the model returns per level: for every subset index in the list,
+    KL(PoE(prior + subset) || prior), averaged over the list."""
+    total = None
+    for idx in subset_index_list:
+        key = (int(idx), mu_list.shape[0], mu_list.device)
+        keep = _KEEP.get(key)
+        if keep is None:                # built once per (subset, batch, device): no host-to-device copy inside a captured step
+            keep = _KEEP[key] = torch.tensor([[1.0 if k in SUBSETS_MODALITIES[int(idx)] else 0.0 for k in range(4)]] * mu_list.shape[0],
+                                             dtype=torch.float32, device=mu_list.device)
+        k = _KLD.apply(mu_list, logvar_list, keep)
+        total = k if total is None else total + k
+    return total / len(subset_index_list)
+
+
+def nested_attention(seg, syn):
+    """train.py:242-259: syn * (1 + w) with w the nested tumour-region weight map of the DETACHED segmentation output
+    (w = p_WT where > .5, overridden by p_TC, p_ET where those exceed .5).  The gradient reaches `syn` only."""
+    from . import functional as Fn
+    w = ops.nested_weight(seg.detach().contiguous())
+    return Fn.Gate.apply(syn, w)
+
+
+class DiceCoefficient:
+    """metrics.py:10-48: mean over channels of the thresholded (> 0.5) per-channel Dice, averaged over the batch."""
+
+    def __init__(self, epsilon=1e-6, **kwargs):
+        self.epsilon = epsilon
+
+    def per_channel(self, input, target):
+        red = ops.pair_sums(input.detach(), _as_target(target, input), thr=0.5)
+        return ops.loss_finalize(2, red, eps=self.epsilon)
+
+    def __call__(self, input, target):
+        return self.per_channel(input, target).mean()
+
+
+class DiceRegion(DiceCoefficient):
+    """metrics.py:51-107, mode='sigmoid': the thresholded Dice of one nested region channel (WT / TC / EC)."""
+
+    def __call__(self, input, target, region="WT", mode="sigmoid", epsilon=1e-6):
+        if mode != "sigmoid":
+            raise NotImplementedError("XLSTM_HVED emits sigmoid region maps (SURVEY F7)")
+        return self.per_channel(input, target)[{"WT": 0, "TC": 1, "EC": 2}[region]]

@@ -625,3 +625,78 @@ def vil_bwd(xa, xb, dout, params, ws, grads, nh=4):
     L.check(L.load().xh_vil_bwd(_stream(), _dt(dout), _p(xa), _p(xb), _p(dout), _p(dxin), n, s, c, nh, C.byref(ps), C.byref(gs), _p(ws)),
             "xh_vil_bwd")
     return dxin
+
+
+# ----------------------------------------------------------------------------------------------- loss / metric epilogues
+def _dt_of(t):
+    return _dt(t)
+
+
+def pair_sums(a, b=None, bval=0.0, thr=None):
+    """(N, C, 6) fp64 sums over DHW of (a'b, a'^2, b^2, (a'-b)^2, a', b); a' = (a > thr) when thr is given.  b: a tensor of
+    a's dtype or fp32, or None (= the constant bval)."""
+    n, c, d, h, w, a_bs = _vol(a)
+    red = torch.zeros((n, c, 6), dtype=torch.float64, device=a.device)
+    b_dt, b_bs = _dt(a), 0
+    if b is not None:
+        if tuple(b.shape) != tuple(a.shape):
+            raise ValueError(f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        b_dt, b_bs = _dt(b), _vol(b)[5]
+    L.check(L.load().xh_pair_sums(_stream(), _dt(a), _p(a), a_bs, b_dt, _p(b), b_bs, float(bval), n, c, d * h * w,
+                                  int(thr is not None), float(thr or 0.0), _p(red)), "xh_pair_sums")
+    return red
+
+
+def lincomb(a, b, ca, cb, cc=None, bval=0.0, gscale=None):
+    """out = gscale * (ca[n,c]*a + cb[n,c]*b + cc[n,c]) in a's dtype (b: tensor of a's dtype / fp32, or None = bval;
+    gscale: optional fp32 device scalar)."""
+    n, c, d, h, w, a_bs = _vol(a)
+    out = torch.empty_like(a, memory_format=torch.contiguous_format)
+    b_dt, b_bs = _dt(a), 0
+    if b is not None:
+        b_dt, b_bs = _dt(b), _vol(b)[5]
+    L.check(L.load().xh_lincomb(_stream(), _dt(a), _p(a), a_bs, b_dt, _p(b), b_bs, float(bval), _p(out), _vol(out)[5], n, c,
+                                d * h * w, _p(_f32(ca, "ca")), _p(_f32(cb, "cb")), _p(cc), _p(gscale), 0), "xh_lincomb")
+    return out
+
+
+def loss_finalize(kind, red, count=1.0, eps=1e-6):
+    """kind 0 DiceLoss / 1 mean squared difference: (loss[1], ca[N,C], cb[N,C]); kind 2 thresholded Dice: metric[C]."""
+    n, c = red.shape[:2]
+    out = torch.empty(c if kind == 2 else 1, dtype=torch.float32, device=red.device)
+    ca = cb = None
+    if kind < 2:
+        ca, cb = (torch.empty((n, c), dtype=torch.float32, device=red.device) for _ in range(2))
+    L.check(L.load().xh_loss_finalize(_stream(), kind, _p(red), n, c, float(count), float(eps), _p(out), _p(ca), _p(cb)),
+            "xh_loss_finalize")
+    return (out, ca, cb) if kind < 2 else out
+
+
+def kld_fwd(mu, lv, keep):
+    n, five, L_, d, h, w = mu.shape
+    red = torch.zeros(1, dtype=torch.float64, device=mu.device)
+    L.check(L.load().xh_kld_fwd(_stream(), _dt(mu), _p(mu), _p(lv), _p(keep), n, L_, d * h * w, _p(red)), "xh_kld_fwd")
+    return red
+
+
+def kld_bwd(mu, lv, keep, scale, gscale=None):
+    n, five, L_, d, h, w = mu.shape
+    dmu, dlv = torch.empty_like(mu), torch.empty_like(lv)
+    L.check(L.load().xh_kld_bwd(_stream(), _dt(mu), _p(mu), _p(lv), _p(keep), n, L_, d * h * w, float(scale), _p(gscale), _p(dmu),
+                                _p(dlv)), "xh_kld_bwd")
+    return dmu, dlv
+
+
+def nested_weight(seg):
+    n, c, d, h, w, bs = _vol(seg)
+    if c != 3:
+        raise ValueError("nested weights need the 3 region channels (WT, TC, ET)")
+    out = new_like(seg, (n, 1, d, h, w))
+    L.check(L.load().xh_nested_weight(_stream(), _dt(seg), _p(seg), bs, _p(out), _vol(out)[5], n, d * h * w), "xh_nested_weight")
+    return out
+
+
+def fill(shape, value, like):
+    out = torch.empty(shape, dtype=like.dtype, device=like.device)
+    L.check(L.load().xh_fill(_stream(), _dt(out), _p(out), out.numel(), float(value)), "xh_fill")
+    return out
