@@ -62,16 +62,20 @@ def parse():
     ap.add_argument("--wgrad-overlap", action="store_true",
                     help="launch the weight-gradient kernels on a second HIP stream (measured on MI355X: no gain, 9.88-10.7 ms "
                          "vs 9.96 ms -- the hipGraph's cross-stream dependencies cost what the overlap saves; off by default)")
+    ap.add_argument("--no-wgrad-defer", action="store_true",
+                    help="launch every weight gradient where backward reaches it instead of batching them at the end of backward")
     ap.add_argument("--wgrad-batch", type=int, default=12, help="weight-gradient calls forked to the side stream per batch")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the N=1 run
     return ap.parse_args()
 
 
 def bench_loss(seg, mu, lv, rec):
-    """reaches every parameter the reference's training loss reaches."""
-    loss = seg.float().mean() + rec.float().mean()
+    """seg.mean() + rec.mean() + sum_l (mu_l.mean() + logvar_l.mean()) -- reaches every parameter the
+    reference's training loss reaches.  Each mean is one HIP reduction pass (losses.mean_of), not a cast + ATen reduce."""
+    from xlstm_hved_amd.losses import mean_of
+    loss = mean_of(seg) + mean_of(rec)
     for a, b in zip(mu, lv):
-        loss = loss + a.float().mean() + b.float().mean()
+        loss = loss + mean_of(a) + mean_of(b)
     return loss
 
 
@@ -192,7 +196,8 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1 + rank)   # per-rank synthetic patch
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
     grads = X.parallel.FlatGrads(params)                       # p.grad = views of one flat fp32 bucket
-    ops.set_wgrad_overlap(args.wgrad_overlap, args.wgrad_batch)           # weight gradients on a second HIP stream, joined once per step
+    ops.set_wgrad_overlap(args.wgrad_overlap, args.wgrad_batch)
+    ops.set_wgrad_defer(not args.no_wgrad_defer and not args.wgrad_overlap)   # weight gradients batched at the end of backward           # weight gradients on a second HIP stream, joined once per step
 
     def make_compute(xin):
         # fp16 storage: the activation gradients need the caller's loss scaling, as the reference's GradScaler provides
@@ -413,22 +418,63 @@ def roofline_pass(step, ops, nsteps, dtype):
         flops = 2.0 * y.numel() * k ** 3 * cin / groups
         records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops,
                         f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{y.shape[1]} @{'x'.join(map(str, y.shape[2:]))}"
-                        + (" dgrad" if kw.get("transposed") else "")))
+                        + (" dgrad" if kw.get("transposed") else ""), 1))
         return res
 
+    pending_meta = []
+
     def timed_wg(xa, xb, dy, dws, dbs, **kw):
-        e0, e1 = ev(), ev()
-        e0.record()
-        r = orig_wg(xa, xb, dy, dws, dbs, **kw)
-        e1.record()
         cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
         k, groups = kw["k"], kw.get("groups", 1)
         in_el = xa.numel() + (xb.numel() if xb is not None else 0)
         nbytes = (in_el + dy.numel()) * esz + sum(w.numel() for w in dws) * 4
         flops = 2.0 * dy.numel() * k ** 3 * cin / groups
-        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops,
-                        f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{dy.shape[1]} @{'x'.join(map(str, dy.shape[2:]))} wgrad"))
+        shape = f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{dy.shape[1]} @{'x'.join(map(str, dy.shape[2:]))} wgrad"
+        if kw.get("side") and ops._WG["defer"]:
+            # deferred: launched by the batch flush at the end of backward (timed_flush); remember what it will carry
+            mfma = (k == 3 and kw.get("stride", 1) == 1 and esz == 2 and xa.shape[-1] % 32 == 0 and cin // groups >= 4)
+            cls = ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small") if mfma else "rest"
+            pending_meta.append((cls, nbytes, flops, shape))
+            return orig_wg(xa, xb, dy, dws, dbs, **kw)
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = orig_wg(xa, xb, dy, dws, dbs, **kw)
+        e1.record()
+        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops, shape, 1))
         return r
+
+    orig_flush = ops._flush_deferred
+
+    def timed_flush():
+        """The deferred weight gradients, one bracket per kernel class: the k=3 MFMA problems of a volume class share
+        launches (xh_conv3d_wgrad_batch packs 7 per launch), the rest run one by one."""
+        calls, metas = ops._WG["deferred"], pending_meta[:]
+        ops._WG["deferred"] = []
+        pending_meta.clear()
+        if len(calls) != len(metas):                         # something bypassed the wrapper: do not attribute
+            ops._WG["deferred"] = calls
+            return orig_flush()
+        for cls in ("small", "big"):
+            grp = [(c, m) for c, m in zip(calls, metas) if m[0] == cls]
+            if not grp:
+                continue
+            ops._WG["deferred"] = [c for c, _ in grp]
+            e0, e1 = ev(), ev()
+            e0.record()
+            orig_flush()
+            e1.record()
+            nl = -(-len(grp) // 7)
+            records.append((ops.last_conv_kernel(), e0, e1, sum(m[1] for _, m in grp), sum(m[2] for _, m in grp),
+                            f"{len(grp)} k3 weight gradients of {cls} volumes in {nl} launch(es): " + "; ".join(m[3] for _, m in grp), nl))
+        for c, m in zip(calls, metas):
+            if m[0] != "rest":
+                continue
+            ops._WG["deferred"] = [c]
+            e0, e1 = ev(), ev()
+            e0.record()
+            orig_flush()
+            e1.record()
+            records.append((ops.last_conv_kernel(), e0, e1, m[1], m[2], m[3], 1))
     # calibrate the spin kernel's tick rate, then use a bounded ~60 ms delay per step
     c0, c1 = ev(), ev()
     c0.record()
@@ -438,14 +484,14 @@ def roofline_pass(step, ops, nsteps, dtype):
     ticks_per_ms = 1_000_000 / max(c0.elapsed_time(c1), 1e-3)
     # the delay must outlast the host's enqueue time of one instrumented step (else the GPU catches up and a bracket
     # also spans host launch latency): time one instrumented enqueue, then wait 1.5x that (+20 ms), at most 600 ms
-    ops.conv3d, ops.conv3d_wgrad = timed_fwd, timed_wg
+    ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
     try:
         t_h = time.perf_counter()
         step()
         host_ms = (time.perf_counter() - t_h) * 1e3
         torch.cuda.synchronize()
     finally:
-        ops.conv3d, ops.conv3d_wgrad = orig_fwd, orig_wg
+        ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
     records.clear()
     delay_ms = min(2.0 * host_ms + 30.0, 600.0)
     delay = int(delay_ms * ticks_per_ms)
@@ -460,22 +506,22 @@ def roofline_pass(step, ops, nsteps, dtype):
         empties.append((e0, e1))
     torch.cuda.synchronize()
     overhead_ms = sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
-    ops.conv3d, ops.conv3d_wgrad = timed_fwd, timed_wg
+    ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
     try:
         for _ in range(nsteps):
             torch.cuda._sleep(delay)
             step()
         torch.cuda.synchronize()
     finally:
-        ops.conv3d, ops.conv3d_wgrad = orig_fwd, orig_wg
+        ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
     # every (kernel instance, shape) occurs a fixed number of times per step; the n-th occurrence of each step forms one
     # sample group whose MEDIAN over the steps is taken (a host hiccup that lets the GPU catch up inflates single brackets)
     per_call = {}
     seen = {}
-    for name, e0, e1, nbytes, flops, shape in records:
+    for name, e0, e1, nbytes, flops, shape, nl in records:
         key = (name, shape)
         seen[key] = seen.get(key, 0) + 1
-        per_call.setdefault(key, []).append((max(e0.elapsed_time(e1) - overhead_ms, 1e-3), nbytes, flops))
+        per_call.setdefault(key, []).append((max(e0.elapsed_time(e1) - overhead_ms * nl, 1e-3), nbytes, flops, nl))
     agg = {}
     for (name, shape), calls in per_call.items():
         per_step = len(calls) // nsteps if len(calls) % nsteps == 0 else 0
@@ -486,10 +532,10 @@ def roofline_pass(step, ops, nsteps, dtype):
                 a[1] += ts[len(ts) // 2] * nsteps
         else:
             a[1] += sum(c[0] for c in calls)
-        a[0] += len(calls)
+        a[0] += sum(c[3] for c in calls)                      # launches (a batch bracket spans several)
         a[2] += sum(c[1] for c in calls)
         a[3] += sum(c[2] for c in calls)
-        a[4][shape] = a[4].get(shape, 0) + len(calls)
+        a[4][shape] = a[4].get(shape, 0) + sum(c[3] for c in calls)
     ops.set_wgrad_overlap(overlap_was)
     total_ms = sum(a[1] for a in agg.values())
     name, (cnt, ms_sum, bytes_sum, flops_sum, shapes) = max(agg.items(), key=lambda kv: kv[1][1])

@@ -110,6 +110,13 @@ int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* 
  * db[co] += sum dy.  Desc describes the FORWARD conv; ptrs: xa/xb/pre_* = forward input, `ea` = dY with
  * batch stride ea_bs.  dw[i]/db[i] are laid out like w[i]/b[i], fp32, ACCUMULATED into (caller zeroes). */
 int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
+/* The weight gradients of `n` convolutions in as few launches as possible: d[i] / p[i] / dw[i] / db[i] are what
+ * xh_conv3d_wgrad would take for problem i (db may be NULL, db[i][j] may be NULL).  Weight gradients are off the critical
+ * path of a backward pass, so a caller can collect them and issue this once at the end: the k=3 MFMA problems of a
+ * (storage type, volume class) share launches 7 at a time (their workgroups run side by side instead of 16 latency-bound
+ * launches one after the other), everything else is forwarded to xh_conv3d_wgrad.  Same accumulate (+=) semantics. */
+int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p,
+                          float* const (*dw)[4], float* const (*db)[4]);
 /* Scratch (bytes) xh_conv3d_wgrad wants in p->ws for this shape (per-workgroup partial gradients of the 7^3 MFMA weight
  * gradient); 0 = none.  With less, the call uses the vector kernel. */
 long long xh_conv3d_wgrad_workspace_bytes(const xh_conv_desc* d);
@@ -313,7 +320,7 @@ int xh_lincomb(void* stream, int dtype, const void* a, long long a_bs, int b_dty
                void* out, long long o_bs, int N, int C, long long DHW, const float* ca, const float* cb, const float* cc,
                const float* gscale, int accumulate);
 /* Sums of xh_pair_sums -> scalar loss / per-channel metric + the per-(n,c) coefficients of xh_lincomb, on the device:
- * kind 0 DiceLoss, 1 mean squared difference (count = number of elements), 2 thresholded Dice metric (out[C]).
+ * kind 0 DiceLoss, 1 mean squared difference (count = number of elements), 2 thresholded Dice metric (out[C]), 3 mean of a.
  * gscale (xh_lincomb, xh_kld_bwd): optional device scalar multiplying the result (the upstream gradient). */
 int xh_loss_finalize(void* stream, int kind, const double* red, int N, int C, double count, double eps, float* out, float* ca,
                      float* cb);
@@ -327,8 +334,8 @@ int xh_kld_bwd(void* stream, int dtype, const void* mu_stack, const void* lv_sta
 /* Nested tumour-region weight map (train.py:244-248,252-256): from the 3 sigmoid channels (WT, TC, ET) of seg,
  * w = p0 > .5 ? p0 : 0, overridden by p1 where p1 > .5, then by p2 where p2 > .5.  w has 1 channel. */
 int xh_nested_weight(void* stream, int dtype, const void* seg, long long seg_bs, void* w, long long w_bs, int N, long long DHW);
-/* out[0..n) = v in the storage type (constant upstream gradients of mean-type losses). */
-int xh_fill(void* stream, int dtype, void* out, long long n, float v);
+/* out[0..n) = v (* gscale[0] when given) in the storage type (constant upstream gradients of mean-type losses). */
+int xh_fill(void* stream, int dtype, void* out, long long n, float v, const float* gscale);
 
 #ifdef __cplusplus
 }

@@ -59,3 +59,15 @@ def test_losses_full_size_one_pass_properties():
     q = (1 - t).bfloat16()
     assert abs(X.DiceLoss()(q, t).item() - 1.0) < 1e-6                           # disjoint masks: dice 0
     assert abs(X.mse_loss(q, t).item() - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mean_of_matches_torch_mean(dtype):
+    torch.manual_seed(1)
+    for shape in ((2, 3, 8, 12, 16), (1, 5, 2, 4, 4, 8)):
+        x = torch.randn(shape, device=DEV).to(dtype).requires_grad_(True)
+        m = X.losses.mean_of(x)
+        (m * 3.0).backward()
+        ref = x.detach().float().mean()
+        assert abs(m.item() - ref.item()) < 1e-6
+        assert torch.allclose(x.grad.float(), torch.full(shape, 3.0 / x.numel(), device=DEV).to(dtype).float())

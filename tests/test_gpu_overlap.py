@@ -1,5 +1,6 @@
-"""-m gpu: weight gradients on the side stream (ops.set_wgrad_overlap) give the same gradients as the single-stream step,
-eagerly and through a hipGraph replay."""
+"""-m gpu: weight gradients deferred and batched (ops.set_wgrad_defer -> xh_conv3d_wgrad_batch, the multi-problem MFMA
+kernel) or on the side stream (ops.set_wgrad_overlap) give the same gradients as the plain per-call step, eagerly and
+through a hipGraph replay, for bf16 and fp16 storage."""
 import pytest
 import torch
 
@@ -12,15 +13,16 @@ import xlstm_hved_amd as X  # noqa: E402
 DEV = "cuda"
 
 
-def _grads(overlap, graph):
+def _grads(mode, graph, dtype=torch.bfloat16):
     m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     m.load_state_dict(load("weights_seed1"), strict=True)
     m = m.to(DEV).train()
     torch.manual_seed(3)
-    x = torch.rand(1, 4, 64, 64, 64).to(DEV, torch.bfloat16)
-    eps = [torch.randn(1, 2 ** l, 32 >> l, 32 >> l, 32 >> l).to(DEV, torch.bfloat16) for l in range(4)]
+    x = torch.rand(1, 4, 64, 64, 64).to(DEV, dtype)
+    eps = [torch.randn(1, 2 ** l, 32 >> l, 32 >> l, 32 >> l).to(DEV, dtype) for l in range(4)]
     fg = X.parallel.FlatGrads(m.parameters())
-    X.ops.set_wgrad_overlap(overlap)
+    X.ops.set_wgrad_overlap(mode == "side")
+    X.ops.set_wgrad_defer(mode == "defer")
     try:
         def step():
             fg.zero()
@@ -45,13 +47,21 @@ def _grads(overlap, graph):
         return fg.flat.clone()
     finally:
         X.ops.set_wgrad_overlap(False)
+        X.ops.set_wgrad_defer(False)
 
 
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
-def test_wgrad_side_stream_matches_single_stream(graph):
-    a = _grads(False, graph)
-    b = _grads(True, graph)
+@pytest.mark.parametrize("mode", ["side", "defer"])
+def test_wgrad_side_stream_and_deferred_batch_match_plain_step(mode, graph):
+    a = _grads("plain", graph)
+    b = _grads(mode, graph)
     assert torch.isfinite(b).all()
     scale = a.abs().max().item()
     # fp32 atomics accumulate in a different order on every run: compare to round-off of the largest gradient
     assert (a - b).abs().max().item() <= 2e-4 * scale, (a - b).abs().max().item() / scale
+
+
+def test_deferred_batch_fp16_and_batch2():
+    a = _grads("plain", False, torch.float16)
+    b = _grads("defer", False, torch.float16)
+    assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item()

@@ -56,6 +56,7 @@ SIGNATURES = {
     "xh_conv3d_wgrad_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * 4), C.POINTER(vp * 4)]),
+    "xh_conv3d_wgrad_batch": (I, [vp, I, vp, vp, vp, vp]),
     "xh_moments": (I, [vp, I, vp, ll, I, I, ll, vp, ll]),
     "xh_norm_finalize": (I, [vp, I, vp, I, I, ll, I, F, vp, vp, vp, vp, I, vp, vp, vp, vp]),
     "xh_affine_act": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, I, F]),
@@ -92,7 +93,7 @@ SIGNATURES = {
     "xh_kld_fwd": (I, [vp, I, vp, vp, vp, I, I, ll, vp]),
     "xh_kld_bwd": (I, [vp, I, vp, vp, vp, I, I, ll, F, vp, vp, vp]),
     "xh_nested_weight": (I, [vp, I, vp, ll, vp, ll, I, ll]),
-    "xh_fill": (I, [vp, I, vp, ll, F]),
+    "xh_fill": (I, [vp, I, vp, ll, F, vp]),
     "xh_vil_workspace_floats": (ll, [I, I, I]),
     "xh_vil_fwd": (I, [vp, I, vp, vp, vp, I, I, I, I, I, C.POINTER(VilParams), vp]),
     "xh_vil_bwd": (I, [vp, I, vp, vp, vp, vp, I, I, I, I, C.POINTER(VilParams), C.POINTER(VilParams), vp]),

@@ -1210,7 +1210,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv7_mfma.hip
 int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
 int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
-static int g_use_mfma = 1;
+int g_use_mfma = 1;
 int g_xh_disable = 0;
 static char g_last_kernel[96] = "";
 void xh_note_kernel(const char* fmt, ...) {

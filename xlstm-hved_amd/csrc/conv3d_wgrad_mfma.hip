@@ -33,8 +33,8 @@ struct WgMK {
 };
 
 template <int FMT, int CP, int NT>
-__global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
-  typedef h16<FMT> ST;                                // storage type: ST or f16_t
+__device__ __forceinline__ void conv3_wgrad_body(const WgMK& a, const int bid_x, const int bid_y, const int grid_x) {
+  typedef h16<FMT> ST;                                // storage type: bf16_t or f16_t
   constexpr int NWV = NT / 64;
   constexpr int TH = 8, IH = TH + 2;
   constexpr int ROWB = 96;                            // 48 voxels: [ow0-8, ow0+40)
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g4 = lane >> 4, nn = lane & 15;
-  int y = blockIdx.y;
+  int y = bid_y;
   const int ct = y % a.nctile; y /= a.nctile;
   const int nt = y % a.ntile;
   const int set = y / a.ntile;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
   const long long hw = (long long)H * W, dhw = (long long)D * hw;
   const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
   const long long odhw = (long long)Do * Ho * Wo;
-  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  int wk = xcd_swizzle(bid_x, grid_x);
   const int tw = wk % a.tilesW; wk /= a.tilesW;
   const int th = wk % a.tilesH; wk /= a.tilesH;
   const int ds = wk % a.dsegs;
@@ -248,16 +248,45 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
   }
 }
 
-// returns XH_OK if launched, 1 if not eligible
-int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
-  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return 1;
-  if (d->W % 32 != 0 || d->Wo != d->W) return 1;
+template <int FMT, int CP, int NT>
+__global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
+  conv3_wgrad_body<FMT, CP, NT>(a, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// Several weight-gradient problems in ONE launch.  The weight gradients of a backward pass are off its critical path
+// (nothing reads them before the optimizer / the all-reduce), and the small-volume ones are latency-bound on their own --
+// a few dozen workgroups each, 35 us whatever the shape.  Deferred to the end of backward and launched together, their
+// workgroups fill the chip side by side.  The problem table travels in the kernel arguments (no device-side table, no
+// host-to-device copy: capture-safe); a workgroup finds its problem from the prefix of workgroup counts.
+constexpr int WG_MULTI = 7;
+struct WgMulti {
+  int n;
+  int off[WG_MULTI + 1];      // first linear workgroup of problem i
+  int gx[WG_MULTI];           // grid x extent of problem i (its y extent follows from off)
+  WgMK p[WG_MULTI];
+};
+template <int FMT, int CP, int NT>
+__global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_multi_kernel(const WgMulti m) {
+  const int b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < WG_MULTI; ++k)
+    if (k < m.n && b >= m.off[k]) i = k;
+  const int local = b - m.off[i];
+  conv3_wgrad_body<FMT, CP, NT>(m.p[i], local % m.gx[i], local / m.gx[i], m.gx[i]);
+}
+
+struct WgPlan { WgMK a; unsigned gx; int ny; size_t shm; bool big; int cp; };
+// fills the launch plan; returns false when the shape is not eligible for the MFMA weight gradient
+static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgPlan* pl) {
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return false;
+  if (d->W % 32 != 0 || d->Wo != d->W) return false;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
-  if (cin_g < 4) return 1;
-  if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return 1;
-  if (((long long)d->D * d->H * d->W) % 8) return 1;
-  if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return 1;
-  WgMK a;
+  if (cin_g < 4) return false;
+  if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return false;
+  if (((long long)d->D * d->H * d->W) % 8) return false;
+  if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
+  WgMK& a = pl->a;
   a.d = *d; a.p = *p;
   if (!d->pre) a.d.pre_slope = 1.f;
   for (int i = 0; i < 4; ++i) { a.dw[i] = i < d->n_wptr ? dw[i] : nullptr; a.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
@@ -277,10 +306,11 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
     if ((g_mfma_abl & 128) && a.cin_set > 4) cp = 8;
     if ((g_mfma_abl & 256) && a.cin_set > 8) cp = 16;
   }
+  pl->cp = cp;
   a.ntile = cdiv(a.cout_set, 16);
   a.nctile = cdiv(a.cin_set, cp);
   const int ny = (d->groups / gs) * a.ntile * a.nctile;
-  if (ny > 65535) return 1;
+  if (ny > 65535) return false;
   a.tilesW = d->W / 32; a.tilesH = cdiv(d->Ho, 8);
   const int cols = a.tilesW * a.tilesH;
   // small volumes: fewer, longer runs so the per-workgroup LDS reduction + atomics pass amortises
@@ -292,13 +322,26 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   a.sd = cdiv(d->Do, dsegs);
   a.dsegs = cdiv(d->Do, a.sd);
   const long long gx = (long long)cols * a.dsegs * d->N;
-  if (gx > 2147483647LL) return 1;
-  dim3 grid((unsigned)gx, ny, 1);
+  if (gx > 2147483647LL) return false;
+  pl->gx = (unsigned)gx;
+  pl->ny = ny;
   const size_t ring = (size_t)4 * cp * (10 * 96 + 16);
   const size_t red = (size_t)(16 * cp * 27 + 16) * sizeof(float);
-  const size_t shm = ring > red ? ring : red;
+  pl->shm = ring > red ? ring : red;
+  pl->big = big_vol;
+  return true;
+}
+
+// returns XH_OK if launched, 1 if not eligible
+int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
+  WgPlan pl;
+  if (!wg_plan(d, p, dw, db, &pl)) return 1;
+  const WgMK& a = pl.a;
+  dim3 grid(pl.gx, pl.ny, 1);
+  const size_t shm = pl.shm;
   hipStream_t st = (hipStream_t)stream;
-  const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
+  const bool big = pl.big;
+  const int cp = pl.cp;
 #define LW(C)                                                                                     \
   do {                                                                                            \
     if (d->dtype == XH_F16) {                                                                     \
@@ -316,5 +359,65 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
     default: LW(16);
   }
 #undef LW
+  return xh_launch_status();
+}
+
+// Weight gradients of `n` convolutions (see xlstm_hved.h).  Problems the MFMA kernel can take (k = 3, stride 1, 16-bit
+// storage, >= 4 input channels per group, the default 4-channel tiles) are grouped by (storage format, volume class) and
+// launched WG_MULTI at a time; the others go through xh_conv3d_wgrad one by one.
+extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
+extern int g_use_mfma;
+extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p,
+                                     float* const (*dw)[4], float* const (*db)[4]) {
+  if (n < 0 || (n > 0 && (!d || !p || !dw))) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc_all = XH_OK;
+  WgMulti* m = new WgMulti;
+  for (int cls = 0; cls < 4; ++cls) {                 // (fmt, big)
+    const int fmt = cls >> 1, big = cls & 1;
+    m->n = 0; m->off[0] = 0;
+    size_t shm = 0;
+    auto flush = [&]() {
+      if (m->n == 0) return;
+      const int total = m->off[m->n];
+      xh_note_kernel("conv3_wgrad_mfma_multi_kernel<%d, 4, %d>", fmt, big ? 256 : 512);
+      if (fmt) {
+        if (big) hipLaunchKernelGGL((conv3_wgrad_mfma_multi_kernel<1, 4, 256>), dim3(total), dim3(256), shm, st, *m);
+        else hipLaunchKernelGGL((conv3_wgrad_mfma_multi_kernel<1, 4, 512>), dim3(total), dim3(512), shm, st, *m);
+      } else {
+        if (big) hipLaunchKernelGGL((conv3_wgrad_mfma_multi_kernel<0, 4, 256>), dim3(total), dim3(256), shm, st, *m);
+        else hipLaunchKernelGGL((conv3_wgrad_mfma_multi_kernel<0, 4, 512>), dim3(total), dim3(512), shm, st, *m);
+      }
+      m->n = 0; m->off[0] = 0; shm = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      if (!d[i] || !p[i]) { delete m; return XH_ERR_ARG; }
+      WgPlan pl;
+      const bool ok = g_use_mfma && !d[i]->transposed && p[i]->ea && wg_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &pl) && pl.cp == 4;
+      if (!ok) {
+        if (cls == 0) {                               // not batchable: the ordinary entry point, once
+          const int rc = xh_conv3d_wgrad(stream, d[i], p[i], dw[i], db ? db[i] : nullptr);
+          if (rc != XH_OK) rc_all = rc;
+        }
+        continue;
+      }
+      if ((d[i]->dtype == XH_F16 ? 1 : 0) != fmt || (pl.big ? 1 : 0) != big) continue;
+      const long long blocks = (long long)pl.gx * pl.ny;
+      if (blocks > (1 << 24)) {                       // too large to share a launch: on its own
+        if (xh_conv3_wgrad_mfma_try(stream, d[i], p[i], dw[i], db ? db[i] : nullptr) != XH_OK) rc_all = XH_ERR_HIP;
+        continue;
+      }
+      const int k = m->n;
+      m->p[k] = pl.a;
+      m->gx[k] = (int)pl.gx;
+      m->off[k + 1] = m->off[k] + (int)blocks;
+      if (pl.shm > shm) shm = pl.shm;
+      m->n = k + 1;
+      if (m->n == WG_MULTI) flush();
+    }
+    flush();
+  }
+  delete m;
+  if (rc_all != XH_OK) return rc_all;
   return xh_launch_status();
 }

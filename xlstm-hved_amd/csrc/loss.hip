@@ -234,6 +234,7 @@ extern "C" int xh_nested_weight(void* stream, int dtype, const void* seg, long l
 //          d loss / d a = ca*a + cb*b with ca = 4 I/(C D^2), cb = -2/(C D)   (clamped: ca = 0, cb = -2/(C eps))
 //  kind 1  mean squared difference (nn.MSELoss, GANLoss): loss = sum d^2 / count; ca = 2/count, cb = -2/count
 //  kind 2  thresholded Dice metric (metrics.py:40-48,99-107): out[c] = mean_n (2 I + eps) / (sum a' + sum b + eps)
+//  kind 3  mean of a (the SURVEY 8(d) benchmark loss): out[0] = sum a / count
 __global__ __launch_bounds__(64) void loss_finalize_kernel(int kind, const double* red, int N, int C, double count, double eps,
                                                           float* out, float* ca, float* cb) {
   const int t = threadIdx.x;
@@ -261,17 +262,23 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(int kind, const doubl
       out[0] = (float)(sacc / count);
     }
     for (int i = t; i < N * C; i += 64) { ca[i] = (float)(2.0 / count); cb[i] = (float)(-2.0 / count); }
-  } else {
+  } else if (kind == 2) {
     if (t < C) {
       double m = 0;
       for (int n = 0; n < N; ++n) { const double* r = red + ((long long)n * C + t) * 6; m += (2.0 * r[0] + eps) / (r[4] + r[5] + eps); }
       out[t] = (float)(m / N);
     }
+  } else {                                            // kind 3: plain mean of a (slot 4)
+    if (t == 0) {
+      double sacc = 0;
+      for (int i = 0; i < N * C; ++i) sacc += red[(long long)i * 6 + 4];
+      out[0] = (float)(sacc / count);
+    }
   }
 }
 extern "C" int xh_loss_finalize(void* stream, int kind, const double* red, int N, int C, double count, double eps, float* out,
                                 float* ca, float* cb) {
-  if (!red || !out || N <= 0 || C <= 0 || C > 64 || kind < 0 || kind > 2) return XH_ERR_ARG;
+  if (!red || !out || N <= 0 || C <= 0 || (C > 64 && (kind == 0 || kind == 2)) || kind < 0 || kind > 3) return XH_ERR_ARG;
   if (kind < 2 && (!ca || !cb)) return XH_ERR_ARG;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kind, red, N, C, count, eps, out, ca, cb);
   return xh_launch_status();
@@ -279,7 +286,8 @@ extern "C" int xh_loss_finalize(void* stream, int kind, const double* red, int N
 
 // fill: out[i] = v  (the constant upstream gradients of mean-type losses, in the storage type)
 template <typename T>
-__global__ __launch_bounds__(256) void fill_kernel(T* out, long long n, float v) {
+__global__ __launch_bounds__(256) void fill_kernel(T* out, long long n, float v, const float* gs) {
+  if (gs) v *= gs[0];
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i + 3 < n) {
     const float o[4] = {v, v, v, v};
@@ -288,9 +296,9 @@ __global__ __launch_bounds__(256) void fill_kernel(T* out, long long n, float v)
     for (long long k = i; k < n; ++k) stf(out, k, v);
   }
 }
-extern "C" int xh_fill(void* stream, int dtype, void* out, long long n, float v) {
+extern "C" int xh_fill(void* stream, int dtype, void* out, long long n, float v, const float* gscale) {
   if (!out || n <= 0) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  XH_DISPATCH_T(dtype, hipLaunchKernelGGL(fill_kernel<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (T*)out, n, v););
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL(fill_kernel<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (T*)out, n, v, gscale););
   return xh_launch_status();
 }

@@ -134,6 +134,26 @@ def nested_attention(seg, syn):
     return Fn.Gate.apply(syn, w)
 
 
+class _Mean(Function):
+    @staticmethod
+    def forward(ctx, t):
+        v = t if t.dim() == 5 else t.reshape(t.shape[0], -1, *t.shape[-3:])       # (N,5,L,d,h,w) stacks -> (N,5L,d,h,w)
+        v = v.contiguous()
+        red = ops.pair_sums(v)
+        ctx.meta = (tuple(t.shape), t.dtype, t.device, t.numel())
+        return ops.loss_finalize(3, red, count=t.numel()).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype, device, numel = ctx.meta
+        return ops.fill(shape, 1.0 / numel, dtype, device, gscale=g.float().reshape(1).contiguous())
+
+
+def mean_of(t):
+    """t.float().mean() as one reduction pass (+ one fill in backward): the terms of the SURVEY 8(d) benchmark loss."""
+    return _Mean.apply(t)
+
+
 class DiceCoefficient:
     """metrics.py:10-48: mean over channels of the thresholded (> 0.5) per-channel Dice, averaged over the batch."""
 

@@ -254,7 +254,7 @@ def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None)
 # capture the fork/join becomes a parallel branch of the graph.  Only calls whose targets are existing .grad buffers
 # (functional._targets "direct" accumulation, e.g. parallel.FlatGrads) may overlap: a freshly allocated gradient that
 # autograd consumes on the compute stream must be complete when backward() returns it.
-_WG = {"on": False, "streams": {}, "keep": [], "forked": set(), "pending": [], "batch": 12}
+_WG = {"on": False, "streams": {}, "keep": [], "forked": set(), "pending": [], "batch": 12, "defer": False, "deferred": []}
 
 
 def set_wgrad_overlap(enabled, batch=None):
@@ -289,6 +289,7 @@ def _flush_wgrads():
 def join_wgrad_stream():
     """Launches what is still pending and orders the compute stream behind every weight-gradient launch issued on the
     side stream since the last join."""
+    _flush_deferred()
     _flush_wgrads()
     for dev in list(_WG["forked"]):
         torch.cuda.current_stream(dev).wait_stream(_WG["streams"][dev])
@@ -296,14 +297,8 @@ def join_wgrad_stream():
     _WG["keep"].clear()
 
 
-def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=False):
-    """Accumulates into the fp32 tensors dws (and dbs, may be None) the weight/bias gradients.  side=True: the targets are
-    long-lived gradient buffers, so the launch may go to the weight-gradient stream when overlap is enabled."""
-    if side and _WG["on"] and xa.is_cuda:
-        _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre)))
-        if len(_WG["pending"]) >= _WG["batch"]:
-            _flush_wgrads()
-        return
+def _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre):
+    """Marshals one weight-gradient problem: (desc, ptrs, dw[4], db[4], keep-alive list)."""
     lib = L.load()
     n, cout, do, ho, wo, dy_bs = _vol(dy)
     _check_weights(dws, dbs, xa.shape[1] + (xb.shape[1] if xb is not None else 0), cout, groups, k, False, "conv3d_wgrad")
@@ -316,13 +311,57 @@ def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=
         ptrs.pre_sc, ptrs.pre_sh = _p(pre[0]), _p(pre[1])
     dw = _arr4([_f32(t, "dw") for t in dws])
     db = _arr4([_f32(t, "db") for t in (dbs or [])])
+    keep = [xa, xb, dy, pre, dws, dbs]
     need = lib.xh_conv3d_wgrad_workspace_bytes(C.byref(desc)) if _MFMA[0] else 0
     if need > 0:
         ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
         ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
-        if _WG["forked"]:
-            _WG["keep"].append(ws)
-    L.check(lib.xh_conv3d_wgrad(_stream(), C.byref(desc), C.byref(ptrs), C.byref(dw), C.byref(db)), "xh_conv3d_wgrad")
+        keep.append(ws)
+    return desc, ptrs, dw, db, keep
+
+
+def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=False):
+    """Accumulates into the fp32 tensors dws (and dbs, may be None) the weight/bias gradients.  side=True: the targets are
+    long-lived gradient buffers, so the call may be deferred and batched (set_wgrad_defer) or go to the weight-gradient
+    stream (set_wgrad_overlap)."""
+    if side and xa.is_cuda and _WG["defer"]:
+        _WG["deferred"].append(_wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre))
+        return
+    if side and _WG["on"] and xa.is_cuda:
+        _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre)))
+        if len(_WG["pending"]) >= _WG["batch"]:
+            _flush_wgrads()
+        return
+    desc, ptrs, dw, db, keep = _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre)
+    if _WG["forked"]:
+        _WG["keep"].append(keep)
+    L.check(L.load().xh_conv3d_wgrad(_stream(), C.byref(desc), C.byref(ptrs), C.byref(dw), C.byref(db)), "xh_conv3d_wgrad")
+
+
+def set_wgrad_defer(enabled):
+    """Collect the weight-gradient calls of a backward pass and issue them together at join_wgrad_stream() through
+    xh_conv3d_wgrad_batch: the k=3 MFMA problems share launches (default off; the caller must join before reading
+    gradients -- parallel.FlatGrads.all_reduce / .zero do)."""
+    if not enabled:
+        join_wgrad_stream()
+    _WG["defer"] = bool(enabled)
+
+
+def _flush_deferred():
+    calls = _WG["deferred"]
+    if not calls:
+        return
+    _WG["deferred"] = []
+    n = len(calls)
+    descs = (C.POINTER(L.ConvDesc) * n)(*[C.pointer(c[0]) for c in calls])
+    ptrs = (C.POINTER(L.ConvPtrs) * n)(*[C.pointer(c[1]) for c in calls])
+    dws = ((C.c_void_p * 4) * n)()
+    dbs = ((C.c_void_p * 4) * n)()
+    for i, c in enumerate(calls):
+        for j in range(4):
+            dws[i][j] = c[2][j]
+            dbs[i][j] = c[3][j]
+    L.check(L.load().xh_conv3d_wgrad_batch(_stream(), n, descs, ptrs, dws, dbs), "xh_conv3d_wgrad_batch")
 
 
 # ----------------------------------------------------------------------------------------------- norms
@@ -665,6 +704,9 @@ def loss_finalize(kind, red, count=1.0, eps=1e-6):
     n, c = red.shape[:2]
     out = torch.empty(c if kind == 2 else 1, dtype=torch.float32, device=red.device)
     ca = cb = None
+    if kind == 3:
+        L.check(L.load().xh_loss_finalize(_stream(), 3, _p(red), n, c, float(count), float(eps), _p(out), None, None), "xh_loss_finalize")
+        return out
     if kind < 2:
         ca, cb = (torch.empty((n, c), dtype=torch.float32, device=red.device) for _ in range(2))
     L.check(L.load().xh_loss_finalize(_stream(), kind, _p(red), n, c, float(count), float(eps), _p(out), _p(ca), _p(cb)),
@@ -696,7 +738,7 @@ def nested_weight(seg):
     return out
 
 
-def fill(shape, value, like):
-    out = torch.empty(shape, dtype=like.dtype, device=like.device)
-    L.check(L.load().xh_fill(_stream(), _dt(out), _p(out), out.numel(), float(value)), "xh_fill")
+def fill(shape, value, dtype, device, gscale=None):
+    out = torch.empty(shape, dtype=dtype, device=device)
+    L.check(L.load().xh_fill(_stream(), _dt(out), _p(out), out.numel(), float(value), _p(gscale)), "xh_fill")
     return out
