@@ -367,6 +367,32 @@ def extras(model, x, grads, nsteps):
         (bench_loss(a[0], a[1][0], a[1][1], a[2][0]) + bench_loss(b[0], b[1][0], b[1][1], b[2][0])).backward()
     res = {"forward_only_ms": timed(fwd_only), "two_forwards_fwd_bwd_ms": timed(two_plain),
            "two_forwards_shared_encoder_fwd_bwd_ms": timed(two_shared)}
+    # the reference's whole optimisation step (train.py:208-296) -- two shared-encoder generator forwards, the
+    # HIP loss epilogues, three discriminator passes (stock PyTorch modules: f1 is open) and both backward passes
+    try:
+        import xlstm_hved_amd as X
+        from xlstm_hved_amd.train_step import TrainStep
+        torch.manual_seed(2)
+        disc = X.Discriminator(in_channels=7)
+        disc.apply(X.init_weights)
+        disc = disc.to(x.device)
+        ts = TrainStep(model, disc, storage=x.dtype)
+        mask = (torch.rand(x.shape[0], 3, *x.shape[2:], device=x.device) > 0.7).float()
+
+        def train_step():
+            ts.compute(x, mask, [6])
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(3, nsteps // 4)):
+            train_step()
+        torch.cuda.synchronize()
+        res["train_step_eager_ms"] = (time.perf_counter() - t0) / max(3, nsteps // 4) * 1e3
+        res["train_step_note"] = ("train.py:208-296 without the optimizer updates: 2 generator forwards (shared encoder) + Dice/MSE/KLD/"
+                                  "LSGAN epilogues on HIP + 3 Discriminator passes (stock PyTorch under autocast) + both backward passes; eager")
+    except Exception as e:                                    # an extras failure must not cost the headline line
+        res["train_step_error"] = repr(e)[:200]
     # one 240 x 240 x 155 volume, 128^3 windows every 64 voxels (18 windows), posterior mean, eval mode
     from xlstm_hved_amd.inference import eval_overlap_volume
     vol = torch.rand(1, 4, 240, 240, 155, device=x.device).to(x.dtype)

@@ -1,0 +1,110 @@
+"""-m gpu: one optimisation step of train.py:208-296 (TrainStep: two shared-encoder forwards, HIP loss epilogues, LSGAN
+terms through the discriminator, generator + discriminator backward) against the same step assembled from the CPU oracle
+(two plain oracle forwards + oracle loss restatements + the same stock Discriminator on the CPU)."""
+import pytest
+import torch
+
+from gpu_common import load
+
+pytestmark = pytest.mark.gpu
+
+import xlstm_hved_amd as X  # noqa: E402
+import xlstm_hved_oracle as O  # noqa: E402
+from xlstm_hved_amd.train_step import TrainStep  # noqa: E402
+
+DEV = "cuda"
+ALPHA, BETA = 0.1, 0.2            # train.py:176-177
+
+
+def _inputs(S=32):
+    torch.manual_seed(7)
+    x = torch.rand(1, 4, S, S, S)
+    mask = (torch.rand(1, 3, S, S, S) > 0.7).float()
+    eps = [[torch.randn(1, 2 ** l, S >> (l + 1), S >> (l + 1), S >> (l + 1)) for l in range(4)] for _ in range(2)]
+    return x, mask, eps
+
+
+def _disc():
+    torch.manual_seed(11)
+    d = X.Discriminator(in_channels=7)
+    d.apply(X.init_weights)
+    return d
+
+
+def _oracle_step(w, disc, x, mask, eps, subset):
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+    f_out, _, _, _, f_rec = O.xlstm_hved_forward(sd, x, 14, eps_list=eps[0], training=True)
+    m_out, _, mu, lv, m_rec = O.xlstm_hved_forward(sd, x, subset[0], eps_list=eps[1], training=True)
+    dice, m_dice = O.dice_loss(f_out, mask), O.dice_loss(m_out, mask)
+    recon = ((m_rec - x) ** 2).mean()
+    kld = sum(O.compute_kld(mu[l], lv[l], subset) for l in range(4)) / 4
+    atten_f = f_rec.detach() * (1 + O.nested_weight(f_out.detach()))
+    atten_m = m_rec * (1 + O.nested_weight(m_out.detach()))
+    fake = torch.cat([m_out, atten_m], 1)
+    g_gan = ((disc(fake) - 1.0) ** 2).mean()
+    loss = dice + m_dice + BETA * recon + BETA * kld + ALPHA * g_gan
+    loss.backward()
+    gg = {k: v.grad.clone() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    for p in disc.parameters():
+        p.grad = None
+    real = torch.cat([f_out.detach(), atten_f], 1)
+    loss_d = ALPHA * 0.5 * ((disc(fake.detach()) ** 2).mean() + ((disc(real) - 1.0) ** 2).mean())
+    loss_d.backward()
+    gd = {k: p.grad.clone() for k, p in disc.named_parameters()}
+    return dict(dice=dice, m_dice=m_dice, recon=recon, kld=kld, g_gan=g_gan, loss=loss, loss_d=loss_d), gg, gd
+
+
+@pytest.mark.parametrize("shared", [True, False], ids=["shared_encoder", "two_forwards"])
+def test_train_step_fp32_vs_oracle(shared):
+    x, mask, eps = _inputs()
+    subset = [6]
+    w = load("weights_seed1")
+    want, gg, gd = _oracle_step(w, _disc(), x, mask, eps, subset)
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(w, strict=True)
+    m = m.to(DEV).train()
+    ts = TrainStep(m, _disc().to(DEV), alpha=ALPHA, beta=BETA, storage=torch.float32, shared_encoder=shared)
+    eps_dev = [[e.to(DEV) for e in el] for el in eps]
+    got = ts.compute(x.to(DEV), mask.to(DEV), subset, eps_lists=eps_dev)
+    torch.cuda.synchronize()
+    for k in ("dice", "m_dice", "recon", "kld", "g_gan", "loss", "loss_d"):
+        a, b = got[k].item(), want[k].item()
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (k, a, b)
+    gscale = max(v.abs().max().item() for v in gg.values())
+    worst, num, den = 0.0, 0.0, 0.0
+    for k, p in m.named_parameters():
+        if k.startswith("init_blocks."):
+            continue                                  # mathematically zero gradient behind an InstanceNorm
+        kk = k.replace("decoders.", "srdecoder.sdecoders.", 1) if k.startswith("decoders.") else k
+        if kk in gg:
+            e = (p.grad.cpu() - gg[kk]).abs().max().item() / gscale
+            worst = max(worst, e)
+            num += ((p.grad.cpu() - gg[kk]) ** 2).sum().item()
+            den += (gg[kk] ** 2).sum().item()
+            # fp32 vs fp32 on a network that amplifies round-off ~1e4x: 2e-2 of the largest gradient per tensor,
+            # 5e-3 relative L2 over all of them
+            assert e < 2e-2, (k, e)
+    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5
+    dscale = max(v.abs().max().item() for v in gd.values())
+    for k, p in ts.disc.named_parameters():
+        assert (p.grad.cpu() - gd[k]).abs().max().item() <= 5e-3 * dscale, k
+    print(f"train step ({'shared encoder' if shared else 'two forwards'}): loss {got['loss'].item():.6f} (oracle {want['loss'].item():.6f}), "
+          f"worst scaled generator-gradient deviation {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_train_step_16bit_runs_and_updates(dtype):
+    x, mask, _ = _inputs(64)
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(load("weights_seed1"), strict=True)
+    m = m.to(DEV).train()
+    d = _disc().to(DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt_d = torch.optim.Adam(d.parameters(), lr=1e-4)
+    ts = TrainStep(m, d, opt, opt_d, storage=dtype)
+    before = m.final_conv.weight.detach().clone()
+    parts = ts.step(x.to(DEV), mask.to(DEV), [3])
+    torch.cuda.synchronize()
+    assert ts.check_finite() and torch.isfinite(parts["loss"]) and torch.isfinite(parts["loss_d"])
+    assert not torch.equal(before, m.final_conv.weight.detach())
+    assert ts.loss_scale == (65536.0 if dtype == torch.float16 else 1.0)
