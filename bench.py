@@ -368,7 +368,7 @@ def extras(model, x, grads, nsteps):
     res = {"forward_only_ms": timed(fwd_only), "two_forwards_fwd_bwd_ms": timed(two_plain),
            "two_forwards_shared_encoder_fwd_bwd_ms": timed(two_shared)}
     # the reference's whole optimisation step (train.py:208-296) -- two shared-encoder generator forwards, the
-    # HIP loss epilogues, three discriminator passes (stock PyTorch modules: f1 is open) and both backward passes
+    # HIP loss epilogues, three discriminator passes (channels-last implicit-GEMM MFMA convolutions) and both backward passes
     try:
         import xlstm_hved_amd as X
         from xlstm_hved_amd.train_step import TrainStep
@@ -390,7 +390,7 @@ def extras(model, x, grads, nsteps):
         torch.cuda.synchronize()
         res["train_step_eager_ms"] = (time.perf_counter() - t0) / max(3, nsteps // 4) * 1e3
         res["train_step_note"] = ("train.py:208-296 without the optimizer updates: 2 generator forwards (shared encoder) + Dice/MSE/KLD/"
-                                  "LSGAN epilogues on HIP + 3 Discriminator passes (stock PyTorch under autocast) + both backward passes; eager")
+                                  "LSGAN epilogues on HIP + 3 Discriminator passes (csrc/dconv.hip implicit GEMMs) + both backward passes; eager")
     except Exception as e:                                    # an extras failure must not cost the headline line
         res["train_step_error"] = repr(e)[:200]
     # one 240 x 240 x 155 volume, 128^3 windows every 64 voxels (18 windows), posterior mean, eval mode

@@ -24,9 +24,9 @@ def _inputs(S=32):
     return x, mask, eps
 
 
-def _disc():
+def _disc(hip=False):
     torch.manual_seed(11)
-    d = X.Discriminator(in_channels=7)
+    d = (X.Discriminator if hip else X.DiscriminatorReference)(in_channels=7)
     d.apply(X.init_weights)
     return d
 
@@ -98,7 +98,7 @@ def test_train_step_16bit_runs_and_updates(dtype):
     m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     m.load_state_dict(load("weights_seed1"), strict=True)
     m = m.to(DEV).train()
-    d = _disc().to(DEV)
+    d = _disc(hip=True).to(DEV)
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     opt_d = torch.optim.Adam(d.parameters(), lr=1e-4)
     ts = TrainStep(m, d, opt, opt_d, storage=dtype)

@@ -1,0 +1,605 @@
+// Discriminator convolutions (RA_HVED.py:204-236, buildingblocks.py:342-358) as implicit GEMMs on the matrix cores.
+//
+// The discriminator is the one MFMA-bound object of a training step (7 -> 64 -> 128 -> 256 -> 512 -> 1 channels,
+// k = 3, strides 1,2,2,2,1; ~250 GFLOP per forward at 128^3, three passes per step) and it is self-contained, so inside it the
+// activations are kept CHANNELS-LAST ([n][d][h][w][C], 16-bit): the K axis of the GEMM (input channels of one tap) is then
+// contiguous in memory and a 16 x 32 MFMA operand row is one 64-byte run of one voxel -- no im2col buffer, no transposition.
+//
+//   forward      Y[m][co] = sum_{tap, ci} X[src(m, tap)][ci] * W[co][ci][tap]          M = voxels, N = Cout, K = 27 * Cin
+//   data grad    dX[m][ci] = sum_{tap, co} dY[src'(m, tap)][co] * W[co][ci][tap]       same kernel, roles swapped; for stride 2
+//                the destination voxels are processed in their 8 parity classes so that only the taps that reach a class are
+//                walked (27 tap visits in total instead of 8 x 27)
+//   weight grad  dW[tap][co][ci] = sum_m dY[m][co] * X[src(m, tap)][ci]                M = Cout, N = Cin, K = voxels: both operands
+//                are needed K(voxel)-major, i.e. transposed -- staged row-major in LDS and read with ds_read_b64_tr_b16
+//
+// Workgroup = 4 waves, tile 128 x 128 (or 256 x 16 for the 8-channel ends), K step 32, two LDS buffers, register-staged
+// loads one step ahead, mfma_f32_16x16x32 with a 4 x 4 accumulator block per wave.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+struct DTaps { int n; int t[3]; int off[3]; };
+
+struct DConvK {
+  const u16* x; const u16* w; const float* bias; u16* y; double* red;
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn;
+  int Jd, Jh, Jw;          // rows of this launch per sample: (jd, jh, jw), destination index = j * omul + p
+  int omul, pd, ph, pw;
+  int smul;                // source index = j * smul + off[tap]
+  DTaps td, th, tw;
+  int rowmode;             // 1: Cs == 8: one K step = the 3 kw taps x 8 channels of a row (+ 8 zero-weight), tw ignored
+  int act; float slope;
+  int wtap_stride;         // elements between consecutive taps in w (= Cn * Kc)
+  int Kc;                  // K extent of one step group in w rows (Cs, or 32 in rowmode)
+};
+
+// LDS images: rows of 64 bytes (32 x 16-bit), the 16-byte chunk index XORed with (row >> 2) & 3 so that the 16 rows a
+// ds_read_b128 lane group touches land on all 64 banks
+__device__ __forceinline__ int sw64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int FMT, int WGN, int TN>
+__global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
+  constexpr int WGM = 4 / WGN;
+  constexpr int BM = WGM * 64, BN = WGN * TN * 16;
+  constexpr int AB = BM * 64, BB = BN * 64;              // bytes per A / B buffer
+  constexpr int NA = BM * 4 / 256, NB = (BN * 4 + 255) / 256;
+  constexpr int OUTB = BM * BN * 2;
+  constexpr int SM = 2 * (AB + BB) > OUTB ? 2 * (AB + BB) : OUTB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WGN, wn = wv % WGN;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int n = blockIdx.z, mt = blockIdx.x, cn0 = blockIdx.y * BN;
+  const int R = a.Jd * a.Jh * a.Jw;
+
+  // ---- staging plan: A rows (source voxel base coordinates), B columns ----
+  int a_row[NA], a_sd[NA], a_sh[NA], a_sw[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (tid >> 2) + i * 64;
+    const int m = mt * BM + row;
+    a_row[i] = row;
+    a_ok[i] = m < R;
+    const int mm = a_ok[i] ? m : 0;
+    const int jw = mm % a.Jw, t2 = mm / a.Jw;
+    const int jh = t2 % a.Jh, jd = t2 / a.Jh;
+    a_sd[i] = jd * a.smul; a_sh[i] = jh * a.smul; a_sw[i] = jw * a.smul;
+  }
+  const int ch = tid & 3;
+  const long long xs_n = (long long)n * a.Di * a.Hi * a.Wi;
+  uint4 ra[NA], rb[NB];
+  const int nsteps_c = a.rowmode ? 1 : a.Cs / 32;
+  const int ntw = a.rowmode ? 1 : a.tw.n;
+  const int nsteps = a.td.n * a.th.n * ntw * nsteps_c;
+
+  auto load_step = [&](int s) {
+    const int cs = s % nsteps_c; int t = s / nsteps_c;
+    const int iw = t % ntw; t /= ntw;
+    const int ih = t % a.th.n, id = t / a.th.n;
+    const int tap = a.rowmode ? (a.td.t[id] * 3 + a.th.t[ih]) : ((a.td.t[id] * 3 + a.th.t[ih]) * 3 + a.tw.t[iw]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int d = a_sd[i] + a.td.off[id], h = a_sh[i] + a.th.off[ih];
+      int w = a_sw[i] + (a.rowmode ? (ch - 1) : a.tw.off[iw]);
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi) {
+        const u16* p = a.x + ((xs_n + ((long long)d * a.Hi + h) * a.Wi + w) * a.Cs) + (a.rowmode ? 0 : cs * 32 + ch * 8);
+        ra[i] = *reinterpret_cast<const uint4*>(p);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int col = (tid >> 2) + i * 64;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (col < BN && cn0 + col < a.Cn)
+        rb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)(cn0 + col) * a.Kc + cs * 32 + ch * 8);
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned char* As = smem + buf * (AB + BB);
+    unsigned char* Bs = As + AB;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + sw64(a_row[i], ch)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int col = (tid >> 2) + i * 64;
+      if (col < BN) *reinterpret_cast<uint4*>(Bs + sw64(col, ch)) = rb[i];
+    }
+  };
+
+  f32x4_t acc[4][TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_step(s + 1);
+    const unsigned char* As = smem + buf * (AB + BB);
+    const unsigned char* Bs = As + AB;
+    h16x8 af[4], bf[TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const h16x8*>(As + sw64(wm * 64 + i * 16 + r16, kg));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h16x8*>(Bs + sw64((wn * TN + j) * 16 + r16, kg));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
+    if (s + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, activation, rounding, column sums (InstanceNorm statistics), tile transposed through LDS ----
+  u16* s_out = reinterpret_cast<u16*>(smem);              // [BM][BN]; every wave is past its last fragment read (barrier above)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = (wn * TN + j) * 16 + r16;
+    const int cn = cn0 + col;
+    const float bias = (a.bias && cn < a.Cn) ? a.bias[cn] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + i * 16 + kg * 4 + r;
+        float v = acc[i][j][r] + bias;
+        if (a.act == XH_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+        const u16 q = cvt_out<FMT>(v);
+        s_out[row * BN + col] = q;
+        if (a.red && mt * BM + row < R) { const float vr = cvt_in<FMT>(q); s0 += (double)vr; s1 += (double)vr * (double)vr; }
+      }
+    if (a.red) {
+      s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      if (kg == 0 && cn < a.Cn) {
+        atomicAdd(&a.red[((long long)n * a.Cn + cn) * 2], s0);
+        atomicAdd(&a.red[((long long)n * a.Cn + cn) * 2 + 1], s1);
+      }
+    }
+  }
+  __syncthreads();
+  const long long ys_n = (long long)n * a.Do * a.Ho * a.Wo;
+  constexpr int CPR = BN / 8;                             // 16-byte chunks per tile row
+  for (int c = tid; c < BM * CPR; c += 256) {
+    const int row = c / CPR, part = c % CPR;
+    const int m = mt * BM + row;
+    if (m >= R) continue;
+    const int jw = m % a.Jw, t2 = m / a.Jw;
+    const int jh = t2 % a.Jh, jd = t2 / a.Jh;
+    const long long vox = ys_n + ((long long)(jd * a.omul + a.pd) * a.Ho + (jh * a.omul + a.ph)) * a.Wo + (jw * a.omul + a.pw);
+    const int cn = cn0 + part * 8;
+    if (cn + 8 <= a.Cn && (a.Cn & 7) == 0) {
+      *reinterpret_cast<uint4*>(a.y + vox * a.Cn + cn) = *reinterpret_cast<const uint4*>(s_out + row * BN + part * 8);
+    } else {
+      for (int e = 0; e < 8 && cn + e < a.Cn; ++e) a.y[vox * a.Cn + cn + e] = s_out[row * BN + part * 8 + e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient: dw[tap][cn][cs] += sum_m dY[m][cn] * X[src(m, tap)][cs]   (fp32, packed order; split over voxel ranges)
+struct DWgK {
+  const u16* x; const u16* dy; float* dw;
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn, stride;
+  int msplit;              // voxel-range splits (grid z = 27 * msplit)
+  long long M;             // N * Do * Ho * Wo
+};
+// LDS image of a [32 voxel][128 channel] tile for transposed reads: 256-byte rows, the 16-byte chunk index XORed with
+// ((row & 3) << 2) | ((row >> 2) & 3)  (conflict-free ds_read_b64_tr_b16 of 4-row blocks)
+__device__ __forceinline__ int sw256(int row, int chunk) { return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+template <int FMT, int WGN, int TMW, int TNW>
+__global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
+  // waves: WGM x WGN over (cn, cs); a wave owns TMW x TNW tiles of 16 x 16
+  constexpr int WGM = 4 / WGN;
+  constexpr int BMc = WGM * TMW * 16, BNc = WGN * TNW * 16;   // channels of dY / of X per workgroup (<= 128 each)
+  constexpr int TB = 32 * 256;                              // bytes per staged tile (32 voxels x 128 channels)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WGN, wn = wv % WGN;
+  const int r16 = lane & 15, kg = lane >> 4, q = r16 >> 2, p = r16 & 3;
+  const int cs0 = blockIdx.x * BNc, cn0 = blockIdx.y * BMc;
+  const int tap = blockIdx.z % 27, split = blockIdx.z / 27;
+  const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+  const long long per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
+  const long long m_begin = (long long)split * per, m_end = m_begin + per < a.M ? m_begin + per : a.M;
+  // staging: a tile is 32 rows x 16 chunks = 512 chunks -> 2 per thread per operand
+  uint4 ry[2], rx[2];
+  auto load_step = [&](long long m0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int row = c >> 4, chn = c & 15;
+      const long long m = m0 + row;
+      ry[i] = rx[i] = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        if (cn0 + chn * 8 < a.Cn && chn * 8 < BMc) ry[i] = *reinterpret_cast<const uint4*>(a.dy + m * a.Cn + cn0 + chn * 8);
+        if (cs0 + chn * 8 < a.Cs && chn * 8 < BNc) {
+          long long t = m;
+          const int ow = (int)(t % a.Wo); t /= a.Wo;
+          const int oh = (int)(t % a.Ho); t /= a.Ho;
+          const int od = (int)(t % a.Do); const int n = (int)(t / a.Do);
+          const int d = od * a.stride + kd - 1, h = oh * a.stride + kh - 1, w = ow * a.stride + kw - 1;
+          if ((unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi)
+            rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)n * a.Di + d) * a.Hi + h) * a.Wi + w) * a.Cs + cs0 + chn * 8);
+        }
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned char* Ys = smem + buf * 2 * TB;
+    unsigned char* Xs = Ys + TB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int row = c >> 4, chn = c & 15;
+      *reinterpret_cast<uint4*>(Ys + sw256(row, chn)) = ry[i];
+      *reinterpret_cast<uint4*>(Xs + sw256(row, chn)) = rx[i];
+    }
+  };
+  f32x4_t acc[TMW][TNW];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (m_begin < m_end) {
+    load_step(m_begin);
+    store_step(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long long m0 = m_begin; m0 < m_end; m0 += 32, buf ^= 1) {
+    if (m0 + 32 < m_end) load_step(m0 + 32);
+    const unsigned char* Ys = smem + buf * 2 * TB;
+    const unsigned char* Xs = Ys + TB;
+    // transposed fragments: lane (i = r16, kg) needs tile[8 kg + e][c0 + i], e = 0..7 = two 4-row blocks; within a 16-lane
+    // group lane 4q + p supplies the address of row (block row q), columns c0 + 4p .. +3
+    h16x8 af[TMW], bf[TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+      const int c0 = (wm * TMW + i) * 16;                   // first channel of the tile
+      const int chn = (c0 >> 3) + (p >> 1);
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Ys + sw256(8 * kg + q, chn) + 8 * (p & 1)));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Ys + sw256(8 * kg + 4 + q, chn) + 8 * (p & 1)));
+      af[i] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int c0 = (wn * TNW + j) * 16;
+      const int chn = (c0 >> 3) + (p >> 1);
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Xs + sw256(8 * kg + q, chn) + 8 * (p & 1)));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Xs + sw256(8 * kg + 4 + q, chn) + 8 * (p & 1)));
+      bf[j] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
+    if (m0 + 32 < m_end) store_step(buf ^ 1);
+    __syncthreads();
+  }
+  // D[i = cn][j = cs]: lane holds column cs = r16, rows cn = 4 kg + r
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int cs = cs0 + (wn * TNW + j) * 16 + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cn = cn0 + (wm * TMW + i) * 16 + kg * 4 + r;
+        if (cn < a.Cn && cs < a.Cs) atomicAdd(&a.dw[((long long)tap * a.Cn + cn) * a.Cs + cs], acc[i][j][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// parameter-sized helpers: weight packing / gradient unpacking
+//  mode 0 forward:   out[tap][co (< Cout)][ci (< CinPad)]        = w[co][ci][tap]      (zero for ci >= Cin)
+//  mode 1 data grad: out[tap][ci (< CinPad)][co (< CoutPad)]     = w[co][ci][tap]      (zero rows / columns beyond Cin / Cout)
+//  mode 2 row mode (CinPad == 8): out[(kd,kh)][co][kw * 8 + ci]  = w[co][ci][(kd,kh,kw)], zero for k >= 24
+__global__ __launch_bounds__(256) void dpack_kernel(const float* w, u16* out, int Cout, int Cin, int CoutPad, int CinPad, int mode, int fmt,
+                                                   long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = 0.f;
+  if (mode == 0) {
+    const int ci = (int)(i % CinPad); long long t = i / CinPad;
+    const int co = (int)(t % Cout); const int tap = (int)(t / Cout);
+    if (ci < Cin) v = w[((long long)co * Cin + ci) * 27 + tap];
+  } else if (mode == 1) {
+    const int co = (int)(i % CoutPad); long long t = i / CoutPad;
+    const int ci = (int)(t % CinPad); const int tap = (int)(t / CinPad);
+    if (ci < Cin && co < Cout) v = w[((long long)co * Cin + ci) * 27 + tap];
+  } else {
+    const int k = (int)(i % 32); long long t = i / 32;
+    const int co = (int)(t % Cout); const int r9 = (int)(t / Cout);
+    const int kw = k >> 3, ci = k & 7;
+    if (kw < 3 && ci < Cin) v = w[((long long)co * Cin + ci) * 27 + r9 * 3 + kw];
+  }
+  out[i] = fmt ? f2hf(v) : f2bf(v);
+}
+// dw_param[co][ci][tap] += dwp[tap][co (row stride CoutPad rows)][ci (< CinPad)]
+__global__ __launch_bounds__(256) void dunpack_kernel(const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int tap = (int)(i % 27); long long t = i / 27;
+  const int ci = (int)(t % Cin); const int co = (int)(t / Cin);
+  dw[i] += dwp[((long long)tap * CoutPad + co) * CinPad + ci];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// channels-last elementwise stages
+//  cl_from: NCDHW sources (CA channels of xa, CB of xb) -> [n][v][Cpad] (zero padded);  cl_to: the adjoint (split back)
+template <typename T>
+__global__ __launch_bounds__(256) void cl_from_kernel(const T* xa, long long xa_bs, int CA, const T* xb, long long xb_bs, int CB, u16* out,
+                                                     int Cpad, long long V, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // over N * V
+  if (i >= total) return;
+  const long long n = i / V, v = i % V;
+  for (int c = 0; c < Cpad; ++c) {
+    float f = 0.f;
+    if (c < CA) f = ldf(xa, n * xa_bs + (long long)c * V + v);
+    else if (c < CA + CB) f = ldf(xb, n * xb_bs + (long long)(c - CA) * V + v);
+    out[i * Cpad + c] = cvt_out<FmtOf<T>::v>(f);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cl_to_kernel(const u16* g, int Cpad, T* da, long long da_bs, int CA, T* db, long long db_bs, int CB,
+                                                   long long V, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long n = i / V, v = i % V;
+  for (int c = 0; c < CA + CB; ++c) {
+    const float f = cvt_in<FmtOf<T>::v>(g[i * Cpad + c]);
+    if (c < CA) stf(da, n * da_bs + (long long)c * V + v, f);
+    else stf(db, n * db_bs + (long long)(c - CA) * V + v, f);
+  }
+}
+
+// y = leaky(x * sc[n,c] + sh[n,c], slope) on [n][v][C]; one thread = 8 channels of one voxel
+template <int FMT>
+__global__ __launch_bounds__(256) void cl_affine_act_kernel(const u16* x, u16* y, const float* sc, const float* sh, float slope, int C,
+                                                           long long V, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // over N * V * C/8
+  if (i >= total) return;
+  const int c8 = C >> 3;
+  const int cc = (int)(i % c8) * 8;
+  const long long n = (i / c8) / V;
+  const uint4 t = *reinterpret_cast<const uint4*>(x + i * 8);
+  const unsigned u[4] = {t.x, t.y, t.z, t.w};
+  unsigned o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float* s0 = sc + n * C + cc + 2 * k;
+    const float* h0 = sh + n * C + cc + 2 * k;
+    const float a0 = leaky(cvt_lo<FMT>(u[k]) * s0[0] + h0[0], slope), a1 = leaky(cvt_hi<FMT>(u[k]) * s0[1] + h0[1], slope);
+    o[k] = cvt_pack<FMT>(a0, a1);
+  }
+  *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// backward through y = leaky(x*sc + sh): g = dy * leaky'(.)
+//  MODE 0: red[n][c][0] += sum_v g, red[n][c][1] += sum_v g*x        (reduce only)
+//  MODE 1: dx = A[n,c]*g + Cc[n,c]*x + B[n,c]                       (norm backward apply)
+//  MODE 2: dx = g and red[n][c][0] += sum_v g                       (plain activation backward + bias gradient)
+// grid (blocks over voxels, C/8 groups... ) -- one thread walks voxels of its 8 channels
+template <int FMT, int MODE>
+__global__ __launch_bounds__(256) void cl_bwd_kernel(const u16* dy, const u16* x, u16* dx, const float* sc, const float* sh, float slope,
+                                                    const float* A, const float* B, const float* Cc, double* red, int C, long long V,
+                                                    int vchunk) {
+  // block: 256 threads = (256 / c8) voxel lanes x c8 channel groups when c8 <= 256
+  const int c8 = C >> 3;
+  const int cg = threadIdx.x % c8, vl = threadIdx.x / c8, nvl = 256 / c8;
+  const int n = blockIdx.y;
+  const long long v0 = (long long)blockIdx.x * vchunk, v1 = v0 + vchunk < V ? v0 + vchunk : V;
+  const int cc = cg * 8;
+  float fs[8], fh[8], fA[8], fB[8], fC[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    fs[k] = sc ? sc[n * C + cc + k] : 1.f; fh[k] = sh ? sh[n * C + cc + k] : 0.f;
+    if (MODE == 1) { fA[k] = A[n * C + cc + k]; fB[k] = B[n * C + cc + k]; fC[k] = Cc[n * C + cc + k]; }
+  }
+  double s0[8], s1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
+  if (vl < nvl)
+    for (long long v = v0 + vl; v < v1; v += nvl) {
+      const long long o = ((long long)n * V + v) * C + cc;
+      const uint4 td = *reinterpret_cast<const uint4*>(dy + o);
+      const uint4 tx = *reinterpret_cast<const uint4*>(x + o);
+      const unsigned ud[4] = {td.x, td.y, td.z, td.w}, ux[4] = {tx.x, tx.y, tx.z, tx.w};
+      unsigned oo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float g[2], xv[2] = {cvt_lo<FMT>(ux[k]), cvt_hi<FMT>(ux[k])};
+        g[0] = cvt_lo<FMT>(ud[k]); g[1] = cvt_hi<FMT>(ud[k]);
+        float r[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int kk = 2 * k + e;
+          if ((xv[e] * fs[kk] + fh[kk]) <= 0.f) g[e] *= slope;
+          if (MODE == 0) { s0[kk] += (double)g[e]; s1[kk] += (double)g[e] * (double)xv[e]; }
+          if (MODE == 1) r[e] = fA[kk] * g[e] + fC[kk] * xv[e] + fB[kk];
+          if (MODE == 2) { r[e] = g[e]; s0[kk] += (double)cvt_in<FMT>(cvt_out<FMT>(g[e])); }
+        }
+        if (MODE != 0) oo[k] = cvt_pack<FMT>(r[0], r[1]);
+      }
+      if (MODE != 0) *reinterpret_cast<uint4*>(dx + o) = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+    }
+  if (MODE != 1) {
+    __shared__ double s_acc[2][512];                   // [which][c8 * 8] (C <= 512)
+    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&s_acc[0][0])[i] = 0.0;
+    __syncthreads();
+    if (vl < nvl)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&s_acc[0][cc + k], s0[k]);
+        if (MODE == 0) atomicAdd(&s_acc[1][cc + k], s1[k]);
+      }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      atomicAdd(&red[((long long)n * C + c) * 2], s_acc[0][c]);
+      if (MODE == 0) atomicAdd(&red[((long long)n * C + c) * 2 + 1], s_acc[1][c]);
+    }
+  }
+}
+
+// =================================================================================================================
+// host entry points
+// =================================================================================================================
+static void fill_taps(DTaps* t, int mode, int stride, int parity) {
+  // mode 0 forward: all taps, source = j*stride + (t - 1);  mode 1 data gradient: stride 1: source = j + 1 - t;
+  // stride 2: destination o = 2j + parity; parity 0 -> tap 1 (source j), parity 1 -> taps 0 (source j + 1), 2 (source j)
+  if (mode == 0) { t->n = 3; for (int k = 0; k < 3; ++k) { t->t[k] = k; t->off[k] = k - 1; } return; }
+  if (stride == 1) { t->n = 3; for (int k = 0; k < 3; ++k) { t->t[k] = k; t->off[k] = 1 - k; } return; }
+  if (parity == 0) { t->n = 1; t->t[0] = 1; t->off[0] = 0; return; }
+  t->n = 2; t->t[0] = 0; t->off[0] = 1; t->t[1] = 2; t->off[1] = 0;
+}
+
+template <int FMT>
+static void launch_dconv(hipStream_t st, const DConvK& a, int N) {
+  const int R = a.Jd * a.Jh * a.Jw;
+  if (a.Cn <= 16) {
+    dim3 grid(cdiv(R, 256), cdiv(a.Cn, 16), N);
+    hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid(cdiv(R, 128), cdiv(a.Cn, 128), N);
+    hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4>), grid, dim3(256), 0, st, a);
+  }
+}
+
+// Channels-last k=3, pad=1 convolution of the discriminator.  mode 0: forward (x: [N][Di..][Cs] -> y: [N][Do..][Cn],
+// Do = (Di - 1)/stride + 1); mode 1: data gradient (x = dY [N][Di..][Cs = Cout], y = dX [N][Do..][Cn = Cin_pad], Di = (Do-1)/stride+1).
+// w: weights packed by xh_dconv_pack (mode 0/2 for forward, 1 for the data gradient).  bias/red optional (forward).
+extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const void* x, const void* w, const float* bias, void* y,
+                           double* red, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope) {
+  if (!x || !w || !y || N <= 0 || N > 65535 || Cs <= 0 || Cn <= 0) return XH_ERR_ARG;
+  if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
+  if (!(stride == 1 || stride == 2) || (mode != 0 && mode != 1)) return XH_ERR_ARG;
+  const bool rowmode = mode == 0 && Cs == 8;
+  if (!rowmode && (Cs % 32)) return XH_ERR_ARG;
+  if (rowmode && stride != 1) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DConvK a;
+  a.x = (const u16*)x; a.w = (const u16*)w; a.bias = bias; a.y = (u16*)y; a.red = red;
+  a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn;
+  a.rowmode = rowmode ? 1 : 0; a.act = act; a.slope = slope;
+  a.Kc = rowmode ? 32 : Cs;
+  a.wtap_stride = Cn * a.Kc;
+  const int classes = (mode == 1 && stride == 2) ? 8 : 1;
+  for (int cls = 0; cls < classes; ++cls) {
+    const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+    a.omul = classes == 8 ? 2 : 1; a.pd = pd; a.ph = ph; a.pw = pw;
+    a.smul = mode == 0 ? stride : 1;
+    a.Jd = classes == 8 ? (Do - pd + 1) / 2 : Do;
+    a.Jh = classes == 8 ? (Ho - ph + 1) / 2 : Ho;
+    a.Jw = classes == 8 ? (Wo - pw + 1) / 2 : Wo;
+    if (a.Jd <= 0 || a.Jh <= 0 || a.Jw <= 0) continue;
+    fill_taps(&a.td, mode, stride, pd); fill_taps(&a.th, mode, stride, ph); fill_taps(&a.tw, mode, stride, pw);
+    if (dtype == XH_F16) launch_dconv<1>(st, a, N); else launch_dconv<0>(st, a, N);
+  }
+  return xh_launch_status();
+}
+
+// dwp[tap][Cn][Cs] (fp32, caller zeroes) += sum over output voxels of dY[m][cn] * X[src][cs]
+extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void* x, const void* dy, float* dwp, int N, int Di, int Hi,
+                                 int Wi, int Do, int Ho, int Wo, int Cs, int Cn) {
+  if (!x || !dy || !dwp || N <= 0 || (Cs % 8) || (Cn % 8)) return XH_ERR_ARG;
+  if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
+  DWgK a;
+  a.x = (const u16*)x; a.dy = (const u16*)dy; a.dw = dwp;
+  a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn; a.stride = stride;
+  a.M = (long long)N * Do * Ho * Wo;
+  hipStream_t st = (hipStream_t)stream;
+  const bool narrow = Cs <= 16;
+  const int bn = narrow ? 16 : 128, bm = narrow ? 64 : 128;
+  const int tiles = cdiv(Cs, bn) * cdiv(Cn, bm);
+  int msplit = cdiv(1024, tiles * 27);
+  const long long max_split = a.M / 512 > 0 ? a.M / 512 : 1;
+  if (msplit > max_split) msplit = (int)max_split;
+  if (msplit < 1) msplit = 1;
+  a.msplit = msplit;
+  dim3 grid(cdiv(Cs, bn), cdiv(Cn, bm), 27 * msplit);
+  if (narrow) {
+    if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_cl_kernel<1, 1, 1, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwgrad_cl_kernel<0, 1, 1, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_cl_kernel<1, 2, 4, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwgrad_cl_kernel<0, 2, 4, 4>), grid, dim3(256), 0, st, a);
+  }
+  return xh_launch_status();
+}
+
+extern "C" int xh_dconv_pack(void* stream, int dtype, int mode, const float* w, void* out, int Cout, int Cin, int CoutPad, int CinPad) {
+  if (!w || !out || mode < 0 || mode > 2 || CoutPad < Cout || CinPad < Cin) return XH_ERR_ARG;
+  const long long total = mode == 2 ? 9LL * Cout * 32 : (mode == 0 ? 27LL * Cout * CinPad : 27LL * CinPad * CoutPad);
+  hipLaunchKernelGGL(dpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u16*)out, Cout, Cin, CoutPad,
+                     CinPad, mode, dtype == XH_F16 ? 1 : 0, total);
+  return xh_launch_status();
+}
+extern "C" int xh_dconv_unpack_grad(void* stream, const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad) {
+  if (!dwp || !dw || CoutPad < Cout || CinPad < Cin) return XH_ERR_ARG;
+  const long long total = 27LL * Cout * Cin;
+  hipLaunchKernelGGL(dunpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dwp, dw, Cout, Cin, CoutPad, CinPad, total);
+  return xh_launch_status();
+}
+
+extern "C" int xh_cl_from_ncdhw(void* stream, int dtype, const void* xa, long long xa_bs, int CA, const void* xb, long long xb_bs, int CB,
+                                void* out, int Cpad, int N, long long V) {
+  if (!xa || !out || CA + CB > Cpad) return XH_ERR_ARG;
+  if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
+  const long long total = (long long)N * V;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XH_F16) hipLaunchKernelGGL(cl_from_kernel<f16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const f16_t*)xa, xa_bs, CA, (const f16_t*)xb, xb_bs, CB, (u16*)out, Cpad, V, total);
+  else hipLaunchKernelGGL(cl_from_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)xa, xa_bs, CA, (const bf16_t*)xb, xb_bs, CB, (u16*)out, Cpad, V, total);
+  return xh_launch_status();
+}
+extern "C" int xh_cl_to_ncdhw(void* stream, int dtype, const void* g, int Cpad, void* da, long long da_bs, int CA, void* db, long long db_bs,
+                              int CB, int N, long long V) {
+  if (!g || !da || CA + CB > Cpad) return XH_ERR_ARG;
+  if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
+  const long long total = (long long)N * V;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XH_F16) hipLaunchKernelGGL(cl_to_kernel<f16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u16*)g, Cpad, (f16_t*)da, da_bs, CA, (f16_t*)db, db_bs, CB, V, total);
+  else hipLaunchKernelGGL(cl_to_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u16*)g, Cpad, (bf16_t*)da, da_bs, CA, (bf16_t*)db, db_bs, CB, V, total);
+  return xh_launch_status();
+}
+
+extern "C" int xh_cl_affine_act(void* stream, int dtype, const void* x, void* y, const float* sc, const float* sh, float slope, int N, int C,
+                                long long V) {
+  if (!x || !y || !sc || !sh || (C % 8)) return XH_ERR_ARG;
+  if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
+  const long long total = (long long)N * V * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XH_F16) hipLaunchKernelGGL(cl_affine_act_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u16*)x, (u16*)y, sc, sh, slope, C, V, total);
+  else hipLaunchKernelGGL(cl_affine_act_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u16*)x, (u16*)y, sc, sh, slope, C, V, total);
+  return xh_launch_status();
+}
+
+// mode 0: reduce (red += [sum g, sum g*x]); 1: dx = A*g + Cc*x + B; 2: dx = g, red[..][0] += sum g.   g = dy * leaky'(x*sc + sh)
+extern "C" int xh_cl_act_bwd(void* stream, int dtype, int mode, const void* dy, const void* x, void* dx, const float* sc, const float* sh,
+                             float slope, const float* A, const float* B, const float* Cc, double* red, int N, int C, long long V) {
+  if (!dy || !x || (C % 8) || C > 512 || (256 % (C / 8)) || mode < 0 || mode > 2) return XH_ERR_ARG;
+  if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
+  if ((mode != 0 && !dx) || (mode != 1 && !red) || (mode == 1 && (!A || !B || !Cc))) return XH_ERR_ARG;
+  const int nvl = 256 / (C / 8);
+  long long blocks = (V + nvl * 16 - 1) / (nvl * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  const int vchunk = (int)((V + blocks - 1) / blocks);
+  dim3 grid((unsigned)((V + vchunk - 1) / vchunk), N);
+  hipStream_t st = (hipStream_t)stream;
+#define LB(F, M) hipLaunchKernelGGL((cl_bwd_kernel<F, M>), grid, dim3(256), 0, st, (const u16*)dy, (const u16*)x, (u16*)dx, sc, sh, slope, A, B, Cc, red, C, V, vchunk)
+  if (dtype == XH_F16) { if (mode == 0) LB(1, 0); else if (mode == 1) LB(1, 1); else LB(1, 2); }
+  else { if (mode == 0) LB(0, 0); else if (mode == 1) LB(0, 1); else LB(0, 2); }
+#undef LB
+  return xh_launch_status();
+}

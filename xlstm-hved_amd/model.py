@@ -110,31 +110,6 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
         return level_outputs, rfinal, (souts if seg else None)
 
 
-class Discriminator(nn.Module):
-    """RA_HVED.py:204-236.  Next-row component: stock PyTorch for now, not on the measured path."""
-
-    def __init__(self, in_channels=3, f_maps=64, ks=3, num_levels=4, strides=(1, 2, 2, 2)):
-        super().__init__()
-        if isinstance(f_maps, int):
-            f_maps = number_of_features_per_level(f_maps, num_levels)
-        blocks = []
-        for i, (out_f, st) in enumerate(zip(f_maps, strides)):
-            layers = [nn.Conv3d(in_channels, out_f, ks, stride=st, padding=1)]
-            if i > 0:
-                layers.append(nn.InstanceNorm3d(out_f))
-            layers.append(nn.LeakyReLU(0.2, inplace=True))
-            blocks.append(nn.Sequential(*layers))
-            in_channels = out_f
-        self.disc = nn.ModuleList(blocks)
-        self.last = nn.Conv3d(512, 1, ks, padding=1, bias=False)
-
-    def forward(self, x, input_level=0):
-        for level, block in enumerate(self.disc):
-            if level >= input_level:
-                x = block(x)
-        return self.last(x)
-
-
 class AbstractFusion3DUNet(nn.Module):
     """RA_HVED.py:239-687."""
 
