@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   constexpr int OUTB = BM * BN * 2;
   constexpr int SM = 2 * (AB + BB) > OUTB ? 2 * (AB + BB) : OUTB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  __shared__ double s_stat[WGM * BN * 2];                // per-wave-row column sums of the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WGN, wn = wv % WGN;
   const int r16 = lane & 15, kg = lane >> 4;
@@ -159,9 +160,18 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     if (a.red) {
       s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      if (kg == 0 && cn < a.Cn) {
-        atomicAdd(&a.red[((long long)n * a.Cn + cn) * 2], s0);
-        atomicAdd(&a.red[((long long)n * a.Cn + cn) * 2 + 1], s1);
+      if (kg == 0) { s_stat[(wm * BN + col) * 2] = s0; s_stat[(wm * BN + col) * 2 + 1] = s1; }
+    }
+  }
+  __syncthreads();
+  if (a.red) {                                            // one fp64 atomic per (column, moment) per workgroup
+    for (int i = tid; i < BN * 2; i += 256) {
+      const int col = i >> 1;
+      if (cn0 + col < a.Cn) {
+        double t = 0.0;
+#pragma unroll
+        for (int m2 = 0; m2 < WGM; ++m2) t += s_stat[(m2 * BN + col) * 2 + (i & 1)];
+        atomicAdd(&a.red[((long long)n * a.Cn + cn0 + col) * 2 + (i & 1)], t);
       }
     }
   }
@@ -298,6 +308,142 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
         if (cn < a.Cn && cs < a.Cs) atomicAdd(&a.dw[((long long)tap * a.Cn + cn) * a.Cs + cs], acc[i][j][r]);
       }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient of the FIRST conv (8 padded input channels): with so few channels per tap the 27 taps become the N axis
+// of the GEMM -- dW[cn][(tap, ci)] = sum_m dY[m][cn] * X[src(m, tap)][ci], N = 27 x 8 = 216 (14 tiles of 16) -- so that dY
+// is streamed ONCE (not once per tap) and a 32-voxel step carries 14 MFMAs per wave instead of one.
+__device__ __forceinline__ int sw512(int row, int chunk) { return row * 512 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
+  constexpr int YB = 32 * 256, XB = 32 * 512;            // bytes per staged dY / X-columns tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4, q = r16 >> 2, p = r16 & 3;
+  const int cn0 = blockIdx.x * 64;
+  const int split = blockIdx.y;
+  const long long per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
+  const long long m_begin = (long long)split * per, m_end = m_begin + per < a.M ? m_begin + per : a.M;
+  uint4 ry, rx[4];
+  auto load_step = [&](long long m0) {
+    {
+      const int row = tid >> 3, chn = tid & 7;
+      const long long m = m0 + row;
+      ry = make_uint4(0, 0, 0, 0);
+      if (m < m_end && cn0 + chn * 8 < a.Cn) ry = *reinterpret_cast<const uint4*>(a.dy + m * a.Cn + cn0 + chn * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int slot = tid + i * 256;
+      const int row = slot >> 5, tap = slot & 31;
+      const long long m = m0 + row;
+      rx[i] = make_uint4(0, 0, 0, 0);
+      if (m < m_end && tap < 27) {
+        long long t = m;
+        const int ow = (int)(t % a.Wo); t /= a.Wo;
+        const int oh = (int)(t % a.Ho); t /= a.Ho;
+        const int od = (int)(t % a.Do); const int n = (int)(t / a.Do);
+        const int d = od * a.stride + tap / 9 - 1, h = oh * a.stride + (tap / 3) % 3 - 1, w = ow * a.stride + tap % 3 - 1;
+        if ((unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi)
+          rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)n * a.Di + d) * a.Hi + h) * a.Wi + w) * 8);
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    unsigned char* Ys = smem + buf * (YB + XB);
+    unsigned char* Xs = Ys + YB;
+    *reinterpret_cast<uint4*>(Ys + sw256(tid >> 3, tid & 7)) = ry;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int slot = tid + i * 256;
+      *reinterpret_cast<uint4*>(Xs + sw512(slot >> 5, slot & 31)) = rx[i];
+    }
+  };
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (m_begin < m_end) {
+    load_step(m_begin);
+    store_step(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (long long m0 = m_begin; m0 < m_end; m0 += 32, buf ^= 1) {
+    if (m0 + 32 < m_end) load_step(m0 + 32);
+    const unsigned char* Ys = smem + buf * (YB + XB);
+    const unsigned char* Xs = Ys + YB;
+    h16x8 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int chn = 2 * i + (p >> 1);
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Ys + sw256(8 * kg + q, chn) + 8 * (p & 1)));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Ys + sw256(8 * kg + 4 + q, chn) + 8 * (p & 1)));
+      af[i] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nt = wv + 4 * j;                              // N tile (16 of the 224 (tap, ci) columns); tiles 14, 15 are all padding
+      const int chn = 2 * nt + (p >> 1);                      // < 32 always (nt <= 15)
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Xs + sw512(8 * kg + q, chn) + 8 * (p & 1)));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Xs + sw512(8 * kg + 4 + q, chn) + 8 * (p & 1)));
+      bf[j] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
+    if (m0 + 32 < m_end) store_step(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = (wv + 4 * j) * 16 + r16;
+      const int tap = col >> 3, ci = col & 7;
+      if (tap >= 27) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cn = cn0 + i * 16 + kg * 4 + r;
+        if (cn < a.Cn) atomicAdd(&a.dw[((long long)tap * a.Cn + cn) * 8 + ci], acc[i][j][r]);
+      }
+    }
+}
+
+// forward of the LAST conv (Cout = 1): a dot product of 27 x Cs values per output voxel -- one wave per voxel
+template <int FMT>
+__global__ __launch_bounds__(256) void dconv_cout1_kernel(const u16* x, const u16* w, u16* y, int N, int D, int H, int W, int Cs) {
+  const int lane = threadIdx.x & 63;
+  const long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long V = (long long)D * H * W;
+  if (v >= (long long)N * V) return;
+  const int n = (int)(v / V);
+  long long t = v % V;
+  const int ow = (int)(t % W); t /= W;
+  const int oh = (int)(t % H); const int od = (int)(t / H);
+  float acc = 0.f;
+  for (int tap = 0; tap < 27; ++tap) {
+    const int d = od + tap / 9 - 1, h = oh + (tap / 3) % 3 - 1, ww = ow + tap % 3 - 1;
+    if ((unsigned)d >= (unsigned)D || (unsigned)h >= (unsigned)H || (unsigned)ww >= (unsigned)W) continue;     // wave-uniform
+    const u16* xp = x + ((((long long)n * D + d) * H + h) * W + ww) * Cs;
+    const u16* wp = w + (long long)tap * Cs;
+    for (int c = lane * 8; c < Cs; c += 512) {
+      const uint4 a = *reinterpret_cast<const uint4*>(xp + c);
+      const uint4 b = *reinterpret_cast<const uint4*>(wp + c);
+      const unsigned ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc = fmaf(cvt_lo<FMT>(ua[k]), cvt_lo<FMT>(ub[k]), acc);
+        acc = fmaf(cvt_hi<FMT>(ua[k]), cvt_hi<FMT>(ub[k]), acc);
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) y[v] = cvt_out<FMT>(acc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -494,6 +640,13 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
   a.rowmode = rowmode ? 1 : 0; a.act = act; a.slope = slope;
   a.Kc = rowmode ? 32 : Cs;
   a.wtap_stride = Cn * a.Kc;
+  if (mode == 0 && Cn == 1 && stride == 1 && !bias && !red && act == XH_ACT_NONE && !rowmode && (Cs % 8) == 0) {
+    const long long waves = (long long)N * Do * Ho * Wo;
+    const unsigned nb = (unsigned)((waves + 3) / 4);
+    if (dtype == XH_F16) hipLaunchKernelGGL(dconv_cout1_kernel<1>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
+    else hipLaunchKernelGGL(dconv_cout1_kernel<0>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
+    return xh_launch_status();
+  }
   const int classes = (mode == 1 && stride == 2) ? 8 : 1;
   for (int cls = 0; cls < classes; ++cls) {
     const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
@@ -519,6 +672,17 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void
   a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn; a.stride = stride;
   a.M = (long long)N * Do * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
+  if (Cs == 8) {                                          // first conv: the taps ride on the N axis
+    const int tiles = cdiv(Cn, 64);
+    int msplit = cdiv(1024, tiles);
+    const long long max_split = a.M / 256 > 0 ? a.M / 256 : 1;
+    if (msplit > max_split) msplit = (int)max_split;
+    a.msplit = msplit;
+    dim3 grid(tiles, msplit);
+    if (dtype == XH_F16) hipLaunchKernelGGL(dwgrad_c8_kernel<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dwgrad_c8_kernel<0>, grid, dim3(256), 0, st, a);
+    return xh_launch_status();
+  }
   const bool narrow = Cs <= 16;
   const int bn = narrow ? 16 : 128, bm = narrow ? 64 : 128;
   const int tiles = cdiv(Cs, bn) * cdiv(Cn, bm);

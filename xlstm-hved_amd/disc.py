@@ -106,14 +106,21 @@ class DiscFn(Function):
         w0, w1, w2, w3, wl = sv[20:25]
         n, cin, sp, dt = ctx.meta
         dev = dout.device
-        bufs, rets = _targets(ctx.params)
+        # parameter gradients are skipped when no parameter asks for one (TrainStep freezes the discriminator for the
+        # generator's pass: train.py:265 computes them there too, and optimizer_d.zero_grad() at :282 throws them away)
+        need_w = any(ctx.needs_input_grad[1:])
+        if need_w:
+            bufs, rets = _targets(ctx.params)
+        else:
+            bufs, rets = [None] * 9, [None] * 9
         g_w0, g_b0, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wl = bufs
         cnt3 = sp[3][0] * sp[3][1] * sp[3][2]
         # last conv (512 -> 1): its single gradient channel is padded to 32 so that it is a K step of the GEMMs
         dy = torch.zeros((n,) + sp[3] + (32,), dtype=dt, device=dev)
         dy[..., 0] = dout.reshape((n,) + sp[3]).to(dt)
         c3 = wl.shape[1]
-        _unpack(_wgrad(acts[3], dy, 1, n, sp[3], sp[3], c3, 32), g_wl, 32, c3)
+        if need_w:
+            _unpack(_wgrad(acts[3], dy, 1, n, sp[3], sp[3], c3, 32), g_wl, 32, c3)
         da = _conv(dy, _pack(wl, 1, 32, c3, dt), None, 1, 1, n, sp[3], sp[3], 32, c3)
         for k, wk, g_w in ((3, w3, g_w3), (2, w2, g_w2), (1, w1, g_w1)):
             cs, cn = wk.shape[1], wk.shape[0]
@@ -128,7 +135,8 @@ class DiscFn(Function):
             dc = torch.empty_like(c)
             L.check(lib.xh_cl_act_bwd(_s(), args[0], 1, args[1], args[2], dc.data_ptr(), sc.data_ptr(), sh.data_ptr(), SLOPE, A.data_ptr(),
                                       B.data_ptr(), Cc.data_ptr(), None, n, cn, cnt), "xh_cl_act_bwd")
-            _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k - 1], sp[k], cs, cn), g_w, cn, cs)
+            if need_w:
+                _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k - 1], sp[k], cs, cn), g_w, cn, cs)
             da = _conv(dc, _pack(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k], sp[k - 1], cn, cs)
         # block 0: conv + bias -> LeakyReLU (no norm): g = da * leaky'(y0), bias gradient = sum g
         c0 = w0.shape[0]
@@ -137,8 +145,9 @@ class DiscFn(Function):
         g0 = torch.empty_like(acts[0])
         L.check(lib.xh_cl_act_bwd(_s(), ops._dt(g0), 2, da.data_ptr(), acts[0].data_ptr(), g0.data_ptr(), None, None, SLOPE, None, None, None,
                                   red0.data_ptr(), n, c0, V), "xh_cl_act_bwd")
-        g_b0 += red0[:, :, 0].sum(0).float()
-        _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[0], 8, c0), g_w0, c0, 8)
+        if need_w:
+            g_b0 += red0[:, :, 0].sum(0).float()
+            _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[0], 8, c0), g_w0, c0, 8)
         dx = None
         if ctx.needs_input_grad[0]:
             dxin = _conv(g0, _pack(w0, 1, c0, 8, dt), None, 1, 1, n, sp[0], sp[0], c0, 8)

@@ -70,7 +70,16 @@ class TrainStep:
         atten_f_x = losses.nested_attention(f_out, f_rec.detach())              # train.py:242-259
         atten_m_x = losses.nested_attention(m_out, m_rec)
         fake = torch.cat([m_out, atten_m_x], 1)
-        g_gan = self.gan(self._disc(fake).float(), True)                        # train.py:260-261
+        # the discriminator is frozen for the generator's pass: its parameter gradients from this backward are discarded
+        # by the reference anyway (optimizer_d.zero_grad(), train.py:282), so they are not computed
+        dparams = [p for p in self.disc.parameters() if p.requires_grad]
+        for p in dparams:
+            p.requires_grad_(False)
+        try:
+            g_gan = self.gan(self._disc(fake).float(), True)                    # train.py:260-261
+        finally:
+            for p in dparams:
+                p.requires_grad_(True)
         loss = dice + m_dice + self.beta * recon + self.beta * kld + self.alpha * g_gan
         parts = dict(dice=dice, m_dice=m_dice, recon=recon, kld=kld, g_gan=g_gan)
         real = torch.cat([f_out.detach(), atten_f_x.detach()], 1)
@@ -93,9 +102,6 @@ class TrainStep:
         ops.join_wgrad_stream()
         if s != 1.0:
             self.grads.flat.mul_(1.0 / s)
-        # the generator's backward also reached the discriminator's parameters (train.py:265 does the same and
-        # optimizer_d.zero_grad() at train.py:282 discards it)
-        self.grads_d.zero()
         loss_d = self.discriminator_forward(fake, real)
         (loss_d * s if s != 1.0 else loss_d).backward()
         if s != 1.0:
