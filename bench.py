@@ -390,7 +390,11 @@ def extras(model, x, grads, nsteps):
         torch.cuda.synchronize()
         res["train_step_eager_ms"] = (time.perf_counter() - t0) / max(3, nsteps // 4) * 1e3
         res["train_step_note"] = ("train.py:208-296 without the optimizer updates: 2 generator forwards (shared encoder) + Dice/MSE/KLD/"
-                                  "LSGAN epilogues on HIP + 3 Discriminator passes (csrc/dconv.hip implicit GEMMs) + both backward passes; eager")
+                                  "LSGAN epilogues on HIP + 3 Discriminator passes (csrc/dconv.hip implicit GEMMs) + both backward passes")
+        try:
+            res["train_step_graph_ms"] = time_graph(train_step, max(3, nsteps // 2))
+        except Exception as e:
+            res["train_step_graph_error"] = repr(e)[:200]
     except Exception as e:                                    # an extras failure must not cost the headline line
         res["train_step_error"] = repr(e)[:200]
     # one 240 x 240 x 155 volume, 128^3 windows every 64 voxels (18 windows), posterior mean, eval mode

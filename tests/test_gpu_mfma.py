@@ -148,10 +148,10 @@ def test_mfma_conv_full_size_128_vs_stock(cfg, dtype):
     xa, xb = (xg[:, :cfg["split"]], xg[:, cfg["split"]:]) if "split" in cfg else (xg, None)
     y, red = X.functional.in_lrelu_conv(xa, xb, wg, bg, 1, g, out_stats=True)
     k_fwd = X.ops.last_conv_kernel()
-    assert "conv3_mfma_kernel" in k_fwd and ", 256, 32, 8>" in k_fwd, k_fwd
+    assert "conv3_mfma_kernel" in k_fwd and ", 256, 32, 8, 2>" in k_fwd, k_fwd
     (y.float() * wgt.to(DEV)).sum().backward()
     k_bwd = X.ops.last_conv_kernel()              # the data gradient is the last conv launch of InLreluConv.backward
-    assert "conv3_mfma_kernel" in k_bwd and ", 256, 32, 8>" in k_bwd, k_bwd
+    assert "conv3_mfma_kernel" in k_bwd and ", 256, 32, 8, 2>" in k_bwd, k_bwd
     torch.cuda.synchronize()
     xo = x.float().requires_grad_(True)
     wo = [w.clone().requires_grad_(True) for w in ws]

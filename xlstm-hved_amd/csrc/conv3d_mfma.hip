@@ -455,7 +455,8 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const size_t shm = (size_t)4 * (a.th + 2) * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 32 * sizeof(double);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);
-  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d, %d, %d>", d->dtype == XH_F16 ? 1 : 0, a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512), a.tw == 16 ? 16 : 32, a.th);
+  xh_note_kernel("conv3_mfma_kernel<%d, %d, %d, %d, %d, %d>", d->dtype == XH_F16 ? 1 : 0, a.cinp, a.tw == 16 ? 512 : (big ? 256 : 512),
+                 a.tw == 16 ? 16 : 32, a.th, a.th == 4 ? 3 : ((big && g_mfma_occ && a.cinp <= 8 && a.tw != 16) ? 4 : 2));
   for (int sidx = 0; sidx < a.nsplit; ++sidx) {
   if (a.nsplit > 1) {
     a.cin_off = sidx * a.cin_blk;

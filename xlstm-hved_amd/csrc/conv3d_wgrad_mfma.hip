@@ -261,8 +261,10 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_kernel(const WgMK a) {
 constexpr int WG_MULTI = 7;
 struct WgMulti {
   int n;
-  int off[WG_MULTI + 1];      // first linear workgroup of problem i
-  int gx[WG_MULTI];           // grid x extent of problem i (its y extent follows from off)
+  int off[WG_MULTI + 1];      // first linear workgroup of problem i: a multiple of 8, so that the workgroup -> XCD dealing
+                              // (round robin over the launch) is the one the problem's own XCD remap assumes
+  int gx[WG_MULTI];           // grid x extent of problem i
+  int nb[WG_MULTI];           // workgroups of problem i (gx * gy); the padding up to off[i + 1] exits at once
   WgMK p[WG_MULTI];
 };
 template <int FMT, int CP, int NT>
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_multi_kernel(const WgM
   for (int k = 1; k < WG_MULTI; ++k)
     if (k < m.n && b >= m.off[k]) i = k;
   const int local = b - m.off[i];
+  if (local >= m.nb[i]) return;                          // alignment padding
   conv3_wgrad_body<FMT, CP, NT>(m.p[i], local % m.gx[i], local / m.gx[i], m.gx[i]);
 }
 
@@ -410,7 +413,8 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
       const int k = m->n;
       m->p[k] = pl.a;
       m->gx[k] = (int)pl.gx;
-      m->off[k + 1] = m->off[k] + (int)blocks;
+      m->nb[k] = (int)blocks;
+      m->off[k + 1] = m->off[k] + (int)((blocks + 7) / 8 * 8);
       if (pl.shm > shm) shm = pl.shm;
       m->n = k + 1;
       if (m->n == WG_MULTI) flush();
