@@ -66,6 +66,8 @@ def parse():
                     help="launch every weight gradient where backward reaches it instead of batching them at the end of backward")
     ap.add_argument("--wgrad-batch", type=int, default=12, help="weight-gradient calls forked to the side stream per batch")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the N=1 run
+    ap.add_argument("--force-spawn", action="store_true",
+                    help="take the self-spawning path of a launcher-less `--gpus N` run even for N = 1 (tests)")
     return ap.parse_args()
 
 
@@ -152,7 +154,7 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.size, args.batch)))
         return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_spawn) and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_workers(args))
     # stdout must carry exactly ONE line (the JSON).  Native libraries (RCCL prints a version banner at communicator
     # creation, flushed at exit) write to file descriptor 1 too, so fd 1 is pointed at stderr for the whole run and the

@@ -40,6 +40,17 @@ def test_bench_force_dist_rccl_allreduce_with_graph_capture():
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["parallelism"] == "dp1"
 
 
+def test_bench_self_spawn_path_relays_one_json_line():
+    """`python bench.py --gpus N` without a launcher spawns its workers itself; exercised here with one worker (--force-spawn)
+    going through the RCCL path (--force-dist): rank 0's single JSON line must come out of the parent's stdout."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-spawn", "--force-dist", "--steps", "2",
+                        "--warmup", "1", "--size", "64", "--no-cpu", "--no-roofline", "--no-modes"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0])["n_gpus"] == 1
+
+
 def test_bench_gpus_n_without_launcher_fails_cleanly_when_devices_are_missing():
     """`python bench.py --gpus 2` (no torchrun) spawns its own workers; on a 1-GPU box it must exit non-zero with a message
     and without touching the device (the driver runs the same form on an 8-GPU node)."""

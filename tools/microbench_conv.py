@@ -38,7 +38,7 @@ if __name__ == "__main__":
         nbytes = (cin + cout) * S ** 3 * 2
         flops = 2 * cout * S ** 3 * 27 * cin / g
         if abl:
-            for mask, name in [(0, "full"), (2, "no loads"), (4, "no mfma loop"), (8, "no stores"), (14, "nothing"), (30, "nothing-noLDSstore"), (62, "nothing-nostore-nopad")]:
+            for mask, name in [(0, "full"), (2, "no loads"), (4, "no mfma loop"), (8, "no stores"), (14, "nothing"), (30, "nothing-noLDSstore"), (62, "nothing-nostore-nopad"), (2048, "no atomics"), (2048 + 62, "nothing, no atomics")]:
                 L.load().xh_set_option(1, mask)
                 print(f"{cin}->{cout} g{g} @{S}: {name:16s} {bench(call):7.1f} us")
             L.load().xh_set_option(1, 0)

@@ -377,6 +377,192 @@ __global__ __launch_bounds__(NT, MW) void conv3_mfma_kernel(const ConvMK a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-tile variant for <= 4 input channels per channel set (the decoder / skip-return 4 -> 4 and 4 -> 12 convs, the
+// dominant kernel instance of the step in round 1).  The sliding-window kernel above is bound by its per-plane chain
+// (global load -> LDS write -> barrier -> 80 MFMAs -> stores, 16 times in a row, at two workgroups per CU): with 4
+// channels the matrix work per plane is too small to hide anything behind.  Here a workgroup stages the halo tile of a
+// TD x 8 x 32 output block ONCE ((TD+2) x 10 x 36 voxels x 4 channels = 29 KB for TD = 8), takes one barrier, and every
+// wave then runs its output rows straight through (MFMA + epilogue, no further synchronisation).  Latency hiding comes
+// from occupancy instead of from a software pipeline: ~30 KB of LDS and <= 128 VGPRs put 4 workgroups on a CU, so one
+// workgroup's load phase overlaps the others' matrix phase.  Same LDS image (channels-last, XOR swizzle), same K walk, same
+// packed B fragments and the same accumulator-layout epilogue as conv3_mfma_kernel.
+template <int FMT, int TD>
+__global__ __launch_bounds__(256, 4) void conv3_tile4_kernel(const ConvMK a) {
+  typedef h16<FMT> ST;
+  constexpr int CINP = 4, TW = 32, TH = 8, NWV = 4, NSEG = 2;
+  constexpr int IH = TH + 2, IWP = TW + 4, ID = TD + 2;
+  constexpr int VB = CINP * 2;
+  constexpr int PLANE = IH * IWP * VB;                // 2880 bytes
+  constexpr int CPR = 2, NCH = 18, NM = 5;
+  constexpr int NG = TW / 8 + 2;                      // 8-voxel groups covering [ow0 - 8, ow0 + TW + 8)
+  constexpr int NITEM = ID * IH * NG;
+  constexpr int NIT = (NITEM + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_in = smem;                         // ID * PLANE
+  double* s_red = reinterpret_cast<double*>(smem + ((ID * PLANE + 15) & ~15));     // [NWV][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g4 = lane >> 4, nn = lane & 15;
+  const int y = blockIdx.y;
+  const int set = y / a.ntile, nt = y % a.ntile;
+  const int n = blockIdx.z;
+  const int cin0 = set * a.cin_stride + a.cin_off;
+  const int cin_end = (set + 1) * a.cin_stride;
+  const int co_base = set * a.cout_set + nt * 16;
+  const int co_lim = min(16, a.cout_set - nt * 16);
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
+  const long long odhw = (long long)Do * Ho * Wo;
+  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH;
+  const int ds = wk / a.tilesH;
+  const int oh0 = th * TH, ow0 = tw * TW, od0 = ds * TD;
+
+  // ---- stage the whole halo tile (norm + activation applied on the way, zero padding after it) ----
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + it * 256;
+    if (item >= NITEM) break;
+    const int gi = item % NG;
+    int r = item / NG;
+    const int hy = r % IH, dz = r / IH;
+    const int gq = gi - 1;
+    const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 + gq * 8;
+    const bool inb = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+    float v[4][8];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = cin0 + cc;
+      const bool live = inb && cc < a.cin_blk && c < cin_end;
+      uint4 raw = make_uint4(0, 0, 0, 0);
+      float sc = 1.f, sh = 0.f;
+      if (live && !(a.abl & 2)) {
+        const ST* src = (c < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
+                                    : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
+                        (long long)gd * hw + (long long)gh * W + gw;
+        raw = *reinterpret_cast<const uint4*>(src);
+        if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+      }
+      const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float lo = cvt_lo<FMT>(u[k]), hi = cvt_hi<FMT>(u[k]);
+        if (a.d.pre) {
+          lo = leaky(lo * sc + sh, a.d.pre_slope);
+          hi = leaky(hi * sc + sh, a.d.pre_slope);
+        }
+        v[cc][2 * k] = live ? lo : 0.f;
+        v[cc][2 * k + 1] = live ? hi : 0.f;
+      }
+    }
+    const int base = dz * PLANE + (hy * IWP) * VB;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int wx = gq * 8 + k + 1;                  // tile column of voxel gw + k (column 0 = ow0 - 1)
+      if (wx >= 0 && wx < IWP && !(a.abl & 16)) {
+        uint2 pk;
+        pk.x = cvt_pack<FMT>(v[0][k], v[1][k]);
+        pk.y = cvt_pack<FMT>(v[2][k], v[3][k]);
+        *reinterpret_cast<uint2*>(s_in + swz(base + wx * VB)) = pk;
+      }
+    }
+  }
+  // ---- B fragments and A offsets (as in conv3_mfma_kernel) ----
+  bf16x8 bfrag[NM];
+  int aoff[NM];
+  {
+    const bf16x8* wpk = reinterpret_cast<const bf16x8*>(a.p.ws) + (long long)y * NM * 64;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      bfrag[i] = wpk[i * 64 + lane];
+      const int c = 4 * i + g4;
+      const int cc = c < NCH ? c : 0;
+      const int r9 = cc / CPR, j = cc % CPR;
+      aoff[i] = (r9 / 3) * PLANE + ((r9 % 3) * IWP + nn) * VB + j * 16;
+    }
+  }
+  const int eco = nn;
+  const int co = co_base + eco;
+  const bool co_ok = eco < co_lim;
+  float bias = 0.f, esc = 0.f, esh = 0.f;
+  const ST* eplane = nullptr;
+  if (co_ok) {
+    const int g = co / a.Cout_g, gpp = a.d.groups / a.d.n_wptr;
+    const float* bp = a.p.b[g / gpp];
+    if (bp) bias = bp[(g % gpp) * a.Cout_g + co % a.Cout_g];
+    if (a.d.epi == 1) {
+      esc = a.p.e_sc[n * a.d.Cout + co];
+      esh = a.p.e_sh[n * a.d.Cout + co];
+      eplane = co < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co * odhw
+                            : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co - a.d.Cea) * odhw;
+    }
+  }
+  ST* yplane = (ST*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
+  double s0 = 0.0, s1 = 0.0;
+  __syncthreads();
+
+  // ---- every wave: its share of the TD x TH output rows, no further barriers ----
+  for (int row = wv; row < TD * TH; row += NWV) {
+    const int dz = row / TH, rr = row % TH;
+    const int od = od0 + dz, oh = oh0 + rr;
+    if (od >= Do || oh >= Ho) continue;               // wave-uniform
+    f32x4 acc[NSEG];
+#pragma unroll
+    for (int wt = 0; wt < NSEG; ++wt) {
+      const int rowoff = dz * PLANE + (rr * IWP + wt * 16) * VB;
+      acc[wt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!(a.abl & 4))
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const int ao = rowoff + aoff[i];
+        const uint2 lo = *reinterpret_cast<const uint2*>(s_in + swz(ao));
+        const uint2 hi = *reinterpret_cast<const uint2*>(s_in + swz(ao + 8));
+        const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        acc[wt] = mfma16x16x32<FMT>(av, bfrag[i], acc[wt]);
+      }
+    }
+    if (!co_ok) continue;
+#pragma unroll
+    for (int wt = 0; wt < NSEG; ++wt) {
+      const long long sp = ((long long)od * Ho + oh) * Wo + ow0 + wt * 16 + 4 * g4;
+      float o[4] = {acc[wt][0], acc[wt][1], acc[wt][2], acc[wt][3]};
+      float ev[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.d.epi == 1) ld4(eplane, sp, ev);
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = apply_act(o[r] + bias, a.d.act, a.d.act_slope);
+        if (a.d.epi == 1) {
+          v = cvt_in<FMT>(cvt_out<FMT>(v * ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope)));
+          t0 += v; t1 += v * ev[r];
+        } else if (a.d.epi == 2) {
+          v = cvt_in<FMT>(cvt_out<FMT>(v));
+          t0 += v; t1 += v * v;
+        }
+        o[r] = v;
+      }
+      if (a.d.epi) { s0 += (double)t0; s1 += (double)t1; }
+      if (!(a.abl & 8)) st4(yplane, sp, o);
+    }
+  }
+  if (a.d.epi) {
+    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    if (lane < 16) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
+    __syncthreads();
+    if (tid < 32) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w8 = 0; w8 < NWV; ++w8) tot += s_red[w8 * 32 + tid];
+      const int c = tid >> 1;
+      if (c < co_lim && !(a.abl & 2048)) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co_base + c) * 2 + (tid & 1)], tot);
+    }
+  }
+}
+
 static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return 1;
   if (d->W % 16 != 0 || d->Wo != d->W) return 1;
@@ -466,6 +652,17 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     a.p.ws = (char*)p->ws + pb * sidx;
   }
   hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
+  if (a.cinp == 4 && a.tw == 32 && a.th == 8 && a.nsplit == 1 && !(g_mfma_abl & 1024)) {
+    // whole-tile kernel: TD x 8 x 32 output blocks, one barrier (see conv3_tile4_kernel)
+    constexpr int TD = 8;
+    const int tilesD = cdiv(d->Do, TD);
+    dim3 gridt(a.tilesW * a.tilesH * tilesD, ny, d->N);
+    const size_t shmt = (((size_t)(TD + 2) * 10 * 36 * 8 + 15) & ~(size_t)15) + 4 * 32 * sizeof(double);
+    xh_note_kernel("conv3_tile4_kernel<%d, %d>", d->dtype == XH_F16 ? 1 : 0, TD);
+    if (d->dtype == XH_F16) hipLaunchKernelGGL((conv3_tile4_kernel<1, TD>), gridt, dim3(256), shmt, st, a);
+    else hipLaunchKernelGGL((conv3_tile4_kernel<0, TD>), gridt, dim3(256), shmt, st, a);
+    continue;
+  }
 #define LM(F, C)                                                                                                \
   do {                                                                                                          \
     static bool attr_done = false;                                                                              \
