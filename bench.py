@@ -74,11 +74,8 @@ def parse():
 def bench_loss(seg, mu, lv, rec):
     """seg.mean() + rec.mean() + sum_l (mu_l.mean() + logvar_l.mean()) -- reaches every parameter the
     reference's training loss reaches.  Each mean is one HIP reduction pass (losses.mean_of), not a cast + ATen reduce."""
-    from xlstm_hved_amd.losses import mean_of
-    loss = mean_of(seg) + mean_of(rec)
-    for a, b in zip(mu, lv):
-        loss = loss + mean_of(a) + mean_of(b)
-    return loss
+    from xlstm_hved_amd.losses import sum_of_means
+    return sum_of_means([seg, rec] + [t for ab in zip(mu, lv) for t in ab])
 
 
 def cpu_baseline(size, batch, budget_s=60.0, sweep=(8, 16, 32, 64)):

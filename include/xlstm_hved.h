@@ -320,7 +320,8 @@ int xh_lincomb(void* stream, int dtype, const void* a, long long a_bs, int b_dty
                void* out, long long o_bs, int N, int C, long long DHW, const float* ca, const float* cb, const float* cc,
                const float* gscale, int accumulate);
 /* Sums of xh_pair_sums -> scalar loss / per-channel metric + the per-(n,c) coefficients of xh_lincomb, on the device:
- * kind 0 DiceLoss, 1 mean squared difference (count = number of elements), 2 thresholded Dice metric (out[C]), 3 mean of a.
+ * kind 0 DiceLoss, 1 mean squared difference (count = number of elements), 2 thresholded Dice metric (out[C]), 3 mean of a,
+ * 4 weighted sum over the rows of red (slot 4) with the INPUT weights ca[N*C] (several means finished by one launch).
  * gscale (xh_lincomb, xh_kld_bwd): optional device scalar multiplying the result (the upstream gradient). */
 int xh_loss_finalize(void* stream, int kind, const double* red, int N, int C, double count, double eps, float* out, float* ca,
                      float* cb);

@@ -71,3 +71,14 @@ def test_mean_of_matches_torch_mean(dtype):
         ref = x.detach().float().mean()
         assert abs(m.item() - ref.item()) < 1e-6
         assert torch.allclose(x.grad.float(), torch.full(shape, 3.0 / x.numel(), device=DEV).to(dtype).float())
+
+
+def test_sum_of_means_matches_torch():
+    torch.manual_seed(2)
+    ts = [torch.randn(s, device=DEV).bfloat16().requires_grad_(True) for s in ((1, 3, 8, 8, 8), (1, 5, 1, 4, 4, 4), (2, 4, 6, 6, 10))]
+    m = X.losses.sum_of_means(ts)
+    (m * 2.0).backward()
+    ref = sum(t.detach().float().mean() for t in ts)
+    assert abs(m.item() - ref.item()) < 1e-6
+    for t in ts:
+        assert torch.allclose(t.grad.float(), torch.full(t.shape, 2.0 / t.numel(), device=DEV).bfloat16().float())

@@ -37,6 +37,65 @@ class BasicConv(nn.Module):
         return Fn.ConvInLrelu.apply(x, self.conv.weight, self.groups)
 
 
+# BatchNorm `num_batches_tracked` counters: a network forward touches a dozen of them; updated one by one that is a dozen
+# 4-microsecond launches.  Inside `BNCounters.collect()` (the model's forward) the increments are only recorded, and applied
+# at the end as ONE add on a flat int64 buffer the counters are views of.  Outside it (a block used on its own) the counter
+# is incremented directly.
+class BNCounters:
+    active = None
+
+    def __init__(self):
+        self.flat, self.mods, self.inc_cache = None, [], {}
+
+    def bind(self, root):
+        """Points every BatchNorm3d counter of `root` at a slot of one flat buffer (re-done when the device changed or a
+        load_state_dict / .to() replaced the buffers)."""
+        mods = [m for m in root.modules() if isinstance(m, nn.BatchNorm3d) and m.num_batches_tracked is not None]
+        if not mods:
+            self.flat, self.mods = None, []
+            return
+        dev = mods[0].num_batches_tracked.device
+        ok = (self.flat is not None and self.flat.device == dev and len(mods) == len(self.mods) and
+              all(m.num_batches_tracked.data_ptr() == self.flat.data_ptr() + 8 * i for i, m in enumerate(mods)))
+        if not ok:
+            flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in mods]).to(torch.int64).contiguous()
+            for i, m in enumerate(mods):
+                m._buffers["num_batches_tracked"] = flat[i]
+            self.flat, self.mods, self.inc_cache = flat, mods, {}
+        self.index = {id(m): i for i, m in enumerate(self.mods)}
+
+    def collect(self, root):
+        self.bind(root)
+        self.pending = {}
+        return self
+
+    def __enter__(self):
+        BNCounters.active = self
+        return self
+
+    def __exit__(self, *exc):
+        BNCounters.active = None
+        if self.flat is not None and self.pending and exc[0] is None:
+            key = tuple(sorted(self.pending.items()))
+            inc = self.inc_cache.get(key)
+            if inc is None:                      # built once per pattern of increments (no host-to-device copy per step)
+                v = [0] * len(self.mods)
+                for i, s_ in key:
+                    v[i] = s_
+                inc = self.inc_cache[key] = torch.tensor(v, dtype=torch.int64, device=self.flat.device)
+            self.flat.add_(inc)
+        return False
+
+
+def bn_tick(bn, steps):
+    c = BNCounters.active
+    if c is not None and c.flat is not None and id(bn) in c.index:
+        i = c.index[id(bn)]
+        c.pending[i] = c.pending.get(i, 0) + steps
+    else:
+        bn.num_batches_tracked += steps
+
+
 class SingleConv(nn.Module):
     """buildingblocks.py:440-461 (+ create_conv :381-437) for the two layer orders XLSTM-HVED can reach
     (SURVEY F4/F10): 'ilc' and 'gcr'.  Sub-module names follow create_conv."""
@@ -292,8 +351,8 @@ class DuSEAttention(nn.Module):
                             b2.running_var, self.fc_comb.weight, self.fc_comb.bias, self.fc_ch1.weight, self.fc_ch1.bias,
                             self.fc_ch2.weight, self.fc_ch2.bias, sqw, sqb, adjw, adjb, b1.weight, b1.bias, b2.weight, b2.bias)
         if self.training:
-            b1.num_batches_tracked += 1
-            b2.num_batches_tracked += 1
+            bn_tick(b1, 1)
+            bn_tick(b2, 1)
         return out
 
 
@@ -363,8 +422,8 @@ class SkipReturnAttention(nn.Sequential):
             c1.dwconv.weight, c1.pwconv.weight, c1.pwconv.bias, c1.norm.weight, c1.norm.bias,
             c2.dwconv.weight, c2.pwconv.weight, c2.pwconv.bias, c2.norm.weight, c2.norm.bias, sa.conv.weight)
         if self.training:
-            c1.norm.num_batches_tracked += steps
-            c2.norm.num_batches_tracked += steps
+            bn_tick(c1.norm, steps)
+            bn_tick(c2.norm, steps)
         return a
 
 

@@ -235,6 +235,7 @@ extern "C" int xh_nested_weight(void* stream, int dtype, const void* seg, long l
 //  kind 1  mean squared difference (nn.MSELoss, GANLoss): loss = sum d^2 / count; ca = 2/count, cb = -2/count
 //  kind 2  thresholded Dice metric (metrics.py:40-48,99-107): out[c] = mean_n (2 I + eps) / (sum a' + sum b + eps)
 //  kind 3  mean of a (the SURVEY 8(d) benchmark loss): out[0] = sum a / count
+//  kind 4  sum_i w[i] * (sum of tensor i), w = ca (an INPUT here): several means in one finalisation
 __global__ __launch_bounds__(64) void loss_finalize_kernel(int kind, const double* red, int N, int C, double count, double eps,
                                                           float* out, float* ca, float* cb) {
   const int t = threadIdx.x;
@@ -268,18 +269,24 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(int kind, const doubl
       for (int n = 0; n < N; ++n) { const double* r = red + ((long long)n * C + t) * 6; m += (2.0 * r[0] + eps) / (r[4] + r[5] + eps); }
       out[t] = (float)(m / N);
     }
-  } else {                                            // kind 3: plain mean of a (slot 4)
+  } else if (kind == 3) {                             // plain mean of a (slot 4)
     if (t == 0) {
       double sacc = 0;
       for (int i = 0; i < N * C; ++i) sacc += red[(long long)i * 6 + 4];
       out[0] = (float)(sacc / count);
     }
+  } else {                                            // kind 4: weighted sum of several tensors' sums: sum_i red[i][4] * ca[i]
+    if (t == 0) {
+      double sacc = 0;
+      for (int i = 0; i < N * C; ++i) sacc += red[(long long)i * 6 + 4] * (double)ca[i];
+      out[0] = (float)sacc;
+    }
   }
 }
 extern "C" int xh_loss_finalize(void* stream, int kind, const double* red, int N, int C, double count, double eps, float* out,
                                 float* ca, float* cb) {
-  if (!red || !out || N <= 0 || C <= 0 || (C > 64 && (kind == 0 || kind == 2)) || kind < 0 || kind > 3) return XH_ERR_ARG;
-  if (kind < 2 && (!ca || !cb)) return XH_ERR_ARG;
+  if (!red || !out || N <= 0 || C <= 0 || (C > 64 && (kind == 0 || kind == 2)) || kind < 0 || kind > 4) return XH_ERR_ARG;
+  if ((kind < 2 && (!ca || !cb)) || (kind == 4 && !ca)) return XH_ERR_ARG;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kind, red, N, C, count, eps, out, ca, cb);
   return xh_launch_status();
 }

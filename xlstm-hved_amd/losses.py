@@ -154,6 +154,34 @@ def mean_of(t):
     return _Mean.apply(t)
 
 
+class _SumOfMeans(Function):
+    @staticmethod
+    def forward(ctx, *ts):
+        dev = ts[0].device
+        key = (tuple(t.numel() for t in ts), dev)
+        w = _WEIGHTS.get(key)
+        if w is None:
+            w = _WEIGHTS[key] = torch.tensor([1.0 / t.numel() for t in ts], dtype=torch.float32, device=dev)
+        red = ops.zeros_f64(dev, (len(ts), 1, 6))
+        for i, t in enumerate(ts):
+            ops.pair_sums(t.contiguous().view(1, 1, 1, 1, -1), red=red[i:i + 1])
+        ctx.meta = [(tuple(t.shape), t.dtype, t.device, t.numel()) for t in ts]
+        return ops.loss_finalize(4, red, count=w).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g.float().reshape(1).contiguous()
+        return tuple(ops.fill(shape, 1.0 / numel, dtype, device, gscale=gs) for shape, dtype, device, numel in ctx.meta)
+
+
+_WEIGHTS = {}
+
+
+def sum_of_means(tensors):
+    """sum_i t_i.float().mean(): one reduction pass per tensor and ONE finalisation (the SURVEY 8(d) benchmark loss)."""
+    return _SumOfMeans.apply(*tensors)
+
+
 class DiceCoefficient:
     """metrics.py:10-48: mean over channels of the thresholded (> 0.5) per-channel Dice, averaged over the batch."""
 

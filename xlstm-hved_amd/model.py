@@ -208,8 +208,9 @@ class AbstractFusion3DUNet(nn.Module):
                 eps_list=None):
         """RA_HVED.py:510-648.  `eps_list` (optional, not in the reference signature) injects the reparameterisation
         noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
-        enc = self._encode(x, bn_steps=4)
-        return self._decode(enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list)
+        with self._bn_counters():
+            enc = self._encode(x, bn_steps=4)
+            return self._decode(enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list)
 
     def forward_shared(self, x, calls, seg=True, recon=False):
         """Several forwards of the SAME input that differ only in the modality subset / sampling (train.py:224-225 runs
@@ -218,12 +219,21 @@ class AbstractFusion3DUNet(nn.Module):
         once and only PoE -> reparameterisation -> decoders run per call.  `calls` is a list of dicts with the per-call
         keyword arguments of forward() (subset_idx_list, instance_missing, drop, valid, eps_list).  Returns the list of
         forward() results.  BatchNorm buffers of the skip-return attention advance 4 steps per call, as they would."""
-        enc = self._encode(x, bn_steps=4 * len(calls))
-        outs = []
-        for kw in calls:
-            outs.append(self._decode(enc, kw.get("subset_idx_list", [14]), kw.get("instance_missing", False), kw.get("drop"),
-                                     seg, recon, kw.get("valid", False), kw.get("eps_list")))
+        with self._bn_counters():
+            enc = self._encode(x, bn_steps=4 * len(calls))
+            outs = []
+            for kw in calls:
+                outs.append(self._decode(enc, kw.get("subset_idx_list", [14]), kw.get("instance_missing", False), kw.get("drop"),
+                                         seg, recon, kw.get("valid", False), kw.get("eps_list")))
         return outs
+
+    def _bn_counters(self):
+        """One flat update of all BatchNorm `num_batches_tracked` counters per forward (blocks.BNCounters)."""
+        from .blocks import BNCounters
+        c = self.__dict__.get("_bnc")
+        if c is None:
+            c = self.__dict__["_bnc"] = BNCounters()
+        return c.collect(self)
 
     def _encode(self, x, bn_steps):
         """The input-only part: per-level DRB outputs (4 streams x [mu | logvar] before PoE) and the skip-return feature."""
@@ -274,13 +284,21 @@ class AbstractFusion3DUNet(nn.Module):
         n = x.shape[0]
         keep = self._keep_mask(x, subset_idx_list, instance_missing, drop)
         mu_list, logvar_list, feats = [], [], []
+        noise = None
+        if not valid and eps_list is None:
+            # RA_HVED.py:744 draws N(0,1) noise per level; here ONE draw (in the storage type) serves the four levels
+            shapes = [(n, self.MVAE_latents[l]) + tuple(f.shape[2:]) for l, f in enumerate(feat_list)]
+            sizes = [int(torch.Size(s_).numel()) for s_ in shapes]
+            flat = torch.randn(sum(sizes), device=x.device, dtype=x.dtype)
+            noise, o = [], 0
+            for s_, k in zip(shapes, sizes):
+                noise.append(flat[o:o + k].view(s_))
+                o += k
         for level, feat in enumerate(feat_list):
             L_ = self.MVAE_latents[level]
             eps = None
             if not valid:
-                shape = (n, L_) + tuple(feat.shape[2:])
-                eps = eps_list[level] if eps_list is not None else torch.randn(shape, device=x.device, dtype=torch.float32)
-                eps = eps.to(device=x.device, dtype=x.dtype).contiguous()
+                eps = noise[level] if noise is not None else eps_list[level].to(device=x.device, dtype=x.dtype).contiguous()
             z, mu, lv = Fn.PoE.apply(feat, keep, eps, L_, bool(instance_missing))
             mu_list.append(mu)
             logvar_list.append(lv)

@@ -671,11 +671,13 @@ def _dt_of(t):
     return _dt(t)
 
 
-def pair_sums(a, b=None, bval=0.0, thr=None):
+def pair_sums(a, b=None, bval=0.0, thr=None, red=None):
     """(N, C, 6) fp64 sums over DHW of (a'b, a'^2, b^2, (a'-b)^2, a', b); a' = (a > thr) when thr is given.  b: a tensor of
-    a's dtype or fp32, or None (= the constant bval)."""
+    a's dtype or fp32, or None (= the constant bval).  `red`: zeroed (N, C, 6) fp64 destination (default: a slice of the
+    per-forward scratch arena -- the sums are consumed by the finalisation launch that follows)."""
     n, c, d, h, w, a_bs = _vol(a)
-    red = torch.zeros((n, c, 6), dtype=torch.float64, device=a.device)
+    if red is None:
+        red = zeros_f64(a.device, (n, c, 6))
     b_dt, b_bs = _dt(a), 0
     if b is not None:
         if tuple(b.shape) != tuple(a.shape):
@@ -706,6 +708,9 @@ def loss_finalize(kind, red, count=1.0, eps=1e-6):
     ca = cb = None
     if kind == 3:
         L.check(L.load().xh_loss_finalize(_stream(), 3, _p(red), n, c, float(count), float(eps), _p(out), None, None), "xh_loss_finalize")
+        return out
+    if kind == 4:                        # eps carries the weights tensor here
+        L.check(L.load().xh_loss_finalize(_stream(), 4, _p(red), n, c, 1.0, 0.0, _p(out), _p(_f32(count, "weights")), None), "xh_loss_finalize")
         return out
     if kind < 2:
         ca, cb = (torch.empty((n, c), dtype=torch.float32, device=red.device) for _ in range(2))
