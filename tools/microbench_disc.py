@@ -32,7 +32,11 @@ for cin, cout, s, sp in layers:
     w = torch.randn(cout, 7 if cin == 8 else cin, 3, 3, 3, device="cuda") * 0.05
     wp = D._pack(w, 2 if cin == 8 else 0, cout, cin, dt)
     red = torch.zeros(1, cout, 2, dtype=torch.float64, device="cuda")
-    t_f = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red))
+    lib = X._lib.load()
+    lib.xh_set_option(5, 1)
+    t_f1 = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red if cout > 1 else None))
+    lib.xh_set_option(5, 2)
+    t_f = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red if cout > 1 else None))
     cop = max(32, cout)
     dy = torch.randn(1, so, so, so, cop, device="cuda").to(dt)
     wpt = D._pack(w, 1, cop, cin, dt)
@@ -41,7 +45,7 @@ for cin, cout, s, sp in layers:
     dy8 = torch.randn(1, so, so, so, co8, device="cuda").to(dt)
     t_w = bench(lambda: D._wgrad(x, dy8, s, 1, (sp,) * 3, (so,) * 3, cin, co8))
     fl = 2.0 * cout * (7 if cin == 8 else cin) * 27 * so ** 3
-    print(f"{cin:3d}->{cout:3d} s{s} @{sp}^3: fwd {t_f:8.1f} us ({fl / t_f / 1e6:6.1f} TF/s)  dgrad {t_d:8.1f} us ({fl / t_d / 1e6:6.1f})  wgrad {t_w:8.1f} us ({fl / t_w / 1e6:6.1f})   [{fl / 1e9:.1f} GFLOP]")
+    print(f"{cin:3d}->{cout:3d} s{s} @{sp}^3: fwd[K32] {t_f1:7.1f} us fwd {t_f:8.1f} us ({fl / t_f / 1e6:6.1f} TF/s)  dgrad {t_d:8.1f} us ({fl / t_d / 1e6:6.1f})  wgrad {t_w:8.1f} us ({fl / t_w / 1e6:6.1f})   [{fl / 1e9:.1f} GFLOP]")
     tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
 print("sum of conv launches: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms" % tuple(v / 1e3 for v in tot.values()))
 m = X.Discriminator(in_channels=7); m.apply(X.init_weights); m = m.cuda()

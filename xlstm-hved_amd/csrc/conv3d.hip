@@ -1227,6 +1227,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 2) { g_xh_disable = value; return XH_OK; }
   if (key == 3) { extern int g_mfma_wgs; g_mfma_wgs = value > 0 ? value : 512; return XH_OK; }
   if (key == 4) { extern int g_mfma_occ; g_mfma_occ = value; return XH_OK; }
+  if (key == 5) { extern int g_dconv_kq; g_dconv_kq = value == 1 ? 1 : 2; return XH_OK; }
   return XH_ERR_ARG;
 }
 

@@ -38,13 +38,19 @@ struct DConvK {
 // LDS images: rows of 64 bytes (32 x 16-bit), the 16-byte chunk index XORed with (row >> 2) & 3 so that the 16 rows a
 // ds_read_b128 lane group touches land on all 64 banks
 __device__ __forceinline__ int sw64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// rows of 64 * KQ bytes: KQ = 2 (128-byte rows): XOR with row & 7 over the 8 chunks
+template <int KQ> __device__ __forceinline__ int swr(int row, int chunk) {
+  return KQ == 1 ? sw64(row, chunk) : row * 128 + ((chunk ^ (row & 7)) << 4);
+}
 
-template <int FMT, int WGN, int TN>
+// KQ = 32-channel quarters per K step (1: K step 32, 2: K step 64 -- half the barriers, twice the matrix work between them)
+template <int FMT, int WGN, int TN, int KQ = 1>
 __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   constexpr int WGM = 4 / WGN;
   constexpr int BM = WGM * 64, BN = WGN * TN * 16;
-  constexpr int AB = BM * 64, BB = BN * 64;              // bytes per A / B buffer
-  constexpr int NA = BM * 4 / 256, NB = (BN * 4 + 255) / 256;
+  constexpr int RB = 64 * KQ, CPRW = 4 * KQ;             // bytes / 16-byte chunks per LDS row
+  constexpr int AB = BM * RB, BB = BN * RB;              // bytes per A / B buffer
+  constexpr int NA = BM * CPRW / 256, NB = (BN * CPRW + 255) / 256;
   constexpr int OUTB = BM * BN * 2;
   constexpr int SM = 2 * (AB + BB) > OUTB ? 2 * (AB + BB) : OUTB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   bool a_ok[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = (tid >> 2) + i * 64;
+    const int row = tid / CPRW + i * (256 / CPRW);
     const int m = mt * BM + row;
     a_row[i] = row;
     a_ok[i] = m < R;
@@ -69,10 +75,10 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     const int jh = t2 % a.Jh, jd = t2 / a.Jh;
     a_sd[i] = jd * a.smul; a_sh[i] = jh * a.smul; a_sw[i] = jw * a.smul;
   }
-  const int ch = tid & 3;
+  const int ch = tid % CPRW;
   const long long xs_n = (long long)n * a.Di * a.Hi * a.Wi;
   uint4 ra[NA], rb[NB];
-  const int nsteps_c = a.rowmode ? 1 : a.Cs / 32;
+  const int nsteps_c = a.rowmode ? 1 : a.Cs / (32 * KQ);
   const int ntw = a.rowmode ? 1 : a.tw.n;
   const int nsteps = a.td.n * a.th.n * ntw * nsteps_c;
 
@@ -87,27 +93,27 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
       int w = a_sw[i] + (a.rowmode ? (ch - 1) : a.tw.off[iw]);
       ra[i] = make_uint4(0, 0, 0, 0);
       if (a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi) {
-        const u16* p = a.x + ((xs_n + ((long long)d * a.Hi + h) * a.Wi + w) * a.Cs) + (a.rowmode ? 0 : cs * 32 + ch * 8);
+        const u16* p = a.x + ((xs_n + ((long long)d * a.Hi + h) * a.Wi + w) * a.Cs) + (a.rowmode ? 0 : cs * 32 * KQ + ch * 8);
         ra[i] = *reinterpret_cast<const uint4*>(p);
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int col = (tid >> 2) + i * 64;
+      const int col = tid / CPRW + i * (256 / CPRW);
       rb[i] = make_uint4(0, 0, 0, 0);
       if (col < BN && cn0 + col < a.Cn)
-        rb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)(cn0 + col) * a.Kc + cs * 32 + ch * 8);
+        rb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)(cn0 + col) * a.Kc + cs * 32 * KQ + ch * 8);
     }
   };
   auto store_step = [&](int buf) {
     unsigned char* As = smem + buf * (AB + BB);
     unsigned char* Bs = As + AB;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + sw64(a_row[i], ch)) = ra[i];
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + swr<KQ>(a_row[i], ch)) = ra[i];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int col = (tid >> 2) + i * 64;
-      if (col < BN) *reinterpret_cast<uint4*>(Bs + sw64(col, ch)) = rb[i];
+      const int col = tid / CPRW + i * (256 / CPRW);
+      if (col < BN) *reinterpret_cast<uint4*>(Bs + swr<KQ>(col, ch)) = rb[i];
     }
   };
 
@@ -125,15 +131,18 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     if (s + 1 < nsteps) load_step(s + 1);
     const unsigned char* As = smem + buf * (AB + BB);
     const unsigned char* Bs = As + AB;
-    h16x8 af[4], bf[TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const h16x8*>(As + sw64(wm * 64 + i * 16 + r16, kg));
+    for (int kq = 0; kq < KQ; ++kq) {
+      h16x8 af[4], bf[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h16x8*>(Bs + sw64((wn * TN + j) * 16 + r16, kg));
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const h16x8*>(As + swr<KQ>(wm * 64 + i * 16 + r16, kq * 4 + kg));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h16x8*>(Bs + swr<KQ>((wn * TN + j) * 16 + r16, kq * 4 + kg));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
+    }
     if (s + 1 < nsteps) store_step(buf ^ 1);
     __syncthreads();
   }
@@ -601,6 +610,7 @@ __global__ __launch_bounds__(256) void cl_bwd_kernel(const u16* dy, const u16* x
 // =================================================================================================================
 // host entry points
 // =================================================================================================================
+int g_dconv_kq = 2;        // xh_set_option(5, 1|2): K step of the discriminator's implicit GEMM in 32-channel quarters
 static void fill_taps(DTaps* t, int mode, int stride, int parity) {
   // mode 0 forward: all taps, source = j*stride + (t - 1);  mode 1 data gradient: stride 1: source = j + 1 - t;
   // stride 2: destination o = 2j + parity; parity 0 -> tap 1 (source j), parity 1 -> taps 0 (source j + 1), 2 (source j)
@@ -618,7 +628,9 @@ static void launch_dconv(hipStream_t st, const DConvK& a, int N) {
     hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1>), grid, dim3(256), 0, st, a);
   } else {
     dim3 grid(cdiv(R, 128), cdiv(a.Cn, 128), N);
-    hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4>), grid, dim3(256), 0, st, a);
+    extern int g_dconv_kq;
+    if (!a.rowmode && (a.Cs % 64) == 0 && g_dconv_kq == 2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4>), grid, dim3(256), 0, st, a);
   }
 }
 
