@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NT, MW) void conv3_mfma_kernel(const ConvMK a) {
 // workgroup's load phase overlaps the others' matrix phase.  Same LDS image (channels-last, XOR swizzle), same K walk, same
 // packed B fragments and the same accumulator-layout epilogue as conv3_mfma_kernel.
 template <int FMT, int TD>
-__global__ __launch_bounds__(256, 4) void conv3_tile4_kernel(const ConvMK a) {
+__global__ __launch_bounds__(256, 4) void conv3_mfma_tile4_kernel(const ConvMK a) {
   typedef h16<FMT> ST;
   constexpr int CINP = 4, TW = 32, TH = 8, NWV = 4, NSEG = 2;
   constexpr int IH = TH + 2, IWP = TW + 4, ID = TD + 2;
@@ -653,14 +653,14 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   }
   hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
   if (a.cinp == 4 && a.tw == 32 && a.th == 8 && a.nsplit == 1 && !(g_mfma_abl & 1024)) {
-    // whole-tile kernel: TD x 8 x 32 output blocks, one barrier (see conv3_tile4_kernel)
+    // whole-tile kernel: TD x 8 x 32 output blocks, one barrier (see conv3_mfma_tile4_kernel)
     constexpr int TD = 8;
     const int tilesD = cdiv(d->Do, TD);
     dim3 gridt(a.tilesW * a.tilesH * tilesD, ny, d->N);
     const size_t shmt = (((size_t)(TD + 2) * 10 * 36 * 8 + 15) & ~(size_t)15) + 4 * 32 * sizeof(double);
-    xh_note_kernel("conv3_tile4_kernel<%d, %d>", d->dtype == XH_F16 ? 1 : 0, TD);
-    if (d->dtype == XH_F16) hipLaunchKernelGGL((conv3_tile4_kernel<1, TD>), gridt, dim3(256), shmt, st, a);
-    else hipLaunchKernelGGL((conv3_tile4_kernel<0, TD>), gridt, dim3(256), shmt, st, a);
+    xh_note_kernel("conv3_mfma_tile4_kernel<%d, %d>", d->dtype == XH_F16 ? 1 : 0, TD);
+    if (d->dtype == XH_F16) hipLaunchKernelGGL((conv3_mfma_tile4_kernel<1, TD>), gridt, dim3(256), shmt, st, a);
+    else hipLaunchKernelGGL((conv3_mfma_tile4_kernel<0, TD>), gridt, dim3(256), shmt, st, a);
     continue;
   }
 #define LM(F, C)                                                                                                \

@@ -215,7 +215,10 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   a.tilesH = cdiv(d->H, rows);
   const int cols = a.tilesW * a.tilesH;
   int dsegs = cdiv(512, cols * d->N);
-  const int max_segs = d->D >= 8 ? d->D / 8 : 1;      // runs of >= 8 planes: 6 halo planes are staged per run
+  // runs of >= 8 planes (6 halo planes are staged per run) -- but on small volumes (<= 64^3) that leaves 8-64 workgroups on
+  // 256 CUs and the run time is the serial chain of one workgroup (81 us at 32^3 and 64^3, like 128^3): runs of 2 there
+  const int min_run = (long long)d->D * d->H * d->W <= (1 << 18) ? 2 : 8;
+  const int max_segs = d->D >= min_run ? d->D / min_run : 1;
   if (dsegs > max_segs) dsegs = max_segs;
   if (dsegs < 1) dsegs = 1;
   a.sd = cdiv(d->D, dsegs);
