@@ -27,6 +27,9 @@ CASES = [
     dict(cin=96, cout=32, groups=1, sp=(4, 8, 16), split=32),
     dict(cin=28, cout=8, groups=1, sp=(4, 8, 32)),            # uneven split (16 + 12)
     dict(cin=128, cout=64, groups=4, sp=(4, 8, 16)),          # grouped, 32 channels per group: split-K inside each group
+    dict(cin=64, cout=128, groups=4, sp=(8, 8, 8)),           # 8-wide volumes (level 4): wgrad K steps of 4 rows x 8 voxels
+    dict(cin=32, cout=16, groups=1, sp=(5, 7, 8)),            # ... ragged D/H
+    dict(cin=32, cout=16, groups=1, sp=(5, 11, 16)),          # 16-wide, ragged H: wgrad K steps of 2 rows x 16 voxels
 ]
 
 
@@ -188,6 +191,21 @@ def test_wgrad_mfma_full_size_128_kernel_name(dtype):
     ref = torch.nn.functional.conv3d(x.float().transpose(0, 1), dy.float().transpose(0, 1), padding=1).transpose(0, 1)
     assert l2_err(dw, ref) < TOL[dtype]["dw"]
     assert l2_err(db, dy.float().sum((0, 2, 3, 4))) < 1e-3
+
+
+@pytest.mark.parametrize("w", [16, 8])
+def test_wgrad_mfma_narrow_volume_kernel_name(w):
+    """16- and 8-wide volumes (levels 3 and 4 of a 128^3 patch) take the MFMA weight-gradient kernel too (2 / 4 rows per
+    K step); checked numerically by test_mfma_conv_forward_backward."""
+    x = torch.randn(1, 16, 8, w, w, device=DEV).bfloat16()
+    dy = torch.randn(1, 16, 8, w, w, device=DEV).bfloat16()
+    dw, db = torch.zeros(16, 16, 3, 3, 3, device=DEV), torch.zeros(16, device=DEV)
+    X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
+    name = X.ops.last_conv_kernel()
+    assert "conv3_wgrad_mfma_kernel" in name, name
+    ref = torch.nn.grad.conv3d_weight(x.float(), dw.shape, dy.float(), padding=1)
+    assert l2_err(dw.cpu(), ref.cpu()) < 2e-3
+    assert l2_err(db.cpu(), dy.float().sum((0, 2, 3, 4)).cpu()) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])

@@ -468,10 +468,9 @@ __global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int 
 // ---------------------------------------------------------------------------------------------------
 // k = 1 forward / dgrad: no halo, inputs straight from global memory (4 voxels per lane, vectorised).
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int COB, bool VEC>
+template <typename T, int COB, bool VEC, int CIC = 4>   // CIC input channels per step: their loads are issued together
 __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
   constexpr int VW = VEC ? VWT<T>::v : 4;              // 16-byte runs when the layout allows
-  constexpr int CIC = 4;                               // input channels per step: their loads are issued together
   __shared__ float s_w[132 * COB];
   __shared__ double s_red[4 * 2 * COB];
   const int tid = threadIdx.x;
@@ -1081,6 +1080,20 @@ template <typename T> static const char* tname() { return FmtOf<T>::v == 0 ? "bf
     else { LAUNCH_FWD(T, K, S, COB, 2); }                            \
   } while (0)
 
+// Launch-plan tunables of the small streaming kernels (xh_set_option keys 6..8; 0 = the built-in rule, which is what
+// tools/microbench_small.py measured best at this network's shapes)
+static int g_dw_minsd = 0;     // key 6: fewest planes a depthwise sliding-window workgroup marches through
+static int g_dw_target = 1024; // key 7: workgroup count the depth split of the sliding-window kernels aims at
+static int g_c1w_wgs = 320;    // key 8: workgroup count the k = 1 weight gradient aims at
+
+// Planes per sliding-window segment: at 128^3 the kernels are issue-bound and the two halo planes per segment cost more
+// than the extra workgroups return (8 planes); at 64^3 / 32^3 the launch is a latency chain of one load per plane over
+// too few waves, and shorter segments win (64^3: 22 -> 16 us with 4; 32^3: 22 -> 11 us with 2).
+static int dw_min_planes(long long dhw) {
+  if (g_dw_minsd > 0) return g_dw_minsd;
+  return dhw >= (1 << 21) ? 8 : dhw >= (1 << 18) ? 4 : 2;
+}
+
 template <typename T>
 static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
@@ -1093,6 +1106,15 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     const bool vec = (dhw % VW1 == 0) && (d->xa_bs % VW1 == 0) && (d->xb_bs % VW1 == 0) && (d->y_bs % VW1 == 0) &&
                      (d->epi != 1 || (d->ea_bs % VW1 == 0 && d->eb_bs % VW1 == 0));
     long long gx1 = (dhw + 256 * VW1 - 1) / (256 * VW1);
+    // few lanes (the deep levels): the run time is the per-lane chain of Cin/CIC dependent load steps, so take narrow
+    // output blocks (more workgroups) with 16 channels in flight per step
+    if (vec && cin_g >= 16 && cout_g >= 2 && gx1 * a.ncob * d->N * d->groups < 128) {
+      a = make_k(d, p, 2, 8);
+      dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
+      xh_note_kernel("conv1x1_kernel<%s, 2, true, 16>", tname<T>());
+      hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      return xh_launch_status();
+    }
     const long long cap1 = cdiv(2048, a.ncob * d->N * d->groups);
     if (gx1 > cap1) gx1 = cap1;
     dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
@@ -1120,8 +1142,8 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
         a.tilesW = cdiv(d->W, txn * VW);
         a.tilesH = cdiv(d->H, 256 / txn);
         const int base = a.tilesW * a.tilesH * d->Cin * d->N;
-        int dsegs = cdiv(1024, base);
-        if (dsegs > d->D / 8) dsegs = d->D / 8;
+        int dsegs = cdiv(g_dw_target, base);
+        if (dsegs > d->D / dw_min_planes(dhw3)) dsegs = d->D / dw_min_planes(dhw3);
         if (dsegs < 1) dsegs = 1;
         const int sd = cdiv(d->D, dsegs);
         dsegs = cdiv(d->D, sd);
@@ -1227,6 +1249,9 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 2) { g_xh_disable = value; return XH_OK; }
   if (key == 3) { extern int g_mfma_wgs; g_mfma_wgs = value > 0 ? value : 512; return XH_OK; }
   if (key == 4) { extern int g_mfma_occ; g_mfma_occ = value; return XH_OK; }
+  if (key == 6) { g_dw_minsd = value < 0 ? 0 : value; return XH_OK; }
+  if (key == 7) { g_dw_target = value < 1 ? 1 : value; return XH_OK; }
+  if (key == 8) { g_c1w_wgs = value < 1 ? 320 : value; return XH_OK; }
   if (key == 5) { extern int g_dconv_kq; g_dconv_kq = value == 1 ? 1 : 2; return XH_OK; }
   return XH_ERR_ARG;
 }
@@ -1692,8 +1717,10 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
     const bool vec = (dhw1 % VW1 == 0) && (d->xa_bs % VW1 == 0) && (d->xb_bs % VW1 == 0) && (d->ea_bs % VW1 == 0);
     const long long total = (long long)d->N * dhw1 / (vec ? VW1 : 1);
     const int ny1 = cdiv(cin_g, 4) * cdiv(cout_g, 4) * d->groups;
-    int gx = (int)((total + 256 * 8 - 1) / (256 * 8));
-    const int cap = cdiv(2048, ny1);
+    // Every workgroup ends in a pass of same-address device-scope atomics, which serialise (~65 ns each across the 8
+    // XCDs): a few hundred workgroups is the optimum between the per-lane load chain and that tail.
+    int gx = (int)((total + 255) / 256);
+    const int cap = cdiv(g_c1w_wgs, ny1);
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     dim3 grid(gx, cdiv(cin_g, 4) * cdiv(cout_g, 4), d->groups);
@@ -1713,8 +1740,8 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
       wa.c.tilesW = cdiv(d->W, txn * VW);
       wa.c.tilesH = cdiv(d->H, 256 / txn);
       const int base = wa.c.tilesW * wa.c.tilesH * d->Cin * d->N;
-      int dsegs = cdiv(1024, base);
-      if (dsegs > d->D / 8) dsegs = d->D / 8;
+      int dsegs = cdiv(g_dw_target, base);
+      if (dsegs > d->D / dw_min_planes(dhw3)) dsegs = d->D / dw_min_planes(dhw3);
       if (dsegs < 1) dsegs = 1;
       const int sd = cdiv(d->D, dsegs);
       dsegs = cdiv(d->D, sd);

@@ -12,6 +12,8 @@
 //    fragments with v_alignbyte: 3 LDS reads + 8 VALU per 3 MFMAs.
 //  * Each wave keeps all 3*ceil(9/(16/CP)) accumulator tiles in registers for the whole run of planes; one LDS
 //    reduction across waves and one pass of contiguous fp32 atomics per workgroup at the end.
+//  * Narrow volumes (W = 16 / 8, the deep levels): the 32 voxels of a K step are 2 / 4 consecutive rows of 16 / 8 voxels
+//    (a.rs rows per step); only the lane -> (row, chunk) mapping changes.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
@@ -30,6 +32,7 @@ struct WgMK {
   int cout_set;     // output channels of a set
   int ntile;        // 16-wide output-channel tiles per set
   int nctile;       // CP-wide input-channel tiles per set
+  int rs;           // rows per MFMA K group: 1 (W % 32 == 0), 2 (W == 16), 4 (W == 8)
 };
 
 template <int FMT, int CP, int NT>
@@ -74,17 +77,20 @@ __device__ __forceinline__ void conv3_wgrad_body(const WgMK& a, const int bid_x,
 
   // ---- column role of this lane ----
   const int cil = nn % CP, rsel = nn / CP;
+  const int rs = a.rs, cw = 4 / rs;                   // rows per K step, 16-byte chunks per row
+  const int rsub = g4 / cw, chunk = g4 % cw;          // this lane's row within the step and chunk within the row
+  const int nrg = TH / rs;                            // row groups (K steps) per plane
   int boff[TPK], bkd[TPK];                            // in-plane byte offset (row kh, channel, chunk g4+1) and kd per tile
 #pragma unroll
   for (int t = 0; t < TPK; ++t) {
     int r9 = t * R + rsel;
     if (r9 > 8) r9 = 8;                               // column unused: any valid address
     bkd[t] = r9 / 3;
-    boff[t] = cil * CHS + (r9 % 3) * ROWB + (g4 + 1) * 16;
+    boff[t] = cil * CHS + (r9 % 3 + rsub) * ROWB + (chunk + 1) * 16;
   }
   // ---- A operand source: dY row of channel co_base + nn ----
   const bool a_ok = nn < co_lim;
-  const ST* dyp = (const ST*)a.p.ea + n * a.d.ea_bs + (long long)(co_base + (a_ok ? nn : 0)) * odhw + ow0 + g4 * 8;
+  const ST* dyp = (const ST*)a.p.ea + n * a.d.ea_bs + (long long)(co_base + (a_ok ? nn : 0)) * odhw + ow0 + chunk * 8;
 
   // ---- staging plan ----
   const ST* sp_src[NIT];
@@ -158,9 +164,10 @@ __device__ __forceinline__ void conv3_wgrad_body(const WgMK& a, const int bid_x,
   auto load_dy = [&](int d) {
 #pragma unroll
     for (int ri = 0; ri < RPW; ++ri) {
-      const int oh = oh0 + wv + ri * NWV;
+      const int rg = wv + ri * NWV;
+      const int oh = oh0 + rg * rs + rsub;
       a_nxt[ri] = make_uint4(0, 0, 0, 0);
-      if (a_ok && wv + ri * NWV < TH && oh < Ho) a_nxt[ri] = *reinterpret_cast<const uint4*>(dyp + ((long long)d * Ho + oh) * Wo);
+      if (a_ok && rg < nrg && oh < Ho) a_nxt[ri] = *reinterpret_cast<const uint4*>(dyp + ((long long)d * Ho + oh) * Wo);
     }
   };
   load_dy(d_begin);
@@ -175,9 +182,9 @@ __device__ __forceinline__ void conv3_wgrad_body(const WgMK& a, const int bid_x,
     const int sbase = d + 3;
 #pragma unroll
     for (int ri = 0; ri < RPW; ++ri) {
-      const int rr = wv + ri * NWV;
-      const int oh = oh0 + rr;
-      if (rr >= TH || oh >= Ho) continue;
+      const int rg = wv + ri * NWV;
+      const int rr = rg * rs;                           // first row of the step (block-uniform per wave)
+      if (rg >= nrg || oh0 + rr >= Ho) continue;
       // A fragment: 8 voxels of dY
       const uint4 araw = a_cur[ri];
       const bf16x8 av = __builtin_bit_cast(bf16x8, araw);
@@ -283,7 +290,7 @@ struct WgPlan { WgMK a; unsigned gx; int ny; size_t shm; bool big; int cp; };
 // fills the launch plan; returns false when the shape is not eligible for the MFMA weight gradient
 static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgPlan* pl) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return false;
-  if (d->W % 32 != 0 || d->Wo != d->W) return false;
+  if ((d->W % 32 != 0 && d->W != 16 && d->W != 8) || d->Wo != d->W) return false;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g < 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return false;
@@ -314,7 +321,8 @@ static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const d
   a.nctile = cdiv(a.cin_set, cp);
   const int ny = (d->groups / gs) * a.ntile * a.nctile;
   if (ny > 65535) return false;
-  a.tilesW = d->W / 32; a.tilesH = cdiv(d->Ho, 8);
+  a.rs = d->W >= 32 ? 1 : 32 / d->W;
+  a.tilesW = cdiv(d->W, 32); a.tilesH = cdiv(d->Ho, 8);
   const int cols = a.tilesW * a.tilesH;
   // small volumes: fewer, longer runs so the per-workgroup LDS reduction + atomics pass amortises
   const bool big_vol = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);

@@ -193,15 +193,19 @@ __global__ __launch_bounds__(128) void vil_pre2_kernel(int S, xh_vil_params p, V
 }
 
 // -------------------------------------------------------------------------------------------------
-// gate scans: one wave per (batch, head).  F = inclusive cumsum of logsigmoid(f) (fp64 carry),
-// G = inclusive prefix max of g = i - F with its arg index.  Lane L owns a contiguous chunk; cross-lane
-// carries move through wavefront shuffles.
+// gate scans: one 1024-lane workgroup per (batch, head).  F = inclusive cumsum of logsigmoid(f) (fp64 carry),
+// G = inclusive prefix max of g = i - F with its arg index.  A lane owns a short contiguous chunk (4 tokens at
+// S = 4096, so a wave reads 1 KB runs); carries move through wavefront shuffles, then across the 16 waves through LDS.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void vil_scan_kernel(int S, VilWs w) {
-  const int lane = threadIdx.x;
+constexpr int SCAN_T = 1024, SCAN_W = SCAN_T / 64;
+__global__ __launch_bounds__(SCAN_T) void vil_scan_kernel(int S, VilWs w) {
+  __shared__ double s_sum[SCAN_W];
+  __shared__ float s_max[SCAN_W];
+  __shared__ int s_arg[SCAN_W];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long long base = (long long)blockIdx.x * S;
-  const int chunk = (S + 63) / 64;
-  const int t0 = lane * chunk, t1 = min(S, t0 + chunk);
+  const int chunk = (S + SCAN_T - 1) / SCAN_T;
+  const int t0 = min(S, tid * chunk), t1 = min(S, t0 + chunk);
   double loc = 0.0;
   for (int t = t0; t < t1; ++t) loc += (double)logsigmoid_(w.fg[base + t]);
   double inc = loc;
@@ -210,7 +214,10 @@ __global__ __launch_bounds__(64) void vil_scan_kernel(int S, VilWs w) {
     const double up = __shfl_up(inc, o, 64);
     if (lane >= o) inc += up;
   }
-  double run = inc - loc;   // exclusive prefix
+  if (lane == 63) s_sum[wv] = inc;
+  __syncthreads();
+  double run = inc - loc;   // exclusive prefix within the wave ...
+  for (int i = 0; i < wv; ++i) run += s_sum[i];   // ... plus the waves before it
   float lmax = -INFINITY;
   int larg = t0;
   for (int t = t0; t < t1; ++t) {
@@ -228,9 +235,15 @@ __global__ __launch_bounds__(64) void vil_scan_kernel(int S, VilWs w) {
     const int ua = __shfl_up(pa, o, 64);
     if (lane >= o && um >= pm) { pm = um; pa = ua; }   // earlier index wins ties
   }
-  float em = __shfl_up(pm, 1, 64);
-  int ea = __shfl_up(pa, 1, 64);
-  if (lane == 0) { em = -INFINITY; ea = 0; }
+  if (lane == 63) { s_max[wv] = pm; s_arg[wv] = pa; }
+  __syncthreads();
+  float em = -INFINITY;
+  int ea = 0;
+  for (int i = 0; i < wv; ++i)
+    if (s_max[i] > em) { em = s_max[i]; ea = s_arg[i]; }
+  const float xm = __shfl_up(pm, 1, 64);
+  const int xa = __shfl_up(pa, 1, 64);
+  if (lane > 0 && xm > em) { em = xm; ea = xa; }
   for (int t = t0; t < t1; ++t) {
     const float g = w.ig[base + t] - w.F[base + t];
     if (g > em) { em = g; ea = t; }
@@ -240,11 +253,12 @@ __global__ __launch_bounds__(64) void vil_scan_kernel(int S, VilWs w) {
 }
 
 // reverse scan for the backward: df_t = sigmoid(-f_t) * sum_{t'>=t} dF_t'
-__global__ __launch_bounds__(64) void vil_rscan_kernel(int S, VilWs w) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(SCAN_T) void vil_rscan_kernel(int S, VilWs w) {
+  __shared__ double s_sum[SCAN_W];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long long base = (long long)blockIdx.x * S;
-  const int chunk = (S + 63) / 64;
-  const int t0 = lane * chunk, t1 = min(S, t0 + chunk);
+  const int chunk = (S + SCAN_T - 1) / SCAN_T;
+  const int t0 = min(S, tid * chunk), t1 = min(S, t0 + chunk);
   // dF_t = rq_t - ck_t + dm_t - dscat_t ;  di_t = ck_t + dscat_t
   double loc = 0.0;
   for (int t = t0; t < t1; ++t) loc += (double)(w.rq[base + t] - w.ck[base + t] + w.dm[base + t] - w.dscat[base + t]);
@@ -254,7 +268,10 @@ __global__ __launch_bounds__(64) void vil_rscan_kernel(int S, VilWs w) {
     const double dn = __shfl_down(inc, o, 64);
     if (lane + o < 64) inc += dn;
   }
-  double run = inc - loc;   // sum over later lanes
+  if (lane == 0) s_sum[wv] = inc;
+  __syncthreads();
+  double run = inc - loc;   // sum over the later lanes of the wave ...
+  for (int i = wv + 1; i < SCAN_W; ++i) run += s_sum[i];   // ... and the later waves
   for (int t = t1 - 1; t >= t0; --t) {
     run += (double)(w.rq[base + t] - w.ck[base + t] + w.dm[base + t] - w.dscat[base + t]);
     const float f = w.fg[base + t];
@@ -1099,7 +1116,7 @@ static int vil_fwd_impl(hipStream_t st, const T* xa, const T* xb, T* out, int B,
   ws_layout(&w, ws, B, S, C);
   hipLaunchKernelGGL((vil_pre1_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, xb, S, *p, w);
   hipLaunchKernelGGL((vil_pre2_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, w);
-  hipLaunchKernelGGL(vil_scan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
+  hipLaunchKernelGGL(vil_scan_kernel, dim3(B * NH), dim3(SCAN_T), 0, st, S, w);
   const long long rows_f = (long long)B * NH * S;
   if (DH == 16 && !(g_xh_disable & 8)) {              // chunk-recurrent form on the matrix cores
     const int nchunk = cdiv(S, CL);
@@ -1136,7 +1153,7 @@ static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, co
     hipLaunchKernelGGL((mlstm_bwd_kv_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
   }
   hipLaunchKernelGGL((mlstm_bwd_dots_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, w);
-  hipLaunchKernelGGL(vil_rscan_kernel, dim3(B * NH), dim3(64), 0, st, S, w);
+  hipLaunchKernelGGL(vil_rscan_kernel, dim3(B * NH), dim3(SCAN_T), 0, st, S, w);
   hipLaunchKernelGGL((vil_pre2_bwd_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, *g, w);
   hipLaunchKernelGGL((vil_pre1_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, dxin, S, *p, *g, w);
   return xh_launch_status();
