@@ -38,7 +38,7 @@ def c1_case(cin, cout, S, dt):
     return fwd, wg, (cin + cout) * S ** 3 * x.element_size()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--reducers" not in sys.argv:
     dt = torch.bfloat16
     print("== depthwise k3 (forward, wgrad): min planes per segment (0 = built-in rule)")
     for C, S in [(4, 128), (8, 64), (16, 32)]:
@@ -72,3 +72,25 @@ if __name__ == "__main__":
         ops.set_mfma(True)
         print(f"k3 wgrad {cin}->{cout} g{g} @{S}: vector {res[0][0]:6.1f} us ({res[0][1]}), MFMA {res[1][0]:6.1f} us ({res[1][1]})")
     sys.stdout.flush()
+
+
+def reducers():
+    """moments / act_bwd_reduce / pair_sums at the step's shapes vs the reducing kernels' workgroup target (key 9)."""
+    dt = torch.bfloat16
+    for C, S in [(4, 128), (16, 128), (8, 64), (32, 64), (16, 32)]:
+        x = torch.randn(1, C, S, S, S, device="cuda").to(dt)
+        dy = torch.randn(1, C, S, S, S, device="cuda").to(dt)
+        sc = torch.rand(1, C, device="cuda") + 0.5; sh = torch.randn(1, C, device="cuda")
+        red = torch.zeros(1, C, 2, dtype=torch.float64, device="cuda")
+        line = f"C={C:3d} @{S:3d} ({x.numel() * 2 / 1e6:5.1f} MB/tensor):"
+        for tgt in (2048, 1024, 512, 256):
+            opt(9, tgt)
+            tm = bench(lambda: ops.moments(x, red))
+            ta = bench(lambda: ops.act_bwd_reduce(dy, x, sc, sh, 0.01))
+            line += f"  wg{tgt}: moments {tm:5.1f} act_bwd_reduce {ta:5.1f}"
+        print(line)
+    opt(9, 0)
+
+
+if __name__ == "__main__" and "--reducers" in sys.argv:
+    reducers()

@@ -1252,6 +1252,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 6) { g_dw_minsd = value < 0 ? 0 : value; return XH_OK; }
   if (key == 7) { g_dw_target = value < 1 ? 1 : value; return XH_OK; }
   if (key == 8) { g_c1w_wgs = value < 1 ? 320 : value; return XH_OK; }
+  if (key == 9) { extern int g_red_wgs; g_red_wgs = value < 0 ? 0 : value; return XH_OK; }
   if (key == 5) { extern int g_dconv_kq; g_dconv_kq = value == 1 ? 1 : 2; return XH_OK; }
   return XH_ERR_ARG;
 }

@@ -2,16 +2,12 @@
 // trilinear resampling, product-of-experts + reparameterisation, attention gates.
 // One lane handles 4 consecutive voxels of one (n, c) row (16 B fp32 / 8 B bf16 accesses) when the row
 // length and strides allow it, otherwise a scalar tail path.  Reductions: fp32 in the lane, fp32 across
-// the block, fp64 atomics across blocks.
+// the block, fp64 atomics across blocks (few workgroups per address: red_grid below).
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
 #define EW_BLOCK 256
-// voxels per lane: 16-byte accesses for both storage types (4 fp32 or 8 bf16)
-// elements of one (n,c) row covered by a block: 16 vector iterations per lane, so a 128^3 row is 128 (fp32: 256)
-// workgroups -- enough to fill the chip with >= 4 channels, and few enough that the per-workgroup fp64 atomics of
-// the reducing kernels do not serialise on one address
-template <typename T> constexpr int ew_chunk() { return EW_BLOCK * VWT<T>::v * 16; }
+// voxels per lane: 16-byte accesses for both storage types (4 fp32 or 8 x 16-bit)
 
 template <typename T, int N>
 __device__ __forceinline__ void ldrow(const T* p, long long q, int valid, bool vec, float (&o)[N]) {
@@ -46,6 +42,25 @@ template <typename T>
 static inline dim3 row_grid(long long dhw, int C, int N) {
   const long long maxb = (dhw + EW_BLOCK * VWT<T>::v - 1) / (EW_BLOCK * VWT<T>::v);
   long long want = (2048 + (long long)C * N - 1) / ((long long)C * N);
+  if (want < 1) want = 1;
+  return dim3((unsigned)(want < maxb ? want : maxb), C, N);
+}
+// Kernels that end in fp64 atomics on one address per (n, c) row (moments, act_bwd_reduce, duse_gate_bwd_row): the
+// device-scope atomics of one address serialise across the 8 XCDs at ~50 ns each, so 512 workgroups per row cost 28 us
+// whatever the row holds (4 channels @128^3: 27.5 us with 512 per row, 8.6 us with 64).  At most 64 workgroups per row,
+// ~1024 per launch, and no workgroup below 16 KB (measured optimum at every shape of the step, tools/microbench_small.py
+// --reducers).
+int g_red_wgs = 0;      // xh_set_option(9, n): overrides the ~1024 workgroup target (experiments)
+template <typename T>
+static inline dim3 red_grid(long long dhw, int C, int N) {
+  const long long maxb = (dhw + EW_BLOCK * VWT<T>::v - 1) / (EW_BLOCK * VWT<T>::v);
+  const long long rows = (long long)C * N;
+  long long want = ((g_red_wgs > 0 ? g_red_wgs : 1024) + rows - 1) / rows;
+  if (g_red_wgs <= 0) {
+    const long long by_bytes = dhw * (long long)sizeof(T) / (16 * 1024);
+    if (want > 64) want = 64;
+    if (want > by_bytes) want = by_bytes;
+  }
   if (want < 1) want = 1;
   return dim3((unsigned)(want < maxb ? want : maxb), C, N);
 }
@@ -90,7 +105,7 @@ extern "C" int xh_moments(void* stream, int dtype, const void* x, long long x_bs
                           double* red, long long red_rs) {
   if (!x || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   const bool vec32 = vec_ok<float>(DHW, {x_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs});
-  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
+  const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
     hipLaunchKernelGGL(moments_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs, vec32);
   else if (dtype == XH_BF16)
@@ -220,7 +235,7 @@ extern "C" int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long l
                                  int N, int C, long long DHW, const float* sc, const float* sh, float slope, double* red) {
   if (!dy || !x || !sc || !sh || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs});
-  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
+  const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
     hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red, vec32);
   else if (dtype == XH_BF16)
@@ -997,57 +1012,92 @@ extern "C" int xh_poe_bwd(void* stream, int dtype, const void* feat, const float
 }
 
 // ---------------------------------------------------------------------------------------- channel pool / gates
-// One lane per voxel; loops over channels (C <= 128).  grid: (chunks over DHW, 1, N)
+// One lane per 16-byte run of voxels (8 x 16-bit / 4 x fp32; element-wise tail when the layout does not allow the wide
+// accesses); loops over channels (C <= 128).  grid: (chunks over the runs, 1, N)
+#define VOX_LOOP_BEGIN                                                                                               \
+  constexpr int VW = VWT<T>::v;                                                                                      \
+  const int n = blockIdx.z;                                                                                          \
+  const long long nrun = (dhw + VW - 1) / VW;                                                                        \
+  for (long long run = (long long)blockIdx.x * 256 + threadIdx.x; run < nrun; run += (long long)gridDim.x * 256) {   \
+    const long long q = run * VW;                                                                                    \
+    const int valid = (int)min((long long)VW, dhw - q);
+#define VOX_LOOP_END }
 template <typename T>
 __global__ __launch_bounds__(256) void channel_pool_fwd_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
-                                                              long long dhw) {
-  const int n = blockIdx.z;
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
-    const T* xp = x + n * x_bs + p;
-    float m = -INFINITY, s = 0.f;
+                                                              long long dhw, bool vec) {
+  VOX_LOOP_BEGIN
+    const T* xp = x + n * x_bs;
+    float m[VW], s[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
     for (int c = 0; c < C; ++c) {
-      const float v = ldf(xp, (long long)c * dhw);
-      m = (v > m || v != v) ? v : m;
-      s += v;
+      float xv[VW];
+      ldrow(xp + (long long)c * dhw, q, valid, vec, xv);
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        m[v] = (xv[v] > m[v] || xv[v] != xv[v]) ? xv[v] : m[v];
+        s[v] += xv[v];
+      }
     }
-    stf(y + n * y_bs, p, m);
-    stf(y + n * y_bs, dhw + p, s / (float)C);
-  }
+#pragma unroll
+    for (int v = 0; v < VW; ++v) s[v] = s[v] / (float)C;
+    strow(y + n * y_bs, q, valid, vec, m);
+    strow(y + n * y_bs + dhw, q, valid, vec, s);
+  VOX_LOOP_END
 }
 template <typename T>
 __global__ __launch_bounds__(256) void channel_pool_bwd_kernel(const T* x, long long x_bs, const T* dy, long long dy_bs,
-                                                              T* dx, long long dx_bs, int C, long long dhw, int accumulate) {
-  const int n = blockIdx.z;
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
-    const T* xp = x + n * x_bs + p;
-    float m = -INFINITY;
-    int arg = 0;
+                                                              T* dx, long long dx_bs, int C, long long dhw, int accumulate,
+                                                              bool vec) {
+  VOX_LOOP_BEGIN
+    const T* xp = x + n * x_bs;
+    float m[VW];
+    int arg[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; arg[v] = 0; }
     for (int c = 0; c < C; ++c) {
-      const float v = ldf(xp, (long long)c * dhw);
-      if (v > m || v != v) { m = v; arg = c; }
+      float xv[VW];
+      ldrow(xp + (long long)c * dhw, q, valid, vec, xv);
+#pragma unroll
+      for (int v = 0; v < VW; ++v)
+        if (xv[v] > m[v] || xv[v] != xv[v]) { m[v] = xv[v]; arg[v] = c; }
     }
-    const float g0 = ldf(dy + n * dy_bs, p), g1 = ldf(dy + n * dy_bs, dhw + p) / (float)C;
-    T* dp = dx + n * dx_bs + p;
+    float g0[VW], g1[VW];
+    ldrow(dy + n * dy_bs, q, valid, vec, g0);
+    ldrow(dy + n * dy_bs + dhw, q, valid, vec, g1);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) g1[v] = g1[v] / (float)C;
+    T* dp = dx + n * dx_bs;
     for (int c = 0; c < C; ++c) {
-      const float prev = accumulate ? ldf((const T*)dp, (long long)c * dhw) : 0.f;
-      stf(dp, (long long)c * dhw, prev + g1 + (c == arg ? g0 : 0.f));
+      float o[VW];
+      if (accumulate) {
+        ldrow((const T*)dp + (long long)c * dhw, q, valid, vec, o);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) o[v] = 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < VW; ++v) o[v] = o[v] + g1[v] + (c == arg[v] ? g0[v] : 0.f);
+      strow(dp + (long long)c * dhw, q, valid, vec, o);
     }
-  }
+  VOX_LOOP_END
 }
-static inline dim3 vox_grid(long long dhw, int N) {
-  long long b = (dhw + 255) / 256;
-  if (b > 4096) b = 4096;
+template <typename T>
+static inline dim3 vox_grid(long long dhw, int N, int cap = 4096) {
+  const long long nrun = (dhw + VWT<T>::v - 1) / VWT<T>::v;
+  long long b = (nrun + 255) / 256;
+  if (b > cap) b = cap;
   return dim3((unsigned)b, 1, N);
 }
 extern "C" int xh_channel_pool_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
                                    int C, long long DHW) {
   if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(channel_pool_fwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW);
+    hipLaunchKernelGGL(channel_pool_fwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, vec_ok<float>(DHW, {x_bs, y_bs}));
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(channel_pool_fwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW);
+    hipLaunchKernelGGL(channel_pool_fwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, vec_ok<bf16_t>(DHW, {x_bs, y_bs}));
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(channel_pool_fwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW);
+    hipLaunchKernelGGL(channel_pool_fwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, vec_ok<f16_t>(DHW, {x_bs, y_bs}));
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1056,11 +1106,11 @@ extern "C" int xh_channel_pool_bwd(void* stream, int dtype, const void* x, long 
                                    void* dx, long long dx_bs, int N, int C, long long DHW, int accumulate) {
   if (!x || !dy || !dx || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(channel_pool_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, DHW, accumulate);
+    hipLaunchKernelGGL(channel_pool_bwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, DHW, accumulate, vec_ok<float>(DHW, {x_bs, dy_bs, dx_bs}));
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(channel_pool_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, DHW, accumulate);
+    hipLaunchKernelGGL(channel_pool_bwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, DHW, accumulate, vec_ok<bf16_t>(DHW, {x_bs, dy_bs, dx_bs}));
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(channel_pool_bwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, C, DHW, accumulate);
+    hipLaunchKernelGGL(channel_pool_bwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, C, DHW, accumulate, vec_ok<f16_t>(DHW, {x_bs, dy_bs, dx_bs}));
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1083,25 +1133,47 @@ __global__ __launch_bounds__(EW_BLOCK) void gate_fwd_kernel(const T* x, long lon
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* x, long long x_bs, const T* s, long long s_bs, const T* dy,
                                                       long long dy_bs, T* dx, long long dx_bs, T* ds, long long ds_bs, int C,
-                                                      long long dhw, int acc_dx, int acc_ds) {
-  const int n = blockIdx.z;
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
-    const float g1 = 1.f + ldf(s + n * s_bs, p);
-    float a = 0.f;
+                                                      long long dhw, int acc_dx, int acc_ds, bool vec) {
+  VOX_LOOP_BEGIN
+    float g1[VW], a[VW];
+    ldrow(s + n * s_bs, q, valid, vec, g1);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { g1[v] = 1.f + g1[v]; a[v] = 0.f; }
     for (int c = 0; c < C; ++c) {
-      const long long o = (long long)c * dhw + p;
-      const float g = ldf(dy + n * dy_bs, o);
-      a = fmaf(g, ldf(x + n * x_bs, o), a);
+      const long long off = (long long)c * dhw;
+      float g[VW], xv[VW];
+      ldrow(dy + n * dy_bs + off, q, valid, vec, g);
+      ldrow(x + n * x_bs + off, q, valid, vec, xv);
+#pragma unroll
+      for (int v = 0; v < VW; ++v) a[v] = fmaf(g[v], xv[v], a[v]);
       if (dx) {
-        T* dp = dx + n * dx_bs;
-        stf(dp, o, g * g1 + (acc_dx ? ldf((const T*)dp, o) : 0.f));
+        T* dp = dx + n * dx_bs + off;
+        float o[VW];
+        if (acc_dx) {
+          ldrow((const T*)dp, q, valid, vec, o);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VW; ++v) o[v] = 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < VW; ++v) o[v] = g[v] * g1[v] + o[v];
+        strow(dp, q, valid, vec, o);
       }
     }
     if (ds) {
       T* sp = ds + n * ds_bs;
-      stf(sp, p, a + (acc_ds ? ldf((const T*)sp, p) : 0.f));
+      float o[VW];
+      if (acc_ds) {
+        ldrow((const T*)sp, q, valid, vec, o);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) o[v] = 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < VW; ++v) o[v] = a[v] + o[v];
+      strow(sp, q, valid, vec, o);
     }
-  }
+  VOX_LOOP_END
 }
 extern "C" int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y,
                            long long y_bs, int N, int C, long long DHW) {
@@ -1123,11 +1195,11 @@ extern "C" int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_b
                            int C, long long DHW, int acc_dx, int acc_ds) {
   if (!x || !s || !dy || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(gate_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, (float*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
+    hipLaunchKernelGGL(gate_bwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, (float*)ds, ds_bs, C, DHW, acc_dx, acc_ds, vec_ok<float>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs}));
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, (bf16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
+    hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, (bf16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds, vec_ok<bf16_t>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs}));
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(gate_bwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, (f16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds);
+    hipLaunchKernelGGL(gate_bwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, (f16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds, vec_ok<f16_t>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs}));
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1177,13 +1249,20 @@ __global__ __launch_bounds__(EW_BLOCK) void duse_gate_bwd_row_kernel(const T* x,
 }
 template <typename T>
 __global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* x, long long x_bs, const T* du, long long du_bs,
-                                                              T* dsp, long long dsp_bs, int C, long long dhw) {
-  const int n = blockIdx.z;
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
-    float a = 0.f;
-    for (int c = 0; c < C; ++c) a = fmaf(ldf(du + n * du_bs, (long long)c * dhw + p), ldf(x + n * x_bs, (long long)c * dhw + p), a);
-    stf(dsp + n * dsp_bs, p, a);
-  }
+                                                              T* dsp, long long dsp_bs, int C, long long dhw, bool vec) {
+  VOX_LOOP_BEGIN
+    float a[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) a[v] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float g[VW], xv[VW];
+      ldrow(du + n * du_bs + (long long)c * dhw, q, valid, vec, g);
+      ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+#pragma unroll
+      for (int v = 0; v < VW; ++v) a[v] = fmaf(g[v], xv[v], a[v]);
+    }
+    strow(dsp + n * dsp_bs, q, valid, vec, a);
+  VOX_LOOP_END
 }
 extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                                 long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW) {
@@ -1205,16 +1284,16 @@ extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long lon
                                 long long dsp_bs, double* dch, int N, int C, long long DHW) {
   if (!x || !ch || !sp || !du || !dx || !dsp || !dch || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   const bool vec32 = vec_ok<float>(DHW, {x_bs, sp_bs, du_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, sp_bs, du_bs, dx_bs});
-  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
+  const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32) {
     hipLaunchKernelGGL(duse_gate_bwd_row_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (const float*)du, du_bs, (float*)dx, dx_bs, dch, C, DHW, vec32);
-    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)du, du_bs, (float*)dsp, dsp_bs, C, DHW);
+    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)du, du_bs, (float*)dsp, dsp_bs, C, DHW, vec_ok<float>(DHW, {x_bs, du_bs, dsp_bs}));
   } else if (dtype == XH_BF16) {
     hipLaunchKernelGGL(duse_gate_bwd_row_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW, vec16);
-    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW);
+    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW, vec_ok<bf16_t>(DHW, {x_bs, du_bs, dsp_bs}));
   } else if (dtype == XH_F16) {
     hipLaunchKernelGGL(duse_gate_bwd_row_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (const f16_t*)du, du_bs, (f16_t*)dx, dx_bs, dch, C, DHW, vec16);
-    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)du, du_bs, (f16_t*)dsp, dsp_bs, C, DHW);
+    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)du, du_bs, (f16_t*)dsp, dsp_bs, C, DHW, vec_ok<f16_t>(DHW, {x_bs, du_bs, dsp_bs}));
   } else {
     return XH_ERR_DTYPE;
   }
@@ -1359,59 +1438,100 @@ extern "C" int xh_duse_fc_bwd(void* stream, const double* red_r, const double* r
 // r_c = relu(relu(t_c*sc+sh) + x_c);  a = sigmoid(w0*max_c r + w1*mean_c r)
 template <typename T>
 __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* t, const T* x, const float* sc, const float* sh,
-                                                          const float* w2, T* a, int C, long long dhw) {
-  const int n = blockIdx.z;
+                                                          const float* w2, T* a, int C, long long dhw, bool vec) {
   const float w0 = w2[0], w1 = w2[1];
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
-    float m = -INFINITY, s = 0.f;
+  VOX_LOOP_BEGIN
+    float m[VW], s[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
     for (int c = 0; c < C; ++c) {
-      const long long o = ((long long)n * C + c) * dhw + p;
-      float y = ldf(t, o) * sc[n * C + c] + sh[n * C + c];
-      y = y > 0.f ? y : 0.f;
-      float r = y + ldf(x, o);
-      r = r > 0.f ? r : 0.f;
-      m = r > m ? r : m;
-      s += r;
+      const long long o = ((long long)n * C + c) * dhw;
+      const float scv = sc[n * C + c], shv = sh[n * C + c];
+      float tv[VW], xv[VW];
+      ldrow(t + o, q, valid, vec, tv);
+      ldrow(x + o, q, valid, vec, xv);
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        float y = tv[v] * scv + shv;
+        y = y > 0.f ? y : 0.f;
+        float r = y + xv[v];
+        r = r > 0.f ? r : 0.f;
+        m[v] = r > m[v] ? r : m[v];
+        s[v] += r;
+      }
     }
-    stf(a, (long long)n * dhw + p, sigmoidf_(w0 * m + w1 * s / (float)C));
-  }
+    float out[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) out[v] = sigmoidf_(w0 * m[v] + w1 * s[v] / (float)C);
+    strow(a + (long long)n * dhw, q, valid, vec, out);
+  VOX_LOOP_END
 }
 template <typename T>
 __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* t, const T* x, const float* sc, const float* sh,
                                                           const float* w2, const T* a, const T* da, T* dtg, T* dx,
-                                                          double* dw2acc, int C, long long dhw, int acc_dx) {
+                                                          double* dw2acc, int C, long long dhw, int acc_dx, bool vec) {
   __shared__ double s_red[4 * 2];
-  const int n = blockIdx.z;
   const float w0 = w2[0], w1 = w2[1];
   double sacc[2] = {0.0, 0.0};
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < dhw; p += (long long)gridDim.x * 256) {
-    float m = -INFINITY, s = 0.f;
-    int arg = 0;
+  VOX_LOOP_BEGIN
+    float m[VW], s[VW];
+    int arg[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; arg[v] = 0; }
     for (int c = 0; c < C; ++c) {
-      const long long o = ((long long)n * C + c) * dhw + p;
-      float y = ldf(t, o) * sc[n * C + c] + sh[n * C + c];
-      y = y > 0.f ? y : 0.f;
-      float r = y + ldf(x, o);
-      r = r > 0.f ? r : 0.f;
-      if (r > m) { m = r; arg = c; }
-      s += r;
+      const long long o = ((long long)n * C + c) * dhw;
+      const float scv = sc[n * C + c], shv = sh[n * C + c];
+      float tv[VW], xv[VW];
+      ldrow(t + o, q, valid, vec, tv);
+      ldrow(x + o, q, valid, vec, xv);
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        float y = tv[v] * scv + shv;
+        y = y > 0.f ? y : 0.f;
+        float r = y + xv[v];
+        r = r > 0.f ? r : 0.f;
+        if (r > m[v]) { m[v] = r; arg[v] = c; }
+        s[v] += r;
+      }
     }
-    const float av = ldf(a, (long long)n * dhw + p);
-    const float dpre = ldf(da, (long long)n * dhw + p) * av * (1.f - av);
-    sacc[0] += (double)(dpre * m);
-    sacc[1] += (double)(dpre * (s / (float)C));
-    const float gmax = dpre * w0, gmean = dpre * w1 / (float)C;
+    float av[VW], dpre[VW];
+    ldrow(a + (long long)n * dhw, q, valid, vec, av);
+    ldrow(da + (long long)n * dhw, q, valid, vec, dpre);
+    float t0 = 0.f, t1 = 0.f;                           // lanes past the row end: a = da = 0, so they add nothing
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      dpre[v] = dpre[v] * av[v] * (1.f - av[v]);
+      t0 = fmaf(dpre[v], m[v], t0);
+      t1 = fmaf(dpre[v], s[v] / (float)C, t1);
+    }
+    sacc[0] += (double)t0;
+    sacc[1] += (double)t1;
     for (int c = 0; c < C; ++c) {
-      const long long o = ((long long)n * C + c) * dhw + p;
-      const float yraw = ldf(t, o) * sc[n * C + c] + sh[n * C + c];
-      const float y = yraw > 0.f ? yraw : 0.f;
-      const float r = y + ldf(x, o);
-      float dr = gmean + (c == arg ? gmax : 0.f);
-      dr = r > 0.f ? dr : 0.f;
-      stf(dx, o, dr + (acc_dx ? ldf((const T*)dx, o) : 0.f));
-      stf(dtg, o, yraw > 0.f ? dr : 0.f);
+      const long long o = ((long long)n * C + c) * dhw;
+      const float scv = sc[n * C + c], shv = sh[n * C + c];
+      float tv[VW], xv[VW], odx[VW], odt[VW];
+      ldrow(t + o, q, valid, vec, tv);
+      ldrow(x + o, q, valid, vec, xv);
+      if (acc_dx) {
+        ldrow((const T*)dx + o, q, valid, vec, odx);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) odx[v] = 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        const float yraw = tv[v] * scv + shv;
+        const float y = yraw > 0.f ? yraw : 0.f;
+        const float r = y + xv[v];
+        float dr = dpre[v] * w1 / (float)C + (c == arg[v] ? dpre[v] * w0 : 0.f);
+        dr = r > 0.f ? dr : 0.f;
+        odx[v] = dr + odx[v];
+        odt[v] = yraw > 0.f ? dr : 0.f;
+      }
+      strow(dx + o, q, valid, vec, odx);
+      strow(dtg + o, q, valid, vec, odt);
     }
-  }
+  VOX_LOOP_END
   block_sum_d<2>(sacc, s_red, 4);
   if (threadIdx.x < 2) atomicAdd(&dw2acc[threadIdx.x], s_red[threadIdx.x]);
 }
@@ -1419,11 +1539,11 @@ extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const voi
                                const float* w2, void* a, int N, int C, long long DHW) {
   if (!t || !x || !sc || !sh || !w2 || !a || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(skr_tail_fwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW);
+    hipLaunchKernelGGL(skr_tail_fwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW, vec_ok<float>(DHW, {}));
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(skr_tail_fwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW);
+    hipLaunchKernelGGL(skr_tail_fwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW, vec_ok<bf16_t>(DHW, {}));
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(skr_tail_fwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW);
+    hipLaunchKernelGGL(skr_tail_fwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW, vec_ok<f16_t>(DHW, {}));
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1433,11 +1553,11 @@ extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const voi
                                int N, int C, long long DHW, int acc_dx) {
   if (!t || !x || !sc || !sh || !w2 || !a || !da || !dtg || !dx || !dw2 || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(skr_tail_bwd_kernel<float>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx);
+    hipLaunchKernelGGL(skr_tail_bwd_kernel<float>, vox_grid<float>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx, vec_ok<float>(DHW, {}));
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(skr_tail_bwd_kernel<bf16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx);
+    hipLaunchKernelGGL(skr_tail_bwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx, vec_ok<bf16_t>(DHW, {}));
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(skr_tail_bwd_kernel<f16_t>, vox_grid(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx);
+    hipLaunchKernelGGL(skr_tail_bwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx, vec_ok<f16_t>(DHW, {}));
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
