@@ -38,7 +38,7 @@ def c1_case(cin, cout, S, dt):
     return fwd, wg, (cin + cout) * S ** 3 * x.element_size()
 
 
-if __name__ == "__main__" and "--reducers" not in sys.argv:
+if __name__ == "__main__" and "--reducers" not in sys.argv and "--gates" not in sys.argv:
     dt = torch.bfloat16
     print("== depthwise k3 (forward, wgrad): min planes per segment (0 = built-in rule)")
     for C, S in [(4, 128), (8, 64), (16, 32)]:
@@ -94,3 +94,33 @@ def reducers():
 
 if __name__ == "__main__" and "--reducers" in sys.argv:
     reducers()
+
+
+def gates():
+    """gate_bwd fused (dx and ds in one lane-per-run kernel) vs split (row kernel for dx + channel-sum kernel for ds)."""
+    import ctypes as C
+    dt = torch.bfloat16
+    lib = L.load()
+    for Cc, S in [(4, 128), (16, 128), (8, 64), (16, 32)]:
+        x = torch.randn(1, Cc, S, S, S, device="cuda").to(dt)
+        dy = torch.randn(1, Cc, S, S, S, device="cuda").to(dt)
+        s = torch.rand(1, 1, S, S, S, device="cuda").to(dt)
+        dx = torch.empty_like(x); ds = torch.empty_like(s)
+        st = lambda: torch.cuda.current_stream().cuda_stream
+        dhw = S ** 3
+
+        def fused():
+            lib.xh_gate_bwd(st(), L.XH_BF16, x.data_ptr(), Cc * dhw, s.data_ptr(), dhw, dy.data_ptr(), Cc * dhw, dx.data_ptr(), Cc * dhw,
+                            ds.data_ptr(), dhw, 1, Cc, dhw, 0, 0)
+
+        def split():
+            lib.xh_gate_fwd(st(), L.XH_BF16, dy.data_ptr(), Cc * dhw, s.data_ptr(), dhw, dx.data_ptr(), Cc * dhw, 1, Cc, dhw)
+            lib.xh_gate_bwd(st(), L.XH_BF16, x.data_ptr(), Cc * dhw, s.data_ptr(), dhw, dy.data_ptr(), Cc * dhw, None, 0,
+                            ds.data_ptr(), dhw, 1, Cc, dhw, 0, 0)
+        mb = (3 * Cc + 2) * dhw * 2 / 1e6
+        tf, ts = bench(fused), bench(split)
+        print(f"gate_bwd C={Cc:2d} @{S:3d} ({mb:6.1f} MB): fused {tf:6.1f} us ({mb / tf * 1e-3:5.2f} TB/s)   split {ts:6.1f} us")
+
+
+if __name__ == "__main__" and "--gates" in sys.argv:
+    gates()

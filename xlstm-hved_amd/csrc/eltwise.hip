@@ -9,18 +9,21 @@
 #define EW_BLOCK 256
 // voxels per lane: 16-byte accesses for both storage types (4 fp32 or 8 x 16-bit)
 
-template <typename T, int N>
-__device__ __forceinline__ void ldrow(const T* p, long long q, int valid, bool vec, float (&o)[N]) {
-  if (vec && valid == N) {
+// VEC: the layout allows 16-byte accesses (vec_ok below) -- a compile-time flag, so the wide path is straight-line code
+// whose loads the scheduler can issue back to back (a run-time flag puts every load in its own branch with the wait for
+// it right behind).
+template <bool VEC, typename T, int N>
+__device__ __forceinline__ void ldrow(const T* p, long long q, int valid, float (&o)[N]) {
+  if constexpr (VEC) {
     ldvec(p, q, o);
   } else {
 #pragma unroll
     for (int v = 0; v < N; ++v) o[v] = v < valid ? ldf(p, q + v) : 0.f;
   }
 }
-template <typename T, int N>
-__device__ __forceinline__ void strow(T* p, long long q, int valid, bool vec, const float (&o)[N]) {
-  if (vec && valid == N) {
+template <bool VEC, typename T, int N>
+__device__ __forceinline__ void strow(T* p, long long q, int valid, const float (&o)[N]) {
+  if constexpr (VEC) {
     stvec(p, q, o);
   } else {
 #pragma unroll
@@ -75,9 +78,9 @@ static inline dim3 red_grid(long long dhw, int C, int N) {
 #define ROW_LOOP_END }
 
 // ---------------------------------------------------------------------------------------- moments
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long x_bs, long long dhw, double* red,
-                                                          long long red_rs, bool vec) {
+                                                          long long red_rs) {
   // Per-lane sums in fp64: the statistics feed var = E[x^2] - mean^2, which cancels mean^2/var digits, and the network
   // amplifies any error in them ~1e4x; fp64 adds are free next to the HBM stream.
   __shared__ double s_red[4 * 2];
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long
   }
   ROW_LOOP_BEGIN
     float v[VW];
-    ldrow(xp, q, valid, vec, v);
+    ldrow<VEC>(xp, q, valid, v);
     float t0 = 0.f, t1 = 0.f;                           // one vector's worth in fp32, then folded into the fp64 sums
 #pragma unroll
     for (int i = 0; i < VW; ++i) { t0 += v[i]; t1 = fmaf(v[i], v[i], t1); }
@@ -107,11 +110,11 @@ extern "C" int xh_moments(void* stream, int dtype, const void* x, long long x_bs
   const bool vec32 = vec_ok<float>(DHW, {x_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs});
   const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(moments_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs, vec32);
+    { if (vec32) hipLaunchKernelGGL((moments_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs); else hipLaunchKernelGGL((moments_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(moments_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs, vec16);
+    { if (vec16) hipLaunchKernelGGL((moments_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs); else hipLaunchKernelGGL((moments_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(moments_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, DHW, red, red_rs, vec16);
+    { if (vec16) hipLaunchKernelGGL((moments_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, DHW, red, red_rs); else hipLaunchKernelGGL((moments_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, DHW, red, red_rs); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -173,19 +176,19 @@ extern "C" int xh_norm_finalize(void* stream, int mode, const double* red, int N
 }
 
 // ---------------------------------------------------------------------------------------- affine + act
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
                                                              long long dhw, const float* sc, const float* sh, int act,
-                                                             float slope, bool vec) {
+                                                             float slope) {
   const float a = sc ? sc[blockIdx.z * C + blockIdx.y] : 1.f, b = sh ? sh[blockIdx.z * C + blockIdx.y] : 0.f;
   ROW_LOOP_BEGIN
     const T* xp = x + n * x_bs + (long long)c * dhw;
     T* yp = y + n * y_bs + (long long)c * dhw;
     float v[VW];
-    ldrow(xp, q, valid, vec, v);
+    ldrow<VEC>(xp, q, valid, v);
 #pragma unroll
     for (int i = 0; i < VW; ++i) v[i] = apply_act(v[i] * a + b, act, slope);
-    strow(yp, q, valid, vec, v);
+    strow<VEC>(yp, q, valid, v);
   ROW_LOOP_END
 }
 
@@ -195,28 +198,28 @@ extern "C" int xh_affine_act(void* stream, int dtype, const void* x, long long x
   const bool vec32 = vec_ok<float>(DHW, {x_bs, y_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, y_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(affine_act_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope, vec32);
+    { if (vec32) hipLaunchKernelGGL((affine_act_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope); else hipLaunchKernelGGL((affine_act_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope, vec16);
+    { if (vec16) hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope); else hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(affine_act_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, sc, sh, act, slope, vec16);
+    { if (vec16) hipLaunchKernelGGL((affine_act_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, sc, sh, act, slope); else hipLaunchKernelGGL((affine_act_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, sc, sh, act, slope); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
 }
 
 // ---------------------------------------------------------------------------------------- act/norm backward
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
                                                                  int C, long long dhw, const float* sc, const float* sh,
-                                                                 float slope, double* red, bool vec) {
+                                                                 float slope, double* red) {
   __shared__ double s_red[4 * 2];
   const float a = sc[blockIdx.z * C + blockIdx.y], b = sh[blockIdx.z * C + blockIdx.y];
   double s[2] = {0.0, 0.0};
   ROW_LOOP_BEGIN
     float g[VW], xv[VW];
-    ldrow(dy + n * dy_bs + (long long)c * dhw, q, valid, vec, g);
-    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q, valid, g);
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
@@ -237,11 +240,11 @@ extern "C" int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long l
   const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs});
   const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red, vec32);
+    { if (vec32) hipLaunchKernelGGL((act_bwd_reduce_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red); else hipLaunchKernelGGL((act_bwd_reduce_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, C, DHW, sc, sh, slope, red); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, C, DHW, sc, sh, slope, red, vec16);
+    { if (vec16) hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, C, DHW, sc, sh, slope, red); else hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, C, DHW, sc, sh, slope, red); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(act_bwd_reduce_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, C, DHW, sc, sh, slope, red, vec16);
+    { if (vec16) hipLaunchKernelGGL((act_bwd_reduce_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, C, DHW, sc, sh, slope, red); else hipLaunchKernelGGL((act_bwd_reduce_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, C, DHW, sc, sh, slope, red); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -303,22 +306,22 @@ extern "C" int xh_norm_bwd_coef(void* stream, int mode, const double* red, int N
   return xh_launch_status();
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void norm_bwd_apply_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
                                                                  T* dx, long long dx_bs, int C, long long dhw,
                                                                  const float* A, const float* B, const float* Cc,
                                                                  int have_g, const float* sc, const float* sh, float slope,
-                                                                 int accumulate, bool vec) {
+                                                                 int accumulate) {
   const int k = blockIdx.z * C + blockIdx.y;
   const float a_ = A[k], b_ = B[k], c_ = Cc[k];
   float tsc = 1.f, tsh = 0.f;
   if (!have_g) { tsc = sc[k]; tsh = sh[k]; }
   ROW_LOOP_BEGIN
     float g[VW], xv[VW], o[VW];
-    ldrow(dy + n * dy_bs + (long long)c * dhw, q, valid, vec, g);
-    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q, valid, g);
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
     T* dp = dx + n * dx_bs + (long long)c * dhw;
-    if (accumulate) ldrow((const T*)dp, q, valid, vec, o);
+    if (accumulate) ldrow<VEC>((const T*)dp, q, valid, o);
     else {
 #pragma unroll
       for (int i = 0; i < VW; ++i) o[i] = 0.f;
@@ -329,19 +332,19 @@ __global__ __launch_bounds__(EW_BLOCK) void norm_bwd_apply_kernel(const T* dy, l
       if (!have_g) gg *= ((xv[i] * tsc + tsh) > 0.f ? 1.f : slope);
       o[i] += a_ * gg + c_ * xv[i] + b_;
     }
-    strow(dp, q, valid, vec, o);
+    strow<VEC>(dp, q, valid, o);
   ROW_LOOP_END
 }
 
 // InstanceNorm flavour with the coefficient step folded in: every workgroup derives A, B, C of its (n, c) row from the
 // raw fp64 sums (sum g, sum g*x), mean and rstd -- a handful of flops -- so the one-block coefficient launch disappears.
 // The statistics arrays may be wider than this tensor's channel count (virtual concat): row stride `stat_rs`.
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
                                                                T* dx, long long dx_bs, int C, long long dhw,
                                                                const double* red, const float* mean, const float* rstd,
                                                                int stat_rs, double count, int have_g, const float* sc,
-                                                               const float* sh, float slope, int accumulate, bool vec) {
+                                                               const float* sh, float slope, int accumulate) {
   const int k = blockIdx.z * stat_rs + blockIdx.y;
   const double rs = rstd[k], mu = mean[k];
   const double S0 = red[k * 2], P = rs * (red[k * 2 + 1] - mu * red[k * 2]);
@@ -350,10 +353,10 @@ __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, lon
   if (!have_g) { tsc = sc[k]; tsh = sh[k]; }
   ROW_LOOP_BEGIN
     float g[VW], xv[VW], o[VW];
-    ldrow(dy + n * dy_bs + (long long)c * dhw, q, valid, vec, g);
-    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q, valid, g);
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
     T* dp = dx + n * dx_bs + (long long)c * dhw;
-    if (accumulate) ldrow((const T*)dp, q, valid, vec, o);
+    if (accumulate) ldrow<VEC>((const T*)dp, q, valid, o);
     else {
 #pragma unroll
       for (int i = 0; i < VW; ++i) o[i] = 0.f;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, lon
       if (!have_g) gg *= ((xv[i] * tsc + tsh) > 0.f ? 1.f : slope);
       o[i] += a_ * gg + c_ * xv[i] + b_;
     }
-    strow(dp, q, valid, vec, o);
+    strow<VEC>(dp, q, valid, o);
   ROW_LOOP_END
 }
 extern "C" int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
@@ -377,11 +380,11 @@ extern "C" int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long lon
   const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec32);
+    { if (vec32) hipLaunchKernelGGL((in_bwd_apply_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((in_bwd_apply_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec16);
+    { if (vec16) hipLaunchKernelGGL((in_bwd_apply_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((in_bwd_apply_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(in_bwd_apply_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, vec16);
+    { if (vec16) hipLaunchKernelGGL((in_bwd_apply_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((in_bwd_apply_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -396,11 +399,11 @@ extern "C" int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long l
   const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec32);
+    { if (vec32) hipLaunchKernelGGL((norm_bwd_apply_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec16);
+    { if (vec16) hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate, vec16);
+    { if (vec16) hipLaunchKernelGGL((norm_bwd_apply_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((norm_bwd_apply_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, A, B, Cc, have_g, sc, sh, slope, accumulate); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -854,19 +857,19 @@ extern "C" int xh_upsample_trilinear_bwd(void* stream, int dtype, const void* dy
 }
 
 // ---------------------------------------------------------------------------------------- add / act bwd
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void add_kernel(const T* a, long long a_bs, const T* b, long long b_bs, T* y,
-                                                      long long y_bs, long long dhw, bool vec) {
+                                                      long long y_bs, long long dhw) {
   ROW_LOOP_BEGIN
     (void)c;
     float u[VW], v[VW];
-    ldrow(a + n * a_bs, q, valid, vec, u);
+    ldrow<VEC>(a + n * a_bs, q, valid, u);
     if (b) {
-      ldrow(b + n * b_bs, q, valid, vec, v);
+      ldrow<VEC>(b + n * b_bs, q, valid, v);
 #pragma unroll
       for (int i = 0; i < VW; ++i) u[i] += v[i];
     }
-    strow(y + n * y_bs, q, valid, vec, u);
+    strow<VEC>(y + n * y_bs, q, valid, u);
   ROW_LOOP_END
 }
 extern "C" int xh_add(void* stream, int dtype, const void* a, long long a_bs, const void* b, long long b_bs, void* y,
@@ -875,11 +878,11 @@ extern "C" int xh_add(void* stream, int dtype, const void* a, long long a_bs, co
   const bool vec32 = vec_ok<float>(CDHW, {a_bs, b_bs, y_bs}), vec16 = vec_ok<bf16_t>(CDHW, {a_bs, b_bs, y_bs});
   const dim3 grid32 = row_grid<float>(CDHW, 1, N), grid16 = row_grid<bf16_t>(CDHW, 1, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(add_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)a, a_bs, (const float*)b, b_bs, (float*)y, y_bs, CDHW, vec32);
+    { if (vec32) hipLaunchKernelGGL((add_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)a, a_bs, (const float*)b, b_bs, (float*)y, y_bs, CDHW); else hipLaunchKernelGGL((add_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)a, a_bs, (const float*)b, b_bs, (float*)y, y_bs, CDHW); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(add_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)a, a_bs, (const bf16_t*)b, b_bs, (bf16_t*)y, y_bs, CDHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((add_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)a, a_bs, (const bf16_t*)b, b_bs, (bf16_t*)y, y_bs, CDHW); else hipLaunchKernelGGL((add_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)a, a_bs, (const bf16_t*)b, b_bs, (bf16_t*)y, y_bs, CDHW); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(add_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)a, a_bs, (const f16_t*)b, b_bs, (f16_t*)y, y_bs, CDHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((add_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)a, a_bs, (const f16_t*)b, b_bs, (f16_t*)y, y_bs, CDHW); else hipLaunchKernelGGL((add_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)a, a_bs, (const f16_t*)b, b_bs, (f16_t*)y, y_bs, CDHW); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1022,63 +1025,82 @@ extern "C" int xh_poe_bwd(void* stream, int dtype, const void* feat, const float
     const long long q = run * VW;                                                                                    \
     const int valid = (int)min((long long)VW, dhw - q);
 #define VOX_LOOP_END }
-template <typename T>
-__global__ __launch_bounds__(256) void channel_pool_fwd_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
-                                                              long long dhw, bool vec) {
+// Channels are walked CB at a time with all of a batch's loads issued before the first use: a lane's channel loop is
+// otherwise one full memory latency per channel (in-order issue, the wait sits right behind each load).
+constexpr int CB = 4;
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void channel_pool_fwd_kernel(const T* __restrict__ x, long long x_bs, T* __restrict__ y,
+                                                              long long y_bs, int C, long long dhw) {
   VOX_LOOP_BEGIN
     const T* xp = x + n * x_bs;
     float m[VW], s[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
-    for (int c = 0; c < C; ++c) {
-      float xv[VW];
-      ldrow(xp + (long long)c * dhw, q, valid, vec, xv);
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float xv[CB][VW];
 #pragma unroll
-      for (int v = 0; v < VW; ++v) {
-        m[v] = (xv[v] > m[v] || xv[v] != xv[v]) ? xv[v] : m[v];
-        s[v] += xv[v];
+      for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          m[v] = (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) ? xv[j][v] : m[v];
+          s[v] += xv[j][v];
+        }
       }
     }
 #pragma unroll
     for (int v = 0; v < VW; ++v) s[v] = s[v] / (float)C;
-    strow(y + n * y_bs, q, valid, vec, m);
-    strow(y + n * y_bs + dhw, q, valid, vec, s);
+    strow<VEC>(y + n * y_bs, q, valid, m);
+    strow<VEC>(y + n * y_bs + dhw, q, valid, s);
   VOX_LOOP_END
 }
-template <typename T>
-__global__ __launch_bounds__(256) void channel_pool_bwd_kernel(const T* x, long long x_bs, const T* dy, long long dy_bs,
-                                                              T* dx, long long dx_bs, int C, long long dhw, int accumulate,
-                                                              bool vec) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void channel_pool_bwd_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ dy,
+                                                              long long dy_bs, T* dx, long long dx_bs, int C, long long dhw,
+                                                              int accumulate) {
   VOX_LOOP_BEGIN
     const T* xp = x + n * x_bs;
-    float m[VW];
+    float m[VW], g0[VW], g1[VW];
     int arg[VW];
+    ldrow<VEC>(dy + n * dy_bs, q, valid, g0);
+    ldrow<VEC>(dy + n * dy_bs + dhw, q, valid, g1);
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; arg[v] = 0; }
-    for (int c = 0; c < C; ++c) {
-      float xv[VW];
-      ldrow(xp + (long long)c * dhw, q, valid, vec, xv);
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float xv[CB][VW];
 #pragma unroll
-      for (int v = 0; v < VW; ++v)
-        if (xv[v] > m[v] || xv[v] != xv[v]) { m[v] = xv[v]; arg[v] = c; }
+      for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v)
+          if (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) { m[v] = xv[j][v]; arg[v] = c0 + j; }
+      }
     }
-    float g0[VW], g1[VW];
-    ldrow(dy + n * dy_bs, q, valid, vec, g0);
-    ldrow(dy + n * dy_bs + dhw, q, valid, vec, g1);
 #pragma unroll
     for (int v = 0; v < VW; ++v) g1[v] = g1[v] / (float)C;
     T* dp = dx + n * dx_bs;
-    for (int c = 0; c < C; ++c) {
-      float o[VW];
-      if (accumulate) {
-        ldrow((const T*)dp + (long long)c * dhw, q, valid, vec, o);
-      } else {
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float o[CB][VW];
 #pragma unroll
-        for (int v = 0; v < VW; ++v) o[v] = 0.f;
+      for (int j = 0; j < CB; ++j) {
+        if (accumulate) {
+          ldrow<VEC>((const T*)dp + (long long)min(c0 + j, C - 1) * dhw, q, valid, o[j]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VW; ++v) o[j][v] = 0.f;
+        }
       }
 #pragma unroll
-      for (int v = 0; v < VW; ++v) o[v] = o[v] + g1[v] + (c == arg[v] ? g0[v] : 0.f);
-      strow(dp + (long long)c * dhw, q, valid, vec, o);
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) o[j][v] = o[j][v] + g1[v] + (c0 + j == arg[v] ? g0[v] : 0.f);
+        strow<VEC>(dp + (long long)(c0 + j) * dhw, q, valid, o[j]);
+      }
     }
   VOX_LOOP_END
 }
@@ -1093,11 +1115,11 @@ extern "C" int xh_channel_pool_fwd(void* stream, int dtype, const void* x, long 
                                    int C, long long DHW) {
   if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(channel_pool_fwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, vec_ok<float>(DHW, {x_bs, y_bs}));
+    { if (vec_ok<float>(DHW, {x_bs, y_bs})) hipLaunchKernelGGL((channel_pool_fwd_kernel<float, true>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW); else hipLaunchKernelGGL((channel_pool_fwd_kernel<float, false>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(channel_pool_fwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, vec_ok<bf16_t>(DHW, {x_bs, y_bs}));
+    { if (vec_ok<bf16_t>(DHW, {x_bs, y_bs})) hipLaunchKernelGGL((channel_pool_fwd_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW); else hipLaunchKernelGGL((channel_pool_fwd_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(channel_pool_fwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, vec_ok<f16_t>(DHW, {x_bs, y_bs}));
+    { if (vec_ok<f16_t>(DHW, {x_bs, y_bs})) hipLaunchKernelGGL((channel_pool_fwd_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW); else hipLaunchKernelGGL((channel_pool_fwd_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1106,72 +1128,78 @@ extern "C" int xh_channel_pool_bwd(void* stream, int dtype, const void* x, long 
                                    void* dx, long long dx_bs, int N, int C, long long DHW, int accumulate) {
   if (!x || !dy || !dx || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(channel_pool_bwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, DHW, accumulate, vec_ok<float>(DHW, {x_bs, dy_bs, dx_bs}));
+    { if (vec_ok<float>(DHW, {x_bs, dy_bs, dx_bs})) hipLaunchKernelGGL((channel_pool_bwd_kernel<float, true>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, DHW, accumulate); else hipLaunchKernelGGL((channel_pool_bwd_kernel<float, false>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, C, DHW, accumulate); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(channel_pool_bwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, DHW, accumulate, vec_ok<bf16_t>(DHW, {x_bs, dy_bs, dx_bs}));
+    { if (vec_ok<bf16_t>(DHW, {x_bs, dy_bs, dx_bs})) hipLaunchKernelGGL((channel_pool_bwd_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, DHW, accumulate); else hipLaunchKernelGGL((channel_pool_bwd_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, C, DHW, accumulate); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(channel_pool_bwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, C, DHW, accumulate, vec_ok<f16_t>(DHW, {x_bs, dy_bs, dx_bs}));
+    { if (vec_ok<f16_t>(DHW, {x_bs, dy_bs, dx_bs})) hipLaunchKernelGGL((channel_pool_bwd_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, C, DHW, accumulate); else hipLaunchKernelGGL((channel_pool_bwd_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, C, DHW, accumulate); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
 }
 
 // y = x*(1+s)
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void gate_fwd_kernel(const T* x, long long x_bs, const T* s, long long s_bs, T* y,
-                                                           long long y_bs, long long dhw, bool vec) {
+                                                           long long y_bs, long long dhw) {
   ROW_LOOP_BEGIN
     float xv[VW], sv[VW];
-    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
-    ldrow(s + n * s_bs, q, valid, vec, sv);
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
+    ldrow<VEC>(s + n * s_bs, q, valid, sv);
 #pragma unroll
     for (int i = 0; i < VW; ++i) xv[i] *= (1.f + sv[i]);
-    strow(y + n * y_bs + (long long)c * dhw, q, valid, vec, xv);
+    strow<VEC>(y + n * y_bs + (long long)c * dhw, q, valid, xv);
   ROW_LOOP_END
 }
 // lane per voxel, loop over channels: dx = dy*(1+s), ds = sum_c dy*x
-template <typename T>
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* x, long long x_bs, const T* s, long long s_bs, const T* dy,
-                                                      long long dy_bs, T* dx, long long dx_bs, T* ds, long long ds_bs, int C,
-                                                      long long dhw, int acc_dx, int acc_ds, bool vec) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ s,
+                                                      long long s_bs, const T* __restrict__ dy, long long dy_bs, T* dx,
+                                                      long long dx_bs, T* ds, long long ds_bs, int C, long long dhw,
+                                                      int acc_dx, int acc_ds) {
   VOX_LOOP_BEGIN
     float g1[VW], a[VW];
-    ldrow(s + n * s_bs, q, valid, vec, g1);
+    ldrow<VEC>(s + n * s_bs, q, valid, g1);
 #pragma unroll
     for (int v = 0; v < VW; ++v) { g1[v] = 1.f + g1[v]; a[v] = 0.f; }
-    for (int c = 0; c < C; ++c) {
-      const long long off = (long long)c * dhw;
-      float g[VW], xv[VW];
-      ldrow(dy + n * dy_bs + off, q, valid, vec, g);
-      ldrow(x + n * x_bs + off, q, valid, vec, xv);
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float g[CB][VW], xv[CB][VW], o[CB][VW];
 #pragma unroll
-      for (int v = 0; v < VW; ++v) a[v] = fmaf(g[v], xv[v], a[v]);
-      if (dx) {
-        T* dp = dx + n * dx_bs + off;
-        float o[VW];
-        if (acc_dx) {
-          ldrow((const T*)dp, q, valid, vec, o);
+      for (int j = 0; j < CB; ++j) {
+        const long long off = (long long)min(c0 + j, C - 1) * dhw;
+        ldrow<VEC>(dy + n * dy_bs + off, q, valid, g[j]);
+        ldrow<VEC>(x + n * x_bs + off, q, valid, xv[j]);
+        if (dx && acc_dx) {
+          ldrow<VEC>((const T*)dx + n * dx_bs + off, q, valid, o[j]);
         } else {
 #pragma unroll
-          for (int v = 0; v < VW; ++v) o[v] = 0.f;
+          for (int v = 0; v < VW; ++v) o[j][v] = 0.f;
         }
+      }
 #pragma unroll
-        for (int v = 0; v < VW; ++v) o[v] = g[v] * g1[v] + o[v];
-        strow(dp, q, valid, vec, o);
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) a[v] = fmaf(g[j][v], xv[j][v], a[v]);
+        if (dx) {
+#pragma unroll
+          for (int v = 0; v < VW; ++v) o[j][v] = g[j][v] * g1[v] + o[j][v];
+          strow<VEC>(dx + n * dx_bs + (long long)(c0 + j) * dhw, q, valid, o[j]);
+        }
       }
     }
     if (ds) {
       T* sp = ds + n * ds_bs;
       float o[VW];
       if (acc_ds) {
-        ldrow((const T*)sp, q, valid, vec, o);
+        ldrow<VEC>((const T*)sp, q, valid, o);
       } else {
 #pragma unroll
         for (int v = 0; v < VW; ++v) o[v] = 0.f;
       }
 #pragma unroll
       for (int v = 0; v < VW; ++v) o[v] = a[v] + o[v];
-      strow(sp, q, valid, vec, o);
+      strow<VEC>(sp, q, valid, o);
     }
   VOX_LOOP_END
 }
@@ -1181,11 +1209,11 @@ extern "C" int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_b
   const bool vec32 = vec_ok<float>(DHW, {x_bs, s_bs, y_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, s_bs, y_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(gate_fwd_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (float*)y, y_bs, DHW, vec32);
+    { if (vec32) hipLaunchKernelGGL((gate_fwd_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (float*)y, y_bs, DHW); else hipLaunchKernelGGL((gate_fwd_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (float*)y, y_bs, DHW); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (bf16_t*)y, y_bs, DHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((gate_fwd_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (bf16_t*)y, y_bs, DHW); else hipLaunchKernelGGL((gate_fwd_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (bf16_t*)y, y_bs, DHW); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(gate_fwd_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (f16_t*)y, y_bs, DHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((gate_fwd_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (f16_t*)y, y_bs, DHW); else hipLaunchKernelGGL((gate_fwd_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (f16_t*)y, y_bs, DHW); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1195,46 +1223,44 @@ extern "C" int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_b
                            int C, long long DHW, int acc_dx, int acc_ds) {
   if (!x || !s || !dy || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(gate_bwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, (float*)ds, ds_bs, C, DHW, acc_dx, acc_ds, vec_ok<float>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs}));
+    { if (vec_ok<float>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs})) hipLaunchKernelGGL((gate_bwd_kernel<float, true>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, (float*)ds, ds_bs, C, DHW, acc_dx, acc_ds); else hipLaunchKernelGGL((gate_bwd_kernel<float, false>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)s, s_bs, (const float*)dy, dy_bs, (float*)dx, dx_bs, (float*)ds, ds_bs, C, DHW, acc_dx, acc_ds); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, (bf16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds, vec_ok<bf16_t>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs}));
+    { if (vec_ok<bf16_t>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs})) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, (bf16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds); else hipLaunchKernelGGL((gate_bwd_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)s, s_bs, (const bf16_t*)dy, dy_bs, (bf16_t*)dx, dx_bs, (bf16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(gate_bwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, (f16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds, vec_ok<f16_t>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs}));
+    { if (vec_ok<f16_t>(DHW, {x_bs, s_bs, dy_bs, dx_bs, ds_bs})) hipLaunchKernelGGL((gate_bwd_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, (f16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds); else hipLaunchKernelGGL((gate_bwd_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)s, s_bs, (const f16_t*)dy, dy_bs, (f16_t*)dx, dx_bs, (f16_t*)ds, ds_bs, C, DHW, acc_dx, acc_ds); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
 }
 
 // ---------------------------------------------------------------------------------------- DuSE gates
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void duse_gate_fwd_kernel(const T* x, long long x_bs, const float* ch, const T* sp,
-                                                                long long sp_bs, T* u, long long u_bs, int C, long long dhw,
-                                                                bool vec) {
+                                                                long long sp_bs, T* u, long long u_bs, int C, long long dhw) {
   const float cg = 1.f + ch[blockIdx.z * C + blockIdx.y];
   ROW_LOOP_BEGIN
     float xv[VW], sv[VW];
-    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
-    ldrow(sp + n * sp_bs, q, valid, vec, sv);
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
+    ldrow<VEC>(sp + n * sp_bs, q, valid, sv);
 #pragma unroll
     for (int i = 0; i < VW; ++i) xv[i] *= (cg + sv[i]);
-    strow(u + n * u_bs + (long long)c * dhw, q, valid, vec, xv);
+    strow<VEC>(u + n * u_bs + (long long)c * dhw, q, valid, xv);
   ROW_LOOP_END
 }
 // lane per voxel over channels; dch via block reduction per channel would need C reductions: instead each
 // block owns one (n, c) row for dch and the dsp accumulation goes through a second voxel-major kernel.
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void duse_gate_bwd_row_kernel(const T* x, long long x_bs, const float* ch, const T* sp,
                                                                     long long sp_bs, const T* du, long long du_bs, T* dx,
-                                                                    long long dx_bs, double* dch, int C, long long dhw,
-                                                                    bool vec) {
+                                                                    long long dx_bs, double* dch, int C, long long dhw) {
   __shared__ double s_red[4];
   const float cg = 1.f + ch[blockIdx.z * C + blockIdx.y];
   double s[1] = {0.0};
   ROW_LOOP_BEGIN
     float xv[VW], sv[VW], g[VW], o[VW];
-    ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
-    ldrow(sp + n * sp_bs, q, valid, vec, sv);
-    ldrow(du + n * du_bs + (long long)c * dhw, q, valid, vec, g);
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
+    ldrow<VEC>(sp + n * sp_bs, q, valid, sv);
+    ldrow<VEC>(du + n * du_bs + (long long)c * dhw, q, valid, g);
     float t0 = 0.f;
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
@@ -1242,26 +1268,35 @@ __global__ __launch_bounds__(EW_BLOCK) void duse_gate_bwd_row_kernel(const T* x,
       t0 = fmaf(g[i], xv[i], t0);
     }
     s[0] += (double)t0;
-    strow(dx + n * dx_bs + (long long)c * dhw, q, valid, vec, o);
+    strow<VEC>(dx + n * dx_bs + (long long)c * dhw, q, valid, o);
   ROW_LOOP_END
   block_sum_d<1>(s, s_red, EW_BLOCK >> 6);
   if (threadIdx.x == 0) atomicAdd(&dch[blockIdx.z * C + blockIdx.y], s_red[0]);
 }
-template <typename T>
-__global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* x, long long x_bs, const T* du, long long du_bs,
-                                                              T* dsp, long long dsp_bs, int C, long long dhw, bool vec) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ du,
+                                                              long long du_bs, T* __restrict__ dsp, long long dsp_bs, int C,
+                                                              long long dhw) {
   VOX_LOOP_BEGIN
     float a[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) a[v] = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float g[VW], xv[VW];
-      ldrow(du + n * du_bs + (long long)c * dhw, q, valid, vec, g);
-      ldrow(x + n * x_bs + (long long)c * dhw, q, valid, vec, xv);
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float g[CB][VW], xv[CB][VW];
 #pragma unroll
-      for (int v = 0; v < VW; ++v) a[v] = fmaf(g[v], xv[v], a[v]);
+      for (int j = 0; j < CB; ++j) {
+        const long long off = (long long)min(c0 + j, C - 1) * dhw;
+        ldrow<VEC>(du + n * du_bs + off, q, valid, g[j]);
+        ldrow<VEC>(x + n * x_bs + off, q, valid, xv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) a[v] = fmaf(g[j][v], xv[j][v], a[v]);
+      }
     }
-    strow(dsp + n * dsp_bs, q, valid, vec, a);
+    strow<VEC>(dsp + n * dsp_bs, q, valid, a);
   VOX_LOOP_END
 }
 extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
@@ -1270,11 +1305,11 @@ extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long lon
   const bool vec32 = vec_ok<float>(DHW, {x_bs, sp_bs, u_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, sp_bs, u_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(duse_gate_fwd_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW, vec32);
+    { if (vec32) hipLaunchKernelGGL((duse_gate_fwd_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_fwd_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(duse_gate_fwd_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((duse_gate_fwd_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_fwd_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(duse_gate_fwd_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (f16_t*)u, u_bs, C, DHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((duse_gate_fwd_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (f16_t*)u, u_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_fwd_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (f16_t*)u, u_bs, C, DHW); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1286,14 +1321,14 @@ extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long lon
   const bool vec32 = vec_ok<float>(DHW, {x_bs, sp_bs, du_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, sp_bs, du_bs, dx_bs});
   const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32) {
-    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (const float*)du, du_bs, (float*)dx, dx_bs, dch, C, DHW, vec32);
-    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)du, du_bs, (float*)dsp, dsp_bs, C, DHW, vec_ok<float>(DHW, {x_bs, du_bs, dsp_bs}));
+    { if (vec32) hipLaunchKernelGGL((duse_gate_bwd_row_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (const float*)du, du_bs, (float*)dx, dx_bs, dch, C, DHW); else hipLaunchKernelGGL((duse_gate_bwd_row_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (const float*)du, du_bs, (float*)dx, dx_bs, dch, C, DHW); }
+    { if (vec_ok<float>(DHW, {x_bs, du_bs, dsp_bs})) hipLaunchKernelGGL((duse_gate_bwd_sp_kernel<float, true>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)du, du_bs, (float*)dsp, dsp_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_bwd_sp_kernel<float, false>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_bs, (const float*)du, du_bs, (float*)dsp, dsp_bs, C, DHW); }
   } else if (dtype == XH_BF16) {
-    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW, vec16);
-    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW, vec_ok<bf16_t>(DHW, {x_bs, du_bs, dsp_bs}));
+    { if (vec16) hipLaunchKernelGGL((duse_gate_bwd_row_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW); else hipLaunchKernelGGL((duse_gate_bwd_row_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (const bf16_t*)du, du_bs, (bf16_t*)dx, dx_bs, dch, C, DHW); }
+    { if (vec_ok<bf16_t>(DHW, {x_bs, du_bs, dsp_bs})) hipLaunchKernelGGL((duse_gate_bwd_sp_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_bwd_sp_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (const bf16_t*)du, du_bs, (bf16_t*)dsp, dsp_bs, C, DHW); }
   } else if (dtype == XH_F16) {
-    hipLaunchKernelGGL(duse_gate_bwd_row_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (const f16_t*)du, du_bs, (f16_t*)dx, dx_bs, dch, C, DHW, vec16);
-    hipLaunchKernelGGL(duse_gate_bwd_sp_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)du, du_bs, (f16_t*)dsp, dsp_bs, C, DHW, vec_ok<f16_t>(DHW, {x_bs, du_bs, dsp_bs}));
+    { if (vec16) hipLaunchKernelGGL((duse_gate_bwd_row_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (const f16_t*)du, du_bs, (f16_t*)dx, dx_bs, dch, C, DHW); else hipLaunchKernelGGL((duse_gate_bwd_row_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (const f16_t*)du, du_bs, (f16_t*)dx, dx_bs, dch, C, DHW); }
+    { if (vec_ok<f16_t>(DHW, {x_bs, du_bs, dsp_bs})) hipLaunchKernelGGL((duse_gate_bwd_sp_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)du, du_bs, (f16_t*)dsp, dsp_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_bwd_sp_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (const f16_t*)du, du_bs, (f16_t*)dsp, dsp_bs, C, DHW); }
   } else {
     return XH_ERR_DTYPE;
   }
@@ -1302,18 +1337,18 @@ extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long lon
 
 // dx (+)= w[c]*d[n,0,p] + k[n,c]   -- finishes the DuSE input gradient: squeeze-conv data gradient (rank-1) plus
 // the global-average-pool gradient.
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void rank1_add_kernel(T* dx, long long dx_bs, const T* d, long long d_bs,
-                                                            const float* w, const float* k, int C, long long dhw, bool vec) {
+                                                            const float* w, const float* k, int C, long long dhw) {
   const float wc = w[blockIdx.y], kc = k ? k[blockIdx.z * C + blockIdx.y] : 0.f;
   ROW_LOOP_BEGIN
     float o[VW], dv[VW];
     T* dp = dx + n * dx_bs + (long long)c * dhw;
-    ldrow((const T*)dp, q, valid, vec, o);
-    ldrow(d + n * d_bs, q, valid, vec, dv);
+    ldrow<VEC>((const T*)dp, q, valid, o);
+    ldrow<VEC>(d + n * d_bs, q, valid, dv);
 #pragma unroll
     for (int i = 0; i < VW; ++i) o[i] += fmaf(wc, dv[i], kc);
-    strow(dp, q, valid, vec, o);
+    strow<VEC>(dp, q, valid, o);
   ROW_LOOP_END
 }
 extern "C" int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, const void* d, long long d_bs,
@@ -1322,11 +1357,11 @@ extern "C" int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, 
   const bool vec32 = vec_ok<float>(DHW, {dx_bs, d_bs}), vec16 = vec_ok<bf16_t>(DHW, {dx_bs, d_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(rank1_add_kernel<float>, grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (float*)dx, dx_bs, (const float*)d, d_bs, w, k, C, DHW, vec32);
+    { if (vec32) hipLaunchKernelGGL((rank1_add_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (float*)dx, dx_bs, (const float*)d, d_bs, w, k, C, DHW); else hipLaunchKernelGGL((rank1_add_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (float*)dx, dx_bs, (const float*)d, d_bs, w, k, C, DHW); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(rank1_add_kernel<bf16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (bf16_t*)dx, dx_bs, (const bf16_t*)d, d_bs, w, k, C, DHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((rank1_add_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (bf16_t*)dx, dx_bs, (const bf16_t*)d, d_bs, w, k, C, DHW); else hipLaunchKernelGGL((rank1_add_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (bf16_t*)dx, dx_bs, (const bf16_t*)d, d_bs, w, k, C, DHW); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(rank1_add_kernel<f16_t>, grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (f16_t*)dx, dx_bs, (const f16_t*)d, d_bs, w, k, C, DHW, vec16);
+    { if (vec16) hipLaunchKernelGGL((rank1_add_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (f16_t*)dx, dx_bs, (const f16_t*)d, d_bs, w, k, C, DHW); else hipLaunchKernelGGL((rank1_add_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (f16_t*)dx, dx_bs, (const f16_t*)d, d_bs, w, k, C, DHW); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1436,67 +1471,82 @@ extern "C" int xh_duse_fc_bwd(void* stream, const double* red_r, const double* r
 
 // ---------------------------------------------------------------------------------------- skip-return tail
 // r_c = relu(relu(t_c*sc+sh) + x_c);  a = sigmoid(w0*max_c r + w1*mean_c r)
-template <typename T>
-__global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* t, const T* x, const float* sc, const float* sh,
-                                                          const float* w2, T* a, int C, long long dhw, bool vec) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
+                                                          const float* sh, const float* w2, T* __restrict__ a, int C,
+                                                          long long dhw) {
   const float w0 = w2[0], w1 = w2[1];
   VOX_LOOP_BEGIN
     float m[VW], s[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
-    for (int c = 0; c < C; ++c) {
-      const long long o = ((long long)n * C + c) * dhw;
-      const float scv = sc[n * C + c], shv = sh[n * C + c];
-      float tv[VW], xv[VW];
-      ldrow(t + o, q, valid, vec, tv);
-      ldrow(x + o, q, valid, vec, xv);
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float tv[CB][VW], xv[CB][VW];
 #pragma unroll
-      for (int v = 0; v < VW; ++v) {
-        float y = tv[v] * scv + shv;
-        y = y > 0.f ? y : 0.f;
-        float r = y + xv[v];
-        r = r > 0.f ? r : 0.f;
-        m[v] = r > m[v] ? r : m[v];
-        s[v] += r;
+      for (int j = 0; j < CB; ++j) {
+        const long long o = ((long long)n * C + min(c0 + j, C - 1)) * dhw;
+        ldrow<VEC>(t + o, q, valid, tv[j]);
+        ldrow<VEC>(x + o, q, valid, xv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+        const float scv = sc[n * C + c0 + j], shv = sh[n * C + c0 + j];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          float y = tv[j][v] * scv + shv;
+          y = y > 0.f ? y : 0.f;
+          float r = y + xv[j][v];
+          r = r > 0.f ? r : 0.f;
+          m[v] = r > m[v] ? r : m[v];
+          s[v] += r;
+        }
       }
     }
     float out[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) out[v] = sigmoidf_(w0 * m[v] + w1 * s[v] / (float)C);
-    strow(a + (long long)n * dhw, q, valid, vec, out);
+    strow<VEC>(a + (long long)n * dhw, q, valid, out);
   VOX_LOOP_END
 }
-template <typename T>
-__global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* t, const T* x, const float* sc, const float* sh,
-                                                          const float* w2, const T* a, const T* da, T* dtg, T* dx,
-                                                          double* dw2acc, int C, long long dhw, int acc_dx, bool vec) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
+                                                          const float* sh, const float* w2, const T* __restrict__ a,
+                                                          const T* __restrict__ da, T* __restrict__ dtg, T* dx,
+                                                          double* dw2acc, int C, long long dhw, int acc_dx) {
   __shared__ double s_red[4 * 2];
   const float w0 = w2[0], w1 = w2[1];
   double sacc[2] = {0.0, 0.0};
   VOX_LOOP_BEGIN
-    float m[VW], s[VW];
+    float m[VW], s[VW], av[VW], dpre[VW];
     int arg[VW];
+    ldrow<VEC>(a + (long long)n * dhw, q, valid, av);
+    ldrow<VEC>(da + (long long)n * dhw, q, valid, dpre);
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; arg[v] = 0; }
-    for (int c = 0; c < C; ++c) {
-      const long long o = ((long long)n * C + c) * dhw;
-      const float scv = sc[n * C + c], shv = sh[n * C + c];
-      float tv[VW], xv[VW];
-      ldrow(t + o, q, valid, vec, tv);
-      ldrow(x + o, q, valid, vec, xv);
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float tv[CB][VW], xv[CB][VW];
 #pragma unroll
-      for (int v = 0; v < VW; ++v) {
-        float y = tv[v] * scv + shv;
-        y = y > 0.f ? y : 0.f;
-        float r = y + xv[v];
-        r = r > 0.f ? r : 0.f;
-        if (r > m[v]) { m[v] = r; arg[v] = c; }
-        s[v] += r;
+      for (int j = 0; j < CB; ++j) {
+        const long long o = ((long long)n * C + min(c0 + j, C - 1)) * dhw;
+        ldrow<VEC>(t + o, q, valid, tv[j]);
+        ldrow<VEC>(x + o, q, valid, xv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+        const float scv = sc[n * C + c0 + j], shv = sh[n * C + c0 + j];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          float y = tv[j][v] * scv + shv;
+          y = y > 0.f ? y : 0.f;
+          float r = y + xv[j][v];
+          r = r > 0.f ? r : 0.f;
+          if (r > m[v]) { m[v] = r; arg[v] = c0 + j; }
+          s[v] += r;
+        }
       }
     }
-    float av[VW], dpre[VW];
-    ldrow(a + (long long)n * dhw, q, valid, vec, av);
-    ldrow(da + (long long)n * dhw, q, valid, vec, dpre);
     float t0 = 0.f, t1 = 0.f;                           // lanes past the row end: a = da = 0, so they add nothing
 #pragma unroll
     for (int v = 0; v < VW; ++v) {
@@ -1506,30 +1556,39 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* t, const T* 
     }
     sacc[0] += (double)t0;
     sacc[1] += (double)t1;
-    for (int c = 0; c < C; ++c) {
-      const long long o = ((long long)n * C + c) * dhw;
-      const float scv = sc[n * C + c], shv = sh[n * C + c];
-      float tv[VW], xv[VW], odx[VW], odt[VW];
-      ldrow(t + o, q, valid, vec, tv);
-      ldrow(x + o, q, valid, vec, xv);
-      if (acc_dx) {
-        ldrow((const T*)dx + o, q, valid, vec, odx);
-      } else {
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float tv[CB][VW], xv[CB][VW], odx[CB][VW];
 #pragma unroll
-        for (int v = 0; v < VW; ++v) odx[v] = 0.f;
+      for (int j = 0; j < CB; ++j) {
+        const long long o = ((long long)n * C + min(c0 + j, C - 1)) * dhw;
+        ldrow<VEC>(t + o, q, valid, tv[j]);
+        ldrow<VEC>(x + o, q, valid, xv[j]);
+        if (acc_dx) {
+          ldrow<VEC>((const T*)dx + o, q, valid, odx[j]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VW; ++v) odx[j][v] = 0.f;
+        }
       }
 #pragma unroll
-      for (int v = 0; v < VW; ++v) {
-        const float yraw = tv[v] * scv + shv;
-        const float y = yraw > 0.f ? yraw : 0.f;
-        const float r = y + xv[v];
-        float dr = dpre[v] * w1 / (float)C + (c == arg[v] ? dpre[v] * w0 : 0.f);
-        dr = r > 0.f ? dr : 0.f;
-        odx[v] = dr + odx[v];
-        odt[v] = yraw > 0.f ? dr : 0.f;
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+        const long long o = ((long long)n * C + c0 + j) * dhw;
+        const float scv = sc[n * C + c0 + j], shv = sh[n * C + c0 + j];
+        float odt[VW];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          const float yraw = tv[j][v] * scv + shv;
+          const float y = yraw > 0.f ? yraw : 0.f;
+          const float r = y + xv[j][v];
+          float dr = dpre[v] * w1 / (float)C + (c0 + j == arg[v] ? dpre[v] * w0 : 0.f);
+          dr = r > 0.f ? dr : 0.f;
+          odx[j][v] = dr + odx[j][v];
+          odt[v] = yraw > 0.f ? dr : 0.f;
+        }
+        strow<VEC>(dx + o, q, valid, odx[j]);
+        strow<VEC>(dtg + o, q, valid, odt);
       }
-      strow(dx + o, q, valid, vec, odx);
-      strow(dtg + o, q, valid, vec, odt);
     }
   VOX_LOOP_END
   block_sum_d<2>(sacc, s_red, 4);
@@ -1539,11 +1598,11 @@ extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const voi
                                const float* w2, void* a, int N, int C, long long DHW) {
   if (!t || !x || !sc || !sh || !w2 || !a || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(skr_tail_fwd_kernel<float>, vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW, vec_ok<float>(DHW, {}));
+    { if (vec_ok<float>(DHW, {})) hipLaunchKernelGGL((skr_tail_fwd_kernel<float, true>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW); else hipLaunchKernelGGL((skr_tail_fwd_kernel<float, false>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(skr_tail_fwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW, vec_ok<bf16_t>(DHW, {}));
+    { if (vec_ok<bf16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_fwd_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW); else hipLaunchKernelGGL((skr_tail_fwd_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(skr_tail_fwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW, vec_ok<f16_t>(DHW, {}));
+    { if (vec_ok<f16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_fwd_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW); else hipLaunchKernelGGL((skr_tail_fwd_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();
@@ -1553,11 +1612,11 @@ extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const voi
                                int N, int C, long long DHW, int acc_dx) {
   if (!t || !x || !sc || !sh || !w2 || !a || !da || !dtg || !dx || !dw2 || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   if (dtype == XH_F32)
-    hipLaunchKernelGGL(skr_tail_bwd_kernel<float>, vox_grid<float>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx, vec_ok<float>(DHW, {}));
+    { if (vec_ok<float>(DHW, {})) hipLaunchKernelGGL((skr_tail_bwd_kernel<float, true>), vox_grid<float>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx); else hipLaunchKernelGGL((skr_tail_bwd_kernel<float, false>), vox_grid<float>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx); }
   else if (dtype == XH_BF16)
-    hipLaunchKernelGGL(skr_tail_bwd_kernel<bf16_t>, vox_grid<bf16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx, vec_ok<bf16_t>(DHW, {}));
+    { if (vec_ok<bf16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_bwd_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx); else hipLaunchKernelGGL((skr_tail_bwd_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx); }
   else if (dtype == XH_F16)
-    hipLaunchKernelGGL(skr_tail_bwd_kernel<f16_t>, vox_grid<f16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx, vec_ok<f16_t>(DHW, {}));
+    { if (vec_ok<f16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_bwd_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx); else hipLaunchKernelGGL((skr_tail_bwd_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx); }
   else
     return XH_ERR_DTYPE;
   return xh_launch_status();

@@ -14,9 +14,9 @@
 
 #define LS_BLOCK 256
 
-template <typename T>
-__device__ __forceinline__ void ld4any(const T* p, long long q, int valid, bool vec, float (&o)[4]) {
-  if (vec && valid == 4) {
+template <bool VEC, typename T>
+__device__ __forceinline__ void ld4any(const T* p, long long q, int valid, float (&o)[4]) {
+  if constexpr (VEC) {                                // compile-time: straight-line loads (see ldrow in eltwise.hip)
     ld4(p, q, o);
   } else {
 #pragma unroll
@@ -25,9 +25,9 @@ __device__ __forceinline__ void ld4any(const T* p, long long q, int valid, bool 
 }
 
 // red[n][c][0..5] += ( sum a'b, sum a'^2, sum b^2, sum (a'-b)^2, sum a', sum b ),  a' = a or (a > thr) when thr_on
-template <typename TA, typename TB>
+template <typename TA, typename TB, bool VEC>
 __global__ __launch_bounds__(LS_BLOCK) void pair_sums_kernel(const TA* a, long long a_bs, const TB* b, long long b_bs, float bval,
-                                                            long long dhw, int thr_on, float thr, double* red, bool vec) {
+                                                            long long dhw, int thr_on, float thr, double* red) {
   __shared__ double s_red[4 * 6];
   const int c = blockIdx.y, n = blockIdx.z;
   const TA* ap = a + n * a_bs + (long long)c * dhw;
@@ -38,8 +38,8 @@ __global__ __launch_bounds__(LS_BLOCK) void pair_sums_kernel(const TA* a, long l
   for (long long q = (long long)blockIdx.x * per + threadIdx.x * 4; q < q_end; q += LS_BLOCK * 4) {
     const int valid = (int)min(4LL, dhw - q);
     float av[4], bv[4] = {bval, bval, bval, bval};
-    ld4any(ap, q, valid, vec, av);
-    if (bp) ld4any(bp, q, valid, vec, bv);
+    ld4any<VEC>(ap, q, valid, av);
+    if (bp) ld4any<VEC>(bp, q, valid, bv);
     float t[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -56,10 +56,10 @@ __global__ __launch_bounds__(LS_BLOCK) void pair_sums_kernel(const TA* a, long l
 }
 
 // out[n,c,:] (+)= ca[n,c]*a + cb[n,c]*b + cc[n,c]     (b NULL: the constant bval)
-template <typename TA, typename TB>
+template <typename TA, typename TB, bool VEC>
 __global__ __launch_bounds__(LS_BLOCK) void lincomb_kernel(const TA* a, long long a_bs, const TB* b, long long b_bs, float bval,
                                                           TA* out, long long o_bs, long long dhw, const float* ca, const float* cb,
-                                                          const float* cc, const float* gs, int accumulate, bool vec) {
+                                                          const float* cc, const float* gs, int accumulate) {
   const int c = blockIdx.y, n = blockIdx.z, C = gridDim.y;
   const TA* ap = a + n * a_bs + (long long)c * dhw;
   const TB* bp = b ? b + n * b_bs + (long long)c * dhw : nullptr;
@@ -71,12 +71,12 @@ __global__ __launch_bounds__(LS_BLOCK) void lincomb_kernel(const TA* a, long lon
   for (long long q = (long long)blockIdx.x * per + threadIdx.x * 4; q < q_end; q += LS_BLOCK * 4) {
     const int valid = (int)min(4LL, dhw - q);
     float av[4], bv[4] = {bval, bval, bval, bval}, ov[4] = {0, 0, 0, 0};
-    ld4any(ap, q, valid, vec, av);
-    if (bp) ld4any(bp, q, valid, vec, bv);
-    if (accumulate) ld4any((const TA*)op, q, valid, vec, ov);
+    ld4any<VEC>(ap, q, valid, av);
+    if (bp) ld4any<VEC>(bp, q, valid, bv);
+    if (accumulate) ld4any<VEC>((const TA*)op, q, valid, ov);
 #pragma unroll
     for (int i = 0; i < 4; ++i) ov[i] += fmaf(fa, av[i], fmaf(fb, bv[i], fc));
-    if (vec && valid == 4) {
+    if constexpr (VEC) {
       st4(op, q, ov);
     } else {
       for (int i = 0; i < valid; ++i) stf(op, q + i, ov[i]);
@@ -84,6 +84,12 @@ __global__ __launch_bounds__(LS_BLOCK) void lincomb_kernel(const TA* a, long lon
   }
 }
 
+// launches KERNEL<TA, TB, vec> on `grid` / `st` (both in scope) with the layout flag as a compile-time argument
+#define LS_VEC(KERNEL, TA, TB, ...)                                                                      \
+  do {                                                                                                   \
+    if (vec) hipLaunchKernelGGL((KERNEL<TA, TB, true>), grid, dim3(LS_BLOCK), 0, st, __VA_ARGS__);       \
+    else hipLaunchKernelGGL((KERNEL<TA, TB, false>), grid, dim3(LS_BLOCK), 0, st, __VA_ARGS__);          \
+  } while (0)
 static inline dim3 ls_grid(long long dhw, int C, int N) {
   const long long maxb = (dhw + LS_BLOCK * 4 - 1) / (LS_BLOCK * 4);
   long long want = (2048 + (long long)C * N - 1) / ((long long)C * N);
@@ -100,9 +106,9 @@ extern "C" int xh_pair_sums(void* stream, int dtype, const void* a, long long a_
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype,
     if (b && b_dtype == XH_F32 && dtype != XH_F32)
-      hipLaunchKernelGGL((pair_sums_kernel<T, float>), grid, dim3(LS_BLOCK), 0, st, (const T*)a, a_bs, (const float*)b, b_bs, bval, DHW, thr_on, thr, red, vec);
+      LS_VEC(pair_sums_kernel, T, float, (const T*)a, a_bs, (const float*)b, b_bs, bval, DHW, thr_on, thr, red);
     else
-      hipLaunchKernelGGL((pair_sums_kernel<T, T>), grid, dim3(LS_BLOCK), 0, st, (const T*)a, a_bs, (const T*)b, b_bs, bval, DHW, thr_on, thr, red, vec););
+      LS_VEC(pair_sums_kernel, T, T, (const T*)a, a_bs, (const T*)b, b_bs, bval, DHW, thr_on, thr, red););
   return xh_launch_status();
 }
 
@@ -116,9 +122,9 @@ extern "C" int xh_lincomb(void* stream, int dtype, const void* a, long long a_bs
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype,
     if (b && b_dtype == XH_F32 && dtype != XH_F32)
-      hipLaunchKernelGGL((lincomb_kernel<T, float>), grid, dim3(LS_BLOCK), 0, st, (const T*)a, a_bs, (const float*)b, b_bs, bval, (T*)out, o_bs, DHW, ca, cb, cc, gscale, accumulate, vec);
+      LS_VEC(lincomb_kernel, T, float, (const T*)a, a_bs, (const float*)b, b_bs, bval, (T*)out, o_bs, DHW, ca, cb, cc, gscale, accumulate);
     else
-      hipLaunchKernelGGL((lincomb_kernel<T, T>), grid, dim3(LS_BLOCK), 0, st, (const T*)a, a_bs, (const T*)b, b_bs, bval, (T*)out, o_bs, DHW, ca, cb, cc, gscale, accumulate, vec););
+      LS_VEC(lincomb_kernel, T, T, (const T*)a, a_bs, (const T*)b, b_bs, bval, (T*)out, o_bs, DHW, ca, cb, cc, gscale, accumulate););
   return xh_launch_status();
 }
 
