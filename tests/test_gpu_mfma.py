@@ -30,6 +30,10 @@ CASES = [
     dict(cin=64, cout=128, groups=4, sp=(8, 8, 8)),           # 8-wide volumes (level 4): wgrad K steps of 4 rows x 8 voxels
     dict(cin=32, cout=16, groups=1, sp=(5, 7, 8)),            # ... ragged D/H
     dict(cin=32, cout=16, groups=1, sp=(5, 11, 16)),          # 16-wide, ragged H: wgrad K steps of 2 rows x 16 voxels
+    dict(cin=4, cout=12, groups=1, sp=(11, 13, 64)),          # quad-channel kernel: three output quads, ragged D/H tiles, two W tiles
+    dict(cin=8, cout=12, groups=1, sp=(5, 9, 32)),            # ... two input quads through the same LDS tile
+    dict(cin=12, cout=12, groups=1, sp=(9, 10, 32), split=8), # ... virtual concat split on a quad boundary
+    dict(cin=24, cout=24, groups=2, sp=(8, 8, 32), split=12), # ... grouped, 12 channels per group
 ]
 
 
@@ -80,6 +84,27 @@ def test_mfma_conv_forward_backward(cfg, dtype):
     gmax = max(w.grad.abs().max() for w in wo)
     for a, b in zip(dw1 + db1, [w.grad for w in wo] + [b.grad for b in bo]):
         assert l2_err(a, b) < t["dw"] or (a - b).abs().max() < t["dw"] * 0.7 * gmax
+
+
+def test_quad_channel_kernel_is_selected():
+    """Convs with <= 12 channels per group on 32-multiple rows take conv3_q4_kernel (forward and data gradient); the others keep
+    the plain implicit-GEMM kernels; xh_set_option(2, 16) switches the quad-channel path off (A/B runs)."""
+    lib = X._lib.load()
+    x = torch.randn(1, 16, 8, 8, 32, device=DEV).bfloat16()
+    w4 = [torch.randn(4, 4, 3, 3, 3, device=DEV) for _ in range(4)]
+    X.ops.conv3d(x, None, w4, None, k=3, cout=16, groups=4)
+    assert "conv3_q4_kernel<0, false, 0>" in X.ops.last_conv_kernel()
+    X.ops.conv3d(x.half(), None, w4, None, k=3, cout=16, groups=4, pre=(torch.ones(1, 16, device=DEV), torch.zeros(1, 16, device=DEV), 0.01),
+                 epi=2, red=torch.zeros(1, 16, 2, dtype=torch.float64, device=DEV))
+    assert "conv3_q4_kernel<1, true, 2>" in X.ops.last_conv_kernel()
+    X.ops.conv3d(x, None, [torch.randn(16, 16, 3, 3, 3, device=DEV)], None, k=3, cout=16)
+    assert "conv3_mfma_kernel" in X.ops.last_conv_kernel()
+    lib.xh_set_option(2, 16)
+    try:
+        X.ops.conv3d(x, None, w4, None, k=3, cout=16, groups=4)
+        assert "conv3_q4_kernel" not in X.ops.last_conv_kernel()
+    finally:
+        lib.xh_set_option(2, 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
@@ -133,9 +158,20 @@ BIG = [
 ]
 
 
+@pytest.mark.parametrize("path", ["q4", "gemm"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("cfg", BIG, ids=lambda c: f"{c['cin']}to{c['cout']}g{c['groups']}")
-def test_mfma_conv_full_size_128_vs_stock(cfg, dtype):
+def test_mfma_conv_full_size_128_vs_stock(cfg, dtype, path):
+    """path q4: the quad-channel W-Toeplitz kernel that carries these shapes in production; path gemm: the plain implicit-GEMM
+    `big` instances (quad-channel path switched off), which remain the kernels for denser groups at this volume class."""
+    X._lib.load().xh_set_option(2, 0 if path == "q4" else 16)
+    try:
+        _full_size_128(cfg, dtype, path)
+    finally:
+        X._lib.load().xh_set_option(2, 0)
+
+
+def _full_size_128(cfg, dtype, path):
     torch.manual_seed(21)
     torch.set_num_threads(min(32, torch.get_num_threads() * 4, __import__("os").cpu_count() or 1))
     S = 128
@@ -151,7 +187,10 @@ def test_mfma_conv_full_size_128_vs_stock(cfg, dtype):
     xa, xb = (xg[:, :cfg["split"]], xg[:, cfg["split"]:]) if "split" in cfg else (xg, None)
     y, red = X.functional.in_lrelu_conv(xa, xb, wg, bg, 1, g, out_stats=True)
     k_fwd = X.ops.last_conv_kernel()
-    big_ok = lambda k: ("conv3_mfma_kernel" in k and ", 256, 32, 8, 2>" in k) or "conv3_mfma_tile4_kernel" in k   # <= 4 input channels: whole-tile kernel
+    if path == "q4":
+        big_ok = lambda k: "conv3_q4_kernel" in k
+    else:
+        big_ok = lambda k: ("conv3_mfma_kernel" in k and ", 256, 32, 8, 2>" in k) or "conv3_mfma_tile4_kernel" in k   # <= 4 input channels: whole-tile kernel
     assert big_ok(k_fwd), k_fwd
     (y.float() * wgt.to(DEV)).sum().backward()
     k_bwd = X.ops.last_conv_kernel()              # the data gradient is the last conv launch of InLreluConv.backward

@@ -421,6 +421,7 @@ __global__ __launch_bounds__(256, 4) void conv3_mfma_tile4_kernel(const ConvMK a
   const int ds = wk / a.tilesH;
   const int oh0 = th * TH, ow0 = tw * TW, od0 = ds * TD;
 
+  if (a.abl & 4096) return;                           // ablation: launch + setup only
   // ---- stage the whole halo tile (norm + activation applied on the way, zero padding after it) ----
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(256, 4) void conv3_mfma_tile4_kernel(const ConvMK a
   ST* yplane = (ST*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
   double s0 = 0.0, s1 = 0.0;
   __syncthreads();
+  if (a.abl & 8192) return;                           // ablation: staging only
 
   // ---- every wave: its share of the TD x TH output rows, no further barriers ----
   for (int row = wv; row < TD * TH; row += NWV) {
@@ -617,9 +619,12 @@ static long long pack_bytes(const xh_conv_desc* d, const ConvMK& a) {
   const int gs = a.nsplit > 1 ? 1 : a.cin_blk / a.Cin_g;
   return (long long)(d->groups / gs) * a.ntile * a.nm * 1024;
 }
+long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d);                            // conv3d_q4.hip
+int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
 extern "C" long long xh_conv3d_workspace_bytes(const xh_conv_desc* d) {
   ConvMK a;
   if (!d || d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return 0;
+  if (const long long q4 = xh_conv3_q4_workspace_bytes(d)) return q4;
   if (mfma_plan(d, &a)) return 0;
   long long need = pack_bytes(d, a) * a.nsplit;
   if (a.nsplit > 1) need += (long long)d->N * d->Cout * d->Do * d->Ho * d->Wo * (long long)sizeof(float);
@@ -629,6 +634,10 @@ extern "C" long long xh_conv3d_workspace_bytes(const xh_conv_desc* d) {
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
 int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   ConvMK a;
+  {                                                   // few channels per group: the quad-channel W-Toeplitz kernel
+    const int r = xh_conv3_q4_try(stream, d, p);
+    if (r != 1) return r;
+  }
   if (mfma_plan(d, &a)) return 1;
   const long long need = xh_conv3d_workspace_bytes(d);
   if (!p->ws || p->ws_bytes < need) return 1;

@@ -1,0 +1,411 @@
+// Quad-channel 3x3x3 stride-1 convolution for gfx950 (forward and data gradient), 16-bit storage: the kernel for convs
+// whose groups have FEW channels (4 -> 4, 12 -> 4, 4 -> 12, the four-stream 16 -> 16 g4 of the encoder, ...), i.e. every
+// 128^3-class conv of XLSTM_HVED (RA_HVED.py:510-648).  A plain implicit GEMM with N = output channels leaves 12 of the 16
+// MFMA columns empty there and, worse, spends its time in per-voxel vector instructions around the matrix cores
+// (measured on conv3_mfma_tile4_kernel, 4 -> 4 @128^3: 51 us, of which 33 us remain with loads, MFMAs and stores removed).
+//
+// W-Toeplitz GEMM on mfma_f32_16x16x32:   D[(c, p)][q] += A[(c, p)][(s, ci)] * B[(s, ci)][q]
+//   q  = one of 16 output "quads" (4 consecutive voxels along W)            -> the N axis
+//   (c, p) = output channel c of the quad of 4, position p inside the quad   -> the M axis (16 rows, all useful)
+//   (s, ci) = input voxel 4q - 2 + s (s = 0..7), input channel ci of 4       -> the K axis (32, 24 of them non-zero)
+//   A[(c, p)][(s, ci)] = W[c][ci][kd][kh][kw = s - p - 1] (0 outside 0..2)  -> one fragment per (kd, kh), in registers
+// so one MFMA per (kd, kh) yields 64 voxels x 4 channels: 9 MFMAs per 64 voxels instead of 20, and
+//  * the B operand of a lane is ONE aligned 16-byte LDS read (input planes are staged channels-last, 8 bytes per voxel);
+//    a wave walks along D and reads every staged row once for its three depth taps (3 reads per 9 MFMAs);
+//  * the accumulator layout is the output layout: lane (q, c) holds 4 consecutive voxels of channel c -> one 8-byte
+//    NCDHW store per lane, all 64 lanes busy, 64-byte runs per row;
+//  * staging applies the producer's InstanceNorm + LeakyReLU on the way in with packed fp32 arithmetic and writes 16-byte
+//    LDS chunks; out-of-volume chunks get scale = shift = 0 (norm path) or a zero byte selector (copy path): no guarded
+//    loads, every global load of a workgroup is in flight before the first one is used;
+//  * the epilogue variant (none / output moments / norm-backward sums) and the input transform are template arguments.
+// One workgroup (4 waves) = an 8 x 8 x 32 (D x H x W) block of outputs of ONE output-channel quad; more input channels are
+// walked quad by quad through the same 28.8 KB LDS tile (4-5 workgroups per CU hide each other's staging phase).
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+
+typedef h16x8 frag8;
+typedef f32x4_t f32x4;
+
+struct ConvQ4 {
+  xh_conv_desc d;
+  xh_conv_ptrs p;
+  int Cin_g, Cout_g, ci4;       // channels per group, input-channel quads per group
+  int tilesW, tilesH, tilesD;
+  float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
+  int abl;
+};
+extern int g_mfma_abl;
+
+namespace {
+constexpr int TW = 32, TH = 8, TD = 8, IH = TH + 2, ID = TD + 2;
+constexpr int PITCH = 288;                  // 36 voxels (ow0 - 2 .. ow0 + 33) x 8 bytes
+constexpr int PLANE = IH * PITCH;
+constexpr int TILE_BYTES = ID * PLANE;      // 28 800
+constexpr int NROWS = ID * IH;              // 100 staged rows
+constexpr int NITEM = NROWS * 4;            // interior items: (row, 8-voxel group)
+constexpr int NEDGE = NROWS * 2;            // edge items: (row, side) -> one voxel pair
+}
+
+__device__ __forceinline__ float q4_weight(const ConvQ4& a, int co, int ci, int tap) {
+  const int g = co / a.Cout_g;
+  if (ci / a.Cin_g != g) return 0.f;
+  const int co_g = co % a.Cout_g, ci_g = ci % a.Cin_g;
+  const int gpp = a.d.groups / a.d.n_wptr;
+  const float* wp = a.p.w[g / gpp];
+  const int gl = g % gpp;
+  if (!a.d.transposed) return wp[((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * 27 + tap];
+  return wp[((long long)(gl * a.Cin_g + ci_g) * a.Cout_g + co_g) * 27 + (26 - tap)];
+}
+
+// ws[((oq * ci4 + cq) * 9 + r9) * 64 + lane][8]: A fragment of (kd, kh) = r9 for output quad oq, input quad cq.
+// Block (0, 0) also finalises the input's InstanceNorm statistics (xh_conv_ptrs.fin_red), like conv3_pack_kernel.
+__global__ __launch_bounds__(256) void conv3_q4_pack_kernel(const ConvQ4 a) {
+  const int oq = blockIdx.y;
+  const int per = a.ci4 * 9 * 512;
+  unsigned short* wf = (unsigned short*)a.p.ws + (long long)oq * per;
+  const int grp = (oq * 4) / a.Cout_g;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < per; idx += gridDim.x * 256) {
+    const int e = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
+    const int r9 = f % 9, cq = f / 9;
+    const int m = l & 15, c = m >> 2, pp = m & 3, g = l >> 4;
+    const int s = 2 * g + (e >> 2), ci = e & 3;
+    const int kw = s - pp - 1;
+    float v = 0.f;
+    if (kw >= 0 && kw <= 2) v = q4_weight(a, oq * 4 + c, grp * a.Cin_g + cq * 4 + ci, r9 * 3 + kw);
+    wf[idx] = a.d.dtype == XH_F16 ? f2hf(v) : f2bf(v);
+  }
+  if (a.p.fin_red && blockIdx.x == 0 && blockIdx.y == 0) {
+    const int total = a.d.N * a.d.Cin;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const double cnt = (double)a.p.fin_count;
+      const double mean = a.p.fin_red[2 * i] / cnt;
+      double var = a.p.fin_red[2 * i + 1] / cnt - mean * mean;
+      if (var < 0) var = 0;
+      const double rstd = 1.0 / sqrt(var + 1e-5);
+      const_cast<float*>(a.p.pre_sc)[i] = (float)rstd;
+      const_cast<float*>(a.p.pre_sh)[i] = (float)(-mean * rstd);
+      a.p.fin_mean[i] = (float)mean;
+      a.p.fin_rstd[i] = (float)rstd;
+    }
+  }
+}
+
+// two values of one channel -> leaky(x * sc + sh) in fp32
+template <int FMT> __device__ __forceinline__ void q4_xf(unsigned u, float sc, float sh, float slope, float& lo, float& hi) {
+  const float a = cvt_lo<FMT>(u) * sc + sh, b = cvt_hi<FMT>(u) * sc + sh;
+  lo = fmaxf(a, a * slope);
+  hi = fmaxf(b, b * slope);
+}
+
+template <int FMT, bool PRE, int EPI>
+__global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
+  typedef h16<FMT> ST;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nn = lane & 15, g4 = lane >> 4;
+  const int oq = blockIdx.y, n = blockIdx.z;
+  const int co0 = oq * 4;
+  const int grp = co0 / a.Cout_g;
+  const int cin_base = grp * a.Cin_g;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  const int Do = a.d.Do, Ho = a.d.Ho;
+  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH;
+  const int td = wk / a.tilesH;
+  const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+  if (a.abl & 4096) return;
+
+  // ---- staging plan (the same for every input-channel quad) ----
+  unsigned i_off[2];            // element offset of the item's 8 voxels inside a channel volume (clamped into the volume)
+  int i_lds[2];                 // LDS byte address of the item's first 16-byte chunk, before the per-chunk XOR
+  int i_par[2];
+  bool i_live[2], i_do[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + it * 256;
+    i_do[it] = item < NITEM;
+    const int gq = item & 3, row = min(item >> 2, NROWS - 1);
+    const int dz = row / IH, hy = row - dz * IH;
+    const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy;
+    i_live[it] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+    const int gdc = min(max(gd, 0), D - 1), ghc = min(max(gh, 0), H - 1);
+    i_off[it] = (unsigned)(((long long)gdc * H + ghc) * W + ow0 + gq * 8);
+    i_lds[it] = row * PITCH;
+    i_par[it] = (row & 1) | ((1 + 4 * gq) << 1);           // bit 0: row parity, rest: first 16-byte slot of the item
+  }
+  unsigned e_off; int e_lds; bool e_live;
+  const bool e_do = tid >= 256 - NEDGE;                // edge items go to the threads with the fewest interior items
+  {
+    const int ei = max(255 - tid, 0) < NEDGE ? 255 - tid : 0;
+    const int row = ei >> 1, side = ei & 1;
+    const int dz = row / IH, hy = row - dz * IH;
+    const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy;
+    const int gw = side ? ow0 + TW : ow0 - 2;
+    e_live = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+    const int gdc = min(max(gd, 0), D - 1), ghc = min(max(gh, 0), H - 1), gwc = min(max(gw, 0), W - 2);
+    e_off = (unsigned)(((long long)gdc * H + ghc) * W + gwc);
+    e_lds = row * PITCH + (((side ? 17 : 0) ^ (row & 1)) << 4);
+  }
+  // ---- B (data) fragment addresses: lane (nn, g4) reads quad (r, qw) of a 2-row x 32-voxel unit; the quad order and the
+  // row-parity XOR of the 16-byte slot make the ds_read_b128 bank-conflict free at a 288-byte pitch ----
+  const int ur = (nn >> 2) & 1;
+  const int qw = (nn >> 3) | ((nn & 3) << 1);
+  const int rowbase = (2 * wv + ur) * PITCH;
+  const int b_off0 = rowbase + ((2 * qw + g4) ^ ur) * 16;          // rows whose parity equals ur's (kh = 0, 2)
+  const int b_off1 = rowbase + ((2 * qw + g4) ^ ur ^ 1) * 16;      // kh = 1
+  // ---- epilogue lane role ----
+  const int co = co0 + g4;
+  const int oh = oh0 + 2 * wv + ur;
+  const int owl = ow0 + 4 * qw;
+  const bool row_ok = oh < Ho;
+  float bias = 0.f, esc = 0.f, esh = 0.f;
+  {
+    const int gpp = a.d.groups / a.d.n_wptr;
+    const float* bp = a.p.b[grp / gpp];
+    if (bp) bias = bp[(grp % gpp) * a.Cout_g + co % a.Cout_g];
+  }
+  const long long odhw = (long long)Do * Ho * a.d.Wo;
+  const ST* eplane = nullptr;
+  if (EPI == 1) {
+    esc = a.p.e_sc[n * a.d.Cout + co];
+    esh = a.p.e_sh[n * a.d.Cout + co];
+    eplane = co < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co * odhw
+                          : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co - a.d.Cea) * odhw;
+  }
+  ST* yplane = (ST*)a.p.y + n * a.d.y_bs + (long long)co * odhw;
+  const long long sp0 = ((long long)od0 * Ho + (row_ok ? oh : 0)) * a.d.Wo + owl;   // + dz * Ho * Wo
+  const long long spd = (long long)Ho * a.d.Wo;
+
+  f32x4 acc[TD];
+#pragma unroll
+  for (int i = 0; i < TD; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint2 eraw[TD];
+
+  const float pslope = a.d.pre_slope;
+  for (int cq = 0; cq < a.ci4; ++cq) {
+    const int c0 = cin_base + cq * 4;
+    const ST* src = c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
+                                : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      sc[cc] = PRE ? a.p.pre_sc[n * a.d.Cin + c0 + cc] : 1.f;
+      sh[cc] = PRE ? a.p.pre_sh[n * a.d.Cin + c0 + cc] : 0.f;
+    }
+    // ---- all global loads of this thread, back to back ----
+    uint4 raw[2][4];
+    unsigned eraw4[4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * dhw + i_off[it]);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) eraw4[cc] = *reinterpret_cast<const unsigned*>(src + cc * dhw + e_off);
+    if (cq > 0) __syncthreads();                      // every wave is done reading the previous quad's tile
+    // ---- transform + channels-last LDS image ----
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (!i_do[it]) continue;
+      const int par = i_par[it] & 1, slot0 = i_par[it] >> 1;
+      uint4 outv[4];                                  // chunk j = voxels 2j, 2j+1 x 4 channels
+      if (PRE) {
+        const float lv = i_live[it] ? 1.f : 0.f;
+        float v[4][8];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float s1 = sc[cc] * lv, s2 = sh[cc] * lv;
+          const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q4_xf<FMT>(u[k], s1, s2, pslope, v[cc][2 * k], v[cc][2 * k + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          outv[j].x = cvt_pack<FMT>(v[0][2 * j], v[1][2 * j]);
+          outv[j].y = cvt_pack<FMT>(v[2][2 * j], v[3][2 * j]);
+          outv[j].z = cvt_pack<FMT>(v[0][2 * j + 1], v[1][2 * j + 1]);
+          outv[j].w = cvt_pack<FMT>(v[2][2 * j + 1], v[3][2 * j + 1]);
+        }
+      } else {
+        const unsigned se = i_live[it] ? 0x05040100u : 0x0c0c0c0cu, so = i_live[it] ? 0x07060302u : 0x0c0c0c0cu;
+        const unsigned u[4][4] = {{raw[it][0].x, raw[it][0].y, raw[it][0].z, raw[it][0].w},
+                                  {raw[it][1].x, raw[it][1].y, raw[it][1].z, raw[it][1].w},
+                                  {raw[it][2].x, raw[it][2].y, raw[it][2].z, raw[it][2].w},
+                                  {raw[it][3].x, raw[it][3].y, raw[it][3].z, raw[it][3].w}};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          outv[j].x = __builtin_amdgcn_perm(u[1][j], u[0][j], se);
+          outv[j].y = __builtin_amdgcn_perm(u[3][j], u[2][j], se);
+          outv[j].z = __builtin_amdgcn_perm(u[1][j], u[0][j], so);
+          outv[j].w = __builtin_amdgcn_perm(u[3][j], u[2][j], so);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<uint4*>(smem + i_lds[it] + (((slot0 + j) ^ par) << 4)) = outv[j];
+    }
+    if (e_do) {
+      uint4 o;
+      if (PRE) {
+        const float lv = e_live ? 1.f : 0.f;
+        float v[4][2];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) q4_xf<FMT>(eraw4[cc], sc[cc] * lv, sh[cc] * lv, pslope, v[cc][0], v[cc][1]);
+        o.x = cvt_pack<FMT>(v[0][0], v[1][0]);
+        o.y = cvt_pack<FMT>(v[2][0], v[3][0]);
+        o.z = cvt_pack<FMT>(v[0][1], v[1][1]);
+        o.w = cvt_pack<FMT>(v[2][1], v[3][1]);
+      } else {
+        const unsigned se = e_live ? 0x05040100u : 0x0c0c0c0cu, so = e_live ? 0x07060302u : 0x0c0c0c0cu;
+        o.x = __builtin_amdgcn_perm(eraw4[1], eraw4[0], se);
+        o.y = __builtin_amdgcn_perm(eraw4[3], eraw4[2], se);
+        o.z = __builtin_amdgcn_perm(eraw4[1], eraw4[0], so);
+        o.w = __builtin_amdgcn_perm(eraw4[3], eraw4[2], so);
+      }
+      *reinterpret_cast<uint4*>(smem + e_lds) = o;
+    }
+    // A (weight) fragments of this (output quad, input quad): 9 x 16 bytes per lane, L2 resident; issued here so that
+    // they travel while the workgroup gathers at the barrier (the staging registers are dead by now)
+    frag8 wfrag[9];
+    {
+      const frag8* wpk = reinterpret_cast<const frag8*>(a.p.ws) + ((long long)oq * a.ci4 + cq) * 9 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) wfrag[i] = wpk[i * 64];
+    }
+    __syncthreads();
+    if (a.abl & 8192) continue;
+    // ---- matrix phase: the wave's two output rows, walking the 10 staged planes once ----
+    if (!(a.abl & 4)) {
+#pragma unroll
+      for (int pz = 0; pz < ID; ++pz) {
+        frag8 bf[3];
+        bf[0] = *reinterpret_cast<const frag8*>(smem + pz * PLANE + b_off0);
+        bf[1] = *reinterpret_cast<const frag8*>(smem + pz * PLANE + PITCH + b_off1);
+        bf[2] = *reinterpret_cast<const frag8*>(smem + pz * PLANE + 2 * PITCH + b_off0);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+          const int dz = pz - kd;
+          if (dz < 0 || dz >= TD) continue;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) acc[dz] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh], acc[dz]);
+        }
+      }
+    }
+  }
+  if (a.abl & 8192) return;
+
+  // ---- epilogue straight from the accumulators: lane (quad, channel) owns 4 consecutive voxels ----
+  if (EPI == 1) {                                     // the raw pre-norm values the norm backward multiplies with
+#pragma unroll
+    for (int dz = 0; dz < TD; ++dz) {
+      const int od = min(od0 + dz, Do - 1);
+      eraw[dz] = *reinterpret_cast<const uint2*>(eplane + ((long long)od * Ho + (row_ok ? oh : 0)) * a.d.Wo + owl);
+    }
+  }
+  double s0 = 0.0, s1 = 0.0;
+  const float aslope = a.act_slope, eslope = a.d.e_slope;
+#pragma unroll
+  for (int dz = 0; dz < TD; ++dz) {
+    if (od0 + dz >= Do || !row_ok) continue;
+    float o[4];
+    float t0 = 0.f, t1 = 0.f;
+    float ev[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == 1) {
+      ev[0] = cvt_lo<FMT>(eraw[dz].x); ev[1] = cvt_hi<FMT>(eraw[dz].x);
+      ev[2] = cvt_lo<FMT>(eraw[dz].y); ev[3] = cvt_hi<FMT>(eraw[dz].y);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[dz][r] + bias;
+      v = fmaxf(v, v * aslope);
+      if (EPI == 1) {
+        v = cvt_in<FMT>(cvt_out<FMT>(v * ((ev[r] * esc + esh) > 0.f ? 1.f : eslope)));
+        t0 += v; t1 += v * ev[r];
+      } else if (EPI == 2) {
+        v = cvt_in<FMT>(cvt_out<FMT>(v));
+        t0 += v; t1 += v * v;
+      }
+      o[r] = v;
+    }
+    if (EPI) { s0 += (double)t0; s1 += (double)t1; }
+    st4(yplane, sp0 + dz * spd, o);
+  }
+  if (EPI) {
+    // lanes of one channel: the 16 lanes nn = 0..15 of a lane group g4
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
+    if (nn == 0) { s_red[wv * 8 + g4 * 2] = s0; s_red[wv * 8 + g4 * 2 + 1] = s1; }
+    __syncthreads();
+    if (tid < 8) {
+      const double tot = s_red[tid] + s_red[8 + tid] + s_red[16 + tid] + s_red[24 + tid];
+      atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], tot);
+    }
+  }
+}
+
+static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
+  extern int g_xh_disable;
+  if (g_xh_disable & 16) return false;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return false;
+  if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
+  if (d->W % TW != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  if (cin_g % 4 || cout_g % 4) return false;
+  if (cin_g > 12 || cout_g > 12) return false;                 // denser groups: the plain implicit GEMM uses the MFMA better
+  if (d->Ca % 4) return false;
+  if (d->epi == 1 && d->Cea % 4) return false;
+  if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return false;
+  const long long dhw = (long long)d->D * d->H * d->W;
+  if (dhw % 8 || dhw >= (1ll << 31)) return false;
+  if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
+  float as = 1.f;
+  if (d->act == XH_ACT_RELU) as = 0.f;
+  else if (d->act == XH_ACT_LRELU) as = d->act_slope;
+  else if (d->act != XH_ACT_NONE) return false;
+  if (!(as >= 0.f && as <= 1.f)) return false;
+  if (d->N > 65535 || d->Cout / 4 > 65535) return false;
+  if (d->D < 4 || d->H < 8) return false;
+  a->d = *d;
+  a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cin_g / 4;
+  a->tilesW = d->W / TW; a->tilesH = cdiv(d->Ho, TH); a->tilesD = cdiv(d->Do, TD);
+  a->act_slope = as;
+  a->abl = g_mfma_abl;
+  return true;
+}
+
+long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
+  ConvQ4 a;
+  if (!q4_plan(d, &a)) return 0;
+  return (long long)(d->Cout / 4) * a.ci4 * 9 * 1024;
+}
+
+// XH_OK if launched, 1 if the shape is not eligible
+int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
+  ConvQ4 a;
+  if (!q4_plan(d, &a)) return 1;
+  const long long need = xh_conv3_q4_workspace_bytes(d);
+  if (!p->ws || p->ws_bytes < need) return 1;
+  a.p = *p;
+  hipStream_t st = (hipStream_t)stream;
+  const int f = d->dtype == XH_F16 ? 1 : 0;
+  hipLaunchKernelGGL(conv3_q4_pack_kernel, dim3(min(a.ci4 * 9 * 2, 18), d->Cout / 4), dim3(256), 0, st, a);
+  dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
+  const size_t shm = TILE_BYTES + 32 * sizeof(double);
+  xh_note_kernel("conv3_q4_kernel<%d, %s, %d>", f, d->pre ? "true" : "false", d->epi);
+#define Q4L(F, P, E) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E>), grid, dim3(256), shm, st, a)
+#define Q4E(F, P)                       \
+  do {                                  \
+    if (d->epi == 0) Q4L(F, P, 0);      \
+    else if (d->epi == 1) Q4L(F, P, 1); \
+    else Q4L(F, P, 2);                  \
+  } while (0)
+  if (f) { if (d->pre) Q4E(1, true); else Q4E(1, false); }
+  else { if (d->pre) Q4E(0, true); else Q4E(0, false); }
+#undef Q4E
+#undef Q4L
+  return xh_launch_status();
+}
