@@ -88,11 +88,12 @@ typedef struct {
   double* red;                                /* [N][Cout][2], caller zeroes, epi!=0 */
   void* ws; long long ws_bytes;               /* scratch for packed bf16 MFMA weight fragments (may be NULL:
                                                  the vector kernel is used); size from xh_conv3d_workspace_bytes */
-  /* Optional fused InstanceNorm finalisation (MFMA path only; needs pre == 1): when fin_red is given, the weight-pack
-   * launch that precedes the conv also turns the raw sums fin_red[n][c] = (sum x, sum x^2) over fin_count voxels into
-   * pre_sc = rstd, pre_sh = -mean*rstd (WRITTEN here, then read by the conv) and fin_mean / fin_rstd (kept for the
+  /* Optional fused InstanceNorm finalisation (MFMA path only; needs pre == 1): when fin_red is given, the conv kernel itself
+   * turns the raw sums fin_red[n][c] = (sum x, sum x^2) over fin_count voxels into scale = rstd, shift = -mean*rstd (every
+   * workgroup for its own input channels, in fp64) and ALSO WRITES pre_sc / pre_sh / fin_mean / fin_rstd (kept for the
    * backward), replacing a separate xh_norm_finalize launch.  A call that cannot take the MFMA path returns an error. */
   const double* fin_red; float* fin_mean; float* fin_rstd; long long fin_count;
+  int ws_packed;                              /* 1: ws already holds this conv's fragments (xh_conv3d_prepack): no pack launch */
 } xh_conv_ptrs;
 
 /* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv
@@ -100,6 +101,13 @@ typedef struct {
 int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
 /* Bytes of p->ws the bf16-MFMA implicit-GEMM path wants for this desc (0: shape not eligible, vector kernel). */
 long long xh_conv3d_workspace_bytes(const xh_conv_desc* d);
+/* Weights are constant within a training step: packs the MFMA weight fragments of n convolutions (forward and data-gradient
+ * calls alike; d[i] / p[i] as xh_conv3d_fwd will receive them -- only shape, weights and ws are read) into their p[i]->ws with
+ * ONE launch per 24 convolutions, instead of one small launch in front of every convolution.  A later xh_conv3d_fwd with
+ * ws_packed = 1 and the same ws skips its own pack.  Convolutions that are not on the MFMA path are skipped.  The caller
+ * re-packs whenever the weights change (xlstm-hved_amd/ops.py: once per forward, keyed by the parameters' version counters).
+ * Reference: the parameters of every nn.Conv3d(k=3) of RA_HVED.py:510-648 / buildingblocks.py:381-461. */
+int xh_conv3d_prepack(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p);
 
 /* Data gradient of a k=3, stride=2, pad=1 conv (the DRB SingleConv, RA_HVED.py:396-397).  Desc fields
  * describe the FORWARD conv (Cin,D,H,W = forward input; Cout,Do,Ho,Wo = forward output); x* = dY

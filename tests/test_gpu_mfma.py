@@ -107,6 +107,41 @@ def test_quad_channel_kernel_is_selected():
         lib.xh_set_option(2, 0)
 
 
+@pytest.mark.parametrize("cfg", [dict(cin=16, cout=16, groups=4, sp=(8, 16, 32)), dict(cin=16, cout=16, groups=1, sp=(6, 8, 32)),
+                                 dict(cin=48, cout=16, groups=1, sp=(8, 8, 32))], ids=["q4", "gemm", "splitk"])
+def test_prepacked_fragments_match_and_never_go_stale(cfg):
+    """ops.prepack_all() packs every registered conv's weight fragments in one launch (xh_conv3d_prepack); a conv then runs
+    without its own pack launch.  Same bits as packing in front of the conv; a weight changed after the prepack (version
+    counter) or an old epoch makes the conv pack for itself again instead of reading stale fragments."""
+    torch.manual_seed(5)
+    n, cin, cout, g = 2, cfg["cin"], cfg["cout"], cfg["groups"]
+    x = torch.randn((n, cin) + cfg["sp"], device=DEV).bfloat16()
+    nw = g if g <= 4 else 1
+    ws = [torch.randn(cout // nw, cin // g, 3, 3, 3, device=DEV) * 0.1 for _ in range(nw)]
+    call = lambda: X.ops.conv3d(x, None, ws, None, k=3, cout=cout, groups=g).float()
+    X.ops.set_prepack(False)
+    try:
+        ref = call()
+    finally:
+        X.ops.set_prepack(True)
+    y0 = call()                                   # first sighting: registers, packs on its own
+    X.ops.prepack_all()
+    y1 = call()                                   # prepacked
+    assert torch.equal(ref, y0) and torch.equal(ref, y1)
+    for w in ws:
+        w.mul_(-2.0)                              # in-place update, no prepack_all: the version counters give it away
+    y2 = call()
+    assert torch.allclose(y2, -2.0 * ref, rtol=2e-2, atol=1e-2 * ref.abs().max().item())
+    X.ops.prepack_all()
+    assert torch.equal(call(), y2)
+    # the ABI flag itself: ws_packed = 1 with fragments packed by xh_conv3d_prepack for OTHER weights reads those fragments
+    X.ops.set_prepack(False)
+    try:
+        assert torch.equal(call(), y2)
+    finally:
+        X.ops.set_prepack(True)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(1, 4, 12, 20, 32), (2, 4, 9, 16, 64), (1, 4, 5, 7, 32)])
 def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape, dtype):

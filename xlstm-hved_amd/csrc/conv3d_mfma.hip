@@ -21,6 +21,7 @@
 //    fused reductions (output moments for the next InstanceNorm, or the leaky'-masked gradient sums of the norm
 //    backward) are accumulated in fp64 registers over the whole run and reduced once.
 #include "common.h"
+#include "conv_pack.h"
 #include "../../include/xlstm_hved.h"
 
 typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
@@ -48,54 +49,38 @@ int g_mfma_abl = 0;
 int g_mfma_wgs = 512;      // xh_set_option(3, n): target workgroup count of the k3 MFMA forward kernel (experiments)
 int g_mfma_occ = 0;        // xh_set_option(4, 1): high-occupancy (<=128 VGPR) instances for CINP <= 8 at 128^3-class volumes
 
-__device__ __forceinline__ float mk_weight(const ConvMK& a, int co, int ci, int tap) {
-  // kernel-view absolute channels; block-diagonal over groups
-  const int g = co / a.Cout_g;
-  if (ci / a.Cin_g != g) return 0.f;
-  const int co_g = co % a.Cout_g, ci_g = ci % a.Cin_g;
-  const int gpp = a.d.groups / a.d.n_wptr;
-  const float* wp = a.p.w[g / gpp];
-  const int gl = g % gpp;
-  if (!a.d.transposed) return wp[((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * 27 + tap];
-  return wp[((long long)(gl * a.Cin_g + ci_g) * a.Cout_g + co_g) * 27 + (26 - tap)];
+static void mk_pack_job(const ConvMK& a, PackJob* j) {
+  for (int i = 0; i < 4; ++i) j->w[i] = a.p.w[i];
+  j->ws = a.p.ws;
+  j->kind = 0;
+  j->f16 = a.d.dtype == XH_F16;
+  j->groups = a.d.groups; j->n_wptr = a.d.n_wptr; j->transposed = a.d.transposed;
+  j->Cin_g = a.Cin_g; j->Cout_g = a.Cout_g;
+  j->ntile = a.ntile; j->cin_stride = a.cin_stride; j->cin_off = a.cin_off; j->cin_blk = a.cin_blk;
+  j->cout_set = a.cout_set; j->nm = a.nm; j->nch = a.nch; j->cpr = a.cpr; j->cinp = a.cinp;
+  j->ci4 = 0;
+  const int gs = a.nsplit > 1 ? 1 : a.cin_blk / a.Cin_g;
+  j->nelem = (a.d.groups / gs) * a.ntile * a.nm * 512;
 }
 
-// ws[y][i][lane][8] = B fragment (k = 8*(lane>>4)..+7, col lane&15) of MFMA i for channel tile y = set*ntile + nt
-__global__ __launch_bounds__(256) void conv3_pack_kernel(const ConvMK a) {
-  const int y = blockIdx.y;
-  const int set = y / a.ntile, nt = y % a.ntile;
-  const int cin0 = set * a.cin_stride + a.cin_off;
-  const int cin_end = (set + 1) * a.cin_stride;
-  const int co_base = set * a.cout_set + nt * 16;
-  const int co_lim = min(16, a.cout_set - nt * 16);
-  unsigned short* wf = (unsigned short*)a.p.ws + (long long)y * a.nm * 512;
-  const int idx = blockIdx.x * 256 + threadIdx.x;     // one fragment element per thread
-  if (idx >= a.nm * 512) return;
-  const int e = idx & 7, l = (idx >> 3) & 63, i = idx >> 9;
-  const int c = 4 * i + (l >> 4);
-  float v = 0.f;
-  if (c < a.nch && (l & 15) < co_lim) {
-    const int r9 = c / a.cpr, j = c % a.cpr;
-    const int flat = j * 8 + e;                       // position inside the row segment: kw*CINP + ci
-    const int kw = flat / a.cinp, ci = flat % a.cinp;
-    if (kw < 3 && ci < a.cin_blk && cin0 + ci < cin_end) v = mk_weight(a, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
+// one convolution's fragments (the launch in front of a convolution whose caller did not prepack)
+__global__ __launch_bounds__(256) void conv3_pack_kernel(const PackJob j) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < j.nelem; idx += gridDim.x * 256) pack_elem(j, idx);
+}
+// the fragments of up to XH_PACK_MAX_JOBS convolutions (xh_conv3d_prepack)
+__global__ __launch_bounds__(256) void conv3_pack_multi_kernel(const PackMulti m) {
+  int i = 0;
+  while (i + 1 < m.n && (int)blockIdx.x >= m.first_block[i + 1]) ++i;
+  const PackJob& j = m.job[i];
+  const int base = ((int)blockIdx.x - m.first_block[i]) * XH_PACK_PER_BLOCK;
+#pragma unroll
+  for (int u = 0; u < XH_PACK_PER_BLOCK / 256; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    if (idx < j.nelem) pack_elem(j, idx);
   }
-  wf[idx] = a.d.dtype == XH_F16 ? f2hf(v) : f2bf(v);
-  // fused InstanceNorm finalisation (xh_conv_ptrs.fin_red): one workgroup turns the raw sums into scale / shift
-  if (a.p.fin_red && blockIdx.x == 0 && blockIdx.y == 0 && a.cin_off == 0) {
-    const int total = a.d.N * a.d.Cin;
-    for (int i = threadIdx.x; i < total; i += 256) {
-      const double cnt = (double)a.p.fin_count;
-      const double mean = a.p.fin_red[2 * i] / cnt;
-      double var = a.p.fin_red[2 * i + 1] / cnt - mean * mean;
-      if (var < 0) var = 0;
-      const double rstd = 1.0 / sqrt(var + 1e-5);
-      const_cast<float*>(a.p.pre_sc)[i] = (float)rstd;
-      const_cast<float*>(a.p.pre_sh)[i] = (float)(-mean * rstd);
-      a.p.fin_mean[i] = (float)mean;
-      a.p.fin_rstd[i] = (float)rstd;
-    }
-  }
+}
+void xh_launch_pack_single(hipStream_t st, const PackJob& j) {
+  hipLaunchKernelGGL(conv3_pack_kernel, dim3(min(cdiv(j.nelem, 2048), 64)), dim3(256), 0, st, j);
 }
 
 // LDS swizzle: XOR the 16-byte chunk index (bits 4..6) with the 256-byte block index (bits 8..10).  Both the 8-voxel
@@ -183,6 +168,24 @@ __global__ __launch_bounds__(NT, MW) void conv3_mfma_kernel(const ConvMK a) {
   ST* yplane = (ST*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
   double s0 = 0.0, s1 = 0.0;     // running statistics in fp64 (block_sum_d note in common.h)
 
+  // ---- fused InstanceNorm finalisation (xh_conv_ptrs.fin_red): every workgroup turns the raw sums of ITS input channels
+  // into scale / shift (fp64, bit-identical across workgroups); workgroup (0, 0, 0) of the first split also leaves them and
+  // mean / rstd in memory for the backward pass ----
+  const bool fin = a.p.fin_red != nullptr;
+  float* s_fin = reinterpret_cast<float*>(s_red);     // [2][CINP] until the plane loop is over
+  if (fin) {
+    const double inv = 1.0 / (double)a.p.fin_count;
+    if (tid < a.cin_blk && cin0 + tid < cin_end) {
+      float m_, r_;
+      const int i = n * a.d.Cin + cin0 + tid;
+      in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], inv, s_fin[tid], s_fin[CINP + tid], m_, r_);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.cin_off == 0)
+      for (int i = tid; i < a.d.N * a.d.Cin; i += NT)
+        in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], inv, const_cast<float*>(a.p.pre_sc)[i],
+                    const_cast<float*>(a.p.pre_sh)[i], a.p.fin_mean[i], a.p.fin_rstd[i]);
+    __syncthreads();
+  }
   // ---- per-thread staging plan (identical for every plane) ----
   const ST* sp_src[NIT][4];     // channel plane base + in-plane offset, or nullptr
   float sp_sc[NIT][4], sp_sh[NIT][4];
@@ -209,7 +212,8 @@ __global__ __launch_bounds__(NT, MW) void conv3_mfma_kernel(const ConvMK a) {
         sp_src[it][cc] = (c < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
                                      : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
                          (long long)gh * W + gw;
-        if (a.d.pre) { sp_sc[it][cc] = a.p.pre_sc[n * a.d.Cin + c]; sp_sh[it][cc] = a.p.pre_sh[n * a.d.Cin + c]; }
+        if (fin) { sp_sc[it][cc] = s_fin[cl]; sp_sh[it][cc] = s_fin[CINP + cl]; }
+        else if (a.d.pre) { sp_sc[it][cc] = a.p.pre_sc[n * a.d.Cin + c]; sp_sh[it][cc] = a.p.pre_sh[n * a.d.Cin + c]; }
       }
     }
   }
@@ -377,194 +381,6 @@ __global__ __launch_bounds__(NT, MW) void conv3_mfma_kernel(const ConvMK a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Whole-tile variant for <= 4 input channels per channel set (the decoder / skip-return 4 -> 4 and 4 -> 12 convs, the
-// dominant kernel instance of the step in round 1).  The sliding-window kernel above is bound by its per-plane chain
-// (global load -> LDS write -> barrier -> 80 MFMAs -> stores, 16 times in a row, at two workgroups per CU): with 4
-// channels the matrix work per plane is too small to hide anything behind.  Here a workgroup stages the halo tile of a
-// TD x 8 x 32 output block ONCE ((TD+2) x 10 x 36 voxels x 4 channels = 29 KB for TD = 8), takes one barrier, and every
-// wave then runs its output rows straight through (MFMA + epilogue, no further synchronisation).  Latency hiding comes
-// from occupancy instead of from a software pipeline: ~30 KB of LDS and <= 128 VGPRs put 4 workgroups on a CU, so one
-// workgroup's load phase overlaps the others' matrix phase.  Same LDS image (channels-last, XOR swizzle), same K walk, same
-// packed B fragments and the same accumulator-layout epilogue as conv3_mfma_kernel.
-template <int FMT, int TD>
-__global__ __launch_bounds__(256, 4) void conv3_mfma_tile4_kernel(const ConvMK a) {
-  typedef h16<FMT> ST;
-  constexpr int CINP = 4, TW = 32, TH = 8, NWV = 4, NSEG = 2;
-  constexpr int IH = TH + 2, IWP = TW + 4, ID = TD + 2;
-  constexpr int VB = CINP * 2;
-  constexpr int PLANE = IH * IWP * VB;                // 2880 bytes
-  constexpr int CPR = 2, NCH = 18, NM = 5;
-  constexpr int NG = TW / 8 + 2;                      // 8-voxel groups covering [ow0 - 8, ow0 + TW + 8)
-  constexpr int NITEM = ID * IH * NG;
-  constexpr int NIT = (NITEM + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* s_in = smem;                         // ID * PLANE
-  double* s_red = reinterpret_cast<double*>(smem + ((ID * PLANE + 15) & ~15));     // [NWV][32]
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int g4 = lane >> 4, nn = lane & 15;
-  const int y = blockIdx.y;
-  const int set = y / a.ntile, nt = y % a.ntile;
-  const int n = blockIdx.z;
-  const int cin0 = set * a.cin_stride + a.cin_off;
-  const int cin_end = (set + 1) * a.cin_stride;
-  const int co_base = set * a.cout_set + nt * 16;
-  const int co_lim = min(16, a.cout_set - nt * 16);
-  const int D = a.d.D, H = a.d.H, W = a.d.W;
-  const long long hw = (long long)H * W, dhw = (long long)D * hw;
-  const int Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
-  const long long odhw = (long long)Do * Ho * Wo;
-  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tw = wk % a.tilesW; wk /= a.tilesW;
-  const int th = wk % a.tilesH;
-  const int ds = wk / a.tilesH;
-  const int oh0 = th * TH, ow0 = tw * TW, od0 = ds * TD;
-
-  if (a.abl & 4096) return;                           // ablation: launch + setup only
-  // ---- stage the whole halo tile (norm + activation applied on the way, zero padding after it) ----
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int item = tid + it * 256;
-    if (item >= NITEM) break;
-    const int gi = item % NG;
-    int r = item / NG;
-    const int hy = r % IH, dz = r / IH;
-    const int gq = gi - 1;
-    const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy, gw = ow0 + gq * 8;
-    const bool inb = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
-    float v[4][8];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int c = cin0 + cc;
-      const bool live = inb && cc < a.cin_blk && c < cin_end;
-      uint4 raw = make_uint4(0, 0, 0, 0);
-      float sc = 1.f, sh = 0.f;
-      if (live && !(a.abl & 2)) {
-        const ST* src = (c < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw
-                                    : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c - a.d.Ca) * dhw) +
-                        (long long)gd * hw + (long long)gh * W + gw;
-        raw = *reinterpret_cast<const uint4*>(src);
-        if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
-      }
-      const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float lo = cvt_lo<FMT>(u[k]), hi = cvt_hi<FMT>(u[k]);
-        if (a.d.pre) {
-          lo = leaky(lo * sc + sh, a.d.pre_slope);
-          hi = leaky(hi * sc + sh, a.d.pre_slope);
-        }
-        v[cc][2 * k] = live ? lo : 0.f;
-        v[cc][2 * k + 1] = live ? hi : 0.f;
-      }
-    }
-    const int base = dz * PLANE + (hy * IWP) * VB;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int wx = gq * 8 + k + 1;                  // tile column of voxel gw + k (column 0 = ow0 - 1)
-      if (wx >= 0 && wx < IWP && !(a.abl & 16)) {
-        uint2 pk;
-        pk.x = cvt_pack<FMT>(v[0][k], v[1][k]);
-        pk.y = cvt_pack<FMT>(v[2][k], v[3][k]);
-        *reinterpret_cast<uint2*>(s_in + swz(base + wx * VB)) = pk;
-      }
-    }
-  }
-  // ---- B fragments and A offsets (as in conv3_mfma_kernel) ----
-  bf16x8 bfrag[NM];
-  int aoff[NM];
-  {
-    const bf16x8* wpk = reinterpret_cast<const bf16x8*>(a.p.ws) + (long long)y * NM * 64;
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      bfrag[i] = wpk[i * 64 + lane];
-      const int c = 4 * i + g4;
-      const int cc = c < NCH ? c : 0;
-      const int r9 = cc / CPR, j = cc % CPR;
-      aoff[i] = (r9 / 3) * PLANE + ((r9 % 3) * IWP + nn) * VB + j * 16;
-    }
-  }
-  const int eco = nn;
-  const int co = co_base + eco;
-  const bool co_ok = eco < co_lim;
-  float bias = 0.f, esc = 0.f, esh = 0.f;
-  const ST* eplane = nullptr;
-  if (co_ok) {
-    const int g = co / a.Cout_g, gpp = a.d.groups / a.d.n_wptr;
-    const float* bp = a.p.b[g / gpp];
-    if (bp) bias = bp[(g % gpp) * a.Cout_g + co % a.Cout_g];
-    if (a.d.epi == 1) {
-      esc = a.p.e_sc[n * a.d.Cout + co];
-      esh = a.p.e_sh[n * a.d.Cout + co];
-      eplane = co < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co * odhw
-                            : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co - a.d.Cea) * odhw;
-    }
-  }
-  ST* yplane = (ST*)a.p.y + n * a.d.y_bs + (long long)(co_ok ? co : co_base) * odhw;
-  double s0 = 0.0, s1 = 0.0;
-  __syncthreads();
-  if (a.abl & 8192) return;                           // ablation: staging only
-
-  // ---- every wave: its share of the TD x TH output rows, no further barriers ----
-  for (int row = wv; row < TD * TH; row += NWV) {
-    const int dz = row / TH, rr = row % TH;
-    const int od = od0 + dz, oh = oh0 + rr;
-    if (od >= Do || oh >= Ho) continue;               // wave-uniform
-    f32x4 acc[NSEG];
-#pragma unroll
-    for (int wt = 0; wt < NSEG; ++wt) {
-      const int rowoff = dz * PLANE + (rr * IWP + wt * 16) * VB;
-      acc[wt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!(a.abl & 4))
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const int ao = rowoff + aoff[i];
-        const uint2 lo = *reinterpret_cast<const uint2*>(s_in + swz(ao));
-        const uint2 hi = *reinterpret_cast<const uint2*>(s_in + swz(ao + 8));
-        const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        acc[wt] = mfma16x16x32<FMT>(av, bfrag[i], acc[wt]);
-      }
-    }
-    if (!co_ok) continue;
-#pragma unroll
-    for (int wt = 0; wt < NSEG; ++wt) {
-      const long long sp = ((long long)od * Ho + oh) * Wo + ow0 + wt * 16 + 4 * g4;
-      float o[4] = {acc[wt][0], acc[wt][1], acc[wt][2], acc[wt][3]};
-      float ev[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.d.epi == 1) ld4(eplane, sp, ev);
-      float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = apply_act(o[r] + bias, a.d.act, a.d.act_slope);
-        if (a.d.epi == 1) {
-          v = cvt_in<FMT>(cvt_out<FMT>(v * ((ev[r] * esc + esh) > 0.f ? 1.f : a.d.e_slope)));
-          t0 += v; t1 += v * ev[r];
-        } else if (a.d.epi == 2) {
-          v = cvt_in<FMT>(cvt_out<FMT>(v));
-          t0 += v; t1 += v * v;
-        }
-        o[r] = v;
-      }
-      if (a.d.epi) { s0 += (double)t0; s1 += (double)t1; }
-      if (!(a.abl & 8)) st4(yplane, sp, o);
-    }
-  }
-  if (a.d.epi) {
-    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-    if (lane < 16) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
-    __syncthreads();
-    if (tid < 32) {
-      double tot = 0.0;
-#pragma unroll
-      for (int w8 = 0; w8 < NWV; ++w8) tot += s_red[w8 * 32 + tid];
-      const int c = tid >> 1;
-      if (c < co_lim && !(a.abl & 2048)) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co_base + c) * 2 + (tid & 1)], tot);
-    }
-  }
-}
-
 static int mfma_plan(const xh_conv_desc* d, ConvMK* a) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return 1;
   if (d->W % 16 != 0 || d->Wo != d->W) return 1;
@@ -660,17 +476,10 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     a.part = reinterpret_cast<float*>((char*)p->ws + pb * a.nsplit);
     a.p.ws = (char*)p->ws + pb * sidx;
   }
-  hipLaunchKernelGGL(conv3_pack_kernel, dim3(a.nm * 2, ny), dim3(256), 0, st, a);
-  if (a.cinp == 4 && a.tw == 32 && a.th == 8 && a.nsplit == 1 && !(g_mfma_abl & 1024)) {
-    // whole-tile kernel: TD x 8 x 32 output blocks, one barrier (see conv3_mfma_tile4_kernel)
-    constexpr int TD = 8;
-    const int tilesD = cdiv(d->Do, TD);
-    dim3 gridt(a.tilesW * a.tilesH * tilesD, ny, d->N);
-    const size_t shmt = (((size_t)(TD + 2) * 10 * 36 * 8 + 15) & ~(size_t)15) + 4 * 32 * sizeof(double);
-    xh_note_kernel("conv3_mfma_tile4_kernel<%d, %d>", d->dtype == XH_F16 ? 1 : 0, TD);
-    if (d->dtype == XH_F16) hipLaunchKernelGGL((conv3_mfma_tile4_kernel<1, TD>), gridt, dim3(256), shmt, st, a);
-    else hipLaunchKernelGGL((conv3_mfma_tile4_kernel<0, TD>), gridt, dim3(256), shmt, st, a);
-    continue;
+  if (!p->ws_packed) {
+    PackJob pj;
+    mk_pack_job(a, &pj);
+    xh_launch_pack_single(st, pj);
   }
 #define LM(F, C)                                                                                                \
   do {                                                                                                          \
@@ -702,5 +511,52 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   }
 #undef LMF
 #undef LM
+  return xh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// xh_conv3d_prepack: the weight fragments of n convolutions in ceil(jobs / 24) launches (a split-K convolution is one
+// job per split).  d[i] / p[i] are what xh_conv3d_fwd will be called with (only the weights, the workspace and the shape
+// are read); a convolution that is not on the MFMA path is skipped.  Afterwards the caller sets xh_conv_ptrs.ws_packed.
+bool xh_conv3_q4_pack_job(const xh_conv_desc* d, const xh_conv_ptrs* p, PackJob* j);        // conv3d_q4.hip
+extern int g_use_mfma;
+extern "C" int xh_conv3d_prepack(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p) {
+  if (n < 0 || (n > 0 && (!d || !p))) return XH_ERR_ARG;
+  if (!g_use_mfma) return XH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  PackMulti m;
+  m.n = 0;
+  m.first_block[0] = 0;
+  auto flush = [&]() {
+    if (m.n == 0) return;
+    hipLaunchKernelGGL(conv3_pack_multi_kernel, dim3(m.first_block[m.n]), dim3(256), 0, st, m);
+    m.n = 0;
+  };
+  auto push = [&](const PackJob& j) {
+    m.job[m.n] = j;
+    m.first_block[m.n + 1] = m.first_block[m.n] + cdiv(j.nelem, XH_PACK_PER_BLOCK);
+    if (++m.n == XH_PACK_MAX_JOBS) flush();
+  };
+  for (int i = 0; i < n; ++i) {
+    if (!d[i] || !p[i]) return XH_ERR_ARG;
+    if (d[i]->k != 3 || d[i]->stride != 1 || d[i]->groups <= 0 || d[i]->Cin % d[i]->groups || d[i]->Cout % d[i]->groups) continue;
+    const long long need = xh_conv3d_workspace_bytes(d[i]);
+    if (!need || !p[i]->ws || p[i]->ws_bytes < need) continue;
+    PackJob j;
+    if (xh_conv3_q4_pack_job(d[i], p[i], &j)) { push(j); continue; }
+    ConvMK a;
+    if (mfma_plan(d[i], &a)) continue;
+    a.p = *p[i];
+    const long long pb = pack_bytes(d[i], a);
+    for (int sidx = 0; sidx < a.nsplit; ++sidx) {
+      if (a.nsplit > 1) {
+        a.cin_off = sidx * a.cin_blk;
+        a.p.ws = (char*)p[i]->ws + pb * sidx;
+      }
+      mk_pack_job(a, &j);
+      push(j);
+    }
+  }
+  flush();
   return xh_launch_status();
 }

@@ -21,6 +21,7 @@
 // One workgroup (4 waves) = an 8 x 8 x 32 (D x H x W) block of outputs of ONE output-channel quad; more input channels are
 // walked quad by quad through the same 28.8 KB LDS tile (4-5 workgroups per CU hide each other's staging phase).
 #include "common.h"
+#include "conv_pack.h"
 #include "../../include/xlstm_hved.h"
 
 typedef h16x8 frag8;
@@ -32,6 +33,7 @@ struct ConvQ4 {
   int Cin_g, Cout_g, ci4;       // channels per group, input-channel quads per group
   int tilesW, tilesH, tilesD;
   float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
+  double fin_inv;               // 1 / fin_count
   int abl;
 };
 extern int g_mfma_abl;
@@ -46,50 +48,6 @@ constexpr int NITEM = NROWS * 4;            // interior items: (row, 8-voxel gro
 constexpr int NEDGE = NROWS * 2;            // edge items: (row, side) -> one voxel pair
 }
 
-__device__ __forceinline__ float q4_weight(const ConvQ4& a, int co, int ci, int tap) {
-  const int g = co / a.Cout_g;
-  if (ci / a.Cin_g != g) return 0.f;
-  const int co_g = co % a.Cout_g, ci_g = ci % a.Cin_g;
-  const int gpp = a.d.groups / a.d.n_wptr;
-  const float* wp = a.p.w[g / gpp];
-  const int gl = g % gpp;
-  if (!a.d.transposed) return wp[((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g) * 27 + tap];
-  return wp[((long long)(gl * a.Cin_g + ci_g) * a.Cout_g + co_g) * 27 + (26 - tap)];
-}
-
-// ws[((oq * ci4 + cq) * 9 + r9) * 64 + lane][8]: A fragment of (kd, kh) = r9 for output quad oq, input quad cq.
-// Block (0, 0) also finalises the input's InstanceNorm statistics (xh_conv_ptrs.fin_red), like conv3_pack_kernel.
-__global__ __launch_bounds__(256) void conv3_q4_pack_kernel(const ConvQ4 a) {
-  const int oq = blockIdx.y;
-  const int per = a.ci4 * 9 * 512;
-  unsigned short* wf = (unsigned short*)a.p.ws + (long long)oq * per;
-  const int grp = (oq * 4) / a.Cout_g;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < per; idx += gridDim.x * 256) {
-    const int e = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
-    const int r9 = f % 9, cq = f / 9;
-    const int m = l & 15, c = m >> 2, pp = m & 3, g = l >> 4;
-    const int s = 2 * g + (e >> 2), ci = e & 3;
-    const int kw = s - pp - 1;
-    float v = 0.f;
-    if (kw >= 0 && kw <= 2) v = q4_weight(a, oq * 4 + c, grp * a.Cin_g + cq * 4 + ci, r9 * 3 + kw);
-    wf[idx] = a.d.dtype == XH_F16 ? f2hf(v) : f2bf(v);
-  }
-  if (a.p.fin_red && blockIdx.x == 0 && blockIdx.y == 0) {
-    const int total = a.d.N * a.d.Cin;
-    for (int i = threadIdx.x; i < total; i += 256) {
-      const double cnt = (double)a.p.fin_count;
-      const double mean = a.p.fin_red[2 * i] / cnt;
-      double var = a.p.fin_red[2 * i + 1] / cnt - mean * mean;
-      if (var < 0) var = 0;
-      const double rstd = 1.0 / sqrt(var + 1e-5);
-      const_cast<float*>(a.p.pre_sc)[i] = (float)rstd;
-      const_cast<float*>(a.p.pre_sh)[i] = (float)(-mean * rstd);
-      a.p.fin_mean[i] = (float)mean;
-      a.p.fin_rstd[i] = (float)rstd;
-    }
-  }
-}
-
 // two values of one channel -> leaky(x * sc + sh) in fp32
 template <int FMT> __device__ __forceinline__ void q4_xf(unsigned u, float sc, float sh, float slope, float& lo, float& hi) {
   const float a = cvt_lo<FMT>(u) * sc + sh, b = cvt_hi<FMT>(u) * sc + sh;
@@ -102,6 +60,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   typedef h16<FMT> ST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8]
+  float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 32 * sizeof(double));   // [2][12]: in-kernel InstanceNorm scale / shift
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g4 = lane >> 4;
@@ -118,6 +77,12 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   const int td = wk / a.tilesH;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
   if (a.abl & 4096) return;
+  // raw InstanceNorm sums of this group's input channels (fused finalisation): requested first, used behind the staging loads
+  double fs1 = 0.0, fs2 = 0.0;
+  if (PRE && a.p.fin_red && tid < a.Cin_g) {
+    fs1 = a.p.fin_red[2 * (n * a.d.Cin + cin_base + tid)];
+    fs2 = a.p.fin_red[2 * (n * a.d.Cin + cin_base + tid) + 1];
+  }
 
   // ---- staging plan (the same for every input-channel quad) ----
   unsigned i_off[2];            // element offset of the item's 8 voxels inside a channel volume (clamped into the volume)
@@ -186,16 +151,11 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   uint2 eraw[TD];
 
   const float pslope = a.d.pre_slope;
+  const bool fin = PRE && a.p.fin_red != nullptr;
   for (int cq = 0; cq < a.ci4; ++cq) {
     const int c0 = cin_base + cq * 4;
     const ST* src = c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
                                 : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw;
-    float sc[4], sh[4];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      sc[cc] = PRE ? a.p.pre_sc[n * a.d.Cin + c0 + cc] : 1.f;
-      sh[cc] = PRE ? a.p.pre_sh[n * a.d.Cin + c0 + cc] : 0.f;
-    }
     // ---- all global loads of this thread, back to back ----
     uint4 raw[2][4];
     unsigned eraw4[4];
@@ -207,6 +167,30 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) eraw4[cc] = *reinterpret_cast<const unsigned*>(src + cc * dhw + e_off);
     if (cq > 0) __syncthreads();                      // every wave is done reading the previous quad's tile
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PRE) {
+      if (fin) {
+        // fused InstanceNorm finalisation (xh_conv_ptrs.fin_red), behind the loads just issued: the raw sums of this
+        // group's channels -> scale / shift in LDS (fp64, the same bits in every workgroup); workgroup (0, 0, 0) also
+        // leaves them and mean / rstd of ALL channels in memory for the backward pass
+        if (cq == 0) {
+          if (tid < a.Cin_g) {
+            float m_, r_;
+            in_finalize(fs1, fs2, a.fin_inv, s_fin[tid], s_fin[12 + tid], m_, r_);
+          }
+          if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+            for (int i = tid; i < a.d.N * a.d.Cin; i += 256)
+              in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], a.fin_inv, const_cast<float*>(a.p.pre_sc)[i],
+                          const_cast<float*>(a.p.pre_sh)[i], a.p.fin_mean[i], a.p.fin_rstd[i]);
+          __syncthreads();
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { sc[cc] = s_fin[cq * 4 + cc]; sh[cc] = s_fin[12 + cq * 4 + cc]; }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { sc[cc] = a.p.pre_sc[n * a.d.Cin + c0 + cc]; sh[cc] = a.p.pre_sh[n * a.d.Cin + c0 + cc]; }
+      }
+    }
     // ---- transform + channels-last LDS image ----
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -377,6 +361,26 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   return true;
 }
 
+static void q4_pack_job(const ConvQ4& a, PackJob* j) {
+  for (int i = 0; i < 4; ++i) j->w[i] = a.p.w[i];
+  j->ws = a.p.ws;
+  j->kind = 1;
+  j->f16 = a.d.dtype == XH_F16;
+  j->groups = a.d.groups; j->n_wptr = a.d.n_wptr; j->transposed = a.d.transposed;
+  j->Cin_g = a.Cin_g; j->Cout_g = a.Cout_g;
+  j->ntile = j->cin_stride = j->cin_off = j->cin_blk = j->cout_set = j->nm = j->nch = j->cpr = j->cinp = 0;
+  j->ci4 = a.ci4;
+  j->nelem = (a.d.Cout / 4) * a.ci4 * 9 * 512;
+}
+bool xh_conv3_q4_pack_job(const xh_conv_desc* d, const xh_conv_ptrs* p, PackJob* j) {
+  ConvQ4 a;
+  if (!q4_plan(d, &a)) return false;
+  a.p = *p;
+  q4_pack_job(a, j);
+  return true;
+}
+void xh_launch_pack_single(hipStream_t st, const PackJob& j);                   // conv3d_mfma.hip
+
 long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
   ConvQ4 a;
   if (!q4_plan(d, &a)) return 0;
@@ -390,11 +394,16 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   const long long need = xh_conv3_q4_workspace_bytes(d);
   if (!p->ws || p->ws_bytes < need) return 1;
   a.p = *p;
+  a.fin_inv = p->fin_count > 0 ? 1.0 / (double)p->fin_count : 0.0;
   hipStream_t st = (hipStream_t)stream;
   const int f = d->dtype == XH_F16 ? 1 : 0;
-  hipLaunchKernelGGL(conv3_q4_pack_kernel, dim3(min(a.ci4 * 9 * 2, 18), d->Cout / 4), dim3(256), 0, st, a);
+  if (!p->ws_packed) {
+    PackJob pj;
+    q4_pack_job(a, &pj);
+    xh_launch_pack_single(st, pj);
+  }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
-  const size_t shm = TILE_BYTES + 32 * sizeof(double);
+  const size_t shm = TILE_BYTES + 32 * sizeof(double) + 24 * sizeof(float);
   xh_note_kernel("conv3_q4_kernel<%d, %s, %d>", f, d->pre ? "true" : "false", d->epi);
 #define Q4L(F, P, E) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E>), grid, dim3(256), shm, st, a)
 #define Q4E(F, P)                       \

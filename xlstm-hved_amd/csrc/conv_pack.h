@@ -1,0 +1,91 @@
+// Weight-fragment packing shared by the k=3 MFMA convolution kernels (conv3d_mfma.hip: implicit-GEMM fragments;
+// conv3d_q4.hip: quad-channel W-Toeplitz fragments), and the in-kernel InstanceNorm finalisation they both use.
+//
+// Weights are constant within a training step, so a caller may pack the fragments of EVERY convolution of the step with one
+// launch up front (xh_conv3d_prepack, conv3_pack_multi_kernel) instead of one small launch in front of each convolution; the
+// job record below is everything a pack needs, small enough for two dozen of them to travel in the kernel arguments.
+#pragma once
+#include "common.h"
+
+struct PackJob {
+  const float* w[4];
+  void* ws;
+  int kind;                                  // 0: implicit-GEMM fragments, 1: quad-channel Toeplitz fragments
+  int f16, groups, n_wptr, transposed, Cin_g, Cout_g;
+  int ntile, cin_stride, cin_off, cin_blk, cout_set, nm, nch, cpr, cinp;   // kind 0 (ConvMK fields of the same names)
+  int ci4;                                                                  // kind 1
+  int nelem;                                 // 16-bit elements to write
+};
+
+// weight of (output channel co, input channel ci, tap) in kernel view (absolute channels; block-diagonal over groups);
+// transposed = data gradient: forward-layout weights with roles swapped and taps flipped
+__device__ __forceinline__ float pack_weight(const PackJob& j, int co, int ci, int tap) {
+  const int g = co / j.Cout_g;
+  if (ci / j.Cin_g != g) return 0.f;
+  const int co_g = co % j.Cout_g, ci_g = ci % j.Cin_g;
+  const int gpp = j.groups / j.n_wptr;
+  const float* wp = j.w[g / gpp];
+  const int gl = g % gpp;
+  if (!j.transposed) return wp[((long long)(gl * j.Cout_g + co_g) * j.Cin_g + ci_g) * 27 + tap];
+  return wp[((long long)(gl * j.Cin_g + ci_g) * j.Cout_g + co_g) * 27 + (26 - tap)];
+}
+
+__device__ __forceinline__ void pack_elem(const PackJob& j, int idx) {
+  float v = 0.f;
+  if (j.kind == 0) {
+    // ws[y][i][lane][8] = B fragment (k = 8*(lane>>4)..+7, col lane&15) of MFMA i for channel tile y = set*ntile + nt
+    const int per = j.nm * 512;
+    const int y = idx / per, r = idx - y * per;
+    const int set = y / j.ntile, nt = y % j.ntile;
+    const int cin0 = set * j.cin_stride + j.cin_off;
+    const int cin_end = (set + 1) * j.cin_stride;
+    const int co_base = set * j.cout_set + nt * 16;
+    const int co_lim = min(16, j.cout_set - nt * 16);
+    const int e = r & 7, l = (r >> 3) & 63, i = r >> 9;
+    const int c = 4 * i + (l >> 4);
+    if (c < j.nch && (l & 15) < co_lim) {
+      const int r9 = c / j.cpr, q = c % j.cpr;
+      const int flat = q * 8 + e;                       // position inside the row segment: kw*CINP + ci
+      const int kw = flat / j.cinp, ci = flat % j.cinp;
+      if (kw < 3 && ci < j.cin_blk && cin0 + ci < cin_end) v = pack_weight(j, co_base + (l & 15), cin0 + ci, r9 * 3 + kw);
+    }
+  } else {
+    // ws[((oq * ci4 + cq) * 9 + r9) * 64 + lane][8]: A fragment of (kd, kh) = r9 for output quad oq, input quad cq:
+    // row m = (c, p) = output channel c of the quad, position p in a voxel quad; k = (s, ci) = input voxel 4q - 2 + s, channel ci
+    const int per = j.ci4 * 9 * 512;
+    const int oq = idx / per, r = idx - oq * per;
+    const int grp = (oq * 4) / j.Cout_g;
+    const int e = r & 7, l = (r >> 3) & 63, f = r >> 9;
+    const int r9 = f % 9, cq = f / 9;
+    const int m = l & 15, c = m >> 2, pp = m & 3, g = l >> 4;
+    const int s = 2 * g + (e >> 2), ci = e & 3;
+    const int kw = s - pp - 1;
+    if (kw >= 0 && kw <= 2) v = pack_weight(j, oq * 4 + c, grp * j.Cin_g + cq * 4 + ci, r9 * 3 + kw);
+  }
+  reinterpret_cast<unsigned short*>(j.ws)[idx] = j.f16 ? f2hf(v) : f2bf(v);
+}
+
+#define XH_PACK_MAX_JOBS 24
+struct PackMulti {
+  PackJob job[XH_PACK_MAX_JOBS];
+  int first_block[XH_PACK_MAX_JOBS + 1];     // workgroup prefix: job i owns blocks [first_block[i], first_block[i+1])
+  int n;
+};
+#define XH_PACK_PER_BLOCK 2048                // elements per workgroup (256 threads x 8)
+
+// InstanceNorm statistics of a channel from its raw sums (s1 = sum x, s2 = sum x^2; xh_conv_ptrs.fin_red): mean and
+// variance in fp64 (the cancellation in E[x^2] - mean^2 needs it), the reciprocal square root in fp32 with one Newton step
+// (<= 1 ulp of the fp32 value xh_norm_finalize rounds to; these kernels feed 16-bit storage).  Cheap enough for every
+// workgroup to evaluate for its own channels; all of them get the same bits.
+__device__ __forceinline__ void in_finalize(double s1, double s2, double inv_count, float& sc, float& sh, float& mean, float& rstd) {
+  const double m = s1 * inv_count;
+  double var = fma(-m, m, s2 * inv_count);
+  if (var < 0) var = 0;
+  const float v = (float)(var + 1e-5);
+  float r = __frsqrt_rn(v);
+  r = r * (1.5f - 0.5f * v * r * r);
+  sc = r;
+  sh = (float)(-m * (double)r);
+  mean = (float)m;
+  rstd = r;
+}

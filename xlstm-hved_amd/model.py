@@ -239,6 +239,7 @@ class AbstractFusion3DUNet(nn.Module):
         """The input-only part: per-level DRB outputs (4 streams x [mu | logvar] before PoE) and the skip-return feature."""
         batched = self.layer_order == "ilc"     # 'ilc' runs the 4 modality streams as one grouped launch per stage
         ops.red_arena_reset(x.device)
+        ops.prepack_all()                       # the MFMA weight fragments of every k=3 conv of the step: one launch per 24
         x = x.contiguous()
         st0 = None
         if batched:

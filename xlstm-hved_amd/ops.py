@@ -117,6 +117,75 @@ def zeros_red(t, n, c):
     return zeros_f64(t.device, (n, c, 2))
 
 
+# ------------------------------------------------------------------------------------- weight fragments
+# The MFMA conv kernels read their weights as packed 16-bit fragments (xh_conv3d_workspace_bytes).  Weights are constant
+# within a step, so instead of one small pack launch in front of each of the ~54 k=3 convolutions (forward and data
+# gradient) the network's forward() calls prepack_all(): ONE launch per 24 convolutions packs every registered conv's
+# fragments into its persistent workspace.  A conv call registers itself the first time it is seen (and packs on its own
+# that time).  An entry is trusted only while (a) it was packed in the current epoch (prepack_all starts a new one) and
+# (b) the version counters of its weight tensors are the ones it was packed at -- anything else packs in front of the conv
+# exactly as before, so a stage called on its own or a weight changed mid-step can never read stale fragments.
+_PACKS = {}
+_PACK_STATE = {"epoch": 0, "arrays": None, "enabled": True}
+
+
+class _PackEntry:
+    __slots__ = ("refs", "ws", "desc", "ptrs", "epoch", "versions", "keep")
+
+    def alive(self):
+        return all(r() is not None for r in self.refs)
+
+
+def set_prepack(enabled):
+    """A/B switch (tests, microbenchmarks): False = every conv packs its own fragments right in front of the launch."""
+    _PACK_STATE["enabled"] = bool(enabled)
+    _PACKS.clear()
+    _PACK_STATE["arrays"] = None
+
+
+def _pack_entry(weights, desc, need, device):
+    key = (tuple(w.data_ptr() for w in weights), desc.dtype, desc.Cin, desc.Cout, desc.groups, desc.transposed, desc.D, desc.H,
+           desc.W, desc.n_wptr, need)
+    e = _PACKS.get(key)
+    if e is not None and e.alive():
+        return e
+    import weakref
+    e = _PackEntry()
+    e.refs = [weakref.ref(w) for w in weights]
+    e.ws = torch.empty(need, dtype=torch.uint8, device=device)
+    e.desc = L.ConvDesc.from_buffer_copy(desc)
+    e.ptrs = L.ConvPtrs()
+    e.ptrs.w = _arr4(list(weights))
+    e.ptrs.ws, e.ptrs.ws_bytes = e.ws.data_ptr(), need
+    e.epoch, e.versions = -1, None
+    _PACKS[key] = e
+    _PACK_STATE["arrays"] = None
+    return e
+
+
+def prepack_all():
+    """Starts a new epoch and packs the fragments of every registered convolution (xh_conv3d_prepack).  Called at the start
+    of the network's forward(); capture-safe (the launches are part of a captured step)."""
+    st = _PACK_STATE
+    st["epoch"] += 1
+    if not st["enabled"] or not _PACKS:
+        return
+    if st["arrays"] is None or any(not e.alive() for e in st["arrays"][0]):
+        for k in [k for k, e in _PACKS.items() if not e.alive()]:
+            del _PACKS[k]
+        ents = list(_PACKS.values())
+        n = len(ents)
+        st["arrays"] = (ents, (C.c_void_p * n)(*[C.addressof(e.desc) for e in ents]),
+                        (C.c_void_p * n)(*[C.addressof(e.ptrs) for e in ents]))
+    ents, darr, parr = st["arrays"]
+    if not ents:
+        return
+    L.check(L.load().xh_conv3d_prepack(_stream(), len(ents), darr, parr), "xh_conv3d_prepack")
+    for e in ents:
+        e.epoch = st["epoch"]
+        e.versions = tuple(r()._version for r in e.refs)
+
+
 # ----------------------------------------------------------------------------------------------- conv
 def _conv_desc(xa, xb, k, stride, groups, cout, n_w, transposed, pre, act, act_slope, epi, e, y_bs, out_sp):
     n, ca, d, h, w, xa_bs = _vol(xa)
@@ -202,7 +271,15 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     if red is not None:
         ptrs.red = _p(red)
     need = lib.xh_conv3d_workspace_bytes(C.byref(desc)) if _MFMA[0] else 0
-    if need:
+    if need and _PACK_STATE["enabled"]:
+        ent = _pack_entry(weights, desc, need, xa.device)
+        ptrs.ws, ptrs.ws_bytes = ent.ws.data_ptr(), need
+        vers = tuple(w._version for w in weights)
+        if ent.epoch == _PACK_STATE["epoch"] and ent.versions == vers:
+            ptrs.ws_packed = 1
+        else:                                   # this call packs; good for the rest of the epoch
+            ent.epoch, ent.versions = _PACK_STATE["epoch"], vers
+    elif need:
         ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
         ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
     if stats is not None:
