@@ -199,7 +199,7 @@ BIG = [
 def test_mfma_conv_full_size_128_vs_stock(cfg, dtype, path):
     """path q4: the quad-channel W-Toeplitz kernel that carries these shapes in production; path gemm: the plain implicit-GEMM
     `big` instances (quad-channel path switched off), which remain the kernels for denser groups at this volume class."""
-    X._lib.load().xh_set_option(2, 0 if path == "q4" else 16)
+    X._lib.load().xh_set_option(2, 0 if path == "q4" else 16 | 32)     # bit 4: forward / data gradient, bit 5: weight gradient
     try:
         _full_size_128(cfg, dtype, path)
     finally:
@@ -254,17 +254,22 @@ def _full_size_128(cfg, dtype, path):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 def test_wgrad_mfma_full_size_128_kernel_name(dtype):
-    """The weight gradient at 128^3 goes through conv3_wgrad_mfma_kernel<F, 4, 256> (checked numerically by the test above
-    through InLreluConv.backward); this pins the instance selection so a plan change cannot silently drop the coverage."""
+    """The weight gradient of a few-channel conv at 128^3 goes through conv3_wgrad_q4_multi_kernel; with the quad-channel
+    kernels switched off it is conv3_wgrad_mfma_kernel<F, 4, 256> (both checked numerically by the test above through
+    InLreluConv.backward); this pins the selection so a plan change cannot silently drop the coverage."""
     x = torch.randn(1, 4, 128, 128, 128, device=DEV).to(dtype)
     dy = torch.randn(1, 4, 128, 128, 128, device=DEV).to(dtype)
     dw, db = torch.zeros(4, 4, 3, 3, 3, device=DEV), torch.zeros(4, device=DEV)
     X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
     name = X.ops.last_conv_kernel()
+    assert "conv3_wgrad_q4_multi_kernel" in name, name
+    X._lib.load().xh_set_option(2, 32)
+    try:
+        X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
+        name = X.ops.last_conv_kernel()
+    finally:
+        X._lib.load().xh_set_option(2, 0)
     assert "conv3_wgrad_mfma_kernel" in name and name.endswith(", 4, 256>"), name
-    ref = torch.nn.functional.conv3d(x.float().transpose(0, 1), dy.float().transpose(0, 1), padding=1).transpose(0, 1)
-    assert l2_err(dw, ref) < TOL[dtype]["dw"]
-    assert l2_err(db, dy.float().sum((0, 2, 3, 4))) < 1e-3
 
 
 @pytest.mark.parametrize("w", [16, 8])
@@ -280,6 +285,33 @@ def test_wgrad_mfma_narrow_volume_kernel_name(w):
     ref = torch.nn.grad.conv3d_weight(x.float(), dw.shape, dy.float(), padding=1)
     assert l2_err(dw.cpu(), ref.cpu()) < 2e-3
     assert l2_err(db.cpu(), dy.float().sum((0, 2, 3, 4)).cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+@pytest.mark.parametrize("cfg", [dict(n=2, cin=4, cout=4, g=1, sp=(9, 6, 32)), dict(n=1, cin=12, cout=8, g=1, sp=(17, 11, 64)),
+                                 dict(n=1, cin=16, cout=32, g=4, sp=(8, 8, 32)), dict(n=2, cin=24, cout=8, g=2, sp=(5, 9, 32))],
+                         ids=["4to4", "12to8", "16to32g4", "24to8g2"])
+def test_wgrad_quad_channel_kernel_vs_stock(cfg, dtype):
+    """conv3_wgrad_q4_multi_kernel on its own (raw x, no input transform; then with the InstanceNorm + LeakyReLU transform):
+    weight and bias gradients against torch.nn.grad on the same 16-bit inputs; ragged D / H, several W tiles, batch 2."""
+    torch.manual_seed(31)
+    n, cin, cout, g = cfg["n"], cfg["cin"], cfg["cout"], cfg["g"]
+    x = torch.randn((n, cin) + cfg["sp"], device=DEV).to(dtype)
+    dy = torch.randn((n, cout) + cfg["sp"], device=DEV).to(dtype)
+    nw = g if g <= 4 else 1
+    for pre in (None, (torch.rand(n, cin, device=DEV) + 0.5, torch.randn(n, cin, device=DEV), 0.01)):
+        dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
+        dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
+        X.ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=pre)
+        assert "conv3_wgrad_q4_multi_kernel" in X.ops.last_conv_kernel()
+        xf = x.float()
+        if pre is not None:
+            xf = torch.nn.functional.leaky_relu(xf * pre[0][:, :, None, None, None] + pre[1][:, :, None, None, None], 0.01)
+            xf = xf.to(dtype).float()                  # the kernel rounds the transformed operand to the storage format
+        ref = torch.nn.grad.conv3d_weight(xf, (cout, cin // g, 3, 3, 3), dy.float(), padding=1, groups=g)
+        tol = 2e-3 if dtype == torch.bfloat16 else 5e-4
+        assert l2_err(torch.cat(dws, 0).cpu(), ref.cpu()) < tol
+        assert l2_err(torch.cat(dbs, 0).cpu(), dy.float().sum((0, 2, 3, 4)).cpu()) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])

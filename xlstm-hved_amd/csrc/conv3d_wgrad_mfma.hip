@@ -16,6 +16,8 @@
 //    (a.rs rows per step); only the lane -> (row, chunk) mapping changes.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
+#include "wgrad_q4.h"
+#include <vector>
 
 typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
 typedef f32x4_t f32x4;
@@ -345,6 +347,13 @@ static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const d
 
 // returns XH_OK if launched, 1 if not eligible
 int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
+  {                                                   // few channels per group: the quad-channel kernel (conv3d_wgrad_q4.hip)
+    WgQ4 q;
+    if (xh_wgrad_q4_plan(d, p, dw, db, &q)) {
+      xh_wgrad_q4_launch((hipStream_t)stream, d->dtype == XH_F16 ? 1 : 0, &q, 1);
+      return xh_launch_status();
+    }
+  }
   WgPlan pl;
   if (!wg_plan(d, p, dw, db, &pl)) return 1;
   const WgMK& a = pl.a;
@@ -383,6 +392,23 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
   if (n < 0 || (n > 0 && (!d || !p || !dw))) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   int rc_all = XH_OK;
+  // quad-channel problems first: WQ_MULTI per launch and storage format
+  std::vector<char> handled(n > 0 ? n : 1, 0);
+  if (g_use_mfma) {
+    for (int cls = 0; cls < 6; ++cls) {               // (storage format, input-channel quads per group)
+      const int fmt = cls / 3, ci4 = cls % 3 + 1;
+      WgQ4 probs[WQ_MULTI];
+      int k = 0;
+      for (int i = 0; i < n; ++i) {
+        if (!d[i] || !p[i]) return XH_ERR_ARG;
+        if (handled[i] || (d[i]->dtype == XH_F16 ? 1 : 0) != fmt || d[i]->groups <= 0 || d[i]->Cin / d[i]->groups != 4 * ci4) continue;
+        if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &probs[k])) continue;
+        handled[i] = 1;
+        if (++k == WQ_MULTI) { xh_wgrad_q4_launch(st, fmt, probs, k); k = 0; }
+      }
+      if (k) xh_wgrad_q4_launch(st, fmt, probs, k);
+    }
+  }
   WgMulti* m = new WgMulti;
   for (int cls = 0; cls < 4; ++cls) {                 // (fmt, big)
     const int fmt = cls >> 1, big = cls & 1;
@@ -403,6 +429,7 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
     };
     for (int i = 0; i < n; ++i) {
       if (!d[i] || !p[i]) { delete m; return XH_ERR_ARG; }
+      if (handled[i]) continue;
       WgPlan pl;
       const bool ok = g_use_mfma && !d[i]->transposed && p[i]->ea && wg_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &pl) && pl.cp == 4;
       if (!ok) {

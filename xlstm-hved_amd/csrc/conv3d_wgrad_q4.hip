@@ -1,0 +1,313 @@
+// Weight / bias gradient of the 3x3x3 stride-1 convolution for groups of FEW channels (4 -> 4, 12 -> 4, the four-stream
+// 16 -> 16 g4, ...: every 128^3-class conv of XLSTM_HVED), 16-bit storage, gfx950.  Companion of conv3d_q4.hip.
+//
+//   dW[co][ci][kd][kh][kw] = sum over voxels v of dY[co][v] * xa[ci][v + (kd, kh, kw) - 1],   xa = leaky(x * sc + sh)
+//
+// GEMM on mfma_f32_16x16x32 with K = 32 voxels of one row, BOTH operands straight from global memory (no LDS staging, no
+// barrier in the main loop):
+//   M = (co of 4, kw):  A[(co, kw)][w] = dY[co][row][w + 1 - kw]   -- the kw shift is applied to dY: an aligned 16-byte load
+//                        plus the neighbouring dword and four v_alignbit; dY never needs a halo, edge elements are masked
+//   N = (ci of 4, kh):  B[w][(ci, kh)] = xa[ci][row + kh - 1][w]   -- ONE aligned 16-byte load per lane, the producer's
+//                        InstanceNorm + LeakyReLU applied in registers; rows / planes outside the volume get scale = shift = 0
+//   kd: a wave walks along D; the x fragment of plane p meets the dY fragments of planes p+1, p, p-1 (three accumulator
+//       tiles), so every x and dY element is loaded once per wave.
+//   Column (ci = 0, kh = 3) -- unused by the taps -- holds the constant 1, so the same MFMAs deliver the bias gradient.
+// A lane's accumulator tile is dW[co = lane>>4][ci = lane&3][kd][kh = (lane>>2)&3][kw = register]: the four waves of a workgroup
+// (four consecutive rows) are summed through LDS and leave one pass of fp32 atomics.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+#include "wgrad_q4.h"
+
+typedef h16x8 frag8;
+typedef f32x4_t f32x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor of a wave-uniform base pointer (readfirstlane makes the uniformity provable to the compiler: without it
+// every buffer_load is wrapped in a waterfall loop).  Loads then take a 32-bit lane offset and a 32-bit scalar offset:
+// no 64-bit address arithmetic in vector registers.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t q4_rsrc(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+struct WgQ4Multi {
+  int n;
+  int off[WQ_MULTI + 1];         // first workgroup of problem i (multiples of 8: the XCD remap of each problem stays valid)
+  WgQ4 p[WQ_MULTI];
+};
+
+template <int FMT, int CI4>
+__device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw) {
+  typedef h16<FMT> ST;
+  constexpr int DEPTH = CI4 == 2 ? 3 : 2;              // steps of loads in flight per wave (register budget, wq4_waves)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nn = lane & 15, g = lane >> 4;
+  // Persistent workgroups: unit = (problem, output-channel quad); its a.wpu workgroups share the unit's a.ntile spatial
+  // tiles and keep their accumulators across tiles, so the LDS reduction + atomics tail is paid once per workgroup (a
+  // workgroup per tile left 1024 x 432 same-address atomics per unit: 35 of the 46 us of a 4 -> 4 @128^3 problem).
+  // Workgroups that share an XCD (equal id mod 8) walk one contiguous eighth of the tiles side by side.
+  const int oq = b / a.wpu, w = b - oq * a.wpu;
+  int t_first, t_stride, t_end;
+  if ((a.ntile & 7) == 0 && (a.wpu & 7) == 0) {
+    const int per = a.ntile >> 3;
+    t_first = (w & 7) * per + (w >> 3); t_stride = a.wpu >> 3; t_end = ((w & 7) + 1) * per;
+  } else {
+    t_first = w; t_stride = a.wpu; t_end = a.ntile;
+  }
+  f32x4 acc[CI4][3];
+#pragma unroll
+  for (int cq = 0; cq < CI4; ++cq)
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) acc[cq][kd] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int D = a.D, H = a.H, W = a.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  const int co0 = oq * 4;
+  const int grp = co0 / a.Cout_g;
+  const int cin_base = grp * a.Cin_g;
+  for (int t = t_first; t < t_end; t += t_stride) {
+  int wk = t;
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH; wk /= a.tilesH;
+  const int ds = wk % a.dsegs;
+  const int n = wk / a.dsegs;
+  const int h = th * 4 + wv, w0 = tw * 32;
+  const bool hrow = h < H;
+  const int d0 = ds * a.sd, d1 = min(D, d0 + a.sd);
+
+  // ---- B role: column (ci = nn & 3, kh = nn >> 2) ----
+  const int ci_l = nn & 3, khB = nn >> 2;
+  const int xrow = h + khB - 1;
+  const bool rowok = hrow && khB < 3 && (unsigned)xrow < (unsigned)H;
+  const int xrow_c = min(max(xrow, 0), H - 1);
+  // loads are "uniform base (SGPRs) + 32-bit lane offset": the lane part is fixed per tile, the plane advances the base
+  const unsigned x_off = (unsigned)(((long long)ci_l * dhw + (long long)xrow_c * W + w0 + 8 * g) * 2);     // bytes
+  __amdgpu_buffer_rsrc_t xrs[CI4];
+  float scl[CI4], shl[CI4];
+#pragma unroll
+  for (int cq = 0; cq < CI4; ++cq) {
+    const int c0 = cin_base + cq * 4, c = c0 + ci_l;
+    xrs[cq] = q4_rsrc(c0 < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)c0 * dhw
+                                : (const ST*)a.xb + n * a.xb_bs + (long long)(c0 - a.Ca) * dhw);
+    float sc = 1.f, sh = 0.f;
+    if (a.pre) { sc = a.pre_sc[n * a.Cin + c]; sh = a.pre_sh[n * a.Cin + c]; }
+    if (!rowok) { sc = 0.f; sh = 0.f; }
+    if (khB == 3 && cq == 0 && ci_l == 0) { sc = 0.f; sh = 1.f; }             // the column of ones: bias gradient
+    scl[cq] = sc; shl[cq] = sh;
+  }
+  const bool onescol = khB == 3;                       // not subject to the plane mask
+  const float pslope = a.pre ? a.pre_slope : 1.f;
+  // ---- A role: row (co = nn >> 2, kw = nn & 3) ----
+  const int co_l = nn >> 2, kwA = nn & 3;
+  const int hc = min(h, H - 1);
+  const __amdgpu_buffer_rsrc_t dyrs = q4_rsrc((const ST*)a.dy + n * a.dy_bs + (long long)co0 * dhw);
+  const unsigned dy_off = (unsigned)(((long long)co_l * dhw + (long long)hc * W + w0 + 8 * g) * 2);          // bytes
+  const int wpos = w0 + 8 * g;
+  const bool left = kwA == 2, right = kwA == 0;
+  // neighbouring dword: elements (wpos - 2, wpos - 1) for kw = 2, (wpos + 8, wpos + 9) for kw = 0; at a row end any valid address
+  const int e_off = (left && wpos > 0) ? -2 : (right && wpos + 8 < W) ? 8 : 0;
+  const unsigned m0 = (left && wpos == 0) ? 0xffff0000u : 0xffffffffu;       // element w = -1 does not exist
+  const unsigned m3 = (right && wpos + 8 == W) ? 0x0000ffffu : 0xffffffffu;  // element w = W does not exist
+  const unsigned shbits = (left || right) ? 16u : 0u;
+
+  const unsigned dye_off = dy_off + 2 * e_off;
+  const int hw2 = (int)(hw * 2);                       // bytes per plane
+  auto load_x = [&](int p, uint4 (&raw)[CI4]) {
+    const int po = min(max(p, 0), D - 1) * hw2;
+#pragma unroll
+    for (int cq = 0; cq < CI4; ++cq)
+      raw[cq] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs[cq], (int)x_off, po, 0));
+  };
+  auto load_dy = [&](int v, uint4& cur, unsigned& ex) {
+    const int po = min(max(v, 0), D - 1) * hw2;
+    cur = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, (int)dy_off, po, 0));
+    ex = __builtin_amdgcn_raw_buffer_load_b32(dyrs, (int)dye_off, po, 0);
+  };
+  auto make_a = [&](const uint4& c, unsigned ex) -> frag8 {
+    // kw = 2: window one voxel to the left, kw = 0: one to the right, kw = 1: as loaded
+    const unsigned l0 = left ? ex : c.x, l1 = left ? c.x : c.y, l2 = left ? c.y : c.z, l3 = left ? c.z : c.w;
+    const unsigned h0 = left ? c.x : c.y, h1 = left ? c.y : c.z, h2 = left ? c.z : c.w, h3 = left ? c.w : ex;
+    uint4 o;                                           // centre rows: shift 0 returns the low operand = the loaded dword
+    o.x = __builtin_amdgcn_alignbit(h0, l0, shbits) & m0;
+    o.y = __builtin_amdgcn_alignbit(h1, l1, shbits);
+    o.z = __builtin_amdgcn_alignbit(h2, l2, shbits);
+    o.w = __builtin_amdgcn_alignbit(h3, l3, shbits) & m3;
+    return __builtin_bit_cast(frag8, o);
+  };
+  auto make_b = [&](const uint4& r, float sc, float sh) -> frag8 {
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+    uint4 o;
+    unsigned* op = &o.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float lo = cvt_lo<FMT>(u[k]) * sc + sh, hi = cvt_hi<FMT>(u[k]) * sc + sh;
+      lo = fmaxf(lo, lo * pslope);
+      hi = fmaxf(hi, hi * pslope);
+      op[k] = cvt_pack<FMT>(lo, hi);
+    }
+    return __builtin_bit_cast(frag8, o);
+  };
+
+  if (hrow) {
+    // A wave is alone with its memory latency (no barrier, no partner doing other work): the loads of DEPTH steps are in
+    // flight at any time, in a register ring unrolled DEPTH times.  Step p consumes x plane p and dY plane p + 1, then
+    // refills its slot with step p + DEPTH.  The steady-state loop is branch-free -- loads from clamped planes, dY
+    // fragments of planes outside [d0, d1) zeroed when they are built, every MFMA unconditional -- because a branch
+    // inside it makes hipcc wait for vmcnt(0) at every step, i.e. one step in flight whatever DEPTH says; steps are
+    // rounded up to a multiple of DEPTH (the extra ones multiply zeros).
+    frag8 af_m1 = frag8{0, 0, 0, 0, 0, 0, 0, 0}, af_0 = af_m1;                   // dY fragments of out planes p - 1, p
+    uint4 xraw[DEPTH][CI4], dcur[DEPTH];
+    unsigned dex[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) { load_x(d0 - 1 + u, xraw[u]); load_dy(d0 + u, dcur[u], dex[u]); }
+    const int p_end = d0 - 1 + (d1 - d0 + 2 + DEPTH - 1) / DEPTH * DEPTH;
+    for (int p0 = d0 - 1; p0 < p_end; p0 += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int p = p0 + u;
+        const unsigned amask = p + 1 < d1 ? 0xffffffffu : 0u;                    // out plane p + 1 belongs to this tile
+        const uint4 ar = __builtin_bit_cast(uint4, make_a(dcur[u], dex[u]));
+        const frag8 af_p1 = __builtin_bit_cast(frag8, make_uint4(ar.x & amask, ar.y & amask, ar.z & amask, ar.w & amask));
+        const float pm = (unsigned)p < (unsigned)D ? 1.f : 0.f;
+        frag8 bf[CI4];
+#pragma unroll
+        for (int cq = 0; cq < CI4; ++cq) {
+          const float sc = onescol ? scl[cq] : scl[cq] * pm, sh = onescol ? shl[cq] : shl[cq] * pm;
+          bf[cq] = make_b(xraw[u][cq], sc, sh);
+        }
+        load_x(p + DEPTH, xraw[u]);
+        load_dy(p + DEPTH + 1, dcur[u], dex[u]);
+#pragma unroll
+        for (int cq = 0; cq < CI4; ++cq) {             // out plane v = p + 1 - kd
+          acc[cq][0] = mfma16x16x32<FMT>(af_p1, bf[cq], acc[cq][0]);
+          acc[cq][1] = mfma16x16x32<FMT>(af_0, bf[cq], acc[cq][1]);
+          acc[cq][2] = mfma16x16x32<FMT>(af_m1, bf[cq], acc[cq][2]);
+        }
+        af_m1 = af_0;
+        af_0 = af_p1;
+      }
+    }
+  }
+
+  }   // tiles
+
+  // ---- sum the four rows of the workgroup in LDS: s_dw[(co_l * 4 CI4 + ci) * 27 + tap], then [4] bias sums ----
+  constexpr int NW = 4 * 4 * CI4 * 27;
+  for (int i = tid; i < NW + 4; i += 256) s_dw[i] = 0.f;
+  __syncthreads();
+  {
+    const int kh = nn >> 2, ci = nn & 3;               // accumulator column
+    if (kh < 3) {
+#pragma unroll
+      for (int cq = 0; cq < CI4; ++cq)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)                  // D row 4 * g + r = (co = g, kw = r)
+            atomicAdd(&s_dw[(g * 4 * CI4 + cq * 4 + ci) * 27 + kd * 9 + kh * 3 + r], acc[cq][kd][r]);
+    } else if (ci == 0) {
+      atomicAdd(&s_dw[NW + g], acc[0][1][1]);          // column of ones x dY row (co = g, kw = 1)
+    }
+  }
+  __syncthreads();
+  if (a.abl & 2048) return;                            // ablation: no global atomics
+  const int gpp = a.groups / a.n_wptr;
+  float* dwp = a.dw[grp / gpp];
+  const int gl = grp % gpp;
+  for (int i = tid; i < NW; i += 256) {
+    const int tap = i % 27;
+    const int r = i / 27;
+    const int ci = r % (4 * CI4), c = r / (4 * CI4);
+    const int co_g = (co0 + c) % a.Cout_g;
+    atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci) * 27 + tap, s_dw[i]);
+  }
+  float* dbp = a.db[grp / gpp];
+  if (dbp && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
+}
+
+// resident workgroups per CU (= waves per SIMD) each instance is built for: 75 / 127 / 143 VGPRs, no spills
+constexpr int wq4_waves(int ci4) { return ci4 == 1 ? 6 : ci4 == 2 ? 4 : 3; }
+template <int FMT, int CI4>
+__global__ __launch_bounds__(256, wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
+  __shared__ float s_dw[4 * 4 * CI4 * 27 + 4];
+  const int b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < WQ_MULTI; ++k)
+    if (k < m.n && b >= m.off[k]) i = k;
+  const int local = b - m.off[i];
+  const WgQ4& a = m.p[i];
+  if (local >= a.nb) return;
+  wgrad_q4_body<FMT, CI4>(a, local, s_dw);
+}
+
+// fills the plan; false when the shape is not for this kernel
+bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgQ4* a) {
+  extern int g_xh_disable;
+  if (g_xh_disable & 32) return false;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1 || d->transposed) return false;
+  if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
+  if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  if (cin_g % 4 || cout_g % 4 || cin_g > 12 || cout_g > 12) return false;
+  if (d->Ca % 4) return false;
+  if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return false;
+  const long long dhw = (long long)d->D * d->H * d->W;
+  if (dhw % 8 || dhw >= (1ll << 27)) return false;     // 32-bit byte offsets inside a channel quad
+  if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
+  if (!p->ea || !p->xa) return false;
+  if (d->D < 4 || d->H < 4) return false;
+  a->xa = p->xa; a->xb = p->xb; a->dy = p->ea;
+  a->pre_sc = p->pre_sc; a->pre_sh = p->pre_sh;
+  for (int i = 0; i < 4; ++i) { a->dw[i] = i < d->n_wptr ? dw[i] : nullptr; a->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  a->xa_bs = d->xa_bs; a->xb_bs = d->xb_bs; a->dy_bs = d->ea_bs;
+  a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->groups = d->groups; a->n_wptr = d->n_wptr; a->Ca = d->Ca;
+  a->D = d->D; a->H = d->H; a->W = d->W;
+  a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cin_g / 4; a->pre = d->pre; a->pre_slope = d->pre_slope;
+  a->tilesW = d->W / 32; a->tilesH = cdiv(d->H, 4);
+  a->nq = d->Cout / 4;
+  // depth segments: tiles of >= 8 planes (x is read sd + 2 planes per tile), ~1024 tiles per unit
+  const long long cols = (long long)a->tilesW * a->tilesH * d->N;
+  int dsegs = (int)((1024 + cols - 1) / cols);
+  const int max_segs = d->D >= 8 ? d->D / 8 : 1;
+  if (dsegs > max_segs) dsegs = max_segs;
+  if (dsegs < 1) dsegs = 1;
+  a->sd = cdiv(d->D, dsegs);
+  a->dsegs = cdiv(d->D, a->sd);
+  const long long nt = cols * a->dsegs;
+  if (nt > (1 << 24)) return false;
+  a->ntile = (int)nt;
+  a->wpu = a->nb = 0;                                  // set per launch (xh_wgrad_q4_launch)
+  { extern int g_mfma_abl; a->abl = g_mfma_abl; }
+  return true;
+}
+
+// launches up to WQ_MULTI planned problems of one storage format
+// launches up to WQ_MULTI planned problems of one storage format and one input-quad count (probs[i].ci4 all equal)
+void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
+  WgQ4Multi m;
+  m.n = n;
+  m.off[0] = 0;
+  const int ci4 = probs[0].ci4;
+  // workgroups per launch: all resident at once, dealt to the units in proportion to their tiles
+  const int budget = wq4_waves(ci4) * 256;
+  double total = 0.0;
+  for (int i = 0; i < n; ++i) total += (double)probs[i].nq * probs[i].ntile;
+  for (int i = 0; i < n; ++i) {
+    m.p[i] = probs[i];
+    WgQ4& a = m.p[i];
+    int w = (int)(budget * (double)a.ntile / total);
+    if (w >= 8) w &= ~7;
+    if (w > a.ntile) w = a.ntile;
+    if (w < 1) w = 1;
+    a.wpu = w;
+    a.nb = a.nq * w;
+    m.off[i + 1] = m.off[i] + ((a.nb + 7) & ~7);
+  }
+  xh_note_kernel("conv3_wgrad_q4_multi_kernel<%d, %d>", fmt, ci4);
+#define WQL(F, C) hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<F, C>), dim3(m.off[n]), dim3(256), 0, st, m)
+  if (fmt) { if (ci4 == 1) WQL(1, 1); else if (ci4 == 2) WQL(1, 2); else WQL(1, 3); }
+  else { if (ci4 == 1) WQL(0, 1); else if (ci4 == 2) WQL(0, 2); else WQL(0, 3); }
+#undef WQL
+}

@@ -1,0 +1,24 @@
+// Problem record of the quad-channel weight-gradient kernel (conv3d_wgrad_q4.hip), shared with the batching entry point.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/xlstm_hved.h"
+
+struct WgQ4 {
+  const void* xa; const void* xb; const void* dy;
+  const float* pre_sc; const float* pre_sh;
+  float* dw[4]; float* db[4];
+  long long xa_bs, xb_bs, dy_bs;
+  int N, Cin, Cout, groups, n_wptr, Ca, D, H, W;
+  int Cin_g, Cout_g, ci4, pre;
+  float pre_slope;
+  int tilesW, tilesH, dsegs, sd;
+  int nq;                        // output-channel quads (= Cout / 4): the units of the problem
+  int ntile;                     // spatial tiles of a unit (tilesW * tilesH * dsegs * N)
+  int wpu;                       // workgroups per unit (each walks ntile / wpu tiles)
+  int nb;                        // workgroups of the problem (nq * wpu)
+  int abl;                       // ablation mask (microbenchmarks)
+};
+
+constexpr int WQ_MULTI = 8;         // problems per launch (the table travels in the kernel arguments)
+bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgQ4* a);
+void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);
