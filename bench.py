@@ -461,8 +461,16 @@ def roofline_pass(step, ops, nsteps, dtype):
         shape = f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{dy.shape[1]} @{'x'.join(map(str, dy.shape[2:]))} wgrad"
         if kw.get("side") and ops._WG["defer"]:
             # deferred: launched by the batch flush at the end of backward (timed_flush); remember what it will carry
-            mfma = (k == 3 and kw.get("stride", 1) == 1 and esz == 2 and xa.shape[-1] % 32 == 0 and cin // groups >= 4)
-            cls = ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small") if mfma else "rest"
+            # the class decides which launch of xh_conv3d_wgrad_batch carries the problem (mirrors its grouping rule):
+            # quad-channel kernel per input-quad count (8 problems per launch), else the implicit-GEMM kernel per volume
+            # class (7 per launch), else one ordinary launch each
+            cg, og, w_ = cin // groups, dy.shape[1] // groups, xa.shape[-1]
+            k3 = k == 3 and kw.get("stride", 1) == 1 and esz == 2
+            q4 = (k3 and w_ % 32 == 0 and cg % 4 == 0 and og % 4 == 0 and cg <= 12 and og <= 12 and xa.shape[2] >= 4
+                  and xa.shape[3] >= 4 and xa.shape[1] % 4 == 0)
+            mfma = k3 and (w_ % 32 == 0 or w_ in (8, 16)) and cg >= 4
+            cls = (f"q4_{cg // 4}" if q4 else ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small")
+                   if mfma else "rest")
             pending_meta.append((cls, nbytes, flops, shape))
             return orig_wg(xa, xb, dy, dws, dbs, **kw)
         e0, e1 = ev(), ev()
@@ -483,7 +491,7 @@ def roofline_pass(step, ops, nsteps, dtype):
         if len(calls) != len(metas):                         # something bypassed the wrapper: do not attribute
             ops._WG["deferred"] = calls
             return orig_flush()
-        for cls in ("small", "big"):
+        for cls in ("q4_1", "q4_2", "q4_3", "small", "big"):
             grp = [(c, m) for c, m in zip(calls, metas) if m[0] == cls]
             if not grp:
                 continue
@@ -492,9 +500,9 @@ def roofline_pass(step, ops, nsteps, dtype):
             e0.record()
             orig_flush()
             e1.record()
-            nl = -(-len(grp) // 7)
+            nl = -(-len(grp) // (8 if cls.startswith("q4") else 7))
             records.append((ops.last_conv_kernel(), e0, e1, sum(m[1] for _, m in grp), sum(m[2] for _, m in grp),
-                            f"{len(grp)} k3 weight gradients of {cls} volumes in {nl} launch(es): " + "; ".join(m[3] for _, m in grp), nl))
+                            f"{len(grp)} k3 weight gradients ({cls}) in {nl} launch(es): " + "; ".join(m[3] for _, m in grp), nl))
         for c, m in zip(calls, metas):
             if m[0] != "rest":
                 continue
@@ -571,7 +579,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     avg_ms, nbytes, flops = ms_sum / cnt, bytes_sum / cnt, flops_sum / cnt
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
     tfl = flops / (avg_ms * 1e-3) / 1e12
-    mfma = "mfma" in name
+    mfma = "mfma" in name or "q4" in name                # the quad-channel kernels are MFMA kernels too
     peak_tf = BF16_MFMA_PEAK_TFLOPS if mfma else FP32_VALU_PEAK_TFLOPS
     # roofline: the kernel is HBM-bound when its arithmetic intensity is below peak_flops / peak_bandwidth
     if flops / nbytes < peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
@@ -598,8 +606,8 @@ def roofline_pass(step, ops, nsteps, dtype):
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:8]},
               "event_pair_overhead_us": overhead_ms * 1e3, "host_enqueue_ms_per_step": host_ms, "device_delay_ms": delay_ms,
               "timing": "HIP events on the launch stream around each launch of the real step (queued behind a device-side "
-                        "delay so launches run back to back as in the graph replay), minus the median empty event pair; the "
-                        "events also span the weight pre-pack / second-stage reduce launches the call issues"})
+                        "delay so launches run back to back as in the graph replay), minus the median empty event pair; weight "
+                        "fragments are prepacked once per step (xh_conv3d_prepack), so a bracket holds the conv launch alone"})
     return r
 
 

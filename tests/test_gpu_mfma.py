@@ -93,10 +93,10 @@ def test_quad_channel_kernel_is_selected():
     x = torch.randn(1, 16, 8, 8, 32, device=DEV).bfloat16()
     w4 = [torch.randn(4, 4, 3, 3, 3, device=DEV) for _ in range(4)]
     X.ops.conv3d(x, None, w4, None, k=3, cout=16, groups=4)
-    assert "conv3_q4_kernel<0, false, 0>" in X.ops.last_conv_kernel()
+    assert "conv3_q4_kernel<0, false, 0, false, false>" in X.ops.last_conv_kernel()
     X.ops.conv3d(x.half(), None, w4, None, k=3, cout=16, groups=4, pre=(torch.ones(1, 16, device=DEV), torch.zeros(1, 16, device=DEV), 0.01),
                  epi=2, red=torch.zeros(1, 16, 2, dtype=torch.float64, device=DEV))
-    assert "conv3_q4_kernel<1, true, 2>" in X.ops.last_conv_kernel()
+    assert "conv3_q4_kernel<1, true, 2, false, false>" in X.ops.last_conv_kernel()
     X.ops.conv3d(x, None, [torch.randn(16, 16, 3, 3, 3, device=DEV)], None, k=3, cout=16)
     assert "conv3_mfma_kernel" in X.ops.last_conv_kernel()
     lib.xh_set_option(2, 16)

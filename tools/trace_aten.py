@@ -8,12 +8,15 @@ import xlstm_hved_amd as X
 torch.manual_seed(1)
 m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS); m.apply(X.init_weights); m = m.cuda().train()
 grads = X.parallel.FlatGrads(list(m.parameters()))
+X.ops.set_wgrad_defer(True)
 x = torch.rand(1, 4, 64, 64, 64, device="cuda").bfloat16()
 def step():
     grads.zero()
     seg, (mu, lv), rec = m(x, [14], recon=True)
-    loss = seg.float().mean() + rec[0].float().mean() + sum(a.float().mean() + b.float().mean() for a, b in zip(mu, lv))
+    from xlstm_hved_amd.losses import sum_of_means
+    loss = sum_of_means([seg, rec[0] if isinstance(rec, (list, tuple)) else rec] + [t for ab in zip(mu, lv) for t in ab])
     loss.backward()
+    X.ops.join_wgrad_stream()
 step(); torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(); torch.cuda.synchronize()

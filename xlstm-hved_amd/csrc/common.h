@@ -44,6 +44,19 @@ template <int FMT> __device__ __forceinline__ float cvt_hi(unsigned u) {
 template <int FMT> __device__ __forceinline__ unsigned cvt_pack(float a, float b) {
   return (unsigned)cvt_out<FMT>(a) | ((unsigned)cvt_out<FMT>(b) << 16);
 }
+// Explicit two-wide forms: a <2 x float> is what hipcc turns into v_pk_fma_f32 / v_pk_mul_f32, and a vector conversion is
+// ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 of exactly the pair given (two scalar conversions of values that end up in one
+// dword let the compiler pair them its own way and then re-shuffle the halves: and + lshl + 2 x or_sdwa per dword).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <int FMT> __device__ __forceinline__ f32x2_t cvt2_in(unsigned u) { return f32x2_t{cvt_lo<FMT>(u), cvt_hi<FMT>(u)}; }
+template <int FMT> __device__ __forceinline__ unsigned cvt2_pack(float a, float b) {      // RNE, a -> low half
+  const f32x2_t v = {a, b};
+  if constexpr (FMT == 0) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ f32x2_t max2(f32x2_t a, f32x2_t b) { return f32x2_t{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
 template <typename T> struct FmtOf { static constexpr int v = -1; };
 template <int FMT> struct FmtOf<h16<FMT>> { static constexpr int v = FMT; };
 

@@ -34,6 +34,7 @@ struct ConvQ4 {
   int tilesW, tilesH, tilesD;
   float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
   double fin_inv;               // 1 / fin_count
+  unsigned char* fan;           // statistics fan-in block of the workspace (zero between launches)
   int abl;
 };
 extern int g_mfma_abl;
@@ -46,16 +47,16 @@ constexpr int TILE_BYTES = ID * PLANE;      // 28 800
 constexpr int NROWS = ID * IH;              // 100 staged rows
 constexpr int NITEM = NROWS * 4;            // interior items: (row, 8-voxel group)
 constexpr int NEDGE = NROWS * 2;            // edge items: (row, side) -> one voxel pair
+constexpr int Q4_FAN = 32;                  // replicas of the statistics fan-in (one 128-byte line each, + 1 top line)
 }
 
-// two values of one channel -> leaky(x * sc + sh) in fp32
-template <int FMT> __device__ __forceinline__ void q4_xf(unsigned u, float sc, float sh, float slope, float& lo, float& hi) {
-  const float a = cvt_lo<FMT>(u) * sc + sh, b = cvt_hi<FMT>(u) * sc + sh;
-  lo = fmaxf(a, a * slope);
-  hi = fmaxf(b, b * slope);
+// two values of one channel -> leaky(x * sc + sh) in fp32 (packed fma / mul; leaky = max(v, slope * v) for 0 <= slope <= 1)
+template <int FMT> __device__ __forceinline__ f32x2_t q4_xf(unsigned u, float sc, float sh, float slope) {
+  const f32x2_t v = cvt2_in<FMT>(u) * f32x2_t{sc, sc} + f32x2_t{sh, sh};
+  return max2(v, v * f32x2_t{slope, slope});
 }
 
-template <int FMT, bool PRE, int EPI>
+template <int FMT, bool PRE, int EPI, bool ACT, bool MULTI>
 __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   typedef h16<FMT> ST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -145,14 +146,17 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   const long long sp0 = ((long long)od0 * Ho + (row_ok ? oh : 0)) * a.d.Wo + owl;   // + dz * Ho * Wo
   const long long spd = (long long)Ho * a.d.Wo;
 
+  // MULTI = more than one input-channel quad per group: the accumulators live across the quad loop (and across its staging
+  // phases: ~30 more registers in flight); the single-quad instances are straight-line code
   f32x4 acc[TD];
 #pragma unroll
   for (int i = 0; i < TD; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ncq = MULTI ? a.ci4 : 1;
   uint2 eraw[TD];
 
   const float pslope = a.d.pre_slope;
   const bool fin = PRE && a.p.fin_red != nullptr;
-  for (int cq = 0; cq < a.ci4; ++cq) {
+  for (int cq = 0; cq < ncq; ++cq) {
     const int c0 = cin_base + cq * 4;
     const ST* src = c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
                                 : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw;
@@ -199,20 +203,20 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
       uint4 outv[4];                                  // chunk j = voxels 2j, 2j+1 x 4 channels
       if (PRE) {
         const float lv = i_live[it] ? 1.f : 0.f;
-        float v[4][8];
+        f32x2_t v[4][4];                              // [channel][voxel pair]
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const float s1 = sc[cc] * lv, s2 = sh[cc] * lv;
           const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) q4_xf<FMT>(u[k], s1, s2, pslope, v[cc][2 * k], v[cc][2 * k + 1]);
+          for (int k = 0; k < 4; ++k) v[cc][k] = q4_xf<FMT>(u[k], s1, s2, pslope);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          outv[j].x = cvt_pack<FMT>(v[0][2 * j], v[1][2 * j]);
-          outv[j].y = cvt_pack<FMT>(v[2][2 * j], v[3][2 * j]);
-          outv[j].z = cvt_pack<FMT>(v[0][2 * j + 1], v[1][2 * j + 1]);
-          outv[j].w = cvt_pack<FMT>(v[2][2 * j + 1], v[3][2 * j + 1]);
+          outv[j].x = cvt2_pack<FMT>(v[0][j].x, v[1][j].x);
+          outv[j].y = cvt2_pack<FMT>(v[2][j].x, v[3][j].x);
+          outv[j].z = cvt2_pack<FMT>(v[0][j].y, v[1][j].y);
+          outv[j].w = cvt2_pack<FMT>(v[2][j].y, v[3][j].y);
         }
       } else {
         const unsigned se = i_live[it] ? 0x05040100u : 0x0c0c0c0cu, so = i_live[it] ? 0x07060302u : 0x0c0c0c0cu;
@@ -236,13 +240,13 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
       uint4 o;
       if (PRE) {
         const float lv = e_live ? 1.f : 0.f;
-        float v[4][2];
+        f32x2_t v[4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) q4_xf<FMT>(eraw4[cc], sc[cc] * lv, sh[cc] * lv, pslope, v[cc][0], v[cc][1]);
-        o.x = cvt_pack<FMT>(v[0][0], v[1][0]);
-        o.y = cvt_pack<FMT>(v[2][0], v[3][0]);
-        o.z = cvt_pack<FMT>(v[0][1], v[1][1]);
-        o.w = cvt_pack<FMT>(v[2][1], v[3][1]);
+        for (int cc = 0; cc < 4; ++cc) v[cc] = q4_xf<FMT>(eraw4[cc], sc[cc] * lv, sh[cc] * lv, pslope);
+        o.x = cvt2_pack<FMT>(v[0].x, v[1].x);
+        o.y = cvt2_pack<FMT>(v[2].x, v[3].x);
+        o.z = cvt2_pack<FMT>(v[0].y, v[1].y);
+        o.w = cvt2_pack<FMT>(v[2].y, v[3].y);
       } else {
         const unsigned se = e_live ? 0x05040100u : 0x0c0c0c0cu, so = e_live ? 0x07060302u : 0x0c0c0c0cu;
         o.x = __builtin_amdgcn_perm(eraw4[1], eraw4[0], se);
@@ -291,32 +295,34 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     }
   }
   double s0 = 0.0, s1 = 0.0;
-  const float aslope = a.act_slope, eslope = a.d.e_slope;
+  const f32x2_t aslope2 = {a.act_slope, a.act_slope}, bias2 = {bias, bias}, esc2 = {esc, esc}, esh2 = {esh, esh};
+  const float eslope = a.d.e_slope;
 #pragma unroll
   for (int dz = 0; dz < TD; ++dz) {
     if (od0 + dz >= Do || !row_ok) continue;
-    float o[4];
-    float t0 = 0.f, t1 = 0.f;
-    float ev[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2_t v[2] = {f32x2_t{acc[dz][0], acc[dz][1]} + bias2, f32x2_t{acc[dz][2], acc[dz][3]} + bias2};
+    if (ACT) { v[0] = max2(v[0], v[0] * aslope2); v[1] = max2(v[1], v[1] * aslope2); }
+    uint2 pk;
     if (EPI == 1) {
-      ev[0] = cvt_lo<FMT>(eraw[dz].x); ev[1] = cvt_hi<FMT>(eraw[dz].x);
-      ev[2] = cvt_lo<FMT>(eraw[dz].y); ev[3] = cvt_hi<FMT>(eraw[dz].y);
-    }
+      const f32x2_t e[2] = {cvt2_in<FMT>(eraw[dz].x), cvt2_in<FMT>(eraw[dz].y)};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = acc[dz][r] + bias;
-      v = fmaxf(v, v * aslope);
-      if (EPI == 1) {
-        v = cvt_in<FMT>(cvt_out<FMT>(v * ((ev[r] * esc + esh) > 0.f ? 1.f : eslope)));
-        t0 += v; t1 += v * ev[r];
-      } else if (EPI == 2) {
-        v = cvt_in<FMT>(cvt_out<FMT>(v));
-        t0 += v; t1 += v * v;
+      for (int q = 0; q < 2; ++q) {
+        const f32x2_t z = e[q] * esc2 + esh2;
+        v[q] = v[q] * f32x2_t{z.x > 0.f ? 1.f : eslope, z.y > 0.f ? 1.f : eslope};
       }
-      o[r] = v;
+      pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
+      const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);           // the values as stored
+      const f32x2_t t = r0 + r1, tt = r0 * e[0] + r1 * e[1];
+      s0 += (double)(t.x + t.y); s1 += (double)(tt.x + tt.y);
+    } else {
+      pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
+      if (EPI == 2) {
+        const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);
+        const f32x2_t t = r0 + r1, tt = r0 * r0 + r1 * r1;
+        s0 += (double)(t.x + t.y); s1 += (double)(tt.x + tt.y);
+      }
     }
-    if (EPI) { s0 += (double)t0; s1 += (double)t1; }
-    st4(yplane, sp0 + dz * spd, o);
+    *reinterpret_cast<uint2*>(yplane + sp0 + dz * spd) = pk;
   }
   if (EPI) {
     // lanes of one channel: the 16 lanes nn = 0..15 of a lane group g4
@@ -324,9 +330,49 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     for (int m = 1; m < 16; m <<= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
     if (nn == 0) { s_red[wv * 8 + g4 * 2] = s0; s_red[wv * 8 + g4 * 2 + 1] = s1; }
     __syncthreads();
+    // Two-level fan-in of the 8 channel sums.  One fp64 atomic per workgroup and value on red[] means 1024 .. 4096 atomic
+    // requests on ONE cache line, which the memory side retires one after the other (~8 ns each: 8 us of a 22 us launch).
+    // Instead a workgroup adds into one of 32 replicas (a line of its own in the workspace), counts itself in on the
+    // replica's counter, the workgroup that completes a replica counts the replica in on the top counter, and the one
+    // that completes the top counter collects the replicas, adds the totals to red[] and leaves every word zero for the
+    // next launch.  Every access is a RETURNING atomic executed at the memory side: a contributor's sums have arrived
+    // before it counts itself in (its adds have returned), and the collector reads by exchange, never through a cache.
+    const int nrep = min((int)gridDim.x, Q4_FAN);
+    const int rep = blockIdx.x % Q4_FAN;
+    unsigned char* fb = a.fan + ((long long)n * gridDim.y + oq) * ((Q4_FAN + 1) * 128);
+    bool* s_last = reinterpret_cast<bool*>(s_fin + 24);
     if (tid < 8) {
       const double tot = s_red[tid] + s_red[8 + tid] + s_red[16 + tid] + s_red[24 + tid];
-      atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], tot);
+      const double old = atomicAdd(reinterpret_cast<double*>(fb + rep * 128) + tid, tot);
+      asm volatile("" ::"v"(old));                    // the add has returned = has been performed
+    }
+    if (tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // all eight adds of this wave
+      const unsigned mine = ((unsigned)gridDim.x - rep + Q4_FAN - 1) / Q4_FAN;      // workgroups of this replica
+      bool last = false;
+      if (__hip_atomic_fetch_add(reinterpret_cast<unsigned*>(fb + rep * 128 + 64), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1)
+        last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(fb + Q4_FAN * 128), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nrep - 1;
+      *s_last = last;
+    }
+    __syncthreads();
+    if (*s_last) {                                    // workgroup-uniform: one workgroup per (sample, channel quad)
+      double v = 0.0;
+      if (tid < 8 * nrep) {
+        const unsigned long long bits = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(fb + (tid >> 3) * 128) + (tid & 7), 0ull,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __builtin_bit_cast(double, bits);
+      }
+      // threads t, t + 8, t + 16, ... hold the replicas of value t & 7: sum over the wave, then over the four waves
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      __syncthreads();
+      if (lane < 8) s_red[wv * 8 + lane] = v;
+      __syncthreads();
+      if (tid < 8) {
+        const double tot = s_red[tid] + s_red[8 + tid] + s_red[16 + tid] + s_red[24 + tid];
+        atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], tot);
+      }
+      if (tid < nrep) __hip_atomic_exchange(reinterpret_cast<unsigned*>(fb + tid * 128 + 64), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_exchange(reinterpret_cast<unsigned*>(fb + Q4_FAN * 128), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -381,10 +427,15 @@ bool xh_conv3_q4_pack_job(const xh_conv_desc* d, const xh_conv_ptrs* p, PackJob*
 }
 void xh_launch_pack_single(hipStream_t st, const PackJob& j);                   // conv3d_mfma.hip
 
+static long long q4_frag_bytes(const xh_conv_desc* d, const ConvQ4& a) {
+  return ((long long)(d->Cout / 4) * a.ci4 * 9 * 1024 + 127) & ~127ll;
+}
+// packed fragments, then one statistics fan-in block per (sample, output quad).  The fan-in words must be ZERO before the
+// first launch that uses the workspace (every launch leaves them zero again): the caller allocates the workspace zeroed.
 long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
   ConvQ4 a;
   if (!q4_plan(d, &a)) return 0;
-  return (long long)(d->Cout / 4) * a.ci4 * 9 * 1024;
+  return q4_frag_bytes(d, a) + (long long)d->N * (d->Cout / 4) * (Q4_FAN + 1) * 128;
 }
 
 // XH_OK if launched, 1 if the shape is not eligible
@@ -395,6 +446,7 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   if (!p->ws || p->ws_bytes < need) return 1;
   a.p = *p;
   a.fin_inv = p->fin_count > 0 ? 1.0 / (double)p->fin_count : 0.0;
+  a.fan = (unsigned char*)p->ws + q4_frag_bytes(d, a);
   hipStream_t st = (hipStream_t)stream;
   const int f = d->dtype == XH_F16 ? 1 : 0;
   if (!p->ws_packed) {
@@ -403,18 +455,29 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
     xh_launch_pack_single(st, pj);
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
-  const size_t shm = TILE_BYTES + 32 * sizeof(double) + 24 * sizeof(float);
-  xh_note_kernel("conv3_q4_kernel<%d, %s, %d>", f, d->pre ? "true" : "false", d->epi);
-#define Q4L(F, P, E) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E>), grid, dim3(256), shm, st, a)
+  const size_t shm = TILE_BYTES + 32 * sizeof(double) + 24 * sizeof(float) + 16;
+  const bool act = a.act_slope != 1.f;
+  xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false");
+#define Q4L(F, P, E, A)                                                                                         \
+  do {                                                                                                          \
+    if (a.ci4 > 1) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, true>), grid, dim3(256), shm, st, a);        \
+    else hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, false>), grid, dim3(256), shm, st, a);                 \
+  } while (0)
+#define Q4A(F, P, E)              \
+  do {                            \
+    if (act) Q4L(F, P, E, true);  \
+    else Q4L(F, P, E, false);     \
+  } while (0)
 #define Q4E(F, P)                       \
   do {                                  \
-    if (d->epi == 0) Q4L(F, P, 0);      \
-    else if (d->epi == 1) Q4L(F, P, 1); \
-    else Q4L(F, P, 2);                  \
+    if (d->epi == 0) Q4A(F, P, 0);      \
+    else if (d->epi == 1) Q4A(F, P, 1); \
+    else Q4A(F, P, 2);                  \
   } while (0)
   if (f) { if (d->pre) Q4E(1, true); else Q4E(1, false); }
   else { if (d->pre) Q4E(0, true); else Q4E(0, false); }
 #undef Q4E
+#undef Q4A
 #undef Q4L
   return xh_launch_status();
 }
