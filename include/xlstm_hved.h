@@ -87,10 +87,7 @@ typedef struct {
   const float* e_sc; const float* e_sh;       /* [N][Cout] */
   double* red;                                /* [N][Cout][2], caller zeroes, epi!=0 */
   void* ws; long long ws_bytes;               /* scratch for packed bf16 MFMA weight fragments (may be NULL:
-                                                 the vector kernel is used); size from xh_conv3d_workspace_bytes.
-                                                 Must be ZERO-FILLED when allocated: the quad-channel kernel keeps
-                                                 the counters of its statistics fan-in there and leaves them zero
-                                                 after every launch.  One workspace serves one launch at a time. */
+                                                 the vector kernel is used); size from xh_conv3d_workspace_bytes */
   /* Optional fused InstanceNorm finalisation (MFMA path only; needs pre == 1): when fin_red is given, the conv kernel itself
    * turns the raw sums fin_red[n][c] = (sum x, sum x^2) over fin_count voxels into scale = rstd, shift = -mean*rstd (every
    * workgroup for its own input channels, in fp64) and ALSO WRITES pre_sc / pre_sh / fin_mean / fin_rstd (kept for the

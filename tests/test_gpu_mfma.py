@@ -142,6 +142,49 @@ def test_prepacked_fragments_match_and_never_go_stale(cfg):
         X.ops.set_prepack(True)
 
 
+@pytest.mark.parametrize("case", ["q4", "gemm", "k1", "dw3"])
+def test_statistics_fan_in_matches_direct_atomics_and_cleans_up(case):
+    """Launches with >= 256 workgroups per (sample, channel block) sum their epilogue statistics through the two-level fan-in
+    of csrc/fanin.h (arena replicas + counters, collected by the last workgroup) instead of same-line atomics.  Same sums as
+    the direct path (xh_set_option(2, 64)) and as the stored output; repeated launches keep accumulating correctly, i.e.
+    every launch leaves the arena zero (a stale counter or replica would show up in the next launch's totals)."""
+    torch.manual_seed(9)
+    lib = X._lib.load()
+    if case == "q4":
+        x = torch.randn(2, 8, 64, 64, 64, device=DEV).bfloat16()
+        w, kw = [torch.randn(4, 4, 3, 3, 3, device=DEV) * 0.1 for _ in range(2)], dict(k=3, cout=8, groups=2)
+    elif case == "gemm":
+        x = torch.randn(1, 16, 64, 64, 64, device=DEV).bfloat16()
+        w, kw = [torch.randn(16, 16, 3, 3, 3, device=DEV) * 0.05], dict(k=3, cout=16)
+    elif case == "k1":
+        x = torch.randn(1, 4, 128, 128, 128, device=DEV).bfloat16()
+        w, kw = [torch.randn(8, 4, 1, 1, 1, device=DEV)], dict(k=1, cout=8)
+    else:
+        x = torch.randn(1, 4, 128, 128, 128, device=DEV).bfloat16()
+        w, kw = [torch.randn(4, 1, 3, 3, 3, device=DEV) * 0.2], dict(k=3, cout=4, groups=4)
+    n, cout = x.shape[0], kw["cout"]
+
+    def run(reps):
+        red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
+        for _ in range(reps):
+            y = X.ops.conv3d(x, None, w, None, epi=2, red=red, **kw)
+        torch.cuda.synchronize()
+        return y, red
+    y, red1 = run(1)
+    _, red3 = run(3)
+    lib.xh_set_option(2, 64)
+    try:
+        _, red_direct = run(1)
+    finally:
+        lib.xh_set_option(2, 0)
+    ys = y.double()
+    ref = torch.stack((ys.sum((2, 3, 4)), (ys * ys).sum((2, 3, 4))), -1)
+    scale = torch.stack((ys.abs().sum((2, 3, 4)), (ys * ys).sum((2, 3, 4))), -1)
+    assert ((red1 - ref).abs() / scale).max().item() < 1e-6
+    assert ((red_direct - ref).abs() / scale).max().item() < 1e-6
+    assert ((red3 - 3 * ref).abs() / scale).max().item() < 3e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(1, 4, 12, 20, 32), (2, 4, 9, 16, 64), (1, 4, 5, 7, 32)])
 def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape, dtype):

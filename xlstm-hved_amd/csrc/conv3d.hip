@@ -13,12 +13,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include "common.h"
+#include "fanin.h"
 #include "../../include/xlstm_hved.h"
 
 struct ConvK {
   xh_conv_desc d;
   xh_conv_ptrs p;
   int Cin_g, Cout_g, ncob, tilesW, tilesH, tilesD;
+  unsigned char* fan;           // statistics fan-in block of this launch (fanin.h), or nullptr: direct atomics
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -110,6 +112,10 @@ __device__ __forceinline__ void conv_reduce_out(const ConvK& a, int n, int g, in
 #pragma unroll
   for (int i = 0; i < COB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
   block_sum_d<2 * COB>(v, s_red, blockDim.x >> 6);
+  // many workgroups per (sample, channel block): two-level fan-in instead of gridDim.x same-line atomics (fanin.h)
+  if (a.fan && !fan_in<2 * COB>(a.fan + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x,
+                                s_red, reinterpret_cast<int*>(s_red + 2 * COB)))
+    return;
   if ((int)threadIdx.x < 2 * COB) {
     const int co_g = cob * COB + (threadIdx.x >> 1);
     if (co_g < a.Cout_g) {
@@ -335,6 +341,9 @@ __global__ __launch_bounds__(256) void conv_dw3_kernel(const ConvK a) {
   if (a.d.epi) {
     double v[2] = {s0, s1};
     block_sum_d<2>(v, s_red, 4);
+    if (a.fan && !fan_in<2>(a.fan + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x, s_red,
+                            reinterpret_cast<int*>(s_red + 2)))
+      return;
     if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], s_red[tid]);
   }
 }
@@ -461,6 +470,9 @@ __global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int 
   if (a.d.epi) {
     double v[2] = {s0, s1};
     block_sum_d<2>(v, s_red, 4);
+    if (a.fan && !fan_in<2>(a.fan + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x, s_red,
+                            reinterpret_cast<int*>(s_red + 2)))
+      return;
     if (tid < 2) atomicAdd(&a.p.red[((long long)n * a.d.Cout + c) * 2 + tid], s_red[tid]);
   }
 }
@@ -1048,6 +1060,19 @@ static int check_desc(const xh_conv_desc* d, const xh_conv_ptrs* p) {
   return XH_OK;
 }
 
+// The statistics fan-in arena (fanin.h): zero when the code object is loaded, left zero by every launch that uses it.
+__device__ unsigned char g_fan_arena[(size_t)FAN_SLOTS * FAN_UNITS * FAN_UNIT_BYTES];
+unsigned char* xh_fan_block(long long units, long long wgs) {
+  if (units < 1 || units > FAN_UNITS || wgs < FAN_MIN_WGS || (g_xh_disable & 64)) return nullptr;
+  static unsigned char* base[16] = {nullptr};
+  static int slot = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_fan_arena)) != hipSuccess) return nullptr;
+  slot = (slot + 1) % FAN_SLOTS;
+  return base[dev] + (size_t)slot * FAN_UNITS * FAN_UNIT_BYTES;
+}
+
 static ConvK make_k(const xh_conv_desc* d, const xh_conv_ptrs* p, int cob, int txn) {
   ConvK a;
   a.d = *d;
@@ -1058,6 +1083,7 @@ static ConvK make_k(const xh_conv_desc* d, const xh_conv_ptrs* p, int cob, int t
   a.tilesW = cdiv(d->Wo, 4 * txn);
   a.tilesH = cdiv(d->Ho, 8);
   a.tilesD = cdiv(d->Do, 32 / txn);
+  a.fan = nullptr;
   return a;
 }
 static int pick_txn(int Wo) { return Wo > 16 ? 8 : (Wo > 8 ? 4 : 2); }
@@ -1085,6 +1111,7 @@ template <typename T> static const char* tname() { return FmtOf<T>::v == 0 ? "bf
 static int g_dw_minsd = 0;     // key 6: fewest planes a depthwise sliding-window workgroup marches through
 static int g_dw_target = 1024; // key 7: workgroup count the depth split of the sliding-window kernels aims at
 static int g_c1w_wgs = 320;    // key 8: workgroup count the k = 1 weight gradient aims at
+static int g_c1_cap = 0;       // key 10: workgroup cap of the k = 1 forward kernel (0 = the built-in rule)
 
 // Planes per sliding-window segment: at 128^3 the kernels are issue-bound and the two halo planes per segment cost more
 // than the extra workgroups return (8 planes); at 64^3 / 32^3 the launch is a latency chain of one load per plane over
@@ -1111,13 +1138,15 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     if (vec && cin_g >= 16 && cout_g >= 2 && gx1 * a.ncob * d->N * d->groups < 128) {
       a = make_k(d, p, 2, 8);
       dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
+      if (d->epi) a.fan = xh_fan_block((long long)grid.y * grid.z, grid.x);
       xh_note_kernel("conv1x1_kernel<%s, 2, true, 16>", tname<T>());
       hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16>), grid, dim3(256), 0, (hipStream_t)stream, a);
       return xh_launch_status();
     }
-    const long long cap1 = cdiv(2048, a.ncob * d->N * d->groups);
+    const long long cap1 = cdiv(g_c1_cap > 0 ? g_c1_cap : 2048, a.ncob * d->N * d->groups);
     if (gx1 > cap1) gx1 = cap1;
     dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
+    if (d->epi) a.fan = xh_fan_block((long long)grid.y * grid.z, grid.x);
 #define L1(COB)                                                                                                  \
   do {                                                                                                           \
     xh_note_kernel("conv1x1_kernel<%s, %d, %s>", tname<T>(), COB, vec ? "true" : "false");                       \
@@ -1148,6 +1177,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
         const int sd = cdiv(d->D, dsegs);
         dsegs = cdiv(d->D, sd);
         dim3 grid(a.tilesW * a.tilesH * dsegs, d->Cin, d->N);
+        if (d->epi) a.fan = xh_fan_block((long long)grid.y * grid.z, grid.x);
         xh_note_kernel("conv_dw3_slide_kernel<%s, %d>", tname<T>(), txn);
         switch (txn) {
           case 4: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, a, sd); break;
@@ -1252,6 +1282,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 6) { g_dw_minsd = value < 0 ? 0 : value; return XH_OK; }
   if (key == 7) { g_dw_target = value < 1 ? 1 : value; return XH_OK; }
   if (key == 8) { g_c1w_wgs = value < 1 ? 320 : value; return XH_OK; }
+  if (key == 10) { g_c1_cap = value < 0 ? 0 : value; return XH_OK; }
   if (key == 9) { extern int g_red_wgs; g_red_wgs = value < 0 ? 0 : value; return XH_OK; }
   if (key == 5) { extern int g_dconv_kq; g_dconv_kq = value == 1 ? 1 : 2; return XH_OK; }
   return XH_ERR_ARG;

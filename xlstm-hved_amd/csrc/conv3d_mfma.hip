@@ -22,6 +22,7 @@
 //    backward) are accumulated in fp64 registers over the whole run and reduced once.
 #include "common.h"
 #include "conv_pack.h"
+#include "fanin.h"
 #include "../../include/xlstm_hved.h"
 
 typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
@@ -44,6 +45,7 @@ struct ConvMK {
   int nsplit, cin_off, part_in, part_out;
   int cin_stride;   // input channels between consecutive sets (= cin_blk unless split: then the whole group's cin_g)
   float* part;
+  unsigned char* fan;  // statistics fan-in block of this launch (fanin.h), or nullptr: direct atomics
 };
 int g_mfma_abl = 0;
 int g_mfma_wgs = 512;      // xh_set_option(3, n): target workgroup count of the k3 MFMA forward kernel (experiments)
@@ -371,10 +373,20 @@ __global__ __launch_bounds__(NT, MW) void conv3_mfma_kernel(const ConvMK a) {
     __syncthreads();
     if (lane < 16) { s_red[wv * 32 + eco * 2] = s0; s_red[wv * 32 + eco * 2 + 1] = s1; }
     __syncthreads();
+    double tot = 0.0;
     if (tid < 32) {
-      double tot = 0.0;
 #pragma unroll
       for (int w8 = 0; w8 < NWV; ++w8) tot += s_red[w8 * 32 + tid];
+    }
+    if (a.fan) {                                       // two-level fan-in instead of gridDim.x same-line atomics (fanin.h)
+      __syncthreads();
+      if (tid < 32) s_red[tid] = tot;
+      if (!fan_in<32>(a.fan + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x, s_red,
+                      reinterpret_cast<int*>(s_red + 32)))
+        return;
+      tot = tid < 32 ? s_red[tid] : 0.0;
+    }
+    if (tid < 32) {
       const int c = tid >> 1;
       if (c < co_lim) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co_base + c) * 2 + (tid & 1)], tot);
     }
@@ -463,6 +475,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const int ny = (d->groups / gs) * a.ntile;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(a.tilesW * a.tilesH * a.dsegs, ny, d->N);
+  a.fan = (d->epi && a.nsplit == 1) ? xh_fan_block((long long)grid.y * grid.z, grid.x) : nullptr;
   const size_t shm = (size_t)4 * (a.th + 2) * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 32 * sizeof(double);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);

@@ -22,6 +22,7 @@
 // walked quad by quad through the same 28.8 KB LDS tile (4-5 workgroups per CU hide each other's staging phase).
 #include "common.h"
 #include "conv_pack.h"
+#include "fanin.h"
 #include "../../include/xlstm_hved.h"
 
 typedef h16x8 frag8;
@@ -34,7 +35,7 @@ struct ConvQ4 {
   int tilesW, tilesH, tilesD;
   float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
   double fin_inv;               // 1 / fin_count
-  unsigned char* fan;           // statistics fan-in block of the workspace (zero between launches)
+  unsigned char* fan;           // statistics fan-in block of this launch (fanin.h), or nullptr: direct atomics
   int abl;
 };
 extern int g_mfma_abl;
@@ -47,7 +48,6 @@ constexpr int TILE_BYTES = ID * PLANE;      // 28 800
 constexpr int NROWS = ID * IH;              // 100 staged rows
 constexpr int NITEM = NROWS * 4;            // interior items: (row, 8-voxel group)
 constexpr int NEDGE = NROWS * 2;            // edge items: (row, side) -> one voxel pair
-constexpr int Q4_FAN = 32;                  // replicas of the statistics fan-in (one 128-byte line each, + 1 top line)
 }
 
 // two values of one channel -> leaky(x * sc + sh) in fp32 (packed fma / mul; leaky = max(v, slope * v) for 0 <= slope <= 1)
@@ -60,8 +60,8 @@ template <int FMT, bool PRE, int EPI, bool ACT, bool MULTI>
 __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   typedef h16<FMT> ST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8]
-  float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 32 * sizeof(double));   // [2][12]: in-kernel InstanceNorm scale / shift
+  double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8], then [8] totals + the fan-in flag
+  float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 48 * sizeof(double));   // [2][12]: in-kernel InstanceNorm scale / shift
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g4 = lane >> 4;
@@ -330,50 +330,18 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     for (int m = 1; m < 16; m <<= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
     if (nn == 0) { s_red[wv * 8 + g4 * 2] = s0; s_red[wv * 8 + g4 * 2 + 1] = s1; }
     __syncthreads();
-    // Two-level fan-in of the 8 channel sums.  One fp64 atomic per workgroup and value on red[] means 1024 .. 4096 atomic
-    // requests on ONE cache line, which the memory side retires one after the other (~8 ns each: 8 us of a 22 us launch).
-    // Instead a workgroup adds into one of 32 replicas (a line of its own in the workspace), counts itself in on the
-    // replica's counter, the workgroup that completes a replica counts the replica in on the top counter, and the one
-    // that completes the top counter collects the replicas, adds the totals to red[] and leaves every word zero for the
-    // next launch.  Every access is a RETURNING atomic executed at the memory side: a contributor's sums have arrived
-    // before it counts itself in (its adds have returned), and the collector reads by exchange, never through a cache.
-    const int nrep = min((int)gridDim.x, Q4_FAN);
-    const int rep = blockIdx.x % Q4_FAN;
-    unsigned char* fb = a.fan + ((long long)n * gridDim.y + oq) * ((Q4_FAN + 1) * 128);
-    bool* s_last = reinterpret_cast<bool*>(s_fin + 24);
+    // the 8 channel sums of the workgroup, then the two-level fan-in of fanin.h (one fp64 atomic per workgroup and value on
+    // red[] is 1024 .. 4096 requests on ONE cache line, retired one after the other: 8 us of a 22 us launch)
     if (tid < 8) {
       const double tot = s_red[tid] + s_red[8 + tid] + s_red[16 + tid] + s_red[24 + tid];
-      const double old = atomicAdd(reinterpret_cast<double*>(fb + rep * 128) + tid, tot);
-      asm volatile("" ::"v"(old));                    // the add has returned = has been performed
+      s_red[32 + tid] = tot;
     }
-    if (tid == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // all eight adds of this wave
-      const unsigned mine = ((unsigned)gridDim.x - rep + Q4_FAN - 1) / Q4_FAN;      // workgroups of this replica
-      bool last = false;
-      if (__hip_atomic_fetch_add(reinterpret_cast<unsigned*>(fb + rep * 128 + 64), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1)
-        last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(fb + Q4_FAN * 128), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nrep - 1;
-      *s_last = last;
-    }
-    __syncthreads();
-    if (*s_last) {                                    // workgroup-uniform: one workgroup per (sample, channel quad)
-      double v = 0.0;
-      if (tid < 8 * nrep) {
-        const unsigned long long bits = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(fb + (tid >> 3) * 128) + (tid & 7), 0ull,
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = __builtin_bit_cast(double, bits);
-      }
-      // threads t, t + 8, t + 16, ... hold the replicas of value t & 7: sum over the wave, then over the four waves
-      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-      __syncthreads();
-      if (lane < 8) s_red[wv * 8 + lane] = v;
-      __syncthreads();
-      if (tid < 8) {
-        const double tot = s_red[tid] + s_red[8 + tid] + s_red[16 + tid] + s_red[24 + tid];
-        atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], tot);
-      }
-      if (tid < nrep) __hip_atomic_exchange(reinterpret_cast<unsigned*>(fb + tid * 128 + 64), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 0) __hip_atomic_exchange(reinterpret_cast<unsigned*>(fb + Q4_FAN * 128), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    double* s_tot = s_red + 32;
+    if (a.fan && !fan_in<8>(a.fan + ((long long)n * gridDim.y + oq) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x, s_tot,
+                            reinterpret_cast<int*>(s_tot + 8)))
+      return;
+    if (!a.fan) __syncthreads();
+    if (tid < 8) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], s_tot[tid]);
   }
 }
 
@@ -427,15 +395,10 @@ bool xh_conv3_q4_pack_job(const xh_conv_desc* d, const xh_conv_ptrs* p, PackJob*
 }
 void xh_launch_pack_single(hipStream_t st, const PackJob& j);                   // conv3d_mfma.hip
 
-static long long q4_frag_bytes(const xh_conv_desc* d, const ConvQ4& a) {
-  return ((long long)(d->Cout / 4) * a.ci4 * 9 * 1024 + 127) & ~127ll;
-}
-// packed fragments, then one statistics fan-in block per (sample, output quad).  The fan-in words must be ZERO before the
-// first launch that uses the workspace (every launch leaves them zero again): the caller allocates the workspace zeroed.
 long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
   ConvQ4 a;
   if (!q4_plan(d, &a)) return 0;
-  return q4_frag_bytes(d, a) + (long long)d->N * (d->Cout / 4) * (Q4_FAN + 1) * 128;
+  return (long long)(d->Cout / 4) * a.ci4 * 9 * 1024;
 }
 
 // XH_OK if launched, 1 if the shape is not eligible
@@ -446,7 +409,7 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   if (!p->ws || p->ws_bytes < need) return 1;
   a.p = *p;
   a.fin_inv = p->fin_count > 0 ? 1.0 / (double)p->fin_count : 0.0;
-  a.fan = (unsigned char*)p->ws + q4_frag_bytes(d, a);
+
   hipStream_t st = (hipStream_t)stream;
   const int f = d->dtype == XH_F16 ? 1 : 0;
   if (!p->ws_packed) {
@@ -455,7 +418,8 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
     xh_launch_pack_single(st, pj);
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
-  const size_t shm = TILE_BYTES + 32 * sizeof(double) + 24 * sizeof(float) + 16;
+  a.fan = d->epi ? xh_fan_block((long long)grid.y * grid.z, grid.x) : nullptr;
+  const size_t shm = TILE_BYTES + 48 * sizeof(double) + 24 * sizeof(float);
   const bool act = a.act_slope != 1.f;
   xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false");
 #define Q4L(F, P, E, A)                                                                                         \

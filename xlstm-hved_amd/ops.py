@@ -152,7 +152,7 @@ def _pack_entry(weights, desc, need, device):
     import weakref
     e = _PackEntry()
     e.refs = [weakref.ref(w) for w in weights]
-    e.ws = torch.zeros(need, dtype=torch.uint8, device=device)      # zeroed: the statistics fan-in words of xh_conv3d_fwd
+    e.ws = torch.empty(need, dtype=torch.uint8, device=device)
     e.desc = L.ConvDesc.from_buffer_copy(desc)
     e.ptrs = L.ConvPtrs()
     e.ptrs.w = _arr4(list(weights))
@@ -280,7 +280,7 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
         else:                                   # this call packs; good for the rest of the epoch
             ent.epoch, ent.versions = _PACK_STATE["epoch"], vers
     elif need:
-        ws = torch.zeros(need, dtype=torch.uint8, device=xa.device)
+        ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
         ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
     if stats is not None:
         if need:            # MFMA path: the pack launch finalises the statistics
