@@ -14,6 +14,13 @@
 //   Column (ci = 0, kh = 3) -- unused by the taps -- holds the constant 1, so the same MFMAs deliver the bias gradient.
 // A lane's accumulator tile is dW[co = lane>>4][ci = lane&3][kd][kh = (lane>>2)&3][kw = register]: the four waves of a workgroup
 // (four consecutive rows) are summed through LDS and leave one pass of fp32 atomics.
+//
+// Measured on MI355X (tools/microbench_wgrad_q4.py, 4 -> 4 @128^3: 26 us without / 44 us with the atomics tail of a lone
+// problem; batched launches hide the tail): the main loop sits at ~1.7 TB/s of algorithmic traffic and did NOT move with
+// prefetch depth 2 -> 4, 4 vs 6 waves per SIMD, two output rows per wave (x fragment of four rows shared by two dY rows: half
+// the input transforms, 2/3 of the x fetches), 64-voxel rows per wave (whole 128-byte lines) or non-power-of-two volumes
+// (96^3, 160^3: same time per voxel) -- those variants were removed again; SQ counters: 51 % of wave cycles waiting on memory,
+// 34 % waiting to issue, SIMD issue slots 59 % busy.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 #include "wgrad_q4.h"
