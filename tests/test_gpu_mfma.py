@@ -87,7 +87,7 @@ def test_mfma_conv_forward_backward(cfg, dtype):
 
 
 def test_quad_channel_kernel_is_selected():
-    """Convs with <= 12 channels per group on 32-multiple rows take conv3_q4_kernel (forward and data gradient); the others keep
+    """Convs with <= 48 channels per group on 32-multiple rows take conv3_q4_kernel (forward and data gradient); the others keep
     the plain implicit-GEMM kernels; xh_set_option(2, 16) switches the quad-channel path off (A/B runs)."""
     lib = X._lib.load()
     x = torch.randn(1, 16, 8, 8, 32, device=DEV).bfloat16()
@@ -97,7 +97,11 @@ def test_quad_channel_kernel_is_selected():
     X.ops.conv3d(x.half(), None, w4, None, k=3, cout=16, groups=4, pre=(torch.ones(1, 16, device=DEV), torch.zeros(1, 16, device=DEV), 0.01),
                  epi=2, red=torch.zeros(1, 16, 2, dtype=torch.float64, device=DEV))
     assert "conv3_q4_kernel<1, true, 2, false, false>" in X.ops.last_conv_kernel()
-    X.ops.conv3d(x, None, [torch.randn(16, 16, 3, 3, 3, device=DEV)], None, k=3, cout=16)
+    x64 = torch.randn(1, 64, 8, 8, 32, device=DEV).bfloat16()
+    X.ops.conv3d(x64, None, [torch.randn(16, 64, 3, 3, 3, device=DEV)], None, k=3, cout=16)      # > 48 channels per group
+    assert "conv3_mfma_kernel" in X.ops.last_conv_kernel()
+    x16 = torch.randn(1, 16, 8, 8, 16, device=DEV).bfloat16()
+    X.ops.conv3d(x16, None, [torch.randn(16, 16, 3, 3, 3, device=DEV)], None, k=3, cout=16)      # 16-wide rows
     assert "conv3_mfma_kernel" in X.ops.last_conv_kernel()
     lib.xh_set_option(2, 16)
     try:

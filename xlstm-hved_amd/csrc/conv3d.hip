@@ -1283,6 +1283,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 7) { g_dw_target = value < 1 ? 1 : value; return XH_OK; }
   if (key == 8) { g_c1w_wgs = value < 1 ? 320 : value; return XH_OK; }
   if (key == 10) { g_c1_cap = value < 0 ? 0 : value; return XH_OK; }
+  if (key == 11) { extern int g_q4_maxc; g_q4_maxc = value < 4 ? 4 : value > 48 ? 48 : value; return XH_OK; }
   if (key == 9) { extern int g_red_wgs; g_red_wgs = value < 0 ? 0 : value; return XH_OK; }
   if (key == 5) { extern int g_dconv_kq; g_dconv_kq = value == 1 ? 1 : 2; return XH_OK; }
   return XH_ERR_ARG;

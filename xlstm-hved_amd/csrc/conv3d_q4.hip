@@ -39,6 +39,7 @@ struct ConvQ4 {
   int abl;
 };
 extern int g_mfma_abl;
+int g_q4_maxc = 48;               // xh_set_option(11, n): most channels per group the quad-channel kernel takes (<= 48)
 
 namespace {
 constexpr int TW = 32, TH = 8, TD = 8, IH = TH + 2, ID = TD + 2;
@@ -48,6 +49,7 @@ constexpr int TILE_BYTES = ID * PLANE;      // 28 800
 constexpr int NROWS = ID * IH;              // 100 staged rows
 constexpr int NITEM = NROWS * 4;            // interior items: (row, 8-voxel group)
 constexpr int NEDGE = NROWS * 2;            // edge items: (row, side) -> one voxel pair
+constexpr int Q4_MAXC = 48;                 // most channels per group the kernel can be asked to take
 }
 
 // two values of one channel -> leaky(x * sc + sh) in fp32 (packed fma / mul; leaky = max(v, slope * v) for 0 <= slope <= 1)
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   typedef h16<FMT> ST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8], then [8] totals + the fan-in flag
-  float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 48 * sizeof(double));   // [2][12]: in-kernel InstanceNorm scale / shift
+  float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 48 * sizeof(double));   // [2][Q4_MAXC]: in-kernel InstanceNorm scale / shift
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g4 = lane >> 4;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
         if (cq == 0) {
           if (tid < a.Cin_g) {
             float m_, r_;
-            in_finalize(fs1, fs2, a.fin_inv, s_fin[tid], s_fin[12 + tid], m_, r_);
+            in_finalize(fs1, fs2, a.fin_inv, s_fin[tid], s_fin[Q4_MAXC + tid], m_, r_);
           }
           if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
             for (int i = tid; i < a.d.N * a.d.Cin; i += 256)
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
           __syncthreads();
         }
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) { sc[cc] = s_fin[cq * 4 + cc]; sh[cc] = s_fin[12 + cq * 4 + cc]; }
+        for (int cc = 0; cc < 4; ++cc) { sc[cc] = s_fin[cq * 4 + cc]; sh[cc] = s_fin[Q4_MAXC + cq * 4 + cc]; }
       } else {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) { sc[cc] = a.p.pre_sc[n * a.d.Cin + c0 + cc]; sh[cc] = a.p.pre_sh[n * a.d.Cin + c0 + cc]; }
@@ -353,7 +355,7 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if (d->W % TW != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g % 4 || cout_g % 4) return false;
-  if (cin_g > 12 || cout_g > 12) return false;                 // denser groups: the plain implicit GEMM uses the MFMA better
+  { extern int g_q4_maxc; if (cin_g > g_q4_maxc || cout_g > g_q4_maxc) return false; }   // denser groups: the plain implicit GEMM
   if (d->Ca % 4) return false;
   if (d->epi == 1 && d->Cea % 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return false;
@@ -419,7 +421,7 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
   a.fan = d->epi ? xh_fan_block((long long)grid.y * grid.z, grid.x) : nullptr;
-  const size_t shm = TILE_BYTES + 48 * sizeof(double) + 24 * sizeof(float);
+  const size_t shm = TILE_BYTES + 48 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
   const bool act = a.act_slope != 1.f;
   xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false");
 #define Q4L(F, P, E, A)                                                                                         \
