@@ -466,10 +466,12 @@ def roofline_pass(step, ops, nsteps, dtype):
             # class (7 per launch), else one ordinary launch each
             cg, og, w_ = cin // groups, dy.shape[1] // groups, xa.shape[-1]
             k3 = k == 3 and kw.get("stride", 1) == 1 and esz == 2
-            q4 = (k3 and w_ % 32 == 0 and cg % 4 == 0 and og % 4 == 0 and cg <= 12 and og <= 12 and xa.shape[2] >= 4
+            q4 = (k3 and w_ % 32 == 0 and cg % 4 == 0 and og % 4 == 0 and cg <= 48 and og <= 48 and xa.shape[2] >= 4
                   and xa.shape[3] >= 4 and xa.shape[1] % 4 == 0)
             mfma = k3 and (w_ % 32 == 0 or w_ in (8, 16)) and cg >= 4
-            cls = (f"q4_{cg // 4}" if q4 else ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small")
+            qs = cg // 4
+            qs = qs if qs <= 3 else 3 if qs % 3 == 0 else 2 if qs % 2 == 0 else 1      # input quads per unit (wgrad_q4 plan)
+            cls = (f"q4_{qs}" if q4 else ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small")
                    if mfma else "rest")
             pending_meta.append((cls, nbytes, flops, shape))
             return orig_wg(xa, xb, dy, dws, dbs, **kw)

@@ -336,8 +336,10 @@ def test_wgrad_mfma_narrow_volume_kernel_name(w):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("cfg", [dict(n=2, cin=4, cout=4, g=1, sp=(9, 6, 32)), dict(n=1, cin=12, cout=8, g=1, sp=(17, 11, 64)),
-                                 dict(n=1, cin=16, cout=32, g=4, sp=(8, 8, 32)), dict(n=2, cin=24, cout=8, g=2, sp=(5, 9, 32))],
-                         ids=["4to4", "12to8", "16to32g4", "24to8g2"])
+                                 dict(n=1, cin=16, cout=32, g=4, sp=(8, 8, 32)), dict(n=2, cin=24, cout=8, g=2, sp=(5, 9, 32)),
+                                 dict(n=1, cin=24, cout=16, g=1, sp=(9, 8, 32)), dict(n=1, cin=16, cout=48, g=1, sp=(8, 5, 64)),
+                                 dict(n=1, cin=20, cout=4, g=1, sp=(8, 8, 32))],
+                         ids=["4to4", "12to8", "16to32g4", "24to8g2", "24to16_chunks3", "16to48_chunks2", "20to4_chunks1"])
 def test_wgrad_quad_channel_kernel_vs_stock(cfg, dtype):
     """conv3_wgrad_q4_multi_kernel on its own (raw x, no input transform; then with the InstanceNorm + LeakyReLU transform):
     weight and bias gradients against torch.nn.grad on the same 16-bit inputs; ragged D / H, several W tiles, batch 2."""

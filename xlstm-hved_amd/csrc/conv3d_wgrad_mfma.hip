@@ -401,8 +401,8 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
       int k = 0;
       for (int i = 0; i < n; ++i) {
         if (!d[i] || !p[i]) return XH_ERR_ARG;
-        if (handled[i] || (d[i]->dtype == XH_F16 ? 1 : 0) != fmt || d[i]->groups <= 0 || d[i]->Cin / d[i]->groups != 4 * ci4) continue;
-        if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &probs[k])) continue;
+        if (handled[i] || (d[i]->dtype == XH_F16 ? 1 : 0) != fmt) continue;
+        if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &probs[k]) || probs[k].ci4 != ci4) continue;
         handled[i] = 1;
         if (++k == WQ_MULTI) { xh_wgrad_q4_launch(st, fmt, probs, k); k = 0; }
       }

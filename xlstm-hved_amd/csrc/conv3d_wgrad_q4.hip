@@ -54,7 +54,8 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
   // tiles and keep their accumulators across tiles, so the LDS reduction + atomics tail is paid once per workgroup (a
   // workgroup per tile left 1024 x 432 same-address atomics per unit: 35 of the 46 us of a 4 -> 4 @128^3 problem).
   // Workgroups that share an XCD (equal id mod 8) walk one contiguous eighth of the tiles side by side.
-  const int oq = b / a.wpu, w = b - oq * a.wpu;
+  const int unit = b / a.wpu, w = b - unit * a.wpu;
+  const int oq = unit / a.nchunk, chunk = unit - oq * a.nchunk;   // unit = (output quad, chunk of CI4 input quads)
   int t_first, t_stride, t_end;
   if ((a.ntile & 7) == 0 && (a.wpu & 7) == 0) {
     const int per = a.ntile >> 3;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
   const long long hw = (long long)H * W, dhw = (long long)D * hw;
   const int co0 = oq * 4;
   const int grp = co0 / a.Cout_g;
-  const int cin_base = grp * a.Cin_g;
+  const int cin_base = grp * a.Cin_g + chunk * 4 * CI4;
   for (int t = t_first; t < t_end; t += t_stride) {
   int wk = t;
   const int tw = wk % a.tilesW; wk /= a.tilesW;
@@ -227,10 +228,10 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
     const int r = i / 27;
     const int ci = r % (4 * CI4), c = r / (4 * CI4);
     const int co_g = (co0 + c) % a.Cout_g;
-    atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci) * 27 + tap, s_dw[i]);
+    atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + chunk * 4 * CI4 + ci) * 27 + tap, s_dw[i]);
   }
   float* dbp = a.db[grp / gpp];
-  if (dbp && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
+  if (dbp && chunk == 0 && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
 }
 
 // resident workgroups per CU (= waves per SIMD) each instance is built for: 75 / 127 / 143 VGPRs, no spills
@@ -257,7 +258,7 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
-  if (cin_g % 4 || cout_g % 4 || cin_g > 12 || cout_g > 12) return false;
+  if (cin_g % 4 || cout_g % 4 || cin_g > 48 || cout_g > 48) return false;
   if (d->Ca % 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
@@ -271,9 +272,13 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   a->xa_bs = d->xa_bs; a->xb_bs = d->xb_bs; a->dy_bs = d->ea_bs;
   a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->groups = d->groups; a->n_wptr = d->n_wptr; a->Ca = d->Ca;
   a->D = d->D; a->H = d->H; a->W = d->W;
-  a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cin_g / 4; a->pre = d->pre; a->pre_slope = d->pre_slope;
+  // input quads per unit: a workgroup keeps 3 accumulator tiles per quad, so groups of more than 3 quads are cut into
+  // equal chunks of 3, 2 or 1 (each chunk re-reads the dY rows)
+  const int q_all = cin_g / 4;
+  const int cs = q_all <= 3 ? q_all : q_all % 3 == 0 ? 3 : q_all % 2 == 0 ? 2 : 1;
+  a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cs; a->nchunk = q_all / cs; a->pre = d->pre; a->pre_slope = d->pre_slope;
   a->tilesW = d->W / 32; a->tilesH = cdiv(d->H, 4);
-  a->nq = d->Cout / 4;
+  a->nq = (d->Cout / 4) * a->nchunk;
   // depth segments: tiles of >= 8 planes (x is read sd + 2 planes per tile), ~1024 tiles per unit
   const long long cols = (long long)a->tilesW * a->tilesH * d->N;
   int dsegs = (int)((1024 + cols - 1) / cols);

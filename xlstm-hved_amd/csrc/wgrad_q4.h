@@ -9,10 +9,11 @@ struct WgQ4 {
   float* dw[4]; float* db[4];
   long long xa_bs, xb_bs, dy_bs;
   int N, Cin, Cout, groups, n_wptr, Ca, D, H, W;
-  int Cin_g, Cout_g, ci4, pre;
+  int Cin_g, Cout_g, ci4, pre;   // ci4 = input-channel quads per unit (1..3)
   float pre_slope;
   int tilesW, tilesH, dsegs, sd;
-  int nq;                        // output-channel quads (= Cout / 4): the units of the problem
+  int nchunk;                    // chunks of ci4 input quads a group's input channels are cut into
+  int nq;                        // units of the problem: (output-channel quad, input chunk) pairs = Cout / 4 * nchunk
   int ntile;                     // spatial tiles of a unit (tilesW * tilesH * dsegs * N)
   int wpu;                       // workgroups per unit (each walks ntile / wpu tiles)
   int nb;                        // workgroups of the problem (nq * wpu)
