@@ -502,6 +502,51 @@ def test_sliding_window_tiler_vs_oracle_windows(subset):
     assert (got_g - got).abs().max().item() < 1e-6          # hipGraph replay of the window forward: same kernels, same result
 
 
+def test_config5_full_volume_240x240x155_fp16_and_fp32():
+    """BASELINE config 5 at full size on the test path: a 240 x 240 x 155 volume, 18 windows of 128^3 every 64 voxels
+    (evaluation.py:279-384), posterior mean, hipGraph replay of the window forward.  fp32 storage: the corner block that only
+    window (0, 0, 0) covers against the CPU oracle's forward of that window (one 128^3 oracle forward, ~10 s); fp16 storage
+    (what config 5 names): finite, inside [0, 1], and within the 16-bit deviation class of the network
+    (test_16bit_storage_vs_oracle_...: seg relative L2 ~1e-2 at 128^3) of the fp32 volume.  Two ranks' shards (rank 0 / 1 of 2,
+    taken one after the other on this one GPU) add up to the unsharded volume."""
+    from xlstm_hved_amd.inference import eval_overlap_volume, window_list
+    from xlstm_hved_amd.parallel import shard_windows
+    torch.manual_seed(4)
+    shape = (240, 240, 155)
+    x = torch.rand((1, 4) + shape)
+    wins = window_list(shape, (128, 128, 128), (64, 64, 64))
+    assert len(wins) == 18 and wins[0] == (0, 0, 0)
+    m = _model(False)
+    got32 = eval_overlap_volume(m, x.to(DEV), 14, use_graph=True).cpu()
+    assert got32.shape == (1, 3) + shape and torch.isfinite(got32).all()
+    with torch.no_grad():
+        p0 = O.xlstm_hved_forward({k: v.clone() for k, v in _weights().items()}, x[:, :, :128, :128, :128], 14, eps_list=None,
+                                  training=False)[0]
+    e = (got32[:, :, :64, :64, :27] - p0[:, :, :64, :64, :27]).abs().max().item()       # W windows start at 0 and 27
+    print(f"config 5 fp32 corner block vs oracle window: max |d| {e:.2e}")
+    assert e < 5e-3
+    got16 = eval_overlap_volume(m, x.to(DEV).half(), 14, use_graph=True).cpu()
+    assert torch.isfinite(got16).all() and got16.min() >= 0 and got16.max() <= 1
+    l2 = ((got16 - got32).norm() / got32.norm()).item()
+    d16 = (_dice(got16, (got32 > 0.5).float()) - 1).abs().max().item()
+    print(f"config 5 fp16 vs fp32 volume: rel L2 {l2:.2e}, Dice deviation {d16:.2e}")
+    assert l2 < 3e-2 and d16 < 1e-2
+    # window sharding at full size: the two shards of a 2-rank run, accumulated here by hand
+    parts = []
+    for r in range(2):
+        mine = [wins[i] for i in shard_windows(len(wins), r, 2)]
+        s_ = torch.zeros((1, 3) + shape, device=DEV)
+        c_ = torch.zeros((1, 1) + shape, device=DEV)
+        with torch.no_grad():
+            for d, h, w in mine:
+                pr = m(x[:, :, d:d + 128, h:h + 128, w:w + 128].to(DEV).contiguous(), subset_idx_list=[14], valid=True)[0].float()
+                s_[:, :, d:d + 128, h:h + 128, w:w + 128] += pr[0]
+                c_[:, :, d:d + 128, h:h + 128, w:w + 128] += 1
+        parts.append((s_, c_))
+    both = ((parts[0][0] + parts[1][0]) / (parts[0][1] + parts[1][1])).cpu()
+    assert (both - got32).abs().max().item() < 1e-5
+
+
 def test_full_size_128_specialised_kernels_vs_generic_train():
     """BASELINE config 2 size, forward + backward: the large-volume kernel variants (256-thread MFMA tiles, 7^3 Toeplitz
     MFMA, sliding-window depthwise, exact-2x trilinear, vectorised stride-2) against the generic kernels they replace.
