@@ -20,7 +20,10 @@
 // prefetch depth 2 -> 4, 4 vs 6 waves per SIMD, two output rows per wave (x fragment of four rows shared by two dY rows: half
 // the input transforms, 2/3 of the x fetches), 64-voxel rows per wave (whole 128-byte lines) or non-power-of-two volumes
 // (96^3, 160^3: same time per voxel) -- those variants were removed again; SQ counters: 51 % of wave cycles waiting on memory,
-// 34 % waiting to issue, SIMD issue slots 59 % busy.
+// 34 % waiting to issue, SIMD issue slots 59 % busy.  Compile-time ablation (tools/abl_wq4.sh, 16 -> 16 g4 @128^3, us without
+// the atomics tail): full 86, MFMAs removed 86, x loads removed 52, dY loads removed 45, both removed 31: the loads cost 55 us
+// ON TOP of 31 us of vector / scalar work -- they do not overlap with it although 12 load sets per SIMD are in flight, and
+// 134 MB in 55 us is 2.4 TB/s: the vector-memory path (16 distinct half-lines per x load, 4-fold replicated dY lanes), not HBM.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 #include "wgrad_q4.h"
@@ -125,12 +128,20 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
     const int po = min(max(p, 0), D - 1) * hw2;
 #pragma unroll
     for (int cq = 0; cq < CI4; ++cq)
+#ifdef WQ4_ABL_NOX
+      raw[cq] = make_uint4(po, x_off, 0, 0);
+#else
       raw[cq] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs[cq], (int)x_off, po, 0));
+#endif
   };
   auto load_dy = [&](int v, uint4& cur, unsigned& ex) {
     const int po = min(max(v, 0), D - 1) * hw2;
+#ifdef WQ4_ABL_NODY
+    cur = make_uint4(po, dy_off, 0, 0); ex = dye_off;
+#else
     cur = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, (int)dy_off, po, 0));
     ex = __builtin_amdgcn_raw_buffer_load_b32(dyrs, (int)dye_off, po, 0);
+#endif
   };
   auto make_a = [&](const uint4& c, unsigned ex) -> frag8 {
     // kw = 2: window one voxel to the left, kw = 0: one to the right, kw = 1: as loaded
@@ -186,12 +197,17 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
         }
         load_x(p + DEPTH, xraw[u]);
         load_dy(p + DEPTH + 1, dcur[u], dex[u]);
+#ifdef WQ4_ABL_NOMFMA
+#pragma unroll
+        for (int cq = 0; cq < CI4; ++cq) asm volatile("" ::"v"(af_p1), "v"(bf[cq]));
+#else
 #pragma unroll
         for (int cq = 0; cq < CI4; ++cq) {             // out plane v = p + 1 - kd
           acc[cq][0] = mfma16x16x32<FMT>(af_p1, bf[cq], acc[cq][0]);
           acc[cq][1] = mfma16x16x32<FMT>(af_0, bf[cq], acc[cq][1]);
           acc[cq][2] = mfma16x16x32<FMT>(af_m1, bf[cq], acc[cq][2]);
         }
+#endif
         af_m1 = af_0;
         af_0 = af_p1;
       }

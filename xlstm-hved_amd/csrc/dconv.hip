@@ -87,23 +87,29 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     const int iw = t % ntw; t /= ntw;
     const int ih = t % a.th.n, id = t / a.th.n;
     const int tap = a.rowmode ? (a.td.t[id] * 3 + a.th.t[ih]) : ((a.td.t[id] * 3 + a.th.t[ih]) * 3 + a.tw.t[iw]);
+    // every load of the step is issued back to back from a clamped (always valid) address and masked afterwards: a guarded
+    // load (`if (in range) load`) costs a branch and an s_waitcnt each and serialises the step's ~8 loads
+    bool okA[NA], okB[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int d = a_sd[i] + a.td.off[id], h = a_sh[i] + a.th.off[ih];
-      int w = a_sw[i] + (a.rowmode ? (ch - 1) : a.tw.off[iw]);
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi) {
-        const u16* p = a.x + ((xs_n + ((long long)d * a.Hi + h) * a.Wi + w) * a.Cs) + (a.rowmode ? 0 : cs * 32 * KQ + ch * 8);
-        ra[i] = *reinterpret_cast<const uint4*>(p);
-      }
+      const int w = a_sw[i] + (a.rowmode ? (ch - 1) : a.tw.off[iw]);
+      okA[i] = a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+      const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
+      const u16* p = a.x + ((xs_n + ((long long)dc * a.Hi + hc) * a.Wi + wc) * a.Cs) + (a.rowmode ? 0 : cs * 32 * KQ + ch * 8);
+      ra[i] = *reinterpret_cast<const uint4*>(p);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int col = tid / CPRW + i * (256 / CPRW);
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (col < BN && cn0 + col < a.Cn)
-        rb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)(cn0 + col) * a.Kc + cs * 32 * KQ + ch * 8);
+      okB[i] = col < BN && cn0 + col < a.Cn;
+      const int cc = min(cn0 + col, a.Cn - 1);
+      rb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)cc * a.Kc + cs * 32 * KQ + ch * 8);
     }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) if (!okA[i]) ra[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) if (!okB[i]) rb[i] = make_uint4(0, 0, 0, 0);
   };
   auto store_step = [&](int buf) {
     unsigned char* As = smem + buf * (AB + BB);
