@@ -139,11 +139,22 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
 #ifdef WQ4_ABL_NODY
     cur = make_uint4(po, dy_off, 0, 0); ex = dye_off;
 #else
-    cur = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, (int)dy_off, po, 0));
-    ex = __builtin_amdgcn_raw_buffer_load_b32(dyrs, (int)dye_off, po, 0);
+    // the four kw lanes of an output channel want the same 16 bytes: only the kw = 1 lane loads them (a quarter of the lane
+    // addresses through the vector-memory path), make_a hands them to its quad by DPP; the neighbour dword is needed by the
+    // kw = 0 / 2 lanes only
+    cur = make_uint4(0, 0, 0, 0);
+    ex = 0;
+    if (kwA == 1) cur = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, (int)dy_off, po, 0));
+    if (left || right) ex = __builtin_amdgcn_raw_buffer_load_b32(dyrs, (int)dye_off, po, 0);
 #endif
   };
-  auto make_a = [&](const uint4& c, unsigned ex) -> frag8 {
+  auto make_a = [&](const uint4& cl, unsigned ex) -> frag8 {
+    // lane 1 of every quad of lanes (kw = 1) holds the loaded 16 bytes: quad broadcast (DPP quad_perm [1, 1, 1, 1])
+    uint4 c;
+    c.x = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.x, 0x55, 0xf, 0xf, true);
+    c.y = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.y, 0x55, 0xf, 0xf, true);
+    c.z = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.z, 0x55, 0xf, 0xf, true);
+    c.w = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.w, 0x55, 0xf, 0xf, true);
     // kw = 2: window one voxel to the left, kw = 0: one to the right, kw = 1: as loaded
     const unsigned l0 = left ? ex : c.x, l1 = left ? c.x : c.y, l2 = left ? c.y : c.z, l3 = left ? c.z : c.w;
     const unsigned h0 = left ? c.x : c.y, h1 = left ? c.y : c.z, h2 = left ? c.z : c.w, h3 = left ? c.w : ex;
