@@ -15,7 +15,7 @@ for (cin, cout, g) in [(4, 4, 1), (16, 16, 4), (12, 4, 1)]:
     dbs = [torch.zeros(cout // g, device="cuda") for _ in range(g)]
     call = lambda: ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=(sc, sh, 0.01))
     line = f"wgrad {cin}->{cout} g{g} @{S}^3:"
-    for m, nm in [(0, "full"), (2048, "no global atomics")]:
+    for m, nm in [(0, "full"), (2048, "no global atomics"), (8192, "own x rows per wave"), (8192 + 2048, "own x rows, no atomics")]:
         L.load().xh_set_option(1, m)
         line += f" {nm} {bench(call):.1f} us |"
     L.load().xh_set_option(1, 0)

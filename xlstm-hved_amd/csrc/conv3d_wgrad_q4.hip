@@ -261,11 +261,231 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
   if (dbp && chunk == 0 && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant with the x operand shared through LDS.  In the body above every wave loads (and transforms) its own three x rows:
+// a workgroup's four waves put 4 KB of lane loads into the vector-memory path per plane for 1.5 KB of distinct data, and that
+// path -- not HBM, not the ALUs -- is what bounds the kernel (file header).  Here the 6 distinct rows of a plane (h0 - 1 ..
+// h0 + 4, 4 CI4 channels, 64 bytes each) are loaded ONCE per workgroup (96 CI4 sixteen-byte items per plane, two planes per
+// round over the 256 threads), transformed once, and written to a 4-plane LDS ring; every wave reads its (ci, kh) fragment
+// from there with one conflict-free ds_read_b128.  One barrier per two planes; the global loads of a round are issued two
+// rounds ahead (4 VGPRs per item in flight).  dY stays per wave (its rows are not shared).
+template <int FMT, int CI4>
+__device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned char* smem) {
+  typedef h16<FMT> ST;
+  constexpr int ROWB = 4 * CI4 * 64 + 32;             // bytes per staged row: 4 CI4 channels x 64 B, + 32 B so that the three kh
+                                                      // rows of a B-fragment read fall on different banks
+  constexpr int PLB = 6 * ROWB;                       // bytes per plane
+  constexpr int NIT = 96 * CI4;                       // 16-byte items per plane
+  constexpr int NI = (NIT + 127) / 128;               // items per thread (a thread serves one of the two planes of a round)
+  constexpr unsigned ONE2 = FMT == 0 ? 0x3F803F80u : 0x3C003C00u;
+  float* s_dw = reinterpret_cast<float*>(smem);       // after the plane loops
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nn = lane & 15, g = lane >> 4;
+  const int unit = b / a.wpu, w = b - unit * a.wpu;
+  const int oq = unit / a.nchunk, chunk = unit - oq * a.nchunk;
+  int t_first, t_stride, t_end;
+  if ((a.ntile & 7) == 0 && (a.wpu & 7) == 0) {
+    const int per = a.ntile >> 3;
+    t_first = (w & 7) * per + (w >> 3); t_stride = a.wpu >> 3; t_end = ((w & 7) + 1) * per;
+  } else {
+    t_first = w; t_stride = a.wpu; t_end = a.ntile;
+  }
+  f32x4 acc[CI4][3];
+#pragma unroll
+  for (int cq = 0; cq < CI4; ++cq)
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) acc[cq][kd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int D = a.D, H = a.H, W = a.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  const int co0 = oq * 4;
+  const int grp = co0 / a.Cout_g;
+  const int cin_base = grp * a.Cin_g + chunk * 4 * CI4;
+  const float pslope = a.pre ? a.pre_slope : 1.f;
+  const int pp = tid >> 7, tl = tid & 127;            // plane of the round this thread stages, id among its 128 threads
+  // B fragment of lane (ci = nn & 3, kh = nn >> 2) in a staged plane; kh = 3 is the constant column (bias gradient)
+  const int ci_l = nn & 3, khB = nn >> 2;
+  const int b_off = (wv + khB) * ROWB + ci_l * 64 + g * 16;
+  const unsigned fillv = ci_l == 0 ? ONE2 : 0u;
+  const int co_l = nn >> 2, kwA = nn & 3;
+  const bool left = kwA == 2, right = kwA == 0;
+  const unsigned shbits = (left || right) ? 16u : 0u;
+  const int hw2 = (int)(hw * 2);
+
+  for (int t = t_first; t < t_end; t += t_stride) {
+    int wk = t;
+    const int tw = wk % a.tilesW; wk /= a.tilesW;
+    const int th = wk % a.tilesH; wk /= a.tilesH;
+    const int ds = wk % a.dsegs;
+    const int n = wk / a.dsegs;
+    const int h0 = th * 4, h = h0 + wv, w0 = tw * 32;
+    const int d0 = ds * a.sd, d1 = min(D, d0 + a.sd);
+    // ---- staging plan of this thread: items tl, tl + 128, ... of a plane = (row r, quad cq, channel ci, chunk gq) ----
+    const ST* i_src[NI];
+    float i_sc[NI], i_sh[NI];
+    int i_lds[NI];
+    bool i_do[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int it = tl + 128 * k;
+      i_do[k] = it < NIT;
+      const int itc = i_do[k] ? it : 0;
+      const int gq = itc & 3, ci = (itc >> 2) & 3, cq = (itc >> 4) % CI4, r = itc / (16 * CI4);
+      const int row = h0 - 1 + r;
+      const bool rok = (unsigned)row < (unsigned)H;
+      const int c = cin_base + cq * 4 + ci;
+      i_src[k] = (c < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)c * dhw : (const ST*)a.xb + n * a.xb_bs + (long long)(c - a.Ca) * dhw) +
+                 (long long)min(max(row, 0), H - 1) * W + w0 + 8 * gq;
+      float sc = 1.f, sh = 0.f;
+      if (a.pre) { sc = a.pre_sc[n * a.Cin + c]; sh = a.pre_sh[n * a.Cin + c]; }
+      i_sc[k] = rok ? sc : 0.f;
+      i_sh[k] = rok ? sh : 0.f;
+      i_lds[k] = r * ROWB + (cq * 4 + ci) * 64 + gq * 16;
+    }
+    // ---- A role (dY): as in wgrad_q4_body ----
+    const __amdgpu_buffer_rsrc_t dyrs = q4_rsrc((const ST*)a.dy + n * a.dy_bs + (long long)co0 * dhw);
+    const unsigned dy_off = (unsigned)(((long long)co_l * dhw + (long long)min(h, H - 1) * W + w0 + 8 * g) * 2);
+    const int wpos = w0 + 8 * g;
+    const int e_off = (left && wpos > 0) ? -2 : (right && wpos + 8 < W) ? 8 : 0;
+    const unsigned m0 = (left && wpos == 0) ? 0xffff0000u : 0xffffffffu;
+    const unsigned m3 = (right && wpos + 8 == W) ? 0x0000ffffu : 0xffffffffu;
+    const unsigned dye_off = dy_off + 2 * e_off;
+    const unsigned rowmask = h < H ? 0xffffffffu : 0u;
+    auto load_dy = [&](int v, uint4& cur, unsigned& ex) {
+      const int po = min(max(v, 0), D - 1) * hw2;
+      cur = make_uint4(0, 0, 0, 0);
+      ex = 0;
+      if (kwA == 1) cur = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, (int)dy_off, po, 0));
+      if (left || right) ex = __builtin_amdgcn_raw_buffer_load_b32(dyrs, (int)dye_off, po, 0);
+    };
+    auto make_a = [&](const uint4& cl, unsigned ex, unsigned amask) -> frag8 {
+      uint4 c;
+      c.x = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.x, 0x55, 0xf, 0xf, true);
+      c.y = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.y, 0x55, 0xf, 0xf, true);
+      c.z = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.z, 0x55, 0xf, 0xf, true);
+      c.w = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.w, 0x55, 0xf, 0xf, true);
+      const unsigned l0 = left ? ex : c.x, l1 = left ? c.x : c.y, l2 = left ? c.y : c.z, l3 = left ? c.z : c.w;
+      const unsigned h0_ = left ? c.x : c.y, h1 = left ? c.y : c.z, h2 = left ? c.z : c.w, h3 = left ? c.w : ex;
+      uint4 o;
+      o.x = __builtin_amdgcn_alignbit(h0_, l0, shbits) & m0 & amask;
+      o.y = __builtin_amdgcn_alignbit(h1, l1, shbits) & amask;
+      o.z = __builtin_amdgcn_alignbit(h2, l2, shbits) & amask;
+      o.w = __builtin_amdgcn_alignbit(h3, l3, shbits) & m3 & amask;
+      return __builtin_bit_cast(frag8, o);
+    };
+    // ---- x staging: round r covers planes d0 - 1 + 2 r (+ pp) ----
+    auto issue = [&](int r, uint4 (&q)[NI]) {
+      const long long po = (long long)min(max(d0 - 1 + 2 * r + pp, 0), D - 1) * hw;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) q[k] = *reinterpret_cast<const uint4*>(i_src[k] + po);
+    };
+    auto commit = [&](int r, const uint4 (&q)[NI]) {
+      const int p = d0 - 1 + 2 * r + pp;
+      const float pm = (unsigned)p < (unsigned)D ? 1.f : 0.f;
+      unsigned char* dst = smem + ((2 * r + pp) & 3) * PLB;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        if (!i_do[k]) continue;
+        const float sc = i_sc[k] * pm, sh = i_sh[k] * pm;
+        const unsigned u[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+        uint4 o;
+        unsigned* op = &o.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x2_t v = cvt2_in<FMT>(u[e]) * f32x2_t{sc, sc} + f32x2_t{sh, sh};
+          const f32x2_t y = max2(v, v * f32x2_t{pslope, pslope});
+          op[e] = cvt2_pack<FMT>(y.x, y.y);
+        }
+        *reinterpret_cast<uint4*>(dst + i_lds[k]) = o;
+      }
+    };
+    frag8 af_m1 = frag8{0, 0, 0, 0, 0, 0, 0, 0}, af_0 = af_m1;
+    auto step = [&](int p, uint4& dc, unsigned& de) {        // x plane p (staged), dY plane p + 1 in (dc, de)
+      const unsigned amask = (p + 1 < d1 ? 0xffffffffu : 0u) & rowmask;
+      const frag8 af_p1 = make_a(dc, de, amask);
+      const unsigned char* src = smem + ((p - (d0 - 1)) & 3) * PLB + b_off;
+      frag8 bf[CI4];
+#pragma unroll
+      for (int cq = 0; cq < CI4; ++cq) {
+        const uint4 r = *reinterpret_cast<const uint4*>(src + cq * 256);
+        const unsigned f = cq == 0 ? fillv : 0u;
+        bf[cq] = __builtin_bit_cast(frag8, khB == 3 ? make_uint4(f, f, f, f) : r);
+      }
+      load_dy(p + 3, dc, de);                                // two steps ahead
+#pragma unroll
+      for (int cq = 0; cq < CI4; ++cq) {
+        acc[cq][0] = mfma16x16x32<FMT>(af_p1, bf[cq], acc[cq][0]);
+        acc[cq][1] = mfma16x16x32<FMT>(af_0, bf[cq], acc[cq][1]);
+        acc[cq][2] = mfma16x16x32<FMT>(af_m1, bf[cq], acc[cq][2]);
+      }
+      af_m1 = af_0;
+      af_0 = af_p1;
+    };
+    const int nround = ((d1 - d0 + 2 + 1) / 2 + 1) & ~1;     // rounds of two planes, an even number of them
+    uint4 qa[NI], qb[NI], dcur0, dcur1;
+    unsigned dex0, dex1;
+    __syncthreads();                                         // the previous tile's planes are no longer read
+    issue(0, qa);
+    issue(1, qb);
+    load_dy(d0, dcur0, dex0);
+    load_dy(d0 + 1, dcur1, dex1);
+    commit(0, qa);
+    issue(2, qa);
+    for (int r = 0; r < nround; r += 2) {
+      __syncthreads();                                       // round r staged; round r - 1 fully read
+      commit(r + 1, qb);
+      issue(r + 3, qb);
+      step(d0 - 1 + 2 * r, dcur0, dex0);
+      step(d0 + 2 * r, dcur1, dex1);
+      __syncthreads();                                       // round r + 1 staged; round r fully read
+      commit(r + 2, qa);
+      issue(r + 4, qa);
+      step(d0 + 1 + 2 * r, dcur0, dex0);
+      step(d0 + 2 + 2 * r, dcur1, dex1);
+    }
+  }   // tiles
+
+  // ---- sum the four rows of the workgroup in LDS (the plane ring is free now), then one pass of fp32 atomics ----
+  constexpr int NW = 4 * 4 * CI4 * 27;
+  __syncthreads();
+  for (int i = tid; i < NW + 4; i += 256) s_dw[i] = 0.f;
+  __syncthreads();
+  {
+    const int kh = nn >> 2, ci = nn & 3;
+    if (kh < 3) {
+#pragma unroll
+      for (int cq = 0; cq < CI4; ++cq)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            atomicAdd(&s_dw[(g * 4 * CI4 + cq * 4 + ci) * 27 + kd * 9 + kh * 3 + r], acc[cq][kd][r]);
+    } else if (ci == 0) {
+      atomicAdd(&s_dw[NW + g], acc[0][1][1]);
+    }
+  }
+  __syncthreads();
+  if (a.abl & 2048) return;
+  const int gpp = a.groups / a.n_wptr;
+  float* dwp = a.dw[grp / gpp];
+  const int gl = grp % gpp;
+  for (int i = tid; i < NW; i += 256) {
+    const int tap = i % 27;
+    const int r = i / 27;
+    const int ci = r % (4 * CI4), c = r / (4 * CI4);
+    const int co_g = (co0 + c) % a.Cout_g;
+    atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + chunk * 4 * CI4 + ci) * 27 + tap, s_dw[i]);
+  }
+  float* dbp = a.db[grp / gpp];
+  if (dbp && chunk == 0 && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
+}
+
 // resident workgroups per CU (= waves per SIMD) each instance is built for: 75 / 127 / 143 VGPRs, no spills
 constexpr int wq4_waves(int ci4) { return ci4 == 1 ? 6 : ci4 == 2 ? 4 : 3; }
-template <int FMT, int CI4>
-__global__ __launch_bounds__(256, wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
-  __shared__ float s_dw[4 * 4 * CI4 * 27 + 4];
+template <int FMT, int CI4, bool LDSX>
+__global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
+  constexpr int RING = 4 * 6 * (4 * CI4 * 64 + 32) + 4 * CI4 * 64 + 64;      // four planes (+ the row the constant column "reads")
+  constexpr int RED = (4 * 4 * CI4 * 27 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDSX && RING > RED ? RING : RED];
   const int b = blockIdx.x;
   int i = 0;
 #pragma unroll
@@ -274,7 +494,8 @@ __global__ __launch_bounds__(256, wq4_waves(CI4)) void conv3_wgrad_q4_multi_kern
   const int local = b - m.off[i];
   const WgQ4& a = m.p[i];
   if (local >= a.nb) return;
-  wgrad_q4_body<FMT, CI4>(a, local, s_dw);
+  if constexpr (LDSX) wgrad_q4_body_lds<FMT, CI4>(a, local, smem);
+  else wgrad_q4_body<FMT, CI4>(a, local, reinterpret_cast<float*>(smem));      // A/B: every wave loads its own x rows
 }
 
 // fills the plan; false when the shape is not for this kernel
@@ -330,7 +551,8 @@ void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   m.off[0] = 0;
   const int ci4 = probs[0].ci4;
   // workgroups per launch: all resident at once, dealt to the units in proportion to their tiles
-  const int budget = wq4_waves(ci4) * 256;
+  extern int g_mfma_abl;
+  const int budget = ((g_mfma_abl & 8192) ? wq4_waves(ci4) : (ci4 == 1 ? 5 : ci4 == 2 ? 4 : 3)) * 256;
   double total = 0.0;
   for (int i = 0; i < n; ++i) total += (double)probs[i].nq * probs[i].ntile;
   for (int i = 0; i < n; ++i) {
@@ -344,8 +566,13 @@ void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
     a.nb = a.nq * w;
     m.off[i + 1] = m.off[i] + ((a.nb + 7) & ~7);
   }
-  xh_note_kernel("conv3_wgrad_q4_multi_kernel<%d, %d>", fmt, ci4);
-#define WQL(F, C) hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<F, C>), dim3(m.off[n]), dim3(256), 0, st, m)
+  const bool ldsx = !(g_mfma_abl & 8192);              // ablation bit 8192: the variant in which every wave loads its own x rows
+  xh_note_kernel("conv3_wgrad_q4_multi_kernel<%d, %d, %s>", fmt, ci4, ldsx ? "true" : "false");
+#define WQL(F, C)                                                                                                        \
+  do {                                                                                                                   \
+    if (ldsx) hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<F, C, true>), dim3(m.off[n]), dim3(256), 0, st, m);         \
+    else hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<F, C, false>), dim3(m.off[n]), dim3(256), 0, st, m);             \
+  } while (0)
   if (fmt) { if (ci4 == 1) WQL(1, 1); else if (ci4 == 2) WQL(1, 2); else WQL(1, 3); }
   else { if (ci4 == 1) WQL(0, 1); else if (ci4 == 2) WQL(0, 2); else WQL(0, 3); }
 #undef WQL
