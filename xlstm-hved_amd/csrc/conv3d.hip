@@ -1112,6 +1112,9 @@ static int g_dw_minsd = 0;     // key 6: fewest planes a depthwise sliding-windo
 static int g_dw_target = 1024; // key 7: workgroup count the depth split of the sliding-window kernels aims at
 static int g_c1w_wgs = 320;    // key 8: workgroup count the k = 1 weight gradient aims at
 static int g_c1_cap = 0;       // key 10: workgroup cap of the k = 1 forward kernel (0 = the built-in rule)
+static int g_wg_slabs = 512;   // key 13: workgroup target of the vector weight-gradient kernel (1 -> 2 k3 @128^3: 75 us with 2048, 40 us with 512)
+static int g_s2w_cap = 512;    // key 12: workgroup cap of the vectorised stride-2 weight gradient (4096: 98 us at 128^3, 512: 41 us -- each workgroup
+                               // ends with a 56-value block reduction and 54 atomics on addresses shared by the whole (channel, group))
 
 // Planes per sliding-window segment: at 128^3 the kernels are issue-bound and the two halo planes per segment cost more
 // than the extra workgroups return (8 planes); at 64^3 / 32^3 the launch is a latency chain of one load per plane over
@@ -1283,6 +1286,8 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 7) { g_dw_target = value < 1 ? 1 : value; return XH_OK; }
   if (key == 8) { g_c1w_wgs = value < 1 ? 320 : value; return XH_OK; }
   if (key == 10) { g_c1_cap = value < 0 ? 0 : value; return XH_OK; }
+  if (key == 12) { g_s2w_cap = value < 16 ? 16 : value; return XH_OK; }
+  if (key == 13) { g_wg_slabs = value < 16 ? 16 : value; return XH_OK; }
   if (key == 11) { extern int g_q4_maxc; g_q4_maxc = value < 4 ? 4 : value > 48 ? 48 : value; return XH_OK; }
   if (key == 9) { extern int g_red_wgs; g_red_wgs = value < 0 ? 0 : value; return XH_OK; }
   if (key == 5) { extern int g_dconv_kq; g_dconv_kq = value == 1 ? 1 : 2; return XH_OK; }
@@ -1800,7 +1805,7 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
       wa.c = make_k(d, p, 1, 8);
       const long long lanes = (long long)d->Do * d->Ho * lw;
       long long gx = (lanes + 255) / 256;
-      const long long cap = cdiv(4096, cin_g * d->groups * d->N);          // few enough workgroups that the atomics tail stays small
+      const long long cap = cdiv(g_s2w_cap, cin_g * d->groups * d->N);     // few enough workgroups that the atomics tail stays small
       if (gx > cap) gx = cap;
       if (gx < 1) gx = 1;
       dim3 grid((unsigned)gx, cin_g, d->N * d->groups);
@@ -1817,7 +1822,7 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
   wa.tiles_total = tiles * d->N;
   // enough slabs to fill the chip, few enough that the end-of-block reduction amortises
   const int ny = cin_g * wa.c.ncob * (d->k == 7 ? 7 : 1) * d->groups;
-  int slabs = cdiv(2048, ny);
+  int slabs = cdiv(g_wg_slabs, ny);
   if (slabs > wa.tiles_total) slabs = wa.tiles_total;
   if (slabs < 1) slabs = 1;
   wa.tiles_per_block = cdiv(wa.tiles_total, slabs);
