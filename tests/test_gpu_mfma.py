@@ -234,7 +234,7 @@ def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape, dtype):
 # InstanceNorm+LeakyReLU prologue and the output-moments epilogue (epi 2), data gradient with the norm-backward epilogue
 # (epi 1, inside InLreluConv.backward), weight and bias gradients.
 BIG = [
-    dict(cin=4, cout=4, groups=1),                 # conv3_mfma_tile4_kernel<F, 8> (whole-tile kernel for <= 4 input channels): decoder level 0 second conv, skr encoder
+    dict(cin=4, cout=4, groups=1),                 # decoder level 0 second conv, skr encoder; gemm path: conv3_mfma_kernel<F, 4, 256, 32, 8>
     dict(cin=12, cout=4, groups=1, split=4),       # <F, 12, 256, 32, 8>: decoder level 0 first conv on the virtual concat
     dict(cin=16, cout=16, groups=4),               # <F, 16, 256, 32, 8>: the four modality encoders, level 0
 ]
@@ -272,7 +272,7 @@ def _full_size_128(cfg, dtype, path):
     if path == "q4":
         big_ok = lambda k: "conv3_q4_kernel" in k
     else:
-        big_ok = lambda k: ("conv3_mfma_kernel" in k and ", 256, 32, 8, 2>" in k) or "conv3_mfma_tile4_kernel" in k   # <= 4 input channels: whole-tile kernel
+        big_ok = lambda k: "conv3_mfma_kernel" in k and ", 256, 32, 8, 2>" in k
     assert big_ok(k_fwd), k_fwd
     (y.float() * wgt.to(DEV)).sum().backward()
     k_bwd = X.ops.last_conv_kernel()              # the data gradient is the last conv launch of InLreluConv.backward
