@@ -424,11 +424,7 @@ def set_wgrad_defer(enabled):
     _WG["defer"] = bool(enabled)
 
 
-def _flush_deferred():
-    calls = _WG["deferred"]
-    if not calls:
-        return
-    _WG["deferred"] = []
+def _batch_call(calls):
     n = len(calls)
     descs = (C.POINTER(L.ConvDesc) * n)(*[C.pointer(c[0]) for c in calls])
     ptrs = (C.POINTER(L.ConvPtrs) * n)(*[C.pointer(c[1]) for c in calls])
@@ -439,6 +435,50 @@ def _flush_deferred():
             dws[i][j] = c[2][j]
             dbs[i][j] = c[3][j]
     L.check(L.load().xh_conv3d_wgrad_batch(_stream(), n, descs, ptrs, dws, dbs), "xh_conv3d_wgrad_batch")
+
+
+def set_wgrad_flush_streams(n):
+    """The deferred weight gradients are independent of each other and of everything after them: with n > 1 the flush
+    forks n - 1 extra HIP streams, deals the problems to them by kernel family (so that the batched k=3 launches stay
+    together) and joins once -- the small latency-bound launches run side by side.  Capture-safe (fork / join through
+    stream waits).  Default 1: MEASURED SLOWER on MI355X (hipGraph replay of the 128^3 step: 6.47 ms with 1 stream, 6.80
+    with 2, 7.82 with 3, 9.14 with 4) -- every launch is already sized to fill the chip, so concurrent launches only contend;
+    kept as an A/B knob (bench.py --wgrad-flush-streams)."""
+    _WG["flush_streams"] = max(1, int(n))
+
+
+def _flush_deferred():
+    calls = _WG["deferred"]
+    if not calls:
+        return
+    _WG["deferred"] = []
+    ns = _WG.get("flush_streams", 1)
+    if ns <= 1 or len(calls) < 2 * ns:
+        return _batch_call(calls)
+    dev = torch.cuda.current_device()
+    pool = _WG.setdefault("flush_pool", {}).setdefault(dev, [])
+    while len(pool) < ns - 1:
+        pool.append(torch.cuda.Stream(dev))
+    # group 0 (current stream): the k = 3 problems (batched launches); the others round-robin over the side streams
+    groups = [[] for _ in range(ns)]
+    rest = 0
+    for c in calls:
+        if c[0].k == 3 and c[0].stride == 1 and c[0].Cin // c[0].groups >= 4:
+            groups[0].append(c)
+        else:
+            groups[1 + rest % (ns - 1)].append(c)
+            rest += 1
+    cur = torch.cuda.current_stream(dev)
+    for i in range(1, ns):
+        if groups[i]:
+            pool[i - 1].wait_stream(cur)
+            with torch.cuda.stream(pool[i - 1]):
+                _batch_call(groups[i])
+    if groups[0]:
+        _batch_call(groups[0])
+    for i in range(1, ns):
+        if groups[i]:
+            cur.wait_stream(pool[i - 1])
 
 
 # ----------------------------------------------------------------------------------------------- norms
