@@ -13,13 +13,14 @@ import xlstm_hved_amd as X  # noqa: E402
 DEV = "cuda"
 
 
-def _grads(mode, graph, dtype=torch.bfloat16):
+def _grads(mode, graph, dtype=torch.bfloat16, size=64):
     m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     m.load_state_dict(load("weights_seed1"), strict=True)
     m = m.to(DEV).train()
     torch.manual_seed(3)
-    x = torch.rand(1, 4, 64, 64, 64).to(DEV, dtype)
-    eps = [torch.randn(1, 2 ** l, 32 >> l, 32 >> l, 32 >> l).to(DEV, dtype) for l in range(4)]
+    x = torch.rand(1, 4, size, size, size).to(DEV, dtype)
+    h = size // 2
+    eps = [torch.randn(1, 2 ** l, h >> l, h >> l, h >> l).to(DEV, dtype) for l in range(4)]
     fg = X.parallel.FlatGrads(m.parameters())
     X.ops.set_wgrad_overlap(mode == "side")
     X.ops.set_wgrad_defer(mode == "defer")
@@ -65,3 +66,21 @@ def test_deferred_batch_fp16_and_batch2():
     a = _grads("plain", False, torch.float16)
     b = _grads("defer", False, torch.float16)
     assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item()
+
+
+def test_bench_configuration_128_graph_replay_matches_eager():
+    """The benchmarked configuration itself (128^3, bf16, deferred weight gradients, prepacked fragments, statistics fan-in --
+    the launches with >= 256 workgroups per channel block only exist at this size): three hipGraph replays give the gradients
+    of the eager step, and the fan-in path gives those of the direct-atomics path (xh_set_option(2, 64))."""
+    lib = X._lib.load()
+    a = _grads("defer", False, size=128)
+    b = _grads("defer", True, size=128)
+    lib.xh_set_option(2, 64)
+    try:
+        c = _grads("defer", False, size=128)
+    finally:
+        lib.xh_set_option(2, 0)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 5e-4 * scale, (a - b).abs().max().item() / scale
+    assert (a - c).abs().max().item() <= 5e-4 * scale, (a - c).abs().max().item() / scale
