@@ -20,6 +20,13 @@
 //  * the epilogue variant (none / output moments / norm-backward sums) and the input transform are template arguments.
 // One workgroup (4 waves) = an 8 x 8 x 32 (D x H x W) block of outputs of ONE output-channel quad; more input channels are
 // walked quad by quad through the same 28.8 KB LDS tile (4-5 workgroups per CU hide each other's staging phase).
+//
+// Measured on MI355X (tools/microbench_big.py --abl, 16 -> 16 g4 @128^3 forward without statistics, 39.5 us): staging
+// 23.7 us, matrix phase + epilogue 13.2 us, launch 2.6 us; statistics + fan-in add 10 us.  SQ counters: the SIMDs' issue slots
+// are 91 % busy (4.1 cycles per instruction): instruction-issue bound, which is why phases of different workgroups do not
+// hide each other.  Tried and dropped: loads of the next input quad issued under the matrix phase of the current one
+// (needs 154-168 VGPRs = 3 workgroups per CU: 12 -> 4 @128^3 33 -> 38 us, the 64^3 / 32^3 shapes unchanged -- those are
+// latency chains of a few dozen workgroups).
 #include "common.h"
 #include "conv_pack.h"
 #include "fanin.h"
