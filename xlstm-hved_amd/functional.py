@@ -51,12 +51,18 @@ def _targets(params):
             bufs.append(None)
             rets.append(None)
             need.append(i)
-    if need:                                  # one zero-fill for all of them (16-float aligned views)
+    if need:                                  # one zero buffer for all of them (16-float aligned views)
         offs, total = [], 0
         for i in need:
             offs.append(total)
             total += (params[i].numel() + 15) // 16 * 16
-        flat = torch.zeros(total, dtype=torch.float32, device=params[need[0]].device)
+        # Gradients of NON-leaf weights (composed 7^3 / head weights) only travel through autograd to the compose kernels
+        # within this backward: a slice of the per-step fp32 zero arena serves (no fill launch).  A LEAF parameter without a
+        # .grad may have the returned tensor adopted as its .grad by AccumulateGrad -- that must be private storage.
+        if all(not params[i].is_leaf for i in need):
+            flat = ops.zeros_f32(params[need[0]].device, total)
+        else:
+            flat = torch.zeros(total, dtype=torch.float32, device=params[need[0]].device)
         for i, o in zip(need, offs):
             z = flat[o:o + params[i].numel()].view(params[i].shape)
             bufs[i] = rets[i] = z

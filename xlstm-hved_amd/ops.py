@@ -102,6 +102,26 @@ def zeros_f64(device, shape):
     return t
 
 
+# fp32 twin of the arena: zero-initialised gradient buffers of weights that are not leaf parameters (composed 7^3 / head
+# weights: their gradients go through autograd to the compose kernels) -- ~11 small fills per backward otherwise.  Slices
+# are handed out during backward and consumed before it ends; the reset at the start of the next forward zeroes them again.
+_ARENA32_FLOATS = 1 << 20         # 4 MiB
+_ARENA32 = {}
+
+
+def zeros_f32(device, numel):
+    a = _ARENA32.get(device)
+    if a is None:
+        a = _ARENA32[device] = [torch.zeros(_ARENA32_FLOATS, dtype=torch.float32, device=device), 0, 0]
+    need = (int(numel) + 15) & ~15
+    if a[1] + need > _ARENA32_FLOATS:
+        return torch.zeros(int(numel), dtype=torch.float32, device=device)
+    t = a[0][a[1]:a[1] + int(numel)]
+    a[1] += need
+    a[2] = max(a[2], a[1])
+    return t
+
+
 def red_arena_reset(device):
     """Zeroes the arena up to its HIGH-WATER mark (one fill) and starts over.  Called where no arena slice is live: the
     start of the network's forward().  The high-water mark (largest extent ever handed out, captures included) rather than
@@ -111,6 +131,10 @@ def red_arena_reset(device):
     if a is not None and a[2] > 0:
         a[0][:a[2]].zero_()
         a[1] = 0
+    b = _ARENA32.get(device)
+    if b is not None and b[2] > 0:
+        b[0][:b[2]].zero_()
+        b[1] = 0
 
 
 def zeros_red(t, n, c):
