@@ -22,13 +22,24 @@ typedef unsigned short u16;
 
 struct DTaps { int n; int t[3]; int off[3]; };
 
+// One class of destination voxels.  Forward / stride-1 data gradient: a single class = all of them.  Stride-2 data gradient:
+// the 8 parity classes (destination = 2 j + p per axis), each with the taps that reach it (1 or 2 per axis); they travel in ONE
+// launch, heaviest first (8 taps .. 1 tap), so that the short classes fill the tail of the long ones instead of running as
+// eight under-filled launches one after the other.
+struct DClass {
+  int Jd, Jh, Jw;          // rows of this class per sample: (jd, jh, jw), destination index = j * omul + p
+  int pd, ph, pw;
+  int tile0;               // first row tile (blockIdx.x) of the class
+  DTaps td, th, tw;
+};
+
 struct DConvK {
   const u16* x; const u16* w; const float* bias; u16* y; double* red;
   int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn;
-  int Jd, Jh, Jw;          // rows of this launch per sample: (jd, jh, jw), destination index = j * omul + p
-  int omul, pd, ph, pw;
+  int omul;
   int smul;                // source index = j * smul + off[tap]
-  DTaps td, th, tw;
+  int ncls;
+  DClass c[8];
   int rowmode;             // 1: Cs == 8: one K step = the 3 kw taps x 8 channels of a row (+ 8 zero-weight), tw ignored
   int act; float slope;
   int wtap_stride;         // elements between consecutive taps in w (= Cn * Kc)
@@ -58,8 +69,13 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WGN, wn = wv % WGN;
   const int r16 = lane & 15, kg = lane >> 4;
-  const int n = blockIdx.z, mt = blockIdx.x, cn0 = blockIdx.y * BN;
-  const int R = a.Jd * a.Jh * a.Jw;
+  const int n = blockIdx.z, cn0 = blockIdx.y * BN;
+  int ci = 0;
+  for (int k = 1; k < a.ncls; ++k)
+    if ((int)blockIdx.x >= a.c[k].tile0) ci = k;
+  const DClass& cl = a.c[ci];
+  const int mt = blockIdx.x - cl.tile0;
+  const int R = cl.Jd * cl.Jh * cl.Jw;
 
   // ---- staging plan: A rows (source voxel base coordinates), B columns ----
   int a_row[NA], a_sd[NA], a_sh[NA], a_sw[NA];
@@ -71,29 +87,29 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     a_row[i] = row;
     a_ok[i] = m < R;
     const int mm = a_ok[i] ? m : 0;
-    const int jw = mm % a.Jw, t2 = mm / a.Jw;
-    const int jh = t2 % a.Jh, jd = t2 / a.Jh;
+    const int jw = mm % cl.Jw, t2 = mm / cl.Jw;
+    const int jh = t2 % cl.Jh, jd = t2 / cl.Jh;
     a_sd[i] = jd * a.smul; a_sh[i] = jh * a.smul; a_sw[i] = jw * a.smul;
   }
   const int ch = tid % CPRW;
   const long long xs_n = (long long)n * a.Di * a.Hi * a.Wi;
   uint4 ra[NA], rb[NB];
   const int nsteps_c = a.rowmode ? 1 : a.Cs / (32 * KQ);
-  const int ntw = a.rowmode ? 1 : a.tw.n;
-  const int nsteps = a.td.n * a.th.n * ntw * nsteps_c;
+  const int ntw = a.rowmode ? 1 : cl.tw.n;
+  const int nsteps = cl.td.n * cl.th.n * ntw * nsteps_c;
 
   auto load_step = [&](int s) {
     const int cs = s % nsteps_c; int t = s / nsteps_c;
     const int iw = t % ntw; t /= ntw;
-    const int ih = t % a.th.n, id = t / a.th.n;
-    const int tap = a.rowmode ? (a.td.t[id] * 3 + a.th.t[ih]) : ((a.td.t[id] * 3 + a.th.t[ih]) * 3 + a.tw.t[iw]);
+    const int ih = t % cl.th.n, id = t / cl.th.n;
+    const int tap = a.rowmode ? (cl.td.t[id] * 3 + cl.th.t[ih]) : ((cl.td.t[id] * 3 + cl.th.t[ih]) * 3 + cl.tw.t[iw]);
     // every load of the step is issued back to back from a clamped (always valid) address and masked afterwards: a guarded
     // load (`if (in range) load`) costs a branch and an s_waitcnt each and serialises the step's ~8 loads
     bool okA[NA], okB[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int d = a_sd[i] + a.td.off[id], h = a_sh[i] + a.th.off[ih];
-      const int w = a_sw[i] + (a.rowmode ? (ch - 1) : a.tw.off[iw]);
+      const int d = a_sd[i] + cl.td.off[id], h = a_sh[i] + cl.th.off[ih];
+      const int w = a_sw[i] + (a.rowmode ? (ch - 1) : cl.tw.off[iw]);
       okA[i] = a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
       const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
       const u16* p = a.x + ((xs_n + ((long long)dc * a.Hi + hc) * a.Wi + wc) * a.Cs) + (a.rowmode ? 0 : cs * 32 * KQ + ch * 8);
@@ -197,9 +213,9 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     const int row = c / CPR, part = c % CPR;
     const int m = mt * BM + row;
     if (m >= R) continue;
-    const int jw = m % a.Jw, t2 = m / a.Jw;
-    const int jh = t2 % a.Jh, jd = t2 / a.Jh;
-    const long long vox = ys_n + ((long long)(jd * a.omul + a.pd) * a.Ho + (jh * a.omul + a.ph)) * a.Wo + (jw * a.omul + a.pw);
+    const int jw = m % cl.Jw, t2 = m / cl.Jw;
+    const int jh = t2 % cl.Jh, jd = t2 / cl.Jh;
+    const long long vox = ys_n + ((long long)(jd * a.omul + cl.pd) * a.Ho + (jh * a.omul + cl.ph)) * a.Wo + (jw * a.omul + cl.pw);
     const int cn = cn0 + part * 8;
     if (cn + 8 <= a.Cn && (a.Cn & 7) == 0) {
       *reinterpret_cast<uint4*>(a.y + vox * a.Cn + cn) = *reinterpret_cast<const uint4*>(s_out + row * BN + part * 8);
@@ -626,16 +642,36 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
   t->n = 2; t->t[0] = 0; t->off[0] = 1; t->t[1] = 2; t->off[1] = 0;
 }
 
+// Tile shape per launch (xh_set_option(14, mask) switches the choices off one by one for A/B measurements):
+//   Cn <= 16          256 x 16   (the 8-channel ends)
+//   Cn <= 64          256 x 64   (a 128-wide tile would be half padding: first conv forward, 64 <- 128 data gradient); K step 32
+//   < 256 tiles       64 x 128   (256 -> 512 @32^3 forward has 128 tiles of 128 x 128: half of the CUs idle)
+//   else              128 x 128
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no 64 x 128
 template <int FMT>
-static void launch_dconv(hipStream_t st, const DConvK& a, int N) {
-  const int R = a.Jd * a.Jh * a.Jw;
-  if (a.Cn <= 16) {
-    dim3 grid(cdiv(R, 256), cdiv(a.Cn, 16), N);
-    hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1>), grid, dim3(256), 0, st, a);
+static void launch_dconv(hipStream_t st, DConvK& a, int N) {
+  extern int g_dconv_kq;
+  const bool kq2 = !a.rowmode && (a.Cs % 64) == 0 && g_dconv_kq == 2;
+  int bm, bn, cfg;
+  if (a.Cn <= 16) { bm = 256; bn = 16; cfg = 0; }
+  else if (a.Cn <= 64 && !(g_dconv_cfg & 2)) { bm = 256; bn = 64; cfg = 1; }
+  else {
+    long long tiles = 0;
+    for (int k = 0; k < a.ncls; ++k) tiles += cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, 128);
+    tiles *= (long long)cdiv(a.Cn, 128) * N;
+    if (tiles < 256 && !(g_dconv_cfg & 4)) { bm = 64; bn = 128; cfg = 3; }
+    else { bm = 128; bn = 128; cfg = 2; }
+  }
+  int t = 0;
+  for (int k = 0; k < a.ncls; ++k) { a.c[k].tile0 = t; t += cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, bm); }
+  dim3 grid(t, cdiv(a.Cn, bn), N);
+  if (cfg == 0) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1>), grid, dim3(256), 0, st, a);
+  else if (cfg == 1) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 4>), grid, dim3(256), 0, st, a);
+  else if (cfg == 3) {
+    if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 2>), grid, dim3(256), 0, st, a);
   } else {
-    dim3 grid(cdiv(R, 128), cdiv(a.Cn, 128), N);
-    extern int g_dconv_kq;
-    if (!a.rowmode && (a.Cs % 64) == 0 && g_dconv_kq == 2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4, 2>), grid, dim3(256), 0, st, a);
+    if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4>), grid, dim3(256), 0, st, a);
   }
 }
@@ -666,15 +702,32 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
     return xh_launch_status();
   }
   const int classes = (mode == 1 && stride == 2) ? 8 : 1;
-  for (int cls = 0; cls < classes; ++cls) {
+  a.omul = classes == 8 ? 2 : 1;
+  a.smul = mode == 0 ? stride : 1;
+  // heaviest class first: parity 1 on an axis = 2 taps on it
+  static const int order[8] = {7, 6, 5, 3, 4, 2, 1, 0};
+  DClass all[8];
+  int nc = 0;
+  for (int k = 0; k < classes; ++k) {
+    const int cls = classes == 8 ? order[k] : 0;
     const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-    a.omul = classes == 8 ? 2 : 1; a.pd = pd; a.ph = ph; a.pw = pw;
-    a.smul = mode == 0 ? stride : 1;
-    a.Jd = classes == 8 ? (Do - pd + 1) / 2 : Do;
-    a.Jh = classes == 8 ? (Ho - ph + 1) / 2 : Ho;
-    a.Jw = classes == 8 ? (Wo - pw + 1) / 2 : Wo;
-    if (a.Jd <= 0 || a.Jh <= 0 || a.Jw <= 0) continue;
-    fill_taps(&a.td, mode, stride, pd); fill_taps(&a.th, mode, stride, ph); fill_taps(&a.tw, mode, stride, pw);
+    DClass& c = all[nc];
+    c.pd = pd; c.ph = ph; c.pw = pw; c.tile0 = 0;
+    c.Jd = classes == 8 ? (Do - pd + 1) / 2 : Do;
+    c.Jh = classes == 8 ? (Ho - ph + 1) / 2 : Ho;
+    c.Jw = classes == 8 ? (Wo - pw + 1) / 2 : Wo;
+    if (c.Jd <= 0 || c.Jh <= 0 || c.Jw <= 0) continue;
+    fill_taps(&c.td, mode, stride, pd); fill_taps(&c.th, mode, stride, ph); fill_taps(&c.tw, mode, stride, pw);
+    ++nc;
+  }
+  if (g_dconv_cfg & 1) {
+    for (int k = 0; k < nc; ++k) {
+      a.ncls = 1; a.c[0] = all[k];
+      if (dtype == XH_F16) launch_dconv<1>(st, a, N); else launch_dconv<0>(st, a, N);
+    }
+  } else if (nc > 0) {
+    a.ncls = nc;
+    for (int k = 0; k < nc; ++k) a.c[k] = all[k];
     if (dtype == XH_F16) launch_dconv<1>(st, a, N); else launch_dconv<0>(st, a, N);
   }
   return xh_launch_status();
