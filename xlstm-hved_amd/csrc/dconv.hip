@@ -29,7 +29,7 @@ struct DTaps { int n; int t[3]; int off[3]; };
 struct DClass {
   int Jd, Jh, Jw;          // rows of this class per sample: (jd, jh, jw), destination index = j * omul + p
   int pd, ph, pw;
-  int tile0;               // first row tile (blockIdx.x) of the class
+  int tile0, ntile;        // row tiles (blockIdx.x) of the class: [tile0, tile0 + ntile)
   DTaps td, th, tw;
 };
 
@@ -38,7 +38,7 @@ struct DConvK {
   int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn;
   int omul;
   int smul;                // source index = j * smul + off[tap]
-  int ncls;
+  int ncls, xcd;
   DClass c[8];
   int rowmode;             // 1: Cs == 8: one K step = the 3 kw taps x 8 channels of a row (+ 8 zero-weight), tw ignored
   int act; float slope;
@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   for (int k = 1; k < a.ncls; ++k)
     if ((int)blockIdx.x >= a.c[k].tile0) ci = k;
   const DClass& cl = a.c[ci];
-  const int mt = blockIdx.x - cl.tile0;
+  // workgroups go round the 8 XCDs in blockIdx order: hand every XCD a contiguous run of the class's row tiles, so that the
+  // rows its taps share (h +- 1, d +- 1) are re-read from its own L2 instead of the fabric
+  int mt = blockIdx.x - cl.tile0;
+  if (a.xcd && !(cl.tile0 & 7) && !(cl.ntile & 7)) mt = xcd_swizzle(mt, cl.ntile);
   const int R = cl.Jd * cl.Jh * cl.Jw;
 
   // ---- staging plan: A rows (source voxel base coordinates), B columns ----
@@ -237,7 +240,9 @@ struct DWgK {
 // ((row & 3) << 2) | ((row >> 2) & 3)  (conflict-free ds_read_b64_tr_b16 of 4-row blocks)
 __device__ __forceinline__ int sw256(int row, int chunk) { return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
 
-template <int FMT, int WGN, int TMW, int TNW>
+// PAIR (Cs == 64): a 128-wide X tile would be half padding, so two consecutive taps share it -- columns 0..63 = tap 2z,
+// 64..127 = tap 2z + 1 (14 pairs; the odd one out has an empty second half): dY is streamed 14 times instead of 27
+template <int FMT, int WGN, int TMW, int TNW, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
   // waves: WGM x WGN over (cn, cs); a wave owns TMW x TNW tiles of 16 x 16
   constexpr int WGM = 4 / WGN;
@@ -248,7 +253,11 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
   const int wm = wv / WGN, wn = wv % WGN;
   const int r16 = lane & 15, kg = lane >> 4, q = r16 >> 2, p = r16 & 3;
   const int cs0 = blockIdx.x * BNc, cn0 = blockIdx.y * BMc;
-  const int tap = blockIdx.z % 27, split = blockIdx.z / 27;
+  constexpr int NTZ = PAIR ? 14 : 27;
+  const int tz = blockIdx.z % NTZ, split = blockIdx.z / NTZ;
+  // the X chunk a thread stages is the same in every step (chunk = tid & 15): its tap is a per-thread constant
+  const int tap = PAIR ? 2 * tz + ((tid & 15) >> 3) : tz;
+  const bool tap_ok = tap < 27;
   const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
   const long long per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
   const long long m_begin = (long long)split * per, m_end = m_begin + per < a.M ? m_begin + per : a.M;
@@ -263,14 +272,15 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
       ry[i] = rx[i] = make_uint4(0, 0, 0, 0);
       if (m < m_end) {
         if (cn0 + chn * 8 < a.Cn && chn * 8 < BMc) ry[i] = *reinterpret_cast<const uint4*>(a.dy + m * a.Cn + cn0 + chn * 8);
-        if (cs0 + chn * 8 < a.Cs && chn * 8 < BNc) {
+        if (PAIR ? tap_ok : (cs0 + chn * 8 < a.Cs && chn * 8 < BNc)) {
           long long t = m;
           const int ow = (int)(t % a.Wo); t /= a.Wo;
           const int oh = (int)(t % a.Ho); t /= a.Ho;
           const int od = (int)(t % a.Do); const int n = (int)(t / a.Do);
           const int d = od * a.stride + kd - 1, h = oh * a.stride + kh - 1, w = ow * a.stride + kw - 1;
           if ((unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi)
-            rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)n * a.Di + d) * a.Hi + h) * a.Wi + w) * a.Cs + cs0 + chn * 8);
+            rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)n * a.Di + d) * a.Hi + h) * a.Wi + w) * a.Cs +
+                                                    (PAIR ? (chn & 7) * 8 : cs0 + chn * 8));
         }
       }
     }
@@ -332,11 +342,13 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
   for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
-      const int cs = cs0 + (wn * TNW + j) * 16 + r16;
+      const int col = (wn * TNW + j) * 16 + r16;
+      const int cs = PAIR ? (col & 63) : cs0 + col;
+      const int otap = PAIR ? 2 * tz + (col >> 6) : tz;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cn = cn0 + (wm * TMW + i) * 16 + kg * 4 + r;
-        if (cn < a.Cn && cs < a.Cs) atomicAdd(&a.dw[((long long)tap * a.Cn + cn) * a.Cs + cs], acc[i][j][r]);
+        if (cn < a.Cn && cs < a.Cs && otap < 27) atomicAdd(&a.dw[((long long)otap * a.Cn + cn) * a.Cs + cs], acc[i][j][r]);
       }
     }
 }
@@ -645,9 +657,10 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 // Tile shape per launch (xh_set_option(14, mask) switches the choices off one by one for A/B measurements):
 //   Cn <= 16          256 x 16   (the 8-channel ends)
 //   Cn <= 64          256 x 64   (a 128-wide tile would be half padding: first conv forward, 64 <- 128 data gradient); K step 32
-//   < 256 tiles       64 x 128   (256 -> 512 @32^3 forward has 128 tiles of 128 x 128: half of the CUs idle)
+//   < 256 tiles       64 x 64    (256 -> 512 @32^3 forward has 128 tiles of 128 x 128: half of the CUs idle, and one workgroup
+//                                per CU cannot hide the gather latency of a K step: 184 us; 64 x 128: 147 us; 64 x 64: 125 us)
 //   else              128 x 128
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no 64 x 128
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5: K step 64 for 256 x 16, bit 6: no XCD remap
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -659,15 +672,22 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
     long long tiles = 0;
     for (int k = 0; k < a.ncls; ++k) tiles += cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, 128);
     tiles *= (long long)cdiv(a.Cn, 128) * N;
-    if (tiles < 256 && !(g_dconv_cfg & 4)) { bm = 64; bn = 128; cfg = 3; }
+    if (tiles < 256 && !(g_dconv_cfg & 4)) { bm = 64; bn = (g_dconv_cfg & 8) ? 128 : 64; cfg = (g_dconv_cfg & 8) ? 3 : 4; }
     else { bm = 128; bn = 128; cfg = 2; }
   }
   int t = 0;
-  for (int k = 0; k < a.ncls; ++k) { a.c[k].tile0 = t; t += cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, bm); }
+  for (int k = 0; k < a.ncls; ++k) { a.c[k].tile0 = t; a.c[k].ntile = cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, bm); t += a.c[k].ntile; }
   dim3 grid(t, cdiv(a.Cn, bn), N);
-  if (cfg == 0) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1>), grid, dim3(256), 0, st, a);
+  a.xcd = ((t & 7) == 0 || grid.y * grid.z == 1) && !(g_dconv_cfg & 64);
+  if (cfg == 0) {
+    if (kq2 && (g_dconv_cfg & 32)) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1>), grid, dim3(256), 0, st, a);
+  }
   else if (cfg == 1) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 4>), grid, dim3(256), 0, st, a);
-  else if (cfg == 3) {
+  else if (cfg == 4) {
+    if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1>), grid, dim3(256), 0, st, a);
+  } else if (cfg == 3) {
     if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 2, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 2>), grid, dim3(256), 0, st, a);
   } else {
@@ -755,15 +775,20 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void
     return xh_launch_status();
   }
   const bool narrow = Cs <= 16;
+  const bool pair = Cs == 64 && !(g_dconv_cfg & 16);
+  const int ntz = pair ? 14 : 27;
   const int bn = narrow ? 16 : 128, bm = narrow ? 64 : 128;
   const int tiles = cdiv(Cs, bn) * cdiv(Cn, bm);
-  int msplit = cdiv(1024, tiles * 27);
+  int msplit = cdiv(1024, tiles * ntz);
   const long long max_split = a.M / 512 > 0 ? a.M / 512 : 1;
   if (msplit > max_split) msplit = (int)max_split;
   if (msplit < 1) msplit = 1;
   a.msplit = msplit;
-  dim3 grid(cdiv(Cs, bn), cdiv(Cn, bm), 27 * msplit);
-  if (narrow) {
+  dim3 grid(cdiv(Cs, bn), cdiv(Cn, bm), ntz * msplit);
+  if (pair) {
+    if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_cl_kernel<1, 2, 4, 4, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwgrad_cl_kernel<0, 2, 4, 4, true>), grid, dim3(256), 0, st, a);
+  } else if (narrow) {
     if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_cl_kernel<1, 1, 1, 1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dwgrad_cl_kernel<0, 1, 1, 1>), grid, dim3(256), 0, st, a);
   } else {
