@@ -55,7 +55,10 @@ template <int KQ> __device__ __forceinline__ int swr(int row, int chunk) {
 }
 
 // KQ = 32-channel quarters per K step (1: K step 32, 2: K step 64 -- half the barriers, twice the matrix work between them)
-template <int FMT, int WGN, int TN, int KQ = 1>
+// PF = K steps in flight in registers (1: the next step only).  Measured on the narrow 256 x 16 tile (64 -> 8 data gradient
+// @128^3, 4 MFMAs per wave per step): PF 1 / 2 / 4 = 753 / 783 / 998 us -- the gather is bound by cache throughput (each dY row
+// is fetched 27 times), not by latency, and the extra registers only cost occupancy.  Kept as an experiment switch
+template <int FMT, int WGN, int TN, int KQ = 1, int PF = 1>
 __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   constexpr int WGM = 4 / WGN;
   constexpr int BM = WGM * 64, BN = WGN * TN * 16;
@@ -96,64 +99,58 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   }
   const int ch = tid % CPRW;
   const long long xs_n = (long long)n * a.Di * a.Hi * a.Wi;
-  uint4 ra[NA], rb[NB];
   const int nsteps_c = a.rowmode ? 1 : a.Cs / (32 * KQ);
   const int ntw = a.rowmode ? 1 : cl.tw.n;
   const int nsteps = cl.td.n * cl.th.n * ntw * nsteps_c;
 
-  auto load_step = [&](int s) {
+  // every load of a step is issued back to back from a clamped (always valid) address; what was out of range is zeroed when
+  // the step is written to LDS (mask bits travel with it): a guarded load (`if (in range) load`) costs a branch and an
+  // s_waitcnt each and serialises the step's ~8 loads
+  auto load_step = [&](int s, uint4 (&qa)[NA], uint4 (&qb)[NB], unsigned& okm) __attribute__((always_inline)) {
     const int cs = s % nsteps_c; int t = s / nsteps_c;
     const int iw = t % ntw; t /= ntw;
     const int ih = t % cl.th.n, id = t / cl.th.n;
     const int tap = a.rowmode ? (cl.td.t[id] * 3 + cl.th.t[ih]) : ((cl.td.t[id] * 3 + cl.th.t[ih]) * 3 + cl.tw.t[iw]);
-    // every load of the step is issued back to back from a clamped (always valid) address and masked afterwards: a guarded
-    // load (`if (in range) load`) costs a branch and an s_waitcnt each and serialises the step's ~8 loads
-    bool okA[NA], okB[NB];
+    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int d = a_sd[i] + cl.td.off[id], h = a_sh[i] + cl.th.off[ih];
       const int w = a_sw[i] + (a.rowmode ? (ch - 1) : cl.tw.off[iw]);
-      okA[i] = a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+      const bool ok = a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+      m |= ok ? 1u << i : 0u;
       const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
       const u16* p = a.x + ((xs_n + ((long long)dc * a.Hi + hc) * a.Wi + wc) * a.Cs) + (a.rowmode ? 0 : cs * 32 * KQ + ch * 8);
-      ra[i] = *reinterpret_cast<const uint4*>(p);
+      qa[i] = *reinterpret_cast<const uint4*>(p);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int col = tid / CPRW + i * (256 / CPRW);
-      okB[i] = col < BN && cn0 + col < a.Cn;
+      const bool ok = col < BN && cn0 + col < a.Cn;
+      m |= ok ? 1u << (NA + i) : 0u;
       const int cc = min(cn0 + col, a.Cn - 1);
-      rb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)cc * a.Kc + cs * 32 * KQ + ch * 8);
+      qb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)cc * a.Kc + cs * 32 * KQ + ch * 8);
     }
-#pragma unroll
-    for (int i = 0; i < NA; ++i) if (!okA[i]) ra[i] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) if (!okB[i]) rb[i] = make_uint4(0, 0, 0, 0);
+    okm = m;
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const uint4 (&qa)[NA], const uint4 (&qb)[NB], unsigned okm) __attribute__((always_inline)) {
     unsigned char* As = smem + buf * (AB + BB);
     unsigned char* Bs = As + AB;
+    const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + swr<KQ>(a_row[i], ch)) = ra[i];
+    for (int i = 0; i < NA; ++i) {
+      uint4 v = qa[i];                                  // (not `ok ? qa[i] : z`: a conditional of two lvalues selects an ADDRESS and
+      if (!((okm >> i) & 1)) v = z;                     //  drags the staging registers into scratch memory)
+      *reinterpret_cast<uint4*>(As + swr<KQ>(a_row[i], ch)) = v;
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int col = tid / CPRW + i * (256 / CPRW);
-      if (col < BN) *reinterpret_cast<uint4*>(Bs + swr<KQ>(col, ch)) = rb[i];
+      uint4 v = qb[i];
+      if (!((okm >> (NA + i)) & 1)) v = z;
+      if (col < BN) *reinterpret_cast<uint4*>(Bs + swr<KQ>(col, ch)) = v;
     }
   };
-
-  f32x4_t acc[4][TN];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  load_step(0);
-  store_step(0);
-  __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nsteps) load_step(s + 1);
+  auto mfma_step = [&](int buf, f32x4_t (&acc)[4][TN]) __attribute__((always_inline)) {
     const unsigned char* As = smem + buf * (AB + BB);
     const unsigned char* Bs = As + AB;
 #pragma unroll
@@ -168,8 +165,57 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
     }
-    if (s + 1 < nsteps) store_step(buf ^ 1);
+  };
+
+  f32x4_t acc[4][TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (PF == 1) {
+    uint4 ra[NA], rb[NB];
+    unsigned okm;
+    load_step(0, ra, rb, okm);
+    store_step(0, ra, rb, okm);
     __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nsteps) load_step(s + 1, ra, rb, okm);
+      mfma_step(buf, acc);
+      if (s + 1 < nsteps) store_step(buf ^ 1, ra, rb, okm);
+      __syncthreads();
+    }
+  } else {
+    // slot u holds step k with k % PF == u; a step's slot is refilled (step + PF) as soon as the step sits in LDS.  The main loop
+    // has no guards (loads past the end re-read the last step, the surplus LDS write goes to the buffer nobody reads again);
+    // the nsteps % PF steps left over are finished from the slots that already hold them
+    static_assert(PF % 2 == 0, "LDS buffer parity rides on the slot index");
+    uint4 ra[PF][NA], rb[PF][NB];
+    unsigned okm[PF];
+    const int last = nsteps - 1;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_step(min(u, last), ra[u], rb[u], okm[u]);
+    store_step(0, ra[0], rb[0], okm[0]);
+    __syncthreads();
+    const int nmain = nsteps / PF * PF;
+    for (int s0 = 0; s0 < nmain; s0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        load_step(min(s0 + u + PF, last), ra[u], rb[u], okm[u]);
+        mfma_step(u & 1, acc);
+        store_step((u + 1) & 1, ra[(u + 1) % PF], rb[(u + 1) % PF], okm[(u + 1) % PF]);
+        __syncthreads();
+      }
+    }
+    const int rem = nsteps - nmain;
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u)
+      if (u < rem) {
+        mfma_step(u & 1, acc);
+        if (u + 1 < rem) store_step((u + 1) & 1, ra[u + 1], rb[u + 1], okm[u + 1]);
+        __syncthreads();
+      }
   }
 
   // ---- epilogue: bias, activation, rounding, column sums (InstanceNorm statistics), tile transposed through LDS ----
@@ -660,7 +706,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 //   < 256 tiles       64 x 64    (256 -> 512 @32^3 forward has 128 tiles of 128 x 128: half of the CUs idle, and one workgroup
 //                                per CU cannot hide the gather latency of a K step: 184 us; 64 x 128: 147 us; 64 x 64: 125 us)
 //   else              128 x 128
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5: K step 64 for 256 x 16, bit 6: no XCD remap
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -680,7 +726,8 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   dim3 grid(t, cdiv(a.Cn, bn), N);
   a.xcd = ((t & 7) == 0 || grid.y * grid.z == 1) && !(g_dconv_cfg & 64);
   if (cfg == 0) {
-    if (kq2 && (g_dconv_cfg & 32)) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 2>), grid, dim3(256), 0, st, a);
+    if (g_dconv_cfg & 32) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 1, 4>), grid, dim3(256), 0, st, a);
+    else if (g_dconv_cfg & 128) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 1, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1>), grid, dim3(256), 0, st, a);
   }
   else if (cfg == 1) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 4>), grid, dim3(256), 0, st, a);
