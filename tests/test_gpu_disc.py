@@ -71,7 +71,8 @@ def test_dconv_forward_dgrad_wgrad_vs_stock(cfg, dtype):
     print(cfg, dtype, f"y {e_y:.2e} sums {e_s:.1e}/{e_q:.1e} dx {e_dx:.2e} dw {e_dw:.2e}")
     k = 1.0 if dtype == torch.bfloat16 else 0.2
     assert e_y < 6e-3 * k and e_dx < 8e-3 * k and e_dw < 8e-3 * k
-    assert e_s < 1e-9 and e_q < 1e-9
+    # channel sums: fp32 over the 64 voxels of a wave's tile, fp64 across tiles (relative to the sum of magnitudes)
+    assert e_s < 2e-6 and e_q < 2e-6
 
 
 @pytest.mark.parametrize("dtype", DT, ids=["bf16", "f16"])

@@ -41,12 +41,20 @@ grads = X.parallel.FlatGrads(list(m.parameters()))
 X.ops.set_wgrad_defer(True)
 x = torch.rand(1, 4, 64, 64, 64, device="cuda").bfloat16()
 from xlstm_hved_amd.losses import sum_of_means
-def step():
-    grads.zero()
-    seg, (mu, lv), rec = m(x, [14], recon=True)
-    loss = sum_of_means([seg, rec[0]] + [t for ab in zip(mu, lv) for t in ab])
-    loss.backward()
-    X.ops.join_wgrad_stream()
+if "--trainstep" in sys.argv:                       # the whole training step (train_step.TrainStep) instead of one fwd+bwd
+    from xlstm_hved_amd.train_step import TrainStep
+    d = X.Discriminator(in_channels=7); d.apply(X.init_weights); d = d.cuda()
+    ts = TrainStep(m, d, storage=torch.bfloat16)
+    mask = (torch.rand(1, 3, 64, 64, 64, device="cuda") > 0.7).float()
+    def step():
+        ts.compute(x, mask, [6])
+else:
+    def step():
+        grads.zero()
+        seg, (mu, lv), rec = m(x, [14], recon=True)
+        loss = sum_of_means([seg, rec[0]] + [t for ab in zip(mu, lv) for t in ab])
+        loss.backward()
+        X.ops.join_wgrad_stream()
 step(); step(); torch.cuda.synchronize()
 ON[0] = True
 step(); torch.cuda.synchronize()

@@ -20,6 +20,15 @@
 typedef short s4_t __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
+// sum over the 16 lanes of a DPP row (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); every lane gets it
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+
 struct DTaps { int n; int t[3]; int off[3]; };
 
 // One class of destination voxels.  Forward / stride-1 data gradient: a single class = all of them.  Stride-2 data gradient:
@@ -65,8 +74,7 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   constexpr int RB = 64 * KQ, CPRW = 4 * KQ;             // bytes / 16-byte chunks per LDS row
   constexpr int AB = BM * RB, BB = BN * RB;              // bytes per A / B buffer
   constexpr int NA = BM * CPRW / 256, NB = (BN * CPRW + 255) / 256;
-  constexpr int OUTB = BM * BN * 2;
-  constexpr int SM = 2 * (AB + BB) > OUTB ? 2 * (AB + BB) : OUTB;
+  constexpr int SM = 2 * (AB + BB);
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
   __shared__ double s_stat[WGM * BN * 2];                // per-wave-row column sums of the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   // workgroups go round the 8 XCDs in blockIdx order: hand every XCD a contiguous run of the class's row tiles, so that the
   // rows its taps share (h +- 1, d +- 1) are re-read from its own L2 instead of the fabric
   int mt = blockIdx.x - cl.tile0;
-  if (a.xcd && !(cl.tile0 & 7) && !(cl.ntile & 7)) mt = xcd_swizzle(mt, cl.ntile);
+  if ((a.xcd & 1) && !(cl.tile0 & 7) && !(cl.ntile & 7)) mt = xcd_swizzle(mt, cl.ntile);
   const int R = cl.Jd * cl.Jh * cl.Jw;
 
   // ---- staging plan: A rows (source voxel base coordinates), B columns ----
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16x16x32<FMT>(bf[j], af[i], acc[i][j]);      // D^T: channels on the rows (epilogue)
     }
   };
 
@@ -218,34 +226,81 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
       }
   }
 
-  // ---- epilogue: bias, activation, rounding, column sums (InstanceNorm statistics), tile transposed through LDS ----
-  u16* s_out = reinterpret_cast<u16*>(smem);              // [BM][BN]; every wave is past its last fragment read (barrier above)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = (wn * TN + j) * 16 + r16;
-    const int cn = cn0 + col;
-    const float bias = (a.bias && cn < a.Cn) ? a.bias[cn] : 0.f;
-    double s0 = 0.0, s1 = 0.0;
+  // ---- epilogue: bias, activation, rounding, column sums (InstanceNorm statistics) ----
+  // The MFMAs ran with the operands swapped (weights on the M side), so a lane holds, for voxel block i and channel block j,
+  // voxel r16 and the four CONSECUTIVE channels 4 kg + r: 8 contiguous bytes of the channels-last output, stored straight
+  // from the registers (the earlier transpose of the tile through LDS -- 64 two-byte LDS writes per lane, two barriers -- cost
+  // 113 of the 290 us of the first conv's forward and 73 of the 349 us of the 64 <- 128 data gradient).
+  if (a.xcd & 2) {                                        // ablation: no epilogue (keeps the accumulators alive)
+    float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
+      for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 12345.678f) a.y[0] = 1;
+    return;
+  }
+  const long long ys_n = (long long)n * a.Do * a.Ho * a.Wo;
+  const bool vec_ok = (a.Cn & 3) == 0;
+  float b4[TN][4], s0[TN][4], s1[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cn = cn0 + (wn * TN + j) * 16 + 4 * kg + r;
+      b4[j][r] = (a.bias && cn < a.Cn) ? a.bias[cn] : 0.f;
+      s0[j][r] = 0.f; s1[j][r] = 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mt * BM + wm * 64 + i * 16 + r16;
+    const bool ok = m < R;
+    const int mm = ok ? m : 0;
+    const int jw = mm % cl.Jw, t2 = mm / cl.Jw;
+    const int jh = t2 % cl.Jh, jd = t2 / cl.Jh;
+    const long long vox = ys_n + ((long long)(jd * a.omul + cl.pd) * a.Ho + (jh * a.omul + cl.ph)) * a.Wo + (jw * a.omul + cl.pw);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cn = cn0 + (wn * TN + j) * 16 + 4 * kg;
+      float v[4];
+#pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = wm * 64 + i * 16 + kg * 4 + r;
-        float v = acc[i][j][r] + bias;
-        if (a.act == XH_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
-        const u16 q = cvt_out<FMT>(v);
-        s_out[row * BN + col] = q;
-        if (a.red && mt * BM + row < R) { const float vr = cvt_in<FMT>(q); s0 += (double)vr; s1 += (double)vr * (double)vr; }
+        v[r] = acc[i][j][r] + b4[j][r];
+        if (a.act == XH_ACT_LRELU) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
       }
-    if (a.red) {
-      s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      if (kg == 0) { s_stat[(wm * BN + col) * 2] = s0; s_stat[(wm * BN + col) * 2 + 1] = s1; }
+      const unsigned q0 = cvt_pack<FMT>(v[0], v[1]), q1 = cvt_pack<FMT>(v[2], v[3]);
+      if (a.red && ok) {                                  // sums of the ROUNDED values: what the next layer normalises
+        const float w0 = cvt_lo<FMT>(q0), w1 = cvt_hi<FMT>(q0), w2 = cvt_lo<FMT>(q1), w3 = cvt_hi<FMT>(q1);
+        s0[j][0] += w0; s0[j][1] += w1; s0[j][2] += w2; s0[j][3] += w3;
+        s1[j][0] += w0 * w0; s1[j][1] += w1 * w1; s1[j][2] += w2 * w2; s1[j][3] += w3 * w3;
+      }
+      if (ok) {
+        if (vec_ok && cn + 4 <= a.Cn) {
+          *reinterpret_cast<uint2*>(a.y + vox * a.Cn + cn) = make_uint2(q0, q1);
+        } else {
+          const u16 qs[4] = {(u16)(q0 & 0xffff), (u16)(q0 >> 16), (u16)(q1 & 0xffff), (u16)(q1 >> 16)};
+          for (int e = 0; e < 4; ++e)
+            if (cn + e < a.Cn) a.y[vox * a.Cn + cn + e] = qs[e];
+        }
+      }
     }
   }
-  __syncthreads();
-  if (a.red) {                                            // one fp64 atomic per (column, moment) per workgroup
-    for (int i = tid; i < BN * 2; i += 256) {
+  if (a.red) {
+    // a lane's partial covers 4 voxels; the 16 lanes of a DPP row (same kg) hold the other voxels of the wave's 64: fp32 over
+    // those 64 values (squares of 16-bit values are exact in fp32), fp64 from there on (across waves, workgroups, launches)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t0 = row16_sum(s0[j][r]), t1 = row16_sum(s1[j][r]);
+        if (r16 == 0) {
+          const int col = (wn * TN + j) * 16 + 4 * kg + r;
+          s_stat[(wm * BN + col) * 2] = (double)t0;
+          s_stat[(wm * BN + col) * 2 + 1] = (double)t1;
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < BN * 2; i += 256) {             // one fp64 atomic per (column, moment) per workgroup
       const int col = i >> 1;
       if (cn0 + col < a.Cn) {
         double t = 0.0;
@@ -253,23 +308,6 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
         for (int m2 = 0; m2 < WGM; ++m2) t += s_stat[(m2 * BN + col) * 2 + (i & 1)];
         atomicAdd(&a.red[((long long)n * a.Cn + cn0 + col) * 2 + (i & 1)], t);
       }
-    }
-  }
-  __syncthreads();
-  const long long ys_n = (long long)n * a.Do * a.Ho * a.Wo;
-  constexpr int CPR = BN / 8;                             // 16-byte chunks per tile row
-  for (int c = tid; c < BM * CPR; c += 256) {
-    const int row = c / CPR, part = c % CPR;
-    const int m = mt * BM + row;
-    if (m >= R) continue;
-    const int jw = m % cl.Jw, t2 = m / cl.Jw;
-    const int jh = t2 % cl.Jh, jd = t2 / cl.Jh;
-    const long long vox = ys_n + ((long long)(jd * a.omul + cl.pd) * a.Ho + (jh * a.omul + cl.ph)) * a.Wo + (jw * a.omul + cl.pw);
-    const int cn = cn0 + part * 8;
-    if (cn + 8 <= a.Cn && (a.Cn & 7) == 0) {
-      *reinterpret_cast<uint4*>(a.y + vox * a.Cn + cn) = *reinterpret_cast<const uint4*>(s_out + row * BN + part * 8);
-    } else {
-      for (int e = 0; e < 8 && cn + e < a.Cn; ++e) a.y[vox * a.Cn + cn + e] = s_out[row * BN + part * 8 + e];
     }
   }
 }
@@ -705,7 +743,8 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 //   Cn <= 64          256 x 64   (a 128-wide tile would be half padding: first conv forward, 64 <- 128 data gradient); K step 32
 //   < 256 tiles       64 x 64    (256 -> 512 @32^3 forward has 128 tiles of 128 x 128: half of the CUs idle, and one workgroup
 //                                per CU cannot hide the gather latency of a K step: 184 us; 64 x 128: 147 us; 64 x 64: 125 us)
-//   else              128 x 128
+//   else              128 x 128  (a 256 x 128 tile with 128 x 64 per wave halves the LDS reads per MFMA but needs 205 VGPRs and
+//                                96 KB of LDS = one workgroup per CU: 64 -> 128 forward 242 -> 349 us, dropped)
 int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
@@ -725,6 +764,7 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   for (int k = 0; k < a.ncls; ++k) { a.c[k].tile0 = t; a.c[k].ntile = cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, bm); t += a.c[k].ntile; }
   dim3 grid(t, cdiv(a.Cn, bn), N);
   a.xcd = ((t & 7) == 0 || grid.y * grid.z == 1) && !(g_dconv_cfg & 64);
+  if (g_dconv_cfg & 512) a.xcd |= 2;
   if (cfg == 0) {
     if (g_dconv_cfg & 32) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 1, 4>), grid, dim3(256), 0, st, a);
     else if (g_dconv_cfg & 128) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 1, 2>), grid, dim3(256), 0, st, a);
