@@ -541,6 +541,87 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
     }
 }
 
+// data gradient of the FIRST conv (64 -> 8 padded input channels, stride 1): the generic kernel gathers every dY row 27 times
+// through the caches for 4 MFMAs per wave per step (750 us @128^3, bound by cache throughput).  Here a workgroup owns a
+// 4 x 4 x 16 block of destination voxels and keeps the 6 x 6 x 18 halo of dY it needs in LDS (32 channels at a time, 80-byte
+// voxel pitch: the 16 lanes of a fragment read sit 20 banks apart), so the 27 taps are 27 shifted LDS reads of the same tile:
+// no barrier and no global activation traffic inside the tap loop; the weight fragment of a tap (1 KB) comes from L1/L2, one
+// tap ahead.  Weights ride on the M side (8 of 16 rows used): a lane ends up with 4 consecutive channels of one voxel.
+struct DDg8K {
+  const u16* g; const u16* w; u16* dx;
+  int N, D, H, W;
+  int td, th, tw;          // tiles per axis
+};
+template <int FMT>
+__global__ __launch_bounds__(256, 3) void dconv_dgrad_c8_kernel(const DDg8K a) {
+  constexpr int PD = 6, PH = 6, PW = 18, NV = PD * PH * PW, PITCH = 80;
+  __shared__ __attribute__((aligned(16))) unsigned char tile[NV * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int per_n = a.td * a.th * a.tw;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int n = b / per_n; b -= n * per_n;
+  const int tw_i = b % a.tw, t2 = b / a.tw;
+  const int th_i = t2 % a.th, td_i = t2 / a.th;
+  const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+  const u16* gn = a.g + (long long)n * a.D * a.H * a.W * 64;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // weights: w[tap][ci (8 rows)][co (64)]; lanes r16 >= 8 are the padding rows of the M side
+  const bool wrow = r16 < 8;
+  const u16* wl = a.w + (wrow ? r16 : 0) * 64 + kg * 8;
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                           // every wave is done reading the first 32 channels
+    for (int idx = tid; idx < NV * 4; idx += 256) {
+      const int p = idx >> 2, c = idx & 3;
+      const int pw = p % PW, q = p / PW;
+      const int ph = q % PH, pd = q / PH;
+      const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+        v = *reinterpret_cast<const uint4*>(gn + (((long long)d * a.H + h) * a.W + w) * 64 + half * 32 + c * 8);
+      *reinterpret_cast<uint4*>(tile + p * PITCH + c * 16) = v;
+    }
+    __syncthreads();
+    uint4 wf = wrow ? *reinterpret_cast<const uint4*>(wl + half * 32) : make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          const uint4 wcur = wf;
+          const int nt = tap + 1 < 27 ? tap + 1 : 26;
+          wf = wrow ? *reinterpret_cast<const uint4*>(wl + (long long)nt * 512 + half * 32) : make_uint4(0, 0, 0, 0);
+          const h16x8 bw = __builtin_bit_cast(h16x8, wcur);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rb = wv * 4 + i;                   // (dz, hy) row of the block
+            const int dz = rb >> 2, hy = rb & 3;
+            // destination (dz, hy, r16) takes tap (kd, kh, kw) from source (+1 - kd, +1 - kh, +1 - kw); halo origin is -1
+            const int p = ((dz + 2 - kd) * PH + (hy + 2 - kh)) * PW + (r16 + 2 - kw);
+            const h16x8 av = *reinterpret_cast<const h16x8*>(tile + p * PITCH + kg * 16);
+            acc[i] = mfma16x16x32<FMT>(bw, av, acc[i]);
+          }
+        }
+      }
+  }
+  // lane: channels 4 kg .. 4 kg + 3 (kg < 2) of voxel (d0 + dz, h0 + hy, w0 + r16)
+  if (kg < 2) {
+    u16* dn = a.dx + (long long)n * a.D * a.H * a.W * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wv * 4 + i;
+      const int d = d0 + (rb >> 2), h = h0 + (rb & 3), w = w0 + r16;
+      if (d < a.D && h < a.H && w < a.W)
+        *reinterpret_cast<uint2*>(dn + (((long long)d * a.H + h) * a.W + w) * 8 + kg * 4) =
+            make_uint2(cvt_pack<FMT>(acc[i][0], acc[i][1]), cvt_pack<FMT>(acc[i][2], acc[i][3]));
+    }
+  }
+}
+
 // forward of the LAST conv (Cout = 1): a dot product of 27 x Cs values per output voxel -- one wave per voxel
 template <int FMT>
 __global__ __launch_bounds__(256) void dconv_cout1_kernel(const u16* x, const u16* w, u16* y, int N, int D, int H, int W, int Cs) {
@@ -745,7 +826,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 //                                per CU cannot hide the gather latency of a K step: 184 us; 64 x 128: 147 us; 64 x 64: 125 us)
 //   else              128 x 128  (a 256 x 128 tile with 128 x 64 per wave halves the LDS reads per MFMA but needs 205 VGPRs and
 //                                96 KB of LDS = one workgroup per CU: 64 -> 128 forward 242 -> 349 us, dropped)
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10: no LDS-halo kernel for the 64 -> 8 data gradient
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -807,6 +888,18 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
     if (dtype == XH_F16) hipLaunchKernelGGL(dconv_cout1_kernel<1>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
     else hipLaunchKernelGGL(dconv_cout1_kernel<0>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
     return xh_launch_status();
+  }
+  if (mode == 1 && stride == 1 && Cs == 64 && Cn == 8 && !bias && !red && act == XH_ACT_NONE && !(g_dconv_cfg & 1024)) {
+    DDg8K k;
+    k.g = (const u16*)x; k.w = (const u16*)w; k.dx = (u16*)y;
+    k.N = N; k.D = Do; k.H = Ho; k.W = Wo;
+    k.td = cdiv(Do, 4); k.th = cdiv(Ho, 4); k.tw = cdiv(Wo, 16);
+    const long long nb = (long long)N * k.td * k.th * k.tw;
+    if (nb < (1LL << 31)) {
+      if (dtype == XH_F16) hipLaunchKernelGGL(dconv_dgrad_c8_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, k);
+      else hipLaunchKernelGGL(dconv_dgrad_c8_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, k);
+      return xh_launch_status();
+    }
   }
   const int classes = (mode == 1 && stride == 2) ? 8 : 1;
   a.omul = classes == 8 ? 2 : 1;
