@@ -345,27 +345,47 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
   const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
   const long long per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
   const long long m_begin = (long long)split * per, m_end = m_begin + per < a.M ? m_begin + per : a.M;
-  // staging: a tile is 32 rows x 16 chunks = 512 chunks -> 2 per thread per operand
+  // staging: a tile is 32 rows x 16 chunks = 512 chunks -> 2 per thread per operand.  A thread's two rows move on by 32 voxels
+  // per step: their (n, od, oh, ow) are carried along instead of being divided out of m every step (three runtime divisions
+  // per load were more VALU work than the step's 16 MFMAs), and every load is issued from a clamped address and masked
+  // afterwards (guards around loads serialise them)
   uint4 ry[2], rx[2];
-  auto load_step = [&](long long m0) {
+  const int chn = tid & 15;
+  const bool y_ok = cn0 + chn * 8 < a.Cn && chn * 8 < BMc;
+  const bool x_ok = PAIR ? tap_ok : (cs0 + chn * 8 < a.Cs && chn * 8 < BNc);
+  const int y_off = y_ok ? cn0 + chn * 8 : 0;
+  const int x_off = x_ok ? (PAIR ? (chn & 7) * 8 : cs0 + chn * 8) : 0;
+  int ow[2], oh[2], od[2], nn[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    long long t = m_begin + (tid >> 4) + i * 16;
+    ow[i] = (int)(t % a.Wo); t /= a.Wo;
+    oh[i] = (int)(t % a.Ho); t /= a.Ho;
+    od[i] = (int)(t % a.Do); nn[i] = (int)(t / a.Do);
+  }
+  auto load_step = [&](long long m0) __attribute__((always_inline)) {     // called with m0 = m_begin, m_begin + 32, ... in order
+    bool oky[2], okx[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256;
-      const int row = c >> 4, chn = c & 15;
-      const long long m = m0 + row;
-      ry[i] = rx[i] = make_uint4(0, 0, 0, 0);
-      if (m < m_end) {
-        if (cn0 + chn * 8 < a.Cn && chn * 8 < BMc) ry[i] = *reinterpret_cast<const uint4*>(a.dy + m * a.Cn + cn0 + chn * 8);
-        if (PAIR ? tap_ok : (cs0 + chn * 8 < a.Cs && chn * 8 < BNc)) {
-          long long t = m;
-          const int ow = (int)(t % a.Wo); t /= a.Wo;
-          const int oh = (int)(t % a.Ho); t /= a.Ho;
-          const int od = (int)(t % a.Do); const int n = (int)(t / a.Do);
-          const int d = od * a.stride + kd - 1, h = oh * a.stride + kh - 1, w = ow * a.stride + kw - 1;
-          if ((unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi)
-            rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)n * a.Di + d) * a.Hi + h) * a.Wi + w) * a.Cs +
-                                                    (PAIR ? (chn & 7) * 8 : cs0 + chn * 8));
-        }
+      const long long m = m0 + (tid >> 4) + i * 16;
+      const bool live = m < m_end;
+      const long long mc = m < a.M ? m : a.M - 1;
+      oky[i] = live && y_ok;
+      ry[i] = *reinterpret_cast<const uint4*>(a.dy + mc * a.Cn + y_off);
+      const int d = od[i] * a.stride + kd - 1, h = oh[i] * a.stride + kh - 1, w = ow[i] * a.stride + kw - 1;
+      okx[i] = live && x_ok && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+      const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
+      const int nc = min(nn[i], a.N - 1);
+      rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)nc * a.Di + dc) * a.Hi + hc) * a.Wi + wc) * a.Cs + x_off);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!oky[i]) ry[i] = make_uint4(0, 0, 0, 0);
+      if (!okx[i]) rx[i] = make_uint4(0, 0, 0, 0);
+      ow[i] += 32;                                        // the row this slot stages next step
+      while (ow[i] >= a.Wo) {
+        ow[i] -= a.Wo;
+        if (++oh[i] == a.Ho) { oh[i] = 0; if (++od[i] == a.Do) { od[i] = 0; ++nn[i]; } }
       }
     }
   };
@@ -454,27 +474,47 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
   const long long per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
   const long long m_begin = (long long)split * per, m_end = m_begin + per < a.M ? m_begin + per : a.M;
   uint4 ry, rx[4];
-  auto load_step = [&](long long m0) {
+  // a thread stages the same tap for its four rows (slot = tid + 256 i: tap = tid & 31, row = (tid >> 5) + 8 i), and each row
+  // moves on by 32 voxels per step: coordinates carried along, loads unconditional from clamped addresses (see dwgrad_cl_kernel)
+  const int xtap = tid & 31;
+  const bool xtap_ok = xtap < 27;
+  const int xkd = xtap / 9, xkh = (xtap / 3) % 3, xkw = xtap % 3;
+  const int ychn = tid & 7;
+  const bool y_ok = cn0 + ychn * 8 < a.Cn;
+  const int y_off = y_ok ? cn0 + ychn * 8 : 0;
+  int ow[4], oh[4], od[4], nn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long t = m_begin + (tid >> 5) + i * 8;
+    ow[i] = (int)(t % a.Wo); t /= a.Wo;
+    oh[i] = (int)(t % a.Ho); t /= a.Ho;
+    od[i] = (int)(t % a.Do); nn[i] = (int)(t / a.Do);
+  }
+  auto load_step = [&](long long m0) __attribute__((always_inline)) {     // m0 = m_begin, m_begin + 32, ... in order
+    bool oky, okx[4];
     {
-      const int row = tid >> 3, chn = tid & 7;
-      const long long m = m0 + row;
-      ry = make_uint4(0, 0, 0, 0);
-      if (m < m_end && cn0 + chn * 8 < a.Cn) ry = *reinterpret_cast<const uint4*>(a.dy + m * a.Cn + cn0 + chn * 8);
+      const long long m = m0 + (tid >> 3);
+      oky = m < m_end && y_ok;
+      const long long mc = m < a.M ? m : a.M - 1;
+      ry = *reinterpret_cast<const uint4*>(a.dy + mc * a.Cn + y_off);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int slot = tid + i * 256;
-      const int row = slot >> 5, tap = slot & 31;
-      const long long m = m0 + row;
-      rx[i] = make_uint4(0, 0, 0, 0);
-      if (m < m_end && tap < 27) {
-        long long t = m;
-        const int ow = (int)(t % a.Wo); t /= a.Wo;
-        const int oh = (int)(t % a.Ho); t /= a.Ho;
-        const int od = (int)(t % a.Do); const int n = (int)(t / a.Do);
-        const int d = od * a.stride + tap / 9 - 1, h = oh * a.stride + (tap / 3) % 3 - 1, w = ow * a.stride + tap % 3 - 1;
-        if ((unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi)
-          rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)n * a.Di + d) * a.Hi + h) * a.Wi + w) * 8);
+      const long long m = m0 + (tid >> 5) + i * 8;
+      const int d = od[i] * a.stride + xkd - 1, h = oh[i] * a.stride + xkh - 1, w = ow[i] * a.stride + xkw - 1;
+      okx[i] = m < m_end && xtap_ok && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+      const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
+      const int nc = min(nn[i], a.N - 1);
+      rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)nc * a.Di + dc) * a.Hi + hc) * a.Wi + wc) * 8);
+    }
+    if (!oky) ry = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!okx[i]) rx[i] = make_uint4(0, 0, 0, 0);
+      ow[i] += 32;
+      while (ow[i] >= a.Wo) {
+        ow[i] -= a.Wo;
+        if (++oh[i] == a.Ho) { oh[i] = 0; if (++od[i] == a.Do) { od[i] = 0; ++nn[i]; } }
       }
     }
   };
