@@ -52,6 +52,15 @@ def test_dconv_forward_dgrad_wgrad_vs_stock(cfg, dtype):
     ys = _nc(y.cpu()).double()
     e_s = ((red[..., 0].cpu() - ys.sum((2, 3, 4))).abs() / ys.abs().sum((2, 3, 4))).max().item()
     e_q = ((red[..., 1].cpu() - (ys * ys).sum((2, 3, 4))).abs() / (ys * ys).sum((2, 3, 4))).max().item()
+    if cin == 7:
+        # without statistics the first conv takes the LDS-halo kernel (bias + LeakyReLU fused); ragged block edges here
+        y2 = D._conv(xcl, D._pack(wd, 2, cout, cpad, dtype), b.to(DEV), 0, s, n, sp, spo, cpad, cout, act=D.L.ACT_LRELU)
+        e_y2 = l2_err(_nc(y2.cpu()), F.leaky_relu(yo, D.SLOPE))
+        assert e_y2 < 6e-3 * (1.0 if dtype == torch.bfloat16 else 0.2), e_y2
+        D.L.load().xh_set_option(14, 2048)                # ... and agrees with the generic kernel
+        y3 = D._conv(xcl, D._pack(wd, 2, cout, cpad, dtype), b.to(DEV), 0, s, n, sp, spo, cpad, cout, act=D.L.ACT_LRELU)
+        D.L.load().xh_set_option(14, 0)
+        assert l2_err(y2.float().cpu(), y3.float().cpu()) < 4e-3 * (1.0 if dtype == torch.bfloat16 else 0.2)
     # data gradient: dY padded to a multiple of 32 channels
     cop = (cout + 31) // 32 * 32
     gyp = torch.zeros(n, cop, *spo, dtype=dtype)

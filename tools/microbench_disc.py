@@ -35,9 +35,9 @@ for cin, cout, s, sp in layers:
     lib = X._lib.load()
     lib.xh_set_option(14, int(os.environ.get("XH_DCFG", "0")))
     lib.xh_set_option(5, 1)
-    t_f1 = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red if cout > 1 else None))
+    t_f1 = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red if cout > 1 and cin > 8 else None))
     lib.xh_set_option(5, 2)
-    t_f = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red if cout > 1 else None))
+    t_f = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red if cout > 1 and cin > 8 else None))
     cop = max(32, cout)
     dy = torch.randn(1, so, so, so, cop, device="cuda").to(dt)
     wpt = D._pack(w, 1, cop, cin, dt)

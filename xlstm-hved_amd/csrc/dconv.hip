@@ -662,6 +662,103 @@ __global__ __launch_bounds__(256, 3) void dconv_dgrad_c8_kernel(const DDg8K a) {
   }
 }
 
+// forward of the FIRST conv (8 padded input channels -> 64, stride 1, bias + LeakyReLU): same block shape as the kernel above.
+// The 6 x 6 x 18 input halo is 10 KB of LDS (16 bytes per voxel); one K step = one (kd, kh) row = 3 kw taps x 8 channels
+// (+ 8 zero-weight lanes), read as ONE 16-byte LDS load per lane: lane (voxel r16, k-group kg) takes voxel r16 + kg of the row.
+// 9 steps x 16 MFMAs per wave, weights (M side, 4 blocks of 16 channels) from L1/L2 one step ahead.  The assignment of output
+// channels to MFMA rows is free, so block j, row m carries channel (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3): a lane
+// then owns 8 CONSECUTIVE channels per block pair and the four k-groups of a voxel write 64 contiguous bytes per store.
+struct DFw8K {
+  const u16* x; const u16* w; const float* bias; u16* y;
+  int N, D, H, W;
+  int td, th, tw;
+  int act; float slope;
+};
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void dconv_fwd_c8_kernel(const DFw8K a) {
+  constexpr int PD = 6, PH = 6, PW = 18, NV = PD * PH * PW;
+  __shared__ __attribute__((aligned(16))) unsigned char tile[(NV + 2) * 16];      // + 2 voxels: the zero-weight lanes of the last row
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int per_n = a.td * a.th * a.tw;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int n = b / per_n; b -= n * per_n;
+  const int tw_i = b % a.tw, t2 = b / a.tw;
+  const int th_i = t2 % a.th, td_i = t2 / a.th;
+  const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+  const u16* xn = a.x + (long long)n * a.D * a.H * a.W * 8;
+  for (int p = tid; p < NV + 2; p += 256) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p < NV) {
+      const int pw = p % PW, q = p / PW;
+      const int ph = q % PH, pd = q / PH;
+      const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
+      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+        v = *reinterpret_cast<const uint4*>(xn + (((long long)d * a.H + h) * a.W + w) * 8);
+    }
+    *reinterpret_cast<uint4*>(tile + p * 16) = v;
+  }
+  // weights: w[r9][co (64)][k (32)]; this lane supplies row m = r16 of block j = channel co_of(j)
+  int wrow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wrow[j] = ((j >> 1) * 32 + (r16 >> 2) * 8 + (j & 1) * 4 + (r16 & 3)) * 32 + kg * 8;
+  uint4 wf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const uint4*>(a.w + wrow[j]);
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll 1
+  for (int r9 = 0; r9 < 9; ++r9) {
+    const int kd = r9 / 3, kh = r9 - kd * 3;
+    h16x8 bw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bw[j] = __builtin_bit_cast(h16x8, wf[j]);
+    const int nr = r9 + 1 < 9 ? r9 + 1 : 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const uint4*>(a.w + nr * 2048 + wrow[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wv * 4 + i;
+      const int dz = rb >> 2, hy = rb & 3;
+      // destination (dz, hy, r16), tap (kd, kh, kw = kg): source (+kd - 1, +kh - 1, +kg - 1), halo origin -1
+      const int p = ((dz + kd) * PH + (hy + kh)) * PW + r16 + kg;
+      const h16x8 av = *reinterpret_cast<const h16x8*>(tile + p * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x32<FMT>(bw[j], av, acc[i][j]);
+    }
+  }
+  // lane: block pair j2 -> channels j2 * 32 + kg * 8 + (0..7) of voxel (d0 + dz, h0 + hy, w0 + r16)
+  float bs[2][8];
+#pragma unroll
+  for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[j2][e] = a.bias ? a.bias[j2 * 32 + kg * 8 + e] : 0.f;
+  u16* yn = a.y + (long long)n * a.D * a.H * a.W * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rb = wv * 4 + i;
+    const int d = d0 + (rb >> 2), h = h0 + (rb & 3), w = w0 + r16;
+    if (d < a.D && h < a.H && w < a.W) {
+      u16* yp = yn + (((long long)d * a.H + h) * a.W + w) * 64 + kg * 8;
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = acc[i][2 * j2 + (e >> 2)][e & 3] + bs[j2][e];
+          if (a.act == XH_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+        }
+        *reinterpret_cast<uint4*>(yp + j2 * 32) =
+            make_uint4(cvt_pack<FMT>(v[0], v[1]), cvt_pack<FMT>(v[2], v[3]), cvt_pack<FMT>(v[4], v[5]), cvt_pack<FMT>(v[6], v[7]));
+      }
+    }
+  }
+}
+
 // forward of the LAST conv (Cout = 1): a dot product of 27 x Cs values per output voxel -- one wave per voxel
 template <int FMT>
 __global__ __launch_bounds__(256) void dconv_cout1_kernel(const u16* x, const u16* w, u16* y, int N, int D, int H, int W, int Cs) {
@@ -866,7 +963,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 //                                per CU cannot hide the gather latency of a K step: 184 us; 64 x 128: 147 us; 64 x 64: 125 us)
 //   else              128 x 128  (a 256 x 128 tile with 128 x 64 per wave halves the LDS reads per MFMA but needs 205 VGPRs and
 //                                96 KB of LDS = one workgroup per CU: 64 -> 128 forward 242 -> 349 us, dropped)
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10: no LDS-halo kernel for the 64 -> 8 data gradient
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -928,6 +1025,18 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
     if (dtype == XH_F16) hipLaunchKernelGGL(dconv_cout1_kernel<1>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
     else hipLaunchKernelGGL(dconv_cout1_kernel<0>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
     return xh_launch_status();
+  }
+  if (rowmode && Cn == 64 && !red && (act == XH_ACT_NONE || act == XH_ACT_LRELU) && !(g_dconv_cfg & 2048)) {
+    DFw8K k;
+    k.x = (const u16*)x; k.w = (const u16*)w; k.bias = bias; k.y = (u16*)y;
+    k.N = N; k.D = Do; k.H = Ho; k.W = Wo; k.act = act; k.slope = slope;
+    k.td = cdiv(Do, 4); k.th = cdiv(Ho, 4); k.tw = cdiv(Wo, 16);
+    const long long nb = (long long)N * k.td * k.th * k.tw;
+    if (nb < (1LL << 31)) {
+      if (dtype == XH_F16) hipLaunchKernelGGL(dconv_fwd_c8_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, k);
+      else hipLaunchKernelGGL(dconv_fwd_c8_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, k);
+      return xh_launch_status();
+    }
   }
   if (mode == 1 && stride == 1 && Cs == 64 && Cn == 8 && !bias && !red && act == XH_ACT_NONE && !(g_dconv_cfg & 1024)) {
     DDg8K k;
