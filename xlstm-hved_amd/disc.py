@@ -35,6 +35,35 @@ def _pack(w, mode, cout_pad, cin_pad, dtype):
     return out
 
 
+# The packed 16-bit weight images depend on the weights alone.  A training step runs the discriminator several times on the
+# same weights (train.py:260,272,276), so inside a `pack_scope()` (TrainStep.compute opens one) an image is built once per
+# (weight tensor, version, layout) and reused by the later passes; outside a scope every call packs afresh, which is what a
+# caller who updates the weights between calls -- or replays a captured forward -- needs.
+_SCOPE = {"depth": 0, "cache": {}}
+
+
+class pack_scope:
+    def __enter__(self):
+        _SCOPE["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _SCOPE["depth"] -= 1
+        if _SCOPE["depth"] == 0:
+            _SCOPE["cache"].clear()
+        return False
+
+
+def _pack_cached(w, mode, cout_pad, cin_pad, dtype):
+    if _SCOPE["depth"] == 0:
+        return _pack(w, mode, cout_pad, cin_pad, dtype)
+    key = (w.data_ptr(), w._version, mode, cout_pad, cin_pad, dtype)
+    hit = _SCOPE["cache"].get(key)
+    if hit is None:
+        hit = _SCOPE["cache"][key] = _pack(w, mode, cout_pad, cin_pad, dtype)
+    return hit
+
+
 def _conv(x, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, red=None, act=L.ACT_NONE):
     y = torch.empty((n,) + tuple(sp_out) + (cn,), dtype=x.dtype, device=x.device)
     L.check(L.load().xh_dconv_cl(_s(), ops._dt(x), mode, stride, x.data_ptr(), wp.data_ptr(), ops._p(bias), y.data_ptr(), ops._p(red), n,
@@ -76,12 +105,12 @@ class DiscFn(Function):
             sp.append(_half(sp[-1]))
         xin = torch.empty((n, d, h, w, 8), dtype=dt, device=dev)
         L.check(lib.xh_cl_from_ncdhw(_s(), ops._dt(x), x.data_ptr(), cin * V, cin, None, 0, 0, xin.data_ptr(), 8, n, V), "xh_cl_from_ncdhw")
-        y0 = _conv(xin, _pack(w0, 2, 64, 8, dt), b0, 0, 1, n, sp[0], sp[0], 8, w0.shape[0], act=L.ACT_LRELU)
+        y0 = _conv(xin, _pack_cached(w0, 2, 64, 8, dt), b0, 0, 1, n, sp[0], sp[0], 8, w0.shape[0], act=L.ACT_LRELU)
         acts, raws, stats = [y0], [], []
         for k, wk in enumerate((w1, w2, w3), 1):
             cs, cn = wk.shape[1], wk.shape[0]
             red = torch.zeros((n, cn, 2), dtype=torch.float64, device=dev)
-            c = _conv(acts[-1], _pack(wk, 0, cn, cs, dt), None, 0, 2, n, sp[k - 1], sp[k], cs, cn, red=red)
+            c = _conv(acts[-1], _pack_cached(wk, 0, cn, cs, dt), None, 0, 2, n, sp[k - 1], sp[k], cs, cn, red=red)
             cnt = sp[k][0] * sp[k][1] * sp[k][2]
             sc, sh, mean, rstd = ops.norm_finalize(ops.MODE_IN, red, n, cn, cnt)
             a = torch.empty_like(c)
@@ -90,7 +119,7 @@ class DiscFn(Function):
             raws.append(c)
             acts.append(a)
             stats.append((sc, sh, mean, rstd))
-        out = _conv(acts[-1], _pack(wl, 0, 1, wl.shape[1], dt), None, 0, 1, n, sp[3], sp[3], wl.shape[1], 1)
+        out = _conv(acts[-1], _pack_cached(wl, 0, 1, wl.shape[1], dt), None, 0, 1, n, sp[3], sp[3], wl.shape[1], 1)
         ctx.save_for_backward(xin, *acts, *raws, *[t for st in stats for t in st], w0, w1, w2, w3, wl)
         ctx.meta = (n, cin, sp, dt)
         ctx.params = params
@@ -121,7 +150,7 @@ class DiscFn(Function):
         c3 = wl.shape[1]
         if need_w:
             _unpack(_wgrad(acts[3], dy, 1, n, sp[3], sp[3], c3, 32), g_wl, 32, c3)
-        da = _conv(dy, _pack(wl, 1, 32, c3, dt), None, 1, 1, n, sp[3], sp[3], 32, c3)
+        da = _conv(dy, _pack_cached(wl, 1, 32, c3, dt), None, 1, 1, n, sp[3], sp[3], 32, c3)
         for k, wk, g_w in ((3, w3, g_w3), (2, w2, g_w2), (1, w1, g_w1)):
             cs, cn = wk.shape[1], wk.shape[0]
             sc, sh, mean, rstd = stats[k - 1]
@@ -137,7 +166,7 @@ class DiscFn(Function):
                                       B.data_ptr(), Cc.data_ptr(), None, n, cn, cnt), "xh_cl_act_bwd")
             if need_w:
                 _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k - 1], sp[k], cs, cn), g_w, cn, cs)
-            da = _conv(dc, _pack(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k], sp[k - 1], cn, cs)
+            da = _conv(dc, _pack_cached(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k], sp[k - 1], cn, cs)
         # block 0: conv + bias -> LeakyReLU (no norm): g = da * leaky'(y0), bias gradient = sum g
         c0 = w0.shape[0]
         V = sp[0][0] * sp[0][1] * sp[0][2]
@@ -150,7 +179,7 @@ class DiscFn(Function):
             _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[0], 8, c0), g_w0, c0, 8)
         dx = None
         if ctx.needs_input_grad[0]:
-            dxin = _conv(g0, _pack(w0, 1, c0, 8, dt), None, 1, 1, n, sp[0], sp[0], c0, 8)
+            dxin = _conv(g0, _pack_cached(w0, 1, c0, 8, dt), None, 1, 1, n, sp[0], sp[0], c0, 8)
             dx = torch.empty((n, cin) + sp[0], dtype=dt, device=dev)
             L.check(lib.xh_cl_to_ncdhw(_s(), ops._dt(dx), dxin.data_ptr(), 8, dx.data_ptr(), cin * V, cin, None, 0, 0, n, V), "xh_cl_to_ncdhw")
         return (dx, *rets)

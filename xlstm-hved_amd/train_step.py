@@ -86,26 +86,36 @@ class TrainStep:
         return loss, parts, (fake.detach(), real, f_out.detach())
 
     def discriminator_forward(self, fake, real):
-        loss_d_fake = self.gan(self._disc(fake).float(), False)                 # train.py:272-277
-        loss_d_real = self.gan(self._disc(real).float(), True)
+        from .disc import Discriminator
+        if isinstance(self.disc, Discriminator) and fake.shape == real.shape:
+            # both passes as one batch: InstanceNorm is per sample, so this is the same arithmetic as train.py:272-277, with
+            # half the launches and twice the rows for the small deep layers (and one weight-gradient pass instead of two)
+            out = self._disc(torch.cat([fake, real], 0)).float()
+            nb = fake.shape[0]
+            loss_d_fake, loss_d_real = self.gan(out[:nb], False), self.gan(out[nb:], True)
+        else:
+            loss_d_fake = self.gan(self._disc(fake).float(), False)             # train.py:272-277
+            loss_d_real = self.gan(self._disc(real).float(), True)
         return self.alpha * (loss_d_fake + loss_d_real) * 0.5                    # train.py:280
 
     # ------------------------------------------------------------------------------------------------
     def compute(self, x, mask, subset_index_list, eps_lists=None):
         """Both backward passes of the step (no optimizer): generator gradients in self.grads, discriminator gradients
         in self.grads_d (unscaled fp32).  Capturable into a hipGraph when the inputs are device resident."""
+        from .disc import pack_scope
         s = self.loss_scale
         self.grads.zero()
         self.grads_d.zero()
-        loss, parts, (fake, real, f_out) = self.generator_forward(x, mask, subset_index_list, eps_lists)
-        (loss * s if s != 1.0 else loss).backward()
-        ops.join_wgrad_stream()
-        if s != 1.0:
-            self.grads.flat.mul_(1.0 / s)
-        loss_d = self.discriminator_forward(fake, real)
-        (loss_d * s if s != 1.0 else loss_d).backward()
-        if s != 1.0:
-            self.grads_d.flat.mul_(1.0 / s)
+        with pack_scope():                                   # the discriminator's weight images are built once for both passes
+            loss, parts, (fake, real, f_out) = self.generator_forward(x, mask, subset_index_list, eps_lists)
+            (loss * s if s != 1.0 else loss).backward()
+            ops.join_wgrad_stream()
+            if s != 1.0:
+                self.grads.flat.mul_(1.0 / s)
+            loss_d = self.discriminator_forward(fake, real)
+            (loss_d * s if s != 1.0 else loss_d).backward()
+            if s != 1.0:
+                self.grads_d.flat.mul_(1.0 / s)
         parts["loss"], parts["loss_d"], parts["f_out"] = loss.detach(), loss_d.detach(), f_out
         return parts
 
