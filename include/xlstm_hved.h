@@ -41,7 +41,13 @@ int xh_abi_version(void);
  *        tiled O(S^2) contraction; A/B tests), bit 4 quad-channel k3 forward / data-gradient kernel, bit 5 quad-channel k3
  *        weight-gradient kernel (both fall back to the implicit-GEMM kernels), bit 6 statistics fan-in (direct atomics).
  * key 3: target workgroup count of the k3 MFMA forward kernel (default 512 = 2 per CU; microbenchmarks: 1024-4096 were 7-25 % slower).
- * key 4: 1 = <=128-VGPR instances of the k3 MFMA forward kernel for <= 8 input channels (microbenchmarks: spills, 2x slower). */
+ * key 4: 1 = <=128-VGPR instances of the k3 MFMA forward kernel for <= 8 input channels (microbenchmarks: spills, 2x slower).
+ * key 5: K step of the discriminator's implicit GEMM in 32-channel quarters (1 | 2, default 2).
+ * key 10-13: launch-plan limits of the generator's conv kernels (microbenchmarks; defaults are the measured optima).
+ * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
+ *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
+ *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 10 / 11 generic kernel instead of the LDS-halo
+ *         kernels of the first conv (data gradient / forward). */
 int xh_set_option(int key, int value);
 /* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call launched (static storage;
  * the same spelling rocprofv3 prints), so measurements can be attributed to a kernel without a profiler attached. */
