@@ -108,3 +108,38 @@ def test_train_step_16bit_runs_and_updates(dtype):
     assert ts.check_finite() and torch.isfinite(parts["loss"]) and torch.isfinite(parts["loss_d"])
     assert not torch.equal(before, m.final_conv.weight.detach())
     assert ts.loss_scale == (65536.0 if dtype == torch.float16 else 1.0)
+
+
+def test_batched_discriminator_step_and_weight_image_cache():
+    """The D update runs its two passes as one batch of 2 and packs the 16-bit weight images once per step: same gradients
+    as two separate passes, and an in-place weight update inside a pack scope is seen by the next pass."""
+    from xlstm_hved_amd import disc as D
+    torch.manual_seed(3)
+    d = _disc(hip=True).to(DEV)
+    ts = TrainStep(torch.nn.Linear(1, 1).to(DEV), d, storage=torch.bfloat16)      # the generator is not used here
+    fake = torch.rand(1, 7, 32, 32, 32, device=DEV).bfloat16()
+    real = torch.rand(1, 7, 32, 32, 32, device=DEV).bfloat16()
+    ts.grads_d.zero()
+    ld = ts.discriminator_forward(fake, real)
+    ld.backward()
+    g_batched = ts.grads_d.flat.clone()
+    ts.grads_d.zero()
+    ld2 = ts.alpha * 0.5 * (ts.gan(d(fake).float(), False) + ts.gan(d(real).float(), True))
+    ld2.backward()
+    g_two = ts.grads_d.flat.clone()
+    torch.cuda.synchronize()
+    assert abs(ld.item() - ld2.item()) <= 1e-5 * abs(ld2.item())
+    assert (g_batched - g_two).abs().max().item() <= 2e-3 * g_two.abs().max().item()
+    # weight images: cached inside a scope, keyed on the weight version
+    with D.pack_scope():
+        y1 = d(fake).float()
+        n_images = len(D._SCOPE["cache"])
+        y1b = d(fake).float()
+        assert len(D._SCOPE["cache"]) == n_images == 5 and torch.equal(y1, y1b)
+        with torch.no_grad():
+            d.last.weight.mul_(2.0)
+        y2 = d(fake).float()
+        assert len(D._SCOPE["cache"]) == n_images + 1
+    assert not D._SCOPE["cache"]
+    torch.cuda.synchronize()
+    assert (y2 - 2.0 * y1).abs().max().item() <= 2e-2 * y1.abs().max().item() + 1e-6
