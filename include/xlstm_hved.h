@@ -46,7 +46,7 @@ int xh_abi_version(void);
  * key 10-13: launch-plan limits of the generator's conv kernels (microbenchmarks; defaults are the measured optima).
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
- *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 10 / 11 generic kernel instead of the LDS-halo
+ *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo
  *         kernels of the first conv (data gradient / forward). */
 int xh_set_option(int key, int value);
 /* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call launched (static storage;

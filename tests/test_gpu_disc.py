@@ -116,3 +116,41 @@ def test_discriminator_forward_backward_vs_stock_modules(dtype):
     k = 1.0 if dtype == torch.bfloat16 else 0.35
     assert e["y"] < 3e-2 * k and e["dx"] < 0.15 * k
     assert all(v < 0.15 * k for kk, v in e.items() if kk not in ("y", "dx"))
+
+
+@pytest.mark.parametrize("mode", ["forward", "dgrad_s2"])
+def test_dconv_256x128_tiles_match_128x128_tiles(mode):
+    """Launches of >= 1024 row tiles take 256 x 128 workgroup tiles (128 x 64 per wave); same numbers as the 128 x 128 plan,
+    and the forward agrees with stock conv3d on a sample of output planes."""
+    torch.manual_seed(9)
+    dtype = torch.bfloat16
+    lib = D.L.load()
+    if mode == "forward":
+        cs, cn, s, sp = 64, 128, 1, (32, 64, 64)
+        spo = sp
+        x = torch.randn(1, *sp, cs, device=DEV).to(dtype)
+        w = torch.randn(cn, cs, 3, 3, 3, device=DEV) * (2.0 / (27 * cs)) ** 0.5
+        wp = D._pack(w, 0, cn, cs, dtype)
+        outs = []
+        for opt in (0, 256):
+            lib.xh_set_option(14, opt)
+            red = torch.zeros(1, cn, 2, dtype=torch.float64, device=DEV)
+            outs.append((D._conv(x, wp, None, 0, s, 1, sp, spo, cs, cn, red=red), red))
+        lib.xh_set_option(14, 0)
+        (y_a, r_a), (y_b, r_b) = outs
+        assert torch.equal(y_a, y_b)
+        assert ((r_a - r_b).abs() / r_b.abs().clamp_min(1.0)).max().item() < 1e-5
+        ref = F.conv3d(_nc(x[:, 10:14].float().cpu()), w.to(dtype).float().cpu(), padding=(0, 1, 1))     # output planes 11, 12
+        assert l2_err(_nc(y_a[:, 11:13].float().cpu()), ref) < 6e-3
+    else:
+        cs, cn, s = 256, 128, 2
+        spo, sp = (16, 32, 32), (32, 64, 64)
+        gy = torch.randn(1, *spo, cs, device=DEV).to(dtype)
+        w = torch.randn(cs, cn, 3, 3, 3, device=DEV) * (2.0 / (27 * cn)) ** 0.5
+        wpt = D._pack(w, 1, cs, cn, dtype)
+        outs = []
+        for opt in (0, 256):
+            lib.xh_set_option(14, opt)
+            outs.append(D._conv(gy, wpt, None, 1, s, 1, spo, sp, cs, cn))
+        lib.xh_set_option(14, 0)
+        assert torch.equal(outs[0], outs[1])

@@ -67,10 +67,12 @@ template <int KQ> __device__ __forceinline__ int swr(int row, int chunk) {
 // PF = K steps in flight in registers (1: the next step only).  Measured on the narrow 256 x 16 tile (64 -> 8 data gradient
 // @128^3, 4 MFMAs per wave per step): PF 1 / 2 / 4 = 753 / 783 / 998 us -- the gather is bound by cache throughput (each dY row
 // is fetched 27 times), not by latency, and the extra registers only cost occupancy.  Kept as an experiment switch
-template <int FMT, int WGN, int TN, int KQ = 1, int PF = 1>
+// TM = 16-row blocks per wave (4: a wave owns 64 rows; 8: 128 rows = a 256 x 128 workgroup tile: 12 fragment reads per 32 MFMAs
+// instead of 16)
+template <int FMT, int WGN, int TN, int KQ = 1, int PF = 1, int TM = 4>
 __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   constexpr int WGM = 4 / WGN;
-  constexpr int BM = WGM * 64, BN = WGN * TN * 16;
+  constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
   constexpr int RB = 64 * KQ, CPRW = 4 * KQ;             // bytes / 16-byte chunks per LDS row
   constexpr int AB = BM * RB, BB = BN * RB;              // bytes per A / B buffer
   constexpr int NA = BM * CPRW / 256, NB = (BN * CPRW + 255) / 256;
@@ -158,26 +160,26 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
       if (col < BN) *reinterpret_cast<uint4*>(Bs + swr<KQ>(col, ch)) = v;
     }
   };
-  auto mfma_step = [&](int buf, f32x4_t (&acc)[4][TN]) __attribute__((always_inline)) {
+  auto mfma_step = [&](int buf, f32x4_t (&acc)[TM][TN]) __attribute__((always_inline)) {
     const unsigned char* As = smem + buf * (AB + BB);
     const unsigned char* Bs = As + AB;
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) {
-      h16x8 af[4], bf[TN];
+      h16x8 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const h16x8*>(As + swr<KQ>(wm * 64 + i * 16 + r16, kq * 4 + kg));
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h16x8*>(As + swr<KQ>((wm * TM + i) * 16 + r16, kq * 4 + kg));
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h16x8*>(Bs + swr<KQ>((wn * TN + j) * 16 + r16, kq * 4 + kg));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma16x16x32<FMT>(bf[j], af[i], acc[i][j]);      // D^T: channels on the rows (epilogue)
     }
   };
 
-  f32x4_t acc[4][TN];
+  f32x4_t acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   if (a.xcd & 2) {                                        // ablation: no epilogue (keeps the accumulators alive)
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (t == 12345.678f) a.y[0] = 1;
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
       s0[j][r] = 0.f; s1[j][r] = 0.f;
     }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = mt * BM + wm * 64 + i * 16 + r16;
+  for (int i = 0; i < TM; ++i) {
+    const int m = mt * BM + (wm * TM + i) * 16 + r16;
     const bool ok = m < R;
     const int mm = ok ? m : 0;
     const int jw = mm % cl.Jw, t2 = mm / cl.Jw;
@@ -961,9 +963,12 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 //   Cn <= 64          256 x 64   (a 128-wide tile would be half padding: first conv forward, 64 <- 128 data gradient); K step 32
 //   < 256 tiles       64 x 64    (256 -> 512 @32^3 forward has 128 tiles of 128 x 128: half of the CUs idle, and one workgroup
 //                                per CU cannot hide the gather latency of a K step: 184 us; 64 x 128: 147 us; 64 x 64: 125 us)
-//   else              128 x 128  (a 256 x 128 tile with 128 x 64 per wave halves the LDS reads per MFMA but needs 205 VGPRs and
-//                                96 KB of LDS = one workgroup per CU: 64 -> 128 forward 242 -> 349 us, dropped)
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward
+//   >= 1024 tiles     256 x 128, 128 x 64 per wave, K step 32: 12 fragment reads per 32 MFMAs instead of 16 (the loop is bound by
+//                                LDS reads), 220 VGPRs / 52 KB = two workgroups per CU: 64 -> 128 forward 238 -> 218 us, 128 <- 256
+//                                data gradient 123 -> 111 us.  (With K step 64 the tile needs 96 KB = one workgroup per CU: 349 us;
+//                                512 x 64 for the 64-channel data gradient: 340 -> 389 us.)
+//   else              128 x 128, K step 64
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -976,6 +981,7 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
     for (int k = 0; k < a.ncls; ++k) tiles += cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, 128);
     tiles *= (long long)cdiv(a.Cn, 128) * N;
     if (tiles < 256 && !(g_dconv_cfg & 4)) { bm = 64; bn = (g_dconv_cfg & 8) ? 128 : 64; cfg = (g_dconv_cfg & 8) ? 3 : 4; }
+    else if (!(g_dconv_cfg & 256) && tiles >= 1024) { bm = 256; bn = 128; cfg = 5; }
     else { bm = 128; bn = 128; cfg = 2; }
   }
   int t = 0;
@@ -996,7 +1002,8 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
     if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 2, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 2>), grid, dim3(256), 0, st, a);
   } else {
-    if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4, 2>), grid, dim3(256), 0, st, a);
+    if (cfg == 5) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4, 1, 1, 8>), grid, dim3(256), 0, st, a);
+    else if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 2, 4>), grid, dim3(256), 0, st, a);
   }
 }
