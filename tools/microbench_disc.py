@@ -34,6 +34,7 @@ for cin, cout, s, sp in layers:
     red = torch.zeros(1, cout, 2, dtype=torch.float64, device="cuda")
     lib = X._lib.load()
     lib.xh_set_option(14, int(os.environ.get("XH_DCFG", "0")))
+    lib.xh_set_option(15, int(os.environ.get("XH_DBIG", "1024")))
     lib.xh_set_option(5, 1)
     t_f1 = bench(lambda: D._conv(x, wp, None, 0, s, 1, (sp,) * 3, (so,) * 3, cin, cout, red=red if cout > 1 and cin > 8 else None))
     lib.xh_set_option(5, 2)

@@ -1292,6 +1292,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 9) { extern int g_red_wgs; g_red_wgs = value < 0 ? 0 : value; return XH_OK; }
   if (key == 5) { extern int g_dconv_kq; g_dconv_kq = value == 1 ? 1 : 2; return XH_OK; }
   if (key == 14) { extern int g_dconv_cfg; g_dconv_cfg = value; return XH_OK; }
+  if (key == 15) { extern int g_dconv_big; g_dconv_big = value < 1 ? 1 : value; return XH_OK; }
   return XH_ERR_ARG;
 }
 

@@ -968,6 +968,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 //                                data gradient 123 -> 111 us.  (With K step 64 the tile needs 96 KB = one workgroup per CU: 349 us;
 //                                512 x 64 for the 64-channel data gradient: 340 -> 389 us.)
 //   else              128 x 128, K step 64
+int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
 int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
@@ -981,7 +982,7 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
     for (int k = 0; k < a.ncls; ++k) tiles += cdiv(a.c[k].Jd * a.c[k].Jh * a.c[k].Jw, 128);
     tiles *= (long long)cdiv(a.Cn, 128) * N;
     if (tiles < 256 && !(g_dconv_cfg & 4)) { bm = 64; bn = (g_dconv_cfg & 8) ? 128 : 64; cfg = (g_dconv_cfg & 8) ? 3 : 4; }
-    else if (!(g_dconv_cfg & 256) && tiles >= 1024) { bm = 256; bn = 128; cfg = 5; }
+    else if (!(g_dconv_cfg & 256) && tiles >= g_dconv_big) { bm = 256; bn = 128; cfg = 5; }
     else { bm = 128; bn = 128; cfg = 2; }
   }
   int t = 0;
