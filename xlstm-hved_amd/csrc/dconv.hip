@@ -583,6 +583,137 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
     }
 }
 
+// The same weight gradient (8 -> 64, stride 1) without the per-step gather: a workgroup walks 4 x 4 x 16 blocks of output voxels;
+// per block the 6 x 6 x 18 halo of X (16 bytes per voxel, 10 KB) and the block's 256 x 64 dY values (eight 32-voxel K steps in
+// the transposed-read layout above) are put in LDS ONCE, and the X operand of a (tap pair, ci) column tile is read straight
+// from the halo -- a tap is an address offset -- with ds_read_b64_tr_b16.  One barrier pair per 256 voxels instead of one per
+// 32, no 27-fold re-fetch of X, the next block's loads in flight behind the 128 MFMAs of the current one.
+struct DWg8HK {
+  const u16* x; const u16* dy; float* dw;
+  int N, D, H, W;
+  int td, th, tw, ntile;
+};
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) {
+  constexpr int PH = 6, PW = 18, NV = 6 * PH * PW;
+  constexpr int YB = 32 * 256;                             // one K step of dY: 32 voxels x (64 of 128) channels, sw256 image
+  __shared__ __attribute__((aligned(16))) unsigned char ys[8 * YB];
+  __shared__ __attribute__((aligned(16))) unsigned char xt[(NV + 1) * 16];          // + one zero voxel for the padding columns
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4, q = r16 >> 2, p = r16 & 3;
+  // X fragment of column tile nt = wv + 4 j: columns = (tap 2 nt + (p >> 1), ci 4 (p & 1) ..): the tap is a constant byte offset
+  int xoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = 2 * (wv + 4 * j) + (p >> 1);
+    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    xoff[j] = t < 27 ? ((kd * PH + kh) * PW + kw) * 16 + 8 * (p & 1) : -1;
+  }
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) *reinterpret_cast<uint4*>(xt + NV * 16) = make_uint4(0, 0, 0, 0);
+  uint4 py[8], px[3];
+  const int per_n = a.td * a.th * a.tw;
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    const int n = t / per_n; int b = t - n * per_n;
+    const int tw_i = b % a.tw; b /= a.tw;
+    const int th_i = b % a.th, td_i = b / a.th;
+    const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
+    const u16* yn = a.dy + (long long)n * a.D * a.H * a.W * 64;
+    const u16* xn = a.x + (long long)n * a.D * a.H * a.W * 8;
+    bool oky[8], okx[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      const int v = idx >> 3, c = idx & 7;
+      const int rb = v >> 4, w = w0 + (v & 15);
+      const int d = d0 + (rb >> 2), h = h0 + (rb & 3);
+      oky[i] = d < a.D && h < a.H && w < a.W;
+      const int dc = min(d, a.D - 1), hc = min(h, a.H - 1), wc = min(w, a.W - 1);
+      py[i] = *reinterpret_cast<const uint4*>(yn + (((long long)dc * a.H + hc) * a.W + wc) * 64 + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int pi = min(tid + i * 256, NV - 1);
+      const int pw = pi % PW, r = pi / PW;
+      const int ph = r % PH, pd = r / PH;
+      const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
+      okx[i] = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+      const int dc = min(max(d, 0), a.D - 1), hc = min(max(h, 0), a.H - 1), wc = min(max(w, 0), a.W - 1);
+      px[i] = *reinterpret_cast<const uint4*>(xn + (((long long)dc * a.H + hc) * a.W + wc) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (!oky[i]) py[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (!okx[i]) px[i] = make_uint4(0, 0, 0, 0);
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      const int v = idx >> 3, c = idx & 7;
+      const int rb = v >> 4;                              // (dz, hy) row of the block; K step = rb >> 1, row in the step = 16 (rb & 1) + w
+      *reinterpret_cast<uint4*>(ys + (rb >> 1) * YB + sw256((rb & 1) * 16 + (v & 15), c)) = py[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int pi = tid + i * 256;
+      if (pi < NV) *reinterpret_cast<uint4*>(xt + pi * 16) = px[i];
+    }
+  };
+  int t = blockIdx.x;
+  if (t < a.ntile) load_tile(t);
+  for (; t < a.ntile; t += gridDim.x) {
+    __syncthreads();                                      // everybody is done with the previous block's tiles
+    store_tile();
+    __syncthreads();
+    if (t + (int)gridDim.x < a.ntile) load_tile(t + gridDim.x);
+#pragma unroll 2
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const unsigned char* Ys = ys + s8 * YB;
+      h16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int chn = 2 * i + (p >> 1);
+        const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Ys + sw256(8 * kg + q, chn) + 8 * (p & 1)));
+        const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(Ys + sw256(8 * kg + 4 + q, chn) + 8 * (p & 1)));
+        af[i] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      // K rows 8 kg + q (+ 4) of the step = voxels w = 8 (kg & 1) + q (+ 4) of block row rb = 2 s8 + (kg >> 1)
+      const int rb = 2 * s8 + (kg >> 1);
+      const int hb = (((rb >> 2) * PH + (rb & 3)) * PW + 8 * (kg & 1) + q) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o_lo = xoff[j] >= 0 ? hb + xoff[j] : NV * 16 + 8 * (p & 1);
+        const int o_hi = xoff[j] >= 0 ? o_lo + 64 : o_lo;
+        const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(xt + o_lo));
+        const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(xt + o_hi));
+        bf[j] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = (wv + 4 * j) * 16 + r16;
+      const int tap = col >> 3, ci = col & 7;
+      if (tap >= 27) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cn = i * 16 + kg * 4 + r;
+        atomicAdd(&a.dw[((long long)tap * 64 + cn) * 8 + ci], acc[i][j][r]);
+      }
+    }
+}
+
 // data gradient of the FIRST conv (64 -> 8 padded input channels, stride 1): the generic kernel gathers every dY row 27 times
 // through the caches for 4 MFMAs per wave per step (750 us @128^3, bound by cache throughput).  Here a workgroup owns a
 // 4 x 4 x 16 block of destination voxels and keeps the 6 x 6 x 18 halo of dY it needs in LDS (32 channels at a time, 80-byte
@@ -969,7 +1100,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity) {
 //                                512 x 64 for the 64-channel data gradient: 340 -> 389 us.)
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1100,6 +1231,20 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void
   a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn; a.stride = stride;
   a.M = (long long)N * Do * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
+  if (Cs == 8 && Cn == 64 && stride == 1 && !(g_dconv_cfg & 8192)) {       // first conv of the network: LDS-halo kernel
+    DWg8HK k;
+    k.x = (const u16*)x; k.dy = (const u16*)dy; k.dw = dwp;
+    k.N = N; k.D = Do; k.H = Ho; k.W = Wo;
+    k.td = cdiv(Do, 4); k.th = cdiv(Ho, 4); k.tw = cdiv(Wo, 16);
+    const long long nt = (long long)N * k.td * k.th * k.tw;
+    if (nt < (1LL << 30)) {
+      k.ntile = (int)nt;
+      const unsigned nwg = (unsigned)(nt < 512 ? nt : 512);
+      if (dtype == XH_F16) hipLaunchKernelGGL(dwgrad_c8_halo_kernel<1>, dim3(nwg), dim3(256), 0, st, k);
+      else hipLaunchKernelGGL(dwgrad_c8_halo_kernel<0>, dim3(nwg), dim3(256), 0, st, k);
+      return xh_launch_status();
+    }
+  }
   if (Cs == 8) {                                          // first conv: the taps ride on the N axis
     const int tiles = cdiv(Cn, 64);
     int msplit = cdiv(1024, tiles);
