@@ -158,6 +158,11 @@ int xh_norm_finalize(void* stream, int mode, const double* red, int N, int C, lo
 /* y = act(x*sc[n,c] + sh[n,c]) -- materialises norm+activation (BasicConv tail, BatchNorm apply). */
 int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
                   long long DHW, const float* sc, const float* sh, int act, float slope);
+/* The same pass with the InstanceNorm finalisation inside: (sc, sh) are derived in the kernel from the raw channel sums
+ * red[N][C][2] a conv epilogue left (count = DHW, eps 1e-5, no affine), and sc / sh / mean / rstd [N][C] are written for the
+ * backward pass.  Replaces xh_norm_finalize(mode 0) + xh_affine_act for BasicConv (buildingblocks.py:13-31) in one launch. */
+int xh_in_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                     long long DHW, const double* red, int act, float slope, float* sc, float* sh, float* mean, float* rstd);
 
 /* Backward reduce through y = leaky(x*sc+sh): g = dy*leaky'(.), red[n][c][0] += g, red[n][c][1] += g*x. */
 int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,

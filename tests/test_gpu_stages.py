@@ -229,3 +229,26 @@ def test_depthwise_k3_sliding_window_kernel_vs_stock(shape, dtype):
         check(y, yo, 2e-5, "dw fwd"), check(xg.grad, xo.grad, 2e-4, "dw dx"), check(m.conv.weight.grad, wo.grad, 2e-4, "dw dw")
     else:
         assert l2_err(y, yo) < 8e-3 and l2_err(xg.grad, xo.grad) < 3e-2 and l2_err(m.conv.weight.grad, wo.grad) < 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_in_affine_act_fused_finalisation_matches_two_launches(dtype):
+    """xh_in_affine_act (InstanceNorm finalisation inside the activation pass) against xh_norm_finalize + xh_affine_act and
+    against InstanceNorm3d + LeakyReLU in fp64; odd volume, two samples."""
+    from xlstm_hved_amd import ops
+    torch.manual_seed(4)
+    n, c, sp = 2, 5, (7, 9, 24)
+    x = (torch.randn(n, c, *sp) * 3.0 + 1.5).to(dtype).to(DEV)
+    red = torch.zeros(n, c, 2, dtype=torch.float64, device=DEV)
+    ops.moments(x, red)
+    y, sc, sh, mean, rstd = ops.in_affine_act(x, red, ops.ACT_LRELU, 0.01)
+    sc2, sh2, mean2, rstd2 = ops.norm_finalize(ops.MODE_IN, red, n, c, sp[0] * sp[1] * sp[2])
+    y2 = ops.affine_act(x, sc2, sh2, ops.ACT_LRELU, 0.01)
+    torch.cuda.synchronize()
+    for a, b in ((sc, sc2), (sh, sh2), (mean, mean2), (rstd, rstd2)):
+        assert ((a - b).abs() <= 4e-7 * b.abs() + 1e-7).all()
+    xd = x.double().cpu()
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(xd, eps=1e-5), 0.01)
+    tol = 2e-6 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 1.5e-3)
+    assert l2_err(y.double().cpu(), want) < tol and l2_err(y2.double().cpu(), want) < tol
+    assert (y.float() - y2.float()).abs().max().item() <= (2e-6 if dtype == torch.float32 else 4e-2)

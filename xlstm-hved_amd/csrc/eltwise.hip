@@ -4,6 +4,7 @@
 // length and strides allow it, otherwise a scalar tail path.  Reductions: fp32 in the lane, fp32 across
 // the block, fp64 atomics across blocks (few workgroups per address: red_grid below).
 #include "common.h"
+#include "conv_pack.h"
 #include "../../include/xlstm_hved.h"
 
 #define EW_BLOCK 256
@@ -176,11 +177,24 @@ extern "C" int xh_norm_finalize(void* stream, int mode, const double* red, int N
 }
 
 // ---------------------------------------------------------------------------------------- affine + act
+// fin_red != nullptr: InstanceNorm finalisation inside the kernel (xh_in_affine_act): (sc, sh) come from the channel's raw sums
+// (every workgroup evaluates the few flops for its own channel, conv_pack.h: in_finalize) and the first workgroup of the channel
+// leaves sc / sh / mean / rstd behind for the backward pass -- no xh_norm_finalize launch between the conv and this pass
 template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
                                                              long long dhw, const float* sc, const float* sh, int act,
-                                                             float slope) {
-  const float a = sc ? sc[blockIdx.z * C + blockIdx.y] : 1.f, b = sh ? sh[blockIdx.z * C + blockIdx.y] : 0.f;
+                                                             float slope, const double* fin_red, double inv_count, float* o_sc,
+                                                             float* o_sh, float* o_mean, float* o_rstd) {
+  float a, b;
+  if (fin_red) {
+    const long long nc = (long long)blockIdx.z * C + blockIdx.y;
+    float m, r;
+    in_finalize(fin_red[nc * 2], fin_red[nc * 2 + 1], inv_count, a, b, m, r);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { o_sc[nc] = a; o_sh[nc] = b; o_mean[nc] = m; o_rstd[nc] = r; }
+  } else {
+    a = sc ? sc[blockIdx.z * C + blockIdx.y] : 1.f;
+    b = sh ? sh[blockIdx.z * C + blockIdx.y] : 0.f;
+  }
   ROW_LOOP_BEGIN
     const T* xp = x + n * x_bs + (long long)c * dhw;
     T* yp = y + n * y_bs + (long long)c * dhw;
@@ -192,20 +206,30 @@ __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long l
   ROW_LOOP_END
 }
 
-extern "C" int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
-                             int C, long long DHW, const float* sc, const float* sh, int act, float slope) {
+static int launch_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C, long long DHW,
+                             const float* sc, const float* sh, int act, float slope, const double* fin_red, double inv_count, float* o_sc,
+                             float* o_sh, float* o_mean, float* o_rstd) {
   if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   const bool vec32 = vec_ok<float>(DHW, {x_bs, y_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, y_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
-  if (dtype == XH_F32)
-    { if (vec32) hipLaunchKernelGGL((affine_act_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope); else hipLaunchKernelGGL((affine_act_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, (float*)y, y_bs, C, DHW, sc, sh, act, slope); }
-  else if (dtype == XH_BF16)
-    { if (vec16) hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope); else hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, (bf16_t*)y, y_bs, C, DHW, sc, sh, act, slope); }
-  else if (dtype == XH_F16)
-    { if (vec16) hipLaunchKernelGGL((affine_act_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, sc, sh, act, slope); else hipLaunchKernelGGL((affine_act_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, (f16_t*)y, y_bs, C, DHW, sc, sh, act, slope); }
-  else
-    return XH_ERR_DTYPE;
+#define AA(T, V, G) hipLaunchKernelGGL((affine_act_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, x_bs, (T*)y, y_bs, C, DHW, sc, sh, act, slope, fin_red, inv_count, o_sc, o_sh, o_mean, o_rstd)
+  if (dtype == XH_F32) { if (vec32) AA(float, true, grid32); else AA(float, false, grid32); }
+  else if (dtype == XH_BF16) { if (vec16) AA(bf16_t, true, grid16); else AA(bf16_t, false, grid16); }
+  else if (dtype == XH_F16) { if (vec16) AA(f16_t, true, grid16); else AA(f16_t, false, grid16); }
+  else return XH_ERR_DTYPE;
+#undef AA
   return xh_launch_status();
+}
+
+extern "C" int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
+                             int C, long long DHW, const float* sc, const float* sh, int act, float slope) {
+  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, sc, sh, act, slope, nullptr, 0.0, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int xh_in_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                                long long DHW, const double* red, int act, float slope, float* sc, float* sh, float* mean, float* rstd) {
+  if (!red || !sc || !sh || !mean || !rstd) return XH_ERR_ARG;
+  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, nullptr, nullptr, act, slope, red, 1.0 / (double)DHW, sc, sh, mean, rstd);
 }
 
 // ---------------------------------------------------------------------------------------- act/norm backward

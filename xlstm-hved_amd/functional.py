@@ -184,8 +184,7 @@ class ConvInLrelu(Function):
         cout, k = weight.shape[0], weight.shape[-1]
         red = ops.zeros_red(x, n, cout)
         y0 = ops.conv3d(x, None, [weight], None, k=k, cout=cout, groups=groups, epi=2, red=red)
-        sc, sh, mean, rstd = ops.norm_finalize(MODE_IN, red, n, cout, _dhw(y0))
-        y = ops.affine_act(y0, sc, sh, ACT_LRELU, LEAK)
+        y, sc, sh, mean, rstd = ops.in_affine_act(y0, red, ACT_LRELU, LEAK)
         ctx.save_for_backward(x, y0, weight, sc, sh, mean, rstd)
         ctx.cfg = (groups, k)
         ctx.params = (weight,)

@@ -532,6 +532,16 @@ def affine_act(x, sc, sh, act, slope=LEAK, out=None):
     return out
 
 
+def in_affine_act(x, red, act, slope=LEAK):
+    """InstanceNorm (from the raw channel sums `red`) + activation in one launch; returns y, sc, sh, mean, rstd."""
+    n, c, d, h, w, bs = _vol(x)
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    sc, sh, mean, rstd = (torch.empty((n, c), dtype=torch.float32, device=x.device) for _ in range(4))
+    L.check(L.load().xh_in_affine_act(_stream(), _dt(x), _p(x), bs, _p(out), _vol(out)[5], n, c, d * h * w, _p(red), act, slope,
+                                      _p(sc), _p(sh), _p(mean), _p(rstd)), "xh_in_affine_act")
+    return out, sc, sh, mean, rstd
+
+
 def act_bwd_reduce(dy, x, sc, sh, slope):
     n, c, d, h, w, bs = _vol(x)
     red = zeros_red(x, n, c)
