@@ -180,6 +180,12 @@ int xh_norm_bwd_coef(void* stream, int mode, const double* red, int N, int C, lo
 int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
                       void* dx, long long dx_bs, int N, int C, long long DHW, const float* A, const float* B,
                       const float* Cc, int have_g, const float* sc, const float* sh, float slope, int accumulate);
+/* xh_norm_bwd_coef + xh_norm_bwd_apply in one launch for BatchNorm (mode 1 train, 2 eval) and GroupNorm (mode 3): the
+ * coefficients are derived inside the kernel from red[N][C][2] = {sum g, sum g*x}, mean, rstd [N][C] (count = DHW), g = dy;
+ * dgamma / dbeta [C] are accumulated as xh_norm_bwd_coef does.  Same arithmetic, same results. */
+int xh_norm_bwd_fused(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                      void* dx, long long dx_bs, int N, int C, long long DHW, const double* red, int gs,
+                      const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta);
 /* InstanceNorm backward in one launch (autograd of nn.InstanceNorm3d in create_conv, buildingblocks.py:431, and in BasicConv,
  * buildingblocks.py:21-24): coefficients derived per (n, c) row from the raw sums red = (sum g, sum g*x) of
  * xh_act_bwd_reduce / the conv epilogue, and the forward's mean / rstd.  red, mean, rstd (and sc, sh when have_g == 0)

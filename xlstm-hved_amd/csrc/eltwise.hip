@@ -360,6 +360,76 @@ __global__ __launch_bounds__(EW_BLOCK) void norm_bwd_apply_kernel(const T* dy, l
   ROW_LOOP_END
 }
 
+// GroupNorm / BatchNorm flavour with the coefficient step folded in (xh_norm_bwd_fused): the arithmetic of
+// norm_bwd_coef_kernel, evaluated by every workgroup for its own (n, c) -- a loop over the gs channels of the group or the N
+// samples of the batch -- and the affine gradients added by the first workgroup of sample 0.  g = dy (activation already undone).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void norm_bwd_fused_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs, T* dx,
+                                                                 long long dx_bs, int mode, const double* red, int N, int C,
+                                                                 long long dhw, int gs, const float* gamma, const float* mean,
+                                                                 const float* rstd, float* dgamma, float* dbeta) {
+  const int cc = blockIdx.y, nn = blockIdx.z;
+  const int i0 = nn * C + cc;
+  const double ga = gamma ? (double)gamma[cc] : 1.0;
+  const double mu = mean[i0], rs = rstd[i0];
+  auto P_of = [&](int k) { return (double)rstd[k] * (red[k * 2 + 1] - (double)mean[k] * red[k * 2]); };
+  double S0 = 0, P = 0, M = 1;
+  const bool writer = blockIdx.x == 0 && nn == 0 && threadIdx.x == 0;
+  if (mode == 1 || mode == 2) {
+    for (int k = 0; k < N; ++k) { S0 += red[(k * C + cc) * 2]; P += P_of(k * C + cc); }
+    if (writer) {
+      if (dgamma) dgamma[cc] += (float)P;
+      if (dbeta) dbeta[cc] += (float)S0;
+    }
+    S0 *= ga; P *= ga; M = (double)dhw * N;
+  } else {
+    const int g0 = (cc / gs) * gs;
+    for (int k = g0; k < g0 + gs; ++k) {
+      const double gk = gamma ? (double)gamma[k] : 1.0;
+      S0 += gk * red[(nn * C + k) * 2];
+      P += gk * P_of(nn * C + k);
+    }
+    M = (double)dhw * gs;
+    if (writer) {
+      double pp = 0, ss = 0;
+      for (int k = 0; k < N; ++k) { pp += P_of(k * C + cc); ss += red[(k * C + cc) * 2]; }
+      if (dgamma) dgamma[cc] += (float)pp;
+      if (dbeta) dbeta[cc] += (float)ss;
+    }
+  }
+  float a_ = (float)(ga * rs), b_ = 0.f, c_ = 0.f;
+  if (mode != 2) {
+    c_ = (float)(-rs * rs * P / M);
+    b_ = (float)(-rs * S0 / M + rs * rs * mu * P / M);
+  }
+  ROW_LOOP_BEGIN
+    float g[VW], xv[VW], o[VW];
+    ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q, valid, g);
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) o[i] = a_ * g[i] + c_ * xv[i] + b_;
+    strow<VEC>(dx + n * dx_bs + (long long)c * dhw, q, valid, o);
+  ROW_LOOP_END
+}
+
+extern "C" int xh_norm_bwd_fused(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                                 void* dx, long long dx_bs, int N, int C, long long DHW, const double* red, int gs,
+                                 const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta) {
+  if (mode < 1 || mode > 3 || !dy || !x || !dx || !red || !mean || !rstd || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535)
+    return XH_ERR_ARG;
+  if (mode == 3 && (gs <= 0 || C % gs)) return XH_ERR_ARG;
+  if (mode != 3) gs = 1;
+  const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
+#define NB(T, V, G) hipLaunchKernelGGL((norm_bwd_fused_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)dy, dy_bs, (const T*)x, x_bs, (T*)dx, dx_bs, mode, red, N, C, DHW, gs, gamma, mean, rstd, dgamma, dbeta)
+  if (dtype == XH_F32) { if (vec32) NB(float, true, grid32); else NB(float, false, grid32); }
+  else if (dtype == XH_BF16) { if (vec16) NB(bf16_t, true, grid16); else NB(bf16_t, false, grid16); }
+  else if (dtype == XH_F16) { if (vec16) NB(f16_t, true, grid16); else NB(f16_t, false, grid16); }
+  else return XH_ERR_DTYPE;
+#undef NB
+  return xh_launch_status();
+}
+
 // InstanceNorm flavour with the coefficient step folded in: every workgroup derives A, B, C of its (n, c) row from the
 // raw fp64 sums (sum g, sum g*x), mean and rstd -- a handful of flops -- so the one-block coefficient launch disappears.
 // The statistics arrays may be wider than this tensor's channel count (virtual concat): row stride `stat_rs`.

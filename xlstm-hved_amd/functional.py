@@ -169,8 +169,7 @@ class GnConvRelu(Function):
             g = ops.conv3d(dyr, None, [weight], None, k=k, cout=c, transposed=True, epi=1, e=e, red=red)
         else:
             g = ops.conv3d_dgrad_s2(dyr, [weight], cin=c, in_spatial=tuple(x.shape[2:]), e=e, red=red)
-        coef = ops.norm_bwd_coef(MODE_GN, red, _dhw(x), mean, rstd, gs=gs, gamma=gamma, dgamma=dgamma, dbeta=dbeta)
-        dx = ops.norm_bwd_apply(g, x, coef, have_g=True)
+        dx = ops.norm_bwd_fused(MODE_GN, g, x, red, mean, rstd, gs=gs, gamma=gamma, dgamma=dgamma, dbeta=dbeta)
         return dx, rw, rgamma, rbeta, None, None
 
 
@@ -406,8 +405,7 @@ class SkipReturnAttention(Function):
         dtg, dx_res, dsaw = ops.skr_tail_bwd(t2, x, sc2, sh2, w2, a, _blk(da))
         # BatchNorm 2
         red = ops.act_bwd_reduce(dtg, t2, sc2, sh2, 1.0)
-        coef = ops.norm_bwd_coef(mode, red, cnt, m2, r2, gamma=g2, dgamma=dg2, dbeta=db2)
-        dt2 = ops.norm_bwd_apply(dtg, t2, coef, have_g=True)
+        dt2 = ops.norm_bwd_fused(mode, dtg, t2, red, m2, r2, gamma=g2, dgamma=dg2, dbeta=db2)
         # pointwise 2
         ops.conv3d_wgrad(u2, None, dt2, [dpw2w], [dpw2b], k=1, side=sd)
         du2 = ops.conv3d(dt2, None, [pw2w], None, k=1, cout=c, transposed=True)
@@ -415,8 +413,7 @@ class SkipReturnAttention(Function):
         ops.conv3d_wgrad(t1, None, du2, [ddw2], None, k=3, groups=c, pre=(sc1, sh1, 0.0), side=sd)
         red = ops.zeros_red(x, n, c)
         gt1 = ops.conv3d(du2, None, [dw2], None, k=3, cout=c, groups=c, transposed=True, epi=1, e=(t1, None, sc1, sh1, 0.0), red=red)
-        coef = ops.norm_bwd_coef(mode, red, cnt, m1, r1, gamma=g1, dgamma=dg1, dbeta=db1)
-        dt1 = ops.norm_bwd_apply(gt1, t1, coef, have_g=True)
+        dt1 = ops.norm_bwd_fused(mode, gt1, t1, red, m1, r1, gamma=g1, dgamma=dg1, dbeta=db1)
         # pointwise 1, depthwise 1
         ops.conv3d_wgrad(u1, None, dt1, [dpw1w], [dpw1b], k=1, side=sd)
         du1 = ops.conv3d(dt1, None, [pw1w], None, k=1, cout=c, transposed=True)
@@ -481,8 +478,7 @@ class DuSE(Function):
         for do, u, sc, sh, m, rs, gam, dg, db in ((dor, u_r, sc1, sh1, m1, rs1, g1, dg1, dbe1), (dos, u_s, sc2, sh2, m2, rs2, g2, dg2, dbe2)):
             do = _blk(do)
             red = ops.act_bwd_reduce(do, u, sc, sh, 1.0)
-            coef = ops.norm_bwd_coef(mode, red, cnt, m, rs, gamma=gam, dgamma=dg, dbeta=db)
-            dus.append(ops.norm_bwd_apply(do, u, coef, have_g=True))
+            dus.append(ops.norm_bwd_fused(mode, do, u, red, m, rs, gamma=gam, dgamma=dg, dbeta=db))
         dsp = torch.empty_like(sp)
         dr, dch1 = ops.duse_gate_bwd(r, ch1, sp[:, 0:1], dus[0], dsp[:, 0:1])
         ds, dch2 = ops.duse_gate_bwd(s, ch2, sp[:, 1:2], dus[1], dsp[:, 1:2])

@@ -573,6 +573,16 @@ def norm_bwd_apply(dy, x, coef, *, have_g, sc=None, sh=None, slope=LEAK, out=Non
     return out
 
 
+def norm_bwd_fused(mode, dy, x, red, mean, rstd, *, gs=1, gamma=None, dgamma=None, dbeta=None):
+    """norm_bwd_coef + norm_bwd_apply(have_g=True) of a BatchNorm / GroupNorm in one launch (count = x's volume)."""
+    n, c, d, h, w, bs = _vol(x)
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    L.check(L.load().xh_norm_bwd_fused(_stream(), _dt(x), mode, _p(dy), _vol(dy)[5], _p(x), bs, _p(out), _vol(out)[5], n, c,
+                                       d * h * w, _p(red), gs, _p(gamma), _p(mean), _p(rstd), _p(dgamma), _p(dbeta)),
+            "xh_norm_bwd_fused")
+    return out
+
+
 def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK, c0=0):
     """InstanceNorm backward of x's channels (window starting at c0 of dy / the statistics) in one launch."""
     n, c, d, h, w, bs = _vol(x)
