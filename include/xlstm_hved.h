@@ -163,6 +163,11 @@ int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* 
  * backward pass.  Replaces xh_norm_finalize(mode 0) + xh_affine_act for BasicConv (buildingblocks.py:13-31) in one launch. */
 int xh_in_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
                      long long DHW, const double* red, int act, float slope, float* sc, float* sh, float* mean, float* rstd);
+/* BatchNorm3d flavour (mode 1 train: batch statistics from red, running statistics updated `steps` times as in
+ * xh_norm_finalize; mode 2 eval: running statistics): DuSEAttention's output norms (modules/DuSFE.py:108-110,151-153). */
+int xh_bn_affine_act(void* stream, int dtype, int mode, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                     long long DHW, const double* red, float eps, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, int steps, int act, float slope, float* sc, float* sh, float* mean, float* rstd);
 
 /* Backward reduce through y = leaky(x*sc+sh): g = dy*leaky'(.), red[n][c][0] += g, red[n][c][1] += g*x. */
 int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,

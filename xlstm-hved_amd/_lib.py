@@ -62,6 +62,7 @@ SIGNATURES = {
     "xh_norm_finalize": (I, [vp, I, vp, I, I, ll, I, F, vp, vp, vp, vp, I, vp, vp, vp, vp]),
     "xh_affine_act": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, I, F]),
     "xh_in_affine_act": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, I, F, vp, vp, vp, vp]),
+    "xh_bn_affine_act": (I, [vp, I, I, vp, ll, vp, ll, I, I, ll, vp, F, vp, vp, vp, vp, I, I, F, vp, vp, vp, vp]),
     "xh_act_bwd_reduce": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, F, vp]),
     "xh_norm_bwd_coef": (I, [vp, I, vp, I, I, ll, I, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_in_bwd_apply": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I, I, vp, vp, F, I]),

@@ -177,23 +177,56 @@ extern "C" int xh_norm_finalize(void* stream, int mode, const double* red, int N
 }
 
 // ---------------------------------------------------------------------------------------- affine + act
-// fin_red != nullptr: InstanceNorm finalisation inside the kernel (xh_in_affine_act): (sc, sh) come from the channel's raw sums
-// (every workgroup evaluates the few flops for its own channel, conv_pack.h: in_finalize) and the first workgroup of the channel
-// leaves sc / sh / mean / rstd behind for the backward pass -- no xh_norm_finalize launch between the conv and this pass
+// The norm finalisation can ride inside this pass (no xh_norm_finalize launch between the producer of the sums and here): every
+// workgroup evaluates the few flops for its own channel and the first workgroup of the channel leaves sc / sh / mean / rstd
+// behind for the backward pass (and updates the BatchNorm running statistics).
+//   mode -1: sc / sh given;  0: InstanceNorm from raw sums (conv_pack.h: in_finalize);  1 / 2: BatchNorm train / eval, the
+//   arithmetic of norm_finalize_kernel
+struct AffFin {
+  int mode;
+  const double* red; int N; double count; float eps;
+  const float* gamma; const float* beta; float* running_mean; float* running_var; int steps;
+  float* o_sc; float* o_sh; float* o_mean; float* o_rstd;
+};
 template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
                                                              long long dhw, const float* sc, const float* sh, int act,
-                                                             float slope, const double* fin_red, double inv_count, float* o_sc,
-                                                             float* o_sh, float* o_mean, float* o_rstd) {
+                                                             float slope, const AffFin f) {
   float a, b;
-  if (fin_red) {
-    const long long nc = (long long)blockIdx.z * C + blockIdx.y;
+  const int cc = blockIdx.y;
+  const long long nc = (long long)blockIdx.z * C + cc;
+  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+  if (f.mode == 0) {
     float m, r;
-    in_finalize(fin_red[nc * 2], fin_red[nc * 2 + 1], inv_count, a, b, m, r);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { o_sc[nc] = a; o_sh[nc] = b; o_mean[nc] = m; o_rstd[nc] = r; }
+    in_finalize(f.red[nc * 2], f.red[nc * 2 + 1], 1.0 / f.count, a, b, m, r);
+    if (writer) { f.o_sc[nc] = a; f.o_sh[nc] = b; f.o_mean[nc] = m; f.o_rstd[nc] = r; }
+  } else if (f.mode > 0) {
+    double mean, var;
+    if (f.mode == 1) {
+      double s0 = 0, s1 = 0;
+      for (int k = 0; k < f.N; ++k) { s0 += f.red[((long long)k * C + cc) * 2]; s1 += f.red[((long long)k * C + cc) * 2 + 1]; }
+      const double M = f.count * f.N;
+      mean = s0 / M;
+      var = s1 / M - mean * mean;
+      if (writer && blockIdx.z == 0 && f.running_mean && f.running_var) {
+        const double keep = pow(0.9, (double)f.steps);
+        const double unb = var * M / (M > 1 ? M - 1 : 1);
+        f.running_mean[cc] = (float)(keep * f.running_mean[cc] + (1 - keep) * mean);
+        f.running_var[cc] = (float)(keep * f.running_var[cc] + (1 - keep) * unb);
+      }
+    } else {
+      mean = f.running_mean[cc];
+      var = f.running_var[cc];
+    }
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)f.eps);
+    const double ga = f.gamma ? (double)f.gamma[cc] : 1.0, be = f.beta ? (double)f.beta[cc] : 0.0;
+    a = (float)(rstd * ga);
+    b = (float)(be - mean * rstd * ga);
+    if (writer) { f.o_sc[nc] = a; f.o_sh[nc] = b; f.o_mean[nc] = (float)mean; f.o_rstd[nc] = (float)rstd; }
   } else {
-    a = sc ? sc[blockIdx.z * C + blockIdx.y] : 1.f;
-    b = sh ? sh[blockIdx.z * C + blockIdx.y] : 0.f;
+    a = sc ? sc[nc] : 1.f;
+    b = sh ? sh[nc] : 0.f;
   }
   ROW_LOOP_BEGIN
     const T* xp = x + n * x_bs + (long long)c * dhw;
@@ -207,12 +240,11 @@ __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long l
 }
 
 static int launch_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C, long long DHW,
-                             const float* sc, const float* sh, int act, float slope, const double* fin_red, double inv_count, float* o_sc,
-                             float* o_sh, float* o_mean, float* o_rstd) {
+                             const float* sc, const float* sh, int act, float slope, const AffFin& f) {
   if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   const bool vec32 = vec_ok<float>(DHW, {x_bs, y_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, y_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
-#define AA(T, V, G) hipLaunchKernelGGL((affine_act_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, x_bs, (T*)y, y_bs, C, DHW, sc, sh, act, slope, fin_red, inv_count, o_sc, o_sh, o_mean, o_rstd)
+#define AA(T, V, G) hipLaunchKernelGGL((affine_act_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, x_bs, (T*)y, y_bs, C, DHW, sc, sh, act, slope, f)
   if (dtype == XH_F32) { if (vec32) AA(float, true, grid32); else AA(float, false, grid32); }
   else if (dtype == XH_BF16) { if (vec16) AA(bf16_t, true, grid16); else AA(bf16_t, false, grid16); }
   else if (dtype == XH_F16) { if (vec16) AA(f16_t, true, grid16); else AA(f16_t, false, grid16); }
@@ -223,13 +255,31 @@ static int launch_affine_act(void* stream, int dtype, const void* x, long long x
 
 extern "C" int xh_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
                              int C, long long DHW, const float* sc, const float* sh, int act, float slope) {
-  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, sc, sh, act, slope, nullptr, 0.0, nullptr, nullptr, nullptr, nullptr);
+  AffFin f{};
+  f.mode = -1;
+  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, sc, sh, act, slope, f);
 }
 
 extern "C" int xh_in_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
                                 long long DHW, const double* red, int act, float slope, float* sc, float* sh, float* mean, float* rstd) {
   if (!red || !sc || !sh || !mean || !rstd) return XH_ERR_ARG;
-  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, nullptr, nullptr, act, slope, red, 1.0 / (double)DHW, sc, sh, mean, rstd);
+  AffFin f{};
+  f.mode = 0; f.red = red; f.N = N; f.count = (double)DHW;
+  f.o_sc = sc; f.o_sh = sh; f.o_mean = mean; f.o_rstd = rstd;
+  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, nullptr, nullptr, act, slope, f);
+}
+
+extern "C" int xh_bn_affine_act(void* stream, int dtype, int mode, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                                long long DHW, const double* red, float eps, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, int steps, int act, float slope, float* sc, float* sh, float* mean, float* rstd) {
+  if ((mode != 1 && mode != 2) || !sc || !sh || !mean || !rstd) return XH_ERR_ARG;
+  if (mode == 1 && !red) return XH_ERR_ARG;
+  if (mode == 2 && (!running_mean || !running_var)) return XH_ERR_ARG;
+  AffFin f{};
+  f.mode = mode; f.red = red; f.N = N; f.count = (double)DHW; f.eps = eps;
+  f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var; f.steps = steps;
+  f.o_sc = sc; f.o_sh = sh; f.o_mean = mean; f.o_rstd = rstd;
+  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, nullptr, nullptr, act, slope, f);
 }
 
 // ---------------------------------------------------------------------------------------- act/norm backward

@@ -457,9 +457,8 @@ class DuSE(Function):
             if training:
                 red = ops.zeros_red(r, n, c)
                 ops.moments(u, red)
-            sc, sh, m, rs = ops.norm_finalize(mode, red, n, c, cnt, gamma=gam, beta=bet, running_mean=rm, running_var=rv,
-                                              steps=1, device=r.device)
-            outs.append(ops.affine_act(u, sc, sh, ACT_NONE))
+            y, sc, sh, m, rs = ops.bn_affine_act(mode, u, red, ACT_NONE, gamma=gam, beta=bet, running_mean=rm, running_var=rv, steps=1)
+            outs.append(y)
             stats += [sc, sh, m, rs]
         ctx.save_for_backward(r, s, red_r, red_s, gvec, ch1, ch2, comb, sp, u_r, u_s, *stats, wc, w1, w2, sqw, adjw, g1, g2)
         ctx.mode = mode

@@ -542,6 +542,18 @@ def in_affine_act(x, red, act, slope=LEAK):
     return out, sc, sh, mean, rstd
 
 
+def bn_affine_act(mode, x, red, act, *, gamma=None, beta=None, running_mean=None, running_var=None, steps=1, slope=LEAK):
+    """BatchNorm finalisation (train: batch statistics from `red`, running statistics updated; eval: running statistics) +
+    activation in one launch; returns y, sc, sh, mean, rstd."""
+    n, c, d, h, w, bs = _vol(x)
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    sc, sh, mean, rstd = (torch.empty((n, c), dtype=torch.float32, device=x.device) for _ in range(4))
+    L.check(L.load().xh_bn_affine_act(_stream(), _dt(x), mode, _p(x), bs, _p(out), _vol(out)[5], n, c, d * h * w, _p(red), NORM_EPS,
+                                      _p(gamma), _p(beta), _p(running_mean), _p(running_var), steps, act, slope, _p(sc), _p(sh),
+                                      _p(mean), _p(rstd)), "xh_bn_affine_act")
+    return out, sc, sh, mean, rstd
+
+
 def act_bwd_reduce(dy, x, sc, sh, slope):
     n, c, d, h, w, bs = _vol(x)
     red = zeros_red(x, n, c)
