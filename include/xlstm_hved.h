@@ -253,6 +253,10 @@ int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const vo
  * (already sigmoid'ed, fp32 [N][C]), sp = spatial gate (1 channel). */
 int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                      long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW);
+/* The same pass, also leaving the channel sums of u (red[N][C][2] += {sum u, sum u^2}, the caller zeroes red) for the
+ * BatchNorm3d that follows (modules/DuSFE.py:151-153): replaces a separate xh_moments pass over u. */
+int xh_duse_gate_fwd_stats(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
+                           long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW, double* red);
 /* dx = du*(1+ch+sp); dsp = sum_c du*x; dch[n][c] += sum_p du*x (double accum buffer red1 [N][C]) */
 int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                      long long sp_bs, const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "xh_gate_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll]),
     "xh_gate_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, ll, I, I]),
     "xh_duse_gate_fwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll]),
+    "xh_duse_gate_fwd_stats": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll, vp]),
     "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll]),
     "xh_rank1_add": (I, [vp, I, vp, ll, vp, ll, vp, vp, I, I, ll]),
     "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -1378,10 +1378,14 @@ extern "C" int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_b
 }
 
 // ---------------------------------------------------------------------------------------- DuSE gates
+// red != nullptr: the channel sums of the (rounded) output for the BatchNorm that follows (red[n][c][0..1] += sum u, sum u^2),
+// as xh_moments would find them in u -- launched on the reduction grid then (few, long workgroups per atomic address)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void duse_gate_fwd_kernel(const T* x, long long x_bs, const float* ch, const T* sp,
-                                                                long long sp_bs, T* u, long long u_bs, int C, long long dhw) {
+                                                                long long sp_bs, T* u, long long u_bs, int C, long long dhw, double* red) {
+  __shared__ double s_red[4 * 2];
   const float cg = 1.f + ch[blockIdx.z * C + blockIdx.y];
+  double s[2] = {0.0, 0.0};
   ROW_LOOP_BEGIN
     float xv[VW], sv[VW];
     ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
@@ -1389,7 +1393,19 @@ __global__ __launch_bounds__(EW_BLOCK) void duse_gate_fwd_kernel(const T* x, lon
 #pragma unroll
     for (int i = 0; i < VW; ++i) xv[i] *= (cg + sv[i]);
     strow<VEC>(u + n * u_bs + (long long)c * dhw, q, valid, xv);
+    if (red) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+        if (i < valid) { const float r = rnd_as((const T*)nullptr, xv[i]); t0 += r; t1 = fmaf(r, r, t1); }
+      s[0] += (double)t0;
+      s[1] += (double)t1;
+    }
   ROW_LOOP_END
+  if (red) {
+    block_sum_d<2>(s, s_red, EW_BLOCK >> 6);
+    if (threadIdx.x < 2) atomicAdd(&red[((long long)blockIdx.z * C + blockIdx.y) * 2 + threadIdx.x], s_red[threadIdx.x]);
+  }
 }
 // lane per voxel over channels; dch via block reduction per channel would need C reductions: instead each
 // block owns one (n, c) row for dch and the dsp accumulation goes through a second voxel-major kernel.
@@ -1443,20 +1459,28 @@ __global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* __restri
     strow<VEC>(dsp + n * dsp_bs, q, valid, a);
   VOX_LOOP_END
 }
-extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
-                                long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW) {
+static int launch_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp, long long sp_bs,
+                                void* u, long long u_bs, int N, int C, long long DHW, double* red) {
   if (!x || !ch || !sp || !u || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   const bool vec32 = vec_ok<float>(DHW, {x_bs, sp_bs, u_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, sp_bs, u_bs});
-  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
-  if (dtype == XH_F32)
-    { if (vec32) hipLaunchKernelGGL((duse_gate_fwd_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_fwd_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, ch, (const float*)sp, sp_bs, (float*)u, u_bs, C, DHW); }
-  else if (dtype == XH_BF16)
-    { if (vec16) hipLaunchKernelGGL((duse_gate_fwd_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_fwd_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, ch, (const bf16_t*)sp, sp_bs, (bf16_t*)u, u_bs, C, DHW); }
-  else if (dtype == XH_F16)
-    { if (vec16) hipLaunchKernelGGL((duse_gate_fwd_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (f16_t*)u, u_bs, C, DHW); else hipLaunchKernelGGL((duse_gate_fwd_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, ch, (const f16_t*)sp, sp_bs, (f16_t*)u, u_bs, C, DHW); }
-  else
-    return XH_ERR_DTYPE;
+  const dim3 grid32 = red ? red_grid<float>(DHW, C, N) : row_grid<float>(DHW, C, N);
+  const dim3 grid16 = red ? red_grid<bf16_t>(DHW, C, N) : row_grid<bf16_t>(DHW, C, N);
+#define DG(T, V, G) hipLaunchKernelGGL((duse_gate_fwd_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, x_bs, ch, (const T*)sp, sp_bs, (T*)u, u_bs, C, DHW, red)
+  if (dtype == XH_F32) { if (vec32) DG(float, true, grid32); else DG(float, false, grid32); }
+  else if (dtype == XH_BF16) { if (vec16) DG(bf16_t, true, grid16); else DG(bf16_t, false, grid16); }
+  else if (dtype == XH_F16) { if (vec16) DG(f16_t, true, grid16); else DG(f16_t, false, grid16); }
+  else return XH_ERR_DTYPE;
+#undef DG
   return xh_launch_status();
+}
+extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
+                                long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW) {
+  return launch_duse_gate_fwd(stream, dtype, x, x_bs, ch, sp, sp_bs, u, u_bs, N, C, DHW, nullptr);
+}
+extern "C" int xh_duse_gate_fwd_stats(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
+                                      long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW, double* red) {
+  if (!red) return XH_ERR_ARG;
+  return launch_duse_gate_fwd(stream, dtype, x, x_bs, ch, sp, sp_bs, u, u_bs, N, C, DHW, red);
 }
 extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                                 long long sp_bs, const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp,

@@ -449,14 +449,12 @@ class DuSE(Function):
         gvec, ch1, ch2 = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc)
         comb = ops.conv3d(r, s, [sqw], [sqb], k=1, cout=1)
         sp = ops.conv3d(comb, None, [adjw], [adjb], k=3, cout=2, act=ACT_SIGMOID)
-        u_r = ops.duse_gate(r, ch1, sp[:, 0:1])
-        u_s = ops.duse_gate(s, ch2, sp[:, 1:2])
+        red_ur = ops.zeros_red(r, n, c) if training else None     # BatchNorm sums of the gated outputs, left by the gate pass
+        red_us = ops.zeros_red(r, n, c) if training else None
+        u_r = ops.duse_gate(r, ch1, sp[:, 0:1], red=red_ur)
+        u_s = ops.duse_gate(s, ch2, sp[:, 1:2], red=red_us)
         outs, stats = [], []
-        for u, gam, bet, rm, rv in ((u_r, g1, be1, rm1, rv1), (u_s, g2, be2, rm2, rv2)):
-            red = None
-            if training:
-                red = ops.zeros_red(r, n, c)
-                ops.moments(u, red)
+        for u, red, gam, bet, rm, rv in ((u_r, red_ur, g1, be1, rm1, rv1), (u_s, red_us, g2, be2, rm2, rv2)):
             y, sc, sh, m, rs = ops.bn_affine_act(mode, u, red, ACT_NONE, gamma=gam, beta=bet, running_mean=rm, running_var=rv, steps=1)
             outs.append(y)
             stats += [sc, sh, m, rs]

@@ -714,11 +714,16 @@ def gate_bwd(x, s, dy, ds_out=None):
     return dx, ds_out
 
 
-def duse_gate(x, ch, sp):
+def duse_gate(x, ch, sp, red=None):
+    """u = x * (1 + ch + sp); with `red` (zeroed (n, c, 2) fp64) the channel sums of u are left there in the same pass."""
     n, c, d, h, w, bs = _vol(x)
     u = new_like(x, (n, c, d, h, w))
-    L.check(L.load().xh_duse_gate_fwd(_stream(), _dt(x), _p(x), bs, _p(ch), _p(sp), _vol(sp)[5], _p(u), _vol(u)[5], n, c, d * h * w),
-            "xh_duse_gate_fwd")
+    if red is None:
+        L.check(L.load().xh_duse_gate_fwd(_stream(), _dt(x), _p(x), bs, _p(ch), _p(sp), _vol(sp)[5], _p(u), _vol(u)[5], n, c,
+                                          d * h * w), "xh_duse_gate_fwd")
+    else:
+        L.check(L.load().xh_duse_gate_fwd_stats(_stream(), _dt(x), _p(x), bs, _p(ch), _p(sp), _vol(sp)[5], _p(u), _vol(u)[5], n, c,
+                                                d * h * w, _p(red)), "xh_duse_gate_fwd_stats")
     return u
 
 
