@@ -144,6 +144,10 @@ long long xh_conv3d_wgrad_workspace_bytes(const xh_conv_desc* d);
  * GroupNorm statistics (buildingblocks.py:429-433; sa_module.py:75; DuSFE.py:108-110). */
 int xh_moments(void* stream, int dtype, const void* x, long long x_bs, int N, int C, long long DHW,
                double* red, long long red_rs);
+/* The same over a virtual concat (xa | xb) -- the decoder's torch.cat((enc, x), 1) input (buildingblocks.py:732) -- in one
+ * launch: red[n][0..CA+CB) gets both. */
+int xh_moments2(void* stream, int dtype, const void* xa, long long xa_bs, int CA, const void* xb, long long xb_bs, int CB,
+                int N, long long DHW, double* red, long long red_rs);
 
 /* Turns moments into the affine pre-transform (sc, sh) consumed by xh_conv3d_fwd/xh_affine_act and the
  * saved (mean, rstd).
@@ -198,6 +202,11 @@ int xh_norm_bwd_fused(void* stream, int dtype, int mode, const void* dy, long lo
 int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs, void* dx,
                     long long dx_bs, int N, int C, long long DHW, const double* red, const float* mean, const float* rstd,
                     int stat_rs, int have_g, const float* sc, const float* sh, float slope, int accumulate);
+/* InstanceNorm backward of a virtual concat in one launch: dy / red / mean / rstd are CA+CB wide, the first CA channels
+ * read xa and write dxa, the others xb / dxb (g given: have_g = 1 of xh_in_bwd_apply). */
+int xh_in_bwd_apply2(void* stream, int dtype, const void* dy, long long dy_bs, const void* xa, long long xa_bs, void* dxa,
+                     long long dxa_bs, int CA, const void* xb, long long xb_bs, void* dxb, long long dxb_bs, int CB, int N,
+                     long long DHW, const double* red, const float* mean, const float* rstd);
 
 /* nn.MaxPool3d(2) (buildingblocks.py:635-636,656-657) and its backward (first maximum in scan order wins). */
 int xh_maxpool2_fwd(void* stream, int dtype, const void* x, void* y, int NC, int D, int H, int W);

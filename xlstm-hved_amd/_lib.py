@@ -59,6 +59,7 @@ SIGNATURES = {
     "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * 4), C.POINTER(vp * 4)]),
     "xh_conv3d_wgrad_batch": (I, [vp, I, vp, vp, vp, vp]),
     "xh_moments": (I, [vp, I, vp, ll, I, I, ll, vp, ll]),
+    "xh_moments2": (I, [vp, I, vp, ll, I, vp, ll, I, I, ll, vp, ll]),
     "xh_norm_finalize": (I, [vp, I, vp, I, I, ll, I, F, vp, vp, vp, vp, I, vp, vp, vp, vp]),
     "xh_affine_act": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, I, F]),
     "xh_in_affine_act": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, I, F, vp, vp, vp, vp]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     "xh_act_bwd_reduce": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, F, vp]),
     "xh_norm_bwd_coef": (I, [vp, I, vp, I, I, ll, I, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_in_bwd_apply": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I, I, vp, vp, F, I]),
+    "xh_in_bwd_apply2": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, vp, ll, vp, ll, I, I, ll, vp, vp, vp]),
     "xh_norm_bwd_apply": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I, vp, vp, F, I]),
     "xh_norm_bwd_fused": (I, [vp, I, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, I, vp, vp, vp, vp, vp]),
     "xh_maxpool2_fwd": (I, [vp, I, vp, vp, I, I, I, I]),

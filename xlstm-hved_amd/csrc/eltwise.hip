@@ -79,9 +79,10 @@ static inline dim3 red_grid(long long dhw, int C, int N) {
 #define ROW_LOOP_END }
 
 // ---------------------------------------------------------------------------------------- moments
+// xb != nullptr: a virtual concat (xa | xb): channels >= ca come from xb (xh_moments2: the decoder's torch.cat input in ONE launch)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long x_bs, long long dhw, double* red,
-                                                          long long red_rs) {
+                                                          long long red_rs, const T* xb, long long xb_bs, int ca) {
   // Per-lane sums in fp64: the statistics feed var = E[x^2] - mean^2, which cancels mean^2/var digits, and the network
   // amplifies any error in them ~1e4x; fp64 adds are free next to the HBM stream.
   __shared__ double s_red[4 * 2];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long
   const T* xp;
   {
     const int c = blockIdx.y, n = blockIdx.z;
-    xp = x + n * x_bs + (long long)c * dhw;
+    xp = (xb && c >= ca) ? xb + n * xb_bs + (long long)(c - ca) * dhw : x + n * x_bs + (long long)c * dhw;
   }
   ROW_LOOP_BEGIN
     float v[VW];
@@ -105,20 +106,27 @@ __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long
   if (threadIdx.x < 2) atomicAdd(&red[blockIdx.z * red_rs + blockIdx.y * 2 + threadIdx.x], s_red[threadIdx.x]);
 }
 
+static int launch_moments(void* stream, int dtype, const void* x, long long x_bs, const void* xb, long long xb_bs, int ca, int N, int C,
+                          long long DHW, double* red, long long red_rs) {
+  if (!x || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  const bool vec32 = vec_ok<float>(DHW, {x_bs, xb_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, xb_bs});
+  const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
+#define MO(T, V, G) hipLaunchKernelGGL((moments_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, x_bs, DHW, red, red_rs, (const T*)xb, xb_bs, ca)
+  if (dtype == XH_F32) { if (vec32) MO(float, true, grid32); else MO(float, false, grid32); }
+  else if (dtype == XH_BF16) { if (vec16) MO(bf16_t, true, grid16); else MO(bf16_t, false, grid16); }
+  else if (dtype == XH_F16) { if (vec16) MO(f16_t, true, grid16); else MO(f16_t, false, grid16); }
+  else return XH_ERR_DTYPE;
+#undef MO
+  return xh_launch_status();
+}
 extern "C" int xh_moments(void* stream, int dtype, const void* x, long long x_bs, int N, int C, long long DHW,
                           double* red, long long red_rs) {
-  if (!x || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  const bool vec32 = vec_ok<float>(DHW, {x_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs});
-  const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
-  if (dtype == XH_F32)
-    { if (vec32) hipLaunchKernelGGL((moments_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs); else hipLaunchKernelGGL((moments_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x, x_bs, DHW, red, red_rs); }
-  else if (dtype == XH_BF16)
-    { if (vec16) hipLaunchKernelGGL((moments_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs); else hipLaunchKernelGGL((moments_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, x_bs, DHW, red, red_rs); }
-  else if (dtype == XH_F16)
-    { if (vec16) hipLaunchKernelGGL((moments_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, DHW, red, red_rs); else hipLaunchKernelGGL((moments_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)x, x_bs, DHW, red, red_rs); }
-  else
-    return XH_ERR_DTYPE;
-  return xh_launch_status();
+  return launch_moments(stream, dtype, x, x_bs, nullptr, 0, C, N, C, DHW, red, red_rs);
+}
+extern "C" int xh_moments2(void* stream, int dtype, const void* xa, long long xa_bs, int CA, const void* xb, long long xb_bs, int CB,
+                           int N, long long DHW, double* red, long long red_rs) {
+  if (!xb || CA <= 0 || CB <= 0) return XH_ERR_ARG;
+  return launch_moments(stream, dtype, xa, xa_bs, xb, xb_bs, CA, N, CA + CB, DHW, red, red_rs);
 }
 
 // ---------------------------------------------------------------------------------------- norm finalize
@@ -488,8 +496,17 @@ __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, lon
                                                                T* dx, long long dx_bs, int C, long long dhw,
                                                                const double* red, const float* mean, const float* rstd,
                                                                int stat_rs, double count, int have_g, const float* sc,
-                                                               const float* sh, float slope, int accumulate) {
+                                                               const float* sh, float slope, int accumulate, const T* xb,
+                                                               long long xb_bs, T* dxb, long long dxb_bs, int ca) {
+  // xb != nullptr: virtual concat (xa | xb): channels >= ca read xb and write dxb (xh_in_bwd_apply2)
   const int k = blockIdx.z * stat_rs + blockIdx.y;
+  const T* xrow;
+  T* drow;
+  {
+    const int c = blockIdx.y, n = blockIdx.z;
+    if (xb && c >= ca) { xrow = xb + n * xb_bs + (long long)(c - ca) * dhw; drow = dxb + n * dxb_bs + (long long)(c - ca) * dhw; }
+    else { xrow = x + n * x_bs + (long long)c * dhw; drow = dx + n * dx_bs + (long long)c * dhw; }
+  }
   const double rs = rstd[k], mu = mean[k];
   const double S0 = red[k * 2], P = rs * (red[k * 2 + 1] - mu * red[k * 2]);
   const float a_ = (float)rs, c_ = (float)(-rs * rs * P / count), b_ = (float)(-rs * S0 / count + rs * rs * mu * P / count);
@@ -498,8 +515,8 @@ __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, lon
   ROW_LOOP_BEGIN
     float g[VW], xv[VW], o[VW];
     ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q, valid, g);
-    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
-    T* dp = dx + n * dx_bs + (long long)c * dhw;
+    ldrow<VEC>(xrow, q, valid, xv);
+    T* dp = drow;
     if (accumulate) ldrow<VEC>((const T*)dp, q, valid, o);
     else {
 #pragma unroll
@@ -514,24 +531,36 @@ __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, lon
     strow<VEC>(dp, q, valid, o);
   ROW_LOOP_END
 }
+static int launch_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs, void* dx,
+                               long long dx_bs, const void* xb, long long xb_bs, void* dxb, long long dxb_bs, int ca, int N, int C,
+                               long long DHW, const double* red, const float* mean, const float* rstd, int stat_rs, int have_g,
+                               const float* sc, const float* sh, float slope, int accumulate) {
+  if (!dy || !x || !dx || !red || !mean || !rstd || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535 || stat_rs < C)
+    return XH_ERR_ARG;
+  if (!have_g && (!sc || !sh)) return XH_ERR_ARG;
+  const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs, xb_bs, dxb_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs, xb_bs, dxb_bs});
+  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
+#define IB(T, V, G) hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)dy, dy_bs, (const T*)x, x_bs, (T*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate, (const T*)xb, xb_bs, (T*)dxb, dxb_bs, ca)
+  if (dtype == XH_F32) { if (vec32) IB(float, true, grid32); else IB(float, false, grid32); }
+  else if (dtype == XH_BF16) { if (vec16) IB(bf16_t, true, grid16); else IB(bf16_t, false, grid16); }
+  else if (dtype == XH_F16) { if (vec16) IB(f16_t, true, grid16); else IB(f16_t, false, grid16); }
+  else return XH_ERR_DTYPE;
+#undef IB
+  return xh_launch_status();
+}
 extern "C" int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
                                void* dx, long long dx_bs, int N, int C, long long DHW, const double* red,
                                const float* mean, const float* rstd, int stat_rs, int have_g, const float* sc,
                                const float* sh, float slope, int accumulate) {
-  if (!dy || !x || !dx || !red || !mean || !rstd || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535 || stat_rs < C)
-    return XH_ERR_ARG;
-  if (!have_g && (!sc || !sh)) return XH_ERR_ARG;
-  const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs});
-  const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
-  if (dtype == XH_F32)
-    { if (vec32) hipLaunchKernelGGL((in_bwd_apply_kernel<float, true>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((in_bwd_apply_kernel<float, false>), grid32, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)dy, dy_bs, (const float*)x, x_bs, (float*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); }
-  else if (dtype == XH_BF16)
-    { if (vec16) hipLaunchKernelGGL((in_bwd_apply_kernel<bf16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((in_bwd_apply_kernel<bf16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)dy, dy_bs, (const bf16_t*)x, x_bs, (bf16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); }
-  else if (dtype == XH_F16)
-    { if (vec16) hipLaunchKernelGGL((in_bwd_apply_kernel<f16_t, true>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); else hipLaunchKernelGGL((in_bwd_apply_kernel<f16_t, false>), grid16, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16_t*)dy, dy_bs, (const f16_t*)x, x_bs, (f16_t*)dx, dx_bs, C, DHW, red, mean, rstd, stat_rs, (double)DHW, have_g, sc, sh, slope, accumulate); }
-  else
-    return XH_ERR_DTYPE;
-  return xh_launch_status();
+  return launch_in_bwd_apply(stream, dtype, dy, dy_bs, x, x_bs, dx, dx_bs, nullptr, 0, nullptr, 0, C, N, C, DHW, red, mean, rstd, stat_rs,
+                             have_g, sc, sh, slope, accumulate);
+}
+extern "C" int xh_in_bwd_apply2(void* stream, int dtype, const void* dy, long long dy_bs, const void* xa, long long xa_bs, void* dxa,
+                                long long dxa_bs, int CA, const void* xb, long long xb_bs, void* dxb, long long dxb_bs, int CB, int N,
+                                long long DHW, const double* red, const float* mean, const float* rstd) {
+  if (!xb || !dxb || CA <= 0 || CB <= 0) return XH_ERR_ARG;
+  return launch_in_bwd_apply(stream, dtype, dy, dy_bs, xa, xa_bs, dxa, dxa_bs, xb, xb_bs, dxb, dxb_bs, CA, N, CA + CB, DHW, red, mean,
+                             rstd, CA + CB, 1, nullptr, nullptr, 1.f, 0);
 }
 
 extern "C" int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,

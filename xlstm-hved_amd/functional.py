@@ -89,9 +89,10 @@ class InLreluConv(Function):
             red = in_stats
         else:
             red = ops.zeros_red(xa, n, cin)
-            ops.moments(xa, red, 0)
             if xb is not None:
-                ops.moments(xb, red, ca)
+                ops.moments2(xa, xb, red)
+            else:
+                ops.moments(xa, red, 0)
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
         red_y = ops.zeros_red(xa, n, cout) if out_stats else None
@@ -123,9 +124,10 @@ class InLreluConv(Function):
                 g = ops.conv3d(dy, None, weights, None, k=k, cout=cin, groups=groups, transposed=True, epi=1, e=e, red=red)
             else:
                 g = ops.conv3d_dgrad_s2(dy, weights, cin=cin, in_spatial=tuple(xa.shape[2:]), groups=groups, e=e, red=red)
-            dxa = ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0)
             if xb is not None:
-                dxb = ops.in_bwd_apply(g, xb, red, mean, rstd, have_g=True, c0=ca)
+                dxa, dxb = ops.in_bwd_apply2(g, xa, xb, red, mean, rstd)
+            else:
+                dxa = ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0)
         return (dxa, dxb, None, None, None, None, None, None, *rws, *rbs)
 
 

@@ -513,6 +513,14 @@ def moments(x, red, c0=0):
     L.check(L.load().xh_moments(_stream(), _dt(x), _p(x), bs, n, c, d * h * w, sl.data_ptr(), red.stride(0)), "xh_moments")
 
 
+def moments2(xa, xb, red):
+    """red[:, :ca+cb] += (sum, sum of squares) of the virtual concat (xa | xb), one launch."""
+    n, ca, d, h, w, bsa = _vol(xa)
+    cb, bsb = xb.shape[1], _vol(xb)[5]
+    L.check(L.load().xh_moments2(_stream(), _dt(xa), _p(xa), bsa, ca, _p(xb), bsb, cb, n, d * h * w, red.data_ptr(), red.stride(0)),
+            "xh_moments2")
+
+
 def norm_finalize(mode, red, n, c, count, *, gs=1, gamma=None, beta=None, running_mean=None, running_var=None,
                   steps=1, device=None):
     dev = red.device if red is not None else device
@@ -606,6 +614,17 @@ def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK
                                      d * h * w, off(red, 2), off(mean), off(rstd), rs, int(have_g), off(sc), off(sh), slope,
                                      0), "xh_in_bwd_apply")
     return out
+
+
+def in_bwd_apply2(dy, xa, xb, red, mean, rstd):
+    """InstanceNorm backward of the virtual concat (xa | xb) from its full-width gradient g = dy, one launch."""
+    n, ca, d, h, w, bsa = _vol(xa)
+    cb, bsb = xb.shape[1], _vol(xb)[5]
+    da = torch.empty_like(xa, memory_format=torch.contiguous_format)
+    db = torch.empty_like(xb, memory_format=torch.contiguous_format)
+    L.check(L.load().xh_in_bwd_apply2(_stream(), _dt(xa), _p(dy), _vol(dy)[5], _p(xa), bsa, _p(da), _vol(da)[5], ca, _p(xb), bsb,
+                                      _p(db), _vol(db)[5], cb, n, d * h * w, _p(red), _p(mean), _p(rstd)), "xh_in_bwd_apply2")
+    return da, db
 
 
 # ----------------------------------------------------------------------------------------------- resampling
