@@ -111,6 +111,36 @@ def test_quad_channel_kernel_is_selected():
         lib.xh_set_option(2, 0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("transposed", [False, True], ids=["fwd", "dgrad"])
+def test_depthwise_conv_through_quad_channel_kernel(transposed, dtype):
+    """A depthwise k3 conv with a multiple of 4 channels on 32-multiple rows runs on the matrix cores as groups of 4 channels
+    with diagonal 4 x 4 weight blocks (conv3_q4_kernel); xh_set_option(2, 128) puts it back on the sliding-window vector
+    kernel.  Same result up to the 16-bit rounding of the weights; bias included; H not a multiple of the tile."""
+    torch.manual_seed(8)
+    lib = X._lib.load()
+    n, c, sp = 2, 8, (8, 34, 64)
+    x = torch.randn((n, c) + sp, device=DEV).to(dtype)
+    ws = [(torch.randn(c, 1, 3, 3, 3, device=DEV) * 0.3).to(dtype).float()]
+    bs = None if transposed else [torch.randn(c, device=DEV)]
+    call = lambda: X.ops.conv3d(x, None, ws, bs, k=3, cout=c, groups=c, transposed=transposed).float()
+    y = call()
+    assert "conv3_q4_kernel" in X.ops.last_conv_kernel()
+    lib.xh_set_option(2, 128)
+    try:
+        y_vec = call()
+        assert "conv3_q4_kernel" not in X.ops.last_conv_kernel()
+    finally:
+        lib.xh_set_option(2, 0)
+    wf = torch.cat(ws, 0)
+    if transposed:
+        ref = torch.nn.functional.conv_transpose3d(x.float(), wf, None, padding=1, groups=c)
+    else:
+        ref = torch.nn.functional.conv3d(x.float(), wf, torch.cat(bs, 0), padding=1, groups=c)
+    tol = 4e-3 if dtype == torch.bfloat16 else 6e-4
+    assert l2_err(y, ref) < tol and l2_err(y_vec, ref) < tol
+
+
 @pytest.mark.parametrize("cfg", [dict(cin=16, cout=16, groups=4, sp=(8, 16, 32)), dict(cin=16, cout=16, groups=1, sp=(6, 8, 32)),
                                  dict(cin=48, cout=16, groups=1, sp=(8, 8, 32))], ids=["q4", "gemm", "splitk"])
 def test_prepacked_fragments_match_and_never_go_stale(cfg):

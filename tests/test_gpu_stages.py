@@ -213,6 +213,9 @@ def test_depthwise_k3_sliding_window_kernel_vs_stock(shape, dtype):
     n, c = shape[:2]
     x = (torch.randn(shape) * 1.3 + 0.2).to(dtype).float()
     w = torch.randn(c, 1, 3, 3, 3) * 0.3
+    # 16-bit storage: where the volume allows it the conv runs on the matrix cores (quad-channel kernel, diagonal 4 x 4 weight
+    # blocks) with the weights rounded to the storage type, as for every other MFMA conv -- the comparator gets the same weights
+    w = w.to(dtype).float()
     xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     yo = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(
         torch.nn.functional.conv3d(xo, wo, None, padding=1, groups=c), eps=1e-5), 0.01)

@@ -52,6 +52,7 @@ int g_mfma_wgs = 512;      // xh_set_option(3, n): target workgroup count of the
 int g_mfma_occ = 0;        // xh_set_option(4, 1): high-occupancy (<=128 VGPR) instances for CINP <= 8 at 128^3-class volumes
 
 static void mk_pack_job(const ConvMK& a, PackJob* j) {
+  j->dw = 0;
   for (int i = 0; i < 4; ++i) j->w[i] = a.p.w[i];
   j->ws = a.p.ws;
   j->kind = 0;

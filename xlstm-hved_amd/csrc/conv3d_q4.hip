@@ -40,6 +40,7 @@ struct ConvQ4 {
   xh_conv_ptrs p;
   int Cin_g, Cout_g, ci4;       // channels per group, input-channel quads per group
   int tilesW, tilesH, tilesD;
+  int dw;                       // depthwise conv presented as groups of 4 channels with diagonal weights (plan, pack only)
   float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
   double fin_inv;               // 1 / fin_count
   unsigned char* fan;           // statistics fan-in block of this launch (fanin.h), or nullptr: direct atomics
@@ -360,7 +361,13 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return false;
   if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   if (d->W % TW != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
-  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  // a depthwise conv (one channel per group) rides as groups of 4 channels whose 4 x 4 weight blocks are diagonal: three
+  // quarters of the MACs multiply zeros, but they are matrix-core MACs -- the vector-ALU sliding-window kernel needs 27 FMAs
+  // per voxel and channel and ran 4 -> 4 @128^3 in 31 us; this kernel takes 17
+  const bool dw = cin_g == 1 && cout_g == 1 && d->groups % 4 == 0 && d->n_wptr > 0 && (d->groups / 4) % d->n_wptr == 0 &&
+                  !(g_xh_disable & 128);
+  if (dw) cin_g = cout_g = 4;
   if (cin_g % 4 || cout_g % 4) return false;
   { extern int g_q4_maxc; if (cin_g > g_q4_maxc || cout_g > g_q4_maxc) return false; }   // denser groups: the plain implicit GEMM
   if (d->Ca % 4) return false;
@@ -377,6 +384,8 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if (d->N > 65535 || d->Cout / 4 > 65535) return false;
   if (d->D < 4 || d->H < 8) return false;
   a->d = *d;
+  a->dw = dw ? 1 : 0;
+  if (dw) a->d.groups = d->groups / 4;
   a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cin_g / 4;
   a->tilesW = d->W / TW; a->tilesH = cdiv(d->Ho, TH); a->tilesD = cdiv(d->Do, TD);
   a->act_slope = as;
@@ -393,6 +402,7 @@ static void q4_pack_job(const ConvQ4& a, PackJob* j) {
   j->Cin_g = a.Cin_g; j->Cout_g = a.Cout_g;
   j->ntile = j->cin_stride = j->cin_off = j->cin_blk = j->cout_set = j->nm = j->nch = j->cpr = j->cinp = 0;
   j->ci4 = a.ci4;
+  j->dw = a.dw;
   j->nelem = (a.d.Cout / 4) * a.ci4 * 9 * 512;
 }
 bool xh_conv3_q4_pack_job(const xh_conv_desc* d, const xh_conv_ptrs* p, PackJob* j) {

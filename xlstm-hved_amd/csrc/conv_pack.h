@@ -14,6 +14,7 @@ struct PackJob {
   int f16, groups, n_wptr, transposed, Cin_g, Cout_g;
   int ntile, cin_stride, cin_off, cin_blk, cout_set, nm, nch, cpr, cinp;   // kind 0 (ConvMK fields of the same names)
   int ci4;                                                                  // kind 1
+  int dw;                                    // kind 1: depthwise conv run as groups of 4 with diagonal 4 x 4 weights (w: [C][1][27])
   int nelem;                                 // 16-bit elements to write
 };
 
@@ -26,6 +27,7 @@ __device__ __forceinline__ float pack_weight(const PackJob& j, int co, int ci, i
   const int gpp = j.groups / j.n_wptr;
   const float* wp = j.w[g / gpp];
   const int gl = g % gpp;
+  if (j.dw) return co_g == ci_g ? wp[(long long)(gl * 4 + co_g) * 27 + (j.transposed ? 26 - tap : tap)] : 0.f;
   if (!j.transposed) return wp[((long long)(gl * j.Cout_g + co_g) * j.Cin_g + ci_g) * 27 + tap];
   return wp[((long long)(gl * j.Cin_g + ci_g) * j.Cout_g + co_g) * 27 + (26 - tap)];
 }
