@@ -467,6 +467,8 @@ def roofline_pass(step, ops, nsteps, dtype):
             # class (7 per launch), else one ordinary launch each
             cg, og, w_ = cin // groups, dy.shape[1] // groups, xa.shape[-1]
             k3 = k == 3 and kw.get("stride", 1) == 1 and esz == 2
+            if cg == 1 and og == 1 and groups % 4 == 0:          # depthwise: groups of 4 with diagonal blocks (wgrad_q4 plan)
+                cg = og = 4
             q4 = (k3 and w_ % 32 == 0 and cg % 4 == 0 and og % 4 == 0 and cg <= 48 and og <= 48 and xa.shape[2] >= 4
                   and xa.shape[3] >= 4 and xa.shape[1] % 4 == 0)
             mfma = k3 and (w_ % 32 == 0 or w_ in (8, 16)) and cg >= 4

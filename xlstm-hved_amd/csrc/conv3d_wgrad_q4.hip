@@ -255,6 +255,10 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
     const int r = i / 27;
     const int ci = r % (4 * CI4), c = r / (4 * CI4);
     const int co_g = (co0 + c) % a.Cout_g;
+    if (a.dwm) {                                         // depthwise: dw[C][1][27], the off-diagonal products are not gradients
+      if (ci == c) atomicAdd(dwp + (long long)(gl * 4 + c) * 27 + tap, s_dw[i]);
+      continue;
+    }
     atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + chunk * 4 * CI4 + ci) * 27 + tap, s_dw[i]);
   }
   float* dbp = a.db[grp / gpp];
@@ -473,6 +477,10 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
     const int r = i / 27;
     const int ci = r % (4 * CI4), c = r / (4 * CI4);
     const int co_g = (co0 + c) % a.Cout_g;
+    if (a.dwm) {                                         // depthwise: dw[C][1][27], the off-diagonal products are not gradients
+      if (ci == c) atomicAdd(dwp + (long long)(gl * 4 + c) * 27 + tap, s_dw[i]);
+      continue;
+    }
     atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + chunk * 4 * CI4 + ci) * 27 + tap, s_dw[i]);
   }
   float* dbp = a.db[grp / gpp];
@@ -505,7 +513,10 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1 || d->transposed) return false;
   if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
-  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups, groups = d->groups;
+  // depthwise: groups of 4 channels, the diagonal of each 4 x 4 block is the gradient (conv3d_q4.hip: q4_plan)
+  const bool dwm = cin_g == 1 && cout_g == 1 && groups % 4 == 0 && d->n_wptr > 0 && (groups / 4) % d->n_wptr == 0 && !(g_xh_disable & 128);
+  if (dwm) { cin_g = cout_g = 4; groups /= 4; }
   if (cin_g % 4 || cout_g % 4 || cin_g > 48 || cout_g > 48) return false;
   if (d->Ca % 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return false;
@@ -518,7 +529,8 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   a->pre_sc = p->pre_sc; a->pre_sh = p->pre_sh;
   for (int i = 0; i < 4; ++i) { a->dw[i] = i < d->n_wptr ? dw[i] : nullptr; a->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
   a->xa_bs = d->xa_bs; a->xb_bs = d->xb_bs; a->dy_bs = d->ea_bs;
-  a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->groups = d->groups; a->n_wptr = d->n_wptr; a->Ca = d->Ca;
+  a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->groups = groups; a->n_wptr = d->n_wptr; a->Ca = d->Ca;
+  a->dwm = dwm ? 1 : 0;
   a->D = d->D; a->H = d->H; a->W = d->W;
   // input quads per unit: a workgroup keeps 3 accumulator tiles per quad, so groups of more than 3 quads are cut into
   // equal chunks of 3, 2 or 1 (each chunk re-reads the dY rows)

@@ -18,6 +18,7 @@ struct WgQ4 {
   int wpu;                       // workgroups per unit (each walks ntile / wpu tiles)
   int nb;                        // workgroups of the problem (nq * wpu)
   int abl;                       // ablation mask (microbenchmarks)
+  int dwm;                       // depthwise problem run as groups of 4: only the diagonal of a 4 x 4 block is a gradient
 };
 
 constexpr int WQ_MULTI = 8;         // problems per launch (the table travels in the kernel arguments)
