@@ -139,6 +139,25 @@ def test_depthwise_conv_through_quad_channel_kernel(transposed, dtype):
         ref = torch.nn.functional.conv3d(x.float(), wf, torch.cat(bs, 0), padding=1, groups=c)
     tol = 4e-3 if dtype == torch.bfloat16 else 6e-4
     assert l2_err(y, ref) < tol and l2_err(y_vec, ref) < tol
+    if not transposed:
+        # weight / bias gradient: the diagonal of the 4 x 4 blocks the quad-channel weight-gradient kernel accumulates
+        dy = torch.randn_like(x)
+        grads = []
+        for opt in (0, 128):
+            lib.xh_set_option(2, opt)
+            try:
+                dw, db = torch.zeros_like(ws[0]), torch.zeros(c, device=DEV)
+                X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3, groups=c)
+                grads.append((dw, db, X.ops.last_conv_kernel()))
+            finally:
+                lib.xh_set_option(2, 0)
+        assert "conv3_wgrad_q4" in grads[0][2] and "q4" not in grads[1][2]
+        xr = x.float().requires_grad_(False)
+        wr = ws[0].clone().requires_grad_(True)
+        br = torch.zeros(c, device=DEV, requires_grad=True)
+        (torch.nn.functional.conv3d(xr, wr, br, padding=1, groups=c) * dy.float()).sum().backward()
+        for dw, db, _ in grads:
+            assert l2_err(dw, wr.grad) < 2e-3 and l2_err(db, br.grad) < 2e-3
 
 
 @pytest.mark.parametrize("cfg", [dict(cin=16, cout=16, groups=4, sp=(8, 16, 32)), dict(cin=16, cout=16, groups=1, sp=(6, 8, 32)),
