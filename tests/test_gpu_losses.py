@@ -75,7 +75,9 @@ def test_mean_of_matches_torch_mean(dtype):
 
 def test_sum_of_means_matches_torch():
     torch.manual_seed(2)
-    ts = [torch.randn(s, device=DEV).bfloat16().requires_grad_(True) for s in ((1, 3, 8, 8, 8), (1, 5, 1, 4, 4, 4), (2, 4, 6, 6, 10))]
+    # the 3 x 64 x 128 x 128 tensor (>= 2^20 elements) is reduced as 16 rows that share its weight
+    ts = [torch.randn(s, device=DEV).bfloat16().requires_grad_(True)
+          for s in ((1, 3, 8, 8, 8), (1, 5, 1, 4, 4, 4), (2, 4, 6, 6, 10), (1, 3, 64, 128, 128))]
     m = X.losses.sum_of_means(ts)
     (m * 2.0).backward()
     ref = sum(t.detach().float().mean() for t in ts)

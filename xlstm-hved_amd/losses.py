@@ -158,13 +158,19 @@ class _SumOfMeans(Function):
     @staticmethod
     def forward(ctx, *ts):
         dev = ts[0].device
+        # a reduction row is summed by at most 64 workgroups (one atomic address): a 128^3 output as ONE row took 47 us.  Large
+        # tensors are cut into 16 rows that all carry the tensor's weight 1 / numel
+        splits = [16 if t.numel() >= (1 << 20) and t.numel() % 128 == 0 else 1 for t in ts]
         key = (tuple(t.numel() for t in ts), dev)
         w = _WEIGHTS.get(key)
         if w is None:
-            w = _WEIGHTS[key] = torch.tensor([1.0 / t.numel() for t in ts], dtype=torch.float32, device=dev)
-        red = ops.zeros_f64(dev, (len(ts), 1, 6))
-        for i, t in enumerate(ts):
-            ops.pair_sums(t.contiguous().view(1, 1, 1, 1, -1), red=red[i:i + 1])
+            w = _WEIGHTS[key] = torch.tensor([1.0 / t.numel() for t, sp in zip(ts, splits) for _ in range(sp)], dtype=torch.float32,
+                                             device=dev)
+        red = ops.zeros_f64(dev, (sum(splits), 1, 6))
+        r0 = 0
+        for t, sp in zip(ts, splits):
+            ops.pair_sums(t.contiguous().view(1, sp, 1, 1, -1), red=red[r0:r0 + sp].view(1, sp, 6))
+            r0 += sp
         ctx.meta = [(tuple(t.shape), t.dtype, t.device, t.numel()) for t in ts]
         return ops.loss_finalize(4, red, count=w).reshape(())
 
