@@ -18,6 +18,7 @@
 #include "../../include/xlstm_hved.h"
 #include "wgrad_q4.h"
 #include <vector>
+#include <algorithm>
 
 typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
 typedef f32x4_t f32x4;
@@ -397,16 +398,34 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
   if (g_use_mfma) {
     for (int cls = 0; cls < 6; ++cls) {               // (storage format, input-channel quads per group)
       const int fmt = cls / 3, ci4 = cls % 3 + 1;
-      WgQ4 probs[WQ_MULTI];
-      int k = 0;
+      std::vector<WgQ4> cl;
+      WgQ4 q;
       for (int i = 0; i < n; ++i) {
         if (!d[i] || !p[i]) return XH_ERR_ARG;
         if (handled[i] || (d[i]->dtype == XH_F16 ? 1 : 0) != fmt) continue;
-        if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &probs[k]) || probs[k].ci4 != ci4) continue;
+        if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &q) || q.ci4 != ci4) continue;
         handled[i] = 1;
-        if (++k == WQ_MULTI) { xh_wgrad_q4_launch(st, fmt, probs, k); k = 0; }
+        cl.push_back(q);
       }
-      if (k) xh_wgrad_q4_launch(st, fmt, probs, k);
+      if (cl.empty()) continue;
+      // as few launches as the problem table allows, of EQUAL work: in arrival order 17 problems went 8 + 8 + 1, and the last
+      // launch -- one 128^3 problem alone on the chip -- took as long as a full one (77 / 152 / 78 us).  Largest first into the
+      // currently lightest launch
+      const int L = ((int)cl.size() + WQ_MULTI - 1) / WQ_MULTI;
+      auto cost = [](const WgQ4& w) { return (double)w.N * w.D * w.H * w.W * w.nq * w.ci4; };
+      std::vector<int> order(cl.size());
+      for (size_t i = 0; i < cl.size(); ++i) order[i] = (int)i;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(cl[a]) > cost(cl[b]); });
+      std::vector<std::vector<WgQ4>> bucket(L);
+      std::vector<double> load(L, 0.0);
+      for (int idx : order) {
+        int best = -1;
+        for (int b = 0; b < L; ++b)
+          if ((int)bucket[b].size() < WQ_MULTI && (best < 0 || load[b] < load[best])) best = b;
+        bucket[best].push_back(cl[idx]);
+        load[best] += cost(cl[idx]);
+      }
+      for (int b = 0; b < L; ++b) xh_wgrad_q4_launch(st, fmt, bucket[b].data(), (int)bucket[b].size());
     }
   }
   WgMulti* m = new WgMulti;
