@@ -40,7 +40,8 @@ int xh_abi_version(void);
  *        kernels, bit 2 vectorised stride-2 conv forward / data gradient, bit 3 chunk-recurrent mLSTM (falls back to the
  *        tiled O(S^2) contraction; A/B tests), bit 4 quad-channel k3 forward / data-gradient kernel, bit 5 quad-channel k3
  *        weight-gradient kernel (both fall back to the implicit-GEMM kernels), bit 6 statistics fan-in (direct atomics),
- *        bit 7 depthwise k3 convs through the quad-channel kernel (fall back to the sliding-window vector kernel).
+ *        bit 7 depthwise k3 convs through the quad-channel kernel (fall back to the sliding-window vector kernel),
+ *        bit 8 input-channel split inside the blocks of the stride-2 vector conv on small outputs.
  * key 3: target workgroup count of the k3 MFMA forward kernel (default 512 = 2 per CU; microbenchmarks: 1024-4096 were 7-25 % slower).
  * key 4: 1 = <=128-VGPR instances of the k3 MFMA forward kernel for <= 8 input channels (microbenchmarks: spills, 2x slower).
  * key 5: K step of the discriminator's implicit GEMM in 32-channel quarters (1 | 2, default 2).

@@ -621,8 +621,11 @@ __global__ __launch_bounds__(256) void conv3_s2_gather_kernel(const ConvK a) {
 // (input columns 2*ow0 .. 2*ow0+VW-1; the one column to the left comes from the neighbouring lane by wave shuffle),
 // i.e. 9 wide loads per input channel instead of 27 two-byte ones per output.  Lanes of a wave tile whole rows.
 // ---------------------------------------------------------------------------------------------------
+// KS > 1 (small outputs: the deep levels launch a few dozen workgroups whose lanes each walk Cin_g x 27 x COB FMAs -- 32 -> 64
+// channels @16^3 -> 8^3 ran 63 us on 32 workgroups): a block keeps 256 / KS lanes and its KS thread groups split the input
+// channels, partial sums meet in LDS (part_off floats into the dynamic segment) and group 0 runs the epilogue.
 template <typename T, int COB>
-__global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW) {
+__global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW, int KS, int part_off) {
   constexpr int VW = VWT<T>::v, OW = VW / 2;
   extern __shared__ float s_dyn[];                    // [Cin_g][27][COB] weights, then reduction scratch
   float* s_w = s_dyn;
@@ -640,10 +643,11 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
   __syncthreads();
   const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
   const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
-  const long long lane_id = (long long)blockIdx.x * 256 + tid;
+  const int LPB = 256 / KS, ks = tid / LPB, tl = tid - ks * LPB;
+  const long long lane_id = (long long)blockIdx.x * LPB + tl;
   const int tx = (int)(lane_id % LW);
   const long long row = lane_id / LW;
-  const bool ok = row < (long long)Do * Ho;
+  bool ok = row < (long long)Do * Ho;
   const int oh = (int)(row % Ho), od = (int)min(row / Ho, (long long)Do - 1);
   const int ow0 = tx * OW;
   float acc[COB][OW];
@@ -651,7 +655,9 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
   for (int i = 0; i < COB; ++i)
 #pragma unroll
     for (int j = 0; j < OW; ++j) acc[i][j] = 0.f;
-  for (int ci_g = 0; ci_g < a.Cin_g; ++ci_g) {
+  const int cpk = (a.Cin_g + KS - 1) / KS;
+  const int ci_end = min(a.Cin_g, (ks + 1) * cpk);
+  for (int ci_g = ks * cpk; ci_g < ci_end; ++ci_g) {
     const int c = g * a.Cin_g + ci_g;
     const T* src = in_plane<T>(a, n, c, dhw) + 2 * ow0;
     float sc = 1.f, sh = 0.f;
@@ -685,6 +691,25 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
 #pragma unroll
           for (int j = 0; j < OW; ++j) acc[co][j] = fmaf(w, r[2 * j + kw], acc[co][j]);
         }
+    }
+  }
+  if (KS > 1) {                                         // block-uniform
+    float* s_part = s_dyn + part_off;                   // [KS - 1][LPB][COB * OW]
+    if (ks > 0) {
+#pragma unroll
+      for (int i = 0; i < COB; ++i)
+#pragma unroll
+        for (int j = 0; j < OW; ++j) s_part[((ks - 1) * LPB + tl) * (COB * OW) + i * OW + j] = acc[i][j];
+    }
+    __syncthreads();
+    if (ks == 0) {
+      for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+        for (int i = 0; i < COB; ++i)
+#pragma unroll
+          for (int j = 0; j < OW; ++j) acc[i][j] += s_part[((k2 - 1) * LPB + tl) * (COB * OW) + i * OW + j];
+    } else {
+      ok = false;
     }
   }
   double s0[COB], s1[COB];
@@ -1230,12 +1255,21 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
                       d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && !(g_xh_disable & 4);
       if (al) {
         const long long lanes = (long long)d->Do * d->Ho * lw;
-        dim3 gridv((unsigned)((lanes + 255) / 256), a.ncob, d->N * d->groups);
+        // input-channel split inside the block while the launch has fewer than 256 workgroups (narrow channel blocks only)
+        int ks = 1;
+        if (cob == 2 && !(g_xh_disable & 256))
+          while (ks < 8 && cdiv((int)lanes, 256 / ks) * a.ncob * d->N * d->groups < 256 && 256 / (2 * ks) >= lw &&
+                 (256 / (2 * ks)) % lw == 0 && cin_g / (2 * ks) >= 2)
+            ks *= 2;
+        const int lpb = 256 / ks;
+        const int part_off = (int)((shm / sizeof(float) + 1) & ~(size_t)1);
+        const size_t shm2 = ks > 1 ? (size_t)part_off * sizeof(float) + (size_t)(ks - 1) * lpb * cob * (VW / 2) * sizeof(float) : shm;
+        dim3 gridv((unsigned)((lanes + lpb - 1) / lpb), a.ncob, d->N * d->groups);
         xh_note_kernel("conv3_s2_vec_kernel<%s, %d>", tname<T>(), cob);
         switch (cob) {
-          case 2: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 2>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw); break;
-          case 4: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 4>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw); break;
-          default: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 8>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw);
+          case 2: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 2>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off); break;
+          case 4: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 4>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off); break;
+          default: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 8>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off);
         }
         return xh_launch_status();
       }
