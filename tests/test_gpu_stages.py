@@ -255,3 +255,29 @@ def test_in_affine_act_fused_finalisation_matches_two_launches(dtype):
     tol = 2e-6 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 1.5e-3)
     assert l2_err(y.double().cpu(), want) < tol and l2_err(y2.double().cpu(), want) < tol
     assert (y.float() - y2.float()).abs().max().item() <= (2e-6 if dtype == torch.float32 else 4e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stride2_conv_channel_split_matches_unsplit(dtype):
+    """Deep-level stride-2 convs (few output voxels, many channels) split the input channels over the thread groups of a block;
+    xh_set_option(2, 256) switches the split off.  Same sums in a different order; also against stock conv3d."""
+    from xlstm_hved_amd import ops
+    torch.manual_seed(6)
+    lib = X._lib.load()
+    n, cin, cout, sp = 1, 32, 64, (16, 16, 16)
+    x = torch.randn(n, cin, *sp, device=DEV).to(dtype)
+    w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, device=DEV)
+    outs = []
+    for opt in (0, 256):
+        lib.xh_set_option(2, opt)
+        try:
+            red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
+            outs.append((ops.conv3d(x, None, [w], [b], k=3, cout=cout, stride=2, epi=2, red=red).float(), red))
+        finally:
+            lib.xh_set_option(2, 0)
+    (y, r), (y0, r0) = outs
+    ref = torch.nn.functional.conv3d(x.float(), w, b, stride=2, padding=1)
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    assert l2_err(y, ref) < tol and l2_err(y0, ref) < tol and l2_err(y, y0) < tol
+    assert ((r - r0).abs() <= 1e-3 * r0.abs() + 1e-2).all()
