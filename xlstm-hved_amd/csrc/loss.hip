@@ -263,11 +263,10 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(int kind, const doubl
     __syncthreads();
     if (t == 0) { double m = 0; for (int c = 0; c < C; ++c) m += s_d[c]; out[0] = (float)(1.0 - m / C); }
   } else if (kind == 1) {
-    if (t == 0) {
-      double sacc = 0;
-      for (int i = 0; i < N * C; ++i) sacc += red[(long long)i * 6 + 3];
-      out[0] = (float)(sacc / count);
-    }
+    double sacc = 0;                                  // one row per lane, then a wave sum: a serial loop of dependent loads on
+    for (int i = t; i < N * C; i += 64) sacc += red[(long long)i * 6 + 3];          // lane 0 cost ~0.4 us per row
+    sacc = wave_sum(sacc);
+    if (t == 0) out[0] = (float)(sacc / count);
     for (int i = t; i < N * C; i += 64) { ca[i] = (float)(2.0 / count); cb[i] = (float)(-2.0 / count); }
   } else if (kind == 2) {
     if (t < C) {
@@ -276,17 +275,15 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(int kind, const doubl
       out[t] = (float)(m / N);
     }
   } else if (kind == 3) {                             // plain mean of a (slot 4)
-    if (t == 0) {
-      double sacc = 0;
-      for (int i = 0; i < N * C; ++i) sacc += red[(long long)i * 6 + 4];
-      out[0] = (float)(sacc / count);
-    }
+    double sacc = 0;
+    for (int i = t; i < N * C; i += 64) sacc += red[(long long)i * 6 + 4];
+    sacc = wave_sum(sacc);
+    if (t == 0) out[0] = (float)(sacc / count);
   } else {                                            // kind 4: weighted sum of several tensors' sums: sum_i red[i][4] * ca[i]
-    if (t == 0) {
-      double sacc = 0;
-      for (int i = 0; i < N * C; ++i) sacc += red[(long long)i * 6 + 4] * (double)ca[i];
-      out[0] = (float)sacc;
-    }
+    double sacc = 0;
+    for (int i = t; i < N * C; i += 64) sacc += red[(long long)i * 6 + 4] * (double)ca[i];
+    sacc = wave_sum(sacc);
+    if (t == 0) out[0] = (float)sacc;
   }
 }
 extern "C" int xh_loss_finalize(void* stream, int kind, const double* red, int N, int C, double count, double eps, float* out,
