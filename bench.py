@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-wgrad-defer", action="store_true",
                     help="launch every weight gradient where backward reaches it instead of batching them at the end of backward")
     ap.add_argument("--wgrad-batch", type=int, default=12, help="weight-gradient calls forked to the side stream per batch")
+    ap.add_argument("--level-streams", action="store_true", help="run the coarse per-level latent chains on side streams (experiment)")
     ap.add_argument("--wgrad-flush-streams", type=int, default=1,
                     help="HIP streams the deferred weight-gradient flush deals its independent problems to (ops.set_wgrad_flush_streams)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the N=1 run
@@ -198,6 +199,7 @@ def main():
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
     grads = X.parallel.FlatGrads(params)                       # p.grad = views of one flat fp32 bucket
     ops.set_wgrad_flush_streams(args.wgrad_flush_streams)
+    ops.set_level_streams(args.level_streams)
     ops.set_wgrad_overlap(args.wgrad_overlap, args.wgrad_batch)
     ops.set_wgrad_defer(not args.no_wgrad_defer and not args.wgrad_overlap)   # weight gradients batched at the end of backward           # weight gradients on a second HIP stream, joined once per step
 

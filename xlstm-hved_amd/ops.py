@@ -141,6 +141,25 @@ def zeros_red(t, n, c):
     return zeros_f64(t.device, (n, c, 2))
 
 
+# side streams for the independent per-level chains of the network's latent path (model._decode); off by default
+_LEVEL_STREAMS = {"on": False, "streams": {}}
+
+
+def set_level_streams(enabled):
+    _LEVEL_STREAMS["on"] = bool(enabled)
+
+
+def level_streams(device, n):
+    """n side streams of `device` (created once), or None when the feature is off."""
+    if not _LEVEL_STREAMS["on"] or n <= 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    have = _LEVEL_STREAMS["streams"].setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
 # ------------------------------------------------------------------------------------- weight fragments
 # The MFMA conv kernels read their weights as packed 16-bit fragments (xh_conv3d_workspace_bytes).  Weights are constant
 # within a step, so instead of one small pack launch in front of each of the ~54 k=3 convolutions (forward and data
