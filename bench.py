@@ -375,7 +375,7 @@ def extras(model, x, grads, nsteps):
         import xlstm_hved_amd as X
         from xlstm_hved_amd.train_step import TrainStep
         torch.manual_seed(2)
-        disc = X.Discriminator(in_channels=7)
+        disc = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2])            # train.py:146
         disc.apply(X.init_weights)
         disc = disc.to(x.device)
         ts = TrainStep(model, disc, storage=x.dtype)

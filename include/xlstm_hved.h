@@ -385,25 +385,27 @@ int xh_nested_weight(void* stream, int dtype, const void* seg, long long seg_bs,
 int xh_fill(void* stream, int dtype, void* out, long long n, float v, const float* gscale);
 
 /* ------------------------------------------------------------------------------------------------
- * Discriminator (RA_HVED.py:204-236, buildingblocks.py:342-358): k=3 convolutions 7 -> 64 -> 128 -> 256 -> 512 -> 1 as
- * implicit GEMMs on the matrix cores.  Inside the discriminator activations are CHANNELS-LAST [N][D][H][W][C], 16-bit
- * (dtype XH_BF16 / XH_F16), C a multiple of 8; weights are re-packed per step by xh_dconv_pack.
+ * Discriminator (RA_HVED.py:204-236, buildingblocks.py:342-358): convolutions 7 -> 64 -> 128 -> 256 -> 512 -> 1 with kernel
+ * size ks = 4 (train.py:146, Pretrain.py:150) or 3 (the class default), padding 1, strides 1,2,2,2,1, as implicit GEMMs on the
+ * matrix cores.  Inside the discriminator activations are CHANNELS-LAST [N][D][H][W][C], 16-bit (dtype XH_BF16 / XH_F16),
+ * C a multiple of 8; weights are re-packed per step by xh_dconv_pack.  Every entry point returns XH_ERR_ARG for ks outside
+ * {3, 4} and for extents that are not those of a padding-1 convolution: out = (in + 2 - ks) / stride + 1.
  * ------------------------------------------------------------------------------------------------ */
-/* mode 0 forward: x [N][Di,Hi,Wi][Cs] -> y [N][Do,Ho,Wo][Cn], Do = (Di-1)/stride+1; Cs a multiple of 32, or 8 (the padded
+/* mode 0 forward: x [N][Di,Hi,Wi][Cs] -> y [N][Do,Ho,Wo][Cn], Do = (Di+2-ks)/stride+1; Cs a multiple of 32, or 8 (the padded
  * 7-channel input: weights packed with mode 2).  bias [Cn] optional; act XH_ACT_NONE / XH_ACT_LRELU(slope); red optional:
  * red[n][cn][0..1] += (sum y, sum y^2) of the stored output (InstanceNorm statistics).
- * mode 1 data gradient: x = dY [N][Di..][Cs = Cout(_pad)], y = dX [N][Do..][Cn = Cin(_pad)], Di = (Do-1)/stride+1, weights packed
- * with mode 1; bias / red / act unused. */
-int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const void* x, const void* w, const float* bias, void* y, double* red,
-                int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope);
-/* dwp[27][Cn][Cs] (fp32, caller zeroes) += sum over output voxels m of dY[m][cn] * X[src(m, tap)][cs]; x = the forward input
+ * mode 1 data gradient: x = dY [N][Di..][Cs = Cout(_pad)], y = dX [N][Do..][Cn = Cin(_pad)], Di = (Do+2-ks)/stride+1, weights
+ * packed with mode 1; bias / red / act unused. */
+int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks, const void* x, const void* w, const float* bias, void* y,
+                double* red, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope);
+/* dwp[ks^3][Cn][Cs] (fp32, caller zeroes) += sum over output voxels m of dY[m][cn] * X[src(m, tap)][cs]; x = the forward input
  * [N][Di..][Cs], dy [N][Do..][Cn]; Cs, Cn multiples of 8. */
-int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void* x, const void* dy, float* dwp, int N, int Di, int Hi, int Wi,
-                      int Do, int Ho, int Wo, int Cs, int Cn);
-/* fp32 nn.Conv3d weight [Cout][Cin][27] -> 16-bit operand image.  mode 0: [27][Cout][CinPad]; mode 1: [27][CinPad][CoutPad];
- * mode 2 (CinPad == 8): [9][Cout][32].  xh_dconv_unpack_grad: dw[Cout][Cin][27] += dwp[27][CoutPad][CinPad]. */
-int xh_dconv_pack(void* stream, int dtype, int mode, const float* w, void* out, int Cout, int Cin, int CoutPad, int CinPad);
-int xh_dconv_unpack_grad(void* stream, const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad);
+int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, const void* x, const void* dy, float* dwp, int N, int Di, int Hi,
+                      int Wi, int Do, int Ho, int Wo, int Cs, int Cn);
+/* fp32 nn.Conv3d weight [Cout][Cin][ks^3] -> 16-bit operand image.  mode 0: [ks^3][Cout][CinPad]; mode 1: [ks^3][CinPad][CoutPad];
+ * mode 2 (CinPad == 8): [ks^2][Cout][32] (k = kw * 8 + ci).  xh_dconv_unpack_grad: dw[Cout][Cin][ks^3] += dwp[ks^3][CoutPad][CinPad]. */
+int xh_dconv_pack(void* stream, int dtype, int mode, int ks, const float* w, void* out, int Cout, int Cin, int CoutPad, int CinPad);
+int xh_dconv_unpack_grad(void* stream, int ks, const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad);
 /* NCDHW (xa: CA channels, xb: CB channels or NULL) -> channels-last [N][V][Cpad] (zero padded), and its adjoint. */
 int xh_cl_from_ncdhw(void* stream, int dtype, const void* xa, long long xa_bs, int CA, const void* xb, long long xb_bs, int CB, void* out,
                      int Cpad, int N, long long V);

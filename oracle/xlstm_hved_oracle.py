@@ -472,6 +472,19 @@ def dice_coefficient(prob, target, eps=1e-6):
     return ((2 * inter + eps) / (den + eps)).mean(0)
 
 
+def discriminator(p, x, strides=(1, 2, 2, 2), slope=0.2):
+    """RA_HVED.py:204-236 Discriminator.forward with buildingblocks.py:342-358 discriminator_block (double=False):
+    disc.0 = Conv3d(k, stride, padding=1) -> LeakyReLU(0.2)  (normalization=False), disc.1..3 = Conv3d -> InstanceNorm3d (no
+    affine, eps 1e-5) -> LeakyReLU(0.2), last = Conv3d(512, 1, k, padding=1, bias=False).  The kernel size is that of the
+    weights (train.py:146 builds ks=4, the class default is 3)."""
+    for i, st in enumerate(strides):
+        x = F.conv3d(x, p[f"disc.{i}.0.weight"], p[f"disc.{i}.0.bias"], stride=st, padding=1)
+        if i > 0:
+            x = F.instance_norm(x, eps=NORM_EPS)
+        x = F.leaky_relu(x, slope)
+    return F.conv3d(x, p["last.weight"], None, padding=1)
+
+
 def bench_loss(prob, mu_list, logvar_list, rec):
     """loss that reaches every used parameter."""
     loss = prob.float().mean() + rec.float().mean()

@@ -464,13 +464,76 @@ def loss_cases():
          nested=f_nested_w.unsqueeze(1), atten=atten, dice_coefficient=dc, dice_region=dcr)
 
 
+DISC_X_SHAPE, DISC_X_SEED, DISC_W_SEED = (2, 7, 40, 36, 44), 501, 7
+
+
+def disc_sample_index(numel, cap=4096):
+    """Positions of a parameter gradient the fixture keeps (every step-th element; whole tensor when small)."""
+    step = max(1, numel // cap)
+    return torch.arange(0, numel, step)
+
+
+def disc_cases():
+    """The adversarial step's Discriminator exactly as train.py:146-147 builds it: Discriminator(in_channels=7, ks=4,
+    strides=[1,2,2,2]) + init_weights, and the class-default ks=3 instance.  11 M parameters: the fixture carries no weights
+    (tests rebuild them with the same seed through xlstm_hved_amd.init_weights and check the stored per-tensor checksums) and
+    keeps a strided sample + sum + abs-sum of every parameter gradient.  fp32 and fp64 reference runs; the oracle must
+    reproduce both."""
+    for ks in (4, 3):
+        torch.manual_seed(DISC_W_SEED)
+        ref = R.Discriminator(in_channels=7, ks=ks, strides=[1, 2, 2, 2])
+        ref.apply(ns.utils.init_weights)
+        sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+        x = rnd(DISC_X_SHAPE, DISC_X_SEED)       # regenerated by the tests from the same seed; checksums below
+        arrs = dict(xsum=x.double().sum(), xabs=x.double().abs().sum(), ks=np.array(ks), names=np.array(list(sd0.keys())))
+        for k, v in sd0.items():
+            arrs["wsum." + k] = v.double().sum()
+            arrs["wabs." + k] = v.double().abs().sum()
+        gy = None
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            m = ref.to(dt)
+            m.zero_grad()
+            xi = x.to(dt).clone().requires_grad_(True)
+            y = m(xi)
+            if gy is None:
+                gy = rnd(y.shape, 502)
+                arrs["gy"] = gy
+            (y * gy.to(dt)).sum().backward()
+            # oracle on the same weights
+            sd = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd0.items()}
+            xo = x.to(dt).clone().requires_grad_(True)
+            yo = O.discriminator(O.P(sd), xo)
+            (yo * gy.to(dt)).sum().backward()
+            tol = 2e-5 if dt == torch.float32 else 1e-12
+            check(f"disc ks{ks} {tag} y", yo, y, tol)
+            check(f"disc ks{ks} {tag} dx", xo.grad, xi.grad, tol * 10)
+            arrs[f"{tag}.y"] = y
+            gx = xi.grad.flatten()
+            arrs[f"{tag}.dx"] = gx[disc_sample_index(gx.numel(), 65536)]
+            arrs[f"{tag}.dxsum"] = gx.double().sum()
+            arrs[f"{tag}.dxabs"] = gx.double().abs().sum()
+            for k, p_ in m.named_parameters():
+                check(f"disc ks{ks} {tag} g.{k}", sd[k].grad, p_.grad, tol * 10)
+                g = p_.grad.flatten()
+                arrs[f"{tag}.g.{k}"] = g[disc_sample_index(g.numel())]
+                arrs[f"{tag}.gsum.{k}"] = g.double().sum()
+                arrs[f"{tag}.gabs.{k}"] = g.double().abs().sum()
+            ref = m.float()
+        save(f"stage_disc_ks{ks}", **arrs)
+        print(f"  oracle vs reference Discriminator(ks={ks}): output, input gradient and 9 parameter gradients agree (fp32, fp64)")
+
+
 if __name__ == "__main__":
     if "--losses-only" in sys.argv:
         loss_cases()
+        sys.exit(0)
+    if "--disc-only" in sys.argv:
+        disc_cases()
         sys.exit(0)
     stage_cases()
     poe_cases()
     network_cases()
     variant_cases()
     loss_cases()
+    disc_cases()
     print("all fixtures written and certified against the oracle")

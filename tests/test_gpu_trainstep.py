@@ -1,9 +1,10 @@
 """-m gpu: one optimisation step of train.py:208-296 (TrainStep: two shared-encoder forwards, HIP loss epilogues, LSGAN
-terms through the discriminator, generator + discriminator backward) against the same step assembled from the CPU oracle
-(two plain oracle forwards + oracle loss restatements + the same stock Discriminator on the CPU)."""
+terms through the ks=4 discriminator of train.py:146, generator + discriminator backward) against the same step assembled
+from the CPU oracle (two plain oracle forwards + oracle loss restatements + oracle.discriminator on the same weights)."""
 import pytest
 import torch
 
+import disc_common as DC
 from gpu_common import load
 
 pytestmark = pytest.mark.gpu
@@ -24,14 +25,21 @@ def _inputs(S=32):
     return x, mask, eps
 
 
-def _disc(hip=False):
-    torch.manual_seed(11)
-    d = (X.Discriminator if hip else X.DiscriminatorReference)(in_channels=7)
-    d.apply(X.init_weights)
+def _disc_state():
+    return DC.seeded_disc_state(4)                   # Discriminator(in_channels=7, ks=4, strides=[1,2,2,2]) + init_weights
+
+
+def _disc(hip=True):
+    d = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2])         # train.py:146
+    d.load_state_dict(_disc_state(), strict=True)
     return d
 
 
-def _oracle_step(w, disc, x, mask, eps, subset):
+def _oracle_step(w, dsd, x, mask, eps, subset):
+    dsd = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+
+    def disc(t):
+        return O.discriminator(O.P(dsd), t)
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
     f_out, _, _, _, f_rec = O.xlstm_hved_forward(sd, x, 14, eps_list=eps[0], training=True)
     m_out, _, mu, lv, m_rec = O.xlstm_hved_forward(sd, x, subset[0], eps_list=eps[1], training=True)
@@ -45,31 +53,16 @@ def _oracle_step(w, disc, x, mask, eps, subset):
     loss = dice + m_dice + BETA * recon + BETA * kld + ALPHA * g_gan
     loss.backward()
     gg = {k: v.grad.clone() for k, v in sd.items() if v.requires_grad and v.grad is not None}
-    for p in disc.parameters():
+    for p in dsd.values():
         p.grad = None
     real = torch.cat([f_out.detach(), atten_f], 1)
     loss_d = ALPHA * 0.5 * ((disc(fake.detach()) ** 2).mean() + ((disc(real) - 1.0) ** 2).mean())
     loss_d.backward()
-    gd = {k: p.grad.clone() for k, p in disc.named_parameters()}
+    gd = {k: p.grad.clone() for k, p in dsd.items()}
     return dict(dice=dice, m_dice=m_dice, recon=recon, kld=kld, g_gan=g_gan, loss=loss, loss_d=loss_d), gg, gd
 
 
-@pytest.mark.parametrize("shared", [True, False], ids=["shared_encoder", "two_forwards"])
-def test_train_step_fp32_vs_oracle(shared):
-    x, mask, eps = _inputs()
-    subset = [6]
-    w = load("weights_seed1")
-    want, gg, gd = _oracle_step(w, _disc(), x, mask, eps, subset)
-    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
-    m.load_state_dict(w, strict=True)
-    m = m.to(DEV).train()
-    ts = TrainStep(m, _disc().to(DEV), alpha=ALPHA, beta=BETA, storage=torch.float32, shared_encoder=shared)
-    eps_dev = [[e.to(DEV) for e in el] for el in eps]
-    got = ts.compute(x.to(DEV), mask.to(DEV), subset, eps_lists=eps_dev)
-    torch.cuda.synchronize()
-    for k in ("dice", "m_dice", "recon", "kld", "g_gan", "loss", "loss_d"):
-        a, b = got[k].item(), want[k].item()
-        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (k, a, b)
+def _grad_devs(m, gg):
     gscale = max(v.abs().max().item() for v in gg.values())
     worst, num, den = 0.0, 0.0, 0.0
     for k, p in m.named_parameters():
@@ -81,15 +74,70 @@ def test_train_step_fp32_vs_oracle(shared):
             worst = max(worst, e)
             num += ((p.grad.cpu() - gg[kk]) ** 2).sum().item()
             den += (gg[kk] ** 2).sum().item()
-            # fp32 vs fp32 on a network that amplifies round-off ~1e4x: 2e-2 of the largest gradient per tensor,
-            # 5e-3 relative L2 over all of them
-            assert e < 2e-2, (k, e)
-    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5
+    return worst, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("shared", [True, False], ids=["shared_encoder", "two_forwards"])
+def test_train_step_fp32_vs_oracle(shared):
+    """fp32 storage: every generator-side quantity at fp32 round-off against the oracle; the discriminator runs on the HIP
+    kernels with fp16 activations (the reference's autocast dtype), so the terms that pass through it carry fp16 rounding."""
+    x, mask, eps = _inputs()
+    subset = [6]
+    w = load("weights_seed1")
+    want, gg, gd = _oracle_step(w, _disc_state(), x, mask, eps, subset)
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(w, strict=True)
+    m = m.to(DEV).train()
+    ts = TrainStep(m, _disc().to(DEV), alpha=ALPHA, beta=BETA, storage=torch.float32, shared_encoder=shared)
+    eps_dev = [[e.to(DEV) for e in el] for el in eps]
+    got = ts.compute(x.to(DEV), mask.to(DEV), subset, eps_lists=eps_dev)
+    torch.cuda.synchronize()
+    for k in ("dice", "m_dice", "recon", "kld"):
+        a, b = got[k].item(), want[k].item()
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (k, a, b)
+    for k, tol in (("g_gan", 5e-3), ("loss_d", 5e-3), ("loss", 1e-3)):          # through the fp16 discriminator
+        a, b = got[k].item(), want[k].item()
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (k, a, b)
+    worst, l2 = _grad_devs(m, gg)
     dscale = max(v.abs().max().item() for v in gd.values())
-    for k, p in ts.disc.named_parameters():
-        assert (p.grad.cpu() - gd[k]).abs().max().item() <= 5e-3 * dscale, k
+    dworst = max((p.grad.cpu() - gd[k]).abs().max().item() / dscale for k, p in ts.disc.named_parameters())
     print(f"train step ({'shared encoder' if shared else 'two forwards'}): loss {got['loss'].item():.6f} (oracle {want['loss'].item():.6f}), "
-          f"worst scaled generator-gradient deviation {worst:.2e}")
+          f"loss_d {got['loss_d'].item():.6f} ({want['loss_d'].item():.6f}), generator gradients worst {worst:.2e} / L2 {l2:.2e}, "
+          f"discriminator gradients worst {dworst:.2e}")
+    # fp32 vs fp32 on a network that amplifies round-off ~1e4x (SURVEY F9) plus the fp16 discriminator's share of the
+    # generator gradient (alpha * dLSGAN/dfake: fp16 activations through three InstanceNorm backward passes, 3e-2 relative L2
+    # on its own, tests/test_gpu_disc.py)
+    assert worst < 6e-2 and l2 < 3e-2, (worst, l2)
+    assert dworst <= 5e-2, dworst
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_train_step_16bit_vs_oracle(dtype):
+    """16-bit storage (the measured training step): every loss term and both gradient sets against the fp32 oracle step.
+    Bands: the storage format's rounding amplified by the randomly initialised network (amp_yardstick.json)."""
+    x, mask, eps = _inputs()
+    subset = [6]
+    w = load("weights_seed1")
+    want, gg, gd = _oracle_step(w, _disc_state(), x, mask, eps, subset)
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(w, strict=True)
+    m = m.to(DEV).train()
+    ts = TrainStep(m, _disc().to(DEV), alpha=ALPHA, beta=BETA, storage=dtype)
+    eps_dev = [[e.to(DEV) for e in el] for el in eps]
+    got = ts.compute(x.to(DEV), mask.to(DEV), subset, eps_lists=eps_dev)
+    torch.cuda.synchronize()
+    assert ts.check_finite()
+    k16 = 1.0 if dtype == torch.bfloat16 else 0.25
+    dev = {k: abs(got[k].item() - want[k].item()) / max(1.0, abs(want[k].item())) for k in ("dice", "m_dice", "recon", "kld", "g_gan", "loss", "loss_d")}
+    worst, l2 = _grad_devs(m, gg)
+    dscale = max(v.abs().max().item() for v in gd.values())
+    dworst = max((p.grad.cpu() - gd[k]).abs().max().item() / dscale for k, p in ts.disc.named_parameters())
+    print(dtype, {k: f"{v:.2e}" for k, v in dev.items()}, f"generator gradients worst {worst:.2e} / L2 {l2:.2e}, discriminator worst {dworst:.2e}")
+    # measured on MI355X (32^3, seeded init_weights): loss terms bf16 <= 2.5e-2 (g_gan) / fp16 <= 5.3e-3; gradients of the randomly
+    # initialised generator (it amplifies a perturbation ~1e4x, SURVEY F9) bf16 0.73 / fp16 0.28 relative L2, discriminator
+    # gradients 0.16 / 0.035 of the largest -- a sanity band on direction and scale, not a precision claim (DESIGN 4)
+    assert all(v < 5e-2 * k16 for v in dev.values()), dev
+    assert l2 < (1.2 if dtype == torch.bfloat16 else 0.45) and dworst < 0.3 * k16, (l2, dworst)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
@@ -98,7 +146,7 @@ def test_train_step_16bit_runs_and_updates(dtype):
     m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     m.load_state_dict(load("weights_seed1"), strict=True)
     m = m.to(DEV).train()
-    d = _disc(hip=True).to(DEV)
+    d = _disc().to(DEV)
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     opt_d = torch.optim.Adam(d.parameters(), lr=1e-4)
     ts = TrainStep(m, d, opt, opt_d, storage=dtype)
@@ -115,7 +163,7 @@ def test_batched_discriminator_step_and_weight_image_cache():
     as two separate passes, and an in-place weight update inside a pack scope is seen by the next pass."""
     from xlstm_hved_amd import disc as D
     torch.manual_seed(3)
-    d = _disc(hip=True).to(DEV)
+    d = _disc().to(DEV)
     ts = TrainStep(torch.nn.Linear(1, 1).to(DEV), d, storage=torch.bfloat16)      # the generator is not used here
     fake = torch.rand(1, 7, 32, 32, 32, device=DEV).bfloat16()
     real = torch.rand(1, 7, 32, 32, 32, device=DEV).bfloat16()

@@ -241,3 +241,27 @@ def test_loss_and_metric_restatements_vs_reference_fixture():
     close(O.nested_weight(g["prob"]), g["nested"], 0, "nested")
     close(O.dice_coefficient(g["prob"], tgt).mean(), g["dice_coefficient"], 1e-6, "dice coefficient")
     close(O.dice_region(g["prob"], tgt), g["dice_region"], 1e-6, "dice region")
+
+
+@pytest.mark.parametrize("ks", [4, 3])
+@pytest.mark.parametrize("tag,dt,tol", [("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-11)])
+def test_discriminator_matches_reference(ks, tag, dt, tol):
+    """oracle.discriminator against the REAL reference class (tests/golden/stage_disc_ks*.npz: train.py:146's
+    Discriminator(in_channels=7, ks=4, strides=[1,2,2,2]) and the ks=3 default): output, input gradient, all 9 parameter
+    gradients (strided samples + sums)."""
+    import disc_common as DC
+    g = DC.load_fixture(ks)
+    sd = {k: v.to(dt).requires_grad_(True) for k, v in DC.seeded_disc_state(ks, g).items()}
+    x = DC.seeded_input(g).to(dt).requires_grad_(True)
+    y = O.discriminator(O.P(sd), x)
+    assert tuple(y.shape) == tuple(g[f"{tag}.y"].shape)
+    close(y, g[f"{tag}.y"], tol, "y")
+    (y * g["gy"].to(dt)).sum().backward()
+    gx = x.grad.flatten()
+    close(gx[DC.sample_index(gx.numel(), 65536)], g[f"{tag}.dx"], tol * 10, "dx")
+    for k, v in sd.items():
+        gr = v.grad.flatten()
+        ref = g[f"{tag}.g.{k}"]
+        scale = max(ref.double().abs().max().item(), 1e-30)
+        assert (gr[DC.sample_index(gr.numel())].double() - ref.double()).abs().max().item() <= tol * 10 * max(scale, 1.0), k
+        assert abs(gr.double().sum().item() - float(g[f"{tag}.gsum.{k}"])) <= tol * 10 * max(float(g[f"{tag}.gabs.{k}"]), 1.0), k

@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 torch.manual_seed(1)
 m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS); m.apply(X.init_weights); m = m.cuda().train()
 torch.manual_seed(2)
-d = X.Discriminator(in_channels=7); d.apply(X.init_weights); d = d.cuda()
+d = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2]); d.apply(X.init_weights); d = d.cuda()
 x = torch.rand(1, 4, 128, 128, 128, device="cuda").bfloat16()
 mask = (torch.rand(1, 3, 128, 128, 128, device="cuda") > 0.7).float()
 ts = TrainStep(m, d, storage=torch.bfloat16)

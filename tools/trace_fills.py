@@ -43,7 +43,7 @@ x = torch.rand(1, 4, 64, 64, 64, device="cuda").bfloat16()
 from xlstm_hved_amd.losses import sum_of_means
 if "--trainstep" in sys.argv:                       # the whole training step (train_step.TrainStep) instead of one fwd+bwd
     from xlstm_hved_amd.train_step import TrainStep
-    d = X.Discriminator(in_channels=7); d.apply(X.init_weights); d = d.cuda()
+    d = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2]); d.apply(X.init_weights); d = d.cuda()
     ts = TrainStep(m, d, storage=torch.bfloat16)
     mask = (torch.rand(1, 3, 64, 64, 64, device="cuda") > 0.7).float()
     def step():

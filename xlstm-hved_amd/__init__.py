@@ -7,7 +7,7 @@ from . import _lib, functional, ops, parallel  # noqa: F401
 from .blocks import (AttenModule2, BasicConv, ChannelPool, Decoder, DoubleConv, DoubleConv_ViL, DuSEAttention, Encoder,  # noqa: F401
                      ProductOfExperts, ProductOfExperts2, ResBlock, SingleConv, SkipReturnAttention, SpacialAttention3D,
                      Upsampling, ViLLayer, number_of_features_per_level)
-from .disc import Discriminator, DiscriminatorReference  # noqa: F401
+from .disc import Discriminator  # noqa: F401
 from .model import (MODELS, SUBSETS_MODALITIES, AbstractFusion3DUNet, ReconDecoder, Seg_Recon_DuSFEDecoder,  # noqa: F401
                     U_HVEDConvDuSFEmViLNet3D, U_HVEDConvDuSFEmViLSkrNet3D, U_HVEDConvDuSFENet3D, U_HVEDConvDuSFESkrNet3D,
                     U_HVEDConvNet3D, U_HVEDConvXLSTMNet3D, XLSTM_HVED, XLSTM_HVED_woDuSFE, XLSTM_HVED_woSMVAE,

@@ -1,14 +1,15 @@
 // Discriminator convolutions (RA_HVED.py:204-236, buildingblocks.py:342-358) as implicit GEMMs on the matrix cores.
 //
 // The discriminator is the one MFMA-bound object of a training step (7 -> 64 -> 128 -> 256 -> 512 -> 1 channels,
-// k = 3, strides 1,2,2,2,1; ~250 GFLOP per forward at 128^3, three passes per step) and it is self-contained, so inside it the
+// strides 1,2,2,2,1, padding 1; kernel size K = 4 as train.py:146 builds it -- 128 -> 127 -> 63 -> 31 -> 15 -> 14 voxels per axis,
+// ~560 GFLOP per forward at 128^3 -- or K = 3, the class default; three passes per step) and it is self-contained, so inside it the
 // activations are kept CHANNELS-LAST ([n][d][h][w][C], 16-bit): the K axis of the GEMM (input channels of one tap) is then
 // contiguous in memory and a 16 x 32 MFMA operand row is one 64-byte run of one voxel -- no im2col buffer, no transposition.
 //
-//   forward      Y[m][co] = sum_{tap, ci} X[src(m, tap)][ci] * W[co][ci][tap]          M = voxels, N = Cout, K = 27 * Cin
+//   forward      Y[m][co] = sum_{tap, ci} X[src(m, tap)][ci] * W[co][ci][tap]          M = voxels, N = Cout, K = K^3 * Cin
 //   data grad    dX[m][ci] = sum_{tap, co} dY[src'(m, tap)][co] * W[co][ci][tap]       same kernel, roles swapped; for stride 2
 //                the destination voxels are processed in their 8 parity classes so that only the taps that reach a class are
-//                walked (27 tap visits in total instead of 8 x 27)
+//                walked (K = 3: 27 tap visits in total instead of 8 x 27; K = 4: 8 taps for every class instead of 64)
 //   weight grad  dW[tap][co][ci] = sum_m dY[m][co] * X[src(m, tap)][ci]                M = Cout, N = Cin, K = voxels: both operands
 //                are needed K(voxel)-major, i.e. transposed -- staged row-major in LDS and read with ds_read_b64_tr_b16
 //
@@ -29,7 +30,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-struct DTaps { int n; int t[3]; int off[3]; };
+struct DTaps { int n; int t[4]; int off[4]; };
 
 // One class of destination voxels.  Forward / stride-1 data gradient: a single class = all of them.  Stride-2 data gradient:
 // the 8 parity classes (destination = 2 j + p per axis), each with the taps that reach it (1 or 2 per axis); they travel in ONE
@@ -49,8 +50,9 @@ struct DConvK {
   int smul;                // source index = j * smul + off[tap]
   int ncls, xcd;
   DClass c[8];
-  int rowmode;             // 1: Cs == 8: one K step = the 3 kw taps x 8 channels of a row (+ 8 zero-weight), tw ignored
+  int rowmode;             // 1: Cs == 8: one K step = the kw taps x 8 channels of a (kd, kh) row (K = 3: + 8 zero-weight), tw ignored
   int act; float slope;
+  int K;                   // kernel size per axis (3 or 4), padding 1
   int wtap_stride;         // elements between consecutive taps in w (= Cn * Kc)
   int Kc;                  // K extent of one step group in w rows (Cs, or 32 in rowmode)
 };
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     const int cs = s % nsteps_c; int t = s / nsteps_c;
     const int iw = t % ntw; t /= ntw;
     const int ih = t % cl.th.n, id = t / cl.th.n;
-    const int tap = a.rowmode ? (cl.td.t[id] * 3 + cl.th.t[ih]) : ((cl.td.t[id] * 3 + cl.th.t[ih]) * 3 + cl.tw.t[iw]);
+    const int tap = a.rowmode ? (cl.td.t[id] * a.K + cl.th.t[ih]) : ((cl.td.t[id] * a.K + cl.th.t[ih]) * a.K + cl.tw.t[iw]);
     unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -319,15 +321,17 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
 struct DWgK {
   const u16* x; const u16* dy; float* dw;
   int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn, stride;
-  int msplit;              // voxel-range splits (grid z = 27 * msplit)
+  int msplit;              // voxel-range splits (grid z = ntz * msplit)
   long long M;             // N * Do * Ho * Wo
+  int K, ntap, ntz;        // kernel size per axis, K^3, tap slots on grid z (ntap, or ceil(ntap / 2) for tap pairs)
 };
 // LDS image of a [32 voxel][128 channel] tile for transposed reads: 256-byte rows, the 16-byte chunk index XORed with
 // ((row & 3) << 2) | ((row >> 2) & 3)  (conflict-free ds_read_b64_tr_b16 of 4-row blocks)
 __device__ __forceinline__ int sw256(int row, int chunk) { return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
 
 // PAIR (Cs == 64): a 128-wide X tile would be half padding, so two consecutive taps share it -- columns 0..63 = tap 2z,
-// 64..127 = tap 2z + 1 (14 pairs; the odd one out has an empty second half): dY is streamed 14 times instead of 27
+// 64..127 = tap 2z + 1 (K = 3: 14 pairs, the odd one out has an empty second half: dY is streamed 14 times instead of 27;
+// K = 4: 32 pairs)
 template <int FMT, int WGN, int TMW, int TNW, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
   // waves: WGM x WGN over (cn, cs); a wave owns TMW x TNW tiles of 16 x 16
@@ -339,12 +343,11 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
   const int wm = wv / WGN, wn = wv % WGN;
   const int r16 = lane & 15, kg = lane >> 4, q = r16 >> 2, p = r16 & 3;
   const int cs0 = blockIdx.x * BNc, cn0 = blockIdx.y * BMc;
-  constexpr int NTZ = PAIR ? 14 : 27;
-  const int tz = blockIdx.z % NTZ, split = blockIdx.z / NTZ;
+  const int tz = blockIdx.z % a.ntz, split = blockIdx.z / a.ntz;
   // the X chunk a thread stages is the same in every step (chunk = tid & 15): its tap is a per-thread constant
   const int tap = PAIR ? 2 * tz + ((tid & 15) >> 3) : tz;
-  const bool tap_ok = tap < 27;
-  const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+  const bool tap_ok = tap < a.ntap;
+  const int kd = tap / (a.K * a.K), kh = (tap / a.K) % a.K, kw = tap % a.K;
   const long long per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
   const long long m_begin = (long long)split * per, m_end = m_begin + per < a.M ? m_begin + per : a.M;
   // staging: a tile is 32 rows x 16 chunks = 512 chunks -> 2 per thread per operand.  A thread's two rows move on by 32 voxels
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cn = cn0 + (wm * TMW + i) * 16 + kg * 4 + r;
-        if (cn < a.Cn && cs < a.Cs && otap < 27) atomicAdd(&a.dw[((long long)otap * a.Cn + cn) * a.Cs + cs], acc[i][j][r]);
+        if (cn < a.Cn && cs < a.Cs && otap < a.ntap) atomicAdd(&a.dw[((long long)otap * a.Cn + cn) * a.Cs + cs], acc[i][j][r]);
       }
     }
 }
@@ -584,18 +587,22 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
 }
 
 // The same weight gradient (8 -> 64, stride 1) without the per-step gather: a workgroup walks 4 x 4 x 16 blocks of output voxels;
-// per block the 6 x 6 x 18 halo of X (16 bytes per voxel, 10 KB) and the block's 256 x 64 dY values (eight 32-voxel K steps in
-// the transposed-read layout above) are put in LDS ONCE, and the X operand of a (tap pair, ci) column tile is read straight
-// from the halo -- a tap is an address offset -- with ds_read_b64_tr_b16.  One barrier pair per 256 voxels instead of one per
-// 32, no 27-fold re-fetch of X, the next block's loads in flight behind the 128 MFMAs of the current one.
+// per block the (3 + K)^2 x (15 + K) halo of X (16 bytes per voxel, 10 / 15 KB) and the block's 256 x 64 dY values (eight
+// 32-voxel K steps in the transposed-read layout above) are put in LDS ONCE, and the X operand of a (tap pair, ci) column tile is
+// read straight from the halo -- a tap is an address offset -- with ds_read_b64_tr_b16.  One barrier pair per 256 voxels instead
+// of one per 32, no K^3-fold re-fetch of X, the next block's loads in flight behind the 128 MFMAs of the current one.
+// K = 4: 64 taps x 8 channels = 512 columns = 32 column tiles: the taps are split in two halves over blockIdx.y (16 tiles each,
+// none of them padding; K = 3 uses 14 of its 16).  (D, H, W) are the OUTPUT extents, the input has (D, H, W) + K - 3.
 struct DWg8HK {
   const u16* x; const u16* dy; float* dw;
   int N, D, H, W;
   int td, th, tw, ntile;
 };
-template <int FMT>
+template <int FMT, int K>
 __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) {
-  constexpr int PH = 6, PW = 18, NV = 6 * PH * PW;
+  constexpr int PD = 3 + K, PH = 3 + K, PW = 15 + K, NV = PD * PH * PW, NX = (NV + 255) / 256, NTAP = K * K * K;
+  const int Dx = a.D + K - 3, Hx = a.H + K - 3, Wx = a.W + K - 3;
+  const int tap0 = blockIdx.y * 32;
   constexpr int YB = 32 * 256;                             // one K step of dY: 32 voxels x (64 of 128) channels, sw256 image
   __shared__ __attribute__((aligned(16))) unsigned char ys[8 * YB];
   __shared__ __attribute__((aligned(16))) unsigned char xt[(NV + 1) * 16];          // + one zero voxel for the padding columns
@@ -605,9 +612,9 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
   int xoff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int t = 2 * (wv + 4 * j) + (p >> 1);
-    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
-    xoff[j] = t < 27 ? ((kd * PH + kh) * PW + kw) * 16 + 8 * (p & 1) : -1;
+    const int t = tap0 + 2 * (wv + 4 * j) + (p >> 1);
+    const int kd = t / (K * K), kh = (t / K) % K, kw = t % K;
+    xoff[j] = t < NTAP ? ((kd * PH + kh) * PW + kw) * 16 + 8 * (p & 1) : -1;
   }
   f32x4_t acc[4][4];
 #pragma unroll
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (tid == 0) *reinterpret_cast<uint4*>(xt + NV * 16) = make_uint4(0, 0, 0, 0);
-  uint4 py[8], px[3];
+  uint4 py[8], px[NX];
   const int per_n = a.td * a.th * a.tw;
   auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int n = t / per_n; int b = t - n * per_n;
@@ -623,8 +630,8 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
     const int th_i = b % a.th, td_i = b / a.th;
     const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
     const u16* yn = a.dy + (long long)n * a.D * a.H * a.W * 64;
-    const u16* xn = a.x + (long long)n * a.D * a.H * a.W * 8;
-    bool oky[8], okx[3];
+    const u16* xn = a.x + (long long)n * Dx * Hx * Wx * 8;
+    bool oky[8], okx[NX];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + i * 256;
@@ -636,19 +643,19 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
       py[i] = *reinterpret_cast<const uint4*>(yn + (((long long)dc * a.H + hc) * a.W + wc) * 64 + c * 8);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int pi = min(tid + i * 256, NV - 1);
       const int pw = pi % PW, r = pi / PW;
       const int ph = r % PH, pd = r / PH;
       const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
-      okx[i] = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-      const int dc = min(max(d, 0), a.D - 1), hc = min(max(h, 0), a.H - 1), wc = min(max(w, 0), a.W - 1);
-      px[i] = *reinterpret_cast<const uint4*>(xn + (((long long)dc * a.H + hc) * a.W + wc) * 8);
+      okx[i] = (unsigned)d < (unsigned)Dx && (unsigned)h < (unsigned)Hx && (unsigned)w < (unsigned)Wx;
+      const int dc = min(max(d, 0), Dx - 1), hc = min(max(h, 0), Hx - 1), wc = min(max(w, 0), Wx - 1);
+      px[i] = *reinterpret_cast<const uint4*>(xn + (((long long)dc * Hx + hc) * Wx + wc) * 8);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) if (!oky[i]) py[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) if (!okx[i]) px[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < NX; ++i) if (!okx[i]) px[i] = make_uint4(0, 0, 0, 0);
   };
   auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
       *reinterpret_cast<uint4*>(ys + (rb >> 1) * YB + sw256((rb & 1) * 16 + (v & 15), c)) = py[i];
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int pi = tid + i * 256;
       if (pi < NV) *reinterpret_cast<uint4*>(xt + pi * 16) = px[i];
     }
@@ -704,8 +711,8 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = (wv + 4 * j) * 16 + r16;
-      const int tap = col >> 3, ci = col & 7;
-      if (tap >= 27) continue;
+      const int tap = tap0 + (col >> 3), ci = col & 7;
+      if (tap >= NTAP) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cn = i * 16 + kg * 4 + r;
@@ -720,14 +727,18 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
 // voxel pitch: the 16 lanes of a fragment read sit 20 banks apart), so the 27 taps are 27 shifted LDS reads of the same tile:
 // no barrier and no global activation traffic inside the tap loop; the weight fragment of a tap (1 KB) comes from L1/L2, one
 // tap ahead.  Weights ride on the M side (8 of 16 rows used): a lane ends up with 4 consecutive channels of one voxel.
+// K = 4: the halo is 7 x 7 x 19 (74 KB at the 80-byte pitch: two workgroups per CU), 64 taps; destination d takes tap kd from
+// source d + 1 - kd, so the halo starts at d0 - (K - 2).  (D, H, W) are the DESTINATION extents (the conv's input), the
+// gradient g has (D, H, W) + 3 - K.
 struct DDg8K {
   const u16* g; const u16* w; u16* dx;
   int N, D, H, W;
   int td, th, tw;          // tiles per axis
 };
-template <int FMT>
-__global__ __launch_bounds__(256, 3) void dconv_dgrad_c8_kernel(const DDg8K a) {
-  constexpr int PD = 6, PH = 6, PW = 18, NV = PD * PH * PW, PITCH = 80;
+template <int FMT, int K>
+__global__ __launch_bounds__(256, K == 3 ? 3 : 2) void dconv_dgrad_c8_kernel(const DDg8K a) {
+  constexpr int PD = 3 + K, PH = 3 + K, PW = 15 + K, NV = PD * PH * PW, PITCH = 80, NTAP = K * K * K;
+  const int Dg = a.D + 3 - K, Hg = a.H + 3 - K, Wg = a.W + 3 - K;
   __shared__ __attribute__((aligned(16))) unsigned char tile[NV * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
@@ -737,7 +748,7 @@ __global__ __launch_bounds__(256, 3) void dconv_dgrad_c8_kernel(const DDg8K a) {
   const int tw_i = b % a.tw, t2 = b / a.tw;
   const int th_i = t2 % a.th, td_i = t2 / a.th;
   const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
-  const u16* gn = a.g + (long long)n * a.D * a.H * a.W * 64;
+  const u16* gn = a.g + (long long)n * Dg * Hg * Wg * 64;
   f32x4_t acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -750,31 +761,31 @@ __global__ __launch_bounds__(256, 3) void dconv_dgrad_c8_kernel(const DDg8K a) {
       const int p = idx >> 2, c = idx & 3;
       const int pw = p % PW, q = p / PW;
       const int ph = q % PH, pd = q / PH;
-      const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
+      const int d = d0 - (K - 2) + pd, h = h0 - (K - 2) + ph, w = w0 - (K - 2) + pw;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-        v = *reinterpret_cast<const uint4*>(gn + (((long long)d * a.H + h) * a.W + w) * 64 + half * 32 + c * 8);
+      if ((unsigned)d < (unsigned)Dg && (unsigned)h < (unsigned)Hg && (unsigned)w < (unsigned)Wg)
+        v = *reinterpret_cast<const uint4*>(gn + (((long long)d * Hg + h) * Wg + w) * 64 + half * 32 + c * 8);
       *reinterpret_cast<uint4*>(tile + p * PITCH + c * 16) = v;
     }
     __syncthreads();
     uint4 wf = wrow ? *reinterpret_cast<const uint4*>(wl + half * 32) : make_uint4(0, 0, 0, 0);
 #pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd)
+    for (int kd = 0; kd < K; ++kd)
 #pragma unroll 1
-      for (int kh = 0; kh < 3; ++kh) {
+      for (int kh = 0; kh < K; ++kh) {
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int tap = (kd * 3 + kh) * 3 + kw;
+        for (int kw = 0; kw < K; ++kw) {
+          const int tap = (kd * K + kh) * K + kw;
           const uint4 wcur = wf;
-          const int nt = tap + 1 < 27 ? tap + 1 : 26;
+          const int nt = tap + 1 < NTAP ? tap + 1 : NTAP - 1;
           wf = wrow ? *reinterpret_cast<const uint4*>(wl + (long long)nt * 512 + half * 32) : make_uint4(0, 0, 0, 0);
           const h16x8 bw = __builtin_bit_cast(h16x8, wcur);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int rb = wv * 4 + i;                   // (dz, hy) row of the block
             const int dz = rb >> 2, hy = rb & 3;
-            // destination (dz, hy, r16) takes tap (kd, kh, kw) from source (+1 - kd, +1 - kh, +1 - kw); halo origin is -1
-            const int p = ((dz + 2 - kd) * PH + (hy + 2 - kh)) * PW + (r16 + 2 - kw);
+            // destination (dz, hy, r16) takes tap (kd, kh, kw) from source (+1 - kd, +1 - kh, +1 - kw); halo origin is -(K - 2)
+            const int p = ((dz + K - 1 - kd) * PH + (hy + K - 1 - kh)) * PW + (r16 + K - 1 - kw);
             const h16x8 av = *reinterpret_cast<const h16x8*>(tile + p * PITCH + kg * 16);
             acc[i] = mfma16x16x32<FMT>(bw, av, acc[i]);
           }
@@ -801,16 +812,19 @@ __global__ __launch_bounds__(256, 3) void dconv_dgrad_c8_kernel(const DDg8K a) {
 // 9 steps x 16 MFMAs per wave, weights (M side, 4 blocks of 16 channels) from L1/L2 one step ahead.  The assignment of output
 // channels to MFMA rows is free, so block j, row m carries channel (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3): a lane
 // then owns 8 CONSECUTIVE channels per block pair and the four k-groups of a voxel write 64 contiguous bytes per store.
+// K = 4: 7 x 7 x 19 halo, 16 (kd, kh) steps whose 4 kw taps x 8 channels fill the 32-deep MFMA exactly (no zero-weight lanes).
+// (D, H, W) are the OUTPUT extents; the input has (D, H, W) + K - 3.
 struct DFw8K {
   const u16* x; const u16* w; const float* bias; u16* y;
   int N, D, H, W;
   int td, th, tw;
   int act; float slope;
 };
-template <int FMT>
+template <int FMT, int K>
 __global__ __launch_bounds__(256, 2) void dconv_fwd_c8_kernel(const DFw8K a) {
-  constexpr int PD = 6, PH = 6, PW = 18, NV = PD * PH * PW;
-  __shared__ __attribute__((aligned(16))) unsigned char tile[(NV + 2) * 16];      // + 2 voxels: the zero-weight lanes of the last row
+  constexpr int PD = 3 + K, PH = 3 + K, PW = 15 + K, NV = PD * PH * PW;
+  const int Dx = a.D + K - 3, Hx = a.H + K - 3, Wx = a.W + K - 3;
+  __shared__ __attribute__((aligned(16))) unsigned char tile[(NV + 2) * 16];      // + 2 voxels: the zero-weight lanes of the last row (K = 3)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
   const int per_n = a.td * a.th * a.tw;
@@ -819,15 +833,15 @@ __global__ __launch_bounds__(256, 2) void dconv_fwd_c8_kernel(const DFw8K a) {
   const int tw_i = b % a.tw, t2 = b / a.tw;
   const int th_i = t2 % a.th, td_i = t2 / a.th;
   const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
-  const u16* xn = a.x + (long long)n * a.D * a.H * a.W * 8;
+  const u16* xn = a.x + (long long)n * Dx * Hx * Wx * 8;
   for (int p = tid; p < NV + 2; p += 256) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (p < NV) {
       const int pw = p % PW, q = p / PW;
       const int ph = q % PH, pd = q / PH;
       const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
-      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-        v = *reinterpret_cast<const uint4*>(xn + (((long long)d * a.H + h) * a.W + w) * 8);
+      if ((unsigned)d < (unsigned)Dx && (unsigned)h < (unsigned)Hx && (unsigned)w < (unsigned)Wx)
+        v = *reinterpret_cast<const uint4*>(xn + (((long long)d * Hx + h) * Wx + w) * 8);
     }
     *reinterpret_cast<uint4*>(tile + p * 16) = v;
   }
@@ -845,12 +859,12 @@ __global__ __launch_bounds__(256, 2) void dconv_fwd_c8_kernel(const DFw8K a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 #pragma unroll 1
-  for (int r9 = 0; r9 < 9; ++r9) {
-    const int kd = r9 / 3, kh = r9 - kd * 3;
+  for (int r9 = 0; r9 < K * K; ++r9) {
+    const int kd = r9 / K, kh = r9 - kd * K;
     h16x8 bw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bw[j] = __builtin_bit_cast(h16x8, wf[j]);
-    const int nr = r9 + 1 < 9 ? r9 + 1 : 8;
+    const int nr = r9 + 1 < K * K ? r9 + 1 : K * K - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const uint4*>(a.w + nr * 2048 + wrow[j]);
 #pragma unroll
@@ -892,9 +906,10 @@ __global__ __launch_bounds__(256, 2) void dconv_fwd_c8_kernel(const DFw8K a) {
   }
 }
 
-// forward of the LAST conv (Cout = 1): a dot product of 27 x Cs values per output voxel -- one wave per voxel
+// forward of the LAST conv (Cout = 1): a dot product of K^3 x Cs values per output voxel -- one wave per voxel.
+// (D, H, W) are the output extents, the input has (D, H, W) + K - 3
 template <int FMT>
-__global__ __launch_bounds__(256) void dconv_cout1_kernel(const u16* x, const u16* w, u16* y, int N, int D, int H, int W, int Cs) {
+__global__ __launch_bounds__(256) void dconv_cout1_kernel(const u16* x, const u16* w, u16* y, int N, int D, int H, int W, int Cs, int K) {
   const int lane = threadIdx.x & 63;
   const long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long V = (long long)D * H * W;
@@ -903,11 +918,12 @@ __global__ __launch_bounds__(256) void dconv_cout1_kernel(const u16* x, const u1
   long long t = v % V;
   const int ow = (int)(t % W); t /= W;
   const int oh = (int)(t % H); const int od = (int)(t / H);
+  const int Dx = D + K - 3, Hx = H + K - 3, Wx = W + K - 3;
   float acc = 0.f;
-  for (int tap = 0; tap < 27; ++tap) {
-    const int d = od + tap / 9 - 1, h = oh + (tap / 3) % 3 - 1, ww = ow + tap % 3 - 1;
-    if ((unsigned)d >= (unsigned)D || (unsigned)h >= (unsigned)H || (unsigned)ww >= (unsigned)W) continue;     // wave-uniform
-    const u16* xp = x + ((((long long)n * D + d) * H + h) * W + ww) * Cs;
+  for (int tap = 0; tap < K * K * K; ++tap) {
+    const int d = od + tap / (K * K) - 1, h = oh + (tap / K) % K - 1, ww = ow + tap % K - 1;
+    if ((unsigned)d >= (unsigned)Dx || (unsigned)h >= (unsigned)Hx || (unsigned)ww >= (unsigned)Wx) continue;     // wave-uniform
+    const u16* xp = x + ((((long long)n * Dx + d) * Hx + h) * Wx + ww) * Cs;
     const u16* wp = w + (long long)tap * Cs;
     for (int c = lane * 8; c < Cs; c += 512) {
       const uint4 a = *reinterpret_cast<const uint4*>(xp + c);
@@ -928,33 +944,35 @@ __global__ __launch_bounds__(256) void dconv_cout1_kernel(const u16* x, const u1
 // parameter-sized helpers: weight packing / gradient unpacking
 //  mode 0 forward:   out[tap][co (< Cout)][ci (< CinPad)]        = w[co][ci][tap]      (zero for ci >= Cin)
 //  mode 1 data grad: out[tap][ci (< CinPad)][co (< CoutPad)]     = w[co][ci][tap]      (zero rows / columns beyond Cin / Cout)
-//  mode 2 row mode (CinPad == 8): out[(kd,kh)][co][kw * 8 + ci]  = w[co][ci][(kd,kh,kw)], zero for k >= 24
+//  mode 2 row mode (CinPad == 8): out[(kd,kh)][co][kw * 8 + ci]  = w[co][ci][(kd,kh,kw)], zero for kw >= K (K = 3: k >= 24)
 __global__ __launch_bounds__(256) void dpack_kernel(const float* w, u16* out, int Cout, int Cin, int CoutPad, int CinPad, int mode, int fmt,
-                                                   long long total) {
+                                                   long long total, int K) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  const int K3 = K * K * K;
   float v = 0.f;
   if (mode == 0) {
     const int ci = (int)(i % CinPad); long long t = i / CinPad;
     const int co = (int)(t % Cout); const int tap = (int)(t / Cout);
-    if (ci < Cin) v = w[((long long)co * Cin + ci) * 27 + tap];
+    if (ci < Cin) v = w[((long long)co * Cin + ci) * K3 + tap];
   } else if (mode == 1) {
     const int co = (int)(i % CoutPad); long long t = i / CoutPad;
     const int ci = (int)(t % CinPad); const int tap = (int)(t / CinPad);
-    if (ci < Cin && co < Cout) v = w[((long long)co * Cin + ci) * 27 + tap];
+    if (ci < Cin && co < Cout) v = w[((long long)co * Cin + ci) * K3 + tap];
   } else {
     const int k = (int)(i % 32); long long t = i / 32;
     const int co = (int)(t % Cout); const int r9 = (int)(t / Cout);
     const int kw = k >> 3, ci = k & 7;
-    if (kw < 3 && ci < Cin) v = w[((long long)co * Cin + ci) * 27 + r9 * 3 + kw];
+    if (kw < K && ci < Cin) v = w[((long long)co * Cin + ci) * K3 + r9 * K + kw];
   }
   out[i] = fmt ? f2hf(v) : f2bf(v);
 }
 // dw_param[co][ci][tap] += dwp[tap][co (row stride CoutPad rows)][ci (< CinPad)]
-__global__ __launch_bounds__(256) void dunpack_kernel(const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad, long long total) {
+__global__ __launch_bounds__(256) void dunpack_kernel(const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad, long long total,
+                                                     int K3) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int tap = (int)(i % 27); long long t = i / 27;
+  const int tap = (int)(i % K3); long long t = i / K3;
   const int ci = (int)(t % Cin); const int co = (int)(t / Cin);
   dw[i] += dwp[((long long)tap * CoutPad + co) * CinPad + ci];
 }
@@ -1080,13 +1098,18 @@ __global__ __launch_bounds__(256) void cl_bwd_kernel(const u16* dy, const u16* x
 // host entry points
 // =================================================================================================================
 int g_dconv_kq = 2;        // xh_set_option(5, 1|2): K step of the discriminator's implicit GEMM in 32-channel quarters
-static void fill_taps(DTaps* t, int mode, int stride, int parity) {
+static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
   // mode 0 forward: all taps, source = j*stride + (t - 1);  mode 1 data gradient: stride 1: source = j + 1 - t;
-  // stride 2: destination o = 2j + parity; parity 0 -> tap 1 (source j), parity 1 -> taps 0 (source j + 1), 2 (source j)
-  if (mode == 0) { t->n = 3; for (int k = 0; k < 3; ++k) { t->t[k] = k; t->off[k] = k - 1; } return; }
-  if (stride == 1) { t->n = 3; for (int k = 0; k < 3; ++k) { t->t[k] = k; t->off[k] = 1 - k; } return; }
-  if (parity == 0) { t->n = 1; t->t[0] = 1; t->off[0] = 0; return; }
-  t->n = 2; t->t[0] = 0; t->off[0] = 1; t->t[1] = 2; t->off[1] = 0;
+  // stride 2: destination o = 2j + parity is reached from source s through tap t = o + 1 - 2s: the taps of parity 1 - parity,
+  // s = j + (parity + 1 - t) / 2.  K = 3: parity 0 -> tap 1 (source j), parity 1 -> taps 0 (j + 1), 2 (j);
+  // K = 4: parity 0 -> taps 1 (j), 3 (j - 1), parity 1 -> taps 0 (j + 1), 2 (j): two per axis for every class
+  t->n = 0;
+  for (int k = 0; k < K; ++k) {
+    if (mode == 1 && stride == 2 && (k & 1) == parity) continue;
+    t->t[t->n] = k;
+    t->off[t->n] = mode == 0 ? k - 1 : (stride == 1 ? 1 - k : (parity + 1 - k) / 2);
+    ++t->n;
+  }
 }
 
 // Tile shape per launch (xh_set_option(14, mask) switches the choices off one by one for A/B measurements):
@@ -1140,14 +1163,21 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   }
 }
 
-// Channels-last k=3, pad=1 convolution of the discriminator.  mode 0: forward (x: [N][Di..][Cs] -> y: [N][Do..][Cn],
-// Do = (Di - 1)/stride + 1); mode 1: data gradient (x = dY [N][Di..][Cs = Cout], y = dX [N][Do..][Cn = Cin_pad], Di = (Do-1)/stride+1).
-// w: weights packed by xh_dconv_pack (mode 0/2 for forward, 1 for the data gradient).  bias/red optional (forward).
-extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const void* x, const void* w, const float* bias, void* y,
+// Channels-last convolution of the discriminator, kernel size ks (3 or 4), padding 1.  mode 0: forward (x: [N][Di..][Cs] ->
+// y: [N][Do..][Cn], Do = (Di + 2 - ks)/stride + 1); mode 1: data gradient (x = dY [N][Di..][Cs = Cout], y = dX [N][Do..][Cn = Cin_pad],
+// Di = (Do + 2 - ks)/stride + 1).  w: weights packed by xh_dconv_pack (mode 0/2 for forward, 1 for the data gradient).
+// bias/red optional (forward).
+extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks, const void* x, const void* w, const float* bias, void* y,
                            double* red, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope) {
   if (!x || !w || !y || N <= 0 || N > 65535 || Cs <= 0 || Cn <= 0) return XH_ERR_ARG;
   if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
-  if (!(stride == 1 || stride == 2) || (mode != 0 && mode != 1)) return XH_ERR_ARG;
+  if (!(stride == 1 || stride == 2) || (mode != 0 && mode != 1) || (ks != 3 && ks != 4)) return XH_ERR_ARG;
+  {                                                       // extents must be those of a padding-1 convolution
+    const int bi[3] = {mode == 0 ? Di : Do, mode == 0 ? Hi : Ho, mode == 0 ? Wi : Wo};
+    const int sm[3] = {mode == 0 ? Do : Di, mode == 0 ? Ho : Hi, mode == 0 ? Wo : Wi};
+    for (int k = 0; k < 3; ++k)
+      if (bi[k] + 2 < ks || sm[k] != (bi[k] + 2 - ks) / stride + 1) return XH_ERR_ARG;
+  }
   const bool rowmode = mode == 0 && Cs == 8;
   if (!rowmode && (Cs % 32)) return XH_ERR_ARG;
   if (rowmode && stride != 1) return XH_ERR_ARG;
@@ -1155,14 +1185,14 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
   DConvK a;
   a.x = (const u16*)x; a.w = (const u16*)w; a.bias = bias; a.y = (u16*)y; a.red = red;
   a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn;
-  a.rowmode = rowmode ? 1 : 0; a.act = act; a.slope = slope;
+  a.rowmode = rowmode ? 1 : 0; a.act = act; a.slope = slope; a.K = ks;
   a.Kc = rowmode ? 32 : Cs;
   a.wtap_stride = Cn * a.Kc;
   if (mode == 0 && Cn == 1 && stride == 1 && !bias && !red && act == XH_ACT_NONE && !rowmode && (Cs % 8) == 0) {
     const long long waves = (long long)N * Do * Ho * Wo;
     const unsigned nb = (unsigned)((waves + 3) / 4);
-    if (dtype == XH_F16) hipLaunchKernelGGL(dconv_cout1_kernel<1>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
-    else hipLaunchKernelGGL(dconv_cout1_kernel<0>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs);
+    if (dtype == XH_F16) hipLaunchKernelGGL(dconv_cout1_kernel<1>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs, ks);
+    else hipLaunchKernelGGL(dconv_cout1_kernel<0>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs, ks);
     return xh_launch_status();
   }
   if (rowmode && Cn == 64 && !red && (act == XH_ACT_NONE || act == XH_ACT_LRELU) && !(g_dconv_cfg & 2048)) {
@@ -1172,8 +1202,13 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
     k.td = cdiv(Do, 4); k.th = cdiv(Ho, 4); k.tw = cdiv(Wo, 16);
     const long long nb = (long long)N * k.td * k.th * k.tw;
     if (nb < (1LL << 31)) {
-      if (dtype == XH_F16) hipLaunchKernelGGL(dconv_fwd_c8_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, k);
-      else hipLaunchKernelGGL(dconv_fwd_c8_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, k);
+      if (ks == 3) {
+        if (dtype == XH_F16) hipLaunchKernelGGL((dconv_fwd_c8_kernel<1, 3>), dim3((unsigned)nb), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((dconv_fwd_c8_kernel<0, 3>), dim3((unsigned)nb), dim3(256), 0, st, k);
+      } else {
+        if (dtype == XH_F16) hipLaunchKernelGGL((dconv_fwd_c8_kernel<1, 4>), dim3((unsigned)nb), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((dconv_fwd_c8_kernel<0, 4>), dim3((unsigned)nb), dim3(256), 0, st, k);
+      }
       return xh_launch_status();
     }
   }
@@ -1184,8 +1219,13 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
     k.td = cdiv(Do, 4); k.th = cdiv(Ho, 4); k.tw = cdiv(Wo, 16);
     const long long nb = (long long)N * k.td * k.th * k.tw;
     if (nb < (1LL << 31)) {
-      if (dtype == XH_F16) hipLaunchKernelGGL(dconv_dgrad_c8_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, k);
-      else hipLaunchKernelGGL(dconv_dgrad_c8_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, k);
+      if (ks == 3) {
+        if (dtype == XH_F16) hipLaunchKernelGGL((dconv_dgrad_c8_kernel<1, 3>), dim3((unsigned)nb), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((dconv_dgrad_c8_kernel<0, 3>), dim3((unsigned)nb), dim3(256), 0, st, k);
+      } else {
+        if (dtype == XH_F16) hipLaunchKernelGGL((dconv_dgrad_c8_kernel<1, 4>), dim3((unsigned)nb), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((dconv_dgrad_c8_kernel<0, 4>), dim3((unsigned)nb), dim3(256), 0, st, k);
+      }
       return xh_launch_status();
     }
   }
@@ -1205,7 +1245,7 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
     c.Jh = classes == 8 ? (Ho - ph + 1) / 2 : Ho;
     c.Jw = classes == 8 ? (Wo - pw + 1) / 2 : Wo;
     if (c.Jd <= 0 || c.Jh <= 0 || c.Jw <= 0) continue;
-    fill_taps(&c.td, mode, stride, pd); fill_taps(&c.th, mode, stride, ph); fill_taps(&c.tw, mode, stride, pw);
+    fill_taps(&c.td, mode, stride, pd, ks); fill_taps(&c.th, mode, stride, ph, ks); fill_taps(&c.tw, mode, stride, pw, ks);
     ++nc;
   }
   if (g_dconv_cfg & 1) {
@@ -1221,12 +1261,14 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, const 
   return xh_launch_status();
 }
 
-// dwp[tap][Cn][Cs] (fp32, caller zeroes) += sum over output voxels of dY[m][cn] * X[src][cs]
-extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void* x, const void* dy, float* dwp, int N, int Di, int Hi,
+// dwp[tap][Cn][Cs] (fp32, caller zeroes) += sum over output voxels of dY[m][cn] * X[src][cs];  ks^3 taps, padding 1
+extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, const void* x, const void* dy, float* dwp, int N, int Di, int Hi,
                                  int Wi, int Do, int Ho, int Wo, int Cs, int Cn) {
-  if (!x || !dy || !dwp || N <= 0 || (Cs % 8) || (Cn % 8)) return XH_ERR_ARG;
+  if (!x || !dy || !dwp || N <= 0 || (Cs % 8) || (Cn % 8) || (ks != 3 && ks != 4) || (stride != 1 && stride != 2)) return XH_ERR_ARG;
   if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
+  if (Do != (Di + 2 - ks) / stride + 1 || Ho != (Hi + 2 - ks) / stride + 1 || Wo != (Wi + 2 - ks) / stride + 1) return XH_ERR_ARG;
   DWgK a;
+  a.K = ks; a.ntap = ks * ks * ks; a.ntz = a.ntap;
   a.x = (const u16*)x; a.dy = (const u16*)dy; a.dw = dwp;
   a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn; a.stride = stride;
   a.M = (long long)N * Do * Ho * Wo;
@@ -1240,12 +1282,17 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void
     if (nt < (1LL << 30)) {
       k.ntile = (int)nt;
       const unsigned nwg = (unsigned)(nt < 512 ? nt : 512);
-      if (dtype == XH_F16) hipLaunchKernelGGL(dwgrad_c8_halo_kernel<1>, dim3(nwg), dim3(256), 0, st, k);
-      else hipLaunchKernelGGL(dwgrad_c8_halo_kernel<0>, dim3(nwg), dim3(256), 0, st, k);
+      if (ks == 3) {
+        if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_c8_halo_kernel<1, 3>), dim3(nwg), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((dwgrad_c8_halo_kernel<0, 3>), dim3(nwg), dim3(256), 0, st, k);
+      } else {                                            // the 64 taps in two halves (grid y)
+        if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_c8_halo_kernel<1, 4>), dim3(nwg, 2), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((dwgrad_c8_halo_kernel<0, 4>), dim3(nwg, 2), dim3(256), 0, st, k);
+      }
       return xh_launch_status();
     }
   }
-  if (Cs == 8) {                                          // first conv: the taps ride on the N axis
+  if (Cs == 8 && ks == 3) {                               // first conv: the taps ride on the N axis
     const int tiles = cdiv(Cn, 64);
     int msplit = cdiv(1024, tiles);
     const long long max_split = a.M / 256 > 0 ? a.M / 256 : 1;
@@ -1258,7 +1305,8 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void
   }
   const bool narrow = Cs <= 16;
   const bool pair = Cs == 64 && !(g_dconv_cfg & 16);
-  const int ntz = pair ? 14 : 27;
+  const int ntz = pair ? (a.ntap + 1) / 2 : a.ntap;
+  a.ntz = ntz;
   const int bn = narrow ? 16 : 128, bm = narrow ? 64 : 128;
   const int tiles = cdiv(Cs, bn) * cdiv(Cn, bm);
   int msplit = cdiv(1024, tiles * ntz);
@@ -1280,17 +1328,21 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, const void
   return xh_launch_status();
 }
 
-extern "C" int xh_dconv_pack(void* stream, int dtype, int mode, const float* w, void* out, int Cout, int Cin, int CoutPad, int CinPad) {
-  if (!w || !out || mode < 0 || mode > 2 || CoutPad < Cout || CinPad < Cin) return XH_ERR_ARG;
-  const long long total = mode == 2 ? 9LL * Cout * 32 : (mode == 0 ? 27LL * Cout * CinPad : 27LL * CinPad * CoutPad);
+extern "C" int xh_dconv_pack(void* stream, int dtype, int mode, int ks, const float* w, void* out, int Cout, int Cin, int CoutPad, int CinPad) {
+  if (!w || !out || mode < 0 || mode > 2 || CoutPad < Cout || CinPad < Cin || (ks != 3 && ks != 4)) return XH_ERR_ARG;
+  if (mode == 2 && CinPad != 8) return XH_ERR_ARG;
+  const long long k3 = (long long)ks * ks * ks;
+  const long long total = mode == 2 ? (long long)ks * ks * Cout * 32 : (mode == 0 ? k3 * Cout * CinPad : k3 * CinPad * CoutPad);
   hipLaunchKernelGGL(dpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u16*)out, Cout, Cin, CoutPad,
-                     CinPad, mode, dtype == XH_F16 ? 1 : 0, total);
+                     CinPad, mode, dtype == XH_F16 ? 1 : 0, total, ks);
   return xh_launch_status();
 }
-extern "C" int xh_dconv_unpack_grad(void* stream, const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad) {
-  if (!dwp || !dw || CoutPad < Cout || CinPad < Cin) return XH_ERR_ARG;
-  const long long total = 27LL * Cout * Cin;
-  hipLaunchKernelGGL(dunpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dwp, dw, Cout, Cin, CoutPad, CinPad, total);
+extern "C" int xh_dconv_unpack_grad(void* stream, int ks, const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad) {
+  if (!dwp || !dw || CoutPad < Cout || CinPad < Cin || (ks != 3 && ks != 4)) return XH_ERR_ARG;
+  const int k3 = ks * ks * ks;
+  const long long total = (long long)k3 * Cout * Cin;
+  hipLaunchKernelGGL(dunpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dwp, dw, Cout, Cin, CoutPad, CinPad,
+                     total, k3);
   return xh_launch_status();
 }
 

@@ -13,9 +13,9 @@ What is specific to this implementation:
     and all parameters / gradients fp32; with fp16 storage the loss is scaled by `loss_scale` (GradScaler's initial 65536,
     train.py:207) and the fp32 gradients are unscaled before the optimizer -- the bookkeeping of GradScaler without its
     per-step host synchronisation (inf check), which `check_finite()` offers on demand;
-  * the Discriminator (RA_HVED.py:204-236) is xlstm_hved_amd.Discriminator (csrc/dconv.hip: channels-last implicit-GEMM
-    convolutions on the matrix cores) for the 16-bit storage modes; the fp32 parity mode takes the stock-module
-    DiscriminatorReference (the HIP discriminator is 16-bit only), which then runs in fp32.
+  * the Discriminator (RA_HVED.py:204-236; train.py:146 builds it with ks=4) is xlstm_hved_amd.Discriminator
+    (csrc/dconv.hip: channels-last implicit-GEMM convolutions on the matrix cores) in every storage mode; its activations
+    are 16-bit like under the reference's autocast, so with fp32 storage it takes its input in fp16 (disc.py).
 """
 import torch
 
@@ -38,13 +38,7 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------------
     def _disc(self, t):
-        from .disc import Discriminator
-        if isinstance(self.disc, Discriminator):
-            return self.disc(t)                           # HIP path: 16-bit storage in, fp32 arithmetic inside
-        if self.storage == torch.float32:
-            return self.disc(t.float())
-        with torch.autocast("cuda", dtype=self.storage):  # stock modules (DiscriminatorReference)
-            return self.disc(t)
+        return self.disc(t)                               # HIP path: 16-bit activations, fp32 arithmetic inside (disc.py)
 
     def generator_forward(self, x, mask, subset_index_list, eps_lists=None):
         """Returns (loss, parts dict, tensors the discriminator step reuses)."""
