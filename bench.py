@@ -47,8 +47,8 @@ MODE_PARITY = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1)
@@ -59,13 +59,13 @@ def parse():
                     help="initialise RCCL and issue the gradient all-reduce even with one rank (exercises the N>1 code path)")
     ap.add_argument("--extras", action="store_true", help="also time forward-only and the shared-encoder two-forward step")
     ap.add_argument("--no-modes", action="store_true", help="skip timing the other storage modes")
+    ap.add_argument("--no-trainstep", action="store_true", help="skip timing the whole training step (train.py:208-296)")
     ap.add_argument("--wgrad-overlap", action="store_true",
                     help="launch the weight-gradient kernels on a second HIP stream (measured on MI355X: no gain, 9.88-10.7 ms "
                          "vs 9.96 ms -- the hipGraph's cross-stream dependencies cost what the overlap saves; off by default)")
     ap.add_argument("--no-wgrad-defer", action="store_true",
                     help="launch every weight gradient where backward reaches it instead of batching them at the end of backward")
     ap.add_argument("--wgrad-batch", type=int, default=12, help="weight-gradient calls forked to the side stream per batch")
-    ap.add_argument("--level-streams", action="store_true", help="run the coarse per-level latent chains on side streams (experiment)")
     ap.add_argument("--wgrad-flush-streams", type=int, default=1,
                     help="HIP streams the deferred weight-gradient flush deals its independent problems to (ops.set_wgrad_flush_streams)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the N=1 run
@@ -199,7 +199,6 @@ def main():
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
     grads = X.parallel.FlatGrads(params)                       # p.grad = views of one flat fp32 bucket
     ops.set_wgrad_flush_streams(args.wgrad_flush_streams)
-    ops.set_level_streams(args.level_streams)
     ops.set_wgrad_overlap(args.wgrad_overlap, args.wgrad_batch)
     ops.set_wgrad_defer(not args.no_wgrad_defer and not args.wgrad_overlap)   # weight gradients batched at the end of backward           # weight gradients on a second HIP stream, joined once per step
 
@@ -302,12 +301,50 @@ def main():
     # GPU to idle inside a bracket (the batched weight-gradient bracket read 369 us next to the CPU leg, 282 us under rocprof)
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline_pass(compute, ops, min(args.steps, 5), dtype)      # rank-local: no collective inside
+    if rank == 0 and world == 1 and not args.no_trainstep:
+        # the whole training step, LAST: TrainStep re-points the generator's .grad at its own bucket
+        try:
+            out.update(train_step_leg(model, x, max(6, min(args.steps, 30))))
+        except Exception as e:                                  # must not cost the headline line
+            out["train_step_error"] = repr(e)[:200]
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         import torch.distributed as dist
         dist.barrier()                                          # rank 0 arrives after its roofline pass
         dist.destroy_process_group()
+
+
+def train_step_leg(model, x, nsteps):
+    """the reference's whole optimisation step (train.py:208-296 without the optimizer updates) -- two
+    shared-encoder generator forwards, the HIP loss epilogues, three passes of the ks=4 Discriminator of train.py:146 (csrc/dconv.hip
+    implicit GEMMs on the matrix cores) and both backward passes -- captured ONCE into a hipGraph and replayed with a different
+    modality subset every step (train.py:222-223), the subset entering as a device mask."""
+    import xlstm_hved_amd as X
+    from xlstm_hved_amd.train_step import TrainStep
+    torch.manual_seed(2)
+    disc = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2])            # train.py:146
+    disc.apply(X.init_weights)
+    disc = disc.to(x.device)
+    ts = TrainStep(model, disc, storage=x.dtype)
+    mask = (torch.rand(x.shape[0], 3, *x.shape[2:], device=x.device) > 0.7).float()
+    xf = x.float()
+    ts.capture(xf, mask)
+    subsets = [[3], [6], [12], [0], [9], [13], [14]]
+    for i in range(3):
+        ts.replay(xf, mask, subsets[i % len(subsets)], update=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(nsteps):
+        ts.replay(xf, mask, subsets[i % len(subsets)], update=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / nsteps * 1e3
+    gflop_d = 561.4 * x.shape[0] * (x.shape[2] / 128.0) ** 3       # one ks=4 discriminator forward (tools/microbench_disc.py)
+    return {"train_step_graph_ms": ms,
+            "train_step_note": ("train.py:208-296 without the optimizer updates, ONE captured hipGraph replayed with a new modality "
+                                f"subset per step: 2 generator forwards (shared encoder) + Dice/MSE/KLD/LSGAN epilogues + 3 passes of "
+                                f"Discriminator(in_channels=7, ks=4, strides=[1,2,2,2]) (~{gflop_d:.0f} GFLOP per forward pass) + both "
+                                f"backward passes; {nsteps} replays timed, subset mask and inputs rewritten before each")}
 
 
 def time_graph(fn, nsteps, warmup=3, thread_local=False):
@@ -380,9 +417,10 @@ def extras(model, x, grads, nsteps):
         disc = disc.to(x.device)
         ts = TrainStep(model, disc, storage=x.dtype)
         mask = (torch.rand(x.shape[0], 3, *x.shape[2:], device=x.device) > 0.7).float()
+        keep6 = ts.keep_mask([6], x.shape[0])
 
         def train_step():
-            ts.compute(x, mask, [6])
+            ts.compute(x, mask, keep6)
         for _ in range(2):
             train_step()
         torch.cuda.synchronize()
@@ -519,13 +557,24 @@ def roofline_pass(step, ops, nsteps, dtype):
             orig_flush()
             e1.record()
             records.append((ops.last_conv_kernel(), e0, e1, m[1], m[2], m[3], 1))
-    # calibrate the spin kernel's tick rate, then use a bounded ~60 ms delay per step
+    # The device-side delay a step is queued behind keeps the WHOLE chip busy (a stream of HBM-bound element-wise passes over a
+    # 256 MB buffer, like the step itself): behind a one-thread spin kernel (torch.cuda._sleep) the GPU sits idle for tens of
+    # milliseconds, power management lowers the clocks, and the first brackets of the step read up to 1.8x long (measured:
+    # 48 us instead of 27 for the dominant conv instance, run to run).
+    junk = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+    for _ in range(5):
+        junk.add_(1.0)
     c0, c1 = ev(), ev()
     c0.record()
-    torch.cuda._sleep(1_000_000)
+    for _ in range(50):
+        junk.add_(1.0)
     c1.record()
     torch.cuda.synchronize()
-    ticks_per_ms = 1_000_000 / max(c0.elapsed_time(c1), 1e-3)
+    pass_ms = max(c0.elapsed_time(c1) / 50.0, 1e-3)
+
+    def gpu_delay(ms):
+        for _ in range(max(1, int(ms / pass_ms))):
+            junk.add_(1.0)
     # the delay must outlast the host's enqueue time of one instrumented step (else the GPU catches up and a bracket
     # also spans host launch latency): time one instrumented enqueue, then wait 1.5x that (+20 ms), at most 600 ms
     ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
@@ -538,10 +587,9 @@ def roofline_pass(step, ops, nsteps, dtype):
         ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
     records.clear()
     delay_ms = min(2.0 * host_ms + 30.0, 600.0)
-    delay = int(delay_ms * ticks_per_ms)
     # an event pair costs a few microseconds of its own (two marker packets): measure empty brackets under the same
     # queued conditions and subtract their median from every bracket
-    torch.cuda._sleep(delay)
+    gpu_delay(delay_ms)
     empties = []
     for _ in range(200):
         e0, e1 = ev(), ev()
@@ -553,7 +601,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
     try:
         for _ in range(nsteps):
-            torch.cuda._sleep(delay)
+            gpu_delay(delay_ms)
             step()
         torch.cuda.synchronize()
     finally:

@@ -103,7 +103,17 @@ typedef struct {
    * backward), replacing a separate xh_norm_finalize launch.  A call that cannot take the MFMA path returns an error. */
   const double* fin_red; float* fin_mean; float* fin_rstd; long long fin_count;
   int ws_packed;                              /* 1: ws already holds this conv's fragments (xh_conv3d_prepack): no pack launch */
+  /* Optional statistics fan-in workspace (epi != 0): xh_fanin_bytes() bytes, 128-byte aligned, ZERO on entry; the launch
+   * leaves it zero again.  With it, launches of >= 256 workgroups per (sample, channel block) sum their epilogue statistics
+   * through a two-level tree in this block instead of same-cache-line atomics on red[] (csrc/fanin.h).  The block is the only
+   * state such a launch shares with others: launches that may run CONCURRENTLY (different streams, parallel branches of one
+   * graph) must be given different blocks; launches ordered on one stream may share one.  NULL / too small: direct atomics. */
+  void* fan; long long fan_bytes;
 } xh_conv_ptrs;
+
+/* Size in bytes of a statistics fan-in workspace (xh_conv_ptrs.fan).  The library allocates no device memory and keeps no
+ * device state of its own: every buffer, this one included, belongs to the caller. */
+long long xh_fanin_bytes(void);
 
 /* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv
  * (transposed=1).  Reference: F.conv3d as used throughout RA_HVED.py:510-648. */

@@ -259,6 +259,48 @@ def test_fp32_full_size_128_vs_oracle(cfg):
             check(sdm[k].float().cpu(), sd[k].float(), 1e-4, k)
 
 
+def test_fp32_full_size_128_backward_vs_oracle():
+    """The benchmarked step itself (BASELINE config 2: 1x4x128^3, train mode, loss of SURVEY 8(d)) forward AND backward in fp32
+    storage against the CPU oracle: every parameter gradient at the full-size instances of the norm-backward, gate-backward,
+    upsample-adjoint and conv data/weight-gradient kernels.  Bounds of the 32^3 golden test: 5e-3 of the largest gradient per
+    tensor; additionally the relative L2 over all gradients."""
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    torch.manual_seed(21)
+    x = torch.rand(1, 4, 128, 128, 128)
+    eps = [torch.randn(1, 2 ** l, 64 >> l, 64 >> l, 64 >> l) for l in range(4)]
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in _weights().items()}
+    prob_o, _, mu_o, lv_o, rec_o = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True)
+    O.bench_loss(prob_o, mu_o, lv_o, rec_o).backward()
+    gref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    m = _model(True)
+    seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps)
+    loss = seg.float().mean() + rec[0].float().mean()
+    for a_, b_ in zip(mu, lv):
+        loss = loss + a_.float().mean() + b_.float().mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    gscale = max(v.abs().max().item() for v in gref.values())
+    worst, wname, num, den, n_checked = 0.0, "", 0.0, 0.0, 0
+    for k, p_ in m.named_parameters():
+        if k.startswith("init_blocks."):
+            continue                                  # mathematically zero gradient behind an InstanceNorm
+        kk = k.replace("decoders.", "srdecoder.sdecoders.", 1) if k.startswith("decoders.") else k
+        if kk not in gref:
+            assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k
+            continue
+        g = p_.grad.cpu()
+        e = (g - gref[kk]).abs().max().item() / gscale
+        if e > worst:
+            worst, wname = e, k
+        num += ((g - gref[kk]) ** 2).sum().item()
+        den += (gref[kk] ** 2).sum().item()
+        n_checked += 1
+    l2 = (num / den) ** 0.5
+    print(f"fp32 128^3 backward vs oracle: {n_checked} parameter gradients, worst {worst:.2e} of the largest ({wname}), relative L2 {l2:.2e}")
+    assert n_checked > 250
+    assert worst < 5e-3 and l2 < 5e-3, (worst, wname, l2)
+
+
 def test_fp32_vs_oracle_64_batch2_train_random_subset():
     torch.manual_seed(9)
     w = _weights()

@@ -191,3 +191,56 @@ def test_batched_discriminator_step_and_weight_image_cache():
     assert not D._SCOPE["cache"]
     torch.cuda.synchronize()
     assert (y2 - 2.0 * y1).abs().max().item() <= 2e-2 * y1.abs().max().item() + 1e-6
+
+
+def test_one_captured_graph_serves_every_subset():
+    """train.py:222-225 draws a new modality subset every step: ONE captured hipGraph of TrainStep.compute must serve them
+    all (the subset enters as a device mask the step overwrites before the replay) and reproduce the eager step."""
+    x, mask, eps = _inputs()
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(load("weights_seed1"), strict=True)
+    m = m.to(DEV).train()
+    ts = TrainStep(m, _disc().to(DEV), alpha=ALPHA, beta=BETA, storage=torch.bfloat16)
+    xd, md = x.to(DEV), mask.to(DEV)
+    eps_dev = [[e.to(DEV) for e in el] for el in eps]
+    ts.capture(torch.zeros_like(xd), torch.zeros_like(md), eps_lists=eps_dev)     # captured on other inputs and subset 14
+    seen = []
+    for subset in ([3], [6], [12]):
+        got = ts.replay(xd, md, subset, eps_lists=eps_dev, update=False)
+        g_graph = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in got.items()}
+        gg, gd = ts.grads.flat.clone(), ts.grads_d.flat.clone()
+        want = ts.compute(xd, md, subset, eps_lists=eps_dev)
+        torch.cuda.synchronize()
+        for k in ("dice", "m_dice", "recon", "kld", "g_gan", "loss", "loss_d"):
+            a, b = g_graph[k].item(), want[k].item()
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (subset, k, a, b)
+        # same kernels, same inputs: only the order of the fp32 atomics in the weight-gradient kernels differs
+        assert (gg - ts.grads.flat).abs().max().item() <= 2e-3 * ts.grads.flat.abs().max().item(), subset
+        assert (gd - ts.grads_d.flat).abs().max().item() <= 2e-3 * ts.grads_d.flat.abs().max().item(), subset
+        seen.append(g_graph["m_dice"].item())
+    assert len({round(v, 6) for v in seen}) == 3          # the three subsets really gave three different steps
+
+
+def test_loss_scale_bookkeeping_follows_gradscaler():
+    """fp16 storage: the scale lives on the device (a captured graph follows it), halves after a step with non-finite gradients
+    -- skipping only the optimizer whose gradients overflowed -- and doubles after `growth_interval` clean steps."""
+    x, mask, _ = _inputs()
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(load("weights_seed1"), strict=True)
+    m = m.to(DEV).train()
+    d = _disc().to(DEV)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-6)
+    opt_d = torch.optim.SGD(d.parameters(), lr=1e-6)
+    ts = TrainStep(m, d, opt, opt_d, storage=torch.float16, growth_interval=4)
+    assert ts.loss_scale == 65536.0
+    ts.set_loss_scale(1024.0)                              # (at 65536 this randomly initialised step overflows on its own)
+    w_g, w_d = m.final_conv.weight.detach().clone(), d.last.weight.detach().clone()
+    parts = ts.compute(x.to(DEV), mask.to(DEV), [5])
+    ts.grads_d.flat[0] = float("inf")                      # an overflow in the discriminator's pass only
+    parts = ts._update(parts)
+    assert parts["skipped"] == ["discriminator"] and ts.loss_scale == 512.0
+    assert not torch.equal(w_g, m.final_conv.weight.detach()) and torch.equal(w_d, d.last.weight.detach())
+    for _ in range(2):                                     # 2 steps x 2 update() calls = 4 clean ones: the scale grows back
+        parts = ts.step(x.to(DEV), mask.to(DEV), [5])
+        assert "skipped" not in parts
+    assert ts.loss_scale == 1024.0

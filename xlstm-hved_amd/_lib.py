@@ -34,6 +34,7 @@ class ConvPtrs(C.Structure):
         ("xa", vp), ("xb", vp), ("w", vp * 4), ("b", vp * 4), ("pre_sc", vp), ("pre_sh", vp), ("y", vp),
         ("ea", vp), ("eb", vp), ("e_sc", vp), ("e_sh", vp), ("red", vp), ("ws", vp), ("ws_bytes", ll),
         ("fin_red", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_count", ll), ("ws_packed", C.c_int),
+        ("fan", vp), ("fan_bytes", ll),
     ]
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "xh_set_option": (I, [I, I]),
     "xh_last_conv_kernel": (C.c_char_p, []),
     "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
+    "xh_fanin_bytes": (ll, []),
     "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_prepack": (I, [vp, I, vp, vp]),
     "xh_conv3d_wgrad_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),

@@ -1085,17 +1085,12 @@ static int check_desc(const xh_conv_desc* d, const xh_conv_ptrs* p) {
   return XH_OK;
 }
 
-// The statistics fan-in arena (fanin.h): zero when the code object is loaded, left zero by every launch that uses it.
-__device__ unsigned char g_fan_arena[(size_t)FAN_SLOTS * FAN_UNITS * FAN_UNIT_BYTES];
-unsigned char* xh_fan_block(long long units, long long wgs) {
+// The statistics fan-in block (fanin.h) is the caller's (xh_conv_ptrs.fan): zero on entry, left zero by the launch.
+extern "C" long long xh_fanin_bytes(void) { return FAN_BLOCK_BYTES; }
+unsigned char* xh_fan_block(void* fan, long long fan_bytes, long long units, long long wgs) {
+  if (!fan || fan_bytes < FAN_BLOCK_BYTES || ((unsigned long long)fan & 127)) return nullptr;
   if (units < 1 || units > FAN_UNITS || wgs < FAN_MIN_WGS || (g_xh_disable & 64)) return nullptr;
-  static unsigned char* base[16] = {nullptr};
-  static int slot = 0;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_fan_arena)) != hipSuccess) return nullptr;
-  slot = (slot + 1) % FAN_SLOTS;
-  return base[dev] + (size_t)slot * FAN_UNITS * FAN_UNIT_BYTES;
+  return (unsigned char*)fan;
 }
 
 static ConvK make_k(const xh_conv_desc* d, const xh_conv_ptrs* p, int cob, int txn) {
@@ -1166,7 +1161,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     if (vec && cin_g >= 16 && cout_g >= 2 && gx1 * a.ncob * d->N * d->groups < 128) {
       a = make_k(d, p, 2, 8);
       dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
-      if (d->epi) a.fan = xh_fan_block((long long)grid.y * grid.z, grid.x);
+      if (d->epi) a.fan = xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x);
       xh_note_kernel("conv1x1_kernel<%s, 2, true, 16>", tname<T>());
       hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16>), grid, dim3(256), 0, (hipStream_t)stream, a);
       return xh_launch_status();
@@ -1174,7 +1169,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     const long long cap1 = cdiv(g_c1_cap > 0 ? g_c1_cap : 2048, a.ncob * d->N * d->groups);
     if (gx1 > cap1) gx1 = cap1;
     dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
-    if (d->epi) a.fan = xh_fan_block((long long)grid.y * grid.z, grid.x);
+    if (d->epi) a.fan = xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x);
 #define L1(COB)                                                                                                  \
   do {                                                                                                           \
     xh_note_kernel("conv1x1_kernel<%s, %d, %s>", tname<T>(), COB, vec ? "true" : "false");                       \
@@ -1205,7 +1200,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
         const int sd = cdiv(d->D, dsegs);
         dsegs = cdiv(d->D, sd);
         dim3 grid(a.tilesW * a.tilesH * dsegs, d->Cin, d->N);
-        if (d->epi) a.fan = xh_fan_block((long long)grid.y * grid.z, grid.x);
+        if (d->epi) a.fan = xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x);
         xh_note_kernel("conv_dw3_slide_kernel<%s, %d>", tname<T>(), txn);
         switch (txn) {
           case 4: hipLaunchKernelGGL((conv_dw3_slide_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, a, sd); break;

@@ -476,7 +476,7 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   const int ny = (d->groups / gs) * a.ntile;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(a.tilesW * a.tilesH * a.dsegs, ny, d->N);
-  a.fan = (d->epi && a.nsplit == 1) ? xh_fan_block((long long)grid.y * grid.z, grid.x) : nullptr;
+  a.fan = (d->epi && a.nsplit == 1) ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
   const size_t shm = (size_t)4 * (a.th + 2) * (a.tw + 4) * a.cinp * 2 + (size_t)8 * 32 * sizeof(double);
   // 8-wave workgroups hide the per-plane serial chain better on small volumes; 4-wave ones win on 128^3-class volumes
   const bool big = (long long)d->Do * d->Ho * d->Wo >= (1 << 20);

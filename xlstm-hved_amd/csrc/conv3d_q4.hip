@@ -437,7 +437,7 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
     xh_launch_pack_single(st, pj);
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
-  a.fan = d->epi ? xh_fan_block((long long)grid.y * grid.z, grid.x) : nullptr;
+  a.fan = d->epi ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
   const size_t shm = TILE_BYTES + 48 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
   const bool act = a.act_slope != 1.f;
   xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false");

@@ -3,17 +3,16 @@
 // A kernel whose every workgroup ends with one fp64 atomicAdd per value on red[n][c][..] puts 512 .. 4096 atomic requests
 // on ONE cache line; device-scope atomics on a line are retired one after the other at the memory side (measured: 8 .. 50 ns
 // each, i.e. 8 us of a 22 us conv launch, 12 us of a 25 us 1x1 launch, whatever the volume holds).  Here a workgroup adds its
-// values into one of FAN_REP replicas of the unit's sums (a line of its own each, in a library-owned device arena), counts
+// values into one of FAN_REP replicas of the unit's sums (a line of its own each, in a caller-provided workspace), counts
 // itself in on the replica's counter; the workgroup that completes a replica counts the replica in on the unit's top counter;
 // the workgroup that completes the top counter collects the replicas by atomic exchange -- which also leaves every word zero
 // for the next launch -- and gets the unit totals back to add them to red[] itself.  Every access to the arena is a RETURNING
 // device-scope atomic executed at the memory side: a contributor's adds have returned before it counts itself in, and the
 // collector never reads through a cache (the L2s of the 8 XCDs are not coherent with each other).
 //
-// Unit = the set of workgroups that sum into the same values (one (sample, channel block) of a launch).  A launch takes one
-// slot of the arena (round robin, xh_fan_block); launches that share a stream never overlap, launches on different streams
-// would have to collide on a slot AND run concurrently to disturb each other -- the library issues epilogue statistics on the
-// caller's one compute stream only.
+// Unit = the set of workgroups that sum into the same values (one (sample, channel block) of a launch).  The block is the
+// CALLER's (xh_conv_ptrs.fan, xh_fanin_bytes() bytes, zero on entry, left zero): the library owns no device memory.  Launches
+// ordered on one stream never overlap and may share a block; launches that can run concurrently need a block each.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,11 +21,11 @@ constexpr int FAN_NV = 32;                          // values per unit (fp64), a
 constexpr int FAN_STRIDE = FAN_NV * 8 + 128;        // bytes per replica: payload, then its counter on a line of its own
 constexpr int FAN_UNIT_BYTES = (FAN_REP + 1) * FAN_STRIDE;
 constexpr int FAN_UNITS = 64;                       // units per launch, at most (else the kernel keeps its direct atomics)
-constexpr int FAN_SLOTS = 8;
 constexpr int FAN_MIN_WGS = 256;                    // fewer workgroups per unit: direct atomics are cheaper
+constexpr long long FAN_BLOCK_BYTES = (long long)FAN_UNITS * FAN_UNIT_BYTES;
 
-// host: arena block for a launch with `units` units of `wgs` workgroups each, or nullptr (direct atomics)
-unsigned char* xh_fan_block(long long units, long long wgs);
+// host: the caller's fan-in block for a launch with `units` units of `wgs` workgroups each, or nullptr (direct atomics)
+unsigned char* xh_fan_block(void* fan, long long fan_bytes, long long units, long long wgs);
 
 // Device side.  Call from ALL threads of the workgroup (contains barriers); s_tot[0..NV) holds this workgroup's values
 // (LDS, written before the call, no barrier needed in between), s_flag is one LDS word.  Returns true in exactly one

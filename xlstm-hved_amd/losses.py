@@ -114,6 +114,8 @@ _KEEP = {}
 def compute_KLD(mu_list, logvar_list, subset_index_list=(14,), choices=(0, 1, 2, 3)):
     """loss.py:85-115 on the (B, 5, L, d, h, w) stacks the model returns per level: for every subset index in the list,
     KL(PoE(prior + subset) || prior), averaged over the list."""
+    if torch.is_tensor(subset_index_list):           # an (N, 4) device keep mask (TrainStep under a captured graph)
+        return _KLD.apply(mu_list, logvar_list, subset_index_list.contiguous())
     total = None
     for idx in subset_index_list:
         key = (int(idx), mu_list.shape[0], mu_list.device)

@@ -192,6 +192,12 @@ class AbstractFusion3DUNet(nn.Module):
 
     def _keep_mask(self, x, subset_idx_list, instance_missing, drop):
         n = x.shape[0]
+        if torch.is_tensor(subset_idx_list):
+            # a device-resident (N, 4) keep mask instead of a subset index (not in the reference signature): the form a captured
+            # hipGraph needs, since train.py:222-223 draws a new subset every step and a mask baked at capture would freeze it
+            if instance_missing or tuple(subset_idx_list.shape) != (n, 4) or subset_idx_list.dtype != torch.float32:
+                raise ValueError("a subset mask is an (N, 4) float32 tensor and excludes instance_missing")
+            return subset_idx_list.to(x.device).contiguous()
         if instance_missing:
             if drop is None:
                 drop = x.float().sum((2, 3, 4)) == 0                                       # RA_HVED.py:515
@@ -297,36 +303,20 @@ class AbstractFusion3DUNet(nn.Module):
             for s_, k in zip(shapes, sizes):
                 noise.append(flat[o:o + k].view(s_))
                 o += k
-        # The four per-level chains (PoE -> VU block -> upsample -> conv block) are independent of each other.  With
-        # ops.set_level_streams(True) the three coarse ones run on side streams next to the finest one (fork / join on the caller's
-        # stream, capturable).  Measured SLOWER (5.96 -> 6.93 ms per step): an experiment switch, off by default.
-        side = ops.level_streams(x.device, len(feat_list) - 1) if x.is_cuda else None
-        main = torch.cuda.current_stream() if side else None
-        if side:
-            fork = torch.cuda.Event()
-            fork.record(main)
-        big = max(range(len(feat_list)), key=lambda l: feat_list[l].shape[2:].numel())
+        # The four per-level chains (PoE -> VU block -> upsample -> conv block) are independent of each other.  Running the three
+        # coarse ones on side streams inside the captured graph was measured SLOWER (5.96 -> 6.93 ms per step, DESIGN.md
+        # section 7) and the switch has been removed; they run back to back on the caller's stream.
         outs = [None] * len(feat_list)
-        k_side = 0
         for level, feat in enumerate(feat_list):
             L_ = self.MVAE_latents[level]
             eps = None
             if not valid:
                 eps = noise[level] if noise is not None else eps_list[level].to(device=x.device, dtype=x.dtype).contiguous()
-            st = None
-            if side and level != big:
-                st = side[k_side]
-                k_side += 1
-                st.wait_event(fork)
-            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
-                z, mu, lv = Fn.PoE.apply(feat, keep, eps, L_, bool(instance_missing))
-                z = self.VU_blocks[level](z)                                                # RA_HVED.py:599
-                z = Fn.Upsample.apply(z, tuple(2 * s for s in z.shape[2:]))                 # RA_HVED.py:600-601
-                z = self.conv_blocks[level](z)                                              # RA_HVED.py:603
+            z, mu, lv = Fn.PoE.apply(feat, keep, eps, L_, bool(instance_missing))
+            z = self.VU_blocks[level](z)                                                    # RA_HVED.py:599
+            z = Fn.Upsample.apply(z, tuple(2 * s for s in z.shape[2:]))                     # RA_HVED.py:600-601
+            z = self.conv_blocks[level](z)                                                  # RA_HVED.py:603
             outs[level] = (z, mu, lv)
-        if side:
-            for st in side[:k_side]:
-                main.wait_stream(st)
         for z, mu, lv in outs:
             mu_list.append(mu)
             logvar_list.append(lv)

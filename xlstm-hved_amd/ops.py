@@ -127,13 +127,17 @@ def red_arena_reset(device):
     start of the network's forward().  The high-water mark (largest extent ever handed out, captures included) rather than
     the current offset: a hipGraph replay dirties the extent it had at capture time without moving the Python-side
     offset, so a smaller eager pass in between must not shrink what the next reset clears."""
+    # Under stream capture the WHOLE arena is zeroed: the captured fill must cover every slice the captured step will
+    # dirty, and the high-water mark only knows what ran before (a step captured without a preceding eager pass of the same
+    # shape would otherwise leave stale sums / gradients for replays 2..N).
+    whole = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
     a = _ARENA.get(device)
-    if a is not None and a[2] > 0:
-        a[0][:a[2]].zero_()
+    if a is not None and (a[2] > 0 or whole):
+        (a[0] if whole else a[0][:a[2]]).zero_()
         a[1] = 0
     b = _ARENA32.get(device)
-    if b is not None and b[2] > 0:
-        b[0][:b[2]].zero_()
+    if b is not None and (b[2] > 0 or whole):
+        (b[0] if whole else b[0][:b[2]]).zero_()
         b[1] = 0
 
 
@@ -141,23 +145,30 @@ def zeros_red(t, n, c):
     return zeros_f64(t.device, (n, c, 2))
 
 
-# side streams for the independent per-level chains of the network's latent path (model._decode); off by default
-_LEVEL_STREAMS = {"on": False, "streams": {}}
+# Statistics fan-in workspaces (xh_conv_ptrs.fan, csrc/fanin.h): the library owns no device memory, so the zero-initialised
+# block a statistics-producing launch sums through is handed in here -- one per (device, stream): launches ordered on a
+# stream never overlap and share it, launches on different streams get different blocks.  While a stream is being captured
+# the device's capture block is used (a captured step is one chain of launches; a block must exist before the capture starts,
+# which any eager launch on the device guarantees -- otherwise the launch simply keeps its direct atomics).
+_FAN = {}
 
 
-def set_level_streams(enabled):
-    _LEVEL_STREAMS["on"] = bool(enabled)
-
-
-def level_streams(device, n):
-    """n side streams of `device` (created once), or None when the feature is off."""
-    if not _LEVEL_STREAMS["on"] or n <= 0:
-        return None
-    key = (device.index if device.index is not None else torch.cuda.current_device())
-    have = _LEVEL_STREAMS["streams"].setdefault(key, [])
-    while len(have) < n:
-        have.append(torch.cuda.Stream(device=device))
-    return have[:n]
+def fan_block(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    per = _FAN.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if per is None:
+        if capturing:
+            return None, 0
+        nbytes = int(L.load().xh_fanin_bytes())
+        per = _FAN[key] = {"bytes": nbytes, "capture": torch.zeros(nbytes, dtype=torch.uint8, device=device), "streams": {}}
+    if capturing:
+        return per["capture"].data_ptr(), per["bytes"]
+    sid = torch.cuda.current_stream(device).cuda_stream
+    blk = per["streams"].get(sid)
+    if blk is None:
+        blk = per["streams"][sid] = torch.zeros(per["bytes"], dtype=torch.uint8, device=device)
+    return blk.data_ptr(), per["bytes"]
 
 
 # ------------------------------------------------------------------------------------- weight fragments
@@ -173,10 +184,16 @@ _PACK_STATE = {"epoch": 0, "arrays": None, "enabled": True}
 
 
 class _PackEntry:
-    __slots__ = ("refs", "ws", "desc", "ptrs", "epoch", "versions", "keep")
+    __slots__ = ("refs", "ws", "desc", "ptrs", "epoch", "versions", "keep", "dptrs")
 
     def alive(self):
-        return all(r() is not None for r in self.refs)
+        """The weight tensors still exist AND still own the storage whose addresses the entry recorded (model.to() /
+        .half() / `p.data = ...` replace the storage under a surviving Parameter: the raw pointers would dangle)."""
+        for r, dp in zip(self.refs, self.dptrs):
+            t = r()
+            if t is None or t.data_ptr() != dp:
+                return False
+        return True
 
 
 def set_prepack(enabled):
@@ -195,6 +212,7 @@ def _pack_entry(weights, desc, need, device):
     import weakref
     e = _PackEntry()
     e.refs = [weakref.ref(w) for w in weights]
+    e.dptrs = [w.data_ptr() for w in weights]
     e.ws = torch.empty(need, dtype=torch.uint8, device=device)
     e.desc = L.ConvDesc.from_buffer_copy(desc)
     e.ptrs = L.ConvPtrs()
@@ -313,6 +331,8 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
         ptrs.e_sc, ptrs.e_sh = _p(_f32(e[2], "e_sc")), _p(_f32(e[3], "e_sh"))
     if red is not None:
         ptrs.red = _p(red)
+        if epi:
+            ptrs.fan, ptrs.fan_bytes = fan_block(xa.device)
     need = lib.xh_conv3d_workspace_bytes(C.byref(desc)) if _MFMA[0] else 0
     if need and _PACK_STATE["enabled"]:
         ent = _pack_entry(weights, desc, need, xa.device)
@@ -362,6 +382,7 @@ def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None)
         desc.eb_bs = _vol(eb)[5] if eb is not None else 0
         desc.e_slope = float(e[4])
         ptrs.ea, ptrs.eb, ptrs.e_sc, ptrs.e_sh, ptrs.red = _p(ea), _p(eb), _p(e[2]), _p(e[3]), _p(red)
+        ptrs.fan, ptrs.fan_bytes = fan_block(dy.device)
     L.check(lib.xh_conv3d_dgrad_s2(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_dgrad_s2")
     return out
 

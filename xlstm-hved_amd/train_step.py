@@ -10,9 +10,13 @@ What is specific to this implementation:
     path: model.forward_shared) -- their mu / logvar stacks are bit-identical in the reference too;
   * every loss term is a HIP reduction (losses.py), the upstream gradients stay on the device;
   * AMP policy: activations in `storage` (fp16 like the reference's autocast, bf16, or fp32), fp32 arithmetic, the ViL block
-    and all parameters / gradients fp32; with fp16 storage the loss is scaled by `loss_scale` (GradScaler's initial 65536,
-    train.py:207) and the fp32 gradients are unscaled before the optimizer -- the bookkeeping of GradScaler without its
-    per-step host synchronisation (inf check), which `check_finite()` offers on demand;
+    and all parameters / gradients fp32; with fp16 storage the loss is scaled by a DEVICE-resident loss scale (GradScaler's
+    initial 65536, train.py:207) and the fp32 gradients are unscaled before the optimizer.  `step()` keeps GradScaler's
+    books (train.py:265-268,283-285): each optimizer is skipped on its own when its gradients are not finite, the scale is
+    halved after a skipped step and doubled after `growth_interval` (2000) clean ones; because the scale is a device scalar a
+    captured hipGraph follows every update;
+  * the modality subset (train.py:222-223 draws a new one every step) enters as a DEVICE mask (N, 4) that `step()` /
+    `replay()` overwrite before the launch: ONE captured hipGraph serves all 15 subsets (`capture()`);
   * the Discriminator (RA_HVED.py:204-236; train.py:146 builds it with ks=4) is xlstm_hved_amd.Discriminator
     (csrc/dconv.hip: channels-last implicit-GEMM convolutions on the matrix cores) in every storage mode; its activations
     are 16-bit like under the reference's autocast, so with fp32 storage it takes its input in fp16 (disc.py).
@@ -23,27 +27,58 @@ from . import losses, ops
 from .parallel import FlatGrads
 
 
+SUBSET_ROWS = None
+
+
+def subset_rows(device):
+    """(15, 4) table: row k = which modalities SUBSETS_MODALITIES[k] keeps (RA_HVED.py:733-738)."""
+    from .model import SUBSETS_MODALITIES
+    return torch.tensor([[1.0 if m in sub else 0.0 for m in range(4)] for sub in SUBSETS_MODALITIES], dtype=torch.float32, device=device)
+
+
 class TrainStep:
     def __init__(self, model, disc, optimizer=None, optimizer_d=None, alpha=0.1, beta=0.2, storage=torch.bfloat16,
-                 loss_scale=None, shared_encoder=True):
+                 loss_scale=None, shared_encoder=True, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         self.model, self.disc = model, disc
         self.optimizer, self.optimizer_d = optimizer, optimizer_d
         self.alpha, self.beta = float(alpha), float(beta)
         self.storage = storage
-        self.loss_scale = float(loss_scale if loss_scale is not None else (65536.0 if storage == torch.float16 else 1.0))
         self.shared_encoder = shared_encoder
         self.dice, self.gan = losses.DiceLoss(), losses.GANLoss()
         self.grads = FlatGrads(model.parameters())             # p.grad = views of one flat fp32 bucket (one fill, one all-reduce)
         self.grads_d = FlatGrads(disc.parameters())
+        dev = self.grads.flat.device
+        # GradScaler's state (torch/amp/grad_scaler.py semantics; the reference re-creates it per epoch at 65536, train.py:207)
+        init = float(loss_scale if loss_scale is not None else (65536.0 if storage == torch.float16 else 1.0))
+        self.scaling = init != 1.0
+        self._scale = torch.full((1,), init, dtype=torch.float32, device=dev)      # device scalar: captured graphs follow it
+        self._inv_scale = torch.full((1,), 1.0 / init, dtype=torch.float32, device=dev)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self._clean_steps = 0
+        self._rows = subset_rows(dev)
+        self._graph = None
+
+    @property
+    def loss_scale(self):
+        return float(self._scale.item())
+
+    def set_loss_scale(self, v):
+        self._scale.fill_(float(v))
+        self._inv_scale.fill_(1.0 / float(v))
 
     # ------------------------------------------------------------------------------------------------
     def _disc(self, t):
         return self.disc(t)                               # HIP path: 16-bit activations, fp32 arithmetic inside (disc.py)
 
-    def generator_forward(self, x, mask, subset_index_list, eps_lists=None):
-        """Returns (loss, parts dict, tensors the discriminator step reuses)."""
+    def keep_mask(self, subset_index_list, n):
+        """(n, 4) device mask of a subset index (the model takes subset_idx_list[0], RA_HVED.py:517-520)."""
+        return self._rows[int(subset_index_list[0])].unsqueeze(0).repeat(n, 1).contiguous()
+
+    def generator_forward(self, x, mask, subset, eps_lists=None):
+        """subset: a list of subset indices like the reference's `subset_index_list`, or an (N, 4) device mask (the form a
+        captured graph uses).  Returns (loss, parts dict, tensors the discriminator step reuses)."""
         xs = x.to(self.storage)
-        calls = [dict(subset_idx_list=[14]), dict(subset_idx_list=list(subset_index_list))]
+        calls = [dict(subset_idx_list=[14]), dict(subset_idx_list=subset if torch.is_tensor(subset) else list(subset))]
         if eps_lists is not None:
             calls[0]["eps_list"], calls[1]["eps_list"] = eps_lists
         if self.shared_encoder:
@@ -58,7 +93,7 @@ class TrainStep:
         recon = losses.mse_loss(m_rec, x)
         kld = None
         for level in range(len(mu)):                                             # train.py:235-239
-            k = losses.compute_KLD(mu[level], lv[level], subset_index_list)
+            k = losses.compute_KLD(mu[level], lv[level], subset)
             kld = k if kld is None else kld + k
         kld = kld / len(mu)
         atten_f_x = losses.nested_attention(f_out, f_rec.detach())              # train.py:242-259
@@ -93,23 +128,23 @@ class TrainStep:
         return self.alpha * (loss_d_fake + loss_d_real) * 0.5                    # train.py:280
 
     # ------------------------------------------------------------------------------------------------
-    def compute(self, x, mask, subset_index_list, eps_lists=None):
+    def compute(self, x, mask, subset, eps_lists=None):
         """Both backward passes of the step (no optimizer): generator gradients in self.grads, discriminator gradients
-        in self.grads_d (unscaled fp32).  Capturable into a hipGraph when the inputs are device resident."""
+        in self.grads_d (unscaled fp32).  Capturable into a hipGraph when the inputs are device resident and `subset` is a
+        device mask (keep_mask()): nothing of the subset or of the loss scale is baked into the capture."""
         from .disc import pack_scope
-        s = self.loss_scale
         self.grads.zero()
         self.grads_d.zero()
         with pack_scope():                                   # the discriminator's weight images are built once for both passes
-            loss, parts, (fake, real, f_out) = self.generator_forward(x, mask, subset_index_list, eps_lists)
-            (loss * s if s != 1.0 else loss).backward()
+            loss, parts, (fake, real, f_out) = self.generator_forward(x, mask, subset, eps_lists)
+            (loss * self._scale[0] if self.scaling else loss).backward()
             ops.join_wgrad_stream()
-            if s != 1.0:
-                self.grads.flat.mul_(1.0 / s)
+            if self.scaling:
+                self.grads.flat.mul_(self._inv_scale)
             loss_d = self.discriminator_forward(fake, real)
-            (loss_d * s if s != 1.0 else loss_d).backward()
-            if s != 1.0:
-                self.grads_d.flat.mul_(1.0 / s)
+            (loss_d * self._scale[0] if self.scaling else loss_d).backward()
+            if self.scaling:
+                self.grads_d.flat.mul_(self._inv_scale)
         parts["loss"], parts["loss_d"], parts["f_out"] = loss.detach(), loss_d.detach(), f_out
         return parts
 
@@ -117,16 +152,66 @@ class TrainStep:
         """GradScaler's overflow check on demand (one host synchronisation): True when every gradient is finite."""
         return bool(torch.isfinite(self.grads.flat).all() and torch.isfinite(self.grads_d.flat).all())
 
-    def step(self, x, mask, subset_index_list):
-        """compute() + the two optimizer steps (train.py:264-268,282-285).  With fp16 storage a non-finite gradient skips
-        both steps and halves the loss scale, like GradScaler."""
-        parts = self.compute(x, mask, subset_index_list)
-        if self.loss_scale != 1.0 and not self.check_finite():
-            self.loss_scale *= 0.5
-            parts["skipped"] = True
-            return parts
-        if self.optimizer is not None:
+    def _update(self, parts):
+        """The two optimizer steps + GradScaler.update() (train.py:264-268,282-285)."""
+        if self.scaling:
+            ok = torch.stack([torch.isfinite(self.grads.flat).all(), torch.isfinite(self.grads_d.flat).all()]).tolist()   # one sync
+        else:
+            ok = [True, True]
+        if ok[0] and self.optimizer is not None:
             self.optimizer.step()
-        if self.optimizer_d is not None:
+        if ok[1] and self.optimizer_d is not None:
             self.optimizer_d.step()
+        if self.scaling:
+            # the reference calls scaler.update() after each scaler.step(): a skipped step backs the scale off once, a clean
+            # step counts towards growth.  The second update() of a step sees the found-inf of the discriminator's pass only.
+            for fin in ok:
+                if not fin:
+                    self.set_loss_scale(self.loss_scale * self.backoff_factor)
+                    self._clean_steps = 0
+                else:
+                    self._clean_steps += 1
+                    if self._clean_steps >= self.growth_interval:
+                        self.set_loss_scale(self.loss_scale * self.growth_factor)
+                        self._clean_steps = 0
+        if not all(ok):
+            parts["skipped"] = [name for name, fin in zip(("generator", "discriminator"), ok) if not fin]
         return parts
+
+    def step(self, x, mask, subset_index_list, eps_lists=None):
+        """compute() + the two optimizer steps (train.py:264-268,282-285), eager."""
+        return self._update(self.compute(x, mask, subset_index_list, eps_lists))
+
+    # ------------------------------------------------------------------------------------------------
+    def capture(self, x, mask, eps_lists=None, warmup=2):
+        """Captures compute() ONCE into a hipGraph on static copies of (x, mask, subset mask[, eps]); `replay()` then serves
+        every subset: it overwrites the static buffers and launches the graph (train.py:222-225 draws a new subset per
+        step -- no re-capture, no per-subset graphs)."""
+        self._sx, self._smask = x.detach().clone(), mask.detach().clone()
+        self._skeep = self.keep_mask([14], x.shape[0])
+        self._seps = None if eps_lists is None else [[e.detach().clone() for e in el] for el in eps_lists]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                        # warm-up on a side stream (allocator pools, weight packs, arenas)
+            for _ in range(warmup):
+                self.compute(self._sx, self._smask, self._skeep, self._seps)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._parts = self.compute(self._sx, self._smask, self._skeep, self._seps)
+        return self
+
+    def replay(self, x, mask, subset_index_list, eps_lists=None, update=True):
+        """One training step through the captured graph (capture() first).  Returns the static `parts` tensors."""
+        if self._graph is None:
+            raise RuntimeError("TrainStep.capture() has not been called")
+        self._sx.copy_(x)
+        self._smask.copy_(mask)
+        self._skeep.copy_(self.keep_mask(subset_index_list, self._sx.shape[0]))
+        if self._seps is not None and eps_lists is not None:
+            for dst_l, src_l in zip(self._seps, eps_lists):
+                for d_, s_ in zip(dst_l, src_l):
+                    d_.copy_(s_)
+        self._graph.replay()
+        return self._update(dict(self._parts)) if update else dict(self._parts)
