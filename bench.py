@@ -101,7 +101,7 @@ def cpu_baseline(size, batch, budget_s=60.0, sweep=(8, 16, 32, 64)):
         eps = [torch.randn(batch, 2 ** l, s >> (l + 1), s >> (l + 1), s >> (l + 1), generator=g) for l in range(4)]
         sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
         t0 = time.perf_counter()
-        prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True)
+        prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True, reference_cost=True)
         O.bench_loss(prob, mu, lv, rec).backward()
         return time.perf_counter() - t0
     small = min(size, 64)

@@ -393,6 +393,15 @@ int xh_kld_bwd(void* stream, int dtype, const void* mu_stack, const void* lv_sta
 int xh_nested_weight(void* stream, int dtype, const void* seg, long long seg_bs, void* w, long long w_bs, int N, long long DHW);
 /* out[0..n) = v (* gscale[0] when given) in the storage type (constant upstream gradients of mean-type losses). */
 int xh_fill(void* stream, int dtype, void* out, long long n, float v, const float* gscale);
+/* Multi-tensor forms (at most XH_MULTI_MAX tensors of ONE storage type per launch; host arrays, read during the call):
+ * xh_multi_sum: red[(row0[t] + b % rows[t]) * 6 + 4] += partial sums of tensor t (fp64; the slot layout of xh_pair_sums, so
+ * xh_loss_finalize kind 4 turns the rows into sum_t w_t * sum(t)); rows[t] spreads a large tensor's workgroups over several
+ * accumulator rows (at most 64 adders each).  xh_multi_fill: tensor t = values[t] (* gscale[0] when given).
+ * Reference use: the SURVEY 8(d) benchmark loss seg.mean() + rec.mean() + sum_l (mu_l.mean() + logvar_l.mean()). */
+#define XH_MULTI_MAX 16
+int xh_multi_sum(void* stream, int dtype, int nt, const void* const* ptrs, const long long* numels, const int* row0, const int* rows,
+                 double* red);
+int xh_multi_fill(void* stream, int dtype, int nt, void* const* ptrs, const long long* numels, const float* values, const float* gscale);
 
 /* ------------------------------------------------------------------------------------------------
  * Discriminator (RA_HVED.py:204-236, buildingblocks.py:342-358): convolutions 7 -> 64 -> 128 -> 256 -> 512 -> 1 with kernel
@@ -405,9 +414,13 @@ int xh_fill(void* stream, int dtype, void* out, long long n, float v, const floa
  * 7-channel input: weights packed with mode 2).  bias [Cn] optional; act XH_ACT_NONE / XH_ACT_LRELU(slope); red optional:
  * red[n][cn][0..1] += (sum y, sum y^2) of the stored output (InstanceNorm statistics).
  * mode 1 data gradient: x = dY [N][Di..][Cs = Cout(_pad)], y = dX [N][Do..][Cn = Cin(_pad)], Di = (Do+2-ks)/stride+1, weights
- * packed with mode 1; bias / red / act unused. */
+ * packed with mode 1; bias / act unused.
+ * mask (optional, [N][Do..][Cn] like y): the result is multiplied by (mask > 0 ? 1 : slope) before it is rounded, stored and
+ * summed into red -- the LeakyReLU backward of the layer below (mask = its stored activation; leaky keeps the sign) fused into
+ * the data gradient, with red[..][0] then carrying that layer's bias gradient. */
 int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks, const void* x, const void* w, const float* bias, void* y,
-                double* red, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope);
+                double* red, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope,
+                const void* mask);
 /* dwp[ks^3][Cn][Cs] (fp32, caller zeroes) += sum over output voxels m of dY[m][cn] * X[src(m, tap)][cs]; x = the forward input
  * [N][Di..][Cs], dy [N][Do..][Cn]; Cs, Cn multiples of 8. */
 int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, const void* x, const void* dy, float* dwp, int N, int Di, int Hi,

@@ -307,7 +307,7 @@ def vil_layer(p, x, recurrent=False):
 # ----------------------------------------------------------------------------------------------
 def xlstm_hved_forward(sd, x, subset_idx=14, instance_missing=False, drop=None, seg=True, recon=True,
                        eps_list=None, training=True, mid_vil=True, skip_return=True, levels=4,
-                       recurrent_mlstm=False, taps=None, order="ilc", seg_recon_decoder=True):
+                       recurrent_mlstm=False, taps=None, order="ilc", seg_recon_decoder=True, reference_cost=False):
     """RA_HVED.py:510-648 AbstractFusion3DUNet.forward for the XLSTM_HVED flag set
     (RA_HVED.py:945-958: skip_return, mid_ViL, seg_recon_decoder, MVAE, MVAE_reduction, 'ilc').
 
@@ -316,6 +316,10 @@ def xlstm_hved_forward(sd, x, subset_idx=14, instance_missing=False, drop=None, 
     eps_list  per-level N(0,1) draws for the reparameterisation (RA_HVED.py:744); None == valid=True.
     training  BatchNorm mode (model.train()/eval()); independent of eps_list/valid like the reference.
     taps      optional dict that receives named intermediates (for per-stage golden vectors).
+    reference_cost  True: evaluate the skip-return attention once PER MODALITY STREAM on the identical input, exactly as the
+              reference does (RA_HVED.py:548-552: 4 x 15 convolutions per level instead of 15) -- the same numbers and the
+              same BatchNorm buffer updates, the reference's arithmetic cost.  bench.py's cpu_baseline leg times this form
+              (the restatement's wall time must match the reference's, tools/calibrate_cpu_baseline.py).
     Returns (seg_prob, seg_logits, mu_list, logvar_list, recon).
     """
     p = P(sd)
@@ -329,7 +333,10 @@ def xlstm_hved_forward(sd, x, subset_idx=14, instance_missing=False, drop=None, 
     mu_list, logvar_list, feats = [], [], []
     skip = None
     for level in range(levels):
-        if skip_return and skip is not None:
+        if skip_return and skip is not None and reference_cost:
+            x_list = [skip_return_attention(p.sub(f"skr_att.{levels - level}"), skip, training, momentum_steps=1) * xi + xi
+                      for xi in x_list]                                             # RA_HVED.py:548-552, stream by stream
+        elif skip_return and skip is not None:
             a = skip_return_attention(p.sub(f"skr_att.{levels - level}"), skip, training)   # skr_att[-level]
             tap(f"skr_att.{level}", a)
             x_list = [a * xi + xi for xi in x_list]                                 # RA_HVED.py:552

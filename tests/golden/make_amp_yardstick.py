@@ -71,5 +71,36 @@ with torch.no_grad():
                 print(name, dn, mode, entry[f"{dn}.{mode}"], flush=True)
         UX.ViLLayer.forward = _orig_vil
         res["cases"][name] = entry
+# ---- the same yardstick on TRAINED-LIKE weights and smooth inputs (tests/golden/make_trained_like.py, tests/synth_blobs.py):
+# the randomly initialised network above amplifies any rounding ~1e4x; a network that has seen a few hundred
+# optimisation steps on smooth data is the fairer picture of what a 16-bit mode costs in use
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth_blobs as SB  # noqa: E402
+tl = os.path.join(HERE, "weights_trained_like.npz")
+if os.path.exists(tl):
+    z = np.load(tl)
+    model.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files}, strict=True)
+    model.eval()
+    tcases = {"trained_like_64_blob7_subset14_eval": (7, 64, 14), "trained_like_64_blob7_subset5_eval": (7, 64, 5),
+              "trained_like_128_blob8_subset14_eval": (8, 128, 14)}
+    with torch.no_grad():
+        for name, (seed, s, k) in tcases.items():
+            x, _ = SB.blob_case(seed, 1, s)
+            if k != 14:
+                keep = O.SUBSETS_MODALITIES[k]
+                for c in range(4):
+                    if c not in keep:
+                        x[:, c] = 0                            # evaluation.py:305-307: dropped modalities are zeroed
+            ref = model(x, [k], recon=True, valid=True)
+            entry = {}
+            for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                UX.ViLLayer.forward = _vil_fp32
+                with torch.autocast("cpu", dtype=dt):
+                    out = model(x, [k], recon=True, valid=True)
+                entry[f"{dn}.vil_fp32"] = metrics(out, ref)
+                print(name, dn, entry[f"{dn}.vil_fp32"], flush=True)
+            UX.ViLLayer.forward = _orig_vil
+            entry["positive_fraction"] = [(ref[0][:, c] > 0.5).float().mean().item() for c in range(3)]
+            res["cases"][name] = entry
 with open(os.path.join(HERE, "amp_yardstick.json"), "w") as f:
     json.dump(res, f, indent=1)

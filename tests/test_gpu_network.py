@@ -188,6 +188,54 @@ def test_16bit_storage_vs_oracle_within_reference_amp_deviation(case, mode):
         assert l2 <= 0.25 * ref16["seg_rel_l2"] and d <= 0.25 * ref16["dice_dev"], (l2, d)
 
 
+TRAINED_CASES = {"trained_like_64_blob7_subset14_eval": (7, 64, 14), "trained_like_64_blob7_subset5_eval": (7, 64, 5),
+                 "trained_like_128_blob8_subset14_eval": (8, 128, 14)}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", sorted(TRAINED_CASES))
+def test_storage_modes_on_trained_like_weights(case, mode):
+    """The storage modes on weights that are NOT a random initialisation: the REAL reference trained for 300 CPU steps on smooth
+    synthetic patches (tests/golden/make_trained_like.py -> weights_trained_like.npz; inputs from tests/synth_blobs.py), eval mode,
+    posterior mean, against the fp32 CPU oracle, next to the reference's own autocast deviation on the same weights and inputs
+    (amp_yardstick.json).  north_star's "Dice within 1e-4" is asserted for fp32 storage; for the 16-bit modes the measured
+    deviation is held below the reference's own AMP deviation of the same dtype and reported."""
+    import synth_blobs as SB
+    seed, size, subset = TRAINED_CASES[case]
+    ys = _yardstick()[case]
+    x, _ = SB.blob_case(seed, 1, size)
+    if subset != 14:
+        for c in range(4):
+            if c not in X.SUBSETS_MODALITIES[subset]:
+                x[:, c] = 0                                   # evaluation.py:305-307
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    w = load("weights_trained_like")
+    sd = {k: v.clone() for k, v in w.items()}
+    with torch.no_grad():
+        prob_o, _, _, _, rec_o = O.xlstm_hved_forward(sd, x, subset, eps_list=None, training=False)
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(w, strict=True)
+    m = m.to(DEV).eval()
+    dt = dict(STORAGE, fp32=torch.float32)[mode]
+    with torch.no_grad():
+        seg, _, rec = m(x.to(DEV, dt), [subset], recon=True, valid=True)
+    seg, rec = seg.float().cpu(), rec[0].float().cpu()
+    l2 = ((seg - prob_o).norm() / prob_o.norm()).item()
+    r2 = ((rec - rec_o).norm() / rec_o.norm()).item()
+    tgt = (prob_o > 0.5).float()
+    d = (_dice(seg, tgt) - 1.0).abs().max().item()
+    flips = int(((seg > 0.5) != (prob_o > 0.5)).sum())
+    pos = [float((prob_o[:, c] > 0.5).float().mean()) for c in range(3)]
+    ref = ys.get(f"{mode}.vil_fp32")
+    print(f"trained-like {case} {mode} storage: seg rel L2 {l2:.3e}, recon rel L2 {r2:.3e}, Dice dev {d:.3e}, mask flips {flips}/{seg.numel()} "
+          f"(positive fractions {pos[0]:.3f}/{pos[1]:.3f}/{pos[2]:.3f})"
+          + (f"; reference {mode}-AMP: seg {ref['seg_rel_l2']:.3e}, Dice dev {ref['dice_dev']:.3e}, flips {ref['mask_flips']}" if ref else ""))
+    if mode == "fp32":
+        assert (seg - prob_o).abs().max().item() < 5e-3 and d < 1e-4, (d,)
+    else:
+        assert d <= max(1e-3, ref["dice_dev"]) and l2 <= max(2e-3, 2 * ref["seg_rel_l2"]), (d, l2, ref)
+
+
 def test_fp16_backward_with_loss_scaling_matches_fp32_gradients():
     """fp16 storage in backward needs the caller's loss scaling, exactly like the reference's GradScaler
     (train.py:207,265-268): activation gradients of a mean() loss at 64^3 are ~1e-7 and vanish in fp16 unscaled.  With

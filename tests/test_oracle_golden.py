@@ -265,3 +265,21 @@ def test_discriminator_matches_reference(ks, tag, dt, tol):
         scale = max(ref.double().abs().max().item(), 1e-30)
         assert (gr[DC.sample_index(gr.numel())].double() - ref.double()).abs().max().item() <= tol * 10 * max(scale, 1.0), k
         assert abs(gr.double().sum().item() - float(g[f"{tag}.gsum.{k}"])) <= tol * 10 * max(float(g[f"{tag}.gabs.{k}"]), 1.0), k
+
+
+def test_reference_cost_mode_is_the_same_function():
+    """reference_cost=True re-evaluates the skip-return attention once per modality stream like RA_HVED.py:548-552 (what
+    bench.py's cpu_baseline leg times): same outputs, same BatchNorm buffers (four momentum steps either way)."""
+    g = load("net32_train_subset14")
+    eps = [g[f"eps{i}"] for i in range(4)]
+    outs, bufs = [], []
+    for rc in (False, True):
+        sd = {k: v.clone() for k, v in _weights(torch.float32).items()}
+        with torch.no_grad():
+            prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, g["x"], 14, eps_list=eps, training=True, reference_cost=rc)
+        outs.append((prob, rec, mu[3]))
+        bufs.append({k: v for k, v in sd.items() if "running" in k or "num_batches" in k})
+    for a, b in zip(outs[0], outs[1]):
+        close(b, a, 1e-6, "reference_cost output")
+    for k, v in bufs[0].items():
+        close(bufs[1][k].double(), v.double(), 1e-6, k)

@@ -15,7 +15,12 @@ d = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2]); d.apply(X.init_w
 x = torch.rand(1, 4, 128, 128, 128, device="cuda").bfloat16()
 mask = (torch.rand(1, 3, 128, 128, 128, device="cuda") > 0.7).float()
 ts = TrainStep(m, d, storage=torch.bfloat16)
-for _ in range(n):
-    ts.compute(x, mask, [6])
+if "--graph" in sys.argv:                      # the captured step replayed with a new subset each time (what bench.py times)
+    ts.capture(x.float(), mask)
+    for i in range(n):
+        ts.replay(x.float(), mask, [[3], [6], [12]][i % 3], update=False)
+else:
+    for _ in range(n):
+        ts.compute(x, mask, [6])
 torch.cuda.synchronize()
 print("steps", n)

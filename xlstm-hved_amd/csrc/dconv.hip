@@ -45,6 +45,9 @@ struct DClass {
 
 struct DConvK {
   const u16* x; const u16* w; const float* bias; u16* y; double* red;
+  const u16* mask;         // optional, [N][Do..][Cn] like y: the result is multiplied by leaky'(mask) = (mask > 0 ? 1 : slope) before
+                           // it is rounded, stored and summed -- the LeakyReLU backward of the layer below, fused into this
+                           // data gradient's epilogue (the separate pass read and wrote the 64-channel 127^3 tensor once more)
   int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn;
   int omul;
   int smul;                // source index = j * smul + off[tap]
@@ -271,6 +274,18 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] + b4[j][r];
         if (a.act == XH_ACT_LRELU) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+      }
+      if (a.mask && ok) {
+        if (vec_ok && cn + 4 <= a.Cn) {
+          const uint2 mm = *reinterpret_cast<const uint2*>(a.mask + vox * a.Cn + cn);
+          if (!(cvt_lo<FMT>(mm.x) > 0.f)) v[0] *= a.slope;
+          if (!(cvt_hi<FMT>(mm.x) > 0.f)) v[1] *= a.slope;
+          if (!(cvt_lo<FMT>(mm.y) > 0.f)) v[2] *= a.slope;
+          if (!(cvt_hi<FMT>(mm.y) > 0.f)) v[3] *= a.slope;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (cn + e < a.Cn && !(cvt_in<FMT>(a.mask[vox * a.Cn + cn + e]) > 0.f)) v[e] *= a.slope;
+        }
       }
       const unsigned q0 = cvt_pack<FMT>(v[0], v[1]), q1 = cvt_pack<FMT>(v[2], v[3]);
       if (a.red && ok) {                                  // sums of the ROUNDED values: what the next layer normalises
@@ -1168,7 +1183,8 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
 // Di = (Do + 2 - ks)/stride + 1).  w: weights packed by xh_dconv_pack (mode 0/2 for forward, 1 for the data gradient).
 // bias/red optional (forward).
 extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks, const void* x, const void* w, const float* bias, void* y,
-                           double* red, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope) {
+                           double* red, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int Cs, int Cn, int act, float slope,
+                           const void* mask) {
   if (!x || !w || !y || N <= 0 || N > 65535 || Cs <= 0 || Cn <= 0) return XH_ERR_ARG;
   if (dtype != XH_BF16 && dtype != XH_F16) return XH_ERR_DTYPE;
   if (!(stride == 1 || stride == 2) || (mode != 0 && mode != 1) || (ks != 3 && ks != 4)) return XH_ERR_ARG;
@@ -1183,19 +1199,19 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
   if (rowmode && stride != 1) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   DConvK a;
-  a.x = (const u16*)x; a.w = (const u16*)w; a.bias = bias; a.y = (u16*)y; a.red = red;
+  a.x = (const u16*)x; a.w = (const u16*)w; a.bias = bias; a.y = (u16*)y; a.red = red; a.mask = (const u16*)mask;
   a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn;
   a.rowmode = rowmode ? 1 : 0; a.act = act; a.slope = slope; a.K = ks;
   a.Kc = rowmode ? 32 : Cs;
   a.wtap_stride = Cn * a.Kc;
-  if (mode == 0 && Cn == 1 && stride == 1 && !bias && !red && act == XH_ACT_NONE && !rowmode && (Cs % 8) == 0) {
+  if (mode == 0 && Cn == 1 && stride == 1 && !bias && !red && !mask && act == XH_ACT_NONE && !rowmode && (Cs % 8) == 0) {
     const long long waves = (long long)N * Do * Ho * Wo;
     const unsigned nb = (unsigned)((waves + 3) / 4);
     if (dtype == XH_F16) hipLaunchKernelGGL(dconv_cout1_kernel<1>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs, ks);
     else hipLaunchKernelGGL(dconv_cout1_kernel<0>, dim3(nb), dim3(256), 0, st, (const u16*)x, (const u16*)w, (u16*)y, N, Do, Ho, Wo, Cs, ks);
     return xh_launch_status();
   }
-  if (rowmode && Cn == 64 && !red && (act == XH_ACT_NONE || act == XH_ACT_LRELU) && !(g_dconv_cfg & 2048)) {
+  if (rowmode && Cn == 64 && !red && !mask && (act == XH_ACT_NONE || act == XH_ACT_LRELU) && !(g_dconv_cfg & 2048)) {
     DFw8K k;
     k.x = (const u16*)x; k.w = (const u16*)w; k.bias = bias; k.y = (u16*)y;
     k.N = N; k.D = Do; k.H = Ho; k.W = Wo; k.act = act; k.slope = slope;
@@ -1212,7 +1228,7 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
       return xh_launch_status();
     }
   }
-  if (mode == 1 && stride == 1 && Cs == 64 && Cn == 8 && !bias && !red && act == XH_ACT_NONE && !(g_dconv_cfg & 1024)) {
+  if (mode == 1 && stride == 1 && Cs == 64 && Cn == 8 && !bias && !red && !mask && act == XH_ACT_NONE && !(g_dconv_cfg & 1024)) {
     DDg8K k;
     k.g = (const u16*)x; k.w = (const u16*)w; k.dx = (u16*)y;
     k.N = N; k.D = Do; k.H = Ho; k.W = Wo;

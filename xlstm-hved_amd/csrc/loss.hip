@@ -306,6 +306,108 @@ __global__ __launch_bounds__(256) void fill_kernel(T* out, long long n, float v,
     for (long long k = i; k < n; ++k) stf(out, k, v);
   }
 }
+// ------------------------------------------------------------------------------------------------ multi-tensor passes
+// A loss that is a sum over MANY tensors (the SURVEY 8(d) benchmark loss: seg, recon and the eight latent stacks) costs one
+// reduction launch and one gradient-fill launch PER tensor when done tensor by tensor -- twenty launches of which sixteen are
+// small enough to be pure launch latency (~5 us each in a replayed graph).  Here the tensors of one dtype travel in ONE
+// launch: the job table rides in the kernel arguments, a workgroup finds its tensor from a prefix of workgroup counts.
+struct XhMulti {
+  const void* p[XH_MULTI_MAX];
+  long long n[XH_MULTI_MAX];
+  float v[XH_MULTI_MAX];         // multi_fill: the value;  multi_sum: unused
+  int row0[XH_MULTI_MAX];        // multi_sum: first row of red[] this tensor adds to
+  int rows[XH_MULTI_MAX];        //            ... and how many rows it spreads its workgroups over (<= 64 adders per row)
+  int wg0[XH_MULTI_MAX + 1];     // prefix of workgroup counts
+  int nt;
+};
+// red[(row0[t] + b % rows[t]) * 6 + 4] += sum of workgroup b's chunk of tensor t   (slot 4 = "sum a" of xh_pair_sums' layout,
+// so xh_loss_finalize kind 4 serves both)
+template <typename T>
+__global__ __launch_bounds__(LS_BLOCK) void multi_sum_kernel(const XhMulti m, double* red) {
+  __shared__ double s_red[4];
+  int t = 0;
+  for (int k = 1; k < m.nt; ++k)
+    if ((int)blockIdx.x >= m.wg0[k]) t = k;
+  const int b = blockIdx.x - m.wg0[t], nb = m.wg0[t + 1] - m.wg0[t];
+  const T* p = (const T*)m.p[t];
+  const long long n = m.n[t];
+  const long long per = ((n + nb - 1) / nb + LS_BLOCK * 4 - 1) / (LS_BLOCK * 4) * (LS_BLOCK * 4);
+  const long long q_end = min(n, (long long)(b + 1) * per);
+  const bool vec = (n % 4 == 0) && (((unsigned long long)p & (4 * sizeof(T) - 1)) == 0);
+  double s[1] = {0.0};
+  for (long long q = (long long)b * per + threadIdx.x * 4; q < q_end; q += LS_BLOCK * 4) {
+    const int valid = (int)min(4LL, n - q);
+    float av[4];
+    if (vec) ld4any<true>(p, q, valid, av); else ld4any<false>(p, q, valid, av);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < valid) acc += av[i];
+    s[0] += (double)acc;
+  }
+  block_sum_d<1>(s, s_red, LS_BLOCK >> 6);
+  if (threadIdx.x == 0) atomicAdd(&red[(long long)(m.row0[t] + b % m.rows[t]) * 6 + 4], s_red[0]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void multi_fill_kernel(const XhMulti m, const float* gs) {
+  int t = 0;
+  for (int k = 1; k < m.nt; ++k)
+    if ((int)blockIdx.x >= m.wg0[k]) t = k;
+  const int b = blockIdx.x - m.wg0[t], nb = m.wg0[t + 1] - m.wg0[t];
+  T* out = (T*)const_cast<void*>(m.p[t]);
+  const long long n = m.n[t];
+  float v = m.v[t];
+  if (gs) v *= gs[0];
+  const bool vec = ((unsigned long long)out & (4 * sizeof(T) - 1)) == 0;
+  const float o[4] = {v, v, v, v};
+  for (long long i = ((long long)b * 256 + threadIdx.x) * 4; i < n; i += (long long)nb * 1024) {
+    if (vec && i + 3 < n) st4(out, i, o);
+    else
+      for (long long k = i; k < n && k < i + 4; ++k) stf(out, k, v);
+  }
+}
+static int multi_plan(XhMulti* m, int nt, const void* const* ptrs, const long long* numels, const float* values, const int* row0,
+                      const int* rows, long long per_wg) {
+  if (nt <= 0 || nt > XH_MULTI_MAX || !ptrs || !numels) return -1;
+  m->nt = nt;
+  int tot = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (!ptrs[t] || numels[t] <= 0) return -1;
+    m->p[t] = ptrs[t]; m->n[t] = numels[t];
+    m->v[t] = values ? values[t] : 0.f;
+    m->row0[t] = row0 ? row0[t] : 0;
+    m->rows[t] = rows ? (rows[t] > 0 ? rows[t] : 1) : 1;
+    long long nb = (numels[t] + per_wg - 1) / per_wg;
+    if (rows && nb > 64LL * m->rows[t]) nb = 64LL * m->rows[t];      // at most 64 adders per atomic address
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    m->wg0[t] = tot;
+    tot += (int)nb;
+  }
+  m->wg0[nt] = tot;
+  return tot;
+}
+extern "C" int xh_multi_sum(void* stream, int dtype, int nt, const void* const* ptrs, const long long* numels, const int* row0, const int* rows,
+                            double* red) {
+  XhMulti m;
+  if (!red || !row0 || !rows) return XH_ERR_ARG;
+  const int tot = multi_plan(&m, nt, ptrs, numels, nullptr, row0, rows, 16384);
+  if (tot <= 0) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL(multi_sum_kernel<T>, dim3((unsigned)tot), dim3(LS_BLOCK), 0, st, m, red););
+  return xh_launch_status();
+}
+extern "C" int xh_multi_fill(void* stream, int dtype, int nt, void* const* ptrs, const long long* numels, const float* values,
+                             const float* gscale) {
+  XhMulti m;
+  if (!values) return XH_ERR_ARG;
+  const int tot = multi_plan(&m, nt, (const void* const*)ptrs, numels, values, nullptr, nullptr, 16384);
+  if (tot <= 0) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL(multi_fill_kernel<T>, dim3((unsigned)tot), dim3(256), 0, st, m, gscale););
+  return xh_launch_status();
+}
+
 extern "C" int xh_fill(void* stream, int dtype, void* out, long long n, float v, const float* gscale) {
   if (!out || n <= 0) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

@@ -72,10 +72,10 @@ def _pack_cached(w, mode, cout_pad, cin_pad, dtype):
     return hit
 
 
-def _conv(x, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, red=None, act=L.ACT_NONE, ks=3):
+def _conv(x, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, red=None, act=L.ACT_NONE, ks=3, mask=None):
     y = torch.empty((n,) + tuple(sp_out) + (cn,), dtype=x.dtype, device=x.device)
     L.check(L.load().xh_dconv_cl(_s(), ops._dt(x), mode, stride, ks, x.data_ptr(), wp.data_ptr(), ops._p(bias), y.data_ptr(), ops._p(red), n,
-                                 *sp_in, *sp_out, cs, cn, act, SLOPE), "xh_dconv_cl")
+                                 *sp_in, *sp_out, cs, cn, act, SLOPE, ops._p(mask)), "xh_dconv_cl")
     return y
 
 
@@ -187,14 +187,14 @@ class DiscFn(Function):
                                       B.data_ptr(), Cc.data_ptr(), None, n, cn, cnt), "xh_cl_act_bwd")
             if need_w:
                 _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k], sp[k + 1], cs, cn, ks=ks, gs=gs), g_w, cn, cs)
-            da = _conv(dc, _pack_cached(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k + 1], sp[k], cn, cs, ks=ks)
-        # block 0: conv + bias -> LeakyReLU (no norm): g = da * leaky'(y0), bias gradient = sum g
+            if k > 1:
+                da = _conv(dc, _pack_cached(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k + 1], sp[k], cn, cs, ks=ks)
+        # block 0: conv + bias -> LeakyReLU (no norm): g0 = da * leaky'(y0), bias gradient = sum g0.  Both ride in the epilogue of
+        # disc.1's data gradient (mask = the stored activation y0): no separate pass over the 64-channel full-resolution tensor
         c0 = w0.shape[0]
-        V0, V1 = sp[0][0] * sp[0][1] * sp[0][2], sp[1][0] * sp[1][1] * sp[1][2]
+        V0 = sp[0][0] * sp[0][1] * sp[0][2]
         red0 = torch.zeros((n, c0, 2), dtype=torch.float64, device=dev)
-        g0 = torch.empty_like(acts[0])
-        L.check(lib.xh_cl_act_bwd(_s(), ops._dt(g0), 2, da.data_ptr(), acts[0].data_ptr(), g0.data_ptr(), None, None, SLOPE, None, None, None,
-                                  red0.data_ptr(), n, c0, V1), "xh_cl_act_bwd")
+        g0 = _conv(dc, _pack_cached(w1, 1, w1.shape[0], c0, dt), None, 1, 2, n, sp[2], sp[1], w1.shape[0], c0, ks=ks, red=red0, mask=acts[0])
         if need_w:
             g_b0 += (red0[:, :, 0].sum(0) / gs if gs is not None else red0[:, :, 0].sum(0)).float()
             _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[1], 8, c0, ks=ks, gs=gs), g_w0, c0, 8)

@@ -980,6 +980,27 @@ def nested_weight(seg):
     return out
 
 
+def multi_sum(tensors, red, row0, rows):
+    """One launch: red[(row0[t] + b % rows[t]), 0, 4] += partial sums of tensors[t] (all of one storage type, <= 16)."""
+    n = len(tensors)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nums = (C.c_longlong * n)(*[t.numel() for t in tensors])
+    r0 = (C.c_int * n)(*row0)
+    rs = (C.c_int * n)(*rows)
+    L.check(L.load().xh_multi_sum(_stream(), _dt(tensors[0]), n, ptrs, nums, r0, rs, _p(red)), "xh_multi_sum")
+
+
+def multi_fill(metas, values, gscale=None):
+    """One launch: new tensors of the (shape, dtype, device) metas (one dtype, <= 16), tensor t filled with values[t] * gscale."""
+    outs = [torch.empty(shape, dtype=dtype, device=device) for shape, dtype, device in metas]
+    n = len(outs)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+    nums = (C.c_longlong * n)(*[t.numel() for t in outs])
+    vals = (C.c_float * n)(*[float(v) for v in values])
+    L.check(L.load().xh_multi_fill(_stream(), _dt(outs[0]), n, ptrs, nums, vals, _p(gscale)), "xh_multi_fill")
+    return outs
+
+
 def fill(shape, value, dtype, device, gscale=None):
     out = torch.empty(shape, dtype=dtype, device=device)
     L.check(L.load().xh_fill(_stream(), _dt(out), _p(out), out.numel(), float(value), _p(gscale)), "xh_fill")
