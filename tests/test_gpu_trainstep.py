@@ -244,3 +244,26 @@ def test_loss_scale_bookkeeping_follows_gradscaler():
         parts = ts.step(x.to(DEV), mask.to(DEV), [5])
         assert "skipped" not in parts
     assert ts.loss_scale == 1024.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_shared_discriminator_pass_equals_recomputed_pass(dtype):
+    """train.py:272 recomputes D(fake.detach()) although train.py:260 has just computed D(fake) with the same weights.  TrainStep
+    reuses the generator pass's activations (DiscShare / forward_pair): same losses and the same discriminator gradients as the
+    step that runs the D update on its own batch of two, bit for bit in the forward."""
+    x, mask, eps = _inputs()
+    res = []
+    for share in (True, False):
+        m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+        m.load_state_dict(load("weights_seed1"), strict=True)
+        m = m.to(DEV).train()
+        ts = TrainStep(m, _disc().to(DEV), alpha=ALPHA, beta=BETA, storage=dtype, share_disc_pass=share,
+                       loss_scale=1024.0 if dtype == torch.float16 else None)     # (at 65536 this random-init step overflows fp16)
+        eps_dev = [[e.to(DEV) for e in el] for el in eps]
+        got = ts.compute(x.to(DEV), mask.to(DEV), [9], eps_lists=eps_dev)
+        torch.cuda.synchronize()
+        res.append((got["loss"].item(), got["loss_d"].item(), got["g_gan"].item(), ts.grads.flat.clone(), ts.grads_d.flat.clone()))
+    a, b = res
+    assert a[0] == b[0] and a[2] == b[2] and abs(a[1] - b[1]) <= 1e-6 * abs(b[1]), (a[:3], b[:3])
+    assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
+    assert (a[4] - b[4]).abs().max().item() <= 2e-3 * b[4].abs().max().item()

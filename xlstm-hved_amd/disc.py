@@ -99,113 +99,206 @@ def conv_out(sp, ks, stride):
 STRIDES = (1, 2, 2, 2, 1)          # disc.0 .. disc.3, last (RA_HVED.py:206,223)
 
 
+class DiscShare:
+    """Activations of one discriminator pass kept so that a second pass can join it in ONE batched backward.
+
+    train.py:260 runs D on the fake sample for the generator's loss and train.py:272 runs D on the SAME values again
+    (`fake.detach()`, the discriminator's weights have not changed in between) for the discriminator's loss: the second forward
+    recomputes the first bit for bit.  With a DiscShare the first pass (Discriminator.forward(x, share=s)) writes its activations
+    into the first half of buffers sized for two batches; Discriminator.forward_pair(real, s) then runs the forward of `real`
+    only, into the second half, and returns the outputs of both -- [D(fake); D(real)] -- as one autograd node whose backward is
+    the batched weight-gradient pass over both halves."""
+
+    def __init__(self):
+        self.bufs = None
+        self.meta = None
+        self.weights = None
+
+
+def _extents(x_shape, ks):
+    n, cin, d, h, w = x_shape
+    sp = [(d, h, w)]                                          # sp[k] = input extents of layer k, sp[k + 1] its output
+    for st in STRIDES:
+        sp.append(conv_out(sp[-1], ks, st))
+    if min(sp[-1]) < 1:
+        raise ValueError(f"input {d}x{h}x{w} is too small for the discriminator (ks={ks})")
+    return sp
+
+
+def _alloc(nb, sp, chans, dt, dev):
+    """Channels-last activation buffers for a batch of nb: xin, acts[0..3], raws[0..2], per-layer statistics, out."""
+    b = {"xin": torch.empty((nb,) + sp[0] + (8,), dtype=dt, device=dev),
+         "acts": [torch.empty((nb,) + sp[k + 1] + (chans[k],), dtype=dt, device=dev) for k in range(4)],
+         "raws": [torch.empty((nb,) + sp[k + 1] + (chans[k],), dtype=dt, device=dev) for k in range(1, 4)],
+         "red": [torch.zeros((nb, chans[k], 2), dtype=torch.float64, device=dev) for k in range(1, 4)],
+         "stats": [[torch.empty((nb, chans[k]), dtype=torch.float32, device=dev) for _ in range(4)] for k in range(1, 4)],
+         "out": torch.empty((nb,) + sp[5] + (1,), dtype=dt, device=dev)}
+    return b
+
+
+def _conv_into(y, x, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, red=None, act=L.ACT_NONE, ks=3, mask=None):
+    L.check(L.load().xh_dconv_cl(_s(), ops._dt(x), mode, stride, ks, x.data_ptr(), wp.data_ptr(), ops._p(bias), y.data_ptr(), ops._p(red), n,
+                                 *sp_in, *sp_out, cs, cn, act, SLOPE, ops._p(mask)), "xh_dconv_cl")
+    return y
+
+
+def _forward(x, params, bufs, lo, sp, ks):
+    """Forward of samples x (n, cin, D, H, W; 16-bit NCDHW) into rows [lo, lo + n) of the activation buffers."""
+    w0, b0, w1, b1, w2, b2, w3, b3, wl = params
+    lib = L.load()
+    n, cin = x.shape[:2]
+    dt = x.dtype
+    V = sp[0][0] * sp[0][1] * sp[0][2]
+    sl = slice(lo, lo + n)
+    xin = bufs["xin"][sl]
+    L.check(lib.xh_cl_from_ncdhw(_s(), ops._dt(x), x.data_ptr(), cin * V, cin, None, 0, 0, xin.data_ptr(), 8, n, V), "xh_cl_from_ncdhw")
+    _conv_into(bufs["acts"][0][sl], xin, _pack_cached(w0, 2, 64, 8, dt), b0, 0, 1, n, sp[0], sp[1], 8, w0.shape[0], act=L.ACT_LRELU, ks=ks)
+    for k, wk in enumerate((w1, w2, w3), 1):
+        cs, cn = wk.shape[1], wk.shape[0]
+        red = bufs["red"][k - 1][sl]
+        c = _conv_into(bufs["raws"][k - 1][sl], bufs["acts"][k - 1][sl], _pack_cached(wk, 0, cn, cs, dt), None, 0, 2, n, sp[k], sp[k + 1],
+                       cs, cn, red=red, ks=ks)
+        cnt = sp[k + 1][0] * sp[k + 1][1] * sp[k + 1][2]
+        sc, sh, mean, rstd = (t[sl] for t in bufs["stats"][k - 1])
+        L.check(lib.xh_norm_finalize(_s(), ops.MODE_IN, red.data_ptr(), n, cn, cnt, 1, ops.NORM_EPS, None, None, None, None, 1,
+                                     sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()), "xh_norm_finalize")
+        a = bufs["acts"][k][sl]
+        L.check(lib.xh_cl_affine_act(_s(), ops._dt(c), c.data_ptr(), a.data_ptr(), sc.data_ptr(), sh.data_ptr(), SLOPE, n, cn, cnt),
+                "xh_cl_affine_act")
+    _conv_into(bufs["out"][sl], bufs["acts"][3][sl], _pack_cached(wl, 0, 1, wl.shape[1], dt), None, 0, 1, n, sp[4], sp[5], wl.shape[1], 1, ks=ks)
+    return bufs["out"][sl]
+
+
+def _backward(bufs, lo, n, sp, ks, dt, cin, weights, params, dout, need_w, need_dx, gs):
+    """Backward over rows [lo, lo + n) of the activation buffers.  Returns (dx or None, parameter-gradient returns)."""
+    from .functional import _targets
+    lib = L.load()
+    w0, w1, w2, w3, wl = weights
+    dev = dout.device
+    sl = slice(lo, lo + n)
+    xin, acts, raws = bufs["xin"][sl], [a[sl] for a in bufs["acts"]], [r[sl] for r in bufs["raws"]]
+    stats = [[t[sl] for t in st] for st in bufs["stats"]]
+    if need_w:
+        gbufs, rets = _targets(params)
+    else:
+        gbufs, rets = [None] * 9, [None] * 9
+    g_w0, g_b0, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wl = gbufs
+    # last conv (512 -> 1): its single gradient channel is padded to 32 so that it is a K step of the GEMMs
+    dy = torch.zeros((n,) + sp[5] + (32,), dtype=dt, device=dev)
+    dy[..., 0] = (dout.reshape((n,) + sp[5]) * gs if gs is not None else dout.reshape((n,) + sp[5])).to(dt)
+    c3 = wl.shape[1]
+    if need_w:
+        _unpack(_wgrad(acts[3], dy, 1, n, sp[4], sp[5], c3, 32, ks=ks, gs=gs), g_wl, 32, c3)
+    da = _conv(dy, _pack_cached(wl, 1, 32, c3, dt), None, 1, 1, n, sp[5], sp[4], 32, c3, ks=ks)
+    dc = None
+    for k, wk, g_w in ((3, w3, g_w3), (2, w2, g_w2), (1, w1, g_w1)):
+        cs, cn = wk.shape[1], wk.shape[0]
+        sc, sh, mean, rstd = stats[k - 1]
+        c = raws[k - 1]
+        cnt = sp[k + 1][0] * sp[k + 1][1] * sp[k + 1][2]
+        red = torch.zeros((n, cn, 2), dtype=torch.float64, device=dev)
+        args = (ops._dt(c), da.data_ptr(), c.data_ptr())
+        L.check(lib.xh_cl_act_bwd(_s(), args[0], 0, args[1], args[2], None, sc.data_ptr(), sh.data_ptr(), SLOPE, None, None, None,
+                                  red.data_ptr(), n, cn, cnt), "xh_cl_act_bwd")
+        A, B, Cc = ops.norm_bwd_coef(ops.MODE_IN, red, cnt, mean, rstd)
+        dc = torch.empty_like(c)
+        L.check(lib.xh_cl_act_bwd(_s(), args[0], 1, args[1], args[2], dc.data_ptr(), sc.data_ptr(), sh.data_ptr(), SLOPE, A.data_ptr(),
+                                  B.data_ptr(), Cc.data_ptr(), None, n, cn, cnt), "xh_cl_act_bwd")
+        if need_w:
+            _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k], sp[k + 1], cs, cn, ks=ks, gs=gs), g_w, cn, cs)
+        if k > 1:
+            da = _conv(dc, _pack_cached(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k + 1], sp[k], cn, cs, ks=ks)
+    if not need_w and not need_dx:
+        return None, rets
+    # block 0: conv + bias -> LeakyReLU (no norm): g0 = da * leaky'(y0), bias gradient = sum g0.  Both ride in the epilogue of
+    # disc.1's data gradient (mask = the stored activation y0): no separate pass over the 64-channel full-resolution tensor
+    c0 = w0.shape[0]
+    V0 = sp[0][0] * sp[0][1] * sp[0][2]
+    red0 = torch.zeros((n, c0, 2), dtype=torch.float64, device=dev)
+    g0 = _conv(dc, _pack_cached(w1, 1, w1.shape[0], c0, dt), None, 1, 2, n, sp[2], sp[1], w1.shape[0], c0, ks=ks, red=red0, mask=acts[0])
+    if need_w:
+        g_b0 += (red0[:, :, 0].sum(0) / gs if gs is not None else red0[:, :, 0].sum(0)).float()
+        _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[1], 8, c0, ks=ks, gs=gs), g_w0, c0, 8)
+    dx = None
+    if need_dx:
+        dxin = _conv(g0, _pack_cached(w0, 1, c0, 8, dt), None, 1, 1, n, sp[1], sp[0], c0, 8, ks=ks)
+        dx = torch.empty((n, cin) + sp[0], dtype=dt, device=dev)
+        L.check(lib.xh_cl_to_ncdhw(_s(), ops._dt(dx), dxin.data_ptr(), 8, dx.data_ptr(), cin * V0, cin, None, 0, 0, n, V0), "xh_cl_to_ncdhw")
+    return dx, rets
+
+
+def _check_input(x, ks):
+    if x.shape[1] > 8 or x.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise TypeError("the HIP discriminator takes <= 8 channels of bf16 / fp16 / fp32 input (train.py:218 runs it under autocast)")
+
+
 class DiscFn(Function):
-    """The whole discriminator as one autograd node: x (N, Cin<=8, D, H, W) 16-bit NCDHW -> (N, 1, D', H', W');
+    """The whole discriminator as one autograd node: x (N, Cin<=8, D, H, W) NCDHW -> (N, 1, D', H', W');
     ks = 4: 128 -> 127 -> 63 -> 31 -> 15 -> 14 per axis, ks = 3: 128 -> 128 -> 64 -> 32 -> 16 -> 16."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, share, *params):
         w0, b0, w1, b1, w2, b2, w3, b3, wl = params
-        lib = L.load()
-        n, cin, d, h, w = x.shape
+        n, cin = x.shape[:2]
         ks = w0.shape[2]
-        if cin > 8 or x.dtype not in (torch.bfloat16, torch.float16, torch.float32):
-            raise TypeError("the HIP discriminator takes <= 8 channels of bf16 / fp16 / fp32 input (train.py:218 runs it under autocast)")
+        _check_input(x, ks)
         in_dt = x.dtype
         if in_dt == torch.float32:
             x = x.to(torch.float16)
         dt, dev = x.dtype, x.device
         x = x.contiguous()
-        V = d * h * w
-        sp = [(d, h, w)]                                      # sp[k] = input extents of layer k, sp[k + 1] its output
-        for st in STRIDES:
-            sp.append(conv_out(sp[-1], ks, st))
-        if min(sp[-1]) < 1:
-            raise ValueError(f"input {d}x{h}x{w} is too small for the discriminator (ks={ks})")
-        xin = torch.empty((n, d, h, w, 8), dtype=dt, device=dev)
-        L.check(lib.xh_cl_from_ncdhw(_s(), ops._dt(x), x.data_ptr(), cin * V, cin, None, 0, 0, xin.data_ptr(), 8, n, V), "xh_cl_from_ncdhw")
-        y0 = _conv(xin, _pack_cached(w0, 2, 64, 8, dt), b0, 0, 1, n, sp[0], sp[1], 8, w0.shape[0], act=L.ACT_LRELU, ks=ks)
-        acts, raws, stats = [y0], [], []
-        for k, wk in enumerate((w1, w2, w3), 1):
-            cs, cn = wk.shape[1], wk.shape[0]
-            red = torch.zeros((n, cn, 2), dtype=torch.float64, device=dev)
-            c = _conv(acts[-1], _pack_cached(wk, 0, cn, cs, dt), None, 0, 2, n, sp[k], sp[k + 1], cs, cn, red=red, ks=ks)
-            cnt = sp[k + 1][0] * sp[k + 1][1] * sp[k + 1][2]
-            sc, sh, mean, rstd = ops.norm_finalize(ops.MODE_IN, red, n, cn, cnt)
-            a = torch.empty_like(c)
-            L.check(lib.xh_cl_affine_act(_s(), ops._dt(c), c.data_ptr(), a.data_ptr(), sc.data_ptr(), sh.data_ptr(), SLOPE, n, cn, cnt),
-                    "xh_cl_affine_act")
-            raws.append(c)
-            acts.append(a)
-            stats.append((sc, sh, mean, rstd))
-        out = _conv(acts[-1], _pack_cached(wl, 0, 1, wl.shape[1], dt), None, 0, 1, n, sp[4], sp[5], wl.shape[1], 1, ks=ks)
-        ctx.save_for_backward(xin, *acts, *raws, *[t for st in stats for t in st], w0, w1, w2, w3, wl)
+        sp = _extents(x.shape, ks)
+        chans = [w0.shape[0], w1.shape[0], w2.shape[0], w3.shape[0]]
+        bufs = _alloc(2 * n if share is not None else n, sp, chans, dt, dev)
+        out = _forward(x, params, bufs, 0, sp, ks)
+        if share is not None:                             # a second pass may join (DiscShare)
+            share.bufs, share.meta = bufs, (n, cin, sp, dt, ks, chans)
+            share.weights = tuple((p, p._version) for p in params)
+        ctx.bufs = bufs
+        ctx.save_for_backward(w0, w1, w2, w3, wl)
         ctx.meta = (n, cin, sp, dt, ks, in_dt)
         ctx.params = params
-        out = out.view(n, 1, *sp[5])                  # one channel: channels-last == NCDHW
-        return out.float() if in_dt == torch.float32 else out
+        out = out.view(n, 1, *sp[5])                      # one channel: channels-last == NCDHW
+        return out.float() if in_dt == torch.float32 else out.clone() if share is not None else out
 
     @staticmethod
     def backward(ctx, dout):
-        from .functional import _targets
-        lib = L.load()
-        sv = ctx.saved_tensors
-        xin, acts, raws = sv[0], sv[1:5], sv[5:8]
-        stats = [sv[8 + 4 * i:12 + 4 * i] for i in range(3)]
-        w0, w1, w2, w3, wl = sv[20:25]
         n, cin, sp, dt, ks, in_dt = ctx.meta
-        dev = dout.device
         # fp32 caller: no outer loss scale protects the fp16 gradients -> a device-side scale (no host synchronisation)
         gs = (GRAD_PEAK / dout.abs().amax().clamp_min(1e-30).float()) if in_dt == torch.float32 else None
         # parameter gradients are skipped when no parameter asks for one (TrainStep freezes the discriminator for the
         # generator's pass: train.py:265 computes them there too, and optimizer_d.zero_grad() at :282 throws them away)
-        need_w = any(ctx.needs_input_grad[1:])
-        if need_w:
-            bufs, rets = _targets(ctx.params)
-        else:
-            bufs, rets = [None] * 9, [None] * 9
-        g_w0, g_b0, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wl = bufs
-        # last conv (512 -> 1): its single gradient channel is padded to 32 so that it is a K step of the GEMMs
-        dy = torch.zeros((n,) + sp[5] + (32,), dtype=dt, device=dev)
-        dy[..., 0] = (dout.reshape((n,) + sp[5]) * gs if gs is not None else dout.reshape((n,) + sp[5])).to(dt)
-        c3 = wl.shape[1]
-        if need_w:
-            _unpack(_wgrad(acts[3], dy, 1, n, sp[4], sp[5], c3, 32, ks=ks, gs=gs), g_wl, 32, c3)
-        da = _conv(dy, _pack_cached(wl, 1, 32, c3, dt), None, 1, 1, n, sp[5], sp[4], 32, c3, ks=ks)
-        for k, wk, g_w in ((3, w3, g_w3), (2, w2, g_w2), (1, w1, g_w1)):
-            cs, cn = wk.shape[1], wk.shape[0]
-            sc, sh, mean, rstd = stats[k - 1]
-            c = raws[k - 1]
-            cnt = sp[k + 1][0] * sp[k + 1][1] * sp[k + 1][2]
-            red = torch.zeros((n, cn, 2), dtype=torch.float64, device=dev)
-            args = (ops._dt(c), da.data_ptr(), c.data_ptr())
-            L.check(lib.xh_cl_act_bwd(_s(), args[0], 0, args[1], args[2], None, sc.data_ptr(), sh.data_ptr(), SLOPE, None, None, None,
-                                      red.data_ptr(), n, cn, cnt), "xh_cl_act_bwd")
-            A, B, Cc = ops.norm_bwd_coef(ops.MODE_IN, red, cnt, mean, rstd)
-            dc = torch.empty_like(c)
-            L.check(lib.xh_cl_act_bwd(_s(), args[0], 1, args[1], args[2], dc.data_ptr(), sc.data_ptr(), sh.data_ptr(), SLOPE, A.data_ptr(),
-                                      B.data_ptr(), Cc.data_ptr(), None, n, cn, cnt), "xh_cl_act_bwd")
-            if need_w:
-                _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k], sp[k + 1], cs, cn, ks=ks, gs=gs), g_w, cn, cs)
-            if k > 1:
-                da = _conv(dc, _pack_cached(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k + 1], sp[k], cn, cs, ks=ks)
-        # block 0: conv + bias -> LeakyReLU (no norm): g0 = da * leaky'(y0), bias gradient = sum g0.  Both ride in the epilogue of
-        # disc.1's data gradient (mask = the stored activation y0): no separate pass over the 64-channel full-resolution tensor
-        c0 = w0.shape[0]
-        V0 = sp[0][0] * sp[0][1] * sp[0][2]
-        red0 = torch.zeros((n, c0, 2), dtype=torch.float64, device=dev)
-        g0 = _conv(dc, _pack_cached(w1, 1, w1.shape[0], c0, dt), None, 1, 2, n, sp[2], sp[1], w1.shape[0], c0, ks=ks, red=red0, mask=acts[0])
-        if need_w:
-            g_b0 += (red0[:, :, 0].sum(0) / gs if gs is not None else red0[:, :, 0].sum(0)).float()
-            _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[1], 8, c0, ks=ks, gs=gs), g_w0, c0, 8)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dxin = _conv(g0, _pack_cached(w0, 1, c0, 8, dt), None, 1, 1, n, sp[1], sp[0], c0, 8, ks=ks)
-            dx = torch.empty((n, cin) + sp[0], dtype=dt, device=dev)
-            L.check(lib.xh_cl_to_ncdhw(_s(), ops._dt(dx), dxin.data_ptr(), 8, dx.data_ptr(), cin * V0, cin, None, 0, 0, n, V0), "xh_cl_to_ncdhw")
-            if in_dt == torch.float32:
-                dx = dx.float() / gs
-        return (dx, *rets)
+        need_w = any(ctx.needs_input_grad[2:])
+        dx, rets = _backward(ctx.bufs, 0, n, sp, ks, dt, cin, ctx.saved_tensors, ctx.params, dout, need_w, ctx.needs_input_grad[0], gs)
+        if dx is not None and in_dt == torch.float32:
+            dx = dx.float() / gs
+        return (dx, None, *rets)
+
+
+class DiscPairFn(Function):
+    """[D(first); D(x)]: the forward of x only, into the second half of the buffers a DiscShare-d first pass left; backward =
+    ONE batched pass over both halves (parameter gradients; x is a detached sample, train.py:272-277)."""
+
+    @staticmethod
+    def forward(ctx, x, share, *params):
+        n, cin, sp, dt, ks, chans = share.meta
+        if x.dtype == torch.float32:
+            x = x.to(dt)
+        if tuple(x.shape) != (n, cin) + sp[0] or x.dtype != dt:
+            raise ValueError("the second pass must have the first pass's shape and storage type")
+        if any(p is not q or p._version != v for p, (q, v) in zip(params, share.weights)):
+            raise RuntimeError("the discriminator's weights changed since the shared first pass: its activations are stale")
+        _forward(x.contiguous(), params, share.bufs, n, sp, ks)
+        ctx.bufs, ctx.meta, ctx.params = share.bufs, share.meta, params
+        ctx.save_for_backward(params[0], params[2], params[4], params[6], params[8])
+        share.bufs = None                                 # one use
+        return ctx.bufs["out"].view(2 * n, 1, *sp[5]).clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, cin, sp, dt, ks, chans = ctx.meta
+        _, rets = _backward(ctx.bufs, 0, 2 * n, sp, ks, dt, cin, ctx.saved_tensors, ctx.params, dout.contiguous(), True, False, None)
+        return (None, None, *rets)
 
 
 class Discriminator(nn.Module):
@@ -230,10 +323,20 @@ class Discriminator(nn.Module):
         self.disc = nn.ModuleList(blocks)
         self.last = nn.Conv3d(512, 1, ks, padding=1, bias=False)
 
-    def forward(self, x, input_level=0):
-        if input_level != 0:
-            raise NotImplementedError("input_level > 0 is not used by train.py")
+    def _params(self):
         ps = []
         for blk in self.disc:
             ps += [blk[0].weight, blk[0].bias]
-        return DiscFn.apply(x, *ps, self.last.weight)
+        return ps + [self.last.weight]
+
+    def forward(self, x, input_level=0, share=None):
+        """`share` (a DiscShare, not in the reference signature): keep this pass's activations so that forward_pair() can
+        batch a second pass with it."""
+        if input_level != 0:
+            raise NotImplementedError("input_level > 0 is not used by train.py")
+        return DiscFn.apply(x, share, *self._params())
+
+    def forward_pair(self, x, share):
+        """[D(first pass's input); D(x)] (2N outputs): only x is run forward, the first pass's activations are reused -- the
+        reference's `disc(fake.detach())` after `disc(fake)` (train.py:260,272) recomputes identical values."""
+        return DiscPairFn.apply(x, share, *self._params())

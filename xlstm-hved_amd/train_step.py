@@ -38,12 +38,14 @@ def subset_rows(device):
 
 class TrainStep:
     def __init__(self, model, disc, optimizer=None, optimizer_d=None, alpha=0.1, beta=0.2, storage=torch.bfloat16,
-                 loss_scale=None, shared_encoder=True, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+                 loss_scale=None, shared_encoder=True, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 share_disc_pass=True):
         self.model, self.disc = model, disc
         self.optimizer, self.optimizer_d = optimizer, optimizer_d
         self.alpha, self.beta = float(alpha), float(beta)
         self.storage = storage
         self.shared_encoder = shared_encoder
+        self.share_disc_pass = share_disc_pass              # D(fake.detach()) of train.py:272 reuses the forward of train.py:260
         self.dice, self.gan = losses.DiceLoss(), losses.GANLoss()
         self.grads = FlatGrads(model.parameters())             # p.grad = views of one flat fp32 bucket (one fill, one all-reduce)
         self.grads_d = FlatGrads(disc.parameters())
@@ -104,19 +106,28 @@ class TrainStep:
         dparams = [p for p in self.disc.parameters() if p.requires_grad]
         for p in dparams:
             p.requires_grad_(False)
+        from .disc import Discriminator, DiscShare
+        share = DiscShare() if (self.share_disc_pass and isinstance(self.disc, Discriminator)) else None
         try:
-            g_gan = self.gan(self._disc(fake).float(), True)                    # train.py:260-261
+            pred_fake = self.disc(fake, share=share) if share is not None else self._disc(fake)
+            g_gan = self.gan(pred_fake.float(), True)                           # train.py:260-261
         finally:
             for p in dparams:
                 p.requires_grad_(True)
         loss = dice + m_dice + self.beta * recon + self.beta * kld + self.alpha * g_gan
         parts = dict(dice=dice, m_dice=m_dice, recon=recon, kld=kld, g_gan=g_gan)
         real = torch.cat([f_out.detach(), atten_f_x.detach()], 1)
-        return loss, parts, (fake.detach(), real, f_out.detach())
+        return loss, parts, (fake.detach(), real, f_out.detach(), share)
 
-    def discriminator_forward(self, fake, real):
+    def discriminator_forward(self, fake, real, share=None):
         from .disc import Discriminator
-        if isinstance(self.disc, Discriminator) and fake.shape == real.shape:
+        if share is not None and share.bufs is not None and fake.shape == real.shape:
+            # train.py:272 runs D on fake.detach() again: the same values through the same weights as train.py:260 -- the
+            # generator pass's activations are reused and only `real` is run forward; the backward is one batch of two
+            out = self.disc.forward_pair(real, share).float()
+            nb = fake.shape[0]
+            loss_d_fake, loss_d_real = self.gan(out[:nb], False), self.gan(out[nb:], True)
+        elif isinstance(self.disc, Discriminator) and fake.shape == real.shape:
             # both passes as one batch: InstanceNorm is per sample, so this is the same arithmetic as train.py:272-277, with
             # half the launches and twice the rows for the small deep layers (and one weight-gradient pass instead of two)
             out = self._disc(torch.cat([fake, real], 0)).float()
@@ -136,12 +147,12 @@ class TrainStep:
         self.grads.zero()
         self.grads_d.zero()
         with pack_scope():                                   # the discriminator's weight images are built once for both passes
-            loss, parts, (fake, real, f_out) = self.generator_forward(x, mask, subset, eps_lists)
+            loss, parts, (fake, real, f_out, share) = self.generator_forward(x, mask, subset, eps_lists)
             (loss * self._scale[0] if self.scaling else loss).backward()
             ops.join_wgrad_stream()
             if self.scaling:
                 self.grads.flat.mul_(self._inv_scale)
-            loss_d = self.discriminator_forward(fake, real)
+            loss_d = self.discriminator_forward(fake, real, share)
             (loss_d * self._scale[0] if self.scaling else loss_d).backward()
             if self.scaling:
                 self.grads_d.flat.mul_(self._inv_scale)
