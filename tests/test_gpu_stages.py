@@ -281,3 +281,35 @@ def test_stride2_conv_channel_split_matches_unsplit(dtype):
     tol = 2e-5 if dtype == torch.float32 else 6e-3
     assert l2_err(y, ref) < tol and l2_err(y0, ref) < tol and l2_err(y, y0) < tol
     assert ((r - r0).abs() <= 1e-3 * r0.abs() + 1e-2).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 12, 16), (1, 16, 16, 16, 32)], ids=["n2c8", "n1c16"])
+def test_fused_gate_maxpool_equals_gate_then_maxpool_then_moments(shape, dtype):
+    """ops.gate_maxpool / gate_maxpool_bwd (the skip-return gate, the next encoder's MaxPool3d(2) and the pooled tensor's channel
+    sums in one pass; RA_HVED.py:552, buildingblocks.py:655-657) against the three separate launches: bit-identical pooled
+    values, sums to fp64 round-off, identical gradients (the arg-max is recomputed from the same rounded products)."""
+    from xlstm_hved_amd import ops
+    torch.manual_seed(4)
+    n, c, d, h, w = shape
+    x = torch.randn(shape, device="cuda").to(dtype)
+    a = torch.sigmoid(torch.randn(n, 1, d, h, w, device="cuda")).to(dtype)
+    x[0, 0, :2, :2, :8] = 0.25                            # ties inside windows: the FIRST maximum in scan order must win in both
+    assert ops.gate_maxpool_ok(x, a)
+    red = torch.zeros(n, c, 2, dtype=torch.float64, device="cuda")
+    y = ops.gate_maxpool(x, a, red)
+    g = ops.gate(x, a)
+    y_ref = ops.maxpool2(g)
+    assert torch.equal(y, y_ref)
+    red_ref = torch.zeros_like(red)
+    ops.moments(y_ref, red_ref, 0)
+    assert ((red - red_ref).abs() / red_ref.abs().clamp_min(1.0)).max().item() < 1e-7    # fp32 over a lane's 4 values, fp64 from there
+    dy = torch.randn_like(y)
+    dx, ds = ops.gate_maxpool_bwd(x, a, dy)
+    dg = ops.maxpool2_bwd(g, dy)
+    dx_ref, ds_ref = ops.gate_bwd(x, a, dg)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    # ds sums the routed contributions over channels: the fused kernel adds four per-wave partial sums, the separate one walks
+    # the channels in order -- fp32 round-off before the rounding to storage
+    assert (ds.float() - ds_ref.float()).abs().max().item() <= 1e-2 * ds_ref.float().abs().max().item() * (1e-4 if dtype == torch.float32 else 1.0)

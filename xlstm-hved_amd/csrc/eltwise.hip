@@ -1406,6 +1406,179 @@ extern "C" int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_b
   return xh_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------- gate + max-pool (+ moments)
+// The skip-return attention gates every modality stream, x_i = a * x_i + x_i (RA_HVED.py:552), right before the next encoder
+// pools it (buildingblocks.py:655-657) and normalises the pooled tensor (the first InstanceNorm of the DoubleConv).  As three
+// launches that is a write + a read of the full-resolution gated tensor (16 channels x 128^3 at level 1) and a moments pass over
+// the pooled one; here ONE pass reads x and the gate, keeps the gated values in registers (rounded to the storage type, so the
+// pooled maxima -- and the arg-max the backward recomputes -- are those of the unfused path bit for bit), writes the pooled
+// tensor and leaves its channel sums.  A lane owns 4 pooled voxels of a row = 8 input voxels x 2 rows x 2 planes.
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+  float a[4], b[4];
+  ld4(p, 0, a); ld4(p, 4, b);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) { ldvec(p, 0, o); }
+template <> __device__ __forceinline__ void ld8<f16_t>(const f16_t* p, float (&o)[8]) { ldvec(p, 0, o); }
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&o)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&o)[8]) {
+  const float a[4] = {o[0], o[1], o[2], o[3]}, b[4] = {o[4], o[5], o[6], o[7]};
+  st4(p, 0, a); st4(p, 4, b);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&o)[8]) { stvec(p, 0, o); }
+template <> __device__ __forceinline__ void st8<f16_t>(f16_t* p, const float (&o)[8]) { stvec(p, 0, o); }
+
+// grid (blocks over runs, C, N); run = 4 pooled voxels along W
+template <typename T>
+__global__ __launch_bounds__(256) void gate_maxpool_fwd_kernel(const T* x, long long x_bs, const T* s, long long s_bs, T* y, long long y_bs,
+                                                              int D, int H, int W, double* red) {
+  __shared__ double s_red[4 * 2];
+  const int c = blockIdx.y, n = blockIdx.z, C = gridDim.y;
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2, Wr = Wo / 4;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw, odhw = (long long)Do * Ho * Wo;
+  const T* xp = x + n * x_bs + (long long)c * dhw;
+  const T* sp = s + n * s_bs;
+  T* yp = y + n * y_bs + (long long)c * odhw;
+  const long long runs = (long long)Do * Ho * Wr;
+  double acc[2] = {0.0, 0.0};
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < runs; r += (long long)gridDim.x * 256) {
+    const int wr = (int)(r % Wr);
+    long long t = r / Wr;
+    const int oh = (int)(t % Ho), od = (int)(t / Ho);
+    const long long base = ((long long)(2 * od) * H + 2 * oh) * W + 8 * wr;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // (dz, dy) rows of the window, in the scan order of max_pool3d
+      const long long o = base + (long long)(k >> 1) * hw + (long long)(k & 1) * W;
+      float xv[8], sv[8];
+      ld8<T>(xp + o, xv);
+      ld8<T>(sp + o, sv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float v = rnd_as(yp, xv[2 * j + e] * (1.f + sv[2 * j + e]));
+          m[j] = (v > m[j] || v != v) ? v : m[j];
+        }
+    }
+    st4(yp, ((long long)od * Ho + oh) * Wo + 4 * wr, m);
+    if (red) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { t0 += m[j]; t1 = fmaf(m[j], m[j], t1); }
+      acc[0] += (double)t0; acc[1] += (double)t1;
+    }
+  }
+  if (red) {
+    block_sum_d<2>(acc, s_red, 4);
+    if (threadIdx.x < 2) atomicAdd(&red[((long long)n * C + c) * 2 + threadIdx.x], s_red[threadIdx.x]);
+  }
+}
+// dx = (arg-max of its window ? dy * (1 + s) : 0), ds = sum_c (arg-max ? dy * x : 0).  A workgroup owns 64 runs; lane = run,
+// wave w takes the channels w, w + 4, ... (a lane-per-run loop over all 16 channels left 256 workgroups of serial work at level
+// 1: one per CU); the four waves' partial ds rows meet in LDS and wave k writes window row k.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ s, long long s_bs,
+                                                              const T* __restrict__ dy, long long dy_bs, T* dx, long long dx_bs, T* ds,
+                                                              long long ds_bs, int C, int D, int H, int W) {
+  __shared__ float s_ds[4 * 4 * 8 * 64];                  // [wave][window row][element][lane]
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2, Wr = Wo / 4;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw, odhw = (long long)Do * Ho * Wo;
+  const long long runs = (long long)Do * Ho * Wr;
+  const long long r = (long long)blockIdx.x * 64 + lane;
+  const bool live = r < runs;
+  const long long rc = live ? r : 0;
+  const int wr = (int)(rc % Wr);
+  const long long t = rc / Wr;
+  const int oh = (int)(t % Ho), od = (int)(t / Ho);
+  const long long base = ((long long)(2 * od) * H + 2 * oh) * W + 8 * wr;
+  const long long obase = ((long long)od * Ho + oh) * Wo + 4 * wr;
+  float g1[4][8], dsv[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ld8<T>(s + n * s_bs + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W, g1[k]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g1[k][e] = 1.f + g1[k][e]; dsv[k][e] = 0.f; }
+  }
+  for (int c = wv; c < C; c += 4) {
+    const T* xp = x + n * x_bs + (long long)c * dhw + base;
+    float xv[4][8], g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ld8<T>(xp + (long long)(k >> 1) * hw + (long long)(k & 1) * W, xv[k]);
+    ld4(dy + n * dy_bs + (long long)c * odhw, obase, g);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0, 0, 0, 0};                          // window position 2 * k + e of the first maximum (scan order)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float v = rnd_as(x, xv[k][2 * j + e] * g1[k][2 * j + e]);
+          if (v > m[j] || v != v) { m[j] = v; arg[j] = 2 * k + e; }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float gg = arg[j] == 2 * k + e ? g[j] : 0.f;
+          o[2 * j + e] = gg * g1[k][2 * j + e];
+          dsv[k][2 * j + e] = fmaf(gg, xv[k][2 * j + e], dsv[k][2 * j + e]);
+        }
+      if (live) st8<T>(dx + n * dx_bs + (long long)c * dhw + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W, o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_ds[((wv * 4 + k) * 8 + e) * 64 + lane] = dsv[k][e];
+  __syncthreads();
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)                             // the same order of additions whatever C is: waves 0, 1, 2, 3
+    o[e] = ((s_ds[((0 * 4 + wv) * 8 + e) * 64 + lane] + s_ds[((1 * 4 + wv) * 8 + e) * 64 + lane]) +
+            s_ds[((2 * 4 + wv) * 8 + e) * 64 + lane]) + s_ds[((3 * 4 + wv) * 8 + e) * 64 + lane];
+  if (live) st8<T>(ds + n * ds_bs + base + (long long)(wv >> 1) * hw + (long long)(wv & 1) * W, o);
+}
+static bool gmp_ok(int D, int H, int W, std::initializer_list<long long> strides) {
+  if (D < 2 || H < 2 || W < 8 || (D & 1) || (H & 1) || (W & 7)) return false;
+  for (long long v : strides)
+    if (v & 7) return false;
+  return true;
+}
+extern "C" int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y, long long y_bs,
+                                   int N, int C, int D, int H, int W, double* red) {
+  if (!x || !s || !y || N <= 0 || C <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  if (!gmp_ok(D, H, W, {x_bs, s_bs, y_bs})) return XH_ERR_ARG;
+  const long long runs = (long long)(D / 2) * (H / 2) * (W / 8);
+  long long nb = (runs + 255) / 256;
+  if (nb > 64) nb = 64;                                   // at most 64 adders per statistics address
+  dim3 grid((unsigned)nb, C, N);
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_fwd_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs, (T*)y, y_bs,
+                                          D, H, W, red););
+  return xh_launch_status();
+}
+extern "C" int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, const void* dy,
+                                   long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N, int C, int D, int H, int W) {
+  if (!x || !s || !dy || !dx || !ds || N <= 0 || C <= 0 || N > 65535) return XH_ERR_ARG;
+  if (!gmp_ok(D, H, W, {x_bs, s_bs, dx_bs, ds_bs}) || (dy_bs & 3)) return XH_ERR_ARG;
+  const long long runs = (long long)(D / 2) * (H / 2) * (W / 8);
+  const long long nb = (runs + 63) / 64;
+  if (nb >= (1ll << 31)) return XH_ERR_ARG;
+  dim3 grid((unsigned)nb, N);
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs, (const T*)dy,
+                                          dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W););
+  return xh_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------- DuSE gates
 // red != nullptr: the channel sums of the (rounded) output for the BatchNorm that follows (red[n][c][0..1] += sum u, sum u^2),
 // as xh_moments would find them in u -- launched on the reduction grid then (few, long workgroups per atomic address)

@@ -358,6 +358,27 @@ class Gate(Function):
         return ops.gate_bwd(x, a, _blk(dy))
 
 
+class GateMaxPool(Function):
+    """MaxPool3d(2)(x * (1 + a)) + the channel sums of the result for the InstanceNorm that follows: the skip-return gate
+    (RA_HVED.py:552), the next encoder's pooling (buildingblocks.py:655-657) and the moments pass of its first SingleConv in
+    ONE launch; backward = arg-max routing and gate backward in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        x, a = x.contiguous(), a.contiguous()
+        red = ops.zeros_red(x, x.shape[0], x.shape[1])
+        y = ops.gate_maxpool(x, a, red)
+        ctx.save_for_backward(x, a)
+        ctx.mark_non_differentiable(red)
+        ctx.set_materialize_grads(False)
+        return y, red
+
+    @staticmethod
+    def backward(ctx, dy, _dred=None):
+        x, a = ctx.saved_tensors
+        return ops.gate_maxpool_bwd(x, a, _blk(dy))
+
+
 class Add(Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -261,15 +261,19 @@ class AbstractFusion3DUNet(nn.Module):
         skip = None
         levels = len(self.encoders)
         for level in range(levels):
+            stp = None
             if self.skip_return and skip is not None:
                 a = self.skr_att[levels - level](skip, steps=bn_steps)                      # skr_att[-level], RA_HVED.py:552
-                X = Fn.Gate.apply(X, a) if batched else [Fn.Gate.apply(xi, a) for xi in X]
+                if batched and level > 0 and ops.gate_maxpool_ok(X, a):
+                    X, stp = Fn.GateMaxPool.apply(X, a)        # gate, this level's pooling and its first norm's sums: one pass
+                else:
+                    X = Fn.Gate.apply(X, a) if batched else [Fn.Gate.apply(xi, a) for xi in X]
             if batched:
-                if level > 0:
+                if level > 0 and stp is None:
                     X = Fn.MaxPool2.apply(X)
                 # each conv's epilogue accumulates the channel sums the next InstanceNorm needs (no separate pass)
                 w, b = self._stream_weights(level, "SingleConv1")
-                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0 if level == 0 else None, out_stats=True,
+                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0 if level == 0 else stp, out_stats=True,
                                          drop_bias=True)                  # consumed by SingleConv2's InstanceNorm only
                 w, b = self._stream_weights(level, "SingleConv2")
                 X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st, out_stats=True)

@@ -3,6 +3,7 @@
 Plumbing only (pointers, strides, shape checks).  No arithmetic happens here and nothing falls back to
 ATen: if the library or a GPU is missing these raise."""
 import ctypes as C
+import os
 
 import torch
 
@@ -771,6 +772,36 @@ def gate_bwd(x, s, dy, ds_out=None):
     L.check(L.load().xh_gate_bwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5],
                                  _p(ds_out), _vol(ds_out)[5], n, c, d * h * w, 0, 0), "xh_gate_bwd")
     return dx, ds_out
+
+
+_GMP = [os.environ.get("XH_NO_GATE_MAXPOOL", "") == ""]          # A/B switch (measurements): the fused gate + max-pool pass
+
+
+def gate_maxpool_ok(x, s):
+    """Shapes the fused gate + max-pool kernels take (else: gate, maxpool2 and moments one after the other)."""
+    n, c, d, h, w, bs = _vol(x)
+    if not _GMP[0]:
+        return False
+    return d % 2 == 0 and h % 2 == 0 and w % 8 == 0 and bs % 8 == 0 and _vol(s)[5] % 8 == 0 and s.shape[1] == 1
+
+
+def gate_maxpool(x, s, red=None):
+    """maxpool2(x * (1 + s)) in one pass; with `red` (zeroed (n, c, 2) fp64) the channel sums of the pooled output too."""
+    n, c, d, h, w, bs = _vol(x)
+    y = new_like(x, (n, c, d // 2, h // 2, w // 2))
+    L.check(L.load().xh_gate_maxpool_fwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(y), _vol(y)[5], n, c, d, h, w, _p(red)),
+            "xh_gate_maxpool_fwd")
+    return y
+
+
+def gate_maxpool_bwd(x, s, dy):
+    n, c, d, h, w, bs = _vol(x)
+    dy = dy.contiguous()
+    dx = new_like(x, (n, c, d, h, w))
+    ds = new_like(x, (n, 1, d, h, w))
+    L.check(L.load().xh_gate_maxpool_bwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5],
+                                         _p(ds), _vol(ds)[5], n, c, d, h, w), "xh_gate_maxpool_bwd")
+    return dx, ds
 
 
 def duse_gate(x, ch, sp, red=None):
