@@ -137,6 +137,10 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        # A/B measurements without code changes: XH_SET_OPTIONS="16=0,2=128" applies xh_set_option(key, value) at load time
+        for kv in filter(None, os.environ.get("XH_SET_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            check(lib.xh_set_option(int(k), int(v)), f"xh_set_option({kv})")
     return _lib
 
 
