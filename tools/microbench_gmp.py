@@ -23,7 +23,7 @@ def bench(fn, n=10, reps=5):
     return e0.elapsed_time(e1) / (n * reps) * 1e3
 
 dt = torch.bfloat16
-for c, sp in ((16, 128), (32, 64), (64, 32)):
+for c, sp in ((16, 128), (32, 64), (64, 32)) if __name__ == "__main__" else ():
     x = torch.randn(1, c, sp, sp, sp, device="cuda").to(dt)
     a = torch.sigmoid(torch.randn(1, 1, sp, sp, sp, device="cuda")).to(dt)
     red = torch.zeros(1, c, 2, dtype=torch.float64, device="cuda")
