@@ -60,13 +60,13 @@ def single_conv(p, x, order="ilc", stride=1, num_groups=8):
     w = p["conv.weight"]
     pad = w.shape[-1] // 2
     if order == "ilc":
-        h = F.leaky_relu(F.instance_norm(x, eps=NORM_EPS), LEAK)
+        h = F.leaky_relu(F.instance_norm(x, eps=NORM_EPS), LEAK, inplace=True)      # nn.LeakyReLU(inplace=True), buildingblocks.py:416
         return F.conv3d(h, w, p["conv.bias"], stride=stride, padding=pad)
     if order == "gcr":
         c = x.shape[1]
         g = num_groups if c >= num_groups else 1          # buildingblocks.py:425-426
         h = F.group_norm(x, g, p["groupnorm.weight"], p["groupnorm.bias"], eps=NORM_EPS)
-        return F.relu(F.conv3d(h, w, None, stride=stride, padding=pad))
+        return F.relu(F.conv3d(h, w, None, stride=stride, padding=pad), inplace=True)    # buildingblocks.py:414
     raise ValueError(order)
 
 
@@ -90,7 +90,7 @@ def basic_conv(p, x, groups=1):
     """buildingblocks.py:13-31 BasicConv: Conv3d(no bias) -> InstanceNorm3d -> LeakyReLU(0.01)."""
     w = p["conv.weight"]
     y = F.conv3d(x, w, None, padding=w.shape[-1] // 2, groups=groups)
-    return F.leaky_relu(F.instance_norm(y, eps=NORM_EPS), LEAK)
+    return F.leaky_relu(F.instance_norm(y, eps=NORM_EPS), LEAK, inplace=True)       # buildingblocks.py:21
 
 
 def upsample_to(x, size):
@@ -153,7 +153,7 @@ def dw_conv_norm(p, x, training, momentum_steps):
     c = x.shape[1]
     y = F.conv3d(x, p["dwconv.weight"], None, padding=1, groups=c)
     y = F.conv3d(y, p["pwconv.weight"], p["pwconv.bias"])
-    return F.relu(batch_norm(p.sub("norm"), y, training, momentum_steps))
+    return F.relu(batch_norm(p.sub("norm"), y, training, momentum_steps), inplace=True)       # sa_module.py:68
 
 
 def skip_return_attention(p, x, training, momentum_steps=4):
@@ -165,7 +165,7 @@ def skip_return_attention(p, x, training, momentum_steps=4):
     r = p.sub("0")
     y = dw_conv_norm(r.sub("conv2"), dw_conv_norm(r.sub("conv1"), x, training, momentum_steps),
                      training, momentum_steps)
-    y = F.relu(y + x)
+    y = F.relu(y + x, inplace=True)                            # sa_module.py:106,135
     pooled = torch.cat([y.max(1, keepdim=True)[0], y.mean(1, keepdim=True)], 1)
     return torch.sigmoid(F.conv3d(pooled, p["1.conv.weight"], None))
 
@@ -498,7 +498,7 @@ def discriminator(p, x, strides=(1, 2, 2, 2), slope=0.2):
         x = F.conv3d(x, p[f"disc.{i}.0.weight"], p[f"disc.{i}.0.bias"], stride=st, padding=1)
         if i > 0:
             x = F.instance_norm(x, eps=NORM_EPS)
-        x = F.leaky_relu(x, slope)
+        x = F.leaky_relu(x, slope, inplace=True)             # buildingblocks.py:350,356
     return F.conv3d(x, p["last.weight"], None, padding=1)
 
 
