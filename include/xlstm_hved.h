@@ -215,10 +215,11 @@ int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, co
                     long long dx_bs, int N, int C, long long DHW, const double* red, const float* mean, const float* rstd,
                     int stat_rs, int have_g, const float* sc, const float* sh, float slope, int accumulate);
 /* InstanceNorm backward of a virtual concat in one launch: dy / red / mean / rstd are CA+CB wide, the first CA channels
- * read xa and write dxa, the others xb / dxb (g given: have_g = 1 of xh_in_bwd_apply). */
+ * read xa and write dxa, the others xb / dxb (g given: have_g = 1 of xh_in_bwd_apply).  accumulate: bit 0: dxa +=, bit 1:
+ * dxb += (the buffer already holds the gradient share of another consumer of that tensor). */
 int xh_in_bwd_apply2(void* stream, int dtype, const void* dy, long long dy_bs, const void* xa, long long xa_bs, void* dxa,
                      long long dxa_bs, int CA, const void* xb, long long xb_bs, void* dxb, long long dxb_bs, int CB, int N,
-                     long long DHW, const double* red, const float* mean, const float* rstd);
+                     long long DHW, const double* red, const float* mean, const float* rstd, int accumulate);
 
 /* nn.MaxPool3d(2) (buildingblocks.py:635-636,656-657) and its backward (first maximum in scan order wins). */
 int xh_maxpool2_fwd(void* stream, int dtype, const void* x, void* y, int NC, int D, int H, int W);
@@ -274,7 +275,8 @@ int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const vo
 int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y, long long y_bs,
                         int N, int C, int D, int H, int W, double* red);
 int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, const void* dy,
-                        long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N, int C, int D, int H, int W);
+                        long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N, int C, int D, int H, int W,
+                        int acc_dx /* 1: dx += (another consumer's gradient share is already there) */);
 int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs,
                 const void* dy, long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N,
                 int C, long long DHW, int acc_dx, int acc_ds);

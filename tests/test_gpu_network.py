@@ -675,3 +675,35 @@ def test_full_size_128_specialised_kernels_vs_generic_train():
           f"MFMA vs vector seg/rec L2 {eb[0]:.2e}/{eb[1]:.2e}, grads {gb:.2e}")
     assert max(ea) < 5e-2 and ga < 5e-2
     assert max(eb) < 0.35 and gb < 0.35
+
+
+@pytest.mark.parametrize("dtype", [torch.float32], ids=["fp32"])
+def test_gradient_slots_equal_autograd_fan_in(dtype):
+    """Fn.fanout (consumers of one forward tensor add their gradient shares into ONE buffer) against autograd's own fan-in adds:
+    same loss, same parameter gradients to the order of the additions.  (fp32 storage: with 16-bit storage the slot form rounds
+    once less per fan-in, and the randomly initialised network turns that last-bit difference into 0.13 of the largest gradient
+    -- the amplification of DESIGN 4, not a property of the protocol; the accumulate flags of the kernels are dtype-generic.)"""
+    from xlstm_hved_amd import functional as Fn
+    torch.manual_seed(31)
+    x = torch.rand(1, 4, 32, 32, 32)
+    eps = [torch.randn(1, 2 ** l, 16 >> l, 16 >> l, 16 >> l) for l in range(4)]
+    res = []
+    for on in (True, False):
+        Fn.set_fanout(on)
+        try:
+            m = _model(True)
+            seg, (mu, lv), rec = m(x.to(DEV, dtype), [14], recon=True, eps_list=eps)
+            loss = seg.float().mean() + rec[0].float().mean()
+            for a_, b_ in zip(mu, lv):
+                loss = loss + a_.float().mean() + b_.float().mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.item(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+        finally:
+            Fn.set_fanout(True)
+    (la, ga), (lb, gb) = res
+    assert la == lb and ga.keys() == gb.keys()
+    scale = max(v.abs().max().item() for v in gb.values())
+    worst = max((ga[k] - gb[k]).abs().max().item() for k in gb) / scale
+    print(f"gradient slots vs autograd fan-in ({dtype}): worst parameter-gradient difference {worst:.2e} of the largest gradient")
+    assert worst < 2e-5

@@ -69,7 +69,7 @@ SIGNATURES = {
     "xh_act_bwd_reduce": (I, [vp, I, vp, ll, vp, ll, I, I, ll, vp, vp, F, vp]),
     "xh_norm_bwd_coef": (I, [vp, I, vp, I, I, ll, I, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_in_bwd_apply": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I, I, vp, vp, F, I]),
-    "xh_in_bwd_apply2": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, vp, ll, vp, ll, I, I, ll, vp, vp, vp]),
+    "xh_in_bwd_apply2": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I]),
     "xh_norm_bwd_apply": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I, vp, vp, F, I]),
     "xh_norm_bwd_fused": (I, [vp, I, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, I, vp, vp, vp, vp, vp]),
     "xh_maxpool2_fwd": (I, [vp, I, vp, vp, I, I, I, I]),
@@ -85,7 +85,7 @@ SIGNATURES = {
     "xh_gate_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll]),
     "xh_gate_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, ll, I, I]),
     "xh_gate_maxpool_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, I, I, I, vp]),
-    "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I]),
+    "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I, I]),
     "xh_duse_gate_fwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll]),
     "xh_duse_gate_fwd_stats": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll, vp]),
     "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll]),

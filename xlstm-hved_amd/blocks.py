@@ -249,10 +249,14 @@ class AttenModule2(nn.Module):
                                      self.enc_spatial2.weight, self.enc_spatial2.bias)
 
     def forward(self, seg_x, enc_x, recon_x=None):
-        pooled = Fn.ChannelPool2.apply(seg_x, enc_x)
+        """enc_x: the encoder feature, or a pair of aliases of it from Fn.fanout (one per consumer here: pooling, gating) when
+        the caller shares the feature with other consumers (one gradient buffer instead of autograd's adds)."""
+        enc_p, enc_g = enc_x if isinstance(enc_x, tuple) else Fn.fanout(enc_x, 2)
+        seg_p, seg_g = Fn.fanout(seg_x, 2)
+        pooled = Fn.ChannelPool2.apply(seg_p, enc_p)
         w, b = self.composed()
         gates = Fn.conv(pooled, [w], [b], act=ACT_SIGMOID)        # [:,0] seg scale, [:,1] enc scale
-        return Fn.GateCat.apply(seg_x, enc_x, gates)
+        return Fn.GateCat.apply(seg_g, enc_g, gates)
 
 
 class Upsampling(nn.Module):
@@ -289,7 +293,7 @@ class Decoder(nn.Module):
 
     def forward(self, encoder_features, x, up_size=None, recon_features=None, out_stats=False):
         kw = dict(out_stats=True) if out_stats else {}
-        x = self.upsampling(encoder_features, x, up_size)
+        x = self.upsampling(encoder_features[0] if isinstance(encoder_features, tuple) else encoder_features, x, up_size)
         if self.RSM:
             return self.basic_module(self.atten_module(x, encoder_features), **kw)
         if encoder_features is not None:

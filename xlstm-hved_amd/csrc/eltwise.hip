@@ -517,7 +517,7 @@ __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, lon
     ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q, valid, g);
     ldrow<VEC>(xrow, q, valid, xv);
     T* dp = drow;
-    if (accumulate) ldrow<VEC>((const T*)dp, q, valid, o);
+    if (xb && blockIdx.y >= ca ? (accumulate & 2) : (accumulate & 1)) ldrow<VEC>((const T*)dp, q, valid, o);     // bit 0: dx, bit 1: dxb
     else {
 #pragma unroll
       for (int i = 0; i < VW; ++i) o[i] = 0.f;
@@ -557,10 +557,10 @@ extern "C" int xh_in_bwd_apply(void* stream, int dtype, const void* dy, long lon
 }
 extern "C" int xh_in_bwd_apply2(void* stream, int dtype, const void* dy, long long dy_bs, const void* xa, long long xa_bs, void* dxa,
                                 long long dxa_bs, int CA, const void* xb, long long xb_bs, void* dxb, long long dxb_bs, int CB, int N,
-                                long long DHW, const double* red, const float* mean, const float* rstd) {
-  if (!xb || !dxb || CA <= 0 || CB <= 0) return XH_ERR_ARG;
+                                long long DHW, const double* red, const float* mean, const float* rstd, int accumulate) {
+  if (!xb || !dxb || CA <= 0 || CB <= 0 || accumulate < 0 || accumulate > 3) return XH_ERR_ARG;
   return launch_in_bwd_apply(stream, dtype, dy, dy_bs, xa, xa_bs, dxa, dxa_bs, xb, xb_bs, dxb, dxb_bs, CA, N, CA + CB, DHW, red, mean,
-                             rstd, CA + CB, 1, nullptr, nullptr, 1.f, 0);
+                             rstd, CA + CB, 1, nullptr, nullptr, 1.f, accumulate);
 }
 
 extern "C" int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_fwd_kernel(const T* x, long 
 template <typename T>
 __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ s, long long s_bs,
                                                               const T* __restrict__ dy, long long dy_bs, T* dx, long long dx_bs, T* ds,
-                                                              long long ds_bs, int C, int D, int H, int W) {
+                                                              long long ds_bs, int C, int D, int H, int W, int acc_dx) {
   __shared__ float s_ds[4 * 4 * 8 * 64];                  // [wave][window row][element][lane]
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int Do = D / 2, Ho = H / 2, Wo = W / 2, Wr = Wo / 4;
@@ -1531,7 +1531,14 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restri
           o[2 * j + e] = gg * g1[k][2 * j + e];
           dsv[k][2 * j + e] = fmaf(gg, xv[k][2 * j + e], dsv[k][2 * j + e]);
         }
-      if (live) st8<T>(dx + n * dx_bs + (long long)c * dhw + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W, o);
+      T* dp = dx + n * dx_bs + (long long)c * dhw + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W;
+      if (acc_dx && live) {                               // += : the gradient buffer already holds another consumer's share
+        float prev[8];
+        ld8<T>((const T*)dp, prev);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += prev[e];
+      }
+      if (live) st8<T>(dp, o);
     }
   }
 #pragma unroll
@@ -1566,7 +1573,8 @@ extern "C" int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long 
   return xh_launch_status();
 }
 extern "C" int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, const void* dy,
-                                   long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N, int C, int D, int H, int W) {
+                                   long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N, int C, int D, int H, int W,
+                                   int acc_dx) {
   if (!x || !s || !dy || !dx || !ds || N <= 0 || C <= 0 || N > 65535) return XH_ERR_ARG;
   if (!gmp_ok(D, H, W, {x_bs, s_bs, dx_bs, ds_bs}) || (dy_bs & 3)) return XH_ERR_ARG;
   const long long runs = (long long)(D / 2) * (H / 2) * (W / 8);
@@ -1575,7 +1583,7 @@ extern "C" int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long 
   dim3 grid((unsigned)nb, N);
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs, (const T*)dy,
-                                          dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W););
+                                          dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W, acc_dx););
   return xh_launch_status();
 }
 

@@ -70,6 +70,76 @@ def _targets(params):
 
 
 # ------------------------------------------------------------------------------------------------------
+# Gradient slots.  A forward tensor with several consumers gets one gradient per consumer, and autograd sums them with an
+# element-wise add launch each (16 per step, the largest over 16 channels x 128^3).  Where the consumers are this package's own
+# Functions, they can add into ONE buffer instead: `fanout(x, n)` hands out n aliases of x that carry a GradSlot; the first
+# slot-aware backward to run allocates the buffer and returns it, the later ones add into it in place (their kernels take an
+# accumulate flag) and return None; Fanout.backward -- which autograd runs after ALL consumers -- returns the buffer and adds
+# whatever a consumer that does not know about slots returned on its own.  Everything is ordered on one stream.
+class GradSlot:
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class Fanout(Function):
+    @staticmethod
+    def forward(ctx, x, n, slot):
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        slot = ctx.slot
+        total = slot.buf
+        slot.buf = None
+        for g in gs:
+            if g is None or (total is not None and g.data_ptr() == total.data_ptr()):
+                continue
+            total = _blk(g) if total is None else ops.add(total, _blk(g), out=total)
+        return total, None, None
+
+
+_FANOUT = [True]
+
+
+def fanout(x, n):
+    """n aliases of x whose consumers share one gradient buffer (see above).  set_fanout(False): plain x, n times (A/B)."""
+    if not _FANOUT[0] or not x.requires_grad:
+        return (x,) * n
+    slot = GradSlot()
+    outs = Fanout.apply(x, n, slot)
+    for o in outs:
+        o._xh_slot = slot
+    return outs
+
+
+def set_fanout(enabled):
+    _FANOUT[0] = bool(enabled)
+
+
+def _slot(t):
+    return getattr(t, "_xh_slot", None) if t is not None else None
+
+
+def _acc(slot):
+    """The buffer a slot-aware backward adds into (None: it is the first -- or there is no slot -- and allocates)."""
+    return slot.buf if slot is not None else None
+
+
+def _ret(slot, t):
+    """What that backward returns for the tensor: the buffer if it has just created it, None if it added into an existing one."""
+    if slot is None:
+        return t
+    if slot.buf is None:
+        slot.buf = t
+        return t
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------
 class InLreluConv(Function):
     """SingleConv 'ilc' (buildingblocks.py:406-433,440-461): Conv3d(LeakyReLU(InstanceNorm3d(x))) + bias, k=3.
 
@@ -101,6 +171,7 @@ class InLreluConv(Function):
         ctx.save_for_backward(xa, xb, sc, sh, mean, rstd, *weights)
         ctx.cfg = (stride, groups, nw, k, cin, ca)
         ctx.params = (weights, biases)
+        ctx.slots = (_slot(xa), _slot(xb))
         if out_stats:
             ctx.mark_non_differentiable(red_y)
             ctx.set_materialize_grads(False)          # no zero-filled "gradient" for the statistics output
@@ -110,6 +181,7 @@ class InLreluConv(Function):
     @staticmethod
     def backward(ctx, dy, _dred=None):
         xa, xb, sc, sh, mean, rstd, *weights = ctx.saved_tensors
+        sa, sb = ctx.slots
         stride, groups, nw, k, cin, ca = ctx.cfg
         dy = _blk(dy)
         dws, rws = _targets(ctx.params[0])
@@ -125,9 +197,10 @@ class InLreluConv(Function):
             else:
                 g = ops.conv3d_dgrad_s2(dy, weights, cin=cin, in_spatial=tuple(xa.shape[2:]), groups=groups, e=e, red=red)
             if xb is not None:
-                dxa, dxb = ops.in_bwd_apply2(g, xa, xb, red, mean, rstd)
+                dxa, dxb = ops.in_bwd_apply2(g, xa, xb, red, mean, rstd, acc_a=_acc(sa), acc_b=_acc(sb))
+                dxa, dxb = _ret(sa, dxa), _ret(sb, dxb)
             else:
-                dxa = ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0)
+                dxa = _ret(sa, ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0, acc=_acc(sa)))
         return (dxa, dxb, None, None, None, None, None, None, *rws, *rbs)
 
 
@@ -258,12 +331,13 @@ class MaxPool2(Function):
     @staticmethod
     def forward(ctx, x):
         ctx.save_for_backward(x)
+        ctx.slot = _slot(x)
         return ops.maxpool2(x)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.maxpool2_bwd(x, _blk(dy))
+        return _ret(ctx.slot, ops.maxpool2_bwd(x, _blk(dy), acc=_acc(ctx.slot)))
 
 
 class Upsample(Function):
@@ -312,13 +386,16 @@ class ChannelPool2(Function):
         ops.channel_pool(a, out[:, 0:2])
         ops.channel_pool(b, out[:, 2:4])
         ctx.save_for_backward(a, b)
+        ctx.slots = (_slot(a), _slot(b))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         a, b = ctx.saved_tensors
+        sa, sb = ctx.slots
         dout = _blk(dout)
-        return ops.channel_pool_bwd(a, dout[:, 0:2]), ops.channel_pool_bwd(b, dout[:, 2:4])
+        return (_ret(sa, ops.channel_pool_bwd(a, dout[:, 0:2], acc=_acc(sa))),
+                _ret(sb, ops.channel_pool_bwd(b, dout[:, 2:4], acc=_acc(sb))))
 
 
 class GateCat(Function):
@@ -331,17 +408,19 @@ class GateCat(Function):
         ops.gate(a, E[:, 0:1], out=out[:, :ca])
         ops.gate(b, E[:, 1:2], out=out[:, ca:])
         ctx.save_for_backward(a, b, E)
+        ctx.slots = (_slot(a), _slot(b))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         a, b, E = ctx.saved_tensors
+        sa, sb = ctx.slots
         dout = _blk(dout)
         ca = a.shape[1]
         dE = torch.empty_like(E)
-        da, _ = ops.gate_bwd(a, E[:, 0:1], dout[:, :ca], ds_out=dE[:, 0:1])
-        db, _ = ops.gate_bwd(b, E[:, 1:2], dout[:, ca:], ds_out=dE[:, 1:2])
-        return da, db, dE
+        da, _ = ops.gate_bwd(a, E[:, 0:1], dout[:, :ca], ds_out=dE[:, 0:1], acc=_acc(sa))
+        db, _ = ops.gate_bwd(b, E[:, 1:2], dout[:, ca:], ds_out=dE[:, 1:2], acc=_acc(sb))
+        return _ret(sa, da), _ret(sb, db), dE
 
 
 class Gate(Function):
@@ -365,6 +444,7 @@ class GateMaxPool(Function):
 
     @staticmethod
     def forward(ctx, x, a):
+        ctx.slot = _slot(x)
         x, a = x.contiguous(), a.contiguous()
         red = ops.zeros_red(x, x.shape[0], x.shape[1])
         y = ops.gate_maxpool(x, a, red)
@@ -376,7 +456,8 @@ class GateMaxPool(Function):
     @staticmethod
     def backward(ctx, dy, _dred=None):
         x, a = ctx.saved_tensors
-        return ops.gate_maxpool_bwd(x, a, _blk(dy))
+        dx, da = ops.gate_maxpool_bwd(x, a, _blk(dy), acc=_acc(ctx.slot))
+        return _ret(ctx.slot, dx), da
 
 
 class Add(Function):

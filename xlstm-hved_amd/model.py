@@ -98,8 +98,11 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
                 fused = seg and type(rdec.basic_module) is DoubleConv and type(sdec.basic_module) is DoubleConv \
                     and rdec.basic_module.SingleConv1.order == "ilc"
                 if fused:                  # the decoders' last convs hand their output sums to DuSE's channel squeeze
-                    rout, st_r = rdec(feat, rout, out_stats=True)
-                    sout, st_s = sdec(feat, sout, out_stats=True)
+                    # the level's feature has three consumers (recon decoder's concat, seg decoder's pooling and gating):
+                    # aliases that share one gradient buffer (Fn.fanout) instead of two element-wise adds by autograd
+                    f_r, f_p, f_g = Fn.fanout(feat, 3) if sdec.RSM else (feat, feat, feat)
+                    rout, st_r = rdec(f_r, rout, out_stats=True)
+                    sout, st_s = sdec((f_p, f_g) if sdec.RSM else feat, sout, out_stats=True)
                     rout, sout = dusfe(rout, sout, st_r, st_s)
                 else:
                     rout = rdec(feat, rout)
@@ -278,7 +281,9 @@ class AbstractFusion3DUNet(nn.Module):
                 w, b = self._stream_weights(level, "SingleConv2")
                 X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st, out_stats=True)
                 drb = [m[0].conv for m in self.DRBs[level]]
-                feat = Fn.in_lrelu_conv(X, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4, in_stats=st)   # RA_HVED.py:569
+                # this level's output feeds its DRB and (gated, pooled) the next level: two consumers, one gradient buffer
+                X_drb, X = Fn.fanout(X, 2) if (level + 1 < levels and self.skip_return) else (X, X)
+                feat = Fn.in_lrelu_conv(X_drb, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4, in_stats=st)   # RA_HVED.py:569
             else:
                 # 'gcr' (U_HVEDConvNet3D / U_HVEDConvXLSTMNet3D defaults): one stream at a time through the same HIP stages
                 X = [enc(xi) for enc, xi in zip(self.encoders[level], X)]

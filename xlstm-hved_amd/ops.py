@@ -644,27 +644,30 @@ def norm_bwd_fused(mode, dy, x, red, mean, rstd, *, gs=1, gamma=None, dgamma=Non
     return out
 
 
-def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK, c0=0):
-    """InstanceNorm backward of x's channels (window starting at c0 of dy / the statistics) in one launch."""
+def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK, c0=0, acc=None):
+    """InstanceNorm backward of x's channels (window starting at c0 of dy / the statistics) in one launch.  `acc`: an existing
+    gradient buffer of x's shape to ADD the result to (functional.GradSlot) instead of a new tensor."""
     n, c, d, h, w, bs = _vol(x)
     rs = mean.shape[1]
     dyv = dy[:, c0:c0 + c] if dy.shape[1] != c else dy
-    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    out = acc if acc is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
     off = lambda t, scale=1: None if t is None else t.data_ptr() + c0 * scale * t.element_size()
     L.check(L.load().xh_in_bwd_apply(_stream(), _dt(x), _p(dyv), _vol(dyv)[5], _p(x), bs, _p(out), _vol(out)[5], n, c,
                                      d * h * w, off(red, 2), off(mean), off(rstd), rs, int(have_g), off(sc), off(sh), slope,
-                                     0), "xh_in_bwd_apply")
+                                     int(acc is not None)), "xh_in_bwd_apply")
     return out
 
 
-def in_bwd_apply2(dy, xa, xb, red, mean, rstd):
-    """InstanceNorm backward of the virtual concat (xa | xb) from its full-width gradient g = dy, one launch."""
+def in_bwd_apply2(dy, xa, xb, red, mean, rstd, acc_a=None, acc_b=None):
+    """InstanceNorm backward of the virtual concat (xa | xb) from its full-width gradient g = dy, one launch.  acc_a / acc_b:
+    existing gradient buffers to add the respective half to."""
     n, ca, d, h, w, bsa = _vol(xa)
     cb, bsb = xb.shape[1], _vol(xb)[5]
-    da = torch.empty_like(xa, memory_format=torch.contiguous_format)
-    db = torch.empty_like(xb, memory_format=torch.contiguous_format)
+    da = acc_a if acc_a is not None else torch.empty_like(xa, memory_format=torch.contiguous_format)
+    db = acc_b if acc_b is not None else torch.empty_like(xb, memory_format=torch.contiguous_format)
     L.check(L.load().xh_in_bwd_apply2(_stream(), _dt(xa), _p(dy), _vol(dy)[5], _p(xa), bsa, _p(da), _vol(da)[5], ca, _p(xb), bsb,
-                                      _p(db), _vol(db)[5], cb, n, d * h * w, _p(red), _p(mean), _p(rstd)), "xh_in_bwd_apply2")
+                                      _p(db), _vol(db)[5], cb, n, d * h * w, _p(red), _p(mean), _p(rstd),
+                                      int(acc_a is not None) | (int(acc_b is not None) << 1)), "xh_in_bwd_apply2")
     return da, db
 
 
@@ -677,11 +680,11 @@ def maxpool2(x):
     return y
 
 
-def maxpool2_bwd(x, dy):
+def maxpool2_bwd(x, dy, acc=None):
     n, c, d, h, w, _ = _vol(x)
     x, dy = x.contiguous(), dy.contiguous()
-    dx = torch.empty_like(x)
-    L.check(L.load().xh_maxpool2_bwd(_stream(), _dt(x), _p(x), _p(dy), _p(dx), n * c, d, h, w, 0), "xh_maxpool2_bwd")
+    dx = acc if (acc is not None and acc.is_contiguous()) else torch.empty_like(x)
+    L.check(L.load().xh_maxpool2_bwd(_stream(), _dt(x), _p(x), _p(dy), _p(dx), n * c, d, h, w, int(dx is acc)), "xh_maxpool2_bwd")
     return dx
 
 
@@ -748,11 +751,11 @@ def channel_pool(x, out):
     L.check(L.load().xh_channel_pool_fwd(_stream(), _dt(x), _p(x), bs, _p(out), _vol(out)[5], n, c, d * h * w), "xh_channel_pool_fwd")
 
 
-def channel_pool_bwd(x, dy):
+def channel_pool_bwd(x, dy, acc=None):
     n, c, d, h, w, bs = _vol(x)
-    dx = new_like(x, (n, c, d, h, w))
-    L.check(L.load().xh_channel_pool_bwd(_stream(), _dt(x), _p(x), bs, _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5], n, c, d * h * w, 0),
-            "xh_channel_pool_bwd")
+    dx = acc if acc is not None else new_like(x, (n, c, d, h, w))
+    L.check(L.load().xh_channel_pool_bwd(_stream(), _dt(x), _p(x), bs, _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5], n, c, d * h * w,
+                                         int(acc is not None)), "xh_channel_pool_bwd")
     return dx
 
 
@@ -764,13 +767,13 @@ def gate(x, s, out=None):
     return out
 
 
-def gate_bwd(x, s, dy, ds_out=None):
+def gate_bwd(x, s, dy, ds_out=None, acc=None):
     n, c, d, h, w, bs = _vol(x)
-    dx = new_like(x, (n, c, d, h, w))
+    dx = acc if acc is not None else new_like(x, (n, c, d, h, w))
     if ds_out is None:
         ds_out = new_like(x, (n, 1, d, h, w))
     L.check(L.load().xh_gate_bwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5],
-                                 _p(ds_out), _vol(ds_out)[5], n, c, d * h * w, 0, 0), "xh_gate_bwd")
+                                 _p(ds_out), _vol(ds_out)[5], n, c, d * h * w, int(acc is not None), 0), "xh_gate_bwd")
     return dx, ds_out
 
 
@@ -794,13 +797,13 @@ def gate_maxpool(x, s, red=None):
     return y
 
 
-def gate_maxpool_bwd(x, s, dy):
+def gate_maxpool_bwd(x, s, dy, acc=None):
     n, c, d, h, w, bs = _vol(x)
     dy = dy.contiguous()
-    dx = new_like(x, (n, c, d, h, w))
+    dx = acc if acc is not None else new_like(x, (n, c, d, h, w))
     ds = new_like(x, (n, 1, d, h, w))
     L.check(L.load().xh_gate_maxpool_bwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5],
-                                         _p(ds), _vol(ds)[5], n, c, d, h, w), "xh_gate_maxpool_bwd")
+                                         _p(ds), _vol(ds)[5], n, c, d, h, w, int(acc is not None)), "xh_gate_maxpool_bwd")
     return dx, ds
 
 
