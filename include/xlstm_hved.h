@@ -267,6 +267,20 @@ int xh_channel_pool_bwd(void* stream, int dtype, const void* x, long long x_bs, 
 int xh_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y,
                 long long y_bs, int N, int C, long long DHW);
 /* dx (+)= dy*(1+s);  ds (+)= sum_c dy*x */
+/* AttenModule2's two pooled / gated tensors in one launch each (buildingblocks.py:279-299): a = the upsampled seg feature (Ca
+ * channels), b = the encoder feature (Cb).  channel_pool2: y (N, 4, ..) = [max_c a, mean_c a, max_c b, mean_c b]; gate2: y (N,
+ * Ca + Cb, ..) = [a (1 + E[:,0]) | b (1 + E[:,1])], E (N, 2, ..); the backward forms take an accumulate flag per input gradient
+ * (1: += into a buffer that already holds another consumer's share) and gate2_bwd writes dE (N, 2, ..). */
+int xh_channel_pool2_fwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
+                         void* y, long long y_bs, int N, long long DHW);
+int xh_channel_pool2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
+                         const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb, long long dxb_bs, int acc_b,
+                         int N, long long DHW);
+int xh_gate2_fwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb, const void* E,
+                 long long E_bs, void* y, long long y_bs, int N, long long DHW);
+int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb, const void* E,
+                 long long E_bs, const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb, long long dxb_bs,
+                 int acc_b, void* dE, long long dE_bs, int N, long long DHW);
 /* Gate + MaxPool3d(2) in one pass (RA_HVED.py:552 followed by buildingblocks.py:655-657): y = maxpool2(x * (1 + s)), the gated
  * values rounded to the storage type before the maximum (bit-identical to xh_gate_fwd + xh_maxpool2_fwd); red (optional):
  * red[n][c][0..1] += (sum y, sum y^2) of the stored output for the InstanceNorm that follows.  D, H even, W a multiple of 8,
@@ -368,6 +382,16 @@ int xh_compose_atten_bwd(void* stream, const float* seg_w, const float* seg_b, c
                          const float* enc_b, const float* enc2_w, int NS, int NE, int E, int K3, const float* gw,
                          const float* gb, float* d_seg_w, float* d_seg_b, float* d_seg2_w, float* d_seg2_b, float* d_enc_w,
                          float* d_enc_b, float* d_enc2_w, float* d_enc2_b);
+/* All parameter compositions of a step in ONE launch per direction.  Job arrays are host memory, read during the call.
+ *  xh_atten_job: p / g = the eight AttenModule2 parameters / their gradient buffers in the order of xh_compose_atten_fwd; forward
+ *    writes w, b; backward reads gw, gb and ACCUMULATES into g.   xh_duse_job: p / g as xh_compose_duse_fwd; out = {sqw, sqb, adjw,
+ *    adjb}, gout their gradients.   xh_head_job: the segmentation head final_conv o sfinals (RA_HVED.py:192-199,640): wf [Co][Cm],
+ *    bf [Co], ws [Cm][Ci], bs [Cm] -> w [Co][Ci] = wf ws, b = wf bs + bf; backward accumulates dwf, dbf, dws, dbs from gw, gb. */
+#define XH_COMPOSE_MAX 4
+typedef struct { const float* p[8]; float* w; float* b; float* g[8]; const float* gw; const float* gb; int NS, NE, E, K3; } xh_atten_job;
+typedef struct { const float* p[10]; float* out[4]; float* g[10]; const float* gout[4]; int C; } xh_duse_job;
+typedef struct { const float *wf, *bf, *ws, *bs; float *w, *b; float *dwf, *dbf, *dws, *dbs; const float *gw, *gb; int Co, Cm, Ci; } xh_head_job;
+int xh_compose_multi(void* stream, int bwd, int na, const xh_atten_job* aj, int nd, const xh_duse_job* dj, int nh, const xh_head_job* hj);
 int xh_compose_duse_fwd(void* stream, const float* const params[10], int C, float* sqw, float* sqb, float* adjw, float* adjb);
 int xh_compose_duse_bwd(void* stream, const float* const params[10], int C, const float* dsqw, const float* dsqb,
                         const float* dadjw, const float* dadjb, float* const grads[10]);

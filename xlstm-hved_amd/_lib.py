@@ -38,6 +38,20 @@ class ConvPtrs(C.Structure):
     ]
 
 
+class AttenJob(C.Structure):       # == xh_atten_job
+    _fields_ = [("p", vp * 8), ("w", vp), ("b", vp), ("g", vp * 8), ("gw", vp), ("gb", vp), ("NS", C.c_int), ("NE", C.c_int),
+                ("E", C.c_int), ("K3", C.c_int)]
+
+
+class DuseJob(C.Structure):        # == xh_duse_job
+    _fields_ = [("p", vp * 10), ("out", vp * 4), ("g", vp * 10), ("gout", vp * 4), ("C", C.c_int)]
+
+
+class HeadJob(C.Structure):        # == xh_head_job
+    _fields_ = [("wf", vp), ("bf", vp), ("ws", vp), ("bs", vp), ("w", vp), ("b", vp), ("dwf", vp), ("dbf", vp), ("dws", vp),
+                ("dbs", vp), ("gw", vp), ("gb", vp), ("Co", C.c_int), ("Cm", C.c_int), ("Ci", C.c_int)]
+
+
 VIL_FIELDS = ["norm_w", "proj_up", "conv_w", "conv_b", "q_w", "k_w", "v_w", "ig_w", "ig_b", "fg_w", "fg_b",
               "outnorm_w", "skip", "proj_down"]
 
@@ -84,6 +98,10 @@ SIGNATURES = {
     "xh_channel_pool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, I]),
     "xh_gate_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll]),
     "xh_gate_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, ll, I, I]),
+    "xh_channel_pool2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, I, ll]),
+    "xh_channel_pool2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, vp, ll, I, I, ll]),
+    "xh_gate2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, ll]),
+    "xh_gate2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, vp, ll, I, vp, ll, I, vp, ll, I, ll]),
     "xh_gate_maxpool_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, I, I, I, vp]),
     "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I, I]),
     "xh_duse_gate_fwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll]),
@@ -93,6 +111,7 @@ SIGNATURES = {
     "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_compose_atten_fwd": (I, [vp] * 9 + [I, I, I, I, vp, vp]),
     "xh_compose_atten_bwd": (I, [vp] * 7 + [I, I, I, I] + [vp] * 10),
+    "xh_compose_multi": (I, [vp, I, I, vp, I, vp, I, vp]),
     "xh_compose_duse_fwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp]),
     "xh_compose_duse_bwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp, C.POINTER(vp * 10)]),
     "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -242,8 +242,16 @@ class AttenModule2(nn.Module):
         self.seg_spatial = nn.Conv3d(in_cha, self.expan * in_cha, k, stride=1, padding=3, groups=in_cha)
         self.seg_spatial2 = nn.Conv3d(self.expan * in_cha, 1, 1, stride=1)
 
+    def compose_params(self):
+        return (self.seg_spatial.weight, self.seg_spatial.bias, self.seg_spatial2.weight, self.seg_spatial2.bias,
+                self.enc_spatial.weight, self.enc_spatial.bias, self.enc_spatial2.weight, self.enc_spatial2.bias)
+
     def composed(self):
-        """w (2,4,7,7,7): row 0 = seg gate over pooled channels 0,1 (rows 2,3 zero), row 1 = enc gate; b (2,)."""
+        """w (2,4,7,7,7): row 0 = seg gate over pooled channels 0,1 (rows 2,3 zero), row 1 = enc gate; b (2,).  Taken from the
+        step's batched composition (model._precompose -> Fn.ComposeAll) when there is one."""
+        pre = self.__dict__.get("_pre")
+        if pre is not None:
+            return pre
         return Fn.ComposeAtten.apply(2, 4, self.expan, self.seg_spatial.weight, self.seg_spatial.bias, self.seg_spatial2.weight,
                                      self.seg_spatial2.bias, self.enc_spatial.weight, self.enc_spatial.bias,
                                      self.enc_spatial2.weight, self.enc_spatial2.bias)
@@ -343,13 +351,16 @@ class DuSEAttention(nn.Module):
         self.conv_fuse_ch2 = nn.Conv3d(c * 3, c, kernel_size=3, padding=1, bias=True)     # dead in the reference
         self.bn_fuse_ch2 = nn.BatchNorm3d(c)
 
+    def compose_params(self):
+        return (self.conv_comb.weight, self.conv_comb.bias, self.conv_squeeze_ch1.weight, self.conv_squeeze_ch1.bias,
+                self.conv_squeeze_ch2.weight, self.conv_squeeze_ch2.bias, self.conv_adjust_ch1.weight, self.conv_adjust_ch1.bias,
+                self.conv_adjust_ch2.weight, self.conv_adjust_ch2.bias)
+
     def forward(self, inp_ch1, inp_ch2, stats1=None, stats2=None):
         """stats1/stats2 (optional): per-(n,c) fp64 [sum, sum of squares] of the inputs from their producers' epilogues."""
         c = inp_ch1.shape[1]
-        sqw, sqb, adjw, adjb = Fn.ComposeDuSE.apply(
-            c, self.conv_comb.weight, self.conv_comb.bias, self.conv_squeeze_ch1.weight, self.conv_squeeze_ch1.bias,
-            self.conv_squeeze_ch2.weight, self.conv_squeeze_ch2.bias, self.conv_adjust_ch1.weight, self.conv_adjust_ch1.bias,
-            self.conv_adjust_ch2.weight, self.conv_adjust_ch2.bias)
+        pre = self.__dict__.get("_pre")                   # the step's batched composition (model._precompose), if any
+        sqw, sqb, adjw, adjb = pre if pre is not None else Fn.ComposeDuSE.apply(c, *self.compose_params())
         b1, b2 = self.bn_fuse_ch1, self.bn_fuse_ch2
         out = Fn.DuSE.apply(inp_ch1, inp_ch2, stats1, stats2, self.training, b1.running_mean, b1.running_var, b2.running_mean,
                             b2.running_var, self.fc_comb.weight, self.fc_comb.bias, self.fc_ch1.weight, self.fc_ch1.bias,

@@ -1406,6 +1406,209 @@ extern "C" int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_b
   return xh_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------- AttenModule2 pairs
+// AttenModule2 (buildingblocks.py:279-299) pools and gates TWO tensors -- the upsampled seg feature a and the encoder feature b:
+// pooled = [ChannelPool(a) | ChannelPool(b)], out = [a (1 + E0) | b (1 + E1)].  As one launch per tensor that is eight launches
+// per level (two pools, two gates, forward and backward), most of them latency at the 64^3 / 32^3 levels; here each of the four
+// steps is ONE launch whose second grid dimension (lane-per-voxel kernels) or channel range (row kernel) selects the tensor.
+template <typename T> struct Pair2 {
+  const T* x[2]; long long x_bs[2]; int C[2];
+  T* dx[2]; long long dx_bs[2]; int acc[2];
+};
+// y (N, 4, ...): channels 2 w, 2 w + 1 = (max_c, mean_c) of x[w]
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void channel_pool2_fwd_kernel(const Pair2<T> p, T* __restrict__ y, long long y_bs, long long dhw) {
+  const int w = blockIdx.y, C = p.C[w];
+  VOX_LOOP_BEGIN
+    const T* xp = p.x[w] + n * p.x_bs[w];
+    float m[VW], s[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float xv[CB][VW];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          m[v] = (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) ? xv[j][v] : m[v];
+          s[v] += xv[j][v];
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VW; ++v) s[v] = s[v] / (float)C;
+    strow<VEC>(y + n * y_bs + (long long)(2 * w) * dhw, q, valid, m);
+    strow<VEC>(y + n * y_bs + (long long)(2 * w + 1) * dhw, q, valid, s);
+  VOX_LOOP_END
+}
+// dy (N, 4, ...) as above -> dx[w] (+)= the pooled gradients routed back (first maximum; mean to every channel)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void channel_pool2_bwd_kernel(const Pair2<T> p, const T* __restrict__ dy, long long dy_bs, long long dhw) {
+  const int w = blockIdx.y, C = p.C[w], accumulate = p.acc[w];
+  VOX_LOOP_BEGIN
+    const T* xp = p.x[w] + n * p.x_bs[w];
+    float m[VW], g0[VW], g1[VW];
+    int arg[VW];
+    ldrow<VEC>(dy + n * dy_bs + (long long)(2 * w) * dhw, q, valid, g0);
+    ldrow<VEC>(dy + n * dy_bs + (long long)(2 * w + 1) * dhw, q, valid, g1);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; arg[v] = 0; }
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float xv[CB][VW];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v)
+          if (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) { m[v] = xv[j][v]; arg[v] = c0 + j; }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VW; ++v) g1[v] = g1[v] / (float)C;
+    T* dp = p.dx[w] + n * p.dx_bs[w];
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float o[CB][VW];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (accumulate) {
+          ldrow<VEC>((const T*)dp + (long long)min(c0 + j, C - 1) * dhw, q, valid, o[j]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VW; ++v) o[j][v] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) o[j][v] = o[j][v] + g1[v] + (c0 + j == arg[v] ? g0[v] : 0.f);
+        strow<VEC>(dp + (long long)(c0 + j) * dhw, q, valid, o[j]);
+      }
+    }
+  VOX_LOOP_END
+}
+// y (N, C0 + C1, ...) = [x0 (1 + E[:,0]) | x1 (1 + E[:,1])]; grid.y = C0 + C1
+template <typename T, bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void gate2_fwd_kernel(const Pair2<T> p, const T* E, long long E_bs, T* y, long long y_bs, long long dhw) {
+  const int w = (int)blockIdx.y >= p.C[0] ? 1 : 0, cl = blockIdx.y - (w ? p.C[0] : 0);
+  ROW_LOOP_BEGIN
+    float xv[VW], sv[VW];
+    ldrow<VEC>(p.x[w] + n * p.x_bs[w] + (long long)cl * dhw, q, valid, xv);
+    ldrow<VEC>(E + n * E_bs + (long long)w * dhw, q, valid, sv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) xv[i] *= (1.f + sv[i]);
+    strow<VEC>(y + n * y_bs + (long long)c * dhw, q, valid, xv);
+  ROW_LOOP_END
+}
+// dy (N, C0 + C1, ...) -> dx[w] (+)= dy (1 + E[:,w]),  dE[:,w] = sum_c dy x[w]
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void gate2_bwd_kernel(const Pair2<T> p, const T* __restrict__ E, long long E_bs, const T* __restrict__ dy,
+                                                       long long dy_bs, T* dE, long long dE_bs, long long dhw) {
+  const int w = blockIdx.y, C = p.C[w], acc_dx = p.acc[w];
+  const long long dyo = (long long)(w ? p.C[0] : 0) * dhw;
+  VOX_LOOP_BEGIN
+    float g1[VW], a[VW];
+    ldrow<VEC>(E + n * E_bs + (long long)w * dhw, q, valid, g1);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) { g1[v] = 1.f + g1[v]; a[v] = 0.f; }
+    T* dxp = p.dx[w];
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      float g[CB][VW], xv[CB][VW], o[CB][VW];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        const long long off = (long long)min(c0 + j, C - 1) * dhw;
+        ldrow<VEC>(dy + n * dy_bs + dyo + off, q, valid, g[j]);
+        ldrow<VEC>(p.x[w] + n * p.x_bs[w] + off, q, valid, xv[j]);
+        if (acc_dx) {
+          ldrow<VEC>((const T*)dxp + n * p.dx_bs[w] + off, q, valid, o[j]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VW; ++v) o[j][v] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j >= C) break;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          a[v] = fmaf(g[j][v], xv[j][v], a[v]);
+          o[j][v] = g[j][v] * g1[v] + o[j][v];
+        }
+        strow<VEC>(dxp + n * p.dx_bs[w] + (long long)(c0 + j) * dhw, q, valid, o[j]);
+      }
+    }
+    strow<VEC>(dE + n * dE_bs + (long long)w * dhw, q, valid, a);
+  VOX_LOOP_END
+}
+template <typename T>
+static Pair2<T> make_pair2(const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb, void* da, long long da_bs,
+                           int acc_a, void* db, long long db_bs, int acc_b) {
+  Pair2<T> p;
+  p.x[0] = (const T*)xa; p.x[1] = (const T*)xb; p.x_bs[0] = xa_bs; p.x_bs[1] = xb_bs; p.C[0] = Ca; p.C[1] = Cb;
+  p.dx[0] = (T*)da; p.dx[1] = (T*)db; p.dx_bs[0] = da_bs; p.dx_bs[1] = db_bs; p.acc[0] = acc_a; p.acc[1] = acc_b;
+  return p;
+}
+#define PAIR_ARGS_OK (xa && xb && N > 0 && N <= 65535 && Ca > 0 && Cb > 0 && Ca <= 128 && Cb <= 128 && DHW > 0)
+extern "C" int xh_channel_pool2_fwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
+                                    void* y, long long y_bs, int N, long long DHW) {
+  if (!PAIR_ARGS_OK || !y) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, {
+    const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, nullptr, 0, 0, nullptr, 0, 0);
+    dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, y_bs})) hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
+    else hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, false>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
+  });
+  return xh_launch_status();
+}
+extern "C" int xh_channel_pool2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
+                                    const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb, long long dxb_bs,
+                                    int acc_b, int N, long long DHW) {
+  if (!PAIR_ARGS_OK || !dy || !dxa || !dxb) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, {
+    const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, dxa, dxa_bs, acc_a, dxb, dxb_bs, acc_b);
+    dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, dy_bs, dxa_bs, dxb_bs}))
+      hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
+    else hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
+  });
+  return xh_launch_status();
+}
+extern "C" int xh_gate2_fwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
+                            const void* E, long long E_bs, void* y, long long y_bs, int N, long long DHW) {
+  if (!PAIR_ARGS_OK || !E || !y) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, {
+    const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, nullptr, 0, 0, nullptr, 0, 0);
+    const dim3 grid = row_grid<T>(DHW, Ca + Cb, N);
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, y_bs}))
+      hipLaunchKernelGGL((gate2_fwd_kernel<T, true>), grid, dim3(EW_BLOCK), 0, st, p, (const T*)E, E_bs, (T*)y, y_bs, DHW);
+    else hipLaunchKernelGGL((gate2_fwd_kernel<T, false>), grid, dim3(EW_BLOCK), 0, st, p, (const T*)E, E_bs, (T*)y, y_bs, DHW);
+  });
+  return xh_launch_status();
+}
+extern "C" int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
+                            const void* E, long long E_bs, const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb,
+                            long long dxb_bs, int acc_b, void* dE, long long dE_bs, int N, long long DHW) {
+  if (!PAIR_ARGS_OK || !E || !dy || !dxa || !dxb || !dE) return XH_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, {
+    const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, dxa, dxa_bs, acc_a, dxb, dxb_bs, acc_b);
+    dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, dy_bs, dxa_bs, dxb_bs, dE_bs}))
+      hipLaunchKernelGGL((gate2_bwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
+    else hipLaunchKernelGGL((gate2_bwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
+  });
+  return xh_launch_status();
+}
+#undef PAIR_ARGS_OK
+
 // ---------------------------------------------------------------------------------------- gate + max-pool (+ moments)
 // The skip-return attention gates every modality stream, x_i = a * x_i + x_i (RA_HVED.py:552), right before the next encoder
 // pools it (buildingblocks.py:655-657) and normalises the pooled tensor (the first InstanceNorm of the DoubleConv).  As three
@@ -2011,9 +2214,9 @@ struct AttenCompose {
   const float *seg_w, *seg_b, *seg2_w, *seg2_b, *enc_w, *enc_b, *enc2_w, *enc2_b;
   int NS, NE, E, K3;
 };
-__global__ __launch_bounds__(256) void compose_atten_fwd_kernel(AttenCompose a, float* w, float* b) {
+__device__ __forceinline__ void compose_atten_fwd_body(const AttenCompose& a, float* w, float* b, int bx, int nbx) {
   const int total = 2 * a.NE * a.K3;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+  for (int idx = bx * 256 + threadIdx.x; idx < total; idx += nbx * 256) {
     const int tap = idx % a.K3, ci = (idx / a.K3) % a.NE, r = idx / (a.K3 * a.NE);
     const float* w1 = r ? a.enc_w : a.seg_w;
     const float* w2 = r ? a.enc2_w : a.seg2_w;
@@ -2022,7 +2225,7 @@ __global__ __launch_bounds__(256) void compose_atten_fwd_kernel(AttenCompose a, 
       for (int e = 0; e < a.E; ++e) v = fmaf(w2[ci * a.E + e], w1[(long long)(ci * a.E + e) * a.K3 + tap], v);
     w[idx] = v;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 2) {
+  if (bx == 0 && threadIdx.x < 2) {
     const int r = threadIdx.x;
     const float* b1 = r ? a.enc_b : a.seg_b;
     const float* w2 = r ? a.enc2_w : a.seg2_w;
@@ -2032,14 +2235,17 @@ __global__ __launch_bounds__(256) void compose_atten_fwd_kernel(AttenCompose a, 
     b[r] = v;
   }
 }
+__global__ __launch_bounds__(256) void compose_atten_fwd_kernel(AttenCompose a, float* w, float* b) {
+  compose_atten_fwd_body(a, w, b, blockIdx.x, gridDim.x);
+}
 struct AttenComposeGrad { float *seg_w, *seg_b, *seg2_w, *seg2_b, *enc_w, *enc_b, *enc2_w, *enc2_b; };
 // one workgroup per first-stage output channel o (seg: NS*E of them, then enc: NE*E); every gradient is accumulated (+=)
-__global__ __launch_bounds__(256) void compose_atten_bwd_kernel(AttenCompose a, AttenComposeGrad g, const float* gw,
-                                                               const float* gb) {
-  __shared__ float s_red[4];
+__device__ __forceinline__ void compose_atten_bwd_body(const AttenCompose& a, const AttenComposeGrad& g, const float* gw, const float* gb,
+                                                       int bx, float* s_red) {
   const int nso = a.NS * a.E;
-  const int r = (int)blockIdx.x >= nso ? 1 : 0;
-  const int o = r ? blockIdx.x - nso : blockIdx.x;
+  if (bx >= nso + a.NE * a.E) return;                    // (multi-job launches: the grid is sized for the largest job)
+  const int r = bx >= nso ? 1 : 0;
+  const int o = r ? bx - nso : bx;
   const int ci = o / a.E;
   const float* w1 = (r ? a.enc_w : a.seg_w) + (long long)o * a.K3;
   const float w2 = (r ? a.enc2_w : a.seg2_w)[o];
@@ -2058,6 +2264,11 @@ __global__ __launch_bounds__(256) void compose_atten_bwd_kernel(AttenCompose a, 
     (r ? g.enc_b : g.seg_b)[o] += w2 * gb[r];
     if (o == 0) (r ? g.enc2_b : g.seg2_b)[0] += gb[r];
   }
+}
+__global__ __launch_bounds__(256) void compose_atten_bwd_kernel(AttenCompose a, AttenComposeGrad g, const float* gw,
+                                                               const float* gb) {
+  __shared__ float s_red[4];
+  compose_atten_bwd_body(a, g, gw, gb, blockIdx.x, s_red);
 }
 extern "C" int xh_compose_atten_fwd(void* stream, const float* seg_w, const float* seg_b, const float* seg2_w,
                                     const float* seg2_b, const float* enc_w, const float* enc_b, const float* enc2_w,
@@ -2089,7 +2300,7 @@ struct DuseCompose {
   const float *comb_w, *comb_b, *sq1_w, *sq1_b, *sq2_w, *sq2_b, *adj1_w, *adj1_b, *adj2_w, *adj2_b;
   int C;
 };
-__global__ __launch_bounds__(256) void compose_duse_fwd_kernel(DuseCompose a, float* sqw, float* sqb, float* adjw, float* adjb) {
+__device__ __forceinline__ void compose_duse_fwd_body(const DuseCompose& a, float* sqw, float* sqb, float* adjw, float* adjb) {
   const float w0 = a.comb_w[0], w1 = a.comb_w[1];
   for (int j = threadIdx.x; j < 2 * a.C; j += 256) sqw[j] = j < a.C ? w0 * a.sq1_w[j] : w1 * a.sq2_w[j - a.C];
   for (int j = threadIdx.x; j < 54; j += 256) adjw[j] = j < 27 ? a.adj1_w[j] : a.adj2_w[j - 27];
@@ -2099,10 +2310,12 @@ __global__ __launch_bounds__(256) void compose_duse_fwd_kernel(DuseCompose a, fl
     adjb[1] = a.adj2_b[0];
   }
 }
+__global__ __launch_bounds__(256) void compose_duse_fwd_kernel(DuseCompose a, float* sqw, float* sqb, float* adjw, float* adjb) {
+  compose_duse_fwd_body(a, sqw, sqb, adjw, adjb);
+}
 struct DuseComposeGrad { float *comb_w, *comb_b, *sq1_w, *sq1_b, *sq2_w, *sq2_b, *adj1_w, *adj1_b, *adj2_w, *adj2_b; };
-__global__ __launch_bounds__(256) void compose_duse_bwd_kernel(DuseCompose a, DuseComposeGrad g, const float* dsqw,
-                                                              const float* dsqb, const float* dadjw, const float* dadjb) {
-  __shared__ float s_red[4 * 2];
+__device__ __forceinline__ void compose_duse_bwd_body(const DuseCompose& a, const DuseComposeGrad& g, const float* dsqw, const float* dsqb,
+                                                      const float* dadjw, const float* dadjb, float* s_red) {
   const float w0 = a.comb_w[0], w1 = a.comb_w[1];
   float acc[2] = {0.f, 0.f};
   for (int j = threadIdx.x; j < a.C; j += 256) {
@@ -2123,6 +2336,112 @@ __global__ __launch_bounds__(256) void compose_duse_bwd_kernel(DuseCompose a, Du
     g.adj1_b[0] += dadjb[0];
     g.adj2_b[0] += dadjb[1];
   }
+}
+__global__ __launch_bounds__(256) void compose_duse_bwd_kernel(DuseCompose a, DuseComposeGrad g, const float* dsqw,
+                                                              const float* dsqb, const float* dadjw, const float* dadjb) {
+  __shared__ float s_red[4 * 2];
+  compose_duse_bwd_body(a, g, dsqw, dsqb, dadjw, dadjb, s_red);
+}
+
+// ---- all parameter compositions of a step in ONE launch per direction (xh_compose_multi): the three AttenModule2 gates, the
+// three DuSE blocks and the segmentation head final_conv o sfinals were twelve + ~ten launches of one to 24 workgroups each,
+// i.e. pure launch latency (~5 us apiece in a replayed graph).  blockIdx.y = job.
+// head: W[co][ci] = sum_m wf[co][m] ws[m][ci], b[co] = bf[co] + sum_m wf[co][m] bs[m]      (RA_HVED.py:192-199,640: 1x1 o 1x1)
+struct ComposeJobs {
+  int na, nd, nh, bwd;
+  AttenCompose a[XH_COMPOSE_MAX]; AttenComposeGrad ag[XH_COMPOSE_MAX];
+  float* aw[XH_COMPOSE_MAX]; float* ab[XH_COMPOSE_MAX]; const float* agw[XH_COMPOSE_MAX]; const float* agb[XH_COMPOSE_MAX];
+  DuseCompose d[XH_COMPOSE_MAX]; DuseComposeGrad dg[XH_COMPOSE_MAX];
+  float* dout[XH_COMPOSE_MAX][4]; const float* dgout[XH_COMPOSE_MAX][4];
+  xh_head_job h;
+};
+__global__ __launch_bounds__(256) void compose_multi_kernel(const ComposeJobs j) {
+  __shared__ float s_red[4 * 2];
+  const int job = blockIdx.y;
+  if (job < j.na) {
+    if (!j.bwd) compose_atten_fwd_body(j.a[job], j.aw[job], j.ab[job], blockIdx.x, gridDim.x);
+    else compose_atten_bwd_body(j.a[job], j.ag[job], j.agw[job], j.agb[job], blockIdx.x, s_red);
+    return;
+  }
+  if (blockIdx.x != 0) return;
+  if (job < j.na + j.nd) {
+    const int k = job - j.na;
+    if (!j.bwd) compose_duse_fwd_body(j.d[k], j.dout[k][0], j.dout[k][1], j.dout[k][2], j.dout[k][3]);
+    else compose_duse_bwd_body(j.d[k], j.dg[k], j.dgout[k][0], j.dgout[k][1], j.dgout[k][2], j.dgout[k][3], s_red);
+    return;
+  }
+  const xh_head_job& h = j.h;
+  const int t = threadIdx.x;
+  if (!j.bwd) {
+    for (int i = t; i < h.Co * h.Ci; i += 256) {
+      const int co = i / h.Ci, ci = i % h.Ci;
+      float v = 0.f;
+      for (int m = 0; m < h.Cm; ++m) v = fmaf(h.wf[co * h.Cm + m], h.ws[m * h.Ci + ci], v);
+      h.w[i] = v;
+    }
+    for (int co = t; co < h.Co; co += 256) {
+      float v = h.bf[co];
+      for (int m = 0; m < h.Cm; ++m) v = fmaf(h.wf[co * h.Cm + m], h.bs[m], v);
+      h.b[co] = v;
+    }
+  } else {
+    for (int i = t; i < h.Co * h.Cm; i += 256) {          // d wf[co][m] += sum_ci gw[co][ci] ws[m][ci] + gb[co] bs[m]
+      const int co = i / h.Cm, m = i % h.Cm;
+      float v = h.gb[co] * h.bs[m];
+      for (int ci = 0; ci < h.Ci; ++ci) v = fmaf(h.gw[co * h.Ci + ci], h.ws[m * h.Ci + ci], v);
+      h.dwf[i] += v;
+    }
+    for (int i = t; i < h.Cm * h.Ci; i += 256) {          // d ws[m][ci] += sum_co wf[co][m] gw[co][ci]
+      const int m = i / h.Ci, ci = i % h.Ci;
+      float v = 0.f;
+      for (int co = 0; co < h.Co; ++co) v = fmaf(h.wf[co * h.Cm + m], h.gw[co * h.Ci + ci], v);
+      h.dws[i] += v;
+    }
+    for (int m = t; m < h.Cm; m += 256) {
+      float v = 0.f;
+      for (int co = 0; co < h.Co; ++co) v = fmaf(h.wf[co * h.Cm + m], h.gb[co], v);
+      h.dbs[m] += v;
+    }
+    for (int co = t; co < h.Co; co += 256) h.dbf[co] += h.gb[co];
+  }
+}
+extern "C" int xh_compose_multi(void* stream, int bwd, int na, const xh_atten_job* aj, int nd, const xh_duse_job* dj, int nh,
+                                const xh_head_job* hj) {
+  if (na < 0 || nd < 0 || nh < 0 || na > XH_COMPOSE_MAX || nd > XH_COMPOSE_MAX || nh > 1 || na + nd + nh == 0) return XH_ERR_ARG;
+  if ((na && !aj) || (nd && !dj) || (nh && !hj)) return XH_ERR_ARG;
+  ComposeJobs j;
+  j.na = na; j.nd = nd; j.nh = nh; j.bwd = bwd ? 1 : 0;
+  int gx = 1;
+  for (int i = 0; i < na; ++i) {
+    const xh_atten_job& s = aj[i];
+    if (s.NS <= 0 || s.NE < s.NS || s.E <= 0 || s.K3 <= 0) return XH_ERR_ARG;
+    for (int k = 0; k < 8; ++k)
+      if (!s.p[k] || (bwd && !s.g[k])) return XH_ERR_ARG;
+    if (bwd ? (!s.gw || !s.gb) : (!s.w || !s.b)) return XH_ERR_ARG;
+    j.a[i] = AttenCompose{s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.p[5], s.p[6], s.p[7], s.NS, s.NE, s.E, s.K3};
+    j.ag[i] = AttenComposeGrad{s.g[0], s.g[1], s.g[2], s.g[3], s.g[4], s.g[5], s.g[6], s.g[7]};
+    j.aw[i] = s.w; j.ab[i] = s.b; j.agw[i] = s.gw; j.agb[i] = s.gb;
+    const int need = bwd ? (s.NS + s.NE) * s.E : cdiv(2 * s.NE * s.K3, 256);
+    if (need > gx) gx = need;
+  }
+  for (int i = 0; i < nd; ++i) {
+    const xh_duse_job& s = dj[i];
+    if (s.C <= 0) return XH_ERR_ARG;
+    for (int k = 0; k < 10; ++k)
+      if (!s.p[k] || (bwd && !s.g[k])) return XH_ERR_ARG;
+    for (int k = 0; k < 4; ++k)
+      if (bwd ? !s.gout[k] : !s.out[k]) return XH_ERR_ARG;
+    j.d[i] = DuseCompose{s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.p[5], s.p[6], s.p[7], s.p[8], s.p[9], s.C};
+    j.dg[i] = DuseComposeGrad{s.g[0], s.g[1], s.g[2], s.g[3], s.g[4], s.g[5], s.g[6], s.g[7], s.g[8], s.g[9]};
+    for (int k = 0; k < 4; ++k) { j.dout[i][k] = s.out[k]; j.dgout[i][k] = s.gout[k]; }
+  }
+  if (nh) {
+    j.h = *hj;
+    if (!j.h.wf || !j.h.bf || !j.h.ws || !j.h.bs || j.h.Co <= 0 || j.h.Cm <= 0 || j.h.Ci <= 0) return XH_ERR_ARG;
+    if (bwd ? (!j.h.gw || !j.h.gb || !j.h.dwf || !j.h.dbf || !j.h.dws || !j.h.dbs) : (!j.h.w || !j.h.b)) return XH_ERR_ARG;
+  }
+  hipLaunchKernelGGL(compose_multi_kernel, dim3(gx, na + nd + nh), dim3(256), 0, (hipStream_t)stream, j);
+  return xh_launch_status();
 }
 extern "C" int xh_compose_duse_fwd(void* stream, const float* const params[10], int C, float* sqw, float* sqb, float* adjw,
                                    float* adjb) {

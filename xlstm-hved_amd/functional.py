@@ -381,10 +381,7 @@ class ChannelPool2(Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        n, _, d, h, w = a.shape
-        out = ops.new_like(a, (n, 4, d, h, w))
-        ops.channel_pool(a, out[:, 0:2])
-        ops.channel_pool(b, out[:, 2:4])
+        out = ops.channel_pool2(a, b)                          # both tensors in one launch
         ctx.save_for_backward(a, b)
         ctx.slots = (_slot(a), _slot(b))
         return out
@@ -393,9 +390,8 @@ class ChannelPool2(Function):
     def backward(ctx, dout):
         a, b = ctx.saved_tensors
         sa, sb = ctx.slots
-        dout = _blk(dout)
-        return (_ret(sa, ops.channel_pool_bwd(a, dout[:, 0:2], acc=_acc(sa))),
-                _ret(sb, ops.channel_pool_bwd(b, dout[:, 2:4], acc=_acc(sb))))
+        da, db = ops.channel_pool2_bwd(a, b, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb))
+        return _ret(sa, da), _ret(sb, db)
 
 
 class GateCat(Function):
@@ -403,10 +399,7 @@ class GateCat(Function):
 
     @staticmethod
     def forward(ctx, a, b, E):
-        n, ca, d, h, w = a.shape
-        out = ops.new_like(a, (n, ca + b.shape[1], d, h, w))
-        ops.gate(a, E[:, 0:1], out=out[:, :ca])
-        ops.gate(b, E[:, 1:2], out=out[:, ca:])
+        out = ops.gate2(a, b, E)                               # both halves of the concat in one launch
         ctx.save_for_backward(a, b, E)
         ctx.slots = (_slot(a), _slot(b))
         return out
@@ -415,11 +408,7 @@ class GateCat(Function):
     def backward(ctx, dout):
         a, b, E = ctx.saved_tensors
         sa, sb = ctx.slots
-        dout = _blk(dout)
-        ca = a.shape[1]
-        dE = torch.empty_like(E)
-        da, _ = ops.gate_bwd(a, E[:, 0:1], dout[:, :ca], ds_out=dE[:, 0:1], acc=_acc(sa))
-        db, _ = ops.gate_bwd(b, E[:, 1:2], dout[:, ca:], ds_out=dE[:, 1:2], acc=_acc(sb))
+        da, db, dE = ops.gate2_bwd(a, b, E, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb))
         return _ret(sa, da), _ret(sb, db), dE
 
 
@@ -643,6 +632,77 @@ class ComposeAtten(Function):
         grads, rets = _targets(ctx.params)
         ops.compose_atten_bwd(ctx.saved_tensors, ns, ne, e, gw.contiguous(), gb.contiguous(), grads)
         return (None, None, None, *rets)
+
+
+class ComposeAll(Function):
+    """Every parameter composition of a forward in ONE launch, and their backward in one (ops.compose_multi): the AttenModule2
+    gates (ComposeAtten), the DuSE blocks (ComposeDuSE) and the segmentation head final_conv o sfinals.  `plan` = (list of
+    (ns, ne, e) per AttenModule2, list of c per DuSE block, has_head); params = 8 per AttenModule2, 10 per DuSE block, then
+    final_conv.weight (Co, Cm), final_conv.bias, sfinals.weight (Cm, Ci), sfinals.bias.  Returns the flat tuple of composed
+    tensors: (w, b) per AttenModule2, (sqw, sqb, adjw, adjb) per DuSE block, (w, b) of the head."""
+
+    @staticmethod
+    def _jobs(plan, params, outs, bwd, grads=None, gouts=None):
+        a_plan, d_plan, has_head = plan
+        atten, duse, head, pi, oi = [], [], None, 0, 0
+        for ns, ne, e in a_plan:
+            j = dict(params=params[pi:pi + 8], ns=ns, ne=ne, e=e)
+            if bwd:
+                j.update(grads=grads[pi:pi + 8], gw=gouts[oi], gb=gouts[oi + 1])
+            else:
+                j.update(w=outs[oi], b=outs[oi + 1])
+            atten.append(j)
+            pi, oi = pi + 8, oi + 2
+        for c in d_plan:
+            j = dict(params=params[pi:pi + 10], c=c)
+            if bwd:
+                j.update(grads=grads[pi:pi + 10], gout=gouts[oi:oi + 4])
+            else:
+                j.update(out=outs[oi:oi + 4])
+            duse.append(j)
+            pi, oi = pi + 10, oi + 4
+        if has_head:
+            wf, bf, ws, bs = params[pi:pi + 4]
+            head = dict(wf=wf, bf=bf, ws=ws, bs=bs)
+            if bwd:
+                head.update(dwf=grads[pi], dbf=grads[pi + 1], dws=grads[pi + 2], dbs=grads[pi + 3], gw=gouts[oi], gb=gouts[oi + 1])
+            else:
+                head.update(w=outs[oi], b=outs[oi + 1])
+        return atten, duse, head
+
+    @staticmethod
+    def forward(ctx, plan, *params):
+        params = tuple(t.contiguous() for t in params)
+        a_plan, d_plan, has_head = plan
+        dev = params[0].device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        outs, pi = [], 0
+        for ns, ne, e in a_plan:
+            k = params[pi].shape[-1]
+            outs += [new(2, ne, k, k, k), new(2)]
+            pi += 8
+        for c in d_plan:
+            outs += [new(1, 2 * c, 1, 1, 1), new(1), new(2, 1, 3, 3, 3), new(2)]
+            pi += 10
+        if has_head:
+            wf, _, ws, _ = params[pi:pi + 4]
+            outs += [new(wf.shape[0], ws.shape[1], 1, 1, 1), new(wf.shape[0])]
+        ops.compose_multi(False, *ComposeAll._jobs(plan, params, outs, False))
+        ctx.plan, ctx.params = plan, params
+        ctx.save_for_backward(*params)
+        ctx.out_meta = [tuple(o.shape) for o in outs]
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        params = ctx.saved_tensors
+        dev = params[0].device
+        gouts = [g.contiguous() if g is not None else torch.zeros(shape, dtype=torch.float32, device=dev)
+                 for g, shape in zip(gouts, ctx.out_meta)]                      # an unused composed tensor: zero gradient
+        grads, rets = _targets(ctx.params)
+        ops.compose_multi(True, *ComposeAll._jobs(ctx.plan, params, None, True, grads=grads, gouts=gouts))
+        return (None, *rets)
 
 
 class ComposeDuSE(Function):

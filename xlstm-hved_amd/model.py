@@ -115,6 +115,12 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
         return level_outputs, rfinal, (souts if seg else None)
 
 
+def x_is_shared_decoder(model):
+    """One recon stream (shared_recon=True: the training configuration) with a single composed seg head."""
+    sr = getattr(model, "srdecoder", None)
+    return sr is not None and len(sr.multi_decoders) == 1 and len(sr.sfinals) == 1 and all(d.RSM for d in sr.sdecoders)
+
+
 class AbstractFusion3DUNet(nn.Module):
     """RA_HVED.py:239-687."""
 
@@ -221,7 +227,11 @@ class AbstractFusion3DUNet(nn.Module):
         noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
         with self._bn_counters():
             enc = self._encode(x, bn_steps=4)
-            return self._decode(enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list)
+            pre = self._precompose(seg)
+            try:
+                return self._decode(enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list)
+            finally:
+                self._drop_precomposed(pre)
 
     def forward_shared(self, x, calls, seg=True, recon=False):
         """Several forwards of the SAME input that differ only in the modality subset / sampling (train.py:224-225 runs
@@ -232,11 +242,52 @@ class AbstractFusion3DUNet(nn.Module):
         forward() results.  BatchNorm buffers of the skip-return attention advance 4 steps per call, as they would."""
         with self._bn_counters():
             enc = self._encode(x, bn_steps=4 * len(calls))
+            pre = self._precompose(seg)                       # the composed weights are the same for every call
             outs = []
-            for kw in calls:
-                outs.append(self._decode(enc, kw.get("subset_idx_list", [14]), kw.get("instance_missing", False), kw.get("drop"),
-                                         seg, recon, kw.get("valid", False), kw.get("eps_list")))
+            try:
+                for kw in calls:
+                    outs.append(self._decode(enc, kw.get("subset_idx_list", [14]), kw.get("instance_missing", False), kw.get("drop"),
+                                             seg, recon, kw.get("valid", False), kw.get("eps_list")))
+            finally:
+                self._drop_precomposed(pre)
         return outs
+
+    def _precompose(self, seg):
+        """All parameter compositions of the decoders in ONE launch (Fn.ComposeAll): the AttenModule2 gates, the DuSE blocks and
+        the segmentation head, each of which otherwise composes its weights with a launch (or a handful of ATen ops) of its own
+        right before it is used -- and scatters the gradients back with another.  The composed tensors are parked on the modules
+        for the duration of this forward; a module called on its own composes for itself as before."""
+        if not (self.seg_recon_decoder and seg and x_is_shared_decoder(self)):
+            return []
+        sr = self.srdecoder
+        attens = [d.atten_module for d in sr.sdecoders if d.RSM]
+        duses = list(sr.dusfe_decoders)[:len(sr.multi_decoders[0])]
+        if not attens or len(attens) > 4 or len(duses) > 4:
+            return []
+        params = []
+        for a in attens:
+            params += a.compose_params()
+        for d in duses:
+            params += d.compose_params()
+        params += [self.final_conv.weight, self.final_conv.bias, sr.sfinals[0].weight, sr.sfinals[0].bias]
+        plan = ([(2, 4, a.expan) for a in attens], [d.conv_squeeze_ch1.in_channels for d in duses], True)
+        outs = Fn.ComposeAll.apply(plan, *params)
+        mods, oi = [], 0
+        for a in attens:
+            a.__dict__["_pre"] = (outs[oi], outs[oi + 1])
+            oi += 2
+            mods.append(a)
+        for d in duses:
+            d.__dict__["_pre"] = tuple(outs[oi:oi + 4])
+            oi += 4
+            mods.append(d)
+        self.__dict__["_head_pre"] = (outs[oi], outs[oi + 1])
+        return mods
+
+    def _drop_precomposed(self, mods):
+        for m_ in mods:
+            m_.__dict__.pop("_pre", None)
+        self.__dict__.pop("_head_pre", None)
 
     def _bn_counters(self):
         """One flat update of all BatchNorm `num_batches_tracked` counters per forward (blocks.BNCounters)."""
@@ -359,6 +410,9 @@ class AbstractFusion3DUNet(nn.Module):
         """sigmoid(final_conv(cat_i sfinals[i](sout_i))) (RA_HVED.py:192-199,640-641).  With the shared decoder (one stream)
         the two 1x1 convs compose into ONE 1x1 conv.  The composition is parameter-sized fp32 arithmetic and must stay fp32
         under a caller's `with autocast():` (train.py:218), hence the explicit autocast-off region."""
+        pre = self.__dict__.get("_head_pre")
+        if pre is not None and sfinals is not None and len(sfinals) == 1:      # composed in the step's batched launch
+            return Fn.conv(souts[0], [pre[0]], [pre[1]], act=ACT_SIGMOID)
         with torch.autocast(device_type=self.final_conv.weight.device.type, enabled=False):
             wf = self.final_conv.weight.float().view(self.final_conv.out_channels, -1)
             bf = self.final_conv.bias.float()

@@ -780,6 +780,48 @@ def gate_bwd(x, s, dy, ds_out=None, acc=None):
 _GMP = [os.environ.get("XH_NO_GATE_MAXPOOL", "") == ""]          # A/B switch (measurements): the fused gate + max-pool pass
 
 
+# AttenModule2's pooled / gated pairs in one launch each (csrc/eltwise.hip, "AttenModule2 pairs")
+def channel_pool2(a, b):
+    n, ca, d, h, w, bsa = _vol(a)
+    cb, bsb = b.shape[1], _vol(b)[5]
+    y = new_like(a, (n, 4, d, h, w))
+    L.check(L.load().xh_channel_pool2_fwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(y), _vol(y)[5], n, d * h * w),
+            "xh_channel_pool2_fwd")
+    return y
+
+
+def channel_pool2_bwd(a, b, dy, acc_a=None, acc_b=None):
+    n, ca, d, h, w, bsa = _vol(a)
+    cb, bsb = b.shape[1], _vol(b)[5]
+    da = acc_a if acc_a is not None else new_like(a, (n, ca, d, h, w))
+    db = acc_b if acc_b is not None else new_like(b, (n, cb, d, h, w))
+    L.check(L.load().xh_channel_pool2_bwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(dy), _vol(dy)[5], _p(da), _vol(da)[5],
+                                          int(acc_a is not None), _p(db), _vol(db)[5], int(acc_b is not None), n, d * h * w),
+            "xh_channel_pool2_bwd")
+    return da, db
+
+
+def gate2(a, b, E):
+    n, ca, d, h, w, bsa = _vol(a)
+    cb, bsb = b.shape[1], _vol(b)[5]
+    y = new_like(a, (n, ca + cb, d, h, w))
+    L.check(L.load().xh_gate2_fwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(E), _vol(E)[5], _p(y), _vol(y)[5], n, d * h * w),
+            "xh_gate2_fwd")
+    return y
+
+
+def gate2_bwd(a, b, E, dy, acc_a=None, acc_b=None):
+    n, ca, d, h, w, bsa = _vol(a)
+    cb, bsb = b.shape[1], _vol(b)[5]
+    da = acc_a if acc_a is not None else new_like(a, (n, ca, d, h, w))
+    db = acc_b if acc_b is not None else new_like(b, (n, cb, d, h, w))
+    dE = torch.empty_like(E, memory_format=torch.contiguous_format)
+    L.check(L.load().xh_gate2_bwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(E), _vol(E)[5], _p(dy), _vol(dy)[5], _p(da),
+                                  _vol(da)[5], int(acc_a is not None), _p(db), _vol(db)[5], int(acc_b is not None), _p(dE), _vol(dE)[5],
+                                  n, d * h * w), "xh_gate2_bwd")
+    return da, db, dE
+
+
 def gate_maxpool_ok(x, s):
     """Shapes the fused gate + max-pool kernels take (else: gate, maxpool2 and moments one after the other)."""
     n, c, d, h, w, bs = _vol(x)
@@ -850,6 +892,38 @@ def compose_atten_bwd(params, ns, ne, e, gw, gb, grads):
     k3 = seg_w[0].numel()
     L.check(L.load().xh_compose_atten_bwd(_stream(), _p(seg_w), _p(seg_b), _p(seg2_w), _p(enc_w), _p(enc_b), _p(enc2_w), ns, ne, e,
                                           k3, _p(gw), _p(gb), *[_p(g) for g in grads]), "xh_compose_atten_bwd")
+
+
+def compose_multi(bwd, atten, duse, head):
+    """All parameter compositions of a step in one launch (xh_compose_multi).
+    atten: list of dicts(params=8 tensors, ns, ne, e, w, b[, grads=8 buffers, gw, gb]); duse: dicts(params=10, c, out=4[, grads=10,
+    gout=4]); head: dict(wf, bf, ws, bs, w, b[, dwf, dbf, dws, dbs, gw, gb]) or None."""
+    na, nd = len(atten), len(duse)
+    aj = (L.AttenJob * max(na, 1))()
+    for j, a in zip(aj, atten):
+        j.p = (C.c_void_p * 8)(*[_p(t) for t in a["params"]])
+        j.NS, j.NE, j.E, j.K3 = a["ns"], a["ne"], a["e"], a["params"][0][0].numel()
+        if bwd:
+            j.g = (C.c_void_p * 8)(*[_p(t) for t in a["grads"]])
+            j.gw, j.gb = _p(a["gw"]), _p(a["gb"])
+        else:
+            j.w, j.b = _p(a["w"]), _p(a["b"])
+    dj = (L.DuseJob * max(nd, 1))()
+    for j, d in zip(dj, duse):
+        j.p = (C.c_void_p * 10)(*[_p(t) for t in d["params"]])
+        j.C = d["c"]
+        if bwd:
+            j.g = (C.c_void_p * 10)(*[_p(t) for t in d["grads"]])
+            j.gout = (C.c_void_p * 4)(*[_p(t) for t in d["gout"]])
+        else:
+            j.out = (C.c_void_p * 4)(*[_p(t) for t in d["out"]])
+    hj = L.HeadJob()
+    if head is not None:
+        for k in ("wf", "bf", "ws", "bs") + (("dwf", "dbf", "dws", "dbs", "gw", "gb") if bwd else ("w", "b")):
+            setattr(hj, k, _p(head[k]))
+        hj.Co, hj.Cm, hj.Ci = head["wf"].shape[0], head["ws"].shape[0], head["ws"].shape[1]
+    L.check(L.load().xh_compose_multi(_stream(), int(bwd), na, C.cast(aj, C.c_void_p), nd, C.cast(dj, C.c_void_p),
+                                      int(head is not None), C.cast(C.pointer(hj), C.c_void_p)), "xh_compose_multi")
 
 
 def _ptr10(ts):
