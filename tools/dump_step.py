@@ -1,0 +1,12 @@
+"""Launch sequence of the LAST replayed step of a rocprofv3 --kernel-trace CSV: index, duration (us), workgroups, kernel.
+usage: dump_step.py <kernel_trace.csv>"""
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows]; n = len(names)
+per = next(p for p in range(200, n // 2) if names[n - p:] == names[n - 2 * p:n - p])
+for i, r in enumerate(rows[n - per:]):
+    g = 1
+    for ax in "XYZ":
+        g *= int(r[f"Grid_Size_{ax}"]) // max(1, int(r[f"Workgroup_Size_{ax}"]))
+    nm = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"])).replace("at::native::", "").replace("vectorized_elementwise_kernel", "vec_elt")
+    print(f"{i:3d} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:6.1f} {g:6d} {nm[:70]}")
