@@ -202,3 +202,17 @@ void xh_note_kernel(const char* fmt, ...);
 extern int g_xh_disable;     // xh_set_option(2, mask): bit 0 = no sliding-window depthwise kernel, bit 1 = no exact-2x upsample kernels
 static inline int xh_launch_status() { return hipGetLastError() == hipSuccess ? XH_OK : XH_ERR_HIP; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Division of a small non-negative index by a launch constant without the 25-instruction reciprocal sequence:
+// m = udiv_magic(d) on the host, q = udiv_fast(n, d, m) on the device; exact while n * d < 2^32 (hosts check their grids).
+static inline unsigned udiv_magic(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d) + 1u : 0u; }
+__device__ __forceinline__ int udiv_fast(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+
+// sum over the 16 lanes of a DPP row (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); every lane gets it
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
+}

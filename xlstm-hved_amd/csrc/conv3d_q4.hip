@@ -40,6 +40,8 @@ struct ConvQ4 {
   xh_conv_ptrs p;
   int Cin_g, Cout_g, ci4;       // channels per group, input-channel quads per group
   int tilesW, tilesH, tilesD;
+  unsigned mW, mH, mQ;          // reciprocals (udiv_magic) of tilesW, tilesH and of the output quads per group
+  int oq_g, gpp;                // output-channel quads per group, groups per weight pointer
   int dw;                       // depthwise conv presented as groups of 4 channels with diagonal weights (plan, pack only)
   float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
   double fin_inv;               // 1 / fin_count
@@ -77,15 +79,14 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   const int nn = lane & 15, g4 = lane >> 4;
   const int oq = blockIdx.y, n = blockIdx.z;
   const int co0 = oq * 4;
-  const int grp = co0 / a.Cout_g;
+  const int grp = udiv_fast(oq, a.oq_g, a.mQ);
   const int cin_base = grp * a.Cin_g;
   const int D = a.d.D, H = a.d.H, W = a.d.W;
   const long long hw = (long long)H * W, dhw = (long long)D * hw;
   const int Do = a.d.Do, Ho = a.d.Ho;
-  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tw = wk % a.tilesW; wk /= a.tilesW;
-  const int th = wk % a.tilesH;
-  const int td = wk / a.tilesH;
+  const int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int wk1 = udiv_fast(wk, a.tilesW, a.mW), tw = wk - wk1 * a.tilesW;
+  const int td = udiv_fast(wk1, a.tilesH, a.mH), th = wk1 - td * a.tilesH;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
   if (a.abl & 4096) return;
   // raw InstanceNorm sums of this group's input channels (fused finalisation): requested first, used behind the staging loads

@@ -21,15 +21,6 @@
 typedef short s4_t __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
-// sum over the 16 lanes of a DPP row (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); every lane gets it
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-  return v;
-}
-
 struct DTaps { int n; int t[4]; int off[4]; };
 
 // One class of destination voxels.  Forward / stride-1 data gradient: a single class = all of them.  Stride-2 data gradient:

@@ -485,6 +485,7 @@ class SkipReturnAttention(Function):
         ctx.save_for_backward(x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2)
         ctx.mode = mode
         ctx.params = (dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2)
+        ctx.saw = saw
         return a
 
     @staticmethod
@@ -515,8 +516,11 @@ class SkipReturnAttention(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(du1, None, [dw1], None, k=3, cout=c, groups=c, transposed=True)
             dx = ops.add(dx, dx_res, out=dx)
-        dsaw_t = dsaw.to(torch.float32).reshape(1, 2, 1, 1, 1)
-        return (dx, None, None, None, None, None, None, *rets, dsaw_t)
+        # the 1x1 attention conv's two weight gradients (fp64 sums): straight into the parameter's gradient buffer (one launch
+        # instead of a cast + autograd's accumulate)
+        (g_saw,), (r_saw,) = _targets((ctx.saw,))
+        g_saw.view(-1).add_(dsaw)
+        return (dx, None, None, None, None, None, None, *rets, r_saw)
 
 
 class DuSE(Function):
