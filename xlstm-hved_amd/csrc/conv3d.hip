@@ -50,20 +50,26 @@ __device__ __forceinline__ const T* epi_plane(const ConvK& a, int n, int c, long
 
 // Epilogue for NV consecutive outputs of one (n, c) row starting at spatial offset `sp`; `valid` = how many of
 // them exist.  Returns partial sums through s0/s1.
-template <typename T, int NV>
+// MODE >= 0: the epilogue variant is a compile-time constant (MODE = xh_conv_desc.epi, no activation); MODE < 0: both are read
+// from the descriptor at run time -- a switch per output value, which for a lane with 64 outputs compiles to a branch forest
+// of several thousand instructions (the k = 1 kernel spent 6 of its 11 us there).  ALIGNED: the launch plan has checked that
+// every run is complete and 16-byte aligned (no scalar fallback paths in the code).
+template <typename T, int NV, int MODE = -1, bool ALIGNED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long long odhw, long long sp, int valid,
                                               float bias, float (&val)[NV], double& s0, double& s1) {
   T* yp = (T*)a.p.y + n * a.d.y_bs + (long long)c * odhw + sp;
   // whole-vector accesses (16 B, or 8 B for 4 bf16) when the run is complete and aligned
   constexpr bool WIDE = NV == VWT<T>::v;
-  const bool vec = (NV == 4 || WIDE) && valid == NV && ((odhw | sp) % NV) == 0;
+  const bool vec = ALIGNED || ((NV == 4 || WIDE) && valid == NV && ((odhw | sp) % NV) == 0);
+  if (ALIGNED) valid = NV;
+  const int epi = MODE >= 0 ? MODE : a.d.epi;
   float ev[NV];
   float esc = 0.f, esh = 0.f;
-  if (a.d.epi == 1) {
+  if (epi == 1) {
     esc = a.p.e_sc[n * a.d.Cout + c];
     esh = a.p.e_sh[n * a.d.Cout + c];
     const T* ep = epi_plane<T>(a, n, c, odhw) + sp;
-    if (vec && ((a.d.ea_bs | a.d.eb_bs) % NV) == 0) {
+    if (ALIGNED || (vec && ((a.d.ea_bs | a.d.eb_bs) % NV) == 0)) {
       if constexpr (WIDE) {
         ldvec(ep, 0, ev);
       } else if constexpr (NV == 4) {
@@ -77,13 +83,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long
   float t0 = 0.f, t1 = 0.f;       // this run in fp32; the lane's running sums are fp64 (statistics precision, common.h)
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    float o = apply_act(val[v] + bias, a.d.act, a.d.act_slope);
+    float o = MODE >= 0 ? val[v] + bias : apply_act(val[v] + bias, a.d.act, a.d.act_slope);
     if (v < valid) {
-      if (a.d.epi == 1) {
+      if (epi == 1) {
         o = rnd_as(yp, o * ((ev[v] * esc + esh) > 0.f ? 1.f : a.d.e_slope));
         t0 += o;
         t1 += o * ev[v];
-      } else if (a.d.epi == 2) {
+      } else if (epi == 2) {
         o = rnd_as(yp, o);
         t0 += o;
         t1 += o * o;
@@ -91,8 +97,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long
     }
     val[v] = o;
   }
-  if (a.d.epi) { s0 += (double)t0; s1 += (double)t1; }
-  if (vec && (a.d.y_bs % NV) == 0) {
+  if (epi) { s0 += (double)t0; s1 += (double)t1; }
+  if (ALIGNED || (vec && (a.d.y_bs % NV) == 0)) {
     if constexpr (WIDE) {
       stvec(yp, 0, val);
     } else if constexpr (NV == 4) {
@@ -480,7 +486,8 @@ __global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int 
 // ---------------------------------------------------------------------------------------------------
 // k = 1 forward / dgrad: no halo, inputs straight from global memory (4 voxels per lane, vectorised).
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int COB, bool VEC, int CIC = 4>   // CIC input channels per step: their loads are issued together
+// MODE: see conv_epilogue (>= 0: no activation, epilogue variant MODE, straight-line code)
+template <typename T, int COB, bool VEC, int CIC = 4, int MODE = -1>   // CIC input channels per step: their loads are issued together
 __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
   constexpr int VW = VEC ? VWT<T>::v : 4;              // 16-byte runs when the layout allows
   __shared__ float s_w[132 * COB];
@@ -494,6 +501,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
     const int co = idx % COB, ci_g = idx / COB, co_g = cob * COB + co;
     s_w[idx] = (co_g < a.Cout_g && ci_g < a.Cin_g) ? conv_weight(a, g, co_g, ci_g, 0, 1) : 0.f;   // pad rows: zero weight
   }
+  float bias[COB];                                      // requested before the barrier: not a round trip of its own in the epilogue
+#pragma unroll
+  for (int co = 0; co < COB; ++co) bias[co] = cob * COB + co < a.Cout_g ? conv_bias(a, g, cob * COB + co) : 0.f;
   __syncthreads();
   double s0[COB], s1[COB];
 #pragma unroll
@@ -539,11 +549,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
       const int co_g = cob * COB + co;
       if (co_g < a.Cout_g) {
         const int c = g * a.Cout_g + co_g;
-        conv_epilogue<T, VW>(a, n, c, dhw, q0, valid, conv_bias(a, g, co_g), acc[co], s0[co], s1[co]);
+        conv_epilogue<T, VW, MODE, VEC>(a, n, c, dhw, q0, valid, bias[co], acc[co], s0[co], s1[co]);
       }
     }
   }
-  if (a.d.epi) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
+  if (MODE >= 0 ? MODE != 0 : a.d.epi != 0) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1155,6 +1165,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     constexpr int VW1 = VWT<T>::v;
     const bool vec = (dhw % VW1 == 0) && (d->xa_bs % VW1 == 0) && (d->xb_bs % VW1 == 0) && (d->y_bs % VW1 == 0) &&
                      (d->epi != 1 || (d->ea_bs % VW1 == 0 && d->eb_bs % VW1 == 0));
+    const int mode = d->act == XH_ACT_NONE ? d->epi : -1;   // compile-time epilogue for the common no-activation launches
     long long gx1 = (dhw + 256 * VW1 - 1) / (256 * VW1);
     // few lanes (the deep levels): the run time is the per-lane chain of Cin/CIC dependent load steps, so take narrow
     // output blocks (more workgroups) with 16 channels in flight per step
@@ -1163,21 +1174,31 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
       dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
       if (d->epi) a.fan = xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x);
       xh_note_kernel("conv1x1_kernel<%s, 2, true, 16>", tname<T>());
-      hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      switch (mode) {
+        case 0: hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16, 0>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 1: hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16, 1>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16, 2>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL((conv1x1_kernel<T, 2, true, 16, -1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      }
       return xh_launch_status();
     }
     const long long cap1 = cdiv(g_c1_cap > 0 ? g_c1_cap : 2048, a.ncob * d->N * d->groups);
     if (gx1 > cap1) gx1 = cap1;
     dim3 grid((unsigned)gx1, a.ncob, d->N * d->groups);
     if (d->epi) a.fan = xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x);
+#define L1M(COB, M) hipLaunchKernelGGL((conv1x1_kernel<T, COB, true, 4, M>), grid, dim3(256), 0, (hipStream_t)stream, a)
 #define L1(COB)                                                                                                  \
   do {                                                                                                           \
     xh_note_kernel("conv1x1_kernel<%s, %d, %s>", tname<T>(), COB, vec ? "true" : "false");                       \
-    if (vec) hipLaunchKernelGGL((conv1x1_kernel<T, COB, true>), grid, dim3(256), 0, (hipStream_t)stream, a);     \
-    else hipLaunchKernelGGL((conv1x1_kernel<T, COB, false>), grid, dim3(256), 0, (hipStream_t)stream, a);        \
+    if (!vec) hipLaunchKernelGGL((conv1x1_kernel<T, COB, false>), grid, dim3(256), 0, (hipStream_t)stream, a);   \
+    else if (mode == 0) L1M(COB, 0);                                                                             \
+    else if (mode == 1) L1M(COB, 1);                                                                             \
+    else if (mode == 2) L1M(COB, 2);                                                                             \
+    else L1M(COB, -1);                                                                                           \
   } while (0)
     switch (cob) { case 1: L1(1); break; case 2: L1(2); break; case 4: L1(4); break; default: L1(8); }
 #undef L1
+#undef L1M
     return xh_launch_status();
   }
   const int txn = pick_txn(d->Wo);

@@ -40,7 +40,7 @@ struct ConvQ4 {
   xh_conv_ptrs p;
   int Cin_g, Cout_g, ci4;       // channels per group, input-channel quads per group
   int tilesW, tilesH, tilesD;
-  unsigned mW, mH, mQ;          // reciprocals (udiv_magic) of tilesW, tilesH and of the output quads per group
+  unsigned mW, mH, mQ, mG;      // reciprocals (udiv_magic) of tilesW, tilesH, oq_g, gpp
   int oq_g, gpp;                // output-channel quads per group, groups per weight pointer
   int dw;                       // depthwise conv presented as groups of 4 channels with diagonal weights (plan, pack only)
   float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   }
 
   // ---- staging plan (the same for every input-channel quad) ----
-  unsigned i_off[2];            // element offset of the item's 8 voxels inside a channel volume (clamped into the volume)
+  unsigned i_off[2];            // byte offset of the item's 8 voxels inside a channel volume (clamped into the volume)
   int i_lds[2];                 // LDS byte address of the item's first 16-byte chunk, before the per-chunk XOR
   int i_par[2];
   bool i_live[2], i_do[2];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy;
     i_live[it] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
     const int gdc = min(max(gd, 0), D - 1), ghc = min(max(gh, 0), H - 1);
-    i_off[it] = (unsigned)(((long long)gdc * H + ghc) * W + ow0 + gq * 8);
+    i_off[it] = (unsigned)((((long long)gdc * H + ghc) * W + ow0 + gq * 8) * (long long)sizeof(ST));
     i_lds[it] = row * PITCH;
     i_par[it] = (row & 1) | ((1 + 4 * gq) << 1);           // bit 0: row parity, rest: first 16-byte slot of the item
   }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     const int gw = side ? ow0 + TW : ow0 - 2;
     e_live = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
     const int gdc = min(max(gd, 0), D - 1), ghc = min(max(gh, 0), H - 1), gwc = min(max(gw, 0), W - 2);
-    e_off = (unsigned)(((long long)gdc * H + ghc) * W + gwc);
+    e_off = (unsigned)((((long long)gdc * H + ghc) * W + gwc) * (long long)sizeof(ST));
     e_lds = row * PITCH + (((side ? 17 : 0) ^ (row & 1)) << 4);
   }
   // ---- B (data) fragment addresses: lane (nn, g4) reads quad (r, qw) of a 2-row x 32-voxel unit; the quad order and the
@@ -134,43 +134,78 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   const int rowbase = (2 * wv + ur) * PITCH;
   const int b_off0 = rowbase + ((2 * qw + g4) ^ ur) * 16;          // rows whose parity equals ur's (kh = 0, 2)
   const int b_off1 = rowbase + ((2 * qw + g4) ^ ur ^ 1) * 16;      // kh = 1
-  // ---- epilogue lane role ----
-  const int co = co0 + g4;
+  // ---- epilogue lane role: lane (quad, channel) owns 4 consecutive voxels of one output row; everything that differs
+  // between lanes is ONE 32-bit byte offset (a.d: dhw < 2^29), the rest of every address is scalar ----
   const int oh = oh0 + 2 * wv + ur;
-  const int owl = ow0 + 4 * qw;
   const bool row_ok = oh < Ho;
+  const int ndz = min(TD, Do - od0);                  // output planes of this tile inside the volume
   float bias = 0.f, esc = 0.f, esh = 0.f;
   {
-    const int gpp = a.d.groups / a.d.n_wptr;
-    const float* bp = a.p.b[grp / gpp];
-    if (bp) bias = bp[(grp % gpp) * a.Cout_g + co % a.Cout_g];
+    const int wp = udiv_fast(grp, a.gpp, a.mG);
+    const float* bp = a.p.b[wp];
+    if (bp) bias = bp[(grp - wp * a.gpp) * a.Cout_g + (oq - grp * a.oq_g) * 4 + g4];
   }
   const long long odhw = (long long)Do * Ho * a.d.Wo;
-  const ST* eplane = nullptr;
+  const unsigned spd_b = (unsigned)(Ho * a.d.Wo) * (unsigned)sizeof(ST);                       // bytes per output plane
+  const unsigned lane_b = (unsigned)(((long long)g4 * odhw + (long long)(row_ok ? oh : 0) * a.d.Wo + ow0 + 4 * qw) * (long long)sizeof(ST));
+  const char* ebase = nullptr;
   if (EPI == 1) {
-    esc = a.p.e_sc[n * a.d.Cout + co];
-    esh = a.p.e_sh[n * a.d.Cout + co];
-    eplane = co < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co * odhw
-                          : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co - a.d.Cea) * odhw;
+    esc = a.p.e_sc[n * a.d.Cout + co0 + g4];
+    esh = a.p.e_sh[n * a.d.Cout + co0 + g4];
+    // a quad never straddles the ea / eb boundary (Cea % 4 == 0)
+    ebase = reinterpret_cast<const char*>(co0 < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co0 * odhw
+                                                        : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co0 - a.d.Cea) * odhw) +
+            (long long)od0 * spd_b;
   }
-  ST* yplane = (ST*)a.p.y + n * a.d.y_bs + (long long)co * odhw;
-  const long long sp0 = ((long long)od0 * Ho + (row_ok ? oh : 0)) * a.d.Wo + owl;   // + dz * Ho * Wo
-  const long long spd = (long long)Ho * a.d.Wo;
+  char* ybase = reinterpret_cast<char*>((ST*)a.p.y + n * a.d.y_bs + (long long)co0 * odhw) + (long long)od0 * spd_b;
 
-  // MULTI = more than one input-channel quad per group: the accumulators live across the quad loop (and across its staging
-  // phases: ~30 more registers in flight); the single-quad instances are straight-line code
   f32x4 acc[TD];
 #pragma unroll
   for (int i = 0; i < TD; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ncq = MULTI ? a.ci4 : 1;
   uint2 eraw[TD];
+  // statistics of this lane: packed fp32 partial sums over its 32 values (the planes of one row); fp64 from the workgroup
+  // level on (16-bit storage: the 2^-24 of a 512-term fp32 partial is far below the storage rounding of every term)
+  f32x2_t ps = {0.f, 0.f}, pq = {0.f, 0.f};
+  const f32x2_t aslope2 = {a.act_slope, a.act_slope}, bias2 = {bias, bias}, esc2 = {esc, esc}, esh2 = {esh, esh};
+  const float eslope = a.d.e_slope;
+  auto epi_load = [&](int dz) {
+    if (EPI == 1 && dz < ndz) eraw[dz] = *reinterpret_cast<const uint2*>(ebase + (unsigned)dz * spd_b + lane_b);
+  };
+  auto epi_do = [&](int dz) {
+    if (dz >= ndz) return;                            // uniform
+    f32x2_t v[2] = {f32x2_t{acc[dz][0], acc[dz][1]} + bias2, f32x2_t{acc[dz][2], acc[dz][3]} + bias2};
+    if (ACT) { v[0] = max2(v[0], v[0] * aslope2); v[1] = max2(v[1], v[1] * aslope2); }
+    uint2 pk;
+    if (EPI == 1) {
+      const f32x2_t e[2] = {cvt2_in<FMT>(eraw[dz].x), cvt2_in<FMT>(eraw[dz].y)};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x2_t z = e[q] * esc2 + esh2, vs = v[q] * f32x2_t{eslope, eslope};
+        v[q] = f32x2_t{z.x > 0.f ? v[q].x : vs.x, z.y > 0.f ? v[q].y : vs.y};
+      }
+      pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
+      const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);           // the values as stored
+      ps += r0 + r1;
+      pq += r0 * e[0] + r1 * e[1];
+    } else {
+      pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
+      if (EPI == 2) {
+        const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);
+        ps += r0 + r1;
+        pq += r0 * r0 + r1 * r1;
+      }
+    }
+    if (row_ok) *reinterpret_cast<uint2*>(ybase + (unsigned)dz * spd_b + lane_b) = pk;
+  };
 
   const float pslope = a.d.pre_slope;
   const bool fin = PRE && a.p.fin_red != nullptr;
   for (int cq = 0; cq < ncq; ++cq) {
     const int c0 = cin_base + cq * 4;
-    const ST* src = c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
-                                : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw;
+    const char* src = reinterpret_cast<const char*>(c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
+                                                                  : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw);
+    const long long dhw_b = dhw * (long long)sizeof(ST);
     // ---- all global loads of this thread, back to back ----
     uint4 raw[2][4];
     unsigned eraw4[4];
@@ -178,9 +213,9 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     for (int it = 0; it < 2; ++it)
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc)
-        raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * dhw + i_off[it]);
+        raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * dhw_b + i_off[it]);
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) eraw4[cc] = *reinterpret_cast<const unsigned*>(src + cc * dhw + e_off);
+    for (int cc = 0; cc < 4; ++cc) eraw4[cc] = *reinterpret_cast<const unsigned*>(src + cc * dhw_b + e_off);
     if (cq > 0) __syncthreads();                      // every wave is done reading the previous quad's tile
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (PRE) {
@@ -277,10 +312,13 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     }
     __syncthreads();
     if (a.abl & 8192) continue;
-    // ---- matrix phase: the wave's two output rows, walking the 10 staged planes once ----
-    if (!(a.abl & 4)) {
+    // ---- matrix phase: the wave's two output rows, walking the 10 staged planes once.  Single-quad instances run the
+    // epilogue of output plane pz - 2 (complete after staged plane pz) inside the walk: its loads are requested two planes
+    // ahead, its vector instructions and stores issue in the shadow of the matrix instructions of the planes that follow ----
+    {
 #pragma unroll
       for (int pz = 0; pz < ID; ++pz) {
+        if (!MULTI && pz < TD) epi_load(pz);
         frag8 bf[3];
         bf[0] = *reinterpret_cast<const frag8*>(smem + pz * PLANE + b_off0);
         bf[1] = *reinterpret_cast<const frag8*>(smem + pz * PLANE + PITCH + b_off1);
@@ -292,54 +330,22 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) acc[dz] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh], acc[dz]);
         }
+        if (!MULTI && pz >= 2) epi_do(pz - 2);
       }
     }
   }
   if (a.abl & 8192) return;
 
-  // ---- epilogue straight from the accumulators: lane (quad, channel) owns 4 consecutive voxels ----
-  if (EPI == 1) {                                     // the raw pre-norm values the norm backward multiplies with
+  if (MULTI) {                                        // accumulators complete only after the last input quad
 #pragma unroll
-    for (int dz = 0; dz < TD; ++dz) {
-      const int od = min(od0 + dz, Do - 1);
-      eraw[dz] = *reinterpret_cast<const uint2*>(eplane + ((long long)od * Ho + (row_ok ? oh : 0)) * a.d.Wo + owl);
-    }
-  }
-  double s0 = 0.0, s1 = 0.0;
-  const f32x2_t aslope2 = {a.act_slope, a.act_slope}, bias2 = {bias, bias}, esc2 = {esc, esc}, esh2 = {esh, esh};
-  const float eslope = a.d.e_slope;
+    for (int dz = 0; dz < TD; ++dz) epi_load(dz);
 #pragma unroll
-  for (int dz = 0; dz < TD; ++dz) {
-    if (od0 + dz >= Do || !row_ok) continue;
-    f32x2_t v[2] = {f32x2_t{acc[dz][0], acc[dz][1]} + bias2, f32x2_t{acc[dz][2], acc[dz][3]} + bias2};
-    if (ACT) { v[0] = max2(v[0], v[0] * aslope2); v[1] = max2(v[1], v[1] * aslope2); }
-    uint2 pk;
-    if (EPI == 1) {
-      const f32x2_t e[2] = {cvt2_in<FMT>(eraw[dz].x), cvt2_in<FMT>(eraw[dz].y)};
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x2_t z = e[q] * esc2 + esh2;
-        v[q] = v[q] * f32x2_t{z.x > 0.f ? 1.f : eslope, z.y > 0.f ? 1.f : eslope};
-      }
-      pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
-      const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);           // the values as stored
-      const f32x2_t t = r0 + r1, tt = r0 * e[0] + r1 * e[1];
-      s0 += (double)(t.x + t.y); s1 += (double)(tt.x + tt.y);
-    } else {
-      pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
-      if (EPI == 2) {
-        const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);
-        const f32x2_t t = r0 + r1, tt = r0 * r0 + r1 * r1;
-        s0 += (double)(t.x + t.y); s1 += (double)(tt.x + tt.y);
-      }
-    }
-    *reinterpret_cast<uint2*>(yplane + sp0 + dz * spd) = pk;
+    for (int dz = 0; dz < TD; ++dz) epi_do(dz);
   }
   if (EPI) {
-    // lanes of one channel: the 16 lanes nn = 0..15 of a lane group g4
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
-    if (nn == 0) { s_red[wv * 8 + g4 * 2] = s0; s_red[wv * 8 + g4 * 2 + 1] = s1; }
+    // lanes of one channel: the 16 lanes nn = 0..15 of a lane group g4 = one DPP row
+    const float t0 = row16_sum(row_ok ? ps.x + ps.y : 0.f), t1 = row16_sum(row_ok ? pq.x + pq.y : 0.f);
+    if (nn == 0) { s_red[wv * 8 + g4 * 2] = (double)t0; s_red[wv * 8 + g4 * 2 + 1] = (double)t1; }
     __syncthreads();
     // the 8 channel sums of the workgroup, then the two-level fan-in of fanin.h (one fp64 atomic per workgroup and value on
     // red[] is 1024 .. 4096 requests on ONE cache line, retired one after the other: 8 us of a 22 us launch)
@@ -375,7 +381,7 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if (d->epi == 1 && d->Cea % 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
-  if (dhw % 8 || dhw >= (1ll << 31)) return false;
+  if (dhw % 8 || dhw >= (1ll << 29)) return false;      // 32-bit byte offsets inside a quad of channel volumes
   if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
   float as = 1.f;
   if (d->act == XH_ACT_RELU) as = 0.f;
@@ -389,6 +395,10 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if (dw) a->d.groups = d->groups / 4;
   a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cin_g / 4;
   a->tilesW = d->W / TW; a->tilesH = cdiv(d->Ho, TH); a->tilesD = cdiv(d->Do, TD);
+  a->oq_g = cout_g / 4; a->gpp = a->d.groups / d->n_wptr;
+  // udiv_fast is exact while index * divisor < 2^32
+  if ((long long)a->tilesW * a->tilesH * a->tilesD * (a->tilesW > a->tilesH ? a->tilesW : a->tilesH) >= (1ll << 32)) return false;
+  a->mW = udiv_magic(a->tilesW); a->mH = udiv_magic(a->tilesH); a->mQ = udiv_magic(a->oq_g); a->mG = udiv_magic(a->gpp);
   a->act_slope = as;
   a->abl = g_mfma_abl;
   return true;

@@ -780,9 +780,26 @@ __device__ __forceinline__ void sthalf(float* p, long long q, const float (&o)[2
   *reinterpret_cast<float2*>(p + q) = make_float2(o[0], o[1]);
 }
 template <int F> __device__ __forceinline__ void sthalf(h16<F>* p, long long q, const float (&o)[4]) { st4(p, q, o); }
+// the same runs as raw registers (requested one plane ahead of their use: 2 / 4 registers per run in flight) and their conversion
+template <typename T> __device__ __forceinline__ uint2 ldraw8(const T* p, long long q) { return *reinterpret_cast<const uint2*>(p + q); }
+template <typename T> __device__ __forceinline__ uint4 ldraw16(const T* p, long long q) { return *reinterpret_cast<const uint4*>(p + q); }
+__device__ __forceinline__ void cvtraw(const float*, uint2 t, float (&o)[2]) { o[0] = __uint_as_float(t.x); o[1] = __uint_as_float(t.y); }
+template <int F> __device__ __forceinline__ void cvtraw(const h16<F>*, uint2 t, float (&o)[4]) {
+  o[0] = cvt_lo<F>(t.x); o[1] = cvt_hi<F>(t.x); o[2] = cvt_lo<F>(t.y); o[3] = cvt_hi<F>(t.y);
+}
+__device__ __forceinline__ void cvtraw(const float*, uint4 t, float (&o)[4]) {
+  o[0] = __uint_as_float(t.x); o[1] = __uint_as_float(t.y); o[2] = __uint_as_float(t.z); o[3] = __uint_as_float(t.w);
+}
+template <int F> __device__ __forceinline__ void cvtraw(const h16<F>*, uint4 t, float (&o)[8]) {
+  const unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { o[2 * k] = cvt_lo<F>(u[k]); o[2 * k + 1] = cvt_hi<F>(u[k]); }
+}
 
+// Both kernels march through the planes of a depth segment; a plane's rows are REQUESTED one step before they are used (raw
+// registers), so the march is not a chain of exposed memory round trips (sd + 2 of them: 10 us for any volume before).
 template <typename T, int TXN>
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C, int D,
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, long long x_bs, T* __restrict__ y, long long y_bs, int C, int D,
                                                             int H, int W, int sd, int tilesW, int tilesH) {
   constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
   const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
@@ -804,15 +821,20 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* x, long lo
   const bool edge_l = tx == 0, edge_r = tx == TXN - 1 || w0 + VI >= W;
   const bool glob_l = edge_l && tilesW > 1 && w0 > 0, glob_r = edge_r && tilesW > 1 && w0 + VI < W;
   float prev[2][VO], cur[2][VO];
+  const int ro[3] = {r0, r1, r2};
+  uint2 raw[3], nxt[3];
+  const T* pl = src + (long long)min(max(d_begin - 1, 0), D - 1) * hw;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) raw[k] = ldraw8(pl, ro[k] + wc);
   for (int p = d_begin - 1; p <= d_end; ++p) {
-    const int pc = min(max(p, 0), D - 1);
-    const T* pl = src + (long long)pc * hw;
+    const T* pn = src + (long long)min(max(p + 1, 0), D - 1) * hw;      // clamped: always a valid plane, unused past d_end
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nxt[k] = ldraw8(pn, ro[k] + wc);
     float rows[3][VI + 2];
-    const int ro[3] = {r0, r1, r2};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float v[VI];
-      ldhalf(pl, ro[k] + wc, v);
+      cvtraw(pl, raw[k], v);
 #pragma unroll
       for (int j = 0; j < VI; ++j) rows[k][j + 1] = v[j];
       float l = __shfl_up(v[VI - 1], 1, 64), r = __shfl_down(v[0], 1, 64);
@@ -821,6 +843,9 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* x, long lo
       rows[k][0] = l;
       rows[k][VI + 1] = r;
     }
+    pl = pn;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) raw[k] = nxt[k];
     // W interpolation of the three rows, then H interpolation into the two output rows of this input row
     float wi[3][VO];
 #pragma unroll
@@ -863,7 +888,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* x, long lo
 // Adjoint of the same stencil: dx[i] = .25 dy[2i-1] + .75 dy[2i] + .75 dy[2i+1] + .25 dy[2i+2] per axis, indices clamped
 // (the clamped forward taps fold back onto the border voxel).  Same lane role, marching through the dy planes.
 template <typename T, int TXN>
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* dy, long long dy_bs, T* dx, long long dx_bs, int C, int D,
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, long long dy_bs, T* __restrict__ dx, long long dx_bs, int C, int D,
                                                             int H, int W, int sd, int tilesW, int tilesH, int accumulate) {
   constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
   const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
@@ -890,15 +915,21 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* dy, long l
   float acc_prev[VI], acc_cur[VI], acc_next[VI];
 #pragma unroll
   for (int j = 0; j < VI; ++j) acc_prev[j] = acc_cur[j] = acc_next[j] = 0.f;
+  // a dy plane = 4 rows of this lane's 16-byte run; requested one step ahead (clamped plane index: always a valid address)
+  auto request = [&](int od, uint4 (&raw)[4]) {
+    const T* pl = src + (long long)min(max(od, 0), Do - 1) * ohw;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[k] = ldraw16(pl, ro[k] + 2 * wc);
+  };
   // V(od)[j]: the H/W-reduced dy plane od for this lane's VI inputs
-  auto plane = [&](int od, float (&V)[VI]) {
+  auto plane = [&](int od, const uint4 (&raw)[4], float (&V)[VI]) {
     const T* pl = src + (long long)min(max(od, 0), Do - 1) * ohw;
 #pragma unroll
     for (int j = 0; j < VI; ++j) V[j] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float v[VO], r[VO + 2];
-      ldvec(pl, ro[k] + 2 * wc, v);
+      cvtraw(pl, raw[k], v);
 #pragma unroll
       for (int i = 0; i < VO; ++i) r[i + 1] = v[i];
       float l = __shfl_up(v[VO - 1], 1, 64), rr = __shfl_down(v[0], 1, 64);
@@ -911,10 +942,15 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* dy, long l
         V[j] = fmaf(ch[k], 0.25f * r[2 * j] + 0.75f * r[2 * j + 1] + 0.75f * r[2 * j + 2] + 0.25f * r[2 * j + 3], V[j]);
     }
   };
+  uint4 re[4], rodd[4], ne[4], no[4];                    // planes 2q, 2q + 1 of this step and of the next one
+  request(2 * (d_begin - 1), re);
+  request(2 * (d_begin - 1) + 1, rodd);
   for (int q = d_begin - 1; q <= d_end; ++q) {          // block-uniform
+    request(2 * q + 2, ne);
+    request(2 * q + 3, no);
     float V[VI];
     if (2 * q >= 2 * d_begin - 1) {                      // even plane 2q: .75 -> q, .25 -> q-1
-      plane(2 * q, V);
+      plane(2 * q, re, V);
 #pragma unroll
       for (int j = 0; j < VI; ++j) { acc_cur[j] = fmaf(0.75f, V[j], acc_cur[j]); acc_prev[j] = fmaf(0.25f, V[j], acc_prev[j]); }
     }
@@ -933,12 +969,14 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* dy, long l
       sthalf(dst, sp, o);
     }
     if (2 * q + 1 <= 2 * d_end) {                        // odd plane 2q+1: .75 -> q, .25 -> q+1
-      plane(2 * q + 1, V);
+      plane(2 * q + 1, rodd, V);
 #pragma unroll
       for (int j = 0; j < VI; ++j) { acc_cur[j] = fmaf(0.75f, V[j], acc_cur[j]); acc_next[j] = fmaf(0.25f, V[j], acc_next[j]); }
     }
 #pragma unroll
     for (int j = 0; j < VI; ++j) { acc_prev[j] = acc_cur[j]; acc_cur[j] = acc_next[j]; acc_next[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { re[k] = ne[k]; rodd[k] = no[k]; }
   }
 }
 
