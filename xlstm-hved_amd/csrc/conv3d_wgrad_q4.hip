@@ -266,21 +266,32 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Variant with the x operand shared through LDS.  In the body above every wave loads (and transforms) its own three x rows:
-// a workgroup's four waves put 4 KB of lane loads into the vector-memory path per plane for 1.5 KB of distinct data, and that
-// path -- not HBM, not the ALUs -- is what bounds the kernel (file header).  Here the 6 distinct rows of a plane (h0 - 1 ..
-// h0 + 4, 4 CI4 channels, 64 bytes each) are loaded ONCE per workgroup (96 CI4 sixteen-byte items per plane, two planes per
-// round over the 256 threads), transformed once, and written to a 4-plane LDS ring; every wave reads its (ci, kh) fragment
-// from there with one conflict-free ds_read_b128.  One barrier per two planes; the global loads of a round are issued two
-// rounds ahead (4 VGPRs per item in flight).  dY stays per wave (its rows are not shared).
+// Variant with BOTH operands staged through LDS (the one the launches use).  In the body above every wave loads (and
+// transforms) its own three x rows and builds its dY fragment per lane: a workgroup's four waves put 4 KB of lane loads into the
+// vector-memory path per plane for 1.5 KB of distinct x, and 64 lanes each spend ~22 vector instructions (quad broadcast,
+// selects, v_alignbit, masks) on a dY fragment whose distinct content is 256 bytes -- the kernel is bound by that path and by
+// vector-instruction issue (SQ counters: 61 vector + 33 scalar instructions per step of 3 MFMAs), not by HBM.  Here, per plane:
+//  * the 6 distinct x rows (h0 - 1 .. h0 + 4, 4 CI4 channels, 64 bytes each) are loaded ONCE per workgroup as 16-byte items,
+//    transformed once (InstanceNorm + LeakyReLU; rows / planes outside the volume become zero) and written to the plane slot;
+//  * the 4 dY rows (4 output channels, 64 bytes each) are loaded once as 8-byte items (one per thread); the item's thread builds
+//    the three kw windows (one voxel left / centre / one voxel right: 4 v_alignbit, the neighbour dwords by DPP from the lanes
+//    next to it, the two row-end dwords by one extra 4-byte load) and writes them interleaved [row][g][co][kw], so that the
+//    A fragment of lane (co, kw, g) is ONE aligned ds_read_b128 and the 16 lanes of a g read 256 consecutive bytes;
+//  * planes outside the depth segment and rows outside the volume are zeroed when staged: the step has no masks;
+//  * the constant column (bias gradient) reads a 16-byte block of ones that sits in every plane slot.
+// A step = 1 + CI4 ds_read_b128 and 3 CI4 MFMAs.  4-plane LDS ring, one barrier per two planes, the global loads of a round
+// issued two rounds ahead (3 + 4 NIX VGPRs per round in flight; every thread has the same loads, none under a branch).
 template <int FMT, int CI4>
 __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned char* smem) {
   typedef h16<FMT> ST;
-  constexpr int ROWB = 4 * CI4 * 64 + 32;             // bytes per staged row: 4 CI4 channels x 64 B, + 32 B so that the three kh
+  constexpr int ROWB = 4 * CI4 * 64 + 32;             // bytes per staged x row: 4 CI4 channels x 64 B, + 32 B so that the three kh
                                                       // rows of a B-fragment read fall on different banks
-  constexpr int PLB = 6 * ROWB;                       // bytes per plane
-  constexpr int NIT = 96 * CI4;                       // 16-byte items per plane
-  constexpr int NI = (NIT + 127) / 128;               // items per thread (a thread serves one of the two planes of a round)
+  constexpr int XB = 6 * ROWB;                        // x rows of a plane
+  constexpr int CONSTB = XB;                          // [16 B of ones][16 B of zeros]
+  constexpr int DYB = XB + 32;                        // dY windows: [row 4][g 4][co 4][kw 4] x 16 B
+  constexpr int PLB = DYB + 4096;                     // bytes per plane slot
+  constexpr int NITX = 96 * CI4;                      // 16-byte x items per plane
+  constexpr int NIX = (NITX + 127) / 128;             // x items per thread (a thread serves one of the two planes of a round)
   constexpr unsigned ONE2 = FMT == 0 ? 0x3F803F80u : 0x3C003C00u;
   float* s_dw = reinterpret_cast<float*>(smem);       // after the plane loops
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -306,14 +317,24 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   const int cin_base = grp * a.Cin_g + chunk * 4 * CI4;
   const float pslope = a.pre ? a.pre_slope : 1.f;
   const int pp = tid >> 7, tl = tid & 127;            // plane of the round this thread stages, id among its 128 threads
-  // B fragment of lane (ci = nn & 3, kh = nn >> 2) in a staged plane; kh = 3 is the constant column (bias gradient)
+  // B fragment of lane (ci = nn & 3, kh = nn >> 2) in a staged plane; kh = 3 is the constant column (bias gradient): ones for
+  // (quad 0, ci 0), zeros elsewhere
   const int ci_l = nn & 3, khB = nn >> 2;
-  const int b_off = (wv + khB) * ROWB + ci_l * 64 + g * 16;
-  const unsigned fillv = ci_l == 0 ? ONE2 : 0u;
-  const int co_l = nn >> 2, kwA = nn & 3;
-  const bool left = kwA == 2, right = kwA == 0;
-  const unsigned shbits = (left || right) ? 16u : 0u;
-  const int hw2 = (int)(hw * 2);
+  int b_off[CI4];
+#pragma unroll
+  for (int cq = 0; cq < CI4; ++cq)
+    b_off[cq] = khB == 3 ? CONSTB + ((cq == 0 && ci_l == 0) ? 0 : 16) : (wv + khB) * ROWB + (cq * 4 + ci_l) * 64 + g * 16;
+  // A fragment of lane (co = nn >> 2, kw = nn & 3): window kw of row wv (kw = 3: an unused accumulator row, any window)
+  const int a_off = DYB + ((wv * 4 + g) * 16 + nn) * 16 - ((nn & 3) == 3 ? 32 : 0);
+  // the constant blocks of the four plane slots (never overwritten by the staging)
+  if (tid < 32) {
+    const int slot = tid >> 3, d = tid & 7;
+    *reinterpret_cast<unsigned*>(smem + slot * PLB + CONSTB + d * 4) = d < 4 ? ONE2 : 0u;
+  }
+  // dY item of this thread: row r, output channel co, 8-byte chunk gq (4 voxels) of the 64-byte row.  Every thread has one (and
+  // the same number of loads in flight: a load under a branch makes hipcc wait for nearly all of them at each commit)
+  const int y_gq = tl & 7, y_co = (tl >> 3) & 3, y_r = tl >> 5;
+  const int y_lds = DYB + ((y_r * 4 + (y_gq >> 1)) * 16 + y_co * 4) * 16 + (y_gq & 1) * 8;      // + kw * 16
 
   for (int t = t_first; t < t_end; t += t_stride) {
     int wk = t;
@@ -321,17 +342,17 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
     const int th = wk % a.tilesH; wk /= a.tilesH;
     const int ds = wk % a.dsegs;
     const int n = wk / a.dsegs;
-    const int h0 = th * 4, h = h0 + wv, w0 = tw * 32;
+    const int h0 = th * 4, w0 = tw * 32;
     const int d0 = ds * a.sd, d1 = min(D, d0 + a.sd);
-    // ---- staging plan of this thread: items tl, tl + 128, ... of a plane = (row r, quad cq, channel ci, chunk gq) ----
-    const ST* i_src[NI];
-    float i_sc[NI], i_sh[NI];
-    int i_lds[NI];
-    bool i_do[NI];
+    // ---- x staging plan of this thread: items tl, tl + 128, ... of a plane = (row r, quad cq, channel ci, chunk gq) ----
+    const ST* i_src[NIX];
+    float i_sc[NIX], i_sh[NIX];
+    int i_lds[NIX];
+    bool i_do[NIX];
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
+    for (int k = 0; k < NIX; ++k) {
       const int it = tl + 128 * k;
-      i_do[k] = it < NIT;
+      i_do[k] = it < NITX;
       const int itc = i_do[k] ? it : 0;
       const int gq = itc & 3, ci = (itc >> 2) & 3, cq = (itc >> 4) % CI4, r = itc / (16 * CI4);
       const int row = h0 - 1 + r;
@@ -345,49 +366,30 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
       i_sh[k] = rok ? sh : 0.f;
       i_lds[k] = r * ROWB + (cq * 4 + ci) * 64 + gq * 16;
     }
-    // ---- A role (dY): as in wgrad_q4_body ----
-    const __amdgpu_buffer_rsrc_t dyrs = q4_rsrc((const ST*)a.dy + n * a.dy_bs + (long long)co0 * dhw);
-    const unsigned dy_off = (unsigned)(((long long)co_l * dhw + (long long)min(h, H - 1) * W + w0 + 8 * g) * 2);
-    const int wpos = w0 + 8 * g;
-    const int e_off = (left && wpos > 0) ? -2 : (right && wpos + 8 < W) ? 8 : 0;
-    const unsigned m0 = (left && wpos == 0) ? 0xffff0000u : 0xffffffffu;
-    const unsigned m3 = (right && wpos + 8 == W) ? 0x0000ffffu : 0xffffffffu;
-    const unsigned dye_off = dy_off + 2 * e_off;
-    const unsigned rowmask = h < H ? 0xffffffffu : 0u;
-    auto load_dy = [&](int v, uint4& cur, unsigned& ex) {
-      const int po = min(max(v, 0), D - 1) * hw2;
-      cur = make_uint4(0, 0, 0, 0);
-      ex = 0;
-      if (kwA == 1) cur = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, (int)dy_off, po, 0));
-      if (left || right) ex = __builtin_amdgcn_raw_buffer_load_b32(dyrs, (int)dye_off, po, 0);
-    };
-    auto make_a = [&](const uint4& cl, unsigned ex, unsigned amask) -> frag8 {
-      uint4 c;
-      c.x = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.x, 0x55, 0xf, 0xf, true);
-      c.y = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.y, 0x55, 0xf, 0xf, true);
-      c.z = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.z, 0x55, 0xf, 0xf, true);
-      c.w = (unsigned)__builtin_amdgcn_mov_dpp((int)cl.w, 0x55, 0xf, 0xf, true);
-      const unsigned l0 = left ? ex : c.x, l1 = left ? c.x : c.y, l2 = left ? c.y : c.z, l3 = left ? c.z : c.w;
-      const unsigned h0_ = left ? c.x : c.y, h1 = left ? c.y : c.z, h2 = left ? c.z : c.w, h3 = left ? c.w : ex;
-      uint4 o;
-      o.x = __builtin_amdgcn_alignbit(h0_, l0, shbits) & m0 & amask;
-      o.y = __builtin_amdgcn_alignbit(h1, l1, shbits) & amask;
-      o.z = __builtin_amdgcn_alignbit(h2, l2, shbits) & amask;
-      o.w = __builtin_amdgcn_alignbit(h3, l3, shbits) & m3 & amask;
-      return __builtin_bit_cast(frag8, o);
-    };
-    // ---- x staging: round r covers planes d0 - 1 + 2 r (+ pp) ----
-    auto issue = [&](int r, uint4 (&q)[NI]) {
-      const long long po = (long long)min(max(d0 - 1 + 2 * r + pp, 0), D - 1) * hw;
+    // ---- dY staging plan ----
+    const int yrow = h0 + y_r;
+    const ST* y_src = (const ST*)a.dy + n * a.dy_bs + (long long)(co0 + y_co) * dhw + (long long)min(yrow, H - 1) * W + w0 + 4 * y_gq;
+    const bool y_edge_l = y_gq == 0 && w0 > 0, y_edge_r = y_gq == 7 && w0 + 32 < W;
+    const ST* y_esrc = y_src + (y_edge_l ? -2 : y_edge_r ? 4 : 0);               // the dword beyond the 64-byte row, if there is one
+    const unsigned y_rowmask = yrow < H ? 0xffffffffu : 0u;
+    const unsigned y_lmask = y_gq == 0 ? (y_edge_l ? 0xffffffffu : 0u) : 0xffffffffu;   // chunk 0 at w = 0: voxel -1 does not exist
+    const unsigned y_rmask = y_gq == 7 ? (y_edge_r ? 0xffffffffu : 0u) : 0xffffffffu;   // last chunk at the row end: voxel W does not exist
+    // ---- staging: round r covers x planes d0 - 1 + 2 r (+ pp) and the dY planes one above them ----
+    auto issue = [&](int r, uint4 (&q)[NIX], uint2& yq, unsigned& ye) {
+      const int p = d0 - 1 + 2 * r + pp;
+      const long long po = (long long)min(max(p, 0), D - 1) * hw;
 #pragma unroll
-      for (int k = 0; k < NI; ++k) q[k] = *reinterpret_cast<const uint4*>(i_src[k] + po);
+      for (int k = 0; k < NIX; ++k) q[k] = *reinterpret_cast<const uint4*>(i_src[k] + po);
+      const long long yo = (long long)min(max(p + 1, 0), D - 1) * hw;
+      yq = *reinterpret_cast<const uint2*>(y_src + yo);
+      ye = *reinterpret_cast<const unsigned*>(y_esrc + yo);
     };
-    auto commit = [&](int r, const uint4 (&q)[NI]) {
+    auto commit = [&](int r, const uint4 (&q)[NIX], const uint2& yq, unsigned ye) {
       const int p = d0 - 1 + 2 * r + pp;
       const float pm = (unsigned)p < (unsigned)D ? 1.f : 0.f;
       unsigned char* dst = smem + ((2 * r + pp) & 3) * PLB;
 #pragma unroll
-      for (int k = 0; k < NI; ++k) {
+      for (int k = 0; k < NIX; ++k) {
         if (!i_do[k]) continue;
         const float sc = i_sc[k] * pm, sh = i_sh[k] * pm;
         const unsigned u[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
@@ -401,20 +403,30 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
         }
         *reinterpret_cast<uint4*>(dst + i_lds[k]) = o;
       }
+      {
+        // out plane v = p + 1 belongs to this tile when d0 <= v < d1 (v >= d0 always holds: p >= d0 - 1)
+        const unsigned am = (p + 1 < d1 ? 0xffffffffu : 0u) & y_rowmask;
+        const unsigned c0 = yq.x & am, c1 = yq.y & am, e = ye & am;
+        // neighbour dwords inside the row: the 8 lanes y_gq = 0..7 of a DPP row half hold its chunks (row_shr:1 / row_shl:1;
+        // the lanes at a row end take the extra dword instead)
+        const unsigned pl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c1, 0x111, 0xf, 0xf, true);
+        const unsigned nx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0, 0x101, 0xf, 0xf, true);
+        const unsigned prev = (y_gq == 0 ? e : pl) & y_lmask, next = (y_gq == 7 ? e : nx) & y_rmask;
+        uint2 wl, wr;                                    // kw = 2: one voxel to the left; kw = 0: one voxel to the right
+        wl.x = __builtin_amdgcn_alignbit(c0, prev, 16); wl.y = __builtin_amdgcn_alignbit(c1, c0, 16);
+        wr.x = __builtin_amdgcn_alignbit(c1, c0, 16);   wr.y = __builtin_amdgcn_alignbit(next, c1, 16);
+        *reinterpret_cast<uint2*>(dst + y_lds) = wr;                              // kw = 0
+        *reinterpret_cast<uint2*>(dst + y_lds + 16) = make_uint2(c0, c1);         // kw = 1
+        *reinterpret_cast<uint2*>(dst + y_lds + 32) = wl;                         // kw = 2
+      }
     };
     frag8 af_m1 = frag8{0, 0, 0, 0, 0, 0, 0, 0}, af_0 = af_m1;
-    auto step = [&](int p, uint4& dc, unsigned& de) {        // x plane p (staged), dY plane p + 1 in (dc, de)
-      const unsigned amask = (p + 1 < d1 ? 0xffffffffu : 0u) & rowmask;
-      const frag8 af_p1 = make_a(dc, de, amask);
-      const unsigned char* src = smem + ((p - (d0 - 1)) & 3) * PLB + b_off;
+    auto step = [&](int p) {                                 // x plane p and dY plane p + 1, both in slot (p - (d0 - 1)) & 3
+      const unsigned char* src = smem + ((p - (d0 - 1)) & 3) * PLB;
+      const frag8 af_p1 = *reinterpret_cast<const frag8*>(src + a_off);
       frag8 bf[CI4];
 #pragma unroll
-      for (int cq = 0; cq < CI4; ++cq) {
-        const uint4 r = *reinterpret_cast<const uint4*>(src + cq * 256);
-        const unsigned f = cq == 0 ? fillv : 0u;
-        bf[cq] = __builtin_bit_cast(frag8, khB == 3 ? make_uint4(f, f, f, f) : r);
-      }
-      load_dy(p + 3, dc, de);                                // two steps ahead
+      for (int cq = 0; cq < CI4; ++cq) bf[cq] = *reinterpret_cast<const frag8*>(src + b_off[cq]);
 #pragma unroll
       for (int cq = 0; cq < CI4; ++cq) {
         acc[cq][0] = mfma16x16x32<FMT>(af_p1, bf[cq], acc[cq][0]);
@@ -425,26 +437,25 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
       af_0 = af_p1;
     };
     const int nround = ((d1 - d0 + 2 + 1) / 2 + 1) & ~1;     // rounds of two planes, an even number of them
-    uint4 qa[NI], qb[NI], dcur0, dcur1;
-    unsigned dex0, dex1;
+    uint4 qa[NIX], qb[NIX];
+    uint2 ya, yb;
+    unsigned ea, eb;
     __syncthreads();                                         // the previous tile's planes are no longer read
-    issue(0, qa);
-    issue(1, qb);
-    load_dy(d0, dcur0, dex0);
-    load_dy(d0 + 1, dcur1, dex1);
-    commit(0, qa);
-    issue(2, qa);
+    issue(0, qa, ya, ea);
+    issue(1, qb, yb, eb);
+    commit(0, qa, ya, ea);
+    issue(2, qa, ya, ea);
     for (int r = 0; r < nround; r += 2) {
       __syncthreads();                                       // round r staged; round r - 1 fully read
-      commit(r + 1, qb);
-      issue(r + 3, qb);
-      step(d0 - 1 + 2 * r, dcur0, dex0);
-      step(d0 + 2 * r, dcur1, dex1);
+      commit(r + 1, qb, yb, eb);
+      issue(r + 3, qb, yb, eb);
+      step(d0 - 1 + 2 * r);
+      step(d0 + 2 * r);
       __syncthreads();                                       // round r + 1 staged; round r fully read
-      commit(r + 2, qa);
-      issue(r + 4, qa);
-      step(d0 + 1 + 2 * r, dcur0, dex0);
-      step(d0 + 2 + 2 * r, dcur1, dex1);
+      commit(r + 2, qa, ya, ea);
+      issue(r + 4, qa, ya, ea);
+      step(d0 + 1 + 2 * r);
+      step(d0 + 2 + 2 * r);
     }
   }   // tiles
 
@@ -491,7 +502,7 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
 constexpr int wq4_waves(int ci4) { return ci4 == 1 ? 6 : ci4 == 2 ? 4 : 3; }
 template <int FMT, int CI4, bool LDSX>
 __global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
-  constexpr int RING = 4 * 6 * (4 * CI4 * 64 + 32) + 4 * CI4 * 64 + 64;      // four planes (+ the row the constant column "reads")
+  constexpr int RING = 4 * (6 * (4 * CI4 * 64 + 32) + 32 + 4096);             // four plane slots: x rows, constant block, dY windows
   constexpr int RED = (4 * 4 * CI4 * 27 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDSX && RING > RED ? RING : RED];
   const int b = blockIdx.x;
