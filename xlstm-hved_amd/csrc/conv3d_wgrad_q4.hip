@@ -284,8 +284,8 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
 template <int FMT, int CI4>
 __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned char* smem) {
   typedef h16<FMT> ST;
-  constexpr int ROWB = 4 * CI4 * 64 + 32;             // bytes per staged x row: 4 CI4 channels x 64 B, + 32 B so that the three kh
-                                                      // rows of a B-fragment read fall on different banks
+  constexpr int ROWB = 4 * CI4 * 64 + 16;             // bytes per staged x row: 4 CI4 channels x 64 B, + 16 B so that the 12 (ci, kh)
+                                                      // lanes of a B-fragment read fall on 12 different 16-byte bank groups
   constexpr int XB = 6 * ROWB;                        // x rows of a plane
   constexpr int CONSTB = XB;                          // [16 B of ones][16 B of zeros]
   constexpr int DYB = XB + 32;                        // dY windows: [row 4][g 4][co 4][kw 4] x 16 B
@@ -316,7 +316,8 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   const int grp = co0 / a.Cout_g;
   const int cin_base = grp * a.Cin_g + chunk * 4 * CI4;
   const float pslope = a.pre ? a.pre_slope : 1.f;
-  const int pp = tid >> 7, tl = tid & 127;            // plane of the round this thread stages, id among its 128 threads
+  // plane of the round this thread stages (wave-uniform: the plane addresses are scalar arithmetic), id among its 128 threads
+  const int pp = __builtin_amdgcn_readfirstlane(tid >> 7), tl = tid & 127;
   // B fragment of lane (ci = nn & 3, kh = nn >> 2) in a staged plane; kh = 3 is the constant column (bias gradient): ones for
   // (quad 0, ci 0), zeros elsewhere
   const int ci_l = nn & 3, khB = nn >> 2;
@@ -324,8 +325,10 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
 #pragma unroll
   for (int cq = 0; cq < CI4; ++cq)
     b_off[cq] = khB == 3 ? CONSTB + ((cq == 0 && ci_l == 0) ? 0 : 16) : (wv + khB) * ROWB + (cq * 4 + ci_l) * 64 + g * 16;
-  // A fragment of lane (co = nn >> 2, kw = nn & 3): window kw of row wv (kw = 3: an unused accumulator row, any window)
-  const int a_off = DYB + ((wv * 4 + g) * 16 + nn) * 16 - ((nn & 3) == 3 ? 32 : 0);
+  // A fragment of lane (co = nn >> 2, kw = nn & 3): window kw of row wv (kw = 3: an unused accumulator row, reads window 1).
+  // Slot of window (co, kw) inside the 256-byte block of (row, g): co * 4 + (kw ^ g) -- the 16 lanes of a g read 16 different
+  // slots, and the 32 lanes of a staging write (one kw, all (g, co), both halves) cover the 64 banks once
+  const int a_off = DYB + ((wv * 4 + g) * 16 + (nn >> 2) * 4 + (((nn & 3) == 3 ? 1 : (nn & 3)) ^ g)) * 16;
   // the constant blocks of the four plane slots (never overwritten by the staging)
   if (tid < 32) {
     const int slot = tid >> 3, d = tid & 7;
@@ -334,7 +337,9 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   // dY item of this thread: row r, output channel co, 8-byte chunk gq (4 voxels) of the 64-byte row.  Every thread has one (and
   // the same number of loads in flight: a load under a branch makes hipcc wait for nearly all of them at each commit)
   const int y_gq = tl & 7, y_co = (tl >> 3) & 3, y_r = tl >> 5;
-  const int y_lds = DYB + ((y_r * 4 + (y_gq >> 1)) * 16 + y_co * 4) * 16 + (y_gq & 1) * 8;      // + kw * 16
+  const int y_g = y_gq >> 1;
+  const int y_lds = DYB + ((y_r * 4 + y_g) * 16 + y_co * 4) * 16 + (y_gq & 1) * 8;              // + (kw ^ g) * 16
+  const int y_lds0 = y_lds + (0 ^ y_g) * 16, y_lds1 = y_lds + (1 ^ y_g) * 16, y_lds2 = y_lds + (2 ^ y_g) * 16;
 
   for (int t = t_first; t < t_end; t += t_stride) {
     int wk = t;
@@ -415,9 +420,9 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
         uint2 wl, wr;                                    // kw = 2: one voxel to the left; kw = 0: one voxel to the right
         wl.x = __builtin_amdgcn_alignbit(c0, prev, 16); wl.y = __builtin_amdgcn_alignbit(c1, c0, 16);
         wr.x = __builtin_amdgcn_alignbit(c1, c0, 16);   wr.y = __builtin_amdgcn_alignbit(next, c1, 16);
-        *reinterpret_cast<uint2*>(dst + y_lds) = wr;                              // kw = 0
-        *reinterpret_cast<uint2*>(dst + y_lds + 16) = make_uint2(c0, c1);         // kw = 1
-        *reinterpret_cast<uint2*>(dst + y_lds + 32) = wl;                         // kw = 2
+        *reinterpret_cast<uint2*>(dst + y_lds0) = wr;                             // kw = 0
+        *reinterpret_cast<uint2*>(dst + y_lds1) = make_uint2(c0, c1);             // kw = 1
+        *reinterpret_cast<uint2*>(dst + y_lds2) = wl;                             // kw = 2
       }
     };
     frag8 af_m1 = frag8{0, 0, 0, 0, 0, 0, 0, 0}, af_0 = af_m1;
@@ -502,7 +507,7 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
 constexpr int wq4_waves(int ci4) { return ci4 == 1 ? 6 : ci4 == 2 ? 4 : 3; }
 template <int FMT, int CI4, bool LDSX>
 __global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
-  constexpr int RING = 4 * (6 * (4 * CI4 * 64 + 32) + 32 + 4096);             // four plane slots: x rows, constant block, dY windows
+  constexpr int RING = 4 * (6 * (4 * CI4 * 64 + 16) + 32 + 4096);             // four plane slots: x rows, constant block, dY windows
   constexpr int RED = (4 * 4 * CI4 * 27 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDSX && RING > RED ? RING : RED];
   const int b = blockIdx.x;
