@@ -26,7 +26,10 @@
 // are 91 % busy (4.1 cycles per instruction): instruction-issue bound, which is why phases of different workgroups do not
 // hide each other.  Tried and dropped: loads of the next input quad issued under the matrix phase of the current one
 // (needs 154-168 VGPRs = 3 workgroups per CU: 12 -> 4 @128^3 33 -> 38 us, the 64^3 / 32^3 shapes unchanged -- those are
-// latency chains of a few dozen workgroups).
+// latency chains of a few dozen workgroups); the epilogue of output plane pz - 2 run inside the plane walk (its loads requested
+// two or four planes ahead, branch-free): 16 -> 16 g4 data gradient 56 -> 48 us in the microbenchmark, whose operands sit in the
+// 256 MB last-level cache, but 58 -> 62 us inside the training step, where they come from HBM (step 5.16 -> 5.19 ms); four of
+// the eight epilogue loads requested before the matrix phase: no change.
 #include "common.h"
 #include "conv_pack.h"
 #include "fanin.h"
@@ -61,6 +64,16 @@ constexpr int NITEM = NROWS * 4;            // interior items: (row, 8-voxel gro
 constexpr int NEDGE = NROWS * 2;            // edge items: (row, side) -> one voxel pair
 constexpr int Q4_MAXC = 48;                 // most channels per group the kernel can be asked to take
 }
+
+// Buffer descriptor of a wave-uniform base pointer, 2 GiB window: accesses at a 32-bit lane offset >= 0x80000000 are out of range,
+// i.e. a load returns 0 and a store is dropped -- predication without a branch (a branch around a vector-memory instruction makes
+// hipcc's s_waitcnt bookkeeping fall back to "wait for everything", which serialises loads that were requested ahead of their use)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t q4_window(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x80000000, 0x00020000);
+}
+constexpr unsigned Q4_OOB = 0xFFFFFFF0u;
 
 // two values of one channel -> leaky(x * sc + sh) in fp32 (packed fma / mul; leaky = max(v, slope * v) for 0 <= slope <= 1)
 template <int FMT> __device__ __forceinline__ f32x2_t q4_xf(unsigned u, float sc, float sh, float slope) {
@@ -148,16 +161,17 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   const long long odhw = (long long)Do * Ho * a.d.Wo;
   const unsigned spd_b = (unsigned)(Ho * a.d.Wo) * (unsigned)sizeof(ST);                       // bytes per output plane
   const unsigned lane_b = (unsigned)(((long long)g4 * odhw + (long long)(row_ok ? oh : 0) * a.d.Wo + ow0 + 4 * qw) * (long long)sizeof(ST));
-  const char* ebase = nullptr;
+  const unsigned lane_bo = row_ok ? lane_b : Q4_OOB;      // rows below the volume: the stores fall outside the window
+  __amdgpu_buffer_rsrc_t ers = q4_window(a.p.y), yrs;
   if (EPI == 1) {
     esc = a.p.e_sc[n * a.d.Cout + co0 + g4];
     esh = a.p.e_sh[n * a.d.Cout + co0 + g4];
     // a quad never straddles the ea / eb boundary (Cea % 4 == 0)
-    ebase = reinterpret_cast<const char*>(co0 < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co0 * odhw
-                                                        : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co0 - a.d.Cea) * odhw) +
-            (long long)od0 * spd_b;
+    ers = q4_window(reinterpret_cast<const char*>(co0 < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co0 * odhw
+                                                                  : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co0 - a.d.Cea) * odhw) +
+                    (long long)od0 * spd_b);
   }
-  char* ybase = reinterpret_cast<char*>((ST*)a.p.y + n * a.d.y_bs + (long long)co0 * odhw) + (long long)od0 * spd_b;
+  yrs = q4_window(reinterpret_cast<char*>((ST*)a.p.y + n * a.d.y_bs + (long long)co0 * odhw) + (long long)od0 * spd_b);
 
   f32x4 acc[TD];
 #pragma unroll
@@ -169,11 +183,14 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   f32x2_t ps = {0.f, 0.f}, pq = {0.f, 0.f};
   const f32x2_t aslope2 = {a.act_slope, a.act_slope}, bias2 = {bias, bias}, esc2 = {esc, esc}, esh2 = {esh, esh};
   const float eslope = a.d.e_slope;
+  // no branch around the loads and stores of the epilogue: planes past the volume are loaded from the last valid plane and
+  // stored outside the window
   auto epi_load = [&](int dz) {
-    if (EPI == 1 && dz < ndz) eraw[dz] = *reinterpret_cast<const uint2*>(ebase + (unsigned)dz * spd_b + lane_b);
+    if (EPI == 1)
+      eraw[dz] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ers, (int)lane_b, (int)((unsigned)min(dz, ndz - 1) * spd_b), 0));
   };
   auto epi_do = [&](int dz) {
-    if (dz >= ndz) return;                            // uniform
+    const bool live = dz < ndz;                       // uniform
     f32x2_t v[2] = {f32x2_t{acc[dz][0], acc[dz][1]} + bias2, f32x2_t{acc[dz][2], acc[dz][3]} + bias2};
     if (ACT) { v[0] = max2(v[0], v[0] * aslope2); v[1] = max2(v[1], v[1] * aslope2); }
     uint2 pk;
@@ -185,18 +202,21 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
         v[q] = f32x2_t{z.x > 0.f ? v[q].x : vs.x, z.y > 0.f ? v[q].y : vs.y};
       }
       pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
-      const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);           // the values as stored
-      ps += r0 + r1;
-      pq += r0 * e[0] + r1 * e[1];
+      if (live) {
+        const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);         // the values as stored
+        ps += r0 + r1;
+        pq += r0 * e[0] + r1 * e[1];
+      }
     } else {
       pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
-      if (EPI == 2) {
+      if (EPI == 2 && live) {
         const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);
         ps += r0 + r1;
         pq += r0 * r0 + r1 * r1;
       }
     }
-    if (row_ok) *reinterpret_cast<uint2*>(ybase + (unsigned)dz * spd_b + lane_b) = pk;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), pk), yrs,
+                                          (int)(live ? lane_bo : Q4_OOB), (int)((unsigned)dz * spd_b), 0);
   };
 
   const float pslope = a.d.pre_slope;
@@ -312,13 +332,10 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     }
     __syncthreads();
     if (a.abl & 8192) continue;
-    // ---- matrix phase: the wave's two output rows, walking the 10 staged planes once.  Single-quad instances run the
-    // epilogue of output plane pz - 2 (complete after staged plane pz) inside the walk: its loads are requested two planes
-    // ahead, its vector instructions and stores issue in the shadow of the matrix instructions of the planes that follow ----
+    // ---- matrix phase: the wave's two output rows, walking the 10 staged planes once ----
     {
 #pragma unroll
       for (int pz = 0; pz < ID; ++pz) {
-        if (!MULTI && pz < TD) epi_load(pz);
         frag8 bf[3];
         bf[0] = *reinterpret_cast<const frag8*>(smem + pz * PLANE + b_off0);
         bf[1] = *reinterpret_cast<const frag8*>(smem + pz * PLANE + PITCH + b_off1);
@@ -330,13 +347,12 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) acc[dz] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh], acc[dz]);
         }
-        if (!MULTI && pz >= 2) epi_do(pz - 2);
       }
     }
   }
   if (a.abl & 8192) return;
 
-  if (MULTI) {                                        // accumulators complete only after the last input quad
+  {
 #pragma unroll
     for (int dz = 0; dz < TD; ++dz) epi_load(dz);
 #pragma unroll
@@ -381,7 +397,7 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if (d->epi == 1 && d->Cea % 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
-  if (dhw % 8 || dhw >= (1ll << 29)) return false;      // 32-bit byte offsets inside a quad of channel volumes
+  if (dhw % 8 || dhw >= (1ll << 28)) return false;      // 31-bit byte offsets inside a quad of channel volumes (q4_window)
   if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
   float as = 1.f;
   if (d->act == XH_ACT_RELU) as = 0.f;
