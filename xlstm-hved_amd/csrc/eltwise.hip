@@ -1253,12 +1253,13 @@ __global__ __launch_bounds__(256) void channel_pool_fwd_kernel(const T* __restri
       for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
           m[v] = (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) ? xv[j][v] : m[v];
           s[v] += xv[j][v];
         }
+              }
       }
     }
 #pragma unroll
@@ -1285,10 +1286,11 @@ __global__ __launch_bounds__(256) void channel_pool_bwd_kernel(const T* __restri
       for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v)
           if (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) { m[v] = xv[j][v]; arg[v] = c0 + j; }
+              }
       }
     }
 #pragma unroll
@@ -1307,10 +1309,11 @@ __global__ __launch_bounds__(256) void channel_pool_bwd_kernel(const T* __restri
       }
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v) o[j][v] = o[j][v] + g1[v] + (c0 + j == arg[v] ? g0[v] : 0.f);
         strow<VEC>(dp + (long long)(c0 + j) * dhw, q, valid, o[j]);
+              }
       }
     }
   VOX_LOOP_END
@@ -1322,6 +1325,9 @@ static inline dim3 vox_grid(long long dhw, int N, int cap = 4096) {
   if (b > cap) b = cap;
   return dim3((unsigned)b, 1, N);
 }
+// The deep levels: a few dozen workgroups whose lanes walk many channels.  Their run time is the lane's chain of dependent
+// load rounds (C / CB of them, a memory latency each), so those launches take the instances with 8 or 16 channels per round.
+static inline bool deep_grid(const dim3& g, int C) { return C >= 8 && (long long)g.x * g.y * g.z < 256; }
 extern "C" int xh_channel_pool_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
                                    int C, long long DHW) {
   if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
@@ -1389,7 +1395,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ x, 
       }
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v) a[v] = fmaf(g[j][v], xv[j][v], a[v]);
         if (dx) {
@@ -1397,6 +1403,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ x, 
           for (int v = 0; v < VW; ++v) o[j][v] = g[j][v] * g1[v] + o[j][v];
           strow<VEC>(dx + n * dx_bs + (long long)(c0 + j) * dhw, q, valid, o[j]);
         }
+              }
       }
     }
     if (ds) {
@@ -1454,7 +1461,7 @@ template <typename T> struct Pair2 {
   T* dx[2]; long long dx_bs[2]; int acc[2];
 };
 // y (N, 4, ...): channels 2 w, 2 w + 1 = (max_c, mean_c) of x[w]
-template <typename T, bool VEC>
+template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void channel_pool2_fwd_kernel(const Pair2<T> p, T* __restrict__ y, long long y_bs, long long dhw) {
   const int w = blockIdx.y, C = p.C[w];
   VOX_LOOP_BEGIN
@@ -1462,18 +1469,19 @@ __global__ __launch_bounds__(256) void channel_pool2_fwd_kernel(const Pair2<T> p
     float m[VW], s[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float xv[CB][VW];
+    for (int c0 = 0; c0 < C; c0 += CBT) {
+      float xv[CBT][VW];
 #pragma unroll
-      for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
+      for (int j = 0; j < CBT; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+      for (int j = 0; j < CBT; ++j) {
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
           m[v] = (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) ? xv[j][v] : m[v];
           s[v] += xv[j][v];
         }
+              }
       }
     }
 #pragma unroll
@@ -1483,7 +1491,7 @@ __global__ __launch_bounds__(256) void channel_pool2_fwd_kernel(const Pair2<T> p
   VOX_LOOP_END
 }
 // dy (N, 4, ...) as above -> dx[w] (+)= the pooled gradients routed back (first maximum; mean to every channel)
-template <typename T, bool VEC>
+template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void channel_pool2_bwd_kernel(const Pair2<T> p, const T* __restrict__ dy, long long dy_bs, long long dhw) {
   const int w = blockIdx.y, C = p.C[w], accumulate = p.acc[w];
   VOX_LOOP_BEGIN
@@ -1494,25 +1502,26 @@ __global__ __launch_bounds__(256) void channel_pool2_bwd_kernel(const Pair2<T> p
     ldrow<VEC>(dy + n * dy_bs + (long long)(2 * w + 1) * dhw, q, valid, g1);
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; arg[v] = 0; }
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float xv[CB][VW];
+    for (int c0 = 0; c0 < C; c0 += CBT) {
+      float xv[CBT][VW];
 #pragma unroll
-      for (int j = 0; j < CB; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
+      for (int j = 0; j < CBT; ++j) ldrow<VEC>(xp + (long long)min(c0 + j, C - 1) * dhw, q, valid, xv[j]);
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+      for (int j = 0; j < CBT; ++j) {
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v)
           if (xv[j][v] > m[v] || xv[j][v] != xv[j][v]) { m[v] = xv[j][v]; arg[v] = c0 + j; }
+              }
       }
     }
 #pragma unroll
     for (int v = 0; v < VW; ++v) g1[v] = g1[v] / (float)C;
     T* dp = p.dx[w] + n * p.dx_bs[w];
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float o[CB][VW];
+    for (int c0 = 0; c0 < C; c0 += CBT) {
+      float o[CBT][VW];
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
+      for (int j = 0; j < CBT; ++j) {
         if (accumulate) {
           ldrow<VEC>((const T*)dp + (long long)min(c0 + j, C - 1) * dhw, q, valid, o[j]);
         } else {
@@ -1521,11 +1530,12 @@ __global__ __launch_bounds__(256) void channel_pool2_bwd_kernel(const Pair2<T> p
         }
       }
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+      for (int j = 0; j < CBT; ++j) {
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v) o[j][v] = o[j][v] + g1[v] + (c0 + j == arg[v] ? g0[v] : 0.f);
         strow<VEC>(dp + (long long)(c0 + j) * dhw, q, valid, o[j]);
+              }
       }
     }
   VOX_LOOP_END
@@ -1544,7 +1554,7 @@ __global__ __launch_bounds__(EW_BLOCK) void gate2_fwd_kernel(const Pair2<T> p, c
   ROW_LOOP_END
 }
 // dy (N, C0 + C1, ...) -> dx[w] (+)= dy (1 + E[:,w]),  dE[:,w] = sum_c dy x[w]
-template <typename T, bool VEC>
+template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void gate2_bwd_kernel(const Pair2<T> p, const T* __restrict__ E, long long E_bs, const T* __restrict__ dy,
                                                        long long dy_bs, T* dE, long long dE_bs, long long dhw) {
   const int w = blockIdx.y, C = p.C[w], acc_dx = p.acc[w];
@@ -1555,10 +1565,10 @@ __global__ __launch_bounds__(256) void gate2_bwd_kernel(const Pair2<T> p, const 
 #pragma unroll
     for (int v = 0; v < VW; ++v) { g1[v] = 1.f + g1[v]; a[v] = 0.f; }
     T* dxp = p.dx[w];
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float g[CB][VW], xv[CB][VW], o[CB][VW];
+    for (int c0 = 0; c0 < C; c0 += CBT) {
+      float g[CBT][VW], xv[CBT][VW], o[CBT][VW];
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
+      for (int j = 0; j < CBT; ++j) {
         const long long off = (long long)min(c0 + j, C - 1) * dhw;
         ldrow<VEC>(dy + n * dy_bs + dyo + off, q, valid, g[j]);
         ldrow<VEC>(p.x[w] + n * p.x_bs[w] + off, q, valid, xv[j]);
@@ -1570,14 +1580,15 @@ __global__ __launch_bounds__(256) void gate2_bwd_kernel(const Pair2<T> p, const 
         }
       }
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+      for (int j = 0; j < CBT; ++j) {
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
           a[v] = fmaf(g[j][v], xv[j][v], a[v]);
           o[j][v] = g[j][v] * g1[v] + o[j][v];
         }
         strow<VEC>(dxp + n * p.dx_bs[w] + (long long)(c0 + j) * dhw, q, valid, o[j]);
+              }
       }
     }
     strow<VEC>(dE + n * dE_bs + (long long)w * dhw, q, valid, a);
@@ -1599,7 +1610,9 @@ extern "C" int xh_channel_pool2_fwd(void* stream, int dtype, const void* xa, lon
   XH_DISPATCH_T(dtype, {
     const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, nullptr, 0, 0, nullptr, 0, 0);
     dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
-    if (vec_ok<T>(DHW, {xa_bs, xb_bs, y_bs})) hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, y_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb))
+      hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, true, 16>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
+    else if (vec_ok<T>(DHW, {xa_bs, xb_bs, y_bs})) hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
     else hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, false>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
   });
   return xh_launch_status();
@@ -1612,7 +1625,9 @@ extern "C" int xh_channel_pool2_bwd(void* stream, int dtype, const void* xa, lon
   XH_DISPATCH_T(dtype, {
     const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, dxa, dxa_bs, acc_a, dxb, dxb_bs, acc_b);
     dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
-    if (vec_ok<T>(DHW, {xa_bs, xb_bs, dy_bs, dxa_bs, dxb_bs}))
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, dy_bs, dxa_bs, dxb_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb))
+      hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, true, 16>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
+    else if (vec_ok<T>(DHW, {xa_bs, xb_bs, dy_bs, dxa_bs, dxb_bs}))
       hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
     else hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
   });
@@ -1639,7 +1654,9 @@ extern "C" int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long x
   XH_DISPATCH_T(dtype, {
     const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, dxa, dxa_bs, acc_a, dxb, dxb_bs, acc_b);
     dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
-    if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, dy_bs, dxa_bs, dxb_bs, dE_bs}))
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, dy_bs, dxa_bs, dxb_bs, dE_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb))
+      hipLaunchKernelGGL((gate2_bwd_kernel<T, true, 8>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
+    else if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, dy_bs, dxa_bs, dxb_bs, dE_bs}))
       hipLaunchKernelGGL((gate2_bwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
     else hipLaunchKernelGGL((gate2_bwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
   });
@@ -1794,6 +1811,99 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restri
             s_ds[((2 * 4 + wv) * 8 + e) * 64 + lane]) + s_ds[((3 * 4 + wv) * 8 + e) * 64 + lane];
   if (live) st8<T>(ds + n * ds_bs + base + (long long)(wv >> 1) * hw + (long long)(wv & 1) * W, o);
 }
+// The same for small volumes (a few dozen workgroups of the kernel above, each wave walking C / 4 channels one memory latency
+// at a time: 64 channels @32^3 took 30 us on 16 workgroups): a workgroup takes 16 runs, the 64 lanes of a wave are 16 runs x 4
+// channel slots, so 16 channels are in flight per workgroup step and there are four times as many workgroups.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_maxpool_bwd_deep_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ s, long long s_bs,
+                                                                   const T* __restrict__ dy, long long dy_bs, T* dx, long long dx_bs, T* ds,
+                                                                   long long ds_bs, int C, int D, int H, int W, int acc_dx) {
+  constexpr int RUNS = 16, SL = 64 / RUNS;
+  __shared__ float s_ds[4 * 4 * 8 * 64];                  // [wave][window row][element][lane]
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rl = lane & (RUNS - 1), slot = lane / RUNS;
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2, Wr = Wo / 4;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw, odhw = (long long)Do * Ho * Wo;
+  const long long runs = (long long)Do * Ho * Wr;
+  const long long r = (long long)blockIdx.x * RUNS + rl;
+  const bool live = r < runs;
+  const long long rc = live ? r : 0;
+  const int wr = (int)(rc % Wr);
+  const long long t = rc / Wr;
+  const int oh = (int)(t % Ho), od = (int)(t / Ho);
+  const long long base = ((long long)(2 * od) * H + 2 * oh) * W + 8 * wr;
+  const long long obase = ((long long)od * Ho + oh) * Wo + 4 * wr;
+  float g1[4][8], dsv[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ld8<T>(s + n * s_bs + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W, g1[k]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g1[k][e] = 1.f + g1[k][e]; dsv[k][e] = 0.f; }
+  }
+  for (int c = wv + 4 * slot; c < C; c += 4 * SL) {
+    const T* xp = x + n * x_bs + (long long)c * dhw + base;
+    float xv[4][8], g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ld8<T>(xp + (long long)(k >> 1) * hw + (long long)(k & 1) * W, xv[k]);
+    ld4(dy + n * dy_bs + (long long)c * odhw, obase, g);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0, 0, 0, 0};                          // window position 2 * k + e of the first maximum (scan order)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float v = rnd_as(x, xv[k][2 * j + e] * g1[k][2 * j + e]);
+          if (v > m[j] || v != v) { m[j] = v; arg[j] = 2 * k + e; }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float gg = arg[j] == 2 * k + e ? g[j] : 0.f;
+          o[2 * j + e] = gg * g1[k][2 * j + e];
+          dsv[k][2 * j + e] = fmaf(gg, xv[k][2 * j + e], dsv[k][2 * j + e]);
+        }
+      T* dp = dx + n * dx_bs + (long long)c * dhw + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W;
+      if (acc_dx && live) {
+        float prev[8];
+        ld8<T>((const T*)dp, prev);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += prev[e];
+      }
+      if (live) st8<T>(dp, o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_ds[((wv * 4 + k) * 8 + e) * 64 + lane] = dsv[k][e];
+  __syncthreads();
+  // thread (k, run) of the first 4 * RUNS: the sum over waves and channel slots, always in the same order
+  if (threadIdx.x < 4 * RUNS) {
+    const int k = threadIdx.x / RUNS, rr = threadIdx.x % RUNS;
+    const long long r2 = (long long)blockIdx.x * RUNS + rr;
+    if (r2 < runs) {
+      const int wr2 = (int)(r2 % Wr);
+      const long long t2 = r2 / Wr;
+      const int oh2 = (int)(t2 % Ho), od2 = (int)(t2 / Ho);
+      const long long base2 = ((long long)(2 * od2) * H + 2 * oh2) * W + 8 * wr2;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float acc = 0.f;
+        for (int w = 0; w < 4; ++w)
+          for (int sl = 0; sl < SL; ++sl) acc += s_ds[((w * 4 + k) * 8 + e) * 64 + sl * RUNS + rr];
+        o[e] = acc;
+      }
+      st8<T>(ds + n * ds_bs + base2 + (long long)(k >> 1) * hw + (long long)(k & 1) * W, o);
+    }
+  }
+}
 static bool gmp_ok(int D, int H, int W, std::initializer_list<long long> strides) {
   if (D < 2 || H < 2 || W < 8 || (D & 1) || (H & 1) || (W & 7)) return false;
   for (long long v : strides)
@@ -1821,8 +1931,14 @@ extern "C" int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long 
   const long long runs = (long long)(D / 2) * (H / 2) * (W / 8);
   const long long nb = (runs + 63) / 64;
   if (nb >= (1ll << 31)) return XH_ERR_ARG;
-  dim3 grid((unsigned)nb, N);
   hipStream_t st = (hipStream_t)stream;
+  if (nb * N < 256 && C >= 16) {                          // the deep levels: 16 runs x 16 channel slots per workgroup
+    dim3 grid((unsigned)((runs + 15) / 16), N);
+    XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_bwd_deep_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs,
+                                            (const T*)dy, dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W, acc_dx););
+    return xh_launch_status();
+  }
+  dim3 grid((unsigned)nb, N);
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs, (const T*)dy,
                                           dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W, acc_dx););
   return xh_launch_status();
@@ -1902,9 +2018,10 @@ __global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* __restri
       }
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
 #pragma unroll
         for (int v = 0; v < VW; ++v) a[v] = fmaf(g[j][v], xv[j][v], a[v]);
+              }
       }
     }
     strow<VEC>(dsp + n * dsp_bs, q, valid, a);
@@ -2090,7 +2207,7 @@ extern "C" int xh_duse_fc_bwd(void* stream, const double* red_r, const double* r
 
 // ---------------------------------------------------------------------------------------- skip-return tail
 // r_c = relu(relu(t_c*sc+sh) + x_c);  a = sigmoid(w0*max_c r + w1*mean_c r)
-template <typename T, bool VEC>
+template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
                                                           const float* sh, const float* w2, T* __restrict__ a, int C,
                                                           long long dhw) {
@@ -2099,17 +2216,17 @@ __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__
     float m[VW], s[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float tv[CB][VW], xv[CB][VW];
+    for (int c0 = 0; c0 < C; c0 += CBT) {
+      float tv[CBT][VW], xv[CBT][VW];
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
+      for (int j = 0; j < CBT; ++j) {
         const long long o = ((long long)n * C + min(c0 + j, C - 1)) * dhw;
         ldrow<VEC>(t + o, q, valid, tv[j]);
         ldrow<VEC>(x + o, q, valid, xv[j]);
       }
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+      for (int j = 0; j < CBT; ++j) {
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
         const float scv = sc[n * C + c0 + j], shv = sh[n * C + c0 + j];
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
@@ -2120,6 +2237,7 @@ __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__
           m[v] = r > m[v] ? r : m[v];
           s[v] += r;
         }
+              }
       }
     }
     float out[VW];
@@ -2128,7 +2246,7 @@ __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__
     strow<VEC>(a + (long long)n * dhw, q, valid, out);
   VOX_LOOP_END
 }
-template <typename T, bool VEC>
+template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
                                                           const float* sh, const float* w2, const T* __restrict__ a,
                                                           const T* __restrict__ da, T* __restrict__ dtg, T* dx,
@@ -2143,17 +2261,17 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
     ldrow<VEC>(da + (long long)n * dhw, q, valid, dpre);
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; arg[v] = 0; }
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float tv[CB][VW], xv[CB][VW];
+    for (int c0 = 0; c0 < C; c0 += CBT) {
+      float tv[CBT][VW], xv[CBT][VW];
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
+      for (int j = 0; j < CBT; ++j) {
         const long long o = ((long long)n * C + min(c0 + j, C - 1)) * dhw;
         ldrow<VEC>(t + o, q, valid, tv[j]);
         ldrow<VEC>(x + o, q, valid, xv[j]);
       }
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+      for (int j = 0; j < CBT; ++j) {
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
         const float scv = sc[n * C + c0 + j], shv = sh[n * C + c0 + j];
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
@@ -2164,6 +2282,7 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
           if (r > m[v]) { m[v] = r; arg[v] = c0 + j; }
           s[v] += r;
         }
+              }
       }
     }
     float t0 = 0.f, t1 = 0.f;                           // lanes past the row end: a = da = 0, so they add nothing
@@ -2175,10 +2294,10 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
     }
     sacc[0] += (double)t0;
     sacc[1] += (double)t1;
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float tv[CB][VW], xv[CB][VW], odx[CB][VW];
+    for (int c0 = 0; c0 < C; c0 += CBT) {
+      float tv[CBT][VW], xv[CBT][VW], odx[CBT][VW];
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
+      for (int j = 0; j < CBT; ++j) {
         const long long o = ((long long)n * C + min(c0 + j, C - 1)) * dhw;
         ldrow<VEC>(t + o, q, valid, tv[j]);
         ldrow<VEC>(x + o, q, valid, xv[j]);
@@ -2190,8 +2309,8 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
         }
       }
 #pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        if (c0 + j >= C) break;
+      for (int j = 0; j < CBT; ++j) {
+        if (c0 + j < C) {                 // predicate, not break: a break in the unrolled loop sends the arrays to scratch
         const long long o = ((long long)n * C + c0 + j) * dhw;
         const float scv = sc[n * C + c0 + j], shv = sh[n * C + c0 + j];
         float odt[VW];
@@ -2207,6 +2326,7 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
         }
         strow<VEC>(dx + o, q, valid, odx[j]);
         strow<VEC>(dtg + o, q, valid, odt);
+              }
       }
     }
   VOX_LOOP_END
@@ -2216,28 +2336,33 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
 extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                                const float* w2, void* a, int N, int C, long long DHW) {
   if (!t || !x || !sc || !sh || !w2 || !a || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
-  if (dtype == XH_F32)
-    { if (vec_ok<float>(DHW, {})) hipLaunchKernelGGL((skr_tail_fwd_kernel<float, true>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW); else hipLaunchKernelGGL((skr_tail_fwd_kernel<float, false>), vox_grid<float>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (float*)a, C, DHW); }
-  else if (dtype == XH_BF16)
-    { if (vec_ok<bf16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_fwd_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW); else hipLaunchKernelGGL((skr_tail_fwd_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (bf16_t*)a, C, DHW); }
-  else if (dtype == XH_F16)
-    { if (vec_ok<f16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_fwd_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW); else hipLaunchKernelGGL((skr_tail_fwd_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (f16_t*)a, C, DHW); }
-  else
-    return XH_ERR_DTYPE;
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, {
+    const dim3 grid = vox_grid<T>(DHW, N);
+    if (vec_ok<T>(DHW, {}) && deep_grid(grid, C))
+      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true, 8>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW);
+    else if (vec_ok<T>(DHW, {}))
+      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW);
+    else
+      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, false>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW);
+  });
   return xh_launch_status();
 }
 extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                                const float* w2, const void* a, const void* da, void* dtg, void* dx, double* dw2,
                                int N, int C, long long DHW, int acc_dx) {
   if (!t || !x || !sc || !sh || !w2 || !a || !da || !dtg || !dx || !dw2 || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
-  if (dtype == XH_F32)
-    { if (vec_ok<float>(DHW, {})) hipLaunchKernelGGL((skr_tail_bwd_kernel<float, true>), vox_grid<float>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx); else hipLaunchKernelGGL((skr_tail_bwd_kernel<float, false>), vox_grid<float>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const float*)t, (const float*)x, sc, sh, w2, (const float*)a, (const float*)da, (float*)dtg, (float*)dx, dw2, C, DHW, acc_dx); }
-  else if (dtype == XH_BF16)
-    { if (vec_ok<bf16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_bwd_kernel<bf16_t, true>), vox_grid<bf16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx); else hipLaunchKernelGGL((skr_tail_bwd_kernel<bf16_t, false>), vox_grid<bf16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)t, (const bf16_t*)x, sc, sh, w2, (const bf16_t*)a, (const bf16_t*)da, (bf16_t*)dtg, (bf16_t*)dx, dw2, C, DHW, acc_dx); }
-  else if (dtype == XH_F16)
-    { if (vec_ok<f16_t>(DHW, {})) hipLaunchKernelGGL((skr_tail_bwd_kernel<f16_t, true>), vox_grid<f16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx); else hipLaunchKernelGGL((skr_tail_bwd_kernel<f16_t, false>), vox_grid<f16_t>(DHW, N, 256), dim3(256), 0, (hipStream_t)stream, (const f16_t*)t, (const f16_t*)x, sc, sh, w2, (const f16_t*)a, (const f16_t*)da, (f16_t*)dtg, (f16_t*)dx, dw2, C, DHW, acc_dx); }
-  else
-    return XH_ERR_DTYPE;
+  hipStream_t st = (hipStream_t)stream;
+#define SKRB(V, ...) hipLaunchKernelGGL((skr_tail_bwd_kernel<T, V, ##__VA_ARGS__>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, \
+                                        (const T*)a, (const T*)da, (T*)dtg, (T*)dx, dw2, C, DHW, acc_dx)
+  XH_DISPATCH_T(dtype, {
+    // one pair of fp64 atomics per workgroup on dw2: at most 1024 of them
+    const dim3 grid = vox_grid<T>(DHW, N, 1024);
+    if (vec_ok<T>(DHW, {}) && deep_grid(grid, C)) SKRB(true, 8);
+    else if (vec_ok<T>(DHW, {})) SKRB(true);
+    else SKRB(false);
+  });
+#undef SKRB
   return xh_launch_status();
 }
 
