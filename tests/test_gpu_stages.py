@@ -313,3 +313,36 @@ def test_fused_gate_maxpool_equals_gate_then_maxpool_then_moments(shape, dtype):
     # ds sums the routed contributions over channels: the fused kernel adds four per-wave partial sums, the separate one walks
     # the channels in order -- fp32 round-off before the rounding to storage
     assert (ds.float() - ds_ref.float()).abs().max().item() <= 1e-2 * ds_ref.float().abs().max().item() * (1e-4 if dtype == torch.float32 else 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 32), (1, 16, 16, 16), (1, 4, 6, 128), (1, 3, 5, 8)])
+def test_one_two_channel_k3_conv_stencil_kernels_vs_stock(shape, dtype):
+    """DuSEAttention's spatial conv (buildingblocks.py:313-327: 1 -> 2 channels + sigmoid), its data gradient (2 -> 1) and its
+    weight gradient run on the streaming stencil kernels of csrc/conv3_tiny.hip; against torch fp32 on the stored values."""
+    import torch.nn.functional as F
+    ops = X.ops
+    n, d, h, w = shape
+    torch.manual_seed(5)
+    x = torch.randn(n, 1, d, h, w, device=DEV).to(dtype)
+    wt = torch.randn(2, 1, 3, 3, 3, device=DEV) * 0.3
+    b = torch.randn(2, device=DEV)
+    tol = 1e-5 if dtype == torch.float32 else (1.2e-2 if dtype == torch.bfloat16 else 2e-3)
+    y = ops.conv3d(x, None, [wt], [b], k=3, cout=2, act=X.ops.ACT_SIGMOID)
+    vw = 4 if dtype == torch.float32 else 8
+    if w % vw == 0 and (w // vw) <= 64 and 64 % (w // vw) == 0:
+        assert ops.last_conv_kernel().startswith("conv3_tiny_kernel<1 -> 2"), ops.last_conv_kernel()
+    ref = torch.sigmoid(F.conv3d(x.float(), wt, b, padding=1))
+    assert l2_err(y.float(), ref) < tol
+    dy = torch.randn(n, 2, d, h, w, device=DEV).to(dtype)
+    dx = ops.conv3d(dy, None, [wt], None, k=3, cout=1, transposed=True)
+    ref_dx = F.conv_transpose3d(dy.float(), wt, padding=1)
+    assert l2_err(dx.float(), ref_dx) < tol
+    dw, db = torch.zeros_like(wt), torch.zeros_like(b)
+    ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
+    xr = x.float().requires_grad_(False)
+    wr = wt.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    (F.conv3d(xr, wr, br, padding=1) * dy.float()).sum().backward()
+    assert l2_err(dw, wr.grad) < 1e-4 and l2_err(db, br.grad) < 1e-4
+    ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)                      # accumulates
+    assert l2_err(dw, 2 * wr.grad) < 1e-4

@@ -16,6 +16,9 @@
 #include "fanin.h"
 #include "../../include/xlstm_hved.h"
 
+int xh_conv3_tiny_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);                                   // conv3_tiny.hip
+int xh_conv3_tiny_wgrad_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* dw, float* db);
+
 struct ConvK {
   xh_conv_desc d;
   xh_conv_ptrs p;
@@ -1360,6 +1363,10 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
     if (r != 1) return r;
   }
   if (p->fin_red) return XH_ERR_ARG;                  // the fused finalisation exists on the MFMA path only
+  {
+    const int r = xh_conv3_tiny_try(stream, d, p);    // conv3_tiny.hip: 1 <-> 2 channels
+    if (r != 1) return r;
+  }
   xh_note_kernel("conv k%d s%d (vector kernel family)", d->k, d->stride);
   XH_DISPATCH_T(d->dtype, return conv_fwd_dispatch<T>(stream, d, p););
 }
@@ -1900,6 +1907,10 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
     if (!dw[i]) return XH_ERR_ARG;
   if (g_use_mfma) {
     const int r = d->k == 7 ? xh_conv7_wgrad_mfma_try(stream, d, p, dw, db) : xh_conv3_wgrad_mfma_try(stream, d, p, dw, db);
+    if (r != 1) return r;
+  }
+  {
+    const int r = xh_conv3_tiny_wgrad_try(stream, d, p, dw[0], db ? db[0] : nullptr);     // conv3_tiny.hip: 1 <-> 2 channels
     if (r != 1) return r;
   }
   xh_note_kernel("conv wgrad k%d s%d (vector kernel family)", d->k, d->stride);
