@@ -176,6 +176,7 @@ bool tiny_ok(const xh_conv_desc* d, const xh_conv_ptrs* p, int& lw) {
 }  // namespace
 
 void xh_note_kernel(const char* fmt, ...);
+int g_tiny_wgs = 512;   // xh_set_option(16, n): workgroups of the weight-gradient kernel (each ends with 56 same-address atomics)
 
 // XH_OK if launched, 1 if the shape is not for these kernels
 int xh_conv3_tiny_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
@@ -216,7 +217,7 @@ int xh_conv3_tiny_wgrad_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   a.D = d->D; a.H = d->H; a.W = d->W; a.LW = lw; a.transposed = 0;
   const long long lanes = (long long)d->D * d->H * lw;
   long long nb = (lanes + 255) / 256;
-  if (nb > 512) nb = 512;                               // each workgroup ends with 56 same-address atomics
+  if (nb > g_tiny_wgs) nb = g_tiny_wgs;
   dim3 grid((unsigned)nb, d->N);
   hipStream_t st = (hipStream_t)stream;
   xh_note_kernel("conv3_tiny_wgrad_kernel<%d -> %d>", d->Cin, d->Cout);
