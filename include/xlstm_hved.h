@@ -313,10 +313,11 @@ int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, con
 int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                     const float* w2, void* a, int N, int C, long long DHW);
 /* Given da: dtg = gradient w.r.t. the BatchNorm output t*sc+sh (already multiplied by both relu'),
- * dx (+)= gradient through the residual branch, dw2[0..1] (fp64, ACCUMULATED) = gradient of the 1x1 conv. */
+ * dx (+)= gradient through the residual branch, and the gradient of the 1x1 conv's two weights ACCUMULATED into dw2[0..1]
+ * (fp64) or, when dw2_f32 is given, into dw2_f32[0..1] (the parameter's fp32 gradient buffer; dw2 may then be NULL). */
 int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                     const float* w2, const void* a, const void* da, void* dtg, void* dx, double* dw2, int N, int C,
-                    long long DHW, int acc_dx);
+                    long long DHW, int acc_dx, float* dw2_f32);
 
 /* dx += w[c]*d[n,0,p] + k[n,c]: rank-1 data gradient of a C->1 1x1 conv plus a per-(n,c) constant (the
  * global-average-pool gradient) -- finishes DuSEAttention's input gradient (modules/DuSFE.py:118,135-140). */
@@ -324,14 +325,17 @@ int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, const void*
                  const float* k, int N, int C, long long DHW);
 
 /* tiny dense layers on pooled features (DuSFE.py:118-127): handled on device, fp32.
- * in: mean_r, mean_s [N][C] from moments; out: ch1, ch2 [N][C] (sigmoid'ed) and saved g [N][C]. */
+ * in: channel sums red_r, red_s [N][C][2] (fp64, from moments or a producer's epilogue); out: ch1, ch2 [N][C] (sigmoid'ed), the
+ * saved g [N][C] and, when `means` is given, the pooled means [N][2C] for the backward call (which then needs no red_r / red_s:
+ * the sums may live in scratch storage that is gone by then). */
 int xh_duse_fc_fwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
                    const float* w_comb, const float* b_comb, const float* w1, const float* b1, const float* w2,
-                   const float* b2, float* g, float* ch1, float* ch2);
+                   const float* b2, float* g, float* ch1, float* ch2, float* means);
+/* means: what xh_duse_fc_fwd left (red_r / red_s are ignored and may be NULL), or NULL: the means are taken from red_r, red_s. */
 int xh_duse_fc_bwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
                    const float* w_comb, const float* w1, const float* w2, const float* g, const float* ch1,
                    const float* ch2, const double* dch1, const double* dch2, float* dw_comb, float* db_comb,
-                   float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s);
+                   float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s, const float* means);
 
 /* ------------------------------------------------------------------------------------------------
  * ViL / mLSTM (UxLSTMEnc_3d.py:42-87, vision_lstm.py:48-506).  All fp32.  Token t = flattened (d,h,w),

@@ -108,15 +108,15 @@ SIGNATURES = {
     "xh_duse_gate_fwd_stats": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll, vp]),
     "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll]),
     "xh_rank1_add": (I, [vp, I, vp, ll, vp, ll, vp, vp, I, I, ll]),
-    "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_compose_atten_fwd": (I, [vp] * 9 + [I, I, I, I, vp, vp]),
     "xh_compose_atten_bwd": (I, [vp] * 7 + [I, I, I, I] + [vp] * 10),
     "xh_compose_multi": (I, [vp, I, I, vp, I, vp, I, vp]),
     "xh_compose_duse_fwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp]),
     "xh_compose_duse_bwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp, C.POINTER(vp * 10)]),
-    "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_skr_tail_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll]),
-    "xh_skr_tail_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
+    "xh_skr_tail_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I, vp]),
     "xh_pair_sums": (I, [vp, I, vp, ll, I, vp, ll, F, I, I, ll, I, F, vp]),
     "xh_lincomb": (I, [vp, I, vp, ll, I, vp, ll, F, vp, ll, I, I, ll, vp, vp, vp, vp, I]),
     "xh_loss_finalize": (I, [vp, I, vp, I, I, C.c_double, C.c_double, vp, vp, vp]),

@@ -2106,7 +2106,7 @@ extern "C" int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, 
 // tiny dense layers of the DuSE channel excitation (single block)
 __global__ void duse_fc_fwd_kernel(const double* red_r, const double* red_s, long long count, int N, int C,
                                    const float* wc, const float* bc, const float* w1, const float* b1, const float* w2,
-                                   const float* b2, float* g, float* ch1, float* ch2) {
+                                   const float* b2, float* g, float* ch1, float* ch2, float* means) {
   extern __shared__ float sm[];   // [N][2C] means, [N][C] g
   float* mean = sm;
   float* gs = sm + N * 2 * C;
@@ -2114,6 +2114,7 @@ __global__ void duse_fc_fwd_kernel(const double* red_r, const double* red_s, lon
     const int n = i / C, c = i % C;
     mean[n * 2 * C + c] = (float)(red_r[i * 2] / (double)count);
     mean[n * 2 * C + C + c] = (float)(red_s[i * 2] / (double)count);
+    if (means) { means[n * 2 * C + c] = mean[n * 2 * C + c]; means[n * 2 * C + C + c] = mean[n * 2 * C + C + c]; }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
@@ -2135,7 +2136,7 @@ __global__ void duse_fc_fwd_kernel(const double* red_r, const double* red_s, lon
 __global__ void duse_fc_bwd_kernel(const double* red_r, const double* red_s, long long count, int N, int C,
                                    const float* wc, const float* w1, const float* w2, const float* g, const float* ch1,
                                    const float* ch2, const double* dch1, const double* dch2, float* dwc, float* dbc,
-                                   float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s) {
+                                   float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s, const float* means) {
   extern __shared__ float sm[];   // mean [N][2C], p1 [N][C], p2 [N][C], dg [N][C]
   float* mean = sm;
   float* p1 = sm + N * 2 * C;
@@ -2143,8 +2144,8 @@ __global__ void duse_fc_bwd_kernel(const double* red_r, const double* red_s, lon
   float* dg = p2 + N * C;
   for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
     const int n = i / C, c = i % C;
-    mean[n * 2 * C + c] = (float)(red_r[i * 2] / (double)count);
-    mean[n * 2 * C + C + c] = (float)(red_s[i * 2] / (double)count);
+    mean[n * 2 * C + c] = means ? means[n * 2 * C + c] : (float)(red_r[i * 2] / (double)count);
+    mean[n * 2 * C + C + c] = means ? means[n * 2 * C + C + c] : (float)(red_s[i * 2] / (double)count);
     p1[i] = (float)dch1[i] * ch1[i] * (1.f - ch1[i]);
     p2[i] = (float)dch2[i] * ch2[i] * (1.f - ch2[i]);
   }
@@ -2185,23 +2186,23 @@ __global__ void duse_fc_bwd_kernel(const double* red_r, const double* red_s, lon
 }
 extern "C" int xh_duse_fc_fwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
                               const float* w_comb, const float* b_comb, const float* w1, const float* b1, const float* w2,
-                              const float* b2, float* g, float* ch1, float* ch2) {
+                              const float* b2, float* g, float* ch1, float* ch2, float* means) {
   if (!red_r || !red_s || !w_comb || !b_comb || !w1 || !b1 || !w2 || !b2 || !g || !ch1 || !ch2 || N <= 0 || C <= 0 || count <= 0) return XH_ERR_ARG;
   const size_t shm = (size_t)N * 3 * C * sizeof(float);
   if (shm > 60000) return XH_ERR_ARG;
-  hipLaunchKernelGGL(duse_fc_fwd_kernel, dim3(1), dim3(256), shm, (hipStream_t)stream, red_r, red_s, count, N, C, w_comb, b_comb, w1, b1, w2, b2, g, ch1, ch2);
+  hipLaunchKernelGGL(duse_fc_fwd_kernel, dim3(1), dim3(256), shm, (hipStream_t)stream, red_r, red_s, count, N, C, w_comb, b_comb, w1, b1, w2, b2, g, ch1, ch2, means);
   return xh_launch_status();
 }
 extern "C" int xh_duse_fc_bwd(void* stream, const double* red_r, const double* red_s, long long count, int N, int C,
                               const float* w_comb, const float* w1, const float* w2, const float* g, const float* ch1,
                               const float* ch2, const double* dch1, const double* dch2, float* dw_comb, float* db_comb,
-                              float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s) {
-  if (!red_r || !red_s || !w_comb || !w1 || !w2 || !g || !ch1 || !ch2 || !dch1 || !dch2 || !dw_comb || !db_comb || !dw1 ||
+                              float* dw1, float* db1, float* dw2, float* db2, float* dmean_r, float* dmean_s, const float* means) {
+  if ((!means && (!red_r || !red_s)) || !w_comb || !w1 || !w2 || !g || !ch1 || !ch2 || !dch1 || !dch2 || !dw_comb || !db_comb || !dw1 ||
       !db1 || !dw2 || !db2 || !dmean_r || !dmean_s || N <= 0 || C <= 0 || count <= 0)
     return XH_ERR_ARG;
   const size_t shm = (size_t)N * 5 * C * sizeof(float);
   if (shm > 60000) return XH_ERR_ARG;
-  hipLaunchKernelGGL(duse_fc_bwd_kernel, dim3(1), dim3(256), shm, (hipStream_t)stream, red_r, red_s, count, N, C, w_comb, w1, w2, g, ch1, ch2, dch1, dch2, dw_comb, db_comb, dw1, db1, dw2, db2, dmean_r, dmean_s);
+  hipLaunchKernelGGL(duse_fc_bwd_kernel, dim3(1), dim3(256), shm, (hipStream_t)stream, red_r, red_s, count, N, C, w_comb, w1, w2, g, ch1, ch2, dch1, dch2, dw_comb, db_comb, dw1, db1, dw2, db2, dmean_r, dmean_s, means);
   return xh_launch_status();
 }
 
@@ -2250,7 +2251,7 @@ template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
                                                           const float* sh, const float* w2, const T* __restrict__ a,
                                                           const T* __restrict__ da, T* __restrict__ dtg, T* dx,
-                                                          double* dw2acc, int C, long long dhw, int acc_dx) {
+                                                          double* dw2acc, int C, long long dhw, int acc_dx, float* dw2f) {
   __shared__ double s_red[4 * 2];
   const float w0 = w2[0], w1 = w2[1];
   double sacc[2] = {0.0, 0.0};
@@ -2331,7 +2332,10 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
     }
   VOX_LOOP_END
   block_sum_d<2>(sacc, s_red, 4);
-  if (threadIdx.x < 2) atomicAdd(&dw2acc[threadIdx.x], s_red[threadIdx.x]);
+  if (threadIdx.x < 2) {
+    if (dw2f) atomicAdd(&dw2f[threadIdx.x], (float)s_red[threadIdx.x]);
+    else atomicAdd(&dw2acc[threadIdx.x], s_red[threadIdx.x]);
+  }
 }
 extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                                const float* w2, void* a, int N, int C, long long DHW) {
@@ -2350,11 +2354,11 @@ extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const voi
 }
 extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                                const float* w2, const void* a, const void* da, void* dtg, void* dx, double* dw2,
-                               int N, int C, long long DHW, int acc_dx) {
-  if (!t || !x || !sc || !sh || !w2 || !a || !da || !dtg || !dx || !dw2 || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
+                               int N, int C, long long DHW, int acc_dx, float* dw2_f32) {
+  if (!t || !x || !sc || !sh || !w2 || !a || !da || !dtg || !dx || (!dw2 && !dw2_f32) || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
 #define SKRB(V, ...) hipLaunchKernelGGL((skr_tail_bwd_kernel<T, V, ##__VA_ARGS__>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, \
-                                        (const T*)a, (const T*)da, (T*)dtg, (T*)dx, dw2, C, DHW, acc_dx)
+                                        (const T*)a, (const T*)da, (T*)dtg, (T*)dx, dw2, C, DHW, acc_dx, dw2_f32)
   XH_DISPATCH_T(dtype, {
     // one pair of fp64 atomics per workgroup on dw2: at most 1024 of them
     const dim3 grid = vox_grid<T>(DHW, N, 1024);

@@ -486,6 +486,7 @@ class SkipReturnAttention(Function):
         ctx.mode = mode
         ctx.params = (dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2)
         ctx.saw = saw
+        ctx.xslot = _slot(x)
         return a
 
     @staticmethod
@@ -496,7 +497,12 @@ class SkipReturnAttention(Function):
         cnt = _dhw(x)
         (ddw1, dpw1w, dpw1b, dg1, db1, ddw2, dpw2w, dpw2b, dg2, db2), rets = _targets(ctx.params)
         sd = _direct(*rets)
-        dtg, dx_res, dsaw = ops.skr_tail_bwd(t2, x, sc2, sh2, w2, a, _blk(da))
+        # the 1x1 attention conv's two weight gradients go straight into the parameter's gradient buffer
+        (g_saw,), (r_saw,) = _targets((ctx.saw,))
+        # x's gradient has two parts (the residual branch here, the first depthwise conv's data gradient at the end); when x
+        # shares a gradient buffer with another consumer (fanout) the residual part is added straight into that buffer
+        slot = ctx.xslot
+        dtg, dx_res, _ = ops.skr_tail_bwd(t2, x, sc2, sh2, w2, a, _blk(da), dw2_out=g_saw.view(-1), dx_acc=_acc(slot))
         # BatchNorm 2
         red = ops.act_bwd_reduce(dtg, t2, sc2, sh2, 1.0)
         dt2 = ops.norm_bwd_fused(mode, dtg, t2, red, m2, r2, gamma=g2, dgamma=dg2, dbeta=db2)
@@ -515,11 +521,7 @@ class SkipReturnAttention(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(du1, None, [dw1], None, k=3, cout=c, groups=c, transposed=True)
-            dx = ops.add(dx, dx_res, out=dx)
-        # the 1x1 attention conv's two weight gradients (fp64 sums): straight into the parameter's gradient buffer (one launch
-        # instead of a cast + autograd's accumulate)
-        (g_saw,), (r_saw,) = _targets((ctx.saw,))
-        g_saw.view(-1).add_(dsaw)
+            dx = _ret(slot, ops.add(dx_res, dx, out=dx_res))
         return (dx, None, None, None, None, None, None, *rets, r_saw)
 
 
@@ -534,16 +536,17 @@ class DuSE(Function):
         n, c = r.shape[:2]
         cnt = _dhw(r)
         mode = MODE_BN_TRAIN if training else MODE_BN_EVAL
-        # the channel sums are saved for backward, so they must outlive the per-forward scratch arena: own storage
-        # (a producer conv's epilogue sums, when given, are copied instead of running a moments pass)
-        red_r = stats_r.clone() if stats_r is not None else torch.zeros((n, c, 2), dtype=torch.float64, device=r.device)
-        red_s = stats_s.clone() if stats_s is not None else torch.zeros((n, c, 2), dtype=torch.float64, device=r.device)
-        if stats_r is None:
+        # the channel sums: a producer conv's epilogue sums when given, else a moments pass; the backward takes the pooled means
+        # duse_fc_fwd leaves in storage of their own (the sums live in the per-forward scratch arena)
+        red_r, red_s = stats_r, stats_s
+        if red_r is None:
+            red_r = ops.zeros_red(r, n, c)
             ops.moments(r, red_r)
-        if stats_s is None:
+        if red_s is None:
+            red_s = ops.zeros_red(s, n, c)
             ops.moments(s, red_s)
         fc = dict(wc=wc, bc=bc, w1=w1, b1=b1, w2=w2, b2=b2)
-        gvec, ch1, ch2 = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc)
+        gvec, ch1, ch2, means = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc)
         comb = ops.conv3d(r, s, [sqw], [sqb], k=1, cout=1)
         sp = ops.conv3d(comb, None, [adjw], [adjb], k=3, cout=2, act=ACT_SIGMOID)
         red_ur = ops.zeros_red(r, n, c) if training else None     # BatchNorm sums of the gated outputs, left by the gate pass
@@ -555,14 +558,14 @@ class DuSE(Function):
             y, sc, sh, m, rs = ops.bn_affine_act(mode, u, red, ACT_NONE, gamma=gam, beta=bet, running_mean=rm, running_var=rv, steps=1)
             outs.append(y)
             stats += [sc, sh, m, rs]
-        ctx.save_for_backward(r, s, red_r, red_s, gvec, ch1, ch2, comb, sp, u_r, u_s, *stats, wc, w1, w2, sqw, adjw, g1, g2)
+        ctx.save_for_backward(r, s, means, gvec, ch1, ch2, comb, sp, u_r, u_s, *stats, wc, w1, w2, sqw, adjw, g1, g2)
         ctx.mode = mode
         ctx.params = (wc, bc, w1, b1, w2, b2, sqw, sqb, adjw, adjb, g1, be1, g2, be2)
         return outs[0], outs[1]
 
     @staticmethod
     def backward(ctx, dor, dos):
-        (r, s, red_r, red_s, gvec, ch1, ch2, comb, sp, u_r, u_s, sc1, sh1, m1, rs1, sc2, sh2, m2, rs2, wc, w1, w2, sqw, adjw,
+        (r, s, means, gvec, ch1, ch2, comb, sp, u_r, u_s, sc1, sh1, m1, rs1, sc2, sh2, m2, rs2, wc, w1, w2, sqw, adjw,
          g1, g2) = ctx.saved_tensors
         mode = ctx.mode
         n, c = r.shape[:2]
@@ -582,7 +585,7 @@ class DuSE(Function):
         ops.conv3d_wgrad(r, s, dcomb, [dsqw], [dsqb], k=1)
         fc = dict(wc=wc, w1=w1, w2=w2)
         fcg = dict(wc=dwc, bc=dbc, w1=dw1, b1=db1, w2=dw2, b2=db2)
-        dmr, dms = ops.duse_fc_bwd(red_r, red_s, cnt, n, c, fc, gvec, ch1, ch2, dch1, dch2, fcg)
+        dmr, dms = ops.duse_fc_bwd(means, cnt, n, c, fc, gvec, ch1, ch2, dch1, dch2, fcg)
         sq = sqw.reshape(-1)
         ops.rank1_add(dr, dcomb, sq[:c].contiguous(), dmr)
         ops.rank1_add(ds, dcomb, sq[c:].contiguous(), dms)

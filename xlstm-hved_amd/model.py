@@ -317,7 +317,9 @@ class AbstractFusion3DUNet(nn.Module):
         for level in range(levels):
             stp = None
             if self.skip_return and skip is not None:
-                a = self.skr_att[levels - level](skip, steps=bn_steps)                      # skr_att[-level], RA_HVED.py:552
+                # the skip feature feeds this level's attention and the next skip encoder: two consumers, one gradient buffer
+                skip_att, skip = Fn.fanout(skip, 2)
+                a = self.skr_att[levels - level](skip_att, steps=bn_steps)                  # skr_att[-level], RA_HVED.py:552
                 if batched and level > 0 and ops.gate_maxpool_ok(X, a):
                     X, stp = Fn.GateMaxPool.apply(X, a)        # gate, this level's pooling and its first norm's sums: one pass
                 else:

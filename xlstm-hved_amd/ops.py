@@ -946,18 +946,20 @@ def compose_duse_bwd(params, c, dsqw, dsqb, dadjw, dadjb, grads):
 
 
 def duse_fc_fwd(red_r, red_s, count, n, c, p):
+    """-> g, ch1, ch2 (n, c) and the pooled means (n, 2c) for duse_fc_bwd (own storage: red_r / red_s may be scratch)."""
     g, ch1, ch2 = (torch.empty((n, c), dtype=torch.float32, device=red_r.device) for _ in range(3))
+    means = torch.empty((n, 2 * c), dtype=torch.float32, device=red_r.device)
     L.check(L.load().xh_duse_fc_fwd(_stream(), _p(red_r), _p(red_s), count, n, c, _p(p["wc"]), _p(p["bc"]), _p(p["w1"]), _p(p["b1"]),
-                                    _p(p["w2"]), _p(p["b2"]), _p(g), _p(ch1), _p(ch2)), "xh_duse_fc_fwd")
-    return g, ch1, ch2
+                                    _p(p["w2"]), _p(p["b2"]), _p(g), _p(ch1), _p(ch2), _p(means)), "xh_duse_fc_fwd")
+    return g, ch1, ch2, means
 
 
-def duse_fc_bwd(red_r, red_s, count, n, c, p, g, ch1, ch2, dch1, dch2, grads):
-    """grads: dict of fp32 buffers (wc, bc, w1, b1, w2, b2) the kernel ACCUMULATES into."""
+def duse_fc_bwd(means, count, n, c, p, g, ch1, ch2, dch1, dch2, grads):
+    """means: from duse_fc_fwd.  grads: dict of fp32 buffers (wc, bc, w1, b1, w2, b2) the kernel ACCUMULATES into."""
     dmr, dms = (torch.empty((n, c), dtype=torch.float32, device=g.device) for _ in range(2))
-    L.check(L.load().xh_duse_fc_bwd(_stream(), _p(red_r), _p(red_s), count, n, c, _p(p["wc"]), _p(p["w1"]), _p(p["w2"]), _p(g), _p(ch1),
+    L.check(L.load().xh_duse_fc_bwd(_stream(), None, None, count, n, c, _p(p["wc"]), _p(p["w1"]), _p(p["w2"]), _p(g), _p(ch1),
                                     _p(ch2), _p(dch1), _p(dch2), _p(grads["wc"]), _p(grads["bc"]), _p(grads["w1"]), _p(grads["b1"]),
-                                    _p(grads["w2"]), _p(grads["b2"]), _p(dmr), _p(dms)), "xh_duse_fc_bwd")
+                                    _p(grads["w2"]), _p(grads["b2"]), _p(dmr), _p(dms), _p(means)), "xh_duse_fc_bwd")
     return dmr, dms
 
 
@@ -968,12 +970,19 @@ def skr_tail(t, x, sc, sh, w2):
     return a
 
 
-def skr_tail_bwd(t, x, sc, sh, w2, a, da):
+def skr_tail_bwd(t, x, sc, sh, w2, a, da, dw2_out=None, dx_acc=None):
+    """dw2_out: contiguous fp32 (2,) buffer the two weight gradients are ACCUMULATED into (the parameter's gradient); else a
+    fresh fp64 pair is returned.  dx_acc: a gradient buffer of x's shape the residual-branch gradient is ADDED into (returned
+    as dx); else a new tensor."""
     n, c, d, h, w, _ = _vol(x)
-    dtg, dx = torch.empty_like(t), torch.empty_like(x)
-    dw2 = zeros_f64(x.device, (2,))
+    if dx_acc is not None and (dx_acc.shape != x.shape or dx_acc.dtype != x.dtype or not dx_acc.is_contiguous()):
+        raise ValueError("skr_tail_bwd: dx_acc must be a contiguous tensor of x's shape and type")
+    dtg, dx = torch.empty_like(t), (dx_acc if dx_acc is not None else torch.empty_like(x))
+    dw2 = None if dw2_out is not None else zeros_f64(x.device, (2,))
+    if dw2_out is not None and (dw2_out.dtype != torch.float32 or dw2_out.numel() != 2 or not dw2_out.is_contiguous()):
+        raise ValueError("skr_tail_bwd: dw2_out must be a contiguous fp32 tensor of 2 elements")
     L.check(L.load().xh_skr_tail_bwd(_stream(), _dt(x), _p(t), _p(x), _p(sc), _p(sh), _p(w2), _p(a), _p(da), _p(dtg), _p(dx), _p(dw2),
-                                     n, c, d * h * w, 0), "xh_skr_tail_bwd")
+                                     n, c, d * h * w, int(dx_acc is not None), _p(dw2_out)), "xh_skr_tail_bwd")
     return dtg, dx, dw2
 
 
