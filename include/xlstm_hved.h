@@ -97,10 +97,12 @@ typedef struct {
   double* red;                                /* [N][Cout][2], caller zeroes, epi!=0 */
   void* ws; long long ws_bytes;               /* scratch for packed bf16 MFMA weight fragments (may be NULL:
                                                  the vector kernel is used); size from xh_conv3d_workspace_bytes */
-  /* Optional fused InstanceNorm finalisation (MFMA path only; needs pre == 1): when fin_red is given, the conv kernel itself
-   * turns the raw sums fin_red[n][c] = (sum x, sum x^2) over fin_count voxels into scale = rstd, shift = -mean*rstd (every
-   * workgroup for its own input channels, in fp64) and ALSO WRITES pre_sc / pre_sh / fin_mean / fin_rstd (kept for the
-   * backward), replacing a separate xh_norm_finalize launch.  A call that cannot take the MFMA path returns an error. */
+  /* Optional fused InstanceNorm finalisation (k = 3: the MFMA path, and the stride-2 convs; needs pre == 1): when fin_red is
+   * given, the conv kernel itself turns the raw sums fin_red[n][c] = (sum x, sum x^2) over fin_count voxels into scale = rstd,
+   * shift = -mean*rstd (every workgroup for its own input channels, in fp64) and ALSO WRITES pre_sc / pre_sh / fin_mean /
+   * fin_rstd (kept for the backward), replacing a separate xh_norm_finalize launch.  A stride-1 call that cannot take the MFMA
+   * path returns an error; a stride-2 call whose kernel cannot take it (fp32 storage, unaligned rows) finalises with a launch
+   * of its own first. */
   const double* fin_red; float* fin_mean; float* fin_rstd; long long fin_count;
   int ws_packed;                              /* 1: ws already holds this conv's fragments (xh_conv3d_prepack): no pack launch */
   /* Optional statistics fan-in workspace (epi != 0): xh_fanin_bytes() bytes, 128-byte aligned, ZERO on entry; the launch

@@ -13,9 +13,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include "common.h"
+#include "conv_pack.h"
 #include "fanin.h"
 #include "../../include/xlstm_hved.h"
 
+extern "C" int xh_norm_finalize(void* stream, int mode, const double* red, int N, int C, long long count, int gs, float eps,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var, int steps, float* sc,
+                                float* sh, float* mean, float* rstd);                                                   // eltwise.hip
 int xh_conv3_tiny_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);                                   // conv3_tiny.hip
 int xh_conv3_tiny_wgrad_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* dw, float* db);
 
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(256) void conv3_s2_gather_kernel(const ConvK a) {
 // channels @16^3 -> 8^3 ran 63 us on 32 workgroups): a block keeps 256 / KS lanes and its KS thread groups split the input
 // channels, partial sums meet in LDS (part_off floats into the dynamic segment) and group 0 runs the epilogue.
 template <typename T, int COB>
-__global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW, int KS, int part_off) {
+__global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW, int KS, int part_off, int fin_off) {
   constexpr int VW = VWT<T>::v, OW = VW / 2;
   extern __shared__ float s_dyn[];                    // [Cin_g][27][COB] weights, then reduction scratch
   float* s_w = s_dyn;
@@ -652,6 +656,23 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
     const int tap = r % 27, ci_g = r / 27;
     const int co_g = cob * COB + co;
     s_w[idx] = co_g < a.Cout_g ? conv_weight(a, g, co_g, ci_g, tap, 27) : 0.f;
+  }
+  // fused InstanceNorm finalisation (xh_conv_ptrs.fin_red; 16-bit storage): the group's scale / shift from the raw sums into
+  // LDS, the same bits in every workgroup; workgroup (0, 0, 0) also leaves them and mean / rstd of ALL channels in memory for
+  // the backward pass -- no norm_finalize launch in front of the stride-2 convs
+  const bool fin = a.p.fin_red != nullptr;
+  float* s_fin = s_dyn + fin_off;                     // [2][Cin_g]
+  if (fin) {
+    const double inv = 1.0 / (double)a.p.fin_count;
+    if (tid < a.Cin_g) {
+      const int c = n * a.d.Cin + g * a.Cin_g + tid;
+      float m_, r_;
+      in_finalize(a.p.fin_red[2 * c], a.p.fin_red[2 * c + 1], inv, s_fin[tid], s_fin[a.Cin_g + tid], m_, r_);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+      for (int i = tid; i < a.d.N * a.d.Cin; i += 256)
+        in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], inv, const_cast<float*>(a.p.pre_sc)[i], const_cast<float*>(a.p.pre_sh)[i],
+                    a.p.fin_mean[i], a.p.fin_rstd[i]);
   }
   __syncthreads();
   const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
@@ -674,7 +695,8 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
     const int c = g * a.Cin_g + ci_g;
     const T* src = in_plane<T>(a, n, c, dhw) + 2 * ow0;
     float sc = 1.f, sh = 0.f;
-    if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
+    if (fin) { sc = s_fin[ci_g]; sh = s_fin[a.Cin_g + ci_g]; }
+    else if (a.d.pre) { sc = a.p.pre_sc[n * a.d.Cin + c]; sh = a.p.pre_sh[n * a.d.Cin + c]; }
     float x[9][VW], m[9];
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
@@ -1282,16 +1304,30 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
             ks *= 2;
         const int lpb = 256 / ks;
         const int part_off = (int)((shm / sizeof(float) + 1) & ~(size_t)1);
-        const size_t shm2 = ks > 1 ? (size_t)part_off * sizeof(float) + (size_t)(ks - 1) * lpb * cob * (VW / 2) * sizeof(float) : shm;
+        size_t shm2 = ks > 1 ? (size_t)part_off * sizeof(float) + (size_t)(ks - 1) * lpb * cob * (VW / 2) * sizeof(float) : shm;
+        if (p->fin_red && sizeof(T) != 2) {             // fp32 storage: the finalisation of xh_norm_finalize, bit for bit
+          const int rc = xh_norm_finalize(stream, 0, p->fin_red, d->N, d->Cin, p->fin_count, 1, 1e-5f, nullptr, nullptr, nullptr, nullptr, 1,
+                                          const_cast<float*>(p->pre_sc), const_cast<float*>(p->pre_sh), p->fin_mean, p->fin_rstd);
+          if (rc) return rc;
+          a.p.fin_red = nullptr;
+        }
+        const int fin_off = (int)((shm2 / sizeof(float) + 1) & ~(size_t)1);
+        if (a.p.fin_red) shm2 = (size_t)fin_off * sizeof(float) + (size_t)2 * cin_g * sizeof(float);
         dim3 gridv((unsigned)((lanes + lpb - 1) / lpb), a.ncob, d->N * d->groups);
         xh_note_kernel("conv3_s2_vec_kernel<%s, %d>", tname<T>(), cob);
         switch (cob) {
-          case 2: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 2>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off); break;
-          case 4: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 4>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off); break;
-          default: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 8>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off);
+          case 2: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 2>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off, fin_off); break;
+          case 4: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 4>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off, fin_off); break;
+          default: hipLaunchKernelGGL((conv3_s2_vec_kernel<T, 8>), gridv, dim3(256), shm2, (hipStream_t)stream, a, lw, ks, part_off, fin_off);
         }
         return xh_launch_status();
       }
+    }
+    if (p->fin_red) {                                   // the gather kernel takes finished scale / shift
+      const int rc = xh_norm_finalize(stream, 0, p->fin_red, d->N, d->Cin, p->fin_count, 1, 1e-5f, nullptr, nullptr, nullptr, nullptr, 1,
+                                      const_cast<float*>(p->pre_sc), const_cast<float*>(p->pre_sh), p->fin_mean, p->fin_rstd);
+      if (rc) return rc;
+      a.p.fin_red = nullptr;
     }
     xh_note_kernel("conv3_s2_gather_kernel<%s, %d>", tname<T>(), cob);
     switch (cob) {
@@ -1363,7 +1399,9 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
     const int r = d->k == 7 ? xh_conv7_mfma_try(stream, d, p) : xh_conv3_mfma_try(stream, d, p);
     if (r != 1) return r;
   }
-  if (p->fin_red) return XH_ERR_ARG;                  // the fused finalisation exists on the MFMA path only
+  // the fused finalisation exists on the MFMA path and in front of the stride-2 convs (which fall back to a finalisation launch
+  // of their own where their kernel cannot take it)
+  if (p->fin_red && !(d->k == 3 && d->stride == 2)) return XH_ERR_ARG;
   {
     const int r = xh_conv3_tiny_try(stream, d, p);    // conv3_tiny.hip: 1 <-> 2 channels
     if (r != 1) return r;

@@ -93,7 +93,7 @@ def zeros_f64(device, shape):
         numel *= int(s_)
     a = _ARENA.get(device)
     if a is None:
-        a = _ARENA[device] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=device), 0, 0]
+        a = _arenas(device)[0]
     need = (numel + 15) & ~15
     if a[1] + need > _ARENA_DOUBLES:
         return torch.zeros(shape, dtype=torch.float64, device=device)
@@ -108,12 +108,20 @@ def zeros_f64(device, shape):
 # are handed out during backward and consumed before it ends; the reset at the start of the next forward zeroes them again.
 _ARENA32_FLOATS = 1 << 20         # 4 MiB
 _ARENA32 = {}
+_ARENA_BYTES = {}                 # both arenas of a device are one allocation (fp64 part first): ONE fill zeroes them
+
+
+def _arenas(device):
+    raw = _ARENA_BYTES[device] = torch.zeros(_ARENA_DOUBLES * 8 + _ARENA32_FLOATS * 4, dtype=torch.uint8, device=device)
+    _ARENA[device] = [raw[:_ARENA_DOUBLES * 8].view(torch.float64), 0, 0]
+    _ARENA32[device] = [raw[_ARENA_DOUBLES * 8:].view(torch.float32), 0, 0]
+    return _ARENA[device], _ARENA32[device]
 
 
 def zeros_f32(device, numel):
     a = _ARENA32.get(device)
     if a is None:
-        a = _ARENA32[device] = [torch.zeros(_ARENA32_FLOATS, dtype=torch.float32, device=device), 0, 0]
+        a = _arenas(device)[1]
     need = (int(numel) + 15) & ~15
     if a[1] + need > _ARENA32_FLOATS:
         return torch.zeros(int(numel), dtype=torch.float32, device=device)
@@ -132,14 +140,17 @@ def red_arena_reset(device):
     # dirty, and the high-water mark only knows what ran before (a step captured without a preceding eager pass of the same
     # shape would otherwise leave stale sums / gradients for replays 2..N).
     whole = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-    a = _ARENA.get(device)
-    if a is not None and (a[2] > 0 or whole):
-        (a[0] if whole else a[0][:a[2]]).zero_()
-        a[1] = 0
-    b = _ARENA32.get(device)
-    if b is not None and (b[2] > 0 or whole):
-        (b[0] if whole else b[0][:b[2]]).zero_()
-        b[1] = 0
+    a, b, raw = _ARENA.get(device), _ARENA32.get(device), _ARENA_BYTES.get(device)
+    if raw is None:
+        return
+    if whole:
+        raw.zero_()                                    # one fill for both arenas
+    elif b[2] > 0:
+        raw[:_ARENA_DOUBLES * 8 + b[2] * 4].zero_()    # the fp64 arena and the used part of the fp32 one, still one fill
+    elif a[2] > 0:
+        a[0][:a[2]].zero_()
+    a[1] = 0
+    b[1] = 0
 
 
 def zeros_red(t, n, c):
@@ -347,7 +358,7 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
         ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
         ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
     if stats is not None:
-        if need:            # MFMA path: the pack launch finalises the statistics
+        if need or (k == 3 and stride == 2):   # MFMA path / stride-2 convs: the conv launch finalises the statistics itself
             ptrs.fin_red, ptrs.fin_mean, ptrs.fin_rstd, ptrs.fin_count = _p(in_stats[0]), _p(stats[2]), _p(stats[3]), int(in_stats[1])
         else:
             L.check(lib.xh_norm_finalize(_stream(), 0, _p(in_stats[0]), n, stats[0].shape[1], int(in_stats[1]), 1, NORM_EPS, None,
