@@ -28,8 +28,11 @@ struct Conv7K {
   int tilesW, tilesH, sd, dsegs;
 };
 
-template <int FMT, int CI, int CO>
-__global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
+// KSPLIT: the depth taps of an output plane are shared by KSPLIT wave pairs (2 KSPLIT waves per workgroup on the same LDS tiles): a
+// fraction of the MFMA chain per wave and KSPLIT waves per SIMD instead of one -- the kernel is parked on LDS fragment reads (6 % MFMA busy
+// with one wave per SIMD), and at 32^3 / 64^3 its run time is the chain of one workgroup.  The partial tiles meet in LDS.
+template <int FMT, int CI, int CO, int KSPLIT = 4>
+__global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_mfma_kernel(const Conv7K a) {
   typedef h16<FMT> ST;                                // storage type: ST or f16_t
   constexpr int PPM = 32 / (8 * CI);                  // depth taps per MFMA (1 for CI = 4, 2 for CI = 2)
   constexpr int NKD = (7 + PPM - 1) / PPM;            // MFMA steps along kd
@@ -40,14 +43,16 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
   constexpr int VB = CI * 2;                          // bytes per voxel in LDS
   constexpr int PLANE = IH * IWP * VB;
   constexpr int NG = TW / 8 + 2;                      // aligned 8-voxel groups covering [ow0 - 8, ow0 + TW + 8)
-  constexpr int NITEM = IH * NG, NIT = (NITEM + 127) / 128;
+  constexpr int NTHR = 128 * KSPLIT;
+  constexpr int NITEM = IH * NG, NIT = (NITEM + NTHR - 1) / NTHR;
   constexpr int GS = 4 / PPM;                         // k-groups per depth tap (4 or 2)
   constexpr int TBL = 8 * 8 * GS * CO * 16;           // B table bytes: [kd 8][kh 8][gslot][co] x 16 B
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_in = smem;                         // 8 * PLANE
   unsigned char* s_tb = smem + 8 * PLANE;             // TBL
+  float* s_part = reinterpret_cast<float*>(smem + 8 * PLANE + TBL);   // [KSPLIT - 1][RT waves][MT][4][64]: partial tiles of the other tap shares
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & (RT - 1), kq = tid >> 7;
   const int g4 = lane >> 4, nn = lane & 15;
   const int n = blockIdx.z;
   const int D = a.d.D, H = a.d.H, W = a.d.W;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
   // ---- B table: entry (kd, kh, gslot, co) = 8 bf16: element e -> (kw, ci) of the k-group ----
   {
     const float* wp = a.p.w[0];
-    for (int idx = tid; idx < 8 * 8 * GS * CO * 8; idx += 128) {
+    for (int idx = tid; idx < 8 * 8 * GS * CO * 8; idx += NTHR) {
       const int e = idx & 7;
       int r = idx >> 3;
       const int co = r % CO; r /= CO;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
   int sp_lds[NIT], sp_gq[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int item = tid + it * 128;
+    const int item = tid + it * NTHR;
     const int gi = item % NG, hy = item / NG;
     const int gq = gi - 1;
     const int gh = oh0 - 3 + hy, gw = ow0 + gq * 8;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int ks = 0; ks < NKD; ++ks) {
+    for (int ks = kq; ks < NKD; ks += KSPLIT) {
       const int kd = ks * PPM + kd_l;                 // this lane's depth tap; kd = 7 is the dummy half of the last step:
       const int kda = kd < 7 ? kd : 6;                // zero weights, and a resident (finite) plane to multiply them with
       const unsigned char* pl = s_in + ((d + kda - 3 + 8) & 7) * PLANE;
@@ -184,9 +189,26 @@ __global__ __launch_bounds__(128, 2) void conv7_mfma_kernel(const Conv7K a) {
       }
     }
     if (more) store_plane(d + 4);
+    if (KSPLIT > 1) {                                  // the other tap shares hand their partial tiles over
+      if (kq > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_part[((((kq - 1) * RT + wv) * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
+      }
+      __syncthreads();
+      if (kq == 0) {
+#pragma unroll
+        for (int q = 0; q < KSPLIT - 1; ++q)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] += s_part[(((q * RT + wv) * MT + mt) * 4 + r) * 64 + lane];
+      }
+    }
     // ---- epilogue: lane = voxels 4*g4 .. +3 of M tile mt, output row jn of this wave's row tile, channel con ----
     const int oh = oh0 + wv * JR + jn;
-    if (oh < H) {
+    if (oh < H && kq == 0) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         float o[4];
@@ -227,7 +249,7 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   hipStream_t st = (hipStream_t)stream;
   const int f = d->dtype == XH_F16 ? 1 : 0;
   if (d->Cin == 4) {
-    const size_t shm = (size_t)8 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16;
+    const size_t shm = (size_t)8 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16 + 3 * 2 * 2 * 4 * 64 * sizeof(float);
     static bool done = false;
     if (!done) {
       (void)hipFuncSetAttribute((const void*)conv7_mfma_kernel<0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -235,13 +257,13 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
       done = true;
     }
     xh_note_kernel("conv7_mfma_kernel<%d, 4, 2>", f);
-    if (f) hipLaunchKernelGGL((conv7_mfma_kernel<1, 4, 2>), grid, dim3(128), shm, st, a);
-    else hipLaunchKernelGGL((conv7_mfma_kernel<0, 4, 2>), grid, dim3(128), shm, st, a);
+    if (f) hipLaunchKernelGGL((conv7_mfma_kernel<1, 4, 2>), grid, dim3(512), shm, st, a);
+    else hipLaunchKernelGGL((conv7_mfma_kernel<0, 4, 2>), grid, dim3(512), shm, st, a);
   } else {
-    const size_t shm = (size_t)8 * (2 * 4 + 6) * 40 * 4 + 8 * 8 * 2 * 4 * 16;
+    const size_t shm = (size_t)8 * (2 * 4 + 6) * 40 * 4 + 8 * 8 * 2 * 4 * 16 + 3 * 2 * 2 * 4 * 64 * sizeof(float);
     xh_note_kernel("conv7_mfma_kernel<%d, 2, 4>", f);
-    if (f) hipLaunchKernelGGL((conv7_mfma_kernel<1, 2, 4>), grid, dim3(128), shm, st, a);
-    else hipLaunchKernelGGL((conv7_mfma_kernel<0, 2, 4>), grid, dim3(128), shm, st, a);
+    if (f) hipLaunchKernelGGL((conv7_mfma_kernel<1, 2, 4>), grid, dim3(512), shm, st, a);
+    else hipLaunchKernelGGL((conv7_mfma_kernel<0, 2, 4>), grid, dim3(512), shm, st, a);
   }
   return xh_launch_status();
 }
