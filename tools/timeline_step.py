@@ -31,7 +31,8 @@ for s, e in zip(S[1:], E[1:]):
         cur_e = max(cur_e, e)
 busy += cur_e - cur_s
 print(f"launches {per}, step period {period:.0f} us, span {span:.0f} us, union busy {busy / 1e3:.0f} us, sum of durations {sum(e - s for s, e in zip(S, E)) / 1e3:.0f} us")
-print(f"idle gaps: {len(gaps)} totalling {sum(gaps):.0f} us (median {sorted(gaps)[len(gaps) // 2]:.2f} us, > 5 us: {sum(1 for g in gaps if g > 5)})")
+med = sorted(gaps)[len(gaps) // 2] if gaps else 0.0
+print(f"idle gaps: {len(gaps)} totalling {sum(gaps):.0f} us (median {med:.2f} us, > 5 us: {sum(1 for g in gaps if g > 5)})")
 
 
 def fam(nm):
