@@ -278,8 +278,10 @@ int xh_channel_pool2_fwd(void* stream, int dtype, const void* xa, long long xa_b
 int xh_channel_pool2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
                          const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb, long long dxb_bs, int acc_b,
                          int N, long long DHW);
+/* red (may be NULL): [N][Ca + Cb][2] fp64, zeroed by the caller: the channel sums (sum y, sum y^2) of the stored output, left
+ * by the same pass for the InstanceNorm of the conv that follows (no xh_moments launch). */
 int xh_gate2_fwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb, const void* E,
-                 long long E_bs, void* y, long long y_bs, int N, long long DHW);
+                 long long E_bs, void* y, long long y_bs, int N, long long DHW, double* red);
 int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb, const void* E,
                  long long E_bs, const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb, long long dxb_bs,
                  int acc_b, void* dE, long long dE_bs, int N, long long DHW);

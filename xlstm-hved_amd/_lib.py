@@ -100,7 +100,7 @@ SIGNATURES = {
     "xh_gate_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, ll, I, I]),
     "xh_channel_pool2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, I, ll]),
     "xh_channel_pool2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, vp, ll, I, I, ll]),
-    "xh_gate2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, ll]),
+    "xh_gate2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, ll, vp]),
     "xh_gate2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, vp, ll, I, vp, ll, I, vp, ll, I, ll]),
     "xh_gate_maxpool_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, I, I, I, vp]),
     "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I, I]),

@@ -150,11 +150,11 @@ class DoubleConv(nn.Module):
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, 1, order, num_groups, padding=padding))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, pool_stride, order, num_groups, padding=padding))
 
-    def forward(self, x, x2=None, out_stats=False):
+    def forward(self, x, x2=None, out_stats=False, in_stats=None):
         if self.SingleConv1.order != "ilc":
             return self.SingleConv2(self.SingleConv1(x, x2))
         # conv1's epilogue feeds conv2's InstanceNorm -- its only consumer, so conv1's bias add is an identity (drop_bias)
-        y1, st1 = self.SingleConv1(x, x2, out_stats=True, drop_bias=True)
+        y1, st1 = self.SingleConv1(x, x2, in_stats=in_stats, out_stats=True, drop_bias=True)
         return self.SingleConv2(y1, in_stats=st1, out_stats=out_stats)
 
 
@@ -256,7 +256,7 @@ class AttenModule2(nn.Module):
                                      self.seg_spatial2.bias, self.enc_spatial.weight, self.enc_spatial.bias,
                                      self.enc_spatial2.weight, self.enc_spatial2.bias)
 
-    def forward(self, seg_x, enc_x, recon_x=None):
+    def forward(self, seg_x, enc_x, recon_x=None, stats=False):
         """enc_x: the encoder feature, or a pair of aliases of it from Fn.fanout (one per consumer here: pooling, gating) when
         the caller shares the feature with other consumers (one gradient buffer instead of autograd's adds)."""
         enc_p, enc_g = enc_x if isinstance(enc_x, tuple) else Fn.fanout(enc_x, 2)
@@ -264,7 +264,7 @@ class AttenModule2(nn.Module):
         pooled = Fn.ChannelPool2.apply(seg_p, enc_p)
         w, b = self.composed()
         gates = Fn.conv(pooled, [w], [b], act=ACT_SIGMOID)        # [:,0] seg scale, [:,1] enc scale
-        return Fn.GateCat.apply(seg_g, enc_g, gates)
+        return Fn.GateCat.apply(seg_g, enc_g, gates, stats)      # stats: (output, its channel sums for the next InstanceNorm)
 
 
 class Upsampling(nn.Module):
@@ -303,6 +303,9 @@ class Decoder(nn.Module):
         kw = dict(out_stats=True) if out_stats else {}
         x = self.upsampling(encoder_features[0] if isinstance(encoder_features, tuple) else encoder_features, x, up_size)
         if self.RSM:
+            if type(self.basic_module) is DoubleConv and self.basic_module.SingleConv1.order == "ilc":
+                y, st = self.atten_module(x, encoder_features, stats=True)   # the gate pass leaves the first InstanceNorm's sums
+                return self.basic_module(y, in_stats=st, **kw)
             return self.basic_module(self.atten_module(x, encoder_features), **kw)
         if encoder_features is not None:
             return self.basic_module(encoder_features, x, **kw)      # virtual torch.cat((enc, x), 1)

@@ -1542,8 +1542,13 @@ __global__ __launch_bounds__(256) void channel_pool2_bwd_kernel(const Pair2<T> p
 }
 // y (N, C0 + C1, ...) = [x0 (1 + E[:,0]) | x1 (1 + E[:,1])]; grid.y = C0 + C1
 template <typename T, bool VEC>
-__global__ __launch_bounds__(EW_BLOCK) void gate2_fwd_kernel(const Pair2<T> p, const T* E, long long E_bs, T* y, long long y_bs, long long dhw) {
+// red != nullptr: also the channel sums (sum y, sum y^2) of the rounded output, for the InstanceNorm of the conv that follows
+// (launched on the reduction grid then, like duse_gate_fwd_kernel)
+__global__ __launch_bounds__(EW_BLOCK) void gate2_fwd_kernel(const Pair2<T> p, const T* E, long long E_bs, T* y, long long y_bs, long long dhw,
+                                                            double* red) {
+  __shared__ double s_red[4 * 2];
   const int w = (int)blockIdx.y >= p.C[0] ? 1 : 0, cl = blockIdx.y - (w ? p.C[0] : 0);
+  double s[2] = {0.0, 0.0};
   ROW_LOOP_BEGIN
     float xv[VW], sv[VW];
     ldrow<VEC>(p.x[w] + n * p.x_bs[w] + (long long)cl * dhw, q, valid, xv);
@@ -1551,7 +1556,19 @@ __global__ __launch_bounds__(EW_BLOCK) void gate2_fwd_kernel(const Pair2<T> p, c
 #pragma unroll
     for (int i = 0; i < VW; ++i) xv[i] *= (1.f + sv[i]);
     strow<VEC>(y + n * y_bs + (long long)c * dhw, q, valid, xv);
+    if (red) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+        if (i < valid) { const float r = rnd_as((const T*)nullptr, xv[i]); t0 += r; t1 = fmaf(r, r, t1); }
+      s[0] += (double)t0;
+      s[1] += (double)t1;
+    }
   ROW_LOOP_END
+  if (red) {
+    block_sum_d<2>(s, s_red, EW_BLOCK >> 6);
+    if (threadIdx.x < 2) atomicAdd(&red[((long long)blockIdx.z * gridDim.y + blockIdx.y) * 2 + threadIdx.x], s_red[threadIdx.x]);
+  }
 }
 // dy (N, C0 + C1, ...) -> dx[w] (+)= dy (1 + E[:,w]),  dE[:,w] = sum_c dy x[w]
 template <typename T, bool VEC, int CBT = CB>
@@ -1634,15 +1651,15 @@ extern "C" int xh_channel_pool2_bwd(void* stream, int dtype, const void* xa, lon
   return xh_launch_status();
 }
 extern "C" int xh_gate2_fwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
-                            const void* E, long long E_bs, void* y, long long y_bs, int N, long long DHW) {
+                            const void* E, long long E_bs, void* y, long long y_bs, int N, long long DHW, double* red) {
   if (!PAIR_ARGS_OK || !E || !y) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype, {
     const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, nullptr, 0, 0, nullptr, 0, 0);
-    const dim3 grid = row_grid<T>(DHW, Ca + Cb, N);
+    const dim3 grid = red ? red_grid<T>(DHW, Ca + Cb, N) : row_grid<T>(DHW, Ca + Cb, N);
     if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, y_bs}))
-      hipLaunchKernelGGL((gate2_fwd_kernel<T, true>), grid, dim3(EW_BLOCK), 0, st, p, (const T*)E, E_bs, (T*)y, y_bs, DHW);
-    else hipLaunchKernelGGL((gate2_fwd_kernel<T, false>), grid, dim3(EW_BLOCK), 0, st, p, (const T*)E, E_bs, (T*)y, y_bs, DHW);
+      hipLaunchKernelGGL((gate2_fwd_kernel<T, true>), grid, dim3(EW_BLOCK), 0, st, p, (const T*)E, E_bs, (T*)y, y_bs, DHW, red);
+    else hipLaunchKernelGGL((gate2_fwd_kernel<T, false>), grid, dim3(EW_BLOCK), 0, st, p, (const T*)E, E_bs, (T*)y, y_bs, DHW, red);
   });
   return xh_launch_status();
 }

@@ -398,18 +398,23 @@ class GateCat(Function):
     """cat[a*(1+E[:,0]), b*(1+E[:,1])] (buildingblocks.py:287,297-299)."""
 
     @staticmethod
-    def forward(ctx, a, b, E):
-        out = ops.gate2(a, b, E)                               # both halves of the concat in one launch
+    def forward(ctx, a, b, E, stats=False):
+        """stats: also return the (n, C, 2) fp64 channel sums of the output (the next conv's InstanceNorm: no moments pass)."""
+        red = ops.zeros_red(a, a.shape[0], a.shape[1] + b.shape[1]) if stats else None
+        out = ops.gate2(a, b, E, red)                          # both halves of the concat in one launch
         ctx.save_for_backward(a, b, E)
         ctx.slots = (_slot(a), _slot(b))
+        if stats:
+            ctx.mark_non_differentiable(red)
+            return out, red
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_):
         a, b, E = ctx.saved_tensors
         sa, sb = ctx.slots
         da, db, dE = ops.gate2_bwd(a, b, E, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb))
-        return _ret(sa, da), _ret(sb, db), dE
+        return _ret(sa, da), _ret(sb, db), dE, None
 
 
 class Gate(Function):

@@ -812,12 +812,13 @@ def channel_pool2_bwd(a, b, dy, acc_a=None, acc_b=None):
     return da, db
 
 
-def gate2(a, b, E):
+def gate2(a, b, E, red=None):
+    """cat[a * (1 + E[:, 0]), b * (1 + E[:, 1])]; with `red` (zeroed (n, ca + cb, 2) fp64) the channel sums of the output too."""
     n, ca, d, h, w, bsa = _vol(a)
     cb, bsb = b.shape[1], _vol(b)[5]
     y = new_like(a, (n, ca + cb, d, h, w))
-    L.check(L.load().xh_gate2_fwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(E), _vol(E)[5], _p(y), _vol(y)[5], n, d * h * w),
-            "xh_gate2_fwd")
+    L.check(L.load().xh_gate2_fwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(E), _vol(E)[5], _p(y), _vol(y)[5], n, d * h * w,
+                                  _p(red)), "xh_gate2_fwd")
     return y
 
 
