@@ -288,7 +288,8 @@ int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int C
 /* Gate + MaxPool3d(2) in one pass (RA_HVED.py:552 followed by buildingblocks.py:655-657): y = maxpool2(x * (1 + s)), the gated
  * values rounded to the storage type before the maximum (bit-identical to xh_gate_fwd + xh_maxpool2_fwd); red (optional):
  * red[n][c][0..1] += (sum y, sum y^2) of the stored output for the InstanceNorm that follows.  D, H even, W a multiple of 8,
- * batch strides multiples of 8.  bwd: dx = dy routed to the first maximum of its window, times (1 + s); ds = sum over channels
+ * batch strides multiples of 8.  fwd with s == NULL: a plain MaxPool3d(2) that leaves the channel sums (bit-identical to
+ * xh_maxpool2_fwd + xh_moments).  bwd: dx = dy routed to the first maximum of its window, times (1 + s); ds = sum over channels
  * of the routed dy times x (s has one channel). */
 int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y, long long y_bs,
                         int N, int C, int D, int H, int W, double* red);

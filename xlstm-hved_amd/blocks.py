@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import functional as Fn
+from . import ops
 from .ops import ACT_SIGMOID
 
 
@@ -217,6 +218,13 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         if self.pooling is not None:
+            first = self.basic_module[0]
+            if type(first) is DoubleConv and first.SingleConv1.order == "ilc" and x.is_cuda and ops.gate_maxpool_ok(x, None):
+                x, st = Fn.MaxPool2Stats.apply(x)            # the pooling leaves the first InstanceNorm's sums
+                x = first(x, in_stats=st)
+                for m in list(self.basic_module)[1:]:
+                    x = m(x)
+                return x
             x = Fn.MaxPool2.apply(x)
         return self.basic_module(x)
 

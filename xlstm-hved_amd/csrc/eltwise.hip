@@ -1714,7 +1714,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_fwd_kernel(const T* x, long 
   const int Do = D / 2, Ho = H / 2, Wo = W / 2, Wr = Wo / 4;
   const long long hw = (long long)H * W, dhw = (long long)D * hw, odhw = (long long)Do * Ho * Wo;
   const T* xp = x + n * x_bs + (long long)c * dhw;
-  const T* sp = s + n * s_bs;
+  const T* sp = s ? s + n * s_bs : nullptr;            // no gate: a plain MaxPool3d(2) that leaves the channel sums of its output
   T* yp = y + n * y_bs + (long long)c * odhw;
   const long long runs = (long long)Do * Ho * Wr;
   double acc[2] = {0.0, 0.0};
@@ -1727,9 +1727,9 @@ __global__ __launch_bounds__(256) void gate_maxpool_fwd_kernel(const T* x, long 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                       // (dz, dy) rows of the window, in the scan order of max_pool3d
       const long long o = base + (long long)(k >> 1) * hw + (long long)(k & 1) * W;
-      float xv[8], sv[8];
+      float xv[8], sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       ld8<T>(xp + o, xv);
-      ld8<T>(sp + o, sv);
+      if (sp) ld8<T>(sp + o, sv);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1929,8 +1929,8 @@ static bool gmp_ok(int D, int H, int W, std::initializer_list<long long> strides
 }
 extern "C" int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y, long long y_bs,
                                    int N, int C, int D, int H, int W, double* red) {
-  if (!x || !s || !y || N <= 0 || C <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
-  if (!gmp_ok(D, H, W, {x_bs, s_bs, y_bs})) return XH_ERR_ARG;
+  if (!x || !y || N <= 0 || C <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  if (!gmp_ok(D, H, W, {x_bs, s ? s_bs : 0, y_bs})) return XH_ERR_ARG;
   const long long runs = (long long)(D / 2) * (H / 2) * (W / 8);
   long long nb = (runs + 255) / 256;
   if (nb > 64) nb = 64;                                   // at most 64 adders per statistics address

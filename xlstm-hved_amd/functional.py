@@ -340,6 +340,27 @@ class MaxPool2(Function):
         return _ret(ctx.slot, ops.maxpool2_bwd(x, _blk(dy), acc=_acc(ctx.slot)))
 
 
+class MaxPool2Stats(Function):
+    """nn.MaxPool3d(2) that also returns the (n, C, 2) fp64 channel sums of its output: the pooling of an 'ilc' encoder and the
+    moments pass of its first InstanceNorm in one launch (xh_gate_maxpool_fwd without a gate)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        ctx.slot = _slot(x)
+        x = x.contiguous()
+        red = ops.zeros_red(x, x.shape[0], x.shape[1])
+        y = ops.gate_maxpool(x, None, red)
+        ctx.mark_non_differentiable(red)
+        ctx.set_materialize_grads(False)
+        return y, red
+
+    @staticmethod
+    def backward(ctx, dy, _dred=None):
+        (x,) = ctx.saved_tensors
+        return _ret(ctx.slot, ops.maxpool2_bwd(x, _blk(dy), acc=_acc(ctx.slot)))
+
+
 class Upsample(Function):
     """F.interpolate(mode='trilinear') to `size` (buildingblocks.py:785-787, RA_HVED.py:600-601)."""
 

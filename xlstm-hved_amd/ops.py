@@ -839,14 +839,18 @@ def gate_maxpool_ok(x, s):
     n, c, d, h, w, bs = _vol(x)
     if not _GMP[0]:
         return False
+    if s is None:                       # max-pool + channel sums, no gate
+        return d % 2 == 0 and h % 2 == 0 and w % 8 == 0 and bs % 8 == 0
     return d % 2 == 0 and h % 2 == 0 and w % 8 == 0 and bs % 8 == 0 and _vol(s)[5] % 8 == 0 and s.shape[1] == 1
 
 
 def gate_maxpool(x, s, red=None):
-    """maxpool2(x * (1 + s)) in one pass; with `red` (zeroed (n, c, 2) fp64) the channel sums of the pooled output too."""
+    """maxpool2(x * (1 + s)) in one pass (s None: maxpool2(x)); with `red` (zeroed (n, c, 2) fp64) the channel sums of the pooled
+    output too."""
     n, c, d, h, w, bs = _vol(x)
     y = new_like(x, (n, c, d // 2, h // 2, w // 2))
-    L.check(L.load().xh_gate_maxpool_fwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(y), _vol(y)[5], n, c, d, h, w, _p(red)),
+    L.check(L.load().xh_gate_maxpool_fwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5] if s is not None else 0, _p(y), _vol(y)[5], n, c, d, h, w,
+                                         _p(red)),
             "xh_gate_maxpool_fwd")
     return y
 
