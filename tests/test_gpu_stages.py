@@ -346,3 +346,48 @@ def test_one_two_channel_k3_conv_stencil_kernels_vs_stock(shape, dtype):
     assert l2_err(dw, wr.grad) < 1e-4 and l2_err(db, br.grad) < 1e-4
     ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)                      # accumulates
     assert l2_err(dw, 2 * wr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_producers_that_leave_the_next_instance_norms_sums_match_a_moments_pass(dtype):
+    """Three passes that also accumulate the channel sums (sum y, sum y^2) of what they store, so that the InstanceNorm of the conv
+    behind them needs no moments launch: the max-pool of the skip-path encoders (xh_gate_maxpool_fwd without a gate), AttenModule2's
+    gate + concat (xh_gate2_fwd) -- both bit-identical in their outputs to the plain passes, sums equal to xh_moments of the output --
+    and the stride-2 conv that finalises its input's InstanceNorm itself (xh_conv_ptrs.fin_red) against the two-launch form."""
+    ops = X.ops
+    torch.manual_seed(7)
+    n, c, d, h, w = 2, 8, 8, 12, 32
+    x = torch.randn(n, c, d, h, w, device=DEV).to(dtype)
+    # --- max-pool + sums
+    assert ops.gate_maxpool_ok(x, None)
+    red = torch.zeros(n, c, 2, dtype=torch.float64, device=DEV)
+    y = ops.gate_maxpool(x, None, red)
+    y_ref = ops.maxpool2(x)
+    assert torch.equal(y, y_ref)
+    red_ref = torch.zeros_like(red)
+    ops.moments(y_ref, red_ref, 0)
+    assert ((red - red_ref).abs() / red_ref.abs().clamp_min(1.0)).max().item() < 1e-7
+    # --- gate + concat + sums
+    b = torch.randn(n, 4, d, h, w, device=DEV).to(dtype)
+    E = torch.sigmoid(torch.randn(n, 2, d, h, w, device=DEV)).to(dtype)
+    red2 = torch.zeros(n, c + 4, 2, dtype=torch.float64, device=DEV)
+    g = ops.gate2(x, b, E, red2)
+    g_ref = ops.gate2(x, b, E)
+    assert torch.equal(g, g_ref)
+    red2_ref = torch.zeros_like(red2)
+    ops.moments(g_ref, red2_ref, 0)
+    assert ((red2 - red2_ref).abs() / red2_ref.abs().clamp_min(1.0)).max().item() < 1e-7
+    # --- stride-2 conv with the finalisation inside (16-bit storage; fp32 storage: the library runs the finalisation launch itself)
+    wts = [torch.randn(2, 2, 3, 3, 3, device=DEV) * 0.2 for _ in range(4)]
+    bs = [torch.randn(2, device=DEV) for _ in range(4)]
+    st = torch.zeros(n, c, 2, dtype=torch.float64, device=DEV)
+    ops.moments(x, st, 0)
+    cnt = d * h * w
+    out = ops.conv3d(x, None, wts, bs, k=3, cout=8, stride=2, groups=4, in_stats=(st, cnt, 0.01))
+    yf, sc, sh, mean, rstd = out
+    sc_r, sh_r, mean_r, rstd_r = ops.norm_finalize(0, st, n, c, cnt)
+    y2 = ops.conv3d(x, None, wts, bs, k=3, cout=8, stride=2, groups=4, pre=(sc_r, sh_r, 0.01))
+    tol = 0 if dtype == torch.float32 else 2e-6            # in-kernel rsqrt + Newton step: <= 1 ulp of the fp32 scale
+    assert (sc - sc_r).abs().max().item() <= tol * sc_r.abs().max().item() + 0.0
+    assert (mean - mean_r).abs().max().item() <= 1e-6 and (rstd - rstd_r).abs().max().item() <= tol * rstd_r.abs().max().item()
+    assert l2_err(yf.float(), y2.float()) < (1e-6 if dtype == torch.float32 else 2e-3)

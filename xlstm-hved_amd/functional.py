@@ -427,6 +427,7 @@ class GateCat(Function):
         ctx.slots = (_slot(a), _slot(b))
         if stats:
             ctx.mark_non_differentiable(red)
+            ctx.set_materialize_grads(False)              # no zero-filled "gradient" of the sums in backward
             return out, red
         return out
 
