@@ -111,31 +111,83 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
 
   // every load of a step is issued back to back from a clamped (always valid) address; what was out of range is zeroed when
   // the step is written to LDS (mask bits travel with it): a guarded load (`if (in range) load`) costs a branch and an
-  // s_waitcnt each and serialises the step's ~8 loads
-  auto load_step = [&](int s, uint4 (&qa)[NA], uint4 (&qb)[NB], unsigned& okm) __attribute__((always_inline)) {
-    const int cs = s % nsteps_c; int t = s / nsteps_c;
-    const int iw = t % ntw; t /= ntw;
-    const int ih = t % cl.th.n, id = t / cl.th.n;
-    const int tap = a.rowmode ? (cl.td.t[id] * a.K + cl.th.t[ih]) : ((cl.td.t[id] * a.K + cl.th.t[ih]) * a.K + cl.tw.t[iw]);
+  // s_waitcnt each and serialises the step's ~8 loads.
+  // Round 3: the step decode and the addresses used to be recomputed per step -- four scalar divisions, and per staged row three
+  // coordinate sums, six clamps, three range checks and a 64-bit address (SQ counters: 9 vector + 6 scalar instructions per
+  // MFMA, the kernel was bound by their issue, not by LDS or the matrix cores).  Now a row keeps ONE 32-bit element offset and a
+  // 12-bit mask of the taps that stay inside the volume; the step (tap, channel quarter) is walked incrementally in scalar
+  // registers and contributes one scalar offset: per row and step an add, a clamp and a mask test.
+  int a_base[NA];
+  unsigned a_msk[NA];
+  const int x_lim = a.Di * a.Hi * a.Wi * a.Cs - 8;        // last 16-byte run of a sample (host: fits 31 bits)
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    a_base[i] = ((a_sd[i] * a.Hi + a_sh[i]) * a.Wi + a_sw[i]) * a.Cs + ch * 8;
     unsigned m = 0;
+    for (int k = 0; k < cl.td.n; ++k) m |= (a_ok[i] && (unsigned)(a_sd[i] + cl.td.off[k]) < (unsigned)a.Di) ? 1u << k : 0u;
+    for (int k = 0; k < cl.th.n; ++k) m |= (a_ok[i] && (unsigned)(a_sh[i] + cl.th.off[k]) < (unsigned)a.Hi) ? 16u << k : 0u;
+    for (int k = 0; k < cl.tw.n; ++k) m |= (a_ok[i] && (unsigned)(a_sw[i] + cl.tw.off[k]) < (unsigned)a.Wi) ? 256u << k : 0u;
+    a_msk[i] = m;
+  }
+  int b_base[NB];
+  unsigned b_okm = 0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int col = tid / CPRW + i * (256 / CPRW);
+    const bool ok = col < BN && cn0 + col < a.Cn;
+    b_okm |= ok ? 1u << (NA + i) : 0u;
+    b_base[i] = min(cn0 + col, a.Cn - 1) * a.Kc + ch * 8;
+  }
+  const u16* x_n = a.x + xs_n * a.Cs;
+  // the step walk (scalar): channel quarter fastest, then the w, h, d taps of the class; it stops at the last step
+  int it_cs = 0, it_w = 0, it_h = 0, it_d = 0, it_s = 0;
+  auto load_step = [&](int s, uint4 (&qa)[NA], uint4 (&qb)[NB], unsigned& okm) __attribute__((always_inline)) {
+    if (a.rowmode) {
+      const int cs = s % nsteps_c; int t = s / nsteps_c;
+      const int iw = t % ntw; t /= ntw;
+      const int ih = t % cl.th.n, id = t / cl.th.n;
+      const int tap = cl.td.t[id] * a.K + cl.th.t[ih];
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int d = a_sd[i] + cl.td.off[id], h = a_sh[i] + cl.th.off[ih];
+        const int w = a_sw[i] + (ch - 1);
+        const bool ok = a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+        m |= ok ? 1u << i : 0u;
+        const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
+        const u16* p = a.x + ((xs_n + ((long long)dc * a.Hi + hc) * a.Wi + wc) * a.Cs);
+        qa[i] = *reinterpret_cast<const uint4*>(p);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int col = tid / CPRW + i * (256 / CPRW);
+        const bool ok = col < BN && cn0 + col < a.Cn;
+        m |= ok ? 1u << (NA + i) : 0u;
+        const int cc = min(cn0 + col, a.Cn - 1);
+        qb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)cc * a.Kc + cs * 32 * KQ + ch * 8);
+      }
+      okm = m;
+      (void)iw;
+      return;
+    }
+    // bring the walk to step s (callers ask for consecutive steps, the last one possibly several times)
+    while (it_s < s) {
+      ++it_s;
+      if (++it_cs == nsteps_c) { it_cs = 0; if (++it_w == cl.tw.n) { it_w = 0; if (++it_h == cl.th.n) { it_h = 0; ++it_d; } } }
+    }
+    const int tap = (cl.td.t[it_d] * a.K + cl.th.t[it_h]) * a.K + cl.tw.t[it_w];
+    const int toff = ((cl.td.off[it_d] * a.Hi + cl.th.off[it_h]) * a.Wi + cl.tw.off[it_w]) * a.Cs + it_cs * 32 * KQ;
+    const int woff = tap * a.wtap_stride + it_cs * 32 * KQ;
+    const unsigned sel = (1u << it_d) | (16u << it_h) | (256u << it_w);
+    unsigned m = b_okm;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int d = a_sd[i] + cl.td.off[id], h = a_sh[i] + cl.th.off[ih];
-      const int w = a_sw[i] + (a.rowmode ? (ch - 1) : cl.tw.off[iw]);
-      const bool ok = a_ok[i] && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
-      m |= ok ? 1u << i : 0u;
-      const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
-      const u16* p = a.x + ((xs_n + ((long long)dc * a.Hi + hc) * a.Wi + wc) * a.Cs) + (a.rowmode ? 0 : cs * 32 * KQ + ch * 8);
-      qa[i] = *reinterpret_cast<const uint4*>(p);
+      m |= ((a_msk[i] & sel) == sel) ? 1u << i : 0u;
+      const int off = min(max(a_base[i] + toff, 0), x_lim);
+      qa[i] = *reinterpret_cast<const uint4*>(x_n + (unsigned)off);
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int col = tid / CPRW + i * (256 / CPRW);
-      const bool ok = col < BN && cn0 + col < a.Cn;
-      m |= ok ? 1u << (NA + i) : 0u;
-      const int cc = min(cn0 + col, a.Cn - 1);
-      qb[i] = *reinterpret_cast<const uint4*>(a.w + (long long)tap * a.wtap_stride + (long long)cc * a.Kc + cs * 32 * KQ + ch * 8);
-    }
+    for (int i = 0; i < NB; ++i) qb[i] = *reinterpret_cast<const uint4*>(a.w + (unsigned)(b_base[i] + woff));
     okm = m;
   };
   auto store_step = [&](int buf, const uint4 (&qa)[NA], const uint4 (&qb)[NB], unsigned okm) __attribute__((always_inline)) {
@@ -1187,6 +1239,8 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
   }
   const bool rowmode = mode == 0 && Cs == 8;
   if (!rowmode && (Cs % 32)) return XH_ERR_ARG;
+  // the staging keeps 32-bit element offsets inside one sample of x and inside w
+  if ((long long)Di * Hi * Wi * Cs >= (1ll << 31) || (long long)ks * ks * ks * Cn * (rowmode ? 32 : Cs) >= (1ll << 31)) return XH_ERR_ARG;
   if (rowmode && stride != 1) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   DConvK a;
