@@ -432,14 +432,14 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
     for (int i = 0; i < 2; ++i) {
       const long long m = m0 + (tid >> 4) + i * 16;
       const bool live = m < m_end;
-      const long long mc = m < a.M ? m : a.M - 1;
+      const unsigned mc = (unsigned)(m < a.M ? m : a.M - 1);        // 32-bit element offsets (host: M * Cn and the x tensor fit 31 bits)
       oky[i] = live && y_ok;
-      ry[i] = *reinterpret_cast<const uint4*>(a.dy + mc * a.Cn + y_off);
+      ry[i] = *reinterpret_cast<const uint4*>(a.dy + (mc * (unsigned)a.Cn + (unsigned)y_off));
       const int d = od[i] * a.stride + kd - 1, h = oh[i] * a.stride + kh - 1, w = ow[i] * a.stride + kw - 1;
       okx[i] = live && x_ok && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
       const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
       const int nc = min(nn[i], a.N - 1);
-      rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)nc * a.Di + dc) * a.Hi + hc) * a.Wi + wc) * a.Cs + x_off);
+      rx[i] = *reinterpret_cast<const uint4*>(a.x + (unsigned)((((nc * a.Di + dc) * a.Hi + hc) * a.Wi + wc) * a.Cs + x_off));
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1333,6 +1333,8 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, co
   a.x = (const u16*)x; a.dy = (const u16*)dy; a.dw = dwp;
   a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cs = Cs; a.Cn = Cn; a.stride = stride;
   a.M = (long long)N * Do * Ho * Wo;
+  // the staging of dwgrad_cl_kernel keeps 32-bit element offsets into x and dY
+  if ((long long)N * Di * Hi * Wi * Cs >= (1ll << 31) || a.M * Cn >= (1ll << 31)) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (Cs == 8 && Cn == 64 && stride == 1 && !(g_dconv_cfg & 8192)) {       // first conv of the network: LDS-halo kernel
     DWg8HK k;
