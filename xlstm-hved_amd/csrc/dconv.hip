@@ -473,8 +473,8 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
     store_step(0);
   }
   __syncthreads();
-  int buf = 0;
-  for (long long m0 = m_begin; m0 < m_end; m0 += 32, buf ^= 1) {
+  // two steps per trip: the LDS buffer index is a literal in each half (fragment addresses = per-lane base + immediate offset)
+  auto step = [&](long long m0, int buf) __attribute__((always_inline)) {
     if (m0 + 32 < m_end) load_step(m0 + 32);
     const unsigned char* Ys = smem + buf * 2 * TB;
     const unsigned char* Xs = Ys + TB;
@@ -503,6 +503,10 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
       for (int j = 0; j < TNW; ++j) acc[i][j] = mfma16x16x32<FMT>(af[i], bf[j], acc[i][j]);
     if (m0 + 32 < m_end) store_step(buf ^ 1);
     __syncthreads();
+  };
+  for (long long m0 = m_begin; m0 < m_end; m0 += 64) {
+    step(m0, 0);
+    if (m0 + 32 < m_end) step(m0 + 32, 1);
   }
   // D[i = cn][j = cs]: lane holds column cs = r16, rows cn = 4 kg + r
 #pragma unroll
