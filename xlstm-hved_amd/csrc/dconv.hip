@@ -139,6 +139,14 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     b_base[i] = min(cn0 + col, a.Cn - 1) * a.Kc + ch * 8;
   }
   const u16* x_n = a.x + xs_n * a.Cs;
+  // x through a buffer descriptor of the sample: a row whose tap falls outside the volume loads from an out-of-range offset and
+  // gets zeros back -- no clamp, no select when the step is written to LDS
+  __amdgpu_buffer_rsrc_t x_rs;
+  {
+    const unsigned long long v = (unsigned long long)x_n;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (x_lim + 8) * 2, 0x00020000);
+  }
   // the step walk (scalar): channel quarter fastest, then the w, h, d taps of the class; it stops at the last step
   int it_cs = 0, it_w = 0, it_h = 0, it_d = 0, it_s = 0;
   auto load_step = [&](int s, uint4 (&qa)[NA], uint4 (&qb)[NB], unsigned& okm) __attribute__((always_inline)) {
@@ -179,12 +187,11 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     const int toff = ((cl.td.off[it_d] * a.Hi + cl.th.off[it_h]) * a.Wi + cl.tw.off[it_w]) * a.Cs + it_cs * 32 * KQ;
     const int woff = tap * a.wtap_stride + it_cs * 32 * KQ;
     const unsigned sel = (1u << it_d) | (16u << it_h) | (256u << it_w);
-    unsigned m = b_okm;
+    unsigned m = b_okm | ((1u << NA) - 1u);            // x rows need no mask: invalid ones arrive as zeros
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      m |= ((a_msk[i] & sel) == sel) ? 1u << i : 0u;
-      const int off = min(max(a_base[i] + toff, 0), x_lim);
-      qa[i] = *reinterpret_cast<const uint4*>(x_n + (unsigned)off);
+      const unsigned off = ((a_msk[i] & sel) == sel) ? (unsigned)(a_base[i] + toff) * 2u : 0xFFFFFFF0u;
+      qa[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) qb[i] = *reinterpret_cast<const uint4*>(a.w + (unsigned)(b_base[i] + woff));
@@ -194,11 +201,16 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     unsigned char* As = smem + buf * (AB + BB);
     unsigned char* Bs = As + AB;
     const uint4 z = make_uint4(0, 0, 0, 0);
+    if (a.rowmode) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      uint4 v = qa[i];                                  // (not `ok ? qa[i] : z`: a conditional of two lvalues selects an ADDRESS and
-      if (!((okm >> i) & 1)) v = z;                     //  drags the staging registers into scratch memory)
-      *reinterpret_cast<uint4*>(As + swr<KQ>(a_row[i], ch)) = v;
+      for (int i = 0; i < NA; ++i) {
+        uint4 v = qa[i];                                // (not `ok ? qa[i] : z`: a conditional of two lvalues selects an ADDRESS and
+        if (!((okm >> i) & 1)) v = z;                   //  drags the staging registers into scratch memory)
+        *reinterpret_cast<uint4*>(As + swr<KQ>(a_row[i], ch)) = v;
+      }
+    } else {                                            // rows outside the volume came back as zeros from the buffer load
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(As + swr<KQ>(a_row[i], ch)) = qa[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
