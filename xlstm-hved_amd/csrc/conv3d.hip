@@ -1095,6 +1095,132 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
   }
 }
 
+// Several k = 1 weight gradients in ONE launch (xh_conv3d_wgrad_batch): the 1x1 problems of a training step are independent
+// of each other, a dozen of them are deferred to the end of the backward pass, and each alone is a few hundred workgroups of
+// 7 - 17 us (launch ramp, a short load chain, the atomics tail).  Workgroup b of the launch belongs to problem i with
+// off[i] <= b < off[i + 1]; inside a problem the decomposition is conv1x1_wgrad_kernel's (4 x 4 channel tile, grid-strided
+// 16-byte runs).  The table travels in the kernel arguments.
+struct C1WP {
+  const void *xa, *xb, *dy;
+  const float *pre_sc, *pre_sh;
+  float* dw[4];
+  float* db[4];
+  long long xa_bs, xb_bs, ea_bs, dhw;
+  int N, Cin, Ca, Cin_g, Cout_g, groups, n_wptr, pre, gx, ny;
+  float pre_slope;
+  int dtype;
+};
+constexpr int C1W_MULTI = 16;
+struct C1WMulti {
+  int n;
+  int off[C1W_MULTI + 1];
+  C1WP p[C1W_MULTI];
+};
+static_assert(sizeof(C1WMulti) <= 3800, "kernel-argument table");
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_multi_kernel(const C1WMulti m) {
+  constexpr int CIB = 4, COB = 4, NACC = CIB * COB + COB, VW = VWT<T>::v;
+  __shared__ float s_red[4 * NACC];
+  const int tid = threadIdx.x;
+  int pi = 0;
+  for (int k = 1; k < C1W_MULTI; ++k)
+    if (k < m.n && (int)blockIdx.x >= m.off[k]) pi = k;
+  const C1WP& a = m.p[pi];
+  const int local = blockIdx.x - m.off[pi];
+  const int gx = a.gx, ny = a.ny;
+  const int bx = local % gx, r1 = local / gx;
+  const int yy = r1 % ny, g = r1 / ny;
+  const int ncib = (a.Cin_g + CIB - 1) / CIB;
+  const int cib = yy % ncib, cob = yy / ncib;
+  const long long dhw = a.dhw;
+  float acc[CIB][COB], dbacc[COB];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i)
+#pragma unroll
+    for (int j = 0; j < COB; ++j) acc[i][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < COB; ++j) dbacc[j] = 0.f;
+  // channels past the end are clamped (always valid addresses, all loads issue together) and masked arithmetically
+  const T* xp[CIB]; const T* yp[COB];
+  float mx[CIB], my[COB], sc[CIB], sh[CIB];
+  long long xbs[CIB];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i) {
+    const int ci_g = cib * CIB + i;
+    mx[i] = ci_g < a.Cin_g ? 1.f : 0.f;
+    const int c = g * a.Cin_g + min(ci_g, a.Cin_g - 1);
+    xp[i] = c < a.Ca ? (const T*)a.xa + (long long)c * dhw : (const T*)a.xb + (long long)(c - a.Ca) * dhw;
+    xbs[i] = c < a.Ca ? a.xa_bs : a.xb_bs;
+    sc[i] = 1.f; sh[i] = 0.f;
+    if (a.pre && a.N == 1) { sc[i] = a.pre_sc[c]; sh[i] = a.pre_sh[c]; }
+  }
+#pragma unroll
+  for (int j = 0; j < COB; ++j) {
+    const int co_g = cob * COB + j;
+    my[j] = co_g < a.Cout_g ? 1.f : 0.f;
+    yp[j] = (const T*)a.dy + (long long)(g * a.Cout_g + min(co_g, a.Cout_g - 1)) * dhw;
+  }
+  const long long per_n = dhw / VW;
+  const long long total = (long long)a.N * per_n;
+  const float slope = a.pre_slope;
+  for (long long q = (long long)bx * 256 + tid; q < total; q += (long long)gx * 256) {
+    const int n = (int)(q / per_n);
+    const long long sp = (q - n * per_n) * VW;
+    float x[CIB][VW], dy[COB][VW];
+#pragma unroll
+    for (int i = 0; i < CIB; ++i) ldvec(xp[i] + n * xbs[i], sp, x[i]);
+#pragma unroll
+    for (int j = 0; j < COB; ++j) ldvec(yp[j] + n * a.ea_bs, sp, dy[j]);
+#pragma unroll
+    for (int i = 0; i < CIB; ++i) {
+      if (a.pre && a.N > 1) {
+        const int c = g * a.Cin_g + min(cib * CIB + i, a.Cin_g - 1);
+        sc[i] = a.pre_sc[n * a.Cin + c]; sh[i] = a.pre_sh[n * a.Cin + c];
+      }
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        float xv = x[i][v];
+        if (a.pre) xv = leaky(xv * sc[i] + sh[i], slope);
+        x[i][v] = xv * mx[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < COB; ++j)
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        dy[j][v] *= my[j];
+        dbacc[j] += dy[j][v];
+      }
+#pragma unroll
+    for (int i = 0; i < CIB; ++i)
+#pragma unroll
+      for (int j = 0; j < COB; ++j)
+#pragma unroll
+        for (int v = 0; v < VW; ++v) acc[i][j] = fmaf(x[i][v], dy[j][v], acc[i][j]);
+  }
+  float v[NACC];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i)
+#pragma unroll
+    for (int j = 0; j < COB; ++j) v[i * COB + j] = acc[i][j];
+#pragma unroll
+  for (int j = 0; j < COB; ++j) v[CIB * COB + j] = dbacc[j];
+  block_sum<NACC>(v, s_red, 4);
+  const int gpp = a.groups / a.n_wptr;
+  const int gl = g % gpp;
+  if (tid < NACC) {
+    if (tid < CIB * COB) {
+      const int ci_g = cib * CIB + tid / COB, co_g = cob * COB + tid % COB;
+      if (ci_g < a.Cin_g && co_g < a.Cout_g)
+        atomicAdd(&a.dw[g / gpp][(long long)(gl * a.Cout_g + co_g) * a.Cin_g + ci_g], s_red[tid]);
+    } else {
+      const int co_g = cob * COB + (tid - CIB * COB);
+      if (cib == 0 && co_g < a.Cout_g && a.db[g / gpp]) atomicAdd(&a.db[g / gpp][gl * a.Cout_g + co_g], s_red[tid]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -1957,6 +2083,68 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
   }
   xh_note_kernel("conv wgrad k%d s%d (vector kernel family)", d->k, d->stride);
   XH_DISPATCH_T(d->dtype, return wgrad_dispatch<T>(stream, d, p, dw, db););
+}
+
+// k = 1 weight gradients of a batch (xh_conv3d_wgrad_batch): those conv1x1_wgrad_multi_kernel can take (16-byte runs) go
+// C1W_MULTI per launch and storage type and are marked in handled[]; the others are left to the caller's one-by-one path.
+static bool c1w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], C1WP* o) {
+  if (check_desc(d, p) || d->k != 1 || d->stride != 1 || d->transposed || !p->ea || !dw) return false;
+  if (d->n_wptr < 1 || d->groups % d->n_wptr) return false;
+  for (int i = 0; i < d->n_wptr; ++i)
+    if (!dw[i]) return false;
+  const int vw = d->dtype == XH_F32 ? 4 : 8;
+  const long long dhw = (long long)d->D * d->H * d->W;
+  if (dhw % vw || d->xa_bs % vw || d->xb_bs % vw || d->ea_bs % vw) return false;
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  o->xa = p->xa; o->xb = p->xb; o->dy = p->ea;
+  o->pre_sc = p->pre_sc; o->pre_sh = p->pre_sh;
+  for (int i = 0; i < 4; ++i) { o->dw[i] = i < d->n_wptr ? dw[i] : nullptr; o->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  o->xa_bs = d->xa_bs; o->xb_bs = d->xb_bs; o->ea_bs = d->ea_bs; o->dhw = dhw;
+  o->N = d->N; o->Cin = d->Cin; o->Ca = d->Ca; o->Cin_g = cin_g; o->Cout_g = cout_g; o->groups = d->groups; o->n_wptr = d->n_wptr;
+  o->pre = d->pre; o->pre_slope = d->pre_slope; o->dtype = d->dtype;
+  o->ny = cdiv(cin_g, 4) * cdiv(cout_g, 4);
+  // every workgroup ends in same-address device-scope atomics, which serialise: a few hundred workgroups per problem (key 8)
+  const long long total = (long long)d->N * dhw / vw;
+  long long gx = (total + 255) / 256;
+  const long long cap = cdiv(g_c1w_wgs, o->ny * d->groups);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  o->gx = (int)gx;
+  return (long long)o->gx * o->ny * d->groups < (1 << 20);
+}
+static int c1w_launch(void* stream, int dtype, const C1WP* v, int n) {
+  C1WMulti m;
+  m.n = n; m.off[0] = 0;
+  for (int i = 0; i < n; ++i) { m.p[i] = v[i]; m.off[i + 1] = m.off[i] + v[i].gx * v[i].ny * v[i].groups; }
+  for (int i = n; i < C1W_MULTI; ++i) m.off[i + 1] = m.off[n];
+  xh_note_kernel("conv1x1_wgrad_multi_kernel<%s>", dtype == XH_F32 ? "float" : (dtype == XH_F16 ? "f16_t" : "bf16_t"));
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_wgrad_multi_kernel<T>), dim3(m.off[n]), dim3(256), 0, (hipStream_t)stream, m););
+  return xh_launch_status();
+}
+int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
+                 float* const (*db)[4], char* handled) {
+  if (g_xh_disable & 512) return XH_OK;
+  int rc_all = XH_OK;
+  const int types[3] = {XH_F32, XH_BF16, XH_F16};
+  for (int t = 0; t < 3; ++t) {
+    C1WP v[C1W_MULTI];
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+      if (handled[i] || !d[i] || !p[i] || d[i]->dtype != types[t]) continue;
+      if (!c1w_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &v[k])) continue;
+      handled[i] = 1;
+      if (++k == C1W_MULTI) {
+        const int rc = c1w_launch(stream, types[t], v, k);
+        if (rc != XH_OK) rc_all = rc;
+        k = 0;
+      }
+    }
+    if (k) {
+      const int rc = c1w_launch(stream, types[t], v, k);
+      if (rc != XH_OK) rc_all = rc;
+    }
+  }
+  return rc_all;
 }
 
 extern "C" int xh_abi_version(void) { return 1; }

@@ -388,6 +388,8 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
 // launched WG_MULTI at a time; the others go through xh_conv3d_wgrad one by one.
 extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
 extern int g_use_mfma;
+int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
+                 float* const (*db)[4], char* handled);
 extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p,
                                      float* const (*dw)[4], float* const (*db)[4]) {
   if (n < 0 || (n > 0 && (!d || !p || !dw))) return XH_ERR_ARG;
@@ -427,6 +429,10 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
       }
       for (int b = 0; b < L; ++b) xh_wgrad_q4_launch(st, fmt, bucket[b].data(), (int)bucket[b].size());
     }
+  }
+  {                                                   // k = 1 problems: conv1x1_wgrad_multi_kernel (conv3d.hip)
+    const int rc = xh_c1w_batch(stream, n, d, p, dw, db, handled.data());
+    if (rc != XH_OK) rc_all = rc;
   }
   WgMulti* m = new WgMulti;
   for (int cls = 0; cls < 4; ++cls) {                 // (fmt, big)
