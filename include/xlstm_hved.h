@@ -42,7 +42,7 @@ int xh_abi_version(void);
  *        weight-gradient kernel (both fall back to the implicit-GEMM kernels), bit 6 statistics fan-in (direct atomics),
  *        bit 7 depthwise k3 convs through the quad-channel kernel (fall back to the sliding-window vector kernel),
  *        bit 8 input-channel split inside the blocks of the stride-2 vector conv on small outputs, bit 9 shared launches of the
- *        k=1 weight gradients of xh_conv3d_wgrad_batch (one launch per problem instead).
+ *        k=1 and stride-2 weight gradients of xh_conv3d_wgrad_batch (one launch per problem instead).
  * key 3: target workgroup count of the k3 MFMA forward kernel (default 512 = 2 per CU; microbenchmarks: 1024-4096 were 7-25 % slower).
  * key 4: 1 = <=128-VGPR instances of the k3 MFMA forward kernel for <= 8 input channels (microbenchmarks: spills, 2x slower).
  * key 5: K step of the discriminator's implicit GEMM in 32-channel quarters (1 | 2, default 2).
@@ -144,8 +144,8 @@ int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, 
  * xh_conv3d_wgrad would take for problem i (db may be NULL, db[i][j] may be NULL).  Weight gradients are off the critical
  * path of a backward pass, so a caller can collect them and issue this once at the end: the k=3 MFMA problems of a
  * (storage type, volume class) share launches 7 at a time (their workgroups run side by side instead of 16 latency-bound
- * launches one after the other), the k=1 problems of a storage type 16 at a time, everything else is forwarded to
- * xh_conv3d_wgrad.  Same accumulate (+=) semantics. */
+ * launches one after the other), the k=1 problems of a storage type 16 at a time, the vectorised k=3 stride-2
+ * problems 4 at a time, everything else is forwarded to xh_conv3d_wgrad.  Same accumulate (+=) semantics. */
 int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p,
                           float* const (*dw)[4], float* const (*db)[4]);
 /* Scratch (bytes) xh_conv3d_wgrad wants in p->ws for this shape (per-workgroup partial gradients of the 7^3 MFMA weight

@@ -86,35 +86,30 @@ def test_bench_configuration_128_graph_replay_matches_eager():
     assert (a - c).abs().max().item() <= 5e-4 * scale, (a - c).abs().max().item() / scale
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_k1_weight_gradients_of_a_batch_share_one_launch(dtype):
-    """xh_conv3d_wgrad_batch sends the k = 1 problems of a step through conv1x1_wgrad_multi_kernel (one launch for up to 16
-    problems): mixed shapes, groups with one weight tensor each, a channel-concatenated input, the producer's norm + LeakyReLU
-    applied on load, batch 2 -- against autograd's weight gradient of the same fp32 values; and the batch equals the
-    one-by-one path (xh_set_option(2, 512))."""
+def _batch_vs_autograd(cases, k, stride, dtype, kernel):
+    """Weight gradients of `cases` (N, Ca, Cb, Cout, groups, S, pre) through the deferred batch, against autograd's weight
+    gradient of the same fp32 values and against the one-by-one path (xh_set_option(2, 512))."""
     import torch.nn.functional as F
     torch.manual_seed(11)
     lib = X._lib.load()
-    #        N  Ca Cb Cout groups S   pre
-    cases = [(1, 4, 0, 4, 1, 32, True), (2, 3, 5, 12, 1, 16, False), (1, 16, 0, 16, 4, 16, True), (1, 2, 0, 1, 1, 32, False),
-             (1, 8, 8, 1, 1, 24, True), (2, 32, 0, 8, 1, 8, False)]
     probs = []
     for n, ca, cb, cout, g, s, pre in cases:
+        so = s // stride
         xa = torch.randn(n, ca, s, s, s, device=DEV).to(dtype)
         xb = torch.randn(n, cb, s, s, s, device=DEV).to(dtype) if cb else None
-        dy = torch.randn(n, cout, s, s, s, device=DEV).to(dtype)
+        dy = torch.randn(n, cout, so, so, so, device=DEV).to(dtype)
         cin = ca + cb
         p = (torch.rand(n, cin, device=DEV) + 0.5, torch.randn(n, cin, device=DEV), 0.01) if pre else None
         probs.append((xa, xb, dy, g, p, cin, cout))
 
-    def run(batched):
+    def run():
         outs = []
-        X.ops.set_wgrad_defer(batched)
+        X.ops.set_wgrad_defer(True)
         try:
             for xa, xb, dy, g, p, cin, cout in probs:
-                dws = [torch.zeros(cout // g, cin // g, 1, 1, 1, device=DEV) for _ in range(g)]
+                dws = [torch.zeros(cout // g, cin // g, k, k, k, device=DEV) for _ in range(g)]
                 dbs = [torch.zeros(cout // g, device=DEV) for _ in range(g)]
-                X.ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=1, groups=g, pre=p, side=True)
+                X.ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=g, pre=p, side=True)
                 outs.append((dws, dbs))
             X.ops.join_wgrad_stream()
         finally:
@@ -122,25 +117,45 @@ def test_k1_weight_gradients_of_a_batch_share_one_launch(dtype):
         torch.cuda.synchronize()
         return outs
 
-    got = run(True)
-    assert "conv1x1_wgrad_multi_kernel" in X.ops.last_conv_kernel()
+    got = run()
+    assert kernel in X.ops.last_conv_kernel(), X.ops.last_conv_kernel()
     lib.xh_set_option(2, 512)
     try:
-        single = run(True)
+        single = run()
         assert "multi" not in X.ops.last_conv_kernel()
     finally:
         lib.xh_set_option(2, 0)
-    tol = 2e-5 if dtype == torch.float32 else 2e-5      # the products are exact fp32 either way; the sums differ in order
     for (xa, xb, dy, g, p, cin, cout), (dws, dbs), (sws, sbs) in zip(probs, got, single):
         x = torch.cat([xa, xb], 1).float() if xb is not None else xa.float()
         if p is not None:
             x = F.leaky_relu(x * p[0][:, :, None, None, None] + p[1][:, :, None, None, None], p[2])
-        w = torch.zeros(cout, cin // g, 1, 1, 1, device=DEV, requires_grad=True)
+        w = torch.zeros(cout, cin // g, k, k, k, device=DEV, requires_grad=True)
         b = torch.zeros(cout, device=DEV, requires_grad=True)
-        F.conv3d(x, w, b, groups=g).backward(dy.float())
+        F.conv3d(x, w, b, stride=stride, padding=k // 2, groups=g).backward(dy.float())
         dw, db = torch.cat(dws, 0), torch.cat(dbs, 0)
-        sw = w.grad.abs().max().item() + 1e-6
+        sw, sb = w.grad.abs().max().item() + 1e-6, b.grad.abs().max().item() + 1e-6
+        # the products are exact fp32 in every path; the sums differ in order
         assert (dw - w.grad).abs().max().item() <= 1e-3 * sw, ((dw - w.grad).abs().max().item() / sw, xa.shape)
-        assert (db - b.grad).abs().max().item() <= 1e-3 * (b.grad.abs().max().item() + 1e-6)
-        assert (dw - torch.cat(sws, 0)).abs().max().item() <= tol * 50 * sw
-        assert (db - torch.cat(sbs, 0)).abs().max().item() <= 1e-3 * (b.grad.abs().max().item() + 1e-6)
+        assert (db - b.grad).abs().max().item() <= 1e-3 * sb
+        assert (dw - torch.cat(sws, 0)).abs().max().item() <= 1e-3 * sw
+        assert (db - torch.cat(sbs, 0)).abs().max().item() <= 1e-3 * sb
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_k1_weight_gradients_of_a_batch_share_one_launch(dtype):
+    """xh_conv3d_wgrad_batch sends the k = 1 problems of a step through conv1x1_wgrad_multi_kernel (one launch for up to 16
+    problems): mixed shapes, groups with one weight tensor each, a channel-concatenated input, the producer's norm + LeakyReLU
+    applied on load, batch 2."""
+    #        N  Ca Cb Cout groups S   pre
+    cases = [(1, 4, 0, 4, 1, 32, True), (2, 3, 5, 12, 1, 16, False), (1, 16, 0, 16, 4, 16, True), (1, 2, 0, 1, 1, 32, False),
+             (1, 8, 8, 1, 1, 24, True), (2, 32, 0, 8, 1, 8, False)]
+    _batch_vs_autograd(cases, 1, 1, dtype, "conv1x1_wgrad_multi_kernel")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stride2_weight_gradients_of_a_batch_share_launches(dtype):
+    """... and the k = 3 stride-2 problems (the DRB convs, RA_HVED.py:569: 4 streams as groups) through
+    conv3_s2_wgrad_vec_multi_kernel, 4 problems per launch: 5 problems = two launches."""
+    cases = [(1, 16, 0, 16, 4, 32, True), (1, 32, 0, 32, 4, 16, True), (2, 8, 0, 4, 1, 32, False), (1, 8, 0, 8, 2, 64, True),
+             (1, 4, 4, 8, 1, 32, False)]
+    _batch_vs_autograd(cases, 3, 2, dtype, "conv3_s2_wgrad_vec_multi_kernel")

@@ -1885,15 +1885,15 @@ __global__ __launch_bounds__(256) void conv_dw3_wgrad_slide_kernel(const WgradK 
 // group, and keeps the 27 x COUT_G partial sums in registers until one block reduction.
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int CO>
-__global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_kernel(const WgradK wa, int LW) {
+__device__ __forceinline__ void s2_wgrad_body(const WgradK& wa, int LW, int bx, int by, int bz, int gdx) {
   const ConvK& a = wa.c;
   constexpr int VW = VWT<T>::v, OW = VW / 2, NACC = 27 * CO + CO;
   __shared__ float s_red[4 * NACC];
   const int tid = threadIdx.x;
-  // blockIdx.y = (chunk of CO output channels of the group, input channel): groups of 8 / 16 output channels (the deep DRB
+  // by = (chunk of CO output channels of the group, input channel): groups of 8 / 16 output channels (the deep DRB
   // convs) run as 2 / 4 chunks of 4 instead of the generic tiled kernel (39 us for 64 -> 32 g4 @32^3)
-  const int ci_g = blockIdx.y % a.Cin_g, co0 = (blockIdx.y / a.Cin_g) * CO;
-  const int n = blockIdx.z / a.d.groups, g = blockIdx.z % a.d.groups;
+  const int ci_g = by % a.Cin_g, co0 = (by / a.Cin_g) * CO;
+  const int n = bz / a.d.groups, g = bz % a.d.groups;
   const int D = a.d.D, H = a.d.H, W = a.d.W, Do = a.d.Do, Ho = a.d.Ho, Wo = a.d.Wo;
   const long long dhw = (long long)D * H * W, odhw = (long long)Do * Ho * Wo;
   const int c = g * a.Cin_g + ci_g;
@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_kernel(const WgradK wa
   for (int j = 0; j < CO; ++j) dbs[j] = 0.f;
   const long long rows = (long long)Do * Ho;
   const long long lanes = rows * LW;
-  for (long long lane_id = (long long)blockIdx.x * 256 + tid; lane_id - tid < lanes; lane_id += (long long)gridDim.x * 256) {
+  for (long long lane_id = (long long)bx * 256 + tid; lane_id - tid < lanes; lane_id += (long long)gdx * 256) {
     const int tx = (int)(lane_id % LW);
     const long long row = lane_id / LW;
     const bool ok = row < rows;
@@ -1967,6 +1967,33 @@ __global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_kernel(const WgradK wa
     atomicAdd(&wa.db[g / gpp][gl * a.Cout_g + co0 + (tid - 27 * CO)], s_red[tid]);
   }
 }
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_kernel(const WgradK wa, int LW) {
+  s2_wgrad_body<T, CO>(wa, LW, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+// up to S2W_MULTI problems of one launch (xh_conv3d_wgrad_batch): workgroup b belongs to problem i with off[i] <= b < off[i + 1]
+constexpr int S2W_MULTI = 4;
+struct S2WMulti {
+  int n;
+  int off[S2W_MULTI + 1];
+  int lw[S2W_MULTI], gx[S2W_MULTI], gy[S2W_MULTI];
+  WgradK p[S2W_MULTI];
+};
+static_assert(sizeof(S2WMulti) <= 3900, "kernel-argument table");
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_multi_kernel(const S2WMulti m) {
+  int pi = 0;
+  for (int k = 1; k < S2W_MULTI; ++k)
+    if (k < m.n && (int)blockIdx.x >= m.off[k]) pi = k;
+  const int local = blockIdx.x - m.off[pi];
+  const int gx = m.gx[pi], gy = m.gy[pi];
+  const int r = local / gx;
+  s2_wgrad_body<T, CO>(m.p[pi], m.lw[pi], local - r * gx, r % gy, r / gy, gx);
+}
+
+// launch plan of the vectorised stride-2 weight gradient; false: not eligible
+static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgradK* wa, int* lw_,
+                     dim3* grid);
 
 template <typename T>
 static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4],
@@ -2020,22 +2047,10 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
       return xh_launch_status();
     }
   }
-  if (d->k == 3 && d->stride == 2 && (cout_g == 2 || cout_g % 4 == 0) && !(g_xh_disable & 4)) {
-    constexpr int VW = VWT<T>::v;
-    const int lw = d->W / VW;
-    const long long dhw2 = (long long)d->D * d->H * d->W, odhw2 = (long long)d->Do * d->Ho * d->Wo;
-    const bool al = d->W % VW == 0 && d->Wo * 2 == d->W && lw >= 1 && lw <= 64 && (64 % lw) == 0 && dhw2 % VW == 0 &&
-                    odhw2 % (VW / 2) == 0 && d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && d->ea_bs % (VW / 2) == 0 &&
-                    (long long)cin_g * (cout_g / (cout_g == 2 ? 2 : 4)) <= 65535 && (long long)d->N * d->groups <= 65535;
-    if (al) {
-      wa.c = make_k(d, p, 1, 8);
-      const int chunks = cout_g == 2 ? 1 : cout_g / 4;
-      const long long lanes = (long long)d->Do * d->Ho * lw;
-      long long gx = (lanes + 255) / 256;
-      const long long cap = cdiv(g_s2w_cap, cin_g * chunks * d->groups * d->N);   // few enough workgroups that the atomics tail stays small
-      if (gx > cap) gx = cap;
-      if (gx < 1) gx = 1;
-      dim3 grid((unsigned)gx, cin_g * chunks, d->N * d->groups);
+  {
+    int lw;
+    dim3 grid;
+    if (s2w_plan(d, p, dw, db, &wa, &lw, &grid)) {
       xh_note_kernel("conv3_s2_wgrad_vec_kernel<%s, %d>", tname<T>(), cout_g == 2 ? 2 : 4);
       if (cout_g == 2) hipLaunchKernelGGL((conv3_s2_wgrad_vec_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, wa, lw);
       else hipLaunchKernelGGL((conv3_s2_wgrad_vec_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, wa, lw);
@@ -2144,6 +2159,73 @@ int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
       if (rc != XH_OK) rc_all = rc;
     }
   }
+  return rc_all;
+}
+
+static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgradK* wa, int* lw_,
+                     dim3* grid) {
+  const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
+  if (!(d->k == 3 && d->stride == 2 && (cout_g == 2 || cout_g % 4 == 0) && !(g_xh_disable & 4))) return false;
+  const int VW = d->dtype == XH_F32 ? 4 : 8;
+  const int lw = d->W / VW;
+  const long long dhw2 = (long long)d->D * d->H * d->W, odhw2 = (long long)d->Do * d->Ho * d->Wo;
+  const bool al = d->W % VW == 0 && d->Wo * 2 == d->W && lw >= 1 && lw <= 64 && (64 % lw) == 0 && dhw2 % VW == 0 &&
+                  odhw2 % (VW / 2) == 0 && d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && d->ea_bs % (VW / 2) == 0 &&
+                  (long long)cin_g * (cout_g / (cout_g == 2 ? 2 : 4)) <= 65535 && (long long)d->N * d->groups <= 65535;
+  if (!al) return false;
+  for (int i = 0; i < 4; ++i) { wa->dw[i] = i < d->n_wptr ? dw[i] : nullptr; wa->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  wa->c = make_k(d, p, 1, 8);
+  wa->tiles_total = wa->tiles_per_block = 0;
+  const int chunks = cout_g == 2 ? 1 : cout_g / 4;
+  const long long lanes = (long long)d->Do * d->Ho * lw;
+  long long gx = (lanes + 255) / 256;
+  const long long cap = cdiv(g_s2w_cap, cin_g * chunks * d->groups * d->N);   // few enough workgroups that the atomics tail stays small
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  *grid = dim3((unsigned)gx, cin_g * chunks, d->N * d->groups);
+  *lw_ = lw;
+  return true;
+}
+// k = 3 stride-2 weight gradients of a batch with groups of 4 k output channels: S2W_MULTI per launch and storage type
+int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
+                 float* const (*db)[4], char* handled) {
+  if (g_xh_disable & 512) return XH_OK;
+  int rc_all = XH_OK;
+  const int types[3] = {XH_F32, XH_BF16, XH_F16};
+  S2WMulti* m = new S2WMulti;
+  for (int t = 0; t < 3; ++t) {
+    m->n = 0; m->off[0] = 0;
+    auto launch = [&]() -> int {
+      XH_DISPATCH_T(types[t], hipLaunchKernelGGL((conv3_s2_wgrad_vec_multi_kernel<T, 4>), dim3(m->off[m->n]), dim3(256), 0,
+                                                 (hipStream_t)stream, *m););
+      return XH_OK;
+    };
+    auto flush = [&]() {
+      if (m->n == 0) return;
+      for (int i = m->n; i < S2W_MULTI; ++i) m->off[i + 1] = m->off[m->n];
+      xh_note_kernel("conv3_s2_wgrad_vec_multi_kernel<%s, 4>", types[t] == XH_F32 ? "float" : (types[t] == XH_F16 ? "f16_t" : "bf16_t"));
+      if (launch() != XH_OK || xh_launch_status() != XH_OK) rc_all = XH_ERR_HIP;
+      m->n = 0; m->off[0] = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      if (handled[i] || !d[i] || !p[i] || d[i]->dtype != types[t]) continue;
+      if (check_desc(d[i], p[i]) || !p[i]->ea || !dw[i] || d[i]->transposed || d[i]->groups <= 0) continue;
+      if ((d[i]->Cout / d[i]->groups) % 4) continue;                  // the two-channel instance keeps its own launch
+      bool ok = true;
+      for (int j = 0; j < d[i]->n_wptr; ++j) ok = ok && dw[i][j];
+      dim3 grid;
+      const int k = m->n;
+      if (!ok || !s2w_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &m->p[k], &m->lw[k], &grid)) continue;
+      const long long blocks = (long long)grid.x * grid.y * grid.z;
+      if (blocks > (1 << 22)) continue;
+      handled[i] = 1;
+      m->gx[k] = (int)grid.x; m->gy[k] = (int)grid.y;
+      m->off[k + 1] = m->off[k] + (int)blocks;
+      if (++m->n == S2W_MULTI) flush();
+    }
+    flush();
+  }
+  delete m;
   return rc_all;
 }
 
