@@ -27,8 +27,10 @@ def _dhw(t):
 
 def _direct(*rets):
     """True when every gradient target of a wgrad call is an existing .grad buffer (nothing is returned to autograd), so
-    the launch may run on the weight-gradient side stream (ops.set_wgrad_overlap)."""
-    return all(r is None for r in rets)
+    the launch may be deferred to the end of backward (ops.set_wgrad_defer) or run on the weight-gradient side stream
+    (ops.set_wgrad_overlap) -- or when the target is the gradient of a tensor composed by ComposeAll (model._precompose marks
+    its outputs): ComposeAll.backward, their only consumer, joins the outstanding weight gradients before it reads them."""
+    return all(r is None or getattr(r, "_xh_joined", False) for r in rets)
 
 
 DIRECT_GRADS = [True]
@@ -65,6 +67,8 @@ def _targets(params):
             flat = torch.zeros(total, dtype=torch.float32, device=params[need[0]].device)
         for i, o in zip(need, offs):
             z = flat[o:o + params[i].numel()].view(params[i].shape)
+            if getattr(params[i], "_xh_joined", False):
+                z._xh_joined = True
             bufs[i] = rets[i] = z
     return bufs, rets
 
@@ -607,9 +611,9 @@ class DuSE(Function):
         dr, dch1 = ops.duse_gate_bwd(r, ch1, sp[:, 0:1], dus[0], dsp[:, 0:1])
         ds, dch2 = ops.duse_gate_bwd(s, ch2, sp[:, 1:2], dus[1], dsp[:, 1:2])
         dpre = ops.act_bwd(dsp, sp, ACT_SIGMOID)
-        ops.conv3d_wgrad(comb, None, dpre, [dadjw], [dadjb], k=3)
+        ops.conv3d_wgrad(comb, None, dpre, [dadjw], [dadjb], k=3, side=_direct(rets[8], rets[9]))
         dcomb = ops.conv3d(dpre, None, [adjw], None, k=3, cout=1, transposed=True)
-        ops.conv3d_wgrad(r, s, dcomb, [dsqw], [dsqb], k=1)
+        ops.conv3d_wgrad(r, s, dcomb, [dsqw], [dsqb], k=1, side=_direct(rets[6], rets[7]))
         fc = dict(wc=wc, w1=w1, w2=w2)
         fcg = dict(wc=dwc, bc=dbc, w1=dw1, b1=db1, w2=dw2, b2=db2)
         dmr, dms = ops.duse_fc_bwd(means, cnt, n, c, fc, gvec, ch1, ch2, dch1, dch2, fcg)
@@ -732,6 +736,7 @@ class ComposeAll(Function):
     def backward(ctx, *gouts):
         params = ctx.saved_tensors
         dev = params[0].device
+        ops.join_wgrad_stream()          # the composed tensors' gradients may still be queued (functional._direct)
         gouts = [g.contiguous() if g is not None else torch.zeros(shape, dtype=torch.float32, device=dev)
                  for g, shape in zip(gouts, ctx.out_meta)]                      # an unused composed tensor: zero gradient
         grads, rets = _targets(ctx.params)

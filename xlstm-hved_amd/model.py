@@ -226,9 +226,11 @@ class AbstractFusion3DUNet(nn.Module):
         """RA_HVED.py:510-648.  `eps_list` (optional, not in the reference signature) injects the reparameterisation
         noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
         with self._bn_counters():
-            enc = self._encode(x, bn_steps=4)
+            # composed first: ComposeAll is then the LAST node of the backward pass, so the weight gradients of the composed
+            # tensors' convs can wait for the end-of-backward batch (functional._direct)
             pre = self._precompose(seg)
             try:
+                enc = self._encode(x, bn_steps=4)
                 return self._decode(enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list)
             finally:
                 self._drop_precomposed(pre)
@@ -241,10 +243,10 @@ class AbstractFusion3DUNet(nn.Module):
         keyword arguments of forward() (subset_idx_list, instance_missing, drop, valid, eps_list).  Returns the list of
         forward() results.  BatchNorm buffers of the skip-return attention advance 4 steps per call, as they would."""
         with self._bn_counters():
-            enc = self._encode(x, bn_steps=4 * len(calls))
             pre = self._precompose(seg)                       # the composed weights are the same for every call
             outs = []
             try:
+                enc = self._encode(x, bn_steps=4 * len(calls))
                 for kw in calls:
                     outs.append(self._decode(enc, kw.get("subset_idx_list", [14]), kw.get("instance_missing", False), kw.get("drop"),
                                              seg, recon, kw.get("valid", False), kw.get("eps_list")))
@@ -272,6 +274,8 @@ class AbstractFusion3DUNet(nn.Module):
         params += [self.final_conv.weight, self.final_conv.bias, sr.sfinals[0].weight, sr.sfinals[0].bias]
         plan = ([(2, 4, a.expan) for a in attens], [d.conv_squeeze_ch1.in_channels for d in duses], True)
         outs = Fn.ComposeAll.apply(plan, *params)
+        for o in outs:
+            o._xh_joined = True          # gradients consumed by ComposeAll.backward only, which joins the weight gradients first
         mods, oi = [], 0
         for a in attens:
             a.__dict__["_pre"] = (outs[oi], outs[oi + 1])

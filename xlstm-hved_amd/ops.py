@@ -915,6 +915,9 @@ def compose_multi(bwd, atten, duse, head):
     atten: list of dicts(params=8 tensors, ns, ne, e, w, b[, grads=8 buffers, gw, gb]); duse: dicts(params=10, c, out=4[, grads=10,
     gout=4]); head: dict(wf, bf, ws, bs, w, b[, dwf, dbf, dws, dbs, gw, gb]) or None."""
     na, nd = len(atten), len(duse)
+    first = atten[0]["params"][0] if na else duse[0]["params"][0] if nd else head["wf"]
+    if not first.is_cuda:
+        raise RuntimeError("xlstm_hved_amd ops need device tensors (the HIP library is the only compute path)")
     aj = (L.AttenJob * max(na, 1))()
     for j, a in zip(aj, atten):
         j.p = (C.c_void_p * 8)(*[_p(t) for t in a["params"]])
