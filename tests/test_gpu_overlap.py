@@ -143,7 +143,7 @@ def _batch_vs_autograd(cases, k, stride, dtype, kernel):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_k1_weight_gradients_of_a_batch_share_one_launch(dtype):
-    """xh_conv3d_wgrad_batch sends the k = 1 problems of a step through conv1x1_wgrad_multi_kernel (one launch for up to 16
+    """xh_conv3d_wgrad_batch sends the k = 1 problems of a step through conv1x1_wgrad_multi_kernel (one launch for up to 20
     problems): mixed shapes, groups with one weight tensor each, a channel-concatenated input, the producer's norm + LeakyReLU
     applied on load, batch 2."""
     #        N  Ca Cb Cout groups S   pre
@@ -159,3 +159,11 @@ def test_stride2_weight_gradients_of_a_batch_share_launches(dtype):
     cases = [(1, 16, 0, 16, 4, 32, True), (1, 32, 0, 32, 4, 16, True), (2, 8, 0, 4, 1, 32, False), (1, 8, 0, 8, 2, 64, True),
              (1, 4, 4, 8, 1, 32, False)]
     _batch_vs_autograd(cases, 3, 2, dtype, "conv3_s2_wgrad_vec_multi_kernel")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_k7_gate_weight_gradients_of_a_batch_share_one_launch(dtype):
+    """... and the 7^3 gate convs of AttenModule2 (buildingblocks.py:283-296, collapsed to 4 -> 2 channels) through
+    conv7_wgrad_mfma_multi_kernel + one second-stage reduction for all of them."""
+    cases = [(1, 4, 0, 2, 1, 64, False), (1, 4, 0, 2, 1, 32, False), (2, 4, 0, 2, 1, 32, False)]
+    _batch_vs_autograd(cases, 7, 1, dtype, "conv7_wgrad_mfma_multi_kernel")

@@ -1110,7 +1110,7 @@ struct C1WP {
   float pre_slope;
   int dtype;
 };
-constexpr int C1W_MULTI = 16;
+constexpr int C1W_MULTI = 20;
 struct C1WMulti {
   int n;
   int off[C1W_MULTI + 1];
@@ -2229,4 +2229,5 @@ int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
   return rc_all;
 }
 
+int xh_check_conv(const xh_conv_desc* d, const xh_conv_ptrs* p) { return check_desc(d, p); }   // for the batch paths of other files
 extern "C" int xh_abi_version(void) { return 1; }

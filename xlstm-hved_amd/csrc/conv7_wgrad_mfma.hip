@@ -18,6 +18,8 @@
 //    512 workgroups x 2744 same-address atomics would serialise.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
+#include <algorithm>
+#include <vector>
 
 typedef h16x8 bf16x8;     // 8 raw 16-bit values (either format)
 typedef f32x4_t f32x4;
@@ -34,7 +36,7 @@ constexpr int K7_NW = 2 * 4 * 343;          // 2744 weight gradients
 constexpr int K7_NPART = K7_NW + 8;         // + 2 bias gradients (padded)
 
 template <int FMT>
-__global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) {
+__device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, const int nwg) {
   constexpr int TH = 8, TW = 32;
   constexpr int XROW = 8 * 64;                        // bytes per (ci, row): 8 shifted copies x 32 bf16
   constexpr int XBUF = 4 * TH * XROW;                 // 16 KB
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) 
   const int g4 = lane >> 4, nn = lane & 15;
   const int D = a.d.D, H = a.d.H, W = a.d.W;
   const long long hw = (long long)H * W, dhw = (long long)D * hw;
-  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  int wk = xcd_swizzle(bid, nwg);
   const int tw = wk % a.tilesW; wk /= a.tilesW;
   const int th = wk % a.tilesH; wk /= a.tilesH;
   const int ds = wk % a.dsegs;
@@ -177,8 +179,45 @@ __global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) 
   }
   if (!xrole && y_item) atomicAdd(&s_red[K7_NW + yco], dbs);
   __syncthreads();
-  float* out = a.part + (long long)blockIdx.x * K7_NPART;
+  float* out = a.part + (long long)bid * K7_NPART;
   for (int i = tid; i < K7_NPART; i += 256) out[i] = s_red[i];
+}
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) {
+  conv7_wgrad_body<FMT>(a, blockIdx.x, gridDim.x);
+}
+// The 7^3 weight gradients of a batch (xh_conv3d_wgrad_batch: the three AttenModule2 gates of a step) in one launch: alone the
+// 64^3 / 32^3 problems are 128 / 64 workgroups of 27 / 21 us next to the 128^3 one's 512 of 55 us.  Workgroup b belongs to
+// problem i with off[i] <= b < off[i + 1] (largest problem first, so the long workgroups start first).
+constexpr int WG7_MULTI = 4;
+struct Wg7Multi {
+  int n;
+  int off[WG7_MULTI + 1];
+  Wg7K p[WG7_MULTI];
+};
+struct Wg7Red {
+  const float* part[WG7_MULTI];
+  float* dw[WG7_MULTI];
+  float* db[WG7_MULTI];
+  int nparts[WG7_MULTI];
+};
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_multi_kernel(const Wg7Multi m) {
+  int pi = 0;
+  for (int k = 1; k < WG7_MULTI; ++k)
+    if (k < m.n && (int)blockIdx.x >= m.off[k]) pi = k;
+  conv7_wgrad_body<FMT>(m.p[pi], blockIdx.x - m.off[pi], m.off[pi + 1] - m.off[pi]);
+}
+__global__ __launch_bounds__(256) void conv7_wgrad_reduce_multi_kernel(const Wg7Red r) {
+  const int i = blockIdx.x * 256 + threadIdx.x, pi = blockIdx.z;
+  if (i >= K7_NW + 2) return;
+  const float* part = r.part[pi];
+  const int nparts = r.nparts[pi];
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = blockIdx.y; k < nparts; k += gridDim.y) s += part[(long long)k * K7_NPART + i];
+  if (i < K7_NW) atomicAdd(&r.dw[pi][i], s);
+  else if (r.db[pi]) atomicAdd(&r.db[pi][i - K7_NW], s);
 }
 
 // second stage: 2746 outputs x 32 slices of the partials; one float atomic per (output, slice)
@@ -240,4 +279,56 @@ int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   hipLaunchKernelGGL(conv7_wgrad_reduce_kernel, dim3(cdiv(K7_NW + 2, 256), nwg < 32 ? nwg : 32), dim3(256), 0, st,
                      (const float*)a.part, nwg, dw[0], db ? db[0] : nullptr);
   return xh_launch_status();
+}
+
+// 7^3 weight gradients of a batch: WG7_MULTI per launch and storage format (marked in handled[]); see conv7_wgrad_mfma_multi_kernel
+int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
+                 float* const (*db)[4], char* handled) {
+  extern int g_xh_disable;
+  int xh_check_conv(const xh_conv_desc* d, const xh_conv_ptrs* p);
+  if (g_xh_disable & 512) return XH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t shm = 2 * 4 * 8 * 8 * 64 + 8 * 2 * 14 * 64 + 64;
+  int rc_all = XH_OK;
+  for (int fmt = 0; fmt < 2; ++fmt) {
+    std::vector<int> idx;
+    for (int i = 0; i < n; ++i) {
+      if (handled[i] || !d[i] || !p[i] || !dw[i] || !dw[i][0] || !p[i]->xa || !p[i]->ea) continue;
+      if ((d[i]->dtype == XH_F16 ? 1 : 0) != fmt || !wg7_eligible(d[i]) || xh_check_conv(d[i], p[i])) continue;
+      if (!p[i]->ws || p[i]->ws_bytes < xh_conv3d_wgrad_workspace_bytes(d[i])) continue;
+      idx.push_back(i);
+    }
+    if (idx.size() < 2) continue;                       // a single problem: the ordinary entry point
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+      return (long long)d[a]->N * d[a]->D * d[a]->H * d[a]->W > (long long)d[b]->N * d[b]->D * d[b]->H * d[b]->W;
+    });
+    for (size_t i0 = 0; i0 < idx.size(); i0 += WG7_MULTI) {
+      Wg7Multi m;
+      Wg7Red r;
+      m.n = (int)std::min<size_t>(WG7_MULTI, idx.size() - i0);
+      m.off[0] = 0;
+      int maxp = 1;
+      for (int k = 0; k < WG7_MULTI; ++k) {
+        if (k >= m.n) { m.off[k + 1] = m.off[m.n]; r.part[k] = nullptr; r.dw[k] = r.db[k] = nullptr; r.nparts[k] = 0; continue; }
+        const int i = idx[i0 + k];
+        Wg7K& a = m.p[k];
+        a.d = *d[i];
+        wg7_plan(d[i], &a);
+        a.x = (const bf16_t*)p[i]->xa; a.x_bs = d[i]->xa_bs;
+        a.dy = (const bf16_t*)p[i]->ea; a.dy_bs = d[i]->ea_bs;
+        a.part = (float*)p[i]->ws;
+        const int nwg = a.tilesW * a.tilesH * a.dsegs * d[i]->N;
+        m.off[k + 1] = m.off[k] + nwg;
+        r.part[k] = a.part; r.dw[k] = dw[i][0]; r.db[k] = db ? db[i][0] : nullptr; r.nparts[k] = nwg;
+        if (nwg > maxp) maxp = nwg;
+        handled[i] = 1;
+      }
+      xh_note_kernel("conv7_wgrad_mfma_multi_kernel<%d>", fmt);
+      if (fmt) hipLaunchKernelGGL(conv7_wgrad_mfma_multi_kernel<1>, dim3(m.off[m.n]), dim3(256), shm, st, m);
+      else hipLaunchKernelGGL(conv7_wgrad_mfma_multi_kernel<0>, dim3(m.off[m.n]), dim3(256), shm, st, m);
+      hipLaunchKernelGGL(conv7_wgrad_reduce_multi_kernel, dim3(cdiv(K7_NW + 2, 256), maxp < 32 ? maxp : 32, m.n), dim3(256), 0, st, r);
+      if (xh_launch_status() != XH_OK) rc_all = XH_ERR_HIP;
+    }
+  }
+  return rc_all;
 }
