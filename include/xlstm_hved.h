@@ -144,7 +144,7 @@ int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, 
  * xh_conv3d_wgrad would take for problem i (db may be NULL, db[i][j] may be NULL).  Weight gradients are off the critical
  * path of a backward pass, so a caller can collect them and issue this once at the end: the k=3 MFMA problems of a
  * (storage type, volume class) share launches 7 at a time (their workgroups run side by side instead of 16 latency-bound
- * launches one after the other), the k=1 problems of a storage type 20 at a time, the 7^3 gate problems 4 at a time, the vectorised k=3 stride-2
+ * launches one after the other), the k=1 problems of a storage type 20 at a time, the 7^3 gate problems 4 at a time, the 1<->2-channel k=3 stencils 8 at a time, the vectorised k=3 stride-2
  * problems 4 at a time, everything else is forwarded to xh_conv3d_wgrad.  Same accumulate (+=) semantics. */
 int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p,
                           float* const (*dw)[4], float* const (*db)[4]);

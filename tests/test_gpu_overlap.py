@@ -167,3 +167,12 @@ def test_k7_gate_weight_gradients_of_a_batch_share_one_launch(dtype):
     conv7_wgrad_mfma_multi_kernel + one second-stage reduction for all of them."""
     cases = [(1, 4, 0, 2, 1, 64, False), (1, 4, 0, 2, 1, 32, False), (2, 4, 0, 2, 1, 32, False)]
     _batch_vs_autograd(cases, 7, 1, dtype, "conv7_wgrad_mfma_multi_kernel")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cin", [1, 2])
+def test_tiny_channel_k3_weight_gradients_of_a_batch_share_one_launch(dtype, cin):
+    """... and the 1 -> 2 / 2 -> 1 channel 3^3 stencils (DuSE's spatial adjust convs, modules/DuSFE.py:113-155) through
+    conv3_tiny_wgrad_multi_kernel."""
+    cases = [(1, cin, 0, 3 - cin, 1, 64, False), (1, cin, 0, 3 - cin, 1, 32, False), (2, cin, 0, 3 - cin, 1, 16, False)]
+    _batch_vs_autograd(cases, 3, 1, dtype, "conv3_tiny_wgrad_multi_kernel")

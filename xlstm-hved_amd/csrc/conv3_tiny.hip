@@ -9,6 +9,8 @@
 //  * weights, bias, activation and the channel counts are compile-time or scalar: straight-line code, no LDS, no barrier;
 //  * the weight gradient keeps its 54 + 2 sums in registers across a grid-stride loop over rows and ends with one block
 //    reduction and one pass of fp32 atomics per workgroup.
+#include <algorithm>
+#include <vector>
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 
@@ -92,10 +94,9 @@ __global__ __launch_bounds__(256) void conv3_tiny_kernel(const TinyK a) {
 }
 
 template <typename T, int CI, int CO>
-__global__ __launch_bounds__(256) void conv3_tiny_wgrad_kernel(const TinyK a) {
+__device__ __forceinline__ void tiny_wgrad_body(const TinyK& a, const int bx, const int n, const int gdx) {
   constexpr int VW = VWT<T>::v, NACC = 27 * CI * CO + CO;
   __shared__ float s_red[4 * NACC];
-  const int n = blockIdx.y;
   const int D = a.D, H = a.H, W = a.W, LW = a.LW;
   const long long dhw = (long long)D * H * W, rows = (long long)D * H, lanes = rows * LW;
   float acc[CO][CI][27], dbs[CO];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void conv3_tiny_wgrad_kernel(const TinyK a) {
       for (int t = 0; t < 27; ++t) acc[co][ci][t] = 0.f;
   }
   // whole workgroups iterate together (the shuffles need every lane of a row)
-  for (long long lane_id = (long long)blockIdx.x * 256 + threadIdx.x; lane_id - threadIdx.x < lanes; lane_id += (long long)gridDim.x * 256) {
+  for (long long lane_id = (long long)bx * 256 + threadIdx.x; lane_id - threadIdx.x < lanes; lane_id += (long long)gdx * 256) {
     const int tx = (int)(lane_id % LW);
     const long long row = lane_id / LW;
     const float okm = row < rows ? 1.f : 0.f;
@@ -158,6 +159,27 @@ __global__ __launch_bounds__(256) void conv3_tiny_wgrad_kernel(const TinyK a) {
   if (tid < 27 * CI * CO) atomicAdd(&a.dw[tid], s_red[tid]);                  // dw is [CO][CI][27]
   else if (tid < NACC && a.db) atomicAdd(&a.db[tid - 27 * CI * CO], s_red[tid]);
 }
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(256) void conv3_tiny_wgrad_kernel(const TinyK a) {
+  tiny_wgrad_body<T, CI, CO>(a, blockIdx.x, blockIdx.y, gridDim.x);
+}
+// the problems of a batch (xh_conv3d_wgrad_batch: the DuSE adjust convs of a step) in one launch; workgroup b belongs to problem
+// i with off[i] <= b < off[i + 1]
+constexpr int TINY_MULTI = 8;
+struct TinyMulti {
+  int n;
+  int off[TINY_MULTI + 1];
+  int gx[TINY_MULTI];
+  TinyK p[TINY_MULTI];
+};
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(256) void conv3_tiny_wgrad_multi_kernel(const TinyMulti m) {
+  int pi = 0;
+  for (int k = 1; k < TINY_MULTI; ++k)
+    if (k < m.n && (int)blockIdx.x >= m.off[k]) pi = k;
+  const int local = blockIdx.x - m.off[pi], gx = m.gx[pi];
+  tiny_wgrad_body<T, CI, CO>(m.p[pi], local % gx, local / gx, gx);
+}
 
 template <typename T>
 bool tiny_ok(const xh_conv_desc* d, const xh_conv_ptrs* p, int& lw) {
@@ -205,19 +227,27 @@ int xh_conv3_tiny_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
 }
 
 // weight / bias gradient of the same convs (dw: [Cout][Cin][27] fp32, accumulated); XH_OK if launched, 1 if not eligible
-int xh_conv3_tiny_wgrad_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* dw, float* db) {
+static int tiny_wgrad_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* dw, float* db, TinyK* a_, int* gx) {
   if (d->transposed || !p->ea || !dw) return 1;
   int lw = 0;
   bool ok = false;
   XH_DISPATCH_T(d->dtype, ok = tiny_ok<T>(d, p, lw) && d->ea_bs % VWT<T>::v == 0;);
   if (!ok) return 1;
-  TinyK a;
+  TinyK& a = *a_;
   a.x = p->xa; a.dy = p->ea; a.y = nullptr; a.w = nullptr; a.b = nullptr; a.dw = dw; a.db = db;
   a.x_bs = d->xa_bs; a.dy_bs = d->ea_bs; a.y_bs = 0;
   a.D = d->D; a.H = d->H; a.W = d->W; a.LW = lw; a.transposed = 0;
   const long long lanes = (long long)d->D * d->H * lw;
   long long nb = (lanes + 255) / 256;
   if (nb > g_tiny_wgs) nb = g_tiny_wgs;
+  *gx = (int)nb;
+  return XH_OK;
+}
+int xh_conv3_tiny_wgrad_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* dw, float* db) {
+  TinyK a;
+  int nb = 0;
+  const int rcp = tiny_wgrad_plan(d, p, dw, db, &a, &nb);
+  if (rcp != XH_OK) return rcp;
   dim3 grid((unsigned)nb, d->N);
   hipStream_t st = (hipStream_t)stream;
   xh_note_kernel("conv3_tiny_wgrad_kernel<%d -> %d>", d->Cin, d->Cout);
@@ -226,4 +256,52 @@ int xh_conv3_tiny_wgrad_try(void* stream, const xh_conv_desc* d, const xh_conv_p
     else hipLaunchKernelGGL((conv3_tiny_wgrad_kernel<T, 2, 1>), grid, dim3(256), 0, st, a);
   });
   return xh_launch_status();
+}
+
+// The problems of a batch this file's weight-gradient kernel takes, TINY_MULTI per launch, storage type and channel shape
+// (marked in handled[]; a lone problem is left to the ordinary entry point)
+int xh_tiny_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
+                        float* const (*db)[4], char* handled) {
+  extern int g_xh_disable;
+  int xh_check_conv(const xh_conv_desc* d, const xh_conv_ptrs* p);
+  if (g_xh_disable & 512) return XH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int rc_all = XH_OK;
+  const int types[3] = {XH_F32, XH_BF16, XH_F16};
+  TinyMulti* m = new TinyMulti;
+  for (int t = 0; t < 3; ++t)
+    for (int cin = 1; cin <= 2; ++cin) {
+      std::vector<int> idx;
+      std::vector<TinyK> ks;
+      std::vector<int> gxs;
+      for (int i = 0; i < n; ++i) {
+        if (handled[i] || !d[i] || !p[i] || !dw[i] || d[i]->dtype != types[t] || d[i]->Cin != cin) continue;
+        if (xh_check_conv(d[i], p[i])) continue;
+        TinyK a; int gx = 0;
+        if (tiny_wgrad_plan(d[i], p[i], dw[i][0], db ? db[i][0] : nullptr, &a, &gx) != XH_OK) continue;
+        idx.push_back(i); ks.push_back(a); gxs.push_back(gx);
+      }
+      if (idx.size() < 2) continue;
+      for (size_t i0 = 0; i0 < idx.size(); i0 += TINY_MULTI) {
+        m->n = (int)std::min<size_t>(TINY_MULTI, idx.size() - i0);
+        m->off[0] = 0;
+        for (int k = 0; k < TINY_MULTI; ++k) {
+          if (k >= m->n) { m->off[k + 1] = m->off[m->n]; m->gx[k] = 1; continue; }
+          m->p[k] = ks[i0 + k]; m->gx[k] = gxs[i0 + k];
+          m->off[k + 1] = m->off[k] + gxs[i0 + k] * d[idx[i0 + k]]->N;
+          handled[idx[i0 + k]] = 1;
+        }
+        xh_note_kernel("conv3_tiny_wgrad_multi_kernel<%d -> %d>", cin, 3 - cin);
+        auto launch = [&]() -> int {
+          XH_DISPATCH_T(types[t], {
+            if (cin == 1) hipLaunchKernelGGL((conv3_tiny_wgrad_multi_kernel<T, 1, 2>), dim3(m->off[m->n]), dim3(256), 0, st, *m);
+            else hipLaunchKernelGGL((conv3_tiny_wgrad_multi_kernel<T, 2, 1>), dim3(m->off[m->n]), dim3(256), 0, st, *m);
+          });
+          return XH_OK;
+        };
+        if (launch() != XH_OK || xh_launch_status() != XH_OK) rc_all = XH_ERR_HIP;
+      }
+    }
+  delete m;
+  return rc_all;
 }

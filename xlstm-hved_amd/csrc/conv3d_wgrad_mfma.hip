@@ -390,6 +390,8 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
 extern int g_use_mfma;
 int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
                  float* const (*db)[4], char* handled);
+int xh_tiny_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
+                        float* const (*db)[4], char* handled);
 int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
                  float* const (*db)[4], char* handled);
 int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
@@ -439,6 +441,8 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
     if (rc != XH_OK) rc_all = rc;
     const int rc2 = xh_s2w_batch(stream, n, d, p, dw, db, handled.data());      // stride-2 k = 3 problems likewise
     if (rc2 != XH_OK) rc_all = rc2;
+    const int rc4 = xh_tiny_wgrad_batch(stream, n, d, p, dw, db, handled.data());    // 1 <-> 2 channel k = 3 stencils (conv3_tiny.hip)
+    if (rc4 != XH_OK) rc_all = rc4;
     const int rc3 = g_use_mfma ? xh_wg7_batch(stream, n, d, p, dw, db, handled.data()) : XH_OK;   // the 7^3 gate convs (conv7_wgrad_mfma.hip)
     if (rc3 != XH_OK) rc_all = rc3;
   }
