@@ -703,6 +703,9 @@ __global__ __launch_bounds__(256) void vil_post_bwd_kernel(const T* dout, int S,
   __syncthreads();
   if (sub < NH) {
     const int h = sub;
+    float acc_sk[DH], acc_nw[DH];
+#pragma unroll
+    for (int j = 0; j < DH; ++j) acc_sk[j] = acc_nw[j] = 0.f;
     if (s < S) {
       const long long ho = (((long long)b * NH + h) * S + s) * DH;
       float hv[DH], xh[DH], dn[DH], mean = 0.f, var = 0.f;
@@ -727,8 +730,8 @@ __global__ __launch_bounds__(256) void vil_post_bwd_kernel(const T* dout, int S,
         const float dhs = dhg * silu_(zv);
         w.dz[to] = dhg * hs * dsilu_(zv);
         w.dxa[to] = dhs * p.skip[c];
-        atomicAdd(&s_acc[c], dhs * xav);          // dskip
-        atomicAdd(&s_acc[I + c], dhs * xh[j]);    // d outnorm weight
+        acc_sk[j] = dhs * xav;                    // dskip
+        acc_nw[j] = dhs * xh[j];                  // d outnorm weight
         dn[j] = dhs * gam;
         m1 += dn[j];
         m2 = fmaf(dn[j], xh[j], m2);
@@ -739,6 +742,15 @@ __global__ __launch_bounds__(256) void vil_post_bwd_kernel(const T* dout, int S,
     } else {
 #pragma unroll
       for (int j = 0; j < DH; ++j) s_hg[tk * (I + 1) + h * DH + j] = 0.f;
+    }
+    // the wave's 8 tokens (lane bits 3..5) summed by shuffles, then one LDS atomic per wave and value (every token's thread
+    // adding into s_acc was 32 colliding atomics per value).  All lanes take part: the partner lanes have sub < NH as well.
+#pragma unroll
+    for (int j = 0; j < DH; ++j) {
+      float a = acc_sk[j], c2 = acc_nw[j];
+      a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      c2 += __shfl_xor(c2, 8, 64); c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+      if ((tid & 63) < 8) { atomicAdd(&s_acc[h * DH + j], a); atomicAdd(&s_acc[I + h * DH + j], c2); }
     }
   }
   __syncthreads();
@@ -920,10 +932,9 @@ __global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params 
   __shared__ float s_d[TT * (3 * I + 1)];      // d[q,k,v]
   __shared__ float s_gate[TT * (2 * NH + 1)];  // di, df per head
   __shared__ float s_gw[2 * NH * 3 * I];
-  __shared__ float s_pw[3 * I * 4];            // local accum of dq_w/dk_w/dv_w
+  float* s_x = s_qkv;                          // after the gate gradients: [TT][2 * I + 1] = silu(xc) | xm of the tile's tokens
   const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
   for (int i = tid; i < NH * 3 * I; i += blockDim.x) { s_gw[i] = p.ig_w[i]; s_gw[NH * 3 * I + i] = p.fg_w[i]; }
-  for (int i = tid; i < 3 * I * 4; i += blockDim.x) s_pw[i] = 0.f;
   const int tk = tid >> 2, h = tid & 3;
   const int s = s0 + tk;
   const bool ok = s < S;
@@ -984,9 +995,6 @@ __global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params 
           dxa4[d] = fmaf(p.q_w[(gb * 4 + o) * 4 + d], dqv, dxa4[d]);
           dxa4[d] = fmaf(p.k_w[(gb * 4 + o) * 4 + d], dkv, dxa4[d]);
           dxm4[d] = fmaf(p.v_w[(gb * 4 + o) * 4 + d], dvv, dxm4[d]);
-          atomicAdd(&s_pw[(gb * 4 + o) * 4 + d], dqv * xa4[d]);
-          atomicAdd(&s_pw[I * 4 + (gb * 4 + o) * 4 + d], dkv * xa4[d]);
-          atomicAdd(&s_pw[2 * I * 4 + (gb * 4 + o) * 4 + d], dvv * xm4[d]);
         }
       }
 #pragma unroll
@@ -995,14 +1003,24 @@ __global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params 
         const float dxa_tot = dxa4[d] + w.dxa[to];
         w.dxc[to] = dxa_tot * dsilu_(w.xc[to]);
         w.dxm[to] = dxm4[d];      // v-path part; conv part added in the next stage
+        s_x[tk * (2 * I + 1) + h * DH + blk * 4 + d] = xa4[d];
+        s_x[tk * (2 * I + 1) + I + h * DH + blk * 4 + d] = xm4[d];
       }
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < DH; ++j) { s_x[tk * (2 * I + 1) + h * DH + j] = 0.f; s_x[tk * (2 * I + 1) + I + h * DH + j] = 0.f; }
   }
   __syncthreads();
-  for (int i = tid; i < I * 4; i += blockDim.x) {
-    atomicAdd(&g.q_w[i], s_pw[i]);
-    atomicAdd(&g.k_w[i], s_pw[I * 4 + i]);
-    atomicAdd(&g.v_w[i], s_pw[2 * I * 4 + i]);
+  // dq_w / dk_w / dv_w [m][d] = sum over the tile's tokens of d{q,k,v}[t][m] * x[t][4 * (m / 4) + d]: one output per thread and
+  // round, the token sum read from LDS (LDS atomics from every token's thread were 32 colliding adds per value: 54 us per launch)
+  for (int idx = tid; idx < 3 * I * 4; idx += blockDim.x) {
+    const int part = idx / (I * 4), r = idx - part * I * 4;
+    const int m = r >> 2, xch = (m & ~3) + (r & 3) + (part == 2 ? I : 0);
+    float a = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < TT; ++t) a = fmaf(s_d[t * (3 * I + 1) + part * I + m], s_x[t * (2 * I + 1) + xch], a);
+    atomicAdd(&(part == 0 ? g.q_w : part == 1 ? g.k_w : g.v_w)[r], a);
   }
 }
 
