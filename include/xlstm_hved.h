@@ -47,6 +47,9 @@ int xh_abi_version(void);
  * key 4: 1 = <=128-VGPR instances of the k3 MFMA forward kernel for <= 8 input channels (microbenchmarks: spills, 2x slower).
  * key 5: K step of the discriminator's implicit GEMM in 32-channel quarters (1 | 2, default 2).
  * key 10-13: launch-plan limits of the generator's conv kernels (microbenchmarks; defaults are the measured optima).
+ * key 16: workgroup cap of the 1<->2-channel k3 stencil kernels (default 512).
+ * key 17: workgroup count below which a quad-channel k3 launch walks 4, then 2 output planes per workgroup instead of 8
+ *         (default 512; 0 = always 8).
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
  *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo

@@ -93,10 +93,10 @@ def test_quad_channel_kernel_is_selected():
     x = torch.randn(1, 16, 8, 8, 32, device=DEV).bfloat16()
     w4 = [torch.randn(4, 4, 3, 3, 3, device=DEV) for _ in range(4)]
     X.ops.conv3d(x, None, w4, None, k=3, cout=16, groups=4)
-    assert "conv3_q4_kernel<0, false, 0, false, false>" in X.ops.last_conv_kernel()
+    assert "conv3_q4_kernel<0, false, 0, false, false" in X.ops.last_conv_kernel()      # (+ ", 2": planes per workgroup)
     X.ops.conv3d(x.half(), None, w4, None, k=3, cout=16, groups=4, pre=(torch.ones(1, 16, device=DEV), torch.zeros(1, 16, device=DEV), 0.01),
                  epi=2, red=torch.zeros(1, 16, 2, dtype=torch.float64, device=DEV))
-    assert "conv3_q4_kernel<1, true, 2, false, false>" in X.ops.last_conv_kernel()
+    assert "conv3_q4_kernel<1, true, 2, false, false" in X.ops.last_conv_kernel()
     x64 = torch.randn(1, 64, 8, 8, 32, device=DEV).bfloat16()
     X.ops.conv3d(x64, None, [torch.randn(16, 64, 3, 3, 3, device=DEV)], None, k=3, cout=16)      # > 48 channels per group
     assert "conv3_mfma_kernel" in X.ops.last_conv_kernel()
@@ -109,6 +109,43 @@ def test_quad_channel_kernel_is_selected():
         assert "conv3_q4_kernel" not in X.ops.last_conv_kernel()
     finally:
         lib.xh_set_option(2, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_quad_channel_kernel_planes_per_workgroup(dtype):
+    """conv3_q4_kernel walks 8, 4 or 2 output planes per workgroup (xh_set_option(17, n): fewer planes while the launch has
+    fewer than n workgroups -- the 64^3 / 32^3 levels of a step).  The three tilings give the same outputs bit for bit (the
+    accumulation order of a voxel does not depend on the tile) and the same statistics to fp64 round-off: forward with the
+    producer's norm on load + output moments, data gradient with the activation mask + norm-backward sums; ragged D and H."""
+    torch.manual_seed(5)
+    lib = X._lib.load()
+    n, cin, cout, sp = 2, 12, 12, (11, 13, 64)
+    x = torch.randn((n, cin) + sp, device=DEV).to(dtype)
+    dy = torch.randn((n, cout) + sp, device=DEV).to(dtype)
+    w = [torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.1]
+    b = [torch.randn(cout, device=DEV)]
+    sc, sh = torch.rand(n, cin, device=DEV) + 0.5, torch.randn(n, cin, device=DEV)
+    outs = {}
+    # workgroups of this launch with 8 / 4 planes each: 2 x 2 tiles x 3 output quads x 2 samples x (2 | 3) = 48 | 72
+    for name, thr in (("8", 0), ("4", 60), ("2", 512)):
+        lib.xh_set_option(17, thr)
+        try:
+            red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
+            y = X.ops.conv3d(x, None, w, b, k=3, cout=cout, pre=(sc, sh, 0.01), epi=2, red=red)
+            kf = X.ops.last_conv_kernel()
+            red2 = torch.zeros(n, cin, 2, dtype=torch.float64, device=DEV)
+            dx = X.ops.conv3d(dy, None, w, None, k=3, cout=cin, transposed=True, epi=1, e=(x, None, sc, sh, 0.01), red=red2)
+            kb = X.ops.last_conv_kernel()
+        finally:
+            lib.xh_set_option(17, 512)
+        suffix = "" if name == "8" else f", {name}"
+        assert kf.endswith(f"true{suffix}>") and kb.endswith(f"true{suffix}>"), (name, kf, kb)
+        outs[name] = (y.float(), red.clone(), dx.float(), red2.clone())
+    for name in ("4", "2"):
+        assert torch.equal(outs[name][0], outs["8"][0]) and torch.equal(outs[name][2], outs["8"][2])
+        for i in (1, 3):
+            a, r = outs[name][i], outs["8"][i]
+            assert (a - r).abs().max().item() <= 1e-5 * r.abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])

@@ -45,6 +45,7 @@ struct ConvQ4 {
   int tilesW, tilesH, tilesD;
   unsigned mW, mH, mQ, mG;      // reciprocals (udiv_magic) of tilesW, tilesH, oq_g, gpp
   int oq_g, gpp;                // output-channel quads per group, groups per weight pointer
+  int td;                       // output planes per workgroup (8 | 4 | 2)
   int dw;                       // depthwise conv presented as groups of 4 channels with diagonal weights (plan, pack only)
   float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
   double fin_inv;               // 1 / fin_count
@@ -53,16 +54,18 @@ struct ConvQ4 {
 };
 extern int g_mfma_abl;
 int g_q4_maxc = 48;               // xh_set_option(11, n): most channels per group the quad-channel kernel takes (<= 48)
+int g_q4_wgs = 512;               // xh_set_option(17, n): workgroup count below which a launch takes 4, then 2 output planes per workgroup (0: always 8)
 
 namespace {
-constexpr int TW = 32, TH = 8, TD = 8, IH = TH + 2, ID = TD + 2;
+constexpr int TW = 32, TH = 8, IH = TH + 2;
 constexpr int PITCH = 288;                  // 36 voxels (ow0 - 2 .. ow0 + 33) x 8 bytes
 constexpr int PLANE = IH * PITCH;
-constexpr int TILE_BYTES = ID * PLANE;      // 28 800
-constexpr int NROWS = ID * IH;              // 100 staged rows
-constexpr int NITEM = NROWS * 4;            // interior items: (row, 8-voxel group)
-constexpr int NEDGE = NROWS * 2;            // edge items: (row, side) -> one voxel pair
 constexpr int Q4_MAXC = 48;                 // most channels per group the kernel can be asked to take
+// TD = output planes per workgroup: 8 (28.8 KB tile, 100 staged rows = two 8-voxel items per thread) for the volumes that fill
+// the chip; 4 / 2 for the 64^3 / 32^3 launches, which are chains of load -> transform -> matrix phase per input quad on a few
+// dozen workgroups: a quarter of the planes per workgroup = four times the workgroups and a shorter chain each (the halo
+// planes are re-read from L2)
+constexpr int q4_tile_bytes(int td) { return (td + 2) * PLANE; }
 }
 
 // Buffer descriptor of a wave-uniform base pointer, 2 GiB window: accesses at a 32-bit lane offset >= 0x80000000 are out of range,
@@ -81,9 +84,11 @@ template <int FMT> __device__ __forceinline__ f32x2_t q4_xf(unsigned u, float sc
   return max2(v, v * f32x2_t{slope, slope});
 }
 
-template <int FMT, bool PRE, int EPI, bool ACT, bool MULTI>
+template <int FMT, bool PRE, int EPI, bool ACT, bool MULTI, int TD = 8>
 __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   typedef h16<FMT> ST;
+  constexpr int ID = TD + 2, TILE_BYTES = ID * PLANE, NROWS = ID * IH, NITEM = NROWS * 4, NEDGE = NROWS * 2;
+  constexpr int NIT = (NITEM + 255) / 256;           // interior items (row, 8-voxel group) per thread; edge items: (row, side)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8], then [8] totals + the fan-in flag
   float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 48 * sizeof(double));   // [2][Q4_MAXC]: in-kernel InstanceNorm scale / shift
@@ -110,12 +115,12 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   }
 
   // ---- staging plan (the same for every input-channel quad) ----
-  unsigned i_off[2];            // byte offset of the item's 8 voxels inside a channel volume (clamped into the volume)
-  int i_lds[2];                 // LDS byte address of the item's first 16-byte chunk, before the per-chunk XOR
-  int i_par[2];
-  bool i_live[2], i_do[2];
+  unsigned i_off[NIT];          // byte offset of the item's 8 voxels inside a channel volume (clamped into the volume)
+  int i_lds[NIT];               // LDS byte address of the item's first 16-byte chunk, before the per-chunk XOR
+  int i_par[NIT];
+  bool i_live[NIT], i_do[NIT];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const int item = tid + it * 256;
     i_do[it] = item < NITEM;
     const int gq = item & 3, row = min(item >> 2, NROWS - 1);
@@ -227,10 +232,10 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
                                                                   : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw);
     const long long dhw_b = dhw * (long long)sizeof(ST);
     // ---- all global loads of this thread, back to back ----
-    uint4 raw[2][4];
+    uint4 raw[NIT][4];
     unsigned eraw4[4];
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < NIT; ++it)
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc)
         raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * dhw_b + i_off[it]);
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     }
     // ---- transform + channels-last LDS image ----
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       if (!i_do[it]) continue;
       const int par = i_par[it] & 1, slot0 = i_par[it] >> 1;
       uint4 outv[4];                                  // chunk j = voxels 2j, 2j+1 x 4 channels
@@ -410,7 +415,17 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   a->dw = dw ? 1 : 0;
   if (dw) a->d.groups = d->groups / 4;
   a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cin_g / 4;
-  a->tilesW = d->W / TW; a->tilesH = cdiv(d->Ho, TH); a->tilesD = cdiv(d->Do, TD);
+  a->tilesW = d->W / TW; a->tilesH = cdiv(d->Ho, TH);
+  {
+    // fewer planes per workgroup while the launch would leave most of the 256 CUs without one (the 64^3 / 32^3 levels)
+    extern int g_q4_wgs;
+    const long long cols = (long long)a->tilesW * a->tilesH * (d->Cout / 4) * d->N;
+    int td = 8;
+    while (td > 2 && cols * cdiv(d->Do, td) < g_q4_wgs) td >>= 1;
+    if (as != 1.f) td = 8;                              // the conv + activation instances exist for 8 planes only
+    a->td = td;
+  }
+  a->tilesD = cdiv(d->Do, a->td);
   a->oq_g = cout_g / 4; a->gpp = a->d.groups / d->n_wptr;
   // udiv_fast is exact while index * divisor < 2^32
   if ((long long)a->tilesW * a->tilesH * a->tilesD * (a->tilesW > a->tilesH ? a->tilesW : a->tilesH) >= (1ll << 32)) return false;
@@ -465,18 +480,21 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
   a.fan = d->epi ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
-  const size_t shm = TILE_BYTES + 48 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
+  const size_t shm = q4_tile_bytes(a.td) + 48 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
   const bool act = a.act_slope != 1.f;
-  xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false");
-#define Q4L(F, P, E, A)                                                                                         \
+  xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s%s>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false",
+                 a.td == 8 ? "" : a.td == 4 ? ", 4" : ", 2");
+#define Q4L(F, P, E, A, T)                                                                                      \
   do {                                                                                                          \
-    if (a.ci4 > 1) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, true>), grid, dim3(256), shm, st, a);        \
-    else hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, false>), grid, dim3(256), shm, st, a);                 \
+    if (a.ci4 > 1) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, true, T>), grid, dim3(256), shm, st, a);     \
+    else hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, false, T>), grid, dim3(256), shm, st, a);              \
   } while (0)
-#define Q4A(F, P, E)              \
-  do {                            \
-    if (act) Q4L(F, P, E, true);  \
-    else Q4L(F, P, E, false);     \
+#define Q4A(F, P, E)                               \
+  do {                                             \
+    if (act) Q4L(F, P, E, true, 8);                \
+    else if (a.td == 8) Q4L(F, P, E, false, 8);    \
+    else if (a.td == 4) Q4L(F, P, E, false, 4);    \
+    else Q4L(F, P, E, false, 2);                   \
   } while (0)
 #define Q4E(F, P)                       \
   do {                                  \
