@@ -239,6 +239,18 @@ int xh_upsample_trilinear_fwd(void* stream, int dtype, const void* x, long long 
                               int N, int C, int D, int H, int W, int Do, int Ho, int Wo);
 int xh_upsample_trilinear_bwd(void* stream, int dtype, const void* dy, long long dy_bs, void* dx, long long dx_bs,
                               int N, int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate);
+/* BasicConv's InstanceNorm3d + LeakyReLU (buildingblocks.py:13-31) applied inside the exact-2x upsampling that follows it
+ * (RA_HVED.py:599-601): y (N, C, 2D, 2H, 2W) = up2x(leaky(IN(x))), IN finalised from the conv epilogue's raw channel sums
+ * red[n][c] = (sum x, sum x^2); sc / sh / mean / rstd (N x C, fp32) are written for the backward pass.  Returns 1 with nothing
+ * launched when the exact-2x kernel does not take the layout (then: xh_in_affine_act + xh_upsample_trilinear_fwd). */
+int xh_upsample2x_in_act_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                             int D, int H, int W, const double* red, float slope, float* sc, float* sh, float* mean, float* rstd);
+/* Its adjoint: dx (N, C, D, H, W) = up2x^T(dy), and red[n][c] += (sum dz, sum dz * y0) with dz = dx * leaky'(y0 * sc + sh) --
+ * the sums of xh_act_bwd_reduce over the values as stored (caller zeroes red).  Returns 1 when not taken (then:
+ * xh_upsample_trilinear_bwd + xh_act_bwd_reduce). */
+int xh_upsample2x_bwd_act_reduce(void* stream, int dtype, const void* dy, long long dy_bs, void* dx, long long dx_bs, int N, int C,
+                                 int D, int H, int W, const void* y0, long long y0_bs, const float* sc, const float* sh,
+                                 float slope, double* red);
 
 /* generic elementwise helpers */
 /* y = a + b  (b may be NULL: copy) with independent batch strides */

@@ -391,3 +391,41 @@ def test_producers_that_leave_the_next_instance_norms_sums_match_a_moments_pass(
     assert (sc - sc_r).abs().max().item() <= tol * sc_r.abs().max().item() + 0.0
     assert (mean - mean_r).abs().max().item() <= 1e-6 and (rstd - rstd_r).abs().max().item() <= tol * rstd_r.abs().max().item()
     assert l2_err(yf.float(), y2.float()) < (1e-6 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(1, 2, 8, 16, 16, 16), (2, 4, 16, 8, 12, 32), (1, 8, 4, 32, 32, 32)], ids=["16", "ragged", "32"])
+def test_vu_block_with_the_upsampling_in_one_launch_vs_stock(shape, dtype):
+    """BasicConv(k=1)(x, up2x=True) = F.interpolate(LeakyReLU(InstanceNorm3d(Conv3d(x))), scale_factor=2, mode='trilinear')
+    (RA_HVED.py:599-601): norm + activation applied inside the upsampling launch (xh_upsample2x_in_act_fwd), its adjoint with the
+    activation-masked norm-backward sums (xh_upsample2x_bwd_act_reduce).  Against stock fp32 modules on the same values, and
+    against the unfused launches (xh_set_option(2, 2): the exact-2x kernels off)."""
+    import torch.nn.functional as F
+    torch.manual_seed(21)
+    n, cin, cout, d, h, w = shape
+    m = X.blocks.BasicConv(cin, cout, 1).to(DEV)
+    x = torch.randn(n, cin, d, h, w, device=DEV).to(dtype)
+    wgt = torch.randn(n, cout, 2 * d, 2 * h, 2 * w, device=DEV)
+
+    def run():
+        m.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        y = m(xg, up2x=True)
+        (y.float() * wgt).sum().backward()
+        return y.float(), xg.grad.float(), m.conv.weight.grad.clone()
+
+    y1, dx1, dw1 = run()
+    lib = X._lib.load()
+    lib.xh_set_option(2, 2)
+    try:
+        y0, dx0, dw0 = run()
+    finally:
+        lib.xh_set_option(2, 0)
+    xr = x.float().requires_grad_(True)
+    wr = m.conv.weight.detach().clone().requires_grad_(True)
+    yr = F.interpolate(F.leaky_relu(F.instance_norm(F.conv3d(xr, wr), eps=1e-5), 0.01), scale_factor=2, mode="trilinear")
+    (yr * wgt).sum().backward()
+    ty, tg = {torch.float32: (2e-5, 2e-4), torch.bfloat16: (8e-3, 3e-2), torch.float16: (1.5e-3, 6e-3)}[dtype]
+    assert l2_err(y1, yr) < ty and l2_err(y1, y0) < ty, (l2_err(y1, yr), l2_err(y1, y0))
+    assert l2_err(dx1, xr.grad) < tg and l2_err(dx1, dx0) < tg, (l2_err(dx1, xr.grad), l2_err(dx1, dx0))
+    assert l2_err(dw1, wr.grad) < tg and l2_err(dw1, dw0) < tg, (l2_err(dw1, wr.grad), l2_err(dw1, dw0))

@@ -90,6 +90,8 @@ SIGNATURES = {
     "xh_maxpool2_bwd": (I, [vp, I, vp, vp, vp, I, I, I, I, I]),
     "xh_upsample_trilinear_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, I, I, I]),
     "xh_upsample_trilinear_bwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, I, I, I, I]),
+    "xh_upsample2x_in_act_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, vp, F, vp, vp, vp, vp]),
+    "xh_upsample2x_bwd_act_reduce": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, vp, ll, vp, vp, F, vp]),
     "xh_add": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, ll]),
     "xh_act_bwd": (I, [vp, I, vp, vp, vp, ll, I]),
     "xh_poe_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll, I]),

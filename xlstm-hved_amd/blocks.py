@@ -34,8 +34,10 @@ class BasicConv(nn.Module):
         self.norm = nn.InstanceNorm3d(out_planes)
         self.relu = nn.LeakyReLU(negative_slope=1e-2, inplace=True)
 
-    def forward(self, x):
-        return Fn.ConvInLrelu.apply(x, self.conv.weight, self.groups)
+    def forward(self, x, up2x=False):
+        """up2x (not in the reference signature): also F.interpolate(scale 2, trilinear) of the result, in the launch that
+        applies the norm (the VU block + upsampling pair of RA_HVED.py:599-601)."""
+        return Fn.ConvInLrelu.apply(x, self.conv.weight, self.groups, up2x)
 
 
 # BatchNorm `num_batches_tracked` counters: a network forward touches a dozen of them; updated one by one that is a dozen

@@ -798,12 +798,23 @@ template <int F> __device__ __forceinline__ void cvtraw(const h16<F>*, uint4 t, 
 
 // Both kernels march through the planes of a depth segment; a plane's rows are REQUESTED one step before they are used (raw
 // registers), so the march is not a chain of exposed memory round trips (sd + 2 of them: 10 us for any volume before).
-template <typename T, int TXN>
+// PRE: the input is a conv output whose InstanceNorm + LeakyReLU have not been applied yet (BasicConv + Upsampling,
+// RA_HVED.py:599-601): finalised here from the raw channel sums `fin.red` and applied to every value on load.
+struct UpFin {
+  const double* red; double inv_count; float slope;
+  float *o_sc, *o_sh, *o_mean, *o_rstd;
+};
+template <typename T, int TXN, bool PRE = false>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, long long x_bs, T* __restrict__ y, long long y_bs, int C, int D,
-                                                            int H, int W, int sd, int tilesW, int tilesH) {
+                                                            int H, int W, int sd, int tilesW, int tilesH, const UpFin fin) {
   constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
   const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
   const int c = blockIdx.y, n = blockIdx.z;
+  float pa = 1.f, pb = 0.f;
+  double fs1 = 0.0, fs2 = 0.0;
+  if (PRE) { fs1 = fin.red[((long long)n * C + c) * 2]; fs2 = fin.red[((long long)n * C + c) * 2 + 1]; }
+  const float pslope = fin.slope;
+  auto pre = [&](float v) { if (PRE) { v = fmaf(v, pa, pb); v = v > 0.f ? v : v * pslope; } return v; };
   int t = blockIdx.x;
   const int tw = t % tilesW; t /= tilesW;
   const int th = t % tilesH;
@@ -826,6 +837,12 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
   const T* pl = src + (long long)min(max(d_begin - 1, 0), D - 1) * hw;
 #pragma unroll
   for (int k = 0; k < 3; ++k) raw[k] = ldraw8(pl, ro[k] + wc);
+  if (PRE) {                                             // behind the first plane's requests
+    const long long nc = (long long)n * C + c;
+    float m, r;
+    in_finalize(fs1, fs2, fin.inv_count, pa, pb, m, r);
+    if (blockIdx.x == 0 && tid == 0) { fin.o_sc[nc] = pa; fin.o_sh[nc] = pb; fin.o_mean[nc] = m; fin.o_rstd[nc] = r; }
+  }
   for (int p = d_begin - 1; p <= d_end; ++p) {
     const T* pn = src + (long long)min(max(p + 1, 0), D - 1) * hw;      // clamped: always a valid plane, unused past d_end
 #pragma unroll
@@ -836,10 +853,10 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
       float v[VI];
       cvtraw(pl, raw[k], v);
 #pragma unroll
-      for (int j = 0; j < VI; ++j) rows[k][j + 1] = v[j];
+      for (int j = 0; j < VI; ++j) { v[j] = pre(v[j]); rows[k][j + 1] = v[j]; }
       float l = __shfl_up(v[VI - 1], 1, 64), r = __shfl_down(v[0], 1, 64);
-      if (edge_l) l = glob_l ? ldf(pl, ro[k] + w0 - 1) : v[0];          // clamped index at the volume border
-      if (edge_r) r = glob_r ? ldf(pl, ro[k] + w0 + VI) : v[VI - 1];
+      if (edge_l) l = glob_l ? pre(ldf(pl, ro[k] + w0 - 1)) : v[0];          // clamped index at the volume border
+      if (edge_r) r = glob_r ? pre(ldf(pl, ro[k] + w0 + VI)) : v[VI - 1];
       rows[k][0] = l;
       rows[k][VI + 1] = r;
     }
@@ -887,12 +904,25 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
 
 // Adjoint of the same stencil: dx[i] = .25 dy[2i-1] + .75 dy[2i] + .75 dy[2i+1] + .25 dy[2i+2] per axis, indices clamped
 // (the clamped forward taps fold back onto the border voxel).  Same lane role, marching through the dy planes.
-template <typename T, int TXN>
+// RED: dx is the gradient of leaky(y0 * sc + sh) (the same BasicConv + Upsampling pair): the kernel also leaves the two sums the
+// InstanceNorm backward needs, red[n][c] += (sum dz, sum dz * y0) with dz = dx * leaky'(.), dx as stored (xh_act_bwd_reduce's).
+struct UpRed {
+  const void* y0; long long y0_bs; const float *sc, *sh; float slope; double* red;
+};
+__device__ __forceinline__ float up_stored(const float*, float v) { return v; }
+template <int F> __device__ __forceinline__ float up_stored(const h16<F>*, float v) { return cvt_lo<F>(cvt_pack<F>(v, 0.f)); }
+template <typename T, int TXN, bool RED = false>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, long long dy_bs, T* __restrict__ dx, long long dx_bs, int C, int D,
-                                                            int H, int W, int sd, int tilesW, int tilesH, int accumulate) {
+                                                            int H, int W, int sd, int tilesW, int tilesH, int accumulate, const UpRed ur) {
   constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
   const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
   const int c = blockIdx.y, n = blockIdx.z;
+  float ra = 1.f, rb = 0.f, rs0 = 0.f, rs1 = 0.f;
+  const T* y0p = nullptr;
+  if (RED) {
+    ra = ur.sc[(long long)n * C + c]; rb = ur.sh[(long long)n * C + c];
+    y0p = (const T*)ur.y0 + n * ur.y0_bs + (long long)c * D * H * W;
+  }
   int t = blockIdx.x;
   const int tw = t % tilesW; t /= tilesW;
   const int th = t % tilesH;
@@ -948,6 +978,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
   for (int q = d_begin - 1; q <= d_end; ++q) {          // block-uniform
     request(2 * q + 2, ne);
     request(2 * q + 3, no);
+    uint2 yraw = {0u, 0u};                               // RED: the y0 run of the plane this step completes, requested up front
+    if (RED) yraw = ldraw8(y0p, (long long)min(max(q - 1, 0), D - 1) * hw + (long long)hc * W + wc);
     float V[VI];
     if (2 * q >= 2 * d_begin - 1) {                      // even plane 2q: .75 -> q, .25 -> q-1
       plane(2 * q, re, V);
@@ -967,6 +999,16 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
         for (int j = 0; j < VI; ++j) o[j] = acc_prev[j];
       }
       sthalf(dst, sp, o);
+      if (RED) {
+        float yv[VI];
+        cvtraw(y0p, yraw, yv);
+#pragma unroll
+        for (int j = 0; j < VI; ++j) {
+          const float gg = up_stored(dst, o[j]) * (fmaf(yv[j], ra, rb) > 0.f ? 1.f : ur.slope);
+          rs0 += gg;
+          rs1 = fmaf(gg, yv[j], rs1);
+        }
+      }
     }
     if (2 * q + 1 <= 2 * d_end) {                        // odd plane 2q+1: .75 -> q, .25 -> q+1
       plane(2 * q + 1, rodd, V);
@@ -977,6 +1019,13 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
     for (int j = 0; j < VI; ++j) { acc_prev[j] = acc_cur[j]; acc_cur[j] = acc_next[j]; acc_next[j] = 0.f; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { re[k] = ne[k]; rodd[k] = no[k]; }
+  }
+  if (RED) {
+    // a lane's partial covers at most sd * VI values in fp32; fp64 from the workgroup level on, as in act_bwd_reduce_kernel
+    __shared__ double s_red[4 * 2];
+    double v[2] = {(double)rs0, (double)rs1};
+    block_sum_d<2>(v, s_red, 4);
+    if (tid < 2) atomicAdd(&ur.red[((long long)n * C + c) * 2 + tid], s_red[tid]);
   }
 }
 
@@ -998,31 +1047,67 @@ static bool upsample2x_plan(int N, int C, int D, int H, int W, long long a_bs, l
   dsegs = (D + sd - 1) / sd;
   return true;
 }
-#define UP2X_LAUNCH(KERNEL, T, ...)                                                                                     \
+#define UP2X_LAUNCH(KERNEL, T, F, ...)                                                                                  \
   switch (txn) {                                                                                                        \
-    case 4: hipLaunchKernelGGL((KERNEL<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;             \
-    case 8: hipLaunchKernelGGL((KERNEL<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;             \
-    case 16: hipLaunchKernelGGL((KERNEL<T, 16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;           \
-    case 32: hipLaunchKernelGGL((KERNEL<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;           \
-    default: hipLaunchKernelGGL((KERNEL<T, 64>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                  \
+    case 4: hipLaunchKernelGGL((KERNEL<T, 4, F>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;          \
+    case 8: hipLaunchKernelGGL((KERNEL<T, 8, F>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;          \
+    case 16: hipLaunchKernelGGL((KERNEL<T, 16, F>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;        \
+    case 32: hipLaunchKernelGGL((KERNEL<T, 32, F>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;        \
+    default: hipLaunchKernelGGL((KERNEL<T, 64, F>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);               \
   }
 template <typename T>
 static int upsample2x_fwd_try(void* stream, const void* x, long long x_bs, void* y, long long y_bs, int N, int C, int D, int H,
-                              int W) {
+                              int W, const UpFin* fin = nullptr) {
   int txn, tilesW, tilesH, sd, dsegs;
   if (!upsample2x_plan<T>(N, C, D, H, W, x_bs, y_bs, txn, tilesW, tilesH, sd, dsegs)) return 1;
   dim3 grid(tilesW * tilesH * dsegs, C, N);
-  UP2X_LAUNCH(upsample2x_fwd_kernel, T, (const T*)x, x_bs, (T*)y, y_bs, C, D, H, W, sd, tilesW, tilesH)
+  if (fin) {
+    UP2X_LAUNCH(upsample2x_fwd_kernel, T, true, (const T*)x, x_bs, (T*)y, y_bs, C, D, H, W, sd, tilesW, tilesH, *fin)
+  } else {
+    UpFin none{};
+    UP2X_LAUNCH(upsample2x_fwd_kernel, T, false, (const T*)x, x_bs, (T*)y, y_bs, C, D, H, W, sd, tilesW, tilesH, none)
+  }
   return xh_launch_status();
 }
 template <typename T>
 static int upsample2x_bwd_try(void* stream, const void* dy, long long dy_bs, void* dx, long long dx_bs, int N, int C, int D,
-                              int H, int W, int accumulate) {
+                              int H, int W, int accumulate, const UpRed* ur = nullptr) {
   int txn, tilesW, tilesH, sd, dsegs;
   if (!upsample2x_plan<T>(N, C, D, H, W, dx_bs, dy_bs, txn, tilesW, tilesH, sd, dsegs)) return 1;
   dim3 grid(tilesW * tilesH * dsegs, C, N);
-  UP2X_LAUNCH(upsample2x_bwd_kernel, T, (const T*)dy, dy_bs, (T*)dx, dx_bs, C, D, H, W, sd, tilesW, tilesH, accumulate)
+  if (ur) {
+    UP2X_LAUNCH(upsample2x_bwd_kernel, T, true, (const T*)dy, dy_bs, (T*)dx, dx_bs, C, D, H, W, sd, tilesW, tilesH, accumulate, *ur)
+  } else {
+    UpRed none{};
+    UP2X_LAUNCH(upsample2x_bwd_kernel, T, false, (const T*)dy, dy_bs, (T*)dx, dx_bs, C, D, H, W, sd, tilesW, tilesH, accumulate, none)
+  }
   return xh_launch_status();
+}
+
+// BasicConv's InstanceNorm + LeakyReLU applied inside the exact-2x trilinear upsampling that follows it (RA_HVED.py:599-601):
+// y = up2x(leaky(IN(x))) with IN finalised from the raw channel sums red[n][c] = (sum x, sum x^2) of the conv epilogue; sc / sh /
+// mean / rstd (N x C) are written for the backward pass.  Returns 1 (nothing launched) when the exact-2x kernel does not take
+// the layout: the caller then runs xh_in_affine_act + xh_upsample_trilinear_fwd.
+extern "C" int xh_upsample2x_in_act_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                                        int D, int H, int W, const double* red, float slope, float* sc, float* sh, float* mean,
+                                        float* rstd) {
+  if (!x || !y || !red || !sc || !sh || !mean || !rstd || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return XH_ERR_ARG;
+  if (g_xh_disable & 2) return 1;
+  UpFin f{red, 1.0 / ((double)D * H * W), slope, sc, sh, mean, rstd};
+  XH_DISPATCH_T(dtype, return upsample2x_fwd_try<T>(stream, x, x_bs, y, y_bs, N, C, D, H, W, &f););
+}
+// ... and its adjoint: dx = up2x^T(dy) (N, C, D, H, W) together with red[n][c] += (sum dz, sum dz * y0), dz = dx * leaky'(y0 * sc
+// + sh): what xh_upsample_trilinear_bwd + xh_act_bwd_reduce leave.  red is accumulated into (caller zeroes).  Returns 1 when
+// the exact-2x kernel does not take the layout.
+extern "C" int xh_upsample2x_bwd_act_reduce(void* stream, int dtype, const void* dy, long long dy_bs, void* dx, long long dx_bs, int N,
+                                            int C, int D, int H, int W, const void* y0, long long y0_bs, const float* sc,
+                                            const float* sh, float slope, double* red) {
+  if (!dy || !dx || !y0 || !sc || !sh || !red || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return XH_ERR_ARG;
+  if (g_xh_disable & 2) return 1;
+  const int vo = dtype == XH_F32 ? 4 : 8;
+  if (y0_bs % vo) return 1;
+  UpRed r{y0, y0_bs, sc, sh, slope, red};
+  XH_DISPATCH_T(dtype, return upsample2x_bwd_try<T>(stream, dy, dy_bs, dx, dx_bs, N, C, D, H, W, 0, &r););
 }
 
 extern "C" int xh_upsample_trilinear_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs,

@@ -257,30 +257,44 @@ class ConvInLrelu(Function):
     RA_HVED.py:401-403) or k=3 depthwise (conv_blocks, RA_HVED.py:406)."""
 
     @staticmethod
-    def forward(ctx, x, weight, groups):
+    def forward(ctx, x, weight, groups, up2x=False):
+        """up2x: also the trilinear 2x upsampling that follows the VU blocks (RA_HVED.py:600-601) -- norm and activation are
+        then applied inside the upsampling launch and the low-resolution activated tensor is never written."""
         n = x.shape[0]
         cout, k = weight.shape[0], weight.shape[-1]
         red = ops.zeros_red(x, n, cout)
         y0 = ops.conv3d(x, None, [weight], None, k=k, cout=cout, groups=groups, epi=2, red=red)
-        y, sc, sh, mean, rstd = ops.in_affine_act(y0, red, ACT_LRELU, LEAK)
+        r = ops.upsample2x_in_act(y0, red, LEAK) if up2x else None
+        if r is not None:
+            y, sc, sh, mean, rstd = r
+        else:
+            y, sc, sh, mean, rstd = ops.in_affine_act(y0, red, ACT_LRELU, LEAK)
+            if up2x:
+                y = ops.upsample(y, tuple(2 * s for s in y.shape[2:]))
         ctx.save_for_backward(x, y0, weight, sc, sh, mean, rstd)
-        ctx.cfg = (groups, k)
+        ctx.cfg = (groups, k, bool(up2x))
         ctx.params = (weight,)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y0, weight, sc, sh, mean, rstd = ctx.saved_tensors
-        groups, k = ctx.cfg
+        groups, k, up2x = ctx.cfg
         dy = _blk(dy)
-        red = ops.act_bwd_reduce(dy, y0, sc, sh, LEAK)
+        r = ops.upsample2x_bwd_act_reduce(dy, y0, sc, sh, LEAK) if up2x else None
+        if r is not None:
+            dy, red = r
+        else:
+            if up2x:
+                dy = ops.upsample_bwd(dy, tuple(y0.shape[2:]))
+            red = ops.act_bwd_reduce(dy, y0, sc, sh, LEAK)
         dy0 = ops.in_bwd_apply(dy, y0, red, mean, rstd, have_g=False, sc=sc, sh=sh, slope=LEAK)
         (dw,), (rw,) = _targets(ctx.params)
         ops.conv3d_wgrad(x, None, dy0, [dw], None, k=k, groups=groups, side=_direct(rw))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy0, None, [weight], None, k=k, cout=x.shape[1], groups=groups, transposed=True)
-        return dx, rw, None
+        return dx, rw, None, None
 
 
 class Conv(Function):

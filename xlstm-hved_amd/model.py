@@ -379,8 +379,7 @@ class AbstractFusion3DUNet(nn.Module):
             if not valid:
                 eps = noise[level] if noise is not None else eps_list[level].to(device=x.device, dtype=x.dtype).contiguous()
             z, mu, lv = Fn.PoE.apply(feat, keep, eps, L_, bool(instance_missing))
-            z = self.VU_blocks[level](z)                                                    # RA_HVED.py:599
-            z = Fn.Upsample.apply(z, tuple(2 * s for s in z.shape[2:]))                     # RA_HVED.py:600-601
+            z = self.VU_blocks[level][0](z, up2x=True)                                      # RA_HVED.py:599-601 (conv block + 2x upsampling)
             z = self.conv_blocks[level](z)                                                  # RA_HVED.py:603
             outs[level] = (z, mu, lv)
         for z, mu, lv in outs:

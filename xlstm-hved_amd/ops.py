@@ -718,6 +718,36 @@ def upsample_bwd(dy, in_size):
     return dx
 
 
+def upsample2x_in_act(x, red, slope=LEAK):
+    """up2x(leaky(InstanceNorm(x))) with the norm finalised from the raw channel sums `red` in the same launch
+    (xh_upsample2x_in_act_fwd); returns (y, sc, sh, mean, rstd), or None when the exact-2x kernel does not take the layout."""
+    n, c, d, h, w, bs = _vol(x)
+    out = new_like(x, (n, c, 2 * d, 2 * h, 2 * w))
+    sc, sh, mean, rstd = (torch.empty((n, c), dtype=torch.float32, device=x.device) for _ in range(4))
+    rc = L.load().xh_upsample2x_in_act_fwd(_stream(), _dt(x), _p(x), bs, _p(out), _vol(out)[5], n, c, d, h, w, _p(red), slope,
+                                           _p(sc), _p(sh), _p(mean), _p(rstd))
+    if rc == 1:
+        return None
+    L.check(rc, "xh_upsample2x_in_act_fwd")
+    return out, sc, sh, mean, rstd
+
+
+def upsample2x_bwd_act_reduce(dy, y0, sc, sh, slope=LEAK):
+    """(dx, red): the adjoint of the exact-2x upsampling and the activation-masked sums of act_bwd_reduce over it, one launch
+    (xh_upsample2x_bwd_act_reduce); None when the exact-2x kernel does not take the layout."""
+    n, c, d, h, w, bs = _vol(y0)
+    if tuple(dy.shape[2:]) != (2 * d, 2 * h, 2 * w):
+        return None
+    dx = new_like(dy, (n, c, d, h, w))
+    red = zeros_red(y0, n, c)
+    rc = L.load().xh_upsample2x_bwd_act_reduce(_stream(), _dt(dy), _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5], n, c, d, h, w, _p(y0), bs,
+                                               _p(sc), _p(sh), slope, _p(red))
+    if rc == 1:
+        return None
+    L.check(rc, "xh_upsample2x_bwd_act_reduce")
+    return dx, red
+
+
 def add(a, b, out=None):
     """out = a + b (b None: copy) for NCDHW-blocked tensors."""
     n, c, d, h, w, a_bs = _vol(a)
