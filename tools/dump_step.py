@@ -8,5 +8,5 @@ for i, r in enumerate(rows[n - per:]):
     g = 1
     for ax in "XYZ":
         g *= int(r[f"Grid_Size_{ax}"]) // max(1, int(r[f"Workgroup_Size_{ax}"]))
-    nm = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"])).replace("at::native::", "").replace("vectorized_elementwise_kernel", "vec_elt")
+    nm = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "")).replace("at::native::", "").replace("vectorized_elementwise_kernel", "vec_elt")
     print(f"{i:3d} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:6.1f} {g:6d} {nm[:70]}")

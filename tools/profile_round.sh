@@ -18,6 +18,7 @@ echo "trace done"
 python3 tools/summarize_rocprof.py $OUT/trace gpurun_out/profiles_out/${TAG}_bench_graph_bf16_kernel_stats.md --steps 28 --title "Round 3 ($TAG): bench.py bf16, hipGraph replay, 128^3 patch" --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 $BENCH  (2 eager + 1 capture + 25 replayed steps)" >> $OUT/trace.log 2>&1 || echo "summarize_rocprof failed"
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) gpurun_out/profiles_out/${TAG}_bench_graph_bf16_kernel_stats.csv
 python3 tools/timeline_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > gpurun_out/profiles_out/${TAG}_timeline.txt 2>&1 || true
+python3 tools/dump_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > gpurun_out/profiles_out/${TAG}_launches.txt 2>&1 || true
 PB="bench.py --steps 4 --warmup 1 --no-cpu --no-roofline --no-modes --no-trainstep"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $PB > $OUT/fetch.log 2>&1
 echo "fetch done"

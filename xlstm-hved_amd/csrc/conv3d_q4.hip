@@ -482,8 +482,8 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   a.fan = d->epi ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
   const size_t shm = q4_tile_bytes(a.td) + 48 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
   const bool act = a.act_slope != 1.f;
-  xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s%s>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false",
-                 a.td == 8 ? "" : a.td == 4 ? ", 4" : ", 2");
+  xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s, %d>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false",
+                 a.td);
 #define Q4L(F, P, E, A, T)                                                                                      \
   do {                                                                                                          \
     if (a.ci4 > 1) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, true, T>), grid, dim3(256), shm, st, a);     \
