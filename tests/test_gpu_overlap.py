@@ -176,3 +176,38 @@ def test_tiny_channel_k3_weight_gradients_of_a_batch_share_one_launch(dtype, cin
     conv3_tiny_wgrad_multi_kernel."""
     cases = [(1, cin, 0, 3 - cin, 1, 64, False), (1, cin, 0, 3 - cin, 1, 32, False), (2, cin, 0, 3 - cin, 1, 16, False)]
     _batch_vs_autograd(cases, 3, 1, dtype, "conv3_tiny_wgrad_multi_kernel")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_deferred_batch_with_a_composition_used_by_two_decoder_passes(dtype):
+    """forward_shared (train.py:224-225: two decoder passes over one encoder pass) uses every composed tensor (7^3 gates, DuSE,
+    head) TWICE.  Their weight gradients accumulate into one buffer per composed tensor, so the deferred batch gives the plain
+    step's gradients (autograd summing per-use gradients would read buffers the deferred launches have not written yet)."""
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(load("weights_seed1"), strict=True)
+    m = m.to(DEV).train()
+    torch.manual_seed(3)
+    size = 32
+    x = torch.rand(1, 4, size, size, size).to(DEV, dtype)
+    h = size // 2
+    eps = [torch.randn(1, 2 ** l, h >> l, h >> l, h >> l).to(DEV, dtype) for l in range(4)]
+    fg = X.parallel.FlatGrads(m.parameters())
+
+    def run(defer):
+        X.ops.set_wgrad_defer(defer)
+        try:
+            fg.zero()
+            outs = m.forward_shared(x, [dict(subset_idx_list=[14], eps_list=eps), dict(subset_idx_list=[6], eps_list=eps)], recon=True)
+            loss = 0.0
+            for k, (seg, (mu, lv), rec) in enumerate(outs):
+                loss = loss + (1 + k) * (seg.float().mean() + rec[0].float().mean() + sum(a.float().mean() + b.float().mean() for a, b in zip(mu, lv)))
+            loss.backward()
+            X.ops.join_wgrad_stream()
+            torch.cuda.synchronize()
+            return fg.flat.clone()
+        finally:
+            X.ops.set_wgrad_defer(False)
+    a, b = run(False), run(True)
+    scale = a.abs().max().item()
+    assert torch.isfinite(b).all() and scale > 0
+    assert (a - b).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2e-4) * scale, (a - b).abs().max().item() / scale

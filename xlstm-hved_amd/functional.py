@@ -28,9 +28,9 @@ def _dhw(t):
 def _direct(*rets):
     """True when every gradient target of a wgrad call is an existing .grad buffer (nothing is returned to autograd), so
     the launch may be deferred to the end of backward (ops.set_wgrad_defer) or run on the weight-gradient side stream
-    (ops.set_wgrad_overlap) -- or when the target is the gradient of a tensor composed by ComposeAll (model._precompose marks
-    its outputs): ComposeAll.backward, their only consumer, joins the outstanding weight gradients before it reads them."""
-    return all(r is None or getattr(r, "_xh_joined", False) for r in rets)
+    (ops.set_wgrad_overlap).  That includes the tensors composed by ComposeAll: each carries a gradient buffer of its own
+    (`_xh_gbuf`, _targets) that every use accumulates into; ComposeAll.backward joins the outstanding launches, then reads it."""
+    return all(r is None for r in rets)
 
 
 DIRECT_GRADS = [True]
@@ -46,6 +46,8 @@ def _targets(params):
     bufs, rets, need = [], [], []
     for i, p in enumerate(params):
         g = p.grad if (p is not None and p.is_leaf and p.requires_grad) else None
+        if g is None and p is not None:
+            g = getattr(p, "_xh_gbuf", None)      # a tensor composed by ComposeAll: its step-long gradient buffer
         if DIRECT_GRADS[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape:
             bufs.append(g)
             rets.append(None)
@@ -67,8 +69,6 @@ def _targets(params):
             flat = torch.zeros(total, dtype=torch.float32, device=params[need[0]].device)
         for i, o in zip(need, offs):
             z = flat[o:o + params[i].numel()].view(params[i].shape)
-            if getattr(params[i], "_xh_joined", False):
-                z._xh_joined = True
             bufs[i] = rets[i] = z
     return bufs, rets
 
@@ -744,15 +744,30 @@ class ComposeAll(Function):
         ctx.save_for_backward(*params)
         ctx.out_meta = [tuple(o.shape) for o in outs]
         ctx.set_materialize_grads(False)
+        # One zeroed fp32 gradient buffer per composed tensor, alive for the step: the convs that use the tensor accumulate
+        # their weight gradients into it (as they do into a leaf's .grad) and hand autograd nothing, so those launches can wait
+        # for the end-of-backward batch however many times the tensor is used (autograd would sum per-use gradients the
+        # moment the second one is returned -- before a deferred launch has written it).  Private storage, not the per-step
+        # arena: a second forward before this one's backward would be handed the same arena slices.
+        ctx.gbufs = None
+        if any(ctx.needs_input_grad):
+            sizes = [(o.numel() + 15) // 16 * 16 for o in outs]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            ctx.gbufs, off = [], 0
+            for o, n_ in zip(outs, sizes):
+                o._xh_gbuf = flat[off:off + o.numel()].view(o.shape)
+                ctx.gbufs.append(o._xh_gbuf)
+                off += n_
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         params = ctx.saved_tensors
         dev = params[0].device
-        ops.join_wgrad_stream()          # the composed tensors' gradients may still be queued (functional._direct)
-        gouts = [g.contiguous() if g is not None else torch.zeros(shape, dtype=torch.float32, device=dev)
-                 for g, shape in zip(gouts, ctx.out_meta)]                      # an unused composed tensor: zero gradient
+        ops.join_wgrad_stream()          # the composed tensors' weight gradients may still be queued (functional._direct)
+        # the step-long buffers hold what the package's own convs accumulated; a consumer that returned a gradient through
+        # autograd instead (a stock op on a composed tensor) is added on top
+        gouts = [buf if g is None else buf.add_(g.reshape(buf.shape)) for g, buf in zip(gouts, ctx.gbufs)]
         grads, rets = _targets(ctx.params)
         ops.compose_multi(True, *ComposeAll._jobs(ctx.plan, params, None, True, grads=grads, gouts=gouts))
         return (None, *rets)

@@ -274,8 +274,8 @@ class AbstractFusion3DUNet(nn.Module):
         params += [self.final_conv.weight, self.final_conv.bias, sr.sfinals[0].weight, sr.sfinals[0].bias]
         plan = ([(2, 4, a.expan) for a in attens], [d.conv_squeeze_ch1.in_channels for d in duses], True)
         outs = Fn.ComposeAll.apply(plan, *params)
-        for o in outs:
-            o._xh_joined = True          # gradients consumed by ComposeAll.backward only, which joins the weight gradients first
+        if outs[0].requires_grad and any(getattr(o, "_xh_gbuf", None) is None for o in outs):
+            raise RuntimeError("ComposeAll: the composed tensors lost their gradient buffers")     # (Function.apply returns forward's own tensors)
         mods, oi = [], 0
         for a in attens:
             a.__dict__["_pre"] = (outs[oi], outs[oi + 1])

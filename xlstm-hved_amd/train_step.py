@@ -39,8 +39,9 @@ def subset_rows(device):
 class TrainStep:
     def __init__(self, model, disc, optimizer=None, optimizer_d=None, alpha=0.1, beta=0.2, storage=torch.bfloat16,
                  loss_scale=None, shared_encoder=True, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
-                 share_disc_pass=True):
+                 share_disc_pass=True, defer_wgrads=True):
         self.model, self.disc = model, disc
+        self.defer_wgrads = bool(defer_wgrads)               # the generator's weight gradients in one end-of-backward batch
         self.optimizer, self.optimizer_d = optimizer, optimizer_d
         self.alpha, self.beta = float(alpha), float(beta)
         self.storage = storage
@@ -148,8 +149,15 @@ class TrainStep:
         self.grads_d.zero()
         with pack_scope():                                   # the discriminator's weight images are built once for both passes
             loss, parts, (fake, real, f_out, share) = self.generator_forward(x, mask, subset, eps_lists)
-            (loss * self._scale[0] if self.scaling else loss).backward()
-            ops.join_wgrad_stream()
+            # the generator's weight gradients go straight into self.grads and nothing reads them before the join: collected
+            # during backward and issued together (xh_conv3d_wgrad_batch: 13 launches instead of one per convolution)
+            was = ops._WG["defer"]
+            ops.set_wgrad_defer(self.defer_wgrads or was)
+            try:
+                (loss * self._scale[0] if self.scaling else loss).backward()
+                ops.join_wgrad_stream()
+            finally:
+                ops.set_wgrad_defer(was)
             if self.scaling:
                 self.grads.flat.mul_(self._inv_scale)
             loss_d = self.discriminator_forward(fake, real, share)
