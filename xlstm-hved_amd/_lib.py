@@ -113,7 +113,7 @@ SIGNATURES = {
     "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_compose_atten_fwd": (I, [vp] * 9 + [I, I, I, I, vp, vp]),
     "xh_compose_atten_bwd": (I, [vp] * 7 + [I, I, I, I] + [vp] * 10),
-    "xh_compose_multi": (I, [vp, I, I, vp, I, vp, I, vp]),
+    "xh_compose_multi": (I, [vp, I, I, vp, I, vp, I, vp, vp, ll]),
     "xh_compose_duse_fwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp]),
     "xh_compose_duse_bwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp, C.POINTER(vp * 10)]),
     "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -2623,10 +2623,15 @@ struct ComposeJobs {
   DuseCompose d[XH_COMPOSE_MAX]; DuseComposeGrad dg[XH_COMPOSE_MAX];
   float* dout[XH_COMPOSE_MAX][4]; const float* dgout[XH_COMPOSE_MAX][4];
   xh_head_job h;
+  float* zero_buf; long long zero_n;                    // forward: also cleared (the composed tensors' gradient buffers of the step)
 };
 __global__ __launch_bounds__(256) void compose_multi_kernel(const ComposeJobs j) {
   __shared__ float s_red[4 * 2];
   const int job = blockIdx.y;
+  if (j.zero_buf)
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < j.zero_n;
+         i += (long long)gridDim.x * gridDim.y * 256)
+      j.zero_buf[i] = 0.f;
   if (job < j.na) {
     if (!j.bwd) compose_atten_fwd_body(j.a[job], j.aw[job], j.ab[job], blockIdx.x, gridDim.x);
     else compose_atten_bwd_body(j.a[job], j.ag[job], j.agw[job], j.agb[job], blockIdx.x, s_red);
@@ -2675,11 +2680,12 @@ __global__ __launch_bounds__(256) void compose_multi_kernel(const ComposeJobs j)
   }
 }
 extern "C" int xh_compose_multi(void* stream, int bwd, int na, const xh_atten_job* aj, int nd, const xh_duse_job* dj, int nh,
-                                const xh_head_job* hj) {
+                                const xh_head_job* hj, float* zero_buf, long long zero_n) {
   if (na < 0 || nd < 0 || nh < 0 || na > XH_COMPOSE_MAX || nd > XH_COMPOSE_MAX || nh > 1 || na + nd + nh == 0) return XH_ERR_ARG;
-  if ((na && !aj) || (nd && !dj) || (nh && !hj)) return XH_ERR_ARG;
+  if ((na && !aj) || (nd && !dj) || (nh && !hj) || zero_n < 0 || (zero_n > 0 && !zero_buf)) return XH_ERR_ARG;
   ComposeJobs j;
   j.na = na; j.nd = nd; j.nh = nh; j.bwd = bwd ? 1 : 0;
+  j.zero_buf = zero_n > 0 ? zero_buf : nullptr; j.zero_n = zero_n;
   int gx = 1;
   for (int i = 0; i < na; ++i) {
     const xh_atten_job& s = aj[i];

@@ -739,7 +739,10 @@ class ComposeAll(Function):
         if has_head:
             wf, _, ws, _ = params[pi:pi + 4]
             outs += [new(wf.shape[0], ws.shape[1], 1, 1, 1), new(wf.shape[0])]
-        ops.compose_multi(False, *ComposeAll._jobs(plan, params, outs, False))
+        # (the gradient buffers below are cleared by the same launch)
+        sizes = [(o.numel() + 15) // 16 * 16 for o in outs]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
+        ops.compose_multi(False, *ComposeAll._jobs(plan, params, outs, False), zero=flat)
         ctx.plan, ctx.params = plan, params
         ctx.save_for_backward(*params)
         ctx.out_meta = [tuple(o.shape) for o in outs]
@@ -750,9 +753,7 @@ class ComposeAll(Function):
         # moment the second one is returned -- before a deferred launch has written it).  Private storage, not the per-step
         # arena: a second forward before this one's backward would be handed the same arena slices.
         ctx.gbufs = None
-        if any(ctx.needs_input_grad):
-            sizes = [(o.numel() + 15) // 16 * 16 for o in outs]
-            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        if flat is not None:
             ctx.gbufs, off = [], 0
             for o, n_ in zip(outs, sizes):
                 o._xh_gbuf = flat[off:off + o.numel()].view(o.shape)

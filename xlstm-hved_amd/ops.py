@@ -940,10 +940,10 @@ def compose_atten_bwd(params, ns, ne, e, gw, gb, grads):
                                           k3, _p(gw), _p(gb), *[_p(g) for g in grads]), "xh_compose_atten_bwd")
 
 
-def compose_multi(bwd, atten, duse, head):
+def compose_multi(bwd, atten, duse, head, zero=None):
     """All parameter compositions of a step in one launch (xh_compose_multi).
     atten: list of dicts(params=8 tensors, ns, ne, e, w, b[, grads=8 buffers, gw, gb]); duse: dicts(params=10, c, out=4[, grads=10,
-    gout=4]); head: dict(wf, bf, ws, bs, w, b[, dwf, dbf, dws, dbs, gw, gb]) or None."""
+    gout=4]); head: dict(wf, bf, ws, bs, w, b[, dwf, dbf, dws, dbs, gw, gb]) or None.  zero: an fp32 tensor the launch also clears."""
     na, nd = len(atten), len(duse)
     first = atten[0]["params"][0] if na else duse[0]["params"][0] if nd else head["wf"]
     if not first.is_cuda:
@@ -972,7 +972,8 @@ def compose_multi(bwd, atten, duse, head):
             setattr(hj, k, _p(head[k]))
         hj.Co, hj.Cm, hj.Ci = head["wf"].shape[0], head["ws"].shape[0], head["ws"].shape[1]
     L.check(L.load().xh_compose_multi(_stream(), int(bwd), na, C.cast(aj, C.c_void_p), nd, C.cast(dj, C.c_void_p),
-                                      int(head is not None), C.cast(C.pointer(hj), C.c_void_p)), "xh_compose_multi")
+                                      int(head is not None), C.cast(C.pointer(hj), C.c_void_p),
+                                      _p(zero), zero.numel() if zero is not None else 0), "xh_compose_multi")
 
 
 def _ptr10(ts):
