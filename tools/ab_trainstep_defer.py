@@ -1,3 +1,6 @@
+"""Generator gradients of one fp32 TrainStep.compute at the test size with and without the deferred weight-gradient batch, and the
+run-to-run noise of each (fp32 atomics): plain vs deferred must sit at the noise level (1e-6 of the largest gradient).
+usage (GPU box): python tools/ab_trainstep_defer.py"""
 import sys, torch
 import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import xlstm_hved_amd as X
