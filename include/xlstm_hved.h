@@ -42,7 +42,7 @@ int xh_abi_version(void);
  *        weight-gradient kernel (both fall back to the implicit-GEMM kernels), bit 6 statistics fan-in (direct atomics),
  *        bit 7 depthwise k3 convs through the quad-channel kernel (fall back to the sliding-window vector kernel),
  *        bit 8 input-channel split inside the blocks of the stride-2 vector conv on small outputs, bit 9 shared launches of the
- *        k=1 and stride-2 weight gradients of xh_conv3d_wgrad_batch (one launch per problem instead).
+ *        k=1 and stride-2 weight gradients of xh_conv3d_wgrad_batch (one launch per problem instead), bit 10 one-pass DuSE gate backward.
  * key 3: target workgroup count of the k3 MFMA forward kernel (default 512 = 2 per CU; microbenchmarks: 1024-4096 were 7-25 % slower).
  * key 4: 1 = <=128-VGPR instances of the k3 MFMA forward kernel for <= 8 input channels (microbenchmarks: spills, 2x slower).
  * key 5: K step of the discriminator's implicit GEMM in 32-channel quarters (1 | 2, default 2).
@@ -325,10 +325,13 @@ int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, con
  * BatchNorm3d that follows (modules/DuSFE.py:151-153): replaces a separate xh_moments pass over u. */
 int xh_duse_gate_fwd_stats(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                            long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW, double* red);
-/* dx = du*(1+ch+sp); dsp = sum_c du*x; dch[n][c] += sum_p du*x (double accum buffer red1 [N][C]) */
+/* dx = du*(1+ch+sp); dsp = sum_c du*x; dch[n][c] += sum_p du*x (double accum buffer red1 [N][C]).  sigmoid_bwd = 1: dsp is stored
+ * times sp*(1-sp), i.e. as the gradient in front of the sigmoid that produced sp (modules/DuSFE.py:113-155) -- only where
+ * xh_duse_gate_bwd_fuses(C) says the one-pass kernel takes the channel count (4 / 8 / 16), XH_ERR_ARG otherwise. */
 int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                      long long sp_bs, const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp,
-                     long long dsp_bs, double* dch, int N, int C, long long DHW);
+                     long long dsp_bs, double* dch, int N, int C, long long DHW, int sigmoid_bwd);
+int xh_duse_gate_bwd_fuses(int C);
 
 /* Skip-return attention tail (sa_module.py:133-135 + attention_blocks.py:119-126):
  * r = relu(relu(t*sc+sh) + x); a = sigmoid(w0*max_c r + w1*mean_c r).  a has 1 channel. */

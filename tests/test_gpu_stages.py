@@ -429,3 +429,42 @@ def test_vu_block_with_the_upsampling_in_one_launch_vs_stock(shape, dtype):
     assert l2_err(y1, yr) < ty and l2_err(y1, y0) < ty, (l2_err(y1, yr), l2_err(y1, y0))
     assert l2_err(dx1, xr.grad) < tg and l2_err(dx1, dx0) < tg, (l2_err(dx1, xr.grad), l2_err(dx1, dx0))
     assert l2_err(dw1, wr.grad) < tg and l2_err(dw1, dw0) < tg, (l2_err(dw1, wr.grad), l2_err(dw1, dw0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("c,sp_shape", [(4, (8, 16, 32)), (8, (5, 7, 9)), (16, (8, 8, 16)), (6, (4, 8, 8))], ids=["c4", "c8_ragged", "c16", "c6_two_pass"])
+def test_duse_gate_backward_in_one_pass_vs_formulas(c, sp_shape, dtype):
+    """xh_duse_gate_bwd for 4 / 8 / 16 channels is one voxel-major pass that also takes dsp through the sigmoid's backward
+    (duse_gate_bwd_fused_kernel); other channel counts (and xh_set_option(2, 1024)) keep the row-major + voxel-major pair and a
+    separate act_bwd.  Both against the formulas dx = du (1 + ch + sp), dsp = sum_c du x, dch = sum_p du x in fp64."""
+    torch.manual_seed(13)
+    n = 2
+    x = torch.randn((n, c) + sp_shape, device=DEV).to(dtype)
+    du = torch.randn((n, c) + sp_shape, device=DEV).to(dtype)
+    sp = torch.sigmoid(torch.randn((n, 1) + sp_shape, device=DEV)).to(dtype)
+    ch = torch.rand(n, c, device=DEV)
+    lib = X._lib.load()
+
+    def run():
+        fused = X.ops.duse_gate_bwd_fuses(c)
+        dsp = torch.empty_like(sp)
+        dx, dch = X.ops.duse_gate_bwd(x, ch, sp, du, dsp, sigmoid_bwd=fused)
+        dpre = dsp if fused else X.ops.act_bwd(dsp, sp, 3)
+        return fused, dx.float(), dpre.float(), dch.clone()
+
+    f1, dx1, dp1, dch1 = run()
+    assert f1 == (c in (4, 8, 16))
+    lib.xh_set_option(2, 1024)
+    try:
+        f0, dx0, dp0, dch0 = run()
+    finally:
+        lib.xh_set_option(2, 0)
+    assert not f0
+    xd, dud, spd = x.double(), du.double(), sp.double()
+    dx_r = dud * (1 + ch.double()[:, :, None, None, None] + spd)
+    dp_r = (dud * xd).sum(1, keepdim=True) * spd * (1 - spd)
+    dch_r = (dud * xd).sum((2, 3, 4))
+    tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+    for got in ((dx1, dp1, dch1), (dx0, dp0, dch0)):
+        assert l2_err(got[0], dx_r.float()) < tol and l2_err(got[1], dp_r.float()) < tol
+        assert (got[2] - dch_r).abs().max().item() <= 1e-4 * dch_r.abs().max().item()

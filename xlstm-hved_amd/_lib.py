@@ -108,7 +108,8 @@ SIGNATURES = {
     "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I, I]),
     "xh_duse_gate_fwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll]),
     "xh_duse_gate_fwd_stats": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll, vp]),
-    "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll]),
+    "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll, I]),
+    "xh_duse_gate_bwd_fuses": (I, [I]),
     "xh_rank1_add": (I, [vp, I, vp, ll, vp, ll, vp, vp, I, I, ll]),
     "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_compose_atten_fwd": (I, [vp] * 9 + [I, I, I, I, vp, vp]),

@@ -2129,6 +2129,78 @@ __global__ __launch_bounds__(256) void duse_gate_bwd_sp_kernel(const T* __restri
     strow<VEC>(dsp + n * dsp_bs, q, valid, a);
   VOX_LOOP_END
 }
+// Both halves in ONE voxel-major pass for C = 4 / 8 / 16 (the decoder levels of the network): a lane walks the channels of its
+// run once -- dx_c = du_c (1 + ch_c + sp), the voxel sum dsp = sum_c du_c x_c, the channel sums dch_c in registers until one block
+// reduction -- instead of reading x and du in a row-major and again in a voxel-major launch.  SIG: dsp is stored times
+// sp (1 - sp), i.e. already through the sigmoid that produced sp (the act_bwd pass behind it).
+template <typename T, bool VEC, int C, bool SIG>
+__global__ __launch_bounds__(256) void duse_gate_bwd_fused_kernel(const T* __restrict__ x, long long x_bs, const float* __restrict__ ch,
+                                                                 const T* __restrict__ sp, long long sp_bs, const T* __restrict__ du,
+                                                                 long long du_bs, T* __restrict__ dx, long long dx_bs,
+                                                                 T* __restrict__ dsp, long long dsp_bs, double* dch, long long dhw) {
+  __shared__ double s_red[4 * C];
+  float cg[C], part[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { cg[c] = 1.f + ch[blockIdx.z * C + c]; part[c] = 0.f; }
+  double tot[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) tot[c] = 0.0;
+  VOX_LOOP_BEGIN
+    float sv[VW], a[VW];
+    ldrow<VEC>(sp + n * sp_bs, q, valid, sv);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) a[v] = 0.f;
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float g[4][VW], xv[4][VW];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ldrow<VEC>(du + n * du_bs + (long long)(c0 + j) * dhw, q, valid, g[j]);
+        ldrow<VEC>(x + n * x_bs + (long long)(c0 + j) * dhw, q, valid, xv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float o[VW], t = 0.f;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          const float gv = v < valid ? g[j][v] : 0.f;
+          o[v] = gv * (cg[c0 + j] + sv[v]);
+          const float pr = gv * xv[j][v];
+          a[v] += pr;
+          t += pr;
+        }
+        part[c0 + j] += t;
+        strow<VEC>(dx + n * dx_bs + (long long)(c0 + j) * dhw, q, valid, o);
+      }
+    }
+    if (SIG) {
+#pragma unroll
+      for (int v = 0; v < VW; ++v) a[v] *= sv[v] * (1.f - sv[v]);
+    }
+    strow<VEC>(dsp + n * dsp_bs, q, valid, a);
+    // fp32 partial over one run, fp64 across the lane's runs (as the row kernel: fp64 from the run level on)
+#pragma unroll
+    for (int c = 0; c < C; ++c) { tot[c] += (double)part[c]; part[c] = 0.f; }
+  VOX_LOOP_END
+  block_sum_d<C>(tot, s_red, 4);
+  if (threadIdx.x < C) atomicAdd(&dch[blockIdx.z * C + threadIdx.x], s_red[threadIdx.x]);
+}
+template <typename T>
+static bool duse_gate_bwd_fused_try(void* stream, const void* x, long long x_bs, const float* ch, const void* sp, long long sp_bs,
+                                    const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp, long long dsp_bs, double* dch,
+                                    int N, int C, long long DHW, int sig) {
+  if ((C != 4 && C != 8 && C != 16) || (g_xh_disable & 1024)) return false;
+  const bool vec = vec_ok<T>(DHW, {x_bs, sp_bs, du_bs, dx_bs, dsp_bs});
+  const dim3 grid = vox_grid<T>(DHW, N, 512);           // every workgroup ends in C same-address fp64 atomics
+#define DGF(CC, V, S) hipLaunchKernelGGL((duse_gate_bwd_fused_kernel<T, V, CC, S>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, x_bs, ch, (const T*)sp, sp_bs, (const T*)du, du_bs, (T*)dx, dx_bs, (T*)dsp, dsp_bs, dch, DHW)
+#define DGS(CC, V) do { if (sig) DGF(CC, V, true); else DGF(CC, V, false); } while (0)
+#define DGV(CC) do { if (vec) DGS(CC, true); else DGS(CC, false); } while (0)
+  if (C == 4) DGV(4); else if (C == 8) DGV(8); else DGV(16);
+#undef DGV
+#undef DGS
+#undef DGF
+  return true;
+}
 static int launch_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp, long long sp_bs,
                                 void* u, long long u_bs, int N, int C, long long DHW, double* red) {
   if (!x || !ch || !sp || !u || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
@@ -2143,6 +2215,7 @@ static int launch_duse_gate_fwd(void* stream, int dtype, const void* x, long lon
 #undef DG
   return xh_launch_status();
 }
+extern "C" int xh_duse_gate_bwd_fuses(int C) { return (C == 4 || C == 8 || C == 16) && !(g_xh_disable & 1024); }
 extern "C" int xh_duse_gate_fwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                                 long long sp_bs, void* u, long long u_bs, int N, int C, long long DHW) {
   return launch_duse_gate_fwd(stream, dtype, x, x_bs, ch, sp, sp_bs, u, u_bs, N, C, DHW, nullptr);
@@ -2154,8 +2227,14 @@ extern "C" int xh_duse_gate_fwd_stats(void* stream, int dtype, const void* x, lo
 }
 extern "C" int xh_duse_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const float* ch, const void* sp,
                                 long long sp_bs, const void* du, long long du_bs, void* dx, long long dx_bs, void* dsp,
-                                long long dsp_bs, double* dch, int N, int C, long long DHW) {
+                                long long dsp_bs, double* dch, int N, int C, long long DHW, int sigmoid_bwd) {
   if (!x || !ch || !sp || !du || !dx || !dsp || !dch || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+  {
+    bool done = false;
+    XH_DISPATCH_T(dtype, done = duse_gate_bwd_fused_try<T>(stream, x, x_bs, ch, sp, sp_bs, du, du_bs, dx, dx_bs, dsp, dsp_bs, dch, N, C, DHW, sigmoid_bwd););
+    if (done) return xh_launch_status();
+  }
+  if (sigmoid_bwd) return XH_ERR_ARG;                  // only the fused pass applies it (C = 4 / 8 / 16): the caller asks xh_duse_gate_bwd_fuses()
   const bool vec32 = vec_ok<float>(DHW, {x_bs, sp_bs, du_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {x_bs, sp_bs, du_bs, dx_bs});
   const dim3 grid32 = red_grid<float>(DHW, C, N), grid16 = red_grid<bf16_t>(DHW, C, N);
   if (dtype == XH_F32) {

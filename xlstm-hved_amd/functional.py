@@ -622,9 +622,10 @@ class DuSE(Function):
             red = ops.act_bwd_reduce(do, u, sc, sh, 1.0)
             dus.append(ops.norm_bwd_fused(mode, do, u, red, m, rs, gamma=gam, dgamma=dg, dbeta=db))
         dsp = torch.empty_like(sp)
-        dr, dch1 = ops.duse_gate_bwd(r, ch1, sp[:, 0:1], dus[0], dsp[:, 0:1])
-        ds, dch2 = ops.duse_gate_bwd(s, ch2, sp[:, 1:2], dus[1], dsp[:, 1:2])
-        dpre = ops.act_bwd(dsp, sp, ACT_SIGMOID)
+        fused = ops.duse_gate_bwd_fuses(c)       # one pass per stream that also takes dsp through the sigmoid's backward
+        dr, dch1 = ops.duse_gate_bwd(r, ch1, sp[:, 0:1], dus[0], dsp[:, 0:1], sigmoid_bwd=fused)
+        ds, dch2 = ops.duse_gate_bwd(s, ch2, sp[:, 1:2], dus[1], dsp[:, 1:2], sigmoid_bwd=fused)
+        dpre = dsp if fused else ops.act_bwd(dsp, sp, ACT_SIGMOID)
         ops.conv3d_wgrad(comb, None, dpre, [dadjw], [dadjb], k=3, side=_direct(rets[8], rets[9]))
         dcomb = ops.conv3d(dpre, None, [adjw], None, k=3, cout=1, transposed=True)
         ops.conv3d_wgrad(r, s, dcomb, [dsqw], [dsqb], k=1, side=_direct(rets[6], rets[7]))

@@ -908,12 +908,19 @@ def duse_gate(x, ch, sp, red=None):
     return u
 
 
-def duse_gate_bwd(x, ch, sp, du, dsp_out):
+def duse_gate_bwd_fuses(c):
+    """True when xh_duse_gate_bwd runs as ONE pass for c channels and can then also store dsp through the sigmoid's backward."""
+    return bool(L.load().xh_duse_gate_bwd_fuses(int(c)))
+
+
+def duse_gate_bwd(x, ch, sp, du, dsp_out, sigmoid_bwd=False):
+    """sigmoid_bwd (only where duse_gate_bwd_fuses(C)): dsp_out = (sum_c du x) * sp (1 - sp) instead of the plain sum."""
     n, c, d, h, w, bs = _vol(x)
     dx = new_like(x, (n, c, d, h, w))
     dch = zeros_f64(x.device, (n, c))
     L.check(L.load().xh_duse_gate_bwd(_stream(), _dt(x), _p(x), bs, _p(ch), _p(sp), _vol(sp)[5], _p(du), _vol(du)[5], _p(dx),
-                                      _vol(dx)[5], _p(dsp_out), _vol(dsp_out)[5], _p(dch), n, c, d * h * w), "xh_duse_gate_bwd")
+                                      _vol(dx)[5], _p(dsp_out), _vol(dsp_out)[5], _p(dch), n, c, d * h * w, int(bool(sigmoid_bwd))),
+            "xh_duse_gate_bwd")
     return dx, dch
 
 
