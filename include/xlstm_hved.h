@@ -271,6 +271,17 @@ int xh_poe_fwd(void* stream, int dtype, const void* feat, const float* keep, con
 /* dfeat = d/dfeat of (z, mu_stack, lv_stack); dmu_stack/dlv_stack may be NULL. */
 int xh_poe_bwd(void* stream, int dtype, const void* feat, const float* keep, const void* eps, const void* dz,
                const void* dmu_stack, const void* dlv_stack, void* dfeat, int N, int L, long long dhw, int mask_mu);
+/* The PoE of several latent levels in ONE launch per direction (the levels of a forward pass are independent): job i carries what
+ * xh_poe_fwd (bwd = 0: feat, keep, eps, z, mu_stack, lv_stack) / xh_poe_bwd (bwd = 1: + dz, dmu_stack, dlv_stack, dfeat) take for
+ * level i.  Job array in host memory, read during the call. */
+#define XH_POE_MAX 8
+typedef struct {
+  const void* feat; const float* keep; const void* eps;
+  void *z, *mu_stack, *lv_stack;
+  const void *dz, *dmu_stack, *dlv_stack; void* dfeat;
+  long long dhw; int N, L, mask_mu;
+} xh_poe_job;
+int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_poe_job* jobs);
 
 /* ------------------------------------------------------------------------------------------------
  * Channel attention glue.

@@ -43,6 +43,11 @@ class AttenJob(C.Structure):       # == xh_atten_job
                 ("E", C.c_int), ("K3", C.c_int)]
 
 
+class PoeJob(C.Structure):         # == xh_poe_job
+    _fields_ = [("feat", vp), ("keep", vp), ("eps", vp), ("z", vp), ("mu_stack", vp), ("lv_stack", vp), ("dz", vp), ("dmu_stack", vp),
+                ("dlv_stack", vp), ("dfeat", vp), ("dhw", ll), ("N", C.c_int), ("L", C.c_int), ("mask_mu", C.c_int)]
+
+
 class DuseJob(C.Structure):        # == xh_duse_job
     _fields_ = [("p", vp * 10), ("out", vp * 4), ("g", vp * 10), ("gout", vp * 4), ("C", C.c_int)]
 
@@ -96,6 +101,7 @@ SIGNATURES = {
     "xh_act_bwd": (I, [vp, I, vp, vp, vp, ll, I]),
     "xh_poe_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
     "xh_poe_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
+    "xh_poe_multi": (I, [vp, I, I, I, vp]),
     "xh_channel_pool_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, ll]),
     "xh_channel_pool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, I]),
     "xh_gate_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll]),

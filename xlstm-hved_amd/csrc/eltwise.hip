@@ -1210,9 +1210,9 @@ extern "C" int xh_act_bwd(void* stream, int dtype, const void* dy, const void* y
 // ---------------------------------------------------------------------------------------- product of experts
 #define POE_EPS 1e-8f
 template <typename T>
-__global__ __launch_bounds__(256) void poe_fwd_kernel(const T* feat, const float* keep, const T* eps, T* z, T* mu_stack,
-                                                     T* lv_stack, int L, long long dhw, long long total, int mask_mu) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+__device__ __forceinline__ void poe_fwd_body(const T* feat, const float* keep, const T* eps, T* z, T* mu_stack, T* lv_stack, int L,
+                                             long long dhw, long long total, int mask_mu, int bx, int gdx) {
+  for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gdx * 256) {
     const long long p = i % dhw;
     const int l = (int)((i / dhw) % L);
     const int n = (int)(i / (dhw * L));
@@ -1240,10 +1240,15 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(const T* feat, const float
   }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void poe_bwd_kernel(const T* feat, const float* keep, const T* eps, const T* dz,
-                                                     const T* dmu_stack, const T* dlv_stack, T* dfeat, int L, long long dhw,
-                                                     long long total, int mask_mu) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+__global__ __launch_bounds__(256) void poe_fwd_kernel(const T* feat, const float* keep, const T* eps, T* z, T* mu_stack,
+                                                     T* lv_stack, int L, long long dhw, long long total, int mask_mu) {
+  poe_fwd_body<T>(feat, keep, eps, z, mu_stack, lv_stack, L, dhw, total, mask_mu, blockIdx.x, gridDim.x);
+}
+template <typename T>
+__device__ __forceinline__ void poe_bwd_body(const T* feat, const float* keep, const T* eps, const T* dz, const T* dmu_stack,
+                                             const T* dlv_stack, T* dfeat, int L, long long dhw, long long total, int mask_mu, int bx,
+                                             int gdx) {
+  for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gdx * 256) {
     const long long p = i % dhw;
     const int l = (int)((i / dhw) % L);
     const int n = (int)(i / (dhw * L));
@@ -1279,6 +1284,45 @@ __global__ __launch_bounds__(256) void poe_bwd_kernel(const T* feat, const float
       stf(dfeat, fo + (long long)L * dhw, dlv);
     }
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void poe_bwd_kernel(const T* feat, const float* keep, const T* eps, const T* dz,
+                                                     const T* dmu_stack, const T* dlv_stack, T* dfeat, int L, long long dhw,
+                                                     long long total, int mask_mu) {
+  poe_bwd_body<T>(feat, keep, eps, dz, dmu_stack, dlv_stack, dfeat, L, dhw, total, mask_mu, blockIdx.x, gridDim.x);
+}
+// The PoE of every latent level of a forward pass (RA_HVED.py:573-597 runs it per level; the levels are independent functions of
+// the encoder outputs) in one launch per direction: four launches of 2 - 1 024 workgroups were four launch floors.
+struct PoeMulti {
+  int n, bwd;
+  int off[XH_POE_MAX + 1];
+  xh_poe_job j[XH_POE_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void poe_multi_kernel(const PoeMulti m) {
+  int pi = 0;
+  for (int k = 1; k < XH_POE_MAX; ++k)
+    if (k < m.n && (int)blockIdx.x >= m.off[k]) pi = k;
+  const xh_poe_job& j = m.j[pi];
+  const int bx = blockIdx.x - m.off[pi], gdx = m.off[pi + 1] - m.off[pi];
+  const long long total = (long long)j.N * j.L * j.dhw;
+  if (!m.bwd) poe_fwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (T*)j.z, (T*)j.mu_stack, (T*)j.lv_stack, j.L, j.dhw, total, j.mask_mu, bx, gdx);
+  else poe_bwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (const T*)j.dz, (const T*)j.dmu_stack, (const T*)j.dlv_stack, (T*)j.dfeat, j.L, j.dhw, total, j.mask_mu, bx, gdx);
+}
+extern "C" int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_poe_job* jobs) {
+  if (n <= 0 || n > XH_POE_MAX || !jobs) return XH_ERR_ARG;
+  PoeMulti m;
+  m.n = n; m.bwd = bwd ? 1 : 0; m.off[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    const xh_poe_job& j = jobs[i];
+    if (!j.feat || !j.keep || j.N <= 0 || j.L <= 0 || j.dhw <= 0) return XH_ERR_ARG;
+    if (bwd ? (!j.dz || !j.dfeat) : (!j.z || !j.mu_stack || !j.lv_stack)) return XH_ERR_ARG;
+    m.j[i] = j;
+    m.off[i + 1] = m.off[i] + flat_grid((long long)j.N * j.L * j.dhw);
+  }
+  for (int i = n; i < XH_POE_MAX; ++i) m.off[i + 1] = m.off[n];
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL(poe_multi_kernel<T>, dim3(m.off[n]), dim3(256), 0, (hipStream_t)stream, m););
+  return xh_launch_status();
 }
 extern "C" int xh_poe_fwd(void* stream, int dtype, const void* feat, const float* keep, const void* eps, void* z,
                           void* mu_stack, void* lv_stack, int N, int L, long long dhw, int mask_mu) {

@@ -415,6 +415,38 @@ class PoE(Function):
         return ops.poe_bwd(feat, keep, eps, g(dz), g(dmu), g(dlv), L_, mask_mu), None, None, None, None
 
 
+class PoEAll(Function):
+    """PoE of every latent level of a forward pass in ONE launch, and their backward in one (ops.poe_*_multi): the levels are
+    independent functions of the encoder outputs (RA_HVED.py:573-597 runs them in the level loop).  apply(keep, Ls, mask_mu,
+    nlev, *feats, *epss) with epss entries None for the posterior mean; returns (z_0, mu_0, lv_0, z_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, keep, Ls, mask_mu, nlev, *te):
+        feats = [t.contiguous() for t in te[:nlev]]
+        epss = list(te[nlev:])
+        outs = ops.poe_fwd_multi(feats, keep, epss, Ls, mask_mu)
+        ctx.save_for_backward(keep, *feats, *[e for e in epss if e is not None])
+        ctx.cfg = (tuple(Ls), mask_mu, nlev, [e is not None for e in epss])
+        ctx.set_materialize_grads(False)
+        return tuple(t for o in outs for t in o)
+
+    @staticmethod
+    def backward(ctx, *g):
+        Ls, mask_mu, nlev, has_eps = ctx.cfg
+        keep, *rest = ctx.saved_tensors
+        feats, it = rest[:nlev], iter(rest[nlev:])
+        epss = [next(it) if h else None for h in has_eps]
+        c = lambda t: None if t is None else t.contiguous()
+        dzs, dmus, dlvs = [], [], []
+        for l in range(nlev):
+            dz = g[3 * l]
+            if dz is None:
+                dz = torch.zeros((feats[l].shape[0], Ls[l]) + tuple(feats[l].shape[2:]), dtype=feats[l].dtype, device=feats[l].device)
+            dzs.append(c(dz)); dmus.append(c(g[3 * l + 1])); dlvs.append(c(g[3 * l + 2]))
+        dfeats = ops.poe_bwd_multi(feats, keep, epss, dzs, dmus, dlvs, Ls, mask_mu)
+        return (None, None, None, None, *dfeats, *([None] * nlev))
+
+
 class ChannelPool2(Function):
     """[ChannelPool(seg_x), ChannelPool(enc_x)] -> 4 channels (buildingblocks.py:279-282)."""
 

@@ -373,12 +373,17 @@ class AbstractFusion3DUNet(nn.Module):
         # coarse ones on side streams inside the captured graph was measured SLOWER (5.96 -> 6.93 ms per step, DESIGN.md
         # section 7) and the switch has been removed; they run back to back on the caller's stream.
         outs = [None] * len(feat_list)
-        for level, feat in enumerate(feat_list):
-            L_ = self.MVAE_latents[level]
-            eps = None
-            if not valid:
-                eps = noise[level] if noise is not None else eps_list[level].to(device=x.device, dtype=x.dtype).contiguous()
-            z, mu, lv = Fn.PoE.apply(feat, keep, eps, L_, bool(instance_missing))
+        nlev = len(feat_list)
+        epss = [None] * nlev
+        if not valid:
+            epss = [noise[l] if noise is not None else eps_list[l].to(device=x.device, dtype=x.dtype).contiguous() for l in range(nlev)]
+        # the PoE of all levels in one launch (they depend on the encoder outputs only)
+        if nlev <= ops.POE_MAX:
+            zml = Fn.PoEAll.apply(keep, tuple(self.MVAE_latents[:nlev]), bool(instance_missing), nlev, *feat_list, *epss)
+        else:
+            zml = [t for l in range(nlev) for t in Fn.PoE.apply(feat_list[l], keep, epss[l], self.MVAE_latents[l], bool(instance_missing))]
+        for level in range(nlev):
+            z, mu, lv = zml[3 * level:3 * level + 3]
             z = self.VU_blocks[level][0](z, up2x=True)                                      # RA_HVED.py:599-601 (conv block + 2x upsampling)
             z = self.conv_blocks[level](z)                                                  # RA_HVED.py:603
             outs[level] = (z, mu, lv)

@@ -785,6 +785,39 @@ def poe_bwd(feat, keep, eps, dz, dmu, dlv, L_, mask_mu):
     return dfeat
 
 
+POE_MAX = 8
+
+
+def poe_fwd_multi(feats, keep, epss, Ls, mask_mu):
+    """poe_fwd for several latent levels in one launch (xh_poe_multi); returns [(z, mu, lv)] per level."""
+    jobs = (L.PoeJob * len(feats))()
+    outs, keepalive = [], []
+    for j, feat, eps, L_ in zip(jobs, feats, epss, Ls):
+        n, c, d, h, w, _ = _vol(feat)
+        z = new_like(feat, (n, L_, d, h, w))
+        mu = new_like(feat, (n, 5, L_, d, h, w))
+        lv = new_like(feat, (n, 5, L_, d, h, w))
+        j.feat, j.keep, j.eps, j.z, j.mu_stack, j.lv_stack = _p(feat), _p(keep), _p(eps), _p(z), _p(mu), _p(lv)
+        j.dhw, j.N, j.L, j.mask_mu = d * h * w, n, L_, int(mask_mu)
+        outs.append((z, mu, lv))
+    L.check(L.load().xh_poe_multi(_stream(), _dt(feats[0]), 0, len(feats), C.cast(jobs, C.c_void_p)), "xh_poe_multi")
+    return outs
+
+
+def poe_bwd_multi(feats, keep, epss, dzs, dmus, dlvs, Ls, mask_mu):
+    """poe_bwd for several latent levels in one launch; returns [dfeat] per level."""
+    jobs = (L.PoeJob * len(feats))()
+    outs = []
+    for j, feat, eps, dz, dmu, dlv, L_ in zip(jobs, feats, epss, dzs, dmus, dlvs, Ls):
+        n, c, d, h, w, _ = _vol(feat)
+        dfeat = torch.empty_like(feat)
+        j.feat, j.keep, j.eps, j.dz, j.dmu_stack, j.dlv_stack, j.dfeat = _p(feat), _p(keep), _p(eps), _p(dz), _p(dmu), _p(dlv), _p(dfeat)
+        j.dhw, j.N, j.L, j.mask_mu = d * h * w, n, L_, int(mask_mu)
+        outs.append(dfeat)
+    L.check(L.load().xh_poe_multi(_stream(), _dt(feats[0]), 1, len(feats), C.cast(jobs, C.c_void_p)), "xh_poe_multi")
+    return outs
+
+
 # ----------------------------------------------------------------------------------------------- attention glue
 def channel_pool(x, out):
     """out (a 2-channel slice) = [max_c x, mean_c x]."""
