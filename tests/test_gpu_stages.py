@@ -468,3 +468,28 @@ def test_duse_gate_backward_in_one_pass_vs_formulas(c, sp_shape, dtype):
     for got in ((dx1, dp1, dch1), (dx0, dp0, dch0)):
         assert l2_err(got[0], dx_r.float()) < tol and l2_err(got[1], dp_r.float()) < tol
         assert (got[2] - dch_r).abs().max().item() <= 1e-4 * dch_r.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_poe_of_all_levels_in_one_launch_equals_the_per_level_launches(dtype):
+    """xh_poe_multi (functional.PoEAll): the PoE / reparameterisation of several latent levels and its backward, bit for bit what
+    xh_poe_fwd / xh_poe_bwd give level by level -- with and without noise, with a dropped modality, batch 2."""
+    torch.manual_seed(17)
+    n = 2
+    shapes = [(1, (8, 8, 8)), (2, (4, 6, 8)), (4, (4, 4, 4)), (8, (2, 2, 2))]
+    feats = [torch.randn((n, 8 * L_) + sp, device=DEV).to(dtype) for L_, sp in shapes]
+    keep = torch.tensor([[1.0, 0.0, 1.0, 1.0], [1.0, 1.0, 1.0, 0.0]], device=DEV)
+    Ls = [L_ for L_, _ in shapes]
+    for with_eps in (True, False):
+        epss = [torch.randn((n, L_) + sp, device=DEV).to(dtype) if with_eps else None for L_, sp in shapes]
+        for mask_mu in (False, True):
+            multi = X.ops.poe_fwd_multi(feats, keep, epss, Ls, mask_mu)
+            dzs = [torch.randn_like(o[0]) for o in multi]
+            dmus = [torch.randn_like(o[1]) for o in multi]
+            dlvs = [torch.randn_like(o[2]) for o in multi]
+            dmulti = X.ops.poe_bwd_multi(feats, keep, epss, dzs, dmus, dlvs, Ls, mask_mu)
+            for l in range(len(shapes)):
+                single = X.ops.poe_fwd(feats[l], keep, epss[l], Ls[l], mask_mu)
+                for a, b in zip(multi[l], single):
+                    assert torch.equal(a, b)
+                assert torch.equal(dmulti[l], X.ops.poe_bwd(feats[l], keep, epss[l], dzs[l], dmus[l], dlvs[l], Ls[l], mask_mu))
