@@ -18,8 +18,9 @@
 //    LDS chunks; out-of-volume chunks get scale = shift = 0 (norm path) or a zero byte selector (copy path): no guarded
 //    loads, every global load of a workgroup is in flight before the first one is used;
 //  * the epilogue variant (none / output moments / norm-backward sums) and the input transform are template arguments.
-// One workgroup (4 waves) = an 8 x 8 x 32 (D x H x W) block of outputs of ONE output-channel quad; more input channels are
-// walked quad by quad through the same 28.8 KB LDS tile (4-5 workgroups per CU hide each other's staging phase).
+// One workgroup (4 waves) = a TD x 8 x 32 (D x H x W) block of outputs of ONE output-channel quad, TD = 8 (4 / 2 on launches that
+// would leave most CUs without a workgroup, see TD below); more input channels are walked quad by quad through the same LDS
+// tile (28.8 KB at TD = 8; 4-5 workgroups per CU hide each other's staging phase).
 //
 // Measured on MI355X (tools/microbench_big.py --abl, 16 -> 16 g4 @128^3 forward without statistics, 39.5 us): staging
 // 23.7 us, matrix phase + epilogue 13.2 us, launch 2.6 us; statistics + fan-in add 10 us.  SQ counters: the SIMDs' issue slots
