@@ -707,3 +707,37 @@ def test_gradient_slots_equal_autograd_fan_in(dtype):
     worst = max((ga[k] - gb[k]).abs().max().item() for k in gb) / scale
     print(f"gradient slots vs autograd fan-in ({dtype}): worst parameter-gradient difference {worst:.2e} of the largest gradient")
     assert worst < 2e-5
+
+
+def test_two_backward_passes_over_one_forward_retain_graph():
+    """Two losses sharing ONE generator forward, backward()ed one after the other with retain_graph=True, must accumulate the same
+    parameter gradients as one backward of their sum -- including the parameters behind the composed tensors (AttenModule2
+    gates, DuSE blocks, the seg head), whose step-long gradient buffers (functional.ComposeAll) must not hand the first pass's
+    sums to the second pass again.  A third pass exercises the refill of a spent buffer."""
+    torch.manual_seed(33)
+    x = torch.rand(1, 4, 32, 32, 32)
+    eps = [torch.randn(1, 2 ** l, 16 >> l, 16 >> l, 16 >> l) for l in range(4)]
+    res = []
+    for split in (False, True):
+        m = _model(True)
+        seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps)
+        l1 = seg.float().mean() + sum(a_.float().mean() for a_ in mu)
+        l2 = rec[0].float().mean() + sum(b_.float().mean() for b_ in lv)
+        l3 = 0.5 * (seg.float() ** 2).mean()
+        if split:
+            l1.backward(retain_graph=True)
+            l2.backward(retain_graph=True)
+            l3.backward()
+        else:
+            (l1 + l2 + l3).backward()
+        torch.cuda.synchronize()
+        res.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    ga, gb = res
+    assert ga.keys() == gb.keys()
+    scale = max(v.abs().max().item() for v in ga.values())
+    worst_k, worst = max(((k, (ga[k] - gb[k]).abs().max().item() / scale) for k in ga), key=lambda t: t[1])
+    composed = [k for k in ga if "atten_module" in k or "dusfe" in k or k.startswith("final_conv") or "sfinals" in k]
+    assert composed, "the test must cover the composed tensors' parameters"
+    cw = max((ga[k] - gb[k]).abs().max().item() / scale for k in composed)
+    print(f"retain_graph: worst parameter-gradient difference {worst:.2e} ({worst_k}); composed-tensor parameters {cw:.2e}")
+    assert worst < 5e-5, (worst_k, worst)

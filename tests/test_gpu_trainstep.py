@@ -267,3 +267,48 @@ def test_shared_discriminator_pass_equals_recomputed_pass(dtype):
     assert a[0] == b[0] and a[2] == b[2] and abs(a[1] - b[1]) <= 1e-6 * abs(b[1]), (a[:3], b[:3])
     assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
     assert (a[4] - b[4]).abs().max().item() <= 2e-3 * b[4].abs().max().item()
+
+
+def test_data_parallel_train_step_through_a_one_rank_rccl_group():
+    """TrainStep(group=...) on a real `nccl` (RCCL) communicator of one rank: the step captured as TWO hipGraphs, the generator
+    bucket's all-reduce on the communication stream between them, the discriminator bucket's after the second -- must give the
+    single-graph step's losses and gradients (a mean over one rank is the identity)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["XH_ROOT"]); sys.path.insert(0, os.path.join(os.environ["XH_ROOT"], "tests")); sys.path.insert(0, os.path.join(os.environ["XH_ROOT"], "oracle"))
+import xlstm_hved_amd as X
+import disc_common as DC
+from gpu_common import load
+from xlstm_hved_amd.train_step import TrainStep
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+torch.manual_seed(7)
+S = 32
+x = torch.rand(1, 4, S, S, S, device=dev); mask = (torch.rand(1, 3, S, S, S, device=dev) > 0.7).float()
+eps = [[torch.randn(1, 2 ** l, S >> (l + 1), S >> (l + 1), S >> (l + 1), device=dev) for l in range(4)] for _ in range(2)]
+res = []
+for grp in (None, dist.group.WORLD):
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS); m.load_state_dict(load("weights_seed1")); m = m.to(dev).train()
+    d = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2]); d.load_state_dict(DC.seeded_disc_state(4)); d = d.to(dev)
+    ts = TrainStep(m, d, storage=torch.bfloat16, group=grp)
+    ts.capture(x, mask, eps_lists=eps)
+    assert (ts._graph2 is not None) == (grp is not None)
+    for sub in ([3], [6]):
+        parts = ts.replay(x, mask, sub, eps_lists=eps, update=False)
+    torch.cuda.synchronize()
+    res.append((parts["loss"].item(), parts["loss_d"].item(), ts.grads.flat.clone(), ts.grads_d.flat.clone()))
+(l0, d0, g0, gd0), (l1, d1, g1, gd1) = res
+assert abs(l0 - l1) <= 1e-5 * max(1, abs(l0)) and abs(d0 - d1) <= 1e-5 * max(1, abs(d0)), (l0, l1, d0, d1)
+eg = ((g0 - g1).norm() / g0.norm()).item(); ed = ((gd0 - gd1).norm() / gd0.norm()).item()
+assert eg < 1e-3 and ed < 1e-3, (eg, ed)          # the order of fp32 atomics only
+assert g0.abs().max() > 0 and gd0.abs().max() > 0
+dist.destroy_process_group()
+print("TS_RCCL_OK", eg, ed)
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29566", XH_ROOT=root))
+    assert r.returncode == 0 and "TS_RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])

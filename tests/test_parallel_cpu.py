@@ -72,3 +72,63 @@ def test_flat_grad_allreduce_two_ranks():
         assert torch.allclose(wg2, torch.full((3, 5), 3.0)) and torch.equal(dead2, torch.zeros(4))
     assert torch.allclose(res[0][4], torch.full((2,), 0.5))     # rank 0: (1 + 0) / 2
     assert res[1][4] is None                                     # rank 1 had no gradient; its zeros were counted
+
+
+def _ts_worker(rank, world, port, q):
+    """TrainStep's data-parallel plumbing with the two halves of the step stubbed (no HIP needed): what is under test is which
+    bucket is reduced when, the mean over ranks, the re-attachment of gradients and the consistent skip decision."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xlstm_hved_amd.train_step import TrainStep
+    torch.manual_seed(0)
+    gen, disc = torch.nn.Linear(4, 3), torch.nn.Linear(3, 2)
+    opt_g, opt_d = torch.optim.SGD(gen.parameters(), lr=1.0), torch.optim.SGD(disc.parameters(), lr=1.0)
+    ts = TrainStep(gen, disc, opt_g, opt_d, storage=torch.float16, group=dist.group.WORLD)
+    assert ts.dp and ts.scaling and ts.loss_scale == 65536.0
+    order = []
+
+    def gen_half(x, mask, subset, eps_lists=None):
+        ts.grads.zero(); ts.grads_d.zero()
+        ts.grads.flat.fill_(float(rank + 1))                       # "generator backward" of this rank
+        if subset == "overflow" and rank == 1:
+            ts.grads.flat[0] = float("inf")                          # one rank overflows: every rank must skip
+        order.append("g")
+        return {"loss": torch.zeros(())}, None
+
+    def disc_half(parts, carry):
+        assert torch.allclose(ts.grads.flat[1:], torch.full_like(ts.grads.flat[1:], 1.5))     # already reduced (CPU: synchronous)
+        ts.grads_d.flat.fill_(10.0 * (rank + 1))
+        order.append("d")
+        parts["loss_d"] = torch.zeros(())
+        return parts
+    ts.compute_generator, ts.compute_discriminator = gen_half, disc_half
+    w0, wd0 = gen.weight.detach().clone(), disc.weight.detach().clone()
+    parts = ts.step(None, None, "plain")
+    g_after, d_after = ts.grads.flat.clone(), ts.grads_d.flat.clone()
+    w1, wd1 = gen.weight.detach().clone(), disc.weight.detach().clone()
+    parts2 = ts.step(None, None, "overflow")
+    q.put((rank, order, g_after.numpy().copy(), d_after.numpy().copy(), (w0 - w1).numpy().copy(), (wd0 - wd1).numpy().copy(),
+           parts2.get("skipped"), ts.loss_scale, (gen.weight.detach() - w1).abs().max().item(),
+           (disc.weight.detach() - wd1).abs().max().item()))
+    dist.destroy_process_group()
+
+
+def test_train_step_buckets_all_reduced_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ts_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, order, g, d, dw, dwd, skipped, scale, gen_moved, disc_moved in res:
+        assert order == ["g", "d", "g", "d"]
+        assert (g == 1.5).all() and (d == 15.0).all()               # means of (1, 2) and (10, 20) on BOTH ranks
+        assert (abs(dw - 1.5) < 1e-6).all() and (abs(dwd - 15.0) < 1e-6).all()     # SGD lr 1: the step applied the reduced gradients
+        # the overflow of rank 1 reaches rank 0 through the sum: both skip the generator, neither skips the discriminator,
+        # one back-off of the loss scale
+        assert skipped == ["generator"] and scale == 32768.0
+        assert gen_moved == 0.0 and disc_moved > 0.0

@@ -774,7 +774,11 @@ class ComposeAll(Function):
             outs += [new(wf.shape[0], ws.shape[1], 1, 1, 1), new(wf.shape[0])]
         # (the gradient buffers below are cleared by the same launch)
         sizes = [(o.numel() + 15) // 16 * 16 for o in outs]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
+        # two copies of the gradient buffers (both cleared here): a SECOND backward over this forward (retain_graph=True, two
+        # losses sharing one generator forward) must not see the first pass's sums again, so backward() moves the composed
+        # tensors on to the clean copy once it has consumed the first (a third pass pays one fill)
+        total = sum(sizes)
+        flat = torch.empty(2 * total, dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
         ops.compose_multi(False, *ComposeAll._jobs(plan, params, outs, False), zero=flat)
         ctx.plan, ctx.params = plan, params
         ctx.save_for_backward(*params)
@@ -787,11 +791,16 @@ class ComposeAll(Function):
         # arena: a second forward before this one's backward would be handed the same arena slices.
         ctx.gbufs = None
         if flat is not None:
-            ctx.gbufs, off = [], 0
+            import weakref
+            ctx.gsets, ctx.gflat, ctx.gcur, ctx.passes = [[], []], (flat[:total], flat[total:]), 0, 0
+            off = 0
             for o, n_ in zip(outs, sizes):
-                o._xh_gbuf = flat[off:off + o.numel()].view(o.shape)
-                ctx.gbufs.append(o._xh_gbuf)
+                for half in (0, 1):
+                    ctx.gsets[half].append(flat[half * total + off:half * total + off + o.numel()].view(o.shape))
+                o._xh_gbuf = ctx.gsets[0][-1]
                 off += n_
+            ctx.gbufs = ctx.gsets[0]
+            ctx.out_refs = [weakref.ref(o) for o in outs]      # (weak: the outputs own this node)
         return tuple(outs)
 
     @staticmethod
@@ -804,6 +813,16 @@ class ComposeAll(Function):
         gouts = [buf if g is None else buf.add_(g.reshape(buf.shape)) for g, buf in zip(gouts, ctx.gbufs)]
         grads, rets = _targets(ctx.params)
         ops.compose_multi(True, *ComposeAll._jobs(ctx.plan, params, None, True, grads=grads, gouts=gouts))
+        # this pass's sums are spent: a later backward over the same forward accumulates into the other (clean) copy
+        ctx.passes += 1
+        ctx.gcur ^= 1
+        if ctx.passes >= 2:
+            ctx.gflat[ctx.gcur].zero_()                      # third and later passes: the copy being returned to is dirty
+        ctx.gbufs = ctx.gsets[ctx.gcur]
+        for r, buf in zip(ctx.out_refs, ctx.gbufs):
+            o = r()
+            if o is not None:
+                o._xh_gbuf = buf
         return (None, *rets)
 
 

@@ -159,13 +159,26 @@ def zeros_red(t, n, c):
 
 # Statistics fan-in workspaces (xh_conv_ptrs.fan, csrc/fanin.h): the library owns no device memory, so the zero-initialised
 # block a statistics-producing launch sums through is handed in here -- one per (device, stream): launches ordered on a
-# stream never overlap and share it, launches on different streams get different blocks.  While a stream is being captured
-# the device's capture block is used (a captured step is one chain of launches; a block must exist before the capture starts,
-# which any eager launch on the device guarantees -- otherwise the launch simply keeps its direct atomics).
+# stream never overlap and share it, launches on different streams get different blocks, every capture gets its own.
 _FAN = {}
 
 
+def begin_capture_scope():
+    """Call right before a stream capture starts: the capture gets a statistics fan-in block of its own (fan_block).  Without it
+    a capture is recognised by the first launch that finds the stream capturing after an eager launch."""
+    for per in _FAN.values():
+        per["in_capture"] = False
+
+
 def fan_block(device):
+    """(pointer, bytes) of the zero-initialised fan-in block for a launch on the current stream (csrc/fanin.h: one block per
+    chain of launches that can be in flight at the same time, every launch leaves it zero).
+
+    Eager launches: one block per (device, stream).  Captured launches: one block per CAPTURE -- two captured graphs may be
+    replayed on different streams at once (bench's forward graph next to TrainStep's, a replay overlapped with a communication
+    stream).  A capture cannot allocate-and-zero without putting a fill into the graph, so blocks are taken from a small stock
+    of pre-zeroed spares that eager launches keep topped up; they are never freed (graphs hold their addresses).  No spare
+    left: (None, 0) -- the launch keeps its direct atomics, which is slower but exact."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     per = _FAN.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
@@ -173,9 +186,19 @@ def fan_block(device):
         if capturing:
             return None, 0
         nbytes = int(L.load().xh_fanin_bytes())
-        per = _FAN[key] = {"bytes": nbytes, "capture": torch.zeros(nbytes, dtype=torch.uint8, device=device), "streams": {}}
+        per = _FAN[key] = {"bytes": nbytes, "streams": {}, "spares": [], "used": [], "cap": None, "in_capture": False}
     if capturing:
-        return per["capture"].data_ptr(), per["bytes"]
+        if not per["in_capture"] or per["cap"] is None:
+            per["in_capture"] = True
+            per["cap"] = per["spares"].pop() if per["spares"] else None
+            if per["cap"] is not None:
+                per["used"].append(per["cap"])
+        if per["cap"] is None:
+            return None, 0
+        return per["cap"].data_ptr(), per["bytes"]
+    per["in_capture"] = False
+    while len(per["spares"]) < 4:
+        per["spares"].append(torch.zeros(per["bytes"], dtype=torch.uint8, device=device))
     sid = torch.cuda.current_stream(device).cuda_stream
     blk = per["streams"].get(sid)
     if blk is None:
@@ -500,6 +523,12 @@ def set_wgrad_defer(enabled):
     _WG["defer"] = bool(enabled)
 
 
+def drop_deferred_wgrads():
+    """Forgets the queued weight-gradient calls without launching them (error paths: a backward that raised, a failed capture)."""
+    _WG["deferred"] = []
+    _WG["pending"] = []
+
+
 def _batch_call(calls):
     n = len(calls)
     descs = (C.POINTER(L.ConvDesc) * n)(*[C.pointer(c[0]) for c in calls])
@@ -694,7 +723,9 @@ def maxpool2(x):
 def maxpool2_bwd(x, dy, acc=None):
     n, c, d, h, w, _ = _vol(x)
     x, dy = x.contiguous(), dy.contiguous()
-    dx = acc if (acc is not None and acc.is_contiguous()) else torch.empty_like(x)
+    if acc is not None and (not acc.is_contiguous() or acc.shape != x.shape or acc.dtype != x.dtype):
+        raise ValueError("maxpool2_bwd: acc must be a contiguous tensor of x's shape and type")   # (a fresh dx would drop this share)
+    dx = acc if acc is not None else torch.empty_like(x)
     L.check(L.load().xh_maxpool2_bwd(_stream(), _dt(x), _p(x), _p(dy), _p(dx), n * c, d, h, w, int(dx is acc)), "xh_maxpool2_bwd")
     return dx
 

@@ -17,6 +17,17 @@ What is specific to this implementation:
     captured hipGraph follows every update;
   * the modality subset (train.py:222-223 draws a new one every step) enters as a DEVICE mask (N, 4) that `step()` /
     `replay()` overwrite before the launch: ONE captured hipGraph serves all 15 subsets (`capture()`);
+  * data parallel (`group=`): one process per GPU, patches sharded by data (the reference only has nn.DataParallel,
+    train.py:148-151).  The generator's flat gradient bucket (1.69 MB fp32) is all-reduced right after the generator's
+    backward ON A COMMUNICATION STREAM, so the collective runs under the discriminator passes; the discriminator's bucket
+    (44.3 MB fp32) is all-reduced after its backward; both before the optimizers step.  With a group the captured step is TWO
+    hipGraphs split at that point (one memory pool), the collectives are issued eagerly between / after them;
+  * GradScaler bookkeeping differs from train.py:265-285 in one documented way: the reference calls scaler.update() between
+    the generator's and the discriminator's pass, so after a generator overflow its discriminator loss is already scaled by
+    the halved scale.  Here both backward passes of a step use the scale the step started with (they may live in one captured
+    graph), so a generator overflow usually overflows the discriminator too; when BOTH optimizers are skipped in one step
+    the scale is backed off ONCE, which is what the reference ends up with.  `reset_scaler()` re-creates the scaler state
+    like the reference does at every epoch (train.py:207);
   * the Discriminator (RA_HVED.py:204-236; train.py:146 builds it with ks=4) is xlstm_hved_amd.Discriminator
     (csrc/dconv.hip: channels-last implicit-GEMM convolutions on the matrix cores) in every storage mode; its activations
     are 16-bit like under the reference's autocast, so with fp32 storage it takes its input in fp16 (disc.py).
@@ -39,8 +50,14 @@ def subset_rows(device):
 class TrainStep:
     def __init__(self, model, disc, optimizer=None, optimizer_d=None, alpha=0.1, beta=0.2, storage=torch.bfloat16,
                  loss_scale=None, shared_encoder=True, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
-                 share_disc_pass=True, defer_wgrads=True):
+                 share_disc_pass=True, defer_wgrads=True, group=None, world_size=None):
+        """group: a torch.distributed process group (or True for the default group) -> data-parallel step, see the module
+        docstring; world_size: its size if it cannot be asked (tests)."""
         self.model, self.disc = model, disc
+        self.group = None if group is True else group
+        self.dp = group is not None
+        self.world = int(world_size) if world_size is not None else None
+        self._comm = None                                    # communication stream (device runs only)
         self.defer_wgrads = bool(defer_wgrads)               # the generator's weight gradients in one end-of-backward batch
         self.optimizer, self.optimizer_d = optimizer, optimizer_d
         self.alpha, self.beta = float(alpha), float(beta)
@@ -54,6 +71,7 @@ class TrainStep:
         # GradScaler's state (torch/amp/grad_scaler.py semantics; the reference re-creates it per epoch at 65536, train.py:207)
         init = float(loss_scale if loss_scale is not None else (65536.0 if storage == torch.float16 else 1.0))
         self.scaling = init != 1.0
+        self._init_scale = init
         self._scale = torch.full((1,), init, dtype=torch.float32, device=dev)      # device scalar: captured graphs follow it
         self._inv_scale = torch.full((1,), 1.0 / init, dtype=torch.float32, device=dev)
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
@@ -68,6 +86,11 @@ class TrainStep:
     def set_loss_scale(self, v):
         self._scale.fill_(float(v))
         self._inv_scale.fill_(1.0 / float(v))
+
+    def reset_scaler(self, loss_scale=None):
+        """A fresh GradScaler: the reference constructs one per epoch (train.py:207).  The growth counter restarts too."""
+        self.set_loss_scale(self._init_scale if loss_scale is None else loss_scale)
+        self._clean_steps = 0
 
     # ------------------------------------------------------------------------------------------------
     def _disc(self, t):
@@ -140,31 +163,96 @@ class TrainStep:
         return self.alpha * (loss_d_fake + loss_d_real) * 0.5                    # train.py:280
 
     # ------------------------------------------------------------------------------------------------
-    def compute(self, x, mask, subset, eps_lists=None):
-        """Both backward passes of the step (no optimizer): generator gradients in self.grads, discriminator gradients
-        in self.grads_d (unscaled fp32).  Capturable into a hipGraph when the inputs are device resident and `subset` is a
-        device mask (keep_mask()): nothing of the subset or of the loss scale is baked into the capture."""
-        from .disc import pack_scope
+    def compute_generator(self, x, mask, subset, eps_lists=None):
+        """First half of the step: both generator forwards, the loss epilogues, the frozen discriminator's pass on the fake sample
+        and the generator's backward.  Leaves the generator's (unscaled fp32) gradients in self.grads and returns
+        (parts, carry) -- `carry` is what compute_discriminator() needs.  Call inside a disc.pack_scope()."""
         self.grads.zero()
         self.grads_d.zero()
+        loss, parts, carry = self.generator_forward(x, mask, subset, eps_lists)
+        # the generator's weight gradients go straight into self.grads and nothing reads them before the join: collected
+        # during backward and issued together (xh_conv3d_wgrad_batch: 13 launches instead of one per convolution)
+        was = ops._WG["defer"]
+        ops.set_wgrad_defer(self.defer_wgrads or was)
+        try:
+            (loss * self._scale[0] if self.scaling else loss).backward()
+            ops.join_wgrad_stream()
+        except BaseException:
+            # a failed backward (or a failed stream capture) leaves a partial batch queued: launching it now would raise a
+            # second error that masks the first -- drop it
+            ops.drop_deferred_wgrads()
+            raise
+        finally:
+            ops._WG["defer"] = was
+        if self.scaling:
+            self.grads.flat.mul_(self._inv_scale)
+        parts["loss"] = loss.detach()
+        return parts, carry
+
+    def compute_discriminator(self, parts, carry):
+        """Second half: the discriminator's loss on (fake.detach(), real) and its backward; gradients in self.grads_d."""
+        fake, real, f_out, share = carry
+        loss_d = self.discriminator_forward(fake, real, share)
+        (loss_d * self._scale[0] if self.scaling else loss_d).backward()
+        if self.scaling:
+            self.grads_d.flat.mul_(self._inv_scale)
+        parts["loss_d"], parts["f_out"] = loss_d.detach(), f_out
+        return parts
+
+    # ---- the data-parallel exchange (SURVEY 8(e)): two flat buckets, two collectives ------------------------------
+    def _world(self):
+        if self.world is None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(self.group)
+        return self.world
+
+    def reduce_generator(self):
+        """All-reduce (mean) of the generator's bucket, issued behind everything queued on the current stream but ON THE
+        COMMUNICATION STREAM: the discriminator passes that follow do not wait for it (join_reductions does)."""
+        if not self.dp:
+            return
+        flat = self.grads.flat
+        if not self.grads.check():
+            self.grads.attach()
+        if flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(flat.device)
+            self._comm.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._comm):
+                self._all_reduce_mean(flat)
+        else:
+            self._all_reduce_mean(flat)
+
+    def reduce_discriminator(self):
+        """Joins the generator's collective, then all-reduces (mean) the discriminator's bucket on the current stream."""
+        if not self.dp:
+            return
+        self.join_reductions()
+        if not self.grads_d.check():
+            self.grads_d.attach()
+        self._all_reduce_mean(self.grads_d.flat)
+
+    def join_reductions(self):
+        if self._comm is not None:
+            torch.cuda.current_stream(self.grads.flat.device).wait_stream(self._comm)
+
+    def _all_reduce_mean(self, flat):
+        import torch.distributed as dist
+        dist.all_reduce(flat, group=self.group)
+        flat.div_(self._world())
+
+    def compute(self, x, mask, subset, eps_lists=None):
+        """Both backward passes of the step (no optimizer): generator gradients in self.grads, discriminator gradients
+        in self.grads_d (unscaled fp32; averaged over the ranks of `group` when there is one).  Without a group it is
+        capturable into ONE hipGraph when the inputs are device resident and `subset` is a device mask (keep_mask()): nothing of
+        the subset or of the loss scale is baked into the capture.  With a group, capture() records the two halves separately
+        and issues the collectives between / after them."""
+        from .disc import pack_scope
         with pack_scope():                                   # the discriminator's weight images are built once for both passes
-            loss, parts, (fake, real, f_out, share) = self.generator_forward(x, mask, subset, eps_lists)
-            # the generator's weight gradients go straight into self.grads and nothing reads them before the join: collected
-            # during backward and issued together (xh_conv3d_wgrad_batch: 13 launches instead of one per convolution)
-            was = ops._WG["defer"]
-            ops.set_wgrad_defer(self.defer_wgrads or was)
-            try:
-                (loss * self._scale[0] if self.scaling else loss).backward()
-                ops.join_wgrad_stream()
-            finally:
-                ops.set_wgrad_defer(was)
-            if self.scaling:
-                self.grads.flat.mul_(self._inv_scale)
-            loss_d = self.discriminator_forward(fake, real, share)
-            (loss_d * self._scale[0] if self.scaling else loss_d).backward()
-            if self.scaling:
-                self.grads_d.flat.mul_(self._inv_scale)
-        parts["loss"], parts["loss_d"], parts["f_out"] = loss.detach(), loss_d.detach(), f_out
+            parts, carry = self.compute_generator(x, mask, subset, eps_lists)
+            self.reduce_generator()                          # runs under the discriminator passes
+            parts = self.compute_discriminator(parts, carry)
+            self.reduce_discriminator()
         return parts
 
     def check_finite(self):
@@ -184,7 +272,11 @@ class TrainStep:
         if self.scaling:
             # the reference calls scaler.update() after each scaler.step(): a skipped step backs the scale off once, a clean
             # step counts towards growth.  The second update() of a step sees the found-inf of the discriminator's pass only.
-            for fin in ok:
+            if not any(ok):
+                ok_books = [False]       # both skipped in one step: ONE back-off (see the module docstring)
+            else:
+                ok_books = ok
+            for fin in ok_books:
                 if not fin:
                     self.set_loss_scale(self.loss_scale * self.backoff_factor)
                     self._clean_steps = 0
@@ -205,7 +297,10 @@ class TrainStep:
     def capture(self, x, mask, eps_lists=None, warmup=2):
         """Captures compute() ONCE into a hipGraph on static copies of (x, mask, subset mask[, eps]); `replay()` then serves
         every subset: it overwrites the static buffers and launches the graph (train.py:222-225 draws a new subset per
-        step -- no re-capture, no per-subset graphs)."""
+        step -- no re-capture, no per-subset graphs).  Data parallel (`group`): TWO graphs sharing one memory pool, split
+        after the generator's backward; replay() issues the generator bucket's all-reduce on the communication stream between
+        them and the discriminator bucket's after the second."""
+        from .disc import pack_scope
         self._sx, self._smask = x.detach().clone(), mask.detach().clone()
         self._skeep = self.keep_mask([14], x.shape[0])
         self._seps = None if eps_lists is None else [[e.detach().clone() for e in el] for el in eps_lists]
@@ -216,13 +311,24 @@ class TrainStep:
                 self.compute(self._sx, self._smask, self._skeep, self._seps)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        mode = "thread_local" if self.dp else "global"       # RCCL's watchdog thread may query events while this thread captures
+        ops.begin_capture_scope()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._parts = self.compute(self._sx, self._smask, self._skeep, self._seps)
+        self._graph2 = None
+        if not self.dp:
+            with torch.cuda.graph(self._graph, capture_error_mode=mode):
+                self._parts = self.compute(self._sx, self._smask, self._skeep, self._seps)
+            return self
+        with pack_scope():
+            with torch.cuda.graph(self._graph, capture_error_mode=mode):
+                parts, carry = self.compute_generator(self._sx, self._smask, self._skeep, self._seps)
+            self._graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode=mode):
+                self._parts = self.compute_discriminator(parts, carry)
         return self
 
     def replay(self, x, mask, subset_index_list, eps_lists=None, update=True):
-        """One training step through the captured graph (capture() first).  Returns the static `parts` tensors."""
+        """One training step through the captured graph(s) (capture() first).  Returns the static `parts` tensors."""
         if self._graph is None:
             raise RuntimeError("TrainStep.capture() has not been called")
         self._sx.copy_(x)
@@ -233,4 +339,8 @@ class TrainStep:
                 for d_, s_ in zip(dst_l, src_l):
                     d_.copy_(s_)
         self._graph.replay()
+        if self._graph2 is not None:
+            self.reduce_generator()                          # on the communication stream, under the second graph
+            self._graph2.replay()
+            self.reduce_discriminator()
         return self._update(dict(self._parts)) if update else dict(self._parts)
