@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--inner", type=int, default=0,
+                    help="passes per timed step (0 = sized so that the timed region lasts --min-timed-s; 1 = the plain K-step loop)")
+    ap.add_argument("--min-timed-s", type=float, default=2.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -124,7 +127,10 @@ def cpu_baseline(size, batch, budget_s=60.0, sweep=(8, 16, 32, 64)):
         used, t = size, run(size)
     sw = ", ".join(f"{c}: {v:.2f} s" for c, v in times.items())
     return {"value": batch * used ** 3 / t, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"one fwd+bwd step of {batch}x4x{used}^3 fp32 through oracle/xlstm_hved_oracle.py (torch "
+            "concurrent_with_gpu_legs": True,
+            "sample": f"(timed in a child process WHILE the GPU legs of this run were being driven from the same host: their "
+                      f"launch threads share the cores, run-to-run spread ~12 %) "
+                      f"one fwd+bwd step of {batch}x4x{used}^3 fp32 through oracle/xlstm_hved_oracle.py (torch "
                       f"{torch.__version__} CPU ops) on {cores} threads of {ncpu}: {t:.2f} s; thread sweep on the "
                       f"{batch}x4x{small}^3 step: {sw}"
                       + ("" if used == size else f"; the {size}^3 step was extrapolated to exceed {budget_s:.0f} s and was not run")}
@@ -264,9 +270,25 @@ def main():
     for _ in range(args.warmup):
         run()
     sync_all()
+    # Inner repeats: the driver's K may be small (20 steps = 0.08 s of GPU time, invisible to its utilisation sampler), so
+    # each of the K timed steps replays the pass `inner` times, sized from a short probe so that the timed region lasts
+    # >= --min-timed-s; ms_per_step and value are per PASS (one forward + backward [+ all-reduce]), inner_repeats is reported.
+    inner = max(1, args.inner)
+    if args.inner == 0:
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run()
+        sync_all()
+        probe = torch.tensor([(time.perf_counter() - t0) / 3.0], device=dev, dtype=torch.float64)
+        if use_dist:
+            import torch.distributed as dist
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)        # every rank must choose the same count
+        inner = max(1, min(1000, int(-(-args.min_timed_s // (probe.item() * max(args.steps, 1))))))
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run()
+        for _ in range(inner):
+            run()
     sync_all()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -274,12 +296,14 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    ms = dt / args.steps * 1e3
-    value = world * B * S ** 3 / (dt / args.steps)
+    passes = args.steps * inner
+    ms = dt / passes * 1e3
+    value = world * B * S ** 3 / (dt / passes)
 
     out = {
         "metric": "voxels/sec fwd+bwd, 4-modality 128^3 patch", "value": value, "unit": "voxels/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "inner_repeats": inner, "timed_region_s": dt,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"XLSTM_HVED fwd+bwd, {B}x4x{S}^3 patch per GPU, f_maps=4 'ilc' (train.py:142-143), "
                                f"train mode, subset [14], recon=True, {args.dtype} activation storage / fp32 arithmetic, "
@@ -310,10 +334,19 @@ def main():
     # GPU to idle inside a bracket (the batched weight-gradient bracket read 369 us next to the CPU leg, 282 us under rocprof)
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline_pass(compute, ops, min(args.steps, 5), dtype)      # rank-local: no collective inside
-    if rank == 0 and world == 1 and not args.no_trainstep:
-        # the whole training step, LAST: TrainStep re-points the generator's .grad at its own bucket
+    if not args.no_trainstep:
+        # the whole training step, LAST: TrainStep re-points the generator's .grad at its own bucket.  With
+        # N > 1 every rank runs it data-parallel (TrainStep(group=...): two graphs, the two bucket all-reduces between / after)
         try:
-            out.update(train_step_leg(model, x, max(6, min(args.steps, 30))))
+            if use_dist:
+                import torch.distributed as dist
+                grp = dist.group.WORLD
+            else:
+                grp = None
+            leg = train_step_leg(model, x, max(6, min(args.steps, 30)), group=grp, world=world,
+                                 mfma_roofline=(rank == 0 and not args.no_roofline))
+            if rank == 0:
+                out.update(leg)
         except Exception as e:                                  # must not cost the headline line
             out["train_step_error"] = repr(e)[:200]
     if rank == 0:
@@ -324,36 +357,180 @@ def main():
         dist.destroy_process_group()
 
 
-def train_step_leg(model, x, nsteps):
+def train_step_leg(model, x, nsteps, group=None, world=1, mfma_roofline=False):
     """the reference's whole optimisation step (train.py:208-296 without the optimizer updates) -- two
     shared-encoder generator forwards, the HIP loss epilogues, three passes of the ks=4 Discriminator of train.py:146 (csrc/dconv.hip
     implicit GEMMs on the matrix cores) and both backward passes -- captured ONCE into a hipGraph and replayed with a different
-    modality subset every step (train.py:222-223), the subset entering as a device mask."""
+    modality subset every step (train.py:222-223), the subset entering as a device mask.  With a process group the step is
+    data parallel: two graphs, the generator bucket's all-reduce on a communication stream under the discriminator passes, the
+    discriminator bucket's (44.3 MB) after them; the slowest rank's time is reported."""
     import xlstm_hved_amd as X
     from xlstm_hved_amd.train_step import TrainStep
     torch.manual_seed(2)
     disc = X.Discriminator(in_channels=7, ks=4, strides=[1, 2, 2, 2])            # train.py:146
     disc.apply(X.init_weights)
     disc = disc.to(x.device)
-    ts = TrainStep(model, disc, storage=x.dtype)
+    ts = TrainStep(model, disc, storage=x.dtype, group=group, world_size=world if group is not None else None)
     mask = (torch.rand(x.shape[0], 3, *x.shape[2:], device=x.device) > 0.7).float()
     xf = x.float()
     ts.capture(xf, mask)
     subsets = [[3], [6], [12], [0], [9], [13], [14]]
+
+    def sync():
+        if group is not None:
+            import torch.distributed as dist
+            dist.barrier(group)
+        torch.cuda.synchronize()
     for i in range(3):
         ts.replay(xf, mask, subsets[i % len(subsets)], update=False)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in range(nsteps):
         ts.replay(xf, mask, subsets[i % len(subsets)], update=False)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / nsteps * 1e3
+    sync()
+    dt = time.perf_counter() - t0
+    if group is not None:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=x.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        dt = t.item()
+    ms = dt / nsteps * 1e3
     gflop_d = 561.4 * x.shape[0] * (x.shape[2] / 128.0) ** 3       # one ks=4 discriminator forward (tools/microbench_disc.py)
-    return {"train_step_graph_ms": ms,
-            "train_step_note": ("train.py:208-296 without the optimizer updates, ONE captured hipGraph replayed with a new modality "
-                                f"subset per step: 2 generator forwards (shared encoder) + Dice/MSE/KLD/LSGAN epilogues + 3 passes of "
-                                f"Discriminator(in_channels=7, ks=4, strides=[1,2,2,2]) (~{gflop_d:.0f} GFLOP per forward pass) + both "
-                                f"backward passes; {nsteps} replays timed, subset mask and inputs rewritten before each")}
+    res = {"train_step_graph_ms": ms, "train_step_ranks": world,
+           "train_step_note": ("train.py:208-296 without the optimizer updates, ONE captured hipGraph replayed with a new modality "
+                               f"subset per step: 2 generator forwards (shared encoder) + Dice/MSE/KLD/LSGAN epilogues + 3 passes of "
+                               f"Discriminator(in_channels=7, ks=4, strides=[1,2,2,2]) (~{gflop_d:.0f} GFLOP per forward pass) + both "
+                               f"backward passes; {nsteps} replays timed, subset mask and inputs rewritten before each"
+                               + ("" if group is None else f"; data parallel over {world} rank(s): two graphs, generator bucket "
+                                  f"({ts.grads.flat.numel() * 4 / 1e6:.2f} MB) all-reduced on a communication stream under the "
+                                  f"discriminator passes, discriminator bucket ({ts.grads_d.flat.numel() * 4 / 1e6:.1f} MB) after them"))}
+    if mfma_roofline:
+        try:
+            res["roofline_mfma"] = mfma_roofline_pass(ts, xf, mask)
+        except Exception as e:
+            res["roofline_mfma_error"] = repr(e)[:200]
+    return res
+
+
+class GpuDelay:
+    """A device-side delay that keeps the WHOLE chip busy (a stream of HBM-bound element-wise passes over a 256 MB buffer, like
+    the step itself): an eager instrumented step queued behind it runs back to back as in a graph replay.  Behind a one-thread
+    spin kernel (torch.cuda._sleep) the GPU sits idle for tens of milliseconds, power management lowers the clocks, and the
+    first brackets of the step read up to 1.8x long (measured: 48 us instead of 27 for the dominant conv instance)."""
+
+    def __init__(self):
+        self.junk = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+        for _ in range(5):
+            self.junk.add_(1.0)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(50):
+            self.junk.add_(1.0)
+        c1.record()
+        torch.cuda.synchronize()
+        self.pass_ms = max(c0.elapsed_time(c1) / 50.0, 1e-3)
+
+    def __call__(self, ms):
+        for _ in range(max(1, int(ms / self.pass_ms))):
+            self.junk.add_(1.0)
+
+    def empty_pair_ms(self, delay_ms):
+        """Median cost of an empty event pair under the same queued conditions (subtracted from every bracket)."""
+        self(delay_ms)
+        empties = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            empties.append((e0, e1))
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
+
+
+def mfma_roofline_pass(ts, x, mask, nsteps=3):
+    """The MFMA-bound objects of the path: every implicit-GEMM launch of the Discriminator inside the REAL training
+    step (forward of the fake and the real sample, data gradients, weight gradients; csrc/dconv.hip) bracketed by HIP events on
+    the launch stream, the eager step queued behind a device-side delay like roofline_pass.  flops = 2 * (conv output voxels) *
+    ks^3 * Cin * Cout with the REAL channel counts (7 input channels, not the padded 8; the 512 -> 1 conv's padding to 32 is not
+    counted).  The dominant instance by total time is the object; the others are listed."""
+    from xlstm_hved_amd import disc as D
+    recs = []
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    orig = (D._conv_into, D._conv, D._wgrad)
+
+    def vox(sp):
+        return sp[0] * sp[1] * sp[2]
+
+    def conv_into(y, x_, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, **kw):
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = orig[0](y, x_, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, **kw)
+        e1.record()
+        ks = kw.get("ks", 3)
+        recs.append((f"dconv_cl forward {min(cs, 7) if cs == 8 else cs}->{cn} s{stride} @{'x'.join(map(str, sp_out))}", e0, e1,
+                     2.0 * n * vox(sp_out) * ks ** 3 * (7 if cs == 8 else cs) * cn))
+        return r
+
+    def conv(x_, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, **kw):
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = orig[1](x_, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, **kw)
+        e1.record()
+        ks = kw.get("ks", 3)
+        o = sp_out if mode == 0 else sp_in                    # conv-output extents (a data gradient's SOURCE)
+        cs_r, cn_r = (1 if cs == 32 else cs), (7 if cn == 8 else cn)
+        recs.append((f"dconv_cl {'forward' if mode == 0 else 'data gradient'} {cn_r if mode else cs_r}{'<-' if mode else '->'}"
+                     f"{cs_r if mode else cn_r} s{stride} @{'x'.join(map(str, o))}" + (" +mask/bias epilogue" if kw.get("mask") is not None else ""),
+                     e0, e1, 2.0 * n * vox(o) * ks ** 3 * cs_r * cn_r))
+        return r
+
+    def wgrad(x_, dy, stride, n, sp_in, sp_out, cs, cn, ks=3, gs=None):
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = orig[2](x_, dy, stride, n, sp_in, sp_out, cs, cn, ks=ks, gs=gs)
+        e1.record()
+        cs_r, cn_r = (7 if cs == 8 else cs), (1 if cn == 32 else cn)
+        recs.append((f"dwgrad_cl {cs_r}->{cn_r} s{stride} @{'x'.join(map(str, sp_out))} (+ zero fill of the packed gradient)", e0, e1,
+                     2.0 * n * vox(sp_out) * ks ** 3 * cs_r * cn_r))
+        return r
+    delay = GpuDelay()
+    keep = ts.keep_mask([6], x.shape[0])
+    D._conv_into, D._conv, D._wgrad = conv_into, conv, wgrad
+    try:
+        t_h = time.perf_counter()
+        ts.compute(x, mask, keep)
+        host_ms = (time.perf_counter() - t_h) * 1e3
+        torch.cuda.synchronize()
+        recs.clear()
+        delay_ms = min(2.0 * host_ms + 30.0, 900.0)
+        overhead = delay.empty_pair_ms(delay_ms)
+        for _ in range(nsteps):
+            delay(delay_ms)
+            ts.compute(x, mask, keep)
+        torch.cuda.synchronize()
+    finally:
+        D._conv_into, D._conv, D._wgrad = orig
+    agg = {}
+    for name, e0, e1, fl in recs:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += max(e0.elapsed_time(e1) - overhead, 1e-3)
+        a[2] += fl
+    rows = {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3, "tflops": v[2] / v[1] / 1e9,
+                "frac_of_dense_peak": v[2] / v[1] / 1e9 / BF16_MFMA_PEAK_TFLOPS} for k, v in agg.items()}
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    name, (cnt, ms_sum, fl_sum) = dom
+    tfl = fl_sum / ms_sum / 1e9
+    total_ms = sum(v[1] for v in agg.values()) / nsteps
+    return {"bound": "mfma", "achieved": tfl, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / BF16_MFMA_PEAK_TFLOPS,
+            "kernel": name, "launches_per_step": cnt / nsteps, "avg_launch_us": ms_sum / cnt * 1e3,
+            "algorithmic_flops_per_launch": fl_sum / cnt, "traffic": None,
+            "discriminator_gemm_ms_per_step": total_ms,
+            "discriminator_gemm_tflops_overall": sum(v[2] for v in agg.values()) / sum(v[1] for v in agg.values()) / 1e9,
+            "instances": dict(sorted(rows.items(), key=lambda kv: -kv[1]["avg_launch_us"] * kv[1]["launches_per_step"])),
+            "timing": "HIP events on the launch stream around every implicit-GEMM launch of the Discriminator inside the eager "
+                      "training step, queued behind a device-side delay; minus the median empty event pair",
+            "event_pair_overhead_us": overhead * 1e3, "host_enqueue_ms_per_step": host_ms}
 
 
 def time_graph(fn, nsteps, warmup=3, thread_local=False):
@@ -574,24 +751,7 @@ def roofline_pass(step, ops, nsteps, dtype):
             orig_flush()
             e1.record()
             records.append((ops.last_conv_kernel(), e0, e1, m[1], m[2], m[3], 1))
-    # The device-side delay a step is queued behind keeps the WHOLE chip busy (a stream of HBM-bound element-wise passes over a
-    # 256 MB buffer, like the step itself): behind a one-thread spin kernel (torch.cuda._sleep) the GPU sits idle for tens of
-    # milliseconds, power management lowers the clocks, and the first brackets of the step read up to 1.8x long (measured:
-    # 48 us instead of 27 for the dominant conv instance, run to run).
-    junk = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
-    for _ in range(5):
-        junk.add_(1.0)
-    c0, c1 = ev(), ev()
-    c0.record()
-    for _ in range(50):
-        junk.add_(1.0)
-    c1.record()
-    torch.cuda.synchronize()
-    pass_ms = max(c0.elapsed_time(c1) / 50.0, 1e-3)
-
-    def gpu_delay(ms):
-        for _ in range(max(1, int(ms / pass_ms))):
-            junk.add_(1.0)
+    gpu_delay = GpuDelay()                   # (see the class: keeps the whole chip busy so the clocks stay up)
     # the delay must outlast the host's enqueue time of one instrumented step (else the GPU catches up and a bracket
     # also spans host launch latency): time one instrumented enqueue, then wait 1.5x that (+20 ms), at most 600 ms
     ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
@@ -606,20 +766,17 @@ def roofline_pass(step, ops, nsteps, dtype):
     delay_ms = min(2.0 * host_ms + 30.0, 600.0)
     # an event pair costs a few microseconds of its own (two marker packets): measure empty brackets under the same
     # queued conditions and subtract their median from every bracket
-    gpu_delay(delay_ms)
-    empties = []
-    for _ in range(200):
-        e0, e1 = ev(), ev()
-        e0.record()
-        e1.record()
-        empties.append((e0, e1))
-    torch.cuda.synchronize()
-    overhead_ms = sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
+    overhead_ms = gpu_delay.empty_pair_ms(delay_ms)
     ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
+    whole = []
     try:
         for _ in range(nsteps):
             gpu_delay(delay_ms)
+            w0, w1 = ev(), ev()
+            w0.record()
             step()
+            w1.record()
+            whole.append((w0, w1))
         torch.cuda.synchronize()
     finally:
         ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
@@ -647,6 +804,8 @@ def roofline_pass(step, ops, nsteps, dtype):
         a[4][shape] = a[4].get(shape, 0) + sum(c[3] for c in calls)
     ops.set_wgrad_overlap(overlap_was)
     total_ms = sum(a[1] for a in agg.values())
+    step_ms = sorted(a.elapsed_time(b) for a, b in whole)[len(whole) // 2]      # one instrumented step, back to back on the device
+    n_brackets = len(records) / nsteps
     name, (cnt, ms_sum, bytes_sum, flops_sum, shapes) = max(agg.items(), key=lambda kv: kv[1][1])
     avg_ms, nbytes, flops = ms_sum / cnt, bytes_sum / cnt, flops_sum / cnt
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
@@ -673,6 +832,12 @@ def roofline_pass(step, ops, nsteps, dtype):
               "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
               "arithmetic_intensity_flop_per_byte": flops / nbytes, "tflops": tfl,
               "share_of_conv_time": ms_sum / total_ms, "conv_time_per_step_ms": total_ms / nsteps,
+              # what the per-kernel fraction above does not see: everything of the step that is NOT a bracketed conv launch
+              # (norm / element-wise passes, ViL, PoE, loss, packs, fills) = the instrumented step minus its conv brackets minus
+              # the event pairs; the rocprof family split of the same step is in profiles/ (r04*_timeline.txt)
+              "instrumented_step_ms": step_ms,
+              "non_conv_ms_per_step": max(step_ms - total_ms / nsteps - n_brackets * overhead_ms, 0.0),
+              "elementwise_ms_per_step": elementwise_from_profile(),
               "other_conv_kernels": {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3,
                                           "GBps": v[2] / v[1] / 1e6, "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()}}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:8]},
@@ -680,7 +845,29 @@ def roofline_pass(step, ops, nsteps, dtype):
               "timing": "HIP events on the launch stream around each launch of the real step (queued behind a device-side "
                         "delay so launches run back to back as in the graph replay), minus the median empty event pair; weight "
                         "fragments are prepacked once per step (xh_conv3d_prepack), so a bracket holds the conv launch alone"})
+    k7 = {k: v for k, v in agg.items() if "conv7_mfma" in k}
+    if k7:
+        cnt7 = sum(v[0] for v in k7.values())
+        ms7 = sum(v[1] for v in k7.values())
+        fl7 = sum(v[3] for v in k7.values())
+        r["gate_conv7"] = {"bound": "mfma", "kernel": "conv7_mfma_kernel (AttenModule2's composed 7^3 gate conv, forward + data gradient)",
+                           "achieved": fl7 / ms7 / 1e9, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": fl7 / ms7 / 1e9 / BF16_MFMA_PEAK_TFLOPS, "launches_per_step": cnt7 / nsteps,
+                           "ms_per_step": ms7 / nsteps,
+                           "note": "flops counted on the composed 4 -> 2 (2 -> 4) channel conv: 2 * out * 343 * Cin"}
     return r
+
+
+def elementwise_from_profile():
+    """The norm / element-wise family's share of a step, from the rocprofv3 kernel trace of this command committed under
+    profiles/ (tools/dump_step.py classifies every launch of one replayed step); None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", "step_families.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return {"ms": t.get("norm_elementwise_ms"), "launches": t.get("norm_elementwise_launches"), "launches_per_step": t.get("launches"),
+            "source": t.get("source")}
 
 
 if __name__ == "__main__":

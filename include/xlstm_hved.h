@@ -53,10 +53,19 @@ int xh_abi_version(void);
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
  *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo
- *         kernels of the first conv (data gradient / forward). */
+ *         kernels of the first conv (data gradient / forward).
+ *
+ * PROCESS-GLOBAL STATE (the only two exceptions to "no mutable state in the library"): the option table behind
+ * xh_set_option (plain ints, e.g. g_q4_maxc / g_q4_wgs in csrc/conv3d_q4.hip) and the name buffer behind xh_last_conv_kernel
+ * are per PROCESS, not per device, stream or call.  They are development / measurement knobs: every option has a default that
+ * is the measured optimum, no product code path (xlstm-hved_amd/*.py outside bench/tests) sets one, and the deployment model is
+ * one process per GPU.  Neither function is thread-safe against concurrent launches from other host threads: set options
+ * before the first launch; read xh_last_conv_kernel on the thread that made the call.  Every other entry point is re-entrant:
+ * all device memory, workspaces and the statistics fan-in block are the caller's, the stream is an argument. */
 int xh_set_option(int key, int value);
-/* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call launched (static storage;
- * the same spelling rocprofv3 prints), so measurements can be attributed to a kernel without a profiler attached. */
+/* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call of THIS PROCESS launched (static
+ * storage, overwritten by the next call on any thread; the same spelling rocprofv3 prints), so measurements can be attributed
+ * to a kernel without a profiler attached.  Measurement aid only. */
 const char* xh_last_conv_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@ Per kernel name (launch averages): every counter found, plus derived figures
   wait_any_frac       SQ_WAIT_ANY / SQ_WAVE_CYCLES                                   parked on s_waitcnt / barrier
   wait_inst_frac      SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                              waiting for an issue slot
   insts_per_wave      SQ_INSTS_VALU.. (all categories summed) / SQ_WAVES
+  lds_bank_conflict_frac  SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS                  LDS bank-conflict cycles per LDS-active cycle
 (MI355X_MICROARCH.md, SQ row: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.)  GRBM_GUI_ACTIVE is summed over the
 8 XCDs by rocprofv3; 256 CUs x 4 SIMDs = 1024 SIMDs."""
 import csv
@@ -58,6 +59,8 @@ def main():
             for src, dstk in (("SQ_ACTIVE_INST_ANY", "issue_busy_frac"), ("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac")):
                 if src in k:
                     k[dstk] = k[src] / wc
+        if k.get("SQ_ACTIVE_INST_LDS", 0) > 0 and "SQ_LDS_BANK_CONFLICT" in k:
+            k["lds_bank_conflict_frac"] = k["SQ_LDS_BANK_CONFLICT"] / k["SQ_ACTIVE_INST_LDS"]     # conflict cycles per LDS-active cycle
         insts = [v for c, v in k.items() if c.startswith("SQ_INSTS_")]
         if insts and k.get("SQ_WAVES", 0) > 0:
             k["insts_per_wave"] = sum(insts) / k["SQ_WAVES"]

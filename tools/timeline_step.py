@@ -1,5 +1,7 @@
 """Timeline of the LAST replayed step of a rocprofv3 --kernel-trace CSV (bench.py under hipGraph replay): busy time, idle gaps
-between consecutive kernels, time by workgroup-count class and by kernel family.  usage: timeline_step.py <kernel_trace.csv>"""
+between consecutive kernels, time by workgroup-count class and by kernel family.
+usage: timeline_step.py <kernel_trace.csv> [families.json [source note]]   (the JSON is what bench.py's roofline object quotes as
+elementwise_ms_per_step: profiles/step_families.json)"""
 import collections
 import csv
 import re
@@ -66,3 +68,13 @@ for k, v in sorted(byf.items(), key=lambda kv: -kv[1][1]):
 for k in ("<64", "<256", "<1024", ">=1024"):
     v = bywg[k]
     print(f"  workgroups {k:7s} {v[0]:4d} launches {v[1]:8.0f} us")
+
+if len(sys.argv) > 2:
+    import json
+    ne = byf["norm / elementwise"]
+    json.dump({"launches": per, "step_period_us": period, "sum_of_durations_us": sum(e - s for s, e in zip(S, E)) / 1e3,
+               "norm_elementwise_launches": ne[0], "norm_elementwise_ms": ne[1] / 1e3,
+               "families": {k: {"launches": v[0], "ms": v[1] / 1e3} for k, v in byf.items()},
+               "workgroup_classes": {k: {"launches": v[0], "ms": v[1] / 1e3} for k, v in bywg.items()},
+               "source": sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 --kernel-trace of bench.py (last replayed step), tools/timeline_step.py"},
+              open(sys.argv[2], "w"), indent=1)

@@ -2,6 +2,9 @@
 shapes of its tensor arguments (and, for the convs, the kernel instance that ran) -- the key to tools/dump_step.py's launch list.
 usage: python tools/trace_ops.py [size] > gpurun_out/ops_trace.txt"""
 import os, sys, types
+if len(sys.argv) > 1 and not sys.argv[1].isdigit():
+    print(__doc__)
+    raise SystemExit(0)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -9,6 +12,9 @@ import xlstm_hved_amd as X
 from bench import bench_loss
 ops = X.ops
 
+if len(sys.argv) > 1 and not sys.argv[1].isdigit():
+    print(__doc__)
+    raise SystemExit(0)
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 LOG = []
 ON = [False]
