@@ -87,7 +87,10 @@ typedef struct {
   int transposed;               /* 1: compute the data-gradient correlation using FORWARD-layout weights
                                    [Cin][Cout/groups][k^3] (roles swapped, taps flipped); stride must be 1 */
   int pre;                      /* 1: input transform v = leaky(x*pre_sc[n,c] + pre_sh[n,c], pre_slope)
-                                   applied before zero padding (slope 1 = affine only) */
+                                   applied before zero padding (slope 1 = affine only)
+                                   2: (data gradients, see xh_conv3d_fuses_norm_bwd) the InstanceNorm backward of the stage behind
+                                   this conv applied on load: v = A*xa + C*px + B, the coefficients of xh_in_bwd_apply derived
+                                   in-kernel from nb_red / nb_mean / nb_rstd; one source (Ca == Cin) */
   float pre_slope;
   int act;                      /* epilogue activation XH_ACT_* (after bias) */
   float act_slope;
@@ -98,6 +101,7 @@ typedef struct {
   int Cea;                      /* epi==1: e channels [0,Cea) from ea, rest from eb */
   long long ea_bs, eb_bs;
   float e_slope;
+  long long px_bs, pd_bs;       /* pre == 2: batch strides of px and pd */
 } xh_conv_desc;
 
 typedef struct {
@@ -124,6 +128,13 @@ typedef struct {
    * state such a launch shares with others: launches that may run CONCURRENTLY (different streams, parallel branches of one
    * graph) must be given different blocks; launches ordered on one stream may share one.  NULL / too small: direct atomics. */
   void* fan; long long fan_bytes;
+  /* pre == 2 (replaces a separate xh_in_bwd_apply pass between two chained data gradients, buildingblocks.py:464-507 backward):
+   * xa = g, the activation-masked data gradient the NEXT conv's backward left (its epi == 1 output), px = the raw tensor that
+   * stage normalised (same layout as xa), nb_red[N][Cin][2] = that launch's sums (sum g, sum g*px), nb_mean / nb_rstd [N][Cin] the
+   * InstanceNorm statistics of px, nb_count = voxels per channel.  pd (optional): the transformed tensor A*g + C*px + B is ALSO
+   * stored there (layout of xa) -- the weight gradient of this conv reads it; written by this launch, complete when it ends. */
+  const void* px; void* pd;
+  const double* nb_red; const float* nb_mean; const float* nb_rstd; long long nb_count;
 } xh_conv_ptrs;
 
 /* Size in bytes of a statistics fan-in workspace (xh_conv_ptrs.fan).  The library allocates no device memory and keeps no
@@ -133,6 +144,9 @@ long long xh_fanin_bytes(void);
 /* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv
  * (transposed=1).  Reference: F.conv3d as used throughout RA_HVED.py:510-648. */
 int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
+/* 1 when xh_conv3d_fwd takes this desc with pre == 2 (the quad-channel MFMA kernel: 16-bit storage, k = 3, stride 1, rows of 32
+ * voxels, <= 48 channels per group, ...); 0: the caller materialises the tensor with xh_in_bwd_apply and calls with pre == 0. */
+int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d);
 /* Bytes of p->ws the bf16-MFMA implicit-GEMM path wants for this desc (0: shape not eligible, vector kernel). */
 long long xh_conv3d_workspace_bytes(const xh_conv_desc* d);
 /* Weights are constant within a training step: packs the MFMA weight fragments of n convolutions (forward and data-gradient
@@ -321,7 +335,9 @@ int xh_gate2_fwd(void* stream, int dtype, const void* xa, long long xa_bs, int C
                  long long E_bs, void* y, long long y_bs, int N, long long DHW, double* red);
 int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb, const void* E,
                  long long E_bs, const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb, long long dxb_bs,
-                 int acc_b, void* dE, long long dE_bs, int N, long long DHW);
+                 int acc_b, void* dE, long long dE_bs, int N, long long DHW, int sig_bwd);
+/* (sig_bwd = 1: E is the output of a sigmoid -- AttenModule2's gates, buildingblocks.py:286,296 -- and dE receives the gradient of its
+ * PRE-activation, dE * E (1 - E): the sigmoid's backward rides in this pass instead of a launch of its own.) */
 /* Gate + MaxPool3d(2) in one pass (RA_HVED.py:552 followed by buildingblocks.py:655-657): y = maxpool2(x * (1 + s)), the gated
  * values rounded to the storage type before the maximum (bit-identical to xh_gate_fwd + xh_maxpool2_fwd); red (optional):
  * red[n][c][0..1] += (sum y, sum y^2) of the stored output for the InstanceNorm that follows.  D, H even, W a multiple of 8,

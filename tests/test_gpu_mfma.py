@@ -472,3 +472,56 @@ def test_k7_gate_conv_full_size_128_vs_stock(dtype):
     print("k7 128^3", dtype, {k: f"{v:.2e}" for k, v in e.items()})
     k = 1.0 if dtype == torch.bfloat16 else 0.2
     assert e["y"] < 8e-3 * k and e["dx"] < 2e-2 * k and e["dw"] < 2e-2 * k and e["db"] < 2e-2 * k, e
+
+
+NB_CASES = [
+    dict(cin=4, mid=4, cout=4, groups=1, sp=(32, 32, 32)),            # decoder level 0 shapes, small launch: 2 / 4-plane tiles
+    dict(cin=16, mid=16, cout=16, groups=4, sp=(16, 24, 64)),         # the four encoder streams: quad per group, two W tiles
+    dict(cin=12, mid=4, cout=4, groups=1, sp=(11, 13, 32), split=4),  # virtual concat in front, ragged D / H tiles (ownership)
+    dict(cin=24, mid=8, cout=8, groups=1, sp=(8, 16, 32), split=8),   # two input quads through the same LDS tile (MULTI)
+    dict(cin=16, mid=32, cout=32, groups=4, sp=(8, 8, 32)),           # 4 -> 8 -> 8 per stream: two quads per group
+    dict(cin=4, mid=4, cout=4, groups=1, sp=(64, 64, 128), n=1),      # >= 512 workgroups: the 8-plane instance
+    dict(cin=16, mid=16, cout=16, groups=4, sp=(8, 8, 16)),           # 16-wide rows: not on the quad-channel kernel -> the pass runs
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES + [torch.float32], ids=["bf16", "f16", "f32"])
+@pytest.mark.parametrize("cfg", NB_CASES)
+def test_norm_backward_folded_into_the_data_gradient_vs_separate_pass(cfg, dtype):
+    """DoubleConv backward (buildingblocks.py:464-507): the InstanceNorm backward between the two data gradients applied by the
+    second one on load (xh_conv_desc.pre == 2, functional._NB_PENDING) against the separate xh_in_bwd_apply pass: input and
+    parameter gradients agree to the rounding of one storage value (both paths round the same fp32 expression once; fp32 storage
+    and shapes the quad-channel kernel does not take run the pass either way and must agree exactly)."""
+    from xlstm_hved_amd import functional as Fn
+    torch.manual_seed(13)
+    n, cin, mid, cout, g = cfg.get("n", 2), cfg["cin"], cfg["mid"], cfg["cout"], cfg["groups"]
+    split = cfg.get("split")
+    x = (torch.randn((n, cin) + cfg["sp"]) * 1.5 + 0.3).to(dtype)
+    mk = lambda co, ci: ([torch.randn(co // g, ci // g, 3, 3, 3) * (2.0 / (27 * ci // g)) ** 0.5 for _ in range(g)], [torch.randn(co // g) for _ in range(g)])
+    (w1, b1), (w2, b2) = mk(mid, cin), mk(cout, mid)
+    wgt = torch.randn((n, cout) + cfg["sp"])
+
+    def run(fold):
+        X.ops.set_norm_bwd_fold(fold)
+        try:
+            xg = x.to(DEV).requires_grad_(True)
+            ps = [[t.to(DEV).requires_grad_(True) for t in l] for l in (w1, b1, w2, b2)]
+            xa, xb = (xg[:, :split], xg[:, split:]) if split else (xg, None)
+            y1, st1 = Fn.in_lrelu_conv(xa, xb, ps[0], ps[1], 1, g, out_stats=True, drop_bias=True)
+            y2 = Fn.in_lrelu_conv(y1, None, ps[2], ps[3], 1, g, in_stats=st1, sole_consumer=True)
+            (y2.float() * wgt.to(DEV)).sum().backward()
+            X.ops.join_wgrad_stream()                   # raises if a hand-over was left untaken
+            torch.cuda.synchronize()
+            return y2.detach(), xg.grad, [t.grad for l in ps for t in l], X.ops.last_conv_kernel()
+        finally:
+            X.ops.set_norm_bwd_fold(True)
+    ya, dxa, ga, _ = run(False)
+    yb, dxb, gb, kern = run(True)
+    assert torch.equal(ya, yb)
+    exact = dtype == torch.float32 or cfg["sp"][2] % 32 != 0
+    tol = 2e-6 if exact else (6e-3 if dtype == torch.bfloat16 else 8e-4)      # (exact: up to the order of the fp64 / fp32 atomics)
+    e_dx = l2_err(dxb, dxa)
+    gscale = max(t.abs().max().item() for t in ga)
+    e_g = max((p - q).abs().max().item() for p, q in zip(gb, ga)) / gscale
+    print(f"norm-backward fold {cfg} {dtype}: dx rel-L2 {e_dx:.2e}, parameter gradients {e_g:.2e} of the largest")
+    assert e_dx <= tol and e_g <= tol, (e_dx, e_g)

@@ -26,6 +26,7 @@ class ConvDesc(C.Structure):
         ("n_wptr", C.c_int), ("transposed", C.c_int), ("pre", C.c_int), ("pre_slope", C.c_float),
         ("act", C.c_int), ("act_slope", C.c_float), ("epi", C.c_int), ("Cea", C.c_int),
         ("ea_bs", ll), ("eb_bs", ll), ("e_slope", C.c_float),
+        ("px_bs", ll), ("pd_bs", ll),
     ]
 
 
@@ -35,6 +36,7 @@ class ConvPtrs(C.Structure):
         ("ea", vp), ("eb", vp), ("e_sc", vp), ("e_sh", vp), ("red", vp), ("ws", vp), ("ws_bytes", ll),
         ("fin_red", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_count", ll), ("ws_packed", C.c_int),
         ("fan", vp), ("fan_bytes", ll),
+        ("px", vp), ("pd", vp), ("nb_red", vp), ("nb_mean", vp), ("nb_rstd", vp), ("nb_count", ll),
     ]
 
 
@@ -74,6 +76,7 @@ SIGNATURES = {
     "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_fanin_bytes": (ll, []),
     "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
+    "xh_conv3d_fuses_norm_bwd": (I, [C.POINTER(ConvDesc)]),
     "xh_conv3d_prepack": (I, [vp, I, vp, vp]),
     "xh_conv3d_wgrad_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
@@ -109,7 +112,7 @@ SIGNATURES = {
     "xh_channel_pool2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, I, ll]),
     "xh_channel_pool2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, vp, ll, I, I, ll]),
     "xh_gate2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, ll, vp]),
-    "xh_gate2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, vp, ll, I, vp, ll, I, vp, ll, I, ll]),
+    "xh_gate2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, vp, ll, I, vp, ll, I, vp, ll, I, ll, I]),
     "xh_gate_maxpool_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, I, I, I, vp]),
     "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I, I]),
     "xh_duse_gate_fwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll]),

@@ -125,13 +125,14 @@ class SingleConv(nn.Module):
         if padding != kernel_size // 2:
             raise NotImplementedError("only 'same' padding is supported")
 
-    def forward(self, x, x2=None, in_stats=None, out_stats=False, drop_bias=False):
+    def forward(self, x, x2=None, in_stats=None, out_stats=False, drop_bias=False, sole_consumer=False):
         """in_stats / out_stats ('ilc' only): take the input's channel sums from the producer's epilogue / also return
         (y, sums of y) accumulated by this conv's epilogue, so chained stages skip their statistics pass.
-        drop_bias ('ilc' only): the only consumer is an InstanceNorm (Fn.in_lrelu_conv)."""
+        drop_bias ('ilc' only): the only consumer is an InstanceNorm (Fn.in_lrelu_conv).  sole_consumer ('ilc' only): x is the
+        output of another 'ilc' SingleConv that nothing else reads (Fn.InLreluConv: norm-backward fold)."""
         if self.order == "ilc":
             return Fn.in_lrelu_conv(x, x2, [self.conv.weight], [self.conv.bias], self.stride, in_stats=in_stats,
-                                    out_stats=out_stats, drop_bias=drop_bias)
+                                    out_stats=out_stats, drop_bias=drop_bias, sole_consumer=sole_consumer)
         if out_stats:
             raise NotImplementedError("out_stats is an 'ilc' feature")
         if x2 is not None:
@@ -158,7 +159,7 @@ class DoubleConv(nn.Module):
             return self.SingleConv2(self.SingleConv1(x, x2))
         # conv1's epilogue feeds conv2's InstanceNorm -- its only consumer, so conv1's bias add is an identity (drop_bias)
         y1, st1 = self.SingleConv1(x, x2, in_stats=in_stats, out_stats=True, drop_bias=True)
-        return self.SingleConv2(y1, in_stats=st1, out_stats=out_stats)
+        return self.SingleConv2(y1, in_stats=st1, out_stats=out_stats, sole_consumer=True)      # y1 never leaves this block
 
 
 class DoubleConv_ViL(DoubleConv):
@@ -273,8 +274,9 @@ class AttenModule2(nn.Module):
         seg_p, seg_g = Fn.fanout(seg_x, 2)
         pooled = Fn.ChannelPool2.apply(seg_p, enc_p)
         w, b = self.composed()
-        gates = Fn.conv(pooled, [w], [b], act=ACT_SIGMOID)        # [:,0] seg scale, [:,1] enc scale
-        return Fn.GateCat.apply(seg_g, enc_g, gates, stats)      # stats: (output, its channel sums for the next InstanceNorm)
+        # the gates' only consumer is the gating pass, whose backward also takes the gradient through the sigmoid (pre_act_grad)
+        gates = Fn.conv(pooled, [w], [b], act=ACT_SIGMOID, pre_act_grad=True)        # [:,0] seg scale, [:,1] enc scale
+        return Fn.GateCat.apply(seg_g, enc_g, gates, stats, True)      # stats: (output, its channel sums for the next InstanceNorm)
 
 
 class Upsampling(nn.Module):

@@ -1241,7 +1241,9 @@ static int check_desc(const xh_conv_desc* d, const xh_conv_ptrs* p) {
   if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= 4))) return XH_ERR_ARG;
   for (int i = 0; i < d->n_wptr; ++i)
     if (!p->w[i]) return XH_ERR_ARG;
-  if (d->pre && (!p->pre_sc || !p->pre_sh)) return XH_ERR_ARG;
+  if (d->pre < 0 || d->pre > 2) return XH_ERR_ARG;
+  if (d->pre == 1 && (!p->pre_sc || !p->pre_sh)) return XH_ERR_ARG;
+  if (d->pre == 2 && (!p->px || !p->nb_red || !p->nb_mean || !p->nb_rstd || p->nb_count <= 0)) return XH_ERR_ARG;
   if (d->N * d->groups > 65535) return XH_ERR_ARG;
   return XH_OK;
 }
@@ -1513,6 +1515,14 @@ extern "C" int xh_set_option(int key, int value) {
   return XH_ERR_ARG;
 }
 
+int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);          // conv3d_q4.hip
+long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d);
+extern "C" int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d) {
+  if (!d || !g_use_mfma || d->epi == 2 || d->act != XH_ACT_NONE) return 0;
+  xh_conv_desc t = *d;
+  t.pre = 2;
+  return xh_conv3_q4_workspace_bytes(&t) > 0 ? 1 : 0;
+}
 extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   int rc = check_desc(d, p);
   if (rc) return rc;
@@ -1521,7 +1531,11 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
   if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cout && !p->eb))) return XH_ERR_ARG;
   if (d->epi == 2 && !p->red) return XH_ERR_ARG;
   if (d->epi < 0 || d->epi > 2) return XH_ERR_ARG;
-  if (p->fin_red && (!d->pre || !p->fin_mean || !p->fin_rstd || p->fin_count <= 0 || d->k != 3)) return XH_ERR_ARG;
+  if (p->fin_red && (d->pre != 1 || !p->fin_mean || !p->fin_rstd || p->fin_count <= 0 || d->k != 3)) return XH_ERR_ARG;
+  if (d->pre == 2) {                                  // norm-backward input: the quad-channel kernel only (xh_conv3d_fuses_norm_bwd)
+    const int r = g_use_mfma ? xh_conv3_q4_try(stream, d, p) : 1;
+    return r == 1 ? XH_ERR_ARG : r;
+  }
   if (g_use_mfma) {
     const int r = d->k == 7 ? xh_conv7_mfma_try(stream, d, p) : xh_conv3_mfma_try(stream, d, p);
     if (r != 1) return r;

@@ -85,14 +85,21 @@ template <int FMT> __device__ __forceinline__ f32x2_t q4_xf(unsigned u, float sc
   return max2(v, v * f32x2_t{slope, slope});
 }
 
-template <int FMT, bool PRE, int EPI, bool ACT, bool MULTI, int TD = 8>
-__global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
+// PRE: 0 = the input as stored, 1 = leaky(x * sc + sh) (the producer's norm + activation), 2 = the InstanceNorm BACKWARD of
+// the stage behind this data gradient applied on load: v = A g + C x + B with g = xa (the masked data gradient the next
+// conv's backward left), x = px (that stage's saved raw input) and per-(n, c) coefficients derived in-kernel from the raw
+// sums nb_red = (sum g, sum g x), mean, rstd -- what xh_in_bwd_apply computes in a pass of its own (reads g, x; writes dx)
+// before this conv reads dx again.  The workgroups of the first output quad of a group also STORE v for the voxels their tile
+// owns (pd): the weight gradient of this conv needs the tensor materialised.
+template <int FMT, int PRE, int EPI, bool ACT, bool MULTI, int TD = 8>
+__global__ __launch_bounds__(256, PRE == 2 ? 3 : 4) void conv3_q4_kernel(const ConvQ4 a) {
   typedef h16<FMT> ST;
   constexpr int ID = TD + 2, TILE_BYTES = ID * PLANE, NROWS = ID * IH, NITEM = NROWS * 4, NEDGE = NROWS * 2;
   constexpr int NIT = (NITEM + 255) / 256;           // interior items (row, 8-voxel group) per thread; edge items: (row, side)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8], then [8] totals + the fan-in flag
   float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 48 * sizeof(double));   // [2][Q4_MAXC]: in-kernel InstanceNorm scale / shift
+                                                                                      // (PRE == 2: [3][Q4_MAXC] = A, C, B)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g4 = lane >> 4;
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   if (a.abl & 4096) return;
   // raw InstanceNorm sums of this group's input channels (fused finalisation): requested first, used behind the staging loads
   double fs1 = 0.0, fs2 = 0.0;
-  if (PRE && a.p.fin_red && tid < a.Cin_g) {
+  if (PRE == 1 && a.p.fin_red && tid < a.Cin_g) {
     fs1 = a.p.fin_red[2 * (n * a.d.Cin + cin_base + tid)];
     fs2 = a.p.fin_red[2 * (n * a.d.Cin + cin_base + tid) + 1];
   }
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   int i_lds[NIT];               // LDS byte address of the item's first 16-byte chunk, before the per-chunk XOR
   int i_par[NIT];
   bool i_live[NIT], i_do[NIT];
+  bool i_own[NIT];              // PRE == 2: this tile owns the item's voxels (not halo, inside the volume) -> side store
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int item = tid + it * 256;
@@ -128,6 +136,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     const int dz = row / IH, hy = row - dz * IH;
     const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy;
     i_live[it] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+    i_own[it] = i_live[it] && i_do[it] && dz >= 1 && dz <= TD && hy >= 1 && hy <= TH;
     const int gdc = min(max(gd, 0), D - 1), ghc = min(max(gh, 0), H - 1);
     i_off[it] = (unsigned)((((long long)gdc * H + ghc) * W + ow0 + gq * 8) * (long long)sizeof(ST));
     i_lds[it] = row * PITCH;
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
   };
 
   const float pslope = a.d.pre_slope;
-  const bool fin = PRE && a.p.fin_red != nullptr;
+  const bool fin = PRE == 1 && a.p.fin_red != nullptr;
   for (int cq = 0; cq < ncq; ++cq) {
     const int c0 = cin_base + cq * 4;
     const char* src = reinterpret_cast<const char*>(c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
@@ -235,6 +244,8 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
     // ---- all global loads of this thread, back to back ----
     uint4 raw[NIT][4];
     unsigned eraw4[4];
+    uint4 rawx[PRE == 2 ? NIT : 1][4];
+    unsigned erawx4[4];
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
 #pragma unroll
@@ -242,9 +253,38 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
         raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * dhw_b + i_off[it]);
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) eraw4[cc] = *reinterpret_cast<const unsigned*>(src + cc * dhw_b + e_off);
+    if (PRE == 2) {
+      const char* srcx = reinterpret_cast<const char*>((const ST*)a.p.px + n * a.d.px_bs + (long long)c0 * dhw);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          rawx[it][cc] = *reinterpret_cast<const uint4*>(srcx + cc * dhw_b + i_off[it]);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) erawx4[cc] = *reinterpret_cast<const unsigned*>(srcx + cc * dhw_b + e_off);
+    }
     if (cq > 0) __syncthreads();                      // every wave is done reading the previous quad's tile
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (PRE) {
+    float cx[4] = {0.f, 0.f, 0.f, 0.f};               // PRE == 2: v = sc * g + cx * x + sh
+    if (PRE == 2) {
+      if (cq == 0) {
+        // the coefficients of xh_in_bwd_apply from the raw sums of this group's channels (fp64, the same bits in every workgroup)
+        if (tid < a.Cin_g) {
+          const long long k = (long long)n * a.d.Cin + cin_base + tid;
+          const double rs = a.p.nb_rstd[k], mu = a.p.nb_mean[k], cnt = (double)a.p.nb_count;
+          const double S0 = a.p.nb_red[k * 2], P = rs * (a.p.nb_red[k * 2 + 1] - mu * S0);
+          s_fin[tid] = (float)rs;
+          s_fin[Q4_MAXC + tid] = (float)(-rs * rs * P / cnt);
+          s_fin[2 * Q4_MAXC + tid] = (float)(-rs * S0 / cnt + rs * rs * mu * P / cnt);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        sc[cc] = s_fin[cq * 4 + cc]; cx[cc] = s_fin[Q4_MAXC + cq * 4 + cc]; sh[cc] = s_fin[2 * Q4_MAXC + cq * 4 + cc];
+      }
+    }
+    if (PRE == 1) {
       if (fin) {
         // fused InstanceNorm finalisation (xh_conv_ptrs.fin_red), behind the loads just issued: the raw sums of this
         // group's channels -> scale / shift in LDS (fp64, the same bits in every workgroup); workgroup (0, 0, 0) also
@@ -268,6 +308,8 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
       }
     }
     // ---- transform + channels-last LDS image ----
+    const bool side = PRE == 2 && a.p.pd != nullptr && oq == grp * a.oq_g;      // one workgroup per (tile, input quad) stores
+    char* dstd = PRE == 2 ? reinterpret_cast<char*>((ST*)a.p.pd + n * a.d.pd_bs + (long long)c0 * dhw) : nullptr;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       if (!i_do[it]) continue;
@@ -280,8 +322,22 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
         for (int cc = 0; cc < 4; ++cc) {
           const float s1 = sc[cc] * lv, s2 = sh[cc] * lv;
           const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
+          if (PRE == 2) {
+            const float s3 = cx[cc] * lv;
+            const unsigned ux[4] = {rawx[it][cc].x, rawx[it][cc].y, rawx[it][cc].z, rawx[it][cc].w};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[cc][k] = q4_xf<FMT>(u[k], s1, s2, pslope);
+            for (int k = 0; k < 4; ++k)
+              v[cc][k] = cvt2_in<FMT>(u[k]) * f32x2_t{s1, s1} + (cvt2_in<FMT>(ux[k]) * f32x2_t{s3, s3} + f32x2_t{s2, s2});
+            if (side && i_own[it]) {                  // the materialised tensor (channel-planar, as stored by xh_in_bwd_apply)
+              uint4 o;
+              o.x = cvt2_pack<FMT>(v[cc][0].x, v[cc][0].y); o.y = cvt2_pack<FMT>(v[cc][1].x, v[cc][1].y);
+              o.z = cvt2_pack<FMT>(v[cc][2].x, v[cc][2].y); o.w = cvt2_pack<FMT>(v[cc][3].x, v[cc][3].y);
+              *reinterpret_cast<uint4*>(dstd + cc * dhw_b + i_off[it]) = o;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[cc][k] = q4_xf<FMT>(u[k], s1, s2, pslope);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -314,7 +370,12 @@ __global__ __launch_bounds__(256, 4) void conv3_q4_kernel(const ConvQ4 a) {
         const float lv = e_live ? 1.f : 0.f;
         f32x2_t v[4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) v[cc] = q4_xf<FMT>(eraw4[cc], sc[cc] * lv, sh[cc] * lv, pslope);
+        for (int cc = 0; cc < 4; ++cc) {
+          if (PRE == 2)
+            v[cc] = cvt2_in<FMT>(eraw4[cc]) * f32x2_t{sc[cc] * lv, sc[cc] * lv} +
+                    (cvt2_in<FMT>(erawx4[cc]) * f32x2_t{cx[cc] * lv, cx[cc] * lv} + f32x2_t{sh[cc] * lv, sh[cc] * lv});
+          else v[cc] = q4_xf<FMT>(eraw4[cc], sc[cc] * lv, sh[cc] * lv, pslope);
+        }
         o.x = cvt2_pack<FMT>(v[0].x, v[1].x);
         o.y = cvt2_pack<FMT>(v[2].x, v[3].x);
         o.z = cvt2_pack<FMT>(v[0].y, v[1].y);
@@ -404,7 +465,8 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
   if (dhw % 8 || dhw >= (1ll << 28)) return false;      // 31-bit byte offsets inside a quad of channel volumes (q4_window)
-  if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
+  if (d->pre == 1 && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
+  if (d->pre == 2 && (d->Ca != d->Cin || (d->px_bs & 7) || (d->pd_bs & 7))) return false;     // one source, 16-byte runs
   float as = 1.f;
   if (d->act == XH_ACT_RELU) as = 0.f;
   else if (d->act == XH_ACT_LRELU) as = d->act_slope;
@@ -481,10 +543,10 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
   a.fan = d->epi ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
-  const size_t shm = q4_tile_bytes(a.td) + 48 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
+  const size_t shm = q4_tile_bytes(a.td) + 48 * sizeof(double) + 3 * Q4_MAXC * sizeof(float);
+  if (d->pre == 2 && (!p->px || !p->nb_red || !p->nb_mean || !p->nb_rstd || p->nb_count <= 0 || d->epi == 2)) return XH_ERR_ARG;
   const bool act = a.act_slope != 1.f;
-  xh_note_kernel("conv3_q4_kernel<%d, %s, %d, %s, %s, %d>", f, d->pre ? "true" : "false", d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false",
-                 a.td);
+  xh_note_kernel("conv3_q4_kernel<%d, %d, %d, %s, %s, %d>", f, d->pre, d->epi, act ? "true" : "false", a.ci4 > 1 ? "true" : "false", a.td);
 #define Q4L(F, P, E, A, T)                                                                                      \
   do {                                                                                                          \
     if (a.ci4 > 1) hipLaunchKernelGGL((conv3_q4_kernel<F, P, E, A, true, T>), grid, dim3(256), shm, st, a);     \
@@ -503,8 +565,24 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
     else if (d->epi == 1) Q4A(F, P, 1); \
     else Q4A(F, P, 2);                  \
   } while (0)
-  if (f) { if (d->pre) Q4E(1, true); else Q4E(1, false); }
-  else { if (d->pre) Q4E(0, true); else Q4E(0, false); }
+  // (pre == 2 exists for the data gradients that carry the norm-backward epilogue or none: epi 0 / 1, no activation)
+#define Q4N(F)                                                        \
+  do {                                                                \
+    if (act) return XH_ERR_ARG;                                       \
+    if (d->epi == 1) {                                                \
+      if (a.td == 8) Q4L(F, 2, 1, false, 8);                          \
+      else if (a.td == 4) Q4L(F, 2, 1, false, 4);                     \
+      else Q4L(F, 2, 1, false, 2);                                    \
+    } else {                                                          \
+      if (a.td == 8) Q4L(F, 2, 0, false, 8);                          \
+      else if (a.td == 4) Q4L(F, 2, 0, false, 4);                     \
+      else Q4L(F, 2, 0, false, 2);                                    \
+    }                                                                 \
+  } while (0)
+  if (d->pre == 2) { if (f) Q4N(1); else Q4N(0); }
+  else if (f) { if (d->pre) Q4E(1, 1); else Q4E(1, 0); }
+  else { if (d->pre) Q4E(0, 1); else Q4E(0, 0); }
+#undef Q4N
 #undef Q4E
 #undef Q4A
 #undef Q4L

@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(EW_BLOCK) void gate2_fwd_kernel(const Pair2<T> p, c
 // dy (N, C0 + C1, ...) -> dx[w] (+)= dy (1 + E[:,w]),  dE[:,w] = sum_c dy x[w]
 template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void gate2_bwd_kernel(const Pair2<T> p, const T* __restrict__ E, long long E_bs, const T* __restrict__ dy,
-                                                       long long dy_bs, T* dE, long long dE_bs, long long dhw) {
+                                                       long long dy_bs, T* dE, long long dE_bs, long long dhw, int sig_bwd) {
   const int w = blockIdx.y, C = p.C[w], acc_dx = p.acc[w];
   const long long dyo = (long long)(w ? p.C[0] : 0) * dhw;
   VOX_LOOP_BEGIN
@@ -1736,6 +1736,10 @@ __global__ __launch_bounds__(256) void gate2_bwd_kernel(const Pair2<T> p, const 
         strow<VEC>(dxp + n * p.dx_bs[w] + (long long)(c0 + j) * dhw, q, valid, o[j]);
               }
       }
+    }
+    if (sig_bwd) {                        // E = sigmoid(pre): store the gradient of the pre-activation, dE * E (1 - E)
+#pragma unroll
+      for (int v = 0; v < VW; ++v) { const float e = g1[v] - 1.f; a[v] *= e * (1.f - e); }
     }
     strow<VEC>(dE + n * dE_bs + (long long)w * dhw, q, valid, a);
   VOX_LOOP_END
@@ -1794,17 +1798,17 @@ extern "C" int xh_gate2_fwd(void* stream, int dtype, const void* xa, long long x
 }
 extern "C" int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int Ca, const void* xb, long long xb_bs, int Cb,
                             const void* E, long long E_bs, const void* dy, long long dy_bs, void* dxa, long long dxa_bs, int acc_a, void* dxb,
-                            long long dxb_bs, int acc_b, void* dE, long long dE_bs, int N, long long DHW) {
+                            long long dxb_bs, int acc_b, void* dE, long long dE_bs, int N, long long DHW, int sig_bwd) {
   if (!PAIR_ARGS_OK || !E || !dy || !dxa || !dxb || !dE) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype, {
     const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, dxa, dxa_bs, acc_a, dxb, dxb_bs, acc_b);
     dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
     if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, dy_bs, dxa_bs, dxb_bs, dE_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb))
-      hipLaunchKernelGGL((gate2_bwd_kernel<T, true, 8>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
+      hipLaunchKernelGGL((gate2_bwd_kernel<T, true, 8>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW, sig_bwd);
     else if (vec_ok<T>(DHW, {xa_bs, xb_bs, E_bs, dy_bs, dxa_bs, dxb_bs, dE_bs}))
-      hipLaunchKernelGGL((gate2_bwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
-    else hipLaunchKernelGGL((gate2_bwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW);
+      hipLaunchKernelGGL((gate2_bwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW, sig_bwd);
+    else hipLaunchKernelGGL((gate2_bwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)E, E_bs, (const T*)dy, dy_bs, (T*)dE, dE_bs, DHW, sig_bwd);
   });
   return xh_launch_status();
 }

@@ -144,6 +144,26 @@ def _ret(slot, t):
 
 
 # ------------------------------------------------------------------------------------------------------
+# Norm-backward fold.  Between the two convs of a DoubleConv the backward pass used to run: data gradient of conv 2 (leaves the
+# masked gradient g and the sums) -> xh_in_bwd_apply (reads g and y1, writes dy1) -> data gradient of conv 1 (reads dy1).  When
+# y1 has no other consumer, conv 2's backward now returns an UNWRITTEN tensor for dy1 and parks (g, y1, sums, statistics) here
+# under its address; conv 1's backward takes the entry and lets its data-gradient launch apply the norm backward while staging
+# (ops.conv3d nb=..., xh_conv_desc.pre == 2), which also writes dy1 for the weight gradient.  Whoever pops an entry fills
+# the tensor -- with the fused launch or, where that does not apply, with the xh_in_bwd_apply pass.  The entry owns the tensor,
+# so its address cannot be reused while it is parked; model.forward() drops leftovers of an aborted backward.
+_NB_PENDING = ops.NB_PENDING
+
+
+def nb_pending_clear():
+    """Start of a forward pass: nothing may be parked.  Leftovers mean the previous backward handed a gradient over that nobody
+    took (an aborted backward, or a consumer this package does not know): its gradients were not valid."""
+    if _NB_PENDING:
+        import warnings
+        warnings.warn(f"xlstm_hved_amd: {len(_NB_PENDING)} norm-backward hand-over(s) of the previous backward pass were never taken; "
+                      "that pass's gradients were incomplete (ops.set_norm_bwd_fold(False) disables the hand-over)")
+        _NB_PENDING.clear()
+
+
 class InLreluConv(Function):
     """SingleConv 'ilc' (buildingblocks.py:406-433,440-461): Conv3d(LeakyReLU(InstanceNorm3d(x))) + bias, k=3.
 
@@ -152,10 +172,13 @@ class InLreluConv(Function):
     RA_HVED.py:548-553, batched along channels)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, in_stats, out_stats, stride, groups, nw, drop_bias, *wb):
+    def forward(ctx, xa, xb, in_stats, out_stats, stride, groups, nw, drop_bias, sole_consumer, *wb):
         """in_stats: the (n, C, 2) fp64 sums [sum x, sum x^2] of xa if its producer already accumulated them in its
         epilogue (then no moments pass is run here); out_stats: also return the same sums of the output, accumulated by
-        this conv's epilogue, for the next stage.  drop_bias: see in_lrelu_conv."""
+        this conv's epilogue, for the next stage.  drop_bias: see in_lrelu_conv.  sole_consumer: xa is the output of another
+        InLreluConv and nothing else reads it (the inside of a DoubleConv): its gradient may be handed over unwritten
+        (_NB_PENDING)."""
+        ctx.sole = bool(sole_consumer) and xb is None
         weights, biases = list(wb[:nw]), list(wb[nw:])
         n, ca = xa.shape[:2]
         cin = ca + (xb.shape[1] if xb is not None else 0)
@@ -190,31 +213,47 @@ class InLreluConv(Function):
         dy = _blk(dy)
         dws, rws = _targets(ctx.params[0])
         dbs, rbs = _targets(ctx.params[1])
-        ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=groups, pre=(sc, sh, LEAK), side=_direct(*rws, *rbs))
+        need_dx = ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1])
+        nb = _NB_PENDING.pop(dy.data_ptr(), None)          # dy handed over unwritten by the next conv's backward (see above)
+        if nb is not None and not (need_dx and stride == 1):
+            ops.in_bwd_apply(nb[0], nb[1], nb[2], nb[3], nb[4], have_g=True, out=dy)       # nobody to fold it into: write it now
+            nb = None
+        if nb is None:
+            ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=groups, pre=(sc, sh, LEAK), side=_direct(*rws, *rbs))
         dxa = dxb = None
-        if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
+        if need_dx:
             n = xa.shape[0]
             red = ops.zeros_red(xa, n, cin)
             e = (xa, xb, sc, sh, LEAK)
-            if stride == 1:
+            if nb is not None:
+                # the data gradient applies the pending norm backward on load and writes dy; the weight gradient, which reads
+                # dy, is issued behind it
+                g = ops.conv3d(nb[0], None, weights, None, k=k, cout=cin, groups=groups, transposed=True, epi=1, e=e, red=red,
+                               nb=(nb[1], nb[2], nb[3], nb[4], dy))
+                ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=k, stride=stride, groups=groups, pre=(sc, sh, LEAK), side=_direct(*rws, *rbs))
+            elif stride == 1:
                 g = ops.conv3d(dy, None, weights, None, k=k, cout=cin, groups=groups, transposed=True, epi=1, e=e, red=red)
             else:
                 g = ops.conv3d_dgrad_s2(dy, weights, cin=cin, in_spatial=tuple(xa.shape[2:]), groups=groups, e=e, red=red)
             if xb is not None:
                 dxa, dxb = ops.in_bwd_apply2(g, xa, xb, red, mean, rstd, acc_a=_acc(sa), acc_b=_acc(sb))
                 dxa, dxb = _ret(sa, dxa), _ret(sb, dxb)
+            elif ctx.sole and sa is None and ops._NB_FOLD[0]:
+                dxa = torch.empty_like(xa, memory_format=torch.contiguous_format)          # written by whoever takes the entry
+                _NB_PENDING[dxa.data_ptr()] = (g, xa, red, mean, rstd, dxa)
             else:
                 dxa = _ret(sa, ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0, acc=_acc(sa)))
-        return (dxa, dxb, None, None, None, None, None, None, *rws, *rbs)
+        return (dxa, dxb, None, None, None, None, None, None, None, *rws, *rbs)
 
 
-def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, out_stats=False, drop_bias=False):
+def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, out_stats=False, drop_bias=False, sole_consumer=False):
     """drop_bias=True: the caller guarantees that every consumer of the output is an InstanceNorm (which subtracts the
     per-channel mean, so IN(conv + b) == IN(conv) exactly): the bias add is skipped and the tensor is stored without the
     offset.  With 16-bit storage that matters: the reference initialises biases N(0,1) (utils.py:199), and a channel
     stored as `offset + small signal` spends its significant bits on the offset.  The bias still gets its gradient (the sum
     of dY, mathematically zero behind an InstanceNorm -- the reference returns round-off there too)."""
-    return InLreluConv.apply(xa, xb, in_stats, bool(out_stats), stride, groups, len(weights), bool(drop_bias), *weights, *biases)
+    return InLreluConv.apply(xa, xb, in_stats, bool(out_stats), stride, groups, len(weights), bool(drop_bias), bool(sole_consumer),
+                             *weights, *biases)
 
 
 class GnConvRelu(Function):
@@ -303,7 +342,9 @@ class Conv(Function):
     carry one weight tensor each."""
 
     @staticmethod
-    def forward(ctx, x, groups, act, nw, has_bias, out_stats, drop_bias, *wb):
+    def forward(ctx, x, groups, act, nw, has_bias, out_stats, drop_bias, pre_act_grad, *wb):
+        """pre_act_grad: the (single) consumer hands back the gradient of the PRE-activation (GateCat sig_bwd): backward skips the
+        activation's own backward pass."""
         weights = list(wb[:nw])
         biases = list(wb[nw:]) if has_bias else None
         cout = sum(w.shape[0] for w in weights)
@@ -311,6 +352,8 @@ class Conv(Function):
         red_y = ops.zeros_red(x, x.shape[0], cout) if out_stats else None     # output channel sums for the next norm
         y = ops.conv3d(x, None, weights, None if drop_bias else biases, k=k, cout=cout, groups=groups, act=act,
                        epi=2 if out_stats else 0, red=red_y)
+        if pre_act_grad:
+            act = ACT_NONE
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *weights)
         ctx.cfg = (groups, act, nw, has_bias, k)
         ctx.params = (weights, biases)
@@ -333,14 +376,15 @@ class Conv(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True)
-        return (dx, None, None, None, None, None, None, *rws, *rbs)
+        return (dx, None, None, None, None, None, None, None, *rws, *rbs)
 
 
-def conv(x, weights, biases=None, groups=1, act=ACT_NONE, out_stats=False, drop_bias=False):
+def conv(x, weights, biases=None, groups=1, act=ACT_NONE, out_stats=False, drop_bias=False, pre_act_grad=False):
     """drop_bias: as in in_lrelu_conv (output consumed only by InstanceNorm; needs act == ACT_NONE)."""
     if drop_bias and act != ACT_NONE:
         raise ValueError("drop_bias needs a linear output")
-    return Conv.apply(x, groups, act, len(weights), biases is not None, bool(out_stats), bool(drop_bias), *weights, *(biases or []))
+    return Conv.apply(x, groups, act, len(weights), biases is not None, bool(out_stats), bool(drop_bias), bool(pre_act_grad),
+                      *weights, *(biases or []))
 
 
 class MaxPool2(Function):
@@ -469,8 +513,11 @@ class GateCat(Function):
     """cat[a*(1+E[:,0]), b*(1+E[:,1])] (buildingblocks.py:287,297-299)."""
 
     @staticmethod
-    def forward(ctx, a, b, E, stats=False):
-        """stats: also return the (n, C, 2) fp64 channel sums of the output (the next conv's InstanceNorm: no moments pass)."""
+    def forward(ctx, a, b, E, stats=False, sig_bwd=False):
+        """stats: also return the (n, C, 2) fp64 channel sums of the output (the next conv's InstanceNorm: no moments pass).
+        sig_bwd: E comes from conv(..., act=ACT_SIGMOID, pre_act_grad=True): backward returns the gradient of the sigmoid's
+        PRE-activation for it (one pass instead of gate backward + sigmoid backward)."""
+        ctx.sig_bwd = bool(sig_bwd)
         red = ops.zeros_red(a, a.shape[0], a.shape[1] + b.shape[1]) if stats else None
         out = ops.gate2(a, b, E, red)                          # both halves of the concat in one launch
         ctx.save_for_backward(a, b, E)
@@ -485,8 +532,8 @@ class GateCat(Function):
     def backward(ctx, dout, *_):
         a, b, E = ctx.saved_tensors
         sa, sb = ctx.slots
-        da, db, dE = ops.gate2_bwd(a, b, E, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb))
-        return _ret(sa, da), _ret(sb, db), dE, None
+        da, db, dE = ops.gate2_bwd(a, b, E, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb), sig_bwd=ctx.sig_bwd)
+        return _ret(sa, da), _ret(sb, db), dE, None, None
 
 
 class Gate(Function):

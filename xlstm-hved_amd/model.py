@@ -305,6 +305,7 @@ class AbstractFusion3DUNet(nn.Module):
         """The input-only part: per-level DRB outputs (4 streams x [mu | logvar] before PoE) and the skip-return feature."""
         batched = self.layer_order == "ilc"     # 'ilc' runs the 4 modality streams as one grouped launch per stage
         ops.red_arena_reset(x.device)
+        Fn.nb_pending_clear()                   # (entries an aborted backward left behind)
         ops.prepack_all()                       # the MFMA weight fragments of every k=3 conv of the step: one launch per 24
         x = x.contiguous()
         st0 = None
@@ -336,7 +337,7 @@ class AbstractFusion3DUNet(nn.Module):
                 X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0 if level == 0 else stp, out_stats=True,
                                          drop_bias=True)                  # consumed by SingleConv2's InstanceNorm only
                 w, b = self._stream_weights(level, "SingleConv2")
-                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st, out_stats=True)
+                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st, out_stats=True, sole_consumer=True)
                 drb = [m[0].conv for m in self.DRBs[level]]
                 # this level's output feeds its DRB and (gated, pooled) the next level: two consumers, one gradient buffer
                 X_drb, X = Fn.fanout(X, 2) if (level + 1 < levels and self.skip_return) else (X, X)

@@ -333,13 +333,34 @@ def _check_weights(weights, biases, cin, cout, groups, k, transposed, what):
             raise ValueError(f"{what}: bias shape {tuple(b.shape)}, expected {(cout // nw,)}")
 
 
+NB_PENDING = {}        # functional.InLreluConv: gradients handed over unwritten, by address (see functional._NB_PENDING)
+_NB_FOLD = [os.environ.get("XH_NO_NB_FOLD", "") == ""]      # A/B switch: the InstanceNorm backward folded into the consuming data gradient
+
+
+def set_norm_bwd_fold(enabled):
+    _NB_FOLD[0] = bool(enabled)
+
+
 def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=False, pre=None, act=ACT_NONE,
-           act_slope=LEAK, epi=0, e=None, red=None, out=None, in_stats=None):
+           act_slope=LEAK, epi=0, e=None, red=None, out=None, in_stats=None, nb=None):
     """y = act(conv(pre(cat[xa, xb])) + b) [+ fused epilogue].  weights/biases: lists of 1 or `groups` fp32 tensors.
     pre = (sc, sh, slope); e = (ea, eb, e_sc, e_sh, e_slope) for epi==1.  `out` may be a channel slice.
     in_stats = (red, count, slope) instead of pre: InstanceNorm + LeakyReLU of the input from its raw channel sums; returns
-    (y, sc, sh, mean, rstd).  On the MFMA path the finalisation rides on the weight-pack launch, else xh_norm_finalize runs."""
+    (y, sc, sh, mean, rstd).  On the MFMA path the finalisation rides on the weight-pack launch, else xh_norm_finalize runs.
+    nb = (px, nb_red, mean, rstd, pd): xa is the masked data gradient g of the stage behind this conv and the conv's real input
+    is that stage's InstanceNorm backward, A*g + C*px + B (xh_conv_desc.pre == 2): applied on load where the kernel can, and
+    stored into `pd` (a tensor of xa's shape) either way -- by this launch, or by an xh_in_bwd_apply pass in front of it."""
     lib = L.load()
+    if nb is not None:
+        px, nb_red, nb_mean, nb_rstd, pd = nb
+        if xb is not None or pre is not None or in_stats is not None:
+            raise ValueError("conv3d: nb excludes xb / pre / in_stats")
+        dsc = _conv_desc(xa, None, k, stride, groups, cout, len(weights), transposed, None, act, act_slope, epi, e, 0,
+                         _out_spatial(*xa.shape[2:], k, stride))
+        dsc.pre, dsc.px_bs, dsc.pd_bs = 2, _vol(px)[5], _vol(pd)[5]
+        if not (_NB_FOLD[0] and _MFMA[0] and lib.xh_conv3d_fuses_norm_bwd(C.byref(dsc))):
+            in_bwd_apply(xa, px, nb_red, nb_mean, nb_rstd, have_g=True, out=pd)
+            xa, nb = pd, None
     n, ca, d, h, w, _ = _vol(xa)
     _check_weights(weights, biases, ca + (xb.shape[1] if xb is not None else 0), cout, groups, k, transposed, "conv3d")
     osp = _out_spatial(d, h, w, k, stride)
@@ -356,6 +377,11 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     desc = _conv_desc(xa, xb, k, stride, groups, cout, len(weights), transposed, pre, act, act_slope, epi, e, y_bs, osp)
     ptrs = L.ConvPtrs()
     ptrs.xa, ptrs.xb = _p(xa), _p(xb)
+    if nb is not None:
+        desc.pre, desc.px_bs, desc.pd_bs = 2, _vol(px)[5], _vol(pd)[5]
+        ptrs.px, ptrs.pd = _p(px), _p(pd)
+        ptrs.nb_red, ptrs.nb_mean, ptrs.nb_rstd = _p(nb_red), _p(_f32(nb_mean, "nb_mean")), _p(_f32(nb_rstd, "nb_rstd"))
+        ptrs.nb_count = d * h * w
     ptrs.w = _arr4([_f32(t, "conv weight") for t in weights])
     ptrs.b = _arr4([_f32(t, "conv bias") for t in (biases or [])])
     if pre is not None:
@@ -465,6 +491,11 @@ def _flush_wgrads():
 def join_wgrad_stream():
     """Launches what is still pending and orders the compute stream behind every weight-gradient launch issued on the
     side stream since the last join."""
+    if NB_PENDING:
+        n_left = len(NB_PENDING)
+        NB_PENDING.clear()
+        raise RuntimeError(f"{n_left} norm-backward hand-over(s) were never taken: a gradient tensor of this backward pass was left "
+                           "unwritten (functional.InLreluConv); ops.set_norm_bwd_fold(False) disables the hand-over")
     _flush_deferred()
     _flush_wgrads()
     for dev in list(_WG["forked"]):
@@ -684,13 +715,14 @@ def norm_bwd_fused(mode, dy, x, red, mean, rstd, *, gs=1, gamma=None, dgamma=Non
     return out
 
 
-def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK, c0=0, acc=None):
+def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK, c0=0, acc=None, out=None):
     """InstanceNorm backward of x's channels (window starting at c0 of dy / the statistics) in one launch.  `acc`: an existing
-    gradient buffer of x's shape to ADD the result to (functional.GradSlot) instead of a new tensor."""
+    gradient buffer of x's shape to ADD the result to (functional.GradSlot) instead of a new tensor; `out`: a tensor to write."""
     n, c, d, h, w, bs = _vol(x)
     rs = mean.shape[1]
     dyv = dy[:, c0:c0 + c] if dy.shape[1] != c else dy
-    out = acc if acc is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
+    if out is None:
+        out = acc if acc is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
     off = lambda t, scale=1: None if t is None else t.data_ptr() + c0 * scale * t.element_size()
     L.check(L.load().xh_in_bwd_apply(_stream(), _dt(x), _p(dyv), _vol(dyv)[5], _p(x), bs, _p(out), _vol(out)[5], n, c,
                                      d * h * w, off(red, 2), off(mean), off(rstd), rs, int(have_g), off(sc), off(sh), slope,
@@ -916,7 +948,8 @@ def gate2(a, b, E, red=None):
     return y
 
 
-def gate2_bwd(a, b, E, dy, acc_a=None, acc_b=None):
+def gate2_bwd(a, b, E, dy, acc_a=None, acc_b=None, sig_bwd=False):
+    """sig_bwd: E is a sigmoid's output; dE comes back as the gradient of the pre-activation (dE * E * (1 - E))."""
     n, ca, d, h, w, bsa = _vol(a)
     cb, bsb = b.shape[1], _vol(b)[5]
     da = acc_a if acc_a is not None else new_like(a, (n, ca, d, h, w))
@@ -924,7 +957,7 @@ def gate2_bwd(a, b, E, dy, acc_a=None, acc_b=None):
     dE = torch.empty_like(E, memory_format=torch.contiguous_format)
     L.check(L.load().xh_gate2_bwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(E), _vol(E)[5], _p(dy), _vol(dy)[5], _p(da),
                                   _vol(da)[5], int(acc_a is not None), _p(db), _vol(db)[5], int(acc_b is not None), _p(dE), _vol(dE)[5],
-                                  n, d * h * w), "xh_gate2_bwd")
+                                  n, d * h * w, int(bool(sig_bwd))), "xh_gate2_bwd")
     return da, db, dE
 
 
