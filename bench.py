@@ -789,6 +789,7 @@ def roofline_pass(step, ops, nsteps, dtype):
         seen[key] = seen.get(key, 0) + 1
         per_call.setdefault(key, []).append((max(e0.elapsed_time(e1) - overhead_ms * nl, 1e-3), nbytes, flops, nl))
     agg = {}
+    shape_us = {}                                             # mean bracket per launch of a (kernel, shape), us
     for (name, shape), calls in per_call.items():
         per_step = len(calls) // nsteps if len(calls) % nsteps == 0 else 0
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, {}])
@@ -802,6 +803,7 @@ def roofline_pass(step, ops, nsteps, dtype):
         a[2] += sum(c[1] for c in calls)
         a[3] += sum(c[2] for c in calls)
         a[4][shape] = a[4].get(shape, 0) + sum(c[3] for c in calls)
+        shape_us[(name, shape)] = sum(c[0] for c in calls) / max(sum(c[3] for c in calls), 1) * 1e3
     ops.set_wgrad_overlap(overlap_was)
     total_ms = sum(a[1] for a in agg.values())
     step_ms = sorted(a.elapsed_time(b) for a, b in whole)[len(whole) // 2]      # one instrumented step, back to back on the device
@@ -829,6 +831,7 @@ def roofline_pass(step, ops, nsteps, dtype):
               "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)",
               "kernel": name, "launches_per_step": cnt / nsteps, "avg_launch_us": avg_ms * 1e3,
               "shapes": {k: v / nsteps for k, v in shapes.items()},
+              "shape_avg_us": {k: round(shape_us[(name, k)], 1) for k in shapes},
               "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
               "arithmetic_intensity_flop_per_byte": flops / nbytes, "tflops": tfl,
               "share_of_conv_time": ms_sum / total_ms, "conv_time_per_step_ms": total_ms / nsteps,
@@ -839,8 +842,9 @@ def roofline_pass(step, ops, nsteps, dtype):
               "non_conv_ms_per_step": max(step_ms - total_ms / nsteps - n_brackets * overhead_ms, 0.0),
               "elementwise_ms_per_step": elementwise_from_profile(),
               "other_conv_kernels": {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3,
-                                          "GBps": v[2] / v[1] / 1e6, "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()}}
-                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:8]},
+                                          "GBps": v[2] / v[1] / 1e6, "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()},
+                                          "shape_avg_us": {a_: round(shape_us[(k, a_)], 1) for a_ in v[4]}}
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:12]},
               "event_pair_overhead_us": overhead_ms * 1e3, "host_enqueue_ms_per_step": host_ms, "device_delay_ms": delay_ms,
               "timing": "HIP events on the launch stream around each launch of the real step (queued behind a device-side "
                         "delay so launches run back to back as in the graph replay), minus the median empty event pair; weight "

@@ -237,6 +237,17 @@ int xh_norm_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, 
 int xh_norm_bwd_fused(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs,
                       void* dx, long long dx_bs, int N, int C, long long DHW, const double* red, int gs,
                       const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta);
+/* Two BatchNorm3d modules over the two channel halves of ONE tensor -- DuSEAttention's bn_fuse_ch1 / bn_fuse_ch2 applied to the
+ * recon | seg pair in one launch each way (modules/DuSFE.py:151-154): channels [0, Chalf) take the first parameter set,
+ * [Chalf, C) the second (its arrays indexed from 0).  Otherwise xh_bn_affine_act / xh_norm_bwd_fused (mode 1 | 2). */
+int xh_bn_affine_act2(void* stream, int dtype, int mode, const void* x, long long x_bs, void* y, long long y_bs, int N, int C, int Chalf,
+                      long long DHW, const double* red, float eps, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, const float* gamma2, const float* beta2, float* running_mean2, float* running_var2, int steps,
+                      int act, float slope, float* sc, float* sh, float* mean, float* rstd);
+int xh_norm_bwd_fused2(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs, void* dx,
+                       long long dx_bs, int N, int C, int Chalf, long long DHW, const double* red, const float* gamma,
+                       const float* gamma2, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dgamma2,
+                       float* dbeta2);
 /* InstanceNorm backward in one launch (autograd of nn.InstanceNorm3d in create_conv, buildingblocks.py:431, and in BasicConv,
  * buildingblocks.py:21-24): coefficients derived per (n, c) row from the raw sums red = (sum g, sum g*x) of
  * xh_act_bwd_reduce / the conv epilogue, and the forward's mean / rstd.  red, mean, rstd (and sc, sh when have_g == 0)

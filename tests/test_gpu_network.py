@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_common import check, load, rel_err, rnd
+from gpu_common import check, l2_err, load, rel_err, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -741,3 +741,44 @@ def test_two_backward_passes_over_one_forward_retain_graph():
     cw = max((ga[k] - gb[k]).abs().max().item() / scale for k in composed)
     print(f"retain_graph: worst parameter-gradient difference {worst:.2e} ({worst_k}); composed-tensor parameters {cw:.2e}")
     assert worst < 5e-5, (worst_k, worst)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("size", [32, 64])
+def test_recon_seg_pair_launches_equal_the_per_stream_decoder(dtype, size):
+    """The shared decoder with its recon | seg pair launches (model._forward_pair: one upsampling / second conv / DuSE gate /
+    BatchNorm launch for both streams, N == 1) against the per-stream decoder (ops.set_pair(False)): same loss, same outputs,
+    same parameter gradients and BatchNorm buffers.  fp32: to the order of the atomics; bf16: the pair path rounds the same
+    values (every kernel computes per element exactly what its one-stream launch does), so it is held to the same band."""
+    torch.manual_seed(35)
+    x = torch.rand(1, 4, size, size, size)
+    eps = [torch.randn(1, 2 ** l, size >> (l + 1), size >> (l + 1), size >> (l + 1)) for l in range(4)]
+    res = []
+    for on in (False, True):
+        X.ops.set_pair(on)
+        try:
+            m = _model(True)
+            seg, (mu, lv), rec = m(x.to(DEV, dtype), [14], recon=True, eps_list=eps)
+            loss = (seg.float() * rnd(seg.shape, 300).to(DEV)).mean() + (rec[0].float() * rnd(rec[0].shape, 301).to(DEV)).mean()
+            for a_, b_ in zip(mu, lv):
+                loss = loss + a_.float().mean() + b_.float().mean()
+            loss.backward()
+            X.ops.join_wgrad_stream()
+            torch.cuda.synchronize()
+            res.append((loss.item(), seg.detach().float(), rec[0].detach().float(),
+                        {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                        {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}))
+        finally:
+            X.ops.set_pair(True)
+    (la, sa, ra, ga, ba), (lb, sb, rb, gb, bb) = res
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert abs(la - lb) <= tol * max(1.0, abs(la)), (la, lb)
+    assert l2_err(sb, sa) <= tol and l2_err(rb, ra) <= tol
+    assert ga.keys() == gb.keys()
+    scale = max(v.abs().max().item() for v in ga.values())
+    wk, worst = max(((k, (ga[k] - gb[k]).abs().max().item() / scale) for k in ga), key=lambda t: t[1])
+    bworst = max((ba[k] - bb[k]).abs().max().item() for k in ba)
+    print(f"pair vs per-stream decoder ({dtype}, {size}^3): loss {la:.6f} / {lb:.6f}, worst parameter-gradient difference {worst:.2e} ({wk}), "
+          f"BatchNorm buffers {bworst:.2e}")
+    assert worst <= (5e-5 if dtype == torch.float32 else 0.2), (wk, worst)
+    assert bworst <= (1e-5 if dtype == torch.float32 else 2e-2)

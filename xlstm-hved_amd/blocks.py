@@ -385,6 +385,21 @@ class DuSEAttention(nn.Module):
             bn_tick(b2, 1)
         return out
 
+    def forward_pair(self, pair, stats):
+        """forward() on the recon | seg pair [inp_ch1 | inp_ch2] (1, 2C, ...) with its channel sums (1, 2C, 2); returns the pair
+        of outputs (Fn.DuSE2: one launch per gate / BatchNorm pass for both streams)."""
+        c = pair.shape[1] // 2
+        pre = self.__dict__.get("_pre")
+        sqw, sqb, adjw, adjb = pre if pre is not None else Fn.ComposeDuSE.apply(c, *self.compose_params())
+        b1, b2 = self.bn_fuse_ch1, self.bn_fuse_ch2
+        out = Fn.DuSE2.apply(pair, stats, self.training, b1.running_mean, b1.running_var, b2.running_mean, b2.running_var,
+                             self.fc_comb.weight, self.fc_comb.bias, self.fc_ch1.weight, self.fc_ch1.bias, self.fc_ch2.weight,
+                             self.fc_ch2.bias, sqw, sqb, adjw, adjb, b1.weight, b1.bias, b2.weight, b2.bias)
+        if self.training:
+            bn_tick(b1, 1)
+            bn_tick(b2, 1)
+        return out
+
 
 # --------------------------------------------------------------------------------------------- skip-return attention
 class ConvNorm(nn.Module):

@@ -195,6 +195,8 @@ struct AffFin {
   const double* red; int N; double count; float eps;
   const float* gamma; const float* beta; float* running_mean; float* running_var; int steps;
   float* o_sc; float* o_sh; float* o_mean; float* o_rstd;
+  // two BatchNorm modules over one tensor (xh_bn_affine_act2): channels >= chalf take the second parameter set, indexed from 0
+  int chalf; const float* gamma2; const float* beta2; float* running_mean2; float* running_var2;
 };
 template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
@@ -210,25 +212,31 @@ __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long l
     if (writer) { f.o_sc[nc] = a; f.o_sh[nc] = b; f.o_mean[nc] = m; f.o_rstd[nc] = r; }
   } else if (f.mode > 0) {
     double mean, var;
+    const bool second = f.chalf > 0 && cc >= f.chalf;
+    const int pc = second ? cc - f.chalf : cc;          // index into the module's own parameter arrays
+    const float* gam = second ? f.gamma2 : f.gamma;
+    const float* bet = second ? f.beta2 : f.beta;
+    float* rmean = second ? f.running_mean2 : f.running_mean;
+    float* rvar = second ? f.running_var2 : f.running_var;
     if (f.mode == 1) {
       double s0 = 0, s1 = 0;
       for (int k = 0; k < f.N; ++k) { s0 += f.red[((long long)k * C + cc) * 2]; s1 += f.red[((long long)k * C + cc) * 2 + 1]; }
       const double M = f.count * f.N;
       mean = s0 / M;
       var = s1 / M - mean * mean;
-      if (writer && blockIdx.z == 0 && f.running_mean && f.running_var) {
+      if (writer && blockIdx.z == 0 && rmean && rvar) {
         const double keep = pow(0.9, (double)f.steps);
         const double unb = var * M / (M > 1 ? M - 1 : 1);
-        f.running_mean[cc] = (float)(keep * f.running_mean[cc] + (1 - keep) * mean);
-        f.running_var[cc] = (float)(keep * f.running_var[cc] + (1 - keep) * unb);
+        rmean[pc] = (float)(keep * rmean[pc] + (1 - keep) * mean);
+        rvar[pc] = (float)(keep * rvar[pc] + (1 - keep) * unb);
       }
     } else {
-      mean = f.running_mean[cc];
-      var = f.running_var[cc];
+      mean = rmean[pc];
+      var = rvar[pc];
     }
     if (var < 0) var = 0;
     const double rstd = 1.0 / sqrt(var + (double)f.eps);
-    const double ga = f.gamma ? (double)f.gamma[cc] : 1.0, be = f.beta ? (double)f.beta[cc] : 0.0;
+    const double ga = gam ? (double)gam[pc] : 1.0, be = bet ? (double)bet[pc] : 0.0;
     a = (float)(rstd * ga);
     b = (float)(be - mean * rstd * ga);
     if (writer) { f.o_sc[nc] = a; f.o_sh[nc] = b; f.o_mean[nc] = (float)mean; f.o_rstd[nc] = (float)rstd; }
@@ -286,6 +294,23 @@ extern "C" int xh_bn_affine_act(void* stream, int dtype, int mode, const void* x
   AffFin f{};
   f.mode = mode; f.red = red; f.N = N; f.count = (double)DHW; f.eps = eps;
   f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var; f.steps = steps;
+  f.o_sc = sc; f.o_sh = sh; f.o_mean = mean; f.o_rstd = rstd;
+  return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, nullptr, nullptr, act, slope, f);
+}
+
+// Two BatchNorm modules over the two channel halves of ONE tensor (DuSEAttention's bn_fuse_ch1 / bn_fuse_ch2 on the recon | seg
+// pair, modules/DuSFE.py:151-154): channels [0, Chalf) use the first parameter set, [Chalf, C) the second.
+extern "C" int xh_bn_affine_act2(void* stream, int dtype, int mode, const void* x, long long x_bs, void* y, long long y_bs, int N, int C,
+                                 int Chalf, long long DHW, const double* red, float eps, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, const float* gamma2, const float* beta2, float* running_mean2,
+                                 float* running_var2, int steps, int act, float slope, float* sc, float* sh, float* mean, float* rstd) {
+  if ((mode != 1 && mode != 2) || !sc || !sh || !mean || !rstd || Chalf <= 0 || Chalf >= C) return XH_ERR_ARG;
+  if (mode == 1 && !red) return XH_ERR_ARG;
+  if (mode == 2 && (!running_mean || !running_var || !running_mean2 || !running_var2)) return XH_ERR_ARG;
+  AffFin f{};
+  f.mode = mode; f.red = red; f.N = N; f.count = (double)DHW; f.eps = eps;
+  f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var; f.steps = steps;
+  f.chalf = Chalf; f.gamma2 = gamma2; f.beta2 = beta2; f.running_mean2 = running_mean2; f.running_var2 = running_var2;
   f.o_sc = sc; f.o_sh = sh; f.o_mean = mean; f.o_rstd = rstd;
   return launch_affine_act(stream, dtype, x, x_bs, y, y_bs, N, C, DHW, nullptr, nullptr, act, slope, f);
 }
@@ -425,9 +450,12 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(EW_BLOCK) void norm_bwd_fused_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs, T* dx,
                                                                  long long dx_bs, int mode, const double* red, int N, int C,
                                                                  long long dhw, int gs, const float* gamma, const float* mean,
-                                                                 const float* rstd, float* dgamma, float* dbeta) {
+                                                                 const float* rstd, float* dgamma, float* dbeta, int chalf,
+                                                                 const float* gamma2, float* dgamma2, float* dbeta2) {
   const int cc = blockIdx.y, nn = blockIdx.z;
   const int i0 = nn * C + cc;
+  // chalf > 0 (BatchNorm modes only): two modules over the channel halves, the second one's arrays indexed from 0
+  if (chalf > 0 && cc >= chalf) { gamma = gamma2 ? gamma2 - chalf : nullptr; dgamma = dgamma2 ? dgamma2 - chalf : nullptr; dbeta = dbeta2 ? dbeta2 - chalf : nullptr; }
   const double ga = gamma ? (double)gamma[cc] : 1.0;
   const double mu = mean[i0], rs = rstd[i0];
   auto P_of = [&](int k) { return (double)rstd[k] * (red[k * 2 + 1] - (double)mean[k] * red[k * 2]); };
@@ -470,22 +498,39 @@ __global__ __launch_bounds__(EW_BLOCK) void norm_bwd_fused_kernel(const T* dy, l
   ROW_LOOP_END
 }
 
-extern "C" int xh_norm_bwd_fused(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs,
+static int launch_norm_bwd_fused(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs,
                                  void* dx, long long dx_bs, int N, int C, long long DHW, const double* red, int gs,
-                                 const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta) {
+                                 const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, int chalf,
+                                 const float* gamma2, float* dgamma2, float* dbeta2) {
   if (mode < 1 || mode > 3 || !dy || !x || !dx || !red || !mean || !rstd || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535)
     return XH_ERR_ARG;
   if (mode == 3 && (gs <= 0 || C % gs)) return XH_ERR_ARG;
+  if (chalf && (mode == 3 || chalf < 0 || chalf >= C)) return XH_ERR_ARG;
   if (mode != 3) gs = 1;
   const bool vec32 = vec_ok<float>(DHW, {dy_bs, x_bs, dx_bs}), vec16 = vec_ok<bf16_t>(DHW, {dy_bs, x_bs, dx_bs});
   const dim3 grid32 = row_grid<float>(DHW, C, N), grid16 = row_grid<bf16_t>(DHW, C, N);
-#define NB(T, V, G) hipLaunchKernelGGL((norm_bwd_fused_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)dy, dy_bs, (const T*)x, x_bs, (T*)dx, dx_bs, mode, red, N, C, DHW, gs, gamma, mean, rstd, dgamma, dbeta)
+#define NB(T, V, G) hipLaunchKernelGGL((norm_bwd_fused_kernel<T, V>), G, dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)dy, dy_bs, (const T*)x, x_bs, (T*)dx, dx_bs, mode, red, N, C, DHW, gs, gamma, mean, rstd, dgamma, dbeta, chalf, gamma2, dgamma2, dbeta2)
   if (dtype == XH_F32) { if (vec32) NB(float, true, grid32); else NB(float, false, grid32); }
   else if (dtype == XH_BF16) { if (vec16) NB(bf16_t, true, grid16); else NB(bf16_t, false, grid16); }
   else if (dtype == XH_F16) { if (vec16) NB(f16_t, true, grid16); else NB(f16_t, false, grid16); }
   else return XH_ERR_DTYPE;
 #undef NB
   return xh_launch_status();
+}
+extern "C" int xh_norm_bwd_fused(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                                 void* dx, long long dx_bs, int N, int C, long long DHW, const double* red, int gs,
+                                 const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta) {
+  return launch_norm_bwd_fused(stream, dtype, mode, dy, dy_bs, x, x_bs, dx, dx_bs, N, C, DHW, red, gs, gamma, mean, rstd, dgamma, dbeta, 0,
+                               nullptr, nullptr, nullptr);
+}
+// BatchNorm backward of two modules over the channel halves of one tensor (see xh_bn_affine_act2); mode 1 | 2.
+extern "C" int xh_norm_bwd_fused2(void* stream, int dtype, int mode, const void* dy, long long dy_bs, const void* x, long long x_bs,
+                                  void* dx, long long dx_bs, int N, int C, int Chalf, long long DHW, const double* red,
+                                  const float* gamma, const float* gamma2, const float* mean, const float* rstd, float* dgamma,
+                                  float* dbeta, float* dgamma2, float* dbeta2) {
+  if (Chalf <= 0) return XH_ERR_ARG;
+  return launch_norm_bwd_fused(stream, dtype, mode, dy, dy_bs, x, x_bs, dx, dx_bs, N, C, DHW, red, 1, gamma, mean, rstd, dgamma, dbeta, Chalf,
+                               gamma2, dgamma2, dbeta2);
 }
 
 // InstanceNorm flavour with the coefficient step folded in: every workgroup derives A, B, C of its (n, c) row from the

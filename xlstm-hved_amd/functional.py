@@ -81,10 +81,46 @@ def _targets(params):
 # accumulate flag) and return None; Fanout.backward -- which autograd runs after ALL consumers -- returns the buffer and adds
 # whatever a consumer that does not know about slots returned on its own.  Everything is ordered on one stream.
 class GradSlot:
-    __slots__ = ("buf",)
+    __slots__ = ("buf", "dest")
 
-    def __init__(self):
+    def __init__(self, dest=None):
         self.buf = None
+        self.dest = dest          # (TwinDest, half) or None: where the FIRST consumer writes (instead of a new tensor)
+
+
+class TwinDest:
+    """Gradient buffer of a recon | seg pair (1, 2C, ...) whose two halves are produced by different consumers: the consumers
+    that know the protocol WRITE their half here (`_out` / `_dst`), so the producer's backward (Upsample2, Split2) finds both
+    halves side by side and runs ONE launch over the pair; anything else handed back is copied in (correct, one pass more).
+    Allocated at the first request of a backward pass."""
+
+    def __init__(self, shape, c, dtype, device):
+        self.shape, self.c, self.dtype, self.device, self.buf = tuple(shape), c, dtype, device, None
+
+    def half(self, i):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        return self.buf[:, i * self.c:(i + 1) * self.c]
+
+    def joined(self, ga, gb):
+        for i, g in enumerate((ga, gb)):
+            h = self.half(i)
+            if g is None:
+                h.zero_()
+            elif g.data_ptr() != h.data_ptr():
+                ops.add(_blk(g), None, out=h)
+        buf, self.buf = self.buf, None          # a retained graph's next backward pass gets a buffer of its own
+        return buf
+
+
+def _dst(d):
+    """The tensor a (TwinDest, half) pair stands for, or None."""
+    return d[0].half(d[1]) if d is not None else None
+
+
+def _out(slot):
+    """Where the FIRST consumer of a slot writes: the slot's destination half, or None (= a new tensor)."""
+    return _dst(slot.dest) if (slot is not None and slot.buf is None) else None
 
 
 class Fanout(Function):
@@ -113,7 +149,7 @@ def fanout(x, n):
     """n aliases of x whose consumers share one gradient buffer (see above).  set_fanout(False): plain x, n times (A/B)."""
     if not _FANOUT[0] or not x.requires_grad:
         return (x,) * n
-    slot = GradSlot()
+    slot = GradSlot(getattr(x, "_xh_dest", None))      # the aliases' shared buffer lands where x's gradient is wanted
     outs = Fanout.apply(x, n, slot)
     for o in outs:
         o._xh_slot = slot
@@ -164,12 +200,17 @@ def nb_pending_clear():
         _NB_PENDING.clear()
 
 
+NB_FOLD_MAX = 1 << 22       # elements of the handed-over tensor up to which the fold pays (measured on MI355X: 16 ch @64^3 gains 4 us,
+                            # 4 ch @128^3 loses 5 us, 16 ch @128^3 loses 9 us -- the element-wise pass streams at 6 TB/s, the conv at 3.3)
+
+
 class InLreluConv(Function):
     """SingleConv 'ilc' (buildingblocks.py:406-433,440-461): Conv3d(LeakyReLU(InstanceNorm3d(x))) + bias, k=3.
 
     Inputs may be a virtual concat (xa | xb) -- the decoder's torch.cat((enc, x), 1) at buildingblocks.py:732 --
     and may be `groups` independent streams with one weight tensor per group (the 4 modality encoders,
     RA_HVED.py:548-553, batched along channels)."""
+    _into = None
 
     @staticmethod
     def forward(ctx, xa, xb, in_stats, out_stats, stride, groups, nw, drop_bias, sole_consumer, *wb):
@@ -179,6 +220,9 @@ class InLreluConv(Function):
         InLreluConv and nothing else reads it (the inside of a DoubleConv): its gradient may be handed over unwritten
         (_NB_PENDING)."""
         ctx.sole = bool(sole_consumer) and xb is None
+        into = InLreluConv._into                  # (y destination, sums destination) set by in_lrelu_conv(into=...)
+        InLreluConv._into = None
+        ctx.dests = (getattr(xa, "_xh_dest", None), getattr(xb, "_xh_dest", None) if xb is not None else None)
         weights, biases = list(wb[:nw]), list(wb[nw:])
         n, ca = xa.shape[:2]
         cin = ca + (xb.shape[1] if xb is not None else 0)
@@ -192,9 +236,10 @@ class InLreluConv(Function):
                 ops.moments(xa, red, 0)
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
-        red_y = ops.zeros_red(xa, n, cout) if out_stats else None
+        red_y = (into[1] if into is not None else ops.zeros_red(xa, n, cout)) if out_stats else None
         y, sc, sh, mean, rstd = ops.conv3d(xa, xb, weights, None if drop_bias else biases, k=k, cout=cout, stride=stride,
-                                           groups=groups, in_stats=(red, _dhw(xa), LEAK), epi=2 if out_stats else 0, red=red_y)
+                                           groups=groups, in_stats=(red, _dhw(xa), LEAK), epi=2 if out_stats else 0, red=red_y,
+                                           out=into[0] if into is not None else None)
         ctx.save_for_backward(xa, xb, sc, sh, mean, rstd, *weights)
         ctx.cfg = (stride, groups, nw, k, cin, ca)
         ctx.params = (weights, biases)
@@ -236,9 +281,11 @@ class InLreluConv(Function):
             else:
                 g = ops.conv3d_dgrad_s2(dy, weights, cin=cin, in_spatial=tuple(xa.shape[2:]), groups=groups, e=e, red=red)
             if xb is not None:
-                dxa, dxb = ops.in_bwd_apply2(g, xa, xb, red, mean, rstd, acc_a=_acc(sa), acc_b=_acc(sb))
+                da_, db_ = ctx.dests
+                dxa, dxb = ops.in_bwd_apply2(g, xa, xb, red, mean, rstd, acc_a=_acc(sa), acc_b=_acc(sb),
+                                             out_a=_out(sa) if sa is not None else _dst(da_), out_b=_out(sb) if sb is not None else _dst(db_))
                 dxa, dxb = _ret(sa, dxa), _ret(sb, dxb)
-            elif ctx.sole and sa is None and ops._NB_FOLD[0]:
+            elif ctx.sole and sa is None and ops._NB_FOLD[0] and xa.numel() <= NB_FOLD_MAX:
                 dxa = torch.empty_like(xa, memory_format=torch.contiguous_format)          # written by whoever takes the entry
                 _NB_PENDING[dxa.data_ptr()] = (g, xa, red, mean, rstd, dxa)
             else:
@@ -246,14 +293,20 @@ class InLreluConv(Function):
         return (dxa, dxb, None, None, None, None, None, None, None, *rws, *rbs)
 
 
-def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, out_stats=False, drop_bias=False, sole_consumer=False):
+def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, out_stats=False, drop_bias=False, sole_consumer=False,
+                  into=None):
     """drop_bias=True: the caller guarantees that every consumer of the output is an InstanceNorm (which subtracts the
     per-channel mean, so IN(conv + b) == IN(conv) exactly): the bias add is skipped and the tensor is stored without the
     offset.  With 16-bit storage that matters: the reference initialises biases N(0,1) (utils.py:199), and a channel
     stored as `offset + small signal` spends its significant bits on the offset.  The bias still gets its gradient (the sum
-    of dY, mathematically zero behind an InstanceNorm -- the reference returns round-off there too)."""
-    return InLreluConv.apply(xa, xb, in_stats, bool(out_stats), stride, groups, len(weights), bool(drop_bias), bool(sole_consumer),
-                             *weights, *biases)
+    of dY, mathematically zero behind an InstanceNorm -- the reference returns round-off there too).
+    into: (y, sums) destinations -- channel slices of a pair buffer the caller owns (the decoder's recon | seg pair)."""
+    InLreluConv._into = into
+    try:
+        return InLreluConv.apply(xa, xb, in_stats, bool(out_stats), stride, groups, len(weights), bool(drop_bias), bool(sole_consumer),
+                                 *weights, *biases)
+    finally:
+        InLreluConv._into = None
 
 
 class GnConvRelu(Function):
@@ -356,6 +409,7 @@ class Conv(Function):
             act = ACT_NONE
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *weights)
         ctx.cfg = (groups, act, nw, has_bias, k)
+        ctx.dest = getattr(x, "_xh_dest", None)
         ctx.params = (weights, biases)
         if out_stats:
             ctx.mark_non_differentiable(red_y)
@@ -375,7 +429,7 @@ class Conv(Function):
         ops.conv3d_wgrad(x, None, dy, dws, dbs, k=k, groups=groups, side=_direct(*rws, *rbs))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True)
+            dx = ops.conv3d(dy, None, weights, None, k=k, cout=x.shape[1], groups=groups, transposed=True, out=_dst(ctx.dest))
         return (dx, None, None, None, None, None, None, None, *rws, *rbs)
 
 
@@ -505,7 +559,7 @@ class ChannelPool2(Function):
     def backward(ctx, dout):
         a, b = ctx.saved_tensors
         sa, sb = ctx.slots
-        da, db = ops.channel_pool2_bwd(a, b, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb))
+        da, db = ops.channel_pool2_bwd(a, b, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb), out_a=_out(sa))
         return _ret(sa, da), _ret(sb, db)
 
 
@@ -532,7 +586,7 @@ class GateCat(Function):
     def backward(ctx, dout, *_):
         a, b, E = ctx.saved_tensors
         sa, sb = ctx.slots
-        da, db, dE = ops.gate2_bwd(a, b, E, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb), sig_bwd=ctx.sig_bwd)
+        da, db, dE = ops.gate2_bwd(a, b, E, _blk(dout), acc_a=_acc(sa), acc_b=_acc(sb), sig_bwd=ctx.sig_bwd, out_a=_out(sa))
         return _ret(sa, da), _ret(sb, db), dE, None, None
 
 
@@ -890,3 +944,158 @@ class ComposeDuSE(Function):
         ops.compose_duse_bwd(ctx.saved_tensors, ctx.c, dsqw.contiguous(), dsqb.contiguous(), dadjw.contiguous(),
                              dadjb.contiguous(), grads)
         return (None, *rets)
+
+
+# ------------------------------------------------------------------------------------------------------
+# The recon | seg PAIR of the shared decoder (RA_HVED.py:158-201).  At every decoder level the reconstruction stream and the
+# segmentation stream run a DoubleConv of identical shape and then meet in DuSEAttention; with one sample per launch (N == 1) a
+# (1, 2C, D, H, W) tensor holding [recon | seg] is, byte for byte, a (2, C, D, H, W) batch, so the existing kernels serve the
+# pair in ONE launch each: the second convs as a grouped conv with one weight pointer per stream, the DuSE gates / their
+# backward / the trilinear resampling as batch-2 or 2C-channel launches, the two BatchNorm modules through the paired-parameter
+# entry points (xh_bn_affine_act2 / xh_norm_bwd_fused2).  Same arithmetic per element as the one-stream launches.
+class Upsample2(Function):
+    """F.interpolate(trilinear) of the pair in one launch; returns the two halves (views of one tensor).  Their gradients are
+    collected side by side through a TwinDest, so the adjoint is one launch as well."""
+
+    @staticmethod
+    def forward(ctx, p, size):
+        c = p.shape[1] // 2
+        u = ops.upsample(p, tuple(size))
+        ctx.in_size = tuple(p.shape[2:])
+        ctx.dest = TwinDest(u.shape, c, u.dtype, u.device)
+        return u[:, :c], u[:, c:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return ops.upsample_bwd(ctx.dest.joined(ga, gb), ctx.in_size), None
+
+
+def upsample2(p, size):
+    a, b = Upsample2.apply(p, tuple(size))
+    dest = a.grad_fn.dest if a.grad_fn is not None and hasattr(a.grad_fn, "dest") else None
+    if dest is not None:
+        a._xh_dest, b._xh_dest = (dest, 0), (dest, 1)
+    return a, b
+
+
+class Split2(Function):
+    """The two halves of a pair tensor as separate tensors (for the heads); gradients rejoin through a TwinDest."""
+
+    @staticmethod
+    def forward(ctx, p):
+        c = p.shape[1] // 2
+        ctx.dest = TwinDest(p.shape, c, p.dtype, p.device)
+        return p[:, :c], p[:, c:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return ctx.dest.joined(ga, gb)
+
+
+def split2(p):
+    a, b = Split2.apply(p)
+    dest = a.grad_fn.dest if a.grad_fn is not None and hasattr(a.grad_fn, "dest") else None
+    if dest is not None:
+        a._xh_dest, b._xh_dest = (dest, 0), (dest, 1)
+    return a, b
+
+
+class InLreluConv2(Function):
+    """The second SingleConv 'ilc' of BOTH decoder streams (buildingblocks.py:464-507 twice) as one grouped launch: ya | yb are
+    the halves of `base` (1, 2C, ...) -- written there by the streams' first convs (in_lrelu_conv(into=...)) --, red_in their
+    channel sums (1, 2C, 2); weights / biases per stream.  Returns (y (1, 2Co, ...), its channel sums)."""
+
+    @staticmethod
+    def forward(ctx, ya, yb, base, red_in, *wb):
+        wa, wb_, ba, bb = wb
+        n, c2 = base.shape[:2]
+        cout = wa.shape[0] + wb_.shape[0]
+        k = wa.shape[-1]
+        red_y = ops.zeros_red(base, n, cout)
+        y, sc, sh, mean, rstd = ops.conv3d(base, None, [wa, wb_], [ba, bb], k=k, cout=cout, groups=2, in_stats=(red_in, _dhw(base), LEAK),
+                                           epi=2, red=red_y)
+        ctx.save_for_backward(base, sc, sh, mean, rstd, wa, wb_)
+        ctx.params = ([wa, wb_], [ba, bb])
+        ctx.k = k
+        ctx.mark_non_differentiable(red_y)
+        ctx.set_materialize_grads(False)
+        return y, red_y
+
+    @staticmethod
+    def backward(ctx, dy, _dred=None):
+        base, sc, sh, mean, rstd, wa, wb_ = ctx.saved_tensors
+        k = ctx.k
+        n, c2 = base.shape[:2]
+        c = c2 // 2
+        dy = _blk(dy)
+        dws, rws = _targets(ctx.params[0])
+        dbs, rbs = _targets(ctx.params[1])
+        ops.conv3d_wgrad(base, None, dy, dws, dbs, k=k, groups=2, pre=(sc, sh, LEAK), side=_direct(*rws, *rbs))
+        red = ops.zeros_red(base, n, c2)
+        g = ops.conv3d(dy, None, [wa, wb_], None, k=k, cout=c2, groups=2, transposed=True, epi=1, e=(base, None, sc, sh, LEAK), red=red)
+        dbase = torch.empty_like(base, memory_format=torch.contiguous_format)
+        halves = [dbase[:, :c], dbase[:, c:]]
+        if ops._NB_FOLD[0] and n == 1 and c * _dhw(base) <= NB_FOLD_MAX:
+            # each stream's first conv takes its half over unwritten (the norm-backward fold, _NB_PENDING)
+            for i, h in enumerate(halves):
+                sl = slice(i * c, (i + 1) * c)
+                _NB_PENDING[h.data_ptr()] = (g[:, sl], base[:, sl], red[:, sl], mean[:, sl], rstd[:, sl], h)
+        else:
+            ops.in_bwd_apply(g, base, red, mean, rstd, have_g=True, out=dbase)
+        return (halves[0], halves[1], None, None, *rws, *rbs)
+
+
+class DuSE2(Function):
+    """DuSEAttention.forward (modules/DuSFE.py:113-155) on the recon | seg pair y = [r | s] (1, 2C, ...): the two gate passes,
+    the two BatchNorm passes and their backward counterparts as ONE launch each (see the section comment); the squeeze conv
+    reads the pair as its 2C input channels.  Returns the pair [out_r | out_s]."""
+
+    @staticmethod
+    def forward(ctx, y, stats, training, rm1, rv1, rm2, rv2, wc, bc, w1, b1, w2, b2, sqw, sqb, adjw, adjb, g1, be1, g2, be2):
+        n, c2 = y.shape[:2]
+        c = c2 // 2
+        sp_shape = tuple(y.shape[2:])
+        cnt = _dhw(y)
+        mode = MODE_BN_TRAIN if training else MODE_BN_EVAL
+        red_r, red_s = stats[:, :c], stats[:, c:]
+        chb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        fc = dict(wc=wc, bc=bc, w1=w1, b1=b1, w2=w2, b2=b2)
+        gvec, ch1, ch2, means = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc, ch_out=chb)
+        comb = ops.conv3d(y, None, [sqw], [sqb], k=1, cout=1)
+        sp = ops.conv3d(comb, None, [adjw], [adjb], k=3, cout=2, act=ACT_SIGMOID)
+        red_u = ops.zeros_red(y, 2, c) if training else None
+        u = ops.duse_gate(y.view((2, c) + sp_shape), chb, sp.view((2, 1) + sp_shape), red=red_u).view(y.shape)
+        out, sc, sh, m, rs = ops.bn_affine_act2(mode, u, red_u.view(1, c2, 2) if red_u is not None else None, ACT_NONE, c, gammas=(g1, g2),
+                                               betas=(be1, be2), running_means=(rm1, rm2), running_vars=(rv1, rv2), steps=1)
+        ctx.save_for_backward(y, means, gvec, chb, comb, sp, u, sc, sh, m, rs, wc, w1, w2, sqw, adjw, g1, g2)
+        ctx.mode = mode
+        ctx.params = (wc, bc, w1, b1, w2, b2, sqw, sqb, adjw, adjb, g1, be1, g2, be2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (y, means, gvec, chb, comb, sp, u, sc, sh, m, rs, wc, w1, w2, sqw, adjw, g1, g2) = ctx.saved_tensors
+        mode = ctx.mode
+        n, c2 = y.shape[:2]
+        c = c2 // 2
+        sp_shape = tuple(y.shape[2:])
+        cnt = _dhw(y)
+        (dwc, dbc, dw1, db1, dw2, db2, dsqw, dsqb, dadjw, dadjb, dg1, dbe1, dg2, dbe2), rets = _targets(ctx.params)
+        dout = _blk(dout)
+        red = ops.act_bwd_reduce(dout, u, sc, sh, 1.0)
+        du = ops.norm_bwd_fused2(mode, dout, u, red, m, rs, c, gammas=(g1, g2), dgammas=(dg1, dg2), dbetas=(dbe1, dbe2))
+        dsp = torch.empty_like(sp)
+        fused = ops.duse_gate_bwd_fuses(c)
+        dx, dch = ops.duse_gate_bwd(y.view((2, c) + sp_shape), chb, sp.view((2, 1) + sp_shape), du.view((2, c) + sp_shape),
+                                    dsp.view((2, 1) + sp_shape), sigmoid_bwd=fused)
+        dpre = dsp if fused else ops.act_bwd(dsp, sp, ACT_SIGMOID)
+        ops.conv3d_wgrad(comb, None, dpre, [dadjw], [dadjb], k=3, side=_direct(rets[8], rets[9]))
+        dcomb = ops.conv3d(dpre, None, [adjw], None, k=3, cout=1, transposed=True)
+        ops.conv3d_wgrad(y, None, dcomb, [dsqw], [dsqb], k=1, side=_direct(rets[6], rets[7]))
+        fc = dict(wc=wc, w1=w1, w2=w2)
+        fcg = dict(wc=dwc, bc=dbc, w1=dw1, b1=db1, w2=dw2, b2=db2)
+        dm = torch.empty((1, c2), dtype=torch.float32, device=y.device)
+        ops.duse_fc_bwd(means, cnt, n, c, fc, gvec, chb[0:1], chb[1:2], dch[0:1], dch[1:2], fcg, dm_out=dm)
+        dx = dx.view(y.shape)
+        ops.rank1_add(dx, dcomb, sqw.reshape(-1).contiguous(), dm)
+        return (dx, None, None, None, None, None, None, *rets)

@@ -92,6 +92,8 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
         reference's zip over `self.dusfe_decoders` (RA_HVED.py:171)."""
         level_outputs = [[] for _ in encoders_features]
         rfinal, souts = [], []
+        if self._pair_ok(x, seg):
+            return self._forward_pair(encoders_features, x, level_outputs)
         for i, rdecs in enumerate(self.multi_decoders):
             rout = sout = x
             for j, (rdec, feat, sdec, dusfe) in enumerate(zip(rdecs, encoders_features, self.sdecoders, self.dusfe_decoders)):
@@ -113,6 +115,49 @@ class Seg_Recon_DuSFEDecoder(nn.Module):
             rfinal.append(Fn.conv(rout, [self.rfinals[i].weight], [self.rfinals[i].bias]))
             souts.append(sout)
         return level_outputs, rfinal, (souts if seg else None)
+
+
+def _pair_methods():
+    def _pair_ok(self, x, seg):
+        """The recon | seg pair path (functional: "The recon | seg PAIR"): one recon stream, one sample, every level a fused 'ilc'
+        DoubleConv pair with AttenModule2 in front of the seg stream."""
+        if not (seg and ops.PAIR[0] and x.is_cuda and x.shape[0] == 1 and len(self.multi_decoders) == 1):
+            return False
+        for rdec, sdec in zip(self.multi_decoders[0], self.sdecoders):
+            if not (type(rdec.basic_module) is DoubleConv and type(sdec.basic_module) is DoubleConv and sdec.RSM and not rdec.RSM
+                    and rdec.basic_module.SingleConv1.order == "ilc" and sdec.basic_module.SingleConv1.order == "ilc"):
+                return False
+        return True
+
+    def _forward_pair(self, encoders_features, x, level_outputs):
+        pair = None                                            # [recon | seg] (1, 2C, ...) after each level's DuSE block
+        for j, (rdec, feat, sdec, dusfe) in enumerate(zip(self.multi_decoders[0], encoders_features, self.sdecoders, self.dusfe_decoders)):
+            f_r, f_p, f_g = Fn.fanout(feat, 3)
+            size = tuple(feat.shape[2:])
+            if pair is None:                                   # both streams start from x: ONE upsampling, two consumers
+                u_r, u_s = Fn.fanout(Fn.Upsample.apply(x, size), 2)
+            else:
+                u_r, u_s = Fn.upsample2(pair, size)
+            rb, sb = rdec.basic_module, sdec.basic_module
+            c = rb.SingleConv1.conv.out_channels
+            y1 = torch.empty((1, 2 * c) + size, dtype=x.dtype, device=x.device)          # the first convs' outputs, side by side
+            red1 = ops.zeros_red(x, 1, 2 * c)
+            g_s, st_s = sdec.atten_module(u_s, (f_p, f_g), stats=True)
+            y1_r, _ = Fn.in_lrelu_conv(f_r, u_r, [rb.SingleConv1.conv.weight], [rb.SingleConv1.conv.bias], out_stats=True, drop_bias=True,
+                                       into=(y1[:, :c], red1[:, :c]))
+            y1_s, _ = Fn.in_lrelu_conv(g_s, None, [sb.SingleConv1.conv.weight], [sb.SingleConv1.conv.bias], in_stats=st_s, out_stats=True,
+                                       drop_bias=True, into=(y1[:, c:], red1[:, c:]))
+            y2, st2 = Fn.InLreluConv2.apply(y1_r, y1_s, y1, red1, rb.SingleConv2.conv.weight, sb.SingleConv2.conv.weight,
+                                            rb.SingleConv2.conv.bias, sb.SingleConv2.conv.bias)
+            pair = dusfe.forward_pair(y2, st2)
+            level_outputs[j].append(pair[:, :c])
+        rout, sout = Fn.split2(pair)
+        rfinal = [Fn.conv(rout, [self.rfinals[0].weight], [self.rfinals[0].bias])]
+        return level_outputs, rfinal, [sout]
+    return _pair_ok, _forward_pair
+
+
+Seg_Recon_DuSFEDecoder._pair_ok, Seg_Recon_DuSFEDecoder._forward_pair = _pair_methods()
 
 
 def x_is_shared_decoder(model):

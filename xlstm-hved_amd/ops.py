@@ -333,6 +333,13 @@ def _check_weights(weights, biases, cin, cout, groups, k, transposed, what):
             raise ValueError(f"{what}: bias shape {tuple(b.shape)}, expected {(cout // nw,)}")
 
 
+PAIR = [os.environ.get("XH_NO_PAIR", "") == ""]             # A/B switch: the decoder's recon | seg pair launches (model._forward_pair)
+
+
+def set_pair(enabled):
+    PAIR[0] = bool(enabled)
+
+
 NB_PENDING = {}        # functional.InLreluConv: gradients handed over unwritten, by address (see functional._NB_PENDING)
 _NB_FOLD = [os.environ.get("XH_NO_NB_FOLD", "") == ""]      # A/B switch: the InstanceNorm backward folded into the consuming data gradient
 
@@ -674,6 +681,29 @@ def bn_affine_act(mode, x, red, act, *, gamma=None, beta=None, running_mean=None
     return out, sc, sh, mean, rstd
 
 
+def bn_affine_act2(mode, x, red, act, chalf, *, gammas, betas, running_means, running_vars, steps=1, slope=LEAK):
+    """bn_affine_act for TWO BatchNorm modules over the channel halves of one tensor (xh_bn_affine_act2): channels [0, chalf) take
+    gammas[0] / betas[0] / ..., the rest the second set."""
+    n, c, d, h, w, bs = _vol(x)
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    sc, sh, mean, rstd = (torch.empty((n, c), dtype=torch.float32, device=x.device) for _ in range(4))
+    L.check(L.load().xh_bn_affine_act2(_stream(), _dt(x), mode, _p(x), bs, _p(out), _vol(out)[5], n, c, int(chalf), d * h * w, _p(red),
+                                       NORM_EPS, _p(gammas[0]), _p(betas[0]), _p(running_means[0]), _p(running_vars[0]), _p(gammas[1]),
+                                       _p(betas[1]), _p(running_means[1]), _p(running_vars[1]), steps, act, slope, _p(sc), _p(sh),
+                                       _p(mean), _p(rstd)), "xh_bn_affine_act2")
+    return out, sc, sh, mean, rstd
+
+
+def norm_bwd_fused2(mode, dy, x, red, mean, rstd, chalf, *, gammas, dgammas, dbetas):
+    """norm_bwd_fused (BatchNorm modes) for two modules over the channel halves of one tensor (xh_norm_bwd_fused2)."""
+    n, c, d, h, w, bs = _vol(x)
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    L.check(L.load().xh_norm_bwd_fused2(_stream(), _dt(x), mode, _p(dy), _vol(dy)[5], _p(x), bs, _p(out), _vol(out)[5], n, c, int(chalf),
+                                        d * h * w, _p(red), _p(gammas[0]), _p(gammas[1]), _p(mean), _p(rstd), _p(dgammas[0]),
+                                        _p(dbetas[0]), _p(dgammas[1]), _p(dbetas[1])), "xh_norm_bwd_fused2")
+    return out
+
+
 def act_bwd_reduce(dy, x, sc, sh, slope):
     n, c, d, h, w, bs = _vol(x)
     red = zeros_red(x, n, c)
@@ -730,13 +760,13 @@ def in_bwd_apply(dy, x, red, mean, rstd, *, have_g, sc=None, sh=None, slope=LEAK
     return out
 
 
-def in_bwd_apply2(dy, xa, xb, red, mean, rstd, acc_a=None, acc_b=None):
+def in_bwd_apply2(dy, xa, xb, red, mean, rstd, acc_a=None, acc_b=None, out_a=None, out_b=None):
     """InstanceNorm backward of the virtual concat (xa | xb) from its full-width gradient g = dy, one launch.  acc_a / acc_b:
-    existing gradient buffers to add the respective half to."""
+    existing gradient buffers to add the respective half to; out_a / out_b: tensors to WRITE the half to (else new ones)."""
     n, ca, d, h, w, bsa = _vol(xa)
     cb, bsb = xb.shape[1], _vol(xb)[5]
-    da = acc_a if acc_a is not None else torch.empty_like(xa, memory_format=torch.contiguous_format)
-    db = acc_b if acc_b is not None else torch.empty_like(xb, memory_format=torch.contiguous_format)
+    da = acc_a if acc_a is not None else out_a if out_a is not None else torch.empty_like(xa, memory_format=torch.contiguous_format)
+    db = acc_b if acc_b is not None else out_b if out_b is not None else torch.empty_like(xb, memory_format=torch.contiguous_format)
     L.check(L.load().xh_in_bwd_apply2(_stream(), _dt(xa), _p(dy), _vol(dy)[5], _p(xa), bsa, _p(da), _vol(da)[5], ca, _p(xb), bsb,
                                       _p(db), _vol(db)[5], cb, n, d * h * w, _p(red), _p(mean), _p(rstd),
                                       int(acc_a is not None) | (int(acc_b is not None) << 1)), "xh_in_bwd_apply2")
@@ -927,10 +957,10 @@ def channel_pool2(a, b):
     return y
 
 
-def channel_pool2_bwd(a, b, dy, acc_a=None, acc_b=None):
+def channel_pool2_bwd(a, b, dy, acc_a=None, acc_b=None, out_a=None):
     n, ca, d, h, w, bsa = _vol(a)
     cb, bsb = b.shape[1], _vol(b)[5]
-    da = acc_a if acc_a is not None else new_like(a, (n, ca, d, h, w))
+    da = acc_a if acc_a is not None else out_a if out_a is not None else new_like(a, (n, ca, d, h, w))
     db = acc_b if acc_b is not None else new_like(b, (n, cb, d, h, w))
     L.check(L.load().xh_channel_pool2_bwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(dy), _vol(dy)[5], _p(da), _vol(da)[5],
                                           int(acc_a is not None), _p(db), _vol(db)[5], int(acc_b is not None), n, d * h * w),
@@ -948,11 +978,12 @@ def gate2(a, b, E, red=None):
     return y
 
 
-def gate2_bwd(a, b, E, dy, acc_a=None, acc_b=None, sig_bwd=False):
-    """sig_bwd: E is a sigmoid's output; dE comes back as the gradient of the pre-activation (dE * E * (1 - E))."""
+def gate2_bwd(a, b, E, dy, acc_a=None, acc_b=None, sig_bwd=False, out_a=None):
+    """sig_bwd: E is a sigmoid's output; dE comes back as the gradient of the pre-activation (dE * E * (1 - E)).  out_a: where to
+    WRITE a's gradient when there is no buffer to add to (else a new tensor)."""
     n, ca, d, h, w, bsa = _vol(a)
     cb, bsb = b.shape[1], _vol(b)[5]
-    da = acc_a if acc_a is not None else new_like(a, (n, ca, d, h, w))
+    da = acc_a if acc_a is not None else out_a if out_a is not None else new_like(a, (n, ca, d, h, w))
     db = acc_b if acc_b is not None else new_like(b, (n, cb, d, h, w))
     dE = torch.empty_like(E, memory_format=torch.contiguous_format)
     L.check(L.load().xh_gate2_bwd(_stream(), _dt(a), _p(a), bsa, ca, _p(b), bsb, cb, _p(E), _vol(E)[5], _p(dy), _vol(dy)[5], _p(da),
@@ -1099,18 +1130,28 @@ def compose_duse_bwd(params, c, dsqw, dsqb, dadjw, dadjb, grads):
                                          C.byref(_ptr10(grads))), "xh_compose_duse_bwd")
 
 
-def duse_fc_fwd(red_r, red_s, count, n, c, p):
-    """-> g, ch1, ch2 (n, c) and the pooled means (n, 2c) for duse_fc_bwd (own storage: red_r / red_s may be scratch)."""
-    g, ch1, ch2 = (torch.empty((n, c), dtype=torch.float32, device=red_r.device) for _ in range(3))
+def duse_fc_fwd(red_r, red_s, count, n, c, p, ch_out=None):
+    """-> g, ch1, ch2 (n, c) and the pooled means (n, 2c) for duse_fc_bwd (own storage: red_r / red_s may be scratch).
+    ch_out: a (2n, c) fp32 tensor whose halves receive ch1 / ch2 (the recon | seg pair gated in one launch)."""
+    g = torch.empty((n, c), dtype=torch.float32, device=red_r.device)
+    if ch_out is not None:
+        ch1, ch2 = ch_out[:n], ch_out[n:]
+    else:
+        ch1, ch2 = (torch.empty((n, c), dtype=torch.float32, device=red_r.device) for _ in range(2))
     means = torch.empty((n, 2 * c), dtype=torch.float32, device=red_r.device)
     L.check(L.load().xh_duse_fc_fwd(_stream(), _p(red_r), _p(red_s), count, n, c, _p(p["wc"]), _p(p["bc"]), _p(p["w1"]), _p(p["b1"]),
                                     _p(p["w2"]), _p(p["b2"]), _p(g), _p(ch1), _p(ch2), _p(means)), "xh_duse_fc_fwd")
     return g, ch1, ch2, means
 
 
-def duse_fc_bwd(means, count, n, c, p, g, ch1, ch2, dch1, dch2, grads):
+def duse_fc_bwd(means, count, n, c, p, g, ch1, ch2, dch1, dch2, grads, dm_out=None):
     """means: from duse_fc_fwd.  grads: dict of fp32 buffers (wc, bc, w1, b1, w2, b2) the kernel ACCUMULATES into."""
-    dmr, dms = (torch.empty((n, c), dtype=torch.float32, device=g.device) for _ in range(2))
+    if dm_out is not None:                    # (n == 1: the halves of one (1, 2c) row)
+        dmr, dms = dm_out[:, :c], dm_out[:, c:]
+        if n != 1:
+            raise ValueError("duse_fc_bwd: dm_out needs n == 1")
+    else:
+        dmr, dms = (torch.empty((n, c), dtype=torch.float32, device=g.device) for _ in range(2))
     L.check(L.load().xh_duse_fc_bwd(_stream(), None, None, count, n, c, _p(p["wc"]), _p(p["w1"]), _p(p["w2"]), _p(g), _p(ch1),
                                     _p(ch2), _p(dch1), _p(dch2), _p(grads["wc"]), _p(grads["bc"]), _p(grads["w1"]), _p(grads["b1"]),
                                     _p(grads["w2"]), _p(grads["b2"]), _p(dmr), _p(dms), _p(means)), "xh_duse_fc_bwd")
