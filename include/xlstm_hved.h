@@ -467,10 +467,15 @@ int xh_compose_atten_bwd(void* stream, const float* seg_w, const float* seg_b, c
 typedef struct { const float* p[8]; float* w; float* b; float* g[8]; const float* gw; const float* gb; int NS, NE, E, K3; } xh_atten_job;
 typedef struct { const float* p[10]; float* out[4]; float* g[10]; const float* gout[4]; int C; } xh_duse_job;
 typedef struct { const float *wf, *bf, *ws, *bs; float *w, *b; float *dwf, *dbf, *dws, *dbs; const float *gw, *gb; int Co, Cm, Ci; } xh_head_job;
+/* xh_sep_job: a depthwise k^3 conv followed by a pointwise 1x1 conv with nothing in between (DWConvNorm, sa_modules/sa_module.py:79-85:
+ *   dwconv -> pwconv -> norm) as ONE dense k^3 conv: w [C][C][K3] = pw[co][ci] * dw[ci][t] (the pointwise bias stays the dense conv's
+ *   bias); backward reads gw [C][C][K3] and ACCUMULATES into g_dw [C][K3], g_pw [C][C]. */
+#define XH_SEP_MAX 8
+typedef struct { const float *dw, *pw; float* w; const float* gw; float *g_dw, *g_pw; int C, K3; } xh_sep_job;
 /* zero_buf / zero_n: `zero_n` floats the same launch clears (the caller's gradient buffers of the composed tensors: the convs that
  * use them accumulate into those during the backward pass); NULL / 0: nothing. */
 int xh_compose_multi(void* stream, int bwd, int na, const xh_atten_job* aj, int nd, const xh_duse_job* dj, int nh, const xh_head_job* hj,
-                     float* zero_buf, long long zero_n);
+                     int ns, const xh_sep_job* sj, float* zero_buf, long long zero_n);
 int xh_compose_duse_fwd(void* stream, const float* const params[10], int C, float* sqw, float* sqb, float* adjw, float* adjb);
 int xh_compose_duse_bwd(void* stream, const float* const params[10], int C, const float* dsqw, const float* dsqb,
                         const float* dadjw, const float* dadjb, float* const grads[10]);

@@ -525,3 +525,47 @@ def test_norm_backward_folded_into_the_data_gradient_vs_separate_pass(cfg, dtype
     e_g = max((p - q).abs().max().item() for p, q in zip(gb, ga)) / gscale
     print(f"norm-backward fold {cfg} {dtype}: dx rel-L2 {e_dx:.2e}, parameter gradients {e_g:.2e} of the largest")
     assert e_dx <= tol and e_g <= tol, (e_dx, e_g)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+@pytest.mark.parametrize("c,sp", [(4, (16, 16, 32)), (8, (8, 16, 32)), (16, (8, 8, 32))])
+def test_skip_return_attention_with_composed_depthwise_pointwise_convs(c, sp, dtype):
+    """ResBlock(lkdw=True) of the skip-return attention (sa_modules/sa_module.py:79-137): each DWConvNorm's depthwise 3^3 conv and
+    pointwise 1x1 conv applied as ONE dense 3^3 conv with weights pw o dw (Fn.ComposeAll sep jobs; gradients scattered back to the
+    two parameters at the end of the backward pass) against the two-conv form in fp32: attention map, input gradient and all
+    parameter gradients within the storage format's band -- and closer than the two-conv form in the same format (one rounding
+    of the intermediate tensor less)."""
+    from xlstm_hved_amd import functional as Fn
+    from xlstm_hved_amd.blocks import SkipReturnAttention
+    torch.manual_seed(17)
+    n = 2
+    x = torch.randn((n, c) + sp)
+    wgt = torch.randn((n, 1) + sp)
+    mod0 = SkipReturnAttention(c)
+    mod0.apply(X.init_weights)
+    sd = {k: v.clone() for k, v in mod0.state_dict().items()}
+
+    def run(dt, composed):
+        m = SkipReturnAttention(c)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        xg = x.to(DEV, dt).requires_grad_(True)
+        if composed:
+            outs = Fn.ComposeAll.apply(([], [], False, (c, c)), *m.compose_params())
+            m.__dict__["_pre"] = (outs[0], outs[1])
+        a = m(xg, steps=1)
+        (a.float() * wgt.to(DEV)).sum().backward()
+        X.ops.join_wgrad_stream()
+        torch.cuda.synchronize()
+        return a.detach().float(), xg.grad.float(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    a0, dx0, g0 = run(torch.float32, False)
+    a1, dx1, g1 = run(dtype, False)
+    a2, dx2, g2 = run(dtype, True)
+    assert g0.keys() == g2.keys(), (sorted(g0), sorted(g2))
+    gs = max(v.abs().max().item() for v in g0.values())
+    e1 = (l2_err(a1, a0), l2_err(dx1, dx0), max((g1[k] - g0[k]).abs().max().item() for k in g0) / gs)
+    e2 = (l2_err(a2, a0), l2_err(dx2, dx0), max((g2[k] - g0[k]).abs().max().item() for k in g0) / gs)
+    print(f"skip-return attention c={c} {dtype}: two convs (a, dx, params) {e1[0]:.2e} {e1[1]:.2e} {e1[2]:.2e}; composed {e2[0]:.2e} {e2[1]:.2e} {e2[2]:.2e}")
+    band = (2e-2, 8e-2, 8e-2) if dtype == torch.bfloat16 else (3e-3, 1.2e-2, 1.2e-2)
+    assert all(a_ <= b_ for a_, b_ in zip(e2, band)), (e2, band)
+    assert e2[0] <= 1.5 * e1[0] + 1e-4 and e2[1] <= 1.5 * e1[1] + 1e-4

@@ -19,6 +19,7 @@ python3 tools/summarize_rocprof.py $OUT/trace gpurun_out/profiles_out/${TAG}_ben
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) gpurun_out/profiles_out/${TAG}_bench_graph_bf16_kernel_stats.csv
 python3 tools/timeline_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) gpurun_out/profiles_out/step_families.json "profiles/${TAG}_timeline.txt: rocprofv3 --kernel-trace -- python3 $BENCH, last replayed step (tools/timeline_step.py)" > gpurun_out/profiles_out/${TAG}_timeline.txt 2>&1 || true
 python3 tools/dump_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > gpurun_out/profiles_out/${TAG}_launches.txt 2>&1 || true
+if [ "${PMC:-1}" = "0" ]; then echo "trace only"; exit 0; fi
 PB="bench.py --steps 4 --warmup 1 --inner 1 --no-cpu --no-roofline --no-modes --no-trainstep"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $PB > $OUT/fetch.log 2>&1
 echo "fetch done"

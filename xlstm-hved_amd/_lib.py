@@ -54,6 +54,10 @@ class DuseJob(C.Structure):        # == xh_duse_job
     _fields_ = [("p", vp * 10), ("out", vp * 4), ("g", vp * 10), ("gout", vp * 4), ("C", C.c_int)]
 
 
+class SepJob(C.Structure):         # == xh_sep_job
+    _fields_ = [("dw", vp), ("pw", vp), ("w", vp), ("gw", vp), ("g_dw", vp), ("g_pw", vp), ("C", C.c_int), ("K3", C.c_int)]
+
+
 class HeadJob(C.Structure):        # == xh_head_job
     _fields_ = [("wf", vp), ("bf", vp), ("ws", vp), ("bs", vp), ("w", vp), ("b", vp), ("dwf", vp), ("dbf", vp), ("dws", vp),
                 ("dbs", vp), ("gw", vp), ("gb", vp), ("Co", C.c_int), ("Cm", C.c_int), ("Ci", C.c_int)]
@@ -125,7 +129,7 @@ SIGNATURES = {
     "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_compose_atten_fwd": (I, [vp] * 9 + [I, I, I, I, vp, vp]),
     "xh_compose_atten_bwd": (I, [vp] * 7 + [I, I, I, I] + [vp] * 10),
-    "xh_compose_multi": (I, [vp, I, I, vp, I, vp, I, vp, vp, ll]),
+    "xh_compose_multi": (I, [vp, I, I, vp, I, vp, I, vp, I, vp, vp, ll]),
     "xh_compose_duse_fwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp]),
     "xh_compose_duse_bwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp, C.POINTER(vp * 10)]),
     "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -459,13 +459,20 @@ class SkipReturnAttention(nn.Sequential):
     def __init__(self, channels):
         super().__init__(ResBlock(channels, channels, lkdw=True), SpacialAttention3D(kernel_size=1))
 
+    def compose_params(self):
+        """(dwconv.weight, pwconv.weight) of the two DWConvNorm blocks: what Fn.ComposeAll turns into two dense 3^3 weights."""
+        c1, c2 = self[0].conv1, self[0].conv2
+        return (c1.dwconv.weight, c1.pwconv.weight, c2.dwconv.weight, c2.pwconv.weight)
+
     def forward(self, x, steps=1):
         rb, sa = self[0], self[1]
         c1, c2 = rb.conv1, rb.conv2
+        pre = self.__dict__.get("_pre")                   # (wc1, wc2) from the step's batched composition (model._precompose)
+        wcs = pre if (pre is not None and x.dtype != torch.float32) else (None, None)
         a = Fn.SkipReturnAttention.apply(
             x, self.training, steps, c1.norm.running_mean, c1.norm.running_var, c2.norm.running_mean, c2.norm.running_var,
             c1.dwconv.weight, c1.pwconv.weight, c1.pwconv.bias, c1.norm.weight, c1.norm.bias,
-            c2.dwconv.weight, c2.pwconv.weight, c2.pwconv.bias, c2.norm.weight, c2.norm.bias, sa.conv.weight)
+            c2.dwconv.weight, c2.pwconv.weight, c2.pwconv.bias, c2.norm.weight, c2.norm.bias, sa.conv.weight, *wcs)
         if self.training:
             bn_tick(c1.norm, steps)
             bn_tick(c2.norm, steps)

@@ -2795,6 +2795,7 @@ struct ComposeJobs {
   DuseCompose d[XH_COMPOSE_MAX]; DuseComposeGrad dg[XH_COMPOSE_MAX];
   float* dout[XH_COMPOSE_MAX][4]; const float* dgout[XH_COMPOSE_MAX][4];
   xh_head_job h;
+  int ns; xh_sep_job s[XH_SEP_MAX];                     // depthwise 3^3 o pointwise 1x1 (sa_modules/sa_module.py:79-85) as one dense 3^3 conv
   float* zero_buf; long long zero_n;                    // forward: also cleared (the composed tensors' gradient buffers of the step)
 };
 __global__ __launch_bounds__(256) void compose_multi_kernel(const ComposeJobs j) {
@@ -2814,6 +2815,31 @@ __global__ __launch_bounds__(256) void compose_multi_kernel(const ComposeJobs j)
     const int k = job - j.na;
     if (!j.bwd) compose_duse_fwd_body(j.d[k], j.dout[k][0], j.dout[k][1], j.dout[k][2], j.dout[k][3]);
     else compose_duse_bwd_body(j.d[k], j.dg[k], j.dgout[k][0], j.dgout[k][1], j.dgout[k][2], j.dgout[k][3], s_red);
+    return;
+  }
+  if (job >= j.na + j.nd + j.nh) {
+    // W[co][ci][t] = pw[co][ci] * dw[ci][t]:  (pointwise o depthwise)(x) as ONE dense k^3 conv (no non-linearity between them)
+    const xh_sep_job& q = j.s[job - j.na - j.nd - j.nh];
+    const int C = q.C, K3 = q.K3, t = threadIdx.x;
+    if (!j.bwd) {
+      for (int i = t; i < C * C * K3; i += 256) {
+        const int tap = i % K3, ci = (i / K3) % C, co = i / (K3 * C);
+        q.w[i] = q.pw[co * C + ci] * q.dw[ci * K3 + tap];
+      }
+    } else {
+      for (int i = t; i < C * C; i += 256) {              // d pw[co][ci] += sum_t gw[co][ci][t] dw[ci][t]
+        const int ci = i % C;
+        float v = 0.f;
+        for (int tap = 0; tap < K3; ++tap) v = fmaf(q.gw[(long long)i * K3 + tap], q.dw[ci * K3 + tap], v);
+        q.g_pw[i] += v;
+      }
+      for (int i = t; i < C * K3; i += 256) {             // d dw[ci][t] += sum_co gw[co][ci][t] pw[co][ci]
+        const int tap = i % K3, ci = i / K3;
+        float v = 0.f;
+        for (int co = 0; co < C; ++co) v = fmaf(q.gw[((long long)co * C + ci) * K3 + tap], q.pw[co * C + ci], v);
+        q.g_dw[i] += v;
+      }
+    }
     return;
   }
   const xh_head_job& h = j.h;
@@ -2852,11 +2878,16 @@ __global__ __launch_bounds__(256) void compose_multi_kernel(const ComposeJobs j)
   }
 }
 extern "C" int xh_compose_multi(void* stream, int bwd, int na, const xh_atten_job* aj, int nd, const xh_duse_job* dj, int nh,
-                                const xh_head_job* hj, float* zero_buf, long long zero_n) {
-  if (na < 0 || nd < 0 || nh < 0 || na > XH_COMPOSE_MAX || nd > XH_COMPOSE_MAX || nh > 1 || na + nd + nh == 0) return XH_ERR_ARG;
-  if ((na && !aj) || (nd && !dj) || (nh && !hj) || zero_n < 0 || (zero_n > 0 && !zero_buf)) return XH_ERR_ARG;
+                                const xh_head_job* hj, int ns, const xh_sep_job* sj, float* zero_buf, long long zero_n) {
+  if (na < 0 || nd < 0 || nh < 0 || ns < 0 || na > XH_COMPOSE_MAX || nd > XH_COMPOSE_MAX || nh > 1 || ns > XH_SEP_MAX || na + nd + nh + ns == 0)
+    return XH_ERR_ARG;
+  if ((na && !aj) || (nd && !dj) || (nh && !hj) || (ns && !sj) || zero_n < 0 || (zero_n > 0 && !zero_buf)) return XH_ERR_ARG;
   ComposeJobs j;
-  j.na = na; j.nd = nd; j.nh = nh; j.bwd = bwd ? 1 : 0;
+  j.na = na; j.nd = nd; j.nh = nh; j.ns = ns; j.bwd = bwd ? 1 : 0;
+  for (int i = 0; i < ns; ++i) {
+    j.s[i] = sj[i];
+    if (!sj[i].dw || !sj[i].pw || sj[i].C <= 0 || sj[i].K3 <= 0 || (bwd ? (!sj[i].gw || !sj[i].g_dw || !sj[i].g_pw) : !sj[i].w)) return XH_ERR_ARG;
+  }
   j.zero_buf = zero_n > 0 ? zero_buf : nullptr; j.zero_n = zero_n;
   int gx = 1;
   for (int i = 0; i < na; ++i) {
@@ -2887,7 +2918,7 @@ extern "C" int xh_compose_multi(void* stream, int bwd, int na, const xh_atten_jo
     if (!j.h.wf || !j.h.bf || !j.h.ws || !j.h.bs || j.h.Co <= 0 || j.h.Cm <= 0 || j.h.Ci <= 0) return XH_ERR_ARG;
     if (bwd ? (!j.h.gw || !j.h.gb || !j.h.dwf || !j.h.dbf || !j.h.dws || !j.h.dbs) : (!j.h.w || !j.h.b)) return XH_ERR_ARG;
   }
-  hipLaunchKernelGGL(compose_multi_kernel, dim3(gx, na + nd + nh), dim3(256), 0, (hipStream_t)stream, j);
+  hipLaunchKernelGGL(compose_multi_kernel, dim3(gx, na + nd + nh + ns), dim3(256), 0, (hipStream_t)stream, j);
   return xh_launch_status();
 }
 extern "C" int xh_compose_duse_fwd(void* stream, const float* const params[10], int C, float* sqw, float* sqb, float* adjw,

@@ -644,33 +644,45 @@ class SkipReturnAttention(Function):
     times to reproduce the reference's 4 evaluations on identical input (RA_HVED.py:548-552)."""
 
     @staticmethod
-    def forward(ctx, x, training, steps, rm1, rv1, rm2, rv2, dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2, saw):
+    def forward(ctx, x, training, steps, rm1, rv1, rm2, rv2, dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2, saw, wc1=None, wc2=None):
+        """wc1 / wc2 (from ComposeAll, 16-bit storage): the dense 3^3 weights pw o dw of the two DWConvNorm blocks -- each block is
+        then ONE conv launch (the depthwise output never exists) and one data gradient in the backward pass."""
         n, c = x.shape[:2]
         cnt = _dhw(x)
         mode = MODE_BN_TRAIN if training else MODE_BN_EVAL
-        u1 = ops.conv3d(x, None, [dw1], None, k=3, cout=c, groups=c)
+        comp = wc1 is not None
         red1 = ops.zeros_red(x, n, c) if training else None
-        t1 = ops.conv3d(u1, None, [pw1w], [pw1b], k=1, cout=c, epi=2 if training else 0, red=red1)
+        if comp:
+            u1 = u2 = None
+            t1 = ops.conv3d(x, None, [wc1], [pw1b], k=3, cout=c, epi=2 if training else 0, red=red1)
+        else:
+            u1 = ops.conv3d(x, None, [dw1], None, k=3, cout=c, groups=c)
+            t1 = ops.conv3d(u1, None, [pw1w], [pw1b], k=1, cout=c, epi=2 if training else 0, red=red1)
         sc1, sh1, m1, r1 = ops.norm_finalize(mode, red1, n, c, cnt, gamma=g1, beta=b1, running_mean=rm1, running_var=rv1,
                                              steps=steps, device=x.device)
-        u2 = ops.conv3d(t1, None, [dw2], None, k=3, cout=c, groups=c, pre=(sc1, sh1, 0.0))
         red2 = ops.zeros_red(x, n, c) if training else None
-        t2 = ops.conv3d(u2, None, [pw2w], [pw2b], k=1, cout=c, epi=2 if training else 0, red=red2)
+        if comp:
+            t2 = ops.conv3d(t1, None, [wc2], [pw2b], k=3, cout=c, pre=(sc1, sh1, 0.0), epi=2 if training else 0, red=red2)
+        else:
+            u2 = ops.conv3d(t1, None, [dw2], None, k=3, cout=c, groups=c, pre=(sc1, sh1, 0.0))
+            t2 = ops.conv3d(u2, None, [pw2w], [pw2b], k=1, cout=c, epi=2 if training else 0, red=red2)
         sc2, sh2, m2, r2 = ops.norm_finalize(mode, red2, n, c, cnt, gamma=g2, beta=b2, running_mean=rm2, running_var=rv2,
                                              steps=steps, device=x.device)
         w2 = saw.reshape(2).contiguous()
         a = ops.skr_tail(t2, x, sc2, sh2, w2)
-        ctx.save_for_backward(x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2)
+        ctx.save_for_backward(x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2, wc1, wc2)
         ctx.mode = mode
         ctx.params = (dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2)
+        ctx.wcs = (wc1, wc2)
         ctx.saw = saw
         ctx.xslot = _slot(x)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        (x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2) = ctx.saved_tensors
+        (x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2, wc1, wc2) = ctx.saved_tensors
         mode = ctx.mode
+        comp = wc1 is not None
         n, c = x.shape[:2]
         cnt = _dhw(x)
         (ddw1, dpw1w, dpw1b, dg1, db1, ddw2, dpw2w, dpw2b, dg2, db2), rets = _targets(ctx.params)
@@ -684,12 +696,26 @@ class SkipReturnAttention(Function):
         # BatchNorm 2
         red = ops.act_bwd_reduce(dtg, t2, sc2, sh2, 1.0)
         dt2 = ops.norm_bwd_fused(mode, dtg, t2, red, m2, r2, gamma=g2, dgamma=dg2, dbeta=db2)
+        red = ops.zeros_red(x, n, c)
+        if comp:
+            # the composed tensors collect their weight gradients in their own buffers (ComposeAll scatters them to dw / pw at the
+            # end of the backward pass); the pointwise biases are the dense convs' biases
+            (gwc1, gwc2), rwc = _targets(ctx.wcs)
+            sdc = sd and _direct(*rwc)
+            ops.conv3d_wgrad(t1, None, dt2, [gwc2], [dpw2b], k=3, pre=(sc1, sh1, 0.0), side=sdc)
+            gt1 = ops.conv3d(dt2, None, [wc2], None, k=3, cout=c, transposed=True, epi=1, e=(t1, None, sc1, sh1, 0.0), red=red)
+            dt1 = ops.norm_bwd_fused(mode, gt1, t1, red, m1, r1, gamma=g1, dgamma=dg1, dbeta=db1)
+            ops.conv3d_wgrad(x, None, dt1, [gwc1], [dpw1b], k=3, side=sdc)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv3d(dt1, None, [wc1], None, k=3, cout=c, transposed=True)
+                dx = _ret(slot, ops.add(dx_res, dx, out=dx_res))
+            return (dx, None, None, None, None, None, None, *rets, r_saw, *rwc)
         # pointwise 2
         ops.conv3d_wgrad(u2, None, dt2, [dpw2w], [dpw2b], k=1, side=sd)
         du2 = ops.conv3d(dt2, None, [pw2w], None, k=1, cout=c, transposed=True)
         # depthwise 2 (input = relu(bn1(t1)))
         ops.conv3d_wgrad(t1, None, du2, [ddw2], None, k=3, groups=c, pre=(sc1, sh1, 0.0), side=sd)
-        red = ops.zeros_red(x, n, c)
         gt1 = ops.conv3d(du2, None, [dw2], None, k=3, cout=c, groups=c, transposed=True, epi=1, e=(t1, None, sc1, sh1, 0.0), red=red)
         dt1 = ops.norm_bwd_fused(mode, gt1, t1, red, m1, r1, gamma=g1, dgamma=dg1, dbeta=db1)
         # pointwise 1, depthwise 1
@@ -700,7 +726,7 @@ class SkipReturnAttention(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d(du1, None, [dw1], None, k=3, cout=c, groups=c, transposed=True)
             dx = _ret(slot, ops.add(dx_res, dx, out=dx_res))
-        return (dx, None, None, None, None, None, None, *rets, r_saw)
+        return (dx, None, None, None, None, None, None, *rets, r_saw, None, None)
 
 
 class DuSE(Function):
@@ -824,12 +850,15 @@ class ComposeAll(Function):
     """Every parameter composition of a forward in ONE launch, and their backward in one (ops.compose_multi): the AttenModule2
     gates (ComposeAtten), the DuSE blocks (ComposeDuSE) and the segmentation head final_conv o sfinals.  `plan` = (list of
     (ns, ne, e) per AttenModule2, list of c per DuSE block, has_head); params = 8 per AttenModule2, 10 per DuSE block, then
-    final_conv.weight (Co, Cm), final_conv.bias, sfinals.weight (Cm, Ci), sfinals.bias.  Returns the flat tuple of composed
-    tensors: (w, b) per AttenModule2, (sqw, sqb, adjw, adjb) per DuSE block, (w, b) of the head."""
+    final_conv.weight (Co, Cm), final_conv.bias, sfinals.weight (Cm, Ci), sfinals.bias, then (dwconv.weight, pwconv.weight) per
+    entry of the optional 4th plan element (channel counts of depthwise o pointwise pairs: the skip-return ResBlock's DWConvNorm,
+    sa_modules/sa_module.py:79-85).  Returns the flat tuple of composed tensors: (w, b) per AttenModule2, (sqw, sqb, adjw, adjb)
+    per DuSE block, (w, b) of the head, one dense (C, C, k, k, k) weight per pair."""
 
     @staticmethod
     def _jobs(plan, params, outs, bwd, grads=None, gouts=None):
-        a_plan, d_plan, has_head = plan
+        a_plan, d_plan, has_head = plan[:3]
+        s_plan = plan[3] if len(plan) > 3 else ()
         atten, duse, head, pi, oi = [], [], None, 0, 0
         for ns, ne, e in a_plan:
             j = dict(params=params[pi:pi + 8], ns=ns, ne=ne, e=e)
@@ -854,12 +883,23 @@ class ComposeAll(Function):
                 head.update(dwf=grads[pi], dbf=grads[pi + 1], dws=grads[pi + 2], dbs=grads[pi + 3], gw=gouts[oi], gb=gouts[oi + 1])
             else:
                 head.update(w=outs[oi], b=outs[oi + 1])
-        return atten, duse, head
+            pi, oi = pi + 4, oi + 2
+        sep = []
+        for _c in s_plan:                                   # depthwise o pointwise (the skip-return ResBlock's DWConvNorm pairs)
+            q = dict(dw=params[pi], pw=params[pi + 1])
+            if bwd:
+                q.update(gw=gouts[oi], g_dw=grads[pi], g_pw=grads[pi + 1])
+            else:
+                q.update(w=outs[oi])
+            sep.append(q)
+            pi, oi = pi + 2, oi + 1
+        return atten, duse, head, sep
 
     @staticmethod
     def forward(ctx, plan, *params):
         params = tuple(t.contiguous() for t in params)
-        a_plan, d_plan, has_head = plan
+        a_plan, d_plan, has_head = plan[:3]
+        s_plan = plan[3] if len(plan) > 3 else ()
         dev = params[0].device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         outs, pi = [], 0
@@ -873,6 +913,11 @@ class ComposeAll(Function):
         if has_head:
             wf, _, ws, _ = params[pi:pi + 4]
             outs += [new(wf.shape[0], ws.shape[1], 1, 1, 1), new(wf.shape[0])]
+            pi += 4
+        for _c in s_plan:
+            dw_ = params[pi]
+            outs.append(new(dw_.shape[0], dw_.shape[0], *dw_.shape[2:]))
+            pi += 2
         # (the gradient buffers below are cleared by the same launch)
         sizes = [(o.numel() + 15) // 16 * 16 for o in outs]
         # two copies of the gradient buffers (both cleared here): a SECOND backward over this forward (retain_graph=True, two
@@ -880,7 +925,8 @@ class ComposeAll(Function):
         # tensors on to the clean copy once it has consumed the first (a third pass pays one fill)
         total = sum(sizes)
         flat = torch.empty(2 * total, dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
-        ops.compose_multi(False, *ComposeAll._jobs(plan, params, outs, False), zero=flat)
+        at_, du_, he_, se_ = ComposeAll._jobs(plan, params, outs, False)
+        ops.compose_multi(False, at_, du_, he_, zero=flat, sep=se_)
         ctx.plan, ctx.params = plan, params
         ctx.save_for_backward(*params)
         ctx.out_meta = [tuple(o.shape) for o in outs]
@@ -913,7 +959,8 @@ class ComposeAll(Function):
         # autograd instead (a stock op on a composed tensor) is added on top
         gouts = [buf if g is None else buf.add_(g.reshape(buf.shape)) for g, buf in zip(gouts, ctx.gbufs)]
         grads, rets = _targets(ctx.params)
-        ops.compose_multi(True, *ComposeAll._jobs(ctx.plan, params, None, True, grads=grads, gouts=gouts))
+        at_, du_, he_, se_ = ComposeAll._jobs(ctx.plan, params, None, True, grads=grads, gouts=gouts)
+        ops.compose_multi(True, at_, du_, he_, sep=se_)
         # this pass's sums are spent: a later backward over the same forward accumulates into the other (clean) copy
         ctx.passes += 1
         ctx.gcur ^= 1

@@ -273,7 +273,7 @@ class AbstractFusion3DUNet(nn.Module):
         with self._bn_counters():
             # composed first: ComposeAll is then the LAST node of the backward pass, so the weight gradients of the composed
             # tensors' convs can wait for the end-of-backward batch (functional._direct)
-            pre = self._precompose(seg)
+            pre = self._precompose(seg, x)
             try:
                 enc = self._encode(x, bn_steps=4)
                 return self._decode(enc, subset_idx_list, instance_missing, drop, seg, recon, valid, eps_list)
@@ -288,7 +288,7 @@ class AbstractFusion3DUNet(nn.Module):
         keyword arguments of forward() (subset_idx_list, instance_missing, drop, valid, eps_list).  Returns the list of
         forward() results.  BatchNorm buffers of the skip-return attention advance 4 steps per call, as they would."""
         with self._bn_counters():
-            pre = self._precompose(seg)                       # the composed weights are the same for every call
+            pre = self._precompose(seg, x)                    # the composed weights are the same for every call
             outs = []
             try:
                 enc = self._encode(x, bn_steps=4 * len(calls))
@@ -299,25 +299,41 @@ class AbstractFusion3DUNet(nn.Module):
                 self._drop_precomposed(pre)
         return outs
 
-    def _precompose(self, seg):
-        """All parameter compositions of the decoders in ONE launch (Fn.ComposeAll): the AttenModule2 gates, the DuSE blocks and
+    def _precompose(self, seg, x=None):
+        """All parameter compositions of a forward in ONE launch (Fn.ComposeAll): the AttenModule2 gates, the DuSE blocks and
         the segmentation head, each of which otherwise composes its weights with a launch (or a handful of ATen ops) of its own
-        right before it is used -- and scatters the gradients back with another.  The composed tensors are parked on the modules
-        for the duration of this forward; a module called on its own composes for itself as before."""
-        if not (self.seg_recon_decoder and seg and x_is_shared_decoder(self)):
-            return []
-        sr = self.srdecoder
-        attens = [d.atten_module for d in sr.sdecoders if d.RSM]
-        duses = list(sr.dusfe_decoders)[:len(sr.multi_decoders[0])]
-        if not attens or len(attens) > 4 or len(duses) > 4:
+        right before it is used -- and scatters the gradients back with another; with 16-bit storage also the skip-return
+        ResBlocks' depthwise o pointwise pairs (one dense 3^3 conv each instead of two launches and a tensor in between; fp32
+        storage keeps the two-conv form: its vector kernels pay for the denser weights).  The composed tensors are parked on the
+        modules for the duration of this forward; a module called on its own composes for itself as before."""
+        dec = self.seg_recon_decoder and seg and x_is_shared_decoder(self)
+        attens, duses = [], []
+        if dec:
+            sr = self.srdecoder
+            attens = [d.atten_module for d in sr.sdecoders if d.RSM]
+            duses = list(sr.dusfe_decoders)[:len(sr.multi_decoders[0])]
+            if not attens or len(attens) > 4 or len(duses) > 4:
+                dec, attens, duses = False, [], []
+        skrs = []
+        if self.skip_return and x is not None and x.dtype != torch.float32 and ops.SEP_COMPOSE[0]:
+            levels = len(self.encoders)
+            skrs = [self.skr_att[levels - level] for level in range(1, levels)]         # the ones forward() calls (RA_HVED.py:552)
+            if len(skrs) > 4:
+                skrs = []
+        if not dec and not skrs:
             return []
         params = []
         for a in attens:
             params += a.compose_params()
         for d in duses:
             params += d.compose_params()
-        params += [self.final_conv.weight, self.final_conv.bias, sr.sfinals[0].weight, sr.sfinals[0].bias]
-        plan = ([(2, 4, a.expan) for a in attens], [d.conv_squeeze_ch1.in_channels for d in duses], True)
+        if dec:
+            params += [self.final_conv.weight, self.final_conv.bias, sr.sfinals[0].weight, sr.sfinals[0].bias]
+        s_plan = []
+        for k in skrs:
+            params += k.compose_params()
+            s_plan += [k[0].conv1.dwconv.weight.shape[0]] * 2
+        plan = ([(2, 4, a.expan) for a in attens], [d.conv_squeeze_ch1.in_channels for d in duses], dec, tuple(s_plan))
         outs = Fn.ComposeAll.apply(plan, *params)
         if outs[0].requires_grad and any(getattr(o, "_xh_gbuf", None) is None for o in outs):
             raise RuntimeError("ComposeAll: the composed tensors lost their gradient buffers")     # (Function.apply returns forward's own tensors)
@@ -330,7 +346,13 @@ class AbstractFusion3DUNet(nn.Module):
             d.__dict__["_pre"] = tuple(outs[oi:oi + 4])
             oi += 4
             mods.append(d)
-        self.__dict__["_head_pre"] = (outs[oi], outs[oi + 1])
+        if dec:
+            self.__dict__["_head_pre"] = (outs[oi], outs[oi + 1])
+            oi += 2
+        for k in skrs:
+            k.__dict__["_pre"] = (outs[oi], outs[oi + 1])
+            oi += 2
+            mods.append(k)
         return mods
 
     def _drop_precomposed(self, mods):

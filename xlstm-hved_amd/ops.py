@@ -340,6 +340,13 @@ def set_pair(enabled):
     PAIR[0] = bool(enabled)
 
 
+SEP_COMPOSE = [os.environ.get("XH_NO_SEP_COMPOSE", "") == ""]      # A/B switch: depthwise o pointwise of the skip-return ResBlocks as one dense conv
+
+
+def set_sep_compose(enabled):
+    SEP_COMPOSE[0] = bool(enabled)
+
+
 NB_PENDING = {}        # functional.InLreluConv: gradients handed over unwritten, by address (see functional._NB_PENDING)
 _NB_FOLD = [os.environ.get("XH_NO_NB_FOLD", "") == ""]      # A/B switch: the InstanceNorm backward folded into the consuming data gradient
 
@@ -1075,12 +1082,13 @@ def compose_atten_bwd(params, ns, ne, e, gw, gb, grads):
                                           k3, _p(gw), _p(gb), *[_p(g) for g in grads]), "xh_compose_atten_bwd")
 
 
-def compose_multi(bwd, atten, duse, head, zero=None):
+def compose_multi(bwd, atten, duse, head, zero=None, sep=()):
     """All parameter compositions of a step in one launch (xh_compose_multi).
     atten: list of dicts(params=8 tensors, ns, ne, e, w, b[, grads=8 buffers, gw, gb]); duse: dicts(params=10, c, out=4[, grads=10,
     gout=4]); head: dict(wf, bf, ws, bs, w, b[, dwf, dbf, dws, dbs, gw, gb]) or None.  zero: an fp32 tensor the launch also clears."""
+    """sep: dicts(dw (C,1,k,k,k), pw (C,C,1,1,1), w (C,C,k,k,k)[, gw, g_dw, g_pw]): depthwise o pointwise as one dense conv."""
     na, nd = len(atten), len(duse)
-    first = atten[0]["params"][0] if na else duse[0]["params"][0] if nd else head["wf"]
+    first = atten[0]["params"][0] if na else duse[0]["params"][0] if nd else head["wf"] if head is not None else sep[0]["dw"]
     if not first.is_cuda:
         raise RuntimeError("xlstm_hved_amd ops need device tensors (the HIP library is the only compute path)")
     aj = (L.AttenJob * max(na, 1))()
@@ -1106,8 +1114,15 @@ def compose_multi(bwd, atten, duse, head, zero=None):
         for k in ("wf", "bf", "ws", "bs") + (("dwf", "dbf", "dws", "dbs", "gw", "gb") if bwd else ("w", "b")):
             setattr(hj, k, _p(head[k]))
         hj.Co, hj.Cm, hj.Ci = head["wf"].shape[0], head["ws"].shape[0], head["ws"].shape[1]
+    sj = (L.SepJob * max(len(sep), 1))()
+    for j, q in zip(sj, sep):
+        j.dw, j.pw, j.C, j.K3 = _p(_f32(q["dw"], "dw")), _p(_f32(q["pw"], "pw")), q["dw"].shape[0], q["dw"][0].numel()
+        if bwd:
+            j.gw, j.g_dw, j.g_pw = _p(q["gw"]), _p(q["g_dw"]), _p(q["g_pw"])
+        else:
+            j.w = _p(q["w"])
     L.check(L.load().xh_compose_multi(_stream(), int(bwd), na, C.cast(aj, C.c_void_p), nd, C.cast(dj, C.c_void_p),
-                                      int(head is not None), C.cast(C.pointer(hj), C.c_void_p),
+                                      int(head is not None), C.cast(C.pointer(hj), C.c_void_p), len(sep), C.cast(sj, C.c_void_p),
                                       _p(zero), zero.numel() if zero is not None else 0), "xh_compose_multi")
 
 
