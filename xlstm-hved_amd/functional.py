@@ -854,6 +854,7 @@ class ComposeAll(Function):
     entry of the optional 4th plan element (channel counts of depthwise o pointwise pairs: the skip-return ResBlock's DWConvNorm,
     sa_modules/sa_module.py:79-85).  Returns the flat tuple of composed tensors: (w, b) per AttenModule2, (sqw, sqb, adjw, adjb)
     per DuSE block, (w, b) of the head, one dense (C, C, k, k, k) weight per pair."""
+    _store = {}
 
     @staticmethod
     def _jobs(plan, params, outs, bwd, grads=None, gouts=None):
@@ -901,7 +902,26 @@ class ComposeAll(Function):
         a_plan, d_plan, has_head = plan[:3]
         s_plan = plan[3] if len(plan) > 3 else ()
         dev = params[0].device
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        # The composed tensors live in PERSISTENT storage per (plan, parameter storages): the same addresses every step, so the
+        # k = 3 convs that use them (the skip-return ResBlocks' dense convs) keep their packed-fragment workspaces and ride in
+        # ops.prepack_all() like every leaf weight -- fresh tensors per step meant a pack launch in front of each of those convs.
+        # What is returned are new aliases of that storage (a step's autograd graph never sees another step's tensor objects).
+        ckey = (plan, tuple(t.data_ptr() for t in params))
+        store = ComposeAll._store.get(ckey)
+        fresh = store is None
+        if fresh:
+            if len(ComposeAll._store) > 16:
+                ComposeAll._store.clear()
+            store = ComposeAll._store[ckey] = []
+        it = iter(store)
+
+        def new(*shape):
+            if fresh:
+                store.append(torch.empty(shape, dtype=torch.float32, device=dev))
+            base = store[-1] if fresh else next(it)
+            alias = base.view(shape)
+            alias._xh_base = base                          # ops._pack_entry keys a conv's packed fragments on the storage
+            return alias
         outs, pi = [], 0
         for ns, ne, e in a_plan:
             k = params[pi].shape[-1]

@@ -246,7 +246,8 @@ def _pack_entry(weights, desc, need, device):
         return e
     import weakref
     e = _PackEntry()
-    e.refs = [weakref.ref(w) for w in weights]
+    # (a tensor composed by functional.ComposeAll is a per-step alias of persistent storage: the entry follows the storage)
+    e.refs = [weakref.ref(getattr(w, "_xh_base", w)) for w in weights]
     e.dptrs = [w.data_ptr() for w in weights]
     e.ws = torch.empty(need, dtype=torch.uint8, device=device)
     e.desc = L.ConvDesc.from_buffer_copy(desc)
