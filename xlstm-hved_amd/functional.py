@@ -906,7 +906,7 @@ class ComposeAll(Function):
         # k = 3 convs that use them (the skip-return ResBlocks' dense convs) keep their packed-fragment workspaces and ride in
         # ops.prepack_all() like every leaf weight -- fresh tensors per step meant a pack launch in front of each of those convs.
         # What is returned are new aliases of that storage (a step's autograd graph never sees another step's tensor objects).
-        ckey = (plan, tuple(t.data_ptr() for t in params))
+        ckey = (repr(plan), tuple(t.data_ptr() for t in params))
         store = ComposeAll._store.get(ckey)
         fresh = store is None
         if fresh:
