@@ -529,6 +529,13 @@ int xh_multi_fill(void* stream, int dtype, int nt, void* const* ptrs, const long
  * C a multiple of 8; weights are re-packed per step by xh_dconv_pack.  Every entry point returns XH_ERR_ARG for ks outside
  * {3, 4} and for extents that are not those of a padding-1 convolution: out = (in + 2 - ks) / stride + 1.
  * ------------------------------------------------------------------------------------------------ */
+/* Exact fp32 route of the Discriminator (parity mode; buildingblocks.py:350,354: nn.Conv3d(c, 2c, ks, stride, padding=1)): direct
+ * NCDHW fp32 convolutions for any kernel size 1..7 with padding 1, stride 1 | 2.  mode 0: y = conv(x, w) + b (b optional);
+ * mode 1: data gradient, x = dY (N, Cout, Do..), y = dX (N, Cin, D..) written; mode 2: weight / bias gradient, x = input, y = dY,
+ * w = dW and b = dB (optional) ACCUMULATED into (the const qualifiers of w / b are cast away in this mode).  ~1 TFLOP/s: for small
+ * patches and tests; the matrix-core entry points below are the product path. */
+int xh_dconv_exact(void* stream, int mode, const float* x, const float* w, const float* b, float* y, int N, int Cin, int Cout, int D, int H,
+                   int W, int Do, int Ho, int Wo, int ks, int stride);
 /* mode 0 forward: x [N][Di,Hi,Wi][Cs] -> y [N][Do,Ho,Wo][Cn], Do = (Di+2-ks)/stride+1; Cs a multiple of 32, or 8 (the padded
  * 7-channel input: weights packed with mode 2).  bias [Cn] optional; act XH_ACT_NONE / XH_ACT_LRELU(slope); red optional:
  * red[n][cn][0..1] += (sum y, sum y^2) of the stored output (InstanceNorm statistics).

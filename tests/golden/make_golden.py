@@ -519,6 +519,33 @@ def disc_cases():
                 arrs[f"{tag}.gsum.{k}"] = g.double().sum()
                 arrs[f"{tag}.gabs.{k}"] = g.double().abs().sum()
             ref = m.float()
+        # the reference's OWN mixed precision on the same weights / input (train.py:218 runs the step under autocast): how far its
+        # output and gradients move from its fp32 run -- the yardstick for the HIP path's 16-bit deviations (LeakyReLU(0.2) masks
+        # flip wherever a 16-bit forward changes a sign, which bounds any 16-bit gradient from below)
+        f32 = {k: torch.from_numpy(np.asarray(arrs[k])) if not torch.is_tensor(arrs[k]) else arrs[k] for k in arrs if k.startswith("f32.")}
+        for tag, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+            try:
+                m = ref.float()
+                m.zero_grad()
+                xi = x.clone().requires_grad_(True)
+                with torch.autocast("cpu", dtype=dt):
+                    y = m(xi)
+                (y.float() * gy).sum().backward()
+                l2 = lambda a, b: float(((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)))
+                arrs[f"amp_{tag}.y"] = np.array(l2(y.detach().float(), f32["f32.y"]))
+                gx = xi.grad.flatten()
+                arrs[f"amp_{tag}.dx"] = np.array(l2(gx[disc_sample_index(gx.numel(), 65536)], f32["f32.dx"]))
+                worst = 0.0
+                for k, p_ in m.named_parameters():
+                    g = p_.grad.flatten()
+                    if k.endswith(".bias") and not k.startswith("disc.0."):
+                        continue                           # a bias in front of an InstanceNorm: its gradient is round-off around zero
+                    worst = max(worst, l2(g[disc_sample_index(g.numel())], f32[f"f32.g.{k}"]))
+                arrs[f"amp_{tag}.g"] = np.array(worst)
+                print(f"  reference Discriminator(ks={ks}) under {tag} autocast vs its fp32 run: y {float(arrs[f'amp_{tag}.y']):.2e}, "
+                      f"dx {float(arrs[f'amp_{tag}.dx']):.2e}, worst parameter gradient {worst:.2e} (relative L2)")
+            except Exception as e:                         # an autocast dtype this torch build cannot run on CPU
+                print(f"  ({tag} autocast yardstick skipped: {e!r})")
         save(f"stage_disc_ks{ks}", **arrs)
         print(f"  oracle vs reference Discriminator(ks={ks}): output, input gradient and 9 parameter gradients agree (fp32, fp64)")
 

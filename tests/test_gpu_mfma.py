@@ -93,10 +93,10 @@ def test_quad_channel_kernel_is_selected():
     x = torch.randn(1, 16, 8, 8, 32, device=DEV).bfloat16()
     w4 = [torch.randn(4, 4, 3, 3, 3, device=DEV) for _ in range(4)]
     X.ops.conv3d(x, None, w4, None, k=3, cout=16, groups=4)
-    assert "conv3_q4_kernel<0, false, 0, false, false" in X.ops.last_conv_kernel()      # (+ ", 2>": planes per workgroup)
+    assert "conv3_q4_kernel<0, 0, 0, false, false" in X.ops.last_conv_kernel()      # (+ ", 2>": planes per workgroup)
     X.ops.conv3d(x.half(), None, w4, None, k=3, cout=16, groups=4, pre=(torch.ones(1, 16, device=DEV), torch.zeros(1, 16, device=DEV), 0.01),
                  epi=2, red=torch.zeros(1, 16, 2, dtype=torch.float64, device=DEV))
-    assert "conv3_q4_kernel<1, true, 2, false, false" in X.ops.last_conv_kernel()
+    assert "conv3_q4_kernel<1, 1, 2, false, false" in X.ops.last_conv_kernel()
     x64 = torch.randn(1, 64, 8, 8, 32, device=DEV).bfloat16()
     X.ops.conv3d(x64, None, [torch.randn(16, 64, 3, 3, 3, device=DEV)], None, k=3, cout=16)      # > 48 channels per group
     assert "conv3_mfma_kernel" in X.ops.last_conv_kernel()

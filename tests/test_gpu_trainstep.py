@@ -79,8 +79,8 @@ def _grad_devs(m, gg):
 
 @pytest.mark.parametrize("shared", [True, False], ids=["shared_encoder", "two_forwards"])
 def test_train_step_fp32_vs_oracle(shared):
-    """fp32 storage: every generator-side quantity at fp32 round-off against the oracle; the discriminator runs on the HIP
-    kernels with fp16 activations (the reference's autocast dtype), so the terms that pass through it carry fp16 rounding."""
+    """fp32 storage, fp32 end to end: the generator's kernels in fp32 and the discriminator on its exact fp32 route
+    (Discriminator.fp32_exact; by default an fp32 input is served in fp16 like under the reference's autocast)."""
     x, mask, eps = _inputs()
     subset = [6]
     w = load("weights_seed1")
@@ -88,36 +88,51 @@ def test_train_step_fp32_vs_oracle(shared):
     m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     m.load_state_dict(w, strict=True)
     m = m.to(DEV).train()
-    ts = TrainStep(m, _disc().to(DEV), alpha=ALPHA, beta=BETA, storage=torch.float32, shared_encoder=shared)
+    disc = _disc().to(DEV)
+    disc.fp32_exact = True                           # fp32 end to end: the exact route of the discriminator (disc.DiscExactFn)
+    ts = TrainStep(m, disc, alpha=ALPHA, beta=BETA, storage=torch.float32, shared_encoder=shared)
     eps_dev = [[e.to(DEV) for e in el] for el in eps]
     got = ts.compute(x.to(DEV), mask.to(DEV), subset, eps_lists=eps_dev)
     torch.cuda.synchronize()
-    for k in ("dice", "m_dice", "recon", "kld"):
+    for k in ("dice", "m_dice", "recon", "kld", "g_gan", "loss_d", "loss"):
         a, b = got[k].item(), want[k].item()
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (k, a, b)
-    for k, tol in (("g_gan", 5e-3), ("loss_d", 5e-3), ("loss", 1e-3)):          # through the fp16 discriminator
-        a, b = got[k].item(), want[k].item()
-        assert abs(a - b) <= tol * max(1.0, abs(b)), (k, a, b)
     worst, l2 = _grad_devs(m, gg)
     dscale = max(v.abs().max().item() for v in gd.values())
     dworst = max((p.grad.cpu() - gd[k]).abs().max().item() / dscale for k, p in ts.disc.named_parameters())
     print(f"train step ({'shared encoder' if shared else 'two forwards'}): loss {got['loss'].item():.6f} (oracle {want['loss'].item():.6f}), "
           f"loss_d {got['loss_d'].item():.6f} ({want['loss_d'].item():.6f}), generator gradients worst {worst:.2e} / L2 {l2:.2e}, "
           f"discriminator gradients worst {dworst:.2e}")
-    # fp32 vs fp32 on a network that amplifies round-off ~1e4x plus the fp16 discriminator's share of the
-    # generator gradient (alpha * dLSGAN/dfake: fp16 activations through three InstanceNorm backward passes, 3e-2 relative L2
-    # on its own, tests/test_gpu_disc.py)
-    assert worst < 6e-2 and l2 < 3e-2, (worst, l2)
-    assert dworst <= 5e-2, dworst
+    # fp32 vs fp32 end to end on a network that amplifies round-off ~1e4x: the bands of the generator-only fp32
+    # comparison (test_gpu_network.py: 5e-3); with the fp16-inside discriminator these read 3.6e-2 / 2.6e-2 / 1.4e-2
+    assert worst < 6e-3 and l2 < 6e-3, (worst, l2)
+    assert dworst <= 2e-3, dworst
 
 
+def _blob_inputs(S=32, seed=11):
+    """A smooth synthetic patch with nested tumour masks (tests/synth_blobs.py: what weights_trained_like.npz was trained on)."""
+    import synth_blobs as SB
+    x, mask = SB.blob_case(seed, 1, S)
+    torch.manual_seed(7)
+    eps = [[torch.randn(1, 2 ** l, S >> (l + 1), S >> (l + 1), S >> (l + 1)) for l in range(4)] for _ in range(2)]
+    return x, mask, eps
+
+
+@pytest.mark.parametrize("weights", ["trained_like", "seed1"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-def test_train_step_16bit_vs_oracle(dtype):
+def test_train_step_16bit_vs_oracle(dtype, weights):
     """16-bit storage (the measured training step): every loss term and both gradient sets against the fp32 oracle step.
-    Bands: the storage format's rounding amplified by the randomly initialised network (amp_yardstick.json)."""
-    x, mask, eps = _inputs()
+
+    `trained_like` -- the REAL reference's weights after 300 CPU training steps (tests/golden/make_trained_like.py) on a smooth
+    synthetic patch -- carries the assertions: bounds that certify direction AND scale of the generator's gradient.  `seed1`
+    (init_weights: N(0,1) biases, a ~1e4x amplifier of any rounding) is reported and only sanity-banded; the
+    discriminator is the seeded initialisation in both (11 M parameters cannot travel as a fixture), its bands are those of
+    tests/test_gpu_disc.py: LeakyReLU(0.2) masks that flip where a 16-bit forward differs from fp32 in sign bound them from below
+    (the reference's own autocast deviates more: tests/golden/amp_yardstick.json "disc")."""
+    trained = weights == "trained_like"
+    x, mask, eps = _blob_inputs() if trained else _inputs()
     subset = [6]
-    w = load("weights_seed1")
+    w = load("weights_trained_like" if trained else "weights_seed1")
     want, gg, gd = _oracle_step(w, _disc_state(), x, mask, eps, subset)
     m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     m.load_state_dict(w, strict=True)
@@ -127,17 +142,23 @@ def test_train_step_16bit_vs_oracle(dtype):
     got = ts.compute(x.to(DEV), mask.to(DEV), subset, eps_lists=eps_dev)
     torch.cuda.synchronize()
     assert ts.check_finite()
-    k16 = 1.0 if dtype == torch.bfloat16 else 0.25
+    bf = dtype == torch.bfloat16
     dev = {k: abs(got[k].item() - want[k].item()) / max(1.0, abs(want[k].item())) for k in ("dice", "m_dice", "recon", "kld", "g_gan", "loss", "loss_d")}
     worst, l2 = _grad_devs(m, gg)
     dscale = max(v.abs().max().item() for v in gd.values())
     dworst = max((p.grad.cpu() - gd[k]).abs().max().item() / dscale for k, p in ts.disc.named_parameters())
-    print(dtype, {k: f"{v:.2e}" for k, v in dev.items()}, f"generator gradients worst {worst:.2e} / L2 {l2:.2e}, discriminator worst {dworst:.2e}")
-    # measured on MI355X (32^3, seeded init_weights): loss terms bf16 <= 2.5e-2 (g_gan) / fp16 <= 5.3e-3; gradients of the randomly
-    # initialised generator (it amplifies a perturbation ~1e4x) bf16 0.73 / fp16 0.28 relative L2, discriminator
-    # gradients 0.16 / 0.035 of the largest -- a sanity band on direction and scale, not a precision claim
-    assert all(v < 5e-2 * k16 for v in dev.values()), dev
-    assert l2 < (1.2 if dtype == torch.bfloat16 else 0.45) and dworst < 0.3 * k16, (l2, dworst)
+    dnum = sum(((p.grad.cpu() - gd[k]) ** 2).sum().item() for k, p in ts.disc.named_parameters())
+    dl2 = (dnum / sum((v ** 2).sum().item() for v in gd.values())) ** 0.5
+    print(f"train step {weights} {dtype}:", {k: f"{v:.2e}" for k, v in dev.items()},
+          f"generator gradients worst {worst:.2e} / L2 {l2:.2e}, discriminator worst {dworst:.2e} / L2 {dl2:.2e}")
+    if trained:
+        assert all(v < (2e-2 if bf else 5e-3) for v in dev.values()), dev
+        assert l2 < (0.1 if bf else 0.03), l2                       # direction and scale of the generator's gradient
+        assert dl2 < (0.2 if bf else 0.06) and dworst < (0.3 if bf else 0.08), (dl2, dworst)
+    else:
+        # random initialisation: a sanity band (measured bf16 0.73 / fp16 0.28 relative L2 of the generator's gradient)
+        assert all(v < (5e-2 if bf else 1.25e-2) for v in dev.values()), dev
+        assert l2 < (1.2 if bf else 0.45) and dworst < (0.3 if bf else 0.08), (l2, dworst)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])

@@ -1476,3 +1476,137 @@ extern "C" int xh_cl_act_bwd(void* stream, int dtype, int mode, const void* dy, 
 #undef LB
   return xh_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Exact fp32 route of the Discriminator (parity mode, small patches): plain NCDHW fp32 direct convolutions for any kernel size
+// with padding 1 -- nn.Conv3d(c, 2c, ks, stride, padding=1) of buildingblocks.py:350,354 -- forward, data gradient and weight /
+// bias gradient.  No matrix cores, no 16-bit operands: fp32 FMA in a fixed order per output, so a training step in fp32 storage
+// can be compared with the CPU oracle end to end (tests/test_gpu_trainstep.py).  One thread per output element / one workgroup
+// per (co, ci) filter: ~1 TFLOP/s, meant for 32^3 .. 64^3 patches; the matrix-core kernels above are the product path.
+struct DxArgs {
+  const float* x; const float* w; const float* b; float* y;      // fwd: x, w, b -> y;  dgrad: x = dy, y = dx;  wgrad: x, y = dy -> w = dw, b = db
+  int N, Cin, Cout, D, H, W, Do, Ho, Wo, ks, stride;
+};
+__global__ __launch_bounds__(256) void dconv_exact_fwd_kernel(const DxArgs a) {
+  const long long total = (long long)a.N * a.Cout * a.Do * a.Ho * a.Wo;
+  const int k3 = a.ks * a.ks * a.ks;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ow = (int)(i % a.Wo);
+    long long r = i / a.Wo;
+    const int oh = (int)(r % a.Ho); r /= a.Ho;
+    const int od = (int)(r % a.Do); r /= a.Do;
+    const int co = (int)(r % a.Cout);
+    const int n = (int)(r / a.Cout);
+    float acc = a.b ? a.b[co] : 0.f;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+      const float* xp = a.x + ((long long)n * a.Cin + ci) * a.D * a.H * a.W;
+      const float* wp = a.w + ((long long)co * a.Cin + ci) * k3;
+      for (int kd = 0; kd < a.ks; ++kd) {
+        const int d = od * a.stride - 1 + kd;
+        if ((unsigned)d >= (unsigned)a.D) continue;
+        for (int kh = 0; kh < a.ks; ++kh) {
+          const int h = oh * a.stride - 1 + kh;
+          if ((unsigned)h >= (unsigned)a.H) continue;
+          for (int kw = 0; kw < a.ks; ++kw) {
+            const int w = ow * a.stride - 1 + kw;
+            if ((unsigned)w >= (unsigned)a.W) continue;
+            acc = fmaf(xp[((long long)d * a.H + h) * a.W + w], wp[(kd * a.ks + kh) * a.ks + kw], acc);
+          }
+        }
+      }
+    }
+    a.y[i] = acc;
+  }
+}
+// dx[n][ci][d][h][w] = sum_co sum_taps dy[n][co][(d + 1 - kd) / s][..] w[co][ci][kd][kh][kw]   (where the division is exact)
+__global__ __launch_bounds__(256) void dconv_exact_dgrad_kernel(const DxArgs a) {
+  const long long total = (long long)a.N * a.Cin * a.D * a.H * a.W;
+  const int k3 = a.ks * a.ks * a.ks;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int w = (int)(i % a.W);
+    long long r = i / a.W;
+    const int h = (int)(r % a.H); r /= a.H;
+    const int d = (int)(r % a.D); r /= a.D;
+    const int ci = (int)(r % a.Cin);
+    const int n = (int)(r / a.Cin);
+    float acc = 0.f;
+    for (int co = 0; co < a.Cout; ++co) {
+      const float* gp = a.x + ((long long)n * a.Cout + co) * a.Do * a.Ho * a.Wo;
+      const float* wp = a.w + ((long long)co * a.Cin + ci) * k3;
+      for (int kd = 0; kd < a.ks; ++kd) {
+        const int td = d + 1 - kd;
+        if (td < 0 || td % a.stride) continue;
+        const int od = td / a.stride;
+        if (od >= a.Do) continue;
+        for (int kh = 0; kh < a.ks; ++kh) {
+          const int th = h + 1 - kh;
+          if (th < 0 || th % a.stride) continue;
+          const int oh = th / a.stride;
+          if (oh >= a.Ho) continue;
+          for (int kw = 0; kw < a.ks; ++kw) {
+            const int tw = w + 1 - kw;
+            if (tw < 0 || tw % a.stride) continue;
+            const int ow = tw / a.stride;
+            if (ow >= a.Wo) continue;
+            acc = fmaf(gp[((long long)od * a.Ho + oh) * a.Wo + ow], wp[(kd * a.ks + kh) * a.ks + kw], acc);
+          }
+        }
+      }
+    }
+    a.y[i] = acc;
+  }
+}
+// one workgroup per (co, ci): dw[co][ci][tap] += sum_n sum_out dy[n][co][out] x[n][ci][out * s - 1 + tap]; db[co] += sum dy (ci == 0)
+__global__ __launch_bounds__(256) void dconv_exact_wgrad_kernel(const DxArgs a) {
+  __shared__ double s_red[4];
+  const int co = blockIdx.x / a.Cin, ci = blockIdx.x % a.Cin;
+  const int k3 = a.ks * a.ks * a.ks;
+  const long long ovol = (long long)a.Do * a.Ho * a.Wo, vol = (long long)a.D * a.H * a.W;
+  for (int tap = 0; tap <= k3; ++tap) {                 // tap == k3: the bias gradient (ci == 0 only)
+    if (tap == k3 && (ci != 0 || !a.b)) break;
+    const int kd = tap / (a.ks * a.ks), kh = (tap / a.ks) % a.ks, kw = tap % a.ks;
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < (long long)a.N * ovol; i += 256) {
+      const int n = (int)(i / ovol);
+      const long long o = i - (long long)n * ovol;
+      const float g = a.y[((long long)n * a.Cout + co) * ovol + o];
+      if (tap == k3) { acc += (double)g; continue; }
+      const int ow = (int)(o % a.Wo), oh = (int)((o / a.Wo) % a.Ho), od = (int)(o / ((long long)a.Wo * a.Ho));
+      const int d = od * a.stride - 1 + kd, h = oh * a.stride - 1 + kh, w = ow * a.stride - 1 + kw;
+      if ((unsigned)d >= (unsigned)a.D || (unsigned)h >= (unsigned)a.H || (unsigned)w >= (unsigned)a.W) continue;
+      acc += (double)g * (double)a.x[((long long)n * a.Cin + ci) * vol + ((long long)d * a.H + h) * a.W + w];
+    }
+    double v[1] = {acc};
+    block_sum_d<1>(v, s_red, 4);
+    if (threadIdx.x == 0) {
+      if (tap == k3) const_cast<float*>(a.b)[co] += (float)s_red[0];
+      else const_cast<float*>(a.w)[((long long)co * a.Cin + ci) * k3 + tap] += (float)s_red[0];
+    }
+    __syncthreads();
+  }
+}
+static int dx_check(const DxArgs& a) {
+  if (!a.x || !a.w || !a.y || a.N <= 0 || a.Cin <= 0 || a.Cout <= 0 || a.ks < 1 || a.ks > 7 || a.stride < 1 || a.stride > 2) return XH_ERR_ARG;
+  if (a.Do != (a.D + 2 - a.ks) / a.stride + 1 || a.Ho != (a.H + 2 - a.ks) / a.stride + 1 || a.Wo != (a.W + 2 - a.ks) / a.stride + 1) return XH_ERR_ARG;
+  if (a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return XH_ERR_ARG;
+  return XH_OK;
+}
+// mode 0: y = conv(x, w) + b;  1: dx (written to y) from dy (= x) and w;  2: dw (= w) += , db (= b, may be NULL) += from x and dy (= y)
+extern "C" int xh_dconv_exact(void* stream, int mode, const float* x, const float* w, const float* b, float* y, int N, int Cin, int Cout,
+                              int D, int H, int W, int Do, int Ho, int Wo, int ks, int stride) {
+  DxArgs a{x, w, b, y, N, Cin, Cout, D, H, W, Do, Ho, Wo, ks, stride};
+  const int rc = dx_check(a);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    const long long total = (long long)N * Cout * Do * Ho * Wo;
+    hipLaunchKernelGGL(dconv_exact_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (long long)65536)), dim3(256), 0, st, a);
+  } else if (mode == 1) {
+    const long long total = (long long)N * Cin * D * H * W;
+    hipLaunchKernelGGL(dconv_exact_dgrad_kernel, dim3((unsigned)min((total + 255) / 256, (long long)65536)), dim3(256), 0, st, a);
+  } else if (mode == 2) {
+    if ((long long)Cout * Cin > 0x7fffffffll) return XH_ERR_ARG;
+    hipLaunchKernelGGL(dconv_exact_wgrad_kernel, dim3((unsigned)(Cout * Cin)), dim3(256), 0, st, a);
+  } else return XH_ERR_ARG;
+  return xh_launch_status();
+}

@@ -301,6 +301,89 @@ class DiscPairFn(Function):
         return (None, None, *rets)
 
 
+def _xconv(mode, x, w, b, y, n, cin, cout, sp_in, sp_out, ks, stride):
+    L.check(L.load().xh_dconv_exact(_s(), mode, ops._p(x), ops._p(w), ops._p(b), ops._p(y), n, cin, cout, *sp_in, *sp_out, ks, stride),
+            "xh_dconv_exact")
+
+
+class DiscExactFn(Function):
+    """The discriminator in EXACT fp32 (Discriminator.fp32_exact): NCDHW fp32 activations, direct fp32 convolutions
+    (xh_dconv_exact), InstanceNorm / LeakyReLU(0.2) through the generic fp32 passes of the generator's path.  No 16-bit operand:
+    a training step in fp32 storage then agrees with the CPU oracle to fp32 round-off end to end.  A parity route (~1 TFLOP/s),
+    not the product path."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        w0, b0, w1, b1, w2, b2, w3, b3, wl = params
+        x = x.contiguous()
+        n, cin = x.shape[:2]
+        ks = w0.shape[2]
+        sp = _extents(x.shape, ks)
+        ws, bs = (w0, w1, w2, w3, wl), (b0, b1, b2, b3, None)
+        new = lambda c, s_: torch.empty((n, c) + tuple(s_), dtype=torch.float32, device=x.device)
+        ins, raws, stats = [x], [], []
+        h = x
+        for k in range(4):
+            c = ws[k].shape[0]
+            raw = new(c, sp[k + 1])
+            _xconv(0, h, ws[k], bs[k], raw, n, ws[k].shape[1], c, sp[k], sp[k + 1], ks, STRIDES[k])
+            raws.append(raw)
+            if k == 0:
+                h = ops.affine_act(raw, None, None, L.ACT_LRELU, SLOPE)
+                stats.append(None)
+            else:
+                red = ops.zeros_red(raw, n, c)
+                ops.moments(raw, red)
+                h, sc, sh, mean, rstd = ops.in_affine_act(raw, red, L.ACT_LRELU, SLOPE)
+                stats.append((sc, sh, mean, rstd))
+            ins.append(h)
+        out = new(1, sp[5])
+        _xconv(0, h, wl, None, out, n, wl.shape[1], 1, sp[4], sp[5], ks, 1)
+        ctx.save_for_backward(*ins, *raws, *[t for st in stats[1:] for t in st], w0, w1, w2, w3, wl)
+        ctx.meta = (n, cin, sp, ks)
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .functional import _targets
+        n, cin, sp, ks = ctx.meta
+        sv = ctx.saved_tensors
+        ins, raws, st, ws = sv[:5], sv[5:9], sv[9:21], sv[21:26]
+        stats = [None] + [st[4 * i:4 * i + 4] for i in range(3)]
+        need_w = any(ctx.needs_input_grad[1:])
+        gb, rets = _targets(ctx.params) if need_w else ([None] * 9, [None] * 9)
+        g_w = (gb[0], gb[2], gb[4], gb[6], gb[8])
+        g_b = (gb[1], gb[3], gb[5], gb[7], None)
+        dy = dout.contiguous().float()
+        new = lambda c, s_: torch.empty((n, c) + tuple(s_), dtype=torch.float32, device=dy.device)
+        if need_w:
+            _xconv(2, ins[4], g_w[4], None, dy, n, ws[4].shape[1], 1, sp[4], sp[5], ks, 1)
+        da = new(ws[4].shape[1], sp[4])
+        _xconv(1, dy, ws[4], None, da, n, ws[4].shape[1], 1, sp[4], sp[5], ks, 1)
+        dx = None
+        for k in (3, 2, 1, 0):
+            c, ci = ws[k].shape[0], ws[k].shape[1]
+            raw = raws[k]
+            if k == 0:                                      # conv + bias -> LeakyReLU
+                one = torch.ones((n, c), dtype=torch.float32, device=dy.device)
+                zero = torch.zeros((n, c), dtype=torch.float32, device=dy.device)
+                dc = ops.norm_bwd_apply(da, raw, (one, zero, zero), have_g=False, sc=one, sh=zero, slope=SLOPE)
+            else:                                           # conv (+ identity bias) -> InstanceNorm -> LeakyReLU
+                sc, sh, mean, rstd = stats[k]
+                red = ops.act_bwd_reduce(da, raw, sc, sh, SLOPE)
+                dc = ops.in_bwd_apply(da, raw, red, mean, rstd, have_g=False, sc=sc, sh=sh, slope=SLOPE)
+            if need_w:
+                _xconv(2, ins[k], g_w[k], g_b[k], dc, n, ci, c, sp[k], sp[k + 1], ks, STRIDES[k])
+            if k > 0 or ctx.needs_input_grad[0]:
+                nxt = new(ci, sp[k])
+                _xconv(1, dc, ws[k], None, nxt, n, ci, c, sp[k], sp[k + 1], ks, STRIDES[k])
+                if k == 0:
+                    dx = nxt
+                da = nxt
+        return (dx, *rets)
+
+
 class Discriminator(nn.Module):
     """RA_HVED.py:204-236 on the HIP path (module docstring).  `Discriminator(in_channels=7, ks=4, strides=[1,2,2,2])` is the
     call of train.py:146 / Pretrain.py:150; ks = 3 is the class default."""
@@ -334,6 +417,8 @@ class Discriminator(nn.Module):
         batch a second pass with it."""
         if input_level != 0:
             raise NotImplementedError("input_level > 0 is not used by train.py")
+        if getattr(self, "fp32_exact", False) and x.dtype == torch.float32:
+            return DiscExactFn.apply(x, *self._params())   # (no shared second pass: forward_pair falls back to two passes)
         return DiscFn.apply(x, share, *self._params())
 
     def forward_pair(self, x, share):
