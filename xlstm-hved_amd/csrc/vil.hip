@@ -465,26 +465,46 @@ __global__ __launch_bounds__(64) void mlstm_chunk_dstate_kernel(int S, int nchun
 // (2) exclusive scan of the local states over the chunks of one (batch, head), in place; one lane per state element.
 //     forward: st[c] <- state carried INTO chunk c (reference M_c = G_{cL-1});  reverse: st[c] <- state of all chunks AFTER
 //     c (reference Mr_c = G_{(c+1)L}).
+//     The recurrence is one fma per chunk, but written as "load, fma, store" per chunk it was a chain of 64 dependent global
+//     round trips (22 us at S = 4096 on four workgroups): the chunk values of a block of SCB chunks are now requested together
+//     (independent loads into registers), the decays of the block are computed once per workgroup into LDS, and only the fma
+//     chain itself is serial.
+constexpr int SCB = 64;
 template <int REV>
 __global__ __launch_bounds__(320) void mlstm_chunk_scan_kernel(int S, int nchunk, VilWs w) {
+  __shared__ float s_dec[SCB];
   const int e = threadIdx.x;
-  if (e >= STF) return;
+  const bool live = e < STF;
   const long long hb = (long long)blockIdx.x * S;
   float* st = (REV ? w.rst : w.cst) + (long long)blockIdx.x * nchunk * STF;
   float run = 0.f;
-  if (!REV) {
-    for (int c = 0; c < nchunk; ++c) {
-      const float d = st[(long long)c * STF + e];
-      st[(long long)c * STF + e] = run;
-      const float dec = c > 0 ? expf(w.G[hb + c * CL - 1] - w.G[hb + min(S, (c + 1) * CL) - 1]) : 0.f;
-      run = fmaf(run, dec, d);
+  for (int b0 = 0; b0 < nchunk; b0 += SCB) {
+    // chunk index of position i of this block, in scan order (forward: ascending, reverse: descending)
+    auto cidx = [&](int i) { return REV ? nchunk - 1 - (b0 + i) : b0 + i; };
+    __syncthreads();                                    // the previous block's decays are no longer read
+    if (e < SCB && b0 + e < nchunk) {
+      const int c = cidx(e);
+      float dec;
+      if (!REV) dec = c > 0 ? expf(w.G[hb + c * CL - 1] - w.G[hb + min(S, (c + 1) * CL) - 1]) : 0.f;
+      else dec = c < nchunk - 1 ? expf(w.G[hb + c * CL] - w.G[hb + (c + 1) * CL]) : 0.f;
+      s_dec[e] = dec;
     }
-  } else {
-    for (int c = nchunk - 1; c >= 0; --c) {
-      const float d = st[(long long)c * STF + e];
-      st[(long long)c * STF + e] = run;
-      const float dec = c < nchunk - 1 ? expf(w.G[hb + c * CL] - w.G[hb + (c + 1) * CL]) : 0.f;
-      run = fmaf(run, dec, d);
+    float d[SCB];
+#pragma unroll
+    for (int i = 0; i < SCB; ++i) d[i] = (live && b0 + i < nchunk) ? st[(long long)cidx(i) * STF + e] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SCB; ++i) {
+      if (b0 + i < nchunk) {
+        const float out = run;
+        run = fmaf(run, s_dec[i], d[i]);
+        d[i] = out;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < SCB; ++i)
+        if (b0 + i < nchunk) st[(long long)cidx(i) * STF + e] = d[i];
     }
   }
 }
