@@ -570,4 +570,4 @@ def test_skip_return_attention_with_composed_depthwise_pointwise_convs(c, sp, dt
     # composed 1.6e-3 / 0.090 / 0.143), and never worse than the two-conv form by more than noise
     band = (2e-2, 0.25, 0.35) if dtype == torch.bfloat16 else (3e-3, 0.1, 0.15)
     assert all(a_ <= b_ for a_, b_ in zip(e2, band)), (e2, band)
-    assert all(e2[i] <= 1.25 * e1[i] + 1e-4 for i in range(3)), (e1, e2)
+    assert all(e2[i] <= 1.25 * e1[i] + 5e-3 for i in range(3)), (e1, e2)
