@@ -25,6 +25,7 @@
 extern "C" {
 #endif
 
+#define XH_MAX_WPTR 8            /* weight / bias / gradient pointers per conv call: one per group for up to 8 groups */
 #define XH_F32 0
 #define XH_BF16 1
 #define XH_F16 2
@@ -58,7 +59,7 @@ int xh_abi_version(void);
  * PROCESS-GLOBAL STATE (the only two exceptions to "no mutable state in the library"): the option table behind
  * xh_set_option (plain ints, e.g. g_q4_maxc / g_q4_wgs in csrc/conv3d_q4.hip) and the name buffer behind xh_last_conv_kernel
  * are per PROCESS, not per device, stream or call.  They are development / measurement knobs: every option has a default that
- * is the measured optimum, no product code path (xlstm-hved_amd/*.py outside bench/tests) sets one, and the deployment model is
+ * is the measured optimum, no product code path (the package's Python files; bench and tests do) sets one, and the deployment model is
  * one process per GPU.  Neither function is thread-safe against concurrent launches from other host threads: set options
  * before the first launch; read xh_last_conv_kernel on the thread that made the call.  Every other entry point is re-entrant:
  * all device memory, workspaces and the statistics fan-in block are the caller's, the stream is an argument. */
@@ -83,7 +84,7 @@ typedef struct {
   int k, stride;                /* k in {1,3,7}; padding = k/2; stride in {1,2} (2 only with k=3) */
   int Ca;                       /* input channels [0,Ca) come from xa, [Ca,Cin) from xb (Ca==Cin: xb unused) */
   long long xa_bs, xb_bs, y_bs; /* batch strides (elements) */
-  int n_wptr;                   /* 1: w[0] holds all groups; ==groups (<=4): w[g] holds group g */
+  int n_wptr;                   /* 1: w[0] holds all groups; ==groups (<= XH_MAX_WPTR): w[g] holds group g */
   int transposed;               /* 1: compute the data-gradient correlation using FORWARD-layout weights
                                    [Cin][Cout/groups][k^3] (roles swapped, taps flipped); stride must be 1 */
   int pre;                      /* 1: input transform v = leaky(x*pre_sc[n,c] + pre_sh[n,c], pre_slope)
@@ -106,7 +107,7 @@ typedef struct {
 
 typedef struct {
   const void* xa; const void* xb;
-  const float* w[4]; const float* b[4];       /* b[i] may be NULL (no bias) */
+  const float* w[XH_MAX_WPTR]; const float* b[XH_MAX_WPTR];       /* b[i] may be NULL (no bias) */
   const float* pre_sc; const float* pre_sh;   /* [N][Cin] when pre */
   void* y;
   const void* ea; const void* eb;             /* epi==1 */
@@ -165,7 +166,7 @@ int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* 
 /* Weight/bias gradient: dw[co][ci][tap] += sum_{n,p} dy[n,co,p] * pre(x)[n,ci,p*stride+tap-pad],
  * db[co] += sum dy.  Desc describes the FORWARD conv; ptrs: xa/xb/pre_* = forward input, `ea` = dY with
  * batch stride ea_bs.  dw[i]/db[i] are laid out like w[i]/b[i], fp32, ACCUMULATED into (caller zeroes). */
-int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
+int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR]);
 /* The weight gradients of `n` convolutions in as few launches as possible: d[i] / p[i] / dw[i] / db[i] are what
  * xh_conv3d_wgrad would take for problem i (db may be NULL, db[i][j] may be NULL).  Weight gradients are off the critical
  * path of a backward pass, so a caller can collect them and issue this once at the end: the k=3 MFMA problems of a
@@ -173,7 +174,7 @@ int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, 
  * launches one after the other), the k=1 problems of a storage type 20 at a time, the 7^3 gate problems 4 at a time, the 1<->2-channel k=3 stencils 8 at a time, the vectorised k=3 stride-2
  * problems 4 at a time, everything else is forwarded to xh_conv3d_wgrad.  Same accumulate (+=) semantics. */
 int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p,
-                          float* const (*dw)[4], float* const (*db)[4]);
+                          float* const (*dw)[XH_MAX_WPTR], float* const (*db)[XH_MAX_WPTR]);
 /* Scratch (bytes) xh_conv3d_wgrad wants in p->ws for this shape (per-workgroup partial gradients of the 7^3 MFMA weight
  * gradient); 0 = none.  With less, the call uses the vector kernel. */
 long long xh_conv3d_wgrad_workspace_bytes(const xh_conv_desc* d);

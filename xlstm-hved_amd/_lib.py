@@ -17,6 +17,9 @@ vp = C.c_void_p
 ll = C.c_longlong
 
 
+MAX_WPTR = 8          # == XH_MAX_WPTR
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("N", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("groups", C.c_int),
@@ -32,7 +35,7 @@ class ConvDesc(C.Structure):
 
 class ConvPtrs(C.Structure):
     _fields_ = [
-        ("xa", vp), ("xb", vp), ("w", vp * 4), ("b", vp * 4), ("pre_sc", vp), ("pre_sh", vp), ("y", vp),
+        ("xa", vp), ("xb", vp), ("w", vp * MAX_WPTR), ("b", vp * MAX_WPTR), ("pre_sc", vp), ("pre_sh", vp), ("y", vp),
         ("ea", vp), ("eb", vp), ("e_sc", vp), ("e_sh", vp), ("red", vp), ("ws", vp), ("ws_bytes", ll),
         ("fin_red", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_count", ll), ("ws_packed", C.c_int),
         ("fan", vp), ("fan_bytes", ll),
@@ -84,7 +87,7 @@ SIGNATURES = {
     "xh_conv3d_prepack": (I, [vp, I, vp, vp]),
     "xh_conv3d_wgrad_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
-    "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * 4), C.POINTER(vp * 4)]),
+    "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * MAX_WPTR), C.POINTER(vp * MAX_WPTR)]),
     "xh_conv3d_wgrad_batch": (I, [vp, I, vp, vp, vp, vp]),
     "xh_moments": (I, [vp, I, vp, ll, I, I, ll, vp, ll]),
     "xh_moments2": (I, [vp, I, vp, ll, I, vp, ll, I, I, ll, vp, ll]),

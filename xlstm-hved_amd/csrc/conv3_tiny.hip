@@ -260,8 +260,8 @@ int xh_conv3_tiny_wgrad_try(void* stream, const xh_conv_desc* d, const xh_conv_p
 
 // The problems of a batch this file's weight-gradient kernel takes, TINY_MULTI per launch, storage type and channel shape
 // (marked in handled[]; a lone problem is left to the ordinary entry point)
-int xh_tiny_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                        float* const (*db)[4], char* handled) {
+int xh_tiny_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                        float* const (*db)[XH_MAX_WPTR], char* handled) {
   extern int g_xh_disable;
   int xh_check_conv(const xh_conv_desc* d, const xh_conv_ptrs* p);
   if (g_xh_disable & 512) return XH_OK;

@@ -857,8 +857,8 @@ __global__ __launch_bounds__(256) void conv3_dgrad_s2_kernel(const ConvK a) {
 // ---------------------------------------------------------------------------------------------------
 struct WgradK {
   ConvK c;
-  float* dw[4];
-  float* db[4];
+  float* dw[XH_MAX_WPTR];
+  float* db[XH_MAX_WPTR];
   int tiles_total;      // N * tiles per sample
   int tiles_per_block;
 };
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const WgradK wa) {
 struct C1WP {
   const void *xa, *xb, *dy;
   const float *pre_sc, *pre_sh;
-  float* dw[4];
+  float* dw[4];                                         // (k = 1 problems with more than 4 weight pointers run one by one)
   float* db[4];
   long long xa_bs, xb_bs, ea_bs, dhw;
   int N, Cin, Ca, Cin_g, Cout_g, groups, n_wptr, pre, gx, ny;
@@ -1238,7 +1238,7 @@ static int check_desc(const xh_conv_desc* d, const xh_conv_ptrs* p) {
   if (d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) return XH_ERR_ARG;
   if (d->Ca < 0 || d->Ca > d->Cin) return XH_ERR_ARG;
   if (!p->xa || (d->Ca < d->Cin && !p->xb)) return XH_ERR_ARG;
-  if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= 4))) return XH_ERR_ARG;
+  if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= XH_MAX_WPTR))) return XH_ERR_ARG;
   for (int i = 0; i < d->n_wptr; ++i)
     if (!p->w[i]) return XH_ERR_ARG;
   if (d->pre < 0 || d->pre > 2) return XH_ERR_ARG;
@@ -1480,8 +1480,8 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
 
 int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv3d_mfma.hip
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);   // conv7_mfma.hip
-int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
-int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
+int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR]);
+int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR]);
 int g_use_mfma = 1;
 int g_xh_disable = 0;
 static char g_last_kernel[96] = "";
@@ -1725,7 +1725,7 @@ extern "C" int xh_conv3d_dgrad_s2(void* stream, const xh_conv_desc* d, const xh_
   if (d->dtype != XH_F32 && d->dtype != XH_BF16 && d->dtype != XH_F16) return XH_ERR_DTYPE;
   if (d->k != 3 || d->stride != 2 || d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return XH_ERR_ARG;
   if (d->Do != (d->D - 1) / 2 + 1 || d->Ho != (d->H - 1) / 2 + 1 || d->Wo != (d->W - 1) / 2 + 1) return XH_ERR_ARG;
-  if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= 4))) return XH_ERR_ARG;
+  if (!(d->n_wptr == 1 || (d->n_wptr == d->groups && d->groups <= XH_MAX_WPTR))) return XH_ERR_ARG;
   for (int i = 0; i < d->n_wptr; ++i)
     if (!p->w[i]) return XH_ERR_ARG;
   if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cin && !p->eb))) return XH_ERR_ARG;
@@ -2007,15 +2007,15 @@ __global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_multi_kernel(const S2W
 }
 
 // launch plan of the vectorised stride-2 weight gradient; false: not eligible
-static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgradK* wa, int* lw_,
+static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgradK* wa, int* lw_,
                      dim3* grid);
 
 template <typename T>
-static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4],
-                          float* const db[4]) {
+static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR],
+                          float* const db[XH_MAX_WPTR]) {
   const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
   WgradK wa;
-  for (int i = 0; i < 4; ++i) { wa.dw[i] = i < d->n_wptr ? dw[i] : nullptr; wa.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  for (int i = 0; i < XH_MAX_WPTR; ++i) { wa.dw[i] = i < d->n_wptr ? dw[i] : nullptr; wa.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
   if (d->k == 1) {
     wa.c = make_k(d, p, 4, 8);
     const long long dhw1 = (long long)d->D * d->H * d->W;
@@ -2096,8 +2096,8 @@ static int wgrad_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_ptr
   return xh_launch_status();
 }
 
-extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4],
-                               float* const db[4]) {
+extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR],
+                               float* const db[XH_MAX_WPTR]) {
   int rc = check_desc(d, p);
   if (rc) return rc;
   if (!p->ea || !dw || d->transposed) return XH_ERR_ARG;
@@ -2117,7 +2117,8 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
 
 // k = 1 weight gradients of a batch (xh_conv3d_wgrad_batch): those conv1x1_wgrad_multi_kernel can take (16-byte runs) go
 // C1W_MULTI per launch and storage type and are marked in handled[]; the others are left to the caller's one-by-one path.
-static bool c1w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], C1WP* o) {
+static bool c1w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], C1WP* o) {
+  if (d->n_wptr > 4) return false;
   if (check_desc(d, p) || d->k != 1 || d->stride != 1 || d->transposed || !p->ea || !dw) return false;
   if (d->n_wptr < 1 || d->groups % d->n_wptr) return false;
   for (int i = 0; i < d->n_wptr; ++i)
@@ -2151,8 +2152,8 @@ static int c1w_launch(void* stream, int dtype, const C1WP* v, int n) {
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL((conv1x1_wgrad_multi_kernel<T>), dim3(m.off[n]), dim3(256), 0, (hipStream_t)stream, m););
   return xh_launch_status();
 }
-int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                 float* const (*db)[4], char* handled) {
+int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                 float* const (*db)[XH_MAX_WPTR], char* handled) {
   if (g_xh_disable & 512) return XH_OK;
   int rc_all = XH_OK;
   const int types[3] = {XH_F32, XH_BF16, XH_F16};
@@ -2177,7 +2178,7 @@ int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
   return rc_all;
 }
 
-static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgradK* wa, int* lw_,
+static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgradK* wa, int* lw_,
                      dim3* grid) {
   const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
   if (!(d->k == 3 && d->stride == 2 && (cout_g == 2 || cout_g % 4 == 0) && !(g_xh_disable & 4))) return false;
@@ -2188,7 +2189,7 @@ static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const 
                   odhw2 % (VW / 2) == 0 && d->xa_bs % VW == 0 && d->xb_bs % VW == 0 && d->ea_bs % (VW / 2) == 0 &&
                   (long long)cin_g * (cout_g / (cout_g == 2 ? 2 : 4)) <= 65535 && (long long)d->N * d->groups <= 65535;
   if (!al) return false;
-  for (int i = 0; i < 4; ++i) { wa->dw[i] = i < d->n_wptr ? dw[i] : nullptr; wa->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  for (int i = 0; i < XH_MAX_WPTR; ++i) { wa->dw[i] = i < d->n_wptr ? dw[i] : nullptr; wa->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
   wa->c = make_k(d, p, 1, 8);
   wa->tiles_total = wa->tiles_per_block = 0;
   const int chunks = cout_g == 2 ? 1 : cout_g / 4;
@@ -2202,8 +2203,8 @@ static bool s2w_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const 
   return true;
 }
 // k = 3 stride-2 weight gradients of a batch with groups of 4 k output channels: S2W_MULTI per launch and storage type
-int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                 float* const (*db)[4], char* handled) {
+int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                 float* const (*db)[XH_MAX_WPTR], char* handled) {
   if (g_xh_disable & 512) return XH_OK;
   int rc_all = XH_OK;
   const int types[3] = {XH_F32, XH_BF16, XH_F16};

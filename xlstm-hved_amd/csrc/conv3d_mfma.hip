@@ -53,7 +53,7 @@ int g_mfma_occ = 0;        // xh_set_option(4, 1): high-occupancy (<=128 VGPR) i
 
 static void mk_pack_job(const ConvMK& a, PackJob* j) {
   j->dw = 0;
-  for (int i = 0; i < 4; ++i) j->w[i] = a.p.w[i];
+  for (int i = 0; i < XH_MAX_WPTR; ++i) j->w[i] = a.p.w[i];
   j->ws = a.p.ws;
   j->kind = 0;
   j->f16 = a.d.dtype == XH_F16;

@@ -499,7 +499,7 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
 }
 
 static void q4_pack_job(const ConvQ4& a, PackJob* j) {
-  for (int i = 0; i < 4; ++i) j->w[i] = a.p.w[i];
+  for (int i = 0; i < XH_MAX_WPTR; ++i) j->w[i] = a.p.w[i];
   j->ws = a.p.ws;
   j->kind = 1;
   j->f16 = a.d.dtype == XH_F16;

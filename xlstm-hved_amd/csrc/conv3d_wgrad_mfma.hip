@@ -26,8 +26,8 @@ typedef f32x4_t f32x4;
 struct WgMK {
   xh_conv_desc d;
   xh_conv_ptrs p;
-  float* dw[4];
-  float* db[4];
+  float* dw[XH_MAX_WPTR];
+  float* db[XH_MAX_WPTR];
   int Cin_g, Cout_g;
   int tilesW, tilesH, sd, dsegs;
   int gs;           // groups per set
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_multi_kernel(const WgM
 
 struct WgPlan { WgMK a; unsigned gx; int ny; size_t shm; bool big; int cp; };
 // fills the launch plan; returns false when the shape is not eligible for the MFMA weight gradient
-static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgPlan* pl) {
+static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgPlan* pl) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return false;
   if ((d->W % 32 != 0 && d->W != 16 && d->W != 8) || d->Wo != d->W) return false;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
@@ -302,7 +302,7 @@ static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const d
   WgMK& a = pl->a;
   a.d = *d; a.p = *p;
   if (!d->pre) a.d.pre_slope = 1.f;
-  for (int i = 0; i < 4; ++i) { a.dw[i] = i < d->n_wptr ? dw[i] : nullptr; a.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  for (int i = 0; i < XH_MAX_WPTR; ++i) { a.dw[i] = i < d->n_wptr ? dw[i] : nullptr; a.db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
   a.Cin_g = cin_g; a.Cout_g = cout_g;
   int gs = 1;
   while (gs * 2 <= d->groups && d->groups % (gs * 2) == 0 && gs * 2 * cin_g <= 16 && gs * 2 * cout_g <= 16) gs *= 2;
@@ -347,7 +347,7 @@ static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const d
 }
 
 // returns XH_OK if launched, 1 if not eligible
-int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
+int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR]) {
   {                                                   // few channels per group: the quad-channel kernel (conv3d_wgrad_q4.hip)
     WgQ4 q;
     if (xh_wgrad_q4_plan(d, p, dw, db, &q)) {
@@ -386,18 +386,18 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
 // Weight gradients of `n` convolutions (see xlstm_hved.h).  Problems the MFMA kernel can take (k = 3, stride 1, 16-bit
 // storage, >= 4 input channels per group, the default 4-channel tiles) are grouped by (storage format, volume class) and
 // launched WG_MULTI at a time; the others go through xh_conv3d_wgrad one by one.
-extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]);
+extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR]);
 extern int g_use_mfma;
-int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                 float* const (*db)[4], char* handled);
-int xh_tiny_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                        float* const (*db)[4], char* handled);
-int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                 float* const (*db)[4], char* handled);
-int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                 float* const (*db)[4], char* handled);
+int xh_c1w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                 float* const (*db)[XH_MAX_WPTR], char* handled);
+int xh_tiny_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                        float* const (*db)[XH_MAX_WPTR], char* handled);
+int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                 float* const (*db)[XH_MAX_WPTR], char* handled);
+int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                 float* const (*db)[XH_MAX_WPTR], char* handled);
 extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p,
-                                     float* const (*dw)[4], float* const (*db)[4]) {
+                                     float* const (*dw)[XH_MAX_WPTR], float* const (*db)[XH_MAX_WPTR]) {
   if (n < 0 || (n > 0 && (!d || !p || !dw))) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   int rc_all = XH_OK;

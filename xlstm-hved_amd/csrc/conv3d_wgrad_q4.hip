@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4
 }
 
 // fills the plan; false when the shape is not for this kernel
-bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgQ4* a) {
+bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgQ4* a) {
   extern int g_xh_disable;
   if (g_xh_disable & 32) return false;
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1 || d->transposed) return false;
@@ -543,7 +543,7 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   if (d->D < 4 || d->H < 4) return false;
   a->xa = p->xa; a->xb = p->xb; a->dy = p->ea;
   a->pre_sc = p->pre_sc; a->pre_sh = p->pre_sh;
-  for (int i = 0; i < 4; ++i) { a->dw[i] = i < d->n_wptr ? dw[i] : nullptr; a->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
+  for (int i = 0; i < XH_MAX_WPTR; ++i) { a->dw[i] = i < d->n_wptr ? dw[i] : nullptr; a->db[i] = (i < d->n_wptr && db) ? db[i] : nullptr; }
   a->xa_bs = d->xa_bs; a->xb_bs = d->xb_bs; a->dy_bs = d->ea_bs;
   a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->groups = groups; a->n_wptr = d->n_wptr; a->Ca = d->Ca;
   a->dwm = dwm ? 1 : 0;

@@ -260,7 +260,7 @@ extern "C" long long xh_conv3d_wgrad_workspace_bytes(const xh_conv_desc* d) {
 }
 
 // returns XH_OK if launched, 1 if not eligible (caller falls back to the vector kernel)
-int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4]) {
+int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR]) {
   if (!wg7_eligible(d)) return 1;
   const long long need = xh_conv3d_wgrad_workspace_bytes(d);
   if (!p->ws || p->ws_bytes < need) return 1;
@@ -282,8 +282,8 @@ int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
 }
 
 // 7^3 weight gradients of a batch: WG7_MULTI per launch and storage format (marked in handled[]); see conv7_wgrad_mfma_multi_kernel
-int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[4],
-                 float* const (*db)[4], char* handled) {
+int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, float* const (*dw)[XH_MAX_WPTR],
+                 float* const (*db)[XH_MAX_WPTR], char* handled) {
   extern int g_xh_disable;
   int xh_check_conv(const xh_conv_desc* d, const xh_conv_ptrs* p);
   if (g_xh_disable & 512) return XH_OK;

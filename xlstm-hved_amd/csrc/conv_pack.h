@@ -5,10 +5,11 @@
 // launch up front (xh_conv3d_prepack, conv3_pack_multi_kernel) instead of one small launch in front of each convolution; the
 // job record below is everything a pack needs, small enough for two dozen of them to travel in the kernel arguments.
 #pragma once
+#include "../../include/xlstm_hved.h"
 #include "common.h"
 
 struct PackJob {
-  const float* w[4];
+  const float* w[XH_MAX_WPTR];
   void* ws;
   int kind;                                  // 0: implicit-GEMM fragments, 1: quad-channel Toeplitz fragments
   int f16, groups, n_wptr, transposed, Cin_g, Cout_g;

@@ -6,7 +6,7 @@
 struct WgQ4 {
   const void* xa; const void* xb; const void* dy;
   const float* pre_sc; const float* pre_sh;
-  float* dw[4]; float* db[4];
+  float* dw[XH_MAX_WPTR]; float* db[XH_MAX_WPTR];
   long long xa_bs, xb_bs, dy_bs;
   int N, Cin, Cout, groups, n_wptr, Ca, D, H, W;
   int Cin_g, Cout_g, ci4, pre;   // ci4 = input-channel quads per unit (1..3)
@@ -22,5 +22,5 @@ struct WgQ4 {
 };
 
 constexpr int WQ_MULTI = 8;         // problems per launch (the table travels in the kernel arguments)
-bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[4], float* const db[4], WgQ4* a);
+bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgQ4* a);
 void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);

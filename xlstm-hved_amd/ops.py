@@ -55,7 +55,7 @@ def _f32(t, what):
 
 
 def _arr4(tensors):
-    a = (C.c_void_p * 4)()
+    a = (C.c_void_p * L.MAX_WPTR)()
     for i, t in enumerate(tensors):
         a[i] = _p(t)
     return a
@@ -579,10 +579,10 @@ def _batch_call(calls):
     n = len(calls)
     descs = (C.POINTER(L.ConvDesc) * n)(*[C.pointer(c[0]) for c in calls])
     ptrs = (C.POINTER(L.ConvPtrs) * n)(*[C.pointer(c[1]) for c in calls])
-    dws = ((C.c_void_p * 4) * n)()
-    dbs = ((C.c_void_p * 4) * n)()
+    dws = ((C.c_void_p * L.MAX_WPTR) * n)()
+    dbs = ((C.c_void_p * L.MAX_WPTR) * n)()
     for i, c in enumerate(calls):
-        for j in range(4):
+        for j in range(L.MAX_WPTR):
             dws[i][j] = c[2][j]
             dbs[i][j] = c[3][j]
     L.check(L.load().xh_conv3d_wgrad_batch(_stream(), n, descs, ptrs, dws, dbs), "xh_conv3d_wgrad_batch")
