@@ -357,10 +357,13 @@ int xh_gate2_bwd(void* stream, int dtype, const void* xa, long long xa_bs, int C
  * xh_maxpool2_fwd + xh_moments).  bwd: dx = dy routed to the first maximum of its window, times (1 + s); ds = sum over channels
  * of the routed dy times x (s has one channel). */
 int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y, long long y_bs,
-                        int N, int C, int D, int H, int W, double* red);
+                        int N, int C, int D, int H, int W, double* red, int Cg);
+/* Cg: the gate applies to channels [0, Cg) only (0 or > C: all) -- the skip stream of the skip-return path rides through the
+ * modality streams' pooling launch ungated (RA_HVED.py:552 gates the four streams, :621 pools the skip stream without a gate);
+ * its channels take no part in ds. */
 int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, const void* dy,
                         long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N, int C, int D, int H, int W,
-                        int acc_dx /* 1: dx += (another consumer's gradient share is already there) */);
+                        int acc_dx /* 1: dx += (another consumer's gradient share is already there) */, int Cg);
 int xh_gate_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs,
                 const void* dy, long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N,
                 int C, long long DHW, int acc_dx, int acc_ds);

@@ -782,3 +782,44 @@ def test_recon_seg_pair_launches_equal_the_per_stream_decoder(dtype, size):
           f"BatchNorm buffers {bworst:.2e}")
     assert worst <= (5e-5 if dtype == torch.float32 else 0.2), (wk, worst)
     assert bworst <= (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("size", [32, 64])
+def test_skip_stream_as_fifth_group_equals_the_separate_skip_encoder(dtype, size):
+    """model._encode5 (N == 1): the skip-return encoder's pooling and two convs per level ride as a fifth group of the modality
+    streams' launches -- against the separate skip encoder (ops.set_stream5(False)): same loss, outputs, parameter gradients and
+    BatchNorm buffers (fp32: to the order of the atomics; bf16: every element goes through the same arithmetic, the band is that
+    of last-bit differences in the statistics amplified by the randomly initialised network)."""
+    torch.manual_seed(37)
+    x = torch.rand(1, 4, size, size, size)
+    eps = [torch.randn(1, 2 ** l, size >> (l + 1), size >> (l + 1), size >> (l + 1)) for l in range(4)]
+    res = []
+    for on in (False, True):
+        X.ops.set_stream5(on)
+        try:
+            m = _model(True)
+            seg, (mu, lv), rec = m(x.to(DEV, dtype), [14], recon=True, eps_list=eps)
+            loss = (seg.float() * rnd(seg.shape, 310).to(DEV)).mean() + (rec[0].float() * rnd(rec[0].shape, 311).to(DEV)).mean()
+            for a_, b_ in zip(mu, lv):
+                loss = loss + a_.float().mean() + b_.float().mean()
+            loss.backward()
+            X.ops.join_wgrad_stream()
+            torch.cuda.synchronize()
+            res.append((loss.item(), seg.detach().float(), rec[0].detach().float(), [t.detach().float() for t in mu],
+                        {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                        {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}))
+        finally:
+            X.ops.set_stream5(True)
+    (la, sa, ra, ma, ga, ba), (lb, sb, rb, mb, gb, bb) = res
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert abs(la - lb) <= tol * max(1.0, abs(la)), (la, lb)
+    assert l2_err(sb, sa) <= tol and l2_err(rb, ra) <= tol and all(l2_err(p, q) <= tol for p, q in zip(mb, ma))
+    assert ga.keys() == gb.keys()
+    scale = max(v.abs().max().item() for v in ga.values())
+    wk, worst = max(((k, (ga[k] - gb[k]).abs().max().item() / scale) for k in ga), key=lambda t: t[1])
+    bworst = max((ba[k] - bb[k]).abs().max().item() for k in ba)
+    print(f"five-stream encoder vs separate skip encoder ({dtype}, {size}^3): loss {la:.6f} / {lb:.6f}, worst parameter-gradient "
+          f"difference {worst:.2e} ({wk}), BatchNorm buffers {bworst:.2e}")
+    assert worst <= (5e-5 if dtype == torch.float32 else 0.2), (wk, worst)
+    assert bworst <= (1e-5 if dtype == torch.float32 else 2e-2)

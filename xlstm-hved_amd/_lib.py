@@ -123,8 +123,8 @@ SIGNATURES = {
     "xh_channel_pool2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, vp, ll, I, I, ll]),
     "xh_gate2_fwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, I, ll, vp]),
     "xh_gate2_bwd": (I, [vp, I, vp, ll, I, vp, ll, I, vp, ll, vp, ll, vp, ll, I, vp, ll, I, vp, ll, I, ll, I]),
-    "xh_gate_maxpool_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, I, I, I, vp]),
-    "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I, I]),
+    "xh_gate_maxpool_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, I, I, I, vp, I]),
+    "xh_gate_maxpool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, vp, ll, vp, ll, I, I, I, I, I, I, I]),
     "xh_duse_gate_fwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll]),
     "xh_duse_gate_fwd_stats": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, I, I, ll, vp]),
     "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll, I]),

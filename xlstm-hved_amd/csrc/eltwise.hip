@@ -1886,9 +1886,10 @@ template <> __device__ __forceinline__ void st8<f16_t>(f16_t* p, const float (&o
 // grid (blocks over runs, C, N); run = 4 pooled voxels along W
 template <typename T>
 __global__ __launch_bounds__(256) void gate_maxpool_fwd_kernel(const T* x, long long x_bs, const T* s, long long s_bs, T* y, long long y_bs,
-                                                              int D, int H, int W, double* red) {
+                                                              int D, int H, int W, double* red, int Cg) {
   __shared__ double s_red[4 * 2];
   const int c = blockIdx.y, n = blockIdx.z, C = gridDim.y;
+  if (c >= Cg) s = nullptr;                             // channels [Cg, C) are pooled ungated (the skip stream riding along)
   const int Do = D / 2, Ho = H / 2, Wo = W / 2, Wr = Wo / 4;
   const long long hw = (long long)H * W, dhw = (long long)D * hw, odhw = (long long)Do * Ho * Wo;
   const T* xp = x + n * x_bs + (long long)c * dhw;
@@ -1935,7 +1936,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_fwd_kernel(const T* x, long 
 template <typename T>
 __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ s, long long s_bs,
                                                               const T* __restrict__ dy, long long dy_bs, T* dx, long long dx_bs, T* ds,
-                                                              long long ds_bs, int C, int D, int H, int W, int acc_dx) {
+                                                              long long ds_bs, int C, int D, int H, int W, int acc_dx, int Cg) {
   __shared__ float s_ds[4 * 4 * 8 * 64];                  // [wave][window row][element][lane]
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int Do = D / 2, Ho = H / 2, Wo = W / 2, Wr = Wo / 4;
@@ -1958,6 +1959,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restri
   }
   for (int c = wv; c < C; c += 4) {
     const T* xp = x + n * x_bs + (long long)c * dhw + base;
+    const bool gated = c < Cg;                          // channels [Cg, C): plain max-pool backward, no share in ds
     float xv[4][8], g[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) ld8<T>(xp + (long long)(k >> 1) * hw + (long long)(k & 1) * W, xv[k]);
@@ -1970,7 +1972,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restri
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float v = rnd_as(x, xv[k][2 * j + e] * g1[k][2 * j + e]);
+          const float v = rnd_as(x, xv[k][2 * j + e] * (gated ? g1[k][2 * j + e] : 1.f));
           if (v > m[j] || v != v) { m[j] = v; arg[j] = 2 * k + e; }
         }
 #pragma unroll
@@ -1981,8 +1983,8 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restri
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const float gg = arg[j] == 2 * k + e ? g[j] : 0.f;
-          o[2 * j + e] = gg * g1[k][2 * j + e];
-          dsv[k][2 * j + e] = fmaf(gg, xv[k][2 * j + e], dsv[k][2 * j + e]);
+          o[2 * j + e] = gated ? gg * g1[k][2 * j + e] : gg;
+          dsv[k][2 * j + e] = fmaf(gated ? gg : 0.f, xv[k][2 * j + e], dsv[k][2 * j + e]);
         }
       T* dp = dx + n * dx_bs + (long long)c * dhw + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W;
       if (acc_dx && live) {                               // += : the gradient buffer already holds another consumer's share
@@ -2012,7 +2014,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void gate_maxpool_bwd_deep_kernel(const T* __restrict__ x, long long x_bs, const T* __restrict__ s, long long s_bs,
                                                                    const T* __restrict__ dy, long long dy_bs, T* dx, long long dx_bs, T* ds,
-                                                                   long long ds_bs, int C, int D, int H, int W, int acc_dx) {
+                                                                   long long ds_bs, int C, int D, int H, int W, int acc_dx, int Cg) {
   constexpr int RUNS = 16, SL = 64 / RUNS;
   __shared__ float s_ds[4 * 4 * 8 * 64];                  // [wave][window row][element][lane]
   const int n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2037,6 +2039,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_deep_kernel(const T* __r
   }
   for (int c = wv + 4 * slot; c < C; c += 4 * SL) {
     const T* xp = x + n * x_bs + (long long)c * dhw + base;
+    const bool gated = c < Cg;                          // channels [Cg, C): plain max-pool backward, no share in ds
     float xv[4][8], g[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) ld8<T>(xp + (long long)(k >> 1) * hw + (long long)(k & 1) * W, xv[k]);
@@ -2049,7 +2052,7 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_deep_kernel(const T* __r
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float v = rnd_as(x, xv[k][2 * j + e] * g1[k][2 * j + e]);
+          const float v = rnd_as(x, xv[k][2 * j + e] * (gated ? g1[k][2 * j + e] : 1.f));
           if (v > m[j] || v != v) { m[j] = v; arg[j] = 2 * k + e; }
         }
 #pragma unroll
@@ -2060,8 +2063,8 @@ __global__ __launch_bounds__(256) void gate_maxpool_bwd_deep_kernel(const T* __r
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const float gg = arg[j] == 2 * k + e ? g[j] : 0.f;
-          o[2 * j + e] = gg * g1[k][2 * j + e];
-          dsv[k][2 * j + e] = fmaf(gg, xv[k][2 * j + e], dsv[k][2 * j + e]);
+          o[2 * j + e] = gated ? gg * g1[k][2 * j + e] : gg;
+          dsv[k][2 * j + e] = fmaf(gated ? gg : 0.f, xv[k][2 * j + e], dsv[k][2 * j + e]);
         }
       T* dp = dx + n * dx_bs + (long long)c * dhw + base + (long long)(k >> 1) * hw + (long long)(k & 1) * W;
       if (acc_dx && live) {
@@ -2106,8 +2109,9 @@ static bool gmp_ok(int D, int H, int W, std::initializer_list<long long> strides
   return true;
 }
 extern "C" int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, void* y, long long y_bs,
-                                   int N, int C, int D, int H, int W, double* red) {
-  if (!x || !y || N <= 0 || C <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
+                                   int N, int C, int D, int H, int W, double* red, int Cg) {
+  if (!x || !y || N <= 0 || C <= 0 || C > 65535 || N > 65535 || Cg < 0) return XH_ERR_ARG;
+  if (Cg == 0 || Cg > C) Cg = C;
   if (!gmp_ok(D, H, W, {x_bs, s ? s_bs : 0, y_bs})) return XH_ERR_ARG;
   const long long runs = (long long)(D / 2) * (H / 2) * (W / 8);
   long long nb = (runs + 255) / 256;
@@ -2115,13 +2119,14 @@ extern "C" int xh_gate_maxpool_fwd(void* stream, int dtype, const void* x, long 
   dim3 grid((unsigned)nb, C, N);
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_fwd_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs, (T*)y, y_bs,
-                                          D, H, W, red););
+                                          D, H, W, red, Cg););
   return xh_launch_status();
 }
 extern "C" int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long long x_bs, const void* s, long long s_bs, const void* dy,
                                    long long dy_bs, void* dx, long long dx_bs, void* ds, long long ds_bs, int N, int C, int D, int H, int W,
-                                   int acc_dx) {
-  if (!x || !s || !dy || !dx || !ds || N <= 0 || C <= 0 || N > 65535) return XH_ERR_ARG;
+                                   int acc_dx, int Cg) {
+  if (!x || !s || !dy || !dx || !ds || N <= 0 || C <= 0 || N > 65535 || Cg < 0) return XH_ERR_ARG;
+  if (Cg == 0 || Cg > C) Cg = C;
   if (!gmp_ok(D, H, W, {x_bs, s_bs, dx_bs, ds_bs}) || (dy_bs & 3)) return XH_ERR_ARG;
   const long long runs = (long long)(D / 2) * (H / 2) * (W / 8);
   const long long nb = (runs + 63) / 64;
@@ -2130,12 +2135,12 @@ extern "C" int xh_gate_maxpool_bwd(void* stream, int dtype, const void* x, long 
   if (nb * N < 256 && C >= 16) {                          // the deep levels: 16 runs x 16 channel slots per workgroup
     dim3 grid((unsigned)((runs + 15) / 16), N);
     XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_bwd_deep_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs,
-                                            (const T*)dy, dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W, acc_dx););
+                                            (const T*)dy, dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W, acc_dx, Cg););
     return xh_launch_status();
   }
   dim3 grid((unsigned)nb, N);
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL(gate_maxpool_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)s, s_bs, (const T*)dy,
-                                          dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W, acc_dx););
+                                          dy_bs, (T*)dx, dx_bs, (T*)ds, ds_bs, C, D, H, W, acc_dx, Cg););
   return xh_launch_status();
 }
 

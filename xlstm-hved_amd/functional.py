@@ -120,7 +120,9 @@ def _dst(d):
 
 def _out(slot):
     """Where the FIRST consumer of a slot writes: the slot's destination half, or None (= a new tensor)."""
-    return _dst(slot.dest) if (slot is not None and slot.buf is None) else None
+    if slot is None or isinstance(slot, SubSlot):
+        return None
+    return _dst(slot.dest) if slot.buf is None else None
 
 
 class Fanout(Function):
@@ -160,12 +162,24 @@ def set_fanout(enabled):
     _FANOUT[0] = bool(enabled)
 
 
+class SubSlot:
+    """A channel range [c0, c1) of a GradSlot's buffer: the gradient slot of a SliceView alias.  A consumer of the slice adds its
+    share straight into that range of the parent's buffer once a consumer of the WHOLE tensor has created it; before that it
+    hands its gradient to autograd like any other op (SliceView.backward embeds it)."""
+    __slots__ = ("parent", "c0", "c1")
+
+    def __init__(self, parent, c0, c1):
+        self.parent, self.c0, self.c1 = parent, c0, c1
+
+
 def _slot(t):
     return getattr(t, "_xh_slot", None) if t is not None else None
 
 
 def _acc(slot):
     """The buffer a slot-aware backward adds into (None: it is the first -- or there is no slot -- and allocates)."""
+    if isinstance(slot, SubSlot):
+        return slot.parent.buf[:, slot.c0:slot.c1] if slot.parent.buf is not None else None
     return slot.buf if slot is not None else None
 
 
@@ -173,10 +187,41 @@ def _ret(slot, t):
     """What that backward returns for the tensor: the buffer if it has just created it, None if it added into an existing one."""
     if slot is None:
         return t
+    if isinstance(slot, SubSlot):
+        return None if slot.parent.buf is not None else t
     if slot.buf is None:
         slot.buf = t
         return t
     return None
+
+
+class SliceView(Function):
+    """x[:, c0:c1] of a fanout alias as a tensor of its own whose consumers add their gradient into that range of the alias'
+    shared buffer (SubSlot).  Plain slicing would have autograd build a zero tensor of x's size per slice and add it."""
+
+    @staticmethod
+    def forward(ctx, x, c0, c1):
+        ctx.meta = (tuple(x.shape), x.dtype, x.device, c0, c1)
+        ctx.set_materialize_grads(False)
+        return x[:, c0:c1]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        shape, dtype, device, c0, c1 = ctx.meta
+        full = torch.zeros(shape, dtype=dtype, device=device)          # (a consumer ran before the whole-tensor one: rare, small)
+        ops.add(_blk(g), None, out=full[:, c0:c1])
+        return full, None, None
+
+
+def slice_view(x, c0, c1):
+    """Channels [c0, c1) of x (one sample per launch: the slice is contiguous); x may be a fanout alias."""
+    y = SliceView.apply(x, c0, c1)
+    ps = _slot(x)
+    if isinstance(ps, GradSlot):
+        y._xh_slot = SubSlot(ps, c0, c1)
+    return y
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -393,6 +438,7 @@ class Conv(Function):
     """Plain Conv3d (+bias) with optional sigmoid: init_blocks / x0_init / heads (RA_HVED.py:323,347,148-149,
     480,640-641) and AttenModule2's collapsed 7^3 convs (buildingblocks.py:283-296).  `groups` streams may
     carry one weight tensor each."""
+    _into = None
 
     @staticmethod
     def forward(ctx, x, groups, act, nw, has_bias, out_stats, drop_bias, pre_act_grad, *wb):
@@ -402,9 +448,10 @@ class Conv(Function):
         biases = list(wb[nw:]) if has_bias else None
         cout = sum(w.shape[0] for w in weights)
         k = weights[0].shape[-1]
+        into, Conv._into = Conv._into, None               # destination (a channel slice of a buffer the caller owns), conv(into=...)
         red_y = ops.zeros_red(x, x.shape[0], cout) if out_stats else None     # output channel sums for the next norm
         y = ops.conv3d(x, None, weights, None if drop_bias else biases, k=k, cout=cout, groups=groups, act=act,
-                       epi=2 if out_stats else 0, red=red_y)
+                       epi=2 if out_stats else 0, red=red_y, out=into)
         if pre_act_grad:
             act = ACT_NONE
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *weights)
@@ -433,12 +480,17 @@ class Conv(Function):
         return (dx, None, None, None, None, None, None, None, *rws, *rbs)
 
 
-def conv(x, weights, biases=None, groups=1, act=ACT_NONE, out_stats=False, drop_bias=False, pre_act_grad=False):
-    """drop_bias: as in in_lrelu_conv (output consumed only by InstanceNorm; needs act == ACT_NONE)."""
+def conv(x, weights, biases=None, groups=1, act=ACT_NONE, out_stats=False, drop_bias=False, pre_act_grad=False, into=None):
+    """drop_bias: as in in_lrelu_conv (output consumed only by InstanceNorm; needs act == ACT_NONE).  into: the tensor to write
+    (a channel slice of a buffer the caller owns)."""
     if drop_bias and act != ACT_NONE:
         raise ValueError("drop_bias needs a linear output")
-    return Conv.apply(x, groups, act, len(weights), biases is not None, bool(out_stats), bool(drop_bias), bool(pre_act_grad),
-                      *weights, *(biases or []))
+    Conv._into = into
+    try:
+        return Conv.apply(x, groups, act, len(weights), biases is not None, bool(out_stats), bool(drop_bias), bool(pre_act_grad),
+                          *weights, *(biases or []))
+    finally:
+        Conv._into = None
 
 
 class MaxPool2(Function):
@@ -625,6 +677,48 @@ class GateMaxPool(Function):
         x, a = ctx.saved_tensors
         dx, da = ops.gate_maxpool_bwd(x, a, _blk(dy), acc=_acc(ctx.slot))
         return _ret(ctx.slot, dx), da
+
+
+class GateMaxPool5(Function):
+    """GateMaxPool on the four modality streams with the SKIP stream riding along ungated: xs = [X (4C) | S (C)] (1, 5C, ...) ->
+    MaxPool3d(2)([X * (1 + a) | S]) and the channel sums of the result -- the skip-return path's own pooling (the Encoder of
+    RA_HVED.py:374-381 starts with MaxPool3d(2)) in the modality streams' launch.  apply(a, base, *parts): parts = (xs,), or the two
+    halves (X, S) of the buffer `base` when different stages produced them (level 0: encoder conv and x0_init)."""
+
+    @staticmethod
+    def forward(ctx, a, base, *parts):
+        xs = base if base is not None else parts[0]
+        n, c5 = xs.shape[:2]
+        cg = c5 // 5 * 4
+        red = ops.zeros_red(xs, n, c5)
+        y = ops.gate_maxpool(xs, a.contiguous(), red, gated=cg)
+        ctx.save_for_backward(xs, a)
+        ctx.cg = cg
+        ctx.slots = tuple(_slot(p) for p in parts)
+        ctx.mark_non_differentiable(red)
+        ctx.set_materialize_grads(False)
+        return y, red
+
+    @staticmethod
+    def backward(ctx, dy, _dred=None):
+        xs, a = ctx.saved_tensors
+        cg = ctx.cg
+        dy = _blk(dy)
+        if len(ctx.slots) == 1:
+            slot = ctx.slots[0]
+            dx, da = ops.gate_maxpool_bwd(xs, a, dy, acc=_acc(slot), gated=cg)
+            return (da, None, _ret(slot, dx))
+        sx, ss = ctx.slots
+        dx, da = ops.gate_maxpool_bwd(xs, a, dy, gated=cg)
+        outs = []
+        for slot, half in ((sx, dx[:, :cg]), (ss, dx[:, cg:])):
+            acc = _acc(slot)
+            if acc is not None:                            # (another consumer of this half ran first)
+                ops.add(acc, half, out=acc)
+                outs.append(None)
+            else:
+                outs.append(_ret(slot, half))
+        return (da, None, *outs)
 
 
 class Add(Function):

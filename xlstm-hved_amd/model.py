@@ -368,8 +368,85 @@ class AbstractFusion3DUNet(nn.Module):
             c = self.__dict__["_bnc"] = BNCounters()
         return c.collect(self)
 
+    def _encode5(self, x, bn_steps):
+        """_encode for one sample per launch with the SKIP stream as a fifth group of the modality streams' launches.  From level 1
+        on the skip-return encoder (RA_HVED.py:374-381,617-621: MaxPool3d(2) -> DoubleConv on the skip feature) has, stage by
+        stage, the shapes of ONE modality encoder of the same level and no dependency on them: its pooling rides in the gate +
+        max-pool launch (ungated channels, Fn.GateMaxPool5), its two convs are group 5 of the grouped conv launches (one weight
+        pointer per group), and so do their data gradients, norm-backward passes and pooling backward.  [X (4C) | S (C)] live in one
+        (1, 5C, ...) tensor; with N == 1 its channel ranges are plain contiguous views (Fn.slice_view) for the consumers that want
+        one part: the DRB convs (X) and the skip-return attention (S)."""
+        ops.red_arena_reset(x.device)
+        Fn.nb_pending_clear()
+        ops.prepack_all()
+        x = x.contiguous()
+        levels = len(self.encoders)
+        X, st0 = Fn.conv(x, [b[0].weight for b in self.init_blocks], [b[0].bias for b in self.init_blocks], groups=4, out_stats=True,
+                         drop_bias=True)
+        feat_list = []
+        # level 0: the four streams' DoubleConv; its second conv and x0_init write the two parts of one buffer
+        w, b = self._stream_weights(0, "SingleConv1")
+        Y, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0, out_stats=True, drop_bias=True)
+        w, b = self._stream_weights(0, "SingleConv2")
+        c4 = sum(t.shape[0] for t in w)
+        c = c4 // 4
+        xs_buf = torch.empty((1, c4 + c) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        red_buf = ops.zeros_red(x, 1, c4)
+        X, st = Fn.in_lrelu_conv(Y, None, w, b, 1, 4, in_stats=st, out_stats=True, sole_consumer=True, into=(xs_buf[:, :c4], red_buf))
+        S = Fn.conv(x, [self.x0_init[0].weight], [self.x0_init[0].bias], into=xs_buf[:, c4:])
+        X_drb, X_main = Fn.fanout(X, 2)
+        drb = [m[0].conv for m in self.DRBs[0]]
+        feat_list.append(Fn.in_lrelu_conv(X_drb, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4, in_stats=st))
+        parts, base = (X_main, S), xs_buf
+        skip = None
+        for level in range(1, levels):
+            if base is not None:                           # level 1: X and S are the two parts of level 0's buffer
+                s_att, s_pool = Fn.fanout(parts[1], 2)
+                a = self.skr_att[levels - level](s_att, steps=bn_steps)
+                P, stp = Fn.GateMaxPool5.apply(a, base, parts[0], s_pool)
+            else:
+                a = self.skr_att[levels - level](parts[1], steps=bn_steps)
+                P, stp = Fn.GateMaxPool5.apply(a, None, parts[0])
+            enc_s = self.skr_encoders[levels - 1 - level].basic_module[0]
+            w, b = self._stream_weights(level, "SingleConv1")
+            w, b = w + [enc_s.SingleConv1.conv.weight], b + [enc_s.SingleConv1.conv.bias]
+            Y, st = Fn.in_lrelu_conv(P, None, w, b, 1, 5, in_stats=stp, out_stats=True, drop_bias=True)
+            w, b = self._stream_weights(level, "SingleConv2")
+            w, b = w + [enc_s.SingleConv2.conv.weight], b + [enc_s.SingleConv2.conv.bias]
+            XS, st = Fn.in_lrelu_conv(Y, None, w, b, 1, 5, in_stats=st, out_stats=True, sole_consumer=True)
+            c5 = XS.shape[1]
+            c4 = c5 // 5 * 4
+            if level + 1 < levels:
+                xs_d, xs_g, xs_a = Fn.fanout(XS, 3)
+                parts, base = (xs_g, Fn.slice_view(xs_a, c4, c5)), None
+            else:
+                xs_d, xs_s = Fn.fanout(XS, 2)
+                skip = Fn.slice_view(xs_s, c4, c5)
+            drb = [m[0].conv for m in self.DRBs[level]]
+            feat_list.append(Fn.in_lrelu_conv(Fn.slice_view(xs_d, 0, c4), None, [m.weight for m in drb], [m.bias for m in drb], 2, 4,
+                                              in_stats=st[:, :c4]))
+        return x, feat_list, skip
+
+    def _encode5_ok(self, x):
+        if not (ops.STREAM5[0] and self.layer_order == "ilc" and self.skip_return and x.is_cuda and x.shape[0] == 1 and len(self.encoders) >= 2):
+            return False
+        for level in range(1, len(self.encoders)):
+            e = self.skr_encoders[len(self.encoders) - 1 - level]
+            if not (e.pooling is not None and len(e.basic_module) == 1 and type(e.basic_module[0]) is DoubleConv
+                    and e.basic_module[0].SingleConv1.order == "ilc"):
+                return False
+            m0 = self.encoders[level][0].basic_module[0]
+            for which in ("SingleConv1", "SingleConv2"):
+                if getattr(m0, which).conv.weight.shape != getattr(e.basic_module[0], which).conv.weight.shape:
+                    return False
+        d, h, w_ = x.shape[2:]
+        nl = len(self.encoders)                             # every pooled level: even D / H, rows of a multiple of 8 voxels
+        return d % (1 << nl) == 0 and h % (1 << nl) == 0 and w_ % (8 << (nl - 2)) == 0 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+
     def _encode(self, x, bn_steps):
         """The input-only part: per-level DRB outputs (4 streams x [mu | logvar] before PoE) and the skip-return feature."""
+        if self._encode5_ok(x):
+            return self._encode5(x, bn_steps)
         batched = self.layer_order == "ilc"     # 'ilc' runs the 4 modality streams as one grouped launch per stage
         ops.red_arena_reset(x.device)
         Fn.nb_pending_clear()                   # (entries an aborted backward left behind)

@@ -348,6 +348,13 @@ def set_sep_compose(enabled):
     SEP_COMPOSE[0] = bool(enabled)
 
 
+STREAM5 = [os.environ.get("XH_NO_STREAM5", "") == ""]     # A/B switch: the skip stream as a fifth group of the encoder launches (model._encode5)
+
+
+def set_stream5(enabled):
+    STREAM5[0] = bool(enabled)
+
+
 NB_PENDING = {}        # functional.InLreluConv: gradients handed over unwritten, by address (see functional._NB_PENDING)
 _NB_FOLD = [os.environ.get("XH_NO_NB_FOLD", "") == ""]      # A/B switch: the InstanceNorm backward folded into the consuming data gradient
 
@@ -1010,24 +1017,24 @@ def gate_maxpool_ok(x, s):
     return d % 2 == 0 and h % 2 == 0 and w % 8 == 0 and bs % 8 == 0 and _vol(s)[5] % 8 == 0 and s.shape[1] == 1
 
 
-def gate_maxpool(x, s, red=None):
+def gate_maxpool(x, s, red=None, gated=0):
     """maxpool2(x * (1 + s)) in one pass (s None: maxpool2(x)); with `red` (zeroed (n, c, 2) fp64) the channel sums of the pooled
-    output too."""
+    output too.  gated: the gate applies to the first `gated` channels only (0: all)."""
     n, c, d, h, w, bs = _vol(x)
     y = new_like(x, (n, c, d // 2, h // 2, w // 2))
     L.check(L.load().xh_gate_maxpool_fwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5] if s is not None else 0, _p(y), _vol(y)[5], n, c, d, h, w,
-                                         _p(red)),
+                                         _p(red), int(gated)),
             "xh_gate_maxpool_fwd")
     return y
 
 
-def gate_maxpool_bwd(x, s, dy, acc=None):
+def gate_maxpool_bwd(x, s, dy, acc=None, gated=0, out=None):
     n, c, d, h, w, bs = _vol(x)
     dy = dy.contiguous()
-    dx = acc if acc is not None else new_like(x, (n, c, d, h, w))
+    dx = acc if acc is not None else out if out is not None else new_like(x, (n, c, d, h, w))
     ds = new_like(x, (n, 1, d, h, w))
     L.check(L.load().xh_gate_maxpool_bwd(_stream(), _dt(x), _p(x), bs, _p(s), _vol(s)[5], _p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5],
-                                         _p(ds), _vol(ds)[5], n, c, d, h, w, int(acc is not None)), "xh_gate_maxpool_bwd")
+                                         _p(ds), _vol(ds)[5], n, c, d, h, w, int(acc is not None), int(gated)), "xh_gate_maxpool_bwd")
     return dx, ds
 
 
