@@ -399,6 +399,18 @@ int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const void* x, const
  * global-average-pool gradient) -- finishes DuSEAttention's input gradient (modules/DuSFE.py:118,135-140). */
 int xh_rank1_add(void* stream, int dtype, void* dx, long long dx_bs, const void* d, long long d_bs, const float* w,
                  const float* k, int N, int C, long long DHW);
+/* DuSEAttention's channel excitation (modules/DuSFE.py:113-133) inside the passes of the recon | seg PAIR (one sample; the pair
+ * (1, 2C, ...) viewed as (2, C, ...)): xh_duse_gate_fc_fwd = xh_duse_fc_fwd + xh_duse_gate_fwd(_stats) in one launch -- every
+ * workgroup derives its channel's gate from the pair's raw sums red_in [2C][2]; ch_out [2][C], g_out [C], means_out [2C] are left
+ * for the backward pass.  xh_rank1_add_fc = xh_duse_fc_bwd + xh_rank1_add: dx[c] += w[c] * d + d(mean)[c] with the pooled-mean
+ * gradient derived in-kernel from dch [2][C] (xh_duse_gate_bwd) and the saved ch / g / means; the first workgroup ACCUMULATES the
+ * six parameter gradients of fc_comb / fc_ch1 / fc_ch2. */
+int xh_duse_gate_fc_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* sp, long long sp_bs, void* u, long long u_bs, int C,
+                        long long DHW, const double* red_in, const float* wc, const float* bc, const float* w1, const float* b1,
+                        const float* w2, const float* b2, float* ch_out, float* g_out, float* means_out, double* red_out);
+int xh_rank1_add_fc(void* stream, int dtype, void* dx, long long dx_bs, const void* d, long long d_bs, const float* w, int C2, long long DHW,
+                    const float* means, const float* g, const float* ch, const double* dch, const float* wc, const float* w1,
+                    const float* w2, float* dwc, float* dbc, float* dw1, float* db1, float* dw2, float* db2);
 
 /* tiny dense layers on pooled features (DuSFE.py:118-127): handled on device, fp32.
  * in: channel sums red_r, red_s [N][C][2] (fp64, from moments or a producer's epilogue); out: ch1, ch2 [N][C] (sigmoid'ed), the

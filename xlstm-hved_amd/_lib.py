@@ -130,6 +130,8 @@ SIGNATURES = {
     "xh_duse_gate_bwd": (I, [vp, I, vp, ll, vp, vp, ll, vp, ll, vp, ll, vp, ll, vp, I, I, ll, I]),
     "xh_duse_gate_bwd_fuses": (I, [I]),
     "xh_rank1_add": (I, [vp, I, vp, ll, vp, ll, vp, vp, I, I, ll]),
+    "xh_duse_gate_fc_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, ll] + [vp] * 11),
+    "xh_rank1_add_fc": (I, [vp, I, vp, ll, vp, ll, vp, I, ll] + [vp] * 13),
     "xh_duse_fc_fwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_compose_atten_fwd": (I, [vp] * 9 + [I, I, I, I, vp, vp]),
     "xh_compose_atten_bwd": (I, [vp] * 7 + [I, I, I, I] + [vp] * 10),

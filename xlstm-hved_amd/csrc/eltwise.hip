@@ -2485,6 +2485,151 @@ extern "C" int xh_duse_fc_bwd(void* stream, const double* red_r, const double* r
   return xh_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------- DuSE pair: the tiny dense layers inside the passes
+// The channel excitation of DuSEAttention (modules/DuSFE.py:113-133: two global average pools -> fc_comb -> fc_ch1 / fc_ch2 ->
+// sigmoid) is 2C^2 + 2C^2 multiply-adds on 2C numbers; as launches of their own (one workgroup forward, one backward) they are
+// ~5 + ~9 us of pure launch latency per decoder level.  For the recon | seg PAIR (one sample: x viewed as (2, C, ...)) every
+// workgroup of the gate pass derives its own channel's gate from the raw channel sums, and every workgroup of the pass that
+// finishes the input gradient derives its channel's pooled-mean gradient; the first workgroup also leaves what the backward
+// pass / the optimizer needs (gate vector, pooled means; parameter gradients).
+struct DuseFc {
+  const double* red;                 // [2C][2] raw sums of the pair (sum x, sum x^2): recon channels first
+  double inv_count;
+  const float *wc, *bc, *w1, *b1, *w2, *b2;
+  float *g_out, *ch_out, *means_out; // [C], [2][C], [2C]
+};
+template <typename T, bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void duse_gate_fc_fwd_kernel(const T* x, long long x_bs, const T* sp, long long sp_bs, T* u, long long u_bs,
+                                                                   int C, long long dhw, double* red, const DuseFc f) {
+  __shared__ double s_red[4 * 2];
+  __shared__ float s_mean[64], s_g[32], s_gate;
+  const int half = blockIdx.z, cc = blockIdx.y, tid = threadIdx.x;
+  for (int k = tid; k < 2 * C; k += EW_BLOCK) s_mean[k] = (float)(f.red[2 * k] * f.inv_count);
+  __syncthreads();
+  for (int j = tid; j < C; j += EW_BLOCK) {
+    float a = f.bc[j];
+    for (int k = 0; k < 2 * C; ++k) a = fmaf(f.wc[j * 2 * C + k], s_mean[k], a);
+    s_g[j] = a;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float* w = half ? f.w2 : f.w1;
+    float a = (half ? f.b2 : f.b1)[cc];
+    for (int k = 0; k < C; ++k) a = fmaf(w[cc * C + k], s_g[k], a);
+    const float ch = sigmoidf_(a);
+    s_gate = 1.f + ch;
+    if (blockIdx.x == 0) {
+      f.ch_out[half * C + cc] = ch;
+      if (half == 0 && cc == 0) {
+        for (int k = 0; k < 2 * C; ++k) f.means_out[k] = s_mean[k];
+        for (int k = 0; k < C; ++k) f.g_out[k] = s_g[k];
+      }
+    }
+  }
+  __syncthreads();
+  const float cg = s_gate;
+  double s[2] = {0.0, 0.0};
+  ROW_LOOP_BEGIN
+    float xv[VW], sv[VW];
+    ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
+    ldrow<VEC>(sp + n * sp_bs, q, valid, sv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) xv[i] *= (cg + sv[i]);
+    strow<VEC>(u + n * u_bs + (long long)c * dhw, q, valid, xv);
+    if (red) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+        if (i < valid) { const float r = rnd_as((const T*)nullptr, xv[i]); t0 += r; t1 = fmaf(r, r, t1); }
+      s[0] += (double)t0;
+      s[1] += (double)t1;
+    }
+  ROW_LOOP_END
+  if (red) {
+    block_sum_d<2>(s, s_red, EW_BLOCK >> 6);
+    if (threadIdx.x < 2) atomicAdd(&red[((long long)blockIdx.z * C + blockIdx.y) * 2 + threadIdx.x], s_red[threadIdx.x]);
+  }
+}
+// x: the pair as (2, C, ...) (batch stride x_bs = C * dhw for a contiguous (1, 2C, ...) tensor); sp (2, 1, ...); red_in: the pair's
+// raw sums [2C][2]; ch_out [2][C], g_out [C], means_out [2C] are written for the backward pass; red_out (optional) [2][C][2] zeroed.
+extern "C" int xh_duse_gate_fc_fwd(void* stream, int dtype, const void* x, long long x_bs, const void* sp, long long sp_bs, void* u, long long u_bs,
+                                   int C, long long DHW, const double* red_in, const float* wc, const float* bc, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, float* ch_out, float* g_out, float* means_out,
+                                   double* red_out) {
+  if (!x || !sp || !u || !red_in || !wc || !bc || !w1 || !b1 || !w2 || !b2 || !ch_out || !g_out || !means_out || C <= 0 || C > 32 || DHW <= 0)
+    return XH_ERR_ARG;
+  DuseFc f{red_in, 1.0 / (double)DHW, wc, bc, w1, b1, w2, b2, g_out, ch_out, means_out};
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, {
+    dim3 grid = red_out ? red_grid<T>(DHW, C, 2) : row_grid<T>(DHW, C, 2);
+    if (vec_ok<T>(DHW, {x_bs, sp_bs, u_bs})) hipLaunchKernelGGL((duse_gate_fc_fwd_kernel<T, true>), grid, dim3(EW_BLOCK), 0, st, (const T*)x, x_bs, (const T*)sp, sp_bs, (T*)u, u_bs, C, DHW, red_out, f);
+    else hipLaunchKernelGGL((duse_gate_fc_fwd_kernel<T, false>), grid, dim3(EW_BLOCK), 0, st, (const T*)x, x_bs, (const T*)sp, sp_bs, (T*)u, u_bs, C, DHW, red_out, f);
+  });
+  return xh_launch_status();
+}
+struct DuseFcBwd {
+  const float *means, *g, *ch;       // [2C], [C], [2][C] saved by the forward pass
+  const double* dch;                 // [2][C]: sum over voxels of du * x per channel (xh_duse_gate_bwd)
+  const float *wc, *w1, *w2;
+  float *dwc, *dbc, *dw1, *db1, *dw2, *db2;     // ACCUMULATED into by the first workgroup
+  float inv_count;
+};
+// dx[c] += w[c] * d + dmean[c] for the pair (1, 2C, ...): xh_rank1_add with the pooled-mean gradient derived in-kernel
+template <typename T, bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void rank1_add_fc_kernel(T* dx, long long dx_bs, const T* d, long long d_bs, const float* w, int C2,
+                                                               long long dhw, const DuseFcBwd f) {
+  __shared__ float s_p[64], s_dg[32], s_k;
+  const int C = C2 / 2, tid = threadIdx.x, kk = blockIdx.y;
+  for (int i = tid; i < C2; i += EW_BLOCK) { const float ch = f.ch[i]; s_p[i] = (float)f.dch[i] * ch * (1.f - ch); }
+  __syncthreads();
+  for (int k = tid; k < C; k += EW_BLOCK) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += f.w1[c * C + k] * s_p[c] + f.w2[c * C + k] * s_p[C + c];
+    s_dg[k] = a;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += f.wc[c * C2 + kk] * s_dg[c];
+    s_k = a * f.inv_count;
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {               // parameter gradients, once
+    for (int i = tid; i < C * C; i += EW_BLOCK) {
+      const int c = i / C, k = i % C;
+      f.dw1[i] += s_p[c] * f.g[k];
+      f.dw2[i] += s_p[C + c] * f.g[k];
+    }
+    for (int i = tid; i < C * C2; i += EW_BLOCK) f.dwc[i] += s_dg[i / C2] * f.means[i % C2];
+    for (int c = tid; c < C; c += EW_BLOCK) { f.db1[c] += s_p[c]; f.db2[c] += s_p[C + c]; f.dbc[c] += s_dg[c]; }
+  }
+  __syncthreads();
+  const float wc = w[blockIdx.y], kc = s_k;
+  ROW_LOOP_BEGIN
+    float o[VW], dv[VW];
+    T* dp = dx + n * dx_bs + (long long)c * dhw;
+    ldrow<VEC>((const T*)dp, q, valid, o);
+    ldrow<VEC>(d + n * d_bs, q, valid, dv);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) o[i] += fmaf(wc, dv[i], kc);
+    strow<VEC>(dp, q, valid, o);
+  ROW_LOOP_END
+}
+extern "C" int xh_rank1_add_fc(void* stream, int dtype, void* dx, long long dx_bs, const void* d, long long d_bs, const float* w, int C2,
+                               long long DHW, const float* means, const float* g, const float* ch, const double* dch, const float* wc,
+                               const float* w1, const float* w2, float* dwc, float* dbc, float* dw1, float* db1, float* dw2, float* db2) {
+  if (!dx || !d || !w || !means || !g || !ch || !dch || !wc || !w1 || !w2 || !dwc || !dbc || !dw1 || !db1 || !dw2 || !db2 || C2 <= 0 || (C2 & 1) ||
+      C2 > 64 || DHW <= 0)
+    return XH_ERR_ARG;
+  DuseFcBwd f{means, g, ch, dch, wc, w1, w2, dwc, dbc, dw1, db1, dw2, db2, 1.f / (float)DHW};
+  hipStream_t st = (hipStream_t)stream;
+  XH_DISPATCH_T(dtype, {
+    dim3 grid = row_grid<T>(DHW, C2, 1);
+    if (vec_ok<T>(DHW, {dx_bs, d_bs})) hipLaunchKernelGGL((rank1_add_fc_kernel<T, true>), grid, dim3(EW_BLOCK), 0, st, (T*)dx, dx_bs, (const T*)d, d_bs, w, C2, DHW, f);
+    else hipLaunchKernelGGL((rank1_add_fc_kernel<T, false>), grid, dim3(EW_BLOCK), 0, st, (T*)dx, dx_bs, (const T*)d, d_bs, w, C2, DHW, f);
+  });
+  return xh_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------- skip-return tail
 // r_c = relu(relu(t_c*sc+sh) + x_c);  a = sigmoid(w0*max_c r + w1*mean_c r)
 template <typename T, bool VEC, int CBT = CB>

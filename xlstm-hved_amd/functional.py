@@ -98,9 +98,10 @@ class TwinDest:
         self.shape, self.c, self.dtype, self.device, self.buf = tuple(shape), c, dtype, device, None
 
     def half(self, i):
+        """Part 0 = channels [0, c), part 1 = the rest (the pair: c = C of 2C; a general split point for Fn.split_at)."""
         if self.buf is None:
             self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
-        return self.buf[:, i * self.c:(i + 1) * self.c]
+        return self.buf[:, :self.c] if i == 0 else self.buf[:, self.c:]
 
     def joined(self, ga, gb):
         for i, g in enumerate((ga, gb)):
@@ -334,7 +335,8 @@ class InLreluConv(Function):
                 dxa = torch.empty_like(xa, memory_format=torch.contiguous_format)          # written by whoever takes the entry
                 _NB_PENDING[dxa.data_ptr()] = (g, xa, red, mean, rstd, dxa)
             else:
-                dxa = _ret(sa, ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0, acc=_acc(sa)))
+                dxa = _ret(sa, ops.in_bwd_apply(g, xa, red, mean, rstd, have_g=True, c0=0, acc=_acc(sa),
+                                                out=_dst(ctx.dests[0]) if sa is None else None))
         return (dxa, dxb, None, None, None, None, None, None, None, *rws, *rbs)
 
 
@@ -1140,21 +1142,25 @@ def upsample2(p, size):
 
 
 class Split2(Function):
-    """The two halves of a pair tensor as separate tensors (for the heads); gradients rejoin through a TwinDest."""
+    """Channels [0, c) and [c, C) of a tensor as separate tensors (the pair's halves for the heads; [X | S] of the five-stream
+    encoder's last level); their gradients rejoin through a TwinDest."""
 
     @staticmethod
-    def forward(ctx, p):
-        c = p.shape[1] // 2
+    def forward(ctx, p, c):
         ctx.dest = TwinDest(p.shape, c, p.dtype, p.device)
         return p[:, :c], p[:, c:]
 
     @staticmethod
     def backward(ctx, ga, gb):
-        return ctx.dest.joined(ga, gb)
+        return ctx.dest.joined(ga, gb), None
 
 
 def split2(p):
-    a, b = Split2.apply(p)
+    return split_at(p, p.shape[1] // 2)
+
+
+def split_at(p, c):
+    a, b = Split2.apply(p, int(c))
     dest = a.grad_fn.dest if a.grad_fn is not None and hasattr(a.grad_fn, "dest") else None
     if dest is not None:
         a._xh_dest, b._xh_dest = (dest, 0), (dest, 1)
@@ -1219,13 +1225,17 @@ class DuSE2(Function):
         cnt = _dhw(y)
         mode = MODE_BN_TRAIN if training else MODE_BN_EVAL
         red_r, red_s = stats[:, :c], stats[:, c:]
-        chb = torch.empty((2, c), dtype=torch.float32, device=y.device)
         fc = dict(wc=wc, bc=bc, w1=w1, b1=b1, w2=w2, b2=b2)
-        gvec, ch1, ch2, means = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc, ch_out=chb)
         comb = ops.conv3d(y, None, [sqw], [sqb], k=1, cout=1)
         sp = ops.conv3d(comb, None, [adjw], [adjb], k=3, cout=2, act=ACT_SIGMOID)
         red_u = ops.zeros_red(y, 2, c) if training else None
-        u = ops.duse_gate(y.view((2, c) + sp_shape), chb, sp.view((2, 1) + sp_shape), red=red_u).view(y.shape)
+        if ops.FC_FOLD[0] and n == 1 and c <= 32:
+            # the channel excitation's dense layers inside the gate pass (every workgroup derives its own channel's gate)
+            u, chb, gvec, means = ops.duse_gate_fc(y, sp, stats, fc, red=red_u)
+        else:
+            chb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+            gvec, ch1, ch2, means = ops.duse_fc_fwd(red_r, red_s, cnt, n, c, fc, ch_out=chb)
+            u = ops.duse_gate(y.view((2, c) + sp_shape), chb, sp.view((2, 1) + sp_shape), red=red_u).view(y.shape)
         out, sc, sh, m, rs = ops.bn_affine_act2(mode, u, red_u.view(1, c2, 2) if red_u is not None else None, ACT_NONE, c, gammas=(g1, g2),
                                                betas=(be1, be2), running_means=(rm1, rm2), running_vars=(rv1, rv2), steps=1)
         ctx.save_for_backward(y, means, gvec, chb, comb, sp, u, sc, sh, m, rs, wc, w1, w2, sqw, adjw, g1, g2)
@@ -1255,8 +1265,11 @@ class DuSE2(Function):
         ops.conv3d_wgrad(y, None, dcomb, [dsqw], [dsqb], k=1, side=_direct(rets[6], rets[7]))
         fc = dict(wc=wc, w1=w1, w2=w2)
         fcg = dict(wc=dwc, bc=dbc, w1=dw1, b1=db1, w2=dw2, b2=db2)
-        dm = torch.empty((1, c2), dtype=torch.float32, device=y.device)
-        ops.duse_fc_bwd(means, cnt, n, c, fc, gvec, chb[0:1], chb[1:2], dch[0:1], dch[1:2], fcg, dm_out=dm)
         dx = dx.view(y.shape)
-        ops.rank1_add(dx, dcomb, sqw.reshape(-1).contiguous(), dm)
+        if ops.FC_FOLD[0] and n == 1 and c <= 32:
+            ops.rank1_add_fc(dx, dcomb, sqw.reshape(-1).contiguous(), means, gvec, chb, dch, fc, fcg)
+        else:
+            dm = torch.empty((1, c2), dtype=torch.float32, device=y.device)
+            ops.duse_fc_bwd(means, cnt, n, c, fc, gvec, chb[0:1], chb[1:2], dch[0:1], dch[1:2], fcg, dm_out=dm)
+            ops.rank1_add(dx, dcomb, sqw.reshape(-1).contiguous(), dm)
         return (dx, None, None, None, None, None, None, *rets)

@@ -419,12 +419,11 @@ class AbstractFusion3DUNet(nn.Module):
             if level + 1 < levels:
                 xs_d, xs_g, xs_a = Fn.fanout(XS, 3)
                 parts, base = (xs_g, Fn.slice_view(xs_a, c4, c5)), None
+                x_drb = Fn.slice_view(xs_d, 0, c4)
             else:
-                xs_d, xs_s = Fn.fanout(XS, 2)
-                skip = Fn.slice_view(xs_s, c4, c5)
+                x_drb, skip = Fn.split_at(XS, c4)         # last level: the DRB convs take X, the mid ViL block takes S
             drb = [m[0].conv for m in self.DRBs[level]]
-            feat_list.append(Fn.in_lrelu_conv(Fn.slice_view(xs_d, 0, c4), None, [m.weight for m in drb], [m.bias for m in drb], 2, 4,
-                                              in_stats=st[:, :c4]))
+            feat_list.append(Fn.in_lrelu_conv(x_drb, None, [m.weight for m in drb], [m.bias for m in drb], 2, 4, in_stats=st[:, :c4]))
         return x, feat_list, skip
 
     def _encode5_ok(self, x):

@@ -1067,6 +1067,35 @@ def duse_gate_bwd(x, ch, sp, du, dsp_out, sigmoid_bwd=False):
     return dx, dch
 
 
+FC_FOLD = [os.environ.get("XH_NO_FC_FOLD", "") == ""]      # A/B switch: DuSE's tiny dense layers inside the pair's gate / input-gradient passes
+
+
+def duse_gate_fc(xpair, sp, red_in, p, red=None):
+    """The pair's gate pass with the channel excitation derived in-kernel (xh_duse_gate_fc_fwd).  xpair (1, 2C, ...), sp (1, 2, ...),
+    red_in (1, 2C, 2) raw sums; p: dict wc, bc, w1, b1, w2, b2.  Returns u (1, 2C, ...), ch (2, C), g (1, C), means (1, 2C)."""
+    n, c2, d, h, w, bs = _vol(xpair)
+    c = c2 // 2
+    u = torch.empty_like(xpair, memory_format=torch.contiguous_format)
+    ch = torch.empty((2, c), dtype=torch.float32, device=xpair.device)
+    g = torch.empty((1, c), dtype=torch.float32, device=xpair.device)
+    means = torch.empty((1, c2), dtype=torch.float32, device=xpair.device)
+    dhw = d * h * w
+    L.check(L.load().xh_duse_gate_fc_fwd(_stream(), _dt(xpair), _p(xpair), c * dhw, _p(sp), dhw, _p(u), c * dhw, c, dhw, _p(red_in),
+                                         _p(p["wc"]), _p(p["bc"]), _p(p["w1"]), _p(p["b1"]), _p(p["w2"]), _p(p["b2"]), _p(ch), _p(g),
+                                         _p(means), _p(red)), "xh_duse_gate_fc_fwd")
+    return u, ch, g, means
+
+
+def rank1_add_fc(dx, d1, w, means, g, ch, dch, p, grads):
+    """dx (1, 2C, ...) += w[c] * d1 + d(mean)[c]; the pooled-mean gradient and the six dense-layer gradients come from the same launch
+    (xh_rank1_add_fc).  p: dict wc, w1, w2; grads: dict wc, bc, w1, b1, w2, b2 (accumulated into)."""
+    n, c2, d, h, ww, bs = _vol(dx)
+    L.check(L.load().xh_rank1_add_fc(_stream(), _dt(dx), _p(dx), bs, _p(d1), _vol(d1)[5], _p(w), c2, d * h * ww, _p(means), _p(g), _p(ch),
+                                     _p(dch), _p(p["wc"]), _p(p["w1"]), _p(p["w2"]), _p(grads["wc"]), _p(grads["bc"]), _p(grads["w1"]),
+                                     _p(grads["b1"]), _p(grads["w2"]), _p(grads["b2"])), "xh_rank1_add_fc")
+    return dx
+
+
 def rank1_add(dx, d1, w, k):
     n, c, d, h, ww, bs = _vol(dx)
     L.check(L.load().xh_rank1_add(_stream(), _dt(dx), _p(dx), bs, _p(d1), _vol(d1)[5], _p(w), _p(k), n, c, d * h * ww), "xh_rank1_add")
