@@ -136,6 +136,11 @@ typedef struct {
    * stored there (layout of xa) -- the weight gradient of this conv reads it; written by this launch, complete when it ends. */
   const void* px; void* pd;
   const double* nb_red; const float* nb_mean; const float* nb_rstd; long long nb_count;
+  /* Optional with fin_red, N == 1 (xh_conv3d_fuses_bn_finalize): the fused finalisation is a training-mode BatchNorm3d instead of an
+   * InstanceNorm -- scale = rstd * fin_gamma[c], shift = fin_beta[c] - mean * rstd * fin_gamma[c] (one sample: batch statistics ==
+   * instance statistics), and the launch also advances the running statistics fin_rm / fin_rv by fin_steps momentum-0.1 updates
+   * with the unbiased variance (what xh_norm_finalize mode 1 does in a launch of its own; sa_modules/sa_module.py:79-85). */
+  const float* fin_gamma; const float* fin_beta; float* fin_rm; float* fin_rv; int fin_steps;
 } xh_conv_ptrs;
 
 /* Size in bytes of a statistics fan-in workspace (xh_conv_ptrs.fan).  The library allocates no device memory and keeps no
@@ -145,6 +150,9 @@ long long xh_fanin_bytes(void);
 /* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv
  * (transposed=1).  Reference: F.conv3d as used throughout RA_HVED.py:510-648. */
 int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
+/* 1 when xh_conv3d_fwd takes this desc (pre == 1) with the BatchNorm flavour of the fused finalisation (fin_gamma ...): the
+ * quad-channel MFMA kernel, one sample. */
+int xh_conv3d_fuses_bn_finalize(const xh_conv_desc* d);
 /* 1 when xh_conv3d_fwd takes this desc with pre == 2 (the quad-channel MFMA kernel: 16-bit storage, k = 3, stride 1, rows of 32
  * voxels, <= 48 channels per group, ...); 0: the caller materialises the tensor with xh_in_bwd_apply and calls with pre == 0. */
 int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d);
@@ -388,6 +396,12 @@ int xh_duse_gate_bwd_fuses(int C);
  * r = relu(relu(t*sc+sh) + x); a = sigmoid(w0*max_c r + w1*mean_c r).  a has 1 channel. */
 int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                     const float* w2, void* a, int N, int C, long long DHW);
+/* xh_skr_tail_fwd with the training-mode BatchNorm3d in front of the tail (sa_modules/sa_module.py:79-85) finalised in the same
+ * launch, one sample, C <= 64: red [C][2] = raw sums (sum t, sum t^2) of t left by the conv epilogue; sc / sh / mean / rstd [C] are
+ * written for the backward pass, running_mean / running_var advanced by `steps` momentum-0.1 updates (unbiased variance). */
+int xh_skr_tail_bn_fwd(void* stream, int dtype, const void* t, const void* x, const double* red, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int steps, const float* w2, void* a, int C, long long DHW, float* sc,
+                       float* sh, float* mean, float* rstd);
 /* Given da: dtg = gradient w.r.t. the BatchNorm output t*sc+sh (already multiplied by both relu'),
  * dx (+)= gradient through the residual branch, and the gradient of the 1x1 conv's two weights ACCUMULATED into dw2[0..1]
  * (fp64) or, when dw2_f32 is given, into dw2_f32[0..1] (the parameter's fp32 gradient buffer; dw2 may then be NULL). */

@@ -527,9 +527,10 @@ def test_norm_backward_folded_into_the_data_gradient_vs_separate_pass(cfg, dtype
     assert e_dx <= tol and e_g <= tol, (e_dx, e_g)
 
 
+@pytest.mark.parametrize("n", [1, 2], ids=["n1_bn_folded", "n2"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("c,sp", [(4, (16, 16, 32)), (8, (8, 16, 32)), (16, (8, 8, 32))])
-def test_skip_return_attention_with_composed_depthwise_pointwise_convs(c, sp, dtype):
+def test_skip_return_attention_with_composed_depthwise_pointwise_convs(c, sp, dtype, n):
     """ResBlock(lkdw=True) of the skip-return attention (sa_modules/sa_module.py:79-137): each DWConvNorm's depthwise 3^3 conv and
     pointwise 1x1 conv applied as ONE dense 3^3 conv with weights pw o dw (Fn.ComposeAll sep jobs; gradients scattered back to the
     two parameters at the end of the backward pass) against the two-conv form in fp32: attention map, input gradient and all
@@ -538,8 +539,7 @@ def test_skip_return_attention_with_composed_depthwise_pointwise_convs(c, sp, dt
     from xlstm_hved_amd import functional as Fn
     from xlstm_hved_amd.blocks import SkipReturnAttention
     torch.manual_seed(17)
-    n = 2
-    x = torch.randn((n, c) + sp)
+    x = torch.randn((n, c) + sp)              # n == 1: the two BatchNorm finalisations ride inside the second conv / the tail pass
     wgt = torch.randn((n, 1) + sp)
     mod0 = SkipReturnAttention(c)
     mod0.apply(X.init_weights)
@@ -557,10 +557,11 @@ def test_skip_return_attention_with_composed_depthwise_pointwise_convs(c, sp, dt
         (a.float() * wgt.to(DEV)).sum().backward()
         X.ops.join_wgrad_stream()
         torch.cuda.synchronize()
-        return a.detach().float(), xg.grad.float(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-    a0, dx0, g0 = run(torch.float32, False)
-    a1, dx1, g1 = run(dtype, False)
-    a2, dx2, g2 = run(dtype, True)
+        bufs = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
+        return a.detach().float(), xg.grad.float(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, bufs
+    (a0, dx0, g0, b0), (a1, dx1, g1, b1), (a2, dx2, g2, b2) = run(torch.float32, False), run(dtype, False), run(dtype, True)
+    bdev = max((b2[k] - b0[k]).abs().max().item() for k in b0)
+    assert bdev <= (2e-2 if dtype == torch.bfloat16 else 3e-3), bdev          # running statistics (16-bit t1 / t2 vs fp32)
     assert g0.keys() == g2.keys(), (sorted(g0), sorted(g2))
     gs = max(v.abs().max().item() for v in g0.values())
     e1 = (l2_err(a1, a0), l2_err(dx1, dx0), max((g1[k] - g0[k]).abs().max().item() for k in g0) / gs)

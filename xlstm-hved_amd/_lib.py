@@ -40,6 +40,7 @@ class ConvPtrs(C.Structure):
         ("fin_red", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_count", ll), ("ws_packed", C.c_int),
         ("fan", vp), ("fan_bytes", ll),
         ("px", vp), ("pd", vp), ("nb_red", vp), ("nb_mean", vp), ("nb_rstd", vp), ("nb_count", ll),
+        ("fin_gamma", vp), ("fin_beta", vp), ("fin_rm", vp), ("fin_rv", vp), ("fin_steps", C.c_int),
     ]
 
 
@@ -84,6 +85,7 @@ SIGNATURES = {
     "xh_fanin_bytes": (ll, []),
     "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_fuses_norm_bwd": (I, [C.POINTER(ConvDesc)]),
+    "xh_conv3d_fuses_bn_finalize": (I, [C.POINTER(ConvDesc)]),
     "xh_conv3d_prepack": (I, [vp, I, vp, vp]),
     "xh_conv3d_wgrad_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
@@ -140,6 +142,7 @@ SIGNATURES = {
     "xh_compose_duse_bwd": (I, [vp, C.POINTER(vp * 10), I, vp, vp, vp, vp, C.POINTER(vp * 10)]),
     "xh_duse_fc_bwd": (I, [vp, vp, vp, ll, I, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_skr_tail_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll]),
+    "xh_skr_tail_bn_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, I, vp, vp, I, ll, vp, vp, vp, vp]),
     "xh_skr_tail_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I, vp]),
     "xh_pair_sums": (I, [vp, I, vp, ll, I, vp, ll, F, I, I, ll, I, F, vp]),
     "xh_lincomb": (I, [vp, I, vp, ll, I, vp, ll, F, vp, ll, I, I, ll, vp, vp, vp, vp, I]),

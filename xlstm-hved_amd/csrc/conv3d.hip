@@ -1517,6 +1517,10 @@ extern "C" int xh_set_option(int key, int value) {
 
 int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);          // conv3d_q4.hip
 long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d);
+extern "C" int xh_conv3d_fuses_bn_finalize(const xh_conv_desc* d) {
+  if (!d || !g_use_mfma || d->pre != 1 || d->N != 1 || d->k != 3) return 0;
+  return xh_conv3_q4_workspace_bytes(d) > 0 ? 1 : 0;
+}
 extern "C" int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d) {
   if (!d || !g_use_mfma || d->epi == 2 || d->act != XH_ACT_NONE) return 0;
   xh_conv_desc t = *d;
@@ -1532,6 +1536,11 @@ extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_
   if (d->epi == 2 && !p->red) return XH_ERR_ARG;
   if (d->epi < 0 || d->epi > 2) return XH_ERR_ARG;
   if (p->fin_red && (d->pre != 1 || !p->fin_mean || !p->fin_rstd || p->fin_count <= 0 || d->k != 3)) return XH_ERR_ARG;
+  if (p->fin_gamma) {                                 // BatchNorm flavour of the fused finalisation: the quad-channel kernel, one sample
+    if (!p->fin_red || !p->fin_beta || d->N != 1 || p->fin_steps < 0) return XH_ERR_ARG;
+    const int r = g_use_mfma ? xh_conv3_q4_try(stream, d, p) : 1;
+    return r == 1 ? XH_ERR_ARG : r;
+  }
   if (d->pre == 2) {                                  // norm-backward input: the quad-channel kernel only (xh_conv3d_fuses_norm_bwd)
     const int r = g_use_mfma ? xh_conv3_q4_try(stream, d, p) : 1;
     return r == 1 ? XH_ERR_ARG : r;

@@ -290,14 +290,33 @@ __global__ __launch_bounds__(256, PRE == 2 ? 3 : 4) void conv3_q4_kernel(const C
         // group's channels -> scale / shift in LDS (fp64, the same bits in every workgroup); workgroup (0, 0, 0) also
         // leaves them and mean / rstd of ALL channels in memory for the backward pass
         if (cq == 0) {
+          // (fin_gamma: a training-mode BatchNorm of ONE sample -- instance statistics, then the affine; xh_conv_ptrs)
+          const float* gam = a.p.fin_gamma;
+          const float* bet = a.p.fin_beta;
           if (tid < a.Cin_g) {
-            float m_, r_;
-            in_finalize(fs1, fs2, a.fin_inv, s_fin[tid], s_fin[Q4_MAXC + tid], m_, r_);
+            float m_, r_, sc_, sh_;
+            in_finalize(fs1, fs2, a.fin_inv, sc_, sh_, m_, r_);
+            if (gam) { const float g_ = gam[cin_base + tid]; sc_ *= g_; sh_ = fmaf(sh_, g_, bet[cin_base + tid]); }
+            s_fin[tid] = sc_; s_fin[Q4_MAXC + tid] = sh_;
           }
           if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-            for (int i = tid; i < a.d.N * a.d.Cin; i += 256)
-              in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], a.fin_inv, const_cast<float*>(a.p.pre_sc)[i],
-                          const_cast<float*>(a.p.pre_sh)[i], a.p.fin_mean[i], a.p.fin_rstd[i]);
+            for (int i = tid; i < a.d.N * a.d.Cin; i += 256) {
+              float sc_, sh_, m_, r_;
+              in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], a.fin_inv, sc_, sh_, m_, r_);
+              if (gam) {                                // N == 1: i is the channel
+                sc_ *= gam[i]; sh_ = fmaf(sh_, gam[i], bet[i]);
+                if (a.p.fin_rm && a.p.fin_rv && a.p.fin_steps > 0) {
+                  const double M = 1.0 / a.fin_inv, mean = a.p.fin_red[2 * i] * a.fin_inv;
+                  double var = a.p.fin_red[2 * i + 1] * a.fin_inv - mean * mean;
+                  if (var < 0) var = 0;
+                  const double keep = pow(0.9, (double)a.p.fin_steps), unb = var * M / (M > 1 ? M - 1 : 1);
+                  a.p.fin_rm[i] = (float)(keep * a.p.fin_rm[i] + (1 - keep) * mean);
+                  a.p.fin_rv[i] = (float)(keep * a.p.fin_rv[i] + (1 - keep) * unb);
+                }
+              }
+              const_cast<float*>(a.p.pre_sc)[i] = sc_; const_cast<float*>(a.p.pre_sh)[i] = sh_;
+              a.p.fin_mean[i] = m_; a.p.fin_rstd[i] = r_;
+            }
           __syncthreads();
         }
 #pragma unroll

@@ -2632,10 +2632,42 @@ extern "C" int xh_rank1_add_fc(void* stream, int dtype, void* dx, long long dx_b
 
 // ---------------------------------------------------------------------------------------- skip-return tail
 // r_c = relu(relu(t_c*sc+sh) + x_c);  a = sigmoid(w0*max_c r + w1*mean_c r)
+// fin.red != nullptr (one sample): the training-mode BatchNorm in front of the tail is finalised HERE from the raw channel sums of
+// t (every workgroup for all C <= 64 channels; the first one leaves sc / sh / mean / rstd for the backward pass and advances
+// the running statistics) -- the one-workgroup xh_norm_finalize launch between the conv and this pass disappears.
+struct SkrFin {
+  const double* red; double inv_count;
+  const float *gamma, *beta; float *rm, *rv; int steps;
+  float *o_sc, *o_sh, *o_mean, *o_rstd;
+};
 template <typename T, bool VEC, int CBT = CB>
 __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
                                                           const float* sh, const float* w2, T* __restrict__ a, int C,
-                                                          long long dhw) {
+                                                          long long dhw, const SkrFin fin) {
+  __shared__ float s_sc[64], s_sh[64];
+  if (fin.red) {
+    const int c = threadIdx.x;
+    if (c < C) {
+      float sc_, sh_, m_, r_;
+      in_finalize(fin.red[2 * c], fin.red[2 * c + 1], fin.inv_count, sc_, sh_, m_, r_);
+      const float g_ = fin.gamma ? fin.gamma[c] : 1.f, b_ = fin.beta ? fin.beta[c] : 0.f;
+      sc_ *= g_; sh_ = fmaf(sh_, g_, b_);
+      s_sc[c] = sc_; s_sh[c] = sh_;
+      if (blockIdx.x == 0 && blockIdx.z == 0) {
+        fin.o_sc[c] = sc_; fin.o_sh[c] = sh_; fin.o_mean[c] = m_; fin.o_rstd[c] = r_;
+        if (fin.rm && fin.rv && fin.steps > 0) {
+          const double M = 1.0 / fin.inv_count, mean = fin.red[2 * c] * fin.inv_count;
+          double var = fin.red[2 * c + 1] * fin.inv_count - mean * mean;
+          if (var < 0) var = 0;
+          const double keep = pow(0.9, (double)fin.steps), unb = var * M / (M > 1 ? M - 1 : 1);
+          fin.rm[c] = (float)(keep * fin.rm[c] + (1 - keep) * mean);
+          fin.rv[c] = (float)(keep * fin.rv[c] + (1 - keep) * unb);
+        }
+      }
+    }
+    __syncthreads();
+    sc = s_sc; sh = s_sh;                                // (one sample: n * C + c == c)
+  }
   const float w0 = w2[0], w1 = w2[1];
   VOX_LOOP_BEGIN
     float m[VW], s[VW];
@@ -2761,20 +2793,34 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
     else atomicAdd(&dw2acc[threadIdx.x], s_red[threadIdx.x]);
   }
 }
-extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
-                               const float* w2, void* a, int N, int C, long long DHW) {
-  if (!t || !x || !sc || !sh || !w2 || !a || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
+static int launch_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh, const float* w2,
+                               void* a, int N, int C, long long DHW, const SkrFin& fin) {
+  if (!t || !x || !w2 || !a || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype, {
     const dim3 grid = vox_grid<T>(DHW, N);
     if (vec_ok<T>(DHW, {}) && deep_grid(grid, C))
-      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true, 8>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW);
+      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true, 8>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW, fin);
     else if (vec_ok<T>(DHW, {}))
-      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW);
+      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW, fin);
     else
-      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, false>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW);
+      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, false>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW, fin);
   });
   return xh_launch_status();
+}
+extern "C" int xh_skr_tail_fwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh, const float* w2,
+                               void* a, int N, int C, long long DHW) {
+  if (!sc || !sh) return XH_ERR_ARG;
+  return launch_skr_tail_fwd(stream, dtype, t, x, sc, sh, w2, a, N, C, DHW, SkrFin{});
+}
+// xh_skr_tail_fwd with the training-mode BatchNorm in front of it finalised in the same launch (one sample, C <= 64): red [C][2]
+// raw sums of t; sc / sh / mean / rstd [C] are written (backward pass), running_mean / running_var advanced by `steps` updates.
+extern "C" int xh_skr_tail_bn_fwd(void* stream, int dtype, const void* t, const void* x, const double* red, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, int steps, const float* w2, void* a, int C,
+                                  long long DHW, float* sc, float* sh, float* mean, float* rstd) {
+  if (!red || !sc || !sh || !mean || !rstd || C > 64 || steps < 0) return XH_ERR_ARG;
+  SkrFin f{red, 1.0 / (double)DHW, gamma, beta, running_mean, running_var, steps, sc, sh, mean, rstd};
+  return launch_skr_tail_fwd(stream, dtype, t, x, sc, sh, w2, a, 1, C, DHW, f);
 }
 extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const void* x, const float* sc, const float* sh,
                                const float* w2, const void* a, const void* da, void* dtg, void* dx, double* dw2,

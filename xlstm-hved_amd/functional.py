@@ -754,18 +754,28 @@ class SkipReturnAttention(Function):
         else:
             u1 = ops.conv3d(x, None, [dw1], None, k=3, cout=c, groups=c)
             t1 = ops.conv3d(u1, None, [pw1w], [pw1b], k=1, cout=c, epi=2 if training else 0, red=red1)
-        sc1, sh1, m1, r1 = ops.norm_finalize(mode, red1, n, c, cnt, gamma=g1, beta=b1, running_mean=rm1, running_var=rv1,
-                                             steps=steps, device=x.device)
         red2 = ops.zeros_red(x, n, c) if training else None
-        if comp:
-            t2 = ops.conv3d(t1, None, [wc2], [pw2b], k=3, cout=c, pre=(sc1, sh1, 0.0), epi=2 if training else 0, red=red2)
+        # (one sample, training: the two BatchNorm finalisations ride inside their consumers -- the second dense conv and the tail
+        # pass -- instead of two one-workgroup launches; a batch statistic of one sample is its instance statistic)
+        bnf = comp and training and n == 1 and c <= 64 and ops.conv3d_fuses_bn(t1, c)
+        if bnf:
+            t2, sc1, sh1, m1, r1 = ops.conv3d(t1, None, [wc2], [pw2b], k=3, cout=c, in_stats=(red1, cnt, 0.0, (g1, b1, rm1, rv1, steps)),
+                                              epi=2, red=red2)
         else:
-            u2 = ops.conv3d(t1, None, [dw2], None, k=3, cout=c, groups=c, pre=(sc1, sh1, 0.0))
-            t2 = ops.conv3d(u2, None, [pw2w], [pw2b], k=1, cout=c, epi=2 if training else 0, red=red2)
-        sc2, sh2, m2, r2 = ops.norm_finalize(mode, red2, n, c, cnt, gamma=g2, beta=b2, running_mean=rm2, running_var=rv2,
-                                             steps=steps, device=x.device)
+            sc1, sh1, m1, r1 = ops.norm_finalize(mode, red1, n, c, cnt, gamma=g1, beta=b1, running_mean=rm1, running_var=rv1,
+                                                 steps=steps, device=x.device)
+            if comp:
+                t2 = ops.conv3d(t1, None, [wc2], [pw2b], k=3, cout=c, pre=(sc1, sh1, 0.0), epi=2 if training else 0, red=red2)
+            else:
+                u2 = ops.conv3d(t1, None, [dw2], None, k=3, cout=c, groups=c, pre=(sc1, sh1, 0.0))
+                t2 = ops.conv3d(u2, None, [pw2w], [pw2b], k=1, cout=c, epi=2 if training else 0, red=red2)
         w2 = saw.reshape(2).contiguous()
-        a = ops.skr_tail(t2, x, sc2, sh2, w2)
+        if bnf:
+            a, sc2, sh2, m2, r2 = ops.skr_tail_bn(t2, x, red2, g2, b2, rm2, rv2, steps, w2)
+        else:
+            sc2, sh2, m2, r2 = ops.norm_finalize(mode, red2, n, c, cnt, gamma=g2, beta=b2, running_mean=rm2, running_var=rv2,
+                                                 steps=steps, device=x.device)
+            a = ops.skr_tail(t2, x, sc2, sh2, w2)
         ctx.save_for_backward(x, u1, t1, u2, t2, a, sc1, sh1, m1, r1, sc2, sh2, m2, r2, dw1, pw1w, g1, dw2, pw2w, g2, w2, wc1, wc2)
         ctx.mode = mode
         ctx.params = (dw1, pw1w, pw1b, g1, b1, dw2, pw2w, pw2b, g2, b2)

@@ -356,6 +356,18 @@ def set_stream5(enabled):
 
 
 NB_PENDING = {}        # functional.InLreluConv: gradients handed over unwritten, by address (see functional._NB_PENDING)
+def conv3d_fuses_bn(x, cout, k=3, groups=1):
+    """True when conv3d(x, ..., in_stats=(red, count, slope, bn)) can finalise a training-mode BatchNorm of x inside its launch."""
+    if not (_BN_FOLD_ON() and _MFMA[0] and x.is_cuda and x.shape[0] == 1):
+        return False
+    d = _conv_desc(x, None, k, 1, groups, cout, 1, False, (None, None, 0.0), ACT_NONE, LEAK, 0, None, 0, _out_spatial(*x.shape[2:], k, 1))
+    return bool(L.load().xh_conv3d_fuses_bn_finalize(C.byref(d)))
+
+
+def _BN_FOLD_ON():
+    return BN_FOLD[0]
+
+
 _NB_FOLD = [os.environ.get("XH_NO_NB_FOLD", "") == ""]      # A/B switch: the InstanceNorm backward folded into the consuming data gradient
 
 
@@ -429,6 +441,12 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
         ws = torch.empty(need, dtype=torch.uint8, device=xa.device)
         ptrs.ws, ptrs.ws_bytes = ws.data_ptr(), need
     if stats is not None:
+        bn = in_stats[3] if len(in_stats) > 3 else None       # (gamma, beta, running_mean, running_var, steps): BatchNorm flavour
+        if bn is not None:
+            if not (n == 1 and lib.xh_conv3d_fuses_bn_finalize(C.byref(desc))):
+                raise ValueError("conv3d: the BatchNorm flavour of the fused finalisation needs one sample on the quad-channel kernel "
+                                 "(ops.conv3d_fuses_bn)")
+            ptrs.fin_gamma, ptrs.fin_beta, ptrs.fin_rm, ptrs.fin_rv, ptrs.fin_steps = _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3]), int(bn[4])
         if need or (k == 3 and stride == 2):   # MFMA path / stride-2 convs: the conv launch finalises the statistics itself
             ptrs.fin_red, ptrs.fin_mean, ptrs.fin_rstd, ptrs.fin_count = _p(in_stats[0]), _p(stats[2]), _p(stats[3]), int(in_stats[1])
         else:
@@ -1215,6 +1233,22 @@ def skr_tail(t, x, sc, sh, w2):
     a = new_like(x, (n, 1, d, h, w))
     L.check(L.load().xh_skr_tail_fwd(_stream(), _dt(x), _p(t), _p(x), _p(sc), _p(sh), _p(w2), _p(a), n, c, d * h * w), "xh_skr_tail_fwd")
     return a
+
+
+BN_FOLD = [os.environ.get("XH_NO_BN_FOLD", "") == ""]      # A/B switch: the skip-return ResBlock's BatchNorm finalisations inside their consumers
+
+
+def skr_tail_bn(t, x, red, gamma, beta, running_mean, running_var, steps, w2):
+    """skr_tail with the training-mode BatchNorm in front of it finalised in the same launch (one sample, xh_skr_tail_bn_fwd);
+    returns (a, sc, sh, mean, rstd)."""
+    n, c, d, h, w, _ = _vol(x)
+    if n != 1:
+        raise ValueError("skr_tail_bn: one sample per launch")
+    a = new_like(x, (n, 1, d, h, w))
+    sc, sh, mean, rstd = (torch.empty((1, c), dtype=torch.float32, device=x.device) for _ in range(4))
+    L.check(L.load().xh_skr_tail_bn_fwd(_stream(), _dt(x), _p(t), _p(x), _p(red), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                        int(steps), _p(w2), _p(a), c, d * h * w, _p(sc), _p(sh), _p(mean), _p(rstd)), "xh_skr_tail_bn_fwd")
+    return a, sc, sh, mean, rstd
 
 
 def skr_tail_bwd(t, x, sc, sh, w2, a, da, dw2_out=None, dx_acc=None):
