@@ -221,18 +221,18 @@ def main():
         # fp16 storage: the activation gradients need the caller's loss scaling, as the reference's GradScaler provides
         # (train.py:207,265-268; initial scale 65536); the unscale of the fp32 parameter gradients is part of the step
         scale = LOSS_SCALE_FP16 if xin.dtype == torch.float16 else 1.0
+        # the backward pass is seeded with a resident scalar (the loss scale, or 1): d(scale * loss) / d(loss), without the
+        # multiply launch and without the ones-fill autograd issues for an implicit seed
+        seed = torch.full((), scale, dtype=torch.float32, device=xin.device)
 
         def compute():
             grads.zero()
             seg, (mu, lv), rec = model(xin, [14], recon=True)
             loss = bench_loss(seg, mu, lv, rec[0])
+            loss.backward(seed if loss.dim() == 0 else seed.view(loss.shape))
+            ops.join_wgrad_stream()                           # the weight-gradient branch rejoins the step here
             if scale != 1.0:
-                (loss * scale).backward()
-                ops.join_wgrad_stream()
                 grads.flat.mul_(1.0 / scale)
-            else:
-                loss.backward()
-                ops.join_wgrad_stream()                       # the weight-gradient branch rejoins the step here
         return compute
     compute = make_compute(x)
 

@@ -87,6 +87,16 @@ class TrainStep:
         self._scale.fill_(float(v))
         self._inv_scale.fill_(1.0 / float(v))
 
+    def _seed(self, loss):
+        """The gradient a backward pass starts from: the loss scale (a device scalar, so a captured graph follows its updates)
+        or a resident 1 -- instead of a multiply launch on the loss and the ones-fill of an implicit seed."""
+        if self.scaling:
+            return self._scale.view(loss.shape)
+        one = self.__dict__.get("_one")
+        if one is None or one.device != loss.device:
+            one = self.__dict__["_one"] = torch.ones((), dtype=torch.float32, device=loss.device)
+        return one.view(loss.shape)
+
     def reset_scaler(self, loss_scale=None):
         """A fresh GradScaler: the reference constructs one per epoch (train.py:207).  The growth counter restarts too."""
         self.set_loss_scale(self._init_scale if loss_scale is None else loss_scale)
@@ -175,7 +185,7 @@ class TrainStep:
         was = ops._WG["defer"]
         ops.set_wgrad_defer(self.defer_wgrads or was)
         try:
-            (loss * self._scale[0] if self.scaling else loss).backward()
+            loss.backward(self._seed(loss))                # d(scale * loss): the device-resident scale (or 1) seeds the pass
             ops.join_wgrad_stream()
         except BaseException:
             # a failed backward (or a failed stream capture) leaves a partial batch queued: launching it now would raise a
@@ -193,7 +203,7 @@ class TrainStep:
         """Second half: the discriminator's loss on (fake.detach(), real) and its backward; gradients in self.grads_d."""
         fake, real, f_out, share = carry
         loss_d = self.discriminator_forward(fake, real, share)
-        (loss_d * self._scale[0] if self.scaling else loss_d).backward()
+        loss_d.backward(self._seed(loss_d))
         if self.scaling:
             self.grads_d.flat.mul_(self._inv_scale)
         parts["loss_d"], parts["f_out"] = loss_d.detach(), f_out
