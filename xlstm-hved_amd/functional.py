@@ -961,6 +961,7 @@ class ComposeAll(Function):
     sa_modules/sa_module.py:79-85).  Returns the flat tuple of composed tensors: (w, b) per AttenModule2, (sqw, sqb, adjw, adjb)
     per DuSE block, (w, b) of the head, one dense (C, C, k, k, k) weight per pair."""
     _store = {}
+    _gen = [0]
 
     @staticmethod
     def _jobs(plan, params, outs, bwd, grads=None, gouts=None):
@@ -1020,13 +1021,16 @@ class ComposeAll(Function):
                 ComposeAll._store.clear()
             store = ComposeAll._store[ckey] = []
         it = iter(store)
+        ComposeAll._gen[0] += 1
+        gen = ComposeAll._gen[0]
 
         def new(*shape):
             if fresh:
                 store.append(torch.empty(shape, dtype=torch.float32, device=dev))
             base = store[-1] if fresh else next(it)
             alias = base.view(shape)
-            alias._xh_base = base                          # ops._pack_entry keys a conv's packed fragments on the storage
+            alias._xh_base = base                          # ops._pack_entry keys a conv's packed fragments on the storage ...
+            alias._xh_gen = base._xh_gen = gen             # ... and tells a stale pack from a fresh one by this stamp (ops._wversion)
             return alias
         outs, pi = [], 0
         for ns, ne, e in a_plan:

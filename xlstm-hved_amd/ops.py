@@ -231,6 +231,14 @@ class _PackEntry:
         return True
 
 
+def _wversion(t):
+    """What tells a stale packed copy of a weight tensor from a fresh one: autograd's version counter for parameters; for the
+    tensors functional.ComposeAll writes with a raw kernel into persistent storage (no version bump) the generation it stamps on
+    them (`_xh_gen`, on the alias and on its storage)."""
+    g = getattr(t, "_xh_gen", None)
+    return t._version if g is None else ("gen", g)
+
+
 def set_prepack(enabled):
     """A/B switch (tests, microbenchmarks): False = every conv packs its own fragments right in front of the launch."""
     _PACK_STATE["enabled"] = bool(enabled)
@@ -280,7 +288,7 @@ def prepack_all():
     L.check(L.load().xh_conv3d_prepack(_stream(), len(ents), darr, parr), "xh_conv3d_prepack")
     for e in ents:
         e.epoch = st["epoch"]
-        e.versions = tuple(r()._version for r in e.refs)
+        e.versions = tuple(_wversion(r()) for r in e.refs)
 
 
 # ----------------------------------------------------------------------------------------------- conv
@@ -432,7 +440,7 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     if need and _PACK_STATE["enabled"]:
         ent = _pack_entry(weights, desc, need, xa.device)
         ptrs.ws, ptrs.ws_bytes = ent.ws.data_ptr(), need
-        vers = tuple(w._version for w in weights)
+        vers = tuple(_wversion(w) for w in weights)
         if ent.epoch == _PACK_STATE["epoch"] and ent.versions == vers:
             ptrs.ws_packed = 1
         else:                                   # this call packs; good for the rest of the epoch
