@@ -51,6 +51,10 @@ int xh_abi_version(void);
  * key 16: workgroup cap of the 1<->2-channel k3 stencil kernels (default 512).
  * key 17: workgroup count below which a quad-channel k3 launch walks 4, then 2 output planes per workgroup instead of 8
  *         (default 512; 0 = always 8).
+ * key 18: 1 = fp32 STORAGE takes the quad-channel matrix-core kernels with two-term fp16 operands (csrc/conv3d_q4s.hip: three fp16
+ *         MFMA products per fp32 product, ~22 significand bits) for k = 3 stride-1 convs and their data gradients instead of the
+ *         fp32 vector kernels; default 0.  In the backward pass the activation gradients then need the caller's loss scale, as
+ *         with fp16 storage.
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
  *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo

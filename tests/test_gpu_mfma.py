@@ -572,3 +572,50 @@ def test_skip_return_attention_with_composed_depthwise_pointwise_convs(c, sp, dt
     band = (2e-2, 0.25, 0.35) if dtype == torch.bfloat16 else (3e-3, 0.1, 0.15)
     assert all(a_ <= b_ for a_, b_ in zip(e2, band)), (e2, band)
     assert all(e2[i] <= 1.25 * e1[i] + 5e-3 for i in range(3)), (e1, e2)
+
+
+Q4S_CASES = [
+    dict(cin=4, cout=4, groups=1, sp=(9, 11, 32)),             # single quad, ragged D / H tiles
+    dict(cin=16, cout=16, groups=4, sp=(8, 16, 64)),           # the four encoder streams, two W tiles
+    dict(cin=12, cout=4, groups=1, sp=(8, 8, 32), split=4),    # decoder conv on a virtual concat: three input quads
+    dict(cin=4, cout=12, groups=1, sp=(6, 8, 32)),             # three output quads
+    dict(cin=20, cout=40, groups=5, sp=(4, 8, 32)),            # five groups (the skip stream riding along), 4 -> 8 each
+    dict(cin=4, cout=4, groups=1, sp=(32, 64, 128), n=1),      # a launch that takes the 4-plane tiles
+]
+
+
+@pytest.mark.parametrize("cfg", Q4S_CASES)
+def test_fp32_storage_through_split_fp16_matrix_cores_vs_fp32_vector_kernels(cfg):
+    """ops.set_fp32_mfma(True): fp32 tensors through conv3_q4s_kernel (x = hi + 2^-11 lo in fp16, three MFMA products per fp32
+    product, fp32 accumulation) against the fp32 FMA kernels on the same inputs: SingleConv 'ilc' forward with its fused
+    InstanceNorm + LeakyReLU and output moments, and the data gradient with the norm-backward epilogue.  ~22 significand bits per
+    product: relative L2 at the 1e-6 level (fp32 round-off is 6e-8; fp16 operands alone would read 3e-4)."""
+    from xlstm_hved_amd import functional as Fn
+    torch.manual_seed(19)
+    n, cin, cout, g = cfg.get("n", 2), cfg["cin"], cfg["cout"], cfg["groups"]
+    split = cfg.get("split")
+    x = torch.randn((n, cin) + cfg["sp"]) * 1.5 + 0.3
+    nw = g
+    ws = [torch.randn(cout // nw, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5 for _ in range(nw)]
+    bs = [torch.randn(cout // nw) for _ in range(nw)]
+    wgt = torch.randn((n, cout) + cfg["sp"])
+
+    def run(on):
+        X.ops.set_fp32_mfma(on)
+        try:
+            xg = x.to(DEV).requires_grad_(True)
+            wg = [w.to(DEV).requires_grad_(True) for w in ws]
+            bg = [b.to(DEV).requires_grad_(True) for b in bs]
+            xa, xb = (xg[:, :split], xg[:, split:]) if split else (xg, None)
+            y, st = Fn.in_lrelu_conv(xa, xb, wg, bg, 1, g, out_stats=True)
+            (y * wgt.to(DEV)).sum().backward()
+            X.ops.join_wgrad_stream()
+            torch.cuda.synchronize()
+            return y.detach().cpu(), st.detach().cpu().clone(), xg.grad.cpu(), [w.grad.cpu() for w in wg], X.ops.last_conv_kernel()
+        finally:
+            X.ops.set_fp32_mfma(False)
+    y0, s0, dx0, dw0, _ = run(False)
+    y1, s1, dx1, dw1, kern = run(True)
+    e = dict(y=l2_err(y1, y0), dx=l2_err(dx1, dx0), st=l2_err(s1, s0), dw=max(l2_err(a_, b_) for a_, b_ in zip(dw1, dw0)))
+    print(cfg, {k: f"{v:.2e}" for k, v in e.items()}, kern)
+    assert e["y"] < 3e-6 and e["dx"] < 6e-6 and e["st"] < 1e-6 and e["dw"] < 3e-5, e

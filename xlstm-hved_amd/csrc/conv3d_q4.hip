@@ -36,48 +36,10 @@
 #include "fanin.h"
 #include "../../include/xlstm_hved.h"
 
-typedef h16x8 frag8;
-typedef f32x4_t f32x4;
-
-struct ConvQ4 {
-  xh_conv_desc d;
-  xh_conv_ptrs p;
-  int Cin_g, Cout_g, ci4;       // channels per group, input-channel quads per group
-  int tilesW, tilesH, tilesD;
-  unsigned mW, mH, mQ, mG;      // reciprocals (udiv_magic) of tilesW, tilesH, oq_g, gpp
-  int oq_g, gpp;                // output-channel quads per group, groups per weight pointer
-  int td;                       // output planes per workgroup (8 | 4 | 2)
-  int dw;                       // depthwise conv presented as groups of 4 channels with diagonal weights (plan, pack only)
-  float act_slope;              // effective epilogue slope: 1 = identity, 0 = ReLU, else LeakyReLU
-  double fin_inv;               // 1 / fin_count
-  unsigned char* fan;           // statistics fan-in block of this launch (fanin.h), or nullptr: direct atomics
-  int abl;
-};
-extern int g_mfma_abl;
+#include "conv_q4.h"
 int g_q4_maxc = 48;               // xh_set_option(11, n): most channels per group the quad-channel kernel takes (<= 48)
 int g_q4_wgs = 512;               // xh_set_option(17, n): workgroup count below which a launch takes 4, then 2 output planes per workgroup (0: always 8)
-
-namespace {
-constexpr int TW = 32, TH = 8, IH = TH + 2;
-constexpr int PITCH = 288;                  // 36 voxels (ow0 - 2 .. ow0 + 33) x 8 bytes
-constexpr int PLANE = IH * PITCH;
-constexpr int Q4_MAXC = 48;                 // most channels per group the kernel can be asked to take
-// TD = output planes per workgroup: 8 (28.8 KB tile, 100 staged rows = two 8-voxel items per thread) for the volumes that fill
-// the chip; 4 / 2 for the 64^3 / 32^3 launches, which are chains of load -> transform -> matrix phase per input quad on a few
-// dozen workgroups: a quarter of the planes per workgroup = four times the workgroups and a shorter chain each (the halo
-// planes are re-read from L2)
-constexpr int q4_tile_bytes(int td) { return (td + 2) * PLANE; }
-}
-
-// Buffer descriptor of a wave-uniform base pointer, 2 GiB window: accesses at a 32-bit lane offset >= 0x80000000 are out of range,
-// i.e. a load returns 0 and a store is dropped -- predication without a branch (a branch around a vector-memory instruction makes
-// hipcc's s_waitcnt bookkeeping fall back to "wait for everything", which serialises loads that were requested ahead of their use)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t q4_window(const void* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x80000000, 0x00020000);
-}
-constexpr unsigned Q4_OOB = 0xFFFFFFF0u;
+int g_q4_f32 = 0;                 // xh_set_option(18, 1): fp32 storage through the matrix cores with two-term fp16 operands (conv3d_q4s.hip)
 
 // two values of one channel -> leaky(x * sc + sh) in fp32 (packed fma / mul; leaky = max(v, slope * v) for 0 <= slope <= 1)
 template <int FMT> __device__ __forceinline__ f32x2_t q4_xf(unsigned u, float sc, float sh, float slope) {
@@ -467,7 +429,10 @@ __global__ __launch_bounds__(256, PRE == 2 ? 3 : 4) void conv3_q4_kernel(const C
 static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   extern int g_xh_disable;
   if (g_xh_disable & 16) return false;
-  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return false;
+  const bool f32 = d->dtype == XH_F32;                 // fp32 storage: conv3d_q4s.hip (two-term fp16 operands), opt-in
+  if (f32 && !g_q4_f32) return false;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32) || d->k != 3 || d->stride != 1) return false;
+  if (f32 && (d->pre == 2 || d->act != XH_ACT_NONE)) return false;
   if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   if (d->W % TW != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
   int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
@@ -483,7 +448,7 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   if (d->epi == 1 && d->Cea % 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
-  if (dhw % 8 || dhw >= (1ll << 28)) return false;      // 31-bit byte offsets inside a quad of channel volumes (q4_window)
+  if (dhw % 8 || dhw >= (f32 ? (1ll << 27) : (1ll << 28))) return false;      // 31-bit byte offsets inside a quad of channel volumes (q4_window)
   if (d->pre == 1 && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
   if (d->pre == 2 && (d->Ca != d->Cin || (d->px_bs & 7) || (d->pd_bs & 7))) return false;     // one source, 16-byte runs
   float as = 1.f;
@@ -505,6 +470,7 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
     int td = 8;
     while (td > 2 && cols * cdiv(d->Do, td) < g_q4_wgs) td >>= 1;
     if (as != 1.f) td = 8;                              // the conv + activation instances exist for 8 planes only
+    if (f32 && td > 4) td = 4;                          // two LDS images per tile: 4 planes keep three workgroups per CU
     a->td = td;
   }
   a->tilesD = cdiv(d->Do, a->td);
@@ -521,7 +487,7 @@ static void q4_pack_job(const ConvQ4& a, PackJob* j) {
   for (int i = 0; i < XH_MAX_WPTR; ++i) j->w[i] = a.p.w[i];
   j->ws = a.p.ws;
   j->kind = 1;
-  j->f16 = a.d.dtype == XH_F16;
+  j->f16 = a.d.dtype == XH_F32 ? 2 : a.d.dtype == XH_F16;      // 2: hi / lo fp16 images (conv3d_q4s.hip)
   j->groups = a.d.groups; j->n_wptr = a.d.n_wptr; j->transposed = a.d.transposed;
   j->Cin_g = a.Cin_g; j->Cout_g = a.Cout_g;
   j->ntile = j->cin_stride = j->cin_off = j->cin_blk = j->cout_set = j->nm = j->nch = j->cpr = j->cinp = 0;
@@ -541,8 +507,9 @@ void xh_launch_pack_single(hipStream_t st, const PackJob& j);                   
 long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
   ConvQ4 a;
   if (!q4_plan(d, &a)) return 0;
-  return (long long)(d->Cout / 4) * a.ci4 * 9 * 1024;
+  return (long long)(d->Cout / 4) * a.ci4 * 9 * 1024 * (d->dtype == XH_F32 ? 2 : 1);
 }
+int xh_conv3_q4s_launch(hipStream_t st, const ConvQ4& a, dim3 grid);           // conv3d_q4s.hip
 
 // XH_OK if launched, 1 if the shape is not eligible
 int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
@@ -562,6 +529,7 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
   a.fan = d->epi ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
+  if (d->dtype == XH_F32) return xh_conv3_q4s_launch(st, a, grid);
   const size_t shm = q4_tile_bytes(a.td) + 48 * sizeof(double) + 3 * Q4_MAXC * sizeof(float);
   if (d->pre == 2 && (!p->px || !p->nb_red || !p->nb_mean || !p->nb_rstd || p->nb_count <= 0 || d->epi == 2)) return XH_ERR_ARG;
   const bool act = a.act_slope != 1.f;

@@ -65,6 +65,12 @@ __device__ __forceinline__ void pack_elem(const PackJob& j, int idx) {
     const int kw = s - pp - 1;
     if (kw >= 0 && kw <= 2) v = pack_weight(j, oq * 4 + c, grp * j.Cin_g + cq * 4 + ci, r9 * 3 + kw);
   }
+  if (j.f16 == 2) {                                     // two-term fp16 image of an fp32 weight: v = hi + 2^-11 lo (conv3d_q4s.hip)
+    const unsigned short hi = f2hf(v);
+    reinterpret_cast<unsigned short*>(j.ws)[idx] = hi;
+    reinterpret_cast<unsigned short*>(j.ws)[(long long)j.nelem + idx] = f2hf((v - hf2f(hi)) * 2048.f);
+    return;
+  }
   reinterpret_cast<unsigned short*>(j.ws)[idx] = j.f16 ? f2hf(v) : f2bf(v);
 }
 

@@ -70,6 +70,20 @@ def set_mfma(enabled):
     L.check(L.load().xh_set_option(0, int(bool(enabled))), "xh_set_option")
 
 
+_FP32_MFMA = [False]
+
+
+def set_fp32_mfma(enabled):
+    """fp32 STORAGE through the quad-channel matrix-core kernels with two-term fp16 operands (xh_set_option(18): csrc/conv3d_q4s.hip
+    for k = 3 stride-1 convs and their data gradients, the 16-bit-operand weight-gradient kernel for their weight gradients)
+    instead of the fp32 vector kernels; default off.  ~22-bit products in the forward pass; in the backward pass the activation
+    gradients must sit in fp16's range: scale the loss as for fp16 storage (bench.py and TrainStep use 65536)."""
+    _FP32_MFMA[0] = bool(enabled)
+    L.check(L.load().xh_set_option(18, int(bool(enabled))), "xh_set_option")
+    _PACKS.clear()
+    _PACK_STATE["arrays"] = None
+
+
 def last_conv_kernel():
     """Template instance launched by the most recent conv3d / conv3d_wgrad call (bench.py attributes timings with it)."""
     return L.load().xh_last_conv_kernel().decode()
