@@ -283,9 +283,15 @@ __global__ __launch_bounds__(256, 3) void conv3_q4s_kernel(const ConvQ4 a) {
       ps += f32x2_t{v[0] + v[1], v[2] + v[3]};
       pq += f32x2_t{v[0] * v[0] + v[1] * v[1], v[2] * v[2] + v[3] * v[3]};
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(4))), v), yrs,
-                                           (int)(live ? lane_bo : Q4_OOB), (int)((unsigned)dz * spd_b), 0);
+    // (two 8-byte stores: a 16-byte buffer store followed by the DPP sums below was seen to write stale data for a few lanes of
+    // the workgroup's last wave, run-to-run varying -- the store's data registers were reused before it had read them)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned so = live ? lane_bo : Q4_OOB;
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}, yrs, (int)so, (int)((unsigned)dz * spd_b), 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])}, yrs, (int)(live ? lane_bo + 8u : Q4_OOB),
+                                          (int)((unsigned)dz * spd_b), 0);
   }
+  asm volatile("s_nop 7" ::: "memory");
   if (EPI) {
     // fp32 storage: the per-lane partial sums of up to 4 * TD values go to fp64 right away
     const double t0 = row16_sum(row_ok ? (double)ps.x + (double)ps.y : 0.0), t1 = row16_sum(row_ok ? (double)pq.x + (double)pq.y : 0.0);
