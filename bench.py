@@ -38,9 +38,18 @@ LOSS_SCALE_FP16 = 65536.0      # torch.cuda.amp.GradScaler's initial scale (the 
 # deviation class of each storage mode from the fp32 reference path (tests/test_gpu_network.py, measured on MI355X at 64^3 / 128^3;
 # yardstick = the reference's own fp16-autocast deviation on the same weights / inputs, tests/golden/amp_yardstick.json)
 # "trained-like": the real reference trained 300 CPU steps on smooth synthetic patches (tests/golden/make_trained_like.py)
+STORAGE_NOTE = {
+    "bf16": "bf16 activation storage / fp32 arithmetic", "fp16": "fp16 activation storage / fp32 arithmetic",
+    "fp32": "fp32 activation storage / fp32 arithmetic",
+    "fp32_mfma": "fp32 activation storage / 3^3 convs as two-term fp16 split on the matrix cores, fp32 accumulation",
+}
 MODE_PARITY = {
     "fp32": "parity mode: seg |d| <= 8e-4, Dice deviation <= 1e-5 vs the CPU oracle at 128^3 on random-init weights, all parameter "
             "gradients within 2.1e-3 of the largest; 0 mask flips of 6.3 M on trained-like weights (SURVEY 8c tolerances 5e-3 / 1e-4)",
+    "fp32_mfma": "parity mode on the matrix cores (fp32 storage; 3^3 quad-channel convs as two-term fp16 split MFMA, weight gradients "
+                 "with fp16 operands, loss scale 65536): seg |d| <= 8.1e-4, Dice deviation <= 1e-5 vs the CPU oracle at 128^3, all "
+                 "parameter gradients within 2.1e-3 of the largest, relative L2 3.3e-3 -- the same figures as fp32 "
+                 "(tests/test_gpu_network.py::test_fp32_full_size_128_{vs,backward_vs}_oracle[split_mfma])",
     "fp16": "Dice deviation 5.5e-4 at 128^3 on trained-like weights (reference fp16-AMP: 8.3e-3); random-init weights: seg rel-L2 "
             "0.010, Dice deviation 3.6e-3 (reference fp16-AMP: 0.111, 4.0e-2)",
     "bf16": "Dice deviation 3.9e-3 at 128^3 on trained-like weights (reference bf16-AMP: 4.9e-2); random-init weights: seg rel-L2 "
@@ -53,7 +62,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp32_mfma"],
+                    help="activation storage; fp32_mfma = fp32 storage with the quad-channel 3^3 convs on the matrix cores through "
+                         "the two-term fp16 split (ops.set_fp32_mfma), run under the fp16 loss scale")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
@@ -198,8 +209,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
         else:
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
-    DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+    DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp32_mfma": torch.float32}
     dtype = DT[args.dtype]
+    ops.set_fp32_mfma(args.dtype == "fp32_mfma")              # process-wide switch, read when a conv is launched (= at capture)
     S, B = args.size, args.batch
 
     torch.manual_seed(1)                                      # same weights on every rank
@@ -217,10 +229,11 @@ def main():
     ops.set_wgrad_overlap(args.wgrad_overlap, args.wgrad_batch)
     ops.set_wgrad_defer(not args.no_wgrad_defer and not args.wgrad_overlap)   # weight gradients batched at the end of backward           # weight gradients on a second HIP stream, joined once per step
 
-    def make_compute(xin):
+    def make_compute(xin, split=False):
         # fp16 storage: the activation gradients need the caller's loss scaling, as the reference's GradScaler provides
-        # (train.py:207,265-268; initial scale 65536); the unscale of the fp32 parameter gradients is part of the step
-        scale = LOSS_SCALE_FP16 if xin.dtype == torch.float16 else 1.0
+        # (train.py:207,265-268; initial scale 65536); the unscale of the fp32 parameter gradients is part of the step.
+        # split (fp32_mfma): fp32 storage, but the activation gradients enter the matrix cores as fp16 pairs -- same scale
+        scale = LOSS_SCALE_FP16 if (xin.dtype == torch.float16 or split) else 1.0
         # the backward pass is seeded with a resident scalar (the loss scale, or 1): d(scale * loss) / d(loss), without the
         # multiply launch and without the ones-fill autograd issues for an implicit seed
         seed = torch.full((), scale, dtype=torch.float32, device=xin.device)
@@ -234,7 +247,7 @@ def main():
             if scale != 1.0:
                 grads.flat.mul_(1.0 / scale)
         return compute
-    compute = make_compute(x)
+    compute = make_compute(x, args.dtype == "fp32_mfma")
 
     def step():
         compute()
@@ -306,7 +319,7 @@ def main():
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"XLSTM_HVED fwd+bwd, {B}x4x{S}^3 patch per GPU, f_maps=4 'ilc' (train.py:142-143), "
-                               f"train mode, subset [14], recon=True, {args.dtype} activation storage / fp32 arithmetic, "
+                               f"train mode, subset [14], recon=True, {STORAGE_NOTE[args.dtype]}, "
                                f"random-init weights, {'hipGraph replay' if graph is not None else 'eager'}",
                    "parallelism": f"dp{world}", "per_gpu_batch": B, "global_batch": B * world},
     }
@@ -318,7 +331,11 @@ def main():
         for name, dt_ in DT.items():
             if name == args.dtype:
                 continue
-            ms_m = time_graph(make_compute(x.to(dt_)), args.steps, args.warmup, thread_local=use_dist)
+            ops.set_fp32_mfma(name == "fp32_mfma")
+            try:
+                ms_m = time_graph(make_compute(x.to(dt_), name == "fp32_mfma"), args.steps, args.warmup, thread_local=use_dist)
+            finally:
+                ops.set_fp32_mfma(args.dtype == "fp32_mfma")
             modes[name] = {"ms_per_step": ms_m, "voxels_per_s": B * S ** 3 / (ms_m * 1e-3), "parity": MODE_PARITY[name]}
         out["modes"] = modes
     if args.extras and rank == 0:

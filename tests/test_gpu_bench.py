@@ -24,7 +24,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert j["steps"] == 3 and j["n_gpus"] == 1 and j["value"] > 0
     assert j["roofline"]["bound"] in ("hbm", "mfma") and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
-    assert set(j["modes"]) == {"bf16", "fp16", "fp32"} and all(m["ms_per_step"] > 0 for m in j["modes"].values())
+    assert set(j["modes"]) == {"bf16", "fp16", "fp32", "fp32_mfma"} and all(m["ms_per_step"] > 0 for m in j["modes"].values())
 
 
 def test_bench_force_dist_rccl_allreduce_with_graph_capture():

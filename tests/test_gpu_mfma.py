@@ -589,7 +589,9 @@ def test_fp32_storage_through_split_fp16_matrix_cores_vs_fp32_vector_kernels(cfg
     """ops.set_fp32_mfma(True): fp32 tensors through conv3_q4s_kernel (x = hi + 2^-11 lo in fp16, three MFMA products per fp32
     product, fp32 accumulation) against the fp32 FMA kernels on the same inputs: SingleConv 'ilc' forward with its fused
     InstanceNorm + LeakyReLU and output moments, and the data gradient with the norm-backward epilogue.  ~22 significand bits per
-    product: relative L2 at the 1e-6 level (fp32 round-off is 6e-8; fp16 operands alone would read 3e-4)."""
+    product: relative L2 at the 1e-6 level (fp32 round-off is 6e-8; fp16 operands alone would read 3e-4).  The weight / bias
+    gradients of the mode come from conv3_wgrad_q4_multi_kernel<2, ...>: fp32 loads, operands rounded ONCE to fp16, fp32
+    accumulation -- a sum over every voxel of independently rounded products, so the 3e-4 per-product error averages down."""
     from xlstm_hved_amd import functional as Fn
     torch.manual_seed(19)
     n, cin, cout, g = cfg.get("n", 2), cfg["cin"], cfg["cout"], cfg["groups"]
@@ -611,11 +613,17 @@ def test_fp32_storage_through_split_fp16_matrix_cores_vs_fp32_vector_kernels(cfg
             (y * wgt.to(DEV)).sum().backward()
             X.ops.join_wgrad_stream()
             torch.cuda.synchronize()
-            return y.detach().cpu(), st.detach().cpu().clone(), xg.grad.cpu(), [w.grad.cpu() for w in wg], X.ops.last_conv_kernel()
+            out = (y.detach().cpu(), st.detach().cpu().clone(), xg.grad.cpu(), [w.grad.cpu() for w in wg] + [torch.cat([b.grad.cpu() for b in bg])])
+            # which kernel a weight gradient of this shape and dtype takes (the backward above ends on its data gradient)
+            scr = [torch.zeros_like(w) for w in wg]
+            X.ops.conv3d_wgrad(xg.detach()[:, :split] if split else xg.detach(), xg.detach()[:, split:] if split else None, wgt.to(DEV), scr, None,
+                               k=3, groups=g)
+            return out + (X.ops.last_conv_kernel(),)
         finally:
             X.ops.set_fp32_mfma(False)
     y0, s0, dx0, dw0, _ = run(False)
     y1, s1, dx1, dw1, kern = run(True)
     e = dict(y=l2_err(y1, y0), dx=l2_err(dx1, dx0), st=l2_err(s1, s0), dw=max(l2_err(a_, b_) for a_, b_ in zip(dw1, dw0)))
     print(cfg, {k: f"{v:.2e}" for k, v in e.items()}, kern)
-    assert e["y"] < 3e-6 and e["dx"] < 6e-6 and e["st"] < 1e-6 and e["dw"] < 3e-5, e
+    assert "wgrad_q4_multi_kernel<2" in kern, kern
+    assert e["y"] < 3e-6 and e["dx"] < 6e-6 and e["st"] < 1e-6 and e["dw"] < 4e-4, e

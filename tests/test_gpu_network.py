@@ -1,6 +1,7 @@
 """-m gpu: the whole XLSTM_HVED forward/backward on the HIP path against (a) the golden vectors generated from the
 real reference at 32^3 and (b) the CPU oracle at other sizes / modes.  Tolerances follow SURVEY.md 8(c)/F9."""
 import numpy as np
+import functools
 import pytest
 import torch
 
@@ -264,11 +265,9 @@ def test_fp16_backward_with_loss_scaling_matches_fp32_gradients():
     assert e < 0.25 and e <= 1.05 * eu
 
 
-@pytest.mark.parametrize("cfg", ["n1_subset14_train", "n2_instance_missing_train"])
-def test_fp32_full_size_128_vs_oracle(cfg):
-    """BASELINE configs 2 and 3 at FULL size (128^3), fp32 storage, against the CPU oracle (not only properties):
-    N=1 all modalities, and N=2 with per-sample modality dropout (instance_missing, masks drawn from the 15 subsets).
-    Tolerances of SURVEY 8(c): seg atol 5e-3, recon 1e-3 of its absmax, Dice deviation 1e-4."""
+@functools.lru_cache(maxsize=None)
+def _oracle_forward_128(cfg):
+    """The CPU oracle's 128^3 forward of a configuration (tens of seconds): shared by the storage / arithmetic variants below."""
     torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
     torch.manual_seed(12)
     n = 1 if cfg.startswith("n1") else 2
@@ -283,15 +282,32 @@ def test_fp32_full_size_128_vs_oracle(cfg):
         kw = dict(instance_missing=True)
     sd = {k: v.clone() for k, v in _weights().items()}
     with torch.no_grad():
-        prob_o, _, mu_o, lv_o, rec_o = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True, **kw)
+        out = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True, **kw)
+    return n, x, eps, kw, sd, out
+
+
+@pytest.mark.parametrize("arith", ["fma", "split_mfma"])
+@pytest.mark.parametrize("cfg", ["n1_subset14_train", "n2_instance_missing_train"])
+def test_fp32_full_size_128_vs_oracle(cfg, arith):
+    """BASELINE configs 2 and 3 at FULL size (128^3), fp32 storage, against the CPU oracle (not only properties):
+    N=1 all modalities, and N=2 with per-sample modality dropout (instance_missing, masks drawn from the 15 subsets).
+    Tolerances of SURVEY 8(c): seg atol 5e-3, recon 1e-3 of its absmax, Dice deviation 1e-4.
+    arith = split_mfma: the same fp32 tensors with ops.set_fp32_mfma(True) -- the quad-channel 3^3 convs on the matrix cores
+    through the two-term fp16 split (conv3d_q4s.hip); the SAME tolerances apply."""
+    n, x, eps, kw, sd, (prob_o, _, mu_o, lv_o, rec_o) = _oracle_forward_128(cfg)
     m = _model(True)
-    with torch.no_grad():
-        seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps, **kw)
+    X.ops.set_fp32_mfma(arith == "split_mfma")
+    try:
+        with torch.no_grad():
+            seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps, **kw)
+        torch.cuda.synchronize()
+    finally:
+        X.ops.set_fp32_mfma(False)
     e_seg, e_rec = (seg.cpu() - prob_o).abs().max().item(), rel_err(rec[0], rec_o)
     tgt = (prob_o > 0.5).float()
     d = (_dice(seg, tgt) - 1.0).abs().max().item()
     flips = ((seg.cpu() > 0.5) != (prob_o > 0.5)).sum().item()
-    print(f"fp32 128^3 {cfg}: seg |d| {e_seg:.2e} recon rel {e_rec:.2e} dice dev {d:.2e} mask flips {flips}/{seg.numel()}")
+    print(f"fp32 128^3 {cfg} [{arith}]: seg |d| {e_seg:.2e} recon rel {e_rec:.2e} dice dev {d:.2e} mask flips {flips}/{seg.numel()}")
     assert e_seg < 5e-3 and e_rec < 1e-3 and d < 1e-4
     # latents of the PRESENT modalities (+ the prior).  A dropped modality's stream sees an all-zero input: every conv
     # output in it is a constant, every InstanceNorm divides round-off by sqrt(eps), so its (masked, unused) mu / logvar
@@ -307,11 +323,8 @@ def test_fp32_full_size_128_vs_oracle(cfg):
             check(sdm[k].float().cpu(), sd[k].float(), 1e-4, k)
 
 
-def test_fp32_full_size_128_backward_vs_oracle():
-    """The benchmarked step itself (BASELINE config 2: 1x4x128^3, train mode, loss of SURVEY 8(d)) forward AND backward in fp32
-    storage against the CPU oracle: every parameter gradient at the full-size instances of the norm-backward, gate-backward,
-    upsample-adjoint and conv data/weight-gradient kernels.  Bounds of the 32^3 golden test: 5e-3 of the largest gradient per
-    tensor; additionally the relative L2 over all gradients."""
+@functools.lru_cache(maxsize=None)
+def _oracle_backward_128():
     torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
     torch.manual_seed(21)
     x = torch.rand(1, 4, 128, 128, 128)
@@ -319,14 +332,36 @@ def test_fp32_full_size_128_backward_vs_oracle():
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in _weights().items()}
     prob_o, _, mu_o, lv_o, rec_o = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True)
     O.bench_loss(prob_o, mu_o, lv_o, rec_o).backward()
-    gref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    return x, eps, {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+@pytest.mark.parametrize("arith", ["fma", "split_mfma"])
+def test_fp32_full_size_128_backward_vs_oracle(arith):
+    """The benchmarked step itself (BASELINE config 2: 1x4x128^3, train mode, loss of SURVEY 8(d)) forward AND backward in fp32
+    storage against the CPU oracle: every parameter gradient at the full-size instances of the norm-backward, gate-backward,
+    upsample-adjoint and conv data/weight-gradient kernels.  Bounds of the 32^3 golden test: 5e-3 of the largest gradient per
+    tensor; additionally the relative L2 over all gradients.
+    arith = split_mfma: ops.set_fp32_mfma(True) -- forward and data gradients of the quad-channel 3^3 convs through the two-term
+    fp16 split, their weight gradients with single-rounded fp16 operands (conv3_wgrad_q4_multi_kernel<2, ...>).  The activation
+    gradients pass through fp16's range on their way into the matrix cores, so the step is run the way the mode is meant to be
+    run: under the reference's initial GradScaler scale (train.py:207: 65536), unscaled afterwards.  Same bounds."""
+    x, eps, gref = _oracle_backward_128()
     m = _model(True)
-    seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps)
-    loss = seg.float().mean() + rec[0].float().mean()
-    for a_, b_ in zip(mu, lv):
-        loss = loss + a_.float().mean() + b_.float().mean()
-    loss.backward()
-    torch.cuda.synchronize()
+    scale = 65536.0 if arith == "split_mfma" else 1.0
+    X.ops.set_fp32_mfma(arith == "split_mfma")
+    try:
+        seg, (mu, lv), rec = m(x.to(DEV), [14], recon=True, eps_list=eps)
+        loss = seg.float().mean() + rec[0].float().mean()
+        for a_, b_ in zip(mu, lv):
+            loss = loss + a_.float().mean() + b_.float().mean()
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+    finally:
+        X.ops.set_fp32_mfma(False)
+    if scale != 1.0:
+        for p_ in m.parameters():
+            if p_.grad is not None:
+                p_.grad.mul_(1.0 / scale)
     gscale = max(v.abs().max().item() for v in gref.values())
     worst, wname, num, den, n_checked = 0.0, "", 0.0, 0.0, 0
     for k, p_ in m.named_parameters():
@@ -344,7 +379,7 @@ def test_fp32_full_size_128_backward_vs_oracle():
         den += (gref[kk] ** 2).sum().item()
         n_checked += 1
     l2 = (num / den) ** 0.5
-    print(f"fp32 128^3 backward vs oracle: {n_checked} parameter gradients, worst {worst:.2e} of the largest ({wname}), relative L2 {l2:.2e}")
+    print(f"fp32 128^3 backward vs oracle [{arith}]: {n_checked} parameter gradients, worst {worst:.2e} of the largest ({wname}), relative L2 {l2:.2e}")
     assert n_checked > 250
     assert worst < 5e-3 and l2 < 5e-3, (worst, wname, l2)
 

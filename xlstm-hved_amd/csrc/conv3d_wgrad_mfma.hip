@@ -351,7 +351,7 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   {                                                   // few channels per group: the quad-channel kernel (conv3d_wgrad_q4.hip)
     WgQ4 q;
     if (xh_wgrad_q4_plan(d, p, dw, db, &q)) {
-      xh_wgrad_q4_launch((hipStream_t)stream, d->dtype == XH_F16 ? 1 : 0, &q, 1);
+      xh_wgrad_q4_launch((hipStream_t)stream, d->dtype == XH_F32 ? 2 : d->dtype == XH_F16 ? 1 : 0, &q, 1);
       return xh_launch_status();
     }
   }
@@ -404,13 +404,13 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
   // quad-channel problems first: WQ_MULTI per launch and storage format
   std::vector<char> handled(n > 0 ? n : 1, 0);
   if (g_use_mfma) {
-    for (int cls = 0; cls < 6; ++cls) {               // (storage format, input-channel quads per group)
+    for (int cls = 0; cls < 9; ++cls) {               // (storage format: bf16 / fp16 / fp32 with fp16 operands, input-channel quads per group)
       const int fmt = cls / 3, ci4 = cls % 3 + 1;
       std::vector<WgQ4> cl;
       WgQ4 q;
       for (int i = 0; i < n; ++i) {
         if (!d[i] || !p[i]) return XH_ERR_ARG;
-        if (handled[i] || (d[i]->dtype == XH_F16 ? 1 : 0) != fmt) continue;
+        if (handled[i] || (d[i]->dtype == XH_F32 ? 2 : d[i]->dtype == XH_F16 ? 1 : 0) != fmt) continue;
         if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &q) || q.ci4 != ci4) continue;
         handled[i] = 1;
         cl.push_back(q);

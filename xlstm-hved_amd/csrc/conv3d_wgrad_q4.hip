@@ -281,9 +281,17 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
 //  * the constant column (bias gradient) reads a 16-byte block of ones that sits in every plane slot.
 // A step = 1 + CI4 ds_read_b128 and 3 CI4 MFMAs.  4-plane LDS ring, one barrier per two planes, the global loads of a round
 // issued two rounds ahead (3 + 4 NIX VGPRs per round in flight; every thread has the same loads, none under a branch).
+// FMT 2 = fp32 STORAGE (xh_set_option(18, 1)): both operands are read as fp32, the x operand transformed in fp32, and both go to
+// LDS as fp16 (CF below): single-rounded fp16 operands, fp32 accumulation.  A weight gradient is a sum over ~10^6 voxels whose
+// operand roundings are independent: the deviation of the sum is ~3e-4 of its size, far inside the parity mode's gradient band;
+// the activation gradients (dY) need the caller's loss scale to sit in fp16's range, like the data gradients of conv3d_q4s.hip.
+template <int FMT> struct WqStore { typedef h16<FMT> T; };
+template <> struct WqStore<2> { typedef float T; };
 template <int FMT, int CI4>
 __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned char* smem) {
-  typedef h16<FMT> ST;
+  typedef typename WqStore<FMT>::T ST;
+  constexpr int CF = FMT == 2 ? 1 : FMT;               // format of the LDS images / MFMA operands
+  constexpr bool F32S = FMT == 2;
   constexpr int ROWB = 4 * CI4 * 64 + 16;             // bytes per staged x row: 4 CI4 channels x 64 B, + 16 B so that the 12 (ci, kh)
                                                       // lanes of a B-fragment read fall on 12 different 16-byte bank groups
   constexpr int XB = 6 * ROWB;                        // x rows of a plane
@@ -292,7 +300,7 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   constexpr int PLB = DYB + 4096;                     // bytes per plane slot
   constexpr int NITX = 96 * CI4;                      // 16-byte x items per plane
   constexpr int NIX = (NITX + 127) / 128;             // x items per thread (a thread serves one of the two planes of a round)
-  constexpr unsigned ONE2 = FMT == 0 ? 0x3F803F80u : 0x3C003C00u;
+  constexpr unsigned ONE2 = CF == 0 ? 0x3F803F80u : 0x3C003C00u;
   float* s_dw = reinterpret_cast<float*>(smem);       // after the plane loops
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g = lane >> 4;
@@ -380,16 +388,30 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
     const unsigned y_lmask = y_gq == 0 ? (y_edge_l ? 0xffffffffu : 0u) : 0xffffffffu;   // chunk 0 at w = 0: voxel -1 does not exist
     const unsigned y_rmask = y_gq == 7 ? (y_edge_r ? 0xffffffffu : 0u) : 0xffffffffu;   // last chunk at the row end: voxel W does not exist
     // ---- staging: round r covers x planes d0 - 1 + 2 r (+ pp) and the dY planes one above them ----
-    auto issue = [&](int r, uint4 (&q)[NIX], uint2& yq, unsigned& ye) {
+    // a staged item: 8 voxels of x (16 bytes of 16-bit storage, 32 of fp32), 4 voxels of dY + the 2 voxels beyond the row end
+    struct XQ { uint4 a; uint4 b; };                   // b: fp32 storage only
+    struct YQ { uint4 v; uint2 e; };                   // 16-bit storage: v.x, v.y and e.x only
+    auto issue = [&](int r, XQ (&q)[NIX], YQ& yq) {
       const int p = d0 - 1 + 2 * r + pp;
       const long long po = (long long)min(max(p, 0), D - 1) * hw;
 #pragma unroll
-      for (int k = 0; k < NIX; ++k) q[k] = *reinterpret_cast<const uint4*>(i_src[k] + po);
+      for (int k = 0; k < NIX; ++k) {
+        q[k].a = *reinterpret_cast<const uint4*>(i_src[k] + po);
+        if (F32S) q[k].b = *reinterpret_cast<const uint4*>(i_src[k] + po + 4);
+        else q[k].b = q[k].a;                          // unused
+      }
       const long long yo = (long long)min(max(p + 1, 0), D - 1) * hw;
-      yq = *reinterpret_cast<const uint2*>(y_src + yo);
-      ye = *reinterpret_cast<const unsigned*>(y_esrc + yo);
+      if (F32S) {
+        yq.v = *reinterpret_cast<const uint4*>(y_src + yo);
+        yq.e = *reinterpret_cast<const uint2*>(y_esrc + yo);
+      } else {
+        const uint2 t = *reinterpret_cast<const uint2*>(y_src + yo);
+        yq.v = uint4{t.x, t.y, 0u, 0u};
+        yq.e.y = 0u;
+        yq.e.x = *reinterpret_cast<const unsigned*>(y_esrc + yo);
+      }
     };
-    auto commit = [&](int r, const uint4 (&q)[NIX], const uint2& yq, unsigned ye) {
+    auto commit = [&](int r, const XQ (&q)[NIX], const YQ& yq) {
       const int p = d0 - 1 + 2 * r + pp;
       const float pm = (unsigned)p < (unsigned)D ? 1.f : 0.f;
       unsigned char* dst = smem + ((2 * r + pp) & 3) * PLB;
@@ -397,21 +419,28 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
       for (int k = 0; k < NIX; ++k) {
         if (!i_do[k]) continue;
         const float sc = i_sc[k] * pm, sh = i_sh[k] * pm;
-        const unsigned u[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+        const unsigned u[8] = {q[k].a.x, q[k].a.y, q[k].a.z, q[k].a.w, q[k].b.x, q[k].b.y, q[k].b.z, q[k].b.w};
         uint4 o;
         unsigned* op = &o.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const f32x2_t v = cvt2_in<FMT>(u[e]) * f32x2_t{sc, sc} + f32x2_t{sh, sh};
+          const f32x2_t xin = F32S ? f32x2_t{__uint_as_float(u[2 * e]), __uint_as_float(u[2 * e + 1])} : cvt2_in<CF>(u[e]);
+          const f32x2_t v = xin * f32x2_t{sc, sc} + f32x2_t{sh, sh};
           const f32x2_t y = max2(v, v * f32x2_t{pslope, pslope});
-          op[e] = cvt2_pack<FMT>(y.x, y.y);
+          op[e] = cvt2_pack<CF>(y.x, y.y);
         }
         *reinterpret_cast<uint4*>(dst + i_lds[k]) = o;
       }
       {
         // out plane v = p + 1 belongs to this tile when d0 <= v < d1 (v >= d0 always holds: p >= d0 - 1)
         const unsigned am = (p + 1 < d1 ? 0xffffffffu : 0u) & y_rowmask;
-        const unsigned c0 = yq.x & am, c1 = yq.y & am, e = ye & am;
+        unsigned y0 = yq.v.x, y1 = yq.v.y, ye = yq.e.x;
+        if (F32S) {                                     // four fp32 voxels -> two packed fp16 pairs; the two beyond the row end -> one
+          y0 = cvt2_pack<CF>(__uint_as_float(yq.v.x), __uint_as_float(yq.v.y));
+          y1 = cvt2_pack<CF>(__uint_as_float(yq.v.z), __uint_as_float(yq.v.w));
+          ye = cvt2_pack<CF>(__uint_as_float(yq.e.x), __uint_as_float(yq.e.y));
+        }
+        const unsigned c0 = y0 & am, c1 = y1 & am, e = ye & am;
         // neighbour dwords inside the row: the 8 lanes y_gq = 0..7 of a DPP row half hold its chunks (row_shr:1 / row_shl:1;
         // the lanes at a row end take the extra dword instead)
         const unsigned pl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c1, 0x111, 0xf, 0xf, true);
@@ -434,31 +463,30 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
       for (int cq = 0; cq < CI4; ++cq) bf[cq] = *reinterpret_cast<const frag8*>(src + b_off[cq]);
 #pragma unroll
       for (int cq = 0; cq < CI4; ++cq) {
-        acc[cq][0] = mfma16x16x32<FMT>(af_p1, bf[cq], acc[cq][0]);
-        acc[cq][1] = mfma16x16x32<FMT>(af_0, bf[cq], acc[cq][1]);
-        acc[cq][2] = mfma16x16x32<FMT>(af_m1, bf[cq], acc[cq][2]);
+        acc[cq][0] = mfma16x16x32<CF>(af_p1, bf[cq], acc[cq][0]);
+        acc[cq][1] = mfma16x16x32<CF>(af_0, bf[cq], acc[cq][1]);
+        acc[cq][2] = mfma16x16x32<CF>(af_m1, bf[cq], acc[cq][2]);
       }
       af_m1 = af_0;
       af_0 = af_p1;
     };
     const int nround = ((d1 - d0 + 2 + 1) / 2 + 1) & ~1;     // rounds of two planes, an even number of them
-    uint4 qa[NIX], qb[NIX];
-    uint2 ya, yb;
-    unsigned ea, eb;
+    XQ qa[NIX], qb[NIX];
+    YQ ya, yb;
     __syncthreads();                                         // the previous tile's planes are no longer read
-    issue(0, qa, ya, ea);
-    issue(1, qb, yb, eb);
-    commit(0, qa, ya, ea);
-    issue(2, qa, ya, ea);
+    issue(0, qa, ya);
+    issue(1, qb, yb);
+    commit(0, qa, ya);
+    issue(2, qa, ya);
     for (int r = 0; r < nround; r += 2) {
       __syncthreads();                                       // round r staged; round r - 1 fully read
-      commit(r + 1, qb, yb, eb);
-      issue(r + 3, qb, yb, eb);
+      commit(r + 1, qb, yb);
+      issue(r + 3, qb, yb);
       step(d0 - 1 + 2 * r);
       step(d0 + 2 * r);
       __syncthreads();                                       // round r + 1 staged; round r fully read
-      commit(r + 2, qa, ya, ea);
-      issue(r + 4, qa, ya, ea);
+      commit(r + 2, qa, ya);
+      issue(r + 4, qa, ya);
       step(d0 + 1 + 2 * r);
       step(d0 + 2 + 2 * r);
     }
@@ -518,7 +546,7 @@ __global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4
   const int local = b - m.off[i];
   const WgQ4& a = m.p[i];
   if (local >= a.nb) return;
-  if constexpr (LDSX) wgrad_q4_body_lds<FMT, CI4>(a, local, smem);
+  if constexpr (LDSX || FMT == 2) wgrad_q4_body_lds<FMT, CI4>(a, local, smem);
   else wgrad_q4_body<FMT, CI4>(a, local, reinterpret_cast<float*>(smem));      // A/B: every wave loads its own x rows
 }
 
@@ -526,7 +554,9 @@ __global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4
 bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgQ4* a) {
   extern int g_xh_disable;
   if (g_xh_disable & 32) return false;
-  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1 || d->transposed) return false;
+  extern int g_q4_f32;
+  const bool f32 = d->dtype == XH_F32 && g_q4_f32;     // fp32 storage, fp16 operands (xh_set_option(18, 1))
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32) || d->k != 3 || d->stride != 1 || d->transposed) return false;
   if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
   int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups, groups = d->groups;
@@ -537,7 +567,7 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   if (d->Ca % 4) return false;
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->ea_bs & 7)) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
-  if (dhw % 8 || dhw >= (1ll << 27)) return false;     // 32-bit byte offsets inside a channel quad
+  if (dhw % 8 || dhw >= (f32 ? (1ll << 26) : (1ll << 27))) return false;     // 32-bit byte offsets inside a channel quad
   if (d->pre && !(d->pre_slope >= 0.f && d->pre_slope <= 1.f)) return false;
   if (!p->ea || !p->xa) return false;
   if (d->D < 4 || d->H < 4) return false;
@@ -571,7 +601,6 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   return true;
 }
 
-// launches up to WQ_MULTI planned problems of one storage format
 // launches up to WQ_MULTI planned problems of one storage format and one input-quad count (probs[i].ci4 all equal)
 void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   WgQ4Multi m;
@@ -594,14 +623,18 @@ void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
     a.nb = a.nq * w;
     m.off[i + 1] = m.off[i] + ((a.nb + 7) & ~7);
   }
-  const bool ldsx = !(g_mfma_abl & 8192);              // ablation bit 8192: the variant in which every wave loads its own x rows
+  const bool ldsx = fmt == 2 || !(g_mfma_abl & 8192);  // ablation bit 8192: the variant in which every wave loads its own x rows
   xh_note_kernel("conv3_wgrad_q4_multi_kernel<%d, %d, %s>", fmt, ci4, ldsx ? "true" : "false");
 #define WQL(F, C)                                                                                                        \
   do {                                                                                                                   \
     if (ldsx) hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<F, C, true>), dim3(m.off[n]), dim3(256), 0, st, m);         \
     else hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<F, C, false>), dim3(m.off[n]), dim3(256), 0, st, m);             \
   } while (0)
-  if (fmt) { if (ci4 == 1) WQL(1, 1); else if (ci4 == 2) WQL(1, 2); else WQL(1, 3); }
+  if (fmt == 2) {                                      // fp32 storage: the LDS variant only
+    if (ci4 == 1) hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<2, 1, true>), dim3(m.off[n]), dim3(256), 0, st, m);
+    else if (ci4 == 2) hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<2, 2, true>), dim3(m.off[n]), dim3(256), 0, st, m);
+    else hipLaunchKernelGGL((conv3_wgrad_q4_multi_kernel<2, 3, true>), dim3(m.off[n]), dim3(256), 0, st, m);
+  } else if (fmt) { if (ci4 == 1) WQL(1, 1); else if (ci4 == 2) WQL(1, 2); else WQL(1, 3); }
   else { if (ci4 == 1) WQL(0, 1); else if (ci4 == 2) WQL(0, 2); else WQL(0, 3); }
 #undef WQL
 }
