@@ -627,3 +627,68 @@ def test_fp32_storage_through_split_fp16_matrix_cores_vs_fp32_vector_kernels(cfg
     print(cfg, {k: f"{v:.2e}" for k, v in e.items()}, kern)
     assert "wgrad_q4_multi_kernel<2" in kern, kern
     assert e["y"] < 3e-6 and e["dx"] < 6e-6 and e["st"] < 1e-6 and e["dw"] < 4e-4, e
+
+
+Q4P_CASES = [
+    dict(cin=16, cout=16, groups=4, sp=(24, 40, 64), n=1),            # four streams: runs of tiles cross output quads
+    dict(cin=12, cout=4, groups=1, sp=(20, 24, 32), n=2, split=4),    # decoder conv on a virtual concat: three input quads per tile, 2 samples
+    dict(cin=4, cout=12, groups=1, sp=(9, 17, 32), n=1),              # ragged D and H tiles
+    dict(cin=8, cout=8, groups=1, sp=(16, 16, 64), n=1),              # two input quads, two output quads
+    dict(cin=4, cout=4, groups=1, sp=(64, 64, 128), n=1),             # 1 024 tiles on the chip
+]
+
+
+@pytest.mark.parametrize("occ3", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", Q4P_CASES)
+def test_persistent_pipelined_q4_kernel_equals_the_per_tile_kernel(cfg, dtype, occ3):
+    """conv3_q4p_kernel (resident workgroups walking runs of tiles, the next stage's loads in flight under the matrix phase and
+    epilogue of the current one; xh_set_option(19, 2) forces it; two or three workgroups per CU) against conv3_q4_kernel on the same operands: forward with the
+    producer's norm + LeakyReLU from explicit scale / shift AND from raw sums (fused finalisation), output moments; data gradient
+    with the leaky'-masked norm-backward sums; plain.  Same products in the same order: the outputs must agree BIT FOR BIT; the
+    fp64 statistics differ in summation order only."""
+    lib = X._lib.load()
+    torch.manual_seed(23)
+    n, cin, cout, g = cfg["n"], cfg["cin"], cfg["cout"], cfg["groups"]
+    split = cfg.get("split")
+    x = (torch.randn((n, cin) + cfg["sp"]) * 1.3 + 0.2).to(DEV, dtype)
+    dy = torch.randn((n, cout) + cfg["sp"]).to(DEV, dtype)
+    ws = [(torch.randn(cout // g, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5).to(DEV) for _ in range(g)]
+    bs = [torch.randn(cout // g).to(DEV) for _ in range(g)]
+    sc, sh = (torch.rand(n, cin) + 0.5).to(DEV), torch.randn(n, cin).to(DEV)
+    cnt = cfg["sp"][0] * cfg["sp"][1] * cfg["sp"][2]
+    xf = x.float()
+    raw = torch.stack([xf.sum((2, 3, 4)), (xf * xf).sum((2, 3, 4))], -1).double().contiguous()
+    xa, xb = (x[:, :split], x[:, split:]) if split else (x, None)
+
+    def run(mode):
+        X._lib.check(lib.xh_set_option(19, mode), "xh_set_option")
+        X._lib.check(lib.xh_set_option(17, 0), "xh_set_option")          # 8 output planes per tile whatever the launch size
+        X._lib.check(lib.xh_set_option(1, 32768 if (occ3 and mode) else 0), "xh_set_option")
+        try:
+            out = {}
+            red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
+            out["fwd"] = X.ops.conv3d(xa, xb, ws, bs, k=3, cout=cout, groups=g, pre=(sc, sh, 0.01), epi=2, red=red)
+            out["fwd_red"], out["k_fwd"] = red, X.ops.last_conv_kernel()
+            red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
+            y, fsc, fsh, fm, fr = X.ops.conv3d(xa, xb, ws, bs, k=3, cout=cout, groups=g, in_stats=(raw, cnt, 0.01), epi=2, red=red)
+            out["fin"], out["fin_red"], out["fin_sc"], out["fin_sh"], out["fin_m"], out["fin_r"] = y, red, fsc, fsh, fm, fr
+            out["k_fin"] = X.ops.last_conv_kernel()
+            out["plain"] = X.ops.conv3d(xa, xb, ws, bs, k=3, cout=cout, groups=g)
+            red = torch.zeros(n, cin, 2, dtype=torch.float64, device=DEV)
+            out["dgrad"] = X.ops.conv3d(dy, None, ws, None, k=3, cout=cin, groups=g, transposed=True, epi=1,
+                                        e=(xa, xb, sc, sh, 0.01), red=red)
+            out["dgrad_red"], out["k_dgrad"] = red, X.ops.last_conv_kernel()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib.xh_set_option(19, 1)
+            lib.xh_set_option(17, 512)
+            lib.xh_set_option(1, 0)
+    a_, b_ = run(0), run(2)
+    assert "conv3_q4_kernel" in a_["k_fwd"] and "conv3_q4p_kernel" in b_["k_fwd"] and "conv3_q4p_kernel" in b_["k_dgrad"], (a_["k_fwd"], b_["k_fwd"])
+    for k_ in ("fwd", "fin", "plain", "dgrad", "fin_sc", "fin_sh", "fin_m", "fin_r"):
+        assert torch.equal(a_[k_], b_[k_]), (k_, (a_[k_].float() - b_[k_].float()).abs().max().item(), a_["k_fin"], b_["k_fin"])
+    for k_ in ("fwd_red", "fin_red", "dgrad_red"):
+        d_ = (a_[k_] - b_[k_]).abs().max().item() / max(a_[k_].abs().max().item(), 1e-30)
+        assert d_ < 1e-9, (k_, d_)

@@ -510,6 +510,7 @@ long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
   return (long long)(d->Cout / 4) * a.ci4 * 9 * 1024 * (d->dtype == XH_F32 ? 2 : 1);
 }
 int xh_conv3_q4s_launch(hipStream_t st, const ConvQ4& a, dim3 grid);           // conv3d_q4s.hip
+int xh_conv3_q4p_try(hipStream_t st, const ConvQ4& a);                         // conv3d_q4p.hip: persistent, pipelined over tiles
 
 // XH_OK if launched, 1 if the shape is not eligible
 int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
@@ -526,6 +527,10 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
     PackJob pj;
     q4_pack_job(a, &pj);
     xh_launch_pack_single(st, pj);
+  }
+  if (d->dtype != XH_F32) {                            // launches with several tiles per workgroup slot: the persistent kernel
+    const int r = xh_conv3_q4p_try(st, a);
+    if (r != 1) return r;
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
   a.fan = d->epi ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
