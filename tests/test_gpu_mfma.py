@@ -355,7 +355,7 @@ def _full_size_128(cfg, dtype, path):
     y, red = X.functional.in_lrelu_conv(xa, xb, wg, bg, 1, g, out_stats=True)
     k_fwd = X.ops.last_conv_kernel()
     if path == "q4":
-        big_ok = lambda k: "conv3_q4_kernel" in k
+        big_ok = lambda k: "conv3_q4_kernel" in k or "conv3_q4p_kernel" in k     # (multi-quad forward launches: the persistent variant)
     else:
         big_ok = lambda k: "conv3_mfma_kernel" in k and ", 256, 32, 8, 2>" in k
     assert big_ok(k_fwd), k_fwd

@@ -22,10 +22,17 @@
 // would leave most CUs without a workgroup, see TD below); more input channels are walked quad by quad through the same LDS
 // tile (28.8 KB at TD = 8; 4-5 workgroups per CU hide each other's staging phase).
 //
-// Measured on MI355X (tools/microbench_big.py --abl, 16 -> 16 g4 @128^3 forward without statistics, 39.5 us): staging
-// 23.7 us, matrix phase + epilogue 13.2 us, launch 2.6 us; statistics + fan-in add 10 us.  SQ counters: the SIMDs' issue slots
-// are 91 % busy (4.1 cycles per instruction): instruction-issue bound, which is why phases of different workgroups do not
-// hide each other.  Tried and dropped: loads of the next input quad issued under the matrix phase of the current one
+// Measured on MI355X -- TWO regimes, do not mix them:
+//  (a) microbenchmark with ONE operand set (tools/microbench_big.py --abl, XH_ROT=1): the 201 MB of a 16 -> 16 g4 @128^3 launch sit
+//      in the 256 MB last-level cache.  Forward without statistics 39.5 us: staging 23.7, matrix phase + epilogue 13.2, launch 2.6;
+//      statistics + fan-in add 10 us.  SQ counters there: issue slots 91 % busy (4.1 cycles per instruction).
+//  (b) in the training step / with operands rotated through 1.6 GB (XH_ROT=8), i.e. from HBM: the same launch 49.2 us (data gradient
+//      with the norm-backward epilogue 59.7 us = 3.4 TB/s = 0.42 of the 8 TB/s peak), staging alone 29.5 us.  SQ counters in the step
+//      (profiles/r04c_pmc_sq.json): issue 17 %, SQ_WAIT_ANY 41 %, MFMA busy 12 %; memory-side counters: TA busy 59 % of
+//      the launch and mostly stalled by the cache, L1 hit rate 60 % -- the tile's 64-byte half-lines and 4-byte edge loads are
+//      what saturates, which is why neither more resident waves nor the persistent prefetching variant (conv3d_q4p.hip) helps
+//      single-quad tiles.
+// Tried and dropped: loads of the next input quad issued under the matrix phase of the current one
 // (needs 154-168 VGPRs = 3 workgroups per CU: 12 -> 4 @128^3 33 -> 38 us, the 64^3 / 32^3 shapes unchanged -- those are
 // latency chains of a few dozen workgroups); the epilogue of output plane pz - 2 run inside the plane walk (its loads requested
 // two or four planes ahead, branch-free): 16 -> 16 g4 data gradient 56 -> 48 us in the microbenchmark, whose operands sit in the

@@ -309,7 +309,7 @@ def _xconv(mode, x, w, b, y, n, cin, cout, sp_in, sp_out, ks, stride):
 class DiscExactFn(Function):
     """The discriminator in EXACT fp32 (Discriminator.fp32_exact): NCDHW fp32 activations, direct fp32 convolutions
     (xh_dconv_exact), InstanceNorm / LeakyReLU(0.2) through the generic fp32 passes of the generator's path.  No 16-bit operand:
-    a training step in fp32 storage then agrees with the CPU oracle to fp32 round-off end to end.  A parity route (~1 TFLOP/s),
+    a training step in fp32 storage then agrees with the fp32 CPU restatement under tests/ to fp32 round-off end to end.  A parity route (~1 TFLOP/s),
     not the product path."""
 
     @staticmethod
