@@ -692,3 +692,65 @@ def test_persistent_pipelined_q4_kernel_equals_the_per_tile_kernel(cfg, dtype, o
     for k_ in ("fwd_red", "fin_red", "dgrad_red"):
         d_ = (a_[k_] - b_[k_]).abs().max().item() / max(a_[k_].abs().max().item(), 1e-30)
         assert d_ < 1e-9, (k_, d_)
+
+
+Q4W_CASES = [
+    dict(cin=16, cout=16, groups=4, sp=(12, 24, 128), n=1),           # the four encoder streams
+    dict(cin=12, cout=4, groups=1, sp=(9, 17, 128), n=2, split=4),    # virtual concat, three input quads, ragged D / H tiles, 2 samples
+    dict(cin=4, cout=12, groups=1, sp=(8, 8, 128), n=1),              # one tile per plane quad
+    dict(cin=8, cout=8, groups=1, sp=(16, 16, 128), n=1),             # two input quads, two output quads
+    dict(cin=4, cout=4, groups=1, sp=(32, 40, 128), n=1),
+    dict(cin=20, cout=40, groups=5, sp=(6, 8, 128), n=1),             # five groups, 4 -> 8 channels each
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", Q4W_CASES)
+def test_full_row_q4_kernel_equals_the_32_wide_tile_kernel(cfg, dtype):
+    """conv3_q4w_kernel (rows of 128 voxels: 4 x 8 x 128 tiles of 8 waves, no W halo, full-line loads; default) against
+    conv3_q4_kernel (xh_set_option(20, 0)) on the same operands: forward with the producer's norm + LeakyReLU from explicit
+    scale / shift and from raw sums (fused finalisation), output moments; data gradient with the leaky'-masked norm-backward sums;
+    plain.  Same products in the same order per output value: the outputs must agree BIT FOR BIT; the statistics differ in the
+    grouping of the fp32 lane partials (32 stored values each, other tile shape) and in fp64 summation order."""
+    lib = X._lib.load()
+    torch.manual_seed(29)
+    n, cin, cout, g = cfg["n"], cfg["cin"], cfg["cout"], cfg["groups"]
+    split = cfg.get("split")
+    x = (torch.randn((n, cin) + cfg["sp"]) * 1.3 + 0.2).to(DEV, dtype)
+    dy = torch.randn((n, cout) + cfg["sp"]).to(DEV, dtype)
+    ws = [(torch.randn(cout // g, cin // g, 3, 3, 3) * (2.0 / (27 * cin // g)) ** 0.5).to(DEV) for _ in range(g)]
+    bs = [torch.randn(cout // g).to(DEV) for _ in range(g)]
+    sc, sh = (torch.rand(n, cin) + 0.5).to(DEV), torch.randn(n, cin).to(DEV)
+    cnt = cfg["sp"][0] * cfg["sp"][1] * cfg["sp"][2]
+    xf = x.float()
+    raw = torch.stack([xf.sum((2, 3, 4)), (xf * xf).sum((2, 3, 4))], -1).double().contiguous()
+    xa, xb = (x[:, :split], x[:, split:]) if split else (x, None)
+
+    def run(wide):
+        X._lib.check(lib.xh_set_option(20, wide), "xh_set_option")
+        X._lib.check(lib.xh_set_option(19, 0), "xh_set_option")
+        try:
+            out = {}
+            red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
+            out["fwd"] = X.ops.conv3d(xa, xb, ws, bs, k=3, cout=cout, groups=g, pre=(sc, sh, 0.01), epi=2, red=red)
+            out["fwd_red"], out["k_fwd"] = red, X.ops.last_conv_kernel()
+            red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
+            y, fsc, fsh, fm, fr = X.ops.conv3d(xa, xb, ws, bs, k=3, cout=cout, groups=g, in_stats=(raw, cnt, 0.01), epi=2, red=red)
+            out["fin"], out["fin_red"], out["fin_sc"], out["fin_sh"], out["fin_m"], out["fin_r"] = y, red, fsc, fsh, fm, fr
+            out["plain"] = X.ops.conv3d(xa, xb, ws, None, k=3, cout=cout, groups=g)
+            red = torch.zeros(n, cin, 2, dtype=torch.float64, device=DEV)
+            out["dgrad"] = X.ops.conv3d(dy, None, ws, None, k=3, cout=cin, groups=g, transposed=True, epi=1,
+                                        e=(xa, xb, sc, sh, 0.01), red=red)
+            out["dgrad_red"], out["k_dgrad"] = red, X.ops.last_conv_kernel()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib.xh_set_option(20, 1)
+            lib.xh_set_option(19, 1)
+    a_, b_ = run(0), run(1)
+    assert "conv3_q4_kernel" in a_["k_fwd"] and "conv3_q4w_kernel" in b_["k_fwd"] and "conv3_q4w_kernel" in b_["k_dgrad"], (a_["k_fwd"], b_["k_fwd"])
+    for k_ in ("fwd", "fin", "plain", "dgrad", "fin_sc", "fin_sh", "fin_m", "fin_r"):
+        assert torch.equal(a_[k_], b_[k_]), (k_, (a_[k_].float() - b_[k_].float()).abs().max().item())
+    for k_ in ("fwd_red", "fin_red", "dgrad_red"):
+        d_ = (a_[k_] - b_[k_]).abs().max().item() / max(a_[k_].abs().max().item(), 1e-30)
+        assert d_ < 1e-6, (k_, d_)

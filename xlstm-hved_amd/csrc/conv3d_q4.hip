@@ -518,6 +518,7 @@ long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
 }
 int xh_conv3_q4s_launch(hipStream_t st, const ConvQ4& a, dim3 grid);           // conv3d_q4s.hip
 int xh_conv3_q4p_try(hipStream_t st, const ConvQ4& a);                         // conv3d_q4p.hip: persistent, pipelined over tiles
+int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a);                               // conv3d_q4w.hip: full-row tiles for 128-wide rows
 
 // XH_OK if launched, 1 if the shape is not eligible
 int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
@@ -535,8 +536,10 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
     q4_pack_job(a, &pj);
     xh_launch_pack_single(st, pj);
   }
-  if (d->dtype != XH_F32) {                            // launches with several tiles per workgroup slot: the persistent kernel
-    const int r = xh_conv3_q4p_try(st, a);
+  if (d->dtype != XH_F32) {
+    int r = xh_conv3_q4w_try(st, a);                   // rows of 128 voxels: full-row tiles
+    if (r != 1) return r;
+    r = xh_conv3_q4p_try(st, a);                       // multi-quad forward launches with several tiles per workgroup slot: the persistent kernel
     if (r != 1) return r;
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);

@@ -1,0 +1,345 @@
+// Full-row variant of the quad-channel 3x3x3 convolution (conv3d_q4.hip) for volumes whose rows are 128 voxels wide -- the
+// 128^3 patches of XLSTM_HVED (RA_HVED.py:510-648; semantics of buildingblocks.py:406-433), where the conv stages spend their
+// time.
+//
+// Why (counters of conv3_q4_kernel on HBM-resident operands): its 8 x 8 x 32 tile reads, per staged row and channel, one
+// 64-byte HALF of a 128-byte line plus two 4-byte edge voxels that sit in lines of their own -- 1 200 line requests for a tile
+// image of 28.8 KB, the texture path busy 59 % of the launch and stalled by the cache for most of that, while neither more
+// resident waves nor prefetching across tiles (conv3d_q4p.hip) changed the 3 us per tile and CU.
+//
+// Here a tile spans the WHOLE row: 4 planes x 8 rows x 128 voxels, one workgroup of 8 waves.
+//   * no W halo at all: the two voxels left and right of a row are the conv's zero padding (two constant LDS slots per staged
+//     row); every global load is a 16-byte piece of a FULL line, 8 consecutive lanes per line: 60 rows x 4 channels x 2 lines =
+//     480 line requests for 4 096 output voxels (2 400 for the same voxels before);
+//   * D / H halo 6 x 10 planes-rows for 4 x 8 (1.875; 1.56 before) -- those re-reads are L2 hits of the neighbouring tiles;
+//   * wave w owns output row w and both 64-voxel halves of it (two N tiles of the W-Toeplitz GEMM): per staged plane 6 LDS reads and
+//     up to 18 MFMAs; same products in the same order as conv3_q4_kernel: the outputs are BIT-IDENTICAL;
+//   * LDS image [plane][row][66 slots of 16 bytes] (slot = 2 voxels x 4 channels, slot 0 / 65 = padding), slot index XORed with bit 4
+//     of itself: the 16 quads of a fragment read (stride 2 slots) and the 8 pieces of a staged line (stride 4 slots) both cover
+//     the 64 banks once.
+// Same template axes as conv3_q4_kernel except: no activation epilogue, no norm-backward-on-load (pre == 2 lives on tensors below
+// 2^22 elements, i.e. not on 128-wide rows); 63 KB of LDS, two workgroups per CU.
+#include "conv_q4.h"
+
+int g_q4_wide = 1;                // xh_set_option(20, n): 0 = never, 1 = rows of 128 voxels take conv3_q4w_kernel
+
+namespace {
+constexpr int WW = 128;                      // row width the kernel is built for
+constexpr int WTD = 4, WTH = 8;              // output planes / rows per workgroup
+constexpr int WID = WTD + 2, WIH = WTH + 2;
+constexpr int WSLOTS = WW / 2 + 2;           // 66
+constexpr int WPITCH = WSLOTS * 16;          // 1056 bytes per staged row
+constexpr int WPLANE = WIH * WPITCH;
+constexpr int WTILE = WID * WPLANE;          // 63 360 bytes
+constexpr int WNROWS = WID * WIH;            // 60
+constexpr int WNITEM = WNROWS * 16;          // (row, 8-voxel piece)
+constexpr int WNIT = (WNITEM + 511) / 512;   // 2
+}
+// physical 16-byte slot of logical slot s inside a row
+__device__ __forceinline__ int q4w_slot(int s) { return s ^ ((s >> 4) & 1); }
+
+template <int FMT> __device__ __forceinline__ f32x2_t q4w_xf(unsigned u, float sc, float sh, float slope) {
+  const f32x2_t v = cvt2_in<FMT>(u) * f32x2_t{sc, sc} + f32x2_t{sh, sh};
+  return max2(v, v * f32x2_t{slope, slope});
+}
+
+template <int FMT, int PRE, int EPI, bool MULTI>
+__global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
+  typedef h16<FMT> ST;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* s_red = reinterpret_cast<double*>(smem + WTILE);             // [8 waves][8], then [8] totals + the fan-in flag
+  float* s_fin = reinterpret_cast<float*>(smem + WTILE + 80 * sizeof(double));   // [2][Q4_MAXC]: in-kernel InstanceNorm scale / shift
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nn = lane & 15, g4 = lane >> 4;
+  const int oq = blockIdx.y, n = blockIdx.z;
+  const int co0 = oq * 4;
+  const int grp = udiv_fast(oq, a.oq_g, a.mQ);
+  const int cin_base = grp * a.Cin_g;
+  const int D = a.d.D, H = a.d.H;
+  const long long hw = (long long)H * WW, dhw = (long long)D * hw;
+  const int Do = a.d.Do, Ho = a.d.Ho;
+  const int tilesH = (Ho + WTH - 1) / WTH;
+  const int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int td = wk / tilesH, th = wk - td * tilesH;
+  const int od0 = td * WTD, oh0 = th * WTH;
+  // raw InstanceNorm sums of this group's input channels (fused finalisation): requested first, used behind the staging loads
+  double fs1 = 0.0, fs2 = 0.0;
+  if (PRE == 1 && a.p.fin_red && tid < a.Cin_g) {
+    fs1 = a.p.fin_red[2 * (n * a.d.Cin + cin_base + tid)];
+    fs2 = a.p.fin_red[2 * (n * a.d.Cin + cin_base + tid) + 1];
+  }
+  // the padding slots of every staged row: zero for the whole launch (the staging never writes them)
+  if (tid < WNROWS * 2) {
+    const int row = tid >> 1, s = (tid & 1) ? WSLOTS - 1 : 0;
+    *reinterpret_cast<uint4*>(smem + row * WPITCH + q4w_slot(s) * 16) = make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- staging plan (the same for every input-channel quad): item = (row, piece j of 8 voxels) ----
+  unsigned i_off[WNIT];
+  int i_lds[WNIT], i_s0[WNIT];
+  bool i_live[WNIT], i_do[WNIT];
+#pragma unroll
+  for (int it = 0; it < WNIT; ++it) {
+    const int item = tid + it * 512;
+    i_do[it] = item < WNITEM;
+    const int j = item & 15, row = min(item >> 4, WNROWS - 1);
+    const int dz = row / WIH, hy = row - dz * WIH;
+    const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy;
+    i_live[it] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+    const int gdc = min(max(gd, 0), D - 1), ghc = min(max(gh, 0), H - 1);
+    i_off[it] = (unsigned)((((long long)gdc * H + ghc) * WW + j * 8) * (long long)sizeof(ST));
+    i_lds[it] = row * WPITCH;
+    i_s0[it] = 1 + 4 * j;                              // first logical slot of the piece
+  }
+  // ---- B (data) fragments: lane (quad nn, k-group g4) of half h reads logical slot 32 h + 2 nn + g4 of input row wv + kh ----
+  const int b_off[2] = {q4w_slot(2 * nn + g4) * 16, q4w_slot(32 + 2 * nn + g4) * 16};
+  // ---- epilogue lane role: lane (quad, channel) owns 4 consecutive voxels of output row oh0 + wv in each half ----
+  const int oh = oh0 + wv;
+  const bool row_ok = oh < Ho;
+  const int ndz = min(WTD, Do - od0);
+  float bias = 0.f, esc = 0.f, esh = 0.f;
+  {
+    const int wp = udiv_fast(grp, a.gpp, a.mG);
+    const float* bp = a.p.b[wp];
+    if (bp) bias = bp[(grp - wp * a.gpp) * a.Cout_g + (oq - grp * a.oq_g) * 4 + g4];
+  }
+  const long long odhw = (long long)Do * Ho * WW;
+  const unsigned spd_b = (unsigned)(Ho * WW) * (unsigned)sizeof(ST);
+  const unsigned lane_b = (unsigned)(((long long)g4 * odhw + (long long)(row_ok ? oh : 0) * WW + 4 * nn) * (long long)sizeof(ST));
+  const unsigned lane_bo = row_ok ? lane_b : Q4_OOB;
+  constexpr unsigned HALF_B = 64 * sizeof(ST);         // byte distance of the two halves of a row
+  __amdgpu_buffer_rsrc_t ers = q4_window(a.p.y), yrs;
+  if (EPI == 1) {
+    esc = a.p.e_sc[n * a.d.Cout + co0 + g4];
+    esh = a.p.e_sh[n * a.d.Cout + co0 + g4];
+    ers = q4_window(reinterpret_cast<const char*>(co0 < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co0 * odhw
+                                                                  : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co0 - a.d.Cea) * odhw) +
+                    (long long)od0 * spd_b);
+  }
+  yrs = q4_window(reinterpret_cast<char*>((ST*)a.p.y + n * a.d.y_bs + (long long)co0 * odhw) + (long long)od0 * spd_b);
+
+  f32x4 acc[WTD][2];
+#pragma unroll
+  for (int i = 0; i < WTD; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int ncq = MULTI ? a.ci4 : 1;
+  const float pslope = a.d.pre_slope;
+  const bool fin = PRE == 1 && a.p.fin_red != nullptr;
+  const long long dhw_b = dhw * (long long)sizeof(ST);
+
+  for (int cq = 0; cq < ncq; ++cq) {
+    const int c0 = cin_base + cq * 4;
+    const char* src = reinterpret_cast<const char*>(c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
+                                                                  : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw);
+    // ---- all global loads of this thread, back to back ----
+    uint4 raw[WNIT][4];
+#pragma unroll
+    for (int it = 0; it < WNIT; ++it)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * dhw_b + i_off[it]);
+    if (cq > 0) __syncthreads();                      // every wave is done reading the previous quad's image
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PRE == 1) {
+      if (fin) {
+        // fused InstanceNorm finalisation (xh_conv_ptrs.fin_red): as in conv3_q4_kernel
+        if (cq == 0) {
+          const float* gam = a.p.fin_gamma;
+          const float* bet = a.p.fin_beta;
+          if (tid < a.Cin_g) {
+            float m_, r_, sc_, sh_;
+            in_finalize(fs1, fs2, a.fin_inv, sc_, sh_, m_, r_);
+            if (gam) { const float g_ = gam[cin_base + tid]; sc_ *= g_; sh_ = fmaf(sh_, g_, bet[cin_base + tid]); }
+            s_fin[tid] = sc_; s_fin[Q4_MAXC + tid] = sh_;
+          }
+          if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+            for (int i = tid; i < a.d.N * a.d.Cin; i += 512) {
+              float sc_, sh_, m_, r_;
+              in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], a.fin_inv, sc_, sh_, m_, r_);
+              if (gam) {                                // N == 1: i is the channel
+                sc_ *= gam[i]; sh_ = fmaf(sh_, gam[i], bet[i]);
+                if (a.p.fin_rm && a.p.fin_rv && a.p.fin_steps > 0) {
+                  const double M = 1.0 / a.fin_inv, mean = a.p.fin_red[2 * i] * a.fin_inv;
+                  double var = a.p.fin_red[2 * i + 1] * a.fin_inv - mean * mean;
+                  if (var < 0) var = 0;
+                  const double keep = pow(0.9, (double)a.p.fin_steps), unb = var * M / (M > 1 ? M - 1 : 1);
+                  a.p.fin_rm[i] = (float)(keep * a.p.fin_rm[i] + (1 - keep) * mean);
+                  a.p.fin_rv[i] = (float)(keep * a.p.fin_rv[i] + (1 - keep) * unb);
+                }
+              }
+              const_cast<float*>(a.p.pre_sc)[i] = sc_; const_cast<float*>(a.p.pre_sh)[i] = sh_;
+              a.p.fin_mean[i] = m_; a.p.fin_rstd[i] = r_;
+            }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { sc[cc] = s_fin[cq * 4 + cc]; sh[cc] = s_fin[Q4_MAXC + cq * 4 + cc]; }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { sc[cc] = a.p.pre_sc[n * a.d.Cin + c0 + cc]; sh[cc] = a.p.pre_sh[n * a.d.Cin + c0 + cc]; }
+      }
+    }
+    // ---- transform + channels-last LDS image ----
+#pragma unroll
+    for (int it = 0; it < WNIT; ++it) {
+      if (!i_do[it]) continue;
+      uint4 outv[4];                                  // slot k = voxels 2k, 2k+1 x 4 channels
+      if (PRE) {
+        const float lv = i_live[it] ? 1.f : 0.f;
+        f32x2_t v[4][4];                              // [channel][voxel pair]
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float s1 = sc[cc] * lv, s2 = sh[cc] * lv;
+          const unsigned u[4] = {raw[it][cc].x, raw[it][cc].y, raw[it][cc].z, raw[it][cc].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[cc][k] = q4w_xf<FMT>(u[k], s1, s2, pslope);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          outv[k].x = cvt2_pack<FMT>(v[0][k].x, v[1][k].x);
+          outv[k].y = cvt2_pack<FMT>(v[2][k].x, v[3][k].x);
+          outv[k].z = cvt2_pack<FMT>(v[0][k].y, v[1][k].y);
+          outv[k].w = cvt2_pack<FMT>(v[2][k].y, v[3][k].y);
+        }
+      } else {
+        const unsigned se = i_live[it] ? 0x05040100u : 0x0c0c0c0cu, so = i_live[it] ? 0x07060302u : 0x0c0c0c0cu;
+        const unsigned u[4][4] = {{raw[it][0].x, raw[it][0].y, raw[it][0].z, raw[it][0].w},
+                                  {raw[it][1].x, raw[it][1].y, raw[it][1].z, raw[it][1].w},
+                                  {raw[it][2].x, raw[it][2].y, raw[it][2].z, raw[it][2].w},
+                                  {raw[it][3].x, raw[it][3].y, raw[it][3].z, raw[it][3].w}};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          outv[k].x = __builtin_amdgcn_perm(u[1][k], u[0][k], se);
+          outv[k].y = __builtin_amdgcn_perm(u[3][k], u[2][k], se);
+          outv[k].z = __builtin_amdgcn_perm(u[1][k], u[0][k], so);
+          outv[k].w = __builtin_amdgcn_perm(u[3][k], u[2][k], so);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<uint4*>(smem + i_lds[it] + q4w_slot(i_s0[it] + k) * 16) = outv[k];
+    }
+    // A (weight) fragments of this (output quad, input quad): issued here so that they travel while the workgroup gathers
+    frag8 wfrag[9];
+    {
+      const frag8* wpk = reinterpret_cast<const frag8*>(a.p.ws) + ((long long)oq * a.ci4 + cq) * 9 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) wfrag[i] = wpk[i * 64];
+    }
+    __syncthreads();
+    // ---- matrix phase: the wave's output row, both halves, walking the 6 staged planes once ----
+#pragma unroll
+    for (int pz = 0; pz < WID; ++pz) {
+      frag8 bf[3][2];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          bf[kh][h] = *reinterpret_cast<const frag8*>(smem + pz * WPLANE + (wv + kh) * WPITCH + b_off[h]);
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int dz = pz - kd;
+        if (dz < 0 || dz >= WTD) continue;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          acc[dz][0] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh][0], acc[dz][0]);
+          acc[dz][1] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh][1], acc[dz][1]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  f32x2_t ps = {0.f, 0.f}, pq = {0.f, 0.f};
+  const f32x2_t bias2 = {bias, bias}, esc2 = {esc, esc}, esh2 = {esh, esh};
+  const f32x2_t esl2 = {a.d.e_slope, a.d.e_slope};
+  uint2 eraw[WTD][2];
+  if (EPI == 1) {
+#pragma unroll
+    for (int dz = 0; dz < WTD; ++dz)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        eraw[dz][h] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ers, (int)(lane_b + h * HALF_B),
+                                                                                      (int)((unsigned)min(dz, ndz - 1) * spd_b), 0));
+  }
+#pragma unroll
+  for (int dz = 0; dz < WTD; ++dz) {
+    const bool live = dz < ndz;                       // uniform
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x2_t v[2] = {f32x2_t{acc[dz][h][0], acc[dz][h][1]} + bias2, f32x2_t{acc[dz][h][2], acc[dz][h][3]} + bias2};
+      uint2 pk;
+      if (EPI == 1) {
+        const f32x2_t e[2] = {cvt2_in<FMT>(eraw[dz][h].x), cvt2_in<FMT>(eraw[dz][h].y)};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x2_t z = e[q] * esc2 + esh2, vs = v[q] * esl2;
+          v[q] = f32x2_t{z.x > 0.f ? v[q].x : vs.x, z.y > 0.f ? v[q].y : vs.y};
+        }
+        pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
+        if (live) {
+          const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);         // the values as stored
+          ps += r0 + r1;
+          pq += r0 * e[0] + r1 * e[1];
+        }
+      } else {
+        pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
+        if (EPI == 2 && live) {
+          const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);
+          ps += r0 + r1;
+          pq += r0 * r0 + r1 * r1;
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), pk), yrs,
+                                            (int)(live ? lane_bo + (row_ok ? h * HALF_B : 0u) : Q4_OOB), (int)((unsigned)dz * spd_b), 0);
+    }
+  }
+  if (EPI) {
+    // lanes of one channel: the 16 lanes nn = 0..15 of a lane group g4 = one DPP row
+    const float t0 = row16_sum(row_ok ? ps.x + ps.y : 0.f), t1 = row16_sum(row_ok ? pq.x + pq.y : 0.f);
+    if (nn == 0) { s_red[wv * 8 + g4 * 2] = (double)t0; s_red[wv * 8 + g4 * 2 + 1] = (double)t1; }
+    __syncthreads();
+    if (tid < 8) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tot += s_red[w * 8 + tid];
+      s_red[64 + tid] = tot;
+    }
+    double* s_tot = s_red + 64;
+    if (a.fan && !fan_in<8>(a.fan + ((long long)n * gridDim.y + oq) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x, s_tot,
+                            reinterpret_cast<int*>(s_tot + 8)))
+      return;
+    if (!a.fan) __syncthreads();
+    if (tid < 8) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], s_tot[tid]);
+  }
+}
+
+// XH_OK if launched, 1 if this launch stays with conv3_q4_kernel.  `a` is a filled plan (q4_plan + pointers).
+int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a) {
+  if (!g_q4_wide || a.d.W != WW || a.d.dtype == XH_F32 || a.act_slope != 1.f || a.d.pre == 2) return 1;
+  if (a.d.D < 4 || a.d.H < 8) return 1;
+  const int tilesD = (a.d.Do + WTD - 1) / WTD, tilesH = (a.d.Ho + WTH - 1) / WTH;
+  dim3 grid(tilesD * tilesH, a.d.Cout / 4, a.d.N);
+  a.fan = a.d.epi ? xh_fan_block(a.p.fan, a.p.fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
+  const size_t shm = WTILE + 80 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
+  const int f = a.d.dtype == XH_F16 ? 1 : 0;
+  const bool multi = a.ci4 > 1;
+  xh_note_kernel("conv3_q4w_kernel<%d, %d, %d, %s>", f, a.d.pre, a.d.epi, multi ? "true" : "false");
+#define QWL(F, P, E, M) hipLaunchKernelGGL((conv3_q4w_kernel<F, P, E, M>), grid, dim3(512), shm, st, a)
+#define QWM(F, P, E)               \
+  do {                             \
+    if (multi) QWL(F, P, E, true); \
+    else QWL(F, P, E, false);      \
+  } while (0)
+#define QWE(F, P)                        \
+  do {                                   \
+    if (a.d.epi == 0) QWM(F, P, 0);      \
+    else if (a.d.epi == 1) QWM(F, P, 1); \
+    else QWM(F, P, 2);                   \
+  } while (0)
+  if (f) { if (a.d.pre) QWE(1, 1); else QWE(1, 0); }
+  else { if (a.d.pre) QWE(0, 1); else QWE(0, 0); }
+#undef QWE
+#undef QWM
+#undef QWL
+  return xh_launch_status();
+}
