@@ -57,8 +57,9 @@ int xh_abi_version(void);
  *         with fp16 storage.
  * key 19: persistent, tile-pipelined variant of the quad-channel k3 kernel (csrc/conv3d_q4p.hip): 0 = never, 1 = forward launches with
  *         several input quads per tile and >= 2048 stages (default: where it was measured to win), 2 = every 8-plane launch.
- * key 20: 1 (default) = quad-channel k3 convs on rows of 128 voxels take the full-row tiles of csrc/conv3d_q4w.hip; 0 = the 32-wide
- *         tiles of csrc/conv3d_q4.hip (A/B switch; the outputs are bit-identical).
+ * key 20: mask of the row widths on which quad-channel k3 convs take the full-row tiles of csrc/conv3d_q4w.hip: bit 1 = 128 voxels,
+ *         bit 0 = 64 voxels (default 3); 0 = always the 32-wide tiles of csrc/conv3d_q4.hip (A/B switch; the outputs are
+ *         bit-identical).
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
  *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo

@@ -701,13 +701,16 @@ Q4W_CASES = [
     dict(cin=8, cout=8, groups=1, sp=(16, 16, 128), n=1),             # two input quads, two output quads
     dict(cin=4, cout=4, groups=1, sp=(32, 40, 128), n=1),
     dict(cin=20, cout=40, groups=5, sp=(6, 8, 128), n=1),             # five groups, 4 -> 8 channels each
+    dict(cin=20, cout=20, groups=5, sp=(16, 24, 64), n=1),            # rows of 64 voxels: one 64-voxel N tile per row
+    dict(cin=24, cout=8, groups=1, sp=(10, 9, 64), n=2, split=8),     # 64-wide, six input quads, ragged tiles, 2 samples
+    dict(cin=8, cout=24, groups=1, sp=(8, 16, 64), n=1),
 ]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", Q4W_CASES)
 def test_full_row_q4_kernel_equals_the_32_wide_tile_kernel(cfg, dtype):
-    """conv3_q4w_kernel (rows of 128 voxels: 4 x 8 x 128 tiles of 8 waves, no W halo, full-line loads; default) against
+    """conv3_q4w_kernel (rows of 128 / 64 voxels: 4 x 8 x W tiles of 8 waves, no W halo, full-line loads; default) against
     conv3_q4_kernel (xh_set_option(20, 0)) on the same operands: forward with the producer's norm + LeakyReLU from explicit
     scale / shift and from raw sums (fused finalisation), output moments; data gradient with the leaky'-masked norm-backward sums;
     plain.  Same products in the same order per output value: the outputs must agree BIT FOR BIT; the statistics differ in the
@@ -745,9 +748,9 @@ def test_full_row_q4_kernel_equals_the_32_wide_tile_kernel(cfg, dtype):
             torch.cuda.synchronize()
             return out
         finally:
-            lib.xh_set_option(20, 1)
+            lib.xh_set_option(20, 3)
             lib.xh_set_option(19, 1)
-    a_, b_ = run(0), run(1)
+    a_, b_ = run(0), run(3)
     assert "conv3_q4_kernel" in a_["k_fwd"] and "conv3_q4w_kernel" in b_["k_fwd"] and "conv3_q4w_kernel" in b_["k_dgrad"], (a_["k_fwd"], b_["k_fwd"])
     for k_ in ("fwd", "fin", "plain", "dgrad", "fin_sc", "fin_sh", "fin_m", "fin_r"):
         assert torch.equal(a_[k_], b_[k_]), (k_, (a_[k_].float() - b_[k_].float()).abs().max().item())

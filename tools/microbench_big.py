@@ -17,7 +17,8 @@ for kv in filter(None, os.environ.get("XH_OPTS", "").split(",")):      # e.g. XH
     L.load().xh_set_option(int(k_), int(v_))
 BASE_ABL = int(os.environ.get("XH_ABL", "0"))
 ROT = int(os.environ.get("XH_ROT", "1"))      # buffer sets walked round-robin: > 1.3 sets of 201 MB no longer sit in the 256 MB last-level cache
-for (cin, cout, g) in [(4, 4, 1), (16, 16, 4), (12, 4, 1), (8, 8, 1)][:int(os.environ.get("XH_NSHAPE", "4"))]:
+SHAPES = [(4, 4, 1), (16, 16, 4), (12, 4, 1), (8, 8, 1)] if S >= 128 else [(8, 8, 1), (20, 20, 5), (20, 40, 5), (24, 8, 1), (16, 16, 2)]
+for (cin, cout, g) in SHAPES[:int(os.environ.get("XH_NSHAPE", "5"))]:
     ws = [torch.randn(cout // g, cin // g, 3, 3, 3, device="cuda") * 0.1 for _ in range(g)]
     bs = [torch.randn(cout // g, device="cuda") for _ in range(g)]
     sc = torch.rand(1, cin, device="cuda") + 0.5; sh = torch.randn(1, cin, device="cuda")

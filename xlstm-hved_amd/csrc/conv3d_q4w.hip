@@ -21,19 +21,23 @@
 // 2^22 elements, i.e. not on 128-wide rows); 63 KB of LDS, two workgroups per CU.
 #include "conv_q4.h"
 
-int g_q4_wide = 1;                // xh_set_option(20, n): 0 = never, 1 = rows of 128 voxels take conv3_q4w_kernel
+int g_q4_wide = 3;                // xh_set_option(20, mask): bit 1 = rows of 128 voxels, bit 0 = rows of 64 voxels take conv3_q4w_kernel
 
 namespace {
-constexpr int WW = 128;                      // row width the kernel is built for
 constexpr int WTD = 4, WTH = 8;              // output planes / rows per workgroup
 constexpr int WID = WTD + 2, WIH = WTH + 2;
-constexpr int WSLOTS = WW / 2 + 2;           // 66
-constexpr int WPITCH = WSLOTS * 16;          // 1056 bytes per staged row
-constexpr int WPLANE = WIH * WPITCH;
-constexpr int WTILE = WID * WPLANE;          // 63 360 bytes
-constexpr int WNROWS = WID * WIH;            // 60
-constexpr int WNITEM = WNROWS * 16;          // (row, 8-voxel piece)
-constexpr int WNIT = (WNITEM + 511) / 512;   // 2
+constexpr int WNROWS = WID * WIH;            // 60 staged rows
+// NH = 64-voxel halves per row: 2 (rows of 128 voxels) or 1 (rows of 64)
+template <int NH> struct QW {
+  static constexpr int WW = 64 * NH;                     // row width the instance is built for
+  static constexpr int SLOTS = WW / 2 + 2;               // 66 | 34
+  static constexpr int PITCH = SLOTS * 16;               // 1056 | 544 bytes per staged row
+  static constexpr int PLANE = WIH * PITCH;
+  static constexpr int TILE = WID * PLANE;               // 63 360 | 32 640 bytes
+  static constexpr int PR = 8 * NH;                      // 8-voxel pieces per row
+  static constexpr int NITEM = WNROWS * PR;              // (row, piece)
+  static constexpr int NIT = (NITEM + 511) / 512;        // 2 | 1
+};
 }
 // physical 16-byte slot of logical slot s inside a row
 __device__ __forceinline__ int q4w_slot(int s) { return s ^ ((s >> 4) & 1); }
@@ -43,9 +47,11 @@ template <int FMT> __device__ __forceinline__ f32x2_t q4w_xf(unsigned u, float s
   return max2(v, v * f32x2_t{slope, slope});
 }
 
-template <int FMT, int PRE, int EPI, bool MULTI>
+template <int FMT, int PRE, int EPI, bool MULTI, int NH>
 __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   typedef h16<FMT> ST;
+  typedef QW<NH> Q;
+  constexpr int WW = Q::WW, WSLOTS = Q::SLOTS, WPITCH = Q::PITCH, WPLANE = Q::PLANE, WTILE = Q::TILE, WNITEM = Q::NITEM, WNIT = Q::NIT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem + WTILE);             // [8 waves][8], then [8] totals + the fan-in flag
   float* s_fin = reinterpret_cast<float*>(smem + WTILE + 80 * sizeof(double));   // [2][Q4_MAXC]: in-kernel InstanceNorm scale / shift
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   for (int it = 0; it < WNIT; ++it) {
     const int item = tid + it * 512;
     i_do[it] = item < WNITEM;
-    const int j = item & 15, row = min(item >> 4, WNROWS - 1);
+    const int j = item & (Q::PR - 1), row = min(item / Q::PR, WNROWS - 1);
     const int dz = row / WIH, hy = row - dz * WIH;
     const int gd = od0 - 1 + dz, gh = oh0 - 1 + hy;
     i_live[it] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
@@ -93,7 +99,9 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
     i_s0[it] = 1 + 4 * j;                              // first logical slot of the piece
   }
   // ---- B (data) fragments: lane (quad nn, k-group g4) of half h reads logical slot 32 h + 2 nn + g4 of input row wv + kh ----
-  const int b_off[2] = {q4w_slot(2 * nn + g4) * 16, q4w_slot(32 + 2 * nn + g4) * 16};
+  int b_off[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) b_off[h] = q4w_slot(32 * h + 2 * nn + g4) * 16;
   // ---- epilogue lane role: lane (quad, channel) owns 4 consecutive voxels of output row oh0 + wv in each half ----
   const int oh = oh0 + wv;
   const bool row_ok = oh < Ho;
@@ -119,9 +127,11 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   }
   yrs = q4_window(reinterpret_cast<char*>((ST*)a.p.y + n * a.d.y_bs + (long long)co0 * odhw) + (long long)od0 * spd_b);
 
-  f32x4 acc[WTD][2];
+  f32x4 acc[WTD][NH];
 #pragma unroll
-  for (int i = 0; i < WTD; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < WTD; ++i)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) acc[i][h] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ncq = MULTI ? a.ci4 : 1;
   const float pslope = a.d.pre_slope;
   const bool fin = PRE == 1 && a.p.fin_red != nullptr;
@@ -229,21 +239,20 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
     // ---- matrix phase: the wave's output row, both halves, walking the 6 staged planes once ----
 #pragma unroll
     for (int pz = 0; pz < WID; ++pz) {
-      frag8 bf[3][2];
+      frag8 bf[3][NH];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
           bf[kh][h] = *reinterpret_cast<const frag8*>(smem + pz * WPLANE + (wv + kh) * WPITCH + b_off[h]);
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd) {
         const int dz = pz - kd;
         if (dz < 0 || dz >= WTD) continue;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          acc[dz][0] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh][0], acc[dz][0]);
-          acc[dz][1] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh][1], acc[dz][1]);
-        }
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int h = 0; h < NH; ++h) acc[dz][h] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh][h], acc[dz][h]);
       }
     }
   }
@@ -252,12 +261,12 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   f32x2_t ps = {0.f, 0.f}, pq = {0.f, 0.f};
   const f32x2_t bias2 = {bias, bias}, esc2 = {esc, esc}, esh2 = {esh, esh};
   const f32x2_t esl2 = {a.d.e_slope, a.d.e_slope};
-  uint2 eraw[WTD][2];
+  uint2 eraw[WTD][NH];
   if (EPI == 1) {
 #pragma unroll
     for (int dz = 0; dz < WTD; ++dz)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < NH; ++h)
         eraw[dz][h] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ers, (int)(lane_b + h * HALF_B),
                                                                                       (int)((unsigned)min(dz, ndz - 1) * spd_b), 0));
   }
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   for (int dz = 0; dz < WTD; ++dz) {
     const bool live = dz < ndz;                       // uniform
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       f32x2_t v[2] = {f32x2_t{acc[dz][h][0], acc[dz][h][1]} + bias2, f32x2_t{acc[dz][h][2], acc[dz][h][3]} + bias2};
       uint2 pk;
       if (EPI == 1) {
@@ -315,20 +324,34 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
 
 // XH_OK if launched, 1 if this launch stays with conv3_q4_kernel.  `a` is a filled plan (q4_plan + pointers).
 int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a) {
-  if (!g_q4_wide || a.d.W != WW || a.d.dtype == XH_F32 || a.act_slope != 1.f || a.d.pre == 2) return 1;
+  const int nh = a.d.W == 128 ? 2 : a.d.W == 64 ? 1 : 0;
+  if (!nh || !(g_q4_wide & nh) || a.d.dtype == XH_F32 || a.act_slope != 1.f || a.d.pre == 2) return 1;
   if (a.d.D < 4 || a.d.H < 8) return 1;
   const int tilesD = (a.d.Do + WTD - 1) / WTD, tilesH = (a.d.Ho + WTH - 1) / WTH;
   dim3 grid(tilesD * tilesH, a.d.Cout / 4, a.d.N);
+  const long long nwg = (long long)grid.x * grid.y * grid.z;
+  // 512 workgroups are resident at once.  Rows of 64 voxels: launches between one and three rounds keep the 32-wide tiles, whose
+  // 256-thread workgroups quantise better (20 -> 20 g5 @64^3: 640 workgroups = 1.25 rounds here, 12.6 -> 13.6 us; 8 -> 8, 16 -> 16 g2,
+  // 24 -> 8 fit one round: 13.2 -> 10.1, 17.7 -> 13.6, 22.3 -> 18.6 us)
+  if (nh == 1 && nwg > 512 && nwg < 1536 && !(a.abl & 262144)) return 1;
   a.fan = a.d.epi ? xh_fan_block(a.p.fan, a.p.fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
-  const size_t shm = WTILE + 80 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
+  // The fan-in ends every workgroup with a returning-atomic round trip: worth it when the launch is ONE resident round (512
+  // workgroups: the tail of same-line atomics is exposed: 4 -> 4 @128^3 data gradient 18.3 -> 17.1 us), a loss when later rounds
+  // would have covered the plain atomics of earlier ones (16 -> 16 g4 forward + moments 48.2 -> 43.6 us).  Bit 131072: never.
+  if (nwg > 512 || (a.abl & 131072)) a.fan = nullptr;
+  const size_t shm = (nh == 2 ? QW<2>::TILE : QW<1>::TILE) + 80 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
   const int f = a.d.dtype == XH_F16 ? 1 : 0;
   const bool multi = a.ci4 > 1;
-  xh_note_kernel("conv3_q4w_kernel<%d, %d, %d, %s>", f, a.d.pre, a.d.epi, multi ? "true" : "false");
-#define QWL(F, P, E, M) hipLaunchKernelGGL((conv3_q4w_kernel<F, P, E, M>), grid, dim3(512), shm, st, a)
+  xh_note_kernel("conv3_q4w_kernel<%d, %d, %d, %s, %d>", f, a.d.pre, a.d.epi, multi ? "true" : "false", nh);
+#define QWN(F, P, E, M)                                                                                    \
+  do {                                                                                                     \
+    if (nh == 2) hipLaunchKernelGGL((conv3_q4w_kernel<F, P, E, M, 2>), grid, dim3(512), shm, st, a);       \
+    else hipLaunchKernelGGL((conv3_q4w_kernel<F, P, E, M, 1>), grid, dim3(512), shm, st, a);               \
+  } while (0)
 #define QWM(F, P, E)               \
   do {                             \
-    if (multi) QWL(F, P, E, true); \
-    else QWL(F, P, E, false);      \
+    if (multi) QWN(F, P, E, true); \
+    else QWN(F, P, E, false);      \
   } while (0)
 #define QWE(F, P)                        \
   do {                                   \
@@ -340,6 +363,6 @@ int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a) {
   else { if (a.d.pre) QWE(0, 1); else QWE(0, 0); }
 #undef QWE
 #undef QWM
-#undef QWL
+#undef QWN
   return xh_launch_status();
 }
