@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--wgrad-batch", type=int, default=12, help="weight-gradient calls forked to the side stream per batch")
     ap.add_argument("--wgrad-flush-streams", type=int, default=1,
                     help="HIP streams the deferred weight-gradient flush deals its independent problems to (ops.set_wgrad_flush_streams)")
+    ap.add_argument("--wgrad-early-flush", action="store_true",
+                    help="A/B: launch the decoder's deferred weight gradients on a side stream when backward reaches the deep levels "
+                         "(ops.set_wgrad_early_flush; measured slower)")
     ap.add_argument("--xh-option", action="append", default=[], metavar="KEY=VALUE",
                     help="xh_set_option(KEY, VALUE) before the run (A/B tests of launch plans; include/xlstm_hved.h lists the keys)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the N=1 run
@@ -225,6 +228,7 @@ def main():
     for kv in args.xh_option:
         k_, v_ = kv.split("=")
         X._lib.check(X._lib.load().xh_set_option(int(k_), int(v_)), "xh_set_option")
+    ops.set_wgrad_early_flush(args.wgrad_early_flush)
     ops.set_wgrad_flush_streams(args.wgrad_flush_streams)
     ops.set_wgrad_overlap(args.wgrad_overlap, args.wgrad_batch)
     ops.set_wgrad_defer(not args.no_wgrad_defer and not args.wgrad_overlap)   # weight gradients batched at the end of backward           # weight gradients on a second HIP stream, joined once per step

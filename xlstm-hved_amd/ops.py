@@ -518,7 +518,8 @@ def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None)
 # capture the fork/join becomes a parallel branch of the graph.  Only calls whose targets are existing .grad buffers
 # (functional._targets "direct" accumulation, e.g. parallel.FlatGrads) may overlap: a freshly allocated gradient that
 # autograd consumes on the compute stream must be complete when backward() returns it.
-_WG = {"on": False, "streams": {}, "keep": [], "forked": set(), "pending": [], "batch": 12, "defer": False, "deferred": []}
+_WG = {"on": False, "streams": {}, "keep": [], "forked": set(), "pending": [], "batch": 12, "defer": False, "deferred": [],
+       "early": False, "early_done": False, "maxvol": 0}
 
 
 def set_wgrad_overlap(enabled, batch=None):
@@ -564,6 +565,7 @@ def join_wgrad_stream():
         torch.cuda.current_stream(dev).wait_stream(_WG["streams"][dev])
     _WG["forked"].clear()
     _WG["keep"].clear()
+    _WG["early_done"], _WG["maxvol"] = False, 0
 
 
 def _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre):
@@ -594,7 +596,11 @@ def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=
     long-lived gradient buffers, so the call may be deferred and batched (set_wgrad_defer) or go to the weight-gradient
     stream (set_wgrad_overlap)."""
     if side and xa.is_cuda and _WG["defer"]:
+        vol = dy.shape[2] * dy.shape[3] * dy.shape[4]
+        if _WG["early"] and not _WG["early_done"] and _WG["deferred"] and vol * 64 <= _WG["maxvol"]:
+            _flush_deferred_early(xa.device)
         _WG["deferred"].append(_wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre))
+        _WG["maxvol"] = max(_WG["maxvol"], vol)
         return
     if side and _WG["on"] and xa.is_cuda:
         _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre)))
@@ -620,6 +626,7 @@ def drop_deferred_wgrads():
     """Forgets the queued weight-gradient calls without launching them (error paths: a backward that raised, a failed capture)."""
     _WG["deferred"] = []
     _WG["pending"] = []
+    _WG["early_done"], _WG["maxvol"] = False, 0
 
 
 def _batch_call(calls):
@@ -633,6 +640,32 @@ def _batch_call(calls):
             dws[i][j] = c[2][j]
             dbs[i][j] = c[3][j]
     L.check(L.load().xh_conv3d_wgrad_batch(_stream(), n, descs, ptrs, dws, dbs), "xh_conv3d_wgrad_batch")
+
+
+def set_wgrad_early_flush(enabled):
+    """Deferred weight gradients (set_wgrad_defer): when the backward pass first descends two resolution levels below the largest
+    volume queued so far, launch what is queued -- the decoder's full- and half-resolution problems, large launches -- on the side
+    stream instead of keeping it for the end.  They then run beside the ~80 launches of the deep levels (32^3 and below, the mLSTM
+    block, PoE: grids of 4 - 512 workgroups that leave most of the chip idle); the rest of the queue is launched at the end of the
+    pass as before.  One fork, one join (capture-safe).  Default OFF: MEASURED SLOWER on MI355X (hipGraph replay of the 128^3 step:
+    3.86 ms without, 4.05 ms with) -- the weight-gradient kernels are persistent workgroups sized to hold every CU for their whole
+    run, so the deep levels' short launches, which ARE the critical path there, queue behind them for wave slots and LDS.  Kept as an
+    A/B knob (bench.py --wgrad-early-flush)."""
+    _WG["early"] = bool(enabled)
+
+
+def _flush_deferred_early(dev):
+    calls = _WG["deferred"]
+    _WG["deferred"] = []
+    _WG["early_done"] = True
+    st = _WG["streams"].get(dev)
+    if st is None:
+        st = _WG["streams"][dev] = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))          # every dY / input of the queue has been issued by now
+    _WG["forked"].add(dev)
+    with torch.cuda.stream(st):
+        _batch_call(calls)
+    _WG["keep"].append(calls)                                # alive until the join: the allocator must not recycle them
 
 
 def set_wgrad_flush_streams(n):
