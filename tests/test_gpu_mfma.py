@@ -129,6 +129,7 @@ def test_quad_channel_kernel_planes_per_workgroup(dtype):
     # workgroups of this launch with 8 / 4 planes each: 2 x 2 tiles x 3 output quads x 2 samples x (2 | 3) = 48 | 72
     for name, thr in (("8", 0), ("4", 60), ("2", 512)):
         lib.xh_set_option(17, thr)
+        lib.xh_set_option(20, 0)                      # the 32-wide tile kernel under test (64-wide rows default to conv3_q4w_kernel)
         try:
             red = torch.zeros(n, cout, 2, dtype=torch.float64, device=DEV)
             y = X.ops.conv3d(x, None, w, b, k=3, cout=cout, pre=(sc, sh, 0.01), epi=2, red=red)
@@ -138,6 +139,7 @@ def test_quad_channel_kernel_planes_per_workgroup(dtype):
             kb = X.ops.last_conv_kernel()
         finally:
             lib.xh_set_option(17, 512)
+            lib.xh_set_option(20, 3)
         assert kf.endswith(f"true, {name}>") and kb.endswith(f"true, {name}>"), (name, kf, kb)
         outs[name] = (y.float(), red.clone(), dx.float(), red2.clone())
     for name in ("4", "2"):
@@ -161,11 +163,11 @@ def test_depthwise_conv_through_quad_channel_kernel(transposed, dtype):
     bs = None if transposed else [torch.randn(c, device=DEV)]
     call = lambda: X.ops.conv3d(x, None, ws, bs, k=3, cout=c, groups=c, transposed=transposed).float()
     y = call()
-    assert "conv3_q4_kernel" in X.ops.last_conv_kernel()
+    assert "conv3_q4w_kernel" in X.ops.last_conv_kernel()          # (rows of 64 voxels: the full-row variant of the quad-channel kernel)
     lib.xh_set_option(2, 128)
     try:
         y_vec = call()
-        assert "conv3_q4_kernel" not in X.ops.last_conv_kernel()
+        assert "conv3_q4" not in X.ops.last_conv_kernel()
     finally:
         lib.xh_set_option(2, 0)
     wf = torch.cat(ws, 0)
@@ -355,7 +357,7 @@ def _full_size_128(cfg, dtype, path):
     y, red = X.functional.in_lrelu_conv(xa, xb, wg, bg, 1, g, out_stats=True)
     k_fwd = X.ops.last_conv_kernel()
     if path == "q4":
-        big_ok = lambda k: "conv3_q4_kernel" in k or "conv3_q4p_kernel" in k     # (multi-quad forward launches: the persistent variant)
+        big_ok = lambda k: "conv3_q4w_kernel" in k            # rows of 128 voxels: the full-row variant of the quad-channel kernel
     else:
         big_ok = lambda k: "conv3_mfma_kernel" in k and ", 256, 32, 8, 2>" in k
     assert big_ok(k_fwd), k_fwd
@@ -664,6 +666,7 @@ def test_persistent_pipelined_q4_kernel_equals_the_per_tile_kernel(cfg, dtype, o
     def run(mode):
         X._lib.check(lib.xh_set_option(19, mode), "xh_set_option")
         X._lib.check(lib.xh_set_option(17, 0), "xh_set_option")          # 8 output planes per tile whatever the launch size
+        X._lib.check(lib.xh_set_option(20, 0), "xh_set_option")          # (rows of 64 / 128 voxels would take the full-row kernel)
         X._lib.check(lib.xh_set_option(1, 32768 if (occ3 and mode) else 0), "xh_set_option")
         try:
             out = {}
@@ -684,6 +687,7 @@ def test_persistent_pipelined_q4_kernel_equals_the_per_tile_kernel(cfg, dtype, o
         finally:
             lib.xh_set_option(19, 1)
             lib.xh_set_option(17, 512)
+            lib.xh_set_option(20, 3)
             lib.xh_set_option(1, 0)
     a_, b_ = run(0), run(2)
     assert "conv3_q4_kernel" in a_["k_fwd"] and "conv3_q4p_kernel" in b_["k_fwd"] and "conv3_q4p_kernel" in b_["k_dgrad"], (a_["k_fwd"], b_["k_fwd"])
@@ -757,3 +761,40 @@ def test_full_row_q4_kernel_equals_the_32_wide_tile_kernel(cfg, dtype):
     for k_ in ("fwd_red", "fin_red", "dgrad_red"):
         d_ = (a_[k_] - b_[k_]).abs().max().item() / max(a_[k_].abs().max().item(), 1e-30)
         assert d_ < 1e-6, (k_, d_)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+@pytest.mark.parametrize("cfg", [dict(n=2, cin=4, cout=4, g=1, sp=(9, 11, 64)), dict(n=1, cin=16, cout=16, g=4, sp=(8, 9, 128)),
+                                 dict(n=1, cin=12, cout=4, g=1, sp=(10, 6, 128)), dict(n=1, cin=24, cout=8, g=1, sp=(6, 7, 64)),
+                                 dict(n=1, cin=20, cout=40, g=5, sp=(5, 8, 64))],
+                         ids=["4to4_w64", "16to16g4_w128", "12to4_w128", "24to8_w64_chunks2", "20to40g5_w64"])
+def test_wgrad_quad_channel_wide_tiles_vs_narrow_tiles_and_stock(cfg, dtype):
+    """Rows of 64 / 128 voxels: conv3_wgrad_q4_multi_kernel walks 2 x 64 tiles (full 128-byte lines; WgQ4.wide, the default there)
+    instead of 4 x 32 (xh_set_option(1, 524288)).  Both against torch.nn.grad on the same 16-bit inputs and against each other (the
+    same products, summed in another order: fp32 round-off); odd H, ragged depth segments, the norm + LeakyReLU input transform."""
+    lib = X._lib.load()
+    torch.manual_seed(37)
+    n, cin, cout, g = cfg["n"], cfg["cin"], cfg["cout"], cfg["g"]
+    x = torch.randn((n, cin) + cfg["sp"], device=DEV).to(dtype)
+    dy = torch.randn((n, cout) + cfg["sp"], device=DEV).to(dtype)
+    nw = g if g <= 4 else 1
+    pre = (torch.rand(n, cin, device=DEV) + 0.5, torch.randn(n, cin, device=DEV), 0.01)
+    res = {}
+    for name, abl in (("wide", 0), ("narrow", 524288)):
+        lib.xh_set_option(1, abl)
+        try:
+            dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
+            dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
+            X.ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=pre)
+            assert "conv3_wgrad_q4_multi_kernel" in X.ops.last_conv_kernel()
+            torch.cuda.synchronize()
+            res[name] = (torch.cat(dws, 0).cpu(), torch.cat(dbs, 0).cpu())
+        finally:
+            lib.xh_set_option(1, 0)
+    xf = torch.nn.functional.leaky_relu(x.float() * pre[0][:, :, None, None, None] + pre[1][:, :, None, None, None], 0.01).to(dtype).float()
+    ref = torch.nn.grad.conv3d_weight(xf, (cout, cin // g, 3, 3, 3), dy.float(), padding=1, groups=g).cpu()
+    tol = 2e-3 if dtype == torch.bfloat16 else 5e-4
+    for name in res:
+        assert l2_err(res[name][0], ref) < tol, (name, l2_err(res[name][0], ref))
+        assert l2_err(res[name][1], dy.float().sum((0, 2, 3, 4)).cpu()) < 1e-4, name
+    assert l2_err(res["wide"][0], res["narrow"][0]) < 2e-6 and l2_err(res["wide"][1], res["narrow"][1]) < 2e-6

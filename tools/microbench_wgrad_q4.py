@@ -7,15 +7,19 @@ import xlstm_hved_amd as X
 from tools.microbench_conv import bench
 ops = X.ops; L = X._lib
 S = int(os.environ.get("XH_S", "128"))
-for (cin, cout, g) in [(4, 4, 1), (16, 16, 4), (12, 4, 1)]:
-    x = torch.randn(1, cin, S, S, S, device="cuda").bfloat16()
-    dy = torch.randn(1, cout, S, S, S, device="cuda").bfloat16()
+ROT = int(os.environ.get("XH_ROT", "1"))      # operand sets walked round-robin (> 1: from HBM instead of the last-level cache)
+for (cin, cout, g) in [(4, 4, 1), (16, 16, 4), (12, 4, 1), (8, 8, 1)]:
+    sets = [(torch.randn(1, cin, S, S, S, device="cuda").bfloat16(), torch.randn(1, cout, S, S, S, device="cuda").bfloat16()) for _ in range(ROT)]
+    tick = [0]
     sc = torch.rand(1, cin, device="cuda") + 0.5; sh = torch.randn(1, cin, device="cuda")
     dws = [torch.zeros(cout // g, cin // g, 3, 3, 3, device="cuda") for _ in range(g)]
     dbs = [torch.zeros(cout // g, device="cuda") for _ in range(g)]
-    call = lambda: ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=(sc, sh, 0.01))
+    def call():
+        tick[0] += 1
+        x, dy = sets[tick[0] % ROT]
+        ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=(sc, sh, 0.01))
     line = f"wgrad {cin}->{cout} g{g} @{S}^3:"
-    for m, nm in [(0, "full"), (2048, "no global atomics"), (8192, "own x rows per wave"), (8192 + 2048, "own x rows, no atomics")]:
+    for m, nm in [(0, "full (2 x 64 tiles)"), (524288, "4 x 32 tiles"), (2048, "no global atomics"), (524288 + 2048, "4 x 32, no atomics")]:
         L.load().xh_set_option(1, m)
         line += f" {nm} {bench(call):.1f} us |"
     L.load().xh_set_option(1, 0)

@@ -292,14 +292,22 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   typedef typename WqStore<FMT>::T ST;
   constexpr int CF = FMT == 2 ? 1 : FMT;               // format of the LDS images / MFMA operands
   constexpr bool F32S = FMT == 2;
-  constexpr int ROWB = 4 * CI4 * 64 + 16;             // bytes per staged x row: 4 CI4 channels x 64 B, + 16 B so that the 12 (ci, kh)
-                                                      // lanes of a B-fragment read fall on 12 different 16-byte bank groups
-  constexpr int XB = 6 * ROWB;                        // x rows of a plane
+  // Two tile shapes, chosen per problem at run time (a.wide; everything that differs is address arithmetic outside the plane loop):
+  //   narrow: 4 rows x 32 voxels -- wave w owns row w; 6 x rows of 64 bytes per channel and plane;
+  //   wide:   2 rows x 64 voxels -- wave w owns row w >> 1, 32-voxel half w & 1; 4 x rows of 128 bytes per channel and plane.  For
+  //           rows of 64 / 128 voxels: every x and dY load is then a piece of a FULL 128-byte line and a row has one pair of
+  //           edge dwords per 64 voxels instead of per 32 (the texture path, not HBM, bounds this kernel: DESIGN 3.6).  Same item
+  //           count per thread (128 CI4 x items per plane instead of 96 CI4 padded to 128 CI4), same dY windows, same MFMAs.
+  const bool wide = a.wide != 0;
+  const int CB = wide ? 144 : 64;                     // bytes per channel inside a staged x row (wide: 128 + 16, bank spreading)
+  const int ROWB = 4 * CI4 * CB + 16;                 // bytes per staged x row; + 16 B so that the 12 (ci, kh) lanes of a B-fragment
+                                                      // read fall on different 16-byte bank groups
+  constexpr int XB = (6 * (4 * CI4 * 64 + 16) > 4 * (4 * CI4 * 144 + 16)) ? 6 * (4 * CI4 * 64 + 16) : 4 * (4 * CI4 * 144 + 16);   // x rows of a plane
   constexpr int CONSTB = XB;                          // [16 B of ones][16 B of zeros]
   constexpr int DYB = XB + 32;                        // dY windows: [row 4][g 4][co 4][kw 4] x 16 B
   constexpr int PLB = DYB + 4096;                     // bytes per plane slot
-  constexpr int NITX = 96 * CI4;                      // 16-byte x items per plane
-  constexpr int NIX = (NITX + 127) / 128;             // x items per thread (a thread serves one of the two planes of a round)
+  const int NITX = (wide ? 128 : 96) * CI4;           // 16-byte x items per plane
+  constexpr int NIX = CI4;                            // x items per thread (a thread serves one of the two planes of a round)
   constexpr unsigned ONE2 = CF == 0 ? 0x3F803F80u : 0x3C003C00u;
   float* s_dw = reinterpret_cast<float*>(smem);       // after the plane loops
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -332,7 +340,8 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   int b_off[CI4];
 #pragma unroll
   for (int cq = 0; cq < CI4; ++cq)
-    b_off[cq] = khB == 3 ? CONSTB + ((cq == 0 && ci_l == 0) ? 0 : 16) : (wv + khB) * ROWB + (cq * 4 + ci_l) * 64 + g * 16;
+    b_off[cq] = khB == 3 ? CONSTB + ((cq == 0 && ci_l == 0) ? 0 : 16)
+                         : ((wide ? (wv >> 1) : wv) + khB) * ROWB + (cq * 4 + ci_l) * CB + (wide ? (wv & 1) * 64 : 0) + g * 16;
   // A fragment of lane (co = nn >> 2, kw = nn & 3): window kw of row wv (kw = 3: an unused accumulator row, reads window 1).
   // Slot of window (co, kw) inside the 256-byte block of (row, g): co * 4 + (kw ^ g) -- the 16 lanes of a g read 16 different
   // slots, and the 32 lanes of a staging write (one kw, all (g, co), both halves) cover the 64 banks once
@@ -344,9 +353,13 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   }
   // dY item of this thread: row r, output channel co, 8-byte chunk gq (4 voxels) of the 64-byte row.  Every thread has one (and
   // the same number of loads in flight: a load under a branch makes hipcc wait for nearly all of them at each commit)
-  const int y_gq = tl & 7, y_co = (tl >> 3) & 3, y_r = tl >> 5;
+  // (wide: 16 chunks per 128-byte row; the row's two halves are the "rows" 2 r, 2 r + 1 of the window image, i.e. of the waves)
+  const int y_q = wide ? (tl & 15) : (tl & 7);        // chunk inside the global row
+  const int y_gq = y_q & 7, y_co = wide ? (tl >> 4) & 3 : (tl >> 3) & 3, y_r = wide ? tl >> 6 : tl >> 5;
+  const int y_vr = wide ? 2 * y_r + (y_q >> 3) : y_r;
+  const bool y_first = y_q == 0, y_last = y_q == (wide ? 15 : 7);
   const int y_g = y_gq >> 1;
-  const int y_lds = DYB + ((y_r * 4 + y_g) * 16 + y_co * 4) * 16 + (y_gq & 1) * 8;              // + (kw ^ g) * 16
+  const int y_lds = DYB + ((y_vr * 4 + y_g) * 16 + y_co * 4) * 16 + (y_gq & 1) * 8;             // + (kw ^ g) * 16
   const int y_lds0 = y_lds + (0 ^ y_g) * 16, y_lds1 = y_lds + (1 ^ y_g) * 16, y_lds2 = y_lds + (2 ^ y_g) * 16;
 
   for (int t = t_first; t < t_end; t += t_stride) {
@@ -355,7 +368,7 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
     const int th = wk % a.tilesH; wk /= a.tilesH;
     const int ds = wk % a.dsegs;
     const int n = wk / a.dsegs;
-    const int h0 = th * 4, w0 = tw * 32;
+    const int h0 = th * (wide ? 2 : 4), w0 = tw * (wide ? 64 : 32), tww = wide ? 64 : 32;
     const int d0 = ds * a.sd, d1 = min(D, d0 + a.sd);
     // ---- x staging plan of this thread: items tl, tl + 128, ... of a plane = (row r, quad cq, channel ci, chunk gq) ----
     const ST* i_src[NIX];
@@ -367,7 +380,8 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
       const int it = tl + 128 * k;
       i_do[k] = it < NITX;
       const int itc = i_do[k] ? it : 0;
-      const int gq = itc & 3, ci = (itc >> 2) & 3, cq = (itc >> 4) % CI4, r = itc / (16 * CI4);
+      const int gq = wide ? itc & 7 : itc & 3, ci = wide ? (itc >> 3) & 3 : (itc >> 2) & 3;
+      const int cq = (wide ? itc >> 5 : itc >> 4) % CI4, r = itc / ((wide ? 32 : 16) * CI4);
       const int row = h0 - 1 + r;
       const bool rok = (unsigned)row < (unsigned)H;
       const int c = cin_base + cq * 4 + ci;
@@ -377,16 +391,16 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
       if (a.pre) { sc = a.pre_sc[n * a.Cin + c]; sh = a.pre_sh[n * a.Cin + c]; }
       i_sc[k] = rok ? sc : 0.f;
       i_sh[k] = rok ? sh : 0.f;
-      i_lds[k] = r * ROWB + (cq * 4 + ci) * 64 + gq * 16;
+      i_lds[k] = r * ROWB + (cq * 4 + ci) * CB + gq * 16;
     }
     // ---- dY staging plan ----
     const int yrow = h0 + y_r;
-    const ST* y_src = (const ST*)a.dy + n * a.dy_bs + (long long)(co0 + y_co) * dhw + (long long)min(yrow, H - 1) * W + w0 + 4 * y_gq;
-    const bool y_edge_l = y_gq == 0 && w0 > 0, y_edge_r = y_gq == 7 && w0 + 32 < W;
+    const ST* y_src = (const ST*)a.dy + n * a.dy_bs + (long long)(co0 + y_co) * dhw + (long long)min(yrow, H - 1) * W + w0 + 4 * y_q;
+    const bool y_edge_l = y_first && w0 > 0, y_edge_r = y_last && w0 + tww < W;
     const ST* y_esrc = y_src + (y_edge_l ? -2 : y_edge_r ? 4 : 0);               // the dword beyond the 64-byte row, if there is one
     const unsigned y_rowmask = yrow < H ? 0xffffffffu : 0u;
-    const unsigned y_lmask = y_gq == 0 ? (y_edge_l ? 0xffffffffu : 0u) : 0xffffffffu;   // chunk 0 at w = 0: voxel -1 does not exist
-    const unsigned y_rmask = y_gq == 7 ? (y_edge_r ? 0xffffffffu : 0u) : 0xffffffffu;   // last chunk at the row end: voxel W does not exist
+    const unsigned y_lmask = y_first ? (y_edge_l ? 0xffffffffu : 0u) : 0xffffffffu;   // chunk 0 at w = 0: voxel -1 does not exist
+    const unsigned y_rmask = y_last ? (y_edge_r ? 0xffffffffu : 0u) : 0xffffffffu;    // last chunk at the row end: voxel W does not exist
     // ---- staging: round r covers x planes d0 - 1 + 2 r (+ pp) and the dY planes one above them ----
     // a staged item: 8 voxels of x (16 bytes of 16-bit storage, 32 of fp32), 4 voxels of dY + the 2 voxels beyond the row end
     struct XQ { uint4 a; uint4 b; };                   // b: fp32 storage only
@@ -445,7 +459,7 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
         // the lanes at a row end take the extra dword instead)
         const unsigned pl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c1, 0x111, 0xf, 0xf, true);
         const unsigned nx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0, 0x101, 0xf, 0xf, true);
-        const unsigned prev = (y_gq == 0 ? e : pl) & y_lmask, next = (y_gq == 7 ? e : nx) & y_rmask;
+        const unsigned prev = (y_first ? e : pl) & y_lmask, next = (y_last ? e : nx) & y_rmask;
         uint2 wl, wr;                                    // kw = 2: one voxel to the left; kw = 0: one voxel to the right
         wl.x = __builtin_amdgcn_alignbit(c0, prev, 16); wl.y = __builtin_amdgcn_alignbit(c1, c0, 16);
         wr.x = __builtin_amdgcn_alignbit(c1, c0, 16);   wr.y = __builtin_amdgcn_alignbit(next, c1, 16);
@@ -535,7 +549,8 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
 constexpr int wq4_waves(int ci4) { return ci4 == 1 ? 6 : ci4 == 2 ? 4 : 3; }
 template <int FMT, int CI4, bool LDSX>
 __global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
-  constexpr int RING = 4 * (6 * (4 * CI4 * 64 + 16) + 32 + 4096);             // four plane slots: x rows, constant block, dY windows
+  constexpr int XBN = 6 * (4 * CI4 * 64 + 16), XBW = 4 * (4 * CI4 * 144 + 16);  // x rows of a plane: narrow / wide tiles (wgrad_q4_body_lds)
+  constexpr int RING = 4 * ((XBN > XBW ? XBN : XBW) + 32 + 4096);             // four plane slots: x rows, constant block, dY windows
   constexpr int RED = (4 * 4 * CI4 * 27 + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDSX && RING > RED ? RING : RED];
   const int b = blockIdx.x;
@@ -583,7 +598,10 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   const int q_all = cin_g / 4;
   const int cs = q_all <= 3 ? q_all : q_all % 3 == 0 ? 3 : q_all % 2 == 0 ? 2 : 1;
   a->Cin_g = cin_g; a->Cout_g = cout_g; a->ci4 = cs; a->nchunk = q_all / cs; a->pre = d->pre; a->pre_slope = d->pre_slope;
-  a->tilesW = d->W / 32; a->tilesH = cdiv(d->H, 4);
+  // rows of 64 / 128 voxels: 2 x 64 tiles (full 128-byte lines); ablation bits 8192 (no LDS staging) / 524288 keep the 4 x 32 tiles
+  { extern int g_mfma_abl; a->wide = (d->W % 64 == 0 && !(g_mfma_abl & (8192 | 524288))) ? 1 : 0; }
+  if (d->dtype == XH_F32) a->wide = 0;                 // fp32 rows of 32 voxels are full lines already
+  a->tilesW = a->wide ? d->W / 64 : d->W / 32; a->tilesH = cdiv(d->H, a->wide ? 2 : 4);
   a->nq = (d->Cout / 4) * a->nchunk;
   // depth segments: tiles of >= 8 planes (x is read sd + 2 planes per tile), ~1024 tiles per unit
   const long long cols = (long long)a->tilesW * a->tilesH * d->N;

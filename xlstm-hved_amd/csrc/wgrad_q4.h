@@ -19,6 +19,7 @@ struct WgQ4 {
   int nb;                        // workgroups of the problem (nq * wpu)
   int abl;                       // ablation mask (microbenchmarks)
   int dwm;                       // depthwise problem run as groups of 4: only the diagonal of a 4 x 4 block is a gradient
+  int wide;                      // tile shape: 0 = 4 rows x 32 voxels, 1 = 2 rows x 64 voxels (rows of 64 / 128 voxels: full-line loads)
 };
 
 constexpr int WQ_MULTI = 8;         // problems per launch (the table travels in the kernel arguments)
