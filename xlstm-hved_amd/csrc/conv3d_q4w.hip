@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
 
   // ---- staging plan (the same for every input-channel quad): item = (row, piece j of 8 voxels) ----
   unsigned i_off[WNIT];
-  int i_lds[WNIT], i_s0[WNIT];
+  int i_lds[WNIT];              // LDS byte address of the piece's first voxel pair; the k-th pair: + 128 k
   bool i_live[WNIT], i_do[WNIT];
 #pragma unroll
   for (int it = 0; it < WNIT; ++it) {
@@ -109,8 +109,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
     i_live[it] = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
     const int gdc = min(max(gd, 0), D - 1), ghc = min(max(gh, 0), H - 1);
     i_off[it] = (unsigned)((((long long)gdc * H + ghc) * WW + j * 8) * (long long)sizeof(ST));
-    i_lds[it] = row * WPITCH;
-    i_s0[it] = ((j >> 3) << 5) + (j & 7);              // physical slot of the piece's first voxel pair; the k-th pair: + 8 k
+    i_lds[it] = row * WPITCH + (((j >> 3) << 5) + (j & 7)) * 16;   // physical slot 32 (j >> 3) + (j & 7) + 8 k
   }
   // ---- B (data) fragments: lane (quad nn, k-group g4) of half h reads logical slot 32 h + 2 nn + g4 of input row wv + kh ----
   int b_off[NH];
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<uint4*>(smem + i_lds[it] + (i_s0[it] + 8 * k) * 16) = outv[k];
+        *reinterpret_cast<uint4*>(smem + i_lds[it] + 128 * k) = outv[k];
     }
     // A (weight) fragments of this (output quad, input quad): issued here so that they travel while the workgroup gathers
     frag8 wfrag[9];
@@ -253,20 +252,20 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
     // ---- matrix phase: the wave's output row, both halves, walking the 6 staged planes once ----
 #pragma unroll
     for (int pz = 0; pz < WID; ++pz) {
-      frag8 bf[3][NH];
+      // (kh outside kd: NH fragments live at a time instead of 3 NH; an accumulator still meets its taps in the same order --
+      // for a given output plane the staged plane fixes kd)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh) {
+        frag8 bf[NH];
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-          bf[kh][h] = *reinterpret_cast<const frag8*>(smem + pz * WPLANE + (wv + kh) * WPITCH + b_off[h]);
+        for (int h = 0; h < NH; ++h) bf[h] = *reinterpret_cast<const frag8*>(smem + pz * WPLANE + (wv + kh) * WPITCH + b_off[h]);
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd) {
-        const int dz = pz - kd;
-        if (dz < 0 || dz >= WTD) continue;
+        for (int kd = 0; kd < 3; ++kd) {
+          const int dz = pz - kd;
+          if (dz < 0 || dz >= WTD) continue;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int h = 0; h < NH; ++h) acc[dz][h] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[kh][h], acc[dz][h]);
+          for (int h = 0; h < NH; ++h) acc[dz][h] = mfma16x16x32<FMT>(wfrag[kd * 3 + kh], bf[h], acc[dz][h]);
+        }
       }
     }
   }
