@@ -798,3 +798,30 @@ def test_wgrad_quad_channel_wide_tiles_vs_narrow_tiles_and_stock(cfg, dtype):
         assert l2_err(res[name][0], ref) < tol, (name, l2_err(res[name][0], ref))
         assert l2_err(res[name][1], dy.float().sum((0, 2, 3, 4)).cpu()) < 1e-4, name
     assert l2_err(res["wide"][0], res["narrow"][0]) < 2e-6 and l2_err(res["wide"][1], res["narrow"][1]) < 2e-6
+
+
+@pytest.mark.parametrize("sp", [(9, 12, 32), (16, 16, 64)])
+def test_k7_gate_weight_gradient_fp32_storage_on_the_matrix_cores(sp):
+    """ops.set_fp32_mfma(True): the 7^3 gate conv's weight / bias gradient for fp32 tensors through conv7_wgrad_mfma_kernel<2> (fp32
+    loads, operands rounded once to fp16, fp32 accumulation) against the fp32 FMA kernel on the same inputs.  A sum over every
+    voxel of independently rounded products: relative L2 at the 1e-4 level (the parity mode's gradient band is 5e-3)."""
+    torch.manual_seed(41)
+    x = torch.randn((2, 4) + sp, device=DEV)
+    dy = torch.randn((2, 2) + sp, device=DEV)
+
+    def run(on):
+        X.ops.set_fp32_mfma(on)
+        try:
+            dw, db = [torch.zeros(2, 4, 7, 7, 7, device=DEV)], [torch.zeros(2, device=DEV)]
+            X.ops.conv3d_wgrad(x, None, dy, dw, db, k=7)
+            torch.cuda.synchronize()
+            return dw[0].cpu(), db[0].cpu(), X.ops.last_conv_kernel()
+        finally:
+            X.ops.set_fp32_mfma(False)
+    w0, b0, k0 = run(False)
+    w1, b1, k1 = run(True)
+    assert "conv7_wgrad_mfma_kernel<2>" in k1 and "mfma" not in k0, (k0, k1)
+    ref = torch.nn.grad.conv3d_weight(x.cpu(), (2, 4, 7, 7, 7), dy.cpu(), padding=3)
+    e0, e1 = l2_err(w0, ref), l2_err(w1, ref)
+    print(sp, f"fp32 FMA {e0:.2e}  fp16 operands {e1:.2e}  bias {l2_err(b1, b0):.2e}")
+    assert e0 < 1e-5 and e1 < 1e-3 and l2_err(b1, b0) < 1e-3

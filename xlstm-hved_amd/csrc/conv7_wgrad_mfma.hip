@@ -26,8 +26,8 @@ typedef f32x4_t f32x4;
 
 struct Wg7K {
   xh_conv_desc d;
-  const bf16_t* x;      // (N, 4, D, H, W)
-  const bf16_t* dy;     // (N, 2, D, H, W)
+  const void* x;        // (N, 4, D, H, W), 16-bit or (FMT 2) fp32 elements
+  const void* dy;       // (N, 2, D, H, W)
   long long x_bs, dy_bs;
   float* part;          // [workgroups][NPART]
   int tilesW, tilesH, sd, dsegs;
@@ -35,8 +35,15 @@ struct Wg7K {
 constexpr int K7_NW = 2 * 4 * 343;          // 2744 weight gradients
 constexpr int K7_NPART = K7_NW + 8;         // + 2 bias gradients (padded)
 
+// FMT 0 / 1: bf16 / fp16 storage.  FMT 2: fp32 STORAGE (xh_set_option(18, 1)): 8-voxel chunks are read as 32 bytes and rounded once
+// to fp16 on their way into LDS (CF = 1 below), fp32 accumulation -- like conv3_wgrad_q4_multi_kernel<2, ...>: a weight gradient
+// sums ~10^6 independently rounded products; dY needs the caller's loss scale for fp16's range.
+template <int FMT> struct W7Store { typedef bf16_t T; };
+template <> struct W7Store<2> { typedef float T; };
 template <int FMT>
 __device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, const int nwg) {
+  typedef typename W7Store<FMT>::T ST;
+  constexpr int CF = FMT == 2 ? 1 : FMT;              // format of the LDS images / MFMA operands
   constexpr int TH = 8, TW = 32;
   constexpr int XROW = 8 * 64;                        // bytes per (ci, row): 8 shifted copies x 32 bf16
   constexpr int XBUF = 4 * TH * XROW;                 // 16 KB
@@ -67,25 +74,34 @@ __device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, c
   const int xc = it & 3, xrow = (it >> 2) & 7, xci = it >> 5;
   const int xh = oh0 + xrow;
   const bool x_ok = xh < H;
-  const bf16_t* xsrc = a.x + n * a.x_bs + (long long)xci * dhw + (long long)min(xh, H - 1) * W + ow0 + 8 * xc;
+  const ST* xsrc = (const ST*)a.x + n * a.x_bs + (long long)xci * dhw + (long long)min(xh, H - 1) * W + ow0 + 8 * xc;
   const bool x_prev = ow0 + 8 * xc - 8 >= 0, x_next = ow0 + 8 * xc + 8 < W;
   // dY item (112 of the 128 threads)
   const int yc = it & 3, yrow = (it >> 2) % DYROWS, yco = (it >> 2) / DYROWS;
   const int yh = oh0 - 3 + yrow;
   const bool y_item = !xrole && it < 2 * DYROWS * 4;
   const bool y_ok = y_item && (unsigned)yh < (unsigned)H;
-  const bf16_t* ysrc = a.dy + n * a.dy_bs + (long long)min(yco, 1) * dhw + (long long)min(max(yh, 0), H - 1) * W + ow0 + 8 * yc;
+  const ST* ysrc = (const ST*)a.dy + n * a.dy_bs + (long long)min(yco, 1) * dhw + (long long)min(max(yh, 0), H - 1) * W + ow0 + 8 * yc;
   const bool y_own_row = yrow >= 3 && yrow < 3 + TH;  // a row of the tile proper (bias gradient counts those once)
 
   uint4 r_prev, r_cur, r_next;                        // x role: the chunk and its neighbours; dY role: r_cur only
   float dbs = 0.f;
+  // 8 voxels at s as 8 packed 16-bit values (fp32 storage: two 16-byte loads, rounded to fp16)
+  auto ld8 = [&](const ST* s) -> uint4 {
+    if constexpr (FMT == 2) {
+      const float4 lo = *reinterpret_cast<const float4*>(s), hi = *reinterpret_cast<const float4*>(s + 4);
+      return make_uint4(cvt2_pack<1>(lo.x, lo.y), cvt2_pack<1>(lo.z, lo.w), cvt2_pack<1>(hi.x, hi.y), cvt2_pack<1>(hi.z, hi.w));
+    } else {
+      return *reinterpret_cast<const uint4*>(s);
+    }
+  };
   auto load_x = [&](int p) {
     r_prev = r_cur = r_next = make_uint4(0, 0, 0, 0);
     if (x_ok && (unsigned)p < (unsigned)D) {
-      const bf16_t* s = xsrc + (long long)p * hw;
-      r_cur = *reinterpret_cast<const uint4*>(s);
-      if (x_prev) r_prev = *reinterpret_cast<const uint4*>(s - 8);
-      if (x_next) r_next = *reinterpret_cast<const uint4*>(s + 8);
+      const ST* s = xsrc + (long long)p * hw;
+      r_cur = ld8(s);
+      if (x_prev) r_prev = ld8(s - 8);
+      if (x_next) r_next = ld8(s + 8);
     }
   };
   auto store_x = [&](int buf) {
@@ -104,7 +120,7 @@ __device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, c
   };
   auto load_dy = [&](int q) {
     r_cur = make_uint4(0, 0, 0, 0);
-    if (y_ok && (unsigned)q < (unsigned)D) r_cur = *reinterpret_cast<const uint4*>(ysrc + (long long)q * hw);
+    if (y_ok && (unsigned)q < (unsigned)D) r_cur = ld8(ysrc + (long long)q * hw);
   };
   auto store_dy = [&](int q) {
     if (!y_item) return;
@@ -112,7 +128,7 @@ __device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, c
     if (y_own_row && q >= p_begin && q < p_end) {
       const unsigned u[4] = {r_cur.x, r_cur.y, r_cur.z, r_cur.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dbs += cvt_lo<FMT>(u[k]) + cvt_hi<FMT>(u[k]);
+      for (int k = 0; k < 4; ++k) dbs += cvt_lo<CF>(u[k]) + cvt_hi<CF>(u[k]);
     }
   };
 
@@ -152,8 +168,8 @@ __device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, c
         const unsigned char* bp = kh_l < 7 ? s_dy + ((p - kd + 3 + 8) & 7) * DYPL + (co_l * DYROWS + ry) * 64 + g4 * 16
                                            : s_zero + g4 * 16;
         const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bp);
-        acc[kd][0] = mfma16x16x32<FMT>(a0, bv, acc[kd][0]);
-        acc[kd][1] = mfma16x16x32<FMT>(a1, bv, acc[kd][1]);
+        acc[kd][0] = mfma16x16x32<CF>(a0, bv, acc[kd][0]);
+        acc[kd][1] = mfma16x16x32<CF>(a1, bv, acc[kd][1]);
       }
     }
     if (more) { if (xrole) store_x(buf ^ 1); else store_dy(p + 4); }
@@ -232,7 +248,10 @@ __global__ __launch_bounds__(256) void conv7_wgrad_reduce_kernel(const float* pa
 }
 
 static bool wg7_eligible(const xh_conv_desc* d) {
-  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return false;
+  extern int g_q4_f32;                               // fp32 storage with fp16 operands: xh_set_option(18, 1)
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !(d->dtype == XH_F32 && g_q4_f32)) || d->k != 7 || d->stride != 1 || d->groups != 1 ||
+      d->n_wptr != 1)
+    return false;
   if (d->Cin != 4 || d->Cout != 2 || d->pre || d->Ca != d->Cin || d->transposed) return false;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;
   if ((d->xa_bs & 7) || (d->ea_bs & 7) || (((long long)d->D * d->H * d->W) & 7)) return false;
@@ -267,14 +286,16 @@ int xh_conv7_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
   Wg7K a;
   a.d = *d;
   wg7_plan(d, &a);
-  a.x = (const bf16_t*)p->xa; a.x_bs = d->xa_bs;
-  a.dy = (const bf16_t*)p->ea; a.dy_bs = d->ea_bs;
+  a.x = p->xa; a.x_bs = d->xa_bs;
+  a.dy = p->ea; a.dy_bs = d->ea_bs;
   a.part = (float*)p->ws;
   const int nwg = a.tilesW * a.tilesH * a.dsegs * d->N;
   const size_t shm = 2 * 4 * 8 * 8 * 64 + 8 * 2 * 14 * 64 + 64;
   hipStream_t st = (hipStream_t)stream;
-  xh_note_kernel("conv7_wgrad_mfma_kernel<%d>", d->dtype == XH_F16 ? 1 : 0);
-  if (d->dtype == XH_F16) hipLaunchKernelGGL(conv7_wgrad_mfma_kernel<1>, dim3(nwg), dim3(256), shm, st, a);
+  const int fmt1 = d->dtype == XH_F32 ? 2 : d->dtype == XH_F16 ? 1 : 0;
+  xh_note_kernel("conv7_wgrad_mfma_kernel<%d>", fmt1);
+  if (fmt1 == 2) hipLaunchKernelGGL(conv7_wgrad_mfma_kernel<2>, dim3(nwg), dim3(256), shm, st, a);
+  else if (fmt1 == 1) hipLaunchKernelGGL(conv7_wgrad_mfma_kernel<1>, dim3(nwg), dim3(256), shm, st, a);
   else hipLaunchKernelGGL(conv7_wgrad_mfma_kernel<0>, dim3(nwg), dim3(256), shm, st, a);
   hipLaunchKernelGGL(conv7_wgrad_reduce_kernel, dim3(cdiv(K7_NW + 2, 256), nwg < 32 ? nwg : 32), dim3(256), 0, st,
                      (const float*)a.part, nwg, dw[0], db ? db[0] : nullptr);
@@ -290,11 +311,11 @@ int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = 2 * 4 * 8 * 8 * 64 + 8 * 2 * 14 * 64 + 64;
   int rc_all = XH_OK;
-  for (int fmt = 0; fmt < 2; ++fmt) {
+  for (int fmt = 0; fmt < 3; ++fmt) {                 // bf16 / fp16 / fp32 storage with fp16 operands
     std::vector<int> idx;
     for (int i = 0; i < n; ++i) {
       if (handled[i] || !d[i] || !p[i] || !dw[i] || !dw[i][0] || !p[i]->xa || !p[i]->ea) continue;
-      if ((d[i]->dtype == XH_F16 ? 1 : 0) != fmt || !wg7_eligible(d[i]) || xh_check_conv(d[i], p[i])) continue;
+      if ((d[i]->dtype == XH_F32 ? 2 : d[i]->dtype == XH_F16 ? 1 : 0) != fmt || !wg7_eligible(d[i]) || xh_check_conv(d[i], p[i])) continue;
       if (!p[i]->ws || p[i]->ws_bytes < xh_conv3d_wgrad_workspace_bytes(d[i])) continue;
       idx.push_back(i);
     }
@@ -314,8 +335,8 @@ int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
         Wg7K& a = m.p[k];
         a.d = *d[i];
         wg7_plan(d[i], &a);
-        a.x = (const bf16_t*)p[i]->xa; a.x_bs = d[i]->xa_bs;
-        a.dy = (const bf16_t*)p[i]->ea; a.dy_bs = d[i]->ea_bs;
+        a.x = p[i]->xa; a.x_bs = d[i]->xa_bs;
+        a.dy = p[i]->ea; a.dy_bs = d[i]->ea_bs;
         a.part = (float*)p[i]->ws;
         const int nwg = a.tilesW * a.tilesH * a.dsegs * d[i]->N;
         m.off[k + 1] = m.off[k] + nwg;
@@ -324,7 +345,8 @@ int xh_wg7_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
         handled[i] = 1;
       }
       xh_note_kernel("conv7_wgrad_mfma_multi_kernel<%d>", fmt);
-      if (fmt) hipLaunchKernelGGL(conv7_wgrad_mfma_multi_kernel<1>, dim3(m.off[m.n]), dim3(256), shm, st, m);
+      if (fmt == 2) hipLaunchKernelGGL(conv7_wgrad_mfma_multi_kernel<2>, dim3(m.off[m.n]), dim3(256), shm, st, m);
+      else if (fmt) hipLaunchKernelGGL(conv7_wgrad_mfma_multi_kernel<1>, dim3(m.off[m.n]), dim3(256), shm, st, m);
       else hipLaunchKernelGGL(conv7_wgrad_mfma_multi_kernel<0>, dim3(m.off[m.n]), dim3(256), shm, st, m);
       hipLaunchKernelGGL(conv7_wgrad_reduce_multi_kernel, dim3(cdiv(K7_NW + 2, 256), maxp < 32 ? maxp : 32, m.n), dim3(256), 0, st, r);
       if (xh_launch_status() != XH_OK) rc_all = XH_ERR_HIP;
