@@ -1394,8 +1394,15 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     return xh_launch_status();
   }
   if (d->k == 3 && d->stride == 1) {
-    const int cob = pick_cob(cout_g, 8);
+    int cob = pick_cob(cout_g, 8);
     ConvK a = make_k(d, p, cob, txn);
+    // small volumes (the 16^3 / 8^3 levels in fp32 storage): a few dozen workgroups whose threads each walk Cin_g x 27 x COB FMAs
+    // -- 80 -> 80 g5 @16^3 ran 108 us on 40 workgroups.  Narrower output-channel blocks: COB times the workgroups, 1 / COB the chain
+    // (a voxel's accumulation order does not depend on the block: same bits)
+    while (cob > 1 && (long long)a.tilesW * a.tilesH * a.tilesD * a.ncob * d->N * d->groups < 256) {
+      cob >>= 1;
+      a = make_k(d, p, cob, txn);
+    }
     dim3 grid(a.tilesW * a.tilesH * a.tilesD, a.ncob, d->N * d->groups);
     switch (cob) {
       case 1: FWD_TXN(T, 3, 1, 1); break;
