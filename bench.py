@@ -863,7 +863,8 @@ def roofline_pass(step, ops, nsteps, dtype):
               "non_conv_ms_per_step": max(step_ms - total_ms / nsteps - n_brackets * overhead_ms, 0.0),
               "elementwise_ms_per_step": elementwise_from_profile(),
               "other_conv_kernels": {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3,
-                                          "GBps": v[2] / v[1] / 1e6, "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()},
+                                          "GBps": v[2] / v[1] / 1e6, "frac_of_hbm_peak": v[2] / v[1] / 1e6 / HBM_PEAK_GBS,
+                                          "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()},
                                           "shape_avg_us": {a_: round(shape_us[(k, a_)], 1) for a_ in v[4]}}
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[1:12]},
               "event_pair_overhead_us": overhead_ms * 1e3, "host_enqueue_ms_per_step": host_ms, "device_delay_ms": delay_ms,
