@@ -684,11 +684,15 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
   bool ok = row < (long long)Do * Ho;
   const int oh = (int)(row % Ho), od = (int)min(row / Ho, (long long)Do - 1);
   const int ow0 = tx * OW;
-  float acc[COB][OW];
+  // accumulators as PAIRS of consecutive outputs (v_pk_fma_f32): output j of a lane reads columns 2 j + kw of its run, i.e. the
+  // even columns for kw = 0 and 2 and the odd ones for kw = 1 -- with the run split into its even and odd columns every tap is
+  // one packed FMA per output pair (the kernel is bound by its vector FMAs: 27 Cin_g COB per output)
+  constexpr int NP = OW / 2;
+  f32x2_t acc2[COB][NP];
 #pragma unroll
   for (int i = 0; i < COB; ++i)
 #pragma unroll
-    for (int j = 0; j < OW; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < NP; ++j) acc2[i][j] = f32x2_t{0.f, 0.f};
   const int cpk = (a.Cin_g + KS - 1) / KS;
   const int ci_end = min(a.Cin_g, (ks + 1) * cpk);
   for (int ci_g = ks * cpk; ci_g < ci_end; ++ci_g) {
@@ -718,16 +722,27 @@ __global__ __launch_bounds__(256) void conv3_s2_vec_kernel(const ConvK a, int LW
       const float l = __shfl_up(r[VW], 1, 64);
       r[0] = tx == 0 ? 0.f : l;                       // column -1 of the volume is padding
       const float* wr = s_w + (ci_g * 27 + r9 * 3) * COB;
+      f32x2_t e0[NP], e1[NP], o0[NP];                 // (r[4p], r[4p+2]), (r[4p+2], r[4p+4]), (r[4p+1], r[4p+3])
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
+      for (int p2 = 0; p2 < NP; ++p2) {
+        e0[p2] = f32x2_t{r[4 * p2], r[4 * p2 + 2]};
+        e1[p2] = f32x2_t{r[4 * p2 + 2], r[4 * p2 + 4]};
+        o0[p2] = f32x2_t{r[4 * p2 + 1], r[4 * p2 + 3]};
+      }
 #pragma unroll
-        for (int co = 0; co < COB; ++co) {
-          const float w = wr[kw * COB + co];
+      for (int co = 0; co < COB; ++co) {
+        const float w0 = wr[co], w1 = wr[COB + co], w2 = wr[2 * COB + co];
 #pragma unroll
-          for (int j = 0; j < OW; ++j) acc[co][j] = fmaf(w, r[2 * j + kw], acc[co][j]);
-        }
+        for (int p2 = 0; p2 < NP; ++p2)               // same order of the three taps per output as the scalar loop had
+          acc2[co][p2] = f32x2_t{w2, w2} * e1[p2] + (f32x2_t{w1, w1} * o0[p2] + (f32x2_t{w0, w0} * e0[p2] + acc2[co][p2]));
+      }
     }
   }
+  float acc[COB][OW];
+#pragma unroll
+  for (int i = 0; i < COB; ++i)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { acc[i][2 * j] = acc2[i][j].x; acc[i][2 * j + 1] = acc2[i][j].y; }
   if (KS > 1) {                                         // block-uniform
     float* s_part = s_dyn + part_off;                   // [KS - 1][LPB][COB * OW]
     if (ks > 0) {
@@ -1433,7 +1448,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
         const long long lanes = (long long)d->Do * d->Ho * lw;
         // input-channel split inside the block while the launch has fewer than 256 workgroups (narrow channel blocks only)
         int ks = 1;
-        if (cob == 2 && !(g_xh_disable & 256))
+        if (cob <= 4 && !(g_xh_disable & 256))
           while (ks < 8 && cdiv((int)lanes, 256 / ks) * a.ncob * d->N * d->groups < 256 && 256 / (2 * ks) >= lw &&
                  (256 / (2 * ks)) % lw == 0 && cin_g / (2 * ks) >= 2)
             ks *= 2;
