@@ -17,8 +17,13 @@
 //   * the weight fragments of a stage and the epilogue operand of its tile (EPI == 1) are requested at the START of the stage,
 //     BEFORE the next stage's operands: vmcnt retires in order, so waiting for them does not wait for the younger prefetch
 //     (requested after it, `s_waitcnt vmcnt(0)` in front of the matrix phase drained the prefetch: 80 us instead of 60);
+//   * the weight fragments are requested at the start of a stage, the epilogue operand behind its transform, both BEFORE the prefetch;
+//   * every load is unconditional (a load under a branch makes hipcc's wait counts conservative on every path that joins);
 //   * statistics: fp32 per tile, fp64 across the tiles of one (sample, output quad), one set of fp64 atomics per run.
-// ~150 VGPRs: three workgroups per CU, all of them with 36 KB of loads in flight nearly all the time.
+// 150 - 230 VGPRs: two workgroups per CU (three spill, and a spill reload waits for vmcnt(0)).
+// WHAT IT MEASURED: the memory waits go (SQ_WAIT_ANY -60 %) and single-quad tiles get SLOWER (16 -> 16 g4 data gradient
+// 59.7 -> 67.5 us): the saturated unit was the texture path (half-line requests), which conv3d_q4w.hip then fixed with full-row
+// tiles.  This kernel remains for 8-plane multi-quad forward launches on rows that are not 64 / 128 voxels wide.
 #include "conv_q4.h"
 
 int g_q4_persist = 1;             // xh_set_option(19, n): 0 = never, 1 = where it wins (xh_conv3_q4p_try), 2 = every 8-plane launch
