@@ -708,6 +708,8 @@ Q4W_CASES = [
     dict(cin=20, cout=20, groups=5, sp=(16, 24, 64), n=1),            # rows of 64 voxels: one 64-voxel N tile per row
     dict(cin=24, cout=8, groups=1, sp=(10, 9, 64), n=2, split=8),     # 64-wide, six input quads, ragged tiles, 2 samples
     dict(cin=8, cout=24, groups=1, sp=(8, 16, 64), n=1),
+    dict(cin=4, cout=4, groups=1, sp=(4, 8, 64), n=3),                # the smallest volume the kernel takes: one tile, 3 samples
+    dict(cin=8, cout=4, groups=1, sp=(5, 9, 128), n=1),               # one plane and one row beyond a tile
 ]
 
 
