@@ -17,7 +17,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 timed on the best of a small thread-count sweep on a bounded sample of the same workload; it runs in a
                 child process next to the GPU legs (a 256-thread host; the GPU timed region is one graph launch per step).
   modes         ms/step and voxels/s of the same step in the other storage modes (fp32 = the parity mode, fp16 = the
-                reference's AMP dtype, bf16), each with the measured deviation class it belongs to (tests/test_gpu_network.py).
+                reference's AMP dtype, bf16), each with the deviation class the test suite measured for it (`parity`, text) and
+                with THIS run's measurement (`parity_measured`: Dice deviation and mask flips of the mode's 128^3 segmentation
+                of the trained-like parity case against the mask the real reference produced, tests/golden/make_mask_128.py).
+  config3       BASELINE config 3: N = 2 at 128^3, per-sample modality dropout drawn per step from the 15 subsets, one hipGraph.
 """
 import subprocess
 import argparse
@@ -77,6 +80,7 @@ def parse():
                     help="initialise RCCL and issue the gradient all-reduce even with one rank (exercises the N>1 code path)")
     ap.add_argument("--extras", action="store_true", help="also time forward-only and the shared-encoder two-forward step")
     ap.add_argument("--no-modes", action="store_true", help="skip timing the other storage modes")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 leg (N = 2, per-step modality dropout)")
     ap.add_argument("--no-trainstep", action="store_true", help="skip timing the whole training step (train.py:208-296)")
     ap.add_argument("--wgrad-overlap", action="store_true",
                     help="launch the weight-gradient kernels on a second HIP stream (measured on MI355X: no gain, 9.88-10.7 ms "
@@ -327,7 +331,7 @@ def main():
                                f"random-init weights, {'hipGraph replay' if graph is not None else 'eager'}",
                    "parallelism": f"dp{world}", "per_gpu_batch": B, "global_batch": B * world},
     }
-    out["parity"] = MODE_PARITY[args.dtype]
+    out["parity"] = MODE_PARITY[args.dtype] + "  [test-suite figures; this run's own measurement: parity_measured]"
     if rank == 0 and world == 1 and not args.no_modes:
         # the same step in the other storage modes (same weights, same patch, hipGraph replay, no collective), so the
         # parity-mode throughput is measured in the same run as the headline
@@ -342,6 +346,19 @@ def main():
                 ops.set_fp32_mfma(args.dtype == "fp32_mfma")
             modes[name] = {"ms_per_step": ms_m, "voxels_per_s": B * S ** 3 / (ms_m * 1e-3), "parity": MODE_PARITY[name]}
         out["modes"] = modes
+        # measured, not quoted: every mode's mask on the 128^3 parity case against the reference's own mask
+        try:
+            mp = measured_parity(dev, DT)
+            out["parity_measured"] = mp
+            for name in modes:
+                modes[name]["parity_measured"] = mp["modes"].get(name)
+        except Exception as e:
+            out["parity_measured_error"] = repr(e)[:200]
+    if rank == 0 and world == 1 and not args.no_config3:
+        try:
+            out["config3"] = config3_leg(model, grads, dev, dtype, S, max(10, min(args.steps, 40)), 3)
+        except Exception as e:
+            out["config3_error"] = repr(e)[:200]
     if args.extras and rank == 0:
         out["extras"] = extras(model, x, grads, args.steps)
     if cpu_proc is not None:
@@ -376,6 +393,100 @@ def main():
         import torch.distributed as dist
         dist.barrier()                                          # rank 0 arrives after its roofline pass
         dist.destroy_process_group()
+
+
+def measured_parity(dev, modes):
+    """MEASURED in this run, per storage mode: the thresholded segmentation of the 128^3 parity case against the mask the REAL
+    reference produced for it (tests/golden/mask_trained_like_128.npz, written by tests/golden/make_mask_128.py from the imported
+    reference; the CPU oracle reproduces it with 0 flips).  Case: weights_trained_like.npz (the reference trained for 300 CPU
+    steps), tests/synth_blobs.blob_case(8, 1, 128), all four modalities, eval mode, posterior mean.  Dice as metrics.py:85-107
+    (threshold 0.5, eps 1e-6), per region channel; `dice_dev` = the largest |Dice - 1| of the three."""
+    import numpy as np
+    import xlstm_hved_amd as X
+    from xlstm_hved_amd import ops
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_blobs as SB
+    gold = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(gold, "mask_trained_like_128.npz"))
+    shape = tuple(int(v) for v in z["shape"])
+    ref = torch.from_numpy(np.unpackbits(z["bits"])[: int(np.prod(shape))].reshape(shape).astype(np.bool_)).to(dev)
+    w = np.load(os.path.join(gold, "weights_trained_like.npz"))
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}, strict=True)
+    m = m.to(dev).eval()
+    x, _ = SB.blob_case(8, 1, 128)
+    x = x.to(dev)
+    was = ops._FP32_MFMA[0]
+    out = {}
+    try:
+        for name, dt_ in modes.items():
+            ops.set_fp32_mfma(name == "fp32_mfma")
+            with torch.no_grad():
+                seg = m(x.to(dt_), [14], recon=True, valid=True)[0]
+            got = seg.float() > 0.5
+            inter = (got & ref).sum((0, 2, 3, 4)).double()
+            den = got.sum((0, 2, 3, 4)).double() + ref.sum((0, 2, 3, 4)).double()
+            dice = (2 * inter + 1e-6) / (den + 1e-6)
+            out[name] = {"dice_dev": float((dice - 1).abs().max()), "dice": [float(v) for v in dice],
+                         "mask_flips": int((got != ref).sum()), "mask_voxels": int(ref.numel()),
+                         "meets_1e-4": bool(float((dice - 1).abs().max()) <= 1e-4)}
+    finally:
+        ops.set_fp32_mfma(was)
+    return {"case": "trained-like weights (reference trained 300 CPU steps), synthetic blob patch 1x4x128^3, subset [14], eval, posterior "
+                    "mean; target = the REAL reference's fp32 mask (tests/golden/mask_trained_like_128.npz)",
+            "positives_per_channel": [int(v) for v in z["pos"]], "modes": out}
+
+
+def config3_leg(model, grads, dev, dtype, size, nsteps, warmup):
+    """BASELINE config 3 (RA_HVED.py:513-520,588-594): N = 2 at 128^3 with per-sample modality dropout, the two
+    samples' subsets drawn anew for every step from the 15 subsets, forward + backward through ONE captured hipGraph.  The graph
+    holds `model(x, [14], instance_missing=True, recon=True)` -- the reference's own detection of dropped modalities
+    (`x.sum((2,3,4)) == 0`, RA_HVED.py:515) runs on the device inside the graph, PoE2 takes the resulting per-sample mask -- so a
+    step only rewrites the input buffer: the full patch times a (2, 4) keep mask (what the reference's data pipeline hands over)."""
+    import xlstm_hved_amd as X
+    from xlstm_hved_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    xfull = torch.rand(2, 4, size, size, size, generator=g).to(dev, dtype)
+    xin = xfull.clone()
+    table = torch.tensor([[1.0 if c in X.SUBSETS_MODALITIES[k] else 0.0 for c in range(4)] for k in range(15)], device=dev).to(dtype)
+    n_all = warmup + nsteps + 2
+    draws = torch.randint(0, 15, (n_all, 2), generator=g)
+    keeps = [table[draws[i].to(dev)].view(2, 4, 1, 1, 1) for i in range(n_all)]       # built before the timed region
+    scale = LOSS_SCALE_FP16 if dtype == torch.float16 else 1.0
+    seed = torch.full((), scale, dtype=torch.float32, device=dev)
+
+    def compute():
+        grads.zero()
+        seg, (mu, lv), rec = model(xin, [14], instance_missing=True, recon=True)
+        bench_loss(seg, mu, lv, rec[0]).backward(seed)
+        ops.join_wgrad_stream()
+        if scale != 1.0:
+            grads.flat.mul_(1.0 / scale)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.mul(xfull, keeps[-1], out=xin)
+        compute()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        compute()
+    for i in range(warmup):
+        torch.mul(xfull, keeps[i], out=xin)
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + nsteps):
+        torch.mul(xfull, keeps[i], out=xin)                   # this step's dropout pattern (inside the timed region)
+        graph.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / nsteps * 1e3
+    finite = bool(torch.isfinite(grads.flat).all())
+    return {"workload": f"XLSTM_HVED fwd+bwd, 2x4x{size}^3 per GPU, instance_missing=True, both samples' modality subsets drawn per step "
+                        f"from the 15 subsets (seeded), one captured hipGraph, input mask rewritten per step inside the timed region",
+            "ms_per_step": ms, "voxels_per_s": 2 * size ** 3 / (ms * 1e-3), "steps": nsteps, "dtype": str(dtype).replace("torch.", ""),
+            "subsets_first_steps": draws[warmup:warmup + 6].tolist(), "gradients_finite": finite}
 
 
 def train_step_leg(model, x, nsteps, group=None, world=1, mfma_roofline=False):
@@ -737,6 +848,34 @@ def roofline_pass(step, ops, nsteps, dtype):
         records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops, shape, 1))
         return r
 
+    # ---- the norm / element-wise family, measured in THIS run: every call of the non-conv stage entry points (statistics,
+    # normalisation forward / backward, activation backward, pooling, trilinear up-sampling and adjoint, gates, DuSE, skip-return
+    # tail, PoE, loss reductions, fills) bracketed the same way.  A call is one launch (a few are two).
+    ELT = ("moments moments2 norm_finalize affine_act in_affine_act bn_affine_act bn_affine_act2 norm_bwd_fused2 act_bwd_reduce "
+           "norm_bwd_coef norm_bwd_apply norm_bwd_fused in_bwd_apply in_bwd_apply2 maxpool2 maxpool2_bwd upsample upsample_bwd "
+           "upsample2x_in_act upsample2x_bwd_act_reduce add act_bwd channel_pool channel_pool_bwd gate gate_bwd channel_pool2 "
+           "channel_pool2_bwd gate2 gate2_bwd gate_maxpool gate_maxpool_bwd duse_gate duse_gate_bwd duse_gate_fc rank1_add_fc "
+           "rank1_add skr_tail skr_tail_bn skr_tail_bwd duse_fc_fwd duse_fc_bwd poe_fwd poe_bwd poe_fwd_multi poe_bwd_multi "
+           "compose_multi pair_sums lincomb loss_finalize kld_fwd kld_bwd nested_weight multi_sum multi_fill fill").split()
+    ELT = [n_ for n_ in ELT if hasattr(ops, n_)]
+    elt_orig = {n_: getattr(ops, n_) for n_ in ELT}
+    elt_records = []
+
+    def elt_wrap(name_, fn_):
+        def timed(*a_, **k_):
+            e0, e1 = ev(), ev()
+            e0.record()
+            r_ = fn_(*a_, **k_)
+            e1.record()
+            elt_records.append((name_, e0, e1))
+            return r_
+        return timed
+    elt_timed = {n_: elt_wrap(n_, f_) for n_, f_ in elt_orig.items()}
+
+    def elt_install(on):
+        for n_ in ELT:
+            setattr(ops, n_, elt_timed[n_] if on else elt_orig[n_])
+
     orig_flush = ops._flush_deferred
 
     def timed_flush():
@@ -776,6 +915,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     # the delay must outlast the host's enqueue time of one instrumented step (else the GPU catches up and a bracket
     # also spans host launch latency): time one instrumented enqueue, then wait 1.5x that (+20 ms), at most 600 ms
     ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
+    elt_install(True)
     try:
         t_h = time.perf_counter()
         step()
@@ -783,12 +923,15 @@ def roofline_pass(step, ops, nsteps, dtype):
         torch.cuda.synchronize()
     finally:
         ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
+        elt_install(False)
     records.clear()
+    elt_records.clear()
     delay_ms = min(2.0 * host_ms + 30.0, 600.0)
     # an event pair costs a few microseconds of its own (two marker packets): measure empty brackets under the same
     # queued conditions and subtract their median from every bracket
     overhead_ms = gpu_delay.empty_pair_ms(delay_ms)
     ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
+    elt_install(True)
     whole = []
     try:
         for _ in range(nsteps):
@@ -801,6 +944,21 @@ def roofline_pass(step, ops, nsteps, dtype):
         torch.cuda.synchronize()
     finally:
         ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
+        elt_install(False)
+    # element-wise family: per entry point, the n-th call of each step across the steps -> median, like the conv brackets
+    elt_by = {}
+    for name_, e0, e1 in elt_records:
+        elt_by.setdefault(name_, []).append(max(e0.elapsed_time(e1) - overhead_ms, 5e-4))
+    elt_tab, elt_ms, elt_calls = {}, 0.0, 0
+    for name_, ts_ in elt_by.items():
+        per = len(ts_) // nsteps
+        if per and len(ts_) % nsteps == 0:
+            tot = sum(sorted(ts_[st * per + j] for st in range(nsteps))[nsteps // 2] for j in range(per))
+        else:
+            per, tot = len(ts_) / nsteps, sum(ts_) / nsteps
+        elt_tab[name_] = {"calls_per_step": per, "ms_per_step": tot}
+        elt_ms += tot
+        elt_calls += per
     # every (kernel instance, shape) occurs a fixed number of times per step; the n-th occurrence of each step forms one
     # sample group whose MEDIAN over the steps is taken (a host hiccup that lets the GPU catch up inflates single brackets)
     per_call = {}
@@ -860,8 +1018,15 @@ def roofline_pass(step, ops, nsteps, dtype):
               # (norm / element-wise passes, ViL, PoE, loss, packs, fills) = the instrumented step minus its conv brackets minus
               # the event pairs; the rocprof family split of the same step is in profiles/ (r04*_timeline.txt)
               "instrumented_step_ms": step_ms,
-              "non_conv_ms_per_step": max(step_ms - total_ms / nsteps - n_brackets * overhead_ms, 0.0),
-              "elementwise_ms_per_step": elementwise_from_profile(),
+              "non_conv_ms_per_step": max(step_ms - total_ms / nsteps - (n_brackets + elt_calls) * overhead_ms, 0.0),
+              # the same family, measured two ways: in THIS run (event brackets around every non-conv stage entry point of the
+              # instrumented steps) and from the rocprofv3 kernel trace of this command committed under profiles/ (a file, not a
+              # measurement of this run -- the key says so)
+              "elementwise_in_run": {"ms_per_step": elt_ms, "calls_per_step": elt_calls,
+                                     "top": dict(sorted(elt_tab.items(), key=lambda kv: -kv[1]["ms_per_step"])[:10]),
+                                     "how": "HIP-event brackets around every norm / element-wise / PoE / loss entry point of ops.py "
+                                            "inside the instrumented steps, minus the median empty pair"},
+              "elementwise_from_committed_profile": elementwise_from_profile(),
               "other_conv_kernels": {k: {"launches_per_step": v[0] / nsteps, "avg_launch_us": v[1] / v[0] * 1e3,
                                           "GBps": v[2] / v[1] / 1e6, "frac_of_hbm_peak": v[2] / v[1] / 1e6 / HBM_PEAK_GBS,
                                           "shapes": {a_: b_ / nsteps for a_, b_ in v[4].items()},

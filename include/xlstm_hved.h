@@ -68,8 +68,10 @@ int xh_abi_version(void);
  * PROCESS-GLOBAL STATE (the only two exceptions to "no mutable state in the library"): the option table behind
  * xh_set_option (plain ints, e.g. g_q4_maxc / g_q4_wgs in csrc/conv3d_q4.hip) and the name buffer behind xh_last_conv_kernel
  * are per PROCESS, not per device, stream or call.  They are development / measurement knobs: every option has a default that
- * is the measured optimum, no product code path (the package's Python files; bench and tests do) sets one, and the deployment model is
- * one process per GPU.  Neither function is thread-safe against concurrent launches from other host threads: set options
+ * is the measured optimum and the deployment model is one process per GPU.  The package's Python files set exactly ONE of them,
+ * and only when the caller asks: ops.set_fp32_mfma(on) writes key 18 (the arithmetic of fp32 storage: matrix cores through the
+ * two-term fp16 split instead of the fp32 vector kernels); it is read when a conv is launched, i.e. at capture time of a graph.
+ * Every other key is written by bench.py, tools/ and tests/ only.  Neither function is thread-safe against concurrent launches from other host threads: set options
  * before the first launch; read xh_last_conv_kernel on the thread that made the call.  Every other entry point is re-entrant:
  * all device memory, workspaces and the statistics fan-in block are the caller's, the stream is an argument. */
 int xh_set_option(int key, int value);

@@ -25,6 +25,14 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert j["roofline"]["bound"] in ("hbm", "mfma") and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
     assert set(j["modes"]) == {"bf16", "fp16", "fp32", "fp32_mfma"} and all(m["ms_per_step"] > 0 for m in j["modes"].values())
+    # measured in the run, not quoted: each mode's 128^3 mask against the real reference's mask; the two fp32-storage arithmetics
+    # meet north_star's Dice tolerance
+    pm = j["parity_measured"]["modes"]
+    assert set(pm) == {"bf16", "fp16", "fp32", "fp32_mfma"}
+    assert pm["fp32"]["dice_dev"] <= 1e-4 and pm["fp32_mfma"]["dice_dev"] <= 1e-4, pm
+    assert pm["fp16"]["dice_dev"] <= pm["bf16"]["dice_dev"] + 1e-3
+    assert j["config3"]["ms_per_step"] > 0 and j["config3"]["gradients_finite"]
+    assert j["roofline"]["elementwise_in_run"]["ms_per_step"] > 0 and j["roofline"]["elementwise_in_run"]["calls_per_step"] > 50
 
 
 def test_bench_force_dist_rccl_allreduce_with_graph_capture():

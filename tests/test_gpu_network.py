@@ -193,14 +193,16 @@ TRAINED_CASES = {"trained_like_64_blob7_subset14_eval": (7, 64, 14), "trained_li
                  "trained_like_128_blob8_subset14_eval": (8, 128, 14)}
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32_mfma", "bf16", "fp16"])
 @pytest.mark.parametrize("case", sorted(TRAINED_CASES))
 def test_storage_modes_on_trained_like_weights(case, mode):
     """The storage modes on weights that are NOT a random initialisation: the REAL reference trained for 300 CPU steps on smooth
     synthetic patches (tests/golden/make_trained_like.py -> weights_trained_like.npz; inputs from tests/synth_blobs.py), eval mode,
     posterior mean, against the fp32 CPU oracle, next to the reference's own autocast deviation on the same weights and inputs
-    (amp_yardstick.json).  north_star's "Dice within 1e-4" is asserted for fp32 storage; for the 16-bit modes the measured
-    deviation is held below the reference's own AMP deviation of the same dtype and reported."""
+    (amp_yardstick.json).  north_star's "Dice within 1e-4" is asserted for fp32 storage in BOTH arithmetics -- the fp32 vector
+    kernels and `fp32_mfma` (ops.set_fp32_mfma: the convs on the matrix cores through the two-term fp16 split, the mode bench.py
+    advertises as the tolerance-meeting one) -- with the same bounds; for the 16-bit modes the measured deviation is held below
+    the reference's own AMP deviation of the same dtype and reported."""
     import synth_blobs as SB
     seed, size, subset = TRAINED_CASES[case]
     ys = _yardstick()[case]
@@ -217,9 +219,14 @@ def test_storage_modes_on_trained_like_weights(case, mode):
     m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     m.load_state_dict(w, strict=True)
     m = m.to(DEV).eval()
-    dt = dict(STORAGE, fp32=torch.float32)[mode]
-    with torch.no_grad():
-        seg, _, rec = m(x.to(DEV, dt), [subset], recon=True, valid=True)
+    dt = dict(STORAGE, fp32=torch.float32, fp32_mfma=torch.float32)[mode]
+    X.ops.set_fp32_mfma(mode == "fp32_mfma")
+    try:
+        with torch.no_grad():
+            seg, _, rec = m(x.to(DEV, dt), [subset], recon=True, valid=True)
+        torch.cuda.synchronize()
+    finally:
+        X.ops.set_fp32_mfma(False)
     seg, rec = seg.float().cpu(), rec[0].float().cpu()
     l2 = ((seg - prob_o).norm() / prob_o.norm()).item()
     r2 = ((rec - rec_o).norm() / rec_o.norm()).item()
@@ -231,8 +238,9 @@ def test_storage_modes_on_trained_like_weights(case, mode):
     print(f"trained-like {case} {mode} storage: seg rel L2 {l2:.3e}, recon rel L2 {r2:.3e}, Dice dev {d:.3e}, mask flips {flips}/{seg.numel()} "
           f"(positive fractions {pos[0]:.3f}/{pos[1]:.3f}/{pos[2]:.3f})"
           + (f"; reference {mode}-AMP: seg {ref['seg_rel_l2']:.3e}, Dice dev {ref['dice_dev']:.3e}, flips {ref['mask_flips']}" if ref else ""))
-    if mode == "fp32":
+    if mode in ("fp32", "fp32_mfma"):
         assert (seg - prob_o).abs().max().item() < 5e-3 and d < 1e-4, (d,)
+        assert flips <= 2, flips                              # fp32 vector kernels: 0 of 6.3 M at 128^3
     else:
         assert d <= max(1e-3, ref["dice_dev"]) and l2 <= max(2e-3, 2 * ref["seg_rel_l2"]), (d, l2, ref)
 
@@ -382,6 +390,91 @@ def test_fp32_full_size_128_backward_vs_oracle(arith):
     print(f"fp32 128^3 backward vs oracle [{arith}]: {n_checked} parameter gradients, worst {worst:.2e} of the largest ({wname}), relative L2 {l2:.2e}")
     assert n_checked > 250
     assert worst < 5e-3 and l2 < 5e-3, (worst, wname, l2)
+
+
+def _mask_pair(x, ka, kb):
+    """x (2, 4, ...) with the modalities outside subsets ka / kb zeroed in sample 0 / 1 (what instance_missing detects,
+    RA_HVED.py:513-520)."""
+    xm = x.clone()
+    for i, k in enumerate((ka, kb)):
+        for c in range(4):
+            if c not in X.SUBSETS_MODALITIES[k]:
+                xm[i, c] = 0
+    return xm
+
+
+def test_config3_all_15_subsets_batch2_128_bf16_and_fp32_oracle():
+    """BASELINE config 3 at FULL size: N = 2 at 128^3 with per-sample modality dropout, every one of the 15 subsets
+    (RA_HVED.py:513-520,588-594,733-738).  Sample 0 carries subset k, sample 1 subset 14 - k, k = 0..14.
+    bf16 storage, all 15 pairs, size-independent properties:
+      * finite, probabilities in [0, 1];
+      * in eval mode (BatchNorm on running statistics: nothing couples the samples) each sample of the N = 2 instance-missing
+        forward equals the N = 1 instance-missing forward of that sample alone to storage round-off (no kernel mixes samples;
+        launch plans -- tile depth, fan-in, the order of fp64 statistics atomics -- may differ with the batch, so the last bit of
+        a statistic may; the count of bit-identical pairs is printed);
+      * the instance-missing forward of (k, k) equals the batch-missing forward `subset_idx_list=[k]` on the same masked input
+        (PoE2 with zeroed experts == PoE over the subset, buildingblocks.py:853-886) to storage round-off;
+      * train mode: one backward per pair group gives finite parameter gradients.
+    fp32 storage against the CPU oracle for three pairs (k = 0, 7, 12), tolerances of SURVEY 8(c)."""
+    torch.manual_seed(33)
+    x = torch.rand(2, 4, 128, 128, 128)
+    m = _model(False)
+    singles, same, worst1 = {}, 0, 0.0
+    with torch.no_grad():
+        for k in range(15):
+            xm = _mask_pair(x, k, 14 - k).to(DEV, torch.bfloat16)
+            seg, (mu, lv), rec = m(xm, [14], instance_missing=True, recon=True, valid=True)
+            assert torch.isfinite(seg.float()).all() and torch.isfinite(rec[0].float()).all(), k
+            assert seg.min() >= 0 and seg.max() <= 1
+            for b_, kk in enumerate((k, 14 - k)):
+                key = (b_, kk)
+                if key not in singles:
+                    s1, _, r1 = m(xm[b_:b_ + 1].contiguous(), [14], instance_missing=True, recon=True, valid=True)
+                    singles[key] = (s1.clone(), r1[0].clone())
+                same += int(torch.equal(seg[b_:b_ + 1], singles[key][0]) and torch.equal(rec[0][b_:b_ + 1], singles[key][1]))
+                e1 = l2_err(seg[b_:b_ + 1], singles[key][0])
+                worst1 = max(worst1, e1)
+                # a random-init XLSTM_HVED amplifies a last-bit difference ~1e4x (SURVEY F9): bf16 storage itself sits at 0.07
+                assert e1 < 0.05, (k, b_, e1)
+                assert ((seg[b_:b_ + 1] > 0.5) != (singles[key][0] > 0.5)).float().mean().item() < 5e-3, (k, b_)
+        worst = 0.0
+        for k in range(15):
+            xm = _mask_pair(x, k, k).to(DEV, torch.bfloat16)
+            seg_i, _, rec_i = m(xm, [14], instance_missing=True, recon=True, valid=True)
+            seg_b, _, rec_b = m(xm, [k], recon=True, valid=True)
+            e = l2_err(seg_i, seg_b)
+            worst = max(worst, e)
+            assert e < 0.05, (k, e)
+            assert ((seg_i > 0.5) != (seg_b > 0.5)).float().mean().item() < 5e-3, k
+    print(f"config 3, bf16, 15 subsets at 2x4x128^3: per-sample results vs N = 1 worst seg rel L2 {worst1:.2e}, {same}/30 bit-identical; "
+          f"instance-missing vs batch-missing worst seg rel L2 {worst:.2e}")
+    m.train(True)
+    for k in (1, 8, 13):
+        xm = _mask_pair(x, k, 14 - k).to(DEV, torch.bfloat16)
+        for p_ in m.parameters():
+            p_.grad = None
+        seg, (mu, lv), rec = m(xm, [14], instance_missing=True, recon=True)
+        loss = seg.float().mean() + rec[0].float().mean() + sum(a.float().mean() + b.float().mean() for a, b in zip(mu, lv))
+        loss.backward()
+        torch.cuda.synchronize()
+        n_g = sum(1 for p_ in m.parameters() if p_.grad is not None)
+        assert n_g > 250 and all(torch.isfinite(p_.grad).all() for p_ in m.parameters() if p_.grad is not None), k
+    del singles
+    # fp32 storage against the CPU oracle
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    m = _model(True)
+    eps = [torch.randn(2, 2 ** l, 64 >> l, 64 >> l, 64 >> l) for l in range(4)]
+    for k in (0, 7, 12):
+        xm = _mask_pair(x, k, 14 - k)
+        sd = {k_: v.clone() for k_, v in _weights().items()}
+        with torch.no_grad():
+            prob_o, _, mu_o, lv_o, rec_o = O.xlstm_hved_forward(sd, xm, 14, eps_list=eps, training=True, instance_missing=True)
+            m.load_state_dict(_weights(), strict=True)        # the BatchNorm buffers of the previous pair
+            seg, (mu, lv), rec = m(xm.to(DEV), [14], recon=True, eps_list=eps, instance_missing=True)
+        e_seg, e_rec = (seg.cpu() - prob_o).abs().max().item(), rel_err(rec[0], rec_o)
+        d = (_dice(seg, (prob_o > 0.5).float()) - 1.0).abs().max().item()
+        print(f"config 3, fp32, subsets ({k}, {14 - k}) at 2x4x128^3 vs oracle: seg |d| {e_seg:.2e} recon rel {e_rec:.2e} dice dev {d:.2e}")
+        assert e_seg < 5e-3 and e_rec < 1e-3 and d < 1e-4, (k, e_seg, e_rec, d)
 
 
 def test_fp32_vs_oracle_64_batch2_train_random_subset():

@@ -284,3 +284,20 @@ def test_reference_cost_mode_is_the_same_function():
         close(b, a, 2e-4, "reference_cost output")
     for k, v in bufs[0].items():
         close(bufs[1][k].double(), v.double(), 1e-5, k)
+
+
+def test_oracle_reproduces_the_reference_mask_at_128():
+    """tests/golden/mask_trained_like_128.npz is the REAL reference's thresholded segmentation of the benchmark-size parity
+    case (make_mask_128.py); bench.py measures every storage mode against it.  The oracle must give the same mask."""
+    import synth_blobs as SB
+    z = np.load(os.path.join(GOLDEN, "mask_trained_like_128.npz"))
+    shape = tuple(int(v) for v in z["shape"])
+    ref = np.unpackbits(z["bits"])[: int(np.prod(shape))].reshape(shape).astype(bool)
+    w = np.load(os.path.join(GOLDEN, "weights_trained_like.npz"))
+    sd = {k: torch.from_numpy(w[k]) for k in w.files}
+    x, _ = SB.blob_case(8, 1, 128)
+    with torch.no_grad():
+        prob = O.xlstm_hved_forward(sd, x, 14, eps_list=None, training=False)[0]
+    got = (prob > 0.5).numpy()
+    assert [int(got[0, c].sum()) for c in range(3)] == [int(v) for v in z["pos"]]
+    assert int((got != ref).sum()) == 0

@@ -7,29 +7,34 @@ from torch import nn
 from torch.nn import init
 
 
+def _draw(fn, **kw):
+    return lambda t: fn(t.data, **kw)
+
+
+# module type -> (weight initialiser, bias initialiser), in the precedence utils.py:191-212 tests them.  One row per stock
+# parameter holder the drop-in classes keep their parameters in; a type that is not listed keeps its constructor values.
+_INIT_TABLE = (
+    (nn.Conv3d, _draw(init.kaiming_normal_), _draw(init.normal_)),
+    (nn.ConvTranspose3d, _draw(init.xavier_normal_), _draw(init.normal_)),
+    (nn.BatchNorm3d, _draw(init.normal_, mean=1, std=0.02), _draw(init.constant_, val=0)),
+    (nn.Linear, _draw(init.xavier_normal_), _draw(init.normal_)),
+)
+
+
 def init_weights(m):
-    """utils.py:191-215: kaiming-normal Conv3d weights, N(0,1) biases, xavier Linear, BatchNorm N(1,0.02)/0, and the
-    reference's nn.ModuleList branch (utils.py:213-215): under `model.apply(init_weights)` the DIRECT children of every
-    ModuleList are initialised a second time (apply visits them as well), which advances the RNG -- reproduced so that
-    the same seed draws the same weights as the reference."""
-    if isinstance(m, nn.Conv3d):
-        init.kaiming_normal_(m.weight.data)
-        if m.bias is not None:
-            init.normal_(m.bias.data)
-    elif isinstance(m, nn.ConvTranspose3d):
-        init.xavier_normal_(m.weight.data)
-        if m.bias is not None:
-            init.normal_(m.bias.data)
-    elif isinstance(m, nn.BatchNorm3d):
-        init.normal_(m.weight.data, mean=1, std=0.02)
-        init.constant_(m.bias.data, 0)
-    elif isinstance(m, nn.Linear):
-        init.xavier_normal_(m.weight.data)
-        if m.bias is not None:
-            init.normal_(m.bias.data)
-    elif isinstance(m, nn.ModuleList):
-        for l in m:
-            init_weights(l)
+    """Seed-compatible with utils.py:191-215 of the reference: the same initialiser per module type, drawn weight first and
+    bias second, so `model.apply(init_weights)` under one seed gives the reference's weights.  The reference also walks the
+    DIRECT children of every nn.ModuleList a second time (utils.py:213-215; `apply` has visited them already), which
+    advances the RNG: reproduced, or the draws after the first ModuleList would differ."""
+    for kind, w_init, b_init in _INIT_TABLE:
+        if isinstance(m, kind):
+            w_init(m.weight)
+            if m.bias is not None:
+                b_init(m.bias)
+            return
+    if isinstance(m, nn.ModuleList):
+        for child in m:
+            init_weights(child)
 
 
 def subset_idx(subset_size=(4,)):
