@@ -189,7 +189,7 @@ def test_depthwise_conv_through_quad_channel_kernel(transposed, dtype):
                 grads.append((dw, db, X.ops.last_conv_kernel()))
             finally:
                 lib.xh_set_option(2, 0)
-        assert "conv3_wgrad_q4" in grads[0][2] and "q4" not in grads[1][2]
+        assert ("conv3_wgrad_q4" in grads[0][2] or "conv3_wgrad_q5" in grads[0][2]) and "q4" not in grads[1][2] and "q5" not in grads[1][2]
         xr = x.float().requires_grad_(False)
         wr = ws[0].clone().requires_grad_(True)
         br = torch.zeros(c, device=DEV, requires_grad=True)
@@ -388,7 +388,8 @@ def _full_size_128(cfg, dtype, path):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 def test_wgrad_mfma_full_size_128_kernel_name(dtype):
-    """The weight gradient of a few-channel conv at 128^3 goes through conv3_wgrad_q4_multi_kernel; with the quad-channel
+    """The weight gradient of a few-channel conv at 128^3 goes through the full-row kernel conv3_wgrad_q5_multi_kernel (round 5;
+    conv3_wgrad_q4_multi_kernel with xh_set_option(21, 0)); with the quad-channel
     kernels switched off it is conv3_wgrad_mfma_kernel<F, 4, 256> (both checked numerically by the test above through
     InLreluConv.backward); this pins the selection so a plan change cannot silently drop the coverage."""
     x = torch.randn(1, 4, 128, 128, 128, device=DEV).to(dtype)
@@ -396,7 +397,13 @@ def test_wgrad_mfma_full_size_128_kernel_name(dtype):
     dw, db = torch.zeros(4, 4, 3, 3, 3, device=DEV), torch.zeros(4, device=DEV)
     X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
     name = X.ops.last_conv_kernel()
-    assert "conv3_wgrad_q4_multi_kernel" in name, name
+    assert "conv3_wgrad_q5_multi_kernel" in name, name
+    X._lib.load().xh_set_option(21, 0)
+    try:
+        X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
+        assert "conv3_wgrad_q4_multi_kernel" in X.ops.last_conv_kernel()
+    finally:
+        X._lib.load().xh_set_option(21, 1)
     X._lib.load().xh_set_option(2, 32)
     try:
         X.ops.conv3d_wgrad(x, None, dy, [dw], [db], k=3)
@@ -784,6 +791,7 @@ def test_wgrad_quad_channel_wide_tiles_vs_narrow_tiles_and_stock(cfg, dtype):
     res = {}
     for name, abl in (("wide", 0), ("narrow", 524288)):
         lib.xh_set_option(1, abl)
+        lib.xh_set_option(21, 0)                       # the full-row kernel (conv3d_wgrad_q5.hip) would take the H % 8 == 0 cases
         try:
             dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
             dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
@@ -793,6 +801,7 @@ def test_wgrad_quad_channel_wide_tiles_vs_narrow_tiles_and_stock(cfg, dtype):
             res[name] = (torch.cat(dws, 0).cpu(), torch.cat(dbs, 0).cpu())
         finally:
             lib.xh_set_option(1, 0)
+            lib.xh_set_option(21, 1)
     xf = torch.nn.functional.leaky_relu(x.float() * pre[0][:, :, None, None, None] + pre[1][:, :, None, None, None], 0.01).to(dtype).float()
     ref = torch.nn.grad.conv3d_weight(xf, (cout, cin // g, 3, 3, 3), dy.float(), padding=1, groups=g).cpu()
     tol = 2e-3 if dtype == torch.bfloat16 else 5e-4
@@ -827,3 +836,84 @@ def test_k7_gate_weight_gradient_fp32_storage_on_the_matrix_cores(sp):
     e0, e1 = l2_err(w0, ref), l2_err(w1, ref)
     print(sp, f"fp32 FMA {e0:.2e}  fp16 operands {e1:.2e}  bias {l2_err(b1, b0):.2e}")
     assert e0 < 1e-5 and e1 < 1e-3 and l2_err(b1, b0) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+@pytest.mark.parametrize("cfg", [dict(n=2, cin=4, cout=4, g=1, sp=(9, 16, 64)), dict(n=1, cin=16, cout=16, g=4, sp=(21, 8, 128)),
+                                 dict(n=1, cin=12, cout=4, g=1, sp=(10, 16, 128), split=4), dict(n=1, cin=24, cout=8, g=1, sp=(6, 8, 64), split=16),
+                                 dict(n=2, cin=20, cout=40, g=5, sp=(5, 8, 64)), dict(n=1, cin=8, cout=8, g=8, sp=(12, 24, 128)),
+                                 dict(n=1, cin=4, cout=12, g=1, sp=(4, 8, 128))],
+                         ids=["4to4_w64_n2", "16to16g4_w128_ragged_segments", "12to4_w128_two_sources", "24to8_w64_two_sources", "20to40g5_w64_n2",
+                              "depthwise8_w128", "4to12_w128_four_planes"])
+def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
+    """conv3_wgrad_q5_multi_kernel (rows of 64 / 128 voxels, H a multiple of 8: 8-row full-row tiles, dY staged once, the kw shift
+    applied at fragment-read time) against conv3_wgrad_q4_multi_kernel (xh_set_option(21, 0)) and torch.nn.grad on the same 16-bit
+    inputs: the same products summed in another order (fp32 round-off between the two kernels); batch 2, groups, several input
+    quads per group (units that re-stage dY), the skip | x two-source input, depthwise as groups of 4, depth segments that do not
+    divide D, the InstanceNorm + LeakyReLU input transform and the bias gradient."""
+    lib = X._lib.load()
+    torch.manual_seed(41)
+    n, cin, cout, g = cfg["n"], cfg["cin"], cfg["cout"], cfg["g"]
+    x = torch.randn((n, cin) + cfg["sp"], device=DEV).to(dtype)
+    dy = torch.randn((n, cout) + cfg["sp"], device=DEV).to(dtype)
+    xa, xb = (x, None) if "split" not in cfg else (x[:, :cfg["split"]].contiguous(), x[:, cfg["split"]:].contiguous())
+    nw = g if g <= 4 else 1
+    for pre in (None, (torch.rand(n, cin, device=DEV) + 0.5, torch.randn(n, cin, device=DEV), 0.01)):
+        res = {}
+        for name, on in (("full", 1), ("tile", 0)):
+            lib.xh_set_option(21, on)
+            try:
+                dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
+                dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
+                X.ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=3, groups=g, pre=pre)
+                kn = X.ops.last_conv_kernel()
+                assert ("conv3_wgrad_q5_multi_kernel" if on else "conv3_wgrad_q4_multi_kernel") in kn, kn
+                torch.cuda.synchronize()
+                res[name] = (torch.cat(dws, 0).cpu(), torch.cat(dbs, 0).cpu())
+            finally:
+                lib.xh_set_option(21, 1)
+        xf = x.float()
+        if pre is not None:
+            xf = torch.nn.functional.leaky_relu(xf * pre[0][:, :, None, None, None] + pre[1][:, :, None, None, None], 0.01).to(dtype).float()
+        ref = torch.nn.grad.conv3d_weight(xf, (cout, cin // g, 3, 3, 3), dy.float(), padding=1, groups=g).cpu()
+        tol = 2e-3 if dtype == torch.bfloat16 else 5e-4
+        assert l2_err(res["full"][0], ref) < tol, l2_err(res["full"][0], ref)
+        assert l2_err(res["full"][1], dy.float().sum((0, 2, 3, 4)).cpu()) < 1e-4
+        assert l2_err(res["full"][0], res["tile"][0]) < 2e-6 and l2_err(res["full"][1], res["tile"][1]) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
+def test_wgrad_full_row_kernel_batched_128_cubed(dtype):
+    """The end-of-backward batch at the benchmark's shapes: xh_conv3d_wgrad_batch with the 128^3 / 64^3 problems of one step (16 -> 16 g4,
+    12 -> 4, 4 -> 4, 8 -> 8 g2 at 128^3; 24 -> 8, 8 -> 8 at 64^3) in ONE call -- several problems per launch, workgroups dealt by
+    volume -- against the same problems through the tile kernel."""
+    lib = X._lib.load()
+    torch.manual_seed(43)
+    probs = [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (8, 8, 2, 128), (24, 8, 1, 64), (8, 8, 1, 64), (32, 32, 4, 64)]
+    data = []
+    for cin, cout, g, s in probs:
+        x = torch.randn(1, cin, s, s, s, device=DEV).to(dtype)
+        dy = (torch.randn(1, cout, s, s, s, device=DEV) * 0.1).to(dtype)
+        pre = (torch.rand(1, cin, device=DEV) + 0.5, torch.randn(1, cin, device=DEV), 0.01)
+        data.append((x, dy, pre, g, cin, cout))
+    res = {}
+    for name, on in (("full", 1), ("tile", 0)):
+        lib.xh_set_option(21, on)
+        X.ops.set_wgrad_defer(True)
+        try:
+            outs = []
+            for x, dy, pre, g, cin, cout in data:
+                nw = g if g <= 4 else 1
+                dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
+                dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
+                X.ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=pre, side=True)
+                outs.append((dws, dbs))
+            X.ops.join_wgrad_stream()
+            torch.cuda.synchronize()
+            res[name] = [(torch.cat(a, 0).cpu(), torch.cat(b, 0).cpu()) for a, b in outs]
+        finally:
+            X.ops.set_wgrad_defer(False)
+            lib.xh_set_option(21, 1)
+    for (a, b), (c, d), pr in zip(res["full"], res["tile"], probs):
+        assert l2_err(a, c) < 5e-6 and l2_err(b, d) < 5e-6, (pr, l2_err(a, c), l2_err(b, d))
+        assert a.abs().max() > 0

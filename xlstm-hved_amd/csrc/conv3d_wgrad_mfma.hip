@@ -404,14 +404,15 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
   // quad-channel problems first: WQ_MULTI per launch and storage format
   std::vector<char> handled(n > 0 ? n : 1, 0);
   if (g_use_mfma) {
-    for (int cls = 0; cls < 9; ++cls) {               // (storage format: bf16 / fp16 / fp32 with fp16 operands, input-channel quads per group)
-      const int fmt = cls / 3, ci4 = cls % 3 + 1;
+    for (int cls = 0; cls < 11; ++cls) {              // (storage format: bf16 / fp16 / fp32 with fp16 operands, input-channel quads per group);
+                                                      // 9, 10: the full-row kernel's problems (bf16 / fp16, conv3d_wgrad_q5.hip)
+      const int full = cls >= 9, fmt = full ? cls - 9 : cls / 3, ci4 = full ? 1 : cls % 3 + 1;
       std::vector<WgQ4> cl;
       WgQ4 q;
       for (int i = 0; i < n; ++i) {
         if (!d[i] || !p[i]) return XH_ERR_ARG;
         if (handled[i] || (d[i]->dtype == XH_F32 ? 2 : d[i]->dtype == XH_F16 ? 1 : 0) != fmt) continue;
-        if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &q) || q.ci4 != ci4) continue;
+        if (!xh_wgrad_q4_plan(d[i], p[i], dw[i], db ? db[i] : nullptr, &q) || q.ci4 != ci4 || q.full != full) continue;
         handled[i] = 1;
         cl.push_back(q);
       }

@@ -616,11 +616,14 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   a->ntile = (int)nt;
   a->wpu = a->nb = 0;                                  // set per launch (xh_wgrad_q4_launch)
   { extern int g_mfma_abl; a->abl = g_mfma_abl; }
+  a->full = 0;
+  if (!(a->abl & (8192 | 524288))) xh_wgrad_q5_replan(d, a);   // rows of 64 / 128 voxels: the full-row kernel (conv3d_wgrad_q5.hip)
   return true;
 }
 
 // launches up to WQ_MULTI planned problems of one storage format and one input-quad count (probs[i].ci4 all equal)
 void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
+  if (probs[0].full) { xh_wgrad_q5_launch(st, fmt, probs, n); return; }
   WgQ4Multi m;
   m.n = n;
   m.off[0] = 0;

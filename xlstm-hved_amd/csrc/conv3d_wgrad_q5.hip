@@ -1,0 +1,349 @@
+// Full-row weight / bias gradient of the quad-channel 3x3x3 stride-1 convolution on rows of 128 or 64 voxels (round 5): every
+// 128^3- and 64^3-level conv of XLSTM_HVED (buildingblocks.py:406-433 backward), 16-bit storage, gfx950.
+//
+//   dW[co][ci][kd][kh][kw] = sum over voxels v of dY[co][v] * xa[ci][v + (kd, kh, kw) - 1],   xa = leaky(x * sc + sh)
+//
+// Same GEMM as conv3d_wgrad_q4.hip (mfma_f32_16x16x32, K = 32 voxels of one row, M = (co of 4, kw), N = (ci of 4, kh), a wave
+// walks along D so a B fragment meets the dY fragments of three planes), different staging.  What bound the 2 x 64 / 4 x 32 tile
+// kernel was instruction issue (profiles/r03d_wgrad_q4_counters.txt: 185 vector + 135 scalar instructions per 128 voxels and
+// channel-quad pair, two thirds of them building THREE shifted copies of every dY row -- 4 v_alignbit, DPP neighbour exchange,
+// edge dwords, masks, three ds_write_b64 per 4 voxels -- because an MFMA operand wants its 8 voxels in one aligned 16-byte
+// LDS read and the kw shift runs along the contraction axis), plus a 1.5 - 2x halo on x rows.
+//
+// Here dY is staged ONCE, unshifted, as a plain 16-byte copy (no vector arithmetic beyond the depth-segment mask) and the kw shift
+// is applied when the A fragment is READ:
+//   * lane (co, kw, g) reads the FIVE dwords that hold voxels 32 c + 8 g - 2 .. + 7 (kw = 2: one voxel to the left) or 32 c + 8 g ..
+//     + 9 (kw = 1, 0) of its line -- the start is a per-lane address -- and funnels neighbouring dwords together with four
+//     v_alignbit whose shift is 16 (kw = 0, 2) or 0 (kw = 1): no selects, no masks, no DPP, and each dY element is written to LDS
+//     once instead of three times.  (gfx950 also serves one ds_read_b128 from a 2-byte-aligned address -- hipcc emits it for an
+//     align-2 access -- but tools/probe/lds_unaligned.hip measured it at 1/9 of the aligned rate: 9.7 against 88 TB/s, 19 TB/s at
+//     4-byte and 38 TB/s at 8-byte alignment; a fragment per 3 MFMAs at that rate makes the LDS pipe the bound.);
+//   * every (row, channel) line has 16 bytes of zeros in front and behind, so the voxels beside a row are the conv's zero padding
+//     and a row has no edge loads;
+//   * a tile is 8 FULL rows (8 waves, wave w owns row w, 2 or 4 chunks of 32 voxels): every global load is a 16-byte piece of a
+//     full line, 16 (8) consecutive lanes per 256-byte (128-byte) row; x halo 10 rows for 8 (1.25; 2.0 / 1.5 before);
+//   * x is loaded as 16-byte items, the producer's InstanceNorm + LeakyReLU applied once per element (packed fp32), rows / planes
+//     outside the volume become zero when staged: the plane step has no masks;
+//   * 4-slot LDS ring of planes (slot p & 3 holds x plane p and dY plane p + 1), rounds of two planes, ONE barrier per round;
+//     the loads of round r + 1 are in flight during the matrix phase of round r;
+//   * one input-channel quad per unit (12 -> 4 is three units that each re-stage the dY rows: cheaper than the 38 KB plane slots of
+//     three quads, which would leave one workgroup per CU);
+//   * persistent workgroups (2 per CU), accumulators kept across a workgroup's tiles, ONE LDS reduction + pass of fp32 atomics.
+// Step of a wave and chunk: 5 ds_read_b32 + 4 v_alignbit (A), 1 ds_read_b128 (B), 3 MFMAs.
+#include "common.h"
+#include "../../include/xlstm_hved.h"
+#include "wgrad_q4.h"
+
+typedef h16x8 frag8;
+typedef f32x4_t f32x4;
+
+struct WgQ5Multi {
+  int n;
+  int off[WQ_MULTI + 1];
+  WgQ4 p[WQ_MULTI];
+};
+
+namespace {
+constexpr int Q5_TH = 8;                      // rows per tile = waves per workgroup
+template <int NH> struct Q5 {
+  static constexpr int W = 64 * NH;
+  static constexpr int PR = W / 8;            // 16-byte pieces per row
+  static constexpr int NC = W / 32;           // K chunks per row
+  static constexpr int CP = 2 * W + 16;       // bytes per (row, channel) line of x (16 B spare: bank spreading of the B reads)
+  static constexpr int XROW = 4 * CP + 16;    // bytes per staged x row (4 channels)
+  static constexpr int XB = (Q5_TH + 2) * XROW;
+  static constexpr int YP = 2 * W + 32;       // bytes per (row, co) line of dY: [16 B zeros][row][16 B zeros]
+  static constexpr int YB = Q5_TH * 4 * YP;
+  static constexpr int SLOT = XB + YB;
+  static constexpr int RING = 4 * SLOT;
+  static constexpr int CONSTB = RING;         // [16 B of ones][16 B of zeros]
+  static constexpr int BYTES = RING + 32;
+  static constexpr int NXI = 2 * (Q5_TH + 2) * 4 * PR;   // x items of a round (two planes)
+  static constexpr int NIX = (NXI + 511) / 512;          // per thread: 3 | 2
+  static constexpr int NYI = 2 * Q5_TH * 4 * PR;         // dY items of a round
+  static constexpr int NIY = NYI / 512;                  // 2 | 1
+};
+}
+
+template <int FMT, int NH>
+__device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned char* smem) {
+  typedef h16<FMT> ST;
+  typedef Q5<NH> Q;
+  constexpr int W = Q::W, PR = Q::PR, NC = Q::NC, NIX = Q::NIX, NIY = Q::NIY;
+  constexpr unsigned ONE2 = FMT == 0 ? 0x3F803F80u : 0x3C003C00u;
+  float* s_dw = reinterpret_cast<float*>(smem);        // after the plane loops
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nn = lane & 15, g = lane >> 4;
+  const int unit = b / a.wpu, w = b - unit * a.wpu;
+  const int oq = unit / a.nchunk, chunk = unit - oq * a.nchunk;
+  int t_first, t_stride, t_end;
+  if ((a.ntile & 7) == 0 && (a.wpu & 7) == 0) {        // workgroups of one XCD walk one contiguous eighth of the tiles
+    const int per = a.ntile >> 3;
+    t_first = (w & 7) * per + (w >> 3); t_stride = a.wpu >> 3; t_end = ((w & 7) + 1) * per;
+  } else {
+    t_first = w; t_stride = a.wpu; t_end = a.ntile;
+  }
+  f32x4 acc[3];
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd) acc[kd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int D = a.D, H = a.H;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  const int co0 = oq * 4;
+  const int grp = co0 / a.Cout_g;
+  const int cin_base = grp * a.Cin_g + chunk * 4;
+  const float pslope = a.pre ? a.pre_slope : 1.f;
+  const f32x2_t ps2 = {pslope, pslope};
+
+  // ---- constants of the launch: the zero blocks in front of and behind every dY line, the ones / zeros block ----
+  for (int i = tid; i < 4 * Q5_TH * 4 * 2; i += 512) {
+    const int slot = i / (Q5_TH * 4 * 2), l = (i >> 1) % (Q5_TH * 4);
+    *reinterpret_cast<uint4*>(smem + slot * Q::SLOT + Q::XB + l * Q::YP + ((i & 1) ? 16 + 2 * W : 0)) = make_uint4(0, 0, 0, 0);
+  }
+  if (tid < 8) *reinterpret_cast<unsigned*>(smem + Q::CONSTB + tid * 4) = tid < 4 ? ONE2 : 0u;
+
+  // ---- fragment addresses ----
+  // B: lane (ci = nn & 3, kh = nn >> 2; g) reads x row wv + kh, channel ci, voxels 32 c + 8 g ..; kh = 3: the constant column (bias gradient)
+  const int ci_l = nn & 3, khB = nn >> 2;
+  const int b_off = khB == 3 ? Q::CONSTB + (ci_l == 0 ? 0 : 16) : (wv + khB) * Q::XROW + ci_l * Q::CP + g * 16;
+  const int b_slot = khB == 3 ? 0 : 1;                 // the constant block is not in a plane slot
+  // A: lane (co = nn >> 2, kw = nn & 3; g) wants dY row wv, channel co, voxels 32 c + 8 g + 1 - kw .. + 7 (kw = 3: an unused
+  // accumulator row, as kw = 1): five dwords from the one that holds its first voxel, funnel-shifted by 16 bits unless kw = 1
+  const int kwA = (nn & 3) == 3 ? 1 : (nn & 3);
+  const int a_off = Q::XB + (wv * 4 + (nn >> 2)) * Q::YP + 16 + 16 * g - (kwA == 2 ? 4 : 0);
+  const unsigned a_sh = kwA == 1 ? 0u : 16u;
+
+  // ---- staging plan, tile-independent part.  x item k of this thread: it = tid + 512 k = (plane pp, row r, channel c, piece j) ----
+  int x_lds[NIX], x_pp[NIX], x_r[NIX], x_c[NIX];
+  bool x_do[NIX];
+#pragma unroll
+  for (int k = 0; k < NIX; ++k) {
+    const int it = tid + 512 * k;
+    x_do[k] = it < Q::NXI;
+    const int itc = x_do[k] ? it : 0;
+    const int j = itc % PR, c = (itc / PR) & 3, r = (itc / (4 * PR)) % (Q5_TH + 2), pp = itc / (4 * PR * (Q5_TH + 2));
+    x_pp[k] = pp; x_r[k] = r; x_c[k] = c;
+    x_lds[k] = pp * Q::SLOT + r * Q::XROW + c * Q::CP + j * 16;
+  }
+  int y_lds[NIY], y_pp[NIY];
+  unsigned y_goff[NIY];                                // element offset inside the (sample, output quad) block, row h0 excluded
+#pragma unroll
+  for (int k = 0; k < NIY; ++k) {
+    const int it = tid + 512 * k;
+    const int j = it % PR, co = (it / PR) & 3, r = (it / (4 * PR)) % Q5_TH, pp = it / (4 * PR * Q5_TH);
+    y_pp[k] = pp;
+    y_lds[k] = pp * Q::SLOT + Q::XB + (r * 4 + co) * Q::YP + 16 + j * 16;
+    y_goff[k] = (unsigned)((long long)co * dhw + (long long)r * W + 8 * j);
+  }
+
+  for (int t = t_first; t < t_end; t += t_stride) {
+    int wk = t;
+    const int th = wk % a.tilesH; wk /= a.tilesH;
+    const int ds = wk % a.dsegs;
+    const int n = wk / a.dsegs;
+    const int h0 = th * Q5_TH;
+    const int d0 = ds * a.sd, d1 = min(D, d0 + a.sd);
+    // ---- per-tile part of the x plan ----
+    const ST* xsrc = (cin_base < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)cin_base * dhw
+                                      : (const ST*)a.xb + n * a.xb_bs + (long long)(cin_base - a.Ca) * dhw);
+    unsigned x_goff[NIX];
+    float x_sc[NIX], x_sh[NIX];
+#pragma unroll
+    for (int k = 0; k < NIX; ++k) {
+      const int row = h0 - 1 + x_r[k];
+      const bool rok = (unsigned)row < (unsigned)H;
+      const int it = tid + 512 * k;
+      const int j = (x_do[k] ? it : 0) % PR;
+      x_goff[k] = (unsigned)((long long)x_c[k] * dhw + (long long)min(max(row, 0), H - 1) * W + 8 * j);
+      float sc = 1.f, sh = 0.f;
+      if (a.pre) { sc = a.pre_sc[n * a.Cin + cin_base + x_c[k]]; sh = a.pre_sh[n * a.Cin + cin_base + x_c[k]]; }
+      x_sc[k] = rok ? sc : 0.f;
+      x_sh[k] = rok ? sh : 0.f;
+    }
+    const ST* ysrc = (const ST*)a.dy + n * a.dy_bs + (long long)co0 * dhw + (long long)h0 * W;
+
+    uint4 xq[NIX], yq[NIY];
+    auto issue = [&](int r) {
+      const int p0 = d0 - 1 + 2 * r;
+#pragma unroll
+      for (int k = 0; k < NIX; ++k) {
+        const long long po = (long long)min(max(p0 + x_pp[k], 0), D - 1) * hw;
+        xq[k] = *reinterpret_cast<const uint4*>(xsrc + po + x_goff[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < NIY; ++k) {
+        const long long po = (long long)min(max(p0 + 1 + y_pp[k], 0), D - 1) * hw;
+        yq[k] = *reinterpret_cast<const uint4*>(ysrc + po + y_goff[k]);
+      }
+    };
+    auto commit = [&](int r) {                           // round r -> slots (2 r) & 3, (2 r + 1) & 3
+      const int p0 = d0 - 1 + 2 * r;
+      unsigned char* dst = smem + ((2 * r) & 3) * Q::SLOT;
+#pragma unroll
+      for (int k = 0; k < NIX; ++k) {
+        if (!x_do[k]) continue;
+        const float pm = (unsigned)(p0 + x_pp[k]) < (unsigned)D ? 1.f : 0.f;
+        const float sc = x_sc[k] * pm, sh = x_sh[k] * pm;
+        const f32x2_t sc2 = {sc, sc}, sh2 = {sh, sh};
+        const unsigned u[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
+        uint4 o;
+        unsigned* op = &o.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x2_t v = cvt2_in<FMT>(u[e]) * sc2 + sh2;
+          const f32x2_t y = max2(v, v * ps2);
+          op[e] = cvt2_pack<FMT>(y.x, y.y);
+        }
+        *reinterpret_cast<uint4*>(dst + x_lds[k]) = o;
+      }
+#pragma unroll
+      for (int k = 0; k < NIY; ++k) {
+        // out plane v = p + 1 belongs to this tile when v < d1 (v >= d0 always holds)
+        const unsigned am = (p0 + 1 + y_pp[k] < d1) ? 0xffffffffu : 0u;
+        *reinterpret_cast<uint4*>(dst + y_lds[k]) = make_uint4(yq[k].x & am, yq[k].y & am, yq[k].z & am, yq[k].w & am);
+      }
+    };
+    frag8 af_m1[NC], af_0[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) af_m1[c] = af_0[c] = frag8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto step = [&](int s) {                             // plane slot s: x plane p, dY plane p + 1
+      const unsigned char* src = smem + s * Q::SLOT;
+      const unsigned char* bsrc = smem + (b_slot ? s * Q::SLOT : 0) + b_off;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const volatile unsigned* ap = reinterpret_cast<const volatile unsigned*>(src + a_off + c * 64);
+        const unsigned e0 = ap[0], e1 = ap[1], e2 = ap[2], e3 = ap[3], e4 = ap[4];
+        const frag8 af_p1 = __builtin_bit_cast(frag8, make_uint4(__builtin_amdgcn_alignbit(e1, e0, a_sh), __builtin_amdgcn_alignbit(e2, e1, a_sh),
+                                                                 __builtin_amdgcn_alignbit(e3, e2, a_sh), __builtin_amdgcn_alignbit(e4, e3, a_sh)));
+        const frag8 bf = *reinterpret_cast<const frag8*>(bsrc + (b_slot ? c * 64 : 0));
+        acc[0] = mfma16x16x32<FMT>(af_p1, bf, acc[0]);
+        acc[1] = mfma16x16x32<FMT>(af_0[c], bf, acc[1]);
+        acc[2] = mfma16x16x32<FMT>(af_m1[c], bf, acc[2]);
+        af_m1[c] = af_0[c];
+        af_0[c] = af_p1;
+      }
+    };
+    const int nround = (d1 - d0 + 2 + 1) / 2;            // x planes d0 - 1 .. d1
+    __syncthreads();                                     // the previous tile's planes are no longer read (first tile: constants written)
+    issue(0);
+    commit(0);
+    if (nround > 1) issue(1);
+    for (int r = 0; r < nround; ++r) {
+      __syncthreads();                                   // round r staged; round r - 1 fully read
+      step((2 * r) & 3);
+      step((2 * r + 1) & 3);
+      if (r + 1 < nround) commit(r + 1);                 // into the slots of round r - 1 (uniform branches: the loads of a round are
+      if (r + 2 < nround) issue(r + 2);                  // all waited for at its commit anyway)
+    }
+  }   // tiles
+
+  // ---- sum the eight rows of the workgroup in LDS (the plane ring is free now), then one pass of fp32 atomics ----
+  constexpr int NW = 4 * 4 * 27;
+  __syncthreads();
+  for (int i = tid; i < NW + 4; i += 512) s_dw[i] = 0.f;
+  __syncthreads();
+  {
+    const int kh = nn >> 2, ci = nn & 3;                // accumulator column; rows 4 g + r = (co = g, kw = r)
+    if (kh < 3) {
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) atomicAdd(&s_dw[(g * 4 + ci) * 27 + kd * 9 + kh * 3 + r], acc[kd][r]);
+    } else if (ci == 0) {
+      atomicAdd(&s_dw[NW + g], acc[1][1]);               // column of ones x dY row (co = g, kw = 1)
+    }
+  }
+  __syncthreads();
+  if (a.abl & 2048) return;                              // ablation: no global atomics
+  const int gpp = a.groups / a.n_wptr;
+  float* dwp = a.dw[grp / gpp];
+  const int gl = grp % gpp;
+  for (int i = tid; i < NW; i += 512) {
+    const int tap = i % 27;
+    const int r = i / 27;
+    const int ci = r & 3, c = r >> 2;
+    const int co_g = (co0 + c) % a.Cout_g;
+    if (a.dwm) {                                         // depthwise: dw[C][1][27], the off-diagonal products are not gradients
+      if (ci == c) atomicAdd(dwp + (long long)(gl * 4 + c) * 27 + tap, s_dw[i]);
+      continue;
+    }
+    atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + chunk * 4 + ci) * 27 + tap, s_dw[i]);
+  }
+  float* dbp = a.db[grp / gpp];
+  if (dbp && chunk == 0 && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(512, 4) void conv3_wgrad_q5_multi_kernel(const WgQ5Multi m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < WQ_MULTI; ++k)
+    if (k < m.n && b >= m.off[k]) i = k;
+  const int local = b - m.off[i];
+  const WgQ4& a = m.p[i];
+  if (local >= a.nb) return;
+  if (a.W == 128) wgrad_q5_body<FMT, 2>(a, local, smem);
+  else wgrad_q5_body<FMT, 1>(a, local, smem);
+}
+
+// Re-plans a quad-channel problem (xh_wgrad_q4_plan has filled `a`) for the full-row kernel; false: it stays with the tile kernel
+int g_q5_on = 1;                                         // xh_set_option(21, 0 / 1)
+bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
+  if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
+  if ((d->W != 128 && d->W != 64) || d->H % Q5_TH || d->D < 4) return false;
+  const long long dhw = (long long)d->D * d->H * d->W;
+  if (4 * dhw >= (1ll << 31)) return false;              // 32-bit element offsets inside a channel quad
+  a->full = 1;
+  a->ci4 = 1;
+  a->nchunk = a->Cin_g / 4;
+  a->nq = (d->Cout / 4) * a->nchunk;
+  a->wide = 0;
+  a->tilesW = 1;
+  a->tilesH = d->H / Q5_TH;
+  return true;                                           // dsegs / sd / ntile / wpu / nb: per launch (xh_wgrad_q5_launch)
+}
+
+// launches up to WQ_MULTI re-planned problems of one storage format
+void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
+  WgQ5Multi m;
+  m.n = n;
+  m.off[0] = 0;
+  const int budget = 512;                                // resident workgroups: 2 per CU
+  // workgroups per unit in proportion to the unit's voxels; then depth segments so that a workgroup walks ~2 tiles of >= 8 planes
+  double total = 0.0;
+  for (int i = 0; i < n; ++i) total += (double)probs[i].nq * probs[i].N * probs[i].D * probs[i].H * probs[i].W;
+  for (int i = 0; i < n; ++i) {
+    m.p[i] = probs[i];
+    WgQ4& a = m.p[i];
+    const double share = (double)a.N * a.D * a.H * a.W / total;      // of one unit
+    int w = (int)(budget * share);
+    if (w < 1) w = 1;
+    const int cols = a.tilesH * a.N;
+    // tiles per unit: at least w (every workgroup busy), segments of >= 8 planes
+    int dsegs = (w + cols - 1) / cols;
+    const int max_segs = a.D >= 8 ? a.D / 8 : 1;
+    if (dsegs > max_segs) dsegs = max_segs;
+    if (dsegs < 1) dsegs = 1;
+    a.sd = (a.D + dsegs - 1) / dsegs;
+    a.dsegs = (a.D + a.sd - 1) / a.sd;
+    a.ntile = cols * a.dsegs;
+    if (w > a.ntile) w = a.ntile;
+    if (w >= 8 && (a.ntile & 7) == 0) w &= ~7;
+    a.wpu = w;
+    a.nb = a.nq * w;
+    m.off[i + 1] = m.off[i] + ((a.nb + 7) & ~7);
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<2>::BYTES);
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<2>::BYTES);
+    attr_done = true;
+  }
+  bool any128 = false;
+  for (int i = 0; i < n; ++i) any128 |= probs[i].W == 128;
+  const size_t shm = any128 ? Q5<2>::BYTES : Q5<1>::BYTES;
+  xh_note_kernel("conv3_wgrad_q5_multi_kernel<%d>", fmt);
+  if (fmt) hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<1>), dim3(m.off[n]), dim3(512), shm, st, m);
+  else hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<0>), dim3(m.off[n]), dim3(512), shm, st, m);
+}

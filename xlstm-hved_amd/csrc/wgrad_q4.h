@@ -20,8 +20,13 @@ struct WgQ4 {
   int abl;                       // ablation mask (microbenchmarks)
   int dwm;                       // depthwise problem run as groups of 4: only the diagonal of a 4 x 4 block is a gradient
   int wide;                      // tile shape: 0 = 4 rows x 32 voxels, 1 = 2 rows x 64 voxels (rows of 64 / 128 voxels: full-line loads)
+  int full;                      // 1: planned for the full-row kernel (conv3d_wgrad_q5.hip: 8 rows x W tiles, one input quad per unit)
 };
 
 constexpr int WQ_MULTI = 8;         // problems per launch (the table travels in the kernel arguments)
 bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgQ4* a);
 void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);
+// conv3d_wgrad_q5.hip: re-plans a planned problem for the full-row kernel (rows of 64 / 128 voxels, 16-bit storage); launch of up to
+// WQ_MULTI such problems of one storage format (xh_wgrad_q4_launch forwards to it)
+bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a);
+void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);
