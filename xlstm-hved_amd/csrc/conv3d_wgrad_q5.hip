@@ -65,7 +65,7 @@ template <int NH> struct Q5 {
 };
 }
 
-template <int FMT, int NH>
+template <int FMT, int NH, int PD>
 __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned char* smem) {
   typedef h16<FMT> ST;
   typedef Q5<NH> Q;
@@ -161,21 +161,29 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     }
     const ST* ysrc = (const ST*)a.dy + n * a.dy_bs + (long long)co0 * dhw + (long long)h0 * W;
 
-    uint4 xq[NIX], yq[NIY];
-    auto issue = [&](int r) {
+    // PD rounds of loads in flight per thread, in PD register buffers used round-robin (the loop is unrolled PD times so that a
+    // buffer is a fixed set of registers).  Every issue is unconditional -- a round beyond the tile's last one loads one dead
+    // line (all offsets collapse to the source's first bytes) -- so that the compiler's vmcnt bookkeeping stays exact: a load
+    // under a branch makes it wait for (nearly) everything at the next use, i.e. one round in flight whatever PD says.
+    struct RB { uint4 x[NIX]; uint4 y[NIY]; };
+    RB q[PD];
+    const int nround = (d1 - d0 + 2 + 1) / 2;            // x planes d0 - 1 .. d1
+    auto issue = [&](int r, RB& rb) {
       const int p0 = d0 - 1 + 2 * r;
+      const bool live = r < nround;
+      const unsigned lm = live ? 0xffffffffu : 0u;
 #pragma unroll
       for (int k = 0; k < NIX; ++k) {
-        const long long po = (long long)min(max(p0 + x_pp[k], 0), D - 1) * hw;
-        xq[k] = *reinterpret_cast<const uint4*>(xsrc + po + x_goff[k]);
+        const long long po = live ? (long long)min(max(p0 + x_pp[k], 0), D - 1) * hw : 0ll;
+        rb.x[k] = *reinterpret_cast<const uint4*>(xsrc + po + (x_goff[k] & lm));
       }
 #pragma unroll
       for (int k = 0; k < NIY; ++k) {
-        const long long po = (long long)min(max(p0 + 1 + y_pp[k], 0), D - 1) * hw;
-        yq[k] = *reinterpret_cast<const uint4*>(ysrc + po + y_goff[k]);
+        const long long po = live ? (long long)min(max(p0 + 1 + y_pp[k], 0), D - 1) * hw : 0ll;
+        rb.y[k] = *reinterpret_cast<const uint4*>(ysrc + po + (y_goff[k] & lm));
       }
     };
-    auto commit = [&](int r) {                           // round r -> slots (2 r) & 3, (2 r + 1) & 3
+    auto commit = [&](int r, const RB& rb) {             // round r -> slots (2 r) & 3, (2 r + 1) & 3
       const int p0 = d0 - 1 + 2 * r;
       unsigned char* dst = smem + ((2 * r) & 3) * Q::SLOT;
 #pragma unroll
@@ -184,7 +192,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
         const float pm = (unsigned)(p0 + x_pp[k]) < (unsigned)D ? 1.f : 0.f;
         const float sc = x_sc[k] * pm, sh = x_sh[k] * pm;
         const f32x2_t sc2 = {sc, sc}, sh2 = {sh, sh};
-        const unsigned u[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
+        const unsigned u[4] = {rb.x[k].x, rb.x[k].y, rb.x[k].z, rb.x[k].w};
         uint4 o;
         unsigned* op = &o.x;
 #pragma unroll
@@ -199,7 +207,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
       for (int k = 0; k < NIY; ++k) {
         // out plane v = p + 1 belongs to this tile when v < d1 (v >= d0 always holds)
         const unsigned am = (p0 + 1 + y_pp[k] < d1) ? 0xffffffffu : 0u;
-        *reinterpret_cast<uint4*>(dst + y_lds[k]) = make_uint4(yq[k].x & am, yq[k].y & am, yq[k].z & am, yq[k].w & am);
+        *reinterpret_cast<uint4*>(dst + y_lds[k]) = make_uint4(rb.y[k].x & am, rb.y[k].y & am, rb.y[k].z & am, rb.y[k].w & am);
       }
     };
     frag8 af_m1[NC], af_0[NC];
@@ -210,7 +218,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
       const unsigned char* bsrc = smem + (b_slot ? s * Q::SLOT : 0) + b_off;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const volatile unsigned* ap = reinterpret_cast<const volatile unsigned*>(src + a_off + c * 64);
+        const unsigned* ap = reinterpret_cast<const unsigned*>(src + a_off + c * 64);
         const unsigned e0 = ap[0], e1 = ap[1], e2 = ap[2], e3 = ap[3], e4 = ap[4];
         const frag8 af_p1 = __builtin_bit_cast(frag8, make_uint4(__builtin_amdgcn_alignbit(e1, e0, a_sh), __builtin_amdgcn_alignbit(e2, e1, a_sh),
                                                                  __builtin_amdgcn_alignbit(e3, e2, a_sh), __builtin_amdgcn_alignbit(e4, e3, a_sh)));
@@ -222,17 +230,25 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
         af_0[c] = af_p1;
       }
     };
-    const int nround = (d1 - d0 + 2 + 1) / 2;            // x planes d0 - 1 .. d1
     __syncthreads();                                     // the previous tile's planes are no longer read (first tile: constants written)
-    issue(0);
-    commit(0);
-    if (nround > 1) issue(1);
-    for (int r = 0; r < nround; ++r) {
-      __syncthreads();                                   // round r staged; round r - 1 fully read
-      step((2 * r) & 3);
-      step((2 * r + 1) & 3);
-      if (r + 1 < nround) commit(r + 1);                 // into the slots of round r - 1 (uniform branches: the loads of a round are
-      if (r + 2 < nround) issue(r + 2);                  // all waited for at its commit anyway)
+#pragma unroll
+    for (int u = 0; u < PD; ++u) issue(u, q[u]);
+    commit(0, q[0]);
+    issue(PD, q[0]);
+    for (int r0 = 0; r0 < nround; r0 += PD) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        const int r = r0 + u;
+        if (r < nround) {                                // uniform
+          __syncthreads();                               // round r staged; round r - 1 fully read
+          step((2 * r) & 3);
+          step((2 * r + 1) & 3);
+        }
+        // round r + 1 into the slots of round r - 1 (a dead round is not committed: past the last barrier its target slots may
+        // still be read); its buffer then takes round r + 1 + PD
+        if (r + 1 < nround) commit(r + 1, q[(u + 1) % PD]);
+        issue(r + 1 + PD, q[(u + 1) % PD]);
+      }
     }
   }   // tiles
 
@@ -272,8 +288,13 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   if (dbp && chunk == 0 && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
 }
 
+// Q5_PD = rounds of loads in flight per thread.  The first version had ONE (128 registers, two workgroups per CU): a round then
+// lasts one memory latency whatever else overlaps -- 16 -> 16 g4 @128^3 60 us, no better than the tile kernel's 58, while 4 -> 4
+// (28 against 38 us) and the 64^3 problems (19 - 35 against 25 - 43 us) already won on their lower instruction count.  Three rounds
+// in 204 registers = ONE workgroup per CU with 3 x 36 KB of loads in flight all the time.
+constexpr int Q5_PD = 3;
 template <int FMT>
-__global__ __launch_bounds__(512, 4) void conv3_wgrad_q5_multi_kernel(const WgQ5Multi m) {
+__global__ __launch_bounds__(512, 2) void conv3_wgrad_q5_multi_kernel(const WgQ5Multi m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   int i = 0;
@@ -283,12 +304,13 @@ __global__ __launch_bounds__(512, 4) void conv3_wgrad_q5_multi_kernel(const WgQ5
   const int local = b - m.off[i];
   const WgQ4& a = m.p[i];
   if (local >= a.nb) return;
-  if (a.W == 128) wgrad_q5_body<FMT, 2>(a, local, smem);
-  else wgrad_q5_body<FMT, 1>(a, local, smem);
+  if (a.W == 128) wgrad_q5_body<FMT, 2, Q5_PD>(a, local, smem);
+  else wgrad_q5_body<FMT, 1, Q5_PD>(a, local, smem);
 }
 
 // Re-plans a quad-channel problem (xh_wgrad_q4_plan has filled `a`) for the full-row kernel; false: it stays with the tile kernel
 int g_q5_on = 1;                                         // xh_set_option(21, 0 / 1)
+int g_q5_wgs = 256;                                      // xh_set_option(22, n): workgroups per launch (one per CU is resident)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
   if ((d->W != 128 && d->W != 64) || d->H % Q5_TH || d->D < 4) return false;
@@ -309,8 +331,9 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   WgQ5Multi m;
   m.n = n;
   m.off[0] = 0;
-  const int budget = 512;                                // resident workgroups: 2 per CU
-  // workgroups per unit in proportion to the unit's voxels; then depth segments so that a workgroup walks ~2 tiles of >= 8 planes
+  extern int g_q5_wgs;
+  const int budget = g_q5_wgs;                           // resident workgroups: 1 per CU
+  // workgroups per unit in proportion to the unit's voxels; then depth segments so that every workgroup of the unit has a tile
   double total = 0.0;
   for (int i = 0; i < n; ++i) total += (double)probs[i].nq * probs[i].N * probs[i].D * probs[i].H * probs[i].W;
   for (int i = 0; i < n; ++i) {
@@ -320,8 +343,7 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
     int w = (int)(budget * share);
     if (w < 1) w = 1;
     const int cols = a.tilesH * a.N;
-    // tiles per unit: at least w (every workgroup busy), segments of >= 8 planes
-    int dsegs = (w + cols - 1) / cols;
+    int dsegs = (w + cols - 1) / cols;                   // tiles per unit: at least w (every workgroup busy), segments of >= 8 planes
     const int max_segs = a.D >= 8 ? a.D / 8 : 1;
     if (dsegs > max_segs) dsegs = max_segs;
     if (dsegs < 1) dsegs = 1;
