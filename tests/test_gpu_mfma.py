@@ -445,7 +445,11 @@ def test_wgrad_quad_channel_kernel_vs_stock(cfg, dtype):
     for pre in (None, (torch.rand(n, cin, device=DEV) + 0.5, torch.randn(n, cin, device=DEV), 0.01)):
         dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
         dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
-        X.ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=pre)
+        X._lib.load().xh_set_option(21, 0)             # H % 8 == 0 cases would take the full-row kernel (tested below)
+        try:
+            X.ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=g, pre=pre)
+        finally:
+            X._lib.load().xh_set_option(21, 1)
         assert "conv3_wgrad_q4_multi_kernel" in X.ops.last_conv_kernel()
         xf = x.float()
         if pre is not None:
@@ -842,11 +846,12 @@ def test_k7_gate_weight_gradient_fp32_storage_on_the_matrix_cores(sp):
 @pytest.mark.parametrize("cfg", [dict(n=2, cin=4, cout=4, g=1, sp=(9, 16, 64)), dict(n=1, cin=16, cout=16, g=4, sp=(21, 8, 128)),
                                  dict(n=1, cin=12, cout=4, g=1, sp=(10, 16, 128), split=4), dict(n=1, cin=24, cout=8, g=1, sp=(6, 8, 64), split=16),
                                  dict(n=2, cin=20, cout=40, g=5, sp=(5, 8, 64)), dict(n=1, cin=8, cout=8, g=8, sp=(12, 24, 128)),
-                                 dict(n=1, cin=4, cout=12, g=1, sp=(4, 8, 128))],
+                                 dict(n=1, cin=4, cout=12, g=1, sp=(4, 8, 128)), dict(n=2, cin=16, cout=32, g=4, sp=(8, 8, 32)),
+                                 dict(n=1, cin=48, cout=16, g=1, sp=(32, 32, 32), split=32), dict(n=1, cin=16, cout=16, g=16, sp=(19, 16, 32))],
                          ids=["4to4_w64_n2", "16to16g4_w128_ragged_segments", "12to4_w128_two_sources", "24to8_w64_two_sources", "20to40g5_w64_n2",
-                              "depthwise8_w128", "4to12_w128_four_planes"])
+                              "depthwise8_w128", "4to12_w128_four_planes", "16to32g4_w32_n2", "48to16_w32_two_sources", "depthwise16_w32"])
 def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
-    """conv3_wgrad_q5_multi_kernel (rows of 64 / 128 voxels, H a multiple of 8: 8-row full-row tiles, dY staged once, the kw shift
+    """conv3_wgrad_q5_multi_kernel (rows of 32 / 64 / 128 voxels, H a multiple of 8: 8-row full-row tiles, dY staged once, the kw shift
     applied at fragment-read time) against conv3_wgrad_q4_multi_kernel (xh_set_option(21, 0)) and torch.nn.grad on the same 16-bit
     inputs: the same products summed in another order (fp32 round-off between the two kernels); batch 2, groups, several input
     quads per group (units that re-stage dY), the skip | x two-source input, depthwise as groups of 4, depth segments that do not
@@ -889,7 +894,8 @@ def test_wgrad_full_row_kernel_batched_128_cubed(dtype):
     volume -- against the same problems through the tile kernel."""
     lib = X._lib.load()
     torch.manual_seed(43)
-    probs = [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (8, 8, 2, 128), (24, 8, 1, 64), (8, 8, 1, 64), (32, 32, 4, 64)]
+    probs = [(16, 16, 4, 128), (12, 4, 1, 128), (4, 4, 1, 128), (8, 8, 2, 128), (24, 8, 1, 64), (8, 8, 1, 64), (32, 32, 4, 64),
+             (16, 16, 4, 128), (12, 4, 1, 128), (48, 16, 1, 32), (16, 16, 1, 32), (40, 80, 5, 32), (20, 40, 5, 64), (8, 8, 8, 64)]
     data = []
     for cin, cout, g, s in probs:
         x = torch.randn(1, cin, s, s, s, device=DEV).to(dtype)

@@ -30,13 +30,16 @@ for (cin, cout, g, S) in shapes:
     L.load().xh_set_option(1, 0); L.load().xh_set_option(21, 1)
     print(line, flush=True)
 # the batch of one step (bench shapes), deferred flush
-allp = [(16, 16, 4, 128), (16, 16, 4, 128), (12, 4, 1, 128), (12, 4, 1, 128), (4, 4, 1, 128), (4, 4, 1, 128), (4, 4, 1, 128),
-        (32, 32, 4, 64), (16, 32, 4, 64), (24, 8, 1, 64), (24, 8, 1, 64), (8, 8, 1, 64), (8, 8, 1, 64), (8, 8, 1, 64), (4, 8, 1, 64)]
+# the 24 quad-channel problems of one 128^3 step (bench.py's roofline object lists them)
+allp = [(8, 8, 2, 128), (4, 4, 4, 128), (4, 4, 1, 128), (4, 4, 1, 128), (16, 16, 4, 128), (16, 16, 4, 128), (12, 4, 1, 128), (12, 4, 1, 128),
+        (8, 8, 8, 64), (20, 40, 5, 64), (20, 20, 5, 64), (16, 16, 2, 64), (8, 8, 1, 64), (8, 8, 1, 64), (24, 8, 1, 64), (24, 8, 1, 64),
+        (16, 16, 16, 32), (32, 32, 2, 32), (16, 16, 1, 32), (16, 16, 1, 32), (40, 80, 5, 32), (40, 40, 5, 32), (48, 16, 1, 32), (48, 16, 1, 32)]
 data = []
 for cin, cout, g, S in allp:
     x = torch.randn(1, cin, S, S, S, device="cuda").bfloat16(); dy = torch.randn(1, cout, S, S, S, device="cuda").bfloat16()
     data.append((x, dy, (torch.rand(1, cin, device="cuda") + 0.5, torch.randn(1, cin, device="cuda"), 0.01), g,
-                 [torch.zeros(cout // g, cin // g, 3, 3, 3, device="cuda") for _ in range(g)], [torch.zeros(cout // g, device="cuda") for _ in range(g)]))
+                 [torch.zeros(cout // (g if g <= 4 else 1), cin // g, 3, 3, 3, device="cuda") for _ in range(g if g <= 4 else 1)],
+                 [torch.zeros(cout // (g if g <= 4 else 1), device="cuda") for _ in range(g if g <= 4 else 1)]))
 def batch():
     ops.set_wgrad_defer(True)
     for x, dy, pre, g, dws, dbs in data:

@@ -420,8 +420,9 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
       // as few launches as the problem table allows, of EQUAL work: in arrival order 17 problems went 8 + 8 + 1, and the last
       // launch -- one 128^3 problem alone on the chip -- took as long as a full one (77 / 152 / 78 us).  Largest first into the
       // currently lightest launch
-      const int L = ((int)cl.size() + WQ_MULTI - 1) / WQ_MULTI;
-      auto cost = [](const WgQ4& w) { return (double)w.N * w.D * w.H * w.W * w.nq * w.ci4; };
+      const int per = full ? Q5_MULTI : WQ_MULTI;
+      const int L = ((int)cl.size() + per - 1) / per;
+      auto cost = [](const WgQ4& w) { return (double)w.N * w.D * w.H * (w.full ? (w.W == 128 ? 128.0 : w.W == 64 ? 90.0 : 70.0) : (double)w.W) * w.nq * w.ci4; };
       std::vector<int> order(cl.size());
       for (size_t i = 0; i < cl.size(); ++i) order[i] = (int)i;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(cl[a]) > cost(cl[b]); });
@@ -430,7 +431,7 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
       for (int idx : order) {
         int best = -1;
         for (int b = 0; b < L; ++b)
-          if ((int)bucket[b].size() < WQ_MULTI && (best < 0 || load[b] < load[best])) best = b;
+          if ((int)bucket[b].size() < per && (best < 0 || load[b] < load[best])) best = b;
         bucket[best].push_back(cl[idx]);
         load[best] += cost(cl[idx]);
       }

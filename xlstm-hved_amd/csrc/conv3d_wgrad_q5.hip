@@ -39,36 +39,38 @@ typedef f32x4_t f32x4;
 
 struct WgQ5Multi {
   int n;
-  int off[WQ_MULTI + 1];
-  WgQ4 p[WQ_MULTI];
+  int off[Q5_MULTI + 1];
+  WgQ4 p[Q5_MULTI];
 };
+static_assert(sizeof(WgQ5Multi) <= 4096, "the problem table travels in the kernel arguments");
 
 namespace {
 constexpr int Q5_TH = 8;                      // rows per tile = waves per workgroup
-template <int NH> struct Q5 {
-  static constexpr int W = 64 * NH;
+template <int NCH> struct Q5 {                // NCH = 32-voxel K chunks per row: rows of 128 | 64 | 32 voxels
+  static constexpr int W = 32 * NCH;
   static constexpr int PR = W / 8;            // 16-byte pieces per row
-  static constexpr int NC = W / 32;           // K chunks per row
+  static constexpr int NC = NCH;
   static constexpr int CP = 2 * W + 16;       // bytes per (row, channel) line of x (16 B spare: bank spreading of the B reads)
   static constexpr int XROW = 4 * CP + 16;    // bytes per staged x row (4 channels)
   static constexpr int XB = (Q5_TH + 2) * XROW;
-  static constexpr int YP = 2 * W + 32;       // bytes per (row, co) line of dY: [16 B zeros][row][16 B zeros]
+  static constexpr int YP = 2 * W + 32;       // bytes per (row, co) line of dY: [16 B zeros][row][16 B zeros]  (2 W + 64, which takes the
+                                              // four co lines of a row to distinct bank groups, measured 7 - 10 % SLOWER: 46.1 -> 49.5 us)
   static constexpr int YB = Q5_TH * 4 * YP;
   static constexpr int SLOT = XB + YB;
   static constexpr int RING = 4 * SLOT;
   static constexpr int CONSTB = RING;         // [16 B of ones][16 B of zeros]
   static constexpr int BYTES = RING + 32;
   static constexpr int NXI = 2 * (Q5_TH + 2) * 4 * PR;   // x items of a round (two planes)
-  static constexpr int NIX = (NXI + 511) / 512;          // per thread: 3 | 2
+  static constexpr int NIX = (NXI + 511) / 512;          // per thread: 3 | 2 | 1
   static constexpr int NYI = 2 * Q5_TH * 4 * PR;         // dY items of a round
-  static constexpr int NIY = NYI / 512;                  // 2 | 1
+  static constexpr int NIY = (NYI + 511) / 512;          // 2 | 1 | 1 (rows of 32 voxels: half the threads)
 };
 }
 
-template <int FMT, int NH, int PD>
+template <int FMT, int NCH, int PD>
 __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned char* smem) {
   typedef h16<FMT> ST;
-  typedef Q5<NH> Q;
+  typedef Q5<NCH> Q;
   constexpr int W = Q::W, PR = Q::PR, NC = Q::NC, NIX = Q::NIX, NIY = Q::NIY;
   constexpr unsigned ONE2 = FMT == 0 ? 0x3F803F80u : 0x3C003C00u;
   float* s_dw = reinterpret_cast<float*>(smem);        // after the plane loops
@@ -125,10 +127,12 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     x_lds[k] = pp * Q::SLOT + r * Q::XROW + c * Q::CP + j * 16;
   }
   int y_lds[NIY], y_pp[NIY];
+  bool y_do[NIY];
   unsigned y_goff[NIY];                                // element offset inside the (sample, output quad) block, row h0 excluded
 #pragma unroll
   for (int k = 0; k < NIY; ++k) {
-    const int it = tid + 512 * k;
+    y_do[k] = tid + 512 * k < Q::NYI;
+    const int it = y_do[k] ? tid + 512 * k : 0;
     const int j = it % PR, co = (it / PR) & 3, r = (it / (4 * PR)) % Q5_TH, pp = it / (4 * PR * Q5_TH);
     y_pp[k] = pp;
     y_lds[k] = pp * Q::SLOT + Q::XB + (r * 4 + co) * Q::YP + 16 + j * 16;
@@ -205,6 +209,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
       }
 #pragma unroll
       for (int k = 0; k < NIY; ++k) {
+        if (!y_do[k]) continue;
         // out plane v = p + 1 belongs to this tile when v < d1 (v >= d0 always holds)
         const unsigned am = (p0 + 1 + y_pp[k] < d1) ? 0xffffffffu : 0u;
         *reinterpret_cast<uint4*>(dst + y_lds[k]) = make_uint4(rb.y[k].x & am, rb.y[k].y & am, rb.y[k].z & am, rb.y[k].w & am);
@@ -299,12 +304,13 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_q5_multi_kernel(const WgQ5
   const int b = blockIdx.x;
   int i = 0;
 #pragma unroll
-  for (int k = 1; k < WQ_MULTI; ++k)
+  for (int k = 1; k < Q5_MULTI; ++k)
     if (k < m.n && b >= m.off[k]) i = k;
   const int local = b - m.off[i];
   const WgQ4& a = m.p[i];
   if (local >= a.nb) return;
-  if (a.W == 128) wgrad_q5_body<FMT, 2, Q5_PD>(a, local, smem);
+  if (a.W == 128) wgrad_q5_body<FMT, 4, Q5_PD>(a, local, smem);
+  else if (a.W == 64) wgrad_q5_body<FMT, 2, Q5_PD>(a, local, smem);
   else wgrad_q5_body<FMT, 1, Q5_PD>(a, local, smem);
 }
 
@@ -313,7 +319,7 @@ int g_q5_on = 1;                                         // xh_set_option(21, 0 
 int g_q5_wgs = 256;                                      // xh_set_option(22, n): workgroups per launch (one per CU is resident)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
-  if ((d->W != 128 && d->W != 64) || d->H % Q5_TH || d->D < 4) return false;
+  if ((d->W != 128 && d->W != 64 && d->W != 32) || d->H % Q5_TH || d->D < 4) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
   if (4 * dhw >= (1ll << 31)) return false;              // 32-bit element offsets inside a channel quad
   a->full = 1;
@@ -326,21 +332,23 @@ bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   return true;                                           // dsegs / sd / ntile / wpu / nb: per launch (xh_wgrad_q5_launch)
 }
 
-// launches up to WQ_MULTI re-planned problems of one storage format
+// launches up to Q5_MULTI re-planned problems of one storage format
 void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   WgQ5Multi m;
   m.n = n;
   m.off[0] = 0;
   extern int g_q5_wgs;
   const int budget = g_q5_wgs;                           // resident workgroups: 1 per CU
-  // workgroups per unit in proportion to the unit's voxels; then depth segments so that every workgroup of the unit has a tile
+  // workgroups per unit in proportion to the unit's ROUNDS (a round = 8 rows x 2 planes; its cost is mostly instruction issue and
+  // grows slowly with the row width: measured ~3 / ~2 us at 128 / 64 voxels), then depth segments so that every workgroup of the
+  // unit has a tile
+  auto ucost = [](const WgQ4& w) { return (double)w.N * w.D * (w.H / Q5_TH) * (w.W == 128 ? 1.0 : w.W == 64 ? 0.7 : 0.55); };
   double total = 0.0;
-  for (int i = 0; i < n; ++i) total += (double)probs[i].nq * probs[i].N * probs[i].D * probs[i].H * probs[i].W;
+  for (int i = 0; i < n; ++i) total += probs[i].nq * ucost(probs[i]);
   for (int i = 0; i < n; ++i) {
     m.p[i] = probs[i];
     WgQ4& a = m.p[i];
-    const double share = (double)a.N * a.D * a.H * a.W / total;      // of one unit
-    int w = (int)(budget * share);
+    int w = (int)(budget * ucost(a) / total + 0.5);
     if (w < 1) w = 1;
     const int cols = a.tilesH * a.N;
     int dsegs = (w + cols - 1) / cols;                   // tiles per unit: at least w (every workgroup busy), segments of >= 8 planes
@@ -358,13 +366,13 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   }
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<2>::BYTES);
-    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<2>::BYTES);
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<4>::BYTES);
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<4>::BYTES);
     attr_done = true;
   }
-  bool any128 = false;
-  for (int i = 0; i < n; ++i) any128 |= probs[i].W == 128;
-  const size_t shm = any128 ? Q5<2>::BYTES : Q5<1>::BYTES;
+  int wmax = 32;
+  for (int i = 0; i < n; ++i) wmax = probs[i].W > wmax ? probs[i].W : wmax;
+  const size_t shm = wmax == 128 ? Q5<4>::BYTES : wmax == 64 ? Q5<2>::BYTES : Q5<1>::BYTES;
   xh_note_kernel("conv3_wgrad_q5_multi_kernel<%d>", fmt);
   if (fmt) hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<1>), dim3(m.off[n]), dim3(512), shm, st, m);
   else hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<0>), dim3(m.off[n]), dim3(512), shm, st, m);

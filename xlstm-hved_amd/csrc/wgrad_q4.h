@@ -24,9 +24,10 @@ struct WgQ4 {
 };
 
 constexpr int WQ_MULTI = 8;         // problems per launch (the table travels in the kernel arguments)
+constexpr int Q5_MULTI = 12;        // the same for the full-row kernel (4 KB of kernel arguments)
 bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgQ4* a);
 void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);
 // conv3d_wgrad_q5.hip: re-plans a planned problem for the full-row kernel (rows of 64 / 128 voxels, 16-bit storage); launch of up to
-// WQ_MULTI such problems of one storage format (xh_wgrad_q4_launch forwards to it)
+// Q5_MULTI such problems of one storage format (xh_wgrad_q4_launch forwards to it)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a);
 void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);
