@@ -867,6 +867,7 @@ def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
         res = {}
         for name, on in (("full", 1), ("tile", 0)):
             lib.xh_set_option(21, on)
+            lib.xh_set_option(23, 1)                   # rows of 32 voxels too (off by default: see conv3d_wgrad_q5.hip)
             try:
                 dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
                 dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
@@ -877,6 +878,7 @@ def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
                 res[name] = (torch.cat(dws, 0).cpu(), torch.cat(dbs, 0).cpu())
             finally:
                 lib.xh_set_option(21, 1)
+                lib.xh_set_option(23, 0)
         xf = x.float()
         if pre is not None:
             xf = torch.nn.functional.leaky_relu(xf * pre[0][:, :, None, None, None] + pre[1][:, :, None, None, None], 0.01).to(dtype).float()

@@ -316,10 +316,15 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_q5_multi_kernel(const WgQ5
 
 // Re-plans a quad-channel problem (xh_wgrad_q4_plan has filled `a`) for the full-row kernel; false: it stays with the tile kernel
 int g_q5_on = 1;                                         // xh_set_option(21, 0 / 1)
+int g_q5_w32 = 0;                                        // xh_set_option(23, 0 / 1): rows of 32 voxels take the full-row kernel too
 int g_q5_wgs = 256;                                      // xh_set_option(22, n): workgroups per launch (one per CU is resident)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
-  if ((d->W != 128 && d->W != 64 && d->W != 32) || d->H % Q5_TH || d->D < 4) return false;
+  extern int g_q5_w32;
+  // rows of 32 voxels (xh_set_option(23, 1)): the instance exists and is tested, but the 32^3 problems of the network are dozens of
+  // units of a few tiles each -- one workgroup per unit and CU leaves most of the launch waiting for them (batch of the step's 24
+  // problems: 433 us with them here, 392 us all on the tile kernel) -- so by default they stay with the tile kernel
+  if ((d->W != 128 && d->W != 64 && !(d->W == 32 && g_q5_w32)) || d->H % Q5_TH || d->D < 4) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
   if (4 * dhw >= (1ll << 31)) return false;              // 32-bit element offsets inside a channel quad
   a->full = 1;
