@@ -1036,12 +1036,12 @@ def roofline_pass(step, ops, nsteps, dtype):
               "timing": "HIP events on the launch stream around each launch of the real step (queued behind a device-side "
                         "delay so launches run back to back as in the graph replay), minus the median empty event pair; weight "
                         "fragments are prepacked once per step (xh_conv3d_prepack), so a bracket holds the conv launch alone"})
-    k7 = {k: v for k, v in agg.items() if "conv7_mfma" in k}
+    k7 = {k: v for k, v in agg.items() if "conv7_mfma" in k or "conv7_as" in k}
     if k7:
         cnt7 = sum(v[0] for v in k7.values())
         ms7 = sum(v[1] for v in k7.values())
         fl7 = sum(v[3] for v in k7.values())
-        r["gate_conv7"] = {"bound": "mfma", "kernel": "conv7_mfma_kernel (AttenModule2's composed 7^3 gate conv, forward + data gradient)",
+        r["gate_conv7"] = {"bound": "mfma", "kernel": "conv7_as_kernel (AttenModule2's composed 7^3 gate conv, forward + data gradient)",
                            "achieved": fl7 / ms7 / 1e9, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": fl7 / ms7 / 1e9 / BF16_MFMA_PEAK_TFLOPS, "launches_per_step": cnt7 / nsteps,
                            "ms_per_step": ms7 / nsteps,

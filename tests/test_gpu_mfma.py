@@ -277,7 +277,7 @@ def test_statistics_fan_in_matches_direct_atomics_and_cleans_up(case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
-@pytest.mark.parametrize("shape", [(1, 4, 12, 20, 32), (2, 4, 9, 16, 64), (1, 4, 5, 7, 32)])
+@pytest.mark.parametrize("shape", [(1, 4, 12, 20, 32), (2, 4, 9, 16, 64), (1, 4, 5, 7, 32), (1, 4, 23, 16, 32), (1, 4, 64, 64, 64)])
 def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape, dtype):
     """AttenModule2's composed 7^3 conv (4 pooled channels -> 2 sigmoid gates) and its data gradient (2 -> 4) on the
     Toeplitz-in-H MFMA kernel, against the vector kernel and stock fp32 ops on the same bf16-representable input."""
@@ -301,7 +301,17 @@ def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape, dtype):
             X.ops.set_mfma(True)
     y1, dx1, dw1, db1, name1 = run(True)
     y0, dx0, dw0, db0, name0 = run(False)
-    assert "conv7_mfma_kernel" in name1 and "conv7_mfma_kernel" not in name0
+    assert "conv7_as_kernel" in name1 and "conv7_" not in name0
+    # the input-stationary kernel (round 5, default) against the output-stationary one it replaces (xh_set_option(24, 0)): the same
+    # products, summed in another order
+    X._lib.load().xh_set_option(24, 0)
+    try:
+        y2, dx2, _, _, name2 = run(True)
+    finally:
+        X._lib.load().xh_set_option(24, 1)
+    assert "conv7_mfma_kernel" in name2
+    tol2 = 4e-3 if dtype == torch.bfloat16 else 5e-4                 # one rounding of the 16-bit outputs
+    assert l2_err(y1, y2) < tol2 and l2_err(dx1, dx2) < tol2, (l2_err(y1, y2), l2_err(dx1, dx2))
     xo, wo, bo = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yo = torch.sigmoid(torch.nn.functional.conv3d(xo, wo, bo, padding=3))
     (yo * g).sum().backward()
@@ -475,7 +485,7 @@ def test_k7_gate_conv_full_size_128_vs_stock(dtype):
     xg = x.to(DEV).requires_grad_(True)
     wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
     y = X.functional.conv(xg, [wg], [bg], act=X.ops.ACT_SIGMOID)
-    assert "conv7_mfma_kernel" in X.ops.last_conv_kernel()
+    assert "conv7_as_kernel" in X.ops.last_conv_kernel()
     (y.float() * g.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     xo, wo, bo = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)

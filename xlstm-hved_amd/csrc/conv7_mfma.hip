@@ -221,6 +221,234 @@ __global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_mfma_kernel(const Conv7
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Input-stationary variant (round 5).  conv7_mfma_kernel above is OUTPUT-plane stationary: for every output plane it re-reads the 7
+// input planes of its depth taps, one A fragment (1 KB per wave) per MFMA plus a B fragment per two -- 1.5 KB of LDS reads per
+// MFMA, i.e. the LDS pipe (128 B / clk / CU) caps the four SIMDs at a third of their matrix rate, and the counters agreed (76 % of
+// wave cycles waiting on LDS, MFMA busy 10.7 %, unchanged for two rounds).  Here
+//   * the INPUT plane is stationary: an A fragment of base plane q is read ONCE and multiplied into the accumulators of all the
+//     output planes it reaches, d = q + 3 - ks PPM (7 for CI = 4; 4 for CI = 2, where an MFMA pairs two depth taps): seven
+//     output planes are in flight per wave, their accumulators rotate through a loop unrolled 7 times (static register indices);
+//   * the B (weight) fragments do not depend on the plane or the column at all: a wave keeps those of ITS input rows in registers
+//     for the whole run (the workgroup's KSPLIT wave pairs split the tile's JR + 6 input rows, not the depth taps);
+//   * so a step is 1 LDS fragment read per 7 (4) MFMAs, and the ring needs the two planes being read plus two incoming: 4 slots.
+// Partial tiles (other wave pairs' rows) meet in LDS when an output plane completes, as before; one barrier per plane.
+// ~220 registers: one workgroup of 8 waves per CU.
+template <int FMT, int CI, int CO, int KSPLIT = 4>
+__global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_as_kernel(const Conv7K a) {
+  typedef h16<FMT> ST;
+  constexpr int PPM = 32 / (8 * CI);
+  constexpr int NKD = (7 + PPM - 1) / PPM;
+  constexpr int JR = 16 / CO;
+  constexpr int RT = 2, TW = 32, MT = 2;
+  constexpr int IH = RT * JR + 6, IWP = TW + 8;
+  constexpr int VB = CI * 2;
+  constexpr int PLANE = IH * IWP * VB;
+  constexpr int NG = TW / 8 + 2;
+  constexpr int NTHR = 128 * KSPLIT;
+  constexpr int NITEM = IH * NG, NIT = (NITEM + NTHR - 1) / NTHR;
+  constexpr int GS = 4 / PPM;
+  constexpr int TBL = 8 * 8 * GS * CO * 16;
+  constexpr int NR = (JR + 6 + KSPLIT - 1) / KSPLIT;  // input rows per wave pair, at most
+  constexpr int NS = 7;                               // output planes in flight
+  constexpr int PART = (KSPLIT - 1) * RT * MT * 4 * 64;   // floats per partial-tile buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_in = smem;                         // 4 * PLANE
+  unsigned char* s_tb = smem + 4 * PLANE;             // TBL
+  float* s_part = reinterpret_cast<float*>(smem + 4 * PLANE + TBL);   // 2 buffers
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & (RT - 1), kq = tid >> 7;
+  const int g4 = lane >> 4, nn = lane & 15;
+  const int n = blockIdx.z;
+  const int D = a.d.D, H = a.d.H, W = a.d.W;
+  const long long hw = (long long)H * W, dhw = (long long)D * hw;
+  int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = wk % a.tilesW; wk /= a.tilesW;
+  const int th = wk % a.tilesH;
+  const int ds = wk / a.tilesH;
+  const int oh0 = th * (RT * JR), ow0 = tw * TW;
+  const int d_begin = ds * a.sd, d_end = min(D, d_begin + a.sd);
+
+  // ---- B table (as in conv7_mfma_kernel) and a zeroed plane ring: a stale slot is read (against zero weights, or into
+  // accumulators that are never stored) and must hold finite values ----
+  {
+    const float* wp = a.p.w[0];
+    for (int idx = tid; idx < 8 * 8 * GS * CO * 8; idx += NTHR) {
+      const int e = idx & 7;
+      int r = idx >> 3;
+      const int co = r % CO; r /= CO;
+      const int gs = r % GS; r /= GS;
+      const int kh = r & 7, kd = r >> 3;
+      const int kw = gs * (8 / CI) + e / CI, ci = e % CI;
+      float v = 0.f;
+      if (kd < 7 && kh < 7 && kw < 7) {
+        const int tap = (kd * 7 + kh) * 7 + kw;
+        v = a.d.transposed ? wp[((long long)ci * CO + co) * 343 + (342 - tap)] : wp[((long long)co * CI + ci) * 343 + tap];
+      }
+      reinterpret_cast<unsigned short*>(s_tb)[idx] = cvt_out<FMT>(v);
+    }
+    for (int i = tid; i < 4 * PLANE / 16; i += NTHR) reinterpret_cast<uint4*>(s_in)[i] = make_uint4(0, 0, 0, 0);
+  }
+  const int jn = nn / CO, con = nn % CO;
+  const int kd_l = PPM == 1 ? 0 : (g4 >> 1);
+  const int gs_l = PPM == 1 ? g4 : (g4 & 1);
+  const int a_col = PPM == 1 ? 2 * g4 : 4 * (g4 & 1);
+  float bias = 0.f;
+  if (a.p.b[0]) bias = a.p.b[0][con];
+
+  // ---- staging plan (as in conv7_mfma_kernel) ----
+  const ST* sp_src[NIT][CI];
+  int sp_lds[NIT], sp_gq[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + it * NTHR;
+    const int gi = item % NG, hy = item / NG;
+    const int gq = gi - 1;
+    const int gh = oh0 - 3 + hy, gw = ow0 + gq * 8;
+    const bool inb = item < NITEM && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+    sp_gq[it] = item < NITEM ? gq : 100;
+    sp_lds[it] = hy * IWP * VB;
+#pragma unroll
+    for (int c = 0; c < CI; ++c)
+      sp_src[it][c] = inb ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw + (long long)gh * W + gw : nullptr;
+  }
+  uint4 raw[NIT][CI];
+  auto load_plane = [&](int gd) {
+    const bool dok = (unsigned)gd < (unsigned)D;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        raw[it][c] = make_uint4(0, 0, 0, 0);
+        if (dok && sp_src[it][c]) raw[it][c] = *reinterpret_cast<const uint4*>(sp_src[it][c] + (long long)gd * hw);
+      }
+  };
+  auto store_plane = [&](int gd) {
+    const int slot = ((gd + 8) & 3) * PLANE;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      unsigned short v[CI][8];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const unsigned u[4] = {raw[it][c].x, raw[it][c].y, raw[it][c].z, raw[it][c].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[c][2 * k] = (unsigned short)(u[k] & 0xffffu); v[c][2 * k + 1] = (unsigned short)(u[k] >> 16); }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int col = sp_gq[it] * 8 + k + 3;
+        if (col >= 0 && col < IWP) {
+          unsigned char* dst = s_in + slot + sp_lds[it] + col * VB;
+          if (CI == 4) {
+            uint2 pk;
+            pk.x = (unsigned)v[0][k] | ((unsigned)v[1][k] << 16);
+            pk.y = (unsigned)v[2][k] | ((unsigned)v[3][k] << 16);
+            *reinterpret_cast<uint2*>(dst) = pk;
+          } else {
+            *reinterpret_cast<unsigned*>(dst) = (unsigned)v[0][k] | ((unsigned)v[1][k] << 16);
+          }
+        }
+      }
+    }
+  };
+  __syncthreads();                                      // table built, ring zeroed
+  // ---- this wave pair's input rows rr = kq, kq + KSPLIT, ... and their B fragments, kept for the whole run ----
+  bf16x8 bfr[NR][NKD];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int rr = kq + i * KSPLIT;
+    const int kh = rr - jn;
+    const int khx = (rr < JR + 6 && (unsigned)kh < 7u) ? kh : 7;       // row 7 of the table is zero
+#pragma unroll
+    for (int ks = 0; ks < NKD; ++ks) {
+      const int kd = ks * PPM + kd_l;
+      bfr[i][ks] = *reinterpret_cast<const bf16x8*>(s_tb + (((kd * 8) + khx) * GS + gs_l) * CO * 16 + con * 16);
+    }
+  }
+  f32x4 acc[NS][MT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: base planes q0, q0 + 1 ----
+  const int q0 = d_begin - 3, nq = (d_end - d_begin) + 6;
+  load_plane(q0); store_plane(q0);
+  load_plane(q0 + 1); store_plane(q0 + 1);
+  __syncthreads();
+  ST* ybase = (ST*)a.p.y + n * a.d.y_bs + (long long)con * dhw;
+  const int oh = oh0 + wv * JR + jn;
+  for (int qq = 0; qq < nq; qq += NS) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int qi = qq + u;
+      if (qi < nq) {                                    // uniform
+        const int q = q0 + qi;
+        load_plane(q + 2);                              // lands behind the MFMAs
+        const unsigned char* pl = s_in + ((q + kd_l + 8) & 3) * PLANE;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int rr = kq + i * KSPLIT;
+          if (rr < JR + 6) {                            // uniform per wave
+            const unsigned char* ar = pl + ((wv * JR + rr) * IWP + nn + a_col) * VB;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const unsigned char* ap = ar + mt * 16 * VB;
+              bf16x8 av;
+              if (CI == 4) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(ap);
+                const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
+                av = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+              } else {
+                const unsigned* a32 = reinterpret_cast<const unsigned*>(ap);
+                av = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
+              }
+#pragma unroll
+              for (int ks = 0; ks < NKD; ++ks) {
+                const int d = q + 3 - ks * PPM;         // the output plane this (base plane, tap step) pair feeds
+                if (d >= d_begin && d < d_end)          // uniform: planes outside the run are not accumulated
+                  acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt] = mfma16x16x32<FMT>(av, bfr[i][ks], acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt]);
+              }
+            }
+          }
+        }
+        // output plane d = q - 3 is complete in slot (u + 4) % NS
+        const int d = q - 3;
+        const bool emit = d >= d_begin;                 // (d < d_end always holds: q <= d_end + 2)
+        float* part = s_part + (qi & 1) * PART;
+        if (emit && kq > 0) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[((((kq - 1) * RT + wv) * MT + mt) * 4 + r) * 64 + lane] = acc[(u + 4) % NS][mt][r];
+        }
+        store_plane(q + 2);
+        __syncthreads();                                // partial tiles visible; plane q + 2 staged; plane q no longer read
+        if (emit && kq == 0) {
+#pragma unroll
+          for (int p_ = 0; p_ < KSPLIT - 1; ++p_)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[(u + 4) % NS][mt][r] += part[(((p_ * RT + wv) * MT + mt) * 4 + r) * 64 + lane];
+          if (oh < H) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              float o[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[(u + 4) % NS][mt][r] + bias, a.d.act, a.d.act_slope);
+              st4(ybase, ((long long)d * H + oh) * W + ow0 + mt * 16 + 4 * g4, o);
+            }
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[(u + 4) % NS][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+}
+
+int g_c7_as = 1;                                       // xh_set_option(24, 0 / 1): conv7_as_kernel (default) / conv7_mfma_kernel
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
@@ -236,7 +464,9 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   a.tilesW = d->W / 32;
   a.tilesH = cdiv(d->H, rows);
   const int cols = a.tilesW * a.tilesH;
-  int dsegs = cdiv(512, cols * d->N);
+  extern int g_c7_as;
+  const bool as = g_c7_as != 0;                        // input-stationary variant (one workgroup per CU): fewer, longer runs
+  int dsegs = cdiv(as ? 256 : 512, cols * d->N);
   // runs of >= 8 planes (6 halo planes are staged per run) -- but on small volumes (<= 64^3) that leaves 8-64 workgroups on
   // 256 CUs and the run time is the serial chain of one workgroup (81 us at 32^3 and 64^3, like 128^3): runs of 2 there
   const int min_run = (long long)d->D * d->H * d->W <= (1 << 18) ? 2 : 8;
@@ -248,6 +478,29 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   dim3 grid(cols * a.dsegs, 1, d->N);
   hipStream_t st = (hipStream_t)stream;
   const int f = d->dtype == XH_F16 ? 1 : 0;
+  if (as) {
+    static bool done_as = false;
+    if (!done_as) {
+      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<1, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<0, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      done_as = true;
+    }
+    const size_t part = (size_t)2 * 3 * 2 * 2 * 4 * 64 * sizeof(float);
+    if (d->Cin == 4) {
+      const size_t shm = (size_t)4 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16 + part;
+      xh_note_kernel("conv7_as_kernel<%d, 4, 2>", f);
+      if (f) hipLaunchKernelGGL((conv7_as_kernel<1, 4, 2>), grid, dim3(512), shm, st, a);
+      else hipLaunchKernelGGL((conv7_as_kernel<0, 4, 2>), grid, dim3(512), shm, st, a);
+    } else {
+      const size_t shm = (size_t)4 * (2 * 4 + 6) * 40 * 4 + 8 * 8 * 2 * 4 * 16 + part;
+      xh_note_kernel("conv7_as_kernel<%d, 2, 4>", f);
+      if (f) hipLaunchKernelGGL((conv7_as_kernel<1, 2, 4>), grid, dim3(512), shm, st, a);
+      else hipLaunchKernelGGL((conv7_as_kernel<0, 2, 4>), grid, dim3(512), shm, st, a);
+    }
+    return xh_launch_status();
+  }
   if (d->Cin == 4) {
     const size_t shm = (size_t)8 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16 + 3 * 2 * 2 * 4 * 64 * sizeof(float);
     static bool done = false;
