@@ -19,5 +19,8 @@ for S in (32, 64, 128):
     L.xh_set_option(24, 0)                            # the output-stationary kernel of rounds 2 - 4
     t_f0 = bench(lambda: ops.conv3d(x, None, [w], [b], k=7, cout=2, act=ops.ACT_SIGMOID))
     t_d0 = bench(lambda: ops.conv3d(dy, None, [w], None, k=7, cout=4, transposed=True))
+    L.xh_set_option(24, 2)                            # input-stationary, weight fragments in registers
+    t_f2 = bench(lambda: ops.conv3d(x, None, [w], [b], k=7, cout=2, act=ops.ACT_SIGMOID))
+    t_d2 = bench(lambda: ops.conv3d(dy, None, [w], None, k=7, cout=4, transposed=True))
     L.xh_set_option(24, 1)
-    print(f"k7 @{S}^3: fwd {t_f:.1f} us (output-stationary {t_f0:.1f}), dgrad {t_d:.1f} us ({t_d0:.1f}), wgrad {t_w:.1f} us", flush=True)
+    print(f"k7 @{S}^3: fwd {t_f:.1f} us (output-stationary {t_f0:.1f}, B in registers {t_f2:.1f}), dgrad {t_d:.1f} us ({t_d0:.1f}, {t_d2:.1f}), wgrad {t_w:.1f} us", flush=True)

@@ -234,8 +234,8 @@ __global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_mfma_kernel(const Conv7
 //   * so a step is 1 LDS fragment read per 7 (4) MFMAs, and the ring needs the two planes being read plus two incoming: 4 slots.
 // Partial tiles (other wave pairs' rows) meet in LDS when an output plane completes, as before; one barrier per plane.
 // ~220 registers: one workgroup of 8 waves per CU.
-template <int FMT, int CI, int CO, int KSPLIT = 4>
-__global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_as_kernel(const Conv7K a) {
+template <int FMT, int CI, int CO, int KSPLIT = 4, bool BREG = false>
+__global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(const Conv7K a) {
   typedef h16<FMT> ST;
   constexpr int PPM = 32 / (8 * CI);
   constexpr int NKD = (7 + PPM - 1) / PPM;
@@ -353,16 +353,19 @@ __global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_as_kernel(const Conv7K 
   };
   __syncthreads();                                      // table built, ring zeroed
   // ---- this wave pair's input rows rr = kq, kq + KSPLIT, ... and their B fragments, kept for the whole run ----
-  bf16x8 bfr[NR][NKD];
+  // BREG: kept in registers for the whole run (112 registers for CI = 4: one workgroup per CU); else re-read from the table per use
+  // (one 16-byte read per two MFMAs, the ring and table of TWO workgroups fit a CU and their phases overlap)
+  bf16x8 bfr[BREG ? NR : 1][BREG ? NKD : 1];
+  int b_off[NR];                                        // table offset of (kd = kd_l, kh = rr - jn); + ks * PPM * 8 * GS * CO * 16 per tap step
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int rr = kq + i * KSPLIT;
     const int kh = rr - jn;
     const int khx = (rr < JR + 6 && (unsigned)kh < 7u) ? kh : 7;       // row 7 of the table is zero
+    b_off[i] = (((kd_l * 8) + khx) * GS + gs_l) * CO * 16 + con * 16;
+    if (BREG) {
 #pragma unroll
-    for (int ks = 0; ks < NKD; ++ks) {
-      const int kd = ks * PPM + kd_l;
-      bfr[i][ks] = *reinterpret_cast<const bf16x8*>(s_tb + (((kd * 8) + khx) * GS + gs_l) * CO * 16 + con * 16);
+      for (int ks = 0; ks < NKD; ++ks) bfr[i][ks] = *reinterpret_cast<const bf16x8*>(s_tb + b_off[i] + ks * PPM * 8 * GS * CO * 16);
     }
   }
   f32x4 acc[NS][MT];
@@ -391,23 +394,28 @@ __global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_as_kernel(const Conv7K 
           const int rr = kq + i * KSPLIT;
           if (rr < JR + 6) {                            // uniform per wave
             const unsigned char* ar = pl + ((wv * JR + rr) * IWP + nn + a_col) * VB;
+            bf16x8 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const unsigned char* ap = ar + mt * 16 * VB;
-              bf16x8 av;
               if (CI == 4) {
                 const uint2 lo = *reinterpret_cast<const uint2*>(ap);
                 const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
-                av = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                av[mt] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
               } else {
                 const unsigned* a32 = reinterpret_cast<const unsigned*>(ap);
-                av = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
+                av[mt] = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
               }
+            }
 #pragma unroll
-              for (int ks = 0; ks < NKD; ++ks) {
-                const int d = q + 3 - ks * PPM;         // the output plane this (base plane, tap step) pair feeds
-                if (d >= d_begin && d < d_end)          // uniform: planes outside the run are not accumulated
-                  acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt] = mfma16x16x32<FMT>(av, bfr[i][ks], acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt]);
+            for (int ks = 0; ks < NKD; ++ks) {
+              const int d = q + 3 - ks * PPM;           // the output plane this (base plane, tap step) pair feeds
+              if (d >= d_begin && d < d_end) {          // uniform: planes outside the run are not accumulated
+                const bf16x8 bv = BREG ? bfr[BREG ? i : 0][BREG ? ks : 0]
+                                       : *reinterpret_cast<const bf16x8*>(s_tb + b_off[i] + ks * PPM * 8 * GS * CO * 16);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                  acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt] = mfma16x16x32<FMT>(av[mt], bv, acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt]);
               }
             }
           }
@@ -448,7 +456,8 @@ __global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_as_kernel(const Conv7K 
   }
 }
 
-int g_c7_as = 1;                                       // xh_set_option(24, 0 / 1): conv7_as_kernel (default) / conv7_mfma_kernel
+int g_c7_as = 1;                                       // xh_set_option(24, v): 0 conv7_mfma_kernel, 1 conv7_as_kernel (weight fragments from LDS,
+                                                       // two workgroups per CU), 2 conv7_as_kernel with the weight fragments in registers
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
@@ -465,8 +474,8 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   a.tilesH = cdiv(d->H, rows);
   const int cols = a.tilesW * a.tilesH;
   extern int g_c7_as;
-  const bool as = g_c7_as != 0;                        // input-stationary variant (one workgroup per CU): fewer, longer runs
-  int dsegs = cdiv(as ? 256 : 512, cols * d->N);
+  const bool as = g_c7_as != 0;                        // input-stationary variant
+  int dsegs = cdiv(g_c7_as == 2 ? 256 : 512, cols * d->N);   // 2: weight fragments in registers, one workgroup per CU
   // runs of >= 8 planes (6 halo planes are staged per run) -- but on small volumes (<= 64^3) that leaves 8-64 workgroups on
   // 256 CUs and the run time is the serial chain of one workgroup (81 us at 32^3 and 64^3, like 128^3): runs of 2 there
   const int min_run = (long long)d->D * d->H * d->W <= (1 << 18) ? 2 : 8;
@@ -481,24 +490,30 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   if (as) {
     static bool done_as = false;
     if (!done_as) {
-      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<1, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<0, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv7_as_kernel<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+#define C7ATTR(F, CI_, CO_)                                                                                                             \
+  (void)hipFuncSetAttribute((const void*)conv7_as_kernel<F, CI_, CO_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);  \
+  (void)hipFuncSetAttribute((const void*)conv7_as_kernel<F, CI_, CO_, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
+      C7ATTR(0, 4, 2); C7ATTR(1, 4, 2); C7ATTR(0, 2, 4); C7ATTR(1, 2, 4);
+#undef C7ATTR
       done_as = true;
     }
     const size_t part = (size_t)2 * 3 * 2 * 2 * 4 * 64 * sizeof(float);
+    const bool breg = g_c7_as == 2;
+#define C7AS(F, CI_, CO_, shm)                                                                                  \
+  do {                                                                                                          \
+    if (breg) hipLaunchKernelGGL((conv7_as_kernel<F, CI_, CO_, 4, true>), grid, dim3(512), shm, st, a);         \
+    else hipLaunchKernelGGL((conv7_as_kernel<F, CI_, CO_, 4, false>), grid, dim3(512), shm, st, a);             \
+  } while (0)
     if (d->Cin == 4) {
       const size_t shm = (size_t)4 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16 + part;
       xh_note_kernel("conv7_as_kernel<%d, 4, 2>", f);
-      if (f) hipLaunchKernelGGL((conv7_as_kernel<1, 4, 2>), grid, dim3(512), shm, st, a);
-      else hipLaunchKernelGGL((conv7_as_kernel<0, 4, 2>), grid, dim3(512), shm, st, a);
+      if (f) C7AS(1, 4, 2, shm); else C7AS(0, 4, 2, shm);
     } else {
       const size_t shm = (size_t)4 * (2 * 4 + 6) * 40 * 4 + 8 * 8 * 2 * 4 * 16 + part;
       xh_note_kernel("conv7_as_kernel<%d, 2, 4>", f);
-      if (f) hipLaunchKernelGGL((conv7_as_kernel<1, 2, 4>), grid, dim3(512), shm, st, a);
-      else hipLaunchKernelGGL((conv7_as_kernel<0, 2, 4>), grid, dim3(512), shm, st, a);
+      if (f) C7AS(1, 2, 4, shm); else C7AS(0, 2, 4, shm);
     }
+#undef C7AS
     return xh_launch_status();
   }
   if (d->Cin == 4) {
