@@ -299,7 +299,11 @@ def test_k7_gate_conv_mfma_vs_vector_vs_stock(shape, dtype):
             return y.detach().float().cpu(), xg.grad.float().cpu(), wg.grad.cpu(), bg.grad.cpu(), name
         finally:
             X.ops.set_mfma(True)
-    y1, dx1, dw1, db1, name1 = run(True)
+    X._lib.load().xh_set_option(24, 3)                 # the input-stationary kernel on every volume (default: >= 2^20 voxels only)
+    try:
+        y1, dx1, dw1, db1, name1 = run(True)
+    finally:
+        X._lib.load().xh_set_option(24, 1)
     y0, dx0, dw0, db0, name0 = run(False)
     assert "conv7_as_kernel" in name1 and "conv7_" not in name0
     # the input-stationary kernel (round 5, default) against the output-stationary one it replaces (xh_set_option(24, 0)): the same

@@ -457,7 +457,8 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
 }
 
 int g_c7_as = 1;                                       // xh_set_option(24, v): 0 conv7_mfma_kernel, 1 conv7_as_kernel (weight fragments from LDS,
-                                                       // two workgroups per CU), 2 conv7_as_kernel with the weight fragments in registers
+                                                       // two workgroups per CU) on volumes of >= 2^20 voxels, 2 the same with the weight
+                                                       // fragments in registers, 3 conv7_as_kernel on every volume (tests)
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
@@ -474,7 +475,12 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   a.tilesH = cdiv(d->H, rows);
   const int cols = a.tilesW * a.tilesH;
   extern int g_c7_as;
-  const bool as = g_c7_as != 0;                        // input-stationary variant
+  // input-stationary variant: measured (tools/microbench_k7.py, bf16) forward / data gradient at 128^3 45.2 / 41.1 us against 50.6 / 43.4
+  // (weight fragments in registers, one workgroup per CU: 48.3 / 51.6), at 64^3 17.8 / 14.0 against 15.3 / 11.2, at 32^3 16.9 / 11.2
+  // against 14.2 / 8.7: runs of 2 planes there stage 8 planes for 2 outputs either way and the longer prologue loses -- so it takes the
+  // volumes of >= 2^20 voxels only.  The LDS traffic per MFMA fell from 1.5 KB to 0.64 KB (0.14 KB with the weights in registers) and the
+  // run time by a tenth: the kernel was never bound by LDS BANDWIDTH but by the read -> MFMA dependency chains of few resident waves.
+  const bool as = g_c7_as != 0 && (g_c7_as > 2 || (long long)d->D * d->H * d->W >= (1 << 20));
   int dsegs = cdiv(g_c7_as == 2 ? 256 : 512, cols * d->N);   // 2: weight fragments in registers, one workgroup per CU
   // runs of >= 8 planes (6 halo planes are staged per run) -- but on small volumes (<= 64^3) that leaves 8-64 workgroups on
   // 256 CUs and the run time is the serial chain of one workgroup (81 us at 32^3 and 64^3, like 128^3): runs of 2 there
