@@ -241,7 +241,7 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
   constexpr int NKD = (7 + PPM - 1) / PPM;
   constexpr int JR = 16 / CO;
   constexpr int RT = 2, TW = 32, MT = 2;
-  constexpr int IH = RT * JR + 6, IWP = TW + 8;
+  constexpr int IH = RT * JR + 6, IWP = TW + 16;      // tile columns = the aligned 8-voxel groups [ow0 - 8, ow0 + TW + 8): column 0 = ow0 - 8
   constexpr int VB = CI * 2;
   constexpr int PLANE = IH * IWP * VB;
   constexpr int NG = TW / 8 + 2;
@@ -296,58 +296,49 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
   float bias = 0.f;
   if (a.p.b[0]) bias = a.p.b[0][con];
 
-  // ---- staging plan (as in conv7_mfma_kernel) ----
-  const ST* sp_src[NIT][CI];
-  int sp_lds[NIT], sp_gq[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int item = tid + it * NTHR;
-    const int gi = item % NG, hy = item / NG;
-    const int gq = gi - 1;
-    const int gh = oh0 - 3 + hy, gw = ow0 + gq * 8;
-    const bool inb = item < NITEM && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
-    sp_gq[it] = item < NITEM ? gq : 100;
-    sp_lds[it] = hy * IWP * VB;
-#pragma unroll
-    for (int c = 0; c < CI; ++c)
-      sp_src[it][c] = inb ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c * dhw + (long long)gh * W + gw : nullptr;
-  }
-  uint4 raw[NIT][CI];
+  // ---- staging: item = (tile row, aligned 8-voxel group) x CI channels: CI 16-byte loads from clamped addresses, zeroed by a mask
+  // when the row / group / plane is outside the volume, interleaved channels-last with v_perm and written as 64 (32) contiguous
+  // bytes.  (conv7_mfma_kernel unpacks to 16-bit values and writes voxel by voxel under a column test: ~180 vector instructions per
+  // item, executed by all 8 waves for the 132 items of a plane -- SQ_INSTS_VALU 10.5 M per launch against 1.6 M MFMAs.)
+  static_assert(NIT == 1, "one item per thread");
+  const bool has_item = tid < NITEM;
+  const int s_gi = (has_item ? tid : 0) % NG, s_hy = (has_item ? tid : 0) / NG;
+  const int s_gh = oh0 - 3 + s_hy, s_gw = ow0 + (s_gi - 1) * 8;
+  const bool s_inb = has_item && (unsigned)s_gh < (unsigned)H && s_gw >= 0 && s_gw < W;
+  const ST* s_src = (const ST*)a.p.xa + n * a.d.xa_bs + (long long)min(max(s_gh, 0), H - 1) * W + min(max(s_gw, 0), W - 8);
+  const int s_lds = (s_hy * IWP + s_gi * 8) * VB;
+  uint4 raw[CI];
   auto load_plane = [&](int gd) {
-    const bool dok = (unsigned)gd < (unsigned)D;
+    const long long po = (long long)min(max(gd, 0), D - 1) * hw;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it)
-#pragma unroll
-      for (int c = 0; c < CI; ++c) {
-        raw[it][c] = make_uint4(0, 0, 0, 0);
-        if (dok && sp_src[it][c]) raw[it][c] = *reinterpret_cast<const uint4*>(sp_src[it][c] + (long long)gd * hw);
-      }
+    for (int c = 0; c < CI; ++c) raw[c] = *reinterpret_cast<const uint4*>(s_src + (long long)c * dhw + po);
   };
   auto store_plane = [&](int gd) {
-    const int slot = ((gd + 8) & 3) * PLANE;
+    if (!has_item) return;
+    const unsigned m = (s_inb && (unsigned)gd < (unsigned)D) ? 0xffffffffu : 0u;
+    unsigned char* dst = s_in + ((gd + 8) & 3) * PLANE + s_lds;
+    if (CI == 4) {
+      const unsigned u[4][4] = {{raw[0].x, raw[0].y, raw[0].z, raw[0].w}, {raw[1].x, raw[1].y, raw[1].z, raw[1].w},
+                                {raw[2].x, raw[2].y, raw[2].z, raw[2].w}, {raw[3].x, raw[3].y, raw[3].z, raw[3].w}};
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      unsigned short v[CI][8];
-#pragma unroll
-      for (int c = 0; c < CI; ++c) {
-        const unsigned u[4] = {raw[it][c].x, raw[it][c].y, raw[it][c].z, raw[it][c].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[c][2 * k] = (unsigned short)(u[k] & 0xffffu); v[c][2 * k + 1] = (unsigned short)(u[k] >> 16); }
+      for (int k2 = 0; k2 < 4; ++k2) {                  // voxels 2 k2, 2 k2 + 1: [c0 c1 | c2 c3] each
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(u[1][k2], u[0][k2], 0x05040100u) & m;
+        o.y = __builtin_amdgcn_perm(u[3][k2], u[2][k2], 0x05040100u) & m;
+        o.z = __builtin_amdgcn_perm(u[1][k2], u[0][k2], 0x07060302u) & m;
+        o.w = __builtin_amdgcn_perm(u[3][k2], u[2][k2], 0x07060302u) & m;
+        *reinterpret_cast<uint4*>(dst + k2 * 16) = o;
       }
+    } else {
+      const unsigned u0[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w}, u1[4] = {raw[1].x, raw[1].y, raw[1].z, raw[1].w};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int col = sp_gq[it] * 8 + k + 3;
-        if (col >= 0 && col < IWP) {
-          unsigned char* dst = s_in + slot + sp_lds[it] + col * VB;
-          if (CI == 4) {
-            uint2 pk;
-            pk.x = (unsigned)v[0][k] | ((unsigned)v[1][k] << 16);
-            pk.y = (unsigned)v[2][k] | ((unsigned)v[3][k] << 16);
-            *reinterpret_cast<uint2*>(dst) = pk;
-          } else {
-            *reinterpret_cast<unsigned*>(dst) = (unsigned)v[0][k] | ((unsigned)v[1][k] << 16);
-          }
-        }
+      for (int h2 = 0; h2 < 2; ++h2) {                  // voxels 4 h2 .. 4 h2 + 3: [c0 c1] each
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(u1[2 * h2], u0[2 * h2], 0x05040100u) & m;
+        o.y = __builtin_amdgcn_perm(u1[2 * h2], u0[2 * h2], 0x07060302u) & m;
+        o.z = __builtin_amdgcn_perm(u1[2 * h2 + 1], u0[2 * h2 + 1], 0x05040100u) & m;
+        o.w = __builtin_amdgcn_perm(u1[2 * h2 + 1], u0[2 * h2 + 1], 0x07060302u) & m;
+        *reinterpret_cast<uint4*>(dst + h2 * 16) = o;
       }
     }
   };
@@ -356,6 +347,7 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
   // BREG: kept in registers for the whole run (112 registers for CI = 4: one workgroup per CU); else re-read from the table per use
   // (one 16-byte read per two MFMAs, the ring and table of TWO workgroups fit a CU and their phases overlap)
   bf16x8 bfr[BREG ? NR : 1][BREG ? NKD : 1];
+  const int z_off = (7 * GS + gs_l) * CO * 16 + con * 16;  // (kd 0, kh 7): a zero row of the table
   int b_off[NR];                                        // table offset of (kd = kd_l, kh = rr - jn); + ks * PPM * 8 * GS * CO * 16 per tap step
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
@@ -393,7 +385,7 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
         for (int i = 0; i < NR; ++i) {
           const int rr = kq + i * KSPLIT;
           if (rr < JR + 6) {                            // uniform per wave
-            const unsigned char* ar = pl + ((wv * JR + rr) * IWP + nn + a_col) * VB;
+            const unsigned char* ar = pl + ((wv * JR + rr) * IWP + nn + a_col + 5) * VB;   // column 0 = ow0 - 8; tap kw reads ow - 3 + kw
             bf16x8 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -410,13 +402,14 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
 #pragma unroll
             for (int ks = 0; ks < NKD; ++ks) {
               const int d = q + 3 - ks * PPM;           // the output plane this (base plane, tap step) pair feeds
-              if (d >= d_begin && d < d_end) {          // uniform: planes outside the run are not accumulated
-                const bf16x8 bv = BREG ? bfr[BREG ? i : 0][BREG ? ks : 0]
-                                       : *reinterpret_cast<const bf16x8*>(s_tb + b_off[i] + ks * PPM * 8 * GS * CO * 16);
+              // planes outside the run take the table's ZERO row instead of a branch around the MFMA (the branches -- 56 per plane --
+              // kept the compiler from issuing the fragment reads ahead of their MFMAs)
+              const bool live = d >= d_begin && d < d_end;
+              const bf16x8 bv = BREG ? (live ? bfr[BREG ? i : 0][BREG ? ks : 0] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0})
+                                     : *reinterpret_cast<const bf16x8*>(s_tb + (live ? b_off[i] + ks * PPM * 8 * GS * CO * 16 : z_off));
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                  acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt] = mfma16x16x32<FMT>(av[mt], bv, acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt]);
-              }
+              for (int mt = 0; mt < MT; ++mt)
+                acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt] = mfma16x16x32<FMT>(av[mt], bv, acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt]);
             }
           }
         }
@@ -511,11 +504,11 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     else hipLaunchKernelGGL((conv7_as_kernel<F, CI_, CO_, 4, false>), grid, dim3(512), shm, st, a);             \
   } while (0)
     if (d->Cin == 4) {
-      const size_t shm = (size_t)4 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16 + part;
+      const size_t shm = (size_t)4 * (2 * 8 + 6) * 48 * 8 + 8 * 8 * 4 * 2 * 16 + part;
       xh_note_kernel("conv7_as_kernel<%d, 4, 2>", f);
       if (f) C7AS(1, 4, 2, shm); else C7AS(0, 4, 2, shm);
     } else {
-      const size_t shm = (size_t)4 * (2 * 4 + 6) * 40 * 4 + 8 * 8 * 2 * 4 * 16 + part;
+      const size_t shm = (size_t)4 * (2 * 4 + 6) * 48 * 4 + 8 * 8 * 2 * 4 * 16 + part;
       xh_note_kernel("conv7_as_kernel<%d, 2, 4>", f);
       if (f) C7AS(1, 2, 4, shm); else C7AS(0, 2, 4, shm);
     }
