@@ -474,7 +474,7 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   // volumes of >= 2^20 voxels only.  The LDS traffic per MFMA fell from 1.5 KB to 0.64 KB (0.14 KB with the weights in registers) and the
   // run time by a tenth: the kernel was never bound by LDS BANDWIDTH but by the read -> MFMA dependency chains of few resident waves.
   const bool as = g_c7_as != 0 && (g_c7_as > 2 || (long long)d->D * d->H * d->W >= (1 << 20));
-  int dsegs = cdiv(g_c7_as == 2 ? 256 : 512, cols * d->N);   // 2: weight fragments in registers, one workgroup per CU
+  int dsegs = cdiv(as && (g_c7_as == 2 || d->Cin == 4) ? 256 : 512, cols * d->N);   // weight fragments in registers: one workgroup per CU
   // runs of >= 8 planes (6 halo planes are staged per run) -- but on small volumes (<= 64^3) that leaves 8-64 workgroups on
   // 256 CUs and the run time is the serial chain of one workgroup (81 us at 32^3 and 64^3, like 128^3): runs of 2 there
   const int min_run = (long long)d->D * d->H * d->W <= (1 << 18) ? 2 : 8;
@@ -497,7 +497,9 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
       done_as = true;
     }
     const size_t part = (size_t)2 * 3 * 2 * 2 * 4 * 64 * sizeof(float);
-    const bool breg = g_c7_as == 2;
+    // measured at 128^3 (after the staging rewrite): forward (CI = 4) 42.9 us with the weight fragments in registers, 46.7 from the table,
+    // 49.3 output-stationary; data gradient (CI = 2) 43.9 / 37.4 / 44.1
+    const bool breg = g_c7_as == 2 || (g_c7_as == 1 && d->Cin == 4);
 #define C7AS(F, CI_, CO_, shm)                                                                                  \
   do {                                                                                                          \
     if (breg) hipLaunchKernelGGL((conv7_as_kernel<F, CI_, CO_, 4, true>), grid, dim3(512), shm, st, a);         \
