@@ -16,6 +16,8 @@
 //     up to 18 MFMAs; same products in the same order as conv3_q4_kernel: the outputs are BIT-IDENTICAL;
 //   * LDS image [plane][row][66 slots of 16 bytes] (slot = 2 voxels x 4 channels + two padding slots), slots and the lane -> quad
 //     assignment permuted so that both the staging writes and the fragment reads are bank-conflict free (q4w_slot below).
+// (Measured and dropped, round 5: requesting the EPI == 1 operand in front of the last matrix phase instead of at the start of the
+// epilogue -- 16 more live registers, 128 with 4 spilled: 16 -> 16 g4 data gradient 49.4 -> 57.1 us, 4 -> 4 16.8 -> 18.8, 12 -> 4 38.4 -> 44.5.)
 // (Measured and dropped: 2 output planes per tile on launches of at most one resident round -- twice the workgroups, but the D halo
 // goes from 1.5 to 2 staged planes per output plane: 4 -> 4 @128^3 16.0 -> 19.9 us, 12 -> 4 30.8 -> 37.2, 8 -> 8 @64^3 9.8 -> 13.0.)
 // Same template axes as conv3_q4_kernel except: no activation epilogue, no norm-backward-on-load (pre == 2 lives on tensors below

@@ -526,11 +526,26 @@ class AbstractFusion3DUNet(nn.Module):
             zml = Fn.PoEAll.apply(keep, tuple(self.MVAE_latents[:nlev]), bool(instance_missing), nlev, *feat_list, *epss)
         else:
             zml = [t for l in range(nlev) for t in Fn.PoE.apply(feat_list[l], keep, epss[l], self.MVAE_latents[l], bool(instance_missing))]
+        side = None
+        if ops.LEVEL_STREAMS[0] and x.is_cuda and nlev > 1:
+            pool = self.__dict__.setdefault("_level_streams", {}).setdefault(x.device, [])
+            while len(pool) < nlev - 1:
+                pool.append(torch.cuda.Stream(x.device))
+            side, cur = pool[:nlev - 1], torch.cuda.current_stream(x.device)
         for level in range(nlev):
             z, mu, lv = zml[3 * level:3 * level + 3]
-            z = self.VU_blocks[level][0](z, up2x=True)                                      # RA_HVED.py:599-601 (conv block + 2x upsampling)
-            z = self.conv_blocks[level](z)                                                  # RA_HVED.py:603
+            st = side[level - 1] if side is not None and level >= 1 else None
+            if st is not None:
+                st.wait_stream(cur)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                z = self.VU_blocks[level][0](z, up2x=True)                                  # RA_HVED.py:599-601 (conv block + 2x upsampling)
+                z = self.conv_blocks[level](z)                                              # RA_HVED.py:603
+            if st is not None:
+                z.record_stream(cur)
             outs[level] = (z, mu, lv)
+        if side is not None:
+            for st in side:
+                cur.wait_stream(st)
         for z, mu, lv in outs:
             mu_list.append(mu)
             logvar_list.append(lv)

@@ -359,6 +359,15 @@ def _check_weights(weights, biases, cin, cout, groups, k, transposed, what):
 PAIR = [os.environ.get("XH_NO_PAIR", "") == ""]             # A/B switch: the decoder's recon | seg pair launches (model._forward_pair)
 
 
+LEVEL_STREAMS = [False]
+
+
+def set_level_streams(enabled):
+    """A/B switch: the three coarse latent-path chains (PoE output -> VU block -> upsampling -> conv block, RA_HVED.py:599-603) on
+    side streams next to the finest one (they are independent of each other until the decoders)."""
+    LEVEL_STREAMS[0] = bool(enabled)
+
+
 def set_pair(enabled):
     PAIR[0] = bool(enabled)
 
