@@ -306,6 +306,40 @@ int xh_upsample2x_bwd_act_reduce(void* stream, int dtype, const void* dy, long l
                                  int D, int H, int W, const void* y0, long long y0_bs, const float* sc, const float* sh,
                                  float slope, double* red);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-problem launches of the five passes of the latent path (RA_HVED.py:599-603: per fusion level PoE output -> BasicConv 1x1
+ * -> 2x upsampling -> BasicConv depthwise 3^3).  The four levels are independent of each other and, except the finest, far too
+ * small to fill the chip: a launch of 4 - 64 workgroups costs its ~5 us of dispatch whatever it holds.  Each entry point below runs
+ * the SAME pass for up to XH_LEVELS_MAX problems in ONE launch (a table of per-problem arguments travels in the kernel arguments;
+ * a workgroup finds its problem from its index).  Semantics per problem = the single-problem entry point named in the struct; the
+ * results are the same bits (same kernel bodies, same per-problem grids).  All problems of a call share dtype.  Returns 1 with
+ * nothing launched when a problem's layout is not taken by the kernel the pass uses (then: the single-problem calls).
+ * ------------------------------------------------------------------------------------------------ */
+#define XH_LEVELS_MAX 4
+typedef struct {                 /* xh_in_affine_act */
+  const void* x; long long x_bs; void* y; long long y_bs; int N, C; long long DHW; const double* red; int act; float slope;
+  float *sc, *sh, *mean, *rstd;
+} xh_in_affine_act_args;
+typedef struct {                 /* xh_act_bwd_reduce */
+  const void* dy; long long dy_bs; const void* x; long long x_bs; int N, C; long long DHW; const float *sc, *sh; float slope; double* red;
+} xh_act_bwd_reduce_args;
+typedef struct {                 /* xh_in_bwd_apply */
+  const void* dy; long long dy_bs; const void* x; long long x_bs; void* dx; long long dx_bs; int N, C; long long DHW; const double* red;
+  const float *mean, *rstd; int stat_rs, have_g; const float *sc, *sh; float slope; int accumulate;
+} xh_in_bwd_apply_args;
+typedef struct {                 /* xh_upsample2x_in_act_fwd */
+  const void* x; long long x_bs; void* y; long long y_bs; int N, C, D, H, W; const double* red; float slope; float *sc, *sh, *mean, *rstd;
+} xh_upsample2x_in_act_args;
+typedef struct {                 /* xh_upsample2x_bwd_act_reduce */
+  const void* dy; long long dy_bs; void* dx; long long dx_bs; int N, C, D, H, W; const void* y0; long long y0_bs; const float *sc, *sh;
+  float slope; double* red;
+} xh_upsample2x_bwd_act_reduce_args;
+int xh_in_affine_act_multi(void* stream, int dtype, int n, const xh_in_affine_act_args* a);
+int xh_act_bwd_reduce_multi(void* stream, int dtype, int n, const xh_act_bwd_reduce_args* a);
+int xh_in_bwd_apply_multi(void* stream, int dtype, int n, const xh_in_bwd_apply_args* a);
+int xh_upsample2x_in_act_multi(void* stream, int dtype, int n, const xh_upsample2x_in_act_args* a);
+int xh_upsample2x_bwd_act_reduce_multi(void* stream, int dtype, int n, const xh_upsample2x_bwd_act_reduce_args* a);
+
 /* generic elementwise helpers */
 /* y = a + b  (b may be NULL: copy) with independent batch strides */
 int xh_add(void* stream, int dtype, const void* a, long long a_bs, const void* b, long long b_bs, void* y,

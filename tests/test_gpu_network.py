@@ -951,3 +951,40 @@ def test_skip_stream_as_fifth_group_equals_the_separate_skip_encoder(dtype, size
           f"difference {worst:.2e} ({wk}), BatchNorm buffers {bworst:.2e}")
     assert worst <= (5e-5 if dtype == torch.float32 else 0.2), (wk, worst)
     assert bworst <= (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("size,n", [(32, 2), (64, 1)])
+def test_latent_path_multi_launches_equal_the_per_level_nodes(dtype, size, n):
+    """Fn.LatentPath (the latent path of the four fusion levels as one autograd node; its element-wise passes -- norm + activation
+    inside the upsampling, the conv block's norm + activation, the activation-masked sums, both InstanceNorm backward passes, the
+    upsampling adjoint -- as ONE multi-problem launch each, xh_*_multi) against the two ConvInLrelu nodes per level
+    (functional.set_latent_batch(False)).  The multi kernels run the per-problem kernel BODIES at the per-problem grids: forward
+    outputs must be bit-identical; parameter gradients agree to the order of the fp64 / fp32 atomics."""
+    torch.manual_seed(47)
+    x = torch.rand(n, 4, size, size, size)
+    eps = [torch.randn(n, 2 ** l, size >> (l + 1), size >> (l + 1), size >> (l + 1)) for l in range(4)]
+    scale_l = 1024.0 if dtype == torch.float16 else 1.0
+    res = []
+    for on in (False, True):
+        X.functional.set_latent_batch(on)
+        try:
+            m = _model(True)
+            seg, (mu, lv), rec = m(x.to(DEV, dtype), [14], recon=True, eps_list=eps)
+            loss = (seg.float() * rnd(seg.shape, 310).to(DEV)).mean() + (rec[0].float() * rnd(rec[0].shape, 311).to(DEV)).mean()
+            for a_, b_ in zip(mu, lv):
+                loss = loss + a_.float().mean() + b_.float().mean()
+            (loss * scale_l).backward()
+            X.ops.join_wgrad_stream()
+            torch.cuda.synchronize()
+            res.append((seg.detach().clone(), rec[0].detach().clone(),
+                        {k: p.grad.clone() / scale_l for k, p in m.named_parameters() if p.grad is not None}))
+        finally:
+            X.functional.set_latent_batch(True)
+    (sa, ra, ga), (sb, rb, gb) = res
+    assert torch.equal(sa, sb) and torch.equal(ra, rb)
+    assert ga.keys() == gb.keys()
+    scale = max(v.abs().max().item() for v in ga.values())
+    wk, worst = max(((k, (ga[k] - gb[k]).abs().max().item() / scale) for k in ga), key=lambda t: t[1])
+    print(f"latent path, multi launches vs per-level nodes ({dtype}, {n}x{size}^3): worst parameter-gradient difference {worst:.2e} ({wk})")
+    assert worst <= (5e-5 if dtype == torch.float32 else 0.2), (wk, worst)

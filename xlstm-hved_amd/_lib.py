@@ -67,6 +67,35 @@ class HeadJob(C.Structure):        # == xh_head_job
                 ("dbs", vp), ("gw", vp), ("gb", vp), ("Co", C.c_int), ("Cm", C.c_int), ("Ci", C.c_int)]
 
 
+MULTI_MAX = 4         # == XH_LEVELS_MAX
+
+
+class InAffineActArgs(C.Structure):          # == xh_in_affine_act_args
+    _fields_ = [("x", vp), ("x_bs", ll), ("y", vp), ("y_bs", ll), ("N", C.c_int), ("C", C.c_int), ("DHW", ll), ("red", vp),
+                ("act", C.c_int), ("slope", C.c_float), ("sc", vp), ("sh", vp), ("mean", vp), ("rstd", vp)]
+
+
+class ActBwdReduceArgs(C.Structure):         # == xh_act_bwd_reduce_args
+    _fields_ = [("dy", vp), ("dy_bs", ll), ("x", vp), ("x_bs", ll), ("N", C.c_int), ("C", C.c_int), ("DHW", ll), ("sc", vp), ("sh", vp),
+                ("slope", C.c_float), ("red", vp)]
+
+
+class InBwdApplyArgs(C.Structure):           # == xh_in_bwd_apply_args
+    _fields_ = [("dy", vp), ("dy_bs", ll), ("x", vp), ("x_bs", ll), ("dx", vp), ("dx_bs", ll), ("N", C.c_int), ("C", C.c_int), ("DHW", ll),
+                ("red", vp), ("mean", vp), ("rstd", vp), ("stat_rs", C.c_int), ("have_g", C.c_int), ("sc", vp), ("sh", vp),
+                ("slope", C.c_float), ("accumulate", C.c_int)]
+
+
+class Upsample2xInActArgs(C.Structure):      # == xh_upsample2x_in_act_args
+    _fields_ = [("x", vp), ("x_bs", ll), ("y", vp), ("y_bs", ll), ("N", C.c_int), ("C", C.c_int), ("D", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("red", vp), ("slope", C.c_float), ("sc", vp), ("sh", vp), ("mean", vp), ("rstd", vp)]
+
+
+class Upsample2xBwdArgs(C.Structure):        # == xh_upsample2x_bwd_act_reduce_args
+    _fields_ = [("dy", vp), ("dy_bs", ll), ("dx", vp), ("dx_bs", ll), ("N", C.c_int), ("C", C.c_int), ("D", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("y0", vp), ("y0_bs", ll), ("sc", vp), ("sh", vp), ("slope", C.c_float), ("red", vp)]
+
+
 VIL_FIELDS = ["norm_w", "proj_up", "conv_w", "conv_b", "q_w", "k_w", "v_w", "ig_w", "ig_b", "fg_w", "fg_b",
               "outnorm_w", "skip", "proj_down"]
 
@@ -112,6 +141,11 @@ SIGNATURES = {
     "xh_upsample_trilinear_bwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, I, I, I, I]),
     "xh_upsample2x_in_act_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, vp, F, vp, vp, vp, vp]),
     "xh_upsample2x_bwd_act_reduce": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, vp, ll, vp, vp, F, vp]),
+    "xh_in_affine_act_multi": (I, [vp, I, I, vp]),
+    "xh_act_bwd_reduce_multi": (I, [vp, I, I, vp]),
+    "xh_in_bwd_apply_multi": (I, [vp, I, I, vp]),
+    "xh_upsample2x_in_act_multi": (I, [vp, I, I, vp]),
+    "xh_upsample2x_bwd_act_reduce_multi": (I, [vp, I, I, vp]),
     "xh_add": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, ll]),
     "xh_act_bwd": (I, [vp, I, vp, vp, vp, ll, I]),
     "xh_poe_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll, I]),

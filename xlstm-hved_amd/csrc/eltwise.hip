@@ -198,10 +198,11 @@ struct AffFin {
   // two BatchNorm modules over one tensor (xh_bn_affine_act2): channels >= chalf take the second parameter set, indexed from 0
   int chalf; const float* gamma2; const float* beta2; float* running_mean2; float* running_var2;
 };
+// (kernel bodies that also run inside a multi-problem launch -- "multi kernels" at the end of this file -- take the block
+// coordinates as PARAMETERS named like the built-ins, so the same text serves both)
 template <typename T, bool VEC>
-__global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
-                                                             long long dhw, const float* sc, const float* sh, int act,
-                                                             float slope, const AffFin f) {
+__device__ __forceinline__ void affine_act_body(const uint3 blockIdx, const uint3 gridDim, const T* x, long long x_bs, T* y, long long y_bs, int C,
+                                                long long dhw, const float* sc, const float* sh, int act, float slope, const AffFin& f) {
   float a, b;
   const int cc = blockIdx.y;
   const long long nc = (long long)blockIdx.z * C + cc;
@@ -253,6 +254,12 @@ __global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long l
     for (int i = 0; i < VW; ++i) v[i] = apply_act(v[i] * a + b, act, slope);
     strow<VEC>(yp, q, valid, v);
   ROW_LOOP_END
+}
+template <typename T, bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void affine_act_kernel(const T* x, long long x_bs, T* y, long long y_bs, int C,
+                                                             long long dhw, const float* sc, const float* sh, int act,
+                                                             float slope, const AffFin f) {
+  affine_act_body<T, VEC>(uint3{blockIdx.x, blockIdx.y, blockIdx.z}, uint3{gridDim.x, gridDim.y, gridDim.z}, x, x_bs, y, y_bs, C, dhw, sc, sh, act, slope, f);
 }
 
 static int launch_affine_act(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N, int C, long long DHW,
@@ -317,9 +324,9 @@ extern "C" int xh_bn_affine_act2(void* stream, int dtype, int mode, const void* 
 
 // ---------------------------------------------------------------------------------------- act/norm backward
 template <typename T, bool VEC>
-__global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
-                                                                 int C, long long dhw, const float* sc, const float* sh,
-                                                                 float slope, double* red) {
+__device__ __forceinline__ void act_bwd_reduce_body(const uint3 blockIdx, const uint3 gridDim, const T* dy, long long dy_bs, const T* x,
+                                                    long long x_bs, int C, long long dhw, const float* sc, const float* sh, float slope,
+                                                    double* red) {
   __shared__ double s_red[4 * 2];
   const float a = sc[blockIdx.z * C + blockIdx.y], b = sh[blockIdx.z * C + blockIdx.y];
   double s[2] = {0.0, 0.0};
@@ -339,6 +346,12 @@ __global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_kernel(const T* dy, l
   ROW_LOOP_END
   block_sum_d<2>(s, s_red, EW_BLOCK >> 6);
   if (threadIdx.x < 2) atomicAdd(&red[((long long)blockIdx.z * C + blockIdx.y) * 2 + threadIdx.x], s_red[threadIdx.x]);
+}
+template <typename T, bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
+                                                                 int C, long long dhw, const float* sc, const float* sh,
+                                                                 float slope, double* red) {
+  act_bwd_reduce_body<T, VEC>(uint3{blockIdx.x, blockIdx.y, blockIdx.z}, uint3{gridDim.x, gridDim.y, gridDim.z}, dy, dy_bs, x, x_bs, C, dhw, sc, sh, slope, red);
 }
 
 extern "C" int xh_act_bwd_reduce(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs,
@@ -537,12 +550,11 @@ extern "C" int xh_norm_bwd_fused2(void* stream, int dtype, int mode, const void*
 // raw fp64 sums (sum g, sum g*x), mean and rstd -- a handful of flops -- so the one-block coefficient launch disappears.
 // The statistics arrays may be wider than this tensor's channel count (virtual concat): row stride `stat_rs`.
 template <typename T, bool VEC>
-__global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
-                                                               T* dx, long long dx_bs, int C, long long dhw,
-                                                               const double* red, const float* mean, const float* rstd,
-                                                               int stat_rs, double count, int have_g, const float* sc,
-                                                               const float* sh, float slope, int accumulate, const T* xb,
-                                                               long long xb_bs, T* dxb, long long dxb_bs, int ca) {
+__device__ __forceinline__ void in_bwd_apply_body(const uint3 blockIdx, const uint3 gridDim, const T* dy, long long dy_bs, const T* x,
+                                                  long long x_bs, T* dx, long long dx_bs, int C, long long dhw, const double* red,
+                                                  const float* mean, const float* rstd, int stat_rs, double count, int have_g,
+                                                  const float* sc, const float* sh, float slope, int accumulate, const T* xb,
+                                                  long long xb_bs, T* dxb, long long dxb_bs, int ca) {
   // xb != nullptr: virtual concat (xa | xb): channels >= ca read xb and write dxb (xh_in_bwd_apply2)
   const int k = blockIdx.z * stat_rs + blockIdx.y;
   const T* xrow;
@@ -575,6 +587,16 @@ __global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, lon
     }
     strow<VEC>(dp, q, valid, o);
   ROW_LOOP_END
+}
+template <typename T, bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_kernel(const T* dy, long long dy_bs, const T* x, long long x_bs,
+                                                               T* dx, long long dx_bs, int C, long long dhw,
+                                                               const double* red, const float* mean, const float* rstd,
+                                                               int stat_rs, double count, int have_g, const float* sc,
+                                                               const float* sh, float slope, int accumulate, const T* xb,
+                                                               long long xb_bs, T* dxb, long long dxb_bs, int ca) {
+  in_bwd_apply_body<T, VEC>(uint3{blockIdx.x, blockIdx.y, blockIdx.z}, uint3{gridDim.x, gridDim.y, gridDim.z}, dy, dy_bs, x, x_bs, dx, dx_bs, C, dhw, red, mean, rstd, stat_rs, count, have_g, sc, sh, slope,
+                            accumulate, xb, xb_bs, dxb, dxb_bs, ca);
 }
 static int launch_in_bwd_apply(void* stream, int dtype, const void* dy, long long dy_bs, const void* x, long long x_bs, void* dx,
                                long long dx_bs, const void* xb, long long xb_bs, void* dxb, long long dxb_bs, int ca, int N, int C,
@@ -850,8 +872,8 @@ struct UpFin {
   float *o_sc, *o_sh, *o_mean, *o_rstd;
 };
 template <typename T, int TXN, bool PRE = false>
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, long long x_bs, T* __restrict__ y, long long y_bs, int C, int D,
-                                                            int H, int W, int sd, int tilesW, int tilesH, const UpFin fin) {
+__device__ __forceinline__ void upsample2x_fwd_body(const uint3 blockIdx, const T* __restrict__ x, long long x_bs, T* __restrict__ y, long long y_bs,
+                                                    int C, int D, int H, int W, int sd, int tilesW, int tilesH, const UpFin& fin) {
   constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
   const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
   const int c = blockIdx.y, n = blockIdx.z;
@@ -947,6 +969,12 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
   }
 }
 
+template <typename T, int TXN, bool PRE = false>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, long long x_bs, T* __restrict__ y, long long y_bs, int C, int D,
+                                                            int H, int W, int sd, int tilesW, int tilesH, const UpFin fin) {
+  upsample2x_fwd_body<T, TXN, PRE>(uint3{blockIdx.x, blockIdx.y, blockIdx.z}, x, x_bs, y, y_bs, C, D, H, W, sd, tilesW, tilesH, fin);
+}
+
 // Adjoint of the same stencil: dx[i] = .25 dy[2i-1] + .75 dy[2i] + .75 dy[2i+1] + .25 dy[2i+2] per axis, indices clamped
 // (the clamped forward taps fold back onto the border voxel).  Same lane role, marching through the dy planes.
 // RED: dx is the gradient of leaky(y0 * sc + sh) (the same BasicConv + Upsampling pair): the kernel also leaves the two sums the
@@ -957,8 +985,8 @@ struct UpRed {
 __device__ __forceinline__ float up_stored(const float*, float v) { return v; }
 template <int F> __device__ __forceinline__ float up_stored(const h16<F>*, float v) { return cvt_lo<F>(cvt_pack<F>(v, 0.f)); }
 template <typename T, int TXN, bool RED = false>
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, long long dy_bs, T* __restrict__ dx, long long dx_bs, int C, int D,
-                                                            int H, int W, int sd, int tilesW, int tilesH, int accumulate, const UpRed ur) {
+__device__ __forceinline__ void upsample2x_bwd_body(const uint3 blockIdx, const T* __restrict__ dy, long long dy_bs, T* __restrict__ dx, long long dx_bs,
+                                                    int C, int D, int H, int W, int sd, int tilesW, int tilesH, int accumulate, const UpRed& ur) {
   constexpr int VO = VWT<T>::v, VI = VO / 2, TH = 256 / TXN;
   const int tid = threadIdx.x, tx = tid % TXN, ty = tid / TXN;
   const int c = blockIdx.y, n = blockIdx.z;
@@ -1072,6 +1100,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
     block_sum_d<2>(v, s_red, 4);
     if (tid < 2) atomicAdd(&ur.red[((long long)n * C + c) * 2 + tid], s_red[tid]);
   }
+}
+
+template <typename T, int TXN, bool RED = false>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, long long dy_bs, T* __restrict__ dx, long long dx_bs, int C, int D,
+                                                            int H, int W, int sd, int tilesW, int tilesH, int accumulate, const UpRed ur) {
+  upsample2x_bwd_body<T, TXN, RED>(uint3{blockIdx.x, blockIdx.y, blockIdx.z}, dy, dy_bs, dx, dx_bs, C, D, H, W, sd, tilesW, tilesH, accumulate, ur);
 }
 
 template <typename T>
@@ -3134,5 +3168,188 @@ extern "C" int xh_compose_duse_bwd(void* stream, const float* const params[10], 
   DuseCompose a{params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7], params[8], params[9], C};
   DuseComposeGrad g{grads[0], grads[1], grads[2], grads[3], grads[4], grads[5], grads[6], grads[7], grads[8], grads[9]};
   hipLaunchKernelGGL(compose_duse_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, g, dsqw, dsqb, dadjw, dadjb);
+  return xh_launch_status();
+}
+
+
+// ======================================================================================================================
+// Multi kernels (include/xlstm_hved.h: "Multi-problem launches of the five passes of the latent path").  One launch, a table of up
+// to XH_LEVELS_MAX problems in the kernel arguments, a 1-D grid: workgroup b belongs to the problem whose [off[i], off[i + 1])
+// holds it and runs that problem's ordinary kernel body at the block coordinates the problem's own launch would have had.
+struct MultiHdr { int n; int off[XH_LEVELS_MAX + 1]; int gx[XH_LEVELS_MAX], gy[XH_LEVELS_MAX], gz[XH_LEVELS_MAX]; };
+__device__ __forceinline__ int multi_find(const MultiHdr& h, uint3& vb, uint3& vg) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < XH_LEVELS_MAX; ++k)
+    if (k < h.n && (int)blockIdx.x >= h.off[k]) i = k;
+  const int local = (int)blockIdx.x - h.off[i];
+  const int gx = h.gx[i], gy = h.gy[i], gz = h.gz[i];
+  if (local >= gx * gy * gz) return -1;
+  const int zy = local / gx;
+  vb = uint3{(unsigned)(local - zy * gx), (unsigned)(zy % gy), (unsigned)(zy / gy)};
+  vg = uint3{(unsigned)gx, (unsigned)gy, (unsigned)gz};
+  return i;
+}
+static void multi_layout(MultiHdr& h, int i, dim3 g) {
+  h.gx[i] = (int)g.x; h.gy[i] = (int)g.y; h.gz[i] = (int)g.z;
+  h.off[i + 1] = h.off[i] + (int)(g.x * g.y * g.z);
+}
+
+struct AffMulti { MultiHdr h; struct P { const void* x; long long x_bs; void* y; long long y_bs; int C; long long dhw; int act; float slope; int vec; AffFin f; } p[XH_LEVELS_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void affine_act_multi_kernel(const AffMulti m) {
+  uint3 vb, vg;
+  const int i = multi_find(m.h, vb, vg);
+  if (i < 0) return;
+  const AffMulti::P& a = m.p[i];
+  if (a.vec) affine_act_body<T, true>(vb, vg, (const T*)a.x, a.x_bs, (T*)a.y, a.y_bs, a.C, a.dhw, nullptr, nullptr, a.act, a.slope, a.f);
+  else affine_act_body<T, false>(vb, vg, (const T*)a.x, a.x_bs, (T*)a.y, a.y_bs, a.C, a.dhw, nullptr, nullptr, a.act, a.slope, a.f);
+}
+extern "C" int xh_in_affine_act_multi(void* stream, int dtype, int n, const xh_in_affine_act_args* q) {
+  if (n < 1 || n > XH_LEVELS_MAX || !q) return XH_ERR_ARG;
+  AffMulti m{};
+  m.h.n = n;
+  for (int i = 0; i < n; ++i) {
+    const xh_in_affine_act_args& a = q[i];
+    if (!a.x || !a.y || !a.red || !a.sc || !a.sh || !a.mean || !a.rstd || a.N <= 0 || a.C <= 0 || a.DHW <= 0 || a.C > 65535 || a.N > 65535)
+      return XH_ERR_ARG;
+    AffMulti::P& p = m.p[i];
+    p.x = a.x; p.x_bs = a.x_bs; p.y = a.y; p.y_bs = a.y_bs; p.C = a.C; p.dhw = a.DHW; p.act = a.act; p.slope = a.slope;
+    p.f = AffFin{};
+    p.f.mode = 0; p.f.red = a.red; p.f.count = (double)a.DHW; p.f.N = a.N;
+    p.f.o_sc = a.sc; p.f.o_sh = a.sh; p.f.o_mean = a.mean; p.f.o_rstd = a.rstd;
+    if (dtype == XH_F32) { p.vec = vec_ok<float>(a.DHW, {a.x_bs, a.y_bs}); multi_layout(m.h, i, row_grid<float>(a.DHW, a.C, a.N)); }
+    else { p.vec = vec_ok<bf16_t>(a.DHW, {a.x_bs, a.y_bs}); multi_layout(m.h, i, row_grid<bf16_t>(a.DHW, a.C, a.N)); }
+  }
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL((affine_act_multi_kernel<T>), dim3(m.h.off[n]), dim3(EW_BLOCK), 0, (hipStream_t)stream, m););
+  return xh_launch_status();
+}
+
+struct AbrMulti { MultiHdr h; struct P { const void* dy; long long dy_bs; const void* x; long long x_bs; int C; long long dhw; const float *sc, *sh; float slope; double* red; int vec; } p[XH_LEVELS_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void act_bwd_reduce_multi_kernel(const AbrMulti m) {
+  uint3 vb, vg;
+  const int i = multi_find(m.h, vb, vg);
+  if (i < 0) return;
+  const AbrMulti::P& a = m.p[i];
+  if (a.vec) act_bwd_reduce_body<T, true>(vb, vg, (const T*)a.dy, a.dy_bs, (const T*)a.x, a.x_bs, a.C, a.dhw, a.sc, a.sh, a.slope, a.red);
+  else act_bwd_reduce_body<T, false>(vb, vg, (const T*)a.dy, a.dy_bs, (const T*)a.x, a.x_bs, a.C, a.dhw, a.sc, a.sh, a.slope, a.red);
+}
+extern "C" int xh_act_bwd_reduce_multi(void* stream, int dtype, int n, const xh_act_bwd_reduce_args* q) {
+  if (n < 1 || n > XH_LEVELS_MAX || !q) return XH_ERR_ARG;
+  AbrMulti m{};
+  m.h.n = n;
+  for (int i = 0; i < n; ++i) {
+    const xh_act_bwd_reduce_args& a = q[i];
+    if (!a.dy || !a.x || !a.sc || !a.sh || !a.red || a.N <= 0 || a.C <= 0 || a.DHW <= 0 || a.C > 65535 || a.N > 65535) return XH_ERR_ARG;
+    AbrMulti::P& p = m.p[i];
+    p.dy = a.dy; p.dy_bs = a.dy_bs; p.x = a.x; p.x_bs = a.x_bs; p.C = a.C; p.dhw = a.DHW; p.sc = a.sc; p.sh = a.sh; p.slope = a.slope; p.red = a.red;
+    if (dtype == XH_F32) { p.vec = vec_ok<float>(a.DHW, {a.dy_bs, a.x_bs}); multi_layout(m.h, i, red_grid<float>(a.DHW, a.C, a.N)); }
+    else { p.vec = vec_ok<bf16_t>(a.DHW, {a.dy_bs, a.x_bs}); multi_layout(m.h, i, red_grid<bf16_t>(a.DHW, a.C, a.N)); }
+  }
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_multi_kernel<T>), dim3(m.h.off[n]), dim3(EW_BLOCK), 0, (hipStream_t)stream, m););
+  return xh_launch_status();
+}
+
+struct IbaMulti {
+  MultiHdr h;
+  struct P { const void* dy; long long dy_bs; const void* x; long long x_bs; void* dx; long long dx_bs; int C; long long dhw; const double* red;
+             const float *mean, *rstd; int stat_rs, have_g; const float *sc, *sh; float slope; int accumulate, vec; } p[XH_LEVELS_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void in_bwd_apply_multi_kernel(const IbaMulti m) {
+  uint3 vb, vg;
+  const int i = multi_find(m.h, vb, vg);
+  if (i < 0) return;
+  const IbaMulti::P& a = m.p[i];
+  if (a.vec) in_bwd_apply_body<T, true>(vb, vg, (const T*)a.dy, a.dy_bs, (const T*)a.x, a.x_bs, (T*)a.dx, a.dx_bs, a.C, a.dhw, a.red, a.mean, a.rstd,
+                                        a.stat_rs, (double)a.dhw, a.have_g, a.sc, a.sh, a.slope, a.accumulate, (const T*)nullptr, 0, (T*)nullptr, 0, a.C);
+  else in_bwd_apply_body<T, false>(vb, vg, (const T*)a.dy, a.dy_bs, (const T*)a.x, a.x_bs, (T*)a.dx, a.dx_bs, a.C, a.dhw, a.red, a.mean, a.rstd,
+                                   a.stat_rs, (double)a.dhw, a.have_g, a.sc, a.sh, a.slope, a.accumulate, (const T*)nullptr, 0, (T*)nullptr, 0, a.C);
+}
+extern "C" int xh_in_bwd_apply_multi(void* stream, int dtype, int n, const xh_in_bwd_apply_args* q) {
+  if (n < 1 || n > XH_LEVELS_MAX || !q) return XH_ERR_ARG;
+  IbaMulti m{};
+  m.h.n = n;
+  for (int i = 0; i < n; ++i) {
+    const xh_in_bwd_apply_args& a = q[i];
+    if (!a.dy || !a.x || !a.dx || !a.red || !a.mean || !a.rstd || a.N <= 0 || a.C <= 0 || a.DHW <= 0 || a.C > 65535 || a.N > 65535 || a.stat_rs < a.C)
+      return XH_ERR_ARG;
+    if (!a.have_g && (!a.sc || !a.sh)) return XH_ERR_ARG;
+    IbaMulti::P& p = m.p[i];
+    p.dy = a.dy; p.dy_bs = a.dy_bs; p.x = a.x; p.x_bs = a.x_bs; p.dx = a.dx; p.dx_bs = a.dx_bs; p.C = a.C; p.dhw = a.DHW; p.red = a.red;
+    p.mean = a.mean; p.rstd = a.rstd; p.stat_rs = a.stat_rs; p.have_g = a.have_g; p.sc = a.sc; p.sh = a.sh; p.slope = a.slope; p.accumulate = a.accumulate;
+    if (dtype == XH_F32) { p.vec = vec_ok<float>(a.DHW, {a.dy_bs, a.x_bs, a.dx_bs}); multi_layout(m.h, i, row_grid<float>(a.DHW, a.C, a.N)); }
+    else { p.vec = vec_ok<bf16_t>(a.DHW, {a.dy_bs, a.x_bs, a.dx_bs}); multi_layout(m.h, i, row_grid<bf16_t>(a.DHW, a.C, a.N)); }
+  }
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL((in_bwd_apply_multi_kernel<T>), dim3(m.h.off[n]), dim3(EW_BLOCK), 0, (hipStream_t)stream, m););
+  return xh_launch_status();
+}
+
+// the exact-2x upsampling pair: the lane tiling (TXN = lanes along W) is a template argument and differs between the levels, so the
+// multi kernel carries every instance a problem can ask for and branches on the problem's (workgroup-uniform) choice
+struct UpfMulti { MultiHdr h; struct P { const void* x; long long x_bs; void* y; long long y_bs; int C, D, H, W, sd, tilesW, tilesH, txn; UpFin fin; } p[XH_LEVELS_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_multi_kernel(const UpfMulti m) {
+  uint3 vb, vg;
+  const int i = multi_find(m.h, vb, vg);
+  if (i < 0) return;
+  const UpfMulti::P& a = m.p[i];
+#define UPF(N_) upsample2x_fwd_body<T, N_, true>(vb, (const T*)a.x, a.x_bs, (T*)a.y, a.y_bs, a.C, a.D, a.H, a.W, a.sd, a.tilesW, a.tilesH, a.fin)
+  switch (a.txn) { case 4: UPF(4); break; case 8: UPF(8); break; case 16: UPF(16); break; case 32: UPF(32); break; default: UPF(64); }
+#undef UPF
+}
+extern "C" int xh_upsample2x_in_act_multi(void* stream, int dtype, int n, const xh_upsample2x_in_act_args* q) {
+  if (n < 1 || n > XH_LEVELS_MAX || !q) return XH_ERR_ARG;
+  if (g_xh_disable & 2) return 1;
+  UpfMulti m{};
+  m.h.n = n;
+  for (int i = 0; i < n; ++i) {
+    const xh_upsample2x_in_act_args& a = q[i];
+    if (!a.x || !a.y || !a.red || !a.sc || !a.sh || !a.mean || !a.rstd || a.N <= 0 || a.C <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0) return XH_ERR_ARG;
+    UpfMulti::P& p = m.p[i];
+    int dsegs;
+    const bool ok = dtype == XH_F32 ? upsample2x_plan<float>(a.N, a.C, a.D, a.H, a.W, a.x_bs, a.y_bs, p.txn, p.tilesW, p.tilesH, p.sd, dsegs)
+                                    : upsample2x_plan<bf16_t>(a.N, a.C, a.D, a.H, a.W, a.x_bs, a.y_bs, p.txn, p.tilesW, p.tilesH, p.sd, dsegs);
+    if (!ok) return 1;
+    p.x = a.x; p.x_bs = a.x_bs; p.y = a.y; p.y_bs = a.y_bs; p.C = a.C; p.D = a.D; p.H = a.H; p.W = a.W;
+    p.fin = UpFin{a.red, 1.0 / ((double)a.D * a.H * a.W), a.slope, a.sc, a.sh, a.mean, a.rstd};
+    multi_layout(m.h, i, dim3(p.tilesW * p.tilesH * dsegs, a.C, a.N));
+  }
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_fwd_multi_kernel<T>), dim3(m.h.off[n]), dim3(256), 0, (hipStream_t)stream, m););
+  return xh_launch_status();
+}
+
+struct UpbMulti { MultiHdr h; struct P { const void* dy; long long dy_bs; void* dx; long long dx_bs; int C, D, H, W, sd, tilesW, tilesH, txn; UpRed ur; } p[XH_LEVELS_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_multi_kernel(const UpbMulti m) {
+  uint3 vb, vg;
+  const int i = multi_find(m.h, vb, vg);
+  if (i < 0) return;
+  const UpbMulti::P& a = m.p[i];
+#define UPB(N_) upsample2x_bwd_body<T, N_, true>(vb, (const T*)a.dy, a.dy_bs, (T*)a.dx, a.dx_bs, a.C, a.D, a.H, a.W, a.sd, a.tilesW, a.tilesH, 0, a.ur)
+  switch (a.txn) { case 4: UPB(4); break; case 8: UPB(8); break; case 16: UPB(16); break; case 32: UPB(32); break; default: UPB(64); }
+#undef UPB
+}
+extern "C" int xh_upsample2x_bwd_act_reduce_multi(void* stream, int dtype, int n, const xh_upsample2x_bwd_act_reduce_args* q) {
+  if (n < 1 || n > XH_LEVELS_MAX || !q) return XH_ERR_ARG;
+  if (g_xh_disable & 2) return 1;
+  UpbMulti m{};
+  m.h.n = n;
+  const int vo = dtype == XH_F32 ? 4 : 8;
+  for (int i = 0; i < n; ++i) {
+    const xh_upsample2x_bwd_act_reduce_args& a = q[i];
+    if (!a.dy || !a.dx || !a.y0 || !a.sc || !a.sh || !a.red || a.N <= 0 || a.C <= 0 || a.D <= 0 || a.H <= 0 || a.W <= 0) return XH_ERR_ARG;
+    if (a.y0_bs % vo) return 1;
+    UpbMulti::P& p = m.p[i];
+    int dsegs;
+    const bool ok = dtype == XH_F32 ? upsample2x_plan<float>(a.N, a.C, a.D, a.H, a.W, a.dx_bs, a.dy_bs, p.txn, p.tilesW, p.tilesH, p.sd, dsegs)
+                                    : upsample2x_plan<bf16_t>(a.N, a.C, a.D, a.H, a.W, a.dx_bs, a.dy_bs, p.txn, p.tilesW, p.tilesH, p.sd, dsegs);
+    if (!ok) return 1;
+    p.dy = a.dy; p.dy_bs = a.dy_bs; p.dx = a.dx; p.dx_bs = a.dx_bs; p.C = a.C; p.D = a.D; p.H = a.H; p.W = a.W;
+    p.ur = UpRed{a.y0, a.y0_bs, a.sc, a.sh, a.slope, a.red};
+    multi_layout(m.h, i, dim3(p.tilesW * p.tilesH * dsegs, a.C, a.N));
+  }
+  XH_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_bwd_multi_kernel<T>), dim3(m.h.off[n]), dim3(256), 0, (hipStream_t)stream, m););
   return xh_launch_status();
 }

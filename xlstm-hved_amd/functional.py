@@ -436,6 +436,84 @@ class ConvInLrelu(Function):
         return dx, rw, None, None
 
 
+LATENT_BATCH = [True]
+
+
+def set_latent_batch(enabled):
+    """A/B switch: the latent path of all fusion levels as one autograd node whose element-wise passes are multi-problem launches
+    (LatentPath) instead of two ConvInLrelu nodes per level."""
+    LATENT_BATCH[0] = bool(enabled)
+
+
+class LatentPath(Function):
+    """RA_HVED.py:599-603 for ALL fusion levels at once: per level z -> BasicConv(1x1) -> 2x trilinear upsampling -> BasicConv
+    (depthwise 3^3), i.e. two ConvInLrelu nodes per level.  The levels do not depend on each other and all but the finest are a few
+    dozen workgroups per launch, so their element-wise passes -- norm + activation inside the upsampling, norm + activation of the
+    conv block, and backward the activation-masked sums, the two InstanceNorm backward passes and the upsampling adjoint -- run as
+    ONE launch per pass for the four levels (ops.*_multi, include/xlstm_hved.h xh_*_multi) instead of one per level: 24 launches
+    of ~5 us less per step.  The convolutions themselves stay one launch per level (different kernels per size).  Same kernel
+    bodies, same per-problem grids: the same bits as the per-level path (tests/test_gpu_network.py)."""
+
+    @staticmethod
+    def forward(ctx, nlev, groups2, *tw):
+        """tw = z_0 .. z_{L-1}, w1_0 .. w1_{L-1} (1x1 weights), w2_0 .. w2_{L-1} (depthwise 3^3 weights); groups2[l] = groups of
+        the level's second conv."""
+        zs, w1s, w2s = tw[:nlev], tw[nlev:2 * nlev], tw[2 * nlev:3 * nlev]
+        y0a, reda = [], []
+        for z, w in zip(zs, w1s):                          # conv 1x1 (+ output moments), one launch per level
+            red = ops.zeros_red(z, z.shape[0], w.shape[0])
+            y0a.append(ops.conv3d(z, None, [w], None, k=1, cout=w.shape[0], groups=1, epi=2, red=red))
+            reda.append(red)
+        ups = ops.upsample2x_in_act_multi(y0a, reda, LEAK)
+        if ups is None:
+            raise RuntimeError("LatentPath: the exact-2x upsampling kernel does not take this layout (use set_latent_batch(False))")
+        y0b, redb = [], []
+        for (u, _, _, _, _), w, g in zip(ups, w2s, groups2):   # depthwise 3^3 (+ output moments)
+            red = ops.zeros_red(u, u.shape[0], w.shape[0])
+            y0b.append(ops.conv3d(u, None, [w], None, k=w.shape[-1], cout=w.shape[0], groups=g, epi=2, red=red))
+            redb.append(red)
+        fin = ops.in_affine_act_multi(y0b, redb, ACT_LRELU, LEAK)
+        saved = []
+        for l in range(nlev):
+            saved += [zs[l], y0a[l], w1s[l], ups[l][1], ups[l][2], ups[l][3], ups[l][4], ups[l][0], y0b[l], w2s[l], fin[l][1], fin[l][2],
+                      fin[l][3], fin[l][4]]
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (nlev, tuple(groups2))
+        ctx.params = (tuple(w1s), tuple(w2s))
+        return tuple(f[0] for f in fin)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        nlev, groups2 = ctx.cfg
+        t = ctx.saved_tensors
+        lv = [t[14 * l:14 * l + 14] for l in range(nlev)]      # z, y0a, w1, sc1, sh1, mean1, rstd1, u, y0b, w2, sc2, sh2, mean2, rstd2
+        dys = [_blk(dy) for dy in dys]
+        # second BasicConv (depthwise 3^3): activation-masked sums, InstanceNorm backward -- one launch each for all levels
+        red2 = ops.act_bwd_reduce_multi(dys, [v[8] for v in lv], [v[10] for v in lv], [v[11] for v in lv], LEAK)
+        dy0b = ops.in_bwd_apply_multi(dys, [v[8] for v in lv], red2, [v[12] for v in lv], [v[13] for v in lv], have_g=False,
+                                      scs=[v[10] for v in lv], shs=[v[11] for v in lv], slope=LEAK)
+        w1s, w2s = ctx.params
+        dws2, rws2 = _targets(w2s)
+        du = []
+        for l, v in enumerate(lv):
+            k = v[9].shape[-1]
+            ops.conv3d_wgrad(v[7], None, dy0b[l], [dws2[l]], None, k=k, groups=groups2[l], side=_direct(rws2[l]))
+            du.append(ops.conv3d(dy0b[l], None, [v[9]], None, k=k, cout=v[7].shape[1], groups=groups2[l], transposed=True))
+        # upsampling adjoint + the first BasicConv's activation-masked sums, then its InstanceNorm backward
+        r = ops.upsample2x_bwd_act_reduce_multi(du, [v[1] for v in lv], [v[3] for v in lv], [v[4] for v in lv], LEAK)
+        if r is None:
+            raise RuntimeError("LatentPath.backward: the exact-2x upsampling adjoint does not take this layout")
+        dy0a = ops.in_bwd_apply_multi([x[0] for x in r], [v[1] for v in lv], [x[1] for x in r], [v[5] for v in lv], [v[6] for v in lv],
+                                      have_g=False, scs=[v[3] for v in lv], shs=[v[4] for v in lv], slope=LEAK)
+        dws1, rws1 = _targets(w1s)
+        dzs = []
+        for l, v in enumerate(lv):
+            ops.conv3d_wgrad(v[0], None, dy0a[l], [dws1[l]], None, k=1, groups=1, side=_direct(rws1[l]))
+            dzs.append(ops.conv3d(dy0a[l], None, [v[2]], None, k=1, cout=v[0].shape[1], groups=1, transposed=True)
+                       if ctx.needs_input_grad[2 + l] else None)
+        return (None, None, *dzs, *rws1, *rws2)
+
+
 class Conv(Function):
     """Plain Conv3d (+bias) with optional sigmoid: init_blocks / x0_init / heads (RA_HVED.py:323,347,148-149,
     480,640-641) and AttenModule2's collapsed 7^3 convs (buildingblocks.py:283-296).  `groups` streams may

@@ -526,13 +526,25 @@ class AbstractFusion3DUNet(nn.Module):
             zml = Fn.PoEAll.apply(keep, tuple(self.MVAE_latents[:nlev]), bool(instance_missing), nlev, *feat_list, *epss)
         else:
             zml = [t for l in range(nlev) for t in Fn.PoE.apply(feat_list[l], keep, epss[l], self.MVAE_latents[l], bool(instance_missing))]
+        batch = (Fn.LATENT_BATCH[0] and x.is_cuda and 1 < nlev <= 4 and not ops.LEVEL_STREAMS[0]
+                 and all(type(self.VU_blocks[l][0]).__name__ == "BasicConv" and self.VU_blocks[l][0].conv.kernel_size[0] == 1
+                         and self.VU_blocks[l][0].groups == 1 and type(self.conv_blocks[l]).__name__ == "BasicConv" for l in range(nlev))
+                 and all(zml[3 * l].shape[-1] % 4 == 0 for l in range(nlev)))
+        if batch:
+            # all levels as ONE autograd node with multi-problem launches for the element-wise passes (Fn.LatentPath)
+            zs = [zml[3 * l] for l in range(nlev)]
+            feats_l = Fn.LatentPath.apply(nlev, tuple(self.conv_blocks[l].groups for l in range(nlev)), *zs,
+                                          *[self.VU_blocks[l][0].conv.weight for l in range(nlev)],
+                                          *[self.conv_blocks[l].conv.weight for l in range(nlev)])
+            for level in range(nlev):
+                outs[level] = (feats_l[level], zml[3 * level + 1], zml[3 * level + 2])
         side = None
         if ops.LEVEL_STREAMS[0] and x.is_cuda and nlev > 1:
             pool = self.__dict__.setdefault("_level_streams", {}).setdefault(x.device, [])
             while len(pool) < nlev - 1:
                 pool.append(torch.cuda.Stream(x.device))
             side, cur = pool[:nlev - 1], torch.cuda.current_stream(x.device)
-        for level in range(nlev):
+        for level in range(0 if not batch else nlev, nlev):
             z, mu, lv = zml[3 * level:3 * level + 3]
             st = side[level - 1] if side is not None and level >= 1 else None
             if st is not None:

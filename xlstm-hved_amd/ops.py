@@ -938,6 +938,102 @@ def upsample2x_bwd_act_reduce(dy, y0, sc, sh, slope=LEAK):
     return dx, red
 
 
+# ---- multi-problem launches of the latent path's passes (include/xlstm_hved.h: xh_*_multi): the same pass over up to 4 tensors of
+# different sizes in ONE launch.  Each returns a list with one entry per problem, shaped like the single-problem op's result.
+def _chunks(seq):
+    return [seq[i:i + L.MULTI_MAX] for i in range(0, len(seq), L.MULTI_MAX)]
+
+
+def in_affine_act_multi(xs, reds, act, slope=LEAK):
+    outs = []
+    for part in _chunks(list(zip(xs, reds))):
+        arr = (L.InAffineActArgs * len(part))()
+        res = []
+        for i, (x, red) in enumerate(part):
+            n, c, d, h, w, bs = _vol(x)
+            out = torch.empty_like(x, memory_format=torch.contiguous_format)
+            sc, sh, mean, rstd = (torch.empty((n, c), dtype=torch.float32, device=x.device) for _ in range(4))
+            arr[i] = L.InAffineActArgs(_p(x), bs, _p(out), _vol(out)[5], n, c, d * h * w, _p(red), act, slope, _p(sc), _p(sh), _p(mean), _p(rstd))
+            res.append((out, sc, sh, mean, rstd))
+        L.check(L.load().xh_in_affine_act_multi(_stream(), _dt(part[0][0]), len(part), C.addressof(arr)), "xh_in_affine_act_multi")
+        outs += res
+    return outs
+
+
+def act_bwd_reduce_multi(dys, xs, scs, shs, slope):
+    outs = []
+    for part in _chunks(list(zip(dys, xs, scs, shs))):
+        arr = (L.ActBwdReduceArgs * len(part))()
+        res = []
+        for i, (dy, x, sc, sh) in enumerate(part):
+            n, c, d, h, w, bs = _vol(x)
+            red = zeros_red(x, n, c)
+            arr[i] = L.ActBwdReduceArgs(_p(dy), _vol(dy)[5], _p(x), bs, n, c, d * h * w, _p(sc), _p(sh), slope, _p(red))
+            res.append(red)
+        L.check(L.load().xh_act_bwd_reduce_multi(_stream(), _dt(part[0][1]), len(part), C.addressof(arr)), "xh_act_bwd_reduce_multi")
+        outs += res
+    return outs
+
+
+def in_bwd_apply_multi(dys, xs, reds, means, rstds, *, have_g, scs=None, shs=None, slope=LEAK):
+    outs = []
+    scs = scs if scs is not None else [None] * len(xs)
+    shs = shs if shs is not None else [None] * len(xs)
+    for part in _chunks(list(zip(dys, xs, reds, means, rstds, scs, shs))):
+        arr = (L.InBwdApplyArgs * len(part))()
+        res = []
+        for i, (dy, x, red, mean, rstd, sc, sh) in enumerate(part):
+            n, c, d, h, w, bs = _vol(x)
+            out = torch.empty_like(x, memory_format=torch.contiguous_format)
+            arr[i] = L.InBwdApplyArgs(_p(dy), _vol(dy)[5], _p(x), bs, _p(out), _vol(out)[5], n, c, d * h * w, _p(red), _p(mean), _p(rstd),
+                                      mean.shape[1], int(have_g), _p(sc), _p(sh), slope, 0)
+            res.append(out)
+        L.check(L.load().xh_in_bwd_apply_multi(_stream(), _dt(part[0][1]), len(part), C.addressof(arr)), "xh_in_bwd_apply_multi")
+        outs += res
+    return outs
+
+
+def upsample2x_in_act_multi(xs, reds, slope=LEAK):
+    """None when a problem's layout is not taken by the exact-2x kernel (the caller then runs the single-problem ops)."""
+    outs = []
+    for part in _chunks(list(zip(xs, reds))):
+        arr = (L.Upsample2xInActArgs * len(part))()
+        res = []
+        for i, (x, red) in enumerate(part):
+            n, c, d, h, w, bs = _vol(x)
+            out = new_like(x, (n, c, 2 * d, 2 * h, 2 * w))
+            sc, sh, mean, rstd = (torch.empty((n, c), dtype=torch.float32, device=x.device) for _ in range(4))
+            arr[i] = L.Upsample2xInActArgs(_p(x), bs, _p(out), _vol(out)[5], n, c, d, h, w, _p(red), slope, _p(sc), _p(sh), _p(mean), _p(rstd))
+            res.append((out, sc, sh, mean, rstd))
+        rc = L.load().xh_upsample2x_in_act_multi(_stream(), _dt(part[0][0]), len(part), C.addressof(arr))
+        if rc == 1:
+            return None
+        L.check(rc, "xh_upsample2x_in_act_multi")
+        outs += res
+    return outs
+
+
+def upsample2x_bwd_act_reduce_multi(dys, y0s, scs, shs, slope=LEAK):
+    outs = []
+    for part in _chunks(list(zip(dys, y0s, scs, shs))):
+        arr = (L.Upsample2xBwdArgs * len(part))()
+        res = []
+        for i, (dy, y0, sc, sh) in enumerate(part):
+            n, c, d, h, w, bs = _vol(y0)
+            if tuple(dy.shape[2:]) != (2 * d, 2 * h, 2 * w):
+                return None
+            dx = new_like(dy, (n, c, d, h, w))
+            red = zeros_red(y0, n, c)
+            arr[i] = L.Upsample2xBwdArgs(_p(dy), _vol(dy)[5], _p(dx), _vol(dx)[5], n, c, d, h, w, _p(y0), bs, _p(sc), _p(sh), slope, _p(red))
+            res.append((dx, red))
+        rc = L.load().xh_upsample2x_bwd_act_reduce_multi(_stream(), _dt(part[0][0]), len(part), C.addressof(arr))
+        if rc == 1:
+            return None
+        L.check(rc, "xh_upsample2x_bwd_act_reduce_multi")
+        outs += res
+    return outs
+
+
 def add(a, b, out=None):
     """out = a + b (b None: copy) for NCDHW-blocked tensors."""
     n, c, d, h, w, a_bs = _vol(a)
