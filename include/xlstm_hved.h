@@ -334,6 +334,9 @@ typedef struct {                 /* xh_upsample2x_bwd_act_reduce */
   const void* dy; long long dy_bs; void* dx; long long dx_bs; int N, C, D, H, W; const void* y0; long long y0_bs; const float *sc, *sh;
   float slope; double* red;
 } xh_upsample2x_bwd_act_reduce_args;
+/* n <= XH_LEVELS_MAX k = 1 convolutions (xh_conv3d_fwd with k == 1: same descriptors) in one launch; all of one storage type, one
+ * epilogue (epi 0 or 2), no activation epilogue.  Returns 1 with nothing launched when that does not hold. */
+int xh_conv1x1_multi(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p);
 int xh_in_affine_act_multi(void* stream, int dtype, int n, const xh_in_affine_act_args* a);
 int xh_act_bwd_reduce_multi(void* stream, int dtype, int n, const xh_act_bwd_reduce_args* a);
 int xh_in_bwd_apply_multi(void* stream, int dtype, int n, const xh_in_bwd_apply_args* a);

@@ -141,6 +141,7 @@ SIGNATURES = {
     "xh_upsample_trilinear_bwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, I, I, I, I]),
     "xh_upsample2x_in_act_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, vp, F, vp, vp, vp, vp]),
     "xh_upsample2x_bwd_act_reduce": (I, [vp, I, vp, ll, vp, ll, I, I, I, I, I, vp, ll, vp, vp, F, vp]),
+    "xh_conv1x1_multi": (I, [vp, I, vp, vp]),
     "xh_in_affine_act_multi": (I, [vp, I, I, vp]),
     "xh_act_bwd_reduce_multi": (I, [vp, I, I, vp]),
     "xh_in_bwd_apply_multi": (I, [vp, I, I, vp]),

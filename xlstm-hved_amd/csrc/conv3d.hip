@@ -494,8 +494,9 @@ __global__ __launch_bounds__(256) void conv_dw3_slide_kernel(const ConvK a, int 
 // k = 1 forward / dgrad: no halo, inputs straight from global memory (4 voxels per lane, vectorised).
 // ---------------------------------------------------------------------------------------------------
 // MODE: see conv_epilogue (>= 0: no activation, epilogue variant MODE, straight-line code)
+// (the body takes the block coordinates as parameters named like the built-ins: it also runs inside conv1x1_multi_kernel)
 template <typename T, int COB, bool VEC, int CIC = 4, int MODE = -1>   // CIC input channels per step: their loads are issued together
-__global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
+__device__ __forceinline__ void conv1x1_body(const uint3 blockIdx, const uint3 gridDim, const ConvK& a) {
   constexpr int VW = VEC ? VWT<T>::v : 4;              // 16-byte runs when the layout allows
   __shared__ float s_w[132 * COB];
   __shared__ double s_red[4 * 2 * COB];
@@ -561,6 +562,35 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
     }
   }
   if (MODE >= 0 ? MODE != 0 : a.d.epi != 0) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
+}
+template <typename T, int COB, bool VEC, int CIC = 4, int MODE = -1>
+__global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
+  conv1x1_body<T, COB, VEC, CIC, MODE>(uint3{blockIdx.x, blockIdx.y, blockIdx.z}, uint3{gridDim.x, gridDim.y, gridDim.z}, a);
+}
+// Up to XH_LEVELS_MAX k = 1 convolutions in ONE launch (xh_conv1x1_multi: the four fusion levels' VU-block convs and their data
+// gradients, RA_HVED.py:599-601): a workgroup finds its problem from its index and runs that problem's ordinary body -- with the
+// output-channel block / channel-step instance the single launch would have picked -- at the problem's own block coordinates.
+struct C1Multi { int n; int off[XH_LEVELS_MAX + 1]; int gx[XH_LEVELS_MAX], gy[XH_LEVELS_MAX], gz[XH_LEVELS_MAX], cob[XH_LEVELS_MAX], cic[XH_LEVELS_MAX]; ConvK p[XH_LEVELS_MAX]; };
+static_assert(sizeof(C1Multi) <= 4096, "the problem table travels in the kernel arguments");
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void conv1x1_multi_kernel(const C1Multi m) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < XH_LEVELS_MAX; ++k)
+    if (k < m.n && (int)blockIdx.x >= m.off[k]) i = k;
+  const int local = (int)blockIdx.x - m.off[i];
+  const int gx = m.gx[i], gy = m.gy[i], gz = m.gz[i];
+  if (local >= gx * gy * gz) return;
+  const int zy = local / gx;
+  const uint3 vb = {(unsigned)(local - zy * gx), (unsigned)(zy % gy), (unsigned)(zy / gy)}, vg = {(unsigned)gx, (unsigned)gy, (unsigned)gz};
+  const ConvK& a = m.p[i];
+  if (m.cic[i] == 16) { conv1x1_body<T, 2, true, 16, MODE>(vb, vg, a); return; }
+  switch (m.cob[i]) {
+    case 1: conv1x1_body<T, 1, true, 4, MODE>(vb, vg, a); break;
+    case 2: conv1x1_body<T, 2, true, 4, MODE>(vb, vg, a); break;
+    case 4: conv1x1_body<T, 4, true, 4, MODE>(vb, vg, a); break;
+    default: conv1x1_body<T, 8, true, 4, MODE>(vb, vg, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1515,6 +1545,62 @@ void xh_note_kernel(const char* fmt, ...) {
 }
 extern "C" const char* xh_last_conv_kernel(void) { return g_last_kernel; }
 extern int g_mfma_abl;
+// Launch plan of a k = 1 convolution (shared by the single launch in conv_fwd_dispatch and xh_conv1x1_multi): output-channel
+// block, channels per step, grid.  false: the layout does not allow 16-byte runs (the single launch then takes its scalar instance).
+template <typename T>
+static bool c1_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, ConvK& a, int& cob, int& cic, dim3& grid) {
+  const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
+  cob = pick_cob(cout_g, 8);
+  cic = 4;
+  a = make_k(d, p, cob, 8);
+  const long long dhw = (long long)d->D * d->H * d->W;
+  constexpr int VW1 = VWT<T>::v;
+  const bool vec = (dhw % VW1 == 0) && (d->xa_bs % VW1 == 0) && (d->xb_bs % VW1 == 0) && (d->y_bs % VW1 == 0) &&
+                   (d->epi != 1 || (d->ea_bs % VW1 == 0 && d->eb_bs % VW1 == 0));
+  long long gx1 = (dhw + 256 * VW1 - 1) / (256 * VW1);
+  if (vec && cin_g >= 16 && cout_g >= 2 && gx1 * a.ncob * d->N * d->groups < 128) {
+    cob = 2; cic = 16;
+    a = make_k(d, p, 2, 8);
+    grid = dim3((unsigned)gx1, a.ncob, d->N * d->groups);
+    return true;
+  }
+  const long long cap1 = cdiv(g_c1_cap > 0 ? g_c1_cap : 2048, a.ncob * d->N * d->groups);
+  if (gx1 > cap1) gx1 = cap1;
+  grid = dim3((unsigned)gx1, a.ncob, d->N * d->groups);
+  return vec;
+}
+static int check_desc(const xh_conv_desc* d, const xh_conv_ptrs* p);
+extern "C" int xh_conv1x1_multi(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p) {
+  if (n < 1 || n > XH_LEVELS_MAX || !d || !p) return XH_ERR_ARG;
+  C1Multi* m = new C1Multi;
+  m->n = n;
+  m->off[0] = 0;
+  const int dtype = d[0] ? d[0]->dtype : -1, epi = d[0] ? d[0]->epi : -1;
+  for (int i = 0; i < n; ++i) {
+    const int rc = check_desc(d[i], p[i]);
+    if (rc) { delete m; return rc; }
+    if (!p[i]->y || (d[i]->epi == 2 && !p[i]->red)) { delete m; return XH_ERR_ARG; }
+    // one storage type, one epilogue (none | output moments), no activation, no cin > 128: else the caller launches them one by one
+    if (d[i]->k != 1 || d[i]->dtype != dtype || d[i]->epi != epi || (epi != 0 && epi != 2) || d[i]->act != XH_ACT_NONE ||
+        d[i]->Cin / d[i]->groups > 128 || d[i]->pre == 2) { delete m; return 1; }
+    dim3 g;
+    bool vec = false;
+    XH_DISPATCH_T(dtype, vec = c1_plan<T>(d[i], p[i], m->p[i], m->cob[i], m->cic[i], g););
+    if (!vec) { delete m; return 1; }
+    m->gx[i] = (int)g.x; m->gy[i] = (int)g.y; m->gz[i] = (int)g.z;
+    m->off[i + 1] = m->off[i] + (int)(g.x * g.y * g.z);
+  }
+  xh_note_kernel("conv1x1_multi_kernel<%d problems, epi %d>", n, epi);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(m->off[n]);
+  XH_DISPATCH_T(dtype, {
+    if (epi == 2) hipLaunchKernelGGL((conv1x1_multi_kernel<T, 2>), grid, dim3(256), 0, st, *m);
+    else hipLaunchKernelGGL((conv1x1_multi_kernel<T, 0>), grid, dim3(256), 0, st, *m);
+  });
+  delete m;
+  return xh_launch_status();
+}
+
 extern "C" int xh_set_option(int key, int value) {
   if (key == 0) { g_use_mfma = value; return XH_OK; }
   if (key == 1) { g_mfma_abl = value; return XH_OK; }

@@ -460,10 +460,14 @@ class LatentPath(Function):
         the level's second conv."""
         zs, w1s, w2s = tw[:nlev], tw[nlev:2 * nlev], tw[2 * nlev:3 * nlev]
         y0a, reda = [], []
-        for z, w in zip(zs, w1s):                          # conv 1x1 (+ output moments), one launch per level
-            red = ops.zeros_red(z, z.shape[0], w.shape[0])
-            y0a.append(ops.conv3d(z, None, [w], None, k=1, cout=w.shape[0], groups=1, epi=2, red=red))
-            reda.append(red)
+        ops.conv1x1_collect()                              # the four 1x1 convs (+ output moments): one launch
+        try:
+            for z, w in zip(zs, w1s):
+                red = ops.zeros_red(z, z.shape[0], w.shape[0])
+                y0a.append(ops.conv3d(z, None, [w], None, k=1, cout=w.shape[0], groups=1, epi=2, red=red))
+                reda.append(red)
+        finally:
+            ops.conv1x1_flush()
         ups = ops.upsample2x_in_act_multi(y0a, reda, LEAK)
         if ups is None:
             raise RuntimeError("LatentPath: the exact-2x upsampling kernel does not take this layout (use set_latent_batch(False))")
@@ -507,10 +511,14 @@ class LatentPath(Function):
                                       have_g=False, scs=[v[3] for v in lv], shs=[v[4] for v in lv], slope=LEAK)
         dws1, rws1 = _targets(w1s)
         dzs = []
-        for l, v in enumerate(lv):
-            ops.conv3d_wgrad(v[0], None, dy0a[l], [dws1[l]], None, k=1, groups=1, side=_direct(rws1[l]))
-            dzs.append(ops.conv3d(dy0a[l], None, [v[2]], None, k=1, cout=v[0].shape[1], groups=1, transposed=True)
-                       if ctx.needs_input_grad[2 + l] else None)
+        ops.conv1x1_collect()                              # the four data gradients of the 1x1 convs: one launch
+        try:
+            for l, v in enumerate(lv):
+                ops.conv3d_wgrad(v[0], None, dy0a[l], [dws1[l]], None, k=1, groups=1, side=_direct(rws1[l]))
+                dzs.append(ops.conv3d(dy0a[l], None, [v[2]], None, k=1, cout=v[0].shape[1], groups=1, transposed=True)
+                           if ctx.needs_input_grad[2 + l] else None)
+        finally:
+            ops.conv1x1_flush()
         return (None, None, *dzs, *rws1, *rws2)
 
 

@@ -484,10 +484,39 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
             L.check(lib.xh_norm_finalize(_stream(), 0, _p(in_stats[0]), n, stats[0].shape[1], int(in_stats[1]), 1, NORM_EPS, None,
                                          None, None, None, 1, _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3])),
                     "xh_norm_finalize")
+    if _C1_COLLECT[0] is not None and k == 1 and stride == 1 and stats is None and nb is None:
+        _C1_COLLECT[0].append((desc, ptrs, (xa, xb, out, weights, biases, pre, e, red)))     # launched by conv1x1_flush()
+        return out
     L.check(lib.xh_conv3d_fwd(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_fwd")
     if stats is not None:
         return (out,) + stats
     return out
+
+
+_C1_COLLECT = [None]
+
+
+def conv1x1_collect():
+    """The k = 1 conv3d calls from here to conv1x1_flush() are recorded instead of launched (their output tensors are returned as
+    usual) and then issued as multi-problem launches of up to 4 (xh_conv1x1_multi): the VU-block convs of the four fusion levels."""
+    _C1_COLLECT[0] = []
+
+
+def conv1x1_flush():
+    calls, _C1_COLLECT[0] = _C1_COLLECT[0] or [], None
+    lib = L.load()
+    for part in _chunks(calls):
+        n = len(part)
+        rc = 1
+        if n > 1:
+            descs = (C.POINTER(L.ConvDesc) * n)(*[C.pointer(c[0]) for c in part])
+            ptrs = (C.POINTER(L.ConvPtrs) * n)(*[C.pointer(c[1]) for c in part])
+            rc = lib.xh_conv1x1_multi(_stream(), n, descs, ptrs)
+        if rc == 1:                               # not batchable (mixed epilogues / layouts): one by one
+            for c in part:
+                L.check(lib.xh_conv3d_fwd(_stream(), C.byref(c[0]), C.byref(c[1])), "xh_conv3d_fwd")
+        else:
+            L.check(rc, "xh_conv1x1_multi")
 
 
 def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None):
