@@ -439,6 +439,11 @@ class ConvInLrelu(Function):
 LATENT_BATCH = [True]
 
 
+class LatentFallback(RuntimeError):
+    """LatentPath cannot take this configuration (the exact-2x upsampling kernels are switched off or do not take the layout):
+    the caller runs the per-level nodes instead."""
+
+
 def set_latent_batch(enabled):
     """A/B switch: the latent path of all fusion levels as one autograd node whose element-wise passes are multi-problem launches
     (LatentPath) instead of two ConvInLrelu nodes per level."""
@@ -470,7 +475,7 @@ class LatentPath(Function):
             ops.conv1x1_flush()
         ups = ops.upsample2x_in_act_multi(y0a, reda, LEAK)
         if ups is None:
-            raise RuntimeError("LatentPath: the exact-2x upsampling kernel does not take this layout (use set_latent_batch(False))")
+            raise LatentFallback("the exact-2x upsampling kernel does not take this layout")
         y0b, redb = [], []
         for (u, _, _, _, _), w, g in zip(ups, w2s, groups2):   # depthwise 3^3 (+ output moments)
             red = ops.zeros_red(u, u.shape[0], w.shape[0])

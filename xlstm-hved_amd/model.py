@@ -533,11 +533,14 @@ class AbstractFusion3DUNet(nn.Module):
         if batch:
             # all levels as ONE autograd node with multi-problem launches for the element-wise passes (Fn.LatentPath)
             zs = [zml[3 * l] for l in range(nlev)]
-            feats_l = Fn.LatentPath.apply(nlev, tuple(self.conv_blocks[l].groups for l in range(nlev)), *zs,
-                                          *[self.VU_blocks[l][0].conv.weight for l in range(nlev)],
-                                          *[self.conv_blocks[l].conv.weight for l in range(nlev)])
-            for level in range(nlev):
-                outs[level] = (feats_l[level], zml[3 * level + 1], zml[3 * level + 2])
+            try:
+                feats_l = Fn.LatentPath.apply(nlev, tuple(self.conv_blocks[l].groups for l in range(nlev)), *zs,
+                                              *[self.VU_blocks[l][0].conv.weight for l in range(nlev)],
+                                              *[self.conv_blocks[l].conv.weight for l in range(nlev)])
+                for level in range(nlev):
+                    outs[level] = (feats_l[level], zml[3 * level + 1], zml[3 * level + 2])
+            except Fn.LatentFallback:
+                batch = False
         side = None
         if ops.LEVEL_STREAMS[0] and x.is_cuda and nlev > 1:
             pool = self.__dict__.setdefault("_level_streams", {}).setdefault(x.device, [])
