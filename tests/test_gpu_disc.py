@@ -70,6 +70,11 @@ def _conv_case(n, cin, cout, s, sp, ks, dtype, seed=5, check_halo_variants=True)
     gcl = _cl(gyp).to(DEV)
     dx = D._conv(gcl, D._pack(wd, 1, cop, cpad, dtype), None, 1, s, n, spo, sp, cop, cpad, ks=ks)
     e["dx"] = l2_err(_nc(dx.cpu())[:, :cin], xo.grad)
+    if s == 2 and cpad % 64 == 0:                         # source-block data gradient (default) vs the gather kernel
+        D.L.load().xh_set_option(14, 16384)
+        dx2 = D._conv(gcl, D._pack(wd, 1, cop, cpad, dtype), None, 1, s, n, spo, sp, cop, cpad, ks=ks)
+        D.L.load().xh_set_option(14, 0)
+        assert l2_err(dx.float().cpu(), dx2.float().cpu()) < 4e-3 * k16
     if cin == 7 and cout == 64 and check_halo_variants:   # LDS-halo data gradient vs the generic kernel
         D.L.load().xh_set_option(14, 1024)
         dx2 = D._conv(gcl, D._pack(wd, 1, cop, cpad, dtype), None, 1, s, n, spo, sp, cop, cpad, ks=ks)
@@ -212,11 +217,17 @@ def test_dconv_256x128_tiles_match_128x128_tiles(mode, ks):
         w = torch.randn(cs, cn, ks, ks, ks, device=DEV) * (2.0 / (ks ** 3 * cn)) ** 0.5
         wpt = D._pack(w, 1, cs, cn, dtype)
         outs = []
-        for opt in (0, 256):
+        for opt in (16384, 16384 | 256, 0):                 # bit 16384: the gather kernel instead of the source-block kernel (round 5)
             lib.xh_set_option(14, opt)
             outs.append(D._conv(gy, wpt, None, 1, s, 1, spo, sp, cs, cn, ks=ks))
         lib.xh_set_option(14, 0)
         assert torch.equal(outs[0], outs[1])
+        # the source-block kernel (default) sums the same products slice by slice instead of tap by tap: fp32 round-off before the
+        # 16-bit rounding of the result
+        assert l2_err(outs[2].float().cpu(), outs[0].float().cpu()) < 2e-3
+        ref = F.conv_transpose3d(_nc(gy.float().cpu()), w.to(dtype).float().cpu(), stride=2, padding=1,
+                                 output_padding=tuple(sp[i] - ((spo[i] - 1) * 2 - 2 + ks) for i in range(3)))
+        assert l2_err(_nc(outs[2].float().cpu()), ref) < 8e-3
 
 
 @pytest.mark.parametrize("ks", [4, 3], ids=["k4", "k3"])

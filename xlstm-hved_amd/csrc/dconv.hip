@@ -387,6 +387,202 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Stride-2 data gradient with the SOURCE BLOCK staged once per channel slice (round 5).
+//
+// dconv_cl_kernel gathers, for every tap and 32-channel K step, the A rows of its 256 destination voxels from global memory: the
+// data gradient 64 <- 128 @63^3 (the dominant launch of a training step: 2 x 1.08 ms at 0.145 of the dense MFMA peak) moves
+// M x K x 2 B = 2.05 M rows x 1 024 x 2 B = 4.2 GB through L1 / L2 for a 64 MB dY -- every dY row is fetched once per tap and per
+// destination parity class, 64 times in all -- plus 1 GB of weight rows, at 20 KB per 1 MFLOP: the launch runs at the rate the
+// cache hierarchy delivers those re-reads (4.7 TB/s), not at the matrix cores' rate.
+//
+// A parity class of a stride-2 data gradient reaches only 2 (K = 4; 1 or 2 for K = 3) source offsets per axis, so a block of
+// 8 x 8 x 8 destination voxels of the class needs a source block of at most 9 x 9 x 9 voxels.  Here a workgroup of 8 waves owns such
+// a block (M = 512 rows) x 64 destination channels; per 32-channel slice of dY it stages
+//   * the source block ONCE: <= 729 rows x 64 B = 46 KB (out-of-volume rows arrive as zeros from the buffer load), and
+//   * the slice's weight rows of all the class's taps: <= 8 x 64 x 64 B = 32 KB,
+// and then runs the taps from LDS: the A fragment of destination row m and tap t is the staged row m + offset(t) -- an address.
+// Per tile that is 4 x 78 KB = 0.3 MB of loads for 67 MFLOP (215 flop / B instead of 52); LDS fragment reads as before (4 + 4 per
+// 16 MFMAs).  One LDS buffer of 79 KB, two workgroups per CU: one stages while the other multiplies.
+// Wave w owns destination plane w of the block (4 M tiles of 2 rows x 8 voxels) and all 4 N tiles; epilogue as dconv_cl_kernel
+// (bias, LeakyReLU mask of the layer below, rounding, channel sums).
+template <int FMT>
+__global__ __launch_bounds__(512, 4) void dconv_dgrad_halo_kernel(const DConvK a) {
+  constexpr int BT = 8, BN = 64, TM = 4, TN = 4;
+  constexpr int A_BYTES = 729 * 64, B_BYTES = 8 * BN * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + A_BYTES;
+  double* s_stat = reinterpret_cast<double*>(smem);      // epilogue: [8 waves][BN][2], after the last matrix phase
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int n = blockIdx.z, cn0 = blockIdx.y * BN;
+  int ci = 0;
+  for (int k = 1; k < a.ncls; ++k)
+    if ((int)blockIdx.x >= a.c[k].tile0) ci = k;
+  const DClass& cl = a.c[ci];
+  int mt = blockIdx.x - cl.tile0;
+  if ((a.xcd & 1) && !(cl.tile0 & 7) && !(cl.ntile & 7)) mt = xcd_swizzle(mt, cl.ntile);
+  const int tnw = (cl.Jw + BT - 1) / BT, tnh = (cl.Jh + BT - 1) / BT;
+  const int tjw = mt % tnw, t1 = mt / tnw;
+  const int tjh = t1 % tnh, tjd = t1 / tnh;
+  const int j0d = tjd * BT, j0h = tjh * BT, j0w = tjw * BT;
+  const int nd = cl.td.n, nh = cl.th.n, nw = cl.tw.n, ntap = nd * nh * nw;
+  int mind = cl.td.off[0], minh = cl.th.off[0], minw = cl.tw.off[0];
+  for (int k = 1; k < nd; ++k) mind = min(mind, cl.td.off[k]);
+  for (int k = 1; k < nh; ++k) minh = min(minh, cl.th.off[k]);
+  for (int k = 1; k < nw; ++k) minw = min(minw, cl.tw.off[k]);
+  const int HD = BT + nd - 1, HH = BT + nh - 1, HW = BT + nw - 1;
+  const int nrows = HD * HH * HW;
+  const long long xs_n = (long long)n * a.Di * a.Hi * a.Wi;
+  const u16* x_n = a.x + xs_n * a.Cs;
+  const int x_lim = a.Di * a.Hi * a.Wi * a.Cs - 8;
+  __amdgpu_buffer_rsrc_t x_rs;
+  {
+    const unsigned long long v = (unsigned long long)x_n;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (x_lim + 8) * 2, 0x00020000);
+  }
+  // ---- staging plan: A items (source row, 16-byte chunk), B items (tap, destination channel, chunk) ----
+  constexpr int NA = (729 * 4 + 511) / 512, NB = (8 * BN * 4) / 512;     // 6, 4
+  unsigned a_off[NA];                                    // byte offset of the row's chunk in the sample (slice 0), or out of range
+  int a_lds[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int it = tid + 512 * i;
+    const int row = it >> 2, ch = it & 3;
+    const bool live = row < nrows;
+    const int rr = live ? row : 0;
+    const int hw_ = rr % HW, t2 = rr / HW;
+    const int hh_ = t2 % HH, hd_ = t2 / HH;
+    const int sd = (j0d + hd_) * a.smul + mind, sh = (j0h + hh_) * a.smul + minh, sw = (j0w + hw_) * a.smul + minw;
+    const bool inb = live && (unsigned)sd < (unsigned)a.Di && (unsigned)sh < (unsigned)a.Hi && (unsigned)sw < (unsigned)a.Wi;
+    a_off[i] = inb ? (unsigned)((((sd * a.Hi + sh) * a.Wi + sw) * a.Cs + ch * 8) * 2) : 0xFFFFFFF0u;
+    a_lds[i] = live ? sw64(row, ch) : -1;
+  }
+  int b_src[NB], b_lds[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int it = tid + 512 * i;
+    const int ch = it & 3, col = (it >> 2) & (BN - 1), t = it >> 8;
+    const bool live = t < ntap;
+    const int tt = live ? t : 0;
+    const int iw = tt % nw, t3 = tt / nw;
+    const int ih = t3 % nh, id = t3 / nh;
+    const int tapk = (cl.td.t[id] * a.K + cl.th.t[ih]) * a.K + cl.tw.t[iw];
+    b_src[i] = live ? tapk * a.wtap_stride + min(cn0 + col, a.Cn - 1) * a.Kc + ch * 8 : -1;
+    b_lds[i] = t * (BN * 64) + sw64(col, ch);
+  }
+  // ---- fragment rows: wave w = destination plane w of the block; M tile i = rows 2 i, 2 i + 1; lane row = (r16 >> 3, r16 & 7) ----
+  int a_row[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_row[i] = (wv * HH + 2 * i + (r16 >> 3)) * HW + (r16 & 7);
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nslice = a.Cs / 32;
+  for (int sl = 0; sl < nslice; ++sl) {
+    uint4 qa[NA], qb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      qa[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)(a_off[i] == 0xFFFFFFF0u ? a_off[i] : a_off[i] + sl * 64), 0, 0));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) qb[i] = *reinterpret_cast<const uint4*>(a.w + (unsigned)(max(b_src[i], 0) + sl * 32));
+    if (sl > 0) __syncthreads();                         // every wave is done with the previous slice's image
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (a_lds[i] >= 0) *reinterpret_cast<uint4*>(As + a_lds[i]) = qa[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (b_src[i] >= 0) *reinterpret_cast<uint4*>(Bs + b_lds[i]) = qb[i];
+    __syncthreads();
+    for (int id = 0; id < nd; ++id)
+      for (int ih = 0; ih < nh; ++ih)
+        for (int iw = 0; iw < nw; ++iw) {
+          const int t = (id * nh + ih) * nw + iw;
+          const int roff = ((cl.td.off[id] - mind) * HH + (cl.th.off[ih] - minh)) * HW + (cl.tw.off[iw] - minw);
+          h16x8 af[TM];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h16x8*>(As + sw64(a_row[i] + roff, kg));
+          const unsigned char* bt = Bs + t * (BN * 64);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const h16x8 bf = *reinterpret_cast<const h16x8*>(bt + sw64(j * 16 + r16, kg));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = mfma16x16x32<FMT>(bf, af[i], acc[i][j]);      // D^T: channels on the rows
+          }
+        }
+  }
+
+  // ---- epilogue (as dconv_cl_kernel): bias, mask of the layer below, rounding, channel sums ----
+  const long long ys_n = (long long)n * a.Do * a.Ho * a.Wo;
+  float b4[TN][4], s0[TN][4], s1[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cn = cn0 + j * 16 + 4 * kg + r;
+      b4[j][r] = (a.bias && cn < a.Cn) ? a.bias[cn] : 0.f;
+      s0[j][r] = 0.f; s1[j][r] = 0.f;
+    }
+  const int jd = j0d + wv;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int jh = j0h + 2 * i + (r16 >> 3), jw = j0w + (r16 & 7);
+    const bool ok = jd < cl.Jd && jh < cl.Jh && jw < cl.Jw;
+    const long long vox = ok ? ys_n + ((long long)(jd * a.omul + cl.pd) * a.Ho + (jh * a.omul + cl.ph)) * a.Wo + (jw * a.omul + cl.pw) : ys_n;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cn = cn0 + j * 16 + 4 * kg;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + b4[j][r];
+        if (a.act == XH_ACT_LRELU) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+      }
+      if (a.mask && ok) {
+        const uint2 mm = *reinterpret_cast<const uint2*>(a.mask + vox * a.Cn + cn);
+        if (!(cvt_lo<FMT>(mm.x) > 0.f)) v[0] *= a.slope;
+        if (!(cvt_hi<FMT>(mm.x) > 0.f)) v[1] *= a.slope;
+        if (!(cvt_lo<FMT>(mm.y) > 0.f)) v[2] *= a.slope;
+        if (!(cvt_hi<FMT>(mm.y) > 0.f)) v[3] *= a.slope;
+      }
+      const unsigned q0 = cvt_pack<FMT>(v[0], v[1]), q1 = cvt_pack<FMT>(v[2], v[3]);
+      if (a.red && ok) {
+        const float w0 = cvt_lo<FMT>(q0), w1 = cvt_hi<FMT>(q0), w2 = cvt_lo<FMT>(q1), w3 = cvt_hi<FMT>(q1);
+        s0[j][0] += w0; s0[j][1] += w1; s0[j][2] += w2; s0[j][3] += w3;
+        s1[j][0] += w0 * w0; s1[j][1] += w1 * w1; s1[j][2] += w2 * w2; s1[j][3] += w3 * w3;
+      }
+      if (ok) *reinterpret_cast<uint2*>(a.y + vox * a.Cn + cn) = make_uint2(q0, q1);
+    }
+  }
+  if (a.red) {
+    __syncthreads();                                     // the LDS images are no longer read
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t0 = row16_sum(s0[j][r]), t1 = row16_sum(s1[j][r]);
+        if (r16 == 0) {
+          const int col = j * 16 + 4 * kg + r;
+          s_stat[(wv * BN + col) * 2] = (double)t0;
+          s_stat[(wv * BN + col) * 2 + 1] = (double)t1;
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < BN * 2; i += 512) {
+      const int col = i >> 1;
+      double t = 0.0;
+#pragma unroll
+      for (int m2 = 0; m2 < 8; ++m2) t += s_stat[(m2 * BN + col) * 2 + (i & 1)];
+      atomicAdd(&a.red[((long long)n * a.Cn + cn0 + col) * 2 + (i & 1)], t);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // weight gradient: dw[tap][cn][cs] += sum_m dY[m][cn] * X[src(m, tap)][cs]   (fp32, packed order; split over voxel ranges)
 struct DWgK {
   const u16* x; const u16* dy; float* dw;
@@ -1197,7 +1393,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //                                512 x 64 for the 64-channel data gradient: 340 -> 389 us.)
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1324,6 +1520,29 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
     if (c.Jd <= 0 || c.Jh <= 0 || c.Jw <= 0) continue;
     fill_taps(&c.td, mode, stride, pd, ks); fill_taps(&c.th, mode, stride, ph, ks); fill_taps(&c.tw, mode, stride, pw, ks);
     ++nc;
+  }
+  if (mode == 1 && stride == 2 && nc > 0 && (Cs % 32) == 0 && (Cn % 64) == 0 && !(g_dconv_cfg & 16384)) {
+    // the source-block kernel (dconv_dgrad_halo_kernel): tiles of 8 x 8 x 8 destination voxels per parity class
+    a.ncls = nc;
+    int t = 0;
+    for (int k = 0; k < nc; ++k) {
+      a.c[k] = all[k];
+      a.c[k].tile0 = t;
+      a.c[k].ntile = cdiv(all[k].Jd, 8) * cdiv(all[k].Jh, 8) * cdiv(all[k].Jw, 8);
+      t += a.c[k].ntile;
+    }
+    dim3 grid(t, Cn / 64, N);
+    a.xcd = ((t & 7) == 0 || grid.y * grid.z == 1) && !(g_dconv_cfg & 64);
+    const size_t shm = 729 * 64 + 8 * 64 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      attr_done = true;
+    }
+    if (dtype == XH_F16) hipLaunchKernelGGL((dconv_dgrad_halo_kernel<1>), grid, dim3(512), shm, st, a);
+    else hipLaunchKernelGGL((dconv_dgrad_halo_kernel<0>), grid, dim3(512), shm, st, a);
+    return xh_launch_status();
   }
   if (g_dconv_cfg & 1) {
     for (int k = 0; k < nc; ++k) {
