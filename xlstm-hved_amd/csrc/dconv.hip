@@ -1393,7 +1393,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //                                512 x 64 for the 64-channel data gradient: 340 -> 389 us.)
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1521,7 +1521,10 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
     fill_taps(&c.td, mode, stride, pd, ks); fill_taps(&c.th, mode, stride, ph, ks); fill_taps(&c.tw, mode, stride, pw, ks);
     ++nc;
   }
-  if (mode == 1 && stride == 2 && nc > 0 && (Cs % 32) == 0 && (Cn % 64) == 0 && !(g_dconv_cfg & 16384)) {
+  // measured (tools/microbench_disc.py, ks = 4, bf16): 64 <- 128 @127^3 691 -> 451 us, 128 <- 256 @63^3 185 -> 178 us, 256 <- 512 @31^3
+  // 97 -> 114 us (256 workgroups of 16 K slices each: the gather kernel's 64 x 64 tiles fill the chip better there)
+  if (mode == 1 && stride == 2 && nc > 0 && (Cs % 32) == 0 && (Cn % 64) == 0 && !(g_dconv_cfg & 16384) &&
+      ((long long)Do * Ho * Wo >= 200000 || (g_dconv_cfg & 32768))) {
     // the source-block kernel (dconv_dgrad_halo_kernel): tiles of 8 x 8 x 8 destination voxels per parity class
     a.ncls = nc;
     int t = 0;
