@@ -1393,7 +1393,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //                                512 x 64 for the 64-channel data gradient: 340 -> 389 us.)
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1421,7 +1421,10 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   }
   else if (cfg == 1) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 4>), grid, dim3(256), 0, st, a);
   else if (cfg == 4) {
-    if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 2>), grid, dim3(256), 0, st, a);
+    // few workgroups (< 256 tiles of 128 x 128), each a chain of hundreds of K steps that one step of prefetch does not cover: TWO
+    // K steps of loads in flight (round 5; 256 -> 512 @31^3 forward 219.7 -> 188.7 us, four steps 186.5; bit 16: one step as before)
+    if (kq2 && !(g_dconv_cfg & 65536)) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 2, 2>), grid, dim3(256), 0, st, a);
+    else if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1>), grid, dim3(256), 0, st, a);
   } else if (cfg == 3) {
     if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 2, 2>), grid, dim3(256), 0, st, a);
