@@ -839,7 +839,9 @@ def roofline_pass(step, ops, nsteps, dtype):
                     and w_ % (16 // esz) == 0 and kw.get("pre") is None)
             k7 = k == 7 and esz == 2 and cin == 4 and dy.shape[1] == 2 and groups == 1 and w_ % 32 == 0 and kw.get("pre") is None
             k1 = k == 1 and kw.get("stride", 1) == 1 and (dy.shape[2] * dy.shape[3] * dy.shape[4]) % (16 // esz) == 0
-            cls = (f"q4_{qs}" if q4 else ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small")
+            # rows of 64 / 128 voxels, H a multiple of 8: the full-row kernel (conv3d_wgrad_q5.hip), 12 problems per launch
+            q5 = q4 and w_ in (64, 128) and xa.shape[3] % 8 == 0
+            cls = ("q5" if q5 else f"q4_{qs}" if q4 else ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small")
                    if mfma else "k1" if k1 else "s2" if s2 else "k7" if k7 else "tiny" if tiny else "rest")
             pending_meta.append((cls, nbytes, flops, shape))
             return orig_wg(xa, xb, dy, dws, dbs, **kw)
@@ -889,7 +891,7 @@ def roofline_pass(step, ops, nsteps, dtype):
         if len(calls) != len(metas):                         # something bypassed the wrapper: do not attribute
             ops._WG["deferred"] = calls
             return orig_flush()
-        for cls in ("q4_1", "q4_2", "q4_3", "k1", "s2", "k7", "tiny", "small", "big"):
+        for cls in ("q5", "q4_1", "q4_2", "q4_3", "k1", "s2", "k7", "tiny", "small", "big"):
             grp = [(c, m) for c, m in zip(calls, metas) if m[0] == cls]
             if not grp:
                 continue
@@ -898,7 +900,7 @@ def roofline_pass(step, ops, nsteps, dtype):
             e0.record()
             orig_flush()
             e1.record()
-            nl = -(-len(grp) // (8 if cls.startswith("q4") else 20 if cls == "k1" else 4 if cls in ("s2", "k7") else 8 if cls == "tiny" else 7))
+            nl = -(-len(grp) // (12 if cls == "q5" else 8 if cls.startswith("q4") else 20 if cls == "k1" else 4 if cls in ("s2", "k7") else 8 if cls == "tiny" else 7))
             if cls == "k7":
                 nl = 2 * nl if len(grp) > 1 else 2            # partial sums + second-stage reduction
             records.append((ops.last_conv_kernel(), e0, e1, sum(m[1] for _, m in grp), sum(m[2] for _, m in grp),
