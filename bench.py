@@ -995,7 +995,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     avg_ms, nbytes, flops = ms_sum / cnt, bytes_sum / cnt, flops_sum / cnt
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
     tfl = flops / (avg_ms * 1e-3) / 1e12
-    mfma = "mfma" in name or "q4" in name                # the quad-channel kernels are MFMA kernels too
+    mfma = "mfma" in name or "q4" in name or "q5" in name   # the quad-channel kernels are MFMA kernels too
     peak_tf = BF16_MFMA_PEAK_TFLOPS if mfma else FP32_VALU_PEAK_TFLOPS
     # roofline: the kernel is HBM-bound when its arithmetic intensity is below peak_flops / peak_bandwidth
     if flops / nbytes < peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):

@@ -78,13 +78,14 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   const int nn = lane & 15, g = lane >> 4;
   const int unit = b / a.wpu, w = b - unit * a.wpu;
   const int oq = unit / a.nchunk, chunk = unit - oq * a.nchunk;
-  int t_first, t_stride, t_end;
-  if ((a.ntile & 7) == 0 && (a.wpu & 7) == 0) {        // workgroups of one XCD walk one contiguous eighth of the tiles
-    const int per = a.ntile >> 3;
-    t_first = (w & 7) * per + (w >> 3); t_stride = a.wpu >> 3; t_end = ((w & 7) + 1) * per;
-  } else {
-    t_first = w; t_stride = a.wpu; t_end = a.ntile;
-  }
+  // A unit's work is the linear sequence of its (column = (sample, 8-row tile), plane) pairs; workgroup w of the unit takes the
+  // w-th of wpu equal shares of it -- a contiguous run of planes, split where it crosses into the next column -- so every workgroup
+  // of a launch has the same number of plane steps to within one (tiles of a fixed depth left 5 - 30 % of the 256 workgroups
+  // short of work or unused: the count per unit had to divide the tile count)
+  const int D_ = a.D;
+  const long long planes = (long long)a.tilesH * a.N * D_;
+  long long p_lo = planes * w / a.wpu;
+  const long long p_hi = planes * (w + 1) / a.wpu;
   f32x4 acc[3];
 #pragma unroll
   for (int kd = 0; kd < 3; ++kd) acc[kd] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -139,13 +140,12 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     y_goff[k] = (unsigned)((long long)co * dhw + (long long)r * W + 8 * j);
   }
 
-  for (int t = t_first; t < t_end; t += t_stride) {
-    int wk = t;
-    const int th = wk % a.tilesH; wk /= a.tilesH;
-    const int ds = wk % a.dsegs;
-    const int n = wk / a.dsegs;
+  while (p_lo < p_hi) {
+    const int col = (int)(p_lo / D_);
+    const int d0 = (int)(p_lo - (long long)col * D_), d1 = (int)min((long long)D_, d0 + (p_hi - p_lo));
+    p_lo += d1 - d0;
+    const int th = col % a.tilesH, n = col / a.tilesH;
     const int h0 = th * Q5_TH;
-    const int d0 = ds * a.sd, d1 = min(D, d0 + a.sd);
     // ---- per-tile part of the x plan ----
     const ST* xsrc = (cin_base < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)cin_base * dhw
                                       : (const ST*)a.xb + n * a.xb_bs + (long long)(cin_base - a.Ca) * dhw);
@@ -350,24 +350,37 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   auto ucost = [](const WgQ4& w) { return (double)w.N * w.D * (w.H / Q5_TH) * (w.W == 128 ? 1.0 : w.W == 64 ? 0.7 : 0.55); };
   double total = 0.0;
   for (int i = 0; i < n; ++i) total += probs[i].nq * ucost(probs[i]);
+  // whole workgroups per unit: the integer part of the unit's share, then the workgroups left over go, one unit (= nq workgroups) at a
+  // time, to the problems with the largest remainder -- never more than `budget` in all (a 257th workgroup would wait for a CU and
+  // double the launch)
+  int wq[Q5_MULTI], used = 0;
+  double frac[Q5_MULTI];
+  for (int i = 0; i < n; ++i) {
+    const double r = budget * ucost(probs[i]) / total;
+    wq[i] = (int)r < 1 ? 1 : (int)r;
+    const long long planes = (long long)probs[i].tilesH * probs[i].N * probs[i].D;
+    if (wq[i] > planes / 4) wq[i] = (int)(planes / 4 > 0 ? planes / 4 : 1);   // runs of at least 4 planes
+    frac[i] = r - wq[i];
+    used += probs[i].nq * wq[i];
+  }
+  for (;;) {
+    int best = -1;
+    for (int i = 0; i < n; ++i) {
+      const long long planes = (long long)probs[i].tilesH * probs[i].N * probs[i].D;
+      if (used + probs[i].nq <= budget && wq[i] + 1 <= planes / 4 && (best < 0 || frac[i] > frac[best])) best = i;
+    }
+    if (best < 0) break;
+    ++wq[best];
+    frac[best] -= 1.0;
+    used += probs[best].nq;
+  }
   for (int i = 0; i < n; ++i) {
     m.p[i] = probs[i];
     WgQ4& a = m.p[i];
-    int w = (int)(budget * ucost(a) / total + 0.5);
-    if (w < 1) w = 1;
-    const int cols = a.tilesH * a.N;
-    int dsegs = (w + cols - 1) / cols;                   // tiles per unit: at least w (every workgroup busy), segments of >= 8 planes
-    const int max_segs = a.D >= 8 ? a.D / 8 : 1;
-    if (dsegs > max_segs) dsegs = max_segs;
-    if (dsegs < 1) dsegs = 1;
-    a.sd = (a.D + dsegs - 1) / dsegs;
-    a.dsegs = (a.D + a.sd - 1) / a.sd;
-    a.ntile = cols * a.dsegs;
-    if (w > a.ntile) w = a.ntile;
-    if (w >= 8 && (a.ntile & 7) == 0) w &= ~7;
-    a.wpu = w;
-    a.nb = a.nq * w;
-    m.off[i + 1] = m.off[i] + ((a.nb + 7) & ~7);
+    a.sd = a.D; a.dsegs = 1; a.ntile = a.tilesH * a.N;             // (informational: the kernel cuts the plane sequence itself)
+    a.wpu = wq[i];
+    a.nb = a.nq * wq[i];
+    m.off[i + 1] = m.off[i] + a.nb;
   }
   static bool attr_done = false;
   if (!attr_done) {
