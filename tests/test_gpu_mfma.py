@@ -856,6 +856,39 @@ def test_k7_gate_weight_gradient_fp32_storage_on_the_matrix_cores(sp):
     assert e0 < 1e-5 and e1 < 1e-3 and l2_err(b1, b0) < 1e-3
 
 
+@pytest.mark.parametrize("sp", [(9, 12, 32), (16, 16, 64), (23, 16, 32)])
+def test_k7_gate_conv_fp32_storage_on_the_matrix_cores(sp):
+    """ops.set_fp32_mfma(True): the composed 7^3 gate conv (4 -> 2 + sigmoid) and its data gradient (2 -> 4) for fp32 tensors through
+    conv7_as_kernel<2, ...> (fp32 loads and stores, operands rounded ONCE to fp16 on their way into LDS, fp32 accumulation) against
+    the fp32 FMA kernel and stock fp32 conv3d on the same inputs: an output is a sum of 1 372 products of independently rounded
+    operands -- relative L2 at the 2e-4 level behind the sigmoid."""
+    torch.manual_seed(43)
+    x = torch.randn((2, 4) + sp, device=DEV)
+    w = torch.randn(2, 4, 7, 7, 7, device=DEV) * 0.05
+    b = torch.randn(2, device=DEV) * 0.1
+    g = torch.randn((2, 2) + sp, device=DEV)
+
+    def run(on):
+        X.ops.set_fp32_mfma(on)
+        try:
+            y = X.ops.conv3d(x, None, [w], [b], k=7, cout=2, act=X.ops.ACT_SIGMOID)
+            k1 = X.ops.last_conv_kernel()
+            dx = X.ops.conv3d(g, None, [w], None, k=7, cout=4, transposed=True)
+            k2 = X.ops.last_conv_kernel()
+            torch.cuda.synchronize()
+            return y.cpu(), dx.cpu(), k1, k2
+        finally:
+            X.ops.set_fp32_mfma(False)
+    y0, dx0, k0a, k0b = run(False)
+    y1, dx1, k1a, k1b = run(True)
+    assert "conv7_as_kernel<2" in k1a and "conv7_as_kernel<2" in k1b and "conv7" not in k0a, (k0a, k1a, k1b)
+    yo = torch.sigmoid(torch.nn.functional.conv3d(x.cpu(), w.cpu(), b.cpu(), padding=3))
+    dxo = torch.nn.functional.conv_transpose3d(g.cpu(), w.cpu(), padding=3)
+    e = (l2_err(y0, yo), l2_err(y1, yo), l2_err(dx0, dxo), l2_err(dx1, dxo))
+    print(sp, "fp32 FMA y %.2e, fp16 operands y %.2e; dx %.2e / %.2e" % e)
+    assert e[0] < 1e-5 and e[2] < 1e-5 and e[1] < 5e-4 and e[3] < 1e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("cfg", [dict(n=2, cin=4, cout=4, g=1, sp=(9, 16, 64)), dict(n=1, cin=16, cout=16, g=4, sp=(21, 8, 128)),
                                  dict(n=1, cin=12, cout=4, g=1, sp=(10, 16, 128), split=4), dict(n=1, cin=24, cout=8, g=1, sp=(6, 8, 64), split=16),

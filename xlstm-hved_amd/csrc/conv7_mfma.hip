@@ -234,9 +234,15 @@ __global__ __launch_bounds__(128 * KSPLIT, 2) void conv7_mfma_kernel(const Conv7
 //   * so a step is 1 LDS fragment read per 7 (4) MFMAs, and the ring needs the two planes being read plus two incoming: 4 slots.
 // Partial tiles (other wave pairs' rows) meet in LDS when an output plane completes, as before; one barrier per plane.
 // ~220 registers: one workgroup of 8 waves per CU.
+// FMT 2 = fp32 STORAGE (the fp32_mfma mode, xh_set_option(18, 1)): x is read and y written as fp32, the operands are rounded ONCE to fp16
+// on their way into LDS / the weight table, fp32 accumulation -- like the weight gradients of that mode (conv7_wgrad_mfma_multi_kernel<2>).
+template <int FMT> struct C7Store { typedef h16<FMT> T; };
+template <> struct C7Store<2> { typedef float T; };
 template <int FMT, int CI, int CO, int KSPLIT = 4, bool BREG = false>
 __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(const Conv7K a) {
-  typedef h16<FMT> ST;
+  typedef typename C7Store<FMT>::T ST;
+  constexpr int CF = FMT == 2 ? 1 : FMT;               // format of the LDS images / MFMA operands
+  constexpr bool F32S = FMT == 2;
   constexpr int PPM = 32 / (8 * CI);
   constexpr int NKD = (7 + PPM - 1) / PPM;
   constexpr int JR = 16 / CO;
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
         const int tap = (kd * 7 + kh) * 7 + kw;
         v = a.d.transposed ? wp[((long long)ci * CO + co) * 343 + (342 - tap)] : wp[((long long)co * CI + ci) * 343 + tap];
       }
-      reinterpret_cast<unsigned short*>(s_tb)[idx] = cvt_out<FMT>(v);
+      reinterpret_cast<unsigned short*>(s_tb)[idx] = cvt_out<CF>(v);
     }
     for (int i = tid; i < 4 * PLANE / 16; i += NTHR) reinterpret_cast<uint4*>(s_in)[i] = make_uint4(0, 0, 0, 0);
   }
@@ -307,19 +313,28 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
   const bool s_inb = has_item && (unsigned)s_gh < (unsigned)H && s_gw >= 0 && s_gw < W;
   const ST* s_src = (const ST*)a.p.xa + n * a.d.xa_bs + (long long)min(max(s_gh, 0), H - 1) * W + min(max(s_gw, 0), W - 8);
   const int s_lds = (s_hy * IWP + s_gi * 8) * VB;
-  uint4 raw[CI];
+  uint4 raw[CI], raw2[F32S ? CI : 1];                   // fp32 storage: 8 voxels = two 16-byte loads per channel
   auto load_plane = [&](int gd) {
     const long long po = (long long)min(max(gd, 0), D - 1) * hw;
 #pragma unroll
-    for (int c = 0; c < CI; ++c) raw[c] = *reinterpret_cast<const uint4*>(s_src + (long long)c * dhw + po);
+    for (int c = 0; c < CI; ++c) {
+      raw[c] = *reinterpret_cast<const uint4*>(s_src + (long long)c * dhw + po);
+      if (F32S) raw2[c] = *reinterpret_cast<const uint4*>(s_src + (long long)c * dhw + po + 4);
+    }
+  };
+  auto to16 = [&](int c) -> uint4 {                     // the channel's 8 voxels as 16-bit pairs
+    if (!F32S) return raw[c];
+    return make_uint4(cvt2_pack<CF>(__uint_as_float(raw[c].x), __uint_as_float(raw[c].y)), cvt2_pack<CF>(__uint_as_float(raw[c].z), __uint_as_float(raw[c].w)),
+                      cvt2_pack<CF>(__uint_as_float(raw2[F32S ? c : 0].x), __uint_as_float(raw2[F32S ? c : 0].y)),
+                      cvt2_pack<CF>(__uint_as_float(raw2[F32S ? c : 0].z), __uint_as_float(raw2[F32S ? c : 0].w)));
   };
   auto store_plane = [&](int gd) {
     if (!has_item) return;
     const unsigned m = (s_inb && (unsigned)gd < (unsigned)D) ? 0xffffffffu : 0u;
     unsigned char* dst = s_in + ((gd + 8) & 3) * PLANE + s_lds;
     if (CI == 4) {
-      const unsigned u[4][4] = {{raw[0].x, raw[0].y, raw[0].z, raw[0].w}, {raw[1].x, raw[1].y, raw[1].z, raw[1].w},
-                                {raw[2].x, raw[2].y, raw[2].z, raw[2].w}, {raw[3].x, raw[3].y, raw[3].z, raw[3].w}};
+      const uint4 r0 = to16(0), r1 = to16(1), r2 = to16(CI > 2 ? 2 : 0), r3 = to16(CI > 3 ? 3 : 0);
+      const unsigned u[4][4] = {{r0.x, r0.y, r0.z, r0.w}, {r1.x, r1.y, r1.z, r1.w}, {r2.x, r2.y, r2.z, r2.w}, {r3.x, r3.y, r3.z, r3.w}};
 #pragma unroll
       for (int k2 = 0; k2 < 4; ++k2) {                  // voxels 2 k2, 2 k2 + 1: [c0 c1 | c2 c3] each
         uint4 o;
@@ -330,7 +345,8 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
         *reinterpret_cast<uint4*>(dst + k2 * 16) = o;
       }
     } else {
-      const unsigned u0[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w}, u1[4] = {raw[1].x, raw[1].y, raw[1].z, raw[1].w};
+      const uint4 r0 = to16(0), r1 = to16(1);
+      const unsigned u0[4] = {r0.x, r0.y, r0.z, r0.w}, u1[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {                  // voxels 4 h2 .. 4 h2 + 3: [c0 c1] each
         uint4 o;
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
                                      : *reinterpret_cast<const bf16x8*>(s_tb + (live ? b_off[i] + ks * PPM * 8 * GS * CO * 16 : z_off));
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
-                acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt] = mfma16x16x32<FMT>(av[mt], bv, acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt]);
+                acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt] = mfma16x16x32<CF>(av[mt], bv, acc[(u + 3 - ks * PPM + 2 * NS) % NS][mt]);
             }
           }
         }
@@ -449,16 +465,20 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
   }
 }
 
+int g_c7_as_f32off = 0;                                // xh_set_option(25, 1): fp32 storage keeps the fp32 vector kernel for the 7^3 convs
 int g_c7_as = 1;                                       // xh_set_option(24, v): 0 conv7_mfma_kernel, 1 conv7_as_kernel (weight fragments from LDS,
                                                        // two workgroups per CU) on volumes of >= 2^20 voxels, 2 the same with the weight
                                                        // fragments in registers, 3 conv7_as_kernel on every volume (tests)
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
-  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
+  extern int g_q4_f32;                               // fp32 storage with fp16 operands: xh_set_option(18, 1)
+  const bool f32s = d->dtype == XH_F32 && g_q4_f32 && !(g_c7_as_f32off);
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32s) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
   if (!((d->Cin == 4 && d->Cout == 2) || (d->Cin == 2 && d->Cout == 4))) return 1;
   if (d->pre || d->epi || d->Ca != d->Cin) return 1;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return 1;
   if ((d->xa_bs & 7) || (d->y_bs & 3) || (((long long)d->D * d->H * d->W) & 7)) return 1;
+  if (f32s && (d->act != XH_ACT_NONE && d->act != XH_ACT_SIGMOID && d->act != XH_ACT_LRELU && d->act != XH_ACT_RELU)) return 1;
   if (d->N > 65535) return 1;
   Conv7K a;
   a.d = *d;
@@ -473,8 +493,8 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   // against 14.2 / 8.7: runs of 2 planes there stage 8 planes for 2 outputs either way and the longer prologue loses -- so it takes the
   // volumes of >= 2^20 voxels only.  The LDS traffic per MFMA fell from 1.5 KB to 0.64 KB (0.14 KB with the weights in registers) and the
   // run time by a tenth: the kernel was never bound by LDS BANDWIDTH but by the read -> MFMA dependency chains of few resident waves.
-  const bool as = g_c7_as != 0 && (g_c7_as > 2 || (long long)d->D * d->H * d->W >= (1 << 20));
-  int dsegs = cdiv(as && (g_c7_as == 2 || d->Cin == 4) ? 256 : 512, cols * d->N);   // weight fragments in registers: one workgroup per CU
+  const bool as = f32s || (g_c7_as != 0 && (g_c7_as > 2 || (long long)d->D * d->H * d->W >= (1 << 20)));
+  int dsegs = cdiv(as && (f32s || g_c7_as == 2 || d->Cin == 4) ? 256 : 512, cols * d->N);   // weight fragments in registers: one workgroup per CU
   // runs of >= 8 planes (6 halo planes are staged per run) -- but on small volumes (<= 64^3) that leaves 8-64 workgroups on
   // 256 CUs and the run time is the serial chain of one workgroup (81 us at 32^3 and 64^3, like 128^3): runs of 2 there
   const int min_run = (long long)d->D * d->H * d->W <= (1 << 18) ? 2 : 8;
@@ -485,21 +505,21 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   a.dsegs = cdiv(d->D, a.sd);
   dim3 grid(cols * a.dsegs, 1, d->N);
   hipStream_t st = (hipStream_t)stream;
-  const int f = d->dtype == XH_F16 ? 1 : 0;
+  const int f = f32s ? 2 : d->dtype == XH_F16 ? 1 : 0;
   if (as) {
     static bool done_as = false;
     if (!done_as) {
 #define C7ATTR(F, CI_, CO_)                                                                                                             \
   (void)hipFuncSetAttribute((const void*)conv7_as_kernel<F, CI_, CO_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);  \
   (void)hipFuncSetAttribute((const void*)conv7_as_kernel<F, CI_, CO_, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
-      C7ATTR(0, 4, 2); C7ATTR(1, 4, 2); C7ATTR(0, 2, 4); C7ATTR(1, 2, 4);
+      C7ATTR(0, 4, 2); C7ATTR(1, 4, 2); C7ATTR(0, 2, 4); C7ATTR(1, 2, 4); C7ATTR(2, 4, 2); C7ATTR(2, 2, 4);
 #undef C7ATTR
       done_as = true;
     }
     const size_t part = (size_t)2 * 3 * 2 * 2 * 4 * 64 * sizeof(float);
     // measured at 128^3 (after the staging rewrite): forward (CI = 4) 42.9 us with the weight fragments in registers, 46.7 from the table,
     // 49.3 output-stationary; data gradient (CI = 2) 43.9 / 37.4 / 44.1
-    const bool breg = g_c7_as == 2 || (g_c7_as == 1 && d->Cin == 4);
+    const bool breg = f32s || g_c7_as == 2 || (g_c7_as == 1 && d->Cin == 4);
 #define C7AS(F, CI_, CO_, shm)                                                                                  \
   do {                                                                                                          \
     if (breg) hipLaunchKernelGGL((conv7_as_kernel<F, CI_, CO_, 4, true>), grid, dim3(512), shm, st, a);         \
@@ -508,11 +528,11 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
     if (d->Cin == 4) {
       const size_t shm = (size_t)4 * (2 * 8 + 6) * 48 * 8 + 8 * 8 * 4 * 2 * 16 + part;
       xh_note_kernel("conv7_as_kernel<%d, 4, 2>", f);
-      if (f) C7AS(1, 4, 2, shm); else C7AS(0, 4, 2, shm);
+      if (f == 2) C7AS(2, 4, 2, shm); else if (f) C7AS(1, 4, 2, shm); else C7AS(0, 4, 2, shm);
     } else {
       const size_t shm = (size_t)4 * (2 * 4 + 6) * 48 * 4 + 8 * 8 * 2 * 4 * 16 + part;
       xh_note_kernel("conv7_as_kernel<%d, 2, 4>", f);
-      if (f) C7AS(1, 2, 4, shm); else C7AS(0, 2, 4, shm);
+      if (f == 2) C7AS(2, 2, 4, shm); else if (f) C7AS(1, 2, 4, shm); else C7AS(0, 2, 4, shm);
     }
 #undef C7AS
     return xh_launch_status();
