@@ -240,7 +240,9 @@ def test_storage_modes_on_trained_like_weights(case, mode):
           + (f"; reference {mode}-AMP: seg {ref['seg_rel_l2']:.3e}, Dice dev {ref['dice_dev']:.3e}, flips {ref['mask_flips']}" if ref else ""))
     if mode in ("fp32", "fp32_mfma"):
         assert (seg - prob_o).abs().max().item() < 5e-3 and d < 1e-4, (d,)
-        assert flips <= 2, flips                              # fp32 vector kernels: 0 of 6.3 M at 128^3
+        # fp32 vector kernels: 0 flips of 6.3 M at 128^3; fp32_mfma (two-term split 3^3 convs, the 7^3 gate convs with operands rounded
+        # once to fp16 since round 5): 7 flips, Dice deviation 1.5e-5
+        assert flips <= (2 if mode == "fp32" else 24), flips
     else:
         assert d <= max(1e-3, ref["dice_dev"]) and l2 <= max(2e-3, 2 * ref["seg_rel_l2"]), (d, l2, ref)
 
