@@ -621,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
   // per load were more VALU work than the step's 16 MFMAs), and every load is issued from a clamped address and masked
   // afterwards (guards around loads serialise them)
   uint4 ry[2], rx[2];
+  unsigned okm = 0;                                       // bits 0, 1: dY pieces to keep, bits 2, 3: X pieces
   const int chn = tid & 15;
   const bool y_ok = cn0 + chn * 8 < a.Cn && chn * 8 < BMc;
   const bool x_ok = PAIR ? tap_ok : (cs0 + chn * 8 < a.Cs && chn * 8 < BNc);
@@ -649,10 +650,10 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
       const int nc = min(nn[i], a.N - 1);
       rx[i] = *reinterpret_cast<const uint4*>(a.x + (unsigned)((((nc * a.Di + dc) * a.Hi + hc) * a.Wi + wc) * a.Cs + x_off));
     }
+    okm = 0;                                              // zeroed in store_step (masks next to the loads would wait for them here)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (!oky[i]) ry[i] = make_uint4(0, 0, 0, 0);
-      if (!okx[i]) rx[i] = make_uint4(0, 0, 0, 0);
+      okm |= (oky[i] ? (1u << i) : 0u) | (okx[i] ? (4u << i) : 0u);
       ow[i] += 32;                                        // the row this slot stages next step
       while (ow[i] >= a.Wo) {
         ow[i] -= a.Wo;
@@ -667,8 +668,11 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256;
       const int row = c >> 4, chn = c & 15;
-      *reinterpret_cast<uint4*>(Ys + sw256(row, chn)) = ry[i];
-      *reinterpret_cast<uint4*>(Xs + sw256(row, chn)) = rx[i];
+      uint4 vy = ry[i], vx = rx[i];
+      if (!((okm >> i) & 1)) vy = make_uint4(0, 0, 0, 0);
+      if (!((okm >> (2 + i)) & 1)) vx = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Ys + sw256(row, chn)) = vy;
+      *reinterpret_cast<uint4*>(Xs + sw256(row, chn)) = vx;
     }
   };
   f32x4_t acc[TMW][TNW];
@@ -733,6 +737,156 @@ __global__ __launch_bounds__(256, 2) void dwgrad_cl_kernel(const DWgK a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// weight gradient of the stride-2 k = 4 convs from a staged SOURCE BLOCK (round 5).  dwgrad_cl_kernel gathers the X rows of one
+// tap pair per 32-voxel step: 16 KB of loads per 2 x 16 MFMAs per wave = 64 flop per loaded byte, and the kernel sits at 0.2 of
+// the MFMA peak waiting on L1.  Here a workgroup of 8 waves owns ONE parity class of taps (k = 4, stride 2: the 64 taps fall
+// into 8 classes of 2 x 2 x 2 taps which read source voxels of one parity) x 64 source channels x 128 destination channels, and
+// walks 4 x 4 x 4 blocks of output voxels: per block it stages the 64 dY rows (16 KB) and the 5 x 5 x 5 source rows of the class
+// ONCE (16 KB) and every wave (= one tap of the class) takes its B fragments from the block at its tap's offset: 32 KB of loads
+// per 8 x 64 MFMAs = 256 flop per byte.  The fragments are transposed reads (ds_read_b64_tr_b16) as in dwgrad_cl_kernel: rows =
+// voxels, a lane supplies the address of one row, so the rows of a tap's fragment may sit anywhere in the block.
+// Source-block layout in LDS: row = hz * 32 + hy * 6 + hx (128 bytes each), 16-byte chunk index XORed with ((row >> 1) & 3) << 1:
+// the 16 rows one transposed read touches (x = 0..3 at two y and two z) then spread evenly over the banks.
+struct DWgHK {
+  const u16* x; const u16* dy; float* dw;
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn;
+  int nbz, nby, nbx, nblk;   // 4 x 4 x 4 blocks of output voxels per axis; N * nbz * nby * nbx
+  int nsplit, ncs, ncn;      // block-range splits; 64-channel tiles of Cs; 128-channel tiles of Cn
+  int dbg;
+  int ngroup;                // nsplit * ncs * ncn; workgroup id = class * ngroup + group (ngroup % 8 == 0: a group's 8 classes,
+};                           // which stream the same dY rows, land on one XCD and share them through its L2)
+template <int FMT>
+__global__ __launch_bounds__(512, 2) void dwgrad_halo_kernel(const DWgHK a) {
+  constexpr int YB = 64 * 256, XB = 160 * 128, BUF = YB + XB;
+  extern __shared__ __attribute__((aligned(256))) unsigned char dwh_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4, q = r16 >> 2, p = r16 & 3;
+  const int cls = blockIdx.x / a.ngroup, grp = blockIdx.x % a.ngroup;
+  const int ez = cls >> 2, ey = (cls >> 1) & 1, ex = cls & 1;          // parity bit of the class's taps per axis
+  const int split = grp / (a.ncs * a.ncn), tile = grp % (a.ncs * a.ncn);
+  const int cs0 = (tile % a.ncs) * 64, cn0 = (tile / a.ncs) * 128;
+  const int per = (a.nblk + a.nsplit - 1) / a.nsplit;
+  const int b_begin = split * per, b_end = min(a.nblk, b_begin + per);
+  // staging: dY 64 rows x 16 chunks, X 125 rows x 8 chunks -> two 16-byte pieces of each per thread, the same pieces of every block
+  const int ych = tid & 15, yx = (tid >> 4) & 3, yy = (tid >> 6) & 3, yz0 = tid >> 8;         // piece i: z = yz0 + 2 i
+  const int xpc = tid & 7;
+  int xz[2], xy[2], xx[2], xrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int l = (tid >> 3) + 64 * i;                     // 0..127, rows >= 125 do not exist
+    xz[i] = l / 25; xy[i] = (l % 25) / 5; xx[i] = l % 5;
+    xrow[i] = l < 125 ? xz[i] * 32 + xy[i] * 6 + xx[i] : -1;
+  }
+  // the loads of a block are only ISSUED here (clamped addresses); what falls outside the volume is zeroed when the registers are
+  // written to LDS a whole block of MFMAs later -- masking next to the loads makes hipcc wait for them on the spot
+  uint4 ry[2], rx[2];
+  unsigned okm = 0;                                        // bits 0, 1: dY pieces inside, bits 2, 3: X pieces inside
+  int nb_x = 0, nb_y = 0, nb_z = 0, nb_n = 0;              // coordinates of the next block to load (carried, not divided out)
+  {
+    int t = b_begin;
+    nb_x = t % a.nbx; t /= a.nbx;
+    nb_y = t % a.nby; t /= a.nby;
+    nb_z = t % a.nbz; nb_n = t / a.nbz;
+  }
+  auto load_block = [&]() __attribute__((always_inline)) {   // called for b_begin, b_begin + 1, ... in order
+    const int bx = nb_x, by = nb_y, bz = nb_z, n = nb_n;
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int od = bz * 4 + yz0 + 2 * i, oh = by * 4 + yy, ow = bx * 4 + yx;
+      okm |= (od < a.Do && oh < a.Ho && ow < a.Wo) ? (1u << i) : 0u;
+      const unsigned row = (unsigned)(((n * a.Do + min(od, a.Do - 1)) * a.Ho + min(oh, a.Ho - 1)) * a.Wo + min(ow, a.Wo - 1));
+      ry[i] = *reinterpret_cast<const uint4*>(a.dy + (row * (unsigned)a.Cn + (unsigned)(cn0 + ych * 8)));
+      const int d = 2 * (bz * 4 + xz[i]) + ez - 1, h = 2 * (by * 4 + xy[i]) + ey - 1, w = 2 * (bx * 4 + xx[i]) + ex - 1;
+      okm |= (xrow[i] >= 0 && (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi) ? (4u << i) : 0u;
+      const int dc = min(max(d, 0), a.Di - 1), hc = min(max(h, 0), a.Hi - 1), wc = min(max(w, 0), a.Wi - 1);
+      rx[i] = *reinterpret_cast<const uint4*>(a.x + ((unsigned)(((n * a.Di + dc) * a.Hi + hc) * a.Wi + wc) * (unsigned)a.Cs + (unsigned)(cs0 + xpc * 8)));
+    }
+    if (++nb_x == a.nbx) { nb_x = 0; if (++nb_y == a.nby) { nb_y = 0; if (++nb_z == a.nbz) { nb_z = 0; ++nb_n; } } }
+  };
+  auto store_block = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* Ys = dwh_smem + buf * BUF;
+    unsigned char* Xs = Ys + YB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(Ys + sw256(((yz0 + 2 * i) * 4 + yy) * 4 + yx, ych)) = (okm >> i) & 1 ? ry[i] : make_uint4(0, 0, 0, 0);
+      if (xrow[i] >= 0)
+        *reinterpret_cast<uint4*>(Xs + xrow[i] * 128 + ((xpc ^ (((xrow[i] >> 1) & 3) << 1)) << 4)) = (okm >> (2 + i)) & 1 ? rx[i] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  // fragment addresses: dY rows 32 s + 8 kg + q (+ 4), X rows of the voxels (z = 2 s + (kg >> 1), y = 2 (kg & 1) (+ 1), x = q) at the
+  // wave's tap (jz, jy, jx); the tile index of a read enters as an XOR of bits 5..7 (the swizzles only touch the chunk bits)
+  const int jz = wv >> 2, jy = (wv >> 1) & 1, jx = wv & 1;
+  const int ph = p >> 1, pb = (p & 1) * 8;
+  unsigned a_base[2], b_base[2];
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi) {
+    const int row = 8 * kg + q + 4 * hi;
+    const int ca = ((row & 3) << 2) | ((row >> 2) & 3);
+    a_base[hi] = (unsigned)(row * 256 + ((ph ^ ca) << 4) + pb);
+    const int hr = ((kg >> 1) + jz) * 32 + (2 * (kg & 1) + hi + jy) * 6 + q + jx;
+    b_base[hi] = (unsigned)(YB + hr * 128 + (((hr >> 1) & 3) << 5) + (ph << 4) + pb);
+  }
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (b_begin < b_end) {
+    load_block();
+    store_block(0);
+  }
+  __syncthreads();
+  auto step = [&](int b, int buf) __attribute__((always_inline)) {
+    if (b + 1 < b_end && !(a.dbg & 1)) load_block();
+    const unsigned char* S = dwh_smem + buf * BUF;
+    auto rd_a = [&](int n) __attribute__((always_inline)) {        // dY fragment n = 8 s + tile
+      const int s = n >> 3, i = n & 7;
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(S + (a_base[0] ^ (unsigned)(i << 5)) + s * 32 * 256));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(S + (a_base[1] ^ (unsigned)(i << 5)) + s * 32 * 256));
+      return h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto rd_b = [&](int s, int j) __attribute__((always_inline)) {
+      const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(S + (b_base[0] ^ (unsigned)(j << 5)) + s * 64 * 128));
+      const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(S + (b_base[1] ^ (unsigned)(j << 5)) + s * 64 * 128));
+      return h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    // the transposed reads come back after ~300 cycles when eight waves queue them, a group of four MFMAs lasts 64: the dY fragments
+    // are requested AHEAD fragments before their group (hipcc's own schedule keeps one in flight and the matrix cores wait on LDS)
+    constexpr int AHEAD = 3;
+    h16x8 bf[2][4], aq[AHEAD + 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[0][j] = rd_b(0, j);
+#pragma unroll
+    for (int n = 0; n < AHEAD; ++n) aq[n] = rd_a(n);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      if (n + AHEAD < 16) aq[(n + AHEAD) % (AHEAD + 1)] = rd_a(n + AHEAD);
+      if (n >= 2 && n < 6) bf[1][n - 2] = rd_b(1, n - 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[n & 7][j] = mfma16x16x32<FMT>(aq[n % (AHEAD + 1)], bf[n >> 3][j], acc[n & 7][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (b + 1 < b_end && !(a.dbg & 2)) store_block(buf ^ 1);
+    __syncthreads();
+  };
+  for (int b = b_begin; b < b_end; b += 2) {
+    step(b, 0);
+    if (b + 1 < b_end) step(b + 1, 1);
+  }
+  // D[i = cn][j = cs]: lane holds column cs = r16, rows cn = 4 kg + r, of the wave's tap
+  const int otap = ((2 * jz + ez) * 4 + 2 * jy + ey) * 4 + 2 * jx + ex;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(&a.dw[((long long)otap * a.Cn + cn0 + i * 16 + kg * 4 + r) * a.Cs + cs0 + j * 16 + r16], acc[i][j][r]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // weight gradient of the FIRST conv (8 padded input channels): with so few channels per tap the 27 taps become the N axis
 // of the GEMM -- dW[cn][(tap, ci)] = sum_m dY[m][cn] * X[src(m, tap)][ci], N = 27 x 8 = 216 (14 tiles of 16) -- so that dY
 // is streamed ONCE (not once per tap) and a 32-voxel step carries 14 MFMAs per wave instead of one.
@@ -749,6 +903,7 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
   const long long per = ((a.M + a.msplit - 1) / a.msplit + 31) / 32 * 32;
   const long long m_begin = (long long)split * per, m_end = m_begin + per < a.M ? m_begin + per : a.M;
   uint4 ry, rx[4];
+  unsigned okm = 0;                                       // bits 0..3: X pieces to keep, bit 4: the dY piece
   // a thread stages the same tap for its four rows (slot = tid + 256 i: tap = tid & 31, row = (tid >> 5) + 8 i), and each row
   // moves on by 32 voxels per step: coordinates carried along, loads unconditional from clamped addresses (see dwgrad_cl_kernel)
   const int xtap = tid & 31;
@@ -782,10 +937,10 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
       const int nc = min(nn[i], a.N - 1);
       rx[i] = *reinterpret_cast<const uint4*>(a.x + ((((long long)nc * a.Di + dc) * a.Hi + hc) * a.Wi + wc) * 8);
     }
-    if (!oky) ry = make_uint4(0, 0, 0, 0);
+    okm = oky ? 16u : 0u;                                 // zeroed in store_step (masks next to the loads would wait for them here)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (!okx[i]) rx[i] = make_uint4(0, 0, 0, 0);
+      okm |= okx[i] ? (1u << i) : 0u;
       ow[i] += 32;
       while (ow[i] >= a.Wo) {
         ow[i] -= a.Wo;
@@ -796,11 +951,15 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_kernel(const DWgK a) {
   auto store_step = [&](int buf) {
     unsigned char* Ys = smem + buf * (YB + XB);
     unsigned char* Xs = Ys + YB;
-    *reinterpret_cast<uint4*>(Ys + sw256(tid >> 3, tid & 7)) = ry;
+    uint4 vy = ry;
+    if (!(okm & 16u)) vy = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(Ys + sw256(tid >> 3, tid & 7)) = vy;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int slot = tid + i * 256;
-      *reinterpret_cast<uint4*>(Xs + sw512(slot >> 5, slot & 31)) = rx[i];
+      uint4 vx = rx[i];
+      if (!((okm >> i) & 1)) vx = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Xs + sw512(slot >> 5, slot & 31)) = vx;
     }
   };
   f32x4_t acc[4][4];
@@ -893,6 +1052,7 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (tid == 0) *reinterpret_cast<uint4*>(xt + NV * 16) = make_uint4(0, 0, 0, 0);
   uint4 py[8], px[NX];
+  unsigned okm = 0;                                       // bits 0..7: dY pieces inside the volume, bits 8..: X pieces
   const int per_n = a.td * a.th * a.tw;
   auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int n = t / per_n; int b = t - n * per_n;
@@ -901,14 +1061,14 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
     const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
     const u16* yn = a.dy + (long long)n * a.D * a.H * a.W * 64;
     const u16* xn = a.x + (long long)n * Dx * Hx * Wx * 8;
-    bool oky[8], okx[NX];
+    okm = 0;                                              // zeroing waits until store_tile: masks next to the loads make hipcc wait for them here
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + i * 256;
       const int v = idx >> 3, c = idx & 7;
       const int rb = v >> 4, w = w0 + (v & 15);
       const int d = d0 + (rb >> 2), h = h0 + (rb & 3);
-      oky[i] = d < a.D && h < a.H && w < a.W;
+      okm |= (d < a.D && h < a.H && w < a.W) ? (1u << i) : 0u;
       const int dc = min(d, a.D - 1), hc = min(h, a.H - 1), wc = min(w, a.W - 1);
       py[i] = *reinterpret_cast<const uint4*>(yn + (((long long)dc * a.H + hc) * a.W + wc) * 64 + c * 8);
     }
@@ -918,14 +1078,10 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
       const int pw = pi % PW, r = pi / PW;
       const int ph = r % PH, pd = r / PH;
       const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
-      okx[i] = (unsigned)d < (unsigned)Dx && (unsigned)h < (unsigned)Hx && (unsigned)w < (unsigned)Wx;
+      okm |= ((unsigned)d < (unsigned)Dx && (unsigned)h < (unsigned)Hx && (unsigned)w < (unsigned)Wx) ? (256u << i) : 0u;
       const int dc = min(max(d, 0), Dx - 1), hc = min(max(h, 0), Hx - 1), wc = min(max(w, 0), Wx - 1);
       px[i] = *reinterpret_cast<const uint4*>(xn + (((long long)dc * Hx + hc) * Wx + wc) * 8);
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (!oky[i]) py[i] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) if (!okx[i]) px[i] = make_uint4(0, 0, 0, 0);
   };
   auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -933,12 +1089,16 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
       const int idx = tid + i * 256;
       const int v = idx >> 3, c = idx & 7;
       const int rb = v >> 4;                              // (dz, hy) row of the block; K step = rb >> 1, row in the step = 16 (rb & 1) + w
-      *reinterpret_cast<uint4*>(ys + (rb >> 1) * YB + sw256((rb & 1) * 16 + (v & 15), c)) = py[i];
+      uint4 v4 = py[i];
+      if (!((okm >> i) & 1)) v4 = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(ys + (rb >> 1) * YB + sw256((rb & 1) * 16 + (v & 15), c)) = v4;
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int pi = tid + i * 256;
-      if (pi < NV) *reinterpret_cast<uint4*>(xt + pi * 16) = px[i];
+      uint4 v4 = px[i];
+      if (!((okm >> (8 + i)) & 1)) v4 = make_uint4(0, 0, 0, 0);
+      if (pi < NV) *reinterpret_cast<uint4*>(xt + pi * 16) = v4;
     }
   };
   int t = blockIdx.x;
@@ -1393,7 +1553,8 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //                                512 x 64 for the 64-channel data gradient: 340 -> 389 us.)
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles
+int g_dwh_groups = 32;    // source-block weight gradient: groups of 8 class workgroups per launch (option 26)
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1593,6 +1754,31 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, co
         if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_c8_halo_kernel<1, 4>), dim3(nwg, 2), dim3(256), 0, st, k);
         else hipLaunchKernelGGL((dwgrad_c8_halo_kernel<0, 4>), dim3(nwg, 2), dim3(256), 0, st, k);
       }
+      return xh_launch_status();
+    }
+  }
+  if (stride == 2 && ks == 4 && (Cs % 64) == 0 && (Cn % 128) == 0 && !(g_dconv_cfg & 131072)) {   // source-block kernel
+    DWgHK k;
+    k.x = (const u16*)x; k.dy = (const u16*)dy; k.dw = dwp;
+    k.N = N; k.Di = Di; k.Hi = Hi; k.Wi = Wi; k.Do = Do; k.Ho = Ho; k.Wo = Wo; k.Cs = Cs; k.Cn = Cn;
+    k.nbz = cdiv(Do, 4); k.nby = cdiv(Ho, 4); k.nbx = cdiv(Wo, 4);
+    const long long nblk = (long long)N * k.nbz * k.nby * k.nbx;
+    k.ncs = Cs / 64; k.ncn = Cn / 128;
+    const int tiles = k.ncs * k.ncn;
+    if (nblk < (1LL << 30) && tiles <= 4096) {
+      k.nblk = (int)nblk;
+      int nsplit = tiles >= g_dwh_groups ? 1 : g_dwh_groups / tiles;       // 8 classes x groups workgroups, one per CU
+      if (nsplit > k.nblk) nsplit = k.nblk;
+      k.nsplit = nsplit; k.ngroup = nsplit * tiles; k.dbg = (g_dconv_cfg >> 18) & 7;
+      const size_t shm = 2 * (64 * 256 + 160 * 128);
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)dwgrad_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)dwgrad_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_done = true;
+      }
+      if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_halo_kernel<1>), dim3(8 * k.ngroup), dim3(512), shm, st, k);
+      else hipLaunchKernelGGL((dwgrad_halo_kernel<0>), dim3(8 * k.ngroup), dim3(512), shm, st, k);
       return xh_launch_status();
     }
   }
