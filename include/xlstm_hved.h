@@ -60,10 +60,17 @@ int xh_abi_version(void);
  * key 20: mask of the row widths on which quad-channel k3 convs take the full-row tiles of csrc/conv3d_q4w.hip: bit 1 = 128 voxels,
  *         bit 0 = 64 voxels (default 3); 0 = always the 32-wide tiles of csrc/conv3d_q4.hip (A/B switch; the outputs are
  *         bit-identical).
+ * key 21: 0 = no full-row weight-gradient kernel (csrc/conv3d_wgrad_q5.hip; the 32-wide tile kernel instead).  key 22: its
+ *         workgroup budget per launch (default 256 = one per CU).  key 23: 1 = rows of 32 voxels too (measured slower).
+ * key 24: input-stationary 7^3 gate-conv kernel (csrc/conv7_mfma.hip): 0 never, 1 volumes >= 2^20 voxels (default), 2 B fragments in
+ *         registers, 3 every volume.  key 25: 1 = fp32 storage keeps the fp32 vector kernels for the 7^3 gate convs.
+ * key 26: groups of 8 class workgroups per launch of the discriminator's source-block weight gradient (default 32 = 256 workgroups).
+ * key 27: workgroup target of the row-streaming norm / element-wise kernels (default 2048).
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
  *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo
- *         kernels of the first conv (data gradient / forward).
+ *         kernels of the first conv (data gradient / forward), bit 14 / 17 gather kernels instead of the source-block kernels of the
+ *         stride-2 data gradients / k = 4 weight gradients.
  *
  * PROCESS-GLOBAL STATE (the only two exceptions to "no mutable state in the library"): the option table behind
  * xh_set_option (plain ints, e.g. g_q4_maxc / g_q4_wgs in csrc/conv3d_q4.hip) and the name buffer behind xh_last_conv_kernel

@@ -124,3 +124,29 @@ def gates():
 
 if __name__ == "__main__" and "--gates" in sys.argv:
     gates()
+
+
+def appliers():
+    """in_bwd_apply / affine_act (the two-pass norm's streaming halves) at the step's big shapes vs the row kernels' workgroup
+    target (key 27)."""
+    dt = torch.bfloat16
+    for C, S in [(8, 128), (4, 128), (16, 64), (8, 64)]:
+        x = torch.randn(1, C, S, S, S, device="cuda").to(dt)
+        dy = torch.randn(1, C, S, S, S, device="cuda").to(dt)
+        out = torch.empty_like(x)
+        sc = torch.rand(1, C, device="cuda") + 0.5; sh = torch.randn(1, C, device="cuda")
+        red = torch.randn(1, C, 2, dtype=torch.float64, device="cuda")
+        mean = torch.randn(1, C, device="cuda"); rstd = torch.rand(1, C, device="cuda") + 0.5
+        mb = x.numel() * 2 / 1e6
+        line = f"C={C:3d} @{S:3d} ({mb:5.1f} MB/tensor):"
+        for tgt in (1024, 2048, 4096, 8192, 16384):
+            opt(27, tgt)
+            ta = bench(lambda: ops.in_bwd_apply(dy, x, red, mean, rstd, have_g=False, sc=sc, sh=sh, out=out))
+            tb = bench(lambda: ops.affine_act(x, sc, sh, ops.ACT_LRELU, out=out)) if hasattr(ops, "affine_act") else 0.0
+            line += f"  wg{tgt}: apply {ta:5.1f} ({3 * mb / ta / 1e3:4.2f} TB/s) affine {tb:5.1f}"
+        print(line)
+    opt(27, 2048)
+
+
+if __name__ == "__main__" and "--appliers" in sys.argv:
+    appliers()

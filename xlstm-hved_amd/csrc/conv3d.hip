@@ -1625,6 +1625,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 16) { extern int g_tiny_wgs; g_tiny_wgs = value < 1 ? 1 : value; return XH_OK; }
   if (key == 21) { extern int g_q5_on; g_q5_on = value ? 1 : 0; return XH_OK; }
   if (key == 25) { extern int g_c7_as_f32off; g_c7_as_f32off = value ? 1 : 0; return XH_OK; }
+  if (key == 27) { extern int g_row_wgs; if (value < 64 || value > (1 << 20)) return XH_ERR_ARG; g_row_wgs = value; return XH_OK; }
   if (key == 26) { extern int g_dwh_groups; if (value < 1 || value > 4096) return XH_ERR_ARG; g_dwh_groups = value; return XH_OK; }
   if (key == 24) { extern int g_c7_as; g_c7_as = value < 0 ? 0 : value > 3 ? 3 : value; return XH_OK; }
   if (key == 23) { extern int g_q5_w32; g_q5_w32 = value ? 1 : 0; return XH_OK; }

@@ -752,7 +752,6 @@ struct DWgHK {
   int N, Di, Hi, Wi, Do, Ho, Wo, Cs, Cn;
   int nbz, nby, nbx, nblk;   // 4 x 4 x 4 blocks of output voxels per axis; N * nbz * nby * nbx
   int nsplit, ncs, ncn;      // block-range splits; 64-channel tiles of Cs; 128-channel tiles of Cn
-  int dbg;
   int ngroup;                // nsplit * ncs * ncn; workgroup id = class * ngroup + group (ngroup % 8 == 0: a group's 8 classes,
 };                           // which stream the same dY rows, land on one XCD and share them through its L2)
 template <int FMT>
@@ -838,7 +837,7 @@ __global__ __launch_bounds__(512, 2) void dwgrad_halo_kernel(const DWgHK a) {
   }
   __syncthreads();
   auto step = [&](int b, int buf) __attribute__((always_inline)) {
-    if (b + 1 < b_end && !(a.dbg & 1)) load_block();
+    if (b + 1 < b_end) load_block();
     const unsigned char* S = dwh_smem + buf * BUF;
     auto rd_a = [&](int n) __attribute__((always_inline)) {        // dY fragment n = 8 s + tile
       const int s = n >> 3, i = n & 7;
@@ -868,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void dwgrad_halo_kernel(const DWgHK a) {
       for (int j = 0; j < 4; ++j) acc[n & 7][j] = mfma16x16x32<FMT>(aq[n % (AHEAD + 1)], bf[n >> 3][j], acc[n & 7][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (b + 1 < b_end && !(a.dbg & 2)) store_block(buf ^ 1);
+    if (b + 1 < b_end) store_block(buf ^ 1);
     __syncthreads();
   };
   for (int b = b_begin; b < b_end; b += 2) {
@@ -1769,7 +1768,7 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, co
       k.nblk = (int)nblk;
       int nsplit = tiles >= g_dwh_groups ? 1 : g_dwh_groups / tiles;       // 8 classes x groups workgroups, one per CU
       if (nsplit > k.nblk) nsplit = k.nblk;
-      k.nsplit = nsplit; k.ngroup = nsplit * tiles; k.dbg = (g_dconv_cfg >> 18) & 7;
+      k.nsplit = nsplit; k.ngroup = nsplit * tiles;
       const size_t shm = 2 * (64 * 256 + 160 * 128);
       static bool attr_done = false;
       if (!attr_done) {

@@ -42,10 +42,11 @@ static inline bool vec_ok(long long dhw, std::initializer_list<long long> stride
 }
 // ~2048 workgroups per launch whatever the channel count: few workgroups per (n,c) row when there are many rows (so
 // the per-workgroup fp64 atomics of the reducing kernels do not pile up on one address), many when there are few.
+int g_row_wgs = 2048;   // xh_set_option(27, n): workgroup target of the row-streaming kernels (experiments)
 template <typename T>
 static inline dim3 row_grid(long long dhw, int C, int N) {
   const long long maxb = (dhw + EW_BLOCK * VWT<T>::v - 1) / (EW_BLOCK * VWT<T>::v);
-  long long want = (2048 + (long long)C * N - 1) / ((long long)C * N);
+  long long want = (g_row_wgs + (long long)C * N - 1) / ((long long)C * N);
   if (want < 1) want = 1;
   return dim3((unsigned)(want < maxb ? want : maxb), C, N);
 }
