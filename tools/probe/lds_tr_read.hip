@@ -1,5 +1,6 @@
 // Probe (round 5): throughput of the transposed LDS read ds_read_b64_tr_b16 (the fragment read of the discriminator's weight
 // gradients) next to plain ds_read_b64 / ds_read_b128, with the two address patterns dwgrad_halo_kernel uses.
+// (A first version of this probe spent ~8 vector instructions per read and measured vector issue, ~62 B/clk for every pattern.)
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_tr_read tools/probe/lds_tr_read.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -43,28 +44,29 @@ __global__ __launch_bounds__(512) void timeit(unsigned* out, int iters) {
       base[hi] = (lane + 64 * hi) * 16;
     }
   }
-  unsigned acc = 0;
+  unsigned acc = 0, acc2 = 0;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int t = (MODE == 1 || MODE == 4 || MODE == 5 || MODE == 8) ? (u & 3) : (MODE == 7 ? (u & 3) + (u >> 2) * 256 : u);
+      const int t = (MODE == 1 || MODE == 4 || MODE == 5 || MODE == 8) ? (u & 3) + (u >> 2) * 1024 : (MODE == 7 ? (u & 3) + (u >> 2) * 256 : u);   // (distinct addresses: equal ones would be merged)
 #pragma unroll
       for (int hi = 0; hi < 2; ++hi) {
         const unsigned a = (base[hi] ^ (unsigned)(t << 5)) + ((it & 1) << 13) + ((MODE == 3) ? u * 2048 : 0);
         if (MODE == 3) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(s + a);
-          acc += v.x ^ v.y ^ v.z ^ v.w;
+          acc ^= v.x ^ v.w; acc2 ^= v.y ^ v.z;
         } else if (MODE == 2) {
           const u32x2 v = *reinterpret_cast<const u32x2*>(s + a);
-          acc += v.x ^ v.y;
+          acc ^= v.x; acc2 ^= v.y;
         } else {
           const s4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(s + a));
-          acc += (unsigned)(v[0] ^ v[1]) + (unsigned)(v[2] ^ v[3]);
+          const u32x2 w = __builtin_bit_cast(u32x2, v);
+          acc ^= w.x; acc2 ^= w.y;                          // two VALU per read: the loop stays bound by the LDS, not by vector issue
         }
       }
     }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc + acc2;
 }
 
 int main() {
