@@ -405,7 +405,14 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
 // 16 MFMAs).  One LDS buffer of 79 KB, two workgroups per CU: one stages while the other multiplies.
 // Wave w owns destination plane w of the block (4 M tiles of 2 rows x 8 voxels) and all 4 N tiles; epilogue as dconv_cl_kernel
 // (bias, LeakyReLU mask of the layer below, rounding, channel sums).
-template <int FMT>
+// K4: k = 4, stride 2 -- every class has 2 x 2 x 2 taps, so the block extents (9 x 9 x 9 source rows) are compile-time constants and
+// the staging plan's row decomposition costs multiplies instead of runtime divisions (64 <- 128 @127^3, two samples: 891 -> 865 us).
+// Measured and not kept (round 5): a PERSISTENT form -- one workgroup per CU, both LDS images twice, the next slice (of the next
+// block) in flight under the taps, channel sums carried in registers -- ran 1033 us against 865: with everything but its skeleton
+// switched off (no taps, no loads, no stores) it still took 425 us (plan, LDS stores, four barriers per block at 2 waves per SIMD);
+// the counters of this kernel show 63 % of its wave time parked on waits and LDS bank conflicts in the A-fragment reads (the 8 + 8
+// rows of a fragment start at multiples of 9, not 4, so the chunk swizzle of sw64 does not separate them)
+template <int FMT, bool K4 = false>
 __global__ __launch_bounds__(512, 4) void dconv_dgrad_halo_kernel(const DConvK a) {
   constexpr int BT = 8, BN = 64, TM = 4, TN = 4;
   constexpr int A_BYTES = 729 * 64, B_BYTES = 8 * BN * 64;
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(512, 4) void dconv_dgrad_halo_kernel(const DConvK a
   const int tjw = mt % tnw, t1 = mt / tnw;
   const int tjh = t1 % tnh, tjd = t1 / tnh;
   const int j0d = tjd * BT, j0h = tjh * BT, j0w = tjw * BT;
-  const int nd = cl.td.n, nh = cl.th.n, nw = cl.tw.n, ntap = nd * nh * nw;
+  const int nd = K4 ? 2 : cl.td.n, nh = K4 ? 2 : cl.th.n, nw = K4 ? 2 : cl.tw.n, ntap = nd * nh * nw;
   int mind = cl.td.off[0], minh = cl.th.off[0], minw = cl.tw.off[0];
   for (int k = 1; k < nd; ++k) mind = min(mind, cl.td.off[k]);
   for (int k = 1; k < nh; ++k) minh = min(minh, cl.th.off[k]);
@@ -498,8 +505,11 @@ __global__ __launch_bounds__(512, 4) void dconv_dgrad_halo_kernel(const DConvK a
     for (int i = 0; i < NB; ++i)
       if (b_src[i] >= 0) *reinterpret_cast<uint4*>(Bs + b_lds[i]) = qb[i];
     __syncthreads();
+#pragma unroll 1
     for (int id = 0; id < nd; ++id)
+#pragma unroll 1
       for (int ih = 0; ih < nh; ++ih)
+#pragma unroll 1
         for (int iw = 0; iw < nw; ++iw) {
           const int t = (id * nh + ih) * nw + iw;
           const int roff = ((cl.td.off[id] - mind) * HH + (cl.th.off[ih] - minh)) * HW + (cl.tw.off[iw] - minw);
@@ -1553,7 +1563,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
 int g_dwh_groups = 32;    // source-block weight gradient: groups of 8 class workgroups per launch (option 26)
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients, bit 19: runtime block extents in the k = 4 source-block data gradient
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1702,12 +1712,19 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
     const size_t shm = 729 * 64 + 8 * 64 * 64;
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       attr_done = true;
     }
-    if (dtype == XH_F16) hipLaunchKernelGGL((dconv_dgrad_halo_kernel<1>), grid, dim3(512), shm, st, a);
-    else hipLaunchKernelGGL((dconv_dgrad_halo_kernel<0>), grid, dim3(512), shm, st, a);
+    if (ks == 4 && nc == 8 && !(g_dconv_cfg & 524288)) {
+      if (dtype == XH_F16) hipLaunchKernelGGL((dconv_dgrad_halo_kernel<1, true>), grid, dim3(512), shm, st, a);
+      else hipLaunchKernelGGL((dconv_dgrad_halo_kernel<0, true>), grid, dim3(512), shm, st, a);
+    } else {
+      if (dtype == XH_F16) hipLaunchKernelGGL((dconv_dgrad_halo_kernel<1, false>), grid, dim3(512), shm, st, a);
+      else hipLaunchKernelGGL((dconv_dgrad_halo_kernel<0, false>), grid, dim3(512), shm, st, a);
+    }
     return xh_launch_status();
   }
   if (g_dconv_cfg & 1) {
