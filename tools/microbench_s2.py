@@ -16,7 +16,9 @@ for (cin, cout, g, S) in [(16, 8, 4, 128), (32, 16, 4, 64), (64, 32, 4, 32), (4,
     dbs = [torch.zeros(cout // g, device="cuda") for _ in range(g)]
     fwd = lambda: ops.conv3d(x, None, ws, None, k=3, cout=cout, stride=2, groups=g, pre=(sc, sh, 0.01))
     wg = lambda: ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, stride=2, groups=g, pre=(sc, sh, 0.01))
-    line = f"s2 {cin}->{cout} g{g} @{S}^3: fwd {bench(fwd):.1f} us ({ops.last_conv_kernel()[:24]})"
+    red = torch.zeros(1, cin, 2, dtype=torch.float64, device="cuda")
+    dg = lambda: ops.conv3d_dgrad_s2(dy, ws, cin=cin, in_spatial=(S, S, S), groups=g, e=(x, None, sc, sh, 0.01), red=red)
+    line = f"s2 {cin}->{cout} g{g} @{S}^3: fwd {bench(fwd):.1f} us ({ops.last_conv_kernel()[:24]}) dgrad {bench(dg):.1f} us"
     for cap in (256, 512, 1024, 2048, 4096):
         L.load().xh_set_option(12, cap)
         line += f" | wgrad cap{cap} {bench(wg):.1f} us"
