@@ -376,6 +376,10 @@ def main():
     # GPU to idle inside a bracket (the batched weight-gradient bracket read 369 us next to the CPU leg, 282 us under rocprof)
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline_pass(compute, ops, min(args.steps, 5), dtype)      # rank-local: no collective inside
+        try:
+            out["roofline"]["hbm_stream_measured"] = stream_probe(dev)
+        except Exception as e:
+            out["roofline"]["hbm_stream_measured"] = {"error": repr(e)[:200]}
     if not args.no_trainstep:
         # the whole training step, LAST: TrainStep re-points the generator's .grad at its own bucket.  With
         # N > 1 every rank runs it data-parallel (TrainStep(group=...): two graphs, the two bucket all-reduces between / after)
@@ -774,6 +778,30 @@ def extras(model, x, grads, nsteps):
     finally:
         model.train()
     return res
+
+
+def stream_probe(dev):
+    """What plain streaming reaches on this device with 1 GiB tensors (nothing stays in the memory-side cache): the practical
+    ceiling next to `peak` (the nominal 8 TB/s every fraction in `roofline` is quoted against).  Stock ATen kernels, 10 launches each."""
+    n = 2 ** 29
+    a = torch.empty(n, dtype=torch.bfloat16, device=dev).normal_()
+    b = torch.empty_like(a)
+
+    def t(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    r = {"copy": 2 * n * 2 / t(lambda: b.copy_(a)) / 1e9, "add_2r1w": 3 * n * 2 / t(lambda: torch.add(a, b, out=b)) / 1e9,
+         "fill": n * 2 / t(lambda: b.zero_()) / 1e9, "unit": "GB/s",
+         "what": "1 GiB bf16 tensors: b.copy_(a), torch.add(a, b, out=b), b.zero_(); bytes moved / time"}
+    del a, b
+    return r
 
 
 def roofline_pass(step, ops, nsteps, dtype):

@@ -33,6 +33,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert pm["fp16"]["dice_dev"] <= pm["bf16"]["dice_dev"] + 1e-3
     assert j["config3"]["ms_per_step"] > 0 and j["config3"]["gradients_finite"]
     assert j["roofline"]["elementwise_in_run"]["ms_per_step"] > 0 and j["roofline"]["elementwise_in_run"]["calls_per_step"] > 50
+    # the practical streaming ceiling measured in the run, next to the nominal peak the fractions are quoted against
+    hs = j["roofline"]["hbm_stream_measured"]
+    assert 1000 < hs["copy"] < 8000 and 1000 < hs["add_2r1w"] < 8000, hs
 
 
 def test_bench_force_dist_rccl_allreduce_with_graph_capture():
