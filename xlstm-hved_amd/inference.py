@@ -14,6 +14,8 @@ the volume and divided by the per-voxel window count.  Differences, all delibera
 The model call is `model(crop, subset_idx_list=[subset_idx], valid=valid)[0]` exactly like the reference, so anything with
 that signature works (the tests drive the tiler with a stub model on CPU).
 """
+import weakref
+
 import torch
 
 from .model import SUBSETS_MODALITIES
@@ -38,13 +40,42 @@ def window_list(shape, patch_size, overlap_stepsize):
             for w in window_origins(W, patch_size[2], overlap_stepsize[2])]
 
 
+# Captured window forwards, kept between calls (a whole-volume pass is 18 replays of ~1.3 ms; capturing the graph again for every
+# volume cost as much as ten of them).  Keyed by the model object and everything the captured launches depend on; the graph reads
+# the parameters where they live, so weight updates between volumes are seen.  A change of the model's structure or mode (anything
+# that changes which kernels a forward launches) needs clear_window_graphs().
+_WINDOW_GRAPHS = {}
+
+
+def clear_window_graphs():
+    _WINDOW_GRAPHS.clear()
+
+
+def _window_graph(model, subset_idx, batch_size, channels, patch_size, dtype, device):
+    key = (id(model), bool(model.training), int(subset_idx), int(batch_size), int(channels), tuple(patch_size), dtype, str(device))
+    hit = _WINDOW_GRAPHS.get(key)
+    if hit is not None and hit[0]() is model:            # (an id can be reused by a later object: the weak reference tells)
+        return hit[1:]
+    static_in = torch.zeros((batch_size, channels) + tuple(patch_size), dtype=dtype, device=device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model(static_in, subset_idx_list=[subset_idx], valid=True)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = model(static_in, subset_idx_list=[subset_idx], valid=True)[0]
+    _WINDOW_GRAPHS[key] = (weakref.ref(model), graph, static_in, static_out)
+    return graph, static_in, static_out
+
+
 @torch.no_grad()
 def eval_overlap_volume(model, x, subset_idx=14, patch_size=(128, 128, 128), overlap_stepsize=(64, 64, 64), batch_size=1,
                         draw=None, num_classes=3, rank=0, world=1, group=None, use_graph=False):
     """x: (1, 4, D, H, W) on the model's device.  Returns the (1, num_classes, D, H, W) fp32 overlap-averaged
     probabilities (on every rank when world > 1).  `draw=None` uses the posterior mean (valid=True); an integer averages
     that many random draws per window (evaluation.py:286-291,339-349).  use_graph=True (device tensors, posterior mean
-    only) captures the window forward once into a hipGraph and replays it per window batch: the eager forward is bound
+    only) captures the window forward once into a hipGraph (kept for later volumes: clear_window_graphs()) and replays it per window batch: the eager forward is bound
     by ~300 host-side launches, the replay by the GPU."""
     if x.dim() != 5 or x.shape[0] != 1:
         raise ValueError("expected one volume shaped (1, C, D, H, W)")
@@ -65,15 +96,7 @@ def eval_overlap_volume(model, x, subset_idx=14, patch_size=(128, 128, 128), ove
     count_tot = torch.zeros((1, 1, D, H, W), dtype=torch.float32, device=x.device)
     graph = static_in = static_out = None
     if use_graph and valid and x.is_cuda and mine:
-        static_in = torch.zeros((batch_size, x.shape[1], pd, ph, pw), dtype=x.dtype, device=x.device)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            model(static_in, subset_idx_list=[subset_idx], valid=True)
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = model(static_in, subset_idx_list=[subset_idx], valid=True)[0]
+        graph, static_in, static_out = _window_graph(model, subset_idx, batch_size, x.shape[1], (pd, ph, pw), x.dtype, x.device)
     for i0 in range(0, len(mine), batch_size):
         chunk = mine[i0:i0 + batch_size]
         crops = torch.cat([x[:, :, d:d + pd, h:h + ph, w:w + pw] for d, h, w in chunk], 0).contiguous()
