@@ -363,6 +363,12 @@ def main():
             out["config3"] = config3_leg(model, grads, dev, dtype, S, max(10, min(args.steps, 40)), 3)
         except Exception as e:
             out["config3_error"] = repr(e)[:200]
+    if rank == 0 and world == 1 and not args.no_config3 and S == 128:
+        # BASELINE config 5 on one GPU: sliding-window inference of one whole volume, fp16 as that config names
+        try:
+            out["tiler"] = tiler_leg(model, dev)
+        except Exception as e:
+            out["tiler_error"] = repr(e)[:200]
     if args.extras and rank == 0:
         out["extras"] = extras(model, x, grads, args.steps)
     if cpu_proc is not None:
@@ -778,6 +784,29 @@ def extras(model, x, grads, nsteps):
     finally:
         model.train()
     return res
+
+
+def tiler_leg(model, dev, reps=3):
+    """One 240 x 240 x 155 volume (BraTS extent), 128^3 windows every 64 voxels = 18 windows, posterior mean, eval mode, fp16 storage,
+    the window forward replayed from a captured hipGraph (xlstm_hved_amd.inference.eval_overlap_volume).  Volume resident in HBM."""
+    from xlstm_hved_amd.inference import eval_overlap_volume, window_list
+    vol = torch.rand(1, 4, 240, 240, 155, device=dev).half()
+    was = model.training
+    model.eval()
+    try:
+        eval_overlap_volume(model, vol, 14, use_graph=True)           # captures the window forward
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            prob = eval_overlap_volume(model, vol, 14, use_graph=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+    finally:
+        model.train(was)
+    nwin = len(window_list((240, 240, 155), (128, 128, 128), (64, 64, 64)))
+    return {"workload": "sliding-window inference, 1x4x240x240x155 volume, %d windows of 128^3 every 64 voxels, subset 14, fp16" % nwin,
+            "ms_per_volume": ms, "volume_voxels_per_s": 240 * 240 * 155 / (ms * 1e-3), "windows": nwin,
+            "output_finite": bool(torch.isfinite(prob).all())}
 
 
 def stream_probe(dev):
