@@ -78,14 +78,28 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WGN, wn = wv % WGN;
   const int r16 = lane & 15, kg = lane >> 4;
-  const int n = blockIdx.z, cn0 = blockIdx.y * BN;
+  // (a.xcd & 4) column tile = XCD (forward, 8 % column tiles == 0; 1-D grid): the weights of ONE column tile (BN x K^3 Cs x 2 B, 1 - 2 MB)
+  // then stay in that XCD's 4 MB L2 for the whole launch and every row tile streams its x rows once -- no lockstep between
+  // workgroups needed.  With the (x, y, z) grid an XCD saw every column tile: 256 -> 512 @15^3 fetched 800 MB past L2 for 32 MB of
+  // operands (TCC miss 46 %), the launch ran at the fabric's rate.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd & 4) {
+    const int ny = (a.Cn + BN - 1) / BN, r = 8 / ny;       // r XCDs share a column tile
+    const int k = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    const int t = a.c[0].ntile;
+    const int xx = sl * r + k / ny;                       // row tile x sample
+    by = k % ny;
+    if (xx >= t * a.N) return;
+    bx = xx % t; bz = xx / t;
+  }
+  const int n = bz, cn0 = by * BN;
   int ci = 0;
   for (int k = 1; k < a.ncls; ++k)
-    if ((int)blockIdx.x >= a.c[k].tile0) ci = k;
+    if (bx >= a.c[k].tile0) ci = k;
   const DClass& cl = a.c[ci];
   // workgroups go round the 8 XCDs in blockIdx order: hand every XCD a contiguous run of the class's row tiles, so that the
   // rows its taps share (h +- 1, d +- 1) are re-read from its own L2 instead of the fabric
-  int mt = blockIdx.x - cl.tile0;
+  int mt = bx - cl.tile0;
   if ((a.xcd & 1) && !(cl.tile0 & 7) && !(cl.ntile & 7)) mt = xcd_swizzle(mt, cl.ntile);
   const int R = cl.Jd * cl.Jh * cl.Jw;
 
@@ -1563,7 +1577,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
 int g_dwh_groups = 32;    // source-block weight gradient: groups of 8 class workgroups per launch (option 26)
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients, bit 19: runtime block extents in the k = 4 source-block data gradient
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients, bit 19: runtime block extents in the k = 4 source-block data gradient, bit 20: (x, y, z) grid instead of column tile = XCD in the forward convs
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1584,6 +1598,13 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   dim3 grid(t, cdiv(a.Cn, bn), N);
   a.xcd = ((t & 7) == 0 || grid.y * grid.z == 1) && !(g_dconv_cfg & 64);
   if (g_dconv_cfg & 512) a.xcd |= 2;
+  a.N = N;
+  if (a.ncls == 1 && grid.y >= 2 && (8 % grid.y) == 0 && !a.rowmode && !(g_dconv_cfg & 1048576) &&
+      (long long)bn * a.K * a.K * a.K * a.Cs * 2 <= (3ll << 20)) {        // a column tile's weights fit an XCD's L2 with room for the x stream
+    const int r = 8 / (int)grid.y;
+    a.xcd = 4;
+    grid = dim3(8 * cdiv(t * N, r), 1, 1);
+  }
   if (cfg == 0) {
     if (g_dconv_cfg & 32) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 1, 4>), grid, dim3(256), 0, st, a);
     else if (g_dconv_cfg & 128) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 1, 1, 1, 2>), grid, dim3(256), 0, st, a);
