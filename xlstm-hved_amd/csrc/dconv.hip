@@ -55,8 +55,9 @@ struct DConvK {
 // ds_read_b128 lane group touches land on all 64 banks
 __device__ __forceinline__ int sw64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 // rows of 64 * KQ bytes: KQ = 2 (128-byte rows): XOR with row & 7 over the 8 chunks
+// KQ = 4 (256-byte rows = the whole bank width): XOR with row & 15 over the 16 chunks
 template <int KQ> __device__ __forceinline__ int swr(int row, int chunk) {
-  return KQ == 1 ? sw64(row, chunk) : row * 128 + ((chunk ^ (row & 7)) << 4);
+  return KQ == 1 ? sw64(row, chunk) : KQ == 2 ? row * 128 + ((chunk ^ (row & 7)) << 4) : row * 256 + ((chunk ^ (row & 15)) << 4);
 }
 
 // KQ = 32-channel quarters per K step (1: K step 32, 2: K step 64 -- half the barriers, twice the matrix work between them)
@@ -74,7 +75,11 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
   constexpr int NA = BM * CPRW / 256, NB = (BN * CPRW + 255) / 256;
   constexpr int SM = 2 * (AB + BB);
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
-  __shared__ double s_stat[WGM * BN * 2];                // per-wave-row column sums of the epilogue
+  // per-wave-row column sums of the epilogue; where the two staging buffers already fill the 64 KB of static LDS (KQ = 4) they live in
+  // the first buffer, which nobody reads after the last step's barrier
+  constexpr bool STAT_IN_SMEM = SM + (int)sizeof(double) * WGM * BN * 2 > 65536;
+  __shared__ double s_stat_own[STAT_IN_SMEM ? 1 : WGM * BN * 2];
+  double* s_stat = STAT_IN_SMEM ? reinterpret_cast<double*>(smem) : s_stat_own;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WGN, wn = wv % WGN;
   const int r16 = lane & 15, kg = lane >> 4;
@@ -1577,7 +1582,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
 int g_dwh_groups = 32;    // source-block weight gradient: groups of 8 class workgroups per launch (option 26)
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients, bit 19: runtime block extents in the k = 4 source-block data gradient, bit 20: (x, y, z) grid instead of column tile = XCD in the forward convs
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients, bit 19: runtime block extents in the k = 4 source-block data gradient, bit 20: (x, y, z) grid instead of column tile = XCD in the forward convs, bit 21: no 128-channel K steps on the 64 x 64 tiles
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -1614,7 +1619,12 @@ static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   else if (cfg == 4) {
     // few workgroups (< 256 tiles of 128 x 128), each a chain of hundreds of K steps that one step of prefetch does not cover: TWO
     // K steps of loads in flight (round 5; 256 -> 512 @31^3 forward 219.7 -> 188.7 us, four steps 186.5; bit 16: one step as before)
-    if (kq2 && !(g_dconv_cfg & 65536)) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 2, 2>), grid, dim3(256), 0, st, a);
+    // ... and K steps of 128 channels where the layer has them: a wave's 64 x 16 share is 4 MFMAs per 32 channels against ~100 scalar /
+    // vector / LDS instructions of step overhead (round 5: the 256 -> 512 launch was bound by their issue)
+    // (one resident round of workgroups only: two samples of 256 -> 512 @15^3 are 848 workgroups and ran 297 against 266 us)
+    if (kq2 && (a.Cs % 128) == 0 && (long long)grid.x * grid.y * grid.z <= 512 && !(g_dconv_cfg & 2097152))
+      hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 4, 2>), grid, dim3(256), 0, st, a);
+    else if (kq2 && !(g_dconv_cfg & 65536)) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 2, 2>), grid, dim3(256), 0, st, a);
     else if (kq2) hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dconv_cl_kernel<FMT, 4, 1>), grid, dim3(256), 0, st, a);
   } else if (cfg == 3) {
