@@ -158,6 +158,24 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
     b_base[i] = min(cn0 + col, a.Cn - 1) * a.Kc + ch * 8;
   }
   const u16* x_n = a.x + xs_n * a.Cs;
+  // Tap table (round 5): what a K step needs of its tap -- the source-row offset, the weight offset, the mask-bit selector -- sits in
+  // LDS, written once.  The scalar walk used to fetch the tap's t[] / off[] entries from the kernel arguments inside every step:
+  // 6-7 s_load_dword + s_waitcnt lgkmcnt(0), which also drains the step's LDS reads (SQ counters of 64 -> 128 @63^3: 63 scalar
+  // instructions per step, 37 % of the wave time parked on waits).
+  constexpr bool TAPTAB = true;                           // (false: the scalar walk, kept for A/B)
+  __shared__ __attribute__((aligned(16))) int s_tap[64 * 4];
+  if (TAPTAB && !a.rowmode) {
+    const int ntap = cl.td.n * cl.th.n * cl.tw.n;
+    for (int ti = tid; ti < ntap; ti += 256) {
+      const int iw = ti % cl.tw.n, t3 = ti / cl.tw.n;
+      const int ih = t3 % cl.th.n, id = t3 / cl.th.n;
+      const int tapk = (cl.td.t[id] * a.K + cl.th.t[ih]) * a.K + cl.tw.t[iw];
+      s_tap[ti * 4] = ((cl.td.off[id] * a.Hi + cl.th.off[ih]) * a.Wi + cl.tw.off[iw]) * a.Cs;
+      s_tap[ti * 4 + 1] = tapk * a.wtap_stride;
+      s_tap[ti * 4 + 2] = (int)((1u << id) | (16u << ih) | (256u << iw));
+    }
+    __syncthreads();
+  }
   // x through a buffer descriptor of the sample: a row whose tap falls outside the volume loads from an out-of-range offset and
   // gets zeros back -- no clamp, no select when the step is written to LDS
   __amdgpu_buffer_rsrc_t x_rs;
@@ -198,14 +216,27 @@ __global__ __launch_bounds__(256, 2) void dconv_cl_kernel(const DConvK a) {
       return;
     }
     // bring the walk to step s (callers ask for consecutive steps, the last one possibly several times)
-    while (it_s < s) {
-      ++it_s;
-      if (++it_cs == nsteps_c) { it_cs = 0; if (++it_w == cl.tw.n) { it_w = 0; if (++it_h == cl.th.n) { it_h = 0; ++it_d; } } }
+    int toff, woff;
+    unsigned sel;
+    if constexpr (TAPTAB) {
+      while (it_s < s) {
+        ++it_s;
+        if (++it_cs == nsteps_c) { it_cs = 0; ++it_w; }   // it_w: the tap's index in s_tap
+      }
+      const int4 e = *reinterpret_cast<const int4*>(&s_tap[it_w * 4]);
+      toff = e.x + it_cs * 32 * KQ;
+      woff = e.y + it_cs * 32 * KQ;
+      sel = (unsigned)e.z;
+    } else {
+      while (it_s < s) {
+        ++it_s;
+        if (++it_cs == nsteps_c) { it_cs = 0; if (++it_w == cl.tw.n) { it_w = 0; if (++it_h == cl.th.n) { it_h = 0; ++it_d; } } }
+      }
+      const int tap = (cl.td.t[it_d] * a.K + cl.th.t[it_h]) * a.K + cl.tw.t[it_w];
+      toff = ((cl.td.off[it_d] * a.Hi + cl.th.off[it_h]) * a.Wi + cl.tw.off[it_w]) * a.Cs + it_cs * 32 * KQ;
+      woff = tap * a.wtap_stride + it_cs * 32 * KQ;
+      sel = (1u << it_d) | (16u << it_h) | (256u << it_w);
     }
-    const int tap = (cl.td.t[it_d] * a.K + cl.th.t[it_h]) * a.K + cl.tw.t[it_w];
-    const int toff = ((cl.td.off[it_d] * a.Hi + cl.th.off[it_h]) * a.Wi + cl.tw.off[it_w]) * a.Cs + it_cs * 32 * KQ;
-    const int woff = tap * a.wtap_stride + it_cs * 32 * KQ;
-    const unsigned sel = (1u << it_d) | (16u << it_h) | (256u << it_w);
     unsigned m = b_okm | ((1u << NA) - 1u);            // x rows need no mask: invalid ones arrive as zeros
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
