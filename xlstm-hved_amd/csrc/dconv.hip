@@ -539,21 +539,32 @@ __global__ __launch_bounds__(512, 4) void dconv_dgrad_halo_kernel(const DConvK a
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  const int rd0 = (cl.td.off[0] - mind) * HH * HW, rd1 = (cl.td.off[nd > 1 ? 1 : 0] - mind) * HH * HW;
+  const int rh0 = (cl.th.off[0] - minh) * HW, rh1 = (cl.th.off[nh > 1 ? 1 : 0] - minh) * HW;
+  const int rw0 = cl.tw.off[0] - minw, rw1 = cl.tw.off[nw > 1 ? 1 : 0] - minw;
   const int nslice = a.Cs / 32;
   for (int sl = 0; sl < nslice; ++sl) {
-    uint4 qa[NA], qb[NB];
+    // Two groups, each issued whole and then written: with all ten pieces requested at once hipcc (128 registers) kept the four weight
+    // pieces in SCRATCH -- load, wait, spill, four times in a row -- so a slice paid five exposed memory latencies; now it pays two.
+    {
+      uint4 qa[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      qa[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)(a_off[i] == 0xFFFFFFF0u ? a_off[i] : a_off[i] + sl * 64), 0, 0));
+      for (int i = 0; i < NA; ++i)
+        qa[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)(a_off[i] == 0xFFFFFFF0u ? a_off[i] : a_off[i] + sl * 64), 0, 0));
+      if (sl > 0) __syncthreads();                       // every wave is done with the previous slice's image
 #pragma unroll
-    for (int i = 0; i < NB; ++i) qb[i] = *reinterpret_cast<const uint4*>(a.w + (unsigned)(max(b_src[i], 0) + sl * 32));
-    if (sl > 0) __syncthreads();                         // every wave is done with the previous slice's image
+      for (int i = 0; i < NA; ++i)
+        if (a_lds[i] >= 0) *reinterpret_cast<uint4*>(As + a_lds[i]) = qa[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      uint4 qb[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (a_lds[i] >= 0) *reinterpret_cast<uint4*>(As + a_lds[i]) = qa[i];
+      for (int i = 0; i < NB; ++i) qb[i] = *reinterpret_cast<const uint4*>(a.w + (unsigned)(max(b_src[i], 0) + sl * 32));
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (b_src[i] >= 0) *reinterpret_cast<uint4*>(Bs + b_lds[i]) = qb[i];
+      for (int i = 0; i < NB; ++i)
+        if (b_src[i] >= 0) *reinterpret_cast<uint4*>(Bs + b_lds[i]) = qb[i];
+    }
     __syncthreads();
 #pragma unroll 1
     for (int id = 0; id < nd; ++id)
@@ -562,7 +573,10 @@ __global__ __launch_bounds__(512, 4) void dconv_dgrad_halo_kernel(const DConvK a
 #pragma unroll 1
         for (int iw = 0; iw < nw; ++iw) {
           const int t = (id * nh + ih) * nw + iw;
-          const int roff = ((cl.td.off[id] - mind) * HH + (cl.th.off[ih] - minh)) * HW + (cl.tw.off[iw] - minw);
+          // (K4: the two offsets per axis sit in scalar registers -- indexing the class's tables by the loop counters fetched them from
+          // the kernel arguments inside every tap, with an s_waitcnt that also drained the fragment reads)
+          const int roff = K4 ? (id ? rd1 : rd0) + (ih ? rh1 : rh0) + (iw ? rw1 : rw0)
+                              : ((cl.td.off[id] - mind) * HH + (cl.th.off[ih] - minh)) * HW + (cl.tw.off[iw] - minw);
           h16x8 af[TM];
 #pragma unroll
           for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h16x8*>(As + sw64(a_row[i] + roff, kg));
