@@ -547,8 +547,11 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
 
 // resident workgroups per CU (= waves per SIMD) each instance is built for: 75 / 127 / 143 VGPRs, no spills
 constexpr int wq4_waves(int ci4) { return ci4 == 1 ? 6 : ci4 == 2 ? 4 : 3; }
+// ... of the LDS-staged form; fp32 storage (FMT 2) stages 8 floats per piece: at the 16-bit instances' budgets (128 / 168 registers)
+// hipcc spilled its loop-invariant addresses and reloaded them every step behind s_waitcnt vmcnt(0) -- one workgroup less per CU
+constexpr int wq4_resident(int fmt, int ci4) { return (ci4 == 1 ? 5 : ci4 == 2 ? 4 : 3) - (fmt == 2 && ci4 > 1 ? 1 : 0); }
 template <int FMT, int CI4, bool LDSX>
-__global__ __launch_bounds__(256, LDSX ? (CI4 == 1 ? 5 : CI4 == 2 ? 4 : 3) : wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
+__global__ __launch_bounds__(256, LDSX ? wq4_resident(FMT, CI4) : wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
   constexpr int XBN = 6 * (4 * CI4 * 64 + 16), XBW = 4 * (4 * CI4 * 144 + 16);  // x rows of a plane: narrow / wide tiles (wgrad_q4_body_lds)
   constexpr int RING = 4 * ((XBN > XBW ? XBN : XBW) + 32 + 4096);             // four plane slots: x rows, constant block, dY windows
   constexpr int RED = (4 * 4 * CI4 * 27 + 4) * 4;
@@ -630,7 +633,7 @@ void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   const int ci4 = probs[0].ci4;
   // workgroups per launch: all resident at once, dealt to the units in proportion to their tiles
   extern int g_mfma_abl;
-  const int budget = ((g_mfma_abl & 8192) ? wq4_waves(ci4) : (ci4 == 1 ? 5 : ci4 == 2 ? 4 : 3)) * 256;
+  const int budget = ((g_mfma_abl & 8192) ? wq4_waves(ci4) : wq4_resident(fmt, ci4)) * 256;
   double total = 0.0;
   for (int i = 0; i < n; ++i) total += (double)probs[i].nq * probs[i].ntile;
   for (int i = 0; i < n; ++i) {
