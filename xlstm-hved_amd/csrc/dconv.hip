@@ -1260,29 +1260,51 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void dconv_dgrad_c8_kernel(con
   const u16* wl = a.w + (wrow ? r16 : 0) * 64 + kg * 8;
   for (int half = 0; half < 2; ++half) {
     if (half) __syncthreads();                           // every wave is done reading the first 32 channels
-    for (int idx = tid; idx < NV * 4; idx += 256) {
-      const int p = idx >> 2, c = idx & 3;
-      const int pw = p % PW, q = p / PW;
-      const int ph = q % PH, pd = q / PH;
-      const int d = d0 - (K - 2) + pd, h = h0 - (K - 2) + ph, w = w0 - (K - 2) + pw;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)d < (unsigned)Dg && (unsigned)h < (unsigned)Hg && (unsigned)w < (unsigned)Wg)
-        v = *reinterpret_cast<const uint4*>(gn + (((long long)d * Hg + h) * Wg + w) * 64 + half * 32 + c * 8);
-      *reinterpret_cast<uint4*>(tile + p * PITCH + c * 16) = v;
+    // the halo pieces in groups of 8: every load of a group is issued (from a clamped address) before the first is written -- one
+    // load, one wait, one store per trip made a block pay ~30 memory latencies for 3.4 us of MFMAs (round 5)
+    constexpr int NPC = NV * 4, STG = 8;
+#pragma unroll 1
+    for (int i0 = 0; i0 < NPC; i0 += 256 * STG) {
+      uint4 v[STG];
+      unsigned okm = 0;
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        const int idx = min(i0 + u * 256 + tid, NPC - 1);
+        const int p = idx >> 2, c = idx & 3;
+        const int pw = p % PW, q = p / PW;
+        const int ph = q % PH, pd = q / PH;
+        const int d = d0 - (K - 2) + pd, h = h0 - (K - 2) + ph, w = w0 - (K - 2) + pw;
+        okm |= ((unsigned)d < (unsigned)Dg && (unsigned)h < (unsigned)Hg && (unsigned)w < (unsigned)Wg) ? 1u << u : 0u;
+        const int dc = min(max(d, 0), Dg - 1), hc = min(max(h, 0), Hg - 1), wc = min(max(w, 0), Wg - 1);
+        v[u] = *reinterpret_cast<const uint4*>(gn + (((long long)dc * Hg + hc) * Wg + wc) * 64 + half * 32 + c * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        const int idx = i0 + u * 256 + tid;
+        uint4 t = v[u];
+        if (!((okm >> u) & 1)) t = make_uint4(0, 0, 0, 0);
+        if (idx < NPC) *reinterpret_cast<uint4*>(tile + (idx >> 2) * PITCH + (idx & 3) * 16) = t;
+      }
     }
     __syncthreads();
-    uint4 wf = wrow ? *reinterpret_cast<const uint4*>(wl + half * 32) : make_uint4(0, 0, 0, 0);
+    // weight fragments a whole (kd, kh) row ahead (K taps = 4 K MFMAs per wave between request and use; one tap ahead left the L2
+    // latency of every fragment exposed)
+    uint4 wrow_cur[K], wrow_nxt[K];
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) wrow_cur[kw] = *reinterpret_cast<const uint4*>(wl + (long long)kw * 512 + half * 32);   // (padding rows: zeroed at use)
 #pragma unroll 1
     for (int kd = 0; kd < K; ++kd)
 #pragma unroll 1
       for (int kh = 0; kh < K; ++kh) {
+        {
+          const int nrow = min(kd * K + kh + 1, K * K - 1);
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw)
+            wrow_nxt[kw] = *reinterpret_cast<const uint4*>(wl + (long long)(nrow * K + kw) * 512 + half * 32);
+        }
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
-          const int tap = (kd * K + kh) * K + kw;
-          const uint4 wcur = wf;
-          const int nt = tap + 1 < NTAP ? tap + 1 : NTAP - 1;
-          wf = wrow ? *reinterpret_cast<const uint4*>(wl + (long long)nt * 512 + half * 32) : make_uint4(0, 0, 0, 0);
-          const h16x8 bw = __builtin_bit_cast(h16x8, wcur);
+          const h16x8 bw = __builtin_bit_cast(h16x8, wrow ? wrow_cur[kw] : make_uint4(0, 0, 0, 0));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int rb = wv * 4 + i;                   // (dz, hy) row of the block
@@ -1293,6 +1315,8 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void dconv_dgrad_c8_kernel(con
             acc[i] = mfma16x16x32<FMT>(bw, av, acc[i]);
           }
         }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wrow_cur[kw] = wrow_nxt[kw];
       }
   }
   // lane: channels 4 kg .. 4 kg + 3 (kg < 2) of voxel (d0 + dz, h0 + hy, w0 + r16)
@@ -1337,16 +1361,27 @@ __global__ __launch_bounds__(256, 2) void dconv_fwd_c8_kernel(const DFw8K a) {
   const int th_i = t2 % a.th, td_i = t2 / a.th;
   const int d0 = td_i * 4, h0 = th_i * 4, w0 = tw_i * 16;
   const u16* xn = a.x + (long long)n * Dx * Hx * Wx * 8;
-  for (int p = tid; p < NV + 2; p += 256) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (p < NV) {
+  {
+    // all pieces of the halo requested (clamped addresses) before the first is written: one exposed latency instead of four
+    constexpr int NSTG = (NV + 2 + 255) / 256;
+    uint4 v[NSTG];
+    unsigned okm = 0;
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u) {
+      const int p = min(tid + u * 256, NV - 1);
       const int pw = p % PW, q = p / PW;
       const int ph = q % PH, pd = q / PH;
       const int d = d0 - 1 + pd, h = h0 - 1 + ph, w = w0 - 1 + pw;
-      if ((unsigned)d < (unsigned)Dx && (unsigned)h < (unsigned)Hx && (unsigned)w < (unsigned)Wx)
-        v = *reinterpret_cast<const uint4*>(xn + (((long long)d * Hx + h) * Wx + w) * 8);
+      okm |= (tid + u * 256 < NV && (unsigned)d < (unsigned)Dx && (unsigned)h < (unsigned)Hx && (unsigned)w < (unsigned)Wx) ? 1u << u : 0u;
+      const int dc = min(max(d, 0), Dx - 1), hc = min(max(h, 0), Hx - 1), wc = min(max(w, 0), Wx - 1);
+      v[u] = *reinterpret_cast<const uint4*>(xn + (((long long)dc * Hx + hc) * Wx + wc) * 8);
     }
-    *reinterpret_cast<uint4*>(tile + p * 16) = v;
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u) {
+      uint4 t = v[u];
+      if (!((okm >> u) & 1)) t = make_uint4(0, 0, 0, 0);
+      if (tid + u * 256 < NV + 2) *reinterpret_cast<uint4*>(tile + (tid + u * 256) * 16) = t;
+    }
   }
   // weights: w[r9][co (64)][k (32)]; this lane supplies row m = r16 of block j = channel co_of(j)
   int wrow[4];
