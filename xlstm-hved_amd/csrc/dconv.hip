@@ -1240,6 +1240,9 @@ __global__ __launch_bounds__(256, 2) void dwgrad_c8_halo_kernel(const DWg8HK a) 
 // voxel pitch: the 16 lanes of a fragment read sit 20 banks apart), so the 27 taps are 27 shifted LDS reads of the same tile:
 // no barrier and no global activation traffic inside the tap loop; the weight fragment of a tap (1 KB) comes from L1/L2, one
 // tap ahead.  Weights ride on the M side (8 of 16 rows used): a lane ends up with 4 consecutive channels of one voxel.
+// (Round 5: a dense 64-byte pitch with a chunk XOR that is conflict-free for the real ds_read_b128 lane groups -- they mix two
+// k-groups, this pitch was built for one -- removed every bank conflict and ran 12 % SLOWER: at the 80-byte pitch all 16 fragment
+// reads of a (kd, kh) row are one base register + immediates; the XOR costs vector instructions per read in a loop of 4 MFMAs per tap.)
 // K = 4: the halo is 7 x 7 x 19 (74 KB at the 80-byte pitch: two workgroups per CU), 64 taps; destination d takes tap kd from
 // source d + 1 - kd, so the halo starts at d0 - (K - 2).  (D, H, W) are the DESTINATION extents (the conv's input), the
 // gradient g has (D, H, W) + 3 - K.
