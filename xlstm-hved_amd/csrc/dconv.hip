@@ -1400,24 +1400,31 @@ __global__ __launch_bounds__(256, 2) void dconv_fwd_c8_kernel(const DFw8K a) {
   int wrow[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) wrow[j] = ((j >> 1) * 32 + (r16 >> 2) * 8 + (j & 1) * 4 + (r16 & 3)) * 32 + kg * 8;
-  uint4 wf[4];
+  // weight fragments AH steps ahead (a step = 16 MFMAs per wave = 256 cycles; the 36 / 64 KB of weights do not stay in L1: with one
+  // step of lookahead SQ_WAIT_ANY was 74 % of the wave time, round 5: 200 -> 178 us); the step loop is unrolled so that the ring index
+  // is static.  (The same depth in the 8-channel data gradient needed its tap loops unrolled: 222 registers, 431 -> 470 us, dropped.)
+  constexpr int AH = 4;
+  uint4 wf[AH][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const uint4*>(a.w + wrow[j]);
+  for (int u = 0; u < AH; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[u][j] = *reinterpret_cast<const uint4*>(a.w + (u < K * K ? u : K * K - 1) * 2048 + wrow[j]);
   f32x4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-#pragma unroll 1
+#pragma unroll
   for (int r9 = 0; r9 < K * K; ++r9) {
     const int kd = r9 / K, kh = r9 - kd * K;
     h16x8 bw[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bw[j] = __builtin_bit_cast(h16x8, wf[j]);
-    const int nr = r9 + 1 < K * K ? r9 + 1 : K * K - 1;
+    for (int j = 0; j < 4; ++j) bw[j] = __builtin_bit_cast(h16x8, wf[r9 % AH][j]);
+    if (r9 + AH < K * K) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const uint4*>(a.w + nr * 2048 + wrow[j]);
+      for (int j = 0; j < 4; ++j) wf[r9 % AH][j] = *reinterpret_cast<const uint4*>(a.w + (r9 + AH) * 2048 + wrow[j]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rb = wv * 4 + i;
