@@ -409,7 +409,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_parity(dev, modes):
+def measured_parity(dev, modes, keep_mode=False):
     """MEASURED in this run, per storage mode: the thresholded segmentation of the 128^3 parity case against the mask the REAL
     reference produced for it (tests/golden/mask_trained_like_128.npz, written by tests/golden/make_mask_128.py from the imported
     reference; the CPU oracle reproduces it with 0 flips).  Case: weights_trained_like.npz (the reference trained for 300 CPU
@@ -434,7 +434,8 @@ def measured_parity(dev, modes):
     out = {}
     try:
         for name, dt_ in modes.items():
-            ops.set_fp32_mfma(name == "fp32_mfma")
+            if not keep_mode:                                   # (keep_mode: the caller has set the arithmetic / storage policy)
+                ops.set_fp32_mfma(name == "fp32_mfma")
             with torch.no_grad():
                 seg = m(x.to(dt_), [14], recon=True, valid=True)[0]
             got = seg.float() > 0.5

@@ -136,6 +136,18 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
+// Sigmoid whose STORED value keeps the side of 0.5 its logit is on.  The segmentation is thresholded at `> 0.5` (metrics.py:85-107,
+// RA_HVED.py:640-641): with 16-bit storage a probability in (0.5, 0.5 + ulp / 2] rounds to exactly 0.5 and lands on the wrong side
+// although the logit is positive -- tools/precision_sweep.py: 209 of 6.3 M voxels at bf16, 17 at fp16 from this rounding alone.
+// Such a value is stored as the format's next value above 0.5 instead (an error of <= 1 ulp instead of <= 1/2 ulp on these voxels
+// only); a probability below 0.5 that rounds up to 0.5 already fails `> 0.5` as it should.  fp32 storage: unchanged.
+__device__ __forceinline__ float apply_act_as(const float*, float v, int act, float slope) { return apply_act(v, act, slope); }
+template <int F> __device__ __forceinline__ float apply_act_as(const h16<F>* yp, float v, int act, float slope) {
+  float o = apply_act(v, act, slope);
+  if (act == XH_ACT_SIGMOID && v > 0.f && rnd_as(yp, o) <= 0.5f) o = F == 0 ? 0.50390625f : 0.50048828125f;
+  return o;
+}
+
 // 64-lane wave reductions.  The four steps inside a 16-lane row are DPP moves (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
 // row_mirror: full-rate vector instructions); only the two steps across rows go through the LDS crossbar (ds_bpermute).
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {

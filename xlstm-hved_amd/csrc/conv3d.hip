@@ -90,7 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long
   float t0 = 0.f, t1 = 0.f;       // this run in fp32; the lane's running sums are fp64 (statistics precision, common.h)
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    float o = MODE >= 0 ? val[v] + bias : apply_act(val[v] + bias, a.d.act, a.d.act_slope);
+    float o = MODE >= 0 ? val[v] + bias : apply_act_as(yp, val[v] + bias, a.d.act, a.d.act_slope);
     if (v < valid) {
       if (epi == 1) {
         o = rnd_as(yp, o * ((ev[v] * esc + esh) > 0.f ? 1.f : a.d.e_slope));

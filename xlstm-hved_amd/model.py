@@ -502,13 +502,20 @@ class AbstractFusion3DUNet(nn.Module):
         x, feat_list, skip = enc
         n = x.shape[0]
         keep = self._keep_mask(x, subset_idx_list, instance_missing, drop)
+        sdt = x.dtype
+        if ops.MIXED[0] is not None and x.dtype == torch.float32 and x.is_cuda:
+            # mixed storage (ops.set_mixed_storage): the encoder half ran in fp32 storage; everything the decoder half sees of it
+            # passes through the DRB outputs and the coarsest skip feature (RA_HVED.py:569-626) -- small tensors, cast here
+            sdt = ops.MIXED[0]
+            feat_list = [f.to(sdt) for f in feat_list]
+            skip = skip.to(sdt) if skip is not None else None
         mu_list, logvar_list, feats = [], [], []
         noise = None
         if not valid and eps_list is None:
             # RA_HVED.py:744 draws N(0,1) noise per level; here ONE draw (in the storage type) serves the four levels
             shapes = [(n, self.MVAE_latents[l]) + tuple(f.shape[2:]) for l, f in enumerate(feat_list)]
             sizes = [int(torch.Size(s_).numel()) for s_ in shapes]
-            flat = torch.randn(sum(sizes), device=x.device, dtype=x.dtype)
+            flat = torch.randn(sum(sizes), device=x.device, dtype=sdt)
             noise, o = [], 0
             for s_, k in zip(shapes, sizes):
                 noise.append(flat[o:o + k].view(s_))
@@ -520,7 +527,7 @@ class AbstractFusion3DUNet(nn.Module):
         nlev = len(feat_list)
         epss = [None] * nlev
         if not valid:
-            epss = [noise[l] if noise is not None else eps_list[l].to(device=x.device, dtype=x.dtype).contiguous() for l in range(nlev)]
+            epss = [noise[l] if noise is not None else eps_list[l].to(device=x.device, dtype=sdt).contiguous() for l in range(nlev)]
         # the PoE of all levels in one launch (they depend on the encoder outputs only)
         if nlev <= ops.POE_MAX:
             zml = Fn.PoEAll.apply(keep, tuple(self.MVAE_latents[:nlev]), bool(instance_missing), nlev, *feat_list, *epss)

@@ -84,6 +84,19 @@ def set_fp32_mfma(enabled):
     _PACK_STATE["arrays"] = None
 
 
+MIXED = [None]
+
+
+def set_mixed_storage(dtype):
+    """Mixed storage policy for fp32 inputs: None (default: every tensor in the input's type), or torch.float16 / torch.bfloat16 --
+    the ENCODER half (init blocks, encoders, skip-return path, DRBs) keeps fp32 storage, the decoder half (PoE onwards) stores in
+    this 16-bit type.  tools/precision_sweep.py: the mask flips of 16-bit storage come from the encoder trunk (every rounding
+    there is amplified by all the InstanceNorms behind it), not from the decoders."""
+    if dtype not in (None, torch.float16, torch.bfloat16):
+        raise ValueError("mixed storage: None, torch.float16 or torch.bfloat16")
+    MIXED[0] = dtype
+
+
 def last_conv_kernel():
     """Template instance launched by the most recent conv3d / conv3d_wgrad call (bench.py attributes timings with it)."""
     return L.load().xh_last_conv_kernel().decode()
