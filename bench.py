@@ -111,11 +111,15 @@ def bench_loss(seg, mu, lv, rec):
     return sum_of_means([seg, rec] + [t for ab in zip(mu, lv) for t in ab])
 
 
-def cpu_baseline(size, batch, budget_s=60.0, sweep=(8, 16, 32, 64)):
-    """Times the CPU oracle (functional restatement of the reference path, stock torch ops, fp32) on this host.
-    Thread-count sweep on one 1x4x64^3 fwd+bwd step (stock CPU conv3d stops scaling long before a 256-thread host is
-    full: 256 threads took 771 s per 128^3 step); the best count then runs the full-size step if its extrapolated time
-    fits the budget.  Never touches the GPU (runs in a child process of the N=1 bench)."""
+CPU_BASELINE_THREADS = (16, 32)     # pinned (profiles/cpu_baseline_calibration.json: stock CPU conv3d stops scaling between them)
+
+
+def cpu_baseline(size, batch, threads=CPU_BASELINE_THREADS):
+    """Times the CPU oracle (functional restatement of the reference path, stock torch ops, fp32) on this host: one FULL-SIZE
+    fwd+bwd step at each of the PINNED thread counts, both reported, `value` = the faster.  (Rounds 1-5 chose the count from a
+    64^3 sweep that raced the GPU legs' launch threads -- the driver saw 16 threads / 8.5e4 where the builder saw 32 / 6.2e4; stock
+    CPU conv3d stops scaling long before a 256-thread host is full: 256 threads took 771 s per 128^3 step.)  A warm-up step at
+    64^3 per count (thread pool, allocator) is untimed.  Never touches the GPU (runs in a child process of the N=1 bench)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import xlstm_hved_oracle as O
     import xlstm_hved_amd as X
@@ -134,27 +138,20 @@ def cpu_baseline(size, batch, budget_s=60.0, sweep=(8, 16, 32, 64)):
         prob, _, mu, lv, rec = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True, reference_cost=True)
         O.bench_loss(prob, mu, lv, rec).backward()
         return time.perf_counter() - t0
-    small = min(size, 64)
-    counts = sorted({min(c, ncpu) for c in sweep})
+    counts = sorted({min(c, ncpu) for c in threads})
     times = {}
     for c in counts:
         torch.set_num_threads(c)
-        run(small)                                # untimed: thread pool + allocator warm-up at this count
-        times[c] = run(small)
+        run(min(size, 64))                        # untimed: thread pool + allocator warm-up at this count
+        times[c] = run(size)
     cores = min(times, key=times.get)
-    torch.set_num_threads(cores)
-    used, t = small, times[cores]
-    if size > small and t * (size / small) ** 3 <= budget_s:
-        used, t = size, run(size)
-    sw = ", ".join(f"{c}: {v:.2f} s" for c, v in times.items())
-    return {"value": batch * used ** 3 / t, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "concurrent_with_gpu_legs": True,
-            "sample": f"(timed in a child process WHILE the GPU legs of this run were being driven from the same host: their "
-                      f"launch threads share the cores, run-to-run spread ~12 %) "
-                      f"one fwd+bwd step of {batch}x4x{used}^3 fp32 through oracle/xlstm_hved_oracle.py (torch "
-                      f"{torch.__version__} CPU ops) on {cores} threads of {ncpu}: {t:.2f} s; thread sweep on the "
-                      f"{batch}x4x{small}^3 step: {sw}"
-                      + ("" if used == size else f"; the {size}^3 step was extrapolated to exceed {budget_s:.0f} s and was not run")}
+    per = {str(c): {"seconds": round(t, 3), "voxels_per_s": batch * size ** 3 / t} for c, t in times.items()}
+    return {"value": batch * size ** 3 / times[cores], "unit": "voxels/s", "cores": cores, "kind": "port",
+            "threads_pinned": list(counts), "per_thread_count": per, "concurrent_with_gpu_legs": True,
+            "sample": f"one fwd+bwd step of {batch}x4x{size}^3 fp32 through oracle/xlstm_hved_oracle.py (torch {torch.__version__} "
+                      f"CPU ops) at each pinned thread count of a {ncpu}-thread host: "
+                      + ", ".join(f"{c} threads {t:.2f} s" for c, t in times.items())
+                      + f"; value = the faster ({cores} threads); timed in a child process next to the GPU legs of this run"}
 
 
 def spawn_workers(args):
@@ -854,11 +851,17 @@ def roofline_pass(step, ops, nsteps, dtype):
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
+    c1_meta = []                                              # k = 1 convs recorded between conv1x1_collect() and conv1x1_flush()
+
     def timed_fwd(xa, xb, weights, biases, **kw):
+        collected = ops._C1_COLLECT[0] is not None and kw["k"] == 1      # not launched here: ops.conv1x1_flush issues it (timed_c1_flush)
+        n_before = len(ops._C1_COLLECT[0]) if collected else 0
         e0, e1 = ev(), ev()
-        e0.record()
+        if not collected:
+            e0.record()
         res = orig_fwd(xa, xb, weights, biases, **kw)
-        e1.record()
+        if not collected:
+            e1.record()
         y = res[0] if isinstance(res, tuple) else res         # (y, sc, sh, mean, rstd) when the norm finalisation is fused
         cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
         k, groups = kw["k"], kw.get("groups", 1)
@@ -866,10 +869,31 @@ def roofline_pass(step, ops, nsteps, dtype):
         e_el = y.numel() if kw.get("epi", 0) == 1 else 0          # epi 1 also reads the saved activation once
         nbytes = (in_el + y.numel() + e_el) * esz + sum(w.numel() for w in weights) * 4
         flops = 2.0 * y.numel() * k ** 3 * cin / groups
-        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops,
-                        f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{y.shape[1]} @{'x'.join(map(str, y.shape[2:]))}"
-                        + (" dgrad" if kw.get("transposed") else ""), 1))
+        shape = (f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{y.shape[1]} @{'x'.join(map(str, y.shape[2:]))}"
+                 + (" dgrad" if kw.get("transposed") else ""))
+        if collected and ops._C1_COLLECT[0] is not None and len(ops._C1_COLLECT[0]) > n_before:
+            c1_meta.append((nbytes, flops, shape))
+            return res
+        if collected:                                          # the call was not taken by the collector after all: launched, unbracketed
+            return res
+        records.append((ops.last_conv_kernel(), e0, e1, nbytes, flops, shape, 1))
         return res
+
+    orig_c1_flush = ops.conv1x1_flush
+
+    def timed_c1_flush():
+        """The collected k = 1 convs of the latent path: ONE bracket around the multi-problem launch(es) that carry them."""
+        metas = c1_meta[:]
+        c1_meta.clear()
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = orig_c1_flush()
+        e1.record()
+        if metas:
+            nl = -(-len(metas) // 4)
+            records.append((ops.last_conv_kernel(), e0, e1, sum(m[0] for m in metas), sum(m[1] for m in metas),
+                            f"{len(metas)} k1 convs in {nl} launch(es): " + "; ".join(m[2] for m in metas), nl))
+        return r
 
     pending_meta = []
 
@@ -920,7 +944,8 @@ def roofline_pass(step, ops, nsteps, dtype):
            "upsample2x_in_act upsample2x_bwd_act_reduce add act_bwd channel_pool channel_pool_bwd gate gate_bwd channel_pool2 "
            "channel_pool2_bwd gate2 gate2_bwd gate_maxpool gate_maxpool_bwd duse_gate duse_gate_bwd duse_gate_fc rank1_add_fc "
            "rank1_add skr_tail skr_tail_bn skr_tail_bwd duse_fc_fwd duse_fc_bwd poe_fwd poe_bwd poe_fwd_multi poe_bwd_multi "
-           "compose_multi pair_sums lincomb loss_finalize kld_fwd kld_bwd nested_weight multi_sum multi_fill fill").split()
+           "compose_multi pair_sums lincomb loss_finalize kld_fwd kld_bwd nested_weight multi_sum multi_fill fill "
+           "in_affine_act_multi act_bwd_reduce_multi in_bwd_apply_multi upsample2x_in_act_multi upsample2x_bwd_act_reduce_multi").split()
     ELT = [n_ for n_ in ELT if hasattr(ops, n_)]
     elt_orig = {n_: getattr(ops, n_) for n_ in ELT}
     elt_records = []
@@ -978,7 +1003,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     gpu_delay = GpuDelay()                   # (see the class: keeps the whole chip busy so the clocks stay up)
     # the delay must outlast the host's enqueue time of one instrumented step (else the GPU catches up and a bracket
     # also spans host launch latency): time one instrumented enqueue, then wait 1.5x that (+20 ms), at most 600 ms
-    ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
+    ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred, ops.conv1x1_flush = timed_fwd, timed_wg, timed_flush, timed_c1_flush
     elt_install(True)
     try:
         t_h = time.perf_counter()
@@ -986,7 +1011,7 @@ def roofline_pass(step, ops, nsteps, dtype):
         host_ms = (time.perf_counter() - t_h) * 1e3
         torch.cuda.synchronize()
     finally:
-        ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
+        ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred, ops.conv1x1_flush = orig_fwd, orig_wg, orig_flush, orig_c1_flush
         elt_install(False)
     records.clear()
     elt_records.clear()
@@ -994,7 +1019,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     # an event pair costs a few microseconds of its own (two marker packets): measure empty brackets under the same
     # queued conditions and subtract their median from every bracket
     overhead_ms = gpu_delay.empty_pair_ms(delay_ms)
-    ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = timed_fwd, timed_wg, timed_flush
+    ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred, ops.conv1x1_flush = timed_fwd, timed_wg, timed_flush, timed_c1_flush
     elt_install(True)
     whole = []
     try:
@@ -1007,7 +1032,7 @@ def roofline_pass(step, ops, nsteps, dtype):
             whole.append((w0, w1))
         torch.cuda.synchronize()
     finally:
-        ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred = orig_fwd, orig_wg, orig_flush
+        ops.conv3d, ops.conv3d_wgrad, ops._flush_deferred, ops.conv1x1_flush = orig_fwd, orig_wg, orig_flush, orig_c1_flush
         elt_install(False)
     # element-wise family: per entry point, the n-th call of each step across the steps -> median, like the conv brackets
     elt_by = {}
@@ -1070,8 +1095,35 @@ def roofline_pass(step, ops, nsteps, dtype):
             t = json.load(f)
         if name in t.get("kernels", {}) and t.get("dtype") == {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[dtype]:
             traffic = t["kernels"][name]["hbm_bytes_per_launch"]
+    tmeta = {}
+    if traffic is not None:
+        # how old the committed capture is: the commit it was taken from, commits since (None where there is no .git, e.g. on a
+        # gpurun box) and whether the kernel sources of THIS tree are the ones it was captured with (content hash)
+        age = None
+        if t.get("captured_commit"):
+            try:
+                age = int(subprocess.check_output(["git", "-C", ROOT, "rev-list", "--count", t["captured_commit"] + "..HEAD"],
+                                                  stderr=subprocess.DEVNULL).decode())
+            except Exception:
+                age = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hashlib
+            h = hashlib.sha1()
+            croot = os.path.join(ROOT, "xlstm-hved_amd", "csrc")
+            for f_ in sorted(os.listdir(croot)):
+                if f_.endswith((".hip", ".h")):
+                    h.update(f_.encode())
+                    h.update(open(os.path.join(croot, f_), "rb").read())
+            same = h.hexdigest() == t.get("csrc_sha1")
+        except Exception:
+            same = None
+        tmeta = {"traffic_captured_commit": t.get("captured_commit"), "traffic_captured_date": t.get("captured_date"),
+                 "traffic_age_commits": age, "traffic_kernel_sources_unchanged": same}
+    r.update(tmeta)
     r.update({"traffic": traffic,
-              "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command)",
+              "traffic_source": None if traffic is None else "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; "
+                                                              "a committed capture, not a measurement of this run: see traffic_*)",
               "kernel": name, "launches_per_step": cnt / nsteps, "avg_launch_us": avg_ms * 1e3,
               "shapes": {k: v / nsteps for k, v in shapes.items()},
               "shape_avg_us": {k: round(shape_us[(name, k)], 1) for k in shapes},

@@ -51,10 +51,7 @@ int xh_abi_version(void);
  * key 16: workgroup cap of the 1<->2-channel k3 stencil kernels (default 512).
  * key 17: workgroup count below which a quad-channel k3 launch walks 4, then 2 output planes per workgroup instead of 8
  *         (default 512; 0 = always 8).
- * key 18: 1 = fp32 STORAGE takes the quad-channel matrix-core kernels with two-term fp16 operands (csrc/conv3d_q4s.hip: three fp16
- *         MFMA products per fp32 product, ~22 significand bits) for k = 3 stride-1 convs and their data gradients instead of the
- *         fp32 vector kernels; default 0.  In the backward pass the activation gradients then need the caller's loss scale, as
- *         with fp16 storage.
+ * key 18: REMOVED in round 6 (returns XH_ERR_ARG): the arithmetic of fp32 storage is xh_conv_desc.arith, a field of every call.
  * key 19: persistent, tile-pipelined variant of the quad-channel k3 kernel (csrc/conv3d_q4p.hip): 0 = never, 1 = forward launches with
  *         several input quads per tile and >= 2048 stages (default: where it was measured to win), 2 = every 8-plane launch.
  * key 20: mask of the row widths on which quad-channel k3 convs take the full-row tiles of csrc/conv3d_q4w.hip: bit 1 = 128 voxels,
@@ -63,7 +60,7 @@ int xh_abi_version(void);
  * key 21: 0 = no full-row weight-gradient kernel (csrc/conv3d_wgrad_q5.hip; the 32-wide tile kernel instead).  key 22: its
  *         workgroup budget per launch (default 256 = one per CU).  key 23: 1 = rows of 32 voxels too (measured slower).
  * key 24: input-stationary 7^3 gate-conv kernel (csrc/conv7_mfma.hip): 0 never, 1 volumes >= 2^20 voxels (default), 2 B fragments in
- *         registers, 3 every volume.  key 25: 1 = fp32 storage keeps the fp32 vector kernels for the 7^3 gate convs.
+ *         registers, 3 every volume.  key 25: REMOVED in round 6 (xh_conv_desc.arith bit XH_ARITH_K7_VECTOR).
  * key 26: groups of 8 class workgroups per launch of the discriminator's source-block weight gradient (default 32 = 256 workgroups).
  * key 27: workgroup target of the row-streaming norm / element-wise kernels (default 2048).
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
@@ -75,12 +72,18 @@ int xh_abi_version(void);
  * PROCESS-GLOBAL STATE (the only two exceptions to "no mutable state in the library"): the option table behind
  * xh_set_option (plain ints, e.g. g_q4_maxc / g_q4_wgs in csrc/conv3d_q4.hip) and the name buffer behind xh_last_conv_kernel
  * are per PROCESS, not per device, stream or call.  They are development / measurement knobs: every option has a default that
- * is the measured optimum and the deployment model is one process per GPU.  The package's Python files set exactly ONE of them,
- * and only when the caller asks: ops.set_fp32_mfma(on) writes key 18 (the arithmetic of fp32 storage: matrix cores through the
- * two-term fp16 split instead of the fp32 vector kernels); it is read when a conv is launched, i.e. at capture time of a graph.
- * Every other key is written by bench.py, tools/ and tests/ only.  Neither function is thread-safe against concurrent launches from other host threads: set options
- * before the first launch; read xh_last_conv_kernel on the thread that made the call.  Every other entry point is re-entrant:
- * all device memory, workspaces and the statistics fan-in block are the caller's, the stream is an argument. */
+ * is the measured optimum, the deployment model is one process per GPU, and the package's Python files write none of them
+ * (bench.py, tools/ and tests/ do).
+ * WHAT AN OPTION CAN CHANGE.  No option selects an arithmetic MODE any more: the one that did (key 18, with 25) is now
+ * xh_conv_desc.arith.  The remaining keys choose between kernels / launch plans that compute the same function:
+ *   - bit-identical results whatever the value: keys 3, 10-13, 16, 17, 19, 20, 22, 26, 27 and key 14's tile / remap bits;
+ *   - same products, sums taken in another order (differences at fp32 / fp64 round-off of the sums): key 2 bits 0, 1, 2, 6, 8, 9,
+ *     10; keys 5, 21, 23; key 14's kernel-choice bits;
+ *   - a different kernel FAMILY for the same conv, one operand rounding apart in 16-bit storage (tests hold both to the same
+ *     bounds): key 0 (MFMA vs vector kernels), key 2 bits 3, 4, 5, 7, key 24 (input- vs output-stationary 7^3 kernel).
+ * Neither function is thread-safe against concurrent launches from other host threads: set options before the first launch;
+ * read xh_last_conv_kernel on the thread that made the call.  Every other entry point is re-entrant: all device memory,
+ * workspaces and the statistics fan-in block are the caller's, the stream and the arithmetic mode are arguments. */
 int xh_set_option(int key, int value);
 /* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call of THIS PROCESS launched (static
  * storage, overwritten by the next call on any thread; the same spelling rocprofv3 prints), so measurements can be attributed
@@ -121,7 +124,19 @@ typedef struct {
   long long ea_bs, eb_bs;
   float e_slope;
   long long px_bs, pd_bs;       /* pre == 2: batch strides of px and pd */
+  int arith;                    /* ARITHMETIC of this call when dtype == XH_F32 (16-bit storage ignores it): XH_ARITH_* bits.
+                                   0 (default): the fp32 vector (FMA) kernels.
+                                   XH_ARITH_F32_SPLIT: the matrix cores with every fp32 value as a two-term fp16 pair (csrc/conv3d_q4s.hip:
+                                   three fp16 MFMA products per fp32 product, ~22 significand bits, fp32 accumulation) for k = 3 stride-1
+                                   convs and their data gradients; their weight gradients and the 7^3 gate convs with operands rounded
+                                   ONCE to fp16.  In the backward pass the activation gradients then need the caller's loss scale, as
+                                   with fp16 storage.
+                                   XH_ARITH_K7_VECTOR (with F32_SPLIT): the 7^3 gate convs stay on the fp32 vector kernels.
+                                   The mode is part of the CALL (round 6; it was process state behind xh_set_option keys 18 / 25):
+                                   two models of different modes, or a captured graph next to eager calls, cannot disturb each other. */
 } xh_conv_desc;
+#define XH_ARITH_F32_SPLIT 1
+#define XH_ARITH_K7_VECTOR 2
 
 typedef struct {
   const void* xa; const void* xb;
@@ -378,8 +393,22 @@ typedef struct {
   void *z, *mu_stack, *lv_stack;
   const void *dz, *dmu_stack, *dlv_stack; void* dfeat;
   long long dhw; int N, L, mask_mu;
+  /* In-kernel reparameterisation noise (RA_HVED.py:741-747 draws eps ~ N(0,1) in fp32 with normal_()): when eps == NULL and
+   * rng_used != NULL, element i of this job takes eps_i = the standard normal of Philox4x32-10 keyed by
+   * (seed, *rng_used, rng_stream, i) -- fp32 whatever the storage type, no noise tensor in HBM, no generator launch.
+   * rng_used: TWO 64-bit device words {draw counter, seed} of this forward; the backward call passes the same words and
+   * regenerates the same eps.  See xh_poe_multi for who writes them. */
+  const unsigned long long* rng_used; int rng_stream;
 } xh_poe_job;
-int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_poe_job* jobs);
+/* rng (optional, forward only; required when a job has rng_used and no eps): the caller's generator state, FOUR 64-bit device
+ * words {seed, counter, ticket, reserved}, ticket zero on entry.  Every workgroup of the launch reads `counter` when it starts;
+ * the last workgroup to finish copies {counter, seed} into every job's rng_used words, advances `counter` by one and leaves `ticket` zero -- so
+ * each launch (each replay of a captured graph included) draws fresh noise with no host involvement, and launches ordered on a
+ * stream may share one state.  In a backward call rng is NULL: the jobs' rng_used words already hold their forward's counter and seed. */
+int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_poe_job* jobs, unsigned long long* rng);
+/* out[i] = the standard normal xh_poe_multi draws for element i of a job with (seed, counter, rng_stream) (raw = 0: n fp32 values),
+ * or the four raw Philox4x32-10 output words of counter block i (raw = 1: 4 n uint32 values).  Test / inspection aid. */
+int xh_philox_normal(void* stream, unsigned long long seed, unsigned long long counter, int rng_stream, void* out, long long n, int raw);
 
 /* ------------------------------------------------------------------------------------------------
  * Channel attention glue.

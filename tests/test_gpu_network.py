@@ -394,6 +394,86 @@ def test_fp32_full_size_128_backward_vs_oracle(arith):
     assert worst < 5e-3 and l2 < 5e-3, (worst, wname, l2)
 
 
+@functools.lru_cache(maxsize=None)
+def _oracle_backward_128_trained():
+    """The CPU oracle's forward + backward of the 128^3 parity case (trained-like weights, blob patch 8, train mode, fixed eps)."""
+    import synth_blobs as SB
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    x, _ = SB.blob_case(8, 1, 128)
+    torch.manual_seed(23)
+    eps = [torch.randn(1, 2 ** l, 64 >> l, 64 >> l, 64 >> l) for l in range(4)]
+    w = load("weights_trained_like")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+    prob_o, _, mu_o, lv_o, rec_o = O.xlstm_hved_forward(sd, x, 14, eps_list=eps, training=True)
+    O.bench_loss(prob_o, mu_o, lv_o, rec_o).backward()
+    return x, eps, w, {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+FAMILIES = (("encoders", "encoders."), ("DRBs", "DRBs."), ("skip-return", ("x0_init.", "skr_encoders.", "skr_att.")),
+            ("latent (VU, conv blocks)", ("VU_blocks.", "conv_blocks.")), ("mid ViL", "mViL."),
+            ("seg decoders", ("decoders.", "srdecoder.sdecoders.")), ("recon decoders", "srdecoder.multi_decoders."),
+            ("DuSE", "srdecoder.dusfe_decoders."), ("heads", ("final_conv.", "srdecoder.rfinals.", "srdecoder.sfinals.")))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32_mfma"])
+def test_16bit_full_size_128_backward_vs_oracle_on_trained_like_weights(mode):
+    """The gradients the benchmarked step produces in 16-bit storage, at the benchmarked size, against the CPU oracle
+    (buildingblocks.py:406-433 and everything else of RA_HVED.py:510-648, backward): every parameter gradient of one
+    1x4x128^3 training step (loss of SURVEY 8(d), fixed eps) on the trained-like weights and the smooth blob patch -- the case
+    whose forward the storage-mode tests measure -- with the relative L2 error printed PER PARAMETER FAMILY.  fp16 and fp32_mfma
+    run under the reference's initial GradScaler scale (train.py:207), bf16 unscaled.  16-bit storage rounds every activation
+    and every activation gradient once per tensor; the bounds are the measured class of each mode with margin, and the
+    fp32_mfma row shows what the same comparison gives when only the operands of the matrix-core products are rounded."""
+    x, eps, w, gref = _oracle_backward_128_trained()
+    m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
+    m.load_state_dict(w, strict=True)
+    m = m.to(DEV).train()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32_mfma": torch.float32}[mode]
+    scale = 1.0 if mode == "bf16" else 65536.0
+    m.fp32_arith = "split" if mode == "fp32_mfma" else None
+    seg, (mu, lv), rec = m(x.to(DEV, dt), [14], recon=True, eps_list=eps)
+    loss = seg.float().mean() + rec[0].float().mean()
+    for a_, b_ in zip(mu, lv):
+        loss = loss + a_.float().mean() + b_.float().mean()
+    (loss * scale).backward()
+    X.ops.join_wgrad_stream()
+    torch.cuda.synchronize()
+    got = {}
+    for k, p_ in m.named_parameters():
+        if k.startswith("init_blocks.") or p_.grad is None:
+            continue                                  # mathematically zero gradient behind an InstanceNorm
+        kk = k.replace("decoders.", "srdecoder.sdecoders.", 1) if k.startswith("decoders.") else k
+        if kk in gref:
+            got[kk] = p_.grad.float().cpu() / scale
+    assert len(got) > 250 and all(torch.isfinite(v).all() for v in got.values())
+    num = sum(((got[k] - gref[k]) ** 2).sum().item() for k in got)
+    den = sum((gref[k] ** 2).sum().item() for k in got)
+    l2 = (num / den) ** 0.5
+    gscale = max(v.abs().max().item() for v in gref.values())
+    worst, wname = max((((got[k] - gref[k]).abs().max().item() / gscale, k) for k in got))
+    rows = []
+    for name, pre in FAMILIES:
+        ks = [k for k in got if k.startswith(pre)]
+        if not ks:
+            continue
+        fn = sum(((got[k] - gref[k]) ** 2).sum().item() for k in ks)
+        fd = sum((gref[k] ** 2).sum().item() for k in ks)
+        rows.append((name, len(ks), (fn / max(fd, 1e-30)) ** 0.5, (fd / den) ** 0.5))
+    print(f"{mode} 128^3 backward vs oracle (trained-like weights): {len(got)} parameter gradients, relative L2 {l2:.3e}, "
+          f"worst {worst:.2e} of the largest gradient ({wname})")
+    for name, cnt, e, share in rows:
+        print(f"    {name:26s} {cnt:3d} tensors  relative L2 {e:.3e}   (share of the gradient norm {share:.2f})")
+    # measured on MI355X (round 6): overall bf16 9.2e-2, fp16 3.8e-2, fp32_mfma 1.1e-3; the families that carry the gradient norm:
+    # encoders 0.120 / 0.051 / 1.4e-3, DRBs 2.1e-3 / 3.3e-4 / 5e-6, DuSE 3.3e-3 / 1.7e-3 / 1.8e-3, heads 7.7e-4 / 7.5e-5 / 6.6e-5,
+    # skip-return (3 % of the norm) 0.56 / 0.034 / 3.0e-3.  The recon decoders (6.4e-2) and the mid ViL (1.8e-2) read the same in
+    # EVERY mode, fp32_mfma included: their gradients are < 0.5 % of the norm and largely the mathematically-zero bias gradients
+    # behind InstanceNorms -- round-off in the oracle as much as here -- so families below 2 % of the norm are printed, not bounded.
+    bound = {"bf16": 0.15, "fp16": 0.06, "fp32_mfma": 5e-3}[mode]
+    assert l2 < bound, (mode, l2)
+    fam_bound = {"bf16": 0.9, "fp16": 0.1, "fp32_mfma": 1e-2}[mode]
+    assert all(e < fam_bound for _, _, e, share in rows if share > 0.02), rows
+
+
 def _mask_pair(x, ka, kb):
     """x (2, 4, ...) with the modalities outside subsets ka / kb zeroed in sample 0 / 1 (what instance_missing detects,
     RA_HVED.py:513-520)."""
@@ -722,6 +802,97 @@ def test_sliding_window_tiler_vs_oracle_windows(subset):
     assert (got_g - got).abs().max().item() < 1e-6          # hipGraph replay of the window forward: same kernels, same result
 
 
+def test_two_models_of_different_fp32_arithmetic_interleave_in_one_process():
+    """The arithmetic of fp32 storage is part of every call (xh_conv_desc.arith, round 6; it was process state behind
+    xh_set_option(18)): model A on the fp32 vector kernels and model B on the matrix cores through the two-term fp16 split, their
+    forwards and backwards INTERLEAVED in one process, each give what they give alone.  The process default (ops.set_fp32_mfma) is
+    set the wrong way round for A on purpose: the model's own `fp32_arith` wins; backward passes run outside any scope and take
+    the mode their Functions saved in forward (functional.Function)."""
+    torch.manual_seed(21)
+    x = torch.rand(1, 4, 64, 64, 64).to(DEV)
+    eps = [torch.randn(1, 2 ** l, 32 >> l, 32 >> l, 32 >> l) for l in range(4)]
+    scale = 65536.0
+    kernels = {}
+
+    def fwd(m):
+        seg, (mu, lv), rec = m(x, [14], recon=True, eps_list=eps)
+        loss = seg.float().mean() + rec[0].float().mean() + sum(a.float().mean() + b.float().mean() for a, b in zip(mu, lv))
+        return seg, rec[0], loss
+
+    def bwd(m, loss, tag):
+        (loss * scale).backward()
+        X.ops.join_wgrad_stream()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() / scale for k, p in m.named_parameters() if p.grad is not None}
+
+    def alone(mode):
+        m = _model(True)
+        m.fp32_arith = mode
+        seg, rec, loss = fwd(m)
+        return seg.detach().clone(), rec.detach().clone(), bwd(m, loss, mode)
+    sv, rv, gv = alone("vector")
+    ss, rs, gs = alone("split")
+    assert (sv - ss).abs().max().item() > 0, "the two modes launched the same kernels"
+    X.ops.set_fp32_mfma(True)                                   # process default = split: model A must still run 'vector'
+    try:
+        ma, mb = _model(True), _model(True)
+        ma.fp32_arith, mb.fp32_arith = "vector", "split"
+        sa, ra, la = fwd(ma)
+        sb, rb, lb = fwd(mb)
+        gb = bwd(mb, lb, "split")                               # B's backward first, then A's: neither sees the other's mode
+        ga = bwd(ma, la, "vector")
+    finally:
+        X.ops.set_fp32_mfma(False)
+    # forward: the same launches on the same data (statistics through fp64 atomics: equal to their summation order)
+    assert (sa - sv).abs().max().item() <= 1e-6 and (ra - rv).abs().max().item() <= 1e-5 * rv.abs().max().item()
+    assert (sb - ss).abs().max().item() <= 1e-6 and (rb - rs).abs().max().item() <= 1e-5 * rs.abs().max().item()
+    for got, want, tag in ((ga, gv, "vector"), (gb, gs, "split")):
+        sc = max(v.abs().max().item() for v in want.values())
+        worst = max((got[k] - want[k]).abs().max().item() / sc for k in want)
+        print(f"interleaved vs alone, {tag}: worst parameter-gradient difference {worst:.2e} of the largest gradient")
+        assert worst <= 2e-4, (tag, worst)
+    # and the interleaved runs differ from each other the way the modes do
+    assert (sa - sb).abs().max().item() > 0
+
+
+def test_window_graph_cache_is_per_model_bounded_and_follows_the_parameters():
+    """The kept window graphs (inference._window_graph): they live on the model, at most WINDOW_GRAPHS_MAX of them (LRU), and a graph
+    is captured again when the parameters have moved (model.half() / .to() replace the storage a captured forward reads): without
+    the fingerprint the replay would read freed memory and return garbage silently."""
+    import copy
+    from xlstm_hved_amd import inference as I
+    torch.manual_seed(3)
+    x = torch.rand(1, 4, 32, 32, 32).to(DEV)
+    m = _model(False)
+    kw = dict(patch_size=(32, 32, 32), overlap_stepsize=(32, 32, 32), use_graph=True)
+    eager = I.eval_overlap_volume(m, x, 14, patch_size=(32, 32, 32), overlap_stepsize=(32, 32, 32))
+    a = I.eval_overlap_volume(m, x, 14, **kw)
+    cache = m.__dict__["_xh_window_graphs"]
+    assert len(cache) == 1
+    g0 = next(iter(cache.values()))[1]
+    b = I.eval_overlap_volume(m, x, 14, **kw)
+    assert next(iter(cache.values()))[1] is g0 and torch.equal(a, b)          # second volume: the kept graph
+    for sub in (3, 7, 11):                                                     # more subsets than the bound: oldest entries go
+        I.eval_overlap_volume(m, x, sub, **kw)
+    assert len(cache) == I.WINDOW_GRAPHS_MAX[0] == 2
+    # the parameters move: same values at new addresses, then new values -- the replay must follow both
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.data = p_.data.clone()
+    c = I.eval_overlap_volume(m, x, 14, **kw)
+    assert (c - a).abs().max().item() < 1e-6
+    with torch.no_grad():
+        m.final_conv.bias.data = m.final_conv.bias.data.clone() + 0.5
+    d = I.eval_overlap_volume(m, x, 14, **kw)
+    e = I.eval_overlap_volume(m, x, 14, patch_size=(32, 32, 32), overlap_stepsize=(32, 32, 32))
+    assert (d - e).abs().max().item() < 1e-6 and (d - a).abs().max().item() > 1e-3
+    m2 = copy.deepcopy(m)                                                      # a copy starts without graphs
+    assert len(m2.__dict__["_xh_window_graphs"]) == 0
+    I.clear_window_graphs(m)
+    assert "_xh_window_graphs" not in m.__dict__
+    assert (eager - a).abs().max().item() < 1e-6
+
+
 def test_config5_full_volume_240x240x155_fp16_and_fp32():
     """BASELINE config 5 at full size on the test path: a 240 x 240 x 155 volume, 18 windows of 128^3 every 64 voxels
     (evaluation.py:279-384), posterior mean, hipGraph replay of the window forward.  fp32 storage: the corner block that only
@@ -961,8 +1132,11 @@ def test_latent_path_multi_launches_equal_the_per_level_nodes(dtype, size, n):
     """Fn.LatentPath (the latent path of the four fusion levels as one autograd node; its element-wise passes -- norm + activation
     inside the upsampling, the conv block's norm + activation, the activation-masked sums, both InstanceNorm backward passes, the
     upsampling adjoint -- as ONE multi-problem launch each, xh_*_multi) against the two ConvInLrelu nodes per level
-    (functional.set_latent_batch(False)).  The multi kernels run the per-problem kernel BODIES at the per-problem grids: forward
-    outputs must be bit-identical; parameter gradients agree to the order of the fp64 / fp32 atomics."""
+    (functional.set_latent_batch(False)).  The multi kernels run the per-problem kernel BODIES at the per-problem grids: the same
+    arithmetic per element; the epilogue statistics of the k = 1 convs are summed by direct fp64 atomics in the multi launch and
+    through the fan-in block in a qualifying single launch, so the sums -- and everything normalised with them -- agree to the
+    ORDER of fp64 additions (1e-6 relative; one 16-bit ulp where a value sits on a rounding boundary), not bit for bit.
+    Parameter gradients agree to the order of the fp64 / fp32 atomics (fp32), to the network's 16-bit gradient class (2e-2)."""
     torch.manual_seed(47)
     x = torch.rand(n, 4, size, size, size)
     eps = [torch.randn(n, 2 ** l, size >> (l + 1), size >> (l + 1), size >> (l + 1)) for l in range(4)]
@@ -984,9 +1158,13 @@ def test_latent_path_multi_launches_equal_the_per_level_nodes(dtype, size, n):
         finally:
             X.functional.set_latent_batch(True)
     (sa, ra, ga), (sb, rb, gb) = res
-    assert torch.equal(sa, sb) and torch.equal(ra, rb)
+    ulp = {torch.float32: 1e-6, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    for a_, b_ in ((sa, sb), (ra, rb)):
+        d_ = (a_.float() - b_.float()).abs()
+        assert d_.max().item() <= ulp * max(1.0, a_.float().abs().max().item())           # at most one rounding step apart ...
+        assert (d_ > 1e-6 * max(1.0, a_.float().abs().max().item())).float().mean().item() < 1e-4   # ... and almost nowhere
     assert ga.keys() == gb.keys()
     scale = max(v.abs().max().item() for v in ga.values())
     wk, worst = max(((k, (ga[k] - gb[k]).abs().max().item() / scale) for k in ga), key=lambda t: t[1])
     print(f"latent path, multi launches vs per-level nodes ({dtype}, {n}x{size}^3): worst parameter-gradient difference {worst:.2e} ({wk})")
-    assert worst <= (5e-5 if dtype == torch.float32 else 0.2), (wk, worst)
+    assert worst <= (5e-5 if dtype == torch.float32 else 2e-2), (wk, worst)

@@ -86,6 +86,24 @@ def test_bench_configuration_128_graph_replay_matches_eager():
     assert (a - c).abs().max().item() <= 5e-4 * scale, (a - c).abs().max().item() / scale
 
 
+def test_level_streams_under_graph_capture_match_the_default_path():
+    """ops.set_level_streams (the coarse latent-path chains on side streams) inside a captured step: the side-stream launches
+    become parallel branches of the graph, so they must not share the capture's statistics fan-in block with the origin
+    stream's launches (ops.fan_block hands the block to the capture's origin stream only; the others keep direct atomics).
+    128^3: the size at which launches are large enough to take the fan-in path at all."""
+    a = _grads("defer", True, size=128)
+    X.ops.set_level_streams(True)
+    try:
+        b = _grads("defer", True, size=128)
+        c = _grads("defer", False, size=128)
+    finally:
+        X.ops.set_level_streams(False)
+    assert torch.isfinite(b).all() and torch.isfinite(c).all()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 5e-4 * scale, (a - b).abs().max().item() / scale
+    assert (a - c).abs().max().item() <= 5e-4 * scale, (a - c).abs().max().item() / scale
+
+
 def _batch_vs_autograd(cases, k, stride, dtype, kernel):
     """Weight gradients of `cases` (N, Ca, Cb, Cout, groups, S, pre) through the deferred batch, against autograd's weight
     gradient of the same fp32 values and against the one-by-one path (xh_set_option(2, 512))."""

@@ -90,7 +90,7 @@ def test_library_exports_every_declared_symbol(X):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/xlstm_hved.h but not exported"
     assert set(names) == set(X._lib.SIGNATURES), set(names) ^ set(X._lib.SIGNATURES)
-    assert X._lib.load().xh_abi_version() == 1
+    assert X._lib.load().xh_abi_version() == 2
 
 
 def test_no_cpu_fallback(X):

@@ -301,3 +301,18 @@ def test_oracle_reproduces_the_reference_mask_at_128():
     got = (prob > 0.5).numpy()
     assert [int(got[0, c].sum()) for c in range(3)] == [int(v) for v in z["pos"]]
     assert int((got != ref).sum()) == 0
+
+
+def test_philox_reference_known_answers():
+    """oracle/philox_ref.py (the checker of the in-kernel reparameterisation noise) against the published known-answer vectors of
+    Philox4x32-10 (Random123 kat_vectors), and the mapping of (seed, draw, level, element) onto counter / key words."""
+    import philox_ref as P
+    for c, k, want in P.KAT:
+        got = P.philox4x32_10(np.array(c, dtype=np.uint32)[None], k)[0]
+        assert tuple(int(v) for v in got) == want
+    w = P.poe_noise_words(0xa4093822 | (0x299f31d0 << 32), 0x13198a2e | (0x03707344 << 32), 0x85, 1)
+    # element 0 of level 0x85: counter (0, 0x85 << 24, draw lo, draw hi), key (seed lo, seed hi)
+    ref = P.philox4x32_10(np.array([[0, 0x85000000, 0x13198a2e, 0x03707344]], dtype=np.uint32), (0xa4093822, 0x299f31d0))
+    assert (w == ref).all()
+    z = P.poe_noise(1234, 5, 2, 1 << 16)
+    assert abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.02

@@ -35,6 +35,18 @@ def load(d, counter):
     return acc
 
 
+def csrc_hash():
+    """sha1 over the kernel sources: tells whether a committed capture still describes the kernels of the tree it is read in."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xlstm-hved_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
+
 CALIBRATED = {}      # kernel-name prefix -> FETCH_SIZE factor where a kernel was calibrated otherwise (default 2.0)
 
 
@@ -44,6 +56,8 @@ def main():
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     out = {"dtype": dtype, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace",
            "corrections": "KiB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); includes Infinity-Cache hits",
+           "captured_date": __import__("datetime").datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "csrc_sha1": csrc_hash(),
+           "captured_commit": None,      # the GPU box has no .git: tools/stamp_profile.py fills this in when the file is committed
            "kernels": {}}
     for name in sorted(fe, key=lambda k: -fe[k][1]):
         if name not in wr or name.startswith("at::") or name.startswith("__amd"):

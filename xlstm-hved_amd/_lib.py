@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libxlstm_hved_hip.so")
 
 XH_F32, XH_BF16, XH_F16 = 0, 1, 2
+ARITH_F32_SPLIT, ARITH_K7_VECTOR = 1, 2      # xh_conv_desc.arith bits
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 
 c_fp = C.POINTER(C.c_float)
@@ -29,7 +30,7 @@ class ConvDesc(C.Structure):
         ("n_wptr", C.c_int), ("transposed", C.c_int), ("pre", C.c_int), ("pre_slope", C.c_float),
         ("act", C.c_int), ("act_slope", C.c_float), ("epi", C.c_int), ("Cea", C.c_int),
         ("ea_bs", ll), ("eb_bs", ll), ("e_slope", C.c_float),
-        ("px_bs", ll), ("pd_bs", ll),
+        ("px_bs", ll), ("pd_bs", ll), ("arith", C.c_int),
     ]
 
 
@@ -51,7 +52,8 @@ class AttenJob(C.Structure):       # == xh_atten_job
 
 class PoeJob(C.Structure):         # == xh_poe_job
     _fields_ = [("feat", vp), ("keep", vp), ("eps", vp), ("z", vp), ("mu_stack", vp), ("lv_stack", vp), ("dz", vp), ("dmu_stack", vp),
-                ("dlv_stack", vp), ("dfeat", vp), ("dhw", ll), ("N", C.c_int), ("L", C.c_int), ("mask_mu", C.c_int)]
+                ("dlv_stack", vp), ("dfeat", vp), ("dhw", ll), ("N", C.c_int), ("L", C.c_int), ("mask_mu", C.c_int),
+                ("rng_used", vp), ("rng_stream", C.c_int)]
 
 
 class DuseJob(C.Structure):        # == xh_duse_job
@@ -151,7 +153,8 @@ SIGNATURES = {
     "xh_act_bwd": (I, [vp, I, vp, vp, vp, ll, I]),
     "xh_poe_fwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
     "xh_poe_bwd": (I, [vp, I, vp, vp, vp, vp, vp, vp, vp, I, I, ll, I]),
-    "xh_poe_multi": (I, [vp, I, I, I, vp]),
+    "xh_poe_multi": (I, [vp, I, I, I, vp, vp]),
+    "xh_philox_normal": (I, [vp, C.c_ulonglong, C.c_ulonglong, I, vp, ll, I]),
     "xh_channel_pool_fwd": (I, [vp, I, vp, ll, vp, ll, I, I, ll]),
     "xh_channel_pool_bwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, I]),
     "xh_gate_fwd": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll]),

@@ -231,6 +231,15 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nb) { return (nb & 7) ? b 
 // name of the template instance the last conv launch used (bench.py's roofline object reports it; rocprof names agree)
 void xh_note_kernel(const char* fmt, ...);
 extern int g_xh_disable;     // xh_set_option(2, mask): bit 0 = no sliding-window depthwise kernel, bit 1 = no exact-2x upsample kernels
+// hipFuncSetAttribute (dynamic LDS above 64 KB) holds per DEVICE: a launch site remembers the devices it has set it on
+#define XH_MAX_DEV 64
+static inline bool xh_attr_needed(bool (&done)[XH_MAX_DEV]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= XH_MAX_DEV) return true;
+  if (done[dev]) return false;
+  done[dev] = true;
+  return true;
+}
 static inline int xh_launch_status() { return hipGetLastError() == hipSuccess ? XH_OK : XH_ERR_HIP; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -1621,10 +1621,8 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 17) { extern int g_q4_wgs; g_q4_wgs = value < 0 ? 0 : value; return XH_OK; }
   if (key == 20) { extern int g_q4_wide; g_q4_wide = value & 3; return XH_OK; }
   if (key == 19) { extern int g_q4_persist; g_q4_persist = value < 0 ? 0 : value; return XH_OK; }
-  if (key == 18) { extern int g_q4_f32; g_q4_f32 = value ? 1 : 0; return XH_OK; }
   if (key == 16) { extern int g_tiny_wgs; g_tiny_wgs = value < 1 ? 1 : value; return XH_OK; }
   if (key == 21) { extern int g_q5_on; g_q5_on = value ? 1 : 0; return XH_OK; }
-  if (key == 25) { extern int g_c7_as_f32off; g_c7_as_f32off = value ? 1 : 0; return XH_OK; }
   if (key == 27) { extern int g_row_wgs; if (value < 64 || value > (1 << 20)) return XH_ERR_ARG; g_row_wgs = value; return XH_OK; }
   if (key == 26) { extern int g_dwh_groups; if (value < 1 || value > 4096) return XH_ERR_ARG; g_dwh_groups = value; return XH_OK; }
   if (key == 24) { extern int g_c7_as; g_c7_as = value < 0 ? 0 : value > 3 ? 3 : value; return XH_OK; }
@@ -2385,4 +2383,4 @@ int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
 }
 
 int xh_check_conv(const xh_conv_desc* d, const xh_conv_ptrs* p) { return check_desc(d, p); }   // for the batch paths of other files
-extern "C" int xh_abi_version(void) { return 1; }
+extern "C" int xh_abi_version(void) { return 2; }

@@ -497,12 +497,11 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   }
 #define LM(F, C)                                                                                                \
   do {                                                                                                          \
-    static bool attr_done = false;                                                                              \
-    if (!attr_done) {                                                                                           \
+    static bool attr_done[XH_MAX_DEV] = {};                                                                              \
+    if (xh_attr_needed(attr_done)) {                                                                                           \
       (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<F, C, 256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
       (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<F, C, 512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
       (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<F, C, 512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-      attr_done = true;                                                                                         \
     }                                                                                                           \
     if (a.tw == 16) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 512, 16>), grid, dim3(512), shm, st, a);        \
     else if (a.th == 4) hipLaunchKernelGGL((conv3_mfma_kernel<F, C, 256, 32, 4>), grid, dim3(256), shm, st, a); \

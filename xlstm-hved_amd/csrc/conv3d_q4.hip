@@ -46,7 +46,6 @@
 #include "conv_q4.h"
 int g_q4_maxc = 48;               // xh_set_option(11, n): most channels per group the quad-channel kernel takes (<= 48)
 int g_q4_wgs = 512;               // xh_set_option(17, n): workgroup count below which a launch takes 4, then 2 output planes per workgroup (0: always 8)
-int g_q4_f32 = 0;                 // xh_set_option(18, 1): fp32 storage through the matrix cores with two-term fp16 operands (conv3d_q4s.hip)
 
 // two values of one channel -> leaky(x * sc + sh) in fp32 (packed fma / mul; leaky = max(v, slope * v) for 0 <= slope <= 1)
 template <int FMT> __device__ __forceinline__ f32x2_t q4_xf(unsigned u, float sc, float sh, float slope) {
@@ -437,7 +436,7 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   extern int g_xh_disable;
   if (g_xh_disable & 16) return false;
   const bool f32 = d->dtype == XH_F32;                 // fp32 storage: conv3d_q4s.hip (two-term fp16 operands), opt-in
-  if (f32 && !g_q4_f32) return false;
+  if (f32 && !(d->arith & XH_ARITH_F32_SPLIT)) return false;
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32) || d->k != 3 || d->stride != 1) return false;
   if (f32 && (d->pre == 2 || d->act != XH_ACT_NONE)) return false;
   if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;

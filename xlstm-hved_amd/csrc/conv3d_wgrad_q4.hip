@@ -572,8 +572,7 @@ __global__ __launch_bounds__(256, LDSX ? wq4_resident(FMT, CI4) : wq4_waves(CI4)
 bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgQ4* a) {
   extern int g_xh_disable;
   if (g_xh_disable & 32) return false;
-  extern int g_q4_f32;
-  const bool f32 = d->dtype == XH_F32 && g_q4_f32;     // fp32 storage, fp16 operands (xh_set_option(18, 1))
+  const bool f32 = d->dtype == XH_F32 && (d->arith & XH_ARITH_F32_SPLIT);     // fp32 storage, fp16 operands (xh_conv_desc.arith)
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32) || d->k != 3 || d->stride != 1 || d->transposed) return false;
   if (d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   if (d->W % 32 != 0 || d->Wo != d->W || d->Ho != d->H || d->Do != d->D) return false;

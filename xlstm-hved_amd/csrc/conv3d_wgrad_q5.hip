@@ -382,11 +382,10 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
     a.nb = a.nq * wq[i];
     m.off[i + 1] = m.off[i] + a.nb;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[XH_MAX_DEV] = {};
+  if (xh_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<4>::BYTES);
     (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<4>::BYTES);
-    attr_done = true;
   }
   int wmax = 32;
   for (int i = 0; i < n; ++i) wmax = probs[i].W > wmax ? probs[i].W : wmax;

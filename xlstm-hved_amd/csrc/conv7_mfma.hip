@@ -465,14 +465,13 @@ __global__ __launch_bounds__(128 * KSPLIT, BREG ? 2 : 4) void conv7_as_kernel(co
   }
 }
 
-int g_c7_as_f32off = 0;                                // xh_set_option(25, 1): fp32 storage keeps the fp32 vector kernel for the 7^3 convs
 int g_c7_as = 1;                                       // xh_set_option(24, v): 0 conv7_mfma_kernel, 1 conv7_as_kernel (weight fragments from LDS,
                                                        // two workgroups per CU) on volumes of >= 2^20 voxels, 2 the same with the weight
                                                        // fragments in registers, 3 conv7_as_kernel on every volume (tests)
 // returns XH_OK if launched, 1 if the shape is not eligible (caller falls back to the vector kernel)
 int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
-  extern int g_q4_f32;                               // fp32 storage with fp16 operands: xh_set_option(18, 1)
-  const bool f32s = d->dtype == XH_F32 && g_q4_f32 && !(g_c7_as_f32off);
+  // fp32 storage with operands rounded once to fp16: the call's arithmetic mode (xh_conv_desc.arith)
+  const bool f32s = d->dtype == XH_F32 && (d->arith & XH_ARITH_F32_SPLIT) && !(d->arith & XH_ARITH_K7_VECTOR);
   if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32s) || d->k != 7 || d->stride != 1 || d->groups != 1 || d->n_wptr != 1) return 1;
   if (!((d->Cin == 4 && d->Cout == 2) || (d->Cin == 2 && d->Cout == 4))) return 1;
   if (d->pre || d->epi || d->Ca != d->Cin) return 1;
@@ -507,14 +506,13 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   hipStream_t st = (hipStream_t)stream;
   const int f = f32s ? 2 : d->dtype == XH_F16 ? 1 : 0;
   if (as) {
-    static bool done_as = false;
-    if (!done_as) {
+    static bool done_as[XH_MAX_DEV] = {};
+    if (xh_attr_needed(done_as)) {
 #define C7ATTR(F, CI_, CO_)                                                                                                             \
   (void)hipFuncSetAttribute((const void*)conv7_as_kernel<F, CI_, CO_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);  \
   (void)hipFuncSetAttribute((const void*)conv7_as_kernel<F, CI_, CO_, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
       C7ATTR(0, 4, 2); C7ATTR(1, 4, 2); C7ATTR(0, 2, 4); C7ATTR(1, 2, 4); C7ATTR(2, 4, 2); C7ATTR(2, 2, 4);
 #undef C7ATTR
-      done_as = true;
     }
     const size_t part = (size_t)2 * 3 * 2 * 2 * 4 * 64 * sizeof(float);
     // measured at 128^3 (after the staging rewrite): forward (CI = 4) 42.9 us with the weight fragments in registers, 46.7 from the table,
@@ -539,11 +537,10 @@ int xh_conv7_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
   }
   if (d->Cin == 4) {
     const size_t shm = (size_t)8 * (2 * 8 + 6) * 40 * 8 + 8 * 8 * 4 * 2 * 16 + 3 * 2 * 2 * 4 * 64 * sizeof(float);
-    static bool done = false;
-    if (!done) {
+    static bool done[XH_MAX_DEV] = {};
+    if (xh_attr_needed(done)) {
       (void)hipFuncSetAttribute((const void*)conv7_mfma_kernel<0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       (void)hipFuncSetAttribute((const void*)conv7_mfma_kernel<1, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      done = true;
     }
     xh_note_kernel("conv7_mfma_kernel<%d, 4, 2>", f);
     if (f) hipLaunchKernelGGL((conv7_mfma_kernel<1, 4, 2>), grid, dim3(512), shm, st, a);

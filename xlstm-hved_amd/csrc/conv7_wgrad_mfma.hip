@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void conv7_wgrad_reduce_kernel(const float* pa
 }
 
 static bool wg7_eligible(const xh_conv_desc* d) {
-  extern int g_q4_f32;                               // fp32 storage with fp16 operands: xh_set_option(18, 1)
-  if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !(d->dtype == XH_F32 && g_q4_f32)) || d->k != 7 || d->stride != 1 || d->groups != 1 ||
+  const bool f32s = d->dtype == XH_F32 && (d->arith & XH_ARITH_F32_SPLIT) && !(d->arith & XH_ARITH_K7_VECTOR);   // xh_conv_desc.arith
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32s) || d->k != 7 || d->stride != 1 || d->groups != 1 ||
       d->n_wptr != 1)
     return false;
   if (d->Cin != 4 || d->Cout != 2 || d->pre || d->Ca != d->Cin || d->transposed) return false;

@@ -24,7 +24,7 @@ struct ConvQ4 {
   int abl;
 };
 extern int g_mfma_abl;
-extern int g_q4_maxc, g_q4_wgs, g_q4_f32;
+extern int g_q4_maxc, g_q4_wgs;
 
 namespace {
 constexpr int TW = 32, TH = 8, IH = TH + 2;

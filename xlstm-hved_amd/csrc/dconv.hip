@@ -1828,7 +1828,8 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
   // measured (tools/microbench_disc.py, ks = 4, bf16): 64 <- 128 @127^3 691 -> 451 us, 128 <- 256 @63^3 185 -> 178 us, 256 <- 512 @31^3
   // 97 -> 114 us (256 workgroups of 16 K slices each: the gather kernel's 64 x 64 tiles fill the chip better there)
   if (mode == 1 && stride == 2 && nc > 0 && (Cs % 32) == 0 && (Cn % 64) == 0 && !(g_dconv_cfg & 16384) &&
-      ((long long)Do * Ho * Wo >= 200000 || (g_dconv_cfg & 32768))) {
+      ((long long)Do * Ho * Wo >= 200000 || (g_dconv_cfg & 32768)) &&
+      (long long)Di * Hi * Wi * Cs * 2 < (1ll << 31)) {        // the kernel's source offsets and buffer resource are 32-bit bytes
     // the source-block kernel (dconv_dgrad_halo_kernel): tiles of 8 x 8 x 8 destination voxels per parity class
     a.ncls = nc;
     int t = 0;
@@ -1841,13 +1842,12 @@ extern "C" int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks
     dim3 grid(t, Cn / 64, N);
     a.xcd = ((t & 7) == 0 || grid.y * grid.z == 1) && !(g_dconv_cfg & 64);
     const size_t shm = 729 * 64 + 8 * 64 * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[XH_MAX_DEV] = {};
+    if (xh_attr_needed(attr_done)) {
       (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       (void)hipFuncSetAttribute((const void*)dconv_dgrad_halo_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      attr_done = true;
     }
     if (ks == 4 && nc == 8 && !(g_dconv_cfg & 524288)) {
       if (dtype == XH_F16) hipLaunchKernelGGL((dconv_dgrad_halo_kernel<1, true>), grid, dim3(512), shm, st, a);
@@ -1904,7 +1904,8 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, co
       return xh_launch_status();
     }
   }
-  if (stride == 2 && ks == 4 && (Cs % 64) == 0 && (Cn % 128) == 0 && !(g_dconv_cfg & 131072)) {   // source-block kernel
+  if (stride == 2 && ks == 4 && (Cs % 64) == 0 && (Cn % 128) == 0 && !(g_dconv_cfg & 131072) &&
+      (long long)Di * Hi * Wi * Cs * 2 < (1ll << 31) && (long long)Do * Ho * Wo * Cn * 2 < (1ll << 31)) {   // source-block kernel (32-bit byte offsets per sample)
     DWgHK k;
     k.x = (const u16*)x; k.dy = (const u16*)dy; k.dw = dwp;
     k.N = N; k.Di = Di; k.Hi = Hi; k.Wi = Wi; k.Do = Do; k.Ho = Ho; k.Wo = Wo; k.Cs = Cs; k.Cn = Cn;
@@ -1918,11 +1919,10 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, co
       if (nsplit > k.nblk) nsplit = k.nblk;
       k.nsplit = nsplit; k.ngroup = nsplit * tiles;
       const size_t shm = 2 * (64 * 256 + 160 * 128);
-      static bool attr_done = false;
-      if (!attr_done) {
+      static bool attr_done[XH_MAX_DEV] = {};
+      if (xh_attr_needed(attr_done)) {
         (void)hipFuncSetAttribute((const void*)dwgrad_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         (void)hipFuncSetAttribute((const void*)dwgrad_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_done = true;
       }
       if (dtype == XH_F16) hipLaunchKernelGGL((dwgrad_halo_kernel<1>), dim3(8 * k.ngroup), dim3(512), shm, st, k);
       else hipLaunchKernelGGL((dwgrad_halo_kernel<0>), dim3(8 * k.ngroup), dim3(512), shm, st, k);

@@ -1289,9 +1289,34 @@ extern "C" int xh_act_bwd(void* stream, int dtype, const void* dy, const void* y
 
 // ---------------------------------------------------------------------------------------- product of experts
 #define POE_EPS 1e-8f
+// Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device RNG): counter-based, so element i of draw c is a pure
+// function of (seed, c, stream, i) -- the backward pass regenerates the forward's noise instead of reading it from HBM.
+struct PhiloxKey { unsigned long long seed, ctr; int stream; };
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ void philox_block(const PhiloxKey& k, long long i, unsigned (&o)[4]) {
+  philox4x32_10((unsigned)i, (unsigned)((unsigned long long)i >> 32) | ((unsigned)k.stream << 24), (unsigned)k.ctr, (unsigned)(k.ctr >> 32),
+                (unsigned)k.seed, (unsigned)(k.seed >> 32), o);
+}
+// one standard normal per element (Box-Muller on two 24-bit uniforms in (0, 1): |eps| <= 5.8)
+__device__ __forceinline__ float philox_normal(const PhiloxKey& k, long long i) {
+  unsigned o[4];
+  philox_block(k, i, o);
+  const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.f / 16777216.f), u2 = ((float)(o[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
 template <typename T>
 __device__ __forceinline__ void poe_fwd_body(const T* feat, const float* keep, const T* eps, T* z, T* mu_stack, T* lv_stack, int L,
-                                             long long dhw, long long total, int mask_mu, int bx, int gdx) {
+                                             long long dhw, long long total, int mask_mu, int bx, int gdx, const PhiloxKey* rk = nullptr) {
   for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gdx * 256) {
     const long long p = i % dhw;
     const int l = (int)((i / dhw) % L);
@@ -1316,6 +1341,7 @@ __device__ __forceinline__ void poe_fwd_body(const T* feat, const float* keep, c
     const float pmu = musum / tsum;
     float out = pmu;
     if (eps) out = fmaf(ldf(eps, i), __expf(-0.5f * __logf(tsum)), pmu);
+    else if (rk) out = fmaf(philox_normal(*rk, i), __expf(-0.5f * __logf(tsum)), pmu);
     stf(z, i, out);
   }
 }
@@ -1327,7 +1353,7 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(const T* feat, const float
 template <typename T>
 __device__ __forceinline__ void poe_bwd_body(const T* feat, const float* keep, const T* eps, const T* dz, const T* dmu_stack,
                                              const T* dlv_stack, T* dfeat, int L, long long dhw, long long total, int mask_mu, int bx,
-                                             int gdx) {
+                                             int gdx, const PhiloxKey* rk = nullptr) {
   for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gdx * 256) {
     const long long p = i % dhw;
     const int l = (int)((i / dhw) % L);
@@ -1350,6 +1376,7 @@ __device__ __forceinline__ void poe_bwd_body(const T* feat, const float* keep, c
     const float g = ldf(dz, i);
     float dlvp = 0.f;
     if (eps) dlvp = g * ldf(eps, i) * 0.5f * __expf(-0.5f * __logf(tsum));
+    else if (rk) dlvp = g * philox_normal(*rk, i) * 0.5f * __expf(-0.5f * __logf(tsum));
     const float dtsum = -dlvp / tsum - g * pmu / tsum;
     const long long so = (((long long)n * 5) * L + l) * dhw + p;
 #pragma unroll
@@ -1377,6 +1404,7 @@ struct PoeMulti {
   int n, bwd;
   int off[XH_POE_MAX + 1];
   xh_poe_job j[XH_POE_MAX];
+  unsigned long long* rng;        // forward with in-kernel noise: {seed, counter, ticket, -}; else NULL
 };
 template <typename T>
 __global__ __launch_bounds__(256) void poe_multi_kernel(const PoeMulti m) {
@@ -1386,22 +1414,68 @@ __global__ __launch_bounds__(256) void poe_multi_kernel(const PoeMulti m) {
   const xh_poe_job& j = m.j[pi];
   const int bx = blockIdx.x - m.off[pi], gdx = m.off[pi + 1] - m.off[pi];
   const long long total = (long long)j.N * j.L * j.dhw;
-  if (!m.bwd) poe_fwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (T*)j.z, (T*)j.mu_stack, (T*)j.lv_stack, j.L, j.dhw, total, j.mask_mu, bx, gdx);
-  else poe_bwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (const T*)j.dz, (const T*)j.dmu_stack, (const T*)j.dlv_stack, (T*)j.dfeat, j.L, j.dhw, total, j.mask_mu, bx, gdx);
+  // in-kernel noise: forward reads the generator's counter (every workgroup, before it takes its ticket below -- the counter moves
+  // only after ALL tickets are taken); backward reads the word its forward left in rng_used
+  PhiloxKey rk;
+  const bool draw = !j.eps && j.rng_used && (m.bwd || m.rng);
+  if (m.rng) { rk.seed = m.rng[0]; rk.ctr = m.rng[1]; }
+  if (m.bwd && draw) { rk.seed = j.rng_used[1]; rk.ctr = j.rng_used[0]; }
+  rk.stream = j.rng_stream;
+  if (!m.bwd) poe_fwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (T*)j.z, (T*)j.mu_stack, (T*)j.lv_stack, j.L, j.dhw, total, j.mask_mu, bx, gdx, draw ? &rk : nullptr);
+  else poe_bwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (const T*)j.dz, (const T*)j.dmu_stack, (const T*)j.dlv_stack, (T*)j.dfeat, j.L, j.dhw, total, j.mask_mu, bx, gdx, draw ? &rk : nullptr);
+  if (m.rng) {                                                     // (uniform per launch)
+    __syncthreads();                                               // every lane of this workgroup has read the counter
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned long long t = atomicAdd(&m.rng[2], 1ull);
+      if (t == (unsigned long long)gridDim.x - 1) {                // the last workgroup: record the draw, advance the generator
+        for (int k = 0; k < m.n; ++k)
+          if (m.j[k].rng_used) {
+            unsigned long long* u = const_cast<unsigned long long*>(m.j[k].rng_used);
+            u[0] = rk.ctr; u[1] = rk.seed;
+          }
+        m.rng[1] = rk.ctr + 1;
+        m.rng[2] = 0;
+        __threadfence();
+      }
+    }
+  }
 }
-extern "C" int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_poe_job* jobs) {
+extern "C" int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_poe_job* jobs, unsigned long long* rng) {
   if (n <= 0 || n > XH_POE_MAX || !jobs) return XH_ERR_ARG;
+  if (bwd && rng) return XH_ERR_ARG;
   PoeMulti m;
   m.n = n; m.bwd = bwd ? 1 : 0; m.off[0] = 0;
+  m.rng = rng;
   for (int i = 0; i < n; ++i) {
     const xh_poe_job& j = jobs[i];
     if (!j.feat || !j.keep || j.N <= 0 || j.L <= 0 || j.dhw <= 0) return XH_ERR_ARG;
     if (bwd ? (!j.dz || !j.dfeat) : (!j.z || !j.mu_stack || !j.lv_stack)) return XH_ERR_ARG;
+    if (!bwd && !j.eps && j.rng_used && !rng) return XH_ERR_ARG;   // a drawing job needs the generator state
+    if (j.rng_stream < 0 || j.rng_stream > 255) return XH_ERR_ARG;
     m.j[i] = j;
     m.off[i + 1] = m.off[i] + flat_grid((long long)j.N * j.L * j.dhw);
   }
   for (int i = n; i < XH_POE_MAX; ++i) m.off[i + 1] = m.off[n];
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL(poe_multi_kernel<T>, dim3(m.off[n]), dim3(256), 0, (hipStream_t)stream, m););
+  return xh_launch_status();
+}
+__global__ __launch_bounds__(256) void philox_normal_kernel(PhiloxKey k, void* out, long long n, int raw) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    if (raw) {
+      unsigned o[4];
+      philox_block(k, i, o);
+      reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+      reinterpret_cast<float*>(out)[i] = philox_normal(k, i);
+    }
+  }
+}
+extern "C" int xh_philox_normal(void* stream, unsigned long long seed, unsigned long long counter, int rng_stream, void* out, long long n, int raw) {
+  if (!out || n <= 0 || rng_stream < 0 || rng_stream > 255) return XH_ERR_ARG;
+  PhiloxKey k;
+  k.seed = seed; k.ctr = counter; k.stream = rng_stream;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, k, out, n, raw);
   return xh_launch_status();
 }
 extern "C" int xh_poe_fwd(void* stream, int dtype, const void* feat, const float* keep, const void* eps, void* z,

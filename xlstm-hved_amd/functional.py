@@ -6,9 +6,39 @@ normalised activations.  Reference lines are cited at each stage."""
 import math
 
 import torch
-from torch.autograd import Function
 
 from . import ops
+
+
+class Function(torch.autograd.Function):
+    """torch.autograd.Function whose backward issues its launches in the fp32-storage ARITHMETIC MODE its forward ran in
+    (ops.ARITH: xh_conv_desc.arith of every conv call).  The mode belongs to the call, so a backward pass that autograd runs long
+    after the forward -- outside the model's arith_scope, possibly interleaved with another model's passes -- must carry it along."""
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        fwd, bwd = cls.__dict__.get("forward"), cls.__dict__.get("backward")
+        if fwd is not None:
+            f = fwd.__func__ if isinstance(fwd, staticmethod) else fwd
+
+            def forward(ctx, *a, **k):
+                ctx._xh_arith = ops.ARITH[0]
+                return f(ctx, *a, **k)
+            forward.__doc__ = f.__doc__
+            cls.forward = staticmethod(forward)
+        if bwd is not None:
+            b = bwd.__func__ if isinstance(bwd, staticmethod) else bwd
+
+            def backward(ctx, *g):
+                prev = ops.ARITH[0]
+                ops.ARITH[0] = getattr(ctx, "_xh_arith", None)
+                try:
+                    return b(ctx, *g)
+                finally:
+                    ops.ARITH[0] = prev
+            backward.__doc__ = b.__doc__
+            cls.backward = staticmethod(backward)
+
 from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, LEAK, MODE_BN_EVAL, MODE_BN_TRAIN, MODE_GN, MODE_IN)
 
 
@@ -661,13 +691,19 @@ class PoE(Function):
 class PoEAll(Function):
     """PoE of every latent level of a forward pass in ONE launch, and their backward in one (ops.poe_*_multi): the levels are
     independent functions of the encoder outputs (RA_HVED.py:573-597 runs them in the level loop).  apply(keep, Ls, mask_mu,
-    nlev, *feats, *epss) with epss entries None for the posterior mean; returns (z_0, mu_0, lv_0, z_1, ...)."""
+    nlev, *feats, *epss) with epss entries None for the posterior mean; returns (z_0, mu_0, lv_0, z_1, ...).
+    `PoEAll.rng_state` (set by the caller for one apply): the generator state of in-kernel noise -- levels with eps None then draw
+    eps in the kernel (ops.poe_fwd_multi) and the backward pass regenerates it from the two words the forward recorded."""
+    rng_state = None
 
     @staticmethod
     def forward(ctx, keep, Ls, mask_mu, nlev, *te):
         feats = [t.contiguous() for t in te[:nlev]]
         epss = list(te[nlev:])
-        outs = ops.poe_fwd_multi(feats, keep, epss, Ls, mask_mu)
+        state, PoEAll.rng_state = PoEAll.rng_state, None
+        used = torch.empty(2, dtype=torch.int64, device=keep.device) if state is not None else None
+        outs = ops.poe_fwd_multi(feats, keep, epss, Ls, mask_mu, rng=(state, used) if state is not None else None)
+        ctx.rng_used = used
         ctx.save_for_backward(keep, *feats, *[e for e in epss if e is not None])
         ctx.cfg = (tuple(Ls), mask_mu, nlev, [e is not None for e in epss])
         ctx.set_materialize_grads(False)
@@ -686,7 +722,7 @@ class PoEAll(Function):
             if dz is None:
                 dz = torch.zeros((feats[l].shape[0], Ls[l]) + tuple(feats[l].shape[2:]), dtype=feats[l].dtype, device=feats[l].device)
             dzs.append(c(dz)); dmus.append(c(g[3 * l + 1])); dlvs.append(c(g[3 * l + 2]))
-        dfeats = ops.poe_bwd_multi(feats, keep, epss, dzs, dmus, dlvs, Ls, mask_mu)
+        dfeats = ops.poe_bwd_multi(feats, keep, epss, dzs, dmus, dlvs, Ls, mask_mu, rng_used=ctx.rng_used)
         return (None, None, None, None, *dfeats, *([None] * nlev))
 
 

@@ -14,8 +14,6 @@ the volume and divided by the per-voxel window count.  Differences, all delibera
 The model call is `model(crop, subset_idx_list=[subset_idx], valid=valid)[0]` exactly like the reference, so anything with
 that signature works (the tests drive the tiler with a stub model on CPU).
 """
-import weakref
-
 import torch
 
 from .model import SUBSETS_MODALITIES
@@ -41,21 +39,56 @@ def window_list(shape, patch_size, overlap_stepsize):
 
 
 # Captured window forwards, kept between calls (a whole-volume pass is 18 replays of ~1.3 ms; capturing the graph again for every
-# volume cost as much as ten of them).  Keyed by the model object and everything the captured launches depend on; the graph reads
-# the parameters where they live, so weight updates between volumes are seen.  A change of the model's structure or mode (anything
-# that changes which kernels a forward launches) needs clear_window_graphs().
-_WINDOW_GRAPHS = {}
+# volume cost as much as ten of them).  A captured graph holds its static tensors and a private allocator pool -- at 128^3 the
+# whole forward's activations -- so the cache
+#   * lives ON the model (`model.__dict__["_xh_window_graphs"]`): it goes when the model goes, there is no process-wide table;
+#   * is a small LRU (WINDOW_GRAPHS_MAX entries, default 2: e.g. the fp16 and the fp32 graph of one evaluation): a 15-subset
+#     missing-modality evaluation re-captures per subset instead of holding 15 pools (set_window_graphs_max to trade memory for it);
+#   * is keyed by everything the captured launches depend on, INCLUDING where the parameters and buffers live: the graph reads
+#     them in place (weight updates between volumes are seen), so after model.half() / .to() / load_state_dict(assign=True) the
+#     recorded addresses are stale -- the fingerprint differs and the window is captured again.
+# A change of the model's structure (anything else that changes which kernels a forward launches) needs clear_window_graphs(model).
+WINDOW_GRAPHS_MAX = [2]
 
 
-def clear_window_graphs():
-    _WINDOW_GRAPHS.clear()
+def set_window_graphs_max(n):
+    WINDOW_GRAPHS_MAX[0] = max(1, int(n))
+
+
+class _GraphCache(dict):
+    """The per-model table; a copy or pickle of the model starts with an empty one (graphs are not copyable)."""
+
+    def __deepcopy__(self, memo):
+        return _GraphCache()
+
+    def __reduce__(self):
+        return (_GraphCache, ())
+
+
+def clear_window_graphs(model=None):
+    """Drops the captured window forwards of `model` (and their memory pools)."""
+    if model is not None:
+        model.__dict__.pop("_xh_window_graphs", None)
+
+
+def _fingerprint(model):
+    """Addresses and types of every parameter and buffer: what a captured forward has baked in."""
+    return tuple((t.data_ptr(), t.dtype) for t in list(model.parameters()) + list(model.buffers()))
 
 
 def _window_graph(model, subset_idx, batch_size, channels, patch_size, dtype, device):
-    key = (id(model), bool(model.training), int(subset_idx), int(batch_size), int(channels), tuple(patch_size), dtype, str(device))
-    hit = _WINDOW_GRAPHS.get(key)
-    if hit is not None and hit[0]() is model:            # (an id can be reused by a later object: the weak reference tells)
+    from . import ops
+    cache = model.__dict__.setdefault("_xh_window_graphs", _GraphCache())
+    key = (bool(model.training), int(subset_idx), int(batch_size), int(channels), tuple(patch_size), dtype, str(device),
+           ops.current_arith() if getattr(model, "fp32_arith", None) is None else model.fp32_arith, ops.MIXED[0])
+    fp = _fingerprint(model)
+    hit = cache.pop(key, None)
+    if hit is not None and hit[0] == fp:
+        cache[key] = hit                                 # most recently used last
         return hit[1:]
+    del hit                                              # (stale addresses: its pool is released before the new capture)
+    while len(cache) >= WINDOW_GRAPHS_MAX[0]:
+        cache.pop(next(iter(cache)))
     static_in = torch.zeros((batch_size, channels) + tuple(patch_size), dtype=dtype, device=device)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -65,7 +98,7 @@ def _window_graph(model, subset_idx, batch_size, channels, patch_size, dtype, de
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         static_out = model(static_in, subset_idx_list=[subset_idx], valid=True)[0]
-    _WINDOW_GRAPHS[key] = (weakref.ref(model), graph, static_in, static_out)
+    cache[key] = (fp, graph, static_in, static_out)
     return graph, static_in, static_out
 
 
@@ -75,7 +108,7 @@ def eval_overlap_volume(model, x, subset_idx=14, patch_size=(128, 128, 128), ove
     """x: (1, 4, D, H, W) on the model's device.  Returns the (1, num_classes, D, H, W) fp32 overlap-averaged
     probabilities (on every rank when world > 1).  `draw=None` uses the posterior mean (valid=True); an integer averages
     that many random draws per window (evaluation.py:286-291,339-349).  use_graph=True (device tensors, posterior mean
-    only) captures the window forward once into a hipGraph (kept for later volumes: clear_window_graphs()) and replays it per window batch: the eager forward is bound
+    only) captures the window forward once into a hipGraph (kept on the model for later volumes: clear_window_graphs(model)) and replays it per window batch: the eager forward is bound
     by ~300 host-side launches, the replay by the GPU."""
     if x.dim() != 5 or x.shape[0] != 1:
         raise ValueError("expected one volume shaped (1, C, D, H, W)")

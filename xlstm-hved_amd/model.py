@@ -240,6 +240,27 @@ class AbstractFusion3DUNet(nn.Module):
                                                     MVAE=MVAE, MVAE_reduction=MVAE_reduction, layer_order=layer_order)
 
     # ------------------------------------------------------------------------------------------------
+    def noise_state(self, device):
+        """The reparameterisation-noise generator of this model on `device`: int64[4] = {seed, draw counter, ticket, -} (xh_poe_multi).
+        Created on first use with a seed drawn from torch's default CPU generator (so torch.manual_seed governs it, as it governs
+        RA_HVED.py:744's normal_()); seed_noise() sets it explicitly (data parallel: base seed + rank)."""
+        states = self.__dict__.setdefault("_xh_rng", {})
+        key = str(device)
+        if key not in states:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the model's noise state must exist before a stream capture: run one eager forward first, or call "
+                                   "model.noise_state(device)")
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            states[key] = torch.tensor([seed, 0, 0, 0], dtype=torch.int64).to(device)
+        return states[key]
+
+    def seed_noise(self, seed, device=None):
+        """Restart the reparameterisation noise from (seed, draw 0).  In place: a captured graph keeps drawing from the same words."""
+        devs = [str(device)] if device is not None else list(self.__dict__.get("_xh_rng", {}))
+        for key in devs:
+            st = self.noise_state(torch.device(key))
+            st.copy_(torch.tensor([int(seed), 0, 0, 0], dtype=torch.int64))
+
     def _stream_weights(self, level, which):
         mods = [getattr(e.basic_module[0], which).conv for e in self.encoders[level]]
         return [m.weight for m in mods], [m.bias for m in mods]
@@ -270,7 +291,9 @@ class AbstractFusion3DUNet(nn.Module):
                 eps_list=None):
         """RA_HVED.py:510-648.  `eps_list` (optional, not in the reference signature) injects the reparameterisation
         noise per level for parity tests; by default it is drawn with torch.randn like RA_HVED.py:744."""
-        with self._bn_counters():
+        # `self.fp32_arith` (optional attribute: "split" | "vector" | None = the process default, ops.set_fp32_mfma): the arithmetic of
+        # fp32 storage for THIS model's calls -- forward here, backward through the Functions' saved mode (functional.Function)
+        with ops.arith_scope(getattr(self, "fp32_arith", None)), self._bn_counters():
             # composed first: ComposeAll is then the LAST node of the backward pass, so the weight gradients of the composed
             # tensors' convs can wait for the end-of-backward batch (functional._direct)
             pre = self._precompose(seg, x)
@@ -287,7 +310,7 @@ class AbstractFusion3DUNet(nn.Module):
         once and only PoE -> reparameterisation -> decoders run per call.  `calls` is a list of dicts with the per-call
         keyword arguments of forward() (subset_idx_list, instance_missing, drop, valid, eps_list).  Returns the list of
         forward() results.  BatchNorm buffers of the skip-return attention advance 4 steps per call, as they would."""
-        with self._bn_counters():
+        with ops.arith_scope(getattr(self, "fp32_arith", None)), self._bn_counters():
             pre = self._precompose(seg, x)                    # the composed weights are the same for every call
             outs = []
             try:
@@ -511,8 +534,14 @@ class AbstractFusion3DUNet(nn.Module):
             skip = skip.to(sdt) if skip is not None else None
         mu_list, logvar_list, feats = [], [], []
         noise = None
-        if not valid and eps_list is None:
-            # RA_HVED.py:744 draws N(0,1) noise per level; here ONE draw (in the storage type) serves the four levels
+        nlev = len(feat_list)
+        # RA_HVED.py:744 draws N(0,1) noise per level (fp32, `std.data.new(std.size()).normal_()`).  On the device the PoE kernel
+        # draws it itself: Philox4x32-10 keyed by (this model's seed, a device-resident draw counter the launch advances, level,
+        # element) -- fp32 whatever the storage type, no noise tensor, no generator launch, and a replayed hipGraph draws fresh
+        # noise every replay; the backward pass regenerates the same values (functional.PoEAll)
+        in_kernel = not valid and eps_list is None and x.is_cuda and nlev <= ops.POE_MAX
+        if not valid and eps_list is None and not in_kernel:
+            # (more levels than one launch takes / host tensors: ONE torch draw in the storage type serves the levels)
             shapes = [(n, self.MVAE_latents[l]) + tuple(f.shape[2:]) for l, f in enumerate(feat_list)]
             sizes = [int(torch.Size(s_).numel()) for s_ in shapes]
             flat = torch.randn(sum(sizes), device=x.device, dtype=sdt)
@@ -524,12 +553,13 @@ class AbstractFusion3DUNet(nn.Module):
         # coarse ones on side streams inside the captured graph was measured SLOWER (5.96 -> 6.93 ms per step, DESIGN.md
         # section 7) and the switch has been removed; they run back to back on the caller's stream.
         outs = [None] * len(feat_list)
-        nlev = len(feat_list)
         epss = [None] * nlev
-        if not valid:
+        if not valid and not in_kernel:
             epss = [noise[l] if noise is not None else eps_list[l].to(device=x.device, dtype=sdt).contiguous() for l in range(nlev)]
         # the PoE of all levels in one launch (they depend on the encoder outputs only)
         if nlev <= ops.POE_MAX:
+            if in_kernel:
+                Fn.PoEAll.rng_state = self.noise_state(x.device)
             zml = Fn.PoEAll.apply(keep, tuple(self.MVAE_latents[:nlev]), bool(instance_missing), nlev, *feat_list, *epss)
         else:
             zml = [t for l in range(nlev) for t in Fn.PoE.apply(feat_list[l], keep, epss[l], self.MVAE_latents[l], bool(instance_missing))]

@@ -70,18 +70,49 @@ def set_mfma(enabled):
     L.check(L.load().xh_set_option(0, int(bool(enabled))), "xh_set_option")
 
 
+# Arithmetic of fp32 STORAGE (xh_conv_desc.arith): part of every conv call, not library state.
+#   _FP32_MFMA[0]  the default of this process' Python side (set_fp32_mfma), used by calls made outside any scope;
+#   ARITH[0]       the mode of the calls being issued right now: None = the default, else an arith bit mask.  A model with a
+#                  `fp32_arith` attribute ("split" / "vector") runs its forward inside arith_scope(...), and every
+#                  functional.Function remembers the mode of its forward for its backward -- so two models of different modes can
+#                  interleave forwards and backwards in one process, and a captured graph keeps the mode it was captured with.
 _FP32_MFMA = [False]
+ARITH = [None]
+ARITH_NAMES = {None: None, "vector": 0, "split": L.ARITH_F32_SPLIT, "split_k7vector": L.ARITH_F32_SPLIT | L.ARITH_K7_VECTOR}
 
 
 def set_fp32_mfma(enabled):
-    """fp32 STORAGE through the quad-channel matrix-core kernels with two-term fp16 operands (xh_set_option(18): csrc/conv3d_q4s.hip
-    for k = 3 stride-1 convs and their data gradients, the 16-bit-operand weight-gradient kernel for their weight gradients)
-    instead of the fp32 vector kernels; default off.  ~22-bit products in the forward pass; in the backward pass the activation
-    gradients must sit in fp16's range: scale the loss as for fp16 storage (bench.py and TrainStep use 65536)."""
+    """Default arithmetic of fp32 STORAGE for calls outside an arith_scope: the quad-channel matrix-core kernels with two-term fp16
+    operands (xh_conv_desc.arith = XH_ARITH_F32_SPLIT: csrc/conv3d_q4s.hip for k = 3 stride-1 convs and their data gradients, the
+    16-bit-operand weight-gradient kernels, the 7^3 gate convs with operands rounded once to fp16) instead of the fp32 vector
+    kernels; default off.  ~22-bit products in the forward pass; in the backward pass the activation gradients must sit in
+    fp16's range: scale the loss as for fp16 storage (bench.py and TrainStep use 65536).  Python-side state only: the library
+    takes the mode with every call."""
     _FP32_MFMA[0] = bool(enabled)
-    L.check(L.load().xh_set_option(18, int(bool(enabled))), "xh_set_option")
-    _PACKS.clear()
-    _PACK_STATE["arrays"] = None
+
+
+def current_arith():
+    """The xh_conv_desc.arith value of a conv call issued now."""
+    a = ARITH[0]
+    return (L.ARITH_F32_SPLIT if _FP32_MFMA[0] else 0) if a is None else a
+
+
+class arith_scope:
+    """with arith_scope("split" | "vector" | "split_k7vector" | None | <int>): conv calls inside take that fp32-storage arithmetic
+    (None: leave whatever is current)."""
+
+    def __init__(self, mode):
+        self.mode = ARITH_NAMES[mode] if (mode is None or isinstance(mode, str)) else int(mode)
+
+    def __enter__(self):
+        self.prev = ARITH[0]
+        if self.mode is not None:
+            ARITH[0] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        ARITH[0] = self.prev
+        return False
 
 
 MIXED = [None]
@@ -215,12 +246,17 @@ def fan_block(device):
         nbytes = int(L.load().xh_fanin_bytes())
         per = _FAN[key] = {"bytes": nbytes, "streams": {}, "spares": [], "used": [], "cap": None, "in_capture": False}
     if capturing:
+        sid = torch.cuda.current_stream(device).cuda_stream
         if not per["in_capture"] or per["cap"] is None:
             per["in_capture"] = True
             per["cap"] = per["spares"].pop() if per["spares"] else None
+            per["cap_stream"] = sid
             if per["cap"] is not None:
                 per["used"].append(per["cap"])
-        if per["cap"] is None:
+        # The capture's block belongs to the stream the capture started on: launches captured on a side stream become parallel
+        # branches of the graph (set_level_streams) and could run next to the origin stream's statistics launches -- the block's
+        # contract is ONE launch in flight -- so they keep their direct atomics.
+        if per["cap"] is None or sid != per.get("cap_stream"):
             return None, 0
         return per["cap"].data_ptr(), per["bytes"]
     per["in_capture"] = False
@@ -274,8 +310,8 @@ def set_prepack(enabled):
 
 
 def _pack_entry(weights, desc, need, device):
-    key = (tuple(w.data_ptr() for w in weights), desc.dtype, desc.Cin, desc.Cout, desc.groups, desc.transposed, desc.D, desc.H,
-           desc.W, desc.n_wptr, need)
+    key = (tuple(w.data_ptr() for w in weights), desc.dtype, desc.arith, desc.Cin, desc.Cout, desc.groups, desc.transposed, desc.D,
+           desc.H, desc.W, desc.n_wptr, need)
     e = _PACKS.get(key)
     if e is not None and e.alive():
         return e
@@ -328,6 +364,7 @@ def _conv_desc(xa, xb, k, stride, groups, cout, n_w, transposed, pre, act, act_s
             raise ValueError("second conv source does not match the first")
     desc = L.ConvDesc()
     desc.dtype = _dt(xa)
+    desc.arith = current_arith()
     desc.N, desc.Cin, desc.Cout, desc.groups = n, ca + cb, cout, groups
     desc.D, desc.H, desc.W = d, h, w
     desc.Do, desc.Ho, desc.Wo = out_sp
@@ -541,6 +578,7 @@ def conv3d_dgrad_s2(dy, weights, *, cin, in_spatial, groups=1, e=None, red=None)
     out = new_like(dy, (n, cin, d, h, w))
     desc = L.ConvDesc()
     desc.dtype = _dt(dy)
+    desc.arith = current_arith()
     desc.N, desc.Cin, desc.Cout, desc.groups = n, cin, cout, groups
     desc.D, desc.H, desc.W, desc.Do, desc.Ho, desc.Wo = d, h, w, do, ho, wo
     desc.k, desc.stride, desc.Ca = 3, 2, cout
@@ -596,8 +634,9 @@ def _flush_wgrads():
     st.wait_stream(torch.cuda.current_stream(dev))          # every dY / input of the batch has been issued by now
     _WG["forked"].add(dev)
     with torch.cuda.stream(st):
-        for xa, xb, dy, dws, dbs, kw in pend:
-            conv3d_wgrad(xa, xb, dy, dws, dbs, side=False, **kw)
+        for xa, xb, dy, dws, dbs, kw, ar in pend:
+            with arith_scope(ar):                            # the mode of the backward that queued the call
+                conv3d_wgrad(xa, xb, dy, dws, dbs, side=False, **kw)
     _WG["keep"].extend(pend)                                 # alive until the join: the allocator must not recycle them
     _WG["pending"] = []
 
@@ -654,7 +693,7 @@ def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=
         _WG["maxvol"] = max(_WG["maxvol"], vol)
         return
     if side and _WG["on"] and xa.is_cuda:
-        _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre)))
+        _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre), current_arith()))
         if len(_WG["pending"]) >= _WG["batch"]:
             _flush_wgrads()
         return
@@ -1116,34 +1155,57 @@ def poe_bwd(feat, keep, eps, dz, dmu, dlv, L_, mask_mu):
 POE_MAX = 8
 
 
-def poe_fwd_multi(feats, keep, epss, Ls, mask_mu):
-    """poe_fwd for several latent levels in one launch (xh_poe_multi); returns [(z, mu, lv)] per level."""
+def _rng_words(t, n, what):
+    if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+        raise ValueError(f"{what}: {n} contiguous int64 device words")
+    return t
+
+
+def poe_fwd_multi(feats, keep, epss, Ls, mask_mu, rng=None):
+    """poe_fwd for several latent levels in one launch (xh_poe_multi); returns [(z, mu, lv)] per level.
+    rng = (state, used): the levels whose eps is None draw their noise IN the kernel (Philox4x32-10, fp32) from the generator
+    `state` (int64[4] device tensor: seed, counter, ticket, -; the launch advances the counter) and leave {counter, seed} of the
+    draw in `used` (int64[2]) for poe_bwd_multi.  Without rng, eps None means the posterior mean."""
     jobs = (L.PoeJob * len(feats))()
     outs, keepalive = [], []
-    for j, feat, eps, L_ in zip(jobs, feats, epss, Ls):
+    for lvl, (j, feat, eps, L_) in enumerate(zip(jobs, feats, epss, Ls)):
         n, c, d, h, w, _ = _vol(feat)
         z = new_like(feat, (n, L_, d, h, w))
         mu = new_like(feat, (n, 5, L_, d, h, w))
         lv = new_like(feat, (n, 5, L_, d, h, w))
         j.feat, j.keep, j.eps, j.z, j.mu_stack, j.lv_stack = _p(feat), _p(keep), _p(eps), _p(z), _p(mu), _p(lv)
         j.dhw, j.N, j.L, j.mask_mu = d * h * w, n, L_, int(mask_mu)
+        if rng is not None and eps is None:
+            j.rng_used, j.rng_stream = _p(_rng_words(rng[1], 2, "rng used")), lvl
         outs.append((z, mu, lv))
-    L.check(L.load().xh_poe_multi(_stream(), _dt(feats[0]), 0, len(feats), C.cast(jobs, C.c_void_p)), "xh_poe_multi")
+    state = _p(_rng_words(rng[0], 4, "rng state")) if rng is not None else None
+    L.check(L.load().xh_poe_multi(_stream(), _dt(feats[0]), 0, len(feats), C.cast(jobs, C.c_void_p), state), "xh_poe_multi")
     return outs
 
 
-def poe_bwd_multi(feats, keep, epss, dzs, dmus, dlvs, Ls, mask_mu):
-    """poe_bwd for several latent levels in one launch; returns [dfeat] per level."""
+def poe_bwd_multi(feats, keep, epss, dzs, dmus, dlvs, Ls, mask_mu, rng_used=None):
+    """poe_bwd for several latent levels in one launch; returns [dfeat] per level.  rng_used: the `used` words of the forward
+    (levels with eps None regenerate their noise from them)."""
     jobs = (L.PoeJob * len(feats))()
     outs = []
-    for j, feat, eps, dz, dmu, dlv, L_ in zip(jobs, feats, epss, dzs, dmus, dlvs, Ls):
+    for lvl, (j, feat, eps, dz, dmu, dlv, L_) in enumerate(zip(jobs, feats, epss, dzs, dmus, dlvs, Ls)):
         n, c, d, h, w, _ = _vol(feat)
         dfeat = torch.empty_like(feat)
         j.feat, j.keep, j.eps, j.dz, j.dmu_stack, j.dlv_stack, j.dfeat = _p(feat), _p(keep), _p(eps), _p(dz), _p(dmu), _p(dlv), _p(dfeat)
         j.dhw, j.N, j.L, j.mask_mu = d * h * w, n, L_, int(mask_mu)
+        if rng_used is not None and eps is None:
+            j.rng_used, j.rng_stream = _p(_rng_words(rng_used, 2, "rng used")), lvl
         outs.append(dfeat)
-    L.check(L.load().xh_poe_multi(_stream(), _dt(feats[0]), 1, len(feats), C.cast(jobs, C.c_void_p)), "xh_poe_multi")
+    L.check(L.load().xh_poe_multi(_stream(), _dt(feats[0]), 1, len(feats), C.cast(jobs, C.c_void_p), None), "xh_poe_multi")
     return outs
+
+
+def philox_normal(seed, counter, stream, n, device, raw=False):
+    """The noise xh_poe_multi draws for (seed, counter, level = stream): n fp32 normals, or (n, 4) raw Philox words (int32 bits)."""
+    out = torch.empty((n, 4), dtype=torch.int32, device=device) if raw else torch.empty(n, dtype=torch.float32, device=device)
+    L.check(L.load().xh_philox_normal(_stream(), int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1), int(stream), _p(out), n, int(raw)),
+            "xh_philox_normal")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- attention glue
