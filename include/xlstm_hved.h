@@ -388,6 +388,8 @@ int xh_poe_bwd(void* stream, int dtype, const void* feat, const float* keep, con
  * xh_poe_fwd (bwd = 0: feat, keep, eps, z, mu_stack, lv_stack) / xh_poe_bwd (bwd = 1: + dz, dmu_stack, dlv_stack, dfeat) take for
  * level i.  Job array in host memory, read during the call. */
 #define XH_POE_MAX 8
+#define XH_RNG_LINES 32
+#define XH_RNG_WORDS (16 * (2 + XH_RNG_LINES))
 typedef struct {
   const void* feat; const float* keep; const void* eps;
   void *z, *mu_stack, *lv_stack;
@@ -400,9 +402,10 @@ typedef struct {
    * regenerates the same eps.  See xh_poe_multi for who writes them. */
   const unsigned long long* rng_used; int rng_stream;
 } xh_poe_job;
-/* rng (optional, forward only; required when a job has rng_used and no eps): the caller's generator state, FOUR 64-bit device
- * words {seed, counter, ticket, reserved}, ticket zero on entry.  Every workgroup of the launch reads `counter` when it starts;
- * the last workgroup to finish copies {counter, seed} into every job's rng_used words, advances `counter` by one and leaves `ticket` zero -- so
+/* rng (optional, forward only; required when a job has rng_used and no eps): the caller's generator state, XH_RNG_WORDS 64-bit
+ * device words: {seed, counter, 14 unused, then 1 + XH_RNG_LINES ticket words on cache lines of their own}, all but the first two
+ * zero on entry.  Every workgroup of the launch reads `counter` when it starts and takes a ticket when it is done;
+ * the last workgroup to finish copies {counter, seed} into every job's rng_used words, advances `counter` by one and leaves the ticket words zero -- so
  * each launch (each replay of a captured graph included) draws fresh noise with no host involvement, and launches ordered on a
  * stream may share one state.  In a backward call rng is NULL: the jobs' rng_used words already hold their forward's counter and seed. */
 int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_poe_job* jobs, unsigned long long* rng);

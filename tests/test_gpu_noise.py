@@ -59,11 +59,12 @@ def test_poe_draws_exactly_that_noise_and_backward_regenerates_it(dtype):
     keep = torch.tensor([[1.0, 0.0, 1.0, 1.0], [1.0, 1.0, 1.0, 0.0]], device=DEV)
     Ls = [L_ for L_, _ in shapes]
     seed = 0x1234567887654321
-    state = torch.tensor([seed, 41, 0, 0], dtype=torch.int64).to(DEV)
+    state = X.ops.rng_state(seed, DEV)
+    state[1] = 41
     used = torch.zeros(2, dtype=torch.int64, device=DEV)
     got = X.ops.poe_fwd_multi(feats, keep, [None] * 4, Ls, False, rng=(state, used))
     torch.cuda.synchronize()
-    assert state.tolist() == [seed, 42, 0, 0] and used.tolist() == [41, seed]
+    assert state[:2].tolist() == [seed, 42] and int(state[2:].abs().sum()) == 0 and used.tolist() == [41, seed]
     epss = [X.ops.philox_normal(seed, 41, l, n * L_ * int(np.prod(sp)), DEV).view((n, L_) + sp) for l, (L_, sp) in enumerate(shapes)]
     want = X.ops.poe_fwd_multi(feats, keep, [e.to(dtype) for e in epss], Ls, False)
     tol = {torch.float32: 0.0, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
@@ -101,11 +102,11 @@ def test_model_noise_is_seeded_advances_per_forward_and_per_graph_replay():
     st = m.noise_state(torch.device(DEV, torch.cuda.current_device()))
     m.seed_noise(77)
     torch.cuda.synchronize()
-    assert st.tolist() == [77, 0, 0, 0]
+    assert st[:2].tolist() == [77, 0] and int(st[2:].abs().sum()) == 0
     seg0, (mu0, lv0), rec0 = m(x, [14], recon=True)
     seg1, _, _ = m(x, [14], recon=True)
     torch.cuda.synchronize()
-    assert st.tolist() == [77, 2, 0, 0] and (seg0 - seg1).abs().max().item() > 1e-4
+    assert st[:2].tolist() == [77, 2] and int(st[2:].abs().sum()) == 0 and (seg0 - seg1).abs().max().item() > 1e-4
     m.seed_noise(77)
     seg0b, _, _ = m(x, [14], recon=True)
     assert (seg0 - seg0b).abs().max().item() <= 1e-6               # same seed, same draw: the same forward (to the order of the fp64 statistics atomics)
@@ -143,7 +144,7 @@ def test_model_noise_is_seeded_advances_per_forward_and_per_graph_replay():
         g.replay()
         outs.append(out.clone())
     torch.cuda.synchronize()
-    assert st.tolist()[1] == c0 + 3 and st.tolist()[2] == 0
+    assert st.tolist()[1] == c0 + 3 and int(st[2:].abs().sum()) == 0
     assert (outs[0] - outs[1]).abs().max().item() > 1e-4 and (outs[1] - outs[2]).abs().max().item() > 1e-4
     with torch.no_grad():
         eps_r = [X.ops.philox_normal(5, c0 + 2, l, e.numel(), DEV).view(e.shape) for l, e in enumerate(eps)]

@@ -49,7 +49,9 @@ for k, v in list(vars(ops).items()):
 
 torch.manual_seed(1)
 m = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS); m.apply(X.init_weights); m = m.cuda().train()
-x = torch.rand(1, 4, S, S, S, device="cuda").bfloat16()
+MODE = os.environ.get("XH_TRACE_MODE", "bf16")          # bf16 | fp16 | fp32 | fp32_mfma
+x = torch.rand(1, 4, S, S, S, device="cuda").to({"bf16": torch.bfloat16, "fp16": torch.float16}.get(MODE, torch.float32))
+ops.set_fp32_mfma(MODE == "fp32_mfma")
 grads = X.parallel.FlatGrads(list(m.parameters()))
 ops.set_wgrad_defer(True)
 for it in range(2):

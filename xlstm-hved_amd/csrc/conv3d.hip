@@ -69,7 +69,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long
   constexpr bool WIDE = NV == VWT<T>::v;
   const bool vec = ALIGNED || ((NV == 4 || WIDE) && valid == NV && ((odhw | sp) % NV) == 0);
   if (ALIGNED) valid = NV;
-  const int epi = MODE >= 0 ? MODE : a.d.epi;
+  const int epi = MODE == 3 ? 0 : MODE >= 0 ? MODE : a.d.epi;       // MODE 3: sigmoid (stored threshold-exact, common.h), no epilogue
   float ev[NV];
   float esc = 0.f, esh = 0.f;
   if (epi == 1) {
@@ -90,7 +90,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, int n, int c, long
   float t0 = 0.f, t1 = 0.f;       // this run in fp32; the lane's running sums are fp64 (statistics precision, common.h)
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    float o = MODE >= 0 ? val[v] + bias : apply_act_as(yp, val[v] + bias, a.d.act, a.d.act_slope);
+    float o = MODE == 3 ? apply_act_as(yp, val[v] + bias, XH_ACT_SIGMOID, 0.f)
+                        : MODE >= 0 ? val[v] + bias : apply_act_as(yp, val[v] + bias, a.d.act, a.d.act_slope);
     if (v < valid) {
       if (epi == 1) {
         o = rnd_as(yp, o * ((ev[v] * esc + esh) > 0.f ? 1.f : a.d.e_slope));
@@ -561,7 +562,7 @@ __device__ __forceinline__ void conv1x1_body(const uint3 blockIdx, const uint3 g
       }
     }
   }
-  if (MODE >= 0 ? MODE != 0 : a.d.epi != 0) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
+  if (MODE >= 0 ? (MODE == 1 || MODE == 2) : a.d.epi != 0) conv_reduce_out<COB>(a, n, g, cob, s0, s1, s_red);
 }
 template <typename T, int COB, bool VEC, int CIC = 4, int MODE = -1>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const ConvK a) {
@@ -1363,7 +1364,8 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     constexpr int VW1 = VWT<T>::v;
     const bool vec = (dhw % VW1 == 0) && (d->xa_bs % VW1 == 0) && (d->xb_bs % VW1 == 0) && (d->y_bs % VW1 == 0) &&
                      (d->epi != 1 || (d->ea_bs % VW1 == 0 && d->eb_bs % VW1 == 0));
-    const int mode = d->act == XH_ACT_NONE ? d->epi : -1;   // compile-time epilogue for the common no-activation launches
+    // compile-time epilogue for the common launches: no activation (mode = epi), or the sigmoid head (mode 3)
+    const int mode = d->act == XH_ACT_NONE ? d->epi : (d->act == XH_ACT_SIGMOID && d->epi == 0) ? 3 : -1;
     long long gx1 = (dhw + 256 * VW1 - 1) / (256 * VW1);
     // few lanes (the deep levels): the run time is the per-lane chain of Cin/CIC dependent load steps, so take narrow
     // output blocks (more workgroups) with 16 channels in flight per step
@@ -1392,6 +1394,7 @@ static int conv_fwd_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
     else if (mode == 0) L1M(COB, 0);                                                                             \
     else if (mode == 1) L1M(COB, 1);                                                                             \
     else if (mode == 2) L1M(COB, 2);                                                                             \
+    else if (mode == 3) L1M(COB, 3);                                                                             \
     else L1M(COB, -1);                                                                                           \
   } while (0)
     switch (cob) { case 1: L1(1); break; case 2: L1(2); break; case 4: L1(4); break; default: L1(8); }

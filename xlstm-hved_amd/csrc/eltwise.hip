@@ -1312,11 +1312,13 @@ __device__ __forceinline__ float philox_normal(const PhiloxKey& k, long long i) 
   unsigned o[4];
   philox_block(k, i, o);
   const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.f / 16777216.f), u2 = ((float)(o[1] >> 8) + 0.5f) * (1.f / 16777216.f);
-  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+  // v_log_f32 (log2) and v_cos_f32 (argument in revolutions: cos(2 pi u2) is one instruction) instead of the library's logf / cosf,
+  // whose argument reduction made the PoE launches 10 us longer than the pass they replace a noise tensor in
+  return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
 template <typename T>
 __device__ __forceinline__ void poe_fwd_body(const T* feat, const float* keep, const T* eps, T* z, T* mu_stack, T* lv_stack, int L,
-                                             long long dhw, long long total, int mask_mu, int bx, int gdx, const PhiloxKey* rk = nullptr) {
+                                             long long dhw, long long total, int mask_mu, int bx, int gdx, bool draw = false, PhiloxKey rk = PhiloxKey{0, 0, 0}) {
   for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gdx * 256) {
     const long long p = i % dhw;
     const int l = (int)((i / dhw) % L);
@@ -1341,7 +1343,7 @@ __device__ __forceinline__ void poe_fwd_body(const T* feat, const float* keep, c
     const float pmu = musum / tsum;
     float out = pmu;
     if (eps) out = fmaf(ldf(eps, i), __expf(-0.5f * __logf(tsum)), pmu);
-    else if (rk) out = fmaf(philox_normal(*rk, i), __expf(-0.5f * __logf(tsum)), pmu);
+    else if (draw) out = fmaf(philox_normal(rk, i), __expf(-0.5f * __logf(tsum)), pmu);
     stf(z, i, out);
   }
 }
@@ -1353,7 +1355,7 @@ __global__ __launch_bounds__(256) void poe_fwd_kernel(const T* feat, const float
 template <typename T>
 __device__ __forceinline__ void poe_bwd_body(const T* feat, const float* keep, const T* eps, const T* dz, const T* dmu_stack,
                                              const T* dlv_stack, T* dfeat, int L, long long dhw, long long total, int mask_mu, int bx,
-                                             int gdx, const PhiloxKey* rk = nullptr) {
+                                             int gdx, bool draw = false, PhiloxKey rk = PhiloxKey{0, 0, 0}) {
   for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gdx * 256) {
     const long long p = i % dhw;
     const int l = (int)((i / dhw) % L);
@@ -1376,7 +1378,7 @@ __device__ __forceinline__ void poe_bwd_body(const T* feat, const float* keep, c
     const float g = ldf(dz, i);
     float dlvp = 0.f;
     if (eps) dlvp = g * ldf(eps, i) * 0.5f * __expf(-0.5f * __logf(tsum));
-    else if (rk) dlvp = g * philox_normal(*rk, i) * 0.5f * __expf(-0.5f * __logf(tsum));
+    else if (draw) dlvp = g * philox_normal(rk, i) * 0.5f * __expf(-0.5f * __logf(tsum));
     const float dtsum = -dlvp / tsum - g * pmu / tsum;
     const long long so = (((long long)n * 5) * L + l) * dhw + p;
 #pragma unroll
@@ -1416,27 +1418,36 @@ __global__ __launch_bounds__(256) void poe_multi_kernel(const PoeMulti m) {
   const long long total = (long long)j.N * j.L * j.dhw;
   // in-kernel noise: forward reads the generator's counter (every workgroup, before it takes its ticket below -- the counter moves
   // only after ALL tickets are taken); backward reads the word its forward left in rng_used
-  PhiloxKey rk;
+  PhiloxKey rk = {0ull, 0ull, 0};
   const bool draw = !j.eps && j.rng_used && (m.bwd || m.rng);
   if (m.rng) { rk.seed = m.rng[0]; rk.ctr = m.rng[1]; }
   if (m.bwd && draw) { rk.seed = j.rng_used[1]; rk.ctr = j.rng_used[0]; }
   rk.stream = j.rng_stream;
-  if (!m.bwd) poe_fwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (T*)j.z, (T*)j.mu_stack, (T*)j.lv_stack, j.L, j.dhw, total, j.mask_mu, bx, gdx, draw ? &rk : nullptr);
-  else poe_bwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (const T*)j.dz, (const T*)j.dmu_stack, (const T*)j.dlv_stack, (T*)j.dfeat, j.L, j.dhw, total, j.mask_mu, bx, gdx, draw ? &rk : nullptr);
+  if (!m.bwd) poe_fwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (T*)j.z, (T*)j.mu_stack, (T*)j.lv_stack, j.L, j.dhw, total, j.mask_mu, bx, gdx, draw, rk);
+  else poe_bwd_body<T>((const T*)j.feat, j.keep, (const T*)j.eps, (const T*)j.dz, (const T*)j.dmu_stack, (const T*)j.dlv_stack, (T*)j.dfeat, j.L, j.dhw, total, j.mask_mu, bx, gdx, draw, rk);
   if (m.rng) {                                                     // (uniform per launch)
-    __syncthreads();                                               // every lane of this workgroup has read the counter
+    // No fences: the ticket only has to come after this workgroup's READS of the counter, and those have completed -- their values
+    // went into the stores above (the barrier collects the lanes); the words written below are read by LATER launches only.
+    __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence();
-      const unsigned long long t = atomicAdd(&m.rng[2], 1ull);
-      if (t == (unsigned long long)gridDim.x - 1) {                // the last workgroup: record the draw, advance the generator
+      // two-level ticket: 32 first-level words on cache lines of their own (1 360 tickets on ONE word serialise at the memory side:
+      // +16 us on this launch), the workgroup that completes a word takes a second-level ticket; the last of those is the last
+      // workgroup of the launch.  Words are left zero for the next launch.
+      const unsigned G = gridDim.x, nl = G < XH_RNG_LINES ? G : XH_RNG_LINES, l = blockIdx.x % XH_RNG_LINES;
+      unsigned long long* w1 = m.rng + 16 * (2 + l);
+      unsigned long long* w2 = m.rng + 16;
+      bool last = false;
+      if (atomicAdd(w1, 1ull) == (unsigned long long)((G - l + XH_RNG_LINES - 1) / XH_RNG_LINES) - 1) {
+        *w1 = 0;
+        if (atomicAdd(w2, 1ull) == (unsigned long long)nl - 1) { *w2 = 0; last = true; }
+      }
+      if (last) {                                                  // the last workgroup: record the draw, advance the generator
         for (int k = 0; k < m.n; ++k)
           if (m.j[k].rng_used) {
             unsigned long long* u = const_cast<unsigned long long*>(m.j[k].rng_used);
             u[0] = rk.ctr; u[1] = rk.seed;
           }
         m.rng[1] = rk.ctr + 1;
-        m.rng[2] = 0;
-        __threadfence();
       }
     }
   }
@@ -1454,7 +1465,8 @@ extern "C" int xh_poe_multi(void* stream, int dtype, int bwd, int n, const xh_po
     if (!bwd && !j.eps && j.rng_used && !rng) return XH_ERR_ARG;   // a drawing job needs the generator state
     if (j.rng_stream < 0 || j.rng_stream > 255) return XH_ERR_ARG;
     m.j[i] = j;
-    m.off[i + 1] = m.off[i] + flat_grid((long long)j.N * j.L * j.dhw);
+    int nb = flat_grid((long long)j.N * j.L * j.dhw);
+    m.off[i + 1] = m.off[i] + nb;
   }
   for (int i = n; i < XH_POE_MAX; ++i) m.off[i + 1] = m.off[n];
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL(poe_multi_kernel<T>, dim3(m.off[n]), dim3(256), 0, (hipStream_t)stream, m););

@@ -241,7 +241,7 @@ class AbstractFusion3DUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def noise_state(self, device):
-        """The reparameterisation-noise generator of this model on `device`: int64[4] = {seed, draw counter, ticket, -} (xh_poe_multi).
+        """The reparameterisation-noise generator of this model on `device`: ops.rng_state = {seed, draw counter, ticket words} (xh_poe_multi).
         Created on first use with a seed drawn from torch's default CPU generator (so torch.manual_seed governs it, as it governs
         RA_HVED.py:744's normal_()); seed_noise() sets it explicitly (data parallel: base seed + rank)."""
         states = self.__dict__.setdefault("_xh_rng", {})
@@ -251,7 +251,7 @@ class AbstractFusion3DUNet(nn.Module):
                 raise RuntimeError("the model's noise state must exist before a stream capture: run one eager forward first, or call "
                                    "model.noise_state(device)")
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            states[key] = torch.tensor([seed, 0, 0, 0], dtype=torch.int64).to(device)
+            states[key] = ops.rng_state(seed, device)
         return states[key]
 
     def seed_noise(self, seed, device=None):
@@ -259,7 +259,7 @@ class AbstractFusion3DUNet(nn.Module):
         devs = [str(device)] if device is not None else list(self.__dict__.get("_xh_rng", {}))
         for key in devs:
             st = self.noise_state(torch.device(key))
-            st.copy_(torch.tensor([int(seed), 0, 0, 0], dtype=torch.int64))
+            st.copy_(ops.rng_state(seed, "cpu"))
 
     def _stream_weights(self, level, which):
         mods = [getattr(e.basic_module[0], which).conv for e in self.encoders[level]]
@@ -338,7 +338,9 @@ class AbstractFusion3DUNet(nn.Module):
             if not attens or len(attens) > 4 or len(duses) > 4:
                 dec, attens, duses = False, [], []
         skrs = []
-        if self.skip_return and x is not None and x.dtype != torch.float32 and ops.SEP_COMPOSE[0]:
+        # (fp32 storage on the matrix cores -- arith "split" -- takes the dense form too: the two-term split kernel serves a dense
+        # 4 -> 4 conv, while the separable form falls to the generic fp32 stencils: 0.28 ms of the 6.07 ms step in round 5)
+        if self.skip_return and x is not None and ops.SEP_COMPOSE[0] and (x.dtype != torch.float32 or (ops.current_arith() & 1)):
             levels = len(self.encoders)
             skrs = [self.skr_att[levels - level] for level in range(1, levels)]         # the ones forward() calls (RA_HVED.py:552)
             if len(skrs) > 4:

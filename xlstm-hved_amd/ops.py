@@ -1155,6 +1155,16 @@ def poe_bwd(feat, keep, eps, dz, dmu, dlv, L_, mask_mu):
 POE_MAX = 8
 
 
+RNG_WORDS = 16 * (2 + 32)          # == XH_RNG_WORDS: {seed, counter, ..., ticket lines}
+
+
+def rng_state(seed, device):
+    """A fresh generator state for poe_fwd_multi(rng=...): int64[RNG_WORDS] = {seed, draw counter 0, zeros (ticket words)}."""
+    st = torch.zeros(RNG_WORDS, dtype=torch.int64)
+    st[0] = int(seed)
+    return st.to(device)
+
+
 def _rng_words(t, n, what):
     if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
         raise ValueError(f"{what}: {n} contiguous int64 device words")
@@ -1164,7 +1174,7 @@ def _rng_words(t, n, what):
 def poe_fwd_multi(feats, keep, epss, Ls, mask_mu, rng=None):
     """poe_fwd for several latent levels in one launch (xh_poe_multi); returns [(z, mu, lv)] per level.
     rng = (state, used): the levels whose eps is None draw their noise IN the kernel (Philox4x32-10, fp32) from the generator
-    `state` (int64[4] device tensor: seed, counter, ticket, -; the launch advances the counter) and leave {counter, seed} of the
+    `state` (ops.rng_state: int64[RNG_WORDS] device tensor {seed, counter, ticket words}; the launch advances the counter) and leave {counter, seed} of the
     draw in `used` (int64[2]) for poe_bwd_multi.  Without rng, eps None means the posterior mean."""
     jobs = (L.PoeJob * len(feats))()
     outs, keepalive = [], []
@@ -1178,7 +1188,7 @@ def poe_fwd_multi(feats, keep, epss, Ls, mask_mu, rng=None):
         if rng is not None and eps is None:
             j.rng_used, j.rng_stream = _p(_rng_words(rng[1], 2, "rng used")), lvl
         outs.append((z, mu, lv))
-    state = _p(_rng_words(rng[0], 4, "rng state")) if rng is not None else None
+    state = _p(_rng_words(rng[0], RNG_WORDS, "rng state")) if rng is not None else None
     L.check(L.load().xh_poe_multi(_stream(), _dt(feats[0]), 0, len(feats), C.cast(jobs, C.c_void_p), state), "xh_poe_multi")
     return outs
 
