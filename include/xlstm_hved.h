@@ -198,6 +198,15 @@ long long xh_conv3d_workspace_bytes(const xh_conv_desc* d);
  * re-packs whenever the weights change (xlstm-hved_amd/ops.py: once per forward, keyed by the parameters' version counters).
  * Reference: the parameters of every nn.Conv3d(k=3) of RA_HVED.py:510-648 / buildingblocks.py:381-461. */
 int xh_conv3d_prepack(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p);
+/* The same packing in ONE launch for any number of convolutions (up to 256 pack jobs), for callers that pack the same set every step:
+ * xh_conv3d_prepack_table writes the job table of the n convolutions (pointers and shapes; what xh_conv3d_prepack would put into its
+ * kernel arguments) into xh_conv3d_prepack_table_bytes() bytes of HOST memory -- no launch, no device access; the caller copies the
+ * table to device memory it owns (once, and again whenever a weight or workspace ADDRESS or the set changes -- weight VALUES may
+ * change freely) and calls xh_conv3d_prepack_run(stream, device copy, nblocks) every step, with nblocks = the second int of the
+ * table.  Replaces ceil(jobs / 24) launches of 10-15 us by one (the 54 convolutions of XLSTM_HVED: three -> one). */
+long long xh_conv3d_prepack_table_bytes(void);
+int xh_conv3d_prepack_table(int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, void* host_table);
+int xh_conv3d_prepack_run(void* stream, const void* dev_table, int nblocks);
 
 /* Data gradient of a k=3, stride=2, pad=1 conv (the DRB SingleConv, RA_HVED.py:396-397).  Desc fields
  * describe the FORWARD conv (Cin,D,H,W = forward input; Cout,Do,Ho,Wo = forward output); x* = dY

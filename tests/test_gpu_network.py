@@ -855,6 +855,35 @@ def test_two_models_of_different_fp32_arithmetic_interleave_in_one_process():
     assert (sa - sb).abs().max().item() > 0
 
 
+def test_weight_fragments_packed_through_the_device_table_equal_the_kernel_argument_launches():
+    """ops.prepack_all: ONE launch through a device-resident job table (xh_conv3d_prepack_table / _run) against the
+    ceil(jobs / 24) kernel-argument launches of xh_conv3d_prepack -- the same pack_elem on the same jobs: every workspace holds the
+    same bytes, so the forward is the same; a weight update between steps is seen (values are read at pack time, only addresses
+    are in the table)."""
+    torch.manual_seed(6)
+    x = torch.rand(1, 4, 64, 64, 64).to(DEV, torch.bfloat16)
+    m = _model(False)
+
+    def run():
+        with torch.no_grad():
+            seg = m(x, [14], valid=True)[0]
+        return seg, {k: e.ws.clone() for k, e in X.ops._PACKS.items() if e.alive()}
+    X.ops.set_pack_table(False)
+    try:
+        run()                                          # registers the convolutions
+        s0, w0 = run()
+    finally:
+        X.ops.set_pack_table(True)
+    s1, w1 = run()
+    assert X.ops._PACK_STATE["table"] is not None and X.ops._PACK_STATE["table"][1] > 0
+    assert len(w0) > 15 and w0.keys() == w1.keys() and all(torch.equal(w0[k], w1[k]) for k in w0)
+    assert (s0.float() - s1.float()).abs().max().item() <= 2.0 ** -7           # (statistics atomics: order of fp64 additions)
+    with torch.no_grad():
+        m.encoders[0][0].basic_module[0].SingleConv1.conv.weight.mul_(1.5)
+    s2, w2 = run()
+    assert any(not torch.equal(w1[k], w2[k]) for k in w1)
+
+
 def test_window_graph_cache_is_per_model_bounded_and_follows_the_parameters():
     """The kept window graphs (inference._window_graph): they live on the model, at most WINDOW_GRAPHS_MAX of them (LRU), and a graph
     is captured again when the parameters have moved (model.half() / .to() replace the storage a captured forward reads): without

@@ -118,6 +118,9 @@ SIGNATURES = {
     "xh_conv3d_fuses_norm_bwd": (I, [C.POINTER(ConvDesc)]),
     "xh_conv3d_fuses_bn_finalize": (I, [C.POINTER(ConvDesc)]),
     "xh_conv3d_prepack": (I, [vp, I, vp, vp]),
+    "xh_conv3d_prepack_table_bytes": (ll, []),
+    "xh_conv3d_prepack_table": (I, [I, vp, vp, vp]),
+    "xh_conv3d_prepack_run": (I, [vp, vp, I]),
     "xh_conv3d_wgrad_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_dgrad_s2": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_conv3d_wgrad": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(vp * MAX_WPTR), C.POINTER(vp * MAX_WPTR)]),

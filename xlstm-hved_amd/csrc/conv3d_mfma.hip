@@ -82,6 +82,26 @@ __global__ __launch_bounds__(256) void conv3_pack_multi_kernel(const PackMulti m
     if (idx < j.nelem) pack_elem(j, idx);
   }
 }
+// The same for ANY number of convolutions in ONE launch: the job table lives in device memory (xh_conv3d_prepack_table: the caller
+// builds it on the host once per set of convolutions and keeps a device copy), so it is not bound by the 4 KB of kernel arguments.
+// Table: {int n; int nblocks; int first_block[XH_PACK_TABLE_MAX + 1]; PackJob job[n]}.
+#define XH_PACK_TABLE_MAX 256
+struct PackTableHead { int n, nblocks; int first_block[XH_PACK_TABLE_MAX + 1]; int pad_; };
+__global__ __launch_bounds__(256) void conv3_pack_table_kernel(const PackTableHead* __restrict__ h) {
+  const PackJob* jobs = reinterpret_cast<const PackJob*>(h + 1);
+  int lo = 0, hi = h->n - 1;                            // the job whose block range holds blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= h->first_block[mid]) lo = mid; else hi = mid - 1;
+  }
+  const PackJob j = jobs[lo];
+  const int base = ((int)blockIdx.x - h->first_block[lo]) * XH_PACK_PER_BLOCK;
+#pragma unroll
+  for (int u = 0; u < XH_PACK_PER_BLOCK / 256; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    if (idx < j.nelem) pack_elem(j, idx);
+  }
+}
 void xh_launch_pack_single(hipStream_t st, const PackJob& j) {
   hipLaunchKernelGGL(conv3_pack_kernel, dim3(min(cdiv(j.nelem, 2048), 64)), dim3(256), 0, st, j);
 }
@@ -533,23 +553,8 @@ int xh_conv3_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p
 // are read); a convolution that is not on the MFMA path is skipped.  Afterwards the caller sets xh_conv_ptrs.ws_packed.
 bool xh_conv3_q4_pack_job(const xh_conv_desc* d, const xh_conv_ptrs* p, PackJob* j);        // conv3d_q4.hip
 extern int g_use_mfma;
-extern "C" int xh_conv3d_prepack(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p) {
-  if (n < 0 || (n > 0 && (!d || !p))) return XH_ERR_ARG;
-  if (!g_use_mfma) return XH_OK;
-  hipStream_t st = (hipStream_t)stream;
-  PackMulti m;
-  m.n = 0;
-  m.first_block[0] = 0;
-  auto flush = [&]() {
-    if (m.n == 0) return;
-    hipLaunchKernelGGL(conv3_pack_multi_kernel, dim3(m.first_block[m.n]), dim3(256), 0, st, m);
-    m.n = 0;
-  };
-  auto push = [&](const PackJob& j) {
-    m.job[m.n] = j;
-    m.first_block[m.n + 1] = m.first_block[m.n] + cdiv(j.nelem, XH_PACK_PER_BLOCK);
-    if (++m.n == XH_PACK_MAX_JOBS) flush();
-  };
+// every pack job of the n convolutions, in order, handed to `push`; XH_ERR_ARG on a null entry
+template <typename PUSH> static int pack_jobs_of(int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, PUSH push) {
   for (int i = 0; i < n; ++i) {
     if (!d[i] || !p[i]) return XH_ERR_ARG;
     if (d[i]->k != 3 || d[i]->stride != 1 || d[i]->groups <= 0 || d[i]->Cin % d[i]->groups || d[i]->Cout % d[i]->groups) continue;
@@ -570,6 +575,51 @@ extern "C" int xh_conv3d_prepack(void* stream, int n, const xh_conv_desc* const*
       push(j);
     }
   }
+  return XH_OK;
+}
+extern "C" int xh_conv3d_prepack(void* stream, int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p) {
+  if (n < 0 || (n > 0 && (!d || !p))) return XH_ERR_ARG;
+  if (!g_use_mfma) return XH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  PackMulti m;
+  m.n = 0;
+  m.first_block[0] = 0;
+  auto flush = [&]() {
+    if (m.n == 0) return;
+    hipLaunchKernelGGL(conv3_pack_multi_kernel, dim3(m.first_block[m.n]), dim3(256), 0, st, m);
+    m.n = 0;
+  };
+  const int rc = pack_jobs_of(n, d, p, [&](const PackJob& j) {
+    m.job[m.n] = j;
+    m.first_block[m.n + 1] = m.first_block[m.n] + cdiv(j.nelem, XH_PACK_PER_BLOCK);
+    if (++m.n == XH_PACK_MAX_JOBS) flush();
+  });
+  if (rc) return rc;
   flush();
+  return xh_launch_status();
+}
+extern "C" long long xh_conv3d_prepack_table_bytes(void) { return (long long)sizeof(PackTableHead) + (long long)XH_PACK_TABLE_MAX * sizeof(PackJob); }
+extern "C" int xh_conv3d_prepack_table(int n, const xh_conv_desc* const* d, const xh_conv_ptrs* const* p, void* host_table) {
+  if (n < 0 || (n > 0 && (!d || !p)) || !host_table) return XH_ERR_ARG;
+  PackTableHead* h = reinterpret_cast<PackTableHead*>(host_table);
+  PackJob* jobs = reinterpret_cast<PackJob*>(h + 1);
+  h->n = 0; h->nblocks = 0; h->first_block[0] = 0; h->pad_ = 0;
+  if (!g_use_mfma) return XH_OK;
+  bool full = false;
+  const int rc = pack_jobs_of(n, d, p, [&](const PackJob& j) {
+    if (h->n >= XH_PACK_TABLE_MAX) { full = true; return; }
+    jobs[h->n] = j;
+    h->first_block[h->n + 1] = h->first_block[h->n] + cdiv(j.nelem, XH_PACK_PER_BLOCK);
+    ++h->n;
+  });
+  if (rc) return rc;
+  if (full) return XH_ERR_ARG;
+  h->nblocks = h->first_block[h->n];
+  return XH_OK;
+}
+extern "C" int xh_conv3d_prepack_run(void* stream, const void* dev_table, int nblocks) {
+  if (nblocks < 0 || (nblocks > 0 && !dev_table)) return XH_ERR_ARG;
+  if (nblocks == 0) return XH_OK;
+  hipLaunchKernelGGL(conv3_pack_table_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackTableHead*>(dev_table));
   return xh_launch_status();
 }

@@ -302,6 +302,14 @@ def _wversion(t):
     return t._version if g is None else ("gen", g)
 
 
+_PACK_TABLE = [os.environ.get("XH_NO_PACK_TABLE", "") == ""]     # A/B switch: one launch through a device-resident job table
+
+
+def set_pack_table(enabled):
+    _PACK_TABLE[0] = bool(enabled)
+    _PACK_STATE["table"] = None
+
+
 def set_prepack(enabled):
     """A/B switch (tests, microbenchmarks): False = every conv packs its own fragments right in front of the launch."""
     _PACK_STATE["enabled"] = bool(enabled)
@@ -345,10 +353,27 @@ def prepack_all():
         n = len(ents)
         st["arrays"] = (ents, (C.c_void_p * n)(*[C.addressof(e.desc) for e in ents]),
                         (C.c_void_p * n)(*[C.addressof(e.ptrs) for e in ents]))
+        st["table"] = None
     ents, darr, parr = st["arrays"]
     if not ents:
         return
-    L.check(L.load().xh_conv3d_prepack(_stream(), len(ents), darr, parr), "xh_conv3d_prepack")
+    lib = L.load()
+    # ONE launch through a device-resident job table (xh_conv3d_prepack_table): built on the host when the set of convolutions
+    # changes and copied to the device outside any capture; a set that changes under capture takes the kernel-argument launches
+    if st.get("table") is None and ents and not torch.cuda.is_current_stream_capturing() and _PACK_TABLE[0]:
+        nbytes = int(lib.xh_conv3d_prepack_table_bytes())
+        host = (C.c_char * nbytes)()
+        if lib.xh_conv3d_prepack_table(len(ents), darr, parr, C.cast(host, C.c_void_p)) == 0:
+            head = (C.c_int * 2).from_buffer(host)
+            dev = torch.frombuffer(host, dtype=torch.uint8).to(ents[0].ws.device)
+            st["table"] = (dev, int(head[1]), ents[0].ws.device)
+            # never freed: a captured graph replays the table it was captured with (like the fan-in blocks); 40 KB each
+            st.setdefault("tables_keep", []).append(dev)
+    tab = st.get("table")
+    if tab is not None and tab[2] == ents[0].ws.device:
+        L.check(lib.xh_conv3d_prepack_run(_stream(), tab[0].data_ptr(), tab[1]), "xh_conv3d_prepack_run")
+    else:
+        L.check(lib.xh_conv3d_prepack(_stream(), len(ents), darr, parr), "xh_conv3d_prepack")
     for e in ents:
         e.epoch = st["epoch"]
         e.versions = tuple(_wversion(r()) for r in e.refs)
