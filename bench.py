@@ -918,7 +918,7 @@ def roofline_pass(step, ops, nsteps, dtype):
             mfma = k3 and (w_ % 32 == 0 or w_ in (8, 16)) and cg >= 4
             qs = cg // 4
             qs = qs if qs <= 3 else 3 if qs % 3 == 0 else 2 if qs % 2 == 0 else 1      # input quads per unit (wgrad_q4 plan)
-            s2 = k == 3 and kw.get("stride", 1) == 2 and (dy.shape[1] // groups) % 4 == 0 and w_ % (16 // esz) == 0
+            s2 = k == 3 and kw.get("stride", 1) == 2 and ((dy.shape[1] // groups) % 4 == 0 or dy.shape[1] // groups == 2) and w_ % (16 // esz) == 0
             tiny = (k == 3 and kw.get("stride", 1) == 1 and groups == 1 and (cin, dy.shape[1]) in ((1, 2), (2, 1))
                     and w_ % (16 // esz) == 0 and kw.get("pre") is None)
             k7 = k == 7 and esz == 2 and cin == 4 and dy.shape[1] == 2 and groups == 1 and w_ % 32 == 0 and kw.get("pre") is None

@@ -173,9 +173,10 @@ def test_k1_weight_gradients_of_a_batch_share_one_launch(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_stride2_weight_gradients_of_a_batch_share_launches(dtype):
     """... and the k = 3 stride-2 problems (the DRB convs, RA_HVED.py:569: 4 streams as groups) through
-    conv3_s2_wgrad_vec_multi_kernel, 4 problems per launch: 5 problems = two launches."""
+    conv3_s2_wgrad_vec_multi_kernel, 4 problems per launch: 6 problems = two launches.  Groups of TWO output channels (the
+    level-0 DRB conv, 16 -> 8 in 4 groups) share the launches of the groups of four since round 6."""
     cases = [(1, 16, 0, 16, 4, 32, True), (1, 32, 0, 32, 4, 16, True), (2, 8, 0, 4, 1, 32, False), (1, 8, 0, 8, 2, 64, True),
-             (1, 4, 4, 8, 1, 32, False)]
+             (1, 4, 4, 8, 1, 32, False), (1, 16, 0, 8, 4, 32, True)]
     _batch_vs_autograd(cases, 3, 2, dtype, "conv3_s2_wgrad_vec_multi_kernel")
 
 

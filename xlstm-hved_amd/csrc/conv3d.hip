@@ -2131,11 +2131,13 @@ constexpr int S2W_MULTI = 4;
 struct S2WMulti {
   int n;
   int off[S2W_MULTI + 1];
-  int lw[S2W_MULTI], gx[S2W_MULTI], gy[S2W_MULTI];
+  int lw[S2W_MULTI], gx[S2W_MULTI], gy[S2W_MULTI], co[S2W_MULTI];     // co: output channels per workgroup (2: groups of two; else 4)
   WgradK p[S2W_MULTI];
 };
 static_assert(sizeof(S2WMulti) <= 3900, "kernel-argument table");
-template <typename T, int CO>
+// Both instances of the body in one kernel: the two-channel problem (the level-0 DRB conv, 41 us alone on 512 workgroups -- bound by
+// the latency of its load chain, not by bandwidth) runs NEXT TO the four-channel problems of the deeper levels instead of after them.
+template <typename T>
 __global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_multi_kernel(const S2WMulti m) {
   int pi = 0;
   for (int k = 1; k < S2W_MULTI; ++k)
@@ -2143,7 +2145,8 @@ __global__ __launch_bounds__(256) void conv3_s2_wgrad_vec_multi_kernel(const S2W
   const int local = blockIdx.x - m.off[pi];
   const int gx = m.gx[pi], gy = m.gy[pi];
   const int r = local / gx;
-  s2_wgrad_body<T, CO>(m.p[pi], m.lw[pi], local - r * gx, r % gy, r / gy, gx);
+  if (m.co[pi] == 2) s2_wgrad_body<T, 2>(m.p[pi], m.lw[pi], local - r * gx, r % gy, r / gy, gx);
+  else s2_wgrad_body<T, 4>(m.p[pi], m.lw[pi], local - r * gx, r % gy, r / gy, gx);
 }
 
 // launch plan of the vectorised stride-2 weight gradient; false: not eligible
@@ -2352,21 +2355,20 @@ int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
   for (int t = 0; t < 3; ++t) {
     m->n = 0; m->off[0] = 0;
     auto launch = [&]() -> int {
-      XH_DISPATCH_T(types[t], hipLaunchKernelGGL((conv3_s2_wgrad_vec_multi_kernel<T, 4>), dim3(m->off[m->n]), dim3(256), 0,
+      XH_DISPATCH_T(types[t], hipLaunchKernelGGL((conv3_s2_wgrad_vec_multi_kernel<T>), dim3(m->off[m->n]), dim3(256), 0,
                                                  (hipStream_t)stream, *m););
       return XH_OK;
     };
     auto flush = [&]() {
       if (m->n == 0) return;
       for (int i = m->n; i < S2W_MULTI; ++i) m->off[i + 1] = m->off[m->n];
-      xh_note_kernel("conv3_s2_wgrad_vec_multi_kernel<%s, 4>", types[t] == XH_F32 ? "float" : (types[t] == XH_F16 ? "f16_t" : "bf16_t"));
+      xh_note_kernel("conv3_s2_wgrad_vec_multi_kernel<%s>", types[t] == XH_F32 ? "float" : (types[t] == XH_F16 ? "f16_t" : "bf16_t"));
       if (launch() != XH_OK || xh_launch_status() != XH_OK) rc_all = XH_ERR_HIP;
       m->n = 0; m->off[0] = 0;
     };
     for (int i = 0; i < n; ++i) {
       if (handled[i] || !d[i] || !p[i] || d[i]->dtype != types[t]) continue;
       if (check_desc(d[i], p[i]) || !p[i]->ea || !dw[i] || d[i]->transposed || d[i]->groups <= 0) continue;
-      if ((d[i]->Cout / d[i]->groups) % 4) continue;                  // the two-channel instance keeps its own launch
       bool ok = true;
       for (int j = 0; j < d[i]->n_wptr; ++j) ok = ok && dw[i][j];
       dim3 grid;
@@ -2376,6 +2378,7 @@ int xh_s2w_batch(void* stream, int n, const xh_conv_desc* const* d, const xh_con
       if (blocks > (1 << 22)) continue;
       handled[i] = 1;
       m->gx[k] = (int)grid.x; m->gy[k] = (int)grid.y;
+      m->co[k] = (d[i]->Cout / d[i]->groups) == 2 ? 2 : 4;
       m->off[k + 1] = m->off[k] + (int)blocks;
       if (++m->n == S2W_MULTI) flush();
     }
