@@ -134,6 +134,18 @@ typedef struct {
                                    XH_ARITH_K7_VECTOR (with F32_SPLIT): the 7^3 gate convs stay on the fp32 vector kernels.
                                    The mode is part of the CALL (round 6; it was process state behind xh_set_option keys 18 / 25):
                                    two models of different modes, or a captured graph next to eager calls, cannot disturb each other. */
+  int bcast;                    /* 0, or 4: a BROADCAST operand (round 6).  Logical channel c of the operand reads channel c / 4 of the
+                                   tensor given, which has a quarter of the channels: the four channels of a group are one stored
+                                   channel seen through four different (pre_sc, pre_sh) / (e_sc, e_sh) pairs.
+                                     xh_conv3d_fwd, transposed == 0: the operand is the input xa (Ca == Cin, 4 input channels per group);
+                                     xh_conv3d_fwd, transposed == 1, epi == 1: the operand is e (ea; Cea == Cout, 4 per group), and y may
+                                       be NULL: the masked gradient is then only summed (red), not stored;
+                                     xh_conv3d_wgrad[_batch]: the operand is the forward input xa.
+                                   This is how the first conv of XLSTM_HVED's encoders reads the init blocks' 1x1 convs WITHOUT their
+                                   output ever being stored: InstanceNorm(w_c x + b_c) = sign(w_c) (x - mean) / sqrt(var + eps / w_c^2), a
+                                   per-channel affine of the input modality itself (RA_HVED.py:345-349,548-553; xh_init_fold_fwd).
+                                   Served by the full-row quad-channel kernels only (16-bit storage, k = 3, stride 1, rows of 64 / 128
+                                   voxels, H a multiple of 8, D >= 4: xh_conv3d_supports_bcast); anything else returns XH_ERR_ARG. */
 } xh_conv_desc;
 #define XH_ARITH_F32_SPLIT 1
 #define XH_ARITH_K7_VECTOR 2
@@ -174,6 +186,10 @@ typedef struct {
    * instance statistics), and the launch also advances the running statistics fin_rm / fin_rv by fin_steps momentum-0.1 updates
    * with the unbiased variance (what xh_norm_finalize mode 1 does in a launch of its own; sa_modules/sa_module.py:79-85). */
   const float* fin_gamma; const float* fin_beta; float* fin_rm; float* fin_rv; int fin_steps;
+  /* Optional with a broadcast e operand (xh_conv_desc.bcast, transposed, epi == 1): e_ctr[N][Cout], a per-channel centre; the second
+   * sum is then red[n][c][1] += g * (e - e_ctr[n][c]).  With e_ctr = the channel mean of e the caller gets sum g (e - mean) without
+   * the cancellation of sum g e - mean sum g (five digits for an input modality whose spread is small against its mean). */
+  const float* e_ctr;
 } xh_conv_ptrs;
 
 /* Size in bytes of a statistics fan-in workspace (xh_conv_ptrs.fan).  The library allocates no device memory and keeps no
@@ -189,6 +205,21 @@ int xh_conv3d_fuses_bn_finalize(const xh_conv_desc* d);
 /* 1 when xh_conv3d_fwd takes this desc with pre == 2 (the quad-channel MFMA kernel: 16-bit storage, k = 3, stride 1, rows of 32
  * voxels, <= 48 channels per group, ...); 0: the caller materialises the tensor with xh_in_bwd_apply and calls with pre == 0. */
 int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d);
+/* 1 when every call of the broadcast form of this desc's convolution (forward, data gradient with e broadcast, weight gradient)
+ * is served: d describes the FORWARD conv with bcast set. */
+int xh_conv3d_supports_bcast(const xh_conv_desc* d);
+/* The init blocks' 1x1 convs (RA_HVED.py:345-349: one modality -> B channels, X_c = w_c x_m + b_c) folded into the InstanceNorm that
+ * is their only consumer: IN(X_c) = sc_c x_m + sh_c with sc_c = w_c R_c, sh_c = -w_c mean_m R_c, R_c = 1 / sqrt(w_c^2 var_m + eps)
+ * (the bias drops out).  red_x[N][M][2] = fp64 sums (sum x, sum x^2) of the M stored channels over `count` voxels; w[m] = the B
+ * weights of modality m; sc / sh / rstd / ctr: [N][M * B], ctr = fp32(mean_m) (the e_ctr of the data gradient).  The first encoder
+ * conv then reads x itself (xh_conv_desc.bcast). */
+int xh_init_fold_fwd(void* stream, const double* red_x, long long count, int N, int M, int B, const float* const w[XH_MAX_WPTR],
+                     float eps, float* sc, float* sh, float* rstd, float* ctr);
+/* Backward of the fold: red_g[N][M * B][2] = (sum g, sum g (x - ctr)) left by the first conv's data gradient (epi == 1 with the
+ * broadcast e operand and e_ctr = ctr); dw[m][j] += eps R^3 sum g (x - mean), the exact gradient of the init weight (the bias
+ * gradient is exactly zero). */
+int xh_init_fold_bwd(void* stream, const double* red_x, long long count, int N, int M, int B, const float* const w[XH_MAX_WPTR],
+                     float eps, const double* red_g, float* const dw[XH_MAX_WPTR]);
 /* Bytes of p->ws the bf16-MFMA implicit-GEMM path wants for this desc (0: shape not eligible, vector kernel). */
 long long xh_conv3d_workspace_bytes(const xh_conv_desc* d);
 /* Weights are constant within a training step: packs the MFMA weight fragments of n convolutions (forward and data-gradient

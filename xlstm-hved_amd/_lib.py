@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("n_wptr", C.c_int), ("transposed", C.c_int), ("pre", C.c_int), ("pre_slope", C.c_float),
         ("act", C.c_int), ("act_slope", C.c_float), ("epi", C.c_int), ("Cea", C.c_int),
         ("ea_bs", ll), ("eb_bs", ll), ("e_slope", C.c_float),
-        ("px_bs", ll), ("pd_bs", ll), ("arith", C.c_int),
+        ("px_bs", ll), ("pd_bs", ll), ("arith", C.c_int), ("bcast", C.c_int),
     ]
 
 
@@ -41,7 +41,7 @@ class ConvPtrs(C.Structure):
         ("fin_red", vp), ("fin_mean", vp), ("fin_rstd", vp), ("fin_count", ll), ("ws_packed", C.c_int),
         ("fan", vp), ("fan_bytes", ll),
         ("px", vp), ("pd", vp), ("nb_red", vp), ("nb_mean", vp), ("nb_rstd", vp), ("nb_count", ll),
-        ("fin_gamma", vp), ("fin_beta", vp), ("fin_rm", vp), ("fin_rv", vp), ("fin_steps", C.c_int),
+        ("fin_gamma", vp), ("fin_beta", vp), ("fin_rm", vp), ("fin_rv", vp), ("fin_steps", C.c_int), ("e_ctr", vp),
     ]
 
 
@@ -116,6 +116,9 @@ SIGNATURES = {
     "xh_fanin_bytes": (ll, []),
     "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_fuses_norm_bwd": (I, [C.POINTER(ConvDesc)]),
+    "xh_conv3d_supports_bcast": (I, [C.POINTER(ConvDesc)]),
+    "xh_init_fold_fwd": (I, [vp, vp, ll, I, I, I, C.POINTER(vp * MAX_WPTR), F, vp, vp, vp, vp]),
+    "xh_init_fold_bwd": (I, [vp, vp, ll, I, I, I, C.POINTER(vp * MAX_WPTR), F, vp, C.POINTER(vp * MAX_WPTR)]),
     "xh_conv3d_fuses_bn_finalize": (I, [C.POINTER(ConvDesc)]),
     "xh_conv3d_prepack": (I, [vp, I, vp, vp]),
     "xh_conv3d_prepack_table_bytes": (ll, []),

@@ -1640,6 +1640,14 @@ extern "C" int xh_conv3d_fuses_bn_finalize(const xh_conv_desc* d) {
   if (!d || !g_use_mfma || d->pre != 1 || d->N != 1 || d->k != 3) return 0;
   return xh_conv3_q4_workspace_bytes(d) > 0 ? 1 : 0;
 }
+extern "C" int xh_conv3d_supports_bcast(const xh_conv_desc* d) {
+  if (!d || !g_use_mfma || d->bcast != 4 || d->transposed || d->k != 3 || d->stride != 1 || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return 0;
+  if (d->groups <= 0 || d->Cin != 4 * d->groups || d->Cout != 4 * d->groups || d->Ca != d->Cin) return 0;   // 4 -> 4 per group (the data gradient's e is the input)
+  if ((d->W != 128 && d->W != 64) || d->H % 8 || d->H < 8 || d->D < 4) return 0;
+  const long long dhw = (long long)d->D * d->H * d->W;
+  if (4 * dhw >= (1ll << 27)) return 0;
+  return xh_conv3_q4_workspace_bytes(d) > 0 ? 1 : 0;
+}
 extern "C" int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d) {
   if (!d || !g_use_mfma || d->epi == 2 || d->act != XH_ACT_NONE) return 0;
   xh_conv_desc t = *d;
@@ -1649,8 +1657,15 @@ extern "C" int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d) {
 extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   int rc = check_desc(d, p);
   if (rc) return rc;
-  if (!p->y) return XH_ERR_ARG;
+  if (!p->y && !(d->bcast && d->transposed && d->epi == 1)) return XH_ERR_ARG;
   if (d->transposed && d->stride != 1) return XH_ERR_ARG;
+  if (d->bcast) {                                      // broadcast operand: the full-row quad-channel kernel or nothing
+    if (d->bcast != 4 || d->Ca != d->Cin || p->fin_red || d->pre == 2) return XH_ERR_ARG;
+    if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red)) return XH_ERR_ARG;
+    if (d->epi == 2 && !p->red) return XH_ERR_ARG;
+    const int r = g_use_mfma ? xh_conv3_q4_try(stream, d, p) : 1;
+    return r == 1 ? XH_ERR_ARG : r;
+  }
   if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cout && !p->eb))) return XH_ERR_ARG;
   if (d->epi == 2 && !p->red) return XH_ERR_ARG;
   if (d->epi < 0 || d->epi > 2) return XH_ERR_ARG;
@@ -2246,6 +2261,11 @@ extern "C" int xh_conv3d_wgrad(void* stream, const xh_conv_desc* d, const xh_con
   if (!p->ea || !dw || d->transposed) return XH_ERR_ARG;
   for (int i = 0; i < d->n_wptr; ++i)
     if (!dw[i]) return XH_ERR_ARG;
+  if (d->bcast) {                                      // broadcast input: the full-row quad-channel kernel or nothing
+    if (d->bcast != 4 || d->Ca != d->Cin || d->k != 3) return XH_ERR_ARG;
+    const int r = g_use_mfma ? xh_conv3_wgrad_mfma_try(stream, d, p, dw, db) : 1;
+    return r == 1 ? XH_ERR_ARG : r;
+  }
   if (g_use_mfma) {
     const int r = d->k == 7 ? xh_conv7_wgrad_mfma_try(stream, d, p, dw, db) : xh_conv3_wgrad_mfma_try(stream, d, p, dw, db);
     if (r != 1) return r;

@@ -452,6 +452,10 @@ static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
   { extern int g_q4_maxc; if (cin_g > g_q4_maxc || cout_g > g_q4_maxc) return false; }   // denser groups: the plain implicit GEMM
   if (d->Ca % 4) return false;
   if (d->epi == 1 && d->Cea % 4) return false;
+  if (d->bcast) {                                      // broadcast operand (xh_conv_desc.bcast): 16-bit storage, 4 -> 4 per group, one source
+    if (d->bcast != 4 || f32 || dw || d->pre == 2 || d->Ca != d->Cin || cin_g != 4 || cout_g != 4) return false;
+    if (d->transposed && (d->epi != 1 || d->Cea != d->Cout)) return false;
+  }
   if ((d->xa_bs & 7) || (d->xb_bs & 7) || (d->y_bs & 7) || (d->ea_bs & 7) || (d->eb_bs & 7)) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
   if (dhw % 8 || dhw >= (f32 ? (1ll << 27) : (1ll << 28))) return false;      // 31-bit byte offsets inside a quad of channel volumes (q4_window)
@@ -538,11 +542,13 @@ int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) 
   if (d->dtype != XH_F32) {
     int r = xh_conv3_q4w_try(st, a);                   // rows of 128 voxels: full-row tiles
     if (r != 1) return r;
+    if (d->bcast) return XH_ERR_ARG;                   // (only the full-row kernel reads a broadcast operand)
     r = xh_conv3_q4p_try(st, a);                       // multi-quad forward launches with several tiles per workgroup slot: the persistent kernel
     if (r != 1) return r;
   }
   dim3 grid(a.tilesW * a.tilesH * a.tilesD, d->Cout / 4, d->N);
   a.fan = d->epi ? xh_fan_block(p->fan, p->fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
+  if (d->bcast) return XH_ERR_ARG;
   if (d->dtype == XH_F32) return xh_conv3_q4s_launch(st, a, grid);
   const size_t shm = q4_tile_bytes(a.td) + 48 * sizeof(double) + 3 * Q4_MAXC * sizeof(float);
   if (d->pre == 2 && (!p->px || !p->nb_red || !p->nb_mean || !p->nb_rstd || p->nb_count <= 0 || d->epi == 2)) return XH_ERR_ARG;

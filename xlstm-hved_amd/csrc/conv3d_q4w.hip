@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   const int oh = oh0 + wv;
   const bool row_ok = oh < Ho;
   const int ndz = min(WTD, Do - od0);
-  float bias = 0.f, esc = 0.f, esh = 0.f;
+  float bias = 0.f, esc = 0.f, esh = 0.f, ectr = 0.f;
   {
     const int wp = udiv_fast(grp, a.gpp, a.mG);
     const float* bp = a.p.b[wp];
@@ -132,13 +132,20 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   const long long odhw = (long long)Do * Ho * WW;
   const unsigned spd_b = (unsigned)(Ho * WW) * (unsigned)sizeof(ST);
   const unsigned lane_b = (unsigned)(((long long)g4 * odhw + (long long)(row_ok ? oh : 0) * WW + 4 * qd) * (long long)sizeof(ST));
-  const unsigned lane_bo = row_ok ? lane_b : Q4_OOB;
+  // broadcast operands (xh_conv_desc.bcast): the forward input / the data gradient's e operand is ONE stored channel per group, seen
+  // through four (scale, shift) pairs; a data gradient without y only sums (every store lands outside the window and is dropped)
+  const bool bc_in = a.d.bcast && !a.d.transposed, bc_e = a.d.bcast && a.d.transposed;
+  const bool st_ok = row_ok && a.p.y != nullptr;
+  const unsigned lane_e = bc_e ? (unsigned)(((long long)(row_ok ? oh : 0) * WW + 4 * qd) * (long long)sizeof(ST)) : lane_b;
+  const unsigned lane_bo = st_ok ? lane_b : Q4_OOB;
   constexpr unsigned HALF_B = 64 * sizeof(ST);         // byte distance of the two halves of a row
   __amdgpu_buffer_rsrc_t ers = q4_window(a.p.y), yrs;
   if (EPI == 1) {
     esc = a.p.e_sc[n * a.d.Cout + co0 + g4];
     esh = a.p.e_sh[n * a.d.Cout + co0 + g4];
-    ers = q4_window(reinterpret_cast<const char*>(co0 < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co0 * odhw
+    if (bc_e && a.p.e_ctr) ectr = a.p.e_ctr[n * a.d.Cout + co0 + g4];
+    ers = q4_window(reinterpret_cast<const char*>(bc_e ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)(co0 >> 2) * odhw
+                                                  : co0 < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co0 * odhw
                                                                   : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co0 - a.d.Cea) * odhw) +
                     (long long)od0 * spd_b);
   }
@@ -153,17 +160,19 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   const float pslope = a.d.pre_slope;
   const bool fin = PRE == 1 && a.p.fin_red != nullptr;
   const long long dhw_b = dhw * (long long)sizeof(ST);
+  const long long cs_b = bc_in ? 0 : dhw_b;              // byte distance of the quad's channel planes (0: one stored channel)
 
   for (int cq = 0; cq < ncq; ++cq) {
     const int c0 = cin_base + cq * 4;
-    const char* src = reinterpret_cast<const char*>(c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
+    const char* src = reinterpret_cast<const char*>(bc_in ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)(c0 >> 2) * dhw
+                                                    : c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
                                                                   : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw);
     // ---- all global loads of this thread, back to back ----
     uint4 raw[WNIT][4];
 #pragma unroll
     for (int it = 0; it < WNIT; ++it)
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * dhw_b + i_off[it]);
+      for (int cc = 0; cc < 4; ++cc) raw[it][cc] = *reinterpret_cast<const uint4*>(src + cc * cs_b + i_off[it]);
     if (cq > 0) __syncthreads();                      // every wave is done reading the previous quad's image
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (PRE == 1) {
@@ -277,14 +286,14 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   // ---- epilogue ----
   f32x2_t ps = {0.f, 0.f}, pq = {0.f, 0.f};
   const f32x2_t bias2 = {bias, bias}, esc2 = {esc, esc}, esh2 = {esh, esh};
-  const f32x2_t esl2 = {a.d.e_slope, a.d.e_slope};
+  const f32x2_t esl2 = {a.d.e_slope, a.d.e_slope}, ectr2 = {ectr, ectr};
   uint2 eraw[WTD][NH];
   if (EPI == 1) {
 #pragma unroll
     for (int dz = 0; dz < WTD; ++dz)
 #pragma unroll
       for (int h = 0; h < NH; ++h)
-        eraw[dz][h] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ers, (int)(lane_b + h * HALF_B),
+        eraw[dz][h] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ers, (int)(lane_e + h * HALF_B),
                                                                                       (int)((unsigned)min(dz, ndz - 1) * spd_b), 0));
   }
 #pragma unroll
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
         if (live) {
           const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);         // the values as stored
           ps += r0 + r1;
-          pq += r0 * e[0] + r1 * e[1];
+          pq += r0 * (e[0] - ectr2) + r1 * (e[1] - ectr2);     // (ectr = 0 but for a broadcast e operand: e - 0 is exact)
         }
       } else {
         pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
         }
       }
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), pk), yrs,
-                                            (int)(live ? lane_bo + (row_ok ? h * HALF_B : 0u) : Q4_OOB), (int)((unsigned)dz * spd_b), 0);
+                                            (int)(live ? lane_bo + (st_ok ? h * HALF_B : 0u) : Q4_OOB), (int)((unsigned)dz * spd_b), 0);
     }
   }
   if (EPI) {

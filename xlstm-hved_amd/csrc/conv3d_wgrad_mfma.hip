@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NT, 2) void conv3_wgrad_mfma_multi_kernel(const WgM
 struct WgPlan { WgMK a; unsigned gx; int ny; size_t shm; bool big; int cp; };
 // fills the launch plan; returns false when the shape is not eligible for the MFMA weight gradient
 static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const dw[XH_MAX_WPTR], float* const db[XH_MAX_WPTR], WgPlan* pl) {
-  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1) return false;
+  if ((d->dtype != XH_BF16 && d->dtype != XH_F16) || d->k != 3 || d->stride != 1 || d->bcast) return false;
   if ((d->W % 32 != 0 && d->W != 16 && d->W != 8) || d->Wo != d->W) return false;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g < 4) return false;
@@ -355,6 +355,7 @@ int xh_conv3_wgrad_mfma_try(void* stream, const xh_conv_desc* d, const xh_conv_p
       return xh_launch_status();
     }
   }
+  if (d->bcast) return 1;                              // (a broadcast input is read by the full-row quad-channel kernel only)
   WgPlan pl;
   if (!wg_plan(d, p, dw, db, &pl)) return 1;
   const WgMK& a = pl.a;

@@ -619,7 +619,10 @@ bool xh_wgrad_q4_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const
   a->wpu = a->nb = 0;                                  // set per launch (xh_wgrad_q4_launch)
   { extern int g_mfma_abl; a->abl = g_mfma_abl; }
   a->full = 0;
+  a->bcast = d->bcast ? 1 : 0;
+  if (d->bcast && (d->bcast != 4 || f32 || dwm || cin_g != 4 || d->Ca != d->Cin)) return false;
   if (!(a->abl & (8192 | 524288))) xh_wgrad_q5_replan(d, a);   // rows of 64 / 128 voxels: the full-row kernel (conv3d_wgrad_q5.hip)
+  if (d->bcast && !a->full) return false;               // (only the full-row kernel reads a broadcast input)
   return true;
 }
 

@@ -147,8 +147,9 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     const int th = col % a.tilesH, n = col / a.tilesH;
     const int h0 = th * Q5_TH;
     // ---- per-tile part of the x plan ----
-    const ST* xsrc = (cin_base < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)cin_base * dhw
-                                      : (const ST*)a.xb + n * a.xb_bs + (long long)(cin_base - a.Ca) * dhw);
+    const ST* xsrc = a.bcast ? (const ST*)a.xa + n * a.xa_bs + (long long)(cin_base >> 2) * dhw      // one stored channel, four transforms
+                     : (cin_base < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)cin_base * dhw
+                                        : (const ST*)a.xb + n * a.xb_bs + (long long)(cin_base - a.Ca) * dhw);
     unsigned x_goff[NIX];
     float x_sc[NIX], x_sh[NIX];
 #pragma unroll
@@ -157,7 +158,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
       const bool rok = (unsigned)row < (unsigned)H;
       const int it = tid + 512 * k;
       const int j = (x_do[k] ? it : 0) % PR;
-      x_goff[k] = (unsigned)((long long)x_c[k] * dhw + (long long)min(max(row, 0), H - 1) * W + 8 * j);
+      x_goff[k] = (unsigned)((a.bcast ? 0ll : (long long)x_c[k] * dhw) + (long long)min(max(row, 0), H - 1) * W + 8 * j);
       float sc = 1.f, sh = 0.f;
       if (a.pre) { sc = a.pre_sc[n * a.Cin + cin_base + x_c[k]]; sh = a.pre_sh[n * a.Cin + cin_base + x_c[k]]; }
       x_sc[k] = rok ? sc : 0.f;

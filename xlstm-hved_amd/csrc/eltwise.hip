@@ -1287,6 +1287,70 @@ extern "C" int xh_act_bwd(void* stream, int dtype, const void* dy, const void* y
   return xh_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------- init-block fold
+// The init blocks are 1x1 convs from ONE modality to B channels (RA_HVED.py:345-349): X_c = w_c x_m + b_c, and their only consumer
+// is an InstanceNorm (the first SingleConv of the encoder, buildingblocks.py:406-433).  IN(X_c) = (x_m - mean_m) w_c R_c with
+// R_c = 1 / sqrt(w_c^2 var_m + eps): an affine of the INPUT -- so the 16-channel tensor X is never stored; the first conv reads x
+// through (sc, sh) per logical channel (xh_conv_desc.bcast).  These two parameter-sized kernels are the bookkeeping.
+struct FoldW { const float* w[XH_MAX_WPTR]; float* dw[XH_MAX_WPTR]; };
+__global__ __launch_bounds__(64) void init_fold_fwd_k(const double* __restrict__ red_x, double inv_count, int N, int M, int B, FoldW fw, float eps,
+                                                      float* sc, float* sh, float* rstd, float* ctr) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= N * M * B) return;
+  const int c = i % (M * B), n = i / (M * B), m = c / B;
+  const double mean = red_x[2 * (n * M + m)] * inv_count;
+  double var = red_x[2 * (n * M + m) + 1] * inv_count - mean * mean;
+  if (var < 0) var = 0;
+  const double w = (double)fw.w[m][c - m * B];
+  const double R = 1.0 / sqrt(w * w * var + (double)eps);
+  sc[i] = (float)(w * R);
+  sh[i] = (float)(-w * mean * R);
+  rstd[i] = (float)R;
+  ctr[i] = (float)mean;
+}
+// backward: the data gradient of the first conv left S0 = sum g, S1 = sum g (x - ctr) per logical channel (g = d loss / d IN(X_c),
+// masked by the activation; e = the raw input, centred on ctr = fp32(mean_m): xh_conv_ptrs.e_ctr -- sum g x - mean sum g would cancel
+// five digits).  Chain rule through mean and variance of X_c = w_c x + b_c:
+//   d loss / d w_c = eps R_c^3 sum g (x - mean_m) = eps R_c^3 (S1 - (mean_m - ctr) S0),   d loss / d b_c = 0
+// (both exactly; for |w_c| sigma << sqrt(eps) the factor eps R^3 reaches eps^-1/2: these gradients are NOT small)
+__global__ __launch_bounds__(64) void init_fold_bwd_k(const double* __restrict__ red_x, double inv_count, int N, int M, int B, FoldW fw, float eps,
+                                                      const double* __restrict__ red_g) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= M * B) return;
+  const int m = c / B;
+  const double w = (double)fw.w[m][c - m * B];
+  double acc = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const double mean = red_x[2 * (n * M + m)] * inv_count;
+    double var = red_x[2 * (n * M + m) + 1] * inv_count - mean * mean;
+    if (var < 0) var = 0;
+    const double R = 1.0 / sqrt(w * w * var + (double)eps);
+    const double S0 = red_g[2 * (n * M * B + c)], S1 = red_g[2 * (n * M * B + c) + 1];
+    acc += (double)eps * R * R * R * (S1 - (mean - (double)(float)mean) * S0);
+  }
+  fw.dw[m][c - m * B] += (float)acc;
+}
+extern "C" int xh_init_fold_fwd(void* stream, const double* red_x, long long count, int N, int M, int B, const float* const w[XH_MAX_WPTR],
+                                float eps, float* sc, float* sh, float* rstd, float* ctr) {
+  if (!red_x || count <= 0 || N <= 0 || M <= 0 || M > XH_MAX_WPTR || B <= 0 || !w || !sc || !sh || !rstd || !ctr) return XH_ERR_ARG;
+  FoldW fw;
+  for (int i = 0; i < XH_MAX_WPTR; ++i) { fw.w[i] = i < M ? w[i] : nullptr; fw.dw[i] = nullptr; if (i < M && !w[i]) return XH_ERR_ARG; }
+  hipLaunchKernelGGL(init_fold_fwd_k, dim3((N * M * B + 63) / 64), dim3(64), 0, (hipStream_t)stream, red_x, 1.0 / (double)count, N, M, B, fw, eps,
+                     sc, sh, rstd, ctr);
+  return xh_launch_status();
+}
+extern "C" int xh_init_fold_bwd(void* stream, const double* red_x, long long count, int N, int M, int B, const float* const w[XH_MAX_WPTR],
+                                float eps, const double* red_g, float* const dw[XH_MAX_WPTR]) {
+  if (!red_x || count <= 0 || N <= 0 || M <= 0 || M > XH_MAX_WPTR || B <= 0 || !w || !red_g || !dw) return XH_ERR_ARG;
+  FoldW fw;
+  for (int i = 0; i < XH_MAX_WPTR; ++i) {
+    fw.w[i] = i < M ? w[i] : nullptr; fw.dw[i] = i < M ? dw[i] : nullptr;
+    if (i < M && (!w[i] || !dw[i])) return XH_ERR_ARG;
+  }
+  hipLaunchKernelGGL(init_fold_bwd_k, dim3((M * B + 63) / 64), dim3(64), 0, (hipStream_t)stream, red_x, 1.0 / (double)count, N, M, B, fw, eps, red_g);
+  return xh_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------- product of experts
 #define POE_EPS 1e-8f
 // Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's device RNG): counter-based, so element i of draw c is a pure

@@ -20,6 +20,7 @@ struct WgQ4 {
   int abl;                       // ablation mask (microbenchmarks)
   int dwm;                       // depthwise problem run as groups of 4: only the diagonal of a 4 x 4 block is a gradient
   int wide;                      // tile shape: 0 = 4 rows x 32 voxels, 1 = 2 rows x 64 voxels (rows of 64 / 128 voxels: full-line loads)
+  int bcast;                     // xh_conv_desc.bcast: the group's four input channels are one stored channel of xa (full-row kernel only)
   int full;                      // 1: planned for the full-row kernel (conv3d_wgrad_q5.hip: 8 rows x W tiles, one input quad per unit)
 };
 

@@ -386,6 +386,78 @@ def in_lrelu_conv(xa, xb, weights, biases, stride=1, groups=1, in_stats=None, ou
         InLreluConv._into = None
 
 
+class InitInLreluConv(Function):
+    """The init blocks (1x1 convs from ONE modality to B channels, RA_HVED.py:345-349,548) and the first SingleConv 'ilc' of the
+    level-0 encoders (buildingblocks.py:406-433) WITHOUT the init convs' output: their only consumer is that SingleConv's
+    InstanceNorm, and IN(w_c x_m + b_c) = sc_c x_m + sh_c is an affine of the input modality itself (ops.init_fold_fwd).  The conv
+    reads x as a broadcast operand (xh_conv_desc.bcast: one stored channel per group through four (sc, sh) pairs).  Removed from the
+    step: the init conv launch and its 16-channel output (the second most flip-sensitive tensor of 16-bit storage,
+    tools/precision_sweep.py), in backward the store of the first conv's data gradient, its InstanceNorm-backward pass and the init
+    convs' weight-gradient problem -- the init weights' gradient is eps R^3 (S1 - mean S0) from the data gradient's epilogue sums
+    (ops.init_fold_bwd; the init biases' gradient is exactly zero)."""
+
+    @staticmethod
+    def forward(ctx, x, nm, *params):
+        init_w, init_b = list(params[:nm]), list(params[nm:2 * nm])
+        conv_w, conv_b = list(params[2 * nm:3 * nm]), list(params[3 * nm:])
+        n, cnt = x.shape[0], _dhw(x)
+        red_x = ops.zeros_red(x, n, nm)
+        ops.moments(x, red_x, 0)
+        sc, sh, _, ctr = ops.init_fold_fwd(red_x, cnt, n, init_w)
+        cout = sum(w.shape[0] for w in conv_w)
+        red_y = ops.zeros_red(x, n, cout)
+        y = ops.conv3d(x, None, conv_w, None, k=3, cout=cout, groups=nm, pre=(sc, sh, LEAK), epi=2, red=red_y, bcast=4)
+        ctx.save_for_backward(x, red_x, sc, sh, ctr, *conv_w, *init_w)
+        ctx.nm = nm
+        ctx.params = (init_w, init_b, conv_w, conv_b)
+        ctx.mark_non_differentiable(red_y)
+        ctx.set_materialize_grads(False)
+        return y, red_y
+
+    @staticmethod
+    def backward(ctx, dy, _dred=None):
+        nm = ctx.nm
+        x, red_x, sc, sh, ctr, *wts = ctx.saved_tensors
+        conv_w, init_w = wts[:nm], wts[nm:]
+        dy = _blk(dy)
+        nb = _NB_PENDING.pop(dy.data_ptr(), None)           # dy handed over unwritten by the next conv's backward: write it now
+        if nb is not None:
+            ops.in_bwd_apply(nb[0], nb[1], nb[2], nb[3], nb[4], have_g=True, out=dy)
+        diw, riw = _targets(ctx.params[0])
+        _, rib = _targets(ctx.params[1])                     # exactly zero: existing buffers are left alone, new ones are zeros
+        dws, rws = _targets(ctx.params[2])
+        dbs, rbs = _targets(ctx.params[3])
+        n, cnt, cin = x.shape[0], _dhw(x), 4 * nm
+        ops.conv3d_wgrad(x, None, dy, dws, dbs, k=3, groups=nm, pre=(sc, sh, LEAK), side=_direct(*rws, *rbs), bcast=4)
+        red = ops.zeros_red(x, n, cin)
+        ops.conv3d(dy, None, conv_w, None, k=3, cout=cin, groups=nm, transposed=True, epi=1, e=(x, None, sc, sh, LEAK, ctr), red=red,
+                   out=False, bcast=4)
+        ops.init_fold_bwd(red_x, cnt, n, init_w, red, diw)
+        return (None, None, *riw, *rib, *rws, *rbs)
+
+
+INIT_FOLD = [True]
+
+
+def set_init_fold(enabled):
+    """A/B switch: the init blocks folded into the first encoder conv (InitInLreluConv); off = the init convs' output is stored."""
+    INIT_FOLD[0] = bool(enabled)
+
+
+def init_fold_ok(x, init_w, conv_w):
+    """The fold applies: one input channel per init block and four output channels (a quad per modality), 16-bit storage on the
+    full-row kernels, no gradient wanted for x."""
+    return (INIT_FOLD[0] and x.is_cuda and not x.requires_grad and len(init_w) == x.shape[1] == len(conv_w)
+            and all(tuple(w.shape) == (4, 1, 1, 1, 1) for w in init_w)
+            and all(tuple(w.shape[:2]) == (4, 4) and w.shape[-1] == 3 for w in conv_w)
+            and ops.conv3d_supports_bcast(x, 4 * len(conv_w), len(conv_w)))
+
+
+def init_in_lrelu_conv(x, init_w, init_b, conv_w, conv_b):
+    """(y, output sums) of conv1(lrelu(IN(init(x)))) with the init blocks folded (InitInLreluConv)."""
+    return InitInLreluConv.apply(x, len(init_w), *init_w, *init_b, *conv_w, *conv_b)
+
+
 class GnConvRelu(Function):
     """SingleConv 'gcr' (buildingblocks.py:421-429): ReLU(Conv3d(GroupNorm(x))), no conv bias."""
 

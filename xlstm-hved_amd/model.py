@@ -406,12 +406,15 @@ class AbstractFusion3DUNet(nn.Module):
         ops.prepack_all()
         x = x.contiguous()
         levels = len(self.encoders)
-        X, st0 = Fn.conv(x, [b[0].weight for b in self.init_blocks], [b[0].bias for b in self.init_blocks], groups=4, out_stats=True,
-                         drop_bias=True)
         feat_list = []
         # level 0: the four streams' DoubleConv; its second conv and x0_init write the two parts of one buffer
         w, b = self._stream_weights(0, "SingleConv1")
-        Y, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0, out_stats=True, drop_bias=True)
+        iw, ib = [blk[0].weight for blk in self.init_blocks], [blk[0].bias for blk in self.init_blocks]
+        if Fn.init_fold_ok(x, iw, w):
+            Y, st = Fn.init_in_lrelu_conv(x, iw, ib, w, b)      # the init blocks' output is never stored (Fn.InitInLreluConv)
+        else:
+            X, st0 = Fn.conv(x, iw, ib, groups=4, out_stats=True, drop_bias=True)
+            Y, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0, out_stats=True, drop_bias=True)
         w, b = self._stream_weights(0, "SingleConv2")
         c4 = sum(t.shape[0] for t in w)
         c = c4 // 4
@@ -477,11 +480,14 @@ class AbstractFusion3DUNet(nn.Module):
         ops.prepack_all()                       # the MFMA weight fragments of every k=3 conv of the step: one launch per 24
         x = x.contiguous()
         st0 = None
-        if batched:
+        iw, ib = [blk[0].weight for blk in self.init_blocks], [blk[0].bias for blk in self.init_blocks]
+        fold = batched and Fn.init_fold_ok(x, iw, self._stream_weights(0, "SingleConv1")[0])
+        if fold:
+            X = x                                   # the init blocks are folded into level 0's first conv (Fn.InitInLreluConv)
+        elif batched:
             # level 0's first InstanceNorm takes its sums from here; it is the init blocks' only consumer, so their bias add
             # is an identity (drop_bias: a channel w*x + b with a small w would otherwise spend its 16-bit mantissa on b)
-            X, st0 = Fn.conv(x, [b[0].weight for b in self.init_blocks], [b[0].bias for b in self.init_blocks], groups=4,
-                             out_stats=True, drop_bias=True)
+            X, st0 = Fn.conv(x, iw, ib, groups=4, out_stats=True, drop_bias=True)
         else:
             X = [Fn.conv(x[:, i:i + 1].contiguous(), [b[0].weight], [b[0].bias]) for i, b in enumerate(self.init_blocks)]
         feat_list = []
@@ -502,8 +508,11 @@ class AbstractFusion3DUNet(nn.Module):
                     X = Fn.MaxPool2.apply(X)
                 # each conv's epilogue accumulates the channel sums the next InstanceNorm needs (no separate pass)
                 w, b = self._stream_weights(level, "SingleConv1")
-                X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0 if level == 0 else stp, out_stats=True,
-                                         drop_bias=True)                  # consumed by SingleConv2's InstanceNorm only
+                if level == 0 and fold:
+                    X, st = Fn.init_in_lrelu_conv(x, iw, ib, w, b)
+                else:
+                    X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st0 if level == 0 else stp, out_stats=True,
+                                             drop_bias=True)              # consumed by SingleConv2's InstanceNorm only
                 w, b = self._stream_weights(level, "SingleConv2")
                 X, st = Fn.in_lrelu_conv(X, None, w, b, 1, 4, in_stats=st, out_stats=True, sole_consumer=True)
                 drb = [m[0].conv for m in self.DRBs[level]]

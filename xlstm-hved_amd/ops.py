@@ -482,15 +482,20 @@ def set_norm_bwd_fold(enabled):
 
 
 def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=False, pre=None, act=ACT_NONE,
-           act_slope=LEAK, epi=0, e=None, red=None, out=None, in_stats=None, nb=None):
+           act_slope=LEAK, epi=0, e=None, red=None, out=None, in_stats=None, nb=None, bcast=0):
     """y = act(conv(pre(cat[xa, xb])) + b) [+ fused epilogue].  weights/biases: lists of 1 or `groups` fp32 tensors.
     pre = (sc, sh, slope); e = (ea, eb, e_sc, e_sh, e_slope) for epi==1.  `out` may be a channel slice.
     in_stats = (red, count, slope) instead of pre: InstanceNorm + LeakyReLU of the input from its raw channel sums; returns
     (y, sc, sh, mean, rstd).  On the MFMA path the finalisation rides on the weight-pack launch, else xh_norm_finalize runs.
     nb = (px, nb_red, mean, rstd, pd): xa is the masked data gradient g of the stage behind this conv and the conv's real input
     is that stage's InstanceNorm backward, A*g + C*px + B (xh_conv_desc.pre == 2): applied on load where the kernel can, and
-    stored into `pd` (a tensor of xa's shape) either way -- by this launch, or by an xh_in_bwd_apply pass in front of it."""
+    stored into `pd` (a tensor of xa's shape) either way -- by this launch, or by an xh_in_bwd_apply pass in front of it.
+    bcast = 4 (xh_conv_desc.bcast): a broadcast operand -- forward: xa has cin / 4 channels, each read by the four input channels of a
+    group through their own pre (sc, sh); transposed with epi == 1: e[0] has cout / 4 channels, and out=False stores nothing (the
+    masked gradient is only summed into `red`; returns None)."""
     lib = L.load()
+    if bcast and (xb is not None or nb is not None or in_stats is not None or bcast != 4 or (out is False and not (transposed and epi == 1))):
+        raise ValueError("conv3d: a broadcast operand takes one source, pre = (sc, sh, slope), bcast = 4")
     if nb is not None:
         px, nb_red, nb_mean, nb_rstd, pd = nb
         if xb is not None or pre is not None or in_stats is not None:
@@ -502,12 +507,13 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
             in_bwd_apply(xa, px, nb_red, nb_mean, nb_rstd, have_g=True, out=pd)
             xa, nb = pd, None
     n, ca, d, h, w, _ = _vol(xa)
-    _check_weights(weights, biases, ca + (xb.shape[1] if xb is not None else 0), cout, groups, k, transposed, "conv3d")
+    cin_l = ca * bcast if (bcast and not transposed) else ca + (xb.shape[1] if xb is not None else 0)     # logical input channels
+    _check_weights(weights, biases, cin_l, cout, groups, k, transposed, "conv3d")
     osp = _out_spatial(d, h, w, k, stride)
     if out is None:
         out = new_like(xa, (n, cout) + osp)
-    y_bs = _vol(out)[5]
-    if tuple(out.shape) != (n, cout) + osp or out.dtype != xa.dtype:
+    y_bs = _vol(out)[5] if out is not False else 0
+    if out is not False and (tuple(out.shape) != (n, cout) + osp or out.dtype != xa.dtype):
         raise ValueError(f"conv output tensor has shape {tuple(out.shape)}, expected {(n, cout) + osp}")
     stats = None
     if in_stats is not None:
@@ -515,6 +521,16 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
         stats = tuple(torch.empty((n, cin), dtype=torch.float32, device=xa.device) for _ in range(4))   # sc, sh, mean, rstd
         pre = (stats[0], stats[1], in_stats[2])
     desc = _conv_desc(xa, xb, k, stride, groups, cout, len(weights), transposed, pre, act, act_slope, epi, e, y_bs, osp)
+    if bcast:
+        desc.bcast = bcast
+        if transposed:
+            if e is None or e[0].shape[1] * bcast != cout or e[1] is not None or e[0].dtype != xa.dtype:
+                raise ValueError("conv3d: the broadcast e operand has cout / 4 channels and one source")
+            desc.Cea = cout
+        else:
+            desc.Cin = desc.Ca = cin_l
+        if pre is not None and (pre[0].numel() != n * cin_l or pre[1].numel() != n * cin_l):
+            raise ValueError("conv3d: pre of a broadcast input is per LOGICAL channel")
     ptrs = L.ConvPtrs()
     ptrs.xa, ptrs.xb = _p(xa), _p(xb)
     if nb is not None:
@@ -526,10 +542,12 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     ptrs.b = _arr4([_f32(t, "conv bias") for t in (biases or [])])
     if pre is not None:
         ptrs.pre_sc, ptrs.pre_sh = _p(_f32(pre[0], "pre_sc")), _p(_f32(pre[1], "pre_sh"))
-    ptrs.y = _p(out)
+    ptrs.y = _p(out) if out is not False else None
     if e is not None:
         ptrs.ea, ptrs.eb = _p(e[0]), _p(e[1])
         ptrs.e_sc, ptrs.e_sh = _p(_f32(e[2], "e_sc")), _p(_f32(e[3], "e_sh"))
+        if len(e) > 5 and e[5] is not None:                 # (broadcast e operand: the centre of the second sum)
+            ptrs.e_ctr = _p(_f32(e[5], "e_ctr"))
     if red is not None:
         ptrs.red = _p(red)
         if epi:
@@ -565,7 +583,42 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     L.check(lib.xh_conv3d_fwd(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_fwd")
     if stats is not None:
         return (out,) + stats
-    return out
+    return out if out is not False else None
+
+
+def conv3d_supports_bcast(x, cout, groups):
+    """True when the broadcast form of the k = 3 conv on x (x: one stored channel per group, 4 logical channels each; cout = 4 *
+    groups) is served in all three directions (xh_conv3d_supports_bcast)."""
+    if not (_MFMA[0] and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == groups and cout == 4 * groups):
+        return False
+    n, ca, d, h, w, bs = _vol(x)
+    desc = L.ConvDesc()
+    desc.dtype, desc.arith, desc.bcast = _dt(x), current_arith(), 4
+    desc.N, desc.Cin, desc.Cout, desc.groups = n, 4 * ca, cout, groups
+    desc.D, desc.H, desc.W, desc.Do, desc.Ho, desc.Wo = d, h, w, d, h, w
+    desc.k, desc.stride, desc.Ca = 3, 1, 4 * ca
+    desc.xa_bs, desc.y_bs, desc.n_wptr = bs, cout * d * h * w, groups
+    desc.pre, desc.pre_slope, desc.epi = 1, LEAK, 2
+    return bool(L.load().xh_conv3d_supports_bcast(C.byref(desc)))
+
+
+def init_fold_fwd(red_x, count, n, weights, eps=NORM_EPS):
+    """InstanceNorm of the init blocks' 1x1 convs as a per-channel affine of their INPUT (xh_init_fold_fwd): red_x (n, M, 2) the fp64
+    sums (sum x, sum x^2) of the M stored channels, weights: M tensors of B values (channel c = m * B + j computes w[m][j] * x_m +
+    bias; the bias drops out of the norm).  Returns (sc, sh, rstd, ctr), each (n, M * B): IN(w x + b) = sc * x + sh; ctr = the fp32
+    channel mean of x (the centre the data gradient's second sum is taken around)."""
+    m, b = len(weights), weights[0].numel()
+    sc, sh, rstd, ctr = (torch.empty((n, m * b), dtype=torch.float32, device=red_x.device) for _ in range(4))
+    L.check(L.load().xh_init_fold_fwd(_stream(), _p(red_x), int(count), n, m, b, C.byref(_arr4([_f32(t.reshape(-1), "init weight") for t in weights])),
+                                      float(eps), _p(sc), _p(sh), _p(rstd), _p(ctr)), "xh_init_fold_fwd")
+    return sc, sh, rstd, ctr
+
+
+def init_fold_bwd(red_x, count, n, weights, red_g, dws, eps=NORM_EPS):
+    """dws[m][j] += d loss / d w[m][j] from the data gradient's sums red_g (n, M * B, 2) = (sum g, sum g (x - ctr)) (xh_init_fold_bwd)."""
+    m, b = len(weights), weights[0].numel()
+    L.check(L.load().xh_init_fold_bwd(_stream(), _p(red_x), int(count), n, m, b, C.byref(_arr4([_f32(t.reshape(-1), "init weight") for t in weights])),
+                                      float(eps), _p(red_g), C.byref(_arr4([_f32(t.reshape(-1), "init dw") for t in dws]))), "xh_init_fold_bwd")
 
 
 _C1_COLLECT = [None]
@@ -683,12 +736,17 @@ def join_wgrad_stream():
     _WG["early_done"], _WG["maxvol"] = False, 0
 
 
-def _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre):
+def _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre, bcast=0):
     """Marshals one weight-gradient problem: (desc, ptrs, dw[4], db[4], keep-alive list)."""
     lib = L.load()
     n, cout, do, ho, wo, dy_bs = _vol(dy)
-    _check_weights(dws, dbs, xa.shape[1] + (xb.shape[1] if xb is not None else 0), cout, groups, k, False, "conv3d_wgrad")
+    cin_l = xa.shape[1] * bcast if bcast else xa.shape[1] + (xb.shape[1] if xb is not None else 0)
+    if bcast and (xb is not None or bcast != 4):
+        raise ValueError("conv3d_wgrad: a broadcast input is one source, bcast = 4")
+    _check_weights(dws, dbs, cin_l, cout, groups, k, False, "conv3d_wgrad")
     desc = _conv_desc(xa, xb, k, stride, groups, cout, len(dws), False, pre, ACT_NONE, LEAK, 0, None, 0, (do, ho, wo))
+    if bcast:
+        desc.bcast, desc.Cin, desc.Ca = bcast, cin_l, cin_l
     desc.ea_bs = dy_bs
     ptrs = L.ConvPtrs()
     ptrs.xa, ptrs.xb, ptrs.ea = _p(xa), _p(xb), _p(dy)
@@ -706,7 +764,7 @@ def _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre):
     return desc, ptrs, dw, db, keep
 
 
-def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=False):
+def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=False, bcast=0):
     """Accumulates into the fp32 tensors dws (and dbs, may be None) the weight/bias gradients.  side=True: the targets are
     long-lived gradient buffers, so the call may be deferred and batched (set_wgrad_defer) or go to the weight-gradient
     stream (set_wgrad_overlap)."""
@@ -714,15 +772,15 @@ def conv3d_wgrad(xa, xb, dy, dws, dbs, *, k, stride=1, groups=1, pre=None, side=
         vol = dy.shape[2] * dy.shape[3] * dy.shape[4]
         if _WG["early"] and not _WG["early_done"] and _WG["deferred"] and vol * 64 <= _WG["maxvol"]:
             _flush_deferred_early(xa.device)
-        _WG["deferred"].append(_wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre))
+        _WG["deferred"].append(_wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre, bcast))
         _WG["maxvol"] = max(_WG["maxvol"], vol)
         return
     if side and _WG["on"] and xa.is_cuda:
-        _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre), current_arith()))
+        _WG["pending"].append((xa, xb, dy, dws, dbs, dict(k=k, stride=stride, groups=groups, pre=pre, bcast=bcast), current_arith()))
         if len(_WG["pending"]) >= _WG["batch"]:
             _flush_wgrads()
         return
-    desc, ptrs, dw, db, keep = _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre)
+    desc, ptrs, dw, db, keep = _wgrad_call(xa, xb, dy, dws, dbs, k, stride, groups, pre, bcast)
     if _WG["forked"]:
         _WG["keep"].append(keep)
     L.check(L.load().xh_conv3d_wgrad(_stream(), C.byref(desc), C.byref(ptrs), C.byref(dw), C.byref(db)), "xh_conv3d_wgrad")
