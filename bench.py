@@ -863,14 +863,19 @@ def roofline_pass(step, ops, nsteps, dtype):
         if not collected:
             e1.record()
         y = res[0] if isinstance(res, tuple) else res         # (y, sc, sh, mean, rstd) when the norm finalisation is fused
-        cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
+        bc = kw.get("bcast", 0)                               # broadcast operand: the tensor read has a quarter of the logical channels
+        cin = xa.shape[1] * (bc if bc and not kw.get("transposed") else 1) + (xb.shape[1] if xb is not None else 0)
         k, groups = kw["k"], kw.get("groups", 1)
         in_el = xa.numel() + (xb.numel() if xb is not None else 0)
-        e_el = y.numel() if kw.get("epi", 0) == 1 else 0          # epi 1 also reads the saved activation once
-        nbytes = (in_el + y.numel() + e_el) * esz + sum(w.numel() for w in weights) * 4
-        flops = 2.0 * y.numel() * k ** 3 * cin / groups
-        shape = (f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{y.shape[1]} @{'x'.join(map(str, y.shape[2:]))}"
-                 + (" dgrad" if kw.get("transposed") else ""))
+        cout_l = kw["cout"]
+        out_sp = tuple(y.shape[2:]) if y is not None else tuple(xa.shape[2:])
+        vox = xa.shape[0] * out_sp[0] * out_sp[1] * out_sp[2]
+        y_el = y.numel() if y is not None else 0              # (a data gradient that only sums stores nothing)
+        e_el = (kw["e"][0].numel() if bc else cout_l * vox) if kw.get("epi", 0) == 1 else 0     # epi 1 also reads the saved activation once
+        nbytes = (in_el + y_el + e_el) * esz + sum(w.numel() for w in weights) * 4
+        flops = 2.0 * cout_l * vox * k ** 3 * cin / groups
+        shape = (f"k{k} s{kw.get('stride', 1)} g{groups} {cin}->{cout_l} @{'x'.join(map(str, out_sp))}"
+                 + (" dgrad" if kw.get("transposed") else "") + (" bcast" if bc else ""))
         if collected and ops._C1_COLLECT[0] is not None and len(ops._C1_COLLECT[0]) > n_before:
             c1_meta.append((nbytes, flops, shape))
             return res
@@ -898,7 +903,7 @@ def roofline_pass(step, ops, nsteps, dtype):
     pending_meta = []
 
     def timed_wg(xa, xb, dy, dws, dbs, **kw):
-        cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
+        cin = xa.shape[1] * (kw.get("bcast", 0) or 1) + (xb.shape[1] if xb is not None else 0)
         k, groups = kw["k"], kw.get("groups", 1)
         in_el = xa.numel() + (xb.numel() if xb is not None else 0)
         nbytes = (in_el + dy.numel()) * esz + sum(w.numel() for w in dws) * 4
@@ -914,7 +919,7 @@ def roofline_pass(step, ops, nsteps, dtype):
             if cg == 1 and og == 1 and groups % 4 == 0:          # depthwise: groups of 4 with diagonal blocks (wgrad_q4 plan)
                 cg = og = 4
             q4 = (k3 and w_ % 32 == 0 and cg % 4 == 0 and og % 4 == 0 and cg <= 48 and og <= 48 and xa.shape[2] >= 4
-                  and xa.shape[3] >= 4 and xa.shape[1] % 4 == 0)
+                  and xa.shape[3] >= 4 and (xa.shape[1] % 4 == 0 or kw.get("bcast")))
             mfma = k3 and (w_ % 32 == 0 or w_ in (8, 16)) and cg >= 4
             qs = cg // 4
             qs = qs if qs <= 3 else 3 if qs % 3 == 0 else 2 if qs % 2 == 0 else 1      # input quads per unit (wgrad_q4 plan)

@@ -708,6 +708,20 @@ int xh_dconv_cl(void* stream, int dtype, int mode, int stride, int ks, const voi
  * [N][Di..][Cs], dy [N][Do..][Cn]; Cs, Cn multiples of 8. */
 int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, const void* x, const void* dy, float* dwp, int N, int Di, int Hi,
                       int Wi, int Do, int Ho, int Wo, int Cs, int Cn);
+/* The discriminator's head, `last` = Conv3d(C, 1, ks, stride 1, padding 1, bias=False) (RA_HVED.py:223): ONE output channel is a
+ * C * ks^3-long dot product per voxel, a reduction rather than a GEMM (as a 16-column MFMA tile the three passes ran at 0.002 of the
+ * matrix peak: 37-97 us each, latency of a few workgroups).  x [N][Di..][C] channels-last 16-bit, C a multiple of 512 (a wave's 64
+ * lanes x 8 channels); wp = the mode-0 image of the weight, [ks^3][C] 16-bit (xh_dconv_pack with Cout = 1); y / dy [N][Do..] 16-bit.
+ *   xh_dlast_fwd:   y[o] = sum_{tap, c} wp[tap][c] x[o + tap - 1][c]                       (fp32 accumulation)
+ *   xh_dlast_dgrad: dx[i][c] = sum_tap dy[i + 1 - tap] wp[tap][c]
+ *   xh_dlast_wgrad: dw[0][c][tap] += scale * sum_{n, o} dy[n][o] x[n][o + tap - 1][c]      (dw: the fp32 PARAMETER layout [1][C][ks^3],
+ *                   accumulated in place: no packed temporary, no unpack launch) */
+int xh_dlast_fwd(void* stream, int dtype, int ks, const void* x, const void* wp, void* y, int N, int Di, int Hi, int Wi, int Do, int Ho,
+                 int Wo, int C);
+int xh_dlast_dgrad(void* stream, int dtype, int ks, const void* dy, const void* wp, void* dx, int N, int Di, int Hi, int Wi, int Do, int Ho,
+                   int Wo, int C);
+int xh_dlast_wgrad(void* stream, int dtype, int ks, const void* x, const void* dy, float* dw, float scale, int N, int Di, int Hi, int Wi,
+                   int Do, int Ho, int Wo, int C);
 /* fp32 nn.Conv3d weight [Cout][Cin][ks^3] -> 16-bit operand image.  mode 0: [ks^3][Cout][CinPad]; mode 1: [ks^3][CinPad][CoutPad];
  * mode 2 (CinPad == 8): [ks^2][Cout][32] (k = kw * 8 + ci).  xh_dconv_unpack_grad: dw[Cout][Cin][ks^3] += dwp[ks^3][CoutPad][CinPad]. */
 int xh_dconv_pack(void* stream, int dtype, int mode, int ks, const float* w, void* out, int Cout, int Cin, int CoutPad, int CinPad);

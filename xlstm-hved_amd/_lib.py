@@ -140,6 +140,9 @@ SIGNATURES = {
     "xh_in_bwd_apply2": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I]),
     "xh_norm_bwd_apply": (I, [vp, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, vp, vp, I, vp, vp, F, I]),
     "xh_norm_bwd_fused": (I, [vp, I, I, vp, ll, vp, ll, vp, ll, I, I, ll, vp, I, vp, vp, vp, vp, vp]),
+    "xh_dlast_fwd": (I, [vp, I, I, vp, vp, vp, I, I, I, I, I, I, I, I]),
+    "xh_dlast_dgrad": (I, [vp, I, I, vp, vp, vp, I, I, I, I, I, I, I, I]),
+    "xh_dlast_wgrad": (I, [vp, I, I, vp, vp, vp, F, I, I, I, I, I, I, I, I]),
     "xh_dconv_exact": (I, [vp, I, vp, vp, vp, vp, I, I, I, I, I, I, I, I, I, I, I]),
     "xh_norm_bwd_fused2": (I, [vp, I, I, vp, ll, vp, ll, vp, ll, I, I, I, ll, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xh_bn_affine_act2": (I, [vp, I, I, vp, ll, vp, ll, I, I, I, ll, vp, F, vp, vp, vp, vp, vp, vp, vp, vp, I, I, F, vp, vp, vp, vp]),

@@ -359,7 +359,7 @@ int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a) {
   // 512 workgroups are resident at once.  Rows of 64 voxels: launches between one and three rounds keep the 32-wide tiles, whose
   // 256-thread workgroups quantise better (20 -> 20 g5 @64^3: 640 workgroups = 1.25 rounds here, 12.6 -> 13.6 us; 8 -> 8, 16 -> 16 g2,
   // 24 -> 8 fit one round: 13.2 -> 10.1, 17.7 -> 13.6, 22.3 -> 18.6 us)
-  if (nh == 1 && nwg > 512 && nwg < 1536 && !(a.abl & 262144)) return 1;
+  if (nh == 1 && nwg > 512 && nwg < 1536 && !(a.abl & 262144) && !a.d.bcast) return 1;      // (a broadcast operand is read here only)
   a.fan = a.d.epi ? xh_fan_block(a.p.fan, a.p.fan_bytes, (long long)grid.y * grid.z, grid.x) : nullptr;
   // The fan-in ends every workgroup with a returning-atomic round trip: worth it when the launch is ONE resident round (512
   // workgroups: the tail of same-line atomics is exposed: 4 -> 4 @128^3 data gradient 18.3 -> 17.1 us), a loss when later rounds

@@ -1965,6 +1965,187 @@ extern "C" int xh_dconv_wgrad_cl(void* stream, int dtype, int stride, int ks, co
   return xh_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The head: Conv3d(C, 1, ks, stride 1, padding 1, bias=False) (RA_HVED.py:223) as three reduction kernels (xlstm_hved.h: xh_dlast_*).
+// A wave owns 4 consecutive voxels of a row; lane l holds channels 8 l .. 8 l + 7 of each 512-channel chunk (one 16-byte load per
+// voxel and chunk); fp32 arithmetic on 16-bit operands.
+template <int FMT> __device__ __forceinline__ void dl_cvt8(const uint4& u, float (&o)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { o[2 * k] = cvt_lo<FMT>(w[k]); o[2 * k + 1] = cvt_hi<FMT>(w[k]); }
+}
+constexpr int DL_OW = 4;
+template <int FMT>
+__global__ __launch_bounds__(256) void dlast_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ wp, u16* __restrict__ y, int N, int Di,
+                                                       int Hi, int Wi, int Do, int Ho, int Wo, int C, int K) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gw = (Wo + DL_OW - 1) / DL_OW;
+  if (wave >= (long long)N * Do * Ho * gw) return;
+  const int owg = (int)(wave % gw); long long t = wave / gw;
+  const int oh = (int)(t % Ho); t /= Ho;
+  const int od = (int)(t % Do); const int n = (int)(t / Do);
+  const int ow0 = owg * DL_OW;
+  float acc[DL_OW] = {0.f, 0.f, 0.f, 0.f};
+  for (int kd = 0; kd < K; ++kd) {
+    const int id = od - 1 + kd;
+    if ((unsigned)id >= (unsigned)Di) continue;
+    for (int kh = 0; kh < K; ++kh) {
+      const int ih = oh - 1 + kh;
+      if ((unsigned)ih >= (unsigned)Hi) continue;
+      const u16* row = x + (((long long)n * Di + id) * Hi + ih) * (long long)Wi * C;
+      for (int c0 = lane * 8; c0 < C; c0 += 512) {
+        float xs[DL_OW + 3][8];                                   // columns ow0 - 1 .. ow0 + DL_OW + K - 3 (K <= 4)
+#pragma unroll
+        for (int s = 0; s < DL_OW + 3; ++s) {
+          const int iw = ow0 - 1 + s;
+          uint4 u = make_uint4(0, 0, 0, 0);
+          if (s < DL_OW + K - 1 && (unsigned)iw < (unsigned)Wi) u = *reinterpret_cast<const uint4*>(row + (long long)iw * C + c0);
+          dl_cvt8<FMT>(u, xs[s]);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          if (kw >= K) break;
+          float wv[8];
+          dl_cvt8<FMT>(*reinterpret_cast<const uint4*>(wp + (long long)((kd * K + kh) * K + kw) * C + c0), wv);
+#pragma unroll
+          for (int o = 0; o < DL_OW; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o] = fmaf(xs[o + kw][e], wv[e], acc[o]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < DL_OW; ++o) {
+    const float s = wave_sum(acc[o]);
+    if (lane == 0 && ow0 + o < Wo) y[(((long long)n * Do + od) * Ho + oh) * Wo + ow0 + o] = cvt_out<FMT>(s);
+  }
+}
+template <int FMT>
+__global__ __launch_bounds__(256) void dlast_dgrad_kernel(const u16* __restrict__ dy, const u16* __restrict__ wp, u16* __restrict__ dx, int N,
+                                                         int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int K) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gw = (Wi + DL_OW - 1) / DL_OW;
+  if (wave >= (long long)N * Di * Hi * gw) return;
+  const int iwg = (int)(wave % gw); long long t = wave / gw;
+  const int ih = (int)(t % Hi); t /= Hi;
+  const int id = (int)(t % Di); const int n = (int)(t / Di);
+  const int iw0 = iwg * DL_OW;
+  for (int c0 = lane * 8; c0 < C; c0 += 512) {
+    float acc[DL_OW][8];
+#pragma unroll
+    for (int v = 0; v < DL_OW; ++v)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[v][e] = 0.f;
+    for (int kd = 0; kd < K; ++kd) {
+      const int od = id + 1 - kd;
+      if ((unsigned)od >= (unsigned)Do) continue;
+      for (int kh = 0; kh < K; ++kh) {
+        const int oh = ih + 1 - kh;
+        if ((unsigned)oh >= (unsigned)Ho) continue;
+        const u16* drow = dy + (((long long)n * Do + od) * Ho + oh) * Wo;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          if (kw >= K) break;
+          float wv[8];
+          dl_cvt8<FMT>(*reinterpret_cast<const uint4*>(wp + (long long)((kd * K + kh) * K + kw) * C + c0), wv);
+#pragma unroll
+          for (int v = 0; v < DL_OW; ++v) {
+            const int ow = iw0 + v + 1 - kw;
+            const float g = (unsigned)ow < (unsigned)Wo ? cvt_in<FMT>(drow[ow]) : 0.f;       // (one address per wave: a broadcast load)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[v][e] = fmaf(g, wv[e], acc[v][e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < DL_OW; ++v) {
+      if (iw0 + v >= Wi) break;
+      uint4 o;
+      o.x = cvt_pack<FMT>(acc[v][0], acc[v][1]); o.y = cvt_pack<FMT>(acc[v][2], acc[v][3]);
+      o.z = cvt_pack<FMT>(acc[v][4], acc[v][5]); o.w = cvt_pack<FMT>(acc[v][6], acc[v][7]);
+      *reinterpret_cast<uint4*>(dx + ((((long long)n * Di + id) * Hi + ih) * Wi + iw0 + v) * (long long)C + c0) = o;
+    }
+  }
+}
+// grid (ks^3 taps, splits of the output voxels); the four waves of a workgroup take interleaved voxels, are summed in LDS, and one
+// lane per channel adds into the parameter gradient
+template <int FMT>
+__global__ __launch_bounds__(256) void dlast_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ dw, float scale,
+                                                         int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int K) {
+  __shared__ float s_acc[3][512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tap = blockIdx.x, kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
+  const long long M = (long long)N * Do * Ho * Wo;
+  const long long per = (M + gridDim.y - 1) / gridDim.y;
+  const long long m0 = per * blockIdx.y, m1 = m0 + per < M ? m0 + per : M;
+  for (int c0 = lane * 8; c0 < C; c0 += 512) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long m = m0 + wv; m < m1; m += 4) {
+      const int ow = (int)(m % Wo); long long t = m / Wo;
+      const int oh = (int)(t % Ho); t /= Ho;
+      const int od = (int)(t % Do); const int n = (int)(t / Do);
+      const int id = od - 1 + kd, ih = oh - 1 + kh, iw = ow - 1 + kw;
+      if ((unsigned)id >= (unsigned)Di || (unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) continue;
+      const float g = cvt_in<FMT>(dy[m]);
+      float xv[8];
+      dl_cvt8<FMT>(*reinterpret_cast<const uint4*>(x + ((((long long)n * Di + id) * Hi + ih) * Wi + iw) * (long long)C + c0), xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(g, xv[e], acc[e]);
+    }
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_acc[wv - 1][lane * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float s = acc[e] + s_acc[0][lane * 8 + e] + s_acc[1][lane * 8 + e] + s_acc[2][lane * 8 + e];
+        atomicAdd(&dw[(long long)(c0 + e) * (K * K * K) + tap], s * scale);
+      }
+    }
+  }
+}
+static bool dlast_ok(int dtype, int ks, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C) {
+  if ((dtype != XH_BF16 && dtype != XH_F16) || (ks != 3 && ks != 4) || N <= 0 || C <= 0 || C % 512) return false;
+  if (Do != Di + 2 - ks + 1 || Ho != Hi + 2 - ks + 1 || Wo != Wi + 2 - ks + 1 || Do <= 0 || Ho <= 0 || Wo <= 0) return false;
+  return (long long)N * Di * Hi * Wi * C < (1ll << 40);
+}
+extern "C" int xh_dlast_fwd(void* stream, int dtype, int ks, const void* x, const void* wp, void* y, int N, int Di, int Hi, int Wi, int Do,
+                            int Ho, int Wo, int C) {
+  if (!x || !wp || !y || !dlast_ok(dtype, ks, N, Di, Hi, Wi, Do, Ho, Wo, C)) return XH_ERR_ARG;
+  const long long waves = (long long)N * Do * Ho * cdiv(Wo, DL_OW);
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  if (dtype == XH_F16) hipLaunchKernelGGL(dlast_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)wp, (u16*)y, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  else hipLaunchKernelGGL(dlast_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)wp, (u16*)y, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  return xh_launch_status();
+}
+extern "C" int xh_dlast_dgrad(void* stream, int dtype, int ks, const void* dy, const void* wp, void* dx, int N, int Di, int Hi, int Wi, int Do,
+                              int Ho, int Wo, int C) {
+  if (!dy || !wp || !dx || !dlast_ok(dtype, ks, N, Di, Hi, Wi, Do, Ho, Wo, C)) return XH_ERR_ARG;
+  const long long waves = (long long)N * Di * Hi * cdiv(Wi, DL_OW);
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  if (dtype == XH_F16) hipLaunchKernelGGL(dlast_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, (const u16*)wp, (u16*)dx, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  else hipLaunchKernelGGL(dlast_dgrad_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, (const u16*)wp, (u16*)dx, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  return xh_launch_status();
+}
+extern "C" int xh_dlast_wgrad(void* stream, int dtype, int ks, const void* x, const void* dy, float* dw, float scale, int N, int Di, int Hi,
+                              int Wi, int Do, int Ho, int Wo, int C) {
+  if (!x || !dy || !dw || !dlast_ok(dtype, ks, N, Di, Hi, Wi, Do, Ho, Wo, C)) return XH_ERR_ARG;
+  const long long M = (long long)N * Do * Ho * Wo;
+  int splits = (int)(M / 256 > 0 ? M / 256 : 1);          // >= 64 voxels per wave; ks^3 x splits workgroups
+  if (splits > 8) splits = 8;
+  const dim3 grid(ks * ks * ks, splits);
+  if (dtype == XH_F16) hipLaunchKernelGGL(dlast_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy, dw, scale, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  else hipLaunchKernelGGL(dlast_wgrad_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy, dw, scale, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  return xh_launch_status();
+}
+
 extern "C" int xh_dconv_pack(void* stream, int dtype, int mode, int ks, const float* w, void* out, int Cout, int Cin, int CoutPad, int CinPad) {
   if (!w || !out || mode < 0 || mode > 2 || CoutPad < Cout || CinPad < Cin || (ks != 3 && ks != 4)) return XH_ERR_ARG;
   if (mode == 2 && CinPad != 8) return XH_ERR_ARG;

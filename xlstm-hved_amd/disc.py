@@ -136,6 +136,17 @@ def _alloc(nb, sp, chans, dt, dev):
     return b
 
 
+HEAD = [True]                      # A/B switch: the head (C -> 1) through the reduction kernels xh_dlast_* instead of 16-column GEMM tiles
+
+
+def set_head_kernels(enabled):
+    HEAD[0] = bool(enabled)
+
+
+def _head_ok(wl):
+    return HEAD[0] and wl.shape[0] == 1 and wl.shape[1] % 512 == 0 and wl.is_contiguous()
+
+
 def _conv_into(y, x, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, red=None, act=L.ACT_NONE, ks=3, mask=None):
     L.check(L.load().xh_dconv_cl(_s(), ops._dt(x), mode, stride, ks, x.data_ptr(), wp.data_ptr(), ops._p(bias), y.data_ptr(), ops._p(red), n,
                                  *sp_in, *sp_out, cs, cn, act, SLOPE, ops._p(mask)), "xh_dconv_cl")
@@ -165,7 +176,12 @@ def _forward(x, params, bufs, lo, sp, ks):
         a = bufs["acts"][k][sl]
         L.check(lib.xh_cl_affine_act(_s(), ops._dt(c), c.data_ptr(), a.data_ptr(), sc.data_ptr(), sh.data_ptr(), SLOPE, n, cn, cnt),
                 "xh_cl_affine_act")
-    _conv_into(bufs["out"][sl], bufs["acts"][3][sl], _pack_cached(wl, 0, 1, wl.shape[1], dt), None, 0, 1, n, sp[4], sp[5], wl.shape[1], 1, ks=ks)
+    if _head_ok(wl):
+        # the head (one output channel): a dot product per voxel, not a GEMM (xh_dlast_fwd)
+        L.check(lib.xh_dlast_fwd(_s(), ops._dt(x), ks, bufs["acts"][3][sl].data_ptr(), _pack_cached(wl, 0, 1, wl.shape[1], dt).data_ptr(),
+                                 bufs["out"][sl].data_ptr(), n, *sp[4], *sp[5], wl.shape[1]), "xh_dlast_fwd")
+    else:
+        _conv_into(bufs["out"][sl], bufs["acts"][3][sl], _pack_cached(wl, 0, 1, wl.shape[1], dt), None, 0, 1, n, sp[4], sp[5], wl.shape[1], 1, ks=ks)
     return bufs["out"][sl]
 
 
@@ -183,13 +199,23 @@ def _backward(bufs, lo, n, sp, ks, dt, cin, weights, params, dout, need_w, need_
     else:
         gbufs, rets = [None] * 9, [None] * 9
     g_w0, g_b0, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wl = gbufs
-    # last conv (512 -> 1): its single gradient channel is padded to 32 so that it is a K step of the GEMMs
-    dy = torch.zeros((n,) + sp[5] + (32,), dtype=dt, device=dev)
-    dy[..., 0] = (dout.reshape((n,) + sp[5]) * gs if gs is not None else dout.reshape((n,) + sp[5])).to(dt)
     c3 = wl.shape[1]
-    if need_w:
-        _unpack(_wgrad(acts[3], dy, 1, n, sp[4], sp[5], c3, 32, ks=ks, gs=gs), g_wl, 32, c3)
-    da = _conv(dy, _pack_cached(wl, 1, 32, c3, dt), None, 1, 1, n, sp[5], sp[4], 32, c3, ks=ks)
+    if _head_ok(wl):
+        # the head's backward as two reduction kernels (xh_dlast_wgrad adds straight into the parameter gradient; xh_dlast_dgrad)
+        dy1 = (dout.reshape((n,) + sp[5]) * gs if gs is not None else dout.reshape((n,) + sp[5])).to(dt).contiguous()
+        if need_w:
+            L.check(lib.xh_dlast_wgrad(_s(), ops._dt(dy1), ks, acts[3].data_ptr(), dy1.data_ptr(), g_wl.data_ptr(),
+                                       1.0 / gs if gs is not None else 1.0, n, *sp[4], *sp[5], c3), "xh_dlast_wgrad")
+        da = torch.empty((n,) + tuple(sp[4]) + (c3,), dtype=dt, device=dev)
+        L.check(lib.xh_dlast_dgrad(_s(), ops._dt(dy1), ks, dy1.data_ptr(), _pack_cached(wl, 0, 1, c3, dt).data_ptr(), da.data_ptr(), n,
+                                   *sp[4], *sp[5], c3), "xh_dlast_dgrad")
+    else:
+        # (other widths: the single gradient channel padded to 32 so that it is a K step of the GEMMs)
+        dy = torch.zeros((n,) + sp[5] + (32,), dtype=dt, device=dev)
+        dy[..., 0] = (dout.reshape((n,) + sp[5]) * gs if gs is not None else dout.reshape((n,) + sp[5])).to(dt)
+        if need_w:
+            _unpack(_wgrad(acts[3], dy, 1, n, sp[4], sp[5], c3, 32, ks=ks, gs=gs), g_wl, 32, c3)
+        da = _conv(dy, _pack_cached(wl, 1, 32, c3, dt), None, 1, 1, n, sp[5], sp[4], 32, c3, ks=ks)
     dc = None
     for k, wk, g_w in ((3, w3, g_w3), (2, w2, g_w2), (1, w1, g_w1)):
         cs, cn = wk.shape[1], wk.shape[0]
