@@ -15,7 +15,7 @@ BENCH="bench.py --steps 20 --warmup 5 --inner 1 --no-cpu --no-roofline --no-mode
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $BENCH > $OUT/trace.log 2>&1
 echo "trace done"
 # steps under the profiler: 2 eager warm-up + 1 capture + (warmup + steps) replays
-python3 tools/summarize_rocprof.py $OUT/trace gpurun_out/profiles_out/${TAG}_bench_graph_bf16_kernel_stats.md --steps 28 --title "Round 5 ($TAG): bench.py bf16, hipGraph replay, 128^3 patch" --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 $BENCH  (2 eager + 1 capture + 25 replayed steps)" >> $OUT/trace.log 2>&1 || echo "summarize_rocprof failed"
+python3 tools/summarize_rocprof.py $OUT/trace gpurun_out/profiles_out/${TAG}_bench_graph_bf16_kernel_stats.md --steps 28 --title "Round 6 ($TAG): bench.py bf16, hipGraph replay, 128^3 patch" --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 $BENCH  (2 eager + 1 capture + 25 replayed steps)" >> $OUT/trace.log 2>&1 || echo "summarize_rocprof failed"
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) gpurun_out/profiles_out/${TAG}_bench_graph_bf16_kernel_stats.csv
 python3 tools/timeline_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) gpurun_out/profiles_out/step_families.json "profiles/${TAG}_timeline.txt: rocprofv3 --kernel-trace -- python3 $BENCH, last replayed step (tools/timeline_step.py)" > gpurun_out/profiles_out/${TAG}_timeline.txt 2>&1 || true
 python3 tools/dump_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > gpurun_out/profiles_out/${TAG}_launches.txt 2>&1 || true

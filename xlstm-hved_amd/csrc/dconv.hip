@@ -1975,9 +1975,13 @@ template <int FMT> __device__ __forceinline__ void dl_cvt8(const uint4& u, float
   for (int k = 0; k < 4; ++k) { o[2 * k] = cvt_lo<FMT>(w[k]); o[2 * k + 1] = cvt_hi<FMT>(w[k]); }
 }
 constexpr int DL_OW = 4;
-template <int FMT>
+// Branch-free bodies with K a template argument, walking the K^2 (kd, kh) rows TWO at a time in a rolled loop: a row outside the
+// volume reads a clamped address and is multiplied by zero, so the loads of two rows (22 pieces of 16 bytes) are in flight together.
+// (With `continue` on the bounds every row was one exposed memory latency: 26 us for 16 steps; fully unrolled the compiler hoisted
+// every load and the kernels took 256 registers, the data gradient spilling 539.)
+template <int FMT, int K>
 __global__ __launch_bounds__(256) void dlast_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ wp, u16* __restrict__ y, int N, int Di,
-                                                       int Hi, int Wi, int Do, int Ho, int Wo, int C, int K) {
+                                                       int Hi, int Wi, int Do, int Ho, int Wo, int C) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int gw = (Wo + DL_OW - 1) / DL_OW;
@@ -1986,28 +1990,41 @@ __global__ __launch_bounds__(256) void dlast_fwd_kernel(const u16* __restrict__ 
   const int oh = (int)(t % Ho); t /= Ho;
   const int od = (int)(t % Do); const int n = (int)(t / Do);
   const int ow0 = owg * DL_OW;
+  constexpr int NS = DL_OW + K - 1;
   float acc[DL_OW] = {0.f, 0.f, 0.f, 0.f};
-  for (int kd = 0; kd < K; ++kd) {
-    const int id = od - 1 + kd;
-    if ((unsigned)id >= (unsigned)Di) continue;
-    for (int kh = 0; kh < K; ++kh) {
-      const int ih = oh - 1 + kh;
-      if ((unsigned)ih >= (unsigned)Hi) continue;
-      const u16* row = x + (((long long)n * Di + id) * Hi + ih) * (long long)Wi * C;
-      for (int c0 = lane * 8; c0 < C; c0 += 512) {
-        float xs[DL_OW + 3][8];                                   // columns ow0 - 1 .. ow0 + DL_OW + K - 3 (K <= 4)
+  float cm[NS];                                           // column masks
 #pragma unroll
-        for (int s = 0; s < DL_OW + 3; ++s) {
-          const int iw = ow0 - 1 + s;
-          uint4 u = make_uint4(0, 0, 0, 0);
-          if (s < DL_OW + K - 1 && (unsigned)iw < (unsigned)Wi) u = *reinterpret_cast<const uint4*>(row + (long long)iw * C + c0);
-          dl_cvt8<FMT>(u, xs[s]);
+  for (int s = 0; s < NS; ++s) cm[s] = (unsigned)(ow0 - 1 + s) < (unsigned)Wi ? 1.f : 0.f;
+  for (int c0 = lane * 8; c0 < C; c0 += 512) {
+#pragma unroll 1
+    for (int t2 = 0; t2 < (K * K + 1) / 2; ++t2) {
+      uint4 xr[2][NS], wr[2][K];
+      float rm[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tt = min(2 * t2 + h, K * K - 1), kd = tt / K, kh = tt - kd * K;
+        const int id = od - 1 + kd, ih = oh - 1 + kh;
+        rm[h] = (2 * t2 + h < K * K && (unsigned)id < (unsigned)Di && (unsigned)ih < (unsigned)Hi) ? 1.f : 0.f;
+        const u16* row = x + (((long long)n * Di + min(max(id, 0), Di - 1)) * Hi + min(max(ih, 0), Hi - 1)) * (long long)Wi * C + c0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) xr[h][s] = *reinterpret_cast<const uint4*>(row + (long long)min(max(ow0 - 1 + s, 0), Wi - 1) * C);
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wr[h][kw] = *reinterpret_cast<const uint4*>(wp + (long long)(tt * K + kw) * C + c0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float xs[NS][8];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          dl_cvt8<FMT>(xr[h][s], xs[s]);
+          const float m = cm[s] * rm[h];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xs[s][e] *= m;
         }
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-          if (kw >= K) break;
+        for (int kw = 0; kw < K; ++kw) {
           float wv[8];
-          dl_cvt8<FMT>(*reinterpret_cast<const uint4*>(wp + (long long)((kd * K + kh) * K + kw) * C + c0), wv);
+          dl_cvt8<FMT>(wr[h][kw], wv);
 #pragma unroll
           for (int o = 0; o < DL_OW; ++o)
 #pragma unroll
@@ -2022,9 +2039,9 @@ __global__ __launch_bounds__(256) void dlast_fwd_kernel(const u16* __restrict__ 
     if (lane == 0 && ow0 + o < Wo) y[(((long long)n * Do + od) * Ho + oh) * Wo + ow0 + o] = cvt_out<FMT>(s);
   }
 }
-template <int FMT>
+template <int FMT, int K>
 __global__ __launch_bounds__(256) void dlast_dgrad_kernel(const u16* __restrict__ dy, const u16* __restrict__ wp, u16* __restrict__ dx, int N,
-                                                         int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int K) {
+                                                         int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int gw = (Wi + DL_OW - 1) / DL_OW;
@@ -2033,33 +2050,45 @@ __global__ __launch_bounds__(256) void dlast_dgrad_kernel(const u16* __restrict_
   const int ih = (int)(t % Hi); t /= Hi;
   const int id = (int)(t % Di); const int n = (int)(t / Di);
   const int iw0 = iwg * DL_OW;
+  constexpr int NS = DL_OW + K - 1;
   for (int c0 = lane * 8; c0 < C; c0 += 512) {
     float acc[DL_OW][8];
 #pragma unroll
     for (int v = 0; v < DL_OW; ++v)
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[v][e] = 0.f;
-    for (int kd = 0; kd < K; ++kd) {
-      const int od = id + 1 - kd;
-      if ((unsigned)od >= (unsigned)Do) continue;
-      for (int kh = 0; kh < K; ++kh) {
-        const int oh = ih + 1 - kh;
-        if ((unsigned)oh >= (unsigned)Ho) continue;
-        const u16* drow = dy + (((long long)n * Do + od) * Ho + oh) * Wo;
+#pragma unroll 1
+    for (int t2 = 0; t2 < (K * K + 1) / 2; ++t2) {
+      uint4 wr[2][K];
+      float g[2][NS];                                     // dY row (od, oh), columns iw0 + 1 - (K - 1) .. iw0 + DL_OW (one address per wave: broadcast loads)
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-          if (kw >= K) break;
+      for (int h = 0; h < 2; ++h) {
+        const int tt = min(2 * t2 + h, K * K - 1), kd = tt / K, kh = tt - kd * K;
+        const int od = id + 1 - kd, oh = ih + 1 - kh;
+        const bool rok = 2 * t2 + h < K * K && (unsigned)od < (unsigned)Do && (unsigned)oh < (unsigned)Ho;
+        const u16* drow = dy + (((long long)n * Do + min(max(od, 0), Do - 1)) * Ho + min(max(oh, 0), Ho - 1)) * Wo;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int ow = iw0 + 1 - (K - 1) + s;
+          const float v = cvt_in<FMT>(drow[min(max(ow, 0), Wo - 1)]);
+          g[h][s] = rok && (unsigned)ow < (unsigned)Wo ? v : 0.f;
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wr[h][kw] = *reinterpret_cast<const uint4*>(wp + (long long)(tt * K + kw) * C + c0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
           float wv[8];
-          dl_cvt8<FMT>(*reinterpret_cast<const uint4*>(wp + (long long)((kd * K + kh) * K + kw) * C + c0), wv);
+          dl_cvt8<FMT>(wr[h][kw], wv);
 #pragma unroll
           for (int v = 0; v < DL_OW; ++v) {
-            const int ow = iw0 + v + 1 - kw;
-            const float g = (unsigned)ow < (unsigned)Wo ? cvt_in<FMT>(drow[ow]) : 0.f;       // (one address per wave: a broadcast load)
+            const float gv = g[h][v + (K - 1) - kw];                  // column ow = iw0 + v + 1 - kw
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[v][e] = fmaf(g, wv[e], acc[v][e]);
+            for (int e = 0; e < 8; ++e) acc[v][e] = fmaf(gv, wv[e], acc[v][e]);
           }
         }
-      }
     }
 #pragma unroll
     for (int v = 0; v < DL_OW; ++v) {
@@ -2071,30 +2100,47 @@ __global__ __launch_bounds__(256) void dlast_dgrad_kernel(const u16* __restrict_
     }
   }
 }
-// grid (ks^3 taps, splits of the output voxels); the four waves of a workgroup take interleaved voxels, are summed in LDS, and one
+// grid (ks^3 taps, splits of the output ROWS); the 16 waves of a workgroup take interleaved rows (n, od, oh) and walk each row in
+// groups of 7 voxels whose loads are issued together (unconditional: a voxel outside the input reads a clamped address and is
+// multiplied by zero -- 86 dependent load -> fma steps per wave made the first version 140 us); the waves are summed in LDS and one
 // lane per channel adds into the parameter gradient
+constexpr int DLW_WAVES = 16, DLW_U = 7;
 template <int FMT>
-__global__ __launch_bounds__(256) void dlast_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ dw, float scale,
-                                                         int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int K) {
-  __shared__ float s_acc[3][512];
+__global__ __launch_bounds__(64 * DLW_WAVES) void dlast_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ dw,
+                                                                    float scale, int N, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int K) {
+  __shared__ float s_acc[DLW_WAVES - 1][512];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tap = blockIdx.x, kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
-  const long long M = (long long)N * Do * Ho * Wo;
-  const long long per = (M + gridDim.y - 1) / gridDim.y;
-  const long long m0 = per * blockIdx.y, m1 = m0 + per < M ? m0 + per : M;
+  const int R = N * Do * Ho;
+  const int per = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = per * blockIdx.y, r1 = r0 + per < R ? r0 + per : R;
   for (int c0 = lane * 8; c0 < C; c0 += 512) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long long m = m0 + wv; m < m1; m += 4) {
-      const int ow = (int)(m % Wo); long long t = m / Wo;
-      const int oh = (int)(t % Ho); t /= Ho;
-      const int od = (int)(t % Do); const int n = (int)(t / Do);
-      const int id = od - 1 + kd, ih = oh - 1 + kh, iw = ow - 1 + kw;
-      if ((unsigned)id >= (unsigned)Di || (unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) continue;
-      const float g = cvt_in<FMT>(dy[m]);
-      float xv[8];
-      dl_cvt8<FMT>(*reinterpret_cast<const uint4*>(x + ((((long long)n * Di + id) * Hi + ih) * Wi + iw) * (long long)C + c0), xv);
+    for (int r = r0 + wv; r < r1; r += DLW_WAVES) {
+      const int oh = r % Ho, t = r / Ho;
+      const int od = t % Do, n = t / Do;
+      const int id = od - 1 + kd, ih = oh - 1 + kh;
+      if ((unsigned)id >= (unsigned)Di || (unsigned)ih >= (unsigned)Hi) continue;      // (wave-uniform)
+      const u16* xrow = x + (((long long)n * Di + id) * Hi + ih) * (long long)Wi * C + c0;
+      const u16* drow = dy + (long long)r * Wo;
+      for (int ow0 = 0; ow0 < Wo; ow0 += DLW_U) {
+        uint4 xv[DLW_U];
+        float g[DLW_U];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(g, xv[e], acc[e]);
+        for (int u = 0; u < DLW_U; ++u) {
+          const int ow = ow0 + u, iw = ow - 1 + kw;
+          const bool ok = ow < Wo && (unsigned)iw < (unsigned)Wi;
+          xv[u] = *reinterpret_cast<const uint4*>(xrow + (long long)min(max(iw, 0), Wi - 1) * C);
+          g[u] = ok ? cvt_in<FMT>(drow[min(ow, Wo - 1)]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < DLW_U; ++u) {
+          float xf[8];
+          dl_cvt8<FMT>(xv[u], xf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(g[u], xf[e], acc[e]);
+        }
+      }
     }
     __syncthreads();
     if (wv > 0) {
@@ -2105,7 +2151,9 @@ __global__ __launch_bounds__(256) void dlast_wgrad_kernel(const u16* __restrict_
     if (wv == 0) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float s = acc[e] + s_acc[0][lane * 8 + e] + s_acc[1][lane * 8 + e] + s_acc[2][lane * 8 + e];
+        float s = acc[e];
+#pragma unroll
+        for (int w = 0; w < DLW_WAVES - 1; ++w) s += s_acc[w][lane * 8 + e];
         atomicAdd(&dw[(long long)(c0 + e) * (K * K * K) + tap], s * scale);
       }
     }
@@ -2121,8 +2169,10 @@ extern "C" int xh_dlast_fwd(void* stream, int dtype, int ks, const void* x, cons
   if (!x || !wp || !y || !dlast_ok(dtype, ks, N, Di, Hi, Wi, Do, Ho, Wo, C)) return XH_ERR_ARG;
   const long long waves = (long long)N * Do * Ho * cdiv(Wo, DL_OW);
   const dim3 grid((unsigned)((waves + 3) / 4));
-  if (dtype == XH_F16) hipLaunchKernelGGL(dlast_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)wp, (u16*)y, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
-  else hipLaunchKernelGGL(dlast_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)wp, (u16*)y, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+#define DLF(F, K) hipLaunchKernelGGL((dlast_fwd_kernel<F, K>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)wp, (u16*)y, N, Di, Hi, Wi, Do, Ho, Wo, C)
+  if (dtype == XH_F16) { if (ks == 4) DLF(1, 4); else DLF(1, 3); }
+  else { if (ks == 4) DLF(0, 4); else DLF(0, 3); }
+#undef DLF
   return xh_launch_status();
 }
 extern "C" int xh_dlast_dgrad(void* stream, int dtype, int ks, const void* dy, const void* wp, void* dx, int N, int Di, int Hi, int Wi, int Do,
@@ -2130,19 +2180,21 @@ extern "C" int xh_dlast_dgrad(void* stream, int dtype, int ks, const void* dy, c
   if (!dy || !wp || !dx || !dlast_ok(dtype, ks, N, Di, Hi, Wi, Do, Ho, Wo, C)) return XH_ERR_ARG;
   const long long waves = (long long)N * Di * Hi * cdiv(Wi, DL_OW);
   const dim3 grid((unsigned)((waves + 3) / 4));
-  if (dtype == XH_F16) hipLaunchKernelGGL(dlast_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, (const u16*)wp, (u16*)dx, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
-  else hipLaunchKernelGGL(dlast_dgrad_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, (const u16*)wp, (u16*)dx, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+#define DLD(F, K) hipLaunchKernelGGL((dlast_dgrad_kernel<F, K>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, (const u16*)wp, (u16*)dx, N, Di, Hi, Wi, Do, Ho, Wo, C)
+  if (dtype == XH_F16) { if (ks == 4) DLD(1, 4); else DLD(1, 3); }
+  else { if (ks == 4) DLD(0, 4); else DLD(0, 3); }
+#undef DLD
   return xh_launch_status();
 }
 extern "C" int xh_dlast_wgrad(void* stream, int dtype, int ks, const void* x, const void* dy, float* dw, float scale, int N, int Di, int Hi,
                               int Wi, int Do, int Ho, int Wo, int C) {
   if (!x || !dy || !dw || !dlast_ok(dtype, ks, N, Di, Hi, Wi, Do, Ho, Wo, C)) return XH_ERR_ARG;
-  const long long M = (long long)N * Do * Ho * Wo;
-  int splits = (int)(M / 256 > 0 ? M / 256 : 1);          // >= 64 voxels per wave; ks^3 x splits workgroups
+  const int R = N * Do * Ho;
+  int splits = R / (2 * DLW_WAVES) > 0 ? R / (2 * DLW_WAVES) : 1;      // >= 2 rows per wave; ks^3 x splits workgroups of 16 waves
   if (splits > 8) splits = 8;
   const dim3 grid(ks * ks * ks, splits);
-  if (dtype == XH_F16) hipLaunchKernelGGL(dlast_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy, dw, scale, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
-  else hipLaunchKernelGGL(dlast_wgrad_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy, dw, scale, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  if (dtype == XH_F16) hipLaunchKernelGGL(dlast_wgrad_kernel<1>, grid, dim3(64 * DLW_WAVES), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy, dw, scale, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
+  else hipLaunchKernelGGL(dlast_wgrad_kernel<0>, grid, dim3(64 * DLW_WAVES), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy, dw, scale, N, Di, Hi, Wi, Do, Ho, Wo, C, ks);
   return xh_launch_status();
 }
 
