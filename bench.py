@@ -279,6 +279,7 @@ def main():
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
+        ops.prepare_capture()                                 # weight-pack job table of the step's convolutions, fan-in block
         graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may query events while this thread captures; that must not abort the capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local" if use_dist else "global"):
@@ -482,6 +483,8 @@ def config3_leg(model, grads, dev, dtype, size, nsteps, warmup):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
+    from xlstm_hved_amd import ops as _ops
+    _ops.prepare_capture()
     with torch.cuda.graph(graph):
         compute()
     for i in range(warmup):
@@ -679,6 +682,7 @@ def mfma_roofline_pass(ts, x, mask, nsteps=3):
 
 def time_graph(fn, nsteps, warmup=3, thread_local=False):
     """ms per replay of `fn` captured once into a hipGraph (one untimed eager pass first)."""
+    from xlstm_hved_amd import ops as ops_
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -686,6 +690,7 @@ def time_graph(fn, nsteps, warmup=3, thread_local=False):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
+    ops_.prepare_capture()                                   # weight-pack job table of the step's convolutions, fan-in block
     with torch.cuda.graph(g, capture_error_mode="thread_local" if thread_local else "global"):
         fn()
     for _ in range(warmup):
@@ -709,6 +714,8 @@ def extras(model, x, grads, nsteps):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        from xlstm_hved_amd import ops as _ops
+        _ops.prepare_capture()
         with torch.cuda.graph(g):
             fn()
         for _ in range(3):

@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) void conv3_pack_table_kernel(const PackTableHe
   }
   const PackJob j = jobs[lo];
   const int base = ((int)blockIdx.x - h->first_block[lo]) * XH_PACK_PER_BLOCK;
+  if (j.kind == 1 || (j.kind == 0 && j.f16 != 2)) {     // a lane's 16 bytes at once (nelem is a multiple of 512 in both layouts)
+    const int idx8 = base + 8 * threadIdx.x;
+    if (idx8 < j.nelem) { if (j.kind == 1) pack_elem8_q4(j, idx8); else pack_elem8_mk(j, idx8); }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < XH_PACK_PER_BLOCK / 256; ++u) {
     const int idx = base + u * 256 + threadIdx.x;

@@ -74,6 +74,91 @@ __device__ __forceinline__ void pack_elem(const PackJob& j, int idx) {
   reinterpret_cast<unsigned short*>(j.ws)[idx] = j.f16 ? f2hf(v) : f2bf(v);
 }
 
+// Eight consecutive elements of a quad-channel (kind 1) image -- one A-fragment lane: they share output channel, input quad, (kd, kh)
+// and voxel-quad position, so the index arithmetic (a dozen integer divisions per element in pack_elem) is done once and the lane's
+// 16 bytes are stored at once.  idx8 is a multiple of 8.  Same values as pack_elem.
+__device__ __forceinline__ void pack_elem8_q4(const PackJob& j, int idx8) {
+  const int per = j.ci4 * 9 * 512;
+  const int oq = idx8 / per, r = idx8 - oq * per;
+  const int l = (r >> 3) & 63, f = r >> 9;
+  const int r9 = f % 9, cq = f / 9;
+  const int m = l & 15, c = m >> 2, pp = m & 3, g = l >> 4;
+  const int co = oq * 4 + c;
+  const int grp = co / j.Cout_g, co_g = co - grp * j.Cout_g;
+  const int gpp = j.groups / j.n_wptr;
+  const float* wp = j.w[grp / gpp];
+  const int gl = grp % gpp;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int s = 2 * g + (e >> 2), ci = e & 3;
+    const int kw = s - pp - 1;
+    float x = 0.f;
+    if (kw >= 0 && kw <= 2) {
+      const int ci_g = cq * 4 + ci, tap = r9 * 3 + kw;
+      if (j.dw) x = co_g == ci_g ? wp[(long long)(gl * 4 + co_g) * 27 + (j.transposed ? 26 - tap : tap)] : 0.f;
+      else if (!j.transposed) x = wp[((long long)(gl * j.Cout_g + co_g) * j.Cin_g + ci_g) * 27 + tap];
+      else x = wp[((long long)(gl * j.Cin_g + ci_g) * j.Cout_g + co_g) * 27 + (26 - tap)];
+    }
+    v[e] = x;
+  }
+  unsigned short* ws = reinterpret_cast<unsigned short*>(j.ws);
+  if (j.f16 == 2) {                                     // two-term fp16 image of an fp32 weight (conv3d_q4s.hip)
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hi[e] = f2hf(v[e]); lo[e] = f2hf((v[e] - hf2f(hi[e])) * 2048.f); }
+    uint4 a, b;
+    a.x = hi[0] | ((unsigned)hi[1] << 16); a.y = hi[2] | ((unsigned)hi[3] << 16); a.z = hi[4] | ((unsigned)hi[5] << 16); a.w = hi[6] | ((unsigned)hi[7] << 16);
+    b.x = lo[0] | ((unsigned)lo[1] << 16); b.y = lo[2] | ((unsigned)lo[3] << 16); b.z = lo[4] | ((unsigned)lo[5] << 16); b.w = lo[6] | ((unsigned)lo[7] << 16);
+    *reinterpret_cast<uint4*>(ws + idx8) = a;
+    *reinterpret_cast<uint4*>(ws + (long long)j.nelem + idx8) = b;
+    return;
+  }
+  uint4 o;
+  if (j.f16) { o.x = cvt_pack<1>(v[0], v[1]); o.y = cvt_pack<1>(v[2], v[3]); o.z = cvt_pack<1>(v[4], v[5]); o.w = cvt_pack<1>(v[6], v[7]); }
+  else { o.x = cvt_pack<0>(v[0], v[1]); o.y = cvt_pack<0>(v[2], v[3]); o.z = cvt_pack<0>(v[4], v[5]); o.w = cvt_pack<0>(v[6], v[7]); }
+  *reinterpret_cast<uint4*>(ws + idx8) = o;
+}
+
+// The same for the implicit-GEMM (kind 0) image: eight consecutive elements are one lane's B-fragment row segment -- they share the
+// channel tile, the MFMA index, the column (output channel) and the (kd, kh) row; only (kw, ci) = divmod(q * 8 + e, cinp) moves.
+__device__ __forceinline__ void pack_elem8_mk(const PackJob& j, int idx8) {
+  const int per = j.nm * 512;
+  const int y = idx8 / per, r = idx8 - y * per;
+  const int set = y / j.ntile, nt = y - set * j.ntile;
+  const int cin0 = set * j.cin_stride + j.cin_off;
+  const int cin_end = (set + 1) * j.cin_stride;
+  const int co_lim = min(16, j.cout_set - nt * 16);
+  const int l = (r >> 3) & 63, i = r >> 9;
+  const int c = 4 * i + (l >> 4);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < j.nch && (l & 15) < co_lim) {
+    const int r9 = c / j.cpr, q = c - r9 * j.cpr;
+    const int co = set * j.cout_set + nt * 16 + (l & 15);
+    const int g = co / j.Cout_g, co_g = co - g * j.Cout_g;
+    const int gpp = j.groups / j.n_wptr;
+    const float* wp = j.w[g / gpp];
+    const int gl = g % gpp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int flat = q * 8 + e;
+      const int kw = flat / j.cinp, cib = flat - kw * j.cinp;
+      const int ci = cin0 + cib;
+      if (kw < 3 && cib < j.cin_blk && ci < cin_end && ci / j.Cin_g == g) {
+        const int ci_g = ci - g * j.Cin_g, tap = r9 * 3 + kw;
+        if (j.dw) v[e] = co_g == ci_g ? wp[(long long)(gl * 4 + co_g) * 27 + (j.transposed ? 26 - tap : tap)] : 0.f;
+        else if (!j.transposed) v[e] = wp[((long long)(gl * j.Cout_g + co_g) * j.Cin_g + ci_g) * 27 + tap];
+        else v[e] = wp[((long long)(gl * j.Cin_g + ci_g) * j.Cout_g + co_g) * 27 + (26 - tap)];
+      }
+    }
+  }
+  unsigned short* ws = reinterpret_cast<unsigned short*>(j.ws);
+  uint4 o;
+  if (j.f16) { o.x = cvt_pack<1>(v[0], v[1]); o.y = cvt_pack<1>(v[2], v[3]); o.z = cvt_pack<1>(v[4], v[5]); o.w = cvt_pack<1>(v[6], v[7]); }
+  else { o.x = cvt_pack<0>(v[0], v[1]); o.y = cvt_pack<0>(v[2], v[3]); o.z = cvt_pack<0>(v[4], v[5]); o.w = cvt_pack<0>(v[6], v[7]); }
+  *reinterpret_cast<uint4*>(ws + idx8) = o;
+}
+
 #define XH_PACK_MAX_JOBS 24
 struct PackMulti {
   PackJob job[XH_PACK_MAX_JOBS];

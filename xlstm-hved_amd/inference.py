@@ -96,6 +96,7 @@ def _window_graph(model, subset_idx, batch_size, channels, patch_size, dtype, de
         model(static_in, subset_idx_list=[subset_idx], valid=True)
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
+    ops.prepare_capture()                                # (weight-pack job table, statistics fan-in block of the capture)
     with torch.cuda.graph(graph):
         static_out = model(static_in, subset_idx_list=[subset_idx], valid=True)[0]
     cache[key] = (fp, graph, static_in, static_out)

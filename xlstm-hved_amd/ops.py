@@ -339,13 +339,8 @@ def _pack_entry(weights, desc, need, device):
     return e
 
 
-def prepack_all():
-    """Starts a new epoch and packs the fragments of every registered convolution (xh_conv3d_prepack).  Called at the start
-    of the network's forward(); capture-safe (the launches are part of a captured step)."""
+def _pack_arrays_refresh():
     st = _PACK_STATE
-    st["epoch"] += 1
-    if not st["enabled"] or not _PACKS:
-        return
     if st["arrays"] is None or any(not e.alive() for e in st["arrays"][0]):
         for k in [k for k, e in _PACKS.items() if not e.alive()]:
             del _PACKS[k]
@@ -354,13 +349,15 @@ def prepack_all():
         st["arrays"] = (ents, (C.c_void_p * n)(*[C.addressof(e.desc) for e in ents]),
                         (C.c_void_p * n)(*[C.addressof(e.ptrs) for e in ents]))
         st["table"] = None
+
+
+def _pack_table_refresh():
+    """ONE launch through a device-resident job table (xh_conv3d_prepack_table): built on the host when the set of convolutions
+    changes and copied to the device OUTSIDE any capture; a set that changes under capture takes the kernel-argument launches."""
+    st = _PACK_STATE
     ents, darr, parr = st["arrays"]
-    if not ents:
-        return
-    lib = L.load()
-    # ONE launch through a device-resident job table (xh_conv3d_prepack_table): built on the host when the set of convolutions
-    # changes and copied to the device outside any capture; a set that changes under capture takes the kernel-argument launches
     if st.get("table") is None and ents and not torch.cuda.is_current_stream_capturing() and _PACK_TABLE[0]:
+        lib = L.load()
         nbytes = int(lib.xh_conv3d_prepack_table_bytes())
         host = (C.c_char * nbytes)()
         if lib.xh_conv3d_prepack_table(len(ents), darr, parr, C.cast(host, C.c_void_p)) == 0:
@@ -369,6 +366,33 @@ def prepack_all():
             st["table"] = (dev, int(head[1]), ents[0].ws.device)
             # never freed: a captured graph replays the table it was captured with (like the fan-in blocks); 40 KB each
             st.setdefault("tables_keep", []).append(dev)
+
+
+def prepare_capture():
+    """Call right BEFORE a stream capture of a step that has run eagerly at least once: what a captured launch cannot do for itself
+    is done here -- the weight-pack job table of every convolution registered so far is built and copied to the device (inside
+    the capture prepack_all would fall back to its three kernel-argument launches), and the capture gets a statistics fan-in
+    block of its own (begin_capture_scope)."""
+    begin_capture_scope()
+    if _PACK_STATE["enabled"] and _PACKS and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        _pack_arrays_refresh()
+        if _PACK_STATE["arrays"][0]:
+            _pack_table_refresh()
+
+
+def prepack_all():
+    """Starts a new epoch and packs the fragments of every registered convolution (xh_conv3d_prepack).  Called at the start
+    of the network's forward(); capture-safe (the launches are part of a captured step)."""
+    st = _PACK_STATE
+    st["epoch"] += 1
+    if not st["enabled"] or not _PACKS:
+        return
+    _pack_arrays_refresh()
+    ents, darr, parr = st["arrays"]
+    if not ents:
+        return
+    lib = L.load()
+    _pack_table_refresh()
     tab = st.get("table")
     if tab is not None and tab[2] == ents[0].ws.device:
         L.check(lib.xh_conv3d_prepack_run(_stream(), tab[0].data_ptr(), tab[1]), "xh_conv3d_prepack_run")

@@ -322,7 +322,7 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         mode = "thread_local" if self.dp else "global"       # RCCL's watchdog thread may query events while this thread captures
-        ops.begin_capture_scope()
+        ops.prepare_capture()
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         if not self.dp:
