@@ -82,7 +82,7 @@ def parse():
                     help="initialise RCCL and issue the gradient all-reduce even with one rank (exercises the N>1 code path)")
     ap.add_argument("--extras", action="store_true", help="also time forward-only and the shared-encoder two-forward step")
     ap.add_argument("--no-modes", action="store_true", help="skip timing the other storage modes")
-    ap.add_argument("--level-streams", action="store_true", help="A/B: the coarse latent-path chains on side streams (ops.set_level_streams)")
+    ap.add_argument("--level-streams", action="store_true", help="A/B: the coarse latent-path chains on side streams (ops.set_level_streams; eager launches only: use with --no-graph)")
     ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 leg (N = 2, per-step modality dropout)")
     ap.add_argument("--no-trainstep", action="store_true", help="skip timing the whole training step (train.py:208-296)")
     ap.add_argument("--wgrad-overlap", action="store_true",

@@ -86,11 +86,12 @@ def test_bench_configuration_128_graph_replay_matches_eager():
     assert (a - c).abs().max().item() <= 5e-4 * scale, (a - c).abs().max().item() / scale
 
 
-def test_level_streams_under_graph_capture_match_the_default_path():
-    """ops.set_level_streams (the coarse latent-path chains on side streams) inside a captured step: the side-stream launches
-    become parallel branches of the graph, so they must not share the capture's statistics fan-in block with the origin
-    stream's launches (ops.fan_block hands the block to the capture's origin stream only; the others keep direct atomics).
-    128^3: the size at which launches are large enough to take the fan-in path at all."""
+def test_level_streams_switch_is_inert_under_capture_and_matches_eagerly():
+    """ops.set_level_streams (the coarse latent-path chains on side streams, an A/B switch).  Eagerly it gives the gradients of the
+    one-stream step.  Under stream capture it is INERT (round 6): as parallel graph branches the chains run truly concurrently, and
+    besides the statistics fan-in block (ops.fan_block now hands the capture's block to its origin stream only) tensors
+    allocated on one stream and last read on another can be recycled while the other branch still reads them -- one capture in three
+    came back with gradients off by 1e-3..1e-2.  So a captured step with the switch on is the default step."""
     a = _grads("defer", True, size=128)
     X.ops.set_level_streams(True)
     try:

@@ -574,7 +574,7 @@ class AbstractFusion3DUNet(nn.Module):
             zml = Fn.PoEAll.apply(keep, tuple(self.MVAE_latents[:nlev]), bool(instance_missing), nlev, *feat_list, *epss)
         else:
             zml = [t for l in range(nlev) for t in Fn.PoE.apply(feat_list[l], keep, epss[l], self.MVAE_latents[l], bool(instance_missing))]
-        batch = (Fn.LATENT_BATCH[0] and x.is_cuda and 1 < nlev <= 4 and not ops.LEVEL_STREAMS[0]
+        batch = (Fn.LATENT_BATCH[0] and x.is_cuda and 1 < nlev <= 4 and not (ops.LEVEL_STREAMS[0] and not torch.cuda.is_current_stream_capturing())
                  and all(type(self.VU_blocks[l][0]).__name__ == "BasicConv" and self.VU_blocks[l][0].conv.kernel_size[0] == 1
                          and self.VU_blocks[l][0].groups == 1 and type(self.conv_blocks[l]).__name__ == "BasicConv" for l in range(nlev))
                  and all(zml[3 * l].shape[-1] % 4 == 0 for l in range(nlev)))
@@ -590,7 +590,11 @@ class AbstractFusion3DUNet(nn.Module):
             except Fn.LatentFallback:
                 batch = False
         side = None
-        if ops.LEVEL_STREAMS[0] and x.is_cuda and nlev > 1:
+        # (A/B switch, EAGER only.  Under stream capture it is inert: as parallel branches of a graph the chains really run
+        # concurrently, and tensors that are allocated on one stream and last read on another -- PoE outputs saved by a side-stream
+        # node, gradients handed between streams -- can be recycled by the allocator while the other branch still reads them;
+        # round 6 saw gradients off by 1e-3..1e-2 in one capture out of three.  Measured slower than one stream anyway)
+        if ops.LEVEL_STREAMS[0] and x.is_cuda and nlev > 1 and not torch.cuda.is_current_stream_capturing():
             pool = self.__dict__.setdefault("_level_streams", {}).setdefault(x.device, [])
             while len(pool) < nlev - 1:
                 pool.append(torch.cuda.Stream(x.device))

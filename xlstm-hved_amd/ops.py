@@ -462,8 +462,9 @@ LEVEL_STREAMS = [False]
 
 
 def set_level_streams(enabled):
-    """A/B switch: the three coarse latent-path chains (PoE output -> VU block -> upsampling -> conv block, RA_HVED.py:599-603) on
-    side streams next to the finest one (they are independent of each other until the decoders)."""
+    """A/B switch, eager launches only: the three coarse latent-path chains (PoE output -> VU block -> upsampling -> conv block,
+    RA_HVED.py:599-603) on side streams next to the finest one (they are independent of each other until the decoders).  Inert
+    under stream capture (model._decode says why)."""
     LEVEL_STREAMS[0] = bool(enabled)
 
 
