@@ -199,6 +199,12 @@ long long xh_fanin_bytes(void);
 /* y = act(conv(pre(x)) + b)  [+ epilogue].  Also serves as the data-gradient of a stride-1 conv
  * (transposed=1).  Reference: F.conv3d as used throughout RA_HVED.py:510-648. */
 int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p);
+/* Two INDEPENDENT k = 3 stride-1 convolutions of one shape (same storage type, extents, Cout, pre / epi variant) in ONE launch of
+ * the full-row quad-channel kernel: returns 0 when launched, 1 when the two are not such a pair (nothing launched: the caller calls
+ * xh_conv3d_fwd twice), < 0 on a bad argument.  Both must have their fragments packed (ws_packed).  Same results as two calls.  The
+ * decoder's recon | seg streams (RA_HVED.py:171-183) run convs of identical shape on different inputs; at 64^3 each is half a
+ * resident round of workgroups. */
+int xh_conv3d_fwd_pair(void* stream, const xh_conv_desc* d0, const xh_conv_ptrs* p0, const xh_conv_desc* d1, const xh_conv_ptrs* p1);
 /* 1 when xh_conv3d_fwd takes this desc (pre == 1) with the BatchNorm flavour of the fused finalisation (fin_gamma ...): the
  * quad-channel MFMA kernel, one sample. */
 int xh_conv3d_fuses_bn_finalize(const xh_conv_desc* d);

@@ -972,3 +972,52 @@ def test_wgrad_full_row_kernel_batched_128_cubed(dtype):
     for (a, b), (c, d), pr in zip(res["full"], res["tile"], probs):
         assert l2_err(a, c) < 5e-6 and l2_err(b, d) < 5e-6, (pr, l2_err(a, c), l2_err(b, d))
         assert a.abs().max() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("sp,ca,cb,cout", [((16, 16, 64), 8, 16, 8), ((8, 16, 128), 4, 8, 4), ((16, 16, 32), 16, 32, 16), ((12, 24, 64), 4, 0, 4)])
+def test_two_convs_of_one_shape_in_one_launch_equal_two_launches(dtype, sp, ca, cb, cout):
+    """xh_conv3d_fwd_pair (ops.conv_pair_scope): two independent 'ilc' convs of one shape -- the recon stream's on a virtual concat of
+    two tensors, the seg stream's on one tensor, as in the decoders (buildingblocks.py:732-735) -- issued as ONE launch of the
+    full-row kernel (rows of 64 / 128 voxels) or the tile kernel (rows of 32): the workgroups run the single launch's body at the
+    single launch's block coordinates, so outputs are bit-identical and the epilogue sums equal to their summation order."""
+    torch.manual_seed(13)
+    n = 1
+    cin = ca + cb
+    xa = torch.randn((n, ca) + sp, device=DEV).to(dtype)
+    xb = torch.randn((n, cb) + sp, device=DEV).to(dtype) if cb else None
+    xs = torch.randn((n, cin) + sp, device=DEV).to(dtype)
+    w1 = [torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.1]
+    w2 = [torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.1]
+    cnt = sp[0] * sp[1] * sp[2]
+
+    def stats_of(t, u=None):
+        red = torch.zeros((n, cin, 2), dtype=torch.float64, device=DEV)
+        if u is not None:
+            X.ops.moments2(t, u, red)
+        else:
+            X.ops.moments(t, red, 0)
+        return red
+
+    def run(pair):
+        X.ops.set_conv_pairs(pair)
+        try:
+            X.ops.prepack_all()
+            y = torch.zeros((n, 2 * cout) + sp, dtype=dtype, device=DEV)
+            red = torch.zeros((n, 2 * cout, 2), dtype=torch.float64, device=DEV)
+            r1, r2 = stats_of(xa, xb), stats_of(xs)
+            with X.ops.conv_pair_scope():
+                o1 = X.ops.conv3d(xa, xb, w1, None, k=3, cout=cout, in_stats=(r1, cnt, 0.01), epi=2, red=red[:, :cout], out=y[:, :cout])
+                o2 = X.ops.conv3d(xs, None, w2, None, k=3, cout=cout, in_stats=(r2, cnt, 0.01), epi=2, red=red[:, cout:], out=y[:, cout:])
+            torch.cuda.synchronize()
+            return y.clone(), red.clone(), [t.clone() for t in o1[1:]], [t.clone() for t in o2[1:]], X.ops.last_conv_kernel()
+        finally:
+            X.ops.set_conv_pairs(True)
+    run(True)                                                  # (registers the two convs: the pair needs prepacked fragments)
+    y0, red0, s10, s20, _ = run(False)
+    y1, red1, s11, s21, kern = run(True)
+    assert "pair" in kern, kern
+    assert torch.equal(y0, y1)
+    assert (red0 - red1).abs().max().item() <= 1e-9 * red0.abs().max().item()
+    for a_, b_ in zip(s10 + s20, s11 + s21):
+        assert torch.equal(a_, b_)                             # (scale, shift, mean, rstd written by the fused finalisation)

@@ -113,6 +113,7 @@ SIGNATURES = {
     "xh_set_option": (I, [I, I]),
     "xh_last_conv_kernel": (C.c_char_p, []),
     "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
+    "xh_conv3d_fwd_pair": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_fanin_bytes": (ll, []),
     "xh_conv3d_workspace_bytes": (ll, [C.POINTER(ConvDesc)]),
     "xh_conv3d_fuses_norm_bwd": (I, [C.POINTER(ConvDesc)]),

@@ -1654,6 +1654,25 @@ extern "C" int xh_conv3d_fuses_norm_bwd(const xh_conv_desc* d) {
   t.pre = 2;
   return xh_conv3_q4_workspace_bytes(&t) > 0 ? 1 : 0;
 }
+int xh_conv3_q4_pair_try(void* stream, const xh_conv_desc* d0, const xh_conv_ptrs* p0, const xh_conv_desc* d1, const xh_conv_ptrs* p1);
+// Two independent k = 3 stride-1 convolutions of one shape in one launch; returns 1 (nothing launched) when they are not such a pair.
+extern "C" int xh_conv3d_fwd_pair(void* stream, const xh_conv_desc* d0, const xh_conv_ptrs* p0, const xh_conv_desc* d1, const xh_conv_ptrs* p1) {
+  const xh_conv_desc* ds[2] = {d0, d1};
+  const xh_conv_ptrs* ps[2] = {p0, p1};
+  for (int i = 0; i < 2; ++i) {
+    const int rc = check_desc(ds[i], ps[i]);
+    if (rc) return rc;
+    const xh_conv_desc* d = ds[i];
+    const xh_conv_ptrs* p = ps[i];
+    if (!p->y || d->k != 3 || d->stride != 1 || d->bcast || d->pre == 2 || p->fin_gamma) return 1;
+    if (d->epi == 1 && (!p->ea || !p->e_sc || !p->e_sh || !p->red || (d->Cea < d->Cout && !p->eb))) return XH_ERR_ARG;
+    if (d->epi == 2 && !p->red) return XH_ERR_ARG;
+    if (d->epi < 0 || d->epi > 2) return XH_ERR_ARG;
+    if (p->fin_red && (d->pre != 1 || !p->fin_mean || !p->fin_rstd || p->fin_count <= 0)) return XH_ERR_ARG;
+  }
+  if (!g_use_mfma) return 1;
+  return xh_conv3_q4_pair_try(stream, d0, p0, d1, p1);
+}
 extern "C" int xh_conv3d_fwd(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {
   int rc = check_desc(d, p);
   if (rc) return rc;

@@ -59,26 +59,27 @@ template <int FMT> __device__ __forceinline__ f32x2_t q4_xf(unsigned u, float sc
 // sums nb_red = (sum g, sum g x), mean, rstd -- what xh_in_bwd_apply computes in a pass of its own (reads g, x; writes dx)
 // before this conv reads dx again.  The workgroups of the first output quad of a group also STORE v for the voxels their tile
 // owns (pd): the weight gradient of this conv needs the tensor materialised.
+// (body with the block coordinates as arguments: conv3_q4_kernel passes the launch's own, conv3_q4_pair_kernel those of the problem a
+// workgroup belongs to)
 template <int FMT, int PRE, int EPI, bool ACT, bool MULTI, int TD = 8>
-__global__ __launch_bounds__(256, PRE == 2 ? 3 : 4) void conv3_q4_kernel(const ConvQ4 a) {
+__device__ __forceinline__ void q4_body(const ConvQ4& a, unsigned char* smem, const int bx, const int by, const int bz, const int gdx, const int gdy) {
   typedef h16<FMT> ST;
   constexpr int ID = TD + 2, TILE_BYTES = ID * PLANE, NROWS = ID * IH, NITEM = NROWS * 4, NEDGE = NROWS * 2;
   constexpr int NIT = (NITEM + 255) / 256;           // interior items (row, 8-voxel group) per thread; edge items: (row, side)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem + TILE_BYTES);      // [4 waves][8], then [8] totals + the fan-in flag
   float* s_fin = reinterpret_cast<float*>(smem + TILE_BYTES + 48 * sizeof(double));   // [2][Q4_MAXC]: in-kernel InstanceNorm scale / shift
                                                                                       // (PRE == 2: [3][Q4_MAXC] = A, C, B)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g4 = lane >> 4;
-  const int oq = blockIdx.y, n = blockIdx.z;
+  const int oq = by, n = bz;
   const int co0 = oq * 4;
   const int grp = udiv_fast(oq, a.oq_g, a.mQ);
   const int cin_base = grp * a.Cin_g;
   const int D = a.d.D, H = a.d.H, W = a.d.W;
   const long long hw = (long long)H * W, dhw = (long long)D * hw;
   const int Do = a.d.Do, Ho = a.d.Ho;
-  const int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int wk = xcd_swizzle(bx, gdx);
   const int wk1 = udiv_fast(wk, a.tilesW, a.mW), tw = wk - wk1 * a.tilesW;
   const int td = udiv_fast(wk1, a.tilesH, a.mH), th = wk1 - td * a.tilesH;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, PRE == 2 ? 3 : 4) void conv3_q4_kernel(const C
             if (gam) { const float g_ = gam[cin_base + tid]; sc_ *= g_; sh_ = fmaf(sh_, g_, bet[cin_base + tid]); }
             s_fin[tid] = sc_; s_fin[Q4_MAXC + tid] = sh_;
           }
-          if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+          if (bx == 0 && by == 0 && bz == 0)
             for (int i = tid; i < a.d.N * a.d.Cin; i += 256) {
               float sc_, sh_, m_, r_;
               in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], a.fin_inv, sc_, sh_, m_, r_);
@@ -424,12 +425,26 @@ __global__ __launch_bounds__(256, PRE == 2 ? 3 : 4) void conv3_q4_kernel(const C
       s_red[32 + tid] = tot;
     }
     double* s_tot = s_red + 32;
-    if (a.fan && !fan_in<8>(a.fan + ((long long)n * gridDim.y + oq) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x, s_tot,
+    if (a.fan && !fan_in<8>(a.fan + ((long long)n * gdy + oq) * FAN_UNIT_BYTES, bx, gdx, s_tot,
                             reinterpret_cast<int*>(s_tot + 8)))
       return;
     if (!a.fan) __syncthreads();
     if (tid < 8) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], s_tot[tid]);
   }
+}
+
+template <int FMT, int PRE, int EPI, bool ACT, bool MULTI, int TD = 8>
+__global__ __launch_bounds__(256, PRE == 2 ? 3 : 4) void conv3_q4_kernel(const ConvQ4 a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  q4_body<FMT, PRE, EPI, ACT, MULTI, TD>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+// two independent convolutions of one shape in one launch (xh_conv3d_fwd_pair; rows of 32 voxels: the 32^3 decoder level)
+template <int FMT, int PRE, int EPI, bool MULTI, int TD>
+__global__ __launch_bounds__(256, 4) void conv3_q4_pair_kernel(const ConvQ4 a0, const ConvQ4 a1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = a0.d.N;
+  if ((int)blockIdx.z >= N) q4_body<FMT, PRE, EPI, false, MULTI, TD>(a1, smem, blockIdx.x, blockIdx.y, (int)blockIdx.z - N, gridDim.x, gridDim.y);
+  else q4_body<FMT, PRE, EPI, false, MULTI, TD>(a0, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 static bool q4_plan(const xh_conv_desc* d, ConvQ4* a) {
@@ -522,6 +537,46 @@ long long xh_conv3_q4_workspace_bytes(const xh_conv_desc* d) {
 int xh_conv3_q4s_launch(hipStream_t st, const ConvQ4& a, dim3 grid);           // conv3d_q4s.hip
 int xh_conv3_q4p_try(hipStream_t st, const ConvQ4& a);                         // conv3d_q4p.hip: persistent, pipelined over tiles
 int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a);                               // conv3d_q4w.hip: full-row tiles for 128-wide rows
+
+int xh_conv3_q4w_pair_try(hipStream_t st, ConvQ4& a, ConvQ4& b);              // conv3d_q4w.hip
+static inline bool xh_conv3_q4p_pair_blocked(const ConvQ4&) { return false; }  // (the persistent variant is a single-launch plan; pairs take the tile kernel)
+// Two convolutions in one launch: XH_OK if launched, 1 if they are not a pair the full-row kernel takes
+int xh_conv3_q4_pair_try(void* stream, const xh_conv_desc* d0, const xh_conv_ptrs* p0, const xh_conv_desc* d1, const xh_conv_ptrs* p1) {
+  ConvQ4 a, b;
+  if (!q4_plan(d0, &a) || !q4_plan(d1, &b)) return 1;
+  if (!p0->ws || p0->ws_bytes < xh_conv3_q4_workspace_bytes(d0) || !p1->ws || p1->ws_bytes < xh_conv3_q4_workspace_bytes(d1)) return 1;
+  if (!p0->ws_packed || !p1->ws_packed) return 1;      // (packed up front: xh_conv3d_prepack)
+  a.p = *p0; b.p = *p1;
+  a.fin_inv = p0->fin_count > 0 ? 1.0 / (double)p0->fin_count : 0.0;
+  b.fin_inv = p1->fin_count > 0 ? 1.0 / (double)p1->fin_count : 0.0;
+  const int r = xh_conv3_q4w_pair_try((hipStream_t)stream, a, b);
+  if (r != 1) return r;
+  // rows of 32 voxels: the tile kernel, forward with output moments (the 32^3 level's first decoder convs)
+  if (d0->dtype == XH_F32 || d0->dtype != d1->dtype || d0->W != d1->W || d0->H != d1->H || d0->D != d1->D || d0->N != d1->N ||
+      d0->Cout != d1->Cout || d0->pre != 1 || d1->pre != 1 || d0->epi != 2 || d1->epi != 2 || a.act_slope != 1.f || b.act_slope != 1.f ||
+      (a.ci4 > 1) != (b.ci4 > 1) || a.td != b.td || a.tilesW != b.tilesW || a.tilesH != b.tilesH || a.tilesD != b.tilesD || d0->bcast ||
+      d1->bcast || 2 * d0->N > 65535)
+    return 1;
+  if (a.ci4 > 1 && xh_conv3_q4p_pair_blocked(a)) return 1;
+  dim3 grid(a.tilesW * a.tilesH * a.tilesD, d0->Cout / 4, 2 * d0->N);
+  a.fan = b.fan = nullptr;
+  const size_t shm = q4_tile_bytes(a.td) + 48 * sizeof(double) + 3 * Q4_MAXC * sizeof(float);
+  const int f = d0->dtype == XH_F16 ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  xh_note_kernel("conv3_q4_pair_kernel<%d, 1, 2, %s, %d>", f, a.ci4 > 1 ? "true" : "false", a.td);
+#define Q4P(F, M, T) hipLaunchKernelGGL((conv3_q4_pair_kernel<F, 1, 2, M, T>), grid, dim3(256), shm, st, a, b)
+#define Q4PT(F, M)                 \
+  do {                             \
+    if (a.td == 8) Q4P(F, M, 8);   \
+    else if (a.td == 4) Q4P(F, M, 4); \
+    else Q4P(F, M, 2);             \
+  } while (0)
+  if (f) { if (a.ci4 > 1) Q4PT(1, true); else Q4PT(1, false); }
+  else { if (a.ci4 > 1) Q4PT(0, true); else Q4PT(0, false); }
+#undef Q4PT
+#undef Q4P
+  return xh_launch_status();
+}
 
 // XH_OK if launched, 1 if the shape is not eligible
 int xh_conv3_q4_try(void* stream, const xh_conv_desc* d, const xh_conv_ptrs* p) {

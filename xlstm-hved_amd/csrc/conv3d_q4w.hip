@@ -64,19 +64,20 @@ template <int FMT> __device__ __forceinline__ f32x2_t q4w_xf(unsigned u, float s
   return max2(v, v * f32x2_t{slope, slope});
 }
 
+// The body takes its block coordinates as arguments (bx, by, bz of a grid gdx x gdy x N): conv3_q4w_kernel passes the launch's own,
+// conv3_q4w_pair_kernel those of the problem a workgroup belongs to -- the same arithmetic on the same data either way.
 template <int FMT, int PRE, int EPI, bool MULTI, int NH>
-__global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
+__device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, const int bx, const int by, const int bz, const int gdx, const int gdy) {
   typedef h16<FMT> ST;
   typedef QW<NH> Q;
   constexpr int WW = Q::WW, WSLOTS = Q::SLOTS, WPITCH = Q::PITCH, WPLANE = Q::PLANE, WTILE = Q::TILE, WNITEM = Q::NITEM, WNIT = Q::NIT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem + WTILE);             // [8 waves][8], then [8] totals + the fan-in flag
   float* s_fin = reinterpret_cast<float*>(smem + WTILE + 80 * sizeof(double));   // [2][Q4_MAXC]: in-kernel InstanceNorm scale / shift
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g4 = lane >> 4;
   const int qd = q4w_quad(nn);                       // the quad (4 consecutive voxels of a 64-voxel half) this lane's N column is
-  const int oq = blockIdx.y, n = blockIdx.z;
+  const int oq = by, n = bz;
   const int co0 = oq * 4;
   const int grp = udiv_fast(oq, a.oq_g, a.mQ);
   const int cin_base = grp * a.Cin_g;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   const long long hw = (long long)H * WW, dhw = (long long)D * hw;
   const int Do = a.d.Do, Ho = a.d.Ho;
   const int tilesH = (Ho + WTH - 1) / WTH;
-  const int wk = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int wk = xcd_swizzle(bx, gdx);
   const int td = wk / tilesH, th = wk - td * tilesH;
   const int od0 = td * WTD, oh0 = th * WTH;
   // raw InstanceNorm sums of this group's input channels (fused finalisation): requested first, used behind the staging loads
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
             if (gam) { const float g_ = gam[cin_base + tid]; sc_ *= g_; sh_ = fmaf(sh_, g_, bet[cin_base + tid]); }
             s_fin[tid] = sc_; s_fin[Q4_MAXC + tid] = sh_;
           }
-          if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+          if (bx == 0 && by == 0 && bz == 0)
             for (int i = tid; i < a.d.N * a.d.Cin; i += 512) {
               float sc_, sh_, m_, r_;
               in_finalize(a.p.fin_red[2 * i], a.p.fin_red[2 * i + 1], a.fin_inv, sc_, sh_, m_, r_);
@@ -340,12 +341,61 @@ __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
       s_red[64 + tid] = tot;
     }
     double* s_tot = s_red + 64;
-    if (a.fan && !fan_in<8>(a.fan + ((long long)n * gridDim.y + oq) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x, s_tot,
+    if (a.fan && !fan_in<8>(a.fan + ((long long)n * gdy + oq) * FAN_UNIT_BYTES, bx, gdx, s_tot,
                             reinterpret_cast<int*>(s_tot + 8)))
       return;
     if (!a.fan) __syncthreads();
     if (tid < 8) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], s_tot[tid]);
   }
+}
+
+template <int FMT, int PRE, int EPI, bool MULTI, int NH>
+__global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  q4w_body<FMT, PRE, EPI, MULTI, NH>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+// Two independent convolutions of one shape in ONE launch (xh_conv3d_fwd_pair): grid z = 2 N, the first N planes of workgroups are
+// problem 0.  The recon | seg streams' first decoder convs (buildingblocks.py:732-735: different inputs, the same shapes) are a
+// single resident round each at 64^3 (256 workgroups on 256 CUs x 2 slots) -- together they fill the round.
+template <int FMT, int PRE, int EPI, bool MULTI, int NH>
+__global__ __launch_bounds__(512, 4) void conv3_q4w_pair_kernel(const ConvQ4 a0, const ConvQ4 a1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = a0.d.N;
+  if ((int)blockIdx.z >= N) q4w_body<FMT, PRE, EPI, MULTI, NH>(a1, smem, blockIdx.x, blockIdx.y, (int)blockIdx.z - N, gridDim.x, gridDim.y);
+  else q4w_body<FMT, PRE, EPI, MULTI, NH>(a0, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// XH_OK if launched, 1 if the two plans do not share an instance / a grid (the caller launches them one by one)
+int xh_conv3_q4w_pair_try(hipStream_t st, ConvQ4& a, ConvQ4& b) {
+  const int nh = a.d.W == 128 ? 2 : a.d.W == 64 ? 1 : 0;
+  if (!nh || !(g_q4_wide & nh) || a.d.dtype == XH_F32 || a.act_slope != 1.f || a.d.pre == 2 || a.d.bcast || b.d.bcast) return 1;
+  if (a.d.dtype != b.d.dtype || a.d.W != b.d.W || a.d.H != b.d.H || a.d.D != b.d.D || a.d.N != b.d.N || a.d.Cout != b.d.Cout ||
+      a.d.pre != b.d.pre || a.d.epi != b.d.epi || (a.ci4 > 1) != (b.ci4 > 1) || b.act_slope != 1.f || b.d.pre == 2) return 1;
+  if (a.d.D < 4 || a.d.H < 8 || 2 * a.d.N > 65535) return 1;
+  const int tilesD = (a.d.Do + WTD - 1) / WTD, tilesH = (a.d.Ho + WTH - 1) / WTH;
+  dim3 grid(tilesD * tilesH, a.d.Cout / 4, 2 * a.d.N);
+  a.fan = b.fan = nullptr;                              // (two problems in flight: direct atomics)
+  const size_t shm = (nh == 2 ? QW<2>::TILE : QW<1>::TILE) + 80 * sizeof(double) + 2 * Q4_MAXC * sizeof(float);
+  const int f = a.d.dtype == XH_F16 ? 1 : 0;
+  const bool multi = a.ci4 > 1;
+  xh_note_kernel("conv3_q4w_pair_kernel<%d, %d, %d, %s, %d>", f, a.d.pre, a.d.epi, multi ? "true" : "false", nh);
+#define QPN(F, P, E, M)                                                                                        \
+  do {                                                                                                         \
+    if (nh == 2) hipLaunchKernelGGL((conv3_q4w_pair_kernel<F, P, E, M, 2>), grid, dim3(512), shm, st, a, b);   \
+    else hipLaunchKernelGGL((conv3_q4w_pair_kernel<F, P, E, M, 1>), grid, dim3(512), shm, st, a, b);           \
+  } while (0)
+#define QPM(F, P, E)               \
+  do {                             \
+    if (multi) QPN(F, P, E, true); \
+    else QPN(F, P, E, false);      \
+  } while (0)
+  // (instances: forward with output moments and the data gradient with norm-backward sums -- what the decoder pairs launch)
+  if (a.d.pre == 1 && a.d.epi == 2) { if (f) QPM(1, 1, 2); else QPM(0, 1, 2); }
+  else if (a.d.pre == 0 && a.d.epi == 1) { if (f) QPM(1, 0, 1); else QPM(0, 0, 1); }
+  else return 1;
+#undef QPM
+#undef QPN
+  return xh_launch_status();
 }
 
 // XH_OK if launched, 1 if this launch stays with conv3_q4_kernel.  `a` is a filled plan (q4_plan + pointers).

@@ -143,10 +143,13 @@ def _pair_methods():
             y1 = torch.empty((1, 2 * c) + size, dtype=x.dtype, device=x.device)          # the first convs' outputs, side by side
             red1 = ops.zeros_red(x, 1, 2 * c)
             g_s, st_s = sdec.atten_module(u_s, (f_p, f_g), stats=True)
-            y1_r, _ = Fn.in_lrelu_conv(f_r, u_r, [rb.SingleConv1.conv.weight], [rb.SingleConv1.conv.bias], out_stats=True, drop_bias=True,
-                                       into=(y1[:, :c], red1[:, :c]))
-            y1_s, _ = Fn.in_lrelu_conv(g_s, None, [sb.SingleConv1.conv.weight], [sb.SingleConv1.conv.bias], in_stats=st_s, out_stats=True,
-                                       drop_bias=True, into=(y1[:, c:], red1[:, c:]))
+            # the two first convs have the same shape and different inputs (recon: the virtual concat [feature | upsampled]; seg: the
+            # gated concat): one launch for both where the full-row kernel takes them (ops.conv_pair_scope)
+            with ops.conv_pair_scope():
+                y1_r, _ = Fn.in_lrelu_conv(f_r, u_r, [rb.SingleConv1.conv.weight], [rb.SingleConv1.conv.bias], out_stats=True,
+                                           drop_bias=True, into=(y1[:, :c], red1[:, :c]))
+                y1_s, _ = Fn.in_lrelu_conv(g_s, None, [sb.SingleConv1.conv.weight], [sb.SingleConv1.conv.bias], in_stats=st_s,
+                                           out_stats=True, drop_bias=True, into=(y1[:, c:], red1[:, c:]))
             y2, st2 = Fn.InLreluConv2.apply(y1_r, y1_s, y1, red1, rb.SingleConv2.conv.weight, sb.SingleConv2.conv.weight,
                                             rb.SingleConv2.conv.bias, sb.SingleConv2.conv.bias)
             pair = dusfe.forward_pair(y2, st2)

@@ -605,10 +605,55 @@ def conv3d(xa, xb, weights, biases, *, k, cout, stride=1, groups=1, transposed=F
     if _C1_COLLECT[0] is not None and k == 1 and stride == 1 and stats is None and nb is None:
         _C1_COLLECT[0].append((desc, ptrs, (xa, xb, out, weights, biases, pre, e, red)))     # launched by conv1x1_flush()
         return out
-    L.check(lib.xh_conv3d_fwd(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_fwd")
+    if _PAIR_COLLECT[0] is not None and k == 3 and stride == 1 and not bcast and nb is None and out is not False:
+        # launched by conv_pair_scope.__exit__: two independent convs of one shape share a launch (xh_conv3d_fwd_pair)
+        _PAIR_COLLECT[0].append((desc, ptrs, (xa, xb, out, weights, biases, pre, e, red, stats)))
+    else:
+        L.check(lib.xh_conv3d_fwd(_stream(), C.byref(desc), C.byref(ptrs)), "xh_conv3d_fwd")
     if stats is not None:
         return (out,) + stats
     return out if out is not False else None
+
+
+_PAIR_COLLECT = [None]
+CONV_PAIRS = [os.environ.get("XH_NO_CONV_PAIRS", "") == ""]     # A/B switch
+
+
+def set_conv_pairs(enabled):
+    CONV_PAIRS[0] = bool(enabled)
+
+
+class conv_pair_scope:
+    """with conv_pair_scope(): the k = 3 stride-1 conv3d calls inside are recorded (their output tensors are returned as usual) and
+    issued when the scope ends -- two of them as ONE launch when they are independent convolutions of one shape
+    (xh_conv3d_fwd_pair: the recon | seg streams' first decoder convs), else one by one in the order they were made.  The caller
+    guarantees that nothing inside the scope reads an output of a recorded call."""
+
+    def __enter__(self):
+        self.on = CONV_PAIRS[0] and _PAIR_COLLECT[0] is None
+        if self.on:
+            _PAIR_COLLECT[0] = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if not self.on:
+            return False
+        calls, _PAIR_COLLECT[0] = _PAIR_COLLECT[0], None
+        if et is not None:
+            return False                                  # (an error inside the scope: nothing is launched)
+        lib = L.load()
+        i = 0
+        while i < len(calls):
+            if i + 1 < len(calls):
+                rc = lib.xh_conv3d_fwd_pair(_stream(), C.byref(calls[i][0]), C.byref(calls[i][1]), C.byref(calls[i + 1][0]), C.byref(calls[i + 1][1]))
+                if rc == 0:
+                    i += 2
+                    continue
+                if rc < 0:
+                    L.check(rc, "xh_conv3d_fwd_pair")
+            L.check(lib.xh_conv3d_fwd(_stream(), C.byref(calls[i][0]), C.byref(calls[i][1])), "xh_conv3d_fwd")
+            i += 1
+        return False
 
 
 def conv3d_supports_bcast(x, cout, groups):
