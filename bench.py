@@ -225,6 +225,8 @@ def main():
     model = X.XLSTM_HVED(1, 3, **X.TRAIN_KWARGS)
     model.apply(X.init_weights)
     model = model.to(dev).train()
+    model.noise_state(dev)
+    model.seed_noise(20260 + rank)                             # reparameterisation noise: per rank (seed = base + rank)
     params = [p for p in model.parameters()]
     g = torch.Generator(device="cpu").manual_seed(1 + rank)   # per-rank synthetic patch
     x = torch.rand(B, 4, S, S, S, generator=g).to(dev, dtype)
