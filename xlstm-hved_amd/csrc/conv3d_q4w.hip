@@ -66,7 +66,9 @@ template <int FMT> __device__ __forceinline__ f32x2_t q4w_xf(unsigned u, float s
 
 // The body takes its block coordinates as arguments (bx, by, bz of a grid gdx x gdy x N): conv3_q4w_kernel passes the launch's own,
 // conv3_q4w_pair_kernel those of the problem a workgroup belongs to -- the same arithmetic on the same data either way.
-template <int FMT, int PRE, int EPI, bool MULTI, int NH>
+// BC: a broadcast operand (xh_conv_desc.bcast) -- a template argument so that the ordinary instances carry none of its registers: as
+// run-time flags they cost the dominant data-gradient instance <0, 0, 1, false, 2> six spilled registers (128 of 128 in use).
+template <int FMT, int PRE, int EPI, bool MULTI, int NH, bool BC = false>
 __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, const int bx, const int by, const int bz, const int gdx, const int gdy) {
   typedef h16<FMT> ST;
   typedef QW<NH> Q;
@@ -135,8 +137,8 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
   const unsigned lane_b = (unsigned)(((long long)g4 * odhw + (long long)(row_ok ? oh : 0) * WW + 4 * qd) * (long long)sizeof(ST));
   // broadcast operands (xh_conv_desc.bcast): the forward input / the data gradient's e operand is ONE stored channel per group, seen
   // through four (scale, shift) pairs; a data gradient without y only sums (every store lands outside the window and is dropped)
-  const bool bc_in = a.d.bcast && !a.d.transposed, bc_e = a.d.bcast && a.d.transposed;
-  const bool st_ok = row_ok && a.p.y != nullptr;
+  const bool bc_in = BC && !a.d.transposed, bc_e = BC && a.d.transposed;
+  const bool st_ok = BC ? (row_ok && a.p.y != nullptr) : row_ok;
   const unsigned lane_e = bc_e ? (unsigned)(((long long)(row_ok ? oh : 0) * WW + 4 * qd) * (long long)sizeof(ST)) : lane_b;
   const unsigned lane_bo = st_ok ? lane_b : Q4_OOB;
   constexpr unsigned HALF_B = 64 * sizeof(ST);         // byte distance of the two halves of a row
@@ -144,7 +146,7 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
   if (EPI == 1) {
     esc = a.p.e_sc[n * a.d.Cout + co0 + g4];
     esh = a.p.e_sh[n * a.d.Cout + co0 + g4];
-    if (bc_e && a.p.e_ctr) ectr = a.p.e_ctr[n * a.d.Cout + co0 + g4];
+    if (BC && bc_e && a.p.e_ctr) ectr = a.p.e_ctr[n * a.d.Cout + co0 + g4];
     ers = q4_window(reinterpret_cast<const char*>(bc_e ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)(co0 >> 2) * odhw
                                                   : co0 < a.d.Cea ? (const ST*)a.p.ea + n * a.d.ea_bs + (long long)co0 * odhw
                                                                   : (const ST*)a.p.eb + n * a.d.eb_bs + (long long)(co0 - a.d.Cea) * odhw) +
@@ -315,7 +317,8 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
         if (live) {
           const f32x2_t r0 = cvt2_in<FMT>(pk.x), r1 = cvt2_in<FMT>(pk.y);         // the values as stored
           ps += r0 + r1;
-          pq += r0 * (e[0] - ectr2) + r1 * (e[1] - ectr2);     // (ectr = 0 but for a broadcast e operand: e - 0 is exact)
+          if (BC) pq += r0 * (e[0] - ectr2) + r1 * (e[1] - ectr2);      // (a broadcast e operand: the second sum around its centre)
+          else pq += r0 * e[0] + r1 * e[1];
         }
       } else {
         pk.x = cvt2_pack<FMT>(v[0].x, v[0].y); pk.y = cvt2_pack<FMT>(v[1].x, v[1].y);
@@ -349,10 +352,10 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
   }
 }
 
-template <int FMT, int PRE, int EPI, bool MULTI, int NH>
+template <int FMT, int PRE, int EPI, bool MULTI, int NH, bool BC = false>
 __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  q4w_body<FMT, PRE, EPI, MULTI, NH>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+  q4w_body<FMT, PRE, EPI, MULTI, NH, BC>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 // Two independent convolutions of one shape in ONE launch (xh_conv3d_fwd_pair): grid z = 2 N, the first N planes of workgroups are
 // problem 0.  The recon | seg streams' first decoder convs (buildingblocks.py:732-735: different inputs, the same shapes) are a
@@ -435,6 +438,19 @@ int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a) {
     else if (a.d.epi == 1) QWM(F, P, 1); \
     else QWM(F, P, 2);                   \
   } while (0)
+  if (a.d.bcast) {
+    // broadcast operand: the two instances the init fold launches (forward + moments; data gradient + norm-backward sums), one quad per group
+    if (multi || !((a.d.pre == 1 && a.d.epi == 2 && !a.d.transposed) || (a.d.pre == 0 && a.d.epi == 1 && a.d.transposed))) return XH_ERR_ARG;
+#define QWB(F, P, E)                                                                                               \
+  do {                                                                                                              \
+    if (nh == 2) hipLaunchKernelGGL((conv3_q4w_kernel<F, P, E, false, 2, true>), grid, dim3(512), shm, st, a);      \
+    else hipLaunchKernelGGL((conv3_q4w_kernel<F, P, E, false, 1, true>), grid, dim3(512), shm, st, a);              \
+  } while (0)
+    if (a.d.pre == 1) { if (f) QWB(1, 1, 2); else QWB(0, 1, 2); }
+    else { if (f) QWB(1, 0, 1); else QWB(0, 0, 1); }
+#undef QWB
+    return xh_launch_status();
+  }
   if (f) { if (a.d.pre) QWE(1, 1); else QWE(1, 0); }
   else { if (a.d.pre) QWE(0, 1); else QWE(0, 0); }
 #undef QWE
