@@ -685,6 +685,13 @@ int xh_multi_sum(void* stream, int dtype, int nt, const void* const* ptrs, const
                  double* red);
 int xh_multi_fill(void* stream, int dtype, int nt, void* const* ptrs, const long long* numels, const float* values, const float* gscale);
 
+/* Scalar glue of a loss (train.py:240,262,280: weighted sums of loss terms; loss.py:85-115 averaged over the latent levels at
+ * train.py:235-239): out[0] = sum_i coef[i] * src[i][0] over n <= XH_SCALAR_MAX DEVICE scalars, each fp32 or fp64 (is_f64[i]);
+ * host arrays are read during the call.  xh_scalar_fanout is its backward: out32[i] = out64[i] = coef[i] * g[0]. */
+#define XH_SCALAR_MAX 16
+int xh_scalar_lincomb(void* stream, int n, const void* const* src, const int* is_f64, const double* coef, float* out);
+int xh_scalar_fanout(void* stream, int n, const double* coef, const float* g, float* out32, double* out64);
+
 /* ------------------------------------------------------------------------------------------------
  * Discriminator (RA_HVED.py:204-236, buildingblocks.py:342-358): convolutions 7 -> 64 -> 128 -> 256 -> 512 -> 1 with kernel
  * size ks = 4 (train.py:146, Pretrain.py:150) or 3 (the class default), padding 1, strides 1,2,2,2,1, as implicit GEMMs on the

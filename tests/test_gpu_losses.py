@@ -84,3 +84,68 @@ def test_sum_of_means_matches_torch():
     assert abs(m.item() - ref.item()) < 1e-6
     for t in ts:
         assert torch.allclose(t.grad.float(), torch.full(t.shape, 2.0 / t.numel(), device=DEV).bfloat16().float())
+
+
+def test_loss_terms_combined_in_one_node_match_the_term_by_term_sum():
+    """train.py:262 as losses.combine (ops.scalar_lincomb / scalar_fanout): value and every term's gradient equal the chain of scalar
+    ATen operations; fp32 and fp64 terms mix (the KL reductions are fp64)."""
+    from xlstm_hved_amd import losses
+    torch.manual_seed(3)
+    a = [torch.rand((), device=DEV, dtype=torch.float32, requires_grad=True) for _ in range(3)]
+    b = [torch.rand((), device=DEV, dtype=torch.float64, requires_grad=True) for _ in range(2)]
+    coefs = [1.0, 1.0, 0.2, 0.2, 0.1]
+    tot = losses.combine(a + b, coefs)
+    assert tot.dim() == 0 and tot.dtype == torch.float32
+    seed = torch.full((), 3.0, device=DEV)
+    tot.backward(seed)
+    ref = sum(c * t.detach().double() for c, t in zip(coefs, a + b))
+    assert abs(tot.item() - ref.item()) < 1e-6
+    for c, t in zip(coefs, a + b):
+        assert t.grad.dtype == t.dtype and abs(t.grad.item() - 3.0 * c) < 1e-6
+    with pytest.raises(Exception):
+        X.ops.scalar_lincomb([torch.zeros(2, device=DEV)], [1.0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_gan_pair_loss_equals_the_two_losses_on_the_halves(dtype):
+    """alpha * 0.5 * (GANLoss(D(fake), False) + GANLoss(D(real), True)) (train.py:272-280) as one reduction against a resident
+    label tensor: value and gradient of the two-loss form."""
+    from xlstm_hved_amd import losses
+    torch.manual_seed(4)
+    out = torch.randn(4, 1, 6, 6, 6, device=DEV).to(dtype).requires_grad_(True)
+    one = losses.gan_pair_loss(out, 2, 0.1)
+    one.backward()
+    g1 = out.grad.clone()
+    out.grad = None
+    gan = X.GANLoss()
+    two = 0.1 * (gan(out[:2].float(), False) + gan(out[2:].float(), True)) * 0.5
+    two.backward()
+    assert abs(one.item() - two.item()) <= 1e-6 * max(1.0, abs(two.item()))
+    assert g1.dtype == dtype
+    assert l2_err(g1, out.grad) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+def test_kld_over_the_levels_as_one_node_equals_the_per_level_mean():
+    """train.py:235-239: sum_l compute_KLD(mu[l], lv[l], subset) / 4 -- one node (losses.compute_KLD_levels) against the loop."""
+    from xlstm_hved_amd import losses
+    torch.manual_seed(5)
+    shapes = [(1, 5, 8, 2, 2, 2), (1, 5, 4, 4, 4, 4), (1, 5, 2, 8, 8, 8), (1, 5, 1, 16, 16, 16)]
+    mu = [(0.3 * torch.randn(s, device=DEV)).requires_grad_(True) for s in shapes]
+    lv = [(0.2 * torch.randn(s, device=DEV)).requires_grad_(True) for s in shapes]
+    for subset in ([7], [2, 12], torch.tensor([[1.0, 0.0, 1.0, 1.0]], device=DEV)):
+        for t in mu + lv:
+            t.grad = None
+        one = losses.compute_KLD_levels(mu, lv, subset)
+        one.backward(torch.full((), 2.0, device=DEV))
+        g1 = [t.grad.clone() for t in mu + lv]
+        for t in mu + lv:
+            t.grad = None
+        ref = None
+        for l in range(4):
+            k = X.compute_KLD(mu[l], lv[l], subset)
+            ref = k if ref is None else ref + k
+        ref = ref / 4
+        ref.backward(torch.full((), 2.0, device=DEV))
+        assert abs(one.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item())), (one.item(), ref.item())
+        for a_, t in zip(g1, mu + lv):
+            assert l2_err(a_, t.grad) < 1e-5

@@ -15,6 +15,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $B
 echo "trace done"
 python3 tools/summarize_rocprof.py $OUT/trace gpurun_out/profiles_out/${TAG}_trainstep_graph_bf16_kernel_stats.md --steps 35 --title "Round 6 ($TAG): bench.py with the training-step leg (train.py:208-296, ks=4 Discriminator), bf16, hipGraph replay, 128^3" --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 $BENCH  (generator-only step: 2 eager + 1 capture + 16 replays; training step: 2 eager + 1 capture + 33 replays -- per-launch averages of the dconv_* / dwgrad_* kernels are training-step figures)" >> $OUT/trace.log 2>&1 || echo "summarize_rocprof failed"
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) gpurun_out/profiles_out/${TAG}_trainstep_graph_bf16_kernel_stats.csv
+# the training step is the last graph the command replays: its launch list and family timeline
+python3 tools/dump_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > gpurun_out/profiles_out/${TAG}_trainstep_launches.txt 2>&1 || true
+python3 tools/timeline_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) gpurun_out/profiles_out/trainstep_families.json "profiles/${TAG}_trainstep_timeline.txt: rocprofv3 --kernel-trace -- python3 $BENCH, last replayed training step (tools/timeline_step.py)" > gpurun_out/profiles_out/${TAG}_trainstep_timeline.txt 2>&1 || true
+if [ "${PMC:-1}" = "0" ]; then echo "trace only"; exit 0; fi
 PB="bench.py --steps 3 --warmup 1 --inner 1 --no-cpu --no-roofline --no-modes --no-config3"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1 -- python3 $PB > $OUT/sq1.log 2>&1
 echo "sq1 done"

@@ -14,7 +14,8 @@ from .model import (MODELS, SUBSETS_MODALITIES, AbstractFusion3DUNet, ReconDecod
                     XLSTM_HVED_woViL, find_model_using_name)
 from .utils import init_weights, seed_everything, subset_idx  # noqa: F401
 from . import inference, losses  # noqa: F401
-from .losses import DiceCoefficient, DiceLoss, DiceRegion, GANLoss, MSELoss, compute_KLD, mse_loss, nested_attention  # noqa: F401
+from .losses import (DiceCoefficient, DiceLoss, DiceRegion, GANLoss, MSELoss, combine, compute_KLD, compute_KLD_levels,  # noqa: F401
+                     gan_pair_loss, mse_loss, nested_attention)
 from .inference import eval_overlap_volume  # noqa: F401
 
 TRAIN_KWARGS = dict(multi_stream=4, fusion_level=4, shared_recon=True, recon_skip=True, MVAE_reduction=True,

@@ -199,6 +199,8 @@ SIGNATURES = {
     "xh_kld_bwd": (I, [vp, I, vp, vp, vp, I, I, ll, F, vp, vp, vp]),
     "xh_nested_weight": (I, [vp, I, vp, ll, vp, ll, I, ll]),
     "xh_fill": (I, [vp, I, vp, ll, F, vp]),
+    "xh_scalar_lincomb": (I, [vp, I, vp, vp, vp, vp]),
+    "xh_scalar_fanout": (I, [vp, I, vp, vp, vp, vp]),
     "xh_multi_sum": (I, [vp, I, I, vp, vp, vp, vp, vp]),
     "xh_multi_fill": (I, [vp, I, I, vp, vp, vp, vp]),
     "xh_dconv_cl": (I, [vp, I, I, I, I, vp, vp, vp, vp, vp, I, I, I, I, I, I, I, I, I, I, F, vp]),

@@ -89,11 +89,11 @@ __global__ __launch_bounds__(256) void conv3_pack_multi_kernel(const PackMulti m
 struct PackTableHead { int n, nblocks; int first_block[XH_PACK_TABLE_MAX + 1]; int pad_; };
 __global__ __launch_bounds__(256) void conv3_pack_table_kernel(const PackTableHead* __restrict__ h) {
   const PackJob* jobs = reinterpret_cast<const PackJob*>(h + 1);
-  int lo = 0, hi = h->n - 1;                            // the job whose block range holds blockIdx.x
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if ((int)blockIdx.x >= h->first_block[mid]) lo = mid; else hi = mid - 1;
-  }
+  // the job whose block range holds blockIdx.x = the number of range starts (entries 1 .. n - 1) at or below it.  Thread t tests entry
+  // t + 1: ONE load latency and a counting barrier (a binary search was a chain of log2(n) dependent loads from device memory in
+  // front of every block of a launch whose whole run time is such a chain: 22.5 us for the step's 1 467 blocks)
+  const int nj = h->n;
+  const int lo = __builtin_amdgcn_readfirstlane(__syncthreads_count((int)threadIdx.x + 1 < nj && h->first_block[threadIdx.x + 1] <= (int)blockIdx.x));
   const PackJob j = jobs[lo];
   const int base = ((int)blockIdx.x - h->first_block[lo]) * XH_PACK_PER_BLOCK;
   if (j.kind == 1 || (j.kind == 0 && j.f16 != 2)) {     // a lane's 16 bytes at once (nelem is a multiple of 512 in both layouts)

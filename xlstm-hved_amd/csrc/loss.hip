@@ -414,3 +414,50 @@ extern "C" int xh_fill(void* stream, int dtype, void* out, long long n, float v,
   XH_DISPATCH_T(dtype, hipLaunchKernelGGL(fill_kernel<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (T*)out, n, v, gscale););
   return xh_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ scalar glue of a loss
+// train.py:240,262,280 add five loss terms with three weights, average four KL terms, halve a sum of two: as ATen ops on device
+// scalars that is one ~5 us launch per operation and as many again in backward (60 of the training step's 82 ATen launches).
+// One launch forms the weighted sum of up to XH_SCALAR_MAX device scalars (fp32 or fp64), one launch fans the upstream gradient
+// out to them.
+struct XhScalars {
+  const void* p[XH_SCALAR_MAX];
+  double c[XH_SCALAR_MAX];
+  int f64[XH_SCALAR_MAX];
+  int n;
+};
+__global__ __launch_bounds__(64) void scalar_lincomb_kernel(const XhScalars s, float* out) {
+  const int i = threadIdx.x;
+  double v = 0.0;
+  if (i < s.n) v = s.c[i] * (s.f64[i] ? *reinterpret_cast<const double*>(s.p[i]) : (double)*reinterpret_cast<const float*>(s.p[i]));
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);            // XH_SCALAR_MAX = 16 lanes carry terms
+  if (i == 0) out[0] = (float)v;
+}
+__global__ __launch_bounds__(64) void scalar_fanout_kernel(const XhScalars s, const float* g, float* o32, double* o64) {
+  const int i = threadIdx.x;
+  if (i < s.n) {
+    const double v = s.c[i] * (double)g[0];
+    o32[i] = (float)v;
+    o64[i] = v;
+  }
+}
+extern "C" int xh_scalar_lincomb(void* stream, int n, const void* const* src, const int* is_f64, const double* coef, float* out) {
+  if (n <= 0 || n > XH_SCALAR_MAX || !src || !is_f64 || !coef || !out) return XH_ERR_ARG;
+  XhScalars s;
+  s.n = n;
+  for (int i = 0; i < XH_SCALAR_MAX; ++i) {
+    s.p[i] = i < n ? src[i] : nullptr; s.c[i] = i < n ? coef[i] : 0.0; s.f64[i] = i < n ? is_f64[i] : 0;
+    if (i < n && !src[i]) return XH_ERR_ARG;
+  }
+  hipLaunchKernelGGL(scalar_lincomb_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s, out);
+  return xh_launch_status();
+}
+extern "C" int xh_scalar_fanout(void* stream, int n, const double* coef, const float* g, float* out32, double* out64) {
+  if (n <= 0 || n > XH_SCALAR_MAX || !coef || !g || !out32 || !out64) return XH_ERR_ARG;
+  XhScalars s;
+  s.n = n;
+  for (int i = 0; i < XH_SCALAR_MAX; ++i) { s.p[i] = nullptr; s.c[i] = i < n ? coef[i] : 0.0; s.f64[i] = 0; }
+  hipLaunchKernelGGL(scalar_fanout_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s, g, out32, out64);
+  return xh_launch_status();
+}

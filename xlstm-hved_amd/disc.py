@@ -79,8 +79,10 @@ def _conv(x, wp, bias, mode, stride, n, sp_in, sp_out, cs, cn, red=None, act=L.A
     return y
 
 
-def _wgrad(x, dy, stride, n, sp_in, sp_out, cs, cn, ks=3, gs=None):
-    dwp = torch.zeros(ks ** 3 * cn * cs, dtype=torch.float32, device=x.device)
+def _wgrad(x, dy, stride, n, sp_in, sp_out, cs, cn, ks=3, gs=None, dwp=None):
+    """Packed fp32 weight gradient; `dwp`: a ZEROED destination of ks^3 * cn * cs floats (default: a fresh one)."""
+    if dwp is None:
+        dwp = torch.zeros(ks ** 3 * cn * cs, dtype=torch.float32, device=x.device)
     L.check(L.load().xh_dconv_wgrad_cl(_s(), ops._dt(x), stride, ks, x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), n, *sp_in, *sp_out, cs, cn),
             "xh_dconv_wgrad_cl")
     return dwp.div_(gs) if gs is not None else dwp
@@ -200,6 +202,21 @@ def _backward(bufs, lo, n, sp, ks, dt, cin, weights, params, dout, need_w, need_
         gbufs, rets = [None] * 9, [None] * 9
     g_w0, g_b0, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wl = gbufs
     c3 = wl.shape[1]
+    # every zeroed scratch of the pass in TWO fills: the fp64 sums of the three norm layers + block 0's bias sums, and (with parameter
+    # gradients) the packed fp32 weight gradients of the four convolutions -- instead of one small fill in front of each kernel
+    ws_ = (w1, w2, w3)
+    red_n = [n * wk.shape[0] * 2 for wk in ws_] + [n * w0.shape[0] * 2]
+    red_all = torch.zeros(sum(red_n), dtype=torch.float64, device=dev)
+    red_of, o = [], 0
+    for r in red_n:
+        red_of.append(red_all[o:o + r]); o += r
+    dwp_of = [None] * 4
+    if need_w:
+        dw_n = [ks ** 3 * wk.shape[0] * (8 if wk is w0 else wk.shape[1]) for wk in (w0, w1, w2, w3)]
+        dw_all = torch.zeros(sum(dw_n), dtype=torch.float32, device=dev)
+        o = 0
+        for i, r in enumerate(dw_n):
+            dwp_of[i] = dw_all[o:o + r]; o += r
     if _head_ok(wl):
         # the head's backward as two reduction kernels (xh_dlast_wgrad adds straight into the parameter gradient; xh_dlast_dgrad)
         dy1 = (dout.reshape((n,) + sp[5]) * gs if gs is not None else dout.reshape((n,) + sp[5])).to(dt).contiguous()
@@ -222,7 +239,7 @@ def _backward(bufs, lo, n, sp, ks, dt, cin, weights, params, dout, need_w, need_
         sc, sh, mean, rstd = stats[k - 1]
         c = raws[k - 1]
         cnt = sp[k + 1][0] * sp[k + 1][1] * sp[k + 1][2]
-        red = torch.zeros((n, cn, 2), dtype=torch.float64, device=dev)
+        red = red_of[k - 1].view(n, cn, 2)
         args = (ops._dt(c), da.data_ptr(), c.data_ptr())
         L.check(lib.xh_cl_act_bwd(_s(), args[0], 0, args[1], args[2], None, sc.data_ptr(), sh.data_ptr(), SLOPE, None, None, None,
                                   red.data_ptr(), n, cn, cnt), "xh_cl_act_bwd")
@@ -231,7 +248,7 @@ def _backward(bufs, lo, n, sp, ks, dt, cin, weights, params, dout, need_w, need_
         L.check(lib.xh_cl_act_bwd(_s(), args[0], 1, args[1], args[2], dc.data_ptr(), sc.data_ptr(), sh.data_ptr(), SLOPE, A.data_ptr(),
                                   B.data_ptr(), Cc.data_ptr(), None, n, cn, cnt), "xh_cl_act_bwd")
         if need_w:
-            _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k], sp[k + 1], cs, cn, ks=ks, gs=gs), g_w, cn, cs)
+            _unpack(_wgrad(acts[k - 1], dc, 2, n, sp[k], sp[k + 1], cs, cn, ks=ks, gs=gs, dwp=dwp_of[k]), g_w, cn, cs)
         if k > 1:
             da = _conv(dc, _pack_cached(wk, 1, cn, cs, dt), None, 1, 2, n, sp[k + 1], sp[k], cn, cs, ks=ks)
     if not need_w and not need_dx:
@@ -240,11 +257,11 @@ def _backward(bufs, lo, n, sp, ks, dt, cin, weights, params, dout, need_w, need_
     # disc.1's data gradient (mask = the stored activation y0): no separate pass over the 64-channel full-resolution tensor
     c0 = w0.shape[0]
     V0 = sp[0][0] * sp[0][1] * sp[0][2]
-    red0 = torch.zeros((n, c0, 2), dtype=torch.float64, device=dev)
+    red0 = red_of[3].view(n, c0, 2)
     g0 = _conv(dc, _pack_cached(w1, 1, w1.shape[0], c0, dt), None, 1, 2, n, sp[2], sp[1], w1.shape[0], c0, ks=ks, red=red0, mask=acts[0])
     if need_w:
         g_b0 += (red0[:, :, 0].sum(0) / gs if gs is not None else red0[:, :, 0].sum(0)).float()
-        _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[1], 8, c0, ks=ks, gs=gs), g_w0, c0, 8)
+        _unpack(_wgrad(xin, g0, 1, n, sp[0], sp[1], 8, c0, ks=ks, gs=gs, dwp=dwp_of[0]), g_w0, c0, 8)
     dx = None
     if need_dx:
         dxin = _conv(g0, _pack_cached(w0, 1, c0, 8, dt), None, 1, 1, n, sp[1], sp[0], c0, 8, ks=ks)

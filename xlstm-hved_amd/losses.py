@@ -50,9 +50,10 @@ def _as_target(t, like):
 
 class _MSE(Function):
     @staticmethod
-    def forward(ctx, a, b, bval):
+    def forward(ctx, a, b, bval, scale=1.0):
         red = ops.pair_sums(a, b, bval=bval)
-        loss, ca, cb = ops.loss_finalize(1, red, count=a.numel())
+        # scale * mean: the divisor carries the weight, so the loss AND the coefficients of its gradient come out scaled
+        loss, ca, cb = ops.loss_finalize(1, red, count=a.numel() / float(scale))
         ctx.save_for_backward(a, b, ca, cb)
         ctx.bval = bval
         return loss.reshape(())
@@ -65,7 +66,7 @@ class _MSE(Function):
         db = None
         if b is not None and ctx.needs_input_grad[1]:
             db = ops.lincomb(b, a, ca, cb, gscale=gs) if b.dtype == a.dtype else None
-        return da, db, None
+        return da, db, None, None
 
 
 def mse_loss(a, b):
@@ -91,6 +92,89 @@ class GANLoss(torch.nn.Module):
         return _MSE.apply(input, None, self.real_label if target_is_real else self.fake_label)
 
 
+_LABELS = {}
+
+
+def gan_pair_loss(out, nb, scale=1.0, fake_label=0.0, real_label=1.0):
+    """scale * 0.5 * (GANLoss(out[:nb], False) + GANLoss(out[nb:], True)) (train.py:272-280, least squares) for a batch that
+    holds the fake samples' predictions in its first nb rows and the real samples' in the other nb: ONE reduction against a
+    resident label tensor and one gradient pass over the whole batch, instead of two losses on slices whose backward is two
+    zero-fills, two copies and an add before the discriminator's backward can start."""
+    if out.shape[0] != 2 * nb:
+        raise ValueError("gan_pair_loss takes the predictions of nb fake and nb real samples")
+    key = (tuple(out.shape), out.device, nb, float(fake_label), float(real_label))
+    lab = _LABELS.get(key)
+    if lab is None:                       # built on the first (eager) call: nothing is created inside a captured step
+        lab = torch.empty(out.shape, dtype=torch.float32, device=out.device)
+        lab[:nb] = fake_label
+        lab[nb:] = real_label
+        _LABELS[key] = lab
+    return _MSE.apply(out.contiguous(), lab, 0.0, float(scale))
+
+
+class _Combine(Function):
+    """sum_i coefs[i] * terms[i] over device scalars: one launch forward, one backward (ops.scalar_lincomb / scalar_fanout)."""
+
+    @staticmethod
+    def forward(ctx, coefs, *terms):
+        ctx.coefs = tuple(float(c) for c in coefs)
+        ctx.meta = [(t.dtype, tuple(t.shape)) for t in terms]
+        return ops.scalar_lincomb([t.detach() for t in terms], ctx.coefs).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        o32, o64 = ops.scalar_fanout(ctx.coefs, g.float().reshape(1).contiguous())
+        return (None,) + tuple((o64 if dt == torch.float64 else o32)[i].reshape(shape) if ctx.needs_input_grad[i + 1] else None
+                               for i, (dt, shape) in enumerate(ctx.meta))
+
+
+def combine(terms, coefs):
+    """The weighted sum of loss terms (train.py:262: dice + m_dice + beta * recon + beta * kld + alpha * g_gan) as ONE node."""
+    terms = [t if t.dtype in (torch.float32, torch.float64) else t.float() for t in terms]
+    return _Combine.apply(tuple(coefs), *terms)
+
+
+class _KLDLevels(Function):
+    """mean over the latent levels of compute_KLD (train.py:235-239) for one keep mask: the levels' reductions land in one zeroed
+    block, one launch turns them into the mean; backward is one pass per level scaled by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, keep, *stacks):
+        nl = len(stacks) // 2
+        mus, lvs = [m.contiguous() for m in stacks[:nl]], [v.contiguous() for v in stacks[nl:]]
+        red = ops.zeros_f64(keep.device, (nl * 16,))                  # one 128-byte line per level: the levels' atomics do not meet
+        ctx.scales = []
+        for l in range(nl):
+            n, _, L_, d, h, w = mus[l].shape
+            ctx.scales.append(0.5 / (n * L_ * d * h * w) / nl)
+            ops.kld_fwd(mus[l], lvs[l], keep, red=red[16 * l:16 * l + 1])
+        ctx.save_for_backward(keep, *mus, *lvs)
+        return ops.scalar_lincomb([red[16 * l:16 * l + 1] for l in range(nl)], ctx.scales).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        keep, *stacks = ctx.saved_tensors
+        nl = len(stacks) // 2
+        gs = g.float().reshape(1).contiguous()
+        dmus, dlvs = [], []
+        for l in range(nl):
+            dmu, dlv = ops.kld_bwd(stacks[l], stacks[nl + l], keep, ctx.scales[l], gscale=gs)
+            dmus.append(dmu); dlvs.append(dlv)
+        return (None,) + tuple(dmus) + tuple(dlvs)
+
+
+def compute_KLD_levels(mu_levels, logvar_levels, subset_index_list=(14,)):
+    """sum_l compute_KLD(mu[l], logvar[l], subset) / len(mu) of train.py:235-239 as one node (a device keep mask, or a list of
+    subset indices averaged like loss.py:85-115)."""
+    if torch.is_tensor(subset_index_list):
+        return _KLDLevels.apply(subset_index_list.contiguous(), *mu_levels, *logvar_levels)
+    total = None
+    for idx in subset_index_list:
+        k = _KLDLevels.apply(_keep_of(int(idx), mu_levels[0].shape[0], mu_levels[0].device), *mu_levels, *logvar_levels)
+        total = k if total is None else total + k
+    return total if len(subset_index_list) == 1 else total / len(subset_index_list)
+
+
 class _KLD(Function):
     @staticmethod
     def forward(ctx, mu, lv, keep):
@@ -111,6 +195,15 @@ class _KLD(Function):
 _KEEP = {}
 
 
+def _keep_of(idx, n, device):
+    key = (idx, n, device)
+    keep = _KEEP.get(key)
+    if keep is None:                    # built once per (subset, batch, device): no host-to-device copy inside a captured step
+        keep = _KEEP[key] = torch.tensor([[1.0 if k in SUBSETS_MODALITIES[idx] else 0.0 for k in range(4)]] * n,
+                                         dtype=torch.float32, device=device)
+    return keep
+
+
 def compute_KLD(mu_list, logvar_list, subset_index_list=(14,), choices=(0, 1, 2, 3)):
     """loss.py:85-115 on the (B, 5, L, d, h, w) stacks the model returns per level: for every subset index in the list,
     KL(PoE(prior + subset) || prior), averaged over the list."""
@@ -118,12 +211,7 @@ def compute_KLD(mu_list, logvar_list, subset_index_list=(14,), choices=(0, 1, 2,
         return _KLD.apply(mu_list, logvar_list, subset_index_list.contiguous())
     total = None
     for idx in subset_index_list:
-        key = (int(idx), mu_list.shape[0], mu_list.device)
-        keep = _KEEP.get(key)
-        if keep is None:                # built once per (subset, batch, device): no host-to-device copy inside a captured step
-            keep = _KEEP[key] = torch.tensor([[1.0 if k in SUBSETS_MODALITIES[int(idx)] else 0.0 for k in range(4)]] * mu_list.shape[0],
-                                             dtype=torch.float32, device=mu_list.device)
-        k = _KLD.apply(mu_list, logvar_list, keep)
+        k = _KLD.apply(mu_list, logvar_list, _keep_of(int(idx), mu_list.shape[0], mu_list.device))
         total = k if total is None else total + k
     return total / len(subset_index_list)
 

@@ -1781,9 +1781,34 @@ def loss_finalize(kind, red, count=1.0, eps=1e-6):
     return (out, ca, cb) if kind < 2 else out
 
 
-def kld_fwd(mu, lv, keep):
+def scalar_lincomb(terms, coefs):
+    """sum_i coefs[i] * terms[i] of <= 16 device scalars (fp32 or fp64 tensors of one element) in ONE launch: fp32 (1,)."""
+    n = len(terms)
+    for t in terms:
+        if t.numel() != 1 or t.dtype not in (torch.float32, torch.float64):
+            raise TypeError("scalar_lincomb takes one-element fp32 / fp64 tensors")
+    out = torch.empty(1, dtype=torch.float32, device=terms[0].device)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in terms])
+    f64 = (C.c_int * n)(*[int(t.dtype == torch.float64) for t in terms])
+    cs = (C.c_double * n)(*[float(c) for c in coefs])
+    L.check(L.load().xh_scalar_lincomb(_stream(), n, ptrs, f64, cs, _p(out)), "xh_scalar_lincomb")
+    return out
+
+
+def scalar_fanout(coefs, g):
+    """(fp32 (n,), fp64 (n,)) = coefs * g[0]: the gradients of scalar_lincomb's terms in one launch (g: fp32 device scalar)."""
+    n = len(coefs)
+    o32 = torch.empty(n, dtype=torch.float32, device=g.device)
+    o64 = torch.empty(n, dtype=torch.float64, device=g.device)
+    cs = (C.c_double * n)(*[float(c) for c in coefs])
+    L.check(L.load().xh_scalar_fanout(_stream(), n, cs, _p(_f32(g, "g")), _p(o32), _p(o64)), "xh_scalar_fanout")
+    return o32, o64
+
+
+def kld_fwd(mu, lv, keep, red=None):
     n, five, L_, d, h, w = mu.shape
-    red = torch.zeros(1, dtype=torch.float64, device=mu.device)
+    if red is None:
+        red = torch.zeros(1, dtype=torch.float64, device=mu.device)
     L.check(L.load().xh_kld_fwd(_stream(), _dt(mu), _p(mu), _p(lv), _p(keep), n, L_, d * h * w, _p(red)), "xh_kld_fwd")
     return red
 

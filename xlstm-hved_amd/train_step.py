@@ -127,11 +127,7 @@ class TrainStep:
         dice = self.dice(f_out, mask)                                            # train.py:232-234
         m_dice = self.dice(m_out, mask)
         recon = losses.mse_loss(m_rec, x)
-        kld = None
-        for level in range(len(mu)):                                             # train.py:235-239
-            k = losses.compute_KLD(mu[level], lv[level], subset)
-            kld = k if kld is None else kld + k
-        kld = kld / len(mu)
+        kld = losses.compute_KLD_levels(mu, lv, subset)                          # train.py:235-239: the mean over the levels, one node
         atten_f_x = losses.nested_attention(f_out, f_rec.detach())              # train.py:242-259
         atten_m_x = losses.nested_attention(m_out, m_rec)
         fake = torch.cat([m_out, atten_m_x], 1)
@@ -144,11 +140,12 @@ class TrainStep:
         share = DiscShare() if (self.share_disc_pass and isinstance(self.disc, Discriminator)) else None
         try:
             pred_fake = self.disc(fake, share=share) if share is not None else self._disc(fake)
-            g_gan = self.gan(pred_fake.float(), True)                           # train.py:260-261
+            g_gan = self.gan(pred_fake, True)                                   # train.py:260-261 (the loss reads 16-bit predictions as they are)
         finally:
             for p in dparams:
                 p.requires_grad_(True)
-        loss = dice + m_dice + self.beta * recon + self.beta * kld + self.alpha * g_gan
+        # train.py:262 as ONE node (one launch forward, one backward; term by term it is seven scalar launches and as many back)
+        loss = losses.combine([dice, m_dice, recon, kld, g_gan], [1.0, 1.0, self.beta, self.beta, self.alpha])
         parts = dict(dice=dice, m_dice=m_dice, recon=recon, kld=kld, g_gan=g_gan)
         real = torch.cat([f_out.detach(), atten_f_x.detach()], 1)
         return loss, parts, (fake.detach(), real, f_out.detach(), share)
@@ -158,15 +155,15 @@ class TrainStep:
         if share is not None and share.bufs is not None and fake.shape == real.shape:
             # train.py:272 runs D on fake.detach() again: the same values through the same weights as train.py:260 -- the
             # generator pass's activations are reused and only `real` is run forward; the backward is one batch of two
-            out = self.disc.forward_pair(real, share).float()
-            nb = fake.shape[0]
-            loss_d_fake, loss_d_real = self.gan(out[:nb], False), self.gan(out[nb:], True)
+            # [D(fake); D(real)] against a resident label tensor: alpha * 0.5 * (loss_d_fake + loss_d_real) as one reduction, and ONE
+            # gradient pass over the batch (two losses on slices cost two zero-fills, two copies and an add in backward)
+            out = self.disc.forward_pair(real, share)
+            return losses.gan_pair_loss(out, fake.shape[0], self.alpha, self.gan.fake_label, self.gan.real_label)
         elif isinstance(self.disc, Discriminator) and fake.shape == real.shape:
             # both passes as one batch: InstanceNorm is per sample, so this is the same arithmetic as train.py:272-277, with
             # half the launches and twice the rows for the small deep layers (and one weight-gradient pass instead of two)
-            out = self._disc(torch.cat([fake, real], 0)).float()
-            nb = fake.shape[0]
-            loss_d_fake, loss_d_real = self.gan(out[:nb], False), self.gan(out[nb:], True)
+            out = self._disc(torch.cat([fake, real], 0))
+            return losses.gan_pair_loss(out, fake.shape[0], self.alpha, self.gan.fake_label, self.gan.real_label)
         else:
             loss_d_fake = self.gan(self._disc(fake).float(), False)             # train.py:272-277
             loss_d_real = self.gan(self._disc(real).float(), True)
