@@ -265,3 +265,36 @@ def test_discriminator_exact_fp32_route_vs_reference_fixture(ks):
     print(ks, "exact fp32", {k_: f"{v:.2e}" for k_, v in e.items()})
     # fp32 against fp32 (different summation orders; a LeakyReLU mask flips where a pre-activation is within round-off of zero)
     assert e["y"] < 1e-4 and e["dx"] < 2e-3 and all(v < 2e-3 for kk, v in e.items() if kk not in ("y", "dx")), e
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["bf16", "f16"])
+@pytest.mark.parametrize("ks", [3, 4])
+def test_weight_images_through_lds_tiles_equal_the_element_pack(dtype, ks):
+    """xh_dconv_pack modes 0 / 1 on multiples of 64 channels go through dpack_tile_kernel: the same bytes as the element-per-thread
+    kernel (xh_set_option(14, 4096)), for the layer shapes of the network and the one-output head."""
+    torch.manual_seed(11)
+    for cout, cin in ((128, 64), (256, 128), (1, 512), (64, 192)):
+        w = torch.randn(cout, cin, ks, ks, ks, device=DEV)
+        for mode in (0, 1):
+            if mode == 1 and cout % 64:
+                continue
+            a = D._pack(w, mode, cout, cin, dtype)
+            try:
+                D.L.load().xh_set_option(14, 4096)
+                b = D._pack(w, mode, cout, cin, dtype)
+            finally:
+                D.L.load().xh_set_option(14, 0)
+            torch.cuda.synchronize()
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (cout, cin, mode)
+    # the reducing activation backward with its capped grid (<= 256 workgroups per sample) against the sums taken by torch
+    n, c, v = 2, 64, 40 * 40 * 40
+    dy = torch.randn(n, v, c, device=DEV).to(dtype)
+    x = torch.randn(n, v, c, device=DEV).to(dtype)
+    sc, sh = torch.rand(n, c, device=DEV) + 0.5, torch.randn(n, c, device=DEV) * 0.1
+    red = torch.zeros(n, c, 2, dtype=torch.float64, device=DEV)
+    D.L.check(D.L.load().xh_cl_act_bwd(D._s(), X.ops._dt(dy), 0, dy.data_ptr(), x.data_ptr(), None, sc.data_ptr(), sh.data_ptr(), D.SLOPE,
+                                       None, None, None, red.data_ptr(), n, c, v), "xh_cl_act_bwd")
+    g = dy.double() * torch.where(x.double() * sc.double()[:, None] + sh.double()[:, None] > 0, 1.0, D.SLOPE)
+    ref = torch.stack([g.sum(1), (g * x.double()).sum(1)], -1)
+    torch.cuda.synchronize()
+    assert ((red - ref).abs().max() / ref.abs().max()).item() < 1e-5

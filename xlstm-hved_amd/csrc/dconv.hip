@@ -1525,6 +1525,31 @@ __global__ __launch_bounds__(256) void dpack_kernel(const float* w, u16* out, in
   }
   out[i] = fmt ? f2hf(v) : f2bf(v);
 }
+// Modes 0 / 1 for unpadded multiples of 64 channels: a workgroup moves a (64 inner channels x K^3 taps) tile through LDS.  The element-
+// per-thread kernel above reads fp32 weights K^3 floats apart and writes two bytes per thread (the 256 -> 512 layer: 40 us per image, two
+// images per step); here the tile is read as whole 128-byte lines (mode 0: one contiguous run) and written as 128-byte runs of one tap.
+//   src(j, tap) = w[base + j * jstride + tap],   dst(tap, j) = out[dbase + tap * tstride + j],   j < 64
+template <int FMT>
+__global__ __launch_bounds__(256) void dpack_tile_kernel(const float* __restrict__ w, u16* __restrict__ out, int K3, long long jstride,
+                                                        long long tstride, long long src_x, long long src_y, long long dst_x, long long dst_y) {
+  extern __shared__ float s_pk[];                          // [64][K3 + 1]
+  const float* src = w + blockIdx.x * src_x + blockIdx.y * src_y;
+  u16* dst = out + blockIdx.x * dst_x + blockIdx.y * dst_y;
+  const int P = K3 + 1;
+  for (int e = threadIdx.x; e < 64 * K3; e += 256) {
+    const int j = e / K3, tap = e - j * K3;
+    s_pk[j * P + tap] = src[j * jstride + tap];
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < K3 * 8; it += 256) {
+    const int j8 = it & 7, tap = it >> 3;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = s_pk[(j8 * 8 + q) * P + tap];
+    *reinterpret_cast<uint4*>(dst + tap * tstride + j8 * 8) =
+        make_uint4(cvt_pack<FMT>(v[0], v[1]), cvt_pack<FMT>(v[2], v[3]), cvt_pack<FMT>(v[4], v[5]), cvt_pack<FMT>(v[6], v[7]));
+  }
+}
 // dw_param[co][ci][tap] += dwp[tap][co (row stride CoutPad rows)][ci (< CinPad)]
 __global__ __launch_bounds__(256) void dunpack_kernel(const float* dwp, float* dw, int Cout, int Cin, int CoutPad, int CinPad, long long total,
                                                      int K3) {
@@ -1610,11 +1635,7 @@ __global__ __launch_bounds__(256) void cl_bwd_kernel(const u16* dy, const u16* x
   double s0[8], s1[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
-  if (vl < nvl)
-    for (long long v = v0 + vl; v < v1; v += nvl) {
-      const long long o = ((long long)n * V + v) * C + cc;
-      const uint4 td = *reinterpret_cast<const uint4*>(dy + o);
-      const uint4 tx = *reinterpret_cast<const uint4*>(x + o);
+  auto one = [&](long long o, const uint4 td, const uint4 tx) __attribute__((always_inline)) {
       const unsigned ud[4] = {td.x, td.y, td.z, td.w}, ux[4] = {tx.x, tx.y, tx.z, tx.w};
       unsigned oo[4];
 #pragma unroll
@@ -1633,7 +1654,28 @@ __global__ __launch_bounds__(256) void cl_bwd_kernel(const u16* dy, const u16* x
         if (MODE != 0) oo[k] = cvt_pack<FMT>(r[0], r[1]);
       }
       if (MODE != 0) *reinterpret_cast<uint4*>(dx + o) = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+  };
+  if (vl < nvl) {
+    // four voxels' loads in flight per thread: the reducing modes run with few workgroups (see xh_cl_act_bwd), so a thread's walk is
+    // long and one load pair per trip would be a chain of exposed latencies
+    constexpr int U = 4;
+    long long v = v0 + vl;
+    for (; v + (U - 1) * (long long)nvl < v1; v += U * (long long)nvl) {
+      uint4 td[U], tx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long o = ((long long)n * V + v + u * (long long)nvl) * C + cc;
+        td[u] = *reinterpret_cast<const uint4*>(dy + o);
+        tx[u] = *reinterpret_cast<const uint4*>(x + o);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(((long long)n * V + v + u * (long long)nvl) * C + cc, td[u], tx[u]);
     }
+    for (; v < v1; v += nvl) {
+      const long long o = ((long long)n * V + v) * C + cc;
+      one(o, *reinterpret_cast<const uint4*>(dy + o), *reinterpret_cast<const uint4*>(x + o));
+    }
+  }
   if (MODE != 1) {
     __shared__ double s_acc[2][512];                   // [which][c8 * 8] (C <= 512)
     for (int i = threadIdx.x; i < 2 * 512; i += 256) (&s_acc[0][0])[i] = 0.0;
@@ -1682,7 +1724,7 @@ static void fill_taps(DTaps* t, int mode, int stride, int parity, int K) {
 //   else              128 x 128, K step 64
 int g_dconv_big = 1024;    // xh_set_option(15, n): 256 x 128 tiles from this many 128 x 128 tiles on
 int g_dwh_groups = 32;    // source-block weight gradient: groups of 8 class workgroups per launch (option 26)
-int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients, bit 19: runtime block extents in the k = 4 source-block data gradient, bit 20: (x, y, z) grid instead of column tile = XCD in the forward convs, bit 21: no 128-channel K steps on the 64 x 64 tiles
+int g_dconv_cfg = 0;       // bit 0: one launch per parity class, bit 1: no 256 x 64, bit 2: no small tiles, bit 8: no 256 x 128 tiles, bit 3: 64 x 128 instead of 64 x 64, bit 4: no tap pairs in the weight gradient, bit 5 / 7: 4 / 2 steps in flight for 256 x 16, bit 6: no XCD remap, bit 12: element-per-thread weight pack for every image, bit 10 / 11 / 13: no LDS-halo kernel for the 64 -> 8 data gradient / the 8 -> 64 forward / its weight gradient, bit 14: no source-block kernel for the stride-2 data gradients, bit 15: that kernel on small volumes too, bit 16: one K step of prefetch on the 64 x 64 tiles, bit 17: no source-block kernel for the stride-2 k = 4 weight gradients, bit 19: runtime block extents in the k = 4 source-block data gradient, bit 20: (x, y, z) grid instead of column tile = XCD in the forward convs, bit 21: no 128-channel K steps on the 64 x 64 tiles
 template <int FMT>
 static void launch_dconv(hipStream_t st, DConvK& a, int N) {
   extern int g_dconv_kq;
@@ -2203,6 +2245,19 @@ extern "C" int xh_dconv_pack(void* stream, int dtype, int mode, int ks, const fl
   if (mode == 2 && CinPad != 8) return XH_ERR_ARG;
   const long long k3 = (long long)ks * ks * ks;
   const long long total = mode == 2 ? (long long)ks * ks * Cout * 32 : (mode == 0 ? k3 * Cout * CinPad : k3 * CinPad * CoutPad);
+  if (mode != 2 && CinPad == Cin && CoutPad == Cout && !(g_dconv_cfg & 4096) && (mode == 0 ? Cin % 64 == 0 : Cout % 64 == 0)) {
+    // (xh_set_option(14, 4096): the element-per-thread kernel for every image, A/B and tests)
+    const size_t shm = (size_t)64 * (k3 + 1) * sizeof(float);
+    const dim3 grid(mode == 0 ? Cin / 64 : Cout / 64, mode == 0 ? Cout : Cin);
+    // mode 0: tile (co = y, ci = 64 x + j): src = (co Cin + ci) K3, dst = tap Cout Cin + co Cin + ci
+    // mode 1: tile (ci = y, co = 64 x + j): src = (co Cin + ci) K3, dst = tap Cin Cout + ci Cout + co
+    const long long jstride = mode == 0 ? k3 : (long long)Cin * k3, tstride = (long long)Cout * Cin;
+    const long long src_x = mode == 0 ? 64 * k3 : 64ll * Cin * k3, src_y = mode == 0 ? (long long)Cin * k3 : k3;
+    const long long dst_x = 64, dst_y = mode == 0 ? Cin : Cout;
+    if (dtype == XH_F16) hipLaunchKernelGGL(dpack_tile_kernel<1>, grid, dim3(256), shm, (hipStream_t)stream, w, (u16*)out, (int)k3, jstride, tstride, src_x, src_y, dst_x, dst_y);
+    else hipLaunchKernelGGL(dpack_tile_kernel<0>, grid, dim3(256), shm, (hipStream_t)stream, w, (u16*)out, (int)k3, jstride, tstride, src_x, src_y, dst_x, dst_y);
+    return xh_launch_status();
+  }
   hipLaunchKernelGGL(dpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u16*)out, Cout, Cin, CoutPad,
                      CinPad, mode, dtype == XH_F16 ? 1 : 0, total, ks);
   return xh_launch_status();
@@ -2256,7 +2311,11 @@ extern "C" int xh_cl_act_bwd(void* stream, int dtype, int mode, const void* dy, 
   if ((mode != 0 && !dx) || (mode != 1 && !red) || (mode == 1 && (!A || !B || !Cc))) return XH_ERR_ARG;
   const int nvl = 256 / (C / 8);
   long long blocks = (V + nvl * 16 - 1) / (nvl * 16);
-  if (blocks > 2048) blocks = 2048;
+  // the reducing modes end in one fp64 atomic per (channel, moment) and workgroup, and atomics on ONE address retire one after the
+  // other (~65 ns each): with a workgroup per 16 voxel rows the 128-channel layer of a 128^3 patch (977 workgroups per sample) spent
+  // 64 of its 101 us queueing them.  At most 256 workgroups per sample there; the apply mode keeps its finer grid
+  const long long cap = mode == 1 ? 2048 : 256;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const int vchunk = (int)((V + blocks - 1) / blocks);
   dim3 grid((unsigned)((V + vchunk - 1) / vchunk), N);
