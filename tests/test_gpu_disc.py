@@ -286,6 +286,20 @@ def test_weight_images_through_lds_tiles_equal_the_element_pack(dtype, ks):
                 D.L.load().xh_set_option(14, 0)
             torch.cuda.synchronize()
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (cout, cin, mode)
+    # ... and the way back: packed fp32 weight gradient -> dw[co][ci][tap] +=, tile kernel against the element kernel
+    for cout, cin in ((128, 64), (512, 256)):
+        dwp = torch.randn(ks ** 3 * cout * cin, device=DEV)
+        base = torch.randn(cout, cin, ks, ks, ks, device=DEV)
+        a, b = base.clone(), base.clone()
+        D._unpack(dwp, a, cout, cin)
+        try:
+            D.L.load().xh_set_option(14, 4096)
+            D._unpack(dwp, b, cout, cin)
+        finally:
+            D.L.load().xh_set_option(14, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert torch.allclose(a - base, dwp.view(ks ** 3, cout, cin).permute(1, 2, 0).reshape(cout, cin, ks, ks, ks), atol=1e-6)
     # the reducing activation backward with its capped grid (<= 256 workgroups per sample) against the sums taken by torch
     n, c, v = 2, 64, 40 * 40 * 40
     dy = torch.randn(n, v, c, device=DEV).to(dtype)
