@@ -90,15 +90,26 @@ struct PackTableHead { int n, nblocks; int first_block[XH_PACK_TABLE_MAX + 1]; i
 __global__ __launch_bounds__(256) void conv3_pack_table_kernel(const PackTableHead* __restrict__ h) {
   const PackJob* jobs = reinterpret_cast<const PackJob*>(h + 1);
   // the job whose block range holds blockIdx.x = the number of range starts (entries 1 .. n - 1) at or below it.  Thread t tests entry
-  // t + 1: ONE load latency and a counting barrier (a binary search was a chain of log2(n) dependent loads from device memory in
-  // front of every block of a launch whose whole run time is such a chain: 22.5 us for the step's 1 467 blocks)
+  // t + 1: one load latency and a counting barrier instead of a binary search's chain of dependent loads (no measurable difference
+  // by itself: what bounds the launch are the weight loads, see pack_q4_stage)
   const int nj = h->n;
   const int lo = __builtin_amdgcn_readfirstlane(__syncthreads_count((int)threadIdx.x + 1 < nj && h->first_block[threadIdx.x + 1] <= (int)blockIdx.x));
-  const PackJob j = jobs[lo];
+  // a REFERENCE into the table at a wave-uniform index: the fields arrive by scalar loads.  A copy of the record (`PackJob j = jobs[lo]`,
+  // its pointer array indexed by a run-time group) was placed in scratch memory -- 160 bytes per lane, every field access a trip to
+  // memory, wave launch gated by the scratch ring: the launch held 15 % of the wave slots and took 23 us for 6 MB of output
+  const PackJob& j = jobs[lo];
   const int base = ((int)blockIdx.x - h->first_block[lo]) * XH_PACK_PER_BLOCK;
-  if (j.kind == 1 || (j.kind == 0 && j.f16 != 2)) {     // a lane's 16 bytes at once (nelem is a multiple of 512 in both layouts)
+  if (j.kind == 1) {                                    // quad-channel image: the four fragments' 192 weights through LDS (conv_pack.h)
+    __shared__ float s_w[4 * 48];
+    pack_q4_stage(j, base, s_w);
+    __syncthreads();
     const int idx8 = base + 8 * threadIdx.x;
-    if (idx8 < j.nelem) { if (j.kind == 1) pack_elem8_q4(j, idx8); else pack_elem8_mk(j, idx8); }
+    if (idx8 < j.nelem) pack_elem8_q4_lds(j, idx8, s_w);
+    return;
+  }
+  if (j.kind == 0 && j.f16 != 2) {                      // a lane's 16 bytes at once (nelem is a multiple of 512 in both layouts)
+    const int idx8 = base + 8 * threadIdx.x;
+    if (idx8 < j.nelem) pack_elem8_mk(j, idx8);
     return;
   }
 #pragma unroll

@@ -120,6 +120,62 @@ __device__ __forceinline__ void pack_elem8_q4(const PackJob& j, int idx8) {
   *reinterpret_cast<uint4*>(ws + idx8) = o;
 }
 
+// The quad-channel image again, with the weights of the workgroup's FOUR fragments (4 co x 4 ci x 3 kw of one (kd, kh) each = 48
+// floats) staged in LDS first: pack_elem8_q4 issues 8 scattered 4-byte loads per lane -- 2 048 per workgroup for 192 distinct values
+// (the Toeplitz expansion repeats every weight ~10 times), and the launch was bound by those load instructions, not by its 6 MB of
+// output.  s_w: 4 x 48 floats; the caller has put a barrier behind stage.  Same values as pack_elem8_q4.
+__device__ __forceinline__ void pack_q4_stage(const PackJob& j, int base, float* s_w) {
+  const int t = threadIdx.x;
+  if (t >= 192) return;
+  const int fr = t / 48, i48 = t - fr * 48;
+  const int idx = base + fr * 512;
+  float x = 0.f;
+  if (idx < j.nelem) {
+    const int per = j.ci4 * 9 * 512;
+    const int oq = idx / per, f = (idx - oq * per) >> 9;
+    const int r9 = f % 9, cq = f / 9;
+    const int cc = i48 / 12, cii = (i48 / 3) & 3, kw = i48 % 3;       // s_w[fragment][co of the quad][ci of the quad][kw]
+    const int co = oq * 4 + cc;
+    const int grp = co / j.Cout_g, co_g = co - grp * j.Cout_g;
+    const int gpp = j.groups / j.n_wptr;
+    const float* wp = j.w[grp / gpp];
+    const int gl = grp % gpp;
+    const int ci_g = cq * 4 + cii, tap = r9 * 3 + kw;
+    if (j.dw) x = co_g == ci_g ? wp[(long long)(gl * 4 + co_g) * 27 + (j.transposed ? 26 - tap : tap)] : 0.f;
+    else if (!j.transposed) x = wp[((long long)(gl * j.Cout_g + co_g) * j.Cin_g + ci_g) * 27 + tap];
+    else x = wp[((long long)(gl * j.Cin_g + ci_g) * j.Cout_g + co_g) * 27 + (26 - tap)];
+  }
+  s_w[t] = x;
+}
+__device__ __forceinline__ void pack_elem8_q4_lds(const PackJob& j, int idx8, const float* s_w) {
+  const int l = (idx8 >> 3) & 63;
+  const float* sf = s_w + (threadIdx.x >> 6) * 48;       // thread t packs fragment t / 64 of the workgroup's four
+  const int m = l & 15, c = m >> 2, pp = m & 3, g = l >> 4;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int s = 2 * g + (e >> 2), ci = e & 3;
+    const int kw = s - pp - 1;
+    v[e] = (kw >= 0 && kw <= 2) ? sf[c * 12 + ci * 3 + kw] : 0.f;
+  }
+  unsigned short* ws = reinterpret_cast<unsigned short*>(j.ws);
+  if (j.f16 == 2) {                                     // two-term fp16 image of an fp32 weight (conv3d_q4s.hip)
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hi[e] = f2hf(v[e]); lo[e] = f2hf((v[e] - hf2f(hi[e])) * 2048.f); }
+    uint4 a, b;
+    a.x = hi[0] | ((unsigned)hi[1] << 16); a.y = hi[2] | ((unsigned)hi[3] << 16); a.z = hi[4] | ((unsigned)hi[5] << 16); a.w = hi[6] | ((unsigned)hi[7] << 16);
+    b.x = lo[0] | ((unsigned)lo[1] << 16); b.y = lo[2] | ((unsigned)lo[3] << 16); b.z = lo[4] | ((unsigned)lo[5] << 16); b.w = lo[6] | ((unsigned)lo[7] << 16);
+    *reinterpret_cast<uint4*>(ws + idx8) = a;
+    *reinterpret_cast<uint4*>(ws + (long long)j.nelem + idx8) = b;
+    return;
+  }
+  uint4 o;
+  if (j.f16) { o.x = cvt_pack<1>(v[0], v[1]); o.y = cvt_pack<1>(v[2], v[3]); o.z = cvt_pack<1>(v[4], v[5]); o.w = cvt_pack<1>(v[6], v[7]); }
+  else { o.x = cvt_pack<0>(v[0], v[1]); o.y = cvt_pack<0>(v[2], v[3]); o.z = cvt_pack<0>(v[4], v[5]); o.w = cvt_pack<0>(v[6], v[7]); }
+  *reinterpret_cast<uint4*>(ws + idx8) = o;
+}
+
 // The same for the implicit-GEMM (kind 0) image: eight consecutive elements are one lane's B-fragment row segment -- they share the
 // channel tile, the MFMA index, the column (output channel) and the (kd, kh) row; only (kw, ci) = divmod(q * 8 + e, cinp) moves.
 __device__ __forceinline__ void pack_elem8_mk(const PackJob& j, int idx8) {
@@ -131,26 +187,38 @@ __device__ __forceinline__ void pack_elem8_mk(const PackJob& j, int idx8) {
   const int co_lim = min(16, j.cout_set - nt * 16);
   const int l = (r >> 3) & 63, i = r >> 9;
   const int c = 4 * i + (l >> 4);
-  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (c < j.nch && (l & 15) < co_lim) {
-    const int r9 = c / j.cpr, q = c - r9 * j.cpr;
-    const int co = set * j.cout_set + nt * 16 + (l & 15);
+  // EVERY load is issued, from an address clamped into the weight tensor, and the element is selected afterwards: with the loads
+  // under their validity tests hipcc waits for each one where it is issued -- eight exposed latencies in a row per lane, and the
+  // 107 workgroups of these images were the long pole (~20 us) of the step's pack launch
+  float v[8];
+  {
+    const bool lane_ok = c < j.nch && (l & 15) < co_lim;
+    const int cc = lane_ok ? c : 0;
+    const int r9 = cc / j.cpr, q = cc - r9 * j.cpr;
+    const int co = lane_ok ? set * j.cout_set + nt * 16 + (l & 15) : 0;
     const int g = co / j.Cout_g, co_g = co - g * j.Cout_g;
     const int gpp = j.groups / j.n_wptr;
     const float* wp = j.w[g / gpp];
     const int gl = g % gpp;
+    long long off[8];
+    bool ok[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int flat = q * 8 + e;
       const int kw = flat / j.cinp, cib = flat - kw * j.cinp;
       const int ci = cin0 + cib;
-      if (kw < 3 && cib < j.cin_blk && ci < cin_end && ci / j.Cin_g == g) {
-        const int ci_g = ci - g * j.Cin_g, tap = r9 * 3 + kw;
-        if (j.dw) v[e] = co_g == ci_g ? wp[(long long)(gl * 4 + co_g) * 27 + (j.transposed ? 26 - tap : tap)] : 0.f;
-        else if (!j.transposed) v[e] = wp[((long long)(gl * j.Cout_g + co_g) * j.Cin_g + ci_g) * 27 + tap];
-        else v[e] = wp[((long long)(gl * j.Cin_g + ci_g) * j.Cout_g + co_g) * 27 + (26 - tap)];
-      }
+      bool k = lane_ok && kw < 3 && cib < j.cin_blk && ci < cin_end && ci / j.Cin_g == g;
+      const int ci_g = k ? ci - g * j.Cin_g : 0, tap = k ? r9 * 3 + kw : 0;
+      if (j.dw) { k = k && co_g == ci_g; off[e] = (long long)(gl * 4 + co_g) * 27 + (j.transposed ? 26 - tap : tap); }
+      else if (!j.transposed) off[e] = ((long long)(gl * j.Cout_g + co_g) * j.Cin_g + ci_g) * 27 + tap;
+      else off[e] = ((long long)(gl * j.Cin_g + ci_g) * j.Cout_g + co_g) * 27 + (26 - tap);
+      ok[e] = k;
     }
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = wp[off[e]];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ok[e] ? x[e] : 0.f;
   }
   unsigned short* ws = reinterpret_cast<unsigned short*>(j.ws);
   uint4 o;
