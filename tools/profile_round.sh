@@ -9,7 +9,7 @@ set -e
 TAG=${1:-r03}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=/tmp/prof_$TAG   # raw traces stay on the box (tens of MB); only summaries travel back
+OUT=/tmp/prof_${TAG}_$$   # raw traces stay on the box (tens of MB); only summaries travel back; a directory of its own per run (boxes are reused)
 mkdir -p $OUT gpurun_out/profiles_out
 BENCH="bench.py --steps 20 --warmup 5 --inner 1 --no-cpu --no-roofline --no-modes --no-trainstep --no-config3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $BENCH > $OUT/trace.log 2>&1

@@ -83,41 +83,45 @@ __device__ __forceinline__ void outer_accum(float* dW, const float* a, int lda, 
 
 // -------------------------------------------------------------------------------------------------
 // forward stage 1: gather tokens, LayerNorm (weight 1+w, no bias), proj_up
-// block: 32 tokens x 8 lanes
+// block: PRE1_TT tokens x PRE1_LP lanes (round 6: 16 x 16 -- 256 workgroups for 4 096 tokens and 8 outputs per lane; it was 32 x 8:
+// one wave per SIMD on half the CUs walking 16 outputs x C products each)
 // -------------------------------------------------------------------------------------------------
+constexpr int PRE1_TT = 16, PRE1_LP = 16;
 template <typename T, int C>
-__global__ __launch_bounds__(256) void vil_pre1_kernel(const T* xa, const T* xb, int S, xh_vil_params p, VilWs w) {
-  constexpr int I = 2 * C, TT = 32, O = 4 * C;
+__global__ __launch_bounds__(PRE1_TT * PRE1_LP) void vil_pre1_kernel(const T* xa, const T* xb, int S, xh_vil_params p, VilWs w) {
+  constexpr int I = 2 * C, TT = PRE1_TT, LP = PRE1_LP, NT = TT * LP, O = 4 * C;
   __shared__ float s_w[O * (C + 1)];
   __shared__ float s_t[TT * (C + 1)];
   const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
-  for (int i = tid; i < O * C; i += 256) s_w[(i / C) * (C + 1) + (i % C)] = p.proj_up[i];
-  for (int i = tid; i < TT * C; i += 256) {
+  for (int i = tid; i < O * C; i += NT) s_w[(i / C) * (C + 1) + (i % C)] = p.proj_up[i];
+  for (int i = tid; i < TT * C; i += NT) {
     const int tk = i % TT, c = i / TT;
     const int s = s0 + tk;
     s_t[tk * (C + 1) + c] = s < S ? ld_in(xa, xb, ((long long)b * C + c) * S + s) : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < TT * C; i += 256) {
+  for (int i = tid; i < TT * C; i += NT) {
     const int tk = i / C, c = i % C;
     if (s0 + tk < S) w.tok[((long long)b * S + s0 + tk) * C + c] = s_t[tk * (C + 1) + c];
   }
-  const int tk = tid >> 3, sub = tid & 7;
+  const int tk = tid / LP, sub = tid % LP;
   const int s = s0 + tk;
   float sum = 0.f, sq = 0.f;
-  for (int c = sub; c < C; c += 8) { const float v = s_t[tk * (C + 1) + c]; sum += v; }
-  sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+  for (int c = sub; c < C; c += LP) { const float v = s_t[tk * (C + 1) + c]; sum += v; }
+#pragma unroll
+  for (int o = 1; o < LP; o <<= 1) sum += __shfl_xor(sum, o, 64);
   const float mean = sum / C;
-  for (int c = sub; c < C; c += 8) { const float v = s_t[tk * (C + 1) + c] - mean; sq = fmaf(v, v, sq); }
-  sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+  for (int c = sub; c < C; c += LP) { const float v = s_t[tk * (C + 1) + c] - mean; sq = fmaf(v, v, sq); }
+#pragma unroll
+  for (int o = 1; o < LP; o <<= 1) sq += __shfl_xor(sq, o, 64);
   const float rstd = rsqrtf(sq / C + VIL_EPS);
   if (sub == 0 && s < S) { w.ln_mean[(long long)b * S + s] = mean; w.ln_rstd[(long long)b * S + s] = rstd; }
   __syncthreads();
-  for (int c = sub; c < C; c += 8) s_t[tk * (C + 1) + c] = (s_t[tk * (C + 1) + c] - mean) * rstd * (1.f + p.norm_w[c]);
+  for (int c = sub; c < C; c += LP) s_t[tk * (C + 1) + c] = (s_t[tk * (C + 1) + c] - mean) * rstd * (1.f + p.norm_w[c]);
   __syncthreads();
   if (s < S) {
-    for (int j = 0; j < O / 8; ++j) {
-      const int o = sub * (O / 8) + j;
+    for (int j = 0; j < O / LP; ++j) {
+      const int o = j * LP + sub;                       // a token's lanes take consecutive outputs: weight rows one bank apart, stores coalesced
       float a = 0.f;
 #pragma unroll 8
       for (int k = 0; k < C; ++k) a = fmaf(s_w[o * (C + 1) + k], s_t[tk * (C + 1) + k], a);
@@ -129,14 +133,21 @@ __global__ __launch_bounds__(256) void vil_pre1_kernel(const T* xa, const T* xb,
 
 // -------------------------------------------------------------------------------------------------
 // forward stage 2: causal conv1d (k=4) + SiLU, block-diagonal q/k/v, gate pre-activations
-// block: 32 tokens x NH lanes (lane = head)
+// block: PRE2_TT tokens x 16 lanes at C = 32 (lane = head x 4-channel block of the head; 8 lanes at C = 16).  Round 6: it was 32 tokens x NH lanes, a lane walking its
+// head's 16 channels -- 64 conv taps, 192 projection products and two 192-long gate dot products in a row, their weights fetched from
+// global memory inside the loops, on ONE wave per SIMD (128 workgroups of 128 threads for 4 096 tokens): 22 us of latency.  Four times
+// the lanes, a quarter of the chain each; the gate dot products are split over the head's four lanes and meet by two shuffles.
 // -------------------------------------------------------------------------------------------------
+constexpr int PRE2_TT = 16;     // tokens per workgroup: 256 workgroups for the 4 096 tokens of the 128^3 patch's deepest level (one per CU)
 template <int C>
-__global__ __launch_bounds__(128) void vil_pre2_kernel(int S, xh_vil_params p, VilWs w) {
-  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+__global__ __launch_bounds__(PRE2_TT * NH * (2 * C / NH / 4)) void vil_pre2_kernel(int S, xh_vil_params p, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = PRE2_TT, NB4 = DH / 4;
+  static_assert(NB4 == 4 || NB4 == 2, "lanes per token = NH x (DH / 4): 16 (C = 32) or 8 (C = 16)");
+  constexpr int LPT = NH * NB4;
   __shared__ float s_xm[(TT + 3) * (I + 1)];
   __shared__ float s_qkv[TT * (3 * I + 1)];
   __shared__ float s_gw[2 * NH * 3 * I];
+  __shared__ __attribute__((aligned(16))) float s_pw[4 * I * 4];     // conv_w | q_w | k_w | v_w, each [I][4]: a lane reads rows of four
   const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
   for (int i = tid; i < (TT + 3) * I; i += blockDim.x) {
     const int r = i / I, c = i % I;
@@ -144,51 +155,57 @@ __global__ __launch_bounds__(128) void vil_pre2_kernel(int S, xh_vil_params p, V
     s_xm[r * (I + 1) + c] = (s >= 0 && s < S) ? w.xm[((long long)b * S + s) * I + c] : 0.f;
   }
   for (int i = tid; i < NH * 3 * I; i += blockDim.x) { s_gw[i] = p.ig_w[i]; s_gw[NH * 3 * I + i] = p.fg_w[i]; }
+  for (int i = tid; i < I * 4; i += blockDim.x) {
+    s_pw[i] = p.conv_w[i]; s_pw[I * 4 + i] = p.q_w[i]; s_pw[2 * I * 4 + i] = p.k_w[i]; s_pw[3 * I * 4 + i] = p.v_w[i];
+  }
   __syncthreads();
-  const int tk = tid >> 2, h = tid & 3;
+  const int tk = tid / LPT, h = (tid / NB4) % NH, blk = tid % NB4;
   const int s = s0 + tk;
-  float xa[DH];
+  const int gb = h * NB4 + blk;          // global 4x4 block index
+  const int c0 = h * DH + blk * 4;       // first of the lane's four channels
+  float xa[4];
 #pragma unroll
-  for (int j = 0; j < DH; ++j) {
-    const int c = h * DH + j;
+  for (int d = 0; d < 4; ++d) {
+    const int c = c0 + d;
+    const float4 cw = *reinterpret_cast<const float4*>(s_pw + c * 4);
     float a = p.conv_b[c];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a = fmaf(p.conv_w[c * 4 + t], s_xm[(tk + t) * (I + 1) + c], a);
-    xa[j] = silu_(a);
+    a = fmaf(cw.x, s_xm[(tk + 0) * (I + 1) + c], a);
+    a = fmaf(cw.y, s_xm[(tk + 1) * (I + 1) + c], a);
+    a = fmaf(cw.z, s_xm[(tk + 2) * (I + 1) + c], a);
+    a = fmaf(cw.w, s_xm[(tk + 3) * (I + 1) + c], a);
+    xa[d] = silu_(a);
     if (s < S) w.xc[((long long)b * S + s) * I + c] = a;
   }
 #pragma unroll
-  for (int blk = 0; blk < DH / 4; ++blk) {
-    const int gb = h * (DH / 4) + blk;   // global 4x4 block index
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      float q = 0.f, k = 0.f, v = 0.f;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        q = fmaf(p.q_w[(gb * 4 + o) * 4 + d], xa[blk * 4 + d], q);
-        k = fmaf(p.k_w[(gb * 4 + o) * 4 + d], xa[blk * 4 + d], k);
-        v = fmaf(p.v_w[(gb * 4 + o) * 4 + d], s_xm[(tk + 3) * (I + 1) + h * DH + blk * 4 + d], v);
-      }
-      const int j = blk * 4 + o;
-      s_qkv[tk * (3 * I + 1) + h * DH + j] = q;
-      s_qkv[tk * (3 * I + 1) + I + h * DH + j] = k;
-      s_qkv[tk * (3 * I + 1) + 2 * I + h * DH + j] = v;
-      if (s < S) {
-        const long long o_ = (((long long)b * NH + h) * S + s) * DH + j;
-        w.q[o_] = q; w.k[o_] = k; w.v[o_] = v;
-      }
+  for (int o = 0; o < 4; ++o) {
+    const float4 qw = *reinterpret_cast<const float4*>(s_pw + I * 4 + (gb * 4 + o) * 4);
+    const float4 kw = *reinterpret_cast<const float4*>(s_pw + 2 * I * 4 + (gb * 4 + o) * 4);
+    const float4 vw = *reinterpret_cast<const float4*>(s_pw + 3 * I * 4 + (gb * 4 + o) * 4);
+    const float* xm3 = s_xm + (tk + 3) * (I + 1) + c0;
+    const float q = fmaf(qw.w, xa[3], fmaf(qw.z, xa[2], fmaf(qw.y, xa[1], qw.x * xa[0])));
+    const float k = fmaf(kw.w, xa[3], fmaf(kw.z, xa[2], fmaf(kw.y, xa[1], kw.x * xa[0])));
+    const float v = fmaf(vw.w, xm3[3], fmaf(vw.z, xm3[2], fmaf(vw.y, xm3[1], vw.x * xm3[0])));
+    const int j = blk * 4 + o;
+    s_qkv[tk * (3 * I + 1) + h * DH + j] = q;
+    s_qkv[tk * (3 * I + 1) + I + h * DH + j] = k;
+    s_qkv[tk * (3 * I + 1) + 2 * I + h * DH + j] = v;
+    if (s < S) {
+      const long long o_ = (((long long)b * NH + h) * S + s) * DH + j;
+      w.q[o_] = q; w.k[o_] = k; w.v[o_] = v;
     }
   }
   __syncthreads();
-  float gi = p.ig_b[h], gf = p.fg_b[h];
-  for (int m = 0; m < 3 * I; ++m) {
+  float gi = 0.f, gf = 0.f;
+  for (int m = blk; m < 3 * I; m += NB4) {               // the head's lanes take every NB4-th element of the token's [q, k, v]
     const float x = s_qkv[tk * (3 * I + 1) + m];
     gi = fmaf(s_gw[h * 3 * I + m], x, gi);
     gf = fmaf(s_gw[NH * 3 * I + h * 3 * I + m], x, gf);
   }
-  if (s < S) {
-    w.ig[((long long)b * NH + h) * S + s] = gi;
-    w.fg[((long long)b * NH + h) * S + s] = gf;
+  gi += __shfl_xor(gi, 1, 64); gf += __shfl_xor(gf, 1, 64);
+  if (NB4 == 4) { gi += __shfl_xor(gi, 2, 64); gf += __shfl_xor(gf, 2, 64); }
+  if (s < S && blk == 0) {
+    w.ig[((long long)b * NH + h) * S + s] = gi + p.ig_b[h];
+    w.fg[((long long)b * NH + h) * S + s] = gf + p.fg_b[h];
   }
 }
 
@@ -355,41 +372,52 @@ __global__ __launch_bounds__(256) void mlstm_norm_kernel(long long total, VilWs 
 
 // -------------------------------------------------------------------------------------------------
 // forward stage 3: per-head norm, learnable skip, output gate, proj_down, residuals, scatter to NCDHW
-// block: 32 tokens x 8 lanes
+// block: POST_TT tokens x POST_LP lanes (round 6: 16 x 16, a lane = (head, quarter of the head's channels) in the norm and C / 16
+// outputs of proj_down; it was 32 x 8 with four of a token's eight lanes idle through the norm)
 // -------------------------------------------------------------------------------------------------
+constexpr int POST_TT = 16, POST_LP = 16;
 template <typename T, int C>
-__global__ __launch_bounds__(256) void vil_post_kernel(const T* xa, T* out, int S, int add_xa, xh_vil_params p, VilWs w) {
-  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+__global__ __launch_bounds__(POST_TT * POST_LP) void vil_post_kernel(const T* xa, T* out, int S, int add_xa, xh_vil_params p, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = POST_TT, LP = POST_LP, NT = TT * LP;
+  constexpr int LH = LP / NH, JH = DH / LH;            // lanes per head, channels per lane in the norm
+  static_assert(LP % NH == 0 && DH % LH == 0 && C % LP == 0, "lane map of vil_post_kernel");
   __shared__ float s_w[C * (I + 1)];
   __shared__ float s_hg[TT * (I + 1)];
   __shared__ float s_o[TT * (C + 1)];
   const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
-  for (int i = tid; i < C * I; i += 256) s_w[(i / I) * (I + 1) + (i % I)] = p.proj_down[i];
-  const int tk = tid >> 3, sub = tid & 7;
+  for (int i = tid; i < C * I; i += NT) s_w[(i / I) * (I + 1) + (i % I)] = p.proj_down[i];
+  const int tk = tid / LP, sub = tid % LP;
   const int s = s0 + tk;
-  if (sub < NH && s < S) {
-    const int h = sub;
-    const long long ho = (((long long)b * NH + h) * S + s) * DH;
-    float hv[DH], mean = 0.f, var = 0.f;
+  {
+    const int h = sub / LH, part = sub % LH;
+    const bool live = s < S;
+    const long long ho = (((long long)b * NH + h) * (live ? S : 0) + (live ? s : 0)) * DH + part * JH;
+    float hv[JH], mean = 0.f, var = 0.f;
 #pragma unroll
-    for (int j = 0; j < DH; ++j) { hv[j] = w.h[ho + j]; mean += hv[j]; }
+    for (int j = 0; j < JH; ++j) { hv[j] = live ? w.h[ho + j] : 0.f; mean += hv[j]; }
+#pragma unroll
+    for (int o = 1; o < LH; o <<= 1) mean += __shfl_xor(mean, o, 64);
     mean /= DH;
 #pragma unroll
-    for (int j = 0; j < DH; ++j) { const float d = hv[j] - mean; var = fmaf(d, d, var); }
-    const float rstd = rsqrtf(var / DH + VIL_EPS);
+    for (int j = 0; j < JH; ++j) { const float d = hv[j] - mean; var = fmaf(d, d, var); }
 #pragma unroll
-    for (int j = 0; j < DH; ++j) {
-      const int c = h * DH + j;
-      const long long to = ((long long)b * S + s) * I + c;
-      const float hn = (hv[j] - mean) * rstd * (1.f + p.outnorm_w[c]);
-      const float hs = hn + p.skip[c] * silu_(w.xc[to]);
-      s_hg[tk * (I + 1) + c] = hs * silu_(w.z[to]);
+    for (int o = 1; o < LH; o <<= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = rsqrtf(var / DH + VIL_EPS);
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < JH; ++j) {
+        const int c = h * DH + part * JH + j;
+        const long long to = ((long long)b * S + s) * I + c;
+        const float hn = (hv[j] - mean) * rstd * (1.f + p.outnorm_w[c]);
+        const float hs = hn + p.skip[c] * silu_(w.xc[to]);
+        s_hg[tk * (I + 1) + c] = hs * silu_(w.z[to]);
+      }
     }
   }
   __syncthreads();
   if (s < S) {
-    for (int j = 0; j < C / 8; ++j) {
-      const int o = sub * (C / 8) + j;
+    for (int j = 0; j < C / LP; ++j) {
+      const int o = j * LP + sub;
       float a = w.tok[((long long)b * S + s) * C + o];
 #pragma unroll 8
       for (int k = 0; k < I; ++k) a = fmaf(s_w[o * (I + 1) + k], s_hg[tk * (I + 1) + k], a);
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(256) void vil_post_kernel(const T* xa, T* out, int 
     }
   }
   __syncthreads();
-  for (int i = tid; i < TT * C; i += 256) {
+  for (int i = tid; i < TT * C; i += NT) {
     const int tk2 = i % TT, c = i / TT;
     const int s2 = s0 + tk2;
     if (s2 < S) {
@@ -1152,8 +1180,8 @@ static int vil_fwd_impl(hipStream_t st, const T* xa, const T* xb, T* out, int B,
   constexpr int DH = 2 * C / NH;
   VilWs w;
   ws_layout(&w, ws, B, S, C);
-  hipLaunchKernelGGL((vil_pre1_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, xb, S, *p, w);
-  hipLaunchKernelGGL((vil_pre2_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, w);
+  hipLaunchKernelGGL((vil_pre1_kernel<T, C>), dim3(cdiv(S, PRE1_TT), B), dim3(PRE1_TT * PRE1_LP), 0, st, xa, xb, S, *p, w);
+  hipLaunchKernelGGL((vil_pre2_kernel<C>), dim3(cdiv(S, PRE2_TT), B), dim3(PRE2_TT * NH * (2 * C / NH / 4)), 0, st, S, *p, w);
   hipLaunchKernelGGL(vil_scan_kernel, dim3(B * NH), dim3(SCAN_T), 0, st, S, w);
   const long long rows_f = (long long)B * NH * S;
   if (DH == 16 && !(g_xh_disable & 8)) {              // chunk-recurrent form on the matrix cores
@@ -1167,7 +1195,7 @@ static int vil_fwd_impl(hipStream_t st, const T* xa, const T* xb, T* out, int B,
     hipLaunchKernelGGL((mlstm_fwd_kernel<DH>), dim3(cdiv(S, 32) * MSPLIT, NH, B), dim3(256), 0, st, S, w);
     hipLaunchKernelGGL((mlstm_norm_kernel<DH>), dim3((unsigned)((rows_f + 255) / 256)), dim3(256), 0, st, rows_f, w);
   }
-  hipLaunchKernelGGL((vil_post_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, xa, out, S, add_xa, *p, w);
+  hipLaunchKernelGGL((vil_post_kernel<T, C>), dim3(cdiv(S, POST_TT), B), dim3(POST_TT * POST_LP), 0, st, xa, out, S, add_xa, *p, w);
   return xh_launch_status();
 }
 template <typename T, int C>
