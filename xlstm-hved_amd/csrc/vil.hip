@@ -721,89 +721,96 @@ __global__ __launch_bounds__(256) void mlstm_chunk_bwd_kernel(int S, int nchunk,
 // backward
 // =================================================================================================
 // stage 3 backward: dout (NCDHW) -> dh, dz, dxa(partial: skip path) ; grads of proj_down, skip, outnorm
+// block: 32 tokens x 16 lanes (round 6; it was 32 x 8 with the per-head norm backward -- 16 channels, four passes over them -- on four of
+// a token's eight lanes).  The token count per workgroup stays: every workgroup ends in one global atomic per parameter-gradient
+// element, and atomics on one address retire one after the other.
 template <typename T, int C>
-__global__ __launch_bounds__(256) void vil_post_bwd_kernel(const T* dout, int S, xh_vil_params p, xh_vil_grads g, VilWs w) {
-  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+__global__ __launch_bounds__(512) void vil_post_bwd_kernel(const T* dout, int S, xh_vil_params p, xh_vil_grads g, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = 32, LP = 16, NT = TT * LP;
+  constexpr int LH = LP / NH, JH = DH / LH;             // lanes per head, channels per lane in the norm backward
+  static_assert(LP % NH == 0 && DH % LH == 0 && I % LP == 0, "lane map of vil_post_bwd_kernel");
   __shared__ float s_w[C * (I + 1)];
   __shared__ float s_do[TT * (C + 1)];
   __shared__ float s_hg[TT * (I + 1)];    // forward hg (for dW_down), later reused
   __shared__ float s_dhg[TT * (I + 1)];
   __shared__ float s_acc[2 * I];           // dskip, doutnorm partials
   const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
-  for (int i = tid; i < C * I; i += 256) s_w[(i / I) * (I + 1) + (i % I)] = p.proj_down[i];
-  for (int i = tid; i < 2 * I; i += 256) s_acc[i] = 0.f;
-  for (int i = tid; i < TT * C; i += 256) {
+  for (int i = tid; i < C * I; i += NT) s_w[(i / I) * (I + 1) + (i % I)] = p.proj_down[i];
+  for (int i = tid; i < 2 * I; i += NT) s_acc[i] = 0.f;
+  for (int i = tid; i < TT * C; i += NT) {
     const int tk = i % TT, c = i / TT;
     const int s = s0 + tk;
     s_do[tk * (C + 1) + c] = s < S ? ldf(dout, ((long long)b * C + c) * S + s) : 0.f;
   }
   __syncthreads();
-  const int tk = tid >> 3, sub = tid & 7;
+  const int tk = tid / LP, sub = tid % LP;
   const int s = s0 + tk;
+  const bool live = s < S;
   // dhg = W^T dout
-  for (int j = 0; j < I / 8; ++j) {
-    const int k = sub * (I / 8) + j;
+  for (int j = 0; j < I / LP; ++j) {
+    const int k = j * LP + sub;
     float a = 0.f;
 #pragma unroll 8
     for (int o = 0; o < C; ++o) a = fmaf(s_w[o * (I + 1) + k], s_do[tk * (C + 1) + o], a);
-    s_dhg[tk * (I + 1) + k] = s < S ? a : 0.f;
+    s_dhg[tk * (I + 1) + k] = live ? a : 0.f;
   }
   __syncthreads();
-  if (sub < NH) {
-    const int h = sub;
-    float acc_sk[DH], acc_nw[DH];
+  {
+    const int h = sub / LH, part = sub % LH, cb = h * DH + part * JH;
+    const long long ho = (((long long)b * NH + h) * S + (live ? s : 0)) * DH + part * JH;
+    const long long tb = ((long long)b * S + (live ? s : 0)) * I + cb;
+    float hv[JH], xh[JH], dn[JH], acc_sk[JH], acc_nw[JH], mean = 0.f, var = 0.f;
 #pragma unroll
-    for (int j = 0; j < DH; ++j) acc_sk[j] = acc_nw[j] = 0.f;
-    if (s < S) {
-      const long long ho = (((long long)b * NH + h) * S + s) * DH;
-      float hv[DH], xh[DH], dn[DH], mean = 0.f, var = 0.f;
+    for (int j = 0; j < JH; ++j) { hv[j] = live ? w.h[ho + j] : 0.f; mean += hv[j]; }
 #pragma unroll
-      for (int j = 0; j < DH; ++j) { hv[j] = w.h[ho + j]; mean += hv[j]; }
-      mean /= DH;
+    for (int o = 1; o < LH; o <<= 1) mean += __shfl_xor(mean, o, 64);
+    mean /= DH;
 #pragma unroll
-      for (int j = 0; j < DH; ++j) { const float d = hv[j] - mean; var = fmaf(d, d, var); }
-      const float rstd = rsqrtf(var / DH + VIL_EPS);
-      float m1 = 0.f, m2 = 0.f;
+    for (int j = 0; j < JH; ++j) { const float d = hv[j] - mean; var = fmaf(d, d, var); }
 #pragma unroll
-      for (int j = 0; j < DH; ++j) {
-        const int c = h * DH + j;
-        const long long to = ((long long)b * S + s) * I + c;
-        xh[j] = (hv[j] - mean) * rstd;
-        const float gam = 1.f + p.outnorm_w[c];
-        const float xcv = w.xc[to], zv = w.z[to];
-        const float xav = silu_(xcv);
-        const float hs = xh[j] * gam + p.skip[c] * xav;
-        const float dhg = s_dhg[tk * (I + 1) + c];
-        s_hg[tk * (I + 1) + c] = hs * silu_(zv);
-        const float dhs = dhg * silu_(zv);
-        w.dz[to] = dhg * hs * dsilu_(zv);
-        w.dxa[to] = dhs * p.skip[c];
-        acc_sk[j] = dhs * xav;                    // dskip
-        acc_nw[j] = dhs * xh[j];                  // d outnorm weight
-        dn[j] = dhs * gam;
-        m1 += dn[j];
-        m2 = fmaf(dn[j], xh[j], m2);
+    for (int o = 1; o < LH; o <<= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = rsqrtf(var / DH + VIL_EPS);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      const int c = cb + j;
+      xh[j] = (hv[j] - mean) * rstd;
+      const float gam = 1.f + p.outnorm_w[c];
+      const float xcv = live ? w.xc[tb + j] : 0.f, zv = live ? w.z[tb + j] : 0.f;
+      const float xav = silu_(xcv);
+      const float hs = xh[j] * gam + p.skip[c] * xav;
+      const float dhg = s_dhg[tk * (I + 1) + c];
+      s_hg[tk * (I + 1) + c] = live ? hs * silu_(zv) : 0.f;
+      const float dhs = dhg * silu_(zv);
+      if (live) {
+        w.dz[tb + j] = dhg * hs * dsilu_(zv);
+        w.dxa[tb + j] = dhs * p.skip[c];
       }
-      m1 /= DH; m2 /= DH;
-#pragma unroll
-      for (int j = 0; j < DH; ++j) w.dh[ho + j] = rstd * (dn[j] - m1 - xh[j] * m2);
-    } else {
-#pragma unroll
-      for (int j = 0; j < DH; ++j) s_hg[tk * (I + 1) + h * DH + j] = 0.f;
+      acc_sk[j] = live ? dhs * xav : 0.f;        // dskip
+      acc_nw[j] = live ? dhs * xh[j] : 0.f;      // d outnorm weight
+      dn[j] = dhs * gam;
+      m1 += dn[j];
+      m2 = fmaf(dn[j], xh[j], m2);
     }
-    // the wave's 8 tokens (lane bits 3..5) summed by shuffles, then one LDS atomic per wave and value (every token's thread
-    // adding into s_acc was 32 colliding atomics per value).  All lanes take part: the partner lanes have sub < NH as well.
 #pragma unroll
-    for (int j = 0; j < DH; ++j) {
+    for (int o = 1; o < LH; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+    m1 /= DH; m2 /= DH;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < JH; ++j) w.dh[ho + j] = rstd * (dn[j] - m1 - xh[j] * m2);
+    }
+    // the wave's 4 tokens (lane bits 4, 5) summed by shuffles, then one LDS atomic per wave and value
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
       float a = acc_sk[j], c2 = acc_nw[j];
-      a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-      c2 += __shfl_xor(c2, 8, 64); c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
-      if ((tid & 63) < 8) { atomicAdd(&s_acc[h * DH + j], a); atomicAdd(&s_acc[I + h * DH + j], c2); }
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+      if ((tid & 63) < LP) { atomicAdd(&s_acc[cb + j], a); atomicAdd(&s_acc[I + cb + j], c2); }
     }
   }
   __syncthreads();
   outer_accum(g.proj_down, s_do, C + 1, C, s_hg, I + 1, I, TT);
-  for (int i = tid; i < I; i += 256) { atomicAdd(&g.skip[i], s_acc[i]); atomicAdd(&g.outnorm_w[i], s_acc[I + i]); }
+  for (int i = tid; i < I; i += NT) { atomicAdd(&g.skip[i], s_acc[i]); atomicAdd(&g.outnorm_w[i], s_acc[I + i]); }
 }
 
 // per-token preparation for the mLSTM backward: da' = dh/den', db', dm
@@ -973,31 +980,39 @@ __global__ __launch_bounds__(256) void mlstm_bwd_kv_kernel(int S, VilWs w) {
 }
 
 // stage 2 backward (a): gates + q/k/v projections -> dxc (pre-SiLU conv output grad), dxm via v; param grads
+// block: 32 tokens x NH * (DH / 4) lanes -- a lane = one 4 x 4 block of the block-diagonal projections (round 6; it was 32 tokens x NH
+// lanes, a lane walking its head's 16 channels through every stage on one wave per SIMD; the loops over the workgroup's parameter-
+// gradient elements run on four times the threads)
 template <int C>
-__global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params p, xh_vil_grads g, VilWs w) {
-  constexpr int I = 2 * C, DH = I / NH, TT = 32;
+__global__ __launch_bounds__(32 * NH * (2 * C / NH / 4)) void vil_pre2_bwd_kernel(int S, xh_vil_params p, xh_vil_grads g, VilWs w) {
+  constexpr int I = 2 * C, DH = I / NH, TT = 32, NB4 = DH / 4, LPT = NH * NB4;
   __shared__ float s_qkv[TT * (3 * I + 1)];    // forward [q,k,v]
   __shared__ float s_d[TT * (3 * I + 1)];      // d[q,k,v]
   __shared__ float s_gate[TT * (2 * NH + 1)];  // di, df per head
   __shared__ float s_gw[2 * NH * 3 * I];
+  __shared__ __attribute__((aligned(16))) float s_pw[3 * I * 4];     // q_w | k_w | v_w, each [I][4]
   float* s_x = s_qkv;                          // after the gate gradients: [TT][2 * I + 1] = silu(xc) | xm of the tile's tokens
   const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
   for (int i = tid; i < NH * 3 * I; i += blockDim.x) { s_gw[i] = p.ig_w[i]; s_gw[NH * 3 * I + i] = p.fg_w[i]; }
-  const int tk = tid >> 2, h = tid & 3;
+  for (int i = tid; i < I * 4; i += blockDim.x) { s_pw[i] = p.q_w[i]; s_pw[I * 4 + i] = p.k_w[i]; s_pw[2 * I * 4 + i] = p.v_w[i]; }
+  const int tk = tid / LPT, h = (tid / NB4) % NH, blk = tid % NB4;
   const int s = s0 + tk;
   const bool ok = s < S;
+  const int cb = h * DH + blk * 4;              // the lane's four channels
 #pragma unroll
-  for (int j = 0; j < DH; ++j) {
-    const long long o_ = (((long long)b * NH + h) * S + s) * DH + j;
-    s_qkv[tk * (3 * I + 1) + h * DH + j] = ok ? w.q[o_] : 0.f;
-    s_qkv[tk * (3 * I + 1) + I + h * DH + j] = ok ? w.k[o_] : 0.f;
-    s_qkv[tk * (3 * I + 1) + 2 * I + h * DH + j] = ok ? w.v[o_] : 0.f;
-    s_d[tk * (3 * I + 1) + h * DH + j] = ok ? w.dq[o_] : 0.f;
-    s_d[tk * (3 * I + 1) + I + h * DH + j] = ok ? w.dk[o_] : 0.f;
-    s_d[tk * (3 * I + 1) + 2 * I + h * DH + j] = ok ? w.dv[o_] : 0.f;
+  for (int j = 0; j < 4; ++j) {
+    const long long o_ = (((long long)b * NH + h) * S + (ok ? s : 0)) * DH + blk * 4 + j;
+    s_qkv[tk * (3 * I + 1) + cb + j] = ok ? w.q[o_] : 0.f;
+    s_qkv[tk * (3 * I + 1) + I + cb + j] = ok ? w.k[o_] : 0.f;
+    s_qkv[tk * (3 * I + 1) + 2 * I + cb + j] = ok ? w.v[o_] : 0.f;
+    s_d[tk * (3 * I + 1) + cb + j] = ok ? w.dq[o_] : 0.f;
+    s_d[tk * (3 * I + 1) + I + cb + j] = ok ? w.dk[o_] : 0.f;
+    s_d[tk * (3 * I + 1) + 2 * I + cb + j] = ok ? w.dv[o_] : 0.f;
   }
-  s_gate[tk * (2 * NH + 1) + h] = ok ? w.di[((long long)b * NH + h) * S + s] : 0.f;
-  s_gate[tk * (2 * NH + 1) + NH + h] = ok ? w.df[((long long)b * NH + h) * S + s] : 0.f;
+  if (blk == 0) {
+    s_gate[tk * (2 * NH + 1) + h] = ok ? w.di[((long long)b * NH + h) * S + s] : 0.f;
+    s_gate[tk * (2 * NH + 1) + NH + h] = ok ? w.df[((long long)b * NH + h) * S + s] : 0.f;
+  }
   __syncthreads();
   // gate weight/bias grads
   outer_accum(g.ig_w, s_gate, 2 * NH + 1, NH, s_qkv, 3 * I + 1, 3 * I, TT);
@@ -1008,11 +1023,11 @@ __global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params 
     atomicAdd(tid < NH ? &g.ig_b[tid] : &g.fg_b[tid - NH], a);
   }
   __syncthreads();
-  // d[q,k,v] += W_i^T di + W_f^T df   (each lane updates its own head's 3*DH entries)
+  // d[q,k,v] += W_i^T di + W_f^T df   (each lane updates its own 3 x 4 entries)
   for (int part = 0; part < 3; ++part)
 #pragma unroll
-    for (int j = 0; j < DH; ++j) {
-      const int m = part * I + h * DH + j;
+    for (int j = 0; j < 4; ++j) {
+      const int m = part * I + cb + j;
       float a = s_d[tk * (3 * I + 1) + m];
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh) {
@@ -1024,40 +1039,40 @@ __global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params 
   __syncthreads();
   // through the block-diagonal projections
   if (ok) {
+    const int gb = h * NB4 + blk;
+    float xa4[4], xm4[4], dxa4[4] = {0, 0, 0, 0}, dxm4[4] = {0, 0, 0, 0};
+    const long long to0 = ((long long)b * S + s) * I + cb;
 #pragma unroll
-    for (int blk = 0; blk < DH / 4; ++blk) {
-      const int gb = h * (DH / 4) + blk;
-      float xa4[4], xm4[4], dxa4[4] = {0, 0, 0, 0}, dxm4[4] = {0, 0, 0, 0};
+    for (int d = 0; d < 4; ++d) {
+      xa4[d] = silu_(w.xc[to0 + d]);
+      xm4[d] = w.xm[to0 + d];
+    }
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const long long to = ((long long)b * S + s) * I + h * DH + blk * 4 + d;
-        xa4[d] = silu_(w.xc[to]);
-        xm4[d] = w.xm[to];
-      }
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const int m = h * DH + blk * 4 + o;
-        const float dqv = s_d[tk * (3 * I + 1) + m], dkv = s_d[tk * (3 * I + 1) + I + m], dvv = s_d[tk * (3 * I + 1) + 2 * I + m];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          dxa4[d] = fmaf(p.q_w[(gb * 4 + o) * 4 + d], dqv, dxa4[d]);
-          dxa4[d] = fmaf(p.k_w[(gb * 4 + o) * 4 + d], dkv, dxa4[d]);
-          dxm4[d] = fmaf(p.v_w[(gb * 4 + o) * 4 + d], dvv, dxm4[d]);
-        }
-      }
+    for (int o = 0; o < 4; ++o) {
+      const int m = cb + o;
+      const float dqv = s_d[tk * (3 * I + 1) + m], dkv = s_d[tk * (3 * I + 1) + I + m], dvv = s_d[tk * (3 * I + 1) + 2 * I + m];
+      const float4 qw = *reinterpret_cast<const float4*>(s_pw + (gb * 4 + o) * 4);
+      const float4 kw = *reinterpret_cast<const float4*>(s_pw + I * 4 + (gb * 4 + o) * 4);
+      const float4 vw = *reinterpret_cast<const float4*>(s_pw + 2 * I * 4 + (gb * 4 + o) * 4);
+      const float qv[4] = {qw.x, qw.y, qw.z, qw.w}, kv[4] = {kw.x, kw.y, kw.z, kw.w}, vv[4] = {vw.x, vw.y, vw.z, vw.w};
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const long long to = ((long long)b * S + s) * I + h * DH + blk * 4 + d;
-        const float dxa_tot = dxa4[d] + w.dxa[to];
-        w.dxc[to] = dxa_tot * dsilu_(w.xc[to]);
-        w.dxm[to] = dxm4[d];      // v-path part; conv part added in the next stage
-        s_x[tk * (2 * I + 1) + h * DH + blk * 4 + d] = xa4[d];
-        s_x[tk * (2 * I + 1) + I + h * DH + blk * 4 + d] = xm4[d];
+        dxa4[d] = fmaf(qv[d], dqv, dxa4[d]);
+        dxa4[d] = fmaf(kv[d], dkv, dxa4[d]);
+        dxm4[d] = fmaf(vv[d], dvv, dxm4[d]);
       }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float dxa_tot = dxa4[d] + w.dxa[to0 + d];
+      w.dxc[to0 + d] = dxa_tot * dsilu_(w.xc[to0 + d]);
+      w.dxm[to0 + d] = dxm4[d];      // v-path part; conv part added in the next stage
+      s_x[tk * (2 * I + 1) + cb + d] = xa4[d];
+      s_x[tk * (2 * I + 1) + I + cb + d] = xm4[d];
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < DH; ++j) { s_x[tk * (2 * I + 1) + h * DH + j] = 0.f; s_x[tk * (2 * I + 1) + I + h * DH + j] = 0.f; }
+    for (int d = 0; d < 4; ++d) { s_x[tk * (2 * I + 1) + cb + d] = 0.f; s_x[tk * (2 * I + 1) + I + cb + d] = 0.f; }
   }
   __syncthreads();
   // dq_w / dk_w / dv_w [m][d] = sum over the tile's tokens of d{q,k,v}[t][m] * x[t][4 * (m / 4) + d]: one output per thread and
@@ -1073,10 +1088,14 @@ __global__ __launch_bounds__(128) void vil_pre2_bwd_kernel(int S, xh_vil_params 
 }
 
 // stage 2 backward (b) + stage 1 backward: conv1d backward, proj_up backward, LayerNorm backward, scatter
+// block: 32 tokens x 16 lanes (round 6: twice the threads on the same tile -- every loop over the tile's elements and over the
+// parameter-gradient elements halves, the token count per workgroup, i.e. the depth of the global atomics, stays)
+constexpr int PRE1B_LP = 16, PRE1B_NT = 32 * PRE1B_LP;
 template <typename T, int C>
-__global__ __launch_bounds__(256) void vil_pre1_bwd_kernel(const T* dout, T* dxin, int S, xh_vil_params p, xh_vil_grads g,
+__global__ __launch_bounds__(PRE1B_NT) void vil_pre1_bwd_kernel(const T* dout, T* dxin, int S, xh_vil_params p, xh_vil_grads g,
                                                           VilWs w) {
-  constexpr int I = 2 * C, TT = 32, O = 4 * C;
+  constexpr int I = 2 * C, TT = 32, O = 4 * C, LP = PRE1B_LP, NT = PRE1B_NT;
+  static_assert(C % LP == 0, "lane map of vil_pre1_bwd_kernel");
   __shared__ float s_w[O * (C + 1)];
   __shared__ float s_dxc[(TT + 3) * (I + 1)];
   __shared__ float s_xm[(TT + 3) * (I + 1)];
@@ -1086,11 +1105,11 @@ __global__ __launch_bounds__(256) void vil_pre1_bwd_kernel(const T* dout, T* dxi
   __shared__ float s_cw[I * 5];             // dconv_w (4) + dconv_b
   __shared__ float s_nw[C];
   const int tid = threadIdx.x, b = blockIdx.y, s0 = blockIdx.x * TT;
-  for (int i = tid; i < O * C; i += 256) s_w[(i / C) * (C + 1) + (i % C)] = p.proj_up[i];
-  for (int i = tid; i < I * 5; i += 256) s_cw[i] = 0.f;
-  for (int i = tid; i < C; i += 256) s_nw[i] = 0.f;
+  for (int i = tid; i < O * C; i += NT) s_w[(i / C) * (C + 1) + (i % C)] = p.proj_up[i];
+  for (int i = tid; i < I * 5; i += NT) s_cw[i] = 0.f;
+  for (int i = tid; i < C; i += NT) s_nw[i] = 0.f;
   // dxc rows s0 .. s0+TT+2 ; xm rows s0-3 .. s0+TT-1
-  for (int i = tid; i < (TT + 3) * I; i += 256) {
+  for (int i = tid; i < (TT + 3) * I; i += NT) {
     const int r = i / I, c = i % I;
     const int sd = s0 + r, sx = s0 - 3 + r;
     s_dxc[r * (I + 1) + c] = sd < S ? w.dxc[((long long)b * S + sd) * I + c] : 0.f;
@@ -1098,7 +1117,7 @@ __global__ __launch_bounds__(256) void vil_pre1_bwd_kernel(const T* dout, T* dxi
   }
   __syncthreads();
   // conv backward: dxm[s][c] = sum_j w[c][j]*dxc[s+3-j][c];  dw[c][j] += sum_s dxc[s][c]*xm[s-3+j][c]
-  for (int i = tid; i < TT * I; i += 256) {
+  for (int i = tid; i < TT * I; i += NT) {
     const int tk = i / I, c = i % I;
     const int s = s0 + tk;
     float a = 0.f;
@@ -1110,7 +1129,7 @@ __global__ __launch_bounds__(256) void vil_pre1_bwd_kernel(const T* dout, T* dxi
     s_din[tk * (O + 1) + c] = a;
     s_din[tk * (O + 1) + I + c] = s < S ? w.dz[((long long)b * S + s) * I + c] : 0.f;
   }
-  for (int i = tid; i < I * 5; i += 256) {
+  for (int i = tid; i < I * 5; i += NT) {
     const int c = i / 5, j = i % 5;
     float a = 0.f;
     for (int tk = 0; tk < TT; ++tk) {
@@ -1120,29 +1139,29 @@ __global__ __launch_bounds__(256) void vil_pre1_bwd_kernel(const T* dout, T* dxi
     s_cw[i] = a;
   }
   // recompute LayerNorm output of the tokens
-  const int tk = tid >> 3, sub = tid & 7;
+  const int tk = tid / LP, sub = tid % LP;
   const int s = s0 + tk;
   const bool ok = s < S;
   float mean = 0.f, rstd = 0.f;
   if (ok) { mean = w.ln_mean[(long long)b * S + s]; rstd = w.ln_rstd[(long long)b * S + s]; }
-  for (int c = sub; c < C; c += 8) {
+  for (int c = sub; c < C; c += LP) {
     const float xh = ok ? (w.tok[((long long)b * S + s) * C + c] - mean) * rstd : 0.f;
     s_ln[tk * (C + 1) + c] = xh * (1.f + p.norm_w[c]);
     s_dt[tk * (C + 1) + c] = xh;   // keep xhat
   }
   __syncthreads();
-  for (int i = tid; i < I * 5; i += 256) {
+  for (int i = tid; i < I * 5; i += NT) {
     const int c = i / 5, j = i % 5;
     atomicAdd(j < 4 ? &g.conv_w[c * 4 + j] : &g.conv_b[c], s_cw[i]);
   }
   outer_accum(g.proj_up, s_din, O + 1, O, s_ln, C + 1, C, TT);
   __syncthreads();
   // dln = W_up^T d[xm,z]
-  float dln[C / 8], xh[C / 8];
+  float dln[C / LP], xh[C / LP];
   float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-  for (int j = 0; j < C / 8; ++j) {
-    const int c = sub + 8 * j;
+  for (int j = 0; j < C / LP; ++j) {
+    const int c = sub + LP * j;
     float a = 0.f;
     for (int o = 0; o < O; ++o) a = fmaf(s_w[o * (C + 1) + c], s_din[tk * (O + 1) + o], a);
     xh[j] = s_dt[tk * (C + 1) + c];
@@ -1151,18 +1170,18 @@ __global__ __launch_bounds__(256) void vil_pre1_bwd_kernel(const T* dout, T* dxi
     m1 += dln[j];
     m2 = fmaf(dln[j], xh[j], m2);
   }
-  m1 += __shfl_xor(m1, 1, 64); m1 += __shfl_xor(m1, 2, 64); m1 += __shfl_xor(m1, 4, 64);
-  m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+#pragma unroll
+  for (int o = 1; o < LP; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
   m1 /= C; m2 /= C;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < C / 8; ++j) {
-    const int c = sub + 8 * j;
+  for (int j = 0; j < C / LP; ++j) {
+    const int c = sub + LP * j;
     s_dt[tk * (C + 1) + c] = rstd * (dln[j] - m1 - xh[j] * m2);
   }
   __syncthreads();
-  for (int i = tid; i < C; i += 256) atomicAdd(&g.norm_w[i], s_nw[i]);
-  for (int i = tid; i < TT * C; i += 256) {
+  for (int i = tid; i < C; i += NT) atomicAdd(&g.norm_w[i], s_nw[i]);
+  for (int i = tid; i < TT * C; i += NT) {
     const int tk2 = i % TT, c = i / TT;
     const int s2 = s0 + tk2;
     if (s2 < S) {
@@ -1205,7 +1224,7 @@ static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, co
   VilWs w;
   ws_layout(&w, ws, B, S, C);
   const long long rows = (long long)B * NH * S;
-  hipLaunchKernelGGL((vil_post_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, S, *p, *g, w);
+  hipLaunchKernelGGL((vil_post_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(512), 0, st, dout, S, *p, *g, w);
   hipLaunchKernelGGL((mlstm_bwd_prep_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
   hipLaunchKernelGGL(mlstm_bwd_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
   if (DH == 16 && !(g_xh_disable & 8)) {
@@ -1220,8 +1239,8 @@ static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, co
   }
   hipLaunchKernelGGL((mlstm_bwd_dots_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, w);
   hipLaunchKernelGGL(vil_rscan_kernel, dim3(B * NH), dim3(SCAN_T), 0, st, S, w);
-  hipLaunchKernelGGL((vil_pre2_bwd_kernel<C>), dim3(cdiv(S, 32), B), dim3(128), 0, st, S, *p, *g, w);
-  hipLaunchKernelGGL((vil_pre1_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(256), 0, st, dout, dxin, S, *p, *g, w);
+  hipLaunchKernelGGL((vil_pre2_bwd_kernel<C>), dim3(cdiv(S, 32), B), dim3(32 * NH * (2 * C / NH / 4)), 0, st, S, *p, *g, w);
+  hipLaunchKernelGGL((vil_pre1_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(PRE1B_NT), 0, st, dout, dxin, S, *p, *g, w);
   return xh_launch_status();
 }
 
