@@ -223,8 +223,24 @@ __global__ __launch_bounds__(SCAN_T) void vil_scan_kernel(int S, VilWs w) {
   const long long base = (long long)blockIdx.x * S;
   const int chunk = (S + SCAN_T - 1) / SCAN_T;
   const int t0 = min(S, tid * chunk), t1 = min(S, t0 + chunk);
+  // A lane's chunk is short (4 tokens at S = 4096): it is loaded ONCE into registers -- the three walks over it (sum, prefix + local
+  // maximum, running maximum) were three round trips to memory, the last one re-reading the F this kernel had just written
+  constexpr int CH = 8;
+  const bool reg = chunk <= CH;                   // block-uniform
+  float lfv[CH], gv[CH];
   double loc = 0.0;
-  for (int t = t0; t < t1; ++t) loc += (double)logsigmoid_(w.fg[base + t]);
+  if (reg) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int t = t0 + k;
+      const bool in = t < t1;
+      lfv[k] = in ? logsigmoid_(w.fg[base + (in ? t : 0)]) : 0.f;
+      gv[k] = in ? w.ig[base + (in ? t : 0)] : 0.f;
+      loc += (double)lfv[k];
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) loc += (double)logsigmoid_(w.fg[base + t]);
+  }
   double inc = loc;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -237,12 +253,26 @@ __global__ __launch_bounds__(SCAN_T) void vil_scan_kernel(int S, VilWs w) {
   for (int i = 0; i < wv; ++i) run += s_sum[i];   // ... plus the waves before it
   float lmax = -INFINITY;
   int larg = t0;
-  for (int t = t0; t < t1; ++t) {
-    run += (double)logsigmoid_(w.fg[base + t]);
-    const float Ft = (float)run;
-    w.F[base + t] = Ft;
-    const float g = w.ig[base + t] - Ft;
-    if (g > lmax) { lmax = g; larg = t; }
+  if (reg) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int t = t0 + k;
+      if (t < t1) {
+        run += (double)lfv[k];
+        const float Ft = (float)run;
+        w.F[base + t] = Ft;
+        gv[k] -= Ft;                              // g_t = i_t - F_t
+        if (gv[k] > lmax) { lmax = gv[k]; larg = t; }
+      }
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) {
+      run += (double)logsigmoid_(w.fg[base + t]);
+      const float Ft = (float)run;
+      w.F[base + t] = Ft;
+      const float g = w.ig[base + t] - Ft;
+      if (g > lmax) { lmax = g; larg = t; }
+    }
   }
   float pm = lmax;
   int pa = larg;
@@ -261,6 +291,18 @@ __global__ __launch_bounds__(SCAN_T) void vil_scan_kernel(int S, VilWs w) {
   const float xm = __shfl_up(pm, 1, 64);
   const int xa = __shfl_up(pa, 1, 64);
   if (lane > 0 && xm > em) { em = xm; ea = xa; }
+  if (reg) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int t = t0 + k;
+      if (t < t1) {
+        if (gv[k] > em) { em = gv[k]; ea = t; }
+        w.G[base + t] = em;
+        w.arg[base + t] = ea;
+      }
+    }
+    return;
+  }
   for (int t = t0; t < t1; ++t) {
     const float g = w.ig[base + t] - w.F[base + t];
     if (g > em) { em = g; ea = t; }
@@ -277,8 +319,25 @@ __global__ __launch_bounds__(SCAN_T) void vil_rscan_kernel(int S, VilWs w) {
   const int chunk = (S + SCAN_T - 1) / SCAN_T;
   const int t0 = min(S, tid * chunk), t1 = min(S, t0 + chunk);
   // dF_t = rq_t - ck_t + dm_t - dscat_t ;  di_t = ck_t + dscat_t
+  constexpr int CH = 8;                           // short chunks live in registers (see vil_scan_kernel)
+  const bool reg = chunk <= CH;
+  float dFv[CH], div[CH], sgv[CH];
   double loc = 0.0;
-  for (int t = t0; t < t1; ++t) loc += (double)(w.rq[base + t] - w.ck[base + t] + w.dm[base + t] - w.dscat[base + t]);
+  if (reg) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int t = t0 + k;
+      const bool in = t < t1;
+      const long long o = base + (in ? t : 0);
+      const float ck = w.ck[o], ds = w.dscat[o];
+      dFv[k] = in ? w.rq[o] - ck + w.dm[o] - ds : 0.f;
+      div[k] = ck + ds;
+      sgv[k] = 1.f / (1.f + expf(w.fg[o]));
+      loc += (double)dFv[k];
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) loc += (double)(w.rq[base + t] - w.ck[base + t] + w.dm[base + t] - w.dscat[base + t]);
+  }
   double inc = loc;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -289,6 +348,18 @@ __global__ __launch_bounds__(SCAN_T) void vil_rscan_kernel(int S, VilWs w) {
   __syncthreads();
   double run = inc - loc;   // sum over the later lanes of the wave ...
   for (int i = wv + 1; i < SCAN_W; ++i) run += s_sum[i];   // ... and the later waves
+  if (reg) {
+#pragma unroll
+    for (int k = CH - 1; k >= 0; --k) {
+      const int t = t0 + k;
+      if (t < t1) {
+        run += (double)dFv[k];
+        w.df[base + t] = (float)run * sgv[k];
+        w.di[base + t] = div[k];
+      }
+    }
+    return;
+  }
   for (int t = t1 - 1; t >= t0; --t) {
     run += (double)(w.rq[base + t] - w.ck[base + t] + w.dm[base + t] - w.dscat[base + t]);
     const float f = w.fg[base + t];
@@ -814,27 +885,32 @@ __global__ __launch_bounds__(512) void vil_post_bwd_kernel(const T* dout, int S,
 }
 
 // per-token preparation for the mLSTM backward: da' = dh/den', db', dm
+// one lane per ELEMENT (row, j) -- DH lanes share a row and meet by shuffles: every load and store of the pass is contiguous across the
+// wave (round 6; a lane per row walked its DH elements 64 bytes apart from its neighbours': 14 us for 1.3 MB)
 template <int DH>
 __global__ __launch_bounds__(256) void mlstm_bwd_prep_kernel(int S, long long total, VilWs w) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*NH*S
-  if (i >= total) return;
+  static_assert((DH & (DH - 1)) == 0 && DH <= 64, "DH lanes of a wave share a row");
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*NH*S*DH
+  const bool ok = e < total * DH;
+  const long long ec = ok ? e : 0, i = ec / DH;
+  const int j = (int)(ec - i * DH);
   const float bd = w.bden[i];
   const float m = w.F[i] + w.G[i];
   const float em = expf(-m);
   const float nrm = fmaxf(fabsf(bd), em) + MLSTM_EPS;
-  float dot = 0.f;
+  const float d = w.dh[ec];
+  float dot = d * w.h[ec];
 #pragma unroll
-  for (int j = 0; j < DH; ++j) {
-    const float d = w.dh[i * DH + j];
-    dot = fmaf(d, w.h[i * DH + j], dot);
-    w.dap[i * DH + j] = d / nrm;
+  for (int o = 1; o < DH; o <<= 1) dot += __shfl_xor(dot, o, 64);
+  if (!ok) return;
+  w.dap[e] = d / nrm;
+  w.dq[e] = 0.f; w.dk[e] = 0.f; w.dv[e] = 0.f;                     // atomically accumulated below
+  if (j == 0) {
+    const float dden = -dot / nrm;
+    w.dbp[i] = (fabsf(bd) > em) ? (bd > 0.f ? dden : -dden) : 0.f;
+    w.dm[i] = dden * MLSTM_EPS;
+    w.dscat[i] = 0.f;
   }
-  const float dden = -dot / nrm;
-  w.dbp[i] = (fabsf(bd) > em) ? (bd > 0.f ? dden : -dden) : 0.f;
-  w.dm[i] = dden * MLSTM_EPS;
-  w.dscat[i] = 0.f;
-#pragma unroll
-  for (int j = 0; j < DH; ++j) { w.dq[i * DH + j] = 0.f; w.dk[i * DH + j] = 0.f; w.dv[i * DH + j] = 0.f; }   // atomically accumulated below
 }
 // scatter the stabiliser gradient onto the arg-max key of every row
 __global__ __launch_bounds__(256) void mlstm_bwd_scatter_kernel(int S, long long total, VilWs w) {
@@ -1225,7 +1301,7 @@ static int vil_bwd_impl(hipStream_t st, const T* dout, T* dxin, int B, int S, co
   ws_layout(&w, ws, B, S, C);
   const long long rows = (long long)B * NH * S;
   hipLaunchKernelGGL((vil_post_bwd_kernel<T, C>), dim3(cdiv(S, 32), B), dim3(512), 0, st, dout, S, *p, *g, w);
-  hipLaunchKernelGGL((mlstm_bwd_prep_kernel<DH>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
+  hipLaunchKernelGGL((mlstm_bwd_prep_kernel<DH>), dim3((unsigned)((rows * DH + 255) / 256)), dim3(256), 0, st, S, rows, w);
   hipLaunchKernelGGL(mlstm_bwd_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, S, rows, w);
   if (DH == 16 && !(g_xh_disable & 8)) {
     // the forward's carried states C, n are still in the workspace; the reverse states are built here
