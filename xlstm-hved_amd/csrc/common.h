@@ -107,6 +107,19 @@ template <int F> __device__ __forceinline__ void stvec(h16<F>* p, long long q, c
   *reinterpret_cast<uint4*>(p + q) = t;
 }
 
+// two-element runs (4 bytes of 16-bit storage, 8 of fp32): the narrow lanes of the deep-level element-wise kernels (eltwise.hip)
+__device__ __forceinline__ void ldvec(const float* p, long long q, float (&o)[2]) {
+  const float2 t = *reinterpret_cast<const float2*>(p + q); o[0] = t.x; o[1] = t.y;
+}
+__device__ __forceinline__ void stvec(float* p, long long q, const float (&o)[2]) { *reinterpret_cast<float2*>(p + q) = make_float2(o[0], o[1]); }
+template <int F> __device__ __forceinline__ void ldvec(const h16<F>* p, long long q, float (&o)[2]) {
+  const unsigned u = *reinterpret_cast<const unsigned*>(p + q);
+  o[0] = cvt_lo<F>(u); o[1] = cvt_hi<F>(u);
+}
+template <int F> __device__ __forceinline__ void stvec(h16<F>* p, long long q, const float (&o)[2]) {
+  *reinterpret_cast<unsigned*>(p + q) = cvt_pack<F>(o[0], o[1]);
+}
+
 // 16x16x32 MFMA on either 16-bit format (operands carried as 8 raw shorts = 4 VGPRs; fp32 accumulate)
 typedef short h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));

@@ -1595,6 +1595,15 @@ extern "C" int xh_poe_bwd(void* stream, int dtype, const void* feat, const float
     const long long q = run * VW;                                                                                    \
     const int valid = (int)min((long long)VW, dhw - q);
 #define VOX_LOOP_END }
+// The same with VWX voxels per lane when VWX > 0 (the deep levels: two -- four times the lanes of the 16-byte runs, and room in the
+// registers for four times the channels per round of loads)
+#define VOX_LOOP_BEGIN_W(VWX)                                                                                        \
+  constexpr int VW = (VWX) > 0 ? (VWX) : VWT<T>::v;                                                                  \
+  const int n = blockIdx.z;                                                                                          \
+  const long long nrun = (dhw + VW - 1) / VW;                                                                        \
+  for (long long run = (long long)blockIdx.x * 256 + threadIdx.x; run < nrun; run += (long long)gridDim.x * 256) {   \
+    const long long q = run * VW;                                                                                    \
+    const int valid = (int)min((long long)VW, dhw - q);
 // Channels are walked CB at a time with all of a batch's loads issued before the first use: a lane's channel loop is
 // otherwise one full memory latency per channel (in-order issue, the wait sits right behind each load).
 constexpr int CB = 4;
@@ -1687,6 +1696,17 @@ static inline dim3 vox_grid(long long dhw, int N, int cap = 4096) {
 // The deep levels: a few dozen workgroups whose lanes walk many channels.  Their run time is the lane's chain of dependent
 // load rounds (C / CB of them, a memory latency each), so those launches take the instances with 8 or 16 channels per round.
 static inline bool deep_grid(const dim3& g, int C) { return C >= 8 && (long long)g.x * g.y * g.z < 256; }
+// Round 6: those instances also take TWO voxels per lane instead of eight (DEEP_VW) and DEEP_CB channels per round: at 32 workgroups
+// for the 32^3 level a launch was one wave per SIMD on an eighth of the chip walking 64 - 128 channels in rounds of 8 or 16, twice --
+// 20 us of exposed latency for a megabyte of data.  Four times the lanes, a quarter of the rounds.
+constexpr int DEEP_VW = 2, DEEP_CB = 32;
+template <typename T>
+static inline dim3 vox_grid_deep(long long dhw, int N, int cap = 4096) {
+  const long long nrun = (dhw + DEEP_VW - 1) / DEEP_VW;
+  long long b = (nrun + 255) / 256;
+  if (b > cap) b = cap;
+  return dim3((unsigned)b, 1, N);
+}
 extern "C" int xh_channel_pool_fwd(void* stream, int dtype, const void* x, long long x_bs, void* y, long long y_bs, int N,
                                    int C, long long DHW) {
   if (!x || !y || N <= 0 || C <= 0 || DHW <= 0 || N > 65535) return XH_ERR_ARG;
@@ -1820,10 +1840,10 @@ template <typename T> struct Pair2 {
   T* dx[2]; long long dx_bs[2]; int acc[2];
 };
 // y (N, 4, ...): channels 2 w, 2 w + 1 = (max_c, mean_c) of x[w]
-template <typename T, bool VEC, int CBT = CB>
+template <typename T, bool VEC, int CBT = CB, int VWX = 0>
 __global__ __launch_bounds__(256) void channel_pool2_fwd_kernel(const Pair2<T> p, T* __restrict__ y, long long y_bs, long long dhw) {
   const int w = blockIdx.y, C = p.C[w];
-  VOX_LOOP_BEGIN
+  VOX_LOOP_BEGIN_W(VWX)
     const T* xp = p.x[w] + n * p.x_bs[w];
     float m[VW], s[VW];
 #pragma unroll
@@ -1850,10 +1870,10 @@ __global__ __launch_bounds__(256) void channel_pool2_fwd_kernel(const Pair2<T> p
   VOX_LOOP_END
 }
 // dy (N, 4, ...) as above -> dx[w] (+)= the pooled gradients routed back (first maximum; mean to every channel)
-template <typename T, bool VEC, int CBT = CB>
+template <typename T, bool VEC, int CBT = CB, int VWX = 0>
 __global__ __launch_bounds__(256) void channel_pool2_bwd_kernel(const Pair2<T> p, const T* __restrict__ dy, long long dy_bs, long long dhw) {
   const int w = blockIdx.y, C = p.C[w], accumulate = p.acc[w];
-  VOX_LOOP_BEGIN
+  VOX_LOOP_BEGIN_W(VWX)
     const T* xp = p.x[w] + n * p.x_bs[w];
     float m[VW], g0[VW], g1[VW];
     int arg[VW];
@@ -1990,8 +2010,10 @@ extern "C" int xh_channel_pool2_fwd(void* stream, int dtype, const void* xa, lon
   XH_DISPATCH_T(dtype, {
     const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, nullptr, 0, 0, nullptr, 0, 0);
     dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
-    if (vec_ok<T>(DHW, {xa_bs, xb_bs, y_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb))
-      hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, true, 16>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, y_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb)) {
+      grid = vox_grid_deep<T>(DHW, N); grid.y = 2;
+      hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, true, DEEP_CB, DEEP_VW>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
+    }
     else if (vec_ok<T>(DHW, {xa_bs, xb_bs, y_bs})) hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
     else hipLaunchKernelGGL((channel_pool2_fwd_kernel<T, false>), grid, dim3(256), 0, st, p, (T*)y, y_bs, DHW);
   });
@@ -2005,8 +2027,10 @@ extern "C" int xh_channel_pool2_bwd(void* stream, int dtype, const void* xa, lon
   XH_DISPATCH_T(dtype, {
     const Pair2<T> p = make_pair2<T>(xa, xa_bs, Ca, xb, xb_bs, Cb, dxa, dxa_bs, acc_a, dxb, dxb_bs, acc_b);
     dim3 grid = vox_grid<T>(DHW, N); grid.y = 2;
-    if (vec_ok<T>(DHW, {xa_bs, xb_bs, dy_bs, dxa_bs, dxb_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb))
-      hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, true, 16>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
+    if (vec_ok<T>(DHW, {xa_bs, xb_bs, dy_bs, dxa_bs, dxb_bs}) && deep_grid(grid, Ca < Cb ? Ca : Cb)) {
+      grid = vox_grid_deep<T>(DHW, N); grid.y = 2;
+      hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, true, DEEP_CB, DEEP_VW>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
+    }
     else if (vec_ok<T>(DHW, {xa_bs, xb_bs, dy_bs, dxa_bs, dxb_bs}))
       hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
     else hipLaunchKernelGGL((channel_pool2_bwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)dy, dy_bs, DHW);
@@ -2825,7 +2849,7 @@ struct SkrFin {
   const float *gamma, *beta; float *rm, *rv; int steps;
   float *o_sc, *o_sh, *o_mean, *o_rstd;
 };
-template <typename T, bool VEC, int CBT = CB>
+template <typename T, bool VEC, int CBT = CB, int VWX = 0>
 __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
                                                           const float* sh, const float* w2, T* __restrict__ a, int C,
                                                           long long dhw, const SkrFin fin) {
@@ -2854,7 +2878,7 @@ __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__
     sc = s_sc; sh = s_sh;                                // (one sample: n * C + c == c)
   }
   const float w0 = w2[0], w1 = w2[1];
-  VOX_LOOP_BEGIN
+  VOX_LOOP_BEGIN_W(VWX)
     float m[VW], s[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) { m[v] = -INFINITY; s[v] = 0.f; }
@@ -2888,7 +2912,7 @@ __global__ __launch_bounds__(256) void skr_tail_fwd_kernel(const T* __restrict__
     strow<VEC>(a + (long long)n * dhw, q, valid, out);
   VOX_LOOP_END
 }
-template <typename T, bool VEC, int CBT = CB>
+template <typename T, bool VEC, int CBT = CB, int VWX = 0>
 __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__ t, const T* __restrict__ x, const float* sc,
                                                           const float* sh, const float* w2, const T* __restrict__ a,
                                                           const T* __restrict__ da, T* __restrict__ dtg, T* dx,
@@ -2896,7 +2920,7 @@ __global__ __launch_bounds__(256) void skr_tail_bwd_kernel(const T* __restrict__
   __shared__ double s_red[4 * 2];
   const float w0 = w2[0], w1 = w2[1];
   double sacc[2] = {0.0, 0.0};
-  VOX_LOOP_BEGIN
+  VOX_LOOP_BEGIN_W(VWX)
     float m[VW], s[VW], av[VW], dpre[VW];
     int arg[VW];
     ldrow<VEC>(a + (long long)n * dhw, q, valid, av);
@@ -2985,7 +3009,7 @@ static int launch_skr_tail_fwd(void* stream, int dtype, const void* t, const voi
   XH_DISPATCH_T(dtype, {
     const dim3 grid = vox_grid<T>(DHW, N);
     if (vec_ok<T>(DHW, {}) && deep_grid(grid, C))
-      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true, 8>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW, fin);
+      hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true, DEEP_CB, DEEP_VW>), vox_grid_deep<T>(DHW, N), dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW, fin);
     else if (vec_ok<T>(DHW, {}))
       hipLaunchKernelGGL((skr_tail_fwd_kernel<T, true>), grid, dim3(256), 0, st, (const T*)t, (const T*)x, sc, sh, w2, (T*)a, C, DHW, fin);
     else
@@ -3016,6 +3040,7 @@ extern "C" int xh_skr_tail_bwd(void* stream, int dtype, const void* t, const voi
                                         (const T*)a, (const T*)da, (T*)dtg, (T*)dx, dw2, C, DHW, acc_dx, dw2_f32)
   XH_DISPATCH_T(dtype, {
     // one pair of fp64 atomics per workgroup on dw2: at most 1024 of them
+    // (the narrow-lane instance -- DEEP_VW -- was measured here too: 21.0 -> 22.4 us at 16^3, 14.1 -> 24.4 us at 64^3: not used)
     const dim3 grid = vox_grid<T>(DHW, N, 1024);
     if (vec_ok<T>(DHW, {}) && deep_grid(grid, C)) SKRB(true, 8);
     else if (vec_ok<T>(DHW, {})) SKRB(true);
