@@ -3216,36 +3216,38 @@ __global__ __launch_bounds__(256) void compose_multi_kernel(const ComposeJobs j)
     else compose_atten_bwd_body(j.a[job], j.ag[job], j.agw[job], j.agb[job], blockIdx.x, s_red);
     return;
   }
-  if (blockIdx.x != 0) return;
-  if (job < j.na + j.nd) {
-    const int k = job - j.na;
-    if (!j.bwd) compose_duse_fwd_body(j.d[k], j.dout[k][0], j.dout[k][1], j.dout[k][2], j.dout[k][3]);
-    else compose_duse_bwd_body(j.d[k], j.dg[k], j.dgout[k][0], j.dgout[k][1], j.dgout[k][2], j.dgout[k][3], s_red);
-    return;
-  }
   if (job >= j.na + j.nd + j.nh) {
-    // W[co][ci][t] = pw[co][ci] * dw[ci][t]:  (pointwise o depthwise)(x) as ONE dense k^3 conv (no non-linearity between them)
+    // W[co][ci][t] = pw[co][ci] * dw[ci][t]:  (pointwise o depthwise)(x) as ONE dense k^3 conv (no non-linearity between them).
+    // Every workgroup of the job's grid row takes a share of the elements (as ONE workgroup per job the backward's 256 + 432 dot
+    // products of 27 / 16 strided loads were the launch's long pole: 15 us)
     const xh_sep_job& q = j.s[job - j.na - j.nd - j.nh];
-    const int C = q.C, K3 = q.K3, t = threadIdx.x;
+    const int C = q.C, K3 = q.K3, t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
     if (!j.bwd) {
-      for (int i = t; i < C * C * K3; i += 256) {
+      for (int i = t; i < C * C * K3; i += nt) {
         const int tap = i % K3, ci = (i / K3) % C, co = i / (K3 * C);
         q.w[i] = q.pw[co * C + ci] * q.dw[ci * K3 + tap];
       }
     } else {
-      for (int i = t; i < C * C; i += 256) {              // d pw[co][ci] += sum_t gw[co][ci][t] dw[ci][t]
+      for (int i = t; i < C * C; i += nt) {               // d pw[co][ci] += sum_t gw[co][ci][t] dw[ci][t]
         const int ci = i % C;
         float v = 0.f;
         for (int tap = 0; tap < K3; ++tap) v = fmaf(q.gw[(long long)i * K3 + tap], q.dw[ci * K3 + tap], v);
         q.g_pw[i] += v;
       }
-      for (int i = t; i < C * K3; i += 256) {             // d dw[ci][t] += sum_co gw[co][ci][t] pw[co][ci]
+      for (int i = t; i < C * K3; i += nt) {              // d dw[ci][t] += sum_co gw[co][ci][t] pw[co][ci]
         const int tap = i % K3, ci = i / K3;
         float v = 0.f;
         for (int co = 0; co < C; ++co) v = fmaf(q.gw[((long long)co * C + ci) * K3 + tap], q.pw[co * C + ci], v);
         q.g_dw[i] += v;
       }
     }
+    return;
+  }
+  if (blockIdx.x != 0) return;
+  if (job < j.na + j.nd) {
+    const int k = job - j.na;
+    if (!j.bwd) compose_duse_fwd_body(j.d[k], j.dout[k][0], j.dout[k][1], j.dout[k][2], j.dout[k][3]);
+    else compose_duse_bwd_body(j.d[k], j.dg[k], j.dgout[k][0], j.dgout[k][1], j.dgout[k][2], j.dgout[k][3], s_red);
     return;
   }
   const xh_head_job& h = j.h;
@@ -3295,7 +3297,7 @@ extern "C" int xh_compose_multi(void* stream, int bwd, int na, const xh_atten_jo
     if (!sj[i].dw || !sj[i].pw || sj[i].C <= 0 || sj[i].K3 <= 0 || (bwd ? (!sj[i].gw || !sj[i].g_dw || !sj[i].g_pw) : !sj[i].w)) return XH_ERR_ARG;
   }
   j.zero_buf = zero_n > 0 ? zero_buf : nullptr; j.zero_n = zero_n;
-  int gx = 1;
+  int gx = ns > 0 ? 8 : 1;                               // the separable-conv jobs spread over their grid row
   for (int i = 0; i < na; ++i) {
     const xh_atten_job& s = aj[i];
     if (s.NS <= 0 || s.NE < s.NS || s.E <= 0 || s.K3 <= 0) return XH_ERR_ARG;
