@@ -1146,7 +1146,7 @@ def roofline_pass(step, ops, nsteps, dtype):
               "share_of_conv_time": ms_sum / total_ms, "conv_time_per_step_ms": total_ms / nsteps,
               # what the per-kernel fraction above does not see: everything of the step that is NOT a bracketed conv launch
               # (norm / element-wise passes, ViL, PoE, loss, packs, fills) = the instrumented step minus its conv brackets minus
-              # the event pairs; the rocprof family split of the same step is in profiles/ (r04*_timeline.txt)
+              # the event pairs; the rocprof family split of the same step is in profiles/ (r06z_timeline.txt)
               "instrumented_step_ms": step_ms,
               "non_conv_ms_per_step": max(step_ms - total_ms / nsteps - (n_brackets + elt_calls) * overhead_ms, 0.0),
               # the same family, measured two ways: in THIS run (event brackets around every non-conv stage entry point of the
