@@ -78,6 +78,21 @@ static inline dim3 red_grid(long long dhw, int C, int N) {
   for (long long q = (long long)blockIdx.x * q_per + threadIdx.x * VW; q < q_end; q += EW_BLOCK * VW) { \
     const int valid = (int)min((long long)VW, dhw - q);
 #define ROW_LOOP_END }
+// The reducing kernels run with at most 64 workgroups per row (red_grid), i.e. a thread walks 8 - 16 vectors: four of them per trip,
+// their loads issued together (one load per trip is one exposed latency per trip on a launch with one workgroup per CU).
+// ROW_LOOP4_BEGIN opens the four-vector trips (q, u = 0..3 inside the caller's loops over u; S = the trip's vector stride),
+// ROW_LOOP4_TAIL the single-vector trips behind them.
+#define ROW_LOOP4_BEGIN                                                                        \
+  constexpr int VW = VWT<T>::v;                                                                \
+  const int c = blockIdx.y, n = blockIdx.z;                                                    \
+  const long long q_per = ((dhw + gridDim.x - 1) / gridDim.x + EW_BLOCK * VW - 1) / (EW_BLOCK * VW) * (EW_BLOCK * VW); \
+  const long long q_end = min(dhw, (long long)(blockIdx.x + 1) * q_per);                       \
+  constexpr long long S = (long long)EW_BLOCK * VW;                                            \
+  long long q = (long long)blockIdx.x * q_per + threadIdx.x * VW;                              \
+  for (; q + 3 * S < q_end; q += 4 * S) {
+#define ROW_LOOP4_TAIL }                                                                       \
+  for (; q < q_end; q += S) {                                                                  \
+    const int valid = (int)min((long long)VW, dhw - q);
 
 // ---------------------------------------------------------------------------------------- moments
 // xb != nullptr: a virtual concat (xa | xb): channels >= ca come from xb (xh_moments2: the decoder's torch.cat input in ONE launch)
@@ -93,10 +108,22 @@ __global__ __launch_bounds__(EW_BLOCK) void moments_kernel(const T* x, long long
     const int c = blockIdx.y, n = blockIdx.z;
     xp = (xb && c >= ca) ? xb + n * xb_bs + (long long)(c - ca) * dhw : x + n * x_bs + (long long)c * dhw;
   }
-  ROW_LOOP_BEGIN
+  ROW_LOOP4_BEGIN
+    float v4[4][VW];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ldrow<VEC>(xp, q + u * S, (int)min((long long)VW, dhw - (q + u * S)), v4[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float t0 = 0.f, t1 = 0.f;                         // one vector's worth in fp32, then folded into the fp64 sums
+#pragma unroll
+      for (int i = 0; i < VW; ++i) { t0 += v4[u][i]; t1 = fmaf(v4[u][i], v4[u][i], t1); }
+      s[0] += (double)t0;
+      s[1] += (double)t1;
+    }
+  ROW_LOOP4_TAIL
     float v[VW];
     ldrow<VEC>(xp, q, valid, v);
-    float t0 = 0.f, t1 = 0.f;                           // one vector's worth in fp32, then folded into the fp64 sums
+    float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int i = 0; i < VW; ++i) { t0 += v[i]; t1 = fmaf(v[i], v[i], t1); }
     s[0] += (double)t0;
@@ -331,7 +358,27 @@ __device__ __forceinline__ void act_bwd_reduce_body(const uint3 blockIdx, const 
   __shared__ double s_red[4 * 2];
   const float a = sc[blockIdx.z * C + blockIdx.y], b = sh[blockIdx.z * C + blockIdx.y];
   double s[2] = {0.0, 0.0};
-  ROW_LOOP_BEGIN
+  ROW_LOOP4_BEGIN
+    float g4[4][VW], x4[4][VW];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int vu = (int)min((long long)VW, dhw - (q + u * S));
+      ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q + u * S, vu, g4[u]);
+      ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q + u * S, vu, x4[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < VW; ++i) {
+        const float gg = g4[u][i] * ((x4[u][i] * a + b) > 0.f ? 1.f : slope);
+        t0 += gg;
+        t1 = fmaf(gg, x4[u][i], t1);
+      }
+      s[0] += (double)t0;
+      s[1] += (double)t1;
+    }
+  ROW_LOOP4_TAIL
     float g[VW], xv[VW];
     ldrow<VEC>(dy + n * dy_bs + (long long)c * dhw, q, valid, g);
     ldrow<VEC>(x + n * x_bs + (long long)c * dhw, q, valid, xv);
