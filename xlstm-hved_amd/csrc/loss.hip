@@ -35,7 +35,39 @@ __global__ __launch_bounds__(LS_BLOCK) void pair_sums_kernel(const TA* a, long l
   double s[6] = {0, 0, 0, 0, 0, 0};
   const long long per = ((dhw + gridDim.x - 1) / gridDim.x + LS_BLOCK * 4 - 1) / (LS_BLOCK * 4) * (LS_BLOCK * 4);
   const long long q_end = min(dhw, (long long)(blockIdx.x + 1) * per);
-  for (long long q = (long long)blockIdx.x * per + threadIdx.x * 4; q < q_end; q += LS_BLOCK * 4) {
+  long long q = (long long)blockIdx.x * per + threadIdx.x * 4;
+  if constexpr (VEC) {
+    // four runs per trip, the eight loads issued together (one 8-byte load pair per trip left the three 128^3 reductions of the
+    // training step at 1.5 TB/s); the runs are summed in the same order as one by one
+    constexpr long long S = (long long)LS_BLOCK * 4;
+    for (; q + 3 * S < q_end; q += 4 * S) {
+      float a4[4][4], b4[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ld4(ap, q + u * S, a4[u]);
+      if (bp) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ld4(bp, q + u * S, b4[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) b4[u][i] = bval;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x = thr_on ? (a4[u][i] > thr ? 1.f : 0.f) : a4[u][i];
+          const float y = b4[u][i], d = x - y;
+          t[0] = fmaf(x, y, t[0]); t[1] = fmaf(x, x, t[1]); t[2] = fmaf(y, y, t[2]); t[3] = fmaf(d, d, t[3]); t[4] += x; t[5] += y;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[k] += (double)t[k];
+      }
+    }
+  }
+  for (; q < q_end; q += LS_BLOCK * 4) {
     const int valid = (int)min(4LL, dhw - q);
     float av[4], bv[4] = {bval, bval, bval, bval};
     ld4any<VEC>(ap, q, valid, av);
@@ -97,12 +129,20 @@ static inline dim3 ls_grid(long long dhw, int C, int N) {
   return dim3((unsigned)(want < maxb ? want : maxb), C, N);
 }
 
+// The reducing pass ends in six fp64 atomics per workgroup on the row's six addresses, and atomics on one address retire one after
+// the other (~45 ns): the 683 workgroups per row of a 3-channel 128^3 loss spent 30 us queueing them for 38 MB of input.  At most 64
+// workgroups per row (like the norm reducers of eltwise.hip); a thread's longer walk runs four runs per trip.
+static inline dim3 ls_red_grid(long long dhw, int C, int N) {
+  dim3 g = ls_grid(dhw, C, N);
+  if (g.x > 64) g.x = 64;
+  return g;
+}
 extern "C" int xh_pair_sums(void* stream, int dtype, const void* a, long long a_bs, int b_dtype, const void* b, long long b_bs,
                             float bval, int N, int C, long long DHW, int thr_on, float thr, double* red) {
   if (!a || !red || N <= 0 || C <= 0 || DHW <= 0 || C > 65535 || N > 65535) return XH_ERR_ARG;
   if (b && b_dtype != dtype && b_dtype != XH_F32) return XH_ERR_DTYPE;
   const bool vec = DHW % 4 == 0 && a_bs % 4 == 0 && (!b || b_bs % 4 == 0);
-  const dim3 grid = ls_grid(DHW, C, N);
+  const dim3 grid = ls_red_grid(DHW, C, N);
   hipStream_t st = (hipStream_t)stream;
   XH_DISPATCH_T(dtype,
     if (b && b_dtype == XH_F32 && dtype != XH_F32)
@@ -335,7 +375,18 @@ __global__ __launch_bounds__(LS_BLOCK) void multi_sum_kernel(const XhMulti m, do
   const long long q_end = min(n, (long long)(b + 1) * per);
   const bool vec = (n % 4 == 0) && (((unsigned long long)p & (4 * sizeof(T) - 1)) == 0);
   double s[1] = {0.0};
-  for (long long q = (long long)b * per + threadIdx.x * 4; q < q_end; q += LS_BLOCK * 4) {
+  long long q = (long long)b * per + threadIdx.x * 4;
+  if (vec) {                                            // four runs per trip, their loads issued together (the order of the sums stays)
+    constexpr long long S = (long long)LS_BLOCK * 4;
+    for (; q + 3 * S < q_end; q += 4 * S) {
+      float a4[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ld4any<true>(p, q + u * S, 4, a4[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[0] += (double)(((0.f + a4[u][0]) + a4[u][1]) + a4[u][2] + a4[u][3]);
+    }
+  }
+  for (; q < q_end; q += LS_BLOCK * 4) {
     const int valid = (int)min(4LL, n - q);
     float av[4];
     if (vec) ld4any<true>(p, q, valid, av); else ld4any<false>(p, q, valid, av);
