@@ -219,26 +219,55 @@ __device__ __forceinline__ void conv3_wgrad_body(const WgMK& a, const int bid_x,
     }
   }
   // ---- reduce across waves in LDS (layout of the weight tensor slice [16 co][CP ci][27]) ----
+  // Every wave STORES its accumulators into a slice of its own and the slices are summed by the threads that issue the global
+  // atomics.  (Round 6: this was 36 ds_add_f32 per lane into one shared slice.  LDS floating-point atomics retire about one lane
+  // per two cycles: the 18 432 of a workgroup took 17 of the 26 us of a 16^3 problem -- measured by switching the tail off.)
+  constexpr int NSL = 16 * CP * 27 + 16;                 // floats per slice: [16 co][CP ci][27] + 16 bias sums
+  constexpr bool SLICES = (size_t)NWV * NSL * sizeof(float) <= 64 * 1024;
   __syncthreads();
-  for (int i = tid; i < 16 * CP * 27 + 16; i += NT) s_dw[i] = 0.f;
-  __syncthreads();
+  if constexpr (SLICES) {
+    float* my = s_dw + wv * NSL;
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
+    for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-    for (int t = 0; t < TPK; ++t) {
-      const int r9 = t * R + rsel;
-      if (r9 < 9) {
+      for (int t = 0; t < TPK; ++t) {
+        const int r9 = t * R + rsel;
+        if (r9 < 9) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co_l = g4 * 4 + r;                // D row
-          atomicAdd(&s_dw[(co_l * CP + cil) * 27 + r9 * 3 + kw], acc[kw][t][r]);
+          for (int r = 0; r < 4; ++r) my[((g4 * 4 + r) * CP + cil) * 27 + r9 * 3 + kw] = acc[kw][t][r];
         }
       }
-    }
-  dbsum += __shfl_xor(dbsum, 16, 64);
-  dbsum += __shfl_xor(dbsum, 32, 64);
-  if (lane < 16) atomicAdd(&s_dw[16 * CP * 27 + lane], dbsum);
+    dbsum += __shfl_xor(dbsum, 16, 64);
+    dbsum += __shfl_xor(dbsum, 32, 64);
+    if (lane < 16) my[16 * CP * 27 + lane] = dbsum;
+  } else {
+    for (int i = tid; i < NSL; i += NT) s_dw[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int t = 0; t < TPK; ++t) {
+        const int r9 = t * R + rsel;
+        if (r9 < 9) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(&s_dw[((g4 * 4 + r) * CP + cil) * 27 + r9 * 3 + kw], acc[kw][t][r]);
+        }
+      }
+    dbsum += __shfl_xor(dbsum, 16, 64);
+    dbsum += __shfl_xor(dbsum, 32, 64);
+    if (lane < 16) atomicAdd(&s_dw[16 * CP * 27 + lane], dbsum);
+  }
   __syncthreads();
+  auto total = [&](int i) {
+    if constexpr (SLICES) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) v += s_dw[w * NSL + i];
+      return v;
+    } else {
+      return s_dw[i];
+    }
+  };
   const int gpp = a.d.groups / a.d.n_wptr;
   for (int i = tid; i < 16 * CP * 27; i += NT) {
     const int tap = i % 27;
@@ -249,12 +278,12 @@ __device__ __forceinline__ void conv3_wgrad_body(const WgMK& a, const int bid_x,
     const int g = co / a.Cout_g;
     if (ci / a.Cin_g != g) continue;                  // off the block diagonal
     float* dst = a.dw[g / gpp] + ((long long)((g % gpp) * a.Cout_g + co % a.Cout_g) * a.Cin_g + ci % a.Cin_g) * 27 + tap;
-    atomicAdd(dst, s_dw[i]);
+    atomicAdd(dst, total(i));
   }
   if (ct == 0 && tid < co_lim) {
     const int co = co_base + tid, g = co / a.Cout_g;
     float* dbp = a.db[g / gpp];
-    if (dbp) atomicAdd(&dbp[(g % gpp) * a.Cout_g + co % a.Cout_g], s_dw[16 * CP * 27 + tid]);
+    if (dbp) atomicAdd(&dbp[(g % gpp) * a.Cout_g + co % a.Cout_g], total(16 * CP * 27 + tid));
   }
 }
 
@@ -340,7 +369,9 @@ static bool wg_plan(const xh_conv_desc* d, const xh_conv_ptrs* p, float* const d
   pl->gx = (unsigned)gx;
   pl->ny = ny;
   const size_t ring = (size_t)4 * cp * (10 * 96 + 16);
-  const size_t red = (size_t)(16 * cp * 27 + 16) * sizeof(float);
+  // one slice per wave when that fits 64 KB (the kernel's SLICES), else the single atomically summed slice
+  const size_t slice = (size_t)(16 * cp * 27 + 16) * sizeof(float), nwv = (big_vol ? 256 : 512) / 64;
+  const size_t red = nwv * slice <= 64 * 1024 ? nwv * slice : slice;
   pl->shm = ring > red ? ring : red;
   pl->big = big_vol;
   return true;
