@@ -228,10 +228,11 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
   }   // tiles
 
   // ---- sum the four rows of the workgroup in LDS: s_dw[(co_l * 4 CI4 + ci) * 27 + tap], then [4] bias sums ----
-  constexpr int NW = 4 * 4 * CI4 * 27;
-  for (int i = tid; i < NW + 4; i += 256) s_dw[i] = 0.f;
-  __syncthreads();
+  // (every wave STORES into a slice of its own, the slices are summed by the threads that issue the global atomics: LDS floating-
+  // point atomics retire about a lane per two cycles -- see conv3d_wgrad_mfma.hip)
+  constexpr int NW = 4 * 4 * CI4 * 27, NSL = NW + 4;
   {
+    float* my = s_dw + (tid >> 6) * NSL;
     const int kh = nn >> 2, ci = nn & 3;               // accumulator column
     if (kh < 3) {
 #pragma unroll
@@ -240,11 +241,13 @@ __device__ __forceinline__ void wgrad_q4_body(const WgQ4& a, int b, float* s_dw)
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
           for (int r = 0; r < 3; ++r)                  // D row 4 * g + r = (co = g, kw = r)
-            atomicAdd(&s_dw[(g * 4 * CI4 + cq * 4 + ci) * 27 + kd * 9 + kh * 3 + r], acc[cq][kd][r]);
+            my[(g * 4 * CI4 + cq * 4 + ci) * 27 + kd * 9 + kh * 3 + r] = acc[cq][kd][r];
     } else if (ci == 0) {
-      atomicAdd(&s_dw[NW + g], acc[0][1][1]);          // column of ones x dY row (co = g, kw = 1)
+      my[NW + g] = acc[0][1][1];                       // column of ones x dY row (co = g, kw = 1)
     }
   }
+  __syncthreads();
+  for (int i = tid; i < NSL; i += 256) s_dw[i] = ((s_dw[i] + s_dw[NSL + i]) + s_dw[2 * NSL + i]) + s_dw[3 * NSL + i];
   __syncthreads();
   if (a.abl & 2048) return;                            // ablation: no global atomics
   const int gpp = a.groups / a.n_wptr;
@@ -507,11 +510,10 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
   }   // tiles
 
   // ---- sum the four rows of the workgroup in LDS (the plane ring is free now), then one pass of fp32 atomics ----
-  constexpr int NW = 4 * 4 * CI4 * 27;
-  __syncthreads();
-  for (int i = tid; i < NW + 4; i += 256) s_dw[i] = 0.f;
+  constexpr int NW = 4 * 4 * CI4 * 27, NSL = NW + 4;
   __syncthreads();
   {
+    float* my = s_dw + (tid >> 6) * NSL;                 // a slice per wave, stored (not atomically added: see wgrad_q4_body)
     const int kh = nn >> 2, ci = nn & 3;
     if (kh < 3) {
 #pragma unroll
@@ -520,11 +522,13 @@ __device__ __forceinline__ void wgrad_q4_body_lds(const WgQ4& a, int b, unsigned
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
           for (int r = 0; r < 3; ++r)
-            atomicAdd(&s_dw[(g * 4 * CI4 + cq * 4 + ci) * 27 + kd * 9 + kh * 3 + r], acc[cq][kd][r]);
+            my[(g * 4 * CI4 + cq * 4 + ci) * 27 + kd * 9 + kh * 3 + r] = acc[cq][kd][r];
     } else if (ci == 0) {
-      atomicAdd(&s_dw[NW + g], acc[0][1][1]);
+      my[NW + g] = acc[0][1][1];
     }
   }
+  __syncthreads();
+  for (int i = tid; i < NSL; i += 256) s_dw[i] = ((s_dw[i] + s_dw[NSL + i]) + s_dw[2 * NSL + i]) + s_dw[3 * NSL + i];
   __syncthreads();
   if (a.abl & 2048) return;
   const int gpp = a.groups / a.n_wptr;
@@ -554,7 +558,7 @@ template <int FMT, int CI4, bool LDSX>
 __global__ __launch_bounds__(256, LDSX ? wq4_resident(FMT, CI4) : wq4_waves(CI4)) void conv3_wgrad_q4_multi_kernel(const WgQ4Multi m) {
   constexpr int XBN = 6 * (4 * CI4 * 64 + 16), XBW = 4 * (4 * CI4 * 144 + 16);  // x rows of a plane: narrow / wide tiles (wgrad_q4_body_lds)
   constexpr int RING = 4 * ((XBN > XBW ? XBN : XBW) + 32 + 4096);             // four plane slots: x rows, constant block, dY windows
-  constexpr int RED = (4 * 4 * CI4 * 27 + 4) * 4;
+  constexpr int RED = 4 * (4 * 4 * CI4 * 27 + 4) * 4;                        // a slice of partial sums per wave
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDSX && RING > RED ? RING : RED];
   const int b = blockIdx.x;
   int i = 0;

@@ -259,20 +259,30 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   }   // tiles
 
   // ---- sum the eight rows of the workgroup in LDS (the plane ring is free now), then one pass of fp32 atomics ----
-  constexpr int NW = 4 * 4 * 27;
-  __syncthreads();
-  for (int i = tid; i < NW + 4; i += 512) s_dw[i] = 0.f;
+  // Every wave STORES its accumulators into a slice of its own; the threads that issue the global atomics sum the eight slices.
+  // (It was 28 ds_add_f32 per lane into one slice: LDS floating-point atomics retire about a lane per two cycles -- 14 336 of them
+  // per workgroup, ~13 us at the end of every workgroup of a 115 us launch; found on the MFMA weight gradient of the deep levels,
+  // conv3d_wgrad_mfma.hip.)
+  constexpr int NW = 4 * 4 * 27, NSL = NW + 4;
   __syncthreads();
   {
+    float* my = s_dw + wv * NSL;
     const int kh = nn >> 2, ci = nn & 3;                // accumulator column; rows 4 g + r = (co = g, kw = r)
     if (kh < 3) {
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) atomicAdd(&s_dw[(g * 4 + ci) * 27 + kd * 9 + kh * 3 + r], acc[kd][r]);
+        for (int r = 0; r < 3; ++r) my[(g * 4 + ci) * 27 + kd * 9 + kh * 3 + r] = acc[kd][r];
     } else if (ci == 0) {
-      atomicAdd(&s_dw[NW + g], acc[1][1]);               // column of ones x dY row (co = g, kw = 1)
+      my[NW + g] = acc[1][1];                            // column of ones x dY row (co = g, kw = 1)
     }
+  }
+  __syncthreads();
+  for (int i = tid; i < NSL; i += 512) {                 // slice 0 becomes the sum (each element is read and written by one thread)
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < Q5_TH; ++w) v += s_dw[w * NSL + i];
+    s_dw[i] = v;
   }
   __syncthreads();
   if (a.abl & 2048) return;                              // ablation: no global atomics

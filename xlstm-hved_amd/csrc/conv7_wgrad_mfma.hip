@@ -201,9 +201,14 @@ __device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, c
   }
 
   // ---- reduce the four waves' tiles in LDS: C[(kw, ci)][(kh, co)]: lane holds rows 4*g4 + r -> kw = 4*mt + g4, ci = r ----
-  for (int i = tid; i < K7_NPART; i += 256) s_red[i] = 0.f;
+  // Every wave STORES its 2 744 values into a slice of its own (it holds each of them exactly once) and the slices are summed on the
+  // way out.  Round 6: this was 49 ds_add_f32 per lane into one slice, and LDS floating-point atomics retire about a lane per two
+  // cycles -- 12 500 per workgroup, a fifth of the launch (found on conv3d_wgrad_mfma.hip by switching its tail off).
+  static_assert((size_t)4 * K7_NPART * sizeof(float) <= W7_SHM, "four slices of partial sums in the staging buffers");
+  if (tid < 8) s_red[K7_NW + tid] = 0.f;                 // the bias sums stay atomic (two addresses, a few dozen lanes), in slice 0
   __syncthreads();
   if (kh_l < 7) {
+    float* my = s_red + (tid >> 6) * K7_NPART;
 #pragma unroll
     for (int kd = 0; kd < 7; ++kd)
 #pragma unroll
@@ -211,15 +216,15 @@ __device__ __forceinline__ void conv7_wgrad_body(const Wg7K& a, const int bid, c
         const int kw = 4 * mt + g4;
         if (kw < 7) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            atomicAdd(&s_red[(co_l * 4 + r) * 343 + (kd * 7 + kh_l) * 7 + kw], acc[kd][mt][r]);
+          for (int r = 0; r < 4; ++r) my[(co_l * 4 + r) * 343 + (kd * 7 + kh_l) * 7 + kw] = acc[kd][mt][r];
         }
       }
   }
   if (!xrole && y_item) atomicAdd(&s_red[K7_NW + yco], dbs);
   __syncthreads();
   float* out = a.part + (long long)bid * K7_NPART;
-  for (int i = tid; i < K7_NPART; i += 256) out[i] = s_red[i];
+  for (int i = tid; i < K7_NPART; i += 256)
+    out[i] = i < K7_NW ? ((s_red[i] + s_red[K7_NPART + i]) + s_red[2 * K7_NPART + i]) + s_red[3 * K7_NPART + i] : s_red[i];
 }
 template <int FMT>
 __global__ __launch_bounds__(256, 2) void conv7_wgrad_mfma_kernel(const Wg7K a) {

@@ -1697,19 +1697,22 @@ __global__ __launch_bounds__(256) void cl_bwd_kernel(const u16* dy, const u16* x
     }
   }
   if (MODE != 1) {
-    __shared__ double s_acc[2][512];                   // [which][c8 * 8] (C <= 512)
-    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&s_acc[0][0])[i] = 0.0;
-    __syncthreads();
+    // every thread STORES its eight partial sums ([voxel lane][channel]: nvl * C = 2 048 values whatever C is) and one thread per
+    // channel adds the voxel lanes up -- not LDS atomics: floating-point atomics in LDS retire about a lane per two cycles
+    // (conv3d_wgrad_mfma.hip), 4 096 fp64 ones per workgroup here
+    __shared__ double s_acc[2][2048];
     if (vl < nvl)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        atomicAdd(&s_acc[0][cc + k], s0[k]);
-        if (MODE == 0) atomicAdd(&s_acc[1][cc + k], s1[k]);
+        s_acc[0][vl * C + cc + k] = s0[k];
+        if (MODE == 0) s_acc[1][vl * C + cc + k] = s1[k];
       }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-      atomicAdd(&red[((long long)n * C + c) * 2], s_acc[0][c]);
-      if (MODE == 0) atomicAdd(&red[((long long)n * C + c) * 2 + 1], s_acc[1][c]);
+      double t0 = 0.0, t1 = 0.0;
+      for (int v = 0; v < nvl; ++v) { t0 += s_acc[0][v * C + c]; if (MODE == 0) t1 += s_acc[1][v * C + c]; }
+      atomicAdd(&red[((long long)n * C + c) * 2], t0);
+      if (MODE == 0) atomicAdd(&red[((long long)n * C + c) * 2 + 1], t1);
     }
   }
 }
