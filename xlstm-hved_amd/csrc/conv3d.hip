@@ -1848,6 +1848,11 @@ __global__ __launch_bounds__(256) void conv3_dgrad_s2_vec_kernel(const ConvK a, 
 #pragma unroll
     for (int i = 0; i < CIB; ++i) { v[2 * i] = s0[i]; v[2 * i + 1] = s1[i]; }
     block_sum_d<2 * CIB>(v, s_red, 4);
+    // many workgroups per (sample, group, channel block) -- 1 024 at 128^3: two-level fan-in instead of that many same-line fp64
+    // atomics (fanin.h; the forward kernels have had it since round 3, this one queued 8 - 50 ns x 1 024 behind its last store)
+    if (a.fan && !fan_in<2 * CIB>(a.fan + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * FAN_UNIT_BYTES, blockIdx.x, gridDim.x,
+                                  s_red, reinterpret_cast<int*>(s_red + 2 * CIB)))
+      return;
     if (tid < 2 * CIB) {
       const int ci_g = cib * CIB + (tid >> 1);
       if (ci_g < a.Cin_g) {
@@ -1878,6 +1883,7 @@ static int dgrad_s2_dispatch(void* stream, const xh_conv_desc* d, const xh_conv_
       const long long rows = (long long)(d->D / 2) * (d->H / 2);        // per (d, h) parity class
       const int bpc = (int)((rows * lw + 255) / 256);
       dim3 gridv(4 * bpc, cdiv(cin_g, cib), d->N * d->groups);
+      if (d->epi == 1) a.fan = xh_fan_block(p->fan, p->fan_bytes, (long long)gridv.y * gridv.z, gridv.x);
       switch (cib) {
         case 1: hipLaunchKernelGGL((conv3_dgrad_s2_vec_kernel<T, 1>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw, (int)rows); break;
         case 2: hipLaunchKernelGGL((conv3_dgrad_s2_vec_kernel<T, 2>), gridv, dim3(256), shm, (hipStream_t)stream, a, lw, (int)rows); break;
