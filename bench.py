@@ -633,13 +633,13 @@ def mfma_roofline_pass(ts, x, mask, nsteps=3):
                      e0, e1, 2.0 * n * vox(o) * ks ** 3 * cs_r * cn_r))
         return r
 
-    def wgrad(x_, dy, stride, n, sp_in, sp_out, cs, cn, ks=3, gs=None):
+    def wgrad(x_, dy, stride, n, sp_in, sp_out, cs, cn, ks=3, gs=None, **kw):
         e0, e1 = ev(), ev()
         e0.record()
-        r = orig[2](x_, dy, stride, n, sp_in, sp_out, cs, cn, ks=ks, gs=gs)
+        r = orig[2](x_, dy, stride, n, sp_in, sp_out, cs, cn, ks=ks, gs=gs, **kw)
         e1.record()
         cs_r, cn_r = (7 if cs == 8 else cs), (1 if cn == 32 else cn)
-        recs.append((f"dwgrad_cl {cs_r}->{cn_r} s{stride} @{'x'.join(map(str, sp_out))} (+ zero fill of the packed gradient)", e0, e1,
+        recs.append((f"dwgrad_cl {cs_r}->{cn_r} s{stride} @{'x'.join(map(str, sp_out))}" + ("" if kw.get("dwp") is not None else " (+ zero fill of the packed gradient)"), e0, e1,
                      2.0 * n * vox(sp_out) * ks ** 3 * cs_r * cn_r))
         return r
     delay = GpuDelay()

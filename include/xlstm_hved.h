@@ -63,6 +63,8 @@ int xh_abi_version(void);
  *         registers, 3 every volume.  key 25: REMOVED in round 6 (xh_conv_desc.arith bit XH_ARITH_K7_VECTOR).
  * key 26: groups of 8 class workgroups per launch of the discriminator's source-block weight gradient (default 32 = 256 workgroups).
  * key 27: workgroup target of the row-streaming norm / element-wise kernels (default 2048).
+ * key 28: full-row weight-gradient kernel on rows of 64 voxels: bit 0 = a unit stages two input quads, bit 1 = two output quads
+ *         bit 2 = rows of 128 voxels: three input quads against one staging of dY (default 7; 0 = one quad of each per unit).
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
  *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo
@@ -78,7 +80,7 @@ int xh_abi_version(void);
  * xh_conv_desc.arith.  The remaining keys choose between kernels / launch plans that compute the same function:
  *   - bit-identical results whatever the value: keys 3, 10-13, 16, 17, 19, 20, 22, 26, 27 and key 14's tile / remap bits;
  *   - same products, sums taken in another order (differences at fp32 / fp64 round-off of the sums): key 2 bits 0, 1, 2, 6, 8, 9,
- *     10; keys 5, 21, 23; key 14's kernel-choice bits;
+ *     10; keys 5, 21, 23, 28; key 14's kernel-choice bits;
  *   - a different kernel FAMILY for the same conv, one operand rounding apart in 16-bit storage (tests hold both to the same
  *     bounds): key 0 (MFMA vs vector kernels), key 2 bits 3, 4, 5, 7, key 24 (input- vs output-stationary 7^3 kernel).
  * Neither function is thread-safe against concurrent launches from other host threads: set options before the first launch;

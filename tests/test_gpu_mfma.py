@@ -894,9 +894,12 @@ def test_k7_gate_conv_fp32_storage_on_the_matrix_cores(sp):
                                  dict(n=1, cin=12, cout=4, g=1, sp=(10, 16, 128), split=4), dict(n=1, cin=24, cout=8, g=1, sp=(6, 8, 64), split=16),
                                  dict(n=2, cin=20, cout=40, g=5, sp=(5, 8, 64)), dict(n=1, cin=8, cout=8, g=8, sp=(12, 24, 128)),
                                  dict(n=1, cin=4, cout=12, g=1, sp=(4, 8, 128)), dict(n=2, cin=16, cout=32, g=4, sp=(8, 8, 32)),
-                                 dict(n=1, cin=48, cout=16, g=1, sp=(32, 32, 32), split=32), dict(n=1, cin=16, cout=16, g=16, sp=(19, 16, 32))],
+                                 dict(n=1, cin=48, cout=16, g=1, sp=(32, 32, 32), split=32), dict(n=1, cin=16, cout=16, g=16, sp=(19, 16, 32)),
+                                 dict(n=1, cin=24, cout=8, g=1, sp=(7, 16, 64), split=12), dict(n=2, cin=16, cout=16, g=2, sp=(5, 8, 64)),
+                                 dict(n=1, cin=8, cout=4, g=1, sp=(9, 8, 64)), dict(n=1, cin=8, cout=8, g=8, sp=(6, 8, 64))],
                          ids=["4to4_w64_n2", "16to16g4_w128_ragged_segments", "12to4_w128_two_sources", "24to8_w64_two_sources", "20to40g5_w64_n2",
-                              "depthwise8_w128", "4to12_w128_four_planes", "16to32g4_w32_n2", "48to16_w32_two_sources", "depthwise16_w32"])
+                              "depthwise8_w128", "4to12_w128_four_planes", "16to32g4_w32_n2", "48to16_w32_two_sources", "depthwise16_w32",
+                              "24to8_w64_unit_across_the_sources", "16to16g2_w64_n2_two_by_two_quads", "8to4_w64_two_input_quads", "depthwise8_w64"])
 def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
     """conv3_wgrad_q5_multi_kernel (rows of 32 / 64 / 128 voxels, H a multiple of 8: 8-row full-row tiles, dY staged once, the kw shift
     applied at fragment-read time) against conv3_wgrad_q4_multi_kernel (xh_set_option(21, 0)) and torch.nn.grad on the same 16-bit
@@ -934,6 +937,38 @@ def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
         assert l2_err(res["full"][0], ref) < tol, l2_err(res["full"][0], ref)
         assert l2_err(res["full"][1], dy.float().sum((0, 2, 3, 4)).cpu()) < 1e-4
         assert l2_err(res["full"][0], res["tile"][0]) < 2e-6 and l2_err(res["full"][1], res["tile"][1]) < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [(24, 8, 1, (12, 16, 64), 16), (16, 16, 2, (9, 8, 64), None), (20, 40, 5, (6, 8, 64), None), (8, 4, 1, (8, 24, 64), None),
+                                 (12, 4, 1, (11, 16, 128), 4), (24, 8, 2, (5, 8, 128), None), (24, 4, 1, (4, 8, 128), 8)],
+                         ids=["24to8", "16to16g2", "20to40g5", "8to4", "12to4_w128_three_input_quads", "24to8g2_w128", "24to4_w128_two_chunks_of_three"])
+def test_wgrad_full_row_units_of_two_quads_equal_single_quad_units(cfg):
+    """Rows of 64 voxels (round 6): a unit of conv3_wgrad_q5_multi_kernel stages two input and / or two output quads once and multiplies
+    every pair (xh_set_option(28, ...) bits 0 and 1) instead of one quad of each per unit (28, 0: dY re-staged per input quad, x per
+    output quad); rows of 128 voxels: three input quads against one staging of dY, rounds of one plane (bit 2).  Same products, same
+    order inside a pair: the plans agree to the order of the fp32 atomics."""
+    lib = X._lib.load()
+    torch.manual_seed(47)
+    cin, cout, g, sp, split = cfg
+    x = torch.randn((2, cin) + sp, device=DEV).bfloat16()
+    dy = torch.randn((2, cout) + sp, device=DEV).bfloat16()
+    xa, xb = (x, None) if split is None else (x[:, :split].contiguous(), x[:, split:].contiguous())
+    pre = (torch.rand(2, cin, device=DEV) + 0.5, torch.randn(2, cin, device=DEV), 0.01)
+    nw = g if g <= 4 else 1
+    res = {}
+    for uq in (7, 0, 1, 2, 4):
+        lib.xh_set_option(28, uq)
+        try:
+            dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
+            dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
+            X.ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=3, groups=g, pre=pre)
+            assert "conv3_wgrad_q5_multi_kernel" in X.ops.last_conv_kernel()
+            torch.cuda.synchronize()
+            res[uq] = (torch.cat(dws, 0).cpu(), torch.cat(dbs, 0).cpu())
+        finally:
+            lib.xh_set_option(28, 7)
+    for uq in (7, 1, 2, 4):
+        assert l2_err(res[uq][0], res[0][0]) < 2e-6 and l2_err(res[uq][1], res[0][1]) < 2e-6, (uq, l2_err(res[uq][0], res[0][0]))
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])

@@ -454,7 +454,10 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
       // currently lightest launch
       const int per = full ? Q5_MULTI : WQ_MULTI;
       const int L = ((int)cl.size() + per - 1) / per;
-      auto cost = [](const WgQ4& w) { return (double)w.N * w.D * w.H * (w.full ? (w.W == 128 ? 128.0 : w.W == 64 ? 90.0 : 70.0) : (double)w.W) * w.nq * w.ci4; };
+      auto cost = [](const WgQ4& w) {                   // (full-row units of several quads: as xh_wgrad_q5_launch prices them)
+        const double uf = !w.full || w.uqx * w.uqy == 1 ? 1.0 : w.uqx * w.uqy == 2 ? 1.45 : w.uqx == 3 ? 2.0 : 1.9;
+        return (double)w.N * w.D * w.H * (w.full ? (w.W == 128 ? 128.0 * uf : w.W == 64 ? 90.0 * uf : 70.0) : (double)w.W) * w.nq * w.ci4;
+      };
       std::vector<int> order(cl.size());
       for (size_t i = 0; i < cl.size(); ++i) order[i] = (int)i;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(cl[a]) > cost(cl[b]); });
@@ -466,6 +469,35 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
           if ((int)bucket[b].size() < per && (best < 0 || load[b] < load[best])) best = b;
         bucket[best].push_back(cl[idx]);
         load[best] += cost(cl[idx]);
+      }
+      if (full && L > 1) {
+        // full-row launches: a launch lasts as long as its slowest workgroup under the min-max plan (xh_wgrad_q5_plan), which is not
+        // additive in the problems -- improve the greedy split by single moves and swaps while the sum of planned durations falls
+        extern int g_q5_wgs;
+        auto planned = [&](const std::vector<WgQ4>& v) { int wq[Q5_MULTI]; return v.empty() ? 0.0 : xh_wgrad_q5_plan(v.data(), (int)v.size(), g_q5_wgs, wq); };
+        std::vector<double> T(L);
+        for (int b = 0; b < L; ++b) T[b] = planned(bucket[b]);
+        for (int iter = 0; iter < 32; ++iter) {
+          double gain = 1e-9; int ba = -1, bb = -1, ia = -1, ib = -1;
+          for (int a = 0; a < L; ++a)
+            for (int b2 = 0; b2 < L; ++b2) {
+              if (a == b2) continue;
+              for (int i = 0; i < (int)bucket[a].size(); ++i) {
+                for (int j = -1; j < (int)bucket[b2].size(); ++j) {     // j = -1: move i to b2; else swap i <-> j (a < b2 only)
+                  if (j < 0 ? ((int)bucket[b2].size() >= per || bucket[a].size() <= 1) : a > b2) continue;
+                  std::vector<WgQ4> va = bucket[a], vb = bucket[b2];
+                  if (j < 0) { vb.push_back(va[i]); va.erase(va.begin() + i); }
+                  else std::swap(va[i], vb[j]);
+                  const double g = T[a] + T[b2] - planned(va) - planned(vb);
+                  if (g > gain) { gain = g; ba = a; bb = b2; ia = i; ib = j; }
+                }
+              }
+            }
+          if (ba < 0) break;
+          if (ib < 0) { bucket[bb].push_back(bucket[ba][ia]); bucket[ba].erase(bucket[ba].begin() + ia); }
+          else std::swap(bucket[ba][ia], bucket[bb][ib]);
+          T[ba] = planned(bucket[ba]); T[bb] = planned(bucket[bb]);
+        }
       }
       for (int b = 0; b < L; ++b) xh_wgrad_q4_launch(st, fmt, bucket[b].data(), (int)bucket[b].size());
     }

@@ -33,6 +33,9 @@
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 #include "wgrad_q4.h"
+#include <cstdlib>
+#include <cstdio>
+#include <cmath>
 
 typedef h16x8 frag8;
 typedef f32x4_t f32x4;
@@ -46,31 +49,39 @@ static_assert(sizeof(WgQ5Multi) <= 4096, "the problem table travels in the kerne
 
 namespace {
 constexpr int Q5_TH = 8;                      // rows per tile = waves per workgroup
-template <int NCH> struct Q5 {                // NCH = 32-voxel K chunks per row: rows of 128 | 64 | 32 voxels
+// NCH = 32-voxel K chunks per row: rows of 128 | 64 | 32 voxels; NQX / NQY = input / output channel quads of a unit (round 6: a
+// unit of rows of 64 voxels stages up to two quads of each operand ONCE and multiplies every pair)
+// PPR = planes per round of loads (2; 1 for the three-input-quad units on rows of 128 voxels, whose plane slot is 42 KB)
+template <int NCH, int NQX = 1, int NQY = 1, int PPR = 2> struct Q5 {
   static constexpr int W = 32 * NCH;
   static constexpr int PR = W / 8;            // 16-byte pieces per row
   static constexpr int NC = NCH;
   static constexpr int CP = 2 * W + 16;       // bytes per (row, channel) line of x (16 B spare: bank spreading of the B reads)
   static constexpr int XROW = 4 * CP + 16;    // bytes per staged x row (4 channels)
-  static constexpr int XB = (Q5_TH + 2) * XROW;
+  static constexpr int XB1 = (Q5_TH + 2) * XROW;        // one input quad
+  static constexpr int XB = NQX * XB1;
   static constexpr int YP = 2 * W + 32;       // bytes per (row, co) line of dY: [16 B zeros][row][16 B zeros]  (2 W + 64, which takes the
                                               // four co lines of a row to distinct bank groups, measured 7 - 10 % SLOWER: 46.1 -> 49.5 us)
-  static constexpr int YB = Q5_TH * 4 * YP;
+  static constexpr int YB1 = Q5_TH * 4 * YP;            // one output quad
+  static constexpr int YB = NQY * YB1;
   static constexpr int SLOT = XB + YB;
-  static constexpr int RING = 4 * SLOT;
+  static constexpr int NSLOT = 2 * PPR;          // the round being read + the round being staged
+  static constexpr int RING = NSLOT * SLOT;
   static constexpr int CONSTB = RING;         // [16 B of ones][16 B of zeros]
   static constexpr int BYTES = RING + 32;
-  static constexpr int NXI = 2 * (Q5_TH + 2) * 4 * PR;   // x items of a round (two planes)
-  static constexpr int NIX = (NXI + 511) / 512;          // per thread: 3 | 2 | 1
-  static constexpr int NYI = 2 * Q5_TH * 4 * PR;         // dY items of a round
+  static constexpr int NXI = PPR * NQX * (Q5_TH + 2) * 4 * PR; // x items of a round (two planes)
+  static constexpr int NIX = (NXI + 511) / 512;          // per thread: 3 | 2 | 1 (one quad)
+  static constexpr int NYI = PPR * NQY * Q5_TH * 4 * PR; // dY items of a round
   static constexpr int NIY = (NYI + 511) / 512;          // 2 | 1 | 1 (rows of 32 voxels: half the threads)
 };
 }
 
-template <int FMT, int NCH, int PD>
+template <int FMT, int NCH, int PD, int NQX = 1, int NQY = 1, int PPR = 2>
 __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned char* smem) {
   typedef h16<FMT> ST;
-  typedef Q5<NCH> Q;
+  typedef Q5<NCH, NQX, NQY, PPR> Q;
+  constexpr int NSLOT = Q::NSLOT;
+  constexpr int NP = NQX * NQY;
   constexpr int W = Q::W, PR = Q::PR, NC = Q::NC, NIX = Q::NIX, NIY = Q::NIY;
   constexpr unsigned ONE2 = FMT == 0 ? 0x3F803F80u : 0x3C003C00u;
   float* s_dw = reinterpret_cast<float*>(smem);        // after the plane loops
@@ -86,20 +97,22 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   const long long planes = (long long)a.tilesH * a.N * D_;
   long long p_lo = planes * w / a.wpu;
   const long long p_hi = planes * (w + 1) / a.wpu;
-  f32x4 acc[3];
+  f32x4 acc[NP][3];                                    // pair (qx, qy) = qx * NQY + qy
 #pragma unroll
-  for (int kd = 0; kd < 3; ++kd) acc[kd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) acc[p][kd] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int D = a.D, H = a.H;
   const long long hw = (long long)H * W, dhw = (long long)D * hw;
-  const int co0 = oq * 4;
+  const int co0 = oq * 4 * NQY;                        // a unit's output quads lie in one group (Cout_g % (4 NQY) == 0)
   const int grp = co0 / a.Cout_g;
-  const int cin_base = grp * a.Cin_g + chunk * 4;
+  const int cin_base = grp * a.Cin_g + chunk * 4 * NQX;
   const float pslope = a.pre ? a.pre_slope : 1.f;
   const f32x2_t ps2 = {pslope, pslope};
 
   // ---- constants of the launch: the zero blocks in front of and behind every dY line, the ones / zeros block ----
-  for (int i = tid; i < 4 * Q5_TH * 4 * 2; i += 512) {
-    const int slot = i / (Q5_TH * 4 * 2), l = (i >> 1) % (Q5_TH * 4);
+  for (int i = tid; i < NSLOT * NQY * Q5_TH * 4 * 2; i += 512) {
+    const int slot = i / (NQY * Q5_TH * 4 * 2), l = (i >> 1) % (NQY * Q5_TH * 4);
     *reinterpret_cast<uint4*>(smem + slot * Q::SLOT + Q::XB + l * Q::YP + ((i & 1) ? 16 + 2 * W : 0)) = make_uint4(0, 0, 0, 0);
   }
   if (tid < 8) *reinterpret_cast<unsigned*>(smem + Q::CONSTB + tid * 4) = tid < 4 ? ONE2 : 0u;
@@ -109,6 +122,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   const int ci_l = nn & 3, khB = nn >> 2;
   const int b_off = khB == 3 ? Q::CONSTB + (ci_l == 0 ? 0 : 16) : (wv + khB) * Q::XROW + ci_l * Q::CP + g * 16;
   const int b_slot = khB == 3 ? 0 : 1;                 // the constant block is not in a plane slot
+  const int b_cstep = b_slot ? 64 : 0, b_qstep = b_slot ? Q::XB1 : 0;
   // A: lane (co = nn >> 2, kw = nn & 3; g) wants dY row wv, channel co, voxels 32 c + 8 g + 1 - kw .. + 7 (kw = 3: an unused
   // accumulator row, as kw = 1): five dwords from the one that holds its first voxel, funnel-shifted by 16 bits unless kw = 1
   const int kwA = (nn & 3) == 3 ? 1 : (nn & 3);
@@ -123,9 +137,10 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     const int it = tid + 512 * k;
     x_do[k] = it < Q::NXI;
     const int itc = x_do[k] ? it : 0;
-    const int j = itc % PR, c = (itc / PR) & 3, r = (itc / (4 * PR)) % (Q5_TH + 2), pp = itc / (4 * PR * (Q5_TH + 2));
-    x_pp[k] = pp; x_r[k] = r; x_c[k] = c;
-    x_lds[k] = pp * Q::SLOT + r * Q::XROW + c * Q::CP + j * 16;
+    const int j = itc % PR, c = (itc / PR) & 3, r = (itc / (4 * PR)) % (Q5_TH + 2);
+    const int qx = (itc / (4 * PR * (Q5_TH + 2))) % NQX, pp = itc / (4 * PR * (Q5_TH + 2) * NQX);
+    x_pp[k] = pp; x_r[k] = r; x_c[k] = qx * 4 + c;     // channel inside the unit
+    x_lds[k] = pp * Q::SLOT + qx * Q::XB1 + r * Q::XROW + c * Q::CP + j * 16;
   }
   int y_lds[NIY], y_pp[NIY];
   bool y_do[NIY];
@@ -134,10 +149,11 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   for (int k = 0; k < NIY; ++k) {
     y_do[k] = tid + 512 * k < Q::NYI;
     const int it = y_do[k] ? tid + 512 * k : 0;
-    const int j = it % PR, co = (it / PR) & 3, r = (it / (4 * PR)) % Q5_TH, pp = it / (4 * PR * Q5_TH);
+    const int j = it % PR, co = (it / PR) & 3, r = (it / (4 * PR)) % Q5_TH;
+    const int qy = (it / (4 * PR * Q5_TH)) % NQY, pp = it / (4 * PR * Q5_TH * NQY);
     y_pp[k] = pp;
-    y_lds[k] = pp * Q::SLOT + Q::XB + (r * 4 + co) * Q::YP + 16 + j * 16;
-    y_goff[k] = (unsigned)((long long)co * dhw + (long long)r * W + 8 * j);
+    y_lds[k] = pp * Q::SLOT + Q::XB + qy * Q::YB1 + (r * 4 + co) * Q::YP + 16 + j * 16;
+    y_goff[k] = (unsigned)((long long)(qy * 4 + co) * dhw + (long long)r * W + 8 * j);
   }
 
   while (p_lo < p_hi) {
@@ -147,9 +163,13 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     const int th = col % a.tilesH, n = col / a.tilesH;
     const int h0 = th * Q5_TH;
     // ---- per-tile part of the x plan ----
-    const ST* xsrc = a.bcast ? (const ST*)a.xa + n * a.xa_bs + (long long)(cin_base >> 2) * dhw      // one stored channel, four transforms
-                     : (cin_base < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)cin_base * dhw
-                                        : (const ST*)a.xb + n * a.xb_bs + (long long)(cin_base - a.Ca) * dhw);
+    // the source of an input quad (Ca % 4 == 0: a quad lies in one of the two sources); one quad per unit: one pointer
+    auto quad_src = [&](int cq) {
+      return a.bcast ? (const ST*)a.xa + n * a.xa_bs + (long long)(cq >> 2) * dhw                     // one stored channel, four transforms
+                     : (cq < a.Ca ? (const ST*)a.xa + n * a.xa_bs + (long long)cq * dhw
+                                  : (const ST*)a.xb + n * a.xb_bs + (long long)(cq - a.Ca) * dhw);
+    };
+    const ST* xsrc[NIX];
     unsigned x_goff[NIX];
     float x_sc[NIX], x_sh[NIX];
 #pragma unroll
@@ -158,7 +178,8 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
       const bool rok = (unsigned)row < (unsigned)H;
       const int it = tid + 512 * k;
       const int j = (x_do[k] ? it : 0) % PR;
-      x_goff[k] = (unsigned)((a.bcast ? 0ll : (long long)x_c[k] * dhw) + (long long)min(max(row, 0), H - 1) * W + 8 * j);
+      xsrc[k] = quad_src(cin_base + (x_c[k] & ~3));
+      x_goff[k] = (unsigned)((a.bcast ? 0ll : (long long)(x_c[k] & 3) * dhw) + (long long)min(max(row, 0), H - 1) * W + 8 * j);
       float sc = 1.f, sh = 0.f;
       if (a.pre) { sc = a.pre_sc[n * a.Cin + cin_base + x_c[k]]; sh = a.pre_sh[n * a.Cin + cin_base + x_c[k]]; }
       x_sc[k] = rok ? sc : 0.f;
@@ -172,15 +193,15 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     // under a branch makes it wait for (nearly) everything at the next use, i.e. one round in flight whatever PD says.
     struct RB { uint4 x[NIX]; uint4 y[NIY]; };
     RB q[PD];
-    const int nround = (d1 - d0 + 2 + 1) / 2;            // x planes d0 - 1 .. d1
+    const int nround = (d1 - d0 + 2 + PPR - 1) / PPR;    // x planes d0 - 1 .. d1
     auto issue = [&](int r, RB& rb) {
-      const int p0 = d0 - 1 + 2 * r;
+      const int p0 = d0 - 1 + PPR * r;
       const bool live = r < nround;
       const unsigned lm = live ? 0xffffffffu : 0u;
 #pragma unroll
       for (int k = 0; k < NIX; ++k) {
         const long long po = live ? (long long)min(max(p0 + x_pp[k], 0), D - 1) * hw : 0ll;
-        rb.x[k] = *reinterpret_cast<const uint4*>(xsrc + po + (x_goff[k] & lm));
+        rb.x[k] = *reinterpret_cast<const uint4*>(xsrc[k] + po + (x_goff[k] & lm));
       }
 #pragma unroll
       for (int k = 0; k < NIY; ++k) {
@@ -188,9 +209,9 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
         rb.y[k] = *reinterpret_cast<const uint4*>(ysrc + po + (y_goff[k] & lm));
       }
     };
-    auto commit = [&](int r, const RB& rb) {             // round r -> slots (2 r) & 3, (2 r + 1) & 3
-      const int p0 = d0 - 1 + 2 * r;
-      unsigned char* dst = smem + ((2 * r) & 3) * Q::SLOT;
+    auto commit = [&](int r, const RB& rb) {             // round r -> slots (2 r) & 3, (2 r + 1) & 3  (PPR = 1: slot r & 1)
+      const int p0 = d0 - 1 + PPR * r;
+      unsigned char* dst = smem + ((PPR * r) & (NSLOT - 1)) * Q::SLOT;
 #pragma unroll
       for (int k = 0; k < NIX; ++k) {
         if (!x_do[k]) continue;
@@ -216,24 +237,35 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
         *reinterpret_cast<uint4*>(dst + y_lds[k]) = make_uint4(rb.y[k].x & am, rb.y[k].y & am, rb.y[k].z & am, rb.y[k].w & am);
       }
     };
-    frag8 af_m1[NC], af_0[NC];
+    frag8 af_m1[NQY][NC], af_0[NQY][NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) af_m1[c] = af_0[c] = frag8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int qy = 0; qy < NQY; ++qy)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) af_m1[qy][c] = af_0[qy][c] = frag8{0, 0, 0, 0, 0, 0, 0, 0};
     auto step = [&](int s) {                             // plane slot s: x plane p, dY plane p + 1
       const unsigned char* src = smem + s * Q::SLOT;
       const unsigned char* bsrc = smem + (b_slot ? s * Q::SLOT : 0) + b_off;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const unsigned* ap = reinterpret_cast<const unsigned*>(src + a_off + c * 64);
-        const unsigned e0 = ap[0], e1 = ap[1], e2 = ap[2], e3 = ap[3], e4 = ap[4];
-        const frag8 af_p1 = __builtin_bit_cast(frag8, make_uint4(__builtin_amdgcn_alignbit(e1, e0, a_sh), __builtin_amdgcn_alignbit(e2, e1, a_sh),
-                                                                 __builtin_amdgcn_alignbit(e3, e2, a_sh), __builtin_amdgcn_alignbit(e4, e3, a_sh)));
-        const frag8 bf = *reinterpret_cast<const frag8*>(bsrc + (b_slot ? c * 64 : 0));
-        acc[0] = mfma16x16x32<FMT>(af_p1, bf, acc[0]);
-        acc[1] = mfma16x16x32<FMT>(af_0[c], bf, acc[1]);
-        acc[2] = mfma16x16x32<FMT>(af_m1[c], bf, acc[2]);
-        af_m1[c] = af_0[c];
-        af_0[c] = af_p1;
+        frag8 bf[NQX];
+#pragma unroll
+        for (int qx = 0; qx < NQX; ++qx) bf[qx] = *reinterpret_cast<const frag8*>(bsrc + c * b_cstep + qx * b_qstep);
+#pragma unroll
+        for (int qy = 0; qy < NQY; ++qy) {
+          const unsigned* ap = reinterpret_cast<const unsigned*>(src + a_off + qy * Q::YB1 + c * 64);
+          const unsigned e0 = ap[0], e1 = ap[1], e2 = ap[2], e3 = ap[3], e4 = ap[4];
+          const frag8 af_p1 = __builtin_bit_cast(frag8, make_uint4(__builtin_amdgcn_alignbit(e1, e0, a_sh), __builtin_amdgcn_alignbit(e2, e1, a_sh),
+                                                                   __builtin_amdgcn_alignbit(e3, e2, a_sh), __builtin_amdgcn_alignbit(e4, e3, a_sh)));
+#pragma unroll
+          for (int qx = 0; qx < NQX; ++qx) {
+            f32x4* ac = acc[qx * NQY + qy];
+            ac[0] = mfma16x16x32<FMT>(af_p1, bf[qx], ac[0]);
+            ac[1] = mfma16x16x32<FMT>(af_0[qy][c], bf[qx], ac[1]);
+            ac[2] = mfma16x16x32<FMT>(af_m1[qy][c], bf[qx], ac[2]);
+          }
+          af_m1[qy][c] = af_0[qy][c];
+          af_0[qy][c] = af_p1;
+        }
       }
     };
     __syncthreads();                                     // the previous tile's planes are no longer read (first tile: constants written)
@@ -247,8 +279,8 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
         const int r = r0 + u;
         if (r < nround) {                                // uniform
           __syncthreads();                               // round r staged; round r - 1 fully read
-          step((2 * r) & 3);
-          step((2 * r + 1) & 3);
+#pragma unroll
+          for (int i = 0; i < PPR; ++i) step((PPR * r + i) & (NSLOT - 1));
         }
         // round r + 1 into the slots of round r - 1 (a dead round is not committed: past the last barrier its target slots may
         // still be read); its buffer then takes round r + 1 + PD
@@ -265,23 +297,24 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   // conv3d_wgrad_mfma.hip.)
   constexpr int NW = 4 * 4 * 27, NSL = NW + 4;
   __syncthreads();
-  {
-    float* my = s_dw + wv * NSL;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    float* my = s_dw + (wv * NP + p) * NSL;
     const int kh = nn >> 2, ci = nn & 3;                // accumulator column; rows 4 g + r = (co = g, kw = r)
     if (kh < 3) {
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) my[(g * 4 + ci) * 27 + kd * 9 + kh * 3 + r] = acc[kd][r];
+        for (int r = 0; r < 3; ++r) my[(g * 4 + ci) * 27 + kd * 9 + kh * 3 + r] = acc[p][kd][r];
     } else if (ci == 0) {
-      my[NW + g] = acc[1][1];                            // column of ones x dY row (co = g, kw = 1)
+      my[NW + g] = acc[p][1][1];                         // column of ones x dY row (co = g, kw = 1)
     }
   }
   __syncthreads();
-  for (int i = tid; i < NSL; i += 512) {                 // slice 0 becomes the sum (each element is read and written by one thread)
+  for (int i = tid; i < NP * NSL; i += 512) {            // wave 0's slices become the sums (each element is read and written by one thread)
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < Q5_TH; ++w) v += s_dw[w * NSL + i];
+    for (int w = 0; w < Q5_TH; ++w) v += s_dw[w * NP * NSL + i];
     s_dw[i] = v;
   }
   __syncthreads();
@@ -289,19 +322,22 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   const int gpp = a.groups / a.n_wptr;
   float* dwp = a.dw[grp / gpp];
   const int gl = grp % gpp;
-  for (int i = tid; i < NW; i += 512) {
-    const int tap = i % 27;
-    const int r = i / 27;
+  for (int i = tid; i < NP * NW; i += 512) {
+    const int p = i / NW, e = i - p * NW;                // pair (qx, qy), element of its 4 x 4 x 27 block
+    const int qx = p / NQY, qy = p - qx * NQY;
+    const int tap = e % 27;
+    const int r = e / 27;
     const int ci = r & 3, c = r >> 2;
-    const int co_g = (co0 + c) % a.Cout_g;
-    if (a.dwm) {                                         // depthwise: dw[C][1][27], the off-diagonal products are not gradients
-      if (ci == c) atomicAdd(dwp + (long long)(gl * 4 + c) * 27 + tap, s_dw[i]);
+    const int co_g = (co0 + 4 * qy + c) % a.Cout_g;
+    const float v = s_dw[p * NSL + e];
+    if (a.dwm) {                                         // depthwise: dw[C][1][27], the off-diagonal products are not gradients (one quad per unit)
+      if (ci == c) atomicAdd(dwp + (long long)(gl * 4 + c) * 27 + tap, v);
       continue;
     }
-    atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + chunk * 4 + ci) * 27 + tap, s_dw[i]);
+    atomicAdd(dwp + ((long long)(gl * a.Cout_g + co_g) * a.Cin_g + (chunk * NQX + qx) * 4 + ci) * 27 + tap, v);
   }
-  float* dbp = a.db[grp / gpp];
-  if (dbp && chunk == 0 && tid < 4) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[NW + tid]);
+  float* dbp = a.db[grp / gpp];                          // bias gradient: the pairs of the first input quad of the group
+  if (dbp && chunk == 0 && tid < 4 * NQY) atomicAdd(&dbp[gl * a.Cout_g + (co0 + tid) % a.Cout_g], s_dw[(tid >> 2) * NSL + NW + (tid & 3)]);
 }
 
 // Q5_PD = rounds of loads in flight per thread.  The first version had ONE (128 registers, two workgroups per CU): a round then
@@ -320,15 +356,23 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_q5_multi_kernel(const WgQ5
   const int local = b - m.off[i];
   const WgQ4& a = m.p[i];
   if (local >= a.nb) return;
-  if (a.W == 128) wgrad_q5_body<FMT, 4, Q5_PD>(a, local, smem);
-  else if (a.W == 64) wgrad_q5_body<FMT, 2, Q5_PD>(a, local, smem);
-  else wgrad_q5_body<FMT, 1, Q5_PD>(a, local, smem);
+  if (a.W == 128) {
+    if (a.uqx == 3) wgrad_q5_body<FMT, 4, Q5_PD, 3, 1, 1>(a, local, smem);
+    else wgrad_q5_body<FMT, 4, Q5_PD>(a, local, smem);
+  } else if (a.W == 64) {
+    if (a.uqx == 2 && a.uqy == 2) wgrad_q5_body<FMT, 2, Q5_PD, 2, 2>(a, local, smem);
+    else if (a.uqy == 2) wgrad_q5_body<FMT, 2, Q5_PD, 1, 2>(a, local, smem);
+    else if (a.uqx == 2) wgrad_q5_body<FMT, 2, Q5_PD, 2, 1>(a, local, smem);
+    else wgrad_q5_body<FMT, 2, Q5_PD>(a, local, smem);
+  } else wgrad_q5_body<FMT, 1, Q5_PD>(a, local, smem);
 }
 
 // Re-plans a quad-channel problem (xh_wgrad_q4_plan has filled `a`) for the full-row kernel; false: it stays with the tile kernel
 int g_q5_on = 1;                                         // xh_set_option(21, 0 / 1)
 int g_q5_w32 = 0;                                        // xh_set_option(23, 0 / 1): rows of 32 voxels take the full-row kernel too
 int g_q5_wgs = 256;                                      // xh_set_option(22, n): workgroups per launch (one per CU is resident)
+int g_q5_uq = 7;                                         // xh_set_option(28, bits): rows of 64 voxels, bit 0: two input quads per unit, bit 1: two output quads;
+                                                         // bit 2: rows of 128 voxels, three input quads per unit (one plane per round)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
   extern int g_q5_w32;
@@ -340,12 +384,90 @@ bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   if (4 * dhw >= (1ll << 31)) return false;              // 32-bit element offsets inside a channel quad
   a->full = 1;
   a->ci4 = 1;
-  a->nchunk = a->Cin_g / 4;
-  a->nq = (d->Cout / 4) * a->nchunk;
+  // rows of 64 voxels: a unit stages two input and / or two output quads of a group once and multiplies every pair (the LDS ring of
+  // two quads of each operand is 88 KB there; at 128 voxels a second input quad alone takes it to 125 KB and ~250 registers).
+  // One quad per unit re-stages dY once per input quad and x once per output quad: 24 -> 8 moved 108 channel-volumes for 32.
+  a->uqx = a->uqy = 1;
+  { static bool env_done = false; if (!env_done) { env_done = true; const char* e = getenv("XH_Q5_UQ"); if (e) g_q5_uq = atoi(e) & 7; } }
+  if (d->W == 64 && !a->dwm && !d->bcast && 8 * dhw < (1ll << 31)) {
+    if ((g_q5_uq & 1) && (a->Cin_g / 4) % 2 == 0) a->uqx = 2;
+    if ((g_q5_uq & 2) && (a->Cout_g / 4) % 2 == 0) a->uqy = 2;
+  }
+  // rows of 128 voxels, groups of 3 k input quads (12 -> 4: the recon | seg decoders' first convs at 128^3): three quads against ONE
+  // staging of dY -- 42 KB per plane slot, so a round is one plane and the ring two slots (84 KB)
+  if (d->W == 128 && !a->dwm && !d->bcast && (g_q5_uq & 4) && (a->Cin_g / 4) % 3 == 0 && 12 * dhw < (1ll << 31)) a->uqx = 3;
+  a->nchunk = a->Cin_g / (4 * a->uqx);
+  a->nq = (d->Cout / (4 * a->uqy)) * a->nchunk;
   a->wide = 0;
   a->tilesW = 1;
   a->tilesH = d->H / Q5_TH;
   return true;                                           // dsegs / sd / ntile / wpu / nb: per launch (xh_wgrad_q5_launch)
+}
+
+// Cost of ONE unit of a problem in rounds of a single-quad unit on rows of 128 voxels (a round = 8 rows x 2 planes; its cost is mostly
+// instruction issue and grows slowly with the row width: measured ~3 / ~2 us at 128 / 64 voxels; units of several quads stage
+// (uqx + uqy) / 2 x the bytes and run uqx uqy x the matrix work: factors fitted to the step's batch, tools/scan_q5_step.sh)
+static double q5_ucost(const WgQ4& w) {
+  static double f64 = -1.0, f2, f4, f3;
+  if (f64 < 0) {                                         // (measurement overrides)
+    const char* e;
+    f2 = (e = getenv("XH_Q5_F2")) ? atof(e) : 1.45; f4 = (e = getenv("XH_Q5_F4")) ? atof(e) : 1.9; f3 = (e = getenv("XH_Q5_F3")) ? atof(e) : 2.4;
+    f64 = (e = getenv("XH_Q5_F64")) ? atof(e) : 0.7;
+  }
+  const int pairs = w.uqx * w.uqy;
+  return (double)w.N * w.D * (w.H / Q5_TH) * (w.W == 128 ? (w.uqx == 3 ? f3 : 1.0) : w.W == 64 ? f64 * (pairs == 1 ? 1.0 : pairs == 2 ? f2 : f4) : 0.55);
+}
+
+// Workgroups per unit of the problems of ONE launch: every workgroup of a unit walks an equal run of the unit's planes and all of a
+// launch's workgroups are resident together (one per CU), so the launch lasts as long as its slowest workgroup: the plan is the
+// smallest T with  sum_i nq_i ceil(cost_i / T) <= budget  (min-max; never more than `budget` workgroups unless one per unit
+// already is -- a 257th workgroup would wait for a CU and double the launch).  Until round 6 this was "integer part of the
+// proportional share, then largest remainders": units of 3.3 shares got 3 workgroups and ran 10 % longer than the rest.
+// Returns the planned duration max_i cost_i / wq_i (xh_conv3d_wgrad_batch balances its launches with it).
+double xh_wgrad_q5_plan(const WgQ4* probs, int n, int budget, int* wq) {
+  double c[Q5_MULTI], total = 0.0, hi = 0.0;
+  int cap[Q5_MULTI];
+  for (int i = 0; i < n; ++i) {
+    c[i] = q5_ucost(probs[i]);
+    const long long planes = (long long)probs[i].tilesH * probs[i].N * probs[i].D;
+    cap[i] = (int)(planes / 4 > 0 ? planes / 4 : 1);     // runs of at least 4 planes
+    total += probs[i].nq * c[i];
+    hi = c[i] > hi ? c[i] : hi;
+  }
+  auto need = [&](double T, int* out) {
+    int used = 0;
+    for (int i = 0; i < n; ++i) {
+      int k = (int)ceil(c[i] / T - 1e-9);
+      k = k < 1 ? 1 : k > cap[i] ? cap[i] : k;
+      out[i] = k;
+      used += probs[i].nq * k;
+    }
+    return used;
+  };
+  double lo = total / budget * 0.999;                    // below the smallest conceivable T
+  int tmp[Q5_MULTI];
+  if (need(hi, wq) > budget) {                           // more units than workgroups: one each
+    double T = 0.0;
+    for (int i = 0; i < n; ++i) T = c[i] > T ? c[i] : T;
+    return T;
+  }
+  for (int it = 0; it < 40; ++it) {                      // need() falls with T: bisect to the smallest feasible T
+    const double mid = 0.5 * (lo + hi);
+    if (need(mid, tmp) <= budget) hi = mid; else lo = mid;
+  }
+  int used = need(hi, wq);
+  // workgroups left over (they cannot lower the maximum): to the units that are slowest now, while whole units fit
+  for (;;) {
+    int best = -1;
+    for (int i = 0; i < n; ++i)
+      if (used + probs[i].nq <= budget && wq[i] + 1 <= cap[i] && (best < 0 || c[i] / wq[i] > c[best] / wq[best])) best = i;
+    if (best < 0) break;
+    ++wq[best];
+    used += probs[best].nq;
+  }
+  double T = 0.0;
+  for (int i = 0; i < n; ++i) T = c[i] / wq[i] > T ? c[i] / wq[i] : T;
+  return T;
 }
 
 // launches up to Q5_MULTI re-planned problems of one storage format
@@ -355,52 +477,31 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   m.off[0] = 0;
   extern int g_q5_wgs;
   const int budget = g_q5_wgs;                           // resident workgroups: 1 per CU
-  // workgroups per unit in proportion to the unit's ROUNDS (a round = 8 rows x 2 planes; its cost is mostly instruction issue and
-  // grows slowly with the row width: measured ~3 / ~2 us at 128 / 64 voxels), then depth segments so that every workgroup of the
-  // unit has a tile
-  auto ucost = [](const WgQ4& w) { return (double)w.N * w.D * (w.H / Q5_TH) * (w.W == 128 ? 1.0 : w.W == 64 ? 0.7 : 0.55); };
-  double total = 0.0;
-  for (int i = 0; i < n; ++i) total += probs[i].nq * ucost(probs[i]);
-  // whole workgroups per unit: the integer part of the unit's share, then the workgroups left over go, one unit (= nq workgroups) at a
-  // time, to the problems with the largest remainder -- never more than `budget` in all (a 257th workgroup would wait for a CU and
-  // double the launch)
-  int wq[Q5_MULTI], used = 0;
-  double frac[Q5_MULTI];
-  for (int i = 0; i < n; ++i) {
-    const double r = budget * ucost(probs[i]) / total;
-    wq[i] = (int)r < 1 ? 1 : (int)r;
-    const long long planes = (long long)probs[i].tilesH * probs[i].N * probs[i].D;
-    if (wq[i] > planes / 4) wq[i] = (int)(planes / 4 > 0 ? planes / 4 : 1);   // runs of at least 4 planes
-    frac[i] = r - wq[i];
-    used += probs[i].nq * wq[i];
-  }
-  for (;;) {
-    int best = -1;
-    for (int i = 0; i < n; ++i) {
-      const long long planes = (long long)probs[i].tilesH * probs[i].N * probs[i].D;
-      if (used + probs[i].nq <= budget && wq[i] + 1 <= planes / 4 && (best < 0 || frac[i] > frac[best])) best = i;
-    }
-    if (best < 0) break;
-    ++wq[best];
-    frac[best] -= 1.0;
-    used += probs[best].nq;
-  }
+  int wq[Q5_MULTI];
+  (void)xh_wgrad_q5_plan(probs, n, budget, wq);
   for (int i = 0; i < n; ++i) {
     m.p[i] = probs[i];
     WgQ4& a = m.p[i];
     a.sd = a.D; a.dsegs = 1; a.ntile = a.tilesH * a.N;             // (informational: the kernel cuts the plane sequence itself)
     a.wpu = wq[i];
     a.nb = a.nq * wq[i];
+    if (getenv("XH_Q5_DUMP")) fprintf(stderr, "q5 plan %d: %d->%d g%d W%d uq %dx%d nq %d wpu %d\n", i, a.Cin, a.Cout, a.groups, a.W, a.uqx, a.uqy, a.nq, a.wpu);
     m.off[i + 1] = m.off[i] + a.nb;
   }
   static bool attr_done[XH_MAX_DEV] = {};
   if (xh_attr_needed(attr_done)) {
-    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<4>::BYTES);
-    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Q5<4>::BYTES);
+    constexpr int m0 = Q5<2, 2, 2>::BYTES > Q5<4>::BYTES ? Q5<2, 2, 2>::BYTES : Q5<4>::BYTES;
+    constexpr int mx = Q5<4, 3, 1, 1>::BYTES > m0 ? Q5<4, 3, 1, 1>::BYTES : m0;
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   }
-  int wmax = 32;
-  for (int i = 0; i < n; ++i) wmax = probs[i].W > wmax ? probs[i].W : wmax;
-  const size_t shm = wmax == 128 ? Q5<4>::BYTES : wmax == 64 ? Q5<2>::BYTES : Q5<1>::BYTES;
+  size_t shm = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgQ4& w = probs[i];
+    const size_t need = w.W == 128 ? (w.uqx == 3 ? Q5<4, 3, 1, 1>::BYTES : Q5<4>::BYTES) : w.W == 32 ? Q5<1>::BYTES
+                        : w.uqx == 2 && w.uqy == 2 ? Q5<2, 2, 2>::BYTES : w.uqy == 2 ? Q5<2, 1, 2>::BYTES : w.uqx == 2 ? Q5<2, 2, 1>::BYTES : Q5<2>::BYTES;
+    shm = need > shm ? need : shm;
+  }
   xh_note_kernel("conv3_wgrad_q5_multi_kernel<%d>", fmt);
   if (fmt) hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<1>), dim3(m.off[n]), dim3(512), shm, st, m);
   else hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<0>), dim3(m.off[n]), dim3(512), shm, st, m);

@@ -21,7 +21,8 @@ struct WgQ4 {
   int dwm;                       // depthwise problem run as groups of 4: only the diagonal of a 4 x 4 block is a gradient
   int wide;                      // tile shape: 0 = 4 rows x 32 voxels, 1 = 2 rows x 64 voxels (rows of 64 / 128 voxels: full-line loads)
   int bcast;                     // xh_conv_desc.bcast: the group's four input channels are one stored channel of xa (full-row kernel only)
-  int full;                      // 1: planned for the full-row kernel (conv3d_wgrad_q5.hip: 8 rows x W tiles, one input quad per unit)
+  int full;                      // 1: planned for the full-row kernel (conv3d_wgrad_q5.hip: 8 rows x W tiles)
+  int uqx, uqy;                  // full-row kernel: input / output channel quads a unit stages (1 | 2; 2 on rows of 64 voxels only)
 };
 
 constexpr int WQ_MULTI = 8;         // problems per launch (the table travels in the kernel arguments)
@@ -32,3 +33,5 @@ void xh_wgrad_q4_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);
 // Q5_MULTI such problems of one storage format (xh_wgrad_q4_launch forwards to it)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a);
 void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n);
+// min-max workgroup plan of one full-row launch (wq[i] workgroups per unit of problem i); returns its planned duration in unit rounds
+double xh_wgrad_q5_plan(const WgQ4* probs, int n, int budget, int* wq);
