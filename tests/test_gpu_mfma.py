@@ -917,7 +917,7 @@ def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
         res = {}
         for name, on in (("full", 1), ("tile", 0)):
             lib.xh_set_option(21, on)
-            lib.xh_set_option(23, 1)                   # rows of 32 voxels too (off by default: see conv3d_wgrad_q5.hip)
+            lib.xh_set_option(23, 1)                   # rows of 32 voxels too (the default since round 6: see conv3d_wgrad_q5.hip)
             try:
                 dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
                 dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
@@ -928,7 +928,6 @@ def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
                 res[name] = (torch.cat(dws, 0).cpu(), torch.cat(dbs, 0).cpu())
             finally:
                 lib.xh_set_option(21, 1)
-                lib.xh_set_option(23, 0)
         xf = x.float()
         if pre is not None:
             xf = torch.nn.functional.leaky_relu(xf * pre[0][:, :, None, None, None] + pre[1][:, :, None, None, None], 0.01).to(dtype).float()
@@ -940,10 +939,12 @@ def test_wgrad_full_row_kernel_vs_tile_kernel_and_stock(cfg, dtype):
 
 
 @pytest.mark.parametrize("cfg", [(24, 8, 1, (12, 16, 64), 16), (16, 16, 2, (9, 8, 64), None), (20, 40, 5, (6, 8, 64), None), (8, 4, 1, (8, 24, 64), None),
-                                 (12, 4, 1, (11, 16, 128), 4), (24, 8, 2, (5, 8, 128), None), (24, 4, 1, (4, 8, 128), 8)],
-                         ids=["24to8", "16to16g2", "20to40g5", "8to4", "12to4_w128_three_input_quads", "24to8g2_w128", "24to4_w128_two_chunks_of_three"])
+                                 (12, 4, 1, (11, 16, 128), 4), (24, 8, 2, (5, 8, 128), None), (24, 4, 1, (4, 8, 128), 8),
+                                 (48, 16, 1, (9, 16, 32), 32), (40, 80, 5, (6, 8, 32), None)],
+                         ids=["24to8", "16to16g2", "20to40g5", "8to4", "12to4_w128_three_input_quads", "24to8g2_w128", "24to4_w128_two_chunks_of_three",
+                              "48to16_w32", "40to80g5_w32"])
 def test_wgrad_full_row_units_of_two_quads_equal_single_quad_units(cfg):
-    """Rows of 64 voxels (round 6): a unit of conv3_wgrad_q5_multi_kernel stages two input and / or two output quads once and multiplies
+    """Rows of 64 and of 32 voxels (round 6): a unit of conv3_wgrad_q5_multi_kernel stages two input and / or two output quads once and multiplies
     every pair (xh_set_option(28, ...) bits 0 and 1) instead of one quad of each per unit (28, 0: dY re-staged per input quad, x per
     output quad); rows of 128 voxels: three input quads against one staging of dY, rounds of one plane (bit 2).  Same products, same
     order inside a pair: the plans agree to the order of the fp32 atomics."""

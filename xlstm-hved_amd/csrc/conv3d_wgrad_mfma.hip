@@ -456,7 +456,7 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
       const int L = ((int)cl.size() + per - 1) / per;
       auto cost = [](const WgQ4& w) {                   // (full-row units of several quads: as xh_wgrad_q5_launch prices them)
         const double uf = !w.full || w.uqx * w.uqy == 1 ? 1.0 : w.uqx * w.uqy == 2 ? 1.45 : w.uqx == 3 ? 2.0 : 1.9;
-        return (double)w.N * w.D * w.H * (w.full ? (w.W == 128 ? 128.0 * uf : w.W == 64 ? 90.0 * uf : 70.0) : (double)w.W) * w.nq * w.ci4;
+        return (double)w.N * w.D * w.H * (w.full ? (w.W == 128 ? 128.0 * uf : w.W == 64 ? 90.0 * uf : 70.0 * uf) : (double)w.W) * w.nq * w.ci4;
       };
       std::vector<int> order(cl.size());
       for (size_t i = 0; i < cl.size(); ++i) order[i] = (int)i;

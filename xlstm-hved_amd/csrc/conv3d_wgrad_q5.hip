@@ -68,7 +68,8 @@ template <int NCH, int NQX = 1, int NQY = 1, int PPR = 2> struct Q5 {
   static constexpr int NSLOT = 2 * PPR;          // the round being read + the round being staged
   static constexpr int RING = NSLOT * SLOT;
   static constexpr int CONSTB = RING;         // [16 B of ones][16 B of zeros]
-  static constexpr int BYTES = RING + 32;
+  static constexpr int TAIL = Q5_TH * NQX * NQY * (4 * 4 * 27 + 4) * 4;   // the per-wave slices of partial sums after the plane loops
+  static constexpr int BYTES = RING + 32 > TAIL ? RING + 32 : TAIL;      // (two quads of each operand on rows of 32 voxels: the tail is larger)
   static constexpr int NXI = PPR * NQX * (Q5_TH + 2) * 4 * PR; // x items of a round (two planes)
   static constexpr int NIX = (NXI + 511) / 512;          // per thread: 3 | 2 | 1 (one quad)
   static constexpr int NYI = PPR * NQY * Q5_TH * 4 * PR; // dY items of a round
@@ -296,6 +297,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
   // per workgroup, ~13 us at the end of every workgroup of a 115 us launch; found on the MFMA weight gradient of the deep levels,
   // conv3d_wgrad_mfma.hip.)
   constexpr int NW = 4 * 4 * 27, NSL = NW + 4;
+  static_assert(Q5_TH * NP * NSL * 4 <= Q::BYTES, "the tail's slices fit the launch's LDS");
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
@@ -364,16 +366,25 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_q5_multi_kernel(const WgQ5
     else if (a.uqy == 2) wgrad_q5_body<FMT, 2, Q5_PD, 1, 2>(a, local, smem);
     else if (a.uqx == 2) wgrad_q5_body<FMT, 2, Q5_PD, 2, 1>(a, local, smem);
     else wgrad_q5_body<FMT, 2, Q5_PD>(a, local, smem);
-  } else wgrad_q5_body<FMT, 1, Q5_PD>(a, local, smem);
+  } else {
+    if (a.uqx == 2 && a.uqy == 2) wgrad_q5_body<FMT, 1, Q5_PD, 2, 2>(a, local, smem);
+    else if (a.uqy == 2) wgrad_q5_body<FMT, 1, Q5_PD, 1, 2>(a, local, smem);
+    else if (a.uqx == 2) wgrad_q5_body<FMT, 1, Q5_PD, 2, 1>(a, local, smem);
+    else wgrad_q5_body<FMT, 1, Q5_PD>(a, local, smem);
+  }
 }
 
 // Re-plans a quad-channel problem (xh_wgrad_q4_plan has filled `a`) for the full-row kernel; false: it stays with the tile kernel
 int g_q5_on = 1;                                         // xh_set_option(21, 0 / 1)
-int g_q5_w32 = 0;                                        // xh_set_option(23, 0 / 1): rows of 32 voxels take the full-row kernel too
+int g_q5_w32 = 1;                                        // xh_set_option(23, 0 / 1): rows of 32 voxels take the full-row kernel too (default since
+                                                         // units hold two quads of each operand: round 6)
 int g_q5_wgs = 256;                                      // xh_set_option(22, n): workgroups per launch (one per CU is resident)
 int g_q5_uq = 7;                                         // xh_set_option(28, bits): rows of 64 voxels, bit 0: two input quads per unit, bit 1: two output quads;
                                                          // bit 2: rows of 128 voxels, three input quads per unit (one plane per round)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
+  { static bool env_done = false;                        // (measurement overrides of the option defaults)
+    if (!env_done) { env_done = true; const char* e = getenv("XH_Q5_UQ"); if (e) g_q5_uq = atoi(e) & 7;
+      e = getenv("XH_Q5_W32"); if (e) g_q5_w32 = atoi(e) ? 1 : 0; } }
   if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
   extern int g_q5_w32;
   // rows of 32 voxels (xh_set_option(23, 1)): the instance exists and is tested, but the 32^3 problems of the network are dozens of
@@ -388,8 +399,7 @@ bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   // two quads of each operand is 88 KB there; at 128 voxels a second input quad alone takes it to 125 KB and ~250 registers).
   // One quad per unit re-stages dY once per input quad and x once per output quad: 24 -> 8 moved 108 channel-volumes for 32.
   a->uqx = a->uqy = 1;
-  { static bool env_done = false; if (!env_done) { env_done = true; const char* e = getenv("XH_Q5_UQ"); if (e) g_q5_uq = atoi(e) & 7; } }
-  if (d->W == 64 && !a->dwm && !d->bcast && 8 * dhw < (1ll << 31)) {
+  if ((d->W == 64 || d->W == 32) && !a->dwm && !d->bcast && 8 * dhw < (1ll << 31)) {
     if ((g_q5_uq & 1) && (a->Cin_g / 4) % 2 == 0) a->uqx = 2;
     if ((g_q5_uq & 2) && (a->Cout_g / 4) % 2 == 0) a->uqy = 2;
   }
@@ -408,14 +418,15 @@ bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
 // instruction issue and grows slowly with the row width: measured ~3 / ~2 us at 128 / 64 voxels; units of several quads stage
 // (uqx + uqy) / 2 x the bytes and run uqx uqy x the matrix work: factors fitted to the step's batch, tools/scan_q5_step.sh)
 static double q5_ucost(const WgQ4& w) {
-  static double f64 = -1.0, f2, f4, f3;
+  static double f64 = -1.0, f2, f4, f3, f32;
   if (f64 < 0) {                                         // (measurement overrides)
     const char* e;
     f2 = (e = getenv("XH_Q5_F2")) ? atof(e) : 1.45; f4 = (e = getenv("XH_Q5_F4")) ? atof(e) : 1.9; f3 = (e = getenv("XH_Q5_F3")) ? atof(e) : 2.4;
+    f32 = (e = getenv("XH_Q5_F32")) ? atof(e) : 0.55;
     f64 = (e = getenv("XH_Q5_F64")) ? atof(e) : 0.7;
   }
   const int pairs = w.uqx * w.uqy;
-  return (double)w.N * w.D * (w.H / Q5_TH) * (w.W == 128 ? (w.uqx == 3 ? f3 : 1.0) : w.W == 64 ? f64 * (pairs == 1 ? 1.0 : pairs == 2 ? f2 : f4) : 0.55);
+  return (double)w.N * w.D * (w.H / Q5_TH) * (w.W == 128 ? (w.uqx == 3 ? f3 : 1.0) : (w.W == 64 ? f64 : f32) * (pairs == 1 ? 1.0 : pairs == 2 ? f2 : f4));
 }
 
 // Workgroups per unit of the problems of ONE launch: every workgroup of a unit walks an equal run of the unit's planes and all of a
@@ -498,7 +509,8 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
   size_t shm = 0;
   for (int i = 0; i < n; ++i) {
     const WgQ4& w = probs[i];
-    const size_t need = w.W == 128 ? (w.uqx == 3 ? Q5<4, 3, 1, 1>::BYTES : Q5<4>::BYTES) : w.W == 32 ? Q5<1>::BYTES
+    const size_t need = w.W == 128 ? (w.uqx == 3 ? Q5<4, 3, 1, 1>::BYTES : Q5<4>::BYTES)
+                        : w.W == 32 ? (w.uqx == 2 && w.uqy == 2 ? Q5<1, 2, 2>::BYTES : w.uqy == 2 ? Q5<1, 1, 2>::BYTES : w.uqx == 2 ? Q5<1, 2, 1>::BYTES : Q5<1>::BYTES)
                         : w.uqx == 2 && w.uqy == 2 ? Q5<2, 2, 2>::BYTES : w.uqy == 2 ? Q5<2, 1, 2>::BYTES : w.uqx == 2 ? Q5<2, 2, 1>::BYTES : Q5<2>::BYTES;
     shm = need > shm ? need : shm;
   }
