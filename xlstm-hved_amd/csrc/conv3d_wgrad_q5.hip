@@ -26,10 +26,16 @@
 //     outside the volume become zero when staged: the plane step has no masks;
 //   * 4-slot LDS ring of planes (slot p & 3 holds x plane p and dY plane p + 1), rounds of two planes, ONE barrier per round;
 //     the loads of round r + 1 are in flight during the matrix phase of round r;
-//   * one input-channel quad per unit (12 -> 4 is three units that each re-stage the dY rows: cheaper than the 38 KB plane slots of
-//     three quads, which would leave one workgroup per CU);
-//   * persistent workgroups (2 per CU), accumulators kept across a workgroup's tiles, ONE LDS reduction + pass of fp32 atomics.
-// Step of a wave and chunk: 5 ds_read_b32 + 4 v_alignbit (A), 1 ds_read_b128 (B), 3 MFMAs.
+//   * a UNIT = (NQX input quads, NQY output quads) of one group staged once, every pair multiplied (round 6).  Rows of 128 voxels:
+//     one quad of each (20 KB per plane slot) -- except groups of 3 k input quads (12 -> 4: the first decoder convs), three input quads
+//     against ONE staging of dY on rounds of one plane and a two-slot ring (84 KB).  Rows of 64 / 32 voxels: up to two quads of each
+//     operand (88 / 51 KB): 24 -> 8 at 64^3 was 12 single-quad units that moved 108 channel-volumes for 32 algorithmic, now 3 units
+//     and 54.  A / B fragment reads per MFMA fall with it (2 + 2 reads for 12 MFMAs instead of 4 + 4);
+//   * persistent workgroups (1 per CU: 239 registers), accumulators kept across a workgroup's tiles, ONE LDS reduction + pass of fp32
+//     atomics;
+//   * launch plan: all workgroups of a launch are resident together, so a launch lasts as long as its slowest workgroup -- workgroups
+//     per unit by the min-max rule (xh_wgrad_q5_plan), problems dealt to launches by planned duration (xh_conv3d_wgrad_batch).
+// Step of a wave and chunk (one quad of each): 5 ds_read_b32 + 4 v_alignbit (A), 1 ds_read_b128 (B), 3 MFMAs.
 #include "common.h"
 #include "../../include/xlstm_hved.h"
 #include "wgrad_q4.h"
@@ -387,9 +393,10 @@ bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
       e = getenv("XH_Q5_W32"); if (e) g_q5_w32 = atoi(e) ? 1 : 0; } }
   if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
   extern int g_q5_w32;
-  // rows of 32 voxels (xh_set_option(23, 1)): the instance exists and is tested, but the 32^3 problems of the network are dozens of
-  // units of a few tiles each -- one workgroup per unit and CU leaves most of the launch waiting for them (batch of the step's 24
-  // problems: 433 us with them here, 392 us all on the tile kernel) -- so by default they stay with the tile kernel
+  // rows of 32 voxels (xh_set_option(23, 0) sends them back to the tile kernel): with one quad of each operand per unit the 32^3
+  // problems of the network were ~200 units of a few tiles each and the launch waited for them (batch of the step's 24 problems: 433 us
+  // with them here, 392 us all on the tile kernel); as units of two quads of each operand they are 59 units and ride in the two
+  // full-row launches (+10 us each) instead of three tile-kernel launches (55 us)
   if ((d->W != 128 && d->W != 64 && !(d->W == 32 && g_q5_w32)) || d->H % Q5_TH || d->D < 4) return false;
   const long long dhw = (long long)d->D * d->H * d->W;
   if (4 * dhw >= (1ll << 31)) return false;              // 32-bit element offsets inside a channel quad
