@@ -58,13 +58,14 @@ int xh_abi_version(void);
  *         bit 0 = 64 voxels (default 3); 0 = always the 32-wide tiles of csrc/conv3d_q4.hip (A/B switch; the outputs are
  *         bit-identical).
  * key 21: 0 = no full-row weight-gradient kernel (csrc/conv3d_wgrad_q5.hip; the 32-wide tile kernel instead).  key 22: its
- *         workgroup budget per launch (default 256 = one per CU).  key 23: 1 = rows of 32 voxels too (measured slower).
+ *         workgroup budget per launch (default 256 = one per CU).  key 23: 0 = rows of 32 voxels stay with the tile kernel (default 1 since round 6).
  * key 24: input-stationary 7^3 gate-conv kernel (csrc/conv7_mfma.hip): 0 never, 1 volumes >= 2^20 voxels (default), 2 B fragments in
  *         registers, 3 every volume.  key 25: REMOVED in round 6 (xh_conv_desc.arith bit XH_ARITH_K7_VECTOR).
  * key 26: groups of 8 class workgroups per launch of the discriminator's source-block weight gradient (default 32 = 256 workgroups).
  * key 27: workgroup target of the row-streaming norm / element-wise kernels (default 2048).
  * key 28: full-row weight-gradient kernel on rows of 64 voxels: bit 0 = a unit stages two input quads, bit 1 = two output quads
- *         bit 2 = rows of 128 voxels: three input quads against one staging of dY (default 7; 0 = one quad of each per unit).
+ *         bit 2 = rows of 128 voxels: three input quads against one staging of dY; bit 3 = fp32 storage with fp16 operands takes the
+ *         full-row kernel too (measured slower: off).  Default 7; 0 = one quad of each per unit.
  * key 14: discriminator conv A/B mask (csrc/dconv.hip): bit 0 one launch per parity class, bit 1 no 256x64 tiles, bit 2 no
  *         small tiles, bit 3 64x128 instead of 64x64, bit 4 no tap pairs in the 64-channel weight gradient, bit 5 / 7 register
  *         prefetch of 4 / 2 K steps on the 256x16 tile, bit 6 no XCD remap, bit 8 no 256x128 tiles, bit 10 / 11 generic kernel instead of the LDS-halo

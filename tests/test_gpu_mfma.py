@@ -617,7 +617,7 @@ def test_fp32_storage_through_split_fp16_matrix_cores_vs_fp32_vector_kernels(cfg
     product, fp32 accumulation) against the fp32 FMA kernels on the same inputs: SingleConv 'ilc' forward with its fused
     InstanceNorm + LeakyReLU and output moments, and the data gradient with the norm-backward epilogue.  ~22 significand bits per
     product: relative L2 at the 1e-6 level (fp32 round-off is 6e-8; fp16 operands alone would read 3e-4).  The weight / bias
-    gradients of the mode come from conv3_wgrad_q4_multi_kernel<2, ...>: fp32 loads, operands rounded ONCE to fp16, fp32
+    gradients of the mode come from conv3_wgrad_q4_multi_kernel<2, ...> / conv3_wgrad_q5_multi_kernel<2>: fp32 loads, operands rounded ONCE to fp16, fp32
     accumulation -- a sum over every voxel of independently rounded products, so the 3e-4 per-product error averages down."""
     from xlstm_hved_amd import functional as Fn
     torch.manual_seed(19)
@@ -652,7 +652,7 @@ def test_fp32_storage_through_split_fp16_matrix_cores_vs_fp32_vector_kernels(cfg
     y1, s1, dx1, dw1, kern = run(True)
     e = dict(y=l2_err(y1, y0), dx=l2_err(dx1, dx0), st=l2_err(s1, s0), dw=max(l2_err(a_, b_) for a_, b_ in zip(dw1, dw0)))
     print(cfg, {k: f"{v:.2e}" for k, v in e.items()}, kern)
-    assert "wgrad_q4_multi_kernel<2" in kern, kern
+    assert "wgrad_q4_multi_kernel<2" in kern or "wgrad_q5_multi_kernel<2" in kern, kern   # (full-row kernel: H % 8 == 0 shapes, round 6)
     assert e["y"] < 3e-6 and e["dx"] < 6e-6 and e["st"] < 1e-6 and e["dw"] < 4e-4, e
 
 
@@ -970,6 +970,44 @@ def test_wgrad_full_row_units_of_two_quads_equal_single_quad_units(cfg):
             lib.xh_set_option(28, 7)
     for uq in (7, 1, 2, 4):
         assert l2_err(res[uq][0], res[0][0]) < 2e-6 and l2_err(res[uq][1], res[0][1]) < 2e-6, (uq, l2_err(res[uq][0], res[0][0]))
+
+
+@pytest.mark.parametrize("cfg", [(12, 4, 1, (9, 16, 128), 4), (16, 16, 4, (6, 8, 128), None), (24, 8, 1, (7, 16, 64), 16), (20, 40, 5, (5, 8, 64), None),
+                                 (48, 16, 1, (8, 16, 32), 32), (8, 8, 8, (10, 8, 64), None)],
+                         ids=["12to4_w128", "16to16g4_w128", "24to8_w64", "20to40g5_w64", "48to16_w32", "depthwise8_w64"])
+def test_wgrad_full_row_kernel_fp32_storage_equals_the_tile_kernel(cfg):
+    """fp32 storage on the matrix cores (xh_conv_desc.arith XH_ARITH_F32_SPLIT): conv3_wgrad_q5_multi_kernel<2> (round 6: fp32 loads,
+    operands rounded once to fp16 while staging, two rounds of loads in flight; OPT-IN, xh_set_option(28) bit 3 -- measured slower in
+    the fp32_mfma step than the tile kernel, 695 against 592 us) against conv3_wgrad_q4_multi_kernel<2, ...> -- the same roundings
+    and products, another summation order -- and against torch.nn.grad on the fp32 inputs (the fp16 operand rounding averages down
+    over the voxels)."""
+    lib = X._lib.load()
+    torch.manual_seed(53)
+    cin, cout, g, sp, split = cfg
+    x = torch.randn((2, cin) + sp, device=DEV)
+    dy = torch.randn((2, cout) + sp, device=DEV)
+    xa, xb = (x, None) if split is None else (x[:, :split].contiguous(), x[:, split:].contiguous())
+    pre = (torch.rand(2, cin, device=DEV) + 0.5, torch.randn(2, cin, device=DEV), 0.01)
+    nw = g if g <= 4 else 1
+    res = {}
+    X.ops.set_fp32_mfma(True)
+    try:
+        for name, uq in (("full", 15), ("tile", 7)):
+            lib.xh_set_option(28, uq)
+            dws = [torch.zeros(cout // nw, cin // g, 3, 3, 3, device=DEV) for _ in range(nw)]
+            dbs = [torch.zeros(cout // nw, device=DEV) for _ in range(nw)]
+            X.ops.conv3d_wgrad(xa, xb, dy, dws, dbs, k=3, groups=g, pre=pre)
+            kn = X.ops.last_conv_kernel()
+            assert ("conv3_wgrad_q5_multi_kernel<2>" if uq == 15 else "conv3_wgrad_q4_multi_kernel<2") in kn, kn
+            torch.cuda.synchronize()
+            res[name] = (torch.cat(dws, 0).cpu(), torch.cat(dbs, 0).cpu())
+    finally:
+        lib.xh_set_option(28, 7)
+        X.ops.set_fp32_mfma(False)
+    xf = torch.nn.functional.leaky_relu(x * pre[0][:, :, None, None, None] + pre[1][:, :, None, None, None], 0.01)
+    ref = torch.nn.grad.conv3d_weight(xf, (cout, cin // g, 3, 3, 3), dy, padding=1, groups=g).cpu()
+    assert l2_err(res["full"][0], res["tile"][0]) < 2e-6 and l2_err(res["full"][1], res["tile"][1]) < 2e-6
+    assert l2_err(res["full"][0], ref) < 5e-4 and l2_err(res["full"][1], dy.sum((0, 2, 3, 4)).cpu()) < 5e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])

@@ -1631,7 +1631,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 24) { extern int g_c7_as; g_c7_as = value < 0 ? 0 : value > 3 ? 3 : value; return XH_OK; }
   if (key == 23) { extern int g_q5_w32; g_q5_w32 = value ? 1 : 0; return XH_OK; }
   if (key == 22) { extern int g_q5_wgs; g_q5_wgs = value < 8 ? 8 : value; return XH_OK; }
-  if (key == 28) { extern int g_q5_uq; g_q5_uq = value & 7; return XH_OK; }
+  if (key == 28) { extern int g_q5_uq; g_q5_uq = value & 15; return XH_OK; }
   return XH_ERR_ARG;
 }
 

@@ -436,8 +436,8 @@ extern "C" int xh_conv3d_wgrad_batch(void* stream, int n, const xh_conv_desc* co
   // quad-channel problems first: WQ_MULTI per launch and storage format
   std::vector<char> handled(n > 0 ? n : 1, 0);
   if (g_use_mfma) {
-    for (int cls = 0; cls < 11; ++cls) {              // (storage format: bf16 / fp16 / fp32 with fp16 operands, input-channel quads per group);
-                                                      // 9, 10: the full-row kernel's problems (bf16 / fp16, conv3d_wgrad_q5.hip)
+    for (int cls = 0; cls < 12; ++cls) {              // (storage format: bf16 / fp16 / fp32 with fp16 operands, input-channel quads per group);
+                                                      // 9, 10, 11: the full-row kernel's problems (bf16 / fp16 / fp32, conv3d_wgrad_q5.hip)
       const int full = cls >= 9, fmt = full ? cls - 9 : cls / 3, ci4 = full ? 1 : cls % 3 + 1;
       std::vector<WgQ4> cl;
       WgQ4 q;

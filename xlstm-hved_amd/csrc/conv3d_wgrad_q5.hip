@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cmath>
+#include <type_traits>
 
 typedef h16x8 frag8;
 typedef f32x4_t f32x4;
@@ -85,12 +86,16 @@ template <int NCH, int NQX = 1, int NQY = 1, int PPR = 2> struct Q5 {
 
 template <int FMT, int NCH, int PD, int NQX = 1, int NQY = 1, int PPR = 2>
 __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned char* smem) {
-  typedef h16<FMT> ST;
+  // FMT = 2 (round 6): fp32 STORAGE, operands rounded once to fp16 while staging (xh_conv_desc.arith XH_ARITH_F32_SPLIT; the same
+  // arithmetic as conv3_wgrad_q4_multi_kernel<2, ...>): an item is still 8 voxels = two 16-byte loads, the LDS images are fp16
+  constexpr bool F32S = FMT == 2;
+  constexpr int CF = F32S ? 1 : FMT;                   // format of the LDS images / MFMA operands
+  typedef typename std::conditional<F32S, float, h16<CF>>::type ST;
   typedef Q5<NCH, NQX, NQY, PPR> Q;
   constexpr int NSLOT = Q::NSLOT;
   constexpr int NP = NQX * NQY;
   constexpr int W = Q::W, PR = Q::PR, NC = Q::NC, NIX = Q::NIX, NIY = Q::NIY;
-  constexpr unsigned ONE2 = FMT == 0 ? 0x3F803F80u : 0x3C003C00u;
+  constexpr unsigned ONE2 = CF == 0 ? 0x3F803F80u : 0x3C003C00u;
   float* s_dw = reinterpret_cast<float*>(smem);        // after the plane loops
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g = lane >> 4;
@@ -198,7 +203,7 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
     // buffer is a fixed set of registers).  Every issue is unconditional -- a round beyond the tile's last one loads one dead
     // line (all offsets collapse to the source's first bytes) -- so that the compiler's vmcnt bookkeeping stays exact: a load
     // under a branch makes it wait for (nearly) everything at the next use, i.e. one round in flight whatever PD says.
-    struct RB { uint4 x[NIX]; uint4 y[NIY]; };
+    struct RB { uint4 x[NIX]; uint4 y[NIY]; uint4 x2[F32S ? NIX : 1]; uint4 y2[F32S ? NIY : 1]; };   // x2 / y2: the second half of an fp32 item
     RB q[PD];
     const int nround = (d1 - d0 + 2 + PPR - 1) / PPR;    // x planes d0 - 1 .. d1
     auto issue = [&](int r, RB& rb) {
@@ -209,11 +214,13 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
       for (int k = 0; k < NIX; ++k) {
         const long long po = live ? (long long)min(max(p0 + x_pp[k], 0), D - 1) * hw : 0ll;
         rb.x[k] = *reinterpret_cast<const uint4*>(xsrc[k] + po + (x_goff[k] & lm));
+        if constexpr (F32S) rb.x2[k] = *reinterpret_cast<const uint4*>(xsrc[k] + po + (x_goff[k] & lm) + 4);
       }
 #pragma unroll
       for (int k = 0; k < NIY; ++k) {
         const long long po = live ? (long long)min(max(p0 + 1 + y_pp[k], 0), D - 1) * hw : 0ll;
         rb.y[k] = *reinterpret_cast<const uint4*>(ysrc + po + (y_goff[k] & lm));
+        if constexpr (F32S) rb.y2[k] = *reinterpret_cast<const uint4*>(ysrc + po + (y_goff[k] & lm) + 4);
       }
     };
     auto commit = [&](int r, const RB& rb) {             // round r -> slots (2 r) & 3, (2 r + 1) & 3  (PPR = 1: slot r & 1)
@@ -225,14 +232,16 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
         const float pm = (unsigned)(p0 + x_pp[k]) < (unsigned)D ? 1.f : 0.f;
         const float sc = x_sc[k] * pm, sh = x_sh[k] * pm;
         const f32x2_t sc2 = {sc, sc}, sh2 = {sh, sh};
-        const unsigned u[4] = {rb.x[k].x, rb.x[k].y, rb.x[k].z, rb.x[k].w};
+        const uint4 xh = F32S ? rb.x2[k] : rb.x[k];
+        const unsigned u[8] = {rb.x[k].x, rb.x[k].y, rb.x[k].z, rb.x[k].w, xh.x, xh.y, xh.z, xh.w};
         uint4 o;
         unsigned* op = &o.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const f32x2_t v = cvt2_in<FMT>(u[e]) * sc2 + sh2;
+          const f32x2_t xin = F32S ? f32x2_t{__uint_as_float(u[2 * e]), __uint_as_float(u[2 * e + 1])} : cvt2_in<CF>(u[e]);
+          const f32x2_t v = xin * sc2 + sh2;
           const f32x2_t y = max2(v, v * ps2);
-          op[e] = cvt2_pack<FMT>(y.x, y.y);
+          op[e] = cvt2_pack<CF>(y.x, y.y);
         }
         *reinterpret_cast<uint4*>(dst + x_lds[k]) = o;
       }
@@ -241,7 +250,13 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
         if (!y_do[k]) continue;
         // out plane v = p + 1 belongs to this tile when v < d1 (v >= d0 always holds)
         const unsigned am = (p0 + 1 + y_pp[k] < d1) ? 0xffffffffu : 0u;
-        *reinterpret_cast<uint4*>(dst + y_lds[k]) = make_uint4(rb.y[k].x & am, rb.y[k].y & am, rb.y[k].z & am, rb.y[k].w & am);
+        uint4 yv = rb.y[k];
+        if constexpr (F32S) {
+          const uint4 a0 = rb.y[k], a1 = rb.y2[k];
+          yv = make_uint4(cvt2_pack<CF>(__uint_as_float(a0.x), __uint_as_float(a0.y)), cvt2_pack<CF>(__uint_as_float(a0.z), __uint_as_float(a0.w)),
+                          cvt2_pack<CF>(__uint_as_float(a1.x), __uint_as_float(a1.y)), cvt2_pack<CF>(__uint_as_float(a1.z), __uint_as_float(a1.w)));
+        }
+        *reinterpret_cast<uint4*>(dst + y_lds[k]) = make_uint4(yv.x & am, yv.y & am, yv.z & am, yv.w & am);
       }
     };
     frag8 af_m1[NQY][NC], af_0[NQY][NC];
@@ -266,9 +281,9 @@ __device__ __forceinline__ void wgrad_q5_body(const WgQ4& a, int b, unsigned cha
 #pragma unroll
           for (int qx = 0; qx < NQX; ++qx) {
             f32x4* ac = acc[qx * NQY + qy];
-            ac[0] = mfma16x16x32<FMT>(af_p1, bf[qx], ac[0]);
-            ac[1] = mfma16x16x32<FMT>(af_0[qy][c], bf[qx], ac[1]);
-            ac[2] = mfma16x16x32<FMT>(af_m1[qy][c], bf[qx], ac[2]);
+            ac[0] = mfma16x16x32<CF>(af_p1, bf[qx], ac[0]);
+            ac[1] = mfma16x16x32<CF>(af_0[qy][c], bf[qx], ac[1]);
+            ac[2] = mfma16x16x32<CF>(af_m1[qy][c], bf[qx], ac[2]);
           }
           af_m1[qy][c] = af_0[qy][c];
           af_0[qy][c] = af_p1;
@@ -364,19 +379,20 @@ __global__ __launch_bounds__(512, 2) void conv3_wgrad_q5_multi_kernel(const WgQ5
   const int local = b - m.off[i];
   const WgQ4& a = m.p[i];
   if (local >= a.nb) return;
+  constexpr int PD = FMT == 2 ? 2 : Q5_PD;             // fp32 storage: a round in flight is twice the registers (and bytes)
   if (a.W == 128) {
-    if (a.uqx == 3) wgrad_q5_body<FMT, 4, Q5_PD, 3, 1, 1>(a, local, smem);
-    else wgrad_q5_body<FMT, 4, Q5_PD>(a, local, smem);
+    if (a.uqx == 3) wgrad_q5_body<FMT, 4, PD, 3, 1, 1>(a, local, smem);
+    else wgrad_q5_body<FMT, 4, PD>(a, local, smem);
   } else if (a.W == 64) {
-    if (a.uqx == 2 && a.uqy == 2) wgrad_q5_body<FMT, 2, Q5_PD, 2, 2>(a, local, smem);
-    else if (a.uqy == 2) wgrad_q5_body<FMT, 2, Q5_PD, 1, 2>(a, local, smem);
-    else if (a.uqx == 2) wgrad_q5_body<FMT, 2, Q5_PD, 2, 1>(a, local, smem);
-    else wgrad_q5_body<FMT, 2, Q5_PD>(a, local, smem);
+    if (a.uqx == 2 && a.uqy == 2) wgrad_q5_body<FMT, 2, PD, 2, 2>(a, local, smem);
+    else if (a.uqy == 2) wgrad_q5_body<FMT, 2, PD, 1, 2>(a, local, smem);
+    else if (a.uqx == 2) wgrad_q5_body<FMT, 2, PD, 2, 1>(a, local, smem);
+    else wgrad_q5_body<FMT, 2, PD>(a, local, smem);
   } else {
-    if (a.uqx == 2 && a.uqy == 2) wgrad_q5_body<FMT, 1, Q5_PD, 2, 2>(a, local, smem);
-    else if (a.uqy == 2) wgrad_q5_body<FMT, 1, Q5_PD, 1, 2>(a, local, smem);
-    else if (a.uqx == 2) wgrad_q5_body<FMT, 1, Q5_PD, 2, 1>(a, local, smem);
-    else wgrad_q5_body<FMT, 1, Q5_PD>(a, local, smem);
+    if (a.uqx == 2 && a.uqy == 2) wgrad_q5_body<FMT, 1, PD, 2, 2>(a, local, smem);
+    else if (a.uqy == 2) wgrad_q5_body<FMT, 1, PD, 1, 2>(a, local, smem);
+    else if (a.uqx == 2) wgrad_q5_body<FMT, 1, PD, 2, 1>(a, local, smem);
+    else wgrad_q5_body<FMT, 1, PD>(a, local, smem);
   }
 }
 
@@ -387,11 +403,15 @@ int g_q5_w32 = 1;                                        // xh_set_option(23, 0 
 int g_q5_wgs = 256;                                      // xh_set_option(22, n): workgroups per launch (one per CU is resident)
 int g_q5_uq = 7;                                         // xh_set_option(28, bits): rows of 64 voxels, bit 0: two input quads per unit, bit 1: two output quads;
                                                          // bit 2: rows of 128 voxels, three input quads per unit (one plane per round)
+                                                         // bit 3 (off): fp32 storage takes this kernel too (FMT = 2: measured SLOWER than the tile
+                                                         // kernel in the fp32_mfma step, 2 x 348 us against 592 us: 32-byte items as two 16-byte loads
+                                                         // at a lane stride of 32 bytes, two rounds in flight in 251 registers)
 bool xh_wgrad_q5_replan(const xh_conv_desc* d, WgQ4* a) {
   { static bool env_done = false;                        // (measurement overrides of the option defaults)
-    if (!env_done) { env_done = true; const char* e = getenv("XH_Q5_UQ"); if (e) g_q5_uq = atoi(e) & 7;
+    if (!env_done) { env_done = true; const char* e = getenv("XH_Q5_UQ"); if (e) g_q5_uq = atoi(e) & 15;
       e = getenv("XH_Q5_W32"); if (e) g_q5_w32 = atoi(e) ? 1 : 0; } }
-  if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16)) return false;
+  const bool f32 = d->dtype == XH_F32 && (d->arith & XH_ARITH_F32_SPLIT) && (g_q5_uq & 8);   // fp32 storage, fp16 operands
+  if (!g_q5_on || (d->dtype != XH_BF16 && d->dtype != XH_F16 && !f32)) return false;
   extern int g_q5_w32;
   // rows of 32 voxels (xh_set_option(23, 0) sends them back to the tile kernel): with one quad of each operand per unit the 32^3
   // problems of the network were ~200 units of a few tiles each and the launch waited for them (batch of the step's 24 problems: 433 us
@@ -512,6 +532,7 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
     constexpr int mx = Q5<4, 3, 1, 1>::BYTES > m0 ? Q5<4, 3, 1, 1>::BYTES : m0;
     (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute((const void*)conv3_wgrad_q5_multi_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   }
   size_t shm = 0;
   for (int i = 0; i < n; ++i) {
@@ -522,6 +543,7 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
     shm = need > shm ? need : shm;
   }
   xh_note_kernel("conv3_wgrad_q5_multi_kernel<%d>", fmt);
-  if (fmt) hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<1>), dim3(m.off[n]), dim3(512), shm, st, m);
+  if (fmt == 2) hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<2>), dim3(m.off[n]), dim3(512), shm, st, m);
+  else if (fmt) hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<1>), dim3(m.off[n]), dim3(512), shm, st, m);
   else hipLaunchKernelGGL((conv3_wgrad_q5_multi_kernel<0>), dim3(m.off[n]), dim3(512), shm, st, m);
 }
