@@ -937,8 +937,8 @@ def roofline_pass(step, ops, nsteps, dtype):
                     and w_ % (16 // esz) == 0 and kw.get("pre") is None)
             k7 = k == 7 and esz == 2 and cin == 4 and dy.shape[1] == 2 and groups == 1 and w_ % 32 == 0 and kw.get("pre") is None
             k1 = k == 1 and kw.get("stride", 1) == 1 and (dy.shape[2] * dy.shape[3] * dy.shape[4]) % (16 // esz) == 0
-            # rows of 64 / 128 voxels, H a multiple of 8: the full-row kernel (conv3d_wgrad_q5.hip), 12 problems per launch
-            q5 = q4 and w_ in (64, 128) and xa.shape[3] % 8 == 0
+            # rows of 32 / 64 / 128 voxels, H a multiple of 8: the full-row kernel (conv3d_wgrad_q5.hip), 12 problems per launch
+            q5 = q4 and w_ in (32, 64, 128) and xa.shape[3] % 8 == 0
             cls = ("q5" if q5 else f"q4_{qs}" if q4 else ("big" if dy.shape[2] * dy.shape[3] * dy.shape[4] >= (1 << 20) else "small")
                    if mfma else "k1" if k1 else "s2" if s2 else "k7" if k7 else "tiny" if tiny else "rest")
             pending_meta.append((cls, nbytes, flops, shape))
@@ -1107,8 +1107,16 @@ def roofline_pass(step, ops, nsteps, dtype):
     if os.path.exists(tpath):
         with open(tpath) as f:
             t = json.load(f)
-        if name in t.get("kernels", {}) and t.get("dtype") == {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[dtype]:
-            traffic = t["kernels"][name]["hbm_bytes_per_launch"]
+        if t.get("dtype") == {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[dtype]:
+            ks = t.get("kernels", {})
+            if name in ks:
+                traffic = ks[name]["hbm_bytes_per_launch"]
+            else:
+                # a class of this run may be several template instances of the capture (the name of the class drops trailing
+                # arguments, e.g. the broadcast-operand flag of conv3_q4w_kernel): the launch-weighted mean over them
+                inst = [v for k, v in ks.items() if name.endswith(">") and k.startswith(name[:-1] + ",")]
+                if inst:
+                    traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst)
     tmeta = {}
     if traffic is not None:
         # how old the committed capture is: the commit it was taken from, commits since (None where there is no .git, e.g. on a

@@ -523,7 +523,8 @@ void xh_wgrad_q5_launch(hipStream_t st, int fmt, const WgQ4* probs, int n) {
     a.sd = a.D; a.dsegs = 1; a.ntile = a.tilesH * a.N;             // (informational: the kernel cuts the plane sequence itself)
     a.wpu = wq[i];
     a.nb = a.nq * wq[i];
-    if (getenv("XH_Q5_DUMP")) fprintf(stderr, "q5 plan %d: %d->%d g%d W%d uq %dx%d nq %d wpu %d\n", i, a.Cin, a.Cout, a.groups, a.W, a.uqx, a.uqy, a.nq, a.wpu);
+    static const bool dump = getenv("XH_Q5_DUMP") != nullptr;       // (measurement aid: the plan of every launch on stderr)
+    if (dump) fprintf(stderr, "q5 plan %d: %d->%d g%d W%d uq %dx%d nq %d wpu %d\n", i, a.Cin, a.Cout, a.groups, a.W, a.uqx, a.uqy, a.nq, a.wpu);
     m.off[i + 1] = m.off[i] + a.nb;
   }
   static bool attr_done[XH_MAX_DEV] = {};
