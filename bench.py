@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--inner", type=int, default=0,
                     help="passes per timed step (0 = sized so that the timed region lasts --min-timed-s; 1 = the plain K-step loop)")
-    ap.add_argument("--min-timed-s", type=float, default=2.0)
+    ap.add_argument("--min-timed-s", type=float, default=5.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
