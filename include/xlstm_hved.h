@@ -88,6 +88,12 @@ int xh_abi_version(void);
  * read xh_last_conv_kernel on the thread that made the call.  Every other entry point is re-entrant: all device memory,
  * workspaces and the statistics fan-in block are the caller's, the stream and the arithmetic mode are arguments. */
 int xh_set_option(int key, int value);
+/* Host-side launch plan of the multi-problem weight-gradient launches whose workgroups are all resident together (no device work;
+ * exported so that the plan can be tested without a GPU).  Problem i has units[i] units of cost[i] each (any unit of time); a unit
+ * takes wq[i] workgroups (1 .. cap[i]) that share it equally, so the launch lasts max_i cost[i] / wq[i].  Fills wq with the
+ * assignment that minimises that maximum subject to sum_i units[i] * wq[i] <= budget (when even one workgroup per unit exceeds the
+ * budget: one each), spare workgroups going to the slowest units; returns the planned duration, < 0 on bad arguments. */
+double xh_wgrad_plan_minmax(int n, const double* cost, const int* units, const int* cap, int budget, int* wq);
 /* Name of the kernel template instance the most recent xh_conv3d_fwd / xh_conv3d_wgrad call of THIS PROCESS launched (static
  * storage, overwritten by the next call on any thread; the same spelling rocprofv3 prints), so measurements can be attributed
  * to a kernel without a profiler attached.  Measurement aid only. */

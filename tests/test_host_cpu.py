@@ -79,7 +79,7 @@ def test_unsupported_configurations_are_rejected(X):
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "xlstm_hved.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|long long|const char\*)\s+(xh_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long long|double|const char\*)\s+(xh_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(X):
@@ -91,6 +91,58 @@ def test_library_exports_every_declared_symbol(X):
         assert hasattr(lib, n), f"{n} declared in include/xlstm_hved.h but not exported"
     assert set(names) == set(X._lib.SIGNATURES), set(names) ^ set(X._lib.SIGNATURES)
     assert X._lib.load().xh_abi_version() == 2
+
+
+def test_weight_gradient_launch_plan_is_min_max_optimal(X):
+    """xh_wgrad_plan_minmax (host logic of csrc/conv3d_wgrad_q5.hip, no device work): the workgroups per unit it returns respect the
+    budget and the per-unit caps, and no other assignment within the budget has a smaller maximum of cost / workgroups -- checked
+    against a brute-force search over the candidate durations cost[i] / k.  Also the step's own two launches (round 6: the 64^3
+    units used to get 3 workgroups for 3.3 shares and ran 10 % longer than the rest)."""
+    import ctypes as C
+    import math
+    import random
+    lib = X._lib.load()
+
+    def plan(cost, units, cap, budget):
+        n = len(cost)
+        wq = (C.c_int * n)()
+        T = lib.xh_wgrad_plan_minmax(n, (C.c_double * n)(*cost), (C.c_int * n)(*units), (C.c_int * n)(*cap), budget, wq)
+        return T, list(wq)
+
+    def brute(cost, units, cap, budget):
+        best = None
+        for c in cost:
+            for k in range(1, 600):
+                T = c / k
+                used = sum(u * max(1, min(cp, math.ceil(ci / T - 1e-9))) for ci, u, cp in zip(cost, units, cap))
+                reach = max(ci / max(1, min(cp, math.ceil(ci / T - 1e-9))) for ci, cp in zip(cost, cap))
+                if used <= budget and (best is None or reach < best):
+                    best = reach
+        return best
+
+    rng = random.Random(5)
+    for _ in range(200):
+        n = rng.randint(1, 12)
+        cost = [rng.choice([256.0, 358.4, 519.7, 680.9, 2048.0, 4915.2, 134.0]) * rng.uniform(0.9, 1.1) for _ in range(n)]
+        units = [rng.randint(1, 12) for _ in range(n)]
+        cap = [rng.choice([32, 128, 512]) for _ in range(n)]
+        budget = rng.choice([64, 256, 304])
+        T, wq = plan(cost, units, cap, budget)
+        assert all(1 <= w <= cp for w, cp in zip(wq, cap))
+        if sum(units) > budget:                              # more units than workgroups: one each
+            assert wq == [1] * n
+            continue
+        assert sum(u * w for u, w in zip(units, wq)) <= budget
+        assert abs(T - max(c / w for c, w in zip(cost, wq))) < 1e-9 * T
+        ref = brute(cost, units, cap, budget)
+        assert ref is not None and T <= ref * (1 + 1e-6), (T, ref, cost, units, cap, budget, wq)
+    # bad arguments
+    assert lib.xh_wgrad_plan_minmax(0, None, None, None, 256, None) < 0
+    # one launch of the 128^3 step (costs in rounds of a single-quad unit on rows of 128 voxels)
+    cost = [2048.0] * 5 + [4915.2, 4915.2, 680.9, 680.9, 680.9, 680.9, 134.5]
+    units = [4, 1, 1, 4, 2, 1, 1, 3, 3, 2, 1, 12]
+    T, wq = plan(cost, units, [512] * 5 + [512, 512, 128, 128, 128, 128, 32], 256)
+    assert sum(u * w for u, w in zip(units, wq)) <= 256 and T < 1.06 * sum(c * u for c, u in zip(cost, units)) / 256
 
 
 def test_no_cpu_fallback(X):

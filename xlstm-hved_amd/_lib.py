@@ -111,6 +111,7 @@ I, F = C.c_int, C.c_float
 SIGNATURES = {
     "xh_abi_version": (I, []),
     "xh_set_option": (I, [I, I]),
+    "xh_wgrad_plan_minmax": (C.c_double, [I, c_dp, C.POINTER(I), C.POINTER(I), I, C.POINTER(I)]),
     "xh_last_conv_kernel": (C.c_char_p, []),
     "xh_conv3d_fwd": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),
     "xh_conv3d_fwd_pair": (I, [vp, C.POINTER(ConvDesc), C.POINTER(ConvPtrs), C.POINTER(ConvDesc), C.POINTER(ConvPtrs)]),

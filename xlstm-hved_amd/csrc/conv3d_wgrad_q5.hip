@@ -462,50 +462,57 @@ static double q5_ucost(const WgQ4& w) {
 // already is -- a 257th workgroup would wait for a CU and double the launch).  Until round 6 this was "integer part of the
 // proportional share, then largest remainders": units of 3.3 shares got 3 workgroups and ran 10 % longer than the rest.
 // Returns the planned duration max_i cost_i / wq_i (xh_conv3d_wgrad_batch balances its launches with it).
+extern "C" double xh_wgrad_plan_minmax(int n, const double* cost, const int* units, const int* cap, int budget, int* wq) {
+  if (n <= 0 || !cost || !units || !cap || !wq || budget < 1) return -1.0;
+  double total = 0.0, hi = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (!(cost[i] > 0.0) || units[i] < 1 || cap[i] < 1) return -1.0;
+    total += units[i] * cost[i];
+    hi = cost[i] > hi ? cost[i] : hi;
+  }
+  auto need = [&](double T, int* out) {
+    long long used = 0;
+    for (int i = 0; i < n; ++i) {
+      const double q = ceil(cost[i] / T - 1e-9);
+      int k = q > (double)cap[i] ? cap[i] : (int)q;
+      k = k < 1 ? 1 : k;
+      if (out) out[i] = k;
+      used += (long long)units[i] * k;
+    }
+    return used;
+  };
+  if (need(hi, wq) <= budget) {                          // (else: more units than workgroups -- one each, already in wq)
+    double lo = total / budget * 0.999;                  // below the smallest conceivable T
+    for (int it = 0; it < 48; ++it) {                    // need() falls with T: bisect to the smallest feasible T
+      const double mid = 0.5 * (lo + hi);
+      if (need(mid, nullptr) <= budget) hi = mid; else lo = mid;
+    }
+    long long used = need(hi, wq);
+    // workgroups left over (they cannot lower the maximum): to the units that are slowest now, while whole units fit
+    for (;;) {
+      int best = -1;
+      for (int i = 0; i < n; ++i)
+        if (used + units[i] <= budget && wq[i] + 1 <= cap[i] && (best < 0 || cost[i] / wq[i] > cost[best] / wq[best])) best = i;
+      if (best < 0) break;
+      ++wq[best];
+      used += units[best];
+    }
+  }
+  double T = 0.0;
+  for (int i = 0; i < n; ++i) T = cost[i] / wq[i] > T ? cost[i] / wq[i] : T;
+  return T;
+}
+
 double xh_wgrad_q5_plan(const WgQ4* probs, int n, int budget, int* wq) {
-  double c[Q5_MULTI], total = 0.0, hi = 0.0;
-  int cap[Q5_MULTI];
+  double c[Q5_MULTI];
+  int cap[Q5_MULTI], nq[Q5_MULTI];
   for (int i = 0; i < n; ++i) {
     c[i] = q5_ucost(probs[i]);
     const long long planes = (long long)probs[i].tilesH * probs[i].N * probs[i].D;
     cap[i] = (int)(planes / 4 > 0 ? planes / 4 : 1);     // runs of at least 4 planes
-    total += probs[i].nq * c[i];
-    hi = c[i] > hi ? c[i] : hi;
+    nq[i] = probs[i].nq;
   }
-  auto need = [&](double T, int* out) {
-    int used = 0;
-    for (int i = 0; i < n; ++i) {
-      int k = (int)ceil(c[i] / T - 1e-9);
-      k = k < 1 ? 1 : k > cap[i] ? cap[i] : k;
-      out[i] = k;
-      used += probs[i].nq * k;
-    }
-    return used;
-  };
-  double lo = total / budget * 0.999;                    // below the smallest conceivable T
-  int tmp[Q5_MULTI];
-  if (need(hi, wq) > budget) {                           // more units than workgroups: one each
-    double T = 0.0;
-    for (int i = 0; i < n; ++i) T = c[i] > T ? c[i] : T;
-    return T;
-  }
-  for (int it = 0; it < 40; ++it) {                      // need() falls with T: bisect to the smallest feasible T
-    const double mid = 0.5 * (lo + hi);
-    if (need(mid, tmp) <= budget) hi = mid; else lo = mid;
-  }
-  int used = need(hi, wq);
-  // workgroups left over (they cannot lower the maximum): to the units that are slowest now, while whole units fit
-  for (;;) {
-    int best = -1;
-    for (int i = 0; i < n; ++i)
-      if (used + probs[i].nq <= budget && wq[i] + 1 <= cap[i] && (best < 0 || c[i] / wq[i] > c[best] / wq[best])) best = i;
-    if (best < 0) break;
-    ++wq[best];
-    used += probs[best].nq;
-  }
-  double T = 0.0;
-  for (int i = 0; i < n; ++i) T = c[i] / wq[i] > T ? c[i] / wq[i] : T;
-  return T;
+  return xh_wgrad_plan_minmax(n, c, nq, cap, budget, wq);
 }
 
 // launches up to Q5_MULTI re-planned problems of one storage format
