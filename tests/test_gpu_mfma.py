@@ -735,6 +735,8 @@ Q4W_CASES = [
     dict(cin=8, cout=24, groups=1, sp=(8, 16, 64), n=1),
     dict(cin=4, cout=4, groups=1, sp=(4, 8, 64), n=3),                # the smallest volume the kernel takes: one tile, 3 samples
     dict(cin=8, cout=4, groups=1, sp=(5, 9, 128), n=1),               # one plane and one row beyond a tile
+    dict(cin=24, cout=8, groups=2, sp=(8, 16, 128), n=1),             # data gradient 4 -> 12 per group: workgroups of three output quads (round 6)
+    dict(cin=12, cout=4, groups=1, sp=(8, 24, 64), n=2, split=8),     # the same on rows of 64 voxels, e from two sources, 2 samples
 ]
 
 

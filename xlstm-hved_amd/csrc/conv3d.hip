@@ -1622,7 +1622,7 @@ extern "C" int xh_set_option(int key, int value) {
   if (key == 14) { extern int g_dconv_cfg; g_dconv_cfg = value; return XH_OK; }
   if (key == 15) { extern int g_dconv_big; g_dconv_big = value < 1 ? 1 : value; return XH_OK; }
   if (key == 17) { extern int g_q4_wgs; g_q4_wgs = value < 0 ? 0 : value; return XH_OK; }
-  if (key == 20) { extern int g_q4_wide; g_q4_wide = value & 3; return XH_OK; }
+  if (key == 20) { extern int g_q4_wide; g_q4_wide = value & 7; return XH_OK; }
   if (key == 19) { extern int g_q4_persist; g_q4_persist = value < 0 ? 0 : value; return XH_OK; }
   if (key == 16) { extern int g_tiny_wgs; g_tiny_wgs = value < 1 ? 1 : value; return XH_OK; }
   if (key == 21) { extern int g_q5_on; g_q5_on = value ? 1 : 0; return XH_OK; }

@@ -24,7 +24,8 @@
 // 2^22 elements, i.e. not on 128-wide rows); 63 KB of LDS, two workgroups per CU.
 #include "conv_q4.h"
 
-int g_q4_wide = 3;                // xh_set_option(20, mask): bit 1 = rows of 128 voxels, bit 0 = rows of 64 voxels take conv3_q4w_kernel
+int g_q4_wide = 3;                // xh_set_option(20, mask): bit 1 = rows of 128 voxels, bit 0 = rows of 64 voxels take conv3_q4w_kernel;
+                                  // bit 2: NO workgroups of three output quads (the 4 -> 12 data gradients stage their tile per output quad)
 
 namespace {
 constexpr int WTD = 4, WTH = 8;              // output planes / rows per workgroup
@@ -68,8 +69,13 @@ template <int FMT> __device__ __forceinline__ f32x2_t q4w_xf(unsigned u, float s
 // conv3_q4w_pair_kernel those of the problem a workgroup belongs to -- the same arithmetic on the same data either way.
 // BC: a broadcast operand (xh_conv_desc.bcast) -- a template argument so that the ordinary instances carry none of its registers: as
 // run-time flags they cost the dominant data-gradient instance <0, 0, 1, false, 2> six spilled registers (128 of 128 in use).
-template <int FMT, int PRE, int EPI, bool MULTI, int NH, bool BC = false>
+// NOQ (round 6): output quads of ONE group a workgroup produces from one staged image, one after the other -- the 4 -> 12 data
+// gradients of the first decoder convs staged the same 4-channel tile once per output quad (three workgroups, three transforms of
+// 60 rows); the matrix phase and the epilogue of an output quad are what they were, so the outputs are the same bits.  Single input
+// quad only (the image of a later input quad would overwrite the one the next output quad needs).
+template <int FMT, int PRE, int EPI, bool MULTI, int NH, bool BC = false, int NOQ = 1>
 __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, const int bx, const int by, const int bz, const int gdx, const int gdy) {
+  static_assert(NOQ == 1 || !MULTI, "several output quads per workgroup: one input quad");
   typedef h16<FMT> ST;
   typedef QW<NH> Q;
   constexpr int WW = Q::WW, WSLOTS = Q::SLOTS, WPITCH = Q::PITCH, WPLANE = Q::PLANE, WTILE = Q::TILE, WNITEM = Q::NITEM, WNIT = Q::NIT;
@@ -79,9 +85,8 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nn = lane & 15, g4 = lane >> 4;
   const int qd = q4w_quad(nn);                       // the quad (4 consecutive voxels of a 64-voxel half) this lane's N column is
-  const int oq = by, n = bz;
-  const int co0 = oq * 4;
-  const int grp = udiv_fast(oq, a.oq_g, a.mQ);
+  const int oq0 = by * NOQ, n = bz;
+  const int grp = udiv_fast(oq0, a.oq_g, a.mQ);
   const int cin_base = grp * a.Cin_g;
   const int D = a.d.D, H = a.d.H;
   const long long hw = (long long)H * WW, dhw = (long long)D * hw;
@@ -126,12 +131,6 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
   const int oh = oh0 + wv;
   const bool row_ok = oh < Ho;
   const int ndz = min(WTD, Do - od0);
-  float bias = 0.f, esc = 0.f, esh = 0.f, ectr = 0.f;
-  {
-    const int wp = udiv_fast(grp, a.gpp, a.mG);
-    const float* bp = a.p.b[wp];
-    if (bp) bias = bp[(grp - wp * a.gpp) * a.Cout_g + (oq - grp * a.oq_g) * 4 + g4];
-  }
   const long long odhw = (long long)Do * Ho * WW;
   const unsigned spd_b = (unsigned)(Ho * WW) * (unsigned)sizeof(ST);
   const unsigned lane_b = (unsigned)(((long long)g4 * odhw + (long long)(row_ok ? oh : 0) * WW + 4 * qd) * (long long)sizeof(ST));
@@ -142,6 +141,22 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
   const unsigned lane_e = bc_e ? (unsigned)(((long long)(row_ok ? oh : 0) * WW + 4 * qd) * (long long)sizeof(ST)) : lane_b;
   const unsigned lane_bo = st_ok ? lane_b : Q4_OOB;
   constexpr unsigned HALF_B = 64 * sizeof(ST);         // byte distance of the two halves of a row
+  const int ncq = MULTI ? a.ci4 : 1;
+  const float pslope = a.d.pre_slope;
+  const bool fin = PRE == 1 && a.p.fin_red != nullptr;
+  const long long dhw_b = dhw * (long long)sizeof(ST);
+  const long long cs_b = bc_in ? 0 : dhw_b;              // byte distance of the quad's channel planes (0: one stored channel)
+
+#pragma unroll 1
+  for (int oi = 0; oi < NOQ; ++oi) {                     // (NOQ == 1: the body as it always was)
+  const int oq = oq0 + oi;
+  const int co0 = oq * 4;
+  float bias = 0.f, esc = 0.f, esh = 0.f, ectr = 0.f;
+  {
+    const int wp = udiv_fast(grp, a.gpp, a.mG);
+    const float* bp = a.p.b[wp];
+    if (bp) bias = bp[(grp - wp * a.gpp) * a.Cout_g + (oq - grp * a.oq_g) * 4 + g4];
+  }
   __amdgpu_buffer_rsrc_t ers = q4_window(a.p.y), yrs;
   if (EPI == 1) {
     esc = a.p.e_sc[n * a.d.Cout + co0 + g4];
@@ -159,14 +174,9 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
   for (int i = 0; i < WTD; ++i)
 #pragma unroll
     for (int h = 0; h < NH; ++h) acc[i][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ncq = MULTI ? a.ci4 : 1;
-  const float pslope = a.d.pre_slope;
-  const bool fin = PRE == 1 && a.p.fin_red != nullptr;
-  const long long dhw_b = dhw * (long long)sizeof(ST);
-  const long long cs_b = bc_in ? 0 : dhw_b;              // byte distance of the quad's channel planes (0: one stored channel)
-
   for (int cq = 0; cq < ncq; ++cq) {
     const int c0 = cin_base + cq * 4;
+    if (NOQ == 1 || oi == 0) {                           // (a later output quad of the workgroup finds the image staged)
     const char* src = reinterpret_cast<const char*>(bc_in ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)(c0 >> 2) * dhw
                                                     : c0 < a.d.Ca ? (const ST*)a.p.xa + n * a.d.xa_bs + (long long)c0 * dhw
                                                                   : (const ST*)a.p.xb + n * a.d.xb_bs + (long long)(c0 - a.d.Ca) * dhw);
@@ -257,6 +267,7 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
       for (int k = 0; k < 4; ++k)
         *reinterpret_cast<uint4*>(smem + i_lds[it] + 128 * k) = outv[k];
     }
+    }
     // A (weight) fragments of this (output quad, input quad): issued here so that they travel while the workgroup gathers
     frag8 wfrag[9];
     {
@@ -264,7 +275,7 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
 #pragma unroll
       for (int i = 0; i < 9; ++i) wfrag[i] = wpk[i * 64];
     }
-    __syncthreads();
+    if (NOQ == 1 || oi == 0) __syncthreads();
     // ---- matrix phase: the wave's output row, both halves, walking the 6 staged planes once ----
 #pragma unroll
     for (int pz = 0; pz < WID; ++pz) {
@@ -350,12 +361,13 @@ __device__ __forceinline__ void q4w_body(const ConvQ4& a, unsigned char* smem, c
     if (!a.fan) __syncthreads();
     if (tid < 8) atomicAdd(&a.p.red[((long long)n * a.d.Cout + co0 + (tid >> 1)) * 2 + (tid & 1)], s_tot[tid]);
   }
+  }   // output quads of the workgroup
 }
 
-template <int FMT, int PRE, int EPI, bool MULTI, int NH, bool BC = false>
+template <int FMT, int PRE, int EPI, bool MULTI, int NH, bool BC = false, int NOQ = 1>
 __global__ __launch_bounds__(512, 4) void conv3_q4w_kernel(const ConvQ4 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  q4w_body<FMT, PRE, EPI, MULTI, NH, BC>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+  q4w_body<FMT, PRE, EPI, MULTI, NH, BC, NOQ>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 // Two independent convolutions of one shape in ONE launch (xh_conv3d_fwd_pair): grid z = 2 N, the first N planes of workgroups are
 // problem 0.  The recon | seg streams' first decoder convs (buildingblocks.py:732-735: different inputs, the same shapes) are a
@@ -449,6 +461,17 @@ int xh_conv3_q4w_try(hipStream_t st, ConvQ4& a) {
     if (a.d.pre == 1) { if (f) QWB(1, 1, 2); else QWB(0, 1, 2); }
     else { if (f) QWB(1, 0, 1); else QWB(0, 0, 1); }
 #undef QWB
+    return xh_launch_status();
+  }
+  // several output quads of a group from one staged image (NOQ = 3): the data gradient of an n -> 4 conv with 3 k input quads
+  // (4 -> 12: the decoders' first convs), single input quad, norm-backward sums by direct atomics
+  if (!multi && a.d.pre == 0 && a.d.epi == 1 && a.oq_g % 3 == 0 && (g_q4_wide & 4) == 0) {
+    grid.y = a.d.Cout / 12;
+    a.fan = nullptr;
+    if (f) { if (nh == 2) hipLaunchKernelGGL((conv3_q4w_kernel<1, 0, 1, false, 2, false, 3>), grid, dim3(512), shm, st, a);
+             else hipLaunchKernelGGL((conv3_q4w_kernel<1, 0, 1, false, 1, false, 3>), grid, dim3(512), shm, st, a); }
+    else { if (nh == 2) hipLaunchKernelGGL((conv3_q4w_kernel<0, 0, 1, false, 2, false, 3>), grid, dim3(512), shm, st, a);
+           else hipLaunchKernelGGL((conv3_q4w_kernel<0, 0, 1, false, 1, false, 3>), grid, dim3(512), shm, st, a); }
     return xh_launch_status();
   }
   if (f) { if (a.d.pre) QWE(1, 1); else QWE(1, 0); }
