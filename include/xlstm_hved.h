@@ -56,7 +56,8 @@ int xh_abi_version(void);
  *         several input quads per tile and >= 2048 stages (default: where it was measured to win), 2 = every 8-plane launch.
  * key 20: mask of the row widths on which quad-channel k3 convs take the full-row tiles of csrc/conv3d_q4w.hip: bit 1 = 128 voxels,
  *         bit 0 = 64 voxels (default 3); 0 = always the 32-wide tiles of csrc/conv3d_q4.hip (A/B switch; the outputs are
- *         bit-identical).
+ *         bit-identical).  Bit 2 = 1: no workgroups of three output quads (the 4 -> 12 data gradients stage their tile once per
+ *         output quad, as before round 6; bit-identical too).
  * key 21: 0 = no full-row weight-gradient kernel (csrc/conv3d_wgrad_q5.hip; the 32-wide tile kernel instead).  key 22: its
  *         workgroup budget per launch (default 256 = one per CU).  key 23: 0 = rows of 32 voxels stay with the tile kernel (default 1 since round 6).
  * key 24: input-stationary 7^3 gate-conv kernel (csrc/conv7_mfma.hip): 0 never, 1 volumes >= 2^20 voxels (default), 2 B fragments in
