@@ -396,7 +396,8 @@ def main():
             else:
                 grp = None
             leg = train_step_leg(model, x, max(6, min(args.steps, 30)), group=grp, world=world,
-                                 mfma_roofline=(rank == 0 and not args.no_roofline))
+                                 mfma_roofline=(rank == 0 and world == 1 and not args.no_roofline))   # (its eager pass would issue
+                                                                                                         # rank 0's collectives alone)
             if rank == 0:
                 out.update(leg)
         except Exception as e:                                  # must not cost the headline line
